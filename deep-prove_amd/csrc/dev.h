@@ -1,0 +1,112 @@
+// Device-operations interface between the host orchestrator (transcript, claim routing, proof assembly — the
+// reference's O(log n) host work) and the O(n) table work that lives on the MI355X.
+// One implementation ships in the product: HipDev (hip_dev.hip, hand-written gfx950 kernels). The interface is
+// abstract so that tests/ can plug a CPU test double under the same orchestrator to check host logic without a GPU;
+// there is NO CPU implementation inside the product library (dp_ctx_create fails without a HIP device).
+//
+// K-numbers refer to SURVEY.md §2.3 (the reference's rayon hot loops these ops replace).
+#pragma once
+#include "gl64.h"
+#include "poseidon2.h"
+#include <vector>
+#include <stdexcept>
+#include <string>
+
+namespace dp {
+
+struct DpError : std::runtime_error {
+  int code;
+  DpError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+enum { DP_OK = 0, DP_ERR_ARG = -1, DP_ERR_OOM = -2, DP_ERR_HIP = -3, DP_ERR_SHAPE = -4, DP_ERR_VERIFY = -5, DP_ERR_NODEVICE = -6 };
+#define DP_REQUIRE(cond, code, msg) do { if (!(cond)) throw ::dp::DpError((code), std::string(msg)); } while (0)
+
+// A table of field elements resident in HBM. Base elements are canonical u64, extension elements two u64 (c0,c1).
+struct DBuf {
+  void* p = nullptr;
+  size_t n = 0;
+  bool ext = false;
+  size_t elem_bytes() const { return ext ? 16 : 8; }
+  size_t bytes() const { return n * elem_bytes(); }
+  DBuf slice(size_t off, size_t cnt) const {
+    DBuf r; r.p = (char*)p + off * elem_bytes(); r.n = cnt; r.ext = ext; return r;
+  }
+  bool null() const { return p == nullptr; }
+};
+
+struct ScTerm { int k; int t[3]; };  // product of k (<=3) tables, indices into the table list
+
+// Merkle tree over `nleaves` field elements (merkle_tree.rs:261-329): layer 0 packs leaf pairs (no hashing),
+// upper layers = Poseidon2 compress. All layers live in one buffer of (nleaves-1) digests; layer l starts at digest
+// offset nleaves - (nleaves >> l).
+struct DevTree {
+  DBuf leaves;
+  DBuf nodes;  // base buffer, 4*(nleaves-1) words
+  size_t nleaves = 0;
+  Digest root;
+  unsigned height() const { return dp_ceil_log2(nleaves); }
+};
+// BasefoldCommitmentWithWitness (structure.rs:63-72)
+struct DevCommit {
+  unsigned nv = 0;
+  bool is_base = true;
+  DBuf evals;     // natural order (the polynomial itself)
+  DBuf bh_evals;  // bit-reversed evaluations (== evals when trivial)
+  DevTree tree;   // leaves = bit-reversed RS codeword (raw evaluations when trivial)
+  bool trivial() const { return nv <= 7; }
+  size_t codeword_size() const { return tree.nleaves; }
+};
+struct QueryDesc {  // one (query, tree) pair of the Basefold query phase (K14)
+  const DevTree* tree;
+  size_t p0;  // even index of the opened leaf pair
+};
+
+class Dev {
+ public:
+  virtual ~Dev() {}
+  virtual const char* name() const = 0;
+  // ---- memory. alloc() is an arena (stack discipline via mark/release); persistent allocations outlive proofs.
+  virtual DBuf alloc(size_t n, bool ext) = 0;
+  virtual size_t mark() = 0;
+  virtual void release(size_t m) = 0;
+  virtual DBuf alloc_persistent(size_t n, bool ext) = 0;
+  virtual void free_persistent(DBuf& b) = 0;
+  virtual void upload(const DBuf& dst, const u64* src) = 0;
+  virtual void upload_i64(const DBuf& dst, const int64_t* src) = 0;  // Fieldizer on device
+  virtual void download(const DBuf& src, u64* dst) = 0;
+  virtual void copy(const DBuf& dst, const DBuf& src) = 0;
+  virtual void sync() = 0;
+  // ---- MLE primitives
+  // K4: out[idx] (+)= scale * prod_t (idx_t ? pt[t] : 1 - pt[t])
+  virtual void eq_table(const DBuf& out, const Ext* pt, unsigned k, Ext scale, bool accumulate) = 0;
+  // K1 chain collapsed to one pass: out[i] = sum_x fs[i](x) * eq(x, pt)
+  virtual void mle_eval_batch(const DBuf* fs, int nf, const Ext* pt, unsigned k, Ext* out) = 0;
+  // K2 in one pass: out[c] = sum_r eq(r, pt) * W[r*C + c]      (W base field, R = 2^k rows)
+  virtual void fix_high(const DBuf& out, const DBuf& W, size_t R, size_t C, const Ext* pt) = 0;
+  // ---- sumcheck (K1 + K3): fold every table with r (if given; tabs[i] is replaced), then per term the sums
+  // sum_b prod_j (v_j[2b] + t (v_j[2b+1] - v_j[2b])) for t = 0..k, written consecutively to `out`.
+  virtual void sc_round(DBuf* tabs, int ntabs, const Ext* r, const ScTerm* terms, int nterms, Ext* out) = 0;
+  virtual void sc_finish(DBuf* tabs, int ntabs, Ext r, Ext* finals) = 0;
+  // ---- logup-GKR (K13)
+  virtual void logup_den(const DBuf& out, const DBuf* cols, int ncols, Ext c, Ext chi) = 0;
+  virtual void logup_layer(const DBuf& num_in, const DBuf& den_in, const DBuf& num_out, const DBuf& den_out) = 0;
+  // ---- Basefold (K5-K12, K14)
+  virtual void pcs_init(unsigned full_message_size_log) = 0;
+  virtual DevCommit commit(const DBuf& evals, bool persistent) = 0;
+  virtual void free_commit(DevCommit& c) = 0;
+  virtual DevTree merkle_ext(const DBuf& leaves) = 0;
+  // classic sumcheck round (K12): fold every (f_i, eq_i) of length > 1 with r (if given), then
+  // out[2i] = sum_j f[2j]*eq[2j], out[2i+1] = sum_j (f[2j+1]-f[2j])*(eq[2j+1]-eq[2j]); length-1 pairs give (f*eq, 0)
+  virtual void classic_round(DBuf* fs, DBuf* eqs, int np, const Ext* r, Ext* out) = 0;
+  // K11: acc[j*rep + q] += x[j] * coeff  for q < rep
+  virtual void axpy_rep(const DBuf& acc, const DBuf& x, Ext coeff, size_t rep) = 0;
+  // K10: (optionally) fold the evaluation-form pair arrays with ch, then (optionally) the coefficient-form message
+  virtual void bf_round(DBuf& eq, DBuf& f, const Ext* ch, Ext* msg3) = 0;
+  // K9: FRI fold of a bit-reversed codeword of length 2^(level+1)
+  virtual DBuf fri_fold(const DBuf& oracle, unsigned level, Ext ch) = 0;
+  virtual void bitrev_copy(const DBuf& dst, const DBuf& src) = 0;
+  // K14: for each descriptor: the leaf pair (as stored) followed by the Merkle path (height-1 digests)
+  virtual void query_gather(const QueryDesc* d, size_t nd, std::vector<std::vector<u64>>& out) = 0;
+};
+
+}  // namespace dp

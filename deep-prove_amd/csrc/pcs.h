@@ -1,0 +1,352 @@
+// Basefold<GoldilocksExt2, BasefoldRSParams<PoseidonHasher>> over device-resident polynomials:
+// commit / trivial open / batch_open (mpcs/src/basefold.rs:304-354,466-483,546-770; basefold/commit_phase.rs:187-359;
+// basefold/query_phase.rs:67-102,419-472) and the host-side verifier (basefold.rs:863-1098; query_phase.rs:220-288,
+// 1116-1236). RS code rate 1/2, 200 queries, base-case message 2^7 (encoding/rs.rs:194-215).
+#pragma once
+#include "sumcheck.h"
+
+namespace dp {
+
+constexpr unsigned PCS_RATE_LOG = 1;
+constexpr unsigned PCS_BASECODE_LOG = 7;
+constexpr unsigned PCS_NUM_QUERIES = 200;
+
+inline Commitment pure_commitment(const DevCommit& c) { Commitment r; r.root = c.tree.root; r.num_vars = c.nv; r.is_base = c.is_base; return r; }
+
+// PCS::open for a trivial (<= 7 variables) commitment: the proof is the raw evaluation table (basefold.rs:481-483)
+inline BasefoldProof pcs_open_trivial(Dev& dev, const DevCommit& c) {
+  DP_REQUIRE(c.trivial(), DP_ERR_SHAPE, "pcs_open: only trivial commitments are opened individually (zkml/src/commit/context.rs:295)");
+  BasefoldProof p;
+  FieldVec fv; fv.is_ext = c.evals.ext; fv.w.resize(c.evals.n * (fv.is_ext ? 2 : 1));
+  dev.download(c.evals, fv.w.data());
+  p.trivial_proof.push_back(fv);
+  return p;
+}
+
+struct OpenClaim { const DevCommit* comm; std::vector<Ext> point; Ext eval; };
+
+// PCS::batch_open in the shape zkml uses it: claim i = (poly i, point i) (commit/context.rs:370-383)
+inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vector<OpenClaim>& claims, Transcript& t) {
+  BasefoldProof proof;
+  if (claims.empty()) return proof;  // Proof::trivial(vec![])
+  size_t mk = dev.mark();
+  unsigned num_vars = 0;
+  for (auto& c : claims) {
+    DP_REQUIRE(!c.comm->trivial(), DP_ERR_SHAPE, "batch_open: trivial commitment");
+    DP_REQUIRE(c.point.size() == c.comm->nv, DP_ERR_SHAPE, "batch_open: point length != num_vars");
+    if (c.comm->nv > num_vars) num_vars = c.comm->nv;
+  }
+  DP_REQUIRE(num_vars <= full_log, DP_ERR_SHAPE, "batch_open: polynomial larger than the PCS parameters");
+  size_t np = claims.size();
+  unsigned bsl = dp_ceil_log2(np);
+  std::vector<Ext> tt;
+  for (unsigned i = 0; i < bsl; i++) tt.push_back(t.get_and_append_challenge("batch coeffs"));
+  std::vector<Ext> eq_xt = host_eq_table(tt);
+  Ext target = ex_zero();
+  for (size_t i = 0; i < np; i++)
+    target = ex_add(target, ex_mul(ex_mul(claims[i].eval, ex_from_u64(u64(1) << (num_vars - claims[i].comm->nv))), eq_xt[i]));
+  // ---- classic sumcheck on sum_i eq_xt[i] * eq(x, z_i) * f_i(x)  (sum_check/classic.rs:232-285, coeff.rs:198-345)
+  std::vector<DBuf> fs(np), eqs(np);
+  for (size_t i = 0; i < np; i++) {
+    fs[i] = claims[i].comm->evals;
+    eqs[i] = dev.alloc(fs[i].n, true);
+    dev.eq_table(eqs[i], claims[i].point.data(), claims[i].comm->nv, ex_one(), false);
+  }
+  std::vector<Ext> challenges, raw(2 * np);
+  Ext sum = target, ch = ex_zero();
+  for (unsigned round = 0; round < num_vars; round++) {
+    dev.classic_round(fs.data(), eqs.data(), (int)np, round ? &ch : nullptr, raw.data());
+    size_t size = size_t(1) << (num_vars - round - 1);
+    Ext h0 = ex_zero(), h2 = ex_zero();
+    for (size_t i = 0; i < np; i++) {
+      size_t poly_len = fs[i].n;  // current length after the folds so far
+      Ext c0 = raw[2 * i], c2 = raw[2 * i + 1];
+      size_t multiple;
+      if (poly_len == 1) multiple = size;
+      else if (size < poly_len || size == 1) multiple = 1;
+      else multiple = size / (poly_len >> 1);
+      if (multiple != 1) { Ext m = ex_from_u64(multiple); c0 = ex_mul(c0, m); c2 = ex_mul(c2, m); }
+      h0 = ex_add(h0, ex_mul(eq_xt[i], c0));
+      h2 = ex_add(h2, ex_mul(eq_xt[i], c2));
+    }
+    Ext h1 = ex_sub(ex_sub(sum, ex_dbl(h0)), h2);
+    std::vector<Ext> msg = {h0, h1, h2};
+    for (const Ext& e : msg) t.append_ext(e);
+    ch = t.get_and_append_challenge("sumcheck round");
+    challenges.push_back(ch);
+    sum = ex_add(h0, ex_mul(ch, ex_add(h1, ex_mul(ch, h2))));
+    proof.sumcheck_proof.push_back(msg);
+  }
+  // (the last challenge never needs to be folded in: only the challenges are used below)
+  std::vector<Ext> coeffs(np);
+  for (size_t i = 0; i < np; i++)
+    coeffs[i] = ex_mul(eq_eval(challenges.data(), claims[i].point.data(), claims[i].point.size()), eq_xt[i]);
+
+  // ---- batch_commit_phase (commit_phase.rs:187-359)
+  unsigned num_rounds = num_vars - PCS_BASECODE_LOG;
+  size_t cw_size = size_t(1) << (num_vars + PCS_RATE_LOG);
+  auto zeros = [&](size_t n) { DBuf b = dev.alloc(n, true); std::vector<u64> z(2 * n, 0); dev.upload(b, z.data()); return b; };
+  DBuf running = zeros(cw_size);
+  for (size_t i = 0; i < np; i++) if (claims[i].comm->codeword_size() == cw_size) dev.axpy_rep(running, claims[i].comm->tree.leaves, coeffs[i], 1);
+  DBuf sum_evals = zeros(size_t(1) << num_vars);
+  for (size_t i = 0; i < np; i++) dev.axpy_rep(sum_evals, claims[i].comm->bh_evals, coeffs[i], size_t(1) << (num_vars - claims[i].comm->nv));
+  std::vector<Ext> rev_point(challenges.rbegin(), challenges.rend());
+  DBuf eq = dev.alloc(size_t(1) << num_vars, true);
+  dev.eq_table(eq, rev_point.data(), num_vars, ex_one(), false);  // == bit-reversed eq(point)
+  std::vector<Ext> last(3);
+  dev.bf_round(eq, sum_evals, nullptr, last.data());
+  proof.sumcheck_messages.push_back(last);
+  std::vector<DevTree> trees;
+  DBuf folded; DevTree pending; bool have_pending = false;
+  for (unsigned i = 0; i < num_rounds; i++) {
+    for (const Ext& e : last) t.append_ext(e);
+    Ext c = t.get_and_append_challenge("commit round");
+    if (i > 0) {
+      trees.push_back(pending);
+      bool any = false;
+      for (size_t k = 0; k < np; k++) if (claims[k].comm->codeword_size() == folded.n) any = true;
+      if (any) {
+        running = dev.alloc(folded.n, true);  // the committed oracle (tree leaves) must stay untouched
+        dev.copy(running, folded);
+        for (size_t k = 0; k < np; k++) if (claims[k].comm->codeword_size() == folded.n) dev.axpy_rep(running, claims[k].comm->tree.leaves, coeffs[k], 1);
+      } else running = folded;
+    }
+    folded = dev.fri_fold(running, dp_ceil_log2(running.n) - 1, c);
+    if (i + 1 < num_rounds) {
+      dev.bf_round(eq, sum_evals, &c, last.data());
+      proof.sumcheck_messages.push_back(last);
+      pending = dev.merkle_ext(folded); have_pending = true;
+      t.append_digest(pending.root);
+      proof.roots.push_back(pending.root);
+    } else {
+      dev.bf_round(eq, sum_evals, &c, nullptr);
+      std::vector<u64> w(2 * sum_evals.n);
+      dev.download(sum_evals, w.data());
+      size_t m = sum_evals.n; unsigned lg = dp_ceil_log2(m);
+      proof.final_message.resize(m);
+      for (size_t j = 0; j < m; j++) { size_t r = dp_reverse_bits(j, lg); proof.final_message[r] = ex(w[2 * j], w[2 * j + 1]); }
+      t.append_exts(proof.final_message);
+    }
+  }
+  (void)have_pending;
+  // ---- batch_prover_query_phase (query_phase.rs:67-102, 419-472) and Merkle paths (:1062-1087)
+  std::vector<size_t> qidx;
+  for (unsigned q = 0; q < PCS_NUM_QUERIES; q++) qidx.push_back((size_t)(t.get_and_append_challenge("query indices").c0 % cw_size));
+  std::vector<QueryDesc> descs;
+  unsigned cw_log = num_vars + PCS_RATE_LOG;
+  for (size_t x : qidx) {
+    size_t index = x >> 1;
+    for (auto& tr : trees) { size_t p1 = index | 1; descs.push_back({&tr, p1 - 1}); index >>= 1; }
+    for (auto& c : claims) { size_t xi = x >> (cw_log - c.comm->tree.height()); size_t p1 = xi | 1; descs.push_back({&c.comm->tree, p1 - 1}); }
+  }
+  std::vector<std::vector<u64>> got;
+  dev.query_gather(descs.data(), descs.size(), got);
+  size_t di = 0;
+  auto fill = [&](const QueryDesc& d, const std::vector<u64>& w) {
+    CodewordQuery q; q.is_ext = d.tree->leaves.ext; q.index = d.p0;
+    size_t o = 0;
+    if (q.is_ext) { q.left = ex(w[0], w[1]); q.right = ex(w[2], w[3]); o = 4; } else { q.left = ex(w[0], 0); q.right = ex(w[1], 0); o = 2; }
+    size_t npath = (w.size() - o) / 4;
+    for (size_t j = 0; j < npath; j++) { Digest dg; for (int k = 0; k < 4; k++) dg.v[k] = w[o + 4 * j + k]; q.path.push_back(dg); }
+    return q;
+  };
+  for (size_t x : qidx) {
+    BatchedQuery bq; bq.index = x;
+    for (size_t k = 0; k < trees.size(); k++, di++) bq.oracle_query.push_back(fill(descs[di], got[di]));
+    for (size_t k = 0; k < np; k++, di++) bq.commitments_query.push_back(fill(descs[di], got[di]));
+    proof.queries.push_back(std::move(bq));
+  }
+  dev.release(mk);
+  return proof;
+}
+
+// =================================================================== host verifier
+struct VerifierParams { unsigned full_log = 0; };
+
+inline Digest host_leaf_pair_digest(bool is_ext, Ext l, Ext r) {  // hash_two_leaves* -> hash_or_noop (<= 4 elements: no hash)
+  Digest d;
+  if (is_ext) { d.v[0] = l.c0; d.v[1] = l.c1; d.v[2] = r.c0; d.v[3] = r.c1; }
+  else { d.v[0] = l.c0; d.v[1] = r.c0; d.v[2] = 0; d.v[3] = 0; }
+  return d;
+}
+// authenticate_merkle_path_root (merkle_tree.rs:331-420)
+inline void check_merkle_path(const CodewordQuery& q, const Digest& root) {
+  Digest h = host_leaf_pair_digest(q.is_ext, q.left, q.right);
+  size_t x = q.index >> 1;
+  for (const Digest& sib : q.path) {
+    h = (x & 1) ? host_compress(sib, h) : host_compress(h, sib);
+    x >>= 1;
+  }
+  DP_REQUIRE(h == root, DP_ERR_VERIFY, "merkle path does not authenticate against the root");
+}
+inline Digest host_merkle_root(const FieldVec& leaves) {  // MerkleTree::from_leaves on a small vector
+  size_t n = leaves.len();
+  DP_REQUIRE(n >= 2 && (n & (n - 1)) == 0, DP_ERR_VERIFY, "trivial proof: bad leaf count");
+  std::vector<Digest> cur(n / 2);
+  for (size_t i = 0; i < n / 2; i++) {
+    if (leaves.is_ext) cur[i] = host_leaf_pair_digest(true, ex(leaves.w[4 * i], leaves.w[4 * i + 1]), ex(leaves.w[4 * i + 2], leaves.w[4 * i + 3]));
+    else cur[i] = host_leaf_pair_digest(false, ex(leaves.w[2 * i], 0), ex(leaves.w[2 * i + 1], 0));
+  }
+  while (cur.size() > 1) {
+    std::vector<Digest> nx(cur.size() / 2);
+    for (size_t i = 0; i < nx.size(); i++) nx[i] = host_compress(cur[2 * i], cur[2 * i + 1]);
+    cur = nx;
+  }
+  return cur[0];
+}
+// PCS::verify for trivial proofs (basefold.rs:873-894); does not touch the transcript
+inline void pcs_verify_trivial(const Commitment& comm, const std::vector<Ext>& point, Ext eval, const BasefoldProof& proof) {
+  DP_REQUIRE(proof.is_trivial() && proof.trivial_proof.size() == 1, DP_ERR_VERIFY, "expected a trivial opening proof");
+  const FieldVec& fv = proof.trivial_proof[0];
+  DP_REQUIRE(host_merkle_root(fv) == comm.root, DP_ERR_VERIFY, "trivial proof: Merkle root mismatch");
+  std::vector<Ext> v(fv.len());
+  for (size_t i = 0; i < v.size(); i++) v[i] = fv.is_ext ? ex(fv.w[2 * i], fv.w[2 * i + 1]) : ex(fv.w[i], 0);
+  DP_REQUIRE(ex_eq(host_mle_eval(v, point), eval), DP_ERR_VERIFY, "trivial proof: wrong evaluation");
+}
+// x0 (and w = -1/(2 x0)) of verifier_folding_coeffs (rs.rs:412-456), computed from first principles:
+// x0 = gamma^(2^(full_log+1-level-1)) * omega_{2^(level+1)}^{bitrev(index, level)}
+inline void folding_coeffs(unsigned full_log, unsigned level, size_t index, u64& x0, u64& w) {
+  size_t bi = dp_reverse_bits(index, level);
+  u64 g = GL_G32;  // generator of the 2^(level+1) subgroup
+  for (unsigned i = level + 1; i < 32; i++) g = gl_sqr(g);
+  u64 root = gl_pow(g, bi);
+  u64 gam = GL_GENERATOR;
+  for (unsigned i = 0; i < full_log + PCS_RATE_LOG - level - 1; i++) gam = gl_sqr(gam);
+  x0 = gl_mul(root, gam);
+  w = gl_neg(gl_inv(gl_dbl(x0)));
+}
+inline Ext interpolate2_weights(Ext a0, Ext a1, Ext b1, Ext w, Ext x) { return ex_add(a1, ex_mul(ex_mul(ex_sub(x, a0), ex_sub(b1, a1)), w)); }
+
+struct VerifyClaim { Commitment comm; std::vector<Ext> point; Ext eval; };
+
+// PCS::batch_verify (basefold.rs:964-1098) + batch_verifier_query_phase (query_phase.rs:220-288) + check (:1116-1236)
+inline void pcs_batch_verify(const VerifierParams& vp, const std::vector<VerifyClaim>& claims, const BasefoldProof& proof, Transcript& t) {
+  if (claims.empty() && proof.trivial_proof.empty() && proof.is_trivial()) return;
+  DP_REQUIRE(!claims.empty(), DP_ERR_VERIFY, "batch_verify: proof given but no claims");
+  size_t np = claims.size();
+  unsigned num_vars = 0, min_nv = ~0u;
+  for (auto& c : claims) {
+    DP_REQUIRE(c.point.size() == c.comm.num_vars, DP_ERR_VERIFY, "batch_verify: point length != num_vars");
+    num_vars = std::max(num_vars, c.comm.num_vars); min_nv = std::min(min_nv, c.comm.num_vars);
+  }
+  DP_REQUIRE(min_nv >= PCS_BASECODE_LOG && num_vars <= vp.full_log && !proof.is_trivial(), DP_ERR_VERIFY, "batch_verify: bad shapes");
+  unsigned num_rounds = num_vars - PCS_BASECODE_LOG;
+  unsigned bsl = dp_ceil_log2(np);
+  std::vector<Ext> tt;
+  for (unsigned i = 0; i < bsl; i++) tt.push_back(t.get_and_append_challenge("batch coeffs"));
+  std::vector<Ext> eq_xt = host_eq_table(tt);
+  Ext target = ex_zero();
+  for (size_t i = 0; i < np; i++)
+    target = ex_add(target, ex_mul(ex_mul(claims[i].eval, ex_from_u64(u64(1) << (num_vars - claims[i].comm.num_vars))), eq_xt[i]));
+  // SumCheck::verify (classic.rs:287-330): coefficients form, degree 2
+  DP_REQUIRE(proof.sumcheck_proof.size() == num_vars, DP_ERR_VERIFY, "batch_verify: wrong number of sumcheck rounds");
+  std::vector<Ext> vpoint;
+  Ext sum = target;
+  for (unsigned i = 0; i < num_vars; i++) {
+    const auto& m = proof.sumcheck_proof[i];
+    DP_REQUIRE(m.size() == 3, DP_ERR_VERIFY, "batch_verify: round message must hold 3 coefficients");
+    for (const Ext& e : m) t.append_ext(e);
+    Ext ch = t.get_and_append_challenge("sumcheck round");
+    vpoint.push_back(ch);
+    // msg.sum() = c0 + (c0+c1+c2) must equal the running sum
+    DP_REQUIRE(ex_eq(ex_add(m[0], ex_add(ex_add(m[0], m[1]), m[2])), sum), DP_ERR_VERIFY, "batch_verify: classic sumcheck consistency failure");
+    sum = ex_add(m[0], ex_mul(ch, ex_add(m[1], ex_mul(ch, m[2]))));
+  }
+  Ext new_target = sum;
+  std::vector<Ext> coeffs(np);
+  for (size_t i = 0; i < np; i++)
+    coeffs[i] = ex_mul(eq_eval(vpoint.data(), claims[i].point.data(), claims[i].point.size()), eq_xt[i]);
+  DP_REQUIRE(proof.sumcheck_messages.size() == num_rounds && proof.roots.size() + 1 == num_rounds, DP_ERR_VERIFY, "batch_verify: commit-phase shape");
+  std::vector<Ext> fold_ch;
+  for (unsigned i = 0; i < num_rounds; i++) {
+    DP_REQUIRE(proof.sumcheck_messages[i].size() == 3, DP_ERR_VERIFY, "batch_verify: commit message size");
+    t.append_exts(proof.sumcheck_messages[i]);
+    fold_ch.push_back(t.get_and_append_challenge("commit round"));
+    if (i + 1 < num_rounds) t.append_digest(proof.roots[i]);
+  }
+  DP_REQUIRE(proof.final_message.size() == (size_t(1) << PCS_BASECODE_LOG), DP_ERR_VERIFY, "batch_verify: final message size");
+  t.append_exts(proof.final_message);
+  size_t cw_size = size_t(1) << (num_vars + PCS_RATE_LOG);
+  std::vector<size_t> qidx;
+  for (unsigned q = 0; q < PCS_NUM_QUERIES; q++) qidx.push_back((size_t)(t.get_and_append_challenge("query indices").c0 % cw_size));
+  // partial eq (basefold.rs:1066-1078)
+  std::vector<Ext> rev(fold_ch.rbegin(), fold_ch.rend());
+  Ext coeff = eq_eval(vpoint.data() + (vpoint.size() - fold_ch.size()), rev.data(), fold_ch.size());
+  std::vector<Ext> head(vpoint.begin(), vpoint.end() - fold_ch.size());
+  std::vector<Ext> peq = host_eq_table(head);
+  for (auto& e : peq) e = ex_mul(e, coeff);
+  // final codeword: encode_small(interpolate(bitrev(final_message))) then bit-reverse (query_phase.rs:239-251).
+  // Evaluated directly: message coefficients c (multilinear, bit-reversed order), codeword[k] = sum_i c_i (shift w^k)^i.
+  size_t mlen = proof.final_message.size();
+  std::vector<Ext> msg(mlen);
+  for (size_t j = 0; j < mlen; j++) msg[dp_reverse_bits(j, PCS_BASECODE_LOG)] = proof.final_message[j];
+  for (unsigned i = 1; i <= PCS_BASECODE_LOG; i++) {
+    size_t chunk = size_t(1) << i, half = chunk >> 1;
+    for (size_t c = 0; c < mlen; c += chunk) for (size_t j = half; j < chunk; j++) msg[c + j] = ex_sub(msg[c + j], msg[c + j - half]);
+  }
+  u64 shift = GL_GENERATOR;
+  for (unsigned i = 0; i < vp.full_log - PCS_BASECODE_LOG; i++) shift = gl_sqr(shift);
+  u64 w256 = GL_G32;
+  for (unsigned i = PCS_BASECODE_LOG + PCS_RATE_LOG; i < 32; i++) w256 = gl_sqr(w256);
+  size_t flen = mlen << PCS_RATE_LOG;
+  std::vector<Ext> final_codeword(flen);
+  for (size_t k = 0; k < flen; k++) {
+    u64 x = gl_mul(shift, gl_pow(w256, k));
+    Ext acc = ex_zero();
+    for (size_t i = mlen; i-- > 0;) acc = ex_add(ex_mul_base(acc, x), msg[i]);
+    final_codeword[dp_reverse_bits(k, PCS_BASECODE_LOG + PCS_RATE_LOG)] = acc;
+  }
+  DP_REQUIRE(proof.queries.size() == PCS_NUM_QUERIES, DP_ERR_VERIFY, "batch_verify: wrong number of queries");
+  for (unsigned q = 0; q < PCS_NUM_QUERIES; q++) {
+    const BatchedQuery& bq = proof.queries[q];
+    size_t index = qidx[q];
+    DP_REQUIRE(bq.index == index, DP_ERR_VERIFY, "batch_verify: query index mismatch");
+    DP_REQUIRE(bq.oracle_query.size() == proof.roots.size() && bq.commitments_query.size() == np, DP_ERR_VERIFY, "batch_verify: query shape");
+    for (size_t k = 0; k < bq.oracle_query.size(); k++) check_merkle_path(bq.oracle_query[k], proof.roots[k]);
+    for (size_t k = 0; k < np; k++) {
+      DP_REQUIRE(bq.commitments_query[k].is_ext == !claims[k].comm.is_base, DP_ERR_VERIFY, "batch_verify: field type of opened codeword");
+      check_merkle_path(bq.commitments_query[k], claims[k].comm.root);
+    }
+    Ext cur_l = ex_zero(), cur_r = ex_zero();
+    size_t right_index = index | 1, left_index = right_index - 1;
+    for (unsigned i = 0; i < num_rounds; i++) {
+      for (size_t k = 0; k < np; k++) if (claims[k].comm.num_vars == num_vars - i) {
+        const CodewordQuery& cq = bq.commitments_query[k];
+        DP_REQUIRE((cq.index >> 1) == (left_index >> 1), DP_ERR_VERIFY, "batch_verify: commitment query index");
+        cur_l = ex_add(cur_l, ex_mul(cq.left, coeffs[k]));
+        cur_r = ex_add(cur_r, ex_mul(cq.right, coeffs[k]));
+      }
+      u64 x0, w;
+      folding_coeffs(vp.full_log, num_vars + PCS_RATE_LOG - i - 1, left_index >> 1, x0, w);
+      Ext res = interpolate2_weights(ex_base(x0), cur_l, cur_r, ex_base(w), fold_ch[i]);
+      size_t next_index = right_index >> 1;
+      Ext next_val;
+      if (i + 1 < num_rounds) {
+        right_index = next_index | 1; left_index = right_index - 1;
+        const CodewordQuery& oq = bq.oracle_query[i];
+        DP_REQUIRE(oq.index == left_index && oq.is_ext, DP_ERR_VERIFY, "batch_verify: oracle query index");
+        cur_l = oq.left; cur_r = oq.right;
+        next_val = (next_index & 1) ? cur_r : cur_l;
+      } else {
+        for (size_t k = 0; k < np; k++) if (claims[k].comm.num_vars == num_vars - i - 1) {
+          const CodewordQuery& cq = bq.commitments_query[k];
+          DP_REQUIRE((cq.index >> 1) == (next_index >> 1), DP_ERR_VERIFY, "batch_verify: last-round commitment query index");
+          res = ex_add(res, ex_mul((next_index & 1) ? cq.right : cq.left, coeffs[k]));
+        }
+        next_val = final_codeword[next_index];
+      }
+      DP_REQUIRE(ex_eq(res, next_val), DP_ERR_VERIFY, "batch_verify: folding check failed");
+    }
+  }
+  // final checks (query_phase.rs:264-288)
+  auto zero_plus_one = [](const std::vector<Ext>& p) { return ex_add(ex_add(ex_dbl(p[0]), p[1]), p[2]); };
+  auto eval2 = [](const std::vector<Ext>& p, Ext x) { return ex_add(p[0], ex_add(ex_mul(x, p[1]), ex_mul(ex_mul(x, x), p[2]))); };
+  DP_REQUIRE(ex_eq(new_target, zero_plus_one(proof.sumcheck_messages[0])), DP_ERR_VERIFY, "batch_verify: first commit-phase message does not match the sum");
+  for (unsigned i = 0; i + 1 < num_rounds; i++)
+    DP_REQUIRE(ex_eq(eval2(proof.sumcheck_messages[i], fold_ch[i]), zero_plus_one(proof.sumcheck_messages[i + 1])), DP_ERR_VERIFY, "batch_verify: commit-phase sumcheck chain");
+  Ext ip = ex_zero();
+  for (size_t i = 0; i < mlen; i++) ip = ex_add(ip, ex_mul(proof.final_message[i], peq[i]));
+  DP_REQUIRE(ex_eq(eval2(proof.sumcheck_messages[num_rounds - 1], fold_ch[num_rounds - 1]), ip), DP_ERR_VERIFY, "batch_verify: final message inner product");
+}
+
+}  // namespace dp

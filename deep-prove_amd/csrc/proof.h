@@ -1,0 +1,168 @@
+// Proof objects of the reference (zkml/src/iop/mod.rs:21-44, layers/*.rs, lookup/logup_gkr/structs.rs:313-319,
+// mpcs/src/basefold/structure.rs:334-345, sumcheck/src/structs.rs:42-61) and their canonical u64 stream
+// (ascending NodeId, struct fields in declaration order — SURVEY.md A.12 / F4). The oracle emits the same stream.
+#pragma once
+#include "dev.h"
+#include <map>
+
+namespace dp {
+
+struct Claim { std::vector<Ext> point; Ext eval; };
+struct IOPProof { std::vector<Ext> point; std::vector<std::vector<Ext>> proofs; };
+struct LogUpProof {
+  std::vector<IOPProof> sumcheck_proofs;
+  std::vector<std::vector<Ext>> round_evaluations;
+  std::vector<Claim> output_claims;
+  std::vector<std::vector<Ext>> circuit_outputs;
+  bool is_table = false;
+};
+struct Commitment { Digest root; unsigned num_vars = 0; bool is_base = true; };
+struct FieldVec { bool is_ext = false; std::vector<u64> w; size_t len() const { return is_ext ? w.size() / 2 : w.size(); } };
+struct CodewordQuery { bool is_ext = false; Ext left, right; size_t index = 0; std::vector<Digest> path; };
+struct BatchedQuery { size_t index = 0; std::vector<CodewordQuery> oracle_query, commitments_query; };
+struct BasefoldProof {
+  std::vector<std::vector<Ext>> sumcheck_messages;
+  std::vector<Digest> roots;
+  std::vector<Ext> final_message;
+  std::vector<BatchedQuery> queries;
+  std::vector<std::vector<Ext>> sumcheck_proof;
+  std::vector<FieldVec> trivial_proof;
+  bool is_trivial() const { return sumcheck_messages.empty() && queries.empty() && sumcheck_proof.empty(); }
+};
+enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2 };
+struct DenseProof { IOPProof sumcheck; Ext bias_eval; std::vector<Ext> individual_claims; };
+struct SamePolyProof { IOPProof sumcheck; std::vector<Ext> evals; };
+struct ActivationProof { SamePolyProof io_accumulation; LogUpProof lookup; std::vector<Commitment> commits; };
+struct RequantProof { IOPProof io_accumulation; std::vector<Ext> accumulation_evals; LogUpProof clamping_lookup, shifted_lookup; std::vector<Commitment> commitments; };
+struct LayerProof { int kind = 0; DenseProof dense; ActivationProof act; RequantProof req; };
+struct TableProof { Commitment multiplicity_commit; LogUpProof lookup; };
+struct Proof {
+  std::map<size_t, LayerProof> steps;
+  std::vector<TableProof> table_proofs;
+  BasefoldProof batch_proof;
+  std::vector<BasefoldProof> trivial_proofs;
+};
+
+constexpr u64 PROOF_MAGIC = 0x31464F4F52505044ULL;  // "DPPROOF1"
+
+struct Writer {
+  std::vector<u64> w;
+  void u(u64 v) { w.push_back(v); }
+  void e(Ext x) { w.push_back(x.c0); w.push_back(x.c1); }
+  void ve(const std::vector<Ext>& v) { u(v.size()); for (const Ext& x : v) e(x); }
+  void d(const Digest& x) { for (int i = 0; i < 4; i++) u(x.v[i]); }
+  void iop(const IOPProof& p) { ve(p.point); u(p.proofs.size()); for (auto& r : p.proofs) ve(r); }
+  void claim(const Claim& c) { ve(c.point); e(c.eval); }
+  void logup(const LogUpProof& p) {
+    u(p.sumcheck_proofs.size()); for (auto& s : p.sumcheck_proofs) iop(s);
+    u(p.round_evaluations.size()); for (auto& r : p.round_evaluations) ve(r);
+    u(p.output_claims.size()); for (auto& c : p.output_claims) claim(c);
+    u(p.circuit_outputs.size()); for (auto& c : p.circuit_outputs) ve(c);
+    u(p.is_table ? 1 : 0);
+  }
+  void comm(const Commitment& c) { d(c.root); u(c.num_vars); u(c.is_base ? 1 : 0); }
+  void cq(const CodewordQuery& q) {
+    u(q.is_ext ? 1 : 0);
+    if (q.is_ext) { e(q.left); e(q.right); } else { u(q.left.c0); u(q.right.c0); }
+    u(q.index); u(q.path.size()); for (auto& x : q.path) d(x);
+  }
+  void basefold(const BasefoldProof& p) {
+    u(p.sumcheck_messages.size()); for (auto& m : p.sumcheck_messages) ve(m);
+    u(p.roots.size()); for (auto& r : p.roots) d(r);
+    ve(p.final_message);
+    u(p.queries.size());
+    for (auto& q : p.queries) {
+      u(q.index);
+      u(q.oracle_query.size()); for (auto& c : q.oracle_query) cq(c);
+      u(q.commitments_query.size()); for (auto& c : q.commitments_query) cq(c);
+    }
+    u(p.sumcheck_proof.size()); for (auto& m : p.sumcheck_proof) ve(m);
+    u(p.trivial_proof.size());
+    for (auto& m : p.trivial_proof) { u(m.is_ext ? 1 : 0); u(m.len()); for (u64 x : m.w) u(x); }
+  }
+};
+inline std::vector<u64> serialize_proof(const Proof& p) {
+  Writer w; w.u(PROOF_MAGIC); w.u(p.steps.size());
+  for (auto& kv : p.steps) {
+    const LayerProof& lp = kv.second;
+    w.u(kv.first); w.u((u64)lp.kind);
+    if (lp.kind == L_DENSE) { w.iop(lp.dense.sumcheck); w.e(lp.dense.bias_eval); w.ve(lp.dense.individual_claims); }
+    else if (lp.kind == L_REQUANT) {
+      w.iop(lp.req.io_accumulation); w.ve(lp.req.accumulation_evals); w.logup(lp.req.clamping_lookup); w.logup(lp.req.shifted_lookup);
+      w.u(lp.req.commitments.size()); for (auto& c : lp.req.commitments) w.comm(c);
+    } else {
+      w.iop(lp.act.io_accumulation.sumcheck); w.ve(lp.act.io_accumulation.evals); w.logup(lp.act.lookup);
+      w.u(lp.act.commits.size()); for (auto& c : lp.act.commits) w.comm(c);
+    }
+  }
+  w.u(p.table_proofs.size()); for (auto& tp : p.table_proofs) { w.comm(tp.multiplicity_commit); w.logup(tp.lookup); }
+  w.basefold(p.batch_proof);
+  w.u(p.trivial_proofs.size()); for (auto& tp : p.trivial_proofs) w.basefold(tp);
+  return w.w;
+}
+
+struct Reader {
+  const u64* p; size_t n, pos = 0;
+  Reader(const u64* p_, size_t n_) : p(p_), n(n_) {}
+  u64 u() { DP_REQUIRE(pos < n, DP_ERR_ARG, "proof stream truncated"); return p[pos++]; }
+  size_t len(size_t unit_words = 1) { u64 v = u(); DP_REQUIRE(v * unit_words <= n - pos, DP_ERR_ARG, "proof stream: bad length"); return (size_t)v; }
+  u64 fe() { u64 v = u(); DP_REQUIRE(v < GL_P, DP_ERR_ARG, "proof stream: non-canonical field element"); return v; }
+  Ext e() { u64 a = fe(); u64 b = fe(); return ex(a, b); }
+  std::vector<Ext> ve() { size_t k = len(2); std::vector<Ext> v(k); for (auto& x : v) x = e(); return v; }
+  Digest d() { Digest x; for (int i = 0; i < 4; i++) x.v[i] = fe(); return x; }
+  IOPProof iop() { IOPProof q; q.point = ve(); size_t k = len(); q.proofs.resize(k); for (auto& r : q.proofs) r = ve(); return q; }
+  Claim claim() { Claim c; c.point = ve(); c.eval = e(); return c; }
+  LogUpProof logup() {
+    LogUpProof q; size_t k = len(); q.sumcheck_proofs.resize(k); for (auto& s : q.sumcheck_proofs) s = iop();
+    k = len(); q.round_evaluations.resize(k); for (auto& r : q.round_evaluations) r = ve();
+    k = len(); q.output_claims.resize(k); for (auto& c : q.output_claims) c = claim();
+    k = len(); q.circuit_outputs.resize(k); for (auto& c : q.circuit_outputs) c = ve();
+    q.is_table = u() != 0; return q;
+  }
+  Commitment comm() { Commitment c; c.root = d(); c.num_vars = (unsigned)u(); c.is_base = u() != 0; return c; }
+  CodewordQuery cq() {
+    CodewordQuery q; q.is_ext = u() != 0;
+    if (q.is_ext) { q.left = e(); q.right = e(); } else { q.left = ex(fe(), 0); q.right = ex(fe(), 0); }
+    q.index = (size_t)u(); size_t k = len(4); q.path.resize(k); for (auto& x : q.path) x = d(); return q;
+  }
+  BasefoldProof basefold() {
+    BasefoldProof b; size_t k = len(); b.sumcheck_messages.resize(k); for (auto& m : b.sumcheck_messages) m = ve();
+    k = len(4); b.roots.resize(k); for (auto& r : b.roots) r = d();
+    b.final_message = ve();
+    k = len(); b.queries.resize(k);
+    for (auto& q : b.queries) {
+      q.index = (size_t)u();
+      size_t a = len(); q.oracle_query.resize(a); for (auto& c : q.oracle_query) c = cq();
+      a = len(); q.commitments_query.resize(a); for (auto& c : q.commitments_query) c = cq();
+    }
+    k = len(); b.sumcheck_proof.resize(k); for (auto& m : b.sumcheck_proof) m = ve();
+    k = len(); b.trivial_proof.resize(k);
+    for (auto& m : b.trivial_proof) { m.is_ext = u() != 0; size_t l = len(m.is_ext ? 2 : 1); m.w.resize(l * (m.is_ext ? 2 : 1)); for (auto& x : m.w) x = fe(); }
+    return b;
+  }
+};
+inline Proof deserialize_proof(const u64* words, size_t n) {
+  Reader r(words, n); Proof p;
+  DP_REQUIRE(r.u() == PROOF_MAGIC, DP_ERR_ARG, "bad proof magic");
+  size_t ns = r.len();
+  for (size_t i = 0; i < ns; i++) {
+    size_t id = (size_t)r.u(); LayerProof lp; lp.kind = (int)r.u();
+    if (lp.kind == L_DENSE) { lp.dense.sumcheck = r.iop(); lp.dense.bias_eval = r.e(); lp.dense.individual_claims = r.ve(); }
+    else if (lp.kind == L_REQUANT) {
+      lp.req.io_accumulation = r.iop(); lp.req.accumulation_evals = r.ve(); lp.req.clamping_lookup = r.logup(); lp.req.shifted_lookup = r.logup();
+      size_t k = r.len(); lp.req.commitments.resize(k); for (auto& c : lp.req.commitments) c = r.comm();
+    } else if (lp.kind == L_RELU) {
+      lp.act.io_accumulation.sumcheck = r.iop(); lp.act.io_accumulation.evals = r.ve(); lp.act.lookup = r.logup();
+      size_t k = r.len(); lp.act.commits.resize(k); for (auto& c : lp.act.commits) c = r.comm();
+    } else DP_REQUIRE(false, DP_ERR_ARG, "proof stream: unknown layer kind");
+    p.steps[id] = lp;
+  }
+  size_t nt = r.len(); p.table_proofs.resize(nt);
+  for (auto& tp : p.table_proofs) { tp.multiplicity_commit = r.comm(); tp.lookup = r.logup(); }
+  p.batch_proof = r.basefold();
+  size_t ntr = r.len(); p.trivial_proofs.resize(ntr); for (auto& tp : p.trivial_proofs) tp = r.basefold();
+  DP_REQUIRE(r.pos == n, DP_ERR_ARG, "proof stream: trailing words");
+  return p;
+}
+
+}  // namespace dp

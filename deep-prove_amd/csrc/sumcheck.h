@@ -1,0 +1,149 @@
+// Host orchestration of IOPProverState::prove_parallel (sumcheck/src/prover.rs:498-585) over device-resident tables,
+// and IOPVerifierState::verify (sumcheck/src/verifier.rs:12-168). The transcript stays on the host (as in the
+// reference); per round exactly one device->host message of raw per-term sums and one challenge back.
+#pragma once
+#include "proof.h"
+
+namespace dp {
+
+struct DevVP {  // VirtualPolynomial (multilinear_extensions/src/virtual_poly.rs:50-60) with tables in HBM
+  unsigned nv = 0, max_degree = 0;
+  std::vector<DBuf> tabs;
+  std::vector<Ext> coeffs;
+  std::vector<ScTerm> terms;
+  explicit DevVP(unsigned nv_) : nv(nv_) {}
+  int table_index(const DBuf& b) {
+    for (size_t i = 0; i < tabs.size(); i++) if (tabs[i].p == b.p && tabs[i].n == b.n) return (int)i;  // de-dup by identity
+    tabs.push_back(b);
+    return (int)tabs.size() - 1;
+  }
+  void add_mle_list(std::initializer_list<DBuf> list, Ext coeff) {
+    DP_REQUIRE(list.size() >= 1 && list.size() <= 3, DP_ERR_SHAPE, "sumcheck term degree must be 1..3");
+    ScTerm t; t.k = (int)list.size(); t.t[0] = t.t[1] = t.t[2] = 0;
+    int j = 0;
+    for (const DBuf& b : list) {
+      DP_REQUIRE(b.n == (size_t(1) << nv), DP_ERR_SHAPE, "sumcheck: every table must have max_num_variables variables");
+      t.t[j++] = table_index(b);
+    }
+    if ((unsigned)t.k > max_degree) max_degree = t.k;
+    terms.push_back(t);
+    coeffs.push_back(coeff);
+  }
+};
+
+// value at `at` of the polynomial with values evals[i] at i = 0..n-1 (what `extrapolate`, util.rs:101-136, computes)
+inline Ext lagrange_eval_small(const Ext* evals, size_t n, Ext at) {
+  Ext res = ex_zero();
+  for (size_t i = 0; i < n; i++) {
+    Ext num = ex_one(), den = ex_one();
+    for (size_t j = 0; j < n; j++) {
+      if (j == i) continue;
+      num = ex_mul(num, ex_sub(at, ex_from_u64(j)));
+      den = ex_mul(den, ex_sub(ex_from_u64(i), ex_from_u64(j)));
+    }
+    res = ex_add(res, ex_mul(evals[i], ex_mul(num, ex_inv(den))));
+  }
+  return res;
+}
+
+struct SumcheckOut { IOPProof proof; std::vector<Ext> finals; };
+
+inline SumcheckOut sumcheck_prove(Dev& dev, DevVP& vp, Transcript& t) {
+  SumcheckOut out;
+  unsigned nv = vp.nv, md = vp.max_degree;
+  DP_REQUIRE(nv > 0, DP_ERR_SHAPE, "sumcheck over a constant");
+  size_t mk = dev.mark();
+  t.append_usize(nv);
+  t.append_usize(md);
+  std::vector<DBuf> tabs = vp.tabs;
+  size_t nraw = 0;
+  for (auto& tm : vp.terms) nraw += tm.k + 1;
+  std::vector<Ext> raw(nraw);
+  Ext ch = ex_zero();
+  for (unsigned round = 0; round < nv; round++) {
+    dev.sc_round(tabs.data(), (int)tabs.size(), round ? &ch : nullptr, vp.terms.data(), (int)vp.terms.size(), raw.data());
+    std::vector<Ext> msg(md + 1, ex_zero());
+    size_t off = 0;
+    for (size_t ti = 0; ti < vp.terms.size(); ti++) {
+      unsigned k = vp.terms[ti].k;
+      std::vector<Ext> s(k + 1);
+      for (unsigned j = 0; j <= k; j++) s[j] = ex_mul(raw[off + j], vp.coeffs[ti]);
+      off += k + 1;
+      for (unsigned j = 0; j <= md; j++) {
+        Ext v = j <= k ? s[j] : lagrange_eval_small(s.data(), k + 1, ex_from_u64(j));
+        msg[j] = ex_add(msg[j], v);
+      }
+    }
+    for (const Ext& e : msg) t.append_ext(e);
+    out.proof.proofs.push_back(msg);
+    ch = t.get_and_append_challenge("Internal round");
+    out.proof.point.push_back(ch);
+  }
+  out.finals.resize(tabs.size());
+  dev.sc_finish(tabs.data(), (int)tabs.size(), ch, out.finals.data());
+  dev.release(mk);
+  return out;
+}
+
+// interpolate_uni_poly (sumcheck/src/util.rs:148-195) == Lagrange evaluation on nodes 0..len-1
+struct SubClaim { std::vector<Ext> point; Ext expected_evaluation; };
+inline SubClaim sumcheck_verify(Ext claimed_sum, const IOPProof& proof, unsigned nv, unsigned max_degree, Transcript& t) {
+  SubClaim sc;
+  if (nv == 0) { sc.expected_evaluation = claimed_sum; return sc; }
+  t.append_usize(nv);
+  t.append_usize(max_degree);
+  DP_REQUIRE(proof.proofs.size() >= nv, DP_ERR_VERIFY, "sumcheck proof is incomplete");
+  for (unsigned i = 0; i < nv; i++) {
+    for (const Ext& e : proof.proofs[i]) t.append_ext(e);
+    sc.point.push_back(t.get_and_append_challenge("Internal round"));
+  }
+  Ext expected = claimed_sum;
+  for (unsigned i = 0; i < nv; i++) {
+    const auto& ev = proof.proofs[i];
+    DP_REQUIRE(ev.size() == max_degree + 1, DP_ERR_VERIFY, "sumcheck: incorrect number of evaluations");
+    DP_REQUIRE(ex_eq(ex_add(ev[0], ev[1]), expected), DP_ERR_VERIFY, "sumcheck: round message inconsistent with the claim");
+    expected = lagrange_eval_small(ev.data(), ev.size(), sc.point[i]);
+  }
+  sc.expected_evaluation = expected;
+  return sc;
+}
+
+// host-side small helpers shared by provers and verifiers
+inline std::vector<Ext> host_eq_table(const std::vector<Ext>& r) {  // build_eq_x_r_vec / compute_betas_eval
+  std::vector<Ext> buf(size_t(1) << r.size());
+  buf[0] = ex_one();
+  size_t cur = 1;
+  for (size_t t = r.size(); t-- > 0;) {
+    for (size_t j = cur; j-- > 0;) {
+      Ext prod = ex_mul(r[t], buf[j]);
+      buf[2 * j + 1] = prod;
+      buf[2 * j] = ex_sub(buf[j], prod);
+    }
+    cur *= 2;
+  }
+  return buf;
+}
+inline Ext eq_eval(const Ext* x, const Ext* y, size_t n) {  // virtual_poly.rs:308-322 / commit/mod.rs:41-53
+  Ext res = ex_one();
+  for (size_t i = 0; i < n; i++) {
+    Ext xy = ex_mul(x[i], y[i]);
+    res = ex_mul(res, ex_add(ex_sub(ex_sub(ex_dbl(xy), x[i]), y[i]), ex_one()));
+  }
+  return res;
+}
+inline Ext identity_eval(const std::vector<Ext>& a, const std::vector<Ext>& b) {
+  size_t n = a.size() < b.size() ? a.size() : b.size();
+  return eq_eval(a.data(), b.data(), n);
+}
+// evaluate a small host-resident MLE (verifier side: model inputs/outputs, trivial openings)
+inline Ext host_mle_eval(std::vector<Ext> v, const std::vector<Ext>& pt) {
+  DP_REQUIRE(v.size() == (size_t(1) << pt.size()), DP_ERR_SHAPE, "MLE size does not match the point");
+  for (const Ext& r : pt) {
+    size_t h = v.size() / 2;
+    for (size_t i = 0; i < h; i++) v[i] = ex_lerp(v[2 * i], v[2 * i + 1], r);
+    v.resize(h);
+  }
+  return v[0];
+}
+
+}  // namespace dp

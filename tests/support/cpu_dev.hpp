@@ -1,0 +1,202 @@
+// TEST DOUBLE — lives under tests/, is never compiled into the product library.
+// A plain-loop CPU implementation of dp::Dev so that the host orchestrator (transcript order, claim routing, proof
+// assembly) can be byte-compared against the oracle in the `-m "not gpu"` suite, where no MI355X is present.
+// Every method is the literal spec of the corresponding HIP kernel family in deep-prove_amd/csrc/hip_dev.hip.
+#pragma once
+#include "../../deep-prove_amd/csrc/dev.h"
+#include <cstdlib>
+#include <cstring>
+
+namespace dp {
+
+class CpuDev : public Dev {
+  std::vector<void*> arena_;
+  unsigned full_log_ = 0;
+  static u64* B(const DBuf& b) { return (u64*)b.p; }
+  static Ext* X(const DBuf& b) { return (Ext*)b.p; }
+  static Ext at(const DBuf& b, size_t i) { return b.ext ? X(b)[i] : ex_base(B(b)[i]); }
+ public:
+  ~CpuDev() { release(0); }
+  const char* name() const override { return "cpu-test-double"; }
+  DBuf alloc(size_t n, bool ext) override {
+    DBuf b; b.n = n; b.ext = ext; b.p = aligned_alloc(16, std::max<size_t>(16, n * (ext ? 16 : 8))); arena_.push_back(b.p); return b;
+  }
+  size_t mark() override { return arena_.size(); }
+  void release(size_t m) override { while (arena_.size() > m) { free(arena_.back()); arena_.pop_back(); } }
+  DBuf alloc_persistent(size_t n, bool ext) override { DBuf b; b.n = n; b.ext = ext; b.p = aligned_alloc(16, std::max<size_t>(16, n * (ext ? 16 : 8))); return b; }
+  void free_persistent(DBuf& b) override { if (b.p) free(b.p); b.p = nullptr; }
+  void upload(const DBuf& d, const u64* s) override { memcpy(d.p, s, d.bytes()); }
+  void upload_i64(const DBuf& d, const int64_t* s) override { for (size_t i = 0; i < d.n; i++) B(d)[i] = gl_from_i64(s[i]); }
+  void download(const DBuf& s, u64* d) override { memcpy(d, s.p, s.bytes()); }
+  void copy(const DBuf& d, const DBuf& s) override { memcpy(d.p, s.p, s.bytes()); }
+  void sync() override {}
+  void eq_table(const DBuf& out, const Ext* pt, unsigned k, Ext scale, bool acc) override {
+    for (size_t i = 0; i < (size_t(1) << k); i++) {
+      Ext v = scale;
+      for (unsigned t = 0; t < k; t++) v = ex_mul(v, ((i >> t) & 1) ? pt[t] : ex_sub(ex_one(), pt[t]));
+      X(out)[i] = acc ? ex_add(X(out)[i], v) : v;
+    }
+  }
+  void mle_eval_batch(const DBuf* fs, int nf, const Ext* pt, unsigned k, Ext* out) override {
+    DBuf eq = alloc(size_t(1) << k, true);
+    eq_table(eq, pt, k, ex_one(), false);
+    for (int f = 0; f < nf; f++) {
+      Ext s = ex_zero();
+      for (size_t i = 0; i < fs[f].n; i++) s = ex_add(s, ex_mul(X(eq)[i], at(fs[f], i)));
+      out[f] = s;
+    }
+    release(mark() - 1);
+  }
+  void fix_high(const DBuf& out, const DBuf& W, size_t R, size_t C, const Ext* pt) override {
+    unsigned k = dp_ceil_log2(R);
+    DBuf eq = alloc(R, true);
+    eq_table(eq, pt, k, ex_one(), false);
+    for (size_t c = 0; c < C; c++) {
+      Ext s = ex_zero();
+      for (size_t r = 0; r < R; r++) s = ex_add(s, ex_mul_base(X(eq)[r], B(W)[r * C + c]));
+      X(out)[c] = s;
+    }
+    release(mark() - 1);
+  }
+  DBuf fold(const DBuf& in, Ext r) {
+    DBuf o = alloc(in.n / 2, true);
+    for (size_t i = 0; i < in.n / 2; i++) X(o)[i] = in.ext ? ex_lerp(X(in)[2 * i], X(in)[2 * i + 1], r) : ex_lerp_base(B(in)[2 * i], B(in)[2 * i + 1], r);
+    return o;
+  }
+  void sc_round(DBuf* tabs, int nt, const Ext* r, const ScTerm* terms, int nterms, Ext* out) override {
+    if (r) for (int i = 0; i < nt; i++) tabs[i] = fold(tabs[i], *r);
+    size_t o = 0;
+    for (int ti = 0; ti < nterms; ti++) {
+      int k = terms[ti].k;
+      for (int t = 0; t <= k; t++) out[o + t] = ex_zero();
+      size_t n = tabs[terms[ti].t[0]].n;
+      for (size_t b = 0; b + 1 < n; b += 2)
+        for (int t = 0; t <= k; t++) {
+          Ext p = ex_one();
+          for (int j = 0; j < k; j++) { Ext a = at(tabs[terms[ti].t[j]], b), bb = at(tabs[terms[ti].t[j]], b + 1); p = ex_mul(p, ex_add(a, ex_mul(ex_from_u64(t), ex_sub(bb, a)))); }
+          out[o + t] = ex_add(out[o + t], p);
+        }
+      o += k + 1;
+    }
+  }
+  void sc_finish(DBuf* tabs, int nt, Ext r, Ext* fin) override { for (int i = 0; i < nt; i++) { tabs[i] = fold(tabs[i], r); fin[i] = X(tabs[i])[0]; } }
+  void logup_den(const DBuf& out, const DBuf* cols, int nc, Ext c, Ext chi) override {
+    for (size_t i = 0; i < out.n; i++) { Ext acc = c, pw = ex_one(); for (int j = 0; j < nc; j++) { acc = ex_add(acc, ex_mul_base(pw, B(cols[j])[i])); pw = ex_mul(pw, chi); } X(out)[i] = acc; }
+  }
+  void logup_layer(const DBuf& ni, const DBuf& di, const DBuf& no, const DBuf& dout) override {
+    size_t h = di.n / 2;
+    Ext m1 = ex_neg(ex_one());
+    for (size_t i = 0; i < h; i++) {
+      Ext n1 = ni.null() ? m1 : at(ni, i), n2 = ni.null() ? m1 : at(ni, i + h), d1 = X(di)[i], d2 = X(di)[i + h];
+      X(no)[i] = ex_add(ex_mul(n1, d2), ex_mul(d1, n2));
+      X(dout)[i] = ex_mul(d1, d2);
+    }
+  }
+  void pcs_init(unsigned fl) override { full_log_ = fl; }
+  void bitrev_copy(const DBuf& d, const DBuf& s) override {
+    unsigned lg = dp_ceil_log2(s.n);
+    for (size_t i = 0; i < s.n; i++) { size_t j = dp_reverse_bits(i, lg); if (s.ext) X(d)[j] = X(s)[i]; else B(d)[j] = B(s)[i]; }
+  }
+  DevTree build_tree(const DBuf& leaves, bool persistent) {
+    DevTree t; t.leaves = leaves; t.nleaves = leaves.n;
+    size_t n = leaves.n;
+    t.nodes = persistent ? alloc_persistent(4 * (n - 1), false) : alloc(4 * (n - 1), false);
+    u64* nd = B(t.nodes);
+    for (size_t i = 0; i < n / 2; i++) {
+      u64* d = nd + 4 * i;
+      if (leaves.ext) { d[0] = X(leaves)[2 * i].c0; d[1] = X(leaves)[2 * i].c1; d[2] = X(leaves)[2 * i + 1].c0; d[3] = X(leaves)[2 * i + 1].c1; }
+      else { d[0] = B(leaves)[2 * i]; d[1] = B(leaves)[2 * i + 1]; d[2] = 0; d[3] = 0; }
+    }
+    size_t off = 0, cnt = n / 2;
+    while (cnt > 1) {
+      for (size_t i = 0; i < cnt / 2; i++) poseidon2_compress(nd + 4 * (off + 2 * i), nd + 4 * (off + 2 * i + 1), nd + 4 * (off + cnt + i), POSEIDON2_RC_HOST);
+      off += cnt; cnt /= 2;
+    }
+    for (int k = 0; k < 4; k++) t.root.v[k] = nd[4 * (n - 2) + k];
+    return t;
+  }
+  DevCommit commit(const DBuf& evals, bool persistent) override {
+    DevCommit c; c.nv = dp_ceil_log2(evals.n); c.is_base = !evals.ext; c.evals = evals;
+    auto A = [&](size_t n, bool e) { return persistent ? alloc_persistent(n, e) : alloc(n, e); };
+    if (c.nv <= 7) { c.bh_evals = evals; c.tree = build_tree(evals, persistent); return c; }
+    size_t n = evals.n;
+    DBuf co = alloc(n, evals.ext); copy(co, evals);
+    for (unsigned i = 1; i <= c.nv; i++) {  // interpolate_over_boolean_hypercube
+      size_t chunk = size_t(1) << i, half = chunk >> 1;
+      for (size_t s = 0; s < n; s += chunk) for (size_t j = half; j < chunk; j++) { if (co.ext) X(co)[s + j] = ex_sub(X(co)[s + j], X(co)[s + j - half]); else B(co)[s + j] = gl_sub(B(co)[s + j], B(co)[s + j - half]); }
+    }
+    // RS encode of the bit-reversed coefficient vector on the coset shift*H, |H| = 2n; then bit-reverse the codeword.
+    u64 shift = GL_GENERATOR; for (unsigned i = 0; i < full_log_ - c.nv; i++) shift = gl_sqr(shift);
+    u64 w = GL_G32; for (unsigned i = c.nv + 1; i < 32; i++) w = gl_sqr(w);
+    DBuf cw = A(2 * n, evals.ext);
+    // naive-but-exact DFT is O(n^2); use an in-place radix-2 on a scratch copy instead
+    std::vector<Ext> a(2 * n, ex_zero());
+    for (size_t i = 0; i < n; i++) { size_t j = dp_reverse_bits(i, c.nv); a[j] = ex_mul_base(at(co, i), gl_pow(shift, j)); }
+    // iterative DIT FFT over base-field roots
+    unsigned lg = c.nv + 1; size_t N = 2 * n;
+    for (size_t i = 0; i < N; i++) { size_t j = dp_reverse_bits(i, lg); if (i < j) std::swap(a[i], a[j]); }
+    for (unsigned s = 1; s <= lg; s++) {
+      size_t m = size_t(1) << s, hm = m >> 1; u64 wm = gl_pow(w, N / m);
+      for (size_t k = 0; k < N; k += m) { u64 tw = 1; for (size_t j = 0; j < hm; j++) { Ext t = ex_mul_base(a[k + j + hm], tw), u = a[k + j]; a[k + j] = ex_add(u, t); a[k + j + hm] = ex_sub(u, t); tw = gl_mul(tw, wm); } }
+    }
+    for (size_t i = 0; i < N; i++) { size_t j = dp_reverse_bits(i, lg); if (cw.ext) X(cw)[j] = a[i]; else B(cw)[j] = a[i].c0; }
+    c.bh_evals = A(n, evals.ext); bitrev_copy(c.bh_evals, evals);
+    c.tree = build_tree(cw, persistent);
+    return c;
+  }
+  void free_commit(DevCommit& c) override {
+    if (c.bh_evals.p && c.bh_evals.p != c.evals.p) free_persistent(c.bh_evals);
+    if (c.tree.leaves.p && c.tree.leaves.p != c.evals.p) free_persistent(c.tree.leaves);
+    free_persistent(c.tree.nodes); free_persistent(c.evals);
+  }
+  DevTree merkle_ext(const DBuf& leaves) override { return build_tree(leaves, false); }
+  void classic_round(DBuf* fs, DBuf* eqs, int np, const Ext* r, Ext* out) override {
+    for (int i = 0; i < np; i++) {
+      if (r && fs[i].n > 1) { fs[i] = fold(fs[i], *r); eqs[i] = fold(eqs[i], *r); }
+      Ext c0 = ex_zero(), c2 = ex_zero();
+      if (fs[i].n == 1) c0 = ex_mul(at(fs[i], 0), at(eqs[i], 0));
+      else for (size_t j = 0; j + 1 < fs[i].n; j += 2) {
+        Ext l0 = at(eqs[i], j), l1 = at(eqs[i], j + 1), r0 = at(fs[i], j), r1 = at(fs[i], j + 1);
+        c0 = ex_add(c0, ex_mul(l0, r0)); c2 = ex_add(c2, ex_mul(ex_sub(l1, l0), ex_sub(r1, r0)));
+      }
+      out[2 * i] = c0; out[2 * i + 1] = c2;
+    }
+  }
+  void axpy_rep(const DBuf& acc, const DBuf& x, Ext coeff, size_t rep) override {
+    for (size_t j = 0; j < x.n; j++) { Ext m = ex_mul(at(x, j), coeff); for (size_t q = 0; q < rep; q++) X(acc)[j * rep + q] = ex_add(X(acc)[j * rep + q], m); }
+  }
+  void bf_round(DBuf& eq, DBuf& f, const Ext* ch, Ext* msg) override {
+    if (ch) { eq = fold(eq, *ch); f = fold(f, *ch); }
+    if (!msg) return;
+    Ext c0 = ex_zero(), c1 = ex_zero(), c2 = ex_zero();
+    if (f.n == 1) { msg[0] = msg[1] = msg[2] = X(f)[0]; return; }
+    for (size_t j = 0; j + 1 < f.n; j += 2) {
+      Ext a = X(f)[j], b = ex_sub(X(f)[j + 1], a), ea = X(eq)[j], eb = ex_sub(X(eq)[j + 1], ea);
+      c0 = ex_add(c0, ex_mul(a, ea)); c1 = ex_add(c1, ex_add(ex_mul(b, ea), ex_mul(a, eb))); c2 = ex_add(c2, ex_mul(b, eb));
+    }
+    msg[0] = c0; msg[1] = c1; msg[2] = c2;
+  }
+  DBuf fri_fold(const DBuf& o, unsigned level, Ext ch) override {
+    DBuf out = alloc(o.n / 2, true);
+    u64 g = GL_G32; for (unsigned i = level + 1; i < 32; i++) g = gl_sqr(g);
+    u64 gam = GL_GENERATOR; for (unsigned i = 0; i < full_log_ + 1 - level - 1; i++) gam = gl_sqr(gam);
+    for (size_t i = 0; i < o.n / 2; i++) {
+      u64 x0 = gl_mul(gl_pow(g, dp_reverse_bits(i, level)), gam), w = gl_neg(gl_inv(gl_dbl(x0)));
+      Ext y0 = X(o)[2 * i], y1 = X(o)[2 * i + 1];
+      X(out)[i] = ex_add(y0, ex_mul(ex_mul(ex_sub(ch, ex_base(x0)), ex_sub(y1, y0)), ex_base(w)));
+    }
+    return out;
+  }
+  void query_gather(const QueryDesc* d, size_t nd, std::vector<std::vector<u64>>& out) override {
+    out.resize(nd);
+    for (size_t i = 0; i < nd; i++) {
+      const DevTree& t = *d[i].tree; std::vector<u64>& w = out[i]; w.clear();
+      size_t p0 = d[i].p0;
+      if (t.leaves.ext) { Ext a = X(t.leaves)[p0], b = X(t.leaves)[p0 + 1]; w = {a.c0, a.c1, b.c0, b.c1}; } else w = {B(t.leaves)[p0], B(t.leaves)[p0 + 1]};
+      unsigned h = t.height();
+      for (unsigned l = 0; l + 1 < h; l++) { size_t off = t.nleaves - (t.nleaves >> l); size_t idx = (p0 >> (l + 1)) ^ 1; const u64* dg = B(t.nodes) + 4 * (off + idx); for (int k = 0; k < 4; k++) w.push_back(dg[k]); }
+    }
+  }
+};
+
+}  // namespace dp
