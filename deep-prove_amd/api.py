@@ -1,0 +1,326 @@
+"""Host-side mirror of the reference's operator surface for the sumcheck / logup-GKR / Basefold hot path:
+
+    reference (Rust)                                             here
+    -----------------------------------------------------------  -----------------------------------------
+    transcript::BasicTranscript                                  Transcript
+    multilinear_extensions::DenseMultilinearExtension            Mle (device resident table)
+    sumcheck::IOPProverState::prove_parallel(VirtualPolynomial)  VirtualPolynomial + prove_parallel
+    zkml::lookup::logup_gkr::prover::batch_prove                 logup_batch_prove
+    mpcs::PolynomialCommitmentScheme (Basefold RS/Poseidon)      Basefold.setup/commit/batch_open/batch_verify
+    zkml::Context::generate / Prover::prove / verify             Context.generate / Prover.prove / verify
+
+All O(n) work happens in libdeepprove_hip.so on the MI355X; field elements are canonical python ints / numpy uint64.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, u64p, i64p, i32p, u32p, vp
+
+P = 0xFFFFFFFF00000001
+
+
+def _u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a, a.ctypes.data_as(u64p)
+
+
+def _take(ptr, n):
+    """copy a malloc'ed uint64 buffer returned by the library into numpy and free it"""
+    out = np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.zeros(0, dtype=np.uint64)
+    _lib.load().dp_free(ptr)
+    return out
+
+
+class Device:
+    """dp_ctx: one MI355X, one stream, one arena. Raises if no HIP device is present (no CPU fallback)."""
+
+    def __init__(self, device_id=0):
+        self._lib = _lib.load()
+        h = vp()
+        check(self._lib.dp_ctx_create(device_id, C.byref(h)))
+        self.h = h
+
+    @property
+    def name(self):
+        return self._lib.dp_ctx_name(self.h).decode()
+
+    def profile(self, on):
+        check(self._lib.dp_profile_enable(self.h, 1 if on else 0))
+
+    def profile_report(self):
+        import json
+        s = C.c_char_p()
+        check(self._lib.dp_profile_report(self.h, C.byref(s)))
+        out = json.loads(s.value.decode())
+        return out
+
+    def close(self):
+        if self.h:
+            self._lib.dp_ctx_destroy(self.h)
+            self.h = None
+
+
+class Transcript:
+    """transcript::BasicTranscript (transcript/src/basic.rs:8-54)"""
+
+    def __init__(self, label=b"m2vec"):
+        self._lib = _lib.load()
+        self.h = vp(self._lib.dp_transcript_new(label))
+
+    def append_field_elements(self, elems):
+        a, p = _u64(elems)
+        check(self._lib.dp_transcript_append_elements(self.h, p, a.size))
+
+    def append_message(self, msg: bytes):
+        check(self._lib.dp_transcript_append_message(self.h, msg, len(msg)))
+
+    def get_and_append_challenge(self, label: bytes):
+        out = (C.c_uint64 * 2)()
+        check(self._lib.dp_transcript_challenge(self.h, label, out))
+        return (int(out[0]), int(out[1]))
+
+    def read_challenge(self):
+        out = (C.c_uint64 * 2)()
+        check(self._lib.dp_transcript_challenge(self.h, None, out))
+        return (int(out[0]), int(out[1]))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self._lib.dp_transcript_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def _point(pt):
+    """list of (c0, c1) -> flat uint64"""
+    return np.array([w for e in pt for w in e], dtype=np.uint64)
+
+
+class Mle:
+    """DenseMultilinearExtension resident in HBM (FieldType::Base or FieldType::Ext)."""
+
+    def __init__(self, dev, handle):
+        self.dev, self.h = dev, handle
+        self._lib = _lib.load()
+
+    @staticmethod
+    def from_i64(dev, v):
+        v = np.ascontiguousarray(v, dtype=np.int64)
+        h = vp()
+        check(_lib.load().dp_buf_from_i64(dev.h, v.ctypes.data_as(i64p), v.size, C.byref(h)))
+        return Mle(dev, h)
+
+    @staticmethod
+    def from_base(dev, words):
+        a, p = _u64(words)
+        h = vp()
+        check(_lib.load().dp_buf_upload(dev.h, p, a.size, 0, C.byref(h)))
+        return Mle(dev, h)
+
+    @staticmethod
+    def from_ext(dev, words):
+        a, p = _u64(words)
+        h = vp()
+        check(_lib.load().dp_buf_upload(dev.h, p, a.size // 2, 1, C.byref(h)))
+        return Mle(dev, h)
+
+    def __len__(self):
+        return self._lib.dp_buf_len(self.h)
+
+    @property
+    def is_ext(self):
+        return bool(self._lib.dp_buf_is_ext(self.h))
+
+    @property
+    def num_vars(self):
+        return len(self).bit_length() - 1
+
+    def to_numpy(self):
+        out = np.zeros(len(self) * (2 if self.is_ext else 1), dtype=np.uint64)
+        check(self._lib.dp_buf_download(self.dev.h, self.h, out.ctypes.data_as(u64p)))
+        return out
+
+    def evaluate(self, point):
+        a, p = _u64(_point(point))
+        out = (C.c_uint64 * 2)()
+        check(self._lib.dp_mle_eval(self.dev.h, self.h, p, len(point), out))
+        return (int(out[0]), int(out[1]))
+
+    def fix_high_variables(self, rows, cols, point):
+        """rows x cols base matrix, log2(rows)-coordinate point -> Mle of `cols` extension elements (K2)"""
+        a, p = _u64(_point(point))
+        h = vp()
+        check(self._lib.dp_mle_fix_high(self.dev.h, self.h, rows, cols, p, C.byref(h)))
+        return Mle(self.dev, h)
+
+    def free(self):
+        if self.h:
+            self._lib.dp_buf_free(self.dev.h, self.h)
+            self.h = None
+
+
+def build_eq_x_r(dev, point):
+    a, p = _u64(_point(point))
+    h = vp()
+    check(_lib.load().dp_eq_table(dev.h, p, len(point), C.byref(h)))
+    return Mle(dev, h)
+
+
+class VirtualPolynomial:
+    """sum_i c_i * prod_j MLE  (multilinear_extensions/src/virtual_poly.rs:50-60)"""
+
+    def __init__(self, num_vars):
+        self.num_vars = num_vars
+        self.tables = []
+        self.terms = []  # (coeff (c0,c1), [table indices])
+
+    def add_mle_list(self, mles, coeff=(1, 0)):
+        idx = []
+        for m in mles:
+            for i, t in enumerate(self.tables):
+                if t is m:
+                    idx.append(i)
+                    break
+            else:
+                self.tables.append(m)
+                idx.append(len(self.tables) - 1)
+        self.terms.append((coeff, idx))
+
+
+def prove_parallel(dev, vpoly, transcript):
+    """IOPProverState::prove_parallel: returns (proof_words, final_evaluations)"""
+    lib = _lib.load()
+    nt = len(vpoly.tables)
+    tabs = (vp * nt)(*[t.h for t in vpoly.tables])
+    deg = np.array([len(ix) for _, ix in vpoly.terms], dtype=np.int32)
+    tt = np.zeros(3 * len(vpoly.terms), dtype=np.int32)
+    for i, (_, ix) in enumerate(vpoly.terms):
+        tt[3 * i:3 * i + len(ix)] = ix
+    co = np.array([w for c, _ in vpoly.terms for w in c], dtype=np.uint64)
+    pw, pn = u64p(), C.c_size_t()
+    finals = np.zeros(2 * nt, dtype=np.uint64)
+    check(lib.dp_sumcheck_prove(dev.h, vpoly.num_vars, tabs, nt, deg.ctypes.data_as(i32p), tt.ctypes.data_as(i32p),
+                                co.ctypes.data_as(u64p), len(vpoly.terms), transcript.h, C.byref(pw), C.byref(pn),
+                                finals.ctypes.data_as(u64p)))
+    return _take(pw, pn.value), finals
+
+
+def logup_batch_prove(dev, columns, columns_per_instance, constant_challenge, column_separation_challenge, transcript,
+                      multiplicities=None):
+    lib = _lib.load()
+    cols = (vp * len(columns))(*[c.h for c in columns])
+    cc = (C.c_uint64 * 2)(*constant_challenge)
+    cs = (C.c_uint64 * 2)(*column_separation_challenge)
+    pw, pn = u64p(), C.c_size_t()
+    check(lib.dp_logup_prove(dev.h, cols, len(columns), columns_per_instance,
+                             multiplicities.h if multiplicities is not None else None, cc, cs, transcript.h,
+                             C.byref(pw), C.byref(pn)))
+    return _take(pw, pn.value)
+
+
+class Commitment:
+    def __init__(self, dev, handle, root, poly):
+        self.dev, self.h, self.root, self.poly = dev, handle, root, poly
+
+    @property
+    def num_vars(self):
+        return self.poly.num_vars
+
+    def free(self):
+        if self.h:
+            _lib.load().dp_pcs_commit_free(self.dev.h, self.h)
+            self.h = None
+
+
+class Basefold:
+    """mpcs::PolynomialCommitmentScheme for Basefold<GoldilocksExt2, BasefoldRSParams<PoseidonHasher>>"""
+
+    def __init__(self, dev, max_poly_size):
+        self.dev, self.max_poly_size = dev, max_poly_size
+        check(_lib.load().dp_pcs_setup(dev.h, max_poly_size))
+
+    def commit(self, poly):
+        h = vp()
+        root = (C.c_uint64 * 4)()
+        check(_lib.load().dp_pcs_commit(self.dev.h, poly.h, C.byref(h), root))
+        return Commitment(self.dev, h, [int(x) for x in root], poly)
+
+    def batch_open(self, comms, points, evals, transcript):
+        lib = _lib.load()
+        hs = (vp * len(comms))(*[c.h for c in comms])
+        pf = np.concatenate([_point(p) for p in points]).astype(np.uint64)
+        ev = _point(evals)
+        pw, pn = u64p(), C.c_size_t()
+        check(lib.dp_pcs_batch_open(self.dev.h, hs, len(comms), pf.ctypes.data_as(u64p), ev.ctypes.data_as(u64p),
+                                    transcript.h, C.byref(pw), C.byref(pn)))
+        return _take(pw, pn.value)
+
+    @staticmethod
+    def batch_verify(max_poly_size, roots, num_vars, is_base, points, evals, proof_words, transcript):
+        lib = _lib.load()
+        r = np.array([w for root in roots for w in root], dtype=np.uint64)
+        nv = np.array(num_vars, dtype=np.uint32)
+        ib = np.array([1 if b else 0 for b in is_base], dtype=np.int32)
+        pf = np.concatenate([_point(p) for p in points]).astype(np.uint64)
+        ev = _point(evals)
+        pw = np.ascontiguousarray(proof_words, dtype=np.uint64)
+        check(lib.dp_pcs_batch_verify(max_poly_size, r.ctypes.data_as(u64p), nv.ctypes.data_as(u32p),
+                                      ib.ctypes.data_as(i32p), len(roots), pf.ctypes.data_as(u64p),
+                                      ev.ctypes.data_as(u64p), pw.ctypes.data_as(u64p), pw.size, transcript.h))
+
+
+class Context:
+    """zkml::Context (zkml/src/iop/context.rs:37-52): model commitments + PCS params + lookup tables, device resident."""
+
+    def __init__(self, dev, handle, model_blob):
+        self.dev, self.h, self.model_blob = dev, handle, model_blob
+
+    @staticmethod
+    def generate(dev, model_blob):
+        b = np.ascontiguousarray(model_blob, dtype=np.int64)
+        h = vp()
+        check(_lib.load().dp_model_setup(dev.h, b.ctypes.data_as(i64p), b.size, C.byref(h)))
+        return Context(dev, h, b)
+
+    def verifier_blob(self):
+        pw, pn = u64p(), C.c_size_t()
+        check(_lib.load().dp_model_verifier_blob(self.h, C.byref(pw), C.byref(pn)))
+        return _take(pw, pn.value)
+
+    def free(self):
+        if self.h:
+            _lib.load().dp_model_free(self.h)
+            self.h = None
+
+
+class Prover:
+    """zkml::Prover (zkml/src/iop/prover.rs:40-58). prove() = Model::run on the host + Prover::prove on the device."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.last_prove_ms = None
+
+    def prove(self, input_i64):
+        x = np.ascontiguousarray(input_i64, dtype=np.int64)
+        pw, pn = u64p(), C.c_size_t()
+        out = np.zeros(1 << 20, dtype=np.int64)
+        no = C.c_size_t(out.size)
+        ms = C.c_double()
+        check(_lib.load().dp_model_prove(self.ctx.h, x.ctypes.data_as(i64p), x.size, C.byref(pw), C.byref(pn),
+                                         out.ctypes.data_as(i64p), C.byref(no), C.byref(ms)))
+        self.last_prove_ms = ms.value
+        return _take(pw, pn.value), out[:no.value].copy()
+
+
+def verify(verifier_blob, proof_words, input_i64, output_i64):
+    """zkml::verify (zkml/src/iop/verifier.rs:306-318). Host only. Raises DeepProveError(DP_ERR_VERIFY) on rejection."""
+    vb = np.ascontiguousarray(verifier_blob, dtype=np.uint64)
+    pw = np.ascontiguousarray(proof_words, dtype=np.uint64)
+    x = np.ascontiguousarray(input_i64, dtype=np.int64)
+    y = np.ascontiguousarray(output_i64, dtype=np.int64)
+    check(_lib.load().dp_verify(vb.ctypes.data_as(u64p), vb.size, pw.ctypes.data_as(u64p), pw.size,
+                                x.ctypes.data_as(i64p), x.size, y.ctypes.data_as(i64p), y.size))

@@ -1,0 +1,294 @@
+// extern "C" surface of libdeepprove_hip.so (declared in include/deep_prove_hip.h).
+#include "../../include/deep_prove_hip.h"
+#include "zkml.h"
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+
+namespace dp { Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
+using namespace dp;
+
+struct dp_ctx { Dev* dev; };
+struct dp_buf { DBuf b; };
+struct dp_transcript { Transcript t; };
+struct dp_commit { DevCommit c; };
+struct dp_model { dp_ctx* ctx; std::unique_ptr<Context> zk; };
+
+static thread_local std::string g_err;
+template <class F>
+static int32_t guard(F f) {
+  try { f(); return DP_OK; }
+  catch (const DpError& e) { g_err = e.what(); return e.code; }
+  catch (const std::bad_alloc&) { g_err = "host out of memory"; return DP_ERR_OOM; }
+  catch (const std::exception& e) { g_err = e.what(); return DP_ERR_ARG; }
+  catch (...) { g_err = "unknown error"; return DP_ERR_ARG; }
+}
+static uint64_t* copy_out(const std::vector<u64>& w) {
+  uint64_t* p = (uint64_t*)malloc(std::max<size_t>(w.size(), 1) * 8);
+  if (!p) throw std::bad_alloc();
+  memcpy(p, w.data(), w.size() * 8);
+  return p;
+}
+static std::vector<Ext> read_point(const uint64_t* w, size_t k) {
+  std::vector<Ext> p(k);
+  for (size_t i = 0; i < k; i++) { DP_REQUIRE(w[2 * i] < GL_P && w[2 * i + 1] < GL_P, DP_ERR_ARG, "non-canonical field element"); p[i] = ex(w[2 * i], w[2 * i + 1]); }
+  return p;
+}
+
+extern "C" {
+
+const char* dp_last_error(void) { return g_err.c_str(); }
+void dp_free(void* p) { free(p); }
+
+int32_t dp_ctx_create(int32_t device_id, dp_ctx** out) {
+  return guard([&] { DP_REQUIRE(out, DP_ERR_ARG, "null out"); Dev* d = make_hip_dev(device_id); *out = new dp_ctx{d}; });
+}
+int32_t dp_ctx_destroy(dp_ctx* ctx) { return guard([&] { if (ctx) { delete ctx->dev; delete ctx; } }); }
+const char* dp_ctx_name(const dp_ctx* ctx) { return ctx ? ctx->dev->name() : ""; }
+
+int32_t dp_profile_enable(dp_ctx* ctx, int32_t on) { return guard([&] { DP_REQUIRE(ctx, DP_ERR_ARG, "null ctx"); hip_dev_profile_enable(ctx->dev, on != 0); }); }
+int32_t dp_profile_report(dp_ctx* ctx, char** json) {
+  return guard([&] { DP_REQUIRE(ctx && json, DP_ERR_ARG, "bad arguments"); std::string r = hip_dev_profile_report(ctx->dev); char* p = (char*)malloc(r.size() + 1); if (!p) throw std::bad_alloc(); memcpy(p, r.c_str(), r.size() + 1); *json = p; });
+}
+int32_t dp_buf_from_i64(dp_ctx* ctx, const int64_t* v, size_t n, dp_buf** out) {
+  return guard([&] { DP_REQUIRE(ctx && v && out && n, DP_ERR_ARG, "bad arguments"); DBuf b = ctx->dev->alloc_persistent(n, false); ctx->dev->upload_i64(b, v); *out = new dp_buf{b}; });
+}
+int32_t dp_buf_upload(dp_ctx* ctx, const uint64_t* words, size_t n, int32_t is_ext, dp_buf** out) {
+  return guard([&] {
+    DP_REQUIRE(ctx && words && out && n, DP_ERR_ARG, "bad arguments");
+    for (size_t i = 0; i < n * (is_ext ? 2 : 1); i++) DP_REQUIRE(words[i] < GL_P, DP_ERR_ARG, "non-canonical field element");
+    DBuf b = ctx->dev->alloc_persistent(n, is_ext != 0); ctx->dev->upload(b, words); *out = new dp_buf{b};
+  });
+}
+int32_t dp_buf_download(dp_ctx* ctx, const dp_buf* buf, uint64_t* o) { return guard([&] { DP_REQUIRE(ctx && buf && o, DP_ERR_ARG, "bad arguments"); ctx->dev->download(buf->b, o); }); }
+size_t dp_buf_len(const dp_buf* buf) { return buf ? buf->b.n : 0; }
+int32_t dp_buf_is_ext(const dp_buf* buf) { return buf && buf->b.ext; }
+int32_t dp_buf_free(dp_ctx* ctx, dp_buf* buf) { return guard([&] { if (buf) { ctx->dev->free_persistent(buf->b); delete buf; } }); }
+
+dp_transcript* dp_transcript_new(const char* label) { dp_transcript* t = new dp_transcript(); if (label) t->t.append_message(label); return t; }
+void dp_transcript_free(dp_transcript* t) { delete t; }
+int32_t dp_transcript_append_elements(dp_transcript* t, const uint64_t* e, size_t n) {
+  return guard([&] { DP_REQUIRE(t && (e || !n), DP_ERR_ARG, "bad arguments"); for (size_t i = 0; i < n; i++) { DP_REQUIRE(e[i] < GL_P, DP_ERR_ARG, "non-canonical field element"); t->t.append_field_element(e[i]); } });
+}
+int32_t dp_transcript_append_message(dp_transcript* t, const uint8_t* b, size_t n) { return guard([&] { DP_REQUIRE(t && (b || !n), DP_ERR_ARG, "bad arguments"); t->t.append_message(b, n); }); }
+int32_t dp_transcript_challenge(dp_transcript* t, const char* label, uint64_t out[2]) {
+  return guard([&] { DP_REQUIRE(t && out, DP_ERR_ARG, "bad arguments"); Ext c = label ? t->t.get_and_append_challenge(label) : t->t.read_challenge(); out[0] = c.c0; out[1] = c.c1; });
+}
+
+int32_t dp_eq_table(dp_ctx* ctx, const uint64_t* point, uint32_t k, dp_buf** out) {
+  return guard([&] {
+    DP_REQUIRE(ctx && point && out && k <= 30, DP_ERR_ARG, "bad arguments");
+    std::vector<Ext> p = read_point(point, k);
+    DBuf b = ctx->dev->alloc_persistent(size_t(1) << k, true);
+    ctx->dev->eq_table(b, p.data(), k, ex_one(), false);
+    ctx->dev->sync();
+    *out = new dp_buf{b};
+  });
+}
+int32_t dp_mle_eval(dp_ctx* ctx, const dp_buf* f, const uint64_t* point, uint32_t k, uint64_t out[2]) {
+  return guard([&] {
+    DP_REQUIRE(ctx && f && point && out && f->b.n == (size_t(1) << k), DP_ERR_SHAPE, "MLE size does not match the point");
+    std::vector<Ext> p = read_point(point, k); Ext r;
+    ctx->dev->mle_eval_batch(&f->b, 1, p.data(), k, &r);
+    out[0] = r.c0; out[1] = r.c1;
+  });
+}
+int32_t dp_mle_fix_high(dp_ctx* ctx, const dp_buf* m, size_t rows, size_t cols, const uint64_t* point, dp_buf** out) {
+  return guard([&] {
+    DP_REQUIRE(ctx && m && point && out && is_pow2(rows) && is_pow2(cols) && !m->b.ext && m->b.n == rows * cols, DP_ERR_SHAPE, "fix_high: bad matrix shape");
+    std::vector<Ext> p = read_point(point, dp_ceil_log2(rows));
+    DBuf b = ctx->dev->alloc_persistent(cols, true);
+    ctx->dev->fix_high(b, m->b, rows, cols, p.data());
+    ctx->dev->sync();
+    *out = new dp_buf{b};
+  });
+}
+
+int32_t dp_sumcheck_prove(dp_ctx* ctx, uint32_t nv, const dp_buf* const* tables, int32_t ntables, const int32_t* term_degree,
+                          const int32_t* term_tables, const uint64_t* term_coeffs, int32_t nterms, dp_transcript* t,
+                          uint64_t** proof_words, size_t* proof_nwords, uint64_t* finals) {
+  return guard([&] {
+    DP_REQUIRE(ctx && tables && term_degree && term_tables && term_coeffs && t && proof_words && proof_nwords && ntables > 0 && nterms > 0 && nv > 0, DP_ERR_ARG, "bad arguments");
+    DevVP vp(nv);
+    for (int i = 0; i < ntables; i++) { DP_REQUIRE(tables[i] && tables[i]->b.n == (size_t(1) << nv), DP_ERR_SHAPE, "table length != 2^num_vars"); vp.tabs.push_back(tables[i]->b); }
+    for (int i = 0; i < nterms; i++) {
+      int k = term_degree[i];
+      DP_REQUIRE(k >= 1 && k <= 3, DP_ERR_SHAPE, "term degree must be 1..3");
+      ScTerm st; st.k = k; st.t[0] = st.t[1] = st.t[2] = 0;
+      for (int j = 0; j < k; j++) { int ti = term_tables[3 * i + j]; DP_REQUIRE(ti >= 0 && ti < ntables, DP_ERR_ARG, "term table index"); st.t[j] = ti; }
+      vp.terms.push_back(st); vp.coeffs.push_back(read_point(term_coeffs + 2 * i, 1)[0]);
+      if ((unsigned)k > vp.max_degree) vp.max_degree = k;
+    }
+    SumcheckOut so = sumcheck_prove(*ctx->dev, vp, t->t);
+    Writer w; w.iop(so.proof);
+    *proof_words = copy_out(w.w); *proof_nwords = w.w.size();
+    if (finals) for (int i = 0; i < ntables; i++) { finals[2 * i] = so.finals[i].c0; finals[2 * i + 1] = so.finals[i].c1; }
+  });
+}
+
+int32_t dp_logup_prove(dp_ctx* ctx, const dp_buf* const* columns, int32_t ncols, int32_t cpi, const dp_buf* mult,
+                       const uint64_t cc[2], const uint64_t csc[2], dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords) {
+  return guard([&] {
+    DP_REQUIRE(ctx && columns && ncols > 0 && cc && csc && t && proof_words && proof_nwords && cpi > 0, DP_ERR_ARG, "bad arguments");
+    LogUpInputDev in; in.is_table = mult != nullptr; in.columns_per_instance = cpi;
+    for (int i = 0; i < ncols; i++) { DP_REQUIRE(columns[i], DP_ERR_ARG, "null column"); in.columns.push_back(columns[i]->b); }
+    if (mult) { DP_REQUIRE(!mult->b.ext && mult->b.n == in.columns[0].n, DP_ERR_SHAPE, "multiplicities shape"); in.multiplicities = mult->b; }
+    in.constant_challenge = read_point(cc, 1)[0]; in.column_separation_challenge = read_point(csc, 1)[0];
+    LogUpProof p = logup_batch_prove(*ctx->dev, in, t->t);
+    Writer w; w.logup(p);
+    *proof_words = copy_out(w.w); *proof_nwords = w.w.size();
+  });
+}
+
+int32_t dp_pcs_setup(dp_ctx* ctx, size_t max_poly_size) {
+  return guard([&] { DP_REQUIRE(ctx && is_pow2(max_poly_size), DP_ERR_ARG, "max_poly_size must be a power of two"); ctx->dev->pcs_init(dp_ceil_log2(max_poly_size)); });
+}
+int32_t dp_pcs_commit(dp_ctx* ctx, const dp_buf* poly, dp_commit** out, uint64_t root[4]) {
+  return guard([&] {
+    DP_REQUIRE(ctx && poly && out, DP_ERR_ARG, "bad arguments");
+    DevCommit c = ctx->dev->commit(poly->b, true);
+    if (root) for (int k = 0; k < 4; k++) root[k] = c.tree.root.v[k];
+    *out = new dp_commit{c};
+  });
+}
+int32_t dp_pcs_commit_free(dp_ctx* ctx, dp_commit* c) {
+  return guard([&] {
+    if (!c) return;
+    DevCommit& d = c->c;  // the evaluation table belongs to the caller's dp_buf
+    if (d.bh_evals.p == d.evals.p) d.bh_evals.p = nullptr;
+    if (d.tree.leaves.p == d.evals.p) d.tree.leaves.p = nullptr;
+    d.evals.p = nullptr;
+    ctx->dev->free_commit(d);
+    delete c;
+  });
+}
+static void read_claims(int32_t n, const uint64_t* points_flat, const uint64_t* evals, const std::vector<unsigned>& nvs, std::vector<std::vector<Ext>>& pts, std::vector<Ext>& evs) {
+  size_t off = 0;
+  for (int i = 0; i < n; i++) { pts.push_back(read_point(points_flat + off, nvs[i])); off += 2 * (size_t)nvs[i]; evs.push_back(read_point(evals + 2 * i, 1)[0]); }
+}
+int32_t dp_pcs_batch_open(dp_ctx* ctx, const dp_commit* const* comms, int32_t n, const uint64_t* points_flat, const uint64_t* evals,
+                          dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords) {
+  return guard([&] {
+    DP_REQUIRE(ctx && comms && n > 0 && points_flat && evals && t && proof_words && proof_nwords, DP_ERR_ARG, "bad arguments");
+    std::vector<unsigned> nvs; for (int i = 0; i < n; i++) { DP_REQUIRE(comms[i], DP_ERR_ARG, "null commitment"); nvs.push_back(comms[i]->c.nv); }
+    std::vector<std::vector<Ext>> pts; std::vector<Ext> evs;
+    read_claims(n, points_flat, evals, nvs, pts, evs);
+    std::vector<OpenClaim> oc;
+    for (int i = 0; i < n; i++) oc.push_back({&comms[i]->c, pts[i], evs[i]});
+    unsigned L = 0; for (auto v : nvs) L = std::max(L, v);
+    BasefoldProof p = pcs_batch_open(*ctx->dev, 64, oc, t->t);  // the size check against the PCS parameters happens in commit()
+    Writer w; w.basefold(p);
+    *proof_words = copy_out(w.w); *proof_nwords = w.w.size();
+  });
+}
+int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const uint32_t* num_vars, const int32_t* is_base, int32_t n,
+                            const uint64_t* points_flat, const uint64_t* evals, const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t) {
+  return guard([&] {
+    DP_REQUIRE(roots && num_vars && is_base && n > 0 && points_flat && evals && proof_words && t && is_pow2(max_poly_size), DP_ERR_ARG, "bad arguments");
+    std::vector<unsigned> nvs(num_vars, num_vars + n);
+    std::vector<std::vector<Ext>> pts; std::vector<Ext> evs;
+    read_claims(n, points_flat, evals, nvs, pts, evs);
+    std::vector<VerifyClaim> vc;
+    for (int i = 0; i < n; i++) { Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = roots[4 * i + k]; c.num_vars = nvs[i]; c.is_base = is_base[i] != 0; vc.push_back({c, pts[i], evs[i]}); }
+    Reader r(proof_words, proof_nwords); BasefoldProof p = r.basefold();
+    DP_REQUIRE(r.pos == proof_nwords, DP_ERR_ARG, "proof stream: trailing words");
+    VerifierParams vp; vp.full_log = dp_ceil_log2(max_poly_size);
+    pcs_batch_verify(vp, vc, p, t->t);
+  });
+}
+
+static ModelSpec parse_model(const int64_t* b, size_t n) {
+  size_t pos = 0;
+  auto rd = [&]() { DP_REQUIRE(pos < n, DP_ERR_ARG, "model blob truncated"); return b[pos++]; };
+  ModelSpec m; m.input_len = (size_t)rd(); size_t nl = (size_t)rd();
+  DP_REQUIRE(nl > 0 && nl < 4096, DP_ERR_ARG, "model blob: bad layer count");
+  for (size_t i = 0; i < nl; i++) {
+    LayerSpec l; l.kind = (int)rd();
+    if (l.kind == L_DENSE) {
+      l.nrows = (size_t)rd(); l.ncols = (size_t)rd();
+      DP_REQUIRE(l.nrows && l.ncols && l.nrows * l.ncols + l.nrows <= n - pos, DP_ERR_ARG, "model blob: dense tensor sizes");
+      l.weights.assign(b + pos, b + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols;
+      l.bias.assign(b + pos, b + pos + l.nrows); pos += l.nrows;
+    } else if (l.kind == L_REQUANT) { l.right_shift = (unsigned)rd(); l.fp_scale = (unsigned)rd(); l.fixed_point_multiplier = rd(); l.intermediate_bit_size = (unsigned)rd(); }
+    else DP_REQUIRE(l.kind == L_RELU, DP_ERR_ARG, "model blob: unknown layer kind");
+    m.layers.push_back(std::move(l));
+  }
+  DP_REQUIRE(pos == n, DP_ERR_ARG, "model blob: trailing words");
+  return m;
+}
+int32_t dp_model_setup(dp_ctx* ctx, const int64_t* blob, size_t nwords, dp_model** out) {
+  return guard([&] {
+    DP_REQUIRE(ctx && blob && out, DP_ERR_ARG, "bad arguments");
+    ModelSpec m = parse_model(blob, nwords);
+    std::unique_ptr<dp_model> dm(new dp_model());
+    dm->ctx = ctx; dm->zk = context_generate(*ctx->dev, m);
+    *out = dm.release();
+  });
+}
+int32_t dp_model_free(dp_model* m) { return guard([&] { delete m; }); }
+int32_t dp_model_prove(dp_model* m, const int64_t* input, size_t ninput, uint64_t** proof_words, size_t* proof_nwords,
+                       int64_t* output, size_t* noutput, double* prove_ms) {
+  return guard([&] {
+    DP_REQUIRE(m && input && proof_words && proof_nwords, DP_ERR_ARG, "bad arguments");
+    std::vector<int64_t> in(input, input + ninput);
+    Trace tr = run_model(m->zk->model, in);
+    Transcript t = default_transcript();
+    auto t0 = std::chrono::steady_clock::now();
+    Proof p = prove(*m->zk, tr, t);
+    auto t1 = std::chrono::steady_clock::now();
+    if (prove_ms) *prove_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    std::vector<u64> w = serialize_proof(p);
+    *proof_words = copy_out(w); *proof_nwords = w.size();
+    if (output && noutput) {
+      const auto& o = tr.out.back();
+      DP_REQUIRE(*noutput >= o.size(), DP_ERR_ARG, "output buffer too small");
+      memcpy(output, o.data(), o.size() * 8); *noutput = o.size();
+    }
+  });
+}
+static std::vector<u64> vctx_to_words(const VerifierContext& v) {
+  std::vector<u64> w;
+  w.push_back(0x3158544356504444ULL); w.push_back(v.full_log); w.push_back(v.shape.input_len); w.push_back(v.shape.layers.size());
+  for (auto& l : v.shape.layers) { w.push_back(l.kind); w.push_back(l.nrows); w.push_back(l.ncols); w.push_back(l.right_shift); w.push_back(l.fp_scale); w.push_back((u64)l.fixed_point_multiplier); w.push_back(l.intermediate_bit_size); }
+  w.push_back(v.model_comms.size());
+  for (auto& kv : v.model_comms) {
+    w.push_back(kv.first);
+    for (const char* id : {"DenseBias", "DenseWeight"}) { const Commitment& c = kv.second.at(id); for (int k = 0; k < 4; k++) w.push_back(c.root.v[k]); w.push_back(c.num_vars); w.push_back(c.is_base); }
+  }
+  w.push_back(v.tables.size());
+  for (auto& t : v.tables) { w.push_back(t.kind); w.push_back(t.size); }
+  return w;
+}
+static VerifierContext vctx_from_words(const u64* w, size_t n) {
+  size_t pos = 0;
+  auto rd = [&]() { DP_REQUIRE(pos < n, DP_ERR_ARG, "verifier blob truncated"); return w[pos++]; };
+  VerifierContext v;
+  DP_REQUIRE(rd() == 0x3158544356504444ULL, DP_ERR_ARG, "bad verifier blob magic");
+  v.full_log = (unsigned)rd(); v.shape.input_len = (size_t)rd(); size_t nl = (size_t)rd();
+  DP_REQUIRE(nl < 4096, DP_ERR_ARG, "verifier blob: layer count");
+  for (size_t i = 0; i < nl; i++) { LayerSpec l; l.kind = (int)rd(); l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); l.right_shift = (unsigned)rd(); l.fp_scale = (unsigned)rd(); l.fixed_point_multiplier = (int64_t)rd(); l.intermediate_bit_size = (unsigned)rd(); v.shape.layers.push_back(l); }
+  size_t nc = (size_t)rd(); DP_REQUIRE(nc <= nl, DP_ERR_ARG, "verifier blob: commitments");
+  for (size_t i = 0; i < nc; i++) {
+    size_t id = (size_t)rd();
+    for (const char* pid : {"DenseBias", "DenseWeight"}) { Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = rd(); c.num_vars = (unsigned)rd(); c.is_base = rd() != 0; v.model_comms[id][pid] = c; }
+  }
+  size_t nt = (size_t)rd(); DP_REQUIRE(nt < 64, DP_ERR_ARG, "verifier blob: tables");
+  for (size_t i = 0; i < nt; i++) { TableType t; t.kind = (int)rd(); t.size = (unsigned)rd(); v.tables.push_back(t); }
+  DP_REQUIRE(pos == n, DP_ERR_ARG, "verifier blob: trailing words");
+  return v;
+}
+int32_t dp_model_verifier_blob(const dp_model* m, uint64_t** words, size_t* nwords) {
+  return guard([&] { DP_REQUIRE(m && words && nwords, DP_ERR_ARG, "bad arguments"); std::vector<u64> w = vctx_to_words(m->zk->verifier_ctx()); *words = copy_out(w); *nwords = w.size(); });
+}
+int32_t dp_verify(const uint64_t* vb, size_t vn, const uint64_t* pw, size_t pn, const int64_t* input, size_t ninput, const int64_t* output, size_t noutput) {
+  return guard([&] {
+    DP_REQUIRE(vb && pw && input && output, DP_ERR_ARG, "bad arguments");
+    VerifierContext vc = vctx_from_words(vb, vn);
+    Proof p = deserialize_proof(pw, pn);
+    IO io; io.input.assign(input, input + ninput); io.output.assign(output, output + noutput);
+    Transcript t = default_transcript();
+    verify(vc, p, io, t);
+  });
+}
+
+}  // extern "C"

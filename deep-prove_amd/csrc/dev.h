@@ -18,7 +18,9 @@ struct DpError : std::runtime_error {
   int code;
   DpError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
 };
+#ifndef DEEP_PROVE_HIP_H  // same values as the macros of include/deep_prove_hip.h
 enum { DP_OK = 0, DP_ERR_ARG = -1, DP_ERR_OOM = -2, DP_ERR_HIP = -3, DP_ERR_SHAPE = -4, DP_ERR_VERIFY = -5, DP_ERR_NODEVICE = -6 };
+#endif
 #define DP_REQUIRE(cond, code, msg) do { if (!(cond)) throw ::dp::DpError((code), std::string(msg)); } while (0)
 
 // A table of field elements resident in HBM. Base elements are canonical u64, extension elements two u64 (c0,c1).
@@ -75,6 +77,7 @@ class Dev {
   virtual void upload_i64(const DBuf& dst, const int64_t* src) = 0;  // Fieldizer on device
   virtual void download(const DBuf& src, u64* dst) = 0;
   virtual void copy(const DBuf& dst, const DBuf& src) = 0;
+  virtual void zero(const DBuf& dst) = 0;
   virtual void sync() = 0;
   // ---- MLE primitives
   // K4: out[idx] (+)= scale * prod_t (idx_t ? pt[t] : 1 - pt[t])

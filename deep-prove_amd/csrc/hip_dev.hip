@@ -1,0 +1,827 @@
+// HipDev: the MI355X (gfx950 / CDNA4) implementation of dp::Dev — hand-written HIP kernels for every O(n) loop of
+// the deep-prove sumcheck / logup-GKR / Basefold hot path. All arithmetic is 64-bit modular
+// integer work over Goldilocks: no MFMA anywhere; the kernels are HBM-streaming (K1-K7, K9-K13) or VALU-integer bound
+// (K8 Poseidon2). Wave = 64 lanes, blocks of 256 threads, grids sized to >= a few waves per SIMD on 256 CUs.
+//
+// Layout in HBM: a table of n field elements is a dense array in natural (little-endian index) order; base elements
+// are canonical u64, extension elements are 16-byte {c0,c1} pairs so one `global_load_dwordx4` per lane fetches one
+// element. A sumcheck pair (2b, 2b+1) is therefore 32 contiguous bytes per lane.
+#include "dev.h"
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <algorithm>
+#include <vector>
+#include <string>
+
+namespace dp {
+
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw DpError(DP_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+__constant__ u64 c_rc[DP_POSEIDON2_RC_WORDS];
+
+constexpr int TPB = 256;
+constexpr int MAX_TABS = 32;
+constexpr int MAX_TERMS = 48;
+constexpr int MAX_PT = 32;
+
+struct PointArg { Ext p[MAX_PT]; };
+
+// ------------------------------------------------------------------------------------------------ reductions
+__device__ __forceinline__ u64 shfl_down_u64(u64 v, int d) {
+  int lo = __shfl_down((int)(u32)v, d, 64);
+  int hi = __shfl_down((int)(u32)(v >> 32), d, 64);
+  return ((u64)(u32)hi << 32) | (u64)(u32)lo;
+}
+__device__ __forceinline__ Ext wave_reduce_ext(Ext v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    Ext o = ex(shfl_down_u64(v.c0, d), shfl_down_u64(v.c1, d));
+    v = ex_add(v, o);
+  }
+  return v;
+}
+// sum over the block; result valid in thread 0. `sm` must hold TPB/64 Ext values.
+__device__ __forceinline__ Ext block_reduce_ext(Ext v, Ext* sm) {
+  v = wave_reduce_ext(v);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  Ext r = ex_zero();
+  if (threadIdx.x == 0) {
+    r = sm[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); i++) r = ex_add(r, sm[i]);
+  }
+  return r;
+}
+__device__ __forceinline__ Ext ld_elem(const void* p, bool ext, size_t i) {
+  if (ext) return ((const Ext*)p)[i];
+  return ex_base(((const u64*)p)[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise
+__global__ void k_fieldize(const int64_t* in, u64* out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = gl_from_i64(in[i]);
+}
+__global__ void k_pow_table(u64* out, u64 base, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = gl_pow(base, i);
+}
+// K4: eq(x, pt) computed per index as a product over its bits (k ext multiplications per element, no log-k passes)
+__global__ void k_eq_table(Ext* out, PointArg pt, unsigned k, Ext scale, int acc) {
+  size_t n = size_t(1) << k;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Ext v = scale;
+    for (unsigned t = 0; t < k; t++) {
+      Ext r = pt.p[t];
+      v = ex_mul(v, ((i >> t) & 1) ? r : ex_sub(ex_one(), r));
+    }
+    out[i] = acc ? ex_add(out[i], v) : v;
+  }
+}
+struct EvalArgs { const void* f[8]; int ext[8]; int nf; };
+// out partial[block][f] = sum over the block's x of f(x) * eq(x, pt)
+__global__ void k_mle_eval_partial(EvalArgs a, PointArg pt, unsigned k, Ext* partial) {
+  __shared__ Ext sm[TPB / 64];
+  size_t n = size_t(1) << k;
+  Ext acc[8];
+#pragma unroll
+  for (int f = 0; f < 8; f++) acc[f] = ex_zero();
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Ext e = ex_one();
+    for (unsigned t = 0; t < k; t++) {
+      Ext r = pt.p[t];
+      e = ex_mul(e, ((i >> t) & 1) ? r : ex_sub(ex_one(), r));
+    }
+#pragma unroll
+    for (int f = 0; f < 8; f++)
+      if (f < a.nf) acc[f] = ex_add(acc[f], a.ext[f] ? ex_mul(e, ((const Ext*)a.f[f])[i]) : ex_mul_base(e, ((const u64*)a.f[f])[i]));
+  }
+#pragma unroll
+  for (int f = 0; f < 8; f++) {
+    if (f < a.nf) {
+      Ext r = block_reduce_ext(acc[f], sm);
+      if (threadIdx.x == 0) partial[(size_t)blockIdx.x * 8 + f] = r;
+    }
+  }
+}
+// generic second stage: out[j] = sum_b partial[b*stride + j], one block per j
+__global__ void k_reduce_partials(const Ext* partial, size_t nblocks, size_t stride, Ext* out) {
+  __shared__ Ext sm[TPB / 64];
+  size_t j = blockIdx.x;
+  Ext acc = ex_zero();
+  for (size_t b = threadIdx.x; b < nblocks; b += blockDim.x) acc = ex_add(acc, partial[b * stride + j]);
+  Ext r = block_reduce_ext(acc, sm);
+  if (threadIdx.x == 0) out[j] = r;
+}
+// K2 one pass: partial[split][c] = sum over the split's rows of eq[r] * W[r*C + c]
+__global__ void k_fix_high_partial(const u64* W, const Ext* eq, size_t R, size_t C, size_t rows_per_split, Ext* partial) {
+  size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  size_t r0 = blockIdx.y * rows_per_split, r1 = min(R, r0 + rows_per_split);
+  Ext acc = ex_zero();
+  for (size_t r = r0; r < r1; r++) acc = ex_add(acc, ex_mul_base(eq[r], W[r * C + c]));
+  partial[(size_t)blockIdx.y * C + c] = acc;
+}
+__global__ void k_colsum(const Ext* partial, size_t nsplit, size_t C, Ext* out) {
+  size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  Ext acc = ex_zero();
+  for (size_t s = 0; s < nsplit; s++) acc = ex_add(acc, partial[s * C + c]);
+  out[c] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ sumcheck (K1, K3)
+struct FoldArgs { const void* in[MAX_TABS]; Ext* out[MAX_TABS]; int ext[MAX_TABS]; size_t half[MAX_TABS]; };
+// K1: out[i] = in[2i] + r (in[2i+1] - in[2i]); blockIdx.y selects the table
+__global__ void k_fold(FoldArgs a, Ext r) {
+  int t = blockIdx.y;
+  size_t h = a.half[t];
+  const void* in = a.in[t];
+  Ext* out = a.out[t];
+  if (a.ext[t]) {
+    const Ext* p = (const Ext*)in;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < h; i += (size_t)gridDim.x * blockDim.x) out[i] = ex_lerp(p[2 * i], p[2 * i + 1], r);
+  } else {
+    const u64* p = (const u64*)in;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < h; i += (size_t)gridDim.x * blockDim.x) out[i] = ex_lerp_base(p[2 * i], p[2 * i + 1], r);
+  }
+}
+struct TermArgs { const void* tab[MAX_TABS]; int ext[MAX_TABS]; int k[MAX_TERMS]; int t[MAX_TERMS][3]; size_t npairs; };
+// K3: partial[(term*gridDim.x + block)*4 + t] = sum over the block's pairs of prod_j (a_j + t d_j), t = 0..k
+__global__ void k_sc_terms(TermArgs a, Ext* partial) {
+  __shared__ Ext sm[TPB / 64];
+  int term = blockIdx.y;
+  int k = a.k[term];
+  const void* p0 = a.tab[a.t[term][0]]; bool e0 = a.ext[a.t[term][0]];
+  const void* p1 = a.tab[a.t[term][k > 1 ? 1 : 0]]; bool e1 = a.ext[a.t[term][k > 1 ? 1 : 0]];
+  const void* p2 = a.tab[a.t[term][k > 2 ? 2 : 0]]; bool e2 = a.ext[a.t[term][k > 2 ? 2 : 0]];
+  Ext acc0 = ex_zero(), acc1 = ex_zero(), acc2 = ex_zero(), acc3 = ex_zero();
+  for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < a.npairs; b += (size_t)gridDim.x * blockDim.x) {
+    Ext a0 = ld_elem(p0, e0, 2 * b), b0 = ld_elem(p0, e0, 2 * b + 1);
+    if (k == 1) {
+      acc0 = ex_add(acc0, a0); acc1 = ex_add(acc1, b0);
+    } else if (k == 2) {
+      Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
+      Ext c0 = ex_sub(ex_dbl(b0), a0), c1 = ex_sub(ex_dbl(b1), a1);  // value at t = 2
+      acc0 = ex_add(acc0, ex_mul(a0, a1));
+      acc1 = ex_add(acc1, ex_mul(b0, b1));
+      acc2 = ex_add(acc2, ex_mul(c0, c1));
+    } else {
+      Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
+      Ext a2 = ld_elem(p2, e2, 2 * b), b2 = ld_elem(p2, e2, 2 * b + 1);
+      Ext d0 = ex_sub(b0, a0), d1 = ex_sub(b1, a1), d2 = ex_sub(b2, a2);
+      Ext c0 = ex_add(b0, d0), c1 = ex_add(b1, d1), c2 = ex_add(b2, d2);  // t = 2
+      Ext f0 = ex_add(c0, d0), f1 = ex_add(c1, d1), f2 = ex_add(c2, d2);  // t = 3
+      acc0 = ex_add(acc0, ex_mul(ex_mul(a0, a1), a2));
+      acc1 = ex_add(acc1, ex_mul(ex_mul(b0, b1), b2));
+      acc2 = ex_add(acc2, ex_mul(ex_mul(c0, c1), c2));
+      acc3 = ex_add(acc3, ex_mul(ex_mul(f0, f1), f2));
+    }
+  }
+  size_t base = ((size_t)term * gridDim.x + blockIdx.x) * 4;
+  Ext r;
+  r = block_reduce_ext(acc0, sm); if (threadIdx.x == 0) partial[base + 0] = r;
+  r = block_reduce_ext(acc1, sm); if (threadIdx.x == 0) partial[base + 1] = r;
+  r = block_reduce_ext(acc2, sm); if (threadIdx.x == 0) partial[base + 2] = r;
+  r = block_reduce_ext(acc3, sm); if (threadIdx.x == 0) partial[base + 3] = r;
+}
+// out[term*4 + t] = sum_b partial[(term*nblocks + b)*4 + t]; one block per (term, t)
+__global__ void k_reduce_terms(const Ext* partial, size_t nblocks, Ext* out) {
+  __shared__ Ext sm[TPB / 64];
+  size_t term = blockIdx.x >> 2, t = blockIdx.x & 3;
+  Ext acc = ex_zero();
+  for (size_t b = threadIdx.x; b < nblocks; b += blockDim.x) acc = ex_add(acc, partial[(term * nblocks + b) * 4 + t]);
+  Ext r = block_reduce_ext(acc, sm);
+  if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+// last fold of a sumcheck: every table has 2 elements; results go to one contiguous array
+__global__ void k_finish(FoldArgs a, Ext r, int ntabs, Ext* out) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntabs) return;
+  Ext v;
+  if (a.ext[t]) { const Ext* p = (const Ext*)a.in[t]; v = ex_lerp(p[0], p[1], r); }
+  else { const u64* p = (const u64*)a.in[t]; v = ex_lerp_base(p[0], p[1], r); }
+  out[t] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ logup (K13)
+struct ColsArg { const u64* col[16]; int n; };
+__global__ void k_logup_den(Ext* out, ColsArg cols, Ext c, Ext chi, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Ext acc = c, pw = ex_one();
+    for (int j = 0; j < cols.n; j++) {
+      acc = ex_add(acc, ex_mul_base(pw, cols.col[j][i]));
+      pw = ex_mul(pw, chi);
+    }
+    out[i] = acc;
+  }
+}
+// (n1/d1 + n2/d2) pairing index i with i + half;  num_mode: 0 = all numerators are -1, 1 = base numerators, 2 = ext
+__global__ void k_logup_layer(const void* num, int num_mode, const Ext* den, Ext* num_out, Ext* den_out, size_t half) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
+    Ext d1 = den[i], d2 = den[i + half];
+    Ext nn;
+    if (num_mode == 0) nn = ex_neg(ex_add(d1, d2));
+    else if (num_mode == 1) { const u64* p = (const u64*)num; nn = ex_add(ex_mul_base(d2, p[i]), ex_mul_base(d1, p[i + half])); }
+    else { const Ext* p = (const Ext*)num; nn = ex_add(ex_mul(p[i], d2), ex_mul(d1, p[i + half])); }
+    num_out[i] = nn;
+    den_out[i] = ex_mul(d1, d2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ RS code / NTT (K5-K7)
+template <bool EXT>
+__global__ void k_mobius_stage(void* data, size_t n, unsigned lg_half) {
+  size_t half = size_t(1) << lg_half;
+  for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < n / 2; b += (size_t)gridDim.x * blockDim.x) {
+    size_t lo = ((b >> lg_half) << (lg_half + 1)) | (b & (half - 1));
+    if (EXT) { Ext* p = (Ext*)data; p[lo + half] = ex_sub(p[lo + half], p[lo]); }
+    else { u64* p = (u64*)data; p[lo + half] = gl_sub(p[lo + half], p[lo]); }
+  }
+}
+// cw[2i] = cw[2i+1] = coeff[i] * shift^{bitrev_nv(i)}: bit-reversed, zero-padded, coset-scaled DIT input with the
+// first (trivial, zero-tail) butterfly stage already applied (rs.rs:129-173 "r = 1")
+template <bool EXT>
+__global__ void k_rs_prepare(const void* coeff, void* cw, const u64* pow7, unsigned nv, unsigned L) {
+  size_t n = size_t(1) << nv;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    size_t j = __brevll((unsigned long long)i) >> (64 - nv);
+    u64 s = pow7[j << (L - nv)];
+    if (EXT) { Ext v = ex_mul_base(((const Ext*)coeff)[i], s); ((Ext*)cw)[2 * i] = v; ((Ext*)cw)[2 * i + 1] = v; }
+    else { u64 v = gl_mul(((const u64*)coeff)[i], s); ((u64*)cw)[2 * i] = v; ((u64*)cw)[2 * i + 1] = v; }
+  }
+}
+// one radix-2 DIT stage; twiddle w_{2^(lg_half+1)}^j = tw[j << (L - lg_half)], tw[i] = w_{2^(L+1)}^i
+template <bool EXT>
+__global__ void k_ntt_stage(void* data, size_t N, unsigned lg_half, const u64* tw, unsigned L) {
+  size_t half = size_t(1) << lg_half;
+  for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < N / 2; b += (size_t)gridDim.x * blockDim.x) {
+    size_t j = b & (half - 1);
+    size_t lo = ((b >> lg_half) << (lg_half + 1)) | j;
+    u64 w = tw[j << (L - lg_half)];
+    if (EXT) { Ext* p = (Ext*)data; Ext t = ex_mul_base(p[lo + half], w), u = p[lo]; p[lo] = ex_add(u, t); p[lo + half] = ex_sub(u, t); }
+    else { u64* p = (u64*)data; u64 t = gl_mul(p[lo + half], w), u = p[lo]; p[lo] = gl_add(u, t); p[lo + half] = gl_sub(u, t); }
+  }
+}
+template <bool EXT>
+__global__ void k_bitrev(void* dst, const void* src, unsigned lg) {
+  size_t n = size_t(1) << lg;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    size_t j = lg ? (__brevll((unsigned long long)i) >> (64 - lg)) : 0;
+    if (EXT) ((Ext*)dst)[j] = ((const Ext*)src)[i]; else ((u64*)dst)[j] = ((const u64*)src)[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Merkle (K8)
+// layer 0: digest = the two leaves verbatim (hash_or_noop on <= 4 base elements)
+template <bool EXT>
+__global__ void k_merkle_leaves(const void* leaves, u64* nodes, size_t npairs) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npairs; i += (size_t)gridDim.x * blockDim.x) {
+    u64 d0, d1, d2, d3;
+    if (EXT) { Ext a = ((const Ext*)leaves)[2 * i], b = ((const Ext*)leaves)[2 * i + 1]; d0 = a.c0; d1 = a.c1; d2 = b.c0; d3 = b.c1; }
+    else { d0 = ((const u64*)leaves)[2 * i]; d1 = ((const u64*)leaves)[2 * i + 1]; d2 = 0; d3 = 0; }
+    u64* o = nodes + 4 * i;
+    o[0] = d0; o[1] = d1; o[2] = d2; o[3] = d3;
+  }
+}
+// one Poseidon2 compress (2 permutations) per lane; state held in 8 VGPR pairs, round constants in constant memory
+__global__ void k_merkle_layer(const u64* in, u64* out, size_t cnt) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cnt; i += (size_t)gridDim.x * blockDim.x) {
+    const ulonglong2* p = (const ulonglong2*)(in + 8 * i);
+    ulonglong2 x01 = p[0], x23 = p[1], y01 = p[2], y23 = p[3];
+    u64 x[4] = {x01.x, x01.y, x23.x, x23.y}, y[4] = {y01.x, y01.y, y23.x, y23.y}, o[4];
+    poseidon2_compress(x, y, o, c_rc);
+    ulonglong2* q = (ulonglong2*)(out + 4 * i);
+    q[0] = make_ulonglong2(o[0], o[1]);
+    q[1] = make_ulonglong2(o[2], o[3]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Basefold opening (K9-K12, K14)
+struct PolyDesc { const void* f; const Ext* eq; Ext* fout; Ext* eqout; size_t n; int fext; int pad; };
+// fold every (f, eq) pair of length > 1 by r; blockIdx.y = polynomial
+__global__ void k_classic_fold(const PolyDesc* d, Ext r) {
+  PolyDesc p = d[blockIdx.y];
+  if (p.n <= 1) return;
+  size_t h = p.n / 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < h; i += (size_t)gridDim.x * blockDim.x) {
+    p.eqout[i] = ex_lerp(p.eq[2 * i], p.eq[2 * i + 1], r);
+    if (p.fext) p.fout[i] = ex_lerp(((const Ext*)p.f)[2 * i], ((const Ext*)p.f)[2 * i + 1], r);
+    else p.fout[i] = ex_lerp_base(((const u64*)p.f)[2 * i], ((const u64*)p.f)[2 * i + 1], r);
+  }
+}
+// partial[(poly*gridDim.x + block)*2 + {0,1}]: c0 = sum f0*e0, c2 = sum (f1-f0)(e1-e0)   (coeff.rs:236-345)
+__global__ void k_classic_sums(const PolyDesc* d, Ext* partial) {
+  __shared__ Ext sm[TPB / 64];
+  PolyDesc p = d[blockIdx.y];
+  Ext c0 = ex_zero(), c2 = ex_zero();
+  if (p.n == 1) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) c0 = ex_mul(ld_elem(p.f, p.fext, 0), p.eq[0]);
+  } else {
+    size_t h = p.n / 2;
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < h; j += (size_t)gridDim.x * blockDim.x) {
+      Ext l0 = p.eq[2 * j], l1 = p.eq[2 * j + 1];
+      if (p.fext) {
+        Ext r0 = ((const Ext*)p.f)[2 * j], r1 = ((const Ext*)p.f)[2 * j + 1];
+        c0 = ex_add(c0, ex_mul(l0, r0));
+        c2 = ex_add(c2, ex_mul(ex_sub(l1, l0), ex_sub(r1, r0)));
+      } else {
+        u64 r0 = ((const u64*)p.f)[2 * j], r1 = ((const u64*)p.f)[2 * j + 1];
+        c0 = ex_add(c0, ex_mul_base(l0, r0));
+        c2 = ex_add(c2, ex_mul_base(ex_sub(l1, l0), gl_sub(r1, r0)));
+      }
+    }
+  }
+  size_t base = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+  Ext r;
+  r = block_reduce_ext(c0, sm); if (threadIdx.x == 0) partial[base] = r;
+  r = block_reduce_ext(c2, sm); if (threadIdx.x == 0) partial[base + 1] = r;
+}
+__global__ void k_reduce_pairs(const Ext* partial, size_t nblocks, Ext* out) {
+  __shared__ Ext sm[TPB / 64];
+  size_t poly = blockIdx.x >> 1, t = blockIdx.x & 1;
+  Ext acc = ex_zero();
+  for (size_t b = threadIdx.x; b < nblocks; b += blockDim.x) acc = ex_add(acc, partial[(poly * nblocks + b) * 2 + t]);
+  Ext r = block_reduce_ext(acc, sm);
+  if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+// K11: acc[j*rep + q] += x[j] * coeff
+__global__ void k_axpy_rep(Ext* acc, const void* x, int xext, Ext coeff, size_t n_acc, unsigned lg_rep) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_acc; i += (size_t)gridDim.x * blockDim.x) {
+    size_t j = i >> lg_rep;
+    Ext m = xext ? ex_mul(((const Ext*)x)[j], coeff) : ex_mul_base(coeff, ((const u64*)x)[j]);
+    acc[i] = ex_add(acc[i], m);
+  }
+}
+// K10 message on evaluation-form pairs: [sum a*ea, sum ((b-a)*ea + a*(eb-ea)), sum (b-a)(eb-ea)]
+__global__ void k_bf_msg(const Ext* f, const Ext* eq, size_t npairs, Ext* partial) {
+  __shared__ Ext sm[TPB / 64];
+  Ext c0 = ex_zero(), c1 = ex_zero(), c2 = ex_zero();
+  for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < npairs; j += (size_t)gridDim.x * blockDim.x) {
+    Ext a = f[2 * j], b = ex_sub(f[2 * j + 1], a), ea = eq[2 * j], eb = ex_sub(eq[2 * j + 1], ea);
+    c0 = ex_add(c0, ex_mul(a, ea));
+    c1 = ex_add(c1, ex_add(ex_mul(b, ea), ex_mul(a, eb)));
+    c2 = ex_add(c2, ex_mul(b, eb));
+  }
+  size_t base = (size_t)blockIdx.x * 4;
+  Ext r;
+  r = block_reduce_ext(c0, sm); if (threadIdx.x == 0) partial[base] = r;
+  r = block_reduce_ext(c1, sm); if (threadIdx.x == 0) partial[base + 1] = r;
+  r = block_reduce_ext(c2, sm); if (threadIdx.x == 0) { partial[base + 2] = r; partial[base + 3] = ex_zero(); }
+}
+// K9: out[i] = y0 + (ch - x0)(y1 - y0) w,  x0 = gamma * w_{2^(level+1)}^{bitrev(i)},  w = -1/(2 x0)   (rs.rs:377-410)
+__global__ void k_fri_fold(const Ext* in, Ext* out, size_t nout, unsigned level, const u64* tw, unsigned L, u64 gamma, u64 neg_inv2gamma, Ext ch) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nout; i += (size_t)gridDim.x * blockDim.x) {
+    size_t b = level ? (__brevll((unsigned long long)i) >> (64 - level)) : 0;
+    u64 root = tw[b << (L - level)];
+    u64 x0 = gl_mul(root, gamma);
+    u64 rinv = b == 0 ? 1 : gl_neg(tw[((size_t(1) << level) - b) << (L - level)]);
+    u64 w = gl_mul(neg_inv2gamma, rinv);
+    Ext y0 = in[2 * i], y1 = in[2 * i + 1];
+    Ext t = ex_mul(ex(gl_sub(ch.c0, x0), ch.c1), ex_sub(y1, y0));
+    out[i] = ex_add(y0, ex_mul_base(t, w));
+  }
+}
+struct GatherDesc { const void* leaves; const u64* nodes; size_t nleaves; size_t p0; size_t out_off; int ext; int height; };
+// K14: one wave per (query, tree): leaf pair then the sibling digests bottom-up
+__global__ void k_query_gather(const GatherDesc* d, size_t nd, u64* out) {
+  size_t q = blockIdx.x * (size_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (q >= nd) return;
+  int lane = threadIdx.x & 63;
+  GatherDesc g = d[q];
+  u64* o = out + g.out_off;
+  int nleafw = g.ext ? 4 : 2;
+  if (lane < nleafw) o[lane] = ((const u64*)g.leaves)[g.p0 * (g.ext ? 2 : 1) + lane];
+  int npath = g.height - 1;
+  for (int w = lane; w < npath * 4; w += 64) {
+    int l = w >> 2;
+    size_t off = g.nleaves - (g.nleaves >> l);
+    size_t idx = (g.p0 >> (l + 1)) ^ 1;
+    o[nleafw + w] = g.nodes[4 * (off + idx) + (w & 3)];
+  }
+}
+
+// ================================================================================================ HipDev
+static inline int grid_for(size_t n, int cap = 2048) {
+  size_t b = (n + TPB - 1) / TPB;
+  if (b < 1) b = 1;
+  return (int)std::min<size_t>(b, cap);
+}
+
+struct ProfRec { const char* name; double bytes; hipEvent_t a, b; };
+#define DPL(kern, grid, block, ...) do { prof_begin(#kern); hipLaunchKernelGGL(kern, grid, block, 0, s_, __VA_ARGS__); prof_end(); } while (0)
+
+class HipDev : public Dev {
+  int device_;
+  bool prof_ = false;
+  double nb_ = 0;  // algorithmic bytes of the next launch (SURVEY.md 8d ledger), consumed by prof_begin
+  std::vector<ProfRec> recs_;
+  void prof_begin(const char* name) {
+    if (!prof_) { nb_ = 0; return; }
+    ProfRec r; r.name = name; r.bytes = nb_; nb_ = 0;
+    hipEventCreate(&r.a); hipEventCreate(&r.b);
+    hipEventRecord(r.a, s_);
+    recs_.push_back(r);
+  }
+  void prof_end() { if (prof_) hipEventRecord(recs_.back().b, s_); }
+
+  hipStream_t s_ = nullptr;
+  char* arena_ = nullptr;
+  size_t arena_cap_ = 0, arena_off_ = 0;
+  u64* hres_ = nullptr;   // pinned host staging for small results
+  u64* dres_ = nullptr;   // device result buffer
+  void* hstage_ = nullptr;  // pinned staging for descriptor uploads
+  static constexpr size_t RES_WORDS = 1 << 16;
+  static constexpr size_t STAGE_BYTES = 64 << 20;
+  unsigned L_ = 0;  // full_message_size_log of the current PCS parameters
+  u64* tw_ = nullptr;    // tw[i]   = w_{2^(L+1)}^i, i < 2^L   (all FFT root tables of rs.rs:31-68 in one array)
+  u64* pow7_ = nullptr;  // pow7[i] = 7^i,          i < 2^L   (coset shifts)
+  std::string name_;
+
+  void* arena_alloc(size_t bytes) {
+    size_t off = (arena_off_ + 255) & ~size_t(255);
+    if (off + bytes > arena_cap_) throw DpError(DP_ERR_OOM, "device arena exhausted (raise DP_ARENA_BYTES)");
+    arena_off_ = off + bytes;
+    return arena_ + off;
+  }
+  void fetch(size_t nwords) {
+    DP_REQUIRE(nwords <= RES_WORDS, DP_ERR_ARG, "result too large");
+    HIP_CHECK(hipMemcpyAsync(hres_, dres_, nwords * 8, hipMemcpyDeviceToHost, s_));
+    HIP_CHECK(hipStreamSynchronize(s_));
+  }
+  static PointArg make_point(const Ext* pt, unsigned k) {
+    DP_REQUIRE(k <= MAX_PT, DP_ERR_SHAPE, "point too long");
+    PointArg p;
+    for (unsigned i = 0; i < k; i++) p.p[i] = pt[i];
+    for (unsigned i = k; i < MAX_PT; i++) p.p[i] = ex_zero();
+    return p;
+  }
+
+ public:
+  explicit HipDev(int device) : device_(device) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) throw DpError(DP_ERR_NODEVICE, "no HIP device available: the MI355X path is mandatory, there is no CPU fallback");
+    DP_REQUIRE(device >= 0 && device < cnt, DP_ERR_ARG, "bad device id");
+    HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    name_ = std::string("hip:") + prop.name + ":" + prop.gcnArchName;
+    HIP_CHECK(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
+    const char* env = getenv("DP_ARENA_BYTES");
+    arena_cap_ = env ? strtoull(env, nullptr, 10) : (size_t(12) << 30);
+    HIP_CHECK(hipMalloc((void**)&arena_, arena_cap_));
+    HIP_CHECK(hipHostMalloc((void**)&hres_, RES_WORDS * 8, hipHostMallocDefault));
+    HIP_CHECK(hipMalloc((void**)&dres_, RES_WORDS * 8));
+    HIP_CHECK(hipHostMalloc(&hstage_, STAGE_BYTES, hipHostMallocDefault));
+    HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_rc), POSEIDON2_RC_HOST, sizeof(POSEIDON2_RC_HOST)));
+  }
+  ~HipDev() override {
+    hipSetDevice(device_);
+    if (s_) hipStreamSynchronize(s_);
+    if (tw_) hipFree(tw_);
+    if (pow7_) hipFree(pow7_);
+    if (arena_) hipFree(arena_);
+    if (dres_) hipFree(dres_);
+    if (hres_) hipHostFree(hres_);
+    if (hstage_) hipHostFree(hstage_);
+    if (s_) hipStreamDestroy(s_);
+  }
+  const char* name() const override { return name_.c_str(); }
+  hipStream_t stream() const { return s_; }
+  // per-kernel HIP-event timing on the launch stream (bench.py roofline). report: name -> (launches, total ms, total bytes)
+  void profile_enable(bool on) {
+    hipStreamSynchronize(s_);
+    for (auto& r : recs_) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    recs_.clear();
+    prof_ = on;
+  }
+  std::string profile_report() {
+    hipStreamSynchronize(s_);
+    struct Agg { size_t n = 0; double ms = 0, bytes = 0; };
+    std::vector<std::pair<std::string, Agg>> agg;
+    for (auto& r : recs_) {
+      float ms = 0; hipEventElapsedTime(&ms, r.a, r.b);
+      size_t k = 0; for (; k < agg.size(); k++) if (agg[k].first == r.name) break;
+      if (k == agg.size()) agg.push_back({r.name, Agg()});
+      agg[k].second.n++; agg[k].second.ms += ms; agg[k].second.bytes += r.bytes;
+    }
+    std::string out = "[";
+    for (size_t k = 0; k < agg.size(); k++) {
+      char buf[512];
+      snprintf(buf, sizeof buf, "%s{\"kernel\": \"%s\", \"launches\": %zu, \"total_ms\": %.6f, \"alg_bytes\": %.0f}", k ? ", " : "", agg[k].first.c_str(), agg[k].second.n, agg[k].second.ms, agg[k].second.bytes);
+      out += buf;
+    }
+    return out + "]";
+  }
+
+  // ---- memory
+  DBuf alloc(size_t n, bool ext) override { DBuf b; b.n = n; b.ext = ext; b.p = arena_alloc(std::max<size_t>(n, 1) * (ext ? 16 : 8)); return b; }
+  size_t mark() override { return arena_off_; }
+  void release(size_t m) override { arena_off_ = m; }
+  DBuf alloc_persistent(size_t n, bool ext) override {
+    DBuf b; b.n = n; b.ext = ext;
+    HIP_CHECK(hipSetDevice(device_));
+    HIP_CHECK(hipMalloc(&b.p, std::max<size_t>(n, 1) * (ext ? 16 : 8)));
+    return b;
+  }
+  void free_persistent(DBuf& b) override { if (b.p) { hipStreamSynchronize(s_); hipFree(b.p); b.p = nullptr; } }
+  void upload(const DBuf& d, const u64* src) override {
+    HIP_CHECK(hipMemcpyAsync(d.p, src, d.bytes(), hipMemcpyHostToDevice, s_));
+    HIP_CHECK(hipStreamSynchronize(s_));  // src is pageable host memory owned by the caller
+  }
+  void upload_i64(const DBuf& d, const int64_t* src) override {
+    DP_REQUIRE(!d.ext, DP_ERR_ARG, "upload_i64 needs a base buffer");
+    size_t mk = mark();
+    int64_t* tmp = (int64_t*)arena_alloc(d.n * 8);
+    HIP_CHECK(hipMemcpyAsync(tmp, src, d.n * 8, hipMemcpyHostToDevice, s_));
+    DPL(k_fieldize, dim3(grid_for(d.n)), dim3(TPB), tmp, (u64*)d.p, d.n);
+    HIP_CHECK(hipStreamSynchronize(s_));
+    release(mk);
+  }
+  void download(const DBuf& src, u64* dst) override {
+    HIP_CHECK(hipMemcpyAsync(dst, src.p, src.bytes(), hipMemcpyDeviceToHost, s_));
+    HIP_CHECK(hipStreamSynchronize(s_));
+  }
+  void copy(const DBuf& d, const DBuf& s) override { HIP_CHECK(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, s_)); }
+  void zero(const DBuf& d) override { HIP_CHECK(hipMemsetAsync(d.p, 0, d.bytes(), s_)); }
+  void sync() override { HIP_CHECK(hipStreamSynchronize(s_)); }
+
+  // ---- MLE
+  void eq_table(const DBuf& out, const Ext* pt, unsigned k, Ext scale, bool acc) override {
+    DP_REQUIRE(out.ext && out.n == (size_t(1) << k), DP_ERR_SHAPE, "eq_table: output shape");
+    nb_ = 16.0 * out.n * (acc ? 2 : 1); DPL(k_eq_table, dim3(grid_for(out.n)), dim3(TPB), (Ext*)out.p, make_point(pt, k), k, scale, acc ? 1 : 0);
+  }
+  void mle_eval_batch(const DBuf* fs, int nf, const Ext* pt, unsigned k, Ext* out) override {
+    size_t n = size_t(1) << k;
+    PointArg p = make_point(pt, k);
+    for (int s = 0; s < nf; s += 8) {
+      EvalArgs a; a.nf = std::min(8, nf - s);
+      for (int f = 0; f < 8; f++) { a.f[f] = nullptr; a.ext[f] = 0; }
+      for (int f = 0; f < a.nf; f++) { DP_REQUIRE(fs[s + f].n == n, DP_ERR_SHAPE, "mle_eval: table size != 2^|point|"); a.f[f] = fs[s + f].p; a.ext[f] = fs[s + f].ext; }
+      size_t mk = mark();
+      int g = grid_for(n, 1024);
+      Ext* partial = (Ext*)arena_alloc((size_t)g * 8 * 16);
+      nb_ = [&] { double b = 0; for (int f = 0; f < a.nf; f++) b += fs[s + f].bytes(); return b; }(); DPL(k_mle_eval_partial, dim3(g), dim3(TPB), a, p, k, partial);
+      DPL(k_reduce_partials, dim3(a.nf), dim3(TPB), partial, (size_t)g, (size_t)8, (Ext*)dres_);
+      fetch(2 * a.nf);
+      for (int f = 0; f < a.nf; f++) out[s + f] = ex(hres_[2 * f], hres_[2 * f + 1]);
+      release(mk);
+    }
+  }
+  void fix_high(const DBuf& out, const DBuf& W, size_t R, size_t C, const Ext* pt) override {
+    DP_REQUIRE(!W.ext && W.n == R * C && out.ext && out.n == C, DP_ERR_SHAPE, "fix_high: shapes");
+    unsigned k = dp_ceil_log2(R);
+    size_t mk = mark();
+    DBuf eq = alloc(R, true);
+    eq_table(eq, pt, k, ex_one(), false);
+    size_t nsplit = std::min<size_t>(R, 64);
+    size_t rps = (R + nsplit - 1) / nsplit;
+    Ext* partial = (Ext*)arena_alloc(nsplit * C * 16);
+    dim3 g((unsigned)((C + TPB - 1) / TPB), (unsigned)nsplit);
+    nb_ = 8.0 * R * C + 16.0 * R; DPL(k_fix_high_partial, g, dim3(TPB), (const u64*)W.p, (const Ext*)eq.p, R, C, rps, partial);
+    DPL(k_colsum, dim3((unsigned)((C + TPB - 1) / TPB)), dim3(TPB), partial, nsplit, C, (Ext*)out.p);
+    release(mk);  // safe: stream ordered, later allocations are only written by later kernels
+  }
+
+  // ---- sumcheck
+  void fold_tables(DBuf* tabs, int nt, Ext r) {
+    for (int s = 0; s < nt; s += MAX_TABS) {
+      int m = std::min(MAX_TABS, nt - s);
+      FoldArgs a; size_t maxh = 1;
+      for (int i = 0; i < MAX_TABS; i++) { a.in[i] = nullptr; a.out[i] = nullptr; a.ext[i] = 0; a.half[i] = 0; }
+      for (int i = 0; i < m; i++) {
+        DBuf& t = tabs[s + i];
+        DBuf o = alloc(t.n / 2, true);
+        a.in[i] = t.p; a.out[i] = (Ext*)o.p; a.ext[i] = t.ext; a.half[i] = t.n / 2;
+        maxh = std::max(maxh, t.n / 2);
+        t = o;
+      }
+      nb_ = [&] { double b = 0; for (int i = 0; i < m; i++) b += a.half[i] * (a.ext[i] ? 32.0 : 16.0) + a.half[i] * 16.0; return b; }(); DPL(k_fold, dim3(grid_for(maxh), m), dim3(TPB), a, r);
+    }
+  }
+  void sc_round(DBuf* tabs, int nt, const Ext* r, const ScTerm* terms, int nterms, Ext* out) override {
+    DP_REQUIRE(nt <= MAX_TABS && nterms <= MAX_TERMS && nt > 0 && nterms > 0, DP_ERR_SHAPE, "sumcheck: too many tables/terms for one launch");
+    if (r) fold_tables(tabs, nt, *r);
+    size_t n = tabs[0].n;
+    for (int i = 0; i < nt; i++) DP_REQUIRE(tabs[i].n == n && n >= 2, DP_ERR_SHAPE, "sumcheck: tables must have equal length >= 2");
+    TermArgs a;
+    for (int i = 0; i < MAX_TABS; i++) { a.tab[i] = nullptr; a.ext[i] = 0; }
+    for (int i = 0; i < nt; i++) { a.tab[i] = tabs[i].p; a.ext[i] = tabs[i].ext; }
+    for (int i = 0; i < MAX_TERMS; i++) { a.k[i] = 1; a.t[i][0] = a.t[i][1] = a.t[i][2] = 0; }
+    for (int i = 0; i < nterms; i++) { a.k[i] = terms[i].k; for (int j = 0; j < 3; j++) a.t[i][j] = terms[i].t[j]; }
+    a.npairs = n / 2;
+    size_t mk = mark();
+    int g = grid_for(a.npairs, 512);
+    Ext* partial = (Ext*)arena_alloc((size_t)nterms * g * 4 * 16);
+    nb_ = [&] { double b = 0; for (int i = 0; i < nterms; i++) for (int j = 0; j < terms[i].k; j++) b += tabs[terms[i].t[j]].bytes(); return b; }(); DPL(k_sc_terms, dim3(g, nterms), dim3(TPB), a, partial);
+    DPL(k_reduce_terms, dim3(nterms * 4), dim3(TPB), partial, (size_t)g, (Ext*)dres_);
+    fetch((size_t)nterms * 8);
+    size_t o = 0;
+    for (int i = 0; i < nterms; i++)
+      for (int t = 0; t <= terms[i].k; t++) out[o++] = ex(hres_[(i * 4 + t) * 2], hres_[(i * 4 + t) * 2 + 1]);
+    release(mk);
+  }
+  void sc_finish(DBuf* tabs, int nt, Ext r, Ext* finals) override {
+    DP_REQUIRE(nt <= MAX_TABS, DP_ERR_SHAPE, "sumcheck: too many tables");
+    FoldArgs a;
+    for (int i = 0; i < MAX_TABS; i++) { a.in[i] = nullptr; a.out[i] = nullptr; a.ext[i] = 0; a.half[i] = 0; }
+    for (int i = 0; i < nt; i++) { DP_REQUIRE(tabs[i].n == 2, DP_ERR_SHAPE, "sc_finish: tables must have 2 entries"); a.in[i] = tabs[i].p; a.ext[i] = tabs[i].ext; }
+    DPL(k_finish, dim3(1), dim3(64), a, r, nt, (Ext*)dres_);
+    fetch(2 * (size_t)nt);
+    for (int i = 0; i < nt; i++) finals[i] = ex(hres_[2 * i], hres_[2 * i + 1]);
+  }
+
+  // ---- logup
+  void logup_den(const DBuf& out, const DBuf* cols, int nc, Ext c, Ext chi) override {
+    DP_REQUIRE(nc >= 1 && nc <= 16 && out.ext, DP_ERR_SHAPE, "logup_den: 1..16 columns");
+    ColsArg a; a.n = nc;
+    for (int i = 0; i < 16; i++) a.col[i] = nullptr;
+    for (int i = 0; i < nc; i++) { DP_REQUIRE(!cols[i].ext && cols[i].n == out.n, DP_ERR_SHAPE, "logup_den: column shape"); a.col[i] = (const u64*)cols[i].p; }
+    nb_ = 8.0 * nc * out.n + 16.0 * out.n; DPL(k_logup_den, dim3(grid_for(out.n)), dim3(TPB), (Ext*)out.p, a, c, chi, out.n);
+  }
+  void logup_layer(const DBuf& ni, const DBuf& di, const DBuf& no, const DBuf& dout) override {
+    size_t h = di.n / 2;
+    DP_REQUIRE(di.ext && no.n == h && dout.n == h && (ni.null() || ni.n == di.n), DP_ERR_SHAPE, "logup_layer: shapes");
+    int mode = ni.null() ? 0 : (ni.ext ? 2 : 1);
+    nb_ = (mode == 0 ? 32.0 : mode == 1 ? 48.0 : 64.0) * h + 32.0 * h; DPL(k_logup_layer, dim3(grid_for(h)), dim3(TPB), (const void*)ni.p, mode, (const Ext*)di.p, (Ext*)no.p, (Ext*)dout.p, h);
+  }
+
+  // ---- PCS
+  void pcs_init(unsigned L) override {
+    if (L == L_ && tw_) return;
+    DP_REQUIRE(L >= 1 && L <= 28, DP_ERR_ARG, "pcs_init: unsupported parameter size");
+    HIP_CHECK(hipStreamSynchronize(s_));
+    if (tw_) { hipFree(tw_); tw_ = nullptr; }
+    if (pow7_) { hipFree(pow7_); pow7_ = nullptr; }
+    L_ = L;
+    size_t n = size_t(1) << L;
+    HIP_CHECK(hipMalloc((void**)&tw_, n * 8));
+    HIP_CHECK(hipMalloc((void**)&pow7_, n * 8));
+    u64 w = GL_G32;
+    for (unsigned i = L + 1; i < 32; i++) w = gl_sqr(w);
+    DPL(k_pow_table, dim3(grid_for(n)), dim3(TPB), tw_, w, n);
+    DPL(k_pow_table, dim3(grid_for(n)), dim3(TPB), pow7_, GL_GENERATOR, n);
+    HIP_CHECK(hipStreamSynchronize(s_));
+  }
+  void bitrev_copy(const DBuf& d, const DBuf& s) override {
+    unsigned lg = dp_ceil_log2(s.n);
+    if (s.ext) { nb_ = 32.0 * s.n; DPL(k_bitrev<true>, dim3(grid_for(s.n)), dim3(TPB), d.p, (const void*)s.p, lg); }
+    else { nb_ = 16.0 * s.n; DPL(k_bitrev<false>, dim3(grid_for(s.n)), dim3(TPB), d.p, (const void*)s.p, lg); }
+  }
+  // `nodes` must hold 4*(n-1) words; synchronises (root is copied to the host)
+  DevTree build_tree_into(const DBuf& leaves, const DBuf& nodes) {
+    DevTree t; t.leaves = leaves; t.nleaves = leaves.n; t.nodes = nodes;
+    size_t n = leaves.n;
+    u64* nd = (u64*)t.nodes.p;
+    if (leaves.ext) { nb_ = 16.0 * n + 16.0 * n; DPL(k_merkle_leaves<true>, dim3(grid_for(n / 2)), dim3(TPB), (const void*)leaves.p, nd, n / 2); }
+    else { nb_ = 8.0 * n + 16.0 * n; DPL(k_merkle_leaves<false>, dim3(grid_for(n / 2)), dim3(TPB), (const void*)leaves.p, nd, n / 2); }
+    size_t off = 0, cnt = n / 2;
+    while (cnt > 1) {
+      nb_ = 96.0 * (cnt / 2); DPL(k_merkle_layer, dim3(grid_for(cnt / 2, 4096)), dim3(TPB), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), cnt / 2);
+      off += cnt; cnt /= 2;
+    }
+    HIP_CHECK(hipMemcpyAsync(hres_, nd + 4 * (n - 2), 32, hipMemcpyDeviceToHost, s_));
+    HIP_CHECK(hipStreamSynchronize(s_));
+    for (int k = 0; k < 4; k++) t.root.v[k] = hres_[k];
+    return t;
+  }
+  DevTree build_tree(const DBuf& leaves, bool persistent) {
+    size_t n = leaves.n;
+    DP_REQUIRE(n >= 2 && (n & (n - 1)) == 0, DP_ERR_SHAPE, "merkle: leaf count must be a power of two >= 2");
+    DBuf nodes = persistent ? alloc_persistent(4 * (n - 1), false) : alloc(4 * (n - 1), false);
+    return build_tree_into(leaves, nodes);
+  }
+  DevCommit commit(const DBuf& evals, bool persistent) override {
+    DevCommit c; c.nv = dp_ceil_log2(evals.n); c.is_base = !evals.ext; c.evals = evals;
+    DP_REQUIRE((size_t(1) << c.nv) == evals.n && evals.n >= 2, DP_ERR_SHAPE, "commit: polynomial length must be a power of two >= 2");
+    if (c.nv <= 7) { c.bh_evals = evals; c.tree = build_tree(evals, persistent); return c; }
+    DP_REQUIRE(tw_ && c.nv <= L_, DP_ERR_SHAPE, "commit: polynomial larger than the PCS parameters (PolynomialTooLarge)");
+    size_t n = evals.n;
+    auto A = [&](size_t m, bool e) { return persistent ? alloc_persistent(m, e) : alloc(m, e); };
+    DBuf cw = A(2 * n, evals.ext);
+    c.bh_evals = A(n, evals.ext);
+    DBuf nodes = A(4 * (2 * n - 1), false);
+    size_t mk = mark();
+    DBuf co = alloc(n, evals.ext);
+    DBuf tmp = alloc(2 * n, evals.ext);
+    copy(co, evals);
+    bool E = evals.ext;
+    for (unsigned s = 0; s < c.nv; s++) {  // K5 evaluations -> multilinear coefficients
+      if (E) { nb_ = 32.0 * n; DPL(k_mobius_stage<true>, dim3(grid_for(n / 2)), dim3(TPB), co.p, n, s); }
+      else { nb_ = 16.0 * n; DPL(k_mobius_stage<false>, dim3(grid_for(n / 2)), dim3(TPB), co.p, n, s); }
+    }
+    if (E) { nb_ = 48.0 * n; DPL(k_rs_prepare<true>, dim3(grid_for(n)), dim3(TPB), (const void*)co.p, tmp.p, (const u64*)pow7_, c.nv, L_); }
+    else { nb_ = 24.0 * n; DPL(k_rs_prepare<false>, dim3(grid_for(n)), dim3(TPB), (const void*)co.p, tmp.p, (const u64*)pow7_, c.nv, L_); }
+    for (unsigned s = 1; s <= c.nv; s++) {  // K7 remaining DIT stages on 2n points
+      if (E) { nb_ = 64.0 * n; DPL(k_ntt_stage<true>, dim3(grid_for(n)), dim3(TPB), tmp.p, 2 * n, s, (const u64*)tw_, L_); }
+      else { nb_ = 32.0 * n; DPL(k_ntt_stage<false>, dim3(grid_for(n)), dim3(TPB), tmp.p, 2 * n, s, (const u64*)tw_, L_); }
+    }
+    bitrev_copy(cw, tmp);            // K6
+    bitrev_copy(c.bh_evals, evals);  // K6
+    c.tree = build_tree_into(cw, nodes);  // K8 (synchronises: root to host)
+    release(mk);
+    return c;
+  }
+  void free_commit(DevCommit& c) override {
+    if (c.bh_evals.p && c.bh_evals.p != c.evals.p) free_persistent(c.bh_evals);
+    if (c.tree.leaves.p && c.tree.leaves.p != c.evals.p) free_persistent(c.tree.leaves);
+    free_persistent(c.tree.nodes);
+    free_persistent(c.evals);
+  }
+  DevTree merkle_ext(const DBuf& leaves) override { return build_tree(leaves, false); }
+
+  void classic_round(DBuf* fs, DBuf* eqs, int np, const Ext* r, Ext* out) override {
+    DP_REQUIRE((size_t)np * sizeof(PolyDesc) <= STAGE_BYTES / 2 && (size_t)np * 4 <= RES_WORDS, DP_ERR_SHAPE, "classic_round: too many polynomials");
+    PolyDesc* hd = (PolyDesc*)hstage_;
+    size_t maxn = 1;
+    for (int i = 0; i < np; i++) {
+      DP_REQUIRE(fs[i].n == eqs[i].n && eqs[i].ext, DP_ERR_SHAPE, "classic_round: f/eq shapes");
+      hd[i].f = fs[i].p; hd[i].eq = (const Ext*)eqs[i].p; hd[i].n = fs[i].n; hd[i].fext = fs[i].ext; hd[i].pad = 0; hd[i].fout = nullptr; hd[i].eqout = nullptr;
+      if (r && fs[i].n > 1) {
+        DBuf fo = alloc(fs[i].n / 2, true), eo = alloc(fs[i].n / 2, true);
+        hd[i].fout = (Ext*)fo.p; hd[i].eqout = (Ext*)eo.p;
+        fs[i] = fo; eqs[i] = eo;
+      }
+      maxn = std::max(maxn, hd[i].n);
+    }
+    size_t mk = mark();
+    PolyDesc* dd = (PolyDesc*)arena_alloc((size_t)np * sizeof(PolyDesc));
+    HIP_CHECK(hipMemcpyAsync(dd, hd, (size_t)np * sizeof(PolyDesc), hipMemcpyHostToDevice, s_));
+    if (r) {
+      nb_ = [&] { double b = 0; for (int i = 0; i < np; i++) if (hd[i].fout) b += hd[i].n * (hd[i].fext ? 16.0 : 8.0) + hd[i].n * 16.0 + hd[i].n * 16.0; return b; }(); DPL(k_classic_fold, dim3(grid_for(maxn / 2, 1024), np), dim3(TPB), (const PolyDesc*)dd, *r);
+      // descriptors for the sums: the folded tables
+      HIP_CHECK(hipStreamSynchronize(s_));  // hstage_ is reused below
+      maxn = 1;
+      for (int i = 0; i < np; i++) { hd[i].f = fs[i].p; hd[i].eq = (const Ext*)eqs[i].p; hd[i].n = fs[i].n; hd[i].fext = fs[i].ext; maxn = std::max(maxn, hd[i].n); }
+      HIP_CHECK(hipMemcpyAsync(dd, hd, (size_t)np * sizeof(PolyDesc), hipMemcpyHostToDevice, s_));
+    }
+    int g = grid_for(std::max<size_t>(maxn / 2, 1), 256);
+    Ext* partial = (Ext*)arena_alloc((size_t)np * g * 2 * 16);
+    nb_ = [&] { double b = 0; for (int i = 0; i < np; i++) b += hd[i].n * (hd[i].fext ? 16.0 : 8.0) + hd[i].n * 16.0; return b; }(); DPL(k_classic_sums, dim3(g, np), dim3(TPB), (const PolyDesc*)dd, partial);
+    DPL(k_reduce_pairs, dim3(np * 2), dim3(TPB), partial, (size_t)g, (Ext*)dres_);
+    fetch((size_t)np * 4);
+    for (int i = 0; i < 2 * np; i++) out[i] = ex(hres_[2 * i], hres_[2 * i + 1]);
+    release(mk);
+  }
+  void axpy_rep(const DBuf& acc, const DBuf& x, Ext coeff, size_t rep) override {
+    DP_REQUIRE(acc.ext && acc.n == x.n * rep && (rep & (rep - 1)) == 0, DP_ERR_SHAPE, "axpy_rep: shapes");
+    nb_ = x.bytes() + 32.0 * acc.n; DPL(k_axpy_rep, dim3(grid_for(acc.n)), dim3(TPB), (Ext*)acc.p, (const void*)x.p, (int)x.ext, coeff, acc.n, dp_ceil_log2(rep));
+  }
+  void bf_round(DBuf& eq, DBuf& f, const Ext* ch, Ext* msg) override {
+    DP_REQUIRE(eq.ext && f.ext && eq.n == f.n, DP_ERR_SHAPE, "bf_round: shapes");
+    if (ch) { DBuf t[2] = {eq, f}; fold_tables(t, 2, *ch); eq = t[0]; f = t[1]; }
+    if (!msg) return;
+    if (f.n == 1) { u64 w[2]; download(f, w); msg[0] = msg[1] = msg[2] = ex(w[0], w[1]); return; }
+    size_t mk = mark();
+    int g = grid_for(f.n / 2, 512);
+    Ext* partial = (Ext*)arena_alloc((size_t)g * 4 * 16);
+    nb_ = 32.0 * f.n; DPL(k_bf_msg, dim3(g), dim3(TPB), (const Ext*)f.p, (const Ext*)eq.p, f.n / 2, partial);
+    DPL(k_reduce_partials, dim3(3), dim3(TPB), (const Ext*)partial, (size_t)g, (size_t)4, (Ext*)dres_);
+    fetch(6);
+    for (int i = 0; i < 3; i++) msg[i] = ex(hres_[2 * i], hres_[2 * i + 1]);
+    release(mk);
+  }
+  DBuf fri_fold(const DBuf& o, unsigned level, Ext ch) override {
+    DP_REQUIRE(o.ext && o.n == (size_t(2) << level) && level <= L_, DP_ERR_SHAPE, "fri_fold: shapes");
+    DBuf out = alloc(o.n / 2, true);
+    u64 gam = GL_GENERATOR;
+    for (unsigned i = 0; i < L_ + 1 - level - 1; i++) gam = gl_sqr(gam);
+    u64 ninv = gl_neg(gl_inv(gl_dbl(gam)));  // -1/(2 gamma)
+    nb_ = 16.0 * o.n + 8.0 * o.n; DPL(k_fri_fold, dim3(grid_for(out.n)), dim3(TPB), (const Ext*)o.p, (Ext*)out.p, out.n, level, (const u64*)tw_, L_, gam, ninv, ch);
+    return out;
+  }
+  void query_gather(const QueryDesc* d, size_t nd, std::vector<std::vector<u64>>& out) override {
+    out.resize(nd);
+    if (!nd) return;
+    DP_REQUIRE(nd * sizeof(GatherDesc) <= STAGE_BYTES, DP_ERR_SHAPE, "query_gather: too many descriptors");
+    GatherDesc* hd = (GatherDesc*)hstage_;
+    size_t total = 0;
+    for (size_t i = 0; i < nd; i++) {
+      const DevTree& t = *d[i].tree;
+      hd[i].leaves = t.leaves.p; hd[i].nodes = (const u64*)t.nodes.p; hd[i].nleaves = t.nleaves; hd[i].p0 = d[i].p0;
+      hd[i].ext = t.leaves.ext; hd[i].height = (int)t.height(); hd[i].out_off = total;
+      total += (t.leaves.ext ? 4 : 2) + 4 * (size_t)(t.height() - 1);
+    }
+    size_t mk = mark();
+    GatherDesc* dd = (GatherDesc*)arena_alloc(nd * sizeof(GatherDesc));
+    u64* dout = (u64*)arena_alloc(total * 8);
+    HIP_CHECK(hipMemcpyAsync(dd, hd, nd * sizeof(GatherDesc), hipMemcpyHostToDevice, s_));
+    DPL(k_query_gather, dim3((unsigned)((nd + 3) / 4)), dim3(TPB), (const GatherDesc*)dd, nd, dout);
+    std::vector<u64> flat(total);
+    HIP_CHECK(hipMemcpyAsync(flat.data(), dout, total * 8, hipMemcpyDeviceToHost, s_));
+    HIP_CHECK(hipStreamSynchronize(s_));
+    for (size_t i = 0; i < nd; i++) {
+      size_t len = (hd[i].ext ? 4 : 2) + 4 * (size_t)(hd[i].height - 1);
+      out[i].assign(flat.begin() + hd[i].out_off, flat.begin() + hd[i].out_off + len);
+    }
+    release(mk);
+  }
+};
+
+Dev* make_hip_dev(int device) { return new HipDev(device); }
+void hip_dev_profile_enable(Dev* d, bool on) { static_cast<HipDev*>(d)->profile_enable(on); }
+std::string hip_dev_profile_report(Dev* d) { return static_cast<HipDev*>(d)->profile_report(); }
+
+}  // namespace dp

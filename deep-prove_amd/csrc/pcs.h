@@ -85,7 +85,7 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
   // ---- batch_commit_phase (commit_phase.rs:187-359)
   unsigned num_rounds = num_vars - PCS_BASECODE_LOG;
   size_t cw_size = size_t(1) << (num_vars + PCS_RATE_LOG);
-  auto zeros = [&](size_t n) { DBuf b = dev.alloc(n, true); std::vector<u64> z(2 * n, 0); dev.upload(b, z.data()); return b; };
+  auto zeros = [&](size_t n) { DBuf b = dev.alloc(n, true); dev.zero(b); return b; };
   DBuf running = zeros(cw_size);
   for (size_t i = 0; i < np; i++) if (claims[i].comm->codeword_size() == cw_size) dev.axpy_rep(running, claims[i].comm->tree.leaves, coeffs[i], 1);
   DBuf sum_evals = zeros(size_t(1) << num_vars);

@@ -1,0 +1,129 @@
+/* deep_prove_hip.h — C ABI of the MI355X-native deep-prove hot path (libdeepprove_hip.so).
+ *
+ * This is the boundary a Rust shim (or any FFI) binds to replace the reference's CPU rayon path. Every entry point
+ * cites the reference interface it stands in for (paths relative to the deep-prove repository). Conventions:
+ *   - every function returns int32 status: 0 = ok, negative = DP_ERR_*; nothing throws or aborts across the ABI;
+ *     dp_last_error() returns the message of the last failure on the calling thread;
+ *   - field elements cross the ABI as canonical little-endian uint64 (< p = 2^64-2^32+1); an extension element is
+ *     two consecutive uint64 (c0, c1) of c0 + c1*X, X^2 = 7;
+ *   - a dp_ctx owns one HIP device, one stream and a device arena; calls on one ctx must come from one thread at a
+ *     time (one ctx per GPU, one host thread per ctx);
+ *   - tables live in HBM behind opaque dp_buf handles; host<->device copies are explicit;
+ *   - buffers returned through `uint64_t**` are malloc'ed by the library and released with dp_free();
+ *   - there is NO CPU fallback: dp_ctx_create fails with DP_ERR_NODEVICE when no MI355X/HIP device is present.
+ *     (dp_verify / dp_pcs_batch_verify / dp_transcript_* are host-only by design, as in the reference.)
+ */
+#ifndef DEEP_PROVE_HIP_H
+#define DEEP_PROVE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DP_OK 0
+#define DP_ERR_ARG (-1)
+#define DP_ERR_OOM (-2)
+#define DP_ERR_HIP (-3)
+#define DP_ERR_SHAPE (-4)
+#define DP_ERR_VERIFY (-5)
+#define DP_ERR_NODEVICE (-6)
+
+typedef struct dp_ctx dp_ctx;
+typedef struct dp_buf dp_buf;
+typedef struct dp_transcript dp_transcript;
+typedef struct dp_commit dp_commit;
+typedef struct dp_model dp_model;
+
+const char* dp_last_error(void);
+void dp_free(void* p);
+
+/* ---- device context */
+int32_t dp_ctx_create(int32_t device_id, dp_ctx** out);
+int32_t dp_ctx_destroy(dp_ctx* ctx);
+const char* dp_ctx_name(const dp_ctx* ctx);
+
+/* ---- measurement: per-kernel HIP-event timing on the ctx's launch stream (used by bench.py for the roofline object).
+ * dp_profile_report returns a malloc'ed JSON array [{"kernel","launches","total_ms","alg_bytes"}...]; free with dp_free. */
+int32_t dp_profile_enable(dp_ctx* ctx, int32_t on);
+int32_t dp_profile_report(dp_ctx* ctx, char** json);
+
+/* ---- tables: DenseMultilinearExtension{evaluations: FieldType::{Base,Ext}} (multilinear_extensions/src/mle.rs:137-181) */
+/* Fieldizer::to_field on i64 (zkml/src/quantization/mod.rs:210-220), done on device */
+int32_t dp_buf_from_i64(dp_ctx* ctx, const int64_t* v, size_t n, dp_buf** out);
+/* n elements; words holds n (base) or 2n (ext) canonical uint64 */
+int32_t dp_buf_upload(dp_ctx* ctx, const uint64_t* words, size_t n, int32_t is_ext, dp_buf** out);
+int32_t dp_buf_download(dp_ctx* ctx, const dp_buf* buf, uint64_t* out_words);
+size_t dp_buf_len(const dp_buf* buf);
+int32_t dp_buf_is_ext(const dp_buf* buf);
+int32_t dp_buf_free(dp_ctx* ctx, dp_buf* buf);
+
+/* ---- Fiat-Shamir transcript: transcript::BasicTranscript (transcript/src/basic.rs:8-54, lib.rs:42-78). Host side. */
+dp_transcript* dp_transcript_new(const char* label); /* BasicTranscript::new(label); NULL -> no label absorbed */
+void dp_transcript_free(dp_transcript* t);
+int32_t dp_transcript_append_elements(dp_transcript* t, const uint64_t* base_elems, size_t n); /* append_field_elements */
+int32_t dp_transcript_append_message(dp_transcript* t, const uint8_t* bytes, size_t n);       /* append_message */
+/* label != NULL: get_and_append_challenge(label); label == NULL: read_challenge() */
+int32_t dp_transcript_challenge(dp_transcript* t, const char* label, uint64_t out[2]);
+
+/* ---- MLE primitives */
+/* build_eq_x_r_vec (multilinear_extensions/src/virtual_poly.rs:414-453) / compute_betas_eval (zkml/src/commit/mod.rs:10-28) */
+int32_t dp_eq_table(dp_ctx* ctx, const uint64_t* point, uint32_t k, dp_buf** out);
+/* MultilinearExtension::evaluate (mle.rs:607-623) */
+int32_t dp_mle_eval(dp_ctx* ctx, const dp_buf* f, const uint64_t* point, uint32_t k, uint64_t out[2]);
+/* fix_high_variables_in_place of a rows x cols base matrix at a log2(rows)-coordinate point (mle.rs:562-603 as used by
+ * zkml/src/layers/dense.rs:470-475), in one pass from the base-field weights */
+int32_t dp_mle_fix_high(dp_ctx* ctx, const dp_buf* matrix, size_t rows, size_t cols, const uint64_t* point, dp_buf** out);
+
+/* ---- sumcheck: IOPProverState::prove_parallel(VirtualPolynomial, transcript) (sumcheck/src/prover.rs:498-585).
+ * The virtual polynomial is sum_i coeff_i * prod_{j<degree_i} tables[term_tables[3i+j]]; every table has 2^num_vars
+ * entries. proof_words receives the IOPProof stream {point: len, ext...; rounds: count, (len, ext...)...};
+ * finals receives get_mle_final_evaluations() (2 words per table, table order). */
+int32_t dp_sumcheck_prove(dp_ctx* ctx, uint32_t num_vars, const dp_buf* const* tables, int32_t ntables,
+                          const int32_t* term_degree, const int32_t* term_tables, const uint64_t* term_coeffs,
+                          int32_t nterms, dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords,
+                          uint64_t* finals);
+
+/* ---- logup-GKR: logup_gkr::prover::batch_prove(LogUpInput, transcript) (zkml/src/lookup/logup_gkr/prover.rs:24-198).
+ * multiplicities == NULL -> LogUpInput::Lookup with `cols_per_instance`; else LogUpInput::Table. */
+int32_t dp_logup_prove(dp_ctx* ctx, const dp_buf* const* columns, int32_t ncols, int32_t cols_per_instance,
+                       const dp_buf* multiplicities, const uint64_t constant_challenge[2],
+                       const uint64_t column_separation_challenge[2], dp_transcript* t, uint64_t** proof_words,
+                       size_t* proof_nwords);
+
+/* ---- PCS: mpcs::PolynomialCommitmentScheme for Basefold<GoldilocksExt2, BasefoldRSParams<PoseidonHasher>> */
+/* PCS::setup + PCS::trim (mpcs/src/basefold.rs:278-303): max_poly_size must be a power of two */
+int32_t dp_pcs_setup(dp_ctx* ctx, size_t max_poly_size);
+/* PCS::commit (mpcs/src/basefold.rs:304-354); the commitment keeps a reference to `poly` (do not free it first) */
+int32_t dp_pcs_commit(dp_ctx* ctx, const dp_buf* poly, dp_commit** out, uint64_t root[4]);
+int32_t dp_pcs_commit_free(dp_ctx* ctx, dp_commit* c);
+/* PCS::batch_open with Evaluation::new(i, i, evals[i]) (mpcs/src/basefold.rs:546-770 as called from
+ * zkml/src/commit/context.rs:355-418). points_flat = concatenation of the n points (2*num_vars_i words each). */
+int32_t dp_pcs_batch_open(dp_ctx* ctx, const dp_commit* const* comms, int32_t n, const uint64_t* points_flat,
+                          const uint64_t* evals, dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords);
+/* PCS::batch_verify (mpcs/src/basefold.rs:964-1098). Host only. roots: 4 words per commitment. */
+int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const uint32_t* num_vars,
+                            const int32_t* is_base, int32_t n, const uint64_t* points_flat, const uint64_t* evals,
+                            const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t);
+
+/* ---- model level: Context::generate / Prover::prove / verify (zkml/src/iop/context.rs:109, prover.rs:401,
+ * verifier.rs:306). model_blob (int64): input_len, nlayers, then per layer kind(0 Dense,1 Requant,2 Relu) followed by
+ *   Dense: nrows, ncols, weights[nrows*ncols] row-major, bias[nrows]   (padded to powers of two, already quantised)
+ *   Requant: right_shift, fp_scale, fixed_point_multiplier, intermediate_bit_size
+ *   Relu: (nothing) */
+int32_t dp_model_setup(dp_ctx* ctx, const int64_t* model_blob, size_t nwords, dp_model** out);
+int32_t dp_model_free(dp_model* m);
+/* runs inference on the host (Model::run, not part of proving time) then Prover::prove on the device.
+ * output receives the model output (capacity *noutput on entry, length on exit). prove_ms (nullable) = prove() wall ms */
+int32_t dp_model_prove(dp_model* m, const int64_t* input, size_t ninput, uint64_t** proof_words, size_t* proof_nwords,
+                       int64_t* output, size_t* noutput, double* prove_ms);
+/* serialisable verifier-side context (model commitments, shapes, tables) */
+int32_t dp_model_verifier_blob(const dp_model* m, uint64_t** words, size_t* nwords);
+/* zkml::verify(ctx, proof, io, transcript) — host only, default transcript "m2vec" */
+int32_t dp_verify(const uint64_t* verifier_blob, size_t blob_nwords, const uint64_t* proof_words, size_t proof_nwords,
+                  const int64_t* input, size_t ninput, const int64_t* output, size_t noutput);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -11,6 +11,8 @@
 #include <map>
 #include <unordered_map>
 #include <algorithm>
+#include <thread>
+#include <string>
 
 namespace orc {
 
@@ -260,13 +262,18 @@ static inline Context context_generate(const Model& m) {
   max_poly_len = next_pow2(max_poly_len);
   ctx.max_poly_len = max_poly_len;
   ctx.pp = pcs_setup(max_poly_len);
-  for (size_t id = 0; id < m.layers.size(); id++) {
-    const Layer& l = m.layers[id];
-    if (l.kind != L_DENSE) continue;
-    Mle w = Mle::from_i64(l.weights), b = Mle::from_i64(l.bias);
-    ctx.model_comms[id]["DenseWeight"] = {pcs_commit(ctx.pp, w), w};
-    ctx.model_comms[id]["DenseBias"] = {pcs_commit(ctx.pp, b), b};
-  }
+  // commit/context.rs:79-103 commits the model polynomials with `into_par_iter`; the oracle mirrors that with plain
+  // threads (one per polynomial) — commitments are independent so the result does not depend on the schedule
+  std::vector<std::pair<size_t, const char*>> jobs;
+  for (size_t id = 0; id < m.layers.size(); id++) if (m.layers[id].kind == L_DENSE) { jobs.push_back({id, "DenseWeight"}); jobs.push_back({id, "DenseBias"}); }
+  for (auto& j : jobs) ctx.model_comms[j.first][j.second];  // create map slots before the threads write into them
+  std::vector<std::thread> th;
+  for (auto& j : jobs) th.emplace_back([&ctx, &m, j] {
+    const Layer& l = m.layers[j.first];
+    Mle poly = Mle::from_i64(std::string(j.second) == "DenseWeight" ? l.weights : l.bias);
+    ctx.model_comms[j.first][j.second] = {pcs_commit(ctx.pp, poly), poly};
+  });
+  for (auto& t : th) t.join();
   ctx.tables = tset;  // none of Relu/Range/Clamping has committed columns (lookup/context.rs:492-545)
   return ctx;
 }

@@ -29,6 +29,7 @@ class CpuDev : public Dev {
   void upload_i64(const DBuf& d, const int64_t* s) override { for (size_t i = 0; i < d.n; i++) B(d)[i] = gl_from_i64(s[i]); }
   void download(const DBuf& s, u64* d) override { memcpy(d, s.p, s.bytes()); }
   void copy(const DBuf& d, const DBuf& s) override { memcpy(d.p, s.p, s.bytes()); }
+  void zero(const DBuf& d) override { memset(d.p, 0, d.bytes()); }
   void sync() override {}
   void eq_table(const DBuf& out, const Ext* pt, unsigned k, Ext scale, bool acc) override {
     for (size_t i = 0; i < (size_t(1) << k); i++) {

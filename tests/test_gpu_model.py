@@ -1,0 +1,99 @@
+"""GPU parity of the whole proving path (zkml::Prover::prove) through the C ABI: proof bytes identical to the oracle,
+verifier acceptance, and the BASELINE.json configs."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def prove_both(dev, oracle, mb, x):
+    import deep_prove_amd as dpa
+    blob = mb.blob()
+    ctx = dpa.Context.generate(dev, blob)
+    prover = dpa.Prover(ctx)
+    proof, out = prover.prove(x)
+    h = oracle.model_setup(blob)
+    oproof, oout, _ = oracle.model_prove(h, x)
+    oracle.model_free(h)
+    return ctx, proof, out, oproof, oout
+
+
+@pytest.mark.parametrize("num_dense,width", [(1, 8), (2, 16), (2, 64), (3, 256)])
+def test_mlp_proof_bytes_identical_to_oracle(dev, oracle, num_dense, width):
+    import deep_prove_amd as dpa
+    mb = dpa.models.mlp(num_dense, width, config=20 + width)
+    x = mb.input()
+    ctx, proof, out, oproof, oout = prove_both(dev, oracle, mb, x)
+    assert (out == oout).all() and (out == mb.run(x)).all()
+    assert proof.size == oproof.size, (proof.size, oproof.size)
+    diff = np.nonzero(proof != oproof)[0]
+    assert diff.size == 0, f"first differing word {diff[:5]} of {proof.size}"
+    dpa.verify(ctx.verifier_blob(), proof, x, out)
+    ctx.free()
+
+
+def test_golden_mlp_w8(dev):
+    """committed fixture tests/golden/mlp_w8.npz (made by tests/golden/make_golden.py)"""
+    import deep_prove_amd as dpa
+    g = np.load(os.path.join(ROOT, "tests", "golden", "mlp_w8.npz"))
+    ctx = dpa.Context.generate(dev, g["model_blob"])
+    proof, out = dpa.Prover(ctx).prove(g["input"])
+    assert (out == g["output"]).all()
+    assert proof.size == g["proof"].size and (proof == g["proof"]).all()
+    assert (ctx.verifier_blob() == g["verifier_blob"]).all()
+    ctx.free()
+
+
+def test_config1_dense128_plumbing(dev, oracle):
+    """BASELINE config 1: single Dense 128 -> 128, no lookups"""
+    import deep_prove_amd as dpa
+    mb = dpa.models.dense_128()
+    x = mb.input()
+    ctx, proof, out, oproof, oout = prove_both(dev, oracle, mb, x)
+    assert (out == oout).all() and (proof.size == oproof.size) and (proof == oproof).all()
+    dpa.verify(ctx.verifier_blob(), proof, x, out)
+    ctx.free()
+
+
+def test_proofs_are_deterministic_and_inputs_independent(dev):
+    """two proofs of the same input are byte identical; different inputs both verify against one context (replica mode)"""
+    import deep_prove_amd as dpa
+    mb = dpa.models.mlp(2, 32, config=33)
+    ctx = dpa.Context.generate(dev, mb.blob())
+    vb = ctx.verifier_blob()
+    pr = dpa.Prover(ctx)
+    x0, x1 = mb.input(1000), mb.input(1001)
+    p0, o0 = pr.prove(x0)
+    p0b, _ = pr.prove(x0)
+    p1, o1 = pr.prove(x1)
+    assert (p0 == p0b).all()
+    dpa.verify(vb, p0, x0, o0)
+    dpa.verify(vb, p1, x1, o1)
+    with pytest.raises(dpa.DeepProveError):
+        dpa.verify(vb, p0, x1, o0)  # proof bound to its input
+    bad = p1.copy()
+    bad[bad.size // 2] ^= np.uint64(1)
+    with pytest.raises(dpa.DeepProveError):
+        dpa.verify(vb, bad, x1, o1)
+    ctx.free()
+
+
+def test_config2_dense4m_full_size(dev):
+    """BASELINE config 2: Dense-4M (5 x 1024 MLP, 4.2 M parameters). Bit-exact vs the oracle through the committed
+    sha256 of the oracle's proof stream (tests/golden/dense4m_proof.json) + verifier acceptance at full size."""
+    import deep_prove_amd as dpa
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "dense4m_proof.json")))
+    mb = dpa.models.dense_4m()
+    x = mb.input(gold["input_index"])
+    ctx = dpa.Context.generate(dev, mb.blob())
+    proof, out = dpa.Prover(ctx).prove(x)
+    assert [int(v) for v in out] == gold["output"]
+    assert proof.size == gold["proof_words"]
+    assert hashlib.sha256(proof.tobytes()).hexdigest() == gold["sha256"]
+    dpa.verify(ctx.verifier_blob(), proof, x, out)
+    ctx.free()

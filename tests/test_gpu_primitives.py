@@ -1,0 +1,189 @@
+"""GPU parity tests (run with -m gpu on the MI355X): every device op reached through the C ABI is compared bit-exactly
+with the oracle on the same seeded inputs, and against the committed golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rand_base(rng, n):
+    return rng.integers(0, P, size=n, dtype=np.uint64)
+
+
+def rand_point(rng, k):
+    return [(int(rng.integers(0, P, dtype=np.uint64)), int(rng.integers(0, P, dtype=np.uint64))) for _ in range(k)]
+
+
+def test_native_library_is_loaded(dev):
+    import deep_prove_amd as dpa
+    assert os.path.exists(dpa.LIB_PATH)
+    assert "gfx950" in dev.name or "hip:" in dev.name, dev.name
+
+
+@pytest.mark.parametrize("k", [1, 4, 11, 16])
+def test_eq_table(dev, oracle, k):
+    import deep_prove_amd as dpa
+    rng = np.random.default_rng(k)
+    pt = rand_point(rng, k)
+    got = dpa.build_eq_x_r(dev, pt).to_numpy()
+    assert (got == oracle.eq_table(pt)).all()
+
+
+@pytest.mark.parametrize("nv,ext", [(1, False), (3, True), (10, False), (15, True), (18, False)])
+def test_mle_evaluate(dev, oracle, nv, ext):
+    import deep_prove_amd as dpa
+    rng = np.random.default_rng(100 + nv)
+    w = rand_base(rng, (2 if ext else 1) << nv)
+    m = dpa.Mle.from_ext(dev, w) if ext else dpa.Mle.from_base(dev, w)
+    pt = rand_point(rng, nv)
+    assert m.evaluate(pt) == oracle.mle_eval(w, ext, pt)
+    assert (m.to_numpy() == w).all()
+
+
+def test_fieldizer_and_fix_high_kat(dev, oracle):
+    import deep_prove_amd as dpa
+    # Fieldizer: negative -> p - |v|
+    v = np.array([-1, 0, 1, -127, 127, -(1 << 40), (1 << 40)], dtype=np.int64)
+    got = dpa.Mle.from_i64(dev, np.concatenate([v, [0]])).to_numpy()
+    assert got.tolist()[:7] == [P - 1, 0, 1, P - 127, 127, P - (1 << 40), 1 << 40]
+    # the reference's own KAT (multilinear_extensions/src/test.rs:46-82) through the device path
+    m = dpa.Mle.from_base(dev, np.array([13, 97, 11, 101, 7, 103, 5, 107], dtype=np.uint64))
+    r2 = m.fix_high_variables(4, 2, [(3, 0), (5, 0)]).to_numpy()
+    assert r2.tolist() == [P - 23, 0, 139, 0]
+    r1 = m.fix_high_variables(2, 4, [(5, 0)]).to_numpy()
+    assert r1.tolist() == [P - 17, 0, 127, 0, P - 19, 0, 131, 0]
+
+
+@pytest.mark.parametrize("rows,cols", [(2, 2), (4, 1024), (1024, 4), (256, 512), (1024, 1024)])
+def test_fix_high_matches_oracle(dev, oracle, rows, cols):
+    import deep_prove_amd as dpa
+    rng = np.random.default_rng(rows * 7 + cols)
+    w = rng.integers(-127, 128, size=rows * cols, dtype=np.int64)
+    m = dpa.Mle.from_i64(dev, w)
+    pt = rand_point(rng, rows.bit_length() - 1)
+    got = m.fix_high_variables(rows, cols, pt).to_numpy()
+    assert (got == oracle.fix_high(m.to_numpy(), rows, cols, pt)).all()
+
+
+SC_CASES = [
+    # (nv, [is_ext per table], [(coeff, [table idx])...])
+    (1, [False, False], [((1, 0), [0, 1])]),
+    (2, [True], [((3, 4), [0])]),
+    (7, [False, True, True], [((1, 0), [0, 1]), ((5, 9), [1, 2, 0]), ((2, 0), [2])]),
+    (12, [False, False, False], [((1, 0), [0, 1, 2])]),
+    (13, [True, True, True, True, True], [((1, 0), [0, 1, 4]), ((1, 0), [0, 3, 2]), ((7, 7), [0, 2, 4])]),  # logup layer shape
+    (10, [True, True, True], [((P - 1, 0), [0, 2]), ((P - 1, 0), [0, 1]), ((11, 13), [0, 1, 2])]),         # initial lookup layer shape
+    (16, [False, True], [((1, 0), [0, 1])]),
+]
+
+
+@pytest.mark.parametrize("case", range(len(SC_CASES)))
+def test_sumcheck_prove_parallel(dev, oracle, case):
+    import deep_prove_amd as dpa
+    nv, exts, terms = SC_CASES[case]
+    rng = np.random.default_rng(1000 + case)
+    raw = [rand_base(rng, (2 if e else 1) << nv) for e in exts]
+    mles = [dpa.Mle.from_ext(dev, w) if e else dpa.Mle.from_base(dev, w) for w, e in zip(raw, exts)]
+    vp = dpa.VirtualPolynomial(nv)
+    vp.tables = list(mles)  # keep the oracle's table order
+    vp.terms = [(c, ix) for c, ix in terms]
+    t = dpa.Transcript(b"test")
+    proof, finals = dpa.prove_parallel(dev, vp, t)
+    ot = oracle.transcript(b"test")
+    oproof, ofinals = oracle.sumcheck_prove(nv, raw, exts, terms, ot)
+    assert proof.size == oproof.size and (proof == oproof).all()
+    assert (finals == ofinals).all()
+    assert t.read_challenge() == ot.read_challenge()  # transcripts end in the same state
+
+
+def test_sumcheck_golden_vector(dev):
+    import deep_prove_amd as dpa
+    g = np.load(os.path.join(ROOT, "tests", "golden", "primitives.npz"))
+    a, b = dpa.Mle.from_base(dev, g["poly_base"]), dpa.Mle.from_ext(dev, g["poly_ext"])
+    vp = dpa.VirtualPolynomial(10)
+    vp.add_mle_list([a, b])
+    proof, finals = dpa.prove_parallel(dev, vp, dpa.Transcript(b"test"))
+    assert (proof == g["sumcheck_proof"]).all() and (finals == g["sumcheck_finals"]).all()
+    pt = [tuple(int(x) for x in r) for r in g["point"]]
+    assert (dpa.build_eq_x_r(dev, pt).to_numpy() == g["eq_table"]).all()
+
+
+@pytest.mark.parametrize("nv,ncols,cpi,table", [(2, 2, 2, False), (6, 1, 1, False), (10, 2, 2, False), (10, 5, 1, False), (8, 2, 2, True), (8, 1, 1, True), (14, 2, 2, True)])
+def test_logup_batch_prove(dev, oracle, nv, ncols, cpi, table):
+    import deep_prove_amd as dpa
+    rng = np.random.default_rng(nv * 31 + ncols)
+    n = 1 << nv
+    cols = [rng.integers(0, 1 << 20, size=n, dtype=np.uint64) for _ in range(ncols)]
+    mult = rng.integers(0, 1000, size=n, dtype=np.uint64) if table else None
+    cc, csc = rand_point(rng, 1)[0], rand_point(rng, 1)[0]
+    t = dpa.Transcript(b"test")
+    got = dpa.logup_batch_prove(dev, [dpa.Mle.from_base(dev, c) for c in cols], cpi, cc, csc, t,
+                                dpa.Mle.from_base(dev, mult) if table else None)
+    ot = oracle.transcript(b"test")
+    exp = oracle.logup_prove(cols, cpi, cc, csc, ot, mult)
+    assert got.size == exp.size and (got == exp).all()
+    assert t.read_challenge() == ot.read_challenge()
+
+
+@pytest.mark.parametrize("nv,ext", [(1, False), (2, True), (5, False), (7, True), (8, False), (9, True), (12, False), (13, True), (16, False)])
+def test_pcs_commit_root(dev, oracle, nv, ext):
+    """Basefold::commit: Merkle root over the bit-reversed RS codeword (trivial commitments for <= 7 variables)"""
+    import deep_prove_amd as dpa
+    rng = np.random.default_rng(500 + nv)
+    w = rand_base(rng, (2 if ext else 1) << nv)
+    pcs = dpa.Basefold(dev, 1 << 16)
+    c = pcs.commit(dpa.Mle.from_ext(dev, w) if ext else dpa.Mle.from_base(dev, w))
+    assert c.root == oracle.pcs_commit_root(1 << 16, w, ext)
+
+
+def test_pcs_commit_golden_and_context_dependence(dev, oracle):
+    import deep_prove_amd as dpa
+    g = np.load(os.path.join(ROOT, "tests", "golden", "primitives.npz"))
+    pcs = dpa.Basefold(dev, 1 << 12)
+    assert pcs.commit(dpa.Mle.from_base(dev, g["poly_base"])).root == [int(x) for x in g["root_base"]]
+    assert pcs.commit(dpa.Mle.from_ext(dev, g["poly_ext"])).root == [int(x) for x in g["root_ext"]]
+    # the coset shift depends on the parameter size (rs.rs:494-499): a different max size gives a different commitment
+    pcs2 = dpa.Basefold(dev, 1 << 14)
+    r2 = pcs2.commit(dpa.Mle.from_base(dev, g["poly_base"])).root
+    assert r2 != [int(x) for x in g["root_base"]] and r2 == oracle.pcs_commit_root(1 << 14, g["poly_base"], False)
+
+
+def test_pcs_too_large_polynomial_is_rejected(dev):
+    import deep_prove_amd as dpa
+    pcs = dpa.Basefold(dev, 1 << 10)
+    with pytest.raises(dpa.DeepProveError):
+        pcs.commit(dpa.Mle.from_base(dev, np.zeros(1 << 11, dtype=np.uint64)))
+
+
+@pytest.mark.parametrize("shape", [[(10, False)], [(12, False), (10, False), (12, True), (9, False)], [(8, False), (8, True), (14, False), (11, True), (14, False)]])
+def test_pcs_batch_open_and_verify(dev, oracle, shape):
+    import deep_prove_amd as dpa
+    rng = np.random.default_rng(len(shape) * 17 + shape[0][0])
+    maxsize = 1 << 14
+    pcs = dpa.Basefold(dev, maxsize)
+    raws = [rand_base(rng, (2 if e else 1) << nv) for nv, e in shape]
+    mles = [dpa.Mle.from_ext(dev, w) if e else dpa.Mle.from_base(dev, w) for w, (nv, e) in zip(raws, shape)]
+    comms = [pcs.commit(m) for m in mles]
+    points = [rand_point(rng, nv) for nv, _ in shape]
+    evals = [m.evaluate(p) for m, p in zip(mles, points)]
+    t = dpa.Transcript(b"test")
+    proof = pcs.batch_open(comms, points, evals, t)
+    ot = oracle.transcript(b"test")
+    exp = oracle.pcs_batch_open(maxsize, raws, [e for _, e in shape], points, evals, ot)
+    assert proof.size == exp.size and (proof == exp).all()
+    assert t.read_challenge() == ot.read_challenge()
+    roots = [c.root for c in comms]
+    args = (maxsize, roots, [nv for nv, _ in shape], [not e for _, e in shape], points, evals)
+    dpa.Basefold.batch_verify(*args, proof, dpa.Transcript(b"test"))
+    bad = proof.copy()
+    bad[7] ^= np.uint64(1)
+    with pytest.raises(dpa.DeepProveError):
+        dpa.Basefold.batch_verify(*args, bad, dpa.Transcript(b"test"))
+    wrong = list(evals)
+    wrong[0] = ((evals[0][0] + 1) % P, evals[0][1])
+    with pytest.raises(dpa.DeepProveError):
+        dpa.Basefold.batch_verify(maxsize, roots, [nv for nv, _ in shape], [not e for _, e in shape], points, wrong, proof, dpa.Transcript(b"test"))

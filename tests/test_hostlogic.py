@@ -1,0 +1,25 @@
+"""Host logic of the product (transcript order, claim routing, proof assembly, verifier) checked WITHOUT a GPU: the
+orchestrator of deep-prove_amd/csrc runs over the CPU test double of tests/support/cpu_dev.hpp and is byte-compared with
+the oracle; the product verifier must accept both proofs and reject tampered ones."""
+import subprocess
+
+import pytest
+
+
+def run(binary, *args):
+    return subprocess.run([binary, *map(str, args)], capture_output=True, text=True, timeout=600)
+
+
+@pytest.mark.parametrize("width,seed", [(8, 5), (16, 7), (64, 1)])
+def test_proof_stream_identical_to_oracle_and_accepted(hostlogic_bin, width, seed):
+    r = run(hostlogic_bin, width, seed)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical=1" in r.stdout
+    assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
+
+
+@pytest.mark.parametrize("offset", [3, -1000, 777, -20000])
+def test_tampered_proof_rejected(hostlogic_bin, offset):
+    r = run(hostlogic_bin, 16, 2, offset)
+    assert "verify(oracle,tampered): REJECT" in r.stdout, r.stdout
+    assert "verify(product): ACCEPT" in r.stdout
