@@ -58,6 +58,9 @@ struct DevCommit {
   bool trivial() const { return nv <= 7; }
   size_t codeword_size() const { return tree.nleaves; }
 };
+// fractional-sum tree of one logup instance (zkml/src/lookup/logup_gkr/circuit.rs): layer j has length n >> j;
+// num[0] is null (lookup: all numerators are -1) or the multiplicity column (table)
+struct LogupCircuitDev { std::vector<DBuf> num, den; };
 struct QueryDesc {  // one (query, tree) pair of the Basefold query phase (K14)
   const DevTree* tree;
   size_t p0;  // even index of the opened leaf pair
@@ -93,9 +96,38 @@ class Dev {
   // ---- logup-GKR (K13)
   virtual void logup_den(const DBuf& out, const DBuf* cols, int ncols, Ext c, Ext chi) = 0;
   virtual void logup_layer(const DBuf& num_in, const DBuf& den_in, const DBuf& num_out, const DBuf& den_out) = 0;
+  // all layers of `ninst` instances (columns [i*cpi, (i+1)*cpi) each) and their 4 output values [n0,n1,d0,d1];
+  // devices fuse this into one launch for small tables, the default composes logup_den / logup_layer
+  virtual void logup_build(const DBuf* cols, int cpi, int ninst, const DBuf& mult, Ext c, Ext chi,
+                           std::vector<LogupCircuitDev>& circuits, std::vector<Ext>& outputs) {
+    size_t n = cols[0].n;
+    circuits.clear(); outputs.clear();
+    for (int s = 0; s < ninst; s++) {
+      LogupCircuitDev cd;
+      DBuf den0 = alloc(n, true);
+      logup_den(den0, cols + (size_t)s * cpi, cpi, c, chi);
+      cd.den.push_back(den0);
+      cd.num.push_back(mult);
+      for (size_t len = n; len > 2; len >>= 1) {
+        DBuf nn = alloc(len / 2, true), dn = alloc(len / 2, true);
+        logup_layer(cd.num.back(), cd.den.back(), nn, dn);
+        cd.num.push_back(nn); cd.den.push_back(dn);
+      }
+      u64 w[8];
+      download(cd.num.back(), w); download(cd.den.back(), w + 4);
+      for (int k = 0; k < 4; k++) outputs.push_back(ex(w[2 * k], w[2 * k + 1]));
+      circuits.push_back(cd);
+    }
+  }
   // ---- Basefold (K5-K12, K14)
   virtual void pcs_init(unsigned full_message_size_log) = 0;
   virtual DevCommit commit(const DBuf& evals, bool persistent) = 0;
+  // many commitments at once (same results as commit() on each); devices batch equal-size polynomials
+  virtual std::vector<DevCommit> commit_many(const std::vector<DBuf>& evals, bool persistent) {
+    std::vector<DevCommit> out;
+    for (const DBuf& e : evals) out.push_back(commit(e, persistent));
+    return out;
+  }
   virtual void free_commit(DevCommit& c) = 0;
   virtual DevTree merkle_ext(const DBuf& leaves) = 0;
   // classic sumcheck round (K12): fold every (f_i, eq_i) of length > 1 with r (if given), then

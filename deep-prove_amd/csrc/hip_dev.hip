@@ -12,6 +12,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <vector>
 #include <string>
 
@@ -231,6 +233,50 @@ __global__ void k_logup_layer(const void* num, int num_mode, const Ext* den, Ext
   }
 }
 
+struct LogupTreeDesc { const u64* col[8]; int ncols; int num_mode; const void* num0; Ext* den_all; Ext* num_all; };
+// K13 fused: denominators and every layer of the fractional-sum tree of one instance per workgroup (small tables).
+// den_all: layer j at offset 2n - (2n >> j) (lengths n, n/2, .., 2); num_all: layer j >= 1 at offset n - (2n >> j).
+// out[4*inst..] = [num_last[0], num_last[1], den_last[0], den_last[1]].
+__global__ void __launch_bounds__(1024) k_logup_tree(const LogupTreeDesc* d, size_t n, Ext c, Ext chi, Ext* out) {
+  LogupTreeDesc t = d[blockIdx.x];
+  int tid = threadIdx.x, nt = blockDim.x;
+  Ext* den = t.den_all;
+  for (size_t i = tid; i < n; i += nt) {
+    Ext acc = c, pw = ex_one();
+    for (int j = 0; j < t.ncols; j++) { acc = ex_add(acc, ex_mul_base(pw, t.col[j][i])); pw = ex_mul(pw, chi); }
+    den[i] = acc;
+  }
+  __syncthreads();
+  const void* num = t.num0;
+  int mode = t.num_mode;
+  size_t len = n, doff = 0, noff = 0;
+  Ext* num_out = t.num_all;
+  while (len > 2) {
+    size_t half = len / 2;
+    Ext* dcur = den + doff;
+    Ext* dnext = den + doff + len;
+    for (size_t i = tid; i < half; i += nt) {
+      Ext d1 = dcur[i], d2 = dcur[i + half], nn;
+      if (mode == 0) nn = ex_neg(ex_add(d1, d2));
+      else if (mode == 1) { const u64* p = (const u64*)num; nn = ex_add(ex_mul_base(d2, p[i]), ex_mul_base(d1, p[i + half])); }
+      else { const Ext* p = (const Ext*)num; nn = ex_add(ex_mul(p[i], d2), ex_mul(d1, p[i + half])); }
+      num_out[noff + i] = nn;
+      dnext[i] = ex_mul(d1, d2);
+    }
+    __syncthreads();
+    num = (const void*)(num_out + noff); mode = 2;
+    doff += len; noff += half; len = half;
+  }
+  if (tid < 4) {
+    // len == 2 here: the last layer
+    const Ext* nl = (const Ext*)num; const Ext* dl = den + doff;
+    Ext v;
+    if (tid < 2) { if (mode == 0) v = ex_neg(ex_one()); else if (mode == 1) v = ex_base(((const u64*)num)[tid]); else v = nl[tid]; }
+    else v = dl[tid - 2];
+    out[4 * blockIdx.x + tid] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ RS code / NTT (K5-K7)
 template <bool EXT>
 __global__ void k_mobius_stage(void* data, size_t n, unsigned lg_half) {
@@ -403,6 +449,510 @@ __global__ void k_query_gather(const GatherDesc* d, size_t nd, u64* out) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ lane-parallel Poseidon2
+// One permutation spread over 8 adjacent lanes (lane i holds state[i]): used where there are too few hashes to fill
+// the machine with one-hash-per-lane (the top layers of every Merkle tree), cutting the serial latency of a compress
+// from 2 x ~520 dependent multiplications to 2 x ~100.
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+  int lo = __shfl((int)(u32)v, src, 64);
+  int hi = __shfl((int)(u32)(v >> 32), src, 64);
+  return ((u64)(u32)hi << 32) | (u64)(u32)lo;
+}
+// DPP cross-lane moves (no LDS crossbar round trip): quad permutes and the 8-lane half-row mirror
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_u64(u64 v) {
+  int lo = __builtin_amdgcn_update_dpp(0, (int)(u32)v, CTRL, 0xF, 0xF, false);
+  int hi = __builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), CTRL, 0xF, 0xF, false);
+  return ((u64)(u32)hi << 32) | (u64)(u32)lo;
+}
+constexpr int DPP_QUAD_ROT1 = 0x39;     // quad_perm [1,2,3,0]: lane j reads j+1 (mod 4)
+constexpr int DPP_QUAD_ROT2 = 0x4E;     // quad_perm [2,3,0,1]: lane j reads j+2 == j^2
+constexpr int DPP_QUAD_ROT3 = 0x93;     // quad_perm [3,0,1,2]: lane j reads j+3
+constexpr int DPP_QUAD_XOR1 = 0xB1;     // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_REV = 0x1B;      // quad_perm [3,2,1,0]
+constexpr int DPP_HALF_MIRROR = 0x141;  // row_half_mirror: lane i reads 7-i within its group of 8
+__device__ __forceinline__ u64 p2l_mds_light(u64 s, int lane) {
+  (void)lane;
+  u64 b = dpp_u64<DPP_QUAD_ROT1>(s), c = dpp_u64<DPP_QUAD_ROT2>(s), d = dpp_u64<DPP_QUAD_ROT3>(s);
+  u64 t = gl_add(gl_add(gl_add(gl_add(s, b), gl_add(c, d)), s), gl_dbl(b));  // row j of circ(2,3,1,1)
+  u64 o = dpp_u64<DPP_QUAD_REV>(dpp_u64<DPP_HALF_MIRROR>(t));                // lane i reads i ^ 4
+  return gl_add(gl_dbl(t), o);
+}
+__device__ __forceinline__ u64 p2l_permute(u64 s, int lane) {
+  int i = lane & 7;
+  s = p2l_mds_light(s, lane);
+  for (int r = 0; r < 4; r++) { s = p2_sbox(gl_add(s, c_rc[r * 8 + i])); s = p2l_mds_light(s, lane); }
+  u64 diag = c_rc[86 + i];
+  for (int r = 0; r < 22; r++) {
+    if (i == 0) s = p2_sbox(gl_add(s, c_rc[32 + r]));
+    u64 sum = s;
+    sum = gl_add(sum, dpp_u64<DPP_QUAD_XOR1>(sum));
+    sum = gl_add(sum, dpp_u64<DPP_QUAD_ROT2>(sum));
+    sum = gl_add(sum, dpp_u64<DPP_HALF_MIRROR>(sum));  // every lane of a quad holds the quad sum: any lane of the other quad will do
+    s = gl_add(gl_mul(s, diag), sum);
+  }
+  for (int r = 0; r < 4; r++) { s = p2_sbox(gl_add(s, c_rc[54 + r * 8 + i])); s = p2l_mds_light(s, lane); }
+  return s;
+}
+// in: 8 words (two digests), out: 4 words; executed by the 8 lanes of one group together
+__device__ __forceinline__ void p2l_compress(const u64* in, u64* out, int lane) {
+  int i = lane & 7;
+  u64 s = i < 4 ? in[i] : 0;
+  s = p2l_permute(s, lane);
+  if (i < 4) s = in[4 + i];
+  s = p2l_permute(s, lane);
+  if (i < 4) out[3 - i] = s;
+}
+// one Merkle layer with 8 lanes per node: for layers too narrow to hide the latency of a one-lane compress
+__global__ void __launch_bounds__(1024) k_merkle_layer_lp(const u64* in, u64* out, size_t cnt) {
+  size_t g = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 3;
+  size_t stride = ((size_t)gridDim.x * blockDim.x) >> 3;
+  for (; g < cnt; g += stride) p2l_compress(in + 8 * g, out + 4 * g, threadIdx.x & 63);
+}
+struct TailDesc { u64* nodes; size_t off; size_t cnt; };
+// All Merkle layers above an already computed layer of `cnt` (<= 2048) digests, one workgroup per tree, no relaunch
+// between layers. Wide layers hash one node per lane, narrow ones use the 8-lane permutation. roots[4*tree..] = root.
+__global__ void __launch_bounds__(1024) k_merkle_tail(const TailDesc* d, u64* roots) {
+  TailDesc t = d[blockIdx.x];
+  u64* nd = t.nodes;
+  size_t off = t.off, cnt = t.cnt;
+  int tid = threadIdx.x;
+  while (cnt > 1) {
+    size_t next = cnt / 2;
+    const u64* in = nd + 4 * off;
+    u64* out = nd + 4 * (off + cnt);
+    if (next > blockDim.x) {  // very wide layer: one node per lane; otherwise 8 lanes per node (the DPP permutation is ~8x lower latency)
+      for (size_t i = tid; i < next; i += blockDim.x) {
+        u64 o[4];
+        poseidon2_compress(in + 8 * i, in + 8 * i + 4, o, c_rc);
+        out[4 * i] = o[0]; out[4 * i + 1] = o[1]; out[4 * i + 2] = o[2]; out[4 * i + 3] = o[3];
+      }
+    } else {
+      for (size_t g = tid >> 3; g < next; g += (blockDim.x >> 3)) p2l_compress(in + 8 * g, out + 4 * g, tid & 63);
+    }
+    __syncthreads();
+    off += cnt; cnt = next;
+  }
+  if (tid < 4) roots[4 * blockIdx.x + tid] = nd[4 * off + tid];
+}
+struct SmallCommitDesc { const void* evals; void* cw; void* bh; u64* nodes; };
+// layer 0 of many equally sized trees: blockIdx.y = tree
+template <bool EXT>
+__global__ void k_merkle_leaves_many(const SmallCommitDesc* d, size_t npairs) {
+  const void* leaves = d[blockIdx.y].cw;
+  u64* nodes = d[blockIdx.y].nodes;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npairs; i += (size_t)gridDim.x * blockDim.x) {
+    u64 d0, d1, d2, d3;
+    if (EXT) { Ext a = ((const Ext*)leaves)[2 * i], b = ((const Ext*)leaves)[2 * i + 1]; d0 = a.c0; d1 = a.c1; d2 = b.c0; d3 = b.c1; }
+    else { d0 = ((const u64*)leaves)[2 * i]; d1 = ((const u64*)leaves)[2 * i + 1]; d2 = 0; d3 = 0; }
+    u64* o = nodes + 4 * i;
+    o[0] = d0; o[1] = d1; o[2] = d2; o[3] = d3;
+  }
+}
+template <bool EXT> struct ElemOps;
+template <> struct ElemOps<false> {
+  typedef u64 T;
+  static __device__ __forceinline__ T sub(T a, T b) { return gl_sub(a, b); }
+  static __device__ __forceinline__ T add(T a, T b) { return gl_add(a, b); }
+  static __device__ __forceinline__ T mulb(T a, u64 b) { return gl_mul(a, b); }
+};
+template <> struct ElemOps<true> {
+  typedef Ext T;
+  static __device__ __forceinline__ T sub(T a, T b) { return ex_sub(a, b); }
+  static __device__ __forceinline__ T add(T a, T b) { return ex_add(a, b); }
+  static __device__ __forceinline__ T mulb(T a, u64 b) { return ex_mul_base(a, b); }
+};
+// K5+K6+K7 for a small polynomial entirely in LDS: evaluations -> coefficients (Moebius), coset scale, zero-pad,
+// radix-2 DIT NTT on 2n points, bit-reversed store; also the bit-reversed copy of the evaluations. One workgroup per
+// polynomial (blockIdx.x), dynamic LDS = 3n elements.
+template <bool EXT>
+__global__ void __launch_bounds__(256) k_commit_small(const SmallCommitDesc* d, unsigned nv, unsigned L, const u64* tw, const u64* pow7) {
+  typedef typename ElemOps<EXT>::T T;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  T* A = (T*)lds_raw;  // n coefficients
+  size_t n = size_t(1) << nv, N = 2 * n;
+  T* Bf = A + n;       // 2n NTT buffer
+  SmallCommitDesc pd = d[blockIdx.x];
+  const T* ev = (const T*)pd.evals;
+  T* bh = (T*)pd.bh;
+  T* cw = (T*)pd.cw;
+  int tid = threadIdx.x, nt = blockDim.x;
+  for (size_t i = tid; i < n; i += nt) {
+    T v = ev[i];
+    A[i] = v;
+    bh[__brev((unsigned)i) >> (32 - nv)] = v;
+  }
+  __syncthreads();
+  for (unsigned s = 0; s < nv; s++) {
+    size_t half = size_t(1) << s;
+    for (size_t b = tid; b < n / 2; b += nt) {
+      size_t lo = ((b >> s) << (s + 1)) | (b & (half - 1));
+      A[lo + half] = ElemOps<EXT>::sub(A[lo + half], A[lo]);
+    }
+    __syncthreads();
+  }
+  for (size_t i = tid; i < n; i += nt) {
+    size_t j = __brev((unsigned)i) >> (32 - nv);
+    T v = ElemOps<EXT>::mulb(A[i], pow7[j << (L - nv)]);
+    Bf[2 * i] = v; Bf[2 * i + 1] = v;
+  }
+  __syncthreads();
+  for (unsigned s = 1; s <= nv; s++) {
+    size_t half = size_t(1) << s;
+    for (size_t b = tid; b < n; b += nt) {
+      size_t j = b & (half - 1);
+      size_t lo = ((b >> s) << (s + 1)) | j;
+      T t = ElemOps<EXT>::mulb(Bf[lo + half], tw[j << (L - s)]), u = Bf[lo];
+      Bf[lo] = ElemOps<EXT>::add(u, t);
+      Bf[lo + half] = ElemOps<EXT>::sub(u, t);
+    }
+    __syncthreads();
+  }
+  for (size_t o = tid; o < N; o += nt) cw[o] = Bf[__brev((unsigned)o) >> (32 - (nv + 1))];
+}
+
+// ------------------------------------------------------------------------------------------------ single-launch sumcheck round
+struct ScSmallArgs {
+  const void* in[MAX_TABS]; Ext* out[MAX_TABS]; int in_ext[MAX_TABS];
+  int k[MAX_TERMS]; int t[MAX_TERMS][3];
+  int ntabs, nterms, has_r; size_t n_after; Ext r;
+};
+__device__ __forceinline__ Ext block_reduce_ext_n(Ext v, Ext* sm) {
+  v = wave_reduce_ext(v);
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sm[w] = v;
+  __syncthreads();
+  Ext r = ex_zero();
+  if (threadIdx.x == 0) { r = sm[0]; for (int i = 1; i < (int)(blockDim.x >> 6); i++) r = ex_add(r, sm[i]); }
+  return r;
+}
+// K1 + K3 + final reduction in ONE workgroup for small tables: fold with r (if any), then every term's round sums.
+// Terms are spread over the waves of the block (a term with many pairs is split over several waves), so the only
+// block-wide barriers are the one after the fold and the one before the final combine; wave 0 then writes
+// result[term*4 + t] straight into host-mapped memory and releases `flag = seq`.
+__global__ void __launch_bounds__(1024) k_sc_small(ScSmallArgs a, Ext* result, unsigned long long* flag, unsigned long long seq) {
+  __shared__ Ext part[64 * 4];  // [slot][t], slot = term * wpt + sub  (<= 64 slots)
+  int tid = threadIdx.x, nt = blockDim.x;
+  size_t n = a.n_after;
+  if (a.has_r) {
+    for (int t = 0; t < a.ntabs; t++) {
+      Ext* o = a.out[t];
+      if (a.in_ext[t]) { const Ext* p = (const Ext*)a.in[t]; for (size_t i = tid; i < n; i += nt) o[i] = ex_lerp(p[2 * i], p[2 * i + 1], a.r); }
+      else { const u64* p = (const u64*)a.in[t]; for (size_t i = tid; i < n; i += nt) o[i] = ex_lerp_base(p[2 * i], p[2 * i + 1], a.r); }
+    }
+    __syncthreads();
+  }
+  size_t npairs = n / 2;
+  int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
+  int wpt = a.nterms >= W ? 1 : W / a.nterms;  // waves per term
+  for (int term = wave / wpt; term < a.nterms; term += (wpt == 1 ? W : a.nterms + W)) {
+    int sub = wave % wpt;
+    int k = a.k[term];
+    int i0 = a.t[term][0], i1 = a.t[term][k > 1 ? 1 : 0], i2 = a.t[term][k > 2 ? 2 : 0];
+    const void* p0 = a.has_r ? (const void*)a.out[i0] : a.in[i0]; bool e0 = a.has_r ? true : a.in_ext[i0];
+    const void* p1 = a.has_r ? (const void*)a.out[i1] : a.in[i1]; bool e1 = a.has_r ? true : a.in_ext[i1];
+    const void* p2 = a.has_r ? (const void*)a.out[i2] : a.in[i2]; bool e2 = a.has_r ? true : a.in_ext[i2];
+    Ext acc0 = ex_zero(), acc1 = ex_zero(), acc2 = ex_zero(), acc3 = ex_zero();
+    for (size_t b = (size_t)sub * 64 + lane; b < npairs; b += (size_t)wpt * 64) {
+      Ext a0 = ld_elem(p0, e0, 2 * b), b0 = ld_elem(p0, e0, 2 * b + 1);
+      if (k == 1) { acc0 = ex_add(acc0, a0); acc1 = ex_add(acc1, b0); }
+      else if (k == 2) {
+        Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
+        Ext c0 = ex_sub(ex_dbl(b0), a0), c1 = ex_sub(ex_dbl(b1), a1);
+        acc0 = ex_add(acc0, ex_mul(a0, a1)); acc1 = ex_add(acc1, ex_mul(b0, b1)); acc2 = ex_add(acc2, ex_mul(c0, c1));
+      } else {
+        Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
+        Ext a2 = ld_elem(p2, e2, 2 * b), b2 = ld_elem(p2, e2, 2 * b + 1);
+        Ext d0 = ex_sub(b0, a0), d1 = ex_sub(b1, a1), d2 = ex_sub(b2, a2);
+        Ext c0 = ex_add(b0, d0), c1 = ex_add(b1, d1), c2 = ex_add(b2, d2);
+        Ext f0 = ex_add(c0, d0), f1 = ex_add(c1, d1), f2 = ex_add(c2, d2);
+        acc0 = ex_add(acc0, ex_mul(ex_mul(a0, a1), a2)); acc1 = ex_add(acc1, ex_mul(ex_mul(b0, b1), b2));
+        acc2 = ex_add(acc2, ex_mul(ex_mul(c0, c1), c2)); acc3 = ex_add(acc3, ex_mul(ex_mul(f0, f1), f2));
+      }
+    }
+    acc0 = wave_reduce_ext(acc0); acc1 = wave_reduce_ext(acc1);
+    if (k >= 2) acc2 = wave_reduce_ext(acc2);
+    if (k >= 3) acc3 = wave_reduce_ext(acc3);
+    if (lane == 0) {
+      Ext* o = part + (size_t)(term * wpt + sub) * 4;
+      o[0] = acc0; o[1] = acc1; o[2] = acc2; o[3] = acc3;
+    }
+    if (wpt > 1) break;  // with several waves per term every wave owns exactly one (term, sub)
+  }
+  __syncthreads();
+  if (wave == 0) {
+    for (int e = lane; e < a.nterms * 4; e += 64) {
+      int term = e >> 2, t = e & 3;
+      Ext v = ex_zero();
+      if (wpt == 1) {
+        // terms beyond the first W were accumulated by the same wave in later loop iterations: each has its own slot
+        v = part[(size_t)term * 4 + t];
+      } else {
+        for (int sb = 0; sb < wpt; sb++) v = ex_add(v, part[(size_t)(term * wpt + sb) * 4 + t]);
+      }
+      result[e] = v;
+    }
+    if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// ------------------------------------------------------------------------------------------------ persistent sumcheck
+// A whole (tail of a) sumcheck in ONE launch of ONE workgroup: per round the kernel publishes the raw term sums to
+// host-mapped memory, the host runs the Fiat-Shamir sponge and posts the challenge into a host-mapped mailbox which
+// the kernel polls; then the kernel folds every table and goes on. No kernel launch, no stream synchronisation and no
+// memcpy on the per-round critical path — only two PCIe hops. Ends by publishing the final evaluation of every table.
+__device__ void sc_publish_fwd(Ext* result, const Ext* part, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane);
+__device__ void sc_wait_challenge_fwd(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal);
+struct ScPersistArgs {
+  const void* in[MAX_TABS]; int in_ext[MAX_TABS];
+  Ext* bufA[MAX_TABS]; Ext* bufB[MAX_TABS];
+  int k[MAX_TERMS]; int t[MAX_TERMS][3];
+  int ntabs, nterms, has_r0; size_t n0; Ext r0;
+};
+__device__ __forceinline__ void sc_fold_all(const ScPersistArgs& a, const void* const* cur, const int* cur_ext, Ext* const* dst, size_t n_after, Ext r) {
+  int tid = threadIdx.x, nt = blockDim.x;
+  for (int t = 0; t < a.ntabs; t++) {
+    Ext* o = dst[t];
+    if (cur_ext[t]) { const Ext* p = (const Ext*)cur[t]; for (size_t i = tid; i < n_after; i += nt) o[i] = ex_lerp(p[2 * i], p[2 * i + 1], r); }
+    else { const u64* p = (const u64*)cur[t]; for (size_t i = tid; i < n_after; i += nt) o[i] = ex_lerp_base(p[2 * i], p[2 * i + 1], r); }
+  }
+}
+__global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* result, unsigned long long* flag, const unsigned long long* mailbox, unsigned long long seq0) {
+  __shared__ Ext part[64 * 4];
+  __shared__ unsigned long long chal[3];
+  __shared__ const void* cur[MAX_TABS];
+  __shared__ int cur_ext[MAX_TABS];
+  __shared__ Ext* dstA[MAX_TABS];
+  __shared__ Ext* dstB[MAX_TABS];
+  int tid = threadIdx.x, nt = blockDim.x;
+  int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
+  if (tid < a.ntabs) { cur[tid] = a.in[tid]; cur_ext[tid] = a.in_ext[tid]; dstA[tid] = a.bufA[tid]; dstB[tid] = a.bufB[tid]; }
+  __syncthreads();
+  size_t n = a.n0;
+  unsigned long long seq = seq0;
+  bool useA = true;
+  if (a.has_r0) {
+    sc_fold_all(a, cur, cur_ext, dstA, n / 2, a.r0);
+    __syncthreads();
+    if (tid < a.ntabs) { cur[tid] = dstA[tid]; cur_ext[tid] = 1; }
+    __syncthreads();
+    n /= 2; useA = false;
+  }
+  int wpt = a.nterms >= W ? 1 : W / a.nterms;
+  for (;;) {
+    size_t npairs = n / 2;
+    for (int term = wave / wpt; term < a.nterms; term += (wpt == 1 ? W : a.nterms + W)) {
+      int sub = wave % wpt;
+      int k = a.k[term];
+      int i0 = a.t[term][0], i1 = a.t[term][k > 1 ? 1 : 0], i2 = a.t[term][k > 2 ? 2 : 0];
+      const void* p0 = cur[i0]; bool e0 = cur_ext[i0];
+      const void* p1 = cur[i1]; bool e1 = cur_ext[i1];
+      const void* p2 = cur[i2]; bool e2 = cur_ext[i2];
+      Ext acc0 = ex_zero(), acc1 = ex_zero(), acc2 = ex_zero(), acc3 = ex_zero();
+      for (size_t b = (size_t)sub * 64 + lane; b < npairs; b += (size_t)wpt * 64) {
+        Ext a0 = ld_elem(p0, e0, 2 * b), b0 = ld_elem(p0, e0, 2 * b + 1);
+        if (k == 1) { acc0 = ex_add(acc0, a0); acc1 = ex_add(acc1, b0); }
+        else if (k == 2) {
+          Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
+          Ext c0 = ex_sub(ex_dbl(b0), a0), c1 = ex_sub(ex_dbl(b1), a1);
+          acc0 = ex_add(acc0, ex_mul(a0, a1)); acc1 = ex_add(acc1, ex_mul(b0, b1)); acc2 = ex_add(acc2, ex_mul(c0, c1));
+        } else {
+          Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
+          Ext a2 = ld_elem(p2, e2, 2 * b), b2 = ld_elem(p2, e2, 2 * b + 1);
+          Ext d0 = ex_sub(b0, a0), d1 = ex_sub(b1, a1), d2 = ex_sub(b2, a2);
+          Ext c0 = ex_add(b0, d0), c1 = ex_add(b1, d1), c2 = ex_add(b2, d2);
+          Ext f0 = ex_add(c0, d0), f1 = ex_add(c1, d1), f2 = ex_add(c2, d2);
+          acc0 = ex_add(acc0, ex_mul(ex_mul(a0, a1), a2)); acc1 = ex_add(acc1, ex_mul(ex_mul(b0, b1), b2));
+          acc2 = ex_add(acc2, ex_mul(ex_mul(c0, c1), c2)); acc3 = ex_add(acc3, ex_mul(ex_mul(f0, f1), f2));
+        }
+      }
+      acc0 = wave_reduce_ext(acc0); acc1 = wave_reduce_ext(acc1);
+      if (k >= 2) acc2 = wave_reduce_ext(acc2);
+      if (k >= 3) acc3 = wave_reduce_ext(acc3);
+      if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * 4; o[0] = acc0; o[1] = acc1; o[2] = acc2; o[3] = acc3; }
+      if (wpt > 1) break;
+    }
+    __syncthreads();
+    ++seq;
+    if (wave == 0) { sc_publish_fwd(result, part, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge_fwd(mailbox, seq, chal); }
+    __syncthreads();
+    if (chal[0] == 0) {  // host never answered: publish an abort marker and leave
+      if (tid == 0) __hip_atomic_store(flag, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    Ext r = ex(chal[1], chal[2]);
+    Ext* const* dst = useA ? dstA : dstB;
+    sc_fold_all(a, cur, cur_ext, dst, n / 2, r);
+    __syncthreads();
+    if (tid < a.ntabs) { cur[tid] = dst[tid]; cur_ext[tid] = 1; }
+    __syncthreads();
+    n /= 2; useA = !useA;
+    if (n == 1) {
+      ++seq;
+      if (wave == 0) {
+        for (int e = lane; e < a.ntabs; e += 64) result[e] = ((const Ext*)cur[e])[0];
+        if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+  }
+}
+
+// Same protocol as k_sc_persist, but the tables live in LDS after the first fold (bit-reversed index order, so a fold
+// pairs positions q and q + m/2 and is done in place with no hazards): after the first round no table byte touches
+// global memory again. Dynamic LDS = ntabs * (n0/2) extension elements.
+__device__ __forceinline__ void sc_publish(Ext* result, const Ext* part, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane) {
+  for (int e = lane; e < nterms * 4; e += 64) {
+    int term = e >> 2, t = e & 3;
+    Ext v = ex_zero();
+    if (wpt == 1) v = part[(size_t)term * 4 + t];
+    else for (int sb = 0; sb < wpt; sb++) v = ex_add(v, part[(size_t)(term * wpt + sb) * 4 + t]);
+    result[e] = v;
+  }
+  // the payload stores and the releasing flag store come from this one wave
+  if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// lane 0 of wave 0: poll the host mailbox for `seq` (bounded), leave {ok, c0, c1} in chal[]
+__device__ __forceinline__ void sc_wait_challenge(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal) {
+  unsigned long long got = 0;
+  for (unsigned spin = 0; spin < (1u << 22); spin++) {
+    got = __hip_atomic_load(mailbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (got == seq) break;
+    __builtin_amdgcn_s_sleep(4);
+  }
+  chal[0] = got == seq ? 1 : 0;
+  chal[1] = __hip_atomic_load(mailbox + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  chal[2] = __hip_atomic_load(mailbox + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ void sc_publish_fwd(Ext* result, const Ext* part, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane) { sc_publish(result, part, nterms, wpt, flag, seq, lane); }
+__device__ void sc_wait_challenge_fwd(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal) { sc_wait_challenge(mailbox, seq, chal); }
+__global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* result, unsigned long long* flag, const unsigned long long* mailbox, unsigned long long seq0) {
+  extern __shared__ __align__(16) unsigned char lds_dyn[];
+  Ext* L = (Ext*)lds_dyn;
+  __shared__ Ext part[64 * 4];
+  __shared__ unsigned long long chal[3];
+  int tid = threadIdx.x, nt = blockDim.x;
+  int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
+  int wpt = a.nterms >= W ? 1 : W / a.nterms;
+  unsigned long long seq = seq0;
+  size_t first = a.n0 / 2;
+  unsigned lgf = 0; while ((size_t(1) << lgf) < first) lgf++;
+  Ext r = a.r0;
+  if (!a.has_r0) {
+    // round on the tables as they sit in global memory
+    size_t npairs = a.n0 / 2;
+    for (int term = wave / wpt; term < a.nterms; term += (wpt == 1 ? W : a.nterms + W)) {
+      int sub = wave % wpt;
+      int k = a.k[term];
+      int i0 = a.t[term][0], i1 = a.t[term][k > 1 ? 1 : 0], i2 = a.t[term][k > 2 ? 2 : 0];
+      const void* p0 = a.in[i0]; bool e0 = a.in_ext[i0];
+      const void* p1 = a.in[i1]; bool e1 = a.in_ext[i1];
+      const void* p2 = a.in[i2]; bool e2 = a.in_ext[i2];
+      Ext acc0 = ex_zero(), acc1 = ex_zero(), acc2 = ex_zero(), acc3 = ex_zero();
+      for (size_t b = (size_t)sub * 64 + lane; b < npairs; b += (size_t)wpt * 64) {
+        Ext a0 = ld_elem(p0, e0, 2 * b), b0 = ld_elem(p0, e0, 2 * b + 1);
+        if (k == 1) { acc0 = ex_add(acc0, a0); acc1 = ex_add(acc1, b0); }
+        else if (k == 2) {
+          Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
+          Ext c0 = ex_sub(ex_dbl(b0), a0), c1 = ex_sub(ex_dbl(b1), a1);
+          acc0 = ex_add(acc0, ex_mul(a0, a1)); acc1 = ex_add(acc1, ex_mul(b0, b1)); acc2 = ex_add(acc2, ex_mul(c0, c1));
+        } else {
+          Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
+          Ext a2 = ld_elem(p2, e2, 2 * b), b2 = ld_elem(p2, e2, 2 * b + 1);
+          Ext d0 = ex_sub(b0, a0), d1 = ex_sub(b1, a1), d2 = ex_sub(b2, a2);
+          Ext c0 = ex_add(b0, d0), c1 = ex_add(b1, d1), c2 = ex_add(b2, d2);
+          Ext f0 = ex_add(c0, d0), f1 = ex_add(c1, d1), f2 = ex_add(c2, d2);
+          acc0 = ex_add(acc0, ex_mul(ex_mul(a0, a1), a2)); acc1 = ex_add(acc1, ex_mul(ex_mul(b0, b1), b2));
+          acc2 = ex_add(acc2, ex_mul(ex_mul(c0, c1), c2)); acc3 = ex_add(acc3, ex_mul(ex_mul(f0, f1), f2));
+        }
+      }
+      acc0 = wave_reduce_ext(acc0); acc1 = wave_reduce_ext(acc1);
+      if (k >= 2) acc2 = wave_reduce_ext(acc2);
+      if (k >= 3) acc3 = wave_reduce_ext(acc3);
+      if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * 4; o[0] = acc0; o[1] = acc1; o[2] = acc2; o[3] = acc3; }
+      if (wpt > 1) break;
+    }
+    __syncthreads();
+    ++seq;
+    if (wave == 0) { sc_publish(result, part, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge(mailbox, seq, chal); }
+    __syncthreads();
+    if (chal[0] == 0) { if (tid == 0) __hip_atomic_store(flag, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+    r = ex(chal[1], chal[2]);
+  }
+  // first fold: global -> LDS (bit-reversed positions)
+  for (size_t idx = tid; idx < (size_t)a.ntabs * first; idx += nt) {
+    int t = (int)(idx >> lgf); size_t i = idx & (first - 1);
+    Ext v = a.in_ext[t] ? ex_lerp(((const Ext*)a.in[t])[2 * i], ((const Ext*)a.in[t])[2 * i + 1], r)
+                        : ex_lerp_base(((const u64*)a.in[t])[2 * i], ((const u64*)a.in[t])[2 * i + 1], r);
+    size_t pos = lgf ? (__brev((unsigned)i) >> (32 - lgf)) : 0;
+    L[((size_t)t << lgf) + pos] = v;
+  }
+  __syncthreads();
+  size_t m = first;
+  for (;;) {
+    if (m == 1) {
+      ++seq;
+      if (wave == 0) {
+        for (int e = lane; e < a.ntabs; e += 64) result[e] = L[(size_t)e << lgf];
+        if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+    size_t h = m / 2;
+    for (int term = wave / wpt; term < a.nterms; term += (wpt == 1 ? W : a.nterms + W)) {
+      int sub = wave % wpt;
+      int k = a.k[term];
+      const Ext* p0 = L + ((size_t)a.t[term][0] << lgf);
+      const Ext* p1 = L + ((size_t)a.t[term][k > 1 ? 1 : 0] << lgf);
+      const Ext* p2 = L + ((size_t)a.t[term][k > 2 ? 2 : 0] << lgf);
+      Ext acc0 = ex_zero(), acc1 = ex_zero(), acc2 = ex_zero(), acc3 = ex_zero();
+      for (size_t q = (size_t)sub * 64 + lane; q < h; q += (size_t)wpt * 64) {
+        Ext a0 = p0[q], b0 = p0[q + h];
+        if (k == 1) { acc0 = ex_add(acc0, a0); acc1 = ex_add(acc1, b0); }
+        else if (k == 2) {
+          Ext a1 = p1[q], b1 = p1[q + h];
+          Ext c0 = ex_sub(ex_dbl(b0), a0), c1 = ex_sub(ex_dbl(b1), a1);
+          acc0 = ex_add(acc0, ex_mul(a0, a1)); acc1 = ex_add(acc1, ex_mul(b0, b1)); acc2 = ex_add(acc2, ex_mul(c0, c1));
+        } else {
+          Ext a1 = p1[q], b1 = p1[q + h], a2 = p2[q], b2 = p2[q + h];
+          Ext d0 = ex_sub(b0, a0), d1 = ex_sub(b1, a1), d2 = ex_sub(b2, a2);
+          Ext c0 = ex_add(b0, d0), c1 = ex_add(b1, d1), c2 = ex_add(b2, d2);
+          Ext f0 = ex_add(c0, d0), f1 = ex_add(c1, d1), f2 = ex_add(c2, d2);
+          acc0 = ex_add(acc0, ex_mul(ex_mul(a0, a1), a2)); acc1 = ex_add(acc1, ex_mul(ex_mul(b0, b1), b2));
+          acc2 = ex_add(acc2, ex_mul(ex_mul(c0, c1), c2)); acc3 = ex_add(acc3, ex_mul(ex_mul(f0, f1), f2));
+        }
+      }
+      acc0 = wave_reduce_ext(acc0); acc1 = wave_reduce_ext(acc1);
+      if (k >= 2) acc2 = wave_reduce_ext(acc2);
+      if (k >= 3) acc3 = wave_reduce_ext(acc3);
+      if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * 4; o[0] = acc0; o[1] = acc1; o[2] = acc2; o[3] = acc3; }
+      if (wpt > 1) break;
+    }
+    __syncthreads();
+    ++seq;
+    if (wave == 0) { sc_publish(result, part, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge(mailbox, seq, chal); }
+    __syncthreads();
+    if (chal[0] == 0) { if (tid == 0) __hip_atomic_store(flag, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+    r = ex(chal[1], chal[2]);
+    unsigned lgh = 0; while ((size_t(1) << lgh) < h) lgh++;
+    for (size_t idx = tid; idx < (size_t)a.ntabs * h; idx += nt) {
+      size_t t = idx >> lgh, q = idx & (h - 1);
+      Ext* p = L + (t << lgf);
+      p[q] = ex_lerp(p[q], p[q + h], r);
+    }
+    __syncthreads();
+    m = h;
+  }
+}
+
+// copy a small device result into host-mapped memory and publish it
+// (launched with ONE wave so that payload stores and the releasing flag store come from the same wave)
+__global__ void k_publish(const u64* src, u64* dst, size_t nwords, unsigned long long* flag, unsigned long long seq) {
+  for (size_t i = threadIdx.x; i < nwords; i += blockDim.x) dst[i] = src[i];
+  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ================================================================================================ HipDev
 static inline int grid_for(size_t n, int cap = 2048) {
   size_t b = (n + TPB - 1) / TPB;
@@ -411,6 +961,7 @@ static inline int grid_for(size_t n, int cap = 2048) {
 }
 
 struct ProfRec { const char* name; double bytes; hipEvent_t a, b; };
+#define DPL_LDS(kern, grid, block, lds, ...) do { prof_begin(#kern); hipLaunchKernelGGL(kern, grid, block, lds, s_, __VA_ARGS__); prof_end(); } while (0)
 #define DPL(kern, grid, block, ...) do { prof_begin(#kern); hipLaunchKernelGGL(kern, grid, block, 0, s_, __VA_ARGS__); prof_end(); } while (0)
 
 class HipDev : public Dev {
@@ -430,7 +981,16 @@ class HipDev : public Dev {
   hipStream_t s_ = nullptr;
   char* arena_ = nullptr;
   size_t arena_cap_ = 0, arena_off_ = 0;
-  u64* hres_ = nullptr;   // pinned host staging for small results
+  u64* hres_ = nullptr;   // pinned, device-mapped host memory for small results (zero-copy readback)
+  u64* hres_dev_ = nullptr;  // device view of hres_
+  unsigned long long* hflag_ = nullptr;      // host view of the publish sequence number
+  unsigned long long* hflag_dev_ = nullptr;  // device view
+  unsigned long long seq_ = 0;
+  bool zerocopy_ = true;  // DP_NO_ZEROCOPY=1 falls back to hipMemcpyAsync + hipStreamSynchronize
+  bool persist_ = true;   // DP_NO_PERSIST=1 disables the persistent sumcheck kernel
+  unsigned long long* hmail_ = nullptr;      // host view of the challenge mailbox [seq, c0, c1]
+  unsigned long long* hmail_dev_ = nullptr;  // device view
+  struct ScSession { bool active = false; int ntabs = 0; size_t n = 0; unsigned long long seq = 0; std::vector<Ext*> a, b; bool nextA = true; } sess_;
   u64* dres_ = nullptr;   // device result buffer
   void* hstage_ = nullptr;  // pinned staging for descriptor uploads
   static constexpr size_t RES_WORDS = 1 << 16;
@@ -446,10 +1006,35 @@ class HipDev : public Dev {
     arena_off_ = off + bytes;
     return arena_ + off;
   }
+  // spin (bounded) until the device has published sequence number `seq` into host memory
+  void wait_flag(unsigned long long seq) {
+    volatile unsigned long long* f = hflag_;
+    auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (*f != seq) {
+      if (*f == ~0ull) throw DpError(DP_ERR_HIP, "device aborted a persistent sumcheck (no challenge received)");
+      if ((++spins & 0xFFFF) == 0) {
+        if (hipStreamQuery(s_) == hipSuccess && *f != seq) {  // stream drained but no flag: report instead of hanging
+          HIP_CHECK(hipStreamSynchronize(s_));
+          if (*f == seq) break;
+          throw DpError(DP_ERR_HIP, "zero-copy publish flag never arrived");
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) throw DpError(DP_ERR_HIP, "timeout waiting for the device");
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  // bring `nwords` of dres_ to hres_
   void fetch(size_t nwords) {
     DP_REQUIRE(nwords <= RES_WORDS, DP_ERR_ARG, "result too large");
-    HIP_CHECK(hipMemcpyAsync(hres_, dres_, nwords * 8, hipMemcpyDeviceToHost, s_));
-    HIP_CHECK(hipStreamSynchronize(s_));
+    if (zerocopy_) {
+      unsigned long long seq = ++seq_;
+      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s_, (const u64*)dres_, hres_dev_, nwords, hflag_dev_, seq);
+      wait_flag(seq);
+    } else {
+      HIP_CHECK(hipMemcpyAsync(hres_, dres_, nwords * 8, hipMemcpyDeviceToHost, s_));
+      HIP_CHECK(hipStreamSynchronize(s_));
+    }
   }
   static PointArg make_point(const Ext* pt, unsigned k) {
     DP_REQUIRE(k <= MAX_PT, DP_ERR_SHAPE, "point too long");
@@ -472,10 +1057,19 @@ class HipDev : public Dev {
     const char* env = getenv("DP_ARENA_BYTES");
     arena_cap_ = env ? strtoull(env, nullptr, 10) : (size_t(12) << 30);
     HIP_CHECK(hipMalloc((void**)&arena_, arena_cap_));
-    HIP_CHECK(hipHostMalloc((void**)&hres_, RES_WORDS * 8, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void**)&hres_, RES_WORDS * 8 + 256, hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_CHECK(hipHostGetDevicePointer((void**)&hres_dev_, hres_, 0));
+    hflag_ = (unsigned long long*)(hres_ + RES_WORDS);
+    hflag_dev_ = (unsigned long long*)(hres_dev_ + RES_WORDS);
+    *hflag_ = 0;
+    hmail_ = hflag_ + 8; hmail_dev_ = hflag_dev_ + 8;
+    hmail_[0] = hmail_[1] = hmail_[2] = 0;
+    zerocopy_ = !(getenv("DP_NO_ZEROCOPY") && atoi(getenv("DP_NO_ZEROCOPY")));
+    persist_ = zerocopy_ && !(getenv("DP_NO_PERSIST") && atoi(getenv("DP_NO_PERSIST")));
     HIP_CHECK(hipMalloc((void**)&dres_, RES_WORDS * 8));
     HIP_CHECK(hipHostMalloc(&hstage_, STAGE_BYTES, hipHostMallocDefault));
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_rc), POSEIDON2_RC_HOST, sizeof(POSEIDON2_RC_HOST)));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_persist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS_MAX));
   }
   ~HipDev() override {
     hipSetDevice(device_);
@@ -527,23 +1121,35 @@ class HipDev : public Dev {
     return b;
   }
   void free_persistent(DBuf& b) override { if (b.p) { hipStreamSynchronize(s_); hipFree(b.p); b.p = nullptr; } }
-  void upload(const DBuf& d, const u64* src) override {
-    HIP_CHECK(hipMemcpyAsync(d.p, src, d.bytes(), hipMemcpyHostToDevice, s_));
-    HIP_CHECK(hipStreamSynchronize(s_));  // src is pageable host memory owned by the caller
+  // host <-> device copies go through the pinned staging buffer: hipMemcpyAsync on pageable memory pins the user pages
+  // on the fly, which costs tens of milliseconds per MB on this stack
+  void h2d(void* dst, const void* src, size_t bytes) {
+    for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
+      size_t m = std::min(STAGE_BYTES, bytes - off);
+      memcpy(hstage_, (const char*)src + off, m);
+      HIP_CHECK(hipMemcpyAsync((char*)dst + off, hstage_, m, hipMemcpyHostToDevice, s_));
+      HIP_CHECK(hipStreamSynchronize(s_));
+    }
   }
+  void d2h(void* dst, const void* src, size_t bytes) {
+    for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
+      size_t m = std::min(STAGE_BYTES, bytes - off);
+      HIP_CHECK(hipMemcpyAsync(hstage_, (const char*)src + off, m, hipMemcpyDeviceToHost, s_));
+      HIP_CHECK(hipStreamSynchronize(s_));
+      memcpy((char*)dst + off, hstage_, m);
+    }
+  }
+  void upload(const DBuf& d, const u64* src) override { h2d(d.p, src, d.bytes()); }
   void upload_i64(const DBuf& d, const int64_t* src) override {
     DP_REQUIRE(!d.ext, DP_ERR_ARG, "upload_i64 needs a base buffer");
     size_t mk = mark();
     int64_t* tmp = (int64_t*)arena_alloc(d.n * 8);
-    HIP_CHECK(hipMemcpyAsync(tmp, src, d.n * 8, hipMemcpyHostToDevice, s_));
+    h2d(tmp, src, d.n * 8);
     DPL(k_fieldize, dim3(grid_for(d.n)), dim3(TPB), tmp, (u64*)d.p, d.n);
     HIP_CHECK(hipStreamSynchronize(s_));
     release(mk);
   }
-  void download(const DBuf& src, u64* dst) override {
-    HIP_CHECK(hipMemcpyAsync(dst, src.p, src.bytes(), hipMemcpyDeviceToHost, s_));
-    HIP_CHECK(hipStreamSynchronize(s_));
-  }
+  void download(const DBuf& src, u64* dst) override { d2h(dst, src.p, src.bytes()); }
   void copy(const DBuf& d, const DBuf& s) override { HIP_CHECK(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, s_)); }
   void zero(const DBuf& d) override { HIP_CHECK(hipMemsetAsync(d.p, 0, d.bytes(), s_)); }
   void sync() override { HIP_CHECK(hipStreamSynchronize(s_)); }
@@ -601,11 +1207,87 @@ class HipDev : public Dev {
       nb_ = [&] { double b = 0; for (int i = 0; i < m; i++) b += a.half[i] * (a.ext[i] ? 32.0 : 16.0) + a.half[i] * 16.0; return b; }(); DPL(k_fold, dim3(grid_for(maxh), m), dim3(TPB), a, r);
     }
   }
+  static constexpr size_t SC_LDS_MAX = 128 * 1024;  // dynamic LDS the LDS-resident sumcheck kernel may use
+  static constexpr size_t SC_PERSIST_MAX = 16384;  // sumchecks whose tables are at most this long run in the persistent kernel
+  void post_challenge(Ext r) {
+    hmail_[1] = r.c0; hmail_[2] = r.c1;
+    std::atomic_thread_fence(std::memory_order_release);
+    *(volatile unsigned long long*)hmail_ = sess_.seq;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+  }
+  static constexpr size_t SC_SMALL_MAX = 8192;  // tables up to this length (after the fold) take the one-launch path
   void sc_round(DBuf* tabs, int nt, const Ext* r, const ScTerm* terms, int nterms, Ext* out) override {
     DP_REQUIRE(nt <= MAX_TABS && nterms <= MAX_TERMS && nt > 0 && nterms > 0, DP_ERR_SHAPE, "sumcheck: too many tables/terms for one launch");
+    size_t n_in = tabs[0].n;
+    for (int i = 0; i < nt; i++) DP_REQUIRE(tabs[i].n == n_in, DP_ERR_SHAPE, "sumcheck: tables must have equal length");
+    size_t n_after = r ? n_in / 2 : n_in;
+    DP_REQUIRE(n_after >= 2, DP_ERR_SHAPE, "sumcheck: tables must keep length >= 2");
+    auto read_terms = [&]() {
+      size_t o = 0;
+      for (int i = 0; i < nterms; i++)
+        for (int t = 0; t <= terms[i].k; t++) out[o++] = ex(hres_[(i * 4 + t) * 2], hres_[(i * 4 + t) * 2 + 1]);
+    };
+    if (sess_.active) {  // the persistent kernel is waiting for this challenge
+      DP_REQUIRE(r && nt == sess_.ntabs && n_in == sess_.n, DP_ERR_ARG, "sumcheck session out of sync");
+      post_challenge(*r);
+      wait_flag(++sess_.seq);
+      sess_.n = n_after;
+      for (int i = 0; i < nt; i++) { tabs[i].p = sess_.nextA ? sess_.a[i] : sess_.b[i]; tabs[i].n = n_after; tabs[i].ext = true; }
+      sess_.nextA = !sess_.nextA;
+      read_terms();
+      return;
+    }
+    if (persist_ && n_after <= SC_PERSIST_MAX && n_after >= 4 && (size_t)nterms * 8 <= RES_WORDS) {
+      ScPersistArgs a;
+      for (int i = 0; i < MAX_TABS; i++) { a.in[i] = nullptr; a.in_ext[i] = 0; a.bufA[i] = nullptr; a.bufB[i] = nullptr; }
+      for (int i = 0; i < MAX_TERMS; i++) { a.k[i] = 1; a.t[i][0] = a.t[i][1] = a.t[i][2] = 0; }
+      sess_.a.assign(nt, nullptr); sess_.b.assign(nt, nullptr);
+      // ping-pong buffers: A takes the first fold output, B the second, A the third, ...
+      size_t first = r ? n_after : n_after / 2;
+      for (int i = 0; i < nt; i++) {
+        a.in[i] = tabs[i].p; a.in_ext[i] = tabs[i].ext;
+        sess_.a[i] = (Ext*)alloc(first, true).p; sess_.b[i] = (Ext*)alloc(std::max<size_t>(first / 2, 1), true).p;
+        a.bufA[i] = sess_.a[i]; a.bufB[i] = sess_.b[i];
+      }
+      for (int i = 0; i < nterms; i++) { a.k[i] = terms[i].k; for (int j = 0; j < 3; j++) a.t[i][j] = terms[i].t[j]; }
+      a.ntabs = nt; a.nterms = nterms; a.has_r0 = r ? 1 : 0; a.n0 = n_in; a.r0 = r ? *r : ex_zero();
+      sess_.active = true; sess_.ntabs = nt; sess_.n = n_after; sess_.seq = seq_; sess_.nextA = r ? false : true;
+      // reserve the sequence numbers of all rounds + the final message
+      unsigned rounds = 0; for (size_t m = n_after; m > 1; m >>= 1) rounds++;
+      seq_ += rounds + 1;
+      size_t work = (size_t)nterms * (n_after / 2) + (size_t)nt * n_after / 4;
+      int threads = work >= 2048 ? 1024 : work >= 512 ? 512 : 256;
+      size_t lds = (size_t)nt * (n_in / 2) * 16;
+      if (lds <= SC_LDS_MAX) { nb_ = 0; DPL_LDS(k_sc_persist_lds, dim3(1), dim3(threads), lds, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
+      else { nb_ = 0; DPL(k_sc_persist, dim3(1), dim3(threads), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
+      wait_flag(++sess_.seq);
+      if (r) for (int i = 0; i < nt; i++) { tabs[i].p = sess_.a[i]; tabs[i].n = n_after; tabs[i].ext = true; }
+      read_terms();
+      return;
+    }
+    if (zerocopy_ && n_after <= SC_SMALL_MAX && (size_t)nterms * 8 <= RES_WORDS) {
+      ScSmallArgs a;
+      for (int i = 0; i < MAX_TABS; i++) { a.in[i] = nullptr; a.out[i] = nullptr; a.in_ext[i] = 0; }
+      for (int i = 0; i < MAX_TERMS; i++) { a.k[i] = 1; a.t[i][0] = a.t[i][1] = a.t[i][2] = 0; }
+      double bytes = 0;
+      for (int i = 0; i < nt; i++) {
+        a.in[i] = tabs[i].p; a.in_ext[i] = tabs[i].ext;
+        if (r) { DBuf o = alloc(n_after, true); a.out[i] = (Ext*)o.p; bytes += tabs[i].bytes() + o.bytes(); tabs[i] = o; }
+      }
+      for (int i = 0; i < nterms; i++) { a.k[i] = terms[i].k; for (int j = 0; j < 3; j++) a.t[i][j] = terms[i].t[j]; for (int j = 0; j < terms[i].k; j++) bytes += 16.0 * n_after; }
+      a.ntabs = nt; a.nterms = nterms; a.has_r = r ? 1 : 0; a.n_after = n_after; a.r = r ? *r : ex_zero();
+      unsigned long long seq = ++seq_;
+      size_t work = (size_t)nterms * (n_after / 2) + (r ? (size_t)nt * n_after / 4 : 0);
+      int threads = work >= 2048 ? 1024 : work >= 512 ? 512 : 256;
+      nb_ = bytes; DPL(k_sc_small, dim3(1), dim3(threads), a, (Ext*)hres_dev_, hflag_dev_, seq);
+      wait_flag(seq);
+      size_t o = 0;
+      for (int i = 0; i < nterms; i++)
+        for (int t = 0; t <= terms[i].k; t++) out[o++] = ex(hres_[(i * 4 + t) * 2], hres_[(i * 4 + t) * 2 + 1]);
+      return;
+    }
     if (r) fold_tables(tabs, nt, *r);
     size_t n = tabs[0].n;
-    for (int i = 0; i < nt; i++) DP_REQUIRE(tabs[i].n == n && n >= 2, DP_ERR_SHAPE, "sumcheck: tables must have equal length >= 2");
     TermArgs a;
     for (int i = 0; i < MAX_TABS; i++) { a.tab[i] = nullptr; a.ext[i] = 0; }
     for (int i = 0; i < nt; i++) { a.tab[i] = tabs[i].p; a.ext[i] = tabs[i].ext; }
@@ -625,6 +1307,14 @@ class HipDev : public Dev {
   }
   void sc_finish(DBuf* tabs, int nt, Ext r, Ext* finals) override {
     DP_REQUIRE(nt <= MAX_TABS, DP_ERR_SHAPE, "sumcheck: too many tables");
+    if (sess_.active) {
+      DP_REQUIRE(nt == sess_.ntabs && sess_.n == 2, DP_ERR_ARG, "sumcheck session out of sync at finish");
+      post_challenge(r);
+      wait_flag(++sess_.seq);
+      for (int i = 0; i < nt; i++) finals[i] = ex(hres_[2 * i], hres_[2 * i + 1]);
+      sess_.active = false;
+      return;
+    }
     FoldArgs a;
     for (int i = 0; i < MAX_TABS; i++) { a.in[i] = nullptr; a.out[i] = nullptr; a.ext[i] = 0; a.half[i] = 0; }
     for (int i = 0; i < nt; i++) { DP_REQUIRE(tabs[i].n == 2, DP_ERR_SHAPE, "sc_finish: tables must have 2 entries"); a.in[i] = tabs[i].p; a.ext[i] = tabs[i].ext; }
@@ -646,6 +1336,42 @@ class HipDev : public Dev {
     DP_REQUIRE(di.ext && no.n == h && dout.n == h && (ni.null() || ni.n == di.n), DP_ERR_SHAPE, "logup_layer: shapes");
     int mode = ni.null() ? 0 : (ni.ext ? 2 : 1);
     nb_ = (mode == 0 ? 32.0 : mode == 1 ? 48.0 : 64.0) * h + 32.0 * h; DPL(k_logup_layer, dim3(grid_for(h)), dim3(TPB), (const void*)ni.p, mode, (const Ext*)di.p, (Ext*)no.p, (Ext*)dout.p, h);
+  }
+
+  void logup_build(const DBuf* cols, int cpi, int ninst, const DBuf& mult, Ext c, Ext chi,
+                   std::vector<LogupCircuitDev>& circuits, std::vector<Ext>& outputs) override {
+    size_t n = cols[0].n;
+    if (n > 16384 || n < 4 || cpi > 8 || (size_t)ninst * sizeof(LogupTreeDesc) > STAGE_BYTES || (size_t)ninst * 8 > RES_WORDS) {
+      Dev::logup_build(cols, cpi, ninst, mult, c, chi, circuits, outputs);
+      return;
+    }
+    circuits.clear(); outputs.clear();
+    LogupTreeDesc* hd = (LogupTreeDesc*)hstage_;
+    for (int s = 0; s < ninst; s++) {
+      LogupCircuitDev cd;
+      DBuf den_all = alloc(2 * n, true), num_all = alloc(n, true);
+      LogupTreeDesc& t = hd[s];
+      for (int j = 0; j < 8; j++) t.col[j] = nullptr;
+      for (int j = 0; j < cpi; j++) { const DBuf& col = cols[(size_t)s * cpi + j]; DP_REQUIRE(!col.ext && col.n == n, DP_ERR_SHAPE, "logup: column shape"); t.col[j] = (const u64*)col.p; }
+      t.ncols = cpi; t.num0 = mult.p; t.num_mode = mult.null() ? 0 : (mult.ext ? 2 : 1);
+      t.den_all = (Ext*)den_all.p; t.num_all = (Ext*)num_all.p;
+      size_t doff = 0, noff = 0;
+      cd.num.push_back(mult);
+      for (size_t len = n; len >= 2; len >>= 1) {
+        cd.den.push_back(den_all.slice(doff, len));
+        if (len < n) { cd.num.push_back(num_all.slice(noff, len)); noff += len; }
+        doff += len;
+      }
+      circuits.push_back(cd);
+    }
+    size_t mk = mark();
+    LogupTreeDesc* dd = (LogupTreeDesc*)arena_alloc((size_t)ninst * sizeof(LogupTreeDesc));
+    HIP_CHECK(hipMemcpyAsync(dd, hd, (size_t)ninst * sizeof(LogupTreeDesc), hipMemcpyHostToDevice, s_));
+    int threads = n >= 2048 ? 1024 : n >= 512 ? 512 : 256;
+    nb_ = (double)ninst * (8.0 * cpi * n + 16.0 * 3 * n); DPL(k_logup_tree, dim3(ninst), dim3(threads), (const LogupTreeDesc*)dd, n, c, chi, (Ext*)dres_);
+    fetch((size_t)ninst * 8);
+    for (int i = 0; i < 4 * ninst; i++) outputs.push_back(ex(hres_[2 * i], hres_[2 * i + 1]));
+    release(mk);
   }
 
   // ---- PCS
@@ -670,6 +1396,16 @@ class HipDev : public Dev {
     if (s.ext) { nb_ = 32.0 * s.n; DPL(k_bitrev<true>, dim3(grid_for(s.n)), dim3(TPB), d.p, (const void*)s.p, lg); }
     else { nb_ = 16.0 * s.n; DPL(k_bitrev<false>, dim3(grid_for(s.n)), dim3(TPB), d.p, (const void*)s.p, lg); }
   }
+  // Run k_merkle_tail over `nd` descriptors staged in hstage_ (roots land in dres_[4*i..]); caller fetches.
+  void launch_tails(const TailDesc* hd_in_stage, size_t nd) {
+    size_t mk = mark();
+    TailDesc* dd = (TailDesc*)arena_alloc(nd * sizeof(TailDesc));
+    HIP_CHECK(hipMemcpyAsync(dd, hd_in_stage, nd * sizeof(TailDesc), hipMemcpyHostToDevice, s_));
+    nb_ = 0; DPL(k_merkle_tail, dim3((unsigned)nd), dim3(1024), (const TailDesc*)dd, dres_);
+    release(mk);
+  }
+  static constexpr size_t TAIL_MAX = 1024;   // layers of at most this many digests are finished by k_merkle_tail
+  static constexpr size_t LP_MAX = 1 << 17;  // layers with at most this many parent nodes use the 8-lanes-per-node kernel
   // `nodes` must hold 4*(n-1) words; synchronises (root is copied to the host)
   DevTree build_tree_into(const DBuf& leaves, const DBuf& nodes) {
     DevTree t; t.leaves = leaves; t.nleaves = leaves.n; t.nodes = nodes;
@@ -678,12 +1414,16 @@ class HipDev : public Dev {
     if (leaves.ext) { nb_ = 16.0 * n + 16.0 * n; DPL(k_merkle_leaves<true>, dim3(grid_for(n / 2)), dim3(TPB), (const void*)leaves.p, nd, n / 2); }
     else { nb_ = 8.0 * n + 16.0 * n; DPL(k_merkle_leaves<false>, dim3(grid_for(n / 2)), dim3(TPB), (const void*)leaves.p, nd, n / 2); }
     size_t off = 0, cnt = n / 2;
-    while (cnt > 1) {
-      nb_ = 96.0 * (cnt / 2); DPL(k_merkle_layer, dim3(grid_for(cnt / 2, 4096)), dim3(TPB), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), cnt / 2);
+    while (cnt > TAIL_MAX) {
+      size_t next = cnt / 2;
+      if (next <= LP_MAX) { nb_ = 96.0 * next; DPL(k_merkle_layer_lp, dim3((unsigned)std::min<size_t>((next * 8 + 1023) / 1024, 2048)), dim3(1024), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
+      else { nb_ = 96.0 * next; DPL(k_merkle_layer, dim3(grid_for(next, 4096)), dim3(TPB), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
       off += cnt; cnt /= 2;
     }
-    HIP_CHECK(hipMemcpyAsync(hres_, nd + 4 * (n - 2), 32, hipMemcpyDeviceToHost, s_));
-    HIP_CHECK(hipStreamSynchronize(s_));
+    TailDesc* hd = (TailDesc*)hstage_;
+    hd[0].nodes = nd; hd[0].off = off; hd[0].cnt = cnt;
+    launch_tails(hd, 1);
+    fetch(4);
     for (int k = 0; k < 4; k++) t.root.v[k] = hres_[k];
     return t;
   }
@@ -723,6 +1463,54 @@ class HipDev : public Dev {
     c.tree = build_tree_into(cw, nodes);  // K8 (synchronises: root to host)
     release(mk);
     return c;
+  }
+  // Commit many polynomials at once (witness columns of one inference): equal-size groups share batched launches —
+  // one LDS-resident Moebius+NTT workgroup per polynomial, one layer-0 launch, one fused Merkle-tail workgroup per tree.
+  std::vector<DevCommit> commit_many(const std::vector<DBuf>& evals, bool persistent) override {
+    std::vector<DevCommit> out(evals.size());
+    std::vector<bool> done(evals.size(), false);
+    for (size_t i = 0; i < evals.size(); i++) {
+      if (done[i]) continue;
+      const DBuf& e0 = evals[i];
+      unsigned nv = dp_ceil_log2(e0.n);
+      bool small = (size_t(1) << nv) == e0.n && nv >= 1 && (nv <= 7 || (tw_ && nv <= L_ && nv <= (e0.ext ? 10u : 11u)));
+      if (!small) { out[i] = commit(e0, persistent); done[i] = true; continue; }
+      std::vector<size_t> grp;
+      for (size_t j = i; j < evals.size(); j++) if (!done[j] && evals[j].n == e0.n && evals[j].ext == e0.ext) grp.push_back(j);
+      size_t g = grp.size(), n = e0.n;
+      bool trivial = nv <= 7;
+      size_t nleaves = trivial ? n : 2 * n;
+      DP_REQUIRE(g * sizeof(SmallCommitDesc) + g * sizeof(TailDesc) <= STAGE_BYTES && 4 * g <= RES_WORDS, DP_ERR_SHAPE, "commit_many: group too large");
+      auto A = [&](size_t m, bool e) { return persistent ? alloc_persistent(m, e) : alloc(m, e); };
+      SmallCommitDesc* hd = (SmallCommitDesc*)hstage_;
+      TailDesc* td = (TailDesc*)((char*)hstage_ + g * sizeof(SmallCommitDesc));
+      for (size_t q = 0; q < g; q++) {
+        DevCommit& c = out[grp[q]];
+        const DBuf& ev = evals[grp[q]];
+        c.nv = nv; c.is_base = !ev.ext; c.evals = ev;
+        DBuf cw = trivial ? ev : A(2 * n, ev.ext);
+        c.bh_evals = trivial ? ev : A(n, ev.ext);
+        DBuf nodes = A(4 * (nleaves - 1), false);
+        c.tree.leaves = cw; c.tree.nleaves = nleaves; c.tree.nodes = nodes;
+        hd[q].evals = ev.p; hd[q].cw = cw.p; hd[q].bh = c.bh_evals.p; hd[q].nodes = (u64*)nodes.p;
+        td[q].nodes = (u64*)nodes.p; td[q].off = 0; td[q].cnt = nleaves / 2;
+      }
+      size_t mk = mark();
+      SmallCommitDesc* dd = (SmallCommitDesc*)arena_alloc(g * sizeof(SmallCommitDesc));
+      HIP_CHECK(hipMemcpyAsync(dd, hd, g * sizeof(SmallCommitDesc), hipMemcpyHostToDevice, s_));
+      if (!trivial) {
+        size_t lds = 3 * n * (e0.ext ? 16 : 8);
+        if (e0.ext) { nb_ = g * 64.0 * n; DPL_LDS(k_commit_small<true>, dim3((unsigned)g), dim3(256), lds, (const SmallCommitDesc*)dd, nv, L_, (const u64*)tw_, (const u64*)pow7_); }
+        else { nb_ = g * 32.0 * n; DPL_LDS(k_commit_small<false>, dim3((unsigned)g), dim3(256), lds, (const SmallCommitDesc*)dd, nv, L_, (const u64*)tw_, (const u64*)pow7_); }
+      }
+      if (e0.ext) { nb_ = g * 32.0 * nleaves; DPL(k_merkle_leaves_many<true>, dim3(grid_for(nleaves / 2, 64), (unsigned)g), dim3(TPB), (const SmallCommitDesc*)dd, nleaves / 2); }
+      else { nb_ = g * 24.0 * nleaves; DPL(k_merkle_leaves_many<false>, dim3(grid_for(nleaves / 2, 64), (unsigned)g), dim3(TPB), (const SmallCommitDesc*)dd, nleaves / 2); }
+      launch_tails(td, g);
+      fetch(4 * g);
+      for (size_t q = 0; q < g; q++) { for (int k = 0; k < 4; k++) out[grp[q]].tree.root.v[k] = hres_[4 * q + k]; done[grp[q]] = true; }
+      release(mk);
+    }
+    return out;
   }
   void free_commit(DevCommit& c) override {
     if (c.bh_evals.p && c.bh_evals.p != c.evals.p) free_persistent(c.bh_evals);
@@ -809,9 +1597,11 @@ class HipDev : public Dev {
     u64* dout = (u64*)arena_alloc(total * 8);
     HIP_CHECK(hipMemcpyAsync(dd, hd, nd * sizeof(GatherDesc), hipMemcpyHostToDevice, s_));
     DPL(k_query_gather, dim3((unsigned)((nd + 3) / 4)), dim3(TPB), (const GatherDesc*)dd, nd, dout);
+    std::vector<GatherDesc> hcopy(hd, hd + nd);  // the staging buffer is reused by the download below
+    hd = hcopy.data();
     std::vector<u64> flat(total);
-    HIP_CHECK(hipMemcpyAsync(flat.data(), dout, total * 8, hipMemcpyDeviceToHost, s_));
     HIP_CHECK(hipStreamSynchronize(s_));
+    d2h(flat.data(), dout, total * 8);
     for (size_t i = 0; i < nd; i++) {
       size_t len = (hd[i].ext ? 4 : 2) + 4 * (size_t)(hd[i].height - 1);
       out[i].assign(flat.begin() + hd[i].out_off, flat.begin() + hd[i].out_off + len);

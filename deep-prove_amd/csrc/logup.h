@@ -21,30 +21,17 @@ inline LogUpProof logup_batch_prove(Dev& dev, const LogUpInputDev& in, Transcrip
   DP_REQUIRE((size_t(1) << nvars) == n && n >= 4, DP_ERR_SHAPE, "logup: column length must be a power of two >= 4");
   for (auto& c : in.columns) DP_REQUIRE(c.n == n && !c.ext, DP_ERR_SHAPE, "logup: columns must be base field of equal length");
   // ---- build the fractional-sum trees (one per instance); layer j has length n >> j
-  struct Circuit { std::vector<DBuf> num, den; bool initial_lookup; };
-  std::vector<Circuit> circuits;
   size_t cpi = in.is_table ? in.columns.size() : in.columns_per_instance;
-  for (size_t s = 0; s < in.columns.size(); s += cpi) {
-    Circuit c; c.initial_lookup = !in.is_table;
-    size_t e = std::min(s + cpi, in.columns.size());
-    DBuf den0 = dev.alloc(n, true);
-    dev.logup_den(den0, &in.columns[s], (int)(e - s), in.constant_challenge, in.column_separation_challenge);
-    c.den.push_back(den0);
-    c.num.push_back(in.is_table ? in.multiplicities : DBuf());
-    for (size_t len = n; len > 2; len >>= 1) {
-      DBuf nn = dev.alloc(len / 2, true), dn = dev.alloc(len / 2, true);
-      dev.logup_layer(c.num.back(), c.den.back(), nn, dn);
-      c.num.push_back(nn); c.den.push_back(dn);
-    }
-    circuits.push_back(c);
-  }
+  DP_REQUIRE(in.columns.size() % cpi == 0, DP_ERR_SHAPE, "logup: column count must be a multiple of columns_per_instance");
+  int ninst = (int)(in.columns.size() / cpi);
+  std::vector<LogupCircuitDev> circuits;
+  std::vector<Ext> outs;
+  dev.logup_build(in.columns.data(), (int)cpi, ninst, in.is_table ? in.multiplicities : DBuf(), in.constant_challenge,
+                  in.column_separation_challenge, circuits, outs);
+  const bool initial_lookup = !in.is_table;
   unsigned total_layers = nvars - 1;
   LogUpProof proof; proof.is_table = in.is_table;
-  for (auto& c : circuits) {
-    std::vector<u64> w(8);
-    dev.download(c.num.back(), w.data()); dev.download(c.den.back(), w.data() + 4);
-    proof.circuit_outputs.push_back({ex(w[0], w[1]), ex(w[2], w[3]), ex(w[4], w[5]), ex(w[6], w[7])});
-  }
+  for (int i = 0; i < ninst; i++) proof.circuit_outputs.push_back({outs[4 * i], outs[4 * i + 1], outs[4 * i + 2], outs[4 * i + 3]});
   t.append_field_element(gl_from_u64(circuits.size()));
   for (auto& ev : proof.circuit_outputs) t.append_exts(ev);
   Ext batching = t.get_and_append_challenge("initial_batching");
@@ -69,8 +56,8 @@ inline LogUpProof logup_batch_prove(Dev& dev, const LogUpInputDev& in, Transcrip
     for (auto& c : circuits) {
       size_t li = c.den.size() - 1 - lv;  // layers().iter().rev().skip(1)
       DBuf dlo = c.den[li].slice(0, half), dhi = c.den[li].slice(half, half);
-      bool initial_lookup = c.initial_lookup && li == 0;
-      if (!initial_lookup) {
+      bool init_lk = initial_lookup && li == 0;
+      if (!init_lk) {
         DBuf nlo = c.num[li].slice(0, half), nhi = c.num[li].slice(half, half);
         vp.add_mle_list({eq, nlo, dhi}, cur_alpha);
         vp.add_mle_list({eq, nhi, dlo}, cur_alpha);

@@ -4,6 +4,9 @@
 // 1116-1236). RS code rate 1/2, 200 queries, base-case message 2^7 (encoding/rs.rs:194-215).
 #pragma once
 #include "sumcheck.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace dp {
 
@@ -29,6 +32,9 @@ struct OpenClaim { const DevCommit* comm; std::vector<Ext> point; Ext eval; };
 inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vector<OpenClaim>& claims, Transcript& t) {
   BasefoldProof proof;
   if (claims.empty()) return proof;  // Proof::trivial(vec![])
+  const bool timing = getenv("DP_TIMING") && atoi(getenv("DP_TIMING"));
+  auto tl0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[dp timing]   batch_open: %-20s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tl0).count()); tl0 = t1; };
   size_t mk = dev.mark();
   unsigned num_vars = 0;
   for (auto& c : claims) {
@@ -77,6 +83,7 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
     sum = ex_add(h0, ex_mul(ch, ex_add(h1, ex_mul(ch, h2))));
     proof.sumcheck_proof.push_back(msg);
   }
+  lap("classic sumcheck");
   // (the last challenge never needs to be folded in: only the challenges are used below)
   std::vector<Ext> coeffs(np);
   for (size_t i = 0; i < np; i++)
@@ -129,6 +136,7 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
     }
   }
   (void)have_pending;
+  lap("commit phase");
   // ---- batch_prover_query_phase (query_phase.rs:67-102, 419-472) and Merkle paths (:1062-1087)
   std::vector<size_t> qidx;
   for (unsigned q = 0; q < PCS_NUM_QUERIES; q++) qidx.push_back((size_t)(t.get_and_append_challenge("query indices").c0 % cw_size));
@@ -156,6 +164,7 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
     for (size_t k = 0; k < np; k++, di++) bq.commitments_query.push_back(fill(descs[di], got[di]));
     proof.queries.push_back(std::move(bq));
   }
+  lap("query phase");
   dev.release(mk);
   return proof;
 }

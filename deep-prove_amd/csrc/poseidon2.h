@@ -105,6 +105,53 @@ struct Digest {
   bool operator==(const Digest& o) const { return v[0] == o.v[0] && v[1] == o.v[1] && v[2] == o.v[2] && v[3] == o.v[3]; }
   bool operator!=(const Digest& o) const { return !(*this == o); }
 };
+// Host fast path: the same permutation with lazily reduced intermediates (any u64 is accepted as a residue, results
+// are canonicalised once at the end). Field arithmetic is exact, so the output equals poseidon2_permute's bit for bit
+// (tests compare both against the oracle); it only removes the per-operation canonicalisation branches from the
+// Fiat-Shamir critical path that sits between two device round trips.
+namespace hostnc {
+inline u64 add(u64 a, u64 b) {
+  u64 s; bool c = __builtin_add_overflow(a, b, &s);
+  u64 adj = c ? GL_EPS : 0; bool c2 = __builtin_add_overflow(s, adj, &s);
+  return s + (c2 ? GL_EPS : 0);
+}
+inline u64 red(unsigned __int128 x) {
+  u64 lo = (u64)x, hi = (u64)(x >> 64);
+  u64 hh = hi >> 32, hl = hi & GL_EPS;
+  u64 t0; bool b = __builtin_sub_overflow(lo, hh, &t0);
+  t0 -= b ? GL_EPS : 0;
+  u64 t1 = hl * GL_EPS;
+  u64 r; bool c = __builtin_add_overflow(t0, t1, &r);
+  return r + (c ? GL_EPS : 0);
+}
+inline u64 mul(u64 a, u64 b) { return red((unsigned __int128)a * b); }
+inline u64 sbox(u64 x) { u64 x2 = mul(x, x), x3 = mul(x2, x), x4 = mul(x2, x2); return mul(x3, x4); }
+inline void mat4(u64& a, u64& b, u64& c, u64& d) {
+  u64 t01 = add(a, b), t23 = add(c, d), t0123 = add(t01, t23);
+  u64 t01123 = add(t0123, b), t01233 = add(t0123, d);
+  u64 n3 = add(t01233, add(a, a)), n1 = add(t01123, add(c, c)), n0 = add(t01123, t01), n2 = add(t01233, t23);
+  a = n0; b = n1; c = n2; d = n3;
+}
+inline void mds(u64* s) {
+  mat4(s[0], s[1], s[2], s[3]); mat4(s[4], s[5], s[6], s[7]);
+  for (int k = 0; k < 4; k++) { u64 sum = add(s[k], s[k + 4]); s[k] = add(s[k], sum); s[k + 4] = add(s[k + 4], sum); }
+}
+inline void permute(u64* s) {
+  const u64* rc = POSEIDON2_RC_HOST;
+  mds(s);
+  for (int r = 0; r < 4; r++) { for (int i = 0; i < 8; i++) s[i] = sbox(add(s[i], rc[r * 8 + i])); mds(s); }
+  for (int r = 0; r < 22; r++) {
+    s[0] = sbox(add(s[0], rc[32 + r]));
+    unsigned __int128 acc = 0;  // eight u64 terms: < 2^67
+    for (int i = 0; i < 8; i++) acc += s[i];
+    u64 sum = red(acc);
+    for (int i = 0; i < 8; i++) s[i] = red((unsigned __int128)s[i] * rc[86 + i] + sum);  // < 2^128: no overflow
+  }
+  for (int r = 0; r < 4; r++) { for (int i = 0; i < 8; i++) s[i] = sbox(add(s[i], rc[54 + r * 8 + i])); mds(s); }
+  for (int i = 0; i < 8; i++) s[i] = s[i] >= GL_P ? s[i] - GL_P : s[i];
+}
+}  // namespace hostnc
+
 struct Challenger {
   u64 state[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   u64 in_buf[4];
@@ -114,7 +161,7 @@ struct Challenger {
   void duplexing() {
     for (int i = 0; i < in_len; i++) state[i] = in_buf[i];
     in_len = 0;
-    poseidon2_permute(state, POSEIDON2_RC_HOST);
+    hostnc::permute(state);
     for (int i = 0; i < 4; i++) out_buf[i] = state[i];
     out_len = 4;
   }
@@ -129,8 +176,11 @@ struct Challenger {
   }
 };
 inline Digest host_compress(const Digest& x, const Digest& y) {
-  Digest d;
-  poseidon2_compress(x.v, y.v, d.v, POSEIDON2_RC_HOST);
+  u64 s[8] = {x.v[0], x.v[1], x.v[2], x.v[3], 0, 0, 0, 0};
+  hostnc::permute(s);
+  s[0] = y.v[0]; s[1] = y.v[1]; s[2] = y.v[2]; s[3] = y.v[3];
+  hostnc::permute(s);
+  Digest d; d.v[0] = s[3]; d.v[1] = s[2]; d.v[2] = s[1]; d.v[3] = s[0];
   return d;
 }
 // Transcript<E> with the BasicTranscript behaviour; label bytes -> 8-byte LE words (ff_ext/src/lib.rs:262-272)

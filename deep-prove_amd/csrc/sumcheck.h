@@ -45,6 +45,29 @@ inline Ext lagrange_eval_small(const Ext* evals, size_t n, Ext at) {
   }
   return res;
 }
+// the prover only ever extrapolates from nodes 0..k (k <= 3) to the integer points k+1..3: those Lagrange
+// coefficients are constants, computed once
+inline const u64* extrapolation_coeffs(unsigned k, unsigned at) {  // returns k+1 base-field coefficients
+  static u64 table[4][5][4];
+  static bool ready = false;
+  if (!ready) {
+    for (unsigned kk = 1; kk <= 3; kk++)
+      for (unsigned a = kk + 1; a <= 4; a++)
+        for (unsigned i = 0; i <= kk; i++) {
+          u64 num = 1, den = 1;
+          for (unsigned j = 0; j <= kk; j++) { if (j == i) continue; num = gl_mul(num, gl_sub(a, j)); den = gl_mul(den, gl_sub(i, j)); }
+          table[kk][a][i] = gl_mul(num, gl_inv(den));
+        }
+    ready = true;
+  }
+  return table[k][at];
+}
+inline Ext extrapolate_small(const Ext* evals, unsigned k, unsigned at) {
+  const u64* c = extrapolation_coeffs(k, at);
+  Ext r = ex_zero();
+  for (unsigned i = 0; i <= k; i++) r = ex_add(r, ex_mul_base(evals[i], c[i]));
+  return r;
+}
 
 struct SumcheckOut { IOPProof proof; std::vector<Ext> finals; };
 
@@ -70,7 +93,7 @@ inline SumcheckOut sumcheck_prove(Dev& dev, DevVP& vp, Transcript& t) {
       for (unsigned j = 0; j <= k; j++) s[j] = ex_mul(raw[off + j], vp.coeffs[ti]);
       off += k + 1;
       for (unsigned j = 0; j <= md; j++) {
-        Ext v = j <= k ? s[j] : lagrange_eval_small(s.data(), k + 1, ex_from_u64(j));
+        Ext v = j <= k ? s[j] : extrapolate_small(s.data(), k, j);
         msg[j] = ex_add(msg[j], v);
       }
     }

@@ -13,6 +13,9 @@
 #include <unordered_map>
 #include <algorithm>
 #include <memory>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace dp {
 
@@ -177,12 +180,28 @@ struct ProverState {
   }
 };
 
-inline DBuf upload_column(Dev& dev, const std::vector<int64_t>& v) { DBuf b = dev.alloc(v.size(), false); dev.upload_i64(b, v.data()); return b; }
-
+struct PhaseTimer {  // DP_TIMING=1 prints the host-side wall time of each proving phase to stderr
+  bool on; std::chrono::steady_clock::time_point t0; const char* name;
+  PhaseTimer() : on(getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))), t0(std::chrono::steady_clock::now()), name(nullptr) {}
+  void lap(const char* what) {
+    if (!on) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[dp timing] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+// generate_lookup_witnesses (lookup/context.rs:631-781) with gen_lookup_witness of requant.rs:208-345 / activation.rs:238-318.
+// All witness columns of the inference are produced on the host (tiny integer work on activation vectors), shipped to
+// the device in ONE upload and committed in ONE batched call (the reference commits them one by one on rayon threads).
 inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
   Context& ctx = *ps.ctx; Dev& dev = *ps.dev;
   if (ctx.tables.empty()) return;
+  PhaseTimer wt;
   std::map<TableType, std::unordered_map<int64_t, u64>> counts;
+  struct Col { std::vector<int64_t> v; };
+  std::vector<Col> cols;                       // every i64 column that goes to the device, in commit order first
+  struct Pending { size_t node; int which; std::vector<size_t> col_ids; size_t cpi; TableType tt; };
+  std::vector<Pending> pend;
   for (size_t id = 0; id < ctx.model.layers.size(); id++) {
     const LayerSpec& l = ctx.model.layers[id];
     if (l.kind == L_REQUANT) {
@@ -190,45 +209,82 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       std::vector<int64_t> cin, cout, shifted;
       for (int64_t v : tr.in[id]) { int64_t tmp = v * l.fixed_point_multiplier + rounding; int64_t c = tmp >> shift; cin.push_back(c); cout.push_back(q_clamp(c)); shifted.push_back(tmp & mask); }
       unsigned nchunks = shift / Q_BIT_LEN; int64_t rmask = (int64_t(1) << Q_BIT_LEN) - 1;
-      std::vector<std::vector<int64_t>> chunks(nchunks);
-      for (unsigned j = 0; j < nchunks; j++) for (int64_t s : shifted) chunks[j].push_back((s >> (j * Q_BIT_LEN)) & rmask);
       TableType ct{3, l.clamping_size()}, rt{2, 0};
       int64_t cmax = int64_t(1) << (ct.size - 1);
-      for (auto& chv : chunks) for (int64_t v : chv) counts[rt][v] += 1;
       for (size_t i = 0; i < cin.size(); i++) {
         DP_REQUIRE(cin[i] >= -cmax && cin[i] < cmax, DP_ERR_ARG, "requant: value falls outside the clamping table");
         counts[ct][cin[i] + cout[i] * COLUMN_SEPARATOR] += 1;
       }
-      LogUpWitness wc; wc.columns_per_instance = 2; wc.table_type = ct;
-      for (auto* col : {&cin, &cout}) { DBuf b = upload_column(dev, *col); wc.columns.push_back(b); wc.commits.push_back(dev.commit(b, false)); }
-      LogUpWitness ws; ws.columns_per_instance = 1; ws.table_type = rt;
-      for (auto& chv : chunks) { DBuf b = upload_column(dev, chv); ws.columns.push_back(b); ws.commits.push_back(dev.commit(b, false)); }
-      ps.lookup_witness[id] = {wc, ws};
+      Pending pc{id, 0, {}, 2, ct}, pr{id, 1, {}, 1, rt};
+      pc.col_ids = {cols.size(), cols.size() + 1};
+      cols.push_back({cin}); cols.push_back({cout});
+      for (unsigned j = 0; j < nchunks; j++) {
+        std::vector<int64_t> ch; ch.reserve(shifted.size());
+        for (int64_t sft : shifted) { int64_t v = (sft >> (j * Q_BIT_LEN)) & rmask; ch.push_back(v); counts[rt][v] += 1; }
+        pr.col_ids.push_back(cols.size()); cols.push_back({std::move(ch)});
+      }
+      pend.push_back(pc); pend.push_back(pr);
     } else if (l.kind == L_RELU) {
       TableType rt{0, 0};
       const auto& a = tr.in[id]; const auto& b = tr.out[id];
       for (size_t i = 0; i < a.size(); i++) counts[rt][a[i] + COLUMN_SEPARATOR * b[i]] += 1;
-      LogUpWitness w; w.columns_per_instance = 2; w.table_type = rt;
-      for (auto* col : {&a, &b}) { DBuf d = upload_column(dev, *col); w.columns.push_back(d); w.commits.push_back(dev.commit(d, false)); }
-      ps.lookup_witness[id] = {w};
+      Pending p{id, 0, {cols.size(), cols.size() + 1}, 2, rt};
+      cols.push_back({a}); cols.push_back({b});
+      pend.push_back(p);
     }
   }
+  size_t n_witness_cols = cols.size();
+  wt.lap("  witness: host columns");
+  // table columns (not committed) ride in the same upload
+  struct TabInfo { TableType tt; std::vector<size_t> col_ids; std::vector<u64> mult; };
+  std::vector<TabInfo> tabs;
   for (auto& kv : counts) {
     const TableType& tt = kv.first;
-    std::vector<int64_t> merged; std::vector<std::vector<int64_t>> cols;
-    table_columns(tt, merged, cols);
-    std::unordered_map<int64_t, u64> tc; for (int64_t v : merged) tc[v] += 1;
-    std::vector<u64> mult(merged.size());
+    std::vector<int64_t> merged; std::vector<std::vector<int64_t>> tc;
+    table_columns(tt, merged, tc);
+    std::unordered_map<int64_t, u64> cnt; for (int64_t v : merged) cnt[v] += 1;
+    TabInfo ti; ti.tt = tt; ti.mult.resize(merged.size());
     for (size_t i = 0; i < merged.size(); i++) {
       auto it = kv.second.find(merged[i]);
-      if (it == kv.second.end()) { mult[i] = 0; continue; }
-      u64 c = tc[merged[i]];
-      mult[i] = gl_mul(gl_from_u64(it->second), c != 1 ? gl_inv(gl_from_u64(c)) : 1);
+      if (it == kv.second.end()) { ti.mult[i] = 0; continue; }
+      u64 c = cnt[merged[i]];
+      ti.mult[i] = gl_mul(gl_from_u64(it->second), c != 1 ? gl_inv(gl_from_u64(c)) : 1);
     }
-    LogUpWitness w; w.is_table = true; w.table_type = tt; w.columns_per_instance = cols.size();
-    w.multiplicities = dev.alloc(mult.size(), false); dev.upload(w.multiplicities, mult.data());
-    for (auto& c : cols) w.columns.push_back(upload_column(dev, c));
-    w.commits.push_back(dev.commit(w.multiplicities, false));
+    for (auto& c : tc) { ti.col_ids.push_back(cols.size()); cols.push_back({std::move(c)}); }
+    tabs.push_back(std::move(ti));
+  }
+  wt.lap("  witness: multiplicities");
+  // one upload of all i64 columns, one of all multiplicity vectors
+  size_t total = 0; for (auto& c : cols) total += c.v.size();
+  std::vector<int64_t> flat; flat.reserve(total);
+  std::vector<size_t> offs;
+  for (auto& c : cols) { offs.push_back(flat.size()); flat.insert(flat.end(), c.v.begin(), c.v.end()); }
+  DBuf big = dev.alloc(total, false);
+  dev.upload_i64(big, flat.data());
+  std::vector<DBuf> dcol;
+  for (size_t i = 0; i < cols.size(); i++) dcol.push_back(big.slice(offs[i], cols[i].v.size()));
+  size_t mtotal = 0; for (auto& t : tabs) mtotal += t.mult.size();
+  std::vector<u64> mflat; mflat.reserve(mtotal);
+  std::vector<size_t> moffs;
+  for (auto& t : tabs) { moffs.push_back(mflat.size()); mflat.insert(mflat.end(), t.mult.begin(), t.mult.end()); }
+  DBuf mbig = dev.alloc(mtotal, false);
+  dev.upload(mbig, mflat.data());
+  wt.lap("  witness: uploads");
+  // one batched commit: witness columns in order, then the table multiplicities
+  std::vector<DBuf> to_commit(dcol.begin(), dcol.begin() + n_witness_cols);
+  for (size_t i = 0; i < tabs.size(); i++) to_commit.push_back(mbig.slice(moffs[i], tabs[i].mult.size()));
+  std::vector<DevCommit> comms = dev.commit_many(to_commit, false);
+  wt.lap("  witness: commit_many");
+  for (auto& p : pend) {
+    LogUpWitness w; w.columns_per_instance = p.cpi; w.table_type = p.tt;
+    for (size_t cid : p.col_ids) { w.columns.push_back(dcol[cid]); w.commits.push_back(comms[cid]); }
+    ps.lookup_witness[p.node].push_back(std::move(w));
+  }
+  for (size_t i = 0; i < tabs.size(); i++) {
+    LogUpWitness w; w.is_table = true; w.table_type = tabs[i].tt; w.columns_per_instance = tabs[i].col_ids.size();
+    w.multiplicities = to_commit[n_witness_cols + i];
+    for (size_t cid : tabs[i].col_ids) w.columns.push_back(dcol[cid]);
+    w.commits.push_back(comms[n_witness_cols + i]);
     ps.table_witness.push_back(std::move(w));
   }
   ps.constant_challenge = ps.t->get_and_append_challenge("table_constant");
@@ -335,10 +391,12 @@ inline Claim prove_relu(ProverState& ps, size_t id, const Claim& last, const std
 // Prover::prove(trace). `tr` comes from run_model (inference is not part of proving time in the reference either).
 inline Proof prove(Context& ctx, const Trace& tr, Transcript& t) {
   Dev& dev = *ctx.dev;
+  PhaseTimer pt;
   size_t mk = dev.mark();
   ProverState ps; ps.ctx = &ctx; ps.dev = &dev; ps.t = &t;
   for (auto& kv : ctx.model_comms) for (auto& pc : kv.second) t.append_digest(pc.second.tree.root);
   instantiate_witness_ctx(ps, tr);
+  pt.lap("witness columns + commits");
   const std::vector<int64_t>& out = tr.out.back();
   std::vector<Ext> r = t.read_challenges(dp_ceil_log2(out.size()));
   Claim cur; cur.point = r;
@@ -348,6 +406,7 @@ inline Proof prove(Context& ctx, const Trace& tr, Transcript& t) {
     if (l.kind == L_DENSE) cur = prove_dense(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
     else cur = prove_relu(ps, id, cur, tr.out[id]);
+    if (pt.on) { char b[64]; snprintf(b, sizeof b, "layer %zu (%s)", id, l.kind == L_DENSE ? "dense" : l.kind == L_REQUANT ? "requant" : "relu"); pt.lap(b); }
   }
   Proof proof;
   for (auto& tw : ps.table_witness) {
@@ -355,10 +414,13 @@ inline Proof prove(Context& ctx, const Trace& tr, Transcript& t) {
     ps.add_witness_claim(tw.commits[0], tp.output_claims[0]);
     proof.table_proofs.push_back({pure_commitment(tw.commits[0]), tp});
   }
+  pt.lap("table proofs");
   for (auto& c : ps.trivial_claims) proof.trivial_proofs.push_back(pcs_open_trivial(dev, c.comm));
+  pt.lap("trivial openings");
   std::vector<OpenClaim> oc;
   for (auto& c : ps.claims) oc.push_back({&c.comm, c.claim.point, c.claim.eval});
   proof.batch_proof = pcs_batch_open(dev, ctx.full_log, oc, t);
+  pt.lap("batch_open");
   proof.steps = ps.proofs;
   dev.release(mk);
   return proof;
