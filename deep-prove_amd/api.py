@@ -316,6 +316,23 @@ class Prover:
         return _take(pw, pn.value), out[:no.value].copy()
 
 
+    def prove_batch(self, inputs_i64, concurrency):
+        """independent proofs with up to `concurrency` in flight on this GPU; returns ([proof_words], outputs[nproofs, nout], wall_ms)"""
+        x = np.ascontiguousarray(inputs_i64, dtype=np.int64)
+        nproofs, ninput = x.shape
+        lib = _lib.load()
+        pws = (u64p * nproofs)()
+        pns = (C.c_size_t * nproofs)()
+        cap = 1 << 12
+        outs = np.zeros((nproofs, cap), dtype=np.int64)
+        no = C.c_size_t(0)
+        ms = C.c_double()
+        check(lib.dp_model_prove_batch(self.ctx.h, x.ctypes.data_as(i64p), nproofs, ninput, concurrency, pws, pns,
+                                       outs.ctypes.data_as(i64p), cap, C.byref(no), C.byref(ms)))
+        proofs = [_take(pws[i], pns[i]) for i in range(nproofs)]
+        return proofs, outs[:, :no.value].copy(), ms.value
+
+
 def verify(verifier_blob, proof_words, input_i64, output_i64):
     """zkml::verify (zkml/src/iop/verifier.rs:306-318). Host only. Raises DeepProveError(DP_ERR_VERIFY) on rejection."""
     vb = np.ascontiguousarray(verifier_blob, dtype=np.uint64)

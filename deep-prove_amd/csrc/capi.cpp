@@ -4,15 +4,18 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <mutex>
+#include <thread>
 
-namespace dp { Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
+namespace dp { void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
 using namespace dp;
 
-struct dp_ctx { Dev* dev; };
+struct dp_ctx { Dev* dev; int device_id; };
 struct dp_buf { DBuf b; };
 struct dp_transcript { Transcript t; };
 struct dp_commit { DevCommit c; };
-struct dp_model { dp_ctx* ctx; std::unique_ptr<Context> zk; };
+struct dp_model { dp_ctx* ctx; std::unique_ptr<Context> zk; std::vector<std::unique_ptr<Dev>> workers; };
 
 static thread_local std::string g_err;
 template <class F>
@@ -41,7 +44,7 @@ const char* dp_last_error(void) { return g_err.c_str(); }
 void dp_free(void* p) { free(p); }
 
 int32_t dp_ctx_create(int32_t device_id, dp_ctx** out) {
-  return guard([&] { DP_REQUIRE(out, DP_ERR_ARG, "null out"); Dev* d = make_hip_dev(device_id); *out = new dp_ctx{d}; });
+  return guard([&] { DP_REQUIRE(out, DP_ERR_ARG, "null out"); Dev* d = make_hip_dev(device_id); *out = new dp_ctx{d, device_id}; });
 }
 int32_t dp_ctx_destroy(dp_ctx* ctx) { return guard([&] { if (ctx) { delete ctx->dev; delete ctx; } }); }
 const char* dp_ctx_name(const dp_ctx* ctx) { return ctx ? ctx->dev->name() : ""; }
@@ -237,6 +240,7 @@ int32_t dp_model_prove(dp_model* m, const int64_t* input, size_t ninput, uint64_
     Proof p = prove(*m->zk, tr, t);
     auto t1 = std::chrono::steady_clock::now();
     if (prove_ms) *prove_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    hip_dev_dump_sc_debug(m->ctx->dev);
     std::vector<u64> w = serialize_proof(p);
     *proof_words = copy_out(w); *proof_nwords = w.size();
     if (output && noutput) {
@@ -244,6 +248,46 @@ int32_t dp_model_prove(dp_model* m, const int64_t* input, size_t ninput, uint64_
       DP_REQUIRE(*noutput >= o.size(), DP_ERR_ARG, "output buffer too small");
       memcpy(output, o.data(), o.size() * 8); *noutput = o.size();
     }
+  });
+}
+int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs, size_t ninput, int32_t concurrency,
+                             uint64_t** proof_words, size_t* proof_nwords, int64_t* outputs, size_t noutput_cap, size_t* noutput, double* wall_ms) {
+  return guard([&] {
+    DP_REQUIRE(m && inputs && proof_words && proof_nwords && nproofs > 0 && concurrency > 0 && concurrency <= 64, DP_ERR_ARG, "bad arguments");
+    size_t nw = std::min<size_t>((size_t)concurrency, nproofs);
+    // worker 0 is the model's own context; the others get their own stream + arena on the same GPU and share the
+    // (read-only) model commitments
+    const char* env = getenv("DP_WORKER_ARENA_BYTES");
+    size_t arena = env ? strtoull(env, nullptr, 10) : (size_t(4) << 30);
+    while (m->workers.size() + 1 < nw) { std::unique_ptr<Dev> w(make_hip_worker(m->ctx->device_id, arena)); w->pcs_init(m->zk->full_log); m->workers.push_back(std::move(w)); }
+    std::atomic<size_t> next(0);
+    std::mutex err_mu; std::string err; int err_code = 0;
+    for (size_t i = 0; i < nproofs; i++) { proof_words[i] = nullptr; proof_nwords[i] = 0; }
+    auto t0 = std::chrono::steady_clock::now();
+    auto work = [&](size_t wi) {
+      Dev& dev = wi == 0 ? *m->ctx->dev : *m->workers[wi - 1];
+      try {
+        dev.bind_thread();
+        for (;;) {
+          size_t i = next.fetch_add(1);
+          if (i >= nproofs) break;
+          std::vector<int64_t> in(inputs + i * ninput, inputs + (i + 1) * ninput);
+          Trace tr = run_model(m->zk->model, in);
+          Transcript t = default_transcript();
+          Proof p = prove(*m->zk, dev, tr, t);
+          std::vector<u64> w = serialize_proof(p);
+          proof_words[i] = copy_out(w); proof_nwords[i] = w.size();
+          if (outputs) { const auto& o = tr.out.back(); DP_REQUIRE(o.size() <= noutput_cap, DP_ERR_ARG, "output buffer too small"); memcpy(outputs + i * noutput_cap, o.data(), o.size() * 8); if (noutput) *noutput = o.size(); }
+        }
+      } catch (const DpError& e) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = e.code; err = e.what(); } next = nproofs; }
+      catch (const std::exception& e) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_ARG; err = e.what(); } next = nproofs; }
+    };
+    std::vector<std::thread> th;
+    for (size_t wi = 1; wi < nw; wi++) th.emplace_back(work, wi);
+    work(0);
+    for (auto& t : th) t.join();
+    if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (err_code) { for (size_t i = 0; i < nproofs; i++) { free(proof_words[i]); proof_words[i] = nullptr; } throw DpError(err_code, err); }
   });
 }
 static std::vector<u64> vctx_to_words(const VerifierContext& v) {

@@ -70,6 +70,7 @@ class Dev {
  public:
   virtual ~Dev() {}
   virtual const char* name() const = 0;
+  virtual void bind_thread() {}  // make this context current for the calling host thread
   // ---- memory. alloc() is an arena (stack discipline via mark/release); persistent allocations outlive proofs.
   virtual DBuf alloc(size_t n, bool ext) = 0;
   virtual size_t mark() = 0;

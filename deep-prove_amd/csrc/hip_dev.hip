@@ -613,6 +613,16 @@ __global__ void __launch_bounds__(256) k_commit_small(const SmallCommitDesc* d, 
 }
 
 // ------------------------------------------------------------------------------------------------ single-launch sumcheck round
+__device__ __forceinline__ unsigned long long pub_mix(unsigned long long seq) { return seq * 0x9E3779B97F4A7C15ull + 0x7F4A7C159E3779B9ull; }
+__device__ __forceinline__ void pub_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// one wave: lane l owns words l, l+64, ...; returns (on lane 0) the payload checksum
+__device__ __forceinline__ unsigned long long pub_wave_sum(unsigned long long local) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) local += shfl_down_u64(local, d);
+  return local;
+}
+__device__ void sc_publish_fwd(Ext* result, const Ext* part, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane);
+__device__ void sc_wait_challenge_fwd(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal);
 struct ScSmallArgs {
   const void* in[MAX_TABS]; Ext* out[MAX_TABS]; int in_ext[MAX_TABS];
   int k[MAX_TERMS]; int t[MAX_TERMS][3];
@@ -682,33 +692,20 @@ __global__ void __launch_bounds__(1024) k_sc_small(ScSmallArgs a, Ext* result, u
     if (wpt > 1) break;  // with several waves per term every wave owns exactly one (term, sub)
   }
   __syncthreads();
-  if (wave == 0) {
-    for (int e = lane; e < a.nterms * 4; e += 64) {
-      int term = e >> 2, t = e & 3;
-      Ext v = ex_zero();
-      if (wpt == 1) {
-        // terms beyond the first W were accumulated by the same wave in later loop iterations: each has its own slot
-        v = part[(size_t)term * 4 + t];
-      } else {
-        for (int sb = 0; sb < wpt; sb++) v = ex_add(v, part[(size_t)(term * wpt + sb) * 4 + t]);
-      }
-      result[e] = v;
-    }
-    if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  if (wave == 0) sc_publish_fwd(result, part, a.nterms, wpt, flag, seq, lane);
 }
+
 // ------------------------------------------------------------------------------------------------ persistent sumcheck
 // A whole (tail of a) sumcheck in ONE launch of ONE workgroup: per round the kernel publishes the raw term sums to
 // host-mapped memory, the host runs the Fiat-Shamir sponge and posts the challenge into a host-mapped mailbox which
 // the kernel polls; then the kernel folds every table and goes on. No kernel launch, no stream synchronisation and no
 // memcpy on the per-round critical path — only two PCIe hops. Ends by publishing the final evaluation of every table.
-__device__ void sc_publish_fwd(Ext* result, const Ext* part, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane);
-__device__ void sc_wait_challenge_fwd(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal);
 struct ScPersistArgs {
   const void* in[MAX_TABS]; int in_ext[MAX_TABS];
   Ext* bufA[MAX_TABS]; Ext* bufB[MAX_TABS];
   int k[MAX_TERMS]; int t[MAX_TERMS][3];
   int ntabs, nterms, has_r0; size_t n0; Ext r0;
+  unsigned long long* dbg;  // optional: per-phase cycle counters (DP_SC_DEBUG=1)
 };
 __device__ __forceinline__ void sc_fold_all(const ScPersistArgs& a, const void* const* cur, const int* cur_ext, Ext* const* dst, size_t n_after, Ext r) {
   int tid = threadIdx.x, nt = blockDim.x;
@@ -778,7 +775,7 @@ __global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* resul
     if (wave == 0) { sc_publish_fwd(result, part, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge_fwd(mailbox, seq, chal); }
     __syncthreads();
     if (chal[0] == 0) {  // host never answered: publish an abort marker and leave
-      if (tid == 0) __hip_atomic_store(flag, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (tid == 0) pub_store((u64*)flag, ~0ull);
       return;
     }
     Ext r = ex(chal[1], chal[2]);
@@ -791,8 +788,10 @@ __global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* resul
     if (n == 1) {
       ++seq;
       if (wave == 0) {
-        for (int e = lane; e < a.ntabs; e += 64) result[e] = ((const Ext*)cur[e])[0];
-        if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        unsigned long long cs = 0; u64* rw = (u64*)result;
+        for (int e = lane; e < a.ntabs; e += 64) { Ext v = ((const Ext*)cur[e])[0]; pub_store(rw + 2 * e, v.c0); pub_store(rw + 2 * e + 1, v.c1); cs += (unsigned long long)(2 * e + 1) * v.c0 + (unsigned long long)(2 * e + 2) * v.c1; }
+        cs = pub_wave_sum(cs);
+        if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + cs);
       }
       return;
     }
@@ -802,16 +801,37 @@ __global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* resul
 // Same protocol as k_sc_persist, but the tables live in LDS after the first fold (bit-reversed index order, so a fold
 // pairs positions q and q + m/2 and is done in place with no hazards): after the first round no table byte touches
 // global memory again. Dynamic LDS = ntabs * (n0/2) extension elements.
+// ---- device -> host publication without fences -------------------------------------------------------------------
+// A system-scope release makes the wave wait for an L2 write-back; with many proofs in flight on one GPU that stalls
+// every round behind other proofs' dirty lines. Instead every payload word goes out as a relaxed system-scope store
+// (the result area is fine-grained host memory, nothing is cached) and the flag word carries a TAG that binds the
+// sequence number to the payload: tag = mix(seq) + sum_i (i+1) * word_i. The host accepts a message only when the tag
+// it recomputes from the words it reads matches, so any reordering of the posted writes is harmless.
 __device__ __forceinline__ void sc_publish(Ext* result, const Ext* part, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane) {
+  unsigned long long cs = 0;
+  u64* rw = (u64*)result;
   for (int e = lane; e < nterms * 4; e += 64) {
     int term = e >> 2, t = e & 3;
     Ext v = ex_zero();
     if (wpt == 1) v = part[(size_t)term * 4 + t];
     else for (int sb = 0; sb < wpt; sb++) v = ex_add(v, part[(size_t)(term * wpt + sb) * 4 + t]);
-    result[e] = v;
+    pub_store(rw + 2 * e, v.c0); pub_store(rw + 2 * e + 1, v.c1);
+    cs += (unsigned long long)(2 * e + 1) * v.c0 + (unsigned long long)(2 * e + 2) * v.c1;
   }
-  // the payload stores and the releasing flag store come from this one wave
-  if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  cs = pub_wave_sum(cs);
+  if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + cs);
+}
+// publish `n` extension values held in `src` (LDS or global) by one wave
+__device__ __forceinline__ void sc_publish_vals(Ext* result, const Ext* src, size_t stride, int n, unsigned long long* flag, unsigned long long seq, int lane) {
+  unsigned long long cs = 0;
+  u64* rw = (u64*)result;
+  for (int e = lane; e < n; e += 64) {
+    Ext v = src[(size_t)e * stride];
+    pub_store(rw + 2 * e, v.c0); pub_store(rw + 2 * e + 1, v.c1);
+    cs += (unsigned long long)(2 * e + 1) * v.c0 + (unsigned long long)(2 * e + 2) * v.c1;
+  }
+  cs = pub_wave_sum(cs);
+  if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + cs);
 }
 // lane 0 of wave 0: poll the host mailbox for `seq` (bounded), leave {ok, c0, c1} in chal[]
 __device__ __forceinline__ void sc_wait_challenge(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal) {
@@ -839,6 +859,7 @@ __global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* r
   size_t first = a.n0 / 2;
   unsigned lgf = 0; while ((size_t(1) << lgf) < first) lgf++;
   Ext r = a.r0;
+  unsigned long long c_fold = 0, c_sums = 0, c_pub = 0, c_wait = 0, c_rounds = 0, tk = clock64();
   if (!a.has_r0) {
     // round on the tables as they sit in global memory
     size_t npairs = a.n0 / 2;
@@ -877,7 +898,7 @@ __global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* r
     ++seq;
     if (wave == 0) { sc_publish(result, part, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge(mailbox, seq, chal); }
     __syncthreads();
-    if (chal[0] == 0) { if (tid == 0) __hip_atomic_store(flag, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+    if (chal[0] == 0) { if (tid == 0) pub_store((u64*)flag, ~0ull); return; }
     r = ex(chal[1], chal[2]);
   }
   // first fold: global -> LDS (bit-reversed positions)
@@ -893,13 +914,12 @@ __global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* r
   for (;;) {
     if (m == 1) {
       ++seq;
-      if (wave == 0) {
-        for (int e = lane; e < a.ntabs; e += 64) result[e] = L[(size_t)e << lgf];
-        if (lane == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
+      if (tid == 0 && a.dbg) { atomicAdd(a.dbg + 0, c_fold); atomicAdd(a.dbg + 1, c_sums); atomicAdd(a.dbg + 2, c_pub); atomicAdd(a.dbg + 3, c_wait); atomicAdd(a.dbg + 4, c_rounds); }
+      if (wave == 0) sc_publish_vals(result, L, size_t(1) << lgf, a.ntabs, flag, seq, lane);
       return;
     }
     size_t h = m / 2;
+    if (tid == 0) { unsigned long long now = clock64(); c_fold += now - tk; tk = now; }
     for (int term = wave / wpt; term < a.nterms; term += (wpt == 1 ? W : a.nterms + W)) {
       int sub = wave % wpt;
       int k = a.k[term];
@@ -931,9 +951,15 @@ __global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* r
     }
     __syncthreads();
     ++seq;
-    if (wave == 0) { sc_publish(result, part, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge(mailbox, seq, chal); }
+    if (tid == 0) { unsigned long long now = clock64(); c_sums += now - tk; tk = now; }
+    if (wave == 0) {
+      sc_publish(result, part, a.nterms, wpt, flag, seq, lane);
+      if (tid == 0) { unsigned long long now = clock64(); c_pub += now - tk; tk = now; }
+      if (lane == 0) sc_wait_challenge(mailbox, seq, chal);
+      if (tid == 0) { unsigned long long now = clock64(); c_wait += now - tk; tk = now; c_rounds++; }
+    }
     __syncthreads();
-    if (chal[0] == 0) { if (tid == 0) __hip_atomic_store(flag, ~0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+    if (chal[0] == 0) { if (tid == 0) pub_store((u64*)flag, ~0ull); return; }
     r = ex(chal[1], chal[2]);
     unsigned lgh = 0; while ((size_t(1) << lgh) < h) lgh++;
     for (size_t idx = tid; idx < (size_t)a.ntabs * h; idx += nt) {
@@ -949,8 +975,10 @@ __global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* r
 // copy a small device result into host-mapped memory and publish it
 // (launched with ONE wave so that payload stores and the releasing flag store come from the same wave)
 __global__ void k_publish(const u64* src, u64* dst, size_t nwords, unsigned long long* flag, unsigned long long seq) {
-  for (size_t i = threadIdx.x; i < nwords; i += blockDim.x) dst[i] = src[i];
-  if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  unsigned long long cs = 0;
+  for (size_t i = threadIdx.x; i < nwords; i += blockDim.x) { u64 v = src[i]; pub_store(dst + i, v); cs += (unsigned long long)(i + 1) * v; }
+  cs = pub_wave_sum(cs);
+  if (threadIdx.x == 0) pub_store((u64*)flag, pub_mix(seq) + cs);
 }
 
 // ================================================================================================ HipDev
@@ -986,8 +1014,10 @@ class HipDev : public Dev {
   unsigned long long* hflag_ = nullptr;      // host view of the publish sequence number
   unsigned long long* hflag_dev_ = nullptr;  // device view
   unsigned long long seq_ = 0;
+  unsigned long long last_tag_ = 0;
   bool zerocopy_ = true;  // DP_NO_ZEROCOPY=1 falls back to hipMemcpyAsync + hipStreamSynchronize
   bool persist_ = true;   // DP_NO_PERSIST=1 disables the persistent sumcheck kernel
+  unsigned long long* scdbg_ = nullptr;  // DP_SC_DEBUG=1: device cycle counters of the persistent sumcheck kernel
   unsigned long long* hmail_ = nullptr;      // host view of the challenge mailbox [seq, c0, c1]
   unsigned long long* hmail_dev_ = nullptr;  // device view
   struct ScSession { bool active = false; int ntabs = 0; size_t n = 0; unsigned long long seq = 0; std::vector<Ext*> a, b; bool nextA = true; } sess_;
@@ -1006,23 +1036,36 @@ class HipDev : public Dev {
     arena_off_ = off + bytes;
     return arena_ + off;
   }
-  // spin (bounded) until the device has published sequence number `seq` into host memory
-  void wait_flag(unsigned long long seq) {
+  static unsigned long long pub_mix(unsigned long long seq) { return seq * 0x9E3779B97F4A7C15ull + 0x7F4A7C159E3779B9ull; }
+  // spin (bounded) until the message with sequence number `seq` and `nwords` payload words has fully landed in host
+  // memory: the tag word must equal mix(seq) + sum (i+1)*word_i recomputed from what we read
+  void wait_flag(unsigned long long seq, size_t nwords) {
     volatile unsigned long long* f = hflag_;
+    volatile u64* w = hres_;
     auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
-    while (*f != seq) {
-      if (*f == ~0ull) throw DpError(DP_ERR_HIP, "device aborted a persistent sumcheck (no challenge received)");
-      if ((++spins & 0xFFFF) == 0) {
-        if (hipStreamQuery(s_) == hipSuccess && *f != seq) {  // stream drained but no flag: report instead of hanging
-          HIP_CHECK(hipStreamSynchronize(s_));
-          if (*f == seq) break;
-          throw DpError(DP_ERR_HIP, "zero-copy publish flag never arrived");
-        }
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0) throw DpError(DP_ERR_HIP, "timeout waiting for the device");
+    const unsigned long long base = pub_mix(seq);
+    for (;;) {
+      unsigned long long tag = *f;
+      if (tag == ~0ull) throw DpError(DP_ERR_HIP, "device aborted a persistent sumcheck (no challenge received)");
+      if (tag != last_tag_) {  // something new was written: check it against the payload
+        std::atomic_thread_fence(std::memory_order_acquire);
+        unsigned long long cs = 0;
+        for (size_t i = 0; i < nwords; i++) cs += (unsigned long long)(i + 1) * w[i];
+        if (base + cs == tag) { last_tag_ = tag; return; }
       }
+      __builtin_ia32_pause();
+      if ((++spins & 0xFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
+        throw DpError(DP_ERR_HIP, "timeout waiting for the device");
     }
-    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  // wait until everything queued on the stream so far has executed, without entering hipStreamSynchronize (which
+  // serialises against other host threads driving other proofs on the same GPU): a one-wave kernel posts a tag
+  void stream_wait() {
+    if (!zerocopy_) { HIP_CHECK(hipStreamSynchronize(s_)); return; }
+    unsigned long long seq = ++seq_;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s_, (const u64*)dres_, hres_dev_, (size_t)0, hflag_dev_, seq);
+    wait_flag(seq, 0);
   }
   // bring `nwords` of dres_ to hres_
   void fetch(size_t nwords) {
@@ -1030,7 +1073,7 @@ class HipDev : public Dev {
     if (zerocopy_) {
       unsigned long long seq = ++seq_;
       hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s_, (const u64*)dres_, hres_dev_, nwords, hflag_dev_, seq);
-      wait_flag(seq);
+      wait_flag(seq, nwords);
     } else {
       HIP_CHECK(hipMemcpyAsync(hres_, dres_, nwords * 8, hipMemcpyDeviceToHost, s_));
       HIP_CHECK(hipStreamSynchronize(s_));
@@ -1045,7 +1088,7 @@ class HipDev : public Dev {
   }
 
  public:
-  explicit HipDev(int device) : device_(device) {
+  explicit HipDev(int device, size_t arena_bytes = 0) : device_(device) {
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) throw DpError(DP_ERR_NODEVICE, "no HIP device available: the MI355X path is mandatory, there is no CPU fallback");
     DP_REQUIRE(device >= 0 && device < cnt, DP_ERR_ARG, "bad device id");
@@ -1055,7 +1098,7 @@ class HipDev : public Dev {
     name_ = std::string("hip:") + prop.name + ":" + prop.gcnArchName;
     HIP_CHECK(hipStreamCreateWithFlags(&s_, hipStreamNonBlocking));
     const char* env = getenv("DP_ARENA_BYTES");
-    arena_cap_ = env ? strtoull(env, nullptr, 10) : (size_t(12) << 30);
+    arena_cap_ = arena_bytes ? arena_bytes : env ? strtoull(env, nullptr, 10) : (size_t(12) << 30);
     HIP_CHECK(hipMalloc((void**)&arena_, arena_cap_));
     HIP_CHECK(hipHostMalloc((void**)&hres_, RES_WORDS * 8 + 256, hipHostMallocMapped | hipHostMallocCoherent));
     HIP_CHECK(hipHostGetDevicePointer((void**)&hres_dev_, hres_, 0));
@@ -1066,6 +1109,7 @@ class HipDev : public Dev {
     hmail_[0] = hmail_[1] = hmail_[2] = 0;
     zerocopy_ = !(getenv("DP_NO_ZEROCOPY") && atoi(getenv("DP_NO_ZEROCOPY")));
     persist_ = zerocopy_ && !(getenv("DP_NO_PERSIST") && atoi(getenv("DP_NO_PERSIST")));
+    if (getenv("DP_SC_DEBUG") && atoi(getenv("DP_SC_DEBUG"))) { HIP_CHECK(hipMalloc((void**)&scdbg_, 64)); HIP_CHECK(hipMemset(scdbg_, 0, 64)); }
     HIP_CHECK(hipMalloc((void**)&dres_, RES_WORDS * 8));
     HIP_CHECK(hipHostMalloc(&hstage_, STAGE_BYTES, hipHostMallocDefault));
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_rc), POSEIDON2_RC_HOST, sizeof(POSEIDON2_RC_HOST)));
@@ -1083,6 +1127,12 @@ class HipDev : public Dev {
     if (s_) hipStreamDestroy(s_);
   }
   const char* name() const override { return name_.c_str(); }
+  void dump_sc_debug() {
+    if (!scdbg_) return;
+    unsigned long long h[5]; hipStreamSynchronize(s_); hipMemcpy(h, scdbg_, 40, hipMemcpyDeviceToHost); hipMemset(scdbg_, 0, 64);
+    fprintf(stderr, "[dp sc-debug] rounds %llu: cycles/round fold %.0f sums %.0f publish %.0f wait-for-challenge %.0f\n", h[4], (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4]);
+  }
+  void bind_thread() override { HIP_CHECK(hipSetDevice(device_)); }
   hipStream_t stream() const { return s_; }
   // per-kernel HIP-event timing on the launch stream (bench.py roofline). report: name -> (launches, total ms, total bytes)
   void profile_enable(bool on) {
@@ -1128,14 +1178,14 @@ class HipDev : public Dev {
       size_t m = std::min(STAGE_BYTES, bytes - off);
       memcpy(hstage_, (const char*)src + off, m);
       HIP_CHECK(hipMemcpyAsync((char*)dst + off, hstage_, m, hipMemcpyHostToDevice, s_));
-      HIP_CHECK(hipStreamSynchronize(s_));
+      stream_wait();
     }
   }
   void d2h(void* dst, const void* src, size_t bytes) {
     for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
       size_t m = std::min(STAGE_BYTES, bytes - off);
       HIP_CHECK(hipMemcpyAsync(hstage_, (const char*)src + off, m, hipMemcpyDeviceToHost, s_));
-      HIP_CHECK(hipStreamSynchronize(s_));
+      stream_wait();
       memcpy((char*)dst + off, hstage_, m);
     }
   }
@@ -1146,13 +1196,13 @@ class HipDev : public Dev {
     int64_t* tmp = (int64_t*)arena_alloc(d.n * 8);
     h2d(tmp, src, d.n * 8);
     DPL(k_fieldize, dim3(grid_for(d.n)), dim3(TPB), tmp, (u64*)d.p, d.n);
-    HIP_CHECK(hipStreamSynchronize(s_));
+    stream_wait();
     release(mk);
   }
   void download(const DBuf& src, u64* dst) override { d2h(dst, src.p, src.bytes()); }
   void copy(const DBuf& d, const DBuf& s) override { HIP_CHECK(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, s_)); }
   void zero(const DBuf& d) override { HIP_CHECK(hipMemsetAsync(d.p, 0, d.bytes(), s_)); }
-  void sync() override { HIP_CHECK(hipStreamSynchronize(s_)); }
+  void sync() override { stream_wait(); }
 
   // ---- MLE
   void eq_table(const DBuf& out, const Ext* pt, unsigned k, Ext scale, bool acc) override {
@@ -1230,7 +1280,7 @@ class HipDev : public Dev {
     if (sess_.active) {  // the persistent kernel is waiting for this challenge
       DP_REQUIRE(r && nt == sess_.ntabs && n_in == sess_.n, DP_ERR_ARG, "sumcheck session out of sync");
       post_challenge(*r);
-      wait_flag(++sess_.seq);
+      wait_flag(++sess_.seq, (size_t)nterms * 8);
       sess_.n = n_after;
       for (int i = 0; i < nt; i++) { tabs[i].p = sess_.nextA ? sess_.a[i] : sess_.b[i]; tabs[i].n = n_after; tabs[i].ext = true; }
       sess_.nextA = !sess_.nextA;
@@ -1250,7 +1300,7 @@ class HipDev : public Dev {
         a.bufA[i] = sess_.a[i]; a.bufB[i] = sess_.b[i];
       }
       for (int i = 0; i < nterms; i++) { a.k[i] = terms[i].k; for (int j = 0; j < 3; j++) a.t[i][j] = terms[i].t[j]; }
-      a.ntabs = nt; a.nterms = nterms; a.has_r0 = r ? 1 : 0; a.n0 = n_in; a.r0 = r ? *r : ex_zero();
+      a.ntabs = nt; a.nterms = nterms; a.has_r0 = r ? 1 : 0; a.n0 = n_in; a.r0 = r ? *r : ex_zero(); a.dbg = scdbg_;
       sess_.active = true; sess_.ntabs = nt; sess_.n = n_after; sess_.seq = seq_; sess_.nextA = r ? false : true;
       // reserve the sequence numbers of all rounds + the final message
       unsigned rounds = 0; for (size_t m = n_after; m > 1; m >>= 1) rounds++;
@@ -1260,7 +1310,7 @@ class HipDev : public Dev {
       size_t lds = (size_t)nt * (n_in / 2) * 16;
       if (lds <= SC_LDS_MAX) { nb_ = 0; DPL_LDS(k_sc_persist_lds, dim3(1), dim3(threads), lds, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
       else { nb_ = 0; DPL(k_sc_persist, dim3(1), dim3(threads), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
-      wait_flag(++sess_.seq);
+      wait_flag(++sess_.seq, (size_t)nterms * 8);
       if (r) for (int i = 0; i < nt; i++) { tabs[i].p = sess_.a[i]; tabs[i].n = n_after; tabs[i].ext = true; }
       read_terms();
       return;
@@ -1280,7 +1330,7 @@ class HipDev : public Dev {
       size_t work = (size_t)nterms * (n_after / 2) + (r ? (size_t)nt * n_after / 4 : 0);
       int threads = work >= 2048 ? 1024 : work >= 512 ? 512 : 256;
       nb_ = bytes; DPL(k_sc_small, dim3(1), dim3(threads), a, (Ext*)hres_dev_, hflag_dev_, seq);
-      wait_flag(seq);
+      wait_flag(seq, (size_t)nterms * 8);
       size_t o = 0;
       for (int i = 0; i < nterms; i++)
         for (int t = 0; t <= terms[i].k; t++) out[o++] = ex(hres_[(i * 4 + t) * 2], hres_[(i * 4 + t) * 2 + 1]);
@@ -1310,7 +1360,7 @@ class HipDev : public Dev {
     if (sess_.active) {
       DP_REQUIRE(nt == sess_.ntabs && sess_.n == 2, DP_ERR_ARG, "sumcheck session out of sync at finish");
       post_challenge(r);
-      wait_flag(++sess_.seq);
+      wait_flag(++sess_.seq, (size_t)nt * 2);
       for (int i = 0; i < nt; i++) finals[i] = ex(hres_[2 * i], hres_[2 * i + 1]);
       sess_.active = false;
       return;
@@ -1540,7 +1590,7 @@ class HipDev : public Dev {
     if (r) {
       nb_ = [&] { double b = 0; for (int i = 0; i < np; i++) if (hd[i].fout) b += hd[i].n * (hd[i].fext ? 16.0 : 8.0) + hd[i].n * 16.0 + hd[i].n * 16.0; return b; }(); DPL(k_classic_fold, dim3(grid_for(maxn / 2, 1024), np), dim3(TPB), (const PolyDesc*)dd, *r);
       // descriptors for the sums: the folded tables
-      HIP_CHECK(hipStreamSynchronize(s_));  // hstage_ is reused below
+      stream_wait();  // hstage_ is reused below
       maxn = 1;
       for (int i = 0; i < np; i++) { hd[i].f = fs[i].p; hd[i].eq = (const Ext*)eqs[i].p; hd[i].n = fs[i].n; hd[i].fext = fs[i].ext; maxn = std::max(maxn, hd[i].n); }
       HIP_CHECK(hipMemcpyAsync(dd, hd, (size_t)np * sizeof(PolyDesc), hipMemcpyHostToDevice, s_));
@@ -1600,7 +1650,7 @@ class HipDev : public Dev {
     std::vector<GatherDesc> hcopy(hd, hd + nd);  // the staging buffer is reused by the download below
     hd = hcopy.data();
     std::vector<u64> flat(total);
-    HIP_CHECK(hipStreamSynchronize(s_));
+    stream_wait();
     d2h(flat.data(), dout, total * 8);
     for (size_t i = 0; i < nd; i++) {
       size_t len = (hd[i].ext ? 4 : 2) + 4 * (size_t)(hd[i].height - 1);
@@ -1611,6 +1661,8 @@ class HipDev : public Dev {
 };
 
 Dev* make_hip_dev(int device) { return new HipDev(device); }
+Dev* make_hip_worker(int device, size_t arena_bytes) { return new HipDev(device, arena_bytes); }
+void hip_dev_dump_sc_debug(Dev* d) { static_cast<HipDev*>(d)->dump_sc_debug(); }
 void hip_dev_profile_enable(Dev* d, bool on) { static_cast<HipDev*>(d)->profile_enable(on); }
 std::string hip_dev_profile_report(Dev* d) { return static_cast<HipDev*>(d)->profile_report(); }
 

@@ -3,6 +3,7 @@
 // reference); per round exactly one device->host message of raw per-term sums and one challenge back.
 #pragma once
 #include "proof.h"
+#include <chrono>
 
 namespace dp {
 
@@ -47,20 +48,21 @@ inline Ext lagrange_eval_small(const Ext* evals, size_t n, Ext at) {
 }
 // the prover only ever extrapolates from nodes 0..k (k <= 3) to the integer points k+1..3: those Lagrange
 // coefficients are constants, computed once
-inline const u64* extrapolation_coeffs(unsigned k, unsigned at) {  // returns k+1 base-field coefficients
-  static u64 table[4][5][4];
-  static bool ready = false;
-  if (!ready) {
+struct ExtrapolationTable {
+  u64 c[4][5][4];
+  ExtrapolationTable() {
     for (unsigned kk = 1; kk <= 3; kk++)
       for (unsigned a = kk + 1; a <= 4; a++)
         for (unsigned i = 0; i <= kk; i++) {
           u64 num = 1, den = 1;
           for (unsigned j = 0; j <= kk; j++) { if (j == i) continue; num = gl_mul(num, gl_sub(a, j)); den = gl_mul(den, gl_sub(i, j)); }
-          table[kk][a][i] = gl_mul(num, gl_inv(den));
+          c[kk][a][i] = gl_mul(num, gl_inv(den));
         }
-    ready = true;
   }
-  return table[k][at];
+};
+inline const u64* extrapolation_coeffs(unsigned k, unsigned at) {  // returns k+1 base-field coefficients
+  static const ExtrapolationTable table;  // thread-safe initialisation
+  return table.c[k][at];
 }
 inline Ext extrapolate_small(const Ext* evals, unsigned k, unsigned at) {
   const u64* c = extrapolation_coeffs(k, at);
@@ -70,6 +72,8 @@ inline Ext extrapolate_small(const Ext* evals, unsigned k, unsigned at) {
 }
 
 struct SumcheckOut { IOPProof proof; std::vector<Ext> finals; };
+struct ScStats { double dev_ms = 0, host_ms = 0; size_t rounds = 0; };
+inline ScStats& sc_stats() { static thread_local ScStats s; return s; }
 
 inline SumcheckOut sumcheck_prove(Dev& dev, DevVP& vp, Transcript& t) {
   SumcheckOut out;
@@ -84,7 +88,9 @@ inline SumcheckOut sumcheck_prove(Dev& dev, DevVP& vp, Transcript& t) {
   std::vector<Ext> raw(nraw);
   Ext ch = ex_zero();
   for (unsigned round = 0; round < nv; round++) {
+    auto tq0 = std::chrono::steady_clock::now();
     dev.sc_round(tabs.data(), (int)tabs.size(), round ? &ch : nullptr, vp.terms.data(), (int)vp.terms.size(), raw.data());
+    auto tq1 = std::chrono::steady_clock::now();
     std::vector<Ext> msg(md + 1, ex_zero());
     size_t off = 0;
     for (size_t ti = 0; ti < vp.terms.size(); ti++) {
@@ -101,6 +107,11 @@ inline SumcheckOut sumcheck_prove(Dev& dev, DevVP& vp, Transcript& t) {
     out.proof.proofs.push_back(msg);
     ch = t.get_and_append_challenge("Internal round");
     out.proof.point.push_back(ch);
+    auto tq2 = std::chrono::steady_clock::now();
+    ScStats& st = sc_stats();
+    st.dev_ms += std::chrono::duration<double, std::milli>(tq1 - tq0).count();
+    st.host_ms += std::chrono::duration<double, std::milli>(tq2 - tq1).count();
+    st.rounds++;
   }
   out.finals.resize(tabs.size());
   dev.sc_finish(tabs.data(), (int)tabs.size(), ch, out.finals.data());

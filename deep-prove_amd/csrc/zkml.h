@@ -389,9 +389,11 @@ inline Claim prove_relu(ProverState& ps, size_t id, const Claim& last, const std
 }
 
 // Prover::prove(trace). `tr` comes from run_model (inference is not part of proving time in the reference either).
-inline Proof prove(Context& ctx, const Trace& tr, Transcript& t) {
-  Dev& dev = *ctx.dev;
+// `dev` may be any device context on the GPU that holds `ctx` (the model commitments are only read), so several proofs
+// can be in flight at once, each on its own stream/arena (dp_model_prove_batch).
+inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t) {
   PhaseTimer pt;
+  sc_stats() = ScStats();
   size_t mk = dev.mark();
   ProverState ps; ps.ctx = &ctx; ps.dev = &dev; ps.t = &t;
   for (auto& kv : ctx.model_comms) for (auto& pc : kv.second) t.append_digest(pc.second.tree.root);
@@ -421,10 +423,13 @@ inline Proof prove(Context& ctx, const Trace& tr, Transcript& t) {
   for (auto& c : ps.claims) oc.push_back({&c.comm, c.claim.point, c.claim.eval});
   proof.batch_proof = pcs_batch_open(dev, ctx.full_log, oc, t);
   pt.lap("batch_open");
+  if (pt.on) fprintf(stderr, "[dp timing] sumcheck rounds %zu: device wait %.3f ms, host transcript+algebra %.3f ms\n", sc_stats().rounds, sc_stats().dev_ms, sc_stats().host_ms);
   proof.steps = ps.proofs;
   dev.release(mk);
   return proof;
 }
+
+inline Proof prove(Context& ctx, const Trace& tr, Transcript& t) { return prove(ctx, *ctx.dev, tr, t); }
 
 // ---- verifier (zkml/src/iop/verifier.rs:72-318; layers' verify fns; commit/context.rs:424-599)
 struct IO { std::vector<int64_t> input, output; };

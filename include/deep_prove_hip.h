@@ -117,6 +117,15 @@ int32_t dp_model_free(dp_model* m);
  * output receives the model output (capacity *noutput on entry, length on exit). prove_ms (nullable) = prove() wall ms */
 int32_t dp_model_prove(dp_model* m, const int64_t* input, size_t ninput, uint64_t** proof_words, size_t* proof_nwords,
                        int64_t* output, size_t* noutput, double* prove_ms);
+/* `nproofs` independent proofs (inputs concatenated, `ninput` words each) with up to `concurrency` proofs in flight on
+ * the model's GPU: every in-flight proof has its own host thread, HIP stream and arena; the model commitments are shared
+ * read-only. A single proof is a chain of ~10^3 sequential Fiat-Shamir round trips that cannot fill an MI355X, so this
+ * is how one GPU is saturated (and how BASELINE config 4, a batch of independent proofs, is served).
+ * proof_words / proof_nwords: arrays of nproofs entries (each buffer malloc'ed, release with dp_free);
+ * outputs: nproofs * noutput_cap words (nullable). */
+int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs, size_t ninput, int32_t concurrency,
+                             uint64_t** proof_words, size_t* proof_nwords, int64_t* outputs, size_t noutput_cap,
+                             size_t* noutput, double* wall_ms);
 /* serialisable verifier-side context (model commitments, shapes, tables) */
 int32_t dp_model_verifier_blob(const dp_model* m, uint64_t** words, size_t* nwords);
 /* zkml::verify(ctx, proof, io, transcript) — host only, default transcript "m2vec" */

@@ -97,3 +97,21 @@ def test_config2_dense4m_full_size(dev):
     assert hashlib.sha256(proof.tobytes()).hexdigest() == gold["sha256"]
     dpa.verify(ctx.verifier_blob(), proof, x, out)
     ctx.free()
+
+
+def test_concurrent_batch_matches_sequential(dev):
+    """dp_model_prove_batch: several proofs in flight on one GPU (own stream / arena each, shared model commitments)
+    give exactly the proofs the sequential path gives"""
+    import deep_prove_amd as dpa
+    mb = dpa.models.mlp(2, 64, config=41)
+    ctx = dpa.Context.generate(dev, mb.blob())
+    pr = dpa.Prover(ctx)
+    xs = np.stack([mb.input(2000 + i) for i in range(6)])
+    seq = [pr.prove(x) for x in xs]
+    proofs, outs, _ = pr.prove_batch(xs, 3)
+    vb = ctx.verifier_blob()
+    for i in range(len(xs)):
+        assert (outs[i] == seq[i][1]).all()
+        assert proofs[i].size == seq[i][0].size and (proofs[i] == seq[i][0]).all()
+        dpa.verify(vb, proofs[i], xs[i], outs[i])
+    ctx.free()
