@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="dense_4m", choices=["dense_4m", "mlp_w256"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sumcheck24", action="store_true", help="skip the standalone 2^24 sumcheck roofline section")
     ap.add_argument("--concurrency", type=int, default=0,
                     help="independent proofs in flight per GPU (0 = auto: host cores / ranks on this node, at most 16)")
     args = ap.parse_args()
@@ -129,8 +130,11 @@ def main():
             roofline["note"] = "Poseidon2 Merkle layers are VALU-integer bound (about 520 Goldilocks multiplications per permutation), not HBM bound"
             roofline["poseidon2_perm_per_s"] = round(perms / (dom["total_ms"] * 1e-3), 0)
         cpu = None
+        sc24 = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(mb)
+        if world == 1 and not args.no_sumcheck24:
+            sc24 = sumcheck24(dev, dpa)
         result = {
             "metric": "proofs/sec (prover), Dense-4M" if args.workload == "dense_4m" else "proofs/sec (prover), MLP-w256",
             "value": round(value, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -143,7 +147,7 @@ def main():
                        "single_proof_latency_ms": round(latency_ms, 2), "first_proof_ms": round(first_ms, 2), "host_cores": ncpu,
                        "parallelism": f"replicas x{world} GPUs x {conc} proofs in flight per GPU (independent proofs, no data-path collective)",
                        "proof_words": int(last[0].size), "setup_s": round(setup_s, 2), "verified": True, "device": dev.name},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "sumcheck24": sc24,
         }
         print(json.dumps(result))
     ctx.free()
@@ -151,6 +155,39 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     return result
+
+
+def sumcheck24(dev, dpa, nv=24, k=3):
+    """BASELINE config 5 on one GPU: standalone sumcheck of one product of k base-field MLEs with 2^nv entries
+    (sumcheck/benches/devirgo_sumcheck.rs shape). HBM roofline of the fused fold+sum kernel from HIP-event timings."""
+    import numpy as np
+    n = 1 << nv
+    tabs = [dpa.Mle.from_base(dev, dpa.models.splitmix64(0xD33B0000 ^ (5 << 32) ^ j, n) % np.uint64(dpa.P)) for j in range(k)]
+    vp = dpa.VirtualPolynomial(nv)
+    vp.add_mle_list(tabs)
+    dpa.prove_parallel(dev, vp, dpa.Transcript(b"test"))  # warm
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        dpa.prove_parallel(dev, vp, dpa.Transcript(b"test"))
+    wall_ms = 1000 * (time.perf_counter() - t0) / reps
+    dev.profile(True)
+    dpa.prove_parallel(dev, vp, dpa.Transcript(b"test"))
+    rep = dev.profile_report()
+    dev.profile(False)
+    for t in tabs:
+        t.free()
+    stream = [r for r in rep if r["kernel"].startswith("(k_sc_fused") or r["kernel"] == "k_sc_terms"]
+    ms = sum(r["total_ms"] for r in stream)
+    by = sum(r["alg_bytes"] for r in stream)
+    big = max(stream, key=lambda r: r["total_ms"])
+    big_gbs = (big["alg_bytes"] / big["launches"]) / (big["total_ms"] / big["launches"] * 1e-3) / 1e9
+    return {"workload": f"standalone sumcheck, one product of {k} base MLEs, 2^{nv} entries each (BASELINE config 5 on 1 GPU)",
+            "wall_ms": round(wall_ms, 3), "rounds": nv, "streaming_kernels_ms": round(ms, 3), "alg_bytes": by,
+            "alg_bytes_formula_48kN": 48 * k * n, "achieved_GBps_all_streaming_rounds": round(by / (ms * 1e-3) / 1e9, 1),
+            "dominant_kernel": big["kernel"], "dominant_kernel_GBps": round(big_gbs, 1), "frac_of_hbm_peak": round(big_gbs / HBM_PEAK_GBS, 4),
+            "kernels": [{"kernel": r["kernel"], "launches": r["launches"], "total_ms": round(r["total_ms"], 4),
+                         "GBps": round(r["alg_bytes"] / max(r["total_ms"], 1e-9) / 1e6, 1)} for r in sorted(rep, key=lambda r: -r["total_ms"])[:6]]}
 
 
 def cpu_baseline(mb):

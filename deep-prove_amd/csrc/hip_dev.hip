@@ -160,6 +160,28 @@ __global__ void k_sc_terms(TermArgs a, Ext* partial) {
   const void* p1 = a.tab[a.t[term][k > 1 ? 1 : 0]]; bool e1 = a.ext[a.t[term][k > 1 ? 1 : 0]];
   const void* p2 = a.tab[a.t[term][k > 2 ? 2 : 0]]; bool e2 = a.ext[a.t[term][k > 2 ? 2 : 0]];
   Ext acc0 = ex_zero(), acc1 = ex_zero(), acc2 = ex_zero(), acc3 = ex_zero();
+  if (!e0 && !e1 && !e2) {
+    // every factor is a base-field table (first round of a sumcheck over committed columns): stay in the base field,
+    // as the reference macro does (sumcheck_macro/src/lib.rs:283-296), one 16-byte load per table and pair
+    u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < a.npairs; b += (size_t)gridDim.x * blockDim.x) {
+      ulonglong2 x0 = ((const ulonglong2*)p0)[b];
+      if (k == 1) { s0 = gl_add(s0, x0.x); s1 = gl_add(s1, x0.y); }
+      else if (k == 2) {
+        ulonglong2 x1 = ((const ulonglong2*)p1)[b];
+        u64 c0 = gl_sub(gl_dbl(x0.y), x0.x), c1 = gl_sub(gl_dbl(x1.y), x1.x);
+        s0 = gl_add(s0, gl_mul(x0.x, x1.x)); s1 = gl_add(s1, gl_mul(x0.y, x1.y)); s2 = gl_add(s2, gl_mul(c0, c1));
+      } else {
+        ulonglong2 x1 = ((const ulonglong2*)p1)[b], x2 = ((const ulonglong2*)p2)[b];
+        u64 d0 = gl_sub(x0.y, x0.x), d1 = gl_sub(x1.y, x1.x), d2 = gl_sub(x2.y, x2.x);
+        u64 c0 = gl_add(x0.y, d0), c1 = gl_add(x1.y, d1), c2 = gl_add(x2.y, d2);
+        u64 g0 = gl_add(c0, d0), g1 = gl_add(c1, d1), g2 = gl_add(c2, d2);
+        s0 = gl_add(s0, gl_mul(gl_mul(x0.x, x1.x), x2.x)); s1 = gl_add(s1, gl_mul(gl_mul(x0.y, x1.y), x2.y));
+        s2 = gl_add(s2, gl_mul(gl_mul(c0, c1), c2)); s3 = gl_add(s3, gl_mul(gl_mul(g0, g1), g2));
+      }
+    }
+    acc0 = ex_base(s0); acc1 = ex_base(s1); acc2 = ex_base(s2); acc3 = ex_base(s3);
+  } else
   for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < a.npairs; b += (size_t)gridDim.x * blockDim.x) {
     Ext a0 = ld_elem(p0, e0, 2 * b), b0 = ld_elem(p0, e0, 2 * b + 1);
     if (k == 1) {
@@ -197,6 +219,55 @@ __global__ void k_reduce_terms(const Ext* partial, size_t nblocks, Ext* out) {
   for (size_t b = threadIdx.x; b < nblocks; b += blockDim.x) acc = ex_add(acc, partial[(term * nblocks + b) * 4 + t]);
   Ext r = block_reduce_ext(acc, sm);
   if (threadIdx.x == 0) out[blockIdx.x] = r;
+}
+// K3' (SURVEY.md 2.3): fused fold + round sums for ONE product of K equally typed large tables. Each lane takes 4
+// consecutive elements of every table (32 contiguous bytes for base tables, 64 for extension tables), folds them with r
+// into 2 values, stores those (32 contiguous bytes) and immediately accumulates the next round's sums on that pair —
+// every table byte is read once and every folded byte written once per round (the unfused path reads the folded
+// table a second time). partial[block*4 + t] = sum over the block's pairs of prod_j (f0_j + t (f1_j - f0_j)).
+template <int K, bool BASE>
+__global__ void __launch_bounds__(256) k_sc_fused(const void* in0, const void* in1, const void* in2, Ext* out0, Ext* out1, Ext* out2,
+                                                  size_t nquads, Ext r, Ext* partial) {
+  __shared__ Ext sm[TPB / 64];
+  const void* in[3] = {in0, in1, in2};
+  Ext* out[3] = {out0, out1, out2};
+  Ext acc0 = ex_zero(), acc1 = ex_zero(), acc2 = ex_zero(), acc3 = ex_zero();
+  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < nquads; q += (size_t)gridDim.x * blockDim.x) {
+    Ext f0[K], f1[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      if (BASE) {
+        const ulonglong2* p = (const ulonglong2*)((const u64*)in[j] + 4 * q);
+        ulonglong2 a = p[0], b = p[1];
+        f0[j] = ex_lerp_base(a.x, a.y, r);
+        f1[j] = ex_lerp_base(b.x, b.y, r);
+      } else {
+        const Ext* p = (const Ext*)in[j] + 4 * q;
+        Ext e0 = p[0], e1 = p[1], e2 = p[2], e3 = p[3];
+        f0[j] = ex_lerp(e0, e1, r);
+        f1[j] = ex_lerp(e2, e3, r);
+      }
+      out[j][2 * q] = f0[j];
+      out[j][2 * q + 1] = f1[j];
+    }
+    if (K == 1) { acc0 = ex_add(acc0, f0[0]); acc1 = ex_add(acc1, f1[0]); }
+    else if (K == 2) {
+      Ext c0 = ex_sub(ex_dbl(f1[0]), f0[0]), c1 = ex_sub(ex_dbl(f1[1]), f0[1]);
+      acc0 = ex_add(acc0, ex_mul(f0[0], f0[1])); acc1 = ex_add(acc1, ex_mul(f1[0], f1[1])); acc2 = ex_add(acc2, ex_mul(c0, c1));
+    } else {
+      Ext d0 = ex_sub(f1[0], f0[0]), d1 = ex_sub(f1[1], f0[1]), d2 = ex_sub(f1[2], f0[2]);
+      Ext c0 = ex_add(f1[0], d0), c1 = ex_add(f1[1], d1), c2 = ex_add(f1[2], d2);
+      Ext g0 = ex_add(c0, d0), g1 = ex_add(c1, d1), g2 = ex_add(c2, d2);
+      acc0 = ex_add(acc0, ex_mul(ex_mul(f0[0], f0[1]), f0[2])); acc1 = ex_add(acc1, ex_mul(ex_mul(f1[0], f1[1]), f1[2]));
+      acc2 = ex_add(acc2, ex_mul(ex_mul(c0, c1), c2)); acc3 = ex_add(acc3, ex_mul(ex_mul(g0, g1), g2));
+    }
+  }
+  size_t base = (size_t)blockIdx.x * 4;
+  Ext v;
+  v = block_reduce_ext(acc0, sm); if (threadIdx.x == 0) partial[base + 0] = v;
+  v = block_reduce_ext(acc1, sm); if (threadIdx.x == 0) partial[base + 1] = v;
+  v = block_reduce_ext(acc2, sm); if (threadIdx.x == 0) partial[base + 2] = v;
+  v = block_reduce_ext(acc3, sm); if (threadIdx.x == 0) partial[base + 3] = v;
 }
 // last fold of a sumcheck: every table has 2 elements; results go to one contiguous array
 __global__ void k_finish(FoldArgs a, Ext r, int ntabs, Ext* out) {
@@ -1336,6 +1407,37 @@ class HipDev : public Dev {
         for (int t = 0; t <= terms[i].k; t++) out[o++] = ex(hres_[(i * 4 + t) * 2], hres_[(i * 4 + t) * 2 + 1]);
       return;
     }
+    if (r && nterms == 1 && terms[0].k == nt && n_in >= 8) {
+      bool uniform = true, distinct = true;
+      for (int i = 0; i < nt; i++) { uniform &= tabs[i].ext == tabs[0].ext; for (int j = 0; j < i; j++) distinct &= terms[0].t[i] != terms[0].t[j]; }
+      if (uniform && distinct) {
+        const void* in[3] = {nullptr, nullptr, nullptr}; Ext* outp[3] = {nullptr, nullptr, nullptr};
+        bool base = !tabs[0].ext;
+        double bytes = 0;
+        for (int j = 0; j < nt; j++) {
+          int ti = terms[0].t[j];
+          DBuf o = alloc(n_after, true);
+          in[j] = tabs[ti].p; outp[j] = (Ext*)o.p;
+          bytes += tabs[ti].bytes() + o.bytes();
+          tabs[ti] = o;
+        }
+        size_t nquads = n_in / 4;
+        size_t mk = mark();
+        int g = (int)std::min<size_t>((nquads + TPB - 1) / TPB, 4096);
+        Ext* partial = (Ext*)arena_alloc((size_t)g * 4 * 16);
+        nb_ = bytes;
+        #define LAUNCH_FUSED(KK, BB) DPL((k_sc_fused<KK, BB>), dim3(g), dim3(TPB), in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial)
+        if (nt == 1) { if (base) LAUNCH_FUSED(1, true); else LAUNCH_FUSED(1, false); }
+        else if (nt == 2) { if (base) LAUNCH_FUSED(2, true); else LAUNCH_FUSED(2, false); }
+        else { if (base) LAUNCH_FUSED(3, true); else LAUNCH_FUSED(3, false); }
+        #undef LAUNCH_FUSED
+        DPL(k_reduce_terms, dim3(4), dim3(TPB), (const Ext*)partial, (size_t)g, (Ext*)dres_);
+        fetch(8);
+        for (int t = 0; t <= terms[0].k; t++) out[t] = ex(hres_[2 * t], hres_[2 * t + 1]);
+        release(mk);
+        return;
+      }
+    }
     if (r) fold_tables(tabs, nt, *r);
     size_t n = tabs[0].n;
     TermArgs a;
@@ -1345,7 +1447,7 @@ class HipDev : public Dev {
     for (int i = 0; i < nterms; i++) { a.k[i] = terms[i].k; for (int j = 0; j < 3; j++) a.t[i][j] = terms[i].t[j]; }
     a.npairs = n / 2;
     size_t mk = mark();
-    int g = grid_for(a.npairs, 512);
+    int g = grid_for(a.npairs, 2048);
     Ext* partial = (Ext*)arena_alloc((size_t)nterms * g * 4 * 16);
     nb_ = [&] { double b = 0; for (int i = 0; i < nterms; i++) for (int j = 0; j < terms[i].k; j++) b += tabs[terms[i].t[j]].bytes(); return b; }(); DPL(k_sc_terms, dim3(g, nterms), dim3(TPB), a, partial);
     DPL(k_reduce_terms, dim3(nterms * 4), dim3(TPB), partial, (size_t)g, (Ext*)dres_);

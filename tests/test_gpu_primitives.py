@@ -78,6 +78,11 @@ SC_CASES = [
     (13, [True, True, True, True, True], [((1, 0), [0, 1, 4]), ((1, 0), [0, 3, 2]), ((7, 7), [0, 2, 4])]),  # logup layer shape
     (10, [True, True, True], [((P - 1, 0), [0, 2]), ((P - 1, 0), [0, 1]), ((11, 13), [0, 1, 2])]),         # initial lookup layer shape
     (16, [False, True], [((1, 0), [0, 1])]),
+    # large single products: the fused fold+sum streaming kernel (K3'), then the persistent kernel for the tail
+    (17, [False, False, False], [((1, 0), [0, 1, 2])]),
+    (16, [True, True], [((3, 5), [0, 1])]),
+    (18, [True], [((1, 0), [0])]),
+    (19, [False, False], [((1, 0), [1, 0])]),
 ]
 
 
