@@ -26,6 +26,34 @@ def shard(total, world, rank):
     return list(range(rank, total, world))
 
 
+def timed_region(prove_batch, my_inputs, conc, steps, warmup, dist=None, device_sync=None, reduce_device="cpu"):
+    """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + device sync on both sides; returns
+    (MAX over ranks of the elapsed seconds, result of the last step). A step = one batch of `conc` proofs."""
+    import torch
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        if device_sync is not None:
+            device_sync()
+
+    for i in range(warmup):
+        prove_batch(my_inputs[i * conc:(i + 1) * conc])
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(steps):
+        lo = (warmup + i) * conc
+        last = prove_batch(my_inputs[lo:lo + conc])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    return elapsed, last
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,12 +99,6 @@ def main():
     per_rank = (args.steps + args.warmup) * conc
     my_inputs = np.stack([mb.input(1000 + i) for i in shard(world * per_rank, world, rank)])
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-
     # single-proof latency (sequential, one proof in flight) — reported next to the throughput
     t0 = time.perf_counter()
     prover.prove(my_inputs[0])
@@ -84,20 +106,9 @@ def main():
     t0 = time.perf_counter()
     prover.prove(my_inputs[0])
     latency_ms = 1000 * (time.perf_counter() - t0)
-    for i in range(args.warmup):
-        prover.prove_batch(my_inputs[i * conc:(i + 1) * conc], conc)
-    barrier()
-    t0 = time.perf_counter()
-    last = None
-    for i in range(args.steps):
-        lo = (args.warmup + i) * conc
-        last = prover.prove_batch(my_inputs[lo:lo + conc], conc)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    elapsed, last = timed_region(lambda xs: prover.prove_batch(xs, conc), my_inputs, conc, args.steps, args.warmup, dist,
+                                 torch.cuda.synchronize if torch.cuda.is_available() else None,
+                                 "cuda" if torch.cuda.is_available() else "cpu")
     # every proof of the last batch must verify (host verifier) — an invalid proof voids the measurement
     lo = (args.warmup + args.steps - 1) * conc
     for j in range(conc):
