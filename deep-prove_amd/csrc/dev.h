@@ -86,6 +86,11 @@ class Dev {
   // ---- MLE primitives
   // K4: out[idx] (+)= scale * prod_t (idx_t ? pt[t] : 1 - pt[t])
   virtual void eq_table(const DBuf& out, const Ext* pt, unsigned k, Ext scale, bool accumulate) = 0;
+  // many plain eq tables (scale 1, no accumulation) in one submission — batch_open builds one per opened polynomial
+  struct EqJob { DBuf out; const Ext* pt; unsigned k; };
+  virtual void eq_table_many(const EqJob* jobs, size_t n) {
+    for (size_t i = 0; i < n; i++) eq_table(jobs[i].out, jobs[i].pt, jobs[i].k, ex_one(), false);
+  }
   // K1 chain collapsed to one pass: out[i] = sum_x fs[i](x) * eq(x, pt)
   virtual void mle_eval_batch(const DBuf* fs, int nf, const Ext* pt, unsigned k, Ext* out) = 0;
   // K2 in one pass: out[c] = sum_r eq(r, pt) * W[r*C + c]      (W base field, R = 2^k rows)
@@ -136,6 +141,13 @@ class Dev {
   virtual void classic_round(DBuf* fs, DBuf* eqs, int np, const Ext* r, Ext* out) = 0;
   // K11: acc[j*rep + q] += x[j] * coeff  for q < rep
   virtual void axpy_rep(const DBuf& acc, const DBuf& x, Ext coeff, size_t rep) = 0;
+  // K11 batched: acc = (init ? *init : 0) + sum_d rep_d(x_d) * coeff_d in one pass over acc (field addition is exact,
+  // so the order of accumulation does not matter)
+  struct AxpyJob { DBuf x; Ext coeff; size_t rep; };
+  virtual void axpy_many(const DBuf& acc, const DBuf* init, const AxpyJob* jobs, size_t n) {
+    if (init) copy(acc, *init); else zero(acc);
+    for (size_t i = 0; i < n; i++) axpy_rep(acc, jobs[i].x, jobs[i].coeff, jobs[i].rep);
+  }
   // K10: (optionally) fold the evaluation-form pair arrays with ch, then (optionally) the coefficient-form message
   virtual void bf_round(DBuf& eq, DBuf& f, const Ext* ch, Ext* msg3) = 0;
   // K9: FRI fold of a bit-reversed codeword of length 2^(level+1)

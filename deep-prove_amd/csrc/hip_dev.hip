@@ -521,6 +521,16 @@ __global__ void k_query_gather(const GatherDesc* d, size_t nd, u64* out) {
 }
 
 
+// ---- relaxed system-scope publication helpers (see sc_publish below)
+__device__ __forceinline__ unsigned long long pub_mix(unsigned long long seq) { return seq * 0x9E3779B97F4A7C15ull + 0x7F4A7C159E3779B9ull; }
+__device__ __forceinline__ void pub_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// one wave: lane l owns words l, l+64, ...; returns (on lane 0) the payload checksum
+__device__ __forceinline__ unsigned long long pub_wave_sum(unsigned long long local) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) local += shfl_down_u64(local, d);
+  return local;
+}
+
 // ------------------------------------------------------------------------------------------------ lane-parallel Poseidon2
 // One permutation spread over 8 adjacent lanes (lane i holds state[i]): used where there are too few hashes to fill
 // the machine with one-hash-per-lane (the top layers of every Merkle tree), cutting the serial latency of a compress
@@ -584,7 +594,7 @@ __global__ void __launch_bounds__(1024) k_merkle_layer_lp(const u64* in, u64* ou
 struct TailDesc { u64* nodes; size_t off; size_t cnt; };
 // All Merkle layers above an already computed layer of `cnt` (<= 2048) digests, one workgroup per tree, no relaunch
 // between layers. Wide layers hash one node per lane, narrow ones use the 8-lane permutation. roots[4*tree..] = root.
-__global__ void __launch_bounds__(1024) k_merkle_tail(const TailDesc* d, u64* roots) {
+__global__ void __launch_bounds__(1024) k_merkle_tail(const TailDesc* d, u64* roots, u64* host_result, unsigned long long* flag, unsigned long long seq) {
   TailDesc t = d[blockIdx.x];
   u64* nd = t.nodes;
   size_t off = t.off, cnt = t.cnt;
@@ -606,6 +616,12 @@ __global__ void __launch_bounds__(1024) k_merkle_tail(const TailDesc* d, u64* ro
     off += cnt; cnt = next;
   }
   if (tid < 4) roots[4 * blockIdx.x + tid] = nd[4 * off + tid];
+  if (host_result && tid < 64) {  // single tree: publish the root (4 words) directly
+    unsigned long long cs = 0;
+    if (tid < 4) { u64 v = nd[4 * off + tid]; pub_store(host_result + tid, v); cs = (unsigned long long)(tid + 1) * v; }
+    cs = pub_wave_sum(cs);
+    if (tid == 0) pub_store((u64*)flag, pub_mix(seq) + cs);
+  }
 }
 struct SmallCommitDesc { const void* evals; void* cw; void* bh; u64* nodes; };
 // layer 0 of many equally sized trees: blockIdx.y = tree
@@ -684,14 +700,6 @@ __global__ void __launch_bounds__(256) k_commit_small(const SmallCommitDesc* d, 
 }
 
 // ------------------------------------------------------------------------------------------------ single-launch sumcheck round
-__device__ __forceinline__ unsigned long long pub_mix(unsigned long long seq) { return seq * 0x9E3779B97F4A7C15ull + 0x7F4A7C159E3779B9ull; }
-__device__ __forceinline__ void pub_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-// one wave: lane l owns words l, l+64, ...; returns (on lane 0) the payload checksum
-__device__ __forceinline__ unsigned long long pub_wave_sum(unsigned long long local) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) local += shfl_down_u64(local, d);
-  return local;
-}
 __device__ void sc_publish_fwd(Ext* result, const Ext* part, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane);
 __device__ void sc_wait_challenge_fwd(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal);
 struct ScSmallArgs {
@@ -1043,6 +1051,61 @@ __global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* r
   }
 }
 
+// out[e] = sum_{b < nblocks} partial[(e / inner) * nblocks * inner + b * inner + (e % inner)], e < nout, computed by ONE
+// workgroup (wave w owns outputs w, w+W, ..) and published straight to host-mapped memory with the tag protocol: the
+// second stage of every block-partial reduction needs neither a separate publish launch nor a stream synchronisation.
+__global__ void __launch_bounds__(1024) k_reduce_publish(const Ext* partial, size_t nblocks, size_t inner, int nout, Ext* result, unsigned long long* flag, unsigned long long seq) {
+  __shared__ Ext res[1024];
+  int tid = threadIdx.x, W = blockDim.x >> 6, wave = tid >> 6, lane = tid & 63;
+  for (int e = wave; e < nout; e += W) {
+    size_t base = ((size_t)e / inner) * nblocks * inner + ((size_t)e % inner);
+    Ext acc = ex_zero();
+    for (size_t b = lane; b < nblocks; b += 64) acc = ex_add(acc, partial[base + b * inner]);
+    acc = wave_reduce_ext(acc);
+    if (lane == 0) res[e] = acc;
+  }
+  __syncthreads();
+  if (wave == 0) sc_publish_vals(result, res, 1, nout, flag, seq, lane);
+}
+struct EqDesc { Ext* out; unsigned k; unsigned pad; Ext pt[MAX_PT]; };
+// many eq tables in one launch: blockIdx.y selects the table (batch_open builds one per opened polynomial)
+__global__ void k_eq_table_many(const EqDesc* d) {
+  const EqDesc& e = d[blockIdx.y];
+  size_t n = size_t(1) << e.k;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Ext v = ex_one();
+    for (unsigned t = 0; t < e.k; t++) { Ext r = e.pt[t]; v = ex_mul(v, ((i >> t) & 1) ? r : ex_sub(ex_one(), r)); }
+    e.out[i] = v;
+  }
+}
+struct AxpyDesc { const void* x; int xext; unsigned lg_rep; size_t n_x; Ext coeff; };
+// acc[i] = init[i] (or 0) + sum_d x_d[i >> lg_rep_d] * coeff_d over all descriptors (K11: every codeword / evaluation table merged into
+// the running oracle in ONE pass over acc instead of one launch and one read-modify-write of acc per polynomial)
+__global__ void k_axpy_many(Ext* acc, const Ext* init, size_t n_acc, const AxpyDesc* d, int nd) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_acc; i += (size_t)gridDim.x * blockDim.x) {
+    Ext a = init ? init[i] : ex_zero();
+    for (int q = 0; q < nd; q++) {
+      size_t j = i >> d[q].lg_rep;
+      Ext m = d[q].xext ? ex_mul(((const Ext*)d[q].x)[j], d[q].coeff) : ex_mul_base(d[q].coeff, ((const u64*)d[q].x)[j]);
+      a = ex_add(a, m);
+    }
+    acc[i] = a;
+  }
+}
+// last fold of a sumcheck, results published directly
+__global__ void k_finish_publish(FoldArgs a, Ext r, int ntabs, Ext* result, unsigned long long* flag, unsigned long long seq) {
+  __shared__ Ext res[MAX_TABS];
+  int t = threadIdx.x;
+  if (t < ntabs) {
+    Ext v;
+    if (a.ext[t]) { const Ext* p = (const Ext*)a.in[t]; v = ex_lerp(p[0], p[1], r); }
+    else { const u64* p = (const u64*)a.in[t]; v = ex_lerp_base(p[0], p[1], r); }
+    res[t] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) sc_publish_vals(result, res, 1, ntabs, flag, seq, threadIdx.x);
+}
+
 // copy a small device result into host-mapped memory and publish it
 // (launched with ONE wave so that payload stores and the releasing flag store come from the same wave)
 __global__ void k_publish(const u64* src, u64* dst, size_t nwords, unsigned long long* flag, unsigned long long seq) {
@@ -1053,10 +1116,14 @@ __global__ void k_publish(const u64* src, u64* dst, size_t nwords, unsigned long
 }
 
 // ================================================================================================ HipDev
+// Grid size for grid-stride kernels. DP_MAX_GRID bounds every launch so that, with several proofs in flight on one GPU,
+// a large kernel of one proof cannot occupy every wave slot while another proof's latency-critical one-block kernels
+// wait for a CU.
+static int g_max_grid = [] { const char* e = getenv("DP_MAX_GRID"); return e ? atoi(e) : 1 << 30; }();
 static inline int grid_for(size_t n, int cap = 2048) {
   size_t b = (n + TPB - 1) / TPB;
   if (b < 1) b = 1;
-  return (int)std::min<size_t>(b, cap);
+  return (int)std::min<size_t>(std::min<size_t>(b, cap), (size_t)g_max_grid);
 }
 
 struct ProfRec { const char* name; double bytes; hipEvent_t a, b; };
@@ -1093,9 +1160,12 @@ class HipDev : public Dev {
   unsigned long long* hmail_dev_ = nullptr;  // device view
   struct ScSession { bool active = false; int ntabs = 0; size_t n = 0; unsigned long long seq = 0; std::vector<Ext*> a, b; bool nextA = true; } sess_;
   u64* dres_ = nullptr;   // device result buffer
-  void* hstage_ = nullptr;  // pinned staging for descriptor uploads
+  void* hstage_ = nullptr;  // pinned + device-mapped staging: [0, DESC_BYTES) descriptor ring read by kernels over PCIe, rest = bulk copies
+  char* hstage_dev_ = nullptr;
+  size_t desc_off_ = 0;
   static constexpr size_t RES_WORDS = 1 << 16;
   static constexpr size_t STAGE_BYTES = 64 << 20;
+  static constexpr size_t DESC_BYTES = 4 << 20;
   unsigned L_ = 0;  // full_message_size_log of the current PCS parameters
   u64* tw_ = nullptr;    // tw[i]   = w_{2^(L+1)}^i, i < 2^L   (all FFT root tables of rs.rs:31-68 in one array)
   u64* pow7_ = nullptr;  // pow7[i] = 7^i,          i < 2^L   (coset shifts)
@@ -1123,27 +1193,55 @@ class HipDev : public Dev {
         std::atomic_thread_fence(std::memory_order_acquire);
         unsigned long long cs = 0;
         for (size_t i = 0; i < nwords; i++) cs += (unsigned long long)(i + 1) * w[i];
-        if (base + cs == tag) { last_tag_ = tag; return; }
+        if (base + cs == tag) { last_tag_ = tag; desc_off_ = 0; return; }
       }
       __builtin_ia32_pause();
       if ((++spins & 0xFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
         throw DpError(DP_ERR_HIP, "timeout waiting for the device");
     }
   }
+  // descriptors for batched kernels: written by the host into the mapped ring and read by the kernel directly (no
+  // H2D copy launch). The ring is recycled whenever the host has observed a publication, i.e. the stream is drained.
+  template <class T> T* desc_alloc(size_t count, const T** dev_view) {
+    size_t bytes = (count * sizeof(T) + 63) & ~size_t(63);
+    DP_REQUIRE(bytes <= DESC_BYTES, DP_ERR_SHAPE, "descriptor batch too large");
+    if (desc_off_ + bytes > DESC_BYTES) { stream_wait(); }
+    T* h = (T*)((char*)hstage_ + desc_off_);
+    *dev_view = (const T*)(hstage_dev_ + desc_off_);
+    desc_off_ += bytes;
+    return h;
+  }
+  char* bulk_stage() { return (char*)hstage_ + DESC_BYTES; }
   // wait until everything queued on the stream so far has executed, without entering hipStreamSynchronize (which
   // serialises against other host threads driving other proofs on the same GPU): a one-wave kernel posts a tag
   void stream_wait() {
-    if (!zerocopy_) { HIP_CHECK(hipStreamSynchronize(s_)); return; }
+    if (!zerocopy_) { HIP_CHECK(hipStreamSynchronize(s_)); desc_off_ = 0; return; }
     unsigned long long seq = ++seq_;
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s_, (const u64*)dres_, hres_dev_, (size_t)0, hflag_dev_, seq);
+    nb_ = 0; DPL(k_publish, dim3(1), dim3(64), (const u64*)dres_, hres_dev_, (size_t)0, hflag_dev_, seq);
     wait_flag(seq, 0);
+  }
+  // second stage of a block-partial reduction, published straight to hres_ (see k_reduce_publish); nout <= 1024
+  void reduce_publish(const Ext* partial, size_t nblocks, size_t inner, int nout) {
+    DP_REQUIRE(nout >= 1 && nout <= 1024 && (size_t)nout * 2 <= RES_WORDS, DP_ERR_SHAPE, "reduce_publish: too many outputs");
+    if (!zerocopy_) {
+      if (inner == 4 && nout % 4 == 0 && nout > 4) DPL(k_reduce_terms, dim3(nout), dim3(TPB), partial, nblocks, (Ext*)dres_);
+      else if (inner == 2) DPL(k_reduce_pairs, dim3(nout), dim3(TPB), partial, nblocks, (Ext*)dres_);
+      else if (inner == 4 && nout <= 4) DPL(k_reduce_terms, dim3(4), dim3(TPB), partial, nblocks, (Ext*)dres_);
+      else DPL(k_reduce_partials, dim3(nout), dim3(TPB), partial, nblocks, inner, (Ext*)dres_);
+      fetch((size_t)nout * 2);
+      return;
+    }
+    unsigned long long seq = ++seq_;
+    int threads = nout >= 8 ? 1024 : nout >= 4 ? 256 : 64 * nout;
+    DPL(k_reduce_publish, dim3(1), dim3(threads), partial, nblocks, inner, nout, (Ext*)hres_dev_, hflag_dev_, seq);
+    wait_flag(seq, (size_t)nout * 2);
   }
   // bring `nwords` of dres_ to hres_
   void fetch(size_t nwords) {
     DP_REQUIRE(nwords <= RES_WORDS, DP_ERR_ARG, "result too large");
     if (zerocopy_) {
       unsigned long long seq = ++seq_;
-      hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s_, (const u64*)dres_, hres_dev_, nwords, hflag_dev_, seq);
+      nb_ = 0; DPL(k_publish, dim3(1), dim3(64), (const u64*)dres_, hres_dev_, nwords, hflag_dev_, seq);
       wait_flag(seq, nwords);
     } else {
       HIP_CHECK(hipMemcpyAsync(hres_, dres_, nwords * 8, hipMemcpyDeviceToHost, s_));
@@ -1182,7 +1280,9 @@ class HipDev : public Dev {
     persist_ = zerocopy_ && !(getenv("DP_NO_PERSIST") && atoi(getenv("DP_NO_PERSIST")));
     if (getenv("DP_SC_DEBUG") && atoi(getenv("DP_SC_DEBUG"))) { HIP_CHECK(hipMalloc((void**)&scdbg_, 64)); HIP_CHECK(hipMemset(scdbg_, 0, 64)); }
     HIP_CHECK(hipMalloc((void**)&dres_, RES_WORDS * 8));
-    HIP_CHECK(hipHostMalloc(&hstage_, STAGE_BYTES, hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc(&hstage_, STAGE_BYTES + DESC_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_CHECK(hipHostGetDevicePointer((void**)&hstage_dev_, hstage_, 0));
+    hstage_dev_ += 0;
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_rc), POSEIDON2_RC_HOST, sizeof(POSEIDON2_RC_HOST)));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_persist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS_MAX));
   }
@@ -1247,17 +1347,17 @@ class HipDev : public Dev {
   void h2d(void* dst, const void* src, size_t bytes) {
     for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
       size_t m = std::min(STAGE_BYTES, bytes - off);
-      memcpy(hstage_, (const char*)src + off, m);
-      HIP_CHECK(hipMemcpyAsync((char*)dst + off, hstage_, m, hipMemcpyHostToDevice, s_));
+      memcpy(bulk_stage(), (const char*)src + off, m);
+      nb_ = 0; prof_begin("memcpy_h2d"); HIP_CHECK(hipMemcpyAsync((char*)dst + off, bulk_stage(), m, hipMemcpyHostToDevice, s_)); prof_end();
       stream_wait();
     }
   }
   void d2h(void* dst, const void* src, size_t bytes) {
     for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
       size_t m = std::min(STAGE_BYTES, bytes - off);
-      HIP_CHECK(hipMemcpyAsync(hstage_, (const char*)src + off, m, hipMemcpyDeviceToHost, s_));
+      nb_ = 0; prof_begin("memcpy_d2h"); HIP_CHECK(hipMemcpyAsync(bulk_stage(), (const char*)src + off, m, hipMemcpyDeviceToHost, s_)); prof_end();
       stream_wait();
-      memcpy((char*)dst + off, hstage_, m);
+      memcpy((char*)dst + off, bulk_stage(), m);
     }
   }
   void upload(const DBuf& d, const u64* src) override { h2d(d.p, src, d.bytes()); }
@@ -1271,11 +1371,26 @@ class HipDev : public Dev {
     release(mk);
   }
   void download(const DBuf& src, u64* dst) override { d2h(dst, src.p, src.bytes()); }
-  void copy(const DBuf& d, const DBuf& s) override { HIP_CHECK(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, s_)); }
-  void zero(const DBuf& d) override { HIP_CHECK(hipMemsetAsync(d.p, 0, d.bytes(), s_)); }
+  void copy(const DBuf& d, const DBuf& s) override { nb_ = 2.0 * s.bytes(); prof_begin("memcpy_d2d"); HIP_CHECK(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, s_)); prof_end(); }
+  void zero(const DBuf& d) override { nb_ = (double)d.bytes(); prof_begin("memset"); HIP_CHECK(hipMemsetAsync(d.p, 0, d.bytes(), s_)); prof_end(); }
   void sync() override { stream_wait(); }
 
   // ---- MLE
+  void eq_table_many(const EqJob* jobs, size_t n) override {
+    if (!n) return;
+    if (n * sizeof(EqDesc) + 64 > DESC_BYTES) { Dev::eq_table_many(jobs, n); return; }
+    const EqDesc* dd = nullptr;
+    EqDesc* hd = desc_alloc<EqDesc>(n, &dd);
+    size_t maxn = 1; double bytes = 0;
+    for (size_t i = 0; i < n; i++) {
+      const EqJob& j = jobs[i];
+      DP_REQUIRE(j.out.ext && j.out.n == (size_t(1) << j.k) && j.k <= (unsigned)MAX_PT, DP_ERR_SHAPE, "eq_table_many: output shape");
+      hd[i].out = (Ext*)j.out.p; hd[i].k = j.k; hd[i].pad = 0;
+      for (unsigned t = 0; t < j.k; t++) hd[i].pt[t] = j.pt[t];
+      maxn = std::max(maxn, j.out.n); bytes += 16.0 * j.out.n;
+    }
+    nb_ = bytes; DPL(k_eq_table_many, dim3(grid_for(maxn, 256), (unsigned)n), dim3(TPB), dd);
+  }
   void eq_table(const DBuf& out, const Ext* pt, unsigned k, Ext scale, bool acc) override {
     DP_REQUIRE(out.ext && out.n == (size_t(1) << k), DP_ERR_SHAPE, "eq_table: output shape");
     nb_ = 16.0 * out.n * (acc ? 2 : 1); DPL(k_eq_table, dim3(grid_for(out.n)), dim3(TPB), (Ext*)out.p, make_point(pt, k), k, scale, acc ? 1 : 0);
@@ -1291,8 +1406,7 @@ class HipDev : public Dev {
       int g = grid_for(n, 1024);
       Ext* partial = (Ext*)arena_alloc((size_t)g * 8 * 16);
       nb_ = [&] { double b = 0; for (int f = 0; f < a.nf; f++) b += fs[s + f].bytes(); return b; }(); DPL(k_mle_eval_partial, dim3(g), dim3(TPB), a, p, k, partial);
-      DPL(k_reduce_partials, dim3(a.nf), dim3(TPB), partial, (size_t)g, (size_t)8, (Ext*)dres_);
-      fetch(2 * a.nf);
+      reduce_publish(partial, (size_t)g, 8, a.nf);
       for (int f = 0; f < a.nf; f++) out[s + f] = ex(hres_[2 * f], hres_[2 * f + 1]);
       release(mk);
     }
@@ -1423,7 +1537,7 @@ class HipDev : public Dev {
         }
         size_t nquads = n_in / 4;
         size_t mk = mark();
-        int g = (int)std::min<size_t>((nquads + TPB - 1) / TPB, 4096);
+        int g = grid_for(nquads, 4096);
         Ext* partial = (Ext*)arena_alloc((size_t)g * 4 * 16);
         nb_ = bytes;
         #define LAUNCH_FUSED(KK, BB) DPL((k_sc_fused<KK, BB>), dim3(g), dim3(TPB), in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial)
@@ -1431,8 +1545,7 @@ class HipDev : public Dev {
         else if (nt == 2) { if (base) LAUNCH_FUSED(2, true); else LAUNCH_FUSED(2, false); }
         else { if (base) LAUNCH_FUSED(3, true); else LAUNCH_FUSED(3, false); }
         #undef LAUNCH_FUSED
-        DPL(k_reduce_terms, dim3(4), dim3(TPB), (const Ext*)partial, (size_t)g, (Ext*)dres_);
-        fetch(8);
+        reduce_publish(partial, (size_t)g, 4, 4);
         for (int t = 0; t <= terms[0].k; t++) out[t] = ex(hres_[2 * t], hres_[2 * t + 1]);
         release(mk);
         return;
@@ -1450,8 +1563,7 @@ class HipDev : public Dev {
     int g = grid_for(a.npairs, 2048);
     Ext* partial = (Ext*)arena_alloc((size_t)nterms * g * 4 * 16);
     nb_ = [&] { double b = 0; for (int i = 0; i < nterms; i++) for (int j = 0; j < terms[i].k; j++) b += tabs[terms[i].t[j]].bytes(); return b; }(); DPL(k_sc_terms, dim3(g, nterms), dim3(TPB), a, partial);
-    DPL(k_reduce_terms, dim3(nterms * 4), dim3(TPB), partial, (size_t)g, (Ext*)dres_);
-    fetch((size_t)nterms * 8);
+    reduce_publish(partial, (size_t)g, 4, nterms * 4);
     size_t o = 0;
     for (int i = 0; i < nterms; i++)
       for (int t = 0; t <= terms[i].k; t++) out[o++] = ex(hres_[(i * 4 + t) * 2], hres_[(i * 4 + t) * 2 + 1]);
@@ -1470,8 +1582,8 @@ class HipDev : public Dev {
     FoldArgs a;
     for (int i = 0; i < MAX_TABS; i++) { a.in[i] = nullptr; a.out[i] = nullptr; a.ext[i] = 0; a.half[i] = 0; }
     for (int i = 0; i < nt; i++) { DP_REQUIRE(tabs[i].n == 2, DP_ERR_SHAPE, "sc_finish: tables must have 2 entries"); a.in[i] = tabs[i].p; a.ext[i] = tabs[i].ext; }
-    DPL(k_finish, dim3(1), dim3(64), a, r, nt, (Ext*)dres_);
-    fetch(2 * (size_t)nt);
+    if (zerocopy_) { unsigned long long seq = ++seq_; DPL(k_finish_publish, dim3(1), dim3(64), a, r, nt, (Ext*)hres_dev_, hflag_dev_, seq); wait_flag(seq, 2 * (size_t)nt); }
+    else { DPL(k_finish, dim3(1), dim3(64), a, r, nt, (Ext*)dres_); fetch(2 * (size_t)nt); }
     for (int i = 0; i < nt; i++) finals[i] = ex(hres_[2 * i], hres_[2 * i + 1]);
   }
 
@@ -1493,12 +1605,13 @@ class HipDev : public Dev {
   void logup_build(const DBuf* cols, int cpi, int ninst, const DBuf& mult, Ext c, Ext chi,
                    std::vector<LogupCircuitDev>& circuits, std::vector<Ext>& outputs) override {
     size_t n = cols[0].n;
-    if (n > 16384 || n < 4 || cpi > 8 || (size_t)ninst * sizeof(LogupTreeDesc) > STAGE_BYTES || (size_t)ninst * 8 > RES_WORDS) {
+    if (n > 16384 || n < 4 || cpi > 8 || (size_t)ninst * sizeof(LogupTreeDesc) > DESC_BYTES || (size_t)ninst * 8 > RES_WORDS) {
       Dev::logup_build(cols, cpi, ninst, mult, c, chi, circuits, outputs);
       return;
     }
     circuits.clear(); outputs.clear();
-    LogupTreeDesc* hd = (LogupTreeDesc*)hstage_;
+    const LogupTreeDesc* dd = nullptr;
+    LogupTreeDesc* hd = desc_alloc<LogupTreeDesc>((size_t)ninst, &dd);
     for (int s = 0; s < ninst; s++) {
       LogupCircuitDev cd;
       DBuf den_all = alloc(2 * n, true), num_all = alloc(n, true);
@@ -1517,10 +1630,8 @@ class HipDev : public Dev {
       circuits.push_back(cd);
     }
     size_t mk = mark();
-    LogupTreeDesc* dd = (LogupTreeDesc*)arena_alloc((size_t)ninst * sizeof(LogupTreeDesc));
-    HIP_CHECK(hipMemcpyAsync(dd, hd, (size_t)ninst * sizeof(LogupTreeDesc), hipMemcpyHostToDevice, s_));
     int threads = n >= 2048 ? 1024 : n >= 512 ? 512 : 256;
-    nb_ = (double)ninst * (8.0 * cpi * n + 16.0 * 3 * n); DPL(k_logup_tree, dim3(ninst), dim3(threads), (const LogupTreeDesc*)dd, n, c, chi, (Ext*)dres_);
+    nb_ = (double)ninst * (8.0 * cpi * n + 16.0 * 3 * n); DPL(k_logup_tree, dim3(ninst), dim3(threads), dd, n, c, chi, (Ext*)dres_);
     fetch((size_t)ninst * 8);
     for (int i = 0; i < 4 * ninst; i++) outputs.push_back(ex(hres_[2 * i], hres_[2 * i + 1]));
     release(mk);
@@ -1548,13 +1659,17 @@ class HipDev : public Dev {
     if (s.ext) { nb_ = 32.0 * s.n; DPL(k_bitrev<true>, dim3(grid_for(s.n)), dim3(TPB), d.p, (const void*)s.p, lg); }
     else { nb_ = 16.0 * s.n; DPL(k_bitrev<false>, dim3(grid_for(s.n)), dim3(TPB), d.p, (const void*)s.p, lg); }
   }
-  // Run k_merkle_tail over `nd` descriptors staged in hstage_ (roots land in dres_[4*i..]); caller fetches.
-  void launch_tails(const TailDesc* hd_in_stage, size_t nd) {
-    size_t mk = mark();
-    TailDesc* dd = (TailDesc*)arena_alloc(nd * sizeof(TailDesc));
-    HIP_CHECK(hipMemcpyAsync(dd, hd_in_stage, nd * sizeof(TailDesc), hipMemcpyHostToDevice, s_));
-    nb_ = 0; DPL(k_merkle_tail, dim3((unsigned)nd), dim3(1024), (const TailDesc*)dd, dres_);
-    release(mk);
+  // Run k_merkle_tail over `nd` descriptors of the mapped ring and bring the roots to hres_[4*i..]. A single tree
+  // publishes its root itself; several trees land in dres_ and are published together.
+  void tails_to_host(const TailDesc* dd, size_t nd) {
+    if (nd == 1 && zerocopy_) {
+      unsigned long long seq = ++seq_;
+      nb_ = 0; DPL(k_merkle_tail, dim3(1), dim3(1024), dd, dres_, hres_dev_, hflag_dev_, seq);
+      wait_flag(seq, 4);
+      return;
+    }
+    nb_ = 0; DPL(k_merkle_tail, dim3((unsigned)nd), dim3(1024), dd, dres_, (u64*)nullptr, (unsigned long long*)nullptr, 0ull);
+    fetch(4 * nd);
   }
   static constexpr size_t TAIL_MAX = 1024;   // layers of at most this many digests are finished by k_merkle_tail
   static constexpr size_t LP_MAX = 1 << 17;  // layers with at most this many parent nodes use the 8-lanes-per-node kernel
@@ -1568,14 +1683,14 @@ class HipDev : public Dev {
     size_t off = 0, cnt = n / 2;
     while (cnt > TAIL_MAX) {
       size_t next = cnt / 2;
-      if (next <= LP_MAX) { nb_ = 96.0 * next; DPL(k_merkle_layer_lp, dim3((unsigned)std::min<size_t>((next * 8 + 1023) / 1024, 2048)), dim3(1024), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
+      if (next <= LP_MAX) { nb_ = 96.0 * next; DPL(k_merkle_layer_lp, dim3((unsigned)std::min<size_t>(std::min<size_t>((next * 8 + 1023) / 1024, 2048), (size_t)std::max(1, g_max_grid / 4))), dim3(1024), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
       else { nb_ = 96.0 * next; DPL(k_merkle_layer, dim3(grid_for(next, 4096)), dim3(TPB), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
       off += cnt; cnt /= 2;
     }
-    TailDesc* hd = (TailDesc*)hstage_;
+    const TailDesc* dd = nullptr;
+    TailDesc* hd = desc_alloc<TailDesc>(1, &dd);
     hd[0].nodes = nd; hd[0].off = off; hd[0].cnt = cnt;
-    launch_tails(hd, 1);
-    fetch(4);
+    tails_to_host(dd, 1);
     for (int k = 0; k < 4; k++) t.root.v[k] = hres_[k];
     return t;
   }
@@ -1632,10 +1747,12 @@ class HipDev : public Dev {
       size_t g = grp.size(), n = e0.n;
       bool trivial = nv <= 7;
       size_t nleaves = trivial ? n : 2 * n;
-      DP_REQUIRE(g * sizeof(SmallCommitDesc) + g * sizeof(TailDesc) <= STAGE_BYTES && 4 * g <= RES_WORDS, DP_ERR_SHAPE, "commit_many: group too large");
+      DP_REQUIRE(g * sizeof(SmallCommitDesc) + g * sizeof(TailDesc) + 128 <= DESC_BYTES && 4 * g <= RES_WORDS, DP_ERR_SHAPE, "commit_many: group too large");
       auto A = [&](size_t m, bool e) { return persistent ? alloc_persistent(m, e) : alloc(m, e); };
-      SmallCommitDesc* hd = (SmallCommitDesc*)hstage_;
-      TailDesc* td = (TailDesc*)((char*)hstage_ + g * sizeof(SmallCommitDesc));
+      if (desc_off_ + g * sizeof(SmallCommitDesc) + g * sizeof(TailDesc) + 128 > DESC_BYTES) stream_wait();
+      const SmallCommitDesc* dd = nullptr; const TailDesc* tdd = nullptr;
+      SmallCommitDesc* hd = desc_alloc<SmallCommitDesc>(g, &dd);
+      TailDesc* td = desc_alloc<TailDesc>(g, &tdd);
       for (size_t q = 0; q < g; q++) {
         DevCommit& c = out[grp[q]];
         const DBuf& ev = evals[grp[q]];
@@ -1648,17 +1765,14 @@ class HipDev : public Dev {
         td[q].nodes = (u64*)nodes.p; td[q].off = 0; td[q].cnt = nleaves / 2;
       }
       size_t mk = mark();
-      SmallCommitDesc* dd = (SmallCommitDesc*)arena_alloc(g * sizeof(SmallCommitDesc));
-      HIP_CHECK(hipMemcpyAsync(dd, hd, g * sizeof(SmallCommitDesc), hipMemcpyHostToDevice, s_));
       if (!trivial) {
         size_t lds = 3 * n * (e0.ext ? 16 : 8);
-        if (e0.ext) { nb_ = g * 64.0 * n; DPL_LDS(k_commit_small<true>, dim3((unsigned)g), dim3(256), lds, (const SmallCommitDesc*)dd, nv, L_, (const u64*)tw_, (const u64*)pow7_); }
-        else { nb_ = g * 32.0 * n; DPL_LDS(k_commit_small<false>, dim3((unsigned)g), dim3(256), lds, (const SmallCommitDesc*)dd, nv, L_, (const u64*)tw_, (const u64*)pow7_); }
+        if (e0.ext) { nb_ = g * 64.0 * n; DPL_LDS(k_commit_small<true>, dim3((unsigned)g), dim3(256), lds, dd, nv, L_, (const u64*)tw_, (const u64*)pow7_); }
+        else { nb_ = g * 32.0 * n; DPL_LDS(k_commit_small<false>, dim3((unsigned)g), dim3(256), lds, dd, nv, L_, (const u64*)tw_, (const u64*)pow7_); }
       }
-      if (e0.ext) { nb_ = g * 32.0 * nleaves; DPL(k_merkle_leaves_many<true>, dim3(grid_for(nleaves / 2, 64), (unsigned)g), dim3(TPB), (const SmallCommitDesc*)dd, nleaves / 2); }
-      else { nb_ = g * 24.0 * nleaves; DPL(k_merkle_leaves_many<false>, dim3(grid_for(nleaves / 2, 64), (unsigned)g), dim3(TPB), (const SmallCommitDesc*)dd, nleaves / 2); }
-      launch_tails(td, g);
-      fetch(4 * g);
+      if (e0.ext) { nb_ = g * 32.0 * nleaves; DPL(k_merkle_leaves_many<true>, dim3(grid_for(nleaves / 2, 64), (unsigned)g), dim3(TPB), dd, nleaves / 2); }
+      else { nb_ = g * 24.0 * nleaves; DPL(k_merkle_leaves_many<false>, dim3(grid_for(nleaves / 2, 64), (unsigned)g), dim3(TPB), dd, nleaves / 2); }
+      tails_to_host(tdd, g);
       for (size_t q = 0; q < g; q++) { for (int k = 0; k < 4; k++) out[grp[q]].tree.root.v[k] = hres_[4 * q + k]; done[grp[q]] = true; }
       release(mk);
     }
@@ -1673,8 +1787,10 @@ class HipDev : public Dev {
   DevTree merkle_ext(const DBuf& leaves) override { return build_tree(leaves, false); }
 
   void classic_round(DBuf* fs, DBuf* eqs, int np, const Ext* r, Ext* out) override {
-    DP_REQUIRE((size_t)np * sizeof(PolyDesc) <= STAGE_BYTES / 2 && (size_t)np * 4 <= RES_WORDS, DP_ERR_SHAPE, "classic_round: too many polynomials");
-    PolyDesc* hd = (PolyDesc*)hstage_;
+    DP_REQUIRE((size_t)np * sizeof(PolyDesc) * 2 + 128 <= DESC_BYTES && (size_t)np * 4 <= RES_WORDS && np * 2 <= 1024, DP_ERR_SHAPE, "classic_round: too many polynomials");
+    if (desc_off_ + (size_t)np * sizeof(PolyDesc) * 2 + 128 > DESC_BYTES) stream_wait();
+    const PolyDesc* dd = nullptr;
+    PolyDesc* hd = desc_alloc<PolyDesc>((size_t)np, &dd);
     size_t maxn = 1;
     for (int i = 0; i < np; i++) {
       DP_REQUIRE(fs[i].n == eqs[i].n && eqs[i].ext, DP_ERR_SHAPE, "classic_round: f/eq shapes");
@@ -1687,23 +1803,33 @@ class HipDev : public Dev {
       maxn = std::max(maxn, hd[i].n);
     }
     size_t mk = mark();
-    PolyDesc* dd = (PolyDesc*)arena_alloc((size_t)np * sizeof(PolyDesc));
-    HIP_CHECK(hipMemcpyAsync(dd, hd, (size_t)np * sizeof(PolyDesc), hipMemcpyHostToDevice, s_));
     if (r) {
-      nb_ = [&] { double b = 0; for (int i = 0; i < np; i++) if (hd[i].fout) b += hd[i].n * (hd[i].fext ? 16.0 : 8.0) + hd[i].n * 16.0 + hd[i].n * 16.0; return b; }(); DPL(k_classic_fold, dim3(grid_for(maxn / 2, 1024), np), dim3(TPB), (const PolyDesc*)dd, *r);
-      // descriptors for the sums: the folded tables
-      stream_wait();  // hstage_ is reused below
+      nb_ = [&] { double b = 0; for (int i = 0; i < np; i++) if (hd[i].fout) b += hd[i].n * (hd[i].fext ? 16.0 : 8.0) + hd[i].n * 16.0 + hd[i].n * 16.0; return b; }(); DPL(k_classic_fold, dim3(grid_for(maxn / 2, 1024), np), dim3(TPB), dd, *r);
+      // descriptors for the sums: the folded tables (a second ring slot — the fold may still be reading the first)
+      hd = desc_alloc<PolyDesc>((size_t)np, &dd);
       maxn = 1;
-      for (int i = 0; i < np; i++) { hd[i].f = fs[i].p; hd[i].eq = (const Ext*)eqs[i].p; hd[i].n = fs[i].n; hd[i].fext = fs[i].ext; maxn = std::max(maxn, hd[i].n); }
-      HIP_CHECK(hipMemcpyAsync(dd, hd, (size_t)np * sizeof(PolyDesc), hipMemcpyHostToDevice, s_));
+      for (int i = 0; i < np; i++) { hd[i].f = fs[i].p; hd[i].eq = (const Ext*)eqs[i].p; hd[i].n = fs[i].n; hd[i].fext = fs[i].ext; hd[i].pad = 0; hd[i].fout = nullptr; hd[i].eqout = nullptr; maxn = std::max(maxn, hd[i].n); }
     }
     int g = grid_for(std::max<size_t>(maxn / 2, 1), 256);
     Ext* partial = (Ext*)arena_alloc((size_t)np * g * 2 * 16);
-    nb_ = [&] { double b = 0; for (int i = 0; i < np; i++) b += hd[i].n * (hd[i].fext ? 16.0 : 8.0) + hd[i].n * 16.0; return b; }(); DPL(k_classic_sums, dim3(g, np), dim3(TPB), (const PolyDesc*)dd, partial);
-    DPL(k_reduce_pairs, dim3(np * 2), dim3(TPB), partial, (size_t)g, (Ext*)dres_);
-    fetch((size_t)np * 4);
+    nb_ = [&] { double b = 0; for (int i = 0; i < np; i++) b += hd[i].n * (hd[i].fext ? 16.0 : 8.0) + hd[i].n * 16.0; return b; }(); DPL(k_classic_sums, dim3(g, np), dim3(TPB), dd, partial);
+    reduce_publish(partial, (size_t)g, 2, np * 2);
     for (int i = 0; i < 2 * np; i++) out[i] = ex(hres_[2 * i], hres_[2 * i + 1]);
     release(mk);
+  }
+  void axpy_many(const DBuf& acc, const DBuf* init, const AxpyJob* jobs, size_t n) override {
+    DP_REQUIRE(acc.ext && (!init || (init->ext && init->n == acc.n)), DP_ERR_SHAPE, "axpy_many: accumulator shape");
+    if (n * sizeof(AxpyDesc) + 64 > DESC_BYTES) { Dev::axpy_many(acc, init, jobs, n); return; }
+    const AxpyDesc* dd = nullptr;
+    AxpyDesc* hd = desc_alloc<AxpyDesc>(std::max<size_t>(n, 1), &dd);
+    double bytes = 16.0 * acc.n * (init ? 2 : 1);
+    for (size_t i = 0; i < n; i++) {
+      const AxpyJob& j = jobs[i];
+      DP_REQUIRE(acc.n == j.x.n * j.rep && (j.rep & (j.rep - 1)) == 0, DP_ERR_SHAPE, "axpy_many: shapes");
+      hd[i].x = j.x.p; hd[i].xext = j.x.ext; hd[i].lg_rep = dp_ceil_log2(j.rep); hd[i].n_x = j.x.n; hd[i].coeff = j.coeff;
+      bytes += j.x.bytes();
+    }
+    nb_ = bytes; DPL(k_axpy_many, dim3(grid_for(acc.n)), dim3(TPB), (Ext*)acc.p, init ? (const Ext*)init->p : (const Ext*)nullptr, acc.n, dd, (int)n);
   }
   void axpy_rep(const DBuf& acc, const DBuf& x, Ext coeff, size_t rep) override {
     DP_REQUIRE(acc.ext && acc.n == x.n * rep && (rep & (rep - 1)) == 0, DP_ERR_SHAPE, "axpy_rep: shapes");
@@ -1718,8 +1844,7 @@ class HipDev : public Dev {
     int g = grid_for(f.n / 2, 512);
     Ext* partial = (Ext*)arena_alloc((size_t)g * 4 * 16);
     nb_ = 32.0 * f.n; DPL(k_bf_msg, dim3(g), dim3(TPB), (const Ext*)f.p, (const Ext*)eq.p, f.n / 2, partial);
-    DPL(k_reduce_partials, dim3(3), dim3(TPB), (const Ext*)partial, (size_t)g, (size_t)4, (Ext*)dres_);
-    fetch(6);
+    reduce_publish(partial, (size_t)g, 4, 3);
     for (int i = 0; i < 3; i++) msg[i] = ex(hres_[2 * i], hres_[2 * i + 1]);
     release(mk);
   }
@@ -1735,8 +1860,8 @@ class HipDev : public Dev {
   void query_gather(const QueryDesc* d, size_t nd, std::vector<std::vector<u64>>& out) override {
     out.resize(nd);
     if (!nd) return;
-    DP_REQUIRE(nd * sizeof(GatherDesc) <= STAGE_BYTES, DP_ERR_SHAPE, "query_gather: too many descriptors");
-    GatherDesc* hd = (GatherDesc*)hstage_;
+    const GatherDesc* dd = nullptr;
+    GatherDesc* hd = desc_alloc<GatherDesc>(nd, &dd);
     size_t total = 0;
     for (size_t i = 0; i < nd; i++) {
       const DevTree& t = *d[i].tree;
@@ -1745,12 +1870,8 @@ class HipDev : public Dev {
       total += (t.leaves.ext ? 4 : 2) + 4 * (size_t)(t.height() - 1);
     }
     size_t mk = mark();
-    GatherDesc* dd = (GatherDesc*)arena_alloc(nd * sizeof(GatherDesc));
     u64* dout = (u64*)arena_alloc(total * 8);
-    HIP_CHECK(hipMemcpyAsync(dd, hd, nd * sizeof(GatherDesc), hipMemcpyHostToDevice, s_));
-    DPL(k_query_gather, dim3((unsigned)((nd + 3) / 4)), dim3(TPB), (const GatherDesc*)dd, nd, dout);
-    std::vector<GatherDesc> hcopy(hd, hd + nd);  // the staging buffer is reused by the download below
-    hd = hcopy.data();
+    DPL(k_query_gather, dim3((unsigned)((nd + 3) / 4)), dim3(TPB), dd, nd, dout);
     std::vector<u64> flat(total);
     stream_wait();
     d2h(flat.data(), dout, total * 8);

@@ -53,10 +53,14 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
     target = ex_add(target, ex_mul(ex_mul(claims[i].eval, ex_from_u64(u64(1) << (num_vars - claims[i].comm->nv))), eq_xt[i]));
   // ---- classic sumcheck on sum_i eq_xt[i] * eq(x, z_i) * f_i(x)  (sum_check/classic.rs:232-285, coeff.rs:198-345)
   std::vector<DBuf> fs(np), eqs(np);
-  for (size_t i = 0; i < np; i++) {
-    fs[i] = claims[i].comm->evals;
-    eqs[i] = dev.alloc(fs[i].n, true);
-    dev.eq_table(eqs[i], claims[i].point.data(), claims[i].comm->nv, ex_one(), false);
+  {
+    std::vector<Dev::EqJob> jobs(np);
+    for (size_t i = 0; i < np; i++) {
+      fs[i] = claims[i].comm->evals;
+      eqs[i] = dev.alloc(fs[i].n, true);
+      jobs[i] = {eqs[i], claims[i].point.data(), claims[i].comm->nv};
+    }
+    dev.eq_table_many(jobs.data(), np);
   }
   std::vector<Ext> challenges, raw(2 * np);
   Ext sum = target, ch = ex_zero();
@@ -92,11 +96,20 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
   // ---- batch_commit_phase (commit_phase.rs:187-359)
   unsigned num_rounds = num_vars - PCS_BASECODE_LOG;
   size_t cw_size = size_t(1) << (num_vars + PCS_RATE_LOG);
-  auto zeros = [&](size_t n) { DBuf b = dev.alloc(n, true); dev.zero(b); return b; };
-  DBuf running = zeros(cw_size);
-  for (size_t i = 0; i < np; i++) if (claims[i].comm->codeword_size() == cw_size) dev.axpy_rep(running, claims[i].comm->tree.leaves, coeffs[i], 1);
-  DBuf sum_evals = zeros(size_t(1) << num_vars);
-  for (size_t i = 0; i < np; i++) dev.axpy_rep(sum_evals, claims[i].comm->bh_evals, coeffs[i], size_t(1) << (num_vars - claims[i].comm->nv));
+  std::vector<Dev::AxpyJob> jobs;
+  // running oracle of size `n` = init + sum of the committed codewords of that size, each times its coefficient
+  auto merge_codewords = [&](size_t n, const DBuf* init) {
+    jobs.clear();
+    for (size_t i = 0; i < np; i++) if (claims[i].comm->codeword_size() == n) jobs.push_back({claims[i].comm->tree.leaves, coeffs[i], 1});
+    DBuf b = dev.alloc(n, true);
+    dev.axpy_many(b, init, jobs.data(), jobs.size());
+    return b;
+  };
+  DBuf running = merge_codewords(cw_size, nullptr);
+  DBuf sum_evals = dev.alloc(size_t(1) << num_vars, true);
+  jobs.clear();
+  for (size_t i = 0; i < np; i++) jobs.push_back({claims[i].comm->bh_evals, coeffs[i], size_t(1) << (num_vars - claims[i].comm->nv)});
+  dev.axpy_many(sum_evals, nullptr, jobs.data(), jobs.size());
   std::vector<Ext> rev_point(challenges.rbegin(), challenges.rend());
   DBuf eq = dev.alloc(size_t(1) << num_vars, true);
   dev.eq_table(eq, rev_point.data(), num_vars, ex_one(), false);  // == bit-reversed eq(point)
@@ -112,11 +125,8 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
       trees.push_back(pending);
       bool any = false;
       for (size_t k = 0; k < np; k++) if (claims[k].comm->codeword_size() == folded.n) any = true;
-      if (any) {
-        running = dev.alloc(folded.n, true);  // the committed oracle (tree leaves) must stay untouched
-        dev.copy(running, folded);
-        for (size_t k = 0; k < np; k++) if (claims[k].comm->codeword_size() == folded.n) dev.axpy_rep(running, claims[k].comm->tree.leaves, coeffs[k], 1);
-      } else running = folded;
+      if (any) running = merge_codewords(folded.n, &folded);  // a fresh buffer: the committed oracle (tree leaves) must stay untouched
+      else running = folded;
     }
     folded = dev.fri_fold(running, dp_ceil_log2(running.n) - 1, c);
     if (i + 1 < num_rounds) {
