@@ -188,7 +188,7 @@ def sumcheck24(dev, dpa, nv=24, k=3):
     dev.profile(False)
     for t in tabs:
         t.free()
-    stream = [r for r in rep if r["kernel"].startswith("(k_sc_fused") or r["kernel"] == "k_sc_terms"]
+    stream = [r for r in rep if r["kernel"].startswith("k_sc_fused") or r["kernel"].startswith("k_sc_terms")]
     ms = sum(r["total_ms"] for r in stream)
     by = sum(r["alg_bytes"] for r in stream)
     big = max(stream, key=lambda r: r["total_ms"])

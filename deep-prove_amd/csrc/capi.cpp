@@ -117,7 +117,7 @@ int32_t dp_sumcheck_prove(dp_ctx* ctx, uint32_t nv, const dp_buf* const* tables,
     for (int i = 0; i < nterms; i++) {
       int k = term_degree[i];
       DP_REQUIRE(k >= 1 && k <= 3, DP_ERR_SHAPE, "term degree must be 1..3");
-      ScTerm st; st.k = k; st.t[0] = st.t[1] = st.t[2] = 0;
+      ScTerm st; st.k = k; for (int q = 0; q < SC_MAXK; q++) st.t[q] = 0;
       for (int j = 0; j < k; j++) { int ti = term_tables[3 * i + j]; DP_REQUIRE(ti >= 0 && ti < ntables, DP_ERR_ARG, "term table index"); st.t[j] = ti; }
       vp.terms.push_back(st); vp.coeffs.push_back(read_point(term_coeffs + 2 * i, 1)[0]);
       if ((unsigned)k > vp.max_degree) vp.max_degree = k;
@@ -213,7 +213,15 @@ static ModelSpec parse_model(const int64_t* b, size_t n) {
       l.weights.assign(b + pos, b + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols;
       l.bias.assign(b + pos, b + pos + l.nrows); pos += l.nrows;
     } else if (l.kind == L_REQUANT) { l.right_shift = (unsigned)rd(); l.fp_scale = (unsigned)rd(); l.fixed_point_multiplier = rd(); l.intermediate_bit_size = (unsigned)rd(); }
-    else DP_REQUIRE(l.kind == L_RELU, DP_ERR_ARG, "model blob: unknown layer kind");
+    else if (l.kind == L_CONV) {
+      l.kw = (size_t)rd(); l.kx = (size_t)rd(); l.real_nw = (size_t)rd(); l.nw = (size_t)rd(); for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();
+      DP_REQUIRE(l.kw && l.kx && l.real_nw && l.kw < (1u << 16) && l.kx < (1u << 16) && l.real_nw < (1u << 12), DP_ERR_ARG, "model blob: conv dimensions");
+      size_t nf = l.kw * l.kx * l.real_nw * l.real_nw;
+      DP_REQUIRE(nf + l.kw <= n - pos, DP_ERR_ARG, "model blob: conv tensor sizes");
+      l.weights.assign(b + pos, b + pos + nf); pos += nf;
+      l.bias.assign(b + pos, b + pos + l.kw); pos += l.kw;
+    } else if (l.kind == L_MAXPOOL) { for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd(); }
+    else DP_REQUIRE(l.kind == L_RELU || l.kind == L_FLATTEN, DP_ERR_ARG, "model blob: unknown layer kind");
     m.layers.push_back(std::move(l));
   }
   DP_REQUIRE(pos == n, DP_ERR_ARG, "model blob: trailing words");
@@ -289,37 +297,6 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (err_code) { for (size_t i = 0; i < nproofs; i++) { free(proof_words[i]); proof_words[i] = nullptr; } throw DpError(err_code, err); }
   });
-}
-static std::vector<u64> vctx_to_words(const VerifierContext& v) {
-  std::vector<u64> w;
-  w.push_back(0x3158544356504444ULL); w.push_back(v.full_log); w.push_back(v.shape.input_len); w.push_back(v.shape.layers.size());
-  for (auto& l : v.shape.layers) { w.push_back(l.kind); w.push_back(l.nrows); w.push_back(l.ncols); w.push_back(l.right_shift); w.push_back(l.fp_scale); w.push_back((u64)l.fixed_point_multiplier); w.push_back(l.intermediate_bit_size); }
-  w.push_back(v.model_comms.size());
-  for (auto& kv : v.model_comms) {
-    w.push_back(kv.first);
-    for (const char* id : {"DenseBias", "DenseWeight"}) { const Commitment& c = kv.second.at(id); for (int k = 0; k < 4; k++) w.push_back(c.root.v[k]); w.push_back(c.num_vars); w.push_back(c.is_base); }
-  }
-  w.push_back(v.tables.size());
-  for (auto& t : v.tables) { w.push_back(t.kind); w.push_back(t.size); }
-  return w;
-}
-static VerifierContext vctx_from_words(const u64* w, size_t n) {
-  size_t pos = 0;
-  auto rd = [&]() { DP_REQUIRE(pos < n, DP_ERR_ARG, "verifier blob truncated"); return w[pos++]; };
-  VerifierContext v;
-  DP_REQUIRE(rd() == 0x3158544356504444ULL, DP_ERR_ARG, "bad verifier blob magic");
-  v.full_log = (unsigned)rd(); v.shape.input_len = (size_t)rd(); size_t nl = (size_t)rd();
-  DP_REQUIRE(nl < 4096, DP_ERR_ARG, "verifier blob: layer count");
-  for (size_t i = 0; i < nl; i++) { LayerSpec l; l.kind = (int)rd(); l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); l.right_shift = (unsigned)rd(); l.fp_scale = (unsigned)rd(); l.fixed_point_multiplier = (int64_t)rd(); l.intermediate_bit_size = (unsigned)rd(); v.shape.layers.push_back(l); }
-  size_t nc = (size_t)rd(); DP_REQUIRE(nc <= nl, DP_ERR_ARG, "verifier blob: commitments");
-  for (size_t i = 0; i < nc; i++) {
-    size_t id = (size_t)rd();
-    for (const char* pid : {"DenseBias", "DenseWeight"}) { Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = rd(); c.num_vars = (unsigned)rd(); c.is_base = rd() != 0; v.model_comms[id][pid] = c; }
-  }
-  size_t nt = (size_t)rd(); DP_REQUIRE(nt < 64, DP_ERR_ARG, "verifier blob: tables");
-  for (size_t i = 0; i < nt; i++) { TableType t; t.kind = (int)rd(); t.size = (unsigned)rd(); v.tables.push_back(t); }
-  DP_REQUIRE(pos == n, DP_ERR_ARG, "verifier blob: trailing words");
-  return v;
 }
 int32_t dp_model_verifier_blob(const dp_model* m, uint64_t** words, size_t* nwords) {
   return guard([&] { DP_REQUIRE(m && words && nwords, DP_ERR_ARG, "bad arguments"); std::vector<u64> w = vctx_to_words(m->zk->verifier_ctx()); *words = copy_out(w); *nwords = w.size(); });

@@ -36,7 +36,8 @@ struct DBuf {
   bool null() const { return p == nullptr; }
 };
 
-struct ScTerm { int k; int t[3]; };  // product of k (<=3) tables, indices into the table list
+constexpr int SC_MAXK = 5;  // largest product in the reference's graphs: the maxpool zero-check (4 differences x eq, pooling.rs:405-406)
+struct ScTerm { int k; int t[SC_MAXK]; };  // product of k (<= SC_MAXK) tables, indices into the table list
 
 // Merkle tree over `nleaves` field elements (merkle_tree.rs:261-329): layer 0 packs leaf pairs (no hashing),
 // upper layers = Poseidon2 compress. All layers live in one buffer of (nleaves-1) digests; layer l starts at digest
@@ -90,6 +91,13 @@ class Dev {
   struct EqJob { DBuf out; const Ext* pt; unsigned k; };
   virtual void eq_table_many(const EqJob* jobs, size_t n) {
     for (size_t i = 0; i < n; i++) eq_table(jobs[i].out, jobs[i].pt, jobs[i].k, ex_one(), false);
+  }
+  // out[i] = eq(i mod 2^k, pt): the eq table repeated out.n / 2^k times (the `beta_acc` of convolution.rs:859)
+  virtual void eq_table_tiled(const DBuf& out, const Ext* pt, unsigned k) {
+    size_t n = size_t(1) << k;
+    DP_REQUIRE(out.ext && out.n % n == 0, DP_ERR_SHAPE, "eq_table_tiled: output shape");
+    eq_table(out.slice(0, n), pt, k, ex_one(), false);
+    for (size_t o = n; o < out.n; o += n) copy(out.slice(o, n), out.slice(0, n));
   }
   // K1 chain collapsed to one pass: out[i] = sum_x fs[i](x) * eq(x, pt)
   virtual void mle_eval_batch(const DBuf* fs, int nf, const Ext* pt, unsigned k, Ext* out) = 0;

@@ -71,8 +71,7 @@ __global__ void k_pow_table(u64* out, u64 base, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = gl_pow(base, i);
 }
 // K4: eq(x, pt) computed per index as a product over its bits (k ext multiplications per element, no log-k passes)
-__global__ void k_eq_table(Ext* out, PointArg pt, unsigned k, Ext scale, int acc) {
-  size_t n = size_t(1) << k;
+__global__ void k_eq_table(Ext* out, PointArg pt, unsigned k, Ext scale, int acc, size_t n) {  // n > 2^k: the table repeats
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     Ext v = scale;
     for (unsigned t = 0; t < k; t++) {
@@ -150,19 +149,79 @@ __global__ void k_fold(FoldArgs a, Ext r) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < h; i += (size_t)gridDim.x * blockDim.x) out[i] = ex_lerp_base(p[2 * i], p[2 * i + 1], r);
   }
 }
-struct TermArgs { const void* tab[MAX_TABS]; int ext[MAX_TABS]; int k[MAX_TERMS]; int t[MAX_TERMS][3]; size_t npairs; };
-// K3: partial[(term*gridDim.x + block)*4 + t] = sum over the block's pairs of prod_j (a_j + t d_j), t = 0..k
+constexpr int SC_SLOTS = SC_MAXK + 1;  // evaluations at t = 0..k of a degree-k term, k <= SC_MAXK
+// The round sums of ONE product term over the pairs start, start + stride, .. < npairs: acc[t] += prod_j (lo_j + t (hi_j - lo_j)).
+// `L(j, b, lo, hi)` loads pair b of the j-th factor. Degrees 1..3 (every sumcheck of the Dense / logup / Basefold path)
+// keep their hand-scheduled bodies; degrees 4 and 5 (the maxpool zero-check) walk t with forward differences.
+// HI = false: degrees 1..3 only (every sumcheck of the Dense / logup / Basefold path); HI = true adds degrees 4 and 5 (the
+// maxpool zero-check), walking t = 0..5 with forward differences. Kernels are instantiated for both so that the register
+// needs of the high-degree body never weigh on the common case.
+template <bool HI, class PairLoader>
+__device__ __forceinline__ void sc_accumulate(int k, PairLoader L, size_t start, size_t stride, size_t npairs, Ext (&acc)[SC_SLOTS]) {
+#pragma unroll
+  for (int t = 0; t < SC_SLOTS; t++) acc[t] = ex_zero();
+  if (k == 1) {
+    for (size_t b = start; b < npairs; b += stride) { Ext a0, b0; L(0, b, a0, b0); acc[0] = ex_add(acc[0], a0); acc[1] = ex_add(acc[1], b0); }
+  } else if (k == 2) {
+    for (size_t b = start; b < npairs; b += stride) {
+      Ext a0, b0, a1, b1; L(0, b, a0, b0); L(1, b, a1, b1);
+      Ext c0 = ex_sub(ex_dbl(b0), a0), c1 = ex_sub(ex_dbl(b1), a1);  // value at t = 2
+      acc[0] = ex_add(acc[0], ex_mul(a0, a1)); acc[1] = ex_add(acc[1], ex_mul(b0, b1)); acc[2] = ex_add(acc[2], ex_mul(c0, c1));
+    }
+  } else if (!HI || k == 3) {
+    for (size_t b = start; b < npairs; b += stride) {
+      Ext a0, b0, a1, b1, a2, b2; L(0, b, a0, b0); L(1, b, a1, b1); L(2, b, a2, b2);
+      Ext d0 = ex_sub(b0, a0), d1 = ex_sub(b1, a1), d2 = ex_sub(b2, a2);
+      Ext c0 = ex_add(b0, d0), c1 = ex_add(b1, d1), c2 = ex_add(b2, d2);  // t = 2
+      Ext f0 = ex_add(c0, d0), f1 = ex_add(c1, d1), f2 = ex_add(c2, d2);  // t = 3
+      acc[0] = ex_add(acc[0], ex_mul(ex_mul(a0, a1), a2)); acc[1] = ex_add(acc[1], ex_mul(ex_mul(b0, b1), b2));
+      acc[2] = ex_add(acc[2], ex_mul(ex_mul(c0, c1), c2)); acc[3] = ex_add(acc[3], ex_mul(ex_mul(f0, f1), f2));
+    }
+  } else if (HI) {
+    for (size_t b = start; b < npairs; b += stride) {
+      Ext cur[SC_MAXK], d[SC_MAXK];
+#pragma unroll
+      for (int j = 0; j < SC_MAXK; j++) {
+        if (j < k) { Ext lo, hi; L(j, b, lo, hi); cur[j] = lo; d[j] = ex_sub(hi, lo); }
+        else { cur[j] = ex_one(); d[j] = ex_zero(); }
+      }
+#pragma unroll
+      for (int t = 0; t < SC_SLOTS; t++) {
+        Ext p = ex_mul(ex_mul(cur[0], cur[1]), ex_mul(cur[2], cur[3]));
+        if (k == 5) p = ex_mul(p, cur[4]);
+        acc[t] = ex_add(acc[t], p);
+#pragma unroll
+        for (int j = 0; j < SC_MAXK; j++) cur[j] = ex_add(cur[j], d[j]);
+      }
+    }
+  }
+}
+// number of factor slots a kernel instantiation has to wire up
+template <bool HI> struct ScW { static constexpr int K = HI ? SC_MAXK : 3; };
+// pair loader over tables in global memory (natural order: pair b = elements 2b, 2b+1), base or extension per table
+struct GlobalPairs {
+  const void* p[SC_MAXK]; bool e[SC_MAXK];
+  __device__ __forceinline__ void operator()(int j, size_t b, Ext& lo, Ext& hi) const { lo = ld_elem(p[j], e[j], 2 * b); hi = ld_elem(p[j], e[j], 2 * b + 1); }
+};
+// pair loader over LDS-resident tables kept in bit-reversed order: pair q = positions q, q + h
+struct LdsPairs {
+  const Ext* p[SC_MAXK]; size_t h;
+  __device__ __forceinline__ void operator()(int j, size_t q, Ext& lo, Ext& hi) const { lo = p[j][q]; hi = p[j][q + h]; }
+};
+struct TermArgs { const void* tab[MAX_TABS]; int ext[MAX_TABS]; int k[MAX_TERMS]; int t[MAX_TERMS][SC_MAXK]; size_t npairs; };
+// K3: partial[(term*gridDim.x + block)*SC_SLOTS + t] = sum over the block's pairs of prod_j (a_j + t d_j), t = 0..k
+template <bool HI>
 __global__ void k_sc_terms(TermArgs a, Ext* partial) {
   __shared__ Ext sm[TPB / 64];
   int term = blockIdx.y;
   int k = a.k[term];
-  const void* p0 = a.tab[a.t[term][0]]; bool e0 = a.ext[a.t[term][0]];
-  const void* p1 = a.tab[a.t[term][k > 1 ? 1 : 0]]; bool e1 = a.ext[a.t[term][k > 1 ? 1 : 0]];
-  const void* p2 = a.tab[a.t[term][k > 2 ? 2 : 0]]; bool e2 = a.ext[a.t[term][k > 2 ? 2 : 0]];
-  Ext acc0 = ex_zero(), acc1 = ex_zero(), acc2 = ex_zero(), acc3 = ex_zero();
-  if (!e0 && !e1 && !e2) {
+  Ext acc[SC_SLOTS];
+  bool all_base = k <= 3;
+  for (int j = 0; j < k; j++) all_base = all_base && !a.ext[a.t[term][j]];
+  if (all_base) {
     // every factor is a base-field table (first round of a sumcheck over committed columns): stay in the base field,
     // as the reference macro does (sumcheck_macro/src/lib.rs:283-296), one 16-byte load per table and pair
+    const void* p0 = a.tab[a.t[term][0]]; const void* p1 = a.tab[a.t[term][k > 1 ? 1 : 0]]; const void* p2 = a.tab[a.t[term][k > 2 ? 2 : 0]];
     u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
     for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < a.npairs; b += (size_t)gridDim.x * blockDim.x) {
       ulonglong2 x0 = ((const ulonglong2*)p0)[b];
@@ -180,36 +239,19 @@ __global__ void k_sc_terms(TermArgs a, Ext* partial) {
         s2 = gl_add(s2, gl_mul(gl_mul(c0, c1), c2)); s3 = gl_add(s3, gl_mul(gl_mul(g0, g1), g2));
       }
     }
-    acc0 = ex_base(s0); acc1 = ex_base(s1); acc2 = ex_base(s2); acc3 = ex_base(s3);
-  } else
-  for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < a.npairs; b += (size_t)gridDim.x * blockDim.x) {
-    Ext a0 = ld_elem(p0, e0, 2 * b), b0 = ld_elem(p0, e0, 2 * b + 1);
-    if (k == 1) {
-      acc0 = ex_add(acc0, a0); acc1 = ex_add(acc1, b0);
-    } else if (k == 2) {
-      Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
-      Ext c0 = ex_sub(ex_dbl(b0), a0), c1 = ex_sub(ex_dbl(b1), a1);  // value at t = 2
-      acc0 = ex_add(acc0, ex_mul(a0, a1));
-      acc1 = ex_add(acc1, ex_mul(b0, b1));
-      acc2 = ex_add(acc2, ex_mul(c0, c1));
-    } else {
-      Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
-      Ext a2 = ld_elem(p2, e2, 2 * b), b2 = ld_elem(p2, e2, 2 * b + 1);
-      Ext d0 = ex_sub(b0, a0), d1 = ex_sub(b1, a1), d2 = ex_sub(b2, a2);
-      Ext c0 = ex_add(b0, d0), c1 = ex_add(b1, d1), c2 = ex_add(b2, d2);  // t = 2
-      Ext f0 = ex_add(c0, d0), f1 = ex_add(c1, d1), f2 = ex_add(c2, d2);  // t = 3
-      acc0 = ex_add(acc0, ex_mul(ex_mul(a0, a1), a2));
-      acc1 = ex_add(acc1, ex_mul(ex_mul(b0, b1), b2));
-      acc2 = ex_add(acc2, ex_mul(ex_mul(c0, c1), c2));
-      acc3 = ex_add(acc3, ex_mul(ex_mul(f0, f1), f2));
-    }
+    acc[0] = ex_base(s0); acc[1] = ex_base(s1); acc[2] = ex_base(s2); acc[3] = ex_base(s3); acc[4] = ex_zero(); acc[5] = ex_zero();
+  } else {
+    GlobalPairs L;
+#pragma unroll
+    for (int j = 0; j < ScW<HI>::K; j++) { int ti = a.t[term][j < k ? j : 0]; L.p[j] = a.tab[ti]; L.e[j] = a.ext[ti]; }
+    sc_accumulate<HI>(k, L, blockIdx.x * (size_t)blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, a.npairs, acc);
   }
-  size_t base = ((size_t)term * gridDim.x + blockIdx.x) * 4;
-  Ext r;
-  r = block_reduce_ext(acc0, sm); if (threadIdx.x == 0) partial[base + 0] = r;
-  r = block_reduce_ext(acc1, sm); if (threadIdx.x == 0) partial[base + 1] = r;
-  r = block_reduce_ext(acc2, sm); if (threadIdx.x == 0) partial[base + 2] = r;
-  r = block_reduce_ext(acc3, sm); if (threadIdx.x == 0) partial[base + 3] = r;
+  size_t base = ((size_t)term * gridDim.x + blockIdx.x) * SC_SLOTS;
+#pragma unroll
+  for (int t = 0; t < SC_SLOTS; t++) {
+    if (t <= k) { Ext r = block_reduce_ext(acc[t], sm); if (threadIdx.x == 0) partial[base + t] = r; }
+    else if (threadIdx.x == 0) partial[base + t] = ex_zero();
+  }
 }
 // out[term*4 + t] = sum_b partial[(term*nblocks + b)*4 + t]; one block per (term, t)
 __global__ void k_reduce_terms(const Ext* partial, size_t nblocks, Ext* out) {
@@ -700,11 +742,11 @@ __global__ void __launch_bounds__(256) k_commit_small(const SmallCommitDesc* d, 
 }
 
 // ------------------------------------------------------------------------------------------------ single-launch sumcheck round
-__device__ void sc_publish_fwd(Ext* result, const Ext* part, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane);
+__device__ void sc_publish_fwd(Ext* result, const Ext* part, const int* tk, const int* toff, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane);
 __device__ void sc_wait_challenge_fwd(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal);
 struct ScSmallArgs {
   const void* in[MAX_TABS]; Ext* out[MAX_TABS]; int in_ext[MAX_TABS];
-  int k[MAX_TERMS]; int t[MAX_TERMS][3];
+  int k[MAX_TERMS]; int t[MAX_TERMS][SC_MAXK]; int off[MAX_TERMS];  // off[i] = sum_{j<i} (k_j + 1): slot of term i in the published message
   int ntabs, nterms, has_r; size_t n_after; Ext r;
 };
 __device__ __forceinline__ Ext block_reduce_ext_n(Ext v, Ext* sm) {
@@ -721,8 +763,9 @@ __device__ __forceinline__ Ext block_reduce_ext_n(Ext v, Ext* sm) {
 // Terms are spread over the waves of the block (a term with many pairs is split over several waves), so the only
 // block-wide barriers are the one after the fold and the one before the final combine; wave 0 then writes
 // result[term*4 + t] straight into host-mapped memory and releases `flag = seq`.
+template <bool HI>
 __global__ void __launch_bounds__(1024) k_sc_small(ScSmallArgs a, Ext* result, unsigned long long* flag, unsigned long long seq) {
-  __shared__ Ext part[64 * 4];  // [slot][t], slot = term * wpt + sub  (<= 64 slots)
+  __shared__ Ext part[64 * SC_SLOTS];  // [slot][t], slot = term * wpt + sub  (<= 64 slots)
   int tid = threadIdx.x, nt = blockDim.x;
   size_t n = a.n_after;
   if (a.has_r) {
@@ -739,39 +782,18 @@ __global__ void __launch_bounds__(1024) k_sc_small(ScSmallArgs a, Ext* result, u
   for (int term = wave / wpt; term < a.nterms; term += (wpt == 1 ? W : a.nterms + W)) {
     int sub = wave % wpt;
     int k = a.k[term];
-    int i0 = a.t[term][0], i1 = a.t[term][k > 1 ? 1 : 0], i2 = a.t[term][k > 2 ? 2 : 0];
-    const void* p0 = a.has_r ? (const void*)a.out[i0] : a.in[i0]; bool e0 = a.has_r ? true : a.in_ext[i0];
-    const void* p1 = a.has_r ? (const void*)a.out[i1] : a.in[i1]; bool e1 = a.has_r ? true : a.in_ext[i1];
-    const void* p2 = a.has_r ? (const void*)a.out[i2] : a.in[i2]; bool e2 = a.has_r ? true : a.in_ext[i2];
-    Ext acc0 = ex_zero(), acc1 = ex_zero(), acc2 = ex_zero(), acc3 = ex_zero();
-    for (size_t b = (size_t)sub * 64 + lane; b < npairs; b += (size_t)wpt * 64) {
-      Ext a0 = ld_elem(p0, e0, 2 * b), b0 = ld_elem(p0, e0, 2 * b + 1);
-      if (k == 1) { acc0 = ex_add(acc0, a0); acc1 = ex_add(acc1, b0); }
-      else if (k == 2) {
-        Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
-        Ext c0 = ex_sub(ex_dbl(b0), a0), c1 = ex_sub(ex_dbl(b1), a1);
-        acc0 = ex_add(acc0, ex_mul(a0, a1)); acc1 = ex_add(acc1, ex_mul(b0, b1)); acc2 = ex_add(acc2, ex_mul(c0, c1));
-      } else {
-        Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
-        Ext a2 = ld_elem(p2, e2, 2 * b), b2 = ld_elem(p2, e2, 2 * b + 1);
-        Ext d0 = ex_sub(b0, a0), d1 = ex_sub(b1, a1), d2 = ex_sub(b2, a2);
-        Ext c0 = ex_add(b0, d0), c1 = ex_add(b1, d1), c2 = ex_add(b2, d2);
-        Ext f0 = ex_add(c0, d0), f1 = ex_add(c1, d1), f2 = ex_add(c2, d2);
-        acc0 = ex_add(acc0, ex_mul(ex_mul(a0, a1), a2)); acc1 = ex_add(acc1, ex_mul(ex_mul(b0, b1), b2));
-        acc2 = ex_add(acc2, ex_mul(ex_mul(c0, c1), c2)); acc3 = ex_add(acc3, ex_mul(ex_mul(f0, f1), f2));
-      }
-    }
-    acc0 = wave_reduce_ext(acc0); acc1 = wave_reduce_ext(acc1);
-    if (k >= 2) acc2 = wave_reduce_ext(acc2);
-    if (k >= 3) acc3 = wave_reduce_ext(acc3);
-    if (lane == 0) {
-      Ext* o = part + (size_t)(term * wpt + sub) * 4;
-      o[0] = acc0; o[1] = acc1; o[2] = acc2; o[3] = acc3;
-    }
+    GlobalPairs L;
+#pragma unroll
+    for (int j = 0; j < ScW<HI>::K; j++) { int ti = a.t[term][j < k ? j : 0]; L.p[j] = a.has_r ? (const void*)a.out[ti] : a.in[ti]; L.e[j] = a.has_r ? true : a.in_ext[ti]; }
+    Ext acc[SC_SLOTS];
+    sc_accumulate<HI>(k, L, (size_t)sub * 64 + lane, (size_t)wpt * 64, npairs, acc);
+#pragma unroll
+    for (int t = 0; t < SC_SLOTS; t++) if (t <= k) acc[t] = wave_reduce_ext(acc[t]);
+    if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * SC_SLOTS; for (int t = 0; t < SC_SLOTS; t++) o[t] = acc[t]; }
     if (wpt > 1) break;  // with several waves per term every wave owns exactly one (term, sub)
   }
   __syncthreads();
-  if (wave == 0) sc_publish_fwd(result, part, a.nterms, wpt, flag, seq, lane);
+  if (wave == 0) sc_publish_fwd(result, part, a.k, a.off, a.nterms, wpt, flag, seq, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ persistent sumcheck
@@ -782,7 +804,7 @@ __global__ void __launch_bounds__(1024) k_sc_small(ScSmallArgs a, Ext* result, u
 struct ScPersistArgs {
   const void* in[MAX_TABS]; int in_ext[MAX_TABS];
   Ext* bufA[MAX_TABS]; Ext* bufB[MAX_TABS];
-  int k[MAX_TERMS]; int t[MAX_TERMS][3];
+  int k[MAX_TERMS]; int t[MAX_TERMS][SC_MAXK]; int off[MAX_TERMS];
   int ntabs, nterms, has_r0; size_t n0; Ext r0;
   unsigned long long* dbg;  // optional: per-phase cycle counters (DP_SC_DEBUG=1)
 };
@@ -794,8 +816,9 @@ __device__ __forceinline__ void sc_fold_all(const ScPersistArgs& a, const void* 
     else { const u64* p = (const u64*)cur[t]; for (size_t i = tid; i < n_after; i += nt) o[i] = ex_lerp_base(p[2 * i], p[2 * i + 1], r); }
   }
 }
+template <bool HI>
 __global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* result, unsigned long long* flag, const unsigned long long* mailbox, unsigned long long seq0) {
-  __shared__ Ext part[64 * 4];
+  __shared__ Ext part[64 * SC_SLOTS];
   __shared__ unsigned long long chal[3];
   __shared__ const void* cur[MAX_TABS];
   __shared__ int cur_ext[MAX_TABS];
@@ -821,37 +844,19 @@ __global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* resul
     for (int term = wave / wpt; term < a.nterms; term += (wpt == 1 ? W : a.nterms + W)) {
       int sub = wave % wpt;
       int k = a.k[term];
-      int i0 = a.t[term][0], i1 = a.t[term][k > 1 ? 1 : 0], i2 = a.t[term][k > 2 ? 2 : 0];
-      const void* p0 = cur[i0]; bool e0 = cur_ext[i0];
-      const void* p1 = cur[i1]; bool e1 = cur_ext[i1];
-      const void* p2 = cur[i2]; bool e2 = cur_ext[i2];
-      Ext acc0 = ex_zero(), acc1 = ex_zero(), acc2 = ex_zero(), acc3 = ex_zero();
-      for (size_t b = (size_t)sub * 64 + lane; b < npairs; b += (size_t)wpt * 64) {
-        Ext a0 = ld_elem(p0, e0, 2 * b), b0 = ld_elem(p0, e0, 2 * b + 1);
-        if (k == 1) { acc0 = ex_add(acc0, a0); acc1 = ex_add(acc1, b0); }
-        else if (k == 2) {
-          Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
-          Ext c0 = ex_sub(ex_dbl(b0), a0), c1 = ex_sub(ex_dbl(b1), a1);
-          acc0 = ex_add(acc0, ex_mul(a0, a1)); acc1 = ex_add(acc1, ex_mul(b0, b1)); acc2 = ex_add(acc2, ex_mul(c0, c1));
-        } else {
-          Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
-          Ext a2 = ld_elem(p2, e2, 2 * b), b2 = ld_elem(p2, e2, 2 * b + 1);
-          Ext d0 = ex_sub(b0, a0), d1 = ex_sub(b1, a1), d2 = ex_sub(b2, a2);
-          Ext c0 = ex_add(b0, d0), c1 = ex_add(b1, d1), c2 = ex_add(b2, d2);
-          Ext f0 = ex_add(c0, d0), f1 = ex_add(c1, d1), f2 = ex_add(c2, d2);
-          acc0 = ex_add(acc0, ex_mul(ex_mul(a0, a1), a2)); acc1 = ex_add(acc1, ex_mul(ex_mul(b0, b1), b2));
-          acc2 = ex_add(acc2, ex_mul(ex_mul(c0, c1), c2)); acc3 = ex_add(acc3, ex_mul(ex_mul(f0, f1), f2));
-        }
-      }
-      acc0 = wave_reduce_ext(acc0); acc1 = wave_reduce_ext(acc1);
-      if (k >= 2) acc2 = wave_reduce_ext(acc2);
-      if (k >= 3) acc3 = wave_reduce_ext(acc3);
-      if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * 4; o[0] = acc0; o[1] = acc1; o[2] = acc2; o[3] = acc3; }
+      GlobalPairs L;
+#pragma unroll
+      for (int j = 0; j < ScW<HI>::K; j++) { int ti = a.t[term][j < k ? j : 0]; L.p[j] = cur[ti]; L.e[j] = cur_ext[ti]; }
+      Ext acc[SC_SLOTS];
+      sc_accumulate<HI>(k, L, (size_t)sub * 64 + lane, (size_t)wpt * 64, npairs, acc);
+#pragma unroll
+      for (int t = 0; t < SC_SLOTS; t++) if (t <= k) acc[t] = wave_reduce_ext(acc[t]);
+      if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * SC_SLOTS; for (int t = 0; t < SC_SLOTS; t++) o[t] = acc[t]; }
       if (wpt > 1) break;
     }
     __syncthreads();
     ++seq;
-    if (wave == 0) { sc_publish_fwd(result, part, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge_fwd(mailbox, seq, chal); }
+    if (wave == 0) { sc_publish_fwd(result, part, a.k, a.off, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge_fwd(mailbox, seq, chal); }
     __syncthreads();
     if (chal[0] == 0) {  // host never answered: publish an abort marker and leave
       if (tid == 0) pub_store((u64*)flag, ~0ull);
@@ -886,16 +891,18 @@ __global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* resul
 // (the result area is fine-grained host memory, nothing is cached) and the flag word carries a TAG that binds the
 // sequence number to the payload: tag = mix(seq) + sum_i (i+1) * word_i. The host accepts a message only when the tag
 // it recomputes from the words it reads matches, so any reordering of the posted writes is harmless.
-__device__ __forceinline__ void sc_publish(Ext* result, const Ext* part, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane) {
+__device__ __forceinline__ void sc_publish(Ext* result, const Ext* part, const int* tk, const int* toff, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane) {
   unsigned long long cs = 0;
   u64* rw = (u64*)result;
-  for (int e = lane; e < nterms * 4; e += 64) {
-    int term = e >> 2, t = e & 3;
+  for (int e = lane; e < nterms * SC_SLOTS; e += 64) {
+    int term = e / SC_SLOTS, t = e - term * SC_SLOTS;
+    if (t > tk[term]) continue;  // a degree-k term publishes k + 1 values, packed back to back
     Ext v = ex_zero();
-    if (wpt == 1) v = part[(size_t)term * 4 + t];
-    else for (int sb = 0; sb < wpt; sb++) v = ex_add(v, part[(size_t)(term * wpt + sb) * 4 + t]);
-    pub_store(rw + 2 * e, v.c0); pub_store(rw + 2 * e + 1, v.c1);
-    cs += (unsigned long long)(2 * e + 1) * v.c0 + (unsigned long long)(2 * e + 2) * v.c1;
+    if (wpt == 1) v = part[(size_t)term * SC_SLOTS + t];
+    else for (int sb = 0; sb < wpt; sb++) v = ex_add(v, part[(size_t)(term * wpt + sb) * SC_SLOTS + t]);
+    int o = toff[term] + t;
+    pub_store(rw + 2 * o, v.c0); pub_store(rw + 2 * o + 1, v.c1);
+    cs += (unsigned long long)(2 * o + 1) * v.c0 + (unsigned long long)(2 * o + 2) * v.c1;
   }
   cs = pub_wave_sum(cs);
   if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + cs);
@@ -924,12 +931,13 @@ __device__ __forceinline__ void sc_wait_challenge(const unsigned long long* mail
   chal[1] = __hip_atomic_load(mailbox + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   chal[2] = __hip_atomic_load(mailbox + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ void sc_publish_fwd(Ext* result, const Ext* part, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane) { sc_publish(result, part, nterms, wpt, flag, seq, lane); }
+__device__ void sc_publish_fwd(Ext* result, const Ext* part, const int* tk, const int* toff, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane) { sc_publish(result, part, tk, toff, nterms, wpt, flag, seq, lane); }
 __device__ void sc_wait_challenge_fwd(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal) { sc_wait_challenge(mailbox, seq, chal); }
+template <bool HI>
 __global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* result, unsigned long long* flag, const unsigned long long* mailbox, unsigned long long seq0) {
   extern __shared__ __align__(16) unsigned char lds_dyn[];
   Ext* L = (Ext*)lds_dyn;
-  __shared__ Ext part[64 * 4];
+  __shared__ Ext part[64 * SC_SLOTS];
   __shared__ unsigned long long chal[3];
   int tid = threadIdx.x, nt = blockDim.x;
   int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
@@ -945,37 +953,19 @@ __global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* r
     for (int term = wave / wpt; term < a.nterms; term += (wpt == 1 ? W : a.nterms + W)) {
       int sub = wave % wpt;
       int k = a.k[term];
-      int i0 = a.t[term][0], i1 = a.t[term][k > 1 ? 1 : 0], i2 = a.t[term][k > 2 ? 2 : 0];
-      const void* p0 = a.in[i0]; bool e0 = a.in_ext[i0];
-      const void* p1 = a.in[i1]; bool e1 = a.in_ext[i1];
-      const void* p2 = a.in[i2]; bool e2 = a.in_ext[i2];
-      Ext acc0 = ex_zero(), acc1 = ex_zero(), acc2 = ex_zero(), acc3 = ex_zero();
-      for (size_t b = (size_t)sub * 64 + lane; b < npairs; b += (size_t)wpt * 64) {
-        Ext a0 = ld_elem(p0, e0, 2 * b), b0 = ld_elem(p0, e0, 2 * b + 1);
-        if (k == 1) { acc0 = ex_add(acc0, a0); acc1 = ex_add(acc1, b0); }
-        else if (k == 2) {
-          Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
-          Ext c0 = ex_sub(ex_dbl(b0), a0), c1 = ex_sub(ex_dbl(b1), a1);
-          acc0 = ex_add(acc0, ex_mul(a0, a1)); acc1 = ex_add(acc1, ex_mul(b0, b1)); acc2 = ex_add(acc2, ex_mul(c0, c1));
-        } else {
-          Ext a1 = ld_elem(p1, e1, 2 * b), b1 = ld_elem(p1, e1, 2 * b + 1);
-          Ext a2 = ld_elem(p2, e2, 2 * b), b2 = ld_elem(p2, e2, 2 * b + 1);
-          Ext d0 = ex_sub(b0, a0), d1 = ex_sub(b1, a1), d2 = ex_sub(b2, a2);
-          Ext c0 = ex_add(b0, d0), c1 = ex_add(b1, d1), c2 = ex_add(b2, d2);
-          Ext f0 = ex_add(c0, d0), f1 = ex_add(c1, d1), f2 = ex_add(c2, d2);
-          acc0 = ex_add(acc0, ex_mul(ex_mul(a0, a1), a2)); acc1 = ex_add(acc1, ex_mul(ex_mul(b0, b1), b2));
-          acc2 = ex_add(acc2, ex_mul(ex_mul(c0, c1), c2)); acc3 = ex_add(acc3, ex_mul(ex_mul(f0, f1), f2));
-        }
-      }
-      acc0 = wave_reduce_ext(acc0); acc1 = wave_reduce_ext(acc1);
-      if (k >= 2) acc2 = wave_reduce_ext(acc2);
-      if (k >= 3) acc3 = wave_reduce_ext(acc3);
-      if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * 4; o[0] = acc0; o[1] = acc1; o[2] = acc2; o[3] = acc3; }
+      GlobalPairs L;
+#pragma unroll
+      for (int j = 0; j < ScW<HI>::K; j++) { int ti = a.t[term][j < k ? j : 0]; L.p[j] = a.in[ti]; L.e[j] = a.in_ext[ti]; }
+      Ext acc[SC_SLOTS];
+      sc_accumulate<HI>(k, L, (size_t)sub * 64 + lane, (size_t)wpt * 64, npairs, acc);
+#pragma unroll
+      for (int t = 0; t < SC_SLOTS; t++) if (t <= k) acc[t] = wave_reduce_ext(acc[t]);
+      if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * SC_SLOTS; for (int t = 0; t < SC_SLOTS; t++) o[t] = acc[t]; }
       if (wpt > 1) break;
     }
     __syncthreads();
     ++seq;
-    if (wave == 0) { sc_publish(result, part, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge(mailbox, seq, chal); }
+    if (wave == 0) { sc_publish(result, part, a.k, a.off, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge(mailbox, seq, chal); }
     __syncthreads();
     if (chal[0] == 0) { if (tid == 0) pub_store((u64*)flag, ~0ull); return; }
     r = ex(chal[1], chal[2]);
@@ -1002,37 +992,21 @@ __global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* r
     for (int term = wave / wpt; term < a.nterms; term += (wpt == 1 ? W : a.nterms + W)) {
       int sub = wave % wpt;
       int k = a.k[term];
-      const Ext* p0 = L + ((size_t)a.t[term][0] << lgf);
-      const Ext* p1 = L + ((size_t)a.t[term][k > 1 ? 1 : 0] << lgf);
-      const Ext* p2 = L + ((size_t)a.t[term][k > 2 ? 2 : 0] << lgf);
-      Ext acc0 = ex_zero(), acc1 = ex_zero(), acc2 = ex_zero(), acc3 = ex_zero();
-      for (size_t q = (size_t)sub * 64 + lane; q < h; q += (size_t)wpt * 64) {
-        Ext a0 = p0[q], b0 = p0[q + h];
-        if (k == 1) { acc0 = ex_add(acc0, a0); acc1 = ex_add(acc1, b0); }
-        else if (k == 2) {
-          Ext a1 = p1[q], b1 = p1[q + h];
-          Ext c0 = ex_sub(ex_dbl(b0), a0), c1 = ex_sub(ex_dbl(b1), a1);
-          acc0 = ex_add(acc0, ex_mul(a0, a1)); acc1 = ex_add(acc1, ex_mul(b0, b1)); acc2 = ex_add(acc2, ex_mul(c0, c1));
-        } else {
-          Ext a1 = p1[q], b1 = p1[q + h], a2 = p2[q], b2 = p2[q + h];
-          Ext d0 = ex_sub(b0, a0), d1 = ex_sub(b1, a1), d2 = ex_sub(b2, a2);
-          Ext c0 = ex_add(b0, d0), c1 = ex_add(b1, d1), c2 = ex_add(b2, d2);
-          Ext f0 = ex_add(c0, d0), f1 = ex_add(c1, d1), f2 = ex_add(c2, d2);
-          acc0 = ex_add(acc0, ex_mul(ex_mul(a0, a1), a2)); acc1 = ex_add(acc1, ex_mul(ex_mul(b0, b1), b2));
-          acc2 = ex_add(acc2, ex_mul(ex_mul(c0, c1), c2)); acc3 = ex_add(acc3, ex_mul(ex_mul(f0, f1), f2));
-        }
-      }
-      acc0 = wave_reduce_ext(acc0); acc1 = wave_reduce_ext(acc1);
-      if (k >= 2) acc2 = wave_reduce_ext(acc2);
-      if (k >= 3) acc3 = wave_reduce_ext(acc3);
-      if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * 4; o[0] = acc0; o[1] = acc1; o[2] = acc2; o[3] = acc3; }
+      LdsPairs LP; LP.h = h;
+#pragma unroll
+      for (int j = 0; j < ScW<HI>::K; j++) LP.p[j] = L + ((size_t)a.t[term][j < k ? j : 0] << lgf);
+      Ext acc[SC_SLOTS];
+      sc_accumulate<HI>(k, LP, (size_t)sub * 64 + lane, (size_t)wpt * 64, h, acc);
+#pragma unroll
+      for (int t = 0; t < SC_SLOTS; t++) if (t <= k) acc[t] = wave_reduce_ext(acc[t]);
+      if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * SC_SLOTS; for (int t = 0; t < SC_SLOTS; t++) o[t] = acc[t]; }
       if (wpt > 1) break;
     }
     __syncthreads();
     ++seq;
     if (tid == 0) { unsigned long long now = clock64(); c_sums += now - tk; tk = now; }
     if (wave == 0) {
-      sc_publish(result, part, a.nterms, wpt, flag, seq, lane);
+      sc_publish(result, part, a.k, a.off, a.nterms, wpt, flag, seq, lane);
       if (tid == 0) { unsigned long long now = clock64(); c_pub += now - tk; tk = now; }
       if (lane == 0) sc_wait_challenge(mailbox, seq, chal);
       if (tid == 0) { unsigned long long now = clock64(); c_wait += now - tk; tk = now; c_rounds++; }
@@ -1128,6 +1102,8 @@ static inline int grid_for(size_t n, int cap = 2048) {
 
 struct ProfRec { const char* name; double bytes; hipEvent_t a, b; };
 #define DPL_LDS(kern, grid, block, lds, ...) do { prof_begin(#kern); hipLaunchKernelGGL(kern, grid, block, lds, s_, __VA_ARGS__); prof_end(); } while (0)
+#define DPL_HI(kern, hi, grid, block, ...) do { if (hi) { DPL((kern<true>), grid, block, __VA_ARGS__); } else { DPL((kern<false>), grid, block, __VA_ARGS__); } } while (0)
+#define DPL_LDS_HI(kern, hi, grid, block, lds, ...) do { if (hi) { DPL_LDS((kern<true>), grid, block, lds, __VA_ARGS__); } else { DPL_LDS((kern<false>), grid, block, lds, __VA_ARGS__); } } while (0)
 #define DPL(kern, grid, block, ...) do { prof_begin(#kern); hipLaunchKernelGGL(kern, grid, block, 0, s_, __VA_ARGS__); prof_end(); } while (0)
 
 class HipDev : public Dev {
@@ -1284,7 +1260,8 @@ class HipDev : public Dev {
     HIP_CHECK(hipHostGetDevicePointer((void**)&hstage_dev_, hstage_, 0));
     hstage_dev_ += 0;
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_rc), POSEIDON2_RC_HOST, sizeof(POSEIDON2_RC_HOST)));
-    HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_persist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS_MAX));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_persist_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS_MAX));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_persist_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS_MAX));
   }
   ~HipDev() override {
     hipSetDevice(device_);
@@ -1318,8 +1295,10 @@ class HipDev : public Dev {
     std::vector<std::pair<std::string, Agg>> agg;
     for (auto& r : recs_) {
       float ms = 0; hipEventElapsedTime(&ms, r.a, r.b);
-      size_t k = 0; for (; k < agg.size(); k++) if (agg[k].first == r.name) break;
-      if (k == agg.size()) agg.push_back({r.name, Agg()});
+      std::string nm = r.name;  // "(k_x<3, true>)" -> "k_x<3, true>"
+      if (nm.size() > 2 && nm.front() == '(' && nm.back() == ')') nm = nm.substr(1, nm.size() - 2);
+      size_t k = 0; for (; k < agg.size(); k++) if (agg[k].first == nm) break;
+      if (k == agg.size()) agg.push_back({nm, Agg()});
       agg[k].second.n++; agg[k].second.ms += ms; agg[k].second.bytes += r.bytes;
     }
     std::string out = "[";
@@ -1393,7 +1372,11 @@ class HipDev : public Dev {
   }
   void eq_table(const DBuf& out, const Ext* pt, unsigned k, Ext scale, bool acc) override {
     DP_REQUIRE(out.ext && out.n == (size_t(1) << k), DP_ERR_SHAPE, "eq_table: output shape");
-    nb_ = 16.0 * out.n * (acc ? 2 : 1); DPL(k_eq_table, dim3(grid_for(out.n)), dim3(TPB), (Ext*)out.p, make_point(pt, k), k, scale, acc ? 1 : 0);
+    nb_ = 16.0 * out.n * (acc ? 2 : 1); DPL(k_eq_table, dim3(grid_for(out.n)), dim3(TPB), (Ext*)out.p, make_point(pt, k), k, scale, acc ? 1 : 0, out.n);
+  }
+  void eq_table_tiled(const DBuf& out, const Ext* pt, unsigned k) override {
+    DP_REQUIRE(out.ext && out.n % (size_t(1) << k) == 0, DP_ERR_SHAPE, "eq_table_tiled: output shape");
+    nb_ = 16.0 * out.n; DPL(k_eq_table, dim3(grid_for(out.n)), dim3(TPB), (Ext*)out.p, make_point(pt, k), k, ex_one(), 0, out.n);
   }
   void mle_eval_batch(const DBuf* fs, int nf, const Ext* pt, unsigned k, Ext* out) override {
     size_t n = size_t(1) << k;
@@ -1457,25 +1440,29 @@ class HipDev : public Dev {
     for (int i = 0; i < nt; i++) DP_REQUIRE(tabs[i].n == n_in, DP_ERR_SHAPE, "sumcheck: tables must have equal length");
     size_t n_after = r ? n_in / 2 : n_in;
     DP_REQUIRE(n_after >= 2, DP_ERR_SHAPE, "sumcheck: tables must keep length >= 2");
-    auto read_terms = [&]() {
-      size_t o = 0;
-      for (int i = 0; i < nterms; i++)
-        for (int t = 0; t <= terms[i].k; t++) out[o++] = ex(hres_[(i * 4 + t) * 2], hres_[(i * 4 + t) * 2 + 1]);
+    size_t nraw = 0;  // a degree-k term contributes k + 1 values; single-workgroup kernels publish them packed
+    for (int i = 0; i < nterms; i++) { DP_REQUIRE(terms[i].k >= 1 && terms[i].k <= SC_MAXK, DP_ERR_SHAPE, "sumcheck: term degree must be 1..5"); nraw += terms[i].k + 1; }
+    bool hi = false; for (int i = 0; i < nterms; i++) hi = hi || terms[i].k > 3;
+    auto read_terms = [&]() { for (size_t o = 0; o < nraw; o++) out[o] = ex(hres_[2 * o], hres_[2 * o + 1]); };
+    auto fill_terms = [&](int (*tk), int (*tt)[SC_MAXK], int* toff) {
+      for (int i = 0; i < MAX_TERMS; i++) { tk[i] = 1; for (int j = 0; j < SC_MAXK; j++) tt[i][j] = 0; if (toff) toff[i] = 0; }
+      int o = 0;
+      for (int i = 0; i < nterms; i++) { tk[i] = terms[i].k; for (int j = 0; j < SC_MAXK; j++) tt[i][j] = j < terms[i].k ? terms[i].t[j] : 0; if (toff) toff[i] = o; o += terms[i].k + 1; }
     };
     if (sess_.active) {  // the persistent kernel is waiting for this challenge
       DP_REQUIRE(r && nt == sess_.ntabs && n_in == sess_.n, DP_ERR_ARG, "sumcheck session out of sync");
       post_challenge(*r);
-      wait_flag(++sess_.seq, (size_t)nterms * 8);
+      wait_flag(++sess_.seq, 2 * nraw);
       sess_.n = n_after;
       for (int i = 0; i < nt; i++) { tabs[i].p = sess_.nextA ? sess_.a[i] : sess_.b[i]; tabs[i].n = n_after; tabs[i].ext = true; }
       sess_.nextA = !sess_.nextA;
       read_terms();
       return;
     }
-    if (persist_ && n_after <= SC_PERSIST_MAX && n_after >= 4 && (size_t)nterms * 8 <= RES_WORDS) {
+    if (persist_ && n_after <= SC_PERSIST_MAX && n_after >= 4 && 2 * nraw <= RES_WORDS) {
       ScPersistArgs a;
       for (int i = 0; i < MAX_TABS; i++) { a.in[i] = nullptr; a.in_ext[i] = 0; a.bufA[i] = nullptr; a.bufB[i] = nullptr; }
-      for (int i = 0; i < MAX_TERMS; i++) { a.k[i] = 1; a.t[i][0] = a.t[i][1] = a.t[i][2] = 0; }
+      fill_terms(a.k, a.t, a.off);
       sess_.a.assign(nt, nullptr); sess_.b.assign(nt, nullptr);
       // ping-pong buffers: A takes the first fold output, B the second, A the third, ...
       size_t first = r ? n_after : n_after / 2;
@@ -1484,7 +1471,6 @@ class HipDev : public Dev {
         sess_.a[i] = (Ext*)alloc(first, true).p; sess_.b[i] = (Ext*)alloc(std::max<size_t>(first / 2, 1), true).p;
         a.bufA[i] = sess_.a[i]; a.bufB[i] = sess_.b[i];
       }
-      for (int i = 0; i < nterms; i++) { a.k[i] = terms[i].k; for (int j = 0; j < 3; j++) a.t[i][j] = terms[i].t[j]; }
       a.ntabs = nt; a.nterms = nterms; a.has_r0 = r ? 1 : 0; a.n0 = n_in; a.r0 = r ? *r : ex_zero(); a.dbg = scdbg_;
       sess_.active = true; sess_.ntabs = nt; sess_.n = n_after; sess_.seq = seq_; sess_.nextA = r ? false : true;
       // reserve the sequence numbers of all rounds + the final message
@@ -1493,35 +1479,33 @@ class HipDev : public Dev {
       size_t work = (size_t)nterms * (n_after / 2) + (size_t)nt * n_after / 4;
       int threads = work >= 2048 ? 1024 : work >= 512 ? 512 : 256;
       size_t lds = (size_t)nt * (n_in / 2) * 16;
-      if (lds <= SC_LDS_MAX) { nb_ = 0; DPL_LDS(k_sc_persist_lds, dim3(1), dim3(threads), lds, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
-      else { nb_ = 0; DPL(k_sc_persist, dim3(1), dim3(threads), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
-      wait_flag(++sess_.seq, (size_t)nterms * 8);
+      if (lds <= SC_LDS_MAX) { nb_ = 0; DPL_LDS_HI(k_sc_persist_lds, hi, dim3(1), dim3(threads), lds, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
+      else { nb_ = 0; DPL_HI(k_sc_persist, hi, dim3(1), dim3(threads), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
+      wait_flag(++sess_.seq, 2 * nraw);
       if (r) for (int i = 0; i < nt; i++) { tabs[i].p = sess_.a[i]; tabs[i].n = n_after; tabs[i].ext = true; }
       read_terms();
       return;
     }
-    if (zerocopy_ && n_after <= SC_SMALL_MAX && (size_t)nterms * 8 <= RES_WORDS) {
+    if (zerocopy_ && n_after <= SC_SMALL_MAX && 2 * nraw <= RES_WORDS) {
       ScSmallArgs a;
       for (int i = 0; i < MAX_TABS; i++) { a.in[i] = nullptr; a.out[i] = nullptr; a.in_ext[i] = 0; }
-      for (int i = 0; i < MAX_TERMS; i++) { a.k[i] = 1; a.t[i][0] = a.t[i][1] = a.t[i][2] = 0; }
+      fill_terms(a.k, a.t, a.off);
       double bytes = 0;
       for (int i = 0; i < nt; i++) {
         a.in[i] = tabs[i].p; a.in_ext[i] = tabs[i].ext;
         if (r) { DBuf o = alloc(n_after, true); a.out[i] = (Ext*)o.p; bytes += tabs[i].bytes() + o.bytes(); tabs[i] = o; }
       }
-      for (int i = 0; i < nterms; i++) { a.k[i] = terms[i].k; for (int j = 0; j < 3; j++) a.t[i][j] = terms[i].t[j]; for (int j = 0; j < terms[i].k; j++) bytes += 16.0 * n_after; }
+      for (int i = 0; i < nterms; i++) bytes += 16.0 * n_after * terms[i].k;
       a.ntabs = nt; a.nterms = nterms; a.has_r = r ? 1 : 0; a.n_after = n_after; a.r = r ? *r : ex_zero();
       unsigned long long seq = ++seq_;
       size_t work = (size_t)nterms * (n_after / 2) + (r ? (size_t)nt * n_after / 4 : 0);
       int threads = work >= 2048 ? 1024 : work >= 512 ? 512 : 256;
-      nb_ = bytes; DPL(k_sc_small, dim3(1), dim3(threads), a, (Ext*)hres_dev_, hflag_dev_, seq);
-      wait_flag(seq, (size_t)nterms * 8);
-      size_t o = 0;
-      for (int i = 0; i < nterms; i++)
-        for (int t = 0; t <= terms[i].k; t++) out[o++] = ex(hres_[(i * 4 + t) * 2], hres_[(i * 4 + t) * 2 + 1]);
+      nb_ = bytes; DPL_HI(k_sc_small, hi, dim3(1), dim3(threads), a, (Ext*)hres_dev_, hflag_dev_, seq);
+      wait_flag(seq, 2 * nraw);
+      read_terms();
       return;
     }
-    if (r && nterms == 1 && terms[0].k == nt && n_in >= 8) {
+    if (r && nterms == 1 && terms[0].k == nt && nt <= 3 && n_in >= 8) {
       bool uniform = true, distinct = true;
       for (int i = 0; i < nt; i++) { uniform &= tabs[i].ext == tabs[0].ext; for (int j = 0; j < i; j++) distinct &= terms[0].t[i] != terms[0].t[j]; }
       if (uniform && distinct) {
@@ -1556,17 +1540,17 @@ class HipDev : public Dev {
     TermArgs a;
     for (int i = 0; i < MAX_TABS; i++) { a.tab[i] = nullptr; a.ext[i] = 0; }
     for (int i = 0; i < nt; i++) { a.tab[i] = tabs[i].p; a.ext[i] = tabs[i].ext; }
-    for (int i = 0; i < MAX_TERMS; i++) { a.k[i] = 1; a.t[i][0] = a.t[i][1] = a.t[i][2] = 0; }
-    for (int i = 0; i < nterms; i++) { a.k[i] = terms[i].k; for (int j = 0; j < 3; j++) a.t[i][j] = terms[i].t[j]; }
+    fill_terms(a.k, a.t, nullptr);
     a.npairs = n / 2;
     size_t mk = mark();
     int g = grid_for(a.npairs, 2048);
-    Ext* partial = (Ext*)arena_alloc((size_t)nterms * g * 4 * 16);
-    nb_ = [&] { double b = 0; for (int i = 0; i < nterms; i++) for (int j = 0; j < terms[i].k; j++) b += tabs[terms[i].t[j]].bytes(); return b; }(); DPL(k_sc_terms, dim3(g, nterms), dim3(TPB), a, partial);
-    reduce_publish(partial, (size_t)g, 4, nterms * 4);
+    DP_REQUIRE(nterms * SC_SLOTS <= 1024, DP_ERR_SHAPE, "sumcheck: too many terms for one reduction");
+    Ext* partial = (Ext*)arena_alloc((size_t)nterms * g * SC_SLOTS * 16);
+    nb_ = [&] { double b = 0; for (int i = 0; i < nterms; i++) for (int j = 0; j < terms[i].k; j++) b += tabs[terms[i].t[j]].bytes(); return b; }(); DPL_HI(k_sc_terms, hi, dim3(g, nterms), dim3(TPB), a, partial);
+    reduce_publish(partial, (size_t)g, SC_SLOTS, nterms * SC_SLOTS);
     size_t o = 0;
     for (int i = 0; i < nterms; i++)
-      for (int t = 0; t <= terms[i].k; t++) out[o++] = ex(hres_[(i * 4 + t) * 2], hres_[(i * 4 + t) * 2 + 1]);
+      for (int t = 0; t <= terms[i].k; t++) out[o++] = ex(hres_[(i * SC_SLOTS + t) * 2], hres_[(i * SC_SLOTS + t) * 2 + 1]);
     release(mk);
   }
   void sc_finish(DBuf* tabs, int nt, Ext r, Ext* finals) override {

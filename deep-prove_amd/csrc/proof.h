@@ -29,12 +29,26 @@ struct BasefoldProof {
   std::vector<FieldVec> trivial_proof;
   bool is_trivial() const { return sumcheck_messages.empty() && queries.empty() && sumcheck_proof.empty(); }
 };
-enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2 };
+enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5 };
 struct DenseProof { IOPProof sumcheck; Ext bias_eval; std::vector<Ext> individual_claims; };
 struct SamePolyProof { IOPProof sumcheck; std::vector<Ext> evals; };
 struct ActivationProof { SamePolyProof io_accumulation; LogUpProof lookup; std::vector<Commitment> commits; };
 struct RequantProof { IOPProof io_accumulation; std::vector<Ext> accumulation_evals; LogUpProof clamping_lookup, shifted_lookup; std::vector<Commitment> commitments; };
-struct LayerProof { int kind = 0; DenseProof dense; ActivationProof act; RequantProof req; };
+struct HadamardProof { IOPProof sumcheck; std::vector<Ext> individual_claim; };  // layers/hadamard.rs:51-56
+struct ConvProof {  // layers/convolution.rs:98-127, fields in declaration order
+  IOPProof fft_proof, fft_proof_weights;
+  std::vector<IOPProof> fft_delegation_proof, fft_delegation_proof_weights;
+  IOPProof ifft_proof;
+  std::vector<IOPProof> ifft_delegation_proof;
+  IOPProof hadamard_proof;
+  std::vector<Ext> fft_claims, fft_weight_claims, ifft_claims;
+  std::vector<std::vector<Ext>> fft_delegation_claims, fft_delegation_weights_claims, ifft_delegation_claims;
+  std::vector<Ext> partial_evals, hadamard_clams;
+  Ext bias_claim;
+  HadamardProof clearing_proof;
+};
+struct PoolingProof { IOPProof sumcheck; LogUpProof lookup; std::vector<Ext> zerocheck_evals; size_t variable_gap = 0; std::vector<Commitment> commitments; };  // layers/pooling.rs:60-76
+struct LayerProof { int kind = 0; DenseProof dense; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; };
 struct TableProof { Commitment multiplicity_commit; LogUpProof lookup; };
 struct Proof {
   std::map<size_t, LayerProof> steps;
@@ -53,6 +67,8 @@ struct Writer {
   void d(const Digest& x) { for (int i = 0; i < 4; i++) u(x.v[i]); }
   void iop(const IOPProof& p) { ve(p.point); u(p.proofs.size()); for (auto& r : p.proofs) ve(r); }
   void claim(const Claim& c) { ve(c.point); e(c.eval); }
+  void viop(const std::vector<IOPProof>& v) { u(v.size()); for (auto& x : v) iop(x); }
+  void vve(const std::vector<std::vector<Ext>>& v) { u(v.size()); for (auto& x : v) ve(x); }
   void logup(const LogUpProof& p) {
     u(p.sumcheck_proofs.size()); for (auto& s : p.sumcheck_proofs) iop(s);
     u(p.round_evaluations.size()); for (auto& r : p.round_evaluations) ve(r);
@@ -90,10 +106,21 @@ inline std::vector<u64> serialize_proof(const Proof& p) {
     else if (lp.kind == L_REQUANT) {
       w.iop(lp.req.io_accumulation); w.ve(lp.req.accumulation_evals); w.logup(lp.req.clamping_lookup); w.logup(lp.req.shifted_lookup);
       w.u(lp.req.commitments.size()); for (auto& c : lp.req.commitments) w.comm(c);
-    } else {
+    } else if (lp.kind == L_RELU) {
       w.iop(lp.act.io_accumulation.sumcheck); w.ve(lp.act.io_accumulation.evals); w.logup(lp.act.lookup);
       w.u(lp.act.commits.size()); for (auto& c : lp.act.commits) w.comm(c);
-    }
+    } else if (lp.kind == L_CONV) {
+      const ConvProof& c = lp.conv;
+      w.iop(c.fft_proof); w.iop(c.fft_proof_weights); w.viop(c.fft_delegation_proof); w.viop(c.fft_delegation_proof_weights);
+      w.iop(c.ifft_proof); w.viop(c.ifft_delegation_proof); w.iop(c.hadamard_proof);
+      w.ve(c.fft_claims); w.ve(c.fft_weight_claims); w.ve(c.ifft_claims);
+      w.vve(c.fft_delegation_claims); w.vve(c.fft_delegation_weights_claims); w.vve(c.ifft_delegation_claims);
+      w.ve(c.partial_evals); w.ve(c.hadamard_clams); w.e(c.bias_claim);
+      w.iop(c.clearing_proof.sumcheck); w.ve(c.clearing_proof.individual_claim);
+    } else if (lp.kind == L_MAXPOOL) {
+      w.iop(lp.pool.sumcheck); w.logup(lp.pool.lookup); w.ve(lp.pool.zerocheck_evals); w.u(lp.pool.variable_gap);
+      w.u(lp.pool.commitments.size()); for (auto& c : lp.pool.commitments) w.comm(c);
+    } else DP_REQUIRE(false, DP_ERR_ARG, "serialize_proof: unknown layer kind");
   }
   w.u(p.table_proofs.size()); for (auto& tp : p.table_proofs) { w.comm(tp.multiplicity_commit); w.logup(tp.lookup); }
   w.basefold(p.batch_proof);
@@ -112,6 +139,8 @@ struct Reader {
   Digest d() { Digest x; for (int i = 0; i < 4; i++) x.v[i] = fe(); return x; }
   IOPProof iop() { IOPProof q; q.point = ve(); size_t k = len(); q.proofs.resize(k); for (auto& r : q.proofs) r = ve(); return q; }
   Claim claim() { Claim c; c.point = ve(); c.eval = e(); return c; }
+  std::vector<IOPProof> viop() { size_t k = len(); std::vector<IOPProof> v(k); for (auto& x : v) x = iop(); return v; }
+  std::vector<std::vector<Ext>> vve() { size_t k = len(); std::vector<std::vector<Ext>> v(k); for (auto& x : v) x = ve(); return v; }
   LogUpProof logup() {
     LogUpProof q; size_t k = len(); q.sumcheck_proofs.resize(k); for (auto& s : q.sumcheck_proofs) s = iop();
     k = len(); q.round_evaluations.resize(k); for (auto& r : q.round_evaluations) r = ve();
@@ -154,6 +183,17 @@ inline Proof deserialize_proof(const u64* words, size_t n) {
     } else if (lp.kind == L_RELU) {
       lp.act.io_accumulation.sumcheck = r.iop(); lp.act.io_accumulation.evals = r.ve(); lp.act.lookup = r.logup();
       size_t k = r.len(); lp.act.commits.resize(k); for (auto& c : lp.act.commits) c = r.comm();
+    } else if (lp.kind == L_CONV) {
+      ConvProof& c = lp.conv;
+      c.fft_proof = r.iop(); c.fft_proof_weights = r.iop(); c.fft_delegation_proof = r.viop(); c.fft_delegation_proof_weights = r.viop();
+      c.ifft_proof = r.iop(); c.ifft_delegation_proof = r.viop(); c.hadamard_proof = r.iop();
+      c.fft_claims = r.ve(); c.fft_weight_claims = r.ve(); c.ifft_claims = r.ve();
+      c.fft_delegation_claims = r.vve(); c.fft_delegation_weights_claims = r.vve(); c.ifft_delegation_claims = r.vve();
+      c.partial_evals = r.ve(); c.hadamard_clams = r.ve(); c.bias_claim = r.e();
+      c.clearing_proof.sumcheck = r.iop(); c.clearing_proof.individual_claim = r.ve();
+    } else if (lp.kind == L_MAXPOOL) {
+      lp.pool.sumcheck = r.iop(); lp.pool.lookup = r.logup(); lp.pool.zerocheck_evals = r.ve(); lp.pool.variable_gap = (size_t)r.u();
+      size_t k = r.len(); lp.pool.commitments.resize(k); for (auto& c : lp.pool.commitments) c = r.comm();
     } else DP_REQUIRE(false, DP_ERR_ARG, "proof stream: unknown layer kind");
     p.steps[id] = lp;
   }

@@ -18,9 +18,10 @@ struct DevVP {  // VirtualPolynomial (multilinear_extensions/src/virtual_poly.rs
     tabs.push_back(b);
     return (int)tabs.size() - 1;
   }
-  void add_mle_list(std::initializer_list<DBuf> list, Ext coeff) {
-    DP_REQUIRE(list.size() >= 1 && list.size() <= 3, DP_ERR_SHAPE, "sumcheck term degree must be 1..3");
-    ScTerm t; t.k = (int)list.size(); t.t[0] = t.t[1] = t.t[2] = 0;
+  void add_mle_list(std::initializer_list<DBuf> list, Ext coeff) { add_mle_list(std::vector<DBuf>(list), coeff); }
+  void add_mle_list(const std::vector<DBuf>& list, Ext coeff) {
+    DP_REQUIRE(list.size() >= 1 && list.size() <= (size_t)SC_MAXK, DP_ERR_SHAPE, "sumcheck term degree must be 1..5");
+    ScTerm t; t.k = (int)list.size(); for (int q = 0; q < SC_MAXK; q++) t.t[q] = 0;
     int j = 0;
     for (const DBuf& b : list) {
       DP_REQUIRE(b.n == (size_t(1) << nv), DP_ERR_SHAPE, "sumcheck: every table must have max_num_variables variables");
@@ -46,13 +47,13 @@ inline Ext lagrange_eval_small(const Ext* evals, size_t n, Ext at) {
   }
   return res;
 }
-// the prover only ever extrapolates from nodes 0..k (k <= 3) to the integer points k+1..3: those Lagrange
+// the prover only ever extrapolates from nodes 0..k (k < SC_MAXK) to the integer points k+1..SC_MAXK: those Lagrange
 // coefficients are constants, computed once
 struct ExtrapolationTable {
-  u64 c[4][5][4];
+  u64 c[SC_MAXK + 1][SC_MAXK + 1][SC_MAXK + 1];
   ExtrapolationTable() {
-    for (unsigned kk = 1; kk <= 3; kk++)
-      for (unsigned a = kk + 1; a <= 4; a++)
+    for (unsigned kk = 1; kk < (unsigned)SC_MAXK; kk++)
+      for (unsigned a = kk + 1; a <= (unsigned)SC_MAXK; a++)
         for (unsigned i = 0; i <= kk; i++) {
           u64 num = 1, den = 1;
           for (unsigned j = 0; j <= kk; j++) { if (j == i) continue; num = gl_mul(num, gl_sub(a, j)); den = gl_mul(den, gl_sub(i, j)); }

@@ -10,6 +10,7 @@
 #pragma once
 #include "logup.h"
 #include "pcs.h"
+#include "cnn.h"
 #include <unordered_map>
 #include <algorithm>
 #include <memory>
@@ -26,7 +27,14 @@ constexpr int64_t COLUMN_SEPARATOR = int64_t(1) << 32;
 struct LayerSpec {
   int kind = L_DENSE;
   size_t nrows = 0, ncols = 0;
-  std::vector<int64_t> weights, bias;
+  std::vector<int64_t> weights, bias;  // dense: row major / padded bias; conv: filter [kw][kx][real_nw][real_nw], bias [kw]
+  // conv (layers/convolution.rs:52-83, tensor.rs:409-431): padded filter count kw, padded input channels kx, padded kernel
+  // side real_nw, padded input side nw; unp_out = conv2d_shape of the unpadded tensors (for the garbage-clearing tensor)
+  size_t kw = 0, kx = 0, real_nw = 0, nw = 0;
+  size_t unp_out[3] = {0, 0, 0};
+  size_t pin[3] = {0, 0, 0};  // maxpool: padded input shape [c, h, w]
+  std::shared_ptr<const std::vector<u64>> wfft;  // conv: FFT of every zero-padded kernel, [kw][kx][2 nw^2] (prepare_conv)
+  size_t filter_size() const { return nw * nw; }
   unsigned right_shift = 0, fp_scale = 0, intermediate_bit_size = 0;
   int64_t fixed_point_multiplier = 0;
   unsigned shift() const { return fp_scale + right_shift; }
@@ -51,7 +59,83 @@ inline void table_columns(const TableType& tt, std::vector<int64_t>& merged, std
 }
 
 // ---- inference (the reference's Model::run; CPU pre-processing outside "proving time", zkml/src/bin/bench.rs:341-352)
-struct Trace { std::vector<std::vector<int64_t>> in, out; };
+// ConvData (tensor.rs:326-372) in the base field: what the FFT convolution computes on the way, kept for the prover
+struct ConvTrace {
+  std::vector<u64> input_pad;   // [kx][2n^2]: every input channel reversed (index_x) and zero-padded to the FFT length
+  std::vector<u64> input_fft;   // [kx][2n^2]
+  std::vector<u64> prod;        // [kw][2n^2]: sum_j FFT(x_j) o FFT(w_ij)
+  std::vector<int64_t> output_as_element;  // conv output after the bias, before clearing (convolution.rs:311-316)
+};
+struct Trace { std::vector<std::vector<int64_t>> in, out; std::vector<ConvTrace> conv; };
+// FFT of every kernel of a convolution, zero-padded to 2 nw^2 (index_w, tensor.rs:236-254): computed once per model —
+// the reference recomputes these kw*kx transforms at every inference (tensor.rs:494-507)
+inline std::shared_ptr<const std::vector<u64>> conv_weight_fft(const LayerSpec& l) {
+  size_t N = 2 * l.nw * l.nw, fsz = l.real_nw * l.real_nw;
+  auto w = std::make_shared<std::vector<u64>>(l.kw * l.kx * N, 0);
+  for (size_t ij = 0; ij < l.kw * l.kx; ij++) {
+    u64* o = w->data() + ij * N;
+    for (size_t a = 0; a < l.real_nw; a++) for (size_t b = 0; b < l.real_nw; b++) o[a * l.nw + b] = gl_from_i64(l.weights[ij * fsz + a * l.real_nw + b]);
+    gl_fft(o, N, false);
+  }
+  return w;
+}
+// Tensor::fft_conv (tensor.rs:458-523) + Convolution::op (convolution.rs:303-336)
+inline std::vector<int64_t> conv_op(const LayerSpec& l, const std::vector<int64_t>& x, ConvTrace& ct) {
+  size_t nn = l.nw * l.nw, N = 2 * nn;
+  DP_REQUIRE(x.size() == l.kx * nn, DP_ERR_SHAPE, "conv: input size mismatch");
+  std::shared_ptr<const std::vector<u64>> wf = l.wfft ? l.wfft : conv_weight_fft(l);
+  ct.input_pad.assign(l.kx * N, 0);
+  for (size_t j = 0; j < l.kx; j++) for (size_t t = 0; t < nn; t++) ct.input_pad[j * N + t] = gl_from_i64(x[j * nn + nn - 1 - t]);
+  ct.input_fft = ct.input_pad;
+  for (size_t j = 0; j < l.kx; j++) gl_fft(ct.input_fft.data() + j * N, N, false);
+  ct.prod.assign(l.kw * N, 0);
+  for (size_t i = 0; i < l.kw; i++) {
+    u64* o = ct.prod.data() + i * N;
+    for (size_t j = 0; j < l.kx; j++) {
+      const u64* xf = ct.input_fft.data() + j * N; const u64* w = wf->data() + (i * l.kx + j) * N;
+      for (size_t k = 0; k < N; k++) o[k] = gl_add(o[k], gl_mul(xf[k], w[k]));
+    }
+  }
+  std::vector<u64> out = ct.prod;
+  std::vector<int64_t> o(l.kw * nn);
+  for (size_t i = 0; i < l.kw; i++) {
+    gl_fft(out.data() + i * N, N, true);
+    for (size_t p = 0; p < nn; p++) o[i * nn + p] = gl_to_element(out[i * N + nn - 1 - p]) + l.bias[i];  // index_u + add_bias
+  }
+  ct.output_as_element = o;
+  for (size_t i = 0; i < l.kw; i++) for (size_t j = 0; j < l.nw; j++) for (size_t k = 0; k < l.nw; k++)  // clear_garbage
+    if (!(i < l.unp_out[0] && j < l.unp_out[1] && k < l.unp_out[2])) o[i * nn + j * l.nw + k] = 0;
+  return o;
+}
+// new_clearing_tensor (convolution.rs:1508-1529)
+inline std::vector<int64_t> clearing_tensor(const LayerSpec& l) {
+  std::vector<int64_t> d(l.kw * l.nw * l.nw, 0);
+  for (size_t i = 0; i < l.unp_out[0]; i++) for (size_t j = 0; j < l.unp_out[1]; j++) for (size_t k = 0; k < l.unp_out[2]; k++) d[(i * l.nw + j) * l.nw + k] = 1;
+  return d;
+}
+// Tensor::maxpool2d, kernel = stride = 2 (tensor.rs:1335-1383)
+inline std::vector<int64_t> maxpool_op(const LayerSpec& l, const std::vector<int64_t>& x) {
+  size_t c = l.pin[0], h = l.pin[1], w = l.pin[2], oh = h / 2, ow = w / 2;
+  DP_REQUIRE(x.size() == c * h * w, DP_ERR_SHAPE, "maxpool: input size mismatch");
+  std::vector<int64_t> o(c * oh * ow);
+  for (size_t n = 0; n < c; n++) for (size_t i = 0; i < oh; i++) for (size_t j = 0; j < ow; j++) {
+    const int64_t* p = &x[n * h * w + 2 * i * w + 2 * j];
+    o[(n * oh + i) * ow + j] = std::max(std::max(p[0], p[1]), std::max(p[w], p[w + 1]));
+  }
+  return o;
+}
+// Maxpool2D::compute_polys (pooling.rs:686-767): output - input at the kernel offsets (dy,dx) = (0,0),(1,0),(0,1),(1,1)
+inline std::vector<std::vector<int64_t>> maxpool_diff_polys(const LayerSpec& l, const std::vector<int64_t>& x, const std::vector<int64_t>& out) {
+  size_t c = l.pin[0], h = l.pin[1], w = l.pin[2], oh = h / 2, ow = w / 2;
+  std::vector<std::vector<int64_t>> cols(4, std::vector<int64_t>(out.size()));
+  static const size_t dy[4] = {0, 1, 0, 1}, dx[4] = {0, 0, 1, 1};
+  for (int q = 0; q < 4; q++)
+    for (size_t n = 0; n < c; n++) for (size_t i = 0; i < oh; i++) for (size_t j = 0; j < ow; j++) {
+      size_t oi = (n * oh + i) * ow + j;
+      cols[q][oi] = out[oi] - x[n * h * w + (2 * i + dy[q]) * w + 2 * j + dx[q]];
+    }
+  return cols;
+}
 inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
   Trace tr; std::vector<int64_t> cur = input;
   DP_REQUIRE(cur.size() == m.input_len, DP_ERR_SHAPE, "input length mismatch");
@@ -68,7 +152,11 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
         DP_REQUIRE((v < 0 ? -v : v) <= (int64_t(1) << l.intermediate_bit_size), DP_ERR_ARG, "requant: value exceeds intermediate bit size");
         o.push_back(q_clamp((v * l.fixed_point_multiplier + (int64_t(1) << (sh - 1))) >> sh));
       }
-    } else for (int64_t v : cur) o.push_back(q_relu(v));
+    } else if (l.kind == L_RELU) for (int64_t v : cur) o.push_back(q_relu(v));
+    else if (l.kind == L_CONV) { tr.conv.resize(m.layers.size()); o = conv_op(l, cur, tr.conv[tr.in.size() - 1]); }
+    else if (l.kind == L_MAXPOOL) o = maxpool_op(l, cur);
+    else if (l.kind == L_FLATTEN) o = cur;
+    else DP_REQUIRE(false, DP_ERR_ARG, "unknown layer kind");
     tr.out.push_back(o); cur = o;
   }
   return tr;
@@ -92,16 +180,19 @@ struct Context {
   size_t max_poly_len = 0;
   std::map<size_t, std::map<std::string, DevCommit>> model_comms;  // BTreeMap<NodeId, BTreeMap<PolyId, ..>>
   std::map<size_t, DBuf> weights_dev;                              // base-field weight matrices kept for K2
+  struct ConvDev { DBuf wfft, clearing; };                          // conv: kernel FFTs [kw][kx*2n^2] and the 0/1 clearing tensor
+  std::map<size_t, ConvDev> conv_dev;
   std::vector<TableType> tables;
   VerifierContext verifier_ctx() const {
     VerifierContext v; v.full_log = full_log; v.tables = tables; v.shape.input_len = model.input_len;
-    for (auto& l : model.layers) { LayerSpec s = l; s.weights.clear(); s.bias.clear(); v.shape.layers.push_back(s); }
+    for (auto& l : model.layers) { LayerSpec s = l; s.weights.clear(); s.bias.clear(); s.wfft.reset(); v.shape.layers.push_back(s); }
     for (auto& kv : model_comms) for (auto& pc : kv.second) v.model_comms[kv.first][pc.first] = pure_commitment(pc.second);
     return v;
   }
   ~Context() {
     if (!dev) return;
     for (auto& kv : model_comms) for (auto& pc : kv.second) dev->free_commit(pc.second);
+    for (auto& kv : conv_dev) { dev->free_persistent(kv.second.wfft); dev->free_persistent(kv.second.clearing); }
   }
 };
 
@@ -119,6 +210,15 @@ inline void validate_model(const ModelSpec& m) {
       unsigned cs = l.clamping_size();
       DP_REQUIRE(cs >= 1 && cs <= 24 && cur >= 4, DP_ERR_ARG, "requant: unsupported clamping table size / tensor length");
     } else if (l.kind == L_RELU) { DP_REQUIRE(cur >= 4, DP_ERR_SHAPE, "relu: tensor length must be >= 4"); }
+    else if (l.kind == L_CONV) {
+      DP_REQUIRE(is_pow2(l.kw) && is_pow2(l.kx) && is_pow2(l.real_nw) && is_pow2(l.nw) && l.kw >= 2 && l.nw >= 2 && 2 * l.real_nw <= l.nw, DP_ERR_SHAPE, "conv: padded dimensions must be powers of two, padded kernel <= half the padded input side");
+      DP_REQUIRE(cur == l.kx * l.nw * l.nw && l.weights.size() == l.kw * l.kx * l.real_nw * l.real_nw && l.bias.size() == l.kw, DP_ERR_SHAPE, "conv: tensor sizes");
+      DP_REQUIRE(l.unp_out[0] >= 1 && l.unp_out[0] <= l.kw && l.unp_out[1] >= 1 && l.unp_out[1] <= l.nw && l.unp_out[2] >= 1 && l.unp_out[2] <= l.nw, DP_ERR_SHAPE, "conv: unpadded output shape");
+      cur = l.kw * l.nw * l.nw;
+    } else if (l.kind == L_MAXPOOL) {
+      DP_REQUIRE(is_pow2(l.pin[0]) && is_pow2(l.pin[1]) && is_pow2(l.pin[2]) && l.pin[1] >= 2 && l.pin[2] >= 4 && cur == l.pin[0] * l.pin[1] * l.pin[2] && cur >= 16, DP_ERR_SHAPE, "maxpool: padded input shape");
+      cur /= 4;
+    } else if (l.kind == L_FLATTEN) {}
     else DP_REQUIRE(false, DP_ERR_ARG, "unknown layer kind");
   }
 }
@@ -133,21 +233,34 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
   for (auto& l : m.layers) {
     if (l.kind == L_DENSE) cur = l.nrows;
     else if (l.kind == L_REQUANT) { add({2, 0}); add({3, l.clamping_size()}); mpl = std::max(mpl, next_pow2(cur)); }
-    else { add({0, 0}); mpl = std::max(mpl, next_pow2(cur)); }
+    else if (l.kind == L_RELU) { add({0, 0}); mpl = std::max(mpl, next_pow2(cur)); }
+    else if (l.kind == L_CONV) cur = l.kw * l.nw * l.nw;
+    else if (l.kind == L_MAXPOOL) { add({2, 0}); cur /= 4; mpl = std::max(mpl, next_pow2(cur)); }
   }
   std::sort(ts.begin(), ts.end());
   for (auto& t : ts) mpl = std::max(mpl, size_t(1) << t.vars());
-  for (auto& l : m.layers) if (l.kind == L_DENSE) mpl = std::max(mpl, std::max(next_pow2(l.weights.size()), next_pow2(l.bias.size())));
+  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV) mpl = std::max(mpl, std::max(next_pow2(l.weights.size()), next_pow2(l.bias.size())));
   mpl = next_pow2(mpl);
   ctx->max_poly_len = mpl; ctx->full_log = dp_ceil_log2(mpl); ctx->tables = ts;
   dev.pcs_init(ctx->full_log);
   for (size_t id = 0; id < m.layers.size(); id++) {
-    const LayerSpec& l = m.layers[id];
-    if (l.kind != L_DENSE) continue;
+    LayerSpec& l = ctx->model.layers[id];
+    if (l.kind != L_DENSE && l.kind != L_CONV) continue;
     DBuf w = dev.alloc_persistent(l.weights.size(), false), b = dev.alloc_persistent(l.bias.size(), false);
     dev.upload_i64(w, l.weights.data()); dev.upload_i64(b, l.bias.data());
-    ctx->model_comms[id]["DenseWeight"] = dev.commit(w, true);
-    ctx->model_comms[id]["DenseBias"] = dev.commit(b, true);
+    if (l.kind == L_DENSE) {
+      ctx->model_comms[id]["DenseWeight"] = dev.commit(w, true);
+      ctx->model_comms[id]["DenseBias"] = dev.commit(b, true);
+    } else {  // model polys of a convolution (convolution.rs:452-453,546-553)
+      ctx->model_comms[id]["ConvFilter"] = dev.commit(w, true);
+      ctx->model_comms[id]["ConvBias"] = dev.commit(b, true);
+      l.wfft = conv_weight_fft(l);
+      Context::ConvDev cd;
+      cd.wfft = dev.alloc_persistent(l.wfft->size(), false); dev.upload(cd.wfft, l.wfft->data());
+      std::vector<int64_t> clr = clearing_tensor(l);
+      cd.clearing = dev.alloc_persistent(clr.size(), false); dev.upload_i64(cd.clearing, clr.data());
+      ctx->conv_dev[id] = cd;
+    }
     ctx->weights_dev[id] = w;
   }
   return ctx;
@@ -158,6 +271,7 @@ struct LogUpWitness {
   bool is_table = false;
   std::vector<DevCommit> commits;
   std::vector<DBuf> columns;
+  std::vector<DBuf> extra_columns;  // committed alongside the lookup columns but not looked up (maxpool output)
   size_t columns_per_instance = 1;
   TableType table_type{0, 0};
   DBuf multiplicities;
@@ -200,7 +314,7 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
   std::map<TableType, std::unordered_map<int64_t, u64>> counts;
   struct Col { std::vector<int64_t> v; };
   std::vector<Col> cols;                       // every i64 column that goes to the device, in commit order first
-  struct Pending { size_t node; int which; std::vector<size_t> col_ids; size_t cpi; TableType tt; };
+  struct Pending { size_t node; int which; std::vector<size_t> col_ids; size_t cpi; TableType tt; size_t n_lookup_cols = 0; };
   std::vector<Pending> pend;
   for (size_t id = 0; id < ctx.model.layers.size(); id++) {
     const LayerSpec& l = ctx.model.layers[id];
@@ -230,6 +344,17 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       for (size_t i = 0; i < a.size(); i++) counts[rt][a[i] + COLUMN_SEPARATOR * b[i]] += 1;
       Pending p{id, 0, {cols.size(), cols.size() + 1}, 2, rt};
       cols.push_back({a}); cols.push_back({b});
+      pend.push_back(p);
+    } else if (l.kind == L_MAXPOOL) {  // Pooling::gen_lookup_witness (pooling.rs:206-262): 4 difference columns + the output
+      TableType rt{2, 0};
+      std::vector<std::vector<int64_t>> diffs = maxpool_diff_polys(l, tr.in[id], tr.out[id]);
+      Pending p{id, 0, {}, 1, rt};
+      for (auto& d : diffs) {
+        for (int64_t v : d) { DP_REQUIRE(v >= 0 && v < (int64_t(1) << Q_BIT_LEN), DP_ERR_ARG, "maxpool: difference outside the range table"); counts[rt][v] += 1; }
+        p.col_ids.push_back(cols.size()); cols.push_back({std::move(d)});
+      }
+      p.col_ids.push_back(cols.size()); cols.push_back({tr.out[id]});  // committed, but not a lookup column
+      p.n_lookup_cols = 4;
       pend.push_back(p);
     }
   }
@@ -277,7 +402,11 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
   wt.lap("  witness: commit_many");
   for (auto& p : pend) {
     LogUpWitness w; w.columns_per_instance = p.cpi; w.table_type = p.tt;
-    for (size_t cid : p.col_ids) { w.columns.push_back(dcol[cid]); w.commits.push_back(comms[cid]); }
+    for (size_t q = 0; q < p.col_ids.size(); q++) {
+      size_t cid = p.col_ids[q];
+      if (!p.n_lookup_cols || q < p.n_lookup_cols) w.columns.push_back(dcol[cid]); else w.extra_columns.push_back(dcol[cid]);
+      w.commits.push_back(comms[cid]);
+    }
     ps.lookup_witness[p.node].push_back(std::move(w));
   }
   for (size_t i = 0; i < tabs.size(); i++) {
@@ -388,6 +517,214 @@ inline Claim prove_relu(ProverState& ps, size_t id, const Claim& last, const std
   return input_claim;
 }
 
+// ---- convolution (zkCNN FFT protocol, layers/convolution.rs:697-1080 with the helpers of iop/prover.rs:164-399)
+inline DBuf upload_exts(Dev& dev, const std::vector<Ext>& v) {
+  DBuf b = dev.alloc(v.size(), true);
+  dev.upload(b, (const u64*)v.data());
+  return b;
+}
+struct MatrixEval { std::vector<IOPProof> proofs; std::vector<std::vector<Ext>> claims; };
+// delegate_matrix_evaluation (iop/prover.rs:164-211): the tables of every round are a few hundred elements; beta is
+// built on the device, phi and the intermediate FFT-matrix table ride up in one upload per round
+inline MatrixEval delegate_matrix_evaluation(Dev& dev, Transcript& t, const std::vector<std::vector<Ext>>& f_middle, const std::vector<Ext>& r1, std::vector<Ext> r2, bool is_fft) {
+  std::vector<u64> omegas = phi_pow_init((unsigned)r1.size(), is_fft);
+  MatrixEval me;
+  size_t fm = f_middle.size();
+  for (size_t l = r1.size() - 1; l-- > 0;) {
+    size_t mk = dev.mark();
+    size_t len = f_middle[l].size();
+    unsigned nv = dp_ceil_log2(len);
+    DP_REQUIRE(r2.size() == nv + 1, DP_ERR_SHAPE, "delegation: point length");
+    std::vector<Ext> both = delegation_phi(len, l, fm, r1, r2.back(), omegas, is_fft);
+    both.insert(both.end(), f_middle[l].begin(), f_middle[l].end());
+    DBuf pf = upload_exts(dev, both);
+    DBuf beta = dev.alloc(len, true);
+    dev.eq_table(beta, r2.data(), nv, ex_one(), false);
+    DevVP vp(nv);
+    vp.add_mle_list({beta, pf.slice(0, len), pf.slice(len, len)}, ex_one());
+    SumcheckOut sc = sumcheck_prove(dev, vp, t);
+    dev.release(mk);
+    r2 = sc.proof.point;
+    me.proofs.push_back(sc.proof); me.claims.push_back(sc.finals);
+  }
+  return me;
+}
+struct BatchFFTProof { IOPProof proof; std::vector<Ext> claims; MatrixEval matrix_eval; std::vector<Ext> partial_evals; };
+// prove_batch_fft / prove_batch_ifft (iop/prover.rs:290-398): Y(r1, r2) = sum_i F(r1, i) X(i, r2). X is a base-field
+// matrix [rows][cols] on the device (rows = channels): X(., r2) is one pass of K2 (Dev::fix_high).
+inline BatchFFTProof prove_batch_fft_dev(Dev& dev, Transcript& t, const std::vector<Ext>& r, const DBuf& X, size_t rows, size_t cols, bool inverse) {
+  unsigned l1 = dp_ceil_log2(cols), l2 = dp_ceil_log2(rows);
+  DP_REQUIRE(r.size() >= l1 + l2 && X.n == rows * cols && l1 >= 2, DP_ERR_SHAPE, "batch fft: shapes");
+  std::vector<Ext> r1(r.begin(), r.begin() + l1), r2(r.begin() + l1, r.begin() + l1 + l2);
+  if (inverse) DP_REQUIRE(ex_is_zero(r1[l1 - 1]), DP_ERR_ARG, "Error in randomness init batch ifft");
+  std::vector<Ext> w_red(cols, ex_zero()); std::vector<std::vector<Ext>> f_middle(l1 - 1);
+  phi_g_init(w_red, f_middle, r1, inverse ? ex_inv(ex_from_u64(cols)) : ex_one(), l1, inverse);
+  size_t mk = dev.mark();
+  DBuf fr = upload_exts(dev, w_red);
+  DBuf fmx = dev.alloc(cols, true);
+  dev.fix_high(fmx, X, rows, cols, r2.data());
+  DevVP vp(l1);
+  vp.add_mle_list({fmx, fr}, ex_one());
+  SumcheckOut sc = sumcheck_prove(dev, vp, t);
+  dev.release(mk);
+  BatchFFTProof out; out.proof = sc.proof; out.claims = sc.finals;
+  out.matrix_eval = delegate_matrix_evaluation(dev, t, f_middle, r1, sc.proof.point, inverse);
+  return out;
+}
+// Convolution::prove_batch_fft_weights (convolution.rs:358-443)
+inline BatchFFTProof prove_batch_fft_weights(ProverState& ps, size_t id, const LayerSpec& l, const std::vector<Ext>& r) {
+  Dev& dev = *ps.dev; Transcript& t = *ps.t;
+  size_t padded_rows = 2 * l.nw * l.nw, fsz = l.real_nw * l.real_nw;
+  unsigned l1 = dp_ceil_log2(padded_rows);
+  std::vector<Ext> r1(r.begin(), r.begin() + l1), r2(r.begin() + l1, r.end());
+  DP_REQUIRE(r2.size() == dp_ceil_log2(l.kw * l.kx), DP_ERR_SHAPE, "fft weights: point length");
+  std::vector<Ext> w_red(padded_rows, ex_zero()); std::vector<std::vector<Ext>> f_middle(l1 - 1);
+  phi_g_init(w_red, f_middle, r1, ex_one(), l1, false);
+  size_t mk = dev.mark();
+  // w1_reduced[k] = sum_{i,j} beta(r2)[i*kx + j] * filter[i][j][k]: K2 on the committed filter table
+  DBuf red = dev.alloc(fsz, true);
+  dev.fix_high(red, ps.ctx->weights_dev.at(id), l.kw * l.kx, fsz, r2.data());
+  BatchFFTProof out; out.partial_evals.resize(fsz);
+  dev.download(red, (u64*)out.partial_evals.data());
+  std::vector<Ext> padded(padded_rows, ex_zero());  // index_wf (convolution.rs:1535-1550)
+  for (size_t a = 0; a < l.real_nw; a++) for (size_t b = 0; b < l.real_nw; b++) padded[a * l.nw + b] = out.partial_evals[a * l.real_nw + b];
+  std::vector<Ext> both = padded; both.insert(both.end(), w_red.begin(), w_red.end());
+  DBuf pf = upload_exts(dev, both);
+  DevVP vp(l1);
+  vp.add_mle_list({pf.slice(0, padded_rows), pf.slice(padded_rows, padded_rows)}, ex_one());
+  SumcheckOut sc = sumcheck_prove(dev, vp, t);
+  dev.release(mk);
+  out.proof = sc.proof; out.claims = sc.finals;
+  out.matrix_eval = delegate_matrix_evaluation(dev, t, f_middle, r1, sc.proof.point, false);
+  return out;
+}
+inline Claim prove_conv(ProverState& ps, size_t id, const LayerSpec& l, const Claim& last_in, const ConvTrace& ct) {
+  Dev& dev = *ps.dev; Transcript& t = *ps.t;
+  const Context::ConvDev& cd = ps.ctx->conv_dev.at(id);
+  const auto& comms = ps.ctx->model_comms.at(id);
+  size_t fs = l.filter_size(), N = 2 * fs;
+  unsigned lfs = dp_ceil_log2(fs), lkw = dp_ceil_log2(l.kw), l2n = lfs + 1;
+  DP_REQUIRE(last_in.point.size() == lfs + lkw, DP_ERR_SHAPE, "conv: claim point length");
+  size_t mk = dev.mark();
+  // the tables of this inference: one upload for the three base-field matrices
+  DBuf big = dev.alloc(ct.input_pad.size() + ct.input_fft.size() + ct.prod.size(), false);
+  { std::vector<u64> flat; flat.reserve(big.n); flat.insert(flat.end(), ct.input_pad.begin(), ct.input_pad.end()); flat.insert(flat.end(), ct.input_fft.begin(), ct.input_fft.end()); flat.insert(flat.end(), ct.prod.begin(), ct.prod.end()); dev.upload(big, flat.data()); }
+  DBuf input_pad = big.slice(0, ct.input_pad.size()), input_fft = big.slice(ct.input_pad.size(), ct.input_fft.size()), prod = big.slice(ct.input_pad.size() + ct.input_fft.size(), ct.prod.size());
+  // 1. garbage clearing: hadamard::prove (hadamard.rs:83-130) on (conv output after bias) o (0/1 clearing tensor)
+  HadamardProof clearing_proof;
+  {
+    size_t mk2 = dev.mark();
+    DBuf v1 = dev.alloc(ct.output_as_element.size(), false);
+    dev.upload_i64(v1, ct.output_as_element.data());
+    DBuf beta = dev.alloc(v1.n, true);
+    dev.eq_table(beta, last_in.point.data(), (unsigned)last_in.point.size(), ex_one(), false);
+    DevVP vp((unsigned)last_in.point.size());
+    vp.add_mle_list({v1, cd.clearing, beta}, ex_one());
+    SumcheckOut sc = sumcheck_prove(dev, vp, t);
+    clearing_proof.sumcheck = sc.proof; clearing_proof.individual_claim = {sc.finals[0], sc.finals[1]};
+    dev.release(mk2);
+  }
+  Claim last{clearing_proof.sumcheck.point, clearing_proof.individual_claim[0]};
+  std::vector<Ext> r(last.point.size() + 1, ex_zero()), bias_point(lkw, ex_zero());
+  for (unsigned i = 0; i < lfs; i++) r[i] = ex_sub(ex_one(), last.point[i]);
+  for (unsigned i = 0; i < lkw; i++) { r[i + lfs + 1] = last.point[i + lfs]; bias_point[i] = last.point[i + lfs]; }
+  Ext bias_eval = ex_zero();
+  dev.mle_eval_batch(&comms.at("ConvBias").evals, 1, bias_point.data(), lkw, &bias_eval);
+  // 2. Y = iFFT(prod)
+  BatchFFTProof ifft = prove_batch_fft_dev(dev, t, r, prod, l.kw, N, true);
+  DP_REQUIRE(ifft.proof.point.size() == lfs + 1, DP_ERR_SHAPE, "Error in ifft sumcheck");
+  std::vector<Ext> r_ifft = ifft.proof.point;
+  for (size_t i = l2n; i < r.size(); i++) r_ifft.push_back(r[i]);
+  std::vector<Ext> r1(r_ifft.begin() + l2n, r_ifft.end()), r2(r_ifft.begin(), r_ifft.begin() + l2n);
+  // 3. prod = sum_j FFT(x_j) o FFT(w_ij): cubic sumcheck over (aggregated filter FFT, input FFT, beta). The aggregated
+  //    filter sum_i beta1[i] w[i][j] is transformed by the reference (kx extension-field FFTs); the transform is linear,
+  //    so it equals sum_i beta1[i] FFT(w[i][j]) — one K2 pass over the kernel FFTs kept from setup.
+  IOPProof hadamard_proof; std::vector<Ext> hadamard_claims;
+  {
+    size_t mk2 = dev.mark();
+    DBuf f1 = dev.alloc(l.kx * N, true), f3 = dev.alloc(l.kx * N, true);
+    dev.fix_high(f1, cd.wfft, l.kw, l.kx * N, r1.data());
+    dev.eq_table_tiled(f3, r2.data(), l2n);
+    DevVP vp(dp_ceil_log2(l.kx * N));
+    vp.add_mle_list({f1, input_fft, f3}, ex_one());
+    SumcheckOut sc = sumcheck_prove(dev, vp, t);
+    hadamard_proof = sc.proof; hadamard_claims = sc.finals;
+    dev.release(mk2);
+  }
+  std::vector<Ext> point = hadamard_proof.point; point.insert(point.end(), r1.begin(), r1.end());
+  // 4. FFT of the input and of the weights
+  BatchFFTProof fftp = prove_batch_fft_dev(dev, t, hadamard_proof.point, input_pad, l.kx, N, false);
+  BatchFFTProof wp = prove_batch_fft_weights(ps, id, l, point);
+  std::vector<Ext> weights_rand = t.read_challenges(dp_ceil_log2(l.real_nw * l.real_nw));
+  Claim bias_claim{bias_point, bias_eval};
+  Claim filter_claim; filter_claim.point = weights_rand; filter_claim.point.insert(filter_claim.point.end(), point.begin() + l2n, point.end());
+  filter_claim.eval = host_mle_eval(wp.partial_evals, weights_rand);
+  ps.add_witness_claim(comms.at("ConvBias"), bias_claim);  // add_common_claims: BTreeMap order "ConvBias" < "ConvFilter"
+  ps.add_witness_claim(comms.at("ConvFilter"), filter_claim);
+  LayerProof lp; lp.kind = L_CONV; ConvProof& cp = lp.conv;
+  cp.fft_proof = fftp.proof; cp.fft_claims = fftp.claims; cp.fft_proof_weights = wp.proof; cp.ifft_proof = ifft.proof;
+  cp.fft_delegation_proof = fftp.matrix_eval.proofs; cp.fft_delegation_proof_weights = wp.matrix_eval.proofs; cp.ifft_delegation_proof = ifft.matrix_eval.proofs;
+  cp.hadamard_proof = hadamard_proof; cp.ifft_claims = ifft.claims; cp.fft_weight_claims = wp.claims;
+  cp.fft_delegation_claims = fftp.matrix_eval.claims; cp.fft_delegation_weights_claims = wp.matrix_eval.claims; cp.ifft_delegation_claims = ifft.matrix_eval.claims;
+  cp.hadamard_clams = hadamard_claims; cp.bias_claim = bias_eval; cp.partial_evals = wp.partial_evals; cp.clearing_proof = clearing_proof;
+  ps.proofs[id] = lp;
+  dev.release(mk);
+  std::vector<Ext> input_point = fftp.proof.point;
+  Ext v = ex_inv(ex_sub(ex_one(), input_point.back())); input_point.pop_back();
+  for (auto& ip : input_point) ip = ex_sub(ex_one(), ip);
+  Claim fin; fin.point = input_point;
+  fin.point.insert(fin.point.end(), hadamard_proof.point.begin() + l2n, hadamard_proof.point.end());
+  fin.eval = ex_mul(fftp.claims[0], v);
+  return fin;
+}
+// Pooling::prove_pooling (pooling.rs:342-520)
+inline Claim prove_pooling(ProverState& ps, size_t id, const LayerSpec& l, const Claim& last) {
+  Dev& dev = *ps.dev; Transcript& t = *ps.t;
+  std::vector<LogUpWitness>& ws = ps.lookup_witness.at(id);
+  DP_REQUIRE(ws.size() == 1 && ws[0].columns.size() == 4 && ws[0].extra_columns.size() == 1 && ws[0].commits.size() == 5, DP_ERR_ARG, "pooling: lookup witness shape");
+  LogUpWitness& w = ws[0];
+  LogUpProof lproof = logup_batch_prove(dev, ps.logup_input(w), t);
+  size_t n = w.columns[0].n; unsigned nv = dp_ceil_log2(n);
+  DP_REQUIRE(last.point.size() == nv, DP_ERR_SHAPE, "pooling: claim point length");
+  size_t mk = dev.mark();
+  Ext batch = t.get_and_append_challenge("batch_pooling");
+  DBuf beta = dev.alloc(n, true), last_beta = dev.alloc(n, true);
+  dev.eq_table(beta, lproof.output_claims[0].point.data(), nv, ex_one(), false);
+  dev.eq_table(last_beta, last.point.data(), nv, ex_one(), false);
+  DevVP vp(nv);
+  std::vector<DBuf> all = w.columns; all.push_back(beta);
+  vp.add_mle_list(all, ex_one());  // zero check: prod_i (out - in_i) * eq
+  Ext comb = batch;
+  for (auto& d : w.columns) { vp.add_mle_list({d, beta}, comb); comb = ex_mul(comb, batch); }
+  vp.add_mle_list({w.extra_columns[0], last_beta}, comb);  // the output (committed base column == trace output as field elements)
+  SumcheckOut sc = sumcheck_prove(dev, vp, t);
+  dev.release(mk);
+  const std::vector<Ext>& evals = sc.finals;
+  const size_t ks = 4;
+  Ext output_eval = evals[ks + 1];
+  LayerProof lp; lp.kind = L_MAXPOOL; PoolingProof& pp = lp.pool;
+  pp.sumcheck = sc.proof; pp.lookup = lproof;
+  for (size_t i = 0; i <= ks; i++) {
+    pp.commitments.push_back(pure_commitment(w.commits[i]));
+    ps.add_witness_claim(w.commits[i], {sc.proof.point, i < ks ? evals[i] : output_eval});
+  }
+  unsigned row_log = dp_ceil_log2(l.pin[2]);
+  Ext r1 = t.get_and_append_challenge("input_batching"), r2 = r1;  // `[challenge; 2]`: ONE challenge used twice (pooling.rs:459-462)
+  Ext om1 = ex_sub(ex_one(), r1), om2 = ex_sub(ex_one(), r2);
+  Ext mult[4] = {ex_mul(om1, om2), ex_mul(om1, r2), ex_mul(r1, om2), ex_mul(r1, r2)};
+  Ext zc = ex_zero();
+  for (size_t i = 0; i < ks; i++) zc = ex_add(zc, ex_mul(mult[i], ex_sub(output_eval, evals[i])));
+  Claim next; next.point.push_back(r1);
+  next.point.insert(next.point.end(), sc.proof.point.begin(), sc.proof.point.begin() + (row_log - 1));
+  next.point.push_back(r2);
+  next.point.insert(next.point.end(), sc.proof.point.begin() + (row_log - 1), sc.proof.point.end());
+  next.eval = zc;
+  pp.zerocheck_evals.assign(evals.begin(), evals.begin() + ks); pp.zerocheck_evals.push_back(output_eval);
+  pp.variable_gap = row_log - 1;
+  ps.proofs[id] = lp;
+  return next;
+}
+
 // Prover::prove(trace). `tr` comes from run_model (inference is not part of proving time in the reference either).
 // `dev` may be any device context on the GPU that holds `ctx` (the model commitments are only read), so several proofs
 // can be in flight at once, each on its own stream/arena (dp_model_prove_batch).
@@ -407,8 +744,11 @@ inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t) {
     const LayerSpec& l = ctx.model.layers[id];
     if (l.kind == L_DENSE) cur = prove_dense(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
-    else cur = prove_relu(ps, id, cur, tr.out[id]);
-    if (pt.on) { char b[64]; snprintf(b, sizeof b, "layer %zu (%s)", id, l.kind == L_DENSE ? "dense" : l.kind == L_REQUANT ? "requant" : "relu"); pt.lap(b); }
+    else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, tr.out[id]);
+    else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv.at(id));
+    else if (l.kind == L_MAXPOOL) cur = prove_pooling(ps, id, l, cur);
+    // L_FLATTEN is not provable: the claim passes through unchanged (iop/prover.rs:449-456)
+    if (pt.on) { static const char* nm[] = {"dense", "requant", "relu", "conv", "maxpool", "flatten"}; char b[64]; snprintf(b, sizeof b, "layer %zu (%s)", id, nm[l.kind]); pt.lap(b); }
   }
   Proof proof;
   for (auto& tw : ps.table_witness) {
@@ -445,13 +785,17 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
   auto add_fracs = [&](const LogUpProof& p) {
     for (auto& e : p.circuit_outputs) { DP_REQUIRE(e.size() == 4, DP_ERR_VERIFY, "circuit outputs"); nums.push_back(ex_add(ex_mul(e[0], e[3]), ex_mul(e[1], e[2]))); dens.push_back(ex_mul(e[2], e[3])); }
   };
+  size_t n_provable = 0;
   for (size_t id = 0; id < m.layers.size(); id++) {
+    if (m.layers[id].kind == L_FLATTEN) continue;  // not provable: no proof (verifier.rs:92-96)
+    n_provable++;
     auto it = proof.steps.find(id);
     DP_REQUIRE(it != proof.steps.end() && it->second.kind == m.layers[id].kind, DP_ERR_VERIFY, "missing or mistyped layer proof");
     if (it->second.kind == L_RELU) add_fracs(it->second.act.lookup);
     if (it->second.kind == L_REQUANT) { add_fracs(it->second.req.clamping_lookup); add_fracs(it->second.req.shifted_lookup); }
+    if (it->second.kind == L_MAXPOOL) add_fracs(it->second.pool.lookup);
   }
-  DP_REQUIRE(proof.steps.size() == m.layers.size(), DP_ERR_VERIFY, "unexpected layer proofs");
+  DP_REQUIRE(proof.steps.size() == n_provable, DP_ERR_VERIFY, "unexpected layer proofs");
   for (auto& tp : proof.table_proofs) add_fracs(tp.lookup);
   // output claim
   DP_REQUIRE(is_pow2(io.output.size()) && io.input.size() == m.input_len, DP_ERR_VERIFY, "io shapes");
@@ -467,8 +811,126 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
   size_t cur_len = io.output.size();
   for (size_t id = m.layers.size(); id-- > 0;) {
     const LayerSpec& l = m.layers[id];
+    if (l.kind == L_FLATTEN) continue;  // claims pass through a non-provable node unchanged (verifier.rs:205-209)
     const LayerProof& lp = proof.steps.at(id);
-    if (l.kind == L_DENSE) {  // DenseCtx::verify_dense (dense.rs:576-643)
+    if (l.kind == L_CONV) {  // ConvCtx::verify_convolution (convolution.rs:1141-1386)
+      const ConvProof& cp = lp.conv;
+      size_t fs = l.filter_size();
+      unsigned lfs = dp_ceil_log2(fs), lkw = dp_ceil_log2(l.kw), lkx = dp_ceil_log2(l.kx), l2n = lfs + 1;
+      // hadamard::verify of the garbage clearing (hadamard.rs:133-162); the clearing tensor is public
+      DP_REQUIRE(cur.point.size() == lfs + lkw && cp.clearing_proof.individual_claim.size() == 2, DP_ERR_VERIFY, "conv: shapes");
+      SubClaim hsub = sumcheck_verify(cur.eval, cp.clearing_proof.sumcheck, lfs + lkw, 3, t);
+      { std::vector<int64_t> clr = clearing_tensor(l); std::vector<Ext> cv(clr.size()); for (size_t i = 0; i < cv.size(); i++) cv[i] = ex_from_i64(clr[i]);
+        DP_REQUIRE(ex_eq(host_mle_eval(cv, cp.clearing_proof.sumcheck.point), cp.clearing_proof.individual_claim[1]), DP_ERR_VERIFY, "Hadamard verification failed for v2 eval"); }
+      Ext hbeta = eq_eval(cur.point.data(), cp.clearing_proof.sumcheck.point.data(), cur.point.size());
+      DP_REQUIRE(ex_eq(ex_mul(ex_mul(hbeta, cp.clearing_proof.individual_claim[0]), cp.clearing_proof.individual_claim[1]), hsub.expected_evaluation), DP_ERR_VERIFY, "Hadamard verification failed for product eval");
+      Claim last{cp.clearing_proof.sumcheck.point, cp.clearing_proof.individual_claim[0]};
+      Ext conv_claim = ex_sub(last.eval, cp.bias_claim);
+      // NOTE (reference behaviour, replicated): the sub-claims of the FFT / iFFT / delegation sumchecks are not compared
+      // with the products of the claimed evaluations; only the identity / phi closed forms and the chaining are checked
+      sumcheck_verify(conv_claim, cp.ifft_proof, l2n, 2, t);
+      size_t iter = cp.ifft_delegation_proof.size();
+      DP_REQUIRE(iter == lfs && cp.ifft_delegation_claims.size() == iter && cp.ifft_claims.size() == 2 && cp.ifft_proof.point.size() == l2n, DP_ERR_VERIFY, "Inconsistency in iFFT delegation proofs/aux size");
+      {
+        Ext claim = cp.ifft_claims[1];
+        std::vector<u64> exps = pow_two_omegas((unsigned)iter + 1, true);
+        std::vector<Ext> prev_r = cp.ifft_proof.point;
+        for (size_t i = 0; i < iter; i++) {
+          const IOPProof& dpf = cp.ifft_delegation_proof[i];
+          sumcheck_verify(claim, dpf, (unsigned)(lfs - i), 3, t);
+          DP_REQUIRE(cp.ifft_delegation_claims[i].size() == 3 && dpf.point.size() == lfs - i, DP_ERR_VERIFY, "ifft delegation: shapes");
+          DP_REQUIRE(ex_eq(identity_eval(dpf.point, prev_r), cp.ifft_delegation_claims[i][0]), DP_ERR_VERIFY, "Error in identity evaluation ifft delegation");
+          DP_REQUIRE(ex_eq(phi_eval(dpf.point, ex_sub(ex_one(), last.point[i]), prev_r.back(), exps, false), cp.ifft_delegation_claims[i][1]), DP_ERR_VERIFY, "Error in phi computation ifft delegation");
+          prev_r = dpf.point; claim = cp.ifft_delegation_claims[i][2];
+        }
+        Ext scale = ex_inv(ex_from_u64(u64(1) << (iter + 1)));
+        DP_REQUIRE(ex_eq(claim, ex_add(ex_mul(scale, prev_r[0]), ex_mul(scale, ex_sub(ex_one(), prev_r[0])))), DP_ERR_VERIFY, "Error in final iFFT delegation step");
+      }
+      sumcheck_verify(cp.ifft_claims[0], cp.hadamard_proof, lkx + l2n, 3, t);
+      DP_REQUIRE(cp.hadamard_clams.size() == 3 && cp.hadamard_proof.point.size() == lkx + l2n, DP_ERR_VERIFY, "conv: hadamard shapes");
+      DP_REQUIRE(ex_eq(cp.hadamard_clams[2], identity_eval(cp.ifft_proof.point, cp.hadamard_proof.point)), DP_ERR_VERIFY, "Error in Beta evaluation");
+      auto verify_fft_delegation = [&](Ext claim, const std::vector<IOPProof>& dproofs, const std::vector<std::vector<Ext>>& dclaims, std::vector<Ext> prev_r) {  // convolution.rs:1085-1139
+        size_t it2 = dproofs.size();
+        DP_REQUIRE(it2 == lfs && dclaims.size() == it2, DP_ERR_VERIFY, "Inconsistency in FFT delegation proofs/aux size");
+        std::vector<u64> exps = pow_two_omegas((unsigned)it2 + 1, false);
+        for (size_t i = 0; i < it2; i++) {
+          sumcheck_verify(claim, dproofs[i], (unsigned)(lfs - i), 3, t);
+          DP_REQUIRE(dclaims[i].size() == 3 && dproofs[i].point.size() == lfs - i, DP_ERR_VERIFY, "fft delegation: shapes");
+          DP_REQUIRE(ex_eq(identity_eval(dproofs[i].point, prev_r), dclaims[i][0]), DP_ERR_VERIFY, "Error in identity evaluation fft delegation");
+          DP_REQUIRE(ex_eq(phi_eval(dproofs[i].point, cp.hadamard_proof.point[i], prev_r.back(), exps, i == 0), dclaims[i][1]), DP_ERR_VERIFY, "Error in phi computation fft delegation");
+          claim = dclaims[i][2]; prev_r = dproofs[i].point;
+        }
+        Ext hp = cp.hadamard_proof.point[it2];
+        DP_REQUIRE(ex_eq(claim, ex_sub(ex_add(ex_mul(ex_sub(ex_one(), ex_dbl(hp)), prev_r[0]), ex_one()), prev_r[0])), DP_ERR_VERIFY, "Error in final FFT delegation step");
+      };
+      sumcheck_verify(cp.hadamard_clams[1], cp.fft_proof, l2n, 2, t);
+      DP_REQUIRE(cp.fft_claims.size() == 2 && cp.fft_proof.point.size() == l2n, DP_ERR_VERIFY, "conv: fft shapes");
+      verify_fft_delegation(cp.fft_claims[1], cp.fft_delegation_proof, cp.fft_delegation_claims, cp.fft_proof.point);
+      sumcheck_verify(cp.hadamard_clams[0], cp.fft_proof_weights, l2n, 2, t);
+      DP_REQUIRE(cp.fft_weight_claims.size() == 2 && cp.fft_proof_weights.point.size() == l2n, DP_ERR_VERIFY, "conv: fft weights shapes");
+      verify_fft_delegation(cp.fft_weight_claims[1], cp.fft_delegation_proof_weights, cp.fft_delegation_weights_claims, cp.fft_proof_weights.point);
+      // the padded-weights claim from the partial evaluations
+      std::vector<Ext> weights_point = cp.fft_proof_weights.point;
+      Ext v = ex_inv(ex_sub(ex_one(), weights_point.back())); weights_point.pop_back();
+      DP_REQUIRE(cp.partial_evals.size() == l.real_nw * l.real_nw, DP_ERR_VERIFY, "conv: partial evaluations");
+      Ext yw = ex_zero();
+      for (size_t a = 0; a < l.real_nw; a++) for (size_t b = 0; b < l.real_nw; b++) {
+        size_t num = a * l.nw + b; unsigned bl = 2 * dp_ceil_log2(l.nw);
+        std::vector<Ext> bits(bl); for (unsigned q = 0; q < bl; q++) bits[q] = ex_from_u64((num >> q) & 1);
+        yw = ex_add(yw, ex_mul(cp.partial_evals[a * l.real_nw + b], identity_eval(bits, weights_point)));
+      }
+      DP_REQUIRE(ex_eq(ex_mul(cp.fft_weight_claims[0], v), yw), DP_ERR_VERIFY, "Error in padded_fft evaluation claim");
+      std::vector<Ext> weights_rand = t.read_challenges(dp_ceil_log2(l.real_nw * l.real_nw));
+      std::vector<Ext> point = cp.hadamard_proof.point; point.insert(point.end(), last.point.begin() + lfs, last.point.end());
+      Claim bias_claim{std::vector<Ext>(last.point.begin() + iter, last.point.end()), cp.bias_claim};
+      Claim filter_claim; filter_claim.point = weights_rand; filter_claim.point.insert(filter_claim.point.end(), point.begin() + l2n, point.end());
+      filter_claim.eval = host_mle_eval(cp.partial_evals, weights_rand);
+      auto nit = unused.find(id);
+      DP_REQUIRE(nit != unused.end() && nit->second.count("ConvBias") && nit->second.count("ConvFilter"), DP_ERR_VERIFY, "conv: no commitments for node");
+      add_claim(nit->second.at("ConvBias"), bias_claim);
+      add_claim(nit->second.at("ConvFilter"), filter_claim);
+      unused.erase(nit);
+      std::vector<Ext> input_point = cp.fft_proof.point;
+      v = ex_inv(ex_sub(ex_one(), input_point.back())); input_point.pop_back();
+      for (auto& ip : input_point) ip = ex_sub(ex_one(), ip);
+      input_point.insert(input_point.end(), cp.hadamard_proof.point.begin() + l2n, cp.hadamard_proof.point.end());
+      cur = {input_point, ex_mul(cp.fft_claims[0], v)};
+      cur_len = l.kx * fs;
+    } else if (l.kind == L_MAXPOOL) {  // PoolingCtx::verify_pooling (pooling.rs:528-660)
+      const PoolingProof& pp = lp.pool;
+      TableType rt{2, 0};
+      DP_REQUIRE(chmap.count(rt), DP_ERR_VERIFY, "pooling: no challenge for the range table");
+      LogUpVerifierClaim vcl = verify_logup_proof(pp.lookup, 4, constant_challenge, chmap[rt], t);
+      unsigned nv = dp_ceil_log2(cur_len);
+      Ext bc = t.get_and_append_challenge("batch_pooling");
+      DP_REQUIRE(vcl.claims.size() == 4 && pp.zerocheck_evals.size() == 5 && pp.commitments.size() == 5 && cur.point.size() == nv, DP_ERR_VERIFY, "pooling: shapes");
+      Ext init = ex_zero(), comb = bc;
+      for (auto& c : vcl.claims) { init = ex_add(init, ex_mul(c.eval, comb)); comb = ex_mul(comb, bc); }
+      init = ex_add(init, ex_mul(comb, cur.eval));
+      SubClaim sub = sumcheck_verify(init, pp.sumcheck, nv, 5, t);
+      DP_REQUIRE(vcl.claims[0].point.size() == nv, DP_ERR_VERIFY, "pooling: lookup point size");
+      Ext beta_eval = eq_eval(vcl.claims[0].point.data(), sub.point.data(), nv);
+      Ext last_beta_eval = eq_eval(cur.point.data(), sub.point.data(), nv);
+      const size_t ks = 4;
+      Ext prod = beta_eval, sum = ex_zero(); comb = bc;
+      for (size_t i = 0; i < ks; i++) { prod = ex_mul(prod, pp.zerocheck_evals[i]); sum = ex_add(sum, ex_mul(comb, pp.zerocheck_evals[i])); comb = ex_mul(comb, bc); }
+      Ext output_eval = pp.zerocheck_evals[ks];
+      Ext expected = ex_add(ex_add(prod, ex_mul(sum, beta_eval)), ex_mul(ex_mul(output_eval, last_beta_eval), comb));
+      DP_REQUIRE(ex_eq(expected, sub.expected_evaluation), DP_ERR_VERIFY, "Expected pooling zerocheck claim did not equal the verifier claim");
+      for (size_t i = 0; i <= ks; i++) add_claim(pp.commitments[i], {sub.point, pp.zerocheck_evals[i]});
+      Ext r1 = t.get_and_append_challenge("input_batching"), r2 = r1;
+      Ext om1 = ex_sub(ex_one(), r1), om2 = ex_sub(ex_one(), r2);
+      Ext mult[4] = {ex_mul(om1, om2), ex_mul(om1, r2), ex_mul(r1, om2), ex_mul(r1, r2)};
+      DP_REQUIRE(pp.variable_gap <= sub.point.size(), DP_ERR_VERIFY, "pooling: variable gap");
+      Claim next; next.point.push_back(r1);
+      next.point.insert(next.point.end(), sub.point.begin(), sub.point.begin() + pp.variable_gap);
+      next.point.push_back(r2);
+      next.point.insert(next.point.end(), sub.point.begin() + pp.variable_gap, sub.point.end());
+      next.eval = ex_zero();
+      for (size_t i = 0; i < ks; i++) next.eval = ex_add(next.eval, ex_mul(ex_sub(output_eval, pp.zerocheck_evals[i]), mult[i]));
+      cur = next;
+      cur_len *= 4;
+    } else if (l.kind == L_DENSE) {  // DenseCtx::verify_dense (dense.rs:576-643)
       const DenseProof& dpf = lp.dense;
       DP_REQUIRE(cur.point.size() == dp_ceil_log2(l.nrows) && dpf.individual_claims.size() == 2, DP_ERR_VERIFY, "dense: shapes");
       Ext eval_no_bias = ex_sub(cur.eval, dpf.bias_eval);
@@ -573,6 +1035,59 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
   for (size_t i = 0; i < nums.size(); i++) { fn = ex_add(ex_mul(fn, dens[i]), ex_mul(nums[i], fd)); fd = ex_mul(fd, dens[i]); }
   DP_REQUIRE(ex_is_zero(fn), DP_ERR_VERIFY, "final logup numerator is non-zero");
   DP_REQUIRE(!ex_is_zero(fd), DP_ERR_VERIFY, "final logup denominator is zero");
+}
+
+// ---- serialisable verifier context (what dp_model_verifier_blob hands out and dp_verify consumes)
+inline const char* const* poly_ids() { static const char* const ids[4] = {"DenseBias", "DenseWeight", "ConvBias", "ConvFilter"}; return ids; }
+inline std::vector<u64> vctx_to_words(const VerifierContext& v) {
+  std::vector<u64> w;
+  w.push_back(0x3158544356504444ULL); w.push_back(v.full_log); w.push_back(v.shape.input_len); w.push_back(v.shape.layers.size());
+  for (auto& l : v.shape.layers) {
+    w.push_back(l.kind); w.push_back(l.nrows); w.push_back(l.ncols); w.push_back(l.right_shift); w.push_back(l.fp_scale); w.push_back((u64)l.fixed_point_multiplier); w.push_back(l.intermediate_bit_size);
+    w.push_back(l.kw); w.push_back(l.kx); w.push_back(l.real_nw); w.push_back(l.nw);
+    for (int k = 0; k < 3; k++) w.push_back(l.unp_out[k]);
+    for (int k = 0; k < 3; k++) w.push_back(l.pin[k]);
+  }
+  w.push_back(v.model_comms.size());
+  for (auto& kv : v.model_comms) {
+    w.push_back(kv.first); w.push_back(kv.second.size());
+    for (auto& pc : kv.second) {
+      int code = -1; for (int q = 0; q < 4; q++) if (pc.first == poly_ids()[q]) code = q;
+      DP_REQUIRE(code >= 0, DP_ERR_ARG, "unknown model polynomial id");
+      const Commitment& c = pc.second; w.push_back((u64)code); for (int k = 0; k < 4; k++) w.push_back(c.root.v[k]); w.push_back(c.num_vars); w.push_back(c.is_base);
+    }
+  }
+  w.push_back(v.tables.size());
+  for (auto& t : v.tables) { w.push_back(t.kind); w.push_back(t.size); }
+  return w;
+}
+inline VerifierContext vctx_from_words(const u64* w, size_t n) {
+  size_t pos = 0;
+  auto rd = [&]() { DP_REQUIRE(pos < n, DP_ERR_ARG, "verifier blob truncated"); return w[pos++]; };
+  VerifierContext v;
+  DP_REQUIRE(rd() == 0x3158544356504444ULL, DP_ERR_ARG, "bad verifier blob magic");
+  v.full_log = (unsigned)rd(); v.shape.input_len = (size_t)rd(); size_t nl = (size_t)rd();
+  DP_REQUIRE(nl < 4096, DP_ERR_ARG, "verifier blob: layer count");
+  for (size_t i = 0; i < nl; i++) {
+    LayerSpec l; l.kind = (int)rd(); l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); l.right_shift = (unsigned)rd(); l.fp_scale = (unsigned)rd(); l.fixed_point_multiplier = (int64_t)rd(); l.intermediate_bit_size = (unsigned)rd();
+    l.kw = (size_t)rd(); l.kx = (size_t)rd(); l.real_nw = (size_t)rd(); l.nw = (size_t)rd();
+    for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();
+    for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd();
+    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_FLATTEN, DP_ERR_ARG, "verifier blob: layer kind");
+    if (l.kind == L_CONV) DP_REQUIRE(is_pow2(l.kw) && is_pow2(l.kx) && is_pow2(l.real_nw) && is_pow2(l.nw) && l.kw <= (1u << 16) && l.kx <= (1u << 16) && l.nw <= (1u << 12) && 2 * l.real_nw <= l.nw && l.unp_out[0] <= l.kw && l.unp_out[1] <= l.nw && l.unp_out[2] <= l.nw, DP_ERR_ARG, "verifier blob: conv shape");
+    if (l.kind == L_MAXPOOL) DP_REQUIRE(is_pow2(l.pin[0]) && is_pow2(l.pin[1]) && is_pow2(l.pin[2]) && l.pin[2] >= 2, DP_ERR_ARG, "verifier blob: maxpool shape");
+    v.shape.layers.push_back(l);
+  }
+  size_t nc = (size_t)rd(); DP_REQUIRE(nc <= nl, DP_ERR_ARG, "verifier blob: commitments");
+  for (size_t i = 0; i < nc; i++) {
+    size_t id = (size_t)rd(); size_t np = (size_t)rd();
+    DP_REQUIRE(np <= 4, DP_ERR_ARG, "verifier blob: polynomials per node");
+    for (size_t q = 0; q < np; q++) { u64 code = rd(); DP_REQUIRE(code < 4, DP_ERR_ARG, "verifier blob: polynomial id"); Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = rd(); c.num_vars = (unsigned)rd(); c.is_base = rd() != 0; v.model_comms[id][poly_ids()[code]] = c; }
+  }
+  size_t nt = (size_t)rd(); DP_REQUIRE(nt < 64, DP_ERR_ARG, "verifier blob: tables");
+  for (size_t i = 0; i < nt; i++) { TableType t; t.kind = (int)rd(); t.size = (unsigned)rd(); v.tables.push_back(t); }
+  DP_REQUIRE(pos == n, DP_ERR_ARG, "verifier blob: trailing words");
+  return v;
 }
 
 }  // namespace dp

@@ -5,7 +5,7 @@ import math
 
 import numpy as np
 
-L_DENSE, L_REQUANT, L_RELU = 0, 1, 2
+L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_FLATTEN = 0, 1, 2, 3, 4, 5
 BIT_LEN = 8
 FIXED_POINT_SCALE = 25  # zkml/src/layers/requant.rs:47
 
@@ -49,13 +49,27 @@ def next_pow2(x):
     return 1 << max(0, (x - 1).bit_length())
 
 
+def conv_output_bitsize(kc, kh, kw_):
+    """Convolution::output_bitsize (zkml/src/layers/convolution.rs:349-353), on the unpadded filter"""
+    return 2 * (BIT_LEN - 1) + max(0, (kh * kw_ * kc).bit_length())  # ceil_log2(x + 1) == bit_length(x)
+
+
 class ModelBuilder:
-    def __init__(self, input_len, config=0):
-        self.input_len = next_pow2(input_len)
+    """Builds the already padded, already quantised model the prover consumes, doing what the reference's padding pass
+    does to each node (zkml/src/padding.rs): `input_shape` is an int (vector model) or a (c, h, w) tuple (CNN)."""
+
+    def __init__(self, input_shape, config=0):
+        if isinstance(input_shape, int):
+            input_shape = (input_shape,)
+        self.shape_og = tuple(input_shape)                       # ShapeData.input_shape_og
+        self.shape_pad = tuple(next_pow2(d) for d in input_shape)  # ShapeData.input_shape_padded
+        self.input_shape_og, self.input_shape_pad = self.shape_og, self.shape_pad
+        self.input_len = int(np.prod(self.shape_pad))
         self.layers = []
         self.config = config
         self._tensor_index = 0
         self._cur = self.input_len
+        self._garbage = None  # GarbagePad::Convolution((og, padded)) set by flatten (padding.rs:195-203)
 
     def _tensor(self, n):
         t = quantised_tensor(self.config, self._tensor_index, n)
@@ -64,11 +78,25 @@ class ModelBuilder:
 
     def dense(self, out_features, in_features=None, requant=True, float_abs_max=None):
         """Dense (padded to powers of two; padding rows/cols are zero like Tensor::pad_next_power_of_two) + Requant"""
-        in_features = in_features or self._cur
-        r, c = next_pow2(out_features), next_pow2(in_features)
-        assert c == self._cur
-        w = np.zeros((r, c), dtype=np.int64)
-        w[:out_features, :in_features] = self._tensor(out_features * in_features).reshape(out_features, in_features)
+        if self._garbage is not None:
+            # pad_dense + Tensor::pad_matrix_to_ignore_garbage (padding.rs:288-346, tensor.rs:1627-1675): the columns of the
+            # matrix follow the PADDED (c, h, w) layout of the flattened convolution output; padding positions get zeros
+            og, pad = self._garbage
+            in_features = int(np.prod(og))
+            r, c = next_pow2(out_features), int(np.prod(pad))
+            assert c == self._cur
+            m = self._tensor(out_features * in_features).reshape(out_features, *og)
+            w4 = np.zeros((r,) + tuple(pad), dtype=np.int64)
+            w4[:out_features, :og[0], :og[1], :og[2]] = m
+            w = w4.reshape(r, c)
+            self._garbage = None
+        else:
+            in_features = in_features or self.shape_og[0]
+            r, c = next_pow2(out_features), next_pow2(in_features)
+            assert c == self._cur
+            w = np.zeros((r, c), dtype=np.int64)
+            w[:out_features, :in_features] = self._tensor(out_features * in_features).reshape(out_features, in_features)
+        self.shape_og, self.shape_pad = (out_features,), (r,)
         b = np.zeros(r, dtype=np.int64)
         b[:out_features] = self._tensor(out_features)
         self.layers.append(dict(kind=L_DENSE, nrows=r, ncols=c, weights=w, bias=b))
@@ -87,6 +115,45 @@ class ModelBuilder:
         self.layers.append(dict(kind=L_RELU))
         return self
 
+    def conv(self, out_channels, kernel, requant=True):
+        """Convolution (stride 1, no padding) as pad_conv + into_padded_and_ffted lay it out (padding.rs:218-260,
+        convolution.rs:290-301, tensor.rs:409-431): filter zero padded to powers of two in every dimension, nw = the
+        padded input side; followed by its Requant node"""
+        assert len(self.shape_og) == 3
+        kc, h, w_ = self.shape_og
+        assert h == w_ and self.shape_pad[1] == self.shape_pad[2]
+        kw, kx, rnw = next_pow2(out_channels), next_pow2(kc), next_pow2(kernel)
+        assert kx == self.shape_pad[0]
+        nw = next_pow2(self.shape_pad[1] - rnw + 1)
+        assert nw == self.shape_pad[1], "FFT convolution needs padded kernel <= half of the padded input side"
+        f = np.zeros((kw, kx, rnw, rnw), dtype=np.int64)
+        f[:out_channels, :kc, :kernel, :kernel] = self._tensor(out_channels * kc * kernel * kernel).reshape(out_channels, kc, kernel, kernel)
+        b = np.zeros(kw, dtype=np.int64)
+        b[:out_channels] = self._tensor(out_channels)
+        unp_out = (out_channels, h - kernel + 1, w_ - kernel + 1)
+        self.layers.append(dict(kind=L_CONV, kw=kw, kx=kx, real_nw=rnw, nw=nw, unp_out=unp_out, kernel=kernel, filter=f, bias=b))
+        self.shape_og, self.shape_pad = unp_out, (kw, nw, nw)
+        self._cur = kw * nw * nw
+        if requant:
+            fan_in = kc * kernel * kernel
+            rq = requant_from_multiplier((1.0 / math.sqrt(fan_in)) / 127.0, conv_output_bitsize(kc, kernel, kernel))
+            self.layers.append(dict(kind=L_REQUANT, **rq))
+        return self
+
+    def maxpool(self):
+        """Maxpool2D kernel 2 stride 2 (layers/pooling.rs, padding.rs:205-216)"""
+        assert len(self.shape_og) == 3
+        self.layers.append(dict(kind=L_MAXPOOL, pin=self.shape_pad))
+        self.shape_og = (self.shape_og[0], (self.shape_og[1] - 2) // 2 + 1, (self.shape_og[2] - 2) // 2 + 1)
+        self.shape_pad = (self.shape_pad[0], self.shape_pad[1] // 2, self.shape_pad[2] // 2)
+        self._cur = int(np.prod(self.shape_pad))
+        return self
+
+    def flatten(self):
+        self._garbage = (self.shape_og, self.shape_pad)
+        self.layers.append(dict(kind=L_FLATTEN))
+        return self
+
     def blob(self):
         out = [self.input_len, len(self.layers)]
         parts = [np.array(out, dtype=np.int64)]
@@ -98,12 +165,22 @@ class ModelBuilder:
             elif l["kind"] == L_REQUANT:
                 parts.append(np.array([L_REQUANT, l["right_shift"], l["fp_scale"], l["fixed_point_multiplier"],
                                        l["intermediate_bit_size"]], dtype=np.int64))
+            elif l["kind"] == L_CONV:
+                parts.append(np.array([L_CONV, l["kw"], l["kx"], l["real_nw"], l["nw"], *l["unp_out"]], dtype=np.int64))
+                parts.append(l["filter"].reshape(-1))
+                parts.append(l["bias"])
+            elif l["kind"] == L_MAXPOOL:
+                parts.append(np.array([L_MAXPOOL, *l["pin"]], dtype=np.int64))
             else:
-                parts.append(np.array([L_RELU], dtype=np.int64))
+                parts.append(np.array([l["kind"]], dtype=np.int64))
         return np.concatenate(parts)
 
     def input(self, index=1000):
-        return quantised_tensor(self.config, index, self.input_len)
+        """a synthetic input, already padded (zeros outside the unpadded shape, like Tensor::pad_next_power_of_two)"""
+        og, pad = self.input_shape_og, self.input_shape_pad
+        x = np.zeros(pad, dtype=np.int64)
+        x[tuple(slice(0, d) for d in og)] = quantised_tensor(self.config, index, int(np.prod(og))).reshape(og)
+        return x.reshape(-1)
 
     def run(self, x):
         """quantised inference in numpy (Model::run semantics: Dense matvec + bias, Requant::apply, Relu::apply)"""
@@ -114,8 +191,26 @@ class ModelBuilder:
             elif l["kind"] == L_REQUANT:
                 sh = l["fp_scale"] + l["right_shift"]
                 cur = np.clip((cur * l["fixed_point_multiplier"] + (1 << (sh - 1))) >> sh, -127, 127)
-            else:
+            elif l["kind"] == L_RELU:
                 cur = np.maximum(cur, 0)
+            elif l["kind"] == L_CONV:
+                # direct correlation on the padded tensors; everything outside the unpadded output shape is cleared
+                kw, kx, k, nw = l["kw"], l["kx"], l["kernel"], l["nw"]
+                x = cur.reshape(kx, nw, nw)
+                oc, oh, ow = l["unp_out"]
+                out = np.zeros((kw, nw, nw), dtype=np.int64)
+                for a in range(k):
+                    for b in range(k):
+                        out[:, :oh, :ow] += np.einsum("oc,cyx->oyx", l["filter"][:, :, a, b], x[:, a:a + oh, b:b + ow])
+                out += l["bias"][:, None, None]
+                mask = np.zeros_like(out)
+                mask[:oc, :oh, :ow] = 1
+                cur = (out * mask).reshape(-1)
+            elif l["kind"] == L_MAXPOOL:
+                c, h, w_ = l["pin"]
+                cur = cur.reshape(c, h // 2, 2, w_ // 2, 2).max(axis=(2, 4)).reshape(-1)
+            elif l["kind"] == L_FLATTEN:
+                pass
         return cur
 
 
@@ -139,4 +234,33 @@ def dense_128():
     """BASELINE config 1: a single Dense 128 -> 128, no requant / relu (plumbing case)"""
     mb = ModelBuilder(128, config=1)
     mb.dense(128, 128, requant=False)
+    return mb
+
+
+def cnn(c1, c2, fc1, fc2, fc3, config, input_shape=(3, 32, 32), kernel=5):
+    """zkml/assets/scripts/CNN/cifar-cnn.py:194-254: conv(3,c1,5) relu pool conv(c1,c2,5) relu pool flatten fc1 relu fc2
+    relu fc3; quantisation inserts a Requant after every conv / dense."""
+    mb = ModelBuilder(input_shape, config)
+    mb.conv(c1, kernel).relu().maxpool()
+    mb.conv(c2, kernel).relu().maxpool()
+    mb.flatten()
+    mb.dense(fc1).relu()
+    mb.dense(fc2).relu()
+    mb.dense(fc3)
+    return mb
+
+
+def cnn_264k():
+    """BASELINE config 3: 'CNN 264k' = cifar-cnn.py --num-params 264000 -> c1=12, c2=33, fc1=247, fc2=173, fc3=10
+    (scale = sqrt(264000 / 62006))"""
+    return cnn(12, 33, 247, 173, 10, config=3)
+
+
+def cnn_tiny(config=9):
+    """a small CNN of the same structure for tests (8x8 input, kernel 3)"""
+    mb = ModelBuilder((2, 16, 16), config)
+    mb.conv(3, 3).relu().maxpool()
+    mb.flatten()
+    mb.dense(5).relu()
+    mb.dense(3)
     return mb

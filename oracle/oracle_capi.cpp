@@ -22,6 +22,14 @@ static Model parse_model(const int64_t* b, size_t n) {
     Layer l; l.kind = (LayerKind)rd();
     if (l.kind == L_DENSE) { l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); l.weights.assign(b + pos, b + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols; l.bias.assign(b + pos, b + pos + l.nrows); pos += l.nrows; }
     else if (l.kind == L_REQUANT) { l.right_shift = (unsigned)rd(); l.fp_scale = (unsigned)rd(); l.fixed_point_multiplier = rd(); l.intermediate_bit_size = (unsigned)rd(); }
+    else if (l.kind == L_CONV) {
+      l.kw = (size_t)rd(); l.kx = (size_t)rd(); l.real_nw = (size_t)rd(); l.nw = (size_t)rd(); for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();
+      size_t nf = l.kw * l.kx * l.real_nw * l.real_nw;
+      if (pos + nf + l.kw > n) throw std::runtime_error("model blob truncated");
+      l.weights.assign(b + pos, b + pos + nf); pos += nf; l.bias.assign(b + pos, b + pos + l.kw); pos += l.kw;
+    } else if (l.kind == L_MAXPOOL) { for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd(); }
+    else if (l.kind == L_RELU || l.kind == L_FLATTEN) {}
+    else throw std::runtime_error("model blob: unknown layer kind");
     m.layers.push_back(std::move(l));
   }
   return m;
@@ -137,9 +145,10 @@ int orc_model_setup(const int64_t* blob, size_t nwords, orc_model** out) { retur
 void orc_model_free(orc_model* m) { delete m; }
 int orc_model_prove(orc_model* m, const int64_t* input, size_t ninput, uint64_t** proof_words, size_t* proof_nwords, int64_t* output, size_t* noutput, double* prove_ms) {
   return guard([&] {
-    Transcript t = default_transcript(); Trace tr;
+    Transcript t = default_transcript();
+    Trace tr = run_model(m->ctx.model, std::vector<int64_t>(input, input + ninput));  // inference is not "proving time" (zkml/src/bin/bench.rs:341-408)
     auto t0 = std::chrono::steady_clock::now();
-    Proof p = prove(m->ctx, std::vector<int64_t>(input, input + ninput), t, &tr);
+    Proof p = prove(m->ctx, tr, t);
     auto t1 = std::chrono::steady_clock::now();
     if (prove_ms) *prove_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     std::vector<u64> w = serialize_proof(p);

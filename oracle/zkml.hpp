@@ -169,11 +169,18 @@ static inline LogUpProof logup_batch_prove(const LogUpInput& in, Transcript& t) 
 }
 
 // ------------------------------------------------------------------ model description
-enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2 };
+enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5 };
 struct Layer {
   LayerKind kind;
   size_t nrows = 0, ncols = 0;        // dense (padded to powers of two)
-  std::vector<int64_t> weights, bias;  // row major; bias padded to nrows
+  std::vector<int64_t> weights, bias;  // dense: row major, bias padded to nrows; conv: filter [kw][kx][real_nw][real_nw], bias [kw]
+  // conv (layers/convolution.rs:52-83, tensor.rs:409-431): padded filter count kw, padded input channels kx, padded
+  // kernel side real_nw, padded input side nw (= n_x of fft_conv); unp_out = conv2d_shape of the UNPADDED tensors
+  size_t kw = 0, kx = 0, real_nw = 0, nw = 0;
+  size_t unp_out[3] = {0, 0, 0};
+  // maxpool (layers/pooling.rs): padded input shape [c, h, w]
+  size_t pin[3] = {0, 0, 0};
+  size_t filter_size() const { return nw * nw; }
   unsigned right_shift = 0, fp_scale = 0, intermediate_bit_size = 0;  // requant (requant.rs:46-73)
   int64_t fixed_point_multiplier = 0;
   unsigned shift() const { return fp_scale + right_shift; }
@@ -208,7 +215,108 @@ static inline void table_columns(const TableType& tt, std::vector<int64_t>& merg
 }
 
 // ------------------------------------------------------------------ inference (layers' Evaluate impls)
-struct Trace { std::vector<std::vector<int64_t>> in, out; };  // per node input / output tensors
+// ConvData (tensor.rs:326-372): everything the FFT convolution computes on the way, kept for the prover
+struct ConvData {
+  std::vector<std::vector<E>> input, input_fft, prod, output;
+  std::vector<int64_t> output_as_element;  // conv output AFTER the bias, BEFORE clearing the garbage (convolution.rs:311-316)
+};
+struct Trace { std::vector<std::vector<int64_t>> in, out; std::vector<ConvData> conv; };  // per node input / output tensors
+
+// get_root_of_unity (tensor.rs:220-231)
+static inline E get_root_of_unity(unsigned n) {
+  u64 rou = two_adic_generator(32);
+  for (unsigned i = 0; i < 32 - n; i++) rou = fmul(rou, rou);
+  return e_from(rou);
+}
+// fft (tensor.rs:261-323): flag false -> FFT, true -> iFFT
+static inline void fft(std::vector<E>& v, bool flag) {
+  size_t n = v.size(); unsigned logn = ceil_log2(n);
+  std::vector<size_t> rev(n, 0); std::vector<E> w(n, e_zero());
+  for (size_t i = 1; i < n; i++) rev[i] = (rev[i >> 1] >> 1) | ((i & 1) << (logn - 1));
+  w[0] = e_one();
+  if (n > 1) { w[1] = get_root_of_unity(logn); if (flag) w[1] = einv(w[1]); }
+  for (size_t i = 2; i < n; i++) w[i] = emul(w[i - 1], w[1]);
+  for (size_t i = 0; i < n; i++) if (rev[i] < i) std::swap(v[i], v[rev[i]]);
+  for (size_t i = 2; i <= n; i <<= 1) {
+    size_t half = i >> 1;
+    for (size_t c = 0; c < n; c += i)
+      for (size_t k = 0; k < half; k++) { E u = v[c + k], l = emul(v[c + k + half], w[n / i * k]); v[c + k] = eadd(u, l); v[c + k + half] = esub(u, l); }
+  }
+  if (flag) { E ilen = einv(e_from_u64(n)); for (auto& x : v) x = emul(x, ilen); }
+}
+// index_w / index_wf (tensor.rs:236-254, convolution.rs:1535-1550)
+static inline std::vector<E> index_wf(const std::vector<E>& w, size_t n_real, size_t n, size_t output_len) {
+  std::vector<E> o(output_len, e_zero());
+  for (size_t idx = 0; idx < output_len; idx++) { size_t i = idx / n, j = idx % n; if (i < n_real && j < n_real) o[idx] = w[i * n_real + j]; }
+  return o;
+}
+// IntoElement::to_element (quantization/mod.rs:225-242)
+static inline int64_t to_element(E x) { u64 e = x.c0; return e <= (P >> 1) ? (int64_t)e : -(int64_t)(P - e); }
+// Tensor::fft_conv (tensor.rs:458-523) + Convolution::op (convolution.rs:303-336)
+static inline std::vector<int64_t> conv_op(const Layer& l, const std::vector<int64_t>& x, ConvData& cd) {
+  size_t n_x = l.nw, nn = n_x * n_x, new_n = 2 * nn, fsz = l.real_nw * l.real_nw;
+  if (x.size() != l.kx * nn) throw std::runtime_error("conv: input size mismatch");
+  cd = ConvData();
+  for (size_t j = 0; j < l.kx; j++) {
+    std::vector<E> xin(nn);
+    for (size_t t = 0; t < nn; t++) xin[t] = e_from_i64(x[j * nn + nn - 1 - t]);  // chunk reversed
+    std::vector<E> xf = xin; xf.resize(new_n, e_zero());
+    fft(xf, false);
+    cd.input.push_back(xin); cd.input_fft.push_back(xf);
+  }
+  std::vector<std::vector<E>> out(l.kw, std::vector<E>(2 * l.nw * l.nw, e_zero()));
+  for (size_t i = 0; i < l.kw; i++)
+    for (size_t j = 0; j < l.kx; j++) {
+      std::vector<E> wr(fsz);
+      for (size_t k = 0; k < fsz; k++) wr[k] = e_from_i64(l.weights[i * l.kx * fsz + j * fsz + k]);
+      std::vector<E> wf = index_wf(wr, l.real_nw, l.nw, 2 * l.nw * l.nw);
+      fft(wf, false);
+      for (size_t k = 0; k < out[i].size(); k++) out[i][k] = eadd(out[i][k], emul(cd.input_fft[j][k], wf[k]));
+    }
+  cd.prod = out;
+  for (auto& e : out) fft(e, true);
+  cd.output = out;
+  std::vector<int64_t> o(l.kw * nn);
+  for (size_t i = 0; i < l.kw; i++) for (size_t p = 0; p < nn; p++) o[i * nn + p] = to_element(out[i][nn - 1 - p]);  // index_u
+  for (size_t i = 0; i < l.kw; i++) for (size_t p = 0; p < nn; p++) o[i * nn + p] += l.bias[i];                       // add_bias
+  cd.output_as_element = o;
+  std::vector<int64_t> cleared = o;  // clear_garbage (convolution.rs:1484-1506)
+  for (size_t i = 0; i < l.kw; i++) for (size_t j = 0; j < n_x; j++) for (size_t k = 0; k < n_x; k++)
+    if (!(i < l.unp_out[0] && j < l.unp_out[1] && k < l.unp_out[2])) cleared[i * nn + j * n_x + k] = 0;
+  return cleared;
+}
+// new_clearing_tensor (convolution.rs:1508-1529)
+static inline std::vector<int64_t> new_clearing_tensor(const size_t og[3], const size_t padded[3]) {
+  std::vector<int64_t> d(padded[0] * padded[1] * padded[2], 0);
+  for (size_t i = 0; i < padded[0]; i++) for (size_t j = 0; j < padded[1]; j++) for (size_t k = 0; k < padded[2]; k++)
+    if (i < og[0] && j < og[1] && k < og[2]) d[i * padded[1] * padded[2] + j * padded[2] + k] = 1;
+  return d;
+}
+// Tensor::maxpool2d with kernel = stride = 2 (tensor.rs:1335-1383)
+static inline std::vector<int64_t> maxpool_op(const Layer& l, const std::vector<int64_t>& x) {
+  size_t c = l.pin[0], h = l.pin[1], w = l.pin[2], oh = h / 2, ow = w / 2;
+  if (x.size() != c * h * w) throw std::runtime_error("maxpool: input size mismatch");
+  std::vector<int64_t> o(c * oh * ow);
+  for (size_t n = 0; n < c; n++) for (size_t i = 0; i < oh; i++) for (size_t j = 0; j < ow; j++) {
+    int64_t m = x[n * h * w + 2 * i * w + 2 * j];
+    for (size_t ki = 0; ki < 2; ki++) for (size_t kj = 0; kj < 2; kj++) m = std::max(m, x[n * h * w + (2 * i + ki) * w + 2 * j + kj]);
+    o[n * oh * ow + i * ow + j] = m;
+  }
+  return o;
+}
+// Maxpool2D::compute_polys (pooling.rs:686-767): output - input at the four kernel offsets, in the order
+// (dy,dx) = (0,0), (1,0), (0,1), (1,1), each laid out like the pooled output
+static inline std::vector<std::vector<int64_t>> maxpool_diff_polys(const Layer& l, const std::vector<int64_t>& x, const std::vector<int64_t>& out) {
+  size_t c = l.pin[0], h = l.pin[1], w = l.pin[2], oh = h / 2, ow = w / 2;
+  std::vector<std::vector<int64_t>> cols(4, std::vector<int64_t>(out.size()));
+  static const size_t dy[4] = {0, 1, 0, 1}, dx[4] = {0, 0, 1, 1};
+  for (int q = 0; q < 4; q++)
+    for (size_t n = 0; n < c; n++) for (size_t i = 0; i < oh; i++) for (size_t j = 0; j < ow; j++) {
+      size_t oi = n * oh * ow + i * ow + j;
+      cols[q][oi] = out[oi] - x[n * h * w + (2 * i + dy[q]) * w + 2 * j + dx[q]];
+    }
+  return cols;
+}
 static inline int64_t requant_apply(const Layer& l, int64_t v) {
   unsigned sh = l.shift();
   int64_t tmp = v * l.fixed_point_multiplier + (int64_t(1) << (sh - 1));
@@ -229,7 +337,11 @@ static inline Trace run_model(const Model& m, const std::vector<int64_t>& input)
         if (std::llabs(v) > (int64_t(1) << l.intermediate_bit_size)) throw std::runtime_error("requant: value too large");
         o.push_back(requant_apply(l, v));
       }
-    } else { for (int64_t v : cur) o.push_back(relu_apply(v)); }
+    } else if (l.kind == L_RELU) { for (int64_t v : cur) o.push_back(relu_apply(v)); }
+    else if (l.kind == L_CONV) { tr.conv.resize(m.layers.size()); o = conv_op(l, cur, tr.conv[tr.in.size() - 1]); }
+    else if (l.kind == L_MAXPOOL) o = maxpool_op(l, cur);
+    else if (l.kind == L_FLATTEN) o = cur;
+    else throw std::runtime_error("unknown layer kind");
     tr.out.push_back(o); cur = o;
   }
   return tr;
@@ -254,23 +366,29 @@ static inline Context context_generate(const Model& m) {
   for (auto& l : m.layers) {
     if (l.kind == L_DENSE) { cur_len = l.nrows; }
     else if (l.kind == L_REQUANT) { add_table({2, 0}); add_table({3, l.clamping_size()}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
-    else { add_table({0, 0}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
+    else if (l.kind == L_RELU) { add_table({0, 0}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
+    else if (l.kind == L_CONV) { cur_len = l.kw * l.nw * l.nw; }                                                       // convolution.rs:506-511
+    else if (l.kind == L_MAXPOOL) { add_table({2, 0}); cur_len = l.pin[0] * (l.pin[1] / 2) * (l.pin[2] / 2); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }  // pooling.rs:131-166
   }
   std::sort(tset.begin(), tset.end());
   for (auto& t : tset) max_poly_len = std::max(max_poly_len, size_t(1) << t.multiplicity_poly_vars());
-  for (auto& l : m.layers) if (l.kind == L_DENSE) { max_poly_len = std::max(max_poly_len, next_pow2(l.weights.size())); max_poly_len = std::max(max_poly_len, next_pow2(l.bias.size())); }
+  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV) { max_poly_len = std::max(max_poly_len, next_pow2(l.weights.size())); max_poly_len = std::max(max_poly_len, next_pow2(l.bias.size())); }
   max_poly_len = next_pow2(max_poly_len);
   ctx.max_poly_len = max_poly_len;
   ctx.pp = pcs_setup(max_poly_len);
   // commit/context.rs:79-103 commits the model polynomials with `into_par_iter`; the oracle mirrors that with plain
   // threads (one per polynomial) — commitments are independent so the result does not depend on the schedule
   std::vector<std::pair<size_t, const char*>> jobs;
-  for (size_t id = 0; id < m.layers.size(); id++) if (m.layers[id].kind == L_DENSE) { jobs.push_back({id, "DenseWeight"}); jobs.push_back({id, "DenseBias"}); }
+  for (size_t id = 0; id < m.layers.size(); id++) {
+    if (m.layers[id].kind == L_DENSE) { jobs.push_back({id, "DenseWeight"}); jobs.push_back({id, "DenseBias"}); }
+    if (m.layers[id].kind == L_CONV) { jobs.push_back({id, "ConvFilter"}); jobs.push_back({id, "ConvBias"}); }  // convolution.rs:452-453,546-553
+  }
   for (auto& j : jobs) ctx.model_comms[j.first][j.second];  // create map slots before the threads write into them
   std::vector<std::thread> th;
   for (auto& j : jobs) th.emplace_back([&ctx, &m, j] {
     const Layer& l = m.layers[j.first];
-    Mle poly = Mle::from_i64(std::string(j.second) == "DenseWeight" ? l.weights : l.bias);
+    std::string pid = j.second;
+    Mle poly = Mle::from_i64(pid == "DenseWeight" || pid == "ConvFilter" ? l.weights : l.bias);
     ctx.model_comms[j.first][j.second] = {pcs_commit(ctx.pp, poly), poly};
   });
   for (auto& t : th) t.join();
@@ -283,7 +401,21 @@ struct DenseProof { IOPProof sumcheck; E bias_eval; std::vector<E> individual_cl
 struct SamePolyProof { IOPProof sumcheck; std::vector<E> evals; };
 struct ActivationProof { SamePolyProof io_accumulation; LogUpProof lookup; std::vector<Commitment> commits; };
 struct RequantProof { IOPProof io_accumulation; std::vector<E> accumulation_evals; LogUpProof clamping_lookup, shifted_lookup; std::vector<Commitment> commitments; };
-struct LayerProof { LayerKind kind; DenseProof dense; ActivationProof act; RequantProof req; };
+struct HadamardProof { IOPProof sumcheck; std::vector<E> individual_claim; };  // hadamard.rs:51-56
+struct ConvProof {  // convolution.rs:98-127, fields in declaration order
+  IOPProof fft_proof, fft_proof_weights;
+  std::vector<IOPProof> fft_delegation_proof, fft_delegation_proof_weights;
+  IOPProof ifft_proof;
+  std::vector<IOPProof> ifft_delegation_proof;
+  IOPProof hadamard_proof;
+  std::vector<E> fft_claims, fft_weight_claims, ifft_claims;
+  std::vector<std::vector<E>> fft_delegation_claims, fft_delegation_weights_claims, ifft_delegation_claims;
+  std::vector<E> partial_evals, hadamard_clams;
+  E bias_claim;
+  HadamardProof clearing_proof;
+};
+struct PoolingProof { IOPProof sumcheck; LogUpProof lookup; std::vector<E> zerocheck_evals; size_t variable_gap = 0; std::vector<Commitment> commitments; };  // pooling.rs:60-76
+struct LayerProof { LayerKind kind; DenseProof dense; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; };
 struct TableProof { Commitment multiplicity_commit; LogUpProof lookup; };
 struct Proof {
   std::map<size_t, LayerProof> steps;  // canonical order: ascending NodeId
@@ -346,6 +478,14 @@ static inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       for (size_t i = 0; i < a.size(); i++) count_into(element_count[rt], a[i] + COLUMN_SEPARATOR * b[i]);
       LogUpWitness w; w.is_table = false; w.columns_per_instance = 2; w.table_type = rt;
       for (auto* col : {&a, &b}) { std::vector<u64> ev = to_base(*col); Mle mle = Mle::from_base(ev); w.commits.push_back({pcs_commit(ctx.pp, mle), mle}); w.column_evals.push_back(ev); }
+      ps.lookup_witness[id] = {w};
+    } else if (l.kind == L_MAXPOOL) {  // Pooling::gen_lookup_witness (pooling.rs:206-262)
+      TableType rt{2, 0};
+      std::vector<std::vector<int64_t>> diffs = maxpool_diff_polys(l, tr.in[id], tr.out[id]);
+      for (auto& d : diffs) for (int64_t v : d) count_into(element_count[rt], v);
+      LogUpWitness w; w.is_table = false; w.columns_per_instance = 1; w.table_type = rt;
+      for (auto& d : diffs) { std::vector<u64> ev = to_base(d); Mle mle = Mle::from_base(ev); w.commits.push_back({pcs_commit(ctx.pp, mle), mle}); w.column_evals.push_back(ev); }
+      { Mle mle = Mle::from_base(to_base(tr.out[id])); w.commits.push_back({pcs_commit(ctx.pp, mle), mle}); }  // the output poly is committed too
       ps.lookup_witness[id] = {w};
     }
   }
@@ -465,11 +605,255 @@ static inline Claim prove_relu(ProverState& ps, size_t id, const Claim& last, co
   return input_claim;
 }
 
+// ------------------------------------------------------------------ convolution (zkCNN FFT protocol)
+// phi_pow_init (iop/prover.rs:214-227): powers of the 2^n-th root of unity (inverted when `is_fft`)
+static inline std::vector<E> phi_pow_init(unsigned n, bool is_fft) {
+  size_t length = size_t(1) << n;
+  E phi = get_root_of_unity(n);
+  if (is_fft) phi = einv(phi);
+  std::vector<E> pm(length); pm[0] = e_one();
+  for (size_t i = 1; i < length; i++) pm[i] = emul(pm[i - 1], phi);
+  return pm;
+}
+// phi_g_init (iop/prover.rs:231-284): the FFT / iFFT matrix reduced at rx, with the intermediate tables
+static inline void phi_g_init(std::vector<E>& phi_g, std::vector<std::vector<E>>& mid, const std::vector<E>& rx, E scale, unsigned n, bool is_fft) {
+  std::vector<E> phi_mul = phi_pow_init(n, is_fft);
+  if (is_fft) {
+    phi_g[0] = scale; phi_g[1] = scale;
+    for (unsigned i = 1; i < n + 1; i++) {
+      for (size_t b = 0; b < (size_t(1) << (i - 1)); b++) {
+        size_t l = b, r = b ^ (size_t(1) << (i - 1)); unsigned m = n - i;
+        E tmp1 = esub(e_one(), rx[m]), tmp2 = emul(rx[m], phi_mul[b << m]);
+        phi_g[r] = emul(phi_g[l], esub(tmp1, tmp2));
+        phi_g[l] = emul(phi_g[l], eadd(tmp1, tmp2));
+      }
+      if (i < n) mid[i - 1].assign(phi_g.begin(), phi_g.begin() + (size_t(1) << i));
+    }
+  } else {
+    phi_g[0] = scale;
+    for (unsigned i = 1; i < n; i++) {
+      for (size_t b = 0; b < (size_t(1) << (i - 1)); b++) {
+        size_t l = b, r = b ^ (size_t(1) << (i - 1)); unsigned m = n - i;
+        E tmp1 = esub(e_one(), rx[m]), tmp2 = emul(rx[m], phi_mul[b << m]);
+        phi_g[r] = emul(phi_g[l], esub(tmp1, tmp2));
+        phi_g[l] = emul(phi_g[l], eadd(tmp1, tmp2));
+      }
+      mid[i - 1].assign(phi_g.begin(), phi_g.begin() + (size_t(1) << i));
+    }
+    for (size_t b = 0; b < (size_t(1) << (n - 1)); b++) {
+      E tmp1 = esub(e_one(), rx[0]), tmp2 = emul(rx[0], phi_mul[b]);
+      phi_g[b] = emul(phi_g[b], eadd(tmp1, tmp2));
+    }
+  }
+}
+struct MatrixEval { std::vector<IOPProof> proofs; std::vector<std::vector<E>> claims; };
+// delegate_matrix_evaluation (iop/prover.rs:164-211)
+static inline MatrixEval delegate_matrix_evaluation(Transcript& t, std::vector<std::vector<E>>& f_middle, const std::vector<E>& r1, std::vector<E> r2, bool is_fft) {
+  std::vector<E> omegas = phi_pow_init((unsigned)r1.size(), is_fft);
+  MatrixEval me;
+  size_t fm = f_middle.size();
+  for (size_t l = r1.size() - 1; l-- > 0;) {
+    std::vector<E> phi(f_middle[l].size());
+    std::vector<E> beta = compute_betas_eval(std::vector<E>(r2.begin(), r2.end() - 1));
+    E r2l = r2.back(), r1e = r1[(fm - 1) - l];
+    for (size_t i = 0; i < phi.size(); i++) {
+      E om = omegas[i << ((fm - 1) - l)];
+      if (!is_fft && l == fm - 1) phi[i] = emul(esub(e_one(), r2l), eadd(esub(e_one(), r1e), emul(r1e, om)));
+      else phi[i] = eadd(esub(e_one(), r1e), emul(emul(esub(e_one(), emul(e_from_u64(2), r2l)), r1e), om));
+    }
+    MleP f1 = mk(Mle::from_ext(beta)), f2 = mk(Mle::from_ext(phi)), f3 = mk(Mle::from_ext(f_middle[l]));
+    VirtualPolynomial vp(f1->nv);
+    vp.add_mle_list({f1, f2, f3}, e_one());
+    auto [proof, st] = sumcheck_prove(std::move(vp), t);
+    r2 = proof.point;
+    me.proofs.push_back(proof); me.claims.push_back(st.final_evaluations());
+  }
+  return me;
+}
+struct BatchFFTProof { IOPProof proof; std::vector<E> claims; MatrixEval matrix_eval; std::vector<E> partial_evals; };
+static inline std::vector<E> flatten2(const std::vector<std::vector<E>>& x) { std::vector<E> o; for (auto& v : x) o.insert(o.end(), v.begin(), v.end()); return o; }
+// prove_batch_fft (iop/prover.rs:290-338)
+static inline BatchFFTProof prove_batch_fft(Transcript& t, const std::vector<E>& r, std::vector<std::vector<E>> x) {
+  size_t padded_rows = 2 * x[0].size();
+  for (auto& it : x) it.resize(padded_rows, e_zero());
+  unsigned l1 = log2_strict(x[0].size()), l2 = log2_strict(x.size());
+  std::vector<E> r1(r.begin(), r.begin() + l1), r2(r.begin() + l1, r.begin() + l1 + l2);
+  std::vector<E> w_red(x[0].size(), e_zero()); std::vector<std::vector<E>> f_middle(l1 - 1);
+  phi_g_init(w_red, f_middle, r1, e_one(), l1, false);
+  Mle f_m = Mle::from_ext(flatten2(x));
+  f_m.fix_high_in_place(r2);
+  MleP fm = mk(f_m), fr = mk(Mle::from_ext(w_red));
+  VirtualPolynomial vp(fm->nv);
+  vp.add_mle_list({fm, fr}, e_one());
+  auto [proof, st] = sumcheck_prove(std::move(vp), t);
+  BatchFFTProof out; out.proof = proof; out.claims = st.final_evaluations();
+  out.matrix_eval = delegate_matrix_evaluation(t, f_middle, r1, proof.point, false);
+  return out;
+}
+// prove_batch_ifft (iop/prover.rs:340-398)
+static inline BatchFFTProof prove_batch_ifft(Transcript& t, const std::vector<E>& r, const std::vector<std::vector<E>>& prod) {
+  E scale = einv(e_from_u64(prod[0].size()));
+  unsigned l1 = log2_strict(prod[0].size()), l2 = log2_strict(prod.size());
+  std::vector<E> r1(r.begin(), r.begin() + l1), r2(r.begin() + l1, r.begin() + l1 + l2);
+  if (!e_is_zero(r1[l1 - 1])) throw std::runtime_error("Error in randomness init batch ifft");
+  std::vector<E> w_red(prod[0].size(), e_zero()); std::vector<std::vector<E>> f_middle(l1 - 1);
+  phi_g_init(w_red, f_middle, r1, scale, l1, true);
+  MleP fr = mk(Mle::from_ext(w_red));
+  Mle f_m = Mle::from_ext(flatten2(prod));
+  f_m.fix_high_in_place(r2);
+  MleP fm = mk(f_m);
+  VirtualPolynomial vp(fm->nv);
+  vp.add_mle_list({fm, fr}, e_one());
+  auto [proof, st] = sumcheck_prove(std::move(vp), t);
+  BatchFFTProof out; out.proof = proof; out.claims = st.final_evaluations();
+  out.matrix_eval = delegate_matrix_evaluation(t, f_middle, r1, proof.point, true);
+  return out;
+}
+// Convolution::prove_batch_fft_weights (convolution.rs:358-443)
+static inline BatchFFTProof prove_batch_fft_weights(Transcript& t, const Layer& l, const std::vector<E>& r) {
+  size_t padded_rows = 2 * l.nw * l.nw, fsz = l.real_nw * l.real_nw;
+  unsigned l1 = log2_strict(padded_rows);
+  std::vector<E> r1(r.begin(), r.begin() + l1), r2(r.begin() + l1, r.end());
+  std::vector<E> w_red(padded_rows, e_zero()); std::vector<std::vector<E>> f_middle(l1 - 1);
+  std::vector<E> beta = compute_betas_eval(r2);
+  phi_g_init(w_red, f_middle, r1, e_one(), l1, false);
+  std::vector<E> w1_reduced(fsz, e_zero());
+  for (size_t i = 0; i < l.kw; i++) for (size_t j = 0; j < l.kx; j++) for (size_t k = 0; k < fsz; k++)
+    w1_reduced[k] = eadd(w1_reduced[k], emul(beta[i * l.kx + j], e_from_i64(l.weights[i * fsz * l.kx + j * fsz + k])));
+  BatchFFTProof out; out.partial_evals = w1_reduced;
+  MleP fm = mk(Mle::from_ext(index_wf(w1_reduced, l.real_nw, l.nw, padded_rows))), fr = mk(Mle::from_ext(w_red));
+  VirtualPolynomial vp(fm->nv);
+  vp.add_mle_list({fm, fr}, e_one());
+  auto [proof, st] = sumcheck_prove(std::move(vp), t);
+  out.proof = proof; out.claims = st.final_evaluations();
+  out.matrix_eval = delegate_matrix_evaluation(t, f_middle, r1, proof.point, false);
+  return out;
+}
+// hadamard::prove (hadamard.rs:83-130)
+static inline HadamardProof hadamard_prove(Transcript& t, const Claim& output_claim, const std::vector<int64_t>& v1, const std::vector<int64_t>& v2) {
+  if (output_claim.point.size() != log2_strict(v1.size()) || v1.size() != v2.size()) throw std::runtime_error("hadamard: shapes");
+  auto to_e = [](const std::vector<int64_t>& v) { std::vector<E> o(v.size()); for (size_t i = 0; i < v.size(); i++) o[i] = e_from_i64(v[i]); return o; };
+  MleP beta = mk(Mle::from_ext(compute_betas_eval(output_claim.point))), m1 = mk(Mle::from_ext(to_e(v1))), m2 = mk(Mle::from_ext(to_e(v2)));
+  VirtualPolynomial vp(m1->nv);
+  vp.add_mle_list({m1, m2, beta}, e_one());
+  auto [proof, st] = sumcheck_prove(std::move(vp), t);
+  std::vector<E> fin = st.final_evaluations();
+  return {proof, {fin[0], fin[1]}};
+}
+// Convolution::prove_convolution_step (convolution.rs:697-1080)
+static inline Claim prove_conv(ProverState& ps, size_t id, const Layer& l, const Claim& last_in, const ConvData& pd) {
+  Transcript& t = *ps.t;
+  size_t padded_out[3] = {l.kw, l.nw, l.nw};
+  std::vector<int64_t> clearing = new_clearing_tensor(l.unp_out, padded_out);
+  HadamardProof clearing_proof = hadamard_prove(t, last_in, pd.output_as_element, clearing);
+  Claim last{clearing_proof.sumcheck.point, clearing_proof.individual_claim[0]};
+  unsigned lfs = log2_strict(l.filter_size()), lkw = log2_strict(l.kw);
+  if (lfs + lkw != last.point.size()) throw std::runtime_error("conv: inconsistent random point size");
+  std::vector<E> r(last.point.size() + 1, e_zero()), bias_point(lkw, e_zero());
+  for (unsigned i = 0; i < lfs; i++) r[i] = esub(e_one(), last.point[i]);
+  for (unsigned i = 0; i < lkw; i++) { r[i + lfs + 1] = last.point[i + lfs]; bias_point[i] = last.point[i + lfs]; }
+  E bias_eval = e_zero();
+  if (!bias_point.empty()) bias_eval = Mle::from_i64(l.bias).evaluate(bias_point);
+  else if (l.bias.size() == 1) bias_eval = e_from_i64(l.bias[0]);
+  BatchFFTProof ifft = prove_batch_ifft(t, r, pd.prod);
+  if (ifft.proof.point.size() != lfs + 1) throw std::runtime_error("Error in ifft sumcheck");
+  std::vector<E> r_ifft = ifft.proof.point;
+  unsigned lo = log2_strict(pd.output[0].size());
+  for (size_t i = lo; i < r.size(); i++) r_ifft.push_back(r[i]);
+  std::vector<E> r1(r_ifft.begin() + lo, r_ifft.end()), r2(r_ifft.begin(), r_ifft.begin() + lo);
+  std::vector<E> beta1 = compute_betas_eval(r1), beta2 = compute_betas_eval(r2);
+  std::vector<E> beta_acc; for (size_t i = 0; i < l.kx; i++) beta_acc.insert(beta_acc.end(), beta2.begin(), beta2.end());
+  size_t fsz = l.real_nw * l.real_nw;
+  std::vector<std::vector<E>> agg(l.kx, std::vector<E>(fsz, e_zero()));
+  for (size_t i = 0; i < l.kx; i++) {
+    for (size_t j = 0; j < l.kw; j++) for (size_t k = 0; k < fsz; k++)
+      agg[i][k] = eadd(agg[i][k], emul(beta1[j], e_from_i64(l.weights[j * l.kx * fsz + i * fsz + k])));
+    agg[i] = index_wf(agg[i], l.real_nw, l.nw, 2 * l.nw * l.nw);
+    fft(agg[i], false);
+  }
+  MleP f1 = mk(Mle::from_ext(flatten2(agg))), f2 = mk(Mle::from_ext(flatten2(pd.input_fft))), f3 = mk(Mle::from_ext(beta_acc));
+  VirtualPolynomial vp(f1->nv);
+  vp.add_mle_list({f1, f2, f3}, e_one());
+  auto [hadamard_proof, hst] = sumcheck_prove(std::move(vp), t);
+  std::vector<E> hadamard_claims = hst.final_evaluations();
+  std::vector<E> point = hadamard_proof.point; point.insert(point.end(), r1.begin(), r1.end());
+  BatchFFTProof fftp = prove_batch_fft(t, hadamard_proof.point, pd.input);
+  BatchFFTProof wp = prove_batch_fft_weights(t, l, point);
+  std::vector<E> weights_rand = t.read_challenges(log2_strict(fsz));
+  unsigned l2n = log2_strict(2 * l.nw * l.nw);
+  Claim bias_claim{bias_point, bias_eval};
+  Claim filter_claim; filter_claim.point = weights_rand; filter_claim.point.insert(filter_claim.point.end(), point.begin() + l2n, point.end());
+  filter_claim.eval = Mle::from_ext(wp.partial_evals).evaluate(weights_rand);
+  const auto& comms = ps.ctx->model_comms.at(id);  // add_common_claims: BTreeMap order "ConvBias" < "ConvFilter"
+  ps.add_witness_claim(comms.at("ConvBias"), bias_claim);
+  ps.add_witness_claim(comms.at("ConvFilter"), filter_claim);
+  ConvProof cp;
+  cp.fft_proof = fftp.proof; cp.fft_claims = fftp.claims; cp.fft_proof_weights = wp.proof; cp.ifft_proof = ifft.proof;
+  cp.fft_delegation_proof = fftp.matrix_eval.proofs; cp.fft_delegation_proof_weights = wp.matrix_eval.proofs; cp.ifft_delegation_proof = ifft.matrix_eval.proofs;
+  cp.hadamard_proof = hadamard_proof; cp.ifft_claims = ifft.claims; cp.fft_weight_claims = wp.claims;
+  cp.fft_delegation_claims = fftp.matrix_eval.claims; cp.fft_delegation_weights_claims = wp.matrix_eval.claims; cp.ifft_delegation_claims = ifft.matrix_eval.claims;
+  cp.hadamard_clams = hadamard_claims; cp.bias_claim = bias_eval; cp.partial_evals = wp.partial_evals; cp.clearing_proof = clearing_proof;
+  LayerProof lp; lp.kind = L_CONV; lp.conv = cp; ps.proofs[id] = lp;
+  std::vector<E> input_point = fftp.proof.point;
+  E v = input_point.back(); input_point.pop_back();
+  v = einv(esub(e_one(), v));
+  for (auto& ip : input_point) ip = esub(e_one(), ip);
+  Claim fin; fin.point = input_point;
+  fin.point.insert(fin.point.end(), hadamard_proof.point.begin() + log2_strict(l.filter_size() * 2), hadamard_proof.point.end());
+  fin.eval = emul(fftp.claims[0], v);
+  return fin;
+}
+// Pooling::prove_pooling (pooling.rs:342-520)
+static inline Claim prove_pooling(ProverState& ps, size_t id, const Layer& l, const Claim& last, const std::vector<E>& output) {
+  Transcript& t = *ps.t;
+  std::vector<LogUpWitness> ws = ps.lookup_witness.at(id);
+  if (ws.size() != 1) throw std::runtime_error("pooling: one lookup witness expected");
+  LogUpInput in = ps.logup_input(ws[0]);
+  LogUpProof lproof = logup_batch_prove(in, t);
+  unsigned nv = log2_strict(output.size());
+  std::vector<MleP> diff; for (auto& c : in.column_evals) diff.push_back(mk(Mle::from_base(c)));
+  VirtualPolynomial vp(nv);
+  const std::vector<E>& lookup_point = lproof.output_claims[0].point;
+  E batch = t.get_and_append_challenge("batch_pooling");
+  MleP beta = mk(Mle::from_ext(compute_betas_eval(lookup_point))), last_beta = mk(Mle::from_ext(compute_betas_eval(last.point)));
+  E comb = batch;
+  std::vector<std::pair<std::vector<MleP>, E>> parts;
+  for (auto& d : diff) { parts.push_back({{d, beta}, comb}); comb = emul(comb, batch); }
+  std::vector<MleP> all = diff; all.push_back(beta);
+  vp.add_mle_list(all, e_one());
+  for (auto& pr : parts) vp.add_mle_list(pr.first, pr.second);
+  MleP out_mle = mk(Mle::from_ext(output));
+  vp.add_mle_list({out_mle, last_beta}, comb);
+  auto [proof, st] = sumcheck_prove(std::move(vp), t);
+  std::vector<E> evals = st.final_evaluations();
+  size_t ks = 4;  // kernel_size^2
+  E output_eval = evals[ks + 1];
+  PoolingProof pp; pp.sumcheck = proof; pp.lookup = lproof;
+  for (size_t i = 0; i <= ks; i++) {
+    E ev = i < ks ? evals[i] : output_eval;
+    pp.commitments.push_back(ws[0].commits[i].first.pure());
+    ps.add_witness_claim(ws[0].commits[i], {proof.point, ev});
+  }
+  unsigned row_log = ceil_log2(l.pin[2]);
+  E r1 = t.get_and_append_challenge("input_batching"), r2 = r1;  // [x; 2]: one challenge, used twice (pooling.rs:463-466)
+  E om1 = esub(e_one(), r1), om2 = esub(e_one(), r2);
+  E mult[4] = {emul(om1, om2), emul(om1, r2), emul(r1, om2), emul(r1, r2)};
+  E zc = e_zero();
+  for (size_t i = 0; i < ks; i++) zc = eadd(zc, emul(mult[i], esub(output_eval, evals[i])));
+  Claim next; next.point.push_back(r1);
+  next.point.insert(next.point.end(), proof.point.begin(), proof.point.begin() + (row_log - 1));
+  next.point.push_back(r2);
+  next.point.insert(next.point.end(), proof.point.begin() + (row_log - 1), proof.point.end());
+  next.eval = zc;
+  pp.zerocheck_evals.assign(evals.begin(), evals.begin() + ks); pp.zerocheck_evals.push_back(output_eval);
+  pp.variable_gap = row_log - 1;
+  LayerProof lp; lp.kind = L_MAXPOOL; lp.pool = pp; ps.proofs[id] = lp;
+  return next;
+}
+
 // Prover::prove (iop/prover.rs:401-488)
-static inline Proof prove(const Context& ctx, const std::vector<int64_t>& input, Transcript& t, Trace* trace_out = nullptr) {
+static inline Proof prove(const Context& ctx, const Trace& tr, Transcript& t) {
   ProverState ps; ps.ctx = &ctx; ps.t = &t;
-  Trace tr = run_model(ctx.model, input);
-  if (trace_out) *trace_out = tr;
   // ctx.write_to_transcript: every model commitment root, BTreeMap order (commit/context.rs:181-192)
   for (auto& [id, m] : ctx.model_comms) for (auto& [pid, pc] : m) t.append_digest(pc.first.codeword_tree.root());
   instantiate_witness_ctx(ps, tr);
@@ -481,7 +865,10 @@ static inline Proof prove(const Context& ctx, const std::vector<int64_t>& input,
     const Layer& l = ctx.model.layers[id];
     if (l.kind == L_DENSE) cur = prove_dense(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
-    else cur = prove_relu(ps, id, cur, to_fields(tr.out[id]));
+    else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, to_fields(tr.out[id]));
+    else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv[id]);
+    else if (l.kind == L_MAXPOOL) cur = prove_pooling(ps, id, l, cur, to_fields(tr.out[id]));
+    // L_FLATTEN is not provable: the claim is propagated unchanged (iop/prover.rs:449-456)
   }
   Proof proof;
   // prove_tables (iop/prover.rs:110-157)
@@ -542,9 +929,22 @@ static inline std::vector<u64> serialize_proof(const Proof& p) {
     else if (lp.kind == L_REQUANT) {
       w.iop(lp.req.io_accumulation); w.ve(lp.req.accumulation_evals); w.logup(lp.req.clamping_lookup); w.logup(lp.req.shifted_lookup);
       w.u(lp.req.commitments.size()); for (auto& c : lp.req.commitments) w.comm(c);
-    } else {
+    } else if (lp.kind == L_RELU) {
       w.iop(lp.act.io_accumulation.sumcheck); w.ve(lp.act.io_accumulation.evals); w.logup(lp.act.lookup);
       w.u(lp.act.commits.size()); for (auto& c : lp.act.commits) w.comm(c);
+    } else if (lp.kind == L_CONV) {
+      const ConvProof& c = lp.conv;
+      auto viop = [&](const std::vector<IOPProof>& v) { w.u(v.size()); for (auto& x : v) w.iop(x); };
+      auto vve = [&](const std::vector<std::vector<E>>& v) { w.u(v.size()); for (auto& x : v) w.ve(x); };
+      w.iop(c.fft_proof); w.iop(c.fft_proof_weights); viop(c.fft_delegation_proof); viop(c.fft_delegation_proof_weights);
+      w.iop(c.ifft_proof); viop(c.ifft_delegation_proof); w.iop(c.hadamard_proof);
+      w.ve(c.fft_claims); w.ve(c.fft_weight_claims); w.ve(c.ifft_claims);
+      vve(c.fft_delegation_claims); vve(c.fft_delegation_weights_claims); vve(c.ifft_delegation_claims);
+      w.ve(c.partial_evals); w.ve(c.hadamard_clams); w.e(c.bias_claim);
+      w.iop(c.clearing_proof.sumcheck); w.ve(c.clearing_proof.individual_claim);
+    } else if (lp.kind == L_MAXPOOL) {
+      w.iop(lp.pool.sumcheck); w.logup(lp.pool.lookup); w.ve(lp.pool.zerocheck_evals); w.u(lp.pool.variable_gap);
+      w.u(lp.pool.commitments.size()); for (auto& c : lp.pool.commitments) w.comm(c);
     }
   }
   w.u(p.table_proofs.size()); for (auto& tp : p.table_proofs) { w.comm(tp.multiplicity_commit); w.logup(tp.lookup); }

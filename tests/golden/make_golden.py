@@ -37,23 +37,39 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < nl; i++) { dp::LayerSpec l; l.kind = (int)b[pos++];
     if (l.kind == 0) { l.nrows = b[pos++]; l.ncols = b[pos++]; l.weights.assign(b.begin() + pos, b.begin() + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols; l.bias.assign(b.begin() + pos, b.begin() + pos + l.nrows); pos += l.nrows; }
     else if (l.kind == 1) { l.right_shift = b[pos++]; l.fp_scale = b[pos++]; l.fixed_point_multiplier = b[pos++]; l.intermediate_bit_size = b[pos++]; }
+    else if (l.kind == 3) { l.kw = b[pos++]; l.kx = b[pos++]; l.real_nw = b[pos++]; l.nw = b[pos++]; for (int k = 0; k < 3; k++) l.unp_out[k] = b[pos++];
+      size_t nf = l.kw * l.kx * l.real_nw * l.real_nw; l.weights.assign(b.begin() + pos, b.begin() + pos + nf); pos += nf; l.bias.assign(b.begin() + pos, b.begin() + pos + l.kw); pos += l.kw; }
+    else if (l.kind == 4) { for (int k = 0; k < 3; k++) l.pin[k] = b[pos++]; }
     m.layers.push_back(l); }
-  dp::CpuDev dev; auto ctx = dp::context_generate(dev, m); dp::VerifierContext v = ctx->verifier_ctx();
-  std::vector<uint64_t> w; w.push_back(0x3158544356504444ULL); w.push_back(v.full_log); w.push_back(v.shape.input_len); w.push_back(v.shape.layers.size());
-  for (auto& l : v.shape.layers) { w.push_back(l.kind); w.push_back(l.nrows); w.push_back(l.ncols); w.push_back(l.right_shift); w.push_back(l.fp_scale); w.push_back((uint64_t)l.fixed_point_multiplier); w.push_back(l.intermediate_bit_size); }
-  w.push_back(v.model_comms.size());
-  for (auto& kv : v.model_comms) { w.push_back(kv.first); for (const char* id : {"DenseBias", "DenseWeight"}) { auto& c = kv.second.at(id); for (int k = 0; k < 4; k++) w.push_back(c.root.v[k]); w.push_back(c.num_vars); w.push_back(c.is_base); } }
-  w.push_back(v.tables.size()); for (auto& t : v.tables) { w.push_back(t.kind); w.push_back(t.size); }
+  dp::CpuDev dev; auto ctx = dp::context_generate(dev, m);
+  std::vector<uint64_t> w = dp::vctx_to_words(ctx->verifier_ctx());  // the layout dp_model_verifier_blob hands out
   f = fopen(argv[2], "wb"); fwrite(w.data(), 8, w.size(), f); fclose(f); return 0; }
 '''
-with tempfile.TemporaryDirectory() as td:
-    open(os.path.join(td, "v.cpp"), "w").write(src)
-    blob.tofile(os.path.join(td, "blob.bin"))
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", ROOT, "-o", os.path.join(td, "v"), os.path.join(td, "v.cpp")])
-    subprocess.check_call([os.path.join(td, "v"), os.path.join(td, "blob.bin"), os.path.join(td, "vb.bin")])
-    vblob = np.fromfile(os.path.join(td, "vb.bin"), dtype=np.uint64)
+
+
+def verifier_blob_for(blob):
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "v.cpp"), "w").write(src)
+        blob.tofile(os.path.join(td, "blob.bin"))
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", ROOT, "-o", os.path.join(td, "v"), os.path.join(td, "v.cpp")])
+        subprocess.check_call([os.path.join(td, "v"), os.path.join(td, "blob.bin"), os.path.join(td, "vb.bin")])
+        return np.fromfile(os.path.join(td, "vb.bin"), dtype=np.uint64)
+
+
+vblob = verifier_blob_for(blob)
 dpa.verify(vblob, proof, x, out)
 np.savez_compressed(os.path.join(here, "mlp_w8.npz"), model_blob=blob, input=x, output=out, proof=proof, verifier_blob=vblob)
+
+# ---- a small CNN proof (conv -> requant -> relu -> maxpool -> flatten -> dense -> requant -> relu -> dense -> requant)
+mb = dpa.models.cnn_tiny()
+blob, x = mb.blob(), mb.input()
+h = o.model_setup(blob)
+proof, out, _ = o.model_prove(h, x)
+o.model_free(h)
+assert (out == mb.run(x)).all()
+vblob = verifier_blob_for(blob)
+dpa.verify(vblob, proof, x, out)
+np.savez_compressed(os.path.join(here, "cnn_tiny.npz"), model_blob=blob, input=x, output=out, proof=proof, verifier_blob=vblob)
 
 # ---- primitive vectors
 rng = np.random.default_rng(2025)

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <chrono>
 #include <cmath>
+#include <string>
 
 static uint64_t rs;
 static uint64_t rnd() { rs += 0x9E3779B97F4A7C15ULL; uint64_t z = rs; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
@@ -24,22 +25,52 @@ static dp::LayerSpec requant_for(size_t ncols, double m) {
 }
 static orc::Model to_orc(const dp::ModelSpec& m) {
   orc::Model o; o.input_len = m.input_len;
-  for (auto& l : m.layers) { orc::Layer x; x.kind = (orc::LayerKind)l.kind; x.nrows = l.nrows; x.ncols = l.ncols; x.weights = l.weights; x.bias = l.bias; x.right_shift = l.right_shift; x.fp_scale = l.fp_scale; x.intermediate_bit_size = l.intermediate_bit_size; x.fixed_point_multiplier = l.fixed_point_multiplier; o.layers.push_back(x); }
+  for (auto& l : m.layers) { orc::Layer x; x.kind = (orc::LayerKind)l.kind; x.nrows = l.nrows; x.ncols = l.ncols; x.weights = l.weights; x.bias = l.bias; x.right_shift = l.right_shift; x.fp_scale = l.fp_scale; x.intermediate_bit_size = l.intermediate_bit_size; x.fixed_point_multiplier = l.fixed_point_multiplier;
+    x.kw = l.kw; x.kx = l.kx; x.real_nw = l.real_nw; x.nw = l.nw; for (int k = 0; k < 3; k++) { x.unp_out[k] = l.unp_out[k]; x.pin[k] = l.pin[k]; }
+    o.layers.push_back(x); }
   return o;
 }
+// a small CNN with the structure of the CIFAR model: conv -> requant -> relu -> maxpool -> flatten -> dense -> requant
+static dp::ModelSpec tiny_cnn(std::vector<int64_t>& in) {
+  const size_t C = 2, H = 16, OC = 3, K = 3, KW = 4, KX = 2, RNW = 4, NW = 16, OH = H - K + 1;
+  dp::ModelSpec m; m.input_len = KX * NW * NW;
+  in.assign(m.input_len, 0);
+  for (size_t c = 0; c < C; c++) for (size_t i = 0; i < H * H; i++) in[c * NW * NW + i] = rq();
+  dp::LayerSpec cv; cv.kind = dp::L_CONV; cv.kw = KW; cv.kx = KX; cv.real_nw = RNW; cv.nw = NW; cv.unp_out[0] = OC; cv.unp_out[1] = OH; cv.unp_out[2] = OH;
+  cv.weights.assign(KW * KX * RNW * RNW, 0); cv.bias.assign(KW, 0);
+  for (size_t o = 0; o < OC; o++) { for (size_t c = 0; c < C; c++) for (size_t a = 0; a < K; a++) for (size_t b = 0; b < K; b++) cv.weights[((o * KX + c) * RNW + a) * RNW + b] = rq(); cv.bias[o] = rq(); }
+  m.layers.push_back(cv);
+  dp::LayerSpec rqc = requant_for(1, 1.0 / std::sqrt((double)(C * K * K)) / 127); rqc.intermediate_bit_size = 2 * 7 + dp::dp_ceil_log2(C * K * K + 1);
+  m.layers.push_back(rqc);
+  dp::LayerSpec relu; relu.kind = dp::L_RELU; m.layers.push_back(relu);
+  dp::LayerSpec mp; mp.kind = dp::L_MAXPOOL; mp.pin[0] = KW; mp.pin[1] = NW; mp.pin[2] = NW; m.layers.push_back(mp);
+  dp::LayerSpec fl; fl.kind = dp::L_FLATTEN; m.layers.push_back(fl);
+  const size_t PH = NW / 2, UH = OH / 2, R = 8, COLS = KW * PH * PH;  // dense over the flattened pool output, garbage columns zero
+  dp::LayerSpec d; d.kind = dp::L_DENSE; d.nrows = R; d.ncols = COLS; d.weights.assign(R * COLS, 0); d.bias.assign(R, 0);
+  for (size_t r = 0; r < 5; r++) { for (size_t c = 0; c < OC; c++) for (size_t y = 0; y < UH; y++) for (size_t x = 0; x < UH; x++) d.weights[r * COLS + (c * PH + y) * PH + x] = rq(); d.bias[r] = rq(); }
+  m.layers.push_back(d);
+  m.layers.push_back(requant_for(COLS, 2.5 / std::sqrt((double)(OC * UH * UH)) / 127));
+  return m;
+}
 int main(int argc, char** argv) {
-  size_t W = argc > 1 ? atoi(argv[1]) : 64; rs = argc > 2 ? atoll(argv[2]) : 1; int tamper = argc > 3 ? atoi(argv[3]) : 0;
+  bool cnn = argc > 1 && std::string(argv[1]) == "cnn";
+  size_t W = argc > 1 && !cnn ? atoi(argv[1]) : 64; rs = argc > 2 ? atoll(argv[2]) : 1; int tamper = argc > 3 ? atoi(argv[3][0] == '@' ? argv[3] + 1 : argv[3]) : 0; bool tamper_abs = argc > 3 && argv[3][0] == '@';  // "@i": flip word i, else word size/2 + offset
   dp::ModelSpec m; m.input_len = 4;
   dp::LayerSpec relu; relu.kind = dp::L_RELU;
-  m.layers.push_back(dense(W, 4)); m.layers.push_back(requant_for(4, 0.5 / 127)); m.layers.push_back(relu);
-  m.layers.push_back(dense(W, W)); m.layers.push_back(requant_for(W, 1.0 / std::sqrt((double)W) / 127)); m.layers.push_back(relu);
-  m.layers.push_back(dense(4, W)); m.layers.push_back(requant_for(W, 1.0 / std::sqrt((double)W) / 127)); m.layers.push_back(relu);
-  std::vector<int64_t> in = {rq(), rq(), rq(), rq()};
+  std::vector<int64_t> in;
+  if (cnn) m = tiny_cnn(in);
+  else {
+    m.layers.push_back(dense(W, 4)); m.layers.push_back(requant_for(4, 0.5 / 127)); m.layers.push_back(relu);
+    m.layers.push_back(dense(W, W)); m.layers.push_back(requant_for(W, 1.0 / std::sqrt((double)W) / 127)); m.layers.push_back(relu);
+    m.layers.push_back(dense(4, W)); m.layers.push_back(requant_for(W, 1.0 / std::sqrt((double)W) / 127)); m.layers.push_back(relu);
+    in = {rq(), rq(), rq(), rq()};
+  }
   // oracle
   auto t0 = std::chrono::steady_clock::now();
   orc::Context octx = orc::context_generate(to_orc(m));
   orc::Transcript ot = orc::default_transcript();
-  orc::Proof op = orc::prove(octx, in, ot);
+  orc::Trace otr = orc::run_model(octx.model, in);
+  orc::Proof op = orc::prove(octx, otr, ot);
   std::vector<uint64_t> ow = orc::serialize_proof(op);
   auto t1 = std::chrono::steady_clock::now();
   // product host logic over the CPU double
@@ -62,7 +93,7 @@ int main(int argc, char** argv) {
   int rc = 0;
   for (int which = 0; which < 2; which++) {
     std::vector<uint64_t> w = which ? pw : ow;
-    if (tamper && which == 0) w[w.size() / 2 + tamper] ^= 1;
+    if (tamper && which == 0) w[tamper_abs ? (size_t)tamper : w.size() / 2 + tamper] ^= 1;
     try { dp::Proof q = dp::deserialize_proof(w.data(), w.size()); dp::Transcript vt = dp::default_transcript(); dp::verify(vc, q, io, vt); printf("verify(%s%s): ACCEPT\n", which ? "product" : "oracle", (tamper && !which) ? ",tampered" : ""); }
     catch (const std::exception& e) { printf("verify(%s%s): REJECT: %s\n", which ? "product" : "oracle", (tamper && !which) ? ",tampered" : "", e.what()); if (!(tamper && !which)) rc = 1; }
   }

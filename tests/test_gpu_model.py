@@ -115,3 +115,57 @@ def test_concurrent_batch_matches_sequential(dev):
         assert proofs[i].size == seq[i][0].size and (proofs[i] == seq[i][0]).all()
         dpa.verify(vb, proofs[i], xs[i], outs[i])
     ctx.free()
+
+
+def test_cnn_tiny_proof_bytes_identical_to_oracle(dev, oracle):
+    """conv (zkCNN FFT protocol) -> requant -> relu -> maxpool (degree-5 zero check) -> flatten -> dense ...: the
+    device proof stream equals the oracle's and the host verifier accepts it"""
+    import deep_prove_amd as dpa
+    mb = dpa.models.cnn_tiny()
+    x = mb.input()
+    ctx, proof, out, oproof, oout = prove_both(dev, oracle, mb, x)
+    assert (out == oout).all() and (out == mb.run(x)).all()
+    assert proof.size == oproof.size, (proof.size, oproof.size)
+    diff = np.nonzero(proof != oproof)[0]
+    assert diff.size == 0, f"first differing word {diff[:5]} of {proof.size}"
+    dpa.verify(ctx.verifier_blob(), proof, x, out)
+    bad = proof.copy()
+    bad[900] ^= np.uint64(1)  # inside the convolution proof
+    with pytest.raises(dpa.DeepProveError):
+        dpa.verify(ctx.verifier_blob(), bad, x, out)
+    ctx.free()
+
+
+def test_golden_cnn_tiny(dev):
+    """committed fixture tests/golden/cnn_tiny.npz (made by tests/golden/make_golden.py)"""
+    import deep_prove_amd as dpa
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cnn_tiny.npz"))
+    ctx = dpa.Context.generate(dev, g["model_blob"])
+    proof, out = dpa.Prover(ctx).prove(g["input"])
+    assert (out == g["output"]).all()
+    assert proof.size == g["proof"].size and (proof == g["proof"]).all()
+    assert (ctx.verifier_blob() == g["verifier_blob"]).all()
+    ctx.free()
+
+
+def test_config3_cnn264k_full_size(dev):
+    """BASELINE config 3: CNN-264k on CIFAR-10 shapes (conv 3->12, conv 12->33, fc 825->247->173->10). Bit-exact vs the
+    oracle through the committed sha256 of the oracle's proof stream (tests/golden/cnn264k_proof.json) + verifier
+    acceptance at full size; several proofs in flight give the same bytes."""
+    import deep_prove_amd as dpa
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "cnn264k_proof.json")))
+    mb = dpa.models.cnn_264k()
+    x = mb.input(gold["input_index"])
+    ctx = dpa.Context.generate(dev, mb.blob())
+    pr = dpa.Prover(ctx)
+    proof, out = pr.prove(x)
+    assert [int(v) for v in out] == gold["output"] and (out == mb.run(x)).all()
+    assert proof.size == gold["proof_words"]
+    assert hashlib.sha256(proof.tobytes()).hexdigest() == gold["sha256"]
+    dpa.verify(ctx.verifier_blob(), proof, x, out)
+    xs = np.stack([mb.input(3000 + i) for i in range(4)])
+    proofs, outs, _ = pr.prove_batch(xs, 4)
+    for i in range(len(xs)):
+        assert (outs[i] == mb.run(xs[i])).all()
+        dpa.verify(ctx.verifier_blob(), proofs[i], xs[i], outs[i])
+    ctx.free()

@@ -23,3 +23,19 @@ def test_tampered_proof_rejected(hostlogic_bin, offset):
     r = run(hostlogic_bin, 16, 2, offset)
     assert "verify(oracle,tampered): REJECT" in r.stdout, r.stdout
     assert "verify(product): ACCEPT" in r.stdout
+
+
+@pytest.mark.parametrize("seed", [1, 4])
+def test_cnn_proof_stream_identical_to_oracle_and_accepted(hostlogic_bin, seed):
+    """conv (FFT protocol) -> requant -> relu -> maxpool -> flatten -> dense -> requant"""
+    r = run(hostlogic_bin, "cnn", seed)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical=1" in r.stdout
+    assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
+
+
+@pytest.mark.parametrize("where", ["@40", "@900", "@5000", "-3000"])
+def test_cnn_tampered_proof_rejected(hostlogic_bin, where):
+    r = run(hostlogic_bin, "cnn", 2, where)
+    assert "verify(oracle,tampered): REJECT" in r.stdout, r.stdout
+    assert "verify(product): ACCEPT" in r.stdout
