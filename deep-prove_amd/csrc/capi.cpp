@@ -1,6 +1,7 @@
 // extern "C" surface of libdeepprove_hip.so (declared in include/deep_prove_hip.h).
 #include "../../include/deep_prove_hip.h"
 #include "zkml.h"
+#include "fiber.h"
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -8,7 +9,8 @@
 #include <mutex>
 #include <thread>
 
-namespace dp { void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
+DP_FIBER_SWITCH_ASM
+namespace dp { void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
 using namespace dp;
 
 struct dp_ctx { Dev* dev; int device_id; };
@@ -261,12 +263,12 @@ int32_t dp_model_prove(dp_model* m, const int64_t* input, size_t ninput, uint64_
 int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs, size_t ninput, int32_t concurrency,
                              uint64_t** proof_words, size_t* proof_nwords, int64_t* outputs, size_t noutput_cap, size_t* noutput, double* wall_ms) {
   return guard([&] {
-    DP_REQUIRE(m && inputs && proof_words && proof_nwords && nproofs > 0 && concurrency > 0 && concurrency <= 64, DP_ERR_ARG, "bad arguments");
+    DP_REQUIRE(m && inputs && proof_words && proof_nwords && nproofs > 0 && concurrency > 0 && concurrency <= 256, DP_ERR_ARG, "bad arguments");
     size_t nw = std::min<size_t>((size_t)concurrency, nproofs);
     // worker 0 is the model's own context; the others get their own stream + arena on the same GPU and share the
     // (read-only) model commitments
     const char* env = getenv("DP_WORKER_ARENA_BYTES");
-    size_t arena = env ? strtoull(env, nullptr, 10) : (size_t(4) << 30);
+    size_t arena = env ? strtoull(env, nullptr, 10) : (size_t(3) << 29);
     while (m->workers.size() + 1 < nw) { std::unique_ptr<Dev> w(make_hip_worker(m->ctx->device_id, arena)); w->pcs_init(m->zk->full_log); m->workers.push_back(std::move(w)); }
     std::atomic<size_t> next(0);
     std::mutex err_mu; std::string err; int err_code = 0;
@@ -290,11 +292,25 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
       } catch (const DpError& e) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = e.code; err = e.what(); } next = nproofs; }
       catch (const std::exception& e) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_ARG; err = e.what(); } next = nproofs; }
     };
+    // `nw` proofs in flight on `nth` host threads: every worker is a fiber, fibers are dealt round robin to the threads and
+    // a thread switches to its next fiber whenever the current one waits for the device (fiber.h). The thread count follows
+    // the CPUs the process may really use (cgroup quota), leaving two for the HIP runtime's own threads.
+    const char* te = getenv("DP_HOST_THREADS");
+    size_t nth = te ? (size_t)std::max(1, atoi(te)) : (size_t)std::max(1.0, host_cpu_budget() - 2.0);
+    nth = std::min(nth, nw);
+    auto run_thread = [&](size_t ti) {
+      FiberSched sched;
+      for (size_t wi = ti; wi < nw; wi += nth) fiber_spawn(sched, [&work, wi] { work(wi); });
+      fiber_run_all(sched);
+    };
     std::vector<std::thread> th;
-    for (size_t wi = 1; wi < nw; wi++) th.emplace_back(work, wi);
-    work(0);
+    for (size_t ti = 1; ti < nth; ti++) th.emplace_back(run_thread, ti);
+    run_thread(0);
     for (auto& t : th) t.join();
+    if (getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) fprintf(stderr, "[dp timing] prove_batch: %zu proofs, %zu in flight on %zu host threads, arena peak %.1f MB\n", nproofs, nw, nth, hip_dev_arena_peak(m->ctx->dev) / 1048576.0);
     if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    hip_dev_dump_sc_debug(m->ctx->dev); hip_dev_dump_host_stats(m->ctx->dev);
+    for (size_t wi = 1; wi < nw && wi < 3; wi++) { hip_dev_dump_sc_debug(m->workers[wi - 1].get()); hip_dev_dump_host_stats(m->workers[wi - 1].get()); }
     if (err_code) { for (size_t i = 0; i < nproofs; i++) { free(proof_words[i]); proof_words[i] = nullptr; } throw DpError(err_code, err); }
   });
 }

@@ -1,0 +1,116 @@
+// Cooperative fibers for the host orchestrator. A proof spends most of its wall time waiting for the device (one
+// Fiat-Shamir round trip per sumcheck round, ~2000 waits per proof); a host thread that spins through those waits burns a
+// whole core per proof in flight, and the MI355X boxes give a process ~16 cores per GPU (cgroup quota). With fibers one
+// host thread drives several proofs: every device wait (HipDev::wait_flag) yields to the next proof of the thread instead
+// of spinning. Fibers never migrate between threads (HIP's per-thread state and the thread_locals of this library stay
+// valid). x86-64 System V only (the hosts of MI355X nodes are EPYC).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstdio>
+#include <functional>
+#include <memory>
+#include <string>
+#include <vector>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <immintrin.h>
+
+#if !defined(__x86_64__)
+#error "fiber.h: x86-64 hosts only"
+#endif
+
+// saves the callee-saved registers on the current stack, stores rsp to *save_sp, switches to load_sp and restores
+extern "C" void dp_fiber_switch(void** save_sp, void* load_sp);
+#define DP_FIBER_SWITCH_ASM                                                                                             \
+  __asm__(".text\n.globl dp_fiber_switch\n.type dp_fiber_switch,@function\ndp_fiber_switch:\n"                           \
+          "  pushq %rbp\n  pushq %rbx\n  pushq %r12\n  pushq %r13\n  pushq %r14\n  pushq %r15\n"                         \
+          "  movq %rsp, (%rdi)\n  movq %rsi, %rsp\n"                                                                    \
+          "  popq %r15\n  popq %r14\n  popq %r13\n  popq %r12\n  popq %rbx\n  popq %rbp\n  ret\n"                        \
+          ".size dp_fiber_switch, .-dp_fiber_switch\n");
+
+namespace dp {
+
+struct FiberSched;
+struct Fiber {
+  void* sp = nullptr;
+  void* stack = nullptr;
+  size_t stack_bytes = 0;
+  std::function<void()> fn;
+  bool done = false;
+  FiberSched* sched = nullptr;
+  ~Fiber() { if (stack) munmap(stack, stack_bytes); }
+};
+struct FiberSched {
+  std::vector<std::unique_ptr<Fiber>> fibers;
+  Fiber* cur = nullptr;
+  void* main_sp = nullptr;
+};
+inline FiberSched*& fiber_current_sched() { static thread_local FiberSched* s = nullptr; return s; }
+inline bool fiber_active() { FiberSched* s = fiber_current_sched(); return s && s->cur; }
+// give the thread to the next fiber (called from inside a fiber at a device wait)
+inline void fiber_yield() {
+  FiberSched* s = fiber_current_sched();
+  Fiber* f = s->cur;
+  dp_fiber_switch(&f->sp, s->main_sp);
+}
+inline void fiber_entry_trampoline() {
+  FiberSched* s = fiber_current_sched();
+  Fiber* f = s->cur;
+  f->fn();  // the body catches its own exceptions
+  f->done = true;
+  dp_fiber_switch(&f->sp, s->main_sp);
+  abort();  // a finished fiber is never resumed
+}
+inline void fiber_spawn(FiberSched& s, std::function<void()> fn, size_t stack_bytes = size_t(1) << 20) {
+  std::unique_ptr<Fiber> f(new Fiber());
+  f->fn = std::move(fn); f->sched = &s; f->stack_bytes = stack_bytes;
+  f->stack = mmap(nullptr, stack_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
+  if (f->stack == MAP_FAILED) { f->stack = nullptr; throw std::bad_alloc(); }
+  uintptr_t top = ((uintptr_t)f->stack + stack_bytes) & ~uintptr_t(15);
+  void** sp = (void**)top;
+  *(--sp) = nullptr;                             // fake return address of the trampoline (keeps rsp = 8 mod 16 at entry)
+  *(--sp) = (void*)&fiber_entry_trampoline;      // `ret` of the first switch lands here
+  for (int i = 0; i < 6; i++) *(--sp) = nullptr;  // rbp rbx r12 r13 r14 r15
+  f->sp = (void*)sp;
+  s.fibers.push_back(std::move(f));
+}
+// run every fiber of `s` on the calling thread until all are finished, round robin
+inline void fiber_run_all(FiberSched& s) {
+  FiberSched*& cur = fiber_current_sched();
+  FiberSched* saved = cur;
+  cur = &s;
+  for (;;) {
+    bool alive = false;
+    for (auto& f : s.fibers) {
+      if (f->done) continue;
+      alive = true;
+      s.cur = f.get();
+      dp_fiber_switch(&s.main_sp, f->sp);
+      s.cur = nullptr;
+    }
+    if (!alive) break;
+    _mm_pause();
+  }
+  cur = saved;
+}
+
+// CPUs this process may actually use: the cgroup quota when there is one (cpu.max of cgroup v2, cfs_quota of v1), else
+// the number of hardware threads
+inline double host_cpu_budget() {
+  double hw = 0;
+  { long n = sysconf(_SC_NPROCESSORS_ONLN); hw = n > 0 ? (double)n : 1.0; }
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char a[64]; double period = 0;
+    if (fscanf(f, "%63s %lf", a, &period) == 2 && std::string(a) != "max" && period > 0) { double q = atof(a) / period; fclose(f); return q > 0 && q < hw ? q : hw; }
+    fclose(f);
+  }
+  double quota = -1, period = -1;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(f, "%lf", &quota) != 1) quota = -1; fclose(f); }
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f, "%lf", &period) != 1) period = -1; fclose(f); }
+  if (quota > 0 && period > 0 && quota / period < hw) return quota / period;
+  return hw;
+}
+
+}  // namespace dp

@@ -7,6 +7,7 @@
 // are canonical u64, extension elements are 16-byte {c0,c1} pairs so one `global_load_dwordx4` per lane fetches one
 // element. A sumcheck pair (2b, 2b+1) is therefore 32 contiguous bytes per lane.
 #include "dev.h"
+#include "fiber.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,7 @@ namespace dp {
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw DpError(DP_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 __constant__ u64 c_rc[DP_POSEIDON2_RC_WORDS];
+__constant__ int c_poll_sleep = 1;  // units of s_sleep(4) (~0.1 us) between two polls of the host mailbox (DP_POLL_SLEEP)
 
 constexpr int TPB = 256;
 constexpr int MAX_TABS = 32;
@@ -925,7 +927,7 @@ __device__ __forceinline__ void sc_wait_challenge(const unsigned long long* mail
   for (unsigned spin = 0; spin < (1u << 22); spin++) {
     got = __hip_atomic_load(mailbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (got == seq) break;
-    __builtin_amdgcn_s_sleep(4);
+    for (int q = 0; q < c_poll_sleep; q++) __builtin_amdgcn_s_sleep(4);  // every poll is a PCIe read: keep the rate of all kernels in flight bounded
   }
   chal[0] = got == seq ? 1 : 0;
   chal[1] = __hip_atomic_load(mailbox + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1101,12 +1103,20 @@ static inline int grid_for(size_t n, int cap = 2048) {
 }
 
 struct ProfRec { const char* name; double bytes; hipEvent_t a, b; };
-#define DPL_LDS(kern, grid, block, lds, ...) do { prof_begin(#kern); hipLaunchKernelGGL(kern, grid, block, lds, s_, __VA_ARGS__); prof_end(); } while (0)
+#define DPL_LDS(kern, grid, block, lds, ...) do { prof_begin(#kern); LaunchTimer lt_(this); hipLaunchKernelGGL(kern, grid, block, lds, s_, __VA_ARGS__); lt_.stop(); prof_end(); } while (0)
 #define DPL_HI(kern, hi, grid, block, ...) do { if (hi) { DPL((kern<true>), grid, block, __VA_ARGS__); } else { DPL((kern<false>), grid, block, __VA_ARGS__); } } while (0)
 #define DPL_LDS_HI(kern, hi, grid, block, lds, ...) do { if (hi) { DPL_LDS((kern<true>), grid, block, lds, __VA_ARGS__); } else { DPL_LDS((kern<false>), grid, block, lds, __VA_ARGS__); } } while (0)
-#define DPL(kern, grid, block, ...) do { prof_begin(#kern); hipLaunchKernelGGL(kern, grid, block, 0, s_, __VA_ARGS__); prof_end(); } while (0)
+#define DPL(kern, grid, block, ...) do { prof_begin(#kern); LaunchTimer lt_(this); hipLaunchKernelGGL(kern, grid, block, 0, s_, __VA_ARGS__); lt_.stop(); prof_end(); } while (0)
 
+static const bool g_host_stats = getenv("DP_TIMING") && atoi(getenv("DP_TIMING"));
 class HipDev : public Dev {
+  // host-side cost accounting (DP_TIMING=1): time inside hipLaunchKernel and number of launches / device waits
+  double launch_us_ = 0; size_t nlaunch_ = 0, nwait_ = 0, nyield_ = 0;
+  struct LaunchTimer {
+    HipDev* d; std::chrono::steady_clock::time_point t0;
+    explicit LaunchTimer(HipDev* d_) : d(d_) { if (g_host_stats) t0 = std::chrono::steady_clock::now(); }
+    void stop() { if (g_host_stats) { d->launch_us_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); d->nlaunch_++; } }
+  };
   int device_;
   bool prof_ = false;
   double nb_ = 0;  // algorithmic bytes of the next launch (SURVEY.md 8d ledger), consumed by prof_begin
@@ -1122,7 +1132,7 @@ class HipDev : public Dev {
 
   hipStream_t s_ = nullptr;
   char* arena_ = nullptr;
-  size_t arena_cap_ = 0, arena_off_ = 0;
+  size_t arena_cap_ = 0, arena_off_ = 0, arena_peak_ = 0;
   u64* hres_ = nullptr;   // pinned, device-mapped host memory for small results (zero-copy readback)
   u64* hres_dev_ = nullptr;  // device view of hres_
   unsigned long long* hflag_ = nullptr;      // host view of the publish sequence number
@@ -1131,6 +1141,7 @@ class HipDev : public Dev {
   unsigned long long last_tag_ = 0;
   bool zerocopy_ = true;  // DP_NO_ZEROCOPY=1 falls back to hipMemcpyAsync + hipStreamSynchronize
   bool persist_ = true;   // DP_NO_PERSIST=1 disables the persistent sumcheck kernel
+  size_t excl_ = 0;       // dynamic LDS requested by one-workgroup kernels to keep a CU to themselves (DP_NO_EXCLUSIVE_CU=1: none)
   unsigned long long* scdbg_ = nullptr;  // DP_SC_DEBUG=1: device cycle counters of the persistent sumcheck kernel
   unsigned long long* hmail_ = nullptr;      // host view of the challenge mailbox [seq, c0, c1]
   unsigned long long* hmail_dev_ = nullptr;  // device view
@@ -1149,8 +1160,9 @@ class HipDev : public Dev {
 
   void* arena_alloc(size_t bytes) {
     size_t off = (arena_off_ + 255) & ~size_t(255);
-    if (off + bytes > arena_cap_) throw DpError(DP_ERR_OOM, "device arena exhausted (raise DP_ARENA_BYTES)");
+    if (off + bytes > arena_cap_) throw DpError(DP_ERR_OOM, "device arena exhausted (raise DP_ARENA_BYTES / DP_WORKER_ARENA_BYTES)");
     arena_off_ = off + bytes;
+    if (arena_off_ > arena_peak_) arena_peak_ = arena_off_;
     return arena_ + off;
   }
   static unsigned long long pub_mix(unsigned long long seq) { return seq * 0x9E3779B97F4A7C15ull + 0x7F4A7C159E3779B9ull; }
@@ -1162,6 +1174,7 @@ class HipDev : public Dev {
     auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     const unsigned long long base = pub_mix(seq);
+    nwait_++;
     for (;;) {
       unsigned long long tag = *f;
       if (tag == ~0ull) throw DpError(DP_ERR_HIP, "device aborted a persistent sumcheck (no challenge received)");
@@ -1171,8 +1184,10 @@ class HipDev : public Dev {
         for (size_t i = 0; i < nwords; i++) cs += (unsigned long long)(i + 1) * w[i];
         if (base + cs == tag) { last_tag_ = tag; desc_off_ = 0; return; }
       }
-      __builtin_ia32_pause();
-      if ((++spins & 0xFFFF) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
+      // inside a fiber the wait hands the host thread to the next proof in flight (fiber.h); otherwise spin
+      const bool fib = fiber_active();
+      if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
+      if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
         throw DpError(DP_ERR_HIP, "timeout waiting for the device");
     }
   }
@@ -1260,8 +1275,15 @@ class HipDev : public Dev {
     HIP_CHECK(hipHostGetDevicePointer((void**)&hstage_dev_, hstage_, 0));
     hstage_dev_ += 0;
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_rc), POSEIDON2_RC_HOST, sizeof(POSEIDON2_RC_HOST)));
+    { int ps = getenv("DP_POLL_SLEEP") ? std::max(0, atoi(getenv("DP_POLL_SLEEP"))) : 1; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_poll_sleep), &ps, sizeof(int))); }
     HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_persist_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS_MAX));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_persist_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS_MAX));
+    excl_ = (getenv("DP_NO_EXCLUSIVE_CU") && atoi(getenv("DP_NO_EXCLUSIVE_CU"))) ? 0 : EXCL_LDS;
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXCL_LDS));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_persist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXCL_LDS));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_small<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXCL_LDS));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXCL_LDS));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_merkle_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXCL_LDS));
   }
   ~HipDev() override {
     hipSetDevice(device_);
@@ -1275,6 +1297,12 @@ class HipDev : public Dev {
     if (s_) hipStreamDestroy(s_);
   }
   const char* name() const override { return name_.c_str(); }
+  size_t arena_peak() const { return arena_peak_; }
+  void dump_host_stats() {
+    if (!g_host_stats) return;
+    fprintf(stderr, "[dp timing] device context: %zu launches, %.1f us of host time per launch (%.1f ms total), %zu device waits, %zu fiber yields\n", nlaunch_, nlaunch_ ? launch_us_ / nlaunch_ : 0.0, launch_us_ / 1000.0, nwait_, nyield_);
+    launch_us_ = 0; nlaunch_ = nwait_ = nyield_ = 0;
+  }
   void dump_sc_debug() {
     if (!scdbg_) return;
     unsigned long long h[5]; hipStreamSynchronize(s_); hipMemcpy(h, scdbg_, 40, hipMemcpyDeviceToHost); hipMemset(scdbg_, 0, 64);
@@ -1426,6 +1454,10 @@ class HipDev : public Dev {
     }
   }
   static constexpr size_t SC_LDS_MAX = 128 * 1024;  // dynamic LDS the LDS-resident sumcheck kernel may use
+  // Latency-critical one-workgroup kernels ask for more than half of a CU's 160 KB of LDS even when they need none: two
+  // such workgroups can then never share a CU. The workgroup dispatcher otherwise packs the small persistent kernels of
+  // all proofs in flight onto the same first CUs (4 kernels of 256 threads fit on one), where they time-share the SIMDs.
+  static constexpr size_t EXCL_LDS = 84 * 1024;
   static constexpr size_t SC_PERSIST_MAX = 16384;  // sumchecks whose tables are at most this long run in the persistent kernel
   void post_challenge(Ext r) {
     hmail_[1] = r.c0; hmail_[2] = r.c1;
@@ -1479,8 +1511,8 @@ class HipDev : public Dev {
       size_t work = (size_t)nterms * (n_after / 2) + (size_t)nt * n_after / 4;
       int threads = work >= 2048 ? 1024 : work >= 512 ? 512 : 256;
       size_t lds = (size_t)nt * (n_in / 2) * 16;
-      if (lds <= SC_LDS_MAX) { nb_ = 0; DPL_LDS_HI(k_sc_persist_lds, hi, dim3(1), dim3(threads), lds, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
-      else { nb_ = 0; DPL_HI(k_sc_persist, hi, dim3(1), dim3(threads), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
+      if (lds <= SC_LDS_MAX) { nb_ = 0; DPL_LDS_HI(k_sc_persist_lds, hi, dim3(1), dim3(threads), std::max(lds, excl_), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
+      else { nb_ = 0; DPL_LDS_HI(k_sc_persist, hi, dim3(1), dim3(threads), excl_, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
       wait_flag(++sess_.seq, 2 * nraw);
       if (r) for (int i = 0; i < nt; i++) { tabs[i].p = sess_.a[i]; tabs[i].n = n_after; tabs[i].ext = true; }
       read_terms();
@@ -1500,7 +1532,7 @@ class HipDev : public Dev {
       unsigned long long seq = ++seq_;
       size_t work = (size_t)nterms * (n_after / 2) + (r ? (size_t)nt * n_after / 4 : 0);
       int threads = work >= 2048 ? 1024 : work >= 512 ? 512 : 256;
-      nb_ = bytes; DPL_HI(k_sc_small, hi, dim3(1), dim3(threads), a, (Ext*)hres_dev_, hflag_dev_, seq);
+      nb_ = bytes; DPL_LDS_HI(k_sc_small, hi, dim3(1), dim3(threads), excl_, a, (Ext*)hres_dev_, hflag_dev_, seq);
       wait_flag(seq, 2 * nraw);
       read_terms();
       return;
@@ -1648,11 +1680,11 @@ class HipDev : public Dev {
   void tails_to_host(const TailDesc* dd, size_t nd) {
     if (nd == 1 && zerocopy_) {
       unsigned long long seq = ++seq_;
-      nb_ = 0; DPL(k_merkle_tail, dim3(1), dim3(1024), dd, dres_, hres_dev_, hflag_dev_, seq);
+      nb_ = 0; DPL_LDS(k_merkle_tail, dim3(1), dim3(1024), excl_, dd, dres_, hres_dev_, hflag_dev_, seq);
       wait_flag(seq, 4);
       return;
     }
-    nb_ = 0; DPL(k_merkle_tail, dim3((unsigned)nd), dim3(1024), dd, dres_, (u64*)nullptr, (unsigned long long*)nullptr, 0ull);
+    nb_ = 0; DPL_LDS(k_merkle_tail, dim3((unsigned)nd), dim3(1024), excl_, dd, dres_, (u64*)nullptr, (unsigned long long*)nullptr, 0ull);
     fetch(4 * nd);
   }
   static constexpr size_t TAIL_MAX = 1024;   // layers of at most this many digests are finished by k_merkle_tail
@@ -1870,6 +1902,8 @@ class HipDev : public Dev {
 Dev* make_hip_dev(int device) { return new HipDev(device); }
 Dev* make_hip_worker(int device, size_t arena_bytes) { return new HipDev(device, arena_bytes); }
 void hip_dev_dump_sc_debug(Dev* d) { static_cast<HipDev*>(d)->dump_sc_debug(); }
+size_t hip_dev_arena_peak(Dev* d) { return static_cast<HipDev*>(d)->arena_peak(); }
+void hip_dev_dump_host_stats(Dev* d) { static_cast<HipDev*>(d)->dump_host_stats(); }
 void hip_dev_profile_enable(Dev* d, bool on) { static_cast<HipDev*>(d)->profile_enable(on); }
 std::string hip_dev_profile_report(Dev* d) { return static_cast<HipDev*>(d)->profile_report(); }
 

@@ -39,3 +39,13 @@ def test_cnn_tampered_proof_rejected(hostlogic_bin, where):
     r = run(hostlogic_bin, "cnn", 2, where)
     assert "verify(oracle,tampered): REJECT" in r.stdout, r.stdout
     assert "verify(product): ACCEPT" in r.stdout
+
+
+def test_host_fibers(tmp_path):
+    """deep-prove_amd/csrc/fiber.h: the cooperative fibers that let one host thread drive several proofs in flight"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fiber_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(root, "tests", "support", "fiber_check.cpp")])
+    r = run(exe)
+    assert r.returncode == 0 and "fibers ok=1" in r.stdout, r.stdout + r.stderr

@@ -1,0 +1,13 @@
+"""host-side launch cost / waits per device context with several proofs in flight (DP_TIMING)"""
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "64")
+os.environ["DP_TIMING"] = "1"
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import deep_prove_amd as dpa
+conc = int(sys.argv[1])
+dev = dpa.Device(0); mb = dpa.models.dense_4m(); ctx = dpa.Context.generate(dev, mb.blob()); pr = dpa.Prover(ctx)
+xs = np.stack([mb.input(3000 + i) for i in range(2 * conc)])
+pr.prove_batch(xs[:conc], conc)
+t0 = time.perf_counter(); pr.prove_batch(xs, conc); dt = time.perf_counter() - t0
+print(f"conc={conc} {len(xs)/dt:.1f} proofs/s", file=sys.stderr)
