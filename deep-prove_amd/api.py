@@ -333,6 +333,11 @@ class Prover:
         return proofs, outs[:, :no.value].copy(), ms.value
 
 
+def host_cpu_budget():
+    """CPUs this process may use (cgroup quota, else hardware threads): what the number of proving host threads follows"""
+    return float(_lib.load().dp_host_cpu_budget())
+
+
 def verify(verifier_blob, proof_words, input_i64, output_i64):
     """zkml::verify (zkml/src/iop/verifier.rs:306-318). Host only. Raises DeepProveError(DP_ERR_VERIFY) on rejection."""
     vb = np.ascontiguousarray(verifier_blob, dtype=np.uint64)

@@ -314,6 +314,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     if (err_code) { for (size_t i = 0; i < nproofs; i++) { free(proof_words[i]); proof_words[i] = nullptr; } throw DpError(err_code, err); }
   });
 }
+double dp_host_cpu_budget(void) { return host_cpu_budget(); }
 int32_t dp_model_verifier_blob(const dp_model* m, uint64_t** words, size_t* nwords) {
   return guard([&] { DP_REQUIRE(m && words && nwords, DP_ERR_ARG, "bad arguments"); std::vector<u64> w = vctx_to_words(m->zk->verifier_ctx()); *words = copy_out(w); *nwords = w.size(); });
 }

@@ -1511,8 +1511,11 @@ class HipDev : public Dev {
       size_t work = (size_t)nterms * (n_after / 2) + (size_t)nt * n_after / 4;
       int threads = work >= 2048 ? 1024 : work >= 512 ? 512 : 256;
       size_t lds = (size_t)nt * (n_in / 2) * 16;
-      if (lds <= SC_LDS_MAX) { nb_ = 0; DPL_LDS_HI(k_sc_persist_lds, hi, dim3(1), dim3(threads), std::max(lds, excl_), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
-      else { nb_ = 0; DPL_LDS_HI(k_sc_persist, hi, dim3(1), dim3(threads), excl_, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
+      double tab_bytes = 0; for (int i = 0; i < nt; i++) tab_bytes += (double)n_in * (tabs[i].ext && !r ? 16.0 : tabs[i].ext ? 16.0 : 8.0);
+      // algorithmic HBM bytes of the launch: every table is read once (the LDS variant never touches HBM again; the
+      // global variant also writes and re-reads the halving ping-pong buffers: + 3 x 16 B x n/2 per table in total)
+      if (lds <= SC_LDS_MAX) { nb_ = tab_bytes; DPL_LDS_HI(k_sc_persist_lds, hi, dim3(1), dim3(threads), std::max(lds, excl_), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
+      else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_LDS_HI(k_sc_persist, hi, dim3(1), dim3(threads), excl_, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
       wait_flag(++sess_.seq, 2 * nraw);
       if (r) for (int i = 0; i < nt; i++) { tabs[i].p = sess_.a[i]; tabs[i].n = n_after; tabs[i].ext = true; }
       read_terms();

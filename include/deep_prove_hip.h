@@ -76,8 +76,8 @@ int32_t dp_mle_eval(dp_ctx* ctx, const dp_buf* f, const uint64_t* point, uint32_
 int32_t dp_mle_fix_high(dp_ctx* ctx, const dp_buf* matrix, size_t rows, size_t cols, const uint64_t* point, dp_buf** out);
 
 /* ---- sumcheck: IOPProverState::prove_parallel(VirtualPolynomial, transcript) (sumcheck/src/prover.rs:498-585).
- * The virtual polynomial is sum_i coeff_i * prod_{j<degree_i} tables[term_tables[3i+j]]; every table has 2^num_vars
- * entries. proof_words receives the IOPProof stream {point: len, ext...; rounds: count, (len, ext...)...};
+ * The virtual polynomial is sum_i coeff_i * prod_{j<degree_i} tables[term_tables[3i+j]], degree_i in 1..3 through this
+ * entry point (the model-level provers use products of up to 5 tables); every table has 2^num_vars entries. proof_words receives the IOPProof stream {point: len, ext...; rounds: count, (len, ext...)...};
  * finals receives get_mle_final_evaluations() (2 words per table, table order). */
 int32_t dp_sumcheck_prove(dp_ctx* ctx, uint32_t num_vars, const dp_buf* const* tables, int32_t ntables,
                           const int32_t* term_degree, const int32_t* term_tables, const uint64_t* term_coeffs,
@@ -107,25 +107,36 @@ int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const u
                             const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t);
 
 /* ---- model level: Context::generate / Prover::prove / verify (zkml/src/iop/context.rs:109, prover.rs:401,
- * verifier.rs:306). model_blob (int64): input_len, nlayers, then per layer kind(0 Dense,1 Requant,2 Relu) followed by
- *   Dense: nrows, ncols, weights[nrows*ncols] row-major, bias[nrows]   (padded to powers of two, already quantised)
- *   Requant: right_shift, fp_scale, fixed_point_multiplier, intermediate_bit_size
- *   Relu: (nothing) */
+ * verifier.rs:306). model_blob (int64): input_len, nlayers, then per layer kind (0 Dense, 1 Requant, 2 Relu, 3 Conv,
+ * 4 MaxPool, 5 Flatten) followed by
+ *   Dense: nrows, ncols, weights[nrows*ncols] row-major, bias[nrows]   (padded to powers of two, already quantised; after a
+ *          Flatten the columns follow the padded (c,h,w) layout with zeros at padding positions, tensor.rs:1627-1675)
+ *   Requant: right_shift, fp_scale, fixed_point_multiplier, intermediate_bit_size   (zkml/src/layers/requant.rs:46-73)
+ *   Relu, Flatten: (nothing)
+ *   Conv: kw, kx, real_nw, nw, unpadded output shape (c, h, w), filter[kw*kx*real_nw*real_nw], bias[kw] — the layer as
+ *          pad_conv / into_padded_and_ffted leave it (zkml/src/padding.rs:218-260, tensor.rs:409-431): every dimension a
+ *          power of two, nw = padded input side, stride 1, no padding; proven with the zkCNN FFT protocol
+ *          (zkml/src/layers/convolution.rs:697-1080)
+ *   MaxPool: padded input shape (c, h, w); kernel 2, stride 2 (zkml/src/layers/pooling.rs:342-520) */
 int32_t dp_model_setup(dp_ctx* ctx, const int64_t* model_blob, size_t nwords, dp_model** out);
 int32_t dp_model_free(dp_model* m);
 /* runs inference on the host (Model::run, not part of proving time) then Prover::prove on the device.
  * output receives the model output (capacity *noutput on entry, length on exit). prove_ms (nullable) = prove() wall ms */
 int32_t dp_model_prove(dp_model* m, const int64_t* input, size_t ninput, uint64_t** proof_words, size_t* proof_nwords,
                        int64_t* output, size_t* noutput, double* prove_ms);
-/* `nproofs` independent proofs (inputs concatenated, `ninput` words each) with up to `concurrency` proofs in flight on
- * the model's GPU: every in-flight proof has its own host thread, HIP stream and arena; the model commitments are shared
- * read-only. A single proof is a chain of ~10^3 sequential Fiat-Shamir round trips that cannot fill an MI355X, so this
- * is how one GPU is saturated (and how BASELINE config 4, a batch of independent proofs, is served).
+/* `nproofs` independent proofs (inputs concatenated, `ninput` words each) with up to `concurrency` (<= 256) proofs in
+ * flight on the model's GPU: every in-flight proof has its own HIP stream, arena and host<->device mailbox; the model
+ * commitments are shared read-only. A single proof is a chain of ~10^3 sequential Fiat-Shamir round trips that cannot
+ * fill an MI355X, so this is how one GPU is saturated (and how BASELINE config 4, a batch of independent proofs, is
+ * served). The proofs are driven by min(concurrency, DP_HOST_THREADS or dp_host_cpu_budget() - 2) host threads; a thread
+ * runs its proofs as cooperative fibers and switches proof at every device wait.
  * proof_words / proof_nwords: arrays of nproofs entries (each buffer malloc'ed, release with dp_free);
  * outputs: nproofs * noutput_cap words (nullable). */
 int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs, size_t ninput, int32_t concurrency,
                              uint64_t** proof_words, size_t* proof_nwords, int64_t* outputs, size_t noutput_cap,
                              size_t* noutput, double* wall_ms);
+/* CPUs the process may use: the cgroup CPU quota when there is one, else the number of hardware threads */
+double dp_host_cpu_budget(void);
 /* serialisable verifier-side context (model commitments, shapes, tables) */
 int32_t dp_model_verifier_blob(const dp_model* m, uint64_t** words, size_t* nwords);
 /* zkml::verify(ctx, proof, io, transcript) — host only, default transcript "m2vec" */

@@ -1,0 +1,13 @@
+"""standalone 2^24 sumcheck (BASELINE config 5 on one GPU), a few repetitions — the command the rocprofv3 PMC passes wrap"""
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import deep_prove_amd as dpa
+nv, k = 24, 3
+dev = dpa.Device(0)
+n = 1 << nv
+tabs = [dpa.Mle.from_base(dev, dpa.models.splitmix64(0xD33B0000 ^ (5 << 32) ^ j, n) % np.uint64(dpa.P)) for j in range(k)]
+vp = dpa.VirtualPolynomial(nv)
+vp.add_mle_list(tabs)
+for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
+    t0 = time.perf_counter(); dpa.prove_parallel(dev, vp, dpa.Transcript(b"test")); print(f"{1000 * (time.perf_counter() - t0):.3f} ms")
