@@ -32,6 +32,10 @@ constexpr int MAX_PT = 32;
 
 struct PointArg { Ext p[MAX_PT]; };
 
+// Latency-critical one-workgroup kernels claim the whole register file of their CU (16 waves x 128 VGPRs): together with
+// the LDS reservation no wave of another kernel — in particular the VALU-heavy Poseidon2 Merkle layers of the other proofs in
+// flight, which need only ~30 VGPRs and would otherwise slip onto the same SIMDs — can share the CU with them.
+#define DP_CLAIM_ALL_VGPRS() asm volatile("v_mov_b32 v127, 0" ::: "v127")
 // ------------------------------------------------------------------------------------------------ reductions
 __device__ __forceinline__ u64 shfl_down_u64(u64 v, int d) {
   int lo = __shfl_down((int)(u32)v, d, 64);
@@ -639,6 +643,7 @@ struct TailDesc { u64* nodes; size_t off; size_t cnt; };
 // All Merkle layers above an already computed layer of `cnt` (<= 2048) digests, one workgroup per tree, no relaunch
 // between layers. Wide layers hash one node per lane, narrow ones use the 8-lane permutation. roots[4*tree..] = root.
 __global__ void __launch_bounds__(1024) k_merkle_tail(const TailDesc* d, u64* roots, u64* host_result, unsigned long long* flag, unsigned long long seq) {
+  DP_CLAIM_ALL_VGPRS();
   TailDesc t = d[blockIdx.x];
   u64* nd = t.nodes;
   size_t off = t.off, cnt = t.cnt;
@@ -767,6 +772,7 @@ __device__ __forceinline__ Ext block_reduce_ext_n(Ext v, Ext* sm) {
 // result[term*4 + t] straight into host-mapped memory and releases `flag = seq`.
 template <bool HI>
 __global__ void __launch_bounds__(1024) k_sc_small(ScSmallArgs a, Ext* result, unsigned long long* flag, unsigned long long seq) {
+  DP_CLAIM_ALL_VGPRS();
   __shared__ Ext part[64 * SC_SLOTS];  // [slot][t], slot = term * wpt + sub  (<= 64 slots)
   int tid = threadIdx.x, nt = blockDim.x;
   size_t n = a.n_after;
@@ -820,6 +826,7 @@ __device__ __forceinline__ void sc_fold_all(const ScPersistArgs& a, const void* 
 }
 template <bool HI>
 __global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* result, unsigned long long* flag, const unsigned long long* mailbox, unsigned long long seq0) {
+  DP_CLAIM_ALL_VGPRS();
   __shared__ Ext part[64 * SC_SLOTS];
   __shared__ unsigned long long chal[3];
   __shared__ const void* cur[MAX_TABS];
@@ -937,6 +944,7 @@ __device__ void sc_publish_fwd(Ext* result, const Ext* part, const int* tk, cons
 __device__ void sc_wait_challenge_fwd(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal) { sc_wait_challenge(mailbox, seq, chal); }
 template <bool HI>
 __global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* result, unsigned long long* flag, const unsigned long long* mailbox, unsigned long long seq0) {
+  DP_CLAIM_ALL_VGPRS();
   extern __shared__ __align__(16) unsigned char lds_dyn[];
   Ext* L = (Ext*)lds_dyn;
   __shared__ Ext part[64 * SC_SLOTS];
@@ -1106,9 +1114,12 @@ struct ProfRec { const char* name; double bytes; hipEvent_t a, b; };
 #define DPL_LDS(kern, grid, block, lds, ...) do { prof_begin(#kern); LaunchTimer lt_(this); hipLaunchKernelGGL(kern, grid, block, lds, s_, __VA_ARGS__); lt_.stop(); prof_end(); } while (0)
 #define DPL_HI(kern, hi, grid, block, ...) do { if (hi) { DPL((kern<true>), grid, block, __VA_ARGS__); } else { DPL((kern<false>), grid, block, __VA_ARGS__); } } while (0)
 #define DPL_LDS_HI(kern, hi, grid, block, lds, ...) do { if (hi) { DPL_LDS((kern<true>), grid, block, lds, __VA_ARGS__); } else { DPL_LDS((kern<false>), grid, block, lds, __VA_ARGS__); } } while (0)
-#define DPL(kern, grid, block, ...) do { prof_begin(#kern); LaunchTimer lt_(this); hipLaunchKernelGGL(kern, grid, block, 0, s_, __VA_ARGS__); lt_.stop(); prof_end(); } while (0)
+#define DPL(kern, grid, block, ...) do { prof_begin(#kern); LaunchTimer lt_(this); hipLaunchKernelGGL(kern, grid, block, 0, s_, __VA_ARGS__); lt_.stop(); prof_end(); for (int xl_ = 0; xl_ < g_extra_launches; xl_++) hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, s_); } while (0)
 
 static const bool g_host_stats = getenv("DP_TIMING") && atoi(getenv("DP_TIMING"));
+// experiment knob: DP_EXTRA_LAUNCHES=n queues n empty kernels after every real one (is throughput bound by the number of launches?)
+static const int g_extra_launches = getenv("DP_EXTRA_LAUNCHES") ? atoi(getenv("DP_EXTRA_LAUNCHES")) : 0;
+__global__ void k_noop() {}
 class HipDev : public Dev {
   // host-side cost accounting (DP_TIMING=1): time inside hipLaunchKernel and number of launches / device waits
   double launch_us_ = 0; size_t nlaunch_ = 0, nwait_ = 0, nyield_ = 0;
@@ -1509,7 +1520,7 @@ class HipDev : public Dev {
       unsigned rounds = 0; for (size_t m = n_after; m > 1; m >>= 1) rounds++;
       seq_ += rounds + 1;
       size_t work = (size_t)nterms * (n_after / 2) + (size_t)nt * n_after / 4;
-      int threads = work >= 2048 ? 1024 : work >= 512 ? 512 : 256;
+      int threads = excl_ ? 1024 : work >= 2048 ? 1024 : work >= 512 ? 512 : 256;  // exclusive CU: always the full 16 waves
       size_t lds = (size_t)nt * (n_in / 2) * 16;
       double tab_bytes = 0; for (int i = 0; i < nt; i++) tab_bytes += (double)n_in * (tabs[i].ext && !r ? 16.0 : tabs[i].ext ? 16.0 : 8.0);
       // algorithmic HBM bytes of the launch: every table is read once (the LDS variant never touches HBM again; the
@@ -1534,7 +1545,7 @@ class HipDev : public Dev {
       a.ntabs = nt; a.nterms = nterms; a.has_r = r ? 1 : 0; a.n_after = n_after; a.r = r ? *r : ex_zero();
       unsigned long long seq = ++seq_;
       size_t work = (size_t)nterms * (n_after / 2) + (r ? (size_t)nt * n_after / 4 : 0);
-      int threads = work >= 2048 ? 1024 : work >= 512 ? 512 : 256;
+      int threads = excl_ ? 1024 : work >= 2048 ? 1024 : work >= 512 ? 512 : 256;  // exclusive CU: always the full 16 waves
       nb_ = bytes; DPL_LDS_HI(k_sc_small, hi, dim3(1), dim3(threads), excl_, a, (Ext*)hres_dev_, hflag_dev_, seq);
       wait_flag(seq, 2 * nraw);
       read_terms();
@@ -1691,7 +1702,10 @@ class HipDev : public Dev {
     fetch(4 * nd);
   }
   static constexpr size_t TAIL_MAX = 1024;   // layers of at most this many digests are finished by k_merkle_tail
-  static constexpr size_t LP_MAX = 1 << 17;  // layers with at most this many parent nodes use the 8-lanes-per-node kernel
+  // Layers with at most lp_max_ parent nodes use the 8-lanes-per-node kernel (lowest latency per layer, but ~2.2x the
+  // VALU work of one node per lane and a grid 8x as large: with many proofs in flight those grids fill the chip and
+  // every other stream queues behind them), wider layers hash one node per lane. DP_MERKLE_LP_MAX overrides.
+  size_t lp_max_ = getenv("DP_MERKLE_LP_MAX") ? strtoull(getenv("DP_MERKLE_LP_MAX"), nullptr, 10) : (size_t(1) << 12);
   // `nodes` must hold 4*(n-1) words; synchronises (root is copied to the host)
   DevTree build_tree_into(const DBuf& leaves, const DBuf& nodes) {
     DevTree t; t.leaves = leaves; t.nleaves = leaves.n; t.nodes = nodes;
@@ -1702,7 +1716,7 @@ class HipDev : public Dev {
     size_t off = 0, cnt = n / 2;
     while (cnt > TAIL_MAX) {
       size_t next = cnt / 2;
-      if (next <= LP_MAX) { nb_ = 96.0 * next; DPL(k_merkle_layer_lp, dim3((unsigned)std::min<size_t>(std::min<size_t>((next * 8 + 1023) / 1024, 2048), (size_t)std::max(1, g_max_grid / 4))), dim3(1024), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
+      if (next <= lp_max_) { nb_ = 96.0 * next; DPL(k_merkle_layer_lp, dim3((unsigned)std::min<size_t>(std::min<size_t>((next * 8 + 255) / 256, 8192), (size_t)std::max(1, g_max_grid))), dim3(256), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
       else { nb_ = 96.0 * next; DPL(k_merkle_layer, dim3(grid_for(next, 4096)), dim3(TPB), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
       off += cnt; cnt /= 2;
     }

@@ -10,7 +10,7 @@ ctx = dpa.Context.generate(dev, mb.blob())
 pr = dpa.Prover(ctx)
 print("host cores", os.cpu_count())
 for conc in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8, 16]:
-    xs = np.stack([mb.input(3000 + i) for i in range(2 * conc)])
+    xs = np.stack([mb.input(3000 + i) for i in range(int(os.environ.get("SWEEP_BATCHES", "2")) * conc)])
     pr.prove_batch(xs[:conc], conc)  # warm (creates the workers)
     t0 = time.perf_counter()
     pr.prove_batch(xs, conc)
