@@ -672,7 +672,7 @@ __global__ void __launch_bounds__(1024) k_merkle_tail(const TailDesc* d, u64* ro
     if (tid == 0) pub_store((u64*)flag, pub_mix(seq) + cs);
   }
 }
-struct SmallCommitDesc { const void* evals; void* cw; void* bh; u64* nodes; };
+struct SmallCommitDesc { const void* evals; void* cw; void* bh; u64* nodes; void* tmp; };
 // layer 0 of many equally sized trees: blockIdx.y = tree
 template <bool EXT>
 __global__ void k_merkle_leaves_many(const SmallCommitDesc* d, size_t npairs) {
@@ -746,6 +746,79 @@ __global__ void __launch_bounds__(256) k_commit_small(const SmallCommitDesc* d, 
     __syncthreads();
   }
   for (size_t o = tid; o < N; o += nt) cw[o] = Bf[__brev((unsigned)o) >> (32 - (nv + 1))];
+}
+
+// ---- medium polynomials (2^12..2^14 base elements: the witness columns of a convolution layer), many at once: blockIdx.y
+// (or .x) = polynomial. Four launches replace the 2 nv + 4 per-stage launches of the generic path, for the whole group.
+constexpr unsigned MED_NTT_LG = 13;  // an NTT block of 2^13 base elements (64 KB) lives in LDS
+// K5 + K6 + coset scaling: evaluations -> LDS, all Moebius stages there, then tmp[2i] = tmp[2i+1] = coeff[i] * shift^bitrev(i)
+// (the zero-padded, bit-reversed DIT input after its trivial first stage) and bh[bitrev(i)] = evals[i]
+__global__ void __launch_bounds__(1024) k_med_prepare(const SmallCommitDesc* d, unsigned nv, unsigned L, const u64* pow7) {
+  extern __shared__ __align__(16) unsigned char lds_med[];
+  u64* A = (u64*)lds_med;
+  SmallCommitDesc pd = d[blockIdx.x];
+  const u64* ev = (const u64*)pd.evals; u64* bh = (u64*)pd.bh; u64* tmp = (u64*)pd.tmp;
+  size_t n = size_t(1) << nv;
+  int tid = threadIdx.x, nt = blockDim.x;
+  for (size_t i = tid; i < n; i += nt) { u64 v = ev[i]; A[i] = v; bh[__brev((unsigned)i) >> (32 - nv)] = v; }
+  __syncthreads();
+  for (unsigned s = 0; s < nv; s++) {
+    size_t half = size_t(1) << s;
+    for (size_t b = tid; b < n / 2; b += nt) { size_t lo = ((b >> s) << (s + 1)) | (b & (half - 1)); A[lo + half] = gl_sub(A[lo + half], A[lo]); }
+    __syncthreads();
+  }
+  for (size_t i = tid; i < n; i += nt) {
+    size_t j = __brev((unsigned)i) >> (32 - nv);
+    u64 v = gl_mul(A[i], pow7[j << (L - nv)]);
+    ((ulonglong2*)tmp)[i] = make_ulonglong2(v, v);
+  }
+}
+// DIT stages 1..smax (butterfly span <= 2^MED_NTT_LG) of the 2n-point NTT, one LDS-resident block per workgroup
+__global__ void __launch_bounds__(1024) k_med_ntt_local(const SmallCommitDesc* d, unsigned lgblk, unsigned smax, const u64* tw, unsigned L) {
+  extern __shared__ __align__(16) unsigned char lds_med[];
+  u64* B = (u64*)lds_med;
+  size_t blk = size_t(1) << lgblk;
+  u64* p = (u64*)d[blockIdx.y].tmp + blockIdx.x * blk;
+  int tid = threadIdx.x, nt = blockDim.x;
+  for (size_t i = tid; i < blk; i += nt) B[i] = p[i];
+  __syncthreads();
+  for (unsigned s = 1; s <= smax; s++) {
+    size_t half = size_t(1) << s;
+    for (size_t b = tid; b < blk / 2; b += nt) {
+      size_t j = b & (half - 1), lo = ((b >> s) << (s + 1)) | j;
+      u64 t = gl_mul(B[lo + half], tw[j << (L - s)]), u = B[lo];
+      B[lo] = gl_add(u, t); B[lo + half] = gl_sub(u, t);
+    }
+    __syncthreads();
+  }
+  for (size_t i = tid; i < blk; i += nt) p[i] = B[i];
+}
+__global__ void k_ntt_stage_many(const SmallCommitDesc* d, size_t N, unsigned lg_half, const u64* tw, unsigned L) {
+  u64* p = (u64*)d[blockIdx.y].tmp;
+  size_t half = size_t(1) << lg_half;
+  for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < N / 2; b += (size_t)gridDim.x * blockDim.x) {
+    size_t j = b & (half - 1), lo = ((b >> lg_half) << (lg_half + 1)) | j;
+    u64 t = gl_mul(p[lo + half], tw[j << (L - lg_half)]), u = p[lo];
+    p[lo] = gl_add(u, t); p[lo + half] = gl_sub(u, t);
+  }
+}
+__global__ void k_bitrev_many(const SmallCommitDesc* d, unsigned lg) {
+  const u64* src = (const u64*)d[blockIdx.y].tmp; u64* dst = (u64*)d[blockIdx.y].cw;
+  size_t n = size_t(1) << lg;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[__brevll((unsigned long long)i) >> (64 - lg)] = src[i];
+}
+// one Merkle layer of many equally shaped trees (one Poseidon2 compress per lane): blockIdx.y = tree
+__global__ void k_merkle_layer_many(const TailDesc* td, size_t off, size_t cnt) {
+  u64* nd = td[blockIdx.y].nodes;
+  const u64* in = nd + 4 * off; u64* out = nd + 4 * (off + cnt);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cnt / 2; i += (size_t)gridDim.x * blockDim.x) {
+    const ulonglong2* p = (const ulonglong2*)(in + 8 * i);
+    ulonglong2 x01 = p[0], x23 = p[1], y01 = p[2], y23 = p[3];
+    u64 x[4] = {x01.x, x01.y, x23.x, x23.y}, y[4] = {y01.x, y01.y, y23.x, y23.y}, o[4];
+    poseidon2_compress(x, y, o, c_rc);
+    ulonglong2* q = (ulonglong2*)(out + 4 * i);
+    q[0] = make_ulonglong2(o[0], o[1]); q[1] = make_ulonglong2(o[2], o[3]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ single-launch sumcheck round
@@ -1295,6 +1368,8 @@ class HipDev : public Dev {
     HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_small<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXCL_LDS));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXCL_LDS));
     HIP_CHECK(hipFuncSetAttribute((const void*)k_merkle_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXCL_LDS));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_med_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIP_CHECK(hipFuncSetAttribute((const void*)k_med_ntt_local, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   }
   ~HipDev() override {
     hipSetDevice(device_);
@@ -1766,6 +1841,49 @@ class HipDev : public Dev {
   }
   // Commit many polynomials at once (witness columns of one inference): equal-size groups share batched launches —
   // one LDS-resident Moebius+NTT workgroup per polynomial, one layer-0 launch, one fused Merkle-tail workgroup per tree.
+  // Medium base-field polynomials (2^12..2^14: the witness columns of a convolution) of equal size: Moebius in LDS, the
+  // NTT in LDS-resident blocks of 2^13 points plus at most two global stages, batched Merkle layers — a dozen launches for
+  // the whole group instead of ~45 per polynomial.
+  void commit_medium_group(const std::vector<DBuf>& evals, size_t first, std::vector<DevCommit>& out, std::vector<bool>& done, bool persistent) {
+    const DBuf& e0 = evals[first];
+    unsigned nv = dp_ceil_log2(e0.n);
+    size_t n = e0.n, N = 2 * n;
+    std::vector<size_t> grp;
+    for (size_t j = first; j < evals.size(); j++) if (!done[j] && evals[j].n == n && !evals[j].ext) grp.push_back(j);
+    size_t g = grp.size();
+    DP_REQUIRE(g * (sizeof(SmallCommitDesc) + sizeof(TailDesc)) + 256 <= DESC_BYTES && 4 * g <= RES_WORDS && g <= 65535, DP_ERR_SHAPE, "commit_many: group too large");
+    if (desc_off_ + g * (sizeof(SmallCommitDesc) + sizeof(TailDesc)) + 256 > DESC_BYTES) stream_wait();
+    auto A = [&](size_t m, bool e) { return persistent ? alloc_persistent(m, e) : alloc(m, e); };
+    const SmallCommitDesc* dd = nullptr; const TailDesc* tdd = nullptr;
+    SmallCommitDesc* hd = desc_alloc<SmallCommitDesc>(g, &dd);
+    TailDesc* td = desc_alloc<TailDesc>(g, &tdd);
+    std::vector<DBuf> cws(g), bhs(g), nodes(g);
+    for (size_t q = 0; q < g; q++) { cws[q] = A(N, false); bhs[q] = A(n, false); nodes[q] = A(4 * (N - 1), false); }
+    size_t mk = mark();
+    // layers above TAIL_MAX digests are hashed by batched launches; the tail kernel finishes each tree
+    size_t off = 0, cnt = N / 2;
+    std::vector<std::pair<size_t, size_t>> layers;
+    while (cnt > TAIL_MAX) { layers.push_back({off, cnt}); off += cnt; cnt /= 2; }
+    for (size_t q = 0; q < g; q++) {
+      DevCommit& c = out[grp[q]];
+      const DBuf& ev = evals[grp[q]];
+      c.nv = nv; c.is_base = true; c.evals = ev; c.bh_evals = bhs[q];
+      c.tree.leaves = cws[q]; c.tree.nleaves = N; c.tree.nodes = nodes[q];
+      DBuf tmp = alloc(N, false);
+      hd[q].evals = ev.p; hd[q].cw = cws[q].p; hd[q].bh = bhs[q].p; hd[q].nodes = (u64*)nodes[q].p; hd[q].tmp = tmp.p;
+      td[q].nodes = (u64*)nodes[q].p; td[q].off = off; td[q].cnt = cnt;
+    }
+    nb_ = g * 32.0 * n; DPL_LDS(k_med_prepare, dim3((unsigned)g), dim3(1024), n * 8, dd, nv, L_, (const u64*)pow7_);
+    unsigned lgblk = std::min<unsigned>(nv + 1, MED_NTT_LG), smax = std::min<unsigned>(nv, lgblk - 1);
+    nb_ = g * 32.0 * n; DPL_LDS(k_med_ntt_local, dim3((unsigned)(N >> lgblk), (unsigned)g), dim3(1024), (size_t(1) << lgblk) * 8, dd, lgblk, smax, (const u64*)tw_, L_);
+    for (unsigned st = smax + 1; st <= nv; st++) { nb_ = g * 32.0 * n; DPL(k_ntt_stage_many, dim3(grid_for(n, 64), (unsigned)g), dim3(TPB), dd, N, st, (const u64*)tw_, L_); }
+    nb_ = g * 32.0 * n; DPL(k_bitrev_many, dim3(grid_for(N, 64), (unsigned)g), dim3(TPB), dd, nv + 1);
+    nb_ = g * 24.0 * N; DPL(k_merkle_leaves_many<false>, dim3(grid_for(N / 2, 64), (unsigned)g), dim3(TPB), dd, N / 2);
+    for (auto& l : layers) { nb_ = g * 96.0 * (l.second / 2); DPL(k_merkle_layer_many, dim3(grid_for(l.second / 2, 64), (unsigned)g), dim3(TPB), tdd, l.first, l.second); }
+    tails_to_host(tdd, g);
+    for (size_t q = 0; q < g; q++) { for (int k = 0; k < 4; k++) out[grp[q]].tree.root.v[k] = hres_[4 * q + k]; done[grp[q]] = true; }
+    release(mk);
+  }
   std::vector<DevCommit> commit_many(const std::vector<DBuf>& evals, bool persistent) override {
     std::vector<DevCommit> out(evals.size());
     std::vector<bool> done(evals.size(), false);
@@ -1774,6 +1892,8 @@ class HipDev : public Dev {
       const DBuf& e0 = evals[i];
       unsigned nv = dp_ceil_log2(e0.n);
       bool small = (size_t(1) << nv) == e0.n && nv >= 1 && (nv <= 7 || (tw_ && nv <= L_ && nv <= (e0.ext ? 10u : 11u)));
+      bool medium = !small && !e0.ext && (size_t(1) << nv) == e0.n && tw_ && nv <= L_ && nv >= 12 && nv <= 14;
+      if (medium) { commit_medium_group(evals, i, out, done, persistent); continue; }
       if (!small) { out[i] = commit(e0, persistent); done[i] = true; continue; }
       std::vector<size_t> grp;
       for (size_t j = i; j < evals.size(); j++) if (!done[j] && evals[j].n == e0.n && evals[j].ext == e0.ext) grp.push_back(j);
@@ -1794,7 +1914,7 @@ class HipDev : public Dev {
         c.bh_evals = trivial ? ev : A(n, ev.ext);
         DBuf nodes = A(4 * (nleaves - 1), false);
         c.tree.leaves = cw; c.tree.nleaves = nleaves; c.tree.nodes = nodes;
-        hd[q].evals = ev.p; hd[q].cw = cw.p; hd[q].bh = c.bh_evals.p; hd[q].nodes = (u64*)nodes.p;
+        hd[q].evals = ev.p; hd[q].cw = cw.p; hd[q].bh = c.bh_evals.p; hd[q].nodes = (u64*)nodes.p; hd[q].tmp = nullptr;
         td[q].nodes = (u64*)nodes.p; td[q].off = 0; td[q].cnt = nleaves / 2;
       }
       size_t mk = mark();
