@@ -37,6 +37,10 @@ SIGNATURES = {
     "dp_mle_fix_high": (C.c_int32, [vp, vp, C.c_size_t, C.c_size_t, u64p, C.POINTER(vp)]),
     "dp_sumcheck_prove": (C.c_int32, [vp, C.c_uint32, C.POINTER(vp), C.c_int32, i32p, i32p, u64p, C.c_int32, vp,
                                       C.POINTER(u64p), C.POINTER(C.c_size_t), u64p]),
+    "dp_sc_session_new": (C.c_int32, [vp, C.c_uint32, C.POINTER(vp), C.c_int32, i32p, i32p, C.c_int32, C.POINTER(vp)]),
+    "dp_sc_session_round": (C.c_int32, [vp, u64p, u64p, C.POINTER(C.c_size_t)]),
+    "dp_sc_session_finish": (C.c_int32, [vp, u64p, u64p]),
+    "dp_sc_session_free": (C.c_int32, [vp]),
     "dp_logup_prove": (C.c_int32, [vp, C.POINTER(vp), C.c_int32, C.c_int32, vp, u64p, u64p, vp, C.POINTER(u64p),
                                    C.POINTER(C.c_size_t)]),
     "dp_pcs_setup": (C.c_int32, [vp, C.c_size_t]),

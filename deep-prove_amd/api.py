@@ -76,6 +76,14 @@ class Transcript:
     def append_message(self, msg: bytes):
         check(self._lib.dp_transcript_append_message(self.h, msg, len(msg)))
 
+    def append_usize(self, v: int):
+        """append_message(&v.to_le_bytes()) — how the provers absorb num_vars / max_degree (sumcheck/src/prover.rs:507-511)"""
+        self.append_message(int(v).to_bytes(8, "little"))
+
+    def append_exts(self, exts):
+        """extension elements (c0, c1) absorbed as two base elements each"""
+        self.append_field_elements(np.array([w for e in exts for w in e], dtype=np.uint64))
+
     def get_and_append_challenge(self, label: bytes):
         out = (C.c_uint64 * 2)()
         check(self._lib.dp_transcript_challenge(self.h, label, out))

@@ -131,6 +131,50 @@ int32_t dp_sumcheck_prove(dp_ctx* ctx, uint32_t nv, const dp_buf* const* tables,
   });
 }
 
+// ---- round-level sumcheck (the unit a sharded prover exchanges between devices, sumcheck/src/prover.rs:37-321)
+struct dp_sc_session { dp_ctx* ctx; std::vector<DBuf> tabs; std::vector<ScTerm> terms; size_t nraw; size_t mark; bool first; size_t len; };
+int32_t dp_sc_session_new(dp_ctx* ctx, uint32_t nv, const dp_buf* const* tables, int32_t ntables, const int32_t* term_degree,
+                          const int32_t* term_tables, int32_t nterms, dp_sc_session** out) {
+  return guard([&] {
+    DP_REQUIRE(ctx && tables && term_degree && term_tables && out && ntables > 0 && nterms > 0 && nv > 0, DP_ERR_ARG, "bad arguments");
+    std::unique_ptr<dp_sc_session> s(new dp_sc_session());
+    s->ctx = ctx; s->nraw = 0; s->first = true; s->len = size_t(1) << nv;
+    for (int i = 0; i < ntables; i++) { DP_REQUIRE(tables[i] && tables[i]->b.n == s->len, DP_ERR_SHAPE, "table length != 2^num_vars"); s->tabs.push_back(tables[i]->b); }
+    for (int i = 0; i < nterms; i++) {
+      int k = term_degree[i];
+      DP_REQUIRE(k >= 1 && k <= 3, DP_ERR_SHAPE, "term degree must be 1..3");
+      ScTerm st; st.k = k; for (int q = 0; q < SC_MAXK; q++) st.t[q] = 0;
+      for (int j = 0; j < k; j++) { int ti = term_tables[3 * i + j]; DP_REQUIRE(ti >= 0 && ti < ntables, DP_ERR_ARG, "term table index"); st.t[j] = ti; }
+      s->terms.push_back(st); s->nraw += k + 1;
+    }
+    s->mark = ctx->dev->mark();
+    *out = s.release();
+  });
+}
+/* fold every table with r_prev (NULL in the first round), then the raw per-term sums: (degree_i + 1) extension values per
+ * term, terms back to back (2 words each). Fails once the tables are down to one element: call dp_sc_session_finish. */
+int32_t dp_sc_session_round(dp_sc_session* s, const uint64_t* r_prev, uint64_t* raw_out, size_t* nraw_ext) {
+  return guard([&] {
+    DP_REQUIRE(s && raw_out && (s->first ? r_prev == nullptr : r_prev != nullptr), DP_ERR_ARG, "bad arguments");
+    Ext r = ex_zero(); if (r_prev) r = read_point(r_prev, 1)[0];
+    std::vector<Ext> raw(s->nraw);
+    s->ctx->dev->sc_round(s->tabs.data(), (int)s->tabs.size(), r_prev ? &r : nullptr, s->terms.data(), (int)s->terms.size(), raw.data());
+    s->first = false;
+    for (size_t i = 0; i < raw.size(); i++) { raw_out[2 * i] = raw[i].c0; raw_out[2 * i + 1] = raw[i].c1; }
+    if (nraw_ext) *nraw_ext = raw.size();
+  });
+}
+/* the last fold: one value per table (get_mle_final_evaluations order); ends the session's device work */
+int32_t dp_sc_session_finish(dp_sc_session* s, const uint64_t r_last[2], uint64_t* finals) {
+  return guard([&] {
+    DP_REQUIRE(s && r_last && finals && !s->first, DP_ERR_ARG, "bad arguments");
+    std::vector<Ext> f(s->tabs.size());
+    s->ctx->dev->sc_finish(s->tabs.data(), (int)s->tabs.size(), read_point(r_last, 1)[0], f.data());
+    for (size_t i = 0; i < f.size(); i++) { finals[2 * i] = f[i].c0; finals[2 * i + 1] = f[i].c1; }
+  });
+}
+int32_t dp_sc_session_free(dp_sc_session* s) { return guard([&] { if (s) { s->ctx->dev->release(s->mark); delete s; } }); }
+
 int32_t dp_logup_prove(dp_ctx* ctx, const dp_buf* const* columns, int32_t ncols, int32_t cpi, const dp_buf* mult,
                        const uint64_t cc[2], const uint64_t csc[2], dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords) {
   return guard([&] {

@@ -84,6 +84,20 @@ int32_t dp_sumcheck_prove(dp_ctx* ctx, uint32_t num_vars, const dp_buf* const* t
                           int32_t nterms, dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords,
                           uint64_t* finals);
 
+/* ---- round-level sumcheck: what a sharded prover exchanges between devices. The reference's thread-sharded
+ * IOPProverState::prove_batch_polys (sumcheck/src/prover.rs:37-321) gives every worker a contiguous 1/2^k chunk of each
+ * table, sums the workers' round evaluations and broadcasts one challenge; a session is one worker's side of it: the raw
+ * per-term sums of its chunk per round (the caller adds the shares, applies coefficients / extrapolation and runs the
+ * transcript), then one folded value per table. Tables and term layout as in dp_sumcheck_prove. One session at a time
+ * per dp_ctx; the session borrows the ctx's arena until dp_sc_session_free. */
+typedef struct dp_sc_session dp_sc_session;
+int32_t dp_sc_session_new(dp_ctx* ctx, uint32_t num_vars, const dp_buf* const* tables, int32_t ntables,
+                          const int32_t* term_degree, const int32_t* term_tables, int32_t nterms, dp_sc_session** out);
+/* r_prev == NULL in the first round. raw_out: (degree_i + 1) extension values per term, terms back to back */
+int32_t dp_sc_session_round(dp_sc_session* s, const uint64_t* r_prev, uint64_t* raw_out, size_t* nraw_ext);
+int32_t dp_sc_session_finish(dp_sc_session* s, const uint64_t r_last[2], uint64_t* finals);
+int32_t dp_sc_session_free(dp_sc_session* s);
+
 /* ---- logup-GKR: logup_gkr::prover::batch_prove(LogUpInput, transcript) (zkml/src/lookup/logup_gkr/prover.rs:24-198).
  * multiplicities == NULL -> LogUpInput::Lookup with `cols_per_instance`; else LogUpInput::Table. */
 int32_t dp_logup_prove(dp_ctx* ctx, const dp_buf* const* columns, int32_t ncols, int32_t cols_per_instance,

@@ -61,3 +61,70 @@ def test_shard_is_round_robin_partition():
         parts = [bench.shard(64, world, r) for r in range(world)]
         assert sorted(v for p in parts for v in p) == list(range(64))
         assert all(len(p) == 64 // world for p in parts)
+
+
+# ---------------------------------------------------------------------------------------------- sharded sumcheck
+def _sharded_case(nv=7, seed=5):
+    """k = 3 base tables and a second term, like the standalone sumcheck bench plus a mixed-degree term"""
+    import numpy as np
+    P = 0xFFFFFFFF00000001
+    rng = np.random.default_rng(seed)
+    tabs = [rng.integers(0, P, size=1 << nv, dtype=np.uint64) for _ in range(3)]
+    terms = [((1, 0), [0, 1, 2]), ((5, 7), [1, 2])]
+    return tabs, terms
+
+
+def _prove_sharded_py(tabs, terms, nv, world, rank_or_none, exchange):
+    """drive deep_prove_amd.sharded.prove_sharded with the pure-Python shard backend"""
+    import deep_prove_amd as dpa
+    from support.py_shard import PyShard, words_to_exts
+    chunk = (1 << nv) // world
+    ranks = range(world) if rank_or_none is None else [rank_or_none]
+    shards = [PyShard([[(int(v), 0) for v in t[g * chunk:(g + 1) * chunk]] for t in tabs], terms) for g in ranks]
+    return dpa.sharded.prove_sharded(shards, exchange, nv, terms, dpa.Transcript(b"test"),
+                                     lambda tw: PyShard([words_to_exts(w) for w in tw], terms))
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_sharded_sumcheck_is_bit_identical_to_the_unsharded_oracle_proof(oracle, world):
+    """W workers own contiguous slices (top variables select the worker); shares are added mod p; the last
+    log2(W) rounds run on the merged W-entry tables. The proof stream must equal the oracle's prove_parallel."""
+    import deep_prove_amd as dpa
+    nv = 7
+    tabs, terms = _sharded_case(nv)
+    proof, finals = _prove_sharded_py(tabs, terms, nv, world, None, dpa.sharded.LocalExchange(world))
+    oproof, ofinals = oracle.sumcheck_prove(nv, tabs, [False] * 3, terms, oracle.transcript(b"test"))
+    assert proof.size == oproof.size and (proof == oproof).all()
+    assert (finals == ofinals).all()
+
+
+def _gloo_shard_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import deep_prove_amd as dpa
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    nv = 7
+    tabs, terms = _sharded_case(nv)
+    proof, finals = _prove_sharded_py(tabs, terms, nv, world, rank, dpa.sharded.TorchExchange())
+    q.put((rank, proof.tolist(), finals.tolist()))
+    dist.destroy_process_group()
+
+
+def test_sharded_sumcheck_over_gloo_world_size_2(oracle):
+    """two processes, one shard each, shares all-gathered with torch.distributed (gloo here, RCCL on the GPUs)"""
+    import multiprocessing as mp
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_gloo_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    tabs, terms = _sharded_case(7)
+    oproof, ofinals = oracle.sumcheck_prove(7, tabs, [False] * 3, terms, oracle.transcript(b"test"))
+    for rank, proof, finals in res:
+        assert proof == oproof.tolist() and finals == ofinals.tolist(), f"rank {rank} differs"
