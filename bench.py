@@ -127,10 +127,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sumcheck24", action="store_true", help="skip the standalone 2^24 sumcheck roofline section")
     ap.add_argument("--no-cnn", action="store_true", help="skip the CNN-264k section of a Dense-4M run")
-    ap.add_argument("--concurrency", type=int, default=0, help="independent proofs in flight per GPU (0 = 32)")
+    ap.add_argument("--concurrency", type=int, default=0, help="independent proofs in flight per GPU (0 = 24)")
     args = ap.parse_args()
 
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "64")  # hardware queues for the in-flight proof streams
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # one hardware queue per in-flight proof stream, as many as the GPU serves without time slicing
     import torch
     import numpy as np  # noqa: F401
     import deep_prove_amd as dpa
@@ -155,7 +155,7 @@ def main():
     budget = dpa.api.host_cpu_budget()
     host_threads = max(1, int(budget / max(1, local_world)) - 2)
     os.environ.setdefault("DP_HOST_THREADS", str(host_threads))
-    conc = args.concurrency if args.concurrency > 0 else 32
+    conc = args.concurrency if args.concurrency > 0 else 24
 
     dev = dpa.Device(local_rank)
     main_w = measure_workload(dpa, dev, args.workload, conc, args.steps, args.warmup, world, rank, dist, torch)

@@ -3,6 +3,13 @@ CPU fallback for any device op — a missing .so or a missing HIP device raises.
 import ctypes as C
 import os
 
+# Every proof in flight (and every shard of a sharded sumcheck) owns a HIP stream whose persistent kernels wait for the
+# host: two such streams must never share a hardware queue (the second one's kernels would queue behind a kernel that waits
+# for a challenge the host only sends after the second stream made progress). ROCm multiplexes streams onto
+# GPU_MAX_HW_QUEUES queues (default 4), read when the HIP runtime initialises — so it has to be set before the first HIP
+# call of the process. 24 is the most an MI355X serves without time-slicing the queues (tools/queue_oversub.hip).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdeepprove_hip.so")
 
