@@ -99,6 +99,9 @@ class Dev {
     eq_table(out.slice(0, n), pt, k, ex_one(), false);
     for (size_t o = n; o < out.n; o += n) copy(out.slice(o, n), out.slice(0, n));
   }
+  // eq table that is only ever read by the sumcheck started next (the per-layer eq of logup-GKR): a device may build it
+  // inside that sumcheck's kernel instead of spending a launch on it
+  virtual void eq_table_lazy(const DBuf& out, const Ext* pt, unsigned k) { eq_table(out, pt, k, ex_one(), false); }
   // K1 chain collapsed to one pass: out[i] = sum_x fs[i](x) * eq(x, pt)
   virtual void mle_eval_batch(const DBuf* fs, int nf, const Ext* pt, unsigned k, Ext* out) = 0;
   // K2 in one pass: out[c] = sum_r eq(r, pt) * W[r*C + c]      (W base field, R = 2^k rows)

@@ -888,7 +888,19 @@ struct ScPersistArgs {
   int k[MAX_TERMS]; int t[MAX_TERMS][SC_MAXK]; int off[MAX_TERMS];
   int ntabs, nterms, has_r0; size_t n0; Ext r0;
   unsigned long long* dbg;  // optional: per-phase cycle counters (DP_SC_DEBUG=1)
+  int eq_tab, eq_k;         // eq_tab >= 0: table eq_tab (an extension buffer in global memory) is eq(., eq_pt) and is built here first
+  Ext eq_pt[MAX_PT];
 };
+// out[i] = prod_t (i_t ? pt[t] : 1 - pt[t]) for i < 2^k, by the whole workgroup (ends with a barrier)
+__device__ __forceinline__ void wg_build_eq(Ext* out, const Ext* pt, int k) {
+  size_t n = size_t(1) << k;
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+    Ext v = ex_one();
+    for (int t = 0; t < k; t++) { Ext r = pt[t]; v = ex_mul(v, ((i >> t) & 1) ? r : ex_sub(ex_one(), r)); }
+    out[i] = v;
+  }
+  __syncthreads();
+}
 __device__ __forceinline__ void sc_fold_all(const ScPersistArgs& a, const void* const* cur, const int* cur_ext, Ext* const* dst, size_t n_after, Ext r) {
   int tid = threadIdx.x, nt = blockDim.x;
   for (int t = 0; t < a.ntabs; t++) {
@@ -908,6 +920,7 @@ __global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* resul
   __shared__ Ext* dstB[MAX_TABS];
   int tid = threadIdx.x, nt = blockDim.x;
   int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
+  if (a.eq_tab >= 0) wg_build_eq((Ext*)a.in[a.eq_tab], a.eq_pt, a.eq_k);
   if (tid < a.ntabs) { cur[tid] = a.in[tid]; cur_ext[tid] = a.in_ext[tid]; dstA[tid] = a.bufA[tid]; dstB[tid] = a.bufB[tid]; }
   __syncthreads();
   size_t n = a.n0;
@@ -1025,6 +1038,7 @@ __global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* r
   int tid = threadIdx.x, nt = blockDim.x;
   int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
   int wpt = a.nterms >= W ? 1 : W / a.nterms;
+  if (a.eq_tab >= 0) wg_build_eq((Ext*)a.in[a.eq_tab], a.eq_pt, a.eq_k);
   unsigned long long seq = seq0;
   size_t first = a.n0 / 2;
   unsigned lgf = 0; while ((size_t(1) << lgf) < first) lgf++;
@@ -1488,11 +1502,28 @@ class HipDev : public Dev {
     DP_REQUIRE(out.ext && out.n == (size_t(1) << k), DP_ERR_SHAPE, "eq_table: output shape");
     nb_ = 16.0 * out.n * (acc ? 2 : 1); DPL(k_eq_table, dim3(grid_for(out.n)), dim3(TPB), (Ext*)out.p, make_point(pt, k), k, scale, acc ? 1 : 0, out.n);
   }
+  // ---- lazy eq: remembered here, built inside the persistent sumcheck kernel that consumes it (or materialised by a
+  // plain launch if the next sumcheck takes another path)
+  struct PendingEq { void* p = nullptr; unsigned k = 0; Ext pt[MAX_PT]; } pend_eq_;
+  void eq_table_lazy(const DBuf& out, const Ext* pt, unsigned k) override {
+    DP_REQUIRE(out.ext && out.n == (size_t(1) << k) && k <= (unsigned)MAX_PT, DP_ERR_SHAPE, "eq_table: output shape");
+    flush_pending_eq();
+    if (!persist_) { eq_table(out, pt, k, ex_one(), false); return; }
+    pend_eq_.p = out.p; pend_eq_.k = k;
+    for (unsigned i = 0; i < k; i++) pend_eq_.pt[i] = pt[i];
+  }
+  void flush_pending_eq() {
+    if (!pend_eq_.p) return;
+    DBuf b; b.p = pend_eq_.p; b.n = size_t(1) << pend_eq_.k; b.ext = true;
+    pend_eq_.p = nullptr;
+    eq_table(b, pend_eq_.pt, pend_eq_.k, ex_one(), false);
+  }
   void eq_table_tiled(const DBuf& out, const Ext* pt, unsigned k) override {
     DP_REQUIRE(out.ext && out.n % (size_t(1) << k) == 0, DP_ERR_SHAPE, "eq_table_tiled: output shape");
     nb_ = 16.0 * out.n; DPL(k_eq_table, dim3(grid_for(out.n)), dim3(TPB), (Ext*)out.p, make_point(pt, k), k, ex_one(), 0, out.n);
   }
   void mle_eval_batch(const DBuf* fs, int nf, const Ext* pt, unsigned k, Ext* out) override {
+    flush_pending_eq();
     size_t n = size_t(1) << k;
     PointArg p = make_point(pt, k);
     for (int s = 0; s < nf; s += 8) {
@@ -1577,8 +1608,16 @@ class HipDev : public Dev {
       read_terms();
       return;
     }
+    const bool take_persistent = !sess_.active && persist_ && n_after <= SC_PERSIST_MAX && n_after >= 4 && 2 * nraw <= RES_WORDS;
+    if (pend_eq_.p && !(take_persistent && !r)) flush_pending_eq();
     if (persist_ && n_after <= SC_PERSIST_MAX && n_after >= 4 && 2 * nraw <= RES_WORDS) {
       ScPersistArgs a;
+      a.eq_tab = -1; a.eq_k = 0;
+      if (pend_eq_.p) {
+        for (int i = 0; i < nt; i++) if (tabs[i].p == pend_eq_.p && tabs[i].n == (size_t(1) << pend_eq_.k)) a.eq_tab = i;
+        if (a.eq_tab >= 0) { a.eq_k = (int)pend_eq_.k; for (unsigned i = 0; i < pend_eq_.k; i++) a.eq_pt[i] = pend_eq_.pt[i]; pend_eq_.p = nullptr; }
+        else flush_pending_eq();
+      }
       for (int i = 0; i < MAX_TABS; i++) { a.in[i] = nullptr; a.in_ext[i] = 0; a.bufA[i] = nullptr; a.bufB[i] = nullptr; }
       fill_terms(a.k, a.t, a.off);
       sess_.a.assign(nt, nullptr); sess_.b.assign(nt, nullptr);
@@ -1676,6 +1715,7 @@ class HipDev : public Dev {
   }
   void sc_finish(DBuf* tabs, int nt, Ext r, Ext* finals) override {
     DP_REQUIRE(nt <= MAX_TABS, DP_ERR_SHAPE, "sumcheck: too many tables");
+    flush_pending_eq();
     if (sess_.active) {
       DP_REQUIRE(nt == sess_.ntabs && sess_.n == 2, DP_ERR_ARG, "sumcheck session out of sync at finish");
       post_challenge(r);
@@ -1776,7 +1816,10 @@ class HipDev : public Dev {
     nb_ = 0; DPL_LDS(k_merkle_tail, dim3((unsigned)nd), dim3(1024), excl_, dd, dres_, (u64*)nullptr, (unsigned long long*)nullptr, 0ull);
     fetch(4 * nd);
   }
-  static constexpr size_t TAIL_MAX = 1024;   // layers of at most this many digests are finished by k_merkle_tail
+  // layers of at most this many digests are finished by k_merkle_tail (one workgroup, no relaunch between layers); wider
+  // layers get their own multi-workgroup launch: a 512-parent layer is 4 sequential passes inside the tail workgroup but one
+  // pass spread over 16 CUs as a launch (DP_TAIL_MAX overrides)
+  size_t TAIL_MAX = getenv("DP_TAIL_MAX") ? strtoull(getenv("DP_TAIL_MAX"), nullptr, 10) : 256;
   // Layers with at most lp_max_ parent nodes use the 8-lanes-per-node kernel (lowest latency per layer, but ~2.2x the
   // VALU work of one node per lane and a grid 8x as large: with many proofs in flight those grids fill the chip and
   // every other stream queues behind them), wider layers hash one node per lane. DP_MERKLE_LP_MAX overrides.

@@ -50,7 +50,7 @@ inline LogUpProof logup_batch_prove(Dev& dev, const LogUpInputDev& in, Transcrip
     size_t mk2 = dev.mark();
     size_t half = size_t(1) << lv;
     DBuf eq = dev.alloc(half, true);
-    dev.eq_table(eq, point.data(), lv, ex_one(), false);
+    dev.eq_table_lazy(eq, point.data(), lv);
     DevVP vp(lv);
     Ext cur_alpha = ex_one();
     for (auto& c : circuits) {

@@ -16,17 +16,29 @@ __global__ void spin(const ull* mailbox) {
   for (unsigned s = 0; s < (1u << 30); s++) { if (__hip_atomic_load(mailbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 1) break; __builtin_amdgcn_s_sleep(4); }
 }
 __global__ void stream_rw(ull* p, size_t n) { for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = p[i] * 3 + 1; }
+// same traffic, but the stores are non-temporal (bg=3) / write-through at system scope (bg=4): no dirty lines stay in the L2s
+__global__ void stream_rw_nt(ull* p, size_t n) { for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) __builtin_nontemporal_store(__builtin_nontemporal_load(p + i) * 3 + 1, p + i); }
+__global__ void stream_rw_sc(ull* p, size_t n) { for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) __hip_atomic_store(p + i, p[i] * 3 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// read-only background (bg=5)
+__global__ void stream_ro(ull* p, size_t n, ull* out) { ull a = 0; for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a += p[i]; if (a == 12345) *out = a; }
 int main() {
   int iters = 3000;
-  for (int bg : {0, 1, 2}) for (int n : {1, 4, 16}) {
+  for (int bg : {0, 2, 3, 4, 5}) for (int n : {1, 16}) {
     std::vector<double> res(n);
     std::vector<std::thread> th;
     std::atomic<int> ready(0); std::atomic<int> done(0);
     std::thread bgth;
-    if (bg == 2) bgth = std::thread([&] {
+    if (bg >= 2) bgth = std::thread([&] {
       hipSetDevice(0); hipStream_t s; hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
       ull* p; hipMalloc(&p, 256u << 20);
-      while (done.load() < n) { hipLaunchKernelGGL(stream_rw, dim3(4096), dim3(256), 0, s, p, (size_t)(256u << 20) / 8); hipStreamSynchronize(s); }
+      size_t cnt = (size_t)(256u << 20) / 8;
+      while (done.load() < n) {
+        if (bg == 2) hipLaunchKernelGGL(stream_rw, dim3(4096), dim3(256), 0, s, p, cnt);
+        else if (bg == 3) hipLaunchKernelGGL(stream_rw_nt, dim3(4096), dim3(256), 0, s, p, cnt);
+        else if (bg == 4) hipLaunchKernelGGL(stream_rw_sc, dim3(4096), dim3(256), 0, s, p, cnt);
+        else hipLaunchKernelGGL(stream_ro, dim3(4096), dim3(256), 0, s, p, cnt, p);
+        hipStreamSynchronize(s);
+      }
       hipFree(p); hipStreamDestroy(s);
     });
     for (int t = 0; t < n; t++) th.emplace_back([&, t] {
@@ -45,7 +57,7 @@ int main() {
       hipHostFree(h); hipStreamDestroy(s); hipStreamDestroy(s2);
     });
     for (auto& x : th) x.join();
-    if (bg == 2) bgth.join();
+    if (bg >= 2) bgth.join();
     double avg = 0, mx = 0; for (double v : res) { avg += v / n; mx = v > mx ? v : mx; }
     printf("bg=%d threads=%2d : %.2f us per launch+post round trip (avg), %.2f max\n", bg, n, avg, mx); fflush(stdout);
   }
