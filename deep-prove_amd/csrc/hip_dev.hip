@@ -890,6 +890,10 @@ struct ScPersistArgs {
   unsigned long long* dbg;  // optional: per-phase cycle counters (DP_SC_DEBUG=1)
   int eq_tab, eq_k;         // eq_tab >= 0: table eq_tab (an extension buffer in global memory) is eq(., eq_pt) and is built here first
   Ext eq_pt[MAX_PT];
+  // multi-workgroup phase (k_sc_persist only): workgroup g of nwg owns the contiguous slice [g n0/nwg, (g+1) n0/nwg) of
+  // every table, publishes the sums of its slice into result slot g (slot_ext extension values apart, flag word g) and
+  // leaves after `rounds_a` folds; the host adds the shares. nwg = 1, rounds_a = 0: the whole sumcheck in one workgroup.
+  int nwg, rounds_a, slot_ext;
 };
 // out[i] = prod_t (i_t ? pt[t] : 1 - pt[t]) for i < 2^k, by the whole workgroup (ends with a barrier)
 __device__ __forceinline__ void wg_build_eq(Ext* out, const Ext* pt, int k) {
@@ -901,10 +905,10 @@ __device__ __forceinline__ void wg_build_eq(Ext* out, const Ext* pt, int k) {
   }
   __syncthreads();
 }
-__device__ __forceinline__ void sc_fold_all(const ScPersistArgs& a, const void* const* cur, const int* cur_ext, Ext* const* dst, size_t n_after, Ext r) {
+__device__ __forceinline__ void sc_fold_all(const ScPersistArgs& a, const void* const* cur, const int* cur_ext, Ext* const* dst, size_t n_after, Ext r, size_t dst_off = 0) {
   int tid = threadIdx.x, nt = blockDim.x;
   for (int t = 0; t < a.ntabs; t++) {
-    Ext* o = dst[t];
+    Ext* o = dst[t] + dst_off;
     if (cur_ext[t]) { const Ext* p = (const Ext*)cur[t]; for (size_t i = tid; i < n_after; i += nt) o[i] = ex_lerp(p[2 * i], p[2 * i + 1], r); }
     else { const u64* p = (const u64*)cur[t]; for (size_t i = tid; i < n_after; i += nt) o[i] = ex_lerp_base(p[2 * i], p[2 * i + 1], r); }
   }
@@ -921,9 +925,13 @@ __global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* resul
   int tid = threadIdx.x, nt = blockDim.x;
   int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
   if (a.eq_tab >= 0) wg_build_eq((Ext*)a.in[a.eq_tab], a.eq_pt, a.eq_k);
-  if (tid < a.ntabs) { cur[tid] = a.in[tid]; cur_ext[tid] = a.in_ext[tid]; dstA[tid] = a.bufA[tid]; dstB[tid] = a.bufB[tid]; }
+  const size_t g = blockIdx.x;
+  size_t n = a.n0 / (size_t)a.nwg;  // local slice length
+  if (tid < a.ntabs) { cur[tid] = (const char*)a.in[tid] + g * n * (a.in_ext[tid] ? 16 : 8); cur_ext[tid] = a.in_ext[tid]; dstA[tid] = a.bufA[tid]; dstB[tid] = a.bufB[tid]; }
+  result += g * (size_t)a.slot_ext; flag += g;
+  int folds = 0;
+  size_t lvl_off = 0;
   __syncthreads();
-  size_t n = a.n0;
   unsigned long long seq = seq0;
   bool useA = true;
   if (a.has_r0) {
@@ -958,12 +966,19 @@ __global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* resul
       return;
     }
     Ext r = ex(chal[1], chal[2]);
-    Ext* const* dst = useA ? dstA : dstB;
-    sc_fold_all(a, cur, cur_ext, dst, n / 2, r);
+    // One workgroup: ping-pong between bufA and bufB. Several workgroups: the folded slice goes to its place in the compact
+    // folded table of this level, and every level has its own region of bufA (level 1 at 0, level 2 behind it, ..): the
+    // workgroups sit on different XCDs whose L2s are not coherent with each other, so no address may be written by two
+    // workgroups during the life of the kernel (a stale dirty line of an old level could be written back over a new one).
+    Ext* const* dst = (a.nwg > 1 || useA) ? dstA : dstB;
+    size_t off = a.nwg > 1 ? lvl_off + g * (n / 2) : 0;
+    sc_fold_all(a, cur, cur_ext, dst, n / 2, r, off);
     __syncthreads();
-    if (tid < a.ntabs) { cur[tid] = dst[tid]; cur_ext[tid] = 1; }
+    if (tid < a.ntabs) { cur[tid] = dst[tid] + off; cur_ext[tid] = 1; }
     __syncthreads();
+    lvl_off += (size_t)a.nwg * (n / 2);
     n /= 2; useA = !useA;
+    if (++folds == a.rounds_a) return;  // end of the multi-workgroup phase: the compact folded tables are complete
     if (n == 1) {
       ++seq;
       if (wave == 0) {
@@ -1243,7 +1258,40 @@ class HipDev : public Dev {
   unsigned long long* scdbg_ = nullptr;  // DP_SC_DEBUG=1: device cycle counters of the persistent sumcheck kernel
   unsigned long long* hmail_ = nullptr;      // host view of the challenge mailbox [seq, c0, c1]
   unsigned long long* hmail_dev_ = nullptr;  // device view
-  struct ScSession { bool active = false; int ntabs = 0; size_t n = 0; unsigned long long seq = 0; std::vector<Ext*> a, b; bool nextA = true; } sess_;
+  struct ScSession { bool active = false; int ntabs = 0; size_t n = 0; unsigned long long seq = 0; std::vector<Ext*> a, b; bool nextA = true;
+                     bool multi = false; int G = 0, rounds_a = 0, folds = 0; size_t slot_words = 0, n0 = 0; } sess_;
+  static constexpr int MULTI_MAX_WG = 32;
+  static constexpr size_t MULTI_MIN_N = 4096, MULTI_MAX_N = size_t(1) << 18, MULTI_TARGET_N = 1024;
+  unsigned long long* hmflag_ = nullptr;      // host view of the per-workgroup flags
+  unsigned long long* hmflag_dev_ = nullptr;  // device view
+  unsigned long long last_tag_multi_[MULTI_MAX_WG];
+  bool multi_ = true;  // DP_NO_MULTI=1 disables the multi-workgroup phase of large sumchecks
+  static bool persist_flag_env(const char* name) { const char* e = getenv(name); return !(e && atoi(e)); }
+  // all G workgroups have published round `seq`: every slot's tag matches its payload (same protocol as wait_flag)
+  void wait_flags_multi(unsigned long long seq, size_t nwords, int G, size_t slot_words) {
+    auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    const unsigned long long base = pub_mix(seq);
+    nwait_++;
+    int done = 0;
+    while (done < G) {
+      volatile unsigned long long* f = hmflag_ + done;
+      unsigned long long tag = *f;
+      if (tag == ~0ull) throw DpError(DP_ERR_HIP, "device aborted a persistent sumcheck (no challenge received)");
+      if (tag != last_tag_multi_[done]) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        volatile u64* w = hres_ + (size_t)done * slot_words;
+        unsigned long long cs = 0;
+        for (size_t i = 0; i < nwords; i++) cs += (unsigned long long)(i + 1) * w[i];
+        if (base + cs == tag) { last_tag_multi_[done] = tag; done++; continue; }
+      }
+      const bool fib = fiber_active();
+      if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
+      if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
+        throw DpError(DP_ERR_HIP, "timeout waiting for the device");
+    }
+    desc_off_ = 0;
+  }
   u64* dres_ = nullptr;   // device result buffer
   void* hstage_ = nullptr;  // pinned + device-mapped staging: [0, DESC_BYTES) descriptor ring read by kernels over PCIe, rest = bulk copies
   char* hstage_dev_ = nullptr;
@@ -1358,13 +1406,16 @@ class HipDev : public Dev {
     const char* env = getenv("DP_ARENA_BYTES");
     arena_cap_ = arena_bytes ? arena_bytes : env ? strtoull(env, nullptr, 10) : (size_t(12) << 30);
     HIP_CHECK(hipMalloc((void**)&arena_, arena_cap_));
-    HIP_CHECK(hipHostMalloc((void**)&hres_, RES_WORDS * 8 + 256, hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_CHECK(hipHostMalloc((void**)&hres_, RES_WORDS * 8 + 1024, hipHostMallocMapped | hipHostMallocCoherent));
     HIP_CHECK(hipHostGetDevicePointer((void**)&hres_dev_, hres_, 0));
     hflag_ = (unsigned long long*)(hres_ + RES_WORDS);
     hflag_dev_ = (unsigned long long*)(hres_dev_ + RES_WORDS);
     *hflag_ = 0;
     hmail_ = hflag_ + 8; hmail_dev_ = hflag_dev_ + 8;
     hmail_[0] = hmail_[1] = hmail_[2] = 0;
+    hmflag_ = hflag_ + 32; hmflag_dev_ = hflag_dev_ + 32;  // one flag word per workgroup of a multi-workgroup sumcheck phase
+    for (int i = 0; i < MULTI_MAX_WG; i++) { hmflag_[i] = 0; last_tag_multi_[i] = 0; }
+    multi_ = persist_flag_env("DP_NO_MULTI");
     zerocopy_ = !(getenv("DP_NO_ZEROCOPY") && atoi(getenv("DP_NO_ZEROCOPY")));
     persist_ = zerocopy_ && !(getenv("DP_NO_PERSIST") && atoi(getenv("DP_NO_PERSIST")));
     if (getenv("DP_SC_DEBUG") && atoi(getenv("DP_SC_DEBUG"))) { HIP_CHECK(hipMalloc((void**)&scdbg_, 64)); HIP_CHECK(hipMemset(scdbg_, 0, 64)); }
@@ -1589,6 +1640,7 @@ class HipDev : public Dev {
     for (int i = 0; i < nt; i++) DP_REQUIRE(tabs[i].n == n_in, DP_ERR_SHAPE, "sumcheck: tables must have equal length");
     size_t n_after = r ? n_in / 2 : n_in;
     DP_REQUIRE(n_after >= 2, DP_ERR_SHAPE, "sumcheck: tables must keep length >= 2");
+    // (n_in and r are rewritten below when a multi-workgroup phase hands its folded tables to a single-workgroup session)
     size_t nraw = 0;  // a degree-k term contributes k + 1 values; single-workgroup kernels publish them packed
     for (int i = 0; i < nterms; i++) { DP_REQUIRE(terms[i].k >= 1 && terms[i].k <= SC_MAXK, DP_ERR_SHAPE, "sumcheck: term degree must be 1..5"); nraw += terms[i].k + 1; }
     bool hi = false; for (int i = 0; i < nterms; i++) hi = hi || terms[i].k > 3;
@@ -1598,6 +1650,29 @@ class HipDev : public Dev {
       int o = 0;
       for (int i = 0; i < nterms; i++) { tk[i] = terms[i].k; for (int j = 0; j < SC_MAXK; j++) tt[i][j] = j < terms[i].k ? terms[i].t[j] : 0; if (toff) toff[i] = o; o += terms[i].k + 1; }
     };
+    auto read_shares = [&](int G, size_t slot_words) {  // the round sums are the sums of the workgroups' shares
+      for (size_t o = 0; o < nraw; o++) {
+        Ext acc = ex_zero();
+        for (int g = 0; g < G; g++) { const u64* w = hres_ + (size_t)g * slot_words; acc = ex_add(acc, ex(w[2 * o], w[2 * o + 1])); }
+        out[o] = acc;
+      }
+    };
+    if (sess_.active && sess_.multi) {  // multi-workgroup phase: every workgroup folds its slice with this challenge
+      DP_REQUIRE(r && nt == sess_.ntabs && n_in == sess_.n, DP_ERR_ARG, "sumcheck session out of sync");
+      post_challenge(*r);
+      sess_.folds++;
+      const size_t lvl_off = sess_.n0 - (sess_.n0 >> (sess_.folds - 1));  // level j starts at n0 (1 - 2^-(j-1))
+      for (int i = 0; i < nt; i++) { tabs[i].p = sess_.a[i] + lvl_off; tabs[i].n = n_after; tabs[i].ext = true; }
+      sess_.n = n_after;
+      if (sess_.folds < sess_.rounds_a) {
+        wait_flags_multi(++sess_.seq, 2 * nraw, sess_.G, sess_.slot_words);
+        read_shares(sess_.G, sess_.slot_words);
+        return;
+      }
+      // the kernel leaves after this fold: the compact folded tables feed a single-workgroup session (stream ordered)
+      sess_.active = false; sess_.multi = false;
+      r = nullptr; n_in = n_after;
+    }
     if (sess_.active) {  // the persistent kernel is waiting for this challenge
       DP_REQUIRE(r && nt == sess_.ntabs && n_in == sess_.n, DP_ERR_ARG, "sumcheck session out of sync");
       post_challenge(*r);
@@ -1606,6 +1681,32 @@ class HipDev : public Dev {
       for (int i = 0; i < nt; i++) { tabs[i].p = sess_.nextA ? sess_.a[i] : sess_.b[i]; tabs[i].n = n_after; tabs[i].ext = true; }
       sess_.nextA = !sess_.nextA;
       read_terms();
+      return;
+    }
+    if (!r && multi_ && persist_ && n_in >= MULTI_MIN_N && n_in <= MULTI_MAX_N && nraw * 2 * MULTI_MAX_WG <= RES_WORDS) {
+      // ---- multi-workgroup phase: G workgroups own contiguous slices, fold until the tables are MULTI_TARGET_N long
+      flush_pending_eq();
+      int G = (int)std::min<size_t>(MULTI_MAX_WG, n_in / 512);
+      int rounds_a = (int)(dp_ceil_log2(n_in) - dp_ceil_log2(MULTI_TARGET_N));
+      ScPersistArgs a;
+      for (int i = 0; i < MAX_TABS; i++) { a.in[i] = nullptr; a.in_ext[i] = 0; a.bufA[i] = nullptr; a.bufB[i] = nullptr; }
+      fill_terms(a.k, a.t, a.off);
+      sess_.a.assign(nt, nullptr); sess_.b.assign(nt, nullptr);
+      double bytes = 0;
+      for (int i = 0; i < nt; i++) {
+        a.in[i] = tabs[i].p; a.in_ext[i] = tabs[i].ext;
+        sess_.a[i] = (Ext*)alloc(n_in, true).p; sess_.b[i] = nullptr;  // every fold level has its own region of this buffer
+        a.bufA[i] = sess_.a[i]; a.bufB[i] = nullptr;
+        bytes += tabs[i].bytes() + 3.0 * 16.0 * (n_in / 2);  // read once + the halving folded tables written and re-read
+      }
+      a.ntabs = nt; a.nterms = nterms; a.has_r0 = 0; a.n0 = n_in; a.r0 = ex_zero(); a.dbg = nullptr; a.eq_tab = -1; a.eq_k = 0;
+      a.nwg = G; a.rounds_a = rounds_a; a.slot_ext = (int)nraw;
+      sess_.active = true; sess_.multi = true; sess_.G = G; sess_.rounds_a = rounds_a; sess_.folds = 0; sess_.slot_words = 2 * nraw;
+      sess_.ntabs = nt; sess_.n = n_in; sess_.n0 = n_in; sess_.seq = seq_;
+      seq_ += (unsigned)rounds_a;  // one publication per round of the phase
+      nb_ = bytes; DPL_HI(k_sc_persist, hi, dim3(G), dim3(1024), a, (Ext*)hres_dev_, hmflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq);
+      wait_flags_multi(++sess_.seq, 2 * nraw, G, sess_.slot_words);
+      read_shares(G, sess_.slot_words);
       return;
     }
     const bool take_persistent = !sess_.active && persist_ && n_after <= SC_PERSIST_MAX && n_after >= 4 && 2 * nraw <= RES_WORDS;
@@ -1628,6 +1729,7 @@ class HipDev : public Dev {
         sess_.a[i] = (Ext*)alloc(first, true).p; sess_.b[i] = (Ext*)alloc(std::max<size_t>(first / 2, 1), true).p;
         a.bufA[i] = sess_.a[i]; a.bufB[i] = sess_.b[i];
       }
+      a.nwg = 1; a.rounds_a = 0; a.slot_ext = 0;
       a.ntabs = nt; a.nterms = nterms; a.has_r0 = r ? 1 : 0; a.n0 = n_in; a.r0 = r ? *r : ex_zero(); a.dbg = scdbg_;
       sess_.active = true; sess_.ntabs = nt; sess_.n = n_after; sess_.seq = seq_; sess_.nextA = r ? false : true;
       // reserve the sequence numbers of all rounds + the final message
