@@ -10,7 +10,7 @@
 #include <thread>
 
 DP_FIBER_SWITCH_ASM
-namespace dp { void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
+namespace dp { void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
 using namespace dp;
 
 struct dp_ctx { Dev* dev; int device_id; };
@@ -314,6 +314,9 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     const char* env = getenv("DP_WORKER_ARENA_BYTES");
     size_t arena = env ? strtoull(env, nullptr, 10) : (size_t(3) << 29);
     while (m->workers.size() + 1 < nw) { std::unique_ptr<Dev> w(make_hip_worker(m->ctx->device_id, arena)); w->pcs_init(m->zk->full_log); m->workers.push_back(std::move(w)); }
+    // several proofs in flight: throughput mode on every context (see hip_dev_set_latency_mode)
+    hip_dev_set_latency_mode(m->ctx->dev, nw == 1);
+    for (auto& w : m->workers) hip_dev_set_latency_mode(w.get(), nw == 1);
     std::atomic<size_t> next(0);
     std::mutex err_mu; std::string err; int err_code = 0;
     for (size_t i = 0; i < nproofs; i++) { proof_words[i] = nullptr; proof_nwords[i] = 0; }
@@ -355,6 +358,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     hip_dev_dump_sc_debug(m->ctx->dev); hip_dev_dump_host_stats(m->ctx->dev);
     for (size_t wi = 1; wi < nw && wi < 3; wi++) { hip_dev_dump_sc_debug(m->workers[wi - 1].get()); hip_dev_dump_host_stats(m->workers[wi - 1].get()); }
+    hip_dev_set_latency_mode(m->ctx->dev, true);
     if (err_code) { for (size_t i = 0; i < nproofs; i++) { free(proof_words[i]); proof_words[i] = nullptr; } throw DpError(err_code, err); }
   });
 }

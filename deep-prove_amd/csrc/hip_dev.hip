@@ -1449,6 +1449,7 @@ class HipDev : public Dev {
   }
   const char* name() const override { return name_.c_str(); }
   size_t arena_peak() const { return arena_peak_; }
+  void set_latency_mode(bool on) { multi_ = on && persist_flag_env("DP_NO_MULTI"); }
   void dump_host_stats() {
     if (!g_host_stats) return;
     fprintf(stderr, "[dp timing] device context: %zu launches, %.1f us of host time per launch (%.1f ms total), %zu device waits, %zu fiber yields\n", nlaunch_, nlaunch_ ? launch_us_ / nlaunch_ : 0.0, launch_us_ / 1000.0, nwait_, nyield_);
@@ -2186,6 +2187,9 @@ Dev* make_hip_worker(int device, size_t arena_bytes) { return new HipDev(device,
 void hip_dev_dump_sc_debug(Dev* d) { static_cast<HipDev*>(d)->dump_sc_debug(); }
 size_t hip_dev_arena_peak(Dev* d) { return static_cast<HipDev*>(d)->arena_peak(); }
 void hip_dev_dump_host_stats(Dev* d) { static_cast<HipDev*>(d)->dump_host_stats(); }
+// latency mode (one proof on the GPU): large sumcheck rounds spread over several workgroups; throughput mode (many proofs
+// in flight): one workgroup per sumcheck — spreading costs more CUs and host polls than it saves when the GPU is shared
+void hip_dev_set_latency_mode(Dev* d, bool on) { static_cast<HipDev*>(d)->set_latency_mode(on); }
 void hip_dev_profile_enable(Dev* d, bool on) { static_cast<HipDev*>(d)->profile_enable(on); }
 std::string hip_dev_profile_report(Dev* d) { return static_cast<HipDev*>(d)->profile_report(); }
 
