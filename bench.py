@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BATCHES_PER_STEP = 2
 PUBLISHED = {"dense_4m": 1000.0 / 2335.0, "cnn_264k": 1000.0 / 1242.0}  # reference README.md:17-18 (hardware unstated)
 WORKLOADS = {
     "dense_4m": "Dense-4M MLP (mlp.py --num-dense 5 --layer-width 1024: 4->1024->1024x4->3, Dense+Requant+ReLU blocks, 4.21M params), 1 input per proof",
@@ -36,7 +37,8 @@ def shard(total, world, rank):
 
 def timed_region(prove_batch, my_inputs, conc, steps, warmup, dist=None, device_sync=None, reduce_device="cpu"):
     """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + device sync on both sides; returns
-    (MAX over ranks of the elapsed seconds, result of the last step). A step = one batch of `conc` proofs."""
+    (MAX over ranks of the elapsed seconds, result of the last step). A step = one batch of `conc` proofs (`conc` here is
+    the batch size of a step; how many of them are in flight at once is the prover's business)."""
     import torch
 
     def barrier():
@@ -75,7 +77,8 @@ def measure_workload(dpa, dev, workload, conc, steps, warmup, world, rank, dist,
     setup_s = time.time() - t0
     prover = dpa.Prover(ctx)
     vblob = ctx.verifier_blob()
-    per_rank = (steps + warmup) * conc
+    batch = BATCHES_PER_STEP * conc  # proofs per step: two waves of `conc` in flight, so the drain of a step's tail weighs less
+    per_rank = (steps + warmup) * batch
     my_inputs = np.stack([mb.input(1000 + i) for i in shard(world * per_rank, world, rank)])
     t0 = time.perf_counter()
     prover.prove(my_inputs[0])
@@ -84,11 +87,11 @@ def measure_workload(dpa, dev, workload, conc, steps, warmup, world, rank, dist,
     prover.prove(my_inputs[0])
     latency_ms = 1000 * (time.perf_counter() - t0)
     cuda = torch.cuda.is_available() and (dist is None or dist.get_backend() == "nccl")
-    elapsed, last = timed_region(lambda xs: prover.prove_batch(xs, conc), my_inputs, conc, steps, warmup, dist,
+    elapsed, last = timed_region(lambda xs: prover.prove_batch(xs, conc), my_inputs, batch, steps, warmup, dist,
                                  torch.cuda.synchronize if cuda else None, "cuda" if cuda else "cpu")
     # every proof of the last batch must verify (host verifier) — an invalid proof voids the measurement
-    lo = (warmup + steps - 1) * conc
-    for j in range(conc):
+    lo = (warmup + steps - 1) * batch
+    for j in range(batch):
         dpa.verify(vblob, last[0][j], my_inputs[lo + j], last[1][j])
     return dict(mb=mb, ctx=ctx, prover=prover, inputs=my_inputs, elapsed=elapsed, latency_ms=latency_ms, first_ms=first_ms,
                 setup_s=setup_s, proof_words=int(last[0][0].size))
@@ -175,7 +178,7 @@ def main():
     result = None
     if rank == 0:
         def rate(w, steps):
-            return world * steps * conc / w["elapsed"]
+            return world * steps * BATCHES_PER_STEP * conc / w["elapsed"]
         value = rate(main_w, args.steps)
         # ---- roofline of the dominant kernel of one proof: algorithmic bytes per launch / average launch duration
         rep = kernel_profile(dev, main_w["prover"], main_w["inputs"][0])
@@ -200,7 +203,7 @@ def main():
         if cnn_w is not None:
             csteps = max(1, args.steps - 1)
             cnn = {"metric": "proofs/sec (prover), CNN-264k", "value": round(rate(cnn_w, csteps), 4), "unit": "proofs/s",
-                   "ms_per_step": round(1000.0 * cnn_w["elapsed"] / csteps, 3), "steps": csteps, "proofs_per_step_per_gpu": conc,
+                   "ms_per_step": round(1000.0 * cnn_w["elapsed"] / csteps, 3), "steps": csteps, "proofs_per_step_per_gpu": BATCHES_PER_STEP * conc, "proofs_in_flight_per_gpu": conc,
                    "single_proof_latency_ms": round(cnn_w["latency_ms"], 2), "vs_baseline": round(rate(cnn_w, csteps) / PUBLISHED["cnn_264k"], 3),
                    "baseline_note": "reference README.md:17 CNN-264k proving time 1242 ms on unstated CPU hardware",
                    "workload": WORKLOADS["cnn_264k"], "proof_words": cnn_w["proof_words"], "setup_s": round(cnn_w["setup_s"], 2), "verified": True,
@@ -213,7 +216,7 @@ def main():
             "baseline_note": "reference README.md:17-18 proving times (Dense-4M 2335 ms, CNN-264k 1242 ms) on unstated CPU hardware",
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload], "arithmetic": "Goldilocks p = 2^64 - 2^32 + 1 and its degree-2 extension (canonical u64 words)",
-                       "proofs_per_step_per_gpu": conc, "proofs_per_rank": args.steps * conc,
+                       "proofs_per_step_per_gpu": BATCHES_PER_STEP * conc, "proofs_in_flight_per_gpu": conc, "proofs_per_rank": args.steps * BATCHES_PER_STEP * conc,
                        "single_proof_latency_ms": round(main_w["latency_ms"], 2), "first_proof_ms": round(main_w["first_ms"], 2),
                        "host_cpu_budget": budget, "host_threads_per_rank": int(os.environ["DP_HOST_THREADS"]),
                        "parallelism": f"replicas x{world} GPUs x {conc} proofs in flight per GPU (independent proofs, no data-path collective)",
