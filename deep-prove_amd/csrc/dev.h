@@ -109,6 +109,13 @@ class Dev {
   // ---- sumcheck (K1 + K3): fold every table with r (if given; tabs[i] is replaced), then per term the sums
   // sum_b prod_j (v_j[2b] + t (v_j[2b+1] - v_j[2b])) for t = 0..k, written consecutively to `out`.
   virtual void sc_round(DBuf* tabs, int ntabs, const Ext* r, const ScTerm* terms, int nterms, Ext* out) = 0;
+  // The same round when the caller knows what the round must sum to (only meaningful for ONE term: out[0] + out[1] ==
+  // *claim, the previous round polynomial at its challenge, in raw units): a device may then skip the t = 1 pass and
+  // return out[1] = claim - out[0] — the identity is exact in the field, so the message is bit-identical.
+  virtual void sc_round_claim(DBuf* tabs, int ntabs, const Ext* r, const ScTerm* terms, int nterms, const Ext* claim, Ext* out) {
+    (void)claim;
+    sc_round(tabs, ntabs, r, terms, nterms, out);
+  }
   virtual void sc_finish(DBuf* tabs, int ntabs, Ext r, Ext* finals) = 0;
   // ---- logup-GKR (K13)
   virtual void logup_den(const DBuf& out, const DBuf* cols, int ncols, Ext c, Ext chi) = 0;

@@ -19,41 +19,41 @@ typedef uint32_t u32;
 constexpr u64 GL_P = 0xFFFFFFFF00000001ULL;
 constexpr u64 GL_EPS = 0xFFFFFFFFULL;  // 2^64 mod p = 2^32 - 1
 
+// All primitives are branch-free selects on carry / borrow conditions: on gfx950 a data-dependent `if` around a 64-bit
+// correction compiles to an EXEC-mask region (s_and_saveexec + branch + hazard nops) per operation, which more than doubles
+// the instruction count of the compute-bound kernels (Poseidon2 Merkle layers, fused fold+sum); the select forms below are
+// straight-line VALU.
 DP_HD u64 gl_add(u64 a, u64 b) {
-  u64 s = a + b;
-  // a,b < p: on carry the true value is s + 2^64 = s + EPS (mod p); otherwise one conditional subtract
-  if (s < a) s += GL_EPS;
-  else if (s >= GL_P) s -= GL_P;
-  return s;
+  // a,b < p.  s = a + b, t = s - p = s + EPS (mod 2^64).  a + b >= p  <=>  the first add carried, or s + EPS carries.
+  u64 s, t;
+  bool c1 = __builtin_add_overflow(a, b, &s);
+  bool c2 = __builtin_add_overflow(s, GL_EPS, &t);
+  return (c1 | c2) ? t : s;
 }
 DP_HD u64 gl_sub(u64 a, u64 b) {
-  u64 d = a - b;
-  if (a < b) d -= GL_EPS;  // + p (mod 2^64)
-  return d;
+  u64 d;
+  bool br = __builtin_sub_overflow(a, b, &d);
+  return d - (br ? GL_EPS : 0);  // + p (mod 2^64)
 }
 DP_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 DP_HD u64 gl_dbl(u64 a) { return gl_add(a, a); }
 
 DP_HD void mul64wide(u64 a, u64 b, u64& lo, u64& hi) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  lo = a * b;
-  hi = __umul64hi(a, b);
-#else
-  unsigned __int128 x = (unsigned __int128)a * b;
+  unsigned __int128 x = (unsigned __int128)a * b;  // device: 4 v_mad_u64_u32
   lo = (u64)x;
   hi = (u64)(x >> 64);
-#endif
 }
 // x = hi*2^64 + lo  ->  x mod p   (2^64 = 2^32 - 1, 2^96 = -1 mod p)
 DP_HD u64 gl_reduce128(u64 lo, u64 hi) {
   u64 hh = hi >> 32, hl = hi & GL_EPS;
-  u64 t0 = lo - hh;
-  if (lo < hh) t0 -= GL_EPS;
-  u64 t1 = hl * GL_EPS;  // (hl << 32) - hl, no overflow
-  u64 r = t0 + t1;
-  if (r < t1) r += GL_EPS;
-  if (r >= GL_P) r -= GL_P;
-  return r;
+  u64 t0, r, t;
+  bool br = __builtin_sub_overflow(lo, hh, &t0);
+  t0 -= br ? GL_EPS : 0;            // lo - hh (mod p), any u64 representative
+  u64 t1 = (hl << 32) - hl;         // hl * EPS, no overflow
+  bool c = __builtin_add_overflow(t0, t1, &r);
+  r += c ? GL_EPS : 0;              // cannot carry again: the wrapped sum is < t1 <= 2^64 - 2^32
+  bool c2 = __builtin_add_overflow(r, GL_EPS, &t);
+  return c2 ? t : r;                // r >= p  <=>  r + EPS carries
 }
 DP_HD u64 gl_mul(u64 a, u64 b) {
   u64 lo, hi;

@@ -273,7 +273,9 @@ __global__ void k_reduce_terms(const Ext* partial, size_t nblocks, Ext* out) {
 // into 2 values, stores those (32 contiguous bytes) and immediately accumulates the next round's sums on that pair —
 // every table byte is read once and every folded byte written once per round (the unfused path reads the folded
 // table a second time). partial[block*4 + t] = sum over the block's pairs of prod_j (f0_j + t (f1_j - f0_j)).
-template <int K, bool BASE>
+// SKIP1: the caller knows the round's claimed sum s(0) + s(1), so the t = 1 products are not computed (slot 1 stays 0
+// and the host sets s(1) = claim - s(0)): 2 of the 8 extension products per pair less.
+template <int K, bool BASE, bool SKIP1>
 __global__ void __launch_bounds__(256) k_sc_fused(const void* in0, const void* in1, const void* in2, Ext* out0, Ext* out1, Ext* out2,
                                                   size_t nquads, Ext r, Ext* partial) {
   __shared__ Ext sm[TPB / 64];
@@ -298,15 +300,15 @@ __global__ void __launch_bounds__(256) k_sc_fused(const void* in0, const void* i
       out[j][2 * q] = f0[j];
       out[j][2 * q + 1] = f1[j];
     }
-    if (K == 1) { acc0 = ex_add(acc0, f0[0]); acc1 = ex_add(acc1, f1[0]); }
+    if (K == 1) { acc0 = ex_add(acc0, f0[0]); if (!SKIP1) acc1 = ex_add(acc1, f1[0]); }
     else if (K == 2) {
       Ext c0 = ex_sub(ex_dbl(f1[0]), f0[0]), c1 = ex_sub(ex_dbl(f1[1]), f0[1]);
-      acc0 = ex_add(acc0, ex_mul(f0[0], f0[1])); acc1 = ex_add(acc1, ex_mul(f1[0], f1[1])); acc2 = ex_add(acc2, ex_mul(c0, c1));
+      acc0 = ex_add(acc0, ex_mul(f0[0], f0[1])); if (!SKIP1) acc1 = ex_add(acc1, ex_mul(f1[0], f1[1])); acc2 = ex_add(acc2, ex_mul(c0, c1));
     } else {
       Ext d0 = ex_sub(f1[0], f0[0]), d1 = ex_sub(f1[1], f0[1]), d2 = ex_sub(f1[2], f0[2]);
       Ext c0 = ex_add(f1[0], d0), c1 = ex_add(f1[1], d1), c2 = ex_add(f1[2], d2);
       Ext g0 = ex_add(c0, d0), g1 = ex_add(c1, d1), g2 = ex_add(c2, d2);
-      acc0 = ex_add(acc0, ex_mul(ex_mul(f0[0], f0[1]), f0[2])); acc1 = ex_add(acc1, ex_mul(ex_mul(f1[0], f1[1]), f1[2]));
+      acc0 = ex_add(acc0, ex_mul(ex_mul(f0[0], f0[1]), f0[2])); if (!SKIP1) acc1 = ex_add(acc1, ex_mul(ex_mul(f1[0], f1[1]), f1[2]));
       acc2 = ex_add(acc2, ex_mul(ex_mul(c0, c1), c2)); acc3 = ex_add(acc3, ex_mul(ex_mul(g0, g1), g2));
     }
   }
@@ -1635,6 +1637,12 @@ class HipDev : public Dev {
     std::atomic_thread_fence(std::memory_order_seq_cst);
   }
   static constexpr size_t SC_SMALL_MAX = 8192;  // tables up to this length (after the fold) take the one-launch path
+  const Ext* claim_hint_ = nullptr;  // set for the duration of sc_round_claim: the fused streaming path may skip t = 1
+  void sc_round_claim(DBuf* tabs, int nt, const Ext* r, const ScTerm* terms, int nterms, const Ext* claim, Ext* out) override {
+    claim_hint_ = nterms == 1 ? claim : nullptr;
+    try { sc_round(tabs, nt, r, terms, nterms, out); } catch (...) { claim_hint_ = nullptr; throw; }
+    claim_hint_ = nullptr;
+  }
   void sc_round(DBuf* tabs, int nt, const Ext* r, const ScTerm* terms, int nterms, Ext* out) override {
     DP_REQUIRE(nt <= MAX_TABS && nterms <= MAX_TERMS && nt > 0 && nterms > 0, DP_ERR_SHAPE, "sumcheck: too many tables/terms for one launch");
     size_t n_in = tabs[0].n;
@@ -1787,13 +1795,16 @@ class HipDev : public Dev {
         int g = grid_for(nquads, 4096);
         Ext* partial = (Ext*)arena_alloc((size_t)g * 4 * 16);
         nb_ = bytes;
-        #define LAUNCH_FUSED(KK, BB) DPL((k_sc_fused<KK, BB>), dim3(g), dim3(TPB), in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial)
-        if (nt == 1) { if (base) LAUNCH_FUSED(1, true); else LAUNCH_FUSED(1, false); }
-        else if (nt == 2) { if (base) LAUNCH_FUSED(2, true); else LAUNCH_FUSED(2, false); }
-        else { if (base) LAUNCH_FUSED(3, true); else LAUNCH_FUSED(3, false); }
+        const bool skip1 = claim_hint_ != nullptr;
+        #define LAUNCH_FUSED2(KK, BB) do { if (skip1) DPL((k_sc_fused<KK, BB, true>), dim3(g), dim3(TPB), in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial); \
+                                           else DPL((k_sc_fused<KK, BB, false>), dim3(g), dim3(TPB), in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial); } while (0)
+        #define LAUNCH_FUSED(KK) do { if (base) LAUNCH_FUSED2(KK, true); else LAUNCH_FUSED2(KK, false); } while (0)
+        if (nt == 1) LAUNCH_FUSED(1); else if (nt == 2) LAUNCH_FUSED(2); else LAUNCH_FUSED(3);
         #undef LAUNCH_FUSED
+        #undef LAUNCH_FUSED2
         reduce_publish(partial, (size_t)g, 4, 4);
         for (int t = 0; t <= terms[0].k; t++) out[t] = ex(hres_[2 * t], hres_[2 * t + 1]);
+        if (skip1) out[1] = ex_sub(*claim_hint_, out[0]);  // s(0) + s(1) = claim, exactly
         release(mk);
         return;
       }

@@ -88,9 +88,16 @@ inline SumcheckOut sumcheck_prove(Dev& dev, DevVP& vp, Transcript& t) {
   for (auto& tm : vp.terms) nraw += tm.k + 1;
   std::vector<Ext> raw(nraw);
   Ext ch = ex_zero();
+  const bool single = vp.terms.size() == 1 && ex_eq(vp.coeffs[0], ex_one()) && (unsigned)vp.terms[0].k == md;
   for (unsigned round = 0; round < nv; round++) {
     auto tq0 = std::chrono::steady_clock::now();
-    dev.sc_round(tabs.data(), (int)tabs.size(), round ? &ch : nullptr, vp.terms.data(), (int)vp.terms.size(), raw.data());
+    // one product with coefficient one (the shape of the large standalone sumchecks): the round must sum to the previous
+    // round polynomial at its challenge, which lets the device skip one of its evaluation points
+    if (single && round) {
+      Ext claim = lagrange_eval_small(out.proof.proofs.back().data(), md + 1, ch);
+      dev.sc_round_claim(tabs.data(), (int)tabs.size(), &ch, vp.terms.data(), 1, &claim, raw.data());
+    } else
+      dev.sc_round(tabs.data(), (int)tabs.size(), round ? &ch : nullptr, vp.terms.data(), (int)vp.terms.size(), raw.data());
     auto tq1 = std::chrono::steady_clock::now();
     std::vector<Ext> msg(md + 1, ex_zero());
     size_t off = 0;

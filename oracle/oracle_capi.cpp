@@ -156,6 +156,29 @@ int orc_model_prove(orc_model* m, const int64_t* input, size_t ninput, uint64_t*
     if (output && noutput) { const auto& o = tr.out.back(); if (*noutput < o.size()) throw std::runtime_error("output buffer too small"); memcpy(output, o.data(), o.size() * 8); *noutput = o.size(); }
   });
 }
+// CPU throughput baseline: `threads` host threads each prove `per_thread` independent proofs of the same input (the CPU
+// analogue of the product's proofs in flight; the reference parallelises inside one proof with rayon, which a scalar
+// restatement does not, so replicas are how it fills the cores). Inference is done once, outside the timed region.
+// digest = wrapping sum of the words of every proof stream (all replicas must produce the same proof).
+int orc_model_prove_many(orc_model* m, const int64_t* input, size_t ninput, int32_t threads, int32_t per_thread, double* wall_ms, uint64_t* digest) {
+  return guard([&] {
+    if (threads < 1 || per_thread < 1) throw std::runtime_error("threads and per_thread must be positive");
+    Trace tr = run_model(m->ctx.model, std::vector<int64_t>(input, input + ninput));
+    std::vector<u64> dg(threads, 0); std::vector<std::string> errs(threads);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int i = 0; i < threads; i++) th.emplace_back([&, i] {
+      try {
+        for (int j = 0; j < per_thread; j++) { Transcript t = default_transcript(); Proof p = prove(m->ctx, tr, t); u64 d = 0; for (u64 w : serialize_proof(p)) d += w; dg[i] += d; }
+      } catch (const std::exception& e) { errs[i] = e.what(); }
+    });
+    for (auto& t : th) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
+    *wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    u64 d = 0; for (u64 x : dg) d += x; if (digest) *digest = d;
+  });
+}
 // CPU baseline for the standalone sumcheck bench (config 5 shape): one product of k base tables of 2^nv SplitMix64-derived
 // canonical elements, label "test". Returns wall seconds of prove only.
 int orc_bench_sumcheck(uint32_t nv, int32_t k, uint64_t seed, double* seconds, uint64_t digest[2]) {

@@ -184,6 +184,13 @@ class Oracle:
         self._ok(self.lib.orc_model_prove(h, x.ctypes.data_as(i64p), C.c_size_t(x.size), C.byref(pw), C.byref(pn), out.ctypes.data_as(i64p), C.byref(no), C.byref(ms)))
         return self._take(pw, pn.value), out[:no.value].copy(), ms.value
 
+    def model_prove_many(self, h, x, threads, per_thread=1):
+        """`threads` host threads x `per_thread` independent proofs; returns (wall ms, wrapping word-sum over all proofs)"""
+        x = np.ascontiguousarray(x, dtype=np.int64)
+        ms, dg = C.c_double(), C.c_uint64()
+        self._ok(self.lib.orc_model_prove_many(h, x.ctypes.data_as(i64p), C.c_size_t(x.size), C.c_int32(threads), C.c_int32(per_thread), C.byref(ms), C.byref(dg)))
+        return ms.value, int(dg.value)
+
     def bench_sumcheck(self, nv, k, seed):
         s = C.c_double()
         dg = (C.c_uint64 * 2)()

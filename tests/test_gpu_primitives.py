@@ -83,6 +83,12 @@ SC_CASES = [
     (16, [True, True], [((3, 5), [0, 1])]),
     (18, [True], [((1, 0), [0])]),
     (19, [False, False], [((1, 0), [1, 0])]),
+    # single products with coefficient one above the multi-workgroup range: the fused kernel runs several rounds knowing the
+    # round's claimed sum and skips the t = 1 products (base and extension inputs, degrees 3, 2, 1)
+    (21, [False, False, False], [((1, 0), [0, 1, 2])]),
+    (20, [True, True], [((1, 0), [0, 1])]),
+    (20, [True], [((1, 0), [0])]),
+    (20, [False, False, False], [((1, 1), [2, 0, 1])]),  # same shape, coefficient != 1: no skipping
 ]
 
 

@@ -49,3 +49,14 @@ def test_host_fibers(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", exe, os.path.join(root, "tests", "support", "fiber_check.cpp")])
     r = run(exe)
     assert r.returncode == 0 and "fibers ok=1" in r.stdout, r.stdout + r.stderr
+
+
+def test_field_header_against_wide_arithmetic(tmp_path):
+    """deep-prove_amd/csrc/gl64.h (shared by the host orchestrator and every kernel): branch-free add / sub / 128-bit
+    reduction / extension product against plain `%` arithmetic on edge values and a random sweep"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "field_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "support", "field_check.cpp")])
+    r = run(exe)
+    assert r.returncode == 0 and "bad=0" in r.stdout, r.stdout + r.stderr

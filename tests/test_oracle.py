@@ -105,3 +105,15 @@ def test_cnn_golden_fixture_is_reproducible(oracle):
     bad[1200] ^= np.uint64(1)
     with pytest.raises(dpa.DeepProveError):
         dpa.verify(g["verifier_blob"], bad, g["input"], g["output"])
+
+
+def test_replica_baseline_reproduces_the_single_proof(oracle):
+    """bench.py's cpu_baseline throughput leg (orc_model_prove_many): every replica thread produces the same stream as
+    the single-threaded prove (checked through the wrapping word sum)"""
+    import deep_prove_amd as dpa
+    mb = dpa.models.mlp(2, 16, 1)
+    h = oracle.model_setup(mb.blob())
+    proof, _, _ = oracle.model_prove(h, mb.input(7))
+    wall, dg = oracle.model_prove_many(h, mb.input(7), 3, 2)
+    oracle.model_free(h)
+    assert wall > 0 and dg == (int(proof.sum(dtype=np.uint64)) * 6) % (1 << 64)

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Summarise two rocprofv3 PMC passes (separate FETCH_SIZE and WRITE_SIZE runs of the same command, rocpd databases)
+into the JSON bench.py reads for `roofline.traffic`.
+usage: python tools/pmc_summary.py <fetch.db> <write.db> <out.json> "<command>" [kernel-prefix ...]
+Per kernel: the mean over all its launches (`hbm_bytes_per_launch`, what bench.py's per-launch `achieved` is compared with)
+and the launch with the largest traffic (a sumcheck halves its tables every round, so the first launch is the big one).
+Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE under-reports 16 B/lane coalesced streaming reads by
+2x -> doubled; WRITE_SIZE as reported; both are in KB."""
+import json
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = name.split("(")[0]
+    return name.replace("dp::", "")
+
+
+def per_kernel(path, counter):
+    db = sqlite3.connect(path)
+    out = {}
+    for name, value, dur in db.execute("select kernel_name, value, duration from counters_collection where counter_name = ? order by id", (counter,)):
+        out.setdefault(short(name), []).append((float(value), float(dur)))
+    return out
+
+
+def main():
+    fetch_db, write_db, out_path, command = sys.argv[1:5]
+    prefixes = sys.argv[5:]
+    f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
+    recs = []
+    for k in f:
+        if prefixes and not any(k.startswith(p) for p in prefixes):
+            continue
+        fv, wv = f[k], w.get(k, [])
+        i = max(range(len(fv)), key=lambda j: fv[j][0])
+        fk = sum(v for v, _ in fv) / len(fv)
+        dur = sum(d for _, d in fv) / len(fv)
+        wk = sum(v for v, _ in wv) / max(len(wv), 1)
+        recs.append({"kernel": k, "launches": len(fv), "fetch_size_kb_avg": round(fk, 2), "write_size_kb_avg": round(wk, 2),
+                     "hbm_bytes_per_launch": int(round((2 * fk + wk) * 1024)), "avg_duration_us_under_pmc": round(dur / 1e3, 1),
+                     "largest_launch": {"fetch_size_kb": round(fv[i][0], 2), "write_size_kb": round(wv[i][0], 2) if i < len(wv) else None,
+                                        "hbm_bytes": int(round((2 * fv[i][0] + (wv[i][0] if i < len(wv) else 0.0)) * 1024)),
+                                        "duration_us_under_pmc": round(fv[i][1] / 1e3, 1)}})
+    recs.sort(key=lambda r: -r["hbm_bytes_per_launch"] * r["launches"])
+    json.dump({"command": command, "correction": "FETCH_SIZE x 2 on gfx950 for 16 B/lane coalesced streaming reads (MI355X_MICROARCH.md, HBM section); "
+               "WRITE_SIZE as reported; both in KB", "kernels": recs[:16]}, open(out_path, "w"), indent=1)
+    for r in recs[:8]:
+        print(f"{r['kernel'][:48]:48s} launches={r['launches']:5d} hbm_bytes/launch={r['hbm_bytes_per_launch']:12d} dur_us={r['avg_duration_us_under_pmc']}")
+
+
+if __name__ == "__main__":
+    main()
