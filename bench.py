@@ -319,6 +319,8 @@ def cpu_baseline(mb, workload):
     """the oracle ("port" of the reference CPU path) on a bounded sample of the same workload: one proof on one core (the
     latency), then one proof per host core in parallel (the throughput leg: independent replicas, the CPU analogue of the
     proofs the GPU keeps in flight)"""
+    import numpy as np
+    import deep_prove_amd as dpa
     from support import oracle_lib
     o = oracle_lib.load()
     h = o.model_setup(mb.blob())
