@@ -10,14 +10,17 @@
 #include <thread>
 
 DP_FIBER_SWITCH_ASM
-namespace dp { void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
+namespace dp { struct Cohort; Cohort* hip_cohort_new(); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
 using namespace dp;
 
 struct dp_ctx { Dev* dev; int device_id; };
 struct dp_buf { DBuf b; };
 struct dp_transcript { Transcript t; };
 struct dp_commit { DevCommit c; };
-struct dp_model { dp_ctx* ctx; std::unique_ptr<Context> zk; std::vector<std::unique_ptr<Dev>> workers; };
+struct dp_model {
+  dp_ctx* ctx; std::unique_ptr<Context> zk; std::vector<std::unique_ptr<Dev>> workers; std::vector<dp::Cohort*> cohorts;
+  ~dp_model() { for (auto* c : cohorts) hip_cohort_free(c); }
+};
 
 static thread_local std::string g_err;
 template <class F>
@@ -317,43 +320,69 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     // several proofs in flight: throughput mode on every context (see hip_dev_set_latency_mode)
     hip_dev_set_latency_mode(m->ctx->dev, nw == 1);
     for (auto& w : m->workers) hip_dev_set_latency_mode(w.get(), nw == 1);
+    // Cohorts (hip_dev.hip, struct Cohort): the proofs in flight are grouped into cohorts of DP_COHORT members (default 8)
+    // that prove in lock step — launch number i of all members of a cohort is ONE kernel launch — on one stream and one
+    // host thread per cohort. DP_COHORT=0: every proof on its own stream (the round-1 scheme).
+    const char* ce = getenv("DP_COHORT");
+    size_t csize = ce ? (size_t)std::max(0, atoi(ce)) : 8;
+    size_t nco = (csize >= 1 && nw > 1) ? (nw + csize - 1) / csize : 0;
+    while (m->cohorts.size() < nco) m->cohorts.push_back(hip_cohort_new());
+    auto dev_of = [&](size_t wi) -> Dev& { return wi == 0 ? *m->ctx->dev : *m->workers[wi - 1]; };
     std::atomic<size_t> next(0);
+    const bool timing = getenv("DP_TIMING") && atoi(getenv("DP_TIMING"));
     std::mutex err_mu; std::string err; int err_code = 0;
     for (size_t i = 0; i < nproofs; i++) { proof_words[i] = nullptr; proof_nwords[i] = 0; }
+    for (size_t wi = 0; wi < nw && nco; wi++) hip_dev_cohort_attach(&dev_of(wi), m->cohorts[wi % nco]);
     auto t0 = std::chrono::steady_clock::now();
     auto work = [&](size_t wi) {
-      Dev& dev = wi == 0 ? *m->ctx->dev : *m->workers[wi - 1];
+      Dev& dev = dev_of(wi);
       try {
         dev.bind_thread();
         for (;;) {
           size_t i = next.fetch_add(1);
           if (i >= nproofs) break;
           std::vector<int64_t> in(inputs + i * ninput, inputs + (i + 1) * ninput);
+          auto h0 = std::chrono::steady_clock::now();
           Trace tr = run_model(m->zk->model, in);
+          auto h1 = std::chrono::steady_clock::now();
           Transcript t = default_transcript();
           Proof p = prove(*m->zk, dev, tr, t);
+          auto h2 = std::chrono::steady_clock::now();
           std::vector<u64> w = serialize_proof(p);
+          auto h3 = std::chrono::steady_clock::now();
           proof_words[i] = copy_out(w); proof_nwords[i] = w.size();
+          if (timing && wi == 0) {
+            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            fprintf(stderr, "[dp timing] host phases of one proof: inference %.2f ms, prove %.2f ms (wall, shared thread), serialise %.2f ms, copy out %.2f ms\n", ms(h0, h1), ms(h1, h2), ms(h2, h3), ms(h3, std::chrono::steady_clock::now()));
+          }
           if (outputs) { const auto& o = tr.out.back(); DP_REQUIRE(o.size() <= noutput_cap, DP_ERR_ARG, "output buffer too small"); memcpy(outputs + i * noutput_cap, o.data(), o.size() * 8); if (noutput) *noutput = o.size(); }
         }
       } catch (const DpError& e) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = e.code; err = e.what(); } next = nproofs; }
       catch (const std::exception& e) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_ARG; err = e.what(); } next = nproofs; }
+      // leaving the cohort releases the launches the other members have queued behind this one
+      if (nco) { try { hip_dev_cohort_detach(&dev); } catch (const std::exception& e) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } next = nproofs; } }
     };
-    // `nw` proofs in flight on `nth` host threads: every worker is a fiber, fibers are dealt round robin to the threads and
-    // a thread switches to its next fiber whenever the current one waits for the device (fiber.h). The thread count follows
-    // the CPUs the process may really use (cgroup quota), leaving two for the HIP runtime's own threads.
+    // `nw` proofs in flight on `nth` host threads: every worker is a fiber; a thread switches to its next fiber whenever the
+    // current one waits for the device (fiber.h). All members of a cohort live on one thread (the cohort has no locks);
+    // cohorts (or, without cohorts, workers) are dealt round robin to the threads. The thread count follows the CPUs the
+    // process may really use (cgroup quota), leaving two for the HIP runtime's own threads.
     const char* te = getenv("DP_HOST_THREADS");
     size_t nth = te ? (size_t)std::max(1, atoi(te)) : (size_t)std::max(1.0, host_cpu_budget() - 2.0);
-    nth = std::min(nth, nw);
+    nth = std::min(nth, nco ? nco : nw);
     auto run_thread = [&](size_t ti) {
       FiberSched sched;
-      for (size_t wi = ti; wi < nw; wi += nth) fiber_spawn(sched, [&work, wi] { work(wi); });
+      for (size_t wi = 0; wi < nw; wi++) if ((nco ? wi % nco : wi) % nth == ti) fiber_spawn(sched, [&work, wi] { work(wi); });
       fiber_run_all(sched);
     };
     std::vector<std::thread> th;
     for (size_t ti = 1; ti < nth; ti++) th.emplace_back(run_thread, ti);
     run_thread(0);
     for (auto& t : th) t.join();
+    for (size_t c = 0; c < nco; c++) { try { hip_cohort_drain(m->cohorts[c]); } catch (const std::exception& e) { if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } } }
+    if (nco && getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) {
+      size_t f = 0, p = 0; for (size_t c = 0; c < nco; c++) { size_t a, b; hip_cohort_stats(m->cohorts[c], &a, &b); f += a; p += b; }
+      fprintf(stderr, "[dp timing] %zu cohorts of <= %zu proofs: %zu merged launches for %zu proof launches\n", nco, csize, f, p);
+    }
     if (getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) fprintf(stderr, "[dp timing] prove_batch: %zu proofs, %zu in flight on %zu host threads, arena peak %.1f MB\n", nproofs, nw, nth, hip_dev_arena_peak(m->ctx->dev) / 1048576.0);
     if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     hip_dev_dump_sc_debug(m->ctx->dev); hip_dev_dump_host_stats(m->ctx->dev);

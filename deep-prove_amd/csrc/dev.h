@@ -117,6 +117,17 @@ class Dev {
     sc_round(tabs, ntabs, r, terms, nterms, out);
   }
   virtual void sc_finish(DBuf* tabs, int ntabs, Ext r, Ext* finals) = 0;
+  // All remaining rounds of a sumcheck WITH its Fiat-Shamir transcript on the device, for devices that can keep the sponge
+  // to themselves: called at the top of a round with the tables as sc_round would get them (r = the previous challenge,
+  // not yet folded in, or null in the first round), the coefficient of every term and the transcript's sponge. On `true`
+  // the round messages (max_degree + 1 values each) and challenges of every remaining round have been appended to
+  // `msgs` / `point`, `finals` holds the final evaluation of every table and `ch` is the sponge after the last challenge —
+  // exactly what the per-round path (sc_round / host transcript / sc_finish) produces. `false`: not taken, nothing changed.
+  virtual bool sc_tail(DBuf* tabs, int ntabs, const Ext* r, const ScTerm* terms, const Ext* coeffs, int nterms, unsigned max_degree, Challenger& ch,
+                       std::vector<std::vector<Ext>>& msgs, std::vector<Ext>& point, Ext* finals) {
+    (void)tabs; (void)ntabs; (void)r; (void)terms; (void)coeffs; (void)nterms; (void)max_degree; (void)ch; (void)msgs; (void)point; (void)finals;
+    return false;
+  }
   // ---- logup-GKR (K13)
   virtual void logup_den(const DBuf& out, const DBuf* cols, int ncols, Ext c, Ext chi) = 0;
   virtual void logup_layer(const DBuf& num_in, const DBuf& den_in, const DBuf& num_out, const DBuf& den_out) = 0;

@@ -7,6 +7,7 @@
 // are canonical u64, extension elements are 16-byte {c0,c1} pairs so one `global_load_dwordx4` per lane fetches one
 // element. A sumcheck pair (2b, 2b+1) is therefore 32 contiguous bytes per lane.
 #include "dev.h"
+#include "sumcheck.h"
 #include "fiber.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -14,6 +15,8 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <deque>
+#include <type_traits>
 #include <chrono>
 #include <vector>
 #include <string>
@@ -31,6 +34,31 @@ constexpr int MAX_TERMS = 48;
 constexpr int MAX_PT = 32;
 
 struct PointArg { Ext p[MAX_PT]; };
+
+// ------------------------------------------------------------------------------------------------ launch forms
+// Every kernel of this file is written once, as a device function (KBODY), and gets TWO entry points:
+//   kg<Body>  one proof: the arguments arrive by value in the kernarg segment;
+//   kc<Body>  a cohort of proofs in lock step: ONE launch serves every proof of the cohort, blockIdx.z selects the proof and
+//             the workgroup fetches ITS arguments from a table of argument packs (one ArgPack per proof, written by the host
+//             into a mapped ring; tools/argsrc.hip: uniform reads of such a table cost what kernarg reads cost).
+// blockIdx.x / blockIdx.y keep their meaning inside the body in both forms. See `Cohort` below for the host side.
+#define KBODY __device__ __forceinline__ void
+template <class... A> struct ArgPack;
+template <> struct ArgPack<> {
+  template <class F, class... B> __device__ __forceinline__ void call(F f, const B&... b) const { f(b...); }
+};
+template <class H, class... T> struct ArgPack<H, T...> {
+  H h; ArgPack<T...> t;
+  ArgPack() = default;
+  ArgPack(const H& h_, const T&... t_) : h(h_), t(t_...) {}
+  template <class F, class... B> __device__ __forceinline__ void call(F f, const B&... b) const { t.call(f, b..., h); }
+};
+// parameter list of a body with references stripped: what travels (a body takes its large argument structs by const
+// reference so that both entry points read them in place — kernarg segment / pack table — instead of copying them to scratch)
+template <class T> struct KArgs;
+template <class... A> struct KArgs<void (*)(A...)> {};
+template <auto Body, int MAXT, class... A> __global__ void __launch_bounds__(MAXT) kg(A... a) { Body(a...); }
+template <auto Body, int MAXT, class... A> __global__ void __launch_bounds__(MAXT) kc(const ArgPack<A...>* __restrict__ packs) { packs[blockIdx.z].call(Body); }
 
 // Latency-critical one-workgroup kernels claim the whole register file of their CU (16 waves x 128 VGPRs): together with
 // the LDS reservation no wave of another kernel — in particular the VALU-heavy Poseidon2 Merkle layers of the other proofs in
@@ -70,14 +98,20 @@ __device__ __forceinline__ Ext ld_elem(const void* p, bool ext, size_t i) {
 }
 
 // ------------------------------------------------------------------------------------------------ elementwise
-__global__ void k_fieldize(const int64_t* in, u64* out, size_t n) {
+KBODY k_copy_words(u64* dst, const u64* src, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+KBODY k_zero_words(u64* dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = 0;
+}
+KBODY k_fieldize(const int64_t* in, u64* out, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = gl_from_i64(in[i]);
 }
-__global__ void k_pow_table(u64* out, u64 base, size_t n) {
+KBODY k_pow_table(u64* out, u64 base, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = gl_pow(base, i);
 }
 // K4: eq(x, pt) computed per index as a product over its bits (k ext multiplications per element, no log-k passes)
-__global__ void k_eq_table(Ext* out, PointArg pt, unsigned k, Ext scale, int acc, size_t n) {  // n > 2^k: the table repeats
+KBODY k_eq_table(Ext* out, const PointArg& pt, unsigned k, Ext scale, int acc, size_t n) {  // n > 2^k: the table repeats
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     Ext v = scale;
     for (unsigned t = 0; t < k; t++) {
@@ -89,7 +123,7 @@ __global__ void k_eq_table(Ext* out, PointArg pt, unsigned k, Ext scale, int acc
 }
 struct EvalArgs { const void* f[8]; int ext[8]; int nf; };
 // out partial[block][f] = sum over the block's x of f(x) * eq(x, pt)
-__global__ void k_mle_eval_partial(EvalArgs a, PointArg pt, unsigned k, Ext* partial) {
+KBODY k_mle_eval_partial(const EvalArgs& a, const PointArg& pt, unsigned k, Ext* partial) {
   __shared__ Ext sm[TPB / 64];
   size_t n = size_t(1) << k;
   Ext acc[8];
@@ -114,7 +148,7 @@ __global__ void k_mle_eval_partial(EvalArgs a, PointArg pt, unsigned k, Ext* par
   }
 }
 // generic second stage: out[j] = sum_b partial[b*stride + j], one block per j
-__global__ void k_reduce_partials(const Ext* partial, size_t nblocks, size_t stride, Ext* out) {
+KBODY k_reduce_partials(const Ext* partial, size_t nblocks, size_t stride, Ext* out) {
   __shared__ Ext sm[TPB / 64];
   size_t j = blockIdx.x;
   Ext acc = ex_zero();
@@ -123,7 +157,7 @@ __global__ void k_reduce_partials(const Ext* partial, size_t nblocks, size_t str
   if (threadIdx.x == 0) out[j] = r;
 }
 // K2 one pass: partial[split][c] = sum over the split's rows of eq[r] * W[r*C + c]
-__global__ void k_fix_high_partial(const u64* W, const Ext* eq, size_t R, size_t C, size_t rows_per_split, Ext* partial) {
+KBODY k_fix_high_partial(const u64* W, const Ext* eq, size_t R, size_t C, size_t rows_per_split, Ext* partial) {
   size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (c >= C) return;
   size_t r0 = blockIdx.y * rows_per_split, r1 = min(R, r0 + rows_per_split);
@@ -131,7 +165,7 @@ __global__ void k_fix_high_partial(const u64* W, const Ext* eq, size_t R, size_t
   for (size_t r = r0; r < r1; r++) acc = ex_add(acc, ex_mul_base(eq[r], W[r * C + c]));
   partial[(size_t)blockIdx.y * C + c] = acc;
 }
-__global__ void k_colsum(const Ext* partial, size_t nsplit, size_t C, Ext* out) {
+KBODY k_colsum(const Ext* partial, size_t nsplit, size_t C, Ext* out) {
   size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (c >= C) return;
   Ext acc = ex_zero();
@@ -142,7 +176,7 @@ __global__ void k_colsum(const Ext* partial, size_t nsplit, size_t C, Ext* out) 
 // ------------------------------------------------------------------------------------------------ sumcheck (K1, K3)
 struct FoldArgs { const void* in[MAX_TABS]; Ext* out[MAX_TABS]; int ext[MAX_TABS]; size_t half[MAX_TABS]; };
 // K1: out[i] = in[2i] + r (in[2i+1] - in[2i]); blockIdx.y selects the table
-__global__ void k_fold(FoldArgs a, Ext r) {
+KBODY k_fold(const FoldArgs& a, Ext r) {
   int t = blockIdx.y;
   size_t h = a.half[t];
   const void* in = a.in[t];
@@ -217,7 +251,7 @@ struct LdsPairs {
 struct TermArgs { const void* tab[MAX_TABS]; int ext[MAX_TABS]; int k[MAX_TERMS]; int t[MAX_TERMS][SC_MAXK]; size_t npairs; };
 // K3: partial[(term*gridDim.x + block)*SC_SLOTS + t] = sum over the block's pairs of prod_j (a_j + t d_j), t = 0..k
 template <bool HI>
-__global__ void k_sc_terms(TermArgs a, Ext* partial) {
+KBODY k_sc_terms(const TermArgs& a, Ext* partial) {
   __shared__ Ext sm[TPB / 64];
   int term = blockIdx.y;
   int k = a.k[term];
@@ -260,7 +294,7 @@ __global__ void k_sc_terms(TermArgs a, Ext* partial) {
   }
 }
 // out[term*4 + t] = sum_b partial[(term*nblocks + b)*4 + t]; one block per (term, t)
-__global__ void k_reduce_terms(const Ext* partial, size_t nblocks, Ext* out) {
+KBODY k_reduce_terms(const Ext* partial, size_t nblocks, Ext* out) {
   __shared__ Ext sm[TPB / 64];
   size_t term = blockIdx.x >> 2, t = blockIdx.x & 3;
   Ext acc = ex_zero();
@@ -276,7 +310,7 @@ __global__ void k_reduce_terms(const Ext* partial, size_t nblocks, Ext* out) {
 // SKIP1: the caller knows the round's claimed sum s(0) + s(1), so the t = 1 products are not computed (slot 1 stays 0
 // and the host sets s(1) = claim - s(0)): 2 of the 8 extension products per pair less.
 template <int K, bool BASE, bool SKIP1>
-__global__ void __launch_bounds__(256) k_sc_fused(const void* in0, const void* in1, const void* in2, Ext* out0, Ext* out1, Ext* out2,
+KBODY k_sc_fused(const void* in0, const void* in1, const void* in2, Ext* out0, Ext* out1, Ext* out2,
                                                   size_t nquads, Ext r, Ext* partial) {
   __shared__ Ext sm[TPB / 64];
   const void* in[3] = {in0, in1, in2};
@@ -320,7 +354,7 @@ __global__ void __launch_bounds__(256) k_sc_fused(const void* in0, const void* i
   v = block_reduce_ext(acc3, sm); if (threadIdx.x == 0) partial[base + 3] = v;
 }
 // last fold of a sumcheck: every table has 2 elements; results go to one contiguous array
-__global__ void k_finish(FoldArgs a, Ext r, int ntabs, Ext* out) {
+KBODY k_finish(const FoldArgs& a, Ext r, int ntabs, Ext* out) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= ntabs) return;
   Ext v;
@@ -331,7 +365,7 @@ __global__ void k_finish(FoldArgs a, Ext r, int ntabs, Ext* out) {
 
 // ------------------------------------------------------------------------------------------------ logup (K13)
 struct ColsArg { const u64* col[16]; int n; };
-__global__ void k_logup_den(Ext* out, ColsArg cols, Ext c, Ext chi, size_t n) {
+KBODY k_logup_den(Ext* out, const ColsArg& cols, Ext c, Ext chi, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     Ext acc = c, pw = ex_one();
     for (int j = 0; j < cols.n; j++) {
@@ -342,7 +376,7 @@ __global__ void k_logup_den(Ext* out, ColsArg cols, Ext c, Ext chi, size_t n) {
   }
 }
 // (n1/d1 + n2/d2) pairing index i with i + half;  num_mode: 0 = all numerators are -1, 1 = base numerators, 2 = ext
-__global__ void k_logup_layer(const void* num, int num_mode, const Ext* den, Ext* num_out, Ext* den_out, size_t half) {
+KBODY k_logup_layer(const void* num, int num_mode, const Ext* den, Ext* num_out, Ext* den_out, size_t half) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
     Ext d1 = den[i], d2 = den[i + half];
     Ext nn;
@@ -358,7 +392,7 @@ struct LogupTreeDesc { const u64* col[8]; int ncols; int num_mode; const void* n
 // K13 fused: denominators and every layer of the fractional-sum tree of one instance per workgroup (small tables).
 // den_all: layer j at offset 2n - (2n >> j) (lengths n, n/2, .., 2); num_all: layer j >= 1 at offset n - (2n >> j).
 // out[4*inst..] = [num_last[0], num_last[1], den_last[0], den_last[1]].
-__global__ void __launch_bounds__(1024) k_logup_tree(const LogupTreeDesc* d, size_t n, Ext c, Ext chi, Ext* out) {
+KBODY k_logup_tree(const LogupTreeDesc* d, size_t n, Ext c, Ext chi, Ext* out) {
   LogupTreeDesc t = d[blockIdx.x];
   int tid = threadIdx.x, nt = blockDim.x;
   Ext* den = t.den_all;
@@ -400,7 +434,7 @@ __global__ void __launch_bounds__(1024) k_logup_tree(const LogupTreeDesc* d, siz
 
 // ------------------------------------------------------------------------------------------------ RS code / NTT (K5-K7)
 template <bool EXT>
-__global__ void k_mobius_stage(void* data, size_t n, unsigned lg_half) {
+KBODY k_mobius_stage(void* data, size_t n, unsigned lg_half) {
   size_t half = size_t(1) << lg_half;
   for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < n / 2; b += (size_t)gridDim.x * blockDim.x) {
     size_t lo = ((b >> lg_half) << (lg_half + 1)) | (b & (half - 1));
@@ -411,7 +445,7 @@ __global__ void k_mobius_stage(void* data, size_t n, unsigned lg_half) {
 // cw[2i] = cw[2i+1] = coeff[i] * shift^{bitrev_nv(i)}: bit-reversed, zero-padded, coset-scaled DIT input with the
 // first (trivial, zero-tail) butterfly stage already applied (rs.rs:129-173 "r = 1")
 template <bool EXT>
-__global__ void k_rs_prepare(const void* coeff, void* cw, const u64* pow7, unsigned nv, unsigned L) {
+KBODY k_rs_prepare(const void* coeff, void* cw, const u64* pow7, unsigned nv, unsigned L) {
   size_t n = size_t(1) << nv;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     size_t j = __brevll((unsigned long long)i) >> (64 - nv);
@@ -422,7 +456,7 @@ __global__ void k_rs_prepare(const void* coeff, void* cw, const u64* pow7, unsig
 }
 // one radix-2 DIT stage; twiddle w_{2^(lg_half+1)}^j = tw[j << (L - lg_half)], tw[i] = w_{2^(L+1)}^i
 template <bool EXT>
-__global__ void k_ntt_stage(void* data, size_t N, unsigned lg_half, const u64* tw, unsigned L) {
+KBODY k_ntt_stage(void* data, size_t N, unsigned lg_half, const u64* tw, unsigned L) {
   size_t half = size_t(1) << lg_half;
   for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < N / 2; b += (size_t)gridDim.x * blockDim.x) {
     size_t j = b & (half - 1);
@@ -433,7 +467,7 @@ __global__ void k_ntt_stage(void* data, size_t N, unsigned lg_half, const u64* t
   }
 }
 template <bool EXT>
-__global__ void k_bitrev(void* dst, const void* src, unsigned lg) {
+KBODY k_bitrev(void* dst, const void* src, unsigned lg) {
   size_t n = size_t(1) << lg;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     size_t j = lg ? (__brevll((unsigned long long)i) >> (64 - lg)) : 0;
@@ -444,7 +478,7 @@ __global__ void k_bitrev(void* dst, const void* src, unsigned lg) {
 // ------------------------------------------------------------------------------------------------ Merkle (K8)
 // layer 0: digest = the two leaves verbatim (hash_or_noop on <= 4 base elements)
 template <bool EXT>
-__global__ void k_merkle_leaves(const void* leaves, u64* nodes, size_t npairs) {
+KBODY k_merkle_leaves(const void* leaves, u64* nodes, size_t npairs) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npairs; i += (size_t)gridDim.x * blockDim.x) {
     u64 d0, d1, d2, d3;
     if (EXT) { Ext a = ((const Ext*)leaves)[2 * i], b = ((const Ext*)leaves)[2 * i + 1]; d0 = a.c0; d1 = a.c1; d2 = b.c0; d3 = b.c1; }
@@ -454,7 +488,7 @@ __global__ void k_merkle_leaves(const void* leaves, u64* nodes, size_t npairs) {
   }
 }
 // one Poseidon2 compress (2 permutations) per lane; state held in 8 VGPR pairs, round constants in constant memory
-__global__ void k_merkle_layer(const u64* in, u64* out, size_t cnt) {
+KBODY k_merkle_layer(const u64* in, u64* out, size_t cnt) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cnt; i += (size_t)gridDim.x * blockDim.x) {
     const ulonglong2* p = (const ulonglong2*)(in + 8 * i);
     ulonglong2 x01 = p[0], x23 = p[1], y01 = p[2], y23 = p[3];
@@ -469,7 +503,7 @@ __global__ void k_merkle_layer(const u64* in, u64* out, size_t cnt) {
 // ------------------------------------------------------------------------------------------------ Basefold opening (K9-K12, K14)
 struct PolyDesc { const void* f; const Ext* eq; Ext* fout; Ext* eqout; size_t n; int fext; int pad; };
 // fold every (f, eq) pair of length > 1 by r; blockIdx.y = polynomial
-__global__ void k_classic_fold(const PolyDesc* d, Ext r) {
+KBODY k_classic_fold(const PolyDesc* d, Ext r) {
   PolyDesc p = d[blockIdx.y];
   if (p.n <= 1) return;
   size_t h = p.n / 2;
@@ -480,7 +514,7 @@ __global__ void k_classic_fold(const PolyDesc* d, Ext r) {
   }
 }
 // partial[(poly*gridDim.x + block)*2 + {0,1}]: c0 = sum f0*e0, c2 = sum (f1-f0)(e1-e0)   (coeff.rs:236-345)
-__global__ void k_classic_sums(const PolyDesc* d, Ext* partial) {
+KBODY k_classic_sums(const PolyDesc* d, Ext* partial) {
   __shared__ Ext sm[TPB / 64];
   PolyDesc p = d[blockIdx.y];
   Ext c0 = ex_zero(), c2 = ex_zero();
@@ -506,7 +540,7 @@ __global__ void k_classic_sums(const PolyDesc* d, Ext* partial) {
   r = block_reduce_ext(c0, sm); if (threadIdx.x == 0) partial[base] = r;
   r = block_reduce_ext(c2, sm); if (threadIdx.x == 0) partial[base + 1] = r;
 }
-__global__ void k_reduce_pairs(const Ext* partial, size_t nblocks, Ext* out) {
+KBODY k_reduce_pairs(const Ext* partial, size_t nblocks, Ext* out) {
   __shared__ Ext sm[TPB / 64];
   size_t poly = blockIdx.x >> 1, t = blockIdx.x & 1;
   Ext acc = ex_zero();
@@ -515,7 +549,7 @@ __global__ void k_reduce_pairs(const Ext* partial, size_t nblocks, Ext* out) {
   if (threadIdx.x == 0) out[blockIdx.x] = r;
 }
 // K11: acc[j*rep + q] += x[j] * coeff
-__global__ void k_axpy_rep(Ext* acc, const void* x, int xext, Ext coeff, size_t n_acc, unsigned lg_rep) {
+KBODY k_axpy_rep(Ext* acc, const void* x, int xext, Ext coeff, size_t n_acc, unsigned lg_rep) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_acc; i += (size_t)gridDim.x * blockDim.x) {
     size_t j = i >> lg_rep;
     Ext m = xext ? ex_mul(((const Ext*)x)[j], coeff) : ex_mul_base(coeff, ((const u64*)x)[j]);
@@ -523,7 +557,7 @@ __global__ void k_axpy_rep(Ext* acc, const void* x, int xext, Ext coeff, size_t 
   }
 }
 // K10 message on evaluation-form pairs: [sum a*ea, sum ((b-a)*ea + a*(eb-ea)), sum (b-a)(eb-ea)]
-__global__ void k_bf_msg(const Ext* f, const Ext* eq, size_t npairs, Ext* partial) {
+KBODY k_bf_msg(const Ext* f, const Ext* eq, size_t npairs, Ext* partial) {
   __shared__ Ext sm[TPB / 64];
   Ext c0 = ex_zero(), c1 = ex_zero(), c2 = ex_zero();
   for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < npairs; j += (size_t)gridDim.x * blockDim.x) {
@@ -539,7 +573,7 @@ __global__ void k_bf_msg(const Ext* f, const Ext* eq, size_t npairs, Ext* partia
   r = block_reduce_ext(c2, sm); if (threadIdx.x == 0) { partial[base + 2] = r; partial[base + 3] = ex_zero(); }
 }
 // K9: out[i] = y0 + (ch - x0)(y1 - y0) w,  x0 = gamma * w_{2^(level+1)}^{bitrev(i)},  w = -1/(2 x0)   (rs.rs:377-410)
-__global__ void k_fri_fold(const Ext* in, Ext* out, size_t nout, unsigned level, const u64* tw, unsigned L, u64 gamma, u64 neg_inv2gamma, Ext ch) {
+KBODY k_fri_fold(const Ext* in, Ext* out, size_t nout, unsigned level, const u64* tw, unsigned L, u64 gamma, u64 neg_inv2gamma, Ext ch) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nout; i += (size_t)gridDim.x * blockDim.x) {
     size_t b = level ? (__brevll((unsigned long long)i) >> (64 - level)) : 0;
     u64 root = tw[b << (L - level)];
@@ -553,7 +587,7 @@ __global__ void k_fri_fold(const Ext* in, Ext* out, size_t nout, unsigned level,
 }
 struct GatherDesc { const void* leaves; const u64* nodes; size_t nleaves; size_t p0; size_t out_off; int ext; int height; };
 // K14: one wave per (query, tree): leaf pair then the sibling digests bottom-up
-__global__ void k_query_gather(const GatherDesc* d, size_t nd, u64* out) {
+KBODY k_query_gather(const GatherDesc* d, size_t nd, u64* out) {
   size_t q = blockIdx.x * (size_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (q >= nd) return;
   int lane = threadIdx.x & 63;
@@ -636,7 +670,7 @@ __device__ __forceinline__ void p2l_compress(const u64* in, u64* out, int lane) 
   if (i < 4) out[3 - i] = s;
 }
 // one Merkle layer with 8 lanes per node: for layers too narrow to hide the latency of a one-lane compress
-__global__ void __launch_bounds__(1024) k_merkle_layer_lp(const u64* in, u64* out, size_t cnt) {
+KBODY k_merkle_layer_lp(const u64* in, u64* out, size_t cnt) {
   size_t g = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 3;
   size_t stride = ((size_t)gridDim.x * blockDim.x) >> 3;
   for (; g < cnt; g += stride) p2l_compress(in + 8 * g, out + 4 * g, threadIdx.x & 63);
@@ -644,7 +678,7 @@ __global__ void __launch_bounds__(1024) k_merkle_layer_lp(const u64* in, u64* ou
 struct TailDesc { u64* nodes; size_t off; size_t cnt; };
 // All Merkle layers above an already computed layer of `cnt` (<= 2048) digests, one workgroup per tree, no relaunch
 // between layers. Wide layers hash one node per lane, narrow ones use the 8-lane permutation. roots[4*tree..] = root.
-__global__ void __launch_bounds__(1024) k_merkle_tail(const TailDesc* d, u64* roots, u64* host_result, unsigned long long* flag, unsigned long long seq) {
+KBODY k_merkle_tail(const TailDesc* d, u64* roots, u64* host_result, unsigned long long* flag, unsigned long long seq) {
   DP_CLAIM_ALL_VGPRS();
   TailDesc t = d[blockIdx.x];
   u64* nd = t.nodes;
@@ -677,7 +711,7 @@ __global__ void __launch_bounds__(1024) k_merkle_tail(const TailDesc* d, u64* ro
 struct SmallCommitDesc { const void* evals; void* cw; void* bh; u64* nodes; void* tmp; };
 // layer 0 of many equally sized trees: blockIdx.y = tree
 template <bool EXT>
-__global__ void k_merkle_leaves_many(const SmallCommitDesc* d, size_t npairs) {
+KBODY k_merkle_leaves_many(const SmallCommitDesc* d, size_t npairs) {
   const void* leaves = d[blockIdx.y].cw;
   u64* nodes = d[blockIdx.y].nodes;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npairs; i += (size_t)gridDim.x * blockDim.x) {
@@ -705,7 +739,7 @@ template <> struct ElemOps<true> {
 // radix-2 DIT NTT on 2n points, bit-reversed store; also the bit-reversed copy of the evaluations. One workgroup per
 // polynomial (blockIdx.x), dynamic LDS = 3n elements.
 template <bool EXT>
-__global__ void __launch_bounds__(256) k_commit_small(const SmallCommitDesc* d, unsigned nv, unsigned L, const u64* tw, const u64* pow7) {
+KBODY k_commit_small(const SmallCommitDesc* d, unsigned nv, unsigned L, const u64* tw, const u64* pow7) {
   typedef typename ElemOps<EXT>::T T;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   T* A = (T*)lds_raw;  // n coefficients
@@ -755,7 +789,7 @@ __global__ void __launch_bounds__(256) k_commit_small(const SmallCommitDesc* d, 
 constexpr unsigned MED_NTT_LG = 13;  // an NTT block of 2^13 base elements (64 KB) lives in LDS
 // K5 + K6 + coset scaling: evaluations -> LDS, all Moebius stages there, then tmp[2i] = tmp[2i+1] = coeff[i] * shift^bitrev(i)
 // (the zero-padded, bit-reversed DIT input after its trivial first stage) and bh[bitrev(i)] = evals[i]
-__global__ void __launch_bounds__(1024) k_med_prepare(const SmallCommitDesc* d, unsigned nv, unsigned L, const u64* pow7) {
+KBODY k_med_prepare(const SmallCommitDesc* d, unsigned nv, unsigned L, const u64* pow7) {
   extern __shared__ __align__(16) unsigned char lds_med[];
   u64* A = (u64*)lds_med;
   SmallCommitDesc pd = d[blockIdx.x];
@@ -776,7 +810,7 @@ __global__ void __launch_bounds__(1024) k_med_prepare(const SmallCommitDesc* d, 
   }
 }
 // DIT stages 1..smax (butterfly span <= 2^MED_NTT_LG) of the 2n-point NTT, one LDS-resident block per workgroup
-__global__ void __launch_bounds__(1024) k_med_ntt_local(const SmallCommitDesc* d, unsigned lgblk, unsigned smax, const u64* tw, unsigned L) {
+KBODY k_med_ntt_local(const SmallCommitDesc* d, unsigned lgblk, unsigned smax, const u64* tw, unsigned L) {
   extern __shared__ __align__(16) unsigned char lds_med[];
   u64* B = (u64*)lds_med;
   size_t blk = size_t(1) << lgblk;
@@ -795,7 +829,7 @@ __global__ void __launch_bounds__(1024) k_med_ntt_local(const SmallCommitDesc* d
   }
   for (size_t i = tid; i < blk; i += nt) p[i] = B[i];
 }
-__global__ void k_ntt_stage_many(const SmallCommitDesc* d, size_t N, unsigned lg_half, const u64* tw, unsigned L) {
+KBODY k_ntt_stage_many(const SmallCommitDesc* d, size_t N, unsigned lg_half, const u64* tw, unsigned L) {
   u64* p = (u64*)d[blockIdx.y].tmp;
   size_t half = size_t(1) << lg_half;
   for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < N / 2; b += (size_t)gridDim.x * blockDim.x) {
@@ -804,13 +838,13 @@ __global__ void k_ntt_stage_many(const SmallCommitDesc* d, size_t N, unsigned lg
     p[lo] = gl_add(u, t); p[lo + half] = gl_sub(u, t);
   }
 }
-__global__ void k_bitrev_many(const SmallCommitDesc* d, unsigned lg) {
+KBODY k_bitrev_many(const SmallCommitDesc* d, unsigned lg) {
   const u64* src = (const u64*)d[blockIdx.y].tmp; u64* dst = (u64*)d[blockIdx.y].cw;
   size_t n = size_t(1) << lg;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[__brevll((unsigned long long)i) >> (64 - lg)] = src[i];
 }
 // one Merkle layer of many equally shaped trees (one Poseidon2 compress per lane): blockIdx.y = tree
-__global__ void k_merkle_layer_many(const TailDesc* td, size_t off, size_t cnt) {
+KBODY k_merkle_layer_many(const TailDesc* td, size_t off, size_t cnt) {
   u64* nd = td[blockIdx.y].nodes;
   const u64* in = nd + 4 * off; u64* out = nd + 4 * (off + cnt);
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cnt / 2; i += (size_t)gridDim.x * blockDim.x) {
@@ -846,7 +880,7 @@ __device__ __forceinline__ Ext block_reduce_ext_n(Ext v, Ext* sm) {
 // block-wide barriers are the one after the fold and the one before the final combine; wave 0 then writes
 // result[term*4 + t] straight into host-mapped memory and releases `flag = seq`.
 template <bool HI>
-__global__ void __launch_bounds__(1024) k_sc_small(ScSmallArgs a, Ext* result, unsigned long long* flag, unsigned long long seq) {
+KBODY k_sc_small(const ScSmallArgs& a, Ext* result, unsigned long long* flag, unsigned long long seq) {
   DP_CLAIM_ALL_VGPRS();
   __shared__ Ext part[64 * SC_SLOTS];  // [slot][t], slot = term * wpt + sub  (<= 64 slots)
   int tid = threadIdx.x, nt = blockDim.x;
@@ -877,6 +911,107 @@ __global__ void __launch_bounds__(1024) k_sc_small(ScSmallArgs a, Ext* result, u
   }
   __syncthreads();
   if (wave == 0) sc_publish_fwd(result, part, a.k, a.off, a.nterms, wpt, flag, seq, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ device-side Fiat-Shamir
+// With many proofs in flight the per-round trip to the host (publish the round sums, the host runs the sponge, the kernel
+// polls the mailbox) is what a proof spends its time on: the host threads serve several proofs each and every hop crosses
+// PCIe. A persistent sumcheck can instead keep the transcript to itself: it gets the sponge state of the host transcript
+// (DuplexChallenger<F,P,8,4>, poseidon/src/challenger.rs:14-46 — poseidon2.h `Challenger`), combines the term sums into the
+// round message exactly as sumcheck_prove does (coefficients, extrapolation to max_degree + 1 points: prover.rs:498-585),
+// absorbs it, squeezes the challenge (transcript/src/basic.rs:8-54) and goes on; at the end ONE publication carries all
+// round messages, all challenges, the final evaluations and the sponge state back to the host transcript.
+// Field arithmetic is exact and canonical, so the messages and challenges are the host's bit for bit.
+// The sponge runs on wave 0 with the lane-parallel permutation (p2l_permute: state[i] in lane i of every group of 8).
+struct ScFsArgs {
+  u64 state[8]; u64 in_buf[4]; int in_len, out_len;  // the host Challenger at the start of the first round
+  int md, rounds;                                    // max_degree of the virtual polynomial, rounds the kernel runs
+  u64 label[2]; int nlabel, pad;                     // "Internal round" as transcript words
+  Ext coeff[MAX_TERMS];                              // coefficient of every product term
+};
+__constant__ u64 c_extrap[(SC_MAXK + 1) * (SC_MAXK + 1) * (SC_MAXK + 1)];  // [k][at][i]: extrapolation_coeffs(k, at)[i] of sumcheck.h
+struct WaveChallenger { u64 st, ib; int in_len, out_len; };
+__device__ __forceinline__ void wc_duplex(WaveChallenger& c, int lane) {
+  if ((lane & 7) < c.in_len) c.st = c.ib;
+  c.in_len = 0;
+  c.st = p2l_permute(c.st, lane);
+  c.out_len = 4;
+}
+__device__ __forceinline__ void wc_observe(WaveChallenger& c, u64 v, int lane) {  // v uniform over the wave
+  c.out_len = 0;
+  if ((lane & 7) == c.in_len) c.ib = v;
+  if (++c.in_len == 4) wc_duplex(c, lane);
+}
+__device__ __forceinline__ u64 wc_sample(WaveChallenger& c, int lane) {
+  if (c.in_len != 0 || c.out_len == 0) wc_duplex(c, lane);
+  --c.out_len;
+  return shfl_u64(c.st, c.out_len);
+}
+__device__ __forceinline__ Ext sc_term_sum(const Ext* part, int term, int t, int wpt) {
+  if (wpt == 1) return part[(size_t)term * SC_SLOTS + t];
+  Ext v = ex_zero();
+  for (int sb = 0; sb < wpt; sb++) v = ex_add(v, part[(size_t)(term * wpt + sb) * SC_SLOTS + t]);
+  return v;
+}
+// host result area of a device-driven sumcheck, in words: [rounds x (md+1) message values][rounds challenges][ntabs finals][14 sponge words]
+__device__ __forceinline__ size_t fs_msg_word(const ScFsArgs& f, int round, int j) { return ((size_t)round * (f.md + 1) + j) * 2; }
+__device__ __forceinline__ size_t fs_chal_word(const ScFsArgs& f, int round) { return ((size_t)f.rounds * (f.md + 1) + round) * 2; }
+__device__ __forceinline__ size_t fs_final_word(const ScFsArgs& f) { return ((size_t)f.rounds * (f.md + 2)) * 2; }
+// One round on wave 0 (all 64 lanes): part[] holds the raw term sums. Returns the challenge; `cs` accumulates the checksum
+// of the words this lane has sent to the host.
+__device__ __forceinline__ Ext sc_fs_round(WaveChallenger& wc, const ScFsArgs& f, const Ext* part, const int* tk, int nterms, int wpt, u64* rw, int round, unsigned long long& cs, int lane) {
+  const int j = lane & 7, tg = lane >> 3;
+  Ext acc = ex_zero();
+  if (j <= f.md) {
+    for (int t = tg; t < nterms; t += 8) {
+      int k = tk[t];
+      Ext v;
+      if (j <= k) v = sc_term_sum(part, t, j, wpt);
+      else {
+        const u64* c = c_extrap + ((size_t)k * (SC_MAXK + 1) + j) * (SC_MAXK + 1);
+        v = ex_zero();
+        for (int i = 0; i <= k; i++) v = ex_add(v, ex_mul_base(sc_term_sum(part, t, i, wpt), c[i]));
+      }
+      acc = ex_add(acc, ex_mul(v, f.coeff[t]));
+    }
+  }
+#pragma unroll
+  for (int d = 8; d <= 32; d <<= 1) {
+    Ext o = ex(shfl_u64(acc.c0, lane ^ d), shfl_u64(acc.c1, lane ^ d));
+    acc = ex_add(acc, o);
+  }
+  for (int jj = 0; jj <= f.md; jj++) {
+    u64 c0 = shfl_u64(acc.c0, jj), c1 = shfl_u64(acc.c1, jj);
+    wc_observe(wc, c0, lane); wc_observe(wc, c1, lane);
+    if (lane == 0) { size_t w = fs_msg_word(f, round, jj); pub_store(rw + w, c0); pub_store(rw + w + 1, c1); cs += (unsigned long long)(w + 1) * c0 + (unsigned long long)(w + 2) * c1; }
+  }
+  for (int q = 0; q < f.nlabel; q++) wc_observe(wc, f.label[q], lane);
+  u64 r0 = wc_sample(wc, lane), r1 = wc_sample(wc, lane);
+  if (lane == 0) { size_t w = fs_chal_word(f, round); pub_store(rw + w, r0); pub_store(rw + w + 1, r1); cs += (unsigned long long)(w + 1) * r0 + (unsigned long long)(w + 2) * r1; }
+  return ex(r0, r1);
+}
+// the last message of a device-driven sumcheck: final evaluation of every table (src[e * stride]), the sponge, the tag
+__device__ __forceinline__ void sc_fs_finish(const WaveChallenger& wc, const ScFsArgs& f, const Ext* const* srcs, const Ext* src, size_t stride, int ntabs, u64* rw, unsigned long long* flag, unsigned long long seq, unsigned long long cs, int lane) {
+  size_t w0 = fs_final_word(f);
+  for (int e = lane; e < ntabs; e += 64) {
+    Ext v = srcs ? srcs[e][0] : src[(size_t)e * stride];
+    size_t w = w0 + 2 * e;
+    pub_store(rw + w, v.c0); pub_store(rw + w + 1, v.c1);
+    cs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1;
+  }
+  size_t ws = w0 + 2 * (size_t)ntabs;
+  if (lane < 8) { pub_store(rw + ws + lane, wc.st); cs += (unsigned long long)(ws + lane + 1) * wc.st; }
+  if (lane < 4) { u64 v = lane < wc.in_len ? wc.ib : 0; pub_store(rw + ws + 8 + lane, v); cs += (unsigned long long)(ws + 8 + lane + 1) * v; }
+  if (lane == 0) {
+    u64 a = (u64)wc.in_len, b = (u64)wc.out_len;
+    pub_store(rw + ws + 12, a); pub_store(rw + ws + 13, b);
+    cs += (unsigned long long)(ws + 13) * a + (unsigned long long)(ws + 14) * b;
+  }
+  cs = pub_wave_sum(cs);
+  if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + cs);
+}
+__device__ __forceinline__ void wc_load(WaveChallenger& wc, const ScFsArgs& f, int lane) {
+  wc.st = f.state[lane & 7]; wc.ib = f.in_buf[lane & 3]; wc.in_len = f.in_len; wc.out_len = f.out_len;
 }
 
 // ------------------------------------------------------------------------------------------------ persistent sumcheck
@@ -916,7 +1051,7 @@ __device__ __forceinline__ void sc_fold_all(const ScPersistArgs& a, const void* 
   }
 }
 template <bool HI>
-__global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* result, unsigned long long* flag, const unsigned long long* mailbox, unsigned long long seq0) {
+KBODY k_sc_persist(const ScPersistArgs& a, Ext* result, unsigned long long* flag, const unsigned long long* mailbox, unsigned long long seq0, const ScFsArgs* fs) {
   DP_CLAIM_ALL_VGPRS();
   __shared__ Ext part[64 * SC_SLOTS];
   __shared__ unsigned long long chal[3];
@@ -924,8 +1059,11 @@ __global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* resul
   __shared__ int cur_ext[MAX_TABS];
   __shared__ Ext* dstA[MAX_TABS];
   __shared__ Ext* dstB[MAX_TABS];
+  __shared__ ScFsArgs fsl;
   int tid = threadIdx.x, nt = blockDim.x;
   int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
+  const bool autofs = fs != nullptr;  // device-side Fiat-Shamir (single workgroup only): no host round trips
+  if (autofs) for (int i = tid; i < (int)(sizeof(ScFsArgs) / 8); i += nt) ((u64*)&fsl)[i] = ((const u64*)fs)[i];
   if (a.eq_tab >= 0) wg_build_eq((Ext*)a.in[a.eq_tab], a.eq_pt, a.eq_k);
   const size_t g = blockIdx.x;
   size_t n = a.n0 / (size_t)a.nwg;  // local slice length
@@ -936,6 +1074,9 @@ __global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* resul
   __syncthreads();
   unsigned long long seq = seq0;
   bool useA = true;
+  WaveChallenger wc; wc.st = wc.ib = 0; wc.in_len = wc.out_len = 0;
+  if (autofs) wc_load(wc, fsl, lane);
+  unsigned long long fcs = 0; int round = 0;
   if (a.has_r0) {
     sc_fold_all(a, cur, cur_ext, dstA, n / 2, a.r0);
     __syncthreads();
@@ -961,7 +1102,11 @@ __global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* resul
     }
     __syncthreads();
     ++seq;
-    if (wave == 0) { sc_publish_fwd(result, part, a.k, a.off, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge_fwd(mailbox, seq, chal); }
+    if (wave == 0) {
+      if (autofs) { Ext rr = sc_fs_round(wc, fsl, part, a.k, a.nterms, wpt, (u64*)result, round, fcs, lane); if (lane == 0) { chal[0] = 1; chal[1] = rr.c0; chal[2] = rr.c1; } }
+      else { sc_publish_fwd(result, part, a.k, a.off, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge_fwd(mailbox, seq, chal); }
+    }
+    round++;
     __syncthreads();
     if (chal[0] == 0) {  // host never answered: publish an abort marker and leave
       if (tid == 0) pub_store((u64*)flag, ~0ull);
@@ -983,7 +1128,8 @@ __global__ void __launch_bounds__(1024) k_sc_persist(ScPersistArgs a, Ext* resul
     if (++folds == a.rounds_a) return;  // end of the multi-workgroup phase: the compact folded tables are complete
     if (n == 1) {
       ++seq;
-      if (wave == 0) {
+      if (wave == 0 && autofs) sc_fs_finish(wc, fsl, (const Ext* const*)cur, nullptr, 0, a.ntabs, (u64*)result, flag, seq0 + 1, fcs, lane);
+      else if (wave == 0) {
         unsigned long long cs = 0; u64* rw = (u64*)result;
         for (int e = lane; e < a.ntabs; e += 64) { Ext v = ((const Ext*)cur[e])[0]; pub_store(rw + 2 * e, v.c0); pub_store(rw + 2 * e + 1, v.c1); cs += (unsigned long long)(2 * e + 1) * v.c0 + (unsigned long long)(2 * e + 2) * v.c1; }
         cs = pub_wave_sum(cs);
@@ -1046,15 +1192,21 @@ __device__ __forceinline__ void sc_wait_challenge(const unsigned long long* mail
 __device__ void sc_publish_fwd(Ext* result, const Ext* part, const int* tk, const int* toff, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane) { sc_publish(result, part, tk, toff, nterms, wpt, flag, seq, lane); }
 __device__ void sc_wait_challenge_fwd(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal) { sc_wait_challenge(mailbox, seq, chal); }
 template <bool HI>
-__global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* result, unsigned long long* flag, const unsigned long long* mailbox, unsigned long long seq0) {
+KBODY k_sc_persist_lds(const ScPersistArgs& a, Ext* result, unsigned long long* flag, const unsigned long long* mailbox, unsigned long long seq0, const ScFsArgs* fs) {
   DP_CLAIM_ALL_VGPRS();
   extern __shared__ __align__(16) unsigned char lds_dyn[];
   Ext* L = (Ext*)lds_dyn;
   __shared__ Ext part[64 * SC_SLOTS];
   __shared__ unsigned long long chal[3];
+  __shared__ ScFsArgs fsl;
   int tid = threadIdx.x, nt = blockDim.x;
   int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
   int wpt = a.nterms >= W ? 1 : W / a.nterms;
+  const bool autofs = fs != nullptr;  // device-side Fiat-Shamir: no host round trips
+  if (autofs) { for (int i = tid; i < (int)(sizeof(ScFsArgs) / 8); i += nt) ((u64*)&fsl)[i] = ((const u64*)fs)[i]; __syncthreads(); }
+  WaveChallenger wc; wc.st = wc.ib = 0; wc.in_len = wc.out_len = 0;
+  if (autofs) wc_load(wc, fsl, lane);
+  unsigned long long fcs = 0; int round = 0;
   if (a.eq_tab >= 0) wg_build_eq((Ext*)a.in[a.eq_tab], a.eq_pt, a.eq_k);
   unsigned long long seq = seq0;
   size_t first = a.n0 / 2;
@@ -1079,7 +1231,11 @@ __global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* r
     }
     __syncthreads();
     ++seq;
-    if (wave == 0) { sc_publish(result, part, a.k, a.off, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge(mailbox, seq, chal); }
+    if (wave == 0) {
+      if (autofs) { Ext rr = sc_fs_round(wc, fsl, part, a.k, a.nterms, wpt, (u64*)result, round, fcs, lane); if (lane == 0) { chal[0] = 1; chal[1] = rr.c0; chal[2] = rr.c1; } }
+      else { sc_publish(result, part, a.k, a.off, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge(mailbox, seq, chal); }
+    }
+    round++;
     __syncthreads();
     if (chal[0] == 0) { if (tid == 0) pub_store((u64*)flag, ~0ull); return; }
     r = ex(chal[1], chal[2]);
@@ -1098,7 +1254,8 @@ __global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* r
     if (m == 1) {
       ++seq;
       if (tid == 0 && a.dbg) { atomicAdd(a.dbg + 0, c_fold); atomicAdd(a.dbg + 1, c_sums); atomicAdd(a.dbg + 2, c_pub); atomicAdd(a.dbg + 3, c_wait); atomicAdd(a.dbg + 4, c_rounds); }
-      if (wave == 0) sc_publish_vals(result, L, size_t(1) << lgf, a.ntabs, flag, seq, lane);
+      if (wave == 0 && autofs) sc_fs_finish(wc, fsl, nullptr, L, size_t(1) << lgf, a.ntabs, (u64*)result, flag, seq0 + 1, fcs, lane);
+      else if (wave == 0) sc_publish_vals(result, L, size_t(1) << lgf, a.ntabs, flag, seq, lane);
       return;
     }
     size_t h = m / 2;
@@ -1119,12 +1276,17 @@ __global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* r
     __syncthreads();
     ++seq;
     if (tid == 0) { unsigned long long now = clock64(); c_sums += now - tk; tk = now; }
-    if (wave == 0) {
+    if (wave == 0 && autofs) {
+      Ext rr = sc_fs_round(wc, fsl, part, a.k, a.nterms, wpt, (u64*)result, round, fcs, lane);
+      if (lane == 0) { chal[0] = 1; chal[1] = rr.c0; chal[2] = rr.c1; }
+      if (tid == 0) { unsigned long long now = clock64(); c_wait += now - tk; tk = now; c_rounds++; }
+    } else if (wave == 0) {
       sc_publish(result, part, a.k, a.off, a.nterms, wpt, flag, seq, lane);
       if (tid == 0) { unsigned long long now = clock64(); c_pub += now - tk; tk = now; }
       if (lane == 0) sc_wait_challenge(mailbox, seq, chal);
       if (tid == 0) { unsigned long long now = clock64(); c_wait += now - tk; tk = now; c_rounds++; }
     }
+    round++;
     __syncthreads();
     if (chal[0] == 0) { if (tid == 0) pub_store((u64*)flag, ~0ull); return; }
     r = ex(chal[1], chal[2]);
@@ -1142,7 +1304,7 @@ __global__ void __launch_bounds__(1024) k_sc_persist_lds(ScPersistArgs a, Ext* r
 // out[e] = sum_{b < nblocks} partial[(e / inner) * nblocks * inner + b * inner + (e % inner)], e < nout, computed by ONE
 // workgroup (wave w owns outputs w, w+W, ..) and published straight to host-mapped memory with the tag protocol: the
 // second stage of every block-partial reduction needs neither a separate publish launch nor a stream synchronisation.
-__global__ void __launch_bounds__(1024) k_reduce_publish(const Ext* partial, size_t nblocks, size_t inner, int nout, Ext* result, unsigned long long* flag, unsigned long long seq) {
+KBODY k_reduce_publish(const Ext* partial, size_t nblocks, size_t inner, int nout, Ext* result, unsigned long long* flag, unsigned long long seq) {
   __shared__ Ext res[1024];
   int tid = threadIdx.x, W = blockDim.x >> 6, wave = tid >> 6, lane = tid & 63;
   for (int e = wave; e < nout; e += W) {
@@ -1155,21 +1317,122 @@ __global__ void __launch_bounds__(1024) k_reduce_publish(const Ext* partial, siz
   __syncthreads();
   if (wave == 0) sc_publish_vals(result, res, 1, nout, flag, seq, lane);
 }
+// ---- work-proportional grids for batched kernels over items of very different sizes ------------------------------------
+// blockIdx.y = item wastes most of a launch when one item is 2^20 long and thirty others are 2^10 (every empty workgroup
+// still has to fetch its descriptor before it can leave). Instead the grid is 1-D and `first[i] .. first[i+1]` are the
+// workgroups of item i (first[] sits in front of the descriptors, n + 1 entries): one coalesced load finds the owner.
+__device__ __forceinline__ int seg_find(const unsigned* first, int n, int* slot) {
+  if (threadIdx.x < 64) {
+    for (int base = 0; base < n; base += 64) {
+      int i = base + (int)threadIdx.x;
+      bool mine = i < n && first[i] <= blockIdx.x && blockIdx.x < first[i + 1];
+      if (mine) *slot = i;
+    }
+  }
+  __syncthreads();
+  return *slot;
+}
+// One round of the batch-opening sumcheck (sum_check/classic.rs:232-285, coeff.rs:198-345) over every (f, eq) pair in one
+// launch: fold both tables by r (if has_r and the pair is longer than 1; the folded tables go to fout / eqout) and, in the
+// same pass, the two sums of the FOLDED pair the next message needs: c0 = sum f0 e0, c2 = sum (f1 - f0)(e1 - e0).
+// partial[2 * workgroup + {0,1}]; k_classic_reduce adds the workgroups of each pair and publishes.
+struct ClassicDesc { const void* f; const Ext* eq; Ext* fout; Ext* eqout; size_t n; int fext; int pad; };
+KBODY k_classic_fused(const unsigned* first, const ClassicDesc* d, int np, Ext r, int has_r, Ext* partial) {
+  __shared__ Ext sm[TPB / 64];
+  __shared__ int slot;
+  const int pi = seg_find(first, np, &slot);
+  const ClassicDesc p = d[pi];
+  const size_t b = blockIdx.x - first[pi], nb = first[pi + 1] - first[pi];
+  Ext c0 = ex_zero(), c2 = ex_zero();
+  if (has_r && p.n > 1) {
+    const size_t h = p.n / 2;  // length after the fold
+    if (h == 1) {
+      if (b == 0 && threadIdx.x == 0) {
+        Ext f = p.fext ? ex_lerp(((const Ext*)p.f)[0], ((const Ext*)p.f)[1], r) : ex_lerp_base(((const u64*)p.f)[0], ((const u64*)p.f)[1], r);
+        Ext e = ex_lerp(p.eq[0], p.eq[1], r);
+        p.fout[0] = f; p.eqout[0] = e;
+        c0 = ex_mul(f, e);
+      }
+    } else {
+      for (size_t j = b * blockDim.x + threadIdx.x; j < h / 2; j += nb * blockDim.x) {
+        Ext f0, f1;
+        if (p.fext) { const Ext* q = (const Ext*)p.f + 4 * j; f0 = ex_lerp(q[0], q[1], r); f1 = ex_lerp(q[2], q[3], r); }
+        else { const u64* q = (const u64*)p.f + 4 * j; f0 = ex_lerp_base(q[0], q[1], r); f1 = ex_lerp_base(q[2], q[3], r); }
+        const Ext* qe = p.eq + 4 * j;
+        Ext e0 = ex_lerp(qe[0], qe[1], r), e1 = ex_lerp(qe[2], qe[3], r);
+        p.fout[2 * j] = f0; p.fout[2 * j + 1] = f1; p.eqout[2 * j] = e0; p.eqout[2 * j + 1] = e1;
+        c0 = ex_add(c0, ex_mul(f0, e0));
+        c2 = ex_add(c2, ex_mul(ex_sub(f1, f0), ex_sub(e1, e0)));
+      }
+    }
+  } else if (p.n == 1) {
+    if (b == 0 && threadIdx.x == 0) c0 = ex_mul(ld_elem(p.f, p.fext, 0), p.eq[0]);
+  } else {
+    for (size_t j = b * blockDim.x + threadIdx.x; j < p.n / 2; j += nb * blockDim.x) {
+      Ext l0 = p.eq[2 * j], l1 = p.eq[2 * j + 1];
+      if (p.fext) {
+        Ext r0 = ((const Ext*)p.f)[2 * j], r1 = ((const Ext*)p.f)[2 * j + 1];
+        c0 = ex_add(c0, ex_mul(l0, r0));
+        c2 = ex_add(c2, ex_mul(ex_sub(l1, l0), ex_sub(r1, r0)));
+      } else {
+        u64 r0 = ((const u64*)p.f)[2 * j], r1 = ((const u64*)p.f)[2 * j + 1];
+        c0 = ex_add(c0, ex_mul_base(l0, r0));
+        c2 = ex_add(c2, ex_mul_base(ex_sub(l1, l0), gl_sub(r1, r0)));
+      }
+    }
+  }
+  Ext t;
+  t = block_reduce_ext(c0, sm); if (threadIdx.x == 0) partial[2 * (size_t)blockIdx.x] = t;
+  t = block_reduce_ext(c2, sm); if (threadIdx.x == 0) partial[2 * (size_t)blockIdx.x + 1] = t;
+}
+// out[2 i + t] = sum over the workgroups of pair i of partial[2 w + t], published to the host (np <= 512)
+KBODY k_classic_reduce(const unsigned* first, int np, const Ext* partial, Ext* result, unsigned long long* flag, unsigned long long seq) {
+  __shared__ Ext res[1024];
+  int tid = threadIdx.x, W = blockDim.x >> 6, wave = tid >> 6, lane = tid & 63;
+  for (int i = wave; i < np; i += W) {
+    Ext a0 = ex_zero(), a2 = ex_zero();
+    for (unsigned w = first[i] + lane; w < first[i + 1]; w += 64) { a0 = ex_add(a0, partial[2 * (size_t)w]); a2 = ex_add(a2, partial[2 * (size_t)w + 1]); }
+    a0 = wave_reduce_ext(a0); a2 = wave_reduce_ext(a2);
+    if (lane == 0) { res[2 * i] = a0; res[2 * i + 1] = a2; }
+  }
+  __syncthreads();
+  if (wave == 0) sc_publish_vals(result, res, 1, 2 * np, flag, seq, lane);
+}
 struct EqDesc { Ext* out; unsigned k; unsigned pad; Ext pt[MAX_PT]; };
 // many eq tables in one launch: blockIdx.y selects the table (batch_open builds one per opened polynomial)
-__global__ void k_eq_table_many(const EqDesc* d) {
-  const EqDesc& e = d[blockIdx.y];
-  size_t n = size_t(1) << e.k;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+// eq(i, pt) = lo[i mod 2^kl] * hi[i >> kl]: a workgroup owns EQ_CHUNK consecutive entries of one table, builds the 2^kl
+// low-part products (kl <= 8) and its EQ_CHUNK / 2^kl high-part products in LDS, then spends ONE multiplication per entry
+// instead of k. (Products in the field are exact: the entries are those of build_eq_x_r_vec bit for bit.)
+constexpr unsigned EQ_CHUNK = 4096;
+KBODY k_eq_table_many(const unsigned* first, const EqDesc* d, int nd) {
+  __shared__ Ext lo[256];
+  __shared__ Ext hi[EQ_CHUNK / 256 > 16 ? EQ_CHUNK / 256 : 16];
+  __shared__ int slot;
+  const int di = seg_find(first, nd, &slot);
+  const EqDesc& e = d[di];
+  const size_t n = size_t(1) << e.k;
+  const unsigned kl = e.k < 8 ? e.k : 8;
+  const size_t base = (size_t)(blockIdx.x - first[di]) * EQ_CHUNK;
+  const size_t cnt = n - base < EQ_CHUNK ? n - base : EQ_CHUNK;   // entries of this workgroup (a multiple of 2^kl)
+  if (threadIdx.x < (1u << kl)) {
     Ext v = ex_one();
-    for (unsigned t = 0; t < e.k; t++) { Ext r = e.pt[t]; v = ex_mul(v, ((i >> t) & 1) ? r : ex_sub(ex_one(), r)); }
-    e.out[i] = v;
+    for (unsigned t = 0; t < kl; t++) { Ext r = e.pt[t]; v = ex_mul(v, ((threadIdx.x >> t) & 1) ? r : ex_sub(ex_one(), r)); }
+    lo[threadIdx.x] = v;
   }
+  const size_t nhi = cnt >> kl;
+  if (threadIdx.x < nhi) {
+    size_t h = (base >> kl) + threadIdx.x;
+    Ext v = ex_one();
+    for (unsigned t = kl; t < e.k; t++) { Ext r = e.pt[t]; v = ex_mul(v, ((h >> (t - kl)) & 1) ? r : ex_sub(ex_one(), r)); }
+    hi[threadIdx.x] = v;
+  }
+  __syncthreads();
+  for (size_t q = threadIdx.x; q < cnt; q += blockDim.x) e.out[base + q] = ex_mul(lo[q & ((size_t(1) << kl) - 1)], hi[q >> kl]);
 }
 struct AxpyDesc { const void* x; int xext; unsigned lg_rep; size_t n_x; Ext coeff; };
 // acc[i] = init[i] (or 0) + sum_d x_d[i >> lg_rep_d] * coeff_d over all descriptors (K11: every codeword / evaluation table merged into
 // the running oracle in ONE pass over acc instead of one launch and one read-modify-write of acc per polynomial)
-__global__ void k_axpy_many(Ext* acc, const Ext* init, size_t n_acc, const AxpyDesc* d, int nd) {
+KBODY k_axpy_many(Ext* acc, const Ext* init, size_t n_acc, const AxpyDesc* d, int nd) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_acc; i += (size_t)gridDim.x * blockDim.x) {
     Ext a = init ? init[i] : ex_zero();
     for (int q = 0; q < nd; q++) {
@@ -1181,7 +1444,7 @@ __global__ void k_axpy_many(Ext* acc, const Ext* init, size_t n_acc, const AxpyD
   }
 }
 // last fold of a sumcheck, results published directly
-__global__ void k_finish_publish(FoldArgs a, Ext r, int ntabs, Ext* result, unsigned long long* flag, unsigned long long seq) {
+KBODY k_finish_publish(const FoldArgs& a, Ext r, int ntabs, Ext* result, unsigned long long* flag, unsigned long long seq) {
   __shared__ Ext res[MAX_TABS];
   int t = threadIdx.x;
   if (t < ntabs) {
@@ -1196,7 +1459,7 @@ __global__ void k_finish_publish(FoldArgs a, Ext r, int ntabs, Ext* result, unsi
 
 // copy a small device result into host-mapped memory and publish it
 // (launched with ONE wave so that payload stores and the releasing flag store come from the same wave)
-__global__ void k_publish(const u64* src, u64* dst, size_t nwords, unsigned long long* flag, unsigned long long seq) {
+KBODY k_publish(const u64* src, u64* dst, size_t nwords, unsigned long long* flag, unsigned long long seq) {
   unsigned long long cs = 0;
   for (size_t i = threadIdx.x; i < nwords; i += blockDim.x) { u64 v = src[i]; pub_store(dst + i, v); cs += (unsigned long long)(i + 1) * v; }
   cs = pub_wave_sum(cs);
@@ -1215,18 +1478,132 @@ static inline int grid_for(size_t n, int cap = 2048) {
 }
 
 struct ProfRec { const char* name; double bytes; hipEvent_t a, b; };
-#define DPL_LDS(kern, grid, block, lds, ...) do { prof_begin(#kern); LaunchTimer lt_(this); hipLaunchKernelGGL(kern, grid, block, lds, s_, __VA_ARGS__); lt_.stop(); prof_end(); } while (0)
+// every launch of this file goes through HipDev::launch_: kg<Body> on the context's own stream, or — when the context is a
+// member of a cohort — an argument pack handed to the cohort, which launches kc<Body> once for all its members
+#define DPL_B(kern, maxt, grid, block, lds, ...) do { prof_begin(#kern); LaunchTimer lt_(this); launch_<kern, maxt>(KArgs<decltype(&kern)>(), #kern, grid, block, lds, __VA_ARGS__); lt_.stop(); prof_end(); } while (0)
+#define DPL(kern, grid, block, ...) DPL_B(kern, 1024, grid, block, 0, __VA_ARGS__)
+#define DPL_LDS(kern, grid, block, lds, ...) DPL_B(kern, 1024, grid, block, lds, __VA_ARGS__)
 #define DPL_HI(kern, hi, grid, block, ...) do { if (hi) { DPL((kern<true>), grid, block, __VA_ARGS__); } else { DPL((kern<false>), grid, block, __VA_ARGS__); } } while (0)
 #define DPL_LDS_HI(kern, hi, grid, block, lds, ...) do { if (hi) { DPL_LDS((kern<true>), grid, block, lds, __VA_ARGS__); } else { DPL_LDS((kern<false>), grid, block, lds, __VA_ARGS__); } } while (0)
-#define DPL(kern, grid, block, ...) do { prof_begin(#kern); LaunchTimer lt_(this); hipLaunchKernelGGL(kern, grid, block, 0, s_, __VA_ARGS__); lt_.stop(); prof_end(); for (int xl_ = 0; xl_ < g_extra_launches; xl_++) hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, s_); } while (0)
+#define DP_SET_LDS(kern, maxt, bytes) set_lds_<kern, maxt>(KArgs<decltype(&kern)>(), (int)(bytes))
 
 static const bool g_host_stats = getenv("DP_TIMING") && atoi(getenv("DP_TIMING"));
-// experiment knob: DP_EXTRA_LAUNCHES=n queues n empty kernels after every real one (is throughput bound by the number of launches?)
-static const int g_extra_launches = getenv("DP_EXTRA_LAUNCHES") ? atoi(getenv("DP_EXTRA_LAUNCHES")) : 0;
-__global__ void k_noop() {}
+
+// ------------------------------------------------------------------------------------------------ cohorts
+// A cohort is a set of proofs of the SAME model proved in lock step on one stream by one host thread (each proof a fiber,
+// fiber.h). Proofs of one model issue the same sequence of launches with the same shapes — only pointers and challenges
+// differ — so launch number i of every member is merged into ONE kc<Body> launch with gridDim.z = members: the per-launch
+// costs of the command processor (dispatch, barrier, end-of-kernel cache maintenance — what bounds a GPU that serves two
+// dozen independent streams of tiny kernels) are paid once per cohort step instead of once per proof step.
+// A member never blocks at a launch: it drops its argument pack and goes on to its next wait (where it yields to the next
+// member); whoever completes a launch's set of packs fires it. Everything is driven from the cohort's one host thread.
+struct Cohort {
+  struct Pending {
+    void (*fire)(const Pending&, hipStream_t);  // also the identity of the kernel (one instantiation per Body)
+    const char* name;
+    dim3 g, b; size_t lds, pack_bytes;
+    char* packs; const char* packs_dev;
+    int count, expected;
+    size_t ring_begin, ring_end;
+  };
+  hipStream_t s = nullptr;
+  int members = 0;  // proofs currently in the cohort
+  char* ring = nullptr; const char* ring_dev = nullptr;
+  size_t ring_cap = 0, ring_off = 0;
+  std::deque<Pending> q; size_t q_base = 0;            // q[i] = launch number q_base + i of the common sequence, not yet fired
+  std::deque<std::pair<size_t, size_t>> inflight;      // (launch number, ring_begin) of fired launches not known to have run
+  size_t executed = 0;                                 // every launch number < executed has run to completion
+  size_t nfired = 0, npacks = 0;
+
+  explicit Cohort(size_t ring_bytes = size_t(32) << 20) : ring_cap(ring_bytes) {
+    HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    HIP_CHECK(hipHostMalloc((void**)&ring, ring_cap, hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_CHECK(hipHostGetDevicePointer((void**)&ring_dev, ring, 0));
+  }
+  ~Cohort() { if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); } if (ring) hipHostFree(ring); }
+  Cohort(const Cohort&) = delete;
+  Cohort& operator=(const Cohort&) = delete;
+
+  // ring space for `bytes` (virtual offsets grow monotonically; physical = virtual mod capacity, regions never straddle
+  // the end), never overlapping a region a launch may still read: those of unfired launches and of fired launches not yet
+  // known to have run
+  size_t ring_take(size_t bytes) {
+    bytes = (bytes + 63) & ~size_t(63);
+    while (!inflight.empty() && inflight.front().first < executed) inflight.pop_front();
+    size_t head = ring_off;
+    if (head % ring_cap + bytes > ring_cap) head += ring_cap - head % ring_cap;
+    size_t tail = !inflight.empty() ? inflight.front().second : !q.empty() ? q.front().ring_begin : head;
+    if (bytes > ring_cap || head + bytes - tail > ring_cap) throw DpError(DP_ERR_OOM, "cohort argument ring exhausted (DP_COHORT_RING_BYTES)");
+    ring_off = head + bytes;
+    return head;
+  }
+  // member `li`-th launch of its sequence: add its pack to launch number `li`, fire every launch whose set is complete
+  void submit(size_t li, void (*fire)(const Pending&, hipStream_t), const char* name, dim3 g, dim3 b, size_t lds, const void* pack, size_t pack_bytes) {
+    if (li < q_base) throw DpError(DP_ERR_SHAPE, std::string("cohort out of step: a member reached launch ") + name + " after it was fired (the proofs of a cohort must issue identical launch sequences)");
+    size_t k = li - q_base;
+    if (k > q.size()) throw DpError(DP_ERR_SHAPE, "cohort out of step: launch sequence gap");
+    if (k == q.size()) {
+      Pending p; p.fire = fire; p.name = name; p.g = g; p.b = b; p.lds = lds; p.pack_bytes = pack_bytes; p.count = 0; p.expected = members;
+      p.ring_begin = ring_take(pack_bytes * (size_t)members); p.ring_end = ring_off;
+      p.packs = ring + p.ring_begin % ring_cap; p.packs_dev = ring_dev + p.ring_begin % ring_cap;
+      q.push_back(p);
+    }
+    Pending& p = q[k];
+    if (p.fire != fire || p.g.x != g.x || p.g.y != g.y || p.b.x != b.x || p.lds != lds || p.pack_bytes != pack_bytes)
+      throw DpError(DP_ERR_SHAPE, std::string("cohort out of step: launch ") + name + " of one member meets " + p.name + " of another (the proofs of a cohort must issue identical launch sequences)");
+    if (p.count >= p.expected) throw DpError(DP_ERR_SHAPE, "cohort out of step: too many packs for one launch");
+    memcpy(p.packs + (size_t)p.count * pack_bytes, pack, pack_bytes);
+    p.count++; npacks++;
+    flush();
+  }
+  void flush() {
+    while (!q.empty() && q.front().count >= q.front().expected) {
+      Pending& p = q.front();
+      if (p.count > 0) {
+        std::atomic_thread_fence(std::memory_order_release);
+        p.fire(p, s);
+        inflight.push_back({q_base, p.ring_begin});
+        nfired++;
+      }
+      q.pop_front(); q_base++;
+    }
+  }
+  // a member has seen the result of its launch number `li` (or of a later round of it): everything before it has run
+  void note_executed(size_t li) { if (li > executed) executed = li; }
+  void join() { if (!q.empty()) throw DpError(DP_ERR_SHAPE, "a proof cannot join a cohort in the middle of a step"); members++; }
+  // a member leaves (its proofs are done, or it failed) having issued `li` launches: later launches no longer wait for it
+  void leave(size_t li) {
+    members--;
+    for (size_t k = li > q_base ? li - q_base : 0; k < q.size(); k++) q[k].expected--;
+    flush();
+  }
+  void drain() { HIP_CHECK(hipStreamSynchronize(s)); inflight.clear(); executed = q_base; }
+};
+
+
 class HipDev : public Dev {
   // host-side cost accounting (DP_TIMING=1): time inside hipLaunchKernel and number of launches / device waits
   double launch_us_ = 0; size_t nlaunch_ = 0, nwait_ = 0, nyield_ = 0;
+  // host time between two device waits (the proof's own host work: no yield happens there) and time from the first poll
+  // of a wait to its success (device latency + the other fibers of this thread)
+  struct Chunk { size_t wait; double us; const char* first; const char* last; };
+  std::vector<Chunk> chunks_; const char* first_launch_ = nullptr; const char* last_launch_ = nullptr;
+  double work_us_ = 0, waitlat_us_ = 0; std::chrono::steady_clock::time_point last_exit_{}; bool have_exit_ = false;
+  std::chrono::steady_clock::time_point wait_enter_() {
+    auto t = std::chrono::steady_clock::now();
+    if (g_host_stats && have_exit_) {
+      double c = std::chrono::duration<double, std::micro>(t - last_exit_).count();
+      work_us_ += c;
+      if (c > 150.0 && chunks_.size() < 400) chunks_.push_back({nwait_, c, first_launch_, last_launch_});
+    }
+    first_launch_ = nullptr;
+    return t;
+  }
+  void wait_exit_(std::chrono::steady_clock::time_point t0) {
+    if (!g_host_stats) return;
+    last_exit_ = std::chrono::steady_clock::now(); have_exit_ = true;
+    waitlat_us_ += std::chrono::duration<double, std::micro>(last_exit_ - t0).count();
+  }
   struct LaunchTimer {
     HipDev* d; std::chrono::steady_clock::time_point t0;
     explicit LaunchTimer(HipDev* d_) : d(d_) { if (g_host_stats) t0 = std::chrono::steady_clock::now(); }
@@ -1246,6 +1623,28 @@ class HipDev : public Dev {
   void prof_end() { if (prof_) hipEventRecord(recs_.back().b, s_); }
 
   hipStream_t s_ = nullptr;
+  Cohort* co_ = nullptr;  // non-null while this context proves as a member of a cohort: launches go to the cohort's stream
+  size_t co_li_ = 0;      // number of launches this member has issued into the cohort's common sequence
+  template <auto Body, int MAXT, class... A>
+  static void fire_(const Cohort::Pending& p, hipStream_t s) {
+    hipLaunchKernelGGL((kc<Body, MAXT, std::decay_t<A>...>), dim3(p.g.x, p.g.y, (unsigned)p.count), p.b, p.lds, s, (const ArgPack<std::decay_t<A>...>*)p.packs_dev);
+  }
+  template <auto Body, int MAXT, class... A, class... P>
+  void launch_(KArgs<void (*)(A...)>, const char* name, dim3 g, dim3 b, size_t lds, P... args) {
+    static_assert(sizeof...(A) == sizeof...(P), "kernel argument count");
+    if (g_host_stats) { if (!first_launch_) first_launch_ = name; last_launch_ = name; }
+    if (!co_) { hipLaunchKernelGGL((kg<Body, MAXT, std::decay_t<A>...>), g, b, lds, s_, static_cast<std::decay_t<A>>(args)...); return; }
+    DP_REQUIRE(g.z == 1, DP_ERR_SHAPE, "cohort launches use blockIdx.z for the proof");
+    using Pack = ArgPack<std::decay_t<A>...>;
+    static_assert(std::is_trivially_copyable<Pack>::value && std::is_trivially_destructible<Pack>::value, "argument packs travel as bytes");
+    Pack pk(static_cast<std::decay_t<A>>(args)...);
+    co_->submit(co_li_++, &fire_<Body, MAXT, A...>, name, g, b, lds, &pk, sizeof(Pack));
+  }
+  template <auto Body, int MAXT, class... A>
+  static void set_lds_(KArgs<void (*)(A...)>, int bytes) {
+    HIP_CHECK(hipFuncSetAttribute((const void*)kg<Body, MAXT, std::decay_t<A>...>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    HIP_CHECK(hipFuncSetAttribute((const void*)kc<Body, MAXT, std::decay_t<A>...>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  }
   char* arena_ = nullptr;
   size_t arena_cap_ = 0, arena_off_ = 0, arena_peak_ = 0;
   u64* hres_ = nullptr;   // pinned, device-mapped host memory for small results (zero-copy readback)
@@ -1271,7 +1670,7 @@ class HipDev : public Dev {
   static bool persist_flag_env(const char* name) { const char* e = getenv(name); return !(e && atoi(e)); }
   // all G workgroups have published round `seq`: every slot's tag matches its payload (same protocol as wait_flag)
   void wait_flags_multi(unsigned long long seq, size_t nwords, int G, size_t slot_words) {
-    auto t0 = std::chrono::steady_clock::now();
+    auto t0 = wait_enter_();
     unsigned spins = 0;
     const unsigned long long base = pub_mix(seq);
     nwait_++;
@@ -1293,13 +1692,15 @@ class HipDev : public Dev {
         throw DpError(DP_ERR_HIP, "timeout waiting for the device");
     }
     desc_off_ = 0;
+    if (co_ && co_li_) co_->note_executed(co_li_ - 1);
+    wait_exit_(t0);
   }
   u64* dres_ = nullptr;   // device result buffer
   void* hstage_ = nullptr;  // pinned + device-mapped staging: [0, DESC_BYTES) descriptor ring read by kernels over PCIe, rest = bulk copies
   char* hstage_dev_ = nullptr;
   size_t desc_off_ = 0;
   static constexpr size_t RES_WORDS = 1 << 16;
-  static constexpr size_t STAGE_BYTES = 64 << 20;
+  size_t STAGE_BYTES = size_t(64) << 20;  // bulk staging of this context (workers of a batch get less: stage_bytes of the constructor)
   static constexpr size_t DESC_BYTES = 4 << 20;
   unsigned L_ = 0;  // full_message_size_log of the current PCS parameters
   u64* tw_ = nullptr;    // tw[i]   = w_{2^(L+1)}^i, i < 2^L   (all FFT root tables of rs.rs:31-68 in one array)
@@ -1319,7 +1720,7 @@ class HipDev : public Dev {
   void wait_flag(unsigned long long seq, size_t nwords) {
     volatile unsigned long long* f = hflag_;
     volatile u64* w = hres_;
-    auto t0 = std::chrono::steady_clock::now();
+    auto t0 = wait_enter_();
     unsigned spins = 0;
     const unsigned long long base = pub_mix(seq);
     nwait_++;
@@ -1330,7 +1731,7 @@ class HipDev : public Dev {
         std::atomic_thread_fence(std::memory_order_acquire);
         unsigned long long cs = 0;
         for (size_t i = 0; i < nwords; i++) cs += (unsigned long long)(i + 1) * w[i];
-        if (base + cs == tag) { last_tag_ = tag; desc_off_ = 0; return; }
+        if (base + cs == tag) { last_tag_ = tag; desc_off_ = 0; if (co_ && co_li_) co_->note_executed(co_li_ - 1); wait_exit_(t0); return; }
       }
       // inside a fiber the wait hands the host thread to the next proof in flight (fiber.h); otherwise spin
       const bool fib = fiber_active();
@@ -1396,7 +1797,8 @@ class HipDev : public Dev {
   }
 
  public:
-  explicit HipDev(int device, size_t arena_bytes = 0) : device_(device) {
+  explicit HipDev(int device, size_t arena_bytes = 0, size_t stage_bytes = 0) : device_(device) {
+    if (stage_bytes) STAGE_BYTES = stage_bytes;
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) throw DpError(DP_ERR_NODEVICE, "no HIP device available: the MI355X path is mandatory, there is no CPU fallback");
     DP_REQUIRE(device >= 0 && device < cnt, DP_ERR_ARG, "bad device id");
@@ -1426,17 +1828,21 @@ class HipDev : public Dev {
     HIP_CHECK(hipHostGetDevicePointer((void**)&hstage_dev_, hstage_, 0));
     hstage_dev_ += 0;
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_rc), POSEIDON2_RC_HOST, sizeof(POSEIDON2_RC_HOST)));
+    { std::vector<u64> ex((SC_MAXK + 1) * (SC_MAXK + 1) * (SC_MAXK + 1), 0);  // extrapolation_coeffs(k, at)[i] of sumcheck.h
+      for (unsigned k = 1; k < (unsigned)SC_MAXK; k++) for (unsigned at = k + 1; at <= (unsigned)SC_MAXK; at++) for (unsigned i = 0; i <= k; i++)
+        ex[((size_t)k * (SC_MAXK + 1) + at) * (SC_MAXK + 1) + i] = extrapolation_coeffs(k, at)[i];
+      HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_extrap), ex.data(), ex.size() * 8)); }
     { int ps = getenv("DP_POLL_SLEEP") ? std::max(0, atoi(getenv("DP_POLL_SLEEP"))) : 1; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_poll_sleep), &ps, sizeof(int))); }
-    HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_persist_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS_MAX));
-    HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_persist_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SC_LDS_MAX));
+    DP_SET_LDS((k_sc_persist_lds<false>), 1024, (int)SC_LDS_MAX);
+    DP_SET_LDS((k_sc_persist_lds<true>), 1024, (int)SC_LDS_MAX);
     excl_ = (getenv("DP_NO_EXCLUSIVE_CU") && atoi(getenv("DP_NO_EXCLUSIVE_CU"))) ? 0 : EXCL_LDS;
-    HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXCL_LDS));
-    HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_persist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXCL_LDS));
-    HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_small<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXCL_LDS));
-    HIP_CHECK(hipFuncSetAttribute((const void*)k_sc_small<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXCL_LDS));
-    HIP_CHECK(hipFuncSetAttribute((const void*)k_merkle_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)EXCL_LDS));
-    HIP_CHECK(hipFuncSetAttribute((const void*)k_med_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    HIP_CHECK(hipFuncSetAttribute((const void*)k_med_ntt_local, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    DP_SET_LDS((k_sc_persist<false>), 1024, (int)EXCL_LDS);
+    DP_SET_LDS((k_sc_persist<true>), 1024, (int)EXCL_LDS);
+    DP_SET_LDS((k_sc_small<false>), 1024, (int)EXCL_LDS);
+    DP_SET_LDS((k_sc_small<true>), 1024, (int)EXCL_LDS);
+    DP_SET_LDS(k_merkle_tail, 1024, (int)EXCL_LDS);
+    DP_SET_LDS(k_med_prepare, 1024, 128 * 1024);
+    DP_SET_LDS(k_med_ntt_local, 1024, 64 * 1024);
   }
   ~HipDev() override {
     hipSetDevice(device_);
@@ -1451,11 +1857,13 @@ class HipDev : public Dev {
   }
   const char* name() const override { return name_.c_str(); }
   size_t arena_peak() const { return arena_peak_; }
-  void set_latency_mode(bool on) { multi_ = on && persist_flag_env("DP_NO_MULTI"); }
+  void set_latency_mode(bool on) { multi_ = on && persist_flag_env("DP_NO_MULTI"); devfs_ = devfs_env_ < 0 ? !on : devfs_env_ != 0; }
   void dump_host_stats() {
     if (!g_host_stats) return;
-    fprintf(stderr, "[dp timing] device context: %zu launches, %.1f us of host time per launch (%.1f ms total), %zu device waits, %zu fiber yields\n", nlaunch_, nlaunch_ ? launch_us_ / nlaunch_ : 0.0, launch_us_ / 1000.0, nwait_, nyield_);
-    launch_us_ = 0; nlaunch_ = nwait_ = nyield_ = 0;
+    fprintf(stderr, "[dp timing] device context: %zu launches, %.1f us of host time per launch (%.1f ms total), %zu device waits, %zu fiber yields; host work between waits %.1f ms, inside waits %.1f ms\n", nlaunch_, nlaunch_ ? launch_us_ / nlaunch_ : 0.0, launch_us_ / 1000.0, nwait_, nyield_, work_us_ / 1000.0, waitlat_us_ / 1000.0);
+    if (getenv("DP_HOST_CHUNKS")) for (auto& c : chunks_) fprintf(stderr, "[dp chunk] before wait %zu: %.0f us of host work, launches %s .. %s\n", c.wait, c.us, c.first ? c.first : "-", c.last ? c.last : "-");
+    chunks_.clear();
+    launch_us_ = 0; nlaunch_ = nwait_ = nyield_ = 0; work_us_ = waitlat_us_ = 0; have_exit_ = false;
   }
   void dump_sc_debug() {
     if (!scdbg_) return;
@@ -1505,18 +1913,26 @@ class HipDev : public Dev {
   void free_persistent(DBuf& b) override { if (b.p) { hipStreamSynchronize(s_); hipFree(b.p); b.p = nullptr; } }
   // host <-> device copies go through the pinned staging buffer: hipMemcpyAsync on pageable memory pins the user pages
   // on the fly, which costs tens of milliseconds per MB on this stack
+  // A cohort member moves data with kernels (k_copy_words through the mapped staging buffer, k_zero_words): a memcpy
+  // command queued by one member would overtake the merged launches its cohort has not fired yet.
   void h2d(void* dst, const void* src, size_t bytes) {
     for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
       size_t m = std::min(STAGE_BYTES, bytes - off);
       memcpy(bulk_stage(), (const char*)src + off, m);
-      nb_ = 0; prof_begin("memcpy_h2d"); HIP_CHECK(hipMemcpyAsync((char*)dst + off, bulk_stage(), m, hipMemcpyHostToDevice, s_)); prof_end();
+      if (co_) {
+        DP_REQUIRE(m % 8 == 0, DP_ERR_ARG, "copies are whole words");
+        nb_ = 0; DPL(k_copy_words, dim3(grid_for(m / 8, 256)), dim3(TPB), (u64*)((char*)dst + off), (const u64*)(hstage_dev_ + DESC_BYTES), m / 8);
+      } else { nb_ = 0; prof_begin("memcpy_h2d"); HIP_CHECK(hipMemcpyAsync((char*)dst + off, bulk_stage(), m, hipMemcpyHostToDevice, s_)); prof_end(); }
       stream_wait();
     }
   }
   void d2h(void* dst, const void* src, size_t bytes) {
     for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
       size_t m = std::min(STAGE_BYTES, bytes - off);
-      nb_ = 0; prof_begin("memcpy_d2h"); HIP_CHECK(hipMemcpyAsync(bulk_stage(), (const char*)src + off, m, hipMemcpyDeviceToHost, s_)); prof_end();
+      if (co_) {
+        DP_REQUIRE(m % 8 == 0, DP_ERR_ARG, "copies are whole words");
+        nb_ = 0; DPL(k_copy_words, dim3(grid_for(m / 8, 256)), dim3(TPB), (u64*)(hstage_dev_ + DESC_BYTES), (const u64*)((const char*)src + off), m / 8);
+      } else { nb_ = 0; prof_begin("memcpy_d2h"); HIP_CHECK(hipMemcpyAsync(bulk_stage(), (const char*)src + off, m, hipMemcpyDeviceToHost, s_)); prof_end(); }
       stream_wait();
       memcpy((char*)dst + off, bulk_stage(), m);
     }
@@ -1532,25 +1948,45 @@ class HipDev : public Dev {
     release(mk);
   }
   void download(const DBuf& src, u64* dst) override { d2h(dst, src.p, src.bytes()); }
-  void copy(const DBuf& d, const DBuf& s) override { nb_ = 2.0 * s.bytes(); prof_begin("memcpy_d2d"); HIP_CHECK(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, s_)); prof_end(); }
-  void zero(const DBuf& d) override { nb_ = (double)d.bytes(); prof_begin("memset"); HIP_CHECK(hipMemsetAsync(d.p, 0, d.bytes(), s_)); prof_end(); }
+  void copy(const DBuf& d, const DBuf& s) override {
+    nb_ = 2.0 * s.bytes();
+    if (co_) { if (s.bytes()) DPL(k_copy_words, dim3(grid_for(s.bytes() / 8)), dim3(TPB), (u64*)d.p, (const u64*)s.p, s.bytes() / 8); return; }
+    prof_begin("memcpy_d2d"); HIP_CHECK(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, s_)); prof_end();
+  }
+  void zero(const DBuf& d) override {
+    nb_ = (double)d.bytes();
+    if (co_) { if (d.bytes()) DPL(k_zero_words, dim3(grid_for(d.bytes() / 8)), dim3(TPB), (u64*)d.p, d.bytes() / 8); return; }
+    prof_begin("memset"); HIP_CHECK(hipMemsetAsync(d.p, 0, d.bytes(), s_)); prof_end();
+  }
+  // ---- cohort membership (dp_model_prove_batch): while attached every launch of this context is one pack of a merged launch
+  void cohort_attach(Cohort* co) {
+    DP_REQUIRE(!co_ && !prof_ && zerocopy_, DP_ERR_ARG, "cohort members need the zero-copy publish path and no per-kernel profiling");
+    HIP_CHECK(hipStreamSynchronize(s_));
+    co->join(); co_ = co; co_li_ = co->q_base;
+  }
+  void cohort_detach() { if (co_) { Cohort* c = co_; co_ = nullptr; c->leave(co_li_); } }
+  bool in_cohort() const { return co_ != nullptr; }
   void sync() override { stream_wait(); }
 
   // ---- MLE
   void eq_table_many(const EqJob* jobs, size_t n) override {
     if (!n) return;
-    if (n * sizeof(EqDesc) + 64 > DESC_BYTES) { Dev::eq_table_many(jobs, n); return; }
-    const EqDesc* dd = nullptr;
+    if (n * (sizeof(EqDesc) + 4) + 256 > DESC_BYTES) { Dev::eq_table_many(jobs, n); return; }
+    if (desc_off_ + n * (sizeof(EqDesc) + 4) + 192 > DESC_BYTES) stream_wait();
+    const EqDesc* dd = nullptr; const unsigned* fd = nullptr;
+    unsigned* first = desc_alloc<unsigned>(n + 1, &fd);
     EqDesc* hd = desc_alloc<EqDesc>(n, &dd);
-    size_t maxn = 1; double bytes = 0;
+    unsigned nblk = 0; double bytes = 0;
     for (size_t i = 0; i < n; i++) {
       const EqJob& j = jobs[i];
       DP_REQUIRE(j.out.ext && j.out.n == (size_t(1) << j.k) && j.k <= (unsigned)MAX_PT, DP_ERR_SHAPE, "eq_table_many: output shape");
       hd[i].out = (Ext*)j.out.p; hd[i].k = j.k; hd[i].pad = 0;
       for (unsigned t = 0; t < j.k; t++) hd[i].pt[t] = j.pt[t];
-      maxn = std::max(maxn, j.out.n); bytes += 16.0 * j.out.n;
+      first[i] = nblk; nblk += (unsigned)((j.out.n + EQ_CHUNK - 1) / EQ_CHUNK);  // one workgroup per EQ_CHUNK entries
+      bytes += 16.0 * j.out.n;
     }
-    nb_ = bytes; DPL(k_eq_table_many, dim3(grid_for(maxn, 256), (unsigned)n), dim3(TPB), dd);
+    first[n] = nblk;
+    nb_ = bytes; DPL(k_eq_table_many, dim3(nblk), dim3(TPB), fd, dd, (int)n);
   }
   void eq_table(const DBuf& out, const Ext* pt, unsigned k, Ext scale, bool acc) override {
     DP_REQUIRE(out.ext && out.n == (size_t(1) << k), DP_ERR_SHAPE, "eq_table: output shape");
@@ -1643,6 +2079,77 @@ class HipDev : public Dev {
     try { sc_round(tabs, nt, r, terms, nterms, out); } catch (...) { claim_hint_ = nullptr; throw; }
     claim_hint_ = nullptr;
   }
+  // Every remaining round of a sumcheck in ONE launch with the Fiat-Shamir transcript on the device (ScFsArgs above): used
+  // when several proofs are in flight (DP_DEVICE_FS: 0 never, 1 always, default: throughput mode only — alone, the host
+  // sponge on a 5 GHz core plus two PCIe hops is faster per round than the lane-parallel permutation of one wave).
+  int devfs_env_ = [] { const char* e = getenv("DP_DEVICE_FS"); return e ? atoi(e) : -1; }();
+  bool devfs_ = devfs_env_ > 0;
+  size_t nfs_ = 0;
+  bool sc_tail(DBuf* tabs, int nt, const Ext* r, const ScTerm* terms, const Ext* coeffs, int nterms, unsigned md, Challenger& ch,
+               std::vector<std::vector<Ext>>& msgs, std::vector<Ext>& point, Ext* finals) override {
+    if (!devfs_ || !persist_ || !zerocopy_ || sess_.active) return false;
+    if (nt > MAX_TABS || nterms > MAX_TERMS || nt <= 0 || nterms <= 0 || md < 1 || md > (unsigned)SC_MAXK) return false;
+    size_t n_in = tabs[0].n;
+    for (int i = 0; i < nt; i++) if (tabs[i].n != n_in) return false;
+    size_t n_after = r ? n_in / 2 : n_in;
+    if (n_after > SC_PERSIST_MAX || n_after < 4 || (n_after & (n_after - 1))) return false;
+    bool hi = false;
+    for (int i = 0; i < nterms; i++) { if (terms[i].k < 1 || terms[i].k > SC_MAXK || (unsigned)terms[i].k > md) return false; hi = hi || terms[i].k > 3; }
+    unsigned rounds = 0; for (size_t m = n_after; m > 1; m >>= 1) rounds++;
+    const size_t nwords = (size_t)rounds * (md + 2) * 2 + (size_t)nt * 2 + 14;
+    if (nwords > RES_WORDS) return false;
+    ScPersistArgs a;
+    a.eq_tab = -1; a.eq_k = 0;
+    if (pend_eq_.p && r) flush_pending_eq();
+    if (pend_eq_.p) {
+      for (int i = 0; i < nt; i++) if (tabs[i].p == pend_eq_.p && tabs[i].n == (size_t(1) << pend_eq_.k)) a.eq_tab = i;
+      if (a.eq_tab >= 0) { a.eq_k = (int)pend_eq_.k; for (unsigned i = 0; i < pend_eq_.k; i++) a.eq_pt[i] = pend_eq_.pt[i]; pend_eq_.p = nullptr; }
+      else flush_pending_eq();
+    }
+    for (int i = 0; i < MAX_TABS; i++) { a.in[i] = nullptr; a.in_ext[i] = 0; a.bufA[i] = nullptr; a.bufB[i] = nullptr; }
+    for (int i = 0; i < MAX_TERMS; i++) { a.k[i] = 1; a.off[i] = 0; for (int j = 0; j < SC_MAXK; j++) a.t[i][j] = 0; }
+    { int o = 0; for (int i = 0; i < nterms; i++) { a.k[i] = terms[i].k; for (int j = 0; j < SC_MAXK; j++) a.t[i][j] = j < terms[i].k ? terms[i].t[j] : 0; a.off[i] = o; o += terms[i].k + 1; } }
+    const size_t lds = (size_t)nt * (n_in / 2) * 16;
+    const bool in_lds = lds <= SC_LDS_MAX;
+    size_t first = r ? n_after : n_after / 2;
+    double tab_bytes = 0;
+    for (int i = 0; i < nt; i++) {
+      a.in[i] = tabs[i].p; a.in_ext[i] = tabs[i].ext;
+      if (!in_lds) { a.bufA[i] = (Ext*)alloc(first, true).p; a.bufB[i] = (Ext*)alloc(std::max<size_t>(first / 2, 1), true).p; }
+      tab_bytes += (double)n_in * (tabs[i].ext ? 16.0 : 8.0);
+    }
+    a.nwg = 1; a.rounds_a = 0; a.slot_ext = 0;
+    a.ntabs = nt; a.nterms = nterms; a.has_r0 = r ? 1 : 0; a.n0 = n_in; a.r0 = r ? *r : ex_zero(); a.dbg = scdbg_;
+    const ScFsArgs* fsd = nullptr;
+    ScFsArgs* f = desc_alloc<ScFsArgs>(1, &fsd);
+    for (int i = 0; i < 8; i++) f->state[i] = ch.state[i];
+    for (int i = 0; i < 4; i++) f->in_buf[i] = i < ch.in_len ? ch.in_buf[i] : 0;
+    f->in_len = ch.in_len; f->out_len = ch.out_len; f->md = (int)md; f->rounds = (int)rounds;
+    { static const char lab[] = "Internal round"; size_t n = sizeof(lab) - 1; f->nlabel = 0; f->pad = 0; f->label[0] = f->label[1] = 0;
+      for (size_t i = 0; i < n; i += 8) { u64 v = 0; size_t m = n - i < 8 ? n - i : 8; for (size_t q = 0; q < m; q++) v |= (u64)(uint8_t)lab[i + q] << (8 * q); f->label[f->nlabel++] = gl_from_u64(v); } }
+    for (int i = 0; i < MAX_TERMS; i++) f->coeff[i] = i < nterms ? coeffs[i] : ex_zero();
+    unsigned long long seq = ++seq_;
+    size_t work = (size_t)nterms * (n_after / 2) + (size_t)nt * n_after / 4;
+    int threads = excl_ ? 1024 : work >= 2048 ? 1024 : work >= 512 ? 512 : 256;
+    if (in_lds) { nb_ = tab_bytes; DPL_LDS_HI(k_sc_persist_lds, hi, dim3(1), dim3(threads), std::max(lds, excl_), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
+    else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_LDS_HI(k_sc_persist, hi, dim3(1), dim3(threads), excl_, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
+    wait_flag(seq, nwords);
+    const u64* w = hres_;
+    for (unsigned q = 0; q < rounds; q++) {
+      std::vector<Ext> m(md + 1);
+      for (unsigned j = 0; j <= md; j++) { size_t o = ((size_t)q * (md + 1) + j) * 2; m[j] = ex(w[o], w[o + 1]); }
+      msgs.push_back(std::move(m));
+    }
+    for (unsigned q = 0; q < rounds; q++) { size_t o = ((size_t)rounds * (md + 1) + q) * 2; point.push_back(ex(w[o], w[o + 1])); }
+    size_t wf = (size_t)rounds * (md + 2) * 2;
+    for (int i = 0; i < nt; i++) finals[i] = ex(w[wf + 2 * i], w[wf + 2 * i + 1]);
+    size_t ws = wf + 2 * (size_t)nt;
+    for (int i = 0; i < 8; i++) ch.state[i] = w[ws + i];
+    ch.in_len = (int)w[ws + 12]; ch.out_len = (int)w[ws + 13];
+    for (int i = 0; i < 4; i++) { ch.in_buf[i] = w[ws + 8 + i]; ch.out_buf[i] = ch.state[i]; }
+    nfs_++;
+    return true;
+  }
   void sc_round(DBuf* tabs, int nt, const Ext* r, const ScTerm* terms, int nterms, Ext* out) override {
     DP_REQUIRE(nt <= MAX_TABS && nterms <= MAX_TERMS && nt > 0 && nterms > 0, DP_ERR_SHAPE, "sumcheck: too many tables/terms for one launch");
     size_t n_in = tabs[0].n;
@@ -1713,7 +2220,7 @@ class HipDev : public Dev {
       sess_.active = true; sess_.multi = true; sess_.G = G; sess_.rounds_a = rounds_a; sess_.folds = 0; sess_.slot_words = 2 * nraw;
       sess_.ntabs = nt; sess_.n = n_in; sess_.n0 = n_in; sess_.seq = seq_;
       seq_ += (unsigned)rounds_a;  // one publication per round of the phase
-      nb_ = bytes; DPL_HI(k_sc_persist, hi, dim3(G), dim3(1024), a, (Ext*)hres_dev_, hmflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq);
+      nb_ = bytes; DPL_HI(k_sc_persist, hi, dim3(G), dim3(1024), a, (Ext*)hres_dev_, hmflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr);
       wait_flags_multi(++sess_.seq, 2 * nraw, G, sess_.slot_words);
       read_shares(G, sess_.slot_words);
       return;
@@ -1750,8 +2257,8 @@ class HipDev : public Dev {
       double tab_bytes = 0; for (int i = 0; i < nt; i++) tab_bytes += (double)n_in * (tabs[i].ext && !r ? 16.0 : tabs[i].ext ? 16.0 : 8.0);
       // algorithmic HBM bytes of the launch: every table is read once (the LDS variant never touches HBM again; the
       // global variant also writes and re-reads the halving ping-pong buffers: + 3 x 16 B x n/2 per table in total)
-      if (lds <= SC_LDS_MAX) { nb_ = tab_bytes; DPL_LDS_HI(k_sc_persist_lds, hi, dim3(1), dim3(threads), std::max(lds, excl_), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
-      else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_LDS_HI(k_sc_persist, hi, dim3(1), dim3(threads), excl_, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq); }
+      if (lds <= SC_LDS_MAX) { nb_ = tab_bytes; DPL_LDS_HI(k_sc_persist_lds, hi, dim3(1), dim3(threads), std::max(lds, excl_), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }
+      else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_LDS_HI(k_sc_persist, hi, dim3(1), dim3(threads), excl_, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }
       wait_flag(++sess_.seq, 2 * nraw);
       if (r) for (int i = 0; i < nt; i++) { tabs[i].p = sess_.a[i]; tabs[i].n = n_after; tabs[i].ext = true; }
       read_terms();
@@ -1796,8 +2303,8 @@ class HipDev : public Dev {
         Ext* partial = (Ext*)arena_alloc((size_t)g * 4 * 16);
         nb_ = bytes;
         const bool skip1 = claim_hint_ != nullptr;
-        #define LAUNCH_FUSED2(KK, BB) do { if (skip1) DPL((k_sc_fused<KK, BB, true>), dim3(g), dim3(TPB), in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial); \
-                                           else DPL((k_sc_fused<KK, BB, false>), dim3(g), dim3(TPB), in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial); } while (0)
+        #define LAUNCH_FUSED2(KK, BB) do { if (skip1) DPL_B((k_sc_fused<KK, BB, true>), 256, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial); \
+                                           else DPL_B((k_sc_fused<KK, BB, false>), 256, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial); } while (0)
         #define LAUNCH_FUSED(KK) do { if (base) LAUNCH_FUSED2(KK, true); else LAUNCH_FUSED2(KK, false); } while (0)
         if (nt == 1) LAUNCH_FUSED(1); else if (nt == 2) LAUNCH_FUSED(2); else LAUNCH_FUSED(3);
         #undef LAUNCH_FUSED
@@ -2077,8 +2584,8 @@ class HipDev : public Dev {
       size_t mk = mark();
       if (!trivial) {
         size_t lds = 3 * n * (e0.ext ? 16 : 8);
-        if (e0.ext) { nb_ = g * 64.0 * n; DPL_LDS(k_commit_small<true>, dim3((unsigned)g), dim3(256), lds, dd, nv, L_, (const u64*)tw_, (const u64*)pow7_); }
-        else { nb_ = g * 32.0 * n; DPL_LDS(k_commit_small<false>, dim3((unsigned)g), dim3(256), lds, dd, nv, L_, (const u64*)tw_, (const u64*)pow7_); }
+        if (e0.ext) { nb_ = g * 64.0 * n; DPL_B((k_commit_small<true>), 256, dim3((unsigned)g), dim3(256), lds, dd, nv, L_, (const u64*)tw_, (const u64*)pow7_); }
+        else { nb_ = g * 32.0 * n; DPL_B((k_commit_small<false>), 256, dim3((unsigned)g), dim3(256), lds, dd, nv, L_, (const u64*)tw_, (const u64*)pow7_); }
       }
       if (e0.ext) { nb_ = g * 32.0 * nleaves; DPL(k_merkle_leaves_many<true>, dim3(grid_for(nleaves / 2, 64), (unsigned)g), dim3(TPB), dd, nleaves / 2); }
       else { nb_ = g * 24.0 * nleaves; DPL(k_merkle_leaves_many<false>, dim3(grid_for(nleaves / 2, 64), (unsigned)g), dim3(TPB), dd, nleaves / 2); }
@@ -2097,8 +2604,8 @@ class HipDev : public Dev {
   DevTree merkle_ext(const DBuf& leaves) override { return build_tree(leaves, false); }
 
   void classic_round(DBuf* fs, DBuf* eqs, int np, const Ext* r, Ext* out) override {
-    DP_REQUIRE((size_t)np * sizeof(PolyDesc) * 2 + 128 <= DESC_BYTES && (size_t)np * 4 <= RES_WORDS && np * 2 <= 1024, DP_ERR_SHAPE, "classic_round: too many polynomials");
-    if (desc_off_ + (size_t)np * sizeof(PolyDesc) * 2 + 128 > DESC_BYTES) stream_wait();
+    DP_REQUIRE((size_t)np * (sizeof(PolyDesc) * 2 + sizeof(ClassicDesc) + 4) + 320 <= DESC_BYTES && (size_t)np * 4 <= RES_WORDS && np * 2 <= 1024, DP_ERR_SHAPE, "classic_round: too many polynomials");
+    if (desc_off_ + (size_t)np * (sizeof(PolyDesc) * 2 + sizeof(ClassicDesc) + 4) + 320 > DESC_BYTES) stream_wait();
     const PolyDesc* dd = nullptr;
     PolyDesc* hd = desc_alloc<PolyDesc>((size_t)np, &dd);
     size_t maxn = 1;
@@ -2113,6 +2620,30 @@ class HipDev : public Dev {
       maxn = std::max(maxn, hd[i].n);
     }
     size_t mk = mark();
+    if (zerocopy_) {
+      // one fused launch (fold + sums of the folded tables) on a work-proportional grid, one reduction that publishes
+      const unsigned* fd = nullptr; const ClassicDesc* cdd = nullptr;
+      unsigned* first = desc_alloc<unsigned>((size_t)np + 1, &fd);
+      ClassicDesc* cd = desc_alloc<ClassicDesc>((size_t)np, &cdd);
+      unsigned nblk = 0; double bytes = 0;
+      for (int i = 0; i < np; i++) {
+        cd[i].f = hd[i].f; cd[i].eq = hd[i].eq; cd[i].fout = hd[i].fout; cd[i].eqout = hd[i].eqout; cd[i].n = hd[i].n; cd[i].fext = hd[i].fext; cd[i].pad = 0;
+        const bool folds = r && hd[i].n > 1;
+        size_t items = folds ? hd[i].n / 4 : hd[i].n / 2;  // loop iterations of the pair: 4 (2) entries of each table per iteration
+        size_t nb = std::min<size_t>(std::max<size_t>((items + TPB * 4 - 1) / (TPB * 4), 1), (size_t)std::min(1024, g_max_grid));
+        first[i] = nblk; nblk += (unsigned)nb;
+        bytes += hd[i].n * (hd[i].fext ? 16.0 : 8.0) + hd[i].n * 16.0 + (folds ? hd[i].n * 16.0 : 0.0);
+      }
+      first[np] = nblk;
+      Ext* partial = (Ext*)arena_alloc((size_t)nblk * 2 * 16);
+      unsigned long long seq = ++seq_;
+      nb_ = bytes; DPL(k_classic_fused, dim3(nblk), dim3(TPB), fd, cdd, np, r ? *r : ex_zero(), r ? 1 : 0, partial);
+      nb_ = 0; DPL(k_classic_reduce, dim3(1), dim3(np >= 8 ? 1024 : 256), fd, np, (const Ext*)partial, (Ext*)hres_dev_, hflag_dev_, seq);
+      wait_flag(seq, (size_t)np * 4);
+      for (int i = 0; i < 2 * np; i++) out[i] = ex(hres_[2 * i], hres_[2 * i + 1]);
+      release(mk);
+      return;
+    }
     if (r) {
       nb_ = [&] { double b = 0; for (int i = 0; i < np; i++) if (hd[i].fout) b += hd[i].n * (hd[i].fext ? 16.0 : 8.0) + hd[i].n * 16.0 + hd[i].n * 16.0; return b; }(); DPL(k_classic_fold, dim3(grid_for(maxn / 2, 1024), np), dim3(TPB), dd, *r);
       // descriptors for the sums: the folded tables (a second ring slot — the fold may still be reading the first)
@@ -2194,7 +2725,14 @@ class HipDev : public Dev {
 };
 
 Dev* make_hip_dev(int device) { return new HipDev(device); }
-Dev* make_hip_worker(int device, size_t arena_bytes) { return new HipDev(device, arena_bytes); }
+Dev* make_hip_worker(int device, size_t arena_bytes) { return new HipDev(device, arena_bytes, size_t(16) << 20); }
+// cohorts (lock-step batches of proofs, see struct Cohort): created and driven by dp_model_prove_batch
+Cohort* hip_cohort_new() { const char* e = getenv("DP_COHORT_RING_BYTES"); return e ? new Cohort(strtoull(e, nullptr, 10)) : new Cohort(); }
+void hip_cohort_free(Cohort* c) { delete c; }
+void hip_cohort_drain(Cohort* c) { c->drain(); }
+void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs) { *fired = c->nfired; *packs = c->npacks; c->nfired = c->npacks = 0; }
+void hip_dev_cohort_attach(Dev* d, Cohort* c) { static_cast<HipDev*>(d)->cohort_attach(c); }
+void hip_dev_cohort_detach(Dev* d) { static_cast<HipDev*>(d)->cohort_detach(); }
 void hip_dev_dump_sc_debug(Dev* d) { static_cast<HipDev*>(d)->dump_sc_debug(); }
 size_t hip_dev_arena_peak(Dev* d) { return static_cast<HipDev*>(d)->arena_peak(); }
 void hip_dev_dump_host_stats(Dev* d) { static_cast<HipDev*>(d)->dump_host_stats(); }

@@ -165,11 +165,13 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
     size_t o = 0;
     if (q.is_ext) { q.left = ex(w[0], w[1]); q.right = ex(w[2], w[3]); o = 4; } else { q.left = ex(w[0], 0); q.right = ex(w[1], 0); o = 2; }
     size_t npath = (w.size() - o) / 4;
+    q.path.reserve(npath);
     for (size_t j = 0; j < npath; j++) { Digest dg; for (int k = 0; k < 4; k++) dg.v[k] = w[o + 4 * j + k]; q.path.push_back(dg); }
     return q;
   };
   for (size_t x : qidx) {
     BatchedQuery bq; bq.index = x;
+    bq.oracle_query.reserve(trees.size()); bq.commitments_query.reserve(np);
     for (size_t k = 0; k < trees.size(); k++, di++) bq.oracle_query.push_back(fill(descs[di], got[di]));
     for (size_t k = 0; k < np; k++, di++) bq.commitments_query.push_back(fill(descs[di], got[di]));
     proof.queries.push_back(std::move(bq));

@@ -208,6 +208,7 @@ class Transcript {
   void append_digest(const Digest& d) { for (int i = 0; i < 4; i++) ch_.observe(d.v[i]); }
   Ext read_challenge() { u64 a = ch_.sample(); u64 b = ch_.sample(); return ex(a, b); }
   Ext get_and_append_challenge(const char* label) { append_message(label); return read_challenge(); }
+  Challenger& challenger() { return ch_; }  // for devices that run rounds of the transcript themselves (Dev::sc_tail)
   std::vector<Ext> read_challenges(size_t n) {
     std::vector<Ext> v;
     for (size_t i = 0; i < n; i++) v.push_back(read_challenge());

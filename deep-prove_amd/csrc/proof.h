@@ -98,7 +98,7 @@ struct Writer {
   }
 };
 inline std::vector<u64> serialize_proof(const Proof& p) {
-  Writer w; w.u(PROOF_MAGIC); w.u(p.steps.size());
+  Writer w; w.w.reserve(size_t(1) << 20); w.u(PROOF_MAGIC); w.u(p.steps.size());
   for (auto& kv : p.steps) {
     const LayerProof& lp = kv.second;
     w.u(kv.first); w.u((u64)lp.kind);

@@ -89,8 +89,18 @@ inline SumcheckOut sumcheck_prove(Dev& dev, DevVP& vp, Transcript& t) {
   std::vector<Ext> raw(nraw);
   Ext ch = ex_zero();
   const bool single = vp.terms.size() == 1 && ex_eq(vp.coeffs[0], ex_one()) && (unsigned)vp.terms[0].k == md;
+  out.finals.resize(tabs.size());
+  bool tail = false;
   for (unsigned round = 0; round < nv; round++) {
     auto tq0 = std::chrono::steady_clock::now();
+    // a device that keeps the sponge to itself runs every remaining round (and the final evaluations) in one go
+    if (dev.sc_tail(tabs.data(), (int)tabs.size(), round ? &ch : nullptr, vp.terms.data(), vp.coeffs.data(), (int)vp.terms.size(), md, t.challenger(),
+                    out.proof.proofs, out.proof.point, out.finals.data())) {
+      ScStats& st = sc_stats();
+      st.dev_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count();
+      st.rounds += nv - round; tail = true;
+      break;
+    }
     // one product with coefficient one (the shape of the large standalone sumchecks): the round must sum to the previous
     // round polynomial at its challenge, which lets the device skip one of its evaluation points
     if (single && round) {
@@ -121,8 +131,7 @@ inline SumcheckOut sumcheck_prove(Dev& dev, DevVP& vp, Transcript& t) {
     st.host_ms += std::chrono::duration<double, std::milli>(tq2 - tq1).count();
     st.rounds++;
   }
-  out.finals.resize(tabs.size());
-  dev.sc_finish(tabs.data(), (int)tabs.size(), ch, out.finals.data());
+  if (!tail) dev.sc_finish(tabs.data(), (int)tabs.size(), ch, out.finals.data());
   dev.release(mk);
   return out;
 }

@@ -34,6 +34,9 @@ struct LayerSpec {
   size_t unp_out[3] = {0, 0, 0};
   size_t pin[3] = {0, 0, 0};  // maxpool: padded input shape [c, h, w]
   std::shared_ptr<const std::vector<u64>> wfft;  // conv: FFT of every zero-padded kernel, [kw][kx][2 nw^2] (prepare_conv)
+  // dense: the weights once more as int16 when they all fit (quantised models: |w| <= 127) — the inference that precedes
+  // every proof then streams a quarter of the bytes and its dot products vectorise (pmaddwd); w16_max = max |w|
+  std::shared_ptr<const std::vector<int16_t>> w16; int64_t w16_max = 0;
   size_t filter_size() const { return nw * nw; }
   unsigned right_shift = 0, fp_scale = 0, intermediate_bit_size = 0;
   int64_t fixed_point_multiplier = 0;
@@ -145,6 +148,12 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
     if (l.kind == L_DENSE) {
       DP_REQUIRE(cur.size() == l.ncols, DP_ERR_SHAPE, "dense input size mismatch");
       o.resize(l.nrows);
+      int64_t xmax = 0; for (int64_t v : cur) xmax = std::max(xmax, v < 0 ? -v : v);
+      if (l.w16 && xmax <= 32767 && (double)xmax * (double)l.w16_max * (double)l.ncols < 2.0e9) {  // exact in int32: same integers as below
+        std::vector<int16_t> x16(cur.size()); for (size_t j = 0; j < cur.size(); j++) x16[j] = (int16_t)cur[j];
+        const int16_t* xp = x16.data();
+        for (size_t i = 0; i < l.nrows; i++) { int32_t a = 0; const int16_t* w = l.w16->data() + i * l.ncols; for (size_t j = 0; j < l.ncols; j++) a += (int32_t)w[j] * (int32_t)xp[j]; o[i] = (int64_t)a + l.bias[i]; }
+      } else
       for (size_t i = 0; i < l.nrows; i++) { int64_t a = 0; const int64_t* w = &l.weights[i * l.ncols]; for (size_t j = 0; j < l.ncols; j++) a += w[j] * cur[j]; o[i] = a + l.bias[i]; }
     } else if (l.kind == L_REQUANT) {
       unsigned sh = l.shift();
@@ -185,7 +194,7 @@ struct Context {
   std::vector<TableType> tables;
   VerifierContext verifier_ctx() const {
     VerifierContext v; v.full_log = full_log; v.tables = tables; v.shape.input_len = model.input_len;
-    for (auto& l : model.layers) { LayerSpec s = l; s.weights.clear(); s.bias.clear(); s.wfft.reset(); v.shape.layers.push_back(s); }
+    for (auto& l : model.layers) { LayerSpec s = l; s.weights.clear(); s.bias.clear(); s.wfft.reset(); s.w16.reset(); v.shape.layers.push_back(s); }
     for (auto& kv : model_comms) for (auto& pc : kv.second) v.model_comms[kv.first][pc.first] = pure_commitment(pc.second);
     return v;
   }
@@ -249,6 +258,8 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
     DBuf w = dev.alloc_persistent(l.weights.size(), false), b = dev.alloc_persistent(l.bias.size(), false);
     dev.upload_i64(w, l.weights.data()); dev.upload_i64(b, l.bias.data());
     if (l.kind == L_DENSE) {
+      { int64_t wm = 0; for (int64_t v : l.weights) wm = std::max(wm, v < 0 ? -v : v);
+        if (wm <= 32767) { auto w16 = std::make_shared<std::vector<int16_t>>(l.weights.size()); for (size_t j = 0; j < l.weights.size(); j++) (*w16)[j] = (int16_t)l.weights[j]; l.w16 = w16; l.w16_max = wm; } }
       ctx->model_comms[id]["DenseWeight"] = dev.commit(w, true);
       ctx->model_comms[id]["DenseBias"] = dev.commit(b, true);
     } else {  // model polys of a convolution (convolution.rs:452-453,546-553)
