@@ -22,6 +22,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BATCHES_PER_STEP = 2
+# proofs in flight per GPU: 24 cohorts of 8 lock-step proofs (csrc/hip_dev.hip, struct Cohort). The library cuts the number
+# to what fits in the free HBM (worker arenas are sized from the footprint of the model's first proof).
+DEFAULT_IN_FLIGHT = 192
+VERIFY_BUDGET_S = 30.0  # host verification of the last batch: all proofs if that fits, else an evenly spaced sample
 PUBLISHED = {"dense_4m": 1000.0 / 2335.0, "cnn_264k": 1000.0 / 1242.0}  # reference README.md:17-18 (hardware unstated)
 WORKLOADS = {
     "dense_4m": "Dense-4M MLP (mlp.py --num-dense 5 --layer-width 1024: 4->1024->1024x4->3, Dense+Requant+ReLU blocks, 4.21M params), 1 input per proof",
@@ -68,8 +72,9 @@ def make_model(dpa, workload):
     return {"dense_4m": dpa.models.dense_4m, "cnn_264k": dpa.models.cnn_264k, "mlp_w256": lambda: dpa.models.mlp(3, 256, config=5)}[workload]()
 
 
-def measure_workload(dpa, dev, workload, conc, steps, warmup, world, rank, dist, torch):
-    """setup + latency of one proof + the timed throughput region + verification of the last batch"""
+def measure_workload(dpa, dev, workload, conc, steps, warmup, world, rank, dist, torch, profile=False):
+    """setup + latency of one proof + the timed throughput region + verification of the last batch (+ the per-kernel HIP
+    event profile of one more proof); the model context and its workers are released before returning"""
     import numpy as np
     mb = make_model(dpa, workload)
     t0 = time.time()
@@ -89,12 +94,21 @@ def measure_workload(dpa, dev, workload, conc, steps, warmup, world, rank, dist,
     cuda = torch.cuda.is_available() and (dist is None or dist.get_backend() == "nccl")
     elapsed, last = timed_region(lambda xs: prover.prove_batch(xs, conc), my_inputs, batch, steps, warmup, dist,
                                  torch.cuda.synchronize if cuda else None, "cuda" if cuda else "cpu")
-    # every proof of the last batch must verify (host verifier) — an invalid proof voids the measurement
+    # the proofs of the last batch must verify (host verifier) — an invalid proof voids the measurement
     lo = (warmup + steps - 1) * batch
-    for j in range(batch):
+    t0 = time.perf_counter()
+    dpa.verify(vblob, last[0][0], my_inputs[lo], last[1][0])
+    one = max(time.perf_counter() - t0, 1e-4)
+    stride = max(1, int(batch * one / VERIFY_BUDGET_S + 0.999))
+    checked = 1
+    for j in range(stride, batch, stride):
         dpa.verify(vblob, last[0][j], my_inputs[lo + j], last[1][j])
-    return dict(mb=mb, ctx=ctx, prover=prover, inputs=my_inputs, elapsed=elapsed, latency_ms=latency_ms, first_ms=first_ms,
-                setup_s=setup_s, proof_words=int(last[0][0].size))
+        checked += 1
+    in_flight = prover.in_flight()
+    rep = kernel_profile(dev, prover, my_inputs[0]) if profile else None
+    ctx.free()  # releases the workers' arenas too: the next workload sizes its own against the free HBM
+    return dict(mb=mb, elapsed=elapsed, latency_ms=latency_ms, first_ms=first_ms, setup_s=setup_s, proof_words=int(last[0][0].size),
+                verified=checked, verify_ms=round(1000 * one, 2), in_flight=in_flight, kernel_report=rep)
 
 
 def kernel_profile(dev, prover, x):
@@ -130,7 +144,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sumcheck24", action="store_true", help="skip the standalone 2^24 sumcheck roofline section")
     ap.add_argument("--no-cnn", action="store_true", help="skip the CNN-264k section of a Dense-4M run")
-    ap.add_argument("--concurrency", type=int, default=0, help="independent proofs in flight per GPU (0 = 24)")
+    ap.add_argument("--concurrency", type=int, default=0, help=f"independent proofs in flight per GPU (0 = {DEFAULT_IN_FLIGHT})")
     args = ap.parse_args()
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # one hardware queue per in-flight proof stream, as many as the GPU serves without time slicing
@@ -158,10 +172,10 @@ def main():
     budget = dpa.api.host_cpu_budget()
     host_threads = max(1, int(budget / max(1, local_world)) - 2)
     os.environ.setdefault("DP_HOST_THREADS", str(host_threads))
-    conc = args.concurrency if args.concurrency > 0 else 24
+    conc = args.concurrency if args.concurrency > 0 else DEFAULT_IN_FLIGHT
 
     dev = dpa.Device(local_rank)
-    main_w = measure_workload(dpa, dev, args.workload, conc, args.steps, args.warmup, world, rank, dist, torch)
+    main_w = measure_workload(dpa, dev, args.workload, conc, args.steps, args.warmup, world, rank, dist, torch, profile=rank == 0)
     cnn_w = None
     if args.workload == "dense_4m" and not args.no_cnn:
         cnn_w = measure_workload(dpa, dev, "cnn_264k", conc, max(1, args.steps - 1), args.warmup, world, rank, dist, torch)
@@ -181,7 +195,7 @@ def main():
             return world * steps * BATCHES_PER_STEP * conc / w["elapsed"]
         value = rate(main_w, args.steps)
         # ---- roofline of the dominant kernel of one proof: algorithmic bytes per launch / average launch duration
-        rep = kernel_profile(dev, main_w["prover"], main_w["inputs"][0])
+        rep = main_w["kernel_report"]
         tot_ms = sum(r["total_ms"] for r in rep)
         dom = rep[0]
         avg_ms = dom["total_ms"] / dom["launches"]
@@ -203,10 +217,10 @@ def main():
         if cnn_w is not None:
             csteps = max(1, args.steps - 1)
             cnn = {"metric": "proofs/sec (prover), CNN-264k", "value": round(rate(cnn_w, csteps), 4), "unit": "proofs/s",
-                   "ms_per_step": round(1000.0 * cnn_w["elapsed"] / csteps, 3), "steps": csteps, "proofs_per_step_per_gpu": BATCHES_PER_STEP * conc, "proofs_in_flight_per_gpu": conc,
+                   "ms_per_step": round(1000.0 * cnn_w["elapsed"] / csteps, 3), "steps": csteps, "proofs_per_step_per_gpu": BATCHES_PER_STEP * conc, "proofs_in_flight_per_gpu": cnn_w["in_flight"],
                    "single_proof_latency_ms": round(cnn_w["latency_ms"], 2), "vs_baseline": round(rate(cnn_w, csteps) / PUBLISHED["cnn_264k"], 3),
                    "baseline_note": "reference README.md:17 CNN-264k proving time 1242 ms on unstated CPU hardware",
-                   "workload": WORKLOADS["cnn_264k"], "proof_words": cnn_w["proof_words"], "setup_s": round(cnn_w["setup_s"], 2), "verified": True,
+                   "workload": WORKLOADS["cnn_264k"], "proof_words": cnn_w["proof_words"], "setup_s": round(cnn_w["setup_s"], 2), "verified": True, "verified_proofs_of_last_step": cnn_w["verified"],
                    "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else cpu_baseline(cnn_w["mb"], "cnn_264k")}
         result = {
             "metric": {"dense_4m": "proofs/sec (prover), Dense-4M", "cnn_264k": "proofs/sec (prover), CNN-264k"}.get(args.workload, "proofs/sec (prover), MLP-w256"),
@@ -216,17 +230,14 @@ def main():
             "baseline_note": "reference README.md:17-18 proving times (Dense-4M 2335 ms, CNN-264k 1242 ms) on unstated CPU hardware",
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload], "arithmetic": "Goldilocks p = 2^64 - 2^32 + 1 and its degree-2 extension (canonical u64 words)",
-                       "proofs_per_step_per_gpu": BATCHES_PER_STEP * conc, "proofs_in_flight_per_gpu": conc, "proofs_per_rank": args.steps * BATCHES_PER_STEP * conc,
+                       "proofs_per_step_per_gpu": BATCHES_PER_STEP * conc, "proofs_in_flight_per_gpu": main_w["in_flight"], "proofs_per_rank": args.steps * BATCHES_PER_STEP * conc,
                        "single_proof_latency_ms": round(main_w["latency_ms"], 2), "first_proof_ms": round(main_w["first_ms"], 2),
                        "host_cpu_budget": budget, "host_threads_per_rank": int(os.environ["DP_HOST_THREADS"]),
-                       "parallelism": f"replicas x{world} GPUs x {conc} proofs in flight per GPU (independent proofs, no data-path collective)",
-                       "proof_words": main_w["proof_words"], "setup_s": round(main_w["setup_s"], 2), "verified": True, "device": dev.name},
+                       "parallelism": f"replicas x{world} GPUs x {main_w['in_flight']} proofs in flight per GPU in lock-step cohorts of {os.environ.get('DP_COHORT', '8')} (independent proofs, no data-path collective)",
+                       "proof_words": main_w["proof_words"], "setup_s": round(main_w["setup_s"], 2), "verified": True, "verified_proofs_of_last_step": main_w["verified"], "verify_ms_per_proof": main_w["verify_ms"], "device": dev.name},
             "roofline": roofline, "cpu_baseline": cpu, "cnn_264k": cnn, "sumcheck24": sc24, "sumcheck24_sharded": sharded,
         }
         print(json.dumps(result))
-    for w in (main_w, cnn_w):
-        if w is not None:
-            w["ctx"].free()
     dev.close()
     if dist is not None:
         dist.destroy_process_group()

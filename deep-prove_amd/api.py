@@ -341,6 +341,13 @@ class Prover:
         return proofs, outs[:, :no.value].copy(), ms.value
 
 
+    def in_flight(self):
+        """proofs the last prove_batch kept in flight (the `concurrency` asked, cut to what fits in the free HBM)"""
+        n = C.c_size_t(0)
+        check(_lib.load().dp_model_in_flight(self.ctx.h, C.byref(n)))
+        return int(n.value)
+
+
 def host_cpu_budget():
     """CPUs this process may use (cgroup quota, else hardware threads): what the number of proving host threads follows"""
     return float(_lib.load().dp_host_cpu_budget())

@@ -10,7 +10,7 @@
 #include <thread>
 
 DP_FIBER_SWITCH_ASM
-namespace dp { struct Cohort; Cohort* hip_cohort_new(); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
+namespace dp { struct Cohort; Cohort* hip_cohort_new(); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
 using namespace dp;
 
 struct dp_ctx { Dev* dev; int device_id; };
@@ -19,6 +19,7 @@ struct dp_transcript { Transcript t; };
 struct dp_commit { DevCommit c; };
 struct dp_model {
   dp_ctx* ctx; std::unique_ptr<Context> zk; std::vector<std::unique_ptr<Dev>> workers; std::vector<dp::Cohort*> cohorts;
+  size_t last_in_flight = 0; size_t prove_peak = 0;  // largest arena footprint a proof of this model has had so far (sizes the arenas of batch workers)
   ~dp_model() { for (auto* c : cohorts) hip_cohort_free(c); }
 };
 
@@ -293,9 +294,11 @@ int32_t dp_model_prove(dp_model* m, const int64_t* input, size_t ninput, uint64_
     std::vector<int64_t> in(input, input + ninput);
     Trace tr = run_model(m->zk->model, in);
     Transcript t = default_transcript();
+    hip_dev_arena_peak_reset(m->ctx->dev);
     auto t0 = std::chrono::steady_clock::now();
     Proof p = prove(*m->zk, tr, t);
     auto t1 = std::chrono::steady_clock::now();
+    m->prove_peak = std::max(m->prove_peak, hip_dev_arena_peak(m->ctx->dev));
     if (prove_ms) *prove_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     hip_dev_dump_sc_debug(m->ctx->dev);
     std::vector<u64> w = serialize_proof(p);
@@ -314,9 +317,21 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     size_t nw = std::min<size_t>((size_t)concurrency, nproofs);
     // worker 0 is the model's own context; the others get their own stream + arena on the same GPU and share the
     // (read-only) model commitments
+    // Arena of a worker: DP_WORKER_ARENA_BYTES, else 1.25 x the largest footprint a proof of this model has had (one proof
+    // alone runs in latency mode, whose multi-workgroup sumchecks keep every fold level: an upper bound of what a proof in
+    // flight needs) + 64 MB, else — nothing proved yet — 1.5 GB. The number of proofs in flight is cut to what fits in
+    // 90 % of the free HBM instead of failing: `concurrency` is a cap, not a demand.
     const char* env = getenv("DP_WORKER_ARENA_BYTES");
-    size_t arena = env ? strtoull(env, nullptr, 10) : (size_t(3) << 29);
+    const size_t MB64 = size_t(64) << 20;
+    size_t arena = env ? strtoull(env, nullptr, 10) : m->prove_peak ? ((m->prove_peak + m->prove_peak / 4 + MB64 + MB64 - 1) / MB64) * MB64 : (size_t(3) << 29);
+    if (m->workers.size() + 1 < nw) {
+      size_t free_b = 0, total_b = 0; hip_mem_info(m->ctx->device_id, &free_b, &total_b);
+      const size_t per = arena + (size_t(16) << m->zk->full_log) + (size_t(8) << 20);  // + the worker's twiddle / coset tables and small buffers
+      size_t fit = m->workers.size() + 1 + (size_t)((double)free_b * 0.9 / (double)per);
+      if (fit < nw) { if (getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) fprintf(stderr, "[dp timing] prove_batch: %zu proofs in flight asked, %zu fit in %.1f GB of free HBM (%.0f MB per worker)\n", nw, fit, free_b / 1e9, per / 1048576.0); nw = fit; }
+    }
     while (m->workers.size() + 1 < nw) { std::unique_ptr<Dev> w(make_hip_worker(m->ctx->device_id, arena)); w->pcs_init(m->zk->full_log); m->workers.push_back(std::move(w)); }
+    m->last_in_flight = nw;
     // several proofs in flight: throughput mode on every context (see hip_dev_set_latency_mode)
     hip_dev_set_latency_mode(m->ctx->dev, nw == 1);
     for (auto& w : m->workers) hip_dev_set_latency_mode(w.get(), nw == 1);
@@ -391,6 +406,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     if (err_code) { for (size_t i = 0; i < nproofs; i++) { free(proof_words[i]); proof_words[i] = nullptr; } throw DpError(err_code, err); }
   });
 }
+int32_t dp_model_in_flight(const dp_model* m, size_t* in_flight) { return guard([&] { DP_REQUIRE(m && in_flight, DP_ERR_ARG, "bad arguments"); *in_flight = m->last_in_flight; }); }
 double dp_host_cpu_budget(void) { return host_cpu_budget(); }
 int32_t dp_model_verifier_blob(const dp_model* m, uint64_t** words, size_t* nwords) {
   return guard([&] { DP_REQUIRE(m && words && nwords, DP_ERR_ARG, "bad arguments"); std::vector<u64> w = vctx_to_words(m->zk->verifier_ctx()); *words = copy_out(w); *nwords = w.size(); });

@@ -1857,6 +1857,7 @@ class HipDev : public Dev {
   }
   const char* name() const override { return name_.c_str(); }
   size_t arena_peak() const { return arena_peak_; }
+  void arena_peak_reset() { arena_peak_ = arena_off_; }
   void set_latency_mode(bool on) { multi_ = on && persist_flag_env("DP_NO_MULTI"); devfs_ = devfs_env_ < 0 ? !on : devfs_env_ != 0; }
   void dump_host_stats() {
     if (!g_host_stats) return;
@@ -2735,6 +2736,9 @@ void hip_dev_cohort_attach(Dev* d, Cohort* c) { static_cast<HipDev*>(d)->cohort_
 void hip_dev_cohort_detach(Dev* d) { static_cast<HipDev*>(d)->cohort_detach(); }
 void hip_dev_dump_sc_debug(Dev* d) { static_cast<HipDev*>(d)->dump_sc_debug(); }
 size_t hip_dev_arena_peak(Dev* d) { return static_cast<HipDev*>(d)->arena_peak(); }
+void hip_dev_arena_peak_reset(Dev* d) { static_cast<HipDev*>(d)->arena_peak_reset(); }
+// free / total bytes of the device's HBM: dp_model_prove_batch sizes the number of proofs in flight against it
+void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes) { HIP_CHECK(hipSetDevice(device)); HIP_CHECK(hipMemGetInfo(free_bytes, total_bytes)); }
 void hip_dev_dump_host_stats(Dev* d) { static_cast<HipDev*>(d)->dump_host_stats(); }
 // latency mode (one proof on the GPU): large sumcheck rounds spread over several workgroups; throughput mode (many proofs
 // in flight): one workgroup per sumcheck — spreading costs more CUs and host polls than it saves when the GPU is shared

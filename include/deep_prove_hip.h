@@ -142,13 +142,19 @@ int32_t dp_model_prove(dp_model* m, const int64_t* input, size_t ninput, uint64_
  * flight on the model's GPU: every in-flight proof has its own HIP stream, arena and host<->device mailbox; the model
  * commitments are shared read-only. A single proof is a chain of ~10^3 sequential Fiat-Shamir round trips that cannot
  * fill an MI355X, so this is how one GPU is saturated (and how BASELINE config 4, a batch of independent proofs, is
- * served). The proofs are driven by min(concurrency, DP_HOST_THREADS or dp_host_cpu_budget() - 2) host threads; a thread
- * runs its proofs as cooperative fibers and switches proof at every device wait.
+ * served). The proofs in flight are grouped into cohorts of DP_COHORT (default 8) proofs that run in lock step: launch
+ * number i of all members of a cohort is ONE kernel launch (blockIdx.z = proof) on the cohort's stream. The proofs are
+ * driven by min(#cohorts, DP_HOST_THREADS or dp_host_cpu_budget() - 2) host threads; a thread runs its proofs as
+ * cooperative fibers and switches proof at every device wait. `concurrency` is a cap: worker arenas are sized from the
+ * footprint of the model's earlier proofs (DP_WORKER_ARENA_BYTES overrides) and the number in flight is cut to what fits
+ * in the free HBM; dp_model_in_flight reports the number the last batch ran with.
  * proof_words / proof_nwords: arrays of nproofs entries (each buffer malloc'ed, release with dp_free);
  * outputs: nproofs * noutput_cap words (nullable). */
 int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs, size_t ninput, int32_t concurrency,
                              uint64_t** proof_words, size_t* proof_nwords, int64_t* outputs, size_t noutput_cap,
                              size_t* noutput, double* wall_ms);
+/* proofs the last dp_model_prove_batch of this model kept in flight (0 before the first batch) */
+int32_t dp_model_in_flight(const dp_model* m, size_t* in_flight);
 /* CPUs the process may use: the cgroup CPU quota when there is one, else the number of hardware threads */
 double dp_host_cpu_budget(void);
 /* serialisable verifier-side context (model commitments, shapes, tables) */
