@@ -1,0 +1,22 @@
+"""Dense-4M (or argv[1]) proofs in flight, torch-free — the command the rocprofv3 --kernel-trace --stats pass of the cohort
+scheme wraps: one single proof (latency mode), one warm batch that creates the workers, one measured batch.
+usage: python tools/profile_batch.py [workload] [in_flight]"""
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import deep_prove_amd as dpa
+wl = sys.argv[1] if len(sys.argv) > 1 else "dense_4m"
+conc = int(sys.argv[2]) if len(sys.argv) > 2 else 192
+dev = dpa.Device(0)
+mb = getattr(dpa.models, wl)()
+ctx = dpa.Context.generate(dev, mb.blob())
+pr = dpa.Prover(ctx)
+xs = np.stack([mb.input(3000 + i) for i in range(conc)])
+pr.prove(xs[0])
+pr.prove_batch(xs, conc)
+t0 = time.perf_counter()
+pr.prove_batch(xs, conc)
+dt = time.perf_counter() - t0
+print(f"{wl}: {conc} proofs, {pr.in_flight()} in flight: {conc / dt:.1f} proofs/s under the profiler", flush=True)
+ctx.free()
