@@ -121,15 +121,20 @@ def kernel_profile(dev, prover, x):
     return rep
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of `kernel_prefix` from the committed rocprofv3 PMC passes (profiles/r01_pmc_*.json: separate
-    FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled for 16 B/lane streaming reads as MI355X_MICROARCH.md prescribes)"""
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` (mean over its launches) from the committed rocprofv3 PMC passes (profiles/r*_pmc_*.json,
+    made by tools/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled for 16 B/lane streaming reads as
+    MI355X_MICROARCH.md prescribes). The newest file that knows the exact instantiation wins, else the same kernel name."""
     try:
-        for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
-            if name.startswith("r01_pmc_") and name.endswith(".json"):
-                for rec in json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]:
-                    if rec["kernel"].startswith(kernel_prefix):
-                        return rec
+        recs = []
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if "_pmc_" in name and name.endswith(".json"):
+                recs += json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"]
+        norm = lambda k: k.replace(" ", "")  # noqa: E731
+        for match in (lambda r: norm(r["kernel"]) == norm(kernel), lambda r: r["kernel"].split("<")[0] == kernel.split("<")[0]):
+            for rec in recs:
+                if match(rec):
+                    return rec
     except (OSError, ValueError, KeyError):
         pass
     return None
@@ -209,7 +214,7 @@ def main():
         dom = rep[0]
         avg_ms = dom["total_ms"] / dom["launches"]
         achieved = (dom["alg_bytes"] / dom["launches"]) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        pmc = pmc_traffic(dom["kernel"].split("<")[0])
+        pmc = pmc_traffic(dom["kernel"])
         roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
                     "alg_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"], 1), "launches_per_proof": dom["launches"],

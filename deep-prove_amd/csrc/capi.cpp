@@ -19,7 +19,7 @@ struct dp_transcript { Transcript t; };
 struct dp_commit { DevCommit c; };
 struct dp_model {
   dp_ctx* ctx; std::unique_ptr<Context> zk; std::vector<std::unique_ptr<Dev>> workers; std::vector<dp::Cohort*> cohorts;
-  size_t last_in_flight = 0; size_t prove_peak = 0;  // largest arena footprint a proof of this model has had so far (sizes the arenas of batch workers)
+  size_t last_in_flight = 0, in_flight_cap = 0; size_t prove_peak = 0;  // largest arena footprint a proof of this model has had so far (sizes the arenas of batch workers)
   ~dp_model() { for (auto* c : cohorts) hip_cohort_free(c); }
 };
 
@@ -325,10 +325,14 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     const size_t MB64 = size_t(64) << 20;
     size_t arena = env ? strtoull(env, nullptr, 10) : m->prove_peak ? ((m->prove_peak + m->prove_peak / 4 + MB64 + MB64 - 1) / MB64) * MB64 : (size_t(3) << 29);
     if (m->workers.size() + 1 < nw) {
-      size_t free_b = 0, total_b = 0; hip_mem_info(m->ctx->device_id, &free_b, &total_b);
-      const size_t per = arena + (size_t(16) << m->zk->full_log) + (size_t(8) << 20);  // + the worker's twiddle / coset tables and small buffers
-      size_t fit = m->workers.size() + 1 + (size_t)((double)free_b * 0.9 / (double)per);
-      if (fit < nw) { if (getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) fprintf(stderr, "[dp timing] prove_batch: %zu proofs in flight asked, %zu fit in %.1f GB of free HBM (%.0f MB per worker)\n", nw, fit, free_b / 1e9, per / 1048576.0); nw = fit; }
+      // the cap is fixed by the first batch that needs more workers than exist (later batches must not creep into the reserve)
+      if (!m->in_flight_cap) {
+        size_t free_b = 0, total_b = 0; hip_mem_info(m->ctx->device_id, &free_b, &total_b);
+        const size_t per = arena + (size_t(16) << m->zk->full_log) + (size_t(8) << 20);  // + the worker's twiddle / coset tables and small buffers
+        m->in_flight_cap = m->workers.size() + 1 + (size_t)((double)free_b * 0.9 / (double)per);
+        if (m->in_flight_cap < nw && getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) fprintf(stderr, "[dp timing] prove_batch: %zu proofs in flight asked, %zu fit in %.1f GB of free HBM (%.0f MB per worker)\n", nw, m->in_flight_cap, free_b / 1e9, per / 1048576.0);
+      }
+      nw = std::min(nw, m->in_flight_cap);
     }
     while (m->workers.size() + 1 < nw) { std::unique_ptr<Dev> w(make_hip_worker(m->ctx->device_id, arena)); w->pcs_init(m->zk->full_log); m->workers.push_back(std::move(w)); }
     m->last_in_flight = nw;

@@ -13,6 +13,7 @@ dev = dpa.Device(0)
 mb = getattr(dpa.models, wl)()
 ctx = dpa.Context.generate(dev, mb.blob())
 pr = dpa.Prover(ctx)
+pr.prove(mb.input(2999))  # the footprint of one proof sizes the arenas of the batch workers
 print("host cores", os.cpu_count(), flush=True)
 for spec in args or ["8:8", "8:0", "24:8", "24:0"]:
     f = [int(v) for v in spec.split(":")]
@@ -28,4 +29,4 @@ for spec in args or ["8:8", "8:0", "24:8", "24:0"]:
     t0 = time.perf_counter()
     pr.prove_batch(xs, conc)
     dt = time.perf_counter() - t0
-    print(f"conc={conc:3d} cohort={co:2d} threads={f[2] if len(f) > 2 else 'auto'}  {len(xs) / dt:8.2f} proofs/s   batch of {len(xs)} in {1000 * dt:8.1f} ms", flush=True)
+    print(f"conc={conc:3d} in_flight={pr.in_flight():3d} cohort={co:2d} threads={f[2] if len(f) > 2 else 'auto'}  {len(xs) / dt:8.2f} proofs/s   batch of {len(xs)} in {1000 * dt:8.1f} ms", flush=True)

@@ -12,10 +12,13 @@ import sqlite3
 import sys
 
 
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+from rocpd_summary import short as _short  # decodes the kg<Body> / kc<Body> wrapper names
+
+
 def short(name):
-    name = re.sub(r"^void ", "", name)
-    name = name.split("(")[0]
-    return name.replace("dp::", "")
+    s = _short(name)
+    return s.split(":", 1)[1] if s[:3] in ("kg:", "kc:") else s
 
 
 def per_kernel(path, counter):
