@@ -25,6 +25,7 @@ BATCHES_PER_STEP = 2
 # proofs in flight per GPU: 24 cohorts of 8 lock-step proofs (csrc/hip_dev.hip, struct Cohort). The library cuts the number
 # to what fits in the free HBM (worker arenas are sized from the footprint of the model's first proof).
 DEFAULT_IN_FLIGHT = 192
+SHARDED_WATCHDOG_S = float(os.environ.get("DP_BENCH_SHARDED_WATCHDOG_S", "240"))
 VERIFY_BUDGET_S = float(os.environ.get("DP_BENCH_VERIFY_BUDGET_S", "30"))  # host verification of the last batch: all proofs if that fits, else an evenly spaced sample
 PUBLISHED = {"dense_4m": 1000.0 / 2335.0, "cnn_264k": 1000.0 / 1242.0}  # reference README.md:17-18 (hardware unstated)
 WORKLOADS = {
@@ -194,15 +195,6 @@ def main():
     if args.workload == "dense_4m" and not args.no_cnn:
         cnn_w = measure_workload(dpa, dev, "cnn_264k", conc, max(1, args.steps - 1), args.warmup, world, rank, dist, torch)
 
-    # BASELINE config 5 across the ranks: ONE 2^24 sumcheck, every rank owns a contiguous 1/N slice of each table and the
-    # per-round shares are all-gathered over RCCL (deep_prove_amd/sharded.py). Never allowed to take the headline down.
-    sharded = None
-    if world > 1 and not args.no_sumcheck24:
-        try:
-            sharded = sumcheck24_sharded(dev, dpa, dist, world, rank)
-        except Exception as e:  # noqa: BLE001
-            sharded = {"error": f"{type(e).__name__}: {e}"}
-
     result = None
     if rank == 0:
         def rate(w, steps):
@@ -249,9 +241,34 @@ def main():
                        "host_cpu_budget": budget, "host_threads_per_rank": int(os.environ["DP_HOST_THREADS"]),
                        "parallelism": f"replicas x{world} GPUs x {main_w['in_flight']} proofs in flight per GPU in lock-step cohorts of {os.environ.get('DP_COHORT', '8')} (independent proofs, no data-path collective)",
                        "proof_words": main_w["proof_words"], "setup_s": round(main_w["setup_s"], 2), "verified": True, "verified_proofs_of_last_step": main_w["verified"], "verify_ms_per_proof": main_w["verify_ms"], "device": dev.name},
-            "roofline": roofline, "cpu_baseline": cpu, "cnn_264k": cnn, "sumcheck24": sc24, "sumcheck24_sharded": sharded,
+            "roofline": roofline, "cpu_baseline": cpu, "cnn_264k": cnn, "sumcheck24": sc24, "sumcheck24_sharded": None,
         }
-        print(json.dumps(result))
+
+    # BASELINE config 5 across the ranks: ONE 2^24 sumcheck, every rank owns a contiguous 1/N slice of each table and the
+    # per-round shares are all-gathered over RCCL (deep_prove_amd/sharded.py). It runs AFTER the headline is complete and
+    # under a watchdog: neither an exception nor a collective that never returns may take the JSON line down.
+    if world > 1 and not args.no_sumcheck24:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                result["sumcheck24_sharded"] = {"error": f"no result within {SHARDED_WATCHDOG_S:.0f} s (watchdog)"}
+                print(json.dumps(result), flush=True)
+            else:
+                time.sleep(5.0)  # let rank 0 print first
+            os._exit(0)
+        dog = threading.Timer(SHARDED_WATCHDOG_S, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            sharded = sumcheck24_sharded(dev, dpa, dist, world, rank)
+        except Exception as e:  # noqa: BLE001
+            sharded = {"error": f"{type(e).__name__}: {e}"}
+        dog.cancel()
+        if rank == 0:
+            result["sumcheck24_sharded"] = sharded
+    if rank == 0:
+        print(json.dumps(result), flush=True)
     dev.close()
     if dist is not None:
         dist.destroy_process_group()
