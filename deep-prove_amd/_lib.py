@@ -48,6 +48,8 @@ SIGNATURES = {
     "dp_sc_session_round": (C.c_int32, [vp, u64p, u64p, C.POINTER(C.c_size_t)]),
     "dp_sc_session_finish": (C.c_int32, [vp, u64p, u64p]),
     "dp_sc_session_free": (C.c_int32, [vp]),
+    "dp_sumcheck_verify": (C.c_int32, [C.c_uint32, C.c_uint32, u64p, u64p, C.c_size_t, vp, u64p, u64p]),
+    "dp_logup_verify": (C.c_int32, [u64p, C.c_size_t, C.c_int32, u64p, u64p, vp, u64p, u64p, C.POINTER(u64p), C.POINTER(C.c_size_t)]),
     "dp_logup_prove": (C.c_int32, [vp, C.POINTER(vp), C.c_int32, C.c_int32, vp, u64p, u64p, vp, C.POINTER(u64p),
                                    C.POINTER(C.c_size_t)]),
     "dp_pcs_setup": (C.c_int32, [vp, C.c_size_t]),

@@ -217,6 +217,41 @@ def prove_parallel(dev, vpoly, transcript):
     return _take(pw, pn.value), finals
 
 
+def verify_sumcheck(claimed_sum, proof_words, num_vars, max_degree, transcript):
+    """IOPVerifierState::verify (sumcheck/src/verifier.rs:12-168), host only: returns the SubClaim as
+    (point [(c0, c1)] * num_vars, expected_evaluation (c0, c1)); raises DeepProveError(DP_ERR_VERIFY) on rejection"""
+    pw = np.ascontiguousarray(proof_words, dtype=np.uint64)
+    cs = (C.c_uint64 * 2)(*claimed_sum)
+    pt = np.zeros(2 * max(num_vars, 1), dtype=np.uint64)
+    ev = (C.c_uint64 * 2)()
+    check(_lib.load().dp_sumcheck_verify(num_vars, max_degree, cs, pw.ctypes.data_as(u64p), pw.size, transcript.h,
+                                         pt.ctypes.data_as(u64p), ev))
+    return [(int(pt[2 * i]), int(pt[2 * i + 1])) for i in range(num_vars)], (int(ev[0]), int(ev[1]))
+
+
+def verify_logup(proof_words, num_instances, constant_challenge, column_separation_challenge, transcript):
+    """logup_gkr::verifier::verify_logup_proof (zkml/src/lookup/logup_gkr/verifier.rs:16-211), host only: returns
+    (numerators, denominators, claims) with claims = [(point, eval)]; raises DeepProveError(DP_ERR_VERIFY) on rejection"""
+    pw = np.ascontiguousarray(proof_words, dtype=np.uint64)
+    cc = (C.c_uint64 * 2)(*constant_challenge)
+    cs = (C.c_uint64 * 2)(*column_separation_challenge)
+    num = np.zeros(2 * num_instances, dtype=np.uint64)
+    den = np.zeros(2 * num_instances, dtype=np.uint64)
+    cw, cn = u64p(), C.c_size_t()
+    check(_lib.load().dp_logup_verify(pw.ctypes.data_as(u64p), pw.size, num_instances, cc, cs, transcript.h,
+                                      num.ctypes.data_as(u64p), den.ctypes.data_as(u64p), C.byref(cw), C.byref(cn)))
+    w = _take(cw, cn.value)
+    pos, claims = 1, []
+    for _ in range(int(w[0])):
+        k = int(w[pos]); pos += 1
+        point = [(int(w[pos + 2 * i]), int(w[pos + 2 * i + 1])) for i in range(k)]
+        pos += 2 * k
+        claims.append((point, (int(w[pos]), int(w[pos + 1]))))
+        pos += 2
+    pair = lambda a: [(int(a[2 * i]), int(a[2 * i + 1])) for i in range(num_instances)]  # noqa: E731
+    return pair(num), pair(den), claims
+
+
 def logup_batch_prove(dev, columns, columns_per_instance, constant_challenge, column_separation_challenge, transcript,
                       multiplicities=None):
     lib = _lib.load()

@@ -193,6 +193,35 @@ int32_t dp_logup_prove(dp_ctx* ctx, const dp_buf* const* columns, int32_t ncols,
   });
 }
 
+int32_t dp_sumcheck_verify(uint32_t nv, uint32_t max_degree, const uint64_t claimed_sum[2], const uint64_t* proof_words, size_t proof_nwords,
+                           dp_transcript* t, uint64_t* point, uint64_t expected_evaluation[2]) {
+  return guard([&] {
+    DP_REQUIRE(claimed_sum && proof_words && t && point && expected_evaluation && max_degree >= 1, DP_ERR_ARG, "bad arguments");
+    Reader r(proof_words, proof_nwords); IOPProof p = r.iop();
+    DP_REQUIRE(r.pos == proof_nwords, DP_ERR_ARG, "proof stream: trailing words");
+    SubClaim sc = sumcheck_verify(read_point(claimed_sum, 1)[0], p, nv, max_degree, t->t);
+    for (size_t i = 0; i < sc.point.size(); i++) { point[2 * i] = sc.point[i].c0; point[2 * i + 1] = sc.point[i].c1; }
+    expected_evaluation[0] = sc.expected_evaluation.c0; expected_evaluation[1] = sc.expected_evaluation.c1;
+  });
+}
+int32_t dp_logup_verify(const uint64_t* proof_words, size_t proof_nwords, int32_t num_instances, const uint64_t cc[2], const uint64_t csc[2],
+                        dp_transcript* t, uint64_t* numerators, uint64_t* denominators, uint64_t** claims_words, size_t* claims_nwords) {
+  return guard([&] {
+    DP_REQUIRE(proof_words && num_instances > 0 && cc && csc && t, DP_ERR_ARG, "bad arguments");
+    Reader r(proof_words, proof_nwords); LogUpProof p = r.logup();
+    DP_REQUIRE(r.pos == proof_nwords, DP_ERR_ARG, "proof stream: trailing words");
+    LogUpVerifierClaim vc = verify_logup_proof(p, (size_t)num_instances, read_point(cc, 1)[0], read_point(csc, 1)[0], t->t);
+    for (size_t i = 0; i < vc.numerators.size(); i++) {
+      if (numerators) { numerators[2 * i] = vc.numerators[i].c0; numerators[2 * i + 1] = vc.numerators[i].c1; }
+      if (denominators) { denominators[2 * i] = vc.denominators[i].c0; denominators[2 * i + 1] = vc.denominators[i].c1; }
+    }
+    if (claims_words && claims_nwords) {
+      Writer w; w.u(vc.claims.size()); for (auto& c : vc.claims) w.claim(c);
+      *claims_words = copy_out(w.w); *claims_nwords = w.w.size();
+    }
+  });
+}
+
 int32_t dp_pcs_setup(dp_ctx* ctx, size_t max_poly_size) {
   return guard([&] { DP_REQUIRE(ctx && is_pow2(max_poly_size), DP_ERR_ARG, "max_poly_size must be a power of two"); ctx->dev->pcs_init(dp_ceil_log2(max_poly_size)); });
 }

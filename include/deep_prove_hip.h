@@ -84,6 +84,13 @@ int32_t dp_sumcheck_prove(dp_ctx* ctx, uint32_t num_vars, const dp_buf* const* t
                           int32_t nterms, dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords,
                           uint64_t* finals);
 
+/* IOPVerifierState::verify(claimed_sum, proof, aux_info{max_degree, num_variables}, transcript) -> SubClaim
+ * (sumcheck/src/verifier.rs:12-168). Host only (no dp_ctx: a verifier needs no device). proof_words: the IOPProof stream of
+ * dp_sumcheck_prove. On acceptance point receives the num_vars challenges (2 words each) and expected_evaluation the value
+ * the virtual polynomial must take there; DP_ERR_VERIFY on rejection (the reference panics / returns Err). */
+int32_t dp_sumcheck_verify(uint32_t num_vars, uint32_t max_degree, const uint64_t claimed_sum[2], const uint64_t* proof_words,
+                           size_t proof_nwords, dp_transcript* t, uint64_t* point, uint64_t expected_evaluation[2]);
+
 /* ---- round-level sumcheck: what a sharded prover exchanges between devices. The reference's thread-sharded
  * IOPProverState::prove_batch_polys (sumcheck/src/prover.rs:37-321) gives every worker a contiguous 1/2^k chunk of each
  * table, sums the workers' round evaluations and broadcasts one challenge; a session is one worker's side of it: the raw
@@ -104,6 +111,14 @@ int32_t dp_logup_prove(dp_ctx* ctx, const dp_buf* const* columns, int32_t ncols,
                        const dp_buf* multiplicities, const uint64_t constant_challenge[2],
                        const uint64_t column_separation_challenge[2], dp_transcript* t, uint64_t** proof_words,
                        size_t* proof_nwords);
+/* logup_gkr::verifier::verify_logup_proof(proof, num_instances, constant_challenge, column_separation_challenge, transcript)
+ * (zkml/src/lookup/logup_gkr/verifier.rs:16-211). Host only. On acceptance numerators / denominators receive the fractional
+ * sum of every instance (2 words each; the caller checks that all lookups and their table cancel, lookup/context.rs) and
+ * claims_words the output claims {count; per claim: point (len, ext...), eval} (malloc'ed, release with dp_free);
+ * DP_ERR_VERIFY on rejection. */
+int32_t dp_logup_verify(const uint64_t* proof_words, size_t proof_nwords, int32_t num_instances,
+                        const uint64_t constant_challenge[2], const uint64_t column_separation_challenge[2], dp_transcript* t,
+                        uint64_t* numerators, uint64_t* denominators, uint64_t** claims_words, size_t* claims_nwords);
 
 /* ---- PCS: mpcs::PolynomialCommitmentScheme for Basefold<GoldilocksExt2, BasefoldRSParams<PoseidonHasher>> */
 /* PCS::setup + PCS::trim (mpcs/src/basefold.rs:278-303): max_poly_size must be a power of two */

@@ -1,0 +1,128 @@
+"""The verifier side of the sumcheck / logup-GKR seams through the C ABI (dp_sumcheck_verify, dp_logup_verify: host only,
+no device) — ports of the reference's own tests with the ORACLE as the prover and the PRODUCT as the verifier, so the two
+independent implementations must agree on transcript, message layout and every check:
+  sumcheck/src/test.rs:23-56   random VirtualPolynomial, nv = 1 and 12: verify, then sub-claim == the polynomial at the point
+  zkml/src/lookup/logup_gkr/mod.rs:26-94   two random columns, n = 5..: verify, fractional sums, column claims."""
+import numpy as np
+import pytest
+
+P = 0xFFFFFFFF00000001
+
+
+def _ops():
+    from deep_prove_amd.sharded import e_add, e_mul
+    return e_add, e_mul
+
+
+def _rand_ext(rng):
+    return (int(rng.integers(0, P, dtype=np.uint64)), int(rng.integers(0, P, dtype=np.uint64)))
+
+
+def _random_vp(rng, nv, degree_range, num_products):
+    """VirtualPolynomial::random (virtual_poly.rs:230-262): products of fresh random MLEs with random coefficients, and the sum
+    over the hypercube"""
+    e_add, e_mul = _ops()
+    tables, terms, total = [], [], (0, 0)
+    for _ in range(num_products):
+        k = int(rng.integers(degree_range[0], degree_range[1]))
+        idx = []
+        for _ in range(k):
+            idx.append(len(tables))
+            tables.append(rng.integers(0, P, size=1 << nv, dtype=np.uint64))
+        coeff = _rand_ext(rng)
+        s = 0
+        for b in range(1 << nv):
+            prod = 1
+            for i in idx:
+                prod = prod * int(tables[i][b]) % P
+            s = (s + prod) % P
+        total = e_add(total, e_mul(coeff, (s, 0)))
+        terms.append((coeff, idx))
+    return tables, terms, total
+
+
+@pytest.mark.parametrize("nv,degree_range,num_products", [(1, (2, 4), 3), (12, (2, 4), 3), (5, (1, 2), 2), (7, (3, 4), 1)])
+def test_sumcheck_verifier_port_of_reference_test(oracle, nv, degree_range, num_products):
+    import deep_prove_amd as dpa
+    e_add, e_mul = _ops()
+    rng = np.random.default_rng(1000 + nv)
+    tables, terms, asserted_sum = _random_vp(rng, nv, degree_range, num_products)
+    max_degree = max(len(ix) for _, ix in terms)
+    proof, finals = oracle.sumcheck_prove(nv, tables, [False] * len(tables), terms, oracle.transcript(b"test"))
+    t = dpa.Transcript(b"test")
+    point, expected = dpa.verify_sumcheck(asserted_sum, proof, nv, max_degree, t)
+    # the sub-claim is the virtual polynomial at the point (test.rs:38-49) ...
+    value = (0, 0)
+    for coeff, idx in terms:
+        prod = (1, 0)
+        for i in idx:
+            prod = e_mul(prod, oracle.mle_eval(tables[i], False, point))
+        value = e_add(value, e_mul(coeff, prod))
+    assert value == expected, "wrong subclaim"
+    # ... the proof's point is the verifier's point (test.rs:50-55), the final evaluations are the tables at that point
+    assert int(proof[0]) == nv and [tuple(int(x) for x in proof[1 + 2 * i:3 + 2 * i]) for i in range(nv)] == point
+    for i, tab in enumerate(tables):
+        assert oracle.mle_eval(tab, False, point) == (int(finals[2 * i]), int(finals[2 * i + 1]))
+    # both transcripts are in the same state afterwards
+    ot = oracle.transcript(b"test")
+    oracle.sumcheck_prove(nv, tables, [False] * len(tables), terms, ot)
+    assert ot.read_challenge() == t.read_challenge()
+    # a wrong sum, a tampered round message and a truncated stream are rejected
+    with pytest.raises(dpa.DeepProveError):
+        dpa.verify_sumcheck(e_add(asserted_sum, (1, 0)), proof, nv, max_degree, dpa.Transcript(b"test"))
+    bad = proof.copy()
+    bad[1 + 2 * nv + 2] ^= np.uint64(1)  # evaluation at 0 of the first round (the very last evaluation of a proof only moves the sub-claim)
+    with pytest.raises(dpa.DeepProveError):
+        dpa.verify_sumcheck(asserted_sum, bad, nv, max_degree, dpa.Transcript(b"test"))
+    with pytest.raises(dpa.DeepProveError):
+        dpa.verify_sumcheck(asserted_sum, proof[:-3], nv, max_degree, dpa.Transcript(b"test"))
+
+
+@pytest.mark.parametrize("n", [5, 6, 8, 11])
+def test_logup_verifier_port_of_reference_test(oracle, n):
+    import deep_prove_amd as dpa
+    e_add, e_mul = _ops()
+    rng = np.random.default_rng(2000 + n)
+    cols = [rng.integers(0, P, size=1 << n, dtype=np.uint64) for _ in range(2)]
+    cc, csc = _rand_ext(rng), _rand_ext(rng)
+    proof = oracle.logup_prove(cols, 1, cc, csc, oracle.transcript())  # LogUpInput::new_lookup(columns, .., 1): two instances
+    t = dpa.Transcript()
+    nums, dens, claims = dpa.verify_logup(proof, 2, cc, csc, t)
+    for col, num, den in zip(cols, nums, dens):
+        # sum of the fractions -1 / (c + v) (mod.rs:62-83); Fraction addition keeps (n1 d2 + n2 d1, d1 d2) unnormalised
+        N, D = (0, 0), (1, 0)
+        for v in col:
+            d = e_add(cc, (int(v), 0))
+            N, D = e_add(e_mul(N, d), ((P - D[0]) % P, (P - D[1]) % P)), e_mul(D, d)
+        assert (N, D) == (num, den)
+    assert len(claims) == 2
+    for (point, ev), col in zip(claims, cols):
+        assert len(point) == n and oracle.mle_eval(col, False, point) == ev
+    ot = oracle.transcript()
+    oracle.logup_prove(cols, 1, cc, csc, ot)
+    assert ot.read_challenge() == t.read_challenge()
+    with pytest.raises(dpa.DeepProveError):  # other challenges than the prover's
+        dpa.verify_logup(proof, 2, csc, cc, dpa.Transcript())
+    bad = proof.copy()
+    bad[len(bad) // 2] ^= np.uint64(1)
+    with pytest.raises(dpa.DeepProveError):
+        dpa.verify_logup(bad, 2, cc, csc, dpa.Transcript())
+
+
+def test_logup_table_proof_is_accepted(oracle):
+    """LogUpInput::Table: one instance, the multiplicity column as numerators (the table side of a lookup argument)"""
+    import deep_prove_amd as dpa
+    rng = np.random.default_rng(77)
+    n = 8
+    table = np.arange(1 << n, dtype=np.uint64)
+    mult = rng.integers(0, 50, size=1 << n, dtype=np.uint64)
+    cc, csc = _rand_ext(rng), _rand_ext(rng)
+    proof = oracle.logup_prove([table], 1, cc, csc, oracle.transcript(), multiplicities=mult)
+    nums, dens, claims = dpa.verify_logup(proof, 1, cc, csc, dpa.Transcript())
+    e_add, e_mul = _ops()
+    N, D = (0, 0), (1, 0)
+    for v, m in zip(table, mult):
+        d = e_add(cc, (int(v), 0))
+        N, D = e_add(e_mul(N, d), e_mul(D, (int(m), 0))), e_mul(D, d)
+    assert (N, D) == (nums[0], dens[0])
+    assert len(claims) == 2  # multiplicities, then the table column
