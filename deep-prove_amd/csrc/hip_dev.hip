@@ -1656,6 +1656,15 @@ class HipDev : public Dev {
   bool zerocopy_ = true;  // DP_NO_ZEROCOPY=1 falls back to hipMemcpyAsync + hipStreamSynchronize
   bool persist_ = true;   // DP_NO_PERSIST=1 disables the persistent sumcheck kernel
   size_t excl_ = 0;       // dynamic LDS requested by one-workgroup kernels to keep a CU to themselves (DP_NO_EXCLUSIVE_CU=1: none)
+  // Experiment knobs for the cohort regime (defaults = the measured configuration): with 192 proofs in flight
+  // the exclusive workgroups hold ~100 CUs on average and the batched Merkle tail of a cohort asks for 360 at once.
+  //   DP_COHORT_EXCL=0        members of a cohort do not reserve the CU (single proofs still do)
+  //   DP_TAIL_MANY_EXCL=0     batched tails (several trees per launch) do not reserve the CU
+  //   DP_TAIL_MANY_THREADS=n  workgroup size of batched tails (256 / 512 / 1024): 256 threads x 128 VGPRs = a quarter of a CU
+  bool cohort_excl_ = !(getenv("DP_COHORT_EXCL") && !atoi(getenv("DP_COHORT_EXCL")));
+  bool tail_many_excl_ = !(getenv("DP_TAIL_MANY_EXCL") && !atoi(getenv("DP_TAIL_MANY_EXCL")));
+  int tail_many_threads_ = [] { const char* e = getenv("DP_TAIL_MANY_THREADS"); int v = e ? atoi(e) : 1024; return (v == 256 || v == 512) ? v : 1024; }();
+  size_t excl_now() const { return (co_ && !cohort_excl_) ? 0 : excl_; }
   unsigned long long* scdbg_ = nullptr;  // DP_SC_DEBUG=1: device cycle counters of the persistent sumcheck kernel
   unsigned long long* hmail_ = nullptr;      // host view of the challenge mailbox [seq, c0, c1]
   unsigned long long* hmail_dev_ = nullptr;  // device view
@@ -2131,9 +2140,9 @@ class HipDev : public Dev {
     for (int i = 0; i < MAX_TERMS; i++) f->coeff[i] = i < nterms ? coeffs[i] : ex_zero();
     unsigned long long seq = ++seq_;
     size_t work = (size_t)nterms * (n_after / 2) + (size_t)nt * n_after / 4;
-    int threads = excl_ ? 1024 : work >= 2048 ? 1024 : work >= 512 ? 512 : 256;
-    if (in_lds) { nb_ = tab_bytes; DPL_LDS_HI(k_sc_persist_lds, hi, dim3(1), dim3(threads), std::max(lds, excl_), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
-    else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_LDS_HI(k_sc_persist, hi, dim3(1), dim3(threads), excl_, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
+    int threads = excl_now() ? 1024 : work >= 2048 ? 1024 : work >= 512 ? 512 : 256;
+    if (in_lds) { nb_ = tab_bytes; DPL_LDS_HI(k_sc_persist_lds, hi, dim3(1), dim3(threads), std::max(lds, excl_now()), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
+    else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_LDS_HI(k_sc_persist, hi, dim3(1), dim3(threads), excl_now(), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
     wait_flag(seq, nwords);
     const u64* w = hres_;
     for (unsigned q = 0; q < rounds; q++) {
@@ -2253,13 +2262,13 @@ class HipDev : public Dev {
       unsigned rounds = 0; for (size_t m = n_after; m > 1; m >>= 1) rounds++;
       seq_ += rounds + 1;
       size_t work = (size_t)nterms * (n_after / 2) + (size_t)nt * n_after / 4;
-      int threads = excl_ ? 1024 : work >= 2048 ? 1024 : work >= 512 ? 512 : 256;  // exclusive CU: always the full 16 waves
+      int threads = excl_now() ? 1024 : work >= 2048 ? 1024 : work >= 512 ? 512 : 256;  // exclusive CU: always the full 16 waves
       size_t lds = (size_t)nt * (n_in / 2) * 16;
       double tab_bytes = 0; for (int i = 0; i < nt; i++) tab_bytes += (double)n_in * (tabs[i].ext && !r ? 16.0 : tabs[i].ext ? 16.0 : 8.0);
       // algorithmic HBM bytes of the launch: every table is read once (the LDS variant never touches HBM again; the
       // global variant also writes and re-reads the halving ping-pong buffers: + 3 x 16 B x n/2 per table in total)
-      if (lds <= SC_LDS_MAX) { nb_ = tab_bytes; DPL_LDS_HI(k_sc_persist_lds, hi, dim3(1), dim3(threads), std::max(lds, excl_), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }
-      else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_LDS_HI(k_sc_persist, hi, dim3(1), dim3(threads), excl_, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }
+      if (lds <= SC_LDS_MAX) { nb_ = tab_bytes; DPL_LDS_HI(k_sc_persist_lds, hi, dim3(1), dim3(threads), std::max(lds, excl_now()), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }
+      else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_LDS_HI(k_sc_persist, hi, dim3(1), dim3(threads), excl_now(), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }
       wait_flag(++sess_.seq, 2 * nraw);
       if (r) for (int i = 0; i < nt; i++) { tabs[i].p = sess_.a[i]; tabs[i].n = n_after; tabs[i].ext = true; }
       read_terms();
@@ -2278,8 +2287,8 @@ class HipDev : public Dev {
       a.ntabs = nt; a.nterms = nterms; a.has_r = r ? 1 : 0; a.n_after = n_after; a.r = r ? *r : ex_zero();
       unsigned long long seq = ++seq_;
       size_t work = (size_t)nterms * (n_after / 2) + (r ? (size_t)nt * n_after / 4 : 0);
-      int threads = excl_ ? 1024 : work >= 2048 ? 1024 : work >= 512 ? 512 : 256;  // exclusive CU: always the full 16 waves
-      nb_ = bytes; DPL_LDS_HI(k_sc_small, hi, dim3(1), dim3(threads), excl_, a, (Ext*)hres_dev_, hflag_dev_, seq);
+      int threads = excl_now() ? 1024 : work >= 2048 ? 1024 : work >= 512 ? 512 : 256;  // exclusive CU: always the full 16 waves
+      nb_ = bytes; DPL_LDS_HI(k_sc_small, hi, dim3(1), dim3(threads), excl_now(), a, (Ext*)hres_dev_, hflag_dev_, seq);
       wait_flag(seq, 2 * nraw);
       read_terms();
       return;
@@ -2431,11 +2440,11 @@ class HipDev : public Dev {
   void tails_to_host(const TailDesc* dd, size_t nd) {
     if (nd == 1 && zerocopy_) {
       unsigned long long seq = ++seq_;
-      nb_ = 0; DPL_LDS(k_merkle_tail, dim3(1), dim3(1024), excl_, dd, dres_, hres_dev_, hflag_dev_, seq);
+      nb_ = 0; DPL_LDS(k_merkle_tail, dim3(1), dim3(1024), excl_now(), dd, dres_, hres_dev_, hflag_dev_, seq);
       wait_flag(seq, 4);
       return;
     }
-    nb_ = 0; DPL_LDS(k_merkle_tail, dim3((unsigned)nd), dim3(1024), excl_, dd, dres_, (u64*)nullptr, (unsigned long long*)nullptr, 0ull);
+    nb_ = 0; DPL_LDS(k_merkle_tail, dim3((unsigned)nd), dim3(tail_many_threads_), tail_many_excl_ ? excl_now() : size_t(0), dd, dres_, (u64*)nullptr, (unsigned long long*)nullptr, 0ull);
     fetch(4 * nd);
   }
   // layers of at most this many digests are finished by k_merkle_tail (one workgroup, no relaunch between layers); wider

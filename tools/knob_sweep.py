@@ -1,0 +1,77 @@
+"""Sweep of the cohort-regime knobs on one GPU, torch-free, every configuration in a fresh process (the knobs are read at
+library / context creation) and every measured batch checked (proof 0 == the sequential proof, sampled proofs verify).
+usage: python tools/knob_sweep.py [workload] [out.jsonl] [budget_s]          (driver)
+       python tools/knob_sweep.py --one workload conc                        (one configuration, env = knobs)
+Results: one JSON line per configuration, appended as they finish."""
+import json, os, subprocess, sys, time
+
+CONFIGS = [  # (name, proofs in flight, env)
+    ("base_192", 192, {}),
+    ("base_256", 256, {}),
+    ("threads7_192", 192, {"DP_HOST_THREADS": "7"}),
+    ("threads4_192", 192, {"DP_HOST_THREADS": "4"}),
+    ("tail256_192", 192, {"DP_TAIL_MANY_THREADS": "256", "DP_TAIL_MANY_EXCL": "0"}),
+    ("tail512_192", 192, {"DP_TAIL_MANY_THREADS": "512", "DP_TAIL_MANY_EXCL": "0"}),
+    ("tailnoexcl_192", 192, {"DP_TAIL_MANY_EXCL": "0"}),
+    ("cohort_noexcl_192", 192, {"DP_COHORT_EXCL": "0"}),
+    ("cohort_noexcl_tail256_192", 192, {"DP_COHORT_EXCL": "0", "DP_TAIL_MANY_THREADS": "256", "DP_TAIL_MANY_EXCL": "0"}),
+    ("noexcl_192", 192, {"DP_NO_EXCLUSIVE_CU": "1"}),
+    ("cohort4_192", 192, {"DP_COHORT": "4"}),
+    ("cohort12_192", 192, {"DP_COHORT": "12"}),
+    ("tail256_256", 256, {"DP_TAIL_MANY_THREADS": "256", "DP_TAIL_MANY_EXCL": "0"}),
+    ("hostfs_192", 192, {"DP_DEVICE_FS": "0"}),
+    ("lpmax256_192", 192, {"DP_MERKLE_LP_MAX": "256"}),
+    ("tailmax1024_192", 192, {"DP_TAIL_MAX": "1024"}),
+]
+
+
+def one(wl, conc):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+    sys.path.insert(0, os.getcwd())
+    import numpy as np
+    import deep_prove_amd as dpa
+    dev = dpa.Device(0)
+    mb = getattr(dpa.models, wl)()
+    ctx = dpa.Context.generate(dev, mb.blob())
+    pr = dpa.Prover(ctx)
+    xs = np.stack([mb.input(3000 + i) for i in range(2 * conc)])
+    single, out0 = pr.prove(xs[0])
+    t0 = time.perf_counter(); pr.prove(xs[0]); lat = time.perf_counter() - t0
+    pr.prove_batch(xs[:conc], conc)
+    best = 0.0
+    for _ in range(2):
+        t0 = time.perf_counter(); proofs, outs, _ = pr.prove_batch(xs, conc); dt = time.perf_counter() - t0
+        best = max(best, len(xs) / dt)
+    ok = proofs[0].size == single.size and bool((proofs[0] == single).all())
+    vb = ctx.verifier_blob()
+    for j in (1, len(xs) - 1):
+        dpa.verify(vb, proofs[j], xs[j], outs[j])
+    print(json.dumps({"proofs_per_s": round(best, 2), "in_flight": pr.in_flight(), "latency_ms": round(1000 * lat, 2), "batch0_equals_single": ok, "verified": 2}), flush=True)
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--one":
+        return one(sys.argv[2], int(sys.argv[3]))
+    wl = sys.argv[1] if len(sys.argv) > 1 else "dense_4m"
+    out = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/knob_sweep.jsonl"
+    budget = float(sys.argv[3]) if len(sys.argv) > 3 else 300.0
+    os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+    t0 = time.time()
+    for name, conc, env in CONFIGS:
+        if time.time() - t0 > budget:
+            break
+        e = dict(os.environ); e.update(env)
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", wl, str(conc)], env=e, capture_output=True, text=True, timeout=90)
+            line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+            rec = json.loads(line) if line.startswith("{") else {"error": (r.stderr or r.stdout)[-400:]}
+        except subprocess.TimeoutExpired:
+            rec = {"error": "timeout"}
+        rec.update({"config": name, "workload": wl, "asked": conc, "env": env, "t": round(time.time() - t0, 1)})
+        with open(out, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+        print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()
