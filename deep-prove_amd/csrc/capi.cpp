@@ -348,11 +348,11 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     // (read-only) model commitments
     // Arena of a worker: DP_WORKER_ARENA_BYTES, else 1.25 x the largest footprint a proof of this model has had (one proof
     // alone runs in latency mode, whose multi-workgroup sumchecks keep every fold level: an upper bound of what a proof in
-    // flight needs) + 64 MB, else — nothing proved yet — 1.5 GB. The number of proofs in flight is cut to what fits in
+    // flight needs) + 64 MB (at least 256 MB), else — nothing proved yet — 1.5 GB. The number of proofs in flight is cut to what fits in
     // 90 % of the free HBM instead of failing: `concurrency` is a cap, not a demand.
     const char* env = getenv("DP_WORKER_ARENA_BYTES");
     const size_t MB64 = size_t(64) << 20;
-    size_t arena = env ? strtoull(env, nullptr, 10) : m->prove_peak ? ((m->prove_peak + m->prove_peak / 4 + MB64 + MB64 - 1) / MB64) * MB64 : (size_t(3) << 29);
+    size_t arena = env ? strtoull(env, nullptr, 10) : m->prove_peak ? std::max(4 * MB64, ((m->prove_peak + m->prove_peak / 4 + MB64 + MB64 - 1) / MB64) * MB64) : (size_t(3) << 29);
     if (m->workers.size() + 1 < nw) {
       // the cap is fixed by the first batch that needs more workers than exist (later batches must not creep into the reserve)
       if (!m->in_flight_cap) {

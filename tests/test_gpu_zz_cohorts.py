@@ -9,14 +9,6 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def dev():
-    import deep_prove_amd as dpa
-    d = dpa.Device(0)
-    yield d
-    d.close()
-
-
 def _check(pr, vb, xs, seq, conc):
     import deep_prove_amd as dpa
     proofs, outs, _ = pr.prove_batch(xs, conc)

@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""What a rocprofv3 --kernel-trace of proofs in flight says about the cohort regime. usage:
+  python tools/trace_analyze.py <x_results.db> [--sequence]
+* per-queue busy fraction: sum of (end - start) of a queue's kernels / the queue's span — in these traces the next kernel
+  of a queue starts the instant its predecessor ends, so (end - start) includes the wait for execution resources;
+* duration distribution of the one-wave k_publish (3 us alone): the price of a dispatch under load;
+* CUs held exclusively: workgroups of kernels launched with >= 80 KB of dynamic LDS (the CU reservation of the
+  one-workgroup kernels), resident by the trace's timestamps — time average, quantiles, CU-seconds per kernel;
+* --sequence: the run-length compressed launch sequence of the last proof step of one cohort queue with durations (us)."""
+import sqlite3
+import sys
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+from rocpd_summary import short
+
+
+def quantiles(vals, qs):
+    v = sorted(vals)
+    return [v[min(len(v) - 1, int(q * len(v)))] for q in qs] if v else []
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    rows = db.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x, queue_id, lds_size from kernels order by start").fetchall()
+    kc = [r for r in rows if short(r[0]).startswith("kc:")]
+    if not kc:
+        print("no cohort launches (kc:*) in this trace")
+        return
+    t0, t1 = kc[0][1], max(r[2] for r in kc)
+    span = (t1 - t0) / 1e9
+    print(f"{len(kc)} cohort launches on {len(set(r[7] for r in kc))} queues over {span:.3f} s")
+    busy = []
+    for q in sorted(set(r[7] for r in kc)):
+        rq = [r for r in kc if r[7] == q]
+        busy.append(sum(r[2] - r[1] for r in rq) / max(1, rq[-1][2] - rq[0][1]))
+    print("queue busy fraction (kernel start..end / queue span): min %.2f  mean %.2f  max %.2f" % (min(busy), sum(busy) / len(busy), max(busy)))
+    pub = [(r[2] - r[1]) / 1e3 for r in kc if short(r[0]) == "kc:k_publish"]
+    if pub:
+        print("k_publish start..end (us): p5 %.1f  p50 %.1f  p75 %.1f  p95 %.1f  max %.1f" % tuple(quantiles(pub, (0.05, 0.5, 0.75, 0.95, 0.999999))))
+    excl = [r for r in kc if r[8] >= 80000]
+    wg = lambda r: (r[3] // r[6]) * r[4] * r[5]  # noqa: E731
+    cu_s = sum((r[2] - r[1]) / 1e9 * wg(r) for r in excl)
+    print(f"exclusive workgroups: {cu_s:.1f} CU-seconds -> {cu_s / span:.1f} CUs held on average")
+    by = {}
+    for r in excl:
+        by[short(r[0])] = by.get(short(r[0]), 0.0) + (r[2] - r[1]) / 1e9 * wg(r)
+    for k, v in sorted(by.items(), key=lambda kv: -kv[1]):
+        print(f"   {k:40s} {v:8.2f} CU-s")
+    ev = sorted([(r[1], wg(r)) for r in excl] + [(r[2], -wg(r)) for r in excl])
+    hist, cur, last = {}, 0, ev[0][0] if ev else 0
+    for t, d in ev:
+        hist[cur] = hist.get(cur, 0) + (t - last)
+        last, cur = t, cur + d
+    tot, acc, qs = sum(hist.values()) or 1, 0, {}
+    for k in sorted(hist):
+        acc += hist[k]
+        for q in (0.5, 0.9, 0.99):
+            if q not in qs and acc >= q * tot:
+                qs[q] = k
+    print("exclusive workgroups resident (trace timestamps): p50 %s  p90 %s  p99 %s  max %s" % (qs.get(0.5), qs.get(0.9), qs.get(0.99), max(hist) if hist else 0))
+    if "--sequence" in sys.argv:
+        q = kc[-1][7]
+        seq = [r for r in kc if r[7] == q]
+        seq = seq[len(seq) // 2:]
+        out = []
+        for r in seq:
+            k, d = short(r[0])[3:].replace("k_", ""), (r[2] - r[1]) / 1e3
+            if out and out[-1][0] == k:
+                out[-1][1] += 1; out[-1][2] += d
+            else:
+                out.append([k, 1, d])
+        line = ""
+        for k, c, d in out:
+            item = f"{k}{'x' + str(c) if c > 1 else ''}({d:.0f})"
+            if len(line) + len(item) > 150:
+                print(line); line = ""
+            line += item + " "
+        print(line)
+        print("this half of the queue: wall %.1f ms, kernel start..end %.1f ms" % ((seq[-1][2] - seq[0][1]) / 1e6, sum(r[2] - r[1] for r in seq) / 1e6))
+
+
+if __name__ == "__main__":
+    main()
