@@ -4,6 +4,7 @@
 // Every method is the literal spec of the corresponding HIP kernel family in deep-prove_amd/csrc/hip_dev.hip.
 #pragma once
 #include "../../deep-prove_amd/csrc/dev.h"
+#include "../../deep-prove_amd/csrc/sumcheck.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -81,6 +82,44 @@ class CpuDev : public Dev {
     }
   }
   void sc_finish(DBuf* tabs, int nt, Ext r, Ext* fin) override { for (int i = 0; i < nt; i++) { tabs[i] = fold(tabs[i], r); fin[i] = X(tabs[i])[0]; } }
+  // The contract of Dev::sc_tail (device-side Fiat-Shamir, HipDev's throughput mode), spelled out on the CPU: from the sponge
+  // the host hands over, run every remaining round — raw sums, coefficients and extrapolation to max_degree + 1 evaluations,
+  // absorb, squeeze "Internal round", fold — and hand the sponge back. Off unless device_fs is set (DP_DOUBLE_DEVICE_FS=1 in
+  // the harness); like the device it declines tables outside a size window, so both host paths get exercised in one proof.
+  bool device_fs = false;
+  size_t tails_taken = 0, tails_declined = 0;
+  bool sc_tail(DBuf* tabs, int nt, const Ext* r, const ScTerm* terms, const Ext* coeffs, int nterms, unsigned md, Challenger& ch,
+               std::vector<std::vector<Ext>>& msgs, std::vector<Ext>& point, Ext* finals) override {
+    if (!device_fs) return false;
+    size_t n_after = r ? tabs[0].n / 2 : tabs[0].n;
+    if (n_after < 4 || n_after > 256) { tails_declined++; return false; }
+    tails_taken++;
+    Transcript t("");  // only a carrier for the sponge: its own state is replaced by the caller's
+    t.challenger() = ch;
+    Ext chal = r ? *r : ex_zero();
+    bool have = r != nullptr;
+    size_t nraw = 0; for (int i = 0; i < nterms; i++) nraw += terms[i].k + 1;
+    std::vector<Ext> raw(nraw);
+    for (size_t m = n_after; m > 1; m >>= 1) {
+      sc_round(tabs, nt, have ? &chal : nullptr, terms, nterms, raw.data());
+      std::vector<Ext> msg(md + 1, ex_zero());
+      size_t off = 0;
+      for (int ti = 0; ti < nterms; ti++) {
+        unsigned k = terms[ti].k;
+        std::vector<Ext> s(k + 1);
+        for (unsigned j = 0; j <= k; j++) s[j] = ex_mul(raw[off + j], coeffs[ti]);
+        off += k + 1;
+        for (unsigned j = 0; j <= md; j++) msg[j] = ex_add(msg[j], j <= k ? s[j] : extrapolate_small(s.data(), k, j));
+      }
+      for (const Ext& e : msg) t.append_ext(e);
+      chal = t.get_and_append_challenge("Internal round");
+      have = true;
+      msgs.push_back(msg); point.push_back(chal);
+    }
+    sc_finish(tabs, nt, chal, finals);
+    ch = t.challenger();
+    return true;
+  }
   void logup_den(const DBuf& out, const DBuf* cols, int nc, Ext c, Ext chi) override {
     for (size_t i = 0; i < out.n; i++) { Ext acc = c, pw = ex_one(); for (int j = 0; j < nc; j++) { acc = ex_add(acc, ex_mul_base(pw, B(cols[j])[i])); pw = ex_mul(pw, chi); } X(out)[i] = acc; }
   }

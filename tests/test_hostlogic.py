@@ -6,8 +6,11 @@ import subprocess
 import pytest
 
 
-def run(binary, *args):
-    return subprocess.run([binary, *map(str, args)], capture_output=True, text=True, timeout=600)
+def run(binary, *args, env=None):
+    import os
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([binary, *map(str, args)], capture_output=True, text=True, timeout=600, env=e)
 
 
 @pytest.mark.parametrize("width,seed", [(8, 5), (16, 7), (64, 1)])
@@ -15,6 +18,20 @@ def test_proof_stream_identical_to_oracle_and_accepted(hostlogic_bin, width, see
     r = run(hostlogic_bin, width, seed)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "identical=1" in r.stdout
+    assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
+
+
+@pytest.mark.parametrize("args", [(16, 7), (64, 1), ("cnn", 4)])
+def test_device_side_fiat_shamir_contract(hostlogic_bin, args):
+    """Dev::sc_tail (the persistent sumcheck kernel runs the transcript rounds itself and hands the sponge back): with the
+    CPU double taking the tails of small sumchecks and declining the others, the host orchestrator still produces the
+    oracle's stream byte for byte"""
+    r = run(hostlogic_bin, *args, env={"DP_DOUBLE_DEVICE_FS": "1"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical=1" in r.stdout
+    taken = int(r.stdout.split("sc_tail: ")[1].split()[0])
+    declined = int(r.stdout.split("taken by the double, ")[1].split()[0])
+    assert taken > 10 and declined > 0, r.stdout
     assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
 
 
