@@ -69,6 +69,21 @@ def timed_region(prove_batch, my_inputs, conc, steps, warmup, dist=None, device_
     return elapsed, last
 
 
+def guarded(fn, seconds, on_timeout):
+    """fn() under a watchdog: its result, {"error": ...} if it raises, and `on_timeout()` (from a timer thread) if it has not
+    returned after `seconds` — a collective that never returns cannot be cancelled, only left behind"""
+    import threading
+    dog = threading.Timer(seconds, on_timeout)
+    dog.daemon = True
+    dog.start()
+    try:
+        return fn()
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        dog.cancel()
+
+
 def make_model(dpa, workload):
     return {"dense_4m": dpa.models.dense_4m, "cnn_264k": dpa.models.cnn_264k, "mlp_w256": lambda: dpa.models.mlp(3, 256, config=5)}[workload]()
 
@@ -248,8 +263,6 @@ def main():
     # per-round shares are all-gathered over RCCL (deep_prove_amd/sharded.py). It runs AFTER the headline is complete and
     # under a watchdog: neither an exception nor a collective that never returns may take the JSON line down.
     if world > 1 and not args.no_sumcheck24:
-        import threading
-
         def give_up():
             if rank == 0:
                 result["sumcheck24_sharded"] = {"error": f"no result within {SHARDED_WATCHDOG_S:.0f} s (watchdog)"}
@@ -257,14 +270,7 @@ def main():
             else:
                 time.sleep(5.0)  # let rank 0 print first
             os._exit(0)
-        dog = threading.Timer(SHARDED_WATCHDOG_S, give_up)
-        dog.daemon = True
-        dog.start()
-        try:
-            sharded = sumcheck24_sharded(dev, dpa, dist, world, rank)
-        except Exception as e:  # noqa: BLE001
-            sharded = {"error": f"{type(e).__name__}: {e}"}
-        dog.cancel()
+        sharded = guarded(lambda: sumcheck24_sharded(dev, dpa, dist, world, rank), SHARDED_WATCHDOG_S, give_up)
         if rank == 0:
             result["sumcheck24_sharded"] = sharded
     if rank == 0:

@@ -1515,7 +1515,18 @@ struct Cohort {
   size_t executed = 0;                                 // every launch number < executed has run to completion
   size_t nfired = 0, npacks = 0;
 
+  // DP_COHORT_XCD=1 (experiment, default off): the cohort's stream is confined to ONE XCD (32 CUs, its own L2) with a CU
+  // mask, cohorts dealt round robin over the 8 XCDs — every kernel of a proof then runs under one coherent L2 and cohorts on
+  // different XCDs cannot take each other's CUs. Mask bit i of a multi-XCD device addresses XCD i % 8, CU i / 8.
   explicit Cohort(size_t ring_bytes = size_t(32) << 20) : ring_cap(ring_bytes) {
+    static std::atomic<unsigned> next_xcd{0};
+    const char* xe = getenv("DP_COHORT_XCD");
+    if (xe && atoi(xe)) {
+      unsigned x = next_xcd.fetch_add(1) % 8;
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (unsigned bit = x; bit < 256; bit += 8) mask[bit / 32] |= 1u << (bit % 32);
+      HIP_CHECK(hipExtStreamCreateWithCUMask(&s, 8, mask));
+    } else
     HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     HIP_CHECK(hipHostMalloc((void**)&ring, ring_cap, hipHostMallocMapped | hipHostMallocCoherent));
     HIP_CHECK(hipHostGetDevicePointer((void**)&ring_dev, ring, 0));
@@ -1665,6 +1676,13 @@ class HipDev : public Dev {
   bool tail_many_excl_ = !(getenv("DP_TAIL_MANY_EXCL") && !atoi(getenv("DP_TAIL_MANY_EXCL")));
   int tail_many_threads_ = [] { const char* e = getenv("DP_TAIL_MANY_THREADS"); int v = e ? atoi(e) : 1024; return (v == 256 || v == 512) ? v : 1024; }();
   size_t excl_now() const { return (co_ && !cohort_excl_) ? 0 : excl_; }
+  //   DP_COHORT_PERSIST_THREADS=n  workgroup size of the one-workgroup sumcheck kernels of cohort members (256 / 512 / 1024;
+  //                                default: 1024 when the CU is reserved, else by the amount of work)
+  int cohort_persist_threads_ = [] { const char* e = getenv("DP_COHORT_PERSIST_THREADS"); int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 0; }();
+  int persist_threads(size_t work) const {
+    if (co_ && cohort_persist_threads_) return cohort_persist_threads_;
+    return excl_now() ? 1024 : work >= 2048 ? 1024 : work >= 512 ? 512 : 256;  // exclusive CU: always the full 16 waves
+  }
   unsigned long long* scdbg_ = nullptr;  // DP_SC_DEBUG=1: device cycle counters of the persistent sumcheck kernel
   unsigned long long* hmail_ = nullptr;      // host view of the challenge mailbox [seq, c0, c1]
   unsigned long long* hmail_dev_ = nullptr;  // device view
@@ -2140,7 +2158,7 @@ class HipDev : public Dev {
     for (int i = 0; i < MAX_TERMS; i++) f->coeff[i] = i < nterms ? coeffs[i] : ex_zero();
     unsigned long long seq = ++seq_;
     size_t work = (size_t)nterms * (n_after / 2) + (size_t)nt * n_after / 4;
-    int threads = excl_now() ? 1024 : work >= 2048 ? 1024 : work >= 512 ? 512 : 256;
+    int threads = persist_threads(work);
     if (in_lds) { nb_ = tab_bytes; DPL_LDS_HI(k_sc_persist_lds, hi, dim3(1), dim3(threads), std::max(lds, excl_now()), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
     else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_LDS_HI(k_sc_persist, hi, dim3(1), dim3(threads), excl_now(), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
     wait_flag(seq, nwords);
@@ -2262,7 +2280,7 @@ class HipDev : public Dev {
       unsigned rounds = 0; for (size_t m = n_after; m > 1; m >>= 1) rounds++;
       seq_ += rounds + 1;
       size_t work = (size_t)nterms * (n_after / 2) + (size_t)nt * n_after / 4;
-      int threads = excl_now() ? 1024 : work >= 2048 ? 1024 : work >= 512 ? 512 : 256;  // exclusive CU: always the full 16 waves
+      int threads = persist_threads(work);
       size_t lds = (size_t)nt * (n_in / 2) * 16;
       double tab_bytes = 0; for (int i = 0; i < nt; i++) tab_bytes += (double)n_in * (tabs[i].ext && !r ? 16.0 : tabs[i].ext ? 16.0 : 8.0);
       // algorithmic HBM bytes of the launch: every table is read once (the LDS variant never touches HBM again; the
@@ -2287,7 +2305,7 @@ class HipDev : public Dev {
       a.ntabs = nt; a.nterms = nterms; a.has_r = r ? 1 : 0; a.n_after = n_after; a.r = r ? *r : ex_zero();
       unsigned long long seq = ++seq_;
       size_t work = (size_t)nterms * (n_after / 2) + (r ? (size_t)nt * n_after / 4 : 0);
-      int threads = excl_now() ? 1024 : work >= 2048 ? 1024 : work >= 512 ? 512 : 256;  // exclusive CU: always the full 16 waves
+      int threads = persist_threads(work);
       nb_ = bytes; DPL_LDS_HI(k_sc_small, hi, dim3(1), dim3(threads), excl_now(), a, (Ext*)hres_dev_, hflag_dev_, seq);
       wait_flag(seq, 2 * nraw);
       read_terms();

@@ -128,3 +128,21 @@ def test_sharded_sumcheck_over_gloo_world_size_2(oracle):
     oproof, ofinals = oracle.sumcheck_prove(7, tabs, [False] * 3, terms, oracle.transcript(b"test"))
     for rank, proof, finals in res:
         assert proof == oproof.tolist() and finals == ofinals.tolist(), f"rank {rank} differs"
+
+
+def test_bench_guarded_section():
+    """bench.guarded: the optional sharded-sumcheck section of a multi-GPU run may fail or hang without taking the headline
+    JSON line down"""
+    import threading
+    import time
+    import bench
+    fired = threading.Event()
+    assert bench.guarded(lambda: {"ok": 1}, 5.0, fired.set) == {"ok": 1}
+    out = bench.guarded(lambda: (_ for _ in ()).throw(RuntimeError("rank died")), 5.0, fired.set)
+    assert out == {"error": "RuntimeError: rank died"} and not fired.is_set()
+    bench.guarded(lambda: time.sleep(0.6), 0.2, fired.set)  # a section that outlives its budget: the watchdog fires
+    assert fired.is_set()
+    fired.clear()
+    bench.guarded(lambda: None, 0.2, fired.set)  # ... and is disarmed when the section returns in time
+    time.sleep(0.4)
+    assert not fired.is_set()

@@ -19,6 +19,10 @@ CONFIGS = [  # (name, proofs in flight, env)
     ("cohort4_192", 192, {"DP_COHORT": "4"}),
     ("cohort12_192", 192, {"DP_COHORT": "12"}),
     ("tail256_256", 256, {"DP_TAIL_MANY_THREADS": "256", "DP_TAIL_MANY_EXCL": "0"}),
+    ("xcd_192", 192, {"DP_COHORT_XCD": "1"}),
+    ("xcd_256", 256, {"DP_COHORT_XCD": "1"}),
+    ("persist256_noexcl_192", 192, {"DP_COHORT_EXCL": "0", "DP_COHORT_PERSIST_THREADS": "256"}),
+    ("persist512_192", 192, {"DP_COHORT_PERSIST_THREADS": "512"}),
     ("hostfs_192", 192, {"DP_DEVICE_FS": "0"}),
     ("lpmax256_192", 192, {"DP_MERKLE_LP_MAX": "256"}),
     ("tailmax1024_192", 192, {"DP_TAIL_MAX": "1024"}),
