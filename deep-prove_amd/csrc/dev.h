@@ -154,6 +154,20 @@ class Dev {
       circuits.push_back(cd);
     }
   }
+  // All layers of a logup-GKR batch proof WITH the transcript on the device (the step after sc_tail: one device wait per
+  // lookup argument instead of one per tree layer): from the sponge `ch`, the initial (batching, alpha, lambda) and claim —
+  // the state of logup_batch_prove (logup.h) right before its layer loop — run every layer: absorb the claim, the batched
+  // sumcheck over eq(point, .) and the layer's numerators / denominators, the three challenges, the next claim.
+  // On `true`: layer_msgs[l] / layer_points[l] hold the round messages and challenges of layer l's sumcheck, round_evals[l]
+  // its final evaluations without the eq table, `point` the final point (last sumcheck point + last batching challenge) and
+  // `ch` the sponge after the last challenge. `false`: not taken, nothing changed. No shipped device implements it yet
+  // (the contract is pinned by the CPU double of tests/, which runs logup_layers of logup.h on a private transcript).
+  struct LogupTailArgs { const std::vector<LogupCircuitDev>* circuits; bool initial_lookup, is_table; unsigned total_layers; Ext batching, alpha, lambda, claim; };
+  virtual bool logup_tail(const LogupTailArgs& a, Challenger& ch, std::vector<std::vector<std::vector<Ext>>>& layer_msgs,
+                          std::vector<std::vector<Ext>>& layer_points, std::vector<std::vector<Ext>>& round_evals, std::vector<Ext>& point) {
+    (void)a; (void)ch; (void)layer_msgs; (void)layer_points; (void)round_evals; (void)point;
+    return false;
+  }
   // ---- Basefold (K5-K12, K14)
   virtual void pcs_init(unsigned full_message_size_log) = 0;
   virtual DevCommit commit(const DBuf& evals, bool persistent) = 0;

@@ -13,37 +13,12 @@ struct LogUpInputDev {
   size_t columns_per_instance = 1;
 };
 
-inline LogUpProof logup_batch_prove(Dev& dev, const LogUpInputDev& in, Transcript& t) {
-  size_t mk = dev.mark();
-  DP_REQUIRE(!in.columns.empty(), DP_ERR_ARG, "logup: no columns");
-  size_t n = in.columns[0].n;
-  unsigned nvars = dp_ceil_log2(n);
-  DP_REQUIRE((size_t(1) << nvars) == n && n >= 4, DP_ERR_SHAPE, "logup: column length must be a power of two >= 4");
-  for (auto& c : in.columns) DP_REQUIRE(c.n == n && !c.ext, DP_ERR_SHAPE, "logup: columns must be base field of equal length");
-  // ---- build the fractional-sum trees (one per instance); layer j has length n >> j
-  size_t cpi = in.is_table ? in.columns.size() : in.columns_per_instance;
-  DP_REQUIRE(in.columns.size() % cpi == 0, DP_ERR_SHAPE, "logup: column count must be a multiple of columns_per_instance");
-  int ninst = (int)(in.columns.size() / cpi);
-  std::vector<LogupCircuitDev> circuits;
-  std::vector<Ext> outs;
-  dev.logup_build(in.columns.data(), (int)cpi, ninst, in.is_table ? in.multiplicities : DBuf(), in.constant_challenge,
-                  in.column_separation_challenge, circuits, outs);
-  const bool initial_lookup = !in.is_table;
-  unsigned total_layers = nvars - 1;
-  LogUpProof proof; proof.is_table = in.is_table;
-  for (int i = 0; i < ninst; i++) proof.circuit_outputs.push_back({outs[4 * i], outs[4 * i + 1], outs[4 * i + 2], outs[4 * i + 3]});
-  t.append_field_element(gl_from_u64(circuits.size()));
-  for (auto& ev : proof.circuit_outputs) t.append_exts(ev);
-  Ext batching = t.get_and_append_challenge("initial_batching");
-  Ext alpha = t.get_and_append_challenge("initial_alpha");
-  Ext lambda = t.get_and_append_challenge("initial_lambda");
-  Ext current_claim = ex_zero(), ac = ex_one();
-  for (auto& e : proof.circuit_outputs) {
-    Ext a = ex_add(ex_mul(batching, ex_sub(e[1], e[0])), e[0]);
-    Ext b = ex_add(ex_mul(batching, ex_sub(e[3], e[2])), e[2]);
-    current_claim = ex_add(current_claim, ex_mul(ac, ex_add(a, ex_mul(lambda, b))));
-    ac = ex_mul(ac, alpha);
-  }
+// The layer loop of batch_prove (prover.rs:84-198): for every tree layer, bottom-up from the 2-element outputs, absorb the
+// running claim, prove the batched layer sumcheck, draw (batching, alpha, lambda) and form the next claim. Returns the final
+// point. Shared by logup_batch_prove and by devices / test doubles that implement Dev::logup_tail.
+inline std::vector<Ext> logup_layers(Dev& dev, const std::vector<LogupCircuitDev>& circuits, bool initial_lookup, bool is_table, unsigned total_layers,
+                                     Ext batching, Ext alpha, Ext lambda, Ext current_claim, Transcript& t,
+                                     std::vector<IOPProof>& sumcheck_proofs, std::vector<std::vector<Ext>>& round_evaluations) {
   std::vector<Ext> point = {batching};
   for (unsigned lv = 1; lv <= total_layers; lv++) {
     t.append_ext(current_claim);
@@ -77,9 +52,9 @@ inline LogUpProof logup_batch_prove(Dev& dev, const LogUpInputDev& in, Transcrip
     alpha = t.get_and_append_challenge("logup_alpha");
     lambda = t.get_and_append_challenge("logup_lambda");
     point.push_back(batching);
-    proof.sumcheck_proofs.push_back(sc.proof);
+    sumcheck_proofs.push_back(sc.proof);
     Ext acc = ex_zero(), acomb = ex_one();
-    bool lookup_final = (lv == total_layers) && !in.is_table;  // final_round_claim (prover.rs:201-237)
+    bool lookup_final = (lv == total_layers) && !is_table;  // final_round_claim (prover.rs:201-237)
     if (!lookup_final) {
       for (size_t k = 0; k + 3 < evals.size(); k += 4) {
         const Ext* e = &evals[k];
@@ -96,7 +71,52 @@ inline LogUpProof logup_batch_prove(Dev& dev, const LogUpInputDev& in, Transcrip
       }
     }
     current_claim = acc;
-    proof.round_evaluations.push_back(evals);
+    round_evaluations.push_back(evals);
+  }
+  return point;
+}
+
+inline LogUpProof logup_batch_prove(Dev& dev, const LogUpInputDev& in, Transcript& t) {
+  size_t mk = dev.mark();
+  DP_REQUIRE(!in.columns.empty(), DP_ERR_ARG, "logup: no columns");
+  size_t n = in.columns[0].n;
+  unsigned nvars = dp_ceil_log2(n);
+  DP_REQUIRE((size_t(1) << nvars) == n && n >= 4, DP_ERR_SHAPE, "logup: column length must be a power of two >= 4");
+  for (auto& c : in.columns) DP_REQUIRE(c.n == n && !c.ext, DP_ERR_SHAPE, "logup: columns must be base field of equal length");
+  // ---- build the fractional-sum trees (one per instance); layer j has length n >> j
+  size_t cpi = in.is_table ? in.columns.size() : in.columns_per_instance;
+  DP_REQUIRE(in.columns.size() % cpi == 0, DP_ERR_SHAPE, "logup: column count must be a multiple of columns_per_instance");
+  int ninst = (int)(in.columns.size() / cpi);
+  std::vector<LogupCircuitDev> circuits;
+  std::vector<Ext> outs;
+  dev.logup_build(in.columns.data(), (int)cpi, ninst, in.is_table ? in.multiplicities : DBuf(), in.constant_challenge,
+                  in.column_separation_challenge, circuits, outs);
+  const bool initial_lookup = !in.is_table;
+  unsigned total_layers = nvars - 1;
+  LogUpProof proof; proof.is_table = in.is_table;
+  for (int i = 0; i < ninst; i++) proof.circuit_outputs.push_back({outs[4 * i], outs[4 * i + 1], outs[4 * i + 2], outs[4 * i + 3]});
+  t.append_field_element(gl_from_u64(circuits.size()));
+  for (auto& ev : proof.circuit_outputs) t.append_exts(ev);
+  Ext batching = t.get_and_append_challenge("initial_batching");
+  Ext alpha = t.get_and_append_challenge("initial_alpha");
+  Ext lambda = t.get_and_append_challenge("initial_lambda");
+  Ext current_claim = ex_zero(), ac = ex_one();
+  for (auto& e : proof.circuit_outputs) {
+    Ext a = ex_add(ex_mul(batching, ex_sub(e[1], e[0])), e[0]);
+    Ext b = ex_add(ex_mul(batching, ex_sub(e[3], e[2])), e[2]);
+    current_claim = ex_add(current_claim, ex_mul(ac, ex_add(a, ex_mul(lambda, b))));
+    ac = ex_mul(ac, alpha);
+  }
+  std::vector<Ext> point;
+  {
+    // a device that keeps the sponge to itself runs the whole layer loop (Dev::logup_tail); otherwise layer by layer here
+    Dev::LogupTailArgs ta{&circuits, initial_lookup, in.is_table, total_layers, batching, alpha, lambda, current_claim};
+    std::vector<std::vector<std::vector<Ext>>> lmsgs; std::vector<std::vector<Ext>> lpoints, levals;
+    if (dev.logup_tail(ta, t.challenger(), lmsgs, lpoints, levals, point)) {
+      DP_REQUIRE(lmsgs.size() == total_layers && lpoints.size() == total_layers && levals.size() == total_layers, DP_ERR_SHAPE, "logup_tail: one entry per layer expected");
+      for (unsigned l = 0; l < total_layers; l++) { IOPProof ip; ip.point = lpoints[l]; ip.proofs = lmsgs[l]; proof.sumcheck_proofs.push_back(ip); proof.round_evaluations.push_back(levals[l]); }
+    } else
+      point = logup_layers(dev, circuits, initial_lookup, in.is_table, total_layers, batching, alpha, lambda, current_claim, t, proof.sumcheck_proofs, proof.round_evaluations);
   }
   std::vector<DBuf> base;
   if (in.is_table) base.push_back(in.multiplicities);

@@ -5,6 +5,7 @@
 #pragma once
 #include "../../deep-prove_amd/csrc/dev.h"
 #include "../../deep-prove_amd/csrc/sumcheck.h"
+#include "../../deep-prove_amd/csrc/logup.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -117,6 +118,22 @@ class CpuDev : public Dev {
       msgs.push_back(msg); point.push_back(chal);
     }
     sc_finish(tabs, nt, chal, finals);
+    ch = t.challenger();
+    return true;
+  }
+  // The contract of Dev::logup_tail: the whole layer loop of a logup-GKR proof on a private transcript that starts from the
+  // host's sponge and is handed back at the end (device_logup, DP_DOUBLE_DEVICE_LOGUP=1 in the harness).
+  bool device_logup = false;
+  size_t logup_tails = 0;
+  bool logup_tail(const LogupTailArgs& a, Challenger& ch, std::vector<std::vector<std::vector<Ext>>>& layer_msgs,
+                  std::vector<std::vector<Ext>>& layer_points, std::vector<std::vector<Ext>>& round_evals, std::vector<Ext>& point) override {
+    if (!device_logup) return false;
+    logup_tails++;
+    Transcript t("");
+    t.challenger() = ch;
+    std::vector<IOPProof> proofs;
+    point = logup_layers(*this, *a.circuits, a.initial_lookup, a.is_table, a.total_layers, a.batching, a.alpha, a.lambda, a.claim, t, proofs, round_evals);
+    for (auto& p : proofs) { layer_msgs.push_back(p.proofs); layer_points.push_back(p.point); }
     ch = t.challenger();
     return true;
   }

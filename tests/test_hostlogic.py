@@ -35,6 +35,16 @@ def test_device_side_fiat_shamir_contract(hostlogic_bin, args):
     assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
 
 
+@pytest.mark.parametrize("args,fs", [((16, 7), "0"), ((64, 1), "1"), (("cnn", 4), "1")])
+def test_device_side_logup_contract(hostlogic_bin, args, fs):
+    """Dev::logup_tail (all layers of a logup-GKR proof with the transcript on the device, alone or on top of sc_tail)"""
+    r = run(hostlogic_bin, *args, env={"DP_DOUBLE_DEVICE_LOGUP": "1", "DP_DOUBLE_DEVICE_FS": fs})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical=1" in r.stdout
+    assert int(r.stdout.split("logup_tail: ")[1].split()[0]) >= 6, r.stdout
+    assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
+
+
 @pytest.mark.parametrize("offset", [3, -1000, 777, -20000])
 def test_tampered_proof_rejected(hostlogic_bin, offset):
     r = run(hostlogic_bin, 16, 2, offset)
