@@ -26,7 +26,7 @@ BATCHES_PER_STEP = 2
 # to what fits in the free HBM (worker arenas are sized from the footprint of the model's first proof).
 DEFAULT_IN_FLIGHT = 192
 SHARDED_WATCHDOG_S = float(os.environ.get("DP_BENCH_SHARDED_WATCHDOG_S", "240"))
-VERIFY_BUDGET_S = float(os.environ.get("DP_BENCH_VERIFY_BUDGET_S", "30"))  # host verification of the last batch: all proofs if that fits, else an evenly spaced sample
+VERIFY_BUDGET_S = float(os.environ.get("DP_BENCH_VERIFY_BUDGET_S", "15"))  # host verification of the last batch: all proofs if that fits, else an evenly spaced sample
 PUBLISHED = {"dense_4m": 1000.0 / 2335.0, "cnn_264k": 1000.0 / 1242.0}  # reference README.md:17-18 (hardware unstated)
 WORKLOADS = {
     "dense_4m": "Dense-4M MLP (mlp.py --num-dense 5 --layer-width 1024: 4->1024->1024x4->3, Dense+Requant+ReLU blocks, 4.21M params), 1 input per proof",
