@@ -1140,6 +1140,190 @@ KBODY k_sc_persist(const ScPersistArgs& a, Ext* result, unsigned long long* flag
   }
 }
 
+// ------------------------------------------------------------------------------------------------ whole logup-GKR layer loop
+// Dev::logup_tail (dev.h): every layer of a logup-GKR batch proof (logup_layers of logup.h: absorb the claim, the batched
+// layer sumcheck with its Fiat-Shamir rounds, the three layer challenges, the next claim) in ONE launch of one workgroup —
+// one device wait per lookup argument instead of one per tree layer. EXPERIMENTAL, off unless DP_DEVICE_LOGUP=1: written
+// against the contract pinned by the CPU double (tests/support/cpu_dev.hpp), not yet run on hardware.
+// Tree layers stay where k_logup_tree / k_logup_layer left them (global memory, read once per layer); folded tables
+// ping-pong through bufA / bufB like k_sc_persist. Result area, in words, one block per layer lv = 1..L followed by the
+// sponge: [lv x 4 message values][lv challenges][batching][final evaluations without eq] ... [8 state, 4 input buffer,
+// in_len, out_len]; the tag is mix(seq) + sum over blocks of sum_i (i + 1) * word_i with i relative to the block.
+constexpr int LT_MAXI = 7;   // instances of one batch proof: 1 + 4 * 7 tables <= MAX_TABS, 3 * 7 terms <= MAX_TERMS
+constexpr int LT_MAXL = 16;  // tree layers (columns of at most 2^16 rows; the host side stops far below)
+struct LogupTailDesc {
+  const void* num[LT_MAXI][LT_MAXL];  // numerators of tree layer li: extension; layer 0 of a table instance: the base-field
+                                      // multiplicities; layer 0 of a lookup instance: unused (all numerators are -1)
+  const Ext* den[LT_MAXI][LT_MAXL];
+  Ext* eq; Ext* bufA[MAX_TABS]; Ext* bufB[MAX_TABS];
+  int ninst, nlayers, total_layers, is_table;
+  Ext batching, alpha, lambda, claim;
+  u64 state[8]; u64 in_buf[4]; int in_len, out_len;
+  u64 lab_round[2], lab_batching[2], lab_alpha[2], lab_lambda[2];
+};
+KBODY k_logup_tail(const LogupTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
+  DP_CLAIM_ALL_VGPRS();
+  __shared__ Ext part[64 * SC_SLOTS];
+  __shared__ unsigned long long chal[3];
+  __shared__ const void* cur[MAX_TABS];
+  __shared__ int cur_ext[MAX_TABS];
+  __shared__ int tk[MAX_TERMS];
+  __shared__ int tt[MAX_TERMS][3];
+  __shared__ int s_ntab, s_nterm;
+  __shared__ ScFsArgs fsl;
+  __shared__ LogupTailDesc dl;
+  __shared__ Ext pt[MAX_PT];
+  __shared__ Ext glue[4];  // batching, alpha, lambda, claim of the layer at hand
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < (int)(sizeof(LogupTailDesc) / 8); i += nt) ((u64*)&dl)[i] = ((const u64*)dp)[i];
+  __syncthreads();
+  if (tid == 0) {
+    glue[0] = dl.batching; glue[1] = dl.alpha; glue[2] = dl.lambda; glue[3] = dl.claim; pt[0] = dl.batching;
+    fsl.md = 3; fsl.label[0] = dl.lab_round[0]; fsl.label[1] = dl.lab_round[1]; fsl.nlabel = 2; fsl.pad = 0;
+  }
+  WaveChallenger wc;
+  wc.st = dl.state[lane & 7]; wc.ib = dl.in_buf[lane & 3]; wc.in_len = dl.in_len; wc.out_len = dl.out_len;
+  unsigned long long fcs = 0;
+  size_t wbase = 0;
+  __syncthreads();
+  for (int lv = 1; lv <= dl.total_layers; lv++) {
+    const size_t half = size_t(1) << lv;
+    const int li = dl.nlayers - 1 - lv;  // layers().iter().rev().skip(1)
+    // transcript: the running claim, then the header of the layer's sumcheck (num_vars, max_degree)
+    if (wave == 0) {
+      Ext c = glue[3];
+      wc_observe(wc, c.c0, lane); wc_observe(wc, c.c1, lane);
+      wc_observe(wc, (u64)lv, lane); wc_observe(wc, (u64)3, lane);
+    }
+    wg_build_eq(dl.eq, pt, lv);  // eq(point, .) over the layer's lv variables (ends with a barrier)
+    if (tid == 0) {
+      cur[0] = dl.eq; cur_ext[0] = 1;
+      int ntab = 1, nterm = 0;
+      Ext ca = ex_one();
+      const Ext al = glue[1], la = glue[2];
+      const bool init_lk = !dl.is_table && li == 0;   // initial lookup layer: all numerators are -1
+      const bool nbase = dl.is_table && li == 0;      // table layer 0: base-field multiplicities
+      for (int i = 0; i < dl.ninst; i++) {
+        const Ext* dlo = dl.den[i][li];
+        const Ext* dhi = dlo + half;
+        if (!init_lk) {
+          const void* nlo = dl.num[i][li];
+          const void* nhi = (const char*)nlo + half * (nbase ? 8 : 16);
+          const int t_nlo = ntab, t_dhi = ntab + 1, t_nhi = ntab + 2, t_dlo = ntab + 3;
+          cur[t_nlo] = nlo; cur_ext[t_nlo] = nbase ? 0 : 1;
+          cur[t_dhi] = dhi; cur_ext[t_dhi] = 1;
+          cur[t_nhi] = nhi; cur_ext[t_nhi] = nbase ? 0 : 1;
+          cur[t_dlo] = dlo; cur_ext[t_dlo] = 1;
+          ntab += 4;
+          tk[nterm] = 3; tt[nterm][0] = 0; tt[nterm][1] = t_nlo; tt[nterm][2] = t_dhi; fsl.coeff[nterm] = ca; nterm++;
+          tk[nterm] = 3; tt[nterm][0] = 0; tt[nterm][1] = t_nhi; tt[nterm][2] = t_dlo; fsl.coeff[nterm] = ca; nterm++;
+          tk[nterm] = 3; tt[nterm][0] = 0; tt[nterm][1] = t_dlo; tt[nterm][2] = t_dhi; fsl.coeff[nterm] = ex_mul(ca, la); nterm++;
+        } else {
+          const int t_dhi = ntab, t_dlo = ntab + 1;
+          cur[t_dhi] = dhi; cur_ext[t_dhi] = 1;
+          cur[t_dlo] = dlo; cur_ext[t_dlo] = 1;
+          ntab += 2;
+          tk[nterm] = 2; tt[nterm][0] = 0; tt[nterm][1] = t_dhi; tt[nterm][2] = 0; fsl.coeff[nterm] = ex_neg(ca); nterm++;
+          tk[nterm] = 2; tt[nterm][0] = 0; tt[nterm][1] = t_dlo; tt[nterm][2] = 0; fsl.coeff[nterm] = ex_neg(ca); nterm++;
+          tk[nterm] = 3; tt[nterm][0] = 0; tt[nterm][1] = t_dlo; tt[nterm][2] = t_dhi; fsl.coeff[nterm] = ex_mul(ca, la); nterm++;
+        }
+        ca = ex_mul(ca, al);
+      }
+      s_ntab = ntab; s_nterm = nterm; fsl.rounds = lv;
+    }
+    __syncthreads();
+    const int ntab = s_ntab, nterm = s_nterm;
+    const int wpt = nterm >= W ? 1 : W / nterm;
+    u64* rw = result + wbase;
+    size_t n = half;
+    bool useA = true;
+    for (int round = 0; round < lv; round++) {
+      const size_t npairs = n / 2;
+      for (int term = wave / wpt; term < nterm; term += (wpt == 1 ? W : nterm + W)) {
+        const int sub = wave % wpt;
+        const int k = tk[term];
+        GlobalPairs L;
+#pragma unroll
+        for (int j = 0; j < 3; j++) { int ti = tt[term][j < k ? j : 0]; L.p[j] = cur[ti]; L.e[j] = cur_ext[ti] != 0; }
+        Ext acc[SC_SLOTS];
+        sc_accumulate<false>(k, L, (size_t)sub * 64 + lane, (size_t)wpt * 64, npairs, acc);
+#pragma unroll
+        for (int t = 0; t < SC_SLOTS; t++) if (t <= k) acc[t] = wave_reduce_ext(acc[t]);
+        if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * SC_SLOTS; for (int t = 0; t < SC_SLOTS; t++) o[t] = acc[t]; }
+        if (wpt > 1) break;  // with several waves per term every wave owns exactly one (term, sub)
+      }
+      __syncthreads();
+      if (wave == 0) {
+        Ext rr = sc_fs_round(wc, fsl, part, tk, nterm, wpt, rw, round, fcs, lane);
+        if (lane == 0) { chal[1] = rr.c0; chal[2] = rr.c1; pt[round] = rr; }  // the eq table of this layer is built: pt may take the new point
+      }
+      __syncthreads();
+      const Ext r = ex(chal[1], chal[2]);
+      Ext* const* dst = useA ? dl.bufA : dl.bufB;
+      for (int t = 0; t < ntab; t++) {
+        Ext* o = dst[t];
+        if (cur_ext[t]) { const Ext* q = (const Ext*)cur[t]; for (size_t i = tid; i < npairs; i += nt) o[i] = ex_lerp(q[2 * i], q[2 * i + 1], r); }
+        else { const u64* q = (const u64*)cur[t]; for (size_t i = tid; i < npairs; i += nt) o[i] = ex_lerp_base(q[2 * i], q[2 * i + 1], r); }
+      }
+      __syncthreads();
+      if (tid < ntab) { cur[tid] = dst[tid]; cur_ext[tid] = 1; }
+      __syncthreads();
+      n = npairs; useA = !useA;
+    }
+    // every table is one value now: the layer's evaluations, the three layer challenges, the next claim
+    if (wave == 0) {
+      u64 b0, b1;
+      wc_observe(wc, dl.lab_batching[0], lane); wc_observe(wc, dl.lab_batching[1], lane); b0 = wc_sample(wc, lane); b1 = wc_sample(wc, lane);
+      const Ext nb = ex(b0, b1);
+      wc_observe(wc, dl.lab_alpha[0], lane); wc_observe(wc, dl.lab_alpha[1], lane); b0 = wc_sample(wc, lane); b1 = wc_sample(wc, lane);
+      const Ext na = ex(b0, b1);
+      wc_observe(wc, dl.lab_lambda[0], lane); wc_observe(wc, dl.lab_lambda[1], lane); b0 = wc_sample(wc, lane); b1 = wc_sample(wc, lane);
+      const Ext nl = ex(b0, b1);
+      const size_t wb = (size_t)lv * 10;  // behind lv * 4 message values and lv challenges
+      if (lane == 0) { pub_store(rw + wb, nb.c0); pub_store(rw + wb + 1, nb.c1); fcs += (unsigned long long)(wb + 1) * nb.c0 + (unsigned long long)(wb + 2) * nb.c1; }
+      for (int e = lane; e < ntab - 1; e += 64) {
+        Ext v = ((const Ext*)cur[e + 1])[0];
+        size_t w = wb + 2 + 2 * (size_t)e;
+        pub_store(rw + w, v.c0); pub_store(rw + w + 1, v.c1);
+        fcs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1;
+      }
+      const bool lookup_final = lv == dl.total_layers && !dl.is_table;  // final_round_claim (prover.rs:201-237)
+      Ext acc = ex_zero(), acomb = ex_one();
+      int tb = 1;
+      for (int i = 0; i < dl.ninst; i++) {
+        if (!lookup_final) {
+          Ext e0 = ((const Ext*)cur[tb])[0], e1 = ((const Ext*)cur[tb + 1])[0], e2 = ((const Ext*)cur[tb + 2])[0], e3 = ((const Ext*)cur[tb + 3])[0];
+          Ext a = ex_add(ex_mul(nb, ex_sub(e2, e0)), e0);
+          Ext b = ex_add(ex_mul(nb, ex_sub(e1, e3)), e3);
+          acc = ex_add(acc, ex_mul(acomb, ex_add(a, ex_mul(nl, b))));
+          tb += 4;
+        } else {
+          Ext e0 = ((const Ext*)cur[tb])[0], e1 = ((const Ext*)cur[tb + 1])[0];
+          acc = ex_add(acc, ex_mul(acomb, ex_add(ex_mul(nb, ex_sub(e0, e1)), e1)));
+          tb += 2;
+        }
+        acomb = ex_mul(acomb, na);
+      }
+      if (lane == 0) { glue[0] = nb; glue[1] = na; glue[2] = nl; glue[3] = acc; pt[lv] = nb; }
+    }
+    wbase += ((size_t)lv * 5 + 1 + (size_t)(ntab - 1)) * 2;
+    __syncthreads();
+  }
+  if (wave == 0) {  // the sponge goes back to the host transcript; the tag closes the message
+    u64* rw = result + wbase;
+    if (lane < 8) { pub_store(rw + lane, wc.st); fcs += (unsigned long long)(lane + 1) * wc.st; }
+    if (lane < 4) { u64 v = lane < wc.in_len ? wc.ib : 0; pub_store(rw + 8 + lane, v); fcs += (unsigned long long)(8 + lane + 1) * v; }
+    if (lane == 0) {
+      u64 a = (u64)wc.in_len, b = (u64)wc.out_len;
+      pub_store(rw + 12, a); pub_store(rw + 13, b);
+      fcs += (unsigned long long)13 * a + (unsigned long long)14 * b;
+    }
+    fcs = pub_wave_sum(fcs);
+    if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + fcs);
+  }
+}
+
 // Same protocol as k_sc_persist, but the tables live in LDS after the first fold (bit-reversed index order, so a fold
 // pairs positions q and q + m/2 and is done in place with no hazards): after the first round no table byte touches
 // global memory again. Dynamic LDS = ntabs * (n0/2) extension elements.
@@ -1767,6 +1951,30 @@ class HipDev : public Dev {
         throw DpError(DP_ERR_HIP, "timeout waiting for the device");
     }
   }
+  // wait_flag for a message made of blocks whose checksum runs over block-relative word indices (k_logup_tail)
+  void wait_flag_blocks(unsigned long long seq, const std::vector<size_t>& block_words) {
+    volatile unsigned long long* f = hflag_;
+    volatile u64* w = hres_;
+    auto t0 = wait_enter_();
+    unsigned spins = 0;
+    const unsigned long long base = pub_mix(seq);
+    nwait_++;
+    for (;;) {
+      unsigned long long tag = *f;
+      if (tag == ~0ull) throw DpError(DP_ERR_HIP, "device aborted a persistent kernel");
+      if (tag != last_tag_) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        unsigned long long cs = 0;
+        size_t o = 0;
+        for (size_t bw : block_words) { for (size_t i = 0; i < bw; i++) cs += (unsigned long long)(i + 1) * w[o + i]; o += bw; }
+        if (base + cs == tag) { last_tag_ = tag; desc_off_ = 0; if (co_ && co_li_) co_->note_executed(co_li_ - 1); wait_exit_(t0); return; }
+      }
+      const bool fib = fiber_active();
+      if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
+      if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
+        throw DpError(DP_ERR_HIP, "timeout waiting for the device");
+    }
+  }
   // descriptors for batched kernels: written by the host into the mapped ring and read by the kernel directly (no
   // H2D copy launch). The ring is recycled whenever the host has observed a publication, i.e. the stream is drained.
   template <class T> T* desc_alloc(size_t count, const T** dev_view) {
@@ -1868,6 +2076,7 @@ class HipDev : public Dev {
     DP_SET_LDS((k_sc_small<false>), 1024, (int)EXCL_LDS);
     DP_SET_LDS((k_sc_small<true>), 1024, (int)EXCL_LDS);
     DP_SET_LDS(k_merkle_tail, 1024, (int)EXCL_LDS);
+    if (devlogup_) DP_SET_LDS(k_logup_tail, 1024, (int)EXCL_LDS);
     DP_SET_LDS(k_med_prepare, 1024, 128 * 1024);
     DP_SET_LDS(k_med_ntt_local, 1024, 64 * 1024);
   }
@@ -2176,6 +2385,89 @@ class HipDev : public Dev {
     ch.in_len = (int)w[ws + 12]; ch.out_len = (int)w[ws + 13];
     for (int i = 0; i < 4; i++) { ch.in_buf[i] = w[ws + 8 + i]; ch.out_buf[i] = ch.state[i]; }
     nfs_++;
+    return true;
+  }
+  // ---- Dev::logup_tail: EXPERIMENTAL (DP_DEVICE_LOGUP=1), see k_logup_tail. Declines (returns false) whenever the shape is
+  // outside what the kernel was written for; the caller then runs the layers one by one (logup_layers).
+  static constexpr size_t LOGUP_TAIL_MAX_N = 4096;
+  bool devlogup_ = getenv("DP_DEVICE_LOGUP") && atoi(getenv("DP_DEVICE_LOGUP"));
+  size_t nlogup_tail_ = 0;
+  static void label_words(const char* lab, u64 out[2]) {
+    size_t n = strlen(lab);
+    out[0] = out[1] = 0;
+    for (size_t i = 0, q = 0; i < n && q < 2; i += 8, q++) { u64 v = 0; size_t m = n - i < 8 ? n - i : 8; for (size_t b = 0; b < m; b++) v |= (u64)(uint8_t)lab[i + b] << (8 * b); out[q] = gl_from_u64(v); }
+  }
+  bool logup_tail(const LogupTailArgs& a, Challenger& ch, std::vector<std::vector<std::vector<Ext>>>& layer_msgs,
+                  std::vector<std::vector<Ext>>& layer_points, std::vector<std::vector<Ext>>& round_evals, std::vector<Ext>& point) override {
+    if (!devlogup_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
+    const std::vector<LogupCircuitDev>& cs = *a.circuits;
+    const int ninst = (int)cs.size();
+    if (ninst < 1 || ninst > LT_MAXI) return false;
+    const size_t nlayers = cs[0].den.size();
+    if (nlayers < 2 || nlayers > (size_t)LT_MAXL || a.total_layers != nlayers - 1 || a.initial_lookup == a.is_table) return false;
+    const size_t n = cs[0].den[0].n;
+    if (n > LOGUP_TAIL_MAX_N || n != (size_t(1) << nlayers)) return false;
+    for (const LogupCircuitDev& c : cs) {
+      if (c.den.size() != nlayers || c.num.size() != nlayers) return false;
+      for (size_t li = 0; li < nlayers; li++) {
+        if (c.den[li].n != (n >> li) || !c.den[li].ext || c.den[li].null()) return false;
+        if (li > 0 && (c.num[li].n != (n >> li) || !c.num[li].ext || c.num[li].null())) return false;
+      }
+      if (a.is_table && (c.num[0].null() || c.num[0].ext || c.num[0].n != n)) return false;
+    }
+    // words of the message: one block per layer, then the sponge
+    std::vector<size_t> blocks;
+    size_t nwords = 0;
+    for (unsigned lv = 1; lv <= a.total_layers; lv++) {
+      const bool lookup_final = lv == a.total_layers && !a.is_table;
+      size_t bw = ((size_t)lv * 5 + 1 + (size_t)ninst * (lookup_final ? 2 : 4)) * 2;
+      blocks.push_back(bw); nwords += bw;
+    }
+    blocks.push_back(14); nwords += 14;
+    if (nwords > RES_WORDS) return false;
+    flush_pending_eq();
+    const size_t mk = mark();
+    const size_t half_max = n / 2;
+    const int ntab_max = 1 + 4 * ninst;
+    const LogupTailDesc* dd = nullptr;
+    LogupTailDesc* d = desc_alloc<LogupTailDesc>(1, &dd);
+    memset(d, 0, sizeof(LogupTailDesc));
+    for (int i = 0; i < ninst; i++)
+      for (size_t li = 0; li < nlayers; li++) { d->num[i][li] = cs[i].num[li].p; d->den[i][li] = (const Ext*)cs[i].den[li].p; }
+    d->eq = (Ext*)alloc(half_max, true).p;
+    for (int t = 0; t < ntab_max; t++) { d->bufA[t] = (Ext*)alloc(std::max<size_t>(half_max / 2, 1), true).p; d->bufB[t] = (Ext*)alloc(std::max<size_t>(half_max / 4, 1), true).p; }
+    d->ninst = ninst; d->nlayers = (int)nlayers; d->total_layers = (int)a.total_layers; d->is_table = a.is_table ? 1 : 0;
+    d->batching = a.batching; d->alpha = a.alpha; d->lambda = a.lambda; d->claim = a.claim;
+    for (int i = 0; i < 8; i++) d->state[i] = ch.state[i];
+    for (int i = 0; i < 4; i++) d->in_buf[i] = i < ch.in_len ? ch.in_buf[i] : 0;
+    d->in_len = ch.in_len; d->out_len = ch.out_len;
+    label_words("Internal round", d->lab_round); label_words("logup_batching", d->lab_batching);
+    label_words("logup_alpha", d->lab_alpha); label_words("logup_lambda", d->lab_lambda);
+    const unsigned long long seq = ++seq_;
+    nb_ = 0; for (int i = 0; i < ninst; i++) for (size_t li = 0; li < nlayers; li++) nb_ += 2.0 * 16.0 * (double)(n >> li);
+    DPL_LDS(k_logup_tail, dim3(1), dim3(1024), excl_now(), dd, (u64*)hres_dev_, hflag_dev_, seq);
+    wait_flag_blocks(seq, blocks);
+    const u64* w = hres_;
+    size_t o = 0;
+    for (unsigned lv = 1; lv <= a.total_layers; lv++) {
+      std::vector<std::vector<Ext>> msgs;
+      for (unsigned q = 0; q < lv; q++) { std::vector<Ext> m(4); for (unsigned j = 0; j < 4; j++) { size_t x = o + ((size_t)q * 4 + j) * 2; m[j] = ex(w[x], w[x + 1]); } msgs.push_back(std::move(m)); }
+      std::vector<Ext> pts;
+      for (unsigned q = 0; q < lv; q++) { size_t x = o + ((size_t)lv * 4 + q) * 2; pts.push_back(ex(w[x], w[x + 1])); }
+      const size_t xb = o + (size_t)lv * 10;
+      const Ext batching = ex(w[xb], w[xb + 1]);
+      const size_t nev = blocks[lv - 1] / 2 - ((size_t)lv * 5 + 1);
+      std::vector<Ext> ev;
+      for (size_t e = 0; e < nev; e++) ev.push_back(ex(w[xb + 2 + 2 * e], w[xb + 3 + 2 * e]));
+      if (lv == a.total_layers) { point = pts; point.push_back(batching); }
+      layer_msgs.push_back(std::move(msgs)); layer_points.push_back(std::move(pts)); round_evals.push_back(std::move(ev));
+      o += blocks[lv - 1];
+    }
+    for (int i = 0; i < 8; i++) ch.state[i] = w[o + i];
+    ch.in_len = (int)w[o + 12]; ch.out_len = (int)w[o + 13];
+    for (int i = 0; i < 4; i++) { ch.in_buf[i] = w[o + 8 + i]; ch.out_buf[i] = ch.state[i]; }
+    release(mk);
+    nlogup_tail_++;
     return true;
   }
   void sc_round(DBuf* tabs, int nt, const Ext* r, const ScTerm* terms, int nterms, Ext* out) override {

@@ -23,6 +23,7 @@ CONFIGS = [  # (name, proofs in flight, env)
     ("xcd_256", 256, {"DP_COHORT_XCD": "1"}),
     ("persist256_noexcl_192", 192, {"DP_COHORT_EXCL": "0", "DP_COHORT_PERSIST_THREADS": "256"}),
     ("persist512_192", 192, {"DP_COHORT_PERSIST_THREADS": "512"}),
+    ("devlogup_192", 192, {"DP_DEVICE_LOGUP": "1"}),  # k_logup_tail: written blind in round 1 — a parity failure here is a bug to fix, not noise
     ("hostfs_192", 192, {"DP_DEVICE_FS": "0"}),
     ("lpmax256_192", 192, {"DP_MERKLE_LP_MAX": "256"}),
     ("tailmax1024_192", 192, {"DP_TAIL_MAX": "1024"}),
