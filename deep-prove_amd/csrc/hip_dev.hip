@@ -9,6 +9,7 @@
 #include "dev.h"
 #include "sumcheck.h"
 #include "fiber.h"
+#include "logup_tail.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -1149,18 +1150,7 @@ KBODY k_sc_persist(const ScPersistArgs& a, Ext* result, unsigned long long* flag
 // ping-pong through bufA / bufB like k_sc_persist. Result area, in words, one block per layer lv = 1..L followed by the
 // sponge: [lv x 4 message values][lv challenges][batching][final evaluations without eq] ... [8 state, 4 input buffer,
 // in_len, out_len]; the tag is mix(seq) + sum over blocks of sum_i (i + 1) * word_i with i relative to the block.
-constexpr int LT_MAXI = 7;   // instances of one batch proof: 1 + 4 * 7 tables <= MAX_TABS, 3 * 7 terms <= MAX_TERMS
-constexpr int LT_MAXL = 16;  // tree layers (columns of at most 2^16 rows; the host side stops far below)
-struct LogupTailDesc {
-  const void* num[LT_MAXI][LT_MAXL];  // numerators of tree layer li: extension; layer 0 of a table instance: the base-field
-                                      // multiplicities; layer 0 of a lookup instance: unused (all numerators are -1)
-  const Ext* den[LT_MAXI][LT_MAXL];
-  Ext* eq; Ext* bufA[MAX_TABS]; Ext* bufB[MAX_TABS];
-  int ninst, nlayers, total_layers, is_table;
-  Ext batching, alpha, lambda, claim;
-  u64 state[8]; u64 in_buf[4]; int in_len, out_len;
-  u64 lab_round[2], lab_batching[2], lab_alpha[2], lab_lambda[2];
-};
+static_assert(LT_MAX_TABS == MAX_TABS, "logup_tail.h: table capacity");
 KBODY k_logup_tail(const LogupTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
   DP_CLAIM_ALL_VGPRS();
   __shared__ Ext part[64 * SC_SLOTS];
@@ -1964,9 +1954,7 @@ class HipDev : public Dev {
       if (tag == ~0ull) throw DpError(DP_ERR_HIP, "device aborted a persistent kernel");
       if (tag != last_tag_) {
         std::atomic_thread_fence(std::memory_order_acquire);
-        unsigned long long cs = 0;
-        size_t o = 0;
-        for (size_t bw : block_words) { for (size_t i = 0; i < bw; i++) cs += (unsigned long long)(i + 1) * w[o + i]; o += bw; }
+        const unsigned long long cs = logup_tail_checksum(w, block_words);
         if (base + cs == tag) { last_tag_ = tag; desc_off_ = 0; if (co_ && co_li_) co_->note_executed(co_li_ - 1); wait_exit_(t0); return; }
       }
       const bool fib = fiber_active();
@@ -2389,83 +2377,25 @@ class HipDev : public Dev {
   }
   // ---- Dev::logup_tail: EXPERIMENTAL (DP_DEVICE_LOGUP=1), see k_logup_tail. Declines (returns false) whenever the shape is
   // outside what the kernel was written for; the caller then runs the layers one by one (logup_layers).
-  static constexpr size_t LOGUP_TAIL_MAX_N = 4096;
   bool devlogup_ = getenv("DP_DEVICE_LOGUP") && atoi(getenv("DP_DEVICE_LOGUP"));
   size_t nlogup_tail_ = 0;
-  static void label_words(const char* lab, u64 out[2]) {
-    size_t n = strlen(lab);
-    out[0] = out[1] = 0;
-    for (size_t i = 0, q = 0; i < n && q < 2; i += 8, q++) { u64 v = 0; size_t m = n - i < 8 ? n - i : 8; for (size_t b = 0; b < m; b++) v |= (u64)(uint8_t)lab[i + b] << (8 * b); out[q] = gl_from_u64(v); }
-  }
   bool logup_tail(const LogupTailArgs& a, Challenger& ch, std::vector<std::vector<std::vector<Ext>>>& layer_msgs,
                   std::vector<std::vector<Ext>>& layer_points, std::vector<std::vector<Ext>>& round_evals, std::vector<Ext>& point) override {
     if (!devlogup_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
-    const std::vector<LogupCircuitDev>& cs = *a.circuits;
-    const int ninst = (int)cs.size();
-    if (ninst < 1 || ninst > LT_MAXI) return false;
-    const size_t nlayers = cs[0].den.size();
-    if (nlayers < 2 || nlayers > (size_t)LT_MAXL || a.total_layers != nlayers - 1 || a.initial_lookup == a.is_table) return false;
-    const size_t n = cs[0].den[0].n;
-    if (n > LOGUP_TAIL_MAX_N || n != (size_t(1) << nlayers)) return false;
-    for (const LogupCircuitDev& c : cs) {
-      if (c.den.size() != nlayers || c.num.size() != nlayers) return false;
-      for (size_t li = 0; li < nlayers; li++) {
-        if (c.den[li].n != (n >> li) || !c.den[li].ext || c.den[li].null()) return false;
-        if (li > 0 && (c.num[li].n != (n >> li) || !c.num[li].ext || c.num[li].null())) return false;
-      }
-      if (a.is_table && (c.num[0].null() || c.num[0].ext || c.num[0].n != n)) return false;
-    }
-    // words of the message: one block per layer, then the sponge
-    std::vector<size_t> blocks;
-    size_t nwords = 0;
-    for (unsigned lv = 1; lv <= a.total_layers; lv++) {
-      const bool lookup_final = lv == a.total_layers && !a.is_table;
-      size_t bw = ((size_t)lv * 5 + 1 + (size_t)ninst * (lookup_final ? 2 : 4)) * 2;
-      blocks.push_back(bw); nwords += bw;
-    }
-    blocks.push_back(14); nwords += 14;
+    if (!logup_tail_accepts(a)) return false;
+    const std::vector<size_t> blocks = logup_tail_blocks(a);
+    size_t nwords = 0; for (size_t b : blocks) nwords += b;
     if (nwords > RES_WORDS) return false;
     flush_pending_eq();
     const size_t mk = mark();
-    const size_t half_max = n / 2;
-    const int ntab_max = 1 + 4 * ninst;
     const LogupTailDesc* dd = nullptr;
     LogupTailDesc* d = desc_alloc<LogupTailDesc>(1, &dd);
-    memset(d, 0, sizeof(LogupTailDesc));
-    for (int i = 0; i < ninst; i++)
-      for (size_t li = 0; li < nlayers; li++) { d->num[i][li] = cs[i].num[li].p; d->den[i][li] = (const Ext*)cs[i].den[li].p; }
-    d->eq = (Ext*)alloc(half_max, true).p;
-    for (int t = 0; t < ntab_max; t++) { d->bufA[t] = (Ext*)alloc(std::max<size_t>(half_max / 2, 1), true).p; d->bufB[t] = (Ext*)alloc(std::max<size_t>(half_max / 4, 1), true).p; }
-    d->ninst = ninst; d->nlayers = (int)nlayers; d->total_layers = (int)a.total_layers; d->is_table = a.is_table ? 1 : 0;
-    d->batching = a.batching; d->alpha = a.alpha; d->lambda = a.lambda; d->claim = a.claim;
-    for (int i = 0; i < 8; i++) d->state[i] = ch.state[i];
-    for (int i = 0; i < 4; i++) d->in_buf[i] = i < ch.in_len ? ch.in_buf[i] : 0;
-    d->in_len = ch.in_len; d->out_len = ch.out_len;
-    label_words("Internal round", d->lab_round); label_words("logup_batching", d->lab_batching);
-    label_words("logup_alpha", d->lab_alpha); label_words("logup_lambda", d->lab_lambda);
+    logup_tail_fill(d, a, ch, *this);
     const unsigned long long seq = ++seq_;
-    nb_ = 0; for (int i = 0; i < ninst; i++) for (size_t li = 0; li < nlayers; li++) nb_ += 2.0 * 16.0 * (double)(n >> li);
+    nb_ = 0; for (const LogupCircuitDev& c : *a.circuits) for (const DBuf& l : c.den) nb_ += 2.0 * 16.0 * (double)l.n;
     DPL_LDS(k_logup_tail, dim3(1), dim3(1024), excl_now(), dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
-    const u64* w = hres_;
-    size_t o = 0;
-    for (unsigned lv = 1; lv <= a.total_layers; lv++) {
-      std::vector<std::vector<Ext>> msgs;
-      for (unsigned q = 0; q < lv; q++) { std::vector<Ext> m(4); for (unsigned j = 0; j < 4; j++) { size_t x = o + ((size_t)q * 4 + j) * 2; m[j] = ex(w[x], w[x + 1]); } msgs.push_back(std::move(m)); }
-      std::vector<Ext> pts;
-      for (unsigned q = 0; q < lv; q++) { size_t x = o + ((size_t)lv * 4 + q) * 2; pts.push_back(ex(w[x], w[x + 1])); }
-      const size_t xb = o + (size_t)lv * 10;
-      const Ext batching = ex(w[xb], w[xb + 1]);
-      const size_t nev = blocks[lv - 1] / 2 - ((size_t)lv * 5 + 1);
-      std::vector<Ext> ev;
-      for (size_t e = 0; e < nev; e++) ev.push_back(ex(w[xb + 2 + 2 * e], w[xb + 3 + 2 * e]));
-      if (lv == a.total_layers) { point = pts; point.push_back(batching); }
-      layer_msgs.push_back(std::move(msgs)); layer_points.push_back(std::move(pts)); round_evals.push_back(std::move(ev));
-      o += blocks[lv - 1];
-    }
-    for (int i = 0; i < 8; i++) ch.state[i] = w[o + i];
-    ch.in_len = (int)w[o + 12]; ch.out_len = (int)w[o + 13];
-    for (int i = 0; i < 4; i++) { ch.in_buf[i] = w[o + 8 + i]; ch.out_buf[i] = ch.state[i]; }
+    logup_tail_parse(hres_, a, blocks, ch, layer_msgs, layer_points, round_evals, point);
     release(mk);
     nlogup_tail_++;
     return true;

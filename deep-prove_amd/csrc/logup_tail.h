@@ -1,0 +1,128 @@
+// Host <-> device interface of k_logup_tail (hip_dev.hip): the descriptor the kernel reads, the layout of the message it
+// publishes, and the host code on either side of the launch. Kept apart from hip_dev.hip so that the kernel-emulation test
+// (tests/support/kernel_emul) drives the kernel source with exactly the host code the product uses.
+#pragma once
+#include "dev.h"
+#include <cstring>
+
+namespace dp {
+
+constexpr int LT_MAXI = 7;        // instances of one batch proof: 1 + 4 * 7 tables <= LT_MAX_TABS, 3 * 7 terms <= MAX_TERMS
+constexpr int LT_MAXL = 16;       // tree layers (columns of at most 2^16 rows; logup_tail_accepts stops far below)
+constexpr int LT_MAX_TABS = 32;   // == MAX_TABS of hip_dev.hip
+constexpr size_t LOGUP_TAIL_MAX_N = 4096;
+
+struct LogupTailDesc {
+  const void* num[LT_MAXI][LT_MAXL];  // numerators of tree layer li: extension; layer 0 of a table instance: the base-field
+                                      // multiplicities; layer 0 of a lookup instance: unused (all numerators are -1)
+  const Ext* den[LT_MAXI][LT_MAXL];
+  Ext* eq; Ext* bufA[LT_MAX_TABS]; Ext* bufB[LT_MAX_TABS];
+  int ninst, nlayers, total_layers, is_table;
+  Ext batching, alpha, lambda, claim;
+  u64 state[8]; u64 in_buf[4]; int in_len, out_len;
+  u64 lab_round[2], lab_batching[2], lab_alpha[2], lab_lambda[2];
+};
+
+// a transcript label as the (at most two) field elements append_message makes of it (poseidon2.h Transcript)
+inline void logup_tail_label(const char* lab, u64 out[2]) {
+  size_t n = strlen(lab);
+  out[0] = out[1] = 0;
+  for (size_t i = 0, q = 0; i < n && q < 2; i += 8, q++) {
+    u64 v = 0;
+    size_t m = n - i < 8 ? n - i : 8;
+    for (size_t b = 0; b < m; b++) v |= (u64)(uint8_t)lab[i + b] << (8 * b);
+    out[q] = gl_from_u64(v);
+  }
+}
+
+// the shapes the kernel was written for (everything else runs layer by layer through logup_layers)
+inline bool logup_tail_accepts(const Dev::LogupTailArgs& a) {
+  const std::vector<LogupCircuitDev>& cs = *a.circuits;
+  const int ninst = (int)cs.size();
+  if (ninst < 1 || ninst > LT_MAXI) return false;
+  const size_t nlayers = cs[0].den.size();
+  if (nlayers < 2 || nlayers > (size_t)LT_MAXL || a.total_layers != nlayers - 1 || a.initial_lookup == a.is_table) return false;
+  const size_t n = cs[0].den[0].n;
+  if (n > LOGUP_TAIL_MAX_N || n != (size_t(1) << nlayers)) return false;
+  for (const LogupCircuitDev& c : cs) {
+    if (c.den.size() != nlayers || c.num.size() != nlayers) return false;
+    for (size_t li = 0; li < nlayers; li++) {
+      if (c.den[li].n != (n >> li) || !c.den[li].ext || c.den[li].null()) return false;
+      if (li > 0 && (c.num[li].n != (n >> li) || !c.num[li].ext || c.num[li].null())) return false;
+    }
+    if (a.is_table && (c.num[0].null() || c.num[0].ext || c.num[0].n != n)) return false;
+  }
+  return true;
+}
+
+// Message layout, in words: one block per layer lv = 1..L — [lv x 4 message values][lv challenges][batching][final
+// evaluations without eq: 4 (2 in the last layer of a lookup) per instance] — then the sponge [8 state, 4 input buffer,
+// in_len, out_len]. The tag is mix(seq) + sum over blocks of sum_i (i + 1) * word_i with i relative to the block.
+inline std::vector<size_t> logup_tail_blocks(const Dev::LogupTailArgs& a) {
+  std::vector<size_t> blocks;
+  const size_t ninst = a.circuits->size();
+  for (unsigned lv = 1; lv <= a.total_layers; lv++) {
+    const bool lookup_final = lv == a.total_layers && !a.is_table;
+    blocks.push_back(((size_t)lv * 5 + 1 + ninst * (lookup_final ? 2 : 4)) * 2);
+  }
+  blocks.push_back(14);
+  return blocks;
+}
+
+// scratch the kernel needs, allocated by the caller: eq (n / 2), per table bufA (n / 4) and bufB (n / 8)
+inline void logup_tail_fill(LogupTailDesc* d, const Dev::LogupTailArgs& a, const Challenger& ch, Dev& dev) {
+  const std::vector<LogupCircuitDev>& cs = *a.circuits;
+  const int ninst = (int)cs.size();
+  const size_t nlayers = cs[0].den.size(), n = cs[0].den[0].n, half_max = n / 2;
+  memset((void*)d, 0, sizeof(LogupTailDesc));
+  for (int i = 0; i < ninst; i++)
+    for (size_t li = 0; li < nlayers; li++) { d->num[i][li] = cs[i].num[li].p; d->den[i][li] = (const Ext*)cs[i].den[li].p; }
+  d->eq = (Ext*)dev.alloc(half_max, true).p;
+  for (int t = 0; t < 1 + 4 * ninst; t++) {
+    d->bufA[t] = (Ext*)dev.alloc(std::max<size_t>(half_max / 2, 1), true).p;
+    d->bufB[t] = (Ext*)dev.alloc(std::max<size_t>(half_max / 4, 1), true).p;
+  }
+  d->ninst = ninst; d->nlayers = (int)nlayers; d->total_layers = (int)a.total_layers; d->is_table = a.is_table ? 1 : 0;
+  d->batching = a.batching; d->alpha = a.alpha; d->lambda = a.lambda; d->claim = a.claim;
+  for (int i = 0; i < 8; i++) d->state[i] = ch.state[i];
+  for (int i = 0; i < 4; i++) d->in_buf[i] = i < ch.in_len ? ch.in_buf[i] : 0;
+  d->in_len = ch.in_len; d->out_len = ch.out_len;
+  logup_tail_label("Internal round", d->lab_round); logup_tail_label("logup_batching", d->lab_batching);
+  logup_tail_label("logup_alpha", d->lab_alpha); logup_tail_label("logup_lambda", d->lab_lambda);
+}
+
+inline unsigned long long logup_tail_checksum(const volatile u64* w, const std::vector<size_t>& blocks) {
+  unsigned long long cs = 0;
+  size_t o = 0;
+  for (size_t bw : blocks) { for (size_t i = 0; i < bw; i++) cs += (unsigned long long)(i + 1) * w[o + i]; o += bw; }
+  return cs;
+}
+
+inline void logup_tail_parse(const u64* w, const Dev::LogupTailArgs& a, const std::vector<size_t>& blocks, Challenger& ch,
+                             std::vector<std::vector<std::vector<Ext>>>& layer_msgs, std::vector<std::vector<Ext>>& layer_points,
+                             std::vector<std::vector<Ext>>& round_evals, std::vector<Ext>& point) {
+  size_t o = 0;
+  for (unsigned lv = 1; lv <= a.total_layers; lv++) {
+    std::vector<std::vector<Ext>> msgs;
+    for (unsigned q = 0; q < lv; q++) {
+      std::vector<Ext> m(4);
+      for (unsigned j = 0; j < 4; j++) { size_t x = o + ((size_t)q * 4 + j) * 2; m[j] = ex(w[x], w[x + 1]); }
+      msgs.push_back(std::move(m));
+    }
+    std::vector<Ext> pts;
+    for (unsigned q = 0; q < lv; q++) { size_t x = o + ((size_t)lv * 4 + q) * 2; pts.push_back(ex(w[x], w[x + 1])); }
+    const size_t xb = o + (size_t)lv * 10;
+    const Ext batching = ex(w[xb], w[xb + 1]);
+    const size_t nev = blocks[lv - 1] / 2 - ((size_t)lv * 5 + 1);
+    std::vector<Ext> ev;
+    for (size_t e = 0; e < nev; e++) ev.push_back(ex(w[xb + 2 + 2 * e], w[xb + 3 + 2 * e]));
+    if (lv == a.total_layers) { point = pts; point.push_back(batching); }
+    layer_msgs.push_back(std::move(msgs)); layer_points.push_back(std::move(pts)); round_evals.push_back(std::move(ev));
+    o += blocks[lv - 1];
+  }
+  for (int i = 0; i < 8; i++) ch.state[i] = w[o + i];
+  ch.in_len = (int)w[o + 12]; ch.out_len = (int)w[o + 13];
+  for (int i = 0; i < 4; i++) { ch.in_buf[i] = w[o + 8 + i]; ch.out_buf[i] = ch.state[i]; }
+}
+
+}  // namespace dp

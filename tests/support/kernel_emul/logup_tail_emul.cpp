@@ -1,0 +1,86 @@
+// TEST HARNESS (tests/ only): runs the DEVICE SOURCE of k_logup_tail (cut out of deep-prove_amd/csrc/hip_dev.hip by
+// extract.py) on the SIMT emulator of simt.hpp, driven by the product's own host code (csrc/logup_tail.h: descriptor,
+// message layout, parser), and byte-compares the logup-GKR proof and the transcript state with the layer-by-layer path.
+// usage: logup_tail_emul            (all cases)
+#include "../cpu_dev.hpp"
+#include "../../../deep-prove_amd/csrc/logup_tail.h"
+#include "simt.hpp"
+#include <cstdio>
+DP_FIBER_SWITCH_ASM
+
+namespace dp {
+static u64 c_rc[DP_POSEIDON2_RC_WORDS];
+static u64 c_extrap[(SC_MAXK + 1) * (SC_MAXK + 1) * (SC_MAXK + 1)];
+#include "_build/device_extract.inc"
+
+// the test double with Dev::logup_tail served by the emulated kernel
+struct EmulDev : CpuDev {
+  unsigned threads = 64;
+  size_t taken = 0, declined = 0;
+  bool logup_tail(const LogupTailArgs& a, Challenger& ch, std::vector<std::vector<std::vector<Ext>>>& layer_msgs,
+                  std::vector<std::vector<Ext>>& layer_points, std::vector<std::vector<Ext>>& round_evals, std::vector<Ext>& point) override {
+    if (!logup_tail_accepts(a)) { declined++; return false; }
+    const std::vector<size_t> blocks = logup_tail_blocks(a);
+    size_t nwords = 0; for (size_t b : blocks) nwords += b;
+    const size_t mk = mark();
+    LogupTailDesc d;
+    logup_tail_fill(&d, a, ch, *this);
+    std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
+    unsigned long long flag = 0;
+    const unsigned long long seq = 77 + taken;
+    blockDim.x.v = threads;
+    simt::launch(threads, [&] { k_logup_tail(&d, res.data(), &flag, seq); });
+    if (flag != pub_mix(seq) + logup_tail_checksum(res.data(), blocks)) { fprintf(stderr, "emul: tag does not match the payload\n"); exit(3); }
+    for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: the kernel wrote past its message\n"); exit(3); }
+    logup_tail_parse(res.data(), a, blocks, ch, layer_msgs, layer_points, round_evals, point);
+    release(mk);
+    taken++;
+    return true;
+  }
+};
+}  // namespace dp
+
+static uint64_t rs = 12345;
+static uint64_t rnd() { rs += 0x9E3779B97F4A7C15ULL; uint64_t z = rs; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
+
+static std::vector<uint64_t> prove(dp::Dev& dev, size_t n, int ncols, int cpi, bool table, dp::Ext& after) {
+  using namespace dp;
+  LogUpInputDev in;
+  in.is_table = table; in.columns_per_instance = cpi;
+  std::vector<std::vector<u64>> host((size_t)ncols, std::vector<u64>(n));
+  rs = 1000 + n * 31 + ncols * 7 + (table ? 3 : 0);
+  for (auto& c : host) for (auto& v : c) v = rnd() % GL_P;
+  for (auto& c : host) { DBuf b = dev.alloc(n, false); dev.upload(b, c.data()); in.columns.push_back(b); }
+  if (table) { std::vector<u64> m(n); for (auto& v : m) v = rnd() % 50; DBuf b = dev.alloc(n, false); dev.upload(b, m.data()); in.multiplicities = b; }
+  in.constant_challenge = ex(rnd() % GL_P, rnd() % GL_P); in.column_separation_challenge = ex(rnd() % GL_P, rnd() % GL_P);
+  Transcript t = default_transcript();
+  t.append_field_element(rnd() % GL_P);  // leave the sponge with a partly filled input buffer, as in the middle of a proof
+  LogUpProof p = logup_batch_prove(dev, in, t);
+  after = t.read_challenge();
+  Writer w; w.logup(p);
+  return w.w;
+}
+
+int main() {
+  using namespace dp;
+  setvbuf(stdout, nullptr, _IOLBF, 0);
+  memcpy(c_rc, POSEIDON2_RC_HOST, sizeof(POSEIDON2_RC_HOST));
+  for (unsigned k = 1; k < (unsigned)SC_MAXK; k++) for (unsigned at = k + 1; at <= (unsigned)SC_MAXK; at++) for (unsigned i = 0; i <= k; i++)
+    c_extrap[((size_t)k * (SC_MAXK + 1) + at) * (SC_MAXK + 1) + i] = extrapolation_coeffs(k, at)[i];
+  struct Case { size_t n; int ncols, cpi; bool table; unsigned threads; };
+  const Case cases[] = {{4, 1, 1, false, 64}, {8, 2, 1, false, 64}, {16, 2, 2, false, 64}, {32, 4, 2, false, 256}, {16, 1, 1, true, 64}, {64, 2, 2, true, 256},
+                        {8, 3, 1, false, 1024}, {128, 2, 1, false, 1024}};
+  int rc = 0;
+  for (const Case& c : cases) {
+    CpuDev ref; Ext ref_after;
+    std::vector<uint64_t> want = prove(ref, c.n, c.ncols, c.cpi, c.table, ref_after);
+    EmulDev em; em.threads = c.threads; Ext em_after;
+    std::vector<uint64_t> got = prove(em, c.n, c.ncols, c.cpi, c.table, em_after);
+    size_t first = 0; while (first < want.size() && first < got.size() && want[first] == got[first]) first++;
+    bool ok = want == got && ex_eq(ref_after, em_after) && em.taken == 1;
+    printf("n=%zu columns=%d per_instance=%d %s threads=%u: kernel taken=%zu declined=%zu words=%zu identical=%d first_diff=%zu transcript_after=%d\n", c.n, c.ncols, c.cpi,
+           c.table ? "table " : "lookup", c.threads, em.taken, em.declined, want.size(), want == got, first, ex_eq(ref_after, em_after));
+    if (!ok) rc = 1;
+  }
+  return rc;
+}

@@ -1,0 +1,23 @@
+"""Device SOURCE of deep-prove_amd/csrc/hip_dev.hip executed on the CPU (tests/support/kernel_emul: a fiber-based SIMT
+emulator with __syncthreads, wave shuffles and the DPP moves of the lane-parallel Poseidon2). What it pins without a GPU:
+k_logup_tail — the whole logup-GKR layer loop with device-side Fiat-Shamir in one launch (Dev::logup_tail) — together with
+everything it is built from (sc_accumulate, sc_fs_round, the wave sponge wc_*, p2l_permute, wg_build_eq) and the product's
+host code on both sides of the launch (csrc/logup_tail.h), byte for byte against the layer-by-layer path."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_logup_tail_kernel_on_the_simt_emulator():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    binary = g.build_kernel_emul()
+    r = subprocess.run([binary], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("n=")]
+    assert len(lines) >= 8
+    for ln in lines:
+        assert "kernel taken=1 declined=0" in ln and "identical=1" in ln and "transcript_after=1" in ln, ln
+    assert any("table" in ln for ln in lines) and any("threads=1024" in ln for ln in lines) and any("threads=256" in ln for ln in lines)
