@@ -168,6 +168,21 @@ class Dev {
     (void)a; (void)ch; (void)layer_msgs; (void)layer_points; (void)round_evals; (void)point;
     return false;
   }
+  // A whole logup-GKR batch proof with the transcript on the device: the fractional-sum trees of `ninst` instances (columns
+  // [i*cpi, (i+1)*cpi) each; `mult` non-null: ONE table instance with these multiplicities), the circuit outputs absorbed,
+  // the initial challenges, every layer (as logup_tail) and the evaluations of [mult,] columns at the final point — what
+  // logup_batch_prove (logup.h) does between its shape checks and the assembly of the proof, from the sponge `ch` and back.
+  // `false`: not taken, nothing changed.
+  struct LogupFullOut {
+    std::vector<Ext> outputs;                                   // [n0, n1, d0, d1] per instance
+    std::vector<std::vector<std::vector<Ext>>> layer_msgs;      // per layer: the round messages of its sumcheck
+    std::vector<std::vector<Ext>> layer_points, round_evals;    // per layer: its challenges / final evaluations without eq
+    std::vector<Ext> point, col_evals;                          // final point; [mult,] columns evaluated there
+  };
+  virtual bool logup_full(const DBuf* cols, int cpi, int ninst, const DBuf& mult, Ext c, Ext chi, Challenger& ch, LogupFullOut& out) {
+    (void)cols; (void)cpi; (void)ninst; (void)mult; (void)c; (void)chi; (void)ch; (void)out;
+    return false;
+  }
   // ---- Basefold (K5-K12, K14)
   virtual void pcs_init(unsigned full_message_size_log) = 0;
   virtual DevCommit commit(const DBuf& evals, bool persistent) = 0;

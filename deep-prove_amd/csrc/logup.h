@@ -87,6 +87,21 @@ inline LogUpProof logup_batch_prove(Dev& dev, const LogUpInputDev& in, Transcrip
   size_t cpi = in.is_table ? in.columns.size() : in.columns_per_instance;
   DP_REQUIRE(in.columns.size() % cpi == 0, DP_ERR_SHAPE, "logup: column count must be a multiple of columns_per_instance");
   int ninst = (int)(in.columns.size() / cpi);
+  {
+    // a device that keeps the sponge to itself proves the whole argument in one go (Dev::logup_full)
+    Dev::LogupFullOut fo;
+    if (dev.logup_full(in.columns.data(), (int)cpi, ninst, in.is_table ? in.multiplicities : DBuf(), in.constant_challenge, in.column_separation_challenge, t.challenger(), fo)) {
+      const size_t nbase = in.columns.size() + (in.is_table ? 1 : 0);
+      DP_REQUIRE(fo.outputs.size() == 4 * (size_t)ninst && fo.layer_msgs.size() == nvars - 1 && fo.layer_points.size() == nvars - 1 && fo.round_evals.size() == nvars - 1 &&
+                 fo.point.size() == nvars && fo.col_evals.size() == nbase, DP_ERR_SHAPE, "logup_full: unexpected result shape");
+      LogUpProof proof; proof.is_table = in.is_table;
+      for (int i = 0; i < ninst; i++) proof.circuit_outputs.push_back({fo.outputs[4 * i], fo.outputs[4 * i + 1], fo.outputs[4 * i + 2], fo.outputs[4 * i + 3]});
+      for (unsigned l = 0; l + 1 < nvars; l++) { IOPProof ip; ip.point = fo.layer_points[l]; ip.proofs = fo.layer_msgs[l]; proof.sumcheck_proofs.push_back(ip); proof.round_evaluations.push_back(fo.round_evals[l]); }
+      for (size_t i = 0; i < nbase; i++) proof.output_claims.push_back({fo.point, fo.col_evals[i]});
+      dev.release(mk);
+      return proof;
+    }
+  }
   std::vector<LogupCircuitDev> circuits;
   std::vector<Ext> outs;
   dev.logup_build(in.columns.data(), (int)cpi, ninst, in.is_table ? in.multiplicities : DBuf(), in.constant_challenge,

@@ -137,6 +137,31 @@ class CpuDev : public Dev {
     ch = t.challenger();
     return true;
   }
+  // The contract of Dev::logup_full: the whole of logup_batch_prove on a private transcript seeded with the host's sponge
+  // (device_logup_full, DP_DOUBLE_DEVICE_LOGUP=2 in the harness).
+  bool device_logup_full = false;
+  bool in_full_ = false;
+  size_t logup_fulls = 0;
+  bool logup_full(const DBuf* cols, int cpi, int ninst, const DBuf& mult, Ext c, Ext chi, Challenger& ch, LogupFullOut& out) override {
+    if (!device_logup_full || in_full_) return false;
+    in_full_ = true;
+    LogUpInputDev in;
+    in.is_table = !mult.null(); in.multiplicities = mult; in.columns_per_instance = (size_t)cpi;
+    in.columns.assign(cols, cols + (size_t)cpi * ninst);
+    in.constant_challenge = c; in.column_separation_challenge = chi;
+    Transcript t("");
+    t.challenger() = ch;
+    LogUpProof p = logup_batch_prove(*this, in, t);
+    in_full_ = false;
+    for (auto& o : p.circuit_outputs) for (const Ext& e : o) out.outputs.push_back(e);
+    for (auto& sp : p.sumcheck_proofs) { out.layer_msgs.push_back(sp.proofs); out.layer_points.push_back(sp.point); }
+    out.round_evals = p.round_evaluations;
+    out.point = p.output_claims[0].point;
+    for (auto& oc : p.output_claims) out.col_evals.push_back(oc.eval);
+    ch = t.challenger();
+    logup_fulls++;
+    return true;
+  }
   void logup_den(const DBuf& out, const DBuf* cols, int nc, Ext c, Ext chi) override {
     for (size_t i = 0; i < out.n; i++) { Ext acc = c, pw = ex_one(); for (int j = 0; j < nc; j++) { acc = ex_add(acc, ex_mul_base(pw, B(cols[j])[i])); pw = ex_mul(pw, chi); } X(out)[i] = acc; }
   }

@@ -76,7 +76,8 @@ int main(int argc, char** argv) {
   // product host logic over the CPU double
   dp::CpuDev dev;
   dev.device_fs = getenv("DP_DOUBLE_DEVICE_FS") && atoi(getenv("DP_DOUBLE_DEVICE_FS"));  // exercise the Dev::sc_tail contract (device-side Fiat-Shamir)
-  dev.device_logup = getenv("DP_DOUBLE_DEVICE_LOGUP") && atoi(getenv("DP_DOUBLE_DEVICE_LOGUP"));  // ... and the Dev::logup_tail contract
+  dev.device_logup = getenv("DP_DOUBLE_DEVICE_LOGUP") && atoi(getenv("DP_DOUBLE_DEVICE_LOGUP")) == 1;
+  dev.device_logup_full = getenv("DP_DOUBLE_DEVICE_LOGUP") && atoi(getenv("DP_DOUBLE_DEVICE_LOGUP")) == 2;  // ... or the Dev::logup_full contract  // ... and the Dev::logup_tail contract
   auto ctx = dp::context_generate(dev, m);
   dp::Trace tr = dp::run_model(m, in);
   dp::Transcript pt = dp::default_transcript();
@@ -84,6 +85,7 @@ int main(int argc, char** argv) {
   std::vector<uint64_t> pw = dp::serialize_proof(pp);
   auto t2 = std::chrono::steady_clock::now();
   bool same = ow == pw;
+  if (dev.device_logup_full) printf("logup_full: %zu logup proofs taken by the double\n", dev.logup_fulls);
   if (dev.device_logup) printf("logup_tail: %zu logup layer loops taken by the double\n", dev.logup_tails);
   if (dev.device_fs) printf("sc_tail: %zu sumcheck tails taken by the double, %zu declined\n", dev.tails_taken, dev.tails_declined);
   size_t first = 0; while (first < ow.size() && first < pw.size() && ow[first] == pw[first]) first++;

@@ -45,6 +45,17 @@ def test_device_side_logup_contract(hostlogic_bin, args, fs):
     assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
 
 
+@pytest.mark.parametrize("args,fs", [((16, 7), "0"), ((64, 1), "1"), (("cnn", 4), "1")])
+def test_device_side_whole_logup_contract(hostlogic_bin, args, fs):
+    """Dev::logup_full (a whole logup-GKR batch proof — trees, outputs, initial challenges, layers, column claims — with the
+    transcript on the device)"""
+    r = run(hostlogic_bin, *args, env={"DP_DOUBLE_DEVICE_LOGUP": "2", "DP_DOUBLE_DEVICE_FS": fs})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical=1" in r.stdout
+    assert int(r.stdout.split("logup_full: ")[1].split()[0]) >= 6, r.stdout
+    assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
+
+
 @pytest.mark.parametrize("offset", [3, -1000, 777, -20000])
 def test_tampered_proof_rejected(hostlogic_bin, offset):
     r = run(hostlogic_bin, 16, 2, offset)
