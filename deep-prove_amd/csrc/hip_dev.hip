@@ -1144,7 +1144,8 @@ KBODY k_sc_persist(const ScPersistArgs& a, Ext* result, unsigned long long* flag
 // ------------------------------------------------------------------------------------------------ whole logup-GKR layer loop
 // Dev::logup_tail (dev.h): every layer of a logup-GKR batch proof (logup_layers of logup.h: absorb the claim, the batched
 // layer sumcheck with its Fiat-Shamir rounds, the three layer challenges, the next claim) in ONE launch of one workgroup —
-// one device wait per lookup argument instead of one per tree layer. EXPERIMENTAL, off unless DP_DEVICE_LOGUP=1: written
+// one device wait per lookup argument instead of one per tree layer; in full mode (Dev::logup_full, DP_DEVICE_LOGUP=2) also
+// the trees, the circuit outputs, the initial challenges and the column claims. EXPERIMENTAL, off unless DP_DEVICE_LOGUP is set: written
 // against the contract pinned by the CPU double (tests/support/cpu_dev.hpp), not yet run on hardware.
 // Tree layers stay where k_logup_tree / k_logup_layer left them (global memory, read once per layer); folded tables
 // ping-pong through bufA / bufB like k_sc_persist. Result area, in words, one block per layer lv = 1..L followed by the
@@ -1164,6 +1165,7 @@ KBODY k_logup_tail(const LogupTailDesc* dp, u64* result, unsigned long long* fla
   __shared__ LogupTailDesc dl;
   __shared__ Ext pt[MAX_PT];
   __shared__ Ext glue[4];  // batching, alpha, lambda, claim of the layer at hand
+  __shared__ Ext outs[LT_MAXI * 4];  // full mode: [n0, n1, d0, d1] of every instance
   const int tid = threadIdx.x, nt = blockDim.x;
   const int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
   for (int i = tid; i < (int)(sizeof(LogupTailDesc) / 8); i += nt) ((u64*)&dl)[i] = ((const u64*)dp)[i];
@@ -1177,6 +1179,82 @@ KBODY k_logup_tail(const LogupTailDesc* dp, u64* result, unsigned long long* fla
   unsigned long long fcs = 0;
   size_t wbase = 0;
   __syncthreads();
+  if (dl.full) {
+    // ---- full mode (Dev::logup_full). The fractional-sum tree of every instance, as k_logup_tree builds it: denominators
+    // c + sum_j chi^j col_j, then layer by layer (n1 d2 + d1 n2, d1 d2) over the pairs (i, i + half)
+    const size_t n = dl.n;
+    for (int s = 0; s < dl.ninst; s++) {
+      Ext* den = dl.den_all[s];
+      Ext* num_out = dl.num_all[s];
+      for (size_t i = tid; i < n; i += nt) {
+        Ext acc = dl.c, pw = ex_one();
+        for (int j = 0; j < dl.cpi; j++) { acc = ex_add(acc, ex_mul_base(pw, dl.col[s][j][i])); pw = ex_mul(pw, dl.chi); }
+        den[i] = acc;
+      }
+      __syncthreads();
+      const void* num = dl.mult;
+      int mode = dl.is_table ? 1 : 0;  // 0: all numerators are -1 (lookup), 1: base-field multiplicities (table), 2: extension
+      size_t len = n, doff = 0, noff = 0;
+      while (len > 2) {
+        const size_t half = len / 2;
+        const Ext* dcur = den + doff;
+        Ext* dnext = den + doff + len;
+        for (size_t i = tid; i < half; i += nt) {
+          Ext d1 = dcur[i], d2 = dcur[i + half], nn;
+          if (mode == 0) nn = ex_neg(ex_add(d1, d2));
+          else if (mode == 1) { const u64* q = (const u64*)num; nn = ex_add(ex_mul_base(d2, q[i]), ex_mul_base(d1, q[i + half])); }
+          else { const Ext* q = (const Ext*)num; nn = ex_add(ex_mul(q[i], d2), ex_mul(d1, q[i + half])); }
+          num_out[noff + i] = nn;
+          dnext[i] = ex_mul(d1, d2);
+        }
+        __syncthreads();
+        num = (const void*)(num_out + noff); mode = 2;
+        doff += len; noff += half; len = half;
+      }
+      if (tid < 4) {  // the 2-element top layer: [n0, n1, d0, d1]
+        Ext v;
+        if (tid < 2) { if (mode == 0) v = ex_neg(ex_one()); else if (mode == 1) v = ex_base(((const u64*)num)[tid]); else v = ((const Ext*)num)[tid]; }
+        else v = (den + doff)[tid - 2];
+        outs[4 * s + tid] = v;
+      }
+      __syncthreads();
+    }
+    if (tid == 0)
+      for (int s = 0; s < dl.ninst; s++)
+        for (int li = 0; li < dl.nlayers; li++) {
+          dl.den[s][li] = dl.den_all[s] + (2 * n - ((2 * n) >> li));
+          dl.num[s][li] = li == 0 ? (const void*)dl.mult : (const void*)(dl.num_all[s] + (n - ((2 * n) >> li)));
+        }
+    // transcript: the number of instances, their outputs, the three initial challenges; the first claim
+    if (wave == 0) {
+      wc_observe(wc, (u64)dl.ninst, lane);
+      for (int q = 0; q < 4 * dl.ninst; q++) { Ext v = outs[q]; wc_observe(wc, v.c0, lane); wc_observe(wc, v.c1, lane); }
+      u64 b0, b1;
+      wc_observe(wc, dl.lab_ibatching[0], lane); wc_observe(wc, dl.lab_ibatching[1], lane); b0 = wc_sample(wc, lane); b1 = wc_sample(wc, lane);
+      const Ext bt = ex(b0, b1);
+      wc_observe(wc, dl.lab_ialpha[0], lane); wc_observe(wc, dl.lab_ialpha[1], lane); b0 = wc_sample(wc, lane); b1 = wc_sample(wc, lane);
+      const Ext al = ex(b0, b1);
+      wc_observe(wc, dl.lab_ilambda[0], lane); wc_observe(wc, dl.lab_ilambda[1], lane); b0 = wc_sample(wc, lane); b1 = wc_sample(wc, lane);
+      const Ext la = ex(b0, b1);
+      Ext claim = ex_zero(), ac = ex_one();
+      for (int s = 0; s < dl.ninst; s++) {
+        const Ext* e = outs + 4 * s;
+        Ext a = ex_add(ex_mul(bt, ex_sub(e[1], e[0])), e[0]);
+        Ext b = ex_add(ex_mul(bt, ex_sub(e[3], e[2])), e[2]);
+        claim = ex_add(claim, ex_mul(ac, ex_add(a, ex_mul(la, b))));
+        ac = ex_mul(ac, al);
+      }
+      if (lane == 0) { glue[0] = bt; glue[1] = al; glue[2] = la; glue[3] = claim; pt[0] = bt; }
+      for (int e = lane; e < 4 * dl.ninst; e += 64) {
+        Ext v = outs[e];
+        size_t w = 2 * (size_t)e;
+        pub_store(result + w, v.c0); pub_store(result + w + 1, v.c1);
+        fcs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1;
+      }
+    }
+    wbase = (size_t)dl.ninst * 8;
+    __syncthreads();
+  }
   for (int lv = 1; lv <= dl.total_layers; lv++) {
     const size_t half = size_t(1) << lv;
     const int li = dl.nlayers - 1 - lv;  // layers().iter().rev().skip(1)
@@ -1299,6 +1377,28 @@ KBODY k_logup_tail(const LogupTailDesc* dp, u64* result, unsigned long long* fla
     }
     wbase += ((size_t)lv * 5 + 1 + (size_t)(ntab - 1)) * 2;
     __syncthreads();
+  }
+  if (dl.full) {
+    // ---- full mode: the output claims — [multiplicities,] columns evaluated at the final point (sum_i eq(point, i) col[i])
+    wg_build_eq(dl.eqn, pt, dl.nlayers);
+    const int tcol = dl.is_table ? 1 : 0;
+    const int ncol = tcol + dl.ninst * dl.cpi;
+    u64* rw = result + wbase;
+    for (int cidx = 0; cidx < ncol; cidx++) {
+      const u64* col = cidx < tcol ? dl.mult : dl.col[(cidx - tcol) / dl.cpi][(cidx - tcol) % dl.cpi];
+      Ext acc = ex_zero();
+      for (size_t i = tid; i < dl.n; i += nt) acc = ex_add(acc, ex_mul_base(dl.eqn[i], col[i]));
+      acc = wave_reduce_ext(acc);
+      if (lane == 0) part[wave] = acc;
+      __syncthreads();
+      if (wave == 0) {
+        Ext v = lane < W ? part[lane] : ex_zero();
+        v = wave_reduce_ext(v);
+        if (lane == 0) { size_t w = 2 * (size_t)cidx; pub_store(rw + w, v.c0); pub_store(rw + w + 1, v.c1); fcs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1; }
+      }
+      __syncthreads();
+    }
+    wbase += 2 * (size_t)ncol;
   }
   if (wave == 0) {  // the sponge goes back to the host transcript; the tag closes the message
     u64* rw = result + wbase;
@@ -2064,7 +2164,7 @@ class HipDev : public Dev {
     DP_SET_LDS((k_sc_small<false>), 1024, (int)EXCL_LDS);
     DP_SET_LDS((k_sc_small<true>), 1024, (int)EXCL_LDS);
     DP_SET_LDS(k_merkle_tail, 1024, (int)EXCL_LDS);
-    if (devlogup_) DP_SET_LDS(k_logup_tail, 1024, (int)EXCL_LDS);
+    if (devlogup_ || devlogup_full_) DP_SET_LDS(k_logup_tail, 1024, (int)EXCL_LDS);
     DP_SET_LDS(k_med_prepare, 1024, 128 * 1024);
     DP_SET_LDS(k_med_ntt_local, 1024, 64 * 1024);
   }
@@ -2377,7 +2477,7 @@ class HipDev : public Dev {
   }
   // ---- Dev::logup_tail: EXPERIMENTAL (DP_DEVICE_LOGUP=1), see k_logup_tail. Declines (returns false) whenever the shape is
   // outside what the kernel was written for; the caller then runs the layers one by one (logup_layers).
-  bool devlogup_ = getenv("DP_DEVICE_LOGUP") && atoi(getenv("DP_DEVICE_LOGUP"));
+  bool devlogup_ = getenv("DP_DEVICE_LOGUP") && atoi(getenv("DP_DEVICE_LOGUP")) == 1;
   size_t nlogup_tail_ = 0;
   bool logup_tail(const LogupTailArgs& a, Challenger& ch, std::vector<std::vector<std::vector<Ext>>>& layer_msgs,
                   std::vector<std::vector<Ext>>& layer_points, std::vector<std::vector<Ext>>& round_evals, std::vector<Ext>& point) override {
@@ -2396,6 +2496,30 @@ class HipDev : public Dev {
     DPL_LDS(k_logup_tail, dim3(1), dim3(1024), excl_now(), dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
     logup_tail_parse(hres_, a, blocks, ch, layer_msgs, layer_points, round_evals, point);
+    release(mk);
+    nlogup_tail_++;
+    return true;
+  }
+  // ---- Dev::logup_full: EXPERIMENTAL (DP_DEVICE_LOGUP=2): k_logup_tail in full mode — one launch and one device wait per
+  // logup-GKR batch proof
+  bool devlogup_full_ = getenv("DP_DEVICE_LOGUP") && atoi(getenv("DP_DEVICE_LOGUP")) == 2;
+  bool logup_full(const DBuf* cols, int cpi, int ninst, const DBuf& mult, Ext c, Ext chi, Challenger& ch, LogupFullOut& out) override {
+    if (!devlogup_full_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
+    size_t n = 0;
+    if (!logup_full_accepts(cols, cpi, ninst, mult, &n)) return false;
+    const std::vector<size_t> blocks = logup_full_blocks(n, cpi, ninst, !mult.null());
+    size_t nwords = 0; for (size_t b : blocks) nwords += b;
+    if (nwords > RES_WORDS) return false;
+    flush_pending_eq();
+    const size_t mk = mark();
+    const LogupTailDesc* dd = nullptr;
+    LogupTailDesc* d = desc_alloc<LogupTailDesc>(1, &dd);
+    logup_full_fill(d, cols, cpi, ninst, mult, c, chi, ch, *this);
+    const unsigned long long seq = ++seq_;
+    nb_ = (double)ninst * (8.0 * cpi * n + 16.0 * 3 * n) * 2.0;
+    DPL_LDS(k_logup_tail, dim3(1), dim3(1024), excl_now(), dd, (u64*)hres_dev_, hflag_dev_, seq);
+    wait_flag_blocks(seq, blocks);
+    logup_full_parse(hres_, n, cpi, ninst, !mult.null(), blocks, ch, out);
     release(mk);
     nlogup_tail_++;
     return true;

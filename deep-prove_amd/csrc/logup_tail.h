@@ -10,7 +10,7 @@ namespace dp {
 constexpr int LT_MAXI = 7;        // instances of one batch proof: 1 + 4 * 7 tables <= LT_MAX_TABS, 3 * 7 terms <= MAX_TERMS
 constexpr int LT_MAXL = 16;       // tree layers (columns of at most 2^16 rows; logup_tail_accepts stops far below)
 constexpr int LT_MAX_TABS = 32;   // == MAX_TABS of hip_dev.hip
-constexpr size_t LOGUP_TAIL_MAX_N = 4096;
+constexpr size_t LOGUP_TAIL_MAX_N = 16384;
 
 struct LogupTailDesc {
   const void* num[LT_MAXI][LT_MAXL];  // numerators of tree layer li: extension; layer 0 of a table instance: the base-field
@@ -21,6 +21,16 @@ struct LogupTailDesc {
   Ext batching, alpha, lambda, claim;
   u64 state[8]; u64 in_buf[4]; int in_len, out_len;
   u64 lab_round[2], lab_batching[2], lab_alpha[2], lab_lambda[2];
+  // full mode (Dev::logup_full): the kernel also builds the trees, absorbs the outputs, draws the initial challenges and
+  // evaluates the columns at the final point; num / den above are then derived from den_all / num_all by the kernel
+  int full, cpi;
+  size_t n;                                     // rows of every column
+  const u64* col[LT_MAXI][8];                   // base-field columns of every instance
+  const u64* mult;                              // table: base-field multiplicities (one instance), else null
+  Ext c, chi;                                   // constant / column-separation challenge of the denominators
+  Ext* den_all[LT_MAXI]; Ext* num_all[LT_MAXI]; // tree storage: den layer li at 2n - (2n >> li) (2n values), num layer li >= 1 at n - (2n >> li)
+  Ext* eqn;                                     // n values: eq(final point, .)
+  u64 lab_ibatching[2], lab_ialpha[2], lab_ilambda[2];
 };
 
 // a transcript label as the (at most two) field elements append_message makes of it (poseidon2.h Transcript)
@@ -123,6 +133,75 @@ inline void logup_tail_parse(const u64* w, const Dev::LogupTailArgs& a, const st
   for (int i = 0; i < 8; i++) ch.state[i] = w[o + i];
   ch.in_len = (int)w[o + 12]; ch.out_len = (int)w[o + 13];
   for (int i = 0; i < 4; i++) { ch.in_buf[i] = w[o + 8 + i]; ch.out_buf[i] = ch.state[i]; }
+}
+
+// ---------------------------------------------------------------------------------------------------- full mode
+// Message: [4 outputs per instance] [layer blocks as above] [evaluations of [mult,] columns at the final point] [sponge].
+inline bool logup_full_accepts(const DBuf* cols, int cpi, int ninst, const DBuf& mult, size_t* n_out) {
+  if (ninst < 1 || ninst > LT_MAXI || cpi < 1 || cpi > 8) return false;
+  const size_t n = cols[0].n;
+  if (n < 4 || n > LOGUP_TAIL_MAX_N || (n & (n - 1))) return false;
+  for (int i = 0; i < ninst * cpi; i++) if (cols[i].null() || cols[i].ext || cols[i].n != n) return false;
+  if (!mult.null() && (mult.ext || mult.n != n || ninst != 1)) return false;
+  *n_out = n;
+  return true;
+}
+inline std::vector<size_t> logup_full_blocks(size_t n, int cpi, int ninst, bool is_table) {
+  std::vector<size_t> blocks;
+  blocks.push_back((size_t)ninst * 8);
+  unsigned nvars = dp_ceil_log2(n);
+  for (unsigned lv = 1; lv + 1 <= nvars; lv++) {
+    const bool lookup_final = lv == nvars - 1 && !is_table;
+    blocks.push_back(((size_t)lv * 5 + 1 + (size_t)ninst * (lookup_final ? 2 : 4)) * 2);
+  }
+  blocks.push_back(((size_t)ninst * cpi + (is_table ? 1 : 0)) * 2);
+  blocks.push_back(14);
+  return blocks;
+}
+inline void logup_full_fill(LogupTailDesc* d, const DBuf* cols, int cpi, int ninst, const DBuf& mult, Ext c, Ext chi, const Challenger& ch, Dev& dev) {
+  const size_t n = cols[0].n, half_max = n / 2;
+  memset((void*)d, 0, sizeof(LogupTailDesc));
+  d->full = 1; d->cpi = cpi; d->n = n; d->ninst = ninst; d->is_table = mult.null() ? 0 : 1;
+  d->nlayers = (int)dp_ceil_log2(n); d->total_layers = d->nlayers - 1;
+  for (int i = 0; i < ninst; i++) {
+    for (int j = 0; j < cpi; j++) d->col[i][j] = (const u64*)cols[(size_t)i * cpi + j].p;
+    d->den_all[i] = (Ext*)dev.alloc(2 * n, true).p;
+    d->num_all[i] = (Ext*)dev.alloc(n, true).p;
+  }
+  d->mult = (const u64*)mult.p; d->c = c; d->chi = chi;
+  d->eq = (Ext*)dev.alloc(half_max, true).p;
+  d->eqn = (Ext*)dev.alloc(n, true).p;
+  for (int t = 0; t < 1 + 4 * ninst; t++) {
+    d->bufA[t] = (Ext*)dev.alloc(std::max<size_t>(half_max / 2, 1), true).p;
+    d->bufB[t] = (Ext*)dev.alloc(std::max<size_t>(half_max / 4, 1), true).p;
+  }
+  for (int i = 0; i < 8; i++) d->state[i] = ch.state[i];
+  for (int i = 0; i < 4; i++) d->in_buf[i] = i < ch.in_len ? ch.in_buf[i] : 0;
+  d->in_len = ch.in_len; d->out_len = ch.out_len;
+  logup_tail_label("Internal round", d->lab_round); logup_tail_label("logup_batching", d->lab_batching);
+  logup_tail_label("logup_alpha", d->lab_alpha); logup_tail_label("logup_lambda", d->lab_lambda);
+  logup_tail_label("initial_batching", d->lab_ibatching); logup_tail_label("initial_alpha", d->lab_ialpha); logup_tail_label("initial_lambda", d->lab_ilambda);
+}
+inline void logup_full_parse(const u64* w, size_t n, int cpi, int ninst, bool is_table, const std::vector<size_t>& blocks, Challenger& ch, Dev::LogupFullOut& out) {
+  for (int i = 0; i < 4 * ninst; i++) out.outputs.push_back(ex(w[2 * i], w[2 * i + 1]));
+  const unsigned nvars = dp_ceil_log2(n);
+  // the layer blocks and the sponge are parsed by the tail parser over a view that skips block 0 and the column block
+  std::vector<LogupCircuitDev> none((size_t)ninst);
+  Dev::LogupTailArgs ta{&none, !is_table, is_table, nvars - 1, ex_zero(), ex_zero(), ex_zero(), ex_zero()};
+  std::vector<size_t> lb(blocks.begin() + 1, blocks.end() - 2);
+  lb.push_back(14);
+  size_t o = blocks[0], layer_words = 0;
+  for (size_t i = 0; i + 1 < lb.size(); i++) layer_words += lb[i];
+  // layers
+  {
+    std::vector<u64> view(w + o, w + o + layer_words);
+    const size_t colw = blocks[blocks.size() - 2];
+    view.insert(view.end(), w + o + layer_words + colw, w + o + layer_words + colw + 14);
+    logup_tail_parse(view.data(), ta, lb, ch, out.layer_msgs, out.layer_points, out.round_evals, out.point);
+  }
+  o += layer_words;
+  const size_t ncol = (size_t)ninst * cpi + (is_table ? 1 : 0);
+  for (size_t i = 0; i < ncol; i++) out.col_evals.push_back(ex(w[o + 2 * i], w[o + 2 * i + 1]));
 }
 
 }  // namespace dp

@@ -17,8 +17,36 @@ static u64 c_extrap[(SC_MAXK + 1) * (SC_MAXK + 1) * (SC_MAXK + 1)];
 struct EmulDev : CpuDev {
   unsigned threads = 64;
   size_t taken = 0, declined = 0;
+  bool full = false;  // serve Dev::logup_full (the kernel's full mode) instead of Dev::logup_tail
+  unsigned long long run_kernel(const LogupTailDesc& d, std::vector<u64>& res, const std::vector<size_t>& blocks) {
+    unsigned long long flag = 0;
+    const unsigned long long seq = 77 + taken;
+    blockDim.x.v = threads;
+    simt::launch(threads, [&] { k_logup_tail(&d, res.data(), &flag, seq); });
+    if (flag != pub_mix(seq) + logup_tail_checksum(res.data(), blocks)) { fprintf(stderr, "emul: tag does not match the payload\n"); exit(3); }
+    size_t nwords = 0; for (size_t b : blocks) nwords += b;
+    for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: the kernel wrote past its message\n"); exit(3); }
+    return flag;
+  }
+  bool logup_full(const DBuf* cols, int cpi, int ninst, const DBuf& mult, Ext c, Ext chi, Challenger& ch, LogupFullOut& out) override {
+    size_t n = 0;
+    if (!full) return false;
+    if (!logup_full_accepts(cols, cpi, ninst, mult, &n)) { declined++; return false; }
+    const std::vector<size_t> blocks = logup_full_blocks(n, cpi, ninst, !mult.null());
+    size_t nwords = 0; for (size_t b : blocks) nwords += b;
+    const size_t mk = mark();
+    LogupTailDesc d;
+    logup_full_fill(&d, cols, cpi, ninst, mult, c, chi, ch, *this);
+    std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
+    run_kernel(d, res, blocks);
+    logup_full_parse(res.data(), n, cpi, ninst, !mult.null(), blocks, ch, out);
+    release(mk);
+    taken++;
+    return true;
+  }
   bool logup_tail(const LogupTailArgs& a, Challenger& ch, std::vector<std::vector<std::vector<Ext>>>& layer_msgs,
                   std::vector<std::vector<Ext>>& layer_points, std::vector<std::vector<Ext>>& round_evals, std::vector<Ext>& point) override {
+    if (full) return false;
     if (!logup_tail_accepts(a)) { declined++; return false; }
     const std::vector<size_t> blocks = logup_tail_blocks(a);
     size_t nwords = 0; for (size_t b : blocks) nwords += b;
@@ -26,12 +54,7 @@ struct EmulDev : CpuDev {
     LogupTailDesc d;
     logup_tail_fill(&d, a, ch, *this);
     std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
-    unsigned long long flag = 0;
-    const unsigned long long seq = 77 + taken;
-    blockDim.x.v = threads;
-    simt::launch(threads, [&] { k_logup_tail(&d, res.data(), &flag, seq); });
-    if (flag != pub_mix(seq) + logup_tail_checksum(res.data(), blocks)) { fprintf(stderr, "emul: tag does not match the payload\n"); exit(3); }
-    for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: the kernel wrote past its message\n"); exit(3); }
+    run_kernel(d, res, blocks);
     logup_tail_parse(res.data(), a, blocks, ch, layer_msgs, layer_points, round_evals, point);
     release(mk);
     taken++;
@@ -67,18 +90,20 @@ int main() {
   memcpy(c_rc, POSEIDON2_RC_HOST, sizeof(POSEIDON2_RC_HOST));
   for (unsigned k = 1; k < (unsigned)SC_MAXK; k++) for (unsigned at = k + 1; at <= (unsigned)SC_MAXK; at++) for (unsigned i = 0; i <= k; i++)
     c_extrap[((size_t)k * (SC_MAXK + 1) + at) * (SC_MAXK + 1) + i] = extrapolation_coeffs(k, at)[i];
-  struct Case { size_t n; int ncols, cpi; bool table; unsigned threads; };
-  const Case cases[] = {{4, 1, 1, false, 64}, {8, 2, 1, false, 64}, {16, 2, 2, false, 64}, {32, 4, 2, false, 256}, {16, 1, 1, true, 64}, {64, 2, 2, true, 256},
-                        {8, 3, 1, false, 1024}, {128, 2, 1, false, 1024}};
+  struct Case { size_t n; int ncols, cpi; bool table; unsigned threads; bool full; };
+  const Case cases[] = {{4, 1, 1, false, 64, false}, {8, 2, 1, false, 64, false}, {16, 2, 2, false, 64, false}, {32, 4, 2, false, 256, false}, {16, 1, 1, true, 64, false},
+                        {64, 2, 2, true, 256, false}, {8, 3, 1, false, 1024, false}, {128, 2, 1, false, 1024, false},
+                        {4, 1, 1, false, 64, true}, {8, 2, 1, false, 64, true}, {16, 4, 2, false, 256, true}, {16, 1, 1, true, 64, true}, {64, 3, 3, true, 256, true},
+                        {32, 6, 2, false, 1024, true}, {256, 2, 1, false, 1024, true}};
   int rc = 0;
   for (const Case& c : cases) {
     CpuDev ref; Ext ref_after;
     std::vector<uint64_t> want = prove(ref, c.n, c.ncols, c.cpi, c.table, ref_after);
-    EmulDev em; em.threads = c.threads; Ext em_after;
+    EmulDev em; em.threads = c.threads; em.full = c.full; Ext em_after;
     std::vector<uint64_t> got = prove(em, c.n, c.ncols, c.cpi, c.table, em_after);
     size_t first = 0; while (first < want.size() && first < got.size() && want[first] == got[first]) first++;
     bool ok = want == got && ex_eq(ref_after, em_after) && em.taken == 1;
-    printf("n=%zu columns=%d per_instance=%d %s threads=%u: kernel taken=%zu declined=%zu words=%zu identical=%d first_diff=%zu transcript_after=%d\n", c.n, c.ncols, c.cpi,
+    printf("%s n=%zu columns=%d per_instance=%d %s threads=%u: kernel taken=%zu declined=%zu words=%zu identical=%d first_diff=%zu transcript_after=%d\n", c.full ? "full" : "tail", c.n, c.ncols, c.cpi,
            c.table ? "table " : "lookup", c.threads, em.taken, em.declined, want.size(), want == got, first, ex_eq(ref_after, em_after));
     if (!ok) rc = 1;
   }

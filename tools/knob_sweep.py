@@ -23,7 +23,10 @@ CONFIGS = [  # (name, proofs in flight, env)
     ("xcd_256", 256, {"DP_COHORT_XCD": "1"}),
     ("persist256_noexcl_192", 192, {"DP_COHORT_EXCL": "0", "DP_COHORT_PERSIST_THREADS": "256"}),
     ("persist512_192", 192, {"DP_COHORT_PERSIST_THREADS": "512"}),
-    ("devlogup_192", 192, {"DP_DEVICE_LOGUP": "1"}),  # k_logup_tail: written blind in round 1 — a parity failure here is a bug to fix, not noise
+    # k_logup_tail: written after round 1's GPU budget ran out, validated on the CPU SIMT emulator only (tests/test_kernel_emul.py)
+    ("devlogup_tail_192", 192, {"DP_DEVICE_LOGUP": "1"}),   # the layer loop of every logup proof in one launch
+    ("devlogup_full_192", 192, {"DP_DEVICE_LOGUP": "2"}),   # the whole logup proof (trees, outputs, layers, column claims) in one launch
+    ("devlogup_full_256", 256, {"DP_DEVICE_LOGUP": "2"}),
     ("hostfs_192", 192, {"DP_DEVICE_FS": "0"}),
     ("lpmax256_192", 192, {"DP_MERKLE_LP_MAX": "256"}),
     ("tailmax1024_192", 192, {"DP_TAIL_MAX": "1024"}),
