@@ -2,7 +2,14 @@
 // same synthetic model, byte-compares the canonical proof streams, and runs the product verifier on both.
 // usage: hostlogic_check <width> <seed> [tamper]
 #include "../../oracle/zkml.hpp"
+#ifdef DP_EMUL_DEV  // second build of this harness: every logup proof of the model is served by the emulated k_logup_tail
+#include "kernel_emul/emul_dev.hpp"
+DP_FIBER_SWITCH_ASM
+typedef dp::EmulDev TestDev;
+#else
 #include "cpu_dev.hpp"
+typedef dp::CpuDev TestDev;
+#endif
 #include "../../deep-prove_amd/csrc/zkml.h"
 #include <cstdio>
 #include <chrono>
@@ -74,7 +81,12 @@ int main(int argc, char** argv) {
   std::vector<uint64_t> ow = orc::serialize_proof(op);
   auto t1 = std::chrono::steady_clock::now();
   // product host logic over the CPU double
-  dp::CpuDev dev;
+  TestDev dev;
+#ifdef DP_EMUL_DEV
+  dp::emul_init_constants();
+  dev.full = !(getenv("DP_EMUL_MODE") && atoi(getenv("DP_EMUL_MODE")) == 1);  // DP_EMUL_MODE=1: Dev::logup_tail, else Dev::logup_full
+  dev.threads = getenv("DP_EMUL_THREADS") ? atoi(getenv("DP_EMUL_THREADS")) : 64;
+#endif
   dev.device_fs = getenv("DP_DOUBLE_DEVICE_FS") && atoi(getenv("DP_DOUBLE_DEVICE_FS"));  // exercise the Dev::sc_tail contract (device-side Fiat-Shamir)
   dev.device_logup = getenv("DP_DOUBLE_DEVICE_LOGUP") && atoi(getenv("DP_DOUBLE_DEVICE_LOGUP")) == 1;
   dev.device_logup_full = getenv("DP_DOUBLE_DEVICE_LOGUP") && atoi(getenv("DP_DOUBLE_DEVICE_LOGUP")) == 2;  // ... or the Dev::logup_full contract  // ... and the Dev::logup_tail contract
@@ -85,6 +97,9 @@ int main(int argc, char** argv) {
   std::vector<uint64_t> pw = dp::serialize_proof(pp);
   auto t2 = std::chrono::steady_clock::now();
   bool same = ow == pw;
+#ifdef DP_EMUL_DEV
+  printf("emulated k_logup_tail (%s mode, %u threads): %zu logup proofs taken, %zu declined\n", dev.full ? "full" : "tail", dev.threads, dev.taken, dev.declined);
+#endif
   if (dev.device_logup_full) printf("logup_full: %zu logup proofs taken by the double\n", dev.logup_fulls);
   if (dev.device_logup) printf("logup_tail: %zu logup layer loops taken by the double\n", dev.logup_tails);
   if (dev.device_fs) printf("sc_tail: %zu sumcheck tails taken by the double, %zu declined\n", dev.tails_taken, dev.tails_declined);

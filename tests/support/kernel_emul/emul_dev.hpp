@@ -1,0 +1,69 @@
+// TEST INFRASTRUCTURE: dp::EmulDev — the CPU test double with Dev::logup_tail / Dev::logup_full served by the DEVICE SOURCE of
+// k_logup_tail (cut out of deep-prove_amd/csrc/hip_dev.hip by extract.py) running on the SIMT emulator of simt.hpp, driven by
+// the product's own host code (csrc/logup_tail.h: descriptor, message layout, parser).
+#pragma once
+#include "../cpu_dev.hpp"
+#include "../../../deep-prove_amd/csrc/logup_tail.h"
+#include "simt.hpp"
+#include <cstdio>
+
+namespace dp {
+static u64 c_rc[DP_POSEIDON2_RC_WORDS];
+static u64 c_extrap[(SC_MAXK + 1) * (SC_MAXK + 1) * (SC_MAXK + 1)];
+#include "_build/device_extract.inc"
+inline void emul_init_constants() {
+  memcpy(c_rc, POSEIDON2_RC_HOST, sizeof(POSEIDON2_RC_HOST));
+  for (unsigned k = 1; k < (unsigned)SC_MAXK; k++) for (unsigned at = k + 1; at <= (unsigned)SC_MAXK; at++) for (unsigned i = 0; i <= k; i++)
+    c_extrap[((size_t)k * (SC_MAXK + 1) + at) * (SC_MAXK + 1) + i] = extrapolation_coeffs(k, at)[i];
+}
+
+// the test double with Dev::logup_tail served by the emulated kernel
+struct EmulDev : CpuDev {
+  unsigned threads = 64;
+  size_t taken = 0, declined = 0;
+  bool full = false;  // serve Dev::logup_full (the kernel's full mode) instead of Dev::logup_tail
+  unsigned long long run_kernel(const LogupTailDesc& d, std::vector<u64>& res, const std::vector<size_t>& blocks) {
+    unsigned long long flag = 0;
+    const unsigned long long seq = 77 + taken;
+    blockDim.x.v = threads;
+    simt::launch(threads, [&] { k_logup_tail(&d, res.data(), &flag, seq); });
+    if (flag != pub_mix(seq) + logup_tail_checksum(res.data(), blocks)) { fprintf(stderr, "emul: tag does not match the payload\n"); exit(3); }
+    size_t nwords = 0; for (size_t b : blocks) nwords += b;
+    for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: the kernel wrote past its message\n"); exit(3); }
+    return flag;
+  }
+  bool logup_full(const DBuf* cols, int cpi, int ninst, const DBuf& mult, Ext c, Ext chi, Challenger& ch, LogupFullOut& out) override {
+    size_t n = 0;
+    if (!full) return false;
+    if (!logup_full_accepts(cols, cpi, ninst, mult, &n)) { declined++; return false; }
+    const std::vector<size_t> blocks = logup_full_blocks(n, cpi, ninst, !mult.null());
+    size_t nwords = 0; for (size_t b : blocks) nwords += b;
+    const size_t mk = mark();
+    LogupTailDesc d;
+    logup_full_fill(&d, cols, cpi, ninst, mult, c, chi, ch, *this);
+    std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
+    run_kernel(d, res, blocks);
+    logup_full_parse(res.data(), n, cpi, ninst, !mult.null(), blocks, ch, out);
+    release(mk);
+    taken++;
+    return true;
+  }
+  bool logup_tail(const LogupTailArgs& a, Challenger& ch, std::vector<std::vector<std::vector<Ext>>>& layer_msgs,
+                  std::vector<std::vector<Ext>>& layer_points, std::vector<std::vector<Ext>>& round_evals, std::vector<Ext>& point) override {
+    if (full) return false;
+    if (!logup_tail_accepts(a)) { declined++; return false; }
+    const std::vector<size_t> blocks = logup_tail_blocks(a);
+    size_t nwords = 0; for (size_t b : blocks) nwords += b;
+    const size_t mk = mark();
+    LogupTailDesc d;
+    logup_tail_fill(&d, a, ch, *this);
+    std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
+    run_kernel(d, res, blocks);
+    logup_tail_parse(res.data(), a, blocks, ch, layer_msgs, layer_points, round_evals, point);
+    release(mk);
+    taken++;
+    return true;
+  }
+};
+}  // namespace dp
+

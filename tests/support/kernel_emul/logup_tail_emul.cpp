@@ -2,66 +2,9 @@
 // extract.py) on the SIMT emulator of simt.hpp, driven by the product's own host code (csrc/logup_tail.h: descriptor,
 // message layout, parser), and byte-compares the logup-GKR proof and the transcript state with the layer-by-layer path.
 // usage: logup_tail_emul            (all cases)
-#include "../cpu_dev.hpp"
-#include "../../../deep-prove_amd/csrc/logup_tail.h"
-#include "simt.hpp"
+#include "emul_dev.hpp"
 #include <cstdio>
 DP_FIBER_SWITCH_ASM
-
-namespace dp {
-static u64 c_rc[DP_POSEIDON2_RC_WORDS];
-static u64 c_extrap[(SC_MAXK + 1) * (SC_MAXK + 1) * (SC_MAXK + 1)];
-#include "_build/device_extract.inc"
-
-// the test double with Dev::logup_tail served by the emulated kernel
-struct EmulDev : CpuDev {
-  unsigned threads = 64;
-  size_t taken = 0, declined = 0;
-  bool full = false;  // serve Dev::logup_full (the kernel's full mode) instead of Dev::logup_tail
-  unsigned long long run_kernel(const LogupTailDesc& d, std::vector<u64>& res, const std::vector<size_t>& blocks) {
-    unsigned long long flag = 0;
-    const unsigned long long seq = 77 + taken;
-    blockDim.x.v = threads;
-    simt::launch(threads, [&] { k_logup_tail(&d, res.data(), &flag, seq); });
-    if (flag != pub_mix(seq) + logup_tail_checksum(res.data(), blocks)) { fprintf(stderr, "emul: tag does not match the payload\n"); exit(3); }
-    size_t nwords = 0; for (size_t b : blocks) nwords += b;
-    for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: the kernel wrote past its message\n"); exit(3); }
-    return flag;
-  }
-  bool logup_full(const DBuf* cols, int cpi, int ninst, const DBuf& mult, Ext c, Ext chi, Challenger& ch, LogupFullOut& out) override {
-    size_t n = 0;
-    if (!full) return false;
-    if (!logup_full_accepts(cols, cpi, ninst, mult, &n)) { declined++; return false; }
-    const std::vector<size_t> blocks = logup_full_blocks(n, cpi, ninst, !mult.null());
-    size_t nwords = 0; for (size_t b : blocks) nwords += b;
-    const size_t mk = mark();
-    LogupTailDesc d;
-    logup_full_fill(&d, cols, cpi, ninst, mult, c, chi, ch, *this);
-    std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
-    run_kernel(d, res, blocks);
-    logup_full_parse(res.data(), n, cpi, ninst, !mult.null(), blocks, ch, out);
-    release(mk);
-    taken++;
-    return true;
-  }
-  bool logup_tail(const LogupTailArgs& a, Challenger& ch, std::vector<std::vector<std::vector<Ext>>>& layer_msgs,
-                  std::vector<std::vector<Ext>>& layer_points, std::vector<std::vector<Ext>>& round_evals, std::vector<Ext>& point) override {
-    if (full) return false;
-    if (!logup_tail_accepts(a)) { declined++; return false; }
-    const std::vector<size_t> blocks = logup_tail_blocks(a);
-    size_t nwords = 0; for (size_t b : blocks) nwords += b;
-    const size_t mk = mark();
-    LogupTailDesc d;
-    logup_tail_fill(&d, a, ch, *this);
-    std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
-    run_kernel(d, res, blocks);
-    logup_tail_parse(res.data(), a, blocks, ch, layer_msgs, layer_points, round_evals, point);
-    release(mk);
-    taken++;
-    return true;
-  }
-};
-}  // namespace dp
 
 static uint64_t rs = 12345;
 static uint64_t rnd() { rs += 0x9E3779B97F4A7C15ULL; uint64_t z = rs; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
@@ -87,9 +30,7 @@ static std::vector<uint64_t> prove(dp::Dev& dev, size_t n, int ncols, int cpi, b
 int main() {
   using namespace dp;
   setvbuf(stdout, nullptr, _IOLBF, 0);
-  memcpy(c_rc, POSEIDON2_RC_HOST, sizeof(POSEIDON2_RC_HOST));
-  for (unsigned k = 1; k < (unsigned)SC_MAXK; k++) for (unsigned at = k + 1; at <= (unsigned)SC_MAXK; at++) for (unsigned i = 0; i <= k; i++)
-    c_extrap[((size_t)k * (SC_MAXK + 1) + at) * (SC_MAXK + 1) + i] = extrapolation_coeffs(k, at)[i];
+  emul_init_constants();
   struct Case { size_t n; int ncols, cpi; bool table; unsigned threads; bool full; };
   const Case cases[] = {{4, 1, 1, false, 64, false}, {8, 2, 1, false, 64, false}, {16, 2, 2, false, 64, false}, {32, 4, 2, false, 256, false}, {16, 1, 1, true, 64, false},
                         {64, 2, 2, true, 256, false}, {8, 3, 1, false, 1024, false}, {128, 2, 1, false, 1024, false},

@@ -21,3 +21,27 @@ def test_logup_tail_kernel_on_the_simt_emulator():
     for ln in lines:
         assert "kernel taken=1 declined=0" in ln and "identical=1" in ln and "transcript_after=1" in ln, ln
     assert any("table" in ln for ln in lines) and any("threads=1024" in ln for ln in lines) and any("threads=256" in ln for ln in lines)
+
+
+def _model(args, env):
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.build_kernel_emul()
+    binary = os.path.join(ROOT, "tests", "support", "kernel_emul", "_build", "hostlogic_check_emul")
+    e = dict(os.environ)
+    e.update(env)
+    return subprocess.run([binary, *map(str, args)], capture_output=True, text=True, timeout=900, env=e)
+
+
+def test_whole_model_proofs_with_every_logup_proof_from_the_emulated_kernel():
+    """end to end: the product's orchestrator proves an MLP and a CNN with EVERY logup-GKR proof (lookups and tables) produced
+    by the device source of k_logup_tail on the emulator — full mode (one launch per proof) and tail mode — and the proof
+    streams equal the oracle's byte for byte; the verifier accepts them"""
+    for args, env, least in (((64, 1), {}, 13), ((16, 7), {"DP_EMUL_MODE": "1", "DP_EMUL_THREADS": "256"}, 13), (("cnn", 4), {"DP_EMUL_THREADS": "256"}, 10)):
+        r = _model(args, env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "identical=1" in r.stdout, r.stdout
+        taken = int(r.stdout.split("logup proofs taken")[0].split()[-1])
+        declined = int(r.stdout.split("logup proofs taken, ")[1].split()[0])
+        assert taken >= least and declined == 0, r.stdout
+        assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
