@@ -197,6 +197,17 @@ class Dev {
   // classic sumcheck round (K12): fold every (f_i, eq_i) of length > 1 with r (if given), then
   // out[2i] = sum_j f[2j]*eq[2j], out[2i+1] = sum_j (f[2j+1]-f[2j])*(eq[2j+1]-eq[2j]); length-1 pairs give (f*eq, 0)
   virtual void classic_round(DBuf* fs, DBuf* eqs, int np, const Ext* r, Ext* out) = 0;
+  // The remaining rounds of the batch-opening ("classic") sumcheck of pcs_batch_open (pcs.h) with the transcript on the device.
+  // Called at the top of round `round`, exactly where classic_round would be called (r = the previous challenge, not yet
+  // folded in, or null in round 0), with eq_xt[i] the batching coefficient of pair i and `sum` the running claim. On `true`
+  // the 3-coefficient message and the challenge of every remaining round have been appended to `msgs` / `challenges` and `ch`
+  // is the sponge after the last challenge; fs / eqs are left in an unspecified state (the caller only needs the
+  // challenges from here on). `false`: not taken, nothing changed.
+  struct ClassicTailArgs { DBuf* fs; DBuf* eqs; int np; const Ext* r; const Ext* eq_xt; unsigned num_vars, round; Ext sum; };
+  virtual bool classic_tail(const ClassicTailArgs& a, Challenger& ch, std::vector<std::vector<Ext>>& msgs, std::vector<Ext>& challenges) {
+    (void)a; (void)ch; (void)msgs; (void)challenges;
+    return false;
+  }
   // K11: acc[j*rep + q] += x[j] * coeff  for q < rep
   virtual void axpy_rep(const DBuf& acc, const DBuf& x, Ext coeff, size_t rep) = 0;
   // K11 batched: acc = (init ? *init : 0) + sum_d rep_d(x_d) * coeff_d in one pass over acc (field addition is exact,

@@ -28,6 +28,27 @@ inline BasefoldProof pcs_open_trivial(Dev& dev, const DevCommit& c) {
 
 struct OpenClaim { const DevCommit* comm; std::vector<Ext> point; Ext eval; };
 
+// One round message [h0, h1, h2] of the batch-opening sumcheck from the per-pair sums of Dev::classic_round
+// (CoefficientsProver::prove_round, sum_check/classic/coeff.rs:198-345): pair i contributes eq_xt[i] * (c0, c2), scaled by the
+// number of times its (shorter) hypercube repeats in the round's; h1 follows from the running claim.
+inline std::vector<Ext> classic_round_message(const Ext* raw, const DBuf* fs, const Ext* eq_xt, size_t np, unsigned num_vars, unsigned round, Ext sum) {
+  size_t size = size_t(1) << (num_vars - round - 1);
+  Ext h0 = ex_zero(), h2 = ex_zero();
+  for (size_t i = 0; i < np; i++) {
+    size_t poly_len = fs[i].n;  // current length after the folds so far
+    Ext c0 = raw[2 * i], c2 = raw[2 * i + 1];
+    size_t multiple;
+    if (poly_len == 1) multiple = size;
+    else if (size < poly_len || size == 1) multiple = 1;
+    else multiple = size / (poly_len >> 1);
+    if (multiple != 1) { Ext m = ex_from_u64(multiple); c0 = ex_mul(c0, m); c2 = ex_mul(c2, m); }
+    h0 = ex_add(h0, ex_mul(eq_xt[i], c0));
+    h2 = ex_add(h2, ex_mul(eq_xt[i], c2));
+  }
+  Ext h1 = ex_sub(ex_sub(sum, ex_dbl(h0)), h2);
+  return {h0, h1, h2};
+}
+
 // PCS::batch_open in the shape zkml uses it: claim i = (poly i, point i) (commit/context.rs:370-383)
 inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vector<OpenClaim>& claims, Transcript& t) {
   BasefoldProof proof;
@@ -65,26 +86,18 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
   std::vector<Ext> challenges, raw(2 * np);
   Ext sum = target, ch = ex_zero();
   for (unsigned round = 0; round < num_vars; round++) {
-    dev.classic_round(fs.data(), eqs.data(), (int)np, round ? &ch : nullptr, raw.data());
-    size_t size = size_t(1) << (num_vars - round - 1);
-    Ext h0 = ex_zero(), h2 = ex_zero();
-    for (size_t i = 0; i < np; i++) {
-      size_t poly_len = fs[i].n;  // current length after the folds so far
-      Ext c0 = raw[2 * i], c2 = raw[2 * i + 1];
-      size_t multiple;
-      if (poly_len == 1) multiple = size;
-      else if (size < poly_len || size == 1) multiple = 1;
-      else multiple = size / (poly_len >> 1);
-      if (multiple != 1) { Ext m = ex_from_u64(multiple); c0 = ex_mul(c0, m); c2 = ex_mul(c2, m); }
-      h0 = ex_add(h0, ex_mul(eq_xt[i], c0));
-      h2 = ex_add(h2, ex_mul(eq_xt[i], c2));
+    // a device that keeps the sponge to itself runs every remaining round in one go (Dev::classic_tail)
+    Dev::ClassicTailArgs ta{fs.data(), eqs.data(), (int)np, round ? &ch : nullptr, eq_xt.data(), num_vars, round, sum};
+    if (dev.classic_tail(ta, t.challenger(), proof.sumcheck_proof, challenges)) {
+      DP_REQUIRE(challenges.size() == num_vars && proof.sumcheck_proof.size() == num_vars, DP_ERR_SHAPE, "classic_tail: one message and one challenge per round expected");
+      break;
     }
-    Ext h1 = ex_sub(ex_sub(sum, ex_dbl(h0)), h2);
-    std::vector<Ext> msg = {h0, h1, h2};
+    dev.classic_round(fs.data(), eqs.data(), (int)np, round ? &ch : nullptr, raw.data());
+    std::vector<Ext> msg = classic_round_message(raw.data(), fs.data(), eq_xt.data(), np, num_vars, round, sum);
     for (const Ext& e : msg) t.append_ext(e);
     ch = t.get_and_append_challenge("sumcheck round");
     challenges.push_back(ch);
-    sum = ex_add(h0, ex_mul(ch, ex_add(h1, ex_mul(ch, h2))));
+    sum = ex_add(msg[0], ex_mul(ch, ex_add(msg[1], ex_mul(ch, msg[2]))));
     proof.sumcheck_proof.push_back(msg);
   }
   lap("classic sumcheck");

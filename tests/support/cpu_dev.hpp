@@ -6,6 +6,7 @@
 #include "../../deep-prove_amd/csrc/dev.h"
 #include "../../deep-prove_amd/csrc/sumcheck.h"
 #include "../../deep-prove_amd/csrc/logup.h"
+#include "../../deep-prove_amd/csrc/pcs.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -243,6 +244,32 @@ class CpuDev : public Dev {
       }
       out[2 * i] = c0; out[2 * i + 1] = c2;
     }
+  }
+  // The contract of Dev::classic_tail: the remaining rounds of the batch-opening sumcheck on a private transcript seeded with
+  // the host's sponge (device_classic, DP_DOUBLE_DEVICE_CLASSIC=1 in the harness); like a device it only takes over once the
+  // tables are small
+  bool device_classic = false;
+  size_t classic_tails = 0;
+  bool classic_tail(const ClassicTailArgs& a, Challenger& ch, std::vector<std::vector<Ext>>& msgs, std::vector<Ext>& challenges) override {
+    if (!device_classic) return false;
+    size_t maxn = 0; for (int i = 0; i < a.np; i++) maxn = std::max(maxn, a.fs[i].n);
+    if (maxn > 512) return false;
+    classic_tails++;
+    Transcript t("");
+    t.challenger() = ch;
+    std::vector<Ext> raw(2 * (size_t)a.np);
+    Ext sum = a.sum, c = a.r ? *a.r : ex_zero();
+    for (unsigned round = a.round; round < a.num_vars; round++) {
+      classic_round(a.fs, a.eqs, a.np, round == a.round ? a.r : &c, raw.data());
+      std::vector<Ext> msg = classic_round_message(raw.data(), a.fs, a.eq_xt, (size_t)a.np, a.num_vars, round, sum);
+      for (const Ext& e : msg) t.append_ext(e);
+      c = t.get_and_append_challenge("sumcheck round");
+      challenges.push_back(c);
+      sum = ex_add(msg[0], ex_mul(c, ex_add(msg[1], ex_mul(c, msg[2]))));
+      msgs.push_back(msg);
+    }
+    ch = t.challenger();
+    return true;
   }
   void axpy_rep(const DBuf& acc, const DBuf& x, Ext coeff, size_t rep) override {
     for (size_t j = 0; j < x.n; j++) { Ext m = ex_mul(at(x, j), coeff); for (size_t q = 0; q < rep; q++) X(acc)[j * rep + q] = ex_add(X(acc)[j * rep + q], m); }

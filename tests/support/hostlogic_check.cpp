@@ -88,6 +88,7 @@ int main(int argc, char** argv) {
   dev.threads = getenv("DP_EMUL_THREADS") ? atoi(getenv("DP_EMUL_THREADS")) : 64;
 #endif
   dev.device_fs = getenv("DP_DOUBLE_DEVICE_FS") && atoi(getenv("DP_DOUBLE_DEVICE_FS"));  // exercise the Dev::sc_tail contract (device-side Fiat-Shamir)
+  dev.device_classic = getenv("DP_DOUBLE_DEVICE_CLASSIC") && atoi(getenv("DP_DOUBLE_DEVICE_CLASSIC"));  // ... the Dev::classic_tail contract
   dev.device_logup = getenv("DP_DOUBLE_DEVICE_LOGUP") && atoi(getenv("DP_DOUBLE_DEVICE_LOGUP")) == 1;
   dev.device_logup_full = getenv("DP_DOUBLE_DEVICE_LOGUP") && atoi(getenv("DP_DOUBLE_DEVICE_LOGUP")) == 2;  // ... or the Dev::logup_full contract  // ... and the Dev::logup_tail contract
   auto ctx = dp::context_generate(dev, m);
@@ -100,6 +101,7 @@ int main(int argc, char** argv) {
 #ifdef DP_EMUL_DEV
   printf("emulated k_logup_tail (%s mode, %u threads): %zu logup proofs taken, %zu declined\n", dev.full ? "full" : "tail", dev.threads, dev.taken, dev.declined);
 #endif
+  if (dev.device_classic) printf("classic_tail: %zu batch-opening sumcheck tails taken by the double\n", dev.classic_tails);
   if (dev.device_logup_full) printf("logup_full: %zu logup proofs taken by the double\n", dev.logup_fulls);
   if (dev.device_logup) printf("logup_tail: %zu logup layer loops taken by the double\n", dev.logup_tails);
   if (dev.device_fs) printf("sc_tail: %zu sumcheck tails taken by the double, %zu declined\n", dev.tails_taken, dev.tails_declined);

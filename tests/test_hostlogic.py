@@ -56,6 +56,17 @@ def test_device_side_whole_logup_contract(hostlogic_bin, args, fs):
     assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
 
 
+@pytest.mark.parametrize("args", [(16, 7), (64, 1), ("cnn", 4)])
+def test_device_side_classic_sumcheck_contract(hostlogic_bin, args):
+    """Dev::classic_tail (the last rounds of the batch-opening sumcheck of pcs_batch_open with the transcript on the device),
+    together with the other device-side transcript contracts"""
+    r = run(hostlogic_bin, *args, env={"DP_DOUBLE_DEVICE_CLASSIC": "1", "DP_DOUBLE_DEVICE_LOGUP": "2", "DP_DOUBLE_DEVICE_FS": "1"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical=1" in r.stdout
+    assert int(r.stdout.split("classic_tail: ")[1].split()[0]) >= 1, r.stdout
+    assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
+
+
 @pytest.mark.parametrize("offset", [3, -1000, 777, -20000])
 def test_tampered_proof_rejected(hostlogic_bin, offset):
     r = run(hostlogic_bin, 16, 2, offset)
