@@ -10,6 +10,7 @@
 #include "sumcheck.h"
 #include "fiber.h"
 #include "logup_tail.h"
+#include "classic_tail.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -1414,6 +1415,126 @@ KBODY k_logup_tail(const LogupTailDesc* dp, u64* result, unsigned long long* fla
   }
 }
 
+// ------------------------------------------------------------------------------------------------ batch-opening sumcheck tail
+// Dev::classic_tail (dev.h, classic_tail.h): the remaining rounds of the batch-opening sumcheck of pcs_batch_open — per round
+// fold every (f, eq) pair, the per-pair sums of Dev::classic_round, the 3-coefficient message of classic_round_message
+// (pcs.h), absorb, squeeze "sumcheck round" — in ONE launch of one workgroup once every table is short. A pair belongs to
+// one wave per phase; the phases of a round are separated by barriers. EXPERIMENTAL, off unless DP_DEVICE_CLASSIC=1:
+// checked on the SIMT emulator of tests/, not yet run on hardware.
+KBODY k_classic_tail(const ClassicTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
+  DP_CLAIM_ALL_VGPRS();
+  __shared__ ClassicTailDesc dl;
+  __shared__ Ext raw[2 * CT_MAXP];
+  __shared__ const void* curf[CT_MAXP];
+  __shared__ const Ext* cure[CT_MAXP];
+  __shared__ unsigned clen[CT_MAXP];
+  __shared__ unsigned cext[CT_MAXP];
+  __shared__ unsigned toA[CT_MAXP];
+  __shared__ unsigned long long chal[3];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < (int)(sizeof(ClassicTailDesc) / 8); i += nt) ((u64*)&dl)[i] = ((const u64*)dp)[i];
+  __syncthreads();
+  const int np = dl.np;
+  for (int i = tid; i < np; i += nt) { curf[i] = dl.f[i]; cure[i] = dl.eq[i]; clen[i] = dl.len[i]; cext[i] = dl.f_ext[i]; toA[i] = 1; }
+  WaveChallenger wc;
+  wc.st = dl.state[lane & 7]; wc.ib = dl.in_buf[lane & 3]; wc.in_len = dl.in_len; wc.out_len = dl.out_len;
+  unsigned long long fcs = 0;
+  const int R = (int)(dl.num_vars - dl.round);
+  Ext r = dl.r, sum = dl.sum;
+  bool have_r = dl.has_r != 0;
+  __syncthreads();
+  for (int q = 0; q < R; q++) {
+    if (have_r) {
+      // fold f and eq of every pair that is longer than one value
+      for (int i = wave; i < np; i += W) {
+        const unsigned n = clen[i];
+        if (n <= 1) continue;
+        const unsigned half = n / 2;
+        Ext* df = toA[i] ? dl.fA[i] : dl.fB[i];
+        Ext* de = toA[i] ? dl.eA[i] : dl.eB[i];
+        const Ext* e = cure[i];
+        if (cext[i]) { const Ext* f = (const Ext*)curf[i]; for (unsigned j = lane; j < half; j += 64) df[j] = ex_lerp(f[2 * j], f[2 * j + 1], r); }
+        else { const u64* f = (const u64*)curf[i]; for (unsigned j = lane; j < half; j += 64) df[j] = ex_lerp_base(f[2 * j], f[2 * j + 1], r); }
+        for (unsigned j = lane; j < half; j += 64) de[j] = ex_lerp(e[2 * j], e[2 * j + 1], r);
+      }
+      __syncthreads();
+      for (int i = tid; i < np; i += nt)
+        if (clen[i] > 1) { curf[i] = toA[i] ? dl.fA[i] : dl.fB[i]; cure[i] = toA[i] ? dl.eA[i] : dl.eB[i]; cext[i] = 1; clen[i] /= 2; toA[i] ^= 1; }
+      __syncthreads();
+    }
+    // per pair: c0 = sum_j f[2j] eq[2j], c2 = sum_j (f[2j+1] - f[2j]) (eq[2j+1] - eq[2j]); a single value gives (f eq, 0)
+    for (int i = wave; i < np; i += W) {
+      const unsigned n = clen[i];
+      const Ext* e = cure[i];
+      Ext c0 = ex_zero(), c2 = ex_zero();
+      if (n == 1) { if (lane == 0) c0 = ex_mul(ld_elem(curf[i], cext[i] != 0, 0), e[0]); }
+      else
+        for (unsigned j = lane; j < n / 2; j += 64) {
+          Ext l0 = e[2 * j], l1 = e[2 * j + 1], r0 = ld_elem(curf[i], cext[i] != 0, 2 * j), r1 = ld_elem(curf[i], cext[i] != 0, 2 * j + 1);
+          c0 = ex_add(c0, ex_mul(l0, r0));
+          c2 = ex_add(c2, ex_mul(ex_sub(l1, l0), ex_sub(r1, r0)));
+        }
+      c0 = wave_reduce_ext(c0); c2 = wave_reduce_ext(c2);
+      if (lane == 0) { raw[2 * i] = c0; raw[2 * i + 1] = c2; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // the message [h0, h1, h2] (classic_round_message of pcs.h), the transcript, the next claim
+      const size_t size = size_t(1) << (dl.num_vars - (dl.round + (unsigned)q) - 1);
+      Ext h0 = ex_zero(), h2 = ex_zero();
+      for (int i = lane; i < np; i += 64) {
+        const size_t poly_len = clen[i];
+        Ext c0 = raw[2 * i], c2 = raw[2 * i + 1];
+        size_t multiple;
+        if (poly_len == 1) multiple = size;
+        else if (size < poly_len || size == 1) multiple = 1;
+        else multiple = size / (poly_len >> 1);
+        if (multiple != 1) { Ext m = ex_from_u64((u64)multiple); c0 = ex_mul(c0, m); c2 = ex_mul(c2, m); }
+        h0 = ex_add(h0, ex_mul(dl.eq_xt[i], c0));
+        h2 = ex_add(h2, ex_mul(dl.eq_xt[i], c2));
+      }
+      h0 = wave_reduce_ext(h0); h2 = wave_reduce_ext(h2);
+      h0 = ex(shfl_u64(h0.c0, 0), shfl_u64(h0.c1, 0)); h2 = ex(shfl_u64(h2.c0, 0), shfl_u64(h2.c1, 0));
+      const Ext h1 = ex_sub(ex_sub(sum, ex_dbl(h0)), h2);
+      wc_observe(wc, h0.c0, lane); wc_observe(wc, h0.c1, lane);
+      wc_observe(wc, h1.c0, lane); wc_observe(wc, h1.c1, lane);
+      wc_observe(wc, h2.c0, lane); wc_observe(wc, h2.c1, lane);
+      wc_observe(wc, dl.lab[0], lane); wc_observe(wc, dl.lab[1], lane);
+      const u64 r0 = wc_sample(wc, lane), r1 = wc_sample(wc, lane);
+      const Ext ch = ex(r0, r1);
+      if (lane == 0) {
+        const Ext m[3] = {h0, h1, h2};
+        for (int j = 0; j < 3; j++) {
+          size_t w = ((size_t)q * 3 + j) * 2;
+          pub_store(result + w, m[j].c0); pub_store(result + w + 1, m[j].c1);
+          fcs += (unsigned long long)(w + 1) * m[j].c0 + (unsigned long long)(w + 2) * m[j].c1;
+        }
+        size_t w = ((size_t)R * 3 + q) * 2;
+        pub_store(result + w, r0); pub_store(result + w + 1, r1);
+        fcs += (unsigned long long)(w + 1) * r0 + (unsigned long long)(w + 2) * r1;
+        chal[1] = r0; chal[2] = r1;
+      }
+      sum = ex_add(h0, ex_mul(ch, ex_add(h1, ex_mul(ch, h2))));
+    }
+    __syncthreads();
+    r = ex(chal[1], chal[2]);
+    have_r = true;
+  }
+  if (wave == 0) {  // the sponge goes back to the host transcript; the tag closes the message
+    u64* rw = result + (size_t)R * 8;
+    if (lane < 8) { pub_store(rw + lane, wc.st); fcs += (unsigned long long)(lane + 1) * wc.st; }
+    if (lane < 4) { u64 v = lane < wc.in_len ? wc.ib : 0; pub_store(rw + 8 + lane, v); fcs += (unsigned long long)(8 + lane + 1) * v; }
+    if (lane == 0) {
+      u64 a = (u64)wc.in_len, b = (u64)wc.out_len;
+      pub_store(rw + 12, a); pub_store(rw + 13, b);
+      fcs += (unsigned long long)13 * a + (unsigned long long)14 * b;
+    }
+    fcs = pub_wave_sum(fcs);
+    if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + fcs);
+  }
+}
+
 // Same protocol as k_sc_persist, but the tables live in LDS after the first fold (bit-reversed index order, so a fold
 // pairs positions q and q + m/2 and is done in place with no hazards): after the first round no table byte touches
 // global memory again. Dynamic LDS = ntabs * (n0/2) extension elements.
@@ -2165,6 +2286,7 @@ class HipDev : public Dev {
     DP_SET_LDS((k_sc_small<true>), 1024, (int)EXCL_LDS);
     DP_SET_LDS(k_merkle_tail, 1024, (int)EXCL_LDS);
     if (devlogup_ || devlogup_full_) DP_SET_LDS(k_logup_tail, 1024, (int)EXCL_LDS);
+    if (devclassic_) DP_SET_LDS(k_classic_tail, 1024, (int)EXCL_LDS);
     DP_SET_LDS(k_med_prepare, 1024, 128 * 1024);
     DP_SET_LDS(k_med_ntt_local, 1024, 64 * 1024);
   }
@@ -2498,6 +2620,25 @@ class HipDev : public Dev {
     logup_tail_parse(hres_, a, blocks, ch, layer_msgs, layer_points, round_evals, point);
     release(mk);
     nlogup_tail_++;
+    return true;
+  }
+  // ---- Dev::classic_tail: EXPERIMENTAL (DP_DEVICE_CLASSIC=1): k_classic_tail, the last rounds of the batch-opening sumcheck
+  bool devclassic_ = getenv("DP_DEVICE_CLASSIC") && atoi(getenv("DP_DEVICE_CLASSIC"));
+  bool classic_tail(const ClassicTailArgs& a, Challenger& ch, std::vector<std::vector<Ext>>& msgs, std::vector<Ext>& challenges) override {
+    if (!devclassic_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
+    if (!classic_tail_accepts(a)) return false;
+    const std::vector<size_t> blocks = classic_tail_blocks(a);
+    if (blocks[0] + blocks[1] > RES_WORDS) return false;
+    const size_t mk = mark();
+    const ClassicTailDesc* dd = nullptr;
+    ClassicTailDesc* d = desc_alloc<ClassicTailDesc>(1, &dd);
+    classic_tail_fill(d, a, ch, *this);
+    const unsigned long long seq = ++seq_;
+    nb_ = 0; for (int i = 0; i < a.np; i++) nb_ += a.fs[i].bytes() + a.eqs[i].bytes();
+    DPL_LDS(k_classic_tail, dim3(1), dim3(1024), excl_now(), dd, (u64*)hres_dev_, hflag_dev_, seq);
+    wait_flag_blocks(seq, blocks);
+    classic_tail_parse(hres_, a, ch, msgs, challenges);
+    release(mk);
     return true;
   }
   // ---- Dev::logup_full: EXPERIMENTAL (DP_DEVICE_LOGUP=2): k_logup_tail in full mode — one launch and one device wait per

@@ -100,6 +100,7 @@ int main(int argc, char** argv) {
   bool same = ow == pw;
 #ifdef DP_EMUL_DEV
   printf("emulated k_logup_tail (%s mode, %u threads): %zu logup proofs taken, %zu declined\n", dev.full ? "full" : "tail", dev.threads, dev.taken, dev.declined);
+  printf("emulated k_classic_tail: %zu batch-opening sumcheck tails taken\n", dev.classic_taken);
 #endif
   if (dev.device_classic) printf("classic_tail: %zu batch-opening sumcheck tails taken by the double\n", dev.classic_tails);
   if (dev.device_logup_full) printf("logup_full: %zu logup proofs taken by the double\n", dev.logup_fulls);

@@ -4,6 +4,7 @@
 #pragma once
 #include "../cpu_dev.hpp"
 #include "../../../deep-prove_amd/csrc/logup_tail.h"
+#include "../../../deep-prove_amd/csrc/classic_tail.h"
 #include "simt.hpp"
 #include <cstdio>
 
@@ -31,6 +32,28 @@ struct EmulDev : CpuDev {
     size_t nwords = 0; for (size_t b : blocks) nwords += b;
     for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: the kernel wrote past its message\n"); exit(3); }
     return flag;
+  }
+  bool classic = true;  // serve Dev::classic_tail with the emulated k_classic_tail
+  size_t classic_max_n = 256, classic_taken = 0;
+  bool classic_tail(const ClassicTailArgs& a, Challenger& ch, std::vector<std::vector<Ext>>& msgs, std::vector<Ext>& challenges) override {
+    if (!classic || !classic_tail_accepts(a)) return false;
+    for (int i = 0; i < a.np; i++) if (a.fs[i].n > classic_max_n) return false;  // (emulation speed; the device takes tables up to CLASSIC_TAIL_MAX_N)
+    const std::vector<size_t> blocks = classic_tail_blocks(a);
+    const size_t nwords = blocks[0] + blocks[1];
+    const size_t mk = mark();
+    ClassicTailDesc d;
+    classic_tail_fill(&d, a, ch, *this);
+    std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
+    unsigned long long flag = 0;
+    const unsigned long long seq = 1000 + classic_taken;
+    blockDim.x.v = threads;
+    simt::launch(threads, [&] { k_classic_tail(&d, res.data(), &flag, seq); });
+    if (flag != pub_mix(seq) + logup_tail_checksum(res.data(), blocks)) { fprintf(stderr, "emul: classic tail: tag does not match the payload\n"); exit(3); }
+    for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: classic tail wrote past its message\n"); exit(3); }
+    classic_tail_parse(res.data(), a, ch, msgs, challenges);
+    release(mk);
+    classic_taken++;
+    return true;
   }
   bool logup_full(const DBuf* cols, int cpi, int ninst, const DBuf& mult, Ext c, Ext chi, Challenger& ch, LogupFullOut& out) override {
     size_t n = 0;

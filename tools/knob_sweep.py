@@ -27,6 +27,9 @@ CONFIGS = [  # (name, proofs in flight, env)
     ("devlogup_tail_192", 192, {"DP_DEVICE_LOGUP": "1"}),   # the layer loop of every logup proof in one launch
     ("devlogup_full_192", 192, {"DP_DEVICE_LOGUP": "2"}),   # the whole logup proof (trees, outputs, layers, column claims) in one launch
     ("devlogup_full_256", 256, {"DP_DEVICE_LOGUP": "2"}),
+    ("devclassic_192", 192, {"DP_DEVICE_CLASSIC": "1"}),   # k_classic_tail: the last rounds of the batch-opening sumcheck in one launch
+    ("devall_192", 192, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1"}),
+    ("devall_256", 256, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1"}),
     ("hostfs_192", 192, {"DP_DEVICE_FS": "0"}),
     ("lpmax256_192", 192, {"DP_MERKLE_LP_MAX": "256"}),
     ("tailmax1024_192", 192, {"DP_TAIL_MAX": "1024"}),
