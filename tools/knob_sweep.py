@@ -5,9 +5,16 @@ usage: python tools/knob_sweep.py [workload] [out.jsonl] [budget_s]          (dr
 Results: one JSON line per configuration, appended as they finish."""
 import json, os, subprocess, sys, time
 
-CONFIGS = [  # (name, proofs in flight, env)
+CONFIGS = [  # (name, proofs in flight, env) — in order of importance: the sweep stops when its time budget is spent
     ("base_192", 192, {}),
     ("base_256", 256, {}),
+    # k_logup_tail: written after round 1's GPU budget ran out, validated on the CPU SIMT emulator only (tests/test_kernel_emul.py)
+    ("devlogup_tail_192", 192, {"DP_DEVICE_LOGUP": "1"}),   # the layer loop of every logup proof in one launch
+    ("devlogup_full_192", 192, {"DP_DEVICE_LOGUP": "2"}),   # the whole logup proof (trees, outputs, layers, column claims) in one launch
+    ("devlogup_full_256", 256, {"DP_DEVICE_LOGUP": "2"}),
+    ("devclassic_192", 192, {"DP_DEVICE_CLASSIC": "1"}),   # k_classic_tail: the last rounds of the batch-opening sumcheck in one launch
+    ("devall_192", 192, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1"}),
+    ("devall_256", 256, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1"}),
     ("threads7_192", 192, {"DP_HOST_THREADS": "7"}),
     ("threads4_192", 192, {"DP_HOST_THREADS": "4"}),
     ("tail256_192", 192, {"DP_TAIL_MANY_THREADS": "256", "DP_TAIL_MANY_EXCL": "0"}),
@@ -23,13 +30,6 @@ CONFIGS = [  # (name, proofs in flight, env)
     ("xcd_256", 256, {"DP_COHORT_XCD": "1"}),
     ("persist256_noexcl_192", 192, {"DP_COHORT_EXCL": "0", "DP_COHORT_PERSIST_THREADS": "256"}),
     ("persist512_192", 192, {"DP_COHORT_PERSIST_THREADS": "512"}),
-    # k_logup_tail: written after round 1's GPU budget ran out, validated on the CPU SIMT emulator only (tests/test_kernel_emul.py)
-    ("devlogup_tail_192", 192, {"DP_DEVICE_LOGUP": "1"}),   # the layer loop of every logup proof in one launch
-    ("devlogup_full_192", 192, {"DP_DEVICE_LOGUP": "2"}),   # the whole logup proof (trees, outputs, layers, column claims) in one launch
-    ("devlogup_full_256", 256, {"DP_DEVICE_LOGUP": "2"}),
-    ("devclassic_192", 192, {"DP_DEVICE_CLASSIC": "1"}),   # k_classic_tail: the last rounds of the batch-opening sumcheck in one launch
-    ("devall_192", 192, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1"}),
-    ("devall_256", 256, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1"}),
     ("hostfs_192", 192, {"DP_DEVICE_FS": "0"}),
     ("lpmax256_192", 192, {"DP_MERKLE_LP_MAX": "256"}),
     ("tailmax1024_192", 192, {"DP_TAIL_MAX": "1024"}),
