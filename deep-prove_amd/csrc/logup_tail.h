@@ -10,7 +10,7 @@ namespace dp {
 constexpr int LT_MAXI = 7;        // instances of one batch proof: 1 + 4 * 7 tables <= LT_MAX_TABS, 3 * 7 terms <= MAX_TERMS
 constexpr int LT_MAXL = 16;       // tree layers (columns of at most 2^16 rows; logup_tail_accepts stops far below)
 constexpr int LT_MAX_TABS = 32;   // == MAX_TABS of hip_dev.hip
-constexpr size_t LOGUP_TAIL_MAX_N = 16384;
+constexpr size_t LOGUP_TAIL_MAX_N = 65536;  // = 2^LT_MAXL: one workgroup still walks a 2^15-row table in well under a millisecond per layer
 
 struct LogupTailDesc {
   const void* num[LT_MAXI][LT_MAXL];  // numerators of tree layer li: extension; layer 0 of a table instance: the base-field

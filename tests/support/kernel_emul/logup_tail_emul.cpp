@@ -35,7 +35,8 @@ int main() {
   const Case cases[] = {{4, 1, 1, false, 64, false}, {8, 2, 1, false, 64, false}, {16, 2, 2, false, 64, false}, {32, 4, 2, false, 256, false}, {16, 1, 1, true, 64, false},
                         {64, 2, 2, true, 256, false}, {8, 3, 1, false, 1024, false}, {128, 2, 1, false, 1024, false},
                         {4, 1, 1, false, 64, true}, {8, 2, 1, false, 64, true}, {16, 4, 2, false, 256, true}, {16, 1, 1, true, 64, true}, {64, 3, 3, true, 256, true},
-                        {32, 6, 2, false, 1024, true}, {256, 2, 1, false, 1024, true}};
+                        {32, 6, 2, false, 1024, true}, {256, 2, 1, false, 1024, true},
+                        {4096, 1, 1, true, 1024, true}, {2048, 2, 1, false, 1024, true}, {1024, 2, 2, false, 256, false}};
   int rc = 0;
   for (const Case& c : cases) {
     CpuDev ref; Ext ref_after;
