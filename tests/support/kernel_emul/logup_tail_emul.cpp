@@ -38,7 +38,22 @@ int main() {
                         {32, 6, 2, false, 1024, true}, {256, 2, 1, false, 1024, true},
                         {4096, 1, 1, true, 1024, true}, {2048, 2, 1, false, 1024, true}, {1024, 2, 2, false, 256, false}};
   int rc = 0;
-  for (const Case& c : cases) {
+  std::vector<Case> all(std::begin(cases), std::end(cases));
+  {  // seeded random shapes on top of the hand-picked ones
+    uint64_t saved = rs; rs = 424242;
+    for (int k = 0; k < 16; k++) {
+      Case c;
+      c.table = rnd() % 3 == 0;
+      c.n = size_t(4) << (rnd() % 7);                 // 4 .. 256 rows
+      c.cpi = 1 + (int)(rnd() % 3);
+      c.ncols = c.table ? c.cpi : c.cpi * (1 + (int)(rnd() % 3));  // a table proof is one instance
+      c.threads = 64u << (2 * (rnd() % 3));           // 64 / 256 / 1024
+      c.full = rnd() % 2 == 0;
+      all.push_back(c);
+    }
+    rs = saved;
+  }
+  for (const Case& c : all) {
     CpuDev ref; Ext ref_after;
     std::vector<uint64_t> want = prove(ref, c.n, c.ncols, c.cpi, c.table, ref_after);
     EmulDev em; em.threads = c.threads; em.full = c.full; Ext em_after;

@@ -18,7 +18,7 @@ def test_logup_tail_kernel_on_the_simt_emulator():
     r = subprocess.run([binary], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith(("tail n=", "full n="))]
-    assert len(lines) >= 15 and sum(ln.startswith("full") for ln in lines) >= 7
+    assert len(lines) >= 30 and sum(ln.startswith("full") for ln in lines) >= 10  # hand-picked + 16 seeded random shapes
     for ln in lines:
         assert "kernel taken=1 declined=0" in ln and "identical=1" in ln and "transcript_after=1" in ln, ln
     assert any("table" in ln for ln in lines) and any("threads=1024" in ln for ln in lines) and any("threads=256" in ln for ln in lines)
