@@ -128,6 +128,15 @@ class Dev {
     (void)tabs; (void)ntabs; (void)r; (void)terms; (void)coeffs; (void)nterms; (void)max_degree; (void)ch; (void)msgs; (void)point; (void)finals;
     return false;
   }
+  // The device part of Dense::prove_step (zkml.h prove_dense) in one go, with the transcript on the device: the bias at the
+  // output point, W(point, .) (fix_high), and the whole sumcheck of sum_c W(point, c) * in(c) — header, rounds, challenges.
+  // On `true`: bias_eval, the round messages (3 evaluations each: degree 2) and challenges of the log2(C) rounds, the final
+  // evaluations [W(point, point'), in(point')], and `ch` the sponge after the last challenge. `false`: not taken.
+  struct DenseTailOut { Ext bias_eval; std::vector<std::vector<Ext>> msgs; std::vector<Ext> point; Ext finals[2]; };
+  virtual bool dense_tail(const DBuf& bias, const DBuf& W, size_t R, size_t C, const DBuf& in, const Ext* pt, Challenger& ch, DenseTailOut& out) {
+    (void)bias; (void)W; (void)R; (void)C; (void)in; (void)pt; (void)ch; (void)out;
+    return false;
+  }
   // ---- logup-GKR (K13)
   virtual void logup_den(const DBuf& out, const DBuf* cols, int ncols, Ext c, Ext chi) = 0;
   virtual void logup_layer(const DBuf& num_in, const DBuf& den_in, const DBuf& num_out, const DBuf& den_out) = 0;

@@ -439,14 +439,22 @@ inline Claim prove_dense(ProverState& ps, size_t id, const LayerSpec& l, const C
   size_t mk = dev.mark();
   const auto& comms = ps.ctx->model_comms.at(id);
   Ext bias_eval;
-  dev.mle_eval_batch(&comms.at("DenseBias").evals, 1, last.point.data(), (unsigned)last.point.size(), &bias_eval);
-  DBuf mat = dev.alloc(l.ncols, true);
-  dev.fix_high(mat, ps.ctx->weights_dev.at(id), l.nrows, l.ncols, last.point.data());
   DBuf in = dev.alloc(input.size(), true);  // trace.into_fields(): i64 -> Ext (model/trace.rs:50-92)
   { std::vector<u64> w = ext_words_from_i64(input); dev.upload(in, w.data()); }
-  DevVP vp(dp_ceil_log2(l.ncols));
-  vp.add_mle_list({mat, in}, ex_one());
-  SumcheckOut sc = sumcheck_prove(dev, vp, *ps.t);
+  SumcheckOut sc;
+  Dev::DenseTailOut dto;
+  // a device that keeps the sponge to itself does the bias evaluation, fix_high and the sumcheck in one go (Dev::dense_tail)
+  if (dev.dense_tail(comms.at("DenseBias").evals, ps.ctx->weights_dev.at(id), l.nrows, l.ncols, in, last.point.data(), ps.t->challenger(), dto)) {
+    bias_eval = dto.bias_eval;
+    sc.proof.proofs = dto.msgs; sc.proof.point = dto.point; sc.finals = {dto.finals[0], dto.finals[1]};
+  } else {
+    dev.mle_eval_batch(&comms.at("DenseBias").evals, 1, last.point.data(), (unsigned)last.point.size(), &bias_eval);
+    DBuf mat = dev.alloc(l.ncols, true);
+    dev.fix_high(mat, ps.ctx->weights_dev.at(id), l.nrows, l.ncols, last.point.data());
+    DevVP vp(dp_ceil_log2(l.ncols));
+    vp.add_mle_list({mat, in}, ex_one());
+    sc = sumcheck_prove(dev, vp, *ps.t);
+  }
   std::vector<Ext> point = sc.proof.point; point.insert(point.end(), last.point.begin(), last.point.end());
   ps.add_witness_claim(comms.at("DenseBias"), {last.point, bias_eval});   // BTreeMap order: "DenseBias" < "DenseWeight"
   ps.add_witness_claim(comms.at("DenseWeight"), {point, sc.finals[0]});

@@ -245,6 +245,27 @@ class CpuDev : public Dev {
       out[2 * i] = c0; out[2 * i + 1] = c2;
     }
   }
+  // The contract of Dev::dense_tail: bias evaluation, fix_high and the dense sumcheck on a private transcript seeded with the
+  // host's sponge (device_dense, DP_DOUBLE_DEVICE_DENSE=1 in the harness)
+  bool device_dense = false;
+  size_t dense_tails = 0;
+  bool dense_tail(const DBuf& bias, const DBuf& W, size_t R, size_t C, const DBuf& in, const Ext* pt, Challenger& ch, DenseTailOut& out) override {
+    if (!device_dense) return false;
+    dense_tails++;
+    size_t mk = mark();
+    mle_eval_batch(&bias, 1, pt, dp_ceil_log2(R), &out.bias_eval);
+    DBuf mat = alloc(C, true);
+    fix_high(mat, W, R, C, pt);
+    DevVP vp(dp_ceil_log2(C));
+    vp.add_mle_list({mat, in}, ex_one());
+    Transcript t("");
+    t.challenger() = ch;
+    SumcheckOut sc = sumcheck_prove(*this, vp, t);
+    out.msgs = sc.proof.proofs; out.point = sc.proof.point; out.finals[0] = sc.finals[0]; out.finals[1] = sc.finals[1];
+    ch = t.challenger();
+    release(mk);
+    return true;
+  }
   // The contract of Dev::classic_tail: the remaining rounds of the batch-opening sumcheck on a private transcript seeded with
   // the host's sponge (device_classic, DP_DOUBLE_DEVICE_CLASSIC=1 in the harness); like a device it only takes over once the
   // tables are small

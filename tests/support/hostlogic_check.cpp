@@ -88,6 +88,7 @@ int main(int argc, char** argv) {
   dev.threads = getenv("DP_EMUL_THREADS") ? atoi(getenv("DP_EMUL_THREADS")) : 64;
 #endif
   dev.device_fs = getenv("DP_DOUBLE_DEVICE_FS") && atoi(getenv("DP_DOUBLE_DEVICE_FS"));  // exercise the Dev::sc_tail contract (device-side Fiat-Shamir)
+  dev.device_dense = getenv("DP_DOUBLE_DEVICE_DENSE") && atoi(getenv("DP_DOUBLE_DEVICE_DENSE"));  // ... the Dev::dense_tail contract
   dev.device_classic = getenv("DP_DOUBLE_DEVICE_CLASSIC") && atoi(getenv("DP_DOUBLE_DEVICE_CLASSIC"));  // ... the Dev::classic_tail contract
   dev.device_logup = getenv("DP_DOUBLE_DEVICE_LOGUP") && atoi(getenv("DP_DOUBLE_DEVICE_LOGUP")) == 1;
   dev.device_logup_full = getenv("DP_DOUBLE_DEVICE_LOGUP") && atoi(getenv("DP_DOUBLE_DEVICE_LOGUP")) == 2;  // ... or the Dev::logup_full contract  // ... and the Dev::logup_tail contract
@@ -102,6 +103,7 @@ int main(int argc, char** argv) {
   printf("emulated k_logup_tail (%s mode, %u threads): %zu logup proofs taken, %zu declined\n", dev.full ? "full" : "tail", dev.threads, dev.taken, dev.declined);
   printf("emulated k_classic_tail: %zu batch-opening sumcheck tails taken\n", dev.classic_taken);
 #endif
+  if (dev.device_dense) printf("dense_tail: %zu dense layers taken by the double\n", dev.dense_tails);
   if (dev.device_classic) printf("classic_tail: %zu batch-opening sumcheck tails taken by the double\n", dev.classic_tails);
   if (dev.device_logup_full) printf("logup_full: %zu logup proofs taken by the double\n", dev.logup_fulls);
   if (dev.device_logup) printf("logup_tail: %zu logup layer loops taken by the double\n", dev.logup_tails);
