@@ -11,6 +11,7 @@
 #include "fiber.h"
 #include "logup_tail.h"
 #include "classic_tail.h"
+#include "dense_tail.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -1535,6 +1536,96 @@ KBODY k_classic_tail(const ClassicTailDesc* dp, u64* result, unsigned long long*
   }
 }
 
+// ------------------------------------------------------------------------------------------------ dense layer in one launch
+// Dev::dense_tail (dev.h, dense_tail.h): the bias at the output point, W(point, .) — the one-pass fix_high over the base-field
+// weights — and the degree-2 sumcheck of sum_c W(point, c) in(c) with its transcript, in ONE launch of one workgroup: a
+// 1024 x 1024 layer is 8 MB of weights through one CU (~0.15 ms), cheaper than the five dispatches it replaces when the
+// GPU serves hundreds of proofs. EXPERIMENTAL, off unless DP_DEVICE_DENSE=1: checked on the SIMT emulator of tests/, not
+// yet run on hardware.
+KBODY k_dense_tail(const DenseTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
+  DP_CLAIM_ALL_VGPRS();
+  __shared__ DenseTailDesc dl;
+  __shared__ Ext part[64 * SC_SLOTS];
+  __shared__ unsigned long long chal[3];
+  __shared__ int tk[1];
+  __shared__ ScFsArgs fsl;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < (int)(sizeof(DenseTailDesc) / 8); i += nt) ((u64*)&dl)[i] = ((const u64*)dp)[i];
+  __syncthreads();
+  if (tid == 0) { fsl.md = 2; fsl.rounds = (int)dl.lgC; fsl.label[0] = dl.lab_round[0]; fsl.label[1] = dl.lab_round[1]; fsl.nlabel = 2; fsl.pad = 0; fsl.coeff[0] = ex_one(); tk[0] = 2; }
+  WaveChallenger wc;
+  wc.st = dl.state[lane & 7]; wc.ib = dl.in_buf[lane & 3]; wc.in_len = dl.in_len; wc.out_len = dl.out_len;
+  unsigned long long fcs = 0;
+  const size_t R = dl.R, C = dl.C;
+  wg_build_eq(dl.eqr, dl.pt, (int)dl.lgR);  // eq(point, .) over the rows (ends with a barrier)
+  // bias at the point
+  {
+    Ext acc = ex_zero();
+    for (size_t i = tid; i < R; i += nt) acc = ex_add(acc, ex_mul_base(dl.eqr[i], dl.bias[i]));
+    acc = wave_reduce_ext(acc);
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (wave == 0) {
+      Ext v = lane < W ? part[lane] : ex_zero();
+      v = wave_reduce_ext(v);
+      if (lane == 0) { pub_store(result, v.c0); pub_store(result + 1, v.c1); fcs += (unsigned long long)1 * v.c0 + (unsigned long long)2 * v.c1; }
+    }
+    __syncthreads();
+  }
+  // W(point, c) = sum_r eq(point, r) W[r][c]: consecutive threads read consecutive columns of a row
+  for (size_t c = tid; c < C; c += nt) {
+    Ext acc = ex_zero();
+    for (size_t r = 0; r < R; r++) acc = ex_add(acc, ex_mul_base(dl.eqr[r], dl.W[r * C + c]));
+    dl.mat[c] = acc;
+  }
+  __syncthreads();
+  // the sumcheck of mat * in: header, then log2(C) rounds
+  if (wave == 0) { wc_observe(wc, (u64)dl.lgC, lane); wc_observe(wc, (u64)2, lane); }
+  const Ext* cur[2] = {dl.mat, dl.in};
+  u64* rw = result + 2;
+  size_t n = C;
+  bool useA = true;
+  for (int round = 0; round < (int)dl.lgC; round++) {
+    const size_t npairs = n / 2;
+    {
+      GlobalPairs L;
+      L.p[0] = cur[0]; L.e[0] = true; L.p[1] = cur[1]; L.e[1] = true; L.p[2] = cur[0]; L.e[2] = true;
+      Ext acc[SC_SLOTS];
+      sc_accumulate<false>(2, L, (size_t)tid, (size_t)nt, npairs, acc);  // every wave takes a share of the one term
+#pragma unroll
+      for (int t = 0; t < SC_SLOTS; t++) if (t <= 2) acc[t] = wave_reduce_ext(acc[t]);
+      if (lane == 0) { Ext* o = part + (size_t)wave * SC_SLOTS; for (int t = 0; t < SC_SLOTS; t++) o[t] = acc[t]; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      Ext rr = sc_fs_round(wc, fsl, part, tk, 1, W, rw, round, fcs, lane);  // wpt = W: the term's sums are spread over all waves
+      if (lane == 0) { chal[1] = rr.c0; chal[2] = rr.c1; }
+    }
+    __syncthreads();
+    const Ext r = ex(chal[1], chal[2]);
+    Ext* const* dst = useA ? dl.bufA : dl.bufB;
+    for (int t = 0; t < 2; t++) { const Ext* q = cur[t]; Ext* o = dst[t]; for (size_t i = tid; i < npairs; i += nt) o[i] = ex_lerp(q[2 * i], q[2 * i + 1], r); }
+    __syncthreads();
+    cur[0] = dst[0]; cur[1] = dst[1];
+    n = npairs; useA = !useA;
+  }
+  if (wave == 0) {
+    const size_t wf = (size_t)dl.lgC * 8;  // behind 3 evaluations and one challenge per round
+    if (lane < 2) { Ext v = cur[lane][0]; size_t w = wf + 2 * (size_t)lane; pub_store(rw + w, v.c0); pub_store(rw + w + 1, v.c1); fcs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1; }
+    u64* rs = result + (1 + (size_t)dl.lgC * 4 + 2) * 2;
+    if (lane < 8) { pub_store(rs + lane, wc.st); fcs += (unsigned long long)(lane + 1) * wc.st; }
+    if (lane < 4) { u64 v = lane < wc.in_len ? wc.ib : 0; pub_store(rs + 8 + lane, v); fcs += (unsigned long long)(8 + lane + 1) * v; }
+    if (lane == 0) {
+      u64 a = (u64)wc.in_len, b = (u64)wc.out_len;
+      pub_store(rs + 12, a); pub_store(rs + 13, b);
+      fcs += (unsigned long long)13 * a + (unsigned long long)14 * b;
+    }
+    fcs = pub_wave_sum(fcs);
+    if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + fcs);
+  }
+}
+
 // Same protocol as k_sc_persist, but the tables live in LDS after the first fold (bit-reversed index order, so a fold
 // pairs positions q and q + m/2 and is done in place with no hazards): after the first round no table byte touches
 // global memory again. Dynamic LDS = ntabs * (n0/2) extension elements.
@@ -2287,6 +2378,7 @@ class HipDev : public Dev {
     DP_SET_LDS(k_merkle_tail, 1024, (int)EXCL_LDS);
     if (devlogup_ || devlogup_full_) DP_SET_LDS(k_logup_tail, 1024, (int)EXCL_LDS);
     if (devclassic_) DP_SET_LDS(k_classic_tail, 1024, (int)EXCL_LDS);
+    if (devdense_) DP_SET_LDS(k_dense_tail, 1024, (int)EXCL_LDS);
     DP_SET_LDS(k_med_prepare, 1024, 128 * 1024);
     DP_SET_LDS(k_med_ntt_local, 1024, 64 * 1024);
   }
@@ -2620,6 +2712,25 @@ class HipDev : public Dev {
     logup_tail_parse(hres_, a, blocks, ch, layer_msgs, layer_points, round_evals, point);
     release(mk);
     nlogup_tail_++;
+    return true;
+  }
+  // ---- Dev::dense_tail: EXPERIMENTAL (DP_DEVICE_DENSE=1): k_dense_tail, a Dense layer's device work in one launch
+  bool devdense_ = getenv("DP_DEVICE_DENSE") && atoi(getenv("DP_DEVICE_DENSE"));
+  bool dense_tail(const DBuf& bias, const DBuf& W, size_t R, size_t C, const DBuf& in, const Ext* pt, Challenger& ch, DenseTailOut& out) override {
+    if (!devdense_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
+    if (!dense_tail_accepts(bias, W, R, C, in)) return false;
+    const std::vector<size_t> blocks = dense_tail_blocks(C);
+    flush_pending_eq();
+    const size_t mk = mark();
+    const DenseTailDesc* dd = nullptr;
+    DenseTailDesc* d = desc_alloc<DenseTailDesc>(1, &dd);
+    dense_tail_fill(d, bias, W, R, C, in, pt, ch, *this);
+    const unsigned long long seq = ++seq_;
+    nb_ = 8.0 * (double)R * (double)C + 16.0 * (double)R + 16.0 * (double)C * 4.0;
+    DPL_LDS(k_dense_tail, dim3(1), dim3(1024), excl_now(), dd, (u64*)hres_dev_, hflag_dev_, seq);
+    wait_flag_blocks(seq, blocks);
+    dense_tail_parse(hres_, C, ch, out);
+    release(mk);
     return true;
   }
   // ---- Dev::classic_tail: EXPERIMENTAL (DP_DEVICE_CLASSIC=1): k_classic_tail, the last rounds of the batch-opening sumcheck

@@ -5,6 +5,7 @@
 #include "../cpu_dev.hpp"
 #include "../../../deep-prove_amd/csrc/logup_tail.h"
 #include "../../../deep-prove_amd/csrc/classic_tail.h"
+#include "../../../deep-prove_amd/csrc/dense_tail.h"
 #include "simt.hpp"
 #include <cstdio>
 
@@ -32,6 +33,27 @@ struct EmulDev : CpuDev {
     size_t nwords = 0; for (size_t b : blocks) nwords += b;
     for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: the kernel wrote past its message\n"); exit(3); }
     return flag;
+  }
+  bool dense = true;  // serve Dev::dense_tail with the emulated k_dense_tail
+  size_t dense_taken = 0;
+  bool dense_tail(const DBuf& bias, const DBuf& W, size_t R, size_t C, const DBuf& in, const Ext* pt, Challenger& ch, DenseTailOut& out) override {
+    if (!dense || !dense_tail_accepts(bias, W, R, C, in)) return false;
+    const std::vector<size_t> blocks = dense_tail_blocks(C);
+    size_t nwords = 0; for (size_t b : blocks) nwords += b;
+    const size_t mk = mark();
+    DenseTailDesc d;
+    dense_tail_fill(&d, bias, W, R, C, in, pt, ch, *this);
+    std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
+    unsigned long long flag = 0;
+    const unsigned long long seq = 5000 + dense_taken;
+    blockDim.x.v = threads;
+    simt::launch(threads, [&] { k_dense_tail(&d, res.data(), &flag, seq); });
+    if (flag != pub_mix(seq) + logup_tail_checksum(res.data(), blocks)) { fprintf(stderr, "emul: dense tail: tag does not match the payload\n"); exit(3); }
+    for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: dense tail wrote past its message\n"); exit(3); }
+    dense_tail_parse(res.data(), C, ch, out);
+    release(mk);
+    dense_taken++;
+    return true;
   }
   bool classic = true;  // serve Dev::classic_tail with the emulated k_classic_tail
   size_t classic_max_n = 256, classic_taken = 0;
