@@ -2204,7 +2204,7 @@ class HipDev : public Dev {
       if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
         throw DpError(DP_ERR_HIP, "timeout waiting for the device");
     }
-    desc_off_ = 0;
+    desc_off_ = 0; stage_off_ = 0;
     if (co_ && co_li_) co_->note_executed(co_li_ - 1);
     wait_exit_(t0);
   }
@@ -2212,6 +2212,12 @@ class HipDev : public Dev {
   void* hstage_ = nullptr;  // pinned + device-mapped staging: [0, DESC_BYTES) descriptor ring read by kernels over PCIe, rest = bulk copies
   char* hstage_dev_ = nullptr;
   size_t desc_off_ = 0;
+  // DP_ASYNC_UPLOAD=1 (experiment, default off): small host-to-device copies take successive slots of the bulk staging area
+  // and are not waited for — like descriptors, the slots are recycled when the host observes a later publication of this
+  // stream (everything launched before it has run). Today every upload costs a copy launch, a publish launch and a device wait
+  // (~29 per Dense-4M proof).
+  size_t stage_off_ = 0;
+  bool async_upload_ = getenv("DP_ASYNC_UPLOAD") && atoi(getenv("DP_ASYNC_UPLOAD"));
   static constexpr size_t RES_WORDS = 1 << 16;
   size_t STAGE_BYTES = size_t(64) << 20;  // bulk staging of this context (workers of a batch get less: stage_bytes of the constructor)
   static constexpr size_t DESC_BYTES = 4 << 20;
@@ -2244,7 +2250,7 @@ class HipDev : public Dev {
         std::atomic_thread_fence(std::memory_order_acquire);
         unsigned long long cs = 0;
         for (size_t i = 0; i < nwords; i++) cs += (unsigned long long)(i + 1) * w[i];
-        if (base + cs == tag) { last_tag_ = tag; desc_off_ = 0; if (co_ && co_li_) co_->note_executed(co_li_ - 1); wait_exit_(t0); return; }
+        if (base + cs == tag) { last_tag_ = tag; desc_off_ = 0; stage_off_ = 0; if (co_ && co_li_) co_->note_executed(co_li_ - 1); wait_exit_(t0); return; }
       }
       // inside a fiber the wait hands the host thread to the next proof in flight (fiber.h); otherwise spin
       const bool fib = fiber_active();
@@ -2267,7 +2273,7 @@ class HipDev : public Dev {
       if (tag != last_tag_) {
         std::atomic_thread_fence(std::memory_order_acquire);
         const unsigned long long cs = logup_tail_checksum(w, block_words);
-        if (base + cs == tag) { last_tag_ = tag; desc_off_ = 0; if (co_ && co_li_) co_->note_executed(co_li_ - 1); wait_exit_(t0); return; }
+        if (base + cs == tag) { last_tag_ = tag; desc_off_ = 0; stage_off_ = 0; if (co_ && co_li_) co_->note_executed(co_li_ - 1); wait_exit_(t0); return; }
       }
       const bool fib = fiber_active();
       if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
@@ -2290,7 +2296,7 @@ class HipDev : public Dev {
   // wait until everything queued on the stream so far has executed, without entering hipStreamSynchronize (which
   // serialises against other host threads driving other proofs on the same GPU): a one-wave kernel posts a tag
   void stream_wait() {
-    if (!zerocopy_) { HIP_CHECK(hipStreamSynchronize(s_)); desc_off_ = 0; return; }
+    if (!zerocopy_) { HIP_CHECK(hipStreamSynchronize(s_)); desc_off_ = 0; stage_off_ = 0; return; }
     unsigned long long seq = ++seq_;
     nb_ = 0; DPL(k_publish, dim3(1), dim3(64), (const u64*)dres_, hres_dev_, (size_t)0, hflag_dev_, seq);
     wait_flag(seq, 0);
@@ -2455,6 +2461,17 @@ class HipDev : public Dev {
   // A cohort member moves data with kernels (k_copy_words through the mapped staging buffer, k_zero_words): a memcpy
   // command queued by one member would overtake the merged launches its cohort has not fired yet.
   void h2d(void* dst, const void* src, size_t bytes) {
+    if (async_upload_ && zerocopy_ && bytes > 0 && bytes % 8 == 0 && bytes <= STAGE_BYTES / 4) {
+      const size_t need = (bytes + 255) & ~size_t(255);
+      if (stage_off_ + need > STAGE_BYTES) { stream_wait(); stage_off_ = 0; }
+      char* slot = bulk_stage() + stage_off_;
+      memcpy(slot, src, bytes);
+      if (co_) { nb_ = 0; DPL(k_copy_words, dim3(grid_for(bytes / 8, 256)), dim3(TPB), (u64*)dst, (const u64*)(hstage_dev_ + DESC_BYTES + stage_off_), bytes / 8); }
+      else { nb_ = 0; prof_begin("memcpy_h2d"); HIP_CHECK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, s_)); prof_end(); }
+      stage_off_ += need;
+      return;
+    }
+    if (stage_off_) { stream_wait(); stage_off_ = 0; }  // pending slots of earlier asynchronous uploads must have been read before slot 0 is reused
     for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
       size_t m = std::min(STAGE_BYTES, bytes - off);
       memcpy(bulk_stage(), (const char*)src + off, m);
@@ -2466,6 +2483,7 @@ class HipDev : public Dev {
     }
   }
   void d2h(void* dst, const void* src, size_t bytes) {
+    // (pending upload slots are read by copy kernels that precede this download's copy in the stream: no drain needed)
     for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
       size_t m = std::min(STAGE_BYTES, bytes - off);
       if (co_) {
