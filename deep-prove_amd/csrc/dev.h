@@ -128,6 +128,18 @@ class Dev {
     (void)tabs; (void)ntabs; (void)r; (void)terms; (void)coeffs; (void)nterms; (void)max_degree; (void)ch; (void)msgs; (void)point; (void)finals;
     return false;
   }
+  // eq tables followed by a whole sumcheck over tables that include them (the accumulation sumchecks of Requant and of
+  // same_poly, zkml.h) with the transcript on the device: job j does out[idx] (+)= scale * eq(idx, pt) exactly like eq_table,
+  // in order; then the sumcheck of sum_i coeff_i * prod tables[terms[i]] over `nv` variables — header, rounds, challenges —
+  // as sumcheck_prove runs it. On `true`: round messages (max_degree + 1 evaluations each), challenges, the final evaluation
+  // of every table, `ch` the sponge after the last challenge. `false`: not taken, nothing changed.
+  struct EqAccJob { DBuf out; const Ext* pt; unsigned k; Ext scale; bool accumulate; };
+  struct EqSumOut { std::vector<std::vector<Ext>> msgs; std::vector<Ext> point, finals; };
+  virtual bool eqsum_tail(const EqAccJob* jobs, int njobs, const DBuf* tabs, int ntabs, const ScTerm* terms, const Ext* coeffs, int nterms,
+                          unsigned nv, unsigned max_degree, Challenger& ch, EqSumOut& out) {
+    (void)jobs; (void)njobs; (void)tabs; (void)ntabs; (void)terms; (void)coeffs; (void)nterms; (void)nv; (void)max_degree; (void)ch; (void)out;
+    return false;
+  }
   // The device part of Dense::prove_step (zkml.h prove_dense) in one go, with the transcript on the device: the bias at the
   // output point, W(point, .) (fix_high), and the whole sumcheck of sum_c W(point, c) * in(c) — header, rounds, challenges.
   // On `true`: bias_eval, the round messages (3 evaluations each: degree 2) and challenges of the log2(C) rounds, the final

@@ -136,6 +136,23 @@ inline SumcheckOut sumcheck_prove(Dev& dev, DevVP& vp, Transcript& t) {
   return out;
 }
 
+// eq tables (out[idx] (+)= scale * eq(idx, pt), in order) followed by the sumcheck of a virtual polynomial that contains them:
+// the shape of the accumulation sumchecks of Requant and same_poly. A device that keeps the sponge to itself does both in one
+// go (Dev::eqsum_tail); otherwise the tables are built one by one and sumcheck_prove runs.
+struct EqAcc { DBuf out; std::vector<Ext> pt; Ext scale; bool accumulate; };
+inline SumcheckOut sumcheck_prove_with_eq(Dev& dev, const std::vector<EqAcc>& eqs, DevVP& vp, Transcript& t) {
+  std::vector<Dev::EqAccJob> jobs;
+  for (const EqAcc& e : eqs) jobs.push_back({e.out, e.pt.data(), (unsigned)e.pt.size(), e.scale, e.accumulate});
+  Dev::EqSumOut eo;
+  if (dev.eqsum_tail(jobs.data(), (int)jobs.size(), vp.tabs.data(), (int)vp.tabs.size(), vp.terms.data(), vp.coeffs.data(), (int)vp.terms.size(), vp.nv, vp.max_degree, t.challenger(), eo)) {
+    DP_REQUIRE(eo.msgs.size() == vp.nv && eo.point.size() == vp.nv && eo.finals.size() == vp.tabs.size(), DP_ERR_SHAPE, "eqsum_tail: unexpected result shape");
+    SumcheckOut out; out.proof.proofs = eo.msgs; out.proof.point = eo.point; out.finals = eo.finals;
+    return out;
+  }
+  for (const Dev::EqAccJob& j : jobs) dev.eq_table(j.out, j.pt, j.k, j.scale, j.accumulate);
+  return sumcheck_prove(dev, vp, t);
+}
+
 // interpolate_uni_poly (sumcheck/src/util.rs:148-195) == Lagrange evaluation on nodes 0..len-1
 struct SubClaim { std::vector<Ext> point; Ext expected_evaluation; };
 inline SubClaim sumcheck_verify(Ext claimed_sum, const IOPProof& proof, unsigned nv, unsigned max_degree, Transcript& t) {

@@ -479,9 +479,7 @@ inline Claim prove_requant(ProverState& ps, size_t id, const LayerSpec& l, const
   DBuf clamp_in = cw.columns[0], clamp_out = cw.columns[1];
   DBuf cbeta = dev.alloc(n, true), lbeta = dev.alloc(n, true), sbeta = dev.alloc(n, true);
   DP_REQUIRE(last.point.size() == nv, DP_ERR_SHAPE, "requant: claim point length");
-  dev.eq_table(cbeta, cproof.output_claims[0].point.data(), nv, ex_one(), false);
-  dev.eq_table(lbeta, last.point.data(), nv, ex_one(), false);
-  dev.eq_table(sbeta, sproof.output_claims[0].point.data(), nv, ex_one(), false);
+  std::vector<EqAcc> eqs = {{cbeta, cproof.output_claims[0].point, ex_one(), false}, {lbeta, last.point, ex_one(), false}, {sbeta, sproof.output_claims[0].point, ex_one(), false}};
   Ext b = ps.t->get_and_append_challenge("requant_batching");
   DevVP vp(nv);
   vp.add_mle_list({clamp_out, lbeta}, ex_one());
@@ -490,7 +488,7 @@ inline Claim prove_requant(ProverState& ps, size_t id, const LayerSpec& l, const
   vp.add_mle_list({clamp_in, cbeta}, comb);
   comb = ex_mul(comb, b);
   for (auto& m : sw.columns) { vp.add_mle_list({sbeta, m}, comb); comb = ex_mul(comb, b); }
-  SumcheckOut sc = sumcheck_prove(dev, vp, *ps.t);
+  SumcheckOut sc = sumcheck_prove_with_eq(dev, eqs, vp, *ps.t);
   dev.release(mk);
   const std::vector<Ext>& fin = sc.finals;
   Ext cout_eval = fin[0], cin_eval = fin[3];
@@ -509,13 +507,14 @@ inline SamePolyProof same_poly_prove(Dev& dev, const std::vector<Claim>& claims,
   unsigned nv = dp_ceil_log2(poly.n);
   std::vector<Ext> a = t.read_challenges(claims.size());
   DBuf beta = dev.alloc(poly.n, true);
+  std::vector<EqAcc> eqs;
   for (size_t i = 0; i < claims.size(); i++) {
     DP_REQUIRE(claims[i].point.size() == nv, DP_ERR_SHAPE, "same_poly: claim point length");
-    dev.eq_table(beta, claims[i].point.data(), nv, a[i], i > 0);
+    eqs.push_back({beta, claims[i].point, a[i], i > 0});
   }
   DevVP vp(nv);
   vp.add_mle_list({beta, poly}, ex_one());
-  SumcheckOut sc = sumcheck_prove(dev, vp, t);
+  SumcheckOut sc = sumcheck_prove_with_eq(dev, eqs, vp, t);
   dev.release(mk);
   return {sc.proof, sc.finals};
 }

@@ -245,6 +245,24 @@ class CpuDev : public Dev {
       out[2 * i] = c0; out[2 * i + 1] = c2;
     }
   }
+  // The contract of Dev::eqsum_tail: the eq tables, then the whole sumcheck on a private transcript seeded with the host's sponge
+  // (device_eqsum, DP_DOUBLE_DEVICE_EQSUM=1 in the harness)
+  bool device_eqsum = false;
+  size_t eqsum_tails = 0;
+  bool eqsum_tail(const EqAccJob* jobs, int njobs, const DBuf* tabs, int ntabs, const ScTerm* terms, const Ext* coeffs, int nterms, unsigned nv, unsigned md,
+                  Challenger& ch, EqSumOut& out) override {
+    if (!device_eqsum) return false;
+    eqsum_tails++;
+    for (int j = 0; j < njobs; j++) eq_table(jobs[j].out, jobs[j].pt, jobs[j].k, jobs[j].scale, jobs[j].accumulate);
+    DevVP vp(nv);
+    vp.tabs.assign(tabs, tabs + ntabs); vp.terms.assign(terms, terms + nterms); vp.coeffs.assign(coeffs, coeffs + nterms); vp.max_degree = md;
+    Transcript t("");
+    t.challenger() = ch;
+    SumcheckOut sc = sumcheck_prove(*this, vp, t);
+    out.msgs = sc.proof.proofs; out.point = sc.proof.point; out.finals = sc.finals;
+    ch = t.challenger();
+    return true;
+  }
   // The contract of Dev::dense_tail: bias evaluation, fix_high and the dense sumcheck on a private transcript seeded with the
   // host's sponge (device_dense, DP_DOUBLE_DEVICE_DENSE=1 in the harness)
   bool device_dense = false;

@@ -1,11 +1,11 @@
 #!/bin/bash
-# First GPU call of the next round (about 12 minutes of box time): parity suite, the knob sweep — which is also the first
+# First GPU call of the next round (about 15 minutes of box time): parity suite, the knob sweep — which is also the first
 # hardware run of the experimental kernels (k_logup_tail tail / full mode, k_classic_tail), each configuration checked
 # against the sequential proof — then a kernel trace and the analysis of the best configuration, and the bench line.
 # usage (repo root, on the GPU box): bash tools/next_round_first_call.sh gpurun_out/r02_first
 out=${1:-gpurun_out/r02_first}; mkdir -p "$out"; export TMPDIR=/tmp
 timeout 600 python -m pytest tests -m gpu -x -q > "$out/pytest.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest.log"
-timeout 420 python tools/knob_sweep.py dense_4m "$out/knob_sweep_dense4m.jsonl" 400 > "$out/knob_sweep.log" 2>&1
+timeout 560 python tools/knob_sweep.py dense_4m "$out/knob_sweep_dense4m.jsonl" 520 > "$out/knob_sweep.log" 2>&1
 best=$(python - "$out/knob_sweep_dense4m.jsonl" <<'PY'
 import json, sys
 recs = [json.loads(l) for l in open(sys.argv[1]) if l.strip()]
