@@ -12,6 +12,7 @@
 #include "logup_tail.h"
 #include "classic_tail.h"
 #include "dense_tail.h"
+#include "eqsum_tail.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -1626,6 +1627,99 @@ KBODY k_dense_tail(const DenseTailDesc* dp, u64* result, unsigned long long* fla
   }
 }
 
+// ------------------------------------------------------------------------------------------------ eq tables + sumcheck in one launch
+// Dev::eqsum_tail (dev.h, eqsum_tail.h): the eq tables of an accumulation sumcheck (Requant: three plain tables; same_poly:
+// one table accumulated from scaled eq's) and the whole sumcheck over them with its transcript, in ONE launch of one
+// workgroup. EXPERIMENTAL, off unless DP_DEVICE_EQSUM=1: checked on the SIMT emulator of tests/, not yet run on hardware.
+KBODY k_eqsum_tail(const EqSumDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
+  DP_CLAIM_ALL_VGPRS();
+  __shared__ EqSumDesc dl;
+  __shared__ Ext part[64 * SC_SLOTS];
+  __shared__ unsigned long long chal[3];
+  __shared__ const void* cur[ES_MAXT];
+  __shared__ int cur_ext[ES_MAXT];
+  __shared__ ScFsArgs fsl;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < (int)(sizeof(EqSumDesc) / 8); i += nt) ((u64*)&dl)[i] = ((const u64*)dp)[i];
+  __syncthreads();
+  const int ntab = dl.ntabs, nterm = dl.nterms;
+  if (tid == 0) { fsl.md = (int)dl.md; fsl.rounds = (int)dl.nv; fsl.label[0] = dl.lab_round[0]; fsl.label[1] = dl.lab_round[1]; fsl.nlabel = 2; fsl.pad = 0; }
+  for (int i = tid; i < nterm; i += nt) fsl.coeff[i] = dl.coeff[i];
+  for (int i = tid; i < ntab; i += nt) { cur[i] = dl.tab[i]; cur_ext[i] = dl.tab_ext[i]; }
+  WaveChallenger wc;
+  wc.st = dl.state[lane & 7]; wc.ib = dl.in_buf[lane & 3]; wc.in_len = dl.in_len; wc.out_len = dl.out_len;
+  unsigned long long fcs = 0;
+  const size_t n0 = size_t(1) << dl.nv;
+  // the eq tables, in order: out[idx] (+)= scale * prod_t (idx_t ? pt[t] : 1 - pt[t])
+  for (int j = 0; j < dl.njobs; j++) {
+    Ext* out = dl.job_out[j];
+    const Ext sc = dl.job_scale[j];
+    for (size_t i = tid; i < n0; i += nt) {
+      Ext v = sc;
+      for (unsigned t = 0; t < dl.nv; t++) { Ext r = dl.job_pt[j][t]; v = ex_mul(v, ((i >> t) & 1) ? r : ex_sub(ex_one(), r)); }
+      out[i] = dl.job_acc[j] ? ex_add(out[i], v) : v;
+    }
+    __syncthreads();
+  }
+  if (wave == 0) { wc_observe(wc, (u64)dl.nv, lane); wc_observe(wc, (u64)dl.md, lane); }  // header of the sumcheck
+  const int wpt = nterm >= W ? 1 : W / nterm;
+  size_t n = n0;
+  bool useA = true;
+  for (int round = 0; round < (int)dl.nv; round++) {
+    const size_t npairs = n / 2;
+    for (int term = wave / wpt; term < nterm; term += (wpt == 1 ? W : nterm + W)) {
+      const int sub = wave % wpt;
+      const int k = dl.tk[term];
+      GlobalPairs L;
+#pragma unroll
+      for (int j = 0; j < 3; j++) { int ti = dl.tt[term][j < k ? j : 0]; L.p[j] = cur[ti]; L.e[j] = cur_ext[ti] != 0; }
+      Ext acc[SC_SLOTS];
+      sc_accumulate<false>(k, L, (size_t)sub * 64 + lane, (size_t)wpt * 64, npairs, acc);
+#pragma unroll
+      for (int t = 0; t < SC_SLOTS; t++) if (t <= k) acc[t] = wave_reduce_ext(acc[t]);
+      if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * SC_SLOTS; for (int t = 0; t < SC_SLOTS; t++) o[t] = acc[t]; }
+      if (wpt > 1) break;  // with several waves per term every wave owns exactly one (term, sub)
+    }
+    __syncthreads();
+    if (wave == 0) {
+      Ext rr = sc_fs_round(wc, fsl, part, dl.tk, nterm, wpt, result, round, fcs, lane);
+      if (lane == 0) { chal[1] = rr.c0; chal[2] = rr.c1; }
+    }
+    __syncthreads();
+    const Ext r = ex(chal[1], chal[2]);
+    Ext* const* dst = useA ? dl.bufA : dl.bufB;
+    for (int t = 0; t < ntab; t++) {
+      Ext* o = dst[t];
+      if (cur_ext[t]) { const Ext* q = (const Ext*)cur[t]; for (size_t i = tid; i < npairs; i += nt) o[i] = ex_lerp(q[2 * i], q[2 * i + 1], r); }
+      else { const u64* q = (const u64*)cur[t]; for (size_t i = tid; i < npairs; i += nt) o[i] = ex_lerp_base(q[2 * i], q[2 * i + 1], r); }
+    }
+    __syncthreads();
+    if (tid < ntab) { cur[tid] = dst[tid]; cur_ext[tid] = 1; }
+    __syncthreads();
+    n = npairs; useA = !useA;
+  }
+  if (wave == 0) {
+    const size_t wf = (size_t)dl.nv * (dl.md + 2) * 2;
+    for (int e = lane; e < ntab; e += 64) {
+      Ext v = ((const Ext*)cur[e])[0];
+      size_t w = wf + 2 * (size_t)e;
+      pub_store(result + w, v.c0); pub_store(result + w + 1, v.c1);
+      fcs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1;
+    }
+    u64* rs = result + wf + 2 * (size_t)ntab;
+    if (lane < 8) { pub_store(rs + lane, wc.st); fcs += (unsigned long long)(lane + 1) * wc.st; }
+    if (lane < 4) { u64 v = lane < wc.in_len ? wc.ib : 0; pub_store(rs + 8 + lane, v); fcs += (unsigned long long)(8 + lane + 1) * v; }
+    if (lane == 0) {
+      u64 a = (u64)wc.in_len, b = (u64)wc.out_len;
+      pub_store(rs + 12, a); pub_store(rs + 13, b);
+      fcs += (unsigned long long)13 * a + (unsigned long long)14 * b;
+    }
+    fcs = pub_wave_sum(fcs);
+    if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + fcs);
+  }
+}
+
 // Same protocol as k_sc_persist, but the tables live in LDS after the first fold (bit-reversed index order, so a fold
 // pairs positions q and q + m/2 and is done in place with no hazards): after the first round no table byte touches
 // global memory again. Dynamic LDS = ntabs * (n0/2) extension elements.
@@ -2385,6 +2479,7 @@ class HipDev : public Dev {
     if (devlogup_ || devlogup_full_) DP_SET_LDS(k_logup_tail, 1024, (int)EXCL_LDS);
     if (devclassic_) DP_SET_LDS(k_classic_tail, 1024, (int)EXCL_LDS);
     if (devdense_) DP_SET_LDS(k_dense_tail, 1024, (int)EXCL_LDS);
+    if (deveqsum_) DP_SET_LDS(k_eqsum_tail, 1024, (int)EXCL_LDS);
     DP_SET_LDS(k_med_prepare, 1024, 128 * 1024);
     DP_SET_LDS(k_med_ntt_local, 1024, 64 * 1024);
   }
@@ -2730,6 +2825,27 @@ class HipDev : public Dev {
     logup_tail_parse(hres_, a, blocks, ch, layer_msgs, layer_points, round_evals, point);
     release(mk);
     nlogup_tail_++;
+    return true;
+  }
+  // ---- Dev::eqsum_tail: EXPERIMENTAL (DP_DEVICE_EQSUM=1): k_eqsum_tail, eq tables + accumulation sumcheck in one launch
+  bool deveqsum_ = getenv("DP_DEVICE_EQSUM") && atoi(getenv("DP_DEVICE_EQSUM"));
+  bool eqsum_tail(const EqAccJob* jobs, int njobs, const DBuf* tabs, int ntabs, const ScTerm* terms, const Ext* coeffs, int nterms, unsigned nv, unsigned md,
+                  Challenger& ch, EqSumOut& out) override {
+    if (!deveqsum_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
+    if (!eqsum_tail_accepts(jobs, njobs, tabs, ntabs, terms, nterms, nv, md)) return false;
+    const std::vector<size_t> blocks = eqsum_tail_blocks(ntabs, nv, md);
+    if (blocks[0] + blocks[1] > RES_WORDS) return false;
+    flush_pending_eq();
+    const size_t mk = mark();
+    const EqSumDesc* dd = nullptr;
+    EqSumDesc* d = desc_alloc<EqSumDesc>(1, &dd);
+    eqsum_tail_fill(d, jobs, njobs, tabs, ntabs, terms, coeffs, nterms, nv, md, ch, *this);
+    const unsigned long long seq = ++seq_;
+    nb_ = 0; for (int i = 0; i < ntabs; i++) nb_ += (double)tabs[i].bytes();
+    DPL_LDS(k_eqsum_tail, dim3(1), dim3(1024), excl_now(), dd, (u64*)hres_dev_, hflag_dev_, seq);
+    wait_flag_blocks(seq, blocks);
+    eqsum_tail_parse(hres_, ntabs, nv, md, ch, out);
+    release(mk);
     return true;
   }
   // ---- Dev::dense_tail: EXPERIMENTAL (DP_DEVICE_DENSE=1): k_dense_tail, a Dense layer's device work in one launch

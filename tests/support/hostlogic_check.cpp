@@ -104,6 +104,7 @@ int main(int argc, char** argv) {
   printf("emulated k_logup_tail (%s mode, %u threads): %zu logup proofs taken, %zu declined\n", dev.full ? "full" : "tail", dev.threads, dev.taken, dev.declined);
   printf("emulated k_classic_tail: %zu batch-opening sumcheck tails taken\n", dev.classic_taken);
   printf("emulated k_dense_tail: %zu dense layers taken\n", dev.dense_taken);
+  printf("emulated k_eqsum_tail: %zu eq + sumcheck groups taken\n", dev.eqsum_taken);
 #endif
   if (dev.device_eqsum) printf("eqsum_tail: %zu eq + sumcheck groups taken by the double\n", dev.eqsum_tails);
   if (dev.device_dense) printf("dense_tail: %zu dense layers taken by the double\n", dev.dense_tails);

@@ -6,6 +6,7 @@
 #include "../../../deep-prove_amd/csrc/logup_tail.h"
 #include "../../../deep-prove_amd/csrc/classic_tail.h"
 #include "../../../deep-prove_amd/csrc/dense_tail.h"
+#include "../../../deep-prove_amd/csrc/eqsum_tail.h"
 #include "simt.hpp"
 #include <cstdio>
 
@@ -33,6 +34,28 @@ struct EmulDev : CpuDev {
     size_t nwords = 0; for (size_t b : blocks) nwords += b;
     for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: the kernel wrote past its message\n"); exit(3); }
     return flag;
+  }
+  bool eqsum = true;  // serve Dev::eqsum_tail with the emulated k_eqsum_tail
+  size_t eqsum_taken = 0;
+  bool eqsum_tail(const EqAccJob* jobs, int njobs, const DBuf* tabs, int ntabs, const ScTerm* terms, const Ext* coeffs, int nterms, unsigned nv, unsigned md,
+                  Challenger& ch, EqSumOut& out) override {
+    if (!eqsum || !eqsum_tail_accepts(jobs, njobs, tabs, ntabs, terms, nterms, nv, md)) return false;
+    const std::vector<size_t> blocks = eqsum_tail_blocks(ntabs, nv, md);
+    const size_t nwords = blocks[0] + blocks[1];
+    const size_t mk = mark();
+    EqSumDesc d;
+    eqsum_tail_fill(&d, jobs, njobs, tabs, ntabs, terms, coeffs, nterms, nv, md, ch, *this);
+    std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
+    unsigned long long flag = 0;
+    const unsigned long long seq = 9000 + eqsum_taken;
+    blockDim.x.v = threads;
+    simt::launch(threads, [&] { k_eqsum_tail(&d, res.data(), &flag, seq); });
+    if (flag != pub_mix(seq) + logup_tail_checksum(res.data(), blocks)) { fprintf(stderr, "emul: eqsum tail: tag does not match the payload\n"); exit(3); }
+    for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: eqsum tail wrote past its message\n"); exit(3); }
+    eqsum_tail_parse(res.data(), ntabs, nv, md, ch, out);
+    release(mk);
+    eqsum_taken++;
+    return true;
   }
   bool dense = true;  // serve Dev::dense_tail with the emulated k_dense_tail
   size_t dense_taken = 0;
