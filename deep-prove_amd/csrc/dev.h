@@ -238,6 +238,19 @@ class Dev {
     if (init) copy(acc, *init); else zero(acc);
     for (size_t i = 0; i < n; i++) axpy_rep(acc, jobs[i].x, jobs[i].coeff, jobs[i].rep);
   }
+  // The remaining rounds of the Basefold commit phase (pcs.h commit_rounds: batch_commit_phase, commit_phase.rs:187-359) with
+  // the transcript on the device, from the top of a round i >= 1: absorb `last`, draw the folding challenge, merge the committed
+  // codewords of the running oracle's size into `folded` (merges[j] for tail round j; never in place: `folded` is the leaf
+  // array of a tree), FRI-fold, fold the sumcheck pairs (eq, sum_evals), and — except in the final round — the next message,
+  // the Merkle tree of the folded oracle and its root absorbed; in the final round the final message (sum_evals, bit-reversed
+  // index order) absorbed. On `true`: one message and one tree (leaves, nodes, root; allocated so that they outlive the call)
+  // per non-final round, the final message, `ch` the sponge at the end. `false`: not taken, nothing changed.
+  struct CommitTailArgs { const Ext* last; DBuf folded, eq, sum_evals; unsigned rounds_left; const std::vector<std::vector<AxpyJob>>* merges; };
+  struct CommitTailOut { std::vector<std::vector<Ext>> msgs; std::vector<DevTree> trees; std::vector<Ext> final_message; };
+  virtual bool commit_tail(const CommitTailArgs& a, Challenger& ch, CommitTailOut& out) {
+    (void)a; (void)ch; (void)out;
+    return false;
+  }
   // K10: (optionally) fold the evaluation-form pair arrays with ch, then (optionally) the coefficient-form message
   virtual void bf_round(DBuf& eq, DBuf& f, const Ext* ch, Ext* msg3) = 0;
   // K9: FRI fold of a bit-reversed codeword of length 2^(level+1)

@@ -28,6 +28,56 @@ inline BasefoldProof pcs_open_trivial(Dev& dev, const DevCommit& c) {
 
 struct OpenClaim { const DevCommit* comm; std::vector<Ext> point; Ext eval; };
 
+// Rounds [first, num_rounds) of batch_commit_phase (commit_phase.rs:187-359): per round absorb the pending sumcheck message,
+// draw the folding challenge, merge the committed codewords of the running oracle's size, FRI-fold, fold the sumcheck pairs;
+// then the next message, the Merkle tree of the folded oracle and its root — or, in the last round, the final message.
+// With `allow_tail` a device may take the remaining rounds over at the top of any round >= 1 (Dev::commit_tail).
+struct CommitLoopState { std::vector<Ext> last; DBuf running, folded, eq, sum_evals; DevTree pending; };
+inline void commit_rounds(Dev& dev, const std::vector<std::vector<Dev::AxpyJob>>& merges, unsigned num_rounds, unsigned first, bool allow_tail, CommitLoopState& st,
+                          Transcript& t, std::vector<std::vector<Ext>>& msgs, std::vector<Digest>& roots, std::vector<DevTree>& trees, std::vector<Ext>& final_message) {
+  for (unsigned i = first; i < num_rounds; i++) {
+    if (allow_tail && i > 0) {
+      std::vector<std::vector<Dev::AxpyJob>> rest(merges.begin() + i, merges.end());
+      Dev::CommitTailArgs ta{st.last.data(), st.folded, st.eq, st.sum_evals, num_rounds - i, &rest};
+      Dev::CommitTailOut to;
+      if (dev.commit_tail(ta, t.challenger(), to)) {
+        DP_REQUIRE(to.msgs.size() == num_rounds - i - 1 && to.trees.size() == num_rounds - i - 1, DP_ERR_SHAPE, "commit_tail: one message and one tree per non-final round expected");
+        trees.push_back(st.pending);
+        for (auto& m : to.msgs) msgs.push_back(m);
+        for (auto& tr : to.trees) { roots.push_back(tr.root); trees.push_back(tr); }
+        final_message = to.final_message;
+        return;
+      }
+    }
+    for (const Ext& e : st.last) t.append_ext(e);
+    Ext c = t.get_and_append_challenge("commit round");
+    if (i > 0) {
+      trees.push_back(st.pending);
+      if (!merges[i].empty()) {  // a fresh buffer: the committed oracle (tree leaves) must stay untouched
+        DBuf b = dev.alloc(st.folded.n, true);
+        dev.axpy_many(b, &st.folded, merges[i].data(), merges[i].size());
+        st.running = b;
+      } else st.running = st.folded;
+    }
+    st.folded = dev.fri_fold(st.running, dp_ceil_log2(st.running.n) - 1, c);
+    if (i + 1 < num_rounds) {
+      dev.bf_round(st.eq, st.sum_evals, &c, st.last.data());
+      msgs.push_back(st.last);
+      st.pending = dev.merkle_ext(st.folded);
+      t.append_digest(st.pending.root);
+      roots.push_back(st.pending.root);
+    } else {
+      dev.bf_round(st.eq, st.sum_evals, &c, nullptr);
+      std::vector<u64> w(2 * st.sum_evals.n);
+      dev.download(st.sum_evals, w.data());
+      size_t m = st.sum_evals.n; unsigned lg = dp_ceil_log2(m);
+      final_message.resize(m);
+      for (size_t j = 0; j < m; j++) { size_t r = dp_reverse_bits(j, lg); final_message[r] = ex(w[2 * j], w[2 * j + 1]); }
+      t.append_exts(final_message);
+    }
+  }
+}
+
 // One round message [h0, h1, h2] of the batch-opening sumcheck from the per-pair sums of Dev::classic_round
 // (CoefficientsProver::prove_round, sum_check/classic/coeff.rs:198-345): pair i contributes eq_xt[i] * (c0, c2), scaled by the
 // number of times its (shorter) hypercube repeats in the round's; h1 follows from the running claim.
@@ -130,35 +180,12 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
   dev.bf_round(eq, sum_evals, nullptr, last.data());
   proof.sumcheck_messages.push_back(last);
   std::vector<DevTree> trees;
-  DBuf folded; DevTree pending; bool have_pending = false;
-  for (unsigned i = 0; i < num_rounds; i++) {
-    for (const Ext& e : last) t.append_ext(e);
-    Ext c = t.get_and_append_challenge("commit round");
-    if (i > 0) {
-      trees.push_back(pending);
-      bool any = false;
-      for (size_t k = 0; k < np; k++) if (claims[k].comm->codeword_size() == folded.n) any = true;
-      if (any) running = merge_codewords(folded.n, &folded);  // a fresh buffer: the committed oracle (tree leaves) must stay untouched
-      else running = folded;
-    }
-    folded = dev.fri_fold(running, dp_ceil_log2(running.n) - 1, c);
-    if (i + 1 < num_rounds) {
-      dev.bf_round(eq, sum_evals, &c, last.data());
-      proof.sumcheck_messages.push_back(last);
-      pending = dev.merkle_ext(folded); have_pending = true;
-      t.append_digest(pending.root);
-      proof.roots.push_back(pending.root);
-    } else {
-      dev.bf_round(eq, sum_evals, &c, nullptr);
-      std::vector<u64> w(2 * sum_evals.n);
-      dev.download(sum_evals, w.data());
-      size_t m = sum_evals.n; unsigned lg = dp_ceil_log2(m);
-      proof.final_message.resize(m);
-      for (size_t j = 0; j < m; j++) { size_t r = dp_reverse_bits(j, lg); proof.final_message[r] = ex(w[2 * j], w[2 * j + 1]); }
-      t.append_exts(proof.final_message);
-    }
-  }
-  (void)have_pending;
+  // merges[i]: the committed codewords that join the running oracle at the top of round i (those as long as it is then)
+  std::vector<std::vector<Dev::AxpyJob>> merges(num_rounds);
+  for (unsigned i = 1; i < num_rounds; i++)
+    for (size_t k = 0; k < np; k++) if (claims[k].comm->codeword_size() == (cw_size >> i)) merges[i].push_back({claims[k].comm->tree.leaves, coeffs[k], 1});
+  CommitLoopState st; st.last = last; st.running = running; st.eq = eq; st.sum_evals = sum_evals;
+  commit_rounds(dev, merges, num_rounds, 0, true, st, t, proof.sumcheck_messages, proof.roots, trees, proof.final_message);
   lap("commit phase");
   // ---- batch_prover_query_phase (query_phase.rs:67-102, 419-472) and Merkle paths (:1062-1087)
   std::vector<size_t> qidx;

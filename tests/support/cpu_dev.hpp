@@ -245,6 +245,26 @@ class CpuDev : public Dev {
       out[2 * i] = c0; out[2 * i + 1] = c2;
     }
   }
+  // The contract of Dev::commit_tail: the remaining commit-phase rounds (commit_rounds of pcs.h) on a private transcript seeded
+  // with the host's sponge (device_commit, DP_DOUBLE_DEVICE_COMMIT=1 in the harness); like a device, only for short oracles
+  bool device_commit = false;
+  size_t commit_tails = 0;
+  bool commit_tail(const CommitTailArgs& a, Challenger& ch, CommitTailOut& out) override {
+    if (!device_commit || a.folded.n > 1024) return false;
+    commit_tails++;
+    std::vector<std::vector<AxpyJob>> merges(1);
+    merges.insert(merges.end(), a.merges->begin(), a.merges->end());
+    CommitLoopState st;
+    st.last.assign(a.last, a.last + 3); st.folded = a.folded; st.eq = a.eq; st.sum_evals = a.sum_evals;
+    Transcript t("");
+    t.challenger() = ch;
+    std::vector<Digest> roots;
+    std::vector<DevTree> trees;
+    commit_rounds(*this, merges, a.rounds_left + 1, 1, false, st, t, out.msgs, roots, trees, out.final_message);
+    out.trees.assign(trees.begin() + 1, trees.end());  // (the first entry is the caller's pending tree, pushed by round "1")
+    ch = t.challenger();
+    return true;
+  }
   // The contract of Dev::eqsum_tail: the eq tables, then the whole sumcheck on a private transcript seeded with the host's sponge
   // (device_eqsum, DP_DOUBLE_DEVICE_EQSUM=1 in the harness)
   bool device_eqsum = false;

@@ -88,6 +88,7 @@ int main(int argc, char** argv) {
   dev.threads = getenv("DP_EMUL_THREADS") ? atoi(getenv("DP_EMUL_THREADS")) : 64;
 #endif
   dev.device_fs = getenv("DP_DOUBLE_DEVICE_FS") && atoi(getenv("DP_DOUBLE_DEVICE_FS"));  // exercise the Dev::sc_tail contract (device-side Fiat-Shamir)
+  dev.device_commit = getenv("DP_DOUBLE_DEVICE_COMMIT") && atoi(getenv("DP_DOUBLE_DEVICE_COMMIT"));  // ... the Dev::commit_tail contract
   dev.device_eqsum = getenv("DP_DOUBLE_DEVICE_EQSUM") && atoi(getenv("DP_DOUBLE_DEVICE_EQSUM"));  // ... the Dev::eqsum_tail contract
   dev.device_dense = getenv("DP_DOUBLE_DEVICE_DENSE") && atoi(getenv("DP_DOUBLE_DEVICE_DENSE"));  // ... the Dev::dense_tail contract
   dev.device_classic = getenv("DP_DOUBLE_DEVICE_CLASSIC") && atoi(getenv("DP_DOUBLE_DEVICE_CLASSIC"));  // ... the Dev::classic_tail contract
@@ -106,6 +107,7 @@ int main(int argc, char** argv) {
   printf("emulated k_dense_tail: %zu dense layers taken\n", dev.dense_taken);
   printf("emulated k_eqsum_tail: %zu eq + sumcheck groups taken\n", dev.eqsum_taken);
 #endif
+  if (dev.device_commit) printf("commit_tail: %zu commit-phase tails taken by the double\n", dev.commit_tails);
   if (dev.device_eqsum) printf("eqsum_tail: %zu eq + sumcheck groups taken by the double\n", dev.eqsum_tails);
   if (dev.device_dense) printf("dense_tail: %zu dense layers taken by the double\n", dev.dense_tails);
   if (dev.device_classic) printf("classic_tail: %zu batch-opening sumcheck tails taken by the double\n", dev.classic_tails);

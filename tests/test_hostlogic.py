@@ -60,12 +60,13 @@ def test_device_side_whole_logup_contract(hostlogic_bin, args, fs):
 def test_device_side_classic_sumcheck_contract(hostlogic_bin, args):
     """Dev::classic_tail (the last rounds of the batch-opening sumcheck of pcs_batch_open with the transcript on the device),
     together with the other device-side transcript contracts"""
-    r = run(hostlogic_bin, *args, env={"DP_DOUBLE_DEVICE_CLASSIC": "1", "DP_DOUBLE_DEVICE_DENSE": "1", "DP_DOUBLE_DEVICE_EQSUM": "1", "DP_DOUBLE_DEVICE_LOGUP": "2", "DP_DOUBLE_DEVICE_FS": "1"})
+    r = run(hostlogic_bin, *args, env={"DP_DOUBLE_DEVICE_CLASSIC": "1", "DP_DOUBLE_DEVICE_DENSE": "1", "DP_DOUBLE_DEVICE_EQSUM": "1", "DP_DOUBLE_DEVICE_COMMIT": "1", "DP_DOUBLE_DEVICE_LOGUP": "2", "DP_DOUBLE_DEVICE_FS": "1"})
     assert r.returncode == 0, r.stdout + r.stderr
     assert "identical=1" in r.stdout
     assert int(r.stdout.split("classic_tail: ")[1].split()[0]) >= 1, r.stdout
     assert int(r.stdout.split("dense_tail: ")[1].split()[0]) >= 1, r.stdout  # Dev::dense_tail (bias evaluation + fix_high + sumcheck)
     assert int(r.stdout.split("eqsum_tail: ")[1].split()[0]) >= 2, r.stdout  # Dev::eqsum_tail (eq tables + accumulation sumcheck)
+    assert int(r.stdout.split("commit_tail: ")[1].split()[0]) >= 1, r.stdout  # Dev::commit_tail (the last rounds of the Basefold commit phase)
     assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
 
 
