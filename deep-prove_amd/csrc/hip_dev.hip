@@ -13,6 +13,7 @@
 #include "classic_tail.h"
 #include "dense_tail.h"
 #include "eqsum_tail.h"
+#include "commit_tail.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -1720,6 +1721,184 @@ KBODY k_eqsum_tail(const EqSumDesc* dp, u64* result, unsigned long long* flag, u
   }
 }
 
+// ------------------------------------------------------------------------------------------------ Basefold commit-phase tail
+// Dev::commit_tail (dev.h, commit_tail.h): the last rounds of the Basefold commit phase (commit_rounds of pcs.h) — per round the
+// pending sumcheck message absorbed, the folding challenge, the merge of the committed codewords of the oracle's size, the FRI
+// fold (k_fri_fold's formula), the fold of the sumcheck pairs, the next message (k_bf_msg's sums), the Merkle tree of the folded
+// oracle (k_merkle_tail's layer loop) and its root absorbed; in the last round the final message absorbed — in ONE launch of
+// one workgroup once the oracle is short. EXPERIMENTAL, off unless DP_DEVICE_COMMIT=1: checked on the SIMT emulator of
+// tests/, not yet run on hardware.
+KBODY k_commit_tail(const CommitTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
+  DP_CLAIM_ALL_VGPRS();
+  __shared__ CommitTailDesc dl;
+  __shared__ Ext part[64 * 3];
+  __shared__ unsigned long long chal[3];
+  __shared__ Ext s_last[3];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < (int)(sizeof(CommitTailDesc) / 8); i += nt) ((u64*)&dl)[i] = ((const u64*)dp)[i];
+  __syncthreads();
+  if (tid < 3) s_last[tid] = dl.last[tid];
+  WaveChallenger wc;
+  wc.st = dl.state[lane & 7]; wc.ib = dl.in_buf[lane & 3]; wc.in_len = dl.in_len; wc.out_len = dl.out_len;
+  unsigned long long fcs = 0;
+  const Ext* prev = dl.folded;   // the folded oracle of the previous round
+  const Ext* eq = dl.eq;
+  const Ext* f = dl.f;
+  size_t m = dl.m;
+  bool useA = true;
+  __syncthreads();
+  for (int j = 0; j < dl.rounds; j++) {
+    const size_t n = (size_t)dl.n >> j, half = n / 2;
+    const bool final_round = j == dl.rounds - 1;
+    // transcript: the pending message, then the folding challenge
+    if (wave == 0) {
+      for (int q = 0; q < 3; q++) { Ext v = s_last[q]; wc_observe(wc, v.c0, lane); wc_observe(wc, v.c1, lane); }
+      wc_observe(wc, dl.lab[0], lane); wc_observe(wc, dl.lab[1], lane);
+      const u64 r0 = wc_sample(wc, lane), r1 = wc_sample(wc, lane);
+      if (lane == 0) { chal[1] = r0; chal[2] = r1; }
+    }
+    __syncthreads();
+    const Ext c = ex(chal[1], chal[2]);
+    // the committed codewords as long as the oracle join it (into a fresh buffer: `prev` is the leaf array of a tree)
+    const Ext* src = prev;
+    if (dl.nmerge[j] > 0) {
+      Ext* run = dl.run[j];
+      for (size_t i = tid; i < n; i += nt) {
+        Ext acc = prev[i];
+        for (int k = 0; k < dl.nmerge[j]; k++) {
+          const Ext co = dl.mcoeff[j][k];
+          acc = ex_add(acc, dl.mext[j][k] ? ex_mul(((const Ext*)dl.mcw[j][k])[i], co) : ex_mul_base(co, ((const u64*)dl.mcw[j][k])[i]));
+        }
+        run[i] = acc;
+      }
+      src = run;
+      __syncthreads();
+    }
+    // FRI fold (K9): out[i] = y0 + (c - x0)(y1 - y0) w, x0 = gamma * w_{2^(level+1)}^{bitrev(i)}, w = -1/(2 x0); the last round's
+    // folded oracle is never used
+    if (!final_round) {
+      const unsigned level = dl.level[j], L = dl.L;
+      Ext* out = dl.leaves[j];
+      for (size_t i = tid; i < half; i += nt) {
+        size_t b = level ? (size_t)(__brevll((unsigned long long)i) >> (64 - level)) : 0;
+        u64 root = dl.tw[b << (L - level)];
+        u64 x0 = gl_mul(root, dl.gamma[j]);
+        u64 rinv = b == 0 ? 1 : gl_neg(dl.tw[((size_t(1) << level) - b) << (L - level)]);
+        u64 w = gl_mul(dl.ninv[j], rinv);
+        Ext y0 = src[2 * i], y1 = src[2 * i + 1];
+        Ext t = ex_mul(ex(gl_sub(c.c0, x0), c.c1), ex_sub(y1, y0));
+        out[i] = ex_add(y0, ex_mul_base(t, w));
+      }
+    }
+    // the sumcheck pairs fold with the same challenge
+    Ext* eqd = useA ? dl.eqA : dl.eqB;
+    Ext* fd = useA ? dl.fA : dl.fB;
+    for (size_t i = tid; i < m / 2; i += nt) { eqd[i] = ex_lerp(eq[2 * i], eq[2 * i + 1], c); fd[i] = ex_lerp(f[2 * i], f[2 * i + 1], c); }
+    __syncthreads();
+    eq = eqd; f = fd; m /= 2; useA = !useA;
+    if (!final_round) {
+      // the next message (K10 on evaluation-form pairs): [sum a ea, sum (b ea + a eb), sum b eb]; a single value: three times it
+      Ext c0 = ex_zero(), c1 = ex_zero(), c2 = ex_zero();
+      for (size_t q = tid; q < m / 2; q += nt) {
+        Ext a = f[2 * q], b = ex_sub(f[2 * q + 1], a), ea = eq[2 * q], eb = ex_sub(eq[2 * q + 1], ea);
+        c0 = ex_add(c0, ex_mul(a, ea));
+        c1 = ex_add(c1, ex_add(ex_mul(b, ea), ex_mul(a, eb)));
+        c2 = ex_add(c2, ex_mul(b, eb));
+      }
+      c0 = wave_reduce_ext(c0); c1 = wave_reduce_ext(c1); c2 = wave_reduce_ext(c2);
+      if (lane == 0) { part[wave * 3] = c0; part[wave * 3 + 1] = c1; part[wave * 3 + 2] = c2; }
+      // layer 0 of the tree: leaf pairs packed, no hashing
+      u64* nd = dl.nodes[j];
+      const Ext* lv = dl.leaves[j];
+      for (size_t i = tid; i < half / 2; i += nt) { Ext a = lv[2 * i], b = lv[2 * i + 1]; u64* o = nd + 4 * i; o[0] = a.c0; o[1] = a.c1; o[2] = b.c0; o[3] = b.c1; }
+      __syncthreads();
+      if (wave == 0) {
+        Ext v0 = lane < W ? part[lane * 3] : ex_zero(), v1 = lane < W ? part[lane * 3 + 1] : ex_zero(), v2 = lane < W ? part[lane * 3 + 2] : ex_zero();
+        v0 = wave_reduce_ext(v0); v1 = wave_reduce_ext(v1); v2 = wave_reduce_ext(v2);
+        if (lane == 0) {
+          if (m == 1) { s_last[0] = f[0]; s_last[1] = f[0]; s_last[2] = f[0]; }
+          else { s_last[0] = v0; s_last[1] = v1; s_last[2] = v2; }
+        }
+      }
+      // upper layers: Poseidon2 compress, one node per lane while the layer is wide, 8 lanes per node when it is narrow
+      size_t off = 0, cnt = half / 2;
+      while (cnt > 1) {
+        const size_t next = cnt / 2;
+        const u64* in = nd + 4 * off;
+        u64* out = nd + 4 * (off + cnt);
+        if (next > (size_t)nt) {
+          for (size_t i = tid; i < next; i += nt) {
+            u64 o[4];
+            poseidon2_compress(in + 8 * i, in + 8 * i + 4, o, c_rc);
+            out[4 * i] = o[0]; out[4 * i + 1] = o[1]; out[4 * i + 2] = o[2]; out[4 * i + 3] = o[3];
+          }
+        } else {
+          // every lane takes part in the permutation (no divergence around the cross-lane moves); idle groups redo the last node
+          const size_t groups = (size_t)nt >> 3;
+          for (size_t g0 = 0; g0 < next; g0 += groups) {
+            const size_t g = g0 + ((size_t)tid >> 3);
+            const size_t gg = g < next ? g : next - 1;
+            const int i8 = lane & 7;
+            u64 sv = i8 < 4 ? in[8 * gg + i8] : 0;
+            sv = p2l_permute(sv, lane);
+            if (i8 < 4) sv = in[8 * gg + 4 + i8];
+            sv = p2l_permute(sv, lane);
+            if (g < next && i8 < 4) out[4 * g + (3 - i8)] = sv;
+          }
+        }
+        __syncthreads();
+        off += cnt; cnt = next;
+      }
+      // the message and the root: published, and the root absorbed (the message is absorbed at the top of the next round)
+      if (wave == 0) {
+        const u64* root = nd + 4 * (half - 2);
+        for (int q = 0; q < 4; q++) wc_observe(wc, root[q], lane);
+        if (lane == 0) {
+          u64* rw = result + (size_t)j * 10;
+          for (int q = 0; q < 3; q++) {
+            Ext v = s_last[q];
+            size_t w = (size_t)j * 10 + 2 * q;
+            pub_store(rw + 2 * q, v.c0); pub_store(rw + 2 * q + 1, v.c1);
+            fcs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1;
+          }
+          for (int q = 0; q < 4; q++) { size_t w = (size_t)j * 10 + 6 + q; pub_store(rw + 6 + q, root[q]); fcs += (unsigned long long)(w + 1) * root[q]; }
+        }
+      }
+      __syncthreads();
+      prev = dl.leaves[j];
+    } else {
+      // the final message: the folded sum_evals in bit-reversed index order, absorbed in its natural order
+      if (wave == 0) {
+        unsigned lg = 0; while ((size_t(1) << lg) < m) lg++;
+        u64* rw = result + (size_t)(dl.rounds - 1) * 10;
+        for (size_t r = 0; r < m; r++) {
+          size_t src_i = lg ? (size_t)(__brevll((unsigned long long)r) >> (64 - lg)) : 0;
+          Ext v = f[src_i];
+          wc_observe(wc, v.c0, lane); wc_observe(wc, v.c1, lane);
+          if (lane == 0) {
+            size_t w = (size_t)(dl.rounds - 1) * 10 + 2 * r;
+            pub_store(rw + 2 * r, v.c0); pub_store(rw + 2 * r + 1, v.c1);
+            fcs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1;
+          }
+        }
+      }
+    }
+  }
+  if (wave == 0) {  // the sponge goes back to the host transcript; the tag closes the message
+    u64* rs = result + (size_t)(dl.rounds - 1) * 10 + 2 * m;
+    if (lane < 8) { pub_store(rs + lane, wc.st); fcs += (unsigned long long)(lane + 1) * wc.st; }
+    if (lane < 4) { u64 v = lane < wc.in_len ? wc.ib : 0; pub_store(rs + 8 + lane, v); fcs += (unsigned long long)(8 + lane + 1) * v; }
+    if (lane == 0) {
+      u64 a = (u64)wc.in_len, b = (u64)wc.out_len;
+      pub_store(rs + 12, a); pub_store(rs + 13, b);
+      fcs += (unsigned long long)13 * a + (unsigned long long)14 * b;
+    }
+    fcs = pub_wave_sum(fcs);
+    if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + fcs);
+  }
+}
+
 // Same protocol as k_sc_persist, but the tables live in LDS after the first fold (bit-reversed index order, so a fold
 // pairs positions q and q + m/2 and is done in place with no hazards): after the first round no table byte touches
 // global memory again. Dynamic LDS = ntabs * (n0/2) extension elements.
@@ -2480,6 +2659,7 @@ class HipDev : public Dev {
     if (devclassic_) DP_SET_LDS(k_classic_tail, 1024, (int)EXCL_LDS);
     if (devdense_) DP_SET_LDS(k_dense_tail, 1024, (int)EXCL_LDS);
     if (deveqsum_) DP_SET_LDS(k_eqsum_tail, 1024, (int)EXCL_LDS);
+    if (devcommit_) DP_SET_LDS(k_commit_tail, 1024, (int)EXCL_LDS);
     DP_SET_LDS(k_med_prepare, 1024, 128 * 1024);
     DP_SET_LDS(k_med_ntt_local, 1024, 64 * 1024);
   }
@@ -2825,6 +3005,26 @@ class HipDev : public Dev {
     logup_tail_parse(hres_, a, blocks, ch, layer_msgs, layer_points, round_evals, point);
     release(mk);
     nlogup_tail_++;
+    return true;
+  }
+  // ---- Dev::commit_tail: EXPERIMENTAL (DP_DEVICE_COMMIT=1): k_commit_tail, the last rounds of the Basefold commit phase
+  bool devcommit_ = getenv("DP_DEVICE_COMMIT") && atoi(getenv("DP_DEVICE_COMMIT"));
+  bool commit_tail(const CommitTailArgs& a, Challenger& ch, CommitTailOut& out) override {
+    if (!devcommit_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_ || !tw_) return false;
+    if (!commit_tail_accepts(a) || dp_ceil_log2(a.folded.n) - 1 > L_) return false;
+    const std::vector<size_t> blocks = commit_tail_blocks(a);
+    if (blocks[0] + blocks[1] > RES_WORDS) return false;
+    const CommitTailDesc* dd = nullptr;
+    CommitTailDesc* d = desc_alloc<CommitTailDesc>(1, &dd);
+    std::vector<DevTree> trees;
+    CommitTailDesc fill;
+    commit_tail_fill(&fill, a, ch, *this, (const u64*)tw_, L_, trees);  // (the trees stay allocated: the query phase reads them)
+    memcpy((void*)d, &fill, sizeof(CommitTailDesc));
+    const unsigned long long seq = ++seq_;
+    nb_ = 16.0 * (double)a.folded.n * 2.0 + 32.0 * (double)a.sum_evals.n;
+    DPL_LDS(k_commit_tail, dim3(1), dim3(1024), excl_now(), dd, (u64*)hres_dev_, hflag_dev_, seq);
+    wait_flag_blocks(seq, blocks);
+    commit_tail_parse(hres_, a, ch, trees, out);
     return true;
   }
   // ---- Dev::eqsum_tail: EXPERIMENTAL (DP_DEVICE_EQSUM=1): k_eqsum_tail, eq tables + accumulation sumcheck in one launch

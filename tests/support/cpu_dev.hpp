@@ -14,7 +14,9 @@ namespace dp {
 
 class CpuDev : public Dev {
   std::vector<void*> arena_;
+ protected:
   unsigned full_log_ = 0;
+ private:
   static u64* B(const DBuf& b) { return (u64*)b.p; }
   static Ext* X(const DBuf& b) { return (Ext*)b.p; }
   static Ext at(const DBuf& b, size_t i) { return b.ext ? X(b)[i] : ex_base(B(b)[i]); }

@@ -106,6 +106,7 @@ int main(int argc, char** argv) {
   printf("emulated k_classic_tail: %zu batch-opening sumcheck tails taken\n", dev.classic_taken);
   printf("emulated k_dense_tail: %zu dense layers taken\n", dev.dense_taken);
   printf("emulated k_eqsum_tail: %zu eq + sumcheck groups taken\n", dev.eqsum_taken);
+  printf("emulated k_commit_tail: %zu commit-phase tails taken\n", dev.commit_taken);
 #endif
   if (dev.device_commit) printf("commit_tail: %zu commit-phase tails taken by the double\n", dev.commit_tails);
   if (dev.device_eqsum) printf("eqsum_tail: %zu eq + sumcheck groups taken by the double\n", dev.eqsum_tails);

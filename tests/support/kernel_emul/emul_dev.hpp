@@ -7,6 +7,7 @@
 #include "../../../deep-prove_amd/csrc/classic_tail.h"
 #include "../../../deep-prove_amd/csrc/dense_tail.h"
 #include "../../../deep-prove_amd/csrc/eqsum_tail.h"
+#include "../../../deep-prove_amd/csrc/commit_tail.h"
 #include "simt.hpp"
 #include <cstdio>
 
@@ -34,6 +35,34 @@ struct EmulDev : CpuDev {
     size_t nwords = 0; for (size_t b : blocks) nwords += b;
     for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: the kernel wrote past its message\n"); exit(3); }
     return flag;
+  }
+  bool commit = true;  // serve Dev::commit_tail with the emulated k_commit_tail
+  size_t commit_taken = 0, commit_max_n = 512;
+  std::vector<u64> tw_;  // tw[i] = w_{2^(L+1)}^i, i < 2^L, L = the RS parameter size of this context (what HipDev::pcs_init builds on the device)
+  bool commit_tail(const CommitTailArgs& a, Challenger& ch, CommitTailOut& out) override {
+    if (!commit || !commit_tail_accepts(a) || a.folded.n > commit_max_n) return false;  // (emulation speed; the device takes oracles up to COMMIT_TAIL_MAX_N)
+    const unsigned L = full_log_;
+    if (tw_.size() != (size_t(1) << L)) {
+      u64 w = GL_G32;
+      for (unsigned i = L + 1; i < 32; i++) w = gl_sqr(w);
+      tw_.assign(size_t(1) << L, 1);
+      for (size_t i = 1; i < tw_.size(); i++) tw_[i] = gl_mul(tw_[i - 1], w);
+    }
+    const std::vector<size_t> blocks = commit_tail_blocks(a);
+    const size_t nwords = blocks[0] + blocks[1];
+    CommitTailDesc d;
+    std::vector<DevTree> trees;
+    commit_tail_fill(&d, a, ch, *this, tw_.data(), L, trees);
+    std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
+    unsigned long long flag = 0;
+    const unsigned long long seq = 13000 + commit_taken;
+    blockDim.x.v = threads;
+    simt::launch(threads, [&] { k_commit_tail(&d, res.data(), &flag, seq); });
+    if (flag != pub_mix(seq) + logup_tail_checksum(res.data(), blocks)) { fprintf(stderr, "emul: commit tail: tag does not match the payload\n"); exit(3); }
+    for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: commit tail wrote past its message\n"); exit(3); }
+    commit_tail_parse(res.data(), a, ch, trees, out);
+    commit_taken++;
+    return true;
   }
   bool eqsum = true;  // serve Dev::eqsum_tail with the emulated k_eqsum_tail
   size_t eqsum_taken = 0;

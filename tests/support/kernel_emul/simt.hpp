@@ -75,6 +75,7 @@ static struct { simt::Const x{1}, y{1}, z{1}; } gridDim;
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 inline void __syncthreads() { simt::barrier(); }
+inline unsigned long long __brevll(unsigned long long x) { unsigned long long r = 0; for (int i = 0; i < 64; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
 inline int __shfl(int v, int src, int width = 64) {
   unsigned me = simt::tid();
   return (int)simt::exchange((uint32_t)v, (me & ~63u) | ((unsigned)src & (unsigned)(width - 1)));

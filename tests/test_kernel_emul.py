@@ -2,7 +2,8 @@
 emulator with __syncthreads, wave shuffles and the DPP moves of the lane-parallel Poseidon2). What it pins without a GPU:
 k_logup_tail — the whole logup-GKR layer loop (or, in full mode, the whole logup-GKR proof) with device-side Fiat-Shamir in one
 launch (Dev::logup_tail / Dev::logup_full) —, k_classic_tail (the last rounds of the batch-opening sumcheck) k_dense_tail (bias
-evaluation + fix_high + sumcheck of a Dense layer) and k_eqsum_tail (eq tables + accumulation sumcheck), together with
+evaluation + fix_high + sumcheck of a Dense layer) k_eqsum_tail (eq tables + accumulation sumcheck) and k_commit_tail (FRI fold + merges + sumcheck pairs +
+Merkle trees + roots of the last Basefold commit rounds), together with
 everything it is built from (sc_accumulate, sc_fs_round, the wave sponge wc_*, p2l_permute, wg_build_eq) and the product's
 host code on both sides of the launch (csrc/logup_tail.h), byte for byte against the layer-by-layer path."""
 import os
@@ -49,4 +50,5 @@ def test_whole_model_proofs_with_every_logup_proof_from_the_emulated_kernel():
         assert int(r.stdout.split("emulated k_classic_tail: ")[1].split()[0]) >= 1, r.stdout  # ... and the batch-opening sumcheck tail
         assert int(r.stdout.split("emulated k_dense_tail: ")[1].split()[0]) >= 1, r.stdout    # ... and every Dense layer (bias, fix_high, sumcheck)
         assert int(r.stdout.split("emulated k_eqsum_tail: ")[1].split()[0]) >= 2, r.stdout    # ... and the accumulation sumchecks of Requant / ReLU
+        assert int(r.stdout.split("emulated k_commit_tail: ")[1].split()[0]) >= 1, r.stdout   # ... and the last rounds of the Basefold commit phase
         assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout

@@ -13,19 +13,20 @@ CONFIGS = [  # (name, proofs in flight, env) — in order of importance: the swe
     ("devlogup_full_192", 192, {"DP_DEVICE_LOGUP": "2"}),   # the whole logup proof (trees, outputs, layers, column claims) in one launch
     ("devlogup_full_256", 256, {"DP_DEVICE_LOGUP": "2"}),
     ("devclassic_192", 192, {"DP_DEVICE_CLASSIC": "1"}),   # k_classic_tail: the last rounds of the batch-opening sumcheck in one launch
+    ("devcommit_192", 192, {"DP_DEVICE_COMMIT": "1"}),     # k_commit_tail: the last rounds of the Basefold commit phase (fold, merges, Merkle, roots) in one launch
     ("deveqsum_192", 192, {"DP_DEVICE_EQSUM": "1"}),       # k_eqsum_tail: the eq tables + accumulation sumcheck of Requant / ReLU in one launch
     ("devdense_192", 192, {"DP_DEVICE_DENSE": "1"}),       # k_dense_tail: bias evaluation + fix_high + sumcheck of a Dense layer in one launch
-    ("devall_192", 192, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1"}),
-    ("devall_256", 256, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1"}),
+    ("devall_192", 192, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_DEVICE_COMMIT": "1"}),
+    ("devall_256", 256, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_DEVICE_COMMIT": "1"}),
     ("async_upload_192", 192, {"DP_ASYNC_UPLOAD": "1"}),  # uploads take ring slots of the staging buffer instead of a copy + publish + wait each (~29 per proof)
-    ("devall_async_tailmax2048_192", 192, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_ASYNC_UPLOAD": "1", "DP_TAIL_MAX": "2048"}),
-    ("devall_async_tailmax2048_256", 256, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_ASYNC_UPLOAD": "1", "DP_TAIL_MAX": "2048"}),
+    ("devall_async_tailmax2048_192", 192, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_DEVICE_COMMIT": "1", "DP_ASYNC_UPLOAD": "1", "DP_TAIL_MAX": "2048"}),
+    ("devall_async_tailmax2048_256", 256, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_DEVICE_COMMIT": "1", "DP_ASYNC_UPLOAD": "1", "DP_TAIL_MAX": "2048"}),
     # fewer launches per Merkle tree: one workgroup finishes every tree from 2048 / 4096 digests on (4 - 5 launches less per tree,
     # ~35 trees per Dense-4M proof); validated code path (k_merkle_tail), the default 256 is the single-proof latency optimum
     ("tailmax2048_192", 192, {"DP_TAIL_MAX": "2048"}),
     ("tailmax4096_192", 192, {"DP_TAIL_MAX": "4096"}),
-    ("devall_tailmax2048_192", 192, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_TAIL_MAX": "2048"}),
-    ("devall_tailmax2048_256", 256, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_TAIL_MAX": "2048"}),
+    ("devall_tailmax2048_192", 192, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_DEVICE_COMMIT": "1", "DP_TAIL_MAX": "2048"}),
+    ("devall_tailmax2048_256", 256, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_DEVICE_COMMIT": "1", "DP_TAIL_MAX": "2048"}),
     ("threads7_192", 192, {"DP_HOST_THREADS": "7"}),
     ("threads4_192", 192, {"DP_HOST_THREADS": "4"}),
     ("tail256_192", 192, {"DP_TAIL_MANY_THREADS": "256", "DP_TAIL_MANY_EXCL": "0"}),
