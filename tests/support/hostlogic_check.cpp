@@ -86,6 +86,7 @@ int main(int argc, char** argv) {
   dp::emul_init_constants();
   dev.full = !(getenv("DP_EMUL_MODE") && atoi(getenv("DP_EMUL_MODE")) == 1);  // DP_EMUL_MODE=1: Dev::logup_tail, else Dev::logup_full
   dev.threads = getenv("DP_EMUL_THREADS") ? atoi(getenv("DP_EMUL_THREADS")) : 64;
+  if (getenv("DP_EMUL_COMMIT_MAX_N")) dev.commit_max_n = (size_t)atoll(getenv("DP_EMUL_COMMIT_MAX_N"));  // how long an oracle the emulated commit tail takes over
 #endif
   dev.device_fs = getenv("DP_DOUBLE_DEVICE_FS") && atoi(getenv("DP_DOUBLE_DEVICE_FS"));  // exercise the Dev::sc_tail contract (device-side Fiat-Shamir)
   dev.device_commit = getenv("DP_DOUBLE_DEVICE_COMMIT") && atoi(getenv("DP_DOUBLE_DEVICE_COMMIT"));  // ... the Dev::commit_tail contract
@@ -106,7 +107,7 @@ int main(int argc, char** argv) {
   printf("emulated k_classic_tail: %zu batch-opening sumcheck tails taken\n", dev.classic_taken);
   printf("emulated k_dense_tail: %zu dense layers taken\n", dev.dense_taken);
   printf("emulated k_eqsum_tail: %zu eq + sumcheck groups taken\n", dev.eqsum_taken);
-  printf("emulated k_commit_tail: %zu commit-phase tails taken\n", dev.commit_taken);
+  printf("emulated k_commit_tail: %zu commit-phase tails taken (%zu rounds, %zu codewords merged)\n", dev.commit_taken, dev.commit_rounds_run, dev.commit_merged);
 #endif
   if (dev.device_commit) printf("commit_tail: %zu commit-phase tails taken by the double\n", dev.commit_tails);
   if (dev.device_eqsum) printf("eqsum_tail: %zu eq + sumcheck groups taken by the double\n", dev.eqsum_tails);

@@ -37,7 +37,7 @@ struct EmulDev : CpuDev {
     return flag;
   }
   bool commit = true;  // serve Dev::commit_tail with the emulated k_commit_tail
-  size_t commit_taken = 0, commit_max_n = 512;
+  size_t commit_taken = 0, commit_max_n = 512, commit_rounds_run = 0, commit_merged = 0;
   std::vector<u64> tw_;  // tw[i] = w_{2^(L+1)}^i, i < 2^L, L = the RS parameter size of this context (what HipDev::pcs_init builds on the device)
   bool commit_tail(const CommitTailArgs& a, Challenger& ch, CommitTailOut& out) override {
     if (!commit || !commit_tail_accepts(a) || a.folded.n > commit_max_n) return false;  // (emulation speed; the device takes oracles up to COMMIT_TAIL_MAX_N)
@@ -61,7 +61,8 @@ struct EmulDev : CpuDev {
     if (flag != pub_mix(seq) + logup_tail_checksum(res.data(), blocks)) { fprintf(stderr, "emul: commit tail: tag does not match the payload\n"); exit(3); }
     for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: commit tail wrote past its message\n"); exit(3); }
     commit_tail_parse(res.data(), a, ch, trees, out);
-    commit_taken++;
+    commit_taken++; commit_rounds_run += a.rounds_left;
+    for (auto& mj : *a.merges) commit_merged += mj.size();
     return true;
   }
   bool eqsum = true;  // serve Dev::eqsum_tail with the emulated k_eqsum_tail

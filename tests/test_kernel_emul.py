@@ -40,7 +40,7 @@ def test_whole_model_proofs_with_every_logup_proof_from_the_emulated_kernel():
     """end to end: the product's orchestrator proves an MLP and a CNN with EVERY logup-GKR proof (lookups and tables) produced
     by the device source of k_logup_tail on the emulator — full mode (one launch per proof) and tail mode — and the proof
     streams equal the oracle's byte for byte; the verifier accepts them"""
-    for args, env, least in (((64, 1), {}, 13), ((16, 7), {"DP_EMUL_MODE": "1", "DP_EMUL_THREADS": "256"}, 13), (("cnn", 4), {"DP_EMUL_THREADS": "256"}, 10)):
+    for args, env, least in (((64, 1), {"DP_EMUL_COMMIT_MAX_N": "4096"}, 13), ((16, 7), {"DP_EMUL_MODE": "1", "DP_EMUL_THREADS": "256"}, 13), (("cnn", 4), {"DP_EMUL_THREADS": "256"}, 10)):
         r = _model(args, env)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "identical=1" in r.stdout, r.stdout
@@ -51,4 +51,6 @@ def test_whole_model_proofs_with_every_logup_proof_from_the_emulated_kernel():
         assert int(r.stdout.split("emulated k_dense_tail: ")[1].split()[0]) >= 1, r.stdout    # ... and every Dense layer (bias, fix_high, sumcheck)
         assert int(r.stdout.split("emulated k_eqsum_tail: ")[1].split()[0]) >= 2, r.stdout    # ... and the accumulation sumchecks of Requant / ReLU
         assert int(r.stdout.split("emulated k_commit_tail: ")[1].split()[0]) >= 1, r.stdout   # ... and the last rounds of the Basefold commit phase
+        if "DP_EMUL_COMMIT_MAX_N" in env:  # several rounds in one launch: FRI folds, messages and Merkle trees, not only the final round
+            assert int(r.stdout.split("commit-phase tails taken (")[1].split()[0]) >= 4, r.stdout
         assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
