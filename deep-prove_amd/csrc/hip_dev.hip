@@ -505,6 +505,28 @@ KBODY k_merkle_layer(const u64* in, u64* out, size_t cnt) {
   }
 }
 
+// Several consecutive Merkle layers in ONE launch (DP_MERKLE_FUSE=levels, experiment, default off): workgroup b hashes the
+// 2 * blockDim.x digests [b * 2 blockDim.x, ..) of the input layer down `levels` layers — every layer it produces is consumed
+// by itself only, so a block barrier between layers is all the synchronisation there is — and writes each layer to its place
+// in the tree. With hundreds of proofs in flight a launch costs more than the 24 us of a lane-serial compress.
+// in: the input layer (cnt digests), out: where the layer above it starts (its cnt / 2 digests; the next ones follow).
+KBODY k_merkle_layers(const u64* in, u64* out, size_t cnt, int levels) {
+  const int tid = threadIdx.x;
+  size_t nout = blockDim.x;                              // digests this block produces in the current layer
+  size_t bo = (size_t)blockIdx.x * blockDim.x;           // index of its first one
+  size_t layer_cnt = cnt;
+  for (int l = 0; l < levels; l++) {
+    if ((size_t)tid < nout) {
+      const size_t i = bo + tid;
+      u64 o[4];
+      poseidon2_compress(in + 8 * i, in + 8 * i + 4, o, c_rc);
+      out[4 * i] = o[0]; out[4 * i + 1] = o[1]; out[4 * i + 2] = o[2]; out[4 * i + 3] = o[3];
+    }
+    __syncthreads();
+    in = out; out += 4 * (layer_cnt / 2); layer_cnt /= 2; nout /= 2; bo /= 2;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ Basefold opening (K9-K12, K14)
 struct PolyDesc { const void* f; const Ext* eq; Ext* fout; Ext* eqout; size_t n; int fext; int pad; };
 // fold every (f, eq) pair of length > 1 by r; blockIdx.y = polynomial
@@ -3404,6 +3426,7 @@ class HipDev : public Dev {
   // Layers with at most lp_max_ parent nodes use the 8-lanes-per-node kernel (lowest latency per layer, but ~2.2x the
   // VALU work of one node per lane and a grid 8x as large: with many proofs in flight those grids fill the chip and
   // every other stream queues behind them), wider layers hash one node per lane. DP_MERKLE_LP_MAX overrides.
+  int merkle_fuse_ = getenv("DP_MERKLE_FUSE") ? atoi(getenv("DP_MERKLE_FUSE")) : 0;  // layers per launch of k_merkle_layers (0 / 1: off)
   size_t lp_max_ = getenv("DP_MERKLE_LP_MAX") ? strtoull(getenv("DP_MERKLE_LP_MAX"), nullptr, 10) : (size_t(1) << 12);
   // `nodes` must hold 4*(n-1) words; synchronises (root is copied to the host)
   DevTree build_tree_into(const DBuf& leaves, const DBuf& nodes) {
@@ -3415,6 +3438,16 @@ class HipDev : public Dev {
     size_t off = 0, cnt = n / 2;
     while (cnt > TAIL_MAX) {
       size_t next = cnt / 2;
+      if (merkle_fuse_ > 1 && cnt >= 512) {  // several layers per launch (k_merkle_layers): as many as stay above the tail, at most merkle_fuse_
+        int levels = 0;
+        while (levels < merkle_fuse_ && levels < 8 && (cnt >> (levels + 1)) >= TAIL_MAX && (cnt >> (levels + 1)) >= 1) levels++;
+        if (levels >= 2) {
+          nb_ = 0; for (int l = 0; l < levels; l++) nb_ += 96.0 * (double)(cnt >> (l + 1));
+          DPL(k_merkle_layers, dim3((unsigned)(cnt / 512)), dim3(256), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), cnt, levels);
+          for (int l = 0; l < levels; l++) { off += cnt; cnt /= 2; }
+          continue;
+        }
+      }
       if (next <= lp_max_) { nb_ = 96.0 * next; DPL(k_merkle_layer_lp, dim3((unsigned)std::min<size_t>(std::min<size_t>((next * 8 + 255) / 256, 8192), (size_t)std::max(1, g_max_grid))), dim3(256), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
       else { nb_ = 96.0 * next; DPL(k_merkle_layer, dim3(grid_for(next, 4096)), dim3(TPB), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
       off += cnt; cnt /= 2;

@@ -19,10 +19,12 @@ CONFIGS = [  # (name, proofs in flight, env) — in order of importance: the swe
     ("devall_192", 192, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_DEVICE_COMMIT": "1"}),
     ("devall_256", 256, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_DEVICE_COMMIT": "1"}),
     ("async_upload_192", 192, {"DP_ASYNC_UPLOAD": "1"}),  # uploads take ring slots of the staging buffer instead of a copy + publish + wait each (~29 per proof)
-    ("devall_async_tailmax2048_192", 192, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_DEVICE_COMMIT": "1", "DP_ASYNC_UPLOAD": "1", "DP_TAIL_MAX": "2048"}),
-    ("devall_async_tailmax2048_256", 256, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_DEVICE_COMMIT": "1", "DP_ASYNC_UPLOAD": "1", "DP_TAIL_MAX": "2048"}),
+    ("devall_async_tailmax2048_192", 192, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_DEVICE_COMMIT": "1", "DP_ASYNC_UPLOAD": "1", "DP_TAIL_MAX": "2048", "DP_MERKLE_FUSE": "4"}),
+    ("devall_async_tailmax2048_256", 256, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_DEVICE_COMMIT": "1", "DP_ASYNC_UPLOAD": "1", "DP_TAIL_MAX": "2048", "DP_MERKLE_FUSE": "4"}),
     # fewer launches per Merkle tree: one workgroup finishes every tree from 2048 / 4096 digests on (4 - 5 launches less per tree,
     # ~35 trees per Dense-4M proof); validated code path (k_merkle_tail), the default 256 is the single-proof latency optimum
+    ("merklefuse4_192", 192, {"DP_MERKLE_FUSE": "4"}),   # k_merkle_layers: four Merkle layers per launch (emulator-validated, new on hardware)
+    ("merklefuse4_tailmax2048_192", 192, {"DP_MERKLE_FUSE": "4", "DP_TAIL_MAX": "2048"}),
     ("tailmax2048_192", 192, {"DP_TAIL_MAX": "2048"}),
     ("tailmax4096_192", 192, {"DP_TAIL_MAX": "4096"}),
     ("devall_tailmax2048_192", 192, {"DP_DEVICE_LOGUP": "2", "DP_DEVICE_CLASSIC": "1", "DP_DEVICE_DENSE": "1", "DP_DEVICE_EQSUM": "1", "DP_DEVICE_COMMIT": "1", "DP_TAIL_MAX": "2048"}),
