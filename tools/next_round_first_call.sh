@@ -8,6 +8,7 @@ out=${1:-gpurun_out/r02_first}; mkdir -p "$out"; export TMPDIR=/tmp
 timeout 600 python -m pytest tests -m gpu -x -q > "$out/pytest.log" 2>&1; echo "pytest rc=$?" >> "$out/pytest.log"
 # the default configuration first (validated code only), then the sweep: an experimental kernel that misbehaves cannot cost the baseline
 timeout 400 python bench.py > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/bench.err"
+DP_TEST_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_zz_experimental.py -m gpu -q > "$out/pytest_experimental.log" 2>&1; tail -3 "$out/pytest_experimental.log"
 timeout 560 python tools/knob_sweep.py dense_4m "$out/knob_sweep_dense4m.jsonl" 520 > "$out/knob_sweep.log" 2>&1
 best=$(python - "$out/knob_sweep_dense4m.jsonl" <<'PY'
 import json, sys
