@@ -557,10 +557,9 @@ inline MatrixEval delegate_matrix_evaluation(Dev& dev, Transcript& t, const std:
     both.insert(both.end(), f_middle[l].begin(), f_middle[l].end());
     DBuf pf = upload_exts(dev, both);
     DBuf beta = dev.alloc(len, true);
-    dev.eq_table(beta, r2.data(), nv, ex_one(), false);
     DevVP vp(nv);
     vp.add_mle_list({beta, pf.slice(0, len), pf.slice(len, len)}, ex_one());
-    SumcheckOut sc = sumcheck_prove(dev, vp, t);
+    SumcheckOut sc = sumcheck_prove_with_eq(dev, {{beta, std::vector<Ext>(r2.begin(), r2.begin() + nv), ex_one(), false}}, vp, t);
     dev.release(mk);
     r2 = sc.proof.point;
     me.proofs.push_back(sc.proof); me.claims.push_back(sc.finals);
@@ -635,10 +634,9 @@ inline Claim prove_conv(ProverState& ps, size_t id, const LayerSpec& l, const Cl
     DBuf v1 = dev.alloc(ct.output_as_element.size(), false);
     dev.upload_i64(v1, ct.output_as_element.data());
     DBuf beta = dev.alloc(v1.n, true);
-    dev.eq_table(beta, last_in.point.data(), (unsigned)last_in.point.size(), ex_one(), false);
     DevVP vp((unsigned)last_in.point.size());
     vp.add_mle_list({v1, cd.clearing, beta}, ex_one());
-    SumcheckOut sc = sumcheck_prove(dev, vp, t);
+    SumcheckOut sc = sumcheck_prove_with_eq(dev, {{beta, last_in.point, ex_one(), false}}, vp, t);
     clearing_proof.sumcheck = sc.proof; clearing_proof.individual_claim = {sc.finals[0], sc.finals[1]};
     dev.release(mk2);
   }
@@ -707,15 +705,14 @@ inline Claim prove_pooling(ProverState& ps, size_t id, const LayerSpec& l, const
   size_t mk = dev.mark();
   Ext batch = t.get_and_append_challenge("batch_pooling");
   DBuf beta = dev.alloc(n, true), last_beta = dev.alloc(n, true);
-  dev.eq_table(beta, lproof.output_claims[0].point.data(), nv, ex_one(), false);
-  dev.eq_table(last_beta, last.point.data(), nv, ex_one(), false);
+  std::vector<EqAcc> eqs = {{beta, lproof.output_claims[0].point, ex_one(), false}, {last_beta, last.point, ex_one(), false}};
   DevVP vp(nv);
   std::vector<DBuf> all = w.columns; all.push_back(beta);
   vp.add_mle_list(all, ex_one());  // zero check: prod_i (out - in_i) * eq
   Ext comb = batch;
   for (auto& d : w.columns) { vp.add_mle_list({d, beta}, comb); comb = ex_mul(comb, batch); }
   vp.add_mle_list({w.extra_columns[0], last_beta}, comb);  // the output (committed base column == trace output as field elements)
-  SumcheckOut sc = sumcheck_prove(dev, vp, t);
+  SumcheckOut sc = sumcheck_prove_with_eq(dev, eqs, vp, t);  // (degree 5: fused devices decline, the tables are then built one by one)
   dev.release(mk);
   const std::vector<Ext>& evals = sc.finals;
   const size_t ks = 4;
