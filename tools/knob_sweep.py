@@ -1,6 +1,6 @@
 """Sweep of the cohort-regime knobs on one GPU, torch-free, every configuration in a fresh process (the knobs are read at
 library / context creation) and every measured batch checked (proof 0 == the sequential proof, sampled proofs verify).
-usage: python tools/knob_sweep.py [workload] [out.jsonl] [budget_s]          (driver)
+usage: python tools/knob_sweep.py [workload] [out.jsonl] [budget_s]          (driver; KNOB_ONLY=name,name restricts it)
        python tools/knob_sweep.py --one workload conc                        (one configuration, env = knobs)
 Results: one JSON line per configuration, appended as they finish."""
 import json, os, subprocess, sys, time
@@ -82,7 +82,10 @@ def main():
     budget = float(sys.argv[3]) if len(sys.argv) > 3 else 300.0
     os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
     t0 = time.time()
+    only = set(filter(None, os.environ.get("KNOB_ONLY", "").split(",")))  # KNOB_ONLY=name,name: just these configurations
     for name, conc, env in CONFIGS:
+        if only and name not in only:
+            continue
         if time.time() - t0 > budget:
             break
         e = dict(os.environ); e.update(env)

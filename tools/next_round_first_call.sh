@@ -10,6 +10,7 @@ timeout 600 python -m pytest tests -m gpu -x -q > "$out/pytest.log" 2>&1; echo "
 timeout 400 python bench.py > "$out/bench.json" 2> "$out/bench.err"; echo "bench rc=$?" >> "$out/bench.err"
 DP_TEST_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_zz_experimental.py -m gpu -q > "$out/pytest_experimental.log" 2>&1; tail -3 "$out/pytest_experimental.log"
 timeout 560 python tools/knob_sweep.py dense_4m "$out/knob_sweep_dense4m.jsonl" 520 > "$out/knob_sweep.log" 2>&1
+KNOB_ONLY=base_192,devall_192,devall_async_tailmax2048_192 timeout 200 python tools/knob_sweep.py cnn_264k "$out/knob_sweep_cnn264k.jsonl" 180 >> "$out/knob_sweep.log" 2>&1
 best=$(python - "$out/knob_sweep_dense4m.jsonl" <<'PY'
 import json, sys
 recs = [json.loads(l) for l in open(sys.argv[1]) if l.strip()]
