@@ -27,7 +27,7 @@ SIGNATURES = {
     "dp_ctx_destroy": (C.c_int32, [vp]),
     "dp_ctx_name": (C.c_char_p, [vp]),
     "dp_profile_enable": (C.c_int32, [vp, C.c_int32]),
-    "dp_profile_report": (C.c_int32, [vp, C.POINTER(C.c_char_p)]),
+    "dp_profile_report": (C.c_int32, [vp, C.POINTER(C.c_void_p)]),
     "dp_buf_from_i64": (C.c_int32, [vp, i64p, C.c_size_t, C.POINTER(vp)]),
     "dp_buf_upload": (C.c_int32, [vp, u64p, C.c_size_t, C.c_int32, C.POINTER(vp)]),
     "dp_buf_download": (C.c_int32, [vp, vp, u64p]),
@@ -66,6 +66,7 @@ SIGNATURES = {
                                          C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_double)]),
     "dp_model_verifier_blob": (C.c_int32, [vp, C.POINTER(u64p), C.POINTER(C.c_size_t)]),
     "dp_model_in_flight": (C.c_int32, [vp, C.POINTER(C.c_size_t)]),
+    "dp_model_output_len": (C.c_int32, [vp, C.POINTER(C.c_size_t)]),
     "dp_host_cpu_budget": (C.c_double, []),
     "dp_verify": (C.c_int32, [u64p, C.c_size_t, u64p, C.c_size_t, i64p, C.c_size_t, i64p, C.c_size_t]),
 }

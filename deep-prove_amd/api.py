@@ -41,6 +41,7 @@ class Device:
         h = vp()
         check(self._lib.dp_ctx_create(device_id, C.byref(h)))
         self.h = h
+        self._contexts = []  # live Contexts (dp_model) generated on this device
 
     @property
     def name(self):
@@ -51,12 +52,17 @@ class Device:
 
     def profile_report(self):
         import json
-        s = C.c_char_p()
+        s = C.c_void_p()
         check(self._lib.dp_profile_report(self.h, C.byref(s)))
-        out = json.loads(s.value.decode())
-        return out
+        try:
+            return json.loads(C.string_at(s.value).decode())
+        finally:
+            self._lib.dp_free(s)  # the report is malloc'ed by the library
 
     def close(self):
+        """destroys the dp_ctx; models generated on it hold a dangling device afterwards, so they are freed first"""
+        for c in list(self._contexts):
+            c.free()
         if self.h:
             self._lib.dp_ctx_destroy(self.h)
             self.h = None
@@ -321,6 +327,7 @@ class Context:
 
     def __init__(self, dev, handle, model_blob):
         self.dev, self.h, self.model_blob = dev, handle, model_blob
+        dev._contexts.append(self)
 
     @staticmethod
     def generate(dev, model_blob):
@@ -338,6 +345,8 @@ class Context:
         if self.h:
             _lib.load().dp_model_free(self.h)
             self.h = None
+            if self in self.dev._contexts:
+                self.dev._contexts.remove(self)
 
 
 class Prover:
@@ -346,11 +355,12 @@ class Prover:
     def __init__(self, ctx):
         self.ctx = ctx
         self.last_prove_ms = None
+        self._nout = None
 
     def prove(self, input_i64):
         x = np.ascontiguousarray(input_i64, dtype=np.int64)
         pw, pn = u64p(), C.c_size_t()
-        out = np.zeros(1 << 20, dtype=np.int64)
+        out = np.empty(self.output_len(), dtype=np.int64)
         no = C.c_size_t(out.size)
         ms = C.c_double()
         check(_lib.load().dp_model_prove(self.ctx.h, x.ctypes.data_as(i64p), x.size, C.byref(pw), C.byref(pn),
@@ -366,8 +376,8 @@ class Prover:
         lib = _lib.load()
         pws = (u64p * nproofs)()
         pns = (C.c_size_t * nproofs)()
-        cap = 1 << 12
-        outs = np.zeros((nproofs, cap), dtype=np.int64)
+        cap = self.output_len()
+        outs = np.empty((nproofs, cap), dtype=np.int64)
         no = C.c_size_t(0)
         ms = C.c_double()
         check(lib.dp_model_prove_batch(self.ctx.h, x.ctypes.data_as(i64p), nproofs, ninput, concurrency, pws, pns,
@@ -375,6 +385,14 @@ class Prover:
         proofs = [_take(pws[i], pns[i]) for i in range(nproofs)]
         return proofs, outs[:, :no.value].copy(), ms.value
 
+
+    def output_len(self):
+        """length of the model's output tensor (dp_model_output_len)"""
+        if self._nout is None:
+            n = C.c_size_t(0)
+            check(_lib.load().dp_model_output_len(self.ctx.h, C.byref(n)))
+            self._nout = int(n.value)
+        return self._nout
 
     def in_flight(self):
         """proofs the last prove_batch kept in flight (the `concurrency` asked, cut to what fits in the free HBM)"""

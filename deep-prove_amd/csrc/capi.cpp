@@ -72,7 +72,7 @@ int32_t dp_buf_upload(dp_ctx* ctx, const uint64_t* words, size_t n, int32_t is_e
 int32_t dp_buf_download(dp_ctx* ctx, const dp_buf* buf, uint64_t* o) { return guard([&] { DP_REQUIRE(ctx && buf && o, DP_ERR_ARG, "bad arguments"); ctx->dev->download(buf->b, o); }); }
 size_t dp_buf_len(const dp_buf* buf) { return buf ? buf->b.n : 0; }
 int32_t dp_buf_is_ext(const dp_buf* buf) { return buf && buf->b.ext; }
-int32_t dp_buf_free(dp_ctx* ctx, dp_buf* buf) { return guard([&] { if (buf) { ctx->dev->free_persistent(buf->b); delete buf; } }); }
+int32_t dp_buf_free(dp_ctx* ctx, dp_buf* buf) { return guard([&] { DP_REQUIRE(ctx || !buf, DP_ERR_ARG, "dp_buf_free: null context"); if (buf) { ctx->dev->free_persistent(buf->b); delete buf; } }); }
 
 dp_transcript* dp_transcript_new(const char* label) { dp_transcript* t = new dp_transcript(); if (label) t->t.append_message(label); return t; }
 void dp_transcript_free(dp_transcript* t) { delete t; }
@@ -96,7 +96,8 @@ int32_t dp_eq_table(dp_ctx* ctx, const uint64_t* point, uint32_t k, dp_buf** out
 }
 int32_t dp_mle_eval(dp_ctx* ctx, const dp_buf* f, const uint64_t* point, uint32_t k, uint64_t out[2]) {
   return guard([&] {
-    DP_REQUIRE(ctx && f && point && out && f->b.n == (size_t(1) << k), DP_ERR_SHAPE, "MLE size does not match the point");
+    DP_REQUIRE(ctx && f && point && out, DP_ERR_ARG, "bad arguments");
+    DP_REQUIRE(k < 48 && f->b.n == (size_t(1) << k), DP_ERR_SHAPE, "MLE size does not match the point");
     std::vector<Ext> p = read_point(point, k); Ext r;
     ctx->dev->mle_eval_batch(&f->b, 1, p.data(), k, &r);
     out[0] = r.c0; out[1] = r.c1;
@@ -288,7 +289,8 @@ static ModelSpec parse_model(const int64_t* b, size_t n) {
     LayerSpec l; l.kind = (int)rd();
     if (l.kind == L_DENSE) {
       l.nrows = (size_t)rd(); l.ncols = (size_t)rd();
-      DP_REQUIRE(l.nrows && l.ncols && l.nrows * l.ncols + l.nrows <= n - pos, DP_ERR_ARG, "model blob: dense tensor sizes");
+      size_t nw = 0, tot = 0;  // overflow-checked: a wrapped product would also satisfy validate_model's size equality
+      DP_REQUIRE(l.nrows && l.ncols && !__builtin_mul_overflow(l.nrows, l.ncols, &nw) && !__builtin_add_overflow(nw, l.nrows, &tot) && tot <= n - pos, DP_ERR_ARG, "model blob: dense tensor sizes");
       l.weights.assign(b + pos, b + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols;
       l.bias.assign(b + pos, b + pos + l.nrows); pos += l.nrows;
     } else if (l.kind == L_REQUANT) { l.right_shift = (unsigned)rd(); l.fp_scale = (unsigned)rd(); l.fixed_point_multiplier = rd(); l.intermediate_bit_size = (unsigned)rd(); }
@@ -296,7 +298,7 @@ static ModelSpec parse_model(const int64_t* b, size_t n) {
       l.kw = (size_t)rd(); l.kx = (size_t)rd(); l.real_nw = (size_t)rd(); l.nw = (size_t)rd(); for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();
       DP_REQUIRE(l.kw && l.kx && l.real_nw && l.kw < (1u << 16) && l.kx < (1u << 16) && l.real_nw < (1u << 12), DP_ERR_ARG, "model blob: conv dimensions");
       size_t nf = l.kw * l.kx * l.real_nw * l.real_nw;
-      DP_REQUIRE(nf + l.kw <= n - pos, DP_ERR_ARG, "model blob: conv tensor sizes");
+      DP_REQUIRE(nf <= n - pos && l.kw <= n - pos - nf, DP_ERR_ARG, "model blob: conv tensor sizes");
       l.weights.assign(b + pos, b + pos + nf); pos += nf;
       l.bias.assign(b + pos, b + pos + l.kw); pos += l.kw;
     } else if (l.kind == L_MAXPOOL) { for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd(); }
@@ -407,6 +409,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
         }
       } catch (const DpError& e) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = e.code; err = e.what(); } next = nproofs; }
       catch (const std::exception& e) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_ARG; err = e.what(); } next = nproofs; }
+      catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_ARG; err = "unknown exception in a proof worker"; } next = nproofs; }
       // leaving the cohort releases the launches the other members have queued behind this one
       if (nco) { try { hip_dev_cohort_detach(&dev); } catch (const std::exception& e) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } next = nproofs; } }
     };
@@ -440,6 +443,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
   });
 }
 int32_t dp_model_in_flight(const dp_model* m, size_t* in_flight) { return guard([&] { DP_REQUIRE(m && in_flight, DP_ERR_ARG, "bad arguments"); *in_flight = m->last_in_flight; }); }
+int32_t dp_model_output_len(const dp_model* m, size_t* noutput) { return guard([&] { DP_REQUIRE(m && noutput, DP_ERR_ARG, "bad arguments"); *noutput = model_output_len(m->zk->model); }); }
 double dp_host_cpu_budget(void) { return host_cpu_budget(); }
 int32_t dp_model_verifier_blob(const dp_model* m, uint64_t** words, size_t* nwords) {
   return guard([&] { DP_REQUIRE(m && words && nwords, DP_ERR_ARG, "bad arguments"); std::vector<u64> w = vctx_to_words(m->zk->verifier_ctx()); *words = copy_out(w); *nwords = w.size(); });

@@ -37,6 +37,7 @@ struct Fiber {
   void* sp = nullptr;
   void* stack = nullptr;
   size_t stack_bytes = 0;
+  bool failed = false;  // the body let an exception escape
   std::function<void()> fn;
   bool done = false;
   FiberSched* sched = nullptr;
@@ -58,16 +59,21 @@ inline void fiber_yield() {
 inline void fiber_entry_trampoline() {
   FiberSched* s = fiber_current_sched();
   Fiber* f = s->cur;
-  f->fn();  // the body catches its own exceptions
+  try { f->fn(); } catch (...) { f->failed = true; }  // the body catches its own exceptions; nothing may unwind past this frame (fake return address)
   f->done = true;
   dp_fiber_switch(&f->sp, s->main_sp);
   abort();  // a finished fiber is never resumed
 }
-inline void fiber_spawn(FiberSched& s, std::function<void()> fn, size_t stack_bytes = size_t(1) << 20) {
+// Whole proofs run on these stacks (std::function, exceptions, HIP runtime calls): 4 MB, committed lazily, and the lowest
+// page is a PROT_NONE guard so that an overflow faults instead of corrupting the mapping below (another fiber's stack).
+inline void fiber_spawn(FiberSched& s, std::function<void()> fn, size_t stack_bytes = size_t(4) << 20) {
   std::unique_ptr<Fiber> f(new Fiber());
+  const size_t page = 4096;
+  stack_bytes = ((stack_bytes + page - 1) & ~(page - 1)) + page;
   f->fn = std::move(fn); f->sched = &s; f->stack_bytes = stack_bytes;
   f->stack = mmap(nullptr, stack_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_STACK, -1, 0);
   if (f->stack == MAP_FAILED) { f->stack = nullptr; throw std::bad_alloc(); }
+  mprotect(f->stack, page, PROT_NONE);
   uintptr_t top = ((uintptr_t)f->stack + stack_bytes) & ~uintptr_t(15);
   void** sp = (void**)top;
   *(--sp) = nullptr;                             // fake return address of the trampoline (keeps rsp = 8 mod 16 at entry)

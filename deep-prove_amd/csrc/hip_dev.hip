@@ -31,6 +31,8 @@ namespace dp {
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw DpError(DP_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
 __constant__ u64 c_rc[DP_POSEIDON2_RC_WORDS];
+__constant__ unsigned long long c_poll_timeout_ticks = 2000000000ull;  // 20 s of the 100 MHz constant clock (DP_POLL_TIMEOUT_S)
+__device__ __forceinline__ unsigned long long dp_realtime() { return __builtin_amdgcn_s_memrealtime(); }
 __constant__ int c_poll_sleep = 1;  // units of s_sleep(4) (~0.1 us) between two polls of the host mailbox (DP_POLL_SLEEP)
 
 constexpr int TPB = 256;
@@ -1171,8 +1173,9 @@ KBODY k_sc_persist(const ScPersistArgs& a, Ext* result, unsigned long long* flag
 // Dev::logup_tail (dev.h): every layer of a logup-GKR batch proof (logup_layers of logup.h: absorb the claim, the batched
 // layer sumcheck with its Fiat-Shamir rounds, the three layer challenges, the next claim) in ONE launch of one workgroup —
 // one device wait per lookup argument instead of one per tree layer; in full mode (Dev::logup_full, DP_DEVICE_LOGUP=2) also
-// the trees, the circuit outputs, the initial challenges and the column claims. EXPERIMENTAL, off unless DP_DEVICE_LOGUP is set: written
-// against the contract pinned by the CPU double (tests/support/cpu_dev.hpp), not yet run on hardware.
+// the trees, the circuit outputs, the initial challenges and the column claims. Default in throughput mode (DP_DEVICE_LOGUP=0 / 1 select the
+// layer-by-layer path / the layer loop only); written against the contract pinned by the CPU double (tests/support/cpu_dev.hpp),
+// checked on the SIMT emulator and on MI355X (tests/test_gpu_fused.py).
 // Tree layers stay where k_logup_tree / k_logup_layer left them (global memory, read once per layer); folded tables
 // ping-pong through bufA / bufB like k_sc_persist. Result area, in words, one block per layer lv = 1..L followed by the
 // sponge: [lv x 4 message values][lv challenges][batching][final evaluations without eq] ... [8 state, 4 input buffer,
@@ -1444,8 +1447,8 @@ KBODY k_logup_tail(const LogupTailDesc* dp, u64* result, unsigned long long* fla
 // Dev::classic_tail (dev.h, classic_tail.h): the remaining rounds of the batch-opening sumcheck of pcs_batch_open — per round
 // fold every (f, eq) pair, the per-pair sums of Dev::classic_round, the 3-coefficient message of classic_round_message
 // (pcs.h), absorb, squeeze "sumcheck round" — in ONE launch of one workgroup once every table is short. A pair belongs to
-// one wave per phase; the phases of a round are separated by barriers. EXPERIMENTAL, off unless DP_DEVICE_CLASSIC=1:
-// checked on the SIMT emulator of tests/, not yet run on hardware.
+// one wave per phase; the phases of a round are separated by barriers. Default in throughput mode (DP_DEVICE_CLASSIC=0 turns
+// it off); checked on the SIMT emulator of tests/ and on MI355X (tests/test_gpu_fused.py).
 KBODY k_classic_tail(const ClassicTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
   DP_CLAIM_ALL_VGPRS();
   __shared__ ClassicTailDesc dl;
@@ -1564,8 +1567,8 @@ KBODY k_classic_tail(const ClassicTailDesc* dp, u64* result, unsigned long long*
 // Dev::dense_tail (dev.h, dense_tail.h): the bias at the output point, W(point, .) — the one-pass fix_high over the base-field
 // weights — and the degree-2 sumcheck of sum_c W(point, c) in(c) with its transcript, in ONE launch of one workgroup: a
 // 1024 x 1024 layer is 8 MB of weights through one CU (~0.15 ms), cheaper than the five dispatches it replaces when the
-// GPU serves hundreds of proofs. EXPERIMENTAL, off unless DP_DEVICE_DENSE=1: checked on the SIMT emulator of tests/, not
-// yet run on hardware.
+// GPU serves hundreds of proofs. Default in throughput mode (DP_DEVICE_DENSE=0 turns it off); checked on the SIMT
+// emulator of tests/ and on MI355X (tests/test_gpu_fused.py).
 KBODY k_dense_tail(const DenseTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
   DP_CLAIM_ALL_VGPRS();
   __shared__ DenseTailDesc dl;
@@ -1653,7 +1656,7 @@ KBODY k_dense_tail(const DenseTailDesc* dp, u64* result, unsigned long long* fla
 // ------------------------------------------------------------------------------------------------ eq tables + sumcheck in one launch
 // Dev::eqsum_tail (dev.h, eqsum_tail.h): the eq tables of an accumulation sumcheck (Requant: three plain tables; same_poly:
 // one table accumulated from scaled eq's) and the whole sumcheck over them with its transcript, in ONE launch of one
-// workgroup. EXPERIMENTAL, off unless DP_DEVICE_EQSUM=1: checked on the SIMT emulator of tests/, not yet run on hardware.
+// workgroup. Default in throughput mode (DP_DEVICE_EQSUM=0 turns it off); checked on the SIMT emulator and on MI355X.
 KBODY k_eqsum_tail(const EqSumDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
   DP_CLAIM_ALL_VGPRS();
   __shared__ EqSumDesc dl;
@@ -1748,8 +1751,8 @@ KBODY k_eqsum_tail(const EqSumDesc* dp, u64* result, unsigned long long* flag, u
 // pending sumcheck message absorbed, the folding challenge, the merge of the committed codewords of the oracle's size, the FRI
 // fold (k_fri_fold's formula), the fold of the sumcheck pairs, the next message (k_bf_msg's sums), the Merkle tree of the folded
 // oracle (k_merkle_tail's layer loop) and its root absorbed; in the last round the final message absorbed — in ONE launch of
-// one workgroup once the oracle is short. EXPERIMENTAL, off unless DP_DEVICE_COMMIT=1: checked on the SIMT emulator of
-// tests/, not yet run on hardware.
+// one workgroup once the oracle is short. Default in throughput mode (DP_DEVICE_COMMIT=0 turns it off); checked on the SIMT
+// emulator of tests/ and on MI355X (tests/test_gpu_fused.py).
 KBODY k_commit_tail(const CommitTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
   DP_CLAIM_ALL_VGPRS();
   __shared__ CommitTailDesc dl;
@@ -1958,17 +1961,30 @@ __device__ __forceinline__ void sc_publish_vals(Ext* result, const Ext* src, siz
   cs = pub_wave_sum(cs);
   if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + cs);
 }
-// lane 0 of wave 0: poll the host mailbox for `seq` (bounded), leave {ok, c0, c1} in chal[]
+// lane 0 of wave 0: poll the host mailbox [seq, c0, c1, tag] for `seq`, leave {ok, c0, c1} in chal[]. The seq word is polled
+// with relaxed loads; once it matches, an acquire fence orders the payload loads after it, and the tag word — mix(seq) + c0 +
+// 2*c1, written by the host with the payload (post_challenge) — is checked against what was read: a stale or torn payload is
+// re-polled instead of becoming a wrong challenge (same protocol as the device-to-host direction, wait_flag). The wait is
+// bounded in TIME (c_poll_timeout_ticks of the 100 MHz s_memrealtime clock; DP_POLL_TIMEOUT_S, default 20 s: below the host's
+// own 30 s), not in spins: a host that serves hundreds of proofs from a few threads is slow, not gone.
+__device__ __forceinline__ unsigned long long chal_mix(unsigned long long seq) { return seq * 0x9E3779B97F4A7C15ull + 0x7F4A7C159E3779B9ull; }
 __device__ __forceinline__ void sc_wait_challenge(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal) {
-  unsigned long long got = 0;
-  for (unsigned spin = 0; spin < (1u << 22); spin++) {
-    got = __hip_atomic_load(mailbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (got == seq) break;
+  const unsigned long long t0 = dp_realtime();
+  bool ok = false;
+  unsigned long long c0 = 0, c1 = 0;
+  for (unsigned spin = 0;; spin++) {
+    unsigned long long got = __hip_atomic_load(mailbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (got == seq) {
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      c0 = __hip_atomic_load(mailbox + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      c1 = __hip_atomic_load(mailbox + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      unsigned long long tag = __hip_atomic_load(mailbox + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (tag == chal_mix(seq) + c0 + 2 * c1) { ok = true; break; }
+    }
+    if ((spin & 63) == 63 && dp_realtime() - t0 > c_poll_timeout_ticks) break;
     for (int q = 0; q < c_poll_sleep; q++) __builtin_amdgcn_s_sleep(4);  // every poll is a PCIe read: keep the rate of all kernels in flight bounded
   }
-  chal[0] = got == seq ? 1 : 0;
-  chal[1] = __hip_atomic_load(mailbox + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  chal[2] = __hip_atomic_load(mailbox + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  chal[0] = ok ? 1 : 0; chal[1] = c0; chal[2] = c1;
 }
 __device__ void sc_publish_fwd(Ext* result, const Ext* part, const int* tk, const int* toff, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane) { sc_publish(result, part, tk, toff, nterms, wpt, flag, seq, lane); }
 __device__ void sc_wait_challenge_fwd(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal) { sc_wait_challenge(mailbox, seq, chal); }
@@ -2652,7 +2668,7 @@ class HipDev : public Dev {
     hflag_dev_ = (unsigned long long*)(hres_dev_ + RES_WORDS);
     *hflag_ = 0;
     hmail_ = hflag_ + 8; hmail_dev_ = hflag_dev_ + 8;
-    hmail_[0] = hmail_[1] = hmail_[2] = 0;
+    hmail_[0] = hmail_[1] = hmail_[2] = hmail_[3] = 0;
     hmflag_ = hflag_ + 32; hmflag_dev_ = hflag_dev_ + 32;  // one flag word per workgroup of a multi-workgroup sumcheck phase
     for (int i = 0; i < MULTI_MAX_WG; i++) { hmflag_[i] = 0; last_tag_multi_[i] = 0; }
     multi_ = persist_flag_env("DP_NO_MULTI");
@@ -2668,6 +2684,7 @@ class HipDev : public Dev {
       for (unsigned k = 1; k < (unsigned)SC_MAXK; k++) for (unsigned at = k + 1; at <= (unsigned)SC_MAXK; at++) for (unsigned i = 0; i <= k; i++)
         ex[((size_t)k * (SC_MAXK + 1) + at) * (SC_MAXK + 1) + i] = extrapolation_coeffs(k, at)[i];
       HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_extrap), ex.data(), ex.size() * 8)); }
+    { double ts = getenv("DP_POLL_TIMEOUT_S") ? std::max(0.001, atof(getenv("DP_POLL_TIMEOUT_S"))) : 20.0; unsigned long long tk = (unsigned long long)(ts * 1e8); HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_poll_timeout_ticks), &tk, sizeof(tk))); }
     { int ps = getenv("DP_POLL_SLEEP") ? std::max(0, atoi(getenv("DP_POLL_SLEEP"))) : 1; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_poll_sleep), &ps, sizeof(int))); }
     DP_SET_LDS((k_sc_persist_lds<false>), 1024, (int)SC_LDS_MAX);
     DP_SET_LDS((k_sc_persist_lds<true>), 1024, (int)SC_LDS_MAX);
@@ -2921,7 +2938,7 @@ class HipDev : public Dev {
   static constexpr size_t EXCL_LDS = 84 * 1024;
   static constexpr size_t SC_PERSIST_MAX = 16384;  // sumchecks whose tables are at most this long run in the persistent kernel
   void post_challenge(Ext r) {
-    hmail_[1] = r.c0; hmail_[2] = r.c1;
+    hmail_[1] = r.c0; hmail_[2] = r.c1; hmail_[3] = pub_mix(sess_.seq) + r.c0 + 2 * r.c1;  // tag: the device re-polls a torn payload
     std::atomic_thread_fence(std::memory_order_release);
     *(volatile unsigned long long*)hmail_ = sess_.seq;
     std::atomic_thread_fence(std::memory_order_seq_cst);
@@ -3004,9 +3021,13 @@ class HipDev : public Dev {
     nfs_++;
     return true;
   }
-  // ---- Dev::logup_tail: EXPERIMENTAL (DP_DEVICE_LOGUP=1), see k_logup_tail. Declines (returns false) whenever the shape is
+  // ---- Dev::logup_tail: DP_DEVICE_LOGUP=1, see k_logup_tail. Declines (returns false) whenever the shape is
   // outside what the kernel was written for; the caller then runs the layers one by one (logup_layers).
-  bool devlogup_ = getenv("DP_DEVICE_LOGUP") && atoi(getenv("DP_DEVICE_LOGUP")) == 1;
+  // fused protocol kernels: on by default whenever the device-side transcript is (throughput mode); DP_DEVICE_<X>=0 turns one off.
+  // Validated on MI355X in round 2 (tests/test_gpu_fused.py: every knob alone and all together, Dense-4M and CNN-264k batches
+  // against the sequential proofs; profiles/r02_fused_knob_sweep.jsonl).
+  static int knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+  bool devlogup_ = knob("DP_DEVICE_LOGUP", 2) == 1;
   size_t nlogup_tail_ = 0;
   bool logup_tail(const LogupTailArgs& a, Challenger& ch, std::vector<std::vector<std::vector<Ext>>>& layer_msgs,
                   std::vector<std::vector<Ext>>& layer_points, std::vector<std::vector<Ext>>& round_evals, std::vector<Ext>& point) override {
@@ -3029,8 +3050,8 @@ class HipDev : public Dev {
     nlogup_tail_++;
     return true;
   }
-  // ---- Dev::commit_tail: EXPERIMENTAL (DP_DEVICE_COMMIT=1): k_commit_tail, the last rounds of the Basefold commit phase
-  bool devcommit_ = getenv("DP_DEVICE_COMMIT") && atoi(getenv("DP_DEVICE_COMMIT"));
+  // ---- Dev::commit_tail: DP_DEVICE_COMMIT (default on): k_commit_tail, the last rounds of the Basefold commit phase
+  bool devcommit_ = knob("DP_DEVICE_COMMIT", 1) != 0;
   bool commit_tail(const CommitTailArgs& a, Challenger& ch, CommitTailOut& out) override {
     if (!devcommit_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_ || !tw_) return false;
     if (!commit_tail_accepts(a) || dp_ceil_log2(a.folded.n) - 1 > L_) return false;
@@ -3049,8 +3070,8 @@ class HipDev : public Dev {
     commit_tail_parse(hres_, a, ch, trees, out);
     return true;
   }
-  // ---- Dev::eqsum_tail: EXPERIMENTAL (DP_DEVICE_EQSUM=1): k_eqsum_tail, eq tables + accumulation sumcheck in one launch
-  bool deveqsum_ = getenv("DP_DEVICE_EQSUM") && atoi(getenv("DP_DEVICE_EQSUM"));
+  // ---- Dev::eqsum_tail: DP_DEVICE_EQSUM (default on): k_eqsum_tail, eq tables + accumulation sumcheck in one launch
+  bool deveqsum_ = knob("DP_DEVICE_EQSUM", 1) != 0;
   bool eqsum_tail(const EqAccJob* jobs, int njobs, const DBuf* tabs, int ntabs, const ScTerm* terms, const Ext* coeffs, int nterms, unsigned nv, unsigned md,
                   Challenger& ch, EqSumOut& out) override {
     if (!deveqsum_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
@@ -3070,8 +3091,8 @@ class HipDev : public Dev {
     release(mk);
     return true;
   }
-  // ---- Dev::dense_tail: EXPERIMENTAL (DP_DEVICE_DENSE=1): k_dense_tail, a Dense layer's device work in one launch
-  bool devdense_ = getenv("DP_DEVICE_DENSE") && atoi(getenv("DP_DEVICE_DENSE"));
+  // ---- Dev::dense_tail: DP_DEVICE_DENSE (default on): k_dense_tail, a Dense layer's device work in one launch
+  bool devdense_ = knob("DP_DEVICE_DENSE", 1) != 0;
   bool dense_tail(const DBuf& bias, const DBuf& W, size_t R, size_t C, const DBuf& in, const Ext* pt, Challenger& ch, DenseTailOut& out) override {
     if (!devdense_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
     if (!dense_tail_accepts(bias, W, R, C, in)) return false;
@@ -3089,8 +3110,8 @@ class HipDev : public Dev {
     release(mk);
     return true;
   }
-  // ---- Dev::classic_tail: EXPERIMENTAL (DP_DEVICE_CLASSIC=1): k_classic_tail, the last rounds of the batch-opening sumcheck
-  bool devclassic_ = getenv("DP_DEVICE_CLASSIC") && atoi(getenv("DP_DEVICE_CLASSIC"));
+  // ---- Dev::classic_tail: DP_DEVICE_CLASSIC (default on): k_classic_tail, the last rounds of the batch-opening sumcheck
+  bool devclassic_ = knob("DP_DEVICE_CLASSIC", 1) != 0;
   bool classic_tail(const ClassicTailArgs& a, Challenger& ch, std::vector<std::vector<Ext>>& msgs, std::vector<Ext>& challenges) override {
     if (!devclassic_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
     if (!classic_tail_accepts(a)) return false;
@@ -3108,9 +3129,9 @@ class HipDev : public Dev {
     release(mk);
     return true;
   }
-  // ---- Dev::logup_full: EXPERIMENTAL (DP_DEVICE_LOGUP=2): k_logup_tail in full mode — one launch and one device wait per
+  // ---- Dev::logup_full: DP_DEVICE_LOGUP=2 (the default): k_logup_tail in full mode — one launch and one device wait per
   // logup-GKR batch proof
-  bool devlogup_full_ = getenv("DP_DEVICE_LOGUP") && atoi(getenv("DP_DEVICE_LOGUP")) == 2;
+  bool devlogup_full_ = knob("DP_DEVICE_LOGUP", 2) == 2;
   bool logup_full(const DBuf* cols, int cpi, int ninst, const DBuf& mult, Ext c, Ext chi, Challenger& ch, LogupFullOut& out) override {
     if (!devlogup_full_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
     size_t n = 0;

@@ -146,8 +146,11 @@ inline LogUpProof logup_batch_prove(Dev& dev, const LogUpInputDev& in, Transcrip
 struct LogUpVerifierClaim { std::vector<Claim> claims; std::vector<Ext> numerators, denominators; };
 
 // verify_logup_proof (verifier.rs:16-211). Throws DpError(DP_ERR_VERIFY) on rejection.
+// `expect_table`: 1 / 0 when the caller knows which kind of proof belongs here (a layer's lookup proof vs a table proof:
+// the kind is the verifier's knowledge, not the prover's), -1 to take the proof's own tag as the reference does.
 inline LogUpVerifierClaim verify_logup_proof(const LogUpProof& proof, size_t num_instances, Ext constant_challenge,
-                                             Ext column_separation_challenge, Transcript& t) {
+                                             Ext column_separation_challenge, Transcript& t, int expect_table = -1) {
+  DP_REQUIRE(expect_table < 0 || proof.is_table == (expect_table != 0), DP_ERR_VERIFY, "logup: proof kind (lookup / table) does not match its place in the proof");
   DP_REQUIRE(num_instances > 0 && proof.circuit_outputs.size() == num_instances, DP_ERR_VERIFY, "logup: wrong number of instances");
   t.append_field_element(gl_from_u64(num_instances));
   LogUpVerifierClaim out;

@@ -132,7 +132,8 @@ struct Reader {
   const u64* p; size_t n, pos = 0;
   Reader(const u64* p_, size_t n_) : p(p_), n(n_) {}
   u64 u() { DP_REQUIRE(pos < n, DP_ERR_ARG, "proof stream truncated"); return p[pos++]; }
-  size_t len(size_t unit_words = 1) { u64 v = u(); DP_REQUIRE(v * unit_words <= n - pos, DP_ERR_ARG, "proof stream: bad length"); return (size_t)v; }
+  // a length prefix is bounded by what is left of the stream (division: `v * unit_words` wraps for v >= 2^62)
+  size_t len(size_t unit_words = 1) { u64 v = u(); DP_REQUIRE(v <= (n - pos) / (unit_words ? unit_words : 1), DP_ERR_ARG, "proof stream: bad length"); return (size_t)v; }
   u64 fe() { u64 v = u(); DP_REQUIRE(v < GL_P, DP_ERR_ARG, "proof stream: non-canonical field element"); return v; }
   Ext e() { u64 a = fe(); u64 b = fe(); return ex(a, b); }
   std::vector<Ext> ve() { size_t k = len(2); std::vector<Ext> v(k); for (auto& x : v) x = e(); return v; }

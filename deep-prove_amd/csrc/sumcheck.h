@@ -172,6 +172,11 @@ inline SubClaim sumcheck_verify(Ext claimed_sum, const IOPProof& proof, unsigned
     DP_REQUIRE(ex_eq(ex_add(ev[0], ev[1]), expected), DP_ERR_VERIFY, "sumcheck: round message inconsistent with the claim");
     expected = lagrange_eval_small(ev.data(), ev.size(), sc.point[i]);
   }
+  // IOPProof.point is prover data. The reference verifier ignores it (sumcheck/src/verifier.rs:22-110) while its callers
+  // read it back (logup_gkr/verifier.rs:81, convolution.rs:1150-1386, same_poly.rs:175): an honest prover always sends the
+  // Fiat-Shamir challenges there, so requiring equality changes no proof byte and closes the gap for every caller at once.
+  DP_REQUIRE(proof.point.size() == nv, DP_ERR_VERIFY, "sumcheck: proof point length");
+  for (unsigned i = 0; i < nv; i++) DP_REQUIRE(ex_eq(proof.point[i], sc.point[i]), DP_ERR_VERIFY, "sumcheck: proof point differs from the transcript challenges");
   sc.expected_evaluation = expected;
   return sc;
 }

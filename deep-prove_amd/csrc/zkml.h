@@ -139,6 +139,16 @@ inline std::vector<std::vector<int64_t>> maxpool_diff_polys(const LayerSpec& l, 
     }
   return cols;
 }
+// length of the model's output tensor (the shape propagation of run_model without the arithmetic)
+inline size_t model_output_len(const ModelSpec& m) {
+  size_t cur = m.input_len;
+  for (const LayerSpec& l : m.layers) {
+    if (l.kind == L_DENSE) cur = l.nrows;
+    else if (l.kind == L_CONV) cur = l.kw * l.nw * l.nw;
+    else if (l.kind == L_MAXPOOL) cur = l.pin[0] * (l.pin[1] / 2) * (l.pin[2] / 2);
+  }
+  return cur;
+}
 inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
   Trace tr; std::vector<int64_t> cur = input;
   DP_REQUIRE(cur.size() == m.input_len, DP_ERR_SHAPE, "input length mismatch");
@@ -915,7 +925,7 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       const PoolingProof& pp = lp.pool;
       TableType rt{2, 0};
       DP_REQUIRE(chmap.count(rt), DP_ERR_VERIFY, "pooling: no challenge for the range table");
-      LogUpVerifierClaim vcl = verify_logup_proof(pp.lookup, 4, constant_challenge, chmap[rt], t);
+      LogUpVerifierClaim vcl = verify_logup_proof(pp.lookup, 4, constant_challenge, chmap[rt], t, 0);
       unsigned nv = dp_ceil_log2(cur_len);
       Ext bc = t.get_and_append_challenge("batch_pooling");
       DP_REQUIRE(vcl.claims.size() == 4 && pp.zerocheck_evals.size() == 5 && pp.commitments.size() == 5 && cur.point.size() == nv, DP_ERR_VERIFY, "pooling: shapes");
@@ -964,8 +974,8 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       TableType ct{3, l.clamping_size()};
       DP_REQUIRE(chmap.count(ct), DP_ERR_VERIFY, "requant: no challenge for clamping table");
       size_t inst = l.shift() / Q_BIT_LEN;
-      LogUpVerifierClaim cc = verify_logup_proof(rp.clamping_lookup, 1, constant_challenge, chmap[ct], t);
-      LogUpVerifierClaim scl = verify_logup_proof(rp.shifted_lookup, inst, constant_challenge, ex_one(), t);
+      LogUpVerifierClaim cc = verify_logup_proof(rp.clamping_lookup, 1, constant_challenge, chmap[ct], t, 0);
+      LogUpVerifierClaim scl = verify_logup_proof(rp.shifted_lookup, inst, constant_challenge, ex_one(), t, 0);
       Ext b = t.get_and_append_challenge("requant_batching");
       DP_REQUIRE(cc.claims.size() == 2 && scl.claims.size() == inst && rp.accumulation_evals.size() == 2 + inst && rp.commitments.size() == 2 + inst, DP_ERR_VERIFY, "requant: shapes");
       const std::vector<Ext>& cpt = cc.claims[0].point; const std::vector<Ext>& spt = scl.claims[0].point;
@@ -992,7 +1002,7 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       const ActivationProof& ap = lp.act;
       TableType rt{0, 0};
       DP_REQUIRE(chmap.count(rt), DP_ERR_VERIFY, "relu: no challenge for table");
-      LogUpVerifierClaim vcl = verify_logup_proof(ap.lookup, 1, constant_challenge, chmap[rt], t);
+      LogUpVerifierClaim vcl = verify_logup_proof(ap.lookup, 1, constant_challenge, chmap[rt], t, 0);
       DP_REQUIRE(vcl.claims.size() == 2 && ap.commits.size() == 2 && ap.io_accumulation.evals.size() == 2, DP_ERR_VERIFY, "relu: shapes");
       unsigned nv = dp_ceil_log2(cur_len);
       std::vector<Claim> sp_claims = {cur, vcl.claims[1]};
@@ -1016,7 +1026,7 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
   for (size_t i = 0; i < vc.tables.size(); i++) {
     const TableType& tt = vc.tables[i];
     const TableProof& tp = proof.table_proofs[i];
-    LogUpVerifierClaim v = verify_logup_proof(tp.lookup, 1, constant_challenge, chmap[tt], t);
+    LogUpVerifierClaim v = verify_logup_proof(tp.lookup, 1, constant_challenge, chmap[tt], t, 1);
     add_claim(tp.multiplicity_commit, v.claims[0]);
     const std::vector<Ext>& pt = v.claims[0].point;
     DP_REQUIRE(pt.size() == tt.vars(), DP_ERR_VERIFY, "table: point size");

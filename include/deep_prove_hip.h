@@ -170,6 +170,8 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
                              size_t* noutput, double* wall_ms);
 /* proofs the last dp_model_prove_batch of this model kept in flight (0 before the first batch) */
 int32_t dp_model_in_flight(const dp_model* m, size_t* in_flight);
+/* length (in int64 words) of the model's output tensor: what `output` / `outputs` of the prove calls must hold */
+int32_t dp_model_output_len(const dp_model* m, size_t* noutput);
 /* CPUs the process may use: the cgroup CPU quota when there is one, else the number of hardware threads */
 double dp_host_cpu_budget(void);
 /* serialisable verifier-side context (model commitments, shapes, tables) */
