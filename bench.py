@@ -1,10 +1,13 @@
 #!/usr/bin/env python
 """bench.py — proofs/s of the MI355X-native prover on BASELINE.json's metric configs.
 
-Headline (`value`): Dense-4M (configs[1]). A step = one batch of `concurrency` complete proofs (zkml::Prover::prove:
-witness commitments, layer sumchecks, logup-GKR, table proofs, Basefold batch opening) of distinct synthetic inputs, all in
-flight on one GPU; model weights and their commitments are resident in HBM before the timed region (Context::generate is
-setup, exactly as in the reference harness zkml/src/bin/bench.rs:390-408). The same JSON line carries CNN-264k
+Headline (`value`): Dense-4M (configs[1]). A step = one batch of WAVES_PER_STEP x `concurrency` complete proofs
+(zkml::Prover::prove: witness commitments, layer sumchecks, logup-GKR, table proofs, Basefold batch opening) of distinct
+synthetic inputs, `concurrency` of them in flight on one GPU at any time; model weights and their commitments are resident in
+HBM before the timed region (Context::generate is setup, exactly as in the reference harness zkml/src/bin/bench.rs:390-408).
+The LAST timed step carries the golden input of tests/golden/*_proof.json at a non-zero index and the sha256 of that proof's
+canonical stream must equal the oracle's (`golden_sha256_ok`): what is timed is bit-identical to the reference's algorithm,
+not merely accepted by the verifier. The same JSON line carries CNN-264k
 (configs[2]) measured the same way, the standalone 2^24 sumcheck (configs[4] on one GPU) with its HBM roofline, and the CPU
 baseline (the oracle, i.e. a single-threaded port of the reference CPU path, on a bounded sample).
 Multi-GPU (launched by torch.distributed.run): independent proofs shard across ranks with no data-path collective
@@ -21,10 +24,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BATCHES_PER_STEP = 2
-# proofs in flight per GPU: 24 cohorts of 8 lock-step proofs (csrc/hip_dev.hip, struct Cohort). The library cuts the number
+# proofs per step = WAVES_PER_STEP x proofs in flight: every call of dp_model_prove_batch starts with all cohorts in phase and ends
+# with a drain (~0.2 s together, profiles/r02_waves.jsonl: 1 wave 327, 2 waves 352, 4 waves 410, 8 waves 431 proofs/s), a service
+# feeds its prover continuously
+BATCHES_PER_STEP = 6
+# proofs in flight per GPU: 22 cohorts of 12 lock-step proofs (csrc/hip_dev.hip, struct Cohort). The library cuts the number
 # to what fits in the free HBM (worker arenas are sized from the footprint of the model's first proof).
-DEFAULT_IN_FLIGHT = 192
+DEFAULT_IN_FLIGHT = 256
+GOLDEN = {"dense_4m": "dense4m_proof.json", "cnn_264k": "cnn264k_proof.json"}
+GOLDEN_SLOT = 7  # index inside the last timed step at which the golden input is proved
 SHARDED_WATCHDOG_S = float(os.environ.get("DP_BENCH_SHARDED_WATCHDOG_S", "240"))
 VERIFY_BUDGET_S = float(os.environ.get("DP_BENCH_VERIFY_BUDGET_S", "15"))  # host verification of the last batch: all proofs if that fits, else an evenly spaced sample
 PUBLISHED = {"dense_4m": 1000.0 / 2335.0, "cnn_264k": 1000.0 / 1242.0}  # reference README.md:17-18 (hardware unstated)
@@ -59,6 +67,7 @@ def timed_region(prove_batch, my_inputs, conc, steps, warmup, dist=None, device_
     last = None
     for i in range(steps):
         lo = (warmup + i) * conc
+        last = None  # a step's proofs are 6 MB each: release them before the next step allocates its own
         last = prove_batch(my_inputs[lo:lo + conc])
     barrier()
     elapsed = time.perf_counter() - t0
@@ -101,6 +110,10 @@ def measure_workload(dpa, dev, workload, conc, steps, warmup, world, rank, dist,
     batch = BATCHES_PER_STEP * conc  # proofs per step: two waves of `conc` in flight, so the drain of a step's tail weighs less
     per_rank = (steps + warmup) * batch
     my_inputs = np.stack([mb.input(1000 + i) for i in shard(world * per_rank, world, rank)])
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", GOLDEN[workload]))) if workload in GOLDEN else None
+    lo_last = (warmup + steps - 1) * batch
+    if gold is not None:
+        my_inputs[lo_last + GOLDEN_SLOT] = mb.input(gold["input_index"])
     t0 = time.perf_counter()
     prover.prove(my_inputs[0])
     first_ms = 1000 * (time.perf_counter() - t0)
@@ -120,11 +133,22 @@ def measure_workload(dpa, dev, workload, conc, steps, warmup, world, rank, dist,
     for j in range(stride, batch, stride):
         dpa.verify(vblob, last[0][j], my_inputs[lo + j], last[1][j])
         checked += 1
+    golden_ok = None
+    if gold is not None:  # bit identity of what was timed: the proof of the golden input out of the last timed step (throughput mode)
+        import hashlib
+        g = last[0][GOLDEN_SLOT]
+        golden_ok = bool(g.size == gold["proof_words"] and hashlib.sha256(g.tobytes()).hexdigest() == gold["sha256"] and [int(v) for v in last[1][GOLDEN_SLOT]] == gold["output"])
+        assert golden_ok, f"{workload}: the throughput-mode proof of the golden input differs from the oracle's proof stream"
     in_flight = prover.in_flight()
     rep = kernel_profile(dev, prover, my_inputs[0]) if profile else None
     ctx.free()  # releases the workers' arenas too: the next workload sizes its own against the free HBM
     return dict(mb=mb, elapsed=elapsed, latency_ms=latency_ms, first_ms=first_ms, setup_s=setup_s, proof_words=int(last[0][0].size),
-                verified=checked, verify_ms=round(1000 * one, 2), in_flight=in_flight, kernel_report=rep)
+                verified=checked, verify_ms=round(1000 * one, 2), in_flight=in_flight, kernel_report=rep, golden_ok=golden_ok)
+
+
+def cnn_steps(steps):
+    """timed steps of the CNN-264k section of a Dense-4M run (the headline keeps the K the caller asked for)"""
+    return max(1, min(steps - 1, 5))
 
 
 def kernel_profile(dev, prover, x):
@@ -208,40 +232,57 @@ def main():
     main_w = measure_workload(dpa, dev, args.workload, conc, args.steps, args.warmup, world, rank, dist, torch, profile=rank == 0)
     cnn_w = None
     if args.workload == "dense_4m" and not args.no_cnn:
-        cnn_w = measure_workload(dpa, dev, "cnn_264k", conc, max(1, args.steps - 1), args.warmup, world, rank, dist, torch)
+        cnn_w = measure_workload(dpa, dev, "cnn_264k", conc, cnn_steps(args.steps), min(1, args.warmup), world, rank, dist, torch)
 
     result = None
     if rank == 0:
         def rate(w, steps):
             return world * steps * BATCHES_PER_STEP * conc / w["elapsed"]
         value = rate(main_w, args.steps)
-        # ---- roofline of the dominant kernel of one proof: algorithmic bytes per launch / average launch duration
+        # ---- roofline. The proof is integer work with no dense contraction (MFMA unused by design). Its chip-filling work is
+        # Poseidon2: every Merkle node is one compress() = 2 permutations = ~1040 Goldilocks multiplications for 96 B moved
+        # (10.8 mul/B: VALU-integer bound, HBM irrelevant), so the roofline is priced in compress()/s against the rate the same
+        # kernel reaches on a chip-filling layer, measured NOW on this GPU (dp_probe_compress_rate, HIP events on the launch
+        # stream). `achieved`/`frac` follow the contract (per launch of the dominant chip-filling kernel, HIP-event timed in
+        # one latency-mode proof: small layers cannot fill 256 CUs alone); `job_*` price the whole timed job, where the
+        # layers of the proofs in flight share the chip.
         rep = main_w["kernel_report"]
         tot_ms = sum(r["total_ms"] for r in rep)
-        dom = rep[0]
+        alg_bytes_per_proof = sum(r["alg_bytes"] for r in rep)
+        merkle = [r for r in rep if r["kernel"].startswith("k_merkle_layer")]
+        nodes_per_proof = sum(r["alg_bytes"] for r in merkle) / 96.0
+        peak = dev.probe_compress_rate(1 << 21, 5)
+        wide = [r for r in merkle if r["kernel"] == "k_merkle_layer"]  # the one-node-per-lane kernel of the wide layers (the _lp / tail variants serve layers too narrow to fill the chip)
+        dom = wide[0] if wide else max(merkle, key=lambda r: r["total_ms"]) if merkle else rep[0]
         avg_ms = dom["total_ms"] / dom["launches"]
-        achieved = (dom["alg_bytes"] / dom["launches"]) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        nodes_per_launch = dom["alg_bytes"] / dom["launches"] / 96.0
+        achieved = nodes_per_launch / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
+        job_compress = nodes_per_proof * value / world  # per GPU
         pmc = pmc_traffic(dom["kernel"])
-        roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
-                    "alg_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"], 1), "launches_per_proof": dom["launches"],
-                    "avg_launch_us": round(1000 * avg_ms, 3), "kernel_share_of_gpu_time": round(dom["total_ms"] / tot_ms, 4),
-                    "gpu_busy_ms_per_proof": round(tot_ms, 3),
-                    "note": "the dominant kernel of a proof is the persistent sumcheck kernel: one launch runs every round of a small sumcheck "
-                            "(tables of a few KB..MB, in LDS after the first fold) and spends its time in Fiat-Shamir round trips with the host, so its HBM "
-                            "fraction is ~0 by construction; the HBM-streaming kernels are reported under sumcheck24 (2^24 standalone sumcheck)",
+        by_time = rep[0]
+        roofline = {"bound": "valu-int", "kernel": dom["kernel"], "achieved": round(achieved / 1e9, 4), "peak": round(peak / 1e9, 4), "unit": "Gcompress/s",
+                    "frac": round(achieved / peak, 4) if peak else None, "traffic": pmc["hbm_bytes_per_launch"] if pmc else None,
+                    "alg_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"], 1), "nodes_per_launch": round(nodes_per_launch, 1),
+                    "launches_per_proof": dom["launches"], "avg_launch_us": round(1000 * avg_ms, 3),
+                    "peak_note": "k_merkle_layer on a 2^21-node layer, 5 launches, HIP events, this run; 1 compress = 2 Poseidon2-w8 permutations = ~1040 Goldilocks multiplications",
+                    "job_compress_per_s": round(job_compress / 1e9, 4), "job_frac": round(job_compress / peak, 4) if peak else None,
+                    "job_goldilocks_mul_per_s": round(1040.0 * job_compress / 1e12, 4), "merkle_nodes_per_proof": int(nodes_per_proof),
+                    "job_alg_GBps": round(alg_bytes_per_proof * value / world / 1e9, 1), "job_hbm_frac": round(alg_bytes_per_proof * value / world / 1e9 / HBM_PEAK_GBS, 5),
+                    "alg_bytes_per_proof": int(alg_bytes_per_proof), "gpu_busy_ms_per_proof_latency_mode": round(tot_ms, 3),
+                    "largest_by_time": {"kernel": by_time["kernel"], "bound": "latency", "share_of_gpu_time": round(by_time["total_ms"] / tot_ms, 4), "launches": by_time["launches"],
+                                        "note": "one-workgroup protocol kernels (sumcheck rounds + Fiat-Shamir) are latency-bound by construction: kilobytes of tables, a dependent chain of rounds"},
                     "top_kernels": [{"kernel": r["kernel"], "launches": r["launches"], "total_ms": round(r["total_ms"], 3),
                                      "GBps": round((r["alg_bytes"] / max(r["total_ms"], 1e-9)) / 1e6, 1)} for r in rep[:8]]}
         cpu = None if (world > 1 or args.no_cpu_baseline) else cpu_baseline(main_w["mb"], args.workload)
         sc24 = None if (world > 1 or args.no_sumcheck24) else sumcheck24(dev, dpa)
         cnn = None
         if cnn_w is not None:
-            csteps = max(1, args.steps - 1)
+            csteps = cnn_steps(args.steps)
             cnn = {"metric": "proofs/sec (prover), CNN-264k", "value": round(rate(cnn_w, csteps), 4), "unit": "proofs/s",
                    "ms_per_step": round(1000.0 * cnn_w["elapsed"] / csteps, 3), "steps": csteps, "proofs_per_step_per_gpu": BATCHES_PER_STEP * conc, "proofs_in_flight_per_gpu": cnn_w["in_flight"],
                    "single_proof_latency_ms": round(cnn_w["latency_ms"], 2), "vs_baseline": round(rate(cnn_w, csteps) / PUBLISHED["cnn_264k"], 3),
                    "baseline_note": "reference README.md:17 CNN-264k proving time 1242 ms on unstated CPU hardware",
-                   "workload": WORKLOADS["cnn_264k"], "proof_words": cnn_w["proof_words"], "setup_s": round(cnn_w["setup_s"], 2), "verified": True, "verified_proofs_of_last_step": cnn_w["verified"],
+                   "workload": WORKLOADS["cnn_264k"], "proof_words": cnn_w["proof_words"], "setup_s": round(cnn_w["setup_s"], 2), "verified": True, "golden_sha256_ok": cnn_w["golden_ok"], "verified_proofs_of_last_step": cnn_w["verified"],
                    "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else cpu_baseline(cnn_w["mb"], "cnn_264k")}
         result = {
             "metric": {"dense_4m": "proofs/sec (prover), Dense-4M", "cnn_264k": "proofs/sec (prover), CNN-264k"}.get(args.workload, "proofs/sec (prover), MLP-w256"),
@@ -254,8 +295,8 @@ def main():
                        "proofs_per_step_per_gpu": BATCHES_PER_STEP * conc, "proofs_in_flight_per_gpu": main_w["in_flight"], "proofs_per_rank": args.steps * BATCHES_PER_STEP * conc,
                        "single_proof_latency_ms": round(main_w["latency_ms"], 2), "first_proof_ms": round(main_w["first_ms"], 2),
                        "host_cpu_budget": budget, "host_threads_per_rank": int(os.environ["DP_HOST_THREADS"]),
-                       "parallelism": f"replicas x{world} GPUs x {main_w['in_flight']} proofs in flight per GPU in lock-step cohorts of {os.environ.get('DP_COHORT', '8')} (independent proofs, no data-path collective)",
-                       "proof_words": main_w["proof_words"], "setup_s": round(main_w["setup_s"], 2), "verified": True, "verified_proofs_of_last_step": main_w["verified"], "verify_ms_per_proof": main_w["verify_ms"],
+                       "parallelism": f"replicas x{world} GPUs x {main_w['in_flight']} proofs in flight per GPU in lock-step cohorts of {os.environ.get('DP_COHORT', '12')} (independent proofs, no data-path collective)",
+                       "proof_words": main_w["proof_words"], "setup_s": round(main_w["setup_s"], 2), "verified": True, "golden_sha256_ok": main_w["golden_ok"], "verified_proofs_of_last_step": main_w["verified"], "verify_ms_per_proof": main_w["verify_ms"],
                        "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DP_") or k == "GPU_MAX_HW_QUEUES"}, "device": dev.name},
             "roofline": roofline, "cpu_baseline": cpu, "cnn_264k": cnn, "sumcheck24": sc24, "sumcheck24_sharded": None,
         }

@@ -28,6 +28,7 @@ SIGNATURES = {
     "dp_ctx_name": (C.c_char_p, [vp]),
     "dp_profile_enable": (C.c_int32, [vp, C.c_int32]),
     "dp_profile_report": (C.c_int32, [vp, C.POINTER(C.c_void_p)]),
+    "dp_probe_compress_rate": (C.c_int32, [vp, C.c_size_t, C.c_int32, C.POINTER(C.c_double)]),
     "dp_buf_from_i64": (C.c_int32, [vp, i64p, C.c_size_t, C.POINTER(vp)]),
     "dp_buf_upload": (C.c_int32, [vp, u64p, C.c_size_t, C.c_int32, C.POINTER(vp)]),
     "dp_buf_download": (C.c_int32, [vp, vp, u64p]),

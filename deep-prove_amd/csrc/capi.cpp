@@ -10,7 +10,7 @@
 #include <thread>
 
 DP_FIBER_SWITCH_ASM
-namespace dp { struct Cohort; Cohort* hip_cohort_new(); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
+namespace dp { struct Cohort; Cohort* hip_cohort_new(); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
 using namespace dp;
 
 struct dp_ctx { Dev* dev; int device_id; };
@@ -58,6 +58,9 @@ const char* dp_ctx_name(const dp_ctx* ctx) { return ctx ? ctx->dev->name() : "";
 int32_t dp_profile_enable(dp_ctx* ctx, int32_t on) { return guard([&] { DP_REQUIRE(ctx, DP_ERR_ARG, "null ctx"); hip_dev_profile_enable(ctx->dev, on != 0); }); }
 int32_t dp_profile_report(dp_ctx* ctx, char** json) {
   return guard([&] { DP_REQUIRE(ctx && json, DP_ERR_ARG, "bad arguments"); std::string r = hip_dev_profile_report(ctx->dev); char* p = (char*)malloc(r.size() + 1); if (!p) throw std::bad_alloc(); memcpy(p, r.c_str(), r.size() + 1); *json = p; });
+}
+int32_t dp_probe_compress_rate(dp_ctx* ctx, size_t nodes, int32_t reps, double* per_second) {
+  return guard([&] { DP_REQUIRE(ctx && per_second, DP_ERR_ARG, "bad arguments"); *per_second = hip_dev_probe_compress_rate(ctx->dev, nodes, reps); });
 }
 int32_t dp_buf_from_i64(dp_ctx* ctx, const int64_t* v, size_t n, dp_buf** out) {
   return guard([&] { DP_REQUIRE(ctx && v && out && n, DP_ERR_ARG, "bad arguments"); DBuf b = ctx->dev->alloc_persistent(n, false); ctx->dev->upload_i64(b, v); *out = new dp_buf{b}; });
@@ -374,7 +377,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     // that prove in lock step — launch number i of all members of a cohort is ONE kernel launch — on one stream and one
     // host thread per cohort. DP_COHORT=0: every proof on its own stream (the round-1 scheme).
     const char* ce = getenv("DP_COHORT");
-    size_t csize = ce ? (size_t)std::max(0, atoi(ce)) : 8;
+    size_t csize = ce ? (size_t)std::max(0, atoi(ce)) : 12;  // 256 in flight = 22 cohorts: one hardware queue each (24 are served without time slicing)
     size_t nco = (csize >= 1 && nw > 1) ? (nw + csize - 1) / csize : 0;
     while (m->cohorts.size() < nco) m->cohorts.push_back(hip_cohort_new());
     auto dev_of = [&](size_t wi) -> Dev& { return wi == 0 ? *m->ctx->dev : *m->workers[wi - 1]; };

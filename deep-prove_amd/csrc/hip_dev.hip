@@ -7,6 +7,7 @@
 // are canonical u64, extension elements are 16-byte {c0,c1} pairs so one `global_load_dwordx4` per lane fetches one
 // element. A sumcheck pair (2b, 2b+1) is therefore 32 contiguous bytes per lane.
 #include "dev.h"
+#include "poseidon2_fast.h"
 #include "sumcheck.h"
 #include "fiber.h"
 #include "logup_tail.h"
@@ -33,7 +34,8 @@ namespace dp {
 __constant__ u64 c_rc[DP_POSEIDON2_RC_WORDS];
 __constant__ unsigned long long c_poll_timeout_ticks = 2000000000ull;  // 20 s of the 100 MHz constant clock (DP_POLL_TIMEOUT_S)
 __device__ __forceinline__ unsigned long long dp_realtime() { return __builtin_amdgcn_s_memrealtime(); }
-__constant__ int c_poll_sleep = 1;  // units of s_sleep(4) (~0.1 us) between two polls of the host mailbox (DP_POLL_SLEEP)
+__constant__ int c_poll_sleep = 1;
+__constant__ int c_dbg_skip_hash = 0;  // DP_DEBUG_SKIP_HASH=1: TIMING EXPERIMENT ONLY — wide Merkle layers copy instead of hashing (proofs do not verify)  // units of s_sleep(4) (~0.1 us) between two polls of the host mailbox (DP_POLL_SLEEP)
 
 constexpr int TPB = 256;
 constexpr int MAX_TABS = 32;
@@ -64,13 +66,23 @@ template <class H, class... T> struct ArgPack<H, T...> {
 // reference so that both entry points read them in place — kernarg segment / pack table — instead of copying them to scratch)
 template <class T> struct KArgs;
 template <class... A> struct KArgs<void (*)(A...)> {};
-template <auto Body, int MAXT, class... A> __global__ void __launch_bounds__(MAXT) kg(A... a) { Body(a...); }
-template <auto Body, int MAXT, class... A> __global__ void __launch_bounds__(MAXT) kc(const ArgPack<A...>* __restrict__ packs) { packs[blockIdx.z].call(Body); }
+// FLAGS select how a one-workgroup (latency-critical) body shares the chip:
+//   KF_CLAIM  latency mode, ONE proof on the GPU: the workgroup claims the whole register file of its CU (16 waves x 128 VGPRs;
+//             with the LDS reservation of the launch no wave of another kernel can share the CU);
+//   KF_PRIO   throughput mode, hundreds of proofs in flight: NO reservation at all — 256 threads, no LDS beyond what the body
+//             needs — and raised wave priority instead (s_setprio 3: the SIMD's arbiter issues these waves first, the
+//             Poseidon2 waves of the Merkle layers fill the remaining issue slots). A workgroup that needs an EMPTY CU stalls
+//             the workgroup dispatcher until one drains, and the chip idles meanwhile: tools/hol.hip — two streams of
+//             whole-CU workgroups (16 CUs, 6 % of the chip) halve the throughput of 14 streams of wide kernels, the same
+//             serial work in 256-thread workgroups costs 9 %.
+enum { KF_NONE = 0, KF_CLAIM = 1, KF_PRIO = 2 };
+template <int FLAGS> __device__ __forceinline__ void kf_prologue() {
+  if (FLAGS & KF_CLAIM) asm volatile("v_mov_b32 v127, 0" ::: "v127");
+  if (FLAGS & KF_PRIO) __builtin_amdgcn_s_setprio(3);
+}
+template <auto Body, int MAXT, int FLAGS, class... A> __global__ void __launch_bounds__(MAXT) kg(A... a) { kf_prologue<FLAGS>(); Body(a...); }
+template <auto Body, int MAXT, int FLAGS, class... A> __global__ void __launch_bounds__(MAXT) kc(const ArgPack<A...>* __restrict__ packs) { kf_prologue<FLAGS>(); packs[blockIdx.z].call(Body); }
 
-// Latency-critical one-workgroup kernels claim the whole register file of their CU (16 waves x 128 VGPRs): together with
-// the LDS reservation no wave of another kernel — in particular the VALU-heavy Poseidon2 Merkle layers of the other proofs in
-// flight, which need only ~30 VGPRs and would otherwise slip onto the same SIMDs — can share the CU with them.
-#define DP_CLAIM_ALL_VGPRS() asm volatile("v_mov_b32 v127, 0" ::: "v127")
 // ------------------------------------------------------------------------------------------------ reductions
 __device__ __forceinline__ u64 shfl_down_u64(u64 v, int d) {
   int lo = __shfl_down((int)(u32)v, d, 64);
@@ -494,13 +506,18 @@ KBODY k_merkle_leaves(const void* leaves, u64* nodes, size_t npairs) {
     o[0] = d0; o[1] = d1; o[2] = d2; o[3] = d3;
   }
 }
+// the node hash of the one-node-per-lane Merkle kernels
+__device__ __forceinline__ void merkle_compress(const u64* x, const u64* y, u64* o) {
+  if (c_dbg_skip_hash) { for (int k = 0; k < 4; k++) o[k] = x[k] ^ y[k]; return; }
+  p2f::compress(x, y, o, c_rc);  // poseidon2_fast.h: the same permutation with wide accumulation and any-representative words (1.33x, tools/p2bench.hip)
+}
 // one Poseidon2 compress (2 permutations) per lane; state held in 8 VGPR pairs, round constants in constant memory
 KBODY k_merkle_layer(const u64* in, u64* out, size_t cnt) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cnt; i += (size_t)gridDim.x * blockDim.x) {
     const ulonglong2* p = (const ulonglong2*)(in + 8 * i);
     ulonglong2 x01 = p[0], x23 = p[1], y01 = p[2], y23 = p[3];
     u64 x[4] = {x01.x, x01.y, x23.x, x23.y}, y[4] = {y01.x, y01.y, y23.x, y23.y}, o[4];
-    poseidon2_compress(x, y, o, c_rc);
+    merkle_compress(x, y, o);
     ulonglong2* q = (ulonglong2*)(out + 4 * i);
     q[0] = make_ulonglong2(o[0], o[1]);
     q[1] = make_ulonglong2(o[2], o[3]);
@@ -702,13 +719,13 @@ __device__ __forceinline__ void p2l_compress(const u64* in, u64* out, int lane) 
 KBODY k_merkle_layer_lp(const u64* in, u64* out, size_t cnt) {
   size_t g = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 3;
   size_t stride = ((size_t)gridDim.x * blockDim.x) >> 3;
+  if (c_dbg_skip_hash) { for (; g < cnt; g += stride) if ((threadIdx.x & 7) < 4) out[4 * g + (threadIdx.x & 7)] = in[8 * g + (threadIdx.x & 7)]; return; }
   for (; g < cnt; g += stride) p2l_compress(in + 8 * g, out + 4 * g, threadIdx.x & 63);
 }
 struct TailDesc { u64* nodes; size_t off; size_t cnt; };
 // All Merkle layers above an already computed layer of `cnt` (<= 2048) digests, one workgroup per tree, no relaunch
 // between layers. Wide layers hash one node per lane, narrow ones use the 8-lane permutation. roots[4*tree..] = root.
 KBODY k_merkle_tail(const TailDesc* d, u64* roots, u64* host_result, unsigned long long* flag, unsigned long long seq) {
-  DP_CLAIM_ALL_VGPRS();
   TailDesc t = d[blockIdx.x];
   u64* nd = t.nodes;
   size_t off = t.off, cnt = t.cnt;
@@ -880,7 +897,7 @@ KBODY k_merkle_layer_many(const TailDesc* td, size_t off, size_t cnt) {
     const ulonglong2* p = (const ulonglong2*)(in + 8 * i);
     ulonglong2 x01 = p[0], x23 = p[1], y01 = p[2], y23 = p[3];
     u64 x[4] = {x01.x, x01.y, x23.x, x23.y}, y[4] = {y01.x, y01.y, y23.x, y23.y}, o[4];
-    poseidon2_compress(x, y, o, c_rc);
+    merkle_compress(x, y, o);
     ulonglong2* q = (ulonglong2*)(out + 4 * i);
     q[0] = make_ulonglong2(o[0], o[1]); q[1] = make_ulonglong2(o[2], o[3]);
   }
@@ -910,7 +927,6 @@ __device__ __forceinline__ Ext block_reduce_ext_n(Ext v, Ext* sm) {
 // result[term*4 + t] straight into host-mapped memory and releases `flag = seq`.
 template <bool HI>
 KBODY k_sc_small(const ScSmallArgs& a, Ext* result, unsigned long long* flag, unsigned long long seq) {
-  DP_CLAIM_ALL_VGPRS();
   __shared__ Ext part[64 * SC_SLOTS];  // [slot][t], slot = term * wpt + sub  (<= 64 slots)
   int tid = threadIdx.x, nt = blockDim.x;
   size_t n = a.n_after;
@@ -1081,7 +1097,6 @@ __device__ __forceinline__ void sc_fold_all(const ScPersistArgs& a, const void* 
 }
 template <bool HI>
 KBODY k_sc_persist(const ScPersistArgs& a, Ext* result, unsigned long long* flag, const unsigned long long* mailbox, unsigned long long seq0, const ScFsArgs* fs) {
-  DP_CLAIM_ALL_VGPRS();
   __shared__ Ext part[64 * SC_SLOTS];
   __shared__ unsigned long long chal[3];
   __shared__ const void* cur[MAX_TABS];
@@ -1182,7 +1197,6 @@ KBODY k_sc_persist(const ScPersistArgs& a, Ext* result, unsigned long long* flag
 // in_len, out_len]; the tag is mix(seq) + sum over blocks of sum_i (i + 1) * word_i with i relative to the block.
 static_assert(LT_MAX_TABS == MAX_TABS, "logup_tail.h: table capacity");
 KBODY k_logup_tail(const LogupTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
-  DP_CLAIM_ALL_VGPRS();
   __shared__ Ext part[64 * SC_SLOTS];
   __shared__ unsigned long long chal[3];
   __shared__ const void* cur[MAX_TABS];
@@ -1450,7 +1464,6 @@ KBODY k_logup_tail(const LogupTailDesc* dp, u64* result, unsigned long long* fla
 // one wave per phase; the phases of a round are separated by barriers. Default in throughput mode (DP_DEVICE_CLASSIC=0 turns
 // it off); checked on the SIMT emulator of tests/ and on MI355X (tests/test_gpu_fused.py).
 KBODY k_classic_tail(const ClassicTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
-  DP_CLAIM_ALL_VGPRS();
   __shared__ ClassicTailDesc dl;
   __shared__ Ext raw[2 * CT_MAXP];
   __shared__ const void* curf[CT_MAXP];
@@ -1570,7 +1583,6 @@ KBODY k_classic_tail(const ClassicTailDesc* dp, u64* result, unsigned long long*
 // GPU serves hundreds of proofs. Default in throughput mode (DP_DEVICE_DENSE=0 turns it off); checked on the SIMT
 // emulator of tests/ and on MI355X (tests/test_gpu_fused.py).
 KBODY k_dense_tail(const DenseTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
-  DP_CLAIM_ALL_VGPRS();
   __shared__ DenseTailDesc dl;
   __shared__ Ext part[64 * SC_SLOTS];
   __shared__ unsigned long long chal[3];
@@ -1658,7 +1670,6 @@ KBODY k_dense_tail(const DenseTailDesc* dp, u64* result, unsigned long long* fla
 // one table accumulated from scaled eq's) and the whole sumcheck over them with its transcript, in ONE launch of one
 // workgroup. Default in throughput mode (DP_DEVICE_EQSUM=0 turns it off); checked on the SIMT emulator and on MI355X.
 KBODY k_eqsum_tail(const EqSumDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
-  DP_CLAIM_ALL_VGPRS();
   __shared__ EqSumDesc dl;
   __shared__ Ext part[64 * SC_SLOTS];
   __shared__ unsigned long long chal[3];
@@ -1754,7 +1765,6 @@ KBODY k_eqsum_tail(const EqSumDesc* dp, u64* result, unsigned long long* flag, u
 // one workgroup once the oracle is short. Default in throughput mode (DP_DEVICE_COMMIT=0 turns it off); checked on the SIMT
 // emulator of tests/ and on MI355X (tests/test_gpu_fused.py).
 KBODY k_commit_tail(const CommitTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
-  DP_CLAIM_ALL_VGPRS();
   __shared__ CommitTailDesc dl;
   __shared__ Ext part[64 * 3];
   __shared__ unsigned long long chal[3];
@@ -1990,7 +2000,6 @@ __device__ void sc_publish_fwd(Ext* result, const Ext* part, const int* tk, cons
 __device__ void sc_wait_challenge_fwd(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal) { sc_wait_challenge(mailbox, seq, chal); }
 template <bool HI>
 KBODY k_sc_persist_lds(const ScPersistArgs& a, Ext* result, unsigned long long* flag, const unsigned long long* mailbox, unsigned long long seq0, const ScFsArgs* fs) {
-  DP_CLAIM_ALL_VGPRS();
   extern __shared__ __align__(16) unsigned char lds_dyn[];
   Ext* L = (Ext*)lds_dyn;
   __shared__ Ext part[64 * SC_SLOTS];
@@ -2277,12 +2286,19 @@ static inline int grid_for(size_t n, int cap = 2048) {
 struct ProfRec { const char* name; double bytes; hipEvent_t a, b; };
 // every launch of this file goes through HipDev::launch_: kg<Body> on the context's own stream, or — when the context is a
 // member of a cohort — an argument pack handed to the cohort, which launches kc<Body> once for all its members
-#define DPL_B(kern, maxt, grid, block, lds, ...) do { prof_begin(#kern); LaunchTimer lt_(this); launch_<kern, maxt>(KArgs<decltype(&kern)>(), #kern, grid, block, lds, __VA_ARGS__); lt_.stop(); prof_end(); } while (0)
-#define DPL(kern, grid, block, ...) DPL_B(kern, 1024, grid, block, 0, __VA_ARGS__)
-#define DPL_LDS(kern, grid, block, lds, ...) DPL_B(kern, 1024, grid, block, lds, __VA_ARGS__)
+#define DPL_B(kern, maxt, flags, grid, block, lds, ...) do { prof_begin(#kern); LaunchTimer lt_(this); launch_<kern, maxt, flags>(KArgs<decltype(&kern)>(), #kern, grid, block, lds, __VA_ARGS__); lt_.stop(); prof_end(); } while (0)
+#define DPL(kern, grid, block, ...) DPL_B(kern, 1024, KF_NONE, grid, block, 0, __VA_ARGS__)
+#define DPL_LDS(kern, grid, block, lds, ...) DPL_B(kern, 1024, KF_NONE, grid, block, lds, __VA_ARGS__)
+// one-workgroup-per-proof kernels (persistent sumchecks, fused protocol tails, Merkle tails): `threads` and the CU reservation
+// apply in latency mode; in throughput mode the workgroup shrinks to shared_threads_ and reserves nothing (KF_PRIO above).
+// `lds` = dynamic LDS the body really needs.
+#define DPL_ONE(kern, grid, threads, lds, ...) do { if (shared_now()) { DPL_B(kern, 1024, KF_PRIO, grid, dim3(std::min<unsigned>((unsigned)(threads), (unsigned)shared_threads_)), (size_t)(lds), __VA_ARGS__); } \
+                                                     else { DPL_B(kern, 1024, KF_CLAIM, grid, dim3(threads), std::max<size_t>((size_t)(lds), excl_now()), __VA_ARGS__); } } while (0)
+#define DPL_ONE_HI(kern, hi, grid, threads, lds, ...) do { if (hi) { DPL_ONE((kern<true>), grid, threads, lds, __VA_ARGS__); } else { DPL_ONE((kern<false>), grid, threads, lds, __VA_ARGS__); } } while (0)
 #define DPL_HI(kern, hi, grid, block, ...) do { if (hi) { DPL((kern<true>), grid, block, __VA_ARGS__); } else { DPL((kern<false>), grid, block, __VA_ARGS__); } } while (0)
 #define DPL_LDS_HI(kern, hi, grid, block, lds, ...) do { if (hi) { DPL_LDS((kern<true>), grid, block, lds, __VA_ARGS__); } else { DPL_LDS((kern<false>), grid, block, lds, __VA_ARGS__); } } while (0)
-#define DP_SET_LDS(kern, maxt, bytes) set_lds_<kern, maxt>(KArgs<decltype(&kern)>(), (int)(bytes))
+#define DP_SET_LDS(kern, maxt, bytes) set_lds_<kern, maxt, KF_NONE>(KArgs<decltype(&kern)>(), (int)(bytes))
+#define DP_SET_LDS_ONE(kern, maxt, bytes) do { set_lds_<kern, maxt, KF_CLAIM>(KArgs<decltype(&kern)>(), (int)(bytes)); set_lds_<kern, maxt, KF_PRIO>(KArgs<decltype(&kern)>(), (int)(bytes)); } while (0)
 
 static const bool g_host_stats = getenv("DP_TIMING") && atoi(getenv("DP_TIMING"));
 
@@ -2433,25 +2449,25 @@ class HipDev : public Dev {
   hipStream_t s_ = nullptr;
   Cohort* co_ = nullptr;  // non-null while this context proves as a member of a cohort: launches go to the cohort's stream
   size_t co_li_ = 0;      // number of launches this member has issued into the cohort's common sequence
-  template <auto Body, int MAXT, class... A>
+  template <auto Body, int MAXT, int FLAGS, class... A>
   static void fire_(const Cohort::Pending& p, hipStream_t s) {
-    hipLaunchKernelGGL((kc<Body, MAXT, std::decay_t<A>...>), dim3(p.g.x, p.g.y, (unsigned)p.count), p.b, p.lds, s, (const ArgPack<std::decay_t<A>...>*)p.packs_dev);
+    hipLaunchKernelGGL((kc<Body, MAXT, FLAGS, std::decay_t<A>...>), dim3(p.g.x, p.g.y, (unsigned)p.count), p.b, p.lds, s, (const ArgPack<std::decay_t<A>...>*)p.packs_dev);
   }
-  template <auto Body, int MAXT, class... A, class... P>
+  template <auto Body, int MAXT, int FLAGS, class... A, class... P>
   void launch_(KArgs<void (*)(A...)>, const char* name, dim3 g, dim3 b, size_t lds, P... args) {
     static_assert(sizeof...(A) == sizeof...(P), "kernel argument count");
     if (g_host_stats) { if (!first_launch_) first_launch_ = name; last_launch_ = name; }
-    if (!co_) { hipLaunchKernelGGL((kg<Body, MAXT, std::decay_t<A>...>), g, b, lds, s_, static_cast<std::decay_t<A>>(args)...); return; }
+    if (!co_) { hipLaunchKernelGGL((kg<Body, MAXT, FLAGS, std::decay_t<A>...>), g, b, lds, s_, static_cast<std::decay_t<A>>(args)...); return; }
     DP_REQUIRE(g.z == 1, DP_ERR_SHAPE, "cohort launches use blockIdx.z for the proof");
     using Pack = ArgPack<std::decay_t<A>...>;
     static_assert(std::is_trivially_copyable<Pack>::value && std::is_trivially_destructible<Pack>::value, "argument packs travel as bytes");
     Pack pk(static_cast<std::decay_t<A>>(args)...);
-    co_->submit(co_li_++, &fire_<Body, MAXT, A...>, name, g, b, lds, &pk, sizeof(Pack));
+    co_->submit(co_li_++, &fire_<Body, MAXT, FLAGS, A...>, name, g, b, lds, &pk, sizeof(Pack));
   }
-  template <auto Body, int MAXT, class... A>
+  template <auto Body, int MAXT, int FLAGS, class... A>
   static void set_lds_(KArgs<void (*)(A...)>, int bytes) {
-    HIP_CHECK(hipFuncSetAttribute((const void*)kg<Body, MAXT, std::decay_t<A>...>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    HIP_CHECK(hipFuncSetAttribute((const void*)kc<Body, MAXT, std::decay_t<A>...>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    HIP_CHECK(hipFuncSetAttribute((const void*)kg<Body, MAXT, FLAGS, std::decay_t<A>...>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    HIP_CHECK(hipFuncSetAttribute((const void*)kc<Body, MAXT, FLAGS, std::decay_t<A>...>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   }
   char* arena_ = nullptr;
   size_t arena_cap_ = 0, arena_off_ = 0, arena_peak_ = 0;
@@ -2473,6 +2489,12 @@ class HipDev : public Dev {
   bool tail_many_excl_ = !(getenv("DP_TAIL_MANY_EXCL") && !atoi(getenv("DP_TAIL_MANY_EXCL")));
   int tail_many_threads_ = [] { const char* e = getenv("DP_TAIL_MANY_THREADS"); int v = e ? atoi(e) : 1024; return (v == 256 || v == 512) ? v : 1024; }();
   size_t excl_now() const { return (co_ && !cohort_excl_) ? 0 : excl_; }
+  // throughput mode (several proofs in flight): one-workgroup kernels reserve nothing and run as 256-thread workgroups with
+  // raised wave priority (KF_PRIO). DP_SHARED_TAILS=0 restores the whole-CU workgroups of round 1, DP_SHARED_THREADS = 64..1024.
+  bool shared_tails_ = !(getenv("DP_SHARED_TAILS") && !atoi(getenv("DP_SHARED_TAILS")));
+  int shared_threads_ = [] { const char* e = getenv("DP_SHARED_THREADS"); int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ? v : 256; }();
+  bool throughput_mode_ = false;
+  bool shared_now() const { return throughput_mode_ && shared_tails_; }
   //   DP_COHORT_PERSIST_THREADS=n  workgroup size of the one-workgroup sumcheck kernels of cohort members (256 / 512 / 1024;
   //                                default: 1024 when the CU is reserved, else by the amount of work)
   int cohort_persist_threads_ = [] { const char* e = getenv("DP_COHORT_PERSIST_THREADS"); int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 0; }();
@@ -2523,12 +2545,16 @@ class HipDev : public Dev {
   void* hstage_ = nullptr;  // pinned + device-mapped staging: [0, DESC_BYTES) descriptor ring read by kernels over PCIe, rest = bulk copies
   char* hstage_dev_ = nullptr;
   size_t desc_off_ = 0;
-  // DP_ASYNC_UPLOAD=1 (experiment, default off): small host-to-device copies take successive slots of the bulk staging area
-  // and are not waited for — like descriptors, the slots are recycled when the host observes a later publication of this
-  // stream (everything launched before it has run). Today every upload costs a copy launch, a publish launch and a device wait
-  // (~29 per Dense-4M proof).
+  // Asynchronous uploads (throughput mode; DP_ASYNC_UPLOAD=0 turns them off, =1 forces them for single proofs too): small
+  // host-to-device copies take successive slots of the bulk staging area and are not waited for — like descriptors, the slots
+  // are recycled when the host observes a later publication of this stream (everything launched before it has run). Otherwise
+  // every upload costs a copy launch, a publish launch and a device wait (~29 per Dense-4M proof). The slot arithmetic uses
+  // ASYNC_STAGE, not the context's own staging size: the members of a cohort (the model's context has a larger staging buffer
+  // than the batch workers) must take the same decisions, or the cohort falls out of step.
   size_t stage_off_ = 0;
-  bool async_upload_ = getenv("DP_ASYNC_UPLOAD") && atoi(getenv("DP_ASYNC_UPLOAD"));
+  int async_upload_env_ = [] { const char* e = getenv("DP_ASYNC_UPLOAD"); return e ? atoi(e) : -1; }();
+  bool async_upload_now() const { return async_upload_env_ < 0 ? throughput_mode_ : async_upload_env_ != 0; }
+  static constexpr size_t ASYNC_STAGE = size_t(12) << 20, ASYNC_MAX = size_t(2) << 20;
   static constexpr size_t RES_WORDS = 1 << 16;
   size_t STAGE_BYTES = size_t(64) << 20;  // bulk staging of this context (workers of a batch get less: stage_bytes of the constructor)
   static constexpr size_t DESC_BYTES = 4 << 20;
@@ -2685,20 +2711,21 @@ class HipDev : public Dev {
         ex[((size_t)k * (SC_MAXK + 1) + at) * (SC_MAXK + 1) + i] = extrapolation_coeffs(k, at)[i];
       HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_extrap), ex.data(), ex.size() * 8)); }
     { double ts = getenv("DP_POLL_TIMEOUT_S") ? std::max(0.001, atof(getenv("DP_POLL_TIMEOUT_S"))) : 20.0; unsigned long long tk = (unsigned long long)(ts * 1e8); HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_poll_timeout_ticks), &tk, sizeof(tk))); }
+    { int sk = getenv("DP_DEBUG_SKIP_HASH") ? atoi(getenv("DP_DEBUG_SKIP_HASH")) : 0; if (sk) HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_dbg_skip_hash), &sk, sizeof(int))); }
     { int ps = getenv("DP_POLL_SLEEP") ? std::max(0, atoi(getenv("DP_POLL_SLEEP"))) : 1; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_poll_sleep), &ps, sizeof(int))); }
-    DP_SET_LDS((k_sc_persist_lds<false>), 1024, (int)SC_LDS_MAX);
-    DP_SET_LDS((k_sc_persist_lds<true>), 1024, (int)SC_LDS_MAX);
+    DP_SET_LDS_ONE((k_sc_persist_lds<false>), 1024, (int)SC_LDS_MAX);
+    DP_SET_LDS_ONE((k_sc_persist_lds<true>), 1024, (int)SC_LDS_MAX);
     excl_ = (getenv("DP_NO_EXCLUSIVE_CU") && atoi(getenv("DP_NO_EXCLUSIVE_CU"))) ? 0 : EXCL_LDS;
-    DP_SET_LDS((k_sc_persist<false>), 1024, (int)EXCL_LDS);
-    DP_SET_LDS((k_sc_persist<true>), 1024, (int)EXCL_LDS);
-    DP_SET_LDS((k_sc_small<false>), 1024, (int)EXCL_LDS);
-    DP_SET_LDS((k_sc_small<true>), 1024, (int)EXCL_LDS);
-    DP_SET_LDS(k_merkle_tail, 1024, (int)EXCL_LDS);
-    if (devlogup_ || devlogup_full_) DP_SET_LDS(k_logup_tail, 1024, (int)EXCL_LDS);
-    if (devclassic_) DP_SET_LDS(k_classic_tail, 1024, (int)EXCL_LDS);
-    if (devdense_) DP_SET_LDS(k_dense_tail, 1024, (int)EXCL_LDS);
-    if (deveqsum_) DP_SET_LDS(k_eqsum_tail, 1024, (int)EXCL_LDS);
-    if (devcommit_) DP_SET_LDS(k_commit_tail, 1024, (int)EXCL_LDS);
+    DP_SET_LDS_ONE((k_sc_persist<false>), 1024, (int)EXCL_LDS);
+    DP_SET_LDS_ONE((k_sc_persist<true>), 1024, (int)EXCL_LDS);
+    DP_SET_LDS_ONE((k_sc_small<false>), 1024, (int)EXCL_LDS);
+    DP_SET_LDS_ONE((k_sc_small<true>), 1024, (int)EXCL_LDS);
+    DP_SET_LDS_ONE(k_merkle_tail, 1024, (int)EXCL_LDS);
+    if (devlogup_ || devlogup_full_) DP_SET_LDS_ONE(k_logup_tail, 1024, (int)EXCL_LDS);
+    if (devclassic_) DP_SET_LDS_ONE(k_classic_tail, 1024, (int)EXCL_LDS);
+    if (devdense_) DP_SET_LDS_ONE(k_dense_tail, 1024, (int)EXCL_LDS);
+    if (deveqsum_) DP_SET_LDS_ONE(k_eqsum_tail, 1024, (int)EXCL_LDS);
+    if (devcommit_) DP_SET_LDS_ONE(k_commit_tail, 1024, (int)EXCL_LDS);
     DP_SET_LDS(k_med_prepare, 1024, 128 * 1024);
     DP_SET_LDS(k_med_ntt_local, 1024, 64 * 1024);
   }
@@ -2716,7 +2743,25 @@ class HipDev : public Dev {
   const char* name() const override { return name_.c_str(); }
   size_t arena_peak() const { return arena_peak_; }
   void arena_peak_reset() { arena_peak_ = arena_off_; }
-  void set_latency_mode(bool on) { multi_ = on && persist_flag_env("DP_NO_MULTI"); devfs_ = devfs_env_ < 0 ? !on : devfs_env_ != 0; }
+  // Poseidon2 compress() per second of the one-node-per-lane Merkle kernel on `nodes` nodes (chip-filling when nodes >> 458 752
+  // = 256 CUs x 28 waves x 64 lanes): the VALU-integer peak bench.py prices the whole job's hashing against, measured with
+  // HIP events on this context's stream in the same run. The input is whatever the arena holds: the arithmetic is branch-free.
+  double probe_compress_rate(size_t nodes, int reps) {
+    DP_REQUIRE(!co_ && nodes >= 1024 && reps >= 1, DP_ERR_ARG, "probe: bad arguments");
+    const size_t mk = mark();
+    DBuf in = alloc(8 * nodes, false), out = alloc(4 * nodes, false);
+    nb_ = 0; DPL(k_zero_words, dim3(grid_for(8 * nodes)), dim3(TPB), (u64*)in.p, 8 * nodes);
+    hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+    nb_ = 96.0 * nodes; DPL(k_merkle_layer, dim3(grid_for(nodes, 4096)), dim3(TPB), (const u64*)in.p, (u64*)out.p, nodes);
+    HIP_CHECK(hipEventRecord(a, s_));
+    for (int r = 0; r < reps; r++) { nb_ = 96.0 * nodes; DPL(k_merkle_layer, dim3(grid_for(nodes, 4096)), dim3(TPB), (const u64*)in.p, (u64*)out.p, nodes); }
+    HIP_CHECK(hipEventRecord(b, s_)); HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a); hipEventDestroy(b);
+    release(mk);
+    return ms > 0 ? (double)nodes * reps / (ms * 1e-3) : 0.0;
+  }
+  void set_latency_mode(bool on) { multi_ = on && persist_flag_env("DP_NO_MULTI"); devfs_ = devfs_env_ < 0 ? !on : devfs_env_ != 0; throughput_mode_ = !on; }
   void dump_host_stats() {
     if (!g_host_stats) return;
     fprintf(stderr, "[dp timing] device context: %zu launches, %.1f us of host time per launch (%.1f ms total), %zu device waits, %zu fiber yields; host work between waits %.1f ms, inside waits %.1f ms\n", nlaunch_, nlaunch_ ? launch_us_ / nlaunch_ : 0.0, launch_us_ / 1000.0, nwait_, nyield_, work_us_ / 1000.0, waitlat_us_ / 1000.0);
@@ -2775,9 +2820,9 @@ class HipDev : public Dev {
   // A cohort member moves data with kernels (k_copy_words through the mapped staging buffer, k_zero_words): a memcpy
   // command queued by one member would overtake the merged launches its cohort has not fired yet.
   void h2d(void* dst, const void* src, size_t bytes) {
-    if (async_upload_ && zerocopy_ && bytes > 0 && bytes % 8 == 0 && bytes <= STAGE_BYTES / 4) {
+    if (async_upload_now() && zerocopy_ && bytes > 0 && bytes % 8 == 0 && bytes <= ASYNC_MAX && STAGE_BYTES >= ASYNC_STAGE) {
       const size_t need = (bytes + 255) & ~size_t(255);
-      if (stage_off_ + need > STAGE_BYTES) { stream_wait(); stage_off_ = 0; }
+      if (stage_off_ + need > ASYNC_STAGE) { stream_wait(); stage_off_ = 0; }
       char* slot = bulk_stage() + stage_off_;
       memcpy(slot, src, bytes);
       if (co_) { nb_ = 0; DPL(k_copy_words, dim3(grid_for(bytes / 8, 256)), dim3(TPB), (u64*)dst, (const u64*)(hstage_dev_ + DESC_BYTES + stage_off_), bytes / 8); }
@@ -3002,8 +3047,8 @@ class HipDev : public Dev {
     unsigned long long seq = ++seq_;
     size_t work = (size_t)nterms * (n_after / 2) + (size_t)nt * n_after / 4;
     int threads = persist_threads(work);
-    if (in_lds) { nb_ = tab_bytes; DPL_LDS_HI(k_sc_persist_lds, hi, dim3(1), dim3(threads), std::max(lds, excl_now()), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
-    else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_LDS_HI(k_sc_persist, hi, dim3(1), dim3(threads), excl_now(), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
+    if (in_lds) { nb_ = tab_bytes; DPL_ONE_HI(k_sc_persist_lds, hi, dim3(1), threads, lds, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
+    else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_ONE_HI(k_sc_persist, hi, dim3(1), threads, 0, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
     wait_flag(seq, nwords);
     const u64* w = hres_;
     for (unsigned q = 0; q < rounds; q++) {
@@ -3043,7 +3088,7 @@ class HipDev : public Dev {
     logup_tail_fill(d, a, ch, *this);
     const unsigned long long seq = ++seq_;
     nb_ = 0; for (const LogupCircuitDev& c : *a.circuits) for (const DBuf& l : c.den) nb_ += 2.0 * 16.0 * (double)l.n;
-    DPL_LDS(k_logup_tail, dim3(1), dim3(1024), excl_now(), dd, (u64*)hres_dev_, hflag_dev_, seq);
+    DPL_ONE(k_logup_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
     logup_tail_parse(hres_, a, blocks, ch, layer_msgs, layer_points, round_evals, point);
     release(mk);
@@ -3065,7 +3110,7 @@ class HipDev : public Dev {
     memcpy((void*)d, &fill, sizeof(CommitTailDesc));
     const unsigned long long seq = ++seq_;
     nb_ = 16.0 * (double)a.folded.n * 2.0 + 32.0 * (double)a.sum_evals.n;
-    DPL_LDS(k_commit_tail, dim3(1), dim3(1024), excl_now(), dd, (u64*)hres_dev_, hflag_dev_, seq);
+    DPL_ONE(k_commit_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
     commit_tail_parse(hres_, a, ch, trees, out);
     return true;
@@ -3085,7 +3130,7 @@ class HipDev : public Dev {
     eqsum_tail_fill(d, jobs, njobs, tabs, ntabs, terms, coeffs, nterms, nv, md, ch, *this);
     const unsigned long long seq = ++seq_;
     nb_ = 0; for (int i = 0; i < ntabs; i++) nb_ += (double)tabs[i].bytes();
-    DPL_LDS(k_eqsum_tail, dim3(1), dim3(1024), excl_now(), dd, (u64*)hres_dev_, hflag_dev_, seq);
+    DPL_ONE(k_eqsum_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
     eqsum_tail_parse(hres_, ntabs, nv, md, ch, out);
     release(mk);
@@ -3104,7 +3149,7 @@ class HipDev : public Dev {
     dense_tail_fill(d, bias, W, R, C, in, pt, ch, *this);
     const unsigned long long seq = ++seq_;
     nb_ = 8.0 * (double)R * (double)C + 16.0 * (double)R + 16.0 * (double)C * 4.0;
-    DPL_LDS(k_dense_tail, dim3(1), dim3(1024), excl_now(), dd, (u64*)hres_dev_, hflag_dev_, seq);
+    DPL_ONE(k_dense_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
     dense_tail_parse(hres_, C, ch, out);
     release(mk);
@@ -3123,7 +3168,7 @@ class HipDev : public Dev {
     classic_tail_fill(d, a, ch, *this);
     const unsigned long long seq = ++seq_;
     nb_ = 0; for (int i = 0; i < a.np; i++) nb_ += a.fs[i].bytes() + a.eqs[i].bytes();
-    DPL_LDS(k_classic_tail, dim3(1), dim3(1024), excl_now(), dd, (u64*)hres_dev_, hflag_dev_, seq);
+    DPL_ONE(k_classic_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
     classic_tail_parse(hres_, a, ch, msgs, challenges);
     release(mk);
@@ -3146,7 +3191,7 @@ class HipDev : public Dev {
     logup_full_fill(d, cols, cpi, ninst, mult, c, chi, ch, *this);
     const unsigned long long seq = ++seq_;
     nb_ = (double)ninst * (8.0 * cpi * n + 16.0 * 3 * n) * 2.0;
-    DPL_LDS(k_logup_tail, dim3(1), dim3(1024), excl_now(), dd, (u64*)hres_dev_, hflag_dev_, seq);
+    DPL_ONE(k_logup_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
     logup_full_parse(hres_, n, cpi, ninst, !mult.null(), blocks, ch, out);
     release(mk);
@@ -3223,7 +3268,7 @@ class HipDev : public Dev {
       sess_.active = true; sess_.multi = true; sess_.G = G; sess_.rounds_a = rounds_a; sess_.folds = 0; sess_.slot_words = 2 * nraw;
       sess_.ntabs = nt; sess_.n = n_in; sess_.n0 = n_in; sess_.seq = seq_;
       seq_ += (unsigned)rounds_a;  // one publication per round of the phase
-      nb_ = bytes; DPL_HI(k_sc_persist, hi, dim3(G), dim3(1024), a, (Ext*)hres_dev_, hmflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr);
+      nb_ = bytes; if (hi) { DPL_B((k_sc_persist<true>), 1024, KF_CLAIM, dim3(G), dim3(1024), 0, a, (Ext*)hres_dev_, hmflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); } else { DPL_B((k_sc_persist<false>), 1024, KF_CLAIM, dim3(G), dim3(1024), 0, a, (Ext*)hres_dev_, hmflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }  // (latency mode only: G whole-CU workgroups)
       wait_flags_multi(++sess_.seq, 2 * nraw, G, sess_.slot_words);
       read_shares(G, sess_.slot_words);
       return;
@@ -3260,8 +3305,8 @@ class HipDev : public Dev {
       double tab_bytes = 0; for (int i = 0; i < nt; i++) tab_bytes += (double)n_in * (tabs[i].ext && !r ? 16.0 : tabs[i].ext ? 16.0 : 8.0);
       // algorithmic HBM bytes of the launch: every table is read once (the LDS variant never touches HBM again; the
       // global variant also writes and re-reads the halving ping-pong buffers: + 3 x 16 B x n/2 per table in total)
-      if (lds <= SC_LDS_MAX) { nb_ = tab_bytes; DPL_LDS_HI(k_sc_persist_lds, hi, dim3(1), dim3(threads), std::max(lds, excl_now()), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }
-      else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_LDS_HI(k_sc_persist, hi, dim3(1), dim3(threads), excl_now(), a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }
+      if (lds <= SC_LDS_MAX) { nb_ = tab_bytes; DPL_ONE_HI(k_sc_persist_lds, hi, dim3(1), threads, lds, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }
+      else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_ONE_HI(k_sc_persist, hi, dim3(1), threads, 0, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }
       wait_flag(++sess_.seq, 2 * nraw);
       if (r) for (int i = 0; i < nt; i++) { tabs[i].p = sess_.a[i]; tabs[i].n = n_after; tabs[i].ext = true; }
       read_terms();
@@ -3281,7 +3326,7 @@ class HipDev : public Dev {
       unsigned long long seq = ++seq_;
       size_t work = (size_t)nterms * (n_after / 2) + (r ? (size_t)nt * n_after / 4 : 0);
       int threads = persist_threads(work);
-      nb_ = bytes; DPL_LDS_HI(k_sc_small, hi, dim3(1), dim3(threads), excl_now(), a, (Ext*)hres_dev_, hflag_dev_, seq);
+      nb_ = bytes; DPL_ONE_HI(k_sc_small, hi, dim3(1), threads, 0, a, (Ext*)hres_dev_, hflag_dev_, seq);
       wait_flag(seq, 2 * nraw);
       read_terms();
       return;
@@ -3306,8 +3351,8 @@ class HipDev : public Dev {
         Ext* partial = (Ext*)arena_alloc((size_t)g * 4 * 16);
         nb_ = bytes;
         const bool skip1 = claim_hint_ != nullptr;
-        #define LAUNCH_FUSED2(KK, BB) do { if (skip1) DPL_B((k_sc_fused<KK, BB, true>), 256, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial); \
-                                           else DPL_B((k_sc_fused<KK, BB, false>), 256, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial); } while (0)
+        #define LAUNCH_FUSED2(KK, BB) do { if (skip1) DPL_B((k_sc_fused<KK, BB, true>), 256, KF_NONE, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial); \
+                                           else DPL_B((k_sc_fused<KK, BB, false>), 256, KF_NONE, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial); } while (0)
         #define LAUNCH_FUSED(KK) do { if (base) LAUNCH_FUSED2(KK, true); else LAUNCH_FUSED2(KK, false); } while (0)
         if (nt == 1) LAUNCH_FUSED(1); else if (nt == 2) LAUNCH_FUSED(2); else LAUNCH_FUSED(3);
         #undef LAUNCH_FUSED
@@ -3433,11 +3478,11 @@ class HipDev : public Dev {
   void tails_to_host(const TailDesc* dd, size_t nd) {
     if (nd == 1 && zerocopy_) {
       unsigned long long seq = ++seq_;
-      nb_ = 0; DPL_LDS(k_merkle_tail, dim3(1), dim3(1024), excl_now(), dd, dres_, hres_dev_, hflag_dev_, seq);
+      nb_ = 0; DPL_ONE(k_merkle_tail, dim3(1), 1024, 0, dd, dres_, hres_dev_, hflag_dev_, seq);
       wait_flag(seq, 4);
       return;
     }
-    nb_ = 0; DPL_LDS(k_merkle_tail, dim3((unsigned)nd), dim3(tail_many_threads_), tail_many_excl_ ? excl_now() : size_t(0), dd, dres_, (u64*)nullptr, (unsigned long long*)nullptr, 0ull);
+    nb_ = 0; if (!shared_now() && !tail_many_excl_) { DPL_B(k_merkle_tail, 1024, KF_NONE, dim3((unsigned)nd), dim3(tail_many_threads_), 0, dd, dres_, (u64*)nullptr, (unsigned long long*)nullptr, 0ull); } else DPL_ONE(k_merkle_tail, dim3((unsigned)nd), tail_many_threads_, 0, dd, dres_, (u64*)nullptr, (unsigned long long*)nullptr, 0ull);
     fetch(4 * nd);
   }
   // layers of at most this many digests are finished by k_merkle_tail (one workgroup, no relaunch between layers); wider
@@ -3598,8 +3643,8 @@ class HipDev : public Dev {
       size_t mk = mark();
       if (!trivial) {
         size_t lds = 3 * n * (e0.ext ? 16 : 8);
-        if (e0.ext) { nb_ = g * 64.0 * n; DPL_B((k_commit_small<true>), 256, dim3((unsigned)g), dim3(256), lds, dd, nv, L_, (const u64*)tw_, (const u64*)pow7_); }
-        else { nb_ = g * 32.0 * n; DPL_B((k_commit_small<false>), 256, dim3((unsigned)g), dim3(256), lds, dd, nv, L_, (const u64*)tw_, (const u64*)pow7_); }
+        if (e0.ext) { nb_ = g * 64.0 * n; DPL_B((k_commit_small<true>), 256, KF_NONE, dim3((unsigned)g), dim3(256), lds, dd, nv, L_, (const u64*)tw_, (const u64*)pow7_); }
+        else { nb_ = g * 32.0 * n; DPL_B((k_commit_small<false>), 256, KF_NONE, dim3((unsigned)g), dim3(256), lds, dd, nv, L_, (const u64*)tw_, (const u64*)pow7_); }
       }
       if (e0.ext) { nb_ = g * 32.0 * nleaves; DPL(k_merkle_leaves_many<true>, dim3(grid_for(nleaves / 2, 64), (unsigned)g), dim3(TPB), dd, nleaves / 2); }
       else { nb_ = g * 24.0 * nleaves; DPL(k_merkle_leaves_many<false>, dim3(grid_for(nleaves / 2, 64), (unsigned)g), dim3(TPB), dd, nleaves / 2); }
@@ -3749,6 +3794,7 @@ void hip_dev_cohort_attach(Dev* d, Cohort* c) { static_cast<HipDev*>(d)->cohort_
 void hip_dev_cohort_detach(Dev* d) { static_cast<HipDev*>(d)->cohort_detach(); }
 void hip_dev_dump_sc_debug(Dev* d) { static_cast<HipDev*>(d)->dump_sc_debug(); }
 size_t hip_dev_arena_peak(Dev* d) { return static_cast<HipDev*>(d)->arena_peak(); }
+double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps) { return static_cast<HipDev*>(d)->probe_compress_rate(nodes, reps); }
 void hip_dev_arena_peak_reset(Dev* d) { static_cast<HipDev*>(d)->arena_peak_reset(); }
 // free / total bytes of the device's HBM: dp_model_prove_batch sizes the number of proofs in flight against it
 void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes) { HIP_CHECK(hipSetDevice(device)); HIP_CHECK(hipMemGetInfo(free_bytes, total_bytes)); }

@@ -47,6 +47,10 @@ const char* dp_ctx_name(const dp_ctx* ctx);
  * dp_profile_report returns a malloc'ed JSON array [{"kernel","launches","total_ms","alg_bytes"}...]; free with dp_free. */
 int32_t dp_profile_enable(dp_ctx* ctx, int32_t on);
 int32_t dp_profile_report(dp_ctx* ctx, char** json);
+/* Poseidon2 compress() (poseidon/src/poseidon_hash.rs:65-70, two permutations) per second of the Merkle-layer kernel on a
+ * layer of `nodes` nodes, HIP-event timed on the ctx's stream: the VALU-integer peak of the chip for the hash the whole
+ * protocol is made of (bench.py prices the job's hashing against it). */
+int32_t dp_probe_compress_rate(dp_ctx* ctx, size_t nodes, int32_t reps, double* per_second);
 
 /* ---- tables: DenseMultilinearExtension{evaluations: FieldType::{Base,Ext}} (multilinear_extensions/src/mle.rs:137-181) */
 /* Fieldizer::to_field on i64 (zkml/src/quantization/mod.rs:210-220), done on device */
@@ -157,7 +161,7 @@ int32_t dp_model_prove(dp_model* m, const int64_t* input, size_t ninput, uint64_
  * flight on the model's GPU: every in-flight proof has its own HIP stream, arena and host<->device mailbox; the model
  * commitments are shared read-only. A single proof is a chain of ~10^3 sequential Fiat-Shamir round trips that cannot
  * fill an MI355X, so this is how one GPU is saturated (and how BASELINE config 4, a batch of independent proofs, is
- * served). The proofs in flight are grouped into cohorts of DP_COHORT (default 8) proofs that run in lock step: launch
+ * served). The proofs in flight are grouped into cohorts of DP_COHORT (default 12) proofs that run in lock step: launch
  * number i of all members of a cohort is ONE kernel launch (blockIdx.z = proof) on the cohort's stream. The proofs are
  * driven by min(#cohorts, DP_HOST_THREADS or dp_host_cpu_budget() - 2) host threads; a thread runs its proofs as
  * cooperative fibers and switches proof at every device wait. `concurrency` is a cap: worker arenas are sized from the

@@ -8,6 +8,43 @@ import json, os, subprocess, sys, time
 CONFIGS = [  # (name, proofs in flight, env) — in order of importance: the sweep stops when its time budget is spent
     ("base_192", 192, {}),
     ("base_256", 256, {}),
+    # round 2: one-workgroup kernels shared (256 threads, no CU reservation, raised wave priority) vs whole-CU workgroups
+    ("excl_192", 192, {"DP_SHARED_TAILS": "0"}),
+    ("cohort8_256", 256, {"DP_COHORT": "8"}),
+    ("noasync_256", 256, {"DP_ASYNC_UPLOAD": "0"}),
+    ("fuse4_256", 256, {"DP_MERKLE_FUSE": "4"}),
+    ("tailmax2048_256", 256, {"DP_TAIL_MAX": "2048"}),
+    ("fuse4_tailmax2048_256", 256, {"DP_MERKLE_FUSE": "4", "DP_TAIL_MAX": "2048"}),
+    ("fuse4_tailmax1024_256", 256, {"DP_MERKLE_FUSE": "4", "DP_TAIL_MAX": "1024"}),
+    ("fuse8_tailmax2048_256", 256, {"DP_MERKLE_FUSE": "8", "DP_TAIL_MAX": "2048"}),
+    ("cohort16_fuse4_tailmax2048_256", 256, {"DP_COHORT": "16", "DP_MERKLE_FUSE": "4", "DP_TAIL_MAX": "2048"}),
+    ("cohort12_256", 256, {"DP_COHORT": "12"}),
+    ("cohort16_t16_256", 256, {"DP_COHORT": "16", "DP_HOST_THREADS": "16"}),
+    ("cohort24_256", 256, {"DP_COHORT": "24"}),
+    ("shared512_256", 256, {"DP_SHARED_THREADS": "512"}),
+    ("shared128_256", 256, {"DP_SHARED_THREADS": "128"}),
+    ("cohort32_256", 256, {"DP_COHORT": "32"}),
+    ("cohort64_256", 256, {"DP_COHORT": "64"}),
+    ("cohort32_256_t8", 256, {"DP_COHORT": "32", "DP_HOST_THREADS": "8"}),
+    ("cohort16_256_q16", 256, {"DP_COHORT": "16", "GPU_MAX_HW_QUEUES": "16"}),
+    ("cohort128_256", 256, {"DP_COHORT": "128"}),
+    ("skiphash_256", 256, {"DP_DEBUG_SKIP_HASH": "1"}),  # timing experiment: wide Merkle layers without the Poseidon2 work (proofs do not verify)
+    ("skiphash_192", 192, {"DP_DEBUG_SKIP_HASH": "1"}),
+    ("threads7_256", 256, {"DP_HOST_THREADS": "7"}),
+    # wide kernels capped to a few workgroups per CU (grid-stride loops): do free wave slots shorten the queueing of the small kernels?
+    ("maxgrid32_256", 256, {"DP_MAX_GRID": "32"}),
+    ("maxgrid64_256", 256, {"DP_MAX_GRID": "64"}),
+    ("maxgrid128_256", 256, {"DP_MAX_GRID": "128"}),
+    ("maxgrid256_256", 256, {"DP_MAX_GRID": "256"}),
+    ("maxgrid64_lp256_256", 256, {"DP_MAX_GRID": "64", "DP_MERKLE_LP_MAX": "256"}),
+    ("lp256_256", 256, {"DP_MERKLE_LP_MAX": "256"}),
+    ("lp1024_256", 256, {"DP_MERKLE_LP_MAX": "1024"}),
+    ("shared128_192", 192, {"DP_SHARED_THREADS": "128"}),
+    ("shared512_192", 192, {"DP_SHARED_THREADS": "512"}),
+    ("shared1024_192", 192, {"DP_SHARED_THREADS": "1024"}),
+    ("shared_cohort16_256", 256, {"DP_COHORT": "16"}),
+    ("shared_cohort4_192", 192, {"DP_COHORT": "4"}),
+    ("shared_nofused_192", 192, {"DP_DEVICE_LOGUP": "0", "DP_DEVICE_CLASSIC": "0", "DP_DEVICE_DENSE": "0", "DP_DEVICE_EQSUM": "0", "DP_DEVICE_COMMIT": "0"}),
     # k_logup_tail: written after round 1's GPU budget ran out, validated on the CPU SIMT emulator only (tests/test_kernel_emul.py)
     ("devlogup_tail_192", 192, {"DP_DEVICE_LOGUP": "1"}),   # the layer loop of every logup proof in one launch
     ("devlogup_full_192", 192, {"DP_DEVICE_LOGUP": "2"}),   # the whole logup proof (trees, outputs, layers, column claims) in one launch
@@ -59,7 +96,8 @@ def one(wl, conc):
     mb = getattr(dpa.models, wl)()
     ctx = dpa.Context.generate(dev, mb.blob())
     pr = dpa.Prover(ctx)
-    xs = np.stack([mb.input(3000 + i) for i in range(2 * conc)])
+    waves = int(os.environ.get("KNOB_WAVES", "2"))  # proofs per measured batch = waves x in flight
+    xs = np.stack([mb.input(3000 + i) for i in range(waves * conc)])
     single, out0 = pr.prove(xs[0])
     t0 = time.perf_counter(); pr.prove(xs[0]); lat = time.perf_counter() - t0
     pr.prove_batch(xs[:conc], conc)
@@ -68,7 +106,7 @@ def one(wl, conc):
         t0 = time.perf_counter(); proofs, outs, _ = pr.prove_batch(xs, conc); dt = time.perf_counter() - t0
         best = max(best, len(xs) / dt)
     ok = proofs[0].size == single.size and bool((proofs[0] == single).all())
-    rec = {"proofs_per_s": round(best, 2), "in_flight": pr.in_flight(), "latency_ms": round(1000 * lat, 2), "batch0_equals_single": ok}
+    rec = {"proofs_per_s": round(best, 2), "waves": waves, "in_flight": pr.in_flight(), "latency_ms": round(1000 * lat, 2), "batch0_equals_single": ok}
     if not ok:  # where the experimental path leaves the validated one: first differing word of the canonical stream
         n = min(proofs[0].size, single.size)
         d = np.nonzero(proofs[0][:n] != single[:n])[0]

@@ -58,6 +58,36 @@ def main():
             if q not in qs and acc >= q * tot:
                 qs[q] = k
     print("exclusive workgroups resident (trace timestamps): p50 %s  p90 %s  p99 %s  max %s" % (qs.get(0.5), qs.get(0.9), qs.get(0.99), max(hist) if hist else 0))
+    # --- round 2: where does a cohort's chain spend its time? (second half of every queue = the measured batch)
+    import collections, statistics
+    import numpy as np
+    half = []
+    for q in sorted(set(r[7] for r in kc)):
+        rq = [r for r in kc if r[7] == q]
+        half += rq[len(rq) // 2:]
+    nq = len(set(r[7] for r in half))
+    gap = 0
+    for q in set(r[7] for r in half):
+        rq = [r for r in half if r[7] == q]
+        gap += sum(max(0, b[1] - a[2]) for a, b in zip(rq, rq[1:]))
+    span_q = sum(max(r[2] for r in half if r[7] == q) - min(r[1] for r in half if r[7] == q) for q in set(r[7] for r in half)) / nq
+    print(f"measured batch: {len(half) // nq} launches per queue, queue span {span_q / 1e6:.1f} ms, host gaps {gap / nq / 1e6:.1f} ms per queue")
+    cls = collections.defaultdict(lambda: [0, 0.0])
+    for r in half:
+        k = short(r[0])[3:]
+        c = "one-workgroup tails" if any(t in k for t in ("_tail", "sc_persist", "sc_small")) else "merkle layers" if "merkle_layer" in k else "other"
+        cls[c][0] += 1; cls[c][1] += (r[2] - r[1]) / 1e6
+    for c, (cnt, ms) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
+        print(f"   {c:22s} {cnt / nq:6.1f} launches  {ms / nq:8.1f} ms per queue")
+    starts = np.array(sorted(r[1] for r in kc)); ends = np.array(sorted(r[2] for r in kc))
+    small = [r for r in half if short(r[0]) in ("kc:k_publish", "kc:k_copy_words", "kc:k_fold", "kc:k_reduce_publish", "kc:k_bf_msg", "kc:k_fri_fold")]
+    by = collections.defaultdict(list)
+    for r in small:
+        act = int(np.searchsorted(starts, r[1], "right") - np.searchsorted(ends, r[1], "right"))
+        by[min(28, act) // 4 * 4].append((r[2] - r[1]) / 1e3)
+    print("duration of the SMALL kernels (publish, copy_words, fold, ...) by the number of kernels active on all queues when they start:")
+    for k in sorted(by):
+        print(f"   ~{k:2d} active: n = {len(by[k]):5d}  median {statistics.median(by[k]):8.1f} us")
     if "--sequence" in sys.argv:
         q = kc[-1][7]
         seq = [r for r in kc if r[7] == q]
