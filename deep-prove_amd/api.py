@@ -234,9 +234,7 @@ def prove_parallel(dev, vpoly, transcript):
     nt = len(vpoly.tables)
     tabs = (vp * nt)(*[t.h for t in vpoly.tables])
     deg = np.array([len(ix) for _, ix in vpoly.terms], dtype=np.int32)
-    tt = np.zeros(3 * len(vpoly.terms), dtype=np.int32)
-    for i, (_, ix) in enumerate(vpoly.terms):
-        tt[3 * i:3 * i + len(ix)] = ix
+    tt = np.array([j for _, ix in vpoly.terms for j in ix], dtype=np.int32)  # ragged: the terms' table lists back to back
     co = np.array([w for c, _ in vpoly.terms for w in c], dtype=np.uint64)
     pw, pn = u64p(), C.c_size_t()
     finals = np.zeros(2 * nt, dtype=np.uint64)

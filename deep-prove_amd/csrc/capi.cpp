@@ -13,7 +13,12 @@ DP_FIBER_SWITCH_ASM
 namespace dp { struct Cohort; Cohort* hip_cohort_new(); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
 using namespace dp;
 
-struct dp_ctx { Dev* dev; int device_id; };
+// `mu`: PCS::commit is called from rayon workers in the reference (zkml/src/commit/context.rs:79-103 into_par_iter over
+// nodes, activation.rs:294-304 over columns): the entry points a host would call that way (uploads, commit, frees) take the
+// context's lock and bind the device to the calling thread — the device work of one context is one stream, so concurrent
+// callers are queued, not run in parallel.
+struct dp_ctx { Dev* dev; int device_id; std::recursive_mutex mu; };
+struct CtxLock { std::unique_lock<std::recursive_mutex> l; explicit CtxLock(dp_ctx* c) : l(c->mu) { c->dev->bind_thread(); } };
 struct dp_buf { DBuf b; };
 struct dp_transcript { Transcript t; };
 struct dp_commit { DevCommit c; };
@@ -50,7 +55,7 @@ const char* dp_last_error(void) { return g_err.c_str(); }
 void dp_free(void* p) { free(p); }
 
 int32_t dp_ctx_create(int32_t device_id, dp_ctx** out) {
-  return guard([&] { DP_REQUIRE(out, DP_ERR_ARG, "null out"); Dev* d = make_hip_dev(device_id); *out = new dp_ctx{d, device_id}; });
+  return guard([&] { DP_REQUIRE(out, DP_ERR_ARG, "null out"); Dev* d = make_hip_dev(device_id); dp_ctx* c = new dp_ctx(); c->dev = d; c->device_id = device_id; *out = c; });
 }
 int32_t dp_ctx_destroy(dp_ctx* ctx) { return guard([&] { if (ctx) { delete ctx->dev; delete ctx; } }); }
 const char* dp_ctx_name(const dp_ctx* ctx) { return ctx ? ctx->dev->name() : ""; }
@@ -63,19 +68,20 @@ int32_t dp_probe_compress_rate(dp_ctx* ctx, size_t nodes, int32_t reps, double* 
   return guard([&] { DP_REQUIRE(ctx && per_second, DP_ERR_ARG, "bad arguments"); *per_second = hip_dev_probe_compress_rate(ctx->dev, nodes, reps); });
 }
 int32_t dp_buf_from_i64(dp_ctx* ctx, const int64_t* v, size_t n, dp_buf** out) {
-  return guard([&] { DP_REQUIRE(ctx && v && out && n, DP_ERR_ARG, "bad arguments"); DBuf b = ctx->dev->alloc_persistent(n, false); ctx->dev->upload_i64(b, v); *out = new dp_buf{b}; });
+  return guard([&] { DP_REQUIRE(ctx && v && out && n, DP_ERR_ARG, "bad arguments"); CtxLock lk(ctx); DBuf b = ctx->dev->alloc_persistent(n, false); ctx->dev->upload_i64(b, v); *out = new dp_buf{b}; });
 }
 int32_t dp_buf_upload(dp_ctx* ctx, const uint64_t* words, size_t n, int32_t is_ext, dp_buf** out) {
   return guard([&] {
     DP_REQUIRE(ctx && words && out && n, DP_ERR_ARG, "bad arguments");
     for (size_t i = 0; i < n * (is_ext ? 2 : 1); i++) DP_REQUIRE(words[i] < GL_P, DP_ERR_ARG, "non-canonical field element");
+    CtxLock lk(ctx);
     DBuf b = ctx->dev->alloc_persistent(n, is_ext != 0); ctx->dev->upload(b, words); *out = new dp_buf{b};
   });
 }
-int32_t dp_buf_download(dp_ctx* ctx, const dp_buf* buf, uint64_t* o) { return guard([&] { DP_REQUIRE(ctx && buf && o, DP_ERR_ARG, "bad arguments"); ctx->dev->download(buf->b, o); }); }
+int32_t dp_buf_download(dp_ctx* ctx, const dp_buf* buf, uint64_t* o) { return guard([&] { DP_REQUIRE(ctx && buf && o, DP_ERR_ARG, "bad arguments"); CtxLock lk(ctx); ctx->dev->download(buf->b, o); }); }
 size_t dp_buf_len(const dp_buf* buf) { return buf ? buf->b.n : 0; }
 int32_t dp_buf_is_ext(const dp_buf* buf) { return buf && buf->b.ext; }
-int32_t dp_buf_free(dp_ctx* ctx, dp_buf* buf) { return guard([&] { DP_REQUIRE(ctx || !buf, DP_ERR_ARG, "dp_buf_free: null context"); if (buf) { ctx->dev->free_persistent(buf->b); delete buf; } }); }
+int32_t dp_buf_free(dp_ctx* ctx, dp_buf* buf) { return guard([&] { DP_REQUIRE(ctx || !buf, DP_ERR_ARG, "dp_buf_free: null context"); if (buf) { CtxLock lk(ctx); ctx->dev->free_persistent(buf->b); delete buf; } }); }
 
 dp_transcript* dp_transcript_new(const char* label) { dp_transcript* t = new dp_transcript(); if (label) t->t.append_message(label); return t; }
 void dp_transcript_free(dp_transcript* t) { delete t; }
@@ -117,21 +123,33 @@ int32_t dp_mle_fix_high(dp_ctx* ctx, const dp_buf* m, size_t rows, size_t cols, 
   });
 }
 
+// (tables, ragged term lists) -> DevVP: `finals` follow the caller's table order, so every table enters in that order first
+static void read_terms(DevVP& vp, const dp_buf* const* tables, int32_t ntables, const int32_t* term_degree, const int32_t* term_tables, int32_t nterms, const uint64_t* term_coeffs) {
+  for (int i = 0; i < ntables; i++) {
+    DP_REQUIRE(tables[i], DP_ERR_ARG, "null table");
+    const size_t n = tables[i]->b.n;
+    DP_REQUIRE(n >= 2 && (n & (n - 1)) == 0 && n <= (size_t(1) << vp.nv), DP_ERR_SHAPE, "table length must be 2^k, 1 <= k <= num_vars");
+    vp.tabs.push_back(tables[i]->b);
+  }
+  size_t off = 0;
+  for (int i = 0; i < nterms; i++) {
+    const int k = term_degree[i];
+    DP_REQUIRE(k >= 1 && k <= SC_MAXK, DP_ERR_SHAPE, "term degree must be 1..5");
+    std::vector<DBuf> list;
+    for (int j = 0; j < k; j++) { int ti = term_tables[off + j]; DP_REQUIRE(ti >= 0 && ti < ntables, DP_ERR_ARG, "term table index"); list.push_back(tables[ti]->b); }
+    off += (size_t)k;
+    vp.add_mle_list(list, term_coeffs ? read_point(term_coeffs + 2 * i, 1)[0] : ex_one());
+  }
+  DP_REQUIRE(vp.tabs.size() == (size_t)ntables, DP_ERR_ARG, "the same table was passed twice");
+}
 int32_t dp_sumcheck_prove(dp_ctx* ctx, uint32_t nv, const dp_buf* const* tables, int32_t ntables, const int32_t* term_degree,
                           const int32_t* term_tables, const uint64_t* term_coeffs, int32_t nterms, dp_transcript* t,
                           uint64_t** proof_words, size_t* proof_nwords, uint64_t* finals) {
   return guard([&] {
     DP_REQUIRE(ctx && tables && term_degree && term_tables && term_coeffs && t && proof_words && proof_nwords && ntables > 0 && nterms > 0 && nv > 0, DP_ERR_ARG, "bad arguments");
+    DP_REQUIRE(nv < 48, DP_ERR_SHAPE, "num_vars out of range");
     DevVP vp(nv);
-    for (int i = 0; i < ntables; i++) { DP_REQUIRE(tables[i] && tables[i]->b.n == (size_t(1) << nv), DP_ERR_SHAPE, "table length != 2^num_vars"); vp.tabs.push_back(tables[i]->b); }
-    for (int i = 0; i < nterms; i++) {
-      int k = term_degree[i];
-      DP_REQUIRE(k >= 1 && k <= 3, DP_ERR_SHAPE, "term degree must be 1..3");
-      ScTerm st; st.k = k; for (int q = 0; q < SC_MAXK; q++) st.t[q] = 0;
-      for (int j = 0; j < k; j++) { int ti = term_tables[3 * i + j]; DP_REQUIRE(ti >= 0 && ti < ntables, DP_ERR_ARG, "term table index"); st.t[j] = ti; }
-      vp.terms.push_back(st); vp.coeffs.push_back(read_point(term_coeffs + 2 * i, 1)[0]);
-      if ((unsigned)k > vp.max_degree) vp.max_degree = k;
-    }
+    read_terms(vp, tables, ntables, term_degree, term_tables, nterms, term_coeffs);
     SumcheckOut so = sumcheck_prove(*ctx->dev, vp, t->t);
     Writer w; w.iop(so.proof);
     *proof_words = copy_out(w.w); *proof_nwords = w.w.size();
@@ -145,17 +163,15 @@ int32_t dp_sc_session_new(dp_ctx* ctx, uint32_t nv, const dp_buf* const* tables,
                           const int32_t* term_tables, int32_t nterms, dp_sc_session** out) {
   return guard([&] {
     DP_REQUIRE(ctx && tables && term_degree && term_tables && out && ntables > 0 && nterms > 0 && nv > 0, DP_ERR_ARG, "bad arguments");
+    DP_REQUIRE(nv < 48, DP_ERR_SHAPE, "num_vars out of range");
     std::unique_ptr<dp_sc_session> s(new dp_sc_session());
     s->ctx = ctx; s->nraw = 0; s->first = true; s->len = size_t(1) << nv;
-    for (int i = 0; i < ntables; i++) { DP_REQUIRE(tables[i] && tables[i]->b.n == s->len, DP_ERR_SHAPE, "table length != 2^num_vars"); s->tabs.push_back(tables[i]->b); }
-    for (int i = 0; i < nterms; i++) {
-      int k = term_degree[i];
-      DP_REQUIRE(k >= 1 && k <= 3, DP_ERR_SHAPE, "term degree must be 1..3");
-      ScTerm st; st.k = k; for (int q = 0; q < SC_MAXK; q++) st.t[q] = 0;
-      for (int j = 0; j < k; j++) { int ti = term_tables[3 * i + j]; DP_REQUIRE(ti >= 0 && ti < ntables, DP_ERR_ARG, "term table index"); st.t[j] = ti; }
-      s->terms.push_back(st); s->nraw += k + 1;
-    }
+    DevVP vp(nv);
+    read_terms(vp, tables, ntables, term_degree, term_tables, nterms, nullptr);
+    s->terms = vp.terms;
+    for (const ScTerm& st : s->terms) s->nraw += st.k + 1;
     s->mark = ctx->dev->mark();
+    for (const DBuf& b : vp.tabs) s->tabs.push_back(tile_to(*ctx->dev, b, s->len));  // short tables: see tile_to (sumcheck.h)
     *out = s.release();
   });
 }
@@ -232,6 +248,7 @@ int32_t dp_pcs_setup(dp_ctx* ctx, size_t max_poly_size) {
 int32_t dp_pcs_commit(dp_ctx* ctx, const dp_buf* poly, dp_commit** out, uint64_t root[4]) {
   return guard([&] {
     DP_REQUIRE(ctx && poly && out, DP_ERR_ARG, "bad arguments");
+    CtxLock lk(ctx);  // callable from several threads at once (queued on the context's stream)
     DevCommit c = ctx->dev->commit(poly->b, true);
     if (root) for (int k = 0; k < 4; k++) root[k] = c.tree.root.v[k];
     *out = new dp_commit{c};
@@ -240,12 +257,50 @@ int32_t dp_pcs_commit(dp_ctx* ctx, const dp_buf* poly, dp_commit** out, uint64_t
 int32_t dp_pcs_commit_free(dp_ctx* ctx, dp_commit* c) {
   return guard([&] {
     if (!c) return;
+    CtxLock lk(ctx);
     DevCommit& d = c->c;  // the evaluation table belongs to the caller's dp_buf
     if (d.bh_evals.p == d.evals.p) d.bh_evals.p = nullptr;
     if (d.tree.leaves.p == d.evals.p) d.tree.leaves.p = nullptr;
     d.evals.p = nullptr;
     ctx->dev->free_commit(d);
     delete c;
+  });
+}
+/* PCS::get_pure_commitment (mpcs/src/basefold.rs:459-461) */
+int32_t dp_pcs_commitment(const dp_commit* c, uint64_t root[4], uint32_t* num_vars, int32_t* is_base) {
+  return guard([&] {
+    DP_REQUIRE(c && root, DP_ERR_ARG, "bad arguments");
+    for (int k = 0; k < 4; k++) root[k] = c->c.tree.root.v[k];
+    if (num_vars) *num_vars = c->c.nv;
+    if (is_base) *is_base = c->c.is_base ? 1 : 0;
+  });
+}
+/* PCS::open (mpcs/src/basefold.rs:466-539) as zkml calls it (zkml/src/commit/context.rs:395: polynomials of at most
+ * trivial_num_vars() = 7 variables): the proof is the evaluation table itself, the transcript is not touched. */
+int32_t dp_pcs_open(dp_ctx* ctx, const dp_commit* comm, const uint64_t* point, uint32_t num_vars, const uint64_t eval[2], dp_transcript* t,
+                    uint64_t** proof_words, size_t* proof_nwords) {
+  return guard([&] {
+    DP_REQUIRE(ctx && comm && point && proof_words && proof_nwords, DP_ERR_ARG, "bad arguments");
+    (void)eval; (void)t;  // "Opening does not need eval, except for sanity check" (basefold.rs:471); a trivial opening draws no challenge
+    DP_REQUIRE(num_vars == comm->c.nv, DP_ERR_SHAPE, "point length != the polynomial's number of variables");
+    DP_REQUIRE(comm->c.trivial(), DP_ERR_SHAPE, "dp_pcs_open serves the trivial (<= 7 variable) openings of the zkml path; larger polynomials are opened with dp_pcs_batch_open (commit/context.rs:380-392)");
+    CtxLock lk(ctx);
+    BasefoldProof p = pcs_open_trivial(*ctx->dev, comm->c);
+    Writer w; w.basefold(p);
+    *proof_words = copy_out(w.w); *proof_nwords = w.w.size();
+  });
+}
+/* PCS::verify (mpcs/src/basefold.rs:772-894) for the same case: Merkle root of the opened table + its evaluation. Host only. */
+int32_t dp_pcs_verify(const uint64_t root[4], uint32_t num_vars, int32_t is_base, const uint64_t* point, const uint64_t eval[2],
+                      const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t) {
+  return guard([&] {
+    DP_REQUIRE(root && point && eval && proof_words, DP_ERR_ARG, "bad arguments");
+    (void)t;
+    DP_REQUIRE(num_vars <= PCS_BASECODE_LOG, DP_ERR_SHAPE, "dp_pcs_verify serves trivial (<= 7 variable) openings; batch openings go through dp_pcs_batch_verify");
+    Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = root[k]; c.num_vars = num_vars; c.is_base = is_base != 0;
+    Reader r(proof_words, proof_nwords); BasefoldProof p = r.basefold();
+    DP_REQUIRE(r.pos == proof_nwords, DP_ERR_ARG, "proof stream: trailing words");
+    pcs_verify_trivial(c, read_point(point, num_vars), read_point(eval, 1)[0], p);
   });
 }
 static void read_claims(int32_t n, const uint64_t* points_flat, const uint64_t* evals, const std::vector<unsigned>& nvs, std::vector<std::vector<Ext>>& pts, std::vector<Ext>& evs) {
@@ -256,6 +311,7 @@ int32_t dp_pcs_batch_open(dp_ctx* ctx, const dp_commit* const* comms, int32_t n,
                           dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords) {
   return guard([&] {
     DP_REQUIRE(ctx && comms && n > 0 && points_flat && evals && t && proof_words && proof_nwords, DP_ERR_ARG, "bad arguments");
+    CtxLock lk(ctx);
     std::vector<unsigned> nvs; for (int i = 0; i < n; i++) { DP_REQUIRE(comms[i], DP_ERR_ARG, "null commitment"); nvs.push_back(comms[i]->c.nv); }
     std::vector<std::vector<Ext>> pts; std::vector<Ext> evs;
     read_claims(n, points_flat, evals, nvs, pts, evs);

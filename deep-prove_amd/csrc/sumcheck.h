@@ -24,7 +24,11 @@ struct DevVP {  // VirtualPolynomial (multilinear_extensions/src/virtual_poly.rs
     ScTerm t; t.k = (int)list.size(); for (int q = 0; q < SC_MAXK; q++) t.t[q] = 0;
     int j = 0;
     for (const DBuf& b : list) {
-      DP_REQUIRE(b.n == (size_t(1) << nv), DP_ERR_SHAPE, "sumcheck: every table must have max_num_variables variables");
+      // a table may have FEWER variables than the polynomial (virtual_poly.rs:147-180 only asserts num_vars <= max_num_variables);
+      // the round-sum body indexes every table of a product with the first one's range (sumcheck_macro/src/lib.rs:228-235),
+      // so the tables of one product share their length. A constant is refused as the reference refuses it (prover.rs:663).
+      DP_REQUIRE(b.n >= 2 && (b.n & (b.n - 1)) == 0 && b.n <= (size_t(1) << nv), DP_ERR_SHAPE, "sumcheck: table length must be 2^k, 1 <= k <= max_num_variables");
+      DP_REQUIRE(b.n == list[0].n, DP_ERR_SHAPE, "sumcheck: the tables of one product must have the same number of variables");
       t.t[j++] = table_index(b);
     }
     if ((unsigned)t.k > max_degree) max_degree = t.k;
@@ -72,6 +76,20 @@ inline Ext extrapolate_small(const Ext* evals, unsigned k, unsigned at) {
   return r;
 }
 
+// A table of k < nv variables inside a polynomial of nv variables is f(x_1..x_k), constant in x_(k+1)..x_nv. The reference
+// handles it inside the round function: the table is folded like any other while it has variables, a one-element table is a
+// constant factor, and the round sums are scaled by 2^(nv - (max(log2 len, 1) + round - 1)) (sumcheck_macro/src/lib.rs:236-247).
+// That is exactly the sumcheck of the table TILED to 2^nv entries (index i -> i mod 2^k): while round <= k the tiled sums are
+// 2^(nv-k) copies of the short ones, afterwards the folded tile is the constant f(r_1..r_k) summed over the 2^(nv-round)
+// remaining points, and the final evaluation is that constant. Field arithmetic is exact, so the messages are bit-identical;
+// the device keeps ONE code path (equal-length tables) and pays a copy for a shape zkml's own layers never produce.
+inline DBuf tile_to(Dev& dev, const DBuf& b, size_t n) {
+  if (b.n == n) return b;
+  DBuf out = dev.alloc(n, b.ext);
+  dev.copy(out.slice(0, b.n), b);
+  for (size_t have = b.n; have < n; have *= 2) dev.copy(out.slice(have, have), out.slice(0, have));
+  return out;
+}
 struct SumcheckOut { IOPProof proof; std::vector<Ext> finals; };
 struct ScStats { double dev_ms = 0, host_ms = 0; size_t rounds = 0; };
 inline ScStats& sc_stats() { static thread_local ScStats s; return s; }
@@ -84,6 +102,7 @@ inline SumcheckOut sumcheck_prove(Dev& dev, DevVP& vp, Transcript& t) {
   t.append_usize(nv);
   t.append_usize(md);
   std::vector<DBuf> tabs = vp.tabs;
+  for (DBuf& b : tabs) b = tile_to(dev, b, size_t(1) << nv);
   size_t nraw = 0;
   for (auto& tm : vp.terms) nraw += tm.k + 1;
   std::vector<Ext> raw(nraw);
@@ -144,7 +163,8 @@ inline SumcheckOut sumcheck_prove_with_eq(Dev& dev, const std::vector<EqAcc>& eq
   std::vector<Dev::EqAccJob> jobs;
   for (const EqAcc& e : eqs) jobs.push_back({e.out, e.pt.data(), (unsigned)e.pt.size(), e.scale, e.accumulate});
   Dev::EqSumOut eo;
-  if (dev.eqsum_tail(jobs.data(), (int)jobs.size(), vp.tabs.data(), (int)vp.tabs.size(), vp.terms.data(), vp.coeffs.data(), (int)vp.terms.size(), vp.nv, vp.max_degree, t.challenger(), eo)) {
+  bool full = true; for (const DBuf& b : vp.tabs) full = full && b.n == (size_t(1) << vp.nv);
+  if (full && dev.eqsum_tail(jobs.data(), (int)jobs.size(), vp.tabs.data(), (int)vp.tabs.size(), vp.terms.data(), vp.coeffs.data(), (int)vp.terms.size(), vp.nv, vp.max_degree, t.challenger(), eo)) {
     DP_REQUIRE(eo.msgs.size() == vp.nv && eo.point.size() == vp.nv && eo.finals.size() == vp.tabs.size(), DP_ERR_SHAPE, "eqsum_tail: unexpected result shape");
     SumcheckOut out; out.proof.proofs = eo.msgs; out.proof.point = eo.point; out.finals = eo.finals;
     return out;

@@ -65,9 +65,7 @@ class HipShard:
         self.terms = terms
         tabs = (vp * len(tables))(*[t.h for t in tables])
         deg = np.array([len(ix) for _, ix in terms], dtype=np.int32)
-        tt = np.zeros(3 * len(terms), dtype=np.int32)
-        for i, (_, ix) in enumerate(terms):
-            tt[3 * i:3 * i + len(ix)] = ix
+        tt = np.array([j for _, ix in terms for j in ix], dtype=np.int32)  # ragged: the terms' table lists back to back
         self.h = vp()
         check(self.lib.dp_sc_session_new(dev.h, nv_local, tabs, len(tables), deg.ctypes.data_as(_lib.i32p), tt.ctypes.data_as(_lib.i32p), len(terms), C.byref(self.h)))
         self.nraw = int(sum(len(ix) + 1 for _, ix in terms))

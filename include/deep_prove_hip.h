@@ -6,8 +6,9 @@
  *     dp_last_error() returns the message of the last failure on the calling thread;
  *   - field elements cross the ABI as canonical little-endian uint64 (< p = 2^64-2^32+1); an extension element is
  *     two consecutive uint64 (c0, c1) of c0 + c1*X, X^2 = 7;
- *   - a dp_ctx owns one HIP device, one stream and a device arena; calls on one ctx must come from one thread at a
- *     time (one ctx per GPU, one host thread per ctx);
+ *   - a dp_ctx owns one HIP device, one stream and a device arena: one ctx per GPU, one host thread per ctx — except the
+ *     entry points the reference itself calls from worker threads (table uploads / frees, dp_pcs_commit, dp_pcs_open,
+ *     dp_pcs_batch_open: see dp_pcs_commit), which any thread may call at any time and which are queued internally;
  *   - tables live in HBM behind opaque dp_buf handles; host<->device copies are explicit;
  *   - buffers returned through `uint64_t**` are malloc'ed by the library and released with dp_free();
  *   - there is NO CPU fallback: dp_ctx_create fails with DP_ERR_NODEVICE when no MI355X/HIP device is present.
@@ -80,8 +81,13 @@ int32_t dp_mle_eval(dp_ctx* ctx, const dp_buf* f, const uint64_t* point, uint32_
 int32_t dp_mle_fix_high(dp_ctx* ctx, const dp_buf* matrix, size_t rows, size_t cols, const uint64_t* point, dp_buf** out);
 
 /* ---- sumcheck: IOPProverState::prove_parallel(VirtualPolynomial, transcript) (sumcheck/src/prover.rs:498-585).
- * The virtual polynomial is sum_i coeff_i * prod_{j<degree_i} tables[term_tables[3i+j]], degree_i in 1..3 through this
- * entry point (the model-level provers use products of up to 5 tables); every table has 2^num_vars entries. proof_words receives the IOPProof stream {point: len, ext...; rounds: count, (len, ext...)...};
+ * The virtual polynomial is sum_i coeff_i * prod_{j<degree_i} tables[term_tables[o_i + j]], o_i = degree_0 + .. + degree_(i-1)
+ * (term_tables is the concatenation of the terms' table lists), degree_i in 1..5 as the reference dispatches
+ * (sumcheck/src/prover.rs:706-713). A table has 2^k entries, 1 <= k <= num_vars (VirtualPolynomial::add_mle_list only asserts
+ * num_vars <= max_num_variables, virtual_poly.rs:147-180): a table with fewer variables is constant in the missing (high)
+ * ones and gets the 2^(missing) factor of sumcheck_macro/src/lib.rs:236-247; the tables of ONE product share their length, as
+ * the generated round function assumes. Each table is passed once (they are de-duplicated by identity, like the Arc
+ * pointers of the reference). proof_words receives the IOPProof stream {point: len, ext...; rounds: count, (len, ext...)...};
  * finals receives get_mle_final_evaluations() (2 words per table, table order). */
 int32_t dp_sumcheck_prove(dp_ctx* ctx, uint32_t num_vars, const dp_buf* const* tables, int32_t ntables,
                           const int32_t* term_degree, const int32_t* term_tables, const uint64_t* term_coeffs,
@@ -99,7 +105,8 @@ int32_t dp_sumcheck_verify(uint32_t num_vars, uint32_t max_degree, const uint64_
  * IOPProverState::prove_batch_polys (sumcheck/src/prover.rs:37-321) gives every worker a contiguous 1/2^k chunk of each
  * table, sums the workers' round evaluations and broadcasts one challenge; a session is one worker's side of it: the raw
  * per-term sums of its chunk per round (the caller adds the shares, applies coefficients / extrapolation and runs the
- * transcript), then one folded value per table. Tables and term layout as in dp_sumcheck_prove. One session at a time
+ * transcript), then one folded value per table. Tables and term layout as in dp_sumcheck_prove (degrees 1..5, ragged term
+ * lists, tables of 2^k <= 2^num_vars entries). One session at a time
  * per dp_ctx; the session borrows the ctx's arena until dp_sc_session_free. */
 typedef struct dp_sc_session dp_sc_session;
 int32_t dp_sc_session_new(dp_ctx* ctx, uint32_t num_vars, const dp_buf* const* tables, int32_t ntables,
@@ -127,9 +134,24 @@ int32_t dp_logup_verify(const uint64_t* proof_words, size_t proof_nwords, int32_
 /* ---- PCS: mpcs::PolynomialCommitmentScheme for Basefold<GoldilocksExt2, BasefoldRSParams<PoseidonHasher>> */
 /* PCS::setup + PCS::trim (mpcs/src/basefold.rs:278-303): max_poly_size must be a power of two */
 int32_t dp_pcs_setup(dp_ctx* ctx, size_t max_poly_size);
-/* PCS::commit (mpcs/src/basefold.rs:304-354); the commitment keeps a reference to `poly` (do not free it first) */
+/* PCS::commit (mpcs/src/basefold.rs:304-354); the commitment keeps a reference to `poly` (do not free it first).
+ * Thread-safe: the reference commits from rayon workers (zkml/src/commit/context.rs:79-103, layers/activation.rs:294-304), so
+ * dp_buf_from_i64 / dp_buf_upload / dp_buf_download / dp_buf_free / dp_pcs_commit / dp_pcs_commit_free / dp_pcs_open /
+ * dp_pcs_batch_open may be called on one dp_ctx from several host threads at once; the calls are queued on the context's
+ * stream (a lock, not parallel execution). Everything else on a dp_ctx keeps the one-host-thread-per-context rule. */
 int32_t dp_pcs_commit(dp_ctx* ctx, const dp_buf* poly, dp_commit** out, uint64_t root[4]);
 int32_t dp_pcs_commit_free(dp_ctx* ctx, dp_commit* c);
+/* PCS::get_pure_commitment (mpcs/src/basefold.rs:459-461): BasefoldCommitment{root, num_vars, is_base} (structure.rs:161-166) */
+int32_t dp_pcs_commitment(const dp_commit* c, uint64_t root[4], uint32_t* num_vars, int32_t* is_base);
+/* PCS::open / PCS::verify (mpcs/src/basefold.rs:466-539, 772-894) for the commitments zkml opens one by one: polynomials of
+ * at most PCS::trivial_num_vars() = 7 variables (zkml/src/commit/context.rs:295,395,477), whose opening proof is the
+ * evaluation table itself (BasefoldProof::trivial, structure.rs:352-363) and whose verification is the Merkle root of that
+ * table plus its evaluation; neither touches the transcript. Larger polynomials return DP_ERR_SHAPE: on the zkml path they are
+ * opened together by dp_pcs_batch_open. dp_pcs_verify is host only. */
+int32_t dp_pcs_open(dp_ctx* ctx, const dp_commit* comm, const uint64_t* point, uint32_t num_vars, const uint64_t eval[2],
+                    dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords);
+int32_t dp_pcs_verify(const uint64_t root[4], uint32_t num_vars, int32_t is_base, const uint64_t* point, const uint64_t eval[2],
+                      const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t);
 /* PCS::batch_open with Evaluation::new(i, i, evals[i]) (mpcs/src/basefold.rs:546-770 as called from
  * zkml/src/commit/context.rs:355-418). points_flat = concatenation of the n points (2*num_vars_i words each). */
 int32_t dp_pcs_batch_open(dp_ctx* ctx, const dp_commit* const* comms, int32_t n, const uint64_t* points_flat,

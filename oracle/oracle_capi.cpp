@@ -102,13 +102,15 @@ int orc_mle_eval(const uint64_t* words, size_t n, int is_ext, const uint64_t* po
 int orc_fix_high(const uint64_t* words, size_t rows, size_t cols, const uint64_t* point, uint64_t* out) {
   return guard([&] { Mle m = Mle::from_base(std::vector<u64>(words, words + rows * cols)); m.fix_high_in_place(rd_pt(point, log2_strict(rows))); for (size_t i = 0; i < cols; i++) { E v = m.at(i); out[2 * i] = v.c0; out[2 * i + 1] = v.c1; } });
 }
-int orc_sumcheck_prove(uint32_t nv, const uint64_t* const* tables, const int32_t* is_ext, int32_t ntables, const int32_t* term_degree, const int32_t* term_tables,
+// table_nv[i]: number of variables of table i (<= nv; NULL: every table has nv); term_tables: the terms' table lists back to back
+int orc_sumcheck_prove(uint32_t nv, const uint64_t* const* tables, const int32_t* is_ext, const uint32_t* table_nv, int32_t ntables, const int32_t* term_degree, const int32_t* term_tables,
                        const uint64_t* term_coeffs, int32_t nterms, orc_transcript* t, uint64_t** proof_words, size_t* proof_nwords, uint64_t* finals) {
   return guard([&] {
-    std::vector<MleP> ms; for (int i = 0; i < ntables; i++) ms.push_back(mk(rd_mle(tables[i], size_t(1) << nv, is_ext[i])));
+    std::vector<MleP> ms; for (int i = 0; i < ntables; i++) ms.push_back(mk(rd_mle(tables[i], size_t(1) << (table_nv ? table_nv[i] : nv), is_ext[i])));
     VirtualPolynomial vp(nv);
     for (int i = 0; i < ntables; i++) vp.flattened.push_back(ms[i]);  // keep the caller's table order for `finals`
-    for (int i = 0; i < nterms; i++) { std::vector<MleP> l; for (int j = 0; j < term_degree[i]; j++) l.push_back(ms[term_tables[3 * i + j]]); vp.add_mle_list(l, E{term_coeffs[2 * i], term_coeffs[2 * i + 1]}); }
+    size_t off = 0;
+    for (int i = 0; i < nterms; i++) { std::vector<MleP> l; for (int j = 0; j < term_degree[i]; j++) l.push_back(ms[term_tables[off + j]]); off += term_degree[i]; vp.add_mle_list(l, E{term_coeffs[2 * i], term_coeffs[2 * i + 1]}); }
     auto res = sumcheck_prove(std::move(vp), t->t);
     Writer w; w.iop(res.first);
     *proof_words = copy_out(w.w); *proof_nwords = w.w.size();

@@ -59,7 +59,62 @@ static dp::ModelSpec tiny_cnn(std::vector<int64_t>& in) {
   m.layers.push_back(requant_for(COLS, 2.5 / std::sqrt((double)(OC * UH * UH)) / 127));
   return m;
 }
+// `hostlogic_check sumcheck <seed> <nv>`: the generalised seam 2 (dp_sumcheck_prove's shape: products of 1..5 tables, tables
+// with FEWER variables than the polynomial, base and extension tables mixed) — product orchestrator over the double vs the
+// oracle's restatement of prove_parallel, proof stream + final evaluations + transcript state
+static int sumcheck_mode(uint64_t seed, unsigned nv) {
+  rs = seed;
+  TestDev dev;
+  dev.device_fs = getenv("DP_DOUBLE_DEVICE_FS") && atoi(getenv("DP_DOUBLE_DEVICE_FS"));
+  struct T { unsigned k; bool ext; std::vector<uint64_t> w; };
+  // table i has nv_i variables: full, full, nv-1, nv-1, 1, full(ext), nv-2 (ext), full, full, full
+  const unsigned ks[10] = {nv, nv, nv - 1, nv - 1, 1, nv, nv > 2 ? nv - 2 : 1, nv, nv, nv};
+  const bool exts[10] = {false, true, false, true, false, true, true, false, false, true};
+  std::vector<T> tabs(10);
+  for (int i = 0; i < 10; i++) { tabs[i].k = ks[i]; tabs[i].ext = exts[i]; tabs[i].w.resize((size_t(1) << ks[i]) * (exts[i] ? 2 : 1)); for (auto& x : tabs[i].w) x = rnd() % dp::GL_P; }
+  // products: degree 5 (full), degree 4 (full), degree 2 of nv-1 tables, degree 1 of the 1-variable table, degree 3 mixing base/ext, degree 1 of an nv-2 table
+  const std::vector<std::vector<int>> terms = {{0, 1, 5, 7, 8}, {9, 0, 1, 8}, {2, 3}, {4}, {7, 5, 9}, {6}, {3, 2}};
+  std::vector<orc::MleP> om;
+  for (auto& t : tabs) {
+    if (t.ext) { std::vector<orc::E> e(t.w.size() / 2); for (size_t j = 0; j < e.size(); j++) e[j] = orc::E{t.w[2 * j], t.w[2 * j + 1]}; om.push_back(orc::mk(orc::Mle::from_ext(e))); }
+    else om.push_back(orc::mk(orc::Mle::from_base(t.w)));
+  }
+  orc::VirtualPolynomial ovp(nv);
+  for (auto& m : om) ovp.flattened.push_back(m);
+  dp::DevVP vp(nv);
+  std::vector<dp::DBuf> bufs;
+  for (auto& t : tabs) { dp::DBuf b = dev.alloc_persistent(size_t(1) << t.k, t.ext); dev.upload(b, t.w.data()); bufs.push_back(b); vp.tabs.push_back(b); }
+  for (auto& tm : terms) {
+    uint64_t c0 = rnd() % dp::GL_P, c1 = rnd() % dp::GL_P;
+    std::vector<orc::MleP> ol; std::vector<dp::DBuf> dl;
+    for (int j : tm) { ol.push_back(om[j]); dl.push_back(bufs[j]); }
+    ovp.add_mle_list(ol, orc::E{c0, c1}); vp.add_mle_list(dl, dp::ex(c0, c1));
+  }
+  orc::Transcript ot = orc::default_transcript(); dp::Transcript pt = dp::default_transcript();
+  auto ores = orc::sumcheck_prove(std::move(ovp), ot);
+  dp::SumcheckOut pres = dp::sumcheck_prove(dev, vp, pt);
+  bool same = ores.first.proofs.size() == pres.proof.proofs.size() && ores.first.point.size() == pres.proof.point.size();
+  for (size_t r = 0; same && r < pres.proof.proofs.size(); r++) {
+    same = ores.first.proofs[r].size() == pres.proof.proofs[r].size() && ores.first.point[r].c0 == pres.proof.point[r].c0 && ores.first.point[r].c1 == pres.proof.point[r].c1;
+    for (size_t j = 0; same && j < pres.proof.proofs[r].size(); j++) same = ores.first.proofs[r][j].c0 == pres.proof.proofs[r][j].c0 && ores.first.proofs[r][j].c1 == pres.proof.proofs[r][j].c1;
+  }
+  auto of = ores.second.final_evaluations();
+  bool fsame = of.size() == pres.finals.size();
+  for (size_t i = 0; fsame && i < of.size(); i++) fsame = of[i].c0 == pres.finals[i].c0 && of[i].c1 == pres.finals[i].c1;
+  orc::E oc = ot.get_and_append_challenge("after"); dp::Ext pc = pt.get_and_append_challenge("after");
+  bool tsame = oc.c0 == pc.c0 && oc.c1 == pc.c1;
+  // and the product verifier on the product's proof: claimed sum = message(0) + message(1) of round 1
+  dp::Transcript vt = dp::default_transcript();
+  dp::Ext claimed = dp::ex_add(pres.proof.proofs[0][0], pres.proof.proofs[0][1]);
+  bool vok = true;
+  try { dp::SubClaim sc = dp::sumcheck_verify(claimed, pres.proof, nv, vp.max_degree, vt); (void)sc; } catch (const std::exception& e) { vok = false; printf("verify: %s\n", e.what()); }
+  printf("sumcheck nv=%u max_degree=%u terms=%zu: messages identical=%d finals identical=%d transcript identical=%d verifier=%s", nv, vp.max_degree, terms.size(), same, fsame, tsame, vok ? "ACCEPT" : "REJECT");
+  if (dev.device_fs) printf(" sc_tail taken=%zu declined=%zu", dev.tails_taken, dev.tails_declined);
+  printf("\n");
+  return same && fsame && tsame && vok ? 0 : 2;
+}
 int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "sumcheck") return sumcheck_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 6);
   bool cnn = argc > 1 && std::string(argv[1]) == "cnn";
   size_t W = argc > 1 && !cnn ? atoi(argv[1]) : 64; rs = argc > 2 ? atoll(argv[2]) : 1; int tamper = argc > 3 ? atoi(argv[3][0] == '@' ? argv[3] + 1 : argv[3]) : 0; bool tamper_abs = argc > 3 && argv[3][0] == '@';  // "@i": flip word i, else word size/2 + offset
   dp::ModelSpec m; m.input_len = 4;

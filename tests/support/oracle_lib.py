@@ -121,18 +121,17 @@ class Oracle:
         return out
 
     def sumcheck_prove(self, nv, tables, is_ext, terms, transcript):
-        """tables: list of uint64 arrays; terms: list of (coeff, [idx])"""
+        """tables: list of uint64 arrays (2^k base words or 2 * 2^k ext words each, k <= nv); terms: list of (coeff, [idx])"""
         keep = [np.ascontiguousarray(t, dtype=np.uint64) for t in tables]
+        tnv = np.array([(k.size // (2 if e else 1)).bit_length() - 1 for k, e in zip(keep, is_ext)], dtype=np.uint32)
         tp = (u64p * len(keep))(*[k.ctypes.data_as(u64p) for k in keep])
         ie = np.array([1 if e else 0 for e in is_ext], dtype=np.int32)
         deg = np.array([len(ix) for _, ix in terms], dtype=np.int32)
-        tt = np.zeros(3 * len(terms), dtype=np.int32)
-        for i, (_, ix) in enumerate(terms):
-            tt[3 * i:3 * i + len(ix)] = ix
+        tt = np.array([j for _, ix in terms for j in ix], dtype=np.int32)  # ragged: the terms' table lists back to back
         co = np.array([w for c, _ in terms for w in c], dtype=np.uint64)
         pw, pn = u64p(), C.c_size_t()
         finals = np.zeros(2 * len(keep), dtype=np.uint64)
-        self._ok(self.lib.orc_sumcheck_prove(C.c_uint32(nv), tp, ie.ctypes.data_as(i32p), C.c_int32(len(keep)), deg.ctypes.data_as(i32p),
+        self._ok(self.lib.orc_sumcheck_prove(C.c_uint32(nv), tp, ie.ctypes.data_as(i32p), tnv.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int32(len(keep)), deg.ctypes.data_as(i32p),
                                              tt.ctypes.data_as(i32p), co.ctypes.data_as(u64p), C.c_int32(len(terms)), transcript.h,
                                              C.byref(pw), C.byref(pn), finals.ctypes.data_as(u64p)))
         return self._take(pw, pn.value), finals

@@ -66,3 +66,30 @@ def test_golden_primitive_vectors(oracle):
     t = oracle.transcript(b"test")
     p, f = oracle.sumcheck_prove(10, [g["poly_base"], g["poly_ext"]], [False, True], [((1, 0), [0, 1])], t)
     assert (p == g["sumcheck_proof"]).all() and (f == g["sumcheck_finals"]).all()
+
+
+def build_c_consumer():
+    """tests/support/c_consumer.c with the flags a strict C11 host would use; links libdeepprove_hip.so"""
+    import subprocess
+    import deep_prove_amd as dpa
+    out = os.path.join(ROOT, "tests", "support", "_build", "c_consumer")
+    src = os.path.join(ROOT, "tests", "support", "c_consumer.c")
+    deps = [src, os.path.join(ROOT, "include", "deep_prove_hip.h"), dpa.LIB_PATH]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O1", "-o", out, src, "-L", os.path.dirname(dpa.LIB_PATH),
+                               "-ldeepprove_hip", "-lpthread", "-Wl,-rpath," + os.path.dirname(dpa.LIB_PATH)])
+    return out
+
+
+def test_header_is_c11_and_a_c_program_links_every_entry_point():
+    """the boundary is a C ABI, not a Python one: include/deep_prove_hip.h compiles as strict C11 (-pedantic -Werror), a C
+    program that references every declared entry point links against the library, and its list is the header's list"""
+    import subprocess
+    exe = build_c_consumer()
+    r = subprocess.run([exe, "--symbols"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    src = open(os.path.join(ROOT, "tests", "support", "c_consumer.c")).read()
+    listed = sorted(set(re.findall(r"\(fn_t\)(dp_[a-z0-9_]+)", src)))
+    assert listed == declared_symbols()
+    assert f"{len(listed)} of {len(listed)} entry points resolved" in r.stdout

@@ -89,6 +89,18 @@ SC_CASES = [
     (20, [True, True], [((1, 0), [0, 1])]),
     (20, [True], [((1, 0), [0])]),
     (20, [False, False, False], [((1, 1), [2, 0, 1])]),  # same shape, coefficient != 1: no skipping
+    # round 2: the whole range the reference dispatches (sumcheck/src/prover.rs:706-713): products of 4 and 5 tables
+    # (pooling.rs:430 needs 5), alone, mixed with lower degrees (extrapolated), small and streaming sizes
+    (9, [True, True, True, True, True], [((1, 0), [0, 1, 2, 3, 4])]),
+    (11, [False, True, False, True, True, False], [((3, 1), [0, 1, 2, 3]), ((1, 0), [4, 5]), ((P - 2, 7), [5, 4, 3, 2, 1]), ((9, 0), [0])]),
+    (17, [False, False, True, True], [((1, 0), [0, 1, 2, 3])]),
+    (14, [True, False, False, True, True], [((2, 3), [0, 1, 2, 3, 4]), ((1, 0), [3, 4])]),
+]
+# tables with FEWER variables than the polynomial (sumcheck_macro/src/lib.rs:236-247): (nv, [(table nv, is_ext)], terms)
+SC_MIXED = [
+    (6, [(6, False), (4, True), (4, False), (1, False)], [((1, 0), [0]), ((5, 6), [1, 2]), ((7, 0), [3])]),
+    (12, [(12, True), (12, False), (9, True), (9, True), (9, False), (3, False)], [((1, 0), [0, 1]), ((3, 3), [2, 3, 4]), ((1, 2), [5]), ((8, 0), [4, 2])]),
+    (15, [(15, False), (15, False), (15, True), (14, True), (14, False), (14, False), (14, True), (14, True)], [((1, 0), [0, 1, 2]), ((2, 9), [3, 4, 5, 6, 7])]),
 ]
 
 
@@ -109,6 +121,34 @@ def test_sumcheck_prove_parallel(dev, oracle, case):
     assert proof.size == oproof.size and (proof == oproof).all()
     assert (finals == ofinals).all()
     assert t.read_challenge() == ot.read_challenge()  # transcripts end in the same state
+
+
+@pytest.mark.parametrize("case", range(len(SC_MIXED)))
+def test_sumcheck_tables_with_fewer_variables(dev, oracle, case):
+    """a table of k < num_vars variables is constant in the missing ones: the round sums carry the 2^(missing) factor, after k
+    folds it is a constant factor, its final evaluation is f(r_1..r_k) — through dp_sumcheck_prove, bit-identical to the oracle"""
+    import deep_prove_amd as dpa
+    nv, shapes, terms = SC_MIXED[case]
+    rng = np.random.default_rng(4000 + case)
+    raw = [rand_base(rng, (2 if e else 1) << k) for k, e in shapes]
+    exts = [e for _, e in shapes]
+    mles = [dpa.Mle.from_ext(dev, w) if e else dpa.Mle.from_base(dev, w) for w, e in zip(raw, exts)]
+    vp = dpa.VirtualPolynomial(nv)
+    vp.tables = list(mles)
+    vp.terms = [(c, ix) for c, ix in terms]
+    t = dpa.Transcript(b"test")
+    proof, finals = dpa.prove_parallel(dev, vp, t)
+    ot = oracle.transcript(b"test")
+    oproof, ofinals = oracle.sumcheck_prove(nv, raw, exts, terms, ot)
+    assert proof.size == oproof.size and (proof == oproof).all()
+    assert (finals == ofinals).all()
+    assert t.read_challenge() == ot.read_challenge()
+    # shape violations are refused, not mis-proved: a constant table, tables of one product with different lengths
+    bad = dpa.VirtualPolynomial(nv)
+    bad.tables = [mles[0], mles[1]]
+    bad.terms = [((1, 0), [0, 1])] if shapes[0][0] != shapes[1][0] else [((1, 0), [0, 0, 0, 0, 0, 0])]
+    with pytest.raises(dpa.DeepProveError):
+        dpa.prove_parallel(dev, bad, dpa.Transcript(b"test"))
 
 
 def test_sumcheck_golden_vector(dev):

@@ -112,3 +112,13 @@ def test_field_header_against_wide_arithmetic(tmp_path):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "support", "field_check.cpp")])
     r = run(exe)
     assert r.returncode == 0 and "bad=0" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("nv,seed,fs", [(3, 11, "0"), (6, 12, "0"), (9, 13, "0"), (6, 14, "1"), (11, 15, "1")])
+def test_generalised_sumcheck_seam_matches_oracle(hostlogic_bin, nv, seed, fs):
+    """what dp_sumcheck_prove accepts since round 2: products of 1..5 tables (sumcheck/src/prover.rs:706-713), tables with fewer
+    variables than the polynomial (sumcheck_macro/src/lib.rs:236-247: the 2^missing factor, constants once folded out),
+    base and extension tables mixed — messages, final evaluations and the transcript after the proof equal the oracle's"""
+    r = run(hostlogic_bin, "sumcheck", seed, nv, env={"DP_DOUBLE_DEVICE_FS": fs})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "messages identical=1 finals identical=1 transcript identical=1 verifier=ACCEPT" in r.stdout
