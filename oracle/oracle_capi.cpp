@@ -145,6 +145,11 @@ int orc_pcs_batch_open(size_t max_poly_size, const uint64_t* const* polys, const
 }
 int orc_model_setup(const int64_t* blob, size_t nwords, orc_model** out) { return guard([&] { Model m = parse_model(blob, nwords); orc_model* om = new orc_model{context_generate(m)}; *out = om; }); }
 void orc_model_free(orc_model* m) { delete m; }
+// the sponge traffic of every transcript created on this thread between begin and take: pairs (0, absorbed) / (1, squeezed)
+static thread_local std::vector<u64> g_trace_store;
+int orc_trace_begin() { return guard([&] { g_trace_store.clear(); g_transcript_trace = &g_trace_store; }); }
+int orc_trace_take(uint64_t** words, size_t* nwords) { return guard([&] { g_transcript_trace = nullptr; *words = copy_out(g_trace_store); *nwords = g_trace_store.size(); g_trace_store.clear(); }); }
+int orc_hash_or_noop(const uint64_t* in, size_t n, uint64_t out[4]) { return guard([&] { Digest d = hash_or_noop(in, n); for (int i = 0; i < 4; i++) out[i] = d[i]; }); }
 int orc_model_prove(orc_model* m, const int64_t* input, size_t ninput, uint64_t** proof_words, size_t* proof_nwords, int64_t* output, size_t* noutput, double* prove_ms) {
   return guard([&] {
     Transcript t = default_transcript();

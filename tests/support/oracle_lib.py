@@ -99,6 +99,27 @@ class Oracle:
         self.lib.orc_poseidon2_permute(s.ctypes.data_as(u64p))
         return s
 
+    def trace_begin(self):
+        """record the sponge traffic of every transcript the oracle creates on this thread until trace_take()"""
+        self._ok(self.lib.orc_trace_begin())
+
+    def trace_take(self):
+        """-> uint64 array of (kind, value) pairs: kind 0 = absorbed, 1 = squeezed"""
+        pw, pn = u64p(), C.c_size_t()
+        self._ok(self.lib.orc_trace_take(C.byref(pw), C.byref(pn)))
+        return self._take(pw, pn.value)
+
+    def compress(self, x, y):
+        a, b, o = (C.c_uint64 * 4)(*x), (C.c_uint64 * 4)(*y), (C.c_uint64 * 4)()
+        self.lib.orc_compress(a, b, o)
+        return [int(v) for v in o]
+
+    def hash_or_noop(self, elems):
+        w = np.ascontiguousarray(elems, dtype=np.uint64)
+        o = (C.c_uint64 * 4)()
+        self._ok(self.lib.orc_hash_or_noop(w.ctypes.data_as(u64p), C.c_size_t(w.size), o))
+        return [int(v) for v in o]
+
     def eq_table(self, pt):
         p = _pt(pt)
         out = np.zeros(2 << len(pt), dtype=np.uint64)
