@@ -34,7 +34,6 @@ DEFAULT_IN_FLIGHT = 256
 GOLDEN = {"dense_4m": "dense4m_proof.json", "cnn_264k": "cnn264k_proof.json"}
 GOLDEN_SLOT = 7  # index inside the last timed step at which the golden input is proved
 SHARDED_WATCHDOG_S = float(os.environ.get("DP_BENCH_SHARDED_WATCHDOG_S", "240"))
-VERIFY_BUDGET_S = float(os.environ.get("DP_BENCH_VERIFY_BUDGET_S", "15"))  # host verification of the last batch: all proofs if that fits, else an evenly spaced sample
 PUBLISHED = {"dense_4m": 1000.0 / 2335.0, "cnn_264k": 1000.0 / 1242.0}  # reference README.md:17-18 (hardware unstated)
 WORKLOADS = {
     "dense_4m": "Dense-4M MLP (mlp.py --num-dense 5 --layer-width 1024: 4->1024->1024x4->3, Dense+Requant+ReLU blocks, 4.21M params), 1 input per proof",
@@ -97,7 +96,13 @@ def make_model(dpa, workload):
     return {"dense_4m": dpa.models.dense_4m, "cnn_264k": dpa.models.cnn_264k, "mlp_w256": lambda: dpa.models.mlp(3, 256, config=5)}[workload]()
 
 
-def measure_workload(dpa, dev, workload, conc, steps, warmup, world, rank, dist, torch, profile=False):
+def strong_share(batch, world, rank):
+    """BASELINE config 4 ("Dense 4M, batch of 64 independent proofs sharded 8 x MI355X"): the proofs of ONE fixed batch that rank
+    `rank` proves — a contiguous-by-stride partition, sizes differ by at most one"""
+    return len(shard(batch, world, rank))
+
+
+def measure_workload(dpa, dev, workload, conc, steps, warmup, world, rank, dist, torch, profile=False, strong_batch=0):
     """setup + latency of one proof + the timed throughput region + verification of the last batch (+ the per-kernel HIP
     event profile of one more proof); the model context and its workers are released before returning"""
     import numpy as np
@@ -107,13 +112,20 @@ def measure_workload(dpa, dev, workload, conc, steps, warmup, world, rank, dist,
     setup_s = time.time() - t0
     prover = dpa.Prover(ctx)
     vblob = ctx.verifier_blob()
-    batch = BATCHES_PER_STEP * conc  # proofs per step: two waves of `conc` in flight, so the drain of a step's tail weighs less
-    per_rank = (steps + warmup) * batch
-    my_inputs = np.stack([mb.input(1000 + i) for i in shard(world * per_rank, world, rank)])
+    if strong_batch:  # strong scaling: a step = this rank's share of ONE fixed batch, all of it in flight at once
+        batch = strong_share(strong_batch, world, rank)
+        conc = max(1, min(conc, batch))
+        per_rank = (steps + warmup) * batch
+        my_inputs = np.stack([mb.input(1000 + (s * strong_batch) + j) for s in range(steps + warmup) for j in shard(strong_batch, world, rank)]) if batch else np.zeros((0, mb.input(0).size), dtype=np.int64)
+    else:
+        batch = BATCHES_PER_STEP * conc  # proofs per step: several waves of `conc` in flight, so the ramp and drain of a step weigh less
+        per_rank = (steps + warmup) * batch
+        my_inputs = np.stack([mb.input(1000 + i) for i in shard(world * per_rank, world, rank)])
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", GOLDEN[workload]))) if workload in GOLDEN else None
     lo_last = (warmup + steps - 1) * batch
-    if gold is not None:
-        my_inputs[lo_last + GOLDEN_SLOT] = mb.input(gold["input_index"])
+    gslot = min(GOLDEN_SLOT, batch - 1)
+    if gold is not None and batch:
+        my_inputs[lo_last + gslot] = mb.input(gold["input_index"])
     t0 = time.perf_counter()
     prover.prove(my_inputs[0])
     first_ms = 1000 * (time.perf_counter() - t0)
@@ -123,27 +135,29 @@ def measure_workload(dpa, dev, workload, conc, steps, warmup, world, rank, dist,
     cuda = torch.cuda.is_available() and (dist is None or dist.get_backend() == "nccl")
     elapsed, last = timed_region(lambda xs: prover.prove_batch(xs, conc), my_inputs, batch, steps, warmup, dist,
                                  torch.cuda.synchronize if cuda else None, "cuda" if cuda else "cpu")
-    # the proofs of the last batch must verify (host verifier) — an invalid proof voids the measurement
+    # EVERY proof of the last step must verify — an invalid proof voids the measurement. One proof through the single-threaded
+    # host verifier (dp_verify, the latency figure), then the whole step through dp_verify_batch: protocol checks on the host
+    # threads, the Merkle paths of each proof (125 000 compress() for Dense-4M) authenticated on the GPU in one launch.
     lo = (warmup + steps - 1) * batch
-    t0 = time.perf_counter()
-    dpa.verify(vblob, last[0][0], my_inputs[lo], last[1][0])
-    one = max(time.perf_counter() - t0, 1e-4)
-    stride = max(1, int(batch * one / VERIFY_BUDGET_S + 0.999))
-    checked = 1
-    for j in range(stride, batch, stride):
-        dpa.verify(vblob, last[0][j], my_inputs[lo + j], last[1][j])
-        checked += 1
+    checked, one, vb_ms = 0, 0.0, 0.0
+    if batch:
+        t0 = time.perf_counter()
+        dpa.verify(vblob, last[0][0], my_inputs[lo], last[1][0])
+        one = max(time.perf_counter() - t0, 1e-4)
+        verdicts, vb_ms = dpa.verify_batch(vblob, last[0], my_inputs[lo:lo + batch], last[1], dev=dev)
+        assert not verdicts.any(), f"{workload}: {int((verdicts != 0).sum())} of {batch} proofs of the last step were rejected"
+        checked = batch
     golden_ok = None
-    if gold is not None:  # bit identity of what was timed: the proof of the golden input out of the last timed step (throughput mode)
+    if gold is not None and batch:  # bit identity of what was timed: the proof of the golden input out of the last timed step (throughput mode)
         import hashlib
-        g = last[0][GOLDEN_SLOT]
-        golden_ok = bool(g.size == gold["proof_words"] and hashlib.sha256(g.tobytes()).hexdigest() == gold["sha256"] and [int(v) for v in last[1][GOLDEN_SLOT]] == gold["output"])
+        g = last[0][gslot]
+        golden_ok = bool(g.size == gold["proof_words"] and hashlib.sha256(g.tobytes()).hexdigest() == gold["sha256"] and [int(v) for v in last[1][gslot]] == gold["output"])
         assert golden_ok, f"{workload}: the throughput-mode proof of the golden input differs from the oracle's proof stream"
     in_flight = prover.in_flight()
     rep = kernel_profile(dev, prover, my_inputs[0]) if profile else None
     ctx.free()  # releases the workers' arenas too: the next workload sizes its own against the free HBM
     return dict(mb=mb, elapsed=elapsed, latency_ms=latency_ms, first_ms=first_ms, setup_s=setup_s, proof_words=int(last[0][0].size),
-                verified=checked, verify_ms=round(1000 * one, 2), in_flight=in_flight, kernel_report=rep, golden_ok=golden_ok)
+                verified=checked, verify_ms=round(1000 * one, 2), verify_batch_ms_per_proof=round(vb_ms / max(1, checked), 3), in_flight=in_flight, kernel_report=rep, golden_ok=golden_ok)
 
 
 def cnn_steps(steps):
@@ -189,6 +203,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sumcheck24", action="store_true", help="skip the standalone 2^24 sumcheck roofline section")
     ap.add_argument("--no-cnn", action="store_true", help="skip the CNN-264k section of a Dense-4M run")
+    ap.add_argument("--batch", type=int, default=0, help="BASELINE config 4: ONE fixed batch of this many proofs per step, split over the ranks (strong scaling); "
+                                                         "0 = the default weak-scaling run (fixed work per GPU)")
     ap.add_argument("--concurrency", type=int, default=0, help=f"independent proofs in flight per GPU (0 = {DEFAULT_IN_FLIGHT})")
     args = ap.parse_args()
 
@@ -229,15 +245,15 @@ def main():
     conc = args.concurrency if args.concurrency > 0 else DEFAULT_IN_FLIGHT
 
     dev = dpa.Device(local_rank)
-    main_w = measure_workload(dpa, dev, args.workload, conc, args.steps, args.warmup, world, rank, dist, torch, profile=rank == 0)
+    main_w = measure_workload(dpa, dev, args.workload, conc, args.steps, args.warmup, world, rank, dist, torch, profile=rank == 0, strong_batch=args.batch)
     cnn_w = None
-    if args.workload == "dense_4m" and not args.no_cnn:
+    if args.workload == "dense_4m" and not args.no_cnn and not args.batch:
         cnn_w = measure_workload(dpa, dev, "cnn_264k", conc, cnn_steps(args.steps), min(1, args.warmup), world, rank, dist, torch)
 
     result = None
     if rank == 0:
         def rate(w, steps):
-            return world * steps * BATCHES_PER_STEP * conc / w["elapsed"]
+            return (steps * args.batch if args.batch else world * steps * BATCHES_PER_STEP * conc) / w["elapsed"]
         value = rate(main_w, args.steps)
         # ---- roofline. The proof is integer work with no dense contraction (MFMA unused by design). Its chip-filling work is
         # Poseidon2: every Merkle node is one compress() = 2 permutations = ~1040 Goldilocks multiplications for 96 B moved
@@ -282,21 +298,24 @@ def main():
                    "ms_per_step": round(1000.0 * cnn_w["elapsed"] / csteps, 3), "steps": csteps, "proofs_per_step_per_gpu": BATCHES_PER_STEP * conc, "proofs_in_flight_per_gpu": cnn_w["in_flight"],
                    "single_proof_latency_ms": round(cnn_w["latency_ms"], 2), "vs_baseline": round(rate(cnn_w, csteps) / PUBLISHED["cnn_264k"], 3),
                    "baseline_note": "reference README.md:17 CNN-264k proving time 1242 ms on unstated CPU hardware",
-                   "workload": WORKLOADS["cnn_264k"], "proof_words": cnn_w["proof_words"], "setup_s": round(cnn_w["setup_s"], 2), "verified": True, "golden_sha256_ok": cnn_w["golden_ok"], "verified_proofs_of_last_step": cnn_w["verified"],
+                   "workload": WORKLOADS["cnn_264k"], "proof_words": cnn_w["proof_words"], "setup_s": round(cnn_w["setup_s"], 2), "verified": True, "golden_sha256_ok": cnn_w["golden_ok"], "verified_proofs_of_last_step": cnn_w["verified"], "verify_batch_ms_per_proof": cnn_w["verify_batch_ms_per_proof"],
                    "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else cpu_baseline(cnn_w["mb"], "cnn_264k")}
         result = {
             "metric": {"dense_4m": "proofs/sec (prover), Dense-4M", "cnn_264k": "proofs/sec (prover), CNN-264k"}.get(args.workload, "proofs/sec (prover), MLP-w256"),
             "value": round(value, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1000.0 * main_w["elapsed"] / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1000.0 * main_w["elapsed"] / args.steps, 3), "higher_is_better": True, "scaling": "strong" if args.batch else "weak",
             "vs_baseline": round(value / PUBLISHED[args.workload], 3) if args.workload in PUBLISHED else None,
             "baseline_note": "reference README.md:17-18 proving times (Dense-4M 2335 ms, CNN-264k 1242 ms) on unstated CPU hardware",
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload], "arithmetic": "Goldilocks p = 2^64 - 2^32 + 1 and its degree-2 extension (canonical u64 words)",
-                       "proofs_per_step_per_gpu": BATCHES_PER_STEP * conc, "proofs_in_flight_per_gpu": main_w["in_flight"], "proofs_per_rank": args.steps * BATCHES_PER_STEP * conc,
+                       "proofs_per_step_per_gpu": (strong_share(args.batch, world, 0) if args.batch else BATCHES_PER_STEP * conc), "proofs_in_flight_per_gpu": main_w["in_flight"],
+                       "proofs_per_step_all_gpus": (args.batch if args.batch else world * BATCHES_PER_STEP * conc),
+                       "strong_scaling_note": (f"BASELINE config 4: one batch of {args.batch} independent proofs per step split over {world} GPU(s) (rank r proves proofs r, r+{world}, ...); "
+                                               "every rank commits the model itself (Context::generate recomputed per rank, outside the timed region), no data-path collective") if args.batch else None,
                        "single_proof_latency_ms": round(main_w["latency_ms"], 2), "first_proof_ms": round(main_w["first_ms"], 2),
                        "host_cpu_budget": budget, "host_threads_per_rank": int(os.environ["DP_HOST_THREADS"]),
                        "parallelism": f"replicas x{world} GPUs x {main_w['in_flight']} proofs in flight per GPU in lock-step cohorts of {os.environ.get('DP_COHORT', '12')} (independent proofs, no data-path collective)",
-                       "proof_words": main_w["proof_words"], "setup_s": round(main_w["setup_s"], 2), "verified": True, "golden_sha256_ok": main_w["golden_ok"], "verified_proofs_of_last_step": main_w["verified"], "verify_ms_per_proof": main_w["verify_ms"],
+                       "proof_words": main_w["proof_words"], "setup_s": round(main_w["setup_s"], 2), "verified": True, "golden_sha256_ok": main_w["golden_ok"], "verified_proofs_of_last_step": main_w["verified"], "verify_ms_per_proof": main_w["verify_ms"], "verify_batch_ms_per_proof": main_w["verify_batch_ms_per_proof"],
                        "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DP_") or k == "GPU_MAX_HW_QUEUES"}, "device": dev.name},
             "roofline": roofline, "cpu_baseline": cpu, "cnn_264k": cnn, "sumcheck24": sc24, "sumcheck24_sharded": None,
         }

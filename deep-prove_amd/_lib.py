@@ -72,6 +72,7 @@ SIGNATURES = {
     "dp_model_in_flight": (C.c_int32, [vp, C.POINTER(C.c_size_t)]),
     "dp_model_output_len": (C.c_int32, [vp, C.POINTER(C.c_size_t)]),
     "dp_host_cpu_budget": (C.c_double, []),
+    "dp_verify_batch": (C.c_int32, [vp, u64p, C.c_size_t, C.POINTER(u64p), C.POINTER(C.c_size_t), i64p, C.c_size_t, i64p, C.c_size_t, C.c_size_t, C.c_int32, i32p, C.POINTER(C.c_double)]),
     "dp_verify": (C.c_int32, [u64p, C.c_size_t, u64p, C.c_size_t, i64p, C.c_size_t, i64p, C.c_size_t]),
 }
 

@@ -427,6 +427,23 @@ def host_cpu_budget():
     return float(_lib.load().dp_host_cpu_budget())
 
 
+def verify_batch(verifier_blob, proofs, inputs_i64, outputs_i64, dev=None, threads=0):
+    """dp_verify_batch: verdict per proof (0 accepted, -5 rejected, -1 malformed) and the wall time in ms. With `dev` the Merkle
+    paths are authenticated on the GPU (one launch per proof), the protocol checks run on host threads either way."""
+    vb = np.ascontiguousarray(verifier_blob, dtype=np.uint64)
+    keep = [np.ascontiguousarray(p, dtype=np.uint64) for p in proofs]
+    n = len(keep)
+    pws = (u64p * n)(*[k.ctypes.data_as(u64p) for k in keep])
+    pns = (C.c_size_t * n)(*[k.size for k in keep])
+    x = np.ascontiguousarray(inputs_i64, dtype=np.int64).reshape(n, -1)
+    y = np.ascontiguousarray(outputs_i64, dtype=np.int64).reshape(n, -1)
+    res = np.zeros(n, dtype=np.int32)
+    ms = C.c_double()
+    check(_lib.load().dp_verify_batch(dev.h if dev is not None else None, vb.ctypes.data_as(u64p), vb.size, pws, pns, x.ctypes.data_as(i64p), x.shape[1],
+                                      y.ctypes.data_as(i64p), y.shape[1], n, threads, res.ctypes.data_as(i32p), C.byref(ms)))
+    return res, ms.value
+
+
 def verify(verifier_blob, proof_words, input_i64, output_i64):
     """zkml::verify (zkml/src/iop/verifier.rs:306-318). Host only. Raises DeepProveError(DP_ERR_VERIFY) on rejection."""
     vb = np.ascontiguousarray(verifier_blob, dtype=np.uint64)

@@ -518,4 +518,56 @@ int32_t dp_verify(const uint64_t* vb, size_t vn, const uint64_t* pw, size_t pn, 
   });
 }
 
+/* zkml::verify for a batch of proofs of one model: the protocol checks run on host threads, every Merkle path of a proof is
+ * authenticated on the device in one launch (ctx == NULL: on the host threads as well). results[i] = DP_OK / DP_ERR_VERIFY /
+ * DP_ERR_ARG per proof; returns DP_OK when the batch was processed (whatever the verdicts). */
+int32_t dp_verify_batch(dp_ctx* ctx, const uint64_t* vb, size_t vn, const uint64_t* const* proof_words, const size_t* proof_nwords, const int64_t* inputs, size_t ninput,
+                        const int64_t* outputs, size_t noutput, size_t nproofs, int32_t threads, int32_t* results, double* wall_ms) {
+  return guard([&] {
+    DP_REQUIRE(vb && proof_words && proof_nwords && inputs && outputs && results, DP_ERR_ARG, "bad arguments");
+    auto t0 = std::chrono::steady_clock::now();
+    const VerifierContext vc = vctx_from_words(vb, vn);
+    size_t nth = threads > 0 ? (size_t)threads : (size_t)std::max(1.0, host_cpu_budget() - 2.0);
+    nth = std::max<size_t>(1, std::min(nth, nproofs));
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+      for (;;) {
+        const size_t i = next.fetch_add(1);
+        if (i >= nproofs) return;
+        std::vector<MerkleJob> jobs;
+        try {
+          Proof p = deserialize_proof(proof_words[i], proof_nwords[i]);
+          IO io; io.input.assign(inputs + i * ninput, inputs + (i + 1) * ninput); io.output.assign(outputs + i * noutput, outputs + (i + 1) * noutput);
+          Transcript t = default_transcript();
+          merkle_sink() = &jobs;
+          try { verify(vc, p, io, t); } catch (...) { merkle_sink() = nullptr; throw; }
+          merkle_sink() = nullptr;
+          // the recorded paths: one flat pool of sibling digests + per-path leaf digest, root, leaf-pair index, offset, depth
+          const size_t n = jobs.size();
+          size_t pool_n = 0; for (const MerkleJob& j : jobs) pool_n += j.depth;
+          std::vector<u64> leaf(4 * n), root(4 * n), x(n), off(n), depth(n), pool(4 * pool_n);
+          size_t o = 0;
+          for (size_t k = 0; k < n; k++) {
+            const MerkleJob& j = jobs[k];
+            for (int q = 0; q < 4; q++) { leaf[4 * k + q] = j.leaf.v[q]; root[4 * k + q] = j.root.v[q]; }
+            x[k] = j.x; off[k] = o; depth[k] = j.depth;
+            for (size_t l = 0; l < j.depth; l++) for (int q = 0; q < 4; q++) pool[4 * (o + l) + q] = j.path[l].v[q];
+            o += j.depth;
+          }
+          bool ok;
+          if (ctx) { CtxLock lk(ctx); ok = ctx->dev->merkle_paths_check(leaf.data(), root.data(), x.data(), off.data(), depth.data(), n, pool.data(), pool_n, nullptr); }
+          else { ok = true; for (const MerkleJob& j : jobs) if (!merkle_job_ok(j)) { ok = false; break; } }
+          results[i] = ok ? DP_OK : DP_ERR_VERIFY;
+        } catch (const DpError& e) { merkle_sink() = nullptr; results[i] = e.code == DP_ERR_VERIFY ? DP_ERR_VERIFY : DP_ERR_ARG; }
+        catch (const std::exception&) { merkle_sink() = nullptr; results[i] = DP_ERR_ARG; }
+      }
+    };
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < nth; k++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  });
+}
+
 }  // extern "C"

@@ -256,6 +256,19 @@ class Dev {
   // K9: FRI fold of a bit-reversed codeword of length 2^(level+1)
   virtual DBuf fri_fold(const DBuf& oracle, unsigned level, Ext ch) = 0;
   virtual void bitrev_copy(const DBuf& dst, const DBuf& src) = 0;
+  // verifier side (K8 in reverse): authenticate `n` Merkle paths, each from its leaf-pair digest up to its root
+  // (mpcs/src/util/merkle_tree.rs:331-420): true iff all authenticate; *first_bad = index of one that does not.
+  // leaf / root: 4 words per job; x: index of the leaf pair; path_off / depth: digests [path_off, path_off + depth) of `pool`
+  virtual bool merkle_paths_check(const u64* leaf, const u64* root, const u64* x, const u64* path_off, const u64* depth, size_t n, const u64* pool, size_t pool_digests, size_t* first_bad) {
+    for (size_t j = 0; j < n; j++) {
+      Digest h; for (int k = 0; k < 4; k++) h.v[k] = leaf[4 * j + k];
+      size_t xi = (size_t)x[j];
+      DP_REQUIRE(path_off[j] + depth[j] <= pool_digests, DP_ERR_ARG, "merkle_paths_check: path outside the pool");
+      for (size_t l = 0; l < depth[j]; l++) { Digest sib; for (int k = 0; k < 4; k++) sib.v[k] = pool[4 * (path_off[j] + l) + k]; h = (xi & 1) ? host_compress(sib, h) : host_compress(h, sib); xi >>= 1; }
+      for (int k = 0; k < 4; k++) if (h.v[k] != root[4 * j + k]) { if (first_bad) *first_bad = j; return false; }
+    }
+    return true;
+  }
   // K14: for each descriptor: the leaf pair (as stored) followed by the Merkle path (height-1 digests)
   virtual void query_gather(const QueryDesc* d, size_t nd, std::vector<std::vector<u64>>& out) = 0;
 };

@@ -722,6 +722,24 @@ KBODY k_merkle_layer_lp(const u64* in, u64* out, size_t cnt) {
   if (c_dbg_skip_hash) { for (; g < cnt; g += stride) if ((threadIdx.x & 7) < 4) out[4 * g + (threadIdx.x & 7)] = in[8 * g + (threadIdx.x & 7)]; return; }
   for (; g < cnt; g += stride) p2l_compress(in + 8 * g, out + 4 * g, threadIdx.x & 63);
 }
+// verifier: one Merkle path per lane, from the leaf-pair digest up to the root (authenticate_merkle_path_root,
+// mpcs/src/util/merkle_tree.rs:331-420). meta[3j..] = {index of the leaf pair, first digest of the path in `pool`, depth};
+// bad[0] counts the paths that do not authenticate, bad[1] = the smallest index of one
+KBODY k_merkle_paths(const u64* leaf, const u64* root, const u64* meta, const u64* pool, size_t n, unsigned long long* bad) {
+  for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+    u64 h[4] = {leaf[4 * j], leaf[4 * j + 1], leaf[4 * j + 2], leaf[4 * j + 3]};
+    u64 x = meta[3 * j];
+    const u64* p = pool + 4 * meta[3 * j + 1];
+    const unsigned depth = (unsigned)meta[3 * j + 2];
+    for (unsigned l = 0; l < depth; l++) {
+      u64 sib[4] = {p[4 * l], p[4 * l + 1], p[4 * l + 2], p[4 * l + 3]}, o[4];
+      if (x & 1) p2f::compress(sib, h, o, c_rc); else p2f::compress(h, sib, o, c_rc);
+      h[0] = o[0]; h[1] = o[1]; h[2] = o[2]; h[3] = o[3];
+      x >>= 1;
+    }
+    if (h[0] != root[4 * j] || h[1] != root[4 * j + 1] || h[2] != root[4 * j + 2] || h[3] != root[4 * j + 3]) { atomicAdd(&bad[0], 1ull); atomicMin(&bad[1], (unsigned long long)j); }
+  }
+}
 struct TailDesc { u64* nodes; size_t off; size_t cnt; };
 // All Merkle layers above an already computed layer of `cnt` (<= 2048) digests, one workgroup per tree, no relaunch
 // between layers. Wide layers hash one node per lane, narrow ones use the 8-lane permutation. roots[4*tree..] = root.
@@ -2743,6 +2761,25 @@ class HipDev : public Dev {
   const char* name() const override { return name_.c_str(); }
   size_t arena_peak() const { return arena_peak_; }
   void arena_peak_reset() { arena_peak_ = arena_off_; }
+  // Dev::merkle_paths_check on the GPU: the job arrays go up in one staging pass, one launch, two words come back
+  bool merkle_paths_check(const u64* leaf, const u64* root, const u64* x, const u64* path_off, const u64* depth, size_t n, const u64* pool, size_t pool_digests, size_t* first_bad) override {
+    if (!n) return true;
+    DP_REQUIRE(!co_, DP_ERR_ARG, "merkle_paths_check: not from inside a cohort");
+    const size_t mk = mark();
+    std::vector<u64> meta(3 * n);
+    for (size_t j = 0; j < n; j++) { DP_REQUIRE(path_off[j] + depth[j] <= pool_digests, DP_ERR_ARG, "merkle_paths_check: path outside the pool"); meta[3 * j] = x[j]; meta[3 * j + 1] = path_off[j]; meta[3 * j + 2] = depth[j]; }
+    DBuf dl = alloc(4 * n, false), dr = alloc(4 * n, false), dm = alloc(3 * n, false), dp = alloc(std::max<size_t>(4 * pool_digests, 4), false), db = alloc(2, false);
+    upload(dl, leaf); upload(dr, root); upload(dm, meta.data());
+    if (pool_digests) upload(dp, pool);
+    const u64 init[2] = {0, ~0ull};
+    upload(db, init);
+    nb_ = 96.0 * (double)pool_digests; DPL(k_merkle_paths, dim3(grid_for(n, 4096)), dim3(TPB), (const u64*)dl.p, (const u64*)dr.p, (const u64*)dm.p, (const u64*)dp.p, n, (unsigned long long*)db.p);
+    u64 res[2];
+    download(db, res);
+    release(mk);
+    if (res[0] && first_bad) *first_bad = (size_t)res[1];
+    return res[0] == 0;
+  }
   // Poseidon2 compress() per second of the one-node-per-lane Merkle kernel on `nodes` nodes (chip-filling when nodes >> 458 752
   // = 256 CUs x 28 waves x 64 lanes): the VALU-integer peak bench.py prices the whole job's hashing against, measured with
   // HIP events on this context's stream in the same run. The input is whatever the arena holds: the arithmetic is branch-free.

@@ -230,8 +230,20 @@ inline Digest host_leaf_pair_digest(bool is_ext, Ext l, Ext r) {  // hash_two_le
   else { d.v[0] = l.c0; d.v[1] = r.c0; d.v[2] = 0; d.v[3] = 0; }
   return d;
 }
+// A verifier spends its time here: ~125 000 compress() for one Dense-4M proof (200 queries x (12 oracle trees + ~35
+// commitments) x path depth), 0.4 s of one host core against 0.1 ms of the GPU. A batch verifier therefore only RECORDS the
+// paths while it runs the protocol checks (g_merkle_sink set, per thread) and authenticates all of them at once afterwards
+// (Dev::merkle_paths_check: one path per lane); the paths point into the Proof object, which outlives the check.
+struct MerkleJob { Digest leaf; size_t x; const Digest* path; size_t depth; Digest root; };
+inline std::vector<MerkleJob>*& merkle_sink() { static thread_local std::vector<MerkleJob>* s = nullptr; return s; }
+inline bool merkle_job_ok(const MerkleJob& j) {
+  Digest h = j.leaf; size_t x = j.x;
+  for (size_t l = 0; l < j.depth; l++) { h = (x & 1) ? host_compress(j.path[l], h) : host_compress(h, j.path[l]); x >>= 1; }
+  return h == j.root;
+}
 // authenticate_merkle_path_root (merkle_tree.rs:331-420)
 inline void check_merkle_path(const CodewordQuery& q, const Digest& root) {
+  if (std::vector<MerkleJob>* sink = merkle_sink()) { sink->push_back({host_leaf_pair_digest(q.is_ext, q.left, q.right), q.index >> 1, q.path.data(), q.path.size(), root}); return; }
   Digest h = host_leaf_pair_digest(q.is_ext, q.left, q.right);
   size_t x = q.index >> 1;
   for (const Digest& sib : q.path) {

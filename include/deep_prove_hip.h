@@ -203,6 +203,15 @@ double dp_host_cpu_budget(void);
 /* serialisable verifier-side context (model commitments, shapes, tables) */
 int32_t dp_model_verifier_blob(const dp_model* m, uint64_t** words, size_t* nwords);
 /* zkml::verify(ctx, proof, io, transcript) — host only, default transcript "m2vec" */
+/* zkml::verify for a batch of proofs of one model at prover speed: a verifier's time is Merkle-path hashing (~125 000 Poseidon2
+ * compress() for one Dense-4M proof: 0.4 s of a host core, 0.1 ms of the GPU), so the protocol checks (transcript, sumchecks,
+ * logup, Basefold fold checks: zkml/src/iop/verifier.rs:72-318, mpcs/src/basefold.rs:964-1098) run on `threads` host threads
+ * (0 = CPU budget - 2) and every Merkle path of a proof is authenticated in ONE device launch (mpcs/src/util/merkle_tree.rs:
+ * 331-420; ctx == NULL: on the host threads too). inputs / outputs: nproofs x ninput / noutput words. results[i] = DP_OK,
+ * DP_ERR_VERIFY (rejected) or DP_ERR_ARG (malformed stream); the return value only reports whether the batch was processed. */
+int32_t dp_verify_batch(dp_ctx* ctx, const uint64_t* verifier_blob, size_t blob_nwords, const uint64_t* const* proof_words,
+                        const size_t* proof_nwords, const int64_t* inputs, size_t ninput, const int64_t* outputs, size_t noutput,
+                        size_t nproofs, int32_t threads, int32_t* results, double* wall_ms);
 int32_t dp_verify(const uint64_t* verifier_blob, size_t blob_nwords, const uint64_t* proof_words, size_t proof_nwords,
                   const int64_t* input, size_t ninput, const int64_t* output, size_t noutput);
 

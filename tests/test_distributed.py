@@ -146,3 +146,34 @@ def test_bench_guarded_section():
     bench.guarded(lambda: None, 0.2, fired.set)  # ... and is disarmed when the section returns in time
     time.sleep(0.4)
     assert not fired.is_set()
+
+
+def _strong_worker(rank, world, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    import numpy as np
+    import bench
+    B, steps, warmup = 7, 2, 1  # an odd batch: the shares differ by one
+    mine = bench.strong_share(B, world, rank)
+    ids = [s * B + j for s in range(steps + warmup) for j in bench.shard(B, world, rank)]
+    inputs = np.array(ids, dtype=np.int64).reshape(-1, 1)
+    seen = []
+    elapsed, last = bench.timed_region(lambda xs: (seen.extend(int(v) for v in xs[:, 0]), xs)[1], inputs, mine, steps, warmup, dist)
+    assert seen == ids and len(last) == mine
+    gathered = [None] * world
+    dist.all_gather_object(gathered, ids)
+    assert sorted(v for g in gathered for v in g) == list(range((steps + warmup) * B))  # every proof of every step exactly once
+    open(os.path.join(tmpdir, f"strong{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+def test_config4_fixed_batch_split_over_two_ranks(tmp_path):
+    """bench.py --batch B (BASELINE config 4, strong scaling): the shares of one fixed batch partition it, step by step"""
+    import bench
+    for world in (1, 2, 4, 8):
+        assert sum(bench.strong_share(64, world, r) for r in range(world)) == 64
+        assert max(bench.strong_share(64, world, r) for r in range(world)) == 64 // world
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_strong_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"strong{r}") for r in range(world))

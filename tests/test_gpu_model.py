@@ -169,3 +169,31 @@ def test_config3_cnn264k_full_size(dev):
         assert (outs[i] == mb.run(xs[i])).all()
         dpa.verify(ctx.verifier_blob(), proofs[i], xs[i], outs[i])
     ctx.free()
+
+
+def test_batch_verifier_with_device_side_merkle_paths(dev):
+    """dp_verify_batch with a device: every Merkle path of a proof authenticated in one launch (k_merkle_paths), protocol checks
+    on host threads; the verdicts equal the host verifier's on accepted and on tampered proofs"""
+    import deep_prove_amd as dpa
+    mb = dpa.models.mlp(2, 64, config=47)
+    ctx = dpa.Context.generate(dev, mb.blob())
+    pr = dpa.Prover(ctx)
+    xs = np.stack([mb.input(8000 + i) for i in range(12)])
+    proofs, outs, _ = pr.prove_batch(xs, 12)
+    vb = ctx.verifier_blob()
+    res, ms = dpa.verify_batch(vb, proofs, xs, outs, dev=dev)
+    assert not res.any()
+    tampered = [p for p in proofs]
+    tampered[3] = proofs[3].copy(); tampered[3][-40] ^= np.uint64(1)          # a sibling digest of the last Merkle path
+    tampered[7] = proofs[7].copy(); tampered[7][proofs[7].size // 2] ^= np.uint64(1)
+    tampered[9] = proofs[9][:5000]
+    wrong = outs.copy(); wrong[11, 0] += 1
+    res, _ = dpa.verify_batch(vb, tampered, xs, wrong, dev=dev, threads=4)
+    expect = [0] * 12
+    expect[3] = -5; expect[7] = -5; expect[9] = -1; expect[11] = -5
+    got = [int(v) for v in res]
+    assert got[3] == -5 and got[9] == -1 and got[11] == -5 and got[7] in (-5, -1) and [g for i, g in enumerate(got) if i not in (3, 7, 9, 11)] == [0] * 8, got
+    for i in (3, 11):  # the single-proof host verifier agrees
+        with pytest.raises(dpa.DeepProveError):
+            dpa.verify(vb, tampered[i], xs[i], wrong[i])
+    ctx.free()

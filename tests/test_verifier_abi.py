@@ -3,10 +3,13 @@ no device) — ports of the reference's own tests with the ORACLE as the prover 
 independent implementations must agree on transcript, message layout and every check:
   sumcheck/src/test.rs:23-56   random VirtualPolynomial, nv = 1 and 12: verify, then sub-claim == the polynomial at the point
   zkml/src/lookup/logup_gkr/mod.rs:26-94   two random columns, n = 5..: verify, fractional sums, column claims."""
+import os
+
 import numpy as np
 import pytest
 
 P = 0xFFFFFFFF00000001
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _ops():
@@ -166,3 +169,26 @@ def test_basefold_batch_verify_port_of_reference_round_trips(oracle, shape):
     # the commitment depends on the parameter size (coset shift, rs.rs:494-499): a verifier with other parameters rejects
     with pytest.raises(dpa.DeepProveError):
         dpa.Basefold.batch_verify(maxsize * 4, roots, nvs, is_base, points, evals, proof, dpa.Transcript(b"test"))
+
+
+def test_batch_verifier_host_only_accepts_and_rejects_per_proof():
+    """dp_verify_batch without a device (ctx NULL): protocol checks on host threads with the Merkle paths deferred and then
+    authenticated on the same threads — a verdict per proof: the golden proofs are accepted; a flipped word inside a layer
+    proof, inside a Merkle path of the batch opening, a wrong output and a truncated stream are each rejected on their own"""
+    import deep_prove_amd as dpa
+    for name, inner in (("mlp_w8.npz", 300), ("cnn_tiny.npz", 900)):
+        g = np.load(os.path.join(ROOT, "tests", "golden", name))
+        p = g["proof"]
+        bad_inner = p.copy(); bad_inner[inner] ^= np.uint64(1)
+        bad_path = p.copy(); bad_path[-40] ^= np.uint64(1)
+        proofs = [p, bad_inner, p, bad_path, p[:1000], p]
+        xs = np.stack([g["input"]] * len(proofs))
+        ys = np.stack([g["output"]] * len(proofs))
+        ys[5, 0] += 1
+        res, ms = dpa.verify_batch(g["verifier_blob"], proofs, xs, ys, threads=3)
+        got = [int(v) for v in res]
+        # (a flipped word is a rejection when it stays a canonical field element / consistent length, a malformed stream otherwise)
+        assert got[0] == 0 and got[2] == 0 and got[1] in (-5, -1) and got[3] in (-5, -1) and got[4] == -1 and got[5] == -5, (name, res)
+        if name == "cnn_tiny.npz":
+            assert got[3] == -5  # this one sits in a sibling digest of the batch opening's last Merkle path
+        assert ms > 0
