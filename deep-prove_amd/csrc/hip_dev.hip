@@ -683,28 +683,49 @@ constexpr int DPP_QUAD_ROT3 = 0x93;     // quad_perm [3,0,1,2]: lane j reads j+3
 constexpr int DPP_QUAD_XOR1 = 0xB1;     // quad_perm [1,0,3,2]
 constexpr int DPP_QUAD_REV = 0x1B;      // quad_perm [3,2,1,0]
 constexpr int DPP_HALF_MIRROR = 0x141;  // row_half_mirror: lane i reads 7-i within its group of 8
-__device__ __forceinline__ u64 p2l_mds_light(u64 s, int lane) {
-  (void)lane;
-  u64 b = dpp_u64<DPP_QUAD_ROT1>(s), c = dpp_u64<DPP_QUAD_ROT2>(s), d = dpp_u64<DPP_QUAD_ROT3>(s);
-  u64 t = gl_add(gl_add(gl_add(gl_add(s, b), gl_add(c, d)), s), gl_dbl(b));  // row j of circ(2,3,1,1)
-  u64 o = dpp_u64<DPP_QUAD_REV>(dpp_u64<DPP_HALF_MIRROR>(t));                // lane i reads i ^ 4
-  return gl_add(gl_dbl(t), o);
+constexpr int DPP_QUAD_BCAST0 = 0x00;   // quad_perm [0,0,0,0]: every lane of a quad reads the quad's lane 0
+// The 8-lane permutation in the formulation of poseidon2_fast.h: state words are any u64 representative, the linear layers
+// are accumulated as exact integers (64 + 32 bits) THROUGH the DPP moves and reduced once together with the next round
+// constant. One wave on this dependent chain runs at ~8 cycles per instruction, so instructions are what counts: a modular
+// add is ~9 of them, a wide add 3. (The sponge of every fused protocol kernel and the narrow Merkle layers run on this.)
+template <int CTRL> __device__ __forceinline__ p2f::W dpp_w(p2f::W a) { p2f::W r; r.lo = dpp_u64<CTRL>(a.lo); r.hi = (u32)dpp_u64<CTRL>((u64)a.hi); return r; }
+// external layer circ(2 M4, M4) on the word of this lane: exact, < 21 * 2^64
+__device__ __forceinline__ p2f::W p2l_mds_wide(u64 s) {
+  using namespace p2f;
+  W ws = w_of(s), b = w_of(dpp_u64<DPP_QUAD_ROT1>(s)), c = w_of(dpp_u64<DPP_QUAD_ROT2>(s)), d = w_of(dpp_u64<DPP_QUAD_ROT3>(s));
+  W t = w_add(w_add(w_add(ws, ws), w_add(b, w_add(b, b))), w_add(c, d));  // row j of circ(2,3,1,1): 2s + 3b + c + d
+  W o = dpp_w<DPP_QUAD_REV>(dpp_w<DPP_HALF_MIRROR>(t));                     // lane i reads i ^ 4
+  return w_add(w_add(t, t), o);
 }
+__device__ __forceinline__ u64 p2l_mds_light(u64 s, int lane) { (void)lane; return p2f::canon(p2f::w_reduce(p2l_mds_wide(s))); }
 __device__ __forceinline__ u64 p2l_permute(u64 s, int lane) {
-  int i = lane & 7;
-  s = p2l_mds_light(s, lane);
-  for (int r = 0; r < 4; r++) { s = p2_sbox(gl_add(s, c_rc[r * 8 + i])); s = p2l_mds_light(s, lane); }
-  u64 diag = c_rc[86 + i];
+  using namespace p2f;
+  const int i = lane & 7;
+  W w = p2l_mds_wide(s);
+  for (int r = 0; r < 4; r++) { s = sbox(w_reduce(w_add64(w, c_rc[r * 8 + i]))); w = p2l_mds_wide(s); }
+  s = w_reduce(w);
+  const u64 diag = c_rc[86 + i];
   for (int r = 0; r < 22; r++) {
-    if (i == 0) s = p2_sbox(gl_add(s, c_rc[32 + r]));
-    u64 sum = s;
-    sum = gl_add(sum, dpp_u64<DPP_QUAD_XOR1>(sum));
-    sum = gl_add(sum, dpp_u64<DPP_QUAD_ROT2>(sum));
-    sum = gl_add(sum, dpp_u64<DPP_HALF_MIRROR>(sum));  // every lane of a quad holds the quad sum: any lane of the other quad will do
-    s = gl_add(gl_mul(s, diag), sum);
+    // the words that keep their value this round, summed over the group (independent of the S-box chain below)
+    W rest = i == 0 ? w_of(0) : w_of(s);
+    rest = w_add(rest, dpp_w<DPP_QUAD_XOR1>(rest));
+    rest = w_add(rest, dpp_w<DPP_QUAD_ROT2>(rest));
+    rest = w_add(rest, dpp_w<DPP_HALF_MIRROR>(rest));  // every lane of a quad holds the quad sum: any lane of the other quad will do
+    // x^7 of word 0 (every lane computes, lane 0's counts), broadcast to the group of 8
+    const u64 x7 = sbox(w_reduce(w_add64(w_of(s), c_rc[32 + r])));
+    const u64 q = dpp_u64<DPP_QUAD_BCAST0>(x7), m = dpp_u64<DPP_HALF_MIRROR>(q);
+    const u64 x7b = i < 4 ? q : m;
+    const W sum = w_add64(rest, x7b);
+    // y_i = d_i x_i + sum, one 128 -> 64 reduction (the high word of the product stays below p after + sum)
+    unsigned __int128 pr = (unsigned __int128)(i == 0 ? x7b : s) * diag;
+    u64 lo, hi = (u64)(pr >> 64);
+    bool cy = __builtin_add_overflow((u64)pr, sum.lo, &lo);
+    hi += (u64)sum.hi + (cy ? 1u : 0u);
+    s = red128(lo, hi);
   }
-  for (int r = 0; r < 4; r++) { s = p2_sbox(gl_add(s, c_rc[54 + r * 8 + i])); s = p2l_mds_light(s, lane); }
-  return s;
+  w = w_of(s);
+  for (int r = 0; r < 4; r++) { s = sbox(w_reduce(w_add64(w, c_rc[54 + r * 8 + i]))); w = p2l_mds_wide(s); }
+  return canon(w_reduce(w));  // canonical: the host resumes transcripts from these words
 }
 // in: 8 words (two digests), out: 4 words; executed by the 8 lanes of one group together
 __device__ __forceinline__ void p2l_compress(const u64* in, u64* out, int lane) {
@@ -1140,11 +1161,15 @@ KBODY k_sc_persist(const ScPersistArgs& a, Ext* result, unsigned long long* flag
   if (autofs) wc_load(wc, fsl, lane);
   unsigned long long fcs = 0; int round = 0;
   if (a.has_r0) {
-    sc_fold_all(a, cur, cur_ext, dstA, n / 2, a.r0);
+    // (several workgroups: the fold with the pending challenge fills this workgroup's slice of the first level region of bufA;
+    // the regions of the later levels follow it — see the comment at the round fold below)
+    const size_t off0 = a.nwg > 1 ? g * (n / 2) : 0;
+    sc_fold_all(a, cur, cur_ext, dstA, n / 2, a.r0, off0);
     __syncthreads();
-    if (tid < a.ntabs) { cur[tid] = dstA[tid]; cur_ext[tid] = 1; }
+    if (tid < a.ntabs) { cur[tid] = dstA[tid] + off0; cur_ext[tid] = 1; }
     __syncthreads();
     n /= 2; useA = false;
+    if (a.nwg > 1) lvl_off = (size_t)a.nwg * n;
   }
   int wpt = a.nterms >= W ? 1 : W / a.nterms;
   for (;;) {
@@ -2524,13 +2549,14 @@ class HipDev : public Dev {
   unsigned long long* hmail_ = nullptr;      // host view of the challenge mailbox [seq, c0, c1]
   unsigned long long* hmail_dev_ = nullptr;  // device view
   struct ScSession { bool active = false; int ntabs = 0; size_t n = 0; unsigned long long seq = 0; std::vector<Ext*> a, b; bool nextA = true;
-                     bool multi = false; int G = 0, rounds_a = 0, folds = 0; size_t slot_words = 0, n0 = 0; } sess_;
+                     bool multi = false; int G = 0, rounds_a = 0, folds = 0, shift = 0; size_t slot_words = 0, n0 = 0; } sess_;
   static constexpr int MULTI_MAX_WG = 32;
   static constexpr size_t MULTI_MIN_N = 4096, MULTI_MAX_N = size_t(1) << 18, MULTI_TARGET_N = 1024;
   unsigned long long* hmflag_ = nullptr;      // host view of the per-workgroup flags
   unsigned long long* hmflag_dev_ = nullptr;  // device view
   unsigned long long last_tag_multi_[MULTI_MAX_WG];
   bool multi_ = true;  // DP_NO_MULTI=1 disables the multi-workgroup phase of large sumchecks
+  bool multi_mid_ = getenv("DP_MULTI_MID") && atoi(getenv("DP_MULTI_MID"));
   static bool persist_flag_env(const char* name) { const char* e = getenv(name); return !(e && atoi(e)); }
   // all G workgroups have published round `seq`: every slot's tag matches its payload (same protocol as wait_flag)
   void wait_flags_multi(unsigned long long seq, size_t nwords, int G, size_t slot_words) {
@@ -3040,7 +3066,12 @@ class HipDev : public Dev {
   size_t nfs_ = 0;
   bool sc_tail(DBuf* tabs, int nt, const Ext* r, const ScTerm* terms, const Ext* coeffs, int nterms, unsigned md, Challenger& ch,
                std::vector<std::vector<Ext>>& msgs, std::vector<Ext>& point, Ext* finals) override {
-    if (!devfs_ || !persist_ || !zerocopy_ || sess_.active) return false;
+    // latency mode (one proof on the GPU) keeps the host sponge: a round trip to the host costs 23-35 us per round, the 8-lane
+    // wave sponge ~50-70 us (3-4 permutations of ~16 us: one wave on a dependent chain) — measured on the 2^24 sumcheck, whose
+    // 14-round hand-over phase takes 0.49 ms with the host sponge and 0.99 ms with DP_SC_HANDOVER=1 (profiles/r02_sumcheck24_handover.txt)
+    static const bool handover_env = getenv("DP_SC_HANDOVER") && atoi(getenv("DP_SC_HANDOVER"));
+    const bool handover = handover_env && devfs_env_ < 0 && r && tabs[0].n >= 8192;
+    if (!(devfs_ || handover) || !persist_ || !zerocopy_ || sess_.active) return false;
     if (nt > MAX_TABS || nterms > MAX_TERMS || nt <= 0 || nterms <= 0 || md < 1 || md > (unsigned)SC_MAXK) return false;
     size_t n_in = tabs[0].n;
     for (int i = 0; i < nt; i++) if (tabs[i].n != n_in) return false;
@@ -3262,7 +3293,7 @@ class HipDev : public Dev {
       DP_REQUIRE(r && nt == sess_.ntabs && n_in == sess_.n, DP_ERR_ARG, "sumcheck session out of sync");
       post_challenge(*r);
       sess_.folds++;
-      const size_t lvl_off = sess_.n0 - (sess_.n0 >> (sess_.folds - 1));  // level j starts at n0 (1 - 2^-(j-1))
+      const size_t lvl_off = sess_.n0 - (sess_.n0 >> (sess_.folds - 1 + sess_.shift));  // level j starts at n0 (1 - 2^-(j-1)); one level later when the phase began with a fold
       for (int i = 0; i < nt; i++) { tabs[i].p = sess_.a[i] + lvl_off; tabs[i].n = n_after; tabs[i].ext = true; }
       sess_.n = n_after;
       if (sess_.folds < sess_.rounds_a) {
@@ -3284,11 +3315,15 @@ class HipDev : public Dev {
       read_terms();
       return;
     }
-    if (!r && multi_ && persist_ && n_in >= MULTI_MIN_N && n_in <= MULTI_MAX_N && nraw * 2 * MULTI_MAX_WG <= RES_WORDS) {
-      // ---- multi-workgroup phase: G workgroups own contiguous slices, fold until the tables are MULTI_TARGET_N long
+    if ((!r || multi_mid_) && multi_ && persist_ && n_after >= MULTI_MIN_N && n_in <= MULTI_MAX_N && nraw * 2 * MULTI_MAX_WG <= RES_WORDS) {
+      // ---- multi-workgroup phase: G workgroups own contiguous slices, fold until the tables are MULTI_TARGET_N long. It may
+      // begin in the middle of a sumcheck (r given: the streaming rounds of a large sumcheck hand over as soon as the tables
+      // fit): every workgroup then first folds its slice with the pending challenge. Measured on the 2^24 sumcheck that costs
+      // 75 us per round (32 workgroups x PCIe mailbox) against 23 us for one workgroup in LDS, so it is off unless DP_MULTI_MID=1:
+      // the hand-over from the streaming rounds goes to the device-side transcript instead (sc_tail).
       flush_pending_eq();
-      int G = (int)std::min<size_t>(MULTI_MAX_WG, n_in / 512);
-      int rounds_a = (int)(dp_ceil_log2(n_in) - dp_ceil_log2(MULTI_TARGET_N));
+      int G = (int)std::min<size_t>(MULTI_MAX_WG, n_after / 512);
+      int rounds_a = (int)(dp_ceil_log2(n_after) - dp_ceil_log2(MULTI_TARGET_N));
       ScPersistArgs a;
       for (int i = 0; i < MAX_TABS; i++) { a.in[i] = nullptr; a.in_ext[i] = 0; a.bufA[i] = nullptr; a.bufB[i] = nullptr; }
       fill_terms(a.k, a.t, a.off);
@@ -3300,13 +3335,14 @@ class HipDev : public Dev {
         a.bufA[i] = sess_.a[i]; a.bufB[i] = nullptr;
         bytes += tabs[i].bytes() + 3.0 * 16.0 * (n_in / 2);  // read once + the halving folded tables written and re-read
       }
-      a.ntabs = nt; a.nterms = nterms; a.has_r0 = 0; a.n0 = n_in; a.r0 = ex_zero(); a.dbg = nullptr; a.eq_tab = -1; a.eq_k = 0;
+      a.ntabs = nt; a.nterms = nterms; a.has_r0 = r ? 1 : 0; a.n0 = n_in; a.r0 = r ? *r : ex_zero(); a.dbg = nullptr; a.eq_tab = -1; a.eq_k = 0;
       a.nwg = G; a.rounds_a = rounds_a; a.slot_ext = (int)nraw;
-      sess_.active = true; sess_.multi = true; sess_.G = G; sess_.rounds_a = rounds_a; sess_.folds = 0; sess_.slot_words = 2 * nraw;
-      sess_.ntabs = nt; sess_.n = n_in; sess_.n0 = n_in; sess_.seq = seq_;
+      sess_.active = true; sess_.multi = true; sess_.G = G; sess_.rounds_a = rounds_a; sess_.folds = 0; sess_.shift = r ? 1 : 0; sess_.slot_words = 2 * nraw;
+      sess_.ntabs = nt; sess_.n = n_after; sess_.n0 = n_in; sess_.seq = seq_;
       seq_ += (unsigned)rounds_a;  // one publication per round of the phase
       nb_ = bytes; if (hi) { DPL_B((k_sc_persist<true>), 1024, KF_CLAIM, dim3(G), dim3(1024), 0, a, (Ext*)hres_dev_, hmflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); } else { DPL_B((k_sc_persist<false>), 1024, KF_CLAIM, dim3(G), dim3(1024), 0, a, (Ext*)hres_dev_, hmflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }  // (latency mode only: G whole-CU workgroups)
       wait_flags_multi(++sess_.seq, 2 * nraw, G, sess_.slot_words);
+      if (r) for (int i = 0; i < nt; i++) { tabs[i].p = sess_.a[i]; tabs[i].n = n_after; tabs[i].ext = true; }
       read_shares(G, sess_.slot_words);
       return;
     }

@@ -3,6 +3,7 @@
 // the product's own host code (csrc/logup_tail.h: descriptor, message layout, parser).
 #pragma once
 #include "../cpu_dev.hpp"
+#include "../../../deep-prove_amd/csrc/poseidon2_fast.h"
 #include "../../../deep-prove_amd/csrc/logup_tail.h"
 #include "../../../deep-prove_amd/csrc/classic_tail.h"
 #include "../../../deep-prove_amd/csrc/dense_tail.h"

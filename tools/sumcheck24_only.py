@@ -9,5 +9,10 @@ n = 1 << nv
 tabs = [dpa.Mle.from_base(dev, dpa.models.splitmix64(0xD33B0000 ^ (5 << 32) ^ j, n) % np.uint64(dpa.P)) for j in range(k)]
 vp = dpa.VirtualPolynomial(nv)
 vp.add_mle_list(tabs)
+import hashlib
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
-    t0 = time.perf_counter(); dpa.prove_parallel(dev, vp, dpa.Transcript(b"test")); print(f"{1000 * (time.perf_counter() - t0):.3f} ms")
+    t0 = time.perf_counter(); proof, finals = dpa.prove_parallel(dev, vp, dpa.Transcript(b"test")); print(f"{1000 * (time.perf_counter() - t0):.3f} ms  proof sha256 {hashlib.sha256(proof.tobytes()).hexdigest()[:16]}")
+if os.environ.get("SC24_PROFILE"):
+    dev.profile(True); dpa.prove_parallel(dev, vp, dpa.Transcript(b"test")); rep = dev.profile_report(); dev.profile(False)
+    for r in sorted(rep, key=lambda r: -r["total_ms"])[:8]:
+        print(f'{r["kernel"]:34s} launches {r["launches"]:3d}  total {r["total_ms"]:.4f} ms  {r["alg_bytes"] / max(r["total_ms"], 1e-9) / 1e6:8.1f} GB/s')
