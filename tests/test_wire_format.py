@@ -1,0 +1,78 @@
+"""deep_prove_amd/wire.py: the reference's `rmp_serde::to_vec_named(&Proof)` wire format rebuilt from the canonical stream.
+Unverifiable against the reference here (no Rust toolchain, no reference-serialised proof exists: SURVEY.md 8f2); what these
+tests pin is that the bytes are well-formed MessagePack an independent decoder (the `msgpack` package) reads into the structure
+the reference's serde derives describe (names and order from the cited files), that encode -> decode reproduces the stream up to
+the one thing the reference's own format drops, and that the recalled conventions are switches, not assumptions baked in."""
+import os
+
+import msgpack
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", ["mlp_w8.npz", "cnn_tiny.npz"])
+def test_named_messagepack_structure_and_round_trip(name):
+    from deep_prove_amd import wire
+    p = np.load(os.path.join(ROOT, "tests", "golden", name))["proof"]
+    data = wire.to_rmp(p)
+    m = msgpack.unpackb(data, raw=False, strict_map_key=False)  # an independent MessagePack decoder accepts every byte
+    assert list(m) == ["steps", "table_proofs", "commit"]                       # zkml/src/iop/mod.rs:26-31
+    assert list(m["commit"]) == ["batch_proof", "trivial_proofs"]               # commit/context.rs:230-231
+    bp = m["commit"]["batch_proof"]
+    assert list(bp) == ["sumcheck_messages", "roots", "final_message", "query_result_with_merkle_path", "sumcheck_proof", "trivial_proof"]  # structure.rs:339-344
+    (variant, q), = bp["query_result_with_merkle_path"].items()
+    assert variant == "Batched" and len(q["inner"]) == 200                      # 200 queries, each (index, BatchedSingleQueryResultWithMerklePath)
+    idx, one = q["inner"][0]
+    assert isinstance(idx, int) and list(one) == ["oracle_query", "commitments_query"]
+    cq = one["commitments_query"]["inner"][0]
+    assert list(cq) == ["query", "merkle_path"] and list(cq["query"]) == ["codepoints", "index"] and list(cq["merkle_path"]) == ["inner", "_phantom"]
+    assert cq["merkle_path"]["_phantom"] == [] and list(bp["sumcheck_proof"]) == ["rounds", "phantom"]
+    assert list(bp["sumcheck_proof"]["rounds"][0]) == ["Ext"] and len(bp["sumcheck_proof"]["rounds"][0]["Ext"]) == 3  # Coefficients(FieldType::Ext)
+    for node, lp in m["steps"].items():
+        (kind, body), = lp.items()
+        assert kind in ("Dense", "Requant", "Activation", "Convolution", "Pooling")
+        if kind == "Dense":
+            assert list(body) == ["sumcheck", "bias_eval", "individual_claims"]                                   # dense.rs:57-68
+            assert list(body["sumcheck"]) == ["point", "proofs"] and list(body["sumcheck"]["proofs"][0]) == ["evaluations"]
+            assert list(body["bias_eval"]) == ["value"] and list(body["bias_eval"]["value"][0]) == ["value"]    # Ext2 {value: [Goldilocks {value}; 2]}
+        if kind == "Requant":
+            assert list(body) == ["io_accumulation", "accumulation_evals", "clamping_lookup", "shifted_lookup", "commitments"]  # requant.rs:84-99
+            assert list(body["commitments"][0]) == ["root", "num_vars", "is_base", "num_polys"] and len(body["commitments"][0]["root"]) == 4
+            assert body["clamping_lookup"]["proof_type"] == "Lookup"
+        if kind == "Convolution":
+            assert list(body)[:4] == ["fft_proof", "fft_proof_weights", "fft_delegation_proof", "fft_delegation_proof_weights"] and list(body)[-1] == "clearing_proof"
+    assert all(t["lookup"]["proof_type"] == "Table" for t in m["table_proofs"])
+    assert list(m["steps"]) == sorted(m["steps"])  # HashMap order is arbitrary in the reference; ascending NodeId here
+    # trivial openings: BasefoldProof::trivial -> Single(empty), no sumcheck proof, and FieldType::Base travels WITHOUT its data
+    for t in m["commit"]["trivial_proofs"]:
+        assert t["query_result_with_merkle_path"] == {"Single": {"inner": []}} and t["sumcheck_proof"] is None and t["trivial_proof"] == ["Base"]
+    back = wire.from_rmp(data)
+    assert np.array_equal(back, wire.strip_skipped(p))
+    assert back.size < p.size and wire.stream_equal_modulo_skipped(back, p)    # (the skipped tables are the only difference)
+    assert wire.to_rmp(back) == data                                           # encode(decode(x)) == x
+
+
+def test_recalled_conventions_are_switches():
+    from deep_prove_amd import wire
+    p = np.load(os.path.join(ROOT, "tests", "golden", "mlp_w8.npz"))["proof"]
+
+    class Bare(wire.Conventions):
+        field_as_map = False
+        ext_as_map = False
+        phantom_is_empty_array = False
+    a, b = wire.to_rmp(p), wire.to_rmp(p, Bare)
+    assert len(b) < 0.7 * len(a)
+    m = msgpack.unpackb(b, raw=False, strict_map_key=False)
+    assert isinstance(m["steps"][0]["Dense"]["bias_eval"], list) and m["commit"]["batch_proof"]["sumcheck_proof"]["phantom"] is None
+    assert np.array_equal(wire.from_rmp(b, Bare), wire.from_rmp(a))
+
+
+def test_integers_use_the_smallest_encoding():
+    from deep_prove_amd import wire
+    for v, n in ((0, 1), (127, 1), (128, 2), (255, 2), (256, 3), (65535, 3), (65536, 5), (2**32 - 1, 5), (2**32, 9), (2**64 - 2**32, 9)):
+        out = []
+        wire._pack(v, out, wire.Conventions)
+        assert len(b"".join(out)) == n and msgpack.unpackb(b"".join(out)) == v
+        assert b"".join(out) == msgpack.packb(v)
