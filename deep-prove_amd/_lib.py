@@ -49,6 +49,12 @@ SIGNATURES = {
     "dp_sc_session_round": (C.c_int32, [vp, u64p, u64p, C.POINTER(C.c_size_t)]),
     "dp_sc_session_finish": (C.c_int32, [vp, u64p, u64p]),
     "dp_sc_session_free": (C.c_int32, [vp]),
+    "dp_dist_unique_id": (C.c_int32, [C.POINTER(C.c_uint8)]),
+    "dp_dist_init": (C.c_int32, [vp, C.POINTER(C.c_uint8), C.c_int32, C.c_int32, C.POINTER(vp)]),
+    "dp_dist_free": (C.c_int32, [vp]),
+    "dp_sumcheck_prove_sharded": (C.c_int32, [vp, vp, C.c_uint32, C.POINTER(vp), C.c_int32, i32p, i32p, u64p, C.c_int32, vp, C.POINTER(u64p), C.POINTER(C.c_size_t), u64p]),
+    "dp_sumcheck_prove_sharded_local": (C.c_int32, [C.POINTER(vp), C.c_int32, C.c_uint32, C.POINTER(vp), C.c_int32, i32p, i32p, u64p, C.c_int32, C.POINTER(vp),
+                                                    C.POINTER(u64p), C.POINTER(C.c_size_t), u64p]),
     "dp_sumcheck_verify": (C.c_int32, [C.c_uint32, C.c_uint32, u64p, u64p, C.c_size_t, vp, u64p, u64p]),
     "dp_logup_verify": (C.c_int32, [u64p, C.c_size_t, C.c_int32, u64p, u64p, vp, u64p, u64p, C.POINTER(u64p), C.POINTER(C.c_size_t)]),
     "dp_logup_prove": (C.c_int32, [vp, C.POINTER(vp), C.c_int32, C.c_int32, vp, u64p, u64p, vp, C.POINTER(u64p),

@@ -1,7 +1,11 @@
 // extern "C" surface of libdeepprove_hip.so (declared in include/deep_prove_hip.h).
 #include "../../include/deep_prove_hip.h"
 #include "zkml.h"
+#include "sharded.h"
 #include "fiber.h"
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>  // types and enums only: the functions are resolved with dlopen (no link-time dependency on librccl)
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -156,6 +160,134 @@ int32_t dp_sumcheck_prove(dp_ctx* ctx, uint32_t nv, const dp_buf* const* tables,
     if (finals) for (int i = 0; i < ntables; i++) { finals[2 * i] = so.finals[i].c0; finals[2 * i + 1] = so.finals[i].c1; }
   });
 }
+
+// ---- the sharded prover with its round loop in the library (csrc/sharded.h) and RCCL as the exchange
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+// librccl is looked up at run time: a process that already holds an RCCL (PyTorch bundles one under the same soname) keeps
+// using that copy, and a host that never shards a sumcheck never loads it
+RcclApi& rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (api.lib) break; }
+    if (!api.lib) return;
+    api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+    api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+    api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+    api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+  });
+  DP_REQUIRE(api.lib && api.GetUniqueId && api.CommInitRank && api.AllGather && api.CommDestroy, DP_ERR_HIP, "librccl.so could not be loaded (sharded sumcheck over RCCL)");
+  return api;
+}
+#define RCCL_CHECK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) throw DpError(DP_ERR_HIP, std::string("RCCL: ") + (rccl().GetErrorString ? rccl().GetErrorString(r_) : "error")); } while (0)
+#define HIPRT_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw DpError(DP_ERR_HIP, std::string("HIP: ") + hipGetErrorString(e_)); } while (0)
+}  // namespace
+// one rank's communicator: device send / receive buffers the all-gather runs on, pinned host mirrors, its own stream
+struct dp_dist : Exchange {
+  dp_ctx* ctx = nullptr; ncclComm_t comm = nullptr; int rank_ = 0, world_ = 1; hipStream_t stream = nullptr;
+  u64 *dsend = nullptr, *drecv = nullptr, *hsend = nullptr, *hrecv = nullptr; size_t cap = 0;  // words per rank
+  int world() const override { return world_; }
+  int rank() const override { return rank_; }
+  void reserve(size_t nwords) {
+    if (nwords <= cap) return;
+    release();
+    cap = std::max<size_t>(nwords, 256);
+    HIPRT_CHECK(hipMalloc((void**)&dsend, cap * 8)); HIPRT_CHECK(hipMalloc((void**)&drecv, cap * 8 * world_));
+    HIPRT_CHECK(hipHostMalloc((void**)&hsend, cap * 8, 0)); HIPRT_CHECK(hipHostMalloc((void**)&hrecv, cap * 8 * world_, 0));
+  }
+  void release() { if (dsend) hipFree(dsend); if (drecv) hipFree(drecv); if (hsend) hipHostFree(hsend); if (hrecv) hipHostFree(hrecv); dsend = drecv = hsend = hrecv = nullptr; cap = 0; }
+  // shares travel as u64 device words: ncclAllGather(ncclUint64) over xGMI; the mod-p sum happens on the host afterwards
+  void all_gather(const u64* send, size_t nwords, u64* out) override {
+    ctx->dev->bind_thread();
+    reserve(nwords);
+    memcpy(hsend, send, nwords * 8);
+    HIPRT_CHECK(hipMemcpyAsync(dsend, hsend, nwords * 8, hipMemcpyHostToDevice, stream));
+    RCCL_CHECK(rccl().AllGather(dsend, drecv, nwords, ncclUint64, comm, stream));
+    HIPRT_CHECK(hipMemcpyAsync(hrecv, drecv, nwords * 8 * world_, hipMemcpyDeviceToHost, stream));
+    HIPRT_CHECK(hipStreamSynchronize(stream));
+    memcpy(out, hrecv, nwords * 8 * world_);
+  }
+  ~dp_dist() override { release(); if (comm) rccl().CommDestroy(comm); if (stream) hipStreamDestroy(stream); }
+};
+extern "C" {
+int32_t dp_dist_unique_id(uint8_t id[128]) {
+  return guard([&] { DP_REQUIRE(id, DP_ERR_ARG, "null id"); static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId"); ncclUniqueId u; RCCL_CHECK(rccl().GetUniqueId(&u)); memcpy(id, &u, 128); });
+}
+int32_t dp_dist_init(dp_ctx* ctx, const uint8_t id[128], int32_t rank, int32_t world, dp_dist** out) {
+  return guard([&] {
+    DP_REQUIRE(ctx && id && out && world >= 1 && rank >= 0 && rank < world && (world & (world - 1)) == 0, DP_ERR_ARG, "bad arguments (world must be a power of two)");
+    std::unique_ptr<dp_dist> d(new dp_dist());
+    d->ctx = ctx; d->rank_ = rank; d->world_ = world;
+    ctx->dev->bind_thread();
+    HIPRT_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    ncclUniqueId u; memcpy(&u, id, 128);
+    RCCL_CHECK(rccl().CommInitRank(&d->comm, world, u, rank));
+    *out = d.release();
+  });
+}
+int32_t dp_dist_free(dp_dist* d) { return guard([&] { delete d; }); }
+static void sharded_out(const SumcheckOut& so, size_t ntables, uint64_t** proof_words, size_t* proof_nwords, uint64_t* finals) {
+  Writer w; w.iop(so.proof);
+  *proof_words = copy_out(w.w); *proof_nwords = w.w.size();
+  if (finals) for (size_t i = 0; i < ntables; i++) { finals[2 * i] = so.finals[i].c0; finals[2 * i + 1] = so.finals[i].c1; }
+}
+int32_t dp_sumcheck_prove_sharded(dp_ctx* ctx, dp_dist* dist, uint32_t num_vars, const dp_buf* const* tables, int32_t ntables, const int32_t* term_degree,
+                                  const int32_t* term_tables, const uint64_t* term_coeffs, int32_t nterms, dp_transcript* t,
+                                  uint64_t** proof_words, size_t* proof_nwords, uint64_t* finals) {
+  return guard([&] {
+    DP_REQUIRE(ctx && tables && term_degree && term_tables && term_coeffs && t && proof_words && proof_nwords && ntables > 0 && nterms > 0 && num_vars > 0 && num_vars < 48, DP_ERR_ARG, "bad arguments");
+    DP_REQUIRE(!dist || dist->ctx == ctx, DP_ERR_ARG, "the communicator belongs to another context");
+    SoloExchange solo;
+    Exchange& xch = dist ? static_cast<Exchange&>(*dist) : solo;
+    unsigned k = 0; while ((1 << k) < xch.world()) k++;
+    DP_REQUIRE(num_vars > k, DP_ERR_SHAPE, "more ranks than table entries");
+    DevVP vp(num_vars - k);
+    read_terms(vp, tables, ntables, term_degree, term_tables, nterms, term_coeffs);
+    SumcheckOut so = sumcheck_prove_sharded(*ctx->dev, xch, num_vars, vp, t->t);
+    sharded_out(so, (size_t)ntables, proof_words, proof_nwords, finals);
+  });
+}
+/* `world` contexts driven from ONE process (one thread per rank, exchange in host memory): several contexts on one GPU, tests.
+ * tables: world x ntables handles, rank-major; transcripts: one per rank, all in the same state. Rank 0's output is returned;
+ * every rank's proof is compared with it (DP_ERR_HIP if they differ). */
+int32_t dp_sumcheck_prove_sharded_local(dp_ctx* const* ctxs, int32_t world, uint32_t num_vars, const dp_buf* const* tables, int32_t ntables, const int32_t* term_degree,
+                                        const int32_t* term_tables, const uint64_t* term_coeffs, int32_t nterms, dp_transcript* const* transcripts,
+                                        uint64_t** proof_words, size_t* proof_nwords, uint64_t* finals) {
+  return guard([&] {
+    DP_REQUIRE(ctxs && tables && term_degree && term_tables && term_coeffs && transcripts && proof_words && proof_nwords && world >= 1 && (world & (world - 1)) == 0 && num_vars < 48, DP_ERR_ARG, "bad arguments");
+    unsigned k = 0; while ((1 << k) < world) k++;
+    DP_REQUIRE(num_vars > k, DP_ERR_SHAPE, "more ranks than table entries");
+    ThreadExchangeHub hub(world);
+    std::vector<SumcheckOut> outs(world);
+    std::vector<std::string> errs(world);
+    std::vector<std::thread> th;
+    for (int g = 0; g < world; g++) th.emplace_back([&, g] {
+      try {
+        DP_REQUIRE(ctxs[g] && transcripts[g], DP_ERR_ARG, "null context / transcript");
+        ctxs[g]->dev->bind_thread();
+        DevVP vp(num_vars - k);
+        read_terms(vp, tables + (size_t)g * ntables, ntables, term_degree, term_tables, nterms, term_coeffs);
+        ThreadExchange xch(hub, g);
+        outs[g] = sumcheck_prove_sharded(*ctxs[g]->dev, xch, num_vars, vp, transcripts[g]->t);
+      } catch (const std::exception& e) { errs[g] = e.what(); if (errs[g].empty()) errs[g] = "error"; }
+    });
+    for (auto& x : th) x.join();
+    for (int g = 0; g < world; g++) if (!errs[g].empty()) throw DpError(DP_ERR_HIP, "rank " + std::to_string(g) + ": " + errs[g] + " (a failed rank leaves the others waiting only in real multi-process runs; here all ranks were joined)");
+    Writer w0; w0.iop(outs[0].proof);
+    for (int g = 1; g < world; g++) { Writer w; w.iop(outs[g].proof); DP_REQUIRE(w.w == w0.w, DP_ERR_HIP, "ranks produced different proofs"); }
+    sharded_out(outs[0], (size_t)ntables, proof_words, proof_nwords, finals);
+  });
+}
+}  // extern "C"
 
 // ---- round-level sumcheck (the unit a sharded prover exchanges between devices, sumcheck/src/prover.rs:37-321)
 struct dp_sc_session { dp_ctx* ctx; std::vector<DBuf> tabs; std::vector<ScTerm> terms; size_t nraw; size_t mark; bool first; size_t len; };

@@ -187,3 +187,65 @@ def prove_sharded(shards, exchange, nv, terms, transcript, make_small_shard):
     for m in rounds:
         words += [len(m)] + [w for e in m for w in e]
     return np.array(words, dtype=np.uint64), np.array([w for e in finals for w in e], dtype=np.uint64)
+
+
+# ---------------------------------------------------------------- the in-library loop (csrc/sharded.h): this module is only the driver
+def _pack_terms(terms):
+    deg = np.array([len(ix) for _, ix in terms], dtype=np.int32)
+    tt = np.array([j for _, ix in terms for j in ix], dtype=np.int32)
+    co = np.array([w for c, _ in terms for w in c], dtype=np.uint64)
+    return deg, tt, co
+
+
+class RcclGroup:
+    """dp_dist: this rank's RCCL communicator inside the library. The 128-byte unique id travels over the torch.distributed
+    control plane (an object broadcast: it works on a gloo group too); the data path is ncclAllGather on device buffers."""
+
+    def __init__(self, dev, group=None):
+        import torch.distributed as dist
+        lib = _lib.load()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        ident = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            check(lib.dp_dist_unique_id(ident))
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        ident = (C.c_uint8 * 128)(*box[0])
+        self.h = vp()
+        check(lib.dp_dist_init(dev.h, ident, self.rank, self.world, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            _lib.load().dp_dist_free(self.h)
+            self.h = vp()
+
+
+def prove_sharded_in_library(dev, group, nv, local_tables, terms, transcript):
+    """dp_sumcheck_prove_sharded: the whole round loop (local round sums, ncclAllGather, mod-p sum, host sponge, stage 2) in C++;
+    `group`: an RcclGroup or None (world of one). Returns (proof_words, finals) as api.prove_parallel."""
+    from .api import _take
+    lib = _lib.load()
+    nt = len(local_tables)
+    tabs = (vp * nt)(*[t.h for t in local_tables])
+    deg, tt, co = _pack_terms(terms)
+    pw, pn = _lib.u64p(), C.c_size_t()
+    finals = np.zeros(2 * nt, dtype=np.uint64)
+    check(lib.dp_sumcheck_prove_sharded(dev.h, group.h if group is not None else None, nv, tabs, nt, deg.ctypes.data_as(_lib.i32p), tt.ctypes.data_as(_lib.i32p),
+                                        co.ctypes.data_as(_lib.u64p), len(terms), transcript.h, C.byref(pw), C.byref(pn), finals.ctypes.data_as(_lib.u64p)))
+    return _take(pw, pn.value), finals
+
+
+def prove_sharded_local(devs, nv, tables_per_rank, terms, transcripts):
+    """dp_sumcheck_prove_sharded_local: `len(devs)` contexts of ONE process (threads + an in-memory exchange)"""
+    from .api import _take
+    lib = _lib.load()
+    world, nt = len(devs), len(tables_per_rank[0])
+    ctxs = (vp * world)(*[d.h for d in devs])
+    tabs = (vp * (world * nt))(*[t.h for row in tables_per_rank for t in row])
+    ts = (vp * world)(*[t.h for t in transcripts])
+    deg, tt, co = _pack_terms(terms)
+    pw, pn = _lib.u64p(), C.c_size_t()
+    finals = np.zeros(2 * nt, dtype=np.uint64)
+    check(lib.dp_sumcheck_prove_sharded_local(ctxs, world, nv, tabs, nt, deg.ctypes.data_as(_lib.i32p), tt.ctypes.data_as(_lib.i32p), co.ctypes.data_as(_lib.u64p),
+                                              len(terms), ts, C.byref(pw), C.byref(pn), finals.ctypes.data_as(_lib.u64p)))
+    return _take(pw, pn.value), finals

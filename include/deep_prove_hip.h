@@ -116,6 +116,30 @@ int32_t dp_sc_session_round(dp_sc_session* s, const uint64_t* r_prev, uint64_t* 
 int32_t dp_sc_session_finish(dp_sc_session* s, const uint64_t r_last[2], uint64_t* finals);
 int32_t dp_sc_session_free(dp_sc_session* s);
 
+/* ---- the sharded prover with its round loop IN the library: IOPProverState::prove_batch_polys (sumcheck/src/prover.rs:37-321,
+ * merge step sumcheck/src/util.rs:215-243) across GPUs, one rank per GPU. Rank g of W = 2^k holds the contiguous slice
+ * [g N/W, (g+1) N/W) of every table (tables: THIS rank's slices, 2^(num_vars - k) entries each; num_vars: of the whole
+ * polynomial). Per round: the local round sums (device), ncclAllGather of the shares as u64 device words over xGMI, mod-p sum and
+ * Fiat-Shamir on the host, the same challenge on every rank; after num_vars - k rounds one value per table per rank is gathered
+ * and the last k rounds run identically everywhere. The proof stream and final evaluations are bit-identical to dp_sumcheck_prove
+ * on the whole tables, on every rank. Terms as in dp_sumcheck_prove (full-length local tables only).
+ * Communicator: rank 0 calls dp_dist_unique_id and hands the 128 bytes to the other ranks through whatever control plane the
+ * host has (MPI, torch.distributed, a socket); every rank then calls dp_dist_init (ncclCommInitRank; librccl is loaded with
+ * dlopen on first use). dist == NULL: a world of one. */
+typedef struct dp_dist dp_dist;
+int32_t dp_dist_unique_id(uint8_t id[128]);
+int32_t dp_dist_init(dp_ctx* ctx, const uint8_t id[128], int32_t rank, int32_t world, dp_dist** out);
+int32_t dp_dist_free(dp_dist* d);
+int32_t dp_sumcheck_prove_sharded(dp_ctx* ctx, dp_dist* dist, uint32_t num_vars, const dp_buf* const* tables, int32_t ntables,
+                                  const int32_t* term_degree, const int32_t* term_tables, const uint64_t* term_coeffs,
+                                  int32_t nterms, dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords, uint64_t* finals);
+/* the same loop with `world` contexts driven from ONE process (one thread per rank, exchange in host memory): several
+ * contexts on one GPU. tables: world x ntables handles, rank-major; transcripts: one per rank, all in the same state. */
+int32_t dp_sumcheck_prove_sharded_local(dp_ctx* const* ctxs, int32_t world, uint32_t num_vars, const dp_buf* const* tables,
+                                        int32_t ntables, const int32_t* term_degree, const int32_t* term_tables,
+                                        const uint64_t* term_coeffs, int32_t nterms, dp_transcript* const* transcripts,
+                                        uint64_t** proof_words, size_t* proof_nwords, uint64_t* finals);
+
 /* ---- logup-GKR: logup_gkr::prover::batch_prove(LogUpInput, transcript) (zkml/src/lookup/logup_gkr/prover.rs:24-198).
  * multiplicities == NULL -> LogUpInput::Lookup with `cols_per_instance`; else LogUpInput::Table. */
 int32_t dp_logup_prove(dp_ctx* ctx, const dp_buf* const* columns, int32_t ncols, int32_t cols_per_instance,

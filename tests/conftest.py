@@ -30,7 +30,7 @@ def hostlogic_bin():
     deps += [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle")) if f.endswith(".hpp")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", out, src])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out, src])
     return out
 
 

@@ -113,7 +113,66 @@ static int sumcheck_mode(uint64_t seed, unsigned nv) {
   printf("\n");
   return same && fsame && tsame && vok ? 0 : 2;
 }
+// `hostlogic_check sharded <seed> <nv> <W>`: the in-library sharded prover (csrc/sharded.h) — W ranks as W threads, each with
+// its own double and its contiguous slice of every table, exchanging through ThreadExchange — against the oracle's UNSHARDED
+// prove_parallel of the whole tables: every rank must produce the oracle's messages, final evaluations and transcript state
+#include "../../deep-prove_amd/csrc/sharded.h"
+#include <thread>
+static int sharded_mode(uint64_t seed, unsigned nv, int W) {
+  rs = seed;
+  const bool exts[4] = {false, true, false, true};
+  std::vector<std::vector<uint64_t>> tw(4);
+  for (int i = 0; i < 4; i++) { tw[i].resize((size_t(1) << nv) * (exts[i] ? 2 : 1)); for (auto& x : tw[i]) x = rnd() % dp::GL_P; }
+  const std::vector<std::vector<int>> terms = {{0, 1, 2}, {3, 0}, {2}};
+  std::vector<std::pair<uint64_t, uint64_t>> coeffs; for (size_t i = 0; i < terms.size(); i++) coeffs.push_back({rnd() % dp::GL_P, rnd() % dp::GL_P});
+  std::vector<orc::MleP> om;
+  for (int i = 0; i < 4; i++) {
+    if (exts[i]) { std::vector<orc::E> e(tw[i].size() / 2); for (size_t j = 0; j < e.size(); j++) e[j] = orc::E{tw[i][2 * j], tw[i][2 * j + 1]}; om.push_back(orc::mk(orc::Mle::from_ext(e))); }
+    else om.push_back(orc::mk(orc::Mle::from_base(tw[i])));
+  }
+  orc::VirtualPolynomial ovp(nv);
+  for (auto& m : om) ovp.flattened.push_back(m);
+  for (size_t i = 0; i < terms.size(); i++) { std::vector<orc::MleP> l; for (int j : terms[i]) l.push_back(om[j]); ovp.add_mle_list(l, orc::E{coeffs[i].first, coeffs[i].second}); }
+  orc::Transcript ot = orc::default_transcript();
+  auto ores = orc::sumcheck_prove(std::move(ovp), ot);
+  auto of = ores.second.final_evaluations();
+  orc::E oc = ot.get_and_append_challenge("after");
+  unsigned k = 0; while ((1 << k) < W) k++;
+  const size_t chunk = (size_t(1) << nv) / (size_t)W;
+  dp::ThreadExchangeHub hub(W);
+  std::vector<int> ok(W, 0);
+  std::vector<std::thread> th;
+  for (int g = 0; g < W; g++) th.emplace_back([&, g] {
+    try {
+      TestDev dev;
+      dp::DevVP vp(nv - k);
+      std::vector<dp::DBuf> bufs;
+      for (int i = 0; i < 4; i++) {
+        dp::DBuf b = dev.alloc_persistent(chunk, exts[i]);
+        dev.upload(b, tw[i].data() + (size_t)g * chunk * (exts[i] ? 2 : 1));
+        bufs.push_back(b); vp.tabs.push_back(b);
+      }
+      for (size_t i = 0; i < terms.size(); i++) { std::vector<dp::DBuf> l; for (int j : terms[i]) l.push_back(bufs[j]); vp.add_mle_list(l, dp::ex(coeffs[i].first, coeffs[i].second)); }
+      dp::ThreadExchange xch(hub, g);
+      dp::Transcript pt = dp::default_transcript();
+      dp::SumcheckOut pres = dp::sumcheck_prove_sharded(dev, xch, nv, vp, pt);
+      bool same = pres.proof.proofs.size() == ores.first.proofs.size() && pres.finals.size() == of.size();
+      for (size_t r = 0; same && r < pres.proof.proofs.size(); r++) {
+        same = pres.proof.proofs[r].size() == ores.first.proofs[r].size() && pres.proof.point[r].c0 == ores.first.point[r].c0 && pres.proof.point[r].c1 == ores.first.point[r].c1;
+        for (size_t j = 0; same && j < pres.proof.proofs[r].size(); j++) same = pres.proof.proofs[r][j].c0 == ores.first.proofs[r][j].c0 && pres.proof.proofs[r][j].c1 == ores.first.proofs[r][j].c1;
+      }
+      for (size_t i = 0; same && i < of.size(); i++) same = of[i].c0 == pres.finals[i].c0 && of[i].c1 == pres.finals[i].c1;
+      dp::Ext pc = pt.get_and_append_challenge("after");
+      ok[g] = same && pc.c0 == oc.c0 && pc.c1 == oc.c1;
+    } catch (const std::exception& e) { printf("rank %d: %s\n", g, e.what()); }
+  });
+  for (auto& t : th) t.join();
+  int good = 0; for (int g = 0; g < W; g++) good += ok[g];
+  printf("sharded sumcheck nv=%u world=%d: %d of %d ranks identical to the unsharded oracle proof (messages, finals, transcript)\n", nv, W, good, W);
+  return good == W ? 0 : 2;
+}
 int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "sharded") return sharded_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 4);
   if (argc > 1 && std::string(argv[1]) == "sumcheck") return sumcheck_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 6);
   bool cnn = argc > 1 && std::string(argv[1]) == "cnn";
   size_t W = argc > 1 && !cnn ? atoi(argv[1]) : 64; rs = argc > 2 ? atoll(argv[2]) : 1; int tamper = argc > 3 ? atoi(argv[3][0] == '@' ? argv[3] + 1 : argv[3]) : 0; bool tamper_abs = argc > 3 && argv[3][0] == '@';  // "@i": flip word i, else word size/2 + offset

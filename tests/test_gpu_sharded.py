@@ -77,3 +77,65 @@ def test_sharded_2pow22_roundtrip_properties():
         for d in devs:
             d.close()
     assert proof.size == dproof.size and (proof == dproof).all() and (finals == dfinals).all()
+
+
+@pytest.mark.parametrize("world,nv", [(1, 9), (2, 10), (4, 12), (8, 13), (4, 18)])
+def test_in_library_sharded_loop_on_several_contexts(oracle, world, nv):
+    """dp_sumcheck_prove_sharded_local: the C++ round loop of csrc/sharded.h with `world` device contexts on one GPU, one thread
+    per rank — local round sums on the device, exchange, mod-p sum and sponge in the library, stage 2 on W-entry tables —
+    bit-identical to the oracle's unsharded proof (and every rank's proof equals rank 0's: checked inside the call)"""
+    import deep_prove_amd as dpa
+    rng = np.random.default_rng(300 + nv + world)
+    tabs = [rng.integers(0, P, size=(2 if e else 1) << nv, dtype=np.uint64) for e in (False, True, False)]
+    exts = [False, True, False]
+    terms = [((1, 0), [0, 1, 2]), ((5, 7), [1, 2]), ((9, 0), [0])]
+    chunk = (1 << nv) // world
+    devs = [dpa.Device(0) for _ in range(world)]
+    try:
+        rows = [[(dpa.Mle.from_ext(d, t[2 * g * chunk:2 * (g + 1) * chunk]) if e else dpa.Mle.from_base(d, t[g * chunk:(g + 1) * chunk])) for t, e in zip(tabs, exts)]
+                for g, d in enumerate(devs)]
+        ts = [dpa.Transcript(b"test") for _ in range(world)]
+        proof, finals = dpa.sharded.prove_sharded_local(devs, nv, rows, terms, ts)
+        after = [t.read_challenge() for t in ts]
+        for row in rows:
+            for m in row:
+                m.free()
+    finally:
+        for d in devs:
+            d.close()
+    ot = oracle.transcript(b"test")
+    oproof, ofinals = oracle.sumcheck_prove(nv, tabs, exts, terms, ot)
+    assert proof.size == oproof.size and (proof == oproof).all() and (finals == ofinals).all()
+    assert all(a == after[0] for a in after) and after[0] == ot.read_challenge()  # every rank's transcript ends where the oracle's does
+
+
+def test_in_library_sharded_loop_over_rccl_world_of_one(dev, oracle):
+    """dp_dist_unique_id / dp_dist_init / dp_sumcheck_prove_sharded with a REAL RCCL communicator (librccl through dlopen,
+    ncclCommInitRank, ncclAllGather on device buffers) — a world of one is what a 1-GPU box can run; it exercises every call of
+    the RCCL path except the wire"""
+    import ctypes as C
+    import deep_prove_amd as dpa
+    from deep_prove_amd import _lib
+    lib = _lib.load()
+    ident = (C.c_uint8 * 128)()
+    _lib.check(lib.dp_dist_unique_id(ident))
+    h = _lib.vp()
+    _lib.check(lib.dp_dist_init(dev.h, ident, 0, 1, C.byref(h)))
+
+    class G:
+        pass
+    g = G(); g.h = h
+    nv = 14
+    rng = np.random.default_rng(77)
+    tabs = [rng.integers(0, P, size=1 << nv, dtype=np.uint64) for _ in range(3)]
+    terms = [((1, 0), [0, 1, 2]), ((3, 4), [2, 0])]
+    ms = [dpa.Mle.from_base(dev, t) for t in tabs]
+    try:
+        proof, finals = dpa.sharded.prove_sharded_in_library(dev, g, nv, ms, terms, dpa.Transcript(b"test"))
+        solo, sfinals = dpa.sharded.prove_sharded_in_library(dev, None, nv, ms, terms, dpa.Transcript(b"test"))
+    finally:
+        for m in ms:
+            m.free()
+        _lib.check(lib.dp_dist_free(h))
+    oproof, ofinals = oracle.sumcheck_prove(nv, tabs, [False] * 3, terms, oracle.transcript(b"test"))
+    assert (proof == oproof).all() and (finals == ofinals).all() and (solo == oproof).all() and (sfinals == ofinals).all()

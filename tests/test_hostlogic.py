@@ -122,3 +122,13 @@ def test_generalised_sumcheck_seam_matches_oracle(hostlogic_bin, nv, seed, fs):
     r = run(hostlogic_bin, "sumcheck", seed, nv, env={"DP_DOUBLE_DEVICE_FS": fs})
     assert r.returncode == 0, r.stdout + r.stderr
     assert "messages identical=1 finals identical=1 transcript identical=1 verifier=ACCEPT" in r.stdout
+
+
+@pytest.mark.parametrize("seed,nv,world", [(1, 6, 1), (2, 6, 2), (3, 8, 4), (4, 9, 8), (5, 4, 8)])
+def test_in_library_sharded_sumcheck_matches_unsharded_oracle(hostlogic_bin, seed, nv, world):
+    """csrc/sharded.h — the per-rank round loop of the sharded prover (what dp_sumcheck_prove_sharded runs over RCCL) — with W
+    ranks as W threads over W CPU doubles and an in-memory exchange: every rank's messages, final evaluations and transcript state
+    equal the oracle's UNSHARDED prove_parallel of the whole tables (base and extension tables, three terms, stage 2 included)"""
+    r = run(hostlogic_bin, "sharded", seed, nv, world)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"{world} of {world} ranks identical" in r.stdout
