@@ -820,6 +820,46 @@ template <> struct ElemOps<true> {
   static __device__ __forceinline__ T add(T a, T b) { return ex_add(a, b); }
   static __device__ __forceinline__ T mulb(T a, u64 b) { return ex_mul_base(a, b); }
 };
+// Stages [s_lo, s_hi) of the Moebius transform (NTT = false: p[lo + half] -= p[lo]) or of the radix-2 DIT NTT (NTT = true:
+// butterfly with w = tw[j << (L - s)], j = the index bits below s) in ONE launch, LDS-tiled: a tile is the 2^(s_hi - s_lo + lgc)
+// elements whose index is (hi << s_hi) | (m << s_lo) | (lowblk << lgc) | c for all m < 2^(s_hi - s_lo), c < 2^lgc — the bits
+// the stages act on (m) plus 2^lgc consecutive elements, so that global accesses stay 128-byte segments when the stride
+// 2^s_lo is large; lgc <= s_lo, and with lgc == s_lo the tile is one contiguous block. Tiles partition the array, every stage of
+// the range only pairs elements of one tile: a 2^20-coefficient polynomial takes 2 Moebius + 2 NTT passes instead of 20 + 20
+// per-stage launches over HBM (K5 / K7). In LDS the element sits at (m << lgc) | c.
+template <bool EXT, bool NTT>
+KBODY k_butterfly_pass(void* data, unsigned s_lo, unsigned s_hi, unsigned lgc, const u64* tw, unsigned L) {
+  extern __shared__ __align__(16) unsigned char lds_bp[];
+  typedef typename ElemOps<EXT>::T T;
+  T* A = (T*)lds_bp;
+  T* p = (T*)data;
+  const unsigned span = s_hi - s_lo, lgt = span + lgc;
+  const size_t tile = blockIdx.x;
+  const size_t nlowblk = size_t(1) << (s_lo - lgc);           // tiles per value of the high bits
+  const size_t hi = tile >> (s_lo - lgc), lowblk = tile & (nlowblk - 1);
+  const size_t base = (hi << s_hi) | (lowblk << lgc);
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const size_t telems = size_t(1) << lgt;
+  for (size_t q = tid; q < telems; q += nt) { size_t m = q >> lgc, c = q & ((size_t(1) << lgc) - 1); A[q] = p[base | (m << s_lo) | c]; }
+  __syncthreads();
+  for (unsigned s = s_lo; s < s_hi; s++) {
+    const unsigned b = s - s_lo;                               // the bit of m this stage pairs
+    for (size_t q = tid; q < telems / 2; q += nt) {
+      // q enumerates the pairs: insert a 0 at bit (b + lgc) of the LDS position
+      const size_t lowmask = (size_t(1) << (b + lgc)) - 1;
+      const size_t lo = ((q & ~lowmask) << 1) | (q & lowmask), hi2 = lo | (size_t(1) << (b + lgc));
+      if (NTT) {
+        const size_t m = lo >> lgc, c = lo & ((size_t(1) << lgc) - 1);
+        const size_t j = ((m & ((size_t(1) << b) - 1)) << s_lo) | (lowblk << lgc) | c;   // index bits below s
+        const u64 w = tw[j << (L - s)];
+        T t = ElemOps<EXT>::mulb(A[hi2], w), u = A[lo];
+        A[lo] = ElemOps<EXT>::add(u, t); A[hi2] = ElemOps<EXT>::sub(u, t);
+      } else A[hi2] = ElemOps<EXT>::sub(A[hi2], A[lo]);
+    }
+    __syncthreads();
+  }
+  for (size_t q = tid; q < telems; q += nt) { size_t m = q >> lgc, c = q & ((size_t(1) << lgc) - 1); p[base | (m << s_lo) | c] = A[q]; }
+}
 // K5+K6+K7 for a small polynomial entirely in LDS: evaluations -> coefficients (Moebius), coset scale, zero-pad,
 // radix-2 DIT NTT on 2n points, bit-reversed store; also the bit-reversed copy of the evaluations. One workgroup per
 // polynomial (blockIdx.x), dynamic LDS = 3n elements.
@@ -2770,6 +2810,8 @@ class HipDev : public Dev {
     if (devdense_) DP_SET_LDS_ONE(k_dense_tail, 1024, (int)EXCL_LDS);
     if (deveqsum_) DP_SET_LDS_ONE(k_eqsum_tail, 1024, (int)EXCL_LDS);
     if (devcommit_) DP_SET_LDS_ONE(k_commit_tail, 1024, (int)EXCL_LDS);
+    DP_SET_LDS((k_butterfly_pass<false, false>), 1024, 64 * 1024); DP_SET_LDS((k_butterfly_pass<false, true>), 1024, 64 * 1024);
+    DP_SET_LDS((k_butterfly_pass<true, false>), 1024, 64 * 1024); DP_SET_LDS((k_butterfly_pass<true, true>), 1024, 64 * 1024);
     DP_SET_LDS(k_med_prepare, 1024, 128 * 1024);
     DP_SET_LDS(k_med_ntt_local, 1024, 64 * 1024);
   }
@@ -3604,6 +3646,24 @@ class HipDev : public Dev {
     DBuf nodes = persistent ? alloc_persistent(4 * (n - 1), false) : alloc(4 * (n - 1), false);
     return build_tree_into(leaves, nodes);
   }
+  // stages [s0, s1) of the Moebius transform / DIT NTT of `buf` as LDS-tiled passes (k_butterfly_pass): tiles of 64 KB (2^13 base
+  // or 2^12 extension elements); the first pass works on contiguous blocks, later ones on strided tiles of 128-byte segments
+  bool ntt_stagewise_ = getenv("DP_NTT_STAGEWISE") && atoi(getenv("DP_NTT_STAGEWISE"));
+  void butterfly_passes(const DBuf& buf, unsigned s0, unsigned s1, bool ntt) {
+    const unsigned lgtile = buf.ext ? 12 : 13, lgseg = buf.ext ? 3 : 4;
+    const unsigned lgn = dp_ceil_log2(buf.n);
+    const size_t lds = (size_t(1) << lgtile) * (buf.ext ? 16 : 8);
+    while (s0 < s1) {
+      const unsigned lgc = std::min(s0, lgseg), span = std::min(s1 - s0, std::min(lgtile, lgn) - lgc), s_hi = s0 + span;
+      const size_t tiles = buf.n >> (span + lgc);
+      const size_t bytes = (size_t(1) << (span + lgc)) * (buf.ext ? 16 : 8);
+      nb_ = 2.0 * (double)buf.bytes();
+      if (buf.ext) { if (ntt) { DPL_LDS((k_butterfly_pass<true, true>), dim3((unsigned)tiles), dim3(TPB), bytes, buf.p, s0, s_hi, lgc, (const u64*)tw_, L_); } else { DPL_LDS((k_butterfly_pass<true, false>), dim3((unsigned)tiles), dim3(TPB), bytes, buf.p, s0, s_hi, lgc, (const u64*)tw_, L_); } }
+      else { if (ntt) { DPL_LDS((k_butterfly_pass<false, true>), dim3((unsigned)tiles), dim3(TPB), bytes, buf.p, s0, s_hi, lgc, (const u64*)tw_, L_); } else { DPL_LDS((k_butterfly_pass<false, false>), dim3((unsigned)tiles), dim3(TPB), bytes, buf.p, s0, s_hi, lgc, (const u64*)tw_, L_); } }
+      (void)lds;
+      s0 = s_hi;
+    }
+  }
   DevCommit commit(const DBuf& evals, bool persistent) override {
     DevCommit c; c.nv = dp_ceil_log2(evals.n); c.is_base = !evals.ext; c.evals = evals;
     DP_REQUIRE((size_t(1) << c.nv) == evals.n && evals.n >= 2, DP_ERR_SHAPE, "commit: polynomial length must be a power of two >= 2");
@@ -3619,16 +3679,20 @@ class HipDev : public Dev {
     DBuf tmp = alloc(2 * n, evals.ext);
     copy(co, evals);
     bool E = evals.ext;
-    for (unsigned s = 0; s < c.nv; s++) {  // K5 evaluations -> multilinear coefficients
-      if (E) { nb_ = 32.0 * n; DPL(k_mobius_stage<true>, dim3(grid_for(n / 2)), dim3(TPB), co.p, n, s); }
-      else { nb_ = 16.0 * n; DPL(k_mobius_stage<false>, dim3(grid_for(n / 2)), dim3(TPB), co.p, n, s); }
-    }
+    if (ntt_stagewise_) {
+      for (unsigned s = 0; s < c.nv; s++) {  // K5 evaluations -> multilinear coefficients, one stage per launch (DP_NTT_STAGEWISE=1)
+        if (E) { nb_ = 32.0 * n; DPL(k_mobius_stage<true>, dim3(grid_for(n / 2)), dim3(TPB), co.p, n, s); }
+        else { nb_ = 16.0 * n; DPL(k_mobius_stage<false>, dim3(grid_for(n / 2)), dim3(TPB), co.p, n, s); }
+      }
+    } else butterfly_passes(co, 0, c.nv, false);  // K5 in LDS tiles: 2 passes for 2^20
     if (E) { nb_ = 48.0 * n; DPL(k_rs_prepare<true>, dim3(grid_for(n)), dim3(TPB), (const void*)co.p, tmp.p, (const u64*)pow7_, c.nv, L_); }
     else { nb_ = 24.0 * n; DPL(k_rs_prepare<false>, dim3(grid_for(n)), dim3(TPB), (const void*)co.p, tmp.p, (const u64*)pow7_, c.nv, L_); }
-    for (unsigned s = 1; s <= c.nv; s++) {  // K7 remaining DIT stages on 2n points
-      if (E) { nb_ = 64.0 * n; DPL(k_ntt_stage<true>, dim3(grid_for(n)), dim3(TPB), tmp.p, 2 * n, s, (const u64*)tw_, L_); }
-      else { nb_ = 32.0 * n; DPL(k_ntt_stage<false>, dim3(grid_for(n)), dim3(TPB), tmp.p, 2 * n, s, (const u64*)tw_, L_); }
-    }
+    if (ntt_stagewise_) {
+      for (unsigned s = 1; s <= c.nv; s++) {  // K7 remaining DIT stages on 2n points
+        if (E) { nb_ = 64.0 * n; DPL(k_ntt_stage<true>, dim3(grid_for(n)), dim3(TPB), tmp.p, 2 * n, s, (const u64*)tw_, L_); }
+        else { nb_ = 32.0 * n; DPL(k_ntt_stage<false>, dim3(grid_for(n)), dim3(TPB), tmp.p, 2 * n, s, (const u64*)tw_, L_); }
+      }
+    } else butterfly_passes(tmp, 1, c.nv + 1, true);  // K7 stages 1..nv of the 2n-point DIT
     bitrev_copy(cw, tmp);            // K6
     bitrev_copy(c.bh_evals, evals);  // K6
     c.tree = build_tree_into(cw, nodes);  // K8 (synchronises: root to host)

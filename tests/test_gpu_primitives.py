@@ -191,6 +191,20 @@ def test_pcs_commit_root(dev, oracle, nv, ext):
     assert c.root == oracle.pcs_commit_root(1 << 16, w, ext)
 
 
+@pytest.mark.parametrize("nv,ext,full", [(15, False, 15), (17, True, 18), (20, False, 20), (19, True, 20)])
+def test_pcs_commit_root_large_polynomials(dev, oracle, nv, ext, full):
+    """commits above 2^14 coefficients take the LDS-tiled butterfly passes (k_butterfly_pass: contiguous tile for the low
+    stages, strided 128-byte-segment tiles for the high ones; Moebius and the 2n-point DIT NTT, base and extension) — roots
+    against the oracle, including the coset dependence on the parameter size; the per-stage path (DP_NTT_STAGEWISE) gave the
+    same roots in round 1"""
+    import deep_prove_amd as dpa
+    rng = np.random.default_rng(900 + nv)
+    w = rand_base(rng, (2 if ext else 1) << nv)
+    pcs = dpa.Basefold(dev, 1 << full)
+    c = pcs.commit(dpa.Mle.from_ext(dev, w) if ext else dpa.Mle.from_base(dev, w))
+    assert c.root == oracle.pcs_commit_root(1 << full, w, ext)
+
+
 def test_pcs_commit_golden_and_context_dependence(dev, oracle):
     import deep_prove_amd as dpa
     g = np.load(os.path.join(ROOT, "tests", "golden", "primitives.npz"))
