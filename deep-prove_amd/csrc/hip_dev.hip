@@ -8,6 +8,7 @@
 // element. A sumcheck pair (2b, 2b+1) is therefore 32 contiguous bytes per lane.
 #include "dev.h"
 #include "poseidon2_fast.h"
+#include "gl64_lazy.h"
 #include "sumcheck.h"
 #include "fiber.h"
 #include "logup_tail.h"
@@ -334,7 +335,11 @@ KBODY k_sc_fused(const void* in0, const void* in1, const void* in2, Ext* out0, E
   __shared__ Ext sm[TPB / 64];
   const void* in[3] = {in0, in1, in2};
   Ext* out[3] = {out0, out1, out2};
-  Ext acc0 = ex_zero(), acc1 = ex_zero(), acc2 = ex_zero(), acc3 = ex_zero();
+  // The kernel is VALU-bound (93 % of the issue slots in its base-table round, profiles/r02_pmc_sq_sumcheck24.json), so the
+  // field arithmetic is the lazy kind of gl64_lazy.h: folds as one fused multiply-add with a single reduction per limb,
+  // extension products schoolbook with two reductions, running sums as exact integers reduced once per thread. What is STORED is
+  // canonical (other kernels read the folded tables), what is multiplied is any representative.
+  lz::ExAcc acc0 = lz::acc_zero(), acc1 = lz::acc_zero(), acc2 = lz::acc_zero(), acc3 = lz::acc_zero();
   for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < nquads; q += (size_t)gridDim.x * blockDim.x) {
     Ext f0[K], f1[K];
 #pragma unroll
@@ -342,35 +347,35 @@ KBODY k_sc_fused(const void* in0, const void* in1, const void* in2, Ext* out0, E
       if (BASE) {
         const ulonglong2* p = (const ulonglong2*)((const u64*)in[j] + 4 * q);
         ulonglong2 a = p[0], b = p[1];
-        f0[j] = ex_lerp_base(a.x, a.y, r);
-        f1[j] = ex_lerp_base(b.x, b.y, r);
+        f0[j] = lz::ex_canon(lz::ex_fma_base(r, gl_sub(a.y, a.x), a.x));
+        f1[j] = lz::ex_canon(lz::ex_fma_base(r, gl_sub(b.y, b.x), b.x));
       } else {
         const Ext* p = (const Ext*)in[j] + 4 * q;
         Ext e0 = p[0], e1 = p[1], e2 = p[2], e3 = p[3];
-        f0[j] = ex_lerp(e0, e1, r);
-        f1[j] = ex_lerp(e2, e3, r);
+        f0[j] = lz::ex_canon(lz::ex_fma(r, ex_sub(e1, e0), e0));
+        f1[j] = lz::ex_canon(lz::ex_fma(r, ex_sub(e3, e2), e2));
       }
       out[j][2 * q] = f0[j];
       out[j][2 * q + 1] = f1[j];
     }
-    if (K == 1) { acc0 = ex_add(acc0, f0[0]); if (!SKIP1) acc1 = ex_add(acc1, f1[0]); }
+    if (K == 1) { lz::acc_add(acc0, f0[0]); if (!SKIP1) lz::acc_add(acc1, f1[0]); }
     else if (K == 2) {
       Ext c0 = ex_sub(ex_dbl(f1[0]), f0[0]), c1 = ex_sub(ex_dbl(f1[1]), f0[1]);
-      acc0 = ex_add(acc0, ex_mul(f0[0], f0[1])); if (!SKIP1) acc1 = ex_add(acc1, ex_mul(f1[0], f1[1])); acc2 = ex_add(acc2, ex_mul(c0, c1));
+      lz::acc_add(acc0, lz::ex_mul(f0[0], f0[1])); if (!SKIP1) lz::acc_add(acc1, lz::ex_mul(f1[0], f1[1])); lz::acc_add(acc2, lz::ex_mul(c0, c1));
     } else {
       Ext d0 = ex_sub(f1[0], f0[0]), d1 = ex_sub(f1[1], f0[1]), d2 = ex_sub(f1[2], f0[2]);
       Ext c0 = ex_add(f1[0], d0), c1 = ex_add(f1[1], d1), c2 = ex_add(f1[2], d2);
       Ext g0 = ex_add(c0, d0), g1 = ex_add(c1, d1), g2 = ex_add(c2, d2);
-      acc0 = ex_add(acc0, ex_mul(ex_mul(f0[0], f0[1]), f0[2])); if (!SKIP1) acc1 = ex_add(acc1, ex_mul(ex_mul(f1[0], f1[1]), f1[2]));
-      acc2 = ex_add(acc2, ex_mul(ex_mul(c0, c1), c2)); acc3 = ex_add(acc3, ex_mul(ex_mul(g0, g1), g2));
+      lz::acc_add(acc0, lz::ex_mul(lz::ex_mul(f0[0], f0[1]), f0[2])); if (!SKIP1) lz::acc_add(acc1, lz::ex_mul(lz::ex_mul(f1[0], f1[1]), f1[2]));
+      lz::acc_add(acc2, lz::ex_mul(lz::ex_mul(c0, c1), c2)); lz::acc_add(acc3, lz::ex_mul(lz::ex_mul(g0, g1), g2));
     }
   }
   size_t base = (size_t)blockIdx.x * 4;
   Ext v;
-  v = block_reduce_ext(acc0, sm); if (threadIdx.x == 0) partial[base + 0] = v;
-  v = block_reduce_ext(acc1, sm); if (threadIdx.x == 0) partial[base + 1] = v;
-  v = block_reduce_ext(acc2, sm); if (threadIdx.x == 0) partial[base + 2] = v;
-  v = block_reduce_ext(acc3, sm); if (threadIdx.x == 0) partial[base + 3] = v;
+  v = block_reduce_ext(lz::acc_value(acc0), sm); if (threadIdx.x == 0) partial[base + 0] = v;
+  v = block_reduce_ext(lz::acc_value(acc1), sm); if (threadIdx.x == 0) partial[base + 1] = v;
+  v = block_reduce_ext(lz::acc_value(acc2), sm); if (threadIdx.x == 0) partial[base + 2] = v;
+  v = block_reduce_ext(lz::acc_value(acc3), sm); if (threadIdx.x == 0) partial[base + 3] = v;
 }
 // last fold of a sumcheck: every table has 2 elements; results go to one contiguous array
 KBODY k_finish(const FoldArgs& a, Ext r, int ntabs, Ext* out) {
