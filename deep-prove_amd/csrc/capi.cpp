@@ -32,6 +32,12 @@ struct dp_model {
   ~dp_model() { for (auto* c : cohorts) hip_cohort_free(c); }
 };
 
+// Every cohort stream needs a hardware queue of its own (24 are served without time slicing; the HIP runtime multiplexes streams
+// onto GPU_MAX_HW_QUEUES = 4 by default and reads the variable when it initialises, i.e. at the first HIP call of the process).
+// The library asks for 24 when it is loaded — a host that has not touched HIP yet needs to know nothing; one that has already
+// initialised HIP keeps its setting (dp_model_prove_batch then simply shares queues: slower, not wrong, since no kernel of the
+// throughput path waits for the host).
+__attribute__((constructor)) static void dp_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 static thread_local std::string g_err;
 template <class F>
 static int32_t guard(F f) {
