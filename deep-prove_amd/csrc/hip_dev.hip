@@ -2602,6 +2602,7 @@ class HipDev : public Dev {
   unsigned long long last_tag_multi_[MULTI_MAX_WG];
   bool multi_ = true;  // DP_NO_MULTI=1 disables the multi-workgroup phase of large sumchecks
   bool multi_mid_ = getenv("DP_MULTI_MID") && atoi(getenv("DP_MULTI_MID"));
+  bool persist_global_mid_ = getenv("DP_PERSIST_GLOBAL_MID") && atoi(getenv("DP_PERSIST_GLOBAL_MID"));
   static bool persist_flag_env(const char* name) { const char* e = getenv(name); return !(e && atoi(e)); }
   // all G workgroups have published round `seq`: every slot's tag matches its payload (same protocol as wait_flag)
   void wait_flags_multi(unsigned long long seq, size_t nwords, int G, size_t slot_words) {
@@ -3393,9 +3394,14 @@ class HipDev : public Dev {
       read_shares(G, sess_.slot_words);
       return;
     }
-    const bool take_persistent = !sess_.active && persist_ && n_after <= SC_PERSIST_MAX && n_after >= 4 && 2 * nraw <= RES_WORDS;
+    // A sumcheck that arrives here in the middle (r pending: the streaming rounds of a large one are handing over) enters the
+    // persistent kernel only once its tables fit in LDS: the global-memory variant costs 35 us per round on 2^15..2^13-entry
+    // tables against ~20 us for another streaming / one-launch round (DP_PERSIST_GLOBAL_MID=1 restores the early hand-over).
+    const bool lds_fits = (size_t)nt * (n_in / 2) * 16 <= SC_LDS_MAX;
+    const bool persist_here = persist_ && n_after <= SC_PERSIST_MAX && n_after >= 4 && 2 * nraw <= RES_WORDS && (!r || lds_fits || persist_global_mid_ || throughput_mode_);
+    const bool take_persistent = !sess_.active && persist_here;
     if (pend_eq_.p && !(take_persistent && !r)) flush_pending_eq();
-    if (persist_ && n_after <= SC_PERSIST_MAX && n_after >= 4 && 2 * nraw <= RES_WORDS) {
+    if (persist_here) {
       ScPersistArgs a;
       a.eq_tab = -1; a.eq_k = 0;
       if (pend_eq_.p) {

@@ -37,7 +37,7 @@ typedef struct dp_commit dp_commit;
 typedef struct dp_model dp_model;
 
 const char* dp_last_error(void);
-void dp_free(void* p);
+void dp_free(void* p); /* ONLY for buffers this library returned (they are recycled, not handed back to malloc: DP_OUT_POOL_BYTES) */
 
 /* ---- device context */
 int32_t dp_ctx_create(int32_t device_id, dp_ctx** out);
