@@ -329,9 +329,14 @@ KBODY k_reduce_terms(const Ext* partial, size_t nblocks, Ext* out) {
 // table a second time). partial[block*4 + t] = sum over the block's pairs of prod_j (f0_j + t (f1_j - f0_j)).
 // SKIP1: the caller knows the round's claimed sum s(0) + s(1), so the t = 1 products are not computed (slot 1 stays 0
 // and the host sets s(1) = claim - s(0)): 2 of the 8 extension products per pair less.
+// `counter` non-null: the LAST workgroup to finish (a device-wide ticket) adds up the partials of all workgroups and publishes
+// the four sums to the host itself — no k_reduce_publish launch between two rounds of a large sumcheck. The partials cross
+// XCDs (per-XCD L2s are not coherent with each other): every workgroup releases at agent scope before it takes its ticket, the
+// last one acquires at agent scope before it reads (MI355X_MICROARCH.md, correctness boundaries).
+__device__ void sc_publish_vals_fwd(Ext* result, const Ext* src, size_t stride, int n, unsigned long long* flag, unsigned long long seq, int lane);
 template <int K, bool BASE, bool SKIP1>
 KBODY k_sc_fused(const void* in0, const void* in1, const void* in2, Ext* out0, Ext* out1, Ext* out2,
-                                                  size_t nquads, Ext r, Ext* partial) {
+                                                  size_t nquads, Ext r, Ext* partial, unsigned* counter, Ext* result, unsigned long long* flag, unsigned long long seq) {
   __shared__ Ext sm[TPB / 64];
   const void* in[3] = {in0, in1, in2};
   Ext* out[3] = {out0, out1, out2};
@@ -376,6 +381,26 @@ KBODY k_sc_fused(const void* in0, const void* in1, const void* in2, Ext* out0, E
   v = block_reduce_ext(lz::acc_value(acc1), sm); if (threadIdx.x == 0) partial[base + 1] = v;
   v = block_reduce_ext(lz::acc_value(acc2), sm); if (threadIdx.x == 0) partial[base + 2] = v;
   v = block_reduce_ext(lz::acc_value(acc3), sm); if (threadIdx.x == 0) partial[base + 3] = v;
+  if (counter) {
+    __shared__ int s_last;
+    __shared__ Ext res[4];
+    __threadfence();  // release: this workgroup's partials are visible device-wide
+    if (threadIdx.x == 0) s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (s_last) {
+      __threadfence();  // acquire: read what the other workgroups (other XCDs) wrote
+      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      if (wave < 4) {
+        Ext acc = ex_zero();
+        for (unsigned b = lane; b < gridDim.x; b += 64) acc = ex_add(acc, partial[(size_t)b * 4 + wave]);
+        acc = wave_reduce_ext(acc);
+        if (lane == 0) res[wave] = acc;
+      }
+      __syncthreads();
+      if (wave == 0) sc_publish_vals_fwd(result, res, 1, 4, flag, seq, lane);
+      if (threadIdx.x == 0) *counter = 0;  // the next launch on this stream starts from zero
+    }
+  }
 }
 // last fold of a sumcheck: every table has 2 elements; results go to one contiguous array
 KBODY k_finish(const FoldArgs& a, Ext r, int ntabs, Ext* out) {
@@ -2085,6 +2110,7 @@ __device__ __forceinline__ void sc_wait_challenge(const unsigned long long* mail
   chal[0] = ok ? 1 : 0; chal[1] = c0; chal[2] = c1;
 }
 __device__ void sc_publish_fwd(Ext* result, const Ext* part, const int* tk, const int* toff, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane) { sc_publish(result, part, tk, toff, nterms, wpt, flag, seq, lane); }
+__device__ void sc_publish_vals_fwd(Ext* result, const Ext* src, size_t stride, int n, unsigned long long* flag, unsigned long long seq, int lane) { sc_publish_vals(result, src, stride, n, flag, seq, lane); }
 __device__ void sc_wait_challenge_fwd(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal) { sc_wait_challenge(mailbox, seq, chal); }
 template <bool HI>
 KBODY k_sc_persist_lds(const ScPersistArgs& a, Ext* result, unsigned long long* flag, const unsigned long long* mailbox, unsigned long long seq0, const ScFsArgs* fs) {
@@ -2632,6 +2658,7 @@ class HipDev : public Dev {
     wait_exit_(t0);
   }
   u64* dres_ = nullptr;   // device result buffer
+  unsigned* fused_ticket_ = nullptr;  // "last workgroup" ticket of k_sc_fused (device, zero between launches)
   void* hstage_ = nullptr;  // pinned + device-mapped staging: [0, DESC_BYTES) descriptor ring read by kernels over PCIe, rest = bulk copies
   char* hstage_dev_ = nullptr;
   size_t desc_off_ = 0;
@@ -2792,6 +2819,7 @@ class HipDev : public Dev {
     persist_ = zerocopy_ && !(getenv("DP_NO_PERSIST") && atoi(getenv("DP_NO_PERSIST")));
     if (getenv("DP_SC_DEBUG") && atoi(getenv("DP_SC_DEBUG"))) { HIP_CHECK(hipMalloc((void**)&scdbg_, 64)); HIP_CHECK(hipMemset(scdbg_, 0, 64)); }
     HIP_CHECK(hipMalloc((void**)&dres_, RES_WORDS * 8));
+    HIP_CHECK(hipMalloc((void**)&fused_ticket_, 64)); HIP_CHECK(hipMemset(fused_ticket_, 0, 64));
     HIP_CHECK(hipHostMalloc(&hstage_, STAGE_BYTES + DESC_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
     HIP_CHECK(hipHostGetDevicePointer((void**)&hstage_dev_, hstage_, 0));
     hstage_dev_ += 0;
@@ -2828,6 +2856,7 @@ class HipDev : public Dev {
     if (pow7_) hipFree(pow7_);
     if (arena_) hipFree(arena_);
     if (dres_) hipFree(dres_);
+    if (fused_ticket_) hipFree(fused_ticket_);
     if (hres_) hipHostFree(hres_);
     if (hstage_) hipHostFree(hstage_);
     if (s_) hipStreamDestroy(s_);
@@ -3438,7 +3467,10 @@ class HipDev : public Dev {
       read_terms();
       return;
     }
-    if (zerocopy_ && n_after <= SC_SMALL_MAX && 2 * nraw <= RES_WORDS) {
+    // (a single product still 4096+ entries long after the fold, one proof on the GPU: the streaming kernel below does the
+    // round on many workgroups in ~15 us; the one-workgroup kernel here needs ~55 us for it)
+    const bool stream_instead = !throughput_mode_ && r && nterms == 1 && terms[0].k == nt && nt <= 3 && n_after >= 4096;
+    if (zerocopy_ && n_after <= SC_SMALL_MAX && 2 * nraw <= RES_WORDS && !stream_instead) {
       ScSmallArgs a;
       for (int i = 0; i < MAX_TABS; i++) { a.in[i] = nullptr; a.out[i] = nullptr; a.in_ext[i] = 0; }
       fill_terms(a.k, a.t, a.off);
@@ -3477,13 +3509,22 @@ class HipDev : public Dev {
         Ext* partial = (Ext*)arena_alloc((size_t)g * 4 * 16);
         nb_ = bytes;
         const bool skip1 = claim_hint_ != nullptr;
-        #define LAUNCH_FUSED2(KK, BB) do { if (skip1) DPL_B((k_sc_fused<KK, BB, true>), 256, KF_NONE, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial); \
-                                           else DPL_B((k_sc_fused<KK, BB, false>), 256, KF_NONE, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial); } while (0)
+        // one proof on the GPU: the kernel's last workgroup reduces and publishes (no second launch); cohort members keep the
+        // separate reduction (their workgroups of one launch belong to different proofs)
+        // ... which is OFF (DP_FUSED_TICKET=1): measured on the 2^24 sumcheck, the agent-scope release every workgroup needs before
+        // it takes its ticket is an L2 write-back per workgroup — the fused rounds went from 162 / 40 us to 1122 / 230 us
+        // (4096 write-backs per launch); a separate 14 us reduction launch per round is the cheaper way across XCDs.
+        static const bool ticket_env = getenv("DP_FUSED_TICKET") && atoi(getenv("DP_FUSED_TICKET"));
+        const bool inkernel = ticket_env && zerocopy_ && !co_ && fused_ticket_ != nullptr;
+        unsigned* tick = inkernel ? fused_ticket_ : nullptr;
+        const unsigned long long fseq = inkernel ? ++seq_ : 0;
+        #define LAUNCH_FUSED2(KK, BB) do { if (skip1) DPL_B((k_sc_fused<KK, BB, true>), 256, KF_NONE, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial, tick, (Ext*)hres_dev_, hflag_dev_, fseq); \
+                                           else DPL_B((k_sc_fused<KK, BB, false>), 256, KF_NONE, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial, tick, (Ext*)hres_dev_, hflag_dev_, fseq); } while (0)
         #define LAUNCH_FUSED(KK) do { if (base) LAUNCH_FUSED2(KK, true); else LAUNCH_FUSED2(KK, false); } while (0)
         if (nt == 1) LAUNCH_FUSED(1); else if (nt == 2) LAUNCH_FUSED(2); else LAUNCH_FUSED(3);
         #undef LAUNCH_FUSED
         #undef LAUNCH_FUSED2
-        reduce_publish(partial, (size_t)g, 4, 4);
+        if (inkernel) wait_flag(fseq, 8); else reduce_publish(partial, (size_t)g, 4, 4);
         for (int t = 0; t <= terms[0].k; t++) out[t] = ex(hres_[2 * t], hres_[2 * t + 1]);
         if (skip1) out[1] = ex_sub(*claim_hint_, out[0]);  // s(0) + s(1) = claim, exactly
         release(mk);
