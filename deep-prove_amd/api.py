@@ -319,6 +319,23 @@ class Basefold:
         check(_lib.load().dp_pcs_commit(self.dev.h, poly.h, C.byref(h), root))
         return Commitment(self.dev, h, [int(x) for x in root], poly)
 
+    def open(self, comm, point, eval_, transcript=None):
+        """PCS::open (mpcs/src/basefold.rs:466-544): one polynomial at one point; <= 7 variables: the trivial proof (no transcript)"""
+        pt, ev = _point(point), _point([eval_])
+        pw, pn = u64p(), C.c_size_t()
+        check(_lib.load().dp_pcs_open(self.dev.h, comm.h, pt.ctypes.data_as(u64p), len(point), ev.ctypes.data_as(u64p),
+                                      transcript.h if transcript is not None else None, C.byref(pw), C.byref(pn)))
+        return _take(pw, pn.value)
+
+    @staticmethod
+    def verify(max_poly_size, root, num_vars, is_base, point, eval_, proof_words, transcript=None):
+        """PCS::verify (mpcs/src/basefold.rs:863-962). Host only. Raises DeepProveError(DP_ERR_VERIFY) on rejection."""
+        r = np.array(root, dtype=np.uint64)
+        pt, ev = _point(point), _point([eval_])
+        pw = np.ascontiguousarray(proof_words, dtype=np.uint64)
+        check(_lib.load().dp_pcs_verify(max_poly_size, r.ctypes.data_as(u64p), num_vars, 1 if is_base else 0, pt.ctypes.data_as(u64p),
+                                        ev.ctypes.data_as(u64p), pw.ctypes.data_as(u64p), pw.size, transcript.h if transcript is not None else None))
+
     def batch_open(self, comms, points, evals, transcript):
         lib = _lib.load()
         hs = (vp * len(comms))(*[c.h for c in comms])

@@ -15,7 +15,7 @@
 #include <thread>
 
 DP_FIBER_SWITCH_ASM
-namespace dp { struct Cohort; Cohort* hip_cohort_new(); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
+namespace dp { struct Cohort; Cohort* hip_cohort_new(); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_pcs_share(Dev* worker, Dev* owner); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
 using namespace dp;
 
 // `mu`: PCS::commit is called from rayon workers in the reference (zkml/src/commit/context.rs:79-103 into_par_iter over
@@ -449,32 +449,35 @@ int32_t dp_pcs_commitment(const dp_commit* c, uint64_t root[4], uint32_t* num_va
     if (is_base) *is_base = c->c.is_base ? 1 : 0;
   });
 }
-/* PCS::open (mpcs/src/basefold.rs:466-539) as zkml calls it (zkml/src/commit/context.rs:395: polynomials of at most
- * trivial_num_vars() = 7 variables): the proof is the evaluation table itself, the transcript is not touched. */
+/* PCS::open (mpcs/src/basefold.rs:466-544): one committed polynomial at one point. Up to trivial_num_vars() = 7 variables (the only
+ * case zkml itself reaches, zkml/src/commit/context.rs:395) the proof is the evaluation table and the transcript is not touched;
+ * above, the commit phase (sumcheck interleaved with FRI folds) and 200 queries run on the device. */
 int32_t dp_pcs_open(dp_ctx* ctx, const dp_commit* comm, const uint64_t* point, uint32_t num_vars, const uint64_t eval[2], dp_transcript* t,
                     uint64_t** proof_words, size_t* proof_nwords) {
   return guard([&] {
     DP_REQUIRE(ctx && comm && point && proof_words && proof_nwords, DP_ERR_ARG, "bad arguments");
-    (void)eval; (void)t;  // "Opening does not need eval, except for sanity check" (basefold.rs:471); a trivial opening draws no challenge
+    (void)eval;  // "Opening does not need eval, except for sanity check" (basefold.rs:471)
     DP_REQUIRE(num_vars == comm->c.nv, DP_ERR_SHAPE, "point length != the polynomial's number of variables");
-    DP_REQUIRE(comm->c.trivial(), DP_ERR_SHAPE, "dp_pcs_open serves the trivial (<= 7 variable) openings of the zkml path; larger polynomials are opened with dp_pcs_batch_open (commit/context.rs:380-392)");
+    DP_REQUIRE(comm->c.trivial() || t, DP_ERR_ARG, "a non-trivial opening needs the transcript");
     CtxLock lk(ctx);
-    BasefoldProof p = pcs_open_trivial(*ctx->dev, comm->c);
+    BasefoldProof p = comm->c.trivial() ? pcs_open_trivial(*ctx->dev, comm->c) : pcs_open(*ctx->dev, 64, comm->c, read_point(point, num_vars), t->t);  // (size check against the parameters: commit())
     Writer w; w.basefold(p);
     *proof_words = copy_out(w.w); *proof_nwords = w.w.size();
   });
 }
-/* PCS::verify (mpcs/src/basefold.rs:772-894) for the same case: Merkle root of the opened table + its evaluation. Host only. */
-int32_t dp_pcs_verify(const uint64_t root[4], uint32_t num_vars, int32_t is_base, const uint64_t* point, const uint64_t eval[2],
+/* PCS::verify (mpcs/src/basefold.rs:863-962): trivial proof = Merkle root of the opened table + its evaluation (transcript untouched);
+ * otherwise the commit-phase replay, 200 authenticated fold chains and the sumcheck chain. Host only. */
+int32_t dp_pcs_verify(size_t max_poly_size, const uint64_t root[4], uint32_t num_vars, int32_t is_base, const uint64_t* point, const uint64_t eval[2],
                       const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t) {
   return guard([&] {
-    DP_REQUIRE(root && point && eval && proof_words, DP_ERR_ARG, "bad arguments");
-    (void)t;
-    DP_REQUIRE(num_vars <= PCS_BASECODE_LOG, DP_ERR_SHAPE, "dp_pcs_verify serves trivial (<= 7 variable) openings; batch openings go through dp_pcs_batch_verify");
+    DP_REQUIRE(root && point && eval && proof_words && is_pow2(max_poly_size), DP_ERR_ARG, "bad arguments");
     Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = root[k]; c.num_vars = num_vars; c.is_base = is_base != 0;
     Reader r(proof_words, proof_nwords); BasefoldProof p = r.basefold();
     DP_REQUIRE(r.pos == proof_nwords, DP_ERR_ARG, "proof stream: trailing words");
-    pcs_verify_trivial(c, read_point(point, num_vars), read_point(eval, 1)[0], p);
+    if (p.is_trivial()) { DP_REQUIRE(num_vars <= PCS_BASECODE_LOG, DP_ERR_VERIFY, "trivial proof for a non-trivial commitment"); pcs_verify_trivial(c, read_point(point, num_vars), read_point(eval, 1)[0], p); return; }
+    DP_REQUIRE(t, DP_ERR_ARG, "a non-trivial opening needs the transcript");
+    VerifierParams vp; vp.full_log = dp_ceil_log2(max_poly_size);
+    pcs_verify(vp, c, read_point(point, num_vars), read_point(eval, 1)[0], p, t->t);
   });
 }
 static void read_claims(int32_t n, const uint64_t* points_flat, const uint64_t* evals, const std::vector<unsigned>& nvs, std::vector<std::vector<Ext>>& pts, std::vector<Ext>& evs) {
@@ -577,7 +580,7 @@ int32_t dp_model_prove(dp_model* m, const int64_t* input, size_t ninput, uint64_
 int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs, size_t ninput, int32_t concurrency,
                              uint64_t** proof_words, size_t* proof_nwords, int64_t* outputs, size_t noutput_cap, size_t* noutput, double* wall_ms) {
   return guard([&] {
-    DP_REQUIRE(m && inputs && proof_words && proof_nwords && nproofs > 0 && concurrency > 0 && concurrency <= 256, DP_ERR_ARG, "bad arguments");
+    DP_REQUIRE(m && inputs && proof_words && proof_nwords && nproofs > 0 && concurrency > 0 && concurrency <= 1024, DP_ERR_ARG, "bad arguments");
     size_t nw = std::min<size_t>((size_t)concurrency, nproofs);
     // worker 0 is the model's own context; the others get their own stream + arena on the same GPU and share the
     // (read-only) model commitments
@@ -592,13 +595,16 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
       // the cap is fixed by the first batch that needs more workers than exist (later batches must not creep into the reserve)
       if (!m->in_flight_cap) {
         size_t free_b = 0, total_b = 0; hip_mem_info(m->ctx->device_id, &free_b, &total_b);
-        const size_t per = arena + (size_t(16) << m->zk->full_log) + (size_t(8) << 20);  // + the worker's twiddle / coset tables and small buffers
+        const size_t per = arena + (size_t(24) << 20);  // + the worker's staging and small buffers (the twiddle / coset tables are the context's, shared)
         m->in_flight_cap = m->workers.size() + 1 + (size_t)((double)free_b * 0.9 / (double)per);
         if (m->in_flight_cap < nw && getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) fprintf(stderr, "[dp timing] prove_batch: %zu proofs in flight asked, %zu fit in %.1f GB of free HBM (%.0f MB per worker)\n", nw, m->in_flight_cap, free_b / 1e9, per / 1048576.0);
       }
       nw = std::min(nw, m->in_flight_cap);
     }
-    while (m->workers.size() + 1 < nw) { std::unique_ptr<Dev> w(make_hip_worker(m->ctx->device_id, arena)); w->pcs_init(m->zk->full_log); m->workers.push_back(std::move(w)); }
+    // the context's tables may have been rebuilt for another parameter size since this model was loaded
+    auto share_pcs = [&](Dev* w) { m->ctx->dev->pcs_init(m->zk->full_log); hip_dev_pcs_share(w, m->ctx->dev); };
+    for (auto& w : m->workers) share_pcs(w.get());
+    while (m->workers.size() + 1 < nw) { std::unique_ptr<Dev> w(make_hip_worker(m->ctx->device_id, arena)); share_pcs(w.get()); m->workers.push_back(std::move(w)); }
     m->last_in_flight = nw;
     // several proofs in flight: throughput mode on every context (see hip_dev_set_latency_mode)
     hip_dev_set_latency_mode(m->ctx->dev, nw == 1);

@@ -2678,6 +2678,10 @@ class HipDev : public Dev {
   unsigned L_ = 0;  // full_message_size_log of the current PCS parameters
   u64* tw_ = nullptr;    // tw[i]   = w_{2^(L+1)}^i, i < 2^L   (all FFT root tables of rs.rs:31-68 in one array)
   u64* pow7_ = nullptr;  // pow7[i] = 7^i,          i < 2^L   (coset shifts)
+  // The two tables are read-only after pcs_init: the workers of a model borrow the owning context's pair (pcs_share) — 2 x 8 B x 2^L
+  // per worker otherwise (268 MB at L = 24), and one copy stays hot in L2 for every proof in flight instead of one copy per proof.
+  struct PcsTables { u64* tw = nullptr; u64* pow7 = nullptr; int device = 0; ~PcsTables() { hipSetDevice(device); if (tw) hipFree(tw); if (pow7) hipFree(pow7); } };
+  std::shared_ptr<PcsTables> pcs_tabs_;
   std::string name_;
 
   void* arena_alloc(size_t bytes) {
@@ -2852,8 +2856,7 @@ class HipDev : public Dev {
   ~HipDev() override {
     hipSetDevice(device_);
     if (s_) hipStreamSynchronize(s_);
-    if (tw_) hipFree(tw_);
-    if (pow7_) hipFree(pow7_);
+    pcs_tabs_.reset();
     if (arena_) hipFree(arena_);
     if (dres_) hipFree(dres_);
     if (fused_ticket_) hipFree(fused_ticket_);
@@ -3623,17 +3626,24 @@ class HipDev : public Dev {
     if (L == L_ && tw_) return;
     DP_REQUIRE(L >= 1 && L <= 28, DP_ERR_ARG, "pcs_init: unsupported parameter size");
     HIP_CHECK(hipStreamSynchronize(s_));
-    if (tw_) { hipFree(tw_); tw_ = nullptr; }
-    if (pow7_) { hipFree(pow7_); pow7_ = nullptr; }
+    tw_ = pow7_ = nullptr;
+    pcs_tabs_ = std::make_shared<PcsTables>();
+    pcs_tabs_->device = device_;
     L_ = L;
     size_t n = size_t(1) << L;
-    HIP_CHECK(hipMalloc((void**)&tw_, n * 8));
-    HIP_CHECK(hipMalloc((void**)&pow7_, n * 8));
+    HIP_CHECK(hipMalloc((void**)&pcs_tabs_->tw, n * 8));
+    HIP_CHECK(hipMalloc((void**)&pcs_tabs_->pow7, n * 8));
+    tw_ = pcs_tabs_->tw; pow7_ = pcs_tabs_->pow7;
     u64 w = GL_G32;
     for (unsigned i = L + 1; i < 32; i++) w = gl_sqr(w);
     DPL(k_pow_table, dim3(grid_for(n)), dim3(TPB), tw_, w, n);
     DPL(k_pow_table, dim3(grid_for(n)), dim3(TPB), pow7_, GL_GENERATOR, n);
     HIP_CHECK(hipStreamSynchronize(s_));
+  }
+  void pcs_share(HipDev& owner) {
+    DP_REQUIRE(owner.device_ == device_ && owner.pcs_tabs_, DP_ERR_ARG, "pcs_share: the owner has no tables on this device");
+    HIP_CHECK(hipStreamSynchronize(s_));
+    pcs_tabs_ = owner.pcs_tabs_; tw_ = pcs_tabs_->tw; pow7_ = pcs_tabs_->pow7; L_ = owner.L_;
   }
   void bitrev_copy(const DBuf& d, const DBuf& s) override {
     unsigned lg = dp_ceil_log2(s.n);
@@ -3990,6 +4000,7 @@ void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes) { HIP_CHE
 void hip_dev_dump_host_stats(Dev* d) { static_cast<HipDev*>(d)->dump_host_stats(); }
 // latency mode (one proof on the GPU): large sumcheck rounds spread over several workgroups; throughput mode (many proofs
 // in flight): one workgroup per sumcheck — spreading costs more CUs and host polls than it saves when the GPU is shared
+void hip_dev_pcs_share(Dev* worker, Dev* owner) { static_cast<HipDev*>(worker)->pcs_share(*static_cast<HipDev*>(owner)); }
 void hip_dev_set_latency_mode(Dev* d, bool on) { static_cast<HipDev*>(d)->set_latency_mode(on); }
 void hip_dev_profile_enable(Dev* d, bool on) { static_cast<HipDev*>(d)->profile_enable(on); }
 std::string hip_dev_profile_report(Dev* d) { return static_cast<HipDev*>(d)->profile_report(); }

@@ -28,6 +28,17 @@ inline BasefoldProof pcs_open_trivial(Dev& dev, const DevCommit& c) {
 
 struct OpenClaim { const DevCommit* comm; std::vector<Ext> point; Ext eval; };
 
+// words of Dev::query_gather for one (tree, pair) -> the opened pair with its Merkle path (query_phase.rs:669-700)
+inline CodewordQuery query_from_words(const QueryDesc& d, const std::vector<u64>& w) {
+  CodewordQuery q; q.is_ext = d.tree->leaves.ext; q.index = d.p0;
+  size_t o = 0;
+  if (q.is_ext) { q.left = ex(w[0], w[1]); q.right = ex(w[2], w[3]); o = 4; } else { q.left = ex(w[0], 0); q.right = ex(w[1], 0); o = 2; }
+  size_t npath = (w.size() - o) / 4;
+  q.path.reserve(npath);
+  for (size_t j = 0; j < npath; j++) { Digest dg; for (int k = 0; k < 4; k++) dg.v[k] = w[o + 4 * j + k]; q.path.push_back(dg); }
+  return q;
+}
+
 // Rounds [first, num_rounds) of batch_commit_phase (commit_phase.rs:187-359): per round absorb the pending sumcheck message,
 // draw the folding challenge, merge the committed codewords of the running oracle's size, FRI-fold, fold the sumcheck pairs;
 // then the next message, the Merkle tree of the folded oracle and its root — or, in the last round, the final message.
@@ -200,23 +211,62 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
   std::vector<std::vector<u64>> got;
   dev.query_gather(descs.data(), descs.size(), got);
   size_t di = 0;
-  auto fill = [&](const QueryDesc& d, const std::vector<u64>& w) {
-    CodewordQuery q; q.is_ext = d.tree->leaves.ext; q.index = d.p0;
-    size_t o = 0;
-    if (q.is_ext) { q.left = ex(w[0], w[1]); q.right = ex(w[2], w[3]); o = 4; } else { q.left = ex(w[0], 0); q.right = ex(w[1], 0); o = 2; }
-    size_t npath = (w.size() - o) / 4;
-    q.path.reserve(npath);
-    for (size_t j = 0; j < npath; j++) { Digest dg; for (int k = 0; k < 4; k++) dg.v[k] = w[o + 4 * j + k]; q.path.push_back(dg); }
-    return q;
-  };
   for (size_t x : qidx) {
     BatchedQuery bq; bq.index = x;
     bq.oracle_query.reserve(trees.size()); bq.commitments_query.reserve(np);
-    for (size_t k = 0; k < trees.size(); k++, di++) bq.oracle_query.push_back(fill(descs[di], got[di]));
-    for (size_t k = 0; k < np; k++, di++) bq.commitments_query.push_back(fill(descs[di], got[di]));
+    for (size_t k = 0; k < trees.size(); k++, di++) bq.oracle_query.push_back(query_from_words(descs[di], got[di]));
+    for (size_t k = 0; k < np; k++, di++) bq.commitments_query.push_back(query_from_words(descs[di], got[di]));
     proof.queries.push_back(std::move(bq));
   }
   lap("query phase");
+  dev.release(mk);
+  return proof;
+}
+
+// PCS::open of one committed polynomial at one point (basefold.rs:466-544). commit_phase (commit_phase.rs:30-185) is the batch
+// commit phase with nothing to merge: the first oracle is the committed codeword itself (read as extension elements), the
+// sumcheck runs on eq(point, x) * f(x) over the bit-reversed hypercube evaluations; prover_query_phase (query_phase.rs:31-66,
+// 373-417) opens the pair of the codeword at the query index and one pair per folded oracle. No classic sumcheck, no batch
+// challenge: `sumcheck_proof` stays empty, every query carries exactly one commitment pair (ProofQueriesResultWithMerklePath::Single).
+inline BasefoldProof pcs_open(Dev& dev, unsigned full_log, const DevCommit& c, const std::vector<Ext>& point, Transcript& t) {
+  if (c.trivial()) return pcs_open_trivial(dev, c);  // Proof::trivial(evaluations): the transcript is not touched (basefold.rs:481-483)
+  DP_REQUIRE(point.size() == c.nv, DP_ERR_SHAPE, "open: point length != num_vars");
+  DP_REQUIRE(c.nv <= full_log, DP_ERR_SHAPE, "open: polynomial larger than the PCS parameters");
+  BasefoldProof proof;
+  size_t mk = dev.mark();
+  const unsigned num_vars = c.nv, num_rounds = num_vars - PCS_BASECODE_LOG;
+  const size_t cw_size = size_t(1) << (num_vars + PCS_RATE_LOG);
+  CommitLoopState st;
+  if (c.tree.leaves.ext) st.running = c.tree.leaves;  // fri_fold reads it, the committed leaves stay untouched
+  else { Dev::AxpyJob j{c.tree.leaves, ex_one(), 1}; st.running = dev.alloc(cw_size, true); dev.axpy_many(st.running, nullptr, &j, 1); }
+  st.sum_evals = dev.alloc(size_t(1) << num_vars, true);  // bf_round folds in place: always a copy
+  { Dev::AxpyJob j{c.bh_evals, ex_one(), 1}; dev.axpy_many(st.sum_evals, nullptr, &j, 1); }
+  std::vector<Ext> rev_point(point.rbegin(), point.rend());
+  st.eq = dev.alloc(size_t(1) << num_vars, true);
+  dev.eq_table(st.eq, rev_point.data(), num_vars, ex_one(), false);  // == bit-reversed eq(point)
+  st.last.resize(3);
+  dev.bf_round(st.eq, st.sum_evals, nullptr, st.last.data());
+  proof.sumcheck_messages.push_back(st.last);
+  std::vector<DevTree> trees;
+  std::vector<std::vector<Dev::AxpyJob>> merges(num_rounds);
+  commit_rounds(dev, merges, num_rounds, 0, true, st, t, proof.sumcheck_messages, proof.roots, trees, proof.final_message);
+  std::vector<size_t> qidx;
+  for (unsigned q = 0; q < PCS_NUM_QUERIES; q++) qidx.push_back((size_t)(t.get_and_append_challenge("query indices").c0 % cw_size));
+  std::vector<QueryDesc> descs;
+  for (size_t x : qidx) {
+    size_t index = x >> 1;
+    for (auto& tr : trees) { descs.push_back({&tr, (index | 1) - 1}); index >>= 1; }
+    descs.push_back({&c.tree, (x | 1) - 1});
+  }
+  std::vector<std::vector<u64>> got;
+  dev.query_gather(descs.data(), descs.size(), got);
+  size_t di = 0;
+  for (size_t x : qidx) {
+    BatchedQuery bq; bq.index = x;
+    for (size_t k = 0; k < trees.size(); k++, di++) bq.oracle_query.push_back(query_from_words(descs[di], got[di]));
+    bq.commitments_query.push_back(query_from_words(descs[di], got[di])); di++;
+    proof.queries.push_back(std::move(bq));
+  }
   dev.release(mk);
   return proof;
 }
@@ -292,6 +342,99 @@ inline Ext interpolate2_weights(Ext a0, Ext a1, Ext b1, Ext w, Ext x) { return e
 
 struct VerifyClaim { Commitment comm; std::vector<Ext> point; Ext eval; };
 
+// final codeword: encode_small(interpolate(bitrev(final_message))) then bit-reverse (query_phase.rs:158-172, 239-251).
+// Evaluated directly: message coefficients c (multilinear, bit-reversed order), codeword[k] = sum_i c_i (shift w^k)^i.
+inline std::vector<Ext> final_codeword_of(const VerifierParams& vp, const std::vector<Ext>& final_message) {
+  size_t mlen = final_message.size();
+  std::vector<Ext> msg(mlen);
+  for (size_t j = 0; j < mlen; j++) msg[dp_reverse_bits(j, PCS_BASECODE_LOG)] = final_message[j];
+  for (unsigned i = 1; i <= PCS_BASECODE_LOG; i++) {
+    size_t chunk = size_t(1) << i, half = chunk >> 1;
+    for (size_t c = 0; c < mlen; c += chunk) for (size_t j = half; j < chunk; j++) msg[c + j] = ex_sub(msg[c + j], msg[c + j - half]);
+  }
+  u64 shift = GL_GENERATOR;
+  for (unsigned i = 0; i < vp.full_log - PCS_BASECODE_LOG; i++) shift = gl_sqr(shift);
+  u64 w256 = GL_G32;
+  for (unsigned i = PCS_BASECODE_LOG + PCS_RATE_LOG; i < 32; i++) w256 = gl_sqr(w256);
+  size_t flen = mlen << PCS_RATE_LOG;
+  std::vector<Ext> final_codeword(flen);
+  for (size_t k = 0; k < flen; k++) {
+    u64 x = gl_mul(shift, gl_pow(w256, k));
+    Ext acc = ex_zero();
+    for (size_t i = mlen; i-- > 0;) acc = ex_add(ex_mul_base(acc, x), msg[i]);
+    final_codeword[dp_reverse_bits(k, PCS_BASECODE_LOG + PCS_RATE_LOG)] = acc;
+  }
+  return final_codeword;
+}
+
+// PCS::verify (basefold.rs:863-962) + verifier_query_phase (query_phase.rs:141-211) + SingleQueryResultWithMerklePath::check
+// (:915-974): replay the commit-phase transcript, authenticate every opened pair, fold the codeword pair down the oracles to
+// the final codeword, then the sumcheck chain: eval = h_0(0) + h_0(1), h_i(r_i) = h_{i+1}(0) + h_{i+1}(1), and
+// h_last(r_last) = <final_message, eq(point_head) * eq(point_tail, reversed challenges)>.
+inline void pcs_verify(const VerifierParams& vp, const Commitment& comm, const std::vector<Ext>& point, Ext eval, const BasefoldProof& proof, Transcript& t) {
+  if (proof.is_trivial()) { pcs_verify_trivial(comm, point, eval, proof); return; }
+  const unsigned num_vars = (unsigned)point.size();
+  DP_REQUIRE(num_vars == comm.num_vars && num_vars > PCS_BASECODE_LOG && num_vars <= vp.full_log, DP_ERR_VERIFY, "verify: bad shapes");
+  DP_REQUIRE(proof.sumcheck_proof.empty() && proof.trivial_proof.empty(), DP_ERR_VERIFY, "verify: a single opening carries no batch sumcheck");
+  const unsigned num_rounds = num_vars - PCS_BASECODE_LOG;
+  DP_REQUIRE(proof.sumcheck_messages.size() == num_rounds && proof.roots.size() + 1 == num_rounds, DP_ERR_VERIFY, "verify: commit-phase shape");
+  std::vector<Ext> fold_ch;
+  for (unsigned i = 0; i < num_rounds; i++) {
+    DP_REQUIRE(proof.sumcheck_messages[i].size() == 3, DP_ERR_VERIFY, "verify: commit message size");
+    t.append_exts(proof.sumcheck_messages[i]);
+    fold_ch.push_back(t.get_and_append_challenge("commit round"));
+    if (i + 1 < num_rounds) t.append_digest(proof.roots[i]);
+  }
+  DP_REQUIRE(proof.final_message.size() == (size_t(1) << PCS_BASECODE_LOG), DP_ERR_VERIFY, "verify: final message size");
+  t.append_exts(proof.final_message);
+  const size_t cw_size = size_t(1) << (num_vars + PCS_RATE_LOG);
+  std::vector<size_t> qidx;
+  for (unsigned q = 0; q < PCS_NUM_QUERIES; q++) qidx.push_back((size_t)(t.get_and_append_challenge("query indices").c0 % cw_size));
+  std::vector<Ext> rev(fold_ch.rbegin(), fold_ch.rend());
+  Ext coeff = eq_eval(point.data() + (point.size() - fold_ch.size()), rev.data(), fold_ch.size());
+  std::vector<Ext> head(point.begin(), point.end() - fold_ch.size());
+  std::vector<Ext> peq = host_eq_table(head);
+  for (auto& e : peq) e = ex_mul(e, coeff);
+  std::vector<Ext> final_codeword = final_codeword_of(vp, proof.final_message);
+  DP_REQUIRE(proof.queries.size() == PCS_NUM_QUERIES, DP_ERR_VERIFY, "verify: wrong number of queries");
+  for (unsigned q = 0; q < PCS_NUM_QUERIES; q++) {
+    const BatchedQuery& bq = proof.queries[q];
+    const size_t index = qidx[q];
+    DP_REQUIRE(bq.index == index, DP_ERR_VERIFY, "verify: query index mismatch");
+    DP_REQUIRE(bq.oracle_query.size() == proof.roots.size() && bq.commitments_query.size() == 1, DP_ERR_VERIFY, "verify: query shape");
+    for (size_t k = 0; k < bq.oracle_query.size(); k++) check_merkle_path(bq.oracle_query[k], proof.roots[k]);
+    const CodewordQuery& cq = bq.commitments_query[0];
+    DP_REQUIRE(cq.is_ext == !comm.is_base, DP_ERR_VERIFY, "verify: field type of the opened codeword");
+    check_merkle_path(cq, comm.root);
+    size_t right_index = index | 1, left_index = right_index - 1;
+    DP_REQUIRE(cq.index == left_index, DP_ERR_VERIFY, "verify: commitment query index");
+    Ext cur_l = cq.left, cur_r = cq.right;
+    for (unsigned i = 0; i < num_rounds; i++) {
+      u64 x0, w;
+      folding_coeffs(vp.full_log, num_vars + PCS_RATE_LOG - i - 1, left_index >> 1, x0, w);
+      Ext res = interpolate2_weights(ex_base(x0), cur_l, cur_r, ex_base(w), fold_ch[i]);
+      size_t next_index = right_index >> 1;
+      Ext next_val;
+      if (i + 1 < num_rounds) {
+        right_index = next_index | 1; left_index = right_index - 1;
+        const CodewordQuery& oq = bq.oracle_query[i];
+        DP_REQUIRE(oq.index == left_index && oq.is_ext, DP_ERR_VERIFY, "verify: oracle query index");
+        cur_l = oq.left; cur_r = oq.right;
+        next_val = (next_index & 1) ? cur_r : cur_l;
+      } else next_val = final_codeword[next_index];
+      DP_REQUIRE(ex_eq(res, next_val), DP_ERR_VERIFY, "verify: folding check failed");
+    }
+  }
+  auto zero_plus_one = [](const std::vector<Ext>& p) { return ex_add(ex_add(ex_dbl(p[0]), p[1]), p[2]); };
+  auto eval2 = [](const std::vector<Ext>& p, Ext x) { return ex_add(p[0], ex_add(ex_mul(x, p[1]), ex_mul(ex_mul(x, x), p[2]))); };
+  DP_REQUIRE(ex_eq(eval, zero_plus_one(proof.sumcheck_messages[0])), DP_ERR_VERIFY, "verify: first commit-phase message does not match the evaluation");
+  for (unsigned i = 0; i + 1 < num_rounds; i++)
+    DP_REQUIRE(ex_eq(eval2(proof.sumcheck_messages[i], fold_ch[i]), zero_plus_one(proof.sumcheck_messages[i + 1])), DP_ERR_VERIFY, "verify: commit-phase sumcheck chain");
+  Ext ip = ex_zero();
+  for (size_t i = 0; i < peq.size(); i++) ip = ex_add(ip, ex_mul(proof.final_message[i], peq[i]));
+  DP_REQUIRE(ex_eq(eval2(proof.sumcheck_messages[num_rounds - 1], fold_ch[num_rounds - 1]), ip), DP_ERR_VERIFY, "verify: final message inner product");
+}
+
 // PCS::batch_verify (basefold.rs:964-1098) + batch_verifier_query_phase (query_phase.rs:220-288) + check (:1116-1236)
 inline void pcs_batch_verify(const VerifierParams& vp, const std::vector<VerifyClaim>& claims, const BasefoldProof& proof, Transcript& t) {
   if (claims.empty() && proof.trivial_proof.empty() && proof.is_trivial()) return;
@@ -348,27 +491,8 @@ inline void pcs_batch_verify(const VerifierParams& vp, const std::vector<VerifyC
   std::vector<Ext> head(vpoint.begin(), vpoint.end() - fold_ch.size());
   std::vector<Ext> peq = host_eq_table(head);
   for (auto& e : peq) e = ex_mul(e, coeff);
-  // final codeword: encode_small(interpolate(bitrev(final_message))) then bit-reverse (query_phase.rs:239-251).
-  // Evaluated directly: message coefficients c (multilinear, bit-reversed order), codeword[k] = sum_i c_i (shift w^k)^i.
   size_t mlen = proof.final_message.size();
-  std::vector<Ext> msg(mlen);
-  for (size_t j = 0; j < mlen; j++) msg[dp_reverse_bits(j, PCS_BASECODE_LOG)] = proof.final_message[j];
-  for (unsigned i = 1; i <= PCS_BASECODE_LOG; i++) {
-    size_t chunk = size_t(1) << i, half = chunk >> 1;
-    for (size_t c = 0; c < mlen; c += chunk) for (size_t j = half; j < chunk; j++) msg[c + j] = ex_sub(msg[c + j], msg[c + j - half]);
-  }
-  u64 shift = GL_GENERATOR;
-  for (unsigned i = 0; i < vp.full_log - PCS_BASECODE_LOG; i++) shift = gl_sqr(shift);
-  u64 w256 = GL_G32;
-  for (unsigned i = PCS_BASECODE_LOG + PCS_RATE_LOG; i < 32; i++) w256 = gl_sqr(w256);
-  size_t flen = mlen << PCS_RATE_LOG;
-  std::vector<Ext> final_codeword(flen);
-  for (size_t k = 0; k < flen; k++) {
-    u64 x = gl_mul(shift, gl_pow(w256, k));
-    Ext acc = ex_zero();
-    for (size_t i = mlen; i-- > 0;) acc = ex_add(ex_mul_base(acc, x), msg[i]);
-    final_codeword[dp_reverse_bits(k, PCS_BASECODE_LOG + PCS_RATE_LOG)] = acc;
-  }
+  std::vector<Ext> final_codeword = final_codeword_of(vp, proof.final_message);
   DP_REQUIRE(proof.queries.size() == PCS_NUM_QUERIES, DP_ERR_VERIFY, "batch_verify: wrong number of queries");
   for (unsigned q = 0; q < PCS_NUM_QUERIES; q++) {
     const BatchedQuery& bq = proof.queries[q];

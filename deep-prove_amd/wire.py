@@ -165,6 +165,9 @@ def _basefold(p, c):
     trivial = bool(p["trivial_proof"])
     if trivial or not p["queries"]:
         qr = {"Single": {"inner": []}}  # BasefoldProof::trivial (structure.rs:352-363)
+    elif not p["sumcheck_proof"]:  # PCS::open of one polynomial (basefold.rs:532-544): no batch sumcheck, one commitment pair per query
+        qr = {"Single": {"inner": [[q["index"], {"oracle_query": {"inner": [_cq(x, c) for x in q["oracle_query"]]},
+                                                 "commitment_query": _cq(q["commitments_query"][0], c)}] for q in p["queries"]]}}
     else:
         qr = {"Batched": {"inner": [[q["index"], {"oracle_query": {"inner": [_cq(x, c) for x in q["oracle_query"]]},
                                                   "commitments_query": {"inner": [_cq(x, c) for x in q["commitments_query"]]}}] for q in p["queries"]]}}
@@ -359,7 +362,10 @@ class _Writer:
             self.d(d)
         self.ve(p["final_message"])
         qr = p["query_result_with_merkle_path"]
-        qs = qr["Batched"]["inner"] if "Batched" in qr else []
+        if "Batched" in qr:
+            qs = qr["Batched"]["inner"]
+        else:  # Single: the canonical stream keeps the one commitment pair as a list of one
+            qs = [[idx, {"oracle_query": q["oracle_query"], "commitments_query": {"inner": [q["commitment_query"]]}}] for idx, q in qr["Single"]["inner"]]
         self.w.append(len(qs))
         for idx, q in qs:
             self.w.append(idx)

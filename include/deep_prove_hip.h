@@ -167,15 +167,20 @@ int32_t dp_pcs_commit(dp_ctx* ctx, const dp_buf* poly, dp_commit** out, uint64_t
 int32_t dp_pcs_commit_free(dp_ctx* ctx, dp_commit* c);
 /* PCS::get_pure_commitment (mpcs/src/basefold.rs:459-461): BasefoldCommitment{root, num_vars, is_base} (structure.rs:161-166) */
 int32_t dp_pcs_commitment(const dp_commit* c, uint64_t root[4], uint32_t* num_vars, int32_t* is_base);
-/* PCS::open / PCS::verify (mpcs/src/basefold.rs:466-539, 772-894) for the commitments zkml opens one by one: polynomials of
- * at most PCS::trivial_num_vars() = 7 variables (zkml/src/commit/context.rs:295,395,477), whose opening proof is the
- * evaluation table itself (BasefoldProof::trivial, structure.rs:352-363) and whose verification is the Merkle root of that
- * table plus its evaluation; neither touches the transcript. Larger polynomials return DP_ERR_SHAPE: on the zkml path they are
- * opened together by dp_pcs_batch_open. dp_pcs_verify is host only. */
+/* PCS::open / PCS::verify (mpcs/src/basefold.rs:466-544, 863-962): one committed polynomial at one point.
+ *  - at most PCS::trivial_num_vars() = 7 variables (the case zkml opens one by one, zkml/src/commit/context.rs:295,395,477):
+ *    the proof is the evaluation table itself (BasefoldProof::trivial, structure.rs:352-363), verification is the Merkle root of
+ *    that table plus its evaluation; the transcript is not touched (t may be NULL);
+ *  - more variables: commit_phase (basefold/commit_phase.rs:30-185: sumcheck on eq(point, x) f(x) interleaved with the FRI folds
+ *    of the committed codeword, one Merkle tree per folded oracle) and prover_query_phase (basefold/query_phase.rs:31-66,
+ *    373-417: 200 indices, the codeword pair and one pair per oracle with their Merkle paths) on the device; the proof stream
+ *    is the Basefold proof layout of dp_pcs_batch_open with an empty batch sumcheck and one commitment pair per query
+ *    (ProofQueriesResultWithMerklePath::Single). `eval` is not needed to open (basefold.rs:471).
+ * dp_pcs_verify is host only; max_poly_size = the dp_pcs_setup size of the prover (the code's coset shift depends on it). */
 int32_t dp_pcs_open(dp_ctx* ctx, const dp_commit* comm, const uint64_t* point, uint32_t num_vars, const uint64_t eval[2],
                     dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords);
-int32_t dp_pcs_verify(const uint64_t root[4], uint32_t num_vars, int32_t is_base, const uint64_t* point, const uint64_t eval[2],
-                      const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t);
+int32_t dp_pcs_verify(size_t max_poly_size, const uint64_t root[4], uint32_t num_vars, int32_t is_base, const uint64_t* point,
+                      const uint64_t eval[2], const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t);
 /* PCS::batch_open with Evaluation::new(i, i, evals[i]) (mpcs/src/basefold.rs:546-770 as called from
  * zkml/src/commit/context.rs:355-418). points_flat = concatenation of the n points (2*num_vars_i words each). */
 int32_t dp_pcs_batch_open(dp_ctx* ctx, const dp_commit* const* comms, int32_t n, const uint64_t* points_flat,

@@ -278,6 +278,75 @@ static inline std::vector<E> parallel_pi(const std::vector<E>& evals, const std:
   return {c1, c2, c3};
 }
 
+// Basefold::open of ONE committed polynomial (basefold.rs:466-544; zkml itself only reaches the trivial branch, commit/context.rs:295):
+//   commit_phase (commit_phase.rs:30-185): running_oracle = the committed codeword read as extension elements, running_evals =
+//   the bit-reversed hypercube evaluations kept by commit(), eq = bit-reversed build_eq_x_r_vec(point); first message by
+//   sum_check_first_round; per round: absorb the message, draw "commit round", fold the oracle, (i > 0) keep the tree of the
+//   previous oracle; not the last round: sum_check_challenge_round -> next message, Merkle tree of the folded oracle, root to the
+//   transcript; last round: sum_check_last_round, the bit-reversed evaluations are the final message.
+//   prover_query_phase + basefold_get_query (query_phase.rs:31-66, 373-417): 200 x "query indices" mod the codeword size; the
+//   commitment pair at (x | 1) - 1, then one pair per oracle tree at ((x >> 1) | 1) - 1, ((x >> 2) | 1) - 1, ...
+//   The proof has no batch sumcheck (sumcheck_proof: None) and one commitment query per index (..::Single).
+static inline BasefoldProof pcs_open(const PcsParams& pp, const Mle& poly, const CommitmentWithWitness& comm, const std::vector<E>& point, Transcript& t) {
+  if (comm.is_trivial()) return pcs_open_trivial(poly, comm);
+  if (point.size() != poly.nv) throw std::runtime_error("open: point/poly mismatch");
+  if (poly.nv > pp.full_message_size_log) throw std::runtime_error("open: PolynomialTooLarge");
+  BasefoldProof proof;
+  const unsigned num_vars = poly.nv, num_rounds = num_vars - BASECODE_MSG_SIZE_LOG;
+  const Mle& cw = comm.codeword_tree.leaves;
+  std::vector<E> running_oracle(cw.len());
+  for (size_t j = 0; j < running_oracle.size(); j++) running_oracle[j] = cw.at(j);
+  std::vector<E> running_evals(comm.bh_evals.len());
+  for (size_t j = 0; j < running_evals.size(); j++) running_evals[j] = comm.bh_evals.at(j);
+  std::vector<E> eq = build_eq_x_r_vec(point);
+  reverse_index_bits_in_place(eq);
+  one_level_interp_hc(eq); one_level_interp_hc(running_evals);
+  std::vector<E> last_msg = parallel_pi(running_evals, eq);
+  std::vector<MerkleTree> trees;
+  std::vector<std::vector<Digest>> running_tree_inner;
+  for (unsigned i = 0; i < num_rounds; i++) {
+    for (E e : last_msg) t.append_ext(e);
+    proof.sumcheck_messages.push_back(last_msg);
+    E ch = t.get_and_append_challenge("commit round");
+    std::vector<E> new_running_oracle = basefold_fold(pp, log2_strict(running_oracle.size()) - 1, running_oracle, ch);
+    if (i > 0) { MerkleTree rt; rt.inner = running_tree_inner; rt.leaves = Mle::from_ext(running_oracle); trees.push_back(std::move(rt)); }
+    if (i < num_rounds - 1) {
+      one_level_eval_hc(running_evals, ch); one_level_eval_hc(eq, ch);
+      one_level_interp_hc(eq); one_level_interp_hc(running_evals);
+      last_msg = parallel_pi(running_evals, eq);
+      running_tree_inner = merkelize(Mle::from_ext(new_running_oracle));
+      Digest root = running_tree_inner.back()[0];
+      t.append_digest(root);
+      proof.roots.push_back(root);
+      running_oracle = std::move(new_running_oracle);
+    } else {
+      one_level_eval_hc(running_evals, ch); one_level_eval_hc(eq, ch);
+      reverse_index_bits_in_place(running_evals);
+      t.append_exts(running_evals);
+      proof.final_message = running_evals;
+    }
+  }
+  const size_t codeword_size = comm.codeword_size();
+  std::vector<size_t> qidx;
+  for (unsigned q = 0; q < NUM_QUERIES; q++) qidx.push_back((size_t)(t.get_and_append_challenge("query indices").c0 % codeword_size));
+  for (size_t x_index : qidx) {
+    BatchedQuery bq; bq.index = x_index;
+    size_t index = x_index;
+    { size_t p1 = index | 1, p0 = p1 - 1;
+      CodewordQuery cq; cq.is_ext = cw.is_ext; cq.left = cw.at(p0); cq.right = cw.at(p1); cq.index = p0; cq.path = comm.codeword_tree.path(p0);
+      bq.commitments_query.push_back(std::move(cq)); }
+    index >>= 1;
+    for (auto& tree : trees) {
+      size_t p1 = index | 1, p0 = p1 - 1;
+      CodewordQuery cq; cq.is_ext = true; cq.left = tree.leaves.at(p0); cq.right = tree.leaves.at(p1); cq.index = p0; cq.path = tree.path(p0);
+      bq.oracle_query.push_back(std::move(cq));
+      index >>= 1;
+    }
+    proof.queries.push_back(std::move(bq));
+  }
+  return proof;
+}
+
 struct Evaluation { size_t poly, point; E value; };
 
 // Basefold::batch_open (basefold.rs:546-770) for the zkml call shape (one point per polynomial is NOT assumed

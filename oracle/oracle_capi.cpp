@@ -131,6 +131,16 @@ int orc_logup_prove(const uint64_t* const* columns, int32_t ncols, size_t n, int
 int orc_pcs_commit_root(size_t max_poly_size, const uint64_t* words, size_t n, int is_ext, uint64_t root[4]) {
   return guard([&] { PcsParams pp = pcs_setup(max_poly_size); CommitmentWithWitness c = pcs_commit(pp, rd_mle(words, n, is_ext)); for (int i = 0; i < 4; i++) root[i] = c.codeword_tree.root()[i]; });
 }
+int orc_pcs_open(size_t max_poly_size, const uint64_t* words, size_t n, int is_ext, const uint64_t* point, orc_transcript* t, uint64_t** proof_words, size_t* proof_nwords) {
+  return guard([&] {
+    PcsParams pp = pcs_setup(max_poly_size);
+    Mle poly = rd_mle(words, n, is_ext);
+    CommitmentWithWitness c = pcs_commit(pp, poly);
+    Transcript scratch = default_transcript();
+    BasefoldProof p = pcs_open(pp, poly, c, rd_pt(point, poly.nv), t ? t->t : scratch);
+    Writer w; w.basefold(p); *proof_words = copy_out(w.w); *proof_nwords = w.w.size();
+  });
+}
 int orc_pcs_batch_open(size_t max_poly_size, const uint64_t* const* polys, const size_t* lens, const int32_t* is_ext, int32_t n, const uint64_t* points_flat, const uint64_t* evals,
                        orc_transcript* t, uint64_t** proof_words, size_t* proof_nwords) {
   return guard([&] {

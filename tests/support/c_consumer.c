@@ -3,7 +3,7 @@
  *   seam 2  dp_sumcheck_prove (a degree-4 product + a short table) -> sc_proof.bin, sc_finals.bin
  *   seam 1  dp_pcs_setup, dp_pcs_commit from FOUR THREADS AT ONCE on one dp_ctx (as rayon calls PCS::commit) -> roots.bin,
  *           dp_pcs_commitment, dp_mle_eval, dp_pcs_batch_open -> bo_proof.bin, dp_pcs_batch_verify,
- *           dp_pcs_open / dp_pcs_verify on a 6-variable polynomial -> triv_proof.bin
+ *           dp_pcs_open / dp_pcs_verify on a 6-variable polynomial -> triv_proof.bin, on the 13-variable one -> open_proof.bin
  *   model   dp_model_setup / dp_model_output_len / dp_model_prove / dp_model_verifier_blob / dp_verify -> model_proof.bin
  * Inputs are files written by tests/test_gpu_c_consumer.py, which compares every output with the oracle.
  * usage: c_consumer <workdir>        (c_consumer --symbols: only touch every entry point's address, no device needed) */
@@ -123,10 +123,22 @@ int main(int argc, char** argv) {
     uint64_t* tp = NULL; size_t tn = 0;
     CHECK(dp_pcs_open(ctx, jobs[3].comm, pts, 6, ev6, NULL, &tp, &tn));
     write_u64("triv_proof.bin", tp, tn);
-    CHECK(dp_pcs_verify(roots + 12, 6, 1, pts, ev6, tp, tn, NULL));
+    CHECK(dp_pcs_verify((size_t)1 << 13, roots + 12, 6, 1, pts, ev6, tp, tn, NULL));
     ev6[0] ^= 1;
-    if (dp_pcs_verify(roots + 12, 6, 1, pts, ev6, tp, tn, NULL) != DP_ERR_VERIFY) { fprintf(stderr, "wrong evaluation accepted by dp_pcs_verify\n"); return 1; }
-    if (dp_pcs_open(ctx, jobs[0].comm, pts, 13, evals, NULL, &tp, &tn) != DP_ERR_SHAPE) { fprintf(stderr, "dp_pcs_open must refuse non-trivial commitments\n"); return 1; }
+    if (dp_pcs_verify((size_t)1 << 13, roots + 12, 6, 1, pts, ev6, tp, tn, NULL) != DP_ERR_VERIFY) { fprintf(stderr, "wrong evaluation accepted by dp_pcs_verify\n"); return 1; }
+    dp_free(tp);
+    /* the 13-variable polynomial alone: PCS::open (commit phase + queries on the device) / PCS::verify */
+    dp_transcript* ot = dp_transcript_new("test"); dp_transcript* ovt = dp_transcript_new("test");
+    uint64_t* op = NULL; size_t on = 0;
+    CHECK(dp_pcs_open(ctx, jobs[0].comm, pts, 13, evals, ot, &op, &on));
+    write_u64("open_proof.bin", op, on);
+    CHECK(dp_pcs_verify((size_t)1 << 13, roots, 13, 1, pts, evals, op, on, ovt));
+    evals[0] ^= 1;
+    dp_transcript* ovt2 = dp_transcript_new("test");
+    if (dp_pcs_verify((size_t)1 << 13, roots, 13, 1, pts, evals, op, on, ovt2) != DP_ERR_VERIFY) { fprintf(stderr, "wrong evaluation accepted by dp_pcs_verify (13 variables)\n"); return 1; }
+    evals[0] ^= 1;
+    if (dp_pcs_open(ctx, jobs[0].comm, pts, 13, evals, NULL, &tp, &tn) != DP_ERR_ARG) { fprintf(stderr, "dp_pcs_open of a non-trivial commitment needs a transcript\n"); return 1; }
+    dp_free(op); dp_transcript_free(ot); dp_transcript_free(ovt); dp_transcript_free(ovt2);
     for (int i = 0; i < 4; i++) { CHECK(dp_pcs_commit_free(ctx, jobs[i].comm)); CHECK(dp_buf_free(ctx, jobs[i].buf)); free(words[i]); }
     free(pts);
   }

@@ -171,7 +171,66 @@ static int sharded_mode(uint64_t seed, unsigned nv, int W) {
   printf("sharded sumcheck nv=%u world=%d: %d of %d ranks identical to the unsharded oracle proof (messages, finals, transcript)\n", nv, W, good, W);
   return good == W ? 0 : 2;
 }
+// `hostlogic_check open <seed> <nv> <ext>`: PCS::open of one polynomial (mpcs/src/basefold.rs:466-544) — the product's pcs_open over
+// the double vs the oracle's restatement of commit_phase + prover_query_phase: proof stream, transcript state; then the product's
+// pcs_verify accepts it and rejects a wrong evaluation, a flipped word and a foreign root (the reference's commit_open_verify test
+// shape, mpcs/src/lib.rs:467-540)
+static int open_mode(uint64_t seed, unsigned nv, bool ext) {
+  rs = seed;
+  const unsigned L = nv + 1;  // parameters larger than the polynomial: the coset shift of the code is not the trivial one
+  std::vector<uint64_t> w((size_t(1) << nv) * (ext ? 2 : 1)); for (auto& x : w) x = rnd() % dp::GL_P;
+  std::vector<orc::E> opoint(nv); std::vector<dp::Ext> ppoint(nv);
+  for (unsigned i = 0; i < nv; i++) { uint64_t a = rnd() % dp::GL_P, b = rnd() % dp::GL_P; opoint[i] = orc::E{a, b}; ppoint[i] = dp::ex(a, b); }
+  orc::Mle om;
+  if (ext) { std::vector<orc::E> e(w.size() / 2); for (size_t j = 0; j < e.size(); j++) e[j] = orc::E{w[2 * j], w[2 * j + 1]}; om = orc::Mle::from_ext(e); } else om = orc::Mle::from_base(w);
+  orc::PcsParams pp = orc::pcs_setup(size_t(1) << L);
+  orc::CommitmentWithWitness oc = orc::pcs_commit(pp, om);
+  orc::Transcript ot = orc::default_transcript();
+  const int pre = getenv("HL_PREFIX_WORDS") ? atoi(getenv("HL_PREFIX_WORDS")) : 0;  // sponge alignment at the start of the opening
+  for (int i = 0; i < pre; i++) ot.append_field_element(1000 + i);
+  orc::BasefoldProof op = orc::pcs_open(pp, om, oc, opoint, ot);
+  orc::Writer ow; ow.basefold(op);
+  orc::E oeval = om.evaluate(opoint);
+  orc::E och = ot.get_and_append_challenge("after");
+  TestDev dev; dev.pcs_init(L);
+#ifdef DP_EMUL_DEV
+  dp::emul_init_constants();
+  if (getenv("DP_EMUL_COMMIT_MAX_N")) dev.commit_max_n = (size_t)atoll(getenv("DP_EMUL_COMMIT_MAX_N"));
+  if (getenv("DP_EMUL_THREADS")) dev.threads = (unsigned)atoi(getenv("DP_EMUL_THREADS"));
+#endif
+  dp::DBuf b = dev.alloc_persistent(size_t(1) << nv, ext); dev.upload(b, w.data());
+  dp::DevCommit c = static_cast<dp::Dev&>(dev).commit(b, true);
+  bool root_same = true; for (int k = 0; k < 4; k++) root_same = root_same && c.tree.root.v[k] == oc.codeword_tree.root()[k];
+  dp::Transcript pt = dp::default_transcript();
+  for (int i = 0; i < pre; i++) pt.append_field_element(1000 + i);
+  dp::BasefoldProof pr = dp::pcs_open(dev, L, c, ppoint, pt);
+  dp::Writer pw; pw.basefold(pr);
+  dp::Ext pch = pt.get_and_append_challenge("after");
+  bool same = root_same && pw.w == ow.w && pch.c0 == och.c0 && pch.c1 == och.c1;
+  dp::VerifierParams vp; vp.full_log = L;
+  dp::Commitment pc = dp::pure_commitment(c);
+  dp::Ext eval = dp::ex(oeval.c0, oeval.c1);
+  int accepted = 0, rejected = 0;
+  auto run = [&](const dp::Commitment& cm, dp::Ext ev, const std::vector<uint64_t>& words, unsigned full_log) {
+    try { dp::Reader r(words.data(), words.size()); dp::BasefoldProof q = r.basefold(); dp::Transcript vt = dp::default_transcript(); dp::VerifierParams v2; v2.full_log = full_log; dp::pcs_verify(v2, cm, ppoint, ev, q, vt);
+          dp::Ext vch = vt.get_and_append_challenge("after"); return vch.c0 == och.c0 && vch.c1 == och.c1 ? 1 : 2; }
+    catch (const dp::DpError&) { return 0; }
+  };
+  accepted += run(pc, eval, ow.w, L) == 1;                                             // the oracle's proof, verifier transcript in the prover's state
+  rejected += run(pc, dp::ex_add(eval, dp::ex_one()), ow.w, L) == 0;                   // wrong evaluation
+  { dp::Commitment bad = pc; bad.root.v[1] ^= 1; rejected += run(bad, eval, ow.w, L) == 0; }  // foreign root
+  rejected += run(pc, eval, ow.w, L + 1) == 0;                                         // other parameters: other coset
+  for (size_t at : {size_t(3), ow.w.size() / 3, ow.w.size() / 2, ow.w.size() - 30}) { std::vector<uint64_t> t2 = ow.w; t2[at] ^= 1; rejected += run(pc, eval, t2, L) == 0; }
+  printf("pcs open nv=%u %s: stream+root+transcript %s the oracle (%zu words, %zu rounds, %zu queries); verifier accepted %d of 1, rejected %d of 7\n", nv, ext ? "ext" : "base",
+         same ? "identical to" : "DIFFER from", pw.w.size(), pr.sumcheck_messages.size(), pr.queries.size(), accepted, rejected);
+  if (!same) { size_t d = 0; while (d < pw.w.size() && d < ow.w.size() && pw.w[d] == ow.w[d]) d++; printf("  root same %d, sizes %zu / %zu, first differing word %zu, transcript same %d\n", (int)root_same, pw.w.size(), ow.w.size(), d, (int)(pch.c0 == och.c0 && pch.c1 == och.c1)); }
+#ifdef DP_EMUL_DEV
+  printf("emulated k_commit_tail: %zu commit-phase tails taken (%zu rounds)\n", dev.commit_taken, dev.commit_rounds_run);
+#endif
+  return same && accepted == 1 && rejected == 7 ? 0 : 2;
+}
 int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "open") return open_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 9, argc > 4 && atoi(argv[4]));
   if (argc > 1 && std::string(argv[1]) == "sharded") return sharded_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 4);
   if (argc > 1 && std::string(argv[1]) == "sumcheck") return sumcheck_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 6);
   bool cnn = argc > 1 && std::string(argv[1]) == "cnn";

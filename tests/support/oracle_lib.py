@@ -174,6 +174,14 @@ class Oracle:
         self._ok(self.lib.orc_pcs_commit_root(C.c_size_t(max_poly_size), w.ctypes.data_as(u64p), C.c_size_t(n), C.c_int(1 if is_ext else 0), root))
         return [int(x) for x in root]
 
+    def pcs_open(self, max_poly_size, words, is_ext, point, transcript=None):
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        pt = _pt(point)
+        pw, pn = u64p(), C.c_size_t()
+        self._ok(self.lib.orc_pcs_open(C.c_size_t(max_poly_size), w.ctypes.data_as(u64p), C.c_size_t(w.size // 2 if is_ext else w.size), C.c_int(1 if is_ext else 0),
+                                       pt.ctypes.data_as(u64p), transcript.h if transcript is not None else None, C.byref(pw), C.byref(pn)))
+        return self._take(pw, pn.value)
+
     def pcs_batch_open(self, max_poly_size, polys, is_ext, points, evals, transcript):
         keep = [np.ascontiguousarray(p, dtype=np.uint64) for p in polys]
         pp = (u64p * len(keep))(*[k.ctypes.data_as(u64p) for k in keep])

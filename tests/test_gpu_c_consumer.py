@@ -64,6 +64,10 @@ def test_c11_consumer_matches_the_oracle(oracle, tmp_path):
     # trivial opening: the stream carries the raw table
     tp = rd("triv_proof.bin")
     assert tp.size > 64 and (tp[-64:] == polys[3]).all() and int(tp[-65]) == 64  # ... {count 1, base, length 64, the 64 evaluations}
+    # the 13-variable polynomial opened alone: PCS::open through the C entry == the oracle's commit phase + query phase
+    oop = oracle.pcs_open(1 << 13, polys[0], False, p0, oracle.transcript(b"test"))
+    got = rd("open_proof.bin")
+    assert got.size == oop.size and (got == oop).all()
     # the model proof
     h = oracle.model_setup(mb.blob())
     oproof, oout, _ = oracle.model_prove(h, x)

@@ -224,6 +224,34 @@ def test_pcs_too_large_polynomial_is_rejected(dev):
         pcs.commit(dpa.Mle.from_base(dev, np.zeros(1 << 11, dtype=np.uint64)))
 
 
+@pytest.mark.parametrize("nv,ext,full", [(5, False, 12), (7, True, 12), (8, False, 12), (9, True, 9), (12, False, 14), (13, True, 14), (16, False, 16), (18, False, 19)])
+def test_pcs_open_and_verify_single_polynomial(dev, oracle, nv, ext, full):
+    """PCS::open / PCS::verify of one polynomial (mpcs/src/basefold.rs:466-544, 863-962): the device's commit phase (sumcheck rounds
+    interleaved with FRI folds and Merkle trees, the fused commit tail included) and query phase give the oracle's stream and
+    transcript state, base and extension, trivial and not, parameters equal to and larger than the polynomial"""
+    import deep_prove_amd as dpa
+    rng = np.random.default_rng(7000 + nv)
+    maxsize = 1 << full
+    pcs = dpa.Basefold(dev, maxsize)
+    w = rand_base(rng, (2 if ext else 1) << nv)
+    m = dpa.Mle.from_ext(dev, w) if ext else dpa.Mle.from_base(dev, w)
+    c = pcs.commit(m)
+    point = rand_point(rng, nv)
+    ev = m.evaluate(point)
+    t, ot = dpa.Transcript(b"test"), oracle.transcript(b"test")
+    proof = pcs.open(c, point, ev, t)
+    exp = oracle.pcs_open(maxsize, w, ext, point, ot)
+    assert proof.size == exp.size and (proof == exp).all()
+    assert t.read_challenge() == ot.read_challenge()
+    dpa.Basefold.verify(maxsize, c.root, nv, not ext, point, ev, proof, dpa.Transcript(b"test"))
+    with pytest.raises(dpa.DeepProveError):
+        dpa.Basefold.verify(maxsize, c.root, nv, not ext, point, ((ev[0] + 1) % P, ev[1]), proof, dpa.Transcript(b"test"))
+    bad = proof.copy()
+    bad[-5] ^= np.uint64(1)
+    with pytest.raises(dpa.DeepProveError):
+        dpa.Basefold.verify(maxsize, c.root, nv, not ext, point, ev, bad, dpa.Transcript(b"test"))
+
+
 @pytest.mark.parametrize("shape", [[(10, False)], [(12, False), (10, False), (12, True), (9, False)], [(8, False), (8, True), (14, False), (11, True), (14, False)]])
 def test_pcs_batch_open_and_verify(dev, oracle, shape):
     import deep_prove_amd as dpa

@@ -132,3 +132,15 @@ def test_in_library_sharded_sumcheck_matches_unsharded_oracle(hostlogic_bin, see
     r = run(hostlogic_bin, "sharded", seed, nv, world)
     assert r.returncode == 0, r.stdout + r.stderr
     assert f"{world} of {world} ranks identical" in r.stdout
+
+
+@pytest.mark.parametrize("seed,nv,ext", [(1, 8, 0), (2, 9, 1), (3, 10, 0), (4, 12, 1), (5, 13, 0)])
+def test_single_polynomial_open_matches_oracle_and_verifies(hostlogic_bin, seed, nv, ext):
+    """PCS::open / PCS::verify of ONE polynomial above the trivial size (mpcs/src/basefold.rs:466-544, 863-962; the reference's
+    commit_open_verify round trip, mpcs/src/lib.rs:467-540, base and extension): the product's pcs_open over the CPU double gives
+    the oracle's stream (root, messages, roots, final message, 200 queries with paths) and leaves the transcript in the oracle's
+    state; the product's pcs_verify accepts it with its transcript in the same state, and rejects a wrong evaluation, a foreign
+    root, other PCS parameters and four flipped words"""
+    r = run(hostlogic_bin, "open", seed, nv, ext)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical to the oracle" in r.stdout and "accepted 1 of 1, rejected 7 of 7" in r.stdout

@@ -55,3 +55,14 @@ def test_whole_model_proofs_with_every_logup_proof_from_the_emulated_kernel():
         if "DP_EMUL_COMMIT_MAX_N" in env:  # several rounds in one launch: FRI folds, messages and Merkle trees, not only the final round
             assert int(r.stdout.split("commit-phase tails taken (")[1].split()[0]) >= 4, r.stdout
         assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
+
+
+def test_single_polynomial_open_with_the_emulated_commit_tail():
+    """PCS::open of one polynomial (mpcs/src/basefold.rs:466-544) with the last commit rounds served by the device source of
+    k_commit_tail on the emulator (only the final round, and three / four rounds in one launch): stream, root and transcript
+    state equal the oracle's single-polynomial commit phase + query phase"""
+    for args, env, rounds in ((("open", 3, 9, 0), {}, 1), (("open", 5, 11, 0), {"DP_EMUL_COMMIT_MAX_N": "4096"}, 3), (("open", 7, 12, 1), {"DP_EMUL_COMMIT_MAX_N": "4096", "DP_EMUL_THREADS": "256"}, 4)):
+        r = _model(args, env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "identical to the oracle" in r.stdout and "accepted 1 of 1, rejected 7 of 7" in r.stdout
+        assert f"1 commit-phase tails taken ({rounds} rounds)" in r.stdout, r.stdout

@@ -171,6 +171,41 @@ def test_basefold_batch_verify_port_of_reference_round_trips(oracle, shape):
         dpa.Basefold.batch_verify(maxsize * 4, roots, nvs, is_base, points, evals, proof, dpa.Transcript(b"test"))
 
 
+@pytest.mark.parametrize("nv,ext", [(6, False), (7, True), (8, False), (10, True), (12, False)])
+def test_basefold_single_verify_port_of_reference_round_trip(oracle, nv, ext):
+    """mpcs commit -> open -> verify of one polynomial (mpcs/src/lib.rs:467-540 run_commit_open_verify, base and extension; <= 7
+    variables: the trivial proof): the oracle commits and opens, dp_pcs_verify checks — same transcript state afterwards — and
+    rejects a tampered proof, a wrong evaluation, a wrong root, a wrong point and other parameters"""
+    import deep_prove_amd as dpa
+    rng = np.random.default_rng(4100 + nv)
+    maxsize = 1 << 13
+    w = rng.integers(0, P, size=(2 if ext else 1) << nv, dtype=np.uint64)
+    point = [_rand_ext(rng) for _ in range(nv)]
+    ev = oracle.mle_eval(w, ext, point)
+    root = oracle.pcs_commit_root(maxsize, w, ext)
+    ot = oracle.transcript(b"test")
+    proof = oracle.pcs_open(maxsize, w, ext, point, ot)
+    t = dpa.Transcript(b"test")
+    dpa.Basefold.verify(maxsize, root, nv, not ext, point, ev, proof, t)
+    assert t.read_challenge() == ot.read_challenge()
+    def rejected(**kw):
+        a = dict(max_poly_size=maxsize, root=root, num_vars=nv, is_base=not ext, point=point, eval_=ev, proof_words=proof, transcript=dpa.Transcript(b"test"))
+        a.update(kw)
+        with pytest.raises(dpa.DeepProveError):
+            dpa.Basefold.verify(**a)
+    rejected(eval_=((ev[0] + 1) % P, ev[1]))
+    rejected(root=[root[0], root[1] ^ 1, root[2], root[3]])
+    rejected(point=[((point[0][0] + 1) % P, point[0][1])] + point[1:])
+    bad = proof.copy(); bad[-5] ^= np.uint64(1)  # trivial: an evaluation; otherwise a sibling digest of the last query's path
+    rejected(proof_words=bad)
+    rejected(proof_words=proof[:-2])
+    if nv > 7:
+        rejected(max_poly_size=maxsize * 2)  # the coset shift of the code depends on the parameters (rs.rs:494-499)
+        bad = proof.copy(); bad[4] ^= np.uint64(1)  # the first commit-phase message
+        rejected(proof_words=bad)
+        rejected(is_base=ext)
+
+
 def test_batch_verifier_host_only_accepts_and_rejects_per_proof():
     """dp_verify_batch without a device (ctx NULL): protocol checks on host threads with the Merkle paths deferred and then
     authenticated on the same threads — a verdict per proof: the golden proofs are accepted; a flipped word inside a layer

@@ -8,6 +8,11 @@ import json, os, subprocess, sys, time
 CONFIGS = [  # (name, proofs in flight, env) — in order of importance: the sweep stops when its time budget is spent
     ("base_192", 192, {}),
     ("base_256", 256, {}),
+    # more proofs in flight (the twiddle tables are shared since round 2: 600 MB per proof in flight)
+    ("c16_384", 384, {"DP_COHORT": "16"}),
+    ("c22_512", 512, {"DP_COHORT": "22"}),
+    ("c14_320", 320, {"DP_COHORT": "14"}),
+    ("c12_384", 384, {"DP_COHORT": "12", "GPU_MAX_HW_QUEUES": "32"}),
     # round 2: one-workgroup kernels shared (256 threads, no CU reservation, raised wave priority) vs whole-CU workgroups
     ("excl_192", 192, {"DP_SHARED_TAILS": "0"}),
     ("cohort8_256", 256, {"DP_COHORT": "8"}),
@@ -138,7 +143,7 @@ def main():
             break
         e = dict(os.environ); e.update(env)
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", wl, str(conc)], env=e, capture_output=True, text=True, timeout=90)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", wl, str(conc)], env=e, capture_output=True, text=True, timeout=int(os.environ.get('KNOB_TIMEOUT', '90')))
             line = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
             rec = json.loads(line) if line.startswith("{") else {"error": (r.stderr or r.stdout)[-400:]}
         except subprocess.TimeoutExpired:
