@@ -215,7 +215,7 @@ struct RcclApi {
 };
 // librccl is looked up at run time: a process that already holds an RCCL (PyTorch bundles one under the same soname) keeps
 // using that copy, and a host that never shards a sumcheck never loads it
-RcclApi& rccl() {
+RcclApi* rccl() {  // (a pointer: the definition sits inside the extern "C" block of the ABI)
   static RcclApi api;
   static std::once_flag once;
   std::call_once(once, [] {
@@ -228,9 +228,9 @@ RcclApi& rccl() {
     api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
   });
   DP_REQUIRE(api.lib && api.GetUniqueId && api.CommInitRank && api.AllGather && api.CommDestroy, DP_ERR_HIP, "librccl.so could not be loaded (sharded sumcheck over RCCL)");
-  return api;
+  return &api;
 }
-#define RCCL_CHECK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) throw DpError(DP_ERR_HIP, std::string("RCCL: ") + (rccl().GetErrorString ? rccl().GetErrorString(r_) : "error")); } while (0)
+#define RCCL_CHECK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) throw DpError(DP_ERR_HIP, std::string("RCCL: ") + (rccl()->GetErrorString ? rccl()->GetErrorString(r_) : "error")); } while (0)
 #define HIPRT_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw DpError(DP_ERR_HIP, std::string("HIP: ") + hipGetErrorString(e_)); } while (0)
 }  // namespace
 // one rank's communicator: device send / receive buffers the all-gather runs on, pinned host mirrors, its own stream
@@ -253,16 +253,16 @@ struct dp_dist : Exchange {
     reserve(nwords);
     memcpy(hsend, send, nwords * 8);
     HIPRT_CHECK(hipMemcpyAsync(dsend, hsend, nwords * 8, hipMemcpyHostToDevice, stream));
-    RCCL_CHECK(rccl().AllGather(dsend, drecv, nwords, ncclUint64, comm, stream));
+    RCCL_CHECK(rccl()->AllGather(dsend, drecv, nwords, ncclUint64, comm, stream));
     HIPRT_CHECK(hipMemcpyAsync(hrecv, drecv, nwords * 8 * world_, hipMemcpyDeviceToHost, stream));
     HIPRT_CHECK(hipStreamSynchronize(stream));
     memcpy(out, hrecv, nwords * 8 * world_);
   }
-  ~dp_dist() override { release(); if (comm) rccl().CommDestroy(comm); if (stream) hipStreamDestroy(stream); }
+  ~dp_dist() override { release(); if (comm) rccl()->CommDestroy(comm); if (stream) hipStreamDestroy(stream); }
 };
 extern "C" {
 int32_t dp_dist_unique_id(uint8_t id[128]) {
-  return guard([&] { DP_REQUIRE(id, DP_ERR_ARG, "null id"); static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId"); ncclUniqueId u; RCCL_CHECK(rccl().GetUniqueId(&u)); memcpy(id, &u, 128); });
+  return guard([&] { DP_REQUIRE(id, DP_ERR_ARG, "null id"); static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId"); ncclUniqueId u; RCCL_CHECK(rccl()->GetUniqueId(&u)); memcpy(id, &u, 128); });
 }
 int32_t dp_dist_init(dp_ctx* ctx, const uint8_t id[128], int32_t rank, int32_t world, dp_dist** out) {
   return guard([&] {
@@ -272,7 +272,7 @@ int32_t dp_dist_init(dp_ctx* ctx, const uint8_t id[128], int32_t rank, int32_t w
     ctx->dev->bind_thread();
     HIPRT_CHECK(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     ncclUniqueId u; memcpy(&u, id, 128);
-    RCCL_CHECK(rccl().CommInitRank(&d->comm, world, u, rank));
+    RCCL_CHECK(rccl()->CommInitRank(&d->comm, world, u, rank));
     *out = d.release();
   });
 }
@@ -673,7 +673,10 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
       size_t f = 0, p = 0; for (size_t c = 0; c < nco; c++) { size_t a, b; hip_cohort_stats(m->cohorts[c], &a, &b); f += a; p += b; }
       fprintf(stderr, "[dp timing] %zu cohorts of <= %zu proofs: %zu merged launches for %zu proof launches\n", nco, csize, f, p);
     }
-    if (getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) fprintf(stderr, "[dp timing] prove_batch: %zu proofs, %zu in flight on %zu host threads, arena peak %.1f MB\n", nproofs, nw, nth, hip_dev_arena_peak(m->ctx->dev) / 1048576.0);
+    if (getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) {
+      size_t wpeak = 0; for (auto& w : m->workers) wpeak = std::max(wpeak, hip_dev_arena_peak(w.get()));
+      fprintf(stderr, "[dp timing] prove_batch: %zu proofs, %zu in flight on %zu host threads, arena peak %.1f MB (context), %.1f MB (largest of the workers, arena %.1f MB each)\n", nproofs, nw, nth, hip_dev_arena_peak(m->ctx->dev) / 1048576.0, wpeak / 1048576.0, arena / 1048576.0);
+    }
     if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     hip_dev_dump_sc_debug(m->ctx->dev); hip_dev_dump_host_stats(m->ctx->dev);
     for (size_t wi = 1; wi < nw && wi < 3; wi++) { hip_dev_dump_sc_debug(m->workers[wi - 1].get()); hip_dev_dump_host_stats(m->workers[wi - 1].get()); }

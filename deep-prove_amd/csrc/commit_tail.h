@@ -2,6 +2,7 @@
 // (Dev::commit_tail). Shared with the kernel-emulation test.
 #pragma once
 #include "dev.h"
+#include <cstdlib>
 #include <cstring>
 
 namespace dp {
@@ -9,6 +10,16 @@ namespace dp {
 constexpr int CMT_MAXR = 8;                     // rounds one launch runs
 constexpr int CMT_MAXM = 64;                    // committed codewords merged into the oracle of one round
 constexpr size_t COMMIT_TAIL_MAX_N = 4096;      // the tail takes over when the previous round's folded oracle is at most this long
+// Every round the tail takes saves the ~11 launches and 2 host round trips of a round driven from the host (fold, pair fold, message,
+// reduction, leaves, Merkle layers, Merkle tail) at the price of ONE workgroup doing the work: a single proof (1024 threads, the GPU
+// otherwise idle) is fastest with 4096; with hundreds of proofs in flight the throughput is the same from 4096 to 65536
+// (profiles/r02_ctail_inflight_sweep.jsonl), so throughput mode takes over at 16384 and spends 22 launches less per proof.
+// DP_COMMIT_TAIL_MAX_N overrides both.
+constexpr size_t COMMIT_TAIL_MAX_N_THROUGHPUT = 16384;
+inline size_t commit_tail_max_n(bool throughput_mode) {
+  static const size_t env = [] { const char* e = getenv("DP_COMMIT_TAIL_MAX_N"); size_t x = e ? (size_t)strtoull(e, nullptr, 10) : 0; return x < 2 ? size_t(0) : x; }();
+  return env ? env : throughput_mode ? COMMIT_TAIL_MAX_N_THROUGHPUT : COMMIT_TAIL_MAX_N;
+}
 
 struct CommitTailDesc {
   Ext last[3];
@@ -24,10 +35,10 @@ struct CommitTailDesc {
   u64 lab[2];                                       // "commit round"
 };
 
-inline bool commit_tail_accepts(const Dev::CommitTailArgs& a) {
+inline bool commit_tail_accepts(const Dev::CommitTailArgs& a, size_t max_n = COMMIT_TAIL_MAX_N) {
   if (a.rounds_left < 1 || a.rounds_left > (unsigned)CMT_MAXR || a.merges->size() != a.rounds_left) return false;
   const size_t n = a.folded.n, m = a.sum_evals.n;
-  if (a.folded.null() || !a.folded.ext || n > COMMIT_TAIL_MAX_N || (n & (n - 1)) || (n >> a.rounds_left) < 2) return false;
+  if (a.folded.null() || !a.folded.ext || n > max_n || (n & (n - 1)) || (n >> a.rounds_left) < 2) return false;
   if (a.eq.null() || a.sum_evals.null() || !a.eq.ext || !a.sum_evals.ext || a.eq.n != m || (m & (m - 1)) || (m >> a.rounds_left) < 1) return false;
   for (unsigned j = 0; j < a.rounds_left; j++) {
     if ((*a.merges)[j].size() > (size_t)CMT_MAXM) return false;

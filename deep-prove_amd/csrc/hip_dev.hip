@@ -25,6 +25,7 @@
 #include <deque>
 #include <type_traits>
 #include <chrono>
+#include <map>
 #include <vector>
 #include <string>
 
@@ -2441,6 +2442,21 @@ struct Cohort {
   std::deque<std::pair<size_t, size_t>> inflight;      // (launch number, ring_begin) of fired launches not known to have run
   size_t executed = 0;                                 // every launch number < executed has run to completion
   size_t nfired = 0, npacks = 0;
+  // DP_TIMING: where a cohort's wall time goes — "device phase" = from a fire to the first member that sees a result afterwards,
+  // "host phase" = from that wake-up to the next fire (the members digest the result one after the other on the cohort's
+  // thread; nothing of this cohort is queued on the GPU meanwhile)
+  std::chrono::steady_clock::time_point t_fire_{}, t_wake_{}; bool awake_ = false, have_fire_ = false;
+  double dev_phase_us = 0, host_phase_us = 0; size_t nwakes = 0;
+  void note_wake() {
+    if (awake_ || !have_fire_) return;
+    awake_ = true; t_wake_ = std::chrono::steady_clock::now(); nwakes++;
+    dev_phase_us += std::chrono::duration<double, std::micro>(t_wake_ - t_fire_).count();
+  }
+  void note_fire() {
+    auto t = std::chrono::steady_clock::now();
+    if (awake_) { host_phase_us += std::chrono::duration<double, std::micro>(t - t_wake_).count(); awake_ = false; }
+    t_fire_ = t; have_fire_ = true;
+  }
 
   // DP_COHORT_XCD=1 (experiment, default off): the cohort's stream is confined to ONE XCD (32 CUs, its own L2) with a CU
   // mask, cohorts dealt round robin over the 8 XCDs — every kernel of a proof then runs under one coherent L2 and cohorts on
@@ -2499,6 +2515,7 @@ struct Cohort {
       Pending& p = q.front();
       if (p.count > 0) {
         std::atomic_thread_fence(std::memory_order_release);
+        if (g_host_stats) note_fire();
         p.fire(p, s);
         inflight.push_back({q_base, p.ring_begin});
         nfired++;
@@ -2541,7 +2558,9 @@ class HipDev : public Dev {
     if (!g_host_stats) return;
     last_exit_ = std::chrono::steady_clock::now(); have_exit_ = true;
     waitlat_us_ += std::chrono::duration<double, std::micro>(last_exit_ - t0).count();
+    if (co_) co_->note_wake();
   }
+  std::map<const char*, size_t> by_name_;  // (keys: the string literals of the launch macros)
   struct LaunchTimer {
     HipDev* d; std::chrono::steady_clock::time_point t0;
     explicit LaunchTimer(HipDev* d_) : d(d_) { if (g_host_stats) t0 = std::chrono::steady_clock::now(); }
@@ -2570,7 +2589,7 @@ class HipDev : public Dev {
   template <auto Body, int MAXT, int FLAGS, class... A, class... P>
   void launch_(KArgs<void (*)(A...)>, const char* name, dim3 g, dim3 b, size_t lds, P... args) {
     static_assert(sizeof...(A) == sizeof...(P), "kernel argument count");
-    if (g_host_stats) { if (!first_launch_) first_launch_ = name; last_launch_ = name; }
+    if (g_host_stats) { if (!first_launch_) first_launch_ = name; last_launch_ = name; by_name_[name]++; }
     if (!co_) { hipLaunchKernelGGL((kg<Body, MAXT, FLAGS, std::decay_t<A>...>), g, b, lds, s_, static_cast<std::decay_t<A>>(args)...); return; }
     DP_REQUIRE(g.z == 1, DP_ERR_SHAPE, "cohort launches use blockIdx.z for the proof");
     using Pack = ArgPack<std::decay_t<A>...>;
@@ -2908,6 +2927,12 @@ class HipDev : public Dev {
   void dump_host_stats() {
     if (!g_host_stats) return;
     fprintf(stderr, "[dp timing] device context: %zu launches, %.1f us of host time per launch (%.1f ms total), %zu device waits, %zu fiber yields; host work between waits %.1f ms, inside waits %.1f ms\n", nlaunch_, nlaunch_ ? launch_us_ / nlaunch_ : 0.0, launch_us_ / 1000.0, nwait_, nyield_, work_us_ / 1000.0, waitlat_us_ / 1000.0);
+    if (getenv("DP_LAUNCH_NAMES")) {  // launches by kernel since the last dump (DP_TIMING=1 DP_LAUNCH_NAMES=1)
+      std::vector<std::pair<size_t, const char*>> v; for (auto& kv : by_name_) v.push_back({kv.second, kv.first});
+      std::sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.first > b.first; });
+      for (auto& e : v) fprintf(stderr, "[dp launches] %6zu  %s\n", e.first, e.second);
+    }
+    by_name_.clear();
     if (getenv("DP_HOST_CHUNKS")) for (auto& c : chunks_) fprintf(stderr, "[dp chunk] before wait %zu: %.0f us of host work, launches %s .. %s\n", c.wait, c.us, c.first ? c.first : "-", c.last ? c.last : "-");
     chunks_.clear();
     launch_us_ = 0; nlaunch_ = nwait_ = nyield_ = 0; work_us_ = waitlat_us_ = 0; have_exit_ = false;
@@ -2968,6 +2993,7 @@ class HipDev : public Dev {
       if (stage_off_ + need > ASYNC_STAGE) { stream_wait(); stage_off_ = 0; }
       char* slot = bulk_stage() + stage_off_;
       memcpy(slot, src, bytes);
+      if (g_host_stats) by_name_["  (k_copy_words as upload)"]++;
       if (co_) { nb_ = 0; DPL(k_copy_words, dim3(grid_for(bytes / 8, 256)), dim3(TPB), (u64*)dst, (const u64*)(hstage_dev_ + DESC_BYTES + stage_off_), bytes / 8); }
       else { nb_ = 0; prof_begin("memcpy_h2d"); HIP_CHECK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, s_)); prof_end(); }
       stage_off_ += need;
@@ -2988,6 +3014,7 @@ class HipDev : public Dev {
     // (pending upload slots are read by copy kernels that precede this download's copy in the stream: no drain needed)
     for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
       size_t m = std::min(STAGE_BYTES, bytes - off);
+      if (g_host_stats) by_name_["  (k_copy_words as download)"]++;
       if (co_) {
         DP_REQUIRE(m % 8 == 0, DP_ERR_ARG, "copies are whole words");
         nb_ = 0; DPL(k_copy_words, dim3(grid_for(m / 8, 256)), dim3(TPB), (u64*)(hstage_dev_ + DESC_BYTES), (const u64*)((const char*)src + off), m / 8);
@@ -3247,7 +3274,7 @@ class HipDev : public Dev {
   bool devcommit_ = knob("DP_DEVICE_COMMIT", 1) != 0;
   bool commit_tail(const CommitTailArgs& a, Challenger& ch, CommitTailOut& out) override {
     if (!devcommit_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_ || !tw_) return false;
-    if (!commit_tail_accepts(a) || dp_ceil_log2(a.folded.n) - 1 > L_) return false;
+    if (!commit_tail_accepts(a, commit_tail_max_n(throughput_mode_)) || dp_ceil_log2(a.folded.n) - 1 > L_) return false;
     const std::vector<size_t> blocks = commit_tail_blocks(a);
     if (blocks[0] + blocks[1] > RES_WORDS) return false;
     const CommitTailDesc* dd = nullptr;
@@ -3988,7 +4015,12 @@ Dev* make_hip_worker(int device, size_t arena_bytes) { return new HipDev(device,
 Cohort* hip_cohort_new() { const char* e = getenv("DP_COHORT_RING_BYTES"); return e ? new Cohort(strtoull(e, nullptr, 10)) : new Cohort(); }
 void hip_cohort_free(Cohort* c) { delete c; }
 void hip_cohort_drain(Cohort* c) { c->drain(); }
-void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs) { *fired = c->nfired; *packs = c->npacks; c->nfired = c->npacks = 0; }
+void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs) {
+  *fired = c->nfired; *packs = c->npacks; c->nfired = c->npacks = 0;
+  if (g_host_stats && c->nwakes) fprintf(stderr, "[dp timing] cohort: %zu wake-ups; device phases (fire -> first member sees a result) %.1f ms, host phases (wake-up -> next fire) %.1f ms = %.1f us each\n",
+                                        c->nwakes, c->dev_phase_us / 1000.0, c->host_phase_us / 1000.0, c->host_phase_us / c->nwakes);
+  c->dev_phase_us = c->host_phase_us = 0; c->nwakes = 0; c->awake_ = false; c->have_fire_ = false;
+}
 void hip_dev_cohort_attach(Dev* d, Cohort* c) { static_cast<HipDev*>(d)->cohort_attach(c); }
 void hip_dev_cohort_detach(Dev* d) { static_cast<HipDev*>(d)->cohort_detach(); }
 void hip_dev_dump_sc_debug(Dev* d) { static_cast<HipDev*>(d)->dump_sc_debug(); }

@@ -41,7 +41,7 @@ struct EmulDev : CpuDev {
   size_t commit_taken = 0, commit_max_n = 512, commit_rounds_run = 0, commit_merged = 0;
   std::vector<u64> tw_;  // tw[i] = w_{2^(L+1)}^i, i < 2^L, L = the RS parameter size of this context (what HipDev::pcs_init builds on the device)
   bool commit_tail(const CommitTailArgs& a, Challenger& ch, CommitTailOut& out) override {
-    if (!commit || !commit_tail_accepts(a) || a.folded.n > commit_max_n) return false;  // (emulation speed; the device takes oracles up to COMMIT_TAIL_MAX_N)
+    if (!commit || !commit_tail_accepts(a, commit_max_n)) return false;  // (512 by default for emulation speed; the device takes oracles up to COMMIT_TAIL_MAX_N, 16384 in throughput mode)
     const unsigned L = full_log_;
     if (tw_.size() != (size_t(1) << L)) {
       u64 w = GL_G32;

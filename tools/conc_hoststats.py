@@ -7,7 +7,8 @@ import numpy as np
 import deep_prove_amd as dpa
 conc = int(sys.argv[1])
 dev = dpa.Device(0); mb = dpa.models.dense_4m(); ctx = dpa.Context.generate(dev, mb.blob()); pr = dpa.Prover(ctx)
-xs = np.stack([mb.input(3000 + i) for i in range(2 * conc)])
+xs = np.stack([mb.input(3000 + i) for i in range(4 * conc)])
+pr.prove(xs[0])  # the arena of a worker follows the footprint of a proof already proved
 pr.prove_batch(xs[:conc], conc)
 c0 = time.process_time(); t0 = time.perf_counter(); pr.prove_batch(xs, conc); dt = time.perf_counter() - t0; cpu = time.process_time() - c0
 print(f"conc={conc} {len(xs)/dt:.1f} proofs/s; process CPU {cpu:.2f} s over {dt:.2f} s wall = {cpu/dt:.1f} cores busy (polling included), {1000*cpu/len(xs):.2f} CPU-ms per proof", file=sys.stderr)

@@ -9,6 +9,16 @@ CONFIGS = [  # (name, proofs in flight, env) — in order of importance: the swe
     ("base_192", 192, {}),
     ("base_256", 256, {}),
     # more proofs in flight (the twiddle tables are shared since round 2: 600 MB per proof in flight)
+    # the fused commit tail taking over earlier (default: folded oracle <= 4096)
+    ("ctail16k_256", 256, {"DP_COMMIT_TAIL_MAX_N": "16384"}),
+    ("ctail64k_256", 256, {"DP_COMMIT_TAIL_MAX_N": "65536"}),
+    ("ctail8k_256", 256, {"DP_COMMIT_TAIL_MAX_N": "8192"}),
+    ("ctail32k_256", 256, {"DP_COMMIT_TAIL_MAX_N": "32768"}),
+    ("c20_480_arena480", 480, {"DP_COHORT": "20", "DP_WORKER_ARENA_BYTES": str(480 << 20)}),
+    ("cohort0_256", 256, {"DP_COHORT": "0"}),   # every proof on its own stream (round 1's scheme) with round 2's fused tails
+    ("cohort4_256", 256, {"DP_COHORT": "4"}),
+    ("cohort6_256", 256, {"DP_COHORT": "6"}),
+    ("cohort6_256_q32", 256, {"DP_COHORT": "6", "GPU_MAX_HW_QUEUES": "32"}),
     ("c16_384", 384, {"DP_COHORT": "16"}),
     ("c22_512", 512, {"DP_COHORT": "22"}),
     ("c14_320", 320, {"DP_COHORT": "14"}),

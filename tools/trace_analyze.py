@@ -88,6 +88,33 @@ def main():
     print("duration of the SMALL kernels (publish, copy_words, fold, ...) by the number of kernels active on all queues when they start:")
     for k in sorted(by):
         print(f"   ~{k:2d} active: n = {len(by[k]):5d}  median {statistics.median(by[k]):8.1f} us")
+    # --- what slows the one-workgroup protocol kernels down under load? Their duration against the number of WIDE kernels
+    # (>= 512 workgroups) running meanwhile (16 samples inside every instance), with the solo duration (kg:*, the single proof
+    # of the bench's latency measurement) for reference
+    wg_total = lambda r: max(1, r[3] // max(1, r[6])) * r[4] * r[5]  # noqa: E731
+    wide = [r for r in rows if wg_total(r) >= 512]
+    ws = np.array(sorted(r[1] for r in wide)); we = np.array(sorted(r[2] for r in wide))
+    tails = [r for r in half if any(t in short(r[0]) for t in ("_tail", "sc_persist"))]
+    solo = collections.defaultdict(list)
+    for r in rows:
+        if short(r[0]).startswith("kg:") and any(t in short(r[0]) for t in ("_tail", "sc_persist")):
+            solo[short(r[0])[3:]].append((r[2] - r[1]) / 1e3)
+    tab = collections.defaultdict(lambda: collections.defaultdict(list))
+    edges = (0.05, 0.5, 1.5, 3.0)
+    for r in tails:
+        ts = np.linspace(r[1], r[2], 18)[1:-1]
+        act = float(np.mean(np.searchsorted(ws, ts, "right") - np.searchsorted(we, ts, "right")))
+        b = sum(act > e for e in edges)
+        tab[short(r[0])[3:]][b].append((r[2] - r[1]) / 1e3)
+    print("one-workgroup kernels: median duration (us) by the average number of wide kernels (>= 512 workgroups) running meanwhile")
+    print("   %-28s %9s | %14s %14s %14s %14s %14s" % ("kernel", "solo", "none", "<0.5", "0.5-1.5", "1.5-3", ">3"))
+    for k in sorted(tab, key=lambda k: -sum(sum(v) for v in tab[k].values())):
+        cells = []
+        for b in range(5):
+            v = tab[k].get(b, [])
+            cells.append("%8.0f (%4d)" % (statistics.median(v), len(v)) if v else "       - (   0)")
+        sv = solo.get(k, [])
+        print("   %-28s %9s | %s" % (k[:28], "%.0f" % statistics.median(sv) if sv else "-", " ".join(cells)))
     if "--sequence" in sys.argv:
         q = kc[-1][7]
         seq = [r for r in kc if r[7] == q]
