@@ -51,7 +51,7 @@ def test_cohorts_match_sequential_cnn(dev):
 
 def test_in_flight_is_a_cap_and_arenas_follow_the_model(dev, monkeypatch):
     """worker arenas are sized from the footprint of the model's earlier proofs (no 1.5 GB default per worker), so a small
-    model can keep the API's maximum of 256 proofs in flight; `concurrency` beyond the API limit is an argument error"""
+    model can keep hundreds of proofs in flight (the API's maximum is 1 024); `concurrency` beyond the API limit is an argument error"""
     import deep_prove_amd as dpa
     monkeypatch.delenv("DP_WORKER_ARENA_BYTES", raising=False)
     mb = dpa.models.mlp(2, 16, config=44)
@@ -64,5 +64,5 @@ def test_in_flight_is_a_cap_and_arenas_follow_the_model(dev, monkeypatch):
     assert pr.in_flight() == 64
     assert (proofs[0] == first[0]).all()
     with pytest.raises(dpa.DeepProveError):
-        pr.prove_batch(xs, 257)
+        pr.prove_batch(xs, 1025)
     ctx.free()
