@@ -321,7 +321,7 @@ def main():
                                                "every rank commits the model itself (Context::generate recomputed per rank, outside the timed region), no data-path collective") if args.batch else None,
                        "single_proof_latency_ms": round(main_w["latency_ms"], 2), "single_proof_latency_samples_ms": main_w["latency_samples_ms"], "first_proof_ms": round(main_w["first_ms"], 2),
                        "host_cpu_budget": budget, "host_threads_per_rank": int(os.environ["DP_HOST_THREADS"]),
-                       "parallelism": f"replicas x{world} GPUs x {main_w['in_flight']} proofs in flight per GPU in lock-step cohorts of {os.environ.get('DP_COHORT', '12')} (independent proofs, no data-path collective)",
+                       "parallelism": f"replicas x{world} GPUs x {main_w['in_flight']} proofs in flight per GPU in lock-step cohorts of {os.environ.get('DP_COHORT') or -(-main_w['in_flight'] // 22)} (independent proofs, no data-path collective)",
                        "proof_words": main_w["proof_words"], "setup_s": round(main_w["setup_s"], 2), "verified": True, "golden_sha256_ok": main_w["golden_ok"], "verified_proofs_of_last_step": main_w["verified"], "verify_ms_per_proof": main_w["verify_ms"], "verify_batch_ms_per_proof": main_w["verify_batch_ms_per_proof"],
                        "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DP_") or k == "GPU_MAX_HW_QUEUES"}, "device": dev.name},
             "roofline": roofline, "cpu_baseline": cpu, "cnn_264k": cnn, "sumcheck24": sc24, "sumcheck24_sharded": None,

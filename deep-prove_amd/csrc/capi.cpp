@@ -609,11 +609,14 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     // several proofs in flight: throughput mode on every context (see hip_dev_set_latency_mode)
     hip_dev_set_latency_mode(m->ctx->dev, nw == 1);
     for (auto& w : m->workers) hip_dev_set_latency_mode(w.get(), nw == 1);
-    // Cohorts (hip_dev.hip, struct Cohort): the proofs in flight are grouped into cohorts of DP_COHORT members (default 8)
+    // Cohorts (hip_dev.hip, struct Cohort): the proofs in flight are grouped into cohorts of DP_COHORT members (default: in flight / 22, rounded up)
     // that prove in lock step — launch number i of all members of a cohort is ONE kernel launch — on one stream and one
     // host thread per cohort. DP_COHORT=0: every proof on its own stream (the round-1 scheme).
     const char* ce = getenv("DP_COHORT");
-    size_t csize = ce ? (size_t)std::max(0, atoi(ce)) : 12;  // 256 in flight = 22 cohorts: one hardware queue each (24 are served without time slicing)
+    // Default: as many cohorts as hardware queues serve without time slicing (22 of the 24), each as small as that allows — a merged
+    // launch ends with its slowest member, so small cohorts stall less (batch of 8: 121 ms with cohorts of 1, 165 ms with one cohort
+    // of 8; batch of 64: 262 ms with cohorts of 3, 302 ms with 12; 256 in flight: cohorts of 12; profiles/r02_batch_cohort_sweep.txt)
+    size_t csize = ce ? (size_t)std::max(0, atoi(ce)) : std::max<size_t>(1, (nw + 21) / 22);
     size_t nco = (csize >= 1 && nw > 1) ? (nw + csize - 1) / csize : 0;
     while (m->cohorts.size() < nco) m->cohorts.push_back(hip_cohort_new());
     auto dev_of = [&](size_t wi) -> Dev& { return wi == 0 ? *m->ctx->dev : *m->workers[wi - 1]; };
