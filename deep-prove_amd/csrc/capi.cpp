@@ -15,7 +15,7 @@
 #include <thread>
 
 DP_FIBER_SWITCH_ASM
-namespace dp { struct Cohort; Cohort* hip_cohort_new(); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_pcs_share(Dev* worker, Dev* owner); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
+namespace dp { struct Cohort; Cohort* hip_cohort_new(); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_pcs_share(Dev* worker, Dev* owner); void hip_dump_wg_times(); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
 using namespace dp;
 
 // `mu`: PCS::commit is called from rayon workers in the reference (zkml/src/commit/context.rs:79-103 into_par_iter over
@@ -681,7 +681,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
       fprintf(stderr, "[dp timing] prove_batch: %zu proofs, %zu in flight on %zu host threads, arena peak %.1f MB (context), %.1f MB (largest of the workers, arena %.1f MB each)\n", nproofs, nw, nth, hip_dev_arena_peak(m->ctx->dev) / 1048576.0, wpeak / 1048576.0, arena / 1048576.0);
     }
     if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    hip_dev_dump_sc_debug(m->ctx->dev); hip_dev_dump_host_stats(m->ctx->dev);
+    hip_dev_dump_sc_debug(m->ctx->dev); hip_dev_dump_host_stats(m->ctx->dev); hip_dump_wg_times();
     for (size_t wi = 1; wi < nw && wi < 3; wi++) { hip_dev_dump_sc_debug(m->workers[wi - 1].get()); hip_dev_dump_host_stats(m->workers[wi - 1].get()); }
     hip_dev_set_latency_mode(m->ctx->dev, true);
     if (err_code) { for (size_t i = 0; i < nproofs; i++) { dp_free(proof_words[i]); proof_words[i] = nullptr; } throw DpError(err_code, err); }

@@ -83,7 +83,25 @@ template <int FLAGS> __device__ __forceinline__ void kf_prologue() {
   if (FLAGS & KF_PRIO) __builtin_amdgcn_s_setprio(3);
 }
 template <auto Body, int MAXT, int FLAGS, class... A> __global__ void __launch_bounds__(MAXT) kg(A... a) { kf_prologue<FLAGS>(); Body(a...); }
+#ifdef DP_WG_TIMES
+// DIAGNOSTIC BUILD ONLY (DP_HIPCC_EXTRA=-DDP_WG_TIMES, tools/wg_times.py): every workgroup of k_logup_tail records when it entered and
+// left, on which CU, and which merged launch it belonged to (the address of the launch's argument packs) — how much of a merged
+// launch's duration is the spread between its fastest and its slowest member?
+__shared__ unsigned long long s_dbg_launch;
+__device__ unsigned long long g_wgt[4 * 65536];
+__device__ unsigned g_wgt_n;
+__device__ __forceinline__ void dbg_wg_record(unsigned long long t_in) {
+  unsigned i = atomicAdd(&g_wgt_n, 1u);
+  if (i >= 65536) return;
+  unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
+  unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID, 4 bits
+  g_wgt[4 * i] = t_in; g_wgt[4 * i + 1] = dp_realtime(); g_wgt[4 * i + 2] = s_dbg_launch;
+  g_wgt[4 * i + 3] = (unsigned long long)hw | ((unsigned long long)xcc << 32) | ((unsigned long long)blockIdx.z << 40);
+}
+template <auto Body, int MAXT, int FLAGS, class... A> __global__ void __launch_bounds__(MAXT) kc(const ArgPack<A...>* __restrict__ packs) { kf_prologue<FLAGS>(); if (threadIdx.x == 0) s_dbg_launch = (unsigned long long)packs; packs[blockIdx.z].call(Body); }
+#else
 template <auto Body, int MAXT, int FLAGS, class... A> __global__ void __launch_bounds__(MAXT) kc(const ArgPack<A...>* __restrict__ packs) { kf_prologue<FLAGS>(); packs[blockIdx.z].call(Body); }
+#endif
 
 // ------------------------------------------------------------------------------------------------ reductions
 __device__ __forceinline__ u64 shfl_down_u64(u64 v, int d) {
@@ -1325,6 +1343,9 @@ KBODY k_logup_tail(const LogupTailDesc* dp, u64* result, unsigned long long* fla
   __shared__ Ext outs[LT_MAXI * 4];  // full mode: [n0, n1, d0, d1] of every instance
   const int tid = threadIdx.x, nt = blockDim.x;
   const int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
+#ifdef DP_WG_TIMES
+  const unsigned long long dbg_t_in = dp_realtime();
+#endif
   for (int i = tid; i < (int)(sizeof(LogupTailDesc) / 8); i += nt) ((u64*)&dl)[i] = ((const u64*)dp)[i];
   __syncthreads();
   if (tid == 0) {
@@ -1568,6 +1589,9 @@ KBODY k_logup_tail(const LogupTailDesc* dp, u64* result, unsigned long long* fla
     }
     fcs = pub_wave_sum(fcs);
     if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + fcs);
+#ifdef DP_WG_TIMES
+    if (tid == 0) dbg_wg_record(dbg_t_in);
+#endif
   }
 }
 
@@ -4032,6 +4056,48 @@ void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes) { HIP_CHE
 void hip_dev_dump_host_stats(Dev* d) { static_cast<HipDev*>(d)->dump_host_stats(); }
 // latency mode (one proof on the GPU): large sumcheck rounds spread over several workgroups; throughput mode (many proofs
 // in flight): one workgroup per sumcheck — spreading costs more CUs and host polls than it saves when the GPU is shared
+// DIAGNOSTIC BUILD ONLY (DP_WG_TIMES): per merged launch of k_logup_tail, the spread between its members
+void hip_dump_wg_times() {
+#ifdef DP_WG_TIMES
+  unsigned n = 0; if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wgt_n), sizeof(n)) != hipSuccess) return;
+  n = std::min(n, 65536u);
+  std::vector<unsigned long long> w(4 * (size_t)n);
+  if (n && hipMemcpyFromSymbol(w.data(), HIP_SYMBOL(g_wgt), w.size() * 8) != hipSuccess) return;
+  unsigned zero = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_wgt_n), &zero, sizeof(zero));
+  // s_memrealtime ticks at 100 MHz. Packs addresses recur (a ring): a group = records with one address whose entries lie within 50 ms
+  std::map<unsigned long long, std::vector<size_t>> by;
+  for (size_t i = 0; i < n; i++) by[w[4 * i + 2]].push_back(i);
+  double sum_kernel = 0, sum_med = 0, sum_spread_end = 0, sum_skew = 0, sum_minmax = 0; size_t groups = 0, members = 0, samecu = 0;
+  for (auto& kv : by) {
+    auto idx = kv.second;
+    std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return w[4 * a] < w[4 * b]; });
+    size_t s = 0;
+    while (s < idx.size()) {
+      size_t e = s + 1;
+      while (e < idx.size() && w[4 * idx[e]] - w[4 * idx[s]] < 5000000ull) e++;
+      if (e - s >= 2) {
+        unsigned long long t0 = ~0ull, t0max = 0, t1min = ~0ull, t1 = 0; std::vector<double> dur; std::map<unsigned long long, int> cu;
+        for (size_t k = s; k < e; k++) {
+          size_t i = idx[k];
+          t0 = std::min(t0, w[4 * i]); t0max = std::max(t0max, w[4 * i]); t1min = std::min(t1min, w[4 * i + 1]); t1 = std::max(t1, w[4 * i + 1]);
+          dur.push_back((double)(w[4 * i + 1] - w[4 * i]) / 100.0);
+          unsigned long long id = w[4 * i + 3]; unsigned hw = (unsigned)id; unsigned xcc = (unsigned)(id >> 32) & 0xF;
+          cu[((unsigned long long)xcc << 16) | ((hw >> 8) & 0xFF) | (((hw >> 13) & 0x7) << 12)]++;  // (xcc, se/sh, cu)
+        }
+        std::sort(dur.begin(), dur.end());
+        sum_kernel += (double)(t1 - t0) / 100.0; sum_med += dur[dur.size() / 2]; sum_spread_end += (double)(t1 - t1min) / 100.0; sum_skew += (double)(t0max - t0) / 100.0;
+        sum_minmax += dur.back() - dur.front();
+        for (auto& c : cu) if (c.second > 1) samecu += c.second;
+        groups++; members += e - s;
+      }
+      s = e;
+    }
+  }
+  if (groups) fprintf(stderr, "[dp wg-times] k_logup_tail: %zu merged launches, %.1f members each: first entry -> last exit %.0f us; median member %.0f us; slowest - fastest member %.0f us; "
+                              "start skew (last entry - first entry) %.0f us; last exit - first exit %.0f us; %.1f %% of the members shared a CU with another member of their launch\n",
+                      groups, (double)members / groups, sum_kernel / groups, sum_med / groups, sum_minmax / groups, sum_skew / groups, sum_spread_end / groups, 100.0 * samecu / members);
+#endif
+}
 void hip_dev_pcs_share(Dev* worker, Dev* owner) { static_cast<HipDev*>(worker)->pcs_share(*static_cast<HipDev*>(owner)); }
 void hip_dev_set_latency_mode(Dev* d, bool on) { static_cast<HipDev*>(d)->set_latency_mode(on); }
 void hip_dev_profile_enable(Dev* d, bool on) { static_cast<HipDev*>(d)->profile_enable(on); }
