@@ -106,6 +106,18 @@ class Dev {
   virtual void mle_eval_batch(const DBuf* fs, int nf, const Ext* pt, unsigned k, Ext* out) = 0;
   // K2 in one pass: out[c] = sum_r eq(r, pt) * W[r*C + c]      (W base field, R = 2^k rows)
   virtual void fix_high(const DBuf& out, const DBuf& W, size_t R, size_t C, const Ext* pt) = 0;
+  // out[r] = sum_c eq(pt, c) * W[r][c] for a row-major base table W[R][C]: the LOW log2(C) variables of the MLE fixed at pt in one pass
+  // (fix_variables_in_place by a multi-variable point, what MatMul does with its right matrix: matrix_mul.rs:823). Default: one MLE
+  // evaluation per row; devices override it with one pass over the table.
+  virtual void fix_low(const DBuf& out, const DBuf& W, size_t R, size_t C, const Ext* pt) {
+    DP_REQUIRE(!W.ext && W.n == R * C && out.ext && out.n == R && C >= 2 && (C & (C - 1)) == 0, DP_ERR_SHAPE, "fix_low: shapes");
+    std::vector<DBuf> rows(R);
+    for (size_t r = 0; r < R; r++) rows[r] = W.slice(r * C, C);
+    std::vector<Ext> v(R);
+    const size_t step = 256;
+    for (size_t r = 0; r < R; r += step) mle_eval_batch(rows.data() + r, (int)std::min(step, R - r), pt, dp_ceil_log2(C), v.data() + r);
+    upload(out, (const u64*)v.data());
+  }
   // ---- sumcheck (K1 + K3): fold every table with r (if given; tabs[i] is replaced), then per term the sums
   // sum_b prod_j (v_j[2b] + t (v_j[2b+1] - v_j[2b])) for t = 0..k, written consecutively to `out`.
   virtual void sc_round(DBuf* tabs, int ntabs, const Ext* r, const ScTerm* terms, int nterms, Ext* out) = 0;

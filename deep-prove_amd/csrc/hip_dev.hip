@@ -204,6 +204,19 @@ KBODY k_fix_high_partial(const u64* W, const Ext* eq, size_t R, size_t C, size_t
   for (size_t r = r0; r < r1; r++) acc = ex_add(acc, ex_mul_base(eq[r], W[r * C + c]));
   partial[(size_t)blockIdx.y * C + c] = acc;
 }
+// Dev::fix_low: out[r] = sum_c eq[c] * W[r][c] — one wave per row of a row-major base table, lanes stride along the row (coalesced);
+// HBM-bound: the table is read once (8 R C bytes), eq (16 C bytes) stays in cache
+KBODY k_fix_low(const u64* W, const Ext* eq, Ext* out, size_t R, size_t C) {
+  const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  for (size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < R; r += nwaves) {
+    const u64* row = W + r * C;
+    Ext acc = ex_zero();
+    for (size_t c = lane; c < C; c += 64) acc = ex_add(acc, ex_mul_base(eq[c], row[c]));
+    acc = wave_reduce_ext(acc);
+    if (lane == 0) out[r] = acc;
+  }
+}
 KBODY k_colsum(const Ext* partial, size_t nsplit, size_t C, Ext* out) {
   size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -3151,6 +3164,15 @@ class HipDev : public Dev {
     dim3 g((unsigned)((C + TPB - 1) / TPB), (unsigned)nsplit);
     nb_ = 8.0 * R * C + 16.0 * R; DPL(k_fix_high_partial, g, dim3(TPB), (const u64*)W.p, (const Ext*)eq.p, R, C, rps, partial);
     DPL(k_colsum, dim3((unsigned)((C + TPB - 1) / TPB)), dim3(TPB), partial, nsplit, C, (Ext*)out.p);
+    release(mk);  // safe: stream ordered, later allocations are only written by later kernels
+  }
+
+  void fix_low(const DBuf& out, const DBuf& W, size_t R, size_t C, const Ext* pt) override {
+    DP_REQUIRE(!W.ext && W.n == R * C && out.ext && out.n == R && C >= 2 && (C & (C - 1)) == 0, DP_ERR_SHAPE, "fix_low: shapes");
+    size_t mk = mark();
+    DBuf eq = alloc(C, true);
+    eq_table(eq, pt, dp_ceil_log2(C), ex_one(), false);
+    nb_ = 8.0 * R * C + 16.0 * C + 16.0 * R; DPL(k_fix_low, dim3(grid_for(R * 64)), dim3(TPB), (const u64*)W.p, (const Ext*)eq.p, (Ext*)out.p, R, C);
     release(mk);  // safe: stream ordered, later allocations are only written by later kernels
   }
 

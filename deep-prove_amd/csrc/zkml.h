@@ -28,6 +28,8 @@ struct LayerSpec {
   int kind = L_DENSE;
   size_t nrows = 0, ncols = 0;
   std::vector<int64_t> weights, bias;  // dense: row major / padded bias; conv: filter [kw][kx][real_nw][real_nw], bias [kw]
+  // matmul (layers/matrix_mul.rs, MatMul::new_constant: Input x Weight [+ bias]): the constant RIGHT matrix is weights[nrows][ncols] row major,
+  // the input a row-major [s][nrows] matrix (s = its length / nrows), bias [ncols] or empty; the output is [s][ncols]
   // conv (layers/convolution.rs:52-83, tensor.rs:409-431): padded filter count kw, padded input channels kx, padded kernel
   // side real_nw, padded input side nw; unp_out = conv2d_shape of the unpadded tensors (for the garbage-clearing tensor)
   size_t kw = 0, kx = 0, real_nw = 0, nw = 0;
@@ -144,6 +146,7 @@ inline size_t model_output_len(const ModelSpec& m) {
   size_t cur = m.input_len;
   for (const LayerSpec& l : m.layers) {
     if (l.kind == L_DENSE) cur = l.nrows;
+    else if (l.kind == L_MATMUL) cur = cur / l.nrows * l.ncols;
     else if (l.kind == L_CONV) cur = l.kw * l.nw * l.nw;
     else if (l.kind == L_MAXPOOL) cur = l.pin[0] * (l.pin[1] / 2) * (l.pin[2] / 2);
   }
@@ -165,6 +168,16 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
         for (size_t i = 0; i < l.nrows; i++) { int32_t a = 0; const int16_t* w = l.w16->data() + i * l.ncols; for (size_t j = 0; j < l.ncols; j++) a += (int32_t)w[j] * (int32_t)xp[j]; o[i] = (int64_t)a + l.bias[i]; }
       } else
       for (size_t i = 0; i < l.nrows; i++) { int64_t a = 0; const int64_t* w = &l.weights[i * l.ncols]; for (size_t j = 0; j < l.ncols; j++) a += w[j] * cur[j]; o[i] = a + l.bias[i]; }
+    } else if (l.kind == L_MATMUL) {  // MatMul::op (matrix_mul.rs:230-311): [s][k] times the constant [k][n], the bias added to every row
+      const size_t k = l.nrows, n = l.ncols;
+      DP_REQUIRE(k && cur.size() % k == 0, DP_ERR_SHAPE, "matmul input size mismatch");
+      const size_t s_ = cur.size() / k;
+      o.assign(s_ * n, 0);
+      for (size_t i = 0; i < s_; i++) {
+        int64_t* row = &o[i * n];
+        for (size_t q = 0; q < k; q++) { const int64_t x = cur[i * k + q]; const int64_t* w = &l.weights[q * n]; for (size_t j = 0; j < n; j++) row[j] += x * w[j]; }
+        if (!l.bias.empty()) for (size_t j = 0; j < n; j++) row[j] += l.bias[j];
+      }
     } else if (l.kind == L_REQUANT) {
       unsigned sh = l.shift();
       for (int64_t v : cur) {
@@ -223,6 +236,10 @@ inline void validate_model(const ModelSpec& m) {
       DP_REQUIRE(is_pow2(l.nrows) && is_pow2(l.ncols) && l.nrows >= 2 && l.ncols >= 2, DP_ERR_SHAPE, "dense: padded dimensions must be powers of two >= 2");
       DP_REQUIRE(l.ncols == cur && l.weights.size() == l.nrows * l.ncols && l.bias.size() == l.nrows, DP_ERR_SHAPE, "dense: tensor sizes");
       cur = l.nrows;
+    } else if (l.kind == L_MATMUL) {
+      DP_REQUIRE(is_pow2(l.nrows) && is_pow2(l.ncols) && l.nrows >= 2 && l.ncols >= 2, DP_ERR_SHAPE, "matmul: padded dimensions must be powers of two >= 2");
+      DP_REQUIRE(cur % l.nrows == 0 && cur / l.nrows >= 2 && l.weights.size() == l.nrows * l.ncols && (l.bias.empty() || l.bias.size() == l.ncols), DP_ERR_SHAPE, "matmul: tensor sizes (the input is [s][nrows], s >= 2)");
+      cur = cur / l.nrows * l.ncols;
     } else if (l.kind == L_REQUANT) {
       DP_REQUIRE(l.fixed_point_multiplier > 0 && l.shift() % Q_BIT_LEN == 0 && l.shift() >= Q_BIT_LEN && l.shift() < 63, DP_ERR_ARG, "requant: shift must be a positive multiple of BIT_LEN");
       DP_REQUIRE(l.intermediate_bit_size + l.fp_scale <= 63, DP_ERR_ARG, "requant: intermediate_bit_size + fp_scale > 63");
@@ -251,6 +268,7 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
   auto add = [&](TableType t) { for (auto& x : ts) if (x == t) return; ts.push_back(t); };
   for (auto& l : m.layers) {
     if (l.kind == L_DENSE) cur = l.nrows;
+    else if (l.kind == L_MATMUL) cur = cur / l.nrows * l.ncols;
     else if (l.kind == L_REQUANT) { add({2, 0}); add({3, l.clamping_size()}); mpl = std::max(mpl, next_pow2(cur)); }
     else if (l.kind == L_RELU) { add({0, 0}); mpl = std::max(mpl, next_pow2(cur)); }
     else if (l.kind == L_CONV) cur = l.kw * l.nw * l.nw;
@@ -258,13 +276,21 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
   }
   std::sort(ts.begin(), ts.end());
   for (auto& t : ts) mpl = std::max(mpl, size_t(1) << t.vars());
-  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV) mpl = std::max(mpl, std::max(next_pow2(l.weights.size()), next_pow2(l.bias.size())));
+  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL) mpl = std::max(mpl, std::max(next_pow2(l.weights.size()), next_pow2(l.bias.size())));
   mpl = next_pow2(mpl);
   ctx->max_poly_len = mpl; ctx->full_log = dp_ceil_log2(mpl); ctx->tables = ts;
   dev.pcs_init(ctx->full_log);
   for (size_t id = 0; id < m.layers.size(); id++) {
     LayerSpec& l = ctx->model.layers[id];
-    if (l.kind != L_DENSE && l.kind != L_CONV) continue;
+    if (l.kind != L_DENSE && l.kind != L_CONV && l.kind != L_MATMUL) continue;
+    if (l.kind == L_MATMUL) {  // model polys of a MatMul with a constant matrix (matrix_mul.rs:947-963)
+      DBuf w = dev.alloc_persistent(l.weights.size(), false);
+      dev.upload_i64(w, l.weights.data());
+      ctx->model_comms[id]["MatMulWeight"] = dev.commit(w, true);
+      if (!l.bias.empty()) { DBuf b = dev.alloc_persistent(l.bias.size(), false); dev.upload_i64(b, l.bias.data()); ctx->model_comms[id]["MatMulBias"] = dev.commit(b, true); }
+      ctx->weights_dev[id] = w;
+      continue;
+    }
     DBuf w = dev.alloc_persistent(l.weights.size(), false), b = dev.alloc_persistent(l.bias.size(), false);
     dev.upload_i64(w, l.weights.data()); dev.upload_i64(b, l.bias.data());
     if (l.kind == L_DENSE) {
@@ -439,6 +465,41 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
   }
   ps.constant_challenge = ps.t->get_and_append_challenge("table_constant");
   for (auto& kv : counts) ps.challenge_map[kv.first] = kv.first.label() ? ps.t->get_and_append_challenge(kv.first.label()) : ex_one();
+}
+
+// MatMul::prove_step (layers/matrix_mul.rs:701-873), (Input, Weight) arrangement, right matrix not transposed. split_claim (:339-356):
+// the low variables of the output point address the columns (-> right matrix), the high ones the rows (-> left matrix). The bias is
+// evaluated on the column part; left = input with its row variables fixed (Dev::fix_high over the [s][k] activation), right = the
+// constant matrix with its column variables fixed (Dev::fix_low); one degree-2 sumcheck over the inner dimension. full_points
+// (:364-383): the input claim [sumcheck point | row part] goes to the previous layer, the weight claim [column part | sumcheck point]
+// to the batch opening.
+inline Claim prove_matmul(ProverState& ps, size_t id, const LayerSpec& l, const Claim& last, const std::vector<int64_t>& input) {
+  Dev& dev = *ps.dev;
+  const size_t k = l.nrows, n = l.ncols, s_ = input.size() / k;
+  const unsigned nvc = dp_ceil_log2(n), nvr = dp_ceil_log2(s_);
+  DP_REQUIRE(is_pow2(s_) && s_ * k == input.size() && last.point.size() == nvc + nvr, DP_ERR_SHAPE, "matmul: claim point length");
+  size_t mk = dev.mark();
+  const auto& comms = ps.ctx->model_comms.at(id);
+  const bool hb = !l.bias.empty();
+  std::vector<Ext> pt_right(last.point.begin(), last.point.begin() + nvc), pt_left(last.point.begin() + nvc, last.point.end());
+  Ext bias_eval = ex_zero();
+  if (hb) dev.mle_eval_batch(&comms.at("MatMulBias").evals, 1, pt_right.data(), nvc, &bias_eval);
+  DBuf in = dev.alloc(input.size(), false);
+  dev.upload_i64(in, input.data());
+  DBuf left = dev.alloc(k, true), right = dev.alloc(k, true);
+  dev.fix_high(left, in, s_, k, pt_left.data());
+  dev.fix_low(right, ps.ctx->weights_dev.at(id), k, n, pt_right.data());
+  DevVP vp(dp_ceil_log2(k));
+  vp.add_mle_list({left, right}, ex_one());
+  SumcheckOut sc = sumcheck_prove(dev, vp, *ps.t);
+  std::vector<Ext> point_left = sc.proof.point; point_left.insert(point_left.end(), pt_left.begin(), pt_left.end());
+  std::vector<Ext> point_right = pt_right; point_right.insert(point_right.end(), sc.proof.point.begin(), sc.proof.point.end());
+  if (hb) ps.add_witness_claim(comms.at("MatMulBias"), {pt_right, bias_eval});   // BTreeMap order: "MatMulBias" < "MatMulWeight"
+  ps.add_witness_claim(comms.at("MatMulWeight"), {point_right, sc.finals[1]});
+  LayerProof lp; lp.kind = L_MATMUL; lp.matmul.sumcheck = sc.proof; lp.matmul.individual_claims = sc.finals; lp.matmul.has_bias = hb; lp.matmul.bias_eval = bias_eval;
+  ps.proofs[id] = lp;
+  dev.release(mk);
+  return {point_left, sc.finals[0]};
 }
 
 inline std::vector<u64> ext_words_from_i64(const std::vector<int64_t>& v) { std::vector<u64> w(2 * v.size()); for (size_t i = 0; i < v.size(); i++) { w[2 * i] = gl_from_i64(v[i]); w[2 * i + 1] = 0; } return w; }
@@ -768,6 +829,7 @@ inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t) {
   for (size_t id = ctx.model.layers.size(); id-- > 0;) {
     const LayerSpec& l = ctx.model.layers[id];
     if (l.kind == L_DENSE) cur = prove_dense(ps, id, l, cur, tr.in[id]);
+    else if (l.kind == L_MATMUL) cur = prove_matmul(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
     else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, tr.out[id]);
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv.at(id));
@@ -969,6 +1031,27 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       DP_REQUIRE(ex_eq(ex_mul(dpf.individual_claims[0], dpf.individual_claims[1]), sub.expected_evaluation), DP_ERR_VERIFY, "dense: sumcheck claim failed");
       cur = {sub.point, dpf.individual_claims[1]};
       cur_len = l.ncols;
+    } else if (l.kind == L_MATMUL) {  // MatMulCtx::verify_matmul (matrix_mul.rs:1048-1139), (Input, Weight), right matrix not transposed
+      const MatMulProof& mp = lp.matmul;
+      DP_REQUIRE(l.nrows && cur_len % l.ncols == 0, DP_ERR_VERIFY, "matmul: shapes");
+      const size_t s_ = cur_len / l.ncols;
+      const unsigned nvc = dp_ceil_log2(l.ncols), nvr = dp_ceil_log2(s_);
+      DP_REQUIRE(is_pow2(s_) && cur.point.size() == nvc + nvr && mp.individual_claims.size() == 2, DP_ERR_VERIFY, "matmul: shapes");
+      auto nit = unused.find(id);
+      DP_REQUIRE(nit != unused.end() && nit->second.count("MatMulWeight"), DP_ERR_VERIFY, "matmul: no commitments for node");
+      const bool hb = nit->second.count("MatMulBias") != 0;
+      DP_REQUIRE(mp.has_bias == hb, DP_ERR_VERIFY, "matmul: bias evaluation missing or unexpected");
+      std::vector<Ext> pt_right(cur.point.begin(), cur.point.begin() + nvc), pt_left(cur.point.begin() + nvc, cur.point.end());
+      Ext eval = cur.eval;
+      if (hb) { add_claim(nit->second.at("MatMulBias"), {pt_right, mp.bias_eval}); eval = ex_sub(eval, mp.bias_eval); }
+      SubClaim sub = sumcheck_verify(eval, mp.sumcheck, dp_ceil_log2(l.nrows), 2, t);
+      std::vector<Ext> point_left = sub.point; point_left.insert(point_left.end(), pt_left.begin(), pt_left.end());
+      std::vector<Ext> point_right = pt_right; point_right.insert(point_right.end(), sub.point.begin(), sub.point.end());
+      add_claim(nit->second.at("MatMulWeight"), {point_right, mp.individual_claims[1]});
+      unused.erase(nit);
+      DP_REQUIRE(ex_eq(ex_mul(mp.individual_claims[0], mp.individual_claims[1]), sub.expected_evaluation), DP_ERR_VERIFY, "matmul: sumcheck claim failed");
+      cur = {point_left, mp.individual_claims[0]};
+      cur_len = s_ * l.nrows;
     } else if (l.kind == L_REQUANT) {  // verify_requant (requant.rs:692-817)
       const RequantProof& rp = lp.req;
       TableType ct{3, l.clamping_size()};
@@ -1063,7 +1146,8 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
 }
 
 // ---- serialisable verifier context (what dp_model_verifier_blob hands out and dp_verify consumes)
-inline const char* const* poly_ids() { static const char* const ids[4] = {"DenseBias", "DenseWeight", "ConvBias", "ConvFilter"}; return ids; }
+constexpr int N_POLY_IDS = 6;
+inline const char* const* poly_ids() { static const char* const ids[N_POLY_IDS] = {"DenseBias", "DenseWeight", "ConvBias", "ConvFilter", "MatMulBias", "MatMulWeight"}; return ids; }
 inline std::vector<u64> vctx_to_words(const VerifierContext& v) {
   std::vector<u64> w;
   w.push_back(0x3158544356504444ULL); w.push_back(v.full_log); w.push_back(v.shape.input_len); w.push_back(v.shape.layers.size());
@@ -1077,7 +1161,7 @@ inline std::vector<u64> vctx_to_words(const VerifierContext& v) {
   for (auto& kv : v.model_comms) {
     w.push_back(kv.first); w.push_back(kv.second.size());
     for (auto& pc : kv.second) {
-      int code = -1; for (int q = 0; q < 4; q++) if (pc.first == poly_ids()[q]) code = q;
+      int code = -1; for (int q = 0; q < N_POLY_IDS; q++) if (pc.first == poly_ids()[q]) code = q;
       DP_REQUIRE(code >= 0, DP_ERR_ARG, "unknown model polynomial id");
       const Commitment& c = pc.second; w.push_back((u64)code); for (int k = 0; k < 4; k++) w.push_back(c.root.v[k]); w.push_back(c.num_vars); w.push_back(c.is_base);
     }
@@ -1098,7 +1182,7 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
     l.kw = (size_t)rd(); l.kx = (size_t)rd(); l.real_nw = (size_t)rd(); l.nw = (size_t)rd();
     for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();
     for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd();
-    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_FLATTEN, DP_ERR_ARG, "verifier blob: layer kind");
+    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_MATMUL, DP_ERR_ARG, "verifier blob: layer kind");
     if (l.kind == L_CONV) DP_REQUIRE(is_pow2(l.kw) && is_pow2(l.kx) && is_pow2(l.real_nw) && is_pow2(l.nw) && l.kw <= (1u << 16) && l.kx <= (1u << 16) && l.nw <= (1u << 12) && 2 * l.real_nw <= l.nw && l.unp_out[0] <= l.kw && l.unp_out[1] <= l.nw && l.unp_out[2] <= l.nw, DP_ERR_ARG, "verifier blob: conv shape");
     if (l.kind == L_MAXPOOL) DP_REQUIRE(is_pow2(l.pin[0]) && is_pow2(l.pin[1]) && is_pow2(l.pin[2]) && l.pin[2] >= 2, DP_ERR_ARG, "verifier blob: maxpool shape");
     v.shape.layers.push_back(l);
@@ -1107,7 +1191,7 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
   for (size_t i = 0; i < nc; i++) {
     size_t id = (size_t)rd(); size_t np = (size_t)rd();
     DP_REQUIRE(np <= 4, DP_ERR_ARG, "verifier blob: polynomials per node");
-    for (size_t q = 0; q < np; q++) { u64 code = rd(); DP_REQUIRE(code < 4, DP_ERR_ARG, "verifier blob: polynomial id"); Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = rd(); c.num_vars = (unsigned)rd(); c.is_base = rd() != 0; v.model_comms[id][poly_ids()[code]] = c; }
+    for (size_t q = 0; q < np; q++) { u64 code = rd(); DP_REQUIRE(code < (u64)N_POLY_IDS, DP_ERR_ARG, "verifier blob: polynomial id"); Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = rd(); c.num_vars = (unsigned)rd(); c.is_base = rd() != 0; v.model_comms[id][poly_ids()[code]] = c; }
   }
   size_t nt = (size_t)rd(); DP_REQUIRE(nt < 64, DP_ERR_ARG, "verifier blob: tables");
   for (size_t i = 0; i < nt; i++) { TableType t; t.kind = (int)rd(); t.size = (unsigned)rd(); v.tables.push_back(t); }

@@ -5,7 +5,7 @@ import math
 
 import numpy as np
 
-L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_FLATTEN = 0, 1, 2, 3, 4, 5
+L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_FLATTEN, L_MATMUL = 0, 1, 2, 3, 4, 5, 6
 BIT_LEN = 8
 FIXED_POINT_SCALE = 25  # zkml/src/layers/requant.rs:47
 
@@ -111,6 +111,30 @@ class ModelBuilder:
             self.layers.append(dict(kind=L_REQUANT, **rq))
         return self
 
+    def matmul(self, out_features, bias=True, requant=True):
+        """MatMul::new_constant(right, bias) (layers/matrix_mul.rs:176): the activation is a [seq][features] matrix (both padded to
+        powers of two), the constant RIGHT matrix [features][out_features] — a Linear layer applied to every row of a sequence, the
+        building block of the transformer layers — followed by its Requant node"""
+        assert len(self.shape_og) == 2, "matmul needs a [seq, features] activation"
+        s_og, k_og = self.shape_og
+        s, k = self.shape_pad
+        n = next_pow2(out_features)
+        assert s * k == self._cur and s >= 2
+        w = np.zeros((k, n), dtype=np.int64)
+        w[:k_og, :out_features] = self._tensor(k_og * out_features).reshape(k_og, out_features)
+        b = None
+        if bias:
+            b = np.zeros(n, dtype=np.int64)
+            b[:out_features] = self._tensor(out_features)
+        self.layers.append(dict(kind=L_MATMUL, nrows=k, ncols=n, weights=w, bias=b))
+        self.shape_og, self.shape_pad = (s_og, out_features), (s, n)
+        self._cur = s * n
+        if requant:
+            gain = 1.0 if k_og <= 4 else 2.5
+            rq = requant_from_multiplier(gain / math.sqrt(k_og) / 127.0, dense_output_bitsize(k))
+            self.layers.append(dict(kind=L_REQUANT, **rq))
+        return self
+
     def relu(self):
         self.layers.append(dict(kind=L_RELU))
         return self
@@ -162,6 +186,11 @@ class ModelBuilder:
                 parts.append(np.array([L_DENSE, l["nrows"], l["ncols"]], dtype=np.int64))
                 parts.append(l["weights"].reshape(-1))
                 parts.append(l["bias"])
+            elif l["kind"] == L_MATMUL:
+                parts.append(np.array([L_MATMUL, l["nrows"], l["ncols"], 0 if l["bias"] is None else 1], dtype=np.int64))
+                parts.append(l["weights"].reshape(-1))
+                if l["bias"] is not None:
+                    parts.append(l["bias"])
             elif l["kind"] == L_REQUANT:
                 parts.append(np.array([L_REQUANT, l["right_shift"], l["fp_scale"], l["fixed_point_multiplier"],
                                        l["intermediate_bit_size"]], dtype=np.int64))
@@ -188,6 +217,9 @@ class ModelBuilder:
         for l in self.layers:
             if l["kind"] == L_DENSE:
                 cur = l["weights"] @ cur + l["bias"]
+            elif l["kind"] == L_MATMUL:
+                y = cur.reshape(-1, l["nrows"]) @ l["weights"]
+                cur = (y + l["bias"] if l["bias"] is not None else y).reshape(-1)
             elif l["kind"] == L_REQUANT:
                 sh = l["fp_scale"] + l["right_shift"]
                 cur = np.clip((cur * l["fixed_point_multiplier"] + (1 << (sh - 1))) >> sh, -127, 127)
@@ -222,6 +254,17 @@ def mlp(num_dense, width, config, input_features=4, output_features=3):
     for _ in range(num_dense - 1):
         mb.dense(width, width).relu()
     mb.dense(output_features, width).relu()
+    return mb
+
+
+def seq_mlp(seq, width, config, input_features=4, output_features=3, layers=2):
+    """a per-token MLP over a [seq][features] activation: MatMul(+bias)+Requant+ReLU blocks (the Linear layers of a transformer
+    block applied to every position; layers/matrix_mul.rs with a constant right matrix), the last one without bias"""
+    mb = ModelBuilder((seq, input_features), config)
+    mb.matmul(width).relu()
+    for _ in range(layers - 1):
+        mb.matmul(width).relu()
+    mb.matmul(output_features, bias=False).relu()
     return mb
 
 

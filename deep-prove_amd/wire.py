@@ -26,7 +26,7 @@ import struct
 import numpy as np
 
 MAGIC = 0x31464F4F52505044
-L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL = 0, 1, 2, 3, 4
+L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_MATMUL = 0, 1, 2, 3, 4, 6
 
 
 class Conventions:
@@ -96,6 +96,9 @@ def parse_stream(words):
         node, kind = r.u(), r.u()
         if kind == L_DENSE:
             lp = {"sumcheck": r.iop(), "bias_eval": r.e(), "individual_claims": r.ve()}
+        elif kind == L_MATMUL:
+            lp = {"sumcheck": r.iop(), "individual_claims": r.ve()}
+            lp["bias_eval"] = r.e() if r.u() else None
         elif kind == L_REQUANT:
             lp = {"io_accumulation": r.iop(), "accumulation_evals": r.ve(), "clamping_lookup": r.logup(), "shifted_lookup": r.logup(),
                   "commitments": [r.comm() for _ in range(r.u())]}
@@ -183,6 +186,9 @@ def to_serde_model(tree, conv=Conventions):
     for node, kind, lp in sorted(tree["steps"], key=lambda s: s[0]):
         if kind == L_DENSE:
             v = {"Dense": {"sumcheck": _iop(lp["sumcheck"], c), "bias_eval": _e(lp["bias_eval"], c), "individual_claims": _ve(lp["individual_claims"], c)}}
+        elif kind == L_MATMUL:  # MatMulProof {sumcheck, individual_claims, bias_eval: Option<E>} (layers/matrix_mul.rs:153-161)
+            v = {"MatMul": {"sumcheck": _iop(lp["sumcheck"], c), "individual_claims": _ve(lp["individual_claims"], c),
+                            "bias_eval": None if lp["bias_eval"] is None else _e(lp["bias_eval"], c)}}
         elif kind == L_REQUANT:
             v = {"Requant": {"io_accumulation": _iop(lp["io_accumulation"], c), "accumulation_evals": _ve(lp["accumulation_evals"], c),
                              "clamping_lookup": _logup(lp["clamping_lookup"], c), "shifted_lookup": _logup(lp["shifted_lookup"], c),
@@ -395,12 +401,17 @@ def from_rmp(data, conv=Conventions):
     assert end == len(data), "trailing bytes"
     w = _Writer(conv)
     w.w.append(MAGIC); w.w.append(len(model["steps"]))
-    kinds = {"Dense": L_DENSE, "Requant": L_REQUANT, "Activation": L_RELU, "Convolution": L_CONV, "Pooling": L_MAXPOOL}
+    kinds = {"Dense": L_DENSE, "Requant": L_REQUANT, "Activation": L_RELU, "Convolution": L_CONV, "Pooling": L_MAXPOOL, "MatMul": L_MATMUL}
     for node in sorted(model["steps"]):
         (name, lp), = model["steps"][node].items()
         w.w.append(node); w.w.append(kinds[name])
         if name == "Dense":
             w.iop(lp["sumcheck"]); w.e(lp["bias_eval"]); w.ve(lp["individual_claims"])
+        elif name == "MatMul":
+            w.iop(lp["sumcheck"]); w.ve(lp["individual_claims"])
+            w.w.append(0 if lp["bias_eval"] is None else 1)
+            if lp["bias_eval"] is not None:
+                w.e(lp["bias_eval"])
         elif name == "Requant":
             w.iop(lp["io_accumulation"]); w.ve(lp["accumulation_evals"]); w.logup(lp["clamping_lookup"]); w.logup(lp["shifted_lookup"])
             w.w.append(len(lp["commitments"]))

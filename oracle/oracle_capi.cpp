@@ -21,6 +21,12 @@ static Model parse_model(const int64_t* b, size_t n) {
   for (size_t i = 0; i < nl; i++) {
     Layer l; l.kind = (LayerKind)rd();
     if (l.kind == L_DENSE) { l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); l.weights.assign(b + pos, b + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols; l.bias.assign(b + pos, b + pos + l.nrows); pos += l.nrows; }
+    else if (l.kind == L_MATMUL) {
+      l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); size_t hb = (size_t)rd();
+      if (l.nrows == 0 || l.ncols == 0 || l.nrows > n || l.ncols > n || pos + l.nrows * l.ncols + (hb ? l.ncols : 0) > n) throw std::runtime_error("model blob truncated");
+      l.weights.assign(b + pos, b + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols;
+      if (hb) { l.bias.assign(b + pos, b + pos + l.ncols); pos += l.ncols; }
+    }
     else if (l.kind == L_REQUANT) { l.right_shift = (unsigned)rd(); l.fp_scale = (unsigned)rd(); l.fixed_point_multiplier = rd(); l.intermediate_bit_size = (unsigned)rd(); }
     else if (l.kind == L_CONV) {
       l.kw = (size_t)rd(); l.kx = (size_t)rd(); l.real_nw = (size_t)rd(); l.nw = (size_t)rd(); for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();

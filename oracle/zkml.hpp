@@ -169,10 +169,12 @@ static inline LogUpProof logup_batch_prove(const LogUpInput& in, Transcript& t) 
 }
 
 // ------------------------------------------------------------------ model description
-enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5 };
+enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6 };
 struct Layer {
   LayerKind kind;
-  size_t nrows = 0, ncols = 0;        // dense (padded to powers of two)
+  // dense (padded to powers of two). matmul (layers/matrix_mul.rs, MatMul::new_constant: Input x Weight [+ bias]): the constant RIGHT
+  // matrix is [nrows][ncols] row major, the input a row-major [s][nrows] matrix, bias [ncols] or empty
+  size_t nrows = 0, ncols = 0;
   std::vector<int64_t> weights, bias;  // dense: row major, bias padded to nrows; conv: filter [kw][kx][real_nw][real_nw], bias [kw]
   // conv (layers/convolution.rs:52-83, tensor.rs:409-431): padded filter count kw, padded input channels kx, padded
   // kernel side real_nw, padded input side nw (= n_x of fft_conv); unp_out = conv2d_shape of the UNPADDED tensors
@@ -332,6 +334,12 @@ static inline Trace run_model(const Model& m, const std::vector<int64_t>& input)
       if (cur.size() != l.ncols) throw std::runtime_error("dense input size mismatch");
       o.resize(l.nrows);
       for (size_t i = 0; i < l.nrows; i++) { int64_t a = 0; for (size_t j = 0; j < l.ncols; j++) a += l.weights[i * l.ncols + j] * cur[j]; o[i] = a + l.bias[i]; }
+    } else if (l.kind == L_MATMUL) {  // MatMul::op (matrix_mul.rs:230-311): input [s][k] times the constant [k][n], bias added to every row
+      const size_t k = l.nrows, n = l.ncols;
+      if (cur.size() % k) throw std::runtime_error("matmul input size mismatch");
+      const size_t s_ = cur.size() / k;
+      o.assign(s_ * n, 0);
+      for (size_t i = 0; i < s_; i++) for (size_t j = 0; j < n; j++) { int64_t a = 0; for (size_t q = 0; q < k; q++) a += cur[i * k + q] * l.weights[q * n + j]; o[i * n + j] = a + (l.bias.empty() ? 0 : l.bias[j]); }
     } else if (l.kind == L_REQUANT) {
       for (int64_t v : cur) {
         if (std::llabs(v) > (int64_t(1) << l.intermediate_bit_size)) throw std::runtime_error("requant: value too large");
@@ -365,6 +373,7 @@ static inline Context context_generate(const Model& m) {
   size_t cur_len = m.input_len;
   for (auto& l : m.layers) {
     if (l.kind == L_DENSE) { cur_len = l.nrows; }
+    else if (l.kind == L_MATMUL) { cur_len = cur_len / l.nrows * l.ncols; }
     else if (l.kind == L_REQUANT) { add_table({2, 0}); add_table({3, l.clamping_size()}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
     else if (l.kind == L_RELU) { add_table({0, 0}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
     else if (l.kind == L_CONV) { cur_len = l.kw * l.nw * l.nw; }                                                       // convolution.rs:506-511
@@ -372,7 +381,7 @@ static inline Context context_generate(const Model& m) {
   }
   std::sort(tset.begin(), tset.end());
   for (auto& t : tset) max_poly_len = std::max(max_poly_len, size_t(1) << t.multiplicity_poly_vars());
-  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV) { max_poly_len = std::max(max_poly_len, next_pow2(l.weights.size())); max_poly_len = std::max(max_poly_len, next_pow2(l.bias.size())); }
+  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL) { max_poly_len = std::max(max_poly_len, next_pow2(l.weights.size())); max_poly_len = std::max(max_poly_len, next_pow2(l.bias.size())); }
   max_poly_len = next_pow2(max_poly_len);
   ctx.max_poly_len = max_poly_len;
   ctx.pp = pcs_setup(max_poly_len);
@@ -382,13 +391,14 @@ static inline Context context_generate(const Model& m) {
   for (size_t id = 0; id < m.layers.size(); id++) {
     if (m.layers[id].kind == L_DENSE) { jobs.push_back({id, "DenseWeight"}); jobs.push_back({id, "DenseBias"}); }
     if (m.layers[id].kind == L_CONV) { jobs.push_back({id, "ConvFilter"}); jobs.push_back({id, "ConvBias"}); }  // convolution.rs:452-453,546-553
+    if (m.layers[id].kind == L_MATMUL) { jobs.push_back({id, "MatMulWeight"}); if (!m.layers[id].bias.empty()) jobs.push_back({id, "MatMulBias"}); }  // matrix_mul.rs:947-963
   }
   for (auto& j : jobs) ctx.model_comms[j.first][j.second];  // create map slots before the threads write into them
   std::vector<std::thread> th;
   for (auto& j : jobs) th.emplace_back([&ctx, &m, j] {
     const Layer& l = m.layers[j.first];
     std::string pid = j.second;
-    Mle poly = Mle::from_i64(pid == "DenseWeight" || pid == "ConvFilter" ? l.weights : l.bias);
+    Mle poly = Mle::from_i64(pid == "DenseWeight" || pid == "ConvFilter" || pid == "MatMulWeight" ? l.weights : l.bias);
     ctx.model_comms[j.first][j.second] = {pcs_commit(ctx.pp, poly), poly};
   });
   for (auto& t : th) t.join();
@@ -398,6 +408,7 @@ static inline Context context_generate(const Model& m) {
 
 // ------------------------------------------------------------------ proofs
 struct DenseProof { IOPProof sumcheck; E bias_eval; std::vector<E> individual_claims; };
+struct MatMulProof { IOPProof sumcheck; std::vector<E> individual_claims; bool has_bias = false; E bias_eval{}; };  // matrix_mul.rs:153-161 (bias_eval: Option<E>)
 struct SamePolyProof { IOPProof sumcheck; std::vector<E> evals; };
 struct ActivationProof { SamePolyProof io_accumulation; LogUpProof lookup; std::vector<Commitment> commits; };
 struct RequantProof { IOPProof io_accumulation; std::vector<E> accumulation_evals; LogUpProof clamping_lookup, shifted_lookup; std::vector<Commitment> commitments; };
@@ -415,7 +426,7 @@ struct ConvProof {  // convolution.rs:98-127, fields in declaration order
   HadamardProof clearing_proof;
 };
 struct PoolingProof { IOPProof sumcheck; LogUpProof lookup; std::vector<E> zerocheck_evals; size_t variable_gap = 0; std::vector<Commitment> commitments; };  // pooling.rs:60-76
-struct LayerProof { LayerKind kind; DenseProof dense; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; };
+struct LayerProof { LayerKind kind; DenseProof dense; MatMulProof matmul; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; };
 struct TableProof { Commitment multiplicity_commit; LogUpProof lookup; };
 struct Proof {
   std::map<size_t, LayerProof> steps;  // canonical order: ascending NodeId
@@ -534,6 +545,39 @@ static inline Claim prove_dense(ProverState& ps, size_t id, const Layer& l, cons
   LayerProof lp; lp.kind = L_DENSE; lp.dense = {proof, bias_eval, fin};
   ps.proofs[id] = lp;
   return {proof.point, fin[1]};
+}
+// MatMul::prove_step (layers/matrix_mul.rs:701-873) for the (Input, Weight) arrangement, right matrix not transposed:
+// split_claim (:339-356): the low variables of the output point address columns -> the right matrix, the high ones rows -> the left;
+// the bias (one value per column) is evaluated on the column part and leaves the claim; left.fix_high(rows), right.fix_low(cols);
+// one degree-2 sumcheck over the inner dimension; full_points (:364-383): left at [sumcheck point | row part] (the claim handed to the
+// previous layer), right at [column part | sumcheck point] (opened against the weight commitment).
+static inline Claim prove_matmul(ProverState& ps, size_t id, const Layer& l, const Claim& last, const std::vector<E>& input) {
+  const size_t k = l.nrows, n = l.ncols, s_ = input.size() / k;
+  const unsigned nvc = log2_strict(n), nvr = log2_strict(s_);
+  if (last.point.size() != nvc + nvr) throw std::runtime_error("matmul: claim point size mismatch");
+  std::vector<E> pt_right(last.point.begin(), last.point.begin() + nvc), pt_left(last.point.begin() + nvc, last.point.end());
+  const bool hb = !l.bias.empty();
+  E bias_eval = e_zero();
+  if (hb) bias_eval = Mle::from_i64(l.bias).evaluate(pt_right);  // (last_claim.eval -= bias_eval only matters to the verifier)
+  Mle left = Mle::from_ext(input);
+  left.fix_high_in_place(pt_left);
+  std::vector<E> w(l.weights.size()); for (size_t i = 0; i < w.size(); i++) w[i] = e_from_i64(l.weights[i]);
+  Mle right = Mle::from_ext(w);
+  right.fix_low_in_place(pt_right);
+  if (left.nv != right.nv) throw std::runtime_error("matmul: inner dimensions differ");
+  VirtualPolynomial vp(left.nv);
+  vp.add_mle_list({mk(left), mk(right)}, e_one());
+  auto [proof, st] = sumcheck_prove(std::move(vp), *ps.t);
+  std::vector<E> fin = st.final_evaluations();
+  std::vector<E> point_left = proof.point; point_left.insert(point_left.end(), pt_left.begin(), pt_left.end());
+  std::vector<E> point_right = pt_right; point_right.insert(point_right.end(), proof.point.begin(), proof.point.end());
+  // add_common_claims iterates the node's BTreeMap: "MatMulBias" then "MatMulWeight"
+  const auto& comms = ps.ctx->model_comms.at(id);
+  if (hb) ps.add_witness_claim(comms.at("MatMulBias"), {pt_right, bias_eval});
+  ps.add_witness_claim(comms.at("MatMulWeight"), {point_right, fin[1]});
+  LayerProof lp; lp.kind = L_MATMUL; lp.matmul.sumcheck = proof; lp.matmul.individual_claims = fin; lp.matmul.has_bias = hb; lp.matmul.bias_eval = bias_eval;
+  ps.proofs[id] = lp;
+  return {point_left, fin[0]};
 }
 // Requant::recombine_claims (requant.rs:499-529)
 static inline E recombine_claims(const Layer& l, E clamping_claim, const std::vector<E>& shifted) {
@@ -864,6 +908,7 @@ static inline Proof prove(const Context& ctx, const Trace& tr, Transcript& t) {
   for (size_t id = ctx.model.layers.size(); id-- > 0;) {
     const Layer& l = ctx.model.layers[id];
     if (l.kind == L_DENSE) cur = prove_dense(ps, id, l, cur, to_fields(tr.in[id]));
+    else if (l.kind == L_MATMUL) cur = prove_matmul(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
     else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, to_fields(tr.out[id]));
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv[id]);
@@ -926,6 +971,7 @@ static inline std::vector<u64> serialize_proof(const Proof& p) {
   for (auto& [id, lp] : p.steps) {
     w.u(id); w.u(lp.kind);
     if (lp.kind == L_DENSE) { w.iop(lp.dense.sumcheck); w.e(lp.dense.bias_eval); w.ve(lp.dense.individual_claims); }
+    else if (lp.kind == L_MATMUL) { w.iop(lp.matmul.sumcheck); w.ve(lp.matmul.individual_claims); w.u(lp.matmul.has_bias ? 1 : 0); if (lp.matmul.has_bias) w.e(lp.matmul.bias_eval); }
     else if (lp.kind == L_REQUANT) {
       w.iop(lp.req.io_accumulation); w.ve(lp.req.accumulation_evals); w.logup(lp.req.clamping_lookup); w.logup(lp.req.shifted_lookup);
       w.u(lp.req.commitments.size()); for (auto& c : lp.req.commitments) w.comm(c);

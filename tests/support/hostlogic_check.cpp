@@ -21,6 +21,8 @@ static uint64_t rnd() { rs += 0x9E3779B97F4A7C15ULL; uint64_t z = rs; z = (z ^ (
 static int64_t rq() { return (int64_t)(rnd() % 255) - 127; }
 
 static dp::LayerSpec dense(size_t r, size_t c) { dp::LayerSpec l; l.kind = dp::L_DENSE; l.nrows = r; l.ncols = c; l.weights.resize(r * c); for (auto& x : l.weights) x = rq(); l.bias.resize(r); for (auto& x : l.bias) x = rq(); return l; }
+// MatMul with a constant right matrix [k][n] (layers/matrix_mul.rs, MatMul::new_constant) over a [s][k] activation
+static dp::LayerSpec matmul(size_t k, size_t n, bool bias) { dp::LayerSpec l; l.kind = dp::L_MATMUL; l.nrows = k; l.ncols = n; l.weights.resize(k * n); for (auto& x : l.weights) x = rq(); if (bias) { l.bias.resize(n); for (auto& x : l.bias) x = rq(); } return l; }
 static dp::LayerSpec requant_for(size_t ncols, double m) {
   // Requant::from_multiplier (requant.rs:409-437) with double arithmetic (front-end, out of scope for parity)
   dp::LayerSpec l; l.kind = dp::L_REQUANT;
@@ -234,12 +236,20 @@ int main(int argc, char** argv) {
   if (argc > 1 && std::string(argv[1]) == "sharded") return sharded_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 4);
   if (argc > 1 && std::string(argv[1]) == "sumcheck") return sumcheck_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 6);
   bool cnn = argc > 1 && std::string(argv[1]) == "cnn";
-  size_t W = argc > 1 && !cnn ? atoi(argv[1]) : 64; rs = argc > 2 ? atoll(argv[2]) : 1; int tamper = argc > 3 ? atoi(argv[3][0] == '@' ? argv[3] + 1 : argv[3]) : 0; bool tamper_abs = argc > 3 && argv[3][0] == '@';  // "@i": flip word i, else word size/2 + offset
+  bool seq = argc > 1 && std::string(argv[1]) == "seq";  // `hostlogic_check seq <seed>`: a per-token MLP over a [8][4] activation out of MatMul layers
+  size_t W = argc > 1 && !cnn && !seq ? atoi(argv[1]) : 64; rs = argc > 2 ? atoll(argv[2]) : 1; int tamper = argc > 3 ? atoi(argv[3][0] == '@' ? argv[3] + 1 : argv[3]) : 0; bool tamper_abs = argc > 3 && argv[3][0] == '@';  // "@i": flip word i, else word size/2 + offset
   dp::ModelSpec m; m.input_len = 4;
   dp::LayerSpec relu; relu.kind = dp::L_RELU;
   std::vector<int64_t> in;
   if (cnn) m = tiny_cnn(in);
-  else {
+  else if (seq) {
+    const size_t S = 8, F = 4, H = 16;
+    m.input_len = S * F;
+    m.layers.push_back(matmul(F, H, true)); m.layers.push_back(requant_for(F, 0.5 / 127)); m.layers.push_back(relu);
+    m.layers.push_back(matmul(H, H, true)); m.layers.push_back(requant_for(H, 1.0 / std::sqrt((double)H) / 127)); m.layers.push_back(relu);
+    m.layers.push_back(matmul(H, F, false)); m.layers.push_back(requant_for(H, 1.0 / std::sqrt((double)H) / 127)); m.layers.push_back(relu);
+    in.resize(S * F); for (auto& x : in) x = rq();
+  } else {
     m.layers.push_back(dense(W, 4)); m.layers.push_back(requant_for(4, 0.5 / 127)); m.layers.push_back(relu);
     m.layers.push_back(dense(W, W)); m.layers.push_back(requant_for(W, 1.0 / std::sqrt((double)W) / 127)); m.layers.push_back(relu);
     m.layers.push_back(dense(4, W)); m.layers.push_back(requant_for(W, 1.0 / std::sqrt((double)W) / 127)); m.layers.push_back(relu);

@@ -197,3 +197,40 @@ def test_batch_verifier_with_device_side_merkle_paths(dev):
         with pytest.raises(dpa.DeepProveError):
             dpa.verify(vb, tampered[i], xs[i], wrong[i])
     ctx.free()
+
+
+@pytest.mark.parametrize("seq,width", [(8, 16), (16, 64), (64, 256)])
+def test_matmul_model_proof_bytes_identical_to_oracle(dev, oracle, seq, width):
+    """MatMul with a constant right matrix over a [seq][features] activation (layers/matrix_mul.rs; k_fix_low on the weights,
+    fix_high on the activation, the degree-2 sumcheck): proof stream == the oracle's, the verifier accepts, numpy inference agrees"""
+    import deep_prove_amd as dpa
+    mb = dpa.models.seq_mlp(seq, width, config=60 + seq)
+    x = mb.input()
+    ctx, proof, out, oproof, oout = prove_both(dev, oracle, mb, x)
+    assert (out == oout).all() and (out == mb.run(x)).all()
+    assert proof.size == oproof.size, (proof.size, oproof.size)
+    diff = np.nonzero(proof != oproof)[0]
+    assert diff.size == 0, f"first differing word {diff[:5]} of {proof.size}"
+    dpa.verify(ctx.verifier_blob(), proof, x, out)
+    bad = proof.copy()
+    bad[40] ^= np.uint64(1)
+    with pytest.raises(dpa.DeepProveError):
+        dpa.verify(ctx.verifier_blob(), bad, x, out)
+    # throughput mode (cohorts, device-side Fiat-Shamir): every proof of a batch equals the sequential proof of its input
+    xs = np.stack([mb.input(500 + i) for i in range(8)])
+    proofs, outs, _ = dpa.Prover(ctx).prove_batch(xs, 8)
+    single, sout = dpa.Prover(ctx).prove(xs[5])
+    assert proofs[5].size == single.size and (proofs[5] == single).all() and (outs[5] == sout).all()
+    ctx.free()
+
+
+def test_golden_seq_mlp(dev):
+    """committed fixture tests/golden/seq_mlp.npz (made by tests/golden/make_seq_golden.py)"""
+    import deep_prove_amd as dpa
+    g = np.load(os.path.join(ROOT, "tests", "golden", "seq_mlp.npz"))
+    ctx = dpa.Context.generate(dev, g["model_blob"])
+    proof, out = dpa.Prover(ctx).prove(g["input"])
+    assert (out == g["output"]).all()
+    assert proof.size == g["proof"].size and (proof == g["proof"]).all()
+    assert (ctx.verifier_blob() == g["verifier_blob"]).all()
+    ctx.free()

@@ -144,3 +144,21 @@ def test_single_polynomial_open_matches_oracle_and_verifies(hostlogic_bin, seed,
     r = run(hostlogic_bin, "open", seed, nv, ext)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "identical to the oracle" in r.stdout and "accepted 1 of 1, rejected 7 of 7" in r.stdout
+
+
+@pytest.mark.parametrize("seed", [1, 2, 9])
+def test_matmul_model_proof_stream_identical_to_oracle_and_accepted(hostlogic_bin, seed):
+    """MatMul with a constant right matrix (layers/matrix_mul.rs:701-873, 1048-1139; the Linear layer of a transformer block applied
+    to every row of a [seq][features] activation): three MatMul (+bias / no bias) + Requant + ReLU blocks over an [8][4] input — the
+    product's orchestrator over the CPU double (Dev::fix_high on the activation, Dev::fix_low on the weights, the degree-2 sumcheck,
+    the claims routed to the previous layer / the weight and bias commitments) gives the oracle's stream; the verifier accepts both"""
+    r = run(hostlogic_bin, "seq", seed)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical=1" in r.stdout
+    assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
+
+
+@pytest.mark.parametrize("where", ["@40", "@200", "@2000", "5"])
+def test_matmul_model_tampered_proof_rejected(hostlogic_bin, where):
+    r = run(hostlogic_bin, "seq", 3, where)
+    assert "verify(oracle,tampered): REJECT" in r.stdout, r.stdout + r.stderr

