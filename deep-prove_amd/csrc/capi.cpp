@@ -529,10 +529,11 @@ static ModelSpec parse_model(const int64_t* b, size_t n) {
       DP_REQUIRE(l.nrows && l.ncols && !__builtin_mul_overflow(l.nrows, l.ncols, &nw) && !__builtin_add_overflow(nw, l.nrows, &tot) && tot <= n - pos, DP_ERR_ARG, "model blob: dense tensor sizes");
       l.weights.assign(b + pos, b + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols;
       l.bias.assign(b + pos, b + pos + l.nrows); pos += l.nrows;
-    } else if (l.kind == L_MATMUL) {  // [6, rows of the constant right matrix, its columns, has_bias, weights row major, bias]
-      l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); const size_t hb = (size_t)rd();
+    } else if (l.kind == L_MATMUL) {  // [6, inner dimension k, output columns n, flags, weights ([k][n] row major; [n][k] with TransposeB), bias]
+      l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); const size_t fl = (size_t)rd(), hb = fl & 1;  // flags: 1 = bias, 2 = Config::TransposeB
+      l.mm_transpose = (fl & 2) != 0;
       size_t nw = 0, tot = 0;
-      DP_REQUIRE(l.nrows && l.ncols && hb <= 1 && !__builtin_mul_overflow(l.nrows, l.ncols, &nw) && !__builtin_add_overflow(nw, hb ? l.ncols : 0, &tot) && tot <= n - pos, DP_ERR_ARG, "model blob: matmul tensor sizes");
+      DP_REQUIRE(l.nrows && l.ncols && fl <= 3 && !__builtin_mul_overflow(l.nrows, l.ncols, &nw) && !__builtin_add_overflow(nw, hb ? l.ncols : 0, &tot) && tot <= n - pos, DP_ERR_ARG, "model blob: matmul tensor sizes");
       l.weights.assign(b + pos, b + pos + nw); pos += nw;
       if (hb) { l.bias.assign(b + pos, b + pos + l.ncols); pos += l.ncols; }
     } else if (l.kind == L_REQUANT) { l.right_shift = (unsigned)rd(); l.fp_scale = (unsigned)rd(); l.fixed_point_multiplier = rd(); l.intermediate_bit_size = (unsigned)rd(); }

@@ -29,7 +29,9 @@ struct LayerSpec {
   size_t nrows = 0, ncols = 0;
   std::vector<int64_t> weights, bias;  // dense: row major / padded bias; conv: filter [kw][kx][real_nw][real_nw], bias [kw]
   // matmul (layers/matrix_mul.rs, MatMul::new_constant: Input x Weight [+ bias]): the constant RIGHT matrix is weights[nrows][ncols] row major,
-  // the input a row-major [s][nrows] matrix (s = its length / nrows), bias [ncols] or empty; the output is [s][ncols]
+  // the input a row-major [s][nrows] matrix (s = its length / nrows), bias [ncols] or empty; the output is [s][ncols]. mm_transpose
+  // (Config::TransposeB, matrix_mul.rs:36-39): the constant matrix is stored as [ncols][nrows] and used transposed
+  bool mm_transpose = false;
   // conv (layers/convolution.rs:52-83, tensor.rs:409-431): padded filter count kw, padded input channels kx, padded kernel
   // side real_nw, padded input side nw; unp_out = conv2d_shape of the unpadded tensors (for the garbage-clearing tensor)
   size_t kw = 0, kx = 0, real_nw = 0, nw = 0;
@@ -175,7 +177,8 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
       o.assign(s_ * n, 0);
       for (size_t i = 0; i < s_; i++) {
         int64_t* row = &o[i * n];
-        for (size_t q = 0; q < k; q++) { const int64_t x = cur[i * k + q]; const int64_t* w = &l.weights[q * n]; for (size_t j = 0; j < n; j++) row[j] += x * w[j]; }
+        if (l.mm_transpose) for (size_t j = 0; j < n; j++) { const int64_t* w = &l.weights[j * k]; const int64_t* x = &cur[i * k]; int64_t a = 0; for (size_t q = 0; q < k; q++) a += x[q] * w[q]; row[j] = a; }
+        else for (size_t q = 0; q < k; q++) { const int64_t x = cur[i * k + q]; const int64_t* w = &l.weights[q * n]; for (size_t j = 0; j < n; j++) row[j] += x * w[j]; }
         if (!l.bias.empty()) for (size_t j = 0; j < n; j++) row[j] += l.bias[j];
       }
     } else if (l.kind == L_REQUANT) {
@@ -488,12 +491,15 @@ inline Claim prove_matmul(ProverState& ps, size_t id, const LayerSpec& l, const 
   dev.upload_i64(in, input.data());
   DBuf left = dev.alloc(k, true), right = dev.alloc(k, true);
   dev.fix_high(left, in, s_, k, pt_left.data());
-  dev.fix_low(right, ps.ctx->weights_dev.at(id), k, n, pt_right.data());
+  // not transposed: [k][n], its column variables are the low ones; transposed: stored [n][k], the variables of its rows are the high ones (:815-824)
+  if (l.mm_transpose) dev.fix_high(right, ps.ctx->weights_dev.at(id), n, k, pt_right.data());
+  else dev.fix_low(right, ps.ctx->weights_dev.at(id), k, n, pt_right.data());
   DevVP vp(dp_ceil_log2(k));
   vp.add_mle_list({left, right}, ex_one());
   SumcheckOut sc = sumcheck_prove(dev, vp, *ps.t);
   std::vector<Ext> point_left = sc.proof.point; point_left.insert(point_left.end(), pt_left.begin(), pt_left.end());
-  std::vector<Ext> point_right = pt_right; point_right.insert(point_right.end(), sc.proof.point.begin(), sc.proof.point.end());
+  std::vector<Ext> point_right = l.mm_transpose ? sc.proof.point : pt_right;
+  if (l.mm_transpose) point_right.insert(point_right.end(), pt_right.begin(), pt_right.end()); else point_right.insert(point_right.end(), sc.proof.point.begin(), sc.proof.point.end());
   if (hb) ps.add_witness_claim(comms.at("MatMulBias"), {pt_right, bias_eval});   // BTreeMap order: "MatMulBias" < "MatMulWeight"
   ps.add_witness_claim(comms.at("MatMulWeight"), {point_right, sc.finals[1]});
   LayerProof lp; lp.kind = L_MATMUL; lp.matmul.sumcheck = sc.proof; lp.matmul.individual_claims = sc.finals; lp.matmul.has_bias = hb; lp.matmul.bias_eval = bias_eval;
@@ -1046,7 +1052,8 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       if (hb) { add_claim(nit->second.at("MatMulBias"), {pt_right, mp.bias_eval}); eval = ex_sub(eval, mp.bias_eval); }
       SubClaim sub = sumcheck_verify(eval, mp.sumcheck, dp_ceil_log2(l.nrows), 2, t);
       std::vector<Ext> point_left = sub.point; point_left.insert(point_left.end(), pt_left.begin(), pt_left.end());
-      std::vector<Ext> point_right = pt_right; point_right.insert(point_right.end(), sub.point.begin(), sub.point.end());
+      std::vector<Ext> point_right = l.mm_transpose ? sub.point : pt_right;
+      if (l.mm_transpose) point_right.insert(point_right.end(), pt_right.begin(), pt_right.end()); else point_right.insert(point_right.end(), sub.point.begin(), sub.point.end());
       add_claim(nit->second.at("MatMulWeight"), {point_right, mp.individual_claims[1]});
       unused.erase(nit);
       DP_REQUIRE(ex_eq(ex_mul(mp.individual_claims[0], mp.individual_claims[1]), sub.expected_evaluation), DP_ERR_VERIFY, "matmul: sumcheck claim failed");
@@ -1153,7 +1160,8 @@ inline std::vector<u64> vctx_to_words(const VerifierContext& v) {
   w.push_back(0x3158544356504444ULL); w.push_back(v.full_log); w.push_back(v.shape.input_len); w.push_back(v.shape.layers.size());
   for (auto& l : v.shape.layers) {
     w.push_back(l.kind); w.push_back(l.nrows); w.push_back(l.ncols); w.push_back(l.right_shift); w.push_back(l.fp_scale); w.push_back((u64)l.fixed_point_multiplier); w.push_back(l.intermediate_bit_size);
-    w.push_back(l.kw); w.push_back(l.kx); w.push_back(l.real_nw); w.push_back(l.nw);
+    w.push_back(l.kind == L_MATMUL ? (l.mm_transpose ? 1 : 0) : l.kw);  // (a MatMul has no filter count: the slot carries its transpose flag)
+    w.push_back(l.kx); w.push_back(l.real_nw); w.push_back(l.nw);
     for (int k = 0; k < 3; k++) w.push_back(l.unp_out[k]);
     for (int k = 0; k < 3; k++) w.push_back(l.pin[k]);
   }
@@ -1183,6 +1191,7 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
     for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();
     for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd();
     DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_MATMUL, DP_ERR_ARG, "verifier blob: layer kind");
+    if (l.kind == L_MATMUL) { DP_REQUIRE(l.kw <= 1, DP_ERR_ARG, "verifier blob: matmul flags"); l.mm_transpose = l.kw != 0; l.kw = 0; }
     if (l.kind == L_CONV) DP_REQUIRE(is_pow2(l.kw) && is_pow2(l.kx) && is_pow2(l.real_nw) && is_pow2(l.nw) && l.kw <= (1u << 16) && l.kx <= (1u << 16) && l.nw <= (1u << 12) && 2 * l.real_nw <= l.nw && l.unp_out[0] <= l.kw && l.unp_out[1] <= l.nw && l.unp_out[2] <= l.nw, DP_ERR_ARG, "verifier blob: conv shape");
     if (l.kind == L_MAXPOOL) DP_REQUIRE(is_pow2(l.pin[0]) && is_pow2(l.pin[1]) && is_pow2(l.pin[2]) && l.pin[2] >= 2, DP_ERR_ARG, "verifier blob: maxpool shape");
     v.shape.layers.push_back(l);

@@ -111,7 +111,7 @@ class ModelBuilder:
             self.layers.append(dict(kind=L_REQUANT, **rq))
         return self
 
-    def matmul(self, out_features, bias=True, requant=True):
+    def matmul(self, out_features, bias=True, requant=True, transpose_b=False):
         """MatMul::new_constant(right, bias) (layers/matrix_mul.rs:176): the activation is a [seq][features] matrix (both padded to
         powers of two), the constant RIGHT matrix [features][out_features] — a Linear layer applied to every row of a sequence, the
         building block of the transformer layers — followed by its Requant node"""
@@ -126,7 +126,9 @@ class ModelBuilder:
         if bias:
             b = np.zeros(n, dtype=np.int64)
             b[:out_features] = self._tensor(out_features)
-        self.layers.append(dict(kind=L_MATMUL, nrows=k, ncols=n, weights=w, bias=b))
+        if transpose_b:  # Config::TransposeB: the constant matrix is given as [out_features][features] (e.g. tied embeddings) and used transposed
+            w = np.ascontiguousarray(w.T)
+        self.layers.append(dict(kind=L_MATMUL, nrows=k, ncols=n, weights=w, bias=b, transpose_b=transpose_b))
         self.shape_og, self.shape_pad = (s_og, out_features), (s, n)
         self._cur = s * n
         if requant:
@@ -187,7 +189,7 @@ class ModelBuilder:
                 parts.append(l["weights"].reshape(-1))
                 parts.append(l["bias"])
             elif l["kind"] == L_MATMUL:
-                parts.append(np.array([L_MATMUL, l["nrows"], l["ncols"], 0 if l["bias"] is None else 1], dtype=np.int64))
+                parts.append(np.array([L_MATMUL, l["nrows"], l["ncols"], (0 if l["bias"] is None else 1) | (2 if l["transpose_b"] else 0)], dtype=np.int64))
                 parts.append(l["weights"].reshape(-1))
                 if l["bias"] is not None:
                     parts.append(l["bias"])
@@ -218,7 +220,7 @@ class ModelBuilder:
             if l["kind"] == L_DENSE:
                 cur = l["weights"] @ cur + l["bias"]
             elif l["kind"] == L_MATMUL:
-                y = cur.reshape(-1, l["nrows"]) @ l["weights"]
+                y = cur.reshape(-1, l["nrows"]) @ (l["weights"].T if l["transpose_b"] else l["weights"])
                 cur = (y + l["bias"] if l["bias"] is not None else y).reshape(-1)
             elif l["kind"] == L_REQUANT:
                 sh = l["fp_scale"] + l["right_shift"]
@@ -257,14 +259,14 @@ def mlp(num_dense, width, config, input_features=4, output_features=3):
     return mb
 
 
-def seq_mlp(seq, width, config, input_features=4, output_features=3, layers=2):
+def seq_mlp(seq, width, config, input_features=4, output_features=3, layers=2, transpose_last=False):
     """a per-token MLP over a [seq][features] activation: MatMul(+bias)+Requant+ReLU blocks (the Linear layers of a transformer
     block applied to every position; layers/matrix_mul.rs with a constant right matrix), the last one without bias"""
     mb = ModelBuilder((seq, input_features), config)
     mb.matmul(width).relu()
     for _ in range(layers - 1):
         mb.matmul(width).relu()
-    mb.matmul(output_features, bias=False).relu()
+    mb.matmul(output_features, bias=False, transpose_b=transpose_last).relu()
     return mb
 
 

@@ -22,7 +22,7 @@ static Model parse_model(const int64_t* b, size_t n) {
     Layer l; l.kind = (LayerKind)rd();
     if (l.kind == L_DENSE) { l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); l.weights.assign(b + pos, b + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols; l.bias.assign(b + pos, b + pos + l.nrows); pos += l.nrows; }
     else if (l.kind == L_MATMUL) {
-      l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); size_t hb = (size_t)rd();
+      l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); size_t fl = (size_t)rd(); const size_t hb = fl & 1; l.transpose_b = (fl & 2) != 0;
       if (l.nrows == 0 || l.ncols == 0 || l.nrows > n || l.ncols > n || pos + l.nrows * l.ncols + (hb ? l.ncols : 0) > n) throw std::runtime_error("model blob truncated");
       l.weights.assign(b + pos, b + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols;
       if (hb) { l.bias.assign(b + pos, b + pos + l.ncols); pos += l.ncols; }

@@ -175,6 +175,7 @@ struct Layer {
   // dense (padded to powers of two). matmul (layers/matrix_mul.rs, MatMul::new_constant: Input x Weight [+ bias]): the constant RIGHT
   // matrix is [nrows][ncols] row major, the input a row-major [s][nrows] matrix, bias [ncols] or empty
   size_t nrows = 0, ncols = 0;
+  bool transpose_b = false;  // matmul, Config::TransposeB (matrix_mul.rs:36-39): the constant matrix is stored as [ncols][nrows] and used transposed
   std::vector<int64_t> weights, bias;  // dense: row major, bias padded to nrows; conv: filter [kw][kx][real_nw][real_nw], bias [kw]
   // conv (layers/convolution.rs:52-83, tensor.rs:409-431): padded filter count kw, padded input channels kx, padded
   // kernel side real_nw, padded input side nw (= n_x of fft_conv); unp_out = conv2d_shape of the UNPADDED tensors
@@ -339,7 +340,7 @@ static inline Trace run_model(const Model& m, const std::vector<int64_t>& input)
       if (cur.size() % k) throw std::runtime_error("matmul input size mismatch");
       const size_t s_ = cur.size() / k;
       o.assign(s_ * n, 0);
-      for (size_t i = 0; i < s_; i++) for (size_t j = 0; j < n; j++) { int64_t a = 0; for (size_t q = 0; q < k; q++) a += cur[i * k + q] * l.weights[q * n + j]; o[i * n + j] = a + (l.bias.empty() ? 0 : l.bias[j]); }
+      for (size_t i = 0; i < s_; i++) for (size_t j = 0; j < n; j++) { int64_t a = 0; for (size_t q = 0; q < k; q++) a += cur[i * k + q] * (l.transpose_b ? l.weights[j * k + q] : l.weights[q * n + j]); o[i * n + j] = a + (l.bias.empty() ? 0 : l.bias[j]); }
     } else if (l.kind == L_REQUANT) {
       for (int64_t v : cur) {
         if (std::llabs(v) > (int64_t(1) << l.intermediate_bit_size)) throw std::runtime_error("requant: value too large");
@@ -563,14 +564,16 @@ static inline Claim prove_matmul(ProverState& ps, size_t id, const Layer& l, con
   left.fix_high_in_place(pt_left);
   std::vector<E> w(l.weights.size()); for (size_t i = 0; i < w.size(); i++) w[i] = e_from_i64(l.weights[i]);
   Mle right = Mle::from_ext(w);
-  right.fix_low_in_place(pt_right);
+  // not transposed: [k][n], the column variables are the LOW ones; transposed: stored [n][k], the variables of its rows are the HIGH ones (:815-824)
+  if (l.transpose_b) right.fix_high_in_place(pt_right); else right.fix_low_in_place(pt_right);
   if (left.nv != right.nv) throw std::runtime_error("matmul: inner dimensions differ");
   VirtualPolynomial vp(left.nv);
   vp.add_mle_list({mk(left), mk(right)}, e_one());
   auto [proof, st] = sumcheck_prove(std::move(vp), *ps.t);
   std::vector<E> fin = st.final_evaluations();
   std::vector<E> point_left = proof.point; point_left.insert(point_left.end(), pt_left.begin(), pt_left.end());
-  std::vector<E> point_right = pt_right; point_right.insert(point_right.end(), proof.point.begin(), proof.point.end());
+  std::vector<E> point_right = l.transpose_b ? proof.point : pt_right;
+  if (l.transpose_b) point_right.insert(point_right.end(), pt_right.begin(), pt_right.end()); else point_right.insert(point_right.end(), proof.point.begin(), proof.point.end());
   // add_common_claims iterates the node's BTreeMap: "MatMulBias" then "MatMulWeight"
   const auto& comms = ps.ctx->model_comms.at(id);
   if (hb) ps.add_witness_claim(comms.at("MatMulBias"), {pt_right, bias_eval});

@@ -22,7 +22,7 @@ static int64_t rq() { return (int64_t)(rnd() % 255) - 127; }
 
 static dp::LayerSpec dense(size_t r, size_t c) { dp::LayerSpec l; l.kind = dp::L_DENSE; l.nrows = r; l.ncols = c; l.weights.resize(r * c); for (auto& x : l.weights) x = rq(); l.bias.resize(r); for (auto& x : l.bias) x = rq(); return l; }
 // MatMul with a constant right matrix [k][n] (layers/matrix_mul.rs, MatMul::new_constant) over a [s][k] activation
-static dp::LayerSpec matmul(size_t k, size_t n, bool bias) { dp::LayerSpec l; l.kind = dp::L_MATMUL; l.nrows = k; l.ncols = n; l.weights.resize(k * n); for (auto& x : l.weights) x = rq(); if (bias) { l.bias.resize(n); for (auto& x : l.bias) x = rq(); } return l; }
+static dp::LayerSpec matmul(size_t k, size_t n, bool bias, bool transpose = false) { dp::LayerSpec l; l.kind = dp::L_MATMUL; l.nrows = k; l.ncols = n; l.mm_transpose = transpose; l.weights.resize(k * n); for (auto& x : l.weights) x = rq(); if (bias) { l.bias.resize(n); for (auto& x : l.bias) x = rq(); } return l; }
 static dp::LayerSpec requant_for(size_t ncols, double m) {
   // Requant::from_multiplier (requant.rs:409-437) with double arithmetic (front-end, out of scope for parity)
   dp::LayerSpec l; l.kind = dp::L_REQUANT;
@@ -34,7 +34,7 @@ static dp::LayerSpec requant_for(size_t ncols, double m) {
 }
 static orc::Model to_orc(const dp::ModelSpec& m) {
   orc::Model o; o.input_len = m.input_len;
-  for (auto& l : m.layers) { orc::Layer x; x.kind = (orc::LayerKind)l.kind; x.nrows = l.nrows; x.ncols = l.ncols; x.weights = l.weights; x.bias = l.bias; x.right_shift = l.right_shift; x.fp_scale = l.fp_scale; x.intermediate_bit_size = l.intermediate_bit_size; x.fixed_point_multiplier = l.fixed_point_multiplier;
+  for (auto& l : m.layers) { orc::Layer x; x.kind = (orc::LayerKind)l.kind; x.nrows = l.nrows; x.ncols = l.ncols; x.weights = l.weights; x.bias = l.bias; x.transpose_b = l.mm_transpose; x.right_shift = l.right_shift; x.fp_scale = l.fp_scale; x.intermediate_bit_size = l.intermediate_bit_size; x.fixed_point_multiplier = l.fixed_point_multiplier;
     x.kw = l.kw; x.kx = l.kx; x.real_nw = l.real_nw; x.nw = l.nw; for (int k = 0; k < 3; k++) { x.unp_out[k] = l.unp_out[k]; x.pin[k] = l.pin[k]; }
     o.layers.push_back(x); }
   return o;
@@ -247,7 +247,7 @@ int main(int argc, char** argv) {
     m.input_len = S * F;
     m.layers.push_back(matmul(F, H, true)); m.layers.push_back(requant_for(F, 0.5 / 127)); m.layers.push_back(relu);
     m.layers.push_back(matmul(H, H, true)); m.layers.push_back(requant_for(H, 1.0 / std::sqrt((double)H) / 127)); m.layers.push_back(relu);
-    m.layers.push_back(matmul(H, F, false)); m.layers.push_back(requant_for(H, 1.0 / std::sqrt((double)H) / 127)); m.layers.push_back(relu);
+    m.layers.push_back(matmul(H, F, false, getenv("HL_TRANSPOSE") != nullptr)); m.layers.push_back(requant_for(H, 1.0 / std::sqrt((double)H) / 127)); m.layers.push_back(relu);
     in.resize(S * F); for (auto& x : in) x = rq();
   } else {
     m.layers.push_back(dense(W, 4)); m.layers.push_back(requant_for(4, 0.5 / 127)); m.layers.push_back(relu);

@@ -199,12 +199,12 @@ def test_batch_verifier_with_device_side_merkle_paths(dev):
     ctx.free()
 
 
-@pytest.mark.parametrize("seq,width", [(8, 16), (16, 64), (64, 256)])
-def test_matmul_model_proof_bytes_identical_to_oracle(dev, oracle, seq, width):
+@pytest.mark.parametrize("seq,width,transpose", [(8, 16, False), (16, 64, True), (64, 256, False), (32, 128, True)])
+def test_matmul_model_proof_bytes_identical_to_oracle(dev, oracle, seq, width, transpose):
     """MatMul with a constant right matrix over a [seq][features] activation (layers/matrix_mul.rs; k_fix_low on the weights,
     fix_high on the activation, the degree-2 sumcheck): proof stream == the oracle's, the verifier accepts, numpy inference agrees"""
     import deep_prove_amd as dpa
-    mb = dpa.models.seq_mlp(seq, width, config=60 + seq)
+    mb = dpa.models.seq_mlp(seq, width, config=60 + seq, transpose_last=transpose)  # (Config::TransposeB on the last MatMul)
     x = mb.input()
     ctx, proof, out, oproof, oout = prove_both(dev, oracle, mb, x)
     assert (out == oout).all() and (out == mb.run(x)).all()
