@@ -270,6 +270,12 @@ def seq_mlp(seq, width, config, input_features=4, output_features=3, layers=2, t
     return mb
 
 
+def seq_1m():
+    """a sequence of 64 tokens through two 1024-wide Linear layers (MatMul + bias + Requant + ReLU) and a 1024 -> 3 head: 1.05 M
+    parameters, 2^16-row lookups per block — the MatMul workload of DESIGN.md section 6"""
+    return seq_mlp(64, 1024, config=5, layers=2)
+
+
 def dense_4m():
     """BASELINE config 2: 'Dense 4M' = mlp.py --num-dense 5 --layer-width 1024 (4.21 M parameters)"""
     return mlp(5, 1024, config=2)
