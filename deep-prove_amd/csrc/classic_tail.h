@@ -17,6 +17,7 @@ struct ClassicTailDesc {
   int np, has_r; unsigned num_vars, round;
   Ext r, sum;
   u64 state[8]; u64 in_buf[4]; int in_len, out_len;
+  u64* sp_req; const u64* sp_rep; unsigned long long sp_seq;  // host sponge (sponge_host.h): mapped request / reply areas of this proof and the last sequence number served; null: the sponge runs on the device from `state`
   u64 lab[2];  // "sumcheck round"
 };
 

@@ -32,6 +32,7 @@ struct CommitTailDesc {
   const u64* tw; unsigned L;                        // tw[i] = w_{2^(L+1)}^i, i < 2^L (the RS parameters of the context)
   Ext* eqA; Ext* eqB; Ext* fA; Ext* fB;             // ping-pong of the folded sumcheck pairs
   u64 state[8]; u64 in_buf[4]; int in_len, out_len;
+  u64* sp_req; const u64* sp_rep; unsigned long long sp_seq;  // host sponge (sponge_host.h): mapped request / reply areas of this proof and the last sequence number served; null: the sponge runs on the device from `state`
   u64 lab[2];                                       // "commit round"
 };
 

@@ -14,6 +14,7 @@ struct EqSumDesc {
   int tk[ES_MAXTERM]; int tt[ES_MAXTERM][3]; Ext coeff[ES_MAXTERM];
   int njobs, ntabs, nterms; unsigned nv, md;
   u64 state[8]; u64 in_buf[4]; int in_len, out_len;
+  u64* sp_req; const u64* sp_rep; unsigned long long sp_seq;  // host sponge (sponge_host.h): mapped request / reply areas of this proof and the last sequence number served; null: the sponge runs on the device from `state`
   u64 lab_round[2];  // "Internal round"
 };
 

@@ -16,6 +16,7 @@
 #include "dense_tail.h"
 #include "eqsum_tail.h"
 #include "commit_tail.h"
+#include "sponge_host.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -1109,6 +1110,17 @@ KBODY k_sc_small(const ScSmallArgs& a, Ext* result, unsigned long long* flag, un
 // round messages, all challenges, the final evaluations and the sponge state back to the host transcript.
 // Field arithmetic is exact and canonical, so the messages and challenges are the host's bit for bit.
 // The sponge runs on wave 0 with the lane-parallel permutation (p2l_permute: state[i] in lane i of every group of 8).
+// the reply poll of wc_request: bounded in time like sc_wait_challenge (the emulator of tests/ defines both macros itself and serves
+// the request from inside the poll)
+#ifndef WC_POLL_PAUSE
+#define WC_POLL_BEGIN const unsigned long long wc_t0 = dp_realtime();
+#define WC_POLL_PAUSE(spin) wc_poll_pause(wc_t0, spin)
+__device__ __forceinline__ bool wc_poll_pause(unsigned long long t0, unsigned spin) {
+  if ((spin & 63) == 63 && dp_realtime() - t0 > c_poll_timeout_ticks) return true;
+  for (int q = 0; q < c_poll_sleep; q++) __builtin_amdgcn_s_sleep(4);
+  return false;
+}
+#endif
 struct ScFsArgs {
   u64 state[8]; u64 in_buf[4]; int in_len, out_len;  // the host Challenger at the start of the first round
   int md, rounds;                                    // max_degree of the virtual polynomial, rounds the kernel runs
@@ -1116,7 +1128,44 @@ struct ScFsArgs {
   Ext coeff[MAX_TERMS];                              // coefficient of every product term
 };
 __constant__ u64 c_extrap[(SC_MAXK + 1) * (SC_MAXK + 1) * (SC_MAXK + 1)];  // [k][at][i]: extrapolation_coeffs(k, at)[i] of sumcheck.h
-struct WaveChallenger { u64 st, ib; int in_len, out_len; };
+// Host mode (req != nullptr, DP_HOST_SPONGE=1; sponge_host.h): the sponge stays in the host transcript. Observed words are staged in the
+// mapped request area by lane 0; a sample posts the request (tag = sequence + checksum: the host re-reads until it is complete) and
+// every lane polls the reply area for the sponge's output buffer (uniform decision: the tag and length lane 0 read, the four outputs
+// lanes 0..3 read, validated by the reply's own tag). 2.9 us per round trip against ~12 us per permutation on an 8-lane wave.
+struct WaveChallenger {
+  u64 st, ib; int in_len, out_len;
+  u64* req = nullptr; const u64* rep = nullptr; unsigned n = 0, consumed = 0, failed = 0; unsigned long long rseq = 0, cs = 0; u64 cache = 0;
+};
+__device__ __forceinline__ void wc_host_init(WaveChallenger& c, u64* req, const u64* rep, unsigned long long seq0) {
+  c.req = req; c.rep = rep; c.rseq = seq0; c.n = c.consumed = c.failed = 0; c.cs = 0; c.cache = 0;
+  if (req) c.out_len = 0;  // nothing cached: the first sample asks the host
+}
+__device__ __forceinline__ void wc_request(WaveChallenger& c, int lane, int want) {
+  c.rseq++;
+  if (lane == 0) {
+    pub_store(c.req + 1, (u64)c.n); pub_store(c.req + 2, (u64)c.consumed); pub_store(c.req + 3, (u64)want);
+    pub_store(c.req, wc_req_mix(c.rseq) + c.cs + 3ull * c.n + 5ull * c.consumed + 7ull * (u64)want);
+  }
+  const unsigned long long base = wc_rep_mix(c.rseq);
+  u64 ol = 0, o = 0;
+  bool ok = false;
+  WC_POLL_BEGIN
+  for (unsigned spin = 0;; spin++) {
+    u64 tag = __hip_atomic_load(c.rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    ol = __hip_atomic_load(c.rep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    o = __hip_atomic_load(c.rep + 2 + (lane & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    tag = shfl_u64(tag, 0); ol = shfl_u64(ol, 0);
+    const u64 w = o * (u64)((lane & 3) + 1);
+    const u64 sum = ol + shfl_u64(w, 0) + shfl_u64(w, 1) + shfl_u64(w, 2) + shfl_u64(w, 3);
+    if (tag == base + sum && ol <= 4) { ok = true; break; }
+    if (WC_POLL_PAUSE(spin)) break;
+  }
+  c.n = 0; c.cs = 0; c.consumed = 0;
+  if (ok) { c.out_len = (int)ol; c.cache = o; } else { c.failed = 1; c.out_len = 4; c.cache = 0; }
+}
+// end of a kernel: the words observed since the last sample, and the samples popped since the last reply, reach the host before the
+// kernel's own message does (the host transcript is complete when the proof's thread sees that message)
+__device__ __forceinline__ void wc_finish(WaveChallenger& c, int lane) { if (c.req) wc_request(c, lane, 0); }
 __device__ __forceinline__ void wc_duplex(WaveChallenger& c, int lane) {
   if ((lane & 7) < c.in_len) c.st = c.ib;
   c.in_len = 0;
@@ -1124,11 +1173,22 @@ __device__ __forceinline__ void wc_duplex(WaveChallenger& c, int lane) {
   c.out_len = 4;
 }
 __device__ __forceinline__ void wc_observe(WaveChallenger& c, u64 v, int lane) {  // v uniform over the wave
+  if (c.req) {
+    c.out_len = 0;
+    if (lane == 0) { pub_store(c.req + 4 + c.n, v); c.cs += (unsigned long long)(c.n + 1) * v; }
+    if (++c.n == WC_REQ_CAP) wc_request(c, lane, 0);
+    return;
+  }
   c.out_len = 0;
   if ((lane & 7) == c.in_len) c.ib = v;
   if (++c.in_len == 4) wc_duplex(c, lane);
 }
 __device__ __forceinline__ u64 wc_sample(WaveChallenger& c, int lane) {
+  if (c.req) {
+    if (c.n != 0 || c.out_len == 0) wc_request(c, lane, 1);
+    --c.out_len; c.consumed++;
+    return shfl_u64(c.cache, c.out_len);
+  }
   if (c.in_len != 0 || c.out_len == 0) wc_duplex(c, lane);
   --c.out_len;
   return shfl_u64(c.st, c.out_len);
@@ -1367,6 +1427,7 @@ KBODY k_logup_tail(const LogupTailDesc* dp, u64* result, unsigned long long* fla
   }
   WaveChallenger wc;
   wc.st = dl.state[lane & 7]; wc.ib = dl.in_buf[lane & 3]; wc.in_len = dl.in_len; wc.out_len = dl.out_len;
+  wc_host_init(wc, dl.sp_req, dl.sp_rep, dl.sp_seq);
   unsigned long long fcs = 0;
   size_t wbase = 0;
   __syncthreads();
@@ -1601,7 +1662,8 @@ KBODY k_logup_tail(const LogupTailDesc* dp, u64* result, unsigned long long* fla
       fcs += (unsigned long long)13 * a + (unsigned long long)14 * b;
     }
     fcs = pub_wave_sum(fcs);
-    if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + fcs);
+    wc_finish(wc, lane);  // (host sponge: the transcript is complete before this message is)
+    if (lane == 0) pub_store((u64*)flag, wc.failed ? ~0ull : pub_mix(seq) + fcs);
 #ifdef DP_WG_TIMES
     if (tid == 0) dbg_wg_record(dbg_t_in);
 #endif
@@ -1631,6 +1693,7 @@ KBODY k_classic_tail(const ClassicTailDesc* dp, u64* result, unsigned long long*
   for (int i = tid; i < np; i += nt) { curf[i] = dl.f[i]; cure[i] = dl.eq[i]; clen[i] = dl.len[i]; cext[i] = dl.f_ext[i]; toA[i] = 1; }
   WaveChallenger wc;
   wc.st = dl.state[lane & 7]; wc.ib = dl.in_buf[lane & 3]; wc.in_len = dl.in_len; wc.out_len = dl.out_len;
+  wc_host_init(wc, dl.sp_req, dl.sp_rep, dl.sp_seq);
   unsigned long long fcs = 0;
   const int R = (int)(dl.num_vars - dl.round);
   Ext r = dl.r, sum = dl.sum;
@@ -1723,7 +1786,8 @@ KBODY k_classic_tail(const ClassicTailDesc* dp, u64* result, unsigned long long*
       fcs += (unsigned long long)13 * a + (unsigned long long)14 * b;
     }
     fcs = pub_wave_sum(fcs);
-    if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + fcs);
+    wc_finish(wc, lane);  // (host sponge: the transcript is complete before this message is)
+    if (lane == 0) pub_store((u64*)flag, wc.failed ? ~0ull : pub_mix(seq) + fcs);
   }
 }
 
@@ -1746,6 +1810,7 @@ KBODY k_dense_tail(const DenseTailDesc* dp, u64* result, unsigned long long* fla
   if (tid == 0) { fsl.md = 2; fsl.rounds = (int)dl.lgC; fsl.label[0] = dl.lab_round[0]; fsl.label[1] = dl.lab_round[1]; fsl.nlabel = 2; fsl.pad = 0; fsl.coeff[0] = ex_one(); tk[0] = 2; }
   WaveChallenger wc;
   wc.st = dl.state[lane & 7]; wc.ib = dl.in_buf[lane & 3]; wc.in_len = dl.in_len; wc.out_len = dl.out_len;
+  wc_host_init(wc, dl.sp_req, dl.sp_rep, dl.sp_seq);
   unsigned long long fcs = 0;
   const size_t R = dl.R, C = dl.C;
   wg_build_eq(dl.eqr, dl.pt, (int)dl.lgR);  // eq(point, .) over the rows (ends with a barrier)
@@ -1812,7 +1877,8 @@ KBODY k_dense_tail(const DenseTailDesc* dp, u64* result, unsigned long long* fla
       fcs += (unsigned long long)13 * a + (unsigned long long)14 * b;
     }
     fcs = pub_wave_sum(fcs);
-    if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + fcs);
+    wc_finish(wc, lane);  // (host sponge: the transcript is complete before this message is)
+    if (lane == 0) pub_store((u64*)flag, wc.failed ? ~0ull : pub_mix(seq) + fcs);
   }
 }
 
@@ -1837,6 +1903,7 @@ KBODY k_eqsum_tail(const EqSumDesc* dp, u64* result, unsigned long long* flag, u
   for (int i = tid; i < ntab; i += nt) { cur[i] = dl.tab[i]; cur_ext[i] = dl.tab_ext[i]; }
   WaveChallenger wc;
   wc.st = dl.state[lane & 7]; wc.ib = dl.in_buf[lane & 3]; wc.in_len = dl.in_len; wc.out_len = dl.out_len;
+  wc_host_init(wc, dl.sp_req, dl.sp_rep, dl.sp_seq);
   unsigned long long fcs = 0;
   const size_t n0 = size_t(1) << dl.nv;
   // the eq tables, in order: out[idx] (+)= scale * prod_t (idx_t ? pt[t] : 1 - pt[t])
@@ -1904,7 +1971,8 @@ KBODY k_eqsum_tail(const EqSumDesc* dp, u64* result, unsigned long long* flag, u
       fcs += (unsigned long long)13 * a + (unsigned long long)14 * b;
     }
     fcs = pub_wave_sum(fcs);
-    if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + fcs);
+    wc_finish(wc, lane);  // (host sponge: the transcript is complete before this message is)
+    if (lane == 0) pub_store((u64*)flag, wc.failed ? ~0ull : pub_mix(seq) + fcs);
   }
 }
 
@@ -1927,6 +1995,7 @@ KBODY k_commit_tail(const CommitTailDesc* dp, u64* result, unsigned long long* f
   if (tid < 3) s_last[tid] = dl.last[tid];
   WaveChallenger wc;
   wc.st = dl.state[lane & 7]; wc.ib = dl.in_buf[lane & 3]; wc.in_len = dl.in_len; wc.out_len = dl.out_len;
+  wc_host_init(wc, dl.sp_req, dl.sp_rep, dl.sp_seq);
   unsigned long long fcs = 0;
   const Ext* prev = dl.folded;   // the folded oracle of the previous round
   const Ext* eq = dl.eq;
@@ -2081,7 +2150,8 @@ KBODY k_commit_tail(const CommitTailDesc* dp, u64* result, unsigned long long* f
       fcs += (unsigned long long)13 * a + (unsigned long long)14 * b;
     }
     fcs = pub_wave_sum(fcs);
-    if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + fcs);
+    wc_finish(wc, lane);  // (host sponge: the transcript is complete before this message is)
+    if (lane == 0) pub_store((u64*)flag, wc.failed ? ~0ull : pub_mix(seq) + fcs);
   }
 }
 
@@ -2766,6 +2836,7 @@ class HipDev : public Dev {
         for (size_t i = 0; i < nwords; i++) cs += (unsigned long long)(i + 1) * w[i];
         if (base + cs == tag) { last_tag_ = tag; desc_off_ = 0; stage_off_ = 0; if (co_ && co_li_) co_->note_executed(co_li_ - 1); wait_exit_(t0); return; }
       }
+      sponge_serve_all();  // (host sponge: a waiting thread serves the requests of every proof in flight)
       // inside a fiber the wait hands the host thread to the next proof in flight (fiber.h); otherwise spin
       const bool fib = fiber_active();
       if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
@@ -2789,6 +2860,7 @@ class HipDev : public Dev {
         const unsigned long long cs = logup_tail_checksum(w, block_words);
         if (base + cs == tag) { last_tag_ = tag; desc_off_ = 0; stage_off_ = 0; if (co_ && co_li_) co_->note_executed(co_li_ - 1); wait_exit_(t0); return; }
       }
+      sponge_serve_all();  // (host sponge: a waiting thread serves the requests of every proof in flight)
       const bool fib = fiber_active();
       if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
       if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
@@ -2867,6 +2939,13 @@ class HipDev : public Dev {
     HIP_CHECK(hipMalloc((void**)&arena_, arena_cap_));
     HIP_CHECK(hipHostMalloc((void**)&hres_, RES_WORDS * 8 + 1024, hipHostMallocMapped | hipHostMallocCoherent));
     HIP_CHECK(hipHostGetDevicePointer((void**)&hres_dev_, hres_, 0));
+    if (host_sponge_) {  // request + reply areas of the host-side sponge service (sponge_host.h)
+      HIP_CHECK(hipHostMalloc((void**)&hsp_, (WC_REQ_WORDS + WC_REP_WORDS) * 8, hipHostMallocMapped | hipHostMallocCoherent));
+      memset(hsp_, 0, (WC_REQ_WORDS + WC_REP_WORDS) * 8);
+      HIP_CHECK(hipHostGetDevicePointer((void**)&hsp_dev_, hsp_, 0));
+      sp_slot_ = sponge_slot_new();
+      sp_slot_->req = hsp_; sp_slot_->rep = hsp_ + WC_REQ_WORDS;
+    }
     hflag_ = (unsigned long long*)(hres_ + RES_WORDS);
     hflag_dev_ = (unsigned long long*)(hres_dev_ + RES_WORDS);
     *hflag_ = 0;
@@ -2916,6 +2995,8 @@ class HipDev : public Dev {
     if (arena_) hipFree(arena_);
     if (dres_) hipFree(dres_);
     if (fused_ticket_) hipFree(fused_ticket_);
+    if (sp_slot_) { sponge_disarm_(); sp_slot_->req = sp_slot_->rep = nullptr; }
+    if (hsp_) hipHostFree(hsp_);
     if (hres_) hipHostFree(hres_);
     if (hstage_) hipHostFree(hstage_);
     if (s_) hipStreamDestroy(s_);
@@ -3293,6 +3374,33 @@ class HipDev : public Dev {
   // Validated on MI355X in round 2 (tests/test_gpu_fused.py: every knob alone and all together, Dense-4M and CNN-264k batches
   // against the sequential proofs; profiles/r02_fused_knob_sweep.jsonl).
   static int knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+  // ---- DP_HOST_SPONGE=1 (sponge_host.h): the fused protocol kernels keep the transcript's sponge on the HOST — a kernel posts the
+  // words it absorbs and asks for challenges through a mapped mailbox, any host thread waiting for the device serves the requests of
+  // any proof. Off by default: new at the end of round 2 (the wave sponge costs ~12 us per permutation, the mailbox 2.9 us per round trip).
+  bool host_sponge_ = knob("DP_HOST_SPONGE", 0) != 0;
+  SpongeSlot* sp_slot_ = nullptr; u64* hsp_ = nullptr; u64* hsp_dev_ = nullptr; bool sp_active_ = false;
+  void sponge_disarm_() {
+    if (!sp_active_) return;
+    while (sp_slot_->busy.load(std::memory_order_acquire)) __builtin_ia32_pause();
+    sp_slot_->active.store(0, std::memory_order_release);
+    while (sp_slot_->busy.load(std::memory_order_acquire)) __builtin_ia32_pause();  // a server that had passed the first check
+    sponge_nactive().fetch_sub(1);
+    sp_slot_->ch = nullptr; sp_active_ = false;
+  }
+  // between the descriptor fill and the launch: point the kernel at this context's mailbox and the service at the transcript; after the
+  // wait the transcript is final (done()); the parse functions overwrite it with the kernel's unused sponge words (restore())
+  struct SpongeArm {
+    HipDev* dev; Challenger* ch; bool armed = false; Challenger fin;
+    template <class D> SpongeArm(HipDev* dv, D* d, Challenger& c) : dev(dv), ch(&c) {
+      if (!dv->host_sponge_ || !dv->sp_slot_) return;
+      d->sp_req = dv->hsp_dev_; d->sp_rep = dv->hsp_dev_ + WC_REQ_WORDS; d->sp_seq = dv->sp_slot_->served;
+      dv->sp_slot_->ch = &c; dv->sp_slot_->active.store(1, std::memory_order_release); sponge_nactive().fetch_add(1); dv->sp_active_ = true;
+      armed = true;
+    }
+    void done() { if (armed) { dev->sponge_disarm_(); fin = *ch; } }
+    void restore() { if (armed) { *ch = fin; armed = false; } }
+    ~SpongeArm() { if (armed) dev->sponge_disarm_(); }
+  };
   bool devlogup_ = knob("DP_DEVICE_LOGUP", 2) == 1;
   size_t nlogup_tail_ = 0;
   bool logup_tail(const LogupTailArgs& a, Challenger& ch, std::vector<std::vector<std::vector<Ext>>>& layer_msgs,
@@ -3307,11 +3415,14 @@ class HipDev : public Dev {
     const LogupTailDesc* dd = nullptr;
     LogupTailDesc* d = desc_alloc<LogupTailDesc>(1, &dd);
     logup_tail_fill(d, a, ch, *this);
+    SpongeArm sponge(this, d, ch);
     const unsigned long long seq = ++seq_;
     nb_ = 0; for (const LogupCircuitDev& c : *a.circuits) for (const DBuf& l : c.den) nb_ += 2.0 * 16.0 * (double)l.n;
     DPL_ONE(k_logup_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
+    sponge.done();
     logup_tail_parse(hres_, a, blocks, ch, layer_msgs, layer_points, round_evals, point);
+    sponge.restore();
     release(mk);
     nlogup_tail_++;
     return true;
@@ -3329,11 +3440,14 @@ class HipDev : public Dev {
     CommitTailDesc fill;
     commit_tail_fill(&fill, a, ch, *this, (const u64*)tw_, L_, trees);  // (the trees stay allocated: the query phase reads them)
     memcpy((void*)d, &fill, sizeof(CommitTailDesc));
+    SpongeArm sponge(this, d, ch);
     const unsigned long long seq = ++seq_;
     nb_ = 16.0 * (double)a.folded.n * 2.0 + 32.0 * (double)a.sum_evals.n;
     DPL_ONE(k_commit_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
+    sponge.done();
     commit_tail_parse(hres_, a, ch, trees, out);
+    sponge.restore();
     return true;
   }
   // ---- Dev::eqsum_tail: DP_DEVICE_EQSUM (default on): k_eqsum_tail, eq tables + accumulation sumcheck in one launch
@@ -3349,11 +3463,14 @@ class HipDev : public Dev {
     const EqSumDesc* dd = nullptr;
     EqSumDesc* d = desc_alloc<EqSumDesc>(1, &dd);
     eqsum_tail_fill(d, jobs, njobs, tabs, ntabs, terms, coeffs, nterms, nv, md, ch, *this);
+    SpongeArm sponge(this, d, ch);
     const unsigned long long seq = ++seq_;
     nb_ = 0; for (int i = 0; i < ntabs; i++) nb_ += (double)tabs[i].bytes();
     DPL_ONE(k_eqsum_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
+    sponge.done();
     eqsum_tail_parse(hres_, ntabs, nv, md, ch, out);
+    sponge.restore();
     release(mk);
     return true;
   }
@@ -3368,11 +3485,14 @@ class HipDev : public Dev {
     const DenseTailDesc* dd = nullptr;
     DenseTailDesc* d = desc_alloc<DenseTailDesc>(1, &dd);
     dense_tail_fill(d, bias, W, R, C, in, pt, ch, *this);
+    SpongeArm sponge(this, d, ch);
     const unsigned long long seq = ++seq_;
     nb_ = 8.0 * (double)R * (double)C + 16.0 * (double)R + 16.0 * (double)C * 4.0;
     DPL_ONE(k_dense_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
+    sponge.done();
     dense_tail_parse(hres_, C, ch, out);
+    sponge.restore();
     release(mk);
     return true;
   }
@@ -3387,11 +3507,14 @@ class HipDev : public Dev {
     const ClassicTailDesc* dd = nullptr;
     ClassicTailDesc* d = desc_alloc<ClassicTailDesc>(1, &dd);
     classic_tail_fill(d, a, ch, *this);
+    SpongeArm sponge(this, d, ch);
     const unsigned long long seq = ++seq_;
     nb_ = 0; for (int i = 0; i < a.np; i++) nb_ += a.fs[i].bytes() + a.eqs[i].bytes();
     DPL_ONE(k_classic_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
+    sponge.done();
     classic_tail_parse(hres_, a, ch, msgs, challenges);
+    sponge.restore();
     release(mk);
     return true;
   }
@@ -3410,11 +3533,14 @@ class HipDev : public Dev {
     const LogupTailDesc* dd = nullptr;
     LogupTailDesc* d = desc_alloc<LogupTailDesc>(1, &dd);
     logup_full_fill(d, cols, cpi, ninst, mult, c, chi, ch, *this);
+    SpongeArm sponge(this, d, ch);
     const unsigned long long seq = ++seq_;
     nb_ = (double)ninst * (8.0 * cpi * n + 16.0 * 3 * n) * 2.0;
     DPL_ONE(k_logup_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
+    sponge.done();
     logup_full_parse(hres_, n, cpi, ninst, !mult.null(), blocks, ch, out);
+    sponge.restore();
     release(mk);
     nlogup_tail_++;
     return true;

@@ -20,6 +20,7 @@ struct LogupTailDesc {
   int ninst, nlayers, total_layers, is_table;
   Ext batching, alpha, lambda, claim;
   u64 state[8]; u64 in_buf[4]; int in_len, out_len;
+  u64* sp_req; const u64* sp_rep; unsigned long long sp_seq;  // host sponge (sponge_host.h): mapped request / reply areas of this proof and the last sequence number served; null: the sponge runs on the device from `state`
   u64 lab_round[2], lab_batching[2], lab_alpha[2], lab_lambda[2];
   // full mode (Dev::logup_full): the kernel also builds the trees, absorbs the outputs, draws the initial challenges and
   // evaluates the columns at the final point; num / den above are then derived from den_all / num_all by the kernel

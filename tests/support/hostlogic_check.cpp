@@ -291,6 +291,7 @@ int main(int argc, char** argv) {
   printf("emulated k_dense_tail: %zu dense layers taken\n", dev.dense_taken);
   printf("emulated k_eqsum_tail: %zu eq + sumcheck groups taken\n", dev.eqsum_taken);
   printf("emulated k_commit_tail: %zu commit-phase tails taken (%zu rounds, %zu codewords merged)\n", dev.commit_taken, dev.commit_rounds_run, dev.commit_merged);
+  printf("host sponge service: %zu kernels ran with their sponge on the host, %zu requests served\n", dev.sponge.served_total, dev.sponge.requests());
 #endif
   if (dev.device_commit) printf("commit_tail: %zu commit-phase tails taken by the double\n", dev.commit_tails);
   if (dev.device_eqsum) printf("eqsum_tail: %zu eq + sumcheck groups taken by the double\n", dev.eqsum_tails);

@@ -9,7 +9,11 @@
 #include "../../../deep-prove_amd/csrc/dense_tail.h"
 #include "../../../deep-prove_amd/csrc/eqsum_tail.h"
 #include "../../../deep-prove_amd/csrc/commit_tail.h"
+#include "../../../deep-prove_amd/csrc/sponge_host.h"
 #include "simt.hpp"
+// the reply poll of the device's WaveChallenger in host mode: on the emulator the "host" serves the request from inside the poll
+#define WC_POLL_BEGIN
+#define WC_POLL_PAUSE(spin) (dp::sponge_serve_all(), (spin) > 1000000u)
 #include <cstdio>
 
 namespace dp {
@@ -23,7 +27,23 @@ inline void emul_init_constants() {
 }
 
 // the test double with Dev::logup_tail served by the emulated kernel
+// DP_EMUL_HOST_SPONGE=1: the emulated kernels run their WaveChallenger in HOST mode (sponge_host.h) — requests served from inside the
+// kernel's reply poll (WC_POLL_PAUSE above) by the same service the product's waiting threads run
+struct EmulSponge {
+  std::vector<u64> area; SpongeSlot* slot = nullptr; Challenger* ch = nullptr; Challenger fin; bool armed = false;
+  template <class D> void arm(D& d, Challenger& c) {
+    if (!getenv("DP_EMUL_HOST_SPONGE")) return;
+    if (!slot) { area.assign(WC_REQ_WORDS + WC_REP_WORDS, 0); slot = sponge_slot_new(); slot->req = area.data(); slot->rep = area.data() + WC_REQ_WORDS; }
+    d.sp_req = area.data(); d.sp_rep = area.data() + WC_REQ_WORDS; d.sp_seq = slot->served;
+    slot->ch = &c; ch = &c; slot->active.store(1); sponge_nactive().fetch_add(1); armed = true;
+  }
+  void done() { if (armed) { slot->active.store(0); sponge_nactive().fetch_sub(1); fin = *ch; } }
+  void restore() { if (armed) { *ch = fin; armed = false; served_total += 1; } }
+  size_t served_total = 0;
+  size_t requests() const { return slot ? (size_t)slot->nserved.load() : 0; }
+};
 struct EmulDev : CpuDev {
+  EmulSponge sponge;
   unsigned threads = 64;
   size_t taken = 0, declined = 0;
   bool full = false;  // serve Dev::logup_full (the kernel's full mode) instead of Dev::logup_tail
@@ -54,6 +74,7 @@ struct EmulDev : CpuDev {
     CommitTailDesc d;
     std::vector<DevTree> trees;
     commit_tail_fill(&d, a, ch, *this, tw_.data(), L, trees);
+    sponge.arm(d, ch);
     std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
     unsigned long long flag = 0;
     const unsigned long long seq = 13000 + commit_taken;
@@ -61,7 +82,9 @@ struct EmulDev : CpuDev {
     simt::launch(threads, [&] { k_commit_tail(&d, res.data(), &flag, seq); });
     if (flag != pub_mix(seq) + logup_tail_checksum(res.data(), blocks)) { fprintf(stderr, "emul: commit tail: tag does not match the payload\n"); exit(3); }
     for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: commit tail wrote past its message\n"); exit(3); }
+    sponge.done();
     commit_tail_parse(res.data(), a, ch, trees, out);
+    sponge.restore();
     commit_taken++; commit_rounds_run += a.rounds_left;
     for (auto& mj : *a.merges) commit_merged += mj.size();
     return true;
@@ -76,6 +99,7 @@ struct EmulDev : CpuDev {
     const size_t mk = mark();
     EqSumDesc d;
     eqsum_tail_fill(&d, jobs, njobs, tabs, ntabs, terms, coeffs, nterms, nv, md, ch, *this);
+    sponge.arm(d, ch);
     std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
     unsigned long long flag = 0;
     const unsigned long long seq = 9000 + eqsum_taken;
@@ -83,7 +107,9 @@ struct EmulDev : CpuDev {
     simt::launch(threads, [&] { k_eqsum_tail(&d, res.data(), &flag, seq); });
     if (flag != pub_mix(seq) + logup_tail_checksum(res.data(), blocks)) { fprintf(stderr, "emul: eqsum tail: tag does not match the payload\n"); exit(3); }
     for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: eqsum tail wrote past its message\n"); exit(3); }
+    sponge.done();
     eqsum_tail_parse(res.data(), ntabs, nv, md, ch, out);
+    sponge.restore();
     release(mk);
     eqsum_taken++;
     return true;
@@ -97,6 +123,7 @@ struct EmulDev : CpuDev {
     const size_t mk = mark();
     DenseTailDesc d;
     dense_tail_fill(&d, bias, W, R, C, in, pt, ch, *this);
+    sponge.arm(d, ch);
     std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
     unsigned long long flag = 0;
     const unsigned long long seq = 5000 + dense_taken;
@@ -104,7 +131,9 @@ struct EmulDev : CpuDev {
     simt::launch(threads, [&] { k_dense_tail(&d, res.data(), &flag, seq); });
     if (flag != pub_mix(seq) + logup_tail_checksum(res.data(), blocks)) { fprintf(stderr, "emul: dense tail: tag does not match the payload\n"); exit(3); }
     for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: dense tail wrote past its message\n"); exit(3); }
+    sponge.done();
     dense_tail_parse(res.data(), C, ch, out);
+    sponge.restore();
     release(mk);
     dense_taken++;
     return true;
@@ -119,6 +148,7 @@ struct EmulDev : CpuDev {
     const size_t mk = mark();
     ClassicTailDesc d;
     classic_tail_fill(&d, a, ch, *this);
+    sponge.arm(d, ch);
     std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
     unsigned long long flag = 0;
     const unsigned long long seq = 1000 + classic_taken;
@@ -126,7 +156,9 @@ struct EmulDev : CpuDev {
     simt::launch(threads, [&] { k_classic_tail(&d, res.data(), &flag, seq); });
     if (flag != pub_mix(seq) + logup_tail_checksum(res.data(), blocks)) { fprintf(stderr, "emul: classic tail: tag does not match the payload\n"); exit(3); }
     for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: classic tail wrote past its message\n"); exit(3); }
+    sponge.done();
     classic_tail_parse(res.data(), a, ch, msgs, challenges);
+    sponge.restore();
     release(mk);
     classic_taken++;
     return true;
@@ -140,9 +172,12 @@ struct EmulDev : CpuDev {
     const size_t mk = mark();
     LogupTailDesc d;
     logup_full_fill(&d, cols, cpi, ninst, mult, c, chi, ch, *this);
+    sponge.arm(d, ch);
     std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
     run_kernel(d, res, blocks);
+    sponge.done();
     logup_full_parse(res.data(), n, cpi, ninst, !mult.null(), blocks, ch, out);
+    sponge.restore();
     release(mk);
     taken++;
     return true;
@@ -156,9 +191,12 @@ struct EmulDev : CpuDev {
     const size_t mk = mark();
     LogupTailDesc d;
     logup_tail_fill(&d, a, ch, *this);
+    sponge.arm(d, ch);
     std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
     run_kernel(d, res, blocks);
+    sponge.done();
     logup_tail_parse(res.data(), a, blocks, ch, layer_msgs, layer_points, round_evals, point);
+    sponge.restore();
     release(mk);
     taken++;
     return true;

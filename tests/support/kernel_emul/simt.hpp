@@ -5,6 +5,7 @@
 // hardware requires too.
 // It checks the LOGIC of a kernel (indices, layouts, transcript order, arithmetic), not memory-model or timing behaviour.
 #pragma once
+#include <type_traits>
 #include "../../../deep-prove_amd/csrc/fiber.h"
 #include <cstdint>
 #include <cstdio>
@@ -74,6 +75,7 @@ static struct { simt::Const x{1}, y{1}, z{1}; } gridDim;
 #define DP_CLAIM_ALL_VGPRS() ((void)0)
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
+#define __hip_atomic_load(p, order, scope) (*(volatile const std::remove_pointer_t<decltype(p)>*)(p))
 inline void __syncthreads() { simt::barrier(); }
 inline unsigned long long __brevll(unsigned long long x) { unsigned long long r = 0; for (int i = 0; i < 64; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
 inline int __shfl(int v, int src, int width = 64) {

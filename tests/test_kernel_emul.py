@@ -66,3 +66,19 @@ def test_single_polynomial_open_with_the_emulated_commit_tail():
         assert r.returncode == 0, r.stdout + r.stderr
         assert "identical to the oracle" in r.stdout and "accepted 1 of 1, rejected 7 of 7" in r.stdout
         assert f"1 commit-phase tails taken ({rounds} rounds)" in r.stdout, r.stdout
+
+
+def test_fused_kernels_with_the_sponge_on_the_host():
+    """DP_HOST_SPONGE (csrc/sponge_host.h): the five fused protocol kernels run their WaveChallenger in host mode — observed words
+    staged in a request area, challenges fetched from a reply area, the requests served by the product's own service
+    (sponge_serve_all, here called from inside the kernel's reply poll) on the host transcript — and the proofs of an MLP (single- and
+    multi-round commit tails) and of the CNN still equal the oracle's streams byte for byte"""
+    for args, env in (((16, 7), {}), ((64, 1), {"DP_EMUL_COMMIT_MAX_N": "4096"}), (("cnn", 4), {"DP_EMUL_THREADS": "256"}), (("seq", 2), {})):
+        e = {"DP_EMUL_HOST_SPONGE": "1"}
+        e.update(env)
+        r = _model(args, e)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "identical=1" in r.stdout and "verify(product): ACCEPT" in r.stdout, r.stdout
+        ran = int(r.stdout.split("host sponge service: ")[1].split()[0])
+        served = int(r.stdout.split("sponge on the host, ")[1].split()[0])
+        assert ran >= 10 and served > 10 * ran, r.stdout
