@@ -668,6 +668,10 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     // process may really use (cgroup quota), leaving two for the HIP runtime's own threads.
     const char* te = getenv("DP_HOST_THREADS");
     size_t nth = te ? (size_t)std::max(1, atoi(te)) : (size_t)std::max(1.0, host_cpu_budget() - 2.0);
+    if (!te && getenv("DP_HOST_SPONGE") && atoi(getenv("DP_HOST_SPONGE"))) {  // the sponge servers (csrc/sponge_host.h) spin too: they come out of the same CPU budget
+      const int S = getenv("DP_SPONGE_THREADS") ? std::max(1, atoi(getenv("DP_SPONGE_THREADS"))) : 6;
+      nth = (size_t)std::max(2.0, host_cpu_budget() - 2.0 - (double)S);
+    }
     nth = std::min(nth, nco ? nco : nw);
     auto run_thread = [&](size_t ti) {
       FiberSched sched;

@@ -2836,7 +2836,6 @@ class HipDev : public Dev {
         for (size_t i = 0; i < nwords; i++) cs += (unsigned long long)(i + 1) * w[i];
         if (base + cs == tag) { last_tag_ = tag; desc_off_ = 0; stage_off_ = 0; if (co_ && co_li_) co_->note_executed(co_li_ - 1); wait_exit_(t0); return; }
       }
-      sponge_serve_all();  // (host sponge: a waiting thread serves the requests of every proof in flight)
       // inside a fiber the wait hands the host thread to the next proof in flight (fiber.h); otherwise spin
       const bool fib = fiber_active();
       if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
@@ -2860,7 +2859,6 @@ class HipDev : public Dev {
         const unsigned long long cs = logup_tail_checksum(w, block_words);
         if (base + cs == tag) { last_tag_ = tag; desc_off_ = 0; stage_off_ = 0; if (co_ && co_li_) co_->note_executed(co_li_ - 1); wait_exit_(t0); return; }
       }
-      sponge_serve_all();  // (host sponge: a waiting thread serves the requests of every proof in flight)
       const bool fib = fiber_active();
       if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
       if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
@@ -3045,6 +3043,7 @@ class HipDev : public Dev {
   void dump_host_stats() {
     if (!g_host_stats) return;
     fprintf(stderr, "[dp timing] device context: %zu launches, %.1f us of host time per launch (%.1f ms total), %zu device waits, %zu fiber yields; host work between waits %.1f ms, inside waits %.1f ms\n", nlaunch_, nlaunch_ ? launch_us_ / nlaunch_ : 0.0, launch_us_ / 1000.0, nwait_, nyield_, work_us_ / 1000.0, waitlat_us_ / 1000.0);
+    if (sp_slot_) fprintf(stderr, "[dp timing] host sponge: %llu requests served for this context so far\n", (unsigned long long)sp_slot_->nserved.load());
     if (getenv("DP_LAUNCH_NAMES")) {  // launches by kernel since the last dump (DP_TIMING=1 DP_LAUNCH_NAMES=1)
       std::vector<std::pair<size_t, const char*>> v; for (auto& kv : by_name_) v.push_back({kv.second, kv.first});
       std::sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.first > b.first; });
@@ -3375,8 +3374,8 @@ class HipDev : public Dev {
   // against the sequential proofs; profiles/r02_fused_knob_sweep.jsonl).
   static int knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
   // ---- DP_HOST_SPONGE=1 (sponge_host.h): the fused protocol kernels keep the transcript's sponge on the HOST — a kernel posts the
-  // words it absorbs and asks for challenges through a mapped mailbox, any host thread waiting for the device serves the requests of
-  // any proof. Off by default: new at the end of round 2 (the wave sponge costs ~12 us per permutation, the mailbox 2.9 us per round trip).
+  // words it absorbs and asks for challenges through a mapped mailbox, DP_SPONGE_THREADS server threads answer (the members of a
+  // cohort ask together and sit with different servers). Off by default: new at the end of round 2 (the wave sponge costs ~12 us per permutation, the mailbox 2.9 us per round trip).
   bool host_sponge_ = knob("DP_HOST_SPONGE", 0) != 0;
   SpongeSlot* sp_slot_ = nullptr; u64* hsp_ = nullptr; u64* hsp_dev_ = nullptr; bool sp_active_ = false;
   void sponge_disarm_() {
@@ -3394,6 +3393,7 @@ class HipDev : public Dev {
     template <class D> SpongeArm(HipDev* dv, D* d, Challenger& c) : dev(dv), ch(&c) {
       if (!dv->host_sponge_ || !dv->sp_slot_) return;
       d->sp_req = dv->hsp_dev_; d->sp_rep = dv->hsp_dev_ + WC_REQ_WORDS; d->sp_seq = dv->sp_slot_->served;
+      sponge_servers_start();
       dv->sp_slot_->ch = &c; dv->sp_slot_->active.store(1, std::memory_order_release); sponge_nactive().fetch_add(1); dv->sp_active_ = true;
       armed = true;
     }

@@ -8,8 +8,13 @@
 //   reply area:                [0] tag  [1] out_len  [2..5] the sponge's output buffer;   tag = rep_mix(seq) + out_len + sum_i (i + 1) * out_i
 // A sample on the device pops out[--out_len] like DuplexChallenger::sample (poseidon2.h Challenger).
 #pragma once
+#include "dev.h"
 #include "poseidon2.h"
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <mutex>
+#include <thread>
 
 namespace dp {
 
@@ -19,7 +24,7 @@ DP_HD unsigned long long wc_req_mix(unsigned long long s) { return s * 0xD6E8FEB
 DP_HD unsigned long long wc_rep_mix(unsigned long long s) { return s * 0xA0761D6478BD642Full + 0xE7037ED1A0B428DBull; }
 
 // one proof's side of the service: its request / reply areas (host views) and the transcript sponge the requests act on
-struct SpongeSlot {
+struct alignas(128) SpongeSlot {
   std::atomic<int> active{0}, busy{0};
   volatile u64* req = nullptr; volatile u64* rep = nullptr;
   Challenger* ch = nullptr;
@@ -71,7 +76,27 @@ inline bool sponge_serve_slot(SpongeSlot& s) {
   s.busy.store(0, std::memory_order_release);
   return done;
 }
-// what a waiting host thread does between two polls of its own flag: one pass over every active slot
+// The service of the product: S server threads (DP_SPONGE_THREADS, default 6), server k owns the slots i = k mod S — no slot is looked
+// at by two threads (every thread scanning every mailbox costs ~20 us per round trip in cache-line traffic alone,
+// profiles/r02_mailbox_under_load.txt), and the members of a cohort, whose requests arrive together, sit in slots of different
+// servers. The threads start with the first armed kernel, sleep while nothing is armed, and live until the process ends.
+inline void sponge_server_loop(int id, int S) {
+  SpongeSlot* s = sponge_slots();
+  unsigned idle = 0;
+  for (;;) {
+    if (sponge_nactive().load(std::memory_order_relaxed) == 0) { std::this_thread::sleep_for(std::chrono::microseconds(50)); continue; }
+    const int n = sponge_nslots().load(std::memory_order_acquire);
+    bool any = false;
+    for (int i = id; i < n; i += S) any |= sponge_serve_slot(s[i]);
+    if (any) idle = 0; else if (++idle > 64) __builtin_ia32_pause();
+  }
+}
+inline int sponge_server_count() { static const int S = [] { const char* e = getenv("DP_SPONGE_THREADS"); int v = e ? atoi(e) : 6; return v < 1 ? 1 : v > 64 ? 64 : v; }(); return S; }
+inline void sponge_servers_start() {
+  static std::once_flag once;
+  std::call_once(once, [] { const int S = sponge_server_count(); for (int k = 0; k < S; k++) std::thread(sponge_server_loop, k, S).detach(); });
+}
+// one pass over every active slot by the calling thread (the kernel emulator of tests/ serves requests from inside the kernel's poll)
 inline void sponge_serve_all() {
   if (sponge_nactive().load(std::memory_order_relaxed) == 0) return;
   const int n = sponge_nslots().load(std::memory_order_acquire);

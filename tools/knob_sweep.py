@@ -16,7 +16,8 @@ CONFIGS = [  # (name, proofs in flight, env) — in order of importance: the swe
     ("ctail32k_256", 256, {"DP_COMMIT_TAIL_MAX_N": "32768"}),
     ("c20_480_arena480", 480, {"DP_COHORT": "20", "DP_WORKER_ARENA_BYTES": str(480 << 20)}),
     ("hostsponge_256", 256, {"DP_HOST_SPONGE": "1"}),   # fused kernels, sponge on the host, requests served by every waiting thread (csrc/sponge_host.h)
-    ("hostsponge_c8_256", 256, {"DP_HOST_SPONGE": "1", "DP_COHORT": "8"}),
+    ("hostsponge_s8_256", 256, {"DP_HOST_SPONGE": "1", "DP_SPONGE_THREADS": "8"}),
+    ("hostsponge_s4_256", 256, {"DP_HOST_SPONGE": "1", "DP_SPONGE_THREADS": "4"}),
     ("hostfs_256", 256, {"DP_DEVICE_FS": "0"}),   # sponge on the host: persistent sumchecks poll a mailbox per round, no fused tails (round 1's protocol kernels)
     ("cohort0_256", 256, {"DP_COHORT": "0"}),   # every proof on its own stream (round 1's scheme) with round 2's fused tails
     ("cohort4_256", 256, {"DP_COHORT": "4"}),

@@ -40,8 +40,8 @@ __global__ void busy(unsigned long long* out, int rounds) {
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? atoi(argv[1]) : 3000;
   CK(hipSetDevice(0));
-  struct Cfg { int C, G, T; double work_us; int load; };
-  const Cfg cfgs[] = {{1, 1, 1, 0.0, 0}, {1, 12, 1, 0.0, 0}, {22, 12, 14, 0.0, 0}, {22, 12, 14, 4.5, 0}, {22, 12, 14, 4.5, 1}, {22, 12, 7, 4.5, 1}, {22, 12, 14, 1.5, 1}};
+  struct Cfg { int C, G, T; double work_us; int load; int shared; };  // shared: every thread scans every mailbox and claims a request with a CAS (csrc/sponge_host.h)
+  const Cfg cfgs[] = {{1, 1, 1, 0.0, 0, 0}, {22, 12, 14, 0.0, 0, 0}, {22, 12, 14, 4.5, 0, 0}, {22, 12, 14, 4.5, 0, 1}, {22, 12, 14, 4.5, 1, 1}, {22, 12, 14, 0.0, 0, 1}, {22, 12, 7, 4.5, 0, 1}};
   for (const Cfg& cf : cfgs) {
     const int M = cf.C * cf.G;
     unsigned long long *req, *rep, *ticks, *dreq, *drep, *dticks, *sink;
@@ -55,6 +55,27 @@ int main(int argc, char** argv) {
     std::vector<std::thread> th;
     std::vector<unsigned long long> served(cf.T, 0);
     for (int t = 0; t < cf.T; t++) th.emplace_back([&, t] {
+      if (cf.shared) {  // every thread scans every mailbox; a request is claimed with a CAS on the mailbox's lock word
+        static std::vector<std::atomic<int>> lock(4096); static std::vector<unsigned long long> lastv(4096);
+        if (t == 0) for (int m = 0; m < M; m++) { lock[m] = 0; lastv[m] = 0; }
+        static std::atomic<int> ready(0), finished(0); if (t == 0) { finished = 0; ready = 1; } while (!ready.load()) {}
+        while (finished.load(std::memory_order_relaxed) < M && !done.load(std::memory_order_relaxed)) {
+          for (int m = 0; m < M; m++) {
+            unsigned long long v = __atomic_load_n(req + 8 * m, __ATOMIC_ACQUIRE);
+            if (v == __atomic_load_n(&lastv[m], __ATOMIC_RELAXED)) continue;
+            int e = 0; if (!lock[m].compare_exchange_strong(e, 1, std::memory_order_acquire)) continue;
+            v = __atomic_load_n(req + 8 * m, __ATOMIC_ACQUIRE);
+            if (v != lastv[m]) {
+              if (cf.work_us > 0) { auto t0 = std::chrono::steady_clock::now(); while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < cf.work_us) {} }
+              __atomic_store_n(rep + 8 * m, v, __ATOMIC_RELEASE); __atomic_store_n(&lastv[m], v, __ATOMIC_RELAXED); served[t]++;
+              if ((int)v == iters) finished.fetch_add(1);
+            }
+            lock[m].store(0, std::memory_order_release);
+          }
+        }
+        if (t == 0) { while (finished.load() < M && !done.load()) {} ready = 0; }
+        return;
+      }
       std::vector<int> mine; for (int c = t; c < cf.C; c += cf.T) for (int g = 0; g < cf.G; g++) mine.push_back(c * cf.G + g);
       std::vector<unsigned long long> last(mine.size(), 0);
       size_t fin = 0;
@@ -80,8 +101,8 @@ int main(int argc, char** argv) {
     for (auto& t : th) t.join();
     CK(hipDeviceSynchronize());
     double avg = 0, mx = 0; for (int m = 0; m < M; m++) { double us = (double)ticks[m] / 100.0 / iters; avg += us; mx = std::max(mx, us); }
-    printf("%2d cohorts x %2d workgroups, %2d host threads, %.1f us of host work per request, wide kernel running: %s -> round trip %.2f us average, %.2f us slowest workgroup (wall %.0f ms, %.0f k requests/s)\n",
-           cf.C, cf.G, cf.T, cf.work_us, cf.load ? "yes" : "no ", avg / M, mx, wall, (double)M * iters / wall);
+    printf("%2d cohorts x %2d workgroups, %2d host threads (%s), %.1f us of host work per request, wide kernel running: %s -> round trip %.2f us average, %.2f us slowest workgroup (wall %.0f ms, %.0f k requests/s)\n",
+           cf.C, cf.G, cf.T, cf.shared ? "every thread serves every mailbox" : "a thread serves its cohorts", cf.work_us, cf.load ? "yes" : "no ", avg / M, mx, wall, (double)M * iters / wall);
     for (auto& s : st) hipStreamDestroy(s);
     hipHostFree(req); hipHostFree(rep); hipHostFree(ticks); hipFree(sink);
   }
