@@ -39,6 +39,11 @@ struct dp_model {
 // initialised HIP keeps its setting (dp_model_prove_batch then simply shares queues: slower, not wrong, since no kernel of the
 // throughput path waits for the host).
 __attribute__((constructor)) static void dp_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+// the host transcript's Poseidon2: the AVX-512 permutation of p2_avx512.cpp when the CPU has it (DP_NO_AVX512=1: the scalar code)
+__attribute__((constructor)) static void dp_install_fast_poseidon2() {
+  const char* e = getenv("DP_NO_AVX512");
+  if (!(e && atoi(e)) && dp::p2_cpu_has_avx512()) dp::p2_fast() = dp::p2_permute_avx512;
+}
 static thread_local std::string g_err;
 template <class F>
 static int32_t guard(F f) {
@@ -696,6 +701,13 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     for (size_t wi = 1; wi < nw && wi < 3; wi++) { hip_dev_dump_sc_debug(m->workers[wi - 1].get()); hip_dev_dump_host_stats(m->workers[wi - 1].get()); }
     hip_dev_set_latency_mode(m->ctx->dev, true);
     if (err_code) { for (size_t i = 0; i < nproofs; i++) { dp_free(proof_words[i]); proof_words[i] = nullptr; } throw DpError(err_code, err); }
+  });
+}
+int32_t dp_host_poseidon2(uint64_t state[8], int32_t force_scalar, int32_t* vectorised) {
+  return guard([&] {
+    DP_REQUIRE(state, DP_ERR_ARG, "null state");
+    if (vectorised) *vectorised = dp::p2_fast() != nullptr;
+    if (force_scalar) dp::hostnc::permute_scalar(state); else dp::hostnc::permute(state);
   });
 }
 int32_t dp_model_in_flight(const dp_model* m, size_t* in_flight) { return guard([&] { DP_REQUIRE(m && in_flight, DP_ERR_ARG, "bad arguments"); *in_flight = m->last_in_flight; }); }

@@ -1,0 +1,82 @@
+// Poseidon2-w8 over Goldilocks for the HOST transcript, AVX-512: the eight state words are the eight 64-bit lanes of one register.
+// Same permutation as hostnc::permute (poseidon2.h; ff_ext/src/lib.rs:167-236 wiring, p3 constants) — word for word after the final
+// canonicalisation: intermediate values are arbitrary representatives < 2^64, as in the scalar code.
+//   vmulred: 64x64 -> 128 from four 32x32 products (carry-free schoolbook), then 2^64 = 2^32 - 1, 2^96 = -1 (mod p);
+//   external layer: M4 inside each group of four lanes by lane rotations, then the two halves mixed — on the 32-bit halves of the words,
+//     so the sums (coefficients up to 21) need no modular adds until the recombination;
+//   internal layer: S-box of word 0 in scalar code, the sum of the words by horizontal adds on the halves, diag multiply on all lanes.
+// Built into libdeepprove_hip.so; hostnc::permute dispatches here when the CPU has AVX-512F/DQ (dp_p2_install). The test harnesses of
+// tests/ that include poseidon2.h alone keep the scalar code (tests/test_host_poseidon2.py compares the two).
+#include "poseidon2.h"
+#include <immintrin.h>
+
+namespace dp {
+namespace {
+#define P2V __attribute__((target("avx512f,avx512dq"), always_inline)) static inline
+P2V __m512i veps() { return _mm512_set1_epi64((long long)GL_EPS); }
+P2V __m512i vadd(__m512i a, __m512i b) {
+  const __m512i eps = veps();
+  __m512i s = _mm512_add_epi64(a, b);
+  __mmask8 c = _mm512_cmplt_epu64_mask(s, a);
+  __m512i s2 = _mm512_mask_add_epi64(s, c, s, eps);
+  __mmask8 c2 = (__mmask8)(c & _mm512_cmplt_epu64_mask(s2, eps));
+  return _mm512_mask_add_epi64(s2, c2, s2, eps);
+}
+P2V __m512i vmulred(__m512i a, __m512i b) {
+  const __m512i eps = veps();
+  __m512i ah = _mm512_srli_epi64(a, 32), bh = _mm512_srli_epi64(b, 32);
+  __m512i p00 = _mm512_mul_epu32(a, b), p01 = _mm512_mul_epu32(a, bh), p10 = _mm512_mul_epu32(ah, b), p11 = _mm512_mul_epu32(ah, bh);
+  __m512i t = _mm512_add_epi64(p01, _mm512_srli_epi64(p00, 32));
+  __m512i u = _mm512_add_epi64(p10, _mm512_and_si512(t, eps));
+  __m512i lo = _mm512_or_si512(_mm512_slli_epi64(u, 32), _mm512_and_si512(p00, eps));
+  __m512i hi = _mm512_add_epi64(_mm512_add_epi64(p11, _mm512_srli_epi64(t, 32)), _mm512_srli_epi64(u, 32));
+  __m512i hh = _mm512_srli_epi64(hi, 32), hl = _mm512_and_si512(hi, eps);
+  __mmask8 brw = _mm512_cmplt_epu64_mask(lo, hh);
+  __m512i lo2 = _mm512_sub_epi64(lo, hh);
+  lo2 = _mm512_mask_sub_epi64(lo2, brw, lo2, eps);
+  __m512i t1 = _mm512_sub_epi64(_mm512_slli_epi64(hl, 32), hl);
+  __m512i r = _mm512_add_epi64(lo2, t1);
+  __mmask8 cr = _mm512_cmplt_epu64_mask(r, t1);
+  return _mm512_mask_add_epi64(r, cr, r, eps);
+}
+P2V __m512i vsbox(__m512i x) { __m512i x2 = vmulred(x, x), x3 = vmulred(x2, x), x4 = vmulred(x2, x2); return vmulred(x3, x4); }
+// half = the low or the high 32 bits of every word, as 64-bit lanes: M4 (rows 2 3 1 1 / 1 2 3 1 / 1 1 2 3 / 3 1 1 2) in each group of four, then out = 2 n + swap(n)
+P2V __m512i mds_half(__m512i h) {
+  __m512i r1 = _mm512_permutex_epi64(h, 0x39), r2 = _mm512_permutex_epi64(h, 0x4E), r3 = _mm512_permutex_epi64(h, 0x93);
+  __m512i n = _mm512_add_epi64(_mm512_add_epi64(_mm512_add_epi64(h, h), _mm512_add_epi64(r1, _mm512_add_epi64(r1, r1))), _mm512_add_epi64(r2, r3));
+  return _mm512_add_epi64(_mm512_add_epi64(n, n), _mm512_shuffle_i64x2(n, n, 0x4E));
+}
+P2V __m512i vmds(__m512i v) {
+  const __m512i eps = veps();
+  __m512i ol = mds_half(_mm512_and_si512(v, eps)), oh = mds_half(_mm512_srli_epi64(v, 32));  // each < 21 * 2^32
+  __m512i ohh = _mm512_srli_epi64(oh, 32);                                                      // < 32: its weight 2^64 = 2^32 - 1
+  __m512i x = _mm512_slli_epi64(_mm512_and_si512(oh, eps), 32);
+  __m512i y = _mm512_add_epi64(ol, _mm512_sub_epi64(_mm512_slli_epi64(ohh, 32), ohh));
+  return vadd(x, y);
+}
+}  // namespace
+
+__attribute__((target("avx512f,avx512dq"))) void p2_permute_avx512(u64* s) {
+  const u64* rc = POSEIDON2_RC_HOST;
+  __m512i v = _mm512_loadu_si512((const void*)s);
+  const __m512i diag = _mm512_loadu_si512((const void*)(rc + 86));
+  v = vmds(v);
+  for (int r = 0; r < 4; r++) v = vmds(vsbox(vadd(v, _mm512_loadu_si512((const void*)(rc + r * 8)))));
+  const __m512i eps = veps();
+  for (int r = 0; r < 22; r++) {
+    u64 s0 = (u64)_mm_cvtsi128_si64(_mm512_castsi512_si128(v));
+    s0 = hostnc::sbox(hostnc::add(s0, rc[32 + r]));
+    v = _mm512_mask_set1_epi64(v, 0x01, (long long)s0);
+    const u64 sl = (u64)_mm512_reduce_add_epi64(_mm512_and_si512(v, eps)), sh = (u64)_mm512_reduce_add_epi64(_mm512_srli_epi64(v, 32));
+    const u64 sum = hostnc::red((unsigned __int128)sl + ((unsigned __int128)sh << 32));
+    v = vadd(vmulred(v, diag), _mm512_set1_epi64((long long)sum));
+  }
+  for (int r = 0; r < 4; r++) v = vmds(vsbox(vadd(v, _mm512_loadu_si512((const void*)(rc + 54 + r * 8)))));
+  const __m512i p = _mm512_set1_epi64((long long)GL_P);
+  __mmask8 ge = _mm512_cmpge_epu64_mask(v, p);
+  v = _mm512_mask_sub_epi64(v, ge, v, p);
+  _mm512_storeu_si512((void*)s, v);
+}
+bool p2_cpu_has_avx512() { __builtin_cpu_init(); return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq"); }
+
+}  // namespace dp

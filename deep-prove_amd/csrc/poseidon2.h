@@ -136,7 +136,7 @@ inline void mds(u64* s) {
   mat4(s[0], s[1], s[2], s[3]); mat4(s[4], s[5], s[6], s[7]);
   for (int k = 0; k < 4; k++) { u64 sum = add(s[k], s[k + 4]); s[k] = add(s[k], sum); s[k + 4] = add(s[k + 4], sum); }
 }
-inline void permute(u64* s) {
+inline void permute_scalar(u64* s) {
   const u64* rc = POSEIDON2_RC_HOST;
   mds(s);
   for (int r = 0; r < 4; r++) { for (int i = 0; i < 8; i++) s[i] = sbox(add(s[i], rc[r * 8 + i])); mds(s); }
@@ -150,6 +150,14 @@ inline void permute(u64* s) {
   for (int r = 0; r < 4; r++) { for (int i = 0; i < 8; i++) s[i] = sbox(add(s[i], rc[54 + r * 8 + i])); mds(s); }
   for (int i = 0; i < 8; i++) s[i] = s[i] >= GL_P ? s[i] - GL_P : s[i];
 }
+}  // namespace hostnc
+// the vectorised permutation of p2_avx512.cpp (the eight state words in the eight lanes of an AVX-512 register: 3x the scalar code),
+// installed by the library when the CPU has AVX-512F/DQ (capi.cpp; DP_NO_AVX512=1 keeps the scalar code). Word-for-word equal results.
+void p2_permute_avx512(u64* s);
+bool p2_cpu_has_avx512();
+inline void (*&p2_fast())(u64*) { static void (*f)(u64*) = nullptr; return f; }
+namespace hostnc {
+inline void permute(u64* s) { if (void (*f)(u64*) = p2_fast()) f(s); else permute_scalar(s); }
 }  // namespace hostnc
 
 struct Challenger {

@@ -228,6 +228,10 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
                              uint64_t** proof_words, size_t* proof_nwords, int64_t* outputs, size_t noutput_cap,
                              size_t* noutput, double* wall_ms);
 /* proofs the last dp_model_prove_batch of this model kept in flight (0 before the first batch) */
+/* The Poseidon2-w8 permutation of the HOST transcript (transcript/src/basic.rs over ff_ext/src/lib.rs:167-236), in place on eight canonical
+ * words: the AVX-512 code (csrc/p2_avx512.cpp) when the CPU has AVX-512F/DQ and DP_NO_AVX512 is not set, else scalar; force_scalar != 0
+ * always takes the scalar code. *vectorised (may be NULL) tells which one the library's transcripts use. Host only. */
+int32_t dp_host_poseidon2(uint64_t state[8], int32_t force_scalar, int32_t* vectorised);
 int32_t dp_model_in_flight(const dp_model* m, size_t* in_flight);
 /* length (in int64 words) of the model's output tensor: what `output` / `outputs` of the prove calls must hold */
 int32_t dp_model_output_len(const dp_model* m, size_t* noutput);
