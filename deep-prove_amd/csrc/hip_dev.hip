@@ -1117,7 +1117,7 @@ KBODY k_sc_small(const ScSmallArgs& a, Ext* result, unsigned long long* flag, un
 #define WC_POLL_PAUSE(spin) wc_poll_pause(wc_t0, spin)
 __device__ __forceinline__ bool wc_poll_pause(unsigned long long t0, unsigned spin) {
   if ((spin & 63) == 63 && dp_realtime() - t0 > c_poll_timeout_ticks) return true;
-  for (int q = 0; q < c_poll_sleep; q++) __builtin_amdgcn_s_sleep(4);
+  for (int q = 0; q < c_poll_sleep; q++) __builtin_amdgcn_s_sleep(16);
   return false;
 }
 #endif
@@ -1150,14 +1150,21 @@ __device__ __forceinline__ void wc_request(WaveChallenger& c, int lane, int want
   u64 ol = 0, o = 0;
   bool ok = false;
   WC_POLL_BEGIN
+  u64 seen = __hip_atomic_load(c.rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (the previous reply's tag)
+  seen = shfl_u64(seen, 0);
   for (unsigned spin = 0;; spin++) {
+    // one PCIe read per poll (every lane asks for the same word): the payload is only fetched once the tag word has changed —
+    // 264 workgroups polling three words each saturate the link's read rate and slow every poll down
     u64 tag = __hip_atomic_load(c.rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    ol = __hip_atomic_load(c.rep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    o = __hip_atomic_load(c.rep + 2 + (lane & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    tag = shfl_u64(tag, 0); ol = shfl_u64(ol, 0);
-    const u64 w = o * (u64)((lane & 3) + 1);
-    const u64 sum = ol + shfl_u64(w, 0) + shfl_u64(w, 1) + shfl_u64(w, 2) + shfl_u64(w, 3);
-    if (tag == base + sum && ol <= 4) { ok = true; break; }
+    tag = shfl_u64(tag, 0);
+    if (tag != seen || spin == 0) {
+      ol = __hip_atomic_load(c.rep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      o = __hip_atomic_load(c.rep + 2 + (lane & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      ol = shfl_u64(ol, 0);
+      const u64 w = o * (u64)((lane & 3) + 1);
+      const u64 sum = ol + shfl_u64(w, 0) + shfl_u64(w, 1) + shfl_u64(w, 2) + shfl_u64(w, 3);
+      if (tag == base + sum && ol <= 4) { ok = true; break; }
+    }
     if (WC_POLL_PAUSE(spin)) break;
   }
   c.n = 0; c.cs = 0; c.consumed = 0;
