@@ -32,6 +32,9 @@ struct LayerSpec {
   // the input a row-major [s][nrows] matrix (s = its length / nrows), bias [ncols] or empty; the output is [s][ncols]. mm_transpose
   // (Config::TransposeB, matrix_mul.rs:36-39): the constant matrix is stored as [ncols][nrows] and used transposed
   bool mm_transpose = false;
+  // add (layers/add.rs, Add::new_with(operand)): out = add_left * x + add_right * operand; the operand — a constant tensor as long as the
+  // input, e.g. learned positional embeddings — is `weights`; the multipliers are QuantInfo::left/right_multiplier (add.rs:271-283)
+  int64_t add_left = 1, add_right = 1;
   // conv (layers/convolution.rs:52-83, tensor.rs:409-431): padded filter count kw, padded input channels kx, padded kernel
   // side real_nw, padded input side nw; unp_out = conv2d_shape of the unpadded tensors (for the garbage-clearing tensor)
   size_t kw = 0, kx = 0, real_nw = 0, nw = 0;
@@ -181,6 +184,10 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
         else for (size_t q = 0; q < k; q++) { const int64_t x = cur[i * k + q]; const int64_t* w = &l.weights[q * n]; for (size_t j = 0; j < n; j++) row[j] += x * w[j]; }
         if (!l.bias.empty()) for (size_t j = 0; j < n; j++) row[j] += l.bias[j];
       }
+    } else if (l.kind == L_ADD) {  // Add::evaluate (add.rs:184-210)
+      DP_REQUIRE(cur.size() == l.weights.size(), DP_ERR_SHAPE, "add: operand size mismatch");
+      o.resize(cur.size());
+      for (size_t i = 0; i < cur.size(); i++) o[i] = l.add_left * cur[i] + l.add_right * l.weights[i];
     } else if (l.kind == L_REQUANT) {
       unsigned sh = l.shift();
       for (int64_t v : cur) {
@@ -243,6 +250,8 @@ inline void validate_model(const ModelSpec& m) {
       DP_REQUIRE(is_pow2(l.nrows) && is_pow2(l.ncols) && l.nrows >= 2 && l.ncols >= 2, DP_ERR_SHAPE, "matmul: padded dimensions must be powers of two >= 2");
       DP_REQUIRE(cur % l.nrows == 0 && cur / l.nrows >= 2 && l.weights.size() == l.nrows * l.ncols && (l.bias.empty() || l.bias.size() == l.ncols), DP_ERR_SHAPE, "matmul: tensor sizes (the input is [s][nrows], s >= 2)");
       cur = cur / l.nrows * l.ncols;
+    } else if (l.kind == L_ADD) {
+      DP_REQUIRE(l.weights.size() == cur && cur >= 2 && l.add_left > 0 && l.add_right > 0 && l.add_left < (int64_t(1) << 40) && l.add_right < (int64_t(1) << 40), DP_ERR_SHAPE, "add: the operand must be as long as the input, the multipliers positive");
     } else if (l.kind == L_REQUANT) {
       DP_REQUIRE(l.fixed_point_multiplier > 0 && l.shift() % Q_BIT_LEN == 0 && l.shift() >= Q_BIT_LEN && l.shift() < 63, DP_ERR_ARG, "requant: shift must be a positive multiple of BIT_LEN");
       DP_REQUIRE(l.intermediate_bit_size + l.fp_scale <= 63, DP_ERR_ARG, "requant: intermediate_bit_size + fp_scale > 63");
@@ -279,13 +288,20 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
   }
   std::sort(ts.begin(), ts.end());
   for (auto& t : ts) mpl = std::max(mpl, size_t(1) << t.vars());
-  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL) mpl = std::max(mpl, std::max(next_pow2(l.weights.size()), next_pow2(l.bias.size())));
+  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD) mpl = std::max(mpl, std::max(next_pow2(l.weights.size()), next_pow2(l.bias.size())));
   mpl = next_pow2(mpl);
   ctx->max_poly_len = mpl; ctx->full_log = dp_ceil_log2(mpl); ctx->tables = ts;
   dev.pcs_init(ctx->full_log);
   for (size_t id = 0; id < m.layers.size(); id++) {
     LayerSpec& l = ctx->model.layers[id];
-    if (l.kind != L_DENSE && l.kind != L_CONV && l.kind != L_MATMUL) continue;
+    if (l.kind != L_DENSE && l.kind != L_CONV && l.kind != L_MATMUL && l.kind != L_ADD) continue;
+    if (l.kind == L_ADD) {  // the static operand is a model polynomial: OPERAND_POLY_ID = 0xff, to_string() (add.rs:32,518-522)
+      DBuf w = dev.alloc_persistent(l.weights.size(), false);
+      dev.upload_i64(w, l.weights.data());
+      ctx->model_comms[id]["255"] = dev.commit(w, true);
+      ctx->weights_dev[id] = w;
+      continue;
+    }
     if (l.kind == L_MATMUL) {  // model polys of a MatMul with a constant matrix (matrix_mul.rs:947-963)
       DBuf w = dev.alloc_persistent(l.weights.size(), false);
       dev.upload_i64(w, l.weights.data());
@@ -468,6 +484,26 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
   }
   ps.constant_challenge = ps.t->get_and_append_challenge("table_constant");
   for (auto& kv : counts) ps.challenge_map[kv.first] = kv.first.label() ? ps.t->get_and_append_challenge(kv.first.label()) : ex_one();
+}
+
+// Add::prove_step with a static operand (layers/add.rs:81-145): no sumcheck, no transcript traffic. The input's evaluation at the claim's
+// point (one Dev::mle_eval_batch over the uploaded activation); the operand's evaluation follows from out(r) = M1 x(r) + M2 c(r) and
+// becomes a claim on the operand's commitment; the input claim goes to the previous layer.
+inline Claim prove_add(ProverState& ps, size_t id, const LayerSpec& l, const Claim& last, const std::vector<int64_t>& input) {
+  Dev& dev = *ps.dev;
+  DP_REQUIRE((size_t(1) << last.point.size()) == input.size(), DP_ERR_SHAPE, "add: claim point length");
+  size_t mk = dev.mark();
+  DBuf in = dev.alloc(input.size(), false);
+  dev.upload_i64(in, input.data());
+  Ext left_eval;
+  dev.mle_eval_batch(&in, 1, last.point.data(), (unsigned)last.point.size(), &left_eval);
+  const Ext scaled = ex_mul_base(left_eval, gl_from_i64(l.add_left));
+  const Ext right_eval = ex_mul_base(ex_sub(last.eval, scaled), gl_inv(gl_from_i64(l.add_right)));
+  ps.add_witness_claim(ps.ctx->model_comms.at(id).at("255"), {last.point, right_eval});
+  LayerProof lp; lp.kind = L_ADD; lp.add.left_eval = left_eval; lp.add.right_eval = right_eval;
+  ps.proofs[id] = lp;
+  dev.release(mk);
+  return {last.point, left_eval};
 }
 
 // MatMul::prove_step (layers/matrix_mul.rs:701-873), (Input, Weight) arrangement, right matrix not transposed. split_claim (:339-356):
@@ -836,6 +872,7 @@ inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t) {
     const LayerSpec& l = ctx.model.layers[id];
     if (l.kind == L_DENSE) cur = prove_dense(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_MATMUL) cur = prove_matmul(ps, id, l, cur, tr.in[id]);
+    else if (l.kind == L_ADD) cur = prove_add(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
     else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, tr.out[id]);
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv.at(id));
@@ -1037,6 +1074,16 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       DP_REQUIRE(ex_eq(ex_mul(dpf.individual_claims[0], dpf.individual_claims[1]), sub.expected_evaluation), DP_ERR_VERIFY, "dense: sumcheck claim failed");
       cur = {sub.point, dpf.individual_claims[1]};
       cur_len = l.ncols;
+    } else if (l.kind == L_ADD) {  // AddCtx::verify (add.rs:586-625), static operand
+      const AddProof& ap = lp.add;
+      DP_REQUIRE(cur.point.size() == dp_ceil_log2(cur_len) && l.add_left > 0 && l.add_right > 0, DP_ERR_VERIFY, "add: shapes");
+      const Ext sum = ex_add(ex_mul_base(ap.left_eval, gl_from_i64(l.add_left)), ex_mul_base(ap.right_eval, gl_from_i64(l.add_right)));
+      DP_REQUIRE(ex_eq(sum, cur.eval), DP_ERR_VERIFY, "Add layer verification failed");
+      auto nit = unused.find(id);
+      DP_REQUIRE(nit != unused.end() && nit->second.count("255"), DP_ERR_VERIFY, "add: no commitment for the operand");
+      add_claim(nit->second.at("255"), {cur.point, ap.right_eval});
+      unused.erase(nit);
+      cur = {cur.point, ap.left_eval};
     } else if (l.kind == L_MATMUL) {  // MatMulCtx::verify_matmul (matrix_mul.rs:1048-1139), (Input, Weight), right matrix not transposed
       const MatMulProof& mp = lp.matmul;
       DP_REQUIRE(l.nrows && cur_len % l.ncols == 0, DP_ERR_VERIFY, "matmul: shapes");
@@ -1153,15 +1200,17 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
 }
 
 // ---- serialisable verifier context (what dp_model_verifier_blob hands out and dp_verify consumes)
-constexpr int N_POLY_IDS = 6;
-inline const char* const* poly_ids() { static const char* const ids[N_POLY_IDS] = {"DenseBias", "DenseWeight", "ConvBias", "ConvFilter", "MatMulBias", "MatMulWeight"}; return ids; }
+constexpr int N_POLY_IDS = 7;
+inline const char* const* poly_ids() { static const char* const ids[N_POLY_IDS] = {"DenseBias", "DenseWeight", "ConvBias", "ConvFilter", "MatMulBias", "MatMulWeight", "255"}; return ids; }
 inline std::vector<u64> vctx_to_words(const VerifierContext& v) {
   std::vector<u64> w;
   w.push_back(0x3158544356504444ULL); w.push_back(v.full_log); w.push_back(v.shape.input_len); w.push_back(v.shape.layers.size());
   for (auto& l : v.shape.layers) {
-    w.push_back(l.kind); w.push_back(l.nrows); w.push_back(l.ncols); w.push_back(l.right_shift); w.push_back(l.fp_scale); w.push_back((u64)l.fixed_point_multiplier); w.push_back(l.intermediate_bit_size);
+    w.push_back(l.kind); w.push_back(l.nrows); w.push_back(l.ncols); w.push_back(l.right_shift); w.push_back(l.fp_scale);
+    w.push_back(l.kind == L_ADD ? (u64)l.add_left : (u64)l.fixed_point_multiplier);  // (an Add carries its two multipliers in the requant multiplier / kx slots)
+    w.push_back(l.intermediate_bit_size);
     w.push_back(l.kind == L_MATMUL ? (l.mm_transpose ? 1 : 0) : l.kw);  // (a MatMul has no filter count: the slot carries its transpose flag)
-    w.push_back(l.kx); w.push_back(l.real_nw); w.push_back(l.nw);
+    w.push_back(l.kind == L_ADD ? (u64)l.add_right : l.kx); w.push_back(l.real_nw); w.push_back(l.nw);
     for (int k = 0; k < 3; k++) w.push_back(l.unp_out[k]);
     for (int k = 0; k < 3; k++) w.push_back(l.pin[k]);
   }
@@ -1190,7 +1239,8 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
     l.kw = (size_t)rd(); l.kx = (size_t)rd(); l.real_nw = (size_t)rd(); l.nw = (size_t)rd();
     for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();
     for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd();
-    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_MATMUL, DP_ERR_ARG, "verifier blob: layer kind");
+    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_ADD, DP_ERR_ARG, "verifier blob: layer kind");
+    if (l.kind == L_ADD) { l.add_left = l.fixed_point_multiplier; l.add_right = (int64_t)l.kx; l.fixed_point_multiplier = 0; l.kx = 0; DP_REQUIRE(l.add_left > 0 && l.add_right > 0, DP_ERR_ARG, "verifier blob: add multipliers"); }
     if (l.kind == L_MATMUL) { DP_REQUIRE(l.kw <= 1, DP_ERR_ARG, "verifier blob: matmul flags"); l.mm_transpose = l.kw != 0; l.kw = 0; }
     if (l.kind == L_CONV) DP_REQUIRE(is_pow2(l.kw) && is_pow2(l.kx) && is_pow2(l.real_nw) && is_pow2(l.nw) && l.kw <= (1u << 16) && l.kx <= (1u << 16) && l.nw <= (1u << 12) && 2 * l.real_nw <= l.nw && l.unp_out[0] <= l.kw && l.unp_out[1] <= l.nw && l.unp_out[2] <= l.nw, DP_ERR_ARG, "verifier blob: conv shape");
     if (l.kind == L_MAXPOOL) DP_REQUIRE(is_pow2(l.pin[0]) && is_pow2(l.pin[1]) && is_pow2(l.pin[2]) && l.pin[2] >= 2, DP_ERR_ARG, "verifier blob: maxpool shape");

@@ -5,7 +5,7 @@ import math
 
 import numpy as np
 
-L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_FLATTEN, L_MATMUL = 0, 1, 2, 3, 4, 5, 6
+L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_FLATTEN, L_MATMUL, L_ADD = 0, 1, 2, 3, 4, 5, 6, 7
 BIT_LEN = 8
 FIXED_POINT_SCALE = 25  # zkml/src/layers/requant.rs:47
 
@@ -137,6 +137,20 @@ class ModelBuilder:
             self.layers.append(dict(kind=L_REQUANT, **rq))
         return self
 
+    def add_const(self, left=1, right=1, requant=True):
+        """Add::new_with(operand) (layers/add.rs:72-78): out = left * x + right * operand with a constant operand as long as the
+        activation (learned positional embeddings are added this way, transformer/positional.rs); zeros at the padding positions.
+        Followed by a Requant that brings the sum back into the 8-bit range"""
+        og, pad = self.shape_og, self.shape_pad
+        c = np.zeros(pad, dtype=np.int64)
+        c[tuple(slice(0, d) for d in og)] = self._tensor(int(np.prod(og))).reshape(og)
+        self.layers.append(dict(kind=L_ADD, left=int(left), right=int(right), operand=c.reshape(-1)))
+        if requant:
+            # |left x + right c| <= 127 (left + right): one more bit per doubling; multiplier 1 / (left + right)
+            bits = 8 + int(math.ceil(math.log2(left + right)))
+            self.layers.append(dict(kind=L_REQUANT, **requant_from_multiplier(1.0 / (left + right), bits)))
+        return self
+
     def relu(self):
         self.layers.append(dict(kind=L_RELU))
         return self
@@ -188,6 +202,9 @@ class ModelBuilder:
                 parts.append(np.array([L_DENSE, l["nrows"], l["ncols"]], dtype=np.int64))
                 parts.append(l["weights"].reshape(-1))
                 parts.append(l["bias"])
+            elif l["kind"] == L_ADD:
+                parts.append(np.array([L_ADD, l["left"], l["right"], l["operand"].size], dtype=np.int64))
+                parts.append(l["operand"])
             elif l["kind"] == L_MATMUL:
                 parts.append(np.array([L_MATMUL, l["nrows"], l["ncols"], (0 if l["bias"] is None else 1) | (2 if l["transpose_b"] else 0)], dtype=np.int64))
                 parts.append(l["weights"].reshape(-1))
@@ -219,6 +236,8 @@ class ModelBuilder:
         for l in self.layers:
             if l["kind"] == L_DENSE:
                 cur = l["weights"] @ cur + l["bias"]
+            elif l["kind"] == L_ADD:
+                cur = l["left"] * cur + l["right"] * l["operand"]
             elif l["kind"] == L_MATMUL:
                 y = cur.reshape(-1, l["nrows"]) @ (l["weights"].T if l["transpose_b"] else l["weights"])
                 cur = (y + l["bias"] if l["bias"] is not None else y).reshape(-1)
@@ -259,10 +278,12 @@ def mlp(num_dense, width, config, input_features=4, output_features=3):
     return mb
 
 
-def seq_mlp(seq, width, config, input_features=4, output_features=3, layers=2, transpose_last=False):
+def seq_mlp(seq, width, config, input_features=4, output_features=3, layers=2, transpose_last=False, positional=False):
     """a per-token MLP over a [seq][features] activation: MatMul(+bias)+Requant+ReLU blocks (the Linear layers of a transformer
     block applied to every position; layers/matrix_mul.rs with a constant right matrix), the last one without bias"""
     mb = ModelBuilder((seq, input_features), config)
+    if positional:  # a learned positional table added to the input (transformer/positional.rs -> Add with a static operand)
+        mb.add_const(1, 1)
     mb.matmul(width).relu()
     for _ in range(layers - 1):
         mb.matmul(width).relu()

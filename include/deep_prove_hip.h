@@ -192,7 +192,7 @@ int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const u
 
 /* ---- model level: Context::generate / Prover::prove / verify (zkml/src/iop/context.rs:109, prover.rs:401,
  * verifier.rs:306). model_blob (int64): input_len, nlayers, then per layer kind (0 Dense, 1 Requant, 2 Relu, 3 Conv,
- * 4 MaxPool, 5 Flatten, 6 MatMul) followed by
+ * 4 MaxPool, 5 Flatten, 6 MatMul, 7 Add) followed by
  *   Dense: nrows, ncols, weights[nrows*ncols] row-major, bias[nrows]   (padded to powers of two, already quantised; after a
  *          Flatten the columns follow the padded (c,h,w) layout with zeros at padding positions, tensor.rs:1627-1675)
  *   Requant: right_shift, fp_scale, fixed_point_multiplier, intermediate_bit_size   (zkml/src/layers/requant.rs:46-73)
@@ -205,7 +205,11 @@ int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const u
  *   MatMul: k, n, flags (1 = bias, 2 = Config::TransposeB), weights[k*n] ([k][n] row major; [n][k] with TransposeB), bias[n] if
  *          flagged — MatMul::new_constant (zkml/src/layers/matrix_mul.rs:176, 701-873): the activation is a row-major
  *          [s][k] matrix (s = its length / k, a power of two >= 2), the output [s][n]; the Linear layer of a transformer block
- *          applied to every row of a sequence. (MatMul of two inputs and the other transformer layers are not built.) */
+ *          applied to every row of a sequence.
+ *   Add: left multiplier, right multiplier, n, operand[n] — Add::new_with(operand) (zkml/src/layers/add.rs:72-145): out = left * x +
+ *          right * operand for a constant operand as long as the activation (how learned positional embeddings enter,
+ *          transformer/positional.rs); no sumcheck: the proof is the two evaluations, the operand's goes to its commitment.
+ *   (MatMul / Add of two inputs and the other transformer layers are not built: the model is a chain of nodes.) */
 int32_t dp_model_setup(dp_ctx* ctx, const int64_t* model_blob, size_t nwords, dp_model** out);
 int32_t dp_model_free(dp_model* m);
 /* runs inference on the host (Model::run, not part of proving time) then Prover::prove on the device.

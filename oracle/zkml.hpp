@@ -169,12 +169,15 @@ static inline LogUpProof logup_batch_prove(const LogUpInput& in, Transcript& t) 
 }
 
 // ------------------------------------------------------------------ model description
-enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6 };
+enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7 };
 struct Layer {
   LayerKind kind;
   // dense (padded to powers of two). matmul (layers/matrix_mul.rs, MatMul::new_constant: Input x Weight [+ bias]): the constant RIGHT
   // matrix is [nrows][ncols] row major, the input a row-major [s][nrows] matrix, bias [ncols] or empty
   size_t nrows = 0, ncols = 0;
+  // add (layers/add.rs, Add::new_with(operand)): out = add_left * x + add_right * operand, the operand (a constant tensor as long as the
+  // input, e.g. learned positional embeddings) in `weights`; the multipliers are QuantInfo::left/right_multiplier (add.rs:271-283)
+  int64_t add_left = 1, add_right = 1;
   bool transpose_b = false;  // matmul, Config::TransposeB (matrix_mul.rs:36-39): the constant matrix is stored as [ncols][nrows] and used transposed
   std::vector<int64_t> weights, bias;  // dense: row major, bias padded to nrows; conv: filter [kw][kx][real_nw][real_nw], bias [kw]
   // conv (layers/convolution.rs:52-83, tensor.rs:409-431): padded filter count kw, padded input channels kx, padded
@@ -341,6 +344,10 @@ static inline Trace run_model(const Model& m, const std::vector<int64_t>& input)
       const size_t s_ = cur.size() / k;
       o.assign(s_ * n, 0);
       for (size_t i = 0; i < s_; i++) for (size_t j = 0; j < n; j++) { int64_t a = 0; for (size_t q = 0; q < k; q++) a += cur[i * k + q] * (l.transpose_b ? l.weights[j * k + q] : l.weights[q * n + j]); o[i * n + j] = a + (l.bias.empty() ? 0 : l.bias[j]); }
+    } else if (l.kind == L_ADD) {  // Add::evaluate (add.rs:184-210)
+      if (cur.size() != l.weights.size()) throw std::runtime_error("add: operand size mismatch");
+      o.resize(cur.size());
+      for (size_t i = 0; i < cur.size(); i++) o[i] = l.add_left * cur[i] + l.add_right * l.weights[i];
     } else if (l.kind == L_REQUANT) {
       for (int64_t v : cur) {
         if (std::llabs(v) > (int64_t(1) << l.intermediate_bit_size)) throw std::runtime_error("requant: value too large");
@@ -382,7 +389,7 @@ static inline Context context_generate(const Model& m) {
   }
   std::sort(tset.begin(), tset.end());
   for (auto& t : tset) max_poly_len = std::max(max_poly_len, size_t(1) << t.multiplicity_poly_vars());
-  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL) { max_poly_len = std::max(max_poly_len, next_pow2(l.weights.size())); max_poly_len = std::max(max_poly_len, next_pow2(l.bias.size())); }
+  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD) { max_poly_len = std::max(max_poly_len, next_pow2(l.weights.size())); max_poly_len = std::max(max_poly_len, next_pow2(l.bias.size())); }
   max_poly_len = next_pow2(max_poly_len);
   ctx.max_poly_len = max_poly_len;
   ctx.pp = pcs_setup(max_poly_len);
@@ -392,6 +399,7 @@ static inline Context context_generate(const Model& m) {
   for (size_t id = 0; id < m.layers.size(); id++) {
     if (m.layers[id].kind == L_DENSE) { jobs.push_back({id, "DenseWeight"}); jobs.push_back({id, "DenseBias"}); }
     if (m.layers[id].kind == L_CONV) { jobs.push_back({id, "ConvFilter"}); jobs.push_back({id, "ConvBias"}); }  // convolution.rs:452-453,546-553
+    if (m.layers[id].kind == L_ADD) jobs.push_back({id, "255"});  // OPERAND_POLY_ID = 0xff, to_string() (add.rs:32,520)
     if (m.layers[id].kind == L_MATMUL) { jobs.push_back({id, "MatMulWeight"}); if (!m.layers[id].bias.empty()) jobs.push_back({id, "MatMulBias"}); }  // matrix_mul.rs:947-963
   }
   for (auto& j : jobs) ctx.model_comms[j.first][j.second];  // create map slots before the threads write into them
@@ -399,7 +407,7 @@ static inline Context context_generate(const Model& m) {
   for (auto& j : jobs) th.emplace_back([&ctx, &m, j] {
     const Layer& l = m.layers[j.first];
     std::string pid = j.second;
-    Mle poly = Mle::from_i64(pid == "DenseWeight" || pid == "ConvFilter" || pid == "MatMulWeight" ? l.weights : l.bias);
+    Mle poly = Mle::from_i64(pid == "DenseWeight" || pid == "ConvFilter" || pid == "MatMulWeight" || pid == "255" ? l.weights : l.bias);
     ctx.model_comms[j.first][j.second] = {pcs_commit(ctx.pp, poly), poly};
   });
   for (auto& t : th) t.join();
@@ -409,6 +417,7 @@ static inline Context context_generate(const Model& m) {
 
 // ------------------------------------------------------------------ proofs
 struct DenseProof { IOPProof sumcheck; E bias_eval; std::vector<E> individual_claims; };
+struct AddProof { E left_eval, right_eval; };  // add.rs:59-63
 struct MatMulProof { IOPProof sumcheck; std::vector<E> individual_claims; bool has_bias = false; E bias_eval{}; };  // matrix_mul.rs:153-161 (bias_eval: Option<E>)
 struct SamePolyProof { IOPProof sumcheck; std::vector<E> evals; };
 struct ActivationProof { SamePolyProof io_accumulation; LogUpProof lookup; std::vector<Commitment> commits; };
@@ -427,7 +436,7 @@ struct ConvProof {  // convolution.rs:98-127, fields in declaration order
   HadamardProof clearing_proof;
 };
 struct PoolingProof { IOPProof sumcheck; LogUpProof lookup; std::vector<E> zerocheck_evals; size_t variable_gap = 0; std::vector<Commitment> commitments; };  // pooling.rs:60-76
-struct LayerProof { LayerKind kind; DenseProof dense; MatMulProof matmul; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; };
+struct LayerProof { LayerKind kind; DenseProof dense; MatMulProof matmul; AddProof add; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; };
 struct TableProof { Commitment multiplicity_commit; LogUpProof lookup; };
 struct Proof {
   std::map<size_t, LayerProof> steps;  // canonical order: ascending NodeId
@@ -546,6 +555,16 @@ static inline Claim prove_dense(ProverState& ps, size_t id, const Layer& l, cons
   LayerProof lp; lp.kind = L_DENSE; lp.dense = {proof, bias_eval, fin};
   ps.proofs[id] = lp;
   return {proof.point, fin[1]};
+}
+// Add::prove_step with a static operand (layers/add.rs:81-145): no sumcheck and no transcript traffic — the prover evaluates the input at the
+// claim's point, solves out(r) = M1 x(r) + M2 c(r) for the operand's evaluation and hands that claim to the operand's commitment
+static inline Claim prove_add(ProverState& ps, size_t id, const Layer& l, const Claim& last, const std::vector<E>& input) {
+  E left_eval = Mle::from_ext(input).evaluate(last.point);
+  E right_eval = emul(esub(last.eval, emul(left_eval, e_from_i64(l.add_left))), einv(e_from_i64(l.add_right)));
+  ps.add_witness_claim(ps.ctx->model_comms.at(id).at("255"), {last.point, right_eval});
+  LayerProof lp; lp.kind = L_ADD; lp.add = {left_eval, right_eval};
+  ps.proofs[id] = lp;
+  return {last.point, left_eval};
 }
 // MatMul::prove_step (layers/matrix_mul.rs:701-873) for the (Input, Weight) arrangement, right matrix not transposed:
 // split_claim (:339-356): the low variables of the output point address columns -> the right matrix, the high ones rows -> the left;
@@ -912,6 +931,7 @@ static inline Proof prove(const Context& ctx, const Trace& tr, Transcript& t) {
     const Layer& l = ctx.model.layers[id];
     if (l.kind == L_DENSE) cur = prove_dense(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_MATMUL) cur = prove_matmul(ps, id, l, cur, to_fields(tr.in[id]));
+    else if (l.kind == L_ADD) cur = prove_add(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
     else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, to_fields(tr.out[id]));
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv[id]);
@@ -974,6 +994,7 @@ static inline std::vector<u64> serialize_proof(const Proof& p) {
   for (auto& [id, lp] : p.steps) {
     w.u(id); w.u(lp.kind);
     if (lp.kind == L_DENSE) { w.iop(lp.dense.sumcheck); w.e(lp.dense.bias_eval); w.ve(lp.dense.individual_claims); }
+    else if (lp.kind == L_ADD) { w.e(lp.add.left_eval); w.e(lp.add.right_eval); }
     else if (lp.kind == L_MATMUL) { w.iop(lp.matmul.sumcheck); w.ve(lp.matmul.individual_claims); w.u(lp.matmul.has_bias ? 1 : 0); if (lp.matmul.has_bias) w.e(lp.matmul.bias_eval); }
     else if (lp.kind == L_REQUANT) {
       w.iop(lp.req.io_accumulation); w.ve(lp.req.accumulation_evals); w.logup(lp.req.clamping_lookup); w.logup(lp.req.shifted_lookup);

@@ -34,7 +34,7 @@ static dp::LayerSpec requant_for(size_t ncols, double m) {
 }
 static orc::Model to_orc(const dp::ModelSpec& m) {
   orc::Model o; o.input_len = m.input_len;
-  for (auto& l : m.layers) { orc::Layer x; x.kind = (orc::LayerKind)l.kind; x.nrows = l.nrows; x.ncols = l.ncols; x.weights = l.weights; x.bias = l.bias; x.transpose_b = l.mm_transpose; x.right_shift = l.right_shift; x.fp_scale = l.fp_scale; x.intermediate_bit_size = l.intermediate_bit_size; x.fixed_point_multiplier = l.fixed_point_multiplier;
+  for (auto& l : m.layers) { orc::Layer x; x.kind = (orc::LayerKind)l.kind; x.nrows = l.nrows; x.ncols = l.ncols; x.weights = l.weights; x.bias = l.bias; x.transpose_b = l.mm_transpose; x.add_left = l.add_left; x.add_right = l.add_right; x.right_shift = l.right_shift; x.fp_scale = l.fp_scale; x.intermediate_bit_size = l.intermediate_bit_size; x.fixed_point_multiplier = l.fixed_point_multiplier;
     x.kw = l.kw; x.kx = l.kx; x.real_nw = l.real_nw; x.nw = l.nw; for (int k = 0; k < 3; k++) { x.unp_out[k] = l.unp_out[k]; x.pin[k] = l.pin[k]; }
     o.layers.push_back(x); }
   return o;
@@ -245,6 +245,11 @@ int main(int argc, char** argv) {
   else if (seq) {
     const size_t S = 8, F = 4, H = 16;
     m.input_len = S * F;
+    if (getenv("HL_POSITIONAL")) {  // Add with a static operand (layers/add.rs; the learned positional table of transformer/positional.rs), then a Requant by 1/2
+      dp::LayerSpec a; a.kind = dp::L_ADD; a.add_left = 1; a.add_right = 1; a.weights.resize(S * F); for (auto& x : a.weights) x = rq();
+      m.layers.push_back(a);
+      dp::LayerSpec r2 = requant_for(1, 0.5); r2.intermediate_bit_size = 9; m.layers.push_back(r2);
+    }
     m.layers.push_back(matmul(F, H, true)); m.layers.push_back(requant_for(F, 0.5 / 127)); m.layers.push_back(relu);
     m.layers.push_back(matmul(H, H, true)); m.layers.push_back(requant_for(H, 1.0 / std::sqrt((double)H) / 127)); m.layers.push_back(relu);
     m.layers.push_back(matmul(H, F, false, getenv("HL_TRANSPOSE") != nullptr)); m.layers.push_back(requant_for(H, 1.0 / std::sqrt((double)H) / 127)); m.layers.push_back(relu);

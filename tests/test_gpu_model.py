@@ -199,12 +199,13 @@ def test_batch_verifier_with_device_side_merkle_paths(dev):
     ctx.free()
 
 
-@pytest.mark.parametrize("seq,width,transpose", [(8, 16, False), (16, 64, True), (64, 256, False), (32, 128, True)])
-def test_matmul_model_proof_bytes_identical_to_oracle(dev, oracle, seq, width, transpose):
+@pytest.mark.parametrize("seq,width,transpose,positional", [(8, 16, False, False), (16, 64, True, False), (64, 256, False, True), (32, 128, True, True)])
+def test_matmul_model_proof_bytes_identical_to_oracle(dev, oracle, seq, width, transpose, positional):
     """MatMul with a constant right matrix over a [seq][features] activation (layers/matrix_mul.rs; k_fix_low on the weights,
     fix_high on the activation, the degree-2 sumcheck): proof stream == the oracle's, the verifier accepts, numpy inference agrees"""
     import deep_prove_amd as dpa
-    mb = dpa.models.seq_mlp(seq, width, config=60 + seq, transpose_last=transpose)  # (Config::TransposeB on the last MatMul)
+    # Config::TransposeB on the last MatMul; a positional table added to the input (Add with a static operand, layers/add.rs)
+    mb = dpa.models.seq_mlp(seq, width, config=60 + seq, transpose_last=transpose, positional=positional)
     x = mb.input()
     ctx, proof, out, oproof, oout = prove_both(dev, oracle, mb, x)
     assert (out == oout).all() and (out == mb.run(x)).all()

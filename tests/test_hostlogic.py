@@ -152,7 +152,9 @@ def test_matmul_model_proof_stream_identical_to_oracle_and_accepted(hostlogic_bi
     to every row of a [seq][features] activation): three MatMul (+bias / no bias) + Requant + ReLU blocks over an [8][4] input — the
     product's orchestrator over the CPU double (Dev::fix_high on the activation, Dev::fix_low on the weights, the degree-2 sumcheck,
     the claims routed to the previous layer / the weight and bias commitments) gives the oracle's stream; the verifier accepts both"""
-    for env in ({}, {"HL_TRANSPOSE": "1"}):  # the last MatMul with Config::TransposeB (constant matrix stored [n][k]: fix_high, other claim point)
+    # the last MatMul with Config::TransposeB (constant matrix stored [n][k]: fix_high, other claim point); an Add with a static operand
+    # (layers/add.rs:81-145, 586-625: the learned positional table of transformer/positional.rs) in front of the first MatMul
+    for env in ({}, {"HL_TRANSPOSE": "1"}, {"HL_POSITIONAL": "1"}, {"HL_POSITIONAL": "1", "HL_TRANSPOSE": "1"}):
         r = run(hostlogic_bin, "seq", seed, env=env)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "identical=1" in r.stdout

@@ -90,3 +90,22 @@ def test_matmul_step_in_the_wire_format():
     assert sum(b["bias_eval"] is None for b in mm) == 1 and all(len(b["individual_claims"]) == 2 for b in mm)
     back = wire.from_rmp(data)
     assert wire.stream_equal_modulo_skipped(back, p) and wire.to_rmp(back) == data
+
+
+def test_add_step_in_the_wire_format(oracle):
+    """LayerProof::Add(AddProof {left_eval, right_eval}) (layers/add.rs:59-63): a model with a positional Add proved by the oracle,
+    encoded, decoded by an independent MessagePack reader, and back"""
+    import deep_prove_amd as dpa
+    from deep_prove_amd import wire
+    mb = dpa.models.seq_mlp(8, 16, config=62, positional=True)
+    x = mb.input()
+    h = oracle.model_setup(mb.blob())
+    p, out, _ = oracle.model_prove(h, x)
+    oracle.model_free(h)
+    assert (out == mb.run(x)).all()
+    data = wire.to_rmp(p)
+    m = msgpack.unpackb(data, raw=False, strict_map_key=False)
+    adds = [body for lp in m["steps"].values() for kind, body in lp.items() if kind == "Add"]
+    assert len(adds) == 1 and list(adds[0]) == ["left_eval", "right_eval"]
+    back = wire.from_rmp(data)
+    assert wire.stream_equal_modulo_skipped(back, p) and wire.to_rmp(back) == data
