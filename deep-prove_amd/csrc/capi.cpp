@@ -42,7 +42,7 @@ __attribute__((constructor)) static void dp_default_hw_queues() { setenv("GPU_MA
 // the host transcript's Poseidon2: the AVX-512 permutation of p2_avx512.cpp when the CPU has it (DP_NO_AVX512=1: the scalar code)
 __attribute__((constructor)) static void dp_install_fast_poseidon2() {
   const char* e = getenv("DP_NO_AVX512");
-  if (!(e && atoi(e)) && dp::p2_cpu_has_avx512()) dp::p2_fast() = dp::p2_permute_avx512;
+  if (!(e && atoi(e)) && dp::p2_cpu_has_avx512()) { dp::p2_fast() = dp::p2_permute_avx512; dp::p2_fast_compress8() = dp::p2_compress8_avx512; }
 }
 static thread_local std::string g_err;
 template <class F>
@@ -727,7 +727,12 @@ int32_t dp_verify(const uint64_t* vb, size_t vn, const uint64_t* pw, size_t pn, 
     Proof p = deserialize_proof(pw, pn);
     IO io; io.input.assign(input, input + ninput); io.output.assign(output, output + noutput);
     Transcript t = default_transcript();
-    verify(vc, p, io, t);
+    // the Merkle paths are recorded while the protocol checks run and authenticated together afterwards (eight side by side on AVX-512 CPUs)
+    std::vector<MerkleJob> jobs;
+    merkle_sink() = &jobs;
+    try { verify(vc, p, io, t); } catch (...) { merkle_sink() = nullptr; throw; }
+    merkle_sink() = nullptr;
+    DP_REQUIRE(merkle_jobs_ok(jobs), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
   });
 }
 
@@ -769,7 +774,7 @@ int32_t dp_verify_batch(dp_ctx* ctx, const uint64_t* vb, size_t vn, const uint64
           }
           bool ok;
           if (ctx) { CtxLock lk(ctx); ok = ctx->dev->merkle_paths_check(leaf.data(), root.data(), x.data(), off.data(), depth.data(), n, pool.data(), pool_n, nullptr); }
-          else { ok = true; for (const MerkleJob& j : jobs) if (!merkle_job_ok(j)) { ok = false; break; } }
+          else ok = merkle_jobs_ok(jobs);
           results[i] = ok ? DP_OK : DP_ERR_VERIFY;
         } catch (const DpError& e) { merkle_sink() = nullptr; results[i] = e.code == DP_ERR_VERIFY ? DP_ERR_VERIFY : DP_ERR_ARG; }
         catch (const std::exception&) { merkle_sink() = nullptr; results[i] = DP_ERR_ARG; }

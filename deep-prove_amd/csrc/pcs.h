@@ -4,6 +4,7 @@
 // 1116-1236). RS code rate 1/2, 200 queries, base-case message 2^7 (encoding/rs.rs:194-215).
 #pragma once
 #include "sumcheck.h"
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -290,6 +291,37 @@ inline bool merkle_job_ok(const MerkleJob& j) {
   Digest h = j.leaf; size_t x = j.x;
   for (size_t l = 0; l < j.depth; l++) { h = (x & 1) ? host_compress(j.path[l], h) : host_compress(h, j.path[l]); x >>= 1; }
   return h == j.root;
+}
+// all recorded paths of a proof. With the vectorised compression (p2_avx512.cpp, installed by the library on AVX-512 CPUs) eight paths
+// climb side by side, one per lane, sorted by depth so that the lanes of a group finish together; a finished lane idles masked.
+inline bool merkle_jobs_ok(const std::vector<MerkleJob>& jobs) {
+  auto c8 = p2_fast_compress8();
+  if (!c8 || jobs.size() < 8) { for (const MerkleJob& j : jobs) if (!merkle_job_ok(j)) return false; return true; }
+  std::vector<size_t> order(jobs.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return jobs[a].depth > jobs[b].depth; });
+  for (size_t g = 0; g < order.size(); g += 8) {
+    const size_t m = std::min<size_t>(8, order.size() - g);
+    u64 h[8][4], l[8][4], r[8][4], o[8][4]; size_t x[8], depth[8]; size_t maxd = 0;
+    for (size_t k = 0; k < 8; k++) {
+      const MerkleJob& j = jobs[order[g + (k < m ? k : 0)]];  // (a short last group repeats its first path)
+      for (int q = 0; q < 4; q++) h[k][q] = j.leaf.v[q];
+      x[k] = j.x; depth[k] = j.depth; maxd = std::max(maxd, j.depth);
+    }
+    for (size_t lv = 0; lv < maxd; lv++) {
+      for (size_t k = 0; k < 8; k++) {
+        const MerkleJob& j = jobs[order[g + (k < m ? k : 0)]];
+        static const Digest idle{};
+        const Digest& sib = lv < depth[k] ? j.path[lv] : idle;  // (a lane whose path has ended hashes on, its result is dropped)
+        const bool right_child = (x[k] >> lv) & 1;
+        for (int q = 0; q < 4; q++) { l[k][q] = right_child ? sib.v[q] : h[k][q]; r[k][q] = right_child ? h[k][q] : sib.v[q]; }
+      }
+      c8(l, r, o);
+      for (size_t k = 0; k < 8; k++) if (lv < depth[k]) for (int q = 0; q < 4; q++) h[k][q] = o[k][q];
+    }
+    for (size_t k = 0; k < m; k++) { const MerkleJob& j = jobs[order[g + k]]; for (int q = 0; q < 4; q++) if (h[k][q] != j.root.v[q]) return false; }
+  }
+  return true;
 }
 // authenticate_merkle_path_root (merkle_tree.rs:331-420)
 inline void check_merkle_path(const CodewordQuery& q, const Digest& root) {

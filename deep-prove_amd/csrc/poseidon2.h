@@ -155,7 +155,9 @@ inline void permute_scalar(u64* s) {
 // installed by the library when the CPU has AVX-512F/DQ (capi.cpp; DP_NO_AVX512=1 keeps the scalar code). Word-for-word equal results.
 void p2_permute_avx512(u64* s);
 bool p2_cpu_has_avx512();
+void p2_compress8_avx512(const u64 (*left)[4], const u64 (*right)[4], u64 (*out)[4]);  // eight compressions side by side (lane = pair)
 inline void (*&p2_fast())(u64*) { static void (*f)(u64*) = nullptr; return f; }
+inline void (*&p2_fast_compress8())(const u64 (*)[4], const u64 (*)[4], u64 (*)[4]) { static void (*f)(const u64 (*)[4], const u64 (*)[4], u64 (*)[4]) = nullptr; return f; }
 namespace hostnc {
 inline void permute(u64* s) { if (void (*f)(u64*) = p2_fast()) f(s); else permute_scalar(s); }
 }  // namespace hostnc
