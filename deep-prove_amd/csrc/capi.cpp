@@ -482,7 +482,11 @@ int32_t dp_pcs_verify(size_t max_poly_size, const uint64_t root[4], uint32_t num
     if (p.is_trivial()) { DP_REQUIRE(num_vars <= PCS_BASECODE_LOG, DP_ERR_VERIFY, "trivial proof for a non-trivial commitment"); pcs_verify_trivial(c, read_point(point, num_vars), read_point(eval, 1)[0], p); return; }
     DP_REQUIRE(t, DP_ERR_ARG, "a non-trivial opening needs the transcript");
     VerifierParams vp; vp.full_log = dp_ceil_log2(max_poly_size);
-    pcs_verify(vp, c, read_point(point, num_vars), read_point(eval, 1)[0], p, t->t);
+    std::vector<MerkleJob> jobs;  // (the 200 x (rounds + 1) paths are recorded, then authenticated together: eight side by side on AVX-512 CPUs)
+    merkle_sink() = &jobs;
+    try { pcs_verify(vp, c, read_point(point, num_vars), read_point(eval, 1)[0], p, t->t); } catch (...) { merkle_sink() = nullptr; throw; }
+    merkle_sink() = nullptr;
+    DP_REQUIRE(merkle_jobs_ok(jobs), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
   });
 }
 static void read_claims(int32_t n, const uint64_t* points_flat, const uint64_t* evals, const std::vector<unsigned>& nvs, std::vector<std::vector<Ext>>& pts, std::vector<Ext>& evs) {
@@ -517,7 +521,11 @@ int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const u
     Reader r(proof_words, proof_nwords); BasefoldProof p = r.basefold();
     DP_REQUIRE(r.pos == proof_nwords, DP_ERR_ARG, "proof stream: trailing words");
     VerifierParams vp; vp.full_log = dp_ceil_log2(max_poly_size);
-    pcs_batch_verify(vp, vc, p, t->t);
+    std::vector<MerkleJob> jobs;
+    merkle_sink() = &jobs;
+    try { pcs_batch_verify(vp, vc, p, t->t); } catch (...) { merkle_sink() = nullptr; throw; }
+    merkle_sink() = nullptr;
+    DP_REQUIRE(merkle_jobs_ok(jobs), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
   });
 }
 
