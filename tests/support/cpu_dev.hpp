@@ -64,16 +64,7 @@ class CpuDev : public Dev {
     }
     release(mark() - 1);
   }
-  void fix_low(const DBuf& out, const DBuf& W, size_t R, size_t C, const Ext* pt) override {
-    DBuf eq = alloc(C, true);
-    eq_table(eq, pt, dp_ceil_log2(C), ex_one(), false);
-    for (size_t r = 0; r < R; r++) {
-      Ext s = ex_zero();
-      for (size_t c = 0; c < C; c++) s = ex_add(s, ex_mul_base(X(eq)[c], B(W)[r * C + c]));
-      X(out)[r] = s;
-    }
-    release(mark() - 1);
-  }
+  // (Dev::fix_low: the double keeps the interface's default — one MLE evaluation per row — so that path is exercised too)
   DBuf fold(const DBuf& in, Ext r) {
     DBuf o = alloc(in.n / 2, true);
     for (size_t i = 0; i < in.n / 2; i++) X(o)[i] = in.ext ? ex_lerp(X(in)[2 * i], X(in)[2 * i + 1], r) : ex_lerp_base(B(in)[2 * i], B(in)[2 * i + 1], r);
