@@ -32,6 +32,8 @@ struct LayerSpec {
   // the input a row-major [s][nrows] matrix (s = its length / nrows), bias [ncols] or empty; the output is [s][ncols]. mm_transpose
   // (Config::TransposeB, matrix_mul.rs:36-39): the constant matrix is stored as [ncols][nrows] and used transposed
   bool mm_transpose = false;
+  // embeddings (layers/transformer/embeddings.rs): only as the FIRST layer; the input is a vector of token ids, weights the
+  // [nrows = vocabulary][ncols = embedding size] table, the output [tokens][ncols]
   // add (layers/add.rs, Add::new_with(operand)): out = add_left * x + add_right * operand; the operand — a constant tensor as long as the
   // input, e.g. learned positional embeddings — is `weights`; the multipliers are QuantInfo::left/right_multiplier (add.rs:271-283)
   int64_t add_left = 1, add_right = 1;
@@ -152,6 +154,7 @@ inline size_t model_output_len(const ModelSpec& m) {
   for (const LayerSpec& l : m.layers) {
     if (l.kind == L_DENSE) cur = l.nrows;
     else if (l.kind == L_MATMUL) cur = cur / l.nrows * l.ncols;
+    else if (l.kind == L_EMBED) cur = cur * l.ncols;
     else if (l.kind == L_CONV) cur = l.kw * l.nw * l.nw;
     else if (l.kind == L_MAXPOOL) cur = l.pin[0] * (l.pin[1] / 2) * (l.pin[2] / 2);
   }
@@ -183,6 +186,12 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
         if (l.mm_transpose) for (size_t j = 0; j < n; j++) { const int64_t* w = &l.weights[j * k]; const int64_t* x = &cur[i * k]; int64_t a = 0; for (size_t q = 0; q < k; q++) a += x[q] * w[q]; row[j] = a; }
         else for (size_t q = 0; q < k; q++) { const int64_t x = cur[i * k + q]; const int64_t* w = &l.weights[q * n]; for (size_t j = 0; j < n; j++) row[j] += x * w[j]; }
         if (!l.bias.empty()) for (size_t j = 0; j < n; j++) row[j] += l.bias[j];
+      }
+    } else if (l.kind == L_EMBED) {  // Embeddings::evaluate (embeddings.rs:197-236): row x[i] of the table for every token
+      o.resize(cur.size() * l.ncols);
+      for (size_t i = 0; i < cur.size(); i++) {
+        DP_REQUIRE(cur[i] >= 0 && (size_t)cur[i] < l.nrows, DP_ERR_ARG, "embeddings: token outside the vocabulary");
+        memcpy(&o[i * l.ncols], &l.weights[(size_t)cur[i] * l.ncols], l.ncols * sizeof(int64_t));
       }
     } else if (l.kind == L_ADD) {  // Add::evaluate (add.rs:184-210)
       DP_REQUIRE(cur.size() == l.weights.size(), DP_ERR_SHAPE, "add: operand size mismatch");
@@ -250,6 +259,10 @@ inline void validate_model(const ModelSpec& m) {
       DP_REQUIRE(is_pow2(l.nrows) && is_pow2(l.ncols) && l.nrows >= 2 && l.ncols >= 2, DP_ERR_SHAPE, "matmul: padded dimensions must be powers of two >= 2");
       DP_REQUIRE(cur % l.nrows == 0 && cur / l.nrows >= 2 && l.weights.size() == l.nrows * l.ncols && (l.bias.empty() || l.bias.size() == l.ncols), DP_ERR_SHAPE, "matmul: tensor sizes (the input is [s][nrows], s >= 2)");
       cur = cur / l.nrows * l.ncols;
+    } else if (l.kind == L_EMBED) {
+      DP_REQUIRE(&l == &m.layers[0], DP_ERR_SHAPE, "embeddings: only as the first layer (its input claim is checked against the public tokens)");
+      DP_REQUIRE(is_pow2(l.nrows) && is_pow2(l.ncols) && l.nrows >= 2 && l.ncols >= 2 && l.weights.size() == l.nrows * l.ncols && cur >= 2, DP_ERR_SHAPE, "embeddings: padded table dimensions must be powers of two >= 2");
+      cur = cur * l.ncols;
     } else if (l.kind == L_ADD) {
       DP_REQUIRE(l.weights.size() == cur && cur >= 2 && l.add_left > 0 && l.add_right > 0 && l.add_left < (int64_t(1) << 40) && l.add_right < (int64_t(1) << 40), DP_ERR_SHAPE, "add: the operand must be as long as the input, the multipliers positive");
     } else if (l.kind == L_REQUANT) {
@@ -281,6 +294,7 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
   for (auto& l : m.layers) {
     if (l.kind == L_DENSE) cur = l.nrows;
     else if (l.kind == L_MATMUL) cur = cur / l.nrows * l.ncols;
+    else if (l.kind == L_EMBED) cur = cur * l.ncols;
     else if (l.kind == L_REQUANT) { add({2, 0}); add({3, l.clamping_size()}); mpl = std::max(mpl, next_pow2(cur)); }
     else if (l.kind == L_RELU) { add({0, 0}); mpl = std::max(mpl, next_pow2(cur)); }
     else if (l.kind == L_CONV) cur = l.kw * l.nw * l.nw;
@@ -288,13 +302,20 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
   }
   std::sort(ts.begin(), ts.end());
   for (auto& t : ts) mpl = std::max(mpl, size_t(1) << t.vars());
-  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD) mpl = std::max(mpl, std::max(next_pow2(l.weights.size()), next_pow2(l.bias.size())));
+  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD || l.kind == L_EMBED) mpl = std::max(mpl, std::max(next_pow2(l.weights.size()), next_pow2(l.bias.size())));
   mpl = next_pow2(mpl);
   ctx->max_poly_len = mpl; ctx->full_log = dp_ceil_log2(mpl); ctx->tables = ts;
   dev.pcs_init(ctx->full_log);
   for (size_t id = 0; id < m.layers.size(); id++) {
     LayerSpec& l = ctx->model.layers[id];
-    if (l.kind != L_DENSE && l.kind != L_CONV && l.kind != L_MATMUL && l.kind != L_ADD) continue;
+    if (l.kind != L_DENSE && l.kind != L_CONV && l.kind != L_MATMUL && l.kind != L_ADD && l.kind != L_EMBED) continue;
+    if (l.kind == L_EMBED) {  // the embedding table is a model polynomial (embeddings.rs:271,284-291)
+      DBuf w = dev.alloc_persistent(l.weights.size(), false);
+      dev.upload_i64(w, l.weights.data());
+      ctx->model_comms[id]["EmbeddingMat"] = dev.commit(w, true);
+      ctx->weights_dev[id] = w;
+      continue;
+    }
     if (l.kind == L_ADD) {  // the static operand is a model polynomial: OPERAND_POLY_ID = 0xff, to_string() (add.rs:32,518-522)
       DBuf w = dev.alloc_persistent(l.weights.size(), false);
       dev.upload_i64(w, l.weights.data());
@@ -484,6 +505,34 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
   }
   ps.constant_challenge = ps.t->get_and_append_challenge("table_constant");
   for (auto& kv : counts) ps.challenge_map[kv.first] = kv.first.label() ? ps.t->get_and_append_challenge(kv.first.label()) : ex_one();
+}
+
+// Embeddings::prove (layers/transformer/embeddings.rs:359-462): the matmul protocol on (one-hot(tokens), table) without the one-hot
+// matrix — its row variables fixed at the row part of the claim are reduced[x[i]] += beta(i, row part), a vocabulary-long vector built on
+// the host from the (few) tokens and uploaded; the table's column variables fixed on the device (Dev::fix_low); one degree-2 sumcheck over
+// the vocabulary. The table claim [column part | sumcheck point] goes to the commitment; the one-hot claim [sumcheck point | row part]
+// is the model's input claim, which the verifier checks against the public tokens.
+inline Claim prove_embeddings(ProverState& ps, size_t id, const LayerSpec& l, const Claim& last, const std::vector<int64_t>& tokens) {
+  Dev& dev = *ps.dev;
+  const unsigned nvc = dp_ceil_log2(l.ncols), nvr = dp_ceil_log2(tokens.size());
+  DP_REQUIRE(is_pow2(tokens.size()) && last.point.size() == nvc + nvr, DP_ERR_SHAPE, "embeddings: claim point length");
+  size_t mk = dev.mark();
+  std::vector<Ext> col_pt(last.point.begin(), last.point.begin() + nvc), row_pt(last.point.begin() + nvc, last.point.end());
+  std::vector<Ext> beta = host_eq_table(row_pt), reduced(l.nrows, ex_zero());
+  for (size_t i = 0; i < tokens.size(); i++) reduced[(size_t)tokens[i]] = ex_add(reduced[(size_t)tokens[i]], beta[i]);
+  DBuf in = dev.alloc(l.nrows, true), table = dev.alloc(l.nrows, true);
+  dev.upload(in, (const u64*)reduced.data());
+  dev.fix_low(table, ps.ctx->weights_dev.at(id), l.nrows, l.ncols, col_pt.data());
+  DevVP vp(dp_ceil_log2(l.nrows));
+  vp.add_mle_list({in, table}, ex_one());
+  SumcheckOut sc = sumcheck_prove(dev, vp, *ps.t);
+  std::vector<Ext> one_hot_pt = sc.proof.point; one_hot_pt.insert(one_hot_pt.end(), row_pt.begin(), row_pt.end());
+  std::vector<Ext> table_pt = col_pt; table_pt.insert(table_pt.end(), sc.proof.point.begin(), sc.proof.point.end());
+  ps.add_witness_claim(ps.ctx->model_comms.at(id).at("EmbeddingMat"), {table_pt, sc.finals[1]});
+  LayerProof lp; lp.kind = L_EMBED; lp.matmul.sumcheck = sc.proof; lp.matmul.individual_claims = sc.finals;
+  ps.proofs[id] = lp;
+  dev.release(mk);
+  return {one_hot_pt, sc.finals[0]};
 }
 
 // Add::prove_step with a static operand (layers/add.rs:81-145): no sumcheck, no transcript traffic. The input's evaluation at the claim's
@@ -873,6 +922,7 @@ inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t) {
     if (l.kind == L_DENSE) cur = prove_dense(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_MATMUL) cur = prove_matmul(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_ADD) cur = prove_add(ps, id, l, cur, tr.in[id]);
+    else if (l.kind == L_EMBED) cur = prove_embeddings(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
     else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, tr.out[id]);
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv.at(id));
@@ -1074,6 +1124,23 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       DP_REQUIRE(ex_eq(ex_mul(dpf.individual_claims[0], dpf.individual_claims[1]), sub.expected_evaluation), DP_ERR_VERIFY, "dense: sumcheck claim failed");
       cur = {sub.point, dpf.individual_claims[1]};
       cur_len = l.ncols;
+    } else if (l.kind == L_EMBED) {  // EmbeddingsCtx::verify (embeddings.rs:473-528); the one-hot claim is checked at the very end
+      const MatMulProof& ep = lp.matmul;
+      DP_REQUIRE(id == 0 && l.ncols && cur_len % l.ncols == 0, DP_ERR_VERIFY, "embeddings: shapes");
+      const size_t ntok = cur_len / l.ncols;
+      const unsigned nvc = dp_ceil_log2(l.ncols), nvr = dp_ceil_log2(ntok);
+      DP_REQUIRE(is_pow2(ntok) && cur.point.size() == nvc + nvr && ep.individual_claims.size() == 2, DP_ERR_VERIFY, "embeddings: shapes");
+      std::vector<Ext> col_pt(cur.point.begin(), cur.point.begin() + nvc), row_pt(cur.point.begin() + nvc, cur.point.end());
+      SubClaim sub = sumcheck_verify(cur.eval, ep.sumcheck, dp_ceil_log2(l.nrows), 2, t);
+      std::vector<Ext> one_hot_pt = sub.point; one_hot_pt.insert(one_hot_pt.end(), row_pt.begin(), row_pt.end());
+      std::vector<Ext> table_pt = col_pt; table_pt.insert(table_pt.end(), sub.point.begin(), sub.point.end());
+      auto nit = unused.find(id);
+      DP_REQUIRE(nit != unused.end() && nit->second.count("EmbeddingMat"), DP_ERR_VERIFY, "embeddings: no commitment for the table");
+      add_claim(nit->second.at("EmbeddingMat"), {table_pt, ep.individual_claims[1]});
+      unused.erase(nit);
+      DP_REQUIRE(ex_eq(ex_mul(ep.individual_claims[0], ep.individual_claims[1]), sub.expected_evaluation), DP_ERR_VERIFY, "embeddings: sumcheck claim failed");
+      cur = {one_hot_pt, ep.individual_claims[0]};
+      cur_len = ntok;
     } else if (l.kind == L_ADD) {  // AddCtx::verify (add.rs:586-625), static operand
       const AddProof& ap = lp.add;
       DP_REQUIRE(cur.point.size() == dp_ceil_log2(cur_len) && l.add_left > 0 && l.add_right > 0, DP_ERR_VERIFY, "add: shapes");
@@ -1183,7 +1250,22 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
     DP_REQUIRE(expect.size() + 1 == v.claims.size(), DP_ERR_VERIFY, "table: number of column claims");
     for (size_t k = 0; k < expect.size(); k++) DP_REQUIRE(ex_eq(v.claims[k + 1].eval, expect[k]), DP_ERR_VERIFY, "table: claimed column evaluation is wrong");
   }
-  // input claim (provable/mod.rs:542-565)
+  // input claim (provable/mod.rs:542-565); behind an Embeddings layer it is a claim on the one-hot encoding of the tokens:
+  // sum_i beta(i, r2) * eq(r1, bits(token_i)), r1 = the vocabulary part of the point (verify_input_claim, embeddings.rs:530-571)
+  if (m.layers[0].kind == L_EMBED) {
+    const unsigned vnv = dp_ceil_log2(m.layers[0].nrows);
+    DP_REQUIRE(cur.point.size() == vnv + dp_ceil_log2(io.input.size()), DP_ERR_VERIFY, "input claim is incorrect");
+    std::vector<Ext> r1(cur.point.begin(), cur.point.begin() + vnv), r2(cur.point.begin() + vnv, cur.point.end());
+    std::vector<Ext> beta = host_eq_table(r2);
+    Ext sum = ex_zero();
+    for (size_t i = 0; i < io.input.size(); i++) {
+      DP_REQUIRE(io.input[i] >= 0 && (size_t)io.input[i] < m.layers[0].nrows, DP_ERR_VERIFY, "token outside the vocabulary");
+      Ext sel = beta[i];
+      for (unsigned b = 0; b < vnv; b++) sel = ex_mul(sel, ((io.input[i] >> b) & 1) ? r1[b] : ex_sub(ex_one(), r1[b]));
+      sum = ex_add(sum, sel);
+    }
+    DP_REQUIRE(ex_eq(sum, cur.eval), DP_ERR_VERIFY, "one hot encoding claim is incorrect");
+  } else
   { std::vector<Ext> iv(io.input.size()); for (size_t i = 0; i < iv.size(); i++) iv[i] = ex_from_i64(io.input[i]);
     DP_REQUIRE(cur.point.size() == dp_ceil_log2(iv.size()) && ex_eq(host_mle_eval(iv, cur.point), cur.eval), DP_ERR_VERIFY, "input claim is incorrect"); }
   // commitment openings (commit/context.rs:520-598)
@@ -1200,8 +1282,8 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
 }
 
 // ---- serialisable verifier context (what dp_model_verifier_blob hands out and dp_verify consumes)
-constexpr int N_POLY_IDS = 7;
-inline const char* const* poly_ids() { static const char* const ids[N_POLY_IDS] = {"DenseBias", "DenseWeight", "ConvBias", "ConvFilter", "MatMulBias", "MatMulWeight", "255"}; return ids; }
+constexpr int N_POLY_IDS = 8;
+inline const char* const* poly_ids() { static const char* const ids[N_POLY_IDS] = {"DenseBias", "DenseWeight", "ConvBias", "ConvFilter", "MatMulBias", "MatMulWeight", "255", "EmbeddingMat"}; return ids; }
 inline std::vector<u64> vctx_to_words(const VerifierContext& v) {
   std::vector<u64> w;
   w.push_back(0x3158544356504444ULL); w.push_back(v.full_log); w.push_back(v.shape.input_len); w.push_back(v.shape.layers.size());
@@ -1239,7 +1321,7 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
     l.kw = (size_t)rd(); l.kx = (size_t)rd(); l.real_nw = (size_t)rd(); l.nw = (size_t)rd();
     for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();
     for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd();
-    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_ADD, DP_ERR_ARG, "verifier blob: layer kind");
+    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_EMBED, DP_ERR_ARG, "verifier blob: layer kind");
     if (l.kind == L_ADD) { l.add_left = l.fixed_point_multiplier; l.add_right = (int64_t)l.kx; l.fixed_point_multiplier = 0; l.kx = 0; DP_REQUIRE(l.add_left > 0 && l.add_right > 0, DP_ERR_ARG, "verifier blob: add multipliers"); }
     if (l.kind == L_MATMUL) { DP_REQUIRE(l.kw <= 1, DP_ERR_ARG, "verifier blob: matmul flags"); l.mm_transpose = l.kw != 0; l.kw = 0; }
     if (l.kind == L_CONV) DP_REQUIRE(is_pow2(l.kw) && is_pow2(l.kx) && is_pow2(l.real_nw) && is_pow2(l.nw) && l.kw <= (1u << 16) && l.kx <= (1u << 16) && l.nw <= (1u << 12) && 2 * l.real_nw <= l.nw && l.unp_out[0] <= l.kw && l.unp_out[1] <= l.nw && l.unp_out[2] <= l.nw, DP_ERR_ARG, "verifier blob: conv shape");

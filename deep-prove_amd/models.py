@@ -5,7 +5,7 @@ import math
 
 import numpy as np
 
-L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_FLATTEN, L_MATMUL, L_ADD = 0, 1, 2, 3, 4, 5, 6, 7
+L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_FLATTEN, L_MATMUL, L_ADD, L_EMBED = 0, 1, 2, 3, 4, 5, 6, 7, 8
 BIT_LEN = 8
 FIXED_POINT_SCALE = 25  # zkml/src/layers/requant.rs:47
 
@@ -137,6 +137,19 @@ class ModelBuilder:
             self.layers.append(dict(kind=L_REQUANT, **rq))
         return self
 
+    def embeddings(self, vocab, emb):
+        """Embeddings (layers/transformer/embeddings.rs): the first layer of a model whose input is a vector of token ids; the table is
+        [vocab][emb], both padded to powers of two; the output is the [tokens][emb] matrix of the looked-up rows (no requant: the
+        table holds quantised values already)"""
+        assert not self.layers and len(self.shape_og) == 1, "embeddings must be the first layer, over a 1-d token vector"
+        v, e = next_pow2(vocab), next_pow2(emb)
+        t = np.zeros((v, e), dtype=np.int64)
+        t[:vocab, :emb] = self._tensor(vocab * emb).reshape(vocab, emb)
+        self.layers.append(dict(kind=L_EMBED, nrows=v, ncols=e, table=t, vocab=vocab))
+        self.shape_og, self.shape_pad = (self.shape_og[0], emb), (self.shape_pad[0], e)
+        self._cur = self.shape_pad[0] * e
+        return self
+
     def add_const(self, left=1, right=1, requant=True):
         """Add::new_with(operand) (layers/add.rs:72-78): out = left * x + right * operand with a constant operand as long as the
         activation (learned positional embeddings are added this way, transformer/positional.rs); zeros at the padding positions.
@@ -202,6 +215,9 @@ class ModelBuilder:
                 parts.append(np.array([L_DENSE, l["nrows"], l["ncols"]], dtype=np.int64))
                 parts.append(l["weights"].reshape(-1))
                 parts.append(l["bias"])
+            elif l["kind"] == L_EMBED:
+                parts.append(np.array([L_EMBED, l["nrows"], l["ncols"]], dtype=np.int64))
+                parts.append(l["table"].reshape(-1))
             elif l["kind"] == L_ADD:
                 parts.append(np.array([L_ADD, l["left"], l["right"], l["operand"].size], dtype=np.int64))
                 parts.append(l["operand"])
@@ -226,6 +242,10 @@ class ModelBuilder:
     def input(self, index=1000):
         """a synthetic input, already padded (zeros outside the unpadded shape, like Tensor::pad_next_power_of_two)"""
         og, pad = self.input_shape_og, self.input_shape_pad
+        if self.layers and self.layers[0]["kind"] == L_EMBED:  # token ids (padding positions hold token 0, like a padded prompt)
+            x = np.zeros(pad, dtype=np.int64)
+            x[:og[0]] = np.abs(quantised_tensor(self.config, index, og[0])) % self.layers[0]["vocab"]
+            return x
         x = np.zeros(pad, dtype=np.int64)
         x[tuple(slice(0, d) for d in og)] = quantised_tensor(self.config, index, int(np.prod(og))).reshape(og)
         return x.reshape(-1)
@@ -236,6 +256,8 @@ class ModelBuilder:
         for l in self.layers:
             if l["kind"] == L_DENSE:
                 cur = l["weights"] @ cur + l["bias"]
+            elif l["kind"] == L_EMBED:
+                cur = l["table"][cur].reshape(-1)
             elif l["kind"] == L_ADD:
                 cur = l["left"] * cur + l["right"] * l["operand"]
             elif l["kind"] == L_MATMUL:
@@ -288,6 +310,16 @@ def seq_mlp(seq, width, config, input_features=4, output_features=3, layers=2, t
     for _ in range(layers - 1):
         mb.matmul(width).relu()
     mb.matmul(output_features, bias=False, transpose_b=transpose_last).relu()
+    return mb
+
+
+def token_mlp(seq, vocab, width, config, output_features=3):
+    """tokens -> Embeddings -> + positional table -> two Linear layers per token: the non-attention part of a small language model
+    (layers/transformer/embeddings.rs, layers/add.rs, layers/matrix_mul.rs)"""
+    mb = ModelBuilder((seq,), config)
+    mb.embeddings(vocab, width).add_const(1, 1)
+    mb.matmul(width).relu()
+    mb.matmul(output_features, bias=False).relu()
     return mb
 
 

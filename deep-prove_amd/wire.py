@@ -26,7 +26,7 @@ import struct
 import numpy as np
 
 MAGIC = 0x31464F4F52505044
-L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_MATMUL, L_ADD = 0, 1, 2, 3, 4, 6, 7
+L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_MATMUL, L_ADD, L_EMBED = 0, 1, 2, 3, 4, 6, 7, 8
 
 
 class Conventions:
@@ -96,6 +96,8 @@ def parse_stream(words):
         node, kind = r.u(), r.u()
         if kind == L_DENSE:
             lp = {"sumcheck": r.iop(), "bias_eval": r.e(), "individual_claims": r.ve()}
+        elif kind == L_EMBED:
+            lp = {"sumcheck": r.iop(), "individual_claims": r.ve()}
         elif kind == L_ADD:
             lp = {"left_eval": r.e(), "right_eval": r.e()}
         elif kind == L_MATMUL:
@@ -188,6 +190,8 @@ def to_serde_model(tree, conv=Conventions):
     for node, kind, lp in sorted(tree["steps"], key=lambda s: s[0]):
         if kind == L_DENSE:
             v = {"Dense": {"sumcheck": _iop(lp["sumcheck"], c), "bias_eval": _e(lp["bias_eval"], c), "individual_claims": _ve(lp["individual_claims"], c)}}
+        elif kind == L_EMBED:  # EmbeddingsProof {sumcheck, individual_claims} (layers/transformer/embeddings.rs:60-67)
+            v = {"Embeddings": {"sumcheck": _iop(lp["sumcheck"], c), "individual_claims": _ve(lp["individual_claims"], c)}}
         elif kind == L_ADD:  # AddProof {left_eval, right_eval} (layers/add.rs:59-63)
             v = {"Add": {"left_eval": _e(lp["left_eval"], c), "right_eval": _e(lp["right_eval"], c)}}
         elif kind == L_MATMUL:  # MatMulProof {sumcheck, individual_claims, bias_eval: Option<E>} (layers/matrix_mul.rs:153-161)
@@ -405,12 +409,14 @@ def from_rmp(data, conv=Conventions):
     assert end == len(data), "trailing bytes"
     w = _Writer(conv)
     w.w.append(MAGIC); w.w.append(len(model["steps"]))
-    kinds = {"Dense": L_DENSE, "Requant": L_REQUANT, "Activation": L_RELU, "Convolution": L_CONV, "Pooling": L_MAXPOOL, "MatMul": L_MATMUL, "Add": L_ADD}
+    kinds = {"Dense": L_DENSE, "Requant": L_REQUANT, "Activation": L_RELU, "Convolution": L_CONV, "Pooling": L_MAXPOOL, "MatMul": L_MATMUL, "Add": L_ADD, "Embeddings": L_EMBED}
     for node in sorted(model["steps"]):
         (name, lp), = model["steps"][node].items()
         w.w.append(node); w.w.append(kinds[name])
         if name == "Dense":
             w.iop(lp["sumcheck"]); w.e(lp["bias_eval"]); w.ve(lp["individual_claims"])
+        elif name == "Embeddings":
+            w.iop(lp["sumcheck"]); w.ve(lp["individual_claims"])
         elif name == "Add":
             w.e(lp["left_eval"]); w.e(lp["right_eval"])
         elif name == "MatMul":

@@ -192,7 +192,7 @@ int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const u
 
 /* ---- model level: Context::generate / Prover::prove / verify (zkml/src/iop/context.rs:109, prover.rs:401,
  * verifier.rs:306). model_blob (int64): input_len, nlayers, then per layer kind (0 Dense, 1 Requant, 2 Relu, 3 Conv,
- * 4 MaxPool, 5 Flatten, 6 MatMul, 7 Add) followed by
+ * 4 MaxPool, 5 Flatten, 6 MatMul, 7 Add, 8 Embeddings) followed by
  *   Dense: nrows, ncols, weights[nrows*ncols] row-major, bias[nrows]   (padded to powers of two, already quantised; after a
  *          Flatten the columns follow the padded (c,h,w) layout with zeros at padding positions, tensor.rs:1627-1675)
  *   Requant: right_shift, fp_scale, fixed_point_multiplier, intermediate_bit_size   (zkml/src/layers/requant.rs:46-73)
@@ -209,6 +209,10 @@ int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const u
  *   Add: left multiplier, right multiplier, n, operand[n] — Add::new_with(operand) (zkml/src/layers/add.rs:72-145): out = left * x +
  *          right * operand for a constant operand as long as the activation (how learned positional embeddings enter,
  *          transformer/positional.rs); no sumcheck: the proof is the two evaluations, the operand's goes to its commitment.
+ *   Embeddings: vocabulary, embedding size (both padded to powers of two), table[vocabulary * size] row major — only as the FIRST layer
+ *          (zkml/src/layers/transformer/embeddings.rs:359-571): the model input is then a vector of token ids, the output the
+ *          [tokens][size] matrix of their rows; proved as one-hot(tokens) x table without building the one-hot matrix, the verifier
+ *          checks the resulting one-hot claim against the tokens.
  *   (MatMul / Add of two inputs and the other transformer layers are not built: the model is a chain of nodes.) */
 int32_t dp_model_setup(dp_ctx* ctx, const int64_t* model_blob, size_t nwords, dp_model** out);
 int32_t dp_model_free(dp_model* m);

@@ -169,12 +169,14 @@ static inline LogUpProof logup_batch_prove(const LogUpInput& in, Transcript& t) 
 }
 
 // ------------------------------------------------------------------ model description
-enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7 };
+enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8 };
 struct Layer {
   LayerKind kind;
   // dense (padded to powers of two). matmul (layers/matrix_mul.rs, MatMul::new_constant: Input x Weight [+ bias]): the constant RIGHT
   // matrix is [nrows][ncols] row major, the input a row-major [s][nrows] matrix, bias [ncols] or empty
   size_t nrows = 0, ncols = 0;
+  // embeddings (layers/transformer/embeddings.rs): the FIRST layer of a model; the input is a vector of token ids, weights the
+  // [nrows = vocabulary][ncols = embedding size] table, the output [tokens][ncols]
   // add (layers/add.rs, Add::new_with(operand)): out = add_left * x + add_right * operand, the operand (a constant tensor as long as the
   // input, e.g. learned positional embeddings) in `weights`; the multipliers are QuantInfo::left/right_multiplier (add.rs:271-283)
   int64_t add_left = 1, add_right = 1;
@@ -344,6 +346,12 @@ static inline Trace run_model(const Model& m, const std::vector<int64_t>& input)
       const size_t s_ = cur.size() / k;
       o.assign(s_ * n, 0);
       for (size_t i = 0; i < s_; i++) for (size_t j = 0; j < n; j++) { int64_t a = 0; for (size_t q = 0; q < k; q++) a += cur[i * k + q] * (l.transpose_b ? l.weights[j * k + q] : l.weights[q * n + j]); o[i * n + j] = a + (l.bias.empty() ? 0 : l.bias[j]); }
+    } else if (l.kind == L_EMBED) {  // Embeddings::evaluate (embeddings.rs:197-236): row x[i] of the table for every token
+      o.resize(cur.size() * l.ncols);
+      for (size_t i = 0; i < cur.size(); i++) {
+        if (cur[i] < 0 || (size_t)cur[i] >= l.nrows) throw std::runtime_error("embeddings: token outside the vocabulary");
+        for (size_t j = 0; j < l.ncols; j++) o[i * l.ncols + j] = l.weights[(size_t)cur[i] * l.ncols + j];
+      }
     } else if (l.kind == L_ADD) {  // Add::evaluate (add.rs:184-210)
       if (cur.size() != l.weights.size()) throw std::runtime_error("add: operand size mismatch");
       o.resize(cur.size());
@@ -382,6 +390,7 @@ static inline Context context_generate(const Model& m) {
   for (auto& l : m.layers) {
     if (l.kind == L_DENSE) { cur_len = l.nrows; }
     else if (l.kind == L_MATMUL) { cur_len = cur_len / l.nrows * l.ncols; }
+    else if (l.kind == L_EMBED) { cur_len = cur_len * l.ncols; }
     else if (l.kind == L_REQUANT) { add_table({2, 0}); add_table({3, l.clamping_size()}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
     else if (l.kind == L_RELU) { add_table({0, 0}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
     else if (l.kind == L_CONV) { cur_len = l.kw * l.nw * l.nw; }                                                       // convolution.rs:506-511
@@ -389,7 +398,7 @@ static inline Context context_generate(const Model& m) {
   }
   std::sort(tset.begin(), tset.end());
   for (auto& t : tset) max_poly_len = std::max(max_poly_len, size_t(1) << t.multiplicity_poly_vars());
-  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD) { max_poly_len = std::max(max_poly_len, next_pow2(l.weights.size())); max_poly_len = std::max(max_poly_len, next_pow2(l.bias.size())); }
+  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD || l.kind == L_EMBED) { max_poly_len = std::max(max_poly_len, next_pow2(l.weights.size())); max_poly_len = std::max(max_poly_len, next_pow2(l.bias.size())); }
   max_poly_len = next_pow2(max_poly_len);
   ctx.max_poly_len = max_poly_len;
   ctx.pp = pcs_setup(max_poly_len);
@@ -399,6 +408,7 @@ static inline Context context_generate(const Model& m) {
   for (size_t id = 0; id < m.layers.size(); id++) {
     if (m.layers[id].kind == L_DENSE) { jobs.push_back({id, "DenseWeight"}); jobs.push_back({id, "DenseBias"}); }
     if (m.layers[id].kind == L_CONV) { jobs.push_back({id, "ConvFilter"}); jobs.push_back({id, "ConvBias"}); }  // convolution.rs:452-453,546-553
+    if (m.layers[id].kind == L_EMBED) jobs.push_back({id, "EmbeddingMat"});  // embeddings.rs:271,284-291
     if (m.layers[id].kind == L_ADD) jobs.push_back({id, "255"});  // OPERAND_POLY_ID = 0xff, to_string() (add.rs:32,520)
     if (m.layers[id].kind == L_MATMUL) { jobs.push_back({id, "MatMulWeight"}); if (!m.layers[id].bias.empty()) jobs.push_back({id, "MatMulBias"}); }  // matrix_mul.rs:947-963
   }
@@ -407,7 +417,7 @@ static inline Context context_generate(const Model& m) {
   for (auto& j : jobs) th.emplace_back([&ctx, &m, j] {
     const Layer& l = m.layers[j.first];
     std::string pid = j.second;
-    Mle poly = Mle::from_i64(pid == "DenseWeight" || pid == "ConvFilter" || pid == "MatMulWeight" || pid == "255" ? l.weights : l.bias);
+    Mle poly = Mle::from_i64(pid == "DenseWeight" || pid == "ConvFilter" || pid == "MatMulWeight" || pid == "255" || pid == "EmbeddingMat" ? l.weights : l.bias);
     ctx.model_comms[j.first][j.second] = {pcs_commit(ctx.pp, poly), poly};
   });
   for (auto& t : th) t.join();
@@ -555,6 +565,33 @@ static inline Claim prove_dense(ProverState& ps, size_t id, const Layer& l, cons
   LayerProof lp; lp.kind = L_DENSE; lp.dense = {proof, bias_eval, fin};
   ps.proofs[id] = lp;
   return {proof.point, fin[1]};
+}
+// Embeddings::prove (layers/transformer/embeddings.rs:359-462): the matmul protocol on (one-hot(tokens), table) without ever building
+// the one-hot matrix — its row variables fixed at the row part of the claim give reduced[x[i]] += beta(i, row part) (:382-401); the
+// table's column variables are fixed at the column part; a degree-2 sumcheck over the vocabulary; the table claim
+// [column part | sumcheck point] goes to its commitment, the one-hot claim [sumcheck point | row part] is what the verifier checks
+// against the public tokens (verify_input_claim, :530-571).
+static inline Claim prove_embeddings(ProverState& ps, size_t id, const Layer& l, const Claim& last, const std::vector<int64_t>& tokens) {
+  const unsigned nvc = log2_strict(l.ncols), nvr = log2_strict(tokens.size());
+  if (last.point.size() != nvc + nvr) throw std::runtime_error("embeddings: claim point size mismatch");
+  std::vector<E> col_pt(last.point.begin(), last.point.begin() + nvc), row_pt(last.point.begin() + nvc, last.point.end());
+  std::vector<E> beta = build_eq_x_r_vec(row_pt);
+  std::vector<E> reduced(l.nrows, e_zero());
+  for (size_t i = 0; i < tokens.size(); i++) reduced[(size_t)tokens[i]] = eadd(reduced[(size_t)tokens[i]], beta[i]);
+  std::vector<E> w(l.weights.size()); for (size_t i = 0; i < w.size(); i++) w[i] = e_from_i64(l.weights[i]);
+  Mle table = Mle::from_ext(w);
+  table.fix_low_in_place(col_pt);
+  Mle in = Mle::from_ext(reduced);
+  VirtualPolynomial vp(in.nv);
+  vp.add_mle_list({mk(in), mk(table)}, e_one());
+  auto [proof, st] = sumcheck_prove(std::move(vp), *ps.t);
+  std::vector<E> fin = st.final_evaluations();
+  std::vector<E> one_hot_pt = proof.point; one_hot_pt.insert(one_hot_pt.end(), row_pt.begin(), row_pt.end());
+  std::vector<E> table_pt = col_pt; table_pt.insert(table_pt.end(), proof.point.begin(), proof.point.end());
+  ps.add_witness_claim(ps.ctx->model_comms.at(id).at("EmbeddingMat"), {table_pt, fin[1]});
+  LayerProof lp; lp.kind = L_EMBED; lp.matmul.sumcheck = proof; lp.matmul.individual_claims = fin;  // EmbeddingsProof {sumcheck, individual_claims} (:60-67)
+  ps.proofs[id] = lp;
+  return {one_hot_pt, fin[0]};
 }
 // Add::prove_step with a static operand (layers/add.rs:81-145): no sumcheck and no transcript traffic — the prover evaluates the input at the
 // claim's point, solves out(r) = M1 x(r) + M2 c(r) for the operand's evaluation and hands that claim to the operand's commitment
@@ -932,6 +969,7 @@ static inline Proof prove(const Context& ctx, const Trace& tr, Transcript& t) {
     if (l.kind == L_DENSE) cur = prove_dense(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_MATMUL) cur = prove_matmul(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_ADD) cur = prove_add(ps, id, l, cur, to_fields(tr.in[id]));
+    else if (l.kind == L_EMBED) cur = prove_embeddings(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
     else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, to_fields(tr.out[id]));
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv[id]);
@@ -995,6 +1033,7 @@ static inline std::vector<u64> serialize_proof(const Proof& p) {
     w.u(id); w.u(lp.kind);
     if (lp.kind == L_DENSE) { w.iop(lp.dense.sumcheck); w.e(lp.dense.bias_eval); w.ve(lp.dense.individual_claims); }
     else if (lp.kind == L_ADD) { w.e(lp.add.left_eval); w.e(lp.add.right_eval); }
+    else if (lp.kind == L_EMBED) { w.iop(lp.matmul.sumcheck); w.ve(lp.matmul.individual_claims); }
     else if (lp.kind == L_MATMUL) { w.iop(lp.matmul.sumcheck); w.ve(lp.matmul.individual_claims); w.u(lp.matmul.has_bias ? 1 : 0); if (lp.matmul.has_bias) w.e(lp.matmul.bias_eval); }
     else if (lp.kind == L_REQUANT) {
       w.iop(lp.req.io_accumulation); w.ve(lp.req.accumulation_evals); w.logup(lp.req.clamping_lookup); w.logup(lp.req.shifted_lookup);

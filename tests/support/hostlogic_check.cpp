@@ -245,6 +245,10 @@ int main(int argc, char** argv) {
   else if (seq) {
     const size_t S = 8, F = 4, H = 16;
     m.input_len = S * F;
+    if (getenv("HL_EMBED")) {  // tokens -> Embeddings (layers/transformer/embeddings.rs): a 32-word vocabulary, embedding size F; the model input is S token ids
+      dp::LayerSpec e; e.kind = dp::L_EMBED; e.nrows = 32; e.ncols = F; e.weights.resize(32 * F); for (auto& x : e.weights) x = rq();
+      m.layers.push_back(e); m.input_len = S;
+    }
     if (getenv("HL_POSITIONAL")) {  // Add with a static operand (layers/add.rs; the learned positional table of transformer/positional.rs), then a Requant by 1/2
       dp::LayerSpec a; a.kind = dp::L_ADD; a.add_left = 1; a.add_right = 1; a.weights.resize(S * F); for (auto& x : a.weights) x = rq();
       m.layers.push_back(a);
@@ -253,7 +257,7 @@ int main(int argc, char** argv) {
     m.layers.push_back(matmul(F, H, true)); m.layers.push_back(requant_for(F, 0.5 / 127)); m.layers.push_back(relu);
     m.layers.push_back(matmul(H, H, true)); m.layers.push_back(requant_for(H, 1.0 / std::sqrt((double)H) / 127)); m.layers.push_back(relu);
     m.layers.push_back(matmul(H, F, false, getenv("HL_TRANSPOSE") != nullptr)); m.layers.push_back(requant_for(H, 1.0 / std::sqrt((double)H) / 127)); m.layers.push_back(relu);
-    in.resize(S * F); for (auto& x : in) x = rq();
+    if (getenv("HL_EMBED")) { in.resize(S); for (auto& x : in) x = (int64_t)(rnd() % 32); } else { in.resize(S * F); for (auto& x : in) x = rq(); }
   } else {
     m.layers.push_back(dense(W, 4)); m.layers.push_back(requant_for(4, 0.5 / 127)); m.layers.push_back(relu);
     m.layers.push_back(dense(W, W)); m.layers.push_back(requant_for(W, 1.0 / std::sqrt((double)W) / 127)); m.layers.push_back(relu);

@@ -235,3 +235,24 @@ def test_golden_seq_mlp(dev):
     assert proof.size == g["proof"].size and (proof == g["proof"]).all()
     assert (ctx.verifier_blob() == g["verifier_blob"]).all()
     ctx.free()
+
+
+@pytest.mark.parametrize("seq,vocab,width", [(16, 50, 32), (64, 1000, 256)])
+def test_token_model_proof_bytes_identical_to_oracle(dev, oracle, seq, vocab, width):
+    """tokens -> Embeddings -> + positional table -> MatMul blocks (models.token_mlp; layers/transformer/embeddings.rs, layers/add.rs,
+    layers/matrix_mul.rs): proof stream == the oracle's, verifier accepts (one-hot input claim included), batch proofs == sequential"""
+    import deep_prove_amd as dpa
+    mb = dpa.models.token_mlp(seq, vocab, width, config=70 + seq)
+    x = mb.input()
+    ctx, proof, out, oproof, oout = prove_both(dev, oracle, mb, x)
+    assert (out == oout).all() and (out == mb.run(x)).all()
+    assert proof.size == oproof.size and (proof == oproof).all()
+    dpa.verify(ctx.verifier_blob(), proof, x, out)
+    other = x.copy(); other[1] = (other[1] + 1) % vocab
+    with pytest.raises(dpa.DeepProveError):
+        dpa.verify(ctx.verifier_blob(), proof, other, out)
+    xs = np.stack([mb.input(900 + i) for i in range(8)])
+    proofs, outs, _ = dpa.Prover(ctx).prove_batch(xs, 8)
+    single, sout = dpa.Prover(ctx).prove(xs[6])
+    assert proofs[6].size == single.size and (proofs[6] == single).all() and (outs[6] == sout).all()
+    ctx.free()

@@ -154,7 +154,9 @@ def test_matmul_model_proof_stream_identical_to_oracle_and_accepted(hostlogic_bi
     the claims routed to the previous layer / the weight and bias commitments) gives the oracle's stream; the verifier accepts both"""
     # the last MatMul with Config::TransposeB (constant matrix stored [n][k]: fix_high, other claim point); an Add with a static operand
     # (layers/add.rs:81-145, 586-625: the learned positional table of transformer/positional.rs) in front of the first MatMul
-    for env in ({}, {"HL_TRANSPOSE": "1"}, {"HL_POSITIONAL": "1"}, {"HL_POSITIONAL": "1", "HL_TRANSPOSE": "1"}):
+    # ... and Embeddings as the first layer (layers/transformer/embeddings.rs:359-462, 473-571: tokens in, the one-hot claim checked
+    # by the verifier against the public tokens)
+    for env in ({}, {"HL_TRANSPOSE": "1"}, {"HL_POSITIONAL": "1"}, {"HL_POSITIONAL": "1", "HL_TRANSPOSE": "1"}, {"HL_EMBED": "1"}, {"HL_EMBED": "1", "HL_POSITIONAL": "1"}):
         r = run(hostlogic_bin, "seq", seed, env=env)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "identical=1" in r.stdout

@@ -133,6 +133,36 @@ def test_matmul_golden_fixture_is_reproducible(oracle):
         dpa.verify(g["verifier_blob"], g["proof"], g["input"], wrong)
 
 
+def test_token_model_embeddings_add_matmul_through_the_host_verifier(oracle):
+    """tokens -> Embeddings -> + positional table (Add with a static operand) -> MatMul blocks (models.token_mlp): the oracle proves,
+    numpy inference agrees, the product's host verifier (C ABI) accepts — including the one-hot input claim of the Embeddings layer
+    (embeddings.rs:530-571) — and rejects another prompt, a token outside the vocabulary, a flipped word and a wrong output"""
+    import os, sys
+    import pytest
+    import deep_prove_amd as dpa
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from vblob_helper import verifier_blob_for
+    mb = dpa.models.token_mlp(16, 50, 32, config=71)
+    x = mb.input()
+    assert x.size == 16 and x.max() < 50 and len(set(x.tolist())) > 4
+    h = oracle.model_setup(mb.blob())
+    proof, out, _ = oracle.model_prove(h, x)
+    oracle.model_free(h)
+    assert (out == mb.run(x)).all() and np.abs(out).sum() > 0
+    vb = verifier_blob_for(mb.blob())
+    dpa.verify(vb, proof, x, out)
+    other = x.copy(); other[3] = (other[3] + 1) % 50
+    for bad_x in (other, np.where(np.arange(16) == 5, 63, x), np.where(np.arange(16) == 5, 64, x)):  # 63: inside the padded vocabulary, 64: outside
+        with pytest.raises(dpa.DeepProveError):
+            dpa.verify(vb, proof, bad_x.astype(np.int64), out)
+    bad = proof.copy(); bad[25] ^= np.uint64(1)
+    with pytest.raises(dpa.DeepProveError):
+        dpa.verify(vb, bad, x, out)
+    wrong = out.copy(); wrong[1] += 1
+    with pytest.raises(dpa.DeepProveError):
+        dpa.verify(vb, proof, x, wrong)
+
+
 def test_replica_baseline_reproduces_the_single_proof(oracle):
     """bench.py's cpu_baseline throughput leg (orc_model_prove_many): every replica thread produces the same stream as
     the single-threaded prove (checked through the wrapping word sum)"""
