@@ -542,6 +542,11 @@ static ModelSpec parse_model(const int64_t* b, size_t n) {
       DP_REQUIRE(l.nrows && l.ncols && !__builtin_mul_overflow(l.nrows, l.ncols, &nw) && !__builtin_add_overflow(nw, l.nrows, &tot) && tot <= n - pos, DP_ERR_ARG, "model blob: dense tensor sizes");
       l.weights.assign(b + pos, b + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols;
       l.bias.assign(b + pos, b + pos + l.nrows); pos += l.nrows;
+    } else if (l.kind == L_POSITIONAL) {  // [9, left multiplier, right multiplier, positions (padded), embedding size (padded), table row major]
+      l.add_left = rd(); l.add_right = rd(); l.nrows = (size_t)rd(); l.ncols = (size_t)rd();
+      size_t nw = 0;
+      DP_REQUIRE(l.nrows && l.ncols && !__builtin_mul_overflow(l.nrows, l.ncols, &nw) && nw <= n - pos, DP_ERR_ARG, "model blob: positional table size");
+      l.weights.assign(b + pos, b + pos + nw); pos += nw;
     } else if (l.kind == L_EMBED) {  // [8, vocabulary (padded), embedding size (padded), table row major]
       l.nrows = (size_t)rd(); l.ncols = (size_t)rd();
       size_t nw = 0;

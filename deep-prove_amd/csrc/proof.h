@@ -29,9 +29,10 @@ struct BasefoldProof {
   std::vector<FieldVec> trivial_proof;
   bool is_trivial() const { return sumcheck_messages.empty() && queries.empty() && sumcheck_proof.empty(); }
 };
-enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8 };
+enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8, L_POSITIONAL = 9 };
 struct DenseProof { IOPProof sumcheck; Ext bias_eval; std::vector<Ext> individual_claims; };
 struct AddProof { Ext left_eval = ex_zero(), right_eval = ex_zero(); };  // layers/add.rs:59-63
+struct PositionalProof { std::vector<Ext> sub_matrix_evals; AddProof add_proof; };  // SinglePositionalProof (transformer/positional.rs:45-55), one input
 struct MatMulProof { IOPProof sumcheck; std::vector<Ext> individual_claims; bool has_bias = false; Ext bias_eval = ex_zero(); };  // layers/matrix_mul.rs:153-161 (bias_eval: Option<E>)
 struct SamePolyProof { IOPProof sumcheck; std::vector<Ext> evals; };
 struct ActivationProof { SamePolyProof io_accumulation; LogUpProof lookup; std::vector<Commitment> commits; };
@@ -50,7 +51,7 @@ struct ConvProof {  // layers/convolution.rs:98-127, fields in declaration order
   HadamardProof clearing_proof;
 };
 struct PoolingProof { IOPProof sumcheck; LogUpProof lookup; std::vector<Ext> zerocheck_evals; size_t variable_gap = 0; std::vector<Commitment> commitments; };  // layers/pooling.rs:60-76
-struct LayerProof { int kind = 0; DenseProof dense; MatMulProof matmul; AddProof add; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; };
+struct LayerProof { int kind = 0; DenseProof dense; MatMulProof matmul; AddProof add; PositionalProof pos; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; };
 struct TableProof { Commitment multiplicity_commit; LogUpProof lookup; };
 struct Proof {
   std::map<size_t, LayerProof> steps;
@@ -106,6 +107,7 @@ inline std::vector<u64> serialize_proof(const Proof& p) {
     w.u(kv.first); w.u((u64)lp.kind);
     if (lp.kind == L_DENSE) { w.iop(lp.dense.sumcheck); w.e(lp.dense.bias_eval); w.ve(lp.dense.individual_claims); }
     else if (lp.kind == L_ADD) { w.e(lp.add.left_eval); w.e(lp.add.right_eval); }
+    else if (lp.kind == L_POSITIONAL) { w.u(1); w.ve(lp.pos.sub_matrix_evals); w.e(lp.pos.add_proof.left_eval); w.e(lp.pos.add_proof.right_eval); }  // PositionalProof {proofs: one per input}
     else if (lp.kind == L_EMBED) { w.iop(lp.matmul.sumcheck); w.ve(lp.matmul.individual_claims); }  // EmbeddingsProof {sumcheck, individual_claims} (embeddings.rs:60-67)
     else if (lp.kind == L_MATMUL) { w.iop(lp.matmul.sumcheck); w.ve(lp.matmul.individual_claims); w.u(lp.matmul.has_bias ? 1 : 0); if (lp.matmul.has_bias) w.e(lp.matmul.bias_eval); }
     else if (lp.kind == L_REQUANT) {
@@ -185,6 +187,7 @@ inline Proof deserialize_proof(const u64* words, size_t n) {
     if (lp.kind == L_DENSE) { lp.dense.sumcheck = r.iop(); lp.dense.bias_eval = r.e(); lp.dense.individual_claims = r.ve(); }
     else if (lp.kind == L_ADD) { lp.add.left_eval = r.e(); lp.add.right_eval = r.e(); }
     else if (lp.kind == L_EMBED) { lp.matmul.sumcheck = r.iop(); lp.matmul.individual_claims = r.ve(); }
+    else if (lp.kind == L_POSITIONAL) { DP_REQUIRE(r.u() == 1, DP_ERR_ARG, "proof stream: positional proofs per node"); lp.pos.sub_matrix_evals = r.ve(); lp.pos.add_proof.left_eval = r.e(); lp.pos.add_proof.right_eval = r.e(); }
     else if (lp.kind == L_MATMUL) { lp.matmul.sumcheck = r.iop(); lp.matmul.individual_claims = r.ve(); u64 hb = r.u(); DP_REQUIRE(hb <= 1, DP_ERR_ARG, "proof stream: matmul bias flag"); lp.matmul.has_bias = hb != 0; if (hb) lp.matmul.bias_eval = r.e(); }
     else if (lp.kind == L_REQUANT) {
       lp.req.io_accumulation = r.iop(); lp.req.accumulation_evals = r.ve(); lp.req.clamping_lookup = r.logup(); lp.req.shifted_lookup = r.logup();

@@ -32,6 +32,8 @@ struct LayerSpec {
   // the input a row-major [s][nrows] matrix (s = its length / nrows), bias [ncols] or empty; the output is [s][ncols]. mm_transpose
   // (Config::TransposeB, matrix_mul.rs:36-39): the constant matrix is stored as [ncols][nrows] and used transposed
   bool mm_transpose = false;
+  // positional (layers/transformer/positional.rs, Positional::Learned): weights = the [nrows = positions][ncols = embedding size] table;
+  // out = add_left * x + add_right * table[0 .. tokens) for a [tokens][ncols] activation, tokens <= nrows
   // embeddings (layers/transformer/embeddings.rs): only as the FIRST layer; the input is a vector of token ids, weights the
   // [nrows = vocabulary][ncols = embedding size] table, the output [tokens][ncols]
   // add (layers/add.rs, Add::new_with(operand)): out = add_left * x + add_right * operand; the operand — a constant tensor as long as the
@@ -193,6 +195,10 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
         DP_REQUIRE(cur[i] >= 0 && (size_t)cur[i] < l.nrows, DP_ERR_ARG, "embeddings: token outside the vocabulary");
         memcpy(&o[i * l.ncols], &l.weights[(size_t)cur[i] * l.ncols], l.ncols * sizeof(int64_t));
       }
+    } else if (l.kind == L_POSITIONAL) {  // Positional::evaluate (positional.rs:157-185): the Add layer on (x, the first rows of the table)
+      DP_REQUIRE(l.ncols && cur.size() % l.ncols == 0 && cur.size() <= l.weights.size(), DP_ERR_SHAPE, "positional: input shape");
+      o.resize(cur.size());
+      for (size_t i = 0; i < cur.size(); i++) o[i] = l.add_left * cur[i] + l.add_right * l.weights[i];
     } else if (l.kind == L_ADD) {  // Add::evaluate (add.rs:184-210)
       DP_REQUIRE(cur.size() == l.weights.size(), DP_ERR_SHAPE, "add: operand size mismatch");
       o.resize(cur.size());
@@ -263,6 +269,9 @@ inline void validate_model(const ModelSpec& m) {
       DP_REQUIRE(&l == &m.layers[0], DP_ERR_SHAPE, "embeddings: only as the first layer (its input claim is checked against the public tokens)");
       DP_REQUIRE(is_pow2(l.nrows) && is_pow2(l.ncols) && l.nrows >= 2 && l.ncols >= 2 && l.weights.size() == l.nrows * l.ncols && cur >= 2, DP_ERR_SHAPE, "embeddings: padded table dimensions must be powers of two >= 2");
       cur = cur * l.ncols;
+    } else if (l.kind == L_POSITIONAL) {
+      DP_REQUIRE(is_pow2(l.nrows) && is_pow2(l.ncols) && l.ncols >= 2 && l.weights.size() == l.nrows * l.ncols && cur % l.ncols == 0 && cur <= l.weights.size() && cur >= 2
+                 && l.add_left > 0 && l.add_right > 0 && l.add_left < (int64_t(1) << 40) && l.add_right < (int64_t(1) << 40), DP_ERR_SHAPE, "positional: the table is [positions][embedding size] with at least as many positions as the input has rows");
     } else if (l.kind == L_ADD) {
       DP_REQUIRE(l.weights.size() == cur && cur >= 2 && l.add_left > 0 && l.add_right > 0 && l.add_left < (int64_t(1) << 40) && l.add_right < (int64_t(1) << 40), DP_ERR_SHAPE, "add: the operand must be as long as the input, the multipliers positive");
     } else if (l.kind == L_REQUANT) {
@@ -302,13 +311,20 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
   }
   std::sort(ts.begin(), ts.end());
   for (auto& t : ts) mpl = std::max(mpl, size_t(1) << t.vars());
-  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD || l.kind == L_EMBED) mpl = std::max(mpl, std::max(next_pow2(l.weights.size()), next_pow2(l.bias.size())));
+  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD || l.kind == L_EMBED || l.kind == L_POSITIONAL) mpl = std::max(mpl, std::max(next_pow2(l.weights.size()), next_pow2(l.bias.size())));
   mpl = next_pow2(mpl);
   ctx->max_poly_len = mpl; ctx->full_log = dp_ceil_log2(mpl); ctx->tables = ts;
   dev.pcs_init(ctx->full_log);
   for (size_t id = 0; id < m.layers.size(); id++) {
     LayerSpec& l = ctx->model.layers[id];
-    if (l.kind != L_DENSE && l.kind != L_CONV && l.kind != L_MATMUL && l.kind != L_ADD && l.kind != L_EMBED) continue;
+    if (l.kind != L_DENSE && l.kind != L_CONV && l.kind != L_MATMUL && l.kind != L_ADD && l.kind != L_EMBED && l.kind != L_POSITIONAL) continue;
+    if (l.kind == L_POSITIONAL) {  // the whole table is the model polynomial (positional.rs:229,243-251)
+      DBuf w = dev.alloc_persistent(l.weights.size(), false);
+      dev.upload_i64(w, l.weights.data());
+      ctx->model_comms[id]["PositionalMatrix"] = dev.commit(w, true);
+      ctx->weights_dev[id] = w;
+      continue;
+    }
     if (l.kind == L_EMBED) {  // the embedding table is a model polynomial (embeddings.rs:271,284-291)
       DBuf w = dev.alloc_persistent(l.weights.size(), false);
       dev.upload_i64(w, l.weights.data());
@@ -505,6 +521,45 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
   }
   ps.constant_challenge = ps.t->get_and_append_challenge("table_constant");
   for (auto& kv : counts) ps.challenge_map[kv.first] = kv.first.label() ? ps.t->get_and_append_challenge(kv.first.label()) : ex_one();
+}
+
+// Positional::prove, Learned (layers/transformer/positional.rs:327-452). The Add layer on (input, the first `tokens` rows of the table): both
+// evaluated at the claim's point (Dev::mle_eval_batch; add.rs:81-145 with two inputs: no transcript traffic). Then the slice claim is lifted
+// to the whole committed table: the output claim and the slice claim are absorbed, one coordinate per doubling is drawn (:80-99), the
+// evaluation of every upper-half sub-matrix (rows [tokens 2^k, tokens 2^(k+1)): a contiguous slice of the table on the device) at the
+// point's prefix is sent, and table(point | extras) follows by folding (:106-126).
+inline Claim prove_positional(ProverState& ps, size_t id, const LayerSpec& l, const Claim& last, const std::vector<int64_t>& input) {
+  Dev& dev = *ps.dev;
+  const size_t n = input.size();
+  DP_REQUIRE((size_t(1) << last.point.size()) == n && n <= l.weights.size(), DP_ERR_SHAPE, "positional: claim point length");
+  size_t mk = dev.mark();
+  const DBuf& table = ps.ctx->weights_dev.at(id);
+  DBuf in = dev.alloc(n, false);
+  dev.upload_i64(in, input.data());
+  const unsigned nv_sub = (unsigned)last.point.size(), diff = dp_ceil_log2(l.weights.size()) - nv_sub;
+  DBuf both[2] = {in, table.slice(0, n)};
+  Ext ev2[2];
+  dev.mle_eval_batch(both, 2, last.point.data(), nv_sub, ev2);
+  PositionalProof pp; pp.add_proof.left_eval = ev2[0]; pp.add_proof.right_eval = ev2[1];
+  Transcript& t = *ps.t;
+  t.append_exts(last.point); t.append_ext(last.eval); t.append_exts(last.point); t.append_ext(ev2[1]);
+  std::vector<Ext> point = last.point;
+  for (unsigned k = 0; k < diff; k++) point.push_back(t.read_challenge());
+  Ext acc = ev2[1];
+  for (unsigned k = 0; k < diff; k++) {
+    const size_t len = n << k;
+    DBuf sm = table.slice(len, len);
+    Ext ev;
+    dev.mle_eval_batch(&sm, 1, point.data(), nv_sub + k, &ev);
+    pp.sub_matrix_evals.push_back(ev);
+    const Ext c = point[nv_sub + k];
+    acc = ex_add(ex_mul(acc, ex_sub(ex_one(), c)), ex_mul(ev, c));
+  }
+  ps.add_witness_claim(ps.ctx->model_comms.at(id).at("PositionalMatrix"), {point, acc});
+  LayerProof lp; lp.kind = L_POSITIONAL; lp.pos = pp;
+  ps.proofs[id] = lp;
+  dev.release(mk);
+  return {last.point, pp.add_proof.left_eval};
 }
 
 // Embeddings::prove (layers/transformer/embeddings.rs:359-462): the matmul protocol on (one-hot(tokens), table) without the one-hot
@@ -923,6 +978,7 @@ inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t) {
     else if (l.kind == L_MATMUL) cur = prove_matmul(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_ADD) cur = prove_add(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_EMBED) cur = prove_embeddings(ps, id, l, cur, tr.in[id]);
+    else if (l.kind == L_POSITIONAL) cur = prove_positional(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
     else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, tr.out[id]);
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv.at(id));
@@ -1124,6 +1180,25 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       DP_REQUIRE(ex_eq(ex_mul(dpf.individual_claims[0], dpf.individual_claims[1]), sub.expected_evaluation), DP_ERR_VERIFY, "dense: sumcheck claim failed");
       cur = {sub.point, dpf.individual_claims[1]};
       cur_len = l.ncols;
+    } else if (l.kind == L_POSITIONAL) {  // PositionalCtx::verify (positional.rs:480-583) over AddCtx::verify (add.rs:586-625, two inputs)
+      const PositionalProof& pp = lp.pos;
+      const unsigned nv_sub = (unsigned)cur.point.size(), nv_all = dp_ceil_log2(l.nrows * l.ncols);
+      DP_REQUIRE(nv_sub == dp_ceil_log2(cur_len) && nv_all >= nv_sub && pp.sub_matrix_evals.size() == nv_all - nv_sub && l.add_left > 0 && l.add_right > 0, DP_ERR_VERIFY, "positional: shapes");
+      const Ext sum = ex_add(ex_mul_base(pp.add_proof.left_eval, gl_from_i64(l.add_left)), ex_mul_base(pp.add_proof.right_eval, gl_from_i64(l.add_right)));
+      DP_REQUIRE(ex_eq(sum, cur.eval), DP_ERR_VERIFY, "Add layer verification failed");
+      t.append_exts(cur.point); t.append_ext(cur.eval); t.append_exts(cur.point); t.append_ext(pp.add_proof.right_eval);
+      std::vector<Ext> point = cur.point;
+      Ext acc = pp.add_proof.right_eval;
+      for (size_t k = 0; k < pp.sub_matrix_evals.size(); k++) {
+        const Ext c = t.read_challenge();
+        point.push_back(c);
+      }
+      for (size_t k = 0; k < pp.sub_matrix_evals.size(); k++) { const Ext c = point[nv_sub + k]; acc = ex_add(ex_mul(acc, ex_sub(ex_one(), c)), ex_mul(pp.sub_matrix_evals[k], c)); }
+      auto nit = unused.find(id);
+      DP_REQUIRE(nit != unused.end() && nit->second.count("PositionalMatrix"), DP_ERR_VERIFY, "positional: no commitment for the table");
+      add_claim(nit->second.at("PositionalMatrix"), {point, acc});
+      unused.erase(nit);
+      cur = {cur.point, pp.add_proof.left_eval};
     } else if (l.kind == L_EMBED) {  // EmbeddingsCtx::verify (embeddings.rs:473-528); the one-hot claim is checked at the very end
       const MatMulProof& ep = lp.matmul;
       DP_REQUIRE(id == 0 && l.ncols && cur_len % l.ncols == 0, DP_ERR_VERIFY, "embeddings: shapes");
@@ -1282,17 +1357,17 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
 }
 
 // ---- serialisable verifier context (what dp_model_verifier_blob hands out and dp_verify consumes)
-constexpr int N_POLY_IDS = 8;
-inline const char* const* poly_ids() { static const char* const ids[N_POLY_IDS] = {"DenseBias", "DenseWeight", "ConvBias", "ConvFilter", "MatMulBias", "MatMulWeight", "255", "EmbeddingMat"}; return ids; }
+constexpr int N_POLY_IDS = 9;
+inline const char* const* poly_ids() { static const char* const ids[N_POLY_IDS] = {"DenseBias", "DenseWeight", "ConvBias", "ConvFilter", "MatMulBias", "MatMulWeight", "255", "EmbeddingMat", "PositionalMatrix"}; return ids; }
 inline std::vector<u64> vctx_to_words(const VerifierContext& v) {
   std::vector<u64> w;
   w.push_back(0x3158544356504444ULL); w.push_back(v.full_log); w.push_back(v.shape.input_len); w.push_back(v.shape.layers.size());
   for (auto& l : v.shape.layers) {
     w.push_back(l.kind); w.push_back(l.nrows); w.push_back(l.ncols); w.push_back(l.right_shift); w.push_back(l.fp_scale);
-    w.push_back(l.kind == L_ADD ? (u64)l.add_left : (u64)l.fixed_point_multiplier);  // (an Add carries its two multipliers in the requant multiplier / kx slots)
+    w.push_back(l.kind == L_ADD || l.kind == L_POSITIONAL ? (u64)l.add_left : (u64)l.fixed_point_multiplier);  // (an Add carries its two multipliers in the requant multiplier / kx slots)
     w.push_back(l.intermediate_bit_size);
     w.push_back(l.kind == L_MATMUL ? (l.mm_transpose ? 1 : 0) : l.kw);  // (a MatMul has no filter count: the slot carries its transpose flag)
-    w.push_back(l.kind == L_ADD ? (u64)l.add_right : l.kx); w.push_back(l.real_nw); w.push_back(l.nw);
+    w.push_back(l.kind == L_ADD || l.kind == L_POSITIONAL ? (u64)l.add_right : l.kx); w.push_back(l.real_nw); w.push_back(l.nw);
     for (int k = 0; k < 3; k++) w.push_back(l.unp_out[k]);
     for (int k = 0; k < 3; k++) w.push_back(l.pin[k]);
   }
@@ -1321,8 +1396,8 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
     l.kw = (size_t)rd(); l.kx = (size_t)rd(); l.real_nw = (size_t)rd(); l.nw = (size_t)rd();
     for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();
     for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd();
-    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_EMBED, DP_ERR_ARG, "verifier blob: layer kind");
-    if (l.kind == L_ADD) { l.add_left = l.fixed_point_multiplier; l.add_right = (int64_t)l.kx; l.fixed_point_multiplier = 0; l.kx = 0; DP_REQUIRE(l.add_left > 0 && l.add_right > 0, DP_ERR_ARG, "verifier blob: add multipliers"); }
+    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_POSITIONAL, DP_ERR_ARG, "verifier blob: layer kind");
+    if (l.kind == L_ADD || l.kind == L_POSITIONAL) { l.add_left = l.fixed_point_multiplier; l.add_right = (int64_t)l.kx; l.fixed_point_multiplier = 0; l.kx = 0; DP_REQUIRE(l.add_left > 0 && l.add_right > 0, DP_ERR_ARG, "verifier blob: add multipliers"); }
     if (l.kind == L_MATMUL) { DP_REQUIRE(l.kw <= 1, DP_ERR_ARG, "verifier blob: matmul flags"); l.mm_transpose = l.kw != 0; l.kw = 0; }
     if (l.kind == L_CONV) DP_REQUIRE(is_pow2(l.kw) && is_pow2(l.kx) && is_pow2(l.real_nw) && is_pow2(l.nw) && l.kw <= (1u << 16) && l.kx <= (1u << 16) && l.nw <= (1u << 12) && 2 * l.real_nw <= l.nw && l.unp_out[0] <= l.kw && l.unp_out[1] <= l.nw && l.unp_out[2] <= l.nw, DP_ERR_ARG, "verifier blob: conv shape");
     if (l.kind == L_MAXPOOL) DP_REQUIRE(is_pow2(l.pin[0]) && is_pow2(l.pin[1]) && is_pow2(l.pin[2]) && l.pin[2] >= 2, DP_ERR_ARG, "verifier blob: maxpool shape");

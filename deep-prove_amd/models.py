@@ -5,7 +5,7 @@ import math
 
 import numpy as np
 
-L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_FLATTEN, L_MATMUL, L_ADD, L_EMBED = 0, 1, 2, 3, 4, 5, 6, 7, 8
+L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_FLATTEN, L_MATMUL, L_ADD, L_EMBED, L_POSITIONAL = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 BIT_LEN = 8
 FIXED_POINT_SCALE = 25  # zkml/src/layers/requant.rs:47
 
@@ -150,6 +150,22 @@ class ModelBuilder:
         self._cur = self.shape_pad[0] * e
         return self
 
+    def positional(self, max_positions, left=1, right=1, requant=True):
+        """Positional::Learned (layers/transformer/positional.rs): a [max_positions][features] table is committed, its first `tokens` rows
+        are added to the [tokens][features] activation (out = left * x + right * table[:tokens]); max_positions >= tokens (padded)"""
+        assert len(self.shape_og) == 2
+        s_og, k_og = self.shape_og
+        s, k = self.shape_pad
+        mp = next_pow2(max_positions)
+        assert mp >= s
+        t = np.zeros((mp, k), dtype=np.int64)
+        t[:max_positions, :k_og] = self._tensor(max_positions * k_og).reshape(max_positions, k_og)
+        self.layers.append(dict(kind=L_POSITIONAL, left=int(left), right=int(right), nrows=mp, ncols=k, table=t))
+        if requant:
+            bits = 8 + int(math.ceil(math.log2(left + right)))
+            self.layers.append(dict(kind=L_REQUANT, **requant_from_multiplier(1.0 / (left + right), bits)))
+        return self
+
     def add_const(self, left=1, right=1, requant=True):
         """Add::new_with(operand) (layers/add.rs:72-78): out = left * x + right * operand with a constant operand as long as the
         activation (learned positional embeddings are added this way, transformer/positional.rs); zeros at the padding positions.
@@ -215,6 +231,9 @@ class ModelBuilder:
                 parts.append(np.array([L_DENSE, l["nrows"], l["ncols"]], dtype=np.int64))
                 parts.append(l["weights"].reshape(-1))
                 parts.append(l["bias"])
+            elif l["kind"] == L_POSITIONAL:
+                parts.append(np.array([L_POSITIONAL, l["left"], l["right"], l["nrows"], l["ncols"]], dtype=np.int64))
+                parts.append(l["table"].reshape(-1))
             elif l["kind"] == L_EMBED:
                 parts.append(np.array([L_EMBED, l["nrows"], l["ncols"]], dtype=np.int64))
                 parts.append(l["table"].reshape(-1))
@@ -256,6 +275,8 @@ class ModelBuilder:
         for l in self.layers:
             if l["kind"] == L_DENSE:
                 cur = l["weights"] @ cur + l["bias"]
+            elif l["kind"] == L_POSITIONAL:
+                cur = l["left"] * cur + l["right"] * l["table"].reshape(-1)[:cur.size]
             elif l["kind"] == L_EMBED:
                 cur = l["table"][cur].reshape(-1)
             elif l["kind"] == L_ADD:
@@ -313,11 +334,15 @@ def seq_mlp(seq, width, config, input_features=4, output_features=3, layers=2, t
     return mb
 
 
-def token_mlp(seq, vocab, width, config, output_features=3):
+def token_mlp(seq, vocab, width, config, output_features=3, max_positions=0):
     """tokens -> Embeddings -> + positional table -> two Linear layers per token: the non-attention part of a small language model
     (layers/transformer/embeddings.rs, layers/add.rs, layers/matrix_mul.rs)"""
     mb = ModelBuilder((seq,), config)
-    mb.embeddings(vocab, width).add_const(1, 1)
+    mb.embeddings(vocab, width)
+    if max_positions:  # Positional::Learned: a longer table, its first `seq` rows added (the claim is lifted to the whole table)
+        mb.positional(max_positions)
+    else:
+        mb.add_const(1, 1)
     mb.matmul(width).relu()
     mb.matmul(output_features, bias=False).relu()
     return mb

@@ -26,7 +26,7 @@ import struct
 import numpy as np
 
 MAGIC = 0x31464F4F52505044
-L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_MATMUL, L_ADD, L_EMBED = 0, 1, 2, 3, 4, 6, 7, 8
+L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_MATMUL, L_ADD, L_EMBED, L_POSITIONAL = 0, 1, 2, 3, 4, 6, 7, 8, 9
 
 
 class Conventions:
@@ -96,6 +96,9 @@ def parse_stream(words):
         node, kind = r.u(), r.u()
         if kind == L_DENSE:
             lp = {"sumcheck": r.iop(), "bias_eval": r.e(), "individual_claims": r.ve()}
+        elif kind == L_POSITIONAL:
+            assert r.u() == 1
+            lp = {"sub_matrix_evals": r.ve(), "left_eval": r.e(), "right_eval": r.e()}
         elif kind == L_EMBED:
             lp = {"sumcheck": r.iop(), "individual_claims": r.ve()}
         elif kind == L_ADD:
@@ -190,6 +193,9 @@ def to_serde_model(tree, conv=Conventions):
     for node, kind, lp in sorted(tree["steps"], key=lambda s: s[0]):
         if kind == L_DENSE:
             v = {"Dense": {"sumcheck": _iop(lp["sumcheck"], c), "bias_eval": _e(lp["bias_eval"], c), "individual_claims": _ve(lp["individual_claims"], c)}}
+        elif kind == L_POSITIONAL:  # PositionalProof {proofs: Vec<SinglePositionalProof {sub_matrix_evals, add_proof}>} (transformer/positional.rs:45-61)
+            v = {"Positional": {"proofs": [{"sub_matrix_evals": _ve(lp["sub_matrix_evals"], c),
+                                            "add_proof": {"left_eval": _e(lp["left_eval"], c), "right_eval": _e(lp["right_eval"], c)}}]}}
         elif kind == L_EMBED:  # EmbeddingsProof {sumcheck, individual_claims} (layers/transformer/embeddings.rs:60-67)
             v = {"Embeddings": {"sumcheck": _iop(lp["sumcheck"], c), "individual_claims": _ve(lp["individual_claims"], c)}}
         elif kind == L_ADD:  # AddProof {left_eval, right_eval} (layers/add.rs:59-63)
@@ -409,12 +415,15 @@ def from_rmp(data, conv=Conventions):
     assert end == len(data), "trailing bytes"
     w = _Writer(conv)
     w.w.append(MAGIC); w.w.append(len(model["steps"]))
-    kinds = {"Dense": L_DENSE, "Requant": L_REQUANT, "Activation": L_RELU, "Convolution": L_CONV, "Pooling": L_MAXPOOL, "MatMul": L_MATMUL, "Add": L_ADD, "Embeddings": L_EMBED}
+    kinds = {"Dense": L_DENSE, "Requant": L_REQUANT, "Activation": L_RELU, "Convolution": L_CONV, "Pooling": L_MAXPOOL, "MatMul": L_MATMUL, "Add": L_ADD, "Embeddings": L_EMBED, "Positional": L_POSITIONAL}
     for node in sorted(model["steps"]):
         (name, lp), = model["steps"][node].items()
         w.w.append(node); w.w.append(kinds[name])
         if name == "Dense":
             w.iop(lp["sumcheck"]); w.e(lp["bias_eval"]); w.ve(lp["individual_claims"])
+        elif name == "Positional":
+            assert len(lp["proofs"]) == 1
+            w.w.append(1); w.ve(lp["proofs"][0]["sub_matrix_evals"]); w.e(lp["proofs"][0]["add_proof"]["left_eval"]); w.e(lp["proofs"][0]["add_proof"]["right_eval"])
         elif name == "Embeddings":
             w.iop(lp["sumcheck"]); w.ve(lp["individual_claims"])
         elif name == "Add":

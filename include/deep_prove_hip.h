@@ -192,7 +192,7 @@ int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const u
 
 /* ---- model level: Context::generate / Prover::prove / verify (zkml/src/iop/context.rs:109, prover.rs:401,
  * verifier.rs:306). model_blob (int64): input_len, nlayers, then per layer kind (0 Dense, 1 Requant, 2 Relu, 3 Conv,
- * 4 MaxPool, 5 Flatten, 6 MatMul, 7 Add, 8 Embeddings) followed by
+ * 4 MaxPool, 5 Flatten, 6 MatMul, 7 Add, 8 Embeddings, 9 Positional) followed by
  *   Dense: nrows, ncols, weights[nrows*ncols] row-major, bias[nrows]   (padded to powers of two, already quantised; after a
  *          Flatten the columns follow the padded (c,h,w) layout with zeros at padding positions, tensor.rs:1627-1675)
  *   Requant: right_shift, fp_scale, fixed_point_multiplier, intermediate_bit_size   (zkml/src/layers/requant.rs:46-73)
@@ -213,6 +213,10 @@ int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const u
  *          (zkml/src/layers/transformer/embeddings.rs:359-571): the model input is then a vector of token ids, the output the
  *          [tokens][size] matrix of their rows; proved as one-hot(tokens) x table without building the one-hot matrix, the verifier
  *          checks the resulting one-hot claim against the tokens.
+ *   Positional: left multiplier, right multiplier, positions, embedding size (both padded), table[positions * size] — Positional::Learned
+ *          (zkml/src/layers/transformer/positional.rs:327-583): the first `tokens` rows of the committed table are added to the
+ *          [tokens][size] activation; the proof lifts the claim on that slice to the whole table with one transcript coordinate and
+ *          one sub-matrix evaluation per doubling.
  *   (MatMul / Add of two inputs and the other transformer layers are not built: the model is a chain of nodes.) */
 int32_t dp_model_setup(dp_ctx* ctx, const int64_t* model_blob, size_t nwords, dp_model** out);
 int32_t dp_model_free(dp_model* m);

@@ -21,6 +21,11 @@ static Model parse_model(const int64_t* b, size_t n) {
   for (size_t i = 0; i < nl; i++) {
     Layer l; l.kind = (LayerKind)rd();
     if (l.kind == L_DENSE) { l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); l.weights.assign(b + pos, b + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols; l.bias.assign(b + pos, b + pos + l.nrows); pos += l.nrows; }
+    else if (l.kind == L_POSITIONAL) {
+      l.add_left = rd(); l.add_right = rd(); l.nrows = (size_t)rd(); l.ncols = (size_t)rd();
+      if (l.nrows == 0 || l.ncols == 0 || l.nrows > n || l.ncols > n || pos + l.nrows * l.ncols > n) throw std::runtime_error("model blob truncated");
+      l.weights.assign(b + pos, b + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols;
+    }
     else if (l.kind == L_EMBED) {
       l.nrows = (size_t)rd(); l.ncols = (size_t)rd();
       if (l.nrows == 0 || l.ncols == 0 || l.nrows > n || l.ncols > n || pos + l.nrows * l.ncols > n) throw std::runtime_error("model blob truncated");

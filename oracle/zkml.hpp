@@ -169,12 +169,14 @@ static inline LogUpProof logup_batch_prove(const LogUpInput& in, Transcript& t) 
 }
 
 // ------------------------------------------------------------------ model description
-enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8 };
+enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8, L_POSITIONAL = 9 };
 struct Layer {
   LayerKind kind;
   // dense (padded to powers of two). matmul (layers/matrix_mul.rs, MatMul::new_constant: Input x Weight [+ bias]): the constant RIGHT
   // matrix is [nrows][ncols] row major, the input a row-major [s][nrows] matrix, bias [ncols] or empty
   size_t nrows = 0, ncols = 0;
+  // positional (layers/transformer/positional.rs, Positional::Learned): weights = the [nrows = positions][ncols = embedding size] table,
+  // out = add_left * x + add_right * table[0 .. tokens) for a [tokens][ncols] input, tokens <= nrows
   // embeddings (layers/transformer/embeddings.rs): the FIRST layer of a model; the input is a vector of token ids, weights the
   // [nrows = vocabulary][ncols = embedding size] table, the output [tokens][ncols]
   // add (layers/add.rs, Add::new_with(operand)): out = add_left * x + add_right * operand, the operand (a constant tensor as long as the
@@ -352,6 +354,10 @@ static inline Trace run_model(const Model& m, const std::vector<int64_t>& input)
         if (cur[i] < 0 || (size_t)cur[i] >= l.nrows) throw std::runtime_error("embeddings: token outside the vocabulary");
         for (size_t j = 0; j < l.ncols; j++) o[i * l.ncols + j] = l.weights[(size_t)cur[i] * l.ncols + j];
       }
+    } else if (l.kind == L_POSITIONAL) {  // Positional::evaluate (positional.rs:157-185): the Add layer on (x, the first rows of the table)
+      if (cur.size() % l.ncols || cur.size() > l.weights.size()) throw std::runtime_error("positional: input shape");
+      o.resize(cur.size());
+      for (size_t i = 0; i < cur.size(); i++) o[i] = l.add_left * cur[i] + l.add_right * l.weights[i];
     } else if (l.kind == L_ADD) {  // Add::evaluate (add.rs:184-210)
       if (cur.size() != l.weights.size()) throw std::runtime_error("add: operand size mismatch");
       o.resize(cur.size());
@@ -398,7 +404,7 @@ static inline Context context_generate(const Model& m) {
   }
   std::sort(tset.begin(), tset.end());
   for (auto& t : tset) max_poly_len = std::max(max_poly_len, size_t(1) << t.multiplicity_poly_vars());
-  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD || l.kind == L_EMBED) { max_poly_len = std::max(max_poly_len, next_pow2(l.weights.size())); max_poly_len = std::max(max_poly_len, next_pow2(l.bias.size())); }
+  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD || l.kind == L_EMBED || l.kind == L_POSITIONAL) { max_poly_len = std::max(max_poly_len, next_pow2(l.weights.size())); max_poly_len = std::max(max_poly_len, next_pow2(l.bias.size())); }
   max_poly_len = next_pow2(max_poly_len);
   ctx.max_poly_len = max_poly_len;
   ctx.pp = pcs_setup(max_poly_len);
@@ -408,6 +414,7 @@ static inline Context context_generate(const Model& m) {
   for (size_t id = 0; id < m.layers.size(); id++) {
     if (m.layers[id].kind == L_DENSE) { jobs.push_back({id, "DenseWeight"}); jobs.push_back({id, "DenseBias"}); }
     if (m.layers[id].kind == L_CONV) { jobs.push_back({id, "ConvFilter"}); jobs.push_back({id, "ConvBias"}); }  // convolution.rs:452-453,546-553
+    if (m.layers[id].kind == L_POSITIONAL) jobs.push_back({id, "PositionalMatrix"});  // positional.rs:229,243-251
     if (m.layers[id].kind == L_EMBED) jobs.push_back({id, "EmbeddingMat"});  // embeddings.rs:271,284-291
     if (m.layers[id].kind == L_ADD) jobs.push_back({id, "255"});  // OPERAND_POLY_ID = 0xff, to_string() (add.rs:32,520)
     if (m.layers[id].kind == L_MATMUL) { jobs.push_back({id, "MatMulWeight"}); if (!m.layers[id].bias.empty()) jobs.push_back({id, "MatMulBias"}); }  // matrix_mul.rs:947-963
@@ -417,7 +424,7 @@ static inline Context context_generate(const Model& m) {
   for (auto& j : jobs) th.emplace_back([&ctx, &m, j] {
     const Layer& l = m.layers[j.first];
     std::string pid = j.second;
-    Mle poly = Mle::from_i64(pid == "DenseWeight" || pid == "ConvFilter" || pid == "MatMulWeight" || pid == "255" || pid == "EmbeddingMat" ? l.weights : l.bias);
+    Mle poly = Mle::from_i64(pid == "DenseWeight" || pid == "ConvFilter" || pid == "MatMulWeight" || pid == "255" || pid == "EmbeddingMat" || pid == "PositionalMatrix" ? l.weights : l.bias);
     ctx.model_comms[j.first][j.second] = {pcs_commit(ctx.pp, poly), poly};
   });
   for (auto& t : th) t.join();
@@ -428,6 +435,7 @@ static inline Context context_generate(const Model& m) {
 // ------------------------------------------------------------------ proofs
 struct DenseProof { IOPProof sumcheck; E bias_eval; std::vector<E> individual_claims; };
 struct AddProof { E left_eval, right_eval; };  // add.rs:59-63
+struct PositionalProof { std::vector<E> sub_matrix_evals; AddProof add_proof; };  // SinglePositionalProof (positional.rs:45-55); one input
 struct MatMulProof { IOPProof sumcheck; std::vector<E> individual_claims; bool has_bias = false; E bias_eval{}; };  // matrix_mul.rs:153-161 (bias_eval: Option<E>)
 struct SamePolyProof { IOPProof sumcheck; std::vector<E> evals; };
 struct ActivationProof { SamePolyProof io_accumulation; LogUpProof lookup; std::vector<Commitment> commits; };
@@ -446,7 +454,7 @@ struct ConvProof {  // convolution.rs:98-127, fields in declaration order
   HadamardProof clearing_proof;
 };
 struct PoolingProof { IOPProof sumcheck; LogUpProof lookup; std::vector<E> zerocheck_evals; size_t variable_gap = 0; std::vector<Commitment> commitments; };  // pooling.rs:60-76
-struct LayerProof { LayerKind kind; DenseProof dense; MatMulProof matmul; AddProof add; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; };
+struct LayerProof { LayerKind kind; DenseProof dense; MatMulProof matmul; AddProof add; PositionalProof pos; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; };
 struct TableProof { Commitment multiplicity_commit; LogUpProof lookup; };
 struct Proof {
   std::map<size_t, LayerProof> steps;  // canonical order: ascending NodeId
@@ -565,6 +573,37 @@ static inline Claim prove_dense(ProverState& ps, size_t id, const Layer& l, cons
   LayerProof lp; lp.kind = L_DENSE; lp.dense = {proof, bias_eval, fin};
   ps.proofs[id] = lp;
   return {proof.point, fin[1]};
+}
+// Positional::prove, Learned (layers/transformer/positional.rs:327-452): the Add layer on (input, the first `tokens` rows of the table) gives
+// the evaluations of both at the claim's point (add.rs:81-145, two inputs: no transcript traffic); the claim on the slice is then lifted to
+// one on the WHOLE committed table: the output claim and the slice claim are absorbed, one extra coordinate per doubling is drawn, the
+// prover sends the evaluation of every "upper half" sub-matrix (rows [tokens 2^k, tokens 2^(k+1))) at the prefix of the point, and
+// table(point | extras) = fold_k (acc (1 - c_k) + sub_k c_k) (compute_positional_matrix_claim, :106-126).
+static inline Claim prove_positional(ProverState& ps, size_t id, const Layer& l, const Claim& last, const std::vector<E>& input) {
+  const size_t n = input.size();
+  if ((size_t(1) << last.point.size()) != n) throw std::runtime_error("positional: claim point size mismatch");
+  std::vector<E> sub(n); for (size_t i = 0; i < n; i++) sub[i] = e_from_i64(l.weights[i]);
+  E left_eval = Mle::from_ext(input).evaluate(last.point), right_eval = Mle::from_ext(sub).evaluate(last.point);
+  const unsigned nv_all = log2_strict(l.weights.size()), nv_sub = (unsigned)last.point.size(), diff = nv_all - nv_sub;
+  Transcript& t = *ps.t;
+  t.append_exts(last.point); t.append_ext(last.eval); t.append_exts(last.point); t.append_ext(right_eval);  // sample_random_coordinates (:80-99)
+  std::vector<E> point = last.point;
+  for (unsigned k = 0; k < diff; k++) point.push_back(t.read_challenge());
+  PositionalProof pp; pp.add_proof = {left_eval, right_eval};
+  E acc = right_eval;
+  for (unsigned k = 0; k < diff; k++) {
+    const size_t len = n << k;  // rows [tokens 2^k, tokens 2^(k+1)) of the table, as long as everything below them
+    std::vector<E> sm(len); for (size_t i = 0; i < len; i++) sm[i] = e_from_i64(l.weights[len + i]);
+    std::vector<E> pfx(point.begin(), point.begin() + nv_sub + k);
+    E ev = Mle::from_ext(sm).evaluate(pfx);
+    pp.sub_matrix_evals.push_back(ev);
+    E c = point[nv_sub + k];
+    acc = eadd(emul(acc, esub(e_one(), c)), emul(ev, c));
+  }
+  ps.add_witness_claim(ps.ctx->model_comms.at(id).at("PositionalMatrix"), {point, acc});
+  LayerProof lp; lp.kind = L_POSITIONAL; lp.pos = pp;
+  ps.proofs[id] = lp;
+  return {last.point, left_eval};
 }
 // Embeddings::prove (layers/transformer/embeddings.rs:359-462): the matmul protocol on (one-hot(tokens), table) without ever building
 // the one-hot matrix — its row variables fixed at the row part of the claim give reduced[x[i]] += beta(i, row part) (:382-401); the
@@ -970,6 +1009,7 @@ static inline Proof prove(const Context& ctx, const Trace& tr, Transcript& t) {
     else if (l.kind == L_MATMUL) cur = prove_matmul(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_ADD) cur = prove_add(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_EMBED) cur = prove_embeddings(ps, id, l, cur, tr.in[id]);
+    else if (l.kind == L_POSITIONAL) cur = prove_positional(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
     else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, to_fields(tr.out[id]));
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv[id]);
@@ -1034,6 +1074,7 @@ static inline std::vector<u64> serialize_proof(const Proof& p) {
     if (lp.kind == L_DENSE) { w.iop(lp.dense.sumcheck); w.e(lp.dense.bias_eval); w.ve(lp.dense.individual_claims); }
     else if (lp.kind == L_ADD) { w.e(lp.add.left_eval); w.e(lp.add.right_eval); }
     else if (lp.kind == L_EMBED) { w.iop(lp.matmul.sumcheck); w.ve(lp.matmul.individual_claims); }
+    else if (lp.kind == L_POSITIONAL) { w.u(1); w.ve(lp.pos.sub_matrix_evals); w.e(lp.pos.add_proof.left_eval); w.e(lp.pos.add_proof.right_eval); }  // PositionalProof {proofs: [one per input]}
     else if (lp.kind == L_MATMUL) { w.iop(lp.matmul.sumcheck); w.ve(lp.matmul.individual_claims); w.u(lp.matmul.has_bias ? 1 : 0); if (lp.matmul.has_bias) w.e(lp.matmul.bias_eval); }
     else if (lp.kind == L_REQUANT) {
       w.iop(lp.req.io_accumulation); w.ve(lp.req.accumulation_evals); w.logup(lp.req.clamping_lookup); w.logup(lp.req.shifted_lookup);

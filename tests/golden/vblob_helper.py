@@ -24,6 +24,7 @@ int main(int argc, char** argv) {
     else if (l.kind == 3) { l.kw = b[pos++]; l.kx = b[pos++]; l.real_nw = b[pos++]; l.nw = b[pos++]; for (int k = 0; k < 3; k++) l.unp_out[k] = b[pos++];
       size_t nf = l.kw * l.kx * l.real_nw * l.real_nw; l.weights.assign(b.begin() + pos, b.begin() + pos + nf); pos += nf; l.bias.assign(b.begin() + pos, b.begin() + pos + l.kw); pos += l.kw; }
     else if (l.kind == 4) { for (int k = 0; k < 3; k++) l.pin[k] = b[pos++]; }
+    else if (l.kind == 9) { l.add_left = b[pos++]; l.add_right = b[pos++]; l.nrows = b[pos++]; l.ncols = b[pos++]; l.weights.assign(b.begin() + pos, b.begin() + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols; }
     else if (l.kind == 8) { l.nrows = b[pos++]; l.ncols = b[pos++]; l.weights.assign(b.begin() + pos, b.begin() + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols; }
     else if (l.kind == 7) { l.add_left = b[pos++]; l.add_right = b[pos++]; size_t cnt = b[pos++]; l.weights.assign(b.begin() + pos, b.begin() + pos + cnt); pos += cnt; }
     else if (l.kind == 6) { l.nrows = b[pos++]; l.ncols = b[pos++]; size_t fl = b[pos++], hb = fl & 1; l.mm_transpose = (fl & 2) != 0; l.weights.assign(b.begin() + pos, b.begin() + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols;

@@ -249,6 +249,12 @@ int main(int argc, char** argv) {
       dp::LayerSpec e; e.kind = dp::L_EMBED; e.nrows = 32; e.ncols = F; e.weights.resize(32 * F); for (auto& x : e.weights) x = rq();
       m.layers.push_back(e); m.input_len = S;
     }
+    if (getenv("HL_LEARNED_POS")) {  // Positional::Learned (transformer/positional.rs): a table of HL_LEARNED_POS x S positions, its first S rows added
+      const size_t MP = S * (size_t)atoi(getenv("HL_LEARNED_POS"));
+      dp::LayerSpec a; a.kind = dp::L_POSITIONAL; a.add_left = 1; a.add_right = 1; a.nrows = MP; a.ncols = F; a.weights.resize(MP * F); for (auto& x : a.weights) x = rq();
+      m.layers.push_back(a);
+      dp::LayerSpec r2 = requant_for(1, 0.5); r2.intermediate_bit_size = 9; m.layers.push_back(r2);
+    }
     if (getenv("HL_POSITIONAL")) {  // Add with a static operand (layers/add.rs; the learned positional table of transformer/positional.rs), then a Requant by 1/2
       dp::LayerSpec a; a.kind = dp::L_ADD; a.add_left = 1; a.add_right = 1; a.weights.resize(S * F); for (auto& x : a.weights) x = rq();
       m.layers.push_back(a);

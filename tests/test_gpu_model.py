@@ -237,12 +237,12 @@ def test_golden_seq_mlp(dev):
     ctx.free()
 
 
-@pytest.mark.parametrize("seq,vocab,width", [(16, 50, 32), (64, 1000, 256)])
-def test_token_model_proof_bytes_identical_to_oracle(dev, oracle, seq, vocab, width):
+@pytest.mark.parametrize("seq,vocab,width,max_positions", [(16, 50, 32, 0), (64, 1000, 256, 0), (16, 50, 32, 100), (32, 300, 128, 32)])
+def test_token_model_proof_bytes_identical_to_oracle(dev, oracle, seq, vocab, width, max_positions):
     """tokens -> Embeddings -> + positional table -> MatMul blocks (models.token_mlp; layers/transformer/embeddings.rs, layers/add.rs,
     layers/matrix_mul.rs): proof stream == the oracle's, verifier accepts (one-hot input claim included), batch proofs == sequential"""
     import deep_prove_amd as dpa
-    mb = dpa.models.token_mlp(seq, vocab, width, config=70 + seq)
+    mb = dpa.models.token_mlp(seq, vocab, width, config=70 + seq, max_positions=max_positions)  # (> 0: Positional::Learned instead of the static Add)
     x = mb.input()
     ctx, proof, out, oproof, oout = prove_both(dev, oracle, mb, x)
     assert (out == oout).all() and (out == mb.run(x)).all()

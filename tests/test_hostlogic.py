@@ -156,7 +156,9 @@ def test_matmul_model_proof_stream_identical_to_oracle_and_accepted(hostlogic_bi
     # (layers/add.rs:81-145, 586-625: the learned positional table of transformer/positional.rs) in front of the first MatMul
     # ... and Embeddings as the first layer (layers/transformer/embeddings.rs:359-462, 473-571: tokens in, the one-hot claim checked
     # by the verifier against the public tokens)
-    for env in ({}, {"HL_TRANSPOSE": "1"}, {"HL_POSITIONAL": "1"}, {"HL_POSITIONAL": "1", "HL_TRANSPOSE": "1"}, {"HL_EMBED": "1"}, {"HL_EMBED": "1", "HL_POSITIONAL": "1"}):
+    for env in ({}, {"HL_TRANSPOSE": "1"}, {"HL_POSITIONAL": "1"}, {"HL_POSITIONAL": "1", "HL_TRANSPOSE": "1"}, {"HL_EMBED": "1"}, {"HL_EMBED": "1", "HL_POSITIONAL": "1"},
+                # Positional::Learned (transformer/positional.rs:327-452, 480-583): a table 1x / 4x as long as the sequence; the slice claim lifted to the table
+                {"HL_LEARNED_POS": "1"}, {"HL_LEARNED_POS": "4"}, {"HL_EMBED": "1", "HL_LEARNED_POS": "8"}):
         r = run(hostlogic_bin, "seq", seed, env=env)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "identical=1" in r.stdout

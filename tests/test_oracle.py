@@ -3,6 +3,7 @@ the oracle is pinned by (1) regenerating every third-party constant and checking
 known-answer test the reference holds on this path (multilinear_extensions/src/test.rs:46-82), (3) ports of the
 reference's own algebraic property tests, (4) committed golden vectors produced by the oracle (tests/golden)."""
 import numpy as np
+import pytest
 
 P = 0xFFFFFFFF00000001
 
@@ -133,7 +134,8 @@ def test_matmul_golden_fixture_is_reproducible(oracle):
         dpa.verify(g["verifier_blob"], g["proof"], g["input"], wrong)
 
 
-def test_token_model_embeddings_add_matmul_through_the_host_verifier(oracle):
+@pytest.mark.parametrize("max_positions", [0, 16, 40])
+def test_token_model_embeddings_add_matmul_through_the_host_verifier(oracle, max_positions):
     """tokens -> Embeddings -> + positional table (Add with a static operand) -> MatMul blocks (models.token_mlp): the oracle proves,
     numpy inference agrees, the product's host verifier (C ABI) accepts — including the one-hot input claim of the Embeddings layer
     (embeddings.rs:530-571) — and rejects another prompt, a token outside the vocabulary, a flipped word and a wrong output"""
@@ -142,7 +144,7 @@ def test_token_model_embeddings_add_matmul_through_the_host_verifier(oracle):
     import deep_prove_amd as dpa
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     from vblob_helper import verifier_blob_for
-    mb = dpa.models.token_mlp(16, 50, 32, config=71)
+    mb = dpa.models.token_mlp(16, 50, 32, config=71, max_positions=max_positions)  # 0: Add with a static operand; else Positional::Learned
     x = mb.input()
     assert x.size == 16 and x.max() < 50 and len(set(x.tolist())) > 4
     h = oracle.model_setup(mb.blob())
