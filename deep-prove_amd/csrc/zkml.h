@@ -162,6 +162,25 @@ inline size_t model_output_len(const ModelSpec& m) {
   }
   return cur;
 }
+// the two inner loops of the int16 inference paths, cloned for the vector ISAs of the host (resolved once at load time): the library is
+// built for baseline x86-64, where 32-bit multiplies do not vectorise
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#define DP_HOST_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+#else
+#define DP_HOST_CLONES
+#endif
+DP_HOST_CLONES inline int32_t dot_i16(const int16_t* a, const int16_t* b, size_t n) { int32_t s = 0; for (size_t i = 0; i < n; i++) s += (int32_t)a[i] * (int32_t)b[i]; return s; }
+DP_HOST_CLONES inline void axpy_i16(int32_t* acc, int32_t x, const int16_t* w, size_t n) { for (size_t j = 0; j < n; j++) acc[j] += x * (int32_t)w[j]; }
+// the weights of a Dense / MatMul layer once more as int16 when they all fit (quantised models: |w| <= 127): the inference that precedes
+// every proof then streams a quarter of the bytes and its multiply-adds vectorise in 32-bit lanes
+inline void prepare_fast_inference(LayerSpec& l) {
+  if (l.kind != L_DENSE && l.kind != L_MATMUL) return;
+  int64_t wm = 0; for (int64_t v : l.weights) wm = std::max(wm, v < 0 ? -v : v);
+  if (wm > 32767) return;
+  auto w16 = std::make_shared<std::vector<int16_t>>(l.weights.size());
+  for (size_t j = 0; j < l.weights.size(); j++) (*w16)[j] = (int16_t)l.weights[j];
+  l.w16 = w16; l.w16_max = wm;
+}
 inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
   Trace tr; std::vector<int64_t> cur = input;
   DP_REQUIRE(cur.size() == m.input_len, DP_ERR_SHAPE, "input length mismatch");
@@ -175,7 +194,7 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
       if (l.w16 && xmax <= 32767 && (double)xmax * (double)l.w16_max * (double)l.ncols < 2.0e9) {  // exact in int32: same integers as below
         std::vector<int16_t> x16(cur.size()); for (size_t j = 0; j < cur.size(); j++) x16[j] = (int16_t)cur[j];
         const int16_t* xp = x16.data();
-        for (size_t i = 0; i < l.nrows; i++) { int32_t a = 0; const int16_t* w = l.w16->data() + i * l.ncols; for (size_t j = 0; j < l.ncols; j++) a += (int32_t)w[j] * (int32_t)xp[j]; o[i] = (int64_t)a + l.bias[i]; }
+        for (size_t i = 0; i < l.nrows; i++) o[i] = (int64_t)dot_i16(l.w16->data() + i * l.ncols, xp, l.ncols) + l.bias[i];
       } else
       for (size_t i = 0; i < l.nrows; i++) { int64_t a = 0; const int64_t* w = &l.weights[i * l.ncols]; for (size_t j = 0; j < l.ncols; j++) a += w[j] * cur[j]; o[i] = a + l.bias[i]; }
     } else if (l.kind == L_MATMUL) {  // MatMul::op (matrix_mul.rs:230-311): [s][k] times the constant [k][n], the bias added to every row
@@ -183,6 +202,22 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
       DP_REQUIRE(k && cur.size() % k == 0, DP_ERR_SHAPE, "matmul input size mismatch");
       const size_t s_ = cur.size() / k;
       o.assign(s_ * n, 0);
+      int64_t xmax = 0; for (int64_t v : cur) xmax = std::max(xmax, v < 0 ? -v : v);
+      if (l.w16 && xmax <= 32767 && (double)xmax * (double)l.w16_max * (double)k < 2.0e9) {  // exact in int32: the same integers as the int64 loops below
+        std::vector<int16_t> x16(cur.size()); for (size_t j = 0; j < cur.size(); j++) x16[j] = (int16_t)cur[j];
+        // eight rows of the activation share every pass over the matrix: a row of W (2 KB at n = 1024) is read once per eight tokens
+        const size_t TB = 8;
+        std::vector<int32_t> acc(TB * n);
+        for (size_t i0 = 0; i0 < s_; i0 += TB) {
+          const size_t tb = std::min(TB, s_ - i0);
+          if (l.mm_transpose) { for (size_t j = 0; j < n; j++) { const int16_t* w = l.w16->data() + j * k; for (size_t t = 0; t < tb; t++) acc[t * n + j] = dot_i16(&x16[(i0 + t) * k], w, k); } }
+          else {
+            std::fill(acc.begin(), acc.begin() + tb * n, 0);
+            for (size_t q = 0; q < k; q++) { const int16_t* w = l.w16->data() + q * n; for (size_t t = 0; t < tb; t++) { const int32_t xv = x16[(i0 + t) * k + q]; if (xv) axpy_i16(&acc[t * n], xv, w, n); } }
+          }
+          for (size_t t = 0; t < tb; t++) { int64_t* row = &o[(i0 + t) * n]; const int32_t* a = &acc[t * n]; for (size_t j = 0; j < n; j++) row[j] = (int64_t)a[j] + (l.bias.empty() ? 0 : l.bias[j]); }
+        }
+      } else
       for (size_t i = 0; i < s_; i++) {
         int64_t* row = &o[i * n];
         if (l.mm_transpose) for (size_t j = 0; j < n; j++) { const int64_t* w = &l.weights[j * k]; const int64_t* x = &cur[i * k]; int64_t a = 0; for (size_t q = 0; q < k; q++) a += x[q] * w[q]; row[j] = a; }
@@ -342,6 +377,7 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
     if (l.kind == L_MATMUL) {  // model polys of a MatMul with a constant matrix (matrix_mul.rs:947-963)
       DBuf w = dev.alloc_persistent(l.weights.size(), false);
       dev.upload_i64(w, l.weights.data());
+      prepare_fast_inference(l);
       ctx->model_comms[id]["MatMulWeight"] = dev.commit(w, true);
       if (!l.bias.empty()) { DBuf b = dev.alloc_persistent(l.bias.size(), false); dev.upload_i64(b, l.bias.data()); ctx->model_comms[id]["MatMulBias"] = dev.commit(b, true); }
       ctx->weights_dev[id] = w;
@@ -350,8 +386,7 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
     DBuf w = dev.alloc_persistent(l.weights.size(), false), b = dev.alloc_persistent(l.bias.size(), false);
     dev.upload_i64(w, l.weights.data()); dev.upload_i64(b, l.bias.data());
     if (l.kind == L_DENSE) {
-      { int64_t wm = 0; for (int64_t v : l.weights) wm = std::max(wm, v < 0 ? -v : v);
-        if (wm <= 32767) { auto w16 = std::make_shared<std::vector<int16_t>>(l.weights.size()); for (size_t j = 0; j < l.weights.size(); j++) (*w16)[j] = (int16_t)l.weights[j]; l.w16 = w16; l.w16_max = wm; } }
+      prepare_fast_inference(l);
       ctx->model_comms[id]["DenseWeight"] = dev.commit(w, true);
       ctx->model_comms[id]["DenseBias"] = dev.commit(b, true);
     } else {  // model polys of a convolution (convolution.rs:452-453,546-553)
