@@ -63,6 +63,7 @@ SIGNATURES = {
     "dp_pcs_commit": (C.c_int32, [vp, vp, C.POINTER(vp), u64p]),
     "dp_pcs_commit_free": (C.c_int32, [vp, vp]),
     "dp_pcs_commitment": (C.c_int32, [vp, u64p, u32p, i32p]),
+    "dp_model_infer_host": (C.c_int32, [i64p, C.c_size_t, i64p, C.c_size_t, i64p, C.POINTER(C.c_size_t)]),
     "dp_host_poseidon2": (C.c_int32, [u64p, C.c_int32, C.POINTER(C.c_int32)]),
     "dp_pcs_open": (C.c_int32, [vp, vp, u64p, C.c_uint32, u64p, vp, C.POINTER(u64p), C.POINTER(C.c_size_t)]),
     "dp_pcs_verify": (C.c_int32, [C.c_size_t, u64p, C.c_uint32, C.c_int32, u64p, u64p, u64p, C.c_size_t, vp]),

@@ -444,6 +444,17 @@ def host_cpu_budget():
     return float(_lib.load().dp_host_cpu_budget())
 
 
+def infer_host(model_blob, input_i64):
+    """dp_model_infer_host: the quantised inference of a model blob on the host (Model::run); no device involved"""
+    b = np.ascontiguousarray(model_blob, dtype=np.int64)
+    x = np.ascontiguousarray(input_i64, dtype=np.int64)
+    out = np.empty(max(1 << 16, 4 * x.size), dtype=np.int64)
+    n = C.c_size_t(out.size)
+    rc = _lib.load().dp_model_infer_host(b.ctypes.data_as(i64p), b.size, x.ctypes.data_as(i64p), x.size, out.ctypes.data_as(i64p), C.byref(n))
+    check(rc)
+    return out[:n.value].copy()
+
+
 def verify_batch(verifier_blob, proofs, inputs_i64, outputs_i64, dev=None, threads=0):
     """dp_verify_batch: verdict per proof (0 accepted, -5 rejected, -1 malformed) and the wall time in ms. With `dev` the Merkle
     paths are authenticated on the GPU (one launch per proof), the protocol checks run on host threads either way."""

@@ -725,6 +725,18 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     if (err_code) { for (size_t i = 0; i < nproofs; i++) { dp_free(proof_words[i]); proof_words[i] = nullptr; } throw DpError(err_code, err); }
   });
 }
+int32_t dp_model_infer_host(const int64_t* model_blob, size_t nwords, const int64_t* input, size_t ninput, int64_t* output, size_t* noutput) {
+  return guard([&] {
+    DP_REQUIRE(model_blob && input && output && noutput, DP_ERR_ARG, "bad arguments");
+    ModelSpec m = parse_model(model_blob, nwords);
+    validate_model(m);
+    for (auto& l : m.layers) { prepare_fast_inference(l); if (l.kind == L_CONV) l.wfft = conv_weight_fft(l); }
+    Trace tr = run_model(m, std::vector<int64_t>(input, input + ninput));
+    const auto& o = tr.out.back();
+    DP_REQUIRE(*noutput >= o.size(), DP_ERR_ARG, "output buffer too small");
+    memcpy(output, o.data(), o.size() * 8); *noutput = o.size();
+  });
+}
 int32_t dp_host_poseidon2(uint64_t state[8], int32_t force_scalar, int32_t* vectorised) {
   return guard([&] {
     DP_REQUIRE(state, DP_ERR_ARG, "null state");

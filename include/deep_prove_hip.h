@@ -240,6 +240,9 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
                              uint64_t** proof_words, size_t* proof_nwords, int64_t* outputs, size_t noutput_cap,
                              size_t* noutput, double* wall_ms);
 /* proofs the last dp_model_prove_batch of this model kept in flight (0 before the first batch) */
+/* Model::run (zkml/src/model.rs: quantised inference of the padded model) on the HOST, no device involved: the inference dp_model_prove /
+ * dp_model_prove_batch run before every proof (int16 weights, 32-bit accumulators where exact). *noutput: capacity in, length out. */
+int32_t dp_model_infer_host(const int64_t* model_blob, size_t nwords, const int64_t* input, size_t ninput, int64_t* output, size_t* noutput);
 /* The Poseidon2-w8 permutation of the HOST transcript (transcript/src/basic.rs over ff_ext/src/lib.rs:167-236), in place on eight canonical
  * words: the AVX-512 code (csrc/p2_avx512.cpp) when the CPU has AVX-512F/DQ and DP_NO_AVX512 is not set, else scalar; force_scalar != 0
  * always takes the scalar code. *vectorised (may be NULL) tells which one the library's transcripts use. Host only. */

@@ -1,0 +1,25 @@
+"""dp_model_infer_host: the quantised inference the library runs before every proof (Model::run semantics; int16 weights with 32-bit
+accumulators and vector-ISA clones of the inner loops where exact) against the numpy inference of deep_prove_amd/models.py — at the sizes
+of the measured workloads, where the fast paths are taken, and on inputs that force the 64-bit fallback."""
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("name,args,kw", [("mlp", (2, 64), dict(config=31)), ("dense_4m", (), {}), ("cnn_tiny", (), {}), ("seq_mlp", (16, 64), dict(config=63, transpose_last=True, positional=True)),
+                                          ("seq_1m", (), {}), ("token_mlp", (32, 300, 128), dict(config=72, max_positions=50))])
+def test_library_inference_equals_numpy(name, args, kw):
+    import deep_prove_amd as dpa
+    mb = getattr(dpa.models, name)(*args, **kw)
+    for idx in (1000, 1001):
+        x = mb.input(idx)
+        assert (dpa.infer_host(mb.blob(), x) == mb.run(x)).all()
+
+
+def test_large_inputs_take_the_64_bit_path():
+    """activations beyond int16 (no Requant in front): the int16 shortcut must not be taken, the results stay exact"""
+    import deep_prove_amd as dpa
+    mb = dpa.models.ModelBuilder((8, 4), 5)
+    mb.matmul(16, requant=False).matmul(8, bias=False, requant=False)  # the second MatMul sees un-requantised sums
+    x = mb.input() * 3000
+    assert np.abs(x).max() > 32767
+    assert (dpa.infer_host(mb.blob(), x) == mb.run(x)).all()
