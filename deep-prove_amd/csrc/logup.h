@@ -226,6 +226,12 @@ inline LogUpVerifierClaim verify_logup_proof(const LogUpProof& proof, size_t num
     calc = ex_add(proof.output_claims[0].eval, ex_mul(lambda, ce));
   }
   DP_REQUIRE(ex_eq(calc, current_claim), DP_ERR_VERIFY, "logup: final evaluation mismatch");
+  // the output claims are claims AT THE VERIFIER'S final point. The reference hands the prover-supplied points on (verifier.rs:160-164) —
+  // an honest prover's are this point, so checking costs no proof byte and leaves no word of the stream unbound
+  for (const Claim& c : proof.output_claims) {
+    DP_REQUIRE(c.point.size() == point.size(), DP_ERR_VERIFY, "logup: output claim at a point other than the verifier's");
+    for (size_t i = 0; i < point.size(); i++) DP_REQUIRE(ex_eq(c.point[i], point[i]), DP_ERR_VERIFY, "logup: output claim at a point other than the verifier's");
+  }
   out.claims = proof.output_claims;
   return out;
 }

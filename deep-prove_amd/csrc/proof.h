@@ -139,6 +139,8 @@ struct Reader {
   const u64* p; size_t n, pos = 0;
   Reader(const u64* p_, size_t n_) : p(p_), n(n_) {}
   u64 u() { DP_REQUIRE(pos < n, DP_ERR_ARG, "proof stream truncated"); return p[pos++]; }
+  u64 small(u64 max) { u64 v = u(); DP_REQUIRE(v <= max, DP_ERR_ARG, "proof stream: value out of range"); return v; }  // (values that are narrowed after reading)
+  bool flag() { u64 v = u(); DP_REQUIRE(v <= 1, DP_ERR_ARG, "proof stream: a boolean is 0 or 1"); return v != 0; }  // (one encoding per proof: no malleable streams)
   // a length prefix is bounded by what is left of the stream (division: `v * unit_words` wraps for v >= 2^62)
   size_t len(size_t unit_words = 1) { u64 v = u(); DP_REQUIRE(v <= (n - pos) / (unit_words ? unit_words : 1), DP_ERR_ARG, "proof stream: bad length"); return (size_t)v; }
   u64 fe() { u64 v = u(); DP_REQUIRE(v < GL_P, DP_ERR_ARG, "proof stream: non-canonical field element"); return v; }
@@ -154,11 +156,11 @@ struct Reader {
     k = len(); q.round_evaluations.resize(k); for (auto& r : q.round_evaluations) r = ve();
     k = len(); q.output_claims.resize(k); for (auto& c : q.output_claims) c = claim();
     k = len(); q.circuit_outputs.resize(k); for (auto& c : q.circuit_outputs) c = ve();
-    q.is_table = u() != 0; return q;
+    q.is_table = flag(); return q;
   }
-  Commitment comm() { Commitment c; c.root = d(); c.num_vars = (unsigned)u(); c.is_base = u() != 0; return c; }
+  Commitment comm() { Commitment c; c.root = d(); c.num_vars = (unsigned)small(64); c.is_base = flag(); return c; }
   CodewordQuery cq() {
-    CodewordQuery q; q.is_ext = u() != 0;
+    CodewordQuery q; q.is_ext = flag();
     if (q.is_ext) { q.left = e(); q.right = e(); } else { q.left = ex(fe(), 0); q.right = ex(fe(), 0); }
     q.index = (size_t)u(); size_t k = len(4); q.path.resize(k); for (auto& x : q.path) x = d(); return q;
   }
@@ -174,7 +176,7 @@ struct Reader {
     }
     k = len(); b.sumcheck_proof.resize(k); for (auto& m : b.sumcheck_proof) m = ve();
     k = len(); b.trivial_proof.resize(k);
-    for (auto& m : b.trivial_proof) { m.is_ext = u() != 0; size_t l = len(m.is_ext ? 2 : 1); m.w.resize(l * (m.is_ext ? 2 : 1)); for (auto& x : m.w) x = fe(); }
+    for (auto& m : b.trivial_proof) { m.is_ext = flag(); size_t l = len(m.is_ext ? 2 : 1); m.w.resize(l * (m.is_ext ? 2 : 1)); for (auto& x : m.w) x = fe(); }
     return b;
   }
 };
@@ -183,7 +185,7 @@ inline Proof deserialize_proof(const u64* words, size_t n) {
   DP_REQUIRE(r.u() == PROOF_MAGIC, DP_ERR_ARG, "bad proof magic");
   size_t ns = r.len();
   for (size_t i = 0; i < ns; i++) {
-    size_t id = (size_t)r.u(); LayerProof lp; lp.kind = (int)r.u();
+    size_t id = (size_t)r.u(); LayerProof lp; lp.kind = (int)r.small(255);
     if (lp.kind == L_DENSE) { lp.dense.sumcheck = r.iop(); lp.dense.bias_eval = r.e(); lp.dense.individual_claims = r.ve(); }
     else if (lp.kind == L_ADD) { lp.add.left_eval = r.e(); lp.add.right_eval = r.e(); }
     else if (lp.kind == L_EMBED) { lp.matmul.sumcheck = r.iop(); lp.matmul.individual_claims = r.ve(); }

@@ -23,3 +23,14 @@ def test_large_inputs_take_the_64_bit_path():
     x = mb.input() * 3000
     assert np.abs(x).max() > 32767
     assert (dpa.infer_host(mb.blob(), x) == mb.run(x)).all()
+
+
+def test_mutated_model_blobs_are_rejected_or_run_but_never_crash():
+    """parse_model / validate_model / run_model behind dp_model_infer_host on 2 000 mutated blobs of four model families (flipped bits, huge
+    and negative dimensions, truncations): every call returns (a result or DP_ERR_*), the process survives"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "support", "fuzz_blob.py"), "11", "2000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fuzz done" in r.stdout, r.stdout[-500:] + r.stderr[-2000:]
+    rejected = int(r.stdout.split("rejected")[1].split()[0])
+    assert rejected > 500

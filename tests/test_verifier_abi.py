@@ -227,3 +227,12 @@ def test_batch_verifier_host_only_accepts_and_rejects_per_proof():
         if name == "cnn_tiny.npz":
             assert got[3] == -5  # this one sits in a sibling digest of the batch opening's last Merkle path
         assert ms > 0
+
+
+def test_mutated_proof_streams_never_verify_and_never_crash():
+    """dp_verify on 1 500 mutated golden proofs (MLP, CNN, MatMul models): flipped bits, out-of-range words, truncations, cut and duplicated
+    ranges. Every word of a stream is bound: the only accepted streams are those a mutation left identical to the proof (booleans and
+    narrowed values have one encoding; logup output claims sit at the verifier's point; sumcheck points equal the challenges)"""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "support", "fuzz_proof.py"), "5", "1500"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "accepted-but-different 0" in r.stdout, r.stdout[-800:] + r.stderr[-1500:]
