@@ -70,6 +70,10 @@ SIGNATURES = {
     "dp_pcs_batch_open": (C.c_int32, [vp, C.POINTER(vp), C.c_int32, u64p, u64p, vp, C.POINTER(u64p),
                                       C.POINTER(C.c_size_t)]),
     "dp_pcs_batch_verify": (C.c_int32, [C.c_size_t, u64p, u32p, i32p, C.c_int32, u64p, u64p, u64p, C.c_size_t, vp]),
+    "dp_pcs_batch_commit": (C.c_int32, [vp, C.POINTER(vp), C.c_int32, C.POINTER(vp), u64p]),
+    "dp_pcs_batch_commit_free": (C.c_int32, [vp, vp]),
+    "dp_pcs_simple_batch_open": (C.c_int32, [vp, vp, u64p, C.c_uint32, vp, C.POINTER(u64p), C.POINTER(C.c_size_t)]),
+    "dp_pcs_simple_batch_verify": (C.c_int32, [C.c_size_t, u64p, C.c_uint32, C.c_int32, u64p, u64p, C.c_int32, u64p, C.c_size_t, vp]),
     "dp_model_setup": (C.c_int32, [vp, i64p, C.c_size_t, C.POINTER(vp)]),
     "dp_model_free": (C.c_int32, [vp]),
     "dp_model_prove": (C.c_int32, [vp, i64p, C.c_size_t, C.POINTER(u64p), C.POINTER(C.c_size_t), i64p,

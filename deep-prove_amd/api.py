@@ -306,6 +306,22 @@ class Commitment:
             self.h = None
 
 
+class BatchCommitment:
+    """BasefoldCommitmentWithWitness of several polynomials behind one root (mpcs/src/basefold.rs:356-446)"""
+
+    def __init__(self, dev, handle, root, polys):
+        self.dev, self.h, self.root, self.polys = dev, handle, root, polys
+
+    @property
+    def num_vars(self):
+        return self.polys[0].num_vars
+
+    def free(self):
+        if self.h:
+            _lib.load().dp_pcs_batch_commit_free(self.dev.h, self.h)
+            self.h = None
+
+
 class Basefold:
     """mpcs::PolynomialCommitmentScheme for Basefold<GoldilocksExt2, BasefoldRSParams<PoseidonHasher>>"""
 
@@ -335,6 +351,32 @@ class Basefold:
         pw = np.ascontiguousarray(proof_words, dtype=np.uint64)
         check(_lib.load().dp_pcs_verify(max_poly_size, r.ctypes.data_as(u64p), num_vars, 1 if is_base else 0, pt.ctypes.data_as(u64p),
                                         ev.ctypes.data_as(u64p), pw.ctypes.data_as(u64p), pw.size, transcript.h if transcript is not None else None))
+
+    def batch_commit(self, polys):
+        """PCS::batch_commit (mpcs/src/basefold.rs:356-446): 1..32 polynomials of one size and one field behind ONE Merkle root"""
+        hs = (vp * len(polys))(*[p.h for p in polys])
+        h = vp()
+        root = (C.c_uint64 * 4)()
+        check(_lib.load().dp_pcs_batch_commit(self.dev.h, hs, len(polys), C.byref(h), root))
+        return BatchCommitment(self.dev, h, [int(x) for x in root], list(polys))
+
+    def simple_batch_open(self, comm, point, transcript=None):
+        """PCS::simple_batch_open (mpcs/src/basefold.rs:777-861): every polynomial of a batch commitment at one point"""
+        pt = _point(point)
+        pw, pn = u64p(), C.c_size_t()
+        check(_lib.load().dp_pcs_simple_batch_open(self.dev.h, comm.h, pt.ctypes.data_as(u64p), len(point), transcript.h if transcript is not None else None,
+                                                   C.byref(pw), C.byref(pn)))
+        return _take(pw, pn.value)
+
+    @staticmethod
+    def simple_batch_verify(max_poly_size, root, num_vars, is_base, point, evals, proof_words, transcript=None):
+        """PCS::simple_batch_verify (mpcs/src/basefold.rs:1100-1203). Host only. Raises DeepProveError(DP_ERR_VERIFY) on rejection."""
+        r = np.array(root, dtype=np.uint64)
+        pt, ev = _point(point), _point(evals)
+        pw = np.ascontiguousarray(proof_words, dtype=np.uint64)
+        check(_lib.load().dp_pcs_simple_batch_verify(max_poly_size, r.ctypes.data_as(u64p), num_vars, 1 if is_base else 0, pt.ctypes.data_as(u64p),
+                                                     ev.ctypes.data_as(u64p), len(evals), pw.ctypes.data_as(u64p), pw.size,
+                                                     transcript.h if transcript is not None else None))
 
     def batch_open(self, comms, points, evals, transcript):
         lib = _lib.load()

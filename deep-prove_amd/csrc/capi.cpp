@@ -27,6 +27,7 @@ struct CtxLock { std::unique_lock<std::recursive_mutex> l; explicit CtxLock(dp_c
 struct dp_buf { DBuf b; };
 struct dp_transcript { Transcript t; };
 struct dp_commit { DevCommit c; };
+struct dp_batch_commit { DevBatchCommit c; };
 struct dp_model {
   dp_ctx* ctx; std::unique_ptr<Context> zk; std::vector<std::unique_ptr<Dev>> workers; std::vector<dp::Cohort*> cohorts;
   size_t last_in_flight = 0, in_flight_cap = 0; size_t prove_peak = 0;  // largest arena footprint a proof of this model has had so far (sizes the arenas of batch workers)
@@ -524,6 +525,63 @@ int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const u
     std::vector<MerkleJob> jobs;
     merkle_sink() = &jobs;
     try { pcs_batch_verify(vp, vc, p, t->t); } catch (...) { merkle_sink() = nullptr; throw; }
+    merkle_sink() = nullptr;
+    DP_REQUIRE(merkle_jobs_ok(jobs), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
+  });
+}
+
+/* PCS::batch_commit / simple_batch_open / simple_batch_verify (mpcs/src/basefold.rs:356-446, 777-861, 1100-1203) */
+int32_t dp_pcs_batch_commit(dp_ctx* ctx, const dp_buf* const* polys, int32_t n, dp_batch_commit** out, uint64_t root[4]) {
+  return guard([&] {
+    DP_REQUIRE(ctx && polys && out && n >= 1 && n <= 32, DP_ERR_ARG, "bad arguments (1..32 polynomials)");
+    std::vector<DBuf> ev;
+    for (int i = 0; i < n; i++) { DP_REQUIRE(polys[i], DP_ERR_ARG, "null polynomial"); ev.push_back(polys[i]->b); }
+    CtxLock lk(ctx);
+    DevBatchCommit c = pcs_batch_commit(*ctx->dev, ev, true);
+    if (root) for (int k = 0; k < 4; k++) root[k] = c.root.v[k];
+    *out = new dp_batch_commit{std::move(c)};
+  });
+}
+int32_t dp_pcs_batch_commit_free(dp_ctx* ctx, dp_batch_commit* c) {
+  return guard([&] {
+    if (!c) return;
+    CtxLock lk(ctx);
+    for (DevCommit& d : c->c.polys) {  // the evaluation tables belong to the caller's dp_bufs
+      if (d.bh_evals.p == d.evals.p) d.bh_evals.p = nullptr;
+      if (d.tree.leaves.p == d.evals.p) d.tree.leaves.p = nullptr;
+      d.evals.p = nullptr;
+      ctx->dev->free_commit(d);
+    }
+    if (c->c.tree.leaves.p) ctx->dev->free_persistent(c->c.tree.leaves);
+    if (c->c.tree.nodes.p) ctx->dev->free_persistent(c->c.tree.nodes);
+    delete c;
+  });
+}
+int32_t dp_pcs_simple_batch_open(dp_ctx* ctx, const dp_batch_commit* comm, const uint64_t* point, uint32_t num_vars, dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords) {
+  return guard([&] {
+    DP_REQUIRE(ctx && comm && point && proof_words && proof_nwords, DP_ERR_ARG, "bad arguments");
+    DP_REQUIRE(num_vars == comm->c.nv, DP_ERR_SHAPE, "point length != the polynomials' number of variables");
+    DP_REQUIRE(comm->c.trivial() || t, DP_ERR_ARG, "a non-trivial opening needs the transcript");
+    CtxLock lk(ctx);
+    Transcript scratch;
+    BasefoldProof p = pcs_simple_batch_open(*ctx->dev, comm->c, read_point(point, num_vars), t ? t->t : scratch);
+    Writer w; w.basefold(p);
+    *proof_words = copy_out(w.w); *proof_nwords = w.w.size();
+  });
+}
+int32_t dp_pcs_simple_batch_verify(size_t max_poly_size, const uint64_t root[4], uint32_t num_vars, int32_t is_base, const uint64_t* point, const uint64_t* evals, int32_t n,
+                                   const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t) {
+  return guard([&] {
+    DP_REQUIRE(root && point && evals && n >= 1 && n <= 32 && proof_words && is_pow2(max_poly_size), DP_ERR_ARG, "bad arguments");
+    Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = root[k]; c.num_vars = num_vars; c.is_base = is_base != 0;
+    Reader r(proof_words, proof_nwords); BasefoldProof p = r.basefold();
+    DP_REQUIRE(r.pos == proof_nwords, DP_ERR_ARG, "proof stream: trailing words");
+    DP_REQUIRE(p.is_trivial() || t, DP_ERR_ARG, "a non-trivial opening needs the transcript");
+    VerifierParams vp; vp.full_log = dp_ceil_log2(max_poly_size);
+    Transcript scratch;
+    std::vector<MerkleJob> jobs;
+    merkle_sink() = &jobs;
+    try { pcs_simple_batch_verify(vp, c, read_point(point, num_vars), read_point(evals, (unsigned)n), p, t ? t->t : scratch); } catch (...) { merkle_sink() = nullptr; throw; }
     merkle_sink() = nullptr;
     DP_REQUIRE(merkle_jobs_ok(jobs), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
   });

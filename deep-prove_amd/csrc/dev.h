@@ -227,6 +227,10 @@ class Dev {
   }
   virtual void free_commit(DevCommit& c) = 0;
   virtual DevTree merkle_ext(const DBuf& leaves) = 0;
+  // MerkleTree::from_batch_leaves over k >= 2 codewords of one size and one field (merkle_tree.rs:68-74): the returned tree's `leaves`
+  // are the row hashes (two extension entries per row: hash_or_noop of [cws[0][j], .., cws[k-1][j]]), its nodes from the first hashed
+  // layer up are the batch tree's (pair i = hash_two_digests(hash(row 2i), hash(row 2i+1))), its root the commitment.
+  virtual DevTree batch_tree(const DBuf* cws, int k, bool persistent) { (void)cws; (void)k; (void)persistent; throw DpError(DP_ERR_SHAPE, "batch_tree: not provided by this device"); }
   // classic sumcheck round (K12): fold every (f_i, eq_i) of length > 1 with r (if given), then
   // out[2i] = sum_j f[2j]*eq[2j], out[2i+1] = sum_j (f[2j+1]-f[2j])*(eq[2j+1]-eq[2j]); length-1 pairs give (f*eq, 0)
   virtual void classic_round(DBuf* fs, DBuf* eqs, int np, const Ext* r, Ext* out) = 0;

@@ -587,6 +587,31 @@ KBODY k_merkle_layer(const u64* in, u64* out, size_t cnt) {
   }
 }
 
+// The row hashes of MerkleTree::from_batch_leaves (merkle_tree.rs:261-329; util/hash.rs:32-41): several polynomials of one size share ONE
+// tree whose leaf j is the row [cw_0[j], .., cw_{k-1}[j]]. Lane j writes hash_or_noop(row j) (poseidon_hash.rs:22-28: up to four base words
+// are the digest themselves, zero padded; more go through the sponge: overwrite four lanes, permute, the digest is popped from the back)
+// as the two extension "leaves" 2j, 2j+1 of `out`: the ordinary tree over `out` (k_merkle_leaves packs pairs, layers compress) then IS the
+// batch tree from its first hashed layer up — hash_two_digests(hash(row 2i), hash(row 2i+1)) — so nothing else is specific to batches.
+// Reads are coalesced per polynomial (consecutive lanes, consecutive elements). Not on the zkml path (dp_pcs_batch_commit only).
+constexpr int BATCH_ROW_MAX = 32;
+struct BatchRowPtrs { const u64* cw[BATCH_ROW_MAX]; };
+template <bool EXT>
+KBODY k_batch_row_hash(BatchRowPtrs a, int k, u64* out, size_t n) {
+  constexpr int W = EXT ? 2 : 1;
+  const int m = k * W;
+  for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
+    u64 s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c0 = 0; c0 < m; c0 += 4) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) { const int t = c0 + i; if (t < m) s[i] = a.cw[t / W][W * j + t % W]; }
+      if (m > 4) poseidon2_permute(s, c_rc);
+    }
+    u64* q = out + 4 * j;
+    if (m > 4) { q[0] = s[3]; q[1] = s[2]; q[2] = s[1]; q[3] = s[0]; }
+    else { q[0] = s[0]; q[1] = s[1]; q[2] = s[2]; q[3] = s[3]; }
+  }
+}
+
 // Several consecutive Merkle layers in ONE launch (DP_MERKLE_FUSE=levels, experiment, default off): workgroup b hashes the
 // 2 * blockDim.x digests [b * 2 blockDim.x, ..) of the input layer down `levels` layers — every layer it produces is consumed
 // by itself only, so a block barrier between layers is all the synchronisation there is — and writes each layer to its place
@@ -4066,6 +4091,17 @@ class HipDev : public Dev {
     free_persistent(c.evals);
   }
   DevTree merkle_ext(const DBuf& leaves) override { return build_tree(leaves, false); }
+  DevTree batch_tree(const DBuf* cws, int k, bool persistent) override {
+    DP_REQUIRE(k >= 2 && k <= BATCH_ROW_MAX, DP_ERR_SHAPE, "batch_tree: 2..32 polynomials per tree");
+    const size_t n = cws[0].n; const bool E = cws[0].ext;
+    BatchRowPtrs a{};
+    for (int q = 0; q < k; q++) { DP_REQUIRE(cws[q].n == n && cws[q].ext == E, DP_ERR_SHAPE, "batch_tree: equal sizes and one field expected"); a.cw[q] = (const u64*)cws[q].p; }
+    DBuf rows = persistent ? alloc_persistent(2 * n, true) : alloc(2 * n, true);
+    nb_ = (E ? 16.0 : 8.0) * n * k + 32.0 * n;
+    if (E) { DPL(k_batch_row_hash<true>, dim3(grid_for(n)), dim3(TPB), a, k, (u64*)rows.p, n); }
+    else { DPL(k_batch_row_hash<false>, dim3(grid_for(n)), dim3(TPB), a, k, (u64*)rows.p, n); }
+    return build_tree(rows, persistent);
+  }
 
   void classic_round(DBuf* fs, DBuf* eqs, int np, const Ext* r, Ext* out) override {
     DP_REQUIRE((size_t)np * (sizeof(PolyDesc) * 2 + sizeof(ClassicDesc) + 4) + 320 <= DESC_BYTES && (size_t)np * 4 <= RES_WORDS && np * 2 <= 1024, DP_ERR_SHAPE, "classic_round: too many polynomials");

@@ -272,6 +272,88 @@ inline BasefoldProof pcs_open(Dev& dev, unsigned full_log, const DevCommit& c, c
   return proof;
 }
 
+// PCS::batch_commit (basefold.rs:356-446): k polynomials of one size and one field behind ONE Merkle root. Every polynomial is encoded as in
+// commit() (its own tree is kept: the query phase gathers the opened pairs through it); the common tree is Dev::batch_tree over the
+// codewords (over the raw tables when trivial). One polynomial: the ordinary commitment (merkle_tree.rs:273-285).
+struct DevBatchCommit {
+  std::vector<DevCommit> polys;
+  DevTree tree;  // leaves = row hashes (k >= 2)
+  unsigned nv = 0;
+  bool is_base = true;
+  Digest root;
+  bool trivial() const { return nv <= PCS_BASECODE_LOG; }
+};
+inline DevBatchCommit pcs_batch_commit(Dev& dev, const std::vector<DBuf>& evals, bool persistent) {
+  DP_REQUIRE(!evals.empty(), DP_ERR_ARG, "cannot batch commit to zero polynomials");
+  for (const DBuf& e : evals) DP_REQUIRE(e.n == evals[0].n && e.ext == evals[0].ext, DP_ERR_SHAPE, "cannot batch commit to polynomials of different sizes or fields");
+  DevBatchCommit c;
+  c.polys = dev.commit_many(evals, persistent);
+  c.nv = c.polys[0].nv; c.is_base = c.polys[0].is_base;
+  if (evals.size() == 1) { c.root = c.polys[0].tree.root; return c; }
+  std::vector<DBuf> cws;
+  for (const DevCommit& p : c.polys) cws.push_back(p.tree.leaves);
+  c.tree = dev.batch_tree(cws.data(), (int)cws.size(), persistent);
+  c.root = c.tree.root;
+  return c;
+}
+// PCS::simple_batch_open (basefold.rs:777-861): all polynomials of a batch commitment at ONE point. "batch coeffs" challenges t, eq(t) as
+// the random linear combination; simple_batch_commit_phase (commit_phase.rs:363-503) is the single-polynomial commit phase on
+// sum_k eq(t)_k codeword_k / sum_k eq(t)_k bh_evals_k; simple_batch_prover_query_phase (query_phase.rs:104-139, 474-538) opens the row pair
+// (every polynomial's pair at p0) with ONE Merkle path plus one pair per folded oracle.
+// Stream form of ..::SimpleBatched: `commitments_query` has one entry per polynomial, all with index p0; the path rides on entry 0.
+inline BasefoldProof pcs_simple_batch_open(Dev& dev, const DevBatchCommit& c, const std::vector<Ext>& point, Transcript& t) {
+  BasefoldProof proof;
+  const size_t k = c.polys.size();
+  if (c.trivial()) {  // Proof::trivial(polynomials_bh_evals): the transcript is not touched (basefold.rs:788-790)
+    for (const DevCommit& p : c.polys) { FieldVec fv; fv.is_ext = p.evals.ext; fv.w.resize(p.evals.n * (fv.is_ext ? 2 : 1)); dev.download(p.evals, fv.w.data()); proof.trivial_proof.push_back(std::move(fv)); }
+    return proof;
+  }
+  DP_REQUIRE(point.size() == c.nv, DP_ERR_SHAPE, "simple_batch_open: point length != num_vars");
+  unsigned batch_size_log = 0; while ((size_t(1) << batch_size_log) < k) batch_size_log++;
+  std::vector<Ext> tt;
+  for (unsigned i = 0; i < batch_size_log; i++) tt.push_back(t.get_and_append_challenge("batch coeffs"));
+  std::vector<Ext> eq_xt = host_eq_table(tt);
+  size_t mk = dev.mark();
+  const unsigned num_vars = c.nv, num_rounds = num_vars - PCS_BASECODE_LOG;
+  const size_t cw_size = size_t(1) << (num_vars + PCS_RATE_LOG);
+  CommitLoopState st;
+  std::vector<Dev::AxpyJob> jc, je;
+  for (size_t q = 0; q < k; q++) { jc.push_back({c.polys[q].tree.leaves, eq_xt[q], 1}); je.push_back({c.polys[q].bh_evals, eq_xt[q], 1}); }
+  st.running = dev.alloc(cw_size, true); dev.axpy_many(st.running, nullptr, jc.data(), jc.size());
+  st.sum_evals = dev.alloc(size_t(1) << num_vars, true); dev.axpy_many(st.sum_evals, nullptr, je.data(), je.size());
+  std::vector<Ext> rev_point(point.rbegin(), point.rend());
+  st.eq = dev.alloc(size_t(1) << num_vars, true);
+  dev.eq_table(st.eq, rev_point.data(), num_vars, ex_one(), false);
+  st.last.resize(3);
+  dev.bf_round(st.eq, st.sum_evals, nullptr, st.last.data());
+  proof.sumcheck_messages.push_back(st.last);
+  std::vector<DevTree> trees;
+  std::vector<std::vector<Dev::AxpyJob>> merges(num_rounds);
+  commit_rounds(dev, merges, num_rounds, 0, true, st, t, proof.sumcheck_messages, proof.roots, trees, proof.final_message);
+  std::vector<size_t> qidx;
+  for (unsigned q = 0; q < PCS_NUM_QUERIES; q++) qidx.push_back((size_t)(t.get_and_append_challenge("query indices").c0 % cw_size));
+  std::vector<QueryDesc> descs;
+  for (size_t x : qidx) {
+    size_t index = x >> 1;
+    for (auto& tr : trees) { descs.push_back({&tr, (index | 1) - 1}); index >>= 1; }
+    const size_t p0 = (x | 1) - 1;
+    for (size_t q = 0; q < k; q++) descs.push_back({&c.polys[q].tree, p0});
+    if (k > 1) descs.push_back({&c.tree, 2 * p0});  // row hashes: two entries per row; the first digest of that path is hash(row p0 + 1)
+  }
+  std::vector<std::vector<u64>> got;
+  dev.query_gather(descs.data(), descs.size(), got);
+  size_t di = 0;
+  for (size_t x : qidx) {
+    BatchedQuery bq; bq.index = x;
+    for (size_t j = 0; j < trees.size(); j++, di++) bq.oracle_query.push_back(query_from_words(descs[di], got[di]));
+    for (size_t q = 0; q < k; q++, di++) { CodewordQuery cq = query_from_words(descs[di], got[di]); if (k > 1) cq.path.clear(); bq.commitments_query.push_back(std::move(cq)); }
+    if (k > 1) { CodewordQuery rows = query_from_words(descs[di], got[di]); di++; bq.commitments_query[0].path.assign(rows.path.begin() + 1, rows.path.end()); }
+    proof.queries.push_back(std::move(bq));
+  }
+  dev.release(mk);
+  return proof;
+}
+
 // =================================================================== host verifier
 struct VerifierParams { unsigned full_log = 0; };
 
@@ -354,6 +436,8 @@ inline void pcs_verify_trivial(const Commitment& comm, const std::vector<Ext>& p
   DP_REQUIRE(proof.is_trivial() && proof.trivial_proof.size() == 1, DP_ERR_VERIFY, "expected a trivial opening proof");
   const FieldVec& fv = proof.trivial_proof[0];
   DP_REQUIRE(host_merkle_root(fv) == comm.root, DP_ERR_VERIFY, "trivial proof: Merkle root mismatch");
+  // (the commitment's own description of the polynomial must fit the opened table: the reference never looks at it for a trivial opening)
+  DP_REQUIRE((size_t(1) << comm.num_vars) == fv.len() && comm.is_base == !fv.is_ext, DP_ERR_VERIFY, "trivial proof: table does not match the commitment's shape");
   std::vector<Ext> v(fv.len());
   for (size_t i = 0; i < v.size(); i++) v[i] = fv.is_ext ? ex(fv.w[2 * i], fv.w[2 * i + 1]) : ex(fv.w[i], 0);
   DP_REQUIRE(ex_eq(host_mle_eval(v, point), eval), DP_ERR_VERIFY, "trivial proof: wrong evaluation");
@@ -403,8 +487,31 @@ inline std::vector<Ext> final_codeword_of(const VerifierParams& vp, const std::v
 // (:915-974): replay the commit-phase transcript, authenticate every opened pair, fold the codeword pair down the oracles to
 // the final codeword, then the sumcheck chain: eval = h_0(0) + h_0(1), h_i(r_i) = h_{i+1}(0) + h_{i+1}(1), and
 // h_last(r_last) = <final_message, eq(point_head) * eq(point_tail, reversed challenges)>.
-inline void pcs_verify(const VerifierParams& vp, const Commitment& comm, const std::vector<Ext>& point, Ext eval, const BasefoldProof& proof, Transcript& t) {
-  if (proof.is_trivial()) { pcs_verify_trivial(comm, point, eval, proof); return; }
+// pcs_verify_core, `batch` false: PCS::verify of one polynomial (evals = {eval}); true: PCS::simple_batch_verify (basefold.rs:1100-1203,
+// query_phase.rs:292-371, 1441-1530) of the evals.size() polynomials behind `comm`: "batch coeffs" are drawn first, each query carries
+// one pair per polynomial under ONE Merkle path (row pair digest = hash_two_leaves_batch), the fold chain starts from the eq(t)-weighted
+// sums of the pairs, and the first commit-phase message must sum to <eq(t), evals>.
+inline Digest host_row_hash(const std::vector<CodewordQuery>& qs, bool right) {  // hash_or_noop of [v_0, .., v_{k-1}] (util/hash.rs:17-24)
+  std::vector<u64> w;
+  for (const CodewordQuery& q : qs) { const Ext v = right ? q.right : q.left; w.push_back(v.c0); if (q.is_ext) w.push_back(v.c1); }
+  Digest d{};
+  if (w.size() <= 4) { for (size_t i = 0; i < w.size(); i++) d.v[i] = w[i]; return d; }
+  Challenger ch;
+  for (u64 x : w) ch.observe(x);
+  for (int i = 0; i < 4; i++) d.v[i] = ch.sample();
+  return d;
+}
+inline void pcs_verify_core(const VerifierParams& vp, const Commitment& comm, const std::vector<Ext>& point, const std::vector<Ext>& evals, bool batch, const BasefoldProof& proof, Transcript& t) {
+  const size_t np = evals.size();
+  DP_REQUIRE(np >= 1 && (batch || np == 1), DP_ERR_ARG, "verify: evaluations");
+  std::vector<Ext> eq_xt(1, ex_one());
+  if (batch) {
+    std::vector<Ext> tt;
+    for (unsigned i = 0; i < dp_ceil_log2(np); i++) tt.push_back(t.get_and_append_challenge("batch coeffs"));
+    eq_xt = host_eq_table(tt);
+  }
+  Ext eval = ex_zero();
+  for (size_t k = 0; k < np; k++) eval = ex_add(eval, ex_mul(evals[k], eq_xt[k]));
   const unsigned num_vars = (unsigned)point.size();
   DP_REQUIRE(num_vars == comm.num_vars && num_vars > PCS_BASECODE_LOG && num_vars <= vp.full_log, DP_ERR_VERIFY, "verify: bad shapes");
   DP_REQUIRE(proof.sumcheck_proof.empty() && proof.trivial_proof.empty(), DP_ERR_VERIFY, "verify: a single opening carries no batch sumcheck");
@@ -433,14 +540,24 @@ inline void pcs_verify(const VerifierParams& vp, const Commitment& comm, const s
     const BatchedQuery& bq = proof.queries[q];
     const size_t index = qidx[q];
     DP_REQUIRE(bq.index == index, DP_ERR_VERIFY, "verify: query index mismatch");
-    DP_REQUIRE(bq.oracle_query.size() == proof.roots.size() && bq.commitments_query.size() == 1, DP_ERR_VERIFY, "verify: query shape");
+    DP_REQUIRE(bq.oracle_query.size() == proof.roots.size() && bq.commitments_query.size() == np, DP_ERR_VERIFY, "verify: query shape");
     for (size_t k = 0; k < bq.oracle_query.size(); k++) check_merkle_path(bq.oracle_query[k], proof.roots[k]);
-    const CodewordQuery& cq = bq.commitments_query[0];
-    DP_REQUIRE(cq.is_ext == !comm.is_base, DP_ERR_VERIFY, "verify: field type of the opened codeword");
-    check_merkle_path(cq, comm.root);
     size_t right_index = index | 1, left_index = right_index - 1;
-    DP_REQUIRE(cq.index == left_index, DP_ERR_VERIFY, "verify: commitment query index");
-    Ext cur_l = cq.left, cur_r = cq.right;
+    Ext cur_l = ex_zero(), cur_r = ex_zero();
+    for (size_t k = 0; k < np; k++) {
+      const CodewordQuery& cq = bq.commitments_query[k];
+      DP_REQUIRE(cq.is_ext == !comm.is_base, DP_ERR_VERIFY, "verify: field type of the opened codeword");
+      DP_REQUIRE(cq.index == left_index, DP_ERR_VERIFY, "verify: commitment query index");
+      DP_REQUIRE(k == 0 || cq.path.empty(), DP_ERR_VERIFY, "verify: the row pair has one Merkle path");
+      cur_l = ex_add(cur_l, ex_mul(cq.left, eq_xt[k])); cur_r = ex_add(cur_r, ex_mul(cq.right, eq_xt[k]));
+    }
+    if (np == 1) check_merkle_path(bq.commitments_query[0], comm.root);
+    else {  // authenticate_merkle_path_root_batch (merkle_tree.rs:449-490)
+      const CodewordQuery& c0 = bq.commitments_query[0];
+      Digest h = host_compress(host_row_hash(bq.commitments_query, false), host_row_hash(bq.commitments_query, true));
+      if (std::vector<MerkleJob>* sink = merkle_sink()) sink->push_back({h, c0.index >> 1, c0.path.data(), c0.path.size(), comm.root});
+      else { MerkleJob j{h, c0.index >> 1, c0.path.data(), c0.path.size(), comm.root}; DP_REQUIRE(merkle_job_ok(j), DP_ERR_VERIFY, "merkle path does not authenticate against the root"); }
+    }
     for (unsigned i = 0; i < num_rounds; i++) {
       u64 x0, w;
       folding_coeffs(vp.full_log, num_vars + PCS_RATE_LOG - i - 1, left_index >> 1, x0, w);
@@ -465,6 +582,48 @@ inline void pcs_verify(const VerifierParams& vp, const Commitment& comm, const s
   Ext ip = ex_zero();
   for (size_t i = 0; i < peq.size(); i++) ip = ex_add(ip, ex_mul(proof.final_message[i], peq[i]));
   DP_REQUIRE(ex_eq(eval2(proof.sumcheck_messages[num_rounds - 1], fold_ch[num_rounds - 1]), ip), DP_ERR_VERIFY, "verify: final message inner product");
+}
+inline void pcs_verify(const VerifierParams& vp, const Commitment& comm, const std::vector<Ext>& point, Ext eval, const BasefoldProof& proof, Transcript& t) {
+  if (proof.is_trivial()) { pcs_verify_trivial(comm, point, eval, proof); return; }
+  pcs_verify_core(vp, comm, point, {eval}, false, proof, t);
+}
+// root of MerkleTree::from_batch_leaves over small tables (the trivial branch of simple_batch_verify, basefold.rs:1114-1124)
+inline Digest host_batch_merkle_root(const std::vector<FieldVec>& tabs) {
+  if (tabs.size() == 1) return host_merkle_root(tabs[0]);
+  const size_t n = tabs[0].len();
+  DP_REQUIRE(n >= 2 && (n & (n - 1)) == 0, DP_ERR_VERIFY, "trivial proof: bad leaf count");
+  auto row = [&](size_t j) {
+    std::vector<CodewordQuery> qs;
+    for (const FieldVec& f : tabs) { CodewordQuery q; q.is_ext = f.is_ext; q.left = f.is_ext ? ex(f.w[2 * j], f.w[2 * j + 1]) : ex(f.w[j], 0); qs.push_back(q); }
+    return host_row_hash(qs, false);
+  };
+  std::vector<Digest> cur(n / 2);
+  for (size_t i = 0; i < n / 2; i++) cur[i] = host_compress(row(2 * i), row(2 * i + 1));
+  while (cur.size() > 1) {
+    std::vector<Digest> nx(cur.size() / 2);
+    for (size_t i = 0; i < nx.size(); i++) nx[i] = host_compress(cur[2 * i], cur[2 * i + 1]);
+    cur = nx;
+  }
+  return cur[0];
+}
+// PCS::simple_batch_verify. Trivial proofs: the reference only compares the root of the opened tables (basefold.rs:1114-1124); here every
+// table must also have the commitment's shape and evaluate to its claimed value at the point (costs an honest prover nothing).
+inline void pcs_simple_batch_verify(const VerifierParams& vp, const Commitment& comm, const std::vector<Ext>& point, const std::vector<Ext>& evals, const BasefoldProof& proof, Transcript& t) {
+  DP_REQUIRE(!evals.empty(), DP_ERR_ARG, "simple_batch_verify: no evaluations");
+  if (proof.is_trivial()) {
+    DP_REQUIRE(comm.num_vars <= PCS_BASECODE_LOG && point.size() == comm.num_vars, DP_ERR_VERIFY, "trivial proof for a non-trivial commitment");
+    DP_REQUIRE(proof.trivial_proof.size() == evals.size(), DP_ERR_VERIFY, "trivial proof: one table per polynomial expected");
+    for (const FieldVec& fv : proof.trivial_proof) DP_REQUIRE((size_t(1) << comm.num_vars) == fv.len() && comm.is_base == !fv.is_ext, DP_ERR_VERIFY, "trivial proof: table does not match the commitment's shape");
+    DP_REQUIRE(host_batch_merkle_root(proof.trivial_proof) == comm.root, DP_ERR_VERIFY, "trivial proof: Merkle root mismatch");
+    for (size_t k = 0; k < evals.size(); k++) {
+      const FieldVec& fv = proof.trivial_proof[k];
+      std::vector<Ext> v(fv.len());
+      for (size_t i = 0; i < v.size(); i++) v[i] = fv.is_ext ? ex(fv.w[2 * i], fv.w[2 * i + 1]) : ex(fv.w[i], 0);
+      DP_REQUIRE(ex_eq(host_mle_eval(v, point), evals[k]), DP_ERR_VERIFY, "trivial proof: wrong evaluation");
+    }
+    return;
+  }
+  pcs_verify_core(vp, comm, point, evals, true, proof, t);
 }
 
 // PCS::batch_verify (basefold.rs:964-1098) + batch_verifier_query_phase (query_phase.rs:220-288) + check (:1116-1236)
@@ -541,7 +700,7 @@ inline void pcs_batch_verify(const VerifierParams& vp, const std::vector<VerifyC
     for (unsigned i = 0; i < num_rounds; i++) {
       for (size_t k = 0; k < np; k++) if (claims[k].comm.num_vars == num_vars - i) {
         const CodewordQuery& cq = bq.commitments_query[k];
-        DP_REQUIRE((cq.index >> 1) == (left_index >> 1), DP_ERR_VERIFY, "batch_verify: commitment query index");
+        DP_REQUIRE(cq.index == left_index, DP_ERR_VERIFY, "batch_verify: commitment query index");  // provers emit the index of the LEFT element of the pair
         cur_l = ex_add(cur_l, ex_mul(cq.left, coeffs[k]));
         cur_r = ex_add(cur_r, ex_mul(cq.right, coeffs[k]));
       }
@@ -559,7 +718,7 @@ inline void pcs_batch_verify(const VerifierParams& vp, const std::vector<VerifyC
       } else {
         for (size_t k = 0; k < np; k++) if (claims[k].comm.num_vars == num_vars - i - 1) {
           const CodewordQuery& cq = bq.commitments_query[k];
-          DP_REQUIRE((cq.index >> 1) == (next_index >> 1), DP_ERR_VERIFY, "batch_verify: last-round commitment query index");
+          DP_REQUIRE(cq.index == (next_index | 1) - 1, DP_ERR_VERIFY, "batch_verify: last-round commitment query index");
           res = ex_add(res, ex_mul((next_index & 1) ? cq.right : cq.left, coeffs[k]));
         }
         next_val = final_codeword[next_index];

@@ -190,6 +190,26 @@ int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const u
                             const int32_t* is_base, int32_t n, const uint64_t* points_flat, const uint64_t* evals,
                             const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t);
 
+/* PCS::batch_commit (mpcs/src/basefold.rs:356-446): n polynomials of ONE size and ONE field behind one Merkle root. Every polynomial is
+ * encoded as in dp_pcs_commit; leaf j of the common tree is the row [codeword_0[j], .., codeword_{n-1}[j]] (MerkleTree::from_batch_leaves,
+ * util/merkle_tree.rs:68-74, 261-329: pair hash = hash_two_digests(hash(row 2i), hash(row 2i+1)), util/hash.rs:32-41; raw tables when
+ * trivial). One polynomial gives the ordinary commitment. 1 <= n <= 32. The handle keeps references to the dp_bufs. Not called by zkml. */
+typedef struct dp_batch_commit dp_batch_commit;
+int32_t dp_pcs_batch_commit(dp_ctx* ctx, const dp_buf* const* polys, int32_t n, dp_batch_commit** out, uint64_t root[4]);
+int32_t dp_pcs_batch_commit_free(dp_ctx* ctx, dp_batch_commit* c);
+/* PCS::simple_batch_open / PCS::simple_batch_verify (mpcs/src/basefold.rs:777-861, 1100-1203): all polynomials of a batch commitment at
+ * ONE point. log2(next_pow2(n)) "batch coeffs" challenges t, then the commit phase of dp_pcs_open on sum_k eq(t)_k f_k
+ * (basefold/commit_phase.rs:363-503) and 200 queries, each opening the ROW pair (one pair per polynomial, one Merkle path) and one pair
+ * per folded oracle (basefold/query_phase.rs:104-139, 474-538). Proof stream: the Basefold layout with an empty batch sumcheck and n
+ * commitment entries per query, all with the pair's index, the path on entry 0 (..::SimpleBatched). Trivial sizes (<= 7 variables): the
+ * proof is the n tables, the transcript is not touched; the verifier checks their common root AND (stricter than the reference, which
+ * stops at the root, basefold.rs:1114-1124) each table's shape and evaluation. evals: 2 words per polynomial, commitment order.
+ * dp_pcs_simple_batch_verify is host only. */
+int32_t dp_pcs_simple_batch_open(dp_ctx* ctx, const dp_batch_commit* comm, const uint64_t* point, uint32_t num_vars, dp_transcript* t,
+                                 uint64_t** proof_words, size_t* proof_nwords);
+int32_t dp_pcs_simple_batch_verify(size_t max_poly_size, const uint64_t root[4], uint32_t num_vars, int32_t is_base, const uint64_t* point,
+                                   const uint64_t* evals, int32_t n, const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t);
+
 /* ---- model level: Context::generate / Prover::prove / verify (zkml/src/iop/context.rs:109, prover.rs:401,
  * verifier.rs:306). model_blob (int64): input_len, nlayers, then per layer kind (0 Dense, 1 Requant, 2 Relu, 3 Conv,
  * 4 MaxPool, 5 Flatten, 6 MatMul, 7 Add, 8 Embeddings, 9 Positional) followed by

@@ -287,17 +287,10 @@ static inline std::vector<E> parallel_pi(const std::vector<E>& evals, const std:
 //   prover_query_phase + basefold_get_query (query_phase.rs:31-66, 373-417): 200 x "query indices" mod the codeword size; the
 //   commitment pair at (x | 1) - 1, then one pair per oracle tree at ((x >> 1) | 1) - 1, ((x >> 2) | 1) - 1, ...
 //   The proof has no batch sumcheck (sumcheck_proof: None) and one commitment query per index (..::Single).
-static inline BasefoldProof pcs_open(const PcsParams& pp, const Mle& poly, const CommitmentWithWitness& comm, const std::vector<E>& point, Transcript& t) {
-  if (comm.is_trivial()) return pcs_open_trivial(poly, comm);
-  if (point.size() != poly.nv) throw std::runtime_error("open: point/poly mismatch");
-  if (poly.nv > pp.full_message_size_log) throw std::runtime_error("open: PolynomialTooLarge");
-  BasefoldProof proof;
-  const unsigned num_vars = poly.nv, num_rounds = num_vars - BASECODE_MSG_SIZE_LOG;
-  const Mle& cw = comm.codeword_tree.leaves;
-  std::vector<E> running_oracle(cw.len());
-  for (size_t j = 0; j < running_oracle.size(); j++) running_oracle[j] = cw.at(j);
-  std::vector<E> running_evals(comm.bh_evals.len());
-  for (size_t j = 0; j < running_evals.size(); j++) running_evals[j] = comm.bh_evals.at(j);
+// The commit phase shared by open (commit_phase.rs:30-185) and simple_batch_open (commit_phase.rs:363-503): the two differ only in
+// what the first oracle / the summed evaluations are. Returns the trees of the folded oracles 1..num_rounds-1.
+static inline std::vector<MerkleTree> single_commit_phase(const PcsParams& pp, std::vector<E> running_oracle, std::vector<E> running_evals, const std::vector<E>& point,
+                                                          unsigned num_rounds, Transcript& t, BasefoldProof& proof) {
   std::vector<E> eq = build_eq_x_r_vec(point);
   reverse_index_bits_in_place(eq);
   one_level_interp_hc(eq); one_level_interp_hc(running_evals);
@@ -326,22 +319,130 @@ static inline BasefoldProof pcs_open(const PcsParams& pp, const Mle& poly, const
       proof.final_message = running_evals;
     }
   }
+  return trees;
+}
+static inline void oracle_tree_queries(const std::vector<MerkleTree>& trees, size_t x_index, BatchedQuery& bq) {  // query_phase.rs:399-416 / 511-528
+  size_t index = x_index >> 1;
+  for (auto& tree : trees) {
+    size_t p1 = index | 1, p0 = p1 - 1;
+    CodewordQuery cq; cq.is_ext = true; cq.left = tree.leaves.at(p0); cq.right = tree.leaves.at(p1); cq.index = p0; cq.path = tree.path(p0);
+    bq.oracle_query.push_back(std::move(cq));
+    index >>= 1;
+  }
+}
+static inline BasefoldProof pcs_open(const PcsParams& pp, const Mle& poly, const CommitmentWithWitness& comm, const std::vector<E>& point, Transcript& t) {
+  if (comm.is_trivial()) return pcs_open_trivial(poly, comm);
+  if (point.size() != poly.nv) throw std::runtime_error("open: point/poly mismatch");
+  if (poly.nv > pp.full_message_size_log) throw std::runtime_error("open: PolynomialTooLarge");
+  BasefoldProof proof;
+  const unsigned num_vars = poly.nv, num_rounds = num_vars - BASECODE_MSG_SIZE_LOG;
+  const Mle& cw = comm.codeword_tree.leaves;
+  std::vector<E> running_oracle(cw.len());
+  for (size_t j = 0; j < running_oracle.size(); j++) running_oracle[j] = cw.at(j);
+  std::vector<E> running_evals(comm.bh_evals.len());
+  for (size_t j = 0; j < running_evals.size(); j++) running_evals[j] = comm.bh_evals.at(j);
+  std::vector<MerkleTree> trees = single_commit_phase(pp, std::move(running_oracle), std::move(running_evals), point, num_rounds, t, proof);
   const size_t codeword_size = comm.codeword_size();
   std::vector<size_t> qidx;
   for (unsigned q = 0; q < NUM_QUERIES; q++) qidx.push_back((size_t)(t.get_and_append_challenge("query indices").c0 % codeword_size));
   for (size_t x_index : qidx) {
     BatchedQuery bq; bq.index = x_index;
-    size_t index = x_index;
-    { size_t p1 = index | 1, p0 = p1 - 1;
+    { size_t p1 = x_index | 1, p0 = p1 - 1;
       CodewordQuery cq; cq.is_ext = cw.is_ext; cq.left = cw.at(p0); cq.right = cw.at(p1); cq.index = p0; cq.path = comm.codeword_tree.path(p0);
       bq.commitments_query.push_back(std::move(cq)); }
-    index >>= 1;
-    for (auto& tree : trees) {
-      size_t p1 = index | 1, p0 = p1 - 1;
-      CodewordQuery cq; cq.is_ext = true; cq.left = tree.leaves.at(p0); cq.right = tree.leaves.at(p1); cq.index = p0; cq.path = tree.path(p0);
-      bq.oracle_query.push_back(std::move(cq));
-      index >>= 1;
+    oracle_tree_queries(trees, x_index, bq);
+    proof.queries.push_back(std::move(bq));
+  }
+  return proof;
+}
+
+// ---------------------------------------------------------------- batch_commit / simple_batch_open (several polynomials of one size in ONE tree)
+// MerkleTree::from_batch_leaves (merkle_tree.rs:68-74, 261-329): pair i of the first layer is
+//   hash_two_leaves_batch(a, b) = hash_two_digests(hash(a), hash(b)),  a = [v_k[2i]]_k, b = [v_k[2i+1]]_k  (util/hash.rs:32-41),
+// hash = hash_or_noop over the base words of the row (<= 4 words: the words themselves, zero padded; poseidon_hash.rs:22-28);
+// with ONE polynomial the ordinary tree (hash_two_leaves). Upper layers as always.
+struct BatchCommitmentWithWitness {
+  std::vector<std::vector<Digest>> inner;
+  std::vector<Mle> codewords;  // bit-reversed RS codewords (the raw evaluations when trivial)
+  std::vector<Mle> bh_evals;
+  unsigned num_vars = 0;
+  bool is_base = true;
+  const Digest& root() const { return inner.back()[0]; }
+  bool is_trivial() const { return num_vars <= BASECODE_MSG_SIZE_LOG; }
+  size_t codeword_size() const { return codewords[0].len(); }
+  std::vector<Digest> path(size_t leaf_index) const {
+    std::vector<Digest> p;
+    for (size_t l = 0; l + 1 < inner.size(); l++) p.push_back(inner[l][(leaf_index >> (l + 1)) ^ 1]);
+    return p;
+  }
+};
+static inline Digest batch_row_hash(const std::vector<Mle>& v, size_t j) {
+  std::vector<u64> w;
+  for (const Mle& m : v) { if (m.is_ext) { w.push_back(m.e[j].c0); w.push_back(m.e[j].c1); } else w.push_back(m.b[j]); }
+  return hash_or_noop(w.data(), w.size());
+}
+static inline std::vector<std::vector<Digest>> merkelize_batch(const std::vector<Mle>& v) {
+  if (v.size() == 1) return merkelize(v[0]);
+  unsigned log_v = log2_strict(v[0].len());
+  std::vector<std::vector<Digest>> tree;
+  std::vector<Digest> h(v[0].len() >> 1);
+  for (size_t i = 0; i < h.size(); i++) h[i] = compress(batch_row_hash(v, 2 * i), batch_row_hash(v, 2 * i + 1));
+  tree.push_back(std::move(h));
+  for (unsigned i = 1; i < log_v; i++) {
+    const auto& prev = tree[i - 1];
+    std::vector<Digest> nx(prev.size() / 2);
+    for (size_t j = 0; j < nx.size(); j++) nx[j] = compress(prev[2 * j], prev[2 * j + 1]);
+    tree.push_back(std::move(nx));
+  }
+  return tree;
+}
+// Basefold::batch_commit (basefold.rs:356-446)
+static inline BatchCommitmentWithWitness pcs_batch_commit(const PcsParams& pp, const std::vector<Mle>& polys) {
+  if (polys.empty()) throw std::runtime_error("cannot batch commit to zero polynomials");
+  BatchCommitmentWithWitness c;
+  c.num_vars = polys[0].nv; c.is_base = !polys[0].is_ext;
+  for (const Mle& p : polys) {
+    if (p.nv != c.num_vars) throw std::runtime_error("cannot batch commit to polynomials with different number of variables");
+    if (p.is_ext != polys[0].is_ext) throw std::runtime_error("batch commit: all polynomials must be in the same field");
+    CommitmentWithWitness one = pcs_commit(pp, p);  // get_poly_bh_evals_and_codeword; its own tree is not used
+    c.codewords.push_back(std::move(one.codeword_tree.leaves));
+    c.bh_evals.push_back(std::move(one.bh_evals));
+  }
+  if (c.codewords[0].len() < 2) throw std::runtime_error("batch commit: a tree needs at least one pair of leaves");
+  c.inner = merkelize_batch(c.codewords);
+  return c;
+}
+// Basefold::simple_batch_open (basefold.rs:777-861) + simple_batch_commit_phase + simple_batch_prover_query_phase.
+// Stream form of ..::SimpleBatched: per query `commitments_query` holds one entry per polynomial (its pair of the row pair at p0),
+// all with index p0; the Merkle path of the row pair travels with entry 0, the other entries have an empty path.
+static inline BasefoldProof pcs_simple_batch_open(const PcsParams& pp, const BatchCommitmentWithWitness& comm, const std::vector<E>& point, Transcript& t) {
+  BasefoldProof proof;
+  if (comm.is_trivial()) { proof.trivial = true; proof.trivial_proof = comm.bh_evals; return proof; }  // the transcript is not touched
+  if (point.size() != comm.num_vars) throw std::runtime_error("simple_batch_open: point/poly mismatch");
+  const size_t k = comm.codewords.size();
+  unsigned batch_size_log = 0; while ((size_t(1) << batch_size_log) < k) batch_size_log++;
+  std::vector<E> tt;
+  for (unsigned i = 0; i < batch_size_log; i++) tt.push_back(t.get_and_append_challenge("batch coeffs"));
+  std::vector<E> eq_xt = build_eq_x_r_vec(tt);
+  eq_xt.resize(k);
+  const unsigned num_rounds = comm.num_vars - BASECODE_MSG_SIZE_LOG;
+  std::vector<E> running_oracle(comm.codeword_size(), e_zero()), running_evals(size_t(1) << comm.num_vars, e_zero());
+  for (size_t q = 0; q < k; q++) {
+    for (size_t j = 0; j < running_oracle.size(); j++) running_oracle[j] = eadd(running_oracle[j], emul(comm.codewords[q].at(j), eq_xt[q]));
+    for (size_t j = 0; j < running_evals.size(); j++) running_evals[j] = eadd(running_evals[j], emul(comm.bh_evals[q].at(j), eq_xt[q]));
+  }
+  std::vector<MerkleTree> trees = single_commit_phase(pp, std::move(running_oracle), std::move(running_evals), point, num_rounds, t, proof);
+  std::vector<size_t> qidx;
+  for (unsigned q = 0; q < NUM_QUERIES; q++) qidx.push_back((size_t)(t.get_and_append_challenge("query indices").c0 % comm.codeword_size()));
+  for (size_t x_index : qidx) {
+    BatchedQuery bq; bq.index = x_index;
+    const size_t p1 = x_index | 1, p0 = p1 - 1;
+    for (size_t q = 0; q < k; q++) {
+      CodewordQuery cq; cq.is_ext = comm.codewords[q].is_ext; cq.left = comm.codewords[q].at(p0); cq.right = comm.codewords[q].at(p1); cq.index = p0;
+      if (q == 0) cq.path = comm.path(p0);
+      bq.commitments_query.push_back(std::move(cq));
     }
+    oracle_tree_queries(trees, x_index, bq);
     proof.queries.push_back(std::move(bq));
   }
   return proof;

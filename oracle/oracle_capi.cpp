@@ -174,6 +174,21 @@ int orc_pcs_batch_open(size_t max_poly_size, const uint64_t* const* polys, const
     Writer w; w.basefold(p); *proof_words = copy_out(w.w); *proof_nwords = w.w.size();
   });
 }
+// batch_commit + simple_batch_open of k polynomials of `n` elements each (basefold.rs:356-446, 777-861): root of the common tree and the proof stream
+int orc_pcs_simple_batch_open(size_t max_poly_size, const uint64_t* const* polys, size_t n, int32_t k, int is_ext, const uint64_t* point, orc_transcript* t, uint64_t root[4],
+                              uint64_t** proof_words, size_t* proof_nwords) {
+  return guard([&] {
+    PcsParams pp = pcs_setup(max_poly_size);
+    std::vector<Mle> ps;
+    for (int i = 0; i < k; i++) ps.push_back(rd_mle(polys[i], n, is_ext));
+    BatchCommitmentWithWitness c = pcs_batch_commit(pp, ps);
+    for (int i = 0; i < 4; i++) root[i] = c.root()[i];
+    if (!proof_words) return;
+    Transcript scratch = default_transcript();
+    BasefoldProof p = pcs_simple_batch_open(pp, c, rd_pt(point, c.num_vars), t ? t->t : scratch);
+    Writer w; w.basefold(p); *proof_words = copy_out(w.w); *proof_nwords = w.w.size();
+  });
+}
 int orc_model_setup(const int64_t* blob, size_t nwords, orc_model** out) { return guard([&] { Model m = parse_model(blob, nwords); orc_model* om = new orc_model{context_generate(m)}; *out = om; }); }
 void orc_model_free(orc_model* m) { delete m; }
 // the sponge traffic of every transcript created on this thread between begin and take: pairs (0, absorbed) / (1, squeezed)

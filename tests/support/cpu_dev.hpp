@@ -236,6 +236,20 @@ class CpuDev : public Dev {
     free_persistent(c.tree.nodes); free_persistent(c.evals);
   }
   DevTree merkle_ext(const DBuf& leaves) override { return build_tree(leaves, false); }
+  // Dev::batch_tree: row hashes by the host sponge word by word, then the ordinary tree over them
+  DevTree batch_tree(const DBuf* cws, int k, bool persistent) override {
+    const size_t n = cws[0].n;
+    DBuf rows = persistent ? alloc_persistent(2 * n, true) : alloc(2 * n, true);
+    for (size_t j = 0; j < n; j++) {
+      std::vector<u64> w;
+      for (int q = 0; q < k; q++) { if (cws[q].ext) { w.push_back(X(cws[q])[j].c0); w.push_back(X(cws[q])[j].c1); } else w.push_back(B(cws[q])[j]); }
+      u64 d[4] = {0, 0, 0, 0};
+      if (w.size() <= 4) for (size_t i = 0; i < w.size(); i++) d[i] = w[i];
+      else { Challenger ch; for (u64 x : w) ch.observe(x); for (int i = 0; i < 4; i++) d[i] = ch.sample(); }
+      X(rows)[2 * j] = ex(d[0], d[1]); X(rows)[2 * j + 1] = ex(d[2], d[3]);
+    }
+    return build_tree(rows, persistent);
+  }
   void classic_round(DBuf* fs, DBuf* eqs, int np, const Ext* r, Ext* out) override {
     for (int i = 0; i < np; i++) {
       if (r && fs[i].n > 1) { fs[i] = fold(fs[i], *r); eqs[i] = fold(eqs[i], *r); }

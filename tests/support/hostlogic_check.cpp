@@ -231,7 +231,67 @@ static int open_mode(uint64_t seed, unsigned nv, bool ext) {
 #endif
   return same && accepted == 1 && rejected == 7 ? 0 : 2;
 }
+// `hostlogic_check batchopen <seed> <nv> <ext> <k>`: batch_commit + simple_batch_open of k polynomials behind one root
+// (mpcs/src/basefold.rs:356-446, 777-861; the reference's run_simple_batch_commit_open_verify, mpcs/src/lib.rs) — the product over the
+// double vs the oracle: root, proof stream, transcript; then pcs_simple_batch_verify accepts and rejects tampered inputs.
+static int batchopen_mode(uint64_t seed, unsigned nv, bool ext, int k) {
+  rs = seed;
+  const unsigned L = nv + 1;
+  std::vector<std::vector<uint64_t>> w(k);
+  std::vector<orc::Mle> oms;
+  for (int q = 0; q < k; q++) {
+    w[q].resize((size_t(1) << nv) * (ext ? 2 : 1)); for (auto& x : w[q]) x = rnd() % dp::GL_P;
+    if (ext) { std::vector<orc::E> e(w[q].size() / 2); for (size_t j = 0; j < e.size(); j++) e[j] = orc::E{w[q][2 * j], w[q][2 * j + 1]}; oms.push_back(orc::Mle::from_ext(e)); } else oms.push_back(orc::Mle::from_base(w[q]));
+  }
+  std::vector<orc::E> opoint(nv); std::vector<dp::Ext> ppoint(nv);
+  for (unsigned i = 0; i < nv; i++) { uint64_t a = rnd() % dp::GL_P, b = rnd() % dp::GL_P; opoint[i] = orc::E{a, b}; ppoint[i] = dp::ex(a, b); }
+  orc::PcsParams pp = orc::pcs_setup(size_t(1) << L);
+  orc::BatchCommitmentWithWitness oc = orc::pcs_batch_commit(pp, oms);
+  orc::Transcript ot = orc::default_transcript();
+  orc::BasefoldProof op = orc::pcs_simple_batch_open(pp, oc, opoint, ot);
+  orc::Writer ow; ow.basefold(op);
+  std::vector<dp::Ext> evals;
+  for (int q = 0; q < k; q++) { orc::E e = oms[q].evaluate(opoint); evals.push_back(dp::ex(e.c0, e.c1)); }
+  orc::E och = ot.get_and_append_challenge("after");
+  TestDev dev; dev.pcs_init(L);
+#ifdef DP_EMUL_DEV
+  dp::emul_init_constants();
+#endif
+  std::vector<dp::DBuf> bufs;
+  for (int q = 0; q < k; q++) { dp::DBuf b = dev.alloc_persistent(size_t(1) << nv, ext); dev.upload(b, w[q].data()); bufs.push_back(b); }
+  dp::DevBatchCommit c = dp::pcs_batch_commit(dev, bufs, true);
+  bool root_same = true; for (int i = 0; i < 4; i++) root_same = root_same && c.root.v[i] == oc.root()[i];
+  dp::Transcript pt = dp::default_transcript();
+  dp::BasefoldProof pr = dp::pcs_simple_batch_open(dev, c, ppoint, pt);
+  dp::Writer pw; pw.basefold(pr);
+  dp::Ext pch = pt.get_and_append_challenge("after");
+  bool same = root_same && pw.w == ow.w && pch.c0 == och.c0 && pch.c1 == och.c1;
+  dp::Commitment pc; pc.root = c.root; pc.num_vars = nv; pc.is_base = !ext;
+  int accepted = 0, rejected = 0;
+  auto run = [&](const dp::Commitment& cm, const std::vector<dp::Ext>& ev, const std::vector<uint64_t>& words, unsigned full_log) {
+    try { dp::Reader r(words.data(), words.size()); dp::BasefoldProof q = r.basefold(); if (r.pos != words.size()) return 0; dp::Transcript vt = dp::default_transcript(); dp::VerifierParams v2; v2.full_log = full_log;
+          dp::pcs_simple_batch_verify(v2, cm, ppoint, ev, q, vt);
+          dp::Ext vch = vt.get_and_append_challenge("after"); return vch.c0 == och.c0 && vch.c1 == och.c1 ? 1 : 2; }
+    catch (const dp::DpError&) { return 0; }
+  };
+  accepted += run(pc, evals, ow.w, L) == 1;
+  { auto e2 = evals; e2[k - 1] = dp::ex_add(e2[k - 1], dp::ex_one()); rejected += run(pc, e2, ow.w, L) == 0; }        // one wrong evaluation
+  if (k > 1) { auto e2 = evals; std::swap(e2[0], e2[1]); rejected += (evals[0].c0 == evals[1].c0 && evals[0].c1 == evals[1].c1) || run(pc, e2, ow.w, L) == 0; } else rejected++;  // evaluations in the wrong order
+  { dp::Commitment bad = pc; bad.root.v[2] ^= 1; rejected += run(bad, evals, ow.w, L) == 0; }                          // foreign root
+  { dp::Commitment bad = pc; bad.is_base = !bad.is_base; rejected += run(bad, evals, ow.w, L) == 0; }                  // wrong field in the commitment
+  if (nv > 7) rejected += run(pc, evals, ow.w, L + 1) == 0; else rejected++;                                         // other parameters: other coset (trivial proofs do not depend on them)
+  size_t flips = 0, caught = 0;
+  for (size_t at = 1; at < ow.w.size(); at += std::max<size_t>(1, ow.w.size() / 97)) { std::vector<uint64_t> t2 = ow.w; t2[at] ^= 1; flips++; caught += run(pc, evals, t2, L) == 0; }
+  printf("simple batch open nv=%u %s k=%d: root+stream+transcript %s the oracle (%zu words, %zu queries, %zu tables); verifier accepted %d of 1, rejected %d of 5, caught %zu of %zu single-word flips\n",
+         nv, ext ? "ext" : "base", k, same ? "identical to" : "DIFFER from", pw.w.size(), pr.queries.size(), pr.trivial_proof.size(), accepted, rejected, caught, flips);
+  if (!same) { size_t d = 0; while (d < pw.w.size() && d < ow.w.size() && pw.w[d] == ow.w[d]) d++; printf("  root same %d, sizes %zu / %zu, first differing word %zu, transcript same %d\n", (int)root_same, pw.w.size(), ow.w.size(), d, (int)(pch.c0 == och.c0 && pch.c1 == och.c1)); }
+#ifdef DP_EMUL_DEV
+  printf("emulated k_batch_row_hash: %zu rows hashed\n", dev.batch_rows_hashed);
+#endif
+  return same && accepted == 1 && rejected == 5 && caught == flips ? 0 : 2;
+}
 int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "batchopen") return batchopen_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 9, argc > 4 && atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 3);
   if (argc > 1 && std::string(argv[1]) == "open") return open_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 9, argc > 4 && atoi(argv[4]));
   if (argc > 1 && std::string(argv[1]) == "sharded") return sharded_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 4);
   if (argc > 1 && std::string(argv[1]) == "sumcheck") return sumcheck_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 6);

@@ -57,6 +57,24 @@ struct EmulDev : CpuDev {
     for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: the kernel wrote past its message\n"); exit(3); }
     return flag;
   }
+  // Dev::batch_tree with the row hashes from the device source of k_batch_row_hash (blocks emulated one after the other, grid-stride loop
+  // with fewer lanes than rows); the tree over them is the double's
+  size_t batch_rows_hashed = 0;
+  DevTree batch_tree(const DBuf* cws, int k, bool persistent) override {
+    const size_t n = cws[0].n;
+    DBuf rows = persistent ? alloc_persistent(2 * n, true) : alloc(2 * n, true);
+    BatchRowPtrs a{};
+    for (int q = 0; q < k; q++) a.cw[q] = (const u64*)cws[q].p;
+    const unsigned nblk = n >= 256 ? 3 : 1, th = 64;  // 3 x 64 lanes: every lane takes several rows
+    blockDim.x.v = th; gridDim.x.v = nblk;
+    for (unsigned b = 0; b < nblk; b++) {
+      blockIdx.x.v = b;
+      if (cws[0].ext) simt::launch(th, [&] { k_batch_row_hash<true>(a, k, (u64*)rows.p, n); }); else simt::launch(th, [&] { k_batch_row_hash<false>(a, k, (u64*)rows.p, n); });
+    }
+    blockIdx.x.v = 0; gridDim.x.v = 1;
+    batch_rows_hashed += n;
+    return build_tree(rows, persistent);
+  }
   bool commit = true;  // serve Dev::commit_tail with the emulated k_commit_tail
   size_t commit_taken = 0, commit_max_n = 512, commit_rounds_run = 0, commit_merged = 0;
   std::vector<u64> tw_;  // tw[i] = w_{2^(L+1)}^i, i < 2^L, L = the RS parameter size of this context (what HipDev::pcs_init builds on the device)

@@ -194,6 +194,19 @@ class Oracle:
                                              ev.ctypes.data_as(u64p), transcript.h, C.byref(pw), C.byref(pn)))
         return self._take(pw, pn.value)
 
+    def pcs_simple_batch_open(self, max_poly_size, polys, is_ext, point=None, transcript=None):
+        """batch_commit + simple_batch_open of equally sized polynomials: (root, proof stream); point None: the root only"""
+        keep = [np.ascontiguousarray(p, dtype=np.uint64) for p in polys]
+        pp = (u64p * len(keep))(*[k.ctypes.data_as(u64p) for k in keep])
+        n = keep[0].size // 2 if is_ext else keep[0].size
+        root = (C.c_uint64 * 4)()
+        pw, pn = u64p(), C.c_size_t()
+        pt = _pt(point) if point is not None else None
+        self._ok(self.lib.orc_pcs_simple_batch_open(C.c_size_t(max_poly_size), pp, C.c_size_t(n), C.c_int32(len(keep)), C.c_int(1 if is_ext else 0),
+                                                    pt.ctypes.data_as(u64p) if pt is not None else None, transcript.h if transcript is not None else None, root,
+                                                    C.byref(pw) if pt is not None else None, C.byref(pn) if pt is not None else None))
+        return [int(x) for x in root], (self._take(pw, pn.value) if pt is not None else None)
+
     def model_setup(self, blob):
         b = np.ascontiguousarray(blob, dtype=np.int64)
         h = C.c_void_p()

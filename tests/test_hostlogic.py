@@ -169,3 +169,15 @@ def test_matmul_model_proof_stream_identical_to_oracle_and_accepted(hostlogic_bi
 def test_matmul_model_tampered_proof_rejected(hostlogic_bin, where):
     r = run(hostlogic_bin, "seq", 3, where)
     assert "verify(oracle,tampered): REJECT" in r.stdout, r.stdout + r.stderr
+
+
+def test_batch_commit_and_simple_batch_open_over_the_double(hostlogic_bin):
+    """PCS::batch_commit + simple_batch_open (mpcs/src/basefold.rs:356-446, 777-861): the product's host code over the CPU double —
+    encode every polynomial, the common tree as the ordinary tree over the row hashes (Dev::batch_tree), the commit phase on the
+    eq(t)-weighted sums, the row-pair queries with one path — gives the oracle's root, stream and transcript state for base and extension
+    polynomials, batches of 1..9, trivial sizes; pcs_simple_batch_verify accepts, rejects wrong evaluations / order / root / field /
+    parameters and every one of ~100 single-word flips spread over the stream"""
+    for args in ((1, 9, 0, 3), (2, 9, 1, 3), (3, 10, 0, 5), (4, 9, 1, 2), (5, 8, 0, 1), (6, 8, 0, 4), (7, 5, 0, 4), (8, 5, 1, 3), (9, 3, 0, 7), (10, 1, 0, 2), (11, 11, 0, 9), (12, 9, 1, 1)):
+        r = subprocess.run([hostlogic_bin, "batchopen", *map(str, args)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "identical to the oracle" in r.stdout and "accepted 1 of 1, rejected 5 of 5" in r.stdout, r.stdout

@@ -82,3 +82,14 @@ def test_fused_kernels_with_the_sponge_on_the_host():
         ran = int(r.stdout.split("host sponge service: ")[1].split()[0])
         served = int(r.stdout.split("sponge on the host, ")[1].split()[0])
         assert ran >= 10 and served > 10 * ran, r.stdout
+
+
+def test_batch_tree_row_hashes_from_the_emulated_kernel():
+    """dp_pcs_batch_commit's only own kernel, k_batch_row_hash (hash_or_noop of every row of the batch tree: pass-through up to four words,
+    the overwrite-mode sponge above), from the device source on the emulator — three blocks of 64 lanes, grid-stride — inside the product's
+    batch_commit + simple_batch_open: root, stream and transcript equal the oracle's; base / extension, 2..9 polynomials, trivial sizes"""
+    for args in ((1, 9, 0, 3), (2, 9, 1, 3), (3, 10, 0, 5), (4, 9, 1, 2), (6, 8, 0, 4), (7, 5, 0, 4), (8, 5, 1, 3), (9, 3, 0, 7), (11, 10, 0, 9), (13, 8, 1, 5)):
+        r = _model(("batchopen",) + args, {})
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "identical to the oracle" in r.stdout and "accepted 1 of 1, rejected 5 of 5" in r.stdout, r.stdout
+        assert f"emulated k_batch_row_hash: {2 << args[1] if args[1] > 7 else 1 << args[1]} rows hashed" in r.stdout, r.stdout

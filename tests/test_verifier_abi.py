@@ -206,6 +206,44 @@ def test_basefold_single_verify_port_of_reference_round_trip(oracle, nv, ext):
         rejected(is_base=ext)
 
 
+@pytest.mark.parametrize("nv,ext,k", [(4, False, 4), (6, True, 4), (9, False, 1), (9, False, 4), (9, True, 4), (10, False, 7), (8, True, 3)])
+def test_basefold_simple_batch_verify_port_of_reference_round_trip(oracle, nv, ext, k):
+    """mpcs batch_commit -> simple_batch_open -> simple_batch_verify (mpcs/src/basefold.rs:1254-1297 simple_batch_commit_open_verify_goldilocks:
+    base and extension, batch sizes 1 and 4, the trivial size; plus a batch whose rows need the sponge): the oracle commits and opens,
+    dp_pcs_simple_batch_verify checks — same transcript state afterwards — and rejects tampered proofs, evaluations, roots, points"""
+    import deep_prove_amd as dpa
+    rng = np.random.default_rng(5200 + 16 * nv + k)
+    maxsize = 1 << 12
+    polys = [rng.integers(0, P, size=(2 if ext else 1) << nv, dtype=np.uint64) for _ in range(k)]
+    point = [_rand_ext(rng) for _ in range(nv)]
+    evals = [oracle.mle_eval(w, ext, point) for w in polys]
+    ot = oracle.transcript(b"test")
+    root, proof = oracle.pcs_simple_batch_open(maxsize, polys, ext, point, ot)
+    if k == 1:
+        assert root == oracle.pcs_commit_root(maxsize, polys[0], ext)  # one polynomial: the ordinary tree (merkle_tree.rs:273-285)
+    t = dpa.Transcript(b"test")
+    dpa.Basefold.simple_batch_verify(maxsize, root, nv, not ext, point, evals, proof, t)
+    assert t.read_challenge() == ot.read_challenge()
+    def rejected(**kw):
+        a = dict(max_poly_size=maxsize, root=root, num_vars=nv, is_base=not ext, point=point, evals=evals, proof_words=proof, transcript=dpa.Transcript(b"test"))
+        a.update(kw)
+        with pytest.raises(dpa.DeepProveError):
+            dpa.Basefold.simple_batch_verify(**a)
+    rejected(evals=evals[:-1] + [((evals[-1][0] + 1) % P, evals[-1][1])])
+    if k > 1:
+        rejected(evals=evals[1:] + evals[:1])
+        rejected(evals=evals[:-1])  # a polynomial less than committed
+    rejected(root=[root[0], root[1] ^ 1, root[2], root[3]])
+    rejected(point=[((point[0][0] + 1) % P, point[0][1])] + point[1:])
+    rejected(is_base=ext)
+    rejected(proof_words=proof[:-2])
+    for at in (len(proof) - 5, len(proof) // 2, 4):
+        bad = proof.copy(); bad[at] ^= np.uint64(1)
+        rejected(proof_words=bad)
+    if nv > 7:
+        rejected(max_poly_size=maxsize * 2)
+
+
 def test_batch_verifier_host_only_accepts_and_rejects_per_proof():
     """dp_verify_batch without a device (ctx NULL): protocol checks on host threads with the Merkle paths deferred and then
     authenticated on the same threads — a verdict per proof: the golden proofs are accepted; a flipped word inside a layer
