@@ -70,6 +70,8 @@ SIGNATURES = {
     "dp_pcs_batch_open": (C.c_int32, [vp, C.POINTER(vp), C.c_int32, u64p, u64p, vp, C.POINTER(u64p),
                                       C.POINTER(C.c_size_t)]),
     "dp_pcs_batch_verify": (C.c_int32, [C.c_size_t, u64p, u32p, i32p, C.c_int32, u64p, u64p, u64p, C.c_size_t, vp]),
+    "dp_pcs_batch_open_evals": (C.c_int32, [vp, C.POINTER(vp), C.c_int32, u64p, u32p, C.c_int32, u32p, u32p, u64p, C.c_int32, vp, C.POINTER(u64p), C.POINTER(C.c_size_t)]),
+    "dp_pcs_batch_verify_evals": (C.c_int32, [C.c_size_t, u64p, u32p, i32p, C.c_int32, u64p, u32p, C.c_int32, u32p, u32p, u64p, C.c_int32, u64p, C.c_size_t, vp]),
     "dp_pcs_batch_commit": (C.c_int32, [vp, C.POINTER(vp), C.c_int32, C.POINTER(vp), u64p]),
     "dp_pcs_batch_commit_free": (C.c_int32, [vp, vp]),
     "dp_pcs_simple_batch_open": (C.c_int32, [vp, vp, u64p, C.c_uint32, vp, C.POINTER(u64p), C.POINTER(C.c_size_t)]),

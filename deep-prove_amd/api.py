@@ -306,6 +306,16 @@ class Commitment:
             self.h = None
 
 
+def _eval_lists(points, evals):
+    """flat arrays of an Evaluation list: points, their lengths, (poly, point) indices, values"""
+    pf = np.concatenate([_point(p) for p in points]).astype(np.uint64)
+    pl = np.array([len(p) for p in points], dtype=np.uint32)
+    ep = np.array([e[0] for e in evals], dtype=np.uint32)
+    eq = np.array([e[1] for e in evals], dtype=np.uint32)
+    ev = _point([e[2] for e in evals])
+    return pf, pl, ep, eq, ev
+
+
 class BatchCommitment:
     """BasefoldCommitmentWithWitness of several polynomials behind one root (mpcs/src/basefold.rs:356-446)"""
 
@@ -351,6 +361,27 @@ class Basefold:
         pw = np.ascontiguousarray(proof_words, dtype=np.uint64)
         check(_lib.load().dp_pcs_verify(max_poly_size, r.ctypes.data_as(u64p), num_vars, 1 if is_base else 0, pt.ctypes.data_as(u64p),
                                         ev.ctypes.data_as(u64p), pw.ctypes.data_as(u64p), pw.size, transcript.h if transcript is not None else None))
+
+    def batch_open_evals(self, comms, points, evals, transcript):
+        """PCS::batch_open over a general Evaluation list (mpcs/src/basefold.rs:546-770): evals = [(poly index, point index, value)]"""
+        hs = (vp * len(comms))(*[c.h for c in comms])
+        pf, pl, ep, eq, ev = _eval_lists(points, evals)
+        pw, pn = u64p(), C.c_size_t()
+        check(_lib.load().dp_pcs_batch_open_evals(self.dev.h, hs, len(comms), pf.ctypes.data_as(u64p), pl.ctypes.data_as(u32p), len(points), ep.ctypes.data_as(u32p),
+                                                  eq.ctypes.data_as(u32p), ev.ctypes.data_as(u64p), len(evals), transcript.h, C.byref(pw), C.byref(pn)))
+        return _take(pw, pn.value)
+
+    @staticmethod
+    def batch_verify_evals(max_poly_size, roots, num_vars, is_base, points, evals, proof_words, transcript):
+        """PCS::batch_verify over a general Evaluation list (mpcs/src/basefold.rs:964-1098). Host only."""
+        r = np.array([w for root in roots for w in root], dtype=np.uint64)
+        nv = np.array(num_vars, dtype=np.uint32)
+        ib = np.array([1 if b else 0 for b in is_base], dtype=np.int32)
+        pf, pl, ep, eq, ev = _eval_lists(points, evals)
+        pw = np.ascontiguousarray(proof_words, dtype=np.uint64)
+        check(_lib.load().dp_pcs_batch_verify_evals(max_poly_size, r.ctypes.data_as(u64p), nv.ctypes.data_as(u32p), ib.ctypes.data_as(i32p), len(roots), pf.ctypes.data_as(u64p),
+                                                    pl.ctypes.data_as(u32p), len(points), ep.ctypes.data_as(u32p), eq.ctypes.data_as(u32p), ev.ctypes.data_as(u64p), len(evals),
+                                                    pw.ctypes.data_as(u64p), pw.size, transcript.h))
 
     def batch_commit(self, polys):
         """PCS::batch_commit (mpcs/src/basefold.rs:356-446): 1..32 polynomials of one size and one field behind ONE Merkle root"""

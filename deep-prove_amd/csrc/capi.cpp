@@ -530,6 +530,53 @@ int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const u
   });
 }
 
+/* PCS::batch_open / batch_verify over a general Evaluation list (mpcs/src/basefold.rs:546-770, 964-1098) */
+static void read_eval_lists(const uint64_t* points_flat, const uint32_t* point_num_vars, int32_t n_points, const uint32_t* eval_poly, const uint32_t* eval_point, const uint64_t* eval_values,
+                            int32_t n_evals, int32_t n_polys, std::vector<std::vector<Ext>>& pts, std::vector<size_t>& ep, std::vector<size_t>& eq, std::vector<Ext>& ev) {
+  size_t off = 0;
+  for (int i = 0; i < n_points; i++) { DP_REQUIRE(point_num_vars[i] <= 64, DP_ERR_ARG, "point too long"); pts.push_back(read_point(points_flat + off, point_num_vars[i])); off += 2 * (size_t)point_num_vars[i]; }
+  for (int i = 0; i < n_evals; i++) {
+    DP_REQUIRE(eval_poly[i] < (uint32_t)n_polys && eval_point[i] < (uint32_t)n_points, DP_ERR_ARG, "evaluation refers to a missing polynomial or point");
+    ep.push_back(eval_poly[i]); eq.push_back(eval_point[i]); ev.push_back(read_point(eval_values + 2 * (size_t)i, 1)[0]);
+  }
+}
+int32_t dp_pcs_batch_open_evals(dp_ctx* ctx, const dp_commit* const* comms, int32_t n_polys, const uint64_t* points_flat, const uint32_t* point_num_vars, int32_t n_points,
+                                const uint32_t* eval_poly, const uint32_t* eval_point, const uint64_t* eval_values, int32_t n_evals, dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords) {
+  return guard([&] {
+    DP_REQUIRE(ctx && comms && n_polys > 0 && points_flat && point_num_vars && n_points > 0 && eval_poly && eval_point && eval_values && n_evals > 0 && t && proof_words && proof_nwords, DP_ERR_ARG, "bad arguments");
+    std::vector<std::vector<Ext>> pts; std::vector<size_t> ep, eq; std::vector<Ext> ev;
+    read_eval_lists(points_flat, point_num_vars, n_points, eval_poly, eval_point, eval_values, n_evals, n_polys, pts, ep, eq, ev);
+    std::vector<const DevCommit*> cs;
+    for (int i = 0; i < n_polys; i++) { DP_REQUIRE(comms[i], DP_ERR_ARG, "null commitment"); cs.push_back(&comms[i]->c); }
+    std::vector<EvalClaim> evals;
+    for (int i = 0; i < n_evals; i++) evals.push_back({ep[i], eq[i], ev[i]});
+    CtxLock lk(ctx);
+    BasefoldProof p = pcs_batch_open_evals(*ctx->dev, 64, cs, pts, evals, t->t);
+    Writer w; w.basefold(p);
+    *proof_words = copy_out(w.w); *proof_nwords = w.w.size();
+  });
+}
+int32_t dp_pcs_batch_verify_evals(size_t max_poly_size, const uint64_t* roots, const uint32_t* num_vars, const int32_t* is_base, int32_t n_polys, const uint64_t* points_flat,
+                                  const uint32_t* point_num_vars, int32_t n_points, const uint32_t* eval_poly, const uint32_t* eval_point, const uint64_t* eval_values, int32_t n_evals,
+                                  const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t) {
+  return guard([&] {
+    DP_REQUIRE(roots && num_vars && is_base && n_polys > 0 && points_flat && point_num_vars && n_points > 0 && eval_poly && eval_point && eval_values && n_evals > 0 && proof_words && t && is_pow2(max_poly_size), DP_ERR_ARG, "bad arguments");
+    std::vector<std::vector<Ext>> pts; std::vector<size_t> ep, eq; std::vector<Ext> ev;
+    read_eval_lists(points_flat, point_num_vars, n_points, eval_poly, eval_point, eval_values, n_evals, n_polys, pts, ep, eq, ev);
+    std::vector<Commitment> cs;
+    for (int i = 0; i < n_polys; i++) { Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = roots[4 * i + k]; c.num_vars = num_vars[i]; c.is_base = is_base[i] != 0; cs.push_back(c); }
+    std::vector<VerifyEval> evals;
+    for (int i = 0; i < n_evals; i++) evals.push_back({ep[i], eq[i], ev[i]});
+    Reader r(proof_words, proof_nwords); BasefoldProof p = r.basefold();
+    DP_REQUIRE(r.pos == proof_nwords, DP_ERR_ARG, "proof stream: trailing words");
+    VerifierParams vp; vp.full_log = dp_ceil_log2(max_poly_size);
+    std::vector<MerkleJob> jobs;
+    merkle_sink() = &jobs;
+    try { pcs_batch_verify_evals(vp, cs, pts, evals, p, t->t); } catch (...) { merkle_sink() = nullptr; throw; }
+    merkle_sink() = nullptr;
+    DP_REQUIRE(merkle_jobs_ok(jobs), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
+  });
+}
 /* PCS::batch_commit / simple_batch_open / simple_batch_verify (mpcs/src/basefold.rs:356-446, 777-861, 1100-1203) */
 int32_t dp_pcs_batch_commit(dp_ctx* ctx, const dp_buf* const* polys, int32_t n, dp_batch_commit** out, uint64_t root[4]) {
   return guard([&] {

@@ -111,37 +111,47 @@ inline std::vector<Ext> classic_round_message(const Ext* raw, const DBuf* fs, co
   return {h0, h1, h2};
 }
 
-// PCS::batch_open in the shape zkml uses it: claim i = (poly i, point i) (commit/context.rs:370-383)
-inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vector<OpenClaim>& claims, Transcript& t) {
+// PCS::batch_open (basefold.rs:546-770): `evals` = Evaluation{poly, point, value} over the commitments `comms` and the points `points` —
+// any polynomial at any point of its size, several evaluations per polynomial or per point. The classic sumcheck runs on one
+// (f, eq) pair per EVALUATION (the reference merges the polynomials that share a point first, basefold.rs:607-643: the same round
+// sums, field arithmetic being exact); the commit phase and the queries run per COMMITMENT, with the coefficient of a commitment the
+// sum over its evaluations (basefold.rs:690-701).
+struct EvalClaim { size_t poly, point; Ext eval; };
+inline BasefoldProof pcs_batch_open_evals(Dev& dev, unsigned full_log, const std::vector<const DevCommit*>& comms, const std::vector<std::vector<Ext>>& points,
+                                          const std::vector<EvalClaim>& evals, Transcript& t) {
   BasefoldProof proof;
-  if (claims.empty()) return proof;  // Proof::trivial(vec![])
+  if (comms.empty() && points.empty() && evals.empty()) return proof;  // Proof::trivial(vec![])
+  DP_REQUIRE(!comms.empty() && !evals.empty(), DP_ERR_SHAPE, "batch_open: commitments and evaluations expected");
   const bool timing = getenv("DP_TIMING") && atoi(getenv("DP_TIMING"));
   auto tl0 = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[dp timing]   batch_open: %-20s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - tl0).count()); tl0 = t1; };
   size_t mk = dev.mark();
   unsigned num_vars = 0;
-  for (auto& c : claims) {
-    DP_REQUIRE(!c.comm->trivial(), DP_ERR_SHAPE, "batch_open: trivial commitment");
-    DP_REQUIRE(c.point.size() == c.comm->nv, DP_ERR_SHAPE, "batch_open: point length != num_vars");
-    if (c.comm->nv > num_vars) num_vars = c.comm->nv;
+  for (const DevCommit* c : comms) {
+    DP_REQUIRE(c && !c->trivial(), DP_ERR_SHAPE, "batch_open: trivial commitment");
+    if (c->nv > num_vars) num_vars = c->nv;
+  }
+  for (const EvalClaim& e : evals) {
+    DP_REQUIRE(e.poly < comms.size() && e.point < points.size(), DP_ERR_ARG, "batch_open: evaluation refers to a missing polynomial or point");
+    DP_REQUIRE(points[e.point].size() == comms[e.poly]->nv, DP_ERR_SHAPE, "batch_open: point length != num_vars");
   }
   DP_REQUIRE(num_vars <= full_log, DP_ERR_SHAPE, "batch_open: polynomial larger than the PCS parameters");
-  size_t np = claims.size();
+  const size_t np = evals.size(), nc = comms.size();  // np: (f, eq) pairs of the sumcheck; nc: committed codewords
   unsigned bsl = dp_ceil_log2(np);
   std::vector<Ext> tt;
   for (unsigned i = 0; i < bsl; i++) tt.push_back(t.get_and_append_challenge("batch coeffs"));
   std::vector<Ext> eq_xt = host_eq_table(tt);
   Ext target = ex_zero();
   for (size_t i = 0; i < np; i++)
-    target = ex_add(target, ex_mul(ex_mul(claims[i].eval, ex_from_u64(u64(1) << (num_vars - claims[i].comm->nv))), eq_xt[i]));
+    target = ex_add(target, ex_mul(ex_mul(evals[i].eval, ex_from_u64(u64(1) << (num_vars - comms[evals[i].poly]->nv))), eq_xt[i]));
   // ---- classic sumcheck on sum_i eq_xt[i] * eq(x, z_i) * f_i(x)  (sum_check/classic.rs:232-285, coeff.rs:198-345)
   std::vector<DBuf> fs(np), eqs(np);
   {
     std::vector<Dev::EqJob> jobs(np);
     for (size_t i = 0; i < np; i++) {
-      fs[i] = claims[i].comm->evals;
+      fs[i] = comms[evals[i].poly]->evals;
       eqs[i] = dev.alloc(fs[i].n, true);
-      jobs[i] = {eqs[i], claims[i].point.data(), claims[i].comm->nv};
+      jobs[i] = {eqs[i], points[evals[i].point].data(), comms[evals[i].poly]->nv};
     }
     dev.eq_table_many(jobs.data(), np);
   }
@@ -164,9 +174,11 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
   }
   lap("classic sumcheck");
   // (the last challenge never needs to be folded in: only the challenges are used below)
-  std::vector<Ext> coeffs(np);
-  for (size_t i = 0; i < np; i++)
-    coeffs[i] = ex_mul(eq_eval(challenges.data(), claims[i].point.data(), claims[i].point.size()), eq_xt[i]);
+  std::vector<Ext> coeffs(nc, ex_zero());
+  for (size_t i = 0; i < np; i++) {
+    const std::vector<Ext>& pt = points[evals[i].point];
+    coeffs[evals[i].poly] = ex_add(coeffs[evals[i].poly], ex_mul(eq_eval(challenges.data(), pt.data(), pt.size()), eq_xt[i]));
+  }
 
   // ---- batch_commit_phase (commit_phase.rs:187-359)
   unsigned num_rounds = num_vars - PCS_BASECODE_LOG;
@@ -175,7 +187,7 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
   // running oracle of size `n` = init + sum of the committed codewords of that size, each times its coefficient
   auto merge_codewords = [&](size_t n, const DBuf* init) {
     jobs.clear();
-    for (size_t i = 0; i < np; i++) if (claims[i].comm->codeword_size() == n) jobs.push_back({claims[i].comm->tree.leaves, coeffs[i], 1});
+    for (size_t i = 0; i < nc; i++) if (comms[i]->codeword_size() == n) jobs.push_back({comms[i]->tree.leaves, coeffs[i], 1});
     DBuf b = dev.alloc(n, true);
     dev.axpy_many(b, init, jobs.data(), jobs.size());
     return b;
@@ -183,7 +195,7 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
   DBuf running = merge_codewords(cw_size, nullptr);
   DBuf sum_evals = dev.alloc(size_t(1) << num_vars, true);
   jobs.clear();
-  for (size_t i = 0; i < np; i++) jobs.push_back({claims[i].comm->bh_evals, coeffs[i], size_t(1) << (num_vars - claims[i].comm->nv)});
+  for (size_t i = 0; i < nc; i++) jobs.push_back({comms[i]->bh_evals, coeffs[i], size_t(1) << (num_vars - comms[i]->nv)});
   dev.axpy_many(sum_evals, nullptr, jobs.data(), jobs.size());
   std::vector<Ext> rev_point(challenges.rbegin(), challenges.rend());
   DBuf eq = dev.alloc(size_t(1) << num_vars, true);
@@ -195,7 +207,7 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
   // merges[i]: the committed codewords that join the running oracle at the top of round i (those as long as it is then)
   std::vector<std::vector<Dev::AxpyJob>> merges(num_rounds);
   for (unsigned i = 1; i < num_rounds; i++)
-    for (size_t k = 0; k < np; k++) if (claims[k].comm->codeword_size() == (cw_size >> i)) merges[i].push_back({claims[k].comm->tree.leaves, coeffs[k], 1});
+    for (size_t k = 0; k < nc; k++) if (comms[k]->codeword_size() == (cw_size >> i)) merges[i].push_back({comms[k]->tree.leaves, coeffs[k], 1});
   CommitLoopState st; st.last = last; st.running = running; st.eq = eq; st.sum_evals = sum_evals;
   commit_rounds(dev, merges, num_rounds, 0, true, st, t, proof.sumcheck_messages, proof.roots, trees, proof.final_message);
   lap("commit phase");
@@ -207,21 +219,28 @@ inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vect
   for (size_t x : qidx) {
     size_t index = x >> 1;
     for (auto& tr : trees) { size_t p1 = index | 1; descs.push_back({&tr, p1 - 1}); index >>= 1; }
-    for (auto& c : claims) { size_t xi = x >> (cw_log - c.comm->tree.height()); size_t p1 = xi | 1; descs.push_back({&c.comm->tree, p1 - 1}); }
+    for (const DevCommit* c : comms) { size_t xi = x >> (cw_log - c->tree.height()); size_t p1 = xi | 1; descs.push_back({&c->tree, p1 - 1}); }
   }
   std::vector<std::vector<u64>> got;
   dev.query_gather(descs.data(), descs.size(), got);
   size_t di = 0;
   for (size_t x : qidx) {
     BatchedQuery bq; bq.index = x;
-    bq.oracle_query.reserve(trees.size()); bq.commitments_query.reserve(np);
+    bq.oracle_query.reserve(trees.size()); bq.commitments_query.reserve(nc);
     for (size_t k = 0; k < trees.size(); k++, di++) bq.oracle_query.push_back(query_from_words(descs[di], got[di]));
-    for (size_t k = 0; k < np; k++, di++) bq.commitments_query.push_back(query_from_words(descs[di], got[di]));
+    for (size_t k = 0; k < nc; k++, di++) bq.commitments_query.push_back(query_from_words(descs[di], got[di]));
     proof.queries.push_back(std::move(bq));
   }
   lap("query phase");
   dev.release(mk);
   return proof;
+}
+
+// ... in the shape zkml uses it: claim i = (polynomial i, point i) (commit/context.rs:370-383)
+inline BasefoldProof pcs_batch_open(Dev& dev, unsigned full_log, const std::vector<OpenClaim>& claims, Transcript& t) {
+  std::vector<const DevCommit*> comms; std::vector<std::vector<Ext>> points; std::vector<EvalClaim> evals;
+  for (size_t i = 0; i < claims.size(); i++) { comms.push_back(claims[i].comm); points.push_back(claims[i].point); evals.push_back({i, i, claims[i].eval}); }
+  return pcs_batch_open_evals(dev, full_log, comms, points, evals, t);
 }
 
 // PCS::open of one committed polynomial at one point (basefold.rs:466-544). commit_phase (commit_phase.rs:30-185) is the batch
@@ -627,14 +646,17 @@ inline void pcs_simple_batch_verify(const VerifierParams& vp, const Commitment& 
 }
 
 // PCS::batch_verify (basefold.rs:964-1098) + batch_verifier_query_phase (query_phase.rs:220-288) + check (:1116-1236)
-inline void pcs_batch_verify(const VerifierParams& vp, const std::vector<VerifyClaim>& claims, const BasefoldProof& proof, Transcript& t) {
-  if (claims.empty() && proof.trivial_proof.empty() && proof.is_trivial()) return;
-  DP_REQUIRE(!claims.empty(), DP_ERR_VERIFY, "batch_verify: proof given but no claims");
-  size_t np = claims.size();
+struct VerifyEval { size_t poly, point; Ext eval; };
+inline void pcs_batch_verify_evals(const VerifierParams& vp, const std::vector<Commitment>& comms, const std::vector<std::vector<Ext>>& points, const std::vector<VerifyEval>& evals,
+                                   const BasefoldProof& proof, Transcript& t) {
+  if (comms.empty() && points.empty() && evals.empty() && proof.trivial_proof.empty() && proof.is_trivial()) return;
+  DP_REQUIRE(!comms.empty() && !evals.empty(), DP_ERR_VERIFY, "batch_verify: proof given but no claims");
+  const size_t np = evals.size(), nc = comms.size();
   unsigned num_vars = 0, min_nv = ~0u;
-  for (auto& c : claims) {
-    DP_REQUIRE(c.point.size() == c.comm.num_vars, DP_ERR_VERIFY, "batch_verify: point length != num_vars");
-    num_vars = std::max(num_vars, c.comm.num_vars); min_nv = std::min(min_nv, c.comm.num_vars);
+  for (const Commitment& c : comms) { num_vars = std::max(num_vars, c.num_vars); min_nv = std::min(min_nv, c.num_vars); }
+  for (const VerifyEval& e : evals) {
+    DP_REQUIRE(e.poly < nc && e.point < points.size(), DP_ERR_ARG, "batch_verify: evaluation refers to a missing polynomial or point");
+    DP_REQUIRE(points[e.point].size() == comms[e.poly].num_vars, DP_ERR_VERIFY, "batch_verify: point length != num_vars");
   }
   DP_REQUIRE(min_nv >= PCS_BASECODE_LOG && num_vars <= vp.full_log && !proof.is_trivial(), DP_ERR_VERIFY, "batch_verify: bad shapes");
   unsigned num_rounds = num_vars - PCS_BASECODE_LOG;
@@ -644,7 +666,7 @@ inline void pcs_batch_verify(const VerifierParams& vp, const std::vector<VerifyC
   std::vector<Ext> eq_xt = host_eq_table(tt);
   Ext target = ex_zero();
   for (size_t i = 0; i < np; i++)
-    target = ex_add(target, ex_mul(ex_mul(claims[i].eval, ex_from_u64(u64(1) << (num_vars - claims[i].comm.num_vars))), eq_xt[i]));
+    target = ex_add(target, ex_mul(ex_mul(evals[i].eval, ex_from_u64(u64(1) << (num_vars - comms[evals[i].poly].num_vars))), eq_xt[i]));
   // SumCheck::verify (classic.rs:287-330): coefficients form, degree 2
   DP_REQUIRE(proof.sumcheck_proof.size() == num_vars, DP_ERR_VERIFY, "batch_verify: wrong number of sumcheck rounds");
   std::vector<Ext> vpoint;
@@ -660,9 +682,11 @@ inline void pcs_batch_verify(const VerifierParams& vp, const std::vector<VerifyC
     sum = ex_add(m[0], ex_mul(ch, ex_add(m[1], ex_mul(ch, m[2]))));
   }
   Ext new_target = sum;
-  std::vector<Ext> coeffs(np);
-  for (size_t i = 0; i < np; i++)
-    coeffs[i] = ex_mul(eq_eval(vpoint.data(), claims[i].point.data(), claims[i].point.size()), eq_xt[i]);
+  std::vector<Ext> coeffs(nc, ex_zero());  // per commitment: the sum over its evaluations (basefold.rs:1040-1051)
+  for (size_t i = 0; i < np; i++) {
+    const std::vector<Ext>& pt = points[evals[i].point];
+    coeffs[evals[i].poly] = ex_add(coeffs[evals[i].poly], ex_mul(eq_eval(vpoint.data(), pt.data(), pt.size()), eq_xt[i]));
+  }
   DP_REQUIRE(proof.sumcheck_messages.size() == num_rounds && proof.roots.size() + 1 == num_rounds, DP_ERR_VERIFY, "batch_verify: commit-phase shape");
   std::vector<Ext> fold_ch;
   for (unsigned i = 0; i < num_rounds; i++) {
@@ -689,16 +713,16 @@ inline void pcs_batch_verify(const VerifierParams& vp, const std::vector<VerifyC
     const BatchedQuery& bq = proof.queries[q];
     size_t index = qidx[q];
     DP_REQUIRE(bq.index == index, DP_ERR_VERIFY, "batch_verify: query index mismatch");
-    DP_REQUIRE(bq.oracle_query.size() == proof.roots.size() && bq.commitments_query.size() == np, DP_ERR_VERIFY, "batch_verify: query shape");
+    DP_REQUIRE(bq.oracle_query.size() == proof.roots.size() && bq.commitments_query.size() == nc, DP_ERR_VERIFY, "batch_verify: query shape");
     for (size_t k = 0; k < bq.oracle_query.size(); k++) check_merkle_path(bq.oracle_query[k], proof.roots[k]);
-    for (size_t k = 0; k < np; k++) {
-      DP_REQUIRE(bq.commitments_query[k].is_ext == !claims[k].comm.is_base, DP_ERR_VERIFY, "batch_verify: field type of opened codeword");
-      check_merkle_path(bq.commitments_query[k], claims[k].comm.root);
+    for (size_t k = 0; k < nc; k++) {
+      DP_REQUIRE(bq.commitments_query[k].is_ext == !comms[k].is_base, DP_ERR_VERIFY, "batch_verify: field type of opened codeword");
+      check_merkle_path(bq.commitments_query[k], comms[k].root);
     }
     Ext cur_l = ex_zero(), cur_r = ex_zero();
     size_t right_index = index | 1, left_index = right_index - 1;
     for (unsigned i = 0; i < num_rounds; i++) {
-      for (size_t k = 0; k < np; k++) if (claims[k].comm.num_vars == num_vars - i) {
+      for (size_t k = 0; k < nc; k++) if (comms[k].num_vars == num_vars - i) {
         const CodewordQuery& cq = bq.commitments_query[k];
         DP_REQUIRE(cq.index == left_index, DP_ERR_VERIFY, "batch_verify: commitment query index");  // provers emit the index of the LEFT element of the pair
         cur_l = ex_add(cur_l, ex_mul(cq.left, coeffs[k]));
@@ -716,7 +740,7 @@ inline void pcs_batch_verify(const VerifierParams& vp, const std::vector<VerifyC
         cur_l = oq.left; cur_r = oq.right;
         next_val = (next_index & 1) ? cur_r : cur_l;
       } else {
-        for (size_t k = 0; k < np; k++) if (claims[k].comm.num_vars == num_vars - i - 1) {
+        for (size_t k = 0; k < nc; k++) if (comms[k].num_vars == num_vars - i - 1) {
           const CodewordQuery& cq = bq.commitments_query[k];
           DP_REQUIRE(cq.index == (next_index | 1) - 1, DP_ERR_VERIFY, "batch_verify: last-round commitment query index");
           res = ex_add(res, ex_mul((next_index & 1) ? cq.right : cq.left, coeffs[k]));
@@ -735,6 +759,13 @@ inline void pcs_batch_verify(const VerifierParams& vp, const std::vector<VerifyC
   Ext ip = ex_zero();
   for (size_t i = 0; i < mlen; i++) ip = ex_add(ip, ex_mul(proof.final_message[i], peq[i]));
   DP_REQUIRE(ex_eq(eval2(proof.sumcheck_messages[num_rounds - 1], fold_ch[num_rounds - 1]), ip), DP_ERR_VERIFY, "batch_verify: final message inner product");
+}
+
+// ... in the shape zkml uses it: claim i = (commitment i, point i)
+inline void pcs_batch_verify(const VerifierParams& vp, const std::vector<VerifyClaim>& claims, const BasefoldProof& proof, Transcript& t) {
+  std::vector<Commitment> comms; std::vector<std::vector<Ext>> points; std::vector<VerifyEval> evals;
+  for (size_t i = 0; i < claims.size(); i++) { comms.push_back(claims[i].comm); points.push_back(claims[i].point); evals.push_back({i, i, claims[i].eval}); }
+  pcs_batch_verify_evals(vp, comms, points, evals, proof, t);
 }
 
 }  // namespace dp

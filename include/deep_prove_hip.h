@@ -190,6 +190,20 @@ int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const u
                             const int32_t* is_base, int32_t n, const uint64_t* points_flat, const uint64_t* evals,
                             const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t);
 
+/* PCS::batch_open / PCS::batch_verify with a general `evals: &[Evaluation<E>]` (mpcs/src/basefold.rs:546-770, 964-1098; Evaluation =
+ * {poly, point, value}, mpcs/src/lib.rs:283-304): n_evals evaluations over n_polys commitments and n_points points — any polynomial at
+ * any point of its size, several evaluations per polynomial or per point (the reference's own batch_commit_open_verify tests do that,
+ * mpcs/src/lib.rs:560-700). points_flat = the points one after the other, point_num_vars[i] extension elements each; eval_poly /
+ * eval_point index comms / points; eval_values 2 words each. Same proof layout as dp_pcs_batch_open (one commitment pair per query and
+ * COMMITMENT). dp_pcs_batch_open(comms, n, ..) is the special case eval i = (polynomial i, point i). */
+int32_t dp_pcs_batch_open_evals(dp_ctx* ctx, const dp_commit* const* comms, int32_t n_polys, const uint64_t* points_flat,
+                                const uint32_t* point_num_vars, int32_t n_points, const uint32_t* eval_poly, const uint32_t* eval_point,
+                                const uint64_t* eval_values, int32_t n_evals, dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords);
+int32_t dp_pcs_batch_verify_evals(size_t max_poly_size, const uint64_t* roots, const uint32_t* num_vars, const int32_t* is_base,
+                                  int32_t n_polys, const uint64_t* points_flat, const uint32_t* point_num_vars, int32_t n_points,
+                                  const uint32_t* eval_poly, const uint32_t* eval_point, const uint64_t* eval_values, int32_t n_evals,
+                                  const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t);
+
 /* PCS::batch_commit (mpcs/src/basefold.rs:356-446): n polynomials of ONE size and ONE field behind one Merkle root. Every polynomial is
  * encoded as in dp_pcs_commit; leaf j of the common tree is the row [codeword_0[j], .., codeword_{n-1}[j]] (MerkleTree::from_batch_leaves,
  * util/merkle_tree.rs:68-74, 261-329: pair hash = hash_two_digests(hash(row 2i), hash(row 2i+1)), util/hash.rs:32-41; raw tables when

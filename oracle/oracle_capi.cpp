@@ -174,6 +174,23 @@ int orc_pcs_batch_open(size_t max_poly_size, const uint64_t* const* polys, const
     Writer w; w.basefold(p); *proof_words = copy_out(w.w); *proof_nwords = w.w.size();
   });
 }
+// batch_open over a general Evaluation list (basefold.rs:546-770): polynomial i committed on its own; evals = (poly, point, value)
+int orc_pcs_batch_open_evals(size_t max_poly_size, const uint64_t* const* polys, const size_t* lens, const int32_t* is_ext, int32_t n_polys, const uint64_t* points_flat, const uint32_t* point_num_vars,
+                             int32_t n_points, const uint32_t* eval_poly, const uint32_t* eval_point, const uint64_t* eval_values, int32_t n_evals, orc_transcript* t, uint64_t** proof_words, size_t* proof_nwords) {
+  return guard([&] {
+    PcsParams pp = pcs_setup(max_poly_size);
+    std::vector<Mle> ps; std::vector<CommitmentWithWitness> cs;
+    for (int i = 0; i < n_polys; i++) { ps.push_back(rd_mle(polys[i], lens[i], is_ext[i])); cs.push_back(pcs_commit(pp, ps.back())); }
+    std::vector<const Mle*> pp_; std::vector<const CommitmentWithWitness*> cc;
+    for (int i = 0; i < n_polys; i++) { pp_.push_back(&ps[i]); cc.push_back(&cs[i]); }
+    std::vector<std::vector<E>> pts; size_t off = 0;
+    for (int i = 0; i < n_points; i++) { pts.push_back(rd_pt(points_flat + off, point_num_vars[i])); off += 2 * (size_t)point_num_vars[i]; }
+    std::vector<Evaluation> evs;
+    for (int i = 0; i < n_evals; i++) evs.push_back({(size_t)eval_poly[i], (size_t)eval_point[i], E{eval_values[2 * i], eval_values[2 * i + 1]}});
+    BasefoldProof p = pcs_batch_open(pp, pp_, cc, pts, evs, t->t);
+    Writer w; w.basefold(p); *proof_words = copy_out(w.w); *proof_nwords = w.w.size();
+  });
+}
 // batch_commit + simple_batch_open of k polynomials of `n` elements each (basefold.rs:356-446, 777-861): root of the common tree and the proof stream
 int orc_pcs_simple_batch_open(size_t max_poly_size, const uint64_t* const* polys, size_t n, int32_t k, int is_ext, const uint64_t* point, orc_transcript* t, uint64_t root[4],
                               uint64_t** proof_words, size_t* proof_nwords) {

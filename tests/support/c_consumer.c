@@ -48,7 +48,7 @@ static int symbols_only(void) {
     (fn_t)dp_mle_fix_high, (fn_t)dp_sumcheck_prove, (fn_t)dp_sumcheck_verify, (fn_t)dp_sc_session_new, (fn_t)dp_sc_session_round,
     (fn_t)dp_sc_session_finish, (fn_t)dp_sc_session_free, (fn_t)dp_logup_prove, (fn_t)dp_logup_verify, (fn_t)dp_pcs_setup, (fn_t)dp_pcs_commit,
     (fn_t)dp_pcs_commit_free, (fn_t)dp_pcs_commitment, (fn_t)dp_pcs_open, (fn_t)dp_pcs_verify, (fn_t)dp_pcs_batch_open, (fn_t)dp_pcs_batch_verify,
-    (fn_t)dp_pcs_batch_commit, (fn_t)dp_pcs_batch_commit_free, (fn_t)dp_pcs_simple_batch_open, (fn_t)dp_pcs_simple_batch_verify,
+    (fn_t)dp_pcs_batch_open_evals, (fn_t)dp_pcs_batch_verify_evals, (fn_t)dp_pcs_batch_commit, (fn_t)dp_pcs_batch_commit_free, (fn_t)dp_pcs_simple_batch_open, (fn_t)dp_pcs_simple_batch_verify,
     (fn_t)dp_model_setup, (fn_t)dp_model_free, (fn_t)dp_model_prove, (fn_t)dp_model_prove_batch, (fn_t)dp_model_in_flight, (fn_t)dp_model_output_len,
     (fn_t)dp_host_cpu_budget, (fn_t)dp_host_poseidon2, (fn_t)dp_model_infer_host, (fn_t)dp_model_verifier_blob, (fn_t)dp_verify, (fn_t)dp_verify_batch, (fn_t)dp_dist_unique_id, (fn_t)dp_dist_init, (fn_t)dp_dist_free,
     (fn_t)dp_sumcheck_prove_sharded, (fn_t)dp_sumcheck_prove_sharded_local};

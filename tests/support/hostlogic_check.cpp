@@ -290,7 +290,71 @@ static int batchopen_mode(uint64_t seed, unsigned nv, bool ext, int k) {
 #endif
   return same && accepted == 1 && rejected == 5 && caught == flips ? 0 : 2;
 }
+// `hostlogic_check batchevals <seed> <shape>`: PCS::batch_open over a general Evaluation list (mpcs/src/basefold.rs:546-770) — polynomials that
+// share a point (the reference's run_batch_commit_open_verify shapes, mpcs/src/lib.rs:508-700), one polynomial at two points, a mixed list:
+// the product's pcs_batch_open_evals over the double vs the oracle (which merges the polynomials per point as the reference does)
+static int batchevals_mode(uint64_t seed, int shape) {
+  rs = seed;
+  struct Sh { std::vector<std::pair<unsigned, bool>> polys; std::vector<unsigned> pts; std::vector<std::pair<size_t, size_t>> evs; };
+  const Sh shapes[] = {
+    {{{9, false}, {9, false}}, {9}, {{0, 0}, {1, 0}}},
+    {{{10, false}, {10, true}, {9, false}, {9, false}}, {10, 9}, {{0, 0}, {1, 0}, {2, 1}, {3, 1}}},
+    {{{10, true}}, {10, 10}, {{0, 0}, {0, 1}}},
+    {{{11, false}, {9, true}, {11, true}}, {11, 11, 9}, {{0, 0}, {2, 0}, {0, 1}, {1, 2}, {2, 1}}},
+    {{{8, false}, {12, false}, {8, true}}, {12, 8}, {{1, 0}, {0, 1}, {2, 1}}},
+  };
+  const Sh& sh = shapes[shape];
+  unsigned L = 0; for (auto& p : sh.polys) L = std::max(L, p.first);
+  L += 1;
+  std::vector<std::vector<uint64_t>> w(sh.polys.size());
+  std::vector<orc::Mle> oms;
+  for (size_t q = 0; q < sh.polys.size(); q++) {
+    const bool ext = sh.polys[q].second;
+    w[q].resize((size_t(1) << sh.polys[q].first) * (ext ? 2 : 1)); for (auto& x : w[q]) x = rnd() % dp::GL_P;
+    if (ext) { std::vector<orc::E> e(w[q].size() / 2); for (size_t j = 0; j < e.size(); j++) e[j] = orc::E{w[q][2 * j], w[q][2 * j + 1]}; oms.push_back(orc::Mle::from_ext(e)); } else oms.push_back(orc::Mle::from_base(w[q]));
+  }
+  std::vector<std::vector<orc::E>> opts; std::vector<std::vector<dp::Ext>> ppts;
+  for (unsigned n : sh.pts) { opts.emplace_back(); ppts.emplace_back(); for (unsigned i = 0; i < n; i++) { uint64_t a = rnd() % dp::GL_P, b = rnd() % dp::GL_P; opts.back().push_back(orc::E{a, b}); ppts.back().push_back(dp::ex(a, b)); } }
+  orc::PcsParams pp = orc::pcs_setup(size_t(1) << L);
+  std::vector<orc::CommitmentWithWitness> ocs; for (auto& m : oms) ocs.push_back(orc::pcs_commit(pp, m));
+  std::vector<const orc::Mle*> omp; std::vector<const orc::CommitmentWithWitness*> ocp;
+  for (size_t q = 0; q < oms.size(); q++) { omp.push_back(&oms[q]); ocp.push_back(&ocs[q]); }
+  std::vector<orc::Evaluation> oevs; std::vector<dp::EvalClaim> pevs; std::vector<dp::VerifyEval> vevs;
+  for (auto& e : sh.evs) { orc::E v = oms[e.first].evaluate(opts[e.second]); oevs.push_back({e.first, e.second, v}); pevs.push_back({e.first, e.second, dp::ex(v.c0, v.c1)}); vevs.push_back({e.first, e.second, dp::ex(v.c0, v.c1)}); }
+  orc::Transcript ot = orc::default_transcript();
+  orc::BasefoldProof op = orc::pcs_batch_open(pp, omp, ocp, opts, oevs, ot);
+  orc::Writer ow; ow.basefold(op);
+  orc::E och = ot.get_and_append_challenge("after");
+  TestDev dev; dev.pcs_init(L);
+#ifdef DP_EMUL_DEV
+  dp::emul_init_constants();
+#endif
+  std::vector<dp::DevCommit> cs; std::vector<const dp::DevCommit*> cps; std::vector<dp::Commitment> pcs;
+  for (size_t q = 0; q < w.size(); q++) { dp::DBuf b = dev.alloc_persistent(size_t(1) << sh.polys[q].first, sh.polys[q].second); dev.upload(b, w[q].data()); cs.push_back(static_cast<dp::Dev&>(dev).commit(b, true)); }
+  for (auto& c : cs) { cps.push_back(&c); pcs.push_back(dp::pure_commitment(c)); }
+  dp::Transcript pt = dp::default_transcript();
+  dp::BasefoldProof pr = dp::pcs_batch_open_evals(dev, L, cps, ppts, pevs, pt);
+  dp::Writer pw; pw.basefold(pr);
+  dp::Ext pch = pt.get_and_append_challenge("after");
+  const bool same = pw.w == ow.w && pch.c0 == och.c0 && pch.c1 == och.c1;
+  auto run = [&](const std::vector<dp::VerifyEval>& ev, const std::vector<uint64_t>& words) {
+    try { dp::Reader r(words.data(), words.size()); dp::BasefoldProof q = r.basefold(); if (r.pos != words.size()) return 0; dp::Transcript vt = dp::default_transcript(); dp::VerifierParams v2; v2.full_log = L;
+          dp::pcs_batch_verify_evals(v2, pcs, ppts, ev, q, vt);
+          dp::Ext vch = vt.get_and_append_challenge("after"); return vch.c0 == och.c0 && vch.c1 == och.c1 ? 1 : 2; }
+    catch (const dp::DpError&) { return 0; }
+  };
+  int accepted = run(vevs, pw.w) == 1, rejected = 0;
+  { auto e2 = vevs; e2.back().eval = dp::ex_add(e2.back().eval, dp::ex_one()); rejected += run(e2, pw.w) == 0; }
+  { auto e2 = vevs; e2.pop_back(); rejected += run(e2, pw.w) == 0; }
+  size_t flips = 0, caught = 0;
+  for (size_t at = 1; at < pw.w.size(); at += std::max<size_t>(1, pw.w.size() / 61)) { std::vector<uint64_t> t2 = pw.w; t2[at] ^= 1; flips++; caught += run(vevs, t2) == 0; }
+  printf("batch open, evaluation list %d (%zu polynomials, %zu points, %zu evaluations): stream+transcript %s the oracle (%zu words); verifier accepted %d of 1, rejected %d of 2, caught %zu of %zu single-word flips\n",
+         shape, w.size(), sh.pts.size(), sh.evs.size(), same ? "identical to" : "DIFFER from", pw.w.size(), accepted, rejected, caught, flips);
+  if (!same) { size_t d = 0; while (d < pw.w.size() && d < ow.w.size() && pw.w[d] == ow.w[d]) d++; printf("  sizes %zu / %zu, first differing word %zu\n", pw.w.size(), ow.w.size(), d); }
+  return same && accepted == 1 && rejected == 2 && caught == flips ? 0 : 2;
+}
 int main(int argc, char** argv) {
+  if (argc > 1 && std::string(argv[1]) == "batchevals") return batchevals_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 0);
   if (argc > 1 && std::string(argv[1]) == "batchopen") return batchopen_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 9, argc > 4 && atoi(argv[4]), argc > 5 ? atoi(argv[5]) : 3);
   if (argc > 1 && std::string(argv[1]) == "open") return open_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 9, argc > 4 && atoi(argv[4]));
   if (argc > 1 && std::string(argv[1]) == "sharded") return sharded_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 4);

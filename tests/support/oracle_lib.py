@@ -194,6 +194,24 @@ class Oracle:
                                              ev.ctypes.data_as(u64p), transcript.h, C.byref(pw), C.byref(pn)))
         return self._take(pw, pn.value)
 
+    def pcs_batch_open_evals(self, max_poly_size, polys, is_ext, points, evals, transcript):
+        """batch_open over a general Evaluation list: evals = [(poly index, point index, value)]"""
+        keep = [np.ascontiguousarray(p, dtype=np.uint64) for p in polys]
+        pp = (u64p * len(keep))(*[k.ctypes.data_as(u64p) for k in keep])
+        lens = (C.c_size_t * len(keep))(*[(k.size // 2 if e else k.size) for k, e in zip(keep, is_ext)])
+        ie = np.array([1 if e else 0 for e in is_ext], dtype=np.int32)
+        pf = np.concatenate([_pt(p) for p in points]).astype(np.uint64)
+        pl = np.array([len(p) for p in points], dtype=np.uint32)
+        ep = np.array([e[0] for e in evals], dtype=np.uint32)
+        eq = np.array([e[1] for e in evals], dtype=np.uint32)
+        ev = _pt([e[2] for e in evals])
+        u32p = C.POINTER(C.c_uint32)
+        pw, pn = u64p(), C.c_size_t()
+        self._ok(self.lib.orc_pcs_batch_open_evals(C.c_size_t(max_poly_size), pp, lens, ie.ctypes.data_as(i32p), C.c_int32(len(keep)), pf.ctypes.data_as(u64p), pl.ctypes.data_as(u32p),
+                                                   C.c_int32(len(points)), ep.ctypes.data_as(u32p), eq.ctypes.data_as(u32p), ev.ctypes.data_as(u64p), C.c_int32(len(evals)), transcript.h,
+                                                   C.byref(pw), C.byref(pn)))
+        return self._take(pw, pn.value)
+
     def pcs_simple_batch_open(self, max_poly_size, polys, is_ext, point=None, transcript=None):
         """batch_commit + simple_batch_open of equally sized polynomials: (root, proof stream); point None: the root only"""
         keep = [np.ascontiguousarray(p, dtype=np.uint64) for p in polys]

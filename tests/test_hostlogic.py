@@ -181,3 +181,14 @@ def test_batch_commit_and_simple_batch_open_over_the_double(hostlogic_bin):
         r = subprocess.run([hostlogic_bin, "batchopen", *map(str, args)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "identical to the oracle" in r.stdout and "accepted 1 of 1, rejected 5 of 5" in r.stdout, r.stdout
+
+
+def test_batch_open_over_general_evaluation_lists(hostlogic_bin):
+    """PCS::batch_open with `evals: &[Evaluation]` (mpcs/src/basefold.rs:546-770; the shapes of run_batch_commit_open_verify{,_multiple_sizes},
+    mpcs/src/lib.rs:508-700, a polynomial at two points, mixed lists): the product runs the classic sumcheck on one (f, eq) pair per evaluation
+    and the commit / query phases per commitment; the oracle merges the polynomials per point as the reference does — same stream, same
+    transcript; pcs_batch_verify_evals accepts, rejects a wrong or missing evaluation and every sampled single-word flip"""
+    for shape in range(5):
+        r = subprocess.run([hostlogic_bin, "batchevals", str(shape + 3), str(shape)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "identical to the oracle" in r.stdout and "accepted 1 of 1, rejected 2 of 2" in r.stdout, r.stdout

@@ -93,3 +93,11 @@ def test_batch_tree_row_hashes_from_the_emulated_kernel():
         assert r.returncode == 0, r.stdout + r.stderr
         assert "identical to the oracle" in r.stdout and "accepted 1 of 1, rejected 5 of 5" in r.stdout, r.stdout
         assert f"emulated k_batch_row_hash: {2 << args[1] if args[1] > 7 else 1 << args[1]} rows hashed" in r.stdout, r.stdout
+
+
+def test_general_evaluation_lists_with_the_emulated_sumcheck_tail():
+    """PCS::batch_open over general Evaluation lists with the classic-sumcheck tail and the commit tail from the device source on the emulator"""
+    for shape in (1, 3):
+        r = _model(("batchevals", shape + 3, shape), {})
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "identical to the oracle" in r.stdout and "accepted 1 of 1, rejected 2 of 2" in r.stdout, r.stdout

@@ -206,6 +206,47 @@ def test_basefold_single_verify_port_of_reference_round_trip(oracle, nv, ext):
         rejected(is_base=ext)
 
 
+EVAL_SHAPES = [  # (polynomials as (num_vars, ext), point lengths, evaluations as (poly, point))
+    ([(9, False), (9, False)], [9], [(0, 0), (1, 0)]),                                        # the reference's run_batch_commit_open_verify: one point, two polynomials
+    ([(10, False), (10, True), (9, False), (9, False)], [10, 9], [(0, 0), (1, 0), (2, 1), (3, 1)]),  # ..._multiple_sizes
+    ([(10, True)], [10, 10], [(0, 0), (0, 1)]),                                               # one polynomial at two points
+    ([(11, False), (9, True), (11, True)], [11, 11, 9], [(0, 0), (2, 0), (0, 1), (1, 2), (2, 1)]),
+]
+
+
+@pytest.mark.parametrize("shape", range(len(EVAL_SHAPES)))
+def test_basefold_batch_verify_general_evaluation_lists(oracle, shape):
+    """mpcs batch_open / batch_verify with `evals: &[Evaluation]` (mpcs/src/lib.rs:508-700 run_batch_commit_open_verify{,_multiple_sizes}: polynomials
+    that share a point; plus a polynomial opened at two points and a mixed list): the oracle opens, dp_pcs_batch_verify_evals accepts with the
+    prover's transcript state and rejects a wrong value, swapped indices, a missing evaluation and a flipped proof word"""
+    import deep_prove_amd as dpa
+    polys_s, points_s, evals_s = EVAL_SHAPES[shape]
+    rng = np.random.default_rng(6100 + shape)
+    maxsize = 1 << 12
+    polys = [rng.integers(0, P, size=(2 if e else 1) << nv, dtype=np.uint64) for nv, e in polys_s]
+    points = [[_rand_ext(rng) for _ in range(n)] for n in points_s]
+    evals = [(pi, qi, oracle.mle_eval(polys[pi], polys_s[pi][1], points[qi])) for pi, qi in evals_s]
+    roots = [oracle.pcs_commit_root(maxsize, w, e) for w, (_, e) in zip(polys, polys_s)]
+    ot = oracle.transcript(b"test")
+    proof = oracle.pcs_batch_open_evals(maxsize, polys, [e for _, e in polys_s], points, evals, ot)
+    args = dict(max_poly_size=maxsize, roots=roots, num_vars=[nv for nv, _ in polys_s], is_base=[not e for _, e in polys_s], points=points, evals=evals, proof_words=proof)
+    t = dpa.Transcript(b"test")
+    dpa.Basefold.batch_verify_evals(transcript=t, **args)
+    assert t.read_challenge() == ot.read_challenge()
+    def rejected(**kw):
+        a = dict(args); a.update(kw)
+        with pytest.raises(dpa.DeepProveError):
+            dpa.Basefold.batch_verify_evals(transcript=dpa.Transcript(b"test"), **a)
+    v = evals[-1][2]
+    rejected(evals=evals[:-1] + [(evals[-1][0], evals[-1][1], ((v[0] + 1) % P, v[1]))])
+    rejected(evals=evals[:-1])
+    rejected(evals=[evals[1], evals[0]] + evals[2:])
+    rejected(roots=[[roots[0][0] ^ 1] + roots[0][1:]] + roots[1:])
+    for at in (7, len(proof) // 2, len(proof) - 5):
+        bad = proof.copy(); bad[at] ^= np.uint64(1)
+        rejected(proof_words=bad)
+
+
 @pytest.mark.parametrize("nv,ext,k", [(4, False, 4), (6, True, 4), (9, False, 1), (9, False, 4), (9, True, 4), (10, False, 7), (8, True, 3)])
 def test_basefold_simple_batch_verify_port_of_reference_round_trip(oracle, nv, ext, k):
     """mpcs batch_commit -> simple_batch_open -> simple_batch_verify (mpcs/src/basefold.rs:1254-1297 simple_batch_commit_open_verify_goldilocks:
