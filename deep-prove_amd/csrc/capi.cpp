@@ -619,7 +619,7 @@ int32_t dp_pcs_simple_batch_open(dp_ctx* ctx, const dp_batch_commit* comm, const
 int32_t dp_pcs_simple_batch_verify(size_t max_poly_size, const uint64_t root[4], uint32_t num_vars, int32_t is_base, const uint64_t* point, const uint64_t* evals, int32_t n,
                                    const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t) {
   return guard([&] {
-    DP_REQUIRE(root && point && evals && n >= 1 && n <= 32 && proof_words && is_pow2(max_poly_size), DP_ERR_ARG, "bad arguments");
+    DP_REQUIRE(root && point && evals && n >= 1 && n <= (1 << 20) && proof_words && is_pow2(max_poly_size), DP_ERR_ARG, "bad arguments");
     Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = root[k]; c.num_vars = num_vars; c.is_base = is_base != 0;
     Reader r(proof_words, proof_nwords); BasefoldProof p = r.basefold();
     DP_REQUIRE(r.pos == proof_nwords, DP_ERR_ARG, "proof stream: trailing words");

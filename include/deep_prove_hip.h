@@ -193,7 +193,7 @@ int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const u
 /* PCS::batch_open / PCS::batch_verify with a general `evals: &[Evaluation<E>]` (mpcs/src/basefold.rs:546-770, 964-1098; Evaluation =
  * {poly, point, value}, mpcs/src/lib.rs:283-304): n_evals evaluations over n_polys commitments and n_points points — any polynomial at
  * any point of its size, several evaluations per polynomial or per point (the reference's own batch_commit_open_verify tests do that,
- * mpcs/src/lib.rs:560-700). points_flat = the points one after the other, point_num_vars[i] extension elements each; eval_poly /
+ * mpcs/src/lib.rs:508-700). points_flat = the points one after the other, point_num_vars[i] extension elements each; eval_poly /
  * eval_point index comms / points; eval_values 2 words each. Same proof layout as dp_pcs_batch_open (one commitment pair per query and
  * COMMITMENT). dp_pcs_batch_open(comms, n, ..) is the special case eval i = (polynomial i, point i). */
 int32_t dp_pcs_batch_open_evals(dp_ctx* ctx, const dp_commit* const* comms, int32_t n_polys, const uint64_t* points_flat,

@@ -285,6 +285,35 @@ def test_basefold_simple_batch_verify_port_of_reference_round_trip(oracle, nv, e
         rejected(max_poly_size=maxsize * 2)
 
 
+def test_simple_batch_verifier_rejects_mutated_streams_without_crashing(oracle):
+    """1 200 mutated simple-batch openings (overwritten / incremented words, truncations, cut-out runs, single-bit words in the header): every one
+    is rejected with a status, none crashes the library"""
+    import deep_prove_amd as dpa
+    rng = np.random.default_rng(77)
+    for nv, ext, k in ((9, False, 3), (5, True, 3), (8, True, 5)):
+        polys = [rng.integers(0, P, size=(2 if ext else 1) << nv, dtype=np.uint64) for _ in range(k)]
+        pt = [_rand_ext(rng) for _ in range(nv)]
+        evals = [oracle.mle_eval(w, ext, pt) for w in polys]
+        root, proof = oracle.pcs_simple_batch_open(1 << 11, polys, ext, pt, oracle.transcript(b"t"))
+        dpa.Basefold.simple_batch_verify(1 << 11, root, nv, not ext, pt, evals, proof, dpa.Transcript(b"t"))
+        for it in range(400):
+            p, m = proof.copy(), it % 5
+            if m == 0:
+                p[rng.integers(0, p.size)] = np.uint64(rng.integers(0, 1 << 63))
+            elif m == 1:
+                p = p[:rng.integers(0, p.size)]
+            elif m == 2:
+                i = rng.integers(0, p.size); p[i] = np.uint64((int(p[i]) + 1) & ((1 << 64) - 1))
+            elif m == 3:
+                i = rng.integers(0, p.size - 8); p = np.concatenate([p[:i], p[i + rng.integers(1, 8):]])
+            else:
+                p[rng.integers(0, min(64, p.size))] = np.uint64(1 << int(rng.integers(0, 64)))
+            if p.size == proof.size and (p == proof).all():
+                continue
+            with pytest.raises(dpa.DeepProveError):
+                dpa.Basefold.simple_batch_verify(1 << 11, root, nv, not ext, pt, evals, p, dpa.Transcript(b"t"))
+
+
 def test_batch_verifier_host_only_accepts_and_rejects_per_proof():
     """dp_verify_batch without a device (ctx NULL): protocol checks on host threads with the Merkle paths deferred and then
     authenticated on the same threads — a verdict per proof: the golden proofs are accepted; a flipped word inside a layer
