@@ -487,7 +487,7 @@ int32_t dp_pcs_verify(size_t max_poly_size, const uint64_t root[4], uint32_t num
     merkle_sink() = &jobs;
     try { pcs_verify(vp, c, read_point(point, num_vars), read_point(eval, 1)[0], p, t->t); } catch (...) { merkle_sink() = nullptr; throw; }
     merkle_sink() = nullptr;
-    DP_REQUIRE(merkle_jobs_ok(jobs), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
+    DP_REQUIRE(merkle_jobs_ok(jobs, verify_threads()), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
   });
 }
 static void read_claims(int32_t n, const uint64_t* points_flat, const uint64_t* evals, const std::vector<unsigned>& nvs, std::vector<std::vector<Ext>>& pts, std::vector<Ext>& evs) {
@@ -526,7 +526,7 @@ int32_t dp_pcs_batch_verify(size_t max_poly_size, const uint64_t* roots, const u
     merkle_sink() = &jobs;
     try { pcs_batch_verify(vp, vc, p, t->t); } catch (...) { merkle_sink() = nullptr; throw; }
     merkle_sink() = nullptr;
-    DP_REQUIRE(merkle_jobs_ok(jobs), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
+    DP_REQUIRE(merkle_jobs_ok(jobs, verify_threads()), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
   });
 }
 
@@ -574,7 +574,7 @@ int32_t dp_pcs_batch_verify_evals(size_t max_poly_size, const uint64_t* roots, c
     merkle_sink() = &jobs;
     try { pcs_batch_verify_evals(vp, cs, pts, evals, p, t->t); } catch (...) { merkle_sink() = nullptr; throw; }
     merkle_sink() = nullptr;
-    DP_REQUIRE(merkle_jobs_ok(jobs), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
+    DP_REQUIRE(merkle_jobs_ok(jobs, verify_threads()), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
   });
 }
 /* PCS::batch_commit / simple_batch_open / simple_batch_verify (mpcs/src/basefold.rs:356-446, 777-861, 1100-1203) */
@@ -630,7 +630,7 @@ int32_t dp_pcs_simple_batch_verify(size_t max_poly_size, const uint64_t root[4],
     merkle_sink() = &jobs;
     try { pcs_simple_batch_verify(vp, c, read_point(point, num_vars), read_point(evals, (unsigned)n), p, t ? t->t : scratch); } catch (...) { merkle_sink() = nullptr; throw; }
     merkle_sink() = nullptr;
-    DP_REQUIRE(merkle_jobs_ok(jobs), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
+    DP_REQUIRE(merkle_jobs_ok(jobs, verify_threads()), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
   });
 }
 
@@ -867,7 +867,7 @@ int32_t dp_verify(const uint64_t* vb, size_t vn, const uint64_t* pw, size_t pn, 
     merkle_sink() = &jobs;
     try { verify(vc, p, io, t); } catch (...) { merkle_sink() = nullptr; throw; }
     merkle_sink() = nullptr;
-    DP_REQUIRE(merkle_jobs_ok(jobs), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
+    DP_REQUIRE(merkle_jobs_ok(jobs, verify_threads()), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
   });
 }
 

@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 namespace dp {
 
@@ -395,13 +396,10 @@ inline bool merkle_job_ok(const MerkleJob& j) {
 }
 // all recorded paths of a proof. With the vectorised compression (p2_avx512.cpp, installed by the library on AVX-512 CPUs) eight paths
 // climb side by side, one per lane, sorted by depth so that the lanes of a group finish together; a finished lane idles masked.
-inline bool merkle_jobs_ok(const std::vector<MerkleJob>& jobs) {
-  auto c8 = p2_fast_compress8();
-  if (!c8 || jobs.size() < 8) { for (const MerkleJob& j : jobs) if (!merkle_job_ok(j)) return false; return true; }
-  std::vector<size_t> order(jobs.size());
-  for (size_t i = 0; i < order.size(); i++) order[i] = i;
-  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return jobs[a].depth > jobs[b].depth; });
-  for (size_t g = 0; g < order.size(); g += 8) {
+// groups [first, .., step `stride`) of eight paths each, `order` = the jobs by decreasing depth
+using P2Compress8 = void (*)(const u64 (*)[4], const u64 (*)[4], u64 (*)[4]);
+inline bool merkle_job_groups_ok(const std::vector<MerkleJob>& jobs, const std::vector<size_t>& order, size_t first, size_t stride, P2Compress8 c8) {
+  for (size_t g = first * 8; g < order.size(); g += stride * 8) {
     const size_t m = std::min<size_t>(8, order.size() - g);
     u64 h[8][4], l[8][4], r[8][4], o[8][4]; size_t x[8], depth[8]; size_t maxd = 0;
     for (size_t k = 0; k < 8; k++) {
@@ -423,6 +421,40 @@ inline bool merkle_jobs_ok(const std::vector<MerkleJob>& jobs) {
     for (size_t k = 0; k < m; k++) { const MerkleJob& j = jobs[order[g + k]]; for (int q = 0; q < 4; q++) if (h[k][q] != j.root.v[q]) return false; }
   }
   return true;
+}
+// `threads` > 1 (the single-proof entry points, whose caller has nothing else to do meanwhile): the groups are independent, thread t takes
+// every threads-th one. DP_VERIFY_THREADS (default: up to 8 of the machine's cores).
+inline unsigned verify_threads() {
+  static const unsigned n = [] { const char* e = getenv("DP_VERIFY_THREADS"); unsigned hw = std::thread::hardware_concurrency(); unsigned d = std::max(1u, std::min(8u, hw));
+                                 return e ? (unsigned)std::max(1, atoi(e)) : d; }();
+  return n;
+}
+inline bool merkle_jobs_ok(const std::vector<MerkleJob>& jobs, unsigned threads = 1) {
+  auto c8 = p2_fast_compress8();
+  if (threads > 1 && jobs.size() >= 4096) {
+    std::vector<char> ok(threads, 1);
+    std::vector<std::thread> th;
+    if (!c8) {
+      auto part = [&](unsigned t) { for (size_t i = t; i < jobs.size(); i += threads) if (!merkle_job_ok(jobs[i])) { ok[t] = 0; return; } };
+      for (unsigned t = 1; t < threads; t++) th.emplace_back(part, t);
+      part(0);
+    } else {
+      std::vector<size_t> order(jobs.size());
+      for (size_t i = 0; i < order.size(); i++) order[i] = i;
+      std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return jobs[a].depth > jobs[b].depth; });
+      auto part = [&](unsigned t) { ok[t] = merkle_job_groups_ok(jobs, order, t, threads, c8) ? 1 : 0; };
+      for (unsigned t = 1; t < threads; t++) th.emplace_back(part, t);
+      part(0);
+    }
+    for (auto& t : th) t.join();
+    for (char v : ok) if (!v) return false;
+    return true;
+  }
+  if (!c8 || jobs.size() < 8) { for (const MerkleJob& j : jobs) if (!merkle_job_ok(j)) return false; return true; }
+  std::vector<size_t> order(jobs.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return jobs[a].depth > jobs[b].depth; });
+  return merkle_job_groups_ok(jobs, order, 0, 1, c8);
 }
 // authenticate_merkle_path_root (merkle_tree.rs:331-420)
 inline void check_merkle_path(const CodewordQuery& q, const Digest& root) {
