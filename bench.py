@@ -142,8 +142,8 @@ def measure_workload(dpa, dev, workload, conc, steps, warmup, world, rank, dist,
     elapsed, last = timed_region(lambda xs: prover.prove_batch(xs, conc), my_inputs, batch, steps, warmup, dist,
                                  torch.cuda.synchronize if cuda else None, "cuda" if cuda else "cpu")
     step_ms = list(getattr(timed_region, "step_ms", []))
-    # EVERY proof of the last step must verify — an invalid proof voids the measurement. One proof through the single-threaded
-    # host verifier (dp_verify, the latency figure), then the whole step through dp_verify_batch: protocol checks on the host
+    # EVERY proof of the last step must verify — an invalid proof voids the measurement. One proof through the host-only
+    # verifier (dp_verify, the latency figure: protocol checks on one thread, its Merkle paths on up to 8, DP_VERIFY_THREADS), then the whole step through dp_verify_batch: protocol checks on the host
     # threads, the Merkle paths of each proof (125 000 compress() for Dense-4M) authenticated on the GPU in one launch.
     lo = (warmup + steps - 1) * batch
     checked, one, vb_ms = 0, 0.0, 0.0
