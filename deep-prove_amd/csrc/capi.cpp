@@ -858,8 +858,12 @@ int32_t dp_model_verifier_blob(const dp_model* m, uint64_t** words, size_t* nwor
 int32_t dp_verify(const uint64_t* vb, size_t vn, const uint64_t* pw, size_t pn, const int64_t* input, size_t ninput, const int64_t* output, size_t noutput) {
   return guard([&] {
     DP_REQUIRE(vb && pw && input && output, DP_ERR_ARG, "bad arguments");
+    const bool timing = getenv("DP_TIMING") && atoi(getenv("DP_TIMING"));
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) { if (!timing) return; auto t1 = std::chrono::steady_clock::now(); fprintf(stderr, "[dp timing] dp_verify: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count()); t0 = t1; };
     VerifierContext vc = vctx_from_words(vb, vn);
     Proof p = deserialize_proof(pw, pn);
+    lap("parse");
     IO io; io.input.assign(input, input + ninput); io.output.assign(output, output + noutput);
     Transcript t = default_transcript();
     // the Merkle paths are recorded while the protocol checks run and authenticated together afterwards (eight side by side on AVX-512 CPUs)
@@ -867,7 +871,9 @@ int32_t dp_verify(const uint64_t* vb, size_t vn, const uint64_t* pw, size_t pn, 
     merkle_sink() = &jobs;
     try { verify(vc, p, io, t); } catch (...) { merkle_sink() = nullptr; throw; }
     merkle_sink() = nullptr;
+    lap("protocol checks");
     DP_REQUIRE(merkle_jobs_ok(jobs, verify_threads()), DP_ERR_VERIFY, "merkle path does not authenticate against the root");
+    lap("merkle paths");
   });
 }
 
