@@ -476,7 +476,7 @@ int32_t dp_pcs_open(dp_ctx* ctx, const dp_commit* comm, const uint64_t* point, u
 int32_t dp_pcs_verify(size_t max_poly_size, const uint64_t root[4], uint32_t num_vars, int32_t is_base, const uint64_t* point, const uint64_t eval[2],
                       const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t) {
   return guard([&] {
-    DP_REQUIRE(root && point && eval && proof_words && is_pow2(max_poly_size), DP_ERR_ARG, "bad arguments");
+    DP_REQUIRE(root && point && eval && proof_words && num_vars <= 64 && is_pow2(max_poly_size), DP_ERR_ARG, "bad arguments");
     Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = root[k]; c.num_vars = num_vars; c.is_base = is_base != 0;
     Reader r(proof_words, proof_nwords); BasefoldProof p = r.basefold();
     DP_REQUIRE(r.pos == proof_nwords, DP_ERR_ARG, "proof stream: trailing words");
@@ -492,7 +492,7 @@ int32_t dp_pcs_verify(size_t max_poly_size, const uint64_t root[4], uint32_t num
 }
 static void read_claims(int32_t n, const uint64_t* points_flat, const uint64_t* evals, const std::vector<unsigned>& nvs, std::vector<std::vector<Ext>>& pts, std::vector<Ext>& evs) {
   size_t off = 0;
-  for (int i = 0; i < n; i++) { pts.push_back(read_point(points_flat + off, nvs[i])); off += 2 * (size_t)nvs[i]; evs.push_back(read_point(evals + 2 * i, 1)[0]); }
+  for (int i = 0; i < n; i++) { DP_REQUIRE(nvs[i] <= 64, DP_ERR_ARG, "point too long"); pts.push_back(read_point(points_flat + off, nvs[i])); off += 2 * (size_t)nvs[i]; evs.push_back(read_point(evals + 2 * i, 1)[0]); }
 }
 int32_t dp_pcs_batch_open(dp_ctx* ctx, const dp_commit* const* comms, int32_t n, const uint64_t* points_flat, const uint64_t* evals,
                           dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords) {
@@ -619,7 +619,7 @@ int32_t dp_pcs_simple_batch_open(dp_ctx* ctx, const dp_batch_commit* comm, const
 int32_t dp_pcs_simple_batch_verify(size_t max_poly_size, const uint64_t root[4], uint32_t num_vars, int32_t is_base, const uint64_t* point, const uint64_t* evals, int32_t n,
                                    const uint64_t* proof_words, size_t proof_nwords, dp_transcript* t) {
   return guard([&] {
-    DP_REQUIRE(root && point && evals && n >= 1 && n <= (1 << 20) && proof_words && is_pow2(max_poly_size), DP_ERR_ARG, "bad arguments");
+    DP_REQUIRE(root && point && evals && n >= 1 && n <= (1 << 20) && num_vars <= 64 && proof_words && is_pow2(max_poly_size), DP_ERR_ARG, "bad arguments");
     Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = root[k]; c.num_vars = num_vars; c.is_base = is_base != 0;
     Reader r(proof_words, proof_nwords); BasefoldProof p = r.basefold();
     DP_REQUIRE(r.pos == proof_nwords, DP_ERR_ARG, "proof stream: trailing words");
