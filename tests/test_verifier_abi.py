@@ -340,7 +340,29 @@ def test_batch_verifier_host_only_accepts_and_rejects_per_proof():
 def test_mutated_proof_streams_never_verify_and_never_crash():
     """dp_verify on 1 500 mutated golden proofs (MLP, CNN, MatMul models): flipped bits, out-of-range words, truncations, cut and duplicated
     ranges. Every word of a stream is bound: the only accepted streams are those a mutation left identical to the proof (booleans and
-    narrowed values have one encoding; logup output claims sit at the verifier's point; sumcheck points equal the challenges)"""
+    narrowed values have one encoding; logup output claims sit at the verifier's point; sumcheck points equal the challenges; trivially
+    opened commitments describe their table; opened pairs carry their LEFT index — tools/flip_sweep.py is the exhaustive counterpart,
+    profiles/r02_flip_sweep.txt its result)"""
     import subprocess, sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "support", "fuzz_proof.py"), "5", "1500"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "accepted-but-different 0" in r.stdout, r.stdout[-800:] + r.stderr[-1500:]
+
+
+def test_single_bit_flips_of_every_word_in_two_windows_are_rejected():
+    """the exhaustive sweep of tools/flip_sweep.py on two windows of the golden MLP proof: words 0..700 (layer proofs: every kind of field a
+    step holds, among them the `num_vars` / `is_base` words of trivially opened witness commitments, which the reference never reads) and
+    words 4100..4700 (the first queries of the batch opening: pair values, pair indices, whose lowest bit the reference ignores, path
+    digests): no flipped stream verifies"""
+    import deep_prove_amd as dpa
+    g = np.load(os.path.join(ROOT, "tests", "golden", "mlp_w8.npz"))
+    p0 = g["proof"]
+    dpa.verify(g["verifier_blob"], p0, g["input"], g["output"])
+    accepted = []
+    for lo, hi in ((0, 700), (4100, 4700)):
+        for i in range(lo, hi):
+            p = p0.copy(); p[i] ^= np.uint64(1)
+            try:
+                dpa.verify(g["verifier_blob"], p, g["input"], g["output"]); accepted.append(i)
+            except dpa.DeepProveError:
+                pass
+    assert accepted == []
