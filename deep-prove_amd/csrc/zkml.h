@@ -1383,7 +1383,9 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
   DP_REQUIRE(trivial_claims.size() == proof.trivial_proofs.size(), DP_ERR_VERIFY, "number of trivial proofs");
   for (size_t i = 0; i < trivial_claims.size(); i++) pcs_verify_trivial(trivial_claims[i].comm, trivial_claims[i].point, trivial_claims[i].eval, proof.trivial_proofs[i]);
   VerifierParams vp; vp.full_log = vc.full_log;
-  pcs_batch_verify(vp, claims, proof.batch_proof, t);
+  { const bool timing = getenv("DP_TIMING") && atoi(getenv("DP_TIMING")); auto t0 = std::chrono::steady_clock::now();
+    pcs_batch_verify(vp, claims, proof.batch_proof, t);
+    if (timing) fprintf(stderr, "[dp timing] verify: batch opening (without its Merkle paths) %8.3f ms, %zu claims\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), claims.size()); }
   // global logup check (verifier.rs:273-291)
   Ext fn = ex_zero(), fd = ex_one();
   for (size_t i = 0; i < nums.size(); i++) { fn = ex_add(ex_mul(fn, dens[i]), ex_mul(nums[i], fd)); fd = ex_mul(fd, dens[i]); }
