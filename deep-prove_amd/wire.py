@@ -171,10 +171,17 @@ def _cq(q, c):
     return {"query": {"codepoints": pair, "index": q["index"]}, "merkle_path": {"inner": [_digest(d, c) for d in q["path"]], "_phantom": Phantom()}}
 
 
-def _basefold(p, c):
+def _basefold(p, c, simple_batch=False):
     trivial = bool(p["trivial_proof"])
     if trivial or not p["queries"]:
         qr = {"Single": {"inner": []}}  # BasefoldProof::trivial (structure.rs:352-363)
+    elif simple_batch:  # PCS::simple_batch_open (basefold.rs:846-860): one row pair (a pair per polynomial) and ONE Merkle path per query
+        def row(q):     # SimpleBatchCommitmentSingleQueryResultWithMerklePath {query: {leaves: SimpleBatchLeavesPair, index}, merkle_path} (query_phase.rs:1328-1383, 556-566)
+            cs = q["commitments_query"]
+            assert all(not x["path"] and x["index"] == cs[0]["index"] and x["is_ext"] == cs[0]["is_ext"] for x in cs[1:]), "not a simple-batch opening"
+            leaves = {"Ext": [[_e(x["pair"][0], c), _e(x["pair"][1], c)] for x in cs]} if cs[0]["is_ext"] else {"Base": [[_f(x["pair"][0], c), _f(x["pair"][1], c)] for x in cs]}
+            return {"query": {"leaves": leaves, "index": cs[0]["index"]}, "merkle_path": {"inner": [_digest(d, c) for d in cs[0]["path"]], "_phantom": Phantom()}}
+        qr = {"SimpleBatched": {"inner": [[q["index"], {"oracle_query": {"inner": [_cq(x, c) for x in q["oracle_query"]]}, "commitment_query": row(q)}] for q in p["queries"]]}}
     elif not p["sumcheck_proof"]:  # PCS::open of one polynomial (basefold.rs:532-544): no batch sumcheck, one commitment pair per query
         qr = {"Single": {"inner": [[q["index"], {"oracle_query": {"inner": [_cq(x, c) for x in q["oracle_query"]]},
                                                  "commitment_query": _cq(q["commitments_query"][0], c)}] for q in p["queries"]]}}
@@ -287,6 +294,28 @@ def to_rmp(proof_words, conv=Conventions):
     return b"".join(out)
 
 
+def pcs_proof_to_rmp(proof_words, simple_batch=False, conv=Conventions):
+    """stream of ONE Basefold proof (dp_pcs_open / dp_pcs_batch_open{,_evals} / dp_pcs_simple_batch_open) -> bytes of
+    rmp_serde::to_vec_named(&BasefoldProof) (structure.rs:334-345). The canonical stream carries no variant tag: Batched is recognised by its
+    batch sumcheck, Single by its absence; a simple-batch opening of ONE polynomial has the same stream as a Single one, so the caller says
+    which of the two it holds (`simple_batch`)."""
+    r = _Reader(proof_words)
+    p = r.basefold()
+    assert r.p == len(r.w), "trailing words"
+    out = []
+    _pack(_basefold(p, conv, simple_batch), out, conv)
+    return b"".join(out)
+
+
+def pcs_proof_from_rmp(data, conv=Conventions):
+    """bytes of rmp_serde::to_vec_named(&BasefoldProof) -> the canonical stream of that proof"""
+    model, end = _unpack(data, 0)
+    assert end == len(data), "trailing bytes"
+    w = _Writer(conv)
+    w.basefold(model)
+    return np.array(w.w, dtype=np.uint64)
+
+
 def _unpack(b, p):
     t = b[p]
     if t < 0x80:
@@ -384,6 +413,13 @@ class _Writer:
         qr = p["query_result_with_merkle_path"]
         if "Batched" in qr:
             qs = qr["Batched"]["inner"]
+        elif "SimpleBatched" in qr:  # one stream entry per polynomial, all with the row pair's index, the path on the first
+            qs = []
+            for idx, q in qr["SimpleBatched"]["inner"]:
+                cq = q["commitment_query"]
+                (kind, pairs), = cq["query"]["leaves"].items()
+                ent = [{"query": {"codepoints": {kind: pr}, "index": cq["query"]["index"]}, "merkle_path": {"inner": cq["merkle_path"]["inner"] if k == 0 else []}} for k, pr in enumerate(pairs)]
+                qs.append([idx, {"oracle_query": q["oracle_query"], "commitments_query": {"inner": ent}}])
         else:  # Single: the canonical stream keeps the one commitment pair as a list of one
             qs = [[idx, {"oracle_query": q["oracle_query"], "commitments_query": {"inner": [q["commitment_query"]]}}] for idx, q in qr["Single"]["inner"]]
         self.w.append(len(qs))

@@ -109,3 +109,46 @@ def test_add_step_in_the_wire_format(oracle):
     assert len(adds) == 1 and list(adds[0]) == ["left_eval", "right_eval"]
     back = wire.from_rmp(data)
     assert wire.stream_equal_modulo_skipped(back, p) and wire.to_rmp(back) == data
+
+
+def test_standalone_pcs_proofs_all_three_query_variants(oracle):
+    """ProofQueriesResultWithMerklePath::{Single, Batched, SimpleBatched} (mpcs/src/basefold/structure.rs:292-300) for proofs that leave the PCS
+    entry points on their own: names and nesting as the serde derives give them (query_phase.rs:556-566, 1328-1383, 1419-1440, 1545-1551),
+    read back by an independent MessagePack decoder, and encode -> decode reproduces the stream"""
+    from deep_prove_amd import wire
+    P = 0xFFFFFFFF00000001
+    rng = np.random.default_rng(12)
+    re = lambda: (int(rng.integers(0, P, dtype=np.uint64)), int(rng.integers(0, P, dtype=np.uint64)))
+    for nv, ext, k in ((9, False, 3), (8, True, 2), (9, False, 1), (5, True, 3)):
+        polys = [rng.integers(0, P, size=(2 if ext else 1) << nv, dtype=np.uint64) for _ in range(k)]
+        pt = [re() for _ in range(nv)]
+        _, proof = oracle.pcs_simple_batch_open(1 << 10, polys, ext, pt, oracle.transcript(b"t"))
+        data = wire.pcs_proof_to_rmp(proof, simple_batch=True)
+        m = msgpack.unpackb(data, raw=False, strict_map_key=False)
+        assert list(m) == ["sumcheck_messages", "roots", "final_message", "query_result_with_merkle_path", "sumcheck_proof", "trivial_proof"]
+        (variant, q), = m["query_result_with_merkle_path"].items()
+        if nv <= 7:  # BasefoldProof::trivial: no queries, the k tables travel
+            assert variant == "Single" and q["inner"] == [] and len(m["trivial_proof"]) == k and m["sumcheck_proof"] is None
+        else:
+            assert variant == "SimpleBatched" and len(q["inner"]) == 200 and m["sumcheck_proof"] is None
+            idx, one = q["inner"][0]
+            assert list(one) == ["oracle_query", "commitment_query"] and list(one["commitment_query"]) == ["query", "merkle_path"]
+            assert list(one["commitment_query"]["query"]) == ["leaves", "index"]
+            (ft, pairs), = one["commitment_query"]["query"]["leaves"].items()
+            assert ft == ("Ext" if ext else "Base") and len(pairs) == k and all(len(pr) == 2 for pr in pairs)
+            assert len(one["commitment_query"]["merkle_path"]["inner"]) == nv + 1 - 1  # log2(codeword) - 1 digests: the row pair's sibling is not sent
+        back = wire.pcs_proof_from_rmp(data)
+        assert back.size == proof.size and (back == proof).all()
+    # Single (PCS::open) and Batched (PCS::batch_open over an Evaluation list)
+    w = rng.integers(0, P, size=1 << 9, dtype=np.uint64)
+    pt = [re() for _ in range(9)]
+    single = oracle.pcs_open(1 << 10, w, False, pt, oracle.transcript(b"t"))
+    m = msgpack.unpackb(wire.pcs_proof_to_rmp(single), raw=False, strict_map_key=False)
+    assert list(m["query_result_with_merkle_path"]) == ["Single"] and list(m["query_result_with_merkle_path"]["Single"]["inner"][0][1]) == ["oracle_query", "commitment_query"]
+    assert (wire.pcs_proof_from_rmp(wire.pcs_proof_to_rmp(single)) == single).all()
+    w2 = rng.integers(0, P, size=1 << 9, dtype=np.uint64)
+    evals = [(0, 0, oracle.mle_eval(w, False, pt)), (1, 0, oracle.mle_eval(w2, False, pt))]
+    batched = oracle.pcs_batch_open_evals(1 << 10, [w, w2], [False, False], [pt], evals, oracle.transcript(b"t"))
+    m = msgpack.unpackb(wire.pcs_proof_to_rmp(batched), raw=False, strict_map_key=False)
+    assert list(m["query_result_with_merkle_path"]) == ["Batched"] and len(m["sumcheck_proof"]["rounds"]) == 9
+    assert (wire.pcs_proof_from_rmp(wire.pcs_proof_to_rmp(batched)) == batched).all()
