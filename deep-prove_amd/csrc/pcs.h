@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <system_error>
 #include <thread>
 
 namespace dp {
@@ -436,14 +437,14 @@ inline bool merkle_jobs_ok(const std::vector<MerkleJob>& jobs, unsigned threads 
     std::vector<std::thread> th;
     if (!c8) {
       auto part = [&](unsigned t) { for (size_t i = t; i < jobs.size(); i += threads) if (!merkle_job_ok(jobs[i])) { ok[t] = 0; return; } };
-      for (unsigned t = 1; t < threads; t++) th.emplace_back(part, t);
+      for (unsigned t = 1; t < threads; t++) { try { th.emplace_back(part, t); } catch (const std::system_error&) { part(t); } }  // (no thread to be had: the share is done here)
       part(0);
     } else {
       std::vector<size_t> order(jobs.size());
       for (size_t i = 0; i < order.size(); i++) order[i] = i;
       std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return jobs[a].depth > jobs[b].depth; });
       auto part = [&](unsigned t) { ok[t] = merkle_job_groups_ok(jobs, order, t, threads, c8) ? 1 : 0; };
-      for (unsigned t = 1; t < threads; t++) th.emplace_back(part, t);
+      for (unsigned t = 1; t < threads; t++) { try { th.emplace_back(part, t); } catch (const std::system_error&) { part(t); } }
       part(0);
     }
     for (auto& t : th) t.join();
