@@ -62,29 +62,42 @@ static int32_t guard(F f) {
 // library returned — as the header has always said.
 namespace {
 struct OutHeader { uint64_t magic, cap, pad0, pad1; };
-constexpr uint64_t OUT_MAGIC = 0x44504F55544F4B31ULL;
+constexpr uint64_t OUT_MAGIC = 0x44504F55544F4B31ULL, OUT_IDLE_MAGIC = 0x44504F5554465245ULL;  // handed out / idle in the pool
 struct OutPool {
   std::mutex mu;
   std::multimap<size_t, void*> idle;  // capacity -> block (header address)
-  size_t idle_bytes = 0;
+  size_t idle_bytes = 0, out_bytes = 0, out_peak = 0;
+  // idle blocks kept: at most what was ever handed out at once (one batch of proofs comes back and is handed out again), at least
+  // 1 GB, never more than DP_OUT_POOL_BYTES (default 24 GB)
   size_t limit = [] { const char* e = getenv("DP_OUT_POOL_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t(24) << 30); }();
+  size_t keep() const { return std::min(limit, std::max<size_t>(size_t(1) << 30, out_peak)); }
   void* take(size_t bytes) {
     const size_t cap = (std::max<size_t>(bytes, 8) + 65535) & ~size_t(65535);
     {
       std::lock_guard<std::mutex> g(mu);
       auto it = idle.lower_bound(cap);
-      if (it != idle.end() && it->first <= cap + cap / 4) { void* h = it->second; idle_bytes -= it->first; idle.erase(it); return (char*)h + sizeof(OutHeader); }
+      if (it != idle.end() && it->first <= cap + cap / 4) {
+        OutHeader* h = (OutHeader*)it->second; idle_bytes -= it->first; idle.erase(it);
+        h->magic = OUT_MAGIC; out_bytes += h->cap; out_peak = std::max(out_peak, out_bytes);
+        return (char*)h + sizeof(OutHeader);
+      }
     }
     OutHeader* h = (OutHeader*)malloc(sizeof(OutHeader) + cap);
     if (!h) throw std::bad_alloc();
     h->magic = OUT_MAGIC; h->cap = cap; h->pad0 = h->pad1 = 0;
+    { std::lock_guard<std::mutex> g(mu); out_bytes += cap; out_peak = std::max(out_peak, out_bytes); }
     return (char*)h + sizeof(OutHeader);
   }
-  void give(void* p) {
+  // false: not a block this library handed out (or one already given back) — nothing is touched
+  bool give(void* p) {
     OutHeader* h = (OutHeader*)((char*)p - sizeof(OutHeader));
     std::lock_guard<std::mutex> g(mu);
-    if (idle_bytes + h->cap > limit) { h->magic = 0; free(h); return; }
+    if (h->magic != OUT_MAGIC) return false;
+    out_bytes -= std::min<size_t>(out_bytes, h->cap);
+    if (idle_bytes + h->cap > keep()) { h->magic = 0; free(h); return true; }
+    h->magic = OUT_IDLE_MAGIC;
     idle.emplace((size_t)h->cap, (void*)h); idle_bytes += h->cap;
+    return true;
   }
 };
 OutPool& out_pool() { static OutPool* p = new OutPool(); return *p; }  // (leaked on purpose: callers may free after static destruction)
@@ -104,7 +117,13 @@ static std::vector<Ext> read_point(const uint64_t* w, size_t k) {
 extern "C" {
 
 const char* dp_last_error(void) { return g_err.c_str(); }
-void dp_free(void* p) { if (p) out_pool().give(p); }  // every buffer the library hands out comes from out_alloc (copy_out, dp_profile_report)
+void dp_free(void* p) {
+  if (!p) return;
+  if (!out_pool().give(p)) {  // a foreign pointer or a double free: refuse loudly, corrupt nothing
+    g_err = "dp_free: not a live buffer of this library (foreign pointer or double free) — ignored";
+    fprintf(stderr, "[deep-prove] %s\n", g_err.c_str());
+  }
+}  // every buffer the library hands out comes from out_alloc (copy_out, dp_profile_report)
 
 int32_t dp_ctx_create(int32_t device_id, dp_ctx** out) {
   return guard([&] { DP_REQUIRE(out, DP_ERR_ARG, "null out"); Dev* d = make_hip_dev(device_id); dp_ctx* c = new dp_ctx(); c->dev = d; c->device_id = device_id; *out = c; });
@@ -314,6 +333,13 @@ int32_t dp_sumcheck_prove_sharded_local(dp_ctx* const* ctxs, int32_t world, uint
     DP_REQUIRE(ctxs && tables && term_degree && term_tables && term_coeffs && transcripts && proof_words && proof_nwords && world >= 1 && (world & (world - 1)) == 0 && num_vars < 48, DP_ERR_ARG, "bad arguments");
     unsigned k = 0; while ((1 << k) < world) k++;
     DP_REQUIRE(num_vars > k, DP_ERR_SHAPE, "more ranks than table entries");
+    // every rank's inputs are checked BEFORE a thread exists: a rank that cannot start must not leave the others in an exchange
+    for (int g = 0; g < world; g++) {
+      DP_REQUIRE(ctxs[g] && transcripts[g], DP_ERR_ARG, "null context / transcript");
+      DevVP probe(num_vars - k);
+      read_terms(probe, tables + (size_t)g * ntables, ntables, term_degree, term_tables, nterms, term_coeffs);
+      for (const DBuf& b : probe.tabs) DP_REQUIRE(b.n == (size_t(1) << (num_vars - k)), DP_ERR_SHAPE, "sharded sumcheck: every local table has 2^(num_vars - log2 world) entries");
+    }
     ThreadExchangeHub hub(world);
     std::vector<SumcheckOut> outs(world);
     std::vector<std::string> errs(world);
@@ -326,10 +352,11 @@ int32_t dp_sumcheck_prove_sharded_local(dp_ctx* const* ctxs, int32_t world, uint
         read_terms(vp, tables + (size_t)g * ntables, ntables, term_degree, term_tables, nterms, term_coeffs);
         ThreadExchange xch(hub, g);
         outs[g] = sumcheck_prove_sharded(*ctxs[g]->dev, xch, num_vars, vp, transcripts[g]->t);
-      } catch (const std::exception& e) { errs[g] = e.what(); if (errs[g].empty()) errs[g] = "error"; }
+      } catch (const std::exception& e) { errs[g] = e.what(); if (errs[g].empty()) errs[g] = "error"; hub.abort(); }  // wakes the ranks waiting for this one
     });
     for (auto& x : th) x.join();
-    for (int g = 0; g < world; g++) if (!errs[g].empty()) throw DpError(DP_ERR_HIP, "rank " + std::to_string(g) + ": " + errs[g] + " (a failed rank leaves the others waiting only in real multi-process runs; here all ranks were joined)");
+    for (int g = 0; g < world; g++) if (!errs[g].empty() && errs[g].find("another rank failed") == std::string::npos) throw DpError(DP_ERR_HIP, "rank " + std::to_string(g) + ": " + errs[g]);
+    for (int g = 0; g < world; g++) if (!errs[g].empty()) throw DpError(DP_ERR_HIP, "rank " + std::to_string(g) + ": " + errs[g]);
     Writer w0; w0.iop(outs[0].proof);
     for (int g = 1; g < world; g++) { Writer w; w.iop(outs[g].proof); DP_REQUIRE(w.w == w0.w, DP_ERR_HIP, "ranks produced different proofs"); }
     sharded_out(outs[0], (size_t)ntables, proof_words, proof_nwords, finals);
@@ -809,6 +836,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
       FiberSched sched;
       for (size_t wi = 0; wi < nw; wi++) if ((nco ? wi % nco : wi) % nth == ti) fiber_spawn(sched, [&work, wi] { work(wi); });
       fiber_run_all(sched);
+      for (auto& f : sched.fibers) if (f->failed) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_ARG; err = "an exception escaped a proof worker's fiber"; } }
     };
     std::vector<std::thread> th;
     for (size_t ti = 1; ti < nth; ti++) th.emplace_back(run_thread, ti);

@@ -1,6 +1,7 @@
 // Host <-> device interface of k_commit_tail (hip_dev.hip): the last rounds of the Basefold commit phase in one launch
 // (Dev::commit_tail). Shared with the kernel-emulation test.
 #pragma once
+#include <algorithm>
 #include "dev.h"
 #include <cstdlib>
 #include <cstring>
@@ -17,7 +18,7 @@ constexpr size_t COMMIT_TAIL_MAX_N = 4096;      // the tail takes over when the 
 // DP_COMMIT_TAIL_MAX_N overrides both.
 constexpr size_t COMMIT_TAIL_MAX_N_THROUGHPUT = 16384;
 inline size_t commit_tail_max_n(bool throughput_mode) {
-  static const size_t env = [] { const char* e = getenv("DP_COMMIT_TAIL_MAX_N"); size_t x = e ? (size_t)strtoull(e, nullptr, 10) : 0; return x < 2 ? size_t(0) : x; }();
+  static const size_t env = [] { const char* e = getenv("DP_COMMIT_TAIL_MAX_N"); size_t x = e ? (size_t)strtoull(e, nullptr, 10) : 0; return x < 2 ? size_t(0) : std::min<size_t>(x, size_t(1) << 20); }();  // (clamped: one workgroup would grind through anything larger for seconds)
   return env ? env : throughput_mode ? COMMIT_TAIL_MAX_N_THROUGHPUT : COMMIT_TAIL_MAX_N;
 }
 

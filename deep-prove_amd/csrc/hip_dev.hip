@@ -38,7 +38,14 @@ __constant__ u64 c_rc[DP_POSEIDON2_RC_WORDS];
 __constant__ unsigned long long c_poll_timeout_ticks = 2000000000ull;  // 20 s of the 100 MHz constant clock (DP_POLL_TIMEOUT_S)
 __device__ __forceinline__ unsigned long long dp_realtime() { return __builtin_amdgcn_s_memrealtime(); }
 __constant__ int c_poll_sleep = 1;
-__constant__ int c_dbg_skip_hash = 0;  // DP_DEBUG_SKIP_HASH=1: TIMING EXPERIMENT ONLY — wide Merkle layers copy instead of hashing (proofs do not verify)  // units of s_sleep(4) (~0.1 us) between two polls of the host mailbox (DP_POLL_SLEEP)
+// DIAGNOSTIC BUILDS ONLY (DP_HIPCC_EXTRA=-DDP_DIAG_SKIP_HASH, then DP_DEBUG_SKIP_HASH=1 at run time): wide Merkle layers copy instead of
+// hashing — a timing experiment whose proofs do not verify. The release library does not contain the switch.
+#ifdef DP_DIAG_SKIP_HASH
+__constant__ int c_dbg_skip_hash = 0;
+#define DP_SKIP_HASH_ON() (c_dbg_skip_hash)
+#else
+#define DP_SKIP_HASH_ON() (false)
+#endif
 
 constexpr int TPB = 256;
 constexpr int MAX_TABS = 32;
@@ -571,7 +578,7 @@ KBODY k_merkle_leaves(const void* leaves, u64* nodes, size_t npairs) {
 }
 // the node hash of the one-node-per-lane Merkle kernels
 __device__ __forceinline__ void merkle_compress(const u64* x, const u64* y, u64* o) {
-  if (c_dbg_skip_hash) { for (int k = 0; k < 4; k++) o[k] = x[k] ^ y[k]; return; }
+  if (DP_SKIP_HASH_ON()) { for (int k = 0; k < 4; k++) o[k] = x[k] ^ y[k]; return; }
   p2f::compress(x, y, o, c_rc);  // poseidon2_fast.h: the same permutation with wide accumulation and any-representative words (1.33x, tools/p2bench.hip)
 }
 // one Poseidon2 compress (2 permutations) per lane; state held in 8 VGPR pairs, round constants in constant memory
@@ -828,7 +835,7 @@ __device__ __forceinline__ void p2l_compress(const u64* in, u64* out, int lane) 
 KBODY k_merkle_layer_lp(const u64* in, u64* out, size_t cnt) {
   size_t g = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 3;
   size_t stride = ((size_t)gridDim.x * blockDim.x) >> 3;
-  if (c_dbg_skip_hash) { for (; g < cnt; g += stride) if ((threadIdx.x & 7) < 4) out[4 * g + (threadIdx.x & 7)] = in[8 * g + (threadIdx.x & 7)]; return; }
+  if (DP_SKIP_HASH_ON()) { for (; g < cnt; g += stride) if ((threadIdx.x & 7) < 4) out[4 * g + (threadIdx.x & 7)] = in[8 * g + (threadIdx.x & 7)]; return; }
   for (; g < cnt; g += stride) p2l_compress(in + 8 * g, out + 4 * g, threadIdx.x & 63);
 }
 // verifier: one Merkle path per lane, from the leaf-pair digest up to the root (authenticate_merkle_path_root,
@@ -2709,10 +2716,12 @@ class HipDev : public Dev {
   bool prof_ = false;
   double nb_ = 0;  // algorithmic bytes of the next launch (SURVEY.md 8d ledger), consumed by prof_begin
   std::vector<ProfRec> recs_;
+  std::vector<hipEvent_t> prof_pool_;  // events of earlier profiled runs, reused: creating two events per launch between the launches is what a cold profiled run paid for
+  hipEvent_t prof_event_() { hipEvent_t e; if (!prof_pool_.empty()) { e = prof_pool_.back(); prof_pool_.pop_back(); return e; } hipEventCreate(&e); return e; }
   void prof_begin(const char* name) {
     if (!prof_) { nb_ = 0; return; }
     ProfRec r; r.name = name; r.bytes = nb_; nb_ = 0;
-    hipEventCreate(&r.a); hipEventCreate(&r.b);
+    r.a = prof_event_(); r.b = prof_event_();
     hipEventRecord(r.a, s_);
     recs_.push_back(r);
   }
@@ -2998,7 +3007,9 @@ class HipDev : public Dev {
         ex[((size_t)k * (SC_MAXK + 1) + at) * (SC_MAXK + 1) + i] = extrapolation_coeffs(k, at)[i];
       HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_extrap), ex.data(), ex.size() * 8)); }
     { double ts = getenv("DP_POLL_TIMEOUT_S") ? std::max(0.001, atof(getenv("DP_POLL_TIMEOUT_S"))) : 20.0; unsigned long long tk = (unsigned long long)(ts * 1e8); HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_poll_timeout_ticks), &tk, sizeof(tk))); }
+#ifdef DP_DIAG_SKIP_HASH
     { int sk = getenv("DP_DEBUG_SKIP_HASH") ? atoi(getenv("DP_DEBUG_SKIP_HASH")) : 0; if (sk) HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_dbg_skip_hash), &sk, sizeof(int))); }
+#endif
     { int ps = getenv("DP_POLL_SLEEP") ? std::max(0, atoi(getenv("DP_POLL_SLEEP"))) : 1; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_poll_sleep), &ps, sizeof(int))); }
     DP_SET_LDS_ONE((k_sc_persist_lds<false>), 1024, (int)SC_LDS_MAX);
     DP_SET_LDS_ONE((k_sc_persist_lds<true>), 1024, (int)SC_LDS_MAX);
@@ -3025,7 +3036,7 @@ class HipDev : public Dev {
     if (arena_) hipFree(arena_);
     if (dres_) hipFree(dres_);
     if (fused_ticket_) hipFree(fused_ticket_);
-    if (sp_slot_) { sponge_disarm_(); sp_slot_->req = sp_slot_->rep = nullptr; }
+    if (sp_slot_) { sponge_disarm_(); sponge_slot_free(sp_slot_); sp_slot_ = nullptr; }
     if (hsp_) hipHostFree(hsp_);
     if (hres_) hipHostFree(hres_);
     if (hstage_) hipHostFree(hstage_);
@@ -3038,9 +3049,9 @@ class HipDev : public Dev {
   bool merkle_paths_check(const u64* leaf, const u64* root, const u64* x, const u64* path_off, const u64* depth, size_t n, const u64* pool, size_t pool_digests, size_t* first_bad) override {
     if (!n) return true;
     DP_REQUIRE(!co_, DP_ERR_ARG, "merkle_paths_check: not from inside a cohort");
-    const size_t mk = mark();
     std::vector<u64> meta(3 * n);
     for (size_t j = 0; j < n; j++) { DP_REQUIRE(path_off[j] + depth[j] <= pool_digests, DP_ERR_ARG, "merkle_paths_check: path outside the pool"); meta[3 * j] = x[j]; meta[3 * j + 1] = path_off[j]; meta[3 * j + 2] = depth[j]; }
+    struct ArenaMark { HipDev* d; size_t mk; ~ArenaMark() { d->release(mk); } } guard_{this, mark()};  // released on every exit: an adversarial proof must not leak the arena
     DBuf dl = alloc(4 * n, false), dr = alloc(4 * n, false), dm = alloc(3 * n, false), dp = alloc(std::max<size_t>(4 * pool_digests, 4), false), db = alloc(2, false);
     upload(dl, leaf); upload(dr, root); upload(dm, meta.data());
     if (pool_digests) upload(dp, pool);
@@ -3049,7 +3060,6 @@ class HipDev : public Dev {
     nb_ = 96.0 * (double)pool_digests; DPL(k_merkle_paths, dim3(grid_for(n, 4096)), dim3(TPB), (const u64*)dl.p, (const u64*)dr.p, (const u64*)dm.p, (const u64*)dp.p, n, (unsigned long long*)db.p);
     u64 res[2];
     download(db, res);
-    release(mk);
     if (res[0] && first_bad) *first_bad = (size_t)res[1];
     return res[0] == 0;
   }
@@ -3096,8 +3106,9 @@ class HipDev : public Dev {
   // per-kernel HIP-event timing on the launch stream (bench.py roofline). report: name -> (launches, total ms, total bytes)
   void profile_enable(bool on) {
     hipStreamSynchronize(s_);
-    for (auto& r : recs_) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+    for (auto& r : recs_) { prof_pool_.push_back(r.a); prof_pool_.push_back(r.b); }
     recs_.clear();
+    if (!on) { for (auto e : prof_pool_) hipEventDestroy(e); prof_pool_.clear(); }
     prof_ = on;
   }
   std::string profile_report() {

@@ -458,7 +458,10 @@ inline bool merkle_jobs_ok(const std::vector<MerkleJob>& jobs, unsigned threads 
   return merkle_job_groups_ok(jobs, order, 0, 1, c8);
 }
 // authenticate_merkle_path_root (merkle_tree.rs:331-420)
-inline void check_merkle_path(const CodewordQuery& q, const Digest& root) {
+// `depth`: the height the tree of this codeword must have — 2^depth leaf pairs (a proof that carries a shorter or longer path would
+// otherwise pick its own tree size; the reference takes the path as it comes)
+inline void check_merkle_path(const CodewordQuery& q, const Digest& root, size_t depth) {
+  DP_REQUIRE(q.path.size() == depth, DP_ERR_VERIFY, "merkle path: wrong length for the size of this codeword");
   if (std::vector<MerkleJob>* sink = merkle_sink()) { sink->push_back({host_leaf_pair_digest(q.is_ext, q.left, q.right), q.index >> 1, q.path.data(), q.path.size(), root}); return; }
   Digest h = host_leaf_pair_digest(q.is_ext, q.left, q.right);
   size_t x = q.index >> 1;
@@ -593,7 +596,7 @@ inline void pcs_verify_core(const VerifierParams& vp, const Commitment& comm, co
     const size_t index = qidx[q];
     DP_REQUIRE(bq.index == index, DP_ERR_VERIFY, "verify: query index mismatch");
     DP_REQUIRE(bq.oracle_query.size() == proof.roots.size() && bq.commitments_query.size() == np, DP_ERR_VERIFY, "verify: query shape");
-    for (size_t k = 0; k < bq.oracle_query.size(); k++) check_merkle_path(bq.oracle_query[k], proof.roots[k]);
+    for (size_t k = 0; k < bq.oracle_query.size(); k++) check_merkle_path(bq.oracle_query[k], proof.roots[k], num_vars + PCS_RATE_LOG - k - 2);
     size_t right_index = index | 1, left_index = right_index - 1;
     Ext cur_l = ex_zero(), cur_r = ex_zero();
     for (size_t k = 0; k < np; k++) {
@@ -603,9 +606,10 @@ inline void pcs_verify_core(const VerifierParams& vp, const Commitment& comm, co
       DP_REQUIRE(k == 0 || cq.path.empty(), DP_ERR_VERIFY, "verify: the row pair has one Merkle path");
       cur_l = ex_add(cur_l, ex_mul(cq.left, eq_xt[k])); cur_r = ex_add(cur_r, ex_mul(cq.right, eq_xt[k]));
     }
-    if (np == 1) check_merkle_path(bq.commitments_query[0], comm.root);
+    if (np == 1) check_merkle_path(bq.commitments_query[0], comm.root, num_vars + PCS_RATE_LOG - 1);
     else {  // authenticate_merkle_path_root_batch (merkle_tree.rs:449-490)
       const CodewordQuery& c0 = bq.commitments_query[0];
+      DP_REQUIRE(c0.path.size() == num_vars + PCS_RATE_LOG - 1, DP_ERR_VERIFY, "merkle path: wrong length for the size of this codeword");
       Digest h = host_compress(host_row_hash(bq.commitments_query, false), host_row_hash(bq.commitments_query, true));
       if (std::vector<MerkleJob>* sink = merkle_sink()) sink->push_back({h, c0.index >> 1, c0.path.data(), c0.path.size(), comm.root});
       else { MerkleJob j{h, c0.index >> 1, c0.path.data(), c0.path.size(), comm.root}; DP_REQUIRE(merkle_job_ok(j), DP_ERR_VERIFY, "merkle path does not authenticate against the root"); }
@@ -747,10 +751,10 @@ inline void pcs_batch_verify_evals(const VerifierParams& vp, const std::vector<C
     size_t index = qidx[q];
     DP_REQUIRE(bq.index == index, DP_ERR_VERIFY, "batch_verify: query index mismatch");
     DP_REQUIRE(bq.oracle_query.size() == proof.roots.size() && bq.commitments_query.size() == nc, DP_ERR_VERIFY, "batch_verify: query shape");
-    for (size_t k = 0; k < bq.oracle_query.size(); k++) check_merkle_path(bq.oracle_query[k], proof.roots[k]);
+    for (size_t k = 0; k < bq.oracle_query.size(); k++) check_merkle_path(bq.oracle_query[k], proof.roots[k], num_vars + PCS_RATE_LOG - k - 2);
     for (size_t k = 0; k < nc; k++) {
       DP_REQUIRE(bq.commitments_query[k].is_ext == !comms[k].is_base, DP_ERR_VERIFY, "batch_verify: field type of opened codeword");
-      check_merkle_path(bq.commitments_query[k], comms[k].root);
+      check_merkle_path(bq.commitments_query[k], comms[k].root, comms[k].num_vars + PCS_RATE_LOG - 1);
     }
     Ext cur_l = ex_zero(), cur_r = ex_zero();
     size_t right_index = index | 1, left_index = right_index - 1;

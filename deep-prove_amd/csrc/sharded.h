@@ -29,7 +29,9 @@ struct SoloExchange : Exchange {  // world of one
 // W ranks as W threads of one process (tests, several contexts on one GPU): a reusable barrier around a shared buffer
 struct ThreadExchangeHub {
   int world; std::mutex mu; std::condition_variable cv; std::vector<u64> buf; int arrived = 0, left = 0; unsigned long long gen = 0; size_t nwords = 0;
+  bool aborted = false;  // a rank failed: every rank waiting in (or arriving at) an exchange throws instead of waiting for it forever
   explicit ThreadExchangeHub(int w) : world(w) {}
+  void abort() { { std::lock_guard<std::mutex> lk(mu); aborted = true; } cv.notify_all(); }
 };
 struct ThreadExchange : Exchange {
   ThreadExchangeHub& h; int r;
@@ -38,13 +40,15 @@ struct ThreadExchange : Exchange {
   int rank() const override { return r; }
   void all_gather(const u64* send, size_t nwords, u64* out) override {
     std::unique_lock<std::mutex> lk(h.mu);
-    h.cv.wait(lk, [&] { return h.left == 0; });  // the previous exchange has been read by everyone
+    auto dead = [&] { if (h.aborted) throw DpError(DP_ERR_HIP, "sharded sumcheck: another rank failed, the exchange is abandoned"); };
+    h.cv.wait(lk, [&] { return h.left == 0 || h.aborted; });  // the previous exchange has been read by everyone
+    dead();
     if (h.arrived == 0) { h.nwords = nwords; h.buf.assign((size_t)h.world * nwords, 0); }
-    DP_REQUIRE(nwords == h.nwords, DP_ERR_SHAPE, "sharded sumcheck: ranks disagree on the message size");
+    if (nwords != h.nwords) { h.aborted = true; h.cv.notify_all(); throw DpError(DP_ERR_SHAPE, "sharded sumcheck: ranks disagree on the message size"); }
     for (size_t i = 0; i < nwords; i++) h.buf[(size_t)r * nwords + i] = send[i];
     const unsigned long long my = h.gen;
     if (++h.arrived == h.world) { h.arrived = 0; h.left = h.world; h.gen++; h.cv.notify_all(); }
-    else h.cv.wait(lk, [&] { return h.gen != my; });
+    else { h.cv.wait(lk, [&] { return h.gen != my || h.aborted; }); if (h.gen == my) dead(); }
     for (size_t i = 0; i < (size_t)h.world * nwords; i++) out[i] = h.buf[i];
     if (--h.left == 0) h.cv.notify_all();
   }

@@ -36,7 +36,17 @@ constexpr int SPONGE_MAX_SLOTS = 2048;
 inline SpongeSlot* sponge_slots() { static SpongeSlot s[SPONGE_MAX_SLOTS]; return s; }
 inline std::atomic<int>& sponge_nslots() { static std::atomic<int> n{0}; return n; }
 inline std::atomic<int>& sponge_nactive() { static std::atomic<int> n{0}; return n; }
-inline SpongeSlot* sponge_slot_new() { int i = sponge_nslots().fetch_add(1); DP_REQUIRE(i < SPONGE_MAX_SLOTS, DP_ERR_OOM, "too many device contexts for the host sponge service"); return sponge_slots() + i; }
+// slots of destroyed contexts are handed out again (a long-lived process creates and destroys thousands of contexts)
+inline std::mutex& sponge_free_mu() { static std::mutex m; return m; }
+inline std::vector<SpongeSlot*>& sponge_free_list() { static std::vector<SpongeSlot*> v; return v; }
+inline SpongeSlot* sponge_slot_new() {
+  { std::lock_guard<std::mutex> g(sponge_free_mu()); auto& fl = sponge_free_list(); if (!fl.empty()) { SpongeSlot* s = fl.back(); fl.pop_back(); return s; } }
+  int i = sponge_nslots().fetch_add(1);
+  if (i >= SPONGE_MAX_SLOTS) { sponge_nslots().fetch_sub(1); throw DpError(DP_ERR_OOM, "too many live device contexts for the host sponge service"); }
+  return sponge_slots() + i;
+}
+// the context is gone: the slot is inactive (sponge_disarm_), nobody serves it; its sequence state stays, the next owner continues it
+inline void sponge_slot_free(SpongeSlot* s) { if (!s) return; s->req = s->rep = nullptr; s->ch = nullptr; std::lock_guard<std::mutex> g(sponge_free_mu()); sponge_free_list().push_back(s); }
 
 // DuplexChallenger as the device drives it: drop the samples the device has popped, absorb, and (want) make a sample available
 inline int challenger_serve(Challenger& c, const u64* words, unsigned n, unsigned consumed, bool want, u64 out[4]) {

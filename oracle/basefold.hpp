@@ -7,6 +7,7 @@
 // 275-410,458-501; util/merkle_tree.rs:23-153,261-329; util/hash.rs:25-63; util/arithmetic.rs:120-132;
 // util/arithmetic/hypercube.rs:16-37; sum_check/classic.rs:100-285; sum_check/classic/coeff.rs:198-345.
 #pragma once
+#include "par.hpp"
 #include "mle.hpp"
 #include "poseidon2.hpp"
 
@@ -65,11 +66,13 @@ static inline void interpolate_over_boolean_hypercube(Mle& m) {  // hypercube.rs
   unsigned lg = log2_strict(n);
   for (unsigned i = 1; i <= lg; i++) {
     size_t chunk = size_t(1) << i, half = chunk >> 1;
-    for (size_t c = 0; c < n; c += chunk)
-      for (size_t j = half; j < chunk; j++) {
+    par_for(n / 2, [&](size_t lo, size_t hi) {  // butterfly q: chunk q / half, offset q % half
+      for (size_t q = lo; q < hi; q++) {
+        size_t c = (q / half) * chunk, j = half + (q % half);
         if (m.is_ext) m.e[c + j] = esub(m.e[c + j], m.e[c + j - half]);
         else m.b[c + j] = fsub(m.b[c + j], m.b[c + j - half]);
       }
+    });
   }
 }
 static inline void reverse_bits_mle(Mle& m) {
@@ -88,8 +91,9 @@ static inline void rs_fft(Mle& v, unsigned r, const std::vector<std::vector<u64>
   for (unsigned lg_half_m = r; lg_half_m < lg_n; lg_half_m++) {
     size_t half_m = size_t(1) << lg_half_m, m = half_m * 2;
     const std::vector<u64>& om = root_table[lg_half_m];
-    for (size_t k = 0; k < n; k += m)
-      for (size_t j = 0; j < half_m; j++) {
+    par_for(n / 2, [&](size_t lo, size_t hi) {  // butterfly q: block q / half_m, offset q % half_m
+      for (size_t q = lo; q < hi; q++) {
+        size_t k = (q / half_m) * m, j = q % half_m;
         if (v.is_ext) {
           E t = emul_base(v.e[k + half_m + j], om[j]); E u = v.e[k + j];
           v.e[k + j] = eadd(u, t); v.e[k + half_m + j] = esub(u, t);
@@ -98,6 +102,7 @@ static inline void rs_fft(Mle& v, unsigned r, const std::vector<std::vector<u64>
           v.b[k + j] = fadd(u, t); v.b[k + half_m + j] = fsub(u, t);
         }
       }
+    });
   }
 }
 // RSCode::encode -> encode_internal -> coset_fft (rs.rs:350-354,458-501,175-189)
@@ -142,11 +147,13 @@ static inline E interpolate2_weights(E a0, E a1, E b0, E b1, E w, E x) {
 // basefold_one_round_by_interpolation_weights (commit_phase.rs:511-526)
 static inline std::vector<E> basefold_fold(const PcsParams& pp, unsigned level, const std::vector<E>& vals, E ch) {
   std::vector<E> out(vals.size() / 2);
-  for (size_t i = 0; i < out.size(); i++) {
-    u64 x0, x1, w;
-    prover_folding_coeffs(pp, level, i, x0, x1, w);
-    out[i] = interpolate2_weights(e_from(x0), vals[2 * i], e_from(x1), vals[2 * i + 1], e_from(w), ch);
-  }
+  par_for(out.size(), [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+      u64 x0, x1, w;
+      prover_folding_coeffs(pp, level, i, x0, x1, w);
+      out[i] = interpolate2_weights(e_from(x0), vals[2 * i], e_from(x1), vals[2 * i + 1], e_from(w), ch);
+    }
+  });
   return out;
 }
 
@@ -167,15 +174,17 @@ static inline std::vector<std::vector<Digest>> merkelize(const Mle& v) {  // mer
   unsigned log_v = log2_strict(v.len());
   std::vector<std::vector<Digest>> tree;
   std::vector<Digest> h(v.len() >> 1);
-  for (size_t i = 0; i < h.size(); i++) {
-    if (v.is_ext) { u64 in[4] = {v.e[2 * i].c0, v.e[2 * i].c1, v.e[2 * i + 1].c0, v.e[2 * i + 1].c1}; h[i] = hash_or_noop(in, 4); }
-    else { u64 in[2] = {v.b[2 * i], v.b[2 * i + 1]}; h[i] = hash_or_noop(in, 2); }
-  }
+  par_for(h.size(), [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+      if (v.is_ext) { u64 in[4] = {v.e[2 * i].c0, v.e[2 * i].c1, v.e[2 * i + 1].c0, v.e[2 * i + 1].c1}; h[i] = hash_or_noop(in, 4); }
+      else { u64 in[2] = {v.b[2 * i], v.b[2 * i + 1]}; h[i] = hash_or_noop(in, 2); }
+    }
+  });
   tree.push_back(std::move(h));
   for (unsigned i = 1; i < log_v; i++) {
     const auto& prev = tree[i - 1];
     std::vector<Digest> nx(prev.size() / 2);
-    for (size_t j = 0; j < nx.size(); j++) nx[j] = compress(prev[2 * j], prev[2 * j + 1]);
+    par_for(nx.size(), [&](size_t lo, size_t hi) { for (size_t j = lo; j < hi; j++) nx[j] = compress(prev[2 * j], prev[2 * j + 1]); });
     tree.push_back(std::move(nx));
   }
   return tree;
@@ -264,18 +273,23 @@ static inline void one_level_interp_hc(std::vector<E>& v) {
 }
 static inline void one_level_eval_hc(std::vector<E>& v, E ch) {
   std::vector<E> out(v.size() / 2);
-  for (size_t i = 0; i < out.size(); i++) out[i] = eadd(v[2 * i], emul(ch, v[2 * i + 1]));
+  par_for(out.size(), [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; i++) out[i] = eadd(v[2 * i], emul(ch, v[2 * i + 1])); });
   v = std::move(out);
 }
 static inline std::vector<E> parallel_pi(const std::vector<E>& evals, const std::vector<E>& eq) {
   if (evals.size() == 1) return {evals[0], evals[0], evals[0]};
-  E c1 = e_zero(), c2 = e_zero(), c3 = e_zero();
-  for (size_t i = 0; i + 1 < evals.size(); i += 2) {
-    c1 = eadd(c1, emul(evals[i], eq[i]));
-    c2 = eadd(c2, eadd(emul(evals[i + 1], eq[i]), emul(evals[i], eq[i + 1])));
-    c3 = eadd(c3, emul(evals[i + 1], eq[i + 1]));
-  }
-  return {c1, c2, c3};
+  struct C3 { E c1, c2, c3; };
+  C3 r = par_reduce<C3>(evals.size() / 2, C3{e_zero(), e_zero(), e_zero()}, [&](size_t lo, size_t hi) {
+    C3 a{e_zero(), e_zero(), e_zero()};
+    for (size_t q = lo; q < hi; q++) {
+      size_t i = 2 * q;
+      a.c1 = eadd(a.c1, emul(evals[i], eq[i]));
+      a.c2 = eadd(a.c2, eadd(emul(evals[i + 1], eq[i]), emul(evals[i], eq[i + 1])));
+      a.c3 = eadd(a.c3, emul(evals[i + 1], eq[i + 1]));
+    }
+    return a;
+  }, [](C3 a, C3 b) { return C3{eadd(a.c1, b.c1), eadd(a.c2, b.c2), eadd(a.c3, b.c3)}; });
+  return {r.c1, r.c2, r.c3};
 }
 
 // Basefold::open of ONE committed polynomial (basefold.rs:466-544; zkml itself only reaches the trivial branch, commit/context.rs:295):
@@ -391,7 +405,7 @@ static inline std::vector<std::vector<Digest>> merkelize_batch(const std::vector
   for (unsigned i = 1; i < log_v; i++) {
     const auto& prev = tree[i - 1];
     std::vector<Digest> nx(prev.size() / 2);
-    for (size_t j = 0; j < nx.size(); j++) nx[j] = compress(prev[2 * j], prev[2 * j + 1]);
+    par_for(nx.size(), [&](size_t lo, size_t hi) { for (size_t j = lo; j < hi; j++) nx[j] = compress(prev[2 * j], prev[2 * j + 1]); });
     tree.push_back(std::move(nx));
   }
   return tree;
@@ -516,11 +530,17 @@ static inline BasefoldProof pcs_batch_open(const PcsParams& pp, const std::vecto
         if (size < poly_len || size == 1) { poly_size = size; multiple = 1; }
         else if (size == poly_len) { poly_size = poly_len >> 1; multiple = 2; }
         else { poly_size = poly_len >> 1; multiple = poly_size ? size / poly_size : 1; }
-        for (size_t j = 0; j < poly_size; j++) {
-          E l0 = lhs.at(2 * j), l1 = lhs.at(2 * j + 1), r0 = rhs.at(2 * j), r1 = rhs.at(2 * j + 1);
-          c0 = eadd(c0, emul(l0, r0));
-          c2 = eadd(c2, emul(esub(l1, l0), esub(r1, r0)));
-        }
+        struct C2 { E c0, c2; };
+        C2 cc = par_reduce<C2>(poly_size, C2{e_zero(), e_zero()}, [&](size_t lo, size_t hi) {
+          C2 a{e_zero(), e_zero()};
+          for (size_t j = lo; j < hi; j++) {
+            E l0 = lhs.at(2 * j), l1 = lhs.at(2 * j + 1), r0 = rhs.at(2 * j), r1 = rhs.at(2 * j + 1);
+            a.c0 = eadd(a.c0, emul(l0, r0));
+            a.c2 = eadd(a.c2, emul(esub(l1, l0), esub(r1, r0)));
+          }
+          return a;
+        }, [](C2 a, C2 b) { return C2{eadd(a.c0, b.c0), eadd(a.c2, b.c2)}; });
+        c0 = cc.c0; c2 = cc.c2;
         if (multiple != 1) { E mf = e_from_u64(multiple); c0 = emul(c0, mf); c2 = emul(c2, mf); }
       }
       E sc = merged[i].scalar;
@@ -553,15 +573,17 @@ static inline BasefoldProof pcs_batch_open(const PcsParams& pp, const std::vecto
   std::vector<E> running_oracle(size_t(1) << (num_vars + RATE_LOG), e_zero());
   for (size_t k = 0; k < comms.size(); k++)
     if (comms[k]->codeword_size() == running_oracle.size())
-      for (size_t j = 0; j < running_oracle.size(); j++) running_oracle[j] = eadd(running_oracle[j], emul(comms[k]->codeword_tree.leaves.at(j), coeffs[k]));
+      par_for(running_oracle.size(), [&](size_t lo, size_t hi) { for (size_t j = lo; j < hi; j++) running_oracle[j] = eadd(running_oracle[j], emul(comms[k]->codeword_tree.leaves.at(j), coeffs[k])); });
   std::vector<E> sum_evals(size_t(1) << num_vars, e_zero());
   for (size_t k = 0; k < comms.size(); k++) {
     const Mle& bh = comms[k]->bh_evals;
     size_t rep = size_t(1) << (num_vars - log2_strict(bh.len()));
-    for (size_t j = 0; j < bh.len(); j++) {
-      E mul = emul(bh.at(j), coeffs[k]);
-      for (size_t q = 0; q < rep; q++) sum_evals[j * rep + q] = eadd(sum_evals[j * rep + q], mul);
-    }
+    par_for(bh.len(), [&](size_t lo, size_t hi) {
+      for (size_t j = lo; j < hi; j++) {
+        E mul = emul(bh.at(j), coeffs[k]);
+        for (size_t q = 0; q < rep; q++) sum_evals[j * rep + q] = eadd(sum_evals[j * rep + q], mul);
+      }
+    });
   }
   std::vector<E> eq = build_eq_x_r_vec(point);
   reverse_index_bits_in_place(eq);
@@ -579,7 +601,7 @@ static inline BasefoldProof pcs_batch_open(const PcsParams& pp, const std::vecto
       trees.push_back(std::move(rt));
       for (size_t k = 0; k < comms.size(); k++)
         if (comms[k]->codeword_size() == new_running_oracle.size())
-          for (size_t j = 0; j < new_running_oracle.size(); j++) new_running_oracle[j] = eadd(new_running_oracle[j], emul(comms[k]->codeword_tree.leaves.at(j), coeffs[k]));
+          par_for(new_running_oracle.size(), [&](size_t lo, size_t hi) { for (size_t j = lo; j < hi; j++) new_running_oracle[j] = eadd(new_running_oracle[j], emul(comms[k]->codeword_tree.leaves.at(j), coeffs[k])); });
       running_oracle = new_running_oracle;
     }
     new_running_oracle = basefold_fold(pp, log2_strict(running_oracle.size()) - 1, running_oracle, ch);

@@ -4,6 +4,7 @@
 // (compute_betas_eval, identity_eval). Index convention: little endian, 0b1011 -> P(1,1,0,1) (mle.rs:226-228).
 #pragma once
 #include "field.hpp"
+#include "par.hpp"
 #include <memory>
 #include <utility>
 
@@ -33,11 +34,13 @@ struct Mle {
     assert(nv > 0);
     size_t n = len();
     std::vector<E> out(n / 2);
-    if (is_ext) {
-      for (size_t i = 0; i < n / 2; i++) out[i] = eadd(e[2 * i], emul(esub(e[2 * i + 1], e[2 * i]), r));
-    } else {
-      for (size_t i = 0; i < n / 2; i++) out[i] = eadd(emul_base(r, fsub(b[2 * i + 1], b[2 * i])), e_from(b[2 * i]));
-    }
+    par_for(n / 2, [&](size_t lo, size_t hi) {
+      if (is_ext) {
+        for (size_t i = lo; i < hi; i++) out[i] = eadd(e[2 * i], emul(esub(e[2 * i + 1], e[2 * i]), r));
+      } else {
+        for (size_t i = lo; i < hi; i++) out[i] = eadd(emul_base(r, fsub(b[2 * i + 1], b[2 * i])), e_from(b[2 * i]));
+      }
+    });
     e = std::move(out);
     b.clear();
     is_ext = true;
@@ -51,11 +54,13 @@ struct Mle {
       E r = pt[t];
       size_t half = len() / 2;
       std::vector<E> out(half);
-      if (is_ext) {
-        for (size_t i = 0; i < half; i++) out[i] = eadd(e[i], emul(esub(e[i + half], e[i]), r));
-      } else {
-        for (size_t i = 0; i < half; i++) out[i] = eadd(emul_base(r, fsub(b[i + half], b[i])), e_from(b[i]));
-      }
+      par_for(half, [&](size_t lo, size_t hi) {
+        if (is_ext) {
+          for (size_t i = lo; i < hi; i++) out[i] = eadd(e[i], emul(esub(e[i + half], e[i]), r));
+        } else {
+          for (size_t i = lo; i < hi; i++) out[i] = eadd(emul_base(r, fsub(b[i + half], b[i])), e_from(b[i]));
+        }
+      });
       e = std::move(out);
       b.clear();
       is_ext = true;

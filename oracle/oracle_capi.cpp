@@ -249,6 +249,24 @@ int orc_model_prove_many(orc_model* m, const int64_t* input, size_t ninput, int3
     u64 d = 0; for (u64 x : dg) d += x; if (digest) *digest = d;
   });
 }
+// The "port-mt" CPU baseline: ONE proof on `threads` cores — the oracle's O(n) loops (sumcheck round sums and folds, Merkle
+// layers, RS butterflies, the batch-opening sums and merges) chunked over a fork-join pool with rayon's with_min_len(64), the
+// role rayon plays in the reference (par.hpp). prove() only, as zkml/src/bin/bench.rs:390-408 times it; the digest (wrapping
+// word sum of the proof stream) must equal the single-threaded proof's.
+int orc_model_prove_mt(orc_model* m, const int64_t* input, size_t ninput, int32_t threads, double* wall_ms, uint64_t* digest) {
+  return guard([&] {
+    if (threads < 1) throw std::runtime_error("threads must be positive");
+    Trace tr = run_model(m->ctx.model, std::vector<int64_t>(input, input + ninput));
+    ParScope scope(threads);
+    auto t0 = std::chrono::steady_clock::now();
+    Transcript t = default_transcript();
+    Proof p = prove(m->ctx, tr, t);
+    auto t1 = std::chrono::steady_clock::now();
+    *wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    u64 d = 0; for (u64 w : serialize_proof(p)) d += w;
+    if (digest) *digest = d;
+  });
+}
 // CPU baseline for the standalone sumcheck bench (config 5 shape): one product of k base tables of 2^nv SplitMix64-derived
 // canonical elements, label "test". Returns wall seconds of prove only.
 int orc_bench_sumcheck(uint32_t nv, int32_t k, uint64_t seed, double* seconds, uint64_t digest[2]) {

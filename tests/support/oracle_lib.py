@@ -250,6 +250,13 @@ class Oracle:
         self._ok(self.lib.orc_model_prove_many(h, x.ctypes.data_as(i64p), C.c_size_t(x.size), C.c_int32(threads), C.c_int32(per_thread), C.byref(ms), C.byref(dg)))
         return ms.value, int(dg.value)
 
+    def model_prove_mt(self, h, x, threads):
+        """ONE proof on `threads` cores (oracle/par.hpp); returns (wall ms, wrapping word-sum of the proof stream)"""
+        x = np.ascontiguousarray(x, dtype=np.int64)
+        ms, dg = C.c_double(), C.c_uint64()
+        self._ok(self.lib.orc_model_prove_mt(h, x.ctypes.data_as(i64p), C.c_size_t(x.size), C.c_int32(threads), C.byref(ms), C.byref(dg)))
+        return ms.value, int(dg.value)
+
     def bench_sumcheck(self, nv, k, seed):
         s = C.c_double()
         dg = (C.c_uint64 * 2)()

@@ -177,3 +177,22 @@ def test_config4_fixed_batch_split_over_two_ranks(tmp_path):
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_strong_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"strong{r}") for r in range(world))
+
+
+@pytest.mark.parametrize("extra", [[], ["--batch", "64"]])
+def test_bench_spawns_its_own_ranks(extra):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the driver's BENCH command line looks) re-executes
+    itself under torch.distributed.run: two ranks come up over gloo on 127.0.0.1, all-reduce, rank 0 prints one JSON line.
+    DP_BENCH_LAUNCH_CHECK stops before the device is touched (no GPU on this box)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DP_BENCH_LAUNCH_CHECK="1", DP_DIST_BACKEND="gloo", DP_FORCE_DEVICE="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"] + extra,
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["launch_check"] and rec["world"] == 2 and rec["ranks_seen"] == 2 and rec["batch"] == (64 if extra else 0)

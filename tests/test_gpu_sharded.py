@@ -139,3 +139,72 @@ def test_in_library_sharded_loop_over_rccl_world_of_one(dev, oracle):
         _lib.check(lib.dp_dist_free(h))
     oproof, ofinals = oracle.sumcheck_prove(nv, tabs, [False] * 3, terms, oracle.transcript(b"test"))
     assert (proof == oproof).all() and (finals == ofinals).all() and (solo == oproof).all() and (sfinals == ofinals).all()
+
+
+def _golden_sc(nv):
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sumcheck24.json")))
+    return g["cases"][str(nv)], g["k"]
+
+
+def _check_against_golden(dpa, gold, nv, proof, finals, transcript):
+    import hashlib
+    assert proof.size == gold["proof_words"]
+    assert hashlib.sha256(proof.tobytes()).hexdigest() == gold["sha256"], f"2^{nv} sumcheck: proof stream differs from the oracle's"
+    assert [int(v) for v in finals] == gold["finals"]
+    assert list(transcript.read_challenge()) == gold["next_challenge"]  # the sponge ends where the oracle's does
+    # and the host verifier accepts it: claimed sum = p_0(0) + p_0(1) of the first round message, sub-claim = product of the finals
+    off = 1 + 2 * nv + 1 + 1
+    e0, e1 = (int(proof[off]), int(proof[off + 1])), (int(proof[off + 2]), int(proof[off + 3]))
+    P_ = 0xFFFFFFFF00000001
+    claimed = ((e0[0] + e1[0]) % P_, (e0[1] + e1[1]) % P_)
+    point, expected = dpa.verify_sumcheck(claimed, proof, nv, 3, dpa.Transcript(b"test"))
+
+    def emul(a, b):
+        return ((a[0] * b[0] + 7 * a[1] * b[1]) % P_, (a[0] * b[1] + a[1] * b[0]) % P_)
+    prod = (1, 0)
+    for i in range(3):
+        prod = emul(prod, (int(finals[2 * i]), int(finals[2 * i + 1])))
+    assert prod == expected, "final evaluations do not multiply to the verifier's sub-claim"
+
+
+@pytest.mark.parametrize("nv", [22, 24])
+def test_config5_prove_parallel_at_size_equals_oracle_golden(dev, nv):
+    """BASELINE config 5 at its stated size (and 2^22): the single-GPU prove_parallel bench.py times — streaming rounds with the
+    t = 1 skip, the hand-over to the LDS session, the k_reduce_publish chain — against the oracle's committed sha256
+    (tests/golden/sumcheck24.json, tests/golden/make_sumcheck24_hash.py; shape of sumcheck/benches/devirgo_sumcheck.rs:42-101)"""
+    import deep_prove_amd as dpa
+    gold, k = _golden_sc(nv)
+    tabs = [dpa.Mle.from_base(dev, dpa.models.splitmix64(0xD33B0000 ^ (5 << 32) ^ j, 1 << nv) % np.uint64(P)) for j in range(k)]
+    try:
+        vp = dpa.VirtualPolynomial(nv)
+        vp.add_mle_list(tabs, (1, 0))
+        t = dpa.Transcript(b"test")
+        proof, finals = dpa.prove_parallel(dev, vp, t)
+    finally:
+        for m in tabs:
+            m.free()
+    _check_against_golden(dpa, gold, nv, proof, finals, t)
+
+
+@pytest.mark.parametrize("nv,world", [(22, 4), (24, 8)])
+def test_config5_sharded_in_library_at_size_equals_oracle_golden(nv, world):
+    """the same sumcheck through dp_sumcheck_prove_sharded_local: `world` device contexts (one thread each) own contiguous slices,
+    the round loop runs in the library — W = 8 at 2^24 is BASELINE config 5's partition on one GPU"""
+    import deep_prove_amd as dpa
+    gold, k = _golden_sc(nv)
+    chunk = (1 << nv) // world
+    full = [dpa.models.splitmix64(0xD33B0000 ^ (5 << 32) ^ j, 1 << nv) % np.uint64(P) for j in range(k)]
+    devs = [dpa.Device(0) for _ in range(world)]
+    try:
+        rows = [[dpa.Mle.from_base(d, t[g * chunk:(g + 1) * chunk]) for t in full] for g, d in enumerate(devs)]
+        ts = [dpa.Transcript(b"test") for _ in range(world)]
+        proof, finals = dpa.sharded.prove_sharded_local(devs, nv, rows, [((1, 0), list(range(k)))], ts)
+        for row in rows:
+            for m in row:
+                m.free()
+    finally:
+        for d in devs:
+            d.close()
+    _check_against_golden(dpa, gold, nv, proof, finals, ts[0])

@@ -175,3 +175,19 @@ def test_replica_baseline_reproduces_the_single_proof(oracle):
     wall, dg = oracle.model_prove_many(h, mb.input(7), 3, 2)
     oracle.model_free(h)
     assert wall > 0 and dg == (int(proof.sum(dtype=np.uint64)) * 6) % (1 << 64)
+
+
+def test_multithreaded_oracle_proof_equals_single_threaded(oracle):
+    """oracle/par.hpp (the "port-mt" CPU baseline of bench.py): one proof on 1, 3 and 8 threads — chunked round sums, folds, Merkle
+    layers, RS butterflies — gives the word-for-word sum of the single-threaded proof stream (field arithmetic is exact)"""
+    import numpy as np
+    import deep_prove_amd as dpa
+    for mb in (dpa.models.mlp(2, 64, config=7), dpa.models.cnn_tiny()):
+        h = oracle.model_setup(mb.blob())
+        x = mb.input()
+        proof, _, _ = oracle.model_prove(h, x)
+        want = int(proof.sum(dtype=np.uint64)) % (1 << 64)
+        for threads in (1, 3, 8):
+            _, dg = oracle.model_prove_mt(h, x, threads)
+            assert dg == want, f"{threads} threads"
+        oracle.model_free(h)
