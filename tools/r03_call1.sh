@@ -13,7 +13,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 100 rocprofv3 --kernel-trace --pmc $c -d "$o/proof_$c" -o x -- python tools/proof_only.py dense_4m 3 > "$o/proof_$c.log" 2>&1
 done
 f=$(find "$o/sc24_FETCH_SIZE" -name '*_results.db' | head -1); w=$(find "$o/sc24_WRITE_SIZE" -name '*_results.db' | head -1)
-[ -n "$f" ] && [ -n "$w" ] && python tools/pmc_summary.py --population sumcheck24 --units 3 "$f" "$w" "$o/pmc_sumcheck24.json" "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python tools/sumcheck24_only.py 2 (1 warm-up + 2 repetitions)" k_sc > "$o/pmc_sumcheck24.txt" 2>&1
+[ -n "$f" ] && [ -n "$w" ] && python tools/pmc_summary.py --population sumcheck24 --units 2 "$f" "$w" "$o/pmc_sumcheck24.json" "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python tools/sumcheck24_only.py 2 (2 repetitions)" k_sc > "$o/pmc_sumcheck24.txt" 2>&1
 f=$(find "$o/proof_FETCH_SIZE" -name '*_results.db' | head -1); w=$(find "$o/proof_WRITE_SIZE" -name '*_results.db' | head -1)
 [ -n "$f" ] && [ -n "$w" ] && python tools/pmc_summary.py --after-marker k_merkle_paths --population dense_4m_latency_proofs --units 3 "$f" "$w" "$o/pmc_dense4m_proofs.json" "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python tools/proof_only.py dense_4m 3 (launches after the k_merkle_paths marker: 3 latency-mode proofs, no setup)" > "$o/pmc_dense4m_proofs.txt" 2>&1
 find "$o" -name '*_results.db' -size +8M -delete
