@@ -34,2504 +34,7 @@ namespace dp {
 
 #define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw DpError(DP_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
 
-__constant__ u64 c_rc[DP_POSEIDON2_RC_WORDS];
-__constant__ unsigned long long c_poll_timeout_ticks = 2000000000ull;  // 20 s of the 100 MHz constant clock (DP_POLL_TIMEOUT_S)
-__device__ __forceinline__ unsigned long long dp_realtime() { return __builtin_amdgcn_s_memrealtime(); }
-__constant__ int c_poll_sleep = 1;
-// DIAGNOSTIC BUILDS ONLY (DP_HIPCC_EXTRA=-DDP_DIAG_SKIP_HASH, then DP_DEBUG_SKIP_HASH=1 at run time): wide Merkle layers copy instead of
-// hashing — a timing experiment whose proofs do not verify. The release library does not contain the switch.
-#ifdef DP_DIAG_SKIP_HASH
-__constant__ int c_dbg_skip_hash = 0;
-#define DP_SKIP_HASH_ON() (c_dbg_skip_hash)
-#else
-#define DP_SKIP_HASH_ON() (false)
-#endif
-
-constexpr int TPB = 256;
-constexpr int MAX_TABS = 32;
-constexpr int MAX_TERMS = 48;
-constexpr int MAX_PT = 32;
-
-struct PointArg { Ext p[MAX_PT]; };
-
-// ------------------------------------------------------------------------------------------------ launch forms
-// Every kernel of this file is written once, as a device function (KBODY), and gets TWO entry points:
-//   kg<Body>  one proof: the arguments arrive by value in the kernarg segment;
-//   kc<Body>  a cohort of proofs in lock step: ONE launch serves every proof of the cohort, blockIdx.z selects the proof and
-//             the workgroup fetches ITS arguments from a table of argument packs (one ArgPack per proof, written by the host
-//             into a mapped ring; tools/argsrc.hip: uniform reads of such a table cost what kernarg reads cost).
-// blockIdx.x / blockIdx.y keep their meaning inside the body in both forms. See `Cohort` below for the host side.
-#define KBODY __device__ __forceinline__ void
-template <class... A> struct ArgPack;
-template <> struct ArgPack<> {
-  template <class F, class... B> __device__ __forceinline__ void call(F f, const B&... b) const { f(b...); }
-};
-template <class H, class... T> struct ArgPack<H, T...> {
-  H h; ArgPack<T...> t;
-  ArgPack() = default;
-  ArgPack(const H& h_, const T&... t_) : h(h_), t(t_...) {}
-  template <class F, class... B> __device__ __forceinline__ void call(F f, const B&... b) const { t.call(f, b..., h); }
-};
-// parameter list of a body with references stripped: what travels (a body takes its large argument structs by const
-// reference so that both entry points read them in place — kernarg segment / pack table — instead of copying them to scratch)
-template <class T> struct KArgs;
-template <class... A> struct KArgs<void (*)(A...)> {};
-// FLAGS select how a one-workgroup (latency-critical) body shares the chip:
-//   KF_CLAIM  latency mode, ONE proof on the GPU: the workgroup claims the whole register file of its CU (16 waves x 128 VGPRs;
-//             with the LDS reservation of the launch no wave of another kernel can share the CU);
-//   KF_PRIO   throughput mode, hundreds of proofs in flight: NO reservation at all — 256 threads, no LDS beyond what the body
-//             needs — and raised wave priority instead (s_setprio 3: the SIMD's arbiter issues these waves first, the
-//             Poseidon2 waves of the Merkle layers fill the remaining issue slots). A workgroup that needs an EMPTY CU stalls
-//             the workgroup dispatcher until one drains, and the chip idles meanwhile: tools/hol.hip — two streams of
-//             whole-CU workgroups (16 CUs, 6 % of the chip) halve the throughput of 14 streams of wide kernels, the same
-//             serial work in 256-thread workgroups costs 9 %.
-enum { KF_NONE = 0, KF_CLAIM = 1, KF_PRIO = 2 };
-template <int FLAGS> __device__ __forceinline__ void kf_prologue() {
-  if (FLAGS & KF_CLAIM) asm volatile("v_mov_b32 v127, 0" ::: "v127");
-  if (FLAGS & KF_PRIO) __builtin_amdgcn_s_setprio(3);
-}
-template <auto Body, int MAXT, int FLAGS, class... A> __global__ void __launch_bounds__(MAXT) kg(A... a) { kf_prologue<FLAGS>(); Body(a...); }
-#ifdef DP_WG_TIMES
-// DIAGNOSTIC BUILD ONLY (DP_HIPCC_EXTRA=-DDP_WG_TIMES, tools/wg_times.py): every workgroup of k_logup_tail records when it entered and
-// left, on which CU, and which merged launch it belonged to (the address of the launch's argument packs) — how much of a merged
-// launch's duration is the spread between its fastest and its slowest member?
-__shared__ unsigned long long s_dbg_launch;
-__device__ unsigned long long g_wgt[4 * 65536];
-__device__ unsigned g_wgt_n;
-__device__ __forceinline__ void dbg_wg_record(unsigned long long t_in) {
-  unsigned i = atomicAdd(&g_wgt_n, 1u);
-  if (i >= 65536) return;
-  unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID, all 32 bits
-  unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID, 4 bits
-  g_wgt[4 * i] = t_in; g_wgt[4 * i + 1] = dp_realtime(); g_wgt[4 * i + 2] = s_dbg_launch;
-  g_wgt[4 * i + 3] = (unsigned long long)hw | ((unsigned long long)xcc << 32) | ((unsigned long long)blockIdx.z << 40);
-}
-template <auto Body, int MAXT, int FLAGS, class... A> __global__ void __launch_bounds__(MAXT) kc(const ArgPack<A...>* __restrict__ packs) { kf_prologue<FLAGS>(); if (threadIdx.x == 0) s_dbg_launch = (unsigned long long)packs; packs[blockIdx.z].call(Body); }
-#else
-template <auto Body, int MAXT, int FLAGS, class... A> __global__ void __launch_bounds__(MAXT) kc(const ArgPack<A...>* __restrict__ packs) { kf_prologue<FLAGS>(); packs[blockIdx.z].call(Body); }
-#endif
-
-// ------------------------------------------------------------------------------------------------ reductions
-__device__ __forceinline__ u64 shfl_down_u64(u64 v, int d) {
-  int lo = __shfl_down((int)(u32)v, d, 64);
-  int hi = __shfl_down((int)(u32)(v >> 32), d, 64);
-  return ((u64)(u32)hi << 32) | (u64)(u32)lo;
-}
-__device__ __forceinline__ Ext wave_reduce_ext(Ext v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    Ext o = ex(shfl_down_u64(v.c0, d), shfl_down_u64(v.c1, d));
-    v = ex_add(v, o);
-  }
-  return v;
-}
-// sum over the block; result valid in thread 0. `sm` must hold TPB/64 Ext values.
-__device__ __forceinline__ Ext block_reduce_ext(Ext v, Ext* sm) {
-  v = wave_reduce_ext(v);
-  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) sm[w] = v;
-  __syncthreads();
-  Ext r = ex_zero();
-  if (threadIdx.x == 0) {
-    r = sm[0];
-    for (int i = 1; i < (int)(blockDim.x >> 6); i++) r = ex_add(r, sm[i]);
-  }
-  return r;
-}
-__device__ __forceinline__ Ext ld_elem(const void* p, bool ext, size_t i) {
-  if (ext) return ((const Ext*)p)[i];
-  return ex_base(((const u64*)p)[i]);
-}
-
-// ------------------------------------------------------------------------------------------------ elementwise
-KBODY k_copy_words(u64* dst, const u64* src, size_t n) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
-}
-KBODY k_zero_words(u64* dst, size_t n) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = 0;
-}
-KBODY k_fieldize(const int64_t* in, u64* out, size_t n) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = gl_from_i64(in[i]);
-}
-KBODY k_pow_table(u64* out, u64 base, size_t n) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = gl_pow(base, i);
-}
-// K4: eq(x, pt) computed per index as a product over its bits (k ext multiplications per element, no log-k passes)
-KBODY k_eq_table(Ext* out, const PointArg& pt, unsigned k, Ext scale, int acc, size_t n) {  // n > 2^k: the table repeats
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    Ext v = scale;
-    for (unsigned t = 0; t < k; t++) {
-      Ext r = pt.p[t];
-      v = ex_mul(v, ((i >> t) & 1) ? r : ex_sub(ex_one(), r));
-    }
-    out[i] = acc ? ex_add(out[i], v) : v;
-  }
-}
-struct EvalArgs { const void* f[8]; int ext[8]; int nf; };
-// out partial[block][f] = sum over the block's x of f(x) * eq(x, pt)
-KBODY k_mle_eval_partial(const EvalArgs& a, const PointArg& pt, unsigned k, Ext* partial) {
-  __shared__ Ext sm[TPB / 64];
-  size_t n = size_t(1) << k;
-  Ext acc[8];
-#pragma unroll
-  for (int f = 0; f < 8; f++) acc[f] = ex_zero();
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    Ext e = ex_one();
-    for (unsigned t = 0; t < k; t++) {
-      Ext r = pt.p[t];
-      e = ex_mul(e, ((i >> t) & 1) ? r : ex_sub(ex_one(), r));
-    }
-#pragma unroll
-    for (int f = 0; f < 8; f++)
-      if (f < a.nf) acc[f] = ex_add(acc[f], a.ext[f] ? ex_mul(e, ((const Ext*)a.f[f])[i]) : ex_mul_base(e, ((const u64*)a.f[f])[i]));
-  }
-#pragma unroll
-  for (int f = 0; f < 8; f++) {
-    if (f < a.nf) {
-      Ext r = block_reduce_ext(acc[f], sm);
-      if (threadIdx.x == 0) partial[(size_t)blockIdx.x * 8 + f] = r;
-    }
-  }
-}
-// generic second stage: out[j] = sum_b partial[b*stride + j], one block per j
-KBODY k_reduce_partials(const Ext* partial, size_t nblocks, size_t stride, Ext* out) {
-  __shared__ Ext sm[TPB / 64];
-  size_t j = blockIdx.x;
-  Ext acc = ex_zero();
-  for (size_t b = threadIdx.x; b < nblocks; b += blockDim.x) acc = ex_add(acc, partial[b * stride + j]);
-  Ext r = block_reduce_ext(acc, sm);
-  if (threadIdx.x == 0) out[j] = r;
-}
-// K2 one pass: partial[split][c] = sum over the split's rows of eq[r] * W[r*C + c]
-KBODY k_fix_high_partial(const u64* W, const Ext* eq, size_t R, size_t C, size_t rows_per_split, Ext* partial) {
-  size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  size_t r0 = blockIdx.y * rows_per_split, r1 = min(R, r0 + rows_per_split);
-  Ext acc = ex_zero();
-  for (size_t r = r0; r < r1; r++) acc = ex_add(acc, ex_mul_base(eq[r], W[r * C + c]));
-  partial[(size_t)blockIdx.y * C + c] = acc;
-}
-// Dev::fix_low: out[r] = sum_c eq[c] * W[r][c] — one wave per row of a row-major base table, lanes stride along the row (coalesced);
-// HBM-bound: the table is read once (8 R C bytes), eq (16 C bytes) stays in cache
-KBODY k_fix_low(const u64* W, const Ext* eq, Ext* out, size_t R, size_t C) {
-  const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  for (size_t r = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < R; r += nwaves) {
-    const u64* row = W + r * C;
-    Ext acc = ex_zero();
-    for (size_t c = lane; c < C; c += 64) acc = ex_add(acc, ex_mul_base(eq[c], row[c]));
-    acc = wave_reduce_ext(acc);
-    if (lane == 0) out[r] = acc;
-  }
-}
-KBODY k_colsum(const Ext* partial, size_t nsplit, size_t C, Ext* out) {
-  size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  Ext acc = ex_zero();
-  for (size_t s = 0; s < nsplit; s++) acc = ex_add(acc, partial[s * C + c]);
-  out[c] = acc;
-}
-
-// ------------------------------------------------------------------------------------------------ sumcheck (K1, K3)
-struct FoldArgs { const void* in[MAX_TABS]; Ext* out[MAX_TABS]; int ext[MAX_TABS]; size_t half[MAX_TABS]; };
-// K1: out[i] = in[2i] + r (in[2i+1] - in[2i]); blockIdx.y selects the table
-KBODY k_fold(const FoldArgs& a, Ext r) {
-  int t = blockIdx.y;
-  size_t h = a.half[t];
-  const void* in = a.in[t];
-  Ext* out = a.out[t];
-  if (a.ext[t]) {
-    const Ext* p = (const Ext*)in;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < h; i += (size_t)gridDim.x * blockDim.x) out[i] = ex_lerp(p[2 * i], p[2 * i + 1], r);
-  } else {
-    const u64* p = (const u64*)in;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < h; i += (size_t)gridDim.x * blockDim.x) out[i] = ex_lerp_base(p[2 * i], p[2 * i + 1], r);
-  }
-}
-constexpr int SC_SLOTS = SC_MAXK + 1;  // evaluations at t = 0..k of a degree-k term, k <= SC_MAXK
-// The round sums of ONE product term over the pairs start, start + stride, .. < npairs: acc[t] += prod_j (lo_j + t (hi_j - lo_j)).
-// `L(j, b, lo, hi)` loads pair b of the j-th factor. Degrees 1..3 (every sumcheck of the Dense / logup / Basefold path)
-// keep their hand-scheduled bodies; degrees 4 and 5 (the maxpool zero-check) walk t with forward differences.
-// HI = false: degrees 1..3 only (every sumcheck of the Dense / logup / Basefold path); HI = true adds degrees 4 and 5 (the
-// maxpool zero-check), walking t = 0..5 with forward differences. Kernels are instantiated for both so that the register
-// needs of the high-degree body never weigh on the common case.
-template <bool HI, class PairLoader>
-__device__ __forceinline__ void sc_accumulate(int k, PairLoader L, size_t start, size_t stride, size_t npairs, Ext (&acc)[SC_SLOTS]) {
-#pragma unroll
-  for (int t = 0; t < SC_SLOTS; t++) acc[t] = ex_zero();
-  if (k == 1) {
-    for (size_t b = start; b < npairs; b += stride) { Ext a0, b0; L(0, b, a0, b0); acc[0] = ex_add(acc[0], a0); acc[1] = ex_add(acc[1], b0); }
-  } else if (k == 2) {
-    for (size_t b = start; b < npairs; b += stride) {
-      Ext a0, b0, a1, b1; L(0, b, a0, b0); L(1, b, a1, b1);
-      Ext c0 = ex_sub(ex_dbl(b0), a0), c1 = ex_sub(ex_dbl(b1), a1);  // value at t = 2
-      acc[0] = ex_add(acc[0], ex_mul(a0, a1)); acc[1] = ex_add(acc[1], ex_mul(b0, b1)); acc[2] = ex_add(acc[2], ex_mul(c0, c1));
-    }
-  } else if (!HI || k == 3) {
-    for (size_t b = start; b < npairs; b += stride) {
-      Ext a0, b0, a1, b1, a2, b2; L(0, b, a0, b0); L(1, b, a1, b1); L(2, b, a2, b2);
-      Ext d0 = ex_sub(b0, a0), d1 = ex_sub(b1, a1), d2 = ex_sub(b2, a2);
-      Ext c0 = ex_add(b0, d0), c1 = ex_add(b1, d1), c2 = ex_add(b2, d2);  // t = 2
-      Ext f0 = ex_add(c0, d0), f1 = ex_add(c1, d1), f2 = ex_add(c2, d2);  // t = 3
-      acc[0] = ex_add(acc[0], ex_mul(ex_mul(a0, a1), a2)); acc[1] = ex_add(acc[1], ex_mul(ex_mul(b0, b1), b2));
-      acc[2] = ex_add(acc[2], ex_mul(ex_mul(c0, c1), c2)); acc[3] = ex_add(acc[3], ex_mul(ex_mul(f0, f1), f2));
-    }
-  } else if (HI) {
-    for (size_t b = start; b < npairs; b += stride) {
-      Ext cur[SC_MAXK], d[SC_MAXK];
-#pragma unroll
-      for (int j = 0; j < SC_MAXK; j++) {
-        if (j < k) { Ext lo, hi; L(j, b, lo, hi); cur[j] = lo; d[j] = ex_sub(hi, lo); }
-        else { cur[j] = ex_one(); d[j] = ex_zero(); }
-      }
-#pragma unroll
-      for (int t = 0; t < SC_SLOTS; t++) {
-        Ext p = ex_mul(ex_mul(cur[0], cur[1]), ex_mul(cur[2], cur[3]));
-        if (k == 5) p = ex_mul(p, cur[4]);
-        acc[t] = ex_add(acc[t], p);
-#pragma unroll
-        for (int j = 0; j < SC_MAXK; j++) cur[j] = ex_add(cur[j], d[j]);
-      }
-    }
-  }
-}
-// number of factor slots a kernel instantiation has to wire up
-template <bool HI> struct ScW { static constexpr int K = HI ? SC_MAXK : 3; };
-// pair loader over tables in global memory (natural order: pair b = elements 2b, 2b+1), base or extension per table
-struct GlobalPairs {
-  const void* p[SC_MAXK]; bool e[SC_MAXK];
-  __device__ __forceinline__ void operator()(int j, size_t b, Ext& lo, Ext& hi) const { lo = ld_elem(p[j], e[j], 2 * b); hi = ld_elem(p[j], e[j], 2 * b + 1); }
-};
-// pair loader over LDS-resident tables kept in bit-reversed order: pair q = positions q, q + h
-struct LdsPairs {
-  const Ext* p[SC_MAXK]; size_t h;
-  __device__ __forceinline__ void operator()(int j, size_t q, Ext& lo, Ext& hi) const { lo = p[j][q]; hi = p[j][q + h]; }
-};
-struct TermArgs { const void* tab[MAX_TABS]; int ext[MAX_TABS]; int k[MAX_TERMS]; int t[MAX_TERMS][SC_MAXK]; size_t npairs; };
-// K3: partial[(term*gridDim.x + block)*SC_SLOTS + t] = sum over the block's pairs of prod_j (a_j + t d_j), t = 0..k
-template <bool HI>
-KBODY k_sc_terms(const TermArgs& a, Ext* partial) {
-  __shared__ Ext sm[TPB / 64];
-  int term = blockIdx.y;
-  int k = a.k[term];
-  Ext acc[SC_SLOTS];
-  bool all_base = k <= 3;
-  for (int j = 0; j < k; j++) all_base = all_base && !a.ext[a.t[term][j]];
-  if (all_base) {
-    // every factor is a base-field table (first round of a sumcheck over committed columns): stay in the base field,
-    // as the reference macro does (sumcheck_macro/src/lib.rs:283-296), one 16-byte load per table and pair
-    const void* p0 = a.tab[a.t[term][0]]; const void* p1 = a.tab[a.t[term][k > 1 ? 1 : 0]]; const void* p2 = a.tab[a.t[term][k > 2 ? 2 : 0]];
-    u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < a.npairs; b += (size_t)gridDim.x * blockDim.x) {
-      ulonglong2 x0 = ((const ulonglong2*)p0)[b];
-      if (k == 1) { s0 = gl_add(s0, x0.x); s1 = gl_add(s1, x0.y); }
-      else if (k == 2) {
-        ulonglong2 x1 = ((const ulonglong2*)p1)[b];
-        u64 c0 = gl_sub(gl_dbl(x0.y), x0.x), c1 = gl_sub(gl_dbl(x1.y), x1.x);
-        s0 = gl_add(s0, gl_mul(x0.x, x1.x)); s1 = gl_add(s1, gl_mul(x0.y, x1.y)); s2 = gl_add(s2, gl_mul(c0, c1));
-      } else {
-        ulonglong2 x1 = ((const ulonglong2*)p1)[b], x2 = ((const ulonglong2*)p2)[b];
-        u64 d0 = gl_sub(x0.y, x0.x), d1 = gl_sub(x1.y, x1.x), d2 = gl_sub(x2.y, x2.x);
-        u64 c0 = gl_add(x0.y, d0), c1 = gl_add(x1.y, d1), c2 = gl_add(x2.y, d2);
-        u64 g0 = gl_add(c0, d0), g1 = gl_add(c1, d1), g2 = gl_add(c2, d2);
-        s0 = gl_add(s0, gl_mul(gl_mul(x0.x, x1.x), x2.x)); s1 = gl_add(s1, gl_mul(gl_mul(x0.y, x1.y), x2.y));
-        s2 = gl_add(s2, gl_mul(gl_mul(c0, c1), c2)); s3 = gl_add(s3, gl_mul(gl_mul(g0, g1), g2));
-      }
-    }
-    acc[0] = ex_base(s0); acc[1] = ex_base(s1); acc[2] = ex_base(s2); acc[3] = ex_base(s3); acc[4] = ex_zero(); acc[5] = ex_zero();
-  } else {
-    GlobalPairs L;
-#pragma unroll
-    for (int j = 0; j < ScW<HI>::K; j++) { int ti = a.t[term][j < k ? j : 0]; L.p[j] = a.tab[ti]; L.e[j] = a.ext[ti]; }
-    sc_accumulate<HI>(k, L, blockIdx.x * (size_t)blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, a.npairs, acc);
-  }
-  size_t base = ((size_t)term * gridDim.x + blockIdx.x) * SC_SLOTS;
-#pragma unroll
-  for (int t = 0; t < SC_SLOTS; t++) {
-    if (t <= k) { Ext r = block_reduce_ext(acc[t], sm); if (threadIdx.x == 0) partial[base + t] = r; }
-    else if (threadIdx.x == 0) partial[base + t] = ex_zero();
-  }
-}
-// out[term*4 + t] = sum_b partial[(term*nblocks + b)*4 + t]; one block per (term, t)
-KBODY k_reduce_terms(const Ext* partial, size_t nblocks, Ext* out) {
-  __shared__ Ext sm[TPB / 64];
-  size_t term = blockIdx.x >> 2, t = blockIdx.x & 3;
-  Ext acc = ex_zero();
-  for (size_t b = threadIdx.x; b < nblocks; b += blockDim.x) acc = ex_add(acc, partial[(term * nblocks + b) * 4 + t]);
-  Ext r = block_reduce_ext(acc, sm);
-  if (threadIdx.x == 0) out[blockIdx.x] = r;
-}
-// K3' (SURVEY.md 2.3): fused fold + round sums for ONE product of K equally typed large tables. Each lane takes 4
-// consecutive elements of every table (32 contiguous bytes for base tables, 64 for extension tables), folds them with r
-// into 2 values, stores those (32 contiguous bytes) and immediately accumulates the next round's sums on that pair —
-// every table byte is read once and every folded byte written once per round (the unfused path reads the folded
-// table a second time). partial[block*4 + t] = sum over the block's pairs of prod_j (f0_j + t (f1_j - f0_j)).
-// SKIP1: the caller knows the round's claimed sum s(0) + s(1), so the t = 1 products are not computed (slot 1 stays 0
-// and the host sets s(1) = claim - s(0)): 2 of the 8 extension products per pair less.
-// `counter` non-null: the LAST workgroup to finish (a device-wide ticket) adds up the partials of all workgroups and publishes
-// the four sums to the host itself — no k_reduce_publish launch between two rounds of a large sumcheck. The partials cross
-// XCDs (per-XCD L2s are not coherent with each other): every workgroup releases at agent scope before it takes its ticket, the
-// last one acquires at agent scope before it reads (MI355X_MICROARCH.md, correctness boundaries).
-__device__ void sc_publish_vals_fwd(Ext* result, const Ext* src, size_t stride, int n, unsigned long long* flag, unsigned long long seq, int lane);
-template <int K, bool BASE, bool SKIP1>
-KBODY k_sc_fused(const void* in0, const void* in1, const void* in2, Ext* out0, Ext* out1, Ext* out2,
-                                                  size_t nquads, Ext r, Ext* partial, unsigned* counter, Ext* result, unsigned long long* flag, unsigned long long seq) {
-  __shared__ Ext sm[TPB / 64];
-  const void* in[3] = {in0, in1, in2};
-  Ext* out[3] = {out0, out1, out2};
-  // The kernel is VALU-bound (93 % of the issue slots in its base-table round, profiles/r02_pmc_sq_sumcheck24.json), so the
-  // field arithmetic is the lazy kind of gl64_lazy.h: folds as one fused multiply-add with a single reduction per limb,
-  // extension products schoolbook with two reductions, running sums as exact integers reduced once per thread. What is STORED is
-  // canonical (other kernels read the folded tables), what is multiplied is any representative.
-  lz::ExAcc acc0 = lz::acc_zero(), acc1 = lz::acc_zero(), acc2 = lz::acc_zero(), acc3 = lz::acc_zero();
-  for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < nquads; q += (size_t)gridDim.x * blockDim.x) {
-    Ext f0[K], f1[K];
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-      if (BASE) {
-        const ulonglong2* p = (const ulonglong2*)((const u64*)in[j] + 4 * q);
-        ulonglong2 a = p[0], b = p[1];
-        f0[j] = lz::ex_canon(lz::ex_fma_base(r, gl_sub(a.y, a.x), a.x));
-        f1[j] = lz::ex_canon(lz::ex_fma_base(r, gl_sub(b.y, b.x), b.x));
-      } else {
-        const Ext* p = (const Ext*)in[j] + 4 * q;
-        Ext e0 = p[0], e1 = p[1], e2 = p[2], e3 = p[3];
-        f0[j] = lz::ex_canon(lz::ex_fma(r, ex_sub(e1, e0), e0));
-        f1[j] = lz::ex_canon(lz::ex_fma(r, ex_sub(e3, e2), e2));
-      }
-      out[j][2 * q] = f0[j];
-      out[j][2 * q + 1] = f1[j];
-    }
-    if (K == 1) { lz::acc_add(acc0, f0[0]); if (!SKIP1) lz::acc_add(acc1, f1[0]); }
-    else if (K == 2) {
-      Ext c0 = ex_sub(ex_dbl(f1[0]), f0[0]), c1 = ex_sub(ex_dbl(f1[1]), f0[1]);
-      lz::acc_add(acc0, lz::ex_mul(f0[0], f0[1])); if (!SKIP1) lz::acc_add(acc1, lz::ex_mul(f1[0], f1[1])); lz::acc_add(acc2, lz::ex_mul(c0, c1));
-    } else {
-      Ext d0 = ex_sub(f1[0], f0[0]), d1 = ex_sub(f1[1], f0[1]), d2 = ex_sub(f1[2], f0[2]);
-      Ext c0 = ex_add(f1[0], d0), c1 = ex_add(f1[1], d1), c2 = ex_add(f1[2], d2);
-      Ext g0 = ex_add(c0, d0), g1 = ex_add(c1, d1), g2 = ex_add(c2, d2);
-      lz::acc_add(acc0, lz::ex_mul(lz::ex_mul(f0[0], f0[1]), f0[2])); if (!SKIP1) lz::acc_add(acc1, lz::ex_mul(lz::ex_mul(f1[0], f1[1]), f1[2]));
-      lz::acc_add(acc2, lz::ex_mul(lz::ex_mul(c0, c1), c2)); lz::acc_add(acc3, lz::ex_mul(lz::ex_mul(g0, g1), g2));
-    }
-  }
-  size_t base = (size_t)blockIdx.x * 4;
-  Ext v;
-  v = block_reduce_ext(lz::acc_value(acc0), sm); if (threadIdx.x == 0) partial[base + 0] = v;
-  v = block_reduce_ext(lz::acc_value(acc1), sm); if (threadIdx.x == 0) partial[base + 1] = v;
-  v = block_reduce_ext(lz::acc_value(acc2), sm); if (threadIdx.x == 0) partial[base + 2] = v;
-  v = block_reduce_ext(lz::acc_value(acc3), sm); if (threadIdx.x == 0) partial[base + 3] = v;
-  if (counter) {
-    __shared__ int s_last;
-    __shared__ Ext res[4];
-    __threadfence();  // release: this workgroup's partials are visible device-wide
-    if (threadIdx.x == 0) s_last = atomicAdd(counter, 1u) == gridDim.x - 1;
-    __syncthreads();
-    if (s_last) {
-      __threadfence();  // acquire: read what the other workgroups (other XCDs) wrote
-      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-      if (wave < 4) {
-        Ext acc = ex_zero();
-        for (unsigned b = lane; b < gridDim.x; b += 64) acc = ex_add(acc, partial[(size_t)b * 4 + wave]);
-        acc = wave_reduce_ext(acc);
-        if (lane == 0) res[wave] = acc;
-      }
-      __syncthreads();
-      if (wave == 0) sc_publish_vals_fwd(result, res, 1, 4, flag, seq, lane);
-      if (threadIdx.x == 0) *counter = 0;  // the next launch on this stream starts from zero
-    }
-  }
-}
-// last fold of a sumcheck: every table has 2 elements; results go to one contiguous array
-KBODY k_finish(const FoldArgs& a, Ext r, int ntabs, Ext* out) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= ntabs) return;
-  Ext v;
-  if (a.ext[t]) { const Ext* p = (const Ext*)a.in[t]; v = ex_lerp(p[0], p[1], r); }
-  else { const u64* p = (const u64*)a.in[t]; v = ex_lerp_base(p[0], p[1], r); }
-  out[t] = v;
-}
-
-// ------------------------------------------------------------------------------------------------ logup (K13)
-struct ColsArg { const u64* col[16]; int n; };
-KBODY k_logup_den(Ext* out, const ColsArg& cols, Ext c, Ext chi, size_t n) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    Ext acc = c, pw = ex_one();
-    for (int j = 0; j < cols.n; j++) {
-      acc = ex_add(acc, ex_mul_base(pw, cols.col[j][i]));
-      pw = ex_mul(pw, chi);
-    }
-    out[i] = acc;
-  }
-}
-// (n1/d1 + n2/d2) pairing index i with i + half;  num_mode: 0 = all numerators are -1, 1 = base numerators, 2 = ext
-KBODY k_logup_layer(const void* num, int num_mode, const Ext* den, Ext* num_out, Ext* den_out, size_t half) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < half; i += (size_t)gridDim.x * blockDim.x) {
-    Ext d1 = den[i], d2 = den[i + half];
-    Ext nn;
-    if (num_mode == 0) nn = ex_neg(ex_add(d1, d2));
-    else if (num_mode == 1) { const u64* p = (const u64*)num; nn = ex_add(ex_mul_base(d2, p[i]), ex_mul_base(d1, p[i + half])); }
-    else { const Ext* p = (const Ext*)num; nn = ex_add(ex_mul(p[i], d2), ex_mul(d1, p[i + half])); }
-    num_out[i] = nn;
-    den_out[i] = ex_mul(d1, d2);
-  }
-}
-
-struct LogupTreeDesc { const u64* col[8]; int ncols; int num_mode; const void* num0; Ext* den_all; Ext* num_all; };
-// K13 fused: denominators and every layer of the fractional-sum tree of one instance per workgroup (small tables).
-// den_all: layer j at offset 2n - (2n >> j) (lengths n, n/2, .., 2); num_all: layer j >= 1 at offset n - (2n >> j).
-// out[4*inst..] = [num_last[0], num_last[1], den_last[0], den_last[1]].
-KBODY k_logup_tree(const LogupTreeDesc* d, size_t n, Ext c, Ext chi, Ext* out) {
-  LogupTreeDesc t = d[blockIdx.x];
-  int tid = threadIdx.x, nt = blockDim.x;
-  Ext* den = t.den_all;
-  for (size_t i = tid; i < n; i += nt) {
-    Ext acc = c, pw = ex_one();
-    for (int j = 0; j < t.ncols; j++) { acc = ex_add(acc, ex_mul_base(pw, t.col[j][i])); pw = ex_mul(pw, chi); }
-    den[i] = acc;
-  }
-  __syncthreads();
-  const void* num = t.num0;
-  int mode = t.num_mode;
-  size_t len = n, doff = 0, noff = 0;
-  Ext* num_out = t.num_all;
-  while (len > 2) {
-    size_t half = len / 2;
-    Ext* dcur = den + doff;
-    Ext* dnext = den + doff + len;
-    for (size_t i = tid; i < half; i += nt) {
-      Ext d1 = dcur[i], d2 = dcur[i + half], nn;
-      if (mode == 0) nn = ex_neg(ex_add(d1, d2));
-      else if (mode == 1) { const u64* p = (const u64*)num; nn = ex_add(ex_mul_base(d2, p[i]), ex_mul_base(d1, p[i + half])); }
-      else { const Ext* p = (const Ext*)num; nn = ex_add(ex_mul(p[i], d2), ex_mul(d1, p[i + half])); }
-      num_out[noff + i] = nn;
-      dnext[i] = ex_mul(d1, d2);
-    }
-    __syncthreads();
-    num = (const void*)(num_out + noff); mode = 2;
-    doff += len; noff += half; len = half;
-  }
-  if (tid < 4) {
-    // len == 2 here: the last layer
-    const Ext* nl = (const Ext*)num; const Ext* dl = den + doff;
-    Ext v;
-    if (tid < 2) { if (mode == 0) v = ex_neg(ex_one()); else if (mode == 1) v = ex_base(((const u64*)num)[tid]); else v = nl[tid]; }
-    else v = dl[tid - 2];
-    out[4 * blockIdx.x + tid] = v;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ RS code / NTT (K5-K7)
-template <bool EXT>
-KBODY k_mobius_stage(void* data, size_t n, unsigned lg_half) {
-  size_t half = size_t(1) << lg_half;
-  for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < n / 2; b += (size_t)gridDim.x * blockDim.x) {
-    size_t lo = ((b >> lg_half) << (lg_half + 1)) | (b & (half - 1));
-    if (EXT) { Ext* p = (Ext*)data; p[lo + half] = ex_sub(p[lo + half], p[lo]); }
-    else { u64* p = (u64*)data; p[lo + half] = gl_sub(p[lo + half], p[lo]); }
-  }
-}
-// cw[2i] = cw[2i+1] = coeff[i] * shift^{bitrev_nv(i)}: bit-reversed, zero-padded, coset-scaled DIT input with the
-// first (trivial, zero-tail) butterfly stage already applied (rs.rs:129-173 "r = 1")
-template <bool EXT>
-KBODY k_rs_prepare(const void* coeff, void* cw, const u64* pow7, unsigned nv, unsigned L) {
-  size_t n = size_t(1) << nv;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    size_t j = __brevll((unsigned long long)i) >> (64 - nv);
-    u64 s = pow7[j << (L - nv)];
-    if (EXT) { Ext v = ex_mul_base(((const Ext*)coeff)[i], s); ((Ext*)cw)[2 * i] = v; ((Ext*)cw)[2 * i + 1] = v; }
-    else { u64 v = gl_mul(((const u64*)coeff)[i], s); ((u64*)cw)[2 * i] = v; ((u64*)cw)[2 * i + 1] = v; }
-  }
-}
-// one radix-2 DIT stage; twiddle w_{2^(lg_half+1)}^j = tw[j << (L - lg_half)], tw[i] = w_{2^(L+1)}^i
-template <bool EXT>
-KBODY k_ntt_stage(void* data, size_t N, unsigned lg_half, const u64* tw, unsigned L) {
-  size_t half = size_t(1) << lg_half;
-  for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < N / 2; b += (size_t)gridDim.x * blockDim.x) {
-    size_t j = b & (half - 1);
-    size_t lo = ((b >> lg_half) << (lg_half + 1)) | j;
-    u64 w = tw[j << (L - lg_half)];
-    if (EXT) { Ext* p = (Ext*)data; Ext t = ex_mul_base(p[lo + half], w), u = p[lo]; p[lo] = ex_add(u, t); p[lo + half] = ex_sub(u, t); }
-    else { u64* p = (u64*)data; u64 t = gl_mul(p[lo + half], w), u = p[lo]; p[lo] = gl_add(u, t); p[lo + half] = gl_sub(u, t); }
-  }
-}
-template <bool EXT>
-KBODY k_bitrev(void* dst, const void* src, unsigned lg) {
-  size_t n = size_t(1) << lg;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    size_t j = lg ? (__brevll((unsigned long long)i) >> (64 - lg)) : 0;
-    if (EXT) ((Ext*)dst)[j] = ((const Ext*)src)[i]; else ((u64*)dst)[j] = ((const u64*)src)[i];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ Merkle (K8)
-// layer 0: digest = the two leaves verbatim (hash_or_noop on <= 4 base elements)
-template <bool EXT>
-KBODY k_merkle_leaves(const void* leaves, u64* nodes, size_t npairs) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npairs; i += (size_t)gridDim.x * blockDim.x) {
-    u64 d0, d1, d2, d3;
-    if (EXT) { Ext a = ((const Ext*)leaves)[2 * i], b = ((const Ext*)leaves)[2 * i + 1]; d0 = a.c0; d1 = a.c1; d2 = b.c0; d3 = b.c1; }
-    else { d0 = ((const u64*)leaves)[2 * i]; d1 = ((const u64*)leaves)[2 * i + 1]; d2 = 0; d3 = 0; }
-    u64* o = nodes + 4 * i;
-    o[0] = d0; o[1] = d1; o[2] = d2; o[3] = d3;
-  }
-}
-// the node hash of the one-node-per-lane Merkle kernels
-__device__ __forceinline__ void merkle_compress(const u64* x, const u64* y, u64* o) {
-  if (DP_SKIP_HASH_ON()) { for (int k = 0; k < 4; k++) o[k] = x[k] ^ y[k]; return; }
-  p2f::compress(x, y, o, c_rc);  // poseidon2_fast.h: the same permutation with wide accumulation and any-representative words (1.33x, tools/p2bench.hip)
-}
-// one Poseidon2 compress (2 permutations) per lane; state held in 8 VGPR pairs, round constants in constant memory
-KBODY k_merkle_layer(const u64* in, u64* out, size_t cnt) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cnt; i += (size_t)gridDim.x * blockDim.x) {
-    const ulonglong2* p = (const ulonglong2*)(in + 8 * i);
-    ulonglong2 x01 = p[0], x23 = p[1], y01 = p[2], y23 = p[3];
-    u64 x[4] = {x01.x, x01.y, x23.x, x23.y}, y[4] = {y01.x, y01.y, y23.x, y23.y}, o[4];
-    merkle_compress(x, y, o);
-    ulonglong2* q = (ulonglong2*)(out + 4 * i);
-    q[0] = make_ulonglong2(o[0], o[1]);
-    q[1] = make_ulonglong2(o[2], o[3]);
-  }
-}
-
-// The row hashes of MerkleTree::from_batch_leaves (merkle_tree.rs:261-329; util/hash.rs:32-41): several polynomials of one size share ONE
-// tree whose leaf j is the row [cw_0[j], .., cw_{k-1}[j]]. Lane j writes hash_or_noop(row j) (poseidon_hash.rs:22-28: up to four base words
-// are the digest themselves, zero padded; more go through the sponge: overwrite four lanes, permute, the digest is popped from the back)
-// as the two extension "leaves" 2j, 2j+1 of `out`: the ordinary tree over `out` (k_merkle_leaves packs pairs, layers compress) then IS the
-// batch tree from its first hashed layer up — hash_two_digests(hash(row 2i), hash(row 2i+1)) — so nothing else is specific to batches.
-// Reads are coalesced per polynomial (consecutive lanes, consecutive elements). Not on the zkml path (dp_pcs_batch_commit only).
-constexpr int BATCH_ROW_MAX = 32;
-struct BatchRowPtrs { const u64* cw[BATCH_ROW_MAX]; };
-template <bool EXT>
-KBODY k_batch_row_hash(BatchRowPtrs a, int k, u64* out, size_t n) {
-  constexpr int W = EXT ? 2 : 1;
-  const int m = k * W;
-  for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
-    u64 s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int c0 = 0; c0 < m; c0 += 4) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) { const int t = c0 + i; if (t < m) s[i] = a.cw[t / W][W * j + t % W]; }
-      if (m > 4) poseidon2_permute(s, c_rc);
-    }
-    u64* q = out + 4 * j;
-    if (m > 4) { q[0] = s[3]; q[1] = s[2]; q[2] = s[1]; q[3] = s[0]; }
-    else { q[0] = s[0]; q[1] = s[1]; q[2] = s[2]; q[3] = s[3]; }
-  }
-}
-
-// Several consecutive Merkle layers in ONE launch (DP_MERKLE_FUSE=levels, experiment, default off): workgroup b hashes the
-// 2 * blockDim.x digests [b * 2 blockDim.x, ..) of the input layer down `levels` layers — every layer it produces is consumed
-// by itself only, so a block barrier between layers is all the synchronisation there is — and writes each layer to its place
-// in the tree. With hundreds of proofs in flight a launch costs more than the 24 us of a lane-serial compress.
-// in: the input layer (cnt digests), out: where the layer above it starts (its cnt / 2 digests; the next ones follow).
-KBODY k_merkle_layers(const u64* in, u64* out, size_t cnt, int levels) {
-  const int tid = threadIdx.x;
-  size_t nout = blockDim.x;                              // digests this block produces in the current layer
-  size_t bo = (size_t)blockIdx.x * blockDim.x;           // index of its first one
-  size_t layer_cnt = cnt;
-  for (int l = 0; l < levels; l++) {
-    if ((size_t)tid < nout) {
-      const size_t i = bo + tid;
-      u64 o[4];
-      poseidon2_compress(in + 8 * i, in + 8 * i + 4, o, c_rc);
-      out[4 * i] = o[0]; out[4 * i + 1] = o[1]; out[4 * i + 2] = o[2]; out[4 * i + 3] = o[3];
-    }
-    __syncthreads();
-    in = out; out += 4 * (layer_cnt / 2); layer_cnt /= 2; nout /= 2; bo /= 2;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ Basefold opening (K9-K12, K14)
-struct PolyDesc { const void* f; const Ext* eq; Ext* fout; Ext* eqout; size_t n; int fext; int pad; };
-// fold every (f, eq) pair of length > 1 by r; blockIdx.y = polynomial
-KBODY k_classic_fold(const PolyDesc* d, Ext r) {
-  PolyDesc p = d[blockIdx.y];
-  if (p.n <= 1) return;
-  size_t h = p.n / 2;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < h; i += (size_t)gridDim.x * blockDim.x) {
-    p.eqout[i] = ex_lerp(p.eq[2 * i], p.eq[2 * i + 1], r);
-    if (p.fext) p.fout[i] = ex_lerp(((const Ext*)p.f)[2 * i], ((const Ext*)p.f)[2 * i + 1], r);
-    else p.fout[i] = ex_lerp_base(((const u64*)p.f)[2 * i], ((const u64*)p.f)[2 * i + 1], r);
-  }
-}
-// partial[(poly*gridDim.x + block)*2 + {0,1}]: c0 = sum f0*e0, c2 = sum (f1-f0)(e1-e0)   (coeff.rs:236-345)
-KBODY k_classic_sums(const PolyDesc* d, Ext* partial) {
-  __shared__ Ext sm[TPB / 64];
-  PolyDesc p = d[blockIdx.y];
-  Ext c0 = ex_zero(), c2 = ex_zero();
-  if (p.n == 1) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) c0 = ex_mul(ld_elem(p.f, p.fext, 0), p.eq[0]);
-  } else {
-    size_t h = p.n / 2;
-    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < h; j += (size_t)gridDim.x * blockDim.x) {
-      Ext l0 = p.eq[2 * j], l1 = p.eq[2 * j + 1];
-      if (p.fext) {
-        Ext r0 = ((const Ext*)p.f)[2 * j], r1 = ((const Ext*)p.f)[2 * j + 1];
-        c0 = ex_add(c0, ex_mul(l0, r0));
-        c2 = ex_add(c2, ex_mul(ex_sub(l1, l0), ex_sub(r1, r0)));
-      } else {
-        u64 r0 = ((const u64*)p.f)[2 * j], r1 = ((const u64*)p.f)[2 * j + 1];
-        c0 = ex_add(c0, ex_mul_base(l0, r0));
-        c2 = ex_add(c2, ex_mul_base(ex_sub(l1, l0), gl_sub(r1, r0)));
-      }
-    }
-  }
-  size_t base = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
-  Ext r;
-  r = block_reduce_ext(c0, sm); if (threadIdx.x == 0) partial[base] = r;
-  r = block_reduce_ext(c2, sm); if (threadIdx.x == 0) partial[base + 1] = r;
-}
-KBODY k_reduce_pairs(const Ext* partial, size_t nblocks, Ext* out) {
-  __shared__ Ext sm[TPB / 64];
-  size_t poly = blockIdx.x >> 1, t = blockIdx.x & 1;
-  Ext acc = ex_zero();
-  for (size_t b = threadIdx.x; b < nblocks; b += blockDim.x) acc = ex_add(acc, partial[(poly * nblocks + b) * 2 + t]);
-  Ext r = block_reduce_ext(acc, sm);
-  if (threadIdx.x == 0) out[blockIdx.x] = r;
-}
-// K11: acc[j*rep + q] += x[j] * coeff
-KBODY k_axpy_rep(Ext* acc, const void* x, int xext, Ext coeff, size_t n_acc, unsigned lg_rep) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_acc; i += (size_t)gridDim.x * blockDim.x) {
-    size_t j = i >> lg_rep;
-    Ext m = xext ? ex_mul(((const Ext*)x)[j], coeff) : ex_mul_base(coeff, ((const u64*)x)[j]);
-    acc[i] = ex_add(acc[i], m);
-  }
-}
-// K10 message on evaluation-form pairs: [sum a*ea, sum ((b-a)*ea + a*(eb-ea)), sum (b-a)(eb-ea)]
-KBODY k_bf_msg(const Ext* f, const Ext* eq, size_t npairs, Ext* partial) {
-  __shared__ Ext sm[TPB / 64];
-  Ext c0 = ex_zero(), c1 = ex_zero(), c2 = ex_zero();
-  for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < npairs; j += (size_t)gridDim.x * blockDim.x) {
-    Ext a = f[2 * j], b = ex_sub(f[2 * j + 1], a), ea = eq[2 * j], eb = ex_sub(eq[2 * j + 1], ea);
-    c0 = ex_add(c0, ex_mul(a, ea));
-    c1 = ex_add(c1, ex_add(ex_mul(b, ea), ex_mul(a, eb)));
-    c2 = ex_add(c2, ex_mul(b, eb));
-  }
-  size_t base = (size_t)blockIdx.x * 4;
-  Ext r;
-  r = block_reduce_ext(c0, sm); if (threadIdx.x == 0) partial[base] = r;
-  r = block_reduce_ext(c1, sm); if (threadIdx.x == 0) partial[base + 1] = r;
-  r = block_reduce_ext(c2, sm); if (threadIdx.x == 0) { partial[base + 2] = r; partial[base + 3] = ex_zero(); }
-}
-// K9: out[i] = y0 + (ch - x0)(y1 - y0) w,  x0 = gamma * w_{2^(level+1)}^{bitrev(i)},  w = -1/(2 x0)   (rs.rs:377-410)
-KBODY k_fri_fold(const Ext* in, Ext* out, size_t nout, unsigned level, const u64* tw, unsigned L, u64 gamma, u64 neg_inv2gamma, Ext ch) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nout; i += (size_t)gridDim.x * blockDim.x) {
-    size_t b = level ? (__brevll((unsigned long long)i) >> (64 - level)) : 0;
-    u64 root = tw[b << (L - level)];
-    u64 x0 = gl_mul(root, gamma);
-    u64 rinv = b == 0 ? 1 : gl_neg(tw[((size_t(1) << level) - b) << (L - level)]);
-    u64 w = gl_mul(neg_inv2gamma, rinv);
-    Ext y0 = in[2 * i], y1 = in[2 * i + 1];
-    Ext t = ex_mul(ex(gl_sub(ch.c0, x0), ch.c1), ex_sub(y1, y0));
-    out[i] = ex_add(y0, ex_mul_base(t, w));
-  }
-}
-struct GatherDesc { const void* leaves; const u64* nodes; size_t nleaves; size_t p0; size_t out_off; int ext; int height; };
-// K14: one wave per (query, tree): leaf pair then the sibling digests bottom-up
-KBODY k_query_gather(const GatherDesc* d, size_t nd, u64* out) {
-  size_t q = blockIdx.x * (size_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (q >= nd) return;
-  int lane = threadIdx.x & 63;
-  GatherDesc g = d[q];
-  u64* o = out + g.out_off;
-  int nleafw = g.ext ? 4 : 2;
-  if (lane < nleafw) o[lane] = ((const u64*)g.leaves)[g.p0 * (g.ext ? 2 : 1) + lane];
-  int npath = g.height - 1;
-  for (int w = lane; w < npath * 4; w += 64) {
-    int l = w >> 2;
-    size_t off = g.nleaves - (g.nleaves >> l);
-    size_t idx = (g.p0 >> (l + 1)) ^ 1;
-    o[nleafw + w] = g.nodes[4 * (off + idx) + (w & 3)];
-  }
-}
-
-
-// ---- relaxed system-scope publication helpers (see sc_publish below)
-__device__ __forceinline__ unsigned long long pub_mix(unsigned long long seq) { return seq * 0x9E3779B97F4A7C15ull + 0x7F4A7C159E3779B9ull; }
-__device__ __forceinline__ void pub_store(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-// one wave: lane l owns words l, l+64, ...; returns (on lane 0) the payload checksum
-__device__ __forceinline__ unsigned long long pub_wave_sum(unsigned long long local) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) local += shfl_down_u64(local, d);
-  return local;
-}
-
-// ------------------------------------------------------------------------------------------------ lane-parallel Poseidon2
-// One permutation spread over 8 adjacent lanes (lane i holds state[i]): used where there are too few hashes to fill
-// the machine with one-hash-per-lane (the top layers of every Merkle tree), cutting the serial latency of a compress
-// from 2 x ~520 dependent multiplications to 2 x ~100.
-__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
-  int lo = __shfl((int)(u32)v, src, 64);
-  int hi = __shfl((int)(u32)(v >> 32), src, 64);
-  return ((u64)(u32)hi << 32) | (u64)(u32)lo;
-}
-// DPP cross-lane moves (no LDS crossbar round trip): quad permutes and the 8-lane half-row mirror
-template <int CTRL>
-__device__ __forceinline__ u64 dpp_u64(u64 v) {
-  int lo = __builtin_amdgcn_update_dpp(0, (int)(u32)v, CTRL, 0xF, 0xF, false);
-  int hi = __builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), CTRL, 0xF, 0xF, false);
-  return ((u64)(u32)hi << 32) | (u64)(u32)lo;
-}
-constexpr int DPP_QUAD_ROT1 = 0x39;     // quad_perm [1,2,3,0]: lane j reads j+1 (mod 4)
-constexpr int DPP_QUAD_ROT2 = 0x4E;     // quad_perm [2,3,0,1]: lane j reads j+2 == j^2
-constexpr int DPP_QUAD_ROT3 = 0x93;     // quad_perm [3,0,1,2]: lane j reads j+3
-constexpr int DPP_QUAD_XOR1 = 0xB1;     // quad_perm [1,0,3,2]
-constexpr int DPP_QUAD_REV = 0x1B;      // quad_perm [3,2,1,0]
-constexpr int DPP_HALF_MIRROR = 0x141;  // row_half_mirror: lane i reads 7-i within its group of 8
-constexpr int DPP_QUAD_BCAST0 = 0x00;   // quad_perm [0,0,0,0]: every lane of a quad reads the quad's lane 0
-// The 8-lane permutation in the formulation of poseidon2_fast.h: state words are any u64 representative, the linear layers
-// are accumulated as exact integers (64 + 32 bits) THROUGH the DPP moves and reduced once together with the next round
-// constant. One wave on this dependent chain runs at ~8 cycles per instruction, so instructions are what counts: a modular
-// add is ~9 of them, a wide add 3. (The sponge of every fused protocol kernel and the narrow Merkle layers run on this.)
-template <int CTRL> __device__ __forceinline__ p2f::W dpp_w(p2f::W a) { p2f::W r; r.lo = dpp_u64<CTRL>(a.lo); r.hi = (u32)dpp_u64<CTRL>((u64)a.hi); return r; }
-// external layer circ(2 M4, M4) on the word of this lane: exact, < 21 * 2^64
-__device__ __forceinline__ p2f::W p2l_mds_wide(u64 s) {
-  using namespace p2f;
-  W ws = w_of(s), b = w_of(dpp_u64<DPP_QUAD_ROT1>(s)), c = w_of(dpp_u64<DPP_QUAD_ROT2>(s)), d = w_of(dpp_u64<DPP_QUAD_ROT3>(s));
-  W t = w_add(w_add(w_add(ws, ws), w_add(b, w_add(b, b))), w_add(c, d));  // row j of circ(2,3,1,1): 2s + 3b + c + d
-  W o = dpp_w<DPP_QUAD_REV>(dpp_w<DPP_HALF_MIRROR>(t));                     // lane i reads i ^ 4
-  return w_add(w_add(t, t), o);
-}
-__device__ __forceinline__ u64 p2l_mds_light(u64 s, int lane) { (void)lane; return p2f::canon(p2f::w_reduce(p2l_mds_wide(s))); }
-__device__ __forceinline__ u64 p2l_permute(u64 s, int lane) {
-  using namespace p2f;
-  const int i = lane & 7;
-  W w = p2l_mds_wide(s);
-  for (int r = 0; r < 4; r++) { s = sbox(w_reduce(w_add64(w, c_rc[r * 8 + i]))); w = p2l_mds_wide(s); }
-  s = w_reduce(w);
-  const u64 diag = c_rc[86 + i];
-  for (int r = 0; r < 22; r++) {
-    // the words that keep their value this round, summed over the group (independent of the S-box chain below)
-    W rest = i == 0 ? w_of(0) : w_of(s);
-    rest = w_add(rest, dpp_w<DPP_QUAD_XOR1>(rest));
-    rest = w_add(rest, dpp_w<DPP_QUAD_ROT2>(rest));
-    rest = w_add(rest, dpp_w<DPP_HALF_MIRROR>(rest));  // every lane of a quad holds the quad sum: any lane of the other quad will do
-    // x^7 of word 0 (every lane computes, lane 0's counts), broadcast to the group of 8
-    const u64 x7 = sbox(w_reduce(w_add64(w_of(s), c_rc[32 + r])));
-    const u64 q = dpp_u64<DPP_QUAD_BCAST0>(x7), m = dpp_u64<DPP_HALF_MIRROR>(q);
-    const u64 x7b = i < 4 ? q : m;
-    const W sum = w_add64(rest, x7b);
-    // y_i = d_i x_i + sum, one 128 -> 64 reduction (the high word of the product stays below p after + sum)
-    unsigned __int128 pr = (unsigned __int128)(i == 0 ? x7b : s) * diag;
-    u64 lo, hi = (u64)(pr >> 64);
-    bool cy = __builtin_add_overflow((u64)pr, sum.lo, &lo);
-    hi += (u64)sum.hi + (cy ? 1u : 0u);
-    s = red128(lo, hi);
-  }
-  w = w_of(s);
-  for (int r = 0; r < 4; r++) { s = sbox(w_reduce(w_add64(w, c_rc[54 + r * 8 + i]))); w = p2l_mds_wide(s); }
-  return canon(w_reduce(w));  // canonical: the host resumes transcripts from these words
-}
-// in: 8 words (two digests), out: 4 words; executed by the 8 lanes of one group together
-__device__ __forceinline__ void p2l_compress(const u64* in, u64* out, int lane) {
-  int i = lane & 7;
-  u64 s = i < 4 ? in[i] : 0;
-  s = p2l_permute(s, lane);
-  if (i < 4) s = in[4 + i];
-  s = p2l_permute(s, lane);
-  if (i < 4) out[3 - i] = s;
-}
-// one Merkle layer with 8 lanes per node: for layers too narrow to hide the latency of a one-lane compress
-KBODY k_merkle_layer_lp(const u64* in, u64* out, size_t cnt) {
-  size_t g = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 3;
-  size_t stride = ((size_t)gridDim.x * blockDim.x) >> 3;
-  if (DP_SKIP_HASH_ON()) { for (; g < cnt; g += stride) if ((threadIdx.x & 7) < 4) out[4 * g + (threadIdx.x & 7)] = in[8 * g + (threadIdx.x & 7)]; return; }
-  for (; g < cnt; g += stride) p2l_compress(in + 8 * g, out + 4 * g, threadIdx.x & 63);
-}
-// verifier: one Merkle path per lane, from the leaf-pair digest up to the root (authenticate_merkle_path_root,
-// mpcs/src/util/merkle_tree.rs:331-420). meta[3j..] = {index of the leaf pair, first digest of the path in `pool`, depth};
-// bad[0] counts the paths that do not authenticate, bad[1] = the smallest index of one
-KBODY k_merkle_paths(const u64* leaf, const u64* root, const u64* meta, const u64* pool, size_t n, unsigned long long* bad) {
-  for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < n; j += (size_t)gridDim.x * blockDim.x) {
-    u64 h[4] = {leaf[4 * j], leaf[4 * j + 1], leaf[4 * j + 2], leaf[4 * j + 3]};
-    u64 x = meta[3 * j];
-    const u64* p = pool + 4 * meta[3 * j + 1];
-    const unsigned depth = (unsigned)meta[3 * j + 2];
-    for (unsigned l = 0; l < depth; l++) {
-      u64 sib[4] = {p[4 * l], p[4 * l + 1], p[4 * l + 2], p[4 * l + 3]}, o[4];
-      if (x & 1) p2f::compress(sib, h, o, c_rc); else p2f::compress(h, sib, o, c_rc);
-      h[0] = o[0]; h[1] = o[1]; h[2] = o[2]; h[3] = o[3];
-      x >>= 1;
-    }
-    if (h[0] != root[4 * j] || h[1] != root[4 * j + 1] || h[2] != root[4 * j + 2] || h[3] != root[4 * j + 3]) { atomicAdd(&bad[0], 1ull); atomicMin(&bad[1], (unsigned long long)j); }
-  }
-}
-struct TailDesc { u64* nodes; size_t off; size_t cnt; };
-// All Merkle layers above an already computed layer of `cnt` (<= 2048) digests, one workgroup per tree, no relaunch
-// between layers. Wide layers hash one node per lane, narrow ones use the 8-lane permutation. roots[4*tree..] = root.
-KBODY k_merkle_tail(const TailDesc* d, u64* roots, u64* host_result, unsigned long long* flag, unsigned long long seq) {
-  TailDesc t = d[blockIdx.x];
-  u64* nd = t.nodes;
-  size_t off = t.off, cnt = t.cnt;
-  int tid = threadIdx.x;
-  while (cnt > 1) {
-    size_t next = cnt / 2;
-    const u64* in = nd + 4 * off;
-    u64* out = nd + 4 * (off + cnt);
-    if (next > blockDim.x) {  // very wide layer: one node per lane; otherwise 8 lanes per node (the DPP permutation is ~8x lower latency)
-      for (size_t i = tid; i < next; i += blockDim.x) {
-        u64 o[4];
-        poseidon2_compress(in + 8 * i, in + 8 * i + 4, o, c_rc);
-        out[4 * i] = o[0]; out[4 * i + 1] = o[1]; out[4 * i + 2] = o[2]; out[4 * i + 3] = o[3];
-      }
-    } else {
-      for (size_t g = tid >> 3; g < next; g += (blockDim.x >> 3)) p2l_compress(in + 8 * g, out + 4 * g, tid & 63);
-    }
-    __syncthreads();
-    off += cnt; cnt = next;
-  }
-  if (tid < 4) roots[4 * blockIdx.x + tid] = nd[4 * off + tid];
-  if (host_result && tid < 64) {  // single tree: publish the root (4 words) directly
-    unsigned long long cs = 0;
-    if (tid < 4) { u64 v = nd[4 * off + tid]; pub_store(host_result + tid, v); cs = (unsigned long long)(tid + 1) * v; }
-    cs = pub_wave_sum(cs);
-    if (tid == 0) pub_store((u64*)flag, pub_mix(seq) + cs);
-  }
-}
-struct SmallCommitDesc { const void* evals; void* cw; void* bh; u64* nodes; void* tmp; };
-// layer 0 of many equally sized trees: blockIdx.y = tree
-template <bool EXT>
-KBODY k_merkle_leaves_many(const SmallCommitDesc* d, size_t npairs) {
-  const void* leaves = d[blockIdx.y].cw;
-  u64* nodes = d[blockIdx.y].nodes;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npairs; i += (size_t)gridDim.x * blockDim.x) {
-    u64 d0, d1, d2, d3;
-    if (EXT) { Ext a = ((const Ext*)leaves)[2 * i], b = ((const Ext*)leaves)[2 * i + 1]; d0 = a.c0; d1 = a.c1; d2 = b.c0; d3 = b.c1; }
-    else { d0 = ((const u64*)leaves)[2 * i]; d1 = ((const u64*)leaves)[2 * i + 1]; d2 = 0; d3 = 0; }
-    u64* o = nodes + 4 * i;
-    o[0] = d0; o[1] = d1; o[2] = d2; o[3] = d3;
-  }
-}
-template <bool EXT> struct ElemOps;
-template <> struct ElemOps<false> {
-  typedef u64 T;
-  static __device__ __forceinline__ T sub(T a, T b) { return gl_sub(a, b); }
-  static __device__ __forceinline__ T add(T a, T b) { return gl_add(a, b); }
-  static __device__ __forceinline__ T mulb(T a, u64 b) { return gl_mul(a, b); }
-};
-template <> struct ElemOps<true> {
-  typedef Ext T;
-  static __device__ __forceinline__ T sub(T a, T b) { return ex_sub(a, b); }
-  static __device__ __forceinline__ T add(T a, T b) { return ex_add(a, b); }
-  static __device__ __forceinline__ T mulb(T a, u64 b) { return ex_mul_base(a, b); }
-};
-// Stages [s_lo, s_hi) of the Moebius transform (NTT = false: p[lo + half] -= p[lo]) or of the radix-2 DIT NTT (NTT = true:
-// butterfly with w = tw[j << (L - s)], j = the index bits below s) in ONE launch, LDS-tiled: a tile is the 2^(s_hi - s_lo + lgc)
-// elements whose index is (hi << s_hi) | (m << s_lo) | (lowblk << lgc) | c for all m < 2^(s_hi - s_lo), c < 2^lgc — the bits
-// the stages act on (m) plus 2^lgc consecutive elements, so that global accesses stay 128-byte segments when the stride
-// 2^s_lo is large; lgc <= s_lo, and with lgc == s_lo the tile is one contiguous block. Tiles partition the array, every stage of
-// the range only pairs elements of one tile: a 2^20-coefficient polynomial takes 2 Moebius + 2 NTT passes instead of 20 + 20
-// per-stage launches over HBM (K5 / K7). In LDS the element sits at (m << lgc) | c.
-template <bool EXT, bool NTT>
-KBODY k_butterfly_pass(void* data, unsigned s_lo, unsigned s_hi, unsigned lgc, const u64* tw, unsigned L) {
-  extern __shared__ __align__(16) unsigned char lds_bp[];
-  typedef typename ElemOps<EXT>::T T;
-  T* A = (T*)lds_bp;
-  T* p = (T*)data;
-  const unsigned span = s_hi - s_lo, lgt = span + lgc;
-  const size_t tile = blockIdx.x;
-  const size_t nlowblk = size_t(1) << (s_lo - lgc);           // tiles per value of the high bits
-  const size_t hi = tile >> (s_lo - lgc), lowblk = tile & (nlowblk - 1);
-  const size_t base = (hi << s_hi) | (lowblk << lgc);
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const size_t telems = size_t(1) << lgt;
-  for (size_t q = tid; q < telems; q += nt) { size_t m = q >> lgc, c = q & ((size_t(1) << lgc) - 1); A[q] = p[base | (m << s_lo) | c]; }
-  __syncthreads();
-  for (unsigned s = s_lo; s < s_hi; s++) {
-    const unsigned b = s - s_lo;                               // the bit of m this stage pairs
-    for (size_t q = tid; q < telems / 2; q += nt) {
-      // q enumerates the pairs: insert a 0 at bit (b + lgc) of the LDS position
-      const size_t lowmask = (size_t(1) << (b + lgc)) - 1;
-      const size_t lo = ((q & ~lowmask) << 1) | (q & lowmask), hi2 = lo | (size_t(1) << (b + lgc));
-      if (NTT) {
-        const size_t m = lo >> lgc, c = lo & ((size_t(1) << lgc) - 1);
-        const size_t j = ((m & ((size_t(1) << b) - 1)) << s_lo) | (lowblk << lgc) | c;   // index bits below s
-        const u64 w = tw[j << (L - s)];
-        T t = ElemOps<EXT>::mulb(A[hi2], w), u = A[lo];
-        A[lo] = ElemOps<EXT>::add(u, t); A[hi2] = ElemOps<EXT>::sub(u, t);
-      } else A[hi2] = ElemOps<EXT>::sub(A[hi2], A[lo]);
-    }
-    __syncthreads();
-  }
-  for (size_t q = tid; q < telems; q += nt) { size_t m = q >> lgc, c = q & ((size_t(1) << lgc) - 1); p[base | (m << s_lo) | c] = A[q]; }
-}
-// K5+K6+K7 for a small polynomial entirely in LDS: evaluations -> coefficients (Moebius), coset scale, zero-pad,
-// radix-2 DIT NTT on 2n points, bit-reversed store; also the bit-reversed copy of the evaluations. One workgroup per
-// polynomial (blockIdx.x), dynamic LDS = 3n elements.
-template <bool EXT>
-KBODY k_commit_small(const SmallCommitDesc* d, unsigned nv, unsigned L, const u64* tw, const u64* pow7) {
-  typedef typename ElemOps<EXT>::T T;
-  extern __shared__ __align__(16) unsigned char lds_raw[];
-  T* A = (T*)lds_raw;  // n coefficients
-  size_t n = size_t(1) << nv, N = 2 * n;
-  T* Bf = A + n;       // 2n NTT buffer
-  SmallCommitDesc pd = d[blockIdx.x];
-  const T* ev = (const T*)pd.evals;
-  T* bh = (T*)pd.bh;
-  T* cw = (T*)pd.cw;
-  int tid = threadIdx.x, nt = blockDim.x;
-  for (size_t i = tid; i < n; i += nt) {
-    T v = ev[i];
-    A[i] = v;
-    bh[__brev((unsigned)i) >> (32 - nv)] = v;
-  }
-  __syncthreads();
-  for (unsigned s = 0; s < nv; s++) {
-    size_t half = size_t(1) << s;
-    for (size_t b = tid; b < n / 2; b += nt) {
-      size_t lo = ((b >> s) << (s + 1)) | (b & (half - 1));
-      A[lo + half] = ElemOps<EXT>::sub(A[lo + half], A[lo]);
-    }
-    __syncthreads();
-  }
-  for (size_t i = tid; i < n; i += nt) {
-    size_t j = __brev((unsigned)i) >> (32 - nv);
-    T v = ElemOps<EXT>::mulb(A[i], pow7[j << (L - nv)]);
-    Bf[2 * i] = v; Bf[2 * i + 1] = v;
-  }
-  __syncthreads();
-  for (unsigned s = 1; s <= nv; s++) {
-    size_t half = size_t(1) << s;
-    for (size_t b = tid; b < n; b += nt) {
-      size_t j = b & (half - 1);
-      size_t lo = ((b >> s) << (s + 1)) | j;
-      T t = ElemOps<EXT>::mulb(Bf[lo + half], tw[j << (L - s)]), u = Bf[lo];
-      Bf[lo] = ElemOps<EXT>::add(u, t);
-      Bf[lo + half] = ElemOps<EXT>::sub(u, t);
-    }
-    __syncthreads();
-  }
-  for (size_t o = tid; o < N; o += nt) cw[o] = Bf[__brev((unsigned)o) >> (32 - (nv + 1))];
-}
-
-// ---- medium polynomials (2^12..2^14 base elements: the witness columns of a convolution layer), many at once: blockIdx.y
-// (or .x) = polynomial. Four launches replace the 2 nv + 4 per-stage launches of the generic path, for the whole group.
-constexpr unsigned MED_NTT_LG = 13;  // an NTT block of 2^13 base elements (64 KB) lives in LDS
-// K5 + K6 + coset scaling: evaluations -> LDS, all Moebius stages there, then tmp[2i] = tmp[2i+1] = coeff[i] * shift^bitrev(i)
-// (the zero-padded, bit-reversed DIT input after its trivial first stage) and bh[bitrev(i)] = evals[i]
-KBODY k_med_prepare(const SmallCommitDesc* d, unsigned nv, unsigned L, const u64* pow7) {
-  extern __shared__ __align__(16) unsigned char lds_med[];
-  u64* A = (u64*)lds_med;
-  SmallCommitDesc pd = d[blockIdx.x];
-  const u64* ev = (const u64*)pd.evals; u64* bh = (u64*)pd.bh; u64* tmp = (u64*)pd.tmp;
-  size_t n = size_t(1) << nv;
-  int tid = threadIdx.x, nt = blockDim.x;
-  for (size_t i = tid; i < n; i += nt) { u64 v = ev[i]; A[i] = v; bh[__brev((unsigned)i) >> (32 - nv)] = v; }
-  __syncthreads();
-  for (unsigned s = 0; s < nv; s++) {
-    size_t half = size_t(1) << s;
-    for (size_t b = tid; b < n / 2; b += nt) { size_t lo = ((b >> s) << (s + 1)) | (b & (half - 1)); A[lo + half] = gl_sub(A[lo + half], A[lo]); }
-    __syncthreads();
-  }
-  for (size_t i = tid; i < n; i += nt) {
-    size_t j = __brev((unsigned)i) >> (32 - nv);
-    u64 v = gl_mul(A[i], pow7[j << (L - nv)]);
-    ((ulonglong2*)tmp)[i] = make_ulonglong2(v, v);
-  }
-}
-// DIT stages 1..smax (butterfly span <= 2^MED_NTT_LG) of the 2n-point NTT, one LDS-resident block per workgroup
-KBODY k_med_ntt_local(const SmallCommitDesc* d, unsigned lgblk, unsigned smax, const u64* tw, unsigned L) {
-  extern __shared__ __align__(16) unsigned char lds_med[];
-  u64* B = (u64*)lds_med;
-  size_t blk = size_t(1) << lgblk;
-  u64* p = (u64*)d[blockIdx.y].tmp + blockIdx.x * blk;
-  int tid = threadIdx.x, nt = blockDim.x;
-  for (size_t i = tid; i < blk; i += nt) B[i] = p[i];
-  __syncthreads();
-  for (unsigned s = 1; s <= smax; s++) {
-    size_t half = size_t(1) << s;
-    for (size_t b = tid; b < blk / 2; b += nt) {
-      size_t j = b & (half - 1), lo = ((b >> s) << (s + 1)) | j;
-      u64 t = gl_mul(B[lo + half], tw[j << (L - s)]), u = B[lo];
-      B[lo] = gl_add(u, t); B[lo + half] = gl_sub(u, t);
-    }
-    __syncthreads();
-  }
-  for (size_t i = tid; i < blk; i += nt) p[i] = B[i];
-}
-KBODY k_ntt_stage_many(const SmallCommitDesc* d, size_t N, unsigned lg_half, const u64* tw, unsigned L) {
-  u64* p = (u64*)d[blockIdx.y].tmp;
-  size_t half = size_t(1) << lg_half;
-  for (size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x; b < N / 2; b += (size_t)gridDim.x * blockDim.x) {
-    size_t j = b & (half - 1), lo = ((b >> lg_half) << (lg_half + 1)) | j;
-    u64 t = gl_mul(p[lo + half], tw[j << (L - lg_half)]), u = p[lo];
-    p[lo] = gl_add(u, t); p[lo + half] = gl_sub(u, t);
-  }
-}
-KBODY k_bitrev_many(const SmallCommitDesc* d, unsigned lg) {
-  const u64* src = (const u64*)d[blockIdx.y].tmp; u64* dst = (u64*)d[blockIdx.y].cw;
-  size_t n = size_t(1) << lg;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[__brevll((unsigned long long)i) >> (64 - lg)] = src[i];
-}
-// one Merkle layer of many equally shaped trees (one Poseidon2 compress per lane): blockIdx.y = tree
-KBODY k_merkle_layer_many(const TailDesc* td, size_t off, size_t cnt) {
-  u64* nd = td[blockIdx.y].nodes;
-  const u64* in = nd + 4 * off; u64* out = nd + 4 * (off + cnt);
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cnt / 2; i += (size_t)gridDim.x * blockDim.x) {
-    const ulonglong2* p = (const ulonglong2*)(in + 8 * i);
-    ulonglong2 x01 = p[0], x23 = p[1], y01 = p[2], y23 = p[3];
-    u64 x[4] = {x01.x, x01.y, x23.x, x23.y}, y[4] = {y01.x, y01.y, y23.x, y23.y}, o[4];
-    merkle_compress(x, y, o);
-    ulonglong2* q = (ulonglong2*)(out + 4 * i);
-    q[0] = make_ulonglong2(o[0], o[1]); q[1] = make_ulonglong2(o[2], o[3]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ single-launch sumcheck round
-__device__ void sc_publish_fwd(Ext* result, const Ext* part, const int* tk, const int* toff, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane);
-__device__ void sc_wait_challenge_fwd(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal);
-struct ScSmallArgs {
-  const void* in[MAX_TABS]; Ext* out[MAX_TABS]; int in_ext[MAX_TABS];
-  int k[MAX_TERMS]; int t[MAX_TERMS][SC_MAXK]; int off[MAX_TERMS];  // off[i] = sum_{j<i} (k_j + 1): slot of term i in the published message
-  int ntabs, nterms, has_r; size_t n_after; Ext r;
-};
-__device__ __forceinline__ Ext block_reduce_ext_n(Ext v, Ext* sm) {
-  v = wave_reduce_ext(v);
-  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) sm[w] = v;
-  __syncthreads();
-  Ext r = ex_zero();
-  if (threadIdx.x == 0) { r = sm[0]; for (int i = 1; i < (int)(blockDim.x >> 6); i++) r = ex_add(r, sm[i]); }
-  return r;
-}
-// K1 + K3 + final reduction in ONE workgroup for small tables: fold with r (if any), then every term's round sums.
-// Terms are spread over the waves of the block (a term with many pairs is split over several waves), so the only
-// block-wide barriers are the one after the fold and the one before the final combine; wave 0 then writes
-// result[term*4 + t] straight into host-mapped memory and releases `flag = seq`.
-template <bool HI>
-KBODY k_sc_small(const ScSmallArgs& a, Ext* result, unsigned long long* flag, unsigned long long seq) {
-  __shared__ Ext part[64 * SC_SLOTS];  // [slot][t], slot = term * wpt + sub  (<= 64 slots)
-  int tid = threadIdx.x, nt = blockDim.x;
-  size_t n = a.n_after;
-  if (a.has_r) {
-    for (int t = 0; t < a.ntabs; t++) {
-      Ext* o = a.out[t];
-      if (a.in_ext[t]) { const Ext* p = (const Ext*)a.in[t]; for (size_t i = tid; i < n; i += nt) o[i] = ex_lerp(p[2 * i], p[2 * i + 1], a.r); }
-      else { const u64* p = (const u64*)a.in[t]; for (size_t i = tid; i < n; i += nt) o[i] = ex_lerp_base(p[2 * i], p[2 * i + 1], a.r); }
-    }
-    __syncthreads();
-  }
-  size_t npairs = n / 2;
-  int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
-  int wpt = a.nterms >= W ? 1 : W / a.nterms;  // waves per term
-  for (int term = wave / wpt; term < a.nterms; term += (wpt == 1 ? W : a.nterms + W)) {
-    int sub = wave % wpt;
-    int k = a.k[term];
-    GlobalPairs L;
-#pragma unroll
-    for (int j = 0; j < ScW<HI>::K; j++) { int ti = a.t[term][j < k ? j : 0]; L.p[j] = a.has_r ? (const void*)a.out[ti] : a.in[ti]; L.e[j] = a.has_r ? true : a.in_ext[ti]; }
-    Ext acc[SC_SLOTS];
-    sc_accumulate<HI>(k, L, (size_t)sub * 64 + lane, (size_t)wpt * 64, npairs, acc);
-#pragma unroll
-    for (int t = 0; t < SC_SLOTS; t++) if (t <= k) acc[t] = wave_reduce_ext(acc[t]);
-    if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * SC_SLOTS; for (int t = 0; t < SC_SLOTS; t++) o[t] = acc[t]; }
-    if (wpt > 1) break;  // with several waves per term every wave owns exactly one (term, sub)
-  }
-  __syncthreads();
-  if (wave == 0) sc_publish_fwd(result, part, a.k, a.off, a.nterms, wpt, flag, seq, lane);
-}
-
-// ------------------------------------------------------------------------------------------------ device-side Fiat-Shamir
-// With many proofs in flight the per-round trip to the host (publish the round sums, the host runs the sponge, the kernel
-// polls the mailbox) is what a proof spends its time on: the host threads serve several proofs each and every hop crosses
-// PCIe. A persistent sumcheck can instead keep the transcript to itself: it gets the sponge state of the host transcript
-// (DuplexChallenger<F,P,8,4>, poseidon/src/challenger.rs:14-46 — poseidon2.h `Challenger`), combines the term sums into the
-// round message exactly as sumcheck_prove does (coefficients, extrapolation to max_degree + 1 points: prover.rs:498-585),
-// absorbs it, squeezes the challenge (transcript/src/basic.rs:8-54) and goes on; at the end ONE publication carries all
-// round messages, all challenges, the final evaluations and the sponge state back to the host transcript.
-// Field arithmetic is exact and canonical, so the messages and challenges are the host's bit for bit.
-// The sponge runs on wave 0 with the lane-parallel permutation (p2l_permute: state[i] in lane i of every group of 8).
-// the reply poll of wc_request: bounded in time like sc_wait_challenge (the emulator of tests/ defines both macros itself and serves
-// the request from inside the poll)
-#ifndef WC_POLL_PAUSE
-#define WC_POLL_BEGIN const unsigned long long wc_t0 = dp_realtime();
-#define WC_POLL_PAUSE(spin) wc_poll_pause(wc_t0, spin)
-__device__ __forceinline__ bool wc_poll_pause(unsigned long long t0, unsigned spin) {
-  if ((spin & 63) == 63 && dp_realtime() - t0 > c_poll_timeout_ticks) return true;
-  for (int q = 0; q < c_poll_sleep; q++) __builtin_amdgcn_s_sleep(16);
-  return false;
-}
-#endif
-struct ScFsArgs {
-  u64 state[8]; u64 in_buf[4]; int in_len, out_len;  // the host Challenger at the start of the first round
-  int md, rounds;                                    // max_degree of the virtual polynomial, rounds the kernel runs
-  u64 label[2]; int nlabel, pad;                     // "Internal round" as transcript words
-  Ext coeff[MAX_TERMS];                              // coefficient of every product term
-};
-__constant__ u64 c_extrap[(SC_MAXK + 1) * (SC_MAXK + 1) * (SC_MAXK + 1)];  // [k][at][i]: extrapolation_coeffs(k, at)[i] of sumcheck.h
-// Host mode (req != nullptr, DP_HOST_SPONGE=1; sponge_host.h): the sponge stays in the host transcript. Observed words are staged in the
-// mapped request area by lane 0; a sample posts the request (tag = sequence + checksum: the host re-reads until it is complete) and
-// every lane polls the reply area for the sponge's output buffer (uniform decision: the tag and length lane 0 read, the four outputs
-// lanes 0..3 read, validated by the reply's own tag). 2.9 us per round trip against ~12 us per permutation on an 8-lane wave.
-struct WaveChallenger {
-  u64 st, ib; int in_len, out_len;
-  u64* req = nullptr; const u64* rep = nullptr; unsigned n = 0, consumed = 0, failed = 0; unsigned long long rseq = 0, cs = 0; u64 cache = 0;
-};
-__device__ __forceinline__ void wc_host_init(WaveChallenger& c, u64* req, const u64* rep, unsigned long long seq0) {
-  c.req = req; c.rep = rep; c.rseq = seq0; c.n = c.consumed = c.failed = 0; c.cs = 0; c.cache = 0;
-  if (req) c.out_len = 0;  // nothing cached: the first sample asks the host
-}
-__device__ __forceinline__ void wc_request(WaveChallenger& c, int lane, int want) {
-  c.rseq++;
-  if (lane == 0) {
-    pub_store(c.req + 1, (u64)c.n); pub_store(c.req + 2, (u64)c.consumed); pub_store(c.req + 3, (u64)want);
-    pub_store(c.req, wc_req_mix(c.rseq) + c.cs + 3ull * c.n + 5ull * c.consumed + 7ull * (u64)want);
-  }
-  const unsigned long long base = wc_rep_mix(c.rseq);
-  u64 ol = 0, o = 0;
-  bool ok = false;
-  WC_POLL_BEGIN
-  u64 seen = __hip_atomic_load(c.rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (the previous reply's tag)
-  seen = shfl_u64(seen, 0);
-  for (unsigned spin = 0;; spin++) {
-    // one PCIe read per poll (every lane asks for the same word): the payload is only fetched once the tag word has changed —
-    // 264 workgroups polling three words each saturate the link's read rate and slow every poll down
-    u64 tag = __hip_atomic_load(c.rep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    tag = shfl_u64(tag, 0);
-    if (tag != seen || spin == 0) {
-      ol = __hip_atomic_load(c.rep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      o = __hip_atomic_load(c.rep + 2 + (lane & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      ol = shfl_u64(ol, 0);
-      const u64 w = o * (u64)((lane & 3) + 1);
-      const u64 sum = ol + shfl_u64(w, 0) + shfl_u64(w, 1) + shfl_u64(w, 2) + shfl_u64(w, 3);
-      if (tag == base + sum && ol <= 4) { ok = true; break; }
-    }
-    if (WC_POLL_PAUSE(spin)) break;
-  }
-  c.n = 0; c.cs = 0; c.consumed = 0;
-  if (ok) { c.out_len = (int)ol; c.cache = o; } else { c.failed = 1; c.out_len = 4; c.cache = 0; }
-}
-// end of a kernel: the words observed since the last sample, and the samples popped since the last reply, reach the host before the
-// kernel's own message does (the host transcript is complete when the proof's thread sees that message)
-__device__ __forceinline__ void wc_finish(WaveChallenger& c, int lane) { if (c.req) wc_request(c, lane, 0); }
-__device__ __forceinline__ void wc_duplex(WaveChallenger& c, int lane) {
-  if ((lane & 7) < c.in_len) c.st = c.ib;
-  c.in_len = 0;
-  c.st = p2l_permute(c.st, lane);
-  c.out_len = 4;
-}
-__device__ __forceinline__ void wc_observe(WaveChallenger& c, u64 v, int lane) {  // v uniform over the wave
-  if (c.req) {
-    c.out_len = 0;
-    if (lane == 0) { pub_store(c.req + 4 + c.n, v); c.cs += (unsigned long long)(c.n + 1) * v; }
-    if (++c.n == WC_REQ_CAP) wc_request(c, lane, 0);
-    return;
-  }
-  c.out_len = 0;
-  if ((lane & 7) == c.in_len) c.ib = v;
-  if (++c.in_len == 4) wc_duplex(c, lane);
-}
-__device__ __forceinline__ u64 wc_sample(WaveChallenger& c, int lane) {
-  if (c.req) {
-    if (c.n != 0 || c.out_len == 0) wc_request(c, lane, 1);
-    --c.out_len; c.consumed++;
-    return shfl_u64(c.cache, c.out_len);
-  }
-  if (c.in_len != 0 || c.out_len == 0) wc_duplex(c, lane);
-  --c.out_len;
-  return shfl_u64(c.st, c.out_len);
-}
-__device__ __forceinline__ Ext sc_term_sum(const Ext* part, int term, int t, int wpt) {
-  if (wpt == 1) return part[(size_t)term * SC_SLOTS + t];
-  Ext v = ex_zero();
-  for (int sb = 0; sb < wpt; sb++) v = ex_add(v, part[(size_t)(term * wpt + sb) * SC_SLOTS + t]);
-  return v;
-}
-// host result area of a device-driven sumcheck, in words: [rounds x (md+1) message values][rounds challenges][ntabs finals][14 sponge words]
-__device__ __forceinline__ size_t fs_msg_word(const ScFsArgs& f, int round, int j) { return ((size_t)round * (f.md + 1) + j) * 2; }
-__device__ __forceinline__ size_t fs_chal_word(const ScFsArgs& f, int round) { return ((size_t)f.rounds * (f.md + 1) + round) * 2; }
-__device__ __forceinline__ size_t fs_final_word(const ScFsArgs& f) { return ((size_t)f.rounds * (f.md + 2)) * 2; }
-// One round on wave 0 (all 64 lanes): part[] holds the raw term sums. Returns the challenge; `cs` accumulates the checksum
-// of the words this lane has sent to the host.
-__device__ __forceinline__ Ext sc_fs_round(WaveChallenger& wc, const ScFsArgs& f, const Ext* part, const int* tk, int nterms, int wpt, u64* rw, int round, unsigned long long& cs, int lane) {
-  const int j = lane & 7, tg = lane >> 3;
-  Ext acc = ex_zero();
-  if (j <= f.md) {
-    for (int t = tg; t < nterms; t += 8) {
-      int k = tk[t];
-      Ext v;
-      if (j <= k) v = sc_term_sum(part, t, j, wpt);
-      else {
-        const u64* c = c_extrap + ((size_t)k * (SC_MAXK + 1) + j) * (SC_MAXK + 1);
-        v = ex_zero();
-        for (int i = 0; i <= k; i++) v = ex_add(v, ex_mul_base(sc_term_sum(part, t, i, wpt), c[i]));
-      }
-      acc = ex_add(acc, ex_mul(v, f.coeff[t]));
-    }
-  }
-#pragma unroll
-  for (int d = 8; d <= 32; d <<= 1) {
-    Ext o = ex(shfl_u64(acc.c0, lane ^ d), shfl_u64(acc.c1, lane ^ d));
-    acc = ex_add(acc, o);
-  }
-  for (int jj = 0; jj <= f.md; jj++) {
-    u64 c0 = shfl_u64(acc.c0, jj), c1 = shfl_u64(acc.c1, jj);
-    wc_observe(wc, c0, lane); wc_observe(wc, c1, lane);
-    if (lane == 0) { size_t w = fs_msg_word(f, round, jj); pub_store(rw + w, c0); pub_store(rw + w + 1, c1); cs += (unsigned long long)(w + 1) * c0 + (unsigned long long)(w + 2) * c1; }
-  }
-  for (int q = 0; q < f.nlabel; q++) wc_observe(wc, f.label[q], lane);
-  u64 r0 = wc_sample(wc, lane), r1 = wc_sample(wc, lane);
-  if (lane == 0) { size_t w = fs_chal_word(f, round); pub_store(rw + w, r0); pub_store(rw + w + 1, r1); cs += (unsigned long long)(w + 1) * r0 + (unsigned long long)(w + 2) * r1; }
-  return ex(r0, r1);
-}
-// the last message of a device-driven sumcheck: final evaluation of every table (src[e * stride]), the sponge, the tag
-__device__ __forceinline__ void sc_fs_finish(const WaveChallenger& wc, const ScFsArgs& f, const Ext* const* srcs, const Ext* src, size_t stride, int ntabs, u64* rw, unsigned long long* flag, unsigned long long seq, unsigned long long cs, int lane) {
-  size_t w0 = fs_final_word(f);
-  for (int e = lane; e < ntabs; e += 64) {
-    Ext v = srcs ? srcs[e][0] : src[(size_t)e * stride];
-    size_t w = w0 + 2 * e;
-    pub_store(rw + w, v.c0); pub_store(rw + w + 1, v.c1);
-    cs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1;
-  }
-  size_t ws = w0 + 2 * (size_t)ntabs;
-  if (lane < 8) { pub_store(rw + ws + lane, wc.st); cs += (unsigned long long)(ws + lane + 1) * wc.st; }
-  if (lane < 4) { u64 v = lane < wc.in_len ? wc.ib : 0; pub_store(rw + ws + 8 + lane, v); cs += (unsigned long long)(ws + 8 + lane + 1) * v; }
-  if (lane == 0) {
-    u64 a = (u64)wc.in_len, b = (u64)wc.out_len;
-    pub_store(rw + ws + 12, a); pub_store(rw + ws + 13, b);
-    cs += (unsigned long long)(ws + 13) * a + (unsigned long long)(ws + 14) * b;
-  }
-  cs = pub_wave_sum(cs);
-  if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + cs);
-}
-__device__ __forceinline__ void wc_load(WaveChallenger& wc, const ScFsArgs& f, int lane) {
-  wc.st = f.state[lane & 7]; wc.ib = f.in_buf[lane & 3]; wc.in_len = f.in_len; wc.out_len = f.out_len;
-}
-
-// ------------------------------------------------------------------------------------------------ persistent sumcheck
-// A whole (tail of a) sumcheck in ONE launch of ONE workgroup: per round the kernel publishes the raw term sums to
-// host-mapped memory, the host runs the Fiat-Shamir sponge and posts the challenge into a host-mapped mailbox which
-// the kernel polls; then the kernel folds every table and goes on. No kernel launch, no stream synchronisation and no
-// memcpy on the per-round critical path — only two PCIe hops. Ends by publishing the final evaluation of every table.
-struct ScPersistArgs {
-  const void* in[MAX_TABS]; int in_ext[MAX_TABS];
-  Ext* bufA[MAX_TABS]; Ext* bufB[MAX_TABS];
-  int k[MAX_TERMS]; int t[MAX_TERMS][SC_MAXK]; int off[MAX_TERMS];
-  int ntabs, nterms, has_r0; size_t n0; Ext r0;
-  unsigned long long* dbg;  // optional: per-phase cycle counters (DP_SC_DEBUG=1)
-  int eq_tab, eq_k;         // eq_tab >= 0: table eq_tab (an extension buffer in global memory) is eq(., eq_pt) and is built here first
-  Ext eq_pt[MAX_PT];
-  // multi-workgroup phase (k_sc_persist only): workgroup g of nwg owns the contiguous slice [g n0/nwg, (g+1) n0/nwg) of
-  // every table, publishes the sums of its slice into result slot g (slot_ext extension values apart, flag word g) and
-  // leaves after `rounds_a` folds; the host adds the shares. nwg = 1, rounds_a = 0: the whole sumcheck in one workgroup.
-  int nwg, rounds_a, slot_ext;
-};
-// out[i] = prod_t (i_t ? pt[t] : 1 - pt[t]) for i < 2^k, by the whole workgroup (ends with a barrier)
-__device__ __forceinline__ void wg_build_eq(Ext* out, const Ext* pt, int k) {
-  size_t n = size_t(1) << k;
-  for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
-    Ext v = ex_one();
-    for (int t = 0; t < k; t++) { Ext r = pt[t]; v = ex_mul(v, ((i >> t) & 1) ? r : ex_sub(ex_one(), r)); }
-    out[i] = v;
-  }
-  __syncthreads();
-}
-__device__ __forceinline__ void sc_fold_all(const ScPersistArgs& a, const void* const* cur, const int* cur_ext, Ext* const* dst, size_t n_after, Ext r, size_t dst_off = 0) {
-  int tid = threadIdx.x, nt = blockDim.x;
-  for (int t = 0; t < a.ntabs; t++) {
-    Ext* o = dst[t] + dst_off;
-    if (cur_ext[t]) { const Ext* p = (const Ext*)cur[t]; for (size_t i = tid; i < n_after; i += nt) o[i] = ex_lerp(p[2 * i], p[2 * i + 1], r); }
-    else { const u64* p = (const u64*)cur[t]; for (size_t i = tid; i < n_after; i += nt) o[i] = ex_lerp_base(p[2 * i], p[2 * i + 1], r); }
-  }
-}
-template <bool HI>
-KBODY k_sc_persist(const ScPersistArgs& a, Ext* result, unsigned long long* flag, const unsigned long long* mailbox, unsigned long long seq0, const ScFsArgs* fs) {
-  __shared__ Ext part[64 * SC_SLOTS];
-  __shared__ unsigned long long chal[3];
-  __shared__ const void* cur[MAX_TABS];
-  __shared__ int cur_ext[MAX_TABS];
-  __shared__ Ext* dstA[MAX_TABS];
-  __shared__ Ext* dstB[MAX_TABS];
-  __shared__ ScFsArgs fsl;
-  int tid = threadIdx.x, nt = blockDim.x;
-  int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
-  const bool autofs = fs != nullptr;  // device-side Fiat-Shamir (single workgroup only): no host round trips
-  if (autofs) for (int i = tid; i < (int)(sizeof(ScFsArgs) / 8); i += nt) ((u64*)&fsl)[i] = ((const u64*)fs)[i];
-  if (a.eq_tab >= 0) wg_build_eq((Ext*)a.in[a.eq_tab], a.eq_pt, a.eq_k);
-  const size_t g = blockIdx.x;
-  size_t n = a.n0 / (size_t)a.nwg;  // local slice length
-  if (tid < a.ntabs) { cur[tid] = (const char*)a.in[tid] + g * n * (a.in_ext[tid] ? 16 : 8); cur_ext[tid] = a.in_ext[tid]; dstA[tid] = a.bufA[tid]; dstB[tid] = a.bufB[tid]; }
-  result += g * (size_t)a.slot_ext; flag += g;
-  int folds = 0;
-  size_t lvl_off = 0;
-  __syncthreads();
-  unsigned long long seq = seq0;
-  bool useA = true;
-  WaveChallenger wc; wc.st = wc.ib = 0; wc.in_len = wc.out_len = 0;
-  if (autofs) wc_load(wc, fsl, lane);
-  unsigned long long fcs = 0; int round = 0;
-  if (a.has_r0) {
-    // (several workgroups: the fold with the pending challenge fills this workgroup's slice of the first level region of bufA;
-    // the regions of the later levels follow it — see the comment at the round fold below)
-    const size_t off0 = a.nwg > 1 ? g * (n / 2) : 0;
-    sc_fold_all(a, cur, cur_ext, dstA, n / 2, a.r0, off0);
-    __syncthreads();
-    if (tid < a.ntabs) { cur[tid] = dstA[tid] + off0; cur_ext[tid] = 1; }
-    __syncthreads();
-    n /= 2; useA = false;
-    if (a.nwg > 1) lvl_off = (size_t)a.nwg * n;
-  }
-  int wpt = a.nterms >= W ? 1 : W / a.nterms;
-  for (;;) {
-    size_t npairs = n / 2;
-    for (int term = wave / wpt; term < a.nterms; term += (wpt == 1 ? W : a.nterms + W)) {
-      int sub = wave % wpt;
-      int k = a.k[term];
-      GlobalPairs L;
-#pragma unroll
-      for (int j = 0; j < ScW<HI>::K; j++) { int ti = a.t[term][j < k ? j : 0]; L.p[j] = cur[ti]; L.e[j] = cur_ext[ti]; }
-      Ext acc[SC_SLOTS];
-      sc_accumulate<HI>(k, L, (size_t)sub * 64 + lane, (size_t)wpt * 64, npairs, acc);
-#pragma unroll
-      for (int t = 0; t < SC_SLOTS; t++) if (t <= k) acc[t] = wave_reduce_ext(acc[t]);
-      if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * SC_SLOTS; for (int t = 0; t < SC_SLOTS; t++) o[t] = acc[t]; }
-      if (wpt > 1) break;
-    }
-    __syncthreads();
-    ++seq;
-    if (wave == 0) {
-      if (autofs) { Ext rr = sc_fs_round(wc, fsl, part, a.k, a.nterms, wpt, (u64*)result, round, fcs, lane); if (lane == 0) { chal[0] = 1; chal[1] = rr.c0; chal[2] = rr.c1; } }
-      else { sc_publish_fwd(result, part, a.k, a.off, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge_fwd(mailbox, seq, chal); }
-    }
-    round++;
-    __syncthreads();
-    if (chal[0] == 0) {  // host never answered: publish an abort marker and leave
-      if (tid == 0) pub_store((u64*)flag, ~0ull);
-      return;
-    }
-    Ext r = ex(chal[1], chal[2]);
-    // One workgroup: ping-pong between bufA and bufB. Several workgroups: the folded slice goes to its place in the compact
-    // folded table of this level, and every level has its own region of bufA (level 1 at 0, level 2 behind it, ..): the
-    // workgroups sit on different XCDs whose L2s are not coherent with each other, so no address may be written by two
-    // workgroups during the life of the kernel (a stale dirty line of an old level could be written back over a new one).
-    Ext* const* dst = (a.nwg > 1 || useA) ? dstA : dstB;
-    size_t off = a.nwg > 1 ? lvl_off + g * (n / 2) : 0;
-    sc_fold_all(a, cur, cur_ext, dst, n / 2, r, off);
-    __syncthreads();
-    if (tid < a.ntabs) { cur[tid] = dst[tid] + off; cur_ext[tid] = 1; }
-    __syncthreads();
-    lvl_off += (size_t)a.nwg * (n / 2);
-    n /= 2; useA = !useA;
-    if (++folds == a.rounds_a) return;  // end of the multi-workgroup phase: the compact folded tables are complete
-    if (n == 1) {
-      ++seq;
-      if (wave == 0 && autofs) sc_fs_finish(wc, fsl, (const Ext* const*)cur, nullptr, 0, a.ntabs, (u64*)result, flag, seq0 + 1, fcs, lane);
-      else if (wave == 0) {
-        unsigned long long cs = 0; u64* rw = (u64*)result;
-        for (int e = lane; e < a.ntabs; e += 64) { Ext v = ((const Ext*)cur[e])[0]; pub_store(rw + 2 * e, v.c0); pub_store(rw + 2 * e + 1, v.c1); cs += (unsigned long long)(2 * e + 1) * v.c0 + (unsigned long long)(2 * e + 2) * v.c1; }
-        cs = pub_wave_sum(cs);
-        if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + cs);
-      }
-      return;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ whole logup-GKR layer loop
-// Dev::logup_tail (dev.h): every layer of a logup-GKR batch proof (logup_layers of logup.h: absorb the claim, the batched
-// layer sumcheck with its Fiat-Shamir rounds, the three layer challenges, the next claim) in ONE launch of one workgroup —
-// one device wait per lookup argument instead of one per tree layer; in full mode (Dev::logup_full, DP_DEVICE_LOGUP=2) also
-// the trees, the circuit outputs, the initial challenges and the column claims. Default in throughput mode (DP_DEVICE_LOGUP=0 / 1 select the
-// layer-by-layer path / the layer loop only); written against the contract pinned by the CPU double (tests/support/cpu_dev.hpp),
-// checked on the SIMT emulator and on MI355X (tests/test_gpu_fused.py).
-// Tree layers stay where k_logup_tree / k_logup_layer left them (global memory, read once per layer); folded tables
-// ping-pong through bufA / bufB like k_sc_persist. Result area, in words, one block per layer lv = 1..L followed by the
-// sponge: [lv x 4 message values][lv challenges][batching][final evaluations without eq] ... [8 state, 4 input buffer,
-// in_len, out_len]; the tag is mix(seq) + sum over blocks of sum_i (i + 1) * word_i with i relative to the block.
-static_assert(LT_MAX_TABS == MAX_TABS, "logup_tail.h: table capacity");
-KBODY k_logup_tail(const LogupTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
-  __shared__ Ext part[64 * SC_SLOTS];
-  __shared__ unsigned long long chal[3];
-  __shared__ const void* cur[MAX_TABS];
-  __shared__ int cur_ext[MAX_TABS];
-  __shared__ int tk[MAX_TERMS];
-  __shared__ int tt[MAX_TERMS][3];
-  __shared__ int s_ntab, s_nterm;
-  __shared__ ScFsArgs fsl;
-  __shared__ LogupTailDesc dl;
-  __shared__ Ext pt[MAX_PT];
-  __shared__ Ext glue[4];  // batching, alpha, lambda, claim of the layer at hand
-  __shared__ Ext outs[LT_MAXI * 4];  // full mode: [n0, n1, d0, d1] of every instance
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
-#ifdef DP_WG_TIMES
-  const unsigned long long dbg_t_in = dp_realtime();
-#endif
-  for (int i = tid; i < (int)(sizeof(LogupTailDesc) / 8); i += nt) ((u64*)&dl)[i] = ((const u64*)dp)[i];
-  __syncthreads();
-  if (tid == 0) {
-    glue[0] = dl.batching; glue[1] = dl.alpha; glue[2] = dl.lambda; glue[3] = dl.claim; pt[0] = dl.batching;
-    fsl.md = 3; fsl.label[0] = dl.lab_round[0]; fsl.label[1] = dl.lab_round[1]; fsl.nlabel = 2; fsl.pad = 0;
-  }
-  WaveChallenger wc;
-  wc.st = dl.state[lane & 7]; wc.ib = dl.in_buf[lane & 3]; wc.in_len = dl.in_len; wc.out_len = dl.out_len;
-  wc_host_init(wc, dl.sp_req, dl.sp_rep, dl.sp_seq);
-  unsigned long long fcs = 0;
-  size_t wbase = 0;
-  __syncthreads();
-  if (dl.full) {
-    // ---- full mode (Dev::logup_full). The fractional-sum tree of every instance, as k_logup_tree builds it: denominators
-    // c + sum_j chi^j col_j, then layer by layer (n1 d2 + d1 n2, d1 d2) over the pairs (i, i + half)
-    const size_t n = dl.n;
-    for (int s = 0; s < dl.ninst; s++) {
-      Ext* den = dl.den_all[s];
-      Ext* num_out = dl.num_all[s];
-      for (size_t i = tid; i < n; i += nt) {
-        Ext acc = dl.c, pw = ex_one();
-        for (int j = 0; j < dl.cpi; j++) { acc = ex_add(acc, ex_mul_base(pw, dl.col[s][j][i])); pw = ex_mul(pw, dl.chi); }
-        den[i] = acc;
-      }
-      __syncthreads();
-      const void* num = dl.mult;
-      int mode = dl.is_table ? 1 : 0;  // 0: all numerators are -1 (lookup), 1: base-field multiplicities (table), 2: extension
-      size_t len = n, doff = 0, noff = 0;
-      while (len > 2) {
-        const size_t half = len / 2;
-        const Ext* dcur = den + doff;
-        Ext* dnext = den + doff + len;
-        for (size_t i = tid; i < half; i += nt) {
-          Ext d1 = dcur[i], d2 = dcur[i + half], nn;
-          if (mode == 0) nn = ex_neg(ex_add(d1, d2));
-          else if (mode == 1) { const u64* q = (const u64*)num; nn = ex_add(ex_mul_base(d2, q[i]), ex_mul_base(d1, q[i + half])); }
-          else { const Ext* q = (const Ext*)num; nn = ex_add(ex_mul(q[i], d2), ex_mul(d1, q[i + half])); }
-          num_out[noff + i] = nn;
-          dnext[i] = ex_mul(d1, d2);
-        }
-        __syncthreads();
-        num = (const void*)(num_out + noff); mode = 2;
-        doff += len; noff += half; len = half;
-      }
-      if (tid < 4) {  // the 2-element top layer: [n0, n1, d0, d1]
-        Ext v;
-        if (tid < 2) { if (mode == 0) v = ex_neg(ex_one()); else if (mode == 1) v = ex_base(((const u64*)num)[tid]); else v = ((const Ext*)num)[tid]; }
-        else v = (den + doff)[tid - 2];
-        outs[4 * s + tid] = v;
-      }
-      __syncthreads();
-    }
-    if (tid == 0)
-      for (int s = 0; s < dl.ninst; s++)
-        for (int li = 0; li < dl.nlayers; li++) {
-          dl.den[s][li] = dl.den_all[s] + (2 * n - ((2 * n) >> li));
-          dl.num[s][li] = li == 0 ? (const void*)dl.mult : (const void*)(dl.num_all[s] + (n - ((2 * n) >> li)));
-        }
-    // transcript: the number of instances, their outputs, the three initial challenges; the first claim
-    if (wave == 0) {
-      wc_observe(wc, (u64)dl.ninst, lane);
-      for (int q = 0; q < 4 * dl.ninst; q++) { Ext v = outs[q]; wc_observe(wc, v.c0, lane); wc_observe(wc, v.c1, lane); }
-      u64 b0, b1;
-      wc_observe(wc, dl.lab_ibatching[0], lane); wc_observe(wc, dl.lab_ibatching[1], lane); b0 = wc_sample(wc, lane); b1 = wc_sample(wc, lane);
-      const Ext bt = ex(b0, b1);
-      wc_observe(wc, dl.lab_ialpha[0], lane); wc_observe(wc, dl.lab_ialpha[1], lane); b0 = wc_sample(wc, lane); b1 = wc_sample(wc, lane);
-      const Ext al = ex(b0, b1);
-      wc_observe(wc, dl.lab_ilambda[0], lane); wc_observe(wc, dl.lab_ilambda[1], lane); b0 = wc_sample(wc, lane); b1 = wc_sample(wc, lane);
-      const Ext la = ex(b0, b1);
-      Ext claim = ex_zero(), ac = ex_one();
-      for (int s = 0; s < dl.ninst; s++) {
-        const Ext* e = outs + 4 * s;
-        Ext a = ex_add(ex_mul(bt, ex_sub(e[1], e[0])), e[0]);
-        Ext b = ex_add(ex_mul(bt, ex_sub(e[3], e[2])), e[2]);
-        claim = ex_add(claim, ex_mul(ac, ex_add(a, ex_mul(la, b))));
-        ac = ex_mul(ac, al);
-      }
-      if (lane == 0) { glue[0] = bt; glue[1] = al; glue[2] = la; glue[3] = claim; pt[0] = bt; }
-      for (int e = lane; e < 4 * dl.ninst; e += 64) {
-        Ext v = outs[e];
-        size_t w = 2 * (size_t)e;
-        pub_store(result + w, v.c0); pub_store(result + w + 1, v.c1);
-        fcs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1;
-      }
-    }
-    wbase = (size_t)dl.ninst * 8;
-    __syncthreads();
-  }
-  for (int lv = 1; lv <= dl.total_layers; lv++) {
-    const size_t half = size_t(1) << lv;
-    const int li = dl.nlayers - 1 - lv;  // layers().iter().rev().skip(1)
-    // transcript: the running claim, then the header of the layer's sumcheck (num_vars, max_degree)
-    if (wave == 0) {
-      Ext c = glue[3];
-      wc_observe(wc, c.c0, lane); wc_observe(wc, c.c1, lane);
-      wc_observe(wc, (u64)lv, lane); wc_observe(wc, (u64)3, lane);
-    }
-    wg_build_eq(dl.eq, pt, lv);  // eq(point, .) over the layer's lv variables (ends with a barrier)
-    if (tid == 0) {
-      cur[0] = dl.eq; cur_ext[0] = 1;
-      int ntab = 1, nterm = 0;
-      Ext ca = ex_one();
-      const Ext al = glue[1], la = glue[2];
-      const bool init_lk = !dl.is_table && li == 0;   // initial lookup layer: all numerators are -1
-      const bool nbase = dl.is_table && li == 0;      // table layer 0: base-field multiplicities
-      for (int i = 0; i < dl.ninst; i++) {
-        const Ext* dlo = dl.den[i][li];
-        const Ext* dhi = dlo + half;
-        if (!init_lk) {
-          const void* nlo = dl.num[i][li];
-          const void* nhi = (const char*)nlo + half * (nbase ? 8 : 16);
-          const int t_nlo = ntab, t_dhi = ntab + 1, t_nhi = ntab + 2, t_dlo = ntab + 3;
-          cur[t_nlo] = nlo; cur_ext[t_nlo] = nbase ? 0 : 1;
-          cur[t_dhi] = dhi; cur_ext[t_dhi] = 1;
-          cur[t_nhi] = nhi; cur_ext[t_nhi] = nbase ? 0 : 1;
-          cur[t_dlo] = dlo; cur_ext[t_dlo] = 1;
-          ntab += 4;
-          tk[nterm] = 3; tt[nterm][0] = 0; tt[nterm][1] = t_nlo; tt[nterm][2] = t_dhi; fsl.coeff[nterm] = ca; nterm++;
-          tk[nterm] = 3; tt[nterm][0] = 0; tt[nterm][1] = t_nhi; tt[nterm][2] = t_dlo; fsl.coeff[nterm] = ca; nterm++;
-          tk[nterm] = 3; tt[nterm][0] = 0; tt[nterm][1] = t_dlo; tt[nterm][2] = t_dhi; fsl.coeff[nterm] = ex_mul(ca, la); nterm++;
-        } else {
-          const int t_dhi = ntab, t_dlo = ntab + 1;
-          cur[t_dhi] = dhi; cur_ext[t_dhi] = 1;
-          cur[t_dlo] = dlo; cur_ext[t_dlo] = 1;
-          ntab += 2;
-          tk[nterm] = 2; tt[nterm][0] = 0; tt[nterm][1] = t_dhi; tt[nterm][2] = 0; fsl.coeff[nterm] = ex_neg(ca); nterm++;
-          tk[nterm] = 2; tt[nterm][0] = 0; tt[nterm][1] = t_dlo; tt[nterm][2] = 0; fsl.coeff[nterm] = ex_neg(ca); nterm++;
-          tk[nterm] = 3; tt[nterm][0] = 0; tt[nterm][1] = t_dlo; tt[nterm][2] = t_dhi; fsl.coeff[nterm] = ex_mul(ca, la); nterm++;
-        }
-        ca = ex_mul(ca, al);
-      }
-      s_ntab = ntab; s_nterm = nterm; fsl.rounds = lv;
-    }
-    __syncthreads();
-    const int ntab = s_ntab, nterm = s_nterm;
-    const int wpt = nterm >= W ? 1 : W / nterm;
-    u64* rw = result + wbase;
-    size_t n = half;
-    bool useA = true;
-    for (int round = 0; round < lv; round++) {
-      const size_t npairs = n / 2;
-      for (int term = wave / wpt; term < nterm; term += (wpt == 1 ? W : nterm + W)) {
-        const int sub = wave % wpt;
-        const int k = tk[term];
-        GlobalPairs L;
-#pragma unroll
-        for (int j = 0; j < 3; j++) { int ti = tt[term][j < k ? j : 0]; L.p[j] = cur[ti]; L.e[j] = cur_ext[ti] != 0; }
-        Ext acc[SC_SLOTS];
-        sc_accumulate<false>(k, L, (size_t)sub * 64 + lane, (size_t)wpt * 64, npairs, acc);
-#pragma unroll
-        for (int t = 0; t < SC_SLOTS; t++) if (t <= k) acc[t] = wave_reduce_ext(acc[t]);
-        if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * SC_SLOTS; for (int t = 0; t < SC_SLOTS; t++) o[t] = acc[t]; }
-        if (wpt > 1) break;  // with several waves per term every wave owns exactly one (term, sub)
-      }
-      __syncthreads();
-      if (wave == 0) {
-        Ext rr = sc_fs_round(wc, fsl, part, tk, nterm, wpt, rw, round, fcs, lane);
-        if (lane == 0) { chal[1] = rr.c0; chal[2] = rr.c1; pt[round] = rr; }  // the eq table of this layer is built: pt may take the new point
-      }
-      __syncthreads();
-      const Ext r = ex(chal[1], chal[2]);
-      Ext* const* dst = useA ? dl.bufA : dl.bufB;
-      for (int t = 0; t < ntab; t++) {
-        Ext* o = dst[t];
-        if (cur_ext[t]) { const Ext* q = (const Ext*)cur[t]; for (size_t i = tid; i < npairs; i += nt) o[i] = ex_lerp(q[2 * i], q[2 * i + 1], r); }
-        else { const u64* q = (const u64*)cur[t]; for (size_t i = tid; i < npairs; i += nt) o[i] = ex_lerp_base(q[2 * i], q[2 * i + 1], r); }
-      }
-      __syncthreads();
-      if (tid < ntab) { cur[tid] = dst[tid]; cur_ext[tid] = 1; }
-      __syncthreads();
-      n = npairs; useA = !useA;
-    }
-    // every table is one value now: the layer's evaluations, the three layer challenges, the next claim
-    if (wave == 0) {
-      u64 b0, b1;
-      wc_observe(wc, dl.lab_batching[0], lane); wc_observe(wc, dl.lab_batching[1], lane); b0 = wc_sample(wc, lane); b1 = wc_sample(wc, lane);
-      const Ext nb = ex(b0, b1);
-      wc_observe(wc, dl.lab_alpha[0], lane); wc_observe(wc, dl.lab_alpha[1], lane); b0 = wc_sample(wc, lane); b1 = wc_sample(wc, lane);
-      const Ext na = ex(b0, b1);
-      wc_observe(wc, dl.lab_lambda[0], lane); wc_observe(wc, dl.lab_lambda[1], lane); b0 = wc_sample(wc, lane); b1 = wc_sample(wc, lane);
-      const Ext nl = ex(b0, b1);
-      const size_t wb = (size_t)lv * 10;  // behind lv * 4 message values and lv challenges
-      if (lane == 0) { pub_store(rw + wb, nb.c0); pub_store(rw + wb + 1, nb.c1); fcs += (unsigned long long)(wb + 1) * nb.c0 + (unsigned long long)(wb + 2) * nb.c1; }
-      for (int e = lane; e < ntab - 1; e += 64) {
-        Ext v = ((const Ext*)cur[e + 1])[0];
-        size_t w = wb + 2 + 2 * (size_t)e;
-        pub_store(rw + w, v.c0); pub_store(rw + w + 1, v.c1);
-        fcs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1;
-      }
-      const bool lookup_final = lv == dl.total_layers && !dl.is_table;  // final_round_claim (prover.rs:201-237)
-      Ext acc = ex_zero(), acomb = ex_one();
-      int tb = 1;
-      for (int i = 0; i < dl.ninst; i++) {
-        if (!lookup_final) {
-          Ext e0 = ((const Ext*)cur[tb])[0], e1 = ((const Ext*)cur[tb + 1])[0], e2 = ((const Ext*)cur[tb + 2])[0], e3 = ((const Ext*)cur[tb + 3])[0];
-          Ext a = ex_add(ex_mul(nb, ex_sub(e2, e0)), e0);
-          Ext b = ex_add(ex_mul(nb, ex_sub(e1, e3)), e3);
-          acc = ex_add(acc, ex_mul(acomb, ex_add(a, ex_mul(nl, b))));
-          tb += 4;
-        } else {
-          Ext e0 = ((const Ext*)cur[tb])[0], e1 = ((const Ext*)cur[tb + 1])[0];
-          acc = ex_add(acc, ex_mul(acomb, ex_add(ex_mul(nb, ex_sub(e0, e1)), e1)));
-          tb += 2;
-        }
-        acomb = ex_mul(acomb, na);
-      }
-      if (lane == 0) { glue[0] = nb; glue[1] = na; glue[2] = nl; glue[3] = acc; pt[lv] = nb; }
-    }
-    wbase += ((size_t)lv * 5 + 1 + (size_t)(ntab - 1)) * 2;
-    __syncthreads();
-  }
-  if (dl.full) {
-    // ---- full mode: the output claims — [multiplicities,] columns evaluated at the final point (sum_i eq(point, i) col[i])
-    wg_build_eq(dl.eqn, pt, dl.nlayers);
-    const int tcol = dl.is_table ? 1 : 0;
-    const int ncol = tcol + dl.ninst * dl.cpi;
-    u64* rw = result + wbase;
-    for (int cidx = 0; cidx < ncol; cidx++) {
-      const u64* col = cidx < tcol ? dl.mult : dl.col[(cidx - tcol) / dl.cpi][(cidx - tcol) % dl.cpi];
-      Ext acc = ex_zero();
-      for (size_t i = tid; i < dl.n; i += nt) acc = ex_add(acc, ex_mul_base(dl.eqn[i], col[i]));
-      acc = wave_reduce_ext(acc);
-      if (lane == 0) part[wave] = acc;
-      __syncthreads();
-      if (wave == 0) {
-        Ext v = lane < W ? part[lane] : ex_zero();
-        v = wave_reduce_ext(v);
-        if (lane == 0) { size_t w = 2 * (size_t)cidx; pub_store(rw + w, v.c0); pub_store(rw + w + 1, v.c1); fcs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1; }
-      }
-      __syncthreads();
-    }
-    wbase += 2 * (size_t)ncol;
-  }
-  if (wave == 0) {  // the sponge goes back to the host transcript; the tag closes the message
-    u64* rw = result + wbase;
-    if (lane < 8) { pub_store(rw + lane, wc.st); fcs += (unsigned long long)(lane + 1) * wc.st; }
-    if (lane < 4) { u64 v = lane < wc.in_len ? wc.ib : 0; pub_store(rw + 8 + lane, v); fcs += (unsigned long long)(8 + lane + 1) * v; }
-    if (lane == 0) {
-      u64 a = (u64)wc.in_len, b = (u64)wc.out_len;
-      pub_store(rw + 12, a); pub_store(rw + 13, b);
-      fcs += (unsigned long long)13 * a + (unsigned long long)14 * b;
-    }
-    fcs = pub_wave_sum(fcs);
-    wc_finish(wc, lane);  // (host sponge: the transcript is complete before this message is)
-    if (lane == 0) pub_store((u64*)flag, wc.failed ? ~0ull : pub_mix(seq) + fcs);
-#ifdef DP_WG_TIMES
-    if (tid == 0) dbg_wg_record(dbg_t_in);
-#endif
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ batch-opening sumcheck tail
-// Dev::classic_tail (dev.h, classic_tail.h): the remaining rounds of the batch-opening sumcheck of pcs_batch_open — per round
-// fold every (f, eq) pair, the per-pair sums of Dev::classic_round, the 3-coefficient message of classic_round_message
-// (pcs.h), absorb, squeeze "sumcheck round" — in ONE launch of one workgroup once every table is short. A pair belongs to
-// one wave per phase; the phases of a round are separated by barriers. Default in throughput mode (DP_DEVICE_CLASSIC=0 turns
-// it off); checked on the SIMT emulator of tests/ and on MI355X (tests/test_gpu_fused.py).
-KBODY k_classic_tail(const ClassicTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
-  __shared__ ClassicTailDesc dl;
-  __shared__ Ext raw[2 * CT_MAXP];
-  __shared__ const void* curf[CT_MAXP];
-  __shared__ const Ext* cure[CT_MAXP];
-  __shared__ unsigned clen[CT_MAXP];
-  __shared__ unsigned cext[CT_MAXP];
-  __shared__ unsigned toA[CT_MAXP];
-  __shared__ unsigned long long chal[3];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < (int)(sizeof(ClassicTailDesc) / 8); i += nt) ((u64*)&dl)[i] = ((const u64*)dp)[i];
-  __syncthreads();
-  const int np = dl.np;
-  for (int i = tid; i < np; i += nt) { curf[i] = dl.f[i]; cure[i] = dl.eq[i]; clen[i] = dl.len[i]; cext[i] = dl.f_ext[i]; toA[i] = 1; }
-  WaveChallenger wc;
-  wc.st = dl.state[lane & 7]; wc.ib = dl.in_buf[lane & 3]; wc.in_len = dl.in_len; wc.out_len = dl.out_len;
-  wc_host_init(wc, dl.sp_req, dl.sp_rep, dl.sp_seq);
-  unsigned long long fcs = 0;
-  const int R = (int)(dl.num_vars - dl.round);
-  Ext r = dl.r, sum = dl.sum;
-  bool have_r = dl.has_r != 0;
-  __syncthreads();
-  for (int q = 0; q < R; q++) {
-    if (have_r) {
-      // fold f and eq of every pair that is longer than one value
-      for (int i = wave; i < np; i += W) {
-        const unsigned n = clen[i];
-        if (n <= 1) continue;
-        const unsigned half = n / 2;
-        Ext* df = toA[i] ? dl.fA[i] : dl.fB[i];
-        Ext* de = toA[i] ? dl.eA[i] : dl.eB[i];
-        const Ext* e = cure[i];
-        if (cext[i]) { const Ext* f = (const Ext*)curf[i]; for (unsigned j = lane; j < half; j += 64) df[j] = ex_lerp(f[2 * j], f[2 * j + 1], r); }
-        else { const u64* f = (const u64*)curf[i]; for (unsigned j = lane; j < half; j += 64) df[j] = ex_lerp_base(f[2 * j], f[2 * j + 1], r); }
-        for (unsigned j = lane; j < half; j += 64) de[j] = ex_lerp(e[2 * j], e[2 * j + 1], r);
-      }
-      __syncthreads();
-      for (int i = tid; i < np; i += nt)
-        if (clen[i] > 1) { curf[i] = toA[i] ? dl.fA[i] : dl.fB[i]; cure[i] = toA[i] ? dl.eA[i] : dl.eB[i]; cext[i] = 1; clen[i] /= 2; toA[i] ^= 1; }
-      __syncthreads();
-    }
-    // per pair: c0 = sum_j f[2j] eq[2j], c2 = sum_j (f[2j+1] - f[2j]) (eq[2j+1] - eq[2j]); a single value gives (f eq, 0)
-    for (int i = wave; i < np; i += W) {
-      const unsigned n = clen[i];
-      const Ext* e = cure[i];
-      Ext c0 = ex_zero(), c2 = ex_zero();
-      if (n == 1) { if (lane == 0) c0 = ex_mul(ld_elem(curf[i], cext[i] != 0, 0), e[0]); }
-      else
-        for (unsigned j = lane; j < n / 2; j += 64) {
-          Ext l0 = e[2 * j], l1 = e[2 * j + 1], r0 = ld_elem(curf[i], cext[i] != 0, 2 * j), r1 = ld_elem(curf[i], cext[i] != 0, 2 * j + 1);
-          c0 = ex_add(c0, ex_mul(l0, r0));
-          c2 = ex_add(c2, ex_mul(ex_sub(l1, l0), ex_sub(r1, r0)));
-        }
-      c0 = wave_reduce_ext(c0); c2 = wave_reduce_ext(c2);
-      if (lane == 0) { raw[2 * i] = c0; raw[2 * i + 1] = c2; }
-    }
-    __syncthreads();
-    if (wave == 0) {
-      // the message [h0, h1, h2] (classic_round_message of pcs.h), the transcript, the next claim
-      const size_t size = size_t(1) << (dl.num_vars - (dl.round + (unsigned)q) - 1);
-      Ext h0 = ex_zero(), h2 = ex_zero();
-      for (int i = lane; i < np; i += 64) {
-        const size_t poly_len = clen[i];
-        Ext c0 = raw[2 * i], c2 = raw[2 * i + 1];
-        size_t multiple;
-        if (poly_len == 1) multiple = size;
-        else if (size < poly_len || size == 1) multiple = 1;
-        else multiple = size / (poly_len >> 1);
-        if (multiple != 1) { Ext m = ex_from_u64((u64)multiple); c0 = ex_mul(c0, m); c2 = ex_mul(c2, m); }
-        h0 = ex_add(h0, ex_mul(dl.eq_xt[i], c0));
-        h2 = ex_add(h2, ex_mul(dl.eq_xt[i], c2));
-      }
-      h0 = wave_reduce_ext(h0); h2 = wave_reduce_ext(h2);
-      h0 = ex(shfl_u64(h0.c0, 0), shfl_u64(h0.c1, 0)); h2 = ex(shfl_u64(h2.c0, 0), shfl_u64(h2.c1, 0));
-      const Ext h1 = ex_sub(ex_sub(sum, ex_dbl(h0)), h2);
-      wc_observe(wc, h0.c0, lane); wc_observe(wc, h0.c1, lane);
-      wc_observe(wc, h1.c0, lane); wc_observe(wc, h1.c1, lane);
-      wc_observe(wc, h2.c0, lane); wc_observe(wc, h2.c1, lane);
-      wc_observe(wc, dl.lab[0], lane); wc_observe(wc, dl.lab[1], lane);
-      const u64 r0 = wc_sample(wc, lane), r1 = wc_sample(wc, lane);
-      const Ext ch = ex(r0, r1);
-      if (lane == 0) {
-        const Ext m[3] = {h0, h1, h2};
-        for (int j = 0; j < 3; j++) {
-          size_t w = ((size_t)q * 3 + j) * 2;
-          pub_store(result + w, m[j].c0); pub_store(result + w + 1, m[j].c1);
-          fcs += (unsigned long long)(w + 1) * m[j].c0 + (unsigned long long)(w + 2) * m[j].c1;
-        }
-        size_t w = ((size_t)R * 3 + q) * 2;
-        pub_store(result + w, r0); pub_store(result + w + 1, r1);
-        fcs += (unsigned long long)(w + 1) * r0 + (unsigned long long)(w + 2) * r1;
-        chal[1] = r0; chal[2] = r1;
-      }
-      sum = ex_add(h0, ex_mul(ch, ex_add(h1, ex_mul(ch, h2))));
-    }
-    __syncthreads();
-    r = ex(chal[1], chal[2]);
-    have_r = true;
-  }
-  if (wave == 0) {  // the sponge goes back to the host transcript; the tag closes the message
-    u64* rw = result + (size_t)R * 8;
-    if (lane < 8) { pub_store(rw + lane, wc.st); fcs += (unsigned long long)(lane + 1) * wc.st; }
-    if (lane < 4) { u64 v = lane < wc.in_len ? wc.ib : 0; pub_store(rw + 8 + lane, v); fcs += (unsigned long long)(8 + lane + 1) * v; }
-    if (lane == 0) {
-      u64 a = (u64)wc.in_len, b = (u64)wc.out_len;
-      pub_store(rw + 12, a); pub_store(rw + 13, b);
-      fcs += (unsigned long long)13 * a + (unsigned long long)14 * b;
-    }
-    fcs = pub_wave_sum(fcs);
-    wc_finish(wc, lane);  // (host sponge: the transcript is complete before this message is)
-    if (lane == 0) pub_store((u64*)flag, wc.failed ? ~0ull : pub_mix(seq) + fcs);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ dense layer in one launch
-// Dev::dense_tail (dev.h, dense_tail.h): the bias at the output point, W(point, .) — the one-pass fix_high over the base-field
-// weights — and the degree-2 sumcheck of sum_c W(point, c) in(c) with its transcript, in ONE launch of one workgroup: a
-// 1024 x 1024 layer is 8 MB of weights through one CU (~0.15 ms), cheaper than the five dispatches it replaces when the
-// GPU serves hundreds of proofs. Default in throughput mode (DP_DEVICE_DENSE=0 turns it off); checked on the SIMT
-// emulator of tests/ and on MI355X (tests/test_gpu_fused.py).
-KBODY k_dense_tail(const DenseTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
-  __shared__ DenseTailDesc dl;
-  __shared__ Ext part[64 * SC_SLOTS];
-  __shared__ unsigned long long chal[3];
-  __shared__ int tk[1];
-  __shared__ ScFsArgs fsl;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < (int)(sizeof(DenseTailDesc) / 8); i += nt) ((u64*)&dl)[i] = ((const u64*)dp)[i];
-  __syncthreads();
-  if (tid == 0) { fsl.md = 2; fsl.rounds = (int)dl.lgC; fsl.label[0] = dl.lab_round[0]; fsl.label[1] = dl.lab_round[1]; fsl.nlabel = 2; fsl.pad = 0; fsl.coeff[0] = ex_one(); tk[0] = 2; }
-  WaveChallenger wc;
-  wc.st = dl.state[lane & 7]; wc.ib = dl.in_buf[lane & 3]; wc.in_len = dl.in_len; wc.out_len = dl.out_len;
-  wc_host_init(wc, dl.sp_req, dl.sp_rep, dl.sp_seq);
-  unsigned long long fcs = 0;
-  const size_t R = dl.R, C = dl.C;
-  wg_build_eq(dl.eqr, dl.pt, (int)dl.lgR);  // eq(point, .) over the rows (ends with a barrier)
-  // bias at the point
-  {
-    Ext acc = ex_zero();
-    for (size_t i = tid; i < R; i += nt) acc = ex_add(acc, ex_mul_base(dl.eqr[i], dl.bias[i]));
-    acc = wave_reduce_ext(acc);
-    if (lane == 0) part[wave] = acc;
-    __syncthreads();
-    if (wave == 0) {
-      Ext v = lane < W ? part[lane] : ex_zero();
-      v = wave_reduce_ext(v);
-      if (lane == 0) { pub_store(result, v.c0); pub_store(result + 1, v.c1); fcs += (unsigned long long)1 * v.c0 + (unsigned long long)2 * v.c1; }
-    }
-    __syncthreads();
-  }
-  // W(point, c) = sum_r eq(point, r) W[r][c]: consecutive threads read consecutive columns of a row
-  for (size_t c = tid; c < C; c += nt) {
-    Ext acc = ex_zero();
-    for (size_t r = 0; r < R; r++) acc = ex_add(acc, ex_mul_base(dl.eqr[r], dl.W[r * C + c]));
-    dl.mat[c] = acc;
-  }
-  __syncthreads();
-  // the sumcheck of mat * in: header, then log2(C) rounds
-  if (wave == 0) { wc_observe(wc, (u64)dl.lgC, lane); wc_observe(wc, (u64)2, lane); }
-  const Ext* cur[2] = {dl.mat, dl.in};
-  u64* rw = result + 2;
-  size_t n = C;
-  bool useA = true;
-  for (int round = 0; round < (int)dl.lgC; round++) {
-    const size_t npairs = n / 2;
-    {
-      GlobalPairs L;
-      L.p[0] = cur[0]; L.e[0] = true; L.p[1] = cur[1]; L.e[1] = true; L.p[2] = cur[0]; L.e[2] = true;
-      Ext acc[SC_SLOTS];
-      sc_accumulate<false>(2, L, (size_t)tid, (size_t)nt, npairs, acc);  // every wave takes a share of the one term
-#pragma unroll
-      for (int t = 0; t < SC_SLOTS; t++) if (t <= 2) acc[t] = wave_reduce_ext(acc[t]);
-      if (lane == 0) { Ext* o = part + (size_t)wave * SC_SLOTS; for (int t = 0; t < SC_SLOTS; t++) o[t] = acc[t]; }
-    }
-    __syncthreads();
-    if (wave == 0) {
-      Ext rr = sc_fs_round(wc, fsl, part, tk, 1, W, rw, round, fcs, lane);  // wpt = W: the term's sums are spread over all waves
-      if (lane == 0) { chal[1] = rr.c0; chal[2] = rr.c1; }
-    }
-    __syncthreads();
-    const Ext r = ex(chal[1], chal[2]);
-    Ext* const* dst = useA ? dl.bufA : dl.bufB;
-    for (int t = 0; t < 2; t++) { const Ext* q = cur[t]; Ext* o = dst[t]; for (size_t i = tid; i < npairs; i += nt) o[i] = ex_lerp(q[2 * i], q[2 * i + 1], r); }
-    __syncthreads();
-    cur[0] = dst[0]; cur[1] = dst[1];
-    n = npairs; useA = !useA;
-  }
-  if (wave == 0) {
-    const size_t wf = (size_t)dl.lgC * 8;  // behind 3 evaluations and one challenge per round
-    if (lane < 2) { Ext v = cur[lane][0]; size_t w = wf + 2 * (size_t)lane; pub_store(rw + w, v.c0); pub_store(rw + w + 1, v.c1); fcs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1; }
-    u64* rs = result + (1 + (size_t)dl.lgC * 4 + 2) * 2;
-    if (lane < 8) { pub_store(rs + lane, wc.st); fcs += (unsigned long long)(lane + 1) * wc.st; }
-    if (lane < 4) { u64 v = lane < wc.in_len ? wc.ib : 0; pub_store(rs + 8 + lane, v); fcs += (unsigned long long)(8 + lane + 1) * v; }
-    if (lane == 0) {
-      u64 a = (u64)wc.in_len, b = (u64)wc.out_len;
-      pub_store(rs + 12, a); pub_store(rs + 13, b);
-      fcs += (unsigned long long)13 * a + (unsigned long long)14 * b;
-    }
-    fcs = pub_wave_sum(fcs);
-    wc_finish(wc, lane);  // (host sponge: the transcript is complete before this message is)
-    if (lane == 0) pub_store((u64*)flag, wc.failed ? ~0ull : pub_mix(seq) + fcs);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ eq tables + sumcheck in one launch
-// Dev::eqsum_tail (dev.h, eqsum_tail.h): the eq tables of an accumulation sumcheck (Requant: three plain tables; same_poly:
-// one table accumulated from scaled eq's) and the whole sumcheck over them with its transcript, in ONE launch of one
-// workgroup. Default in throughput mode (DP_DEVICE_EQSUM=0 turns it off); checked on the SIMT emulator and on MI355X.
-KBODY k_eqsum_tail(const EqSumDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
-  __shared__ EqSumDesc dl;
-  __shared__ Ext part[64 * SC_SLOTS];
-  __shared__ unsigned long long chal[3];
-  __shared__ const void* cur[ES_MAXT];
-  __shared__ int cur_ext[ES_MAXT];
-  __shared__ ScFsArgs fsl;
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < (int)(sizeof(EqSumDesc) / 8); i += nt) ((u64*)&dl)[i] = ((const u64*)dp)[i];
-  __syncthreads();
-  const int ntab = dl.ntabs, nterm = dl.nterms;
-  if (tid == 0) { fsl.md = (int)dl.md; fsl.rounds = (int)dl.nv; fsl.label[0] = dl.lab_round[0]; fsl.label[1] = dl.lab_round[1]; fsl.nlabel = 2; fsl.pad = 0; }
-  for (int i = tid; i < nterm; i += nt) fsl.coeff[i] = dl.coeff[i];
-  for (int i = tid; i < ntab; i += nt) { cur[i] = dl.tab[i]; cur_ext[i] = dl.tab_ext[i]; }
-  WaveChallenger wc;
-  wc.st = dl.state[lane & 7]; wc.ib = dl.in_buf[lane & 3]; wc.in_len = dl.in_len; wc.out_len = dl.out_len;
-  wc_host_init(wc, dl.sp_req, dl.sp_rep, dl.sp_seq);
-  unsigned long long fcs = 0;
-  const size_t n0 = size_t(1) << dl.nv;
-  // the eq tables, in order: out[idx] (+)= scale * prod_t (idx_t ? pt[t] : 1 - pt[t])
-  for (int j = 0; j < dl.njobs; j++) {
-    Ext* out = dl.job_out[j];
-    const Ext sc = dl.job_scale[j];
-    for (size_t i = tid; i < n0; i += nt) {
-      Ext v = sc;
-      for (unsigned t = 0; t < dl.nv; t++) { Ext r = dl.job_pt[j][t]; v = ex_mul(v, ((i >> t) & 1) ? r : ex_sub(ex_one(), r)); }
-      out[i] = dl.job_acc[j] ? ex_add(out[i], v) : v;
-    }
-    __syncthreads();
-  }
-  if (wave == 0) { wc_observe(wc, (u64)dl.nv, lane); wc_observe(wc, (u64)dl.md, lane); }  // header of the sumcheck
-  const int wpt = nterm >= W ? 1 : W / nterm;
-  size_t n = n0;
-  bool useA = true;
-  for (int round = 0; round < (int)dl.nv; round++) {
-    const size_t npairs = n / 2;
-    for (int term = wave / wpt; term < nterm; term += (wpt == 1 ? W : nterm + W)) {
-      const int sub = wave % wpt;
-      const int k = dl.tk[term];
-      GlobalPairs L;
-#pragma unroll
-      for (int j = 0; j < 3; j++) { int ti = dl.tt[term][j < k ? j : 0]; L.p[j] = cur[ti]; L.e[j] = cur_ext[ti] != 0; }
-      Ext acc[SC_SLOTS];
-      sc_accumulate<false>(k, L, (size_t)sub * 64 + lane, (size_t)wpt * 64, npairs, acc);
-#pragma unroll
-      for (int t = 0; t < SC_SLOTS; t++) if (t <= k) acc[t] = wave_reduce_ext(acc[t]);
-      if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * SC_SLOTS; for (int t = 0; t < SC_SLOTS; t++) o[t] = acc[t]; }
-      if (wpt > 1) break;  // with several waves per term every wave owns exactly one (term, sub)
-    }
-    __syncthreads();
-    if (wave == 0) {
-      Ext rr = sc_fs_round(wc, fsl, part, dl.tk, nterm, wpt, result, round, fcs, lane);
-      if (lane == 0) { chal[1] = rr.c0; chal[2] = rr.c1; }
-    }
-    __syncthreads();
-    const Ext r = ex(chal[1], chal[2]);
-    Ext* const* dst = useA ? dl.bufA : dl.bufB;
-    for (int t = 0; t < ntab; t++) {
-      Ext* o = dst[t];
-      if (cur_ext[t]) { const Ext* q = (const Ext*)cur[t]; for (size_t i = tid; i < npairs; i += nt) o[i] = ex_lerp(q[2 * i], q[2 * i + 1], r); }
-      else { const u64* q = (const u64*)cur[t]; for (size_t i = tid; i < npairs; i += nt) o[i] = ex_lerp_base(q[2 * i], q[2 * i + 1], r); }
-    }
-    __syncthreads();
-    if (tid < ntab) { cur[tid] = dst[tid]; cur_ext[tid] = 1; }
-    __syncthreads();
-    n = npairs; useA = !useA;
-  }
-  if (wave == 0) {
-    const size_t wf = (size_t)dl.nv * (dl.md + 2) * 2;
-    for (int e = lane; e < ntab; e += 64) {
-      Ext v = ((const Ext*)cur[e])[0];
-      size_t w = wf + 2 * (size_t)e;
-      pub_store(result + w, v.c0); pub_store(result + w + 1, v.c1);
-      fcs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1;
-    }
-    u64* rs = result + wf + 2 * (size_t)ntab;
-    if (lane < 8) { pub_store(rs + lane, wc.st); fcs += (unsigned long long)(lane + 1) * wc.st; }
-    if (lane < 4) { u64 v = lane < wc.in_len ? wc.ib : 0; pub_store(rs + 8 + lane, v); fcs += (unsigned long long)(8 + lane + 1) * v; }
-    if (lane == 0) {
-      u64 a = (u64)wc.in_len, b = (u64)wc.out_len;
-      pub_store(rs + 12, a); pub_store(rs + 13, b);
-      fcs += (unsigned long long)13 * a + (unsigned long long)14 * b;
-    }
-    fcs = pub_wave_sum(fcs);
-    wc_finish(wc, lane);  // (host sponge: the transcript is complete before this message is)
-    if (lane == 0) pub_store((u64*)flag, wc.failed ? ~0ull : pub_mix(seq) + fcs);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ Basefold commit-phase tail
-// Dev::commit_tail (dev.h, commit_tail.h): the last rounds of the Basefold commit phase (commit_rounds of pcs.h) — per round the
-// pending sumcheck message absorbed, the folding challenge, the merge of the committed codewords of the oracle's size, the FRI
-// fold (k_fri_fold's formula), the fold of the sumcheck pairs, the next message (k_bf_msg's sums), the Merkle tree of the folded
-// oracle (k_merkle_tail's layer loop) and its root absorbed; in the last round the final message absorbed — in ONE launch of
-// one workgroup once the oracle is short. Default in throughput mode (DP_DEVICE_COMMIT=0 turns it off); checked on the SIMT
-// emulator of tests/ and on MI355X (tests/test_gpu_fused.py).
-KBODY k_commit_tail(const CommitTailDesc* dp, u64* result, unsigned long long* flag, unsigned long long seq) {
-  __shared__ CommitTailDesc dl;
-  __shared__ Ext part[64 * 3];
-  __shared__ unsigned long long chal[3];
-  __shared__ Ext s_last[3];
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < (int)(sizeof(CommitTailDesc) / 8); i += nt) ((u64*)&dl)[i] = ((const u64*)dp)[i];
-  __syncthreads();
-  if (tid < 3) s_last[tid] = dl.last[tid];
-  WaveChallenger wc;
-  wc.st = dl.state[lane & 7]; wc.ib = dl.in_buf[lane & 3]; wc.in_len = dl.in_len; wc.out_len = dl.out_len;
-  wc_host_init(wc, dl.sp_req, dl.sp_rep, dl.sp_seq);
-  unsigned long long fcs = 0;
-  const Ext* prev = dl.folded;   // the folded oracle of the previous round
-  const Ext* eq = dl.eq;
-  const Ext* f = dl.f;
-  size_t m = dl.m;
-  bool useA = true;
-  __syncthreads();
-  for (int j = 0; j < dl.rounds; j++) {
-    const size_t n = (size_t)dl.n >> j, half = n / 2;
-    const bool final_round = j == dl.rounds - 1;
-    // transcript: the pending message, then the folding challenge
-    if (wave == 0) {
-      for (int q = 0; q < 3; q++) { Ext v = s_last[q]; wc_observe(wc, v.c0, lane); wc_observe(wc, v.c1, lane); }
-      wc_observe(wc, dl.lab[0], lane); wc_observe(wc, dl.lab[1], lane);
-      const u64 r0 = wc_sample(wc, lane), r1 = wc_sample(wc, lane);
-      if (lane == 0) { chal[1] = r0; chal[2] = r1; }
-    }
-    __syncthreads();
-    const Ext c = ex(chal[1], chal[2]);
-    // the committed codewords as long as the oracle join it (into a fresh buffer: `prev` is the leaf array of a tree)
-    const Ext* src = prev;
-    if (dl.nmerge[j] > 0) {
-      Ext* run = dl.run[j];
-      for (size_t i = tid; i < n; i += nt) {
-        Ext acc = prev[i];
-        for (int k = 0; k < dl.nmerge[j]; k++) {
-          const Ext co = dl.mcoeff[j][k];
-          acc = ex_add(acc, dl.mext[j][k] ? ex_mul(((const Ext*)dl.mcw[j][k])[i], co) : ex_mul_base(co, ((const u64*)dl.mcw[j][k])[i]));
-        }
-        run[i] = acc;
-      }
-      src = run;
-      __syncthreads();
-    }
-    // FRI fold (K9): out[i] = y0 + (c - x0)(y1 - y0) w, x0 = gamma * w_{2^(level+1)}^{bitrev(i)}, w = -1/(2 x0); the last round's
-    // folded oracle is never used
-    if (!final_round) {
-      const unsigned level = dl.level[j], L = dl.L;
-      Ext* out = dl.leaves[j];
-      for (size_t i = tid; i < half; i += nt) {
-        size_t b = level ? (size_t)(__brevll((unsigned long long)i) >> (64 - level)) : 0;
-        u64 root = dl.tw[b << (L - level)];
-        u64 x0 = gl_mul(root, dl.gamma[j]);
-        u64 rinv = b == 0 ? 1 : gl_neg(dl.tw[((size_t(1) << level) - b) << (L - level)]);
-        u64 w = gl_mul(dl.ninv[j], rinv);
-        Ext y0 = src[2 * i], y1 = src[2 * i + 1];
-        Ext t = ex_mul(ex(gl_sub(c.c0, x0), c.c1), ex_sub(y1, y0));
-        out[i] = ex_add(y0, ex_mul_base(t, w));
-      }
-    }
-    // the sumcheck pairs fold with the same challenge
-    Ext* eqd = useA ? dl.eqA : dl.eqB;
-    Ext* fd = useA ? dl.fA : dl.fB;
-    for (size_t i = tid; i < m / 2; i += nt) { eqd[i] = ex_lerp(eq[2 * i], eq[2 * i + 1], c); fd[i] = ex_lerp(f[2 * i], f[2 * i + 1], c); }
-    __syncthreads();
-    eq = eqd; f = fd; m /= 2; useA = !useA;
-    if (!final_round) {
-      // the next message (K10 on evaluation-form pairs): [sum a ea, sum (b ea + a eb), sum b eb]; a single value: three times it
-      Ext c0 = ex_zero(), c1 = ex_zero(), c2 = ex_zero();
-      for (size_t q = tid; q < m / 2; q += nt) {
-        Ext a = f[2 * q], b = ex_sub(f[2 * q + 1], a), ea = eq[2 * q], eb = ex_sub(eq[2 * q + 1], ea);
-        c0 = ex_add(c0, ex_mul(a, ea));
-        c1 = ex_add(c1, ex_add(ex_mul(b, ea), ex_mul(a, eb)));
-        c2 = ex_add(c2, ex_mul(b, eb));
-      }
-      c0 = wave_reduce_ext(c0); c1 = wave_reduce_ext(c1); c2 = wave_reduce_ext(c2);
-      if (lane == 0) { part[wave * 3] = c0; part[wave * 3 + 1] = c1; part[wave * 3 + 2] = c2; }
-      // layer 0 of the tree: leaf pairs packed, no hashing
-      u64* nd = dl.nodes[j];
-      const Ext* lv = dl.leaves[j];
-      for (size_t i = tid; i < half / 2; i += nt) { Ext a = lv[2 * i], b = lv[2 * i + 1]; u64* o = nd + 4 * i; o[0] = a.c0; o[1] = a.c1; o[2] = b.c0; o[3] = b.c1; }
-      __syncthreads();
-      if (wave == 0) {
-        Ext v0 = lane < W ? part[lane * 3] : ex_zero(), v1 = lane < W ? part[lane * 3 + 1] : ex_zero(), v2 = lane < W ? part[lane * 3 + 2] : ex_zero();
-        v0 = wave_reduce_ext(v0); v1 = wave_reduce_ext(v1); v2 = wave_reduce_ext(v2);
-        if (lane == 0) {
-          if (m == 1) { s_last[0] = f[0]; s_last[1] = f[0]; s_last[2] = f[0]; }
-          else { s_last[0] = v0; s_last[1] = v1; s_last[2] = v2; }
-        }
-      }
-      // upper layers: Poseidon2 compress, one node per lane while the layer is wide, 8 lanes per node when it is narrow
-      size_t off = 0, cnt = half / 2;
-      while (cnt > 1) {
-        const size_t next = cnt / 2;
-        const u64* in = nd + 4 * off;
-        u64* out = nd + 4 * (off + cnt);
-        if (next > (size_t)nt) {
-          for (size_t i = tid; i < next; i += nt) {
-            u64 o[4];
-            poseidon2_compress(in + 8 * i, in + 8 * i + 4, o, c_rc);
-            out[4 * i] = o[0]; out[4 * i + 1] = o[1]; out[4 * i + 2] = o[2]; out[4 * i + 3] = o[3];
-          }
-        } else {
-          // every lane takes part in the permutation (no divergence around the cross-lane moves); idle groups redo the last node
-          const size_t groups = (size_t)nt >> 3;
-          for (size_t g0 = 0; g0 < next; g0 += groups) {
-            const size_t g = g0 + ((size_t)tid >> 3);
-            const size_t gg = g < next ? g : next - 1;
-            const int i8 = lane & 7;
-            u64 sv = i8 < 4 ? in[8 * gg + i8] : 0;
-            sv = p2l_permute(sv, lane);
-            if (i8 < 4) sv = in[8 * gg + 4 + i8];
-            sv = p2l_permute(sv, lane);
-            if (g < next && i8 < 4) out[4 * g + (3 - i8)] = sv;
-          }
-        }
-        __syncthreads();
-        off += cnt; cnt = next;
-      }
-      // the message and the root: published, and the root absorbed (the message is absorbed at the top of the next round)
-      if (wave == 0) {
-        const u64* root = nd + 4 * (half - 2);
-        for (int q = 0; q < 4; q++) wc_observe(wc, root[q], lane);
-        if (lane == 0) {
-          u64* rw = result + (size_t)j * 10;
-          for (int q = 0; q < 3; q++) {
-            Ext v = s_last[q];
-            size_t w = (size_t)j * 10 + 2 * q;
-            pub_store(rw + 2 * q, v.c0); pub_store(rw + 2 * q + 1, v.c1);
-            fcs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1;
-          }
-          for (int q = 0; q < 4; q++) { size_t w = (size_t)j * 10 + 6 + q; pub_store(rw + 6 + q, root[q]); fcs += (unsigned long long)(w + 1) * root[q]; }
-        }
-      }
-      __syncthreads();
-      prev = dl.leaves[j];
-    } else {
-      // the final message: the folded sum_evals in bit-reversed index order, absorbed in its natural order
-      if (wave == 0) {
-        unsigned lg = 0; while ((size_t(1) << lg) < m) lg++;
-        u64* rw = result + (size_t)(dl.rounds - 1) * 10;
-        for (size_t r = 0; r < m; r++) {
-          size_t src_i = lg ? (size_t)(__brevll((unsigned long long)r) >> (64 - lg)) : 0;
-          Ext v = f[src_i];
-          wc_observe(wc, v.c0, lane); wc_observe(wc, v.c1, lane);
-          if (lane == 0) {
-            size_t w = (size_t)(dl.rounds - 1) * 10 + 2 * r;
-            pub_store(rw + 2 * r, v.c0); pub_store(rw + 2 * r + 1, v.c1);
-            fcs += (unsigned long long)(w + 1) * v.c0 + (unsigned long long)(w + 2) * v.c1;
-          }
-        }
-      }
-    }
-  }
-  if (wave == 0) {  // the sponge goes back to the host transcript; the tag closes the message
-    u64* rs = result + (size_t)(dl.rounds - 1) * 10 + 2 * m;
-    if (lane < 8) { pub_store(rs + lane, wc.st); fcs += (unsigned long long)(lane + 1) * wc.st; }
-    if (lane < 4) { u64 v = lane < wc.in_len ? wc.ib : 0; pub_store(rs + 8 + lane, v); fcs += (unsigned long long)(8 + lane + 1) * v; }
-    if (lane == 0) {
-      u64 a = (u64)wc.in_len, b = (u64)wc.out_len;
-      pub_store(rs + 12, a); pub_store(rs + 13, b);
-      fcs += (unsigned long long)13 * a + (unsigned long long)14 * b;
-    }
-    fcs = pub_wave_sum(fcs);
-    wc_finish(wc, lane);  // (host sponge: the transcript is complete before this message is)
-    if (lane == 0) pub_store((u64*)flag, wc.failed ? ~0ull : pub_mix(seq) + fcs);
-  }
-}
-
-// Same protocol as k_sc_persist, but the tables live in LDS after the first fold (bit-reversed index order, so a fold
-// pairs positions q and q + m/2 and is done in place with no hazards): after the first round no table byte touches
-// global memory again. Dynamic LDS = ntabs * (n0/2) extension elements.
-// ---- device -> host publication without fences -------------------------------------------------------------------
-// A system-scope release makes the wave wait for an L2 write-back; with many proofs in flight on one GPU that stalls
-// every round behind other proofs' dirty lines. Instead every payload word goes out as a relaxed system-scope store
-// (the result area is fine-grained host memory, nothing is cached) and the flag word carries a TAG that binds the
-// sequence number to the payload: tag = mix(seq) + sum_i (i+1) * word_i. The host accepts a message only when the tag
-// it recomputes from the words it reads matches, so any reordering of the posted writes is harmless.
-__device__ __forceinline__ void sc_publish(Ext* result, const Ext* part, const int* tk, const int* toff, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane) {
-  unsigned long long cs = 0;
-  u64* rw = (u64*)result;
-  for (int e = lane; e < nterms * SC_SLOTS; e += 64) {
-    int term = e / SC_SLOTS, t = e - term * SC_SLOTS;
-    if (t > tk[term]) continue;  // a degree-k term publishes k + 1 values, packed back to back
-    Ext v = ex_zero();
-    if (wpt == 1) v = part[(size_t)term * SC_SLOTS + t];
-    else for (int sb = 0; sb < wpt; sb++) v = ex_add(v, part[(size_t)(term * wpt + sb) * SC_SLOTS + t]);
-    int o = toff[term] + t;
-    pub_store(rw + 2 * o, v.c0); pub_store(rw + 2 * o + 1, v.c1);
-    cs += (unsigned long long)(2 * o + 1) * v.c0 + (unsigned long long)(2 * o + 2) * v.c1;
-  }
-  cs = pub_wave_sum(cs);
-  if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + cs);
-}
-// publish `n` extension values held in `src` (LDS or global) by one wave
-__device__ __forceinline__ void sc_publish_vals(Ext* result, const Ext* src, size_t stride, int n, unsigned long long* flag, unsigned long long seq, int lane) {
-  unsigned long long cs = 0;
-  u64* rw = (u64*)result;
-  for (int e = lane; e < n; e += 64) {
-    Ext v = src[(size_t)e * stride];
-    pub_store(rw + 2 * e, v.c0); pub_store(rw + 2 * e + 1, v.c1);
-    cs += (unsigned long long)(2 * e + 1) * v.c0 + (unsigned long long)(2 * e + 2) * v.c1;
-  }
-  cs = pub_wave_sum(cs);
-  if (lane == 0) pub_store((u64*)flag, pub_mix(seq) + cs);
-}
-// lane 0 of wave 0: poll the host mailbox [seq, c0, c1, tag] for `seq`, leave {ok, c0, c1} in chal[]. The seq word is polled
-// with relaxed loads; once it matches, an acquire fence orders the payload loads after it, and the tag word — mix(seq) + c0 +
-// 2*c1, written by the host with the payload (post_challenge) — is checked against what was read: a stale or torn payload is
-// re-polled instead of becoming a wrong challenge (same protocol as the device-to-host direction, wait_flag). The wait is
-// bounded in TIME (c_poll_timeout_ticks of the 100 MHz s_memrealtime clock; DP_POLL_TIMEOUT_S, default 20 s: below the host's
-// own 30 s), not in spins: a host that serves hundreds of proofs from a few threads is slow, not gone.
-__device__ __forceinline__ unsigned long long chal_mix(unsigned long long seq) { return seq * 0x9E3779B97F4A7C15ull + 0x7F4A7C159E3779B9ull; }
-__device__ __forceinline__ void sc_wait_challenge(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal) {
-  const unsigned long long t0 = dp_realtime();
-  bool ok = false;
-  unsigned long long c0 = 0, c1 = 0;
-  for (unsigned spin = 0;; spin++) {
-    unsigned long long got = __hip_atomic_load(mailbox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (got == seq) {
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      c0 = __hip_atomic_load(mailbox + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      c1 = __hip_atomic_load(mailbox + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      unsigned long long tag = __hip_atomic_load(mailbox + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if (tag == chal_mix(seq) + c0 + 2 * c1) { ok = true; break; }
-    }
-    if ((spin & 63) == 63 && dp_realtime() - t0 > c_poll_timeout_ticks) break;
-    for (int q = 0; q < c_poll_sleep; q++) __builtin_amdgcn_s_sleep(4);  // every poll is a PCIe read: keep the rate of all kernels in flight bounded
-  }
-  chal[0] = ok ? 1 : 0; chal[1] = c0; chal[2] = c1;
-}
-__device__ void sc_publish_fwd(Ext* result, const Ext* part, const int* tk, const int* toff, int nterms, int wpt, unsigned long long* flag, unsigned long long seq, int lane) { sc_publish(result, part, tk, toff, nterms, wpt, flag, seq, lane); }
-__device__ void sc_publish_vals_fwd(Ext* result, const Ext* src, size_t stride, int n, unsigned long long* flag, unsigned long long seq, int lane) { sc_publish_vals(result, src, stride, n, flag, seq, lane); }
-__device__ void sc_wait_challenge_fwd(const unsigned long long* mailbox, unsigned long long seq, unsigned long long* chal) { sc_wait_challenge(mailbox, seq, chal); }
-template <bool HI>
-KBODY k_sc_persist_lds(const ScPersistArgs& a, Ext* result, unsigned long long* flag, const unsigned long long* mailbox, unsigned long long seq0, const ScFsArgs* fs) {
-  extern __shared__ __align__(16) unsigned char lds_dyn[];
-  Ext* L = (Ext*)lds_dyn;
-  __shared__ Ext part[64 * SC_SLOTS];
-  __shared__ unsigned long long chal[3];
-  __shared__ ScFsArgs fsl;
-  int tid = threadIdx.x, nt = blockDim.x;
-  int W = nt >> 6, wave = tid >> 6, lane = tid & 63;
-  int wpt = a.nterms >= W ? 1 : W / a.nterms;
-  const bool autofs = fs != nullptr;  // device-side Fiat-Shamir: no host round trips
-  if (autofs) { for (int i = tid; i < (int)(sizeof(ScFsArgs) / 8); i += nt) ((u64*)&fsl)[i] = ((const u64*)fs)[i]; __syncthreads(); }
-  WaveChallenger wc; wc.st = wc.ib = 0; wc.in_len = wc.out_len = 0;
-  if (autofs) wc_load(wc, fsl, lane);
-  unsigned long long fcs = 0; int round = 0;
-  if (a.eq_tab >= 0) wg_build_eq((Ext*)a.in[a.eq_tab], a.eq_pt, a.eq_k);
-  unsigned long long seq = seq0;
-  size_t first = a.n0 / 2;
-  unsigned lgf = 0; while ((size_t(1) << lgf) < first) lgf++;
-  Ext r = a.r0;
-  unsigned long long c_fold = 0, c_sums = 0, c_pub = 0, c_wait = 0, c_rounds = 0, tk = clock64();
-  if (!a.has_r0) {
-    // round on the tables as they sit in global memory
-    size_t npairs = a.n0 / 2;
-    for (int term = wave / wpt; term < a.nterms; term += (wpt == 1 ? W : a.nterms + W)) {
-      int sub = wave % wpt;
-      int k = a.k[term];
-      GlobalPairs L;
-#pragma unroll
-      for (int j = 0; j < ScW<HI>::K; j++) { int ti = a.t[term][j < k ? j : 0]; L.p[j] = a.in[ti]; L.e[j] = a.in_ext[ti]; }
-      Ext acc[SC_SLOTS];
-      sc_accumulate<HI>(k, L, (size_t)sub * 64 + lane, (size_t)wpt * 64, npairs, acc);
-#pragma unroll
-      for (int t = 0; t < SC_SLOTS; t++) if (t <= k) acc[t] = wave_reduce_ext(acc[t]);
-      if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * SC_SLOTS; for (int t = 0; t < SC_SLOTS; t++) o[t] = acc[t]; }
-      if (wpt > 1) break;
-    }
-    __syncthreads();
-    ++seq;
-    if (wave == 0) {
-      if (autofs) { Ext rr = sc_fs_round(wc, fsl, part, a.k, a.nterms, wpt, (u64*)result, round, fcs, lane); if (lane == 0) { chal[0] = 1; chal[1] = rr.c0; chal[2] = rr.c1; } }
-      else { sc_publish(result, part, a.k, a.off, a.nterms, wpt, flag, seq, lane); if (lane == 0) sc_wait_challenge(mailbox, seq, chal); }
-    }
-    round++;
-    __syncthreads();
-    if (chal[0] == 0) { if (tid == 0) pub_store((u64*)flag, ~0ull); return; }
-    r = ex(chal[1], chal[2]);
-  }
-  // first fold: global -> LDS (bit-reversed positions)
-  for (size_t idx = tid; idx < (size_t)a.ntabs * first; idx += nt) {
-    int t = (int)(idx >> lgf); size_t i = idx & (first - 1);
-    Ext v = a.in_ext[t] ? ex_lerp(((const Ext*)a.in[t])[2 * i], ((const Ext*)a.in[t])[2 * i + 1], r)
-                        : ex_lerp_base(((const u64*)a.in[t])[2 * i], ((const u64*)a.in[t])[2 * i + 1], r);
-    size_t pos = lgf ? (__brev((unsigned)i) >> (32 - lgf)) : 0;
-    L[((size_t)t << lgf) + pos] = v;
-  }
-  __syncthreads();
-  size_t m = first;
-  for (;;) {
-    if (m == 1) {
-      ++seq;
-      if (tid == 0 && a.dbg) { atomicAdd(a.dbg + 0, c_fold); atomicAdd(a.dbg + 1, c_sums); atomicAdd(a.dbg + 2, c_pub); atomicAdd(a.dbg + 3, c_wait); atomicAdd(a.dbg + 4, c_rounds); }
-      if (wave == 0 && autofs) sc_fs_finish(wc, fsl, nullptr, L, size_t(1) << lgf, a.ntabs, (u64*)result, flag, seq0 + 1, fcs, lane);
-      else if (wave == 0) sc_publish_vals(result, L, size_t(1) << lgf, a.ntabs, flag, seq, lane);
-      return;
-    }
-    size_t h = m / 2;
-    if (tid == 0) { unsigned long long now = clock64(); c_fold += now - tk; tk = now; }
-    for (int term = wave / wpt; term < a.nterms; term += (wpt == 1 ? W : a.nterms + W)) {
-      int sub = wave % wpt;
-      int k = a.k[term];
-      LdsPairs LP; LP.h = h;
-#pragma unroll
-      for (int j = 0; j < ScW<HI>::K; j++) LP.p[j] = L + ((size_t)a.t[term][j < k ? j : 0] << lgf);
-      Ext acc[SC_SLOTS];
-      sc_accumulate<HI>(k, LP, (size_t)sub * 64 + lane, (size_t)wpt * 64, h, acc);
-#pragma unroll
-      for (int t = 0; t < SC_SLOTS; t++) if (t <= k) acc[t] = wave_reduce_ext(acc[t]);
-      if (lane == 0) { Ext* o = part + (size_t)(term * wpt + sub) * SC_SLOTS; for (int t = 0; t < SC_SLOTS; t++) o[t] = acc[t]; }
-      if (wpt > 1) break;
-    }
-    __syncthreads();
-    ++seq;
-    if (tid == 0) { unsigned long long now = clock64(); c_sums += now - tk; tk = now; }
-    if (wave == 0 && autofs) {
-      Ext rr = sc_fs_round(wc, fsl, part, a.k, a.nterms, wpt, (u64*)result, round, fcs, lane);
-      if (lane == 0) { chal[0] = 1; chal[1] = rr.c0; chal[2] = rr.c1; }
-      if (tid == 0) { unsigned long long now = clock64(); c_wait += now - tk; tk = now; c_rounds++; }
-    } else if (wave == 0) {
-      sc_publish(result, part, a.k, a.off, a.nterms, wpt, flag, seq, lane);
-      if (tid == 0) { unsigned long long now = clock64(); c_pub += now - tk; tk = now; }
-      if (lane == 0) sc_wait_challenge(mailbox, seq, chal);
-      if (tid == 0) { unsigned long long now = clock64(); c_wait += now - tk; tk = now; c_rounds++; }
-    }
-    round++;
-    __syncthreads();
-    if (chal[0] == 0) { if (tid == 0) pub_store((u64*)flag, ~0ull); return; }
-    r = ex(chal[1], chal[2]);
-    unsigned lgh = 0; while ((size_t(1) << lgh) < h) lgh++;
-    for (size_t idx = tid; idx < (size_t)a.ntabs * h; idx += nt) {
-      size_t t = idx >> lgh, q = idx & (h - 1);
-      Ext* p = L + (t << lgf);
-      p[q] = ex_lerp(p[q], p[q + h], r);
-    }
-    __syncthreads();
-    m = h;
-  }
-}
-
-// out[e] = sum_{b < nblocks} partial[(e / inner) * nblocks * inner + b * inner + (e % inner)], e < nout, computed by ONE
-// workgroup (wave w owns outputs w, w+W, ..) and published straight to host-mapped memory with the tag protocol: the
-// second stage of every block-partial reduction needs neither a separate publish launch nor a stream synchronisation.
-KBODY k_reduce_publish(const Ext* partial, size_t nblocks, size_t inner, int nout, Ext* result, unsigned long long* flag, unsigned long long seq) {
-  __shared__ Ext res[1024];
-  int tid = threadIdx.x, W = blockDim.x >> 6, wave = tid >> 6, lane = tid & 63;
-  for (int e = wave; e < nout; e += W) {
-    size_t base = ((size_t)e / inner) * nblocks * inner + ((size_t)e % inner);
-    Ext acc = ex_zero();
-    for (size_t b = lane; b < nblocks; b += 64) acc = ex_add(acc, partial[base + b * inner]);
-    acc = wave_reduce_ext(acc);
-    if (lane == 0) res[e] = acc;
-  }
-  __syncthreads();
-  if (wave == 0) sc_publish_vals(result, res, 1, nout, flag, seq, lane);
-}
-// ---- work-proportional grids for batched kernels over items of very different sizes ------------------------------------
-// blockIdx.y = item wastes most of a launch when one item is 2^20 long and thirty others are 2^10 (every empty workgroup
-// still has to fetch its descriptor before it can leave). Instead the grid is 1-D and `first[i] .. first[i+1]` are the
-// workgroups of item i (first[] sits in front of the descriptors, n + 1 entries): one coalesced load finds the owner.
-__device__ __forceinline__ int seg_find(const unsigned* first, int n, int* slot) {
-  if (threadIdx.x < 64) {
-    for (int base = 0; base < n; base += 64) {
-      int i = base + (int)threadIdx.x;
-      bool mine = i < n && first[i] <= blockIdx.x && blockIdx.x < first[i + 1];
-      if (mine) *slot = i;
-    }
-  }
-  __syncthreads();
-  return *slot;
-}
-// One round of the batch-opening sumcheck (sum_check/classic.rs:232-285, coeff.rs:198-345) over every (f, eq) pair in one
-// launch: fold both tables by r (if has_r and the pair is longer than 1; the folded tables go to fout / eqout) and, in the
-// same pass, the two sums of the FOLDED pair the next message needs: c0 = sum f0 e0, c2 = sum (f1 - f0)(e1 - e0).
-// partial[2 * workgroup + {0,1}]; k_classic_reduce adds the workgroups of each pair and publishes.
-struct ClassicDesc { const void* f; const Ext* eq; Ext* fout; Ext* eqout; size_t n; int fext; int pad; };
-KBODY k_classic_fused(const unsigned* first, const ClassicDesc* d, int np, Ext r, int has_r, Ext* partial) {
-  __shared__ Ext sm[TPB / 64];
-  __shared__ int slot;
-  const int pi = seg_find(first, np, &slot);
-  const ClassicDesc p = d[pi];
-  const size_t b = blockIdx.x - first[pi], nb = first[pi + 1] - first[pi];
-  Ext c0 = ex_zero(), c2 = ex_zero();
-  if (has_r && p.n > 1) {
-    const size_t h = p.n / 2;  // length after the fold
-    if (h == 1) {
-      if (b == 0 && threadIdx.x == 0) {
-        Ext f = p.fext ? ex_lerp(((const Ext*)p.f)[0], ((const Ext*)p.f)[1], r) : ex_lerp_base(((const u64*)p.f)[0], ((const u64*)p.f)[1], r);
-        Ext e = ex_lerp(p.eq[0], p.eq[1], r);
-        p.fout[0] = f; p.eqout[0] = e;
-        c0 = ex_mul(f, e);
-      }
-    } else {
-      for (size_t j = b * blockDim.x + threadIdx.x; j < h / 2; j += nb * blockDim.x) {
-        Ext f0, f1;
-        if (p.fext) { const Ext* q = (const Ext*)p.f + 4 * j; f0 = ex_lerp(q[0], q[1], r); f1 = ex_lerp(q[2], q[3], r); }
-        else { const u64* q = (const u64*)p.f + 4 * j; f0 = ex_lerp_base(q[0], q[1], r); f1 = ex_lerp_base(q[2], q[3], r); }
-        const Ext* qe = p.eq + 4 * j;
-        Ext e0 = ex_lerp(qe[0], qe[1], r), e1 = ex_lerp(qe[2], qe[3], r);
-        p.fout[2 * j] = f0; p.fout[2 * j + 1] = f1; p.eqout[2 * j] = e0; p.eqout[2 * j + 1] = e1;
-        c0 = ex_add(c0, ex_mul(f0, e0));
-        c2 = ex_add(c2, ex_mul(ex_sub(f1, f0), ex_sub(e1, e0)));
-      }
-    }
-  } else if (p.n == 1) {
-    if (b == 0 && threadIdx.x == 0) c0 = ex_mul(ld_elem(p.f, p.fext, 0), p.eq[0]);
-  } else {
-    for (size_t j = b * blockDim.x + threadIdx.x; j < p.n / 2; j += nb * blockDim.x) {
-      Ext l0 = p.eq[2 * j], l1 = p.eq[2 * j + 1];
-      if (p.fext) {
-        Ext r0 = ((const Ext*)p.f)[2 * j], r1 = ((const Ext*)p.f)[2 * j + 1];
-        c0 = ex_add(c0, ex_mul(l0, r0));
-        c2 = ex_add(c2, ex_mul(ex_sub(l1, l0), ex_sub(r1, r0)));
-      } else {
-        u64 r0 = ((const u64*)p.f)[2 * j], r1 = ((const u64*)p.f)[2 * j + 1];
-        c0 = ex_add(c0, ex_mul_base(l0, r0));
-        c2 = ex_add(c2, ex_mul_base(ex_sub(l1, l0), gl_sub(r1, r0)));
-      }
-    }
-  }
-  Ext t;
-  t = block_reduce_ext(c0, sm); if (threadIdx.x == 0) partial[2 * (size_t)blockIdx.x] = t;
-  t = block_reduce_ext(c2, sm); if (threadIdx.x == 0) partial[2 * (size_t)blockIdx.x + 1] = t;
-}
-// out[2 i + t] = sum over the workgroups of pair i of partial[2 w + t], published to the host (np <= 512)
-KBODY k_classic_reduce(const unsigned* first, int np, const Ext* partial, Ext* result, unsigned long long* flag, unsigned long long seq) {
-  __shared__ Ext res[1024];
-  int tid = threadIdx.x, W = blockDim.x >> 6, wave = tid >> 6, lane = tid & 63;
-  for (int i = wave; i < np; i += W) {
-    Ext a0 = ex_zero(), a2 = ex_zero();
-    for (unsigned w = first[i] + lane; w < first[i + 1]; w += 64) { a0 = ex_add(a0, partial[2 * (size_t)w]); a2 = ex_add(a2, partial[2 * (size_t)w + 1]); }
-    a0 = wave_reduce_ext(a0); a2 = wave_reduce_ext(a2);
-    if (lane == 0) { res[2 * i] = a0; res[2 * i + 1] = a2; }
-  }
-  __syncthreads();
-  if (wave == 0) sc_publish_vals(result, res, 1, 2 * np, flag, seq, lane);
-}
-struct EqDesc { Ext* out; unsigned k; unsigned pad; Ext pt[MAX_PT]; };
-// many eq tables in one launch: blockIdx.y selects the table (batch_open builds one per opened polynomial)
-// eq(i, pt) = lo[i mod 2^kl] * hi[i >> kl]: a workgroup owns EQ_CHUNK consecutive entries of one table, builds the 2^kl
-// low-part products (kl <= 8) and its EQ_CHUNK / 2^kl high-part products in LDS, then spends ONE multiplication per entry
-// instead of k. (Products in the field are exact: the entries are those of build_eq_x_r_vec bit for bit.)
-constexpr unsigned EQ_CHUNK = 4096;
-KBODY k_eq_table_many(const unsigned* first, const EqDesc* d, int nd) {
-  __shared__ Ext lo[256];
-  __shared__ Ext hi[EQ_CHUNK / 256 > 16 ? EQ_CHUNK / 256 : 16];
-  __shared__ int slot;
-  const int di = seg_find(first, nd, &slot);
-  const EqDesc& e = d[di];
-  const size_t n = size_t(1) << e.k;
-  const unsigned kl = e.k < 8 ? e.k : 8;
-  const size_t base = (size_t)(blockIdx.x - first[di]) * EQ_CHUNK;
-  const size_t cnt = n - base < EQ_CHUNK ? n - base : EQ_CHUNK;   // entries of this workgroup (a multiple of 2^kl)
-  if (threadIdx.x < (1u << kl)) {
-    Ext v = ex_one();
-    for (unsigned t = 0; t < kl; t++) { Ext r = e.pt[t]; v = ex_mul(v, ((threadIdx.x >> t) & 1) ? r : ex_sub(ex_one(), r)); }
-    lo[threadIdx.x] = v;
-  }
-  const size_t nhi = cnt >> kl;
-  if (threadIdx.x < nhi) {
-    size_t h = (base >> kl) + threadIdx.x;
-    Ext v = ex_one();
-    for (unsigned t = kl; t < e.k; t++) { Ext r = e.pt[t]; v = ex_mul(v, ((h >> (t - kl)) & 1) ? r : ex_sub(ex_one(), r)); }
-    hi[threadIdx.x] = v;
-  }
-  __syncthreads();
-  for (size_t q = threadIdx.x; q < cnt; q += blockDim.x) e.out[base + q] = ex_mul(lo[q & ((size_t(1) << kl) - 1)], hi[q >> kl]);
-}
-struct AxpyDesc { const void* x; int xext; unsigned lg_rep; size_t n_x; Ext coeff; };
-// acc[i] = init[i] (or 0) + sum_d x_d[i >> lg_rep_d] * coeff_d over all descriptors (K11: every codeword / evaluation table merged into
-// the running oracle in ONE pass over acc instead of one launch and one read-modify-write of acc per polynomial)
-KBODY k_axpy_many(Ext* acc, const Ext* init, size_t n_acc, const AxpyDesc* d, int nd) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_acc; i += (size_t)gridDim.x * blockDim.x) {
-    Ext a = init ? init[i] : ex_zero();
-    for (int q = 0; q < nd; q++) {
-      size_t j = i >> d[q].lg_rep;
-      Ext m = d[q].xext ? ex_mul(((const Ext*)d[q].x)[j], d[q].coeff) : ex_mul_base(d[q].coeff, ((const u64*)d[q].x)[j]);
-      a = ex_add(a, m);
-    }
-    acc[i] = a;
-  }
-}
-// last fold of a sumcheck, results published directly
-KBODY k_finish_publish(const FoldArgs& a, Ext r, int ntabs, Ext* result, unsigned long long* flag, unsigned long long seq) {
-  __shared__ Ext res[MAX_TABS];
-  int t = threadIdx.x;
-  if (t < ntabs) {
-    Ext v;
-    if (a.ext[t]) { const Ext* p = (const Ext*)a.in[t]; v = ex_lerp(p[0], p[1], r); }
-    else { const u64* p = (const u64*)a.in[t]; v = ex_lerp_base(p[0], p[1], r); }
-    res[t] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) sc_publish_vals(result, res, 1, ntabs, flag, seq, threadIdx.x);
-}
-
-// copy a small device result into host-mapped memory and publish it
-// (launched with ONE wave so that payload stores and the releasing flag store come from the same wave)
-KBODY k_publish(const u64* src, u64* dst, size_t nwords, unsigned long long* flag, unsigned long long seq) {
-  unsigned long long cs = 0;
-  for (size_t i = threadIdx.x; i < nwords; i += blockDim.x) { u64 v = src[i]; pub_store(dst + i, v); cs += (unsigned long long)(i + 1) * v; }
-  cs = pub_wave_sum(cs);
-  if (threadIdx.x == 0) pub_store((u64*)flag, pub_mix(seq) + cs);
-}
+#include "kernels.inc"
 
 // ================================================================================================ HipDev
 // Grid size for grid-stride kernels. DP_MAX_GRID bounds every launch so that, with several proofs in flight on one GPU,

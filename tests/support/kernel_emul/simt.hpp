@@ -72,6 +72,7 @@ static struct { simt::Const x{1}, y{1}, z{1}; } gridDim;
 #define __shared__ static
 #define __restrict__
 #define KBODY inline void
+#define DP_LDS_FRAME(T, f) static T f  // (one workgroup at a time: the frame of a body is a plain static object here)
 #define DP_CLAIM_ALL_VGPRS() ((void)0)
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
