@@ -3,6 +3,7 @@
 #include "zkml.h"
 #include "sharded.h"
 #include "fiber.h"
+#include "rx.h"
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>  // types and enums only: the functions are resolved with dlopen (no link-time dependency on librccl)
@@ -15,7 +16,7 @@
 #include <thread>
 
 DP_FIBER_SWITCH_ASM
-namespace dp { struct Cohort; Cohort* hip_cohort_new(); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_pcs_share(Dev* worker, Dev* owner); void hip_dump_wg_times(); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
+namespace dp { struct Cohort; Cohort* hip_cohort_new(); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); struct RxEngine; void hip_dev_rx_attach(Dev* d, RxEngine* e, unsigned slot); void hip_dev_rx_detach(Dev* d); void hip_rx_session(int delta); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_pcs_share(Dev* worker, Dev* owner); void hip_dump_wg_times(); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
 using namespace dp;
 
 // `mu`: PCS::commit is called from rayon workers in the reference (zkml/src/commit/context.rs:79-103 into_par_iter over
@@ -31,7 +32,8 @@ struct dp_batch_commit { DevBatchCommit c; };
 struct dp_model {
   dp_ctx* ctx; std::unique_ptr<Context> zk; std::vector<std::unique_ptr<Dev>> workers; std::vector<dp::Cohort*> cohorts;
   size_t last_in_flight = 0, in_flight_cap = 0; size_t prove_peak = 0;  // largest arena footprint a proof of this model has had so far (sizes the arenas of batch workers)
-  ~dp_model() { for (auto* c : cohorts) hip_cohort_free(c); }
+  dp::RxEngine* rx = nullptr;  // the resident executor of this model's GPU (rx.h), created by the first batch that uses it
+  ~dp_model() { for (auto* c : cohorts) hip_cohort_free(c); if (rx) rx_engine_free(rx); }
 };
 
 // Every cohort stream needs a hardware queue of its own (24 are served without time slicing; the HIP runtime multiplexes streams
@@ -778,12 +780,16 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     // Cohorts (hip_dev.hip, struct Cohort): the proofs in flight are grouped into cohorts of DP_COHORT members (default: in flight / 22, rounded up)
     // that prove in lock step — launch number i of all members of a cohort is ONE kernel launch — on one stream and one
     // host thread per cohort. DP_COHORT=0: every proof on its own stream (the round-1 scheme).
+    // DP_RX=1: the resident executor (rx.h) instead of cohorts — every proof is a slot, its launches are step descriptors that two
+    // persistent kernels execute; nothing goes through the command processor while the batch runs
+    const char* rxe = getenv("DP_RX");
+    const bool use_rx = rxe && atoi(rxe) && nw > 1 && nw <= RX_MAX_SLOTS;
     const char* ce = getenv("DP_COHORT");
     // Default: as many cohorts as hardware queues serve without time slicing (22 of the 24), each as small as that allows — a merged
     // launch ends with its slowest member, so small cohorts stall less (batch of 8: 121 ms with cohorts of 1, 165 ms with one cohort
     // of 8; batch of 64: 262 ms with cohorts of 3, 302 ms with 12; 256 in flight: cohorts of 12; profiles/r02_batch_cohort_sweep.txt)
     size_t csize = ce ? (size_t)std::max(0, atoi(ce)) : std::max<size_t>(1, (nw + 21) / 22);
-    size_t nco = (csize >= 1 && nw > 1) ? (nw + csize - 1) / csize : 0;
+    size_t nco = (csize >= 1 && nw > 1 && !use_rx) ? (nw + csize - 1) / csize : 0;
     while (m->cohorts.size() < nco) m->cohorts.push_back(hip_cohort_new());
     auto dev_of = [&](size_t wi) -> Dev& { return wi == 0 ? *m->ctx->dev : *m->workers[wi - 1]; };
     std::atomic<size_t> next(0);
@@ -791,6 +797,16 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     std::mutex err_mu; std::string err; int err_code = 0;
     for (size_t i = 0; i < nproofs; i++) { proof_words[i] = nullptr; proof_nwords[i] = 0; }
     for (size_t wi = 0; wi < nw && nco; wi++) hip_dev_cohort_attach(&dev_of(wi), m->cohorts[wi % nco]);
+    struct RxSession {  // started before the first proof, stopped (workers gone, caches written back) before anything else touches the GPU
+      dp_model* m; bool on = false;
+      ~RxSession() { if (on) { hip_rx_session(-1); try { rx_engine_stop(m->rx); } catch (...) {} } }
+    } rxs{m};
+    if (use_rx) {
+      if (!m->rx) m->rx = rx_engine_new(m->ctx->device_id);
+      rx_engine_start(m->rx, (unsigned)nw);
+      rxs.on = true; hip_rx_session(+1);
+      for (size_t wi = 0; wi < nw; wi++) hip_dev_rx_attach(&dev_of(wi), m->rx, (unsigned)wi);
+    }
     auto t0 = std::chrono::steady_clock::now();
     auto work = [&](size_t wi) {
       Dev& dev = dev_of(wi);
@@ -820,6 +836,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
       catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_ARG; err = "unknown exception in a proof worker"; } next = nproofs; }
       // leaving the cohort releases the launches the other members have queued behind this one
       if (nco) { try { hip_dev_cohort_detach(&dev); } catch (const std::exception& e) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } next = nproofs; } }
+      if (use_rx) hip_dev_rx_detach(&dev);
     };
     // `nw` proofs in flight on `nth` host threads: every worker is a fiber; a thread switches to its next fiber whenever the
     // current one waits for the device (fiber.h). All members of a cohort live on one thread (the cohort has no locks);
@@ -842,6 +859,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     for (size_t ti = 1; ti < nth; ti++) th.emplace_back(run_thread, ti);
     run_thread(0);
     for (auto& t : th) t.join();
+    if (rxs.on) { rxs.on = false; hip_rx_session(-1); try { rx_engine_stop(m->rx); } catch (const std::exception& e) { if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } } }
     for (size_t c = 0; c < nco; c++) { try { hip_cohort_drain(m->cohorts[c]); } catch (const std::exception& e) { if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } } }
     if (nco && getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) {
       size_t f = 0, p = 0; for (size_t c = 0; c < nco; c++) { size_t a, b; hip_cohort_stats(m->cohorts[c], &a, &b); f += a; p += b; }

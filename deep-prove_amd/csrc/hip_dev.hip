@@ -17,6 +17,8 @@
 #include "eqsum_tail.h"
 #include "commit_tail.h"
 #include "sponge_host.h"
+#include "rx.h"
+#include "rx_bodies.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -36,6 +38,14 @@ namespace dp {
 
 #include "kernels.inc"
 
+// ---- the resident executor's view of a body: its index in RX_BODY_LIST (rx_bodies.h; rx.hip switches on the same order) and its class
+template <auto Body> struct RxId { static constexpr int value = -1, klass = -1; };
+enum { RXH_ID_BASE = __COUNTER__ + 1 };
+#define X(c, ...) template <> struct RxId<&__VA_ARGS__> { static constexpr int value = __COUNTER__ - RXH_ID_BASE, klass = (c); };
+RX_BODY_LIST(X)
+#undef X
+static std::atomic<int> g_rx_sessions{0};  // > 0 while a resident executor runs: grid-stride launches use smaller virtual grids
+
 // ================================================================================================ HipDev
 // Grid size for grid-stride kernels. DP_MAX_GRID bounds every launch so that, with several proofs in flight on one GPU,
 // a large kernel of one proof cannot occupy every wave slot while another proof's latency-critical one-block kernels
@@ -44,6 +54,8 @@ static int g_max_grid = [] { const char* e = getenv("DP_MAX_GRID"); return e ? a
 static inline int grid_for(size_t n, int cap = 2048) {
   size_t b = (n + TPB - 1) / TPB;
   if (b < 1) b = 1;
+  // behind the resident executor a proof's tiles run on the workers of ONE XCD (32 CUs): 256 tiles keep them busy, more only costs queue traffic
+  if (g_rx_sessions.load(std::memory_order_relaxed) > 0) cap = std::min(cap, 256);
   return (int)std::min<size_t>(std::min<size_t>(b, cap), (size_t)g_max_grid);
 }
 
@@ -232,6 +244,8 @@ class HipDev : public Dev {
 
   hipStream_t s_ = nullptr;
   Cohort* co_ = nullptr;  // non-null while this context proves as a member of a cohort: launches go to the cohort's stream
+  RxEngine* rx_ = nullptr; unsigned rx_slot_ = 0;  // non-null while this context proves as a slot of the resident executor (rx.h)
+  bool queued_() const { return co_ != nullptr || rx_ != nullptr; }  // launches are packs handed to someone else: data moves with kernels, never with stream commands
   size_t co_li_ = 0;      // number of launches this member has issued into the cohort's common sequence
   template <auto Body, int MAXT, int FLAGS, class... A>
   static void fire_(const Cohort::Pending& p, hipStream_t s) {
@@ -241,11 +255,17 @@ class HipDev : public Dev {
   void launch_(KArgs<void (*)(A...)>, const char* name, dim3 g, dim3 b, size_t lds, P... args) {
     static_assert(sizeof...(A) == sizeof...(P), "kernel argument count");
     if (g_host_stats) { if (!first_launch_) first_launch_ = name; last_launch_ = name; by_name_[name]++; }
-    if (!co_) { hipLaunchKernelGGL((kg<Body, MAXT, FLAGS, std::decay_t<A>...>), g, b, lds, s_, static_cast<std::decay_t<A>>(args)...); return; }
+    if (!co_ && !rx_) { hipLaunchKernelGGL((kg<Body, MAXT, FLAGS, std::decay_t<A>...>), g, b, lds, s_, static_cast<std::decay_t<A>>(args)...); return; }
     DP_REQUIRE(g.z == 1, DP_ERR_SHAPE, "cohort launches use blockIdx.z for the proof");
     using Pack = ArgPack<std::decay_t<A>...>;
     static_assert(std::is_trivially_copyable<Pack>::value && std::is_trivially_destructible<Pack>::value, "argument packs travel as bytes");
     Pack pk(static_cast<std::decay_t<A>>(args)...);
+    if (rx_) {  // a step of this proof's chain on the resident executor (rx.h): no launch, a descriptor in the slot's ring
+      constexpr int id = RxId<Body>::value;
+      DP_REQUIRE(id >= 0, DP_ERR_SHAPE, std::string("kernel ") + name + " is not available in the resident executor (csrc/rx_bodies.h)");
+      rx_submit(rx_, rx_slot_, id, RxId<Body>::klass, FLAGS, g.x, g.y, lds, &pk, sizeof(Pack), name);
+      return;
+    }
     co_->submit(co_li_++, &fire_<Body, MAXT, FLAGS, A...>, name, g, b, lds, &pk, sizeof(Pack));
   }
   template <auto Body, int MAXT, int FLAGS, class... A>
@@ -321,7 +341,7 @@ class HipDev : public Dev {
       const bool fib = fiber_active();
       if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
       if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
-        throw DpError(DP_ERR_HIP, "timeout waiting for the device");
+        throw DpError(DP_ERR_HIP, std::string("timeout waiting for the device") + (rx_ ? "\n" + rx_engine_dump(rx_, rx_slot_) : std::string()));
     }
     desc_off_ = 0; stage_off_ = 0;
     if (co_ && co_li_) co_->note_executed(co_li_ - 1);
@@ -384,7 +404,7 @@ class HipDev : public Dev {
       const bool fib = fiber_active();
       if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
       if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
-        throw DpError(DP_ERR_HIP, "timeout waiting for the device");
+        throw DpError(DP_ERR_HIP, std::string("timeout waiting for the device") + (rx_ ? "\n" + rx_engine_dump(rx_, rx_slot_) : std::string()));
     }
   }
   // wait_flag for a message made of blocks whose checksum runs over block-relative word indices (k_logup_tail)
@@ -406,7 +426,7 @@ class HipDev : public Dev {
       const bool fib = fiber_active();
       if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
       if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
-        throw DpError(DP_ERR_HIP, "timeout waiting for the device");
+        throw DpError(DP_ERR_HIP, std::string("timeout waiting for the device") + (rx_ ? "\n" + rx_engine_dump(rx_, rx_slot_) : std::string()));
     }
   }
   // descriptors for batched kernels: written by the host into the mapped ring and read by the kernel directly (no
@@ -551,7 +571,7 @@ class HipDev : public Dev {
   // Dev::merkle_paths_check on the GPU: the job arrays go up in one staging pass, one launch, two words come back
   bool merkle_paths_check(const u64* leaf, const u64* root, const u64* x, const u64* path_off, const u64* depth, size_t n, const u64* pool, size_t pool_digests, size_t* first_bad) override {
     if (!n) return true;
-    DP_REQUIRE(!co_, DP_ERR_ARG, "merkle_paths_check: not from inside a cohort");
+    DP_REQUIRE(!queued_(), DP_ERR_ARG, "merkle_paths_check: not from inside a cohort / the resident executor");
     std::vector<u64> meta(3 * n);
     for (size_t j = 0; j < n; j++) { DP_REQUIRE(path_off[j] + depth[j] <= pool_digests, DP_ERR_ARG, "merkle_paths_check: path outside the pool"); meta[3 * j] = x[j]; meta[3 * j + 1] = path_off[j]; meta[3 * j + 2] = depth[j]; }
     struct ArenaMark { HipDev* d; size_t mk; ~ArenaMark() { d->release(mk); } } guard_{this, mark()};  // released on every exit: an adversarial proof must not leak the arena
@@ -570,7 +590,7 @@ class HipDev : public Dev {
   // = 256 CUs x 28 waves x 64 lanes): the VALU-integer peak bench.py prices the whole job's hashing against, measured with
   // HIP events on this context's stream in the same run. The input is whatever the arena holds: the arithmetic is branch-free.
   double probe_compress_rate(size_t nodes, int reps) {
-    DP_REQUIRE(!co_ && nodes >= 1024 && reps >= 1, DP_ERR_ARG, "probe: bad arguments");
+    DP_REQUIRE(!queued_() && nodes >= 1024 && reps >= 1, DP_ERR_ARG, "probe: bad arguments");
     const size_t mk = mark();
     DBuf in = alloc(8 * nodes, false), out = alloc(4 * nodes, false);
     nb_ = 0; DPL(k_zero_words, dim3(grid_for(8 * nodes)), dim3(TPB), (u64*)in.p, 8 * nodes);
@@ -657,7 +677,7 @@ class HipDev : public Dev {
       char* slot = bulk_stage() + stage_off_;
       memcpy(slot, src, bytes);
       if (g_host_stats) by_name_["  (k_copy_words as upload)"]++;
-      if (co_) { nb_ = 0; DPL(k_copy_words, dim3(grid_for(bytes / 8, 256)), dim3(TPB), (u64*)dst, (const u64*)(hstage_dev_ + DESC_BYTES + stage_off_), bytes / 8); }
+      if (queued_()) { nb_ = 0; DPL(k_copy_words, dim3(grid_for(bytes / 8, 256)), dim3(TPB), (u64*)dst, (const u64*)(hstage_dev_ + DESC_BYTES + stage_off_), bytes / 8); }
       else { nb_ = 0; prof_begin("memcpy_h2d"); HIP_CHECK(hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, s_)); prof_end(); }
       stage_off_ += need;
       return;
@@ -666,7 +686,7 @@ class HipDev : public Dev {
     for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
       size_t m = std::min(STAGE_BYTES, bytes - off);
       memcpy(bulk_stage(), (const char*)src + off, m);
-      if (co_) {
+      if (queued_()) {
         DP_REQUIRE(m % 8 == 0, DP_ERR_ARG, "copies are whole words");
         nb_ = 0; DPL(k_copy_words, dim3(grid_for(m / 8, 256)), dim3(TPB), (u64*)((char*)dst + off), (const u64*)(hstage_dev_ + DESC_BYTES), m / 8);
       } else { nb_ = 0; prof_begin("memcpy_h2d"); HIP_CHECK(hipMemcpyAsync((char*)dst + off, bulk_stage(), m, hipMemcpyHostToDevice, s_)); prof_end(); }
@@ -678,7 +698,7 @@ class HipDev : public Dev {
     for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
       size_t m = std::min(STAGE_BYTES, bytes - off);
       if (g_host_stats) by_name_["  (k_copy_words as download)"]++;
-      if (co_) {
+      if (queued_()) {
         DP_REQUIRE(m % 8 == 0, DP_ERR_ARG, "copies are whole words");
         nb_ = 0; DPL(k_copy_words, dim3(grid_for(m / 8, 256)), dim3(TPB), (u64*)(hstage_dev_ + DESC_BYTES), (const u64*)((const char*)src + off), m / 8);
       } else { nb_ = 0; prof_begin("memcpy_d2h"); HIP_CHECK(hipMemcpyAsync(bulk_stage(), (const char*)src + off, m, hipMemcpyDeviceToHost, s_)); prof_end(); }
@@ -699,12 +719,12 @@ class HipDev : public Dev {
   void download(const DBuf& src, u64* dst) override { d2h(dst, src.p, src.bytes()); }
   void copy(const DBuf& d, const DBuf& s) override {
     nb_ = 2.0 * s.bytes();
-    if (co_) { if (s.bytes()) DPL(k_copy_words, dim3(grid_for(s.bytes() / 8)), dim3(TPB), (u64*)d.p, (const u64*)s.p, s.bytes() / 8); return; }
+    if (queued_()) { if (s.bytes()) DPL(k_copy_words, dim3(grid_for(s.bytes() / 8)), dim3(TPB), (u64*)d.p, (const u64*)s.p, s.bytes() / 8); return; }
     prof_begin("memcpy_d2d"); HIP_CHECK(hipMemcpyAsync(d.p, s.p, s.bytes(), hipMemcpyDeviceToDevice, s_)); prof_end();
   }
   void zero(const DBuf& d) override {
     nb_ = (double)d.bytes();
-    if (co_) { if (d.bytes()) DPL(k_zero_words, dim3(grid_for(d.bytes() / 8)), dim3(TPB), (u64*)d.p, d.bytes() / 8); return; }
+    if (queued_()) { if (d.bytes()) DPL(k_zero_words, dim3(grid_for(d.bytes() / 8)), dim3(TPB), (u64*)d.p, d.bytes() / 8); return; }
     prof_begin("memset"); HIP_CHECK(hipMemsetAsync(d.p, 0, d.bytes(), s_)); prof_end();
   }
   // ---- cohort membership (dp_model_prove_batch): while attached every launch of this context is one pack of a merged launch
@@ -715,6 +735,13 @@ class HipDev : public Dev {
   }
   void cohort_detach() { if (co_) { Cohort* c = co_; co_ = nullptr; c->leave(co_li_); } }
   bool in_cohort() const { return co_ != nullptr; }
+  // ---- slot of the resident executor (dp_model_prove_batch with DP_RX): while attached every launch is a step descriptor
+  void rx_attach(RxEngine* e, unsigned slot) {
+    DP_REQUIRE(!co_ && !rx_ && !prof_ && zerocopy_, DP_ERR_ARG, "resident-executor slots need the zero-copy publish path and no per-kernel profiling");
+    HIP_CHECK(hipStreamSynchronize(s_));
+    rx_ = e; rx_slot_ = slot;
+  }
+  void rx_detach() { rx_ = nullptr; }
   void sync() override { stream_wait(); }
 
   // ---- MLE
@@ -819,6 +846,8 @@ class HipDev : public Dev {
     }
   }
   static constexpr size_t SC_LDS_MAX = 128 * 1024;  // dynamic LDS the LDS-resident sumcheck kernel may use
+  // (a resident worker of class BIG has 64 KB for the kernel's frame and its tables: larger sumchecks take the global-memory kernel)
+  size_t sc_lds_max() const { return rx_ ? RX_LDS_BIG - 8192 : SC_LDS_MAX; }
   // Latency-critical one-workgroup kernels ask for more than half of a CU's 160 KB of LDS even when they need none: two
   // such workgroups can then never share a CU. The workgroup dispatcher otherwise packs the small persistent kernels of
   // all proofs in flight onto the same first CUs (4 kernels of 256 threads fit on one), where they time-share the SIMDs.
@@ -873,7 +902,7 @@ class HipDev : public Dev {
     for (int i = 0; i < MAX_TERMS; i++) { a.k[i] = 1; a.off[i] = 0; for (int j = 0; j < SC_MAXK; j++) a.t[i][j] = 0; }
     { int o = 0; for (int i = 0; i < nterms; i++) { a.k[i] = terms[i].k; for (int j = 0; j < SC_MAXK; j++) a.t[i][j] = j < terms[i].k ? terms[i].t[j] : 0; a.off[i] = o; o += terms[i].k + 1; } }
     const size_t lds = (size_t)nt * (n_in / 2) * 16;
-    const bool in_lds = lds <= SC_LDS_MAX;
+    const bool in_lds = lds <= sc_lds_max();
     size_t first = r ? n_after : n_after / 2;
     double tab_bytes = 0;
     for (int i = 0; i < nt; i++) {
@@ -1174,7 +1203,7 @@ class HipDev : public Dev {
     // A sumcheck that arrives here in the middle (r pending: the streaming rounds of a large one are handing over) enters the
     // persistent kernel only once its tables fit in LDS: the global-memory variant costs 35 us per round on 2^15..2^13-entry
     // tables against ~20 us for another streaming / one-launch round (DP_PERSIST_GLOBAL_MID=1 restores the early hand-over).
-    const bool lds_fits = (size_t)nt * (n_in / 2) * 16 <= SC_LDS_MAX;
+    const bool lds_fits = (size_t)nt * (n_in / 2) * 16 <= sc_lds_max();
     const bool persist_here = persist_ && n_after <= SC_PERSIST_MAX && n_after >= 4 && 2 * nraw <= RES_WORDS && (!r || lds_fits || persist_global_mid_ || throughput_mode_);
     const bool take_persistent = !sess_.active && persist_here;
     if (pend_eq_.p && !(take_persistent && !r)) flush_pending_eq();
@@ -1208,7 +1237,7 @@ class HipDev : public Dev {
       double tab_bytes = 0; for (int i = 0; i < nt; i++) tab_bytes += (double)n_in * (tabs[i].ext && !r ? 16.0 : tabs[i].ext ? 16.0 : 8.0);
       // algorithmic HBM bytes of the launch: every table is read once (the LDS variant never touches HBM again; the
       // global variant also writes and re-reads the halving ping-pong buffers: + 3 x 16 B x n/2 per table in total)
-      if (lds <= SC_LDS_MAX) { nb_ = tab_bytes; DPL_ONE_HI(k_sc_persist_lds, hi, dim3(1), threads, lds, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }
+      if (lds <= sc_lds_max()) { nb_ = tab_bytes; DPL_ONE_HI(k_sc_persist_lds, hi, dim3(1), threads, lds, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }
       else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_ONE_HI(k_sc_persist, hi, dim3(1), threads, 0, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }
       wait_flag(++sess_.seq, 2 * nraw);
       if (r) for (int i = 0; i < nt; i++) { tabs[i].p = sess_.a[i]; tabs[i].n = n_after; tabs[i].ext = true; }
@@ -1263,7 +1292,7 @@ class HipDev : public Dev {
         // it takes its ticket is an L2 write-back per workgroup — the fused rounds went from 162 / 40 us to 1122 / 230 us
         // (4096 write-backs per launch); a separate 14 us reduction launch per round is the cheaper way across XCDs.
         static const bool ticket_env = getenv("DP_FUSED_TICKET") && atoi(getenv("DP_FUSED_TICKET"));
-        const bool inkernel = ticket_env && zerocopy_ && !co_ && fused_ticket_ != nullptr;
+        const bool inkernel = ticket_env && zerocopy_ && !queued_() && fused_ticket_ != nullptr;
         unsigned* tick = inkernel ? fused_ticket_ : nullptr;
         const unsigned long long fseq = inkernel ? ++seq_ : 0;
         #define LAUNCH_FUSED2(KK, BB) do { if (skip1) DPL_B((k_sc_fused<KK, BB, true>), 256, KF_NONE, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial, tick, (Ext*)hres_dev_, hflag_dev_, fseq); \
@@ -1752,6 +1781,9 @@ void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs) {
 }
 void hip_dev_cohort_attach(Dev* d, Cohort* c) { static_cast<HipDev*>(d)->cohort_attach(c); }
 void hip_dev_cohort_detach(Dev* d) { static_cast<HipDev*>(d)->cohort_detach(); }
+void hip_dev_rx_attach(Dev* d, RxEngine* e, unsigned slot) { static_cast<HipDev*>(d)->rx_attach(e, slot); }
+void hip_dev_rx_detach(Dev* d) { static_cast<HipDev*>(d)->rx_detach(); }
+void hip_rx_session(int delta) { g_rx_sessions.fetch_add(delta); }
 void hip_dev_dump_sc_debug(Dev* d) { static_cast<HipDev*>(d)->dump_sc_debug(); }
 size_t hip_dev_arena_peak(Dev* d) { return static_cast<HipDev*>(d)->arena_peak(); }
 double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps) { return static_cast<HipDev*>(d)->probe_compress_rate(nodes, reps); }
