@@ -261,7 +261,11 @@ RcclApi* rccl() {  // (a pointer: the definition sits inside the extern "C" bloc
 #define HIPRT_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw DpError(DP_ERR_HIP, std::string("HIP: ") + hipGetErrorString(e_)); } while (0)
 }  // namespace
 // one rank's communicator: device send / receive buffers the all-gather runs on, pinned host mirrors, its own stream
-struct dp_dist : Exchange {
+struct dp_dist : Exchange, Dev::ShareExchange {
+  // Dev::ShareExchange: the shares never leave HBM — ncclAllGather on the proving stream itself (stream ordered behind the round's
+  // reduction, in front of the kernel that adds the shares); DP_SHARDED_HOST_EXCHANGE=1 keeps round 2's host path (all_gather below)
+  Dev::ShareExchange* device() override { static const bool host_only = getenv("DP_SHARDED_HOST_EXCHANGE") && atoi(getenv("DP_SHARDED_HOST_EXCHANGE")); return host_only ? nullptr : this; }
+  void all_gather_device(const u64* dsend, size_t nwords, u64* drecv, void* stream_) override;
   dp_ctx* ctx = nullptr; ncclComm_t comm = nullptr; int rank_ = 0, world_ = 1; hipStream_t stream = nullptr;
   u64 *dsend = nullptr, *drecv = nullptr, *hsend = nullptr, *hrecv = nullptr; size_t cap = 0;  // words per rank
   int world() const override { return world_; }
@@ -286,6 +290,33 @@ struct dp_dist : Exchange {
     memcpy(out, hrecv, nwords * 8 * world_);
   }
   ~dp_dist() override { release(); if (comm) rccl()->CommDestroy(comm); if (stream) hipStreamDestroy(stream); }
+};
+void dp_dist::all_gather_device(const u64* dsend, size_t nwords, u64* drecv, void* stream_) {
+  RCCL_CHECK(rccl()->AllGather(dsend, drecv, nwords, ncclUint64, comm, (hipStream_t)stream_));
+}
+// the device exchange of `world` contexts of ONE process (dp_sumcheck_prove_sharded_local): device-to-device copies between the
+// contexts' share buffers, rendezvous through the hub — the test double of ncclAllGather for a 1-GPU box. A rank's send buffer is
+// reused every round, so nobody leaves before everyone's copies have run.
+struct ThreadShareExchange : Dev::ShareExchange {
+  ThreadExchangeHub& h; int r; std::vector<const u64*>& ptrs;
+  ThreadShareExchange(ThreadExchangeHub& hub, int rank_, std::vector<const u64*>& p) : h(hub), r(rank_), ptrs(p) {}
+  int world() const override { return h.world; }
+  void barrier() {
+    std::unique_lock<std::mutex> lk(h.mu);
+    if (h.aborted) throw DpError(DP_ERR_HIP, "sharded sumcheck: another rank failed, the exchange is abandoned");
+    const unsigned long long my = h.gen;
+    if (++h.arrived == h.world) { h.arrived = 0; h.gen++; h.cv.notify_all(); }
+    else { h.cv.wait(lk, [&] { return h.gen != my || h.aborted; }); if (h.gen == my) throw DpError(DP_ERR_HIP, "sharded sumcheck: another rank failed, the exchange is abandoned"); }
+  }
+  void all_gather_device(const u64* dsend, size_t nwords, u64* drecv, void* stream_) override {
+    hipStream_t st = (hipStream_t)stream_;
+    HIPRT_CHECK(hipStreamSynchronize(st));  // this rank's shares are written
+    ptrs[r] = dsend;
+    barrier();                               // everyone's are
+    for (int g = 0; g < h.world; g++) HIPRT_CHECK(hipMemcpyAsync(drecv + (size_t)g * nwords, ptrs[g], nwords * 8, hipMemcpyDeviceToDevice, st));
+    HIPRT_CHECK(hipStreamSynchronize(st));
+    barrier();                               // everyone has copied: the send buffers may be overwritten
+  }
 };
 extern "C" {
 int32_t dp_dist_unique_id(uint8_t id[128]) {
@@ -343,6 +374,8 @@ int32_t dp_sumcheck_prove_sharded_local(dp_ctx* const* ctxs, int32_t world, uint
       for (const DBuf& b : probe.tabs) DP_REQUIRE(b.n == (size_t(1) << (num_vars - k)), DP_ERR_SHAPE, "sharded sumcheck: every local table has 2^(num_vars - log2 world) entries");
     }
     ThreadExchangeHub hub(world);
+    std::vector<const u64*> share_ptrs(world, nullptr);
+    static const bool host_only = getenv("DP_SHARDED_HOST_EXCHANGE") && atoi(getenv("DP_SHARDED_HOST_EXCHANGE"));
     std::vector<SumcheckOut> outs(world);
     std::vector<std::string> errs(world);
     std::vector<std::thread> th;
@@ -353,6 +386,8 @@ int32_t dp_sumcheck_prove_sharded_local(dp_ctx* const* ctxs, int32_t world, uint
         DevVP vp(num_vars - k);
         read_terms(vp, tables + (size_t)g * ntables, ntables, term_degree, term_tables, nterms, term_coeffs);
         ThreadExchange xch(hub, g);
+        ThreadShareExchange sx(hub, g, share_ptrs);
+        if (!host_only) xch.dev_x = &sx;  // the shares stay on the device, as over RCCL (k_shares_sum_publish: one host wait per round)
         outs[g] = sumcheck_prove_sharded(*ctxs[g]->dev, xch, num_vars, vp, transcripts[g]->t);
       } catch (const std::exception& e) { errs[g] = e.what(); if (errs[g].empty()) errs[g] = "error"; hub.abort(); }  // wakes the ranks waiting for this one
     });
@@ -859,7 +894,12 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     for (size_t ti = 1; ti < nth; ti++) th.emplace_back(run_thread, ti);
     run_thread(0);
     for (auto& t : th) t.join();
-    if (rxs.on) { rxs.on = false; hip_rx_session(-1); try { rx_engine_stop(m->rx); } catch (const std::exception& e) { if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } } }
+    if (rxs.on) {
+      rxs.on = false; hip_rx_session(-1);
+      try { rx_engine_stop(m->rx); } catch (const std::exception& e) { if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } }
+      // DP_RX_STATS=<file>: the per-body accounting of this session (the executor's kernel trace), one JSON line per batch
+      if (const char* sf = getenv("DP_RX_STATS")) { if (FILE* f = fopen(sf, "a")) { fprintf(f, "%s\n", rx_engine_stats(m->rx).c_str()); fclose(f); } }
+    }
     for (size_t c = 0; c < nco; c++) { try { hip_cohort_drain(m->cohorts[c]); } catch (const std::exception& e) { if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } } }
     if (nco && getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) {
       size_t f = 0, p = 0; for (size_t c = 0; c < nco; c++) { size_t a, b; hip_cohort_stats(m->cohorts[c], &a, &b); f += a; p += b; }

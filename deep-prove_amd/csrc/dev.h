@@ -129,6 +129,17 @@ class Dev {
     sc_round(tabs, ntabs, r, terms, nterms, out);
   }
   virtual void sc_finish(DBuf* tabs, int ntabs, Ext r, Ext* finals) = 0;
+  // A sharded sumcheck (csrc/sharded.h) whose shares stay on the device: while an exchange is set, sc_round leaves THIS rank's raw
+  // round sums in device memory, has them all-gathered there (ShareExchange: ncclAllGather over xGMI on the context's own stream),
+  // adds the ranks' shares mod p in a one-workgroup kernel and publishes the TOTAL to the host — `out` then holds the sums over
+  // all ranks and the round has cost one host wait. `false`: this device keeps the host exchange (the CPU test double).
+  struct ShareExchange {
+    virtual ~ShareExchange() {}
+    virtual int world() const = 0;
+    // every rank contributes `nwords` u64 words at dsend; drecv receives world * nwords words in rank order; ordered on `stream`
+    virtual void all_gather_device(const u64* dsend, size_t nwords, u64* drecv, void* stream) = 0;
+  };
+  virtual bool sc_set_share_exchange(ShareExchange* x) { (void)x; return false; }
   // All remaining rounds of a sumcheck WITH its Fiat-Shamir transcript on the device, for devices that can keep the sponge
   // to themselves: called at the top of a round with the tables as sc_round would get them (r = the previous challenge,
   // not yet folded in, or null in the first round), the coefficient of every term and the transcript's sponge. On `true`

@@ -450,8 +450,34 @@ class HipDev : public Dev {
     wait_flag(seq, 0);
   }
   // second stage of a block-partial reduction, published straight to hres_ (see k_reduce_publish); nout <= 1024
+  // ---- sharded sumcheck with the shares on the device (Dev::ShareExchange)
+  ShareExchange* share_x_ = nullptr; u64* dshare_ = nullptr; u64* dgather_ = nullptr; size_t dgather_words_ = 0;
+  bool sc_set_share_exchange(ShareExchange* x) override {
+    if (x && (queued_() || !zerocopy_)) return false;
+    if (x) {
+      if (!dshare_) HIP_CHECK(hipMalloc((void**)&dshare_, (RES_WORDS + 8) * 8));
+      const size_t need = RES_WORDS * (size_t)x->world();
+      if (dgather_words_ < need) { if (dgather_) { HIP_CHECK(hipStreamSynchronize(s_)); HIP_CHECK(hipFree(dgather_)); } HIP_CHECK(hipMalloc((void**)&dgather_, need * 8)); dgather_words_ = need; }
+    }
+    share_x_ = x;
+    return true;
+  }
+  // this rank's `nwords` raw words sit at dshare_: gather the ranks' words, add them mod p, bring the total to hres_ (one wait)
+  void share_exchange_(size_t nwords) {
+    DP_REQUIRE(nwords % 2 == 0 && nwords <= RES_WORDS && nwords / 2 <= 1024, DP_ERR_SHAPE, "sharded sumcheck: round message too large");
+    share_x_->all_gather_device(dshare_, nwords, dgather_, (void*)s_);
+    unsigned long long seq = ++seq_;
+    nb_ = 8.0 * (double)nwords * share_x_->world(); DPL(k_shares_sum_publish, dim3(1), dim3(256), (const u64*)dgather_, share_x_->world(), (int)(nwords / 2), (Ext*)hres_dev_, hflag_dev_, seq);
+    wait_flag(seq, nwords);
+  }
   void reduce_publish(const Ext* partial, size_t nblocks, size_t inner, int nout) {
     DP_REQUIRE(nout >= 1 && nout <= 1024 && (size_t)nout * 2 <= RES_WORDS, DP_ERR_SHAPE, "reduce_publish: too many outputs");
+    if (share_x_) {  // the reduction lands in device memory (the tag word too: nobody reads it), the exchange brings the ranks' total to hres_
+      int threads = nout >= 8 ? 1024 : nout >= 4 ? 256 : 64 * nout;
+      DPL(k_reduce_publish, dim3(1), dim3(threads), partial, nblocks, inner, nout, (Ext*)dshare_, (unsigned long long*)(dshare_ + RES_WORDS), 0ull);
+      share_exchange_((size_t)nout * 2);
+      return;
+    }
     if (!zerocopy_) {
       if (inner == 4 && nout % 4 == 0 && nout > 4) DPL(k_reduce_terms, dim3(nout), dim3(TPB), partial, nblocks, (Ext*)dres_);
       else if (inner == 2) DPL(k_reduce_pairs, dim3(nout), dim3(TPB), partial, nblocks, (Ext*)dres_);
@@ -558,6 +584,8 @@ class HipDev : public Dev {
     pcs_tabs_.reset();
     if (arena_) hipFree(arena_);
     if (dres_) hipFree(dres_);
+    if (dshare_) hipFree(dshare_);
+    if (dgather_) hipFree(dgather_);
     if (fused_ticket_) hipFree(fused_ticket_);
     if (sp_slot_) { sponge_disarm_(); sponge_slot_free(sp_slot_); sp_slot_ = nullptr; }
     if (hsp_) hipHostFree(hsp_);
@@ -1169,7 +1197,7 @@ class HipDev : public Dev {
       read_terms();
       return;
     }
-    if ((!r || multi_mid_) && multi_ && persist_ && n_after >= MULTI_MIN_N && n_in <= MULTI_MAX_N && nraw * 2 * MULTI_MAX_WG <= RES_WORDS) {
+    if (!share_x_ && (!r || multi_mid_) && multi_ && persist_ && n_after >= MULTI_MIN_N && n_in <= MULTI_MAX_N && nraw * 2 * MULTI_MAX_WG <= RES_WORDS) {
       // ---- multi-workgroup phase: G workgroups own contiguous slices, fold until the tables are MULTI_TARGET_N long. It may
       // begin in the middle of a sumcheck (r given: the streaming rounds of a large sumcheck hand over as soon as the tables
       // fit): every workgroup then first folds its slice with the pending challenge. Measured on the 2^24 sumcheck that costs
@@ -1204,7 +1232,7 @@ class HipDev : public Dev {
     // persistent kernel only once its tables fit in LDS: the global-memory variant costs 35 us per round on 2^15..2^13-entry
     // tables against ~20 us for another streaming / one-launch round (DP_PERSIST_GLOBAL_MID=1 restores the early hand-over).
     const bool lds_fits = (size_t)nt * (n_in / 2) * 16 <= sc_lds_max();
-    const bool persist_here = persist_ && n_after <= SC_PERSIST_MAX && n_after >= 4 && 2 * nraw <= RES_WORDS && (!r || lds_fits || persist_global_mid_ || throughput_mode_);
+    const bool persist_here = !share_x_ && persist_ && n_after <= SC_PERSIST_MAX && n_after >= 4 && 2 * nraw <= RES_WORDS && (!r || lds_fits || persist_global_mid_ || throughput_mode_);
     const bool take_persistent = !sess_.active && persist_here;
     if (pend_eq_.p && !(take_persistent && !r)) flush_pending_eq();
     if (persist_here) {
@@ -1261,6 +1289,7 @@ class HipDev : public Dev {
       unsigned long long seq = ++seq_;
       size_t work = (size_t)nterms * (n_after / 2) + (r ? (size_t)nt * n_after / 4 : 0);
       int threads = persist_threads(work);
+      if (share_x_) { nb_ = bytes; DPL_ONE_HI(k_sc_small, hi, dim3(1), threads, 0, a, (Ext*)dshare_, (unsigned long long*)(dshare_ + RES_WORDS), seq); share_exchange_(2 * nraw); read_terms(); return; }
       nb_ = bytes; DPL_ONE_HI(k_sc_small, hi, dim3(1), threads, 0, a, (Ext*)hres_dev_, hflag_dev_, seq);
       wait_flag(seq, 2 * nraw);
       read_terms();
@@ -1292,7 +1321,7 @@ class HipDev : public Dev {
         // it takes its ticket is an L2 write-back per workgroup — the fused rounds went from 162 / 40 us to 1122 / 230 us
         // (4096 write-backs per launch); a separate 14 us reduction launch per round is the cheaper way across XCDs.
         static const bool ticket_env = getenv("DP_FUSED_TICKET") && atoi(getenv("DP_FUSED_TICKET"));
-        const bool inkernel = ticket_env && zerocopy_ && !queued_() && fused_ticket_ != nullptr;
+        const bool inkernel = ticket_env && zerocopy_ && !queued_() && !share_x_ && fused_ticket_ != nullptr;
         unsigned* tick = inkernel ? fused_ticket_ : nullptr;
         const unsigned long long fseq = inkernel ? ++seq_ : 0;
         #define LAUNCH_FUSED2(KK, BB) do { if (skip1) DPL_B((k_sc_fused<KK, BB, true>), 256, KF_NONE, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], outp[0], outp[1], outp[2], nquads, *r, partial, tick, (Ext*)hres_dev_, hflag_dev_, fseq); \
@@ -1588,7 +1617,9 @@ class HipDev : public Dev {
       const DBuf& e0 = evals[i];
       unsigned nv = dp_ceil_log2(e0.n);
       bool small = (size_t(1) << nv) == e0.n && nv >= 1 && (nv <= 7 || (tw_ && nv <= L_ && nv <= (e0.ext ? 10u : 11u)));
-      bool medium = !small && !e0.ext && (size_t(1) << nv) == e0.n && tw_ && nv <= L_ && nv >= 12 && nv <= 14;
+      // (the medium path's kernels keep a whole polynomial in up to 128 KB of LDS: not for a resident worker — behind the executor these
+      // sizes take the LDS-tiled passes of the large path, whose extra launches cost nothing there)
+      bool medium = !rx_ && !small && !e0.ext && (size_t(1) << nv) == e0.n && tw_ && nv <= L_ && nv >= 12 && nv <= 14;
       if (medium) { commit_medium_group(evals, i, out, done, persistent); continue; }
       if (!small) { out[i] = commit(e0, persistent); done[i] = true; continue; }
       std::vector<size_t> grp;

@@ -39,6 +39,7 @@ constexpr unsigned RX_DOORBELLS = 1u << 16;   // doorbell ring entries per XCD (
 constexpr unsigned RX_WORKER_THREADS = 256;
 constexpr size_t RX_LDS_BIG = 64 * 1024, RX_LDS_STREAM = 20 * 1024;  // dynamic LDS arena of a worker
 constexpr int RX_NCLASS = 2;
+constexpr int RX_STAT_BODIES = 128;           // per-body counters of the workers (>= number of bodies in rx_bodies.h)
 
 // One step of one proof. 8 words in host-mapped memory; word 0 is a tag over the other seven (torn reads are retried):
 // tag = rx_mix(step + 1) + sum_i (i + 1) * w[i]
@@ -76,6 +77,9 @@ struct alignas(128) RxXcd {
   RxRing ring[RX_NCLASS];
   unsigned long long db_head; unsigned long long db_lock; unsigned long long db_last_poll; unsigned long long pad[13];
   unsigned long long alive[RX_NCLASS], pad2[14];  // workers of each class that have started on this XCD
+  // what the workers of this XCD did (s_memrealtime ticks of 10 ns; read by the host after the session: rx_engine_stats)
+  unsigned long long body_ticks[RX_STAT_BODIES], body_cells[RX_STAT_BODIES], body_tiles[RX_STAT_BODIES];
+  unsigned long long busy_ticks[RX_NCLASS], idle_iters[RX_NCLASS], issue_ticks, doorbells;
 };
 
 // what the worker kernels get (by value)
@@ -105,5 +109,9 @@ bool rx_slot_idle(RxEngine* e, unsigned slot);
 // the host has observed a publication of the slot's LAST pushed step: everything before it has run, its ring space is free
 void rx_slot_confirm(RxEngine* e, unsigned slot);
 std::string rx_engine_dump(RxEngine* e, unsigned slot);  // state of a slot and of its XCD's queues, for error messages
+// per-body accounting of the last session (after rx_engine_stop): JSON {"session_ms", "workers": [stream, big], "busy_frac": [..],
+// "bodies": [{"body", "class", "cells", "tiles", "total_ms", "avg_us_per_tile"}...]} — the executor's stand-in for a kernel trace
+// (rocprofv3 sees two launches per session)
+std::string rx_engine_stats(RxEngine* e);
 
 }  // namespace dp

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <chrono>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -192,6 +193,7 @@ template <int CLS> __global__ void __launch_bounds__(RX_WORKER_THREADS) __attrib
     if (st == 2) break;
     if (st == 0) {  // nothing published for this class on this XCD: back off (bounded: a doorbell must not wait long)
       idle++;
+      if (threadIdx.x == 0 && (idle & 63u) == 0) __hip_atomic_fetch_add(&x->idle_iters[CLS], 64ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (idle < 8) __builtin_amdgcn_s_sleep(8); else if (idle < 64) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(96);
       __syncthreads();
       continue;
@@ -204,6 +206,7 @@ template <int CLS> __global__ void __launch_bounds__(RX_WORKER_THREADS) __attrib
     const int body = (int)(s_bf & 0xFFFFFFFFull);
     const void* pack = (const void*)s_pack;
     __syncthreads();
+    const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
     for (unsigned t = first; t < first + cnt; t++) {
       if (threadIdx.x == 0) { rx_s_block.x = t % gx; rx_s_block.y = t / gx; rx_s_block.z = 0; rx_s_grid.x = gx; rx_s_grid.y = gy; rx_s_grid.z = 1; }
       __syncthreads();
@@ -223,6 +226,12 @@ template <int CLS> __global__ void __launch_bounds__(RX_WORKER_THREADS) __attrib
         rx_try_issue(a, slot, (unsigned)((c >> 28) & 0xFFFu));
       }
       if ((++ran & 255u) == 0) st_sys(a.heartbeat + xcd * RX_NCLASS + CLS, (unsigned long long)ran);
+      const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_in;
+      const int b = body & (RX_STAT_BODIES - 1);
+      __hip_atomic_fetch_add(&x->body_ticks[b], dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&x->body_cells[b], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&x->body_tiles[b], (unsigned long long)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&x->busy_ticks[CLS], dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
   }
@@ -277,6 +286,7 @@ struct RxEngine {
   std::atomic<unsigned long long> db_tail[RX_XCDS];
   unsigned long long session = 0;
   bool running = false; unsigned nslots = 0;
+  std::chrono::steady_clock::time_point t_start{}; double last_session_ms = 0;
   int nworkers[RX_NCLASS] = {0, 0};
   std::mutex mu;
 };
@@ -376,7 +386,7 @@ void rx_engine_start(RxEngine* e, unsigned nslots) {
     else hipLaunchKernelGGL((rxk::k_rx_worker<RX_STREAM>), dim3(e->nworkers[c]), dim3(RX_WORKER_THREADS), RX_LDS_STREAM, e->stream[c], a);
     RX_HIP(hipGetLastError());
   }
-  e->nslots = nslots; e->running = true;
+  e->nslots = nslots; e->running = true; e->t_start = std::chrono::steady_clock::now();
   // every XCD must have workers of both classes resident before a proof is pinned to it
   auto t0 = std::chrono::steady_clock::now();
   for (;;) {
@@ -398,7 +408,7 @@ void rx_engine_stop(RxEngine* e) {
   __atomic_store_n(e->control, 1ull, __ATOMIC_SEQ_CST);
   hipError_t r0 = hipStreamSynchronize(e->stream[0]), r1 = hipStreamSynchronize(e->stream[1]);
   __atomic_store_n(e->control, 0ull, __ATOMIC_SEQ_CST);
-  e->running = false;
+  e->running = false; e->last_session_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - e->t_start).count();
   if (r0 != hipSuccess || r1 != hipSuccess) throw DpError(DP_ERR_HIP, std::string("resident executor: the workers ended with ") + hipGetErrorString(r0 != hipSuccess ? r0 : r1));
 }
 
@@ -453,6 +463,35 @@ void rx_submit(RxEngine* e, unsigned slot, int body, int cls, int flags, unsigne
   const unsigned xcd = e->xcd_of(slot);
   const unsigned long long t = e->db_tail[xcd].fetch_add(1);
   __atomic_store_n(e->doorbells + (size_t)xcd * RX_DOORBELLS + (t & (RX_DOORBELLS - 1)), ((t + 1) << 32) | slot, __ATOMIC_RELEASE);
+}
+
+std::string rx_engine_stats(RxEngine* e) {
+  if (!e || e->running) return "{}";
+  hipSetDevice(e->device);
+  std::vector<RxXcd> x(RX_XCDS);
+  // only the counters at the end of each RxXcd are needed, but the struct is 0.5 MB: copy the tails
+  const size_t off = offsetof(RxXcd, alive);
+  std::vector<char> tail((sizeof(RxXcd) - off) * RX_XCDS);
+  for (int i = 0; i < RX_XCDS; i++) if (hipMemcpy(tail.data() + (size_t)i * (sizeof(RxXcd) - off), (const char*)(e->d_xcd + i) + off, sizeof(RxXcd) - off, hipMemcpyDeviceToHost) != hipSuccess) return "{}";
+  auto at = [&](int i) { return (const RxXcd*)(tail.data() + (size_t)i * (sizeof(RxXcd) - off) - off); };  // (only members from `alive` on are valid)
+  const BodyInfo* bt = body_table();
+  double busy[RX_NCLASS] = {0, 0};
+  for (int i = 0; i < RX_XCDS; i++) for (int c = 0; c < RX_NCLASS; c++) busy[c] += (double)at(i)->busy_ticks[c];
+  std::string out = "{";
+  char buf[512];
+  snprintf(buf, sizeof buf, "\"session_ms\": %.3f, \"workers\": [%d, %d], \"busy_frac\": [%.4f, %.4f], \"bodies\": [", e->last_session_ms, e->nworkers[RX_STREAM], e->nworkers[RX_BIG],
+           e->last_session_ms > 0 ? busy[RX_STREAM] * 1e-5 / (e->last_session_ms * e->nworkers[RX_STREAM]) : 0.0, e->last_session_ms > 0 ? busy[RX_BIG] * 1e-5 / (e->last_session_ms * e->nworkers[RX_BIG]) : 0.0);
+  out += buf;
+  bool firstb = true;
+  for (int b = 0; b < RX_NBODIES_HOST && b < RX_STAT_BODIES; b++) {
+    unsigned long long ticks = 0, cells = 0, tiles = 0;
+    for (int i = 0; i < RX_XCDS; i++) { ticks += at(i)->body_ticks[b]; cells += at(i)->body_cells[b]; tiles += at(i)->body_tiles[b]; }
+    if (!cells) continue;
+    snprintf(buf, sizeof buf, "%s{\"body\": \"%s\", \"class\": \"%s\", \"cells\": %llu, \"tiles\": %llu, \"total_ms\": %.3f, \"avg_us_per_tile\": %.3f}", firstb ? "" : ", ", bt[b].name,
+             bt[b].cls == RX_BIG ? "big" : "stream", cells, tiles, ticks * 1e-5, tiles ? ticks * 1e-2 / (double)tiles : 0.0);
+    out += buf; firstb = false;
+  }
+  return out + "]}";
 }
 
 std::string rx_engine_dump(RxEngine* e, unsigned slot) {

@@ -20,6 +20,8 @@ struct Exchange {
   virtual int rank() const = 0;
   // every rank contributes `nwords` u64 words; `out` receives world * nwords words in rank order
   virtual void all_gather(const u64* send, size_t nwords, u64* out) = 0;
+  // the same exchange on device buffers (Dev::ShareExchange), for devices that keep the round's shares in HBM; null: host exchange only
+  virtual Dev::ShareExchange* device() { return nullptr; }
 };
 struct SoloExchange : Exchange {  // world of one
   int world() const override { return 1; }
@@ -35,6 +37,8 @@ struct ThreadExchangeHub {
 };
 struct ThreadExchange : Exchange {
   ThreadExchangeHub& h; int r;
+  Dev::ShareExchange* dev_x = nullptr;  // (set by the caller that has a device-side implementation: capi.cpp)
+  Dev::ShareExchange* device() override { return dev_x; }
   ThreadExchange(ThreadExchangeHub& hub, int rank_) : h(hub), r(rank_) {}
   int world() const override { return h.world; }
   int rank() const override { return r; }
@@ -98,9 +102,14 @@ inline SumcheckOut sumcheck_prove_sharded(Dev& dev, Exchange& xch, unsigned nv, 
     }
   };
   Ext ch = ex_zero();
+  // shares on the device (ncclAllGather on HBM buffers, the mod-p sum in a kernel, ONE host wait per round) when both the exchange
+  // and the device can; else the shares travel through the host (the CPU double, hosts that bring their own exchange)
+  Dev::ShareExchange* sx = xch.device();
+  bool dev_shares = sx && dev.sc_set_share_exchange(sx);
+  struct Unset { Dev& d; bool& on; ~Unset() { if (on) d.sc_set_share_exchange(nullptr); } } unset{dev, dev_shares};
   auto one_round = [&](bool first, bool local) {
     dev.sc_round(tabs.data(), (int)tabs.size(), first ? nullptr : &ch, vp.terms.data(), (int)vp.terms.size(), raw.data());
-    if (local) gather_sum(); else total = raw;
+    if (local && !dev_shares) gather_sum(); else total = raw;  // (device shares: sc_round already returned the sum over the ranks)
     std::vector<Ext> msg = sharded_message(vp, total);
     for (const Ext& e : msg) t.append_ext(e);
     out.proof.proofs.push_back(msg);
@@ -108,6 +117,7 @@ inline SumcheckOut sumcheck_prove_sharded(Dev& dev, Exchange& xch, unsigned nv, 
     out.proof.point.push_back(ch);
   };
   for (unsigned round = 0; round < nv_local; round++) one_round(round == 0, true);
+  if (dev_shares) { dev.sc_set_share_exchange(nullptr); dev_shares = false; }  // stage 2 runs on every rank alike: nothing to exchange
   std::vector<Ext> fin(nt);
   dev.sc_finish(tabs.data(), (int)tabs.size(), ch, fin.data());
   out.finals.resize(nt);
