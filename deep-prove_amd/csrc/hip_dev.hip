@@ -721,15 +721,49 @@ class HipDev : public Dev {
       stream_wait();
     }
   }
+  static unsigned long long dl_mix_host(unsigned long long seq, unsigned long long chunk) { return (seq * 0x9E3779B97F4A7C15ull + chunk) * 0xD6E8FEB86659FD93ull + 0x2545F4914F6CDD1Dull; }
   void d2h(void* dst, const void* src, size_t bytes) {
     // (pending upload slots are read by copy kernels that precede this download's copy in the stream: no drain needed)
+    if (queued_()) {
+      // cohort member / executor slot: k_download — the copy and its per-chunk tags in one step, every chunk verified here (see the
+      // kernel: a separate "done" publication does not order the copy's PCIe writes before it outside a kernel boundary)
+      DP_REQUIRE(bytes % 8 == 0, DP_ERR_ARG, "copies are whole words");
+      const size_t cap_words = ((STAGE_BYTES - 4096) / (8 * (DL_CHUNK + 1))) * DL_CHUNK;  // payload + one tag word per chunk fit the staging area
+      for (size_t off = 0; off < bytes; off += cap_words * 8) {
+        const size_t nwords = std::min(cap_words, (bytes - off) / 8), nch = (nwords + DL_CHUNK - 1) / DL_CHUNK;
+        const size_t tag_off = (nwords * 8 + 255) & ~size_t(255);
+        if (g_host_stats) by_name_["  (k_download)"]++;
+        const unsigned long long seq = ++seq_;
+        nb_ = 0; DPL(k_download, dim3((unsigned)std::min<size_t>(nch, 256)), dim3(TPB), (const u64*)((const char*)src + off), (u64*)(hstage_dev_ + DESC_BYTES), nwords, (u64*)(hstage_dev_ + DESC_BYTES + tag_off), seq);
+        auto t0 = wait_enter_();
+        nwait_++;
+        volatile u64* pay = (volatile u64*)bulk_stage();
+        volatile u64* tags = (volatile u64*)(bulk_stage() + tag_off);
+        u64* out = (u64*)((char*)dst + off);
+        unsigned spins = 0;
+        for (size_t ch = 0; ch < nch; ch++) {
+          const size_t lo = ch * DL_CHUNK, hi = std::min(lo + DL_CHUNK, nwords);
+          for (;;) {
+            const unsigned long long tag = tags[ch];
+            std::atomic_thread_fence(std::memory_order_acquire);
+            unsigned long long cs = 0;
+            for (size_t i = lo; i < hi; i++) { const u64 v = pay[i]; out[i] = v; cs += (unsigned long long)(i - lo + 1) * v; }
+            if (dl_mix_host(seq, ch) + cs == tag) break;
+            const bool fib = fiber_active();
+            if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
+            if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
+              throw DpError(DP_ERR_HIP, std::string("timeout waiting for a download") + (rx_ ? "\n" + rx_engine_dump(rx_, rx_slot_) : std::string()));
+          }
+        }
+        // every chunk has landed: the copy — and everything queued before it — has run
+        desc_off_ = 0; stage_off_ = 0; if (co_ && co_li_) co_->note_executed(co_li_ - 1);
+        wait_exit_(t0);
+      }
+      return;
+    }
     for (size_t off = 0; off < bytes; off += STAGE_BYTES) {
       size_t m = std::min(STAGE_BYTES, bytes - off);
-      if (g_host_stats) by_name_["  (k_copy_words as download)"]++;
-      if (queued_()) {
-        DP_REQUIRE(m % 8 == 0, DP_ERR_ARG, "copies are whole words");
-        nb_ = 0; DPL(k_copy_words, dim3(grid_for(m / 8, 256)), dim3(TPB), (u64*)(hstage_dev_ + DESC_BYTES), (const u64*)((const char*)src + off), m / 8);
-      } else { nb_ = 0; prof_begin("memcpy_d2h"); HIP_CHECK(hipMemcpyAsync(bulk_stage(), (const char*)src + off, m, hipMemcpyDeviceToHost, s_)); prof_end(); }
+      nb_ = 0; prof_begin("memcpy_d2h"); HIP_CHECK(hipMemcpyAsync(bulk_stage(), (const char*)src + off, m, hipMemcpyDeviceToHost, s_)); prof_end();
       stream_wait();
       memcpy((char*)dst + off, bulk_stage(), m);
     }

@@ -37,8 +37,9 @@ constexpr size_t RX_PACK_RING = size_t(1) << 20;  // bytes of argument packs per
 constexpr unsigned RX_CELLS = 1u << 15;       // cells per (XCD, class) ring (power of two)
 constexpr unsigned RX_DOORBELLS = 1u << 16;   // doorbell ring entries per XCD (power of two)
 constexpr unsigned RX_WORKER_THREADS = 256;
-constexpr size_t RX_LDS_BIG = 64 * 1024, RX_LDS_STREAM = 20 * 1024;  // dynamic LDS arena of a worker
+constexpr size_t RX_LDS_BIG = 64 * 1024, RX_LDS_STREAM = 17 * 1024;  // dynamic LDS arena of a worker (1 BIG + 4 STREAM workers and their statics fit a CU's 160 KB)
 constexpr int RX_NCLASS = 2;
+constexpr unsigned RX_PACK_WORDS_STREAM = 256, RX_PACK_WORDS_BIG = 512;  // largest argument pack a worker stages in LDS (TermArgs 1.6 KB / ScPersistArgs ~3 KB)
 constexpr int RX_STAT_BODIES = 128;           // per-body counters of the workers (>= number of bodies in rx_bodies.h)
 
 // One step of one proof. 8 words in host-mapped memory; word 0 is a tag over the other seven (torn reads are retried):
@@ -49,7 +50,8 @@ struct alignas(64) RxDesc {
   unsigned long long grid;         // gx | gy << 32
   unsigned long long pack;         // device view of the argument pack
   unsigned long long cells;        // tiles per cell | class << 32
-  unsigned long long w5, w6, w7;   // (name of the launch, host side only: diagnostics)
+  unsigned long long pack_words;   // 8-byte words of the pack (the worker stages them in LDS: one PCIe burst per cell)
+  unsigned long long w6, w7;       // step index (diagnostics), checksum
 };
 static_assert(sizeof(RxDesc) == 64, "one descriptor per 64-byte line");
 inline unsigned long long rx_mix(unsigned long long step) { return step * 0x9E3779B97F4A7C15ull + 0x51A7C0DEB16B00B5ull; }
@@ -63,8 +65,8 @@ struct alignas(128) RxSlot {
   const RxDesc* ring;              // device view of the slot's descriptor ring (host-mapped)
   unsigned long long* host_done;   // device view of the host-visible copy of `done`
   // the step in flight (copied from its descriptor by whoever issued it)
-  unsigned long long cur_body_flags, cur_grid, cur_pack;
-  unsigned long long pad[8];
+  unsigned long long cur_body_flags, cur_grid, cur_pack, cur_pack_words;
+  unsigned long long pad[7];
 };
 static_assert(sizeof(RxSlot) == 128, "RxSlot layout");
 

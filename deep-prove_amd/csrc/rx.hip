@@ -109,7 +109,7 @@ __device__ __forceinline__ void rx_try_issue(const RxArgs& a, RxSlot* slot, unsi
     if (!__hip_atomic_compare_exchange_strong(&slot->issued, &expect, s + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;  // someone else took it
     const unsigned gx = (unsigned)(w[2] & 0xFFFFFFFFull), gy = (unsigned)(w[2] >> 32);
     const unsigned ntiles = gx * gy, per = (unsigned)(w[4] & 0xFFFFFFFFull), cls = (unsigned)(w[4] >> 32) & 1u;
-    st_dev(&slot->cur_body_flags, w[1]); st_dev(&slot->cur_grid, w[2]); st_dev(&slot->cur_pack, w[3]);
+    st_dev(&slot->cur_body_flags, w[1]); st_dev(&slot->cur_grid, w[2]); st_dev(&slot->cur_pack, w[3]); st_dev(&slot->cur_pack_words, w[5]);
     st_dev32(&slot->tiles_left, ntiles);
     rx_drain();
     RxRing* r = &a.xcd[slot->xcd].ring[cls];
@@ -164,7 +164,8 @@ __global__ void k_rx_probe(unsigned long long* seen) {
 // per SIMD): one BIG and four STREAM waves share a SIMD's 512 registers. Without the bound the compiler takes 300 registers
 // for the union of the bodies and one worker fills a SIMD.
 template <int CLS> __global__ void __launch_bounds__(RX_WORKER_THREADS) __attribute__((amdgpu_waves_per_eu(CLS == RX_BIG ? 4 : 5, CLS == RX_BIG ? 4 : 5))) k_rx_worker(RxArgs a) {
-  __shared__ unsigned long long s_cell, s_bf, s_grid, s_pack;
+  __shared__ unsigned long long s_cell, s_bf, s_grid, s_pack, s_pack_words;
+  __shared__ __align__(16) unsigned long long s_args[CLS == RX_BIG ? RX_PACK_WORDS_BIG : RX_PACK_WORDS_STREAM];  // the step's argument pack, staged once per cell (the bodies read their arguments many times)
   __shared__ int s_state;  // 0: nothing to do, 1: run s_cell, 2: leave
   const unsigned xcd = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 7u;  // HW_REG_XCC_ID
   RxXcd* x = a.xcd + xcd;
@@ -184,7 +185,7 @@ template <int CLS> __global__ void __launch_bounds__(RX_WORKER_THREADS) __attrib
       }
       if (st == 1) {
         RxSlot* slot = a.slots + ((c >> 28) & 0xFFFu);
-        s_cell = c; s_bf = ld_dev(&slot->cur_body_flags); s_grid = ld_dev(&slot->cur_grid); s_pack = ld_dev(&slot->cur_pack);
+        s_cell = c; s_bf = ld_dev(&slot->cur_body_flags); s_grid = ld_dev(&slot->cur_grid); s_pack = ld_dev(&slot->cur_pack); s_pack_words = ld_dev(&slot->cur_pack_words);
       }
       s_state = st;
     }
@@ -204,7 +205,9 @@ template <int CLS> __global__ void __launch_bounds__(RX_WORKER_THREADS) __attrib
     const unsigned first = (unsigned)((c >> 8) & 0xFFFFFu), cnt = (unsigned)(c & 0xFFu);
     const unsigned gx = (unsigned)(s_grid & 0xFFFFFFFFull), gy = (unsigned)(s_grid >> 32);
     const int body = (int)(s_bf & 0xFFFFFFFFull);
-    const void* pack = (const void*)s_pack;
+    { const unsigned long long* src = (const unsigned long long*)s_pack; const unsigned nw = (unsigned)s_pack_words;
+      for (unsigned i = threadIdx.x; i < nw; i += RX_WORKER_THREADS) s_args[i] = ld_sys(src + i); }
+    const void* pack = (const void*)s_args;
     __syncthreads();
     const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
     for (unsigned t = first; t < first + cnt; t++) {
@@ -279,6 +282,7 @@ struct RxEngine {
     unsigned long long pack_head = 0, pack_tail = 0;       // virtual byte offsets into the pack ring
     unsigned long long pack_end[RX_DESC_RING];             // pack_head after step s (indexed s % RX_DESC_RING): what step s's completion frees
     unsigned long long freed_upto = 0;                     // steps whose pack space has been returned
+    const char* names[RX_DESC_RING];                       // launch names of the ring's steps (diagnostics)
   };
   std::vector<SlotHost> slots;
   std::vector<unsigned> xcds;  // the XCC ids this device answers with (k_rx_probe)
@@ -426,7 +430,7 @@ void rx_submit(RxEngine* e, unsigned slot, int body, int cls, int flags, unsigne
   DP_REQUIRE(gx >= 1 && gy >= 1 && ntiles < (1u << 20), DP_ERR_SHAPE, "resident executor: grid out of range");
   RxEngine::SlotHost& s = e->slots[slot];
   const size_t need = (pack_bytes + 63) & ~size_t(63);
-  DP_REQUIRE(need <= RX_PACK_RING / 4, DP_ERR_SHAPE, "resident executor: argument pack too large");
+  DP_REQUIRE(need <= RX_PACK_RING / 4 && (pack_bytes + 7) / 8 <= (cls == RX_BIG ? RX_PACK_WORDS_BIG : RX_PACK_WORDS_STREAM), DP_ERR_SHAPE, std::string("resident executor: argument pack of ") + name + " too large");
   // ring space: descriptors and packs are recycled as the device reports steps done
   auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
@@ -453,7 +457,8 @@ void rx_submit(RxEngine* e, unsigned slot, int body, int cls, int flags, unsigne
   w[2] = (unsigned long long)gx | ((unsigned long long)gy << 32);
   w[3] = pk_dev;
   w[4] = (unsigned long long)per | ((unsigned long long)(unsigned)cls << 32);
-  w[5] = (unsigned long long)(uintptr_t)name; w[6] = s.pushed;
+  w[5] = (pack_bytes + 7) / 8; w[6] = s.pushed;
+  s.names[s.pushed & (RX_DESC_RING - 1)] = name;
   w[7] = w[0]; for (int i = 1; i < 7; i++) w[7] += (unsigned long long)(i + 1) * w[i];
   for (int i = 1; i < 8; i++) d[i] = w[i];
   std::atomic_thread_fence(std::memory_order_release);
@@ -499,7 +504,7 @@ std::string rx_engine_dump(RxEngine* e, unsigned slot) {
   const RxEngine::SlotHost& s = e->slots[slot];
   const unsigned long long done = slot_done(e, slot);
   const char* nm = "?";
-  if (done < s.pushed) { const unsigned long long* d = (const unsigned long long*)(s.mem + (done & (RX_DESC_RING - 1)) * sizeof(RxDesc)); nm = (const char*)(uintptr_t)d[5]; }
+  if (done < s.pushed) nm = s.names[done & (RX_DESC_RING - 1)];
   std::string hb;
   for (int x = 0; x < RX_XCDS; x++) { char t[64]; snprintf(t, sizeof t, " xcd%d:%llu/%llu", x, e->heartbeat[x * RX_NCLASS + RX_STREAM], e->heartbeat[x * RX_NCLASS + RX_BIG]); hb += t; }
   snprintf(buf, sizeof buf, "[resident executor] slot %u (XCD %u): %llu steps pushed, %llu done, waiting on step %llu (%s); doorbells rung on its XCD: %llu; cells run (stream/big, x256):%s",
