@@ -819,6 +819,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     // persistent kernels execute; nothing goes through the command processor while the batch runs
     const char* rxe = getenv("DP_RX");
     const bool use_rx = rxe && atoi(rxe) && nw > 1 && nw <= RX_MAX_SLOTS;
+    const double rx_stagger_ms = getenv("DP_RX_STAGGER_MS") ? atof(getenv("DP_RX_STAGGER_MS")) : 400.0;
     const char* ce = getenv("DP_COHORT");
     // Default: as many cohorts as hardware queues serve without time slicing (22 of the 24), each as small as that allows — a merged
     // launch ends with its slowest member, so small cohorts stall less (batch of 8: 121 ms with cohorts of 1, 165 ms with one cohort
@@ -847,6 +848,13 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
       Dev& dev = dev_of(wi);
       try {
         dev.bind_thread();
+        // Resident executor: the proofs of a batch must not march in step — all proofs of an XCD would reach their wide steps together
+        // (a burst of 32 x 256 tiles in one FIFO) and sit in their one-workgroup tails together (every STREAM worker idle). The start
+        // of slot wi is delayed by wi / nw of DP_RX_STAGGER_MS (default 400: about half a proof in flight).
+        if (use_rx && rx_stagger_ms > 0 && wi > 0) {
+          const auto until = t0 + std::chrono::microseconds((long long)(1000.0 * rx_stagger_ms * (double)wi / (double)nw));
+          while (std::chrono::steady_clock::now() < until && next.load() < nproofs) { if (fiber_active()) fiber_yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100)); }
+        }
         for (;;) {
           size_t i = next.fetch_add(1);
           if (i >= nproofs) break;
@@ -899,6 +907,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
       try { rx_engine_stop(m->rx); } catch (const std::exception& e) { if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } }
       // DP_RX_STATS=<file>: the per-body accounting of this session (the executor's kernel trace), one JSON line per batch
       if (const char* sf = getenv("DP_RX_STATS")) { if (FILE* f = fopen(sf, "a")) { fprintf(f, "%s\n", rx_engine_stats(m->rx).c_str()); fclose(f); } }
+      if (getenv("DP_RX_TRACE") && getenv("DP_RX_TRACE_FILE")) { if (FILE* f = fopen(getenv("DP_RX_TRACE_FILE"), "w")) { fputs(rx_engine_trace(m->rx).c_str(), f); fclose(f); } }
     }
     for (size_t c = 0; c < nco; c++) { try { hip_cohort_drain(m->cohorts[c]); } catch (const std::exception& e) { if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } } }
     if (nco && getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) {

@@ -55,7 +55,8 @@ static inline int grid_for(size_t n, int cap = 2048) {
   size_t b = (n + TPB - 1) / TPB;
   if (b < 1) b = 1;
   // behind the resident executor a proof's tiles run on the workers of ONE XCD (32 CUs): 256 tiles keep them busy, more only costs queue traffic
-  if (g_rx_sessions.load(std::memory_order_relaxed) > 0) cap = std::min(cap, 256);
+  static const int rx_cap = [] { const char* e = getenv("DP_RX_GRID_CAP"); return e ? std::max(8, atoi(e)) : 32; }();  // (measured: 128 -> 166, 64 -> 197, 32 -> 247 proofs/s, profiles/r03_rx_*)
+  if (g_rx_sessions.load(std::memory_order_relaxed) > 0) cap = std::min(cap, rx_cap);
   return (int)std::min<size_t>(std::min<size_t>(b, cap), (size_t)g_max_grid);
 }
 
@@ -471,7 +472,7 @@ class HipDev : public Dev {
     wait_flag(seq, nwords);
   }
   void reduce_publish(const Ext* partial, size_t nblocks, size_t inner, int nout) {
-    DP_REQUIRE(nout >= 1 && nout <= 1024 && (size_t)nout * 2 <= RES_WORDS, DP_ERR_SHAPE, "reduce_publish: too many outputs");
+    DP_REQUIRE(nout >= 1 && nout <= (rx_ ? 512 : 1024) && (size_t)nout * 2 <= RES_WORDS, DP_ERR_SHAPE, "reduce_publish: too many outputs");
     if (share_x_) {  // the reduction lands in device memory (the tag word too: nobody reads it), the exchange brings the ranks' total to hres_
       int threads = nout >= 8 ? 1024 : nout >= 4 ? 256 : 64 * nout;
       DPL(k_reduce_publish, dim3(1), dim3(threads), partial, nblocks, inner, nout, (Ext*)dshare_, (unsigned long long*)(dshare_ + RES_WORDS), 0ull);
@@ -1738,7 +1739,9 @@ class HipDev : public Dev {
         cd[i].f = hd[i].f; cd[i].eq = hd[i].eq; cd[i].fout = hd[i].fout; cd[i].eqout = hd[i].eqout; cd[i].n = hd[i].n; cd[i].fext = hd[i].fext; cd[i].pad = 0;
         const bool folds = r && hd[i].n > 1;
         size_t items = folds ? hd[i].n / 4 : hd[i].n / 2;  // loop iterations of the pair: 4 (2) entries of each table per iteration
-        size_t nb = std::min<size_t>(std::max<size_t>((items + TPB * 4 - 1) / (TPB * 4), 1), (size_t)std::min(1024, g_max_grid));
+        // (behind the resident executor a tile costs ~20 us of queue protocol whatever it does: 32 iterations per thread instead of 4)
+        const size_t per_blk = rx_ ? (size_t)TPB * 32 : (size_t)TPB * 4;
+        size_t nb = std::min<size_t>(std::max<size_t>((items + per_blk - 1) / per_blk, 1), rx_ ? (size_t)64 : (size_t)std::min(1024, g_max_grid));
         first[i] = nblk; nblk += (unsigned)nb;
         bytes += hd[i].n * (hd[i].fext ? 16.0 : 8.0) + hd[i].n * 16.0 + (folds ? hd[i].n * 16.0 : 0.0);
       }
@@ -1746,6 +1749,7 @@ class HipDev : public Dev {
       Ext* partial = (Ext*)arena_alloc((size_t)nblk * 2 * 16);
       unsigned long long seq = ++seq_;
       nb_ = bytes; DPL(k_classic_fused, dim3(nblk), dim3(TPB), fd, cdd, np, r ? *r : ex_zero(), r ? 1 : 0, partial);
+      DP_REQUIRE(2 * np <= (rx_ ? 512 : 1024), DP_ERR_SHAPE, "classic round: too many polynomials for one reduction");
       nb_ = 0; DPL(k_classic_reduce, dim3(1), dim3(np >= 8 ? 1024 : 256), fd, np, (const Ext*)partial, (Ext*)hres_dev_, hflag_dev_, seq);
       wait_flag(seq, (size_t)np * 4);
       for (int i = 0; i < 2 * np; i++) out[i] = ex(hres_[2 * i], hres_[2 * i + 1]);

@@ -37,8 +37,18 @@ constexpr size_t RX_PACK_RING = size_t(1) << 20;  // bytes of argument packs per
 constexpr unsigned RX_CELLS = 1u << 15;       // cells per (XCD, class) ring (power of two)
 constexpr unsigned RX_DOORBELLS = 1u << 16;   // doorbell ring entries per XCD (power of two)
 constexpr unsigned RX_WORKER_THREADS = 256;
-constexpr size_t RX_LDS_BIG = 64 * 1024, RX_LDS_STREAM = 17 * 1024;  // dynamic LDS arena of a worker (1 BIG + 4 STREAM workers and their statics fit a CU's 160 KB)
+// dynamic LDS arena of a worker. A BIG worker ASKS for 84 KB (RX_LDS_BIG_LAUNCH) although its bodies use at most 64: two of them then
+// cannot share a CU, and the 256 BIG workers — launched first — land one per CU; the STREAM workers (9 KB + 4.5 KB of statics)
+// fill in four per CU behind them (registers: 128 + 4 x 96 of a SIMD's 512). Launched the other way round the STREAM workers pack
+// five to a CU and leave the BIG workers a sixth of the chip.
+constexpr size_t RX_LDS_BIG = 64 * 1024, RX_LDS_BIG_LAUNCH = 84 * 1024, RX_LDS_STREAM = 9 * 1024;
 constexpr int RX_NCLASS = 2;
+// cell rings per XCD: STREAM wide steps, BIG steps, and URGENT = STREAM steps of a few tiles (copies, publications, reductions: the
+// links of every proof's chain) which the STREAM workers take first — behind a burst of 256 four-millisecond Merkle tiles a
+// one-tile step would otherwise wait its turn like a small kernel waits in a command-processor queue
+constexpr int RX_NRINGS = 3, RX_RING_WIDE = 0, RX_RING_BIG = 1, RX_RING_URGENT = 2;
+constexpr unsigned RX_URGENT_TILES = 8;
+constexpr unsigned RX_TRACE_STEPS = 1u << 14;  // steps of ONE slot a session can trace (DP_RX_TRACE)
 constexpr unsigned RX_PACK_WORDS_STREAM = 256, RX_PACK_WORDS_BIG = 512;  // largest argument pack a worker stages in LDS (TermArgs 1.6 KB / ScPersistArgs ~3 KB)
 constexpr int RX_STAT_BODIES = 128;           // per-body counters of the workers (>= number of bodies in rx_bodies.h)
 
@@ -76,7 +86,7 @@ struct alignas(128) RxRing {  // MPMC ring of cells: producers reserve with tail
   unsigned long long cells[RX_CELLS];  // lap + 1 (24 bits) | slot (12) | first tile (20) | tile count (8)
 };
 struct alignas(128) RxXcd {
-  RxRing ring[RX_NCLASS];
+  RxRing ring[RX_NRINGS];
   unsigned long long db_head; unsigned long long db_lock; unsigned long long db_last_poll; unsigned long long pad[13];
   unsigned long long alive[RX_NCLASS], pad2[14];  // workers of each class that have started on this XCD
   // what the workers of this XCD did (s_memrealtime ticks of 10 ns; read by the host after the session: rx_engine_stats)
@@ -92,6 +102,8 @@ struct RxArgs {
   const unsigned long long* control;     // host-mapped: [0] = stop flag
   unsigned long long* heartbeat;         // host-mapped: [xcd * 2 + class] = cells run (diagnostics); [32 + xcd * 2 + class] = "a worker of this class is resident on this XCD"
   unsigned long long session;            // salt of this session's descriptor tags
+  unsigned long long* trace;             // host-mapped, [RX_TRACE_STEPS][4]: issue / first tile start / done ticks and body | tiles << 32 of every step of `trace_slot`
+  unsigned trace_slot;                   // RX_MAX_SLOTS: nothing is traced
   int cls;
 };
 
@@ -115,5 +127,7 @@ std::string rx_engine_dump(RxEngine* e, unsigned slot);  // state of a slot and 
 // "bodies": [{"body", "class", "cells", "tiles", "total_ms", "avg_us_per_tile"}...]} — the executor's stand-in for a kernel trace
 // (rocprofv3 sees two launches per session)
 std::string rx_engine_stats(RxEngine* e);
+// DP_RX_TRACE=<slot>: the timeline of that slot's steps in the last session, one line per step (ticks of 10 ns relative to the first)
+std::string rx_engine_trace(RxEngine* e);
 
 }  // namespace dp

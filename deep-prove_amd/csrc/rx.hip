@@ -109,10 +109,12 @@ __device__ __forceinline__ void rx_try_issue(const RxArgs& a, RxSlot* slot, unsi
     if (!__hip_atomic_compare_exchange_strong(&slot->issued, &expect, s + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;  // someone else took it
     const unsigned gx = (unsigned)(w[2] & 0xFFFFFFFFull), gy = (unsigned)(w[2] >> 32);
     const unsigned ntiles = gx * gy, per = (unsigned)(w[4] & 0xFFFFFFFFull), cls = (unsigned)(w[4] >> 32) & 1u;
+    const unsigned which = cls == RX_BIG ? RX_RING_BIG : ntiles <= RX_URGENT_TILES ? RX_RING_URGENT : RX_RING_WIDE;
+    if (slot_id == a.trace_slot && s < RX_TRACE_STEPS) { st_sys(a.trace + 4 * s, __builtin_amdgcn_s_memrealtime()); st_sys(a.trace + 4 * s + 3, (w[1] & 0xFFFFFFFFull) | ((unsigned long long)ntiles << 32)); }
     st_dev(&slot->cur_body_flags, w[1]); st_dev(&slot->cur_grid, w[2]); st_dev(&slot->cur_pack, w[3]); st_dev(&slot->cur_pack_words, w[5]);
     st_dev32(&slot->tiles_left, ntiles);
     rx_drain();
-    RxRing* r = &a.xcd[slot->xcd].ring[cls];
+    RxRing* r = &a.xcd[slot->xcd].ring[which];
     const unsigned ncells = (ntiles + per - 1) / per;
     const unsigned long long pos = __hip_atomic_fetch_add(&r->tail, (unsigned long long)ncells, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (pos + ncells - ld_dev(&r->head) > RX_CELLS) __builtin_amdgcn_s_sleep(8);  // (ring full: the other workers are draining it)
@@ -169,7 +171,8 @@ template <int CLS> __global__ void __launch_bounds__(RX_WORKER_THREADS) __attrib
   __shared__ int s_state;  // 0: nothing to do, 1: run s_cell, 2: leave
   const unsigned xcd = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 7u;  // HW_REG_XCC_ID
   RxXcd* x = a.xcd + xcd;
-  RxRing* ring = &x->ring[CLS];
+  RxRing* ring = &x->ring[CLS == RX_BIG ? RX_RING_BIG : RX_RING_WIDE];
+  RxRing* urgent = &x->ring[RX_RING_URGENT];
   if (CLS == RX_BIG) __builtin_amdgcn_s_setprio(3);  // the protocol bodies are one-wave dependent chains: issue them first
   if (threadIdx.x == 0 && __hip_atomic_fetch_add(&x->alive[CLS], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) st_sys(a.heartbeat + 32 + xcd * RX_NCLASS + CLS, 1ull);
   unsigned idle = 0, ran = 0;
@@ -177,10 +180,10 @@ template <int CLS> __global__ void __launch_bounds__(RX_WORKER_THREADS) __attrib
     if (threadIdx.x == 0) {
       unsigned long long c = 0;
       int st = 0;
-      if (rx_pop(ring, &c)) st = 1;
+      if ((CLS == RX_STREAM && rx_pop(urgent, &c)) || rx_pop(ring, &c)) st = 1;
       else {
         rx_poll_doorbells(a, x, xcd);
-        if (rx_pop(ring, &c)) st = 1;
+        if ((CLS == RX_STREAM && rx_pop(urgent, &c)) || rx_pop(ring, &c)) st = 1;
         else if ((idle & 15u) == 15u && ld_sys(a.control) != 0) st = 2;
       }
       if (st == 1) {
@@ -210,6 +213,7 @@ template <int CLS> __global__ void __launch_bounds__(RX_WORKER_THREADS) __attrib
     const void* pack = (const void*)s_args;
     __syncthreads();
     const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && first == 0 && ((c >> 28) & 0xFFFu) == a.trace_slot) { const unsigned long long sn = ld_dev(&a.slots[a.trace_slot].issued) - 1; if (sn < RX_TRACE_STEPS) st_sys(a.trace + 4 * sn + 1, t_in); }
     for (unsigned t = first; t < first + cnt; t++) {
       if (threadIdx.x == 0) { rx_s_block.x = t % gx; rx_s_block.y = t / gx; rx_s_block.z = 0; rx_s_grid.x = gx; rx_s_grid.y = gy; rx_s_grid.z = 1; }
       __syncthreads();
@@ -225,6 +229,7 @@ template <int CLS> __global__ void __launch_bounds__(RX_WORKER_THREADS) __attrib
         const unsigned long long s1 = ld_dev(&slot->issued);
         st_dev(&slot->done, s1);
         st_sys(slot->host_done, s1);
+        if (((c >> 28) & 0xFFFu) == a.trace_slot && s1 - 1 < RX_TRACE_STEPS) st_sys(a.trace + 4 * (s1 - 1) + 2, __builtin_amdgcn_s_memrealtime());
         rx_drain();
         rx_try_issue(a, slot, (unsigned)((c >> 28) & 0xFFFu));
       }
@@ -275,7 +280,8 @@ struct RxEngine {
   RxXcd* d_xcd = nullptr; RxSlot* d_slots = nullptr;
   // host-mapped: control, heartbeat, host_done, doorbells (one block); descriptor + pack rings (one block per slot, grown on demand)
   char* hm = nullptr; char* hm_dev = nullptr;
-  unsigned long long *control = nullptr, *heartbeat = nullptr, *host_done = nullptr, *doorbells = nullptr;
+  unsigned long long *control = nullptr, *heartbeat = nullptr, *host_done = nullptr, *doorbells = nullptr, *trace = nullptr;
+  unsigned trace_slot = RX_MAX_SLOTS;
   struct SlotHost {
     char* mem = nullptr; char* mem_dev = nullptr;         // [RX_DESC_RING descriptors][RX_PACK_RING bytes of packs]
     unsigned long long pushed = 0;                         // steps pushed in this session
@@ -304,12 +310,12 @@ RxEngine* rx_engine_new(int device) {
   for (int c = 0; c < RX_NCLASS; c++) RX_HIP(hipStreamCreateWithFlags(&e->stream[c], hipStreamNonBlocking));
   RX_HIP(hipMalloc((void**)&e->d_xcd, sizeof(RxXcd) * RX_XCDS));
   RX_HIP(hipMalloc((void**)&e->d_slots, sizeof(RxSlot) * RX_MAX_SLOTS));
-  const size_t words = 64 + 64 + RX_MAX_SLOTS * 16 + (size_t)RX_XCDS * RX_DOORBELLS;  // host_done: one word per 128-byte line (the device writes them)
+  const size_t words = 64 + 64 + RX_MAX_SLOTS * 16 + (size_t)RX_XCDS * RX_DOORBELLS + (size_t)RX_TRACE_STEPS * 4;  // host_done: one word per 128-byte line (the device writes them)
   RX_HIP(hipHostMalloc((void**)&e->hm, words * 8, hipHostMallocMapped | hipHostMallocCoherent));
   RX_HIP(hipHostGetDevicePointer((void**)&e->hm_dev, e->hm, 0));
   memset(e->hm, 0, words * 8);
-  e->control = (unsigned long long*)e->hm; e->heartbeat = e->control + 64; e->host_done = e->heartbeat + 64; e->doorbells = e->host_done + RX_MAX_SLOTS * 16;
-  RX_HIP(hipFuncSetAttribute((const void*)rxk::k_rx_worker<RX_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RX_LDS_BIG));
+  e->control = (unsigned long long*)e->hm; e->heartbeat = e->control + 64; e->host_done = e->heartbeat + 64; e->doorbells = e->host_done + RX_MAX_SLOTS * 16; e->trace = e->doorbells + (size_t)RX_XCDS * RX_DOORBELLS;
+  RX_HIP(hipFuncSetAttribute((const void*)rxk::k_rx_worker<RX_BIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RX_LDS_BIG_LAUNCH));
   RX_HIP(hipFuncSetAttribute((const void*)rxk::k_rx_worker<RX_STREAM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RX_LDS_STREAM));
   // the Poseidon2 round constants and extrapolation weights of THIS translation unit's device code
   RX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(rxk::c_rc), POSEIDON2_RC_HOST, sizeof(POSEIDON2_RC_HOST)));
@@ -329,7 +335,7 @@ RxEngine* rx_engine_new(int device) {
   hipDeviceProp_t prop; RX_HIP(hipGetDeviceProperties(&prop, device));
   const int cus = prop.multiProcessorCount;
   int per_cu_big = 0, per_cu_stream = 0;
-  RX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_big, (const void*)rxk::k_rx_worker<RX_BIG>, RX_WORKER_THREADS, RX_LDS_BIG));
+  RX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_big, (const void*)rxk::k_rx_worker<RX_BIG>, RX_WORKER_THREADS, RX_LDS_BIG_LAUNCH));
   RX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_stream, (const void*)rxk::k_rx_worker<RX_STREAM>, RX_WORKER_THREADS, RX_LDS_STREAM));
   const char* eb = getenv("DP_RX_BIG_PER_CU"); const char* es = getenv("DP_RX_STREAM_PER_CU");
   const int big = eb ? atoi(eb) : 1, str = es ? atoi(es) : 4;
@@ -375,21 +381,34 @@ void rx_engine_start(RxEngine* e, unsigned nslots) {
   for (int x = 0; x < RX_XCDS; x++) e->db_tail[x].store(0);
   e->control[0] = 0;
   for (int i = 0; i < 48; i++) e->heartbeat[i] = 0;
+  { const char* ts = getenv("DP_RX_TRACE"); e->trace_slot = ts ? (unsigned)atoi(ts) : RX_MAX_SLOTS; if (e->trace_slot < nslots) memset(e->trace, 0, (size_t)RX_TRACE_STEPS * 32); else e->trace_slot = RX_MAX_SLOTS; }
   RX_HIP(hipMemsetAsync(e->d_xcd, 0, sizeof(RxXcd) * RX_XCDS, e->stream[0]));
   RX_HIP(hipMemcpyAsync(e->d_slots, init.data(), sizeof(RxSlot) * nslots, hipMemcpyHostToDevice, e->stream[0]));
   RX_HIP(hipStreamSynchronize(e->stream[0]));
   std::atomic_thread_fence(std::memory_order_seq_cst);
-  for (int c = 0; c < RX_NCLASS; c++) {
+  auto launch = [&](int c) {
     RxArgs a;
     a.xcd = e->d_xcd; a.slots = e->d_slots;
     a.doorbells = (const unsigned long long*)(e->hm_dev + ((char*)e->doorbells - e->hm));
     a.control = (const unsigned long long*)(e->hm_dev + ((char*)e->control - e->hm));
     a.heartbeat = (unsigned long long*)(e->hm_dev + ((char*)e->heartbeat - e->hm));
     a.session = e->session; a.cls = c;
-    if (c == RX_BIG) hipLaunchKernelGGL((rxk::k_rx_worker<RX_BIG>), dim3(e->nworkers[c]), dim3(RX_WORKER_THREADS), RX_LDS_BIG, e->stream[c], a);
+    a.trace = (unsigned long long*)(e->hm_dev + ((char*)e->trace - e->hm)); a.trace_slot = e->trace_slot;
+    if (c == RX_BIG) hipLaunchKernelGGL((rxk::k_rx_worker<RX_BIG>), dim3(e->nworkers[c]), dim3(RX_WORKER_THREADS), RX_LDS_BIG_LAUNCH, e->stream[c], a);
     else hipLaunchKernelGGL((rxk::k_rx_worker<RX_STREAM>), dim3(e->nworkers[c]), dim3(RX_WORKER_THREADS), RX_LDS_STREAM, e->stream[c], a);
     RX_HIP(hipGetLastError());
-  }
+  };
+  // BIG first, and the STREAM workers only once every XCD has reported a BIG worker (see RX_LDS_BIG_LAUNCH)
+  launch(RX_BIG);
+  { auto tb = std::chrono::steady_clock::now();
+    for (;;) {
+      bool all = true;
+      for (unsigned x : e->xcds) if (!__atomic_load_n(e->heartbeat + 32 + x * RX_NCLASS + RX_BIG, __ATOMIC_ACQUIRE)) all = false;
+      if (all || std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count() > 2.0) break;
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    std::this_thread::sleep_for(std::chrono::milliseconds(2)); }  // (the dispatcher places the rest of the BIG grid)
+  launch(RX_STREAM);
   e->nslots = nslots; e->running = true; e->t_start = std::chrono::steady_clock::now();
   // every XCD must have workers of both classes resident before a proof is pinned to it
   auto t0 = std::chrono::steady_clock::now();
@@ -482,8 +501,11 @@ std::string rx_engine_stats(RxEngine* e) {
   const BodyInfo* bt = body_table();
   double busy[RX_NCLASS] = {0, 0};
   for (int i = 0; i < RX_XCDS; i++) for (int c = 0; c < RX_NCLASS; c++) busy[c] += (double)at(i)->busy_ticks[c];
-  std::string out = "{";
+  std::string out = "{\"alive_per_xcd_stream_big\": [";
   char buf[512];
+  for (int i = 0; i < RX_XCDS; i++) { snprintf(buf, sizeof buf, "%s[%llu, %llu]", i ? ", " : "", at(i)->alive[RX_STREAM], at(i)->alive[RX_BIG]); out += buf; }
+  out += "], \"idle_iters_stream_big\": [";
+  { unsigned long long is = 0, ib = 0; for (int i = 0; i < RX_XCDS; i++) { is += at(i)->idle_iters[RX_STREAM]; ib += at(i)->idle_iters[RX_BIG]; } snprintf(buf, sizeof buf, "%llu, %llu], ", is, ib); out += buf; }
   snprintf(buf, sizeof buf, "\"session_ms\": %.3f, \"workers\": [%d, %d], \"busy_frac\": [%.4f, %.4f], \"bodies\": [", e->last_session_ms, e->nworkers[RX_STREAM], e->nworkers[RX_BIG],
            e->last_session_ms > 0 ? busy[RX_STREAM] * 1e-5 / (e->last_session_ms * e->nworkers[RX_STREAM]) : 0.0, e->last_session_ms > 0 ? busy[RX_BIG] * 1e-5 / (e->last_session_ms * e->nworkers[RX_BIG]) : 0.0);
   out += buf;
@@ -497,6 +519,23 @@ std::string rx_engine_stats(RxEngine* e) {
     out += buf; firstb = false;
   }
   return out + "]}";
+}
+
+std::string rx_engine_trace(RxEngine* e) {
+  if (!e || e->running || e->trace_slot >= RX_MAX_SLOTS) return std::string();
+  const BodyInfo* bt = body_table();
+  const unsigned long long n = std::min<unsigned long long>(e->slots[e->trace_slot].pushed, RX_TRACE_STEPS);
+  std::string out = "# step body tiles issue_us start_us done_us | gap_since_prev_done_us queue_us run_us\n";
+  unsigned long long t0 = n ? e->trace[0] : 0, prev_done = t0;
+  char buf[256];
+  for (unsigned long long s = 0; s < n; s++) {
+    const unsigned long long ti = e->trace[4 * s], ts = e->trace[4 * s + 1], td = e->trace[4 * s + 2], bw = e->trace[4 * s + 3];
+    const unsigned body = (unsigned)(bw & 0xFFFFFFFFull), tiles = (unsigned)(bw >> 32);
+    snprintf(buf, sizeof buf, "%llu %s %u %.2f %.2f %.2f | %.2f %.2f %.2f\n", s, body < (unsigned)RX_NBODIES_HOST ? bt[body].name : "?", tiles, (ti - t0) * 0.01, (ts - t0) * 0.01, (td - t0) * 0.01,
+             ((double)ti - (double)prev_done) * 0.01, ((double)ts - (double)ti) * 0.01, ((double)td - (double)ts) * 0.01);
+    out += buf; prev_done = td;
+  }
+  return out;
 }
 
 std::string rx_engine_dump(RxEngine* e, unsigned slot) {
