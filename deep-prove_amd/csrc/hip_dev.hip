@@ -55,7 +55,7 @@ static inline int grid_for(size_t n, int cap = 2048) {
   size_t b = (n + TPB - 1) / TPB;
   if (b < 1) b = 1;
   // behind the resident executor a proof's tiles run on the workers of ONE XCD (32 CUs): 256 tiles keep them busy, more only costs queue traffic
-  static const int rx_cap = [] { const char* e = getenv("DP_RX_GRID_CAP"); return e ? std::max(8, atoi(e)) : 32; }();  // (measured: 128 -> 166, 64 -> 197, 32 -> 247 proofs/s, profiles/r03_rx_*)
+  static const int rx_cap = [] { const char* e = getenv("DP_RX_GRID_CAP"); return e ? std::max(2, atoi(e)) : 8; }();  // (measured, Dense-4M, 256 in flight: 128 -> 166, 64 -> 197, 32 -> 322, 16 -> 358, 8 -> 371, 4 -> 349 proofs/s: profiles/r03_rx_*)
   if (g_rx_sessions.load(std::memory_order_relaxed) > 0) cap = std::min(cap, rx_cap);
   return (int)std::min<size_t>(std::min<size_t>(b, cap), (size_t)g_max_grid);
 }
