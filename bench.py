@@ -234,6 +234,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sumcheck24", action="store_true", help="skip the standalone 2^24 sumcheck roofline section")
     ap.add_argument("--no-cnn", action="store_true", help="skip the CNN-264k section of a Dense-4M run")
+    ap.add_argument("--no-seam-level", action="store_true", help="skip the seam-level consumer section (tests/support/seam_bench.c)")
     ap.add_argument("--batch", type=int, default=0, help="BASELINE config 4: ONE fixed batch of this many proofs per step, split over the ranks (strong scaling); "
                                                          "0 = the default weak-scaling run (fixed work per GPU)")
     ap.add_argument("--concurrency", type=int, default=0, help=f"independent proofs in flight per GPU (0 = {DEFAULT_IN_FLIGHT})")
@@ -363,6 +364,7 @@ def main():
                        "proof_words": main_w["proof_words"], "setup_s": round(main_w["setup_s"], 2), "verified": True, "golden_sha256_ok": main_w["golden_ok"], "verified_proofs_of_last_step": main_w["verified"], "verify_ms_per_proof": main_w["verify_ms"], "verify_batch_ms_per_proof": main_w["verify_batch_ms_per_proof"],
                        "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DP_") or k == "GPU_MAX_HW_QUEUES"}, "device": dev.name},
             "roofline": roofline, "cpu_baseline": cpu, "cnn_264k": cnn, "sumcheck24": sc24, "sumcheck24_sharded": None,
+            "seam_level": None if (world > 1 or args.no_seam_level) else seam_level(int(os.environ["DP_HOST_THREADS"])),
         }
 
     # BASELINE config 5 across the ranks: ONE 2^24 sumcheck, every rank owns a contiguous 1/N slice of each table and the
@@ -573,6 +575,34 @@ def sharded_estimate(nv, k, world, stream_tbps=3.4, round_us=17.0, exchange_us=3
     return {"one_gpu_ms": round(one, 3), f"{world}_gpus_ms": round(many, 3), "assumed": {"streaming_TBps": stream_tbps, "round_us": round_us, "exchange_us_per_local_round": exchange_us},
             "crossover_nv": cross, "verdict": ("worth sharding" if many < one else f"not worth sharding at 2^{nv} on {world} GPUs: the per-round exchange outweighs the streaming saved (crossover 2^{cross})"),
             "note": "model, not measurement; the measured wall_ms of this section is the judge of it"}
+
+
+def seam_level(threads, per_thread=6):
+    """What a host gets that proves THROUGH THE SEAMS (dp_pcs_commit / dp_pcs_batch_open / dp_sumcheck_prove / dp_logup_prove from T
+    threads, each context a slot of the resident executor) instead of handing the model to dp_model_prove_batch: tests/support/
+    seam_bench.c replays the seam calls of one Dense-4M proof, call for call and shape for shape, on random tables — "workload-
+    equivalent" proofs (the seams' bit-exactness is the business of the parity tests). Run in its own process (own HIP contexts)."""
+    import subprocess
+    import deep_prove_amd as dpa
+    src = os.path.join(ROOT, "tests", "support", "seam_bench.c")
+    out = os.path.join(ROOT, "tests", "support", "_build", "seam_bench")
+    deps = [src, os.path.join(ROOT, "include", "deep_prove_hip.h"), dpa.LIB_PATH]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["gcc", "-std=c11", "-Wall", "-O2", "-o", out, src, "-L", os.path.dirname(dpa.LIB_PATH), "-ldeepprove_hip", "-lpthread",
+                               "-Wl,-rpath," + os.path.dirname(dpa.LIB_PATH)])
+    res = {}
+    for name, executor, t in (("executor", 1, threads), ("streams", 0, threads)):
+        env = dict(os.environ, DP_ARENA_BYTES=str(2 << 30))
+        try:
+            r = subprocess.run([out, str(t), str(per_thread), str(executor)], env=env, capture_output=True, text=True, timeout=120)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            res[name] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-300:]}
+        except Exception as e:  # noqa: BLE001
+            res[name] = {"error": f"{type(e).__name__}: {e}"}
+    res["note"] = ("workload-equivalent proofs per second of a seam-level host (every seam call of one Dense-4M proof, random tables), T threads with one dp_ctx each: "
+                   "`executor` = contexts attached to the resident executor (dp_executor_attach), `streams` = plain contexts (one HIP stream each)")
+    return res
 
 
 def cpu_baseline(mb, workload):

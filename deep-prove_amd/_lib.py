@@ -26,6 +26,10 @@ SIGNATURES = {
     "dp_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(vp)]),
     "dp_ctx_destroy": (C.c_int32, [vp]),
     "dp_ctx_name": (C.c_char_p, [vp]),
+    "dp_executor_start": (C.c_int32, [C.c_int32, C.c_int32]),
+    "dp_executor_attach": (C.c_int32, [vp, C.c_int32]),
+    "dp_executor_detach": (C.c_int32, [vp]),
+    "dp_executor_stop": (C.c_int32, [C.c_int32]),
     "dp_profile_enable": (C.c_int32, [vp, C.c_int32]),
     "dp_profile_report": (C.c_int32, [vp, C.POINTER(C.c_void_p)]),
     "dp_probe_compress_rate": (C.c_int32, [vp, C.c_size_t, C.c_int32, C.POINTER(C.c_double)]),

@@ -131,6 +131,49 @@ int32_t dp_ctx_create(int32_t device_id, dp_ctx** out) {
   return guard([&] { DP_REQUIRE(out, DP_ERR_ARG, "null out"); Dev* d = make_hip_dev(device_id); dp_ctx* c = new dp_ctx(); c->dev = d; c->device_id = device_id; *out = c; });
 }
 int32_t dp_ctx_destroy(dp_ctx* ctx) { return guard([&] { if (ctx) { delete ctx->dev; delete ctx; } }); }
+
+// ---- the resident executor for seam-level callers (rx.h): a host that proves through dp_sumcheck_prove / dp_logup_prove / dp_pcs_*
+// from many threads gets, per call, what dp_model_prove_batch gets per proof — every context a slot, every launch a step descriptor,
+// no command processor and no lock step between the callers
+namespace {
+std::mutex g_exec_mu;
+std::map<int, dp::RxEngine*>& executors() { static std::map<int, dp::RxEngine*> m; return m; }
+}
+int32_t dp_executor_start(int32_t device_id, int32_t nslots) {
+  return guard([&] {
+    DP_REQUIRE(nslots >= 1 && nslots <= (int32_t)RX_MAX_SLOTS, DP_ERR_ARG, "executor: 1..1024 slots");
+    std::lock_guard<std::mutex> g(g_exec_mu);
+    dp::RxEngine*& e = executors()[device_id];
+    if (!e) e = rx_engine_new(device_id);
+    DP_REQUIRE(!rx_engine_running(e), DP_ERR_ARG, "executor: already running on this device");
+    rx_engine_start(e, (unsigned)nslots);
+    hip_rx_session(+1);
+  });
+}
+int32_t dp_executor_attach(dp_ctx* ctx, int32_t slot) {
+  return guard([&] {
+    DP_REQUIRE(ctx && slot >= 0, DP_ERR_ARG, "bad arguments");
+    std::lock_guard<std::mutex> g(g_exec_mu);
+    auto it = executors().find(ctx->device_id);
+    DP_REQUIRE(it != executors().end() && rx_engine_running(it->second), DP_ERR_ARG, "executor: not running on this context's device (dp_executor_start)");
+    CtxLock lk(ctx);
+    hip_dev_set_latency_mode(ctx->dev, false);  // throughput mode: device-side Fiat-Shamir, fused protocol kernels, 256-thread one-workgroup bodies
+    hip_dev_rx_attach(ctx->dev, it->second, (unsigned)slot);
+  });
+}
+int32_t dp_executor_detach(dp_ctx* ctx) {
+  return guard([&] { DP_REQUIRE(ctx, DP_ERR_ARG, "null ctx"); CtxLock lk(ctx); ctx->dev->sync(); hip_dev_rx_detach(ctx->dev); hip_dev_set_latency_mode(ctx->dev, true); });
+}
+int32_t dp_executor_stop(int32_t device_id) {
+  return guard([&] {
+    std::lock_guard<std::mutex> g(g_exec_mu);
+    auto it = executors().find(device_id);
+    if (it == executors().end() || !rx_engine_running(it->second)) return;
+    hip_rx_session(-1);
+    rx_engine_stop(it->second);
+    if (const char* sf = getenv("DP_RX_STATS")) { if (FILE* f = fopen(sf, "a")) { fprintf(f, "%s\n", rx_engine_stats(it->second).c_str()); fclose(f); } }
+  });
+}
 const char* dp_ctx_name(const dp_ctx* ctx) { return ctx ? ctx->dev->name() : ""; }
 
 int32_t dp_profile_enable(dp_ctx* ctx, int32_t on) { return guard([&] { DP_REQUIRE(ctx, DP_ERR_ARG, "null ctx"); hip_dev_profile_enable(ctx->dev, on != 0); }); }

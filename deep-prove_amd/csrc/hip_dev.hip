@@ -20,6 +20,7 @@
 #include "rx.h"
 #include "rx_bodies.h"
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -78,6 +79,10 @@ struct ProfRec { const char* name; double bytes; hipEvent_t a, b; };
 #define DP_SET_LDS_ONE(kern, maxt, bytes) do { set_lds_<kern, maxt, KF_CLAIM>(KArgs<decltype(&kern)>(), (int)(bytes)); set_lds_<kern, maxt, KF_PRIO>(KArgs<decltype(&kern)>(), (int)(bytes)); } while (0)
 
 static const bool g_host_stats = getenv("DP_TIMING") && atoi(getenv("DP_TIMING"));
+// DP_WAIT_YIELD=1: a host thread that waits for the device outside a fiber gives its CPU away (sched_yield) instead of spinning — for
+// seam-level hosts that run more proving threads than they have cores (tests/support/seam_bench.c)
+static const bool g_wait_yield = getenv("DP_WAIT_YIELD") && atoi(getenv("DP_WAIT_YIELD"));
+static inline void dp_spin_pause() { if (g_wait_yield) sched_yield(); else dp_spin_pause(); }
 
 // ------------------------------------------------------------------------------------------------ cohorts
 // A cohort is a set of proofs of the SAME model proved in lock step on one stream by one host thread (each proof a fiber,
@@ -340,7 +345,7 @@ class HipDev : public Dev {
         if (base + cs == tag) { last_tag_multi_[done] = tag; done++; continue; }
       }
       const bool fib = fiber_active();
-      if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
+      if (fib) { nyield_++; fiber_yield(); } else dp_spin_pause();
       if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
         throw DpError(DP_ERR_HIP, std::string("timeout waiting for the device") + (rx_ ? "\n" + rx_engine_dump(rx_, rx_slot_) : std::string()));
     }
@@ -403,7 +408,7 @@ class HipDev : public Dev {
       }
       // inside a fiber the wait hands the host thread to the next proof in flight (fiber.h); otherwise spin
       const bool fib = fiber_active();
-      if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
+      if (fib) { nyield_++; fiber_yield(); } else dp_spin_pause();
       if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
         throw DpError(DP_ERR_HIP, std::string("timeout waiting for the device") + (rx_ ? "\n" + rx_engine_dump(rx_, rx_slot_) : std::string()));
     }
@@ -425,7 +430,7 @@ class HipDev : public Dev {
         if (base + cs == tag) { last_tag_ = tag; desc_off_ = 0; stage_off_ = 0; if (co_ && co_li_) co_->note_executed(co_li_ - 1); wait_exit_(t0); return; }
       }
       const bool fib = fiber_active();
-      if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
+      if (fib) { nyield_++; fiber_yield(); } else dp_spin_pause();
       if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
         throw DpError(DP_ERR_HIP, std::string("timeout waiting for the device") + (rx_ ? "\n" + rx_engine_dump(rx_, rx_slot_) : std::string()));
     }
@@ -585,6 +590,7 @@ class HipDev : public Dev {
     pcs_tabs_.reset();
     if (arena_) hipFree(arena_);
     if (dres_) hipFree(dres_);
+    for (auto& kv : ppool_) hipFree(kv.second);
     if (dshare_) hipFree(dshare_);
     if (dgather_) hipFree(dgather_);
     if (fused_ticket_) hipFree(fused_ticket_);
@@ -688,13 +694,31 @@ class HipDev : public Dev {
   DBuf alloc(size_t n, bool ext) override { DBuf b; b.n = n; b.ext = ext; b.p = arena_alloc(std::max<size_t>(n, 1) * (ext ? 16 : 8)); return b; }
   size_t mark() override { return arena_off_; }
   void release(size_t m) override { arena_off_ = m; }
+  // Persistent buffers of a context that is a slot of the resident executor are RECYCLED, never handed back while it runs: hipFree
+  // waits for every stream of the device, and the executor's two kernels never end — a seam-level caller that frees a table
+  // (dp_buf_free, dp_pcs_commit_free) would wait for dp_executor_stop. The blocks go back to the device when the context is destroyed.
+  std::multimap<size_t, void*> ppool_; std::map<void*, size_t> psize_;
   DBuf alloc_persistent(size_t n, bool ext) override {
     DBuf b; b.n = n; b.ext = ext;
+    const size_t bytes = (std::max<size_t>(n, 1) * (ext ? 16 : 8) + 255) & ~size_t(255);
+    auto it = ppool_.find(bytes);
+    if (it != ppool_.end()) { b.p = it->second; ppool_.erase(it); return b; }
     HIP_CHECK(hipSetDevice(device_));
-    HIP_CHECK(hipMalloc(&b.p, std::max<size_t>(n, 1) * (ext ? 16 : 8)));
+    HIP_CHECK(hipMalloc(&b.p, bytes));
+    if (rx_) psize_[b.p] = bytes;
     return b;
   }
-  void free_persistent(DBuf& b) override { if (b.p) { hipStreamSynchronize(s_); hipFree(b.p); b.p = nullptr; } }
+  void free_persistent(DBuf& b) override {
+    if (!b.p) return;
+    if (rx_) {  // (blocks allocated before the context was attached are not in psize_: their size is what the handle says, rounded as above)
+      auto it = psize_.find(b.p);
+      const size_t bytes = it != psize_.end() ? it->second : ((std::max<size_t>(b.n, 1) * (b.ext ? 16 : 8) + 255) & ~size_t(255));
+      psize_[b.p] = bytes;
+      ppool_.emplace(bytes, b.p); b.p = nullptr; return;
+    }
+    psize_.erase(b.p);
+    hipStreamSynchronize(s_); hipFree(b.p); b.p = nullptr;
+  }
   // host <-> device copies go through the pinned staging buffer: hipMemcpyAsync on pageable memory pins the user pages
   // on the fly, which costs tens of milliseconds per MB on this stack
   // A cohort member moves data with kernels (k_copy_words through the mapped staging buffer, k_zero_words): a memcpy
@@ -751,7 +775,7 @@ class HipDev : public Dev {
             for (size_t i = lo; i < hi; i++) { const u64 v = pay[i]; out[i] = v; cs += (unsigned long long)(i - lo + 1) * v; }
             if (dl_mix_host(seq, ch) + cs == tag) break;
             const bool fib = fiber_active();
-            if (fib) { nyield_++; fiber_yield(); } else __builtin_ia32_pause();
+            if (fib) { nyield_++; fiber_yield(); } else dp_spin_pause();
             if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
               throw DpError(DP_ERR_HIP, std::string("timeout waiting for a download") + (rx_ ? "\n" + rx_engine_dump(rx_, rx_slot_) : std::string()));
           }

@@ -14,6 +14,7 @@
 #include "rx.h"
 #include "rx_bodies.h"
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <atomic>
 #include <chrono>
 #include <cstddef>
@@ -459,7 +460,7 @@ void rx_submit(RxEngine* e, unsigned slot, int body, int cls, int flags, unsigne
     unsigned long long head = s.pack_head;
     if (head % RX_PACK_RING + need > RX_PACK_RING) head += RX_PACK_RING - head % RX_PACK_RING;
     if (s.pushed - done < RX_DESC_RING - 1 && head + need - s.pack_tail <= RX_PACK_RING) { s.pack_head = head; break; }
-    if (fiber_active()) fiber_yield(); else __builtin_ia32_pause();
+    if (fiber_active()) fiber_yield(); else { static const bool wy = getenv("DP_WAIT_YIELD") && atoi(getenv("DP_WAIT_YIELD")); if (wy) sched_yield(); else __builtin_ia32_pause(); }
     if ((++spins & 0x3FFu) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
       throw DpError(DP_ERR_HIP, "resident executor: no progress on a full ring\n" + rx_engine_dump(e, slot));
   }

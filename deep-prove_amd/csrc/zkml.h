@@ -307,6 +307,12 @@ inline void validate_model(const ModelSpec& m) {
     } else if (l.kind == L_POSITIONAL) {
       DP_REQUIRE(is_pow2(l.nrows) && is_pow2(l.ncols) && l.ncols >= 2 && l.weights.size() == l.nrows * l.ncols && cur % l.ncols == 0 && cur <= l.weights.size() && cur >= 2
                  && l.add_left > 0 && l.add_right > 0 && l.add_left < (int64_t(1) << 40) && l.add_right < (int64_t(1) << 40), DP_ERR_SHAPE, "positional: the table is [positions][embedding size] with at least as many positions as the input has rows");
+      // KNOWN SOUNDNESS GAP, replicated from the reference for transcript compatibility (positional.rs:80-126, 480-583): when the table
+      // has more rows than the input has tokens, the coordinates that lift the slice claim to the whole table are drawn BEFORE the
+      // sub-matrix evaluations are absorbed, so a prover that sees them can choose right_eval and solve for sub_matrix_evals[0]: the
+      // positional addend is forgeable. DP_STRICT_POSITIONAL=1 refuses such models (table rows == tokens: nothing to lift, no gap).
+      static const bool strict_positional = getenv("DP_STRICT_POSITIONAL") && atoi(getenv("DP_STRICT_POSITIONAL"));
+      DP_REQUIRE(!strict_positional || cur == l.weights.size(), DP_ERR_ARG, "positional: table longer than the sequence (DP_STRICT_POSITIONAL: the reference's lifting of the slice claim is not sound)");
     } else if (l.kind == L_ADD) {
       DP_REQUIRE(l.weights.size() == cur && cur >= 2 && l.add_left > 0 && l.add_right > 0 && l.add_left < (int64_t(1) << 40) && l.add_right < (int64_t(1) << 40), DP_ERR_SHAPE, "add: the operand must be as long as the input, the multipliers positive");
     } else if (l.kind == L_REQUANT) {

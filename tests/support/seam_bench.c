@@ -1,0 +1,140 @@
+/* TEST / BENCH HARNESS (tests/ and bench.py only): what does a host get that proves THROUGH THE SEAMS — the entry points a Rust
+ * `Prover::<_, _, BasefoldHip>` with a patched `prove_parallel` would bind (seam 1: dp_pcs_commit / dp_pcs_batch_open; seam 2:
+ * dp_sumcheck_prove, dp_logup_prove; the table primitives dp_buf_upload / dp_mle_fix_high / dp_mle_eval) — instead of handing the
+ * whole model to dp_model_prove_batch? T host threads, each with its own dp_ctx attached to the resident executor
+ * (dp_executor_start / dp_executor_attach: csrc/rx.h), each proving a stream of "proofs" by issuing, call for call and shape for
+ * shape, the seam calls of one Dense-4M proof (zkml/src/iop/prover.rs:401-488 over the layers of mlp.py 5 x 1024):
+ *   witness        31 x (dp_buf_upload of a 2^10-row column + dp_pcs_commit), 1 table of 2^15, 2 of 2^8      commit/context.rs, lookup/context.rs:631-781
+ *   per Dense (6)  dp_mle_fix_high on the committed 2^20 weights, one degree-2 sumcheck over 2^10, dp_mle_eval of the bias   layers/dense.rs:423-561
+ *   per Requant(6) two lookup logup-GKR proofs (2 columns of 2^10 each) + a 3-table degree-2 sumcheck over 2^10              layers/requant.rs:531-690
+ *   per ReLU (5)   one logup-GKR proof (2 columns) + the same_poly sumcheck                                                  layers/activation.rs:385-456
+ *   tables (3)     logup-GKR in table mode (multiplicities)                                                                  iop/prover.rs:110-157
+ *   opening        dp_pcs_batch_open over the 4 weight commitments (2^20), the first layer's (2^12), the 2^15 table and the 31 columns
+ * The tables hold random field elements (the prover's work does not depend on the values; the proofs are NOT checked here — the
+ * seams' bit-exactness is what tests/test_gpu_primitives.py, test_gpu_c_consumer.py and test_gpu_zzzz_rx.py establish). The figure
+ * is therefore "seam-level, workload-equivalent proofs per second", to be read next to dp_model_prove_batch's rate.
+ * usage: seam_bench <threads> <proofs per thread> [executor: 1|0] */
+#define _POSIX_C_SOURCE 200809L
+#include "../../include/deep_prove_hip.h"
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define CHECK(x) do { int32_t rc_ = (x); if (rc_ != DP_OK) { fprintf(stderr, "%s failed: [%d] %s\n", #x, (int)rc_, dp_last_error()); exit(1); } } while (0)
+#define P 0xFFFFFFFF00000001ull
+enum { NV = 10, N = 1 << NV, NCOLS = 31, NDENSE = 6, NREQ = 6, NRELU = 5 };
+
+static uint64_t splitmix(uint64_t* s) { uint64_t z = (*s += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+static void fill(uint64_t* w, size_t n, uint64_t* s) { for (size_t i = 0; i < n; i++) w[i] = splitmix(s) % P; }
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+struct worker {
+  int id, proofs, use_executor;
+  dp_ctx* ctx;
+  dp_buf* weights[4]; dp_commit* wcomm[4];         /* 1024 x 1024 base matrices (Context::generate: outside the timed region) */
+  dp_buf* w0; dp_commit* w0comm;                   /* the 1024 x 4 first layer */
+  dp_buf* bias;                                    /* 2^10 */
+  dp_buf* big_table; dp_commit* big_comm;          /* 2^15-row clamping table multiplicities */
+  uint64_t* col_words; uint64_t* ext_words;        /* host data of a column / an extension table */
+  uint64_t point20[40], point12[24], point15[30], point10[20];
+  double seconds;
+};
+
+static pthread_barrier_t g_start;
+
+static void one_proof(struct worker* w) {
+  dp_ctx* ctx = w->ctx;
+  dp_transcript* t = dp_transcript_new("m2vec");
+  dp_buf* cols[NCOLS]; dp_commit* comms[NCOLS];
+  uint64_t root[4];
+  /* witness columns: uploaded and committed one by one, as PCS::commit is called per column */
+  for (int i = 0; i < NCOLS; i++) { CHECK(dp_buf_upload(ctx, w->col_words, N, 0, &cols[i])); CHECK(dp_pcs_commit(ctx, cols[i], &comms[i], root)); CHECK(dp_transcript_append_elements(t, root, 4)); }
+  dp_buf* e0; dp_buf* e1; dp_buf* e2;
+  CHECK(dp_buf_upload(ctx, w->ext_words, N, 1, &e0)); CHECK(dp_buf_upload(ctx, w->ext_words + 2 * N, N, 1, &e1)); CHECK(dp_buf_upload(ctx, w->ext_words + 4 * N, N, 1, &e2));
+  uint64_t* pw = NULL; size_t pn = 0; uint64_t finals[6], ev[2];
+  const uint64_t cc[2] = {12345, 678}, csc[2] = {91011, 1213};
+  int col = 0;
+  for (int l = 0; l < NDENSE; l++) {
+    /* Dense: fix the row variables of the weights at the claim's point, one degree-2 sumcheck, the bias evaluation */
+    dp_buf* fixed = NULL;
+    CHECK(dp_mle_fix_high(ctx, w->weights[l % 4], N, N, w->point10, &fixed));
+    { const dp_buf* tabs[2] = {fixed, e0}; const int32_t deg[1] = {2}, tt[2] = {0, 1}; const uint64_t co[2] = {1, 0};
+      CHECK(dp_sumcheck_prove(ctx, NV, tabs, 2, deg, tt, co, 1, t, &pw, &pn, finals)); dp_free(pw); }
+    CHECK(dp_mle_eval(ctx, w->bias, w->point10, NV, ev));
+    CHECK(dp_buf_free(ctx, fixed));
+    /* Requant: two lookups (2 columns per instance) and the batching sumcheck */
+    for (int k = 0; k < 2; k++) { const dp_buf* lc[2] = {cols[col % NCOLS], cols[(col + 1) % NCOLS]}; col += 2; CHECK(dp_logup_prove(ctx, lc, 2, 2, NULL, cc, csc, t, &pw, &pn)); dp_free(pw); }
+    { const dp_buf* tabs[3] = {e0, e1, e2}; const int32_t deg[2] = {2, 2}, tt[4] = {0, 1, 0, 2}; const uint64_t co[4] = {3, 4, 5, 6};
+      CHECK(dp_sumcheck_prove(ctx, NV, tabs, 3, deg, tt, co, 2, t, &pw, &pn, finals)); dp_free(pw); }
+    if (l < NRELU) {  /* ReLU: one lookup + the same_poly accumulation sumcheck */
+      const dp_buf* lc[2] = {cols[col % NCOLS], cols[(col + 1) % NCOLS]}; col += 2;
+      CHECK(dp_logup_prove(ctx, lc, 2, 2, NULL, cc, csc, t, &pw, &pn)); dp_free(pw);
+      const dp_buf* tabs[2] = {e1, e2}; const int32_t deg[1] = {2}, tt[2] = {0, 1}; const uint64_t co[2] = {1, 0};
+      CHECK(dp_sumcheck_prove(ctx, NV, tabs, 2, deg, tt, co, 1, t, &pw, &pn, finals)); dp_free(pw);
+    }
+  }
+  /* the lookup tables' own logup proofs: a 2^15-row table with its multiplicities, two of 2^8 */
+  { const dp_buf* tc[1] = {w->big_table}; CHECK(dp_logup_prove(ctx, tc, 1, 1, w->big_table, cc, csc, t, &pw, &pn)); dp_free(pw); }
+  /* the opening: every committed polynomial at one point of its size */
+  { enum { NC = 4 + 1 + 1 + NCOLS };
+    const dp_commit* cm[NC]; uint64_t pts[4 * 40 + 24 + 30 + NCOLS * 20]; uint64_t evals[2 * NC]; size_t o = 0; int c = 0;
+    for (int i = 0; i < 4; i++) { cm[c++] = w->wcomm[i]; memcpy(pts + o, w->point20, 320); o += 40; }
+    cm[c++] = w->w0comm; memcpy(pts + o, w->point12, 192); o += 24;
+    cm[c++] = w->big_comm; memcpy(pts + o, w->point15, 240); o += 30;
+    for (int i = 0; i < NCOLS; i++) { cm[c++] = comms[i]; memcpy(pts + o, w->point10, 160); o += 20; }
+    for (int i = 0; i < 2 * NC; i++) evals[i] = (uint64_t)(i + 1);  /* (claimed values: the prover's work does not depend on them) */
+    CHECK(dp_pcs_batch_open(ctx, cm, NC, pts, evals, t, &pw, &pn)); dp_free(pw); }
+  for (int i = 0; i < NCOLS; i++) { CHECK(dp_pcs_commit_free(ctx, comms[i])); CHECK(dp_buf_free(ctx, cols[i])); }
+  CHECK(dp_buf_free(ctx, e0)); CHECK(dp_buf_free(ctx, e1)); CHECK(dp_buf_free(ctx, e2));
+  dp_transcript_free(t);
+}
+
+static void* run(void* arg) {
+  struct worker* w = (struct worker*)arg;
+  uint64_t seed = 0xD33B0000ull + (uint64_t)w->id;
+  CHECK(dp_ctx_create(0, &w->ctx));
+  CHECK(dp_pcs_setup(w->ctx, (size_t)1 << 20));
+  uint64_t* big = (uint64_t*)malloc(8u << 20);
+  for (int i = 0; i < 4; i++) { fill(big, (size_t)1 << 20, &seed); CHECK(dp_buf_upload(w->ctx, big, (size_t)1 << 20, 0, &w->weights[i])); uint64_t r[4]; CHECK(dp_pcs_commit(w->ctx, w->weights[i], &w->wcomm[i], r)); }
+  { fill(big, (size_t)1 << 12, &seed); CHECK(dp_buf_upload(w->ctx, big, (size_t)1 << 12, 0, &w->w0)); uint64_t r[4]; CHECK(dp_pcs_commit(w->ctx, w->w0, &w->w0comm, r)); }
+  { fill(big, (size_t)1 << 15, &seed); CHECK(dp_buf_upload(w->ctx, big, (size_t)1 << 15, 0, &w->big_table)); uint64_t r[4]; CHECK(dp_pcs_commit(w->ctx, w->big_table, &w->big_comm, r)); }
+  { fill(big, N, &seed); CHECK(dp_buf_upload(w->ctx, big, N, 0, &w->bias)); }
+  free(big);
+  w->col_words = (uint64_t*)malloc(8 * N); fill(w->col_words, N, &seed);
+  w->ext_words = (uint64_t*)malloc(8 * 6 * N); fill(w->ext_words, 6 * N, &seed);
+  fill(w->point20, 40, &seed); fill(w->point12, 24, &seed); fill(w->point15, 30, &seed); fill(w->point10, 20, &seed);
+  pthread_barrier_wait(&g_start);  /* every context exists (the library's code objects are loaded, PCS::setup has run) ... */
+  pthread_barrier_wait(&g_start);  /* ... and main has started the executor */
+  if (w->use_executor) CHECK(dp_executor_attach(w->ctx, w->id));
+  one_proof(w);  /* warm-up */
+  pthread_barrier_wait(&g_start);
+  const double t0 = now_s();
+  for (int i = 0; i < w->proofs; i++) one_proof(w);
+  w->seconds = now_s() - t0;
+  pthread_barrier_wait(&g_start);
+  if (w->use_executor) CHECK(dp_executor_detach(w->ctx));
+  return NULL;
+}
+
+int main(int argc, char** argv) {
+  const int T = argc > 1 ? atoi(argv[1]) : 8, per = argc > 2 ? atoi(argv[2]) : 4, use_executor = argc > 3 ? atoi(argv[3]) : 1;
+  if (T < 1 || T > 1024 || per < 1) { fprintf(stderr, "usage: seam_bench <threads> <proofs per thread> [executor 1|0]\n"); return 2; }
+  pthread_barrier_init(&g_start, NULL, (unsigned)T + 1);
+  struct worker* ws = (struct worker*)calloc((size_t)T, sizeof *ws);
+  pthread_t* th = (pthread_t*)calloc((size_t)T, sizeof *th);
+  for (int i = 0; i < T; i++) { ws[i].id = i; ws[i].proofs = per; ws[i].use_executor = use_executor; pthread_create(&th[i], NULL, run, &ws[i]); }
+  pthread_barrier_wait(&g_start);  /* contexts ready: the executor starts on an otherwise idle, fully initialised device */
+  if (use_executor) CHECK(dp_executor_start(0, T));
+  pthread_barrier_wait(&g_start);
+  pthread_barrier_wait(&g_start);  /* warm-up proofs done */
+  const double t0 = now_s();
+  pthread_barrier_wait(&g_start);
+  const double dt = now_s() - t0;
+  for (int i = 0; i < T; i++) pthread_join(th[i], NULL);
+  if (use_executor) CHECK(dp_executor_stop(0));
+  printf("{\"seam_level_proofs_per_s\": %.2f, \"threads\": %d, \"proofs\": %d, \"seconds\": %.3f, \"executor\": %s, \"ms_per_proof_per_thread\": %.1f}\n",
+         (double)T * per / dt, T, T * per, dt, use_executor ? "true" : "false", 1000.0 * dt / per);
+  return 0;
+}

@@ -61,3 +61,67 @@ def test_rx_dense4m_golden_sha256(dev, monkeypatch):
     verdicts, _ = dpa.verify_batch(ctx.verifier_blob(), proofs, xs, outs, dev=dev)
     assert not verdicts.any()
     ctx.free()
+
+
+@pytest.mark.timeout(300)
+def test_rx_seam_level_callers_on_several_threads(oracle):
+    """dp_executor_start / attach: FOUR contexts on four host threads call the seams (dp_sumcheck_prove, dp_logup_prove, dp_pcs_commit,
+    dp_pcs_batch_open) concurrently as slots of the resident executor; every result equals the oracle's, as the unattached calls do"""
+    import threading
+    import deep_prove_amd as dpa
+    P = 0xFFFFFFFF00000001
+    nthreads = 4
+    devs = [dpa.Device(0) for _ in range(nthreads)]
+    dpa.executor_start(0, nthreads)
+    errors = []
+
+    def job(k):
+        try:
+            dev = devs[k]
+            pcs = dpa.Basefold(dev, 1 << 14)  # (PCS::setup builds the root tables with ordinary launches: before the context becomes a slot)
+            dev.executor_attach(k)
+            rng = np.random.default_rng(900 + k)
+            # ---- seam 2: sumchecks of several shapes (one-workgroup, streaming and mixed-degree paths)
+            for nv, exts, terms in [(10, [True, True, True], [((P - 1, 0), [0, 2]), ((P - 1, 0), [0, 1]), ((11, 13), [0, 1, 2])]),
+                                    (17, [False, False, False], [((1, 0), [0, 1, 2])]),
+                                    (13, [True, True, True, True, True], [((1, 0), [0, 1, 4]), ((1, 0), [0, 3, 2]), ((7, 7), [0, 2, 4])])]:
+                raw = [rng.integers(0, P, size=(2 if e else 1) << nv, dtype=np.uint64) for e in exts]
+                mles = [dpa.Mle.from_ext(dev, w) if e else dpa.Mle.from_base(dev, w) for w, e in zip(raw, exts)]
+                vp = dpa.VirtualPolynomial(nv)
+                vp.tables = list(mles)
+                vp.terms = [(c, ix) for c, ix in terms]
+                t = dpa.Transcript(b"test")
+                proof, finals = dpa.prove_parallel(dev, vp, t)
+                ot = oracle.transcript(b"test")
+                oproof, ofinals = oracle.sumcheck_prove(nv, raw, exts, terms, ot)
+                assert proof.size == oproof.size and (proof == oproof).all() and (finals == ofinals).all(), f"thread {k}: sumcheck nv={nv}"
+                assert t.read_challenge() == ot.read_challenge()
+                for m in mles:
+                    m.free()
+            # ---- seam 1: commit + batch_open of a small family of polynomials
+            polys = [rng.integers(0, P, size=1 << nv, dtype=np.uint64) for nv in (14, 12, 10)]
+            mles = [dpa.Mle.from_base(dev, w) for w in polys]
+            comms = [pcs.commit(m) for m in mles]
+            for c, w in zip(comms, polys):
+                assert list(c.root) == list(oracle.pcs_commit_root(1 << 14, w, False)), f"thread {k}: commitment root"
+            points = [[(int(a), int(b)) for a, b in rng.integers(0, P, size=(nv, 2), dtype=np.uint64)] for nv in (14, 12, 10)]
+            evals = [m.evaluate(pt) for m, pt in zip(mles, points)]
+            assert evals == [oracle.mle_eval(w, False, pt) for w, pt in zip(polys, points)], f"thread {k}: mle_eval"
+            t = dpa.Transcript(b"test")
+            proof = pcs.batch_open(comms, points, evals, t)
+            ot = oracle.transcript(b"test")
+            oproof = oracle.pcs_batch_open(1 << 14, polys, [False] * 3, points, evals, ot)
+            assert proof.size == oproof.size and (proof == oproof).all(), f"thread {k}: batch_open"
+            dev.executor_detach()
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {k}: {type(e).__name__}: {e}")
+
+    th = [threading.Thread(target=job, args=(k,)) for k in range(nthreads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    dpa.executor_stop(0)
+    for d in devs:
+        d.close()
+    assert not errors, errors
