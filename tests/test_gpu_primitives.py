@@ -280,3 +280,37 @@ def test_pcs_batch_open_and_verify(dev, oracle, shape):
     wrong[0] = ((evals[0][0] + 1) % P, evals[0][1])
     with pytest.raises(dpa.DeepProveError):
         dpa.Basefold.batch_verify(maxsize, roots, [nv for nv, _ in shape], [not e for _, e in shape], points, wrong, proof, dpa.Transcript(b"test"))
+
+
+@pytest.mark.parametrize("case", [1, 2])
+def test_device_sumcheck_accepted_by_the_independent_verifier(dev, case):
+    """the DEVICE prover's proof through tests/support/l1_independent.py (a sumcheck verifier written from the protocol definition on
+    the independent Poseidon2 / transcript): no oracle code and no product code decides this acceptance"""
+    import deep_prove_amd as dpa
+    from support import l0_independent as L
+    from support import l1_independent as L1
+    from test_l1_independent import CASES, _parse_iop
+    nv, exts, terms = CASES[case]
+    rng = np.random.default_rng(700 + case)
+    raw = [rng.integers(0, P, size=(2 if e else 1) << nv, dtype=np.uint64) for e in exts]
+    mles = [dpa.Mle.from_ext(dev, w) if e else dpa.Mle.from_base(dev, w) for w, e in zip(raw, exts)]
+    vp = dpa.VirtualPolynomial(nv)
+    vp.tables = list(mles)
+    vp.terms = [(c, ix) for c, ix in terms]
+    proof, finals = dpa.prove_parallel(dev, vp, dpa.Transcript(b"test"))
+    for m in mles:
+        m.free()
+    point, rounds = _parse_iop(proof)
+    tabs = [[(int(t[2 * k]), int(t[2 * k + 1])) for k in range(t.size // 2)] if e else [(int(v), 0) for v in t] for t, e in zip(raw, exts)]
+    total = (0, 0)
+    for b in range(1 << nv):
+        for coeff, ix in terms:
+            prod = (1, 0)
+            for i in ix:
+                prod = L.ext_mul(prod, tabs[i][b])
+            total = L.ext_add(total, L.ext_mul(coeff, prod))
+    chals, final_claim = L1.verify_sumcheck(total, point, rounds, nv, max(len(ix) for _, ix in terms), L.Transcript(b"test"))
+    value, evals = L1.virtual_poly_at(raw, exts, terms, chals)
+    assert value == final_claim
+    for i, ev in evals.items():
+        assert ev == (int(finals[2 * i]), int(finals[2 * i + 1]))
