@@ -24,6 +24,7 @@ struct ClassicTailDesc {
 inline bool classic_tail_accepts(const Dev::ClassicTailArgs& a) {
   if (a.np < 1 || a.np > CT_MAXP || a.round >= a.num_vars) return false;
   for (int i = 0; i < a.np; i++) {
+    if (a.los && a.los[i].n) return false;  // factored eq tables (Dev::classic_round) are materialised before the tail's length
     if (a.fs[i].n > CLASSIC_TAIL_MAX_N || a.fs[i].n != a.eqs[i].n || !a.eqs[i].ext || a.fs[i].null() || a.eqs[i].null()) return false;
     if (a.fs[i].n == 0 || (a.fs[i].n & (a.fs[i].n - 1))) return false;
   }

@@ -244,14 +244,25 @@ class Dev {
   virtual DevTree batch_tree(const DBuf* cws, int k, bool persistent) { (void)cws; (void)k; (void)persistent; throw DpError(DP_ERR_SHAPE, "batch_tree: not provided by this device"); }
   // classic sumcheck round (K12): fold every (f_i, eq_i) of length > 1 with r (if given), then
   // out[2i] = sum_j f[2j]*eq[2j], out[2i+1] = sum_j (f[2j+1]-f[2j])*(eq[2j+1]-eq[2j]); length-1 pairs give (f*eq, 0)
-  virtual void classic_round(DBuf* fs, DBuf* eqs, int np, const Ext* r, Ext* out) = 0;
+  // `los` (null: none) holds the FACTORED eq tables: los[i].n == 0 means eqs[i] is the table itself (as long as fs[i]); otherwise
+  // table_i[j] = los[i][j mod L] * eqs[i][j / L] with L = los[i].n and fs[i].n = L * eqs[i].n — eq(x, z) is the outer product of the eq
+  // tables of the low and the high coordinates of z (the products are exact: the same field elements as the materialised table),
+  // so a 2^nv-entry table is never written or read. A fold halves los[i] while it is longer than one entry, then eqs[i].
+  virtual void classic_round(DBuf* fs, DBuf* eqs, DBuf* los, int np, const Ext* r, Ext* out) = 0;
+  // How pcs_batch_open represents the eq table of an opened nv-variable polynomial: the number of LOW variables of the factored form
+  // (0: materialise the table), and the length from which on every table is materialised again (the one-workgroup tails and the
+  // last rounds work on plain tables).
+  virtual unsigned classic_eq_split(unsigned nv) { (void)nv; return 0; }
+  virtual size_t classic_eq_materialise_n() { return 8192; }
+  struct EqOuterJob { DBuf out, lo, hi; };  // out[j] = lo[j mod lo.n] * hi[j / lo.n]
+  virtual void eq_outer_many(const EqOuterJob* jobs, size_t n) { (void)jobs; (void)n; throw DpError(DP_ERR_SHAPE, "eq_outer_many: not provided by this device"); }
   // The remaining rounds of the batch-opening ("classic") sumcheck of pcs_batch_open (pcs.h) with the transcript on the device.
   // Called at the top of round `round`, exactly where classic_round would be called (r = the previous challenge, not yet
   // folded in, or null in round 0), with eq_xt[i] the batching coefficient of pair i and `sum` the running claim. On `true`
   // the 3-coefficient message and the challenge of every remaining round have been appended to `msgs` / `challenges` and `ch`
   // is the sponge after the last challenge; fs / eqs are left in an unspecified state (the caller only needs the
   // challenges from here on). `false`: not taken, nothing changed.
-  struct ClassicTailArgs { DBuf* fs; DBuf* eqs; int np; const Ext* r; const Ext* eq_xt; unsigned num_vars, round; Ext sum; };
+  struct ClassicTailArgs { DBuf* fs; DBuf* eqs; DBuf* los; int np; const Ext* r; const Ext* eq_xt; unsigned num_vars, round; Ext sum; };
   virtual bool classic_tail(const ClassicTailArgs& a, Challenger& ch, std::vector<std::vector<Ext>>& msgs, std::vector<Ext>& challenges) {
     (void)a; (void)ch; (void)msgs; (void)challenges;
     return false;

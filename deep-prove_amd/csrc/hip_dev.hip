@@ -1736,19 +1736,44 @@ class HipDev : public Dev {
     return build_tree(rows, persistent);
   }
 
-  void classic_round(DBuf* fs, DBuf* eqs, int np, const Ext* r, Ext* out) override {
+  // factored eq tables of the batch-opening sumcheck (Dev::classic_round): polynomials of 2^15 entries and more keep eq(x, z) as
+  // (low half, high half) — DP_CLASSIC_EQ_SPLIT=0 materialises them as before
+  bool eq_split_ = knob("DP_CLASSIC_EQ_SPLIT", 1) != 0;
+  unsigned classic_eq_split(unsigned nv) override { return eq_split_ && zerocopy_ && nv >= 15 ? nv / 2 : 0; }
+  size_t classic_eq_materialise_n() override { return CLASSIC_TAIL_MAX_N; }
+  void eq_outer_many(const EqOuterJob* jobs, size_t n) override {
+    if (!n) return;
+    DP_REQUIRE(n * sizeof(EqOuterDesc) + 64 <= DESC_BYTES, DP_ERR_SHAPE, "eq_outer_many: too many tables");
+    const EqOuterDesc* dd = nullptr;
+    EqOuterDesc* d = desc_alloc<EqOuterDesc>(n, &dd);
+    size_t maxn = 1; double bytes = 0;
+    for (size_t i = 0; i < n; i++) {
+      const EqOuterJob& j = jobs[i];
+      DP_REQUIRE(j.out.ext && j.lo.ext && j.hi.ext && j.lo.n && !(j.lo.n & (j.lo.n - 1)) && j.out.n == j.lo.n * j.hi.n && j.out.n <= 0xffffffffu, DP_ERR_SHAPE, "eq_outer_many: shapes");
+      d[i].out = (Ext*)j.out.p; d[i].lo = (const Ext*)j.lo.p; d[i].hi = (const Ext*)j.hi.p; d[i].ln = (unsigned)j.lo.n; d[i].n = (unsigned)j.out.n;
+      maxn = std::max(maxn, j.out.n); bytes += 16.0 * j.out.n;
+    }
+    nb_ = bytes; DPL(k_eq_outer_many, dim3(grid_for(maxn, 64), (unsigned)n), dim3(TPB), dd);
+  }
+  void classic_round(DBuf* fs, DBuf* eqs, DBuf* los, int np, const Ext* r, Ext* out) override {
     DP_REQUIRE((size_t)np * (sizeof(PolyDesc) * 2 + sizeof(ClassicDesc) + 4) + 320 <= DESC_BYTES && (size_t)np * 4 <= RES_WORDS && np * 2 <= 1024, DP_ERR_SHAPE, "classic_round: too many polynomials");
     if (desc_off_ + (size_t)np * (sizeof(PolyDesc) * 2 + sizeof(ClassicDesc) + 4) + 320 > DESC_BYTES) stream_wait();
     const PolyDesc* dd = nullptr;
     PolyDesc* hd = desc_alloc<PolyDesc>((size_t)np, &dd);
+    // the factored pairs (los[i].n > 0): lo / loout / ln of the fused launch's descriptor
+    struct Fac { const Ext* lo = nullptr; Ext* loout = nullptr; unsigned ln = 0; };
+    std::vector<Fac> fac((size_t)np);
     size_t maxn = 1;
     for (int i = 0; i < np; i++) {
-      DP_REQUIRE(fs[i].n == eqs[i].n && eqs[i].ext, DP_ERR_SHAPE, "classic_round: f/eq shapes");
+      const size_t ln = los ? los[i].n : 0;
+      DP_REQUIRE(fs[i].n == (ln ? ln : 1) * eqs[i].n && eqs[i].ext && (!ln || (los[i].ext && !(ln & (ln - 1)) && zerocopy_)), DP_ERR_SHAPE, "classic_round: f/eq shapes");
       hd[i].f = fs[i].p; hd[i].eq = (const Ext*)eqs[i].p; hd[i].n = fs[i].n; hd[i].fext = fs[i].ext; hd[i].pad = 0; hd[i].fout = nullptr; hd[i].eqout = nullptr;
+      if (ln) { fac[i].lo = (const Ext*)los[i].p; fac[i].ln = (unsigned)ln; }
       if (r && fs[i].n > 1) {
-        DBuf fo = alloc(fs[i].n / 2, true), eo = alloc(fs[i].n / 2, true);
-        hd[i].fout = (Ext*)fo.p; hd[i].eqout = (Ext*)eo.p;
-        fs[i] = fo; eqs[i] = eo;
+        DBuf fo = alloc(fs[i].n / 2, true);
+        hd[i].fout = (Ext*)fo.p; fs[i] = fo;
+        if (ln > 1) { DBuf lo2 = alloc(ln / 2, true); fac[i].loout = (Ext*)lo2.p; los[i] = lo2; }
+        else { DBuf eo = alloc(eqs[i].n / 2, true); hd[i].eqout = (Ext*)eo.p; eqs[i] = eo; }
       }
       maxn = std::max(maxn, hd[i].n);
     }
@@ -1760,14 +1785,15 @@ class HipDev : public Dev {
       ClassicDesc* cd = desc_alloc<ClassicDesc>((size_t)np, &cdd);
       unsigned nblk = 0; double bytes = 0;
       for (int i = 0; i < np; i++) {
-        cd[i].f = hd[i].f; cd[i].eq = hd[i].eq; cd[i].fout = hd[i].fout; cd[i].eqout = hd[i].eqout; cd[i].n = hd[i].n; cd[i].fext = hd[i].fext; cd[i].pad = 0;
+        cd[i].f = hd[i].f; cd[i].eq = hd[i].eq; cd[i].fout = hd[i].fout; cd[i].eqout = hd[i].eqout; cd[i].n = hd[i].n; cd[i].fext = hd[i].fext;
+        cd[i].ln = fac[i].ln; cd[i].lo = fac[i].lo; cd[i].loout = fac[i].loout;
         const bool folds = r && hd[i].n > 1;
         size_t items = folds ? hd[i].n / 4 : hd[i].n / 2;  // loop iterations of the pair: 4 (2) entries of each table per iteration
         // (behind the resident executor a tile costs ~20 us of queue protocol whatever it does: 32 iterations per thread instead of 4)
         const size_t per_blk = rx_ ? (size_t)TPB * 32 : (size_t)TPB * 4;
         size_t nb = std::min<size_t>(std::max<size_t>((items + per_blk - 1) / per_blk, 1), rx_ ? (size_t)64 : (size_t)std::min(1024, g_max_grid));
         first[i] = nblk; nblk += (unsigned)nb;
-        bytes += hd[i].n * (hd[i].fext ? 16.0 : 8.0) + hd[i].n * 16.0 + (folds ? hd[i].n * 16.0 : 0.0);
+        bytes += hd[i].n * (hd[i].fext ? 16.0 : 8.0) + (folds ? hd[i].n * 8.0 : 0.0) + (fac[i].ln ? 0.0 : hd[i].n * 16.0 + (folds ? hd[i].n * 8.0 : 0.0));
       }
       first[np] = nblk;
       Ext* partial = (Ext*)arena_alloc((size_t)nblk * 2 * 16);

@@ -147,26 +147,46 @@ inline BasefoldProof pcs_batch_open_evals(Dev& dev, unsigned full_log, const std
   for (size_t i = 0; i < np; i++)
     target = ex_add(target, ex_mul(ex_mul(evals[i].eval, ex_from_u64(u64(1) << (num_vars - comms[evals[i].poly]->nv))), eq_xt[i]));
   // ---- classic sumcheck on sum_i eq_xt[i] * eq(x, z_i) * f_i(x)  (sum_check/classic.rs:232-285, coeff.rs:198-345)
-  std::vector<DBuf> fs(np), eqs(np);
+  // eq(x, z_i) of a long polynomial is kept as the outer product of two short tables (Dev::classic_round, `los`): it is never
+  // materialised at 2^nv entries, only once every table has become short
+  std::vector<DBuf> fs(np), eqs(np), los(np);
+  size_t n_factored = 0;
   {
-    std::vector<Dev::EqJob> jobs(np);
+    std::vector<Dev::EqJob> jobs;
     for (size_t i = 0; i < np; i++) {
       fs[i] = comms[evals[i].poly]->evals;
-      eqs[i] = dev.alloc(fs[i].n, true);
-      jobs[i] = {eqs[i], points[evals[i].point].data(), comms[evals[i].poly]->nv};
+      const unsigned nv = comms[evals[i].poly]->nv, m = fs[i].n > dev.classic_eq_materialise_n() ? dev.classic_eq_split(nv) : 0;
+      const Ext* pt = points[evals[i].point].data();
+      if (m > 0 && m < nv) {
+        los[i] = dev.alloc(size_t(1) << m, true); eqs[i] = dev.alloc(size_t(1) << (nv - m), true);
+        jobs.push_back({los[i], pt, m}); jobs.push_back({eqs[i], pt + m, nv - m});
+        n_factored++;
+      } else {
+        eqs[i] = dev.alloc(fs[i].n, true);
+        jobs.push_back({eqs[i], pt, nv});
+      }
     }
-    dev.eq_table_many(jobs.data(), np);
+    dev.eq_table_many(jobs.data(), jobs.size());
   }
   std::vector<Ext> challenges, raw(2 * np);
   Ext sum = target, ch = ex_zero();
   for (unsigned round = 0; round < num_vars; round++) {
+    if (n_factored) {
+      size_t maxn = 0; for (size_t i = 0; i < np; i++) maxn = std::max(maxn, fs[i].n);
+      if (maxn <= dev.classic_eq_materialise_n()) {
+        std::vector<Dev::EqOuterJob> oj;
+        for (size_t i = 0; i < np; i++) if (los[i].n) { DBuf full = dev.alloc(fs[i].n, true); oj.push_back({full, los[i], eqs[i]}); eqs[i] = full; los[i] = DBuf(); }
+        dev.eq_outer_many(oj.data(), oj.size());
+        n_factored = 0;
+      }
+    }
     // a device that keeps the sponge to itself runs every remaining round in one go (Dev::classic_tail)
-    Dev::ClassicTailArgs ta{fs.data(), eqs.data(), (int)np, round ? &ch : nullptr, eq_xt.data(), num_vars, round, sum};
+    Dev::ClassicTailArgs ta{fs.data(), eqs.data(), los.data(), (int)np, round ? &ch : nullptr, eq_xt.data(), num_vars, round, sum};
     if (dev.classic_tail(ta, t.challenger(), proof.sumcheck_proof, challenges)) {
       DP_REQUIRE(challenges.size() == num_vars && proof.sumcheck_proof.size() == num_vars, DP_ERR_SHAPE, "classic_tail: one message and one challenge per round expected");
       break;
     }
-    dev.classic_round(fs.data(), eqs.data(), (int)np, round ? &ch : nullptr, raw.data());
+    dev.classic_round(fs.data(), eqs.data(), los.data(), (int)np, round ? &ch : nullptr, raw.data());
     std::vector<Ext> msg = classic_round_message(raw.data(), fs.data(), eq_xt.data(), np, num_vars, round, sum);
     for (const Ext& e : msg) t.append_ext(e);
     ch = t.get_and_append_challenge("sumcheck round");

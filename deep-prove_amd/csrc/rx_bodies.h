@@ -8,7 +8,7 @@
 #define RX_BIG 1
 #define RX_BODY_LIST(X) \
   X(RX_STREAM, k_copy_words) X(RX_STREAM, k_download) X(RX_STREAM, k_zero_words) X(RX_STREAM, k_fieldize) X(RX_STREAM, k_publish) \
-  X(RX_STREAM, k_eq_table) X(RX_STREAM, k_eq_table_many) X(RX_STREAM, k_mle_eval_partial) X(RX_STREAM, k_reduce_publish) \
+  X(RX_STREAM, k_eq_table) X(RX_STREAM, k_eq_table_many) X(RX_STREAM, k_eq_outer_many) X(RX_STREAM, k_mle_eval_partial) X(RX_STREAM, k_reduce_publish) \
   X(RX_STREAM, k_fix_high_partial) X(RX_STREAM, k_colsum) X(RX_STREAM, k_fix_low) X(RX_STREAM, k_fold) X(RX_STREAM, k_finish_publish) \
   X(RX_STREAM, k_sc_terms<false>) X(RX_BIG, k_sc_terms<true>) \
   X(RX_STREAM, k_sc_fused<1, true, true>) X(RX_STREAM, k_sc_fused<1, true, false>) X(RX_STREAM, k_sc_fused<1, false, true>) X(RX_STREAM, k_sc_fused<1, false, false>) \

@@ -250,13 +250,30 @@ class CpuDev : public Dev {
     }
     return build_tree(rows, persistent);
   }
-  void classic_round(DBuf* fs, DBuf* eqs, int np, const Ext* r, Ext* out) override {
+  // factored eq tables (Dev::classic_round): this double factors every polynomial of 3 or more variables and materialises only at
+  // two entries, so the batch openings of the CPU suite run their rounds on (lo, hi) pairs of every shape
+  unsigned classic_eq_split(unsigned nv) override { return nv >= 3 ? nv / 2 : 0; }
+  size_t classic_eq_materialise_n() override { return 2; }
+  void eq_outer_many(const EqOuterJob* jobs, size_t n) override {
+    for (size_t q = 0; q < n; q++) {
+      const EqOuterJob& j = jobs[q];
+      DP_REQUIRE(j.out.ext && j.lo.ext && j.hi.ext && j.lo.n && j.out.n == j.lo.n * j.hi.n, DP_ERR_SHAPE, "eq_outer_many: shapes");
+      for (size_t i = 0; i < j.out.n; i++) X(j.out)[i] = ex_mul(X(j.lo)[i % j.lo.n], X(j.hi)[i / j.lo.n]);
+    }
+  }
+  void classic_round(DBuf* fs, DBuf* eqs, DBuf* los, int np, const Ext* r, Ext* out) override {
     for (int i = 0; i < np; i++) {
-      if (r && fs[i].n > 1) { fs[i] = fold(fs[i], *r); eqs[i] = fold(eqs[i], *r); }
+      const bool fac = los && los[i].n;
+      DP_REQUIRE(fs[i].n == (fac ? los[i].n : 1) * eqs[i].n, DP_ERR_SHAPE, "classic_round: f/eq shapes");
+      if (r && fs[i].n > 1) {
+        fs[i] = fold(fs[i], *r);
+        if (fac && los[i].n > 1) los[i] = fold(los[i], *r); else eqs[i] = fold(eqs[i], *r);
+      }
+      auto eq_at = [&](size_t j) { return fac ? ex_mul(at(los[i], j % los[i].n), at(eqs[i], j / los[i].n)) : at(eqs[i], j); };
       Ext c0 = ex_zero(), c2 = ex_zero();
-      if (fs[i].n == 1) c0 = ex_mul(at(fs[i], 0), at(eqs[i], 0));
+      if (fs[i].n == 1) c0 = ex_mul(at(fs[i], 0), eq_at(0));
       else for (size_t j = 0; j + 1 < fs[i].n; j += 2) {
-        Ext l0 = at(eqs[i], j), l1 = at(eqs[i], j + 1), r0 = at(fs[i], j), r1 = at(fs[i], j + 1);
+        Ext l0 = eq_at(j), l1 = eq_at(j + 1), r0 = at(fs[i], j), r1 = at(fs[i], j + 1);
         c0 = ex_add(c0, ex_mul(l0, r0)); c2 = ex_add(c2, ex_mul(ex_sub(l1, l0), ex_sub(r1, r0)));
       }
       out[2 * i] = c0; out[2 * i + 1] = c2;
@@ -336,7 +353,7 @@ class CpuDev : public Dev {
     std::vector<Ext> raw(2 * (size_t)a.np);
     Ext sum = a.sum, c = a.r ? *a.r : ex_zero();
     for (unsigned round = a.round; round < a.num_vars; round++) {
-      classic_round(a.fs, a.eqs, a.np, round == a.round ? a.r : &c, raw.data());
+      classic_round(a.fs, a.eqs, a.los, a.np, round == a.round ? a.r : &c, raw.data());
       std::vector<Ext> msg = classic_round_message(raw.data(), a.fs, a.eq_xt, (size_t)a.np, a.num_vars, round, sum);
       for (const Ext& e : msg) t.append_ext(e);
       c = t.get_and_append_challenge("sumcheck round");

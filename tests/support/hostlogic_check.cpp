@@ -408,6 +408,7 @@ int main(int argc, char** argv) {
   dp::emul_init_constants();
   dev.full = !(getenv("DP_EMUL_MODE") && atoi(getenv("DP_EMUL_MODE")) == 1);  // DP_EMUL_MODE=1: Dev::logup_tail, else Dev::logup_full
   dev.threads = getenv("DP_EMUL_THREADS") ? atoi(getenv("DP_EMUL_THREADS")) : 64;
+  if (getenv("DP_EMUL_CLASSIC")) dev.classic = atoi(getenv("DP_EMUL_CLASSIC")) != 0;  // 0: no classic tail — the factored rounds of k_classic_fused run down to two entries
   if (getenv("DP_EMUL_COMMIT_MAX_N")) dev.commit_max_n = (size_t)atoll(getenv("DP_EMUL_COMMIT_MAX_N"));  // how long an oracle the emulated commit tail takes over
 #endif
   dev.device_fs = getenv("DP_DOUBLE_DEVICE_FS") && atoi(getenv("DP_DOUBLE_DEVICE_FS"));  // exercise the Dev::sc_tail contract (device-side Fiat-Shamir)
@@ -427,6 +428,7 @@ int main(int argc, char** argv) {
 #ifdef DP_EMUL_DEV
   printf("emulated k_logup_tail (%s mode, %u threads): %zu logup proofs taken, %zu declined\n", dev.full ? "full" : "tail", dev.threads, dev.taken, dev.declined);
   printf("emulated k_classic_tail: %zu batch-opening sumcheck tails taken\n", dev.classic_taken);
+  printf("emulated k_classic_fused: %zu rounds, %zu factored (lo, hi) pairs; k_eq_outer_many: %zu tables\n", dev.classic_rounds_emulated, dev.classic_factored_pairs, dev.eq_outer_emulated);
   printf("emulated k_dense_tail: %zu dense layers taken\n", dev.dense_taken);
   printf("emulated k_eqsum_tail: %zu eq + sumcheck groups taken\n", dev.eqsum_taken);
   printf("emulated k_commit_tail: %zu commit-phase tails taken (%zu rounds, %zu codewords merged)\n", dev.commit_taken, dev.commit_rounds_run, dev.commit_merged);

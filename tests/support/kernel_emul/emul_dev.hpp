@@ -156,8 +156,52 @@ struct EmulDev : CpuDev {
     dense_taken++;
     return true;
   }
+  // Dev::classic_round from the device source of k_classic_fused — plain and FACTORED eq tables (classic_fused_factored) —, several
+  // 64-lane workgroups per pair emulated one after the other; the sum over the workgroups (k_classic_reduce on the device) is the host's
+  size_t classic_rounds_emulated = 0, classic_factored_pairs = 0, eq_outer_emulated = 0;
+  void classic_round(DBuf* fs, DBuf* eqs, DBuf* los, int np, const Ext* r, Ext* out) override {
+    std::vector<ClassicDesc> cd((size_t)np);
+    std::vector<unsigned> first((size_t)np + 1);
+    unsigned nblk = 0;
+    for (int i = 0; i < np; i++) {
+      const size_t ln = los ? los[i].n : 0;
+      DP_REQUIRE(fs[i].n == (ln ? ln : 1) * eqs[i].n, DP_ERR_SHAPE, "classic_round: f/eq shapes");
+      ClassicDesc& c = cd[i];
+      c.f = fs[i].p; c.eq = (const Ext*)eqs[i].p; c.fout = nullptr; c.eqout = nullptr; c.n = fs[i].n; c.fext = fs[i].ext; c.ln = (unsigned)ln; c.lo = ln ? (const Ext*)los[i].p : nullptr; c.loout = nullptr;
+      if (ln) classic_factored_pairs++;
+      if (r && fs[i].n > 1) {
+        DBuf fo = alloc(fs[i].n / 2, true); c.fout = (Ext*)fo.p; fs[i] = fo;
+        if (ln > 1) { DBuf l2 = alloc(ln / 2, true); c.loout = (Ext*)l2.p; los[i] = l2; }
+        else { DBuf eo = alloc(eqs[i].n / 2, true); c.eqout = (Ext*)eo.p; eqs[i] = eo; }
+      }
+      first[i] = nblk; nblk += c.n >= 64 ? 3 : 1;  // three workgroups of 64 lanes: a grid-stride loop with several turns per lane
+    }
+    first[np] = nblk;
+    std::vector<Ext> partial(2 * (size_t)nblk);
+    blockDim.x.v = 64; gridDim.x.v = nblk;
+    for (unsigned b = 0; b < nblk; b++) {
+      blockIdx.x.v = b;
+      simt::launch(64, [&] { k_classic_fused(first.data(), cd.data(), np, r ? *r : ex_zero(), r ? 1 : 0, partial.data()); });
+    }
+    blockIdx.x.v = 0; gridDim.x.v = 1;
+    for (int i = 0; i < np; i++) {
+      Ext c0 = ex_zero(), c2 = ex_zero();
+      for (unsigned b = first[i]; b < first[i + 1]; b++) { c0 = ex_add(c0, partial[2 * b]); c2 = ex_add(c2, partial[2 * b + 1]); }
+      out[2 * i] = c0; out[2 * i + 1] = c2;
+    }
+    classic_rounds_emulated++;
+  }
+  void eq_outer_many(const EqOuterJob* jobs, size_t n) override {
+    std::vector<EqOuterDesc> d(n);
+    for (size_t i = 0; i < n; i++) { d[i].out = (Ext*)jobs[i].out.p; d[i].lo = (const Ext*)jobs[i].lo.p; d[i].hi = (const Ext*)jobs[i].hi.p; d[i].ln = (unsigned)jobs[i].lo.n; d[i].n = (unsigned)jobs[i].out.n; }
+    blockDim.x.v = 64; gridDim.x.v = 2; gridDim.y.v = (int)n;
+    for (unsigned y = 0; y < n; y++) for (unsigned b = 0; b < 2; b++) { blockIdx.x.v = b; blockIdx.y.v = y; simt::launch(64, [&] { k_eq_outer_many(d.data()); }); }
+    blockIdx.x.v = 0; blockIdx.y.v = 0; gridDim.x.v = 1; gridDim.y.v = 1;
+    eq_outer_emulated += n;
+  }
   bool classic = true;  // serve Dev::classic_tail with the emulated k_classic_tail
   size_t classic_max_n = 256, classic_taken = 0;
+  size_t classic_eq_materialise_n() override { return classic ? classic_max_n : CpuDev::classic_eq_materialise_n(); }  // like the device: plain tables from the tail's length on
   bool classic_tail(const ClassicTailArgs& a, Challenger& ch, std::vector<std::vector<Ext>>& msgs, std::vector<Ext>& challenges) override {
     if (!classic || !classic_tail_accepts(a)) return false;
     for (int i = 0; i < a.np; i++) if (a.fs[i].n > classic_max_n) return false;  // (emulation speed; the device takes tables up to CLASSIC_TAIL_MAX_N)

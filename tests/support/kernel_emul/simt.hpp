@@ -78,6 +78,7 @@ static struct { simt::Const x{1}, y{1}, z{1}; } gridDim;
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 #define __hip_atomic_load(p, order, scope) (*(volatile const std::remove_pointer_t<decltype(p)>*)(p))
 inline void __syncthreads() { simt::barrier(); }
+inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 inline unsigned long long __brevll(unsigned long long x) { unsigned long long r = 0; for (int i = 0; i < 64; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
 inline int __shfl(int v, int src, int width = 64) {
   unsigned me = simt::tid();

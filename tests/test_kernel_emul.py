@@ -37,6 +37,20 @@ def _model(args, env):
     return subprocess.run([binary, *map(str, args)], capture_output=True, text=True, timeout=900, env=e)
 
 
+def test_factored_eq_rounds_of_the_batch_opening_down_to_two_entries():
+    """k_classic_fused on FACTORED eq tables (classic_fused_factored: eq(x, z) as the outer product of two short tables, Dev::classic_round)
+    through every shape of the pair — the low factor folding (4 and more entries), becoming a scalar (2), the high factor folding under
+    the scalar (1), the last fold to one entry — with no classic tail taking over: the proofs equal the oracle's byte for byte"""
+    for args in ((16, 3), ("cnn", 2)):
+        r = _model(args, {"DP_EMUL_CLASSIC": "0"})
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "identical=1" in r.stdout, r.stdout
+        assert int(r.stdout.split("emulated k_classic_tail: ")[1].split()[0]) == 0, r.stdout
+        fused = r.stdout.split("emulated k_classic_fused: ")[1].split()
+        assert int(fused[0]) >= 8 and int(fused[2]) >= 8, r.stdout
+        assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
+
+
 def test_whole_model_proofs_with_every_logup_proof_from_the_emulated_kernel():
     """end to end: the product's orchestrator proves an MLP and a CNN with EVERY logup-GKR proof (lookups and tables) produced
     by the device source of k_logup_tail on the emulator — full mode (one launch per proof) and tail mode — and the proof
@@ -49,6 +63,9 @@ def test_whole_model_proofs_with_every_logup_proof_from_the_emulated_kernel():
         declined = int(r.stdout.split("logup proofs taken, ")[1].split()[0])
         assert taken >= least and declined == 0, r.stdout
         assert int(r.stdout.split("emulated k_classic_tail: ")[1].split()[0]) >= 1, r.stdout  # ... and the batch-opening sumcheck tail
+        fused = r.stdout.split("emulated k_classic_fused: ")[1].split()  # ... and the streamed rounds before it, on factored eq tables
+        assert int(fused[0]) >= 1 and int(fused[2]) >= 1, r.stdout
+        assert int(r.stdout.split("k_eq_outer_many: ")[1].split()[0]) >= 1, r.stdout          # ... written out (k_eq_outer_many) where the tail takes over
         assert int(r.stdout.split("emulated k_dense_tail: ")[1].split()[0]) >= 1, r.stdout    # ... and every Dense layer (bias, fix_high, sumcheck)
         assert int(r.stdout.split("emulated k_eqsum_tail: ")[1].split()[0]) >= 2, r.stdout    # ... and the accumulation sumchecks of Requant / ReLU
         assert int(r.stdout.split("emulated k_commit_tail: ")[1].split()[0]) >= 1, r.stdout   # ... and the last rounds of the Basefold commit phase
