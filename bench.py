@@ -28,9 +28,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # with a drain (~0.2 s together, profiles/r02_waves.jsonl: 1 wave 327, 2 waves 352, 4 waves 410, 8 waves 431 proofs/s), a service
 # feeds its prover continuously
 BATCHES_PER_STEP = 6
-# proofs in flight per GPU: 22 cohorts of 12 lock-step proofs (csrc/hip_dev.hip, struct Cohort). The library cuts the number
-# to what fits in the free HBM (worker arenas are sized from the footprint of the model's first proof).
-DEFAULT_IN_FLIGHT = 256
+# proofs in flight per GPU, in lock-step cohorts (csrc/hip_dev.hip, struct Cohort). The library cuts the number to what fits in the
+# free HBM (worker arenas are sized from the footprint of the model's first proof: 448 MB for Dense-4M since the batch-opening
+# sumcheck keeps its eq tables factored — 576 MB and at most 423 in flight before). 448 against 256 in flight, same build and box,
+# alternating: 466 / 511 against 452 / 448 proofs/s in the bench's own steps (profiles/r03_graph1_bench_inflight.txt), 480 against 453
+# on average in single batches (profiles/r03_cohort_inflight_ab.txt).
+DEFAULT_IN_FLIGHT = 448
 GOLDEN = {"dense_4m": "dense4m_proof.json", "cnn_264k": "cnn264k_proof.json"}
 GOLDEN_SLOT = 7  # index inside the last timed step at which the golden input is proved
 SHARDED_WATCHDOG_S = float(os.environ.get("DP_BENCH_SHARDED_WATCHDOG_S", "240"))

@@ -137,7 +137,8 @@ int32_t dp_ctx_destroy(dp_ctx* ctx) { return guard([&] { if (ctx) { delete ctx->
 // no command processor and no lock step between the callers
 namespace {
 std::mutex g_exec_mu;
-std::map<int, dp::RxEngine*>& executors() { static std::map<int, dp::RxEngine*> m; return m; }
+std::map<int, dp::RxEngine*> g_executors;
+inline std::map<int, dp::RxEngine*>& executors() { return g_executors; }
 }
 int32_t dp_executor_start(int32_t device_id, int32_t nslots) {
   return guard([&] {
@@ -744,10 +745,40 @@ int32_t dp_pcs_simple_batch_verify(size_t max_poly_size, const uint64_t root[4],
 static ModelSpec parse_model(const int64_t* b, size_t n) {
   size_t pos = 0;
   auto rd = [&]() { DP_REQUIRE(pos < n, DP_ERR_ARG, "model blob truncated"); return b[pos++]; };
-  ModelSpec m; m.input_len = (size_t)rd(); size_t nl = (size_t)rd();
+  ModelSpec m; m.input_len = (size_t)rd();
+  // graph form: a NEGATIVE node count, then [#input tensors, their lengths] [#outputs, (node, slot) each] and, in front of every node's
+  // parameters, [#inputs, (node, slot) each] with node = -1 for an input tensor of the model
+  const int64_t nl_raw = rd(); const bool graph = nl_raw < 0; const size_t nl = (size_t)(graph ? -nl_raw : nl_raw);
   DP_REQUIRE(nl > 0 && nl < 4096, DP_ERR_ARG, "model blob: bad layer count");
+  auto rd_edge = [&]() { Edge e; const int64_t f = rd(), sl = rd(); DP_REQUIRE(f >= -1 && f < (int64_t)nl && sl >= 0 && sl < 4096, DP_ERR_ARG, "model blob: edge"); e.from = (int)f; e.slot = (int)sl; return e; };
+  if (graph) {
+    const size_t ni = (size_t)rd(); DP_REQUIRE(ni > 0 && ni < 4096, DP_ERR_ARG, "model blob: input tensor count");
+    for (size_t i = 0; i < ni; i++) m.input_lens.push_back((size_t)rd());
+    const size_t no = (size_t)rd(); DP_REQUIRE(no > 0 && no < 4096, DP_ERR_ARG, "model blob: output tensor count");
+    for (size_t i = 0; i < no; i++) m.outputs.push_back(rd_edge());
+  }
   for (size_t i = 0; i < nl; i++) {
     LayerSpec l; l.kind = (int)rd();
+    if (graph) { const size_t k = (size_t)rd(); DP_REQUIRE(k == 1 || k == 2, DP_ERR_ARG, "model blob: a node has one or two inputs"); for (size_t q = 0; q < k; q++) l.inputs.push_back(rd_edge()); }
+    if (l.kind == L_MATMUL2) {  // [10, inner dimension k, output columns n, flags (2 = Config::TransposeB)]
+      l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); const size_t fl = (size_t)rd();
+      DP_REQUIRE((fl & ~size_t(2)) == 0, DP_ERR_ARG, "model blob: matmul2 flags"); l.mm_transpose = fl != 0;
+    } else if (l.kind == L_ADD2) { l.add_left = rd(); l.add_right = rd(); }  // [11, left multiplier, right multiplier]
+    else if (l.kind == L_CONCAT_MATMUL) {  // [12, shape of A (3), shape of B (3), (concat, mat_mul, output) axis of A (3), of B (3), 0 | 1 + output permutation (3)]
+      for (int d = 0; d < 3; d++) l.cm_a[d] = (size_t)rd();
+      for (int d = 0; d < 3; d++) l.cm_b[d] = (size_t)rd();
+      for (int d = 0; d < 3; d++) { const int64_t x = rd(); DP_REQUIRE(x >= 0 && x < 3, DP_ERR_ARG, "model blob: concat matmul axes"); l.cm_left[d] = (int)x; }
+      for (int d = 0; d < 3; d++) { const int64_t x = rd(); DP_REQUIRE(x >= 0 && x < 3, DP_ERR_ARG, "model blob: concat matmul axes"); l.cm_right[d] = (int)x; }
+      for (int d = 0; d < 3; d++) DP_REQUIRE(l.cm_a[d] && l.cm_b[d] && l.cm_a[d] <= (size_t(1) << 24) && l.cm_b[d] <= (size_t(1) << 24), DP_ERR_ARG, "model blob: concat matmul shapes");
+      const int64_t hp = rd(); DP_REQUIRE(hp == 0 || hp == 1, DP_ERR_ARG, "model blob: concat matmul permutation flag");
+      if (hp) for (int d = 0; d < 3; d++) { const int64_t x = rd(); DP_REQUIRE(x >= 0 && x < 3, DP_ERR_ARG, "model blob: concat matmul permutation"); l.cm_perm.push_back((int)x); }
+    } else if (l.kind == L_QKV) {  // [13, k, n, W_q | W_k | W_v ([k][n] each), b_q | b_k | b_v ([n] each)]
+      l.nrows = (size_t)rd(); l.ncols = (size_t)rd();
+      size_t nw = 0, nw3 = 0, nb3 = 0, tot = 0;
+      DP_REQUIRE(l.nrows && l.ncols && !__builtin_mul_overflow(l.nrows, l.ncols, &nw) && !__builtin_mul_overflow(nw, (size_t)3, &nw3) && !__builtin_mul_overflow(l.ncols, (size_t)3, &nb3) && !__builtin_add_overflow(nw3, nb3, &tot) && tot <= n - pos, DP_ERR_ARG, "model blob: qkv tensor sizes");
+      l.weights.assign(b + pos, b + pos + nw3); pos += nw3;
+      l.bias.assign(b + pos, b + pos + nb3); pos += nb3;
+    } else
     if (l.kind == L_DENSE) {
       l.nrows = (size_t)rd(); l.ncols = (size_t)rd();
       size_t nw = 0, tot = 0;  // overflow-checked: a wrapped product would also satisfy validate_model's size equality
@@ -817,7 +848,7 @@ int32_t dp_model_prove(dp_model* m, const int64_t* input, size_t ninput, uint64_
     std::vector<u64> w = serialize_proof(p);
     *proof_words = copy_out(w); *proof_nwords = w.size();
     if (output && noutput) {
-      const auto& o = tr.out.back();
+      const std::vector<int64_t> o = model_output(m->zk->model, tr);
       DP_REQUIRE(*noutput >= o.size(), DP_ERR_ARG, "output buffer too small");
       memcpy(output, o.data(), o.size() * 8); *noutput = o.size();
     }
@@ -915,7 +946,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
             auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
             fprintf(stderr, "[dp timing] host phases of one proof: inference %.2f ms, prove %.2f ms (wall, shared thread), serialise %.2f ms, copy out %.2f ms\n", ms(h0, h1), ms(h1, h2), ms(h2, h3), ms(h3, std::chrono::steady_clock::now()));
           }
-          if (outputs) { const auto& o = tr.out.back(); DP_REQUIRE(o.size() <= noutput_cap, DP_ERR_ARG, "output buffer too small"); memcpy(outputs + i * noutput_cap, o.data(), o.size() * 8); if (noutput) *noutput = o.size(); }
+          if (outputs) { const std::vector<int64_t> o = model_output(m->zk->model, tr); DP_REQUIRE(o.size() <= noutput_cap, DP_ERR_ARG, "output buffer too small"); memcpy(outputs + i * noutput_cap, o.data(), o.size() * 8); if (noutput) *noutput = o.size(); }
         }
       } catch (const DpError& e) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = e.code; err = e.what(); } next = nproofs; }
       catch (const std::exception& e) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_ARG; err = e.what(); } next = nproofs; }
@@ -975,7 +1006,7 @@ int32_t dp_model_infer_host(const int64_t* model_blob, size_t nwords, const int6
     validate_model(m);
     for (auto& l : m.layers) { prepare_fast_inference(l); if (l.kind == L_CONV) l.wfft = conv_weight_fft(l); }
     Trace tr = run_model(m, std::vector<int64_t>(input, input + ninput));
-    const auto& o = tr.out.back();
+    const std::vector<int64_t> o = model_output(m, tr);
     DP_REQUIRE(*noutput >= o.size(), DP_ERR_ARG, "output buffer too small");
     memcpy(output, o.data(), o.size() * 8); *noutput = o.size();
   });

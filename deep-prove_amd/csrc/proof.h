@@ -29,12 +29,16 @@ struct BasefoldProof {
   std::vector<FieldVec> trivial_proof;
   bool is_trivial() const { return sumcheck_messages.empty() && queries.empty() && sumcheck_proof.empty(); }
 };
-enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8, L_POSITIONAL = 9 };
+enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8, L_POSITIONAL = 9,
+                 L_MATMUL2 = 10, L_ADD2 = 11, L_CONCAT_MATMUL = 12, L_QKV = 13 };  // the two-input forms of MatMul / Add, ConcatMatMul, QKV (nodes of a model GRAPH)
 struct DenseProof { IOPProof sumcheck; Ext bias_eval; std::vector<Ext> individual_claims; };
 struct AddProof { Ext left_eval = ex_zero(), right_eval = ex_zero(); };  // layers/add.rs:59-63
 struct PositionalProof { std::vector<Ext> sub_matrix_evals; AddProof add_proof; };  // SinglePositionalProof (transformer/positional.rs:45-55), one input
 struct MatMulProof { IOPProof sumcheck; std::vector<Ext> individual_claims; bool has_bias = false; Ext bias_eval = ex_zero(); };  // layers/matrix_mul.rs:153-161 (bias_eval: Option<E>)
 struct SamePolyProof { IOPProof sumcheck; std::vector<Ext> evals; };
+struct ConcatMatMulProof { IOPProof sumcheck; std::vector<Ext> individual_claims; };  // layers/concat_matmul.rs:365-373: beta, left, right
+// layers/transformer/qkv.rs:63-83 (declaration order); individual_claims: (input, weight) evaluations of Q, of K, of V
+struct QKVProof { IOPProof sumcheck; SamePolyProof aggregation; std::vector<Ext> pre_bias_evals; std::vector<Ext> individual_claims; };
 struct ActivationProof { SamePolyProof io_accumulation; LogUpProof lookup; std::vector<Commitment> commits; };
 struct RequantProof { IOPProof io_accumulation; std::vector<Ext> accumulation_evals; LogUpProof clamping_lookup, shifted_lookup; std::vector<Commitment> commitments; };
 struct HadamardProof { IOPProof sumcheck; std::vector<Ext> individual_claim; };  // layers/hadamard.rs:51-56
@@ -51,7 +55,7 @@ struct ConvProof {  // layers/convolution.rs:98-127, fields in declaration order
   HadamardProof clearing_proof;
 };
 struct PoolingProof { IOPProof sumcheck; LogUpProof lookup; std::vector<Ext> zerocheck_evals; size_t variable_gap = 0; std::vector<Commitment> commitments; };  // layers/pooling.rs:60-76
-struct LayerProof { int kind = 0; DenseProof dense; MatMulProof matmul; AddProof add; PositionalProof pos; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; };
+struct LayerProof { int kind = 0; DenseProof dense; MatMulProof matmul; AddProof add; PositionalProof pos; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; ConcatMatMulProof cmm; QKVProof qkv; };
 struct TableProof { Commitment multiplicity_commit; LogUpProof lookup; };
 struct Proof {
   std::map<size_t, LayerProof> steps;
@@ -109,7 +113,10 @@ inline std::vector<u64> serialize_proof(const Proof& p) {
     else if (lp.kind == L_ADD) { w.e(lp.add.left_eval); w.e(lp.add.right_eval); }
     else if (lp.kind == L_POSITIONAL) { w.u(1); w.ve(lp.pos.sub_matrix_evals); w.e(lp.pos.add_proof.left_eval); w.e(lp.pos.add_proof.right_eval); }  // PositionalProof {proofs: one per input}
     else if (lp.kind == L_EMBED) { w.iop(lp.matmul.sumcheck); w.ve(lp.matmul.individual_claims); }  // EmbeddingsProof {sumcheck, individual_claims} (embeddings.rs:60-67)
-    else if (lp.kind == L_MATMUL) { w.iop(lp.matmul.sumcheck); w.ve(lp.matmul.individual_claims); w.u(lp.matmul.has_bias ? 1 : 0); if (lp.matmul.has_bias) w.e(lp.matmul.bias_eval); }
+    else if (lp.kind == L_ADD2) { w.e(lp.add.left_eval); w.e(lp.add.right_eval); }
+    else if (lp.kind == L_MATMUL || lp.kind == L_MATMUL2) { w.iop(lp.matmul.sumcheck); w.ve(lp.matmul.individual_claims); w.u(lp.matmul.has_bias ? 1 : 0); if (lp.matmul.has_bias) w.e(lp.matmul.bias_eval); }
+    else if (lp.kind == L_CONCAT_MATMUL) { w.iop(lp.cmm.sumcheck); w.ve(lp.cmm.individual_claims); }
+    else if (lp.kind == L_QKV) { w.iop(lp.qkv.sumcheck); w.iop(lp.qkv.aggregation.sumcheck); w.ve(lp.qkv.aggregation.evals); w.ve(lp.qkv.pre_bias_evals); w.ve(lp.qkv.individual_claims); }
     else if (lp.kind == L_REQUANT) {
       w.iop(lp.req.io_accumulation); w.ve(lp.req.accumulation_evals); w.logup(lp.req.clamping_lookup); w.logup(lp.req.shifted_lookup);
       w.u(lp.req.commitments.size()); for (auto& c : lp.req.commitments) w.comm(c);
@@ -190,7 +197,10 @@ inline Proof deserialize_proof(const u64* words, size_t n) {
     else if (lp.kind == L_ADD) { lp.add.left_eval = r.e(); lp.add.right_eval = r.e(); }
     else if (lp.kind == L_EMBED) { lp.matmul.sumcheck = r.iop(); lp.matmul.individual_claims = r.ve(); }
     else if (lp.kind == L_POSITIONAL) { DP_REQUIRE(r.u() == 1, DP_ERR_ARG, "proof stream: positional proofs per node"); lp.pos.sub_matrix_evals = r.ve(); lp.pos.add_proof.left_eval = r.e(); lp.pos.add_proof.right_eval = r.e(); }
-    else if (lp.kind == L_MATMUL) { lp.matmul.sumcheck = r.iop(); lp.matmul.individual_claims = r.ve(); u64 hb = r.u(); DP_REQUIRE(hb <= 1, DP_ERR_ARG, "proof stream: matmul bias flag"); lp.matmul.has_bias = hb != 0; if (hb) lp.matmul.bias_eval = r.e(); }
+    else if (lp.kind == L_ADD2) { lp.add.left_eval = r.e(); lp.add.right_eval = r.e(); }
+    else if (lp.kind == L_MATMUL || lp.kind == L_MATMUL2) { lp.matmul.sumcheck = r.iop(); lp.matmul.individual_claims = r.ve(); u64 hb = r.u(); DP_REQUIRE(hb <= (lp.kind == L_MATMUL ? 1u : 0u), DP_ERR_ARG, "proof stream: matmul bias flag"); lp.matmul.has_bias = hb != 0; if (hb) lp.matmul.bias_eval = r.e(); }
+    else if (lp.kind == L_CONCAT_MATMUL) { lp.cmm.sumcheck = r.iop(); lp.cmm.individual_claims = r.ve(); }
+    else if (lp.kind == L_QKV) { lp.qkv.sumcheck = r.iop(); lp.qkv.aggregation.sumcheck = r.iop(); lp.qkv.aggregation.evals = r.ve(); lp.qkv.pre_bias_evals = r.ve(); lp.qkv.individual_claims = r.ve(); }
     else if (lp.kind == L_REQUANT) {
       lp.req.io_accumulation = r.iop(); lp.req.accumulation_evals = r.ve(); lp.req.clamping_lookup = r.logup(); lp.req.shifted_lookup = r.logup();
       size_t k = r.len(); lp.req.commitments.resize(k); for (auto& c : lp.req.commitments) c = r.comm();

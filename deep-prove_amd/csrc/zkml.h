@@ -24,8 +24,21 @@ constexpr unsigned Q_BIT_LEN = 8;
 constexpr int64_t Q_MIN = -127, Q_MAX = 127;
 constexpr int64_t COLUMN_SEPARATOR = int64_t(1) << 32;
 
+// Edge of the model graph (Edge, layers/provable/mod.rs:195-229): tensor `slot` produced by node `from`; from < 0: input tensor `slot` of the model
+struct Edge { int from = -1; int slot = 0; };
 struct LayerSpec {
   int kind = L_DENSE;
+  // the node's input edges (Node::inputs); empty = the chain form (output 0 of the node before, the model input for node 0). Nodes are
+  // stored in a topological order: an edge always comes from a smaller id.
+  std::vector<Edge> inputs;
+  // matmul2 (layers/matrix_mul.rs, both operands inputs): [s][nrows] x [nrows][ncols] ([ncols][nrows] under mm_transpose), no bias.
+  // add2 (layers/add.rs, no operand): add_left * a + add_right * b.
+  // qkv (layers/transformer/qkv.rs): weights = W_q | W_k | W_v ([nrows][ncols] each), bias = b_q | b_k | b_v ([ncols] each); outputs Q, K, V.
+  // concat matmul (layers/concat_matmul.rs): rank-3 inputs of shapes cm_a, cm_b; cm_left / cm_right = (concat, mat_mul, output) dimension of
+  // each input; cm_perm = permutation of the [concat][rows][cols] result, empty for none.
+  size_t cm_a[3] = {0, 0, 0}, cm_b[3] = {0, 0, 0};
+  int cm_left[3] = {0, 2, 1}, cm_right[3] = {0, 1, 2};
+  std::vector<int> cm_perm;
   size_t nrows = 0, ncols = 0;
   std::vector<int64_t> weights, bias;  // dense: row major / padded bias; conv: filter [kw][kx][real_nw][real_nw], bias [kw]
   // matmul (layers/matrix_mul.rs, MatMul::new_constant: Input x Weight [+ bias]): the constant RIGHT matrix is weights[nrows][ncols] row major,
@@ -54,7 +67,77 @@ struct LayerSpec {
   unsigned shift() const { return fp_scale + right_shift; }
   unsigned clamping_size() const { return intermediate_bit_size + dp_ceil_log2((size_t)fixed_point_multiplier) - shift(); }
 };
-struct ModelSpec { size_t input_len = 0; std::vector<LayerSpec> layers; };
+// input_lens: the input tensors of the model (empty: a single one of input_len words; otherwise input_len is their sum and an input vector
+// their concatenation); outputs: the edges that are the model's output tensors (empty: output 0 of the last node), concatenated likewise
+struct ModelSpec { size_t input_len = 0; std::vector<LayerSpec> layers; std::vector<size_t> input_lens; std::vector<Edge> outputs; };
+inline size_t out_degree(const LayerSpec& l) { return l.kind == L_QKV ? 3 : 1; }
+inline size_t in_degree(const LayerSpec& l) { return l.kind == L_MATMUL2 || l.kind == L_ADD2 || l.kind == L_CONCAT_MATMUL ? 2 : 1; }
+inline std::vector<Edge> edges_in(const ModelSpec& m, size_t id) {
+  if (!m.layers[id].inputs.empty()) return m.layers[id].inputs;
+  Edge e; e.from = (int)id - 1; e.slot = 0;  // (node 0: from = -1, the model input)
+  return {e};
+}
+inline std::vector<Edge> output_edges(const ModelSpec& m) {
+  if (!m.outputs.empty()) return m.outputs;
+  Edge e; e.from = (int)m.layers.size() - 1;
+  return {e};
+}
+inline std::vector<size_t> input_tensor_lens(const ModelSpec& m) { if (m.input_lens.empty()) return {m.input_len}; return m.input_lens; }
+// Who reads tensor (node, slot): input `port` of node `to`, or — to < 0 — output number `port` of the model. The reference proves graphs in
+// which every tensor has exactly one reader (claims_for_node, provable/mod.rs:235-270); anything else is refused.
+struct Reader_ { int to = -1; int port = 0; };
+inline Reader_ reader_of(const ModelSpec& m, int node, int slot) {
+  Reader_ r; int n = 0;
+  for (size_t id = 0; id < m.layers.size(); id++) { const std::vector<Edge> in = edges_in(m, id); for (size_t q = 0; q < in.size(); q++) if (in[q].from == node && in[q].slot == slot) { r.to = (int)id; r.port = (int)q; n++; } }
+  const std::vector<Edge> outs = output_edges(m);
+  for (size_t q = 0; q < outs.size(); q++) if (outs[q].from == node && outs[q].slot == slot) { r.to = -1; r.port = (int)q; n++; }
+  DP_REQUIRE(n == 1, DP_ERR_SHAPE, "model graph: every tensor needs exactly one reader");
+  return r;
+}
+// The order in which Prover::prove and verify walk the nodes (NodeIterator<_, false>, model/iterator.rs:152-185): repeatedly the SMALLEST id
+// among the nodes all of whose readers have been handled. For a chain: last node first.
+inline std::vector<size_t> proving_order(const ModelSpec& m) {
+  const size_t n = m.layers.size();
+  std::vector<char> handled(n, 0);
+  std::vector<size_t> order;
+  while (order.size() < n) {
+    size_t pick = n;
+    for (size_t id = 0; id < n && pick == n; id++) {
+      if (handled[id]) continue;
+      bool ok = true;
+      for (size_t j = 0; j < out_degree(m.layers[id]) && ok; j++) { const Reader_ r = reader_of(m, (int)id, (int)j); ok = r.to < 0 || handled[(size_t)r.to]; }
+      if (ok) pick = id;
+    }
+    DP_REQUIRE(pick < n, DP_ERR_SHAPE, "model graph: cycle");
+    handled[pick] = 1; order.push_back(pick);
+  }
+  return order;
+}
+// Tensor::permute3d (tensor.rs:1769-1800): axis d of the result is axis order[d] of x
+template <class T> inline std::vector<T> transpose3(const std::vector<T>& x, const size_t dims[3], const int order[3]) {
+  const size_t nd[3] = {dims[order[0]], dims[order[1]], dims[order[2]]};
+  std::vector<T> y(x.size());
+  size_t at[3];
+  for (at[0] = 0; at[0] < dims[0]; at[0]++) for (at[1] = 0; at[1] < dims[1]; at[1]++) for (at[2] = 0; at[2] < dims[2]; at[2]++)
+    y[(at[order[0]] * nd[1] + at[order[1]]) * nd[2] + at[order[2]]] = x[(at[0] * dims[1] + at[1]) * dims[2] + at[2]];
+  return y;
+}
+// ConcatMatMul geometry: an input described by (concat, mat_mul, output) axes is brought to the axes `want` by the order this returns
+// (InputMatrixDimensions::compute_permutation, concat_matmul.rs:101-114); `identity` when nothing moves
+inline void cm_axes_to(const int have[3], const int want[3], int order[3], bool& identity) {
+  identity = have[0] == want[0] && have[1] == want[1] && have[2] == want[2];
+  order[0] = 0; order[1] = 1; order[2] = 2;
+  if (!identity) for (int q = 0; q < 3; q++) order[want[q]] = have[q];
+}
+constexpr int CM_WANT_LEFT[3] = {0, 2, 1}, CM_WANT_RIGHT[3] = {0, 1, 2};  // [concat][rows][inner] times [concat][inner][cols] (concat_matmul.rs:443-465)
+struct CmShape { size_t C, R, M, N; size_t out[3]; };  // chunks, rows, inner, columns; the (permuted) shape of the result
+inline CmShape cm_shape(const LayerSpec& l) {
+  CmShape g;
+  g.C = l.cm_a[l.cm_left[0]]; g.R = l.cm_a[l.cm_left[2]]; g.M = l.cm_a[l.cm_left[1]]; g.N = l.cm_b[l.cm_right[2]];
+  const size_t r[3] = {g.C, g.R, g.N};
+  for (int d = 0; d < 3; d++) g.out[d] = l.cm_perm.empty() ? r[d] : r[l.cm_perm[d]];
+  return g;
+}
 
 struct TableType {
   int kind; unsigned size;  // 0 Relu, 2 Range, 3 Clamping(size)  (derive(Ord) order of lookup/context.rs:55-72)
@@ -80,7 +163,11 @@ struct ConvTrace {
   std::vector<u64> prod;        // [kw][2n^2]: sum_j FFT(x_j) o FFT(w_ij)
   std::vector<int64_t> output_as_element;  // conv output after the bias, before clearing (convolution.rs:311-316)
 };
-struct Trace { std::vector<std::vector<int64_t>> in, out; std::vector<ConvTrace> conv; };
+// per node: first input, first output; in2 = second input of a two-input node; more_out = the outputs after the first (QKV: K, V)
+struct Trace {
+  std::vector<std::vector<int64_t>> in, out, in2; std::vector<std::vector<std::vector<int64_t>>> more_out; std::vector<ConvTrace> conv;
+  const std::vector<int64_t>& tensor(int node, int slot) const { return slot == 0 ? out[(size_t)node] : more_out[(size_t)node][(size_t)slot - 1]; }
+};
 // FFT of every kernel of a convolution, zero-padded to 2 nw^2 (index_w, tensor.rs:236-254): computed once per model —
 // the reference recomputes these kw*kx transforms at every inference (tensor.rs:494-507)
 inline std::shared_ptr<const std::vector<u64>> conv_weight_fft(const LayerSpec& l) {
@@ -151,16 +238,37 @@ inline std::vector<std::vector<int64_t>> maxpool_diff_polys(const LayerSpec& l, 
   return cols;
 }
 // length of the model's output tensor (the shape propagation of run_model without the arithmetic)
-inline size_t model_output_len(const ModelSpec& m) {
-  size_t cur = m.input_len;
-  for (const LayerSpec& l : m.layers) {
+// lens[id] = length of (each of) node id's output tensors; in_len[id] = length of its first input
+inline void tensor_lens(const ModelSpec& m, std::vector<size_t>& lens, std::vector<size_t>* in_len = nullptr, std::vector<size_t>* in2_len = nullptr) {
+  const std::vector<size_t> ins = input_tensor_lens(m);
+  lens.assign(m.layers.size(), 0);
+  if (in_len) in_len->assign(m.layers.size(), 0);
+  if (in2_len) in2_len->assign(m.layers.size(), 0);
+  for (size_t id = 0; id < m.layers.size(); id++) {
+    const LayerSpec& l = m.layers[id];
+    const std::vector<Edge> e = edges_in(m, id);
+    DP_REQUIRE(e.size() == in_degree(l), DP_ERR_SHAPE, "model graph: wrong number of inputs for a node");
+    size_t got[2] = {0, 0};
+    for (size_t q = 0; q < e.size(); q++) {
+      DP_REQUIRE(e[q].from < (int)id && (e[q].from >= 0 ? e[q].slot >= 0 && (size_t)e[q].slot < out_degree(m.layers[(size_t)e[q].from]) : e[q].slot >= 0 && (size_t)e[q].slot < ins.size()), DP_ERR_SHAPE, "model graph: an edge must come from an earlier node or a model input");
+      got[q] = e[q].from < 0 ? ins[(size_t)e[q].slot] : lens[(size_t)e[q].from];
+    }
+    size_t cur = got[0];
+    if (in_len) (*in_len)[id] = got[0];
+    if (in2_len) (*in2_len)[id] = got[1];
     if (l.kind == L_DENSE) cur = l.nrows;
-    else if (l.kind == L_MATMUL) cur = cur / l.nrows * l.ncols;
+    else if (l.kind == L_MATMUL || l.kind == L_MATMUL2 || l.kind == L_QKV) cur = l.nrows ? cur / l.nrows * l.ncols : 0;
     else if (l.kind == L_EMBED) cur = cur * l.ncols;
     else if (l.kind == L_CONV) cur = l.kw * l.nw * l.nw;
     else if (l.kind == L_MAXPOOL) cur = l.pin[0] * (l.pin[1] / 2) * (l.pin[2] / 2);
+    else if (l.kind == L_CONCAT_MATMUL) { const CmShape g = cm_shape(l); cur = g.out[0] * g.out[1] * g.out[2]; }
+    lens[id] = cur;
   }
-  return cur;
+}
+inline size_t model_output_len(const ModelSpec& m) {
+  std::vector<size_t> lens; tensor_lens(m, lens);
+  size_t n = 0; for (const Edge& e : output_edges(m)) n += lens.at((size_t)e.from);
+  return n;
 }
 // the two inner loops of the int16 inference paths, cloned for the vector ISAs of the host (resolved once at load time): the library is
 // built for baseline x86-64, where 32-bit multiplies do not vectorise
@@ -181,12 +289,74 @@ inline void prepare_fast_inference(LayerSpec& l) {
   for (size_t j = 0; j < l.weights.size(); j++) (*w16)[j] = (int16_t)l.weights[j];
   l.w16 = w16; l.w16_max = wm;
 }
+// the model's output tensors, concatenated (ModelSpec::outputs order)
+inline std::vector<int64_t> model_output(const ModelSpec& m, const Trace& tr) {
+  const std::vector<Edge> outs = output_edges(m);
+  if (outs.size() == 1) return tr.tensor(outs[0].from, outs[0].slot);
+  std::vector<int64_t> o;
+  for (const Edge& e : outs) { const std::vector<int64_t>& v = tr.tensor(e.from, e.slot); o.insert(o.end(), v.begin(), v.end()); }
+  return o;
+}
+// plain integer products of the two-input nodes (tiny next to the proving that follows)
+inline std::vector<int64_t> matmul_i64(const int64_t* a, const int64_t* b, size_t s_, size_t k, size_t n, bool b_transposed) {
+  std::vector<int64_t> o(s_ * n, 0);
+  for (size_t i = 0; i < s_; i++) {
+    int64_t* row = &o[i * n];
+    if (b_transposed) for (size_t j = 0; j < n; j++) { int64_t acc = 0; for (size_t q = 0; q < k; q++) acc += a[i * k + q] * b[j * k + q]; row[j] = acc; }
+    else for (size_t q = 0; q < k; q++) { const int64_t x = a[i * k + q]; const int64_t* w = b + q * n; for (size_t j = 0; j < n; j++) row[j] += x * w[j]; }
+  }
+  return o;
+}
 inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
-  Trace tr; std::vector<int64_t> cur = input;
-  DP_REQUIRE(cur.size() == m.input_len, DP_ERR_SHAPE, "input length mismatch");
-  for (auto& l : m.layers) {
+  Trace tr;
+  DP_REQUIRE(input.size() == m.input_len, DP_ERR_SHAPE, "input length mismatch");
+  const std::vector<size_t> in_lens = input_tensor_lens(m);
+  auto fetch = [&](const Edge& e) -> std::vector<int64_t> {
+    if (e.from >= 0) { DP_REQUIRE((size_t)e.from < tr.out.size(), DP_ERR_SHAPE, "model graph: an edge must come from an earlier node"); return tr.tensor(e.from, e.slot); }
+    size_t off = 0; for (int q = 0; q < e.slot; q++) off += in_lens.at((size_t)q);
+    DP_REQUIRE((size_t)e.slot < in_lens.size() && off + in_lens[(size_t)e.slot] <= input.size(), DP_ERR_SHAPE, "model graph: input tensor");
+    return std::vector<int64_t>(input.begin() + off, input.begin() + off + in_lens[(size_t)e.slot]);
+  };
+  tr.in2.resize(m.layers.size()); tr.more_out.resize(m.layers.size());
+  for (size_t id = 0; id < m.layers.size(); id++) {
+    const LayerSpec& l = m.layers[id];
+    const std::vector<Edge> edges = edges_in(m, id);
+    DP_REQUIRE(edges.size() == in_degree(l), DP_ERR_SHAPE, "model graph: wrong number of inputs for a node");
+    std::vector<int64_t> cur = m.layers[id].inputs.empty() && id > 0 ? tr.out[id - 1] : fetch(edges[0]);
     tr.in.push_back(cur);
+    if (edges.size() > 1) tr.in2[id] = fetch(edges[1]);
     std::vector<int64_t> o;
+    if (l.kind == L_MATMUL2) {  // MatMul::op (matrix_mul.rs:230-311) on two inputs
+      const std::vector<int64_t>& b = tr.in2[id];
+      DP_REQUIRE(l.nrows && cur.size() % l.nrows == 0 && b.size() == l.nrows * l.ncols, DP_ERR_SHAPE, "matmul2: input shapes");
+      o = matmul_i64(cur.data(), b.data(), cur.size() / l.nrows, l.nrows, l.ncols, l.mm_transpose);
+    } else if (l.kind == L_ADD2) {  // Add::evaluate (add.rs:184-210) without operand
+      const std::vector<int64_t>& b = tr.in2[id];
+      DP_REQUIRE(cur.size() == b.size(), DP_ERR_SHAPE, "add2: inputs of different lengths");
+      o.resize(cur.size());
+      for (size_t i = 0; i < cur.size(); i++) o[i] = l.add_left * cur[i] + l.add_right * b[i];
+    } else if (l.kind == L_QKV) {  // QKV::evaluate (qkv.rs:275-340, no cache)
+      const size_t k = l.nrows, n = l.ncols;
+      DP_REQUIRE(k && cur.size() % k == 0 && l.weights.size() == 3 * k * n && l.bias.size() == 3 * n, DP_ERR_SHAPE, "qkv: shapes");
+      for (size_t w = 0; w < 3; w++) {
+        std::vector<int64_t> y = matmul_i64(cur.data(), &l.weights[w * k * n], cur.size() / k, k, n, false);
+        for (size_t i = 0; i < y.size(); i++) y[i] += l.bias[w * n + i % n];
+        if (w == 0) o = std::move(y); else tr.more_out[id].push_back(std::move(y));
+      }
+    } else if (l.kind == L_CONCAT_MATMUL) {  // ConcatMatMul::evaluate (concat_matmul.rs:568-616)
+      const std::vector<int64_t>& b0 = tr.in2[id];
+      DP_REQUIRE(cur.size() == l.cm_a[0] * l.cm_a[1] * l.cm_a[2] && b0.size() == l.cm_b[0] * l.cm_b[1] * l.cm_b[2], DP_ERR_SHAPE, "concat matmul: input shapes");
+      const CmShape g = cm_shape(l);
+      int order[3]; bool same;
+      cm_axes_to(l.cm_left, CM_WANT_LEFT, order, same);
+      const std::vector<int64_t> a = same ? cur : transpose3(cur, l.cm_a, order);
+      cm_axes_to(l.cm_right, CM_WANT_RIGHT, order, same);
+      const std::vector<int64_t> b = same ? b0 : transpose3(b0, l.cm_b, order);
+      std::vector<int64_t> r;
+      for (size_t c = 0; c < g.C; c++) { std::vector<int64_t> y = matmul_i64(&a[c * g.R * g.M], &b[c * g.M * g.N], g.R, g.M, g.N, false); r.insert(r.end(), y.begin(), y.end()); }
+      if (l.cm_perm.empty()) o = std::move(r);
+      else { const size_t rs[3] = {g.C, g.R, g.N}; const int po[3] = {l.cm_perm[0], l.cm_perm[1], l.cm_perm[2]}; o = transpose3(r, rs, po); }
+    } else
     if (l.kind == L_DENSE) {
       DP_REQUIRE(cur.size() == l.ncols, DP_ERR_SHAPE, "dense input size mismatch");
       o.resize(l.nrows);
@@ -249,7 +419,7 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
     else if (l.kind == L_MAXPOOL) o = maxpool_op(l, cur);
     else if (l.kind == L_FLATTEN) o = cur;
     else DP_REQUIRE(false, DP_ERR_ARG, "unknown layer kind");
-    tr.out.push_back(o); cur = o;
+    tr.out.push_back(std::move(o));
   }
   return tr;
 }
@@ -276,7 +446,7 @@ struct Context {
   std::map<size_t, ConvDev> conv_dev;
   std::vector<TableType> tables;
   VerifierContext verifier_ctx() const {
-    VerifierContext v; v.full_log = full_log; v.tables = tables; v.shape.input_len = model.input_len;
+    VerifierContext v; v.full_log = full_log; v.tables = tables; v.shape.input_len = model.input_len; v.shape.input_lens = model.input_lens; v.shape.outputs = model.outputs;
     for (auto& l : model.layers) { LayerSpec s = l; s.weights.clear(); s.bias.clear(); s.wfft.reset(); s.w16.reset(); v.shape.layers.push_back(s); }
     for (auto& kv : model_comms) for (auto& pc : kv.second) v.model_comms[kv.first][pc.first] = pure_commitment(pc.second);
     return v;
@@ -289,9 +459,31 @@ struct Context {
 };
 
 inline void validate_model(const ModelSpec& m) {
-  DP_REQUIRE(is_pow2(m.input_len) && !m.layers.empty(), DP_ERR_SHAPE, "model: input length must be a power of two");
-  size_t cur = m.input_len;
-  for (auto& l : m.layers) {
+  DP_REQUIRE(!m.layers.empty() && m.layers.size() < 4096, DP_ERR_SHAPE, "model: no layers");
+  { size_t tot = 0; for (size_t n : input_tensor_lens(m)) { DP_REQUIRE(is_pow2(n), DP_ERR_SHAPE, "model: input length must be a power of two"); tot += n; }
+    DP_REQUIRE(tot == m.input_len, DP_ERR_SHAPE, "model: the input tensors do not add up to input_len"); }
+  std::vector<size_t> lens, in_len, in2_len;
+  tensor_lens(m, lens, &in_len, &in2_len);
+  for (const Edge& e : output_edges(m)) DP_REQUIRE(e.from >= 0 && (size_t)e.from < m.layers.size() && e.slot >= 0 && (size_t)e.slot < out_degree(m.layers[(size_t)e.from]), DP_ERR_SHAPE, "model graph: output edge");
+  for (size_t id = 0; id < m.layers.size(); id++) for (size_t j = 0; j < out_degree(m.layers[id]); j++) reader_of(m, (int)id, (int)j);  // exactly one reader each
+  { std::vector<size_t> ins = input_tensor_lens(m); for (size_t q = 0; q < ins.size(); q++) reader_of(m, -1, (int)q); }
+  for (size_t id = 0; id < m.layers.size(); id++) {
+    const LayerSpec& l = m.layers[id];
+    size_t cur = in_len[id];
+    if (l.kind == L_MATMUL2) {
+      DP_REQUIRE(is_pow2(l.nrows) && is_pow2(l.ncols) && l.nrows >= 2 && l.ncols >= 2 && cur % l.nrows == 0 && cur / l.nrows >= 2 && is_pow2(cur) && in2_len[id] == l.nrows * l.ncols && l.weights.empty() && l.bias.empty(), DP_ERR_SHAPE, "matmul2: [s][k] x [k][n] with powers of two >= 2");
+    } else if (l.kind == L_ADD2) {
+      DP_REQUIRE(cur >= 2 && in2_len[id] == cur && l.add_left > 0 && l.add_right > 0 && l.add_left < (int64_t(1) << 40) && l.add_right < (int64_t(1) << 40), DP_ERR_SHAPE, "add2: two inputs of one length, positive multipliers");
+    } else if (l.kind == L_QKV) {
+      DP_REQUIRE(is_pow2(l.nrows) && is_pow2(l.ncols) && l.nrows >= 2 && l.ncols >= 2 && cur % l.nrows == 0 && cur / l.nrows >= 2 && is_pow2(cur) && l.weights.size() == 3 * l.nrows * l.ncols && l.bias.size() == 3 * l.ncols, DP_ERR_SHAPE, "qkv: [s][k] input, three [k][n] matrices and [n] biases, powers of two >= 2");
+    } else if (l.kind == L_CONCAT_MATMUL) {
+      for (int d = 0; d < 3; d++) DP_REQUIRE(is_pow2(l.cm_a[d]) && is_pow2(l.cm_b[d]), DP_ERR_SHAPE, "concat matmul: padded shapes must be powers of two");
+      auto is_perm = [](const int* p) { return p[0] >= 0 && p[0] < 3 && p[1] >= 0 && p[1] < 3 && p[2] >= 0 && p[2] < 3 && p[0] != p[1] && p[0] != p[2] && p[1] != p[2]; };
+      DP_REQUIRE(is_perm(l.cm_left) && is_perm(l.cm_right) && (l.cm_perm.empty() || (l.cm_perm.size() == 3 && is_perm(l.cm_perm.data()))), DP_ERR_SHAPE, "concat matmul: dimension triples must be permutations of 0, 1, 2");
+      DP_REQUIRE(cur == l.cm_a[0] * l.cm_a[1] * l.cm_a[2] && in2_len[id] == l.cm_b[0] * l.cm_b[1] * l.cm_b[2], DP_ERR_SHAPE, "concat matmul: input lengths");
+      DP_REQUIRE(l.cm_a[l.cm_left[0]] == l.cm_b[l.cm_right[0]] && l.cm_a[l.cm_left[1]] == l.cm_b[l.cm_right[1]] && l.cm_a[l.cm_left[1]] >= 2, DP_ERR_SHAPE, "concat matmul: concat / mat_mul dimensions of the two inputs differ");
+      DP_REQUIRE(lens[id] >= 2, DP_ERR_SHAPE, "concat matmul: output of one entry");
+    } else
     if (l.kind == L_DENSE) {
       DP_REQUIRE(is_pow2(l.nrows) && is_pow2(l.ncols) && l.nrows >= 2 && l.ncols >= 2, DP_ERR_SHAPE, "dense: padded dimensions must be powers of two >= 2");
       DP_REQUIRE(l.ncols == cur && l.weights.size() == l.nrows * l.ncols && l.bias.size() == l.nrows, DP_ERR_SHAPE, "dense: tensor sizes");
@@ -338,26 +530,37 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
   validate_model(m);
   std::unique_ptr<Context> ctx(new Context());
   ctx->dev = &dev; ctx->model = m;
-  size_t mpl = m.input_len, cur = m.input_len;
+  size_t mpl = 0;
+  for (size_t n : input_tensor_lens(m)) mpl = std::max(mpl, n);
   std::vector<TableType> ts;
   auto add = [&](TableType t) { for (auto& x : ts) if (x == t) return; ts.push_back(t); };
-  for (auto& l : m.layers) {
-    if (l.kind == L_DENSE) cur = l.nrows;
-    else if (l.kind == L_MATMUL) cur = cur / l.nrows * l.ncols;
-    else if (l.kind == L_EMBED) cur = cur * l.ncols;
-    else if (l.kind == L_REQUANT) { add({2, 0}); add({3, l.clamping_size()}); mpl = std::max(mpl, next_pow2(cur)); }
+  std::vector<size_t> lens; tensor_lens(m, lens);
+  for (size_t id = 0; id < m.layers.size(); id++) {
+    const LayerSpec& l = m.layers[id];
+    const size_t cur = lens[id];  // (Requant / Relu: also the length of the input; MaxPool: of the output, as the committed polynomials are)
+    if (l.kind == L_REQUANT) { add({2, 0}); add({3, l.clamping_size()}); mpl = std::max(mpl, next_pow2(cur)); }
     else if (l.kind == L_RELU) { add({0, 0}); mpl = std::max(mpl, next_pow2(cur)); }
-    else if (l.kind == L_CONV) cur = l.kw * l.nw * l.nw;
-    else if (l.kind == L_MAXPOOL) { add({2, 0}); cur /= 4; mpl = std::max(mpl, next_pow2(cur)); }
+    else if (l.kind == L_MAXPOOL) { add({2, 0}); mpl = std::max(mpl, next_pow2(cur)); }
   }
   std::sort(ts.begin(), ts.end());
   for (auto& t : ts) mpl = std::max(mpl, size_t(1) << t.vars());
+  for (auto& l : m.layers) if (l.kind == L_QKV) mpl = std::max(mpl, std::max(next_pow2(l.weights.size() / 3), next_pow2(l.bias.size() / 3)));
   for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD || l.kind == L_EMBED || l.kind == L_POSITIONAL) mpl = std::max(mpl, std::max(next_pow2(l.weights.size()), next_pow2(l.bias.size())));
   mpl = next_pow2(mpl);
   ctx->max_poly_len = mpl; ctx->full_log = dp_ceil_log2(mpl); ctx->tables = ts;
   dev.pcs_init(ctx->full_log);
   for (size_t id = 0; id < m.layers.size(); id++) {
     LayerSpec& l = ctx->model.layers[id];
+    if (l.kind == L_QKV) {  // six model polynomials (qkv.rs:388-418); the three weight matrices stay on the device side by side for the prover
+      const size_t kn = l.nrows * l.ncols, n = l.ncols;
+      static const char* const wn[3] = {"WeightQ", "WeightK", "WeightV"}; static const char* const bn[3] = {"BiasQ", "BiasK", "BiasV"};
+      for (size_t q = 0; q < 3; q++) {  // (each commitment owns its evaluation table: the prover reads the matrices from there)
+        DBuf w = dev.alloc_persistent(kn, false), b = dev.alloc_persistent(n, false);
+        dev.upload_i64(w, &l.weights[q * kn]); dev.upload_i64(b, &l.bias[q * n]);
+        ctx->model_comms[id][wn[q]] = dev.commit(w, true); ctx->model_comms[id][bn[q]] = dev.commit(b, true);
+      }
+      continue;
+    }
     if (l.kind != L_DENSE && l.kind != L_CONV && l.kind != L_MATMUL && l.kind != L_ADD && l.kind != L_EMBED && l.kind != L_POSITIONAL) continue;
     if (l.kind == L_POSITIONAL) {  // the whole table is the model polynomial (positional.rs:229,243-251)
       DBuf w = dev.alloc_persistent(l.weights.size(), false);
@@ -689,6 +892,161 @@ inline Claim prove_matmul(ProverState& ps, size_t id, const LayerSpec& l, const 
   return {point_left, sc.finals[0]};
 }
 
+// ---- nodes with two inputs or several outputs (the model as a graph, layers/provable/mod.rs:195-565)
+// MatMul::prove_step (layers/matrix_mul.rs:701-873) when BOTH operands are inputs of the node: the same degree-2 sumcheck over the inner
+// dimension; nothing is committed, both final evaluations leave as claims — [sumcheck point | row part] for the left input,
+// [column part | sumcheck point] (or [sumcheck point | column part] under TransposeB) for the right one.
+inline std::vector<Claim> prove_matmul2(ProverState& ps, size_t id, const LayerSpec& l, const Claim& last, const std::vector<int64_t>& a, const std::vector<int64_t>& b) {
+  Dev& dev = *ps.dev;
+  const size_t k = l.nrows, n = l.ncols, s_ = a.size() / k;
+  const unsigned nvc = dp_ceil_log2(n), nvr = dp_ceil_log2(s_);
+  DP_REQUIRE(is_pow2(s_) && s_ * k == a.size() && b.size() == k * n && last.point.size() == nvc + nvr, DP_ERR_SHAPE, "matmul2: claim point length");
+  size_t mk = dev.mark();
+  std::vector<Ext> cols(last.point.begin(), last.point.begin() + nvc), rows(last.point.begin() + nvc, last.point.end());
+  DBuf da = dev.alloc(a.size(), false), db = dev.alloc(b.size(), false);
+  dev.upload_i64(da, a.data()); dev.upload_i64(db, b.data());
+  DBuf left = dev.alloc(k, true), right = dev.alloc(k, true);
+  dev.fix_high(left, da, s_, k, rows.data());
+  if (l.mm_transpose) dev.fix_high(right, db, n, k, cols.data()); else dev.fix_low(right, db, k, n, cols.data());
+  DevVP vp(dp_ceil_log2(k));
+  vp.add_mle_list({left, right}, ex_one());
+  SumcheckOut sc = sumcheck_prove(dev, vp, *ps.t);
+  dev.release(mk);
+  std::vector<Ext> pl = sc.proof.point; pl.insert(pl.end(), rows.begin(), rows.end());
+  std::vector<Ext> pr;
+  if (l.mm_transpose) { pr = sc.proof.point; pr.insert(pr.end(), cols.begin(), cols.end()); } else { pr = cols; pr.insert(pr.end(), sc.proof.point.begin(), sc.proof.point.end()); }
+  LayerProof lp; lp.kind = L_MATMUL2; lp.matmul.sumcheck = sc.proof; lp.matmul.individual_claims = sc.finals; lp.matmul.has_bias = false;
+  ps.proofs[id] = lp;
+  return {{pl, sc.finals[0]}, {pr, sc.finals[1]}};
+}
+// Add::prove_step without operand (layers/add.rs:81-145): both inputs at the claim's point in one Dev::mle_eval_batch
+inline std::vector<Claim> prove_add2(ProverState& ps, size_t id, const Claim& last, const std::vector<int64_t>& a, const std::vector<int64_t>& b) {
+  Dev& dev = *ps.dev;
+  DP_REQUIRE((size_t(1) << last.point.size()) == a.size() && a.size() == b.size(), DP_ERR_SHAPE, "add2: claim point length");
+  size_t mk = dev.mark();
+  DBuf tabs[2] = {dev.alloc(a.size(), false), dev.alloc(b.size(), false)};
+  dev.upload_i64(tabs[0], a.data()); dev.upload_i64(tabs[1], b.data());
+  Ext ev[2];
+  dev.mle_eval_batch(tabs, 2, last.point.data(), (unsigned)last.point.size(), ev);
+  dev.release(mk);
+  LayerProof lp; lp.kind = L_ADD2; lp.add.left_eval = ev[0]; lp.add.right_eval = ev[1];
+  ps.proofs[id] = lp;
+  return {{last.point, ev[0]}, {last.point, ev[1]}};
+}
+// The point of ConcatMatMul's output claim by axis (MatrixPermutations::split_output_claim_point, concat_matmul.rs:295-343): the last axis of
+// the (permuted) output owns the low coordinates; returned for the axes of the un-permuted [concat][rows][cols] result
+struct CmPoint { std::vector<Ext> concat, row, col; };
+inline CmPoint cm_split_point(const LayerSpec& l, const CmShape& g, const std::vector<Ext>& point) {
+  size_t nv[3], total = 0;
+  for (int d = 0; d < 3; d++) { nv[d] = dp_ceil_log2(g.out[d]); total += nv[d]; }
+  DP_REQUIRE(point.size() == total, DP_ERR_SHAPE, "concat matmul: claim point length");
+  std::vector<Ext> by_axis[3];
+  size_t end = point.size();
+  for (int d = 0; d < 3; d++) { by_axis[d].assign(point.begin() + (end - nv[d]), point.begin() + end); end -= nv[d]; }
+  int at[3] = {0, 1, 2};  // at[axis of the plain result] = where the permutation put it
+  if (!l.cm_perm.empty()) for (int i = 0; i < 3; i++) at[l.cm_perm[i]] = i;
+  return {by_axis[at[0]], by_axis[at[1]], by_axis[at[2]]};
+}
+// InputMatrixDimensions::input_mle_for_proving (concat_matmul.rs:134-166) on the device: the rank-3 input with the coordinates of its
+// OUTPUT axis fixed at `pt`; the table that is left runs over [concat][mat_mul]. Whether the tensor is re-laid first follows the reference
+// (it decides which axis the remaining variables see as low).
+inline DBuf cm_fix_output_axis(Dev& dev, const std::vector<int64_t>& x, const size_t dims[3], const int axes[3], const std::vector<Ext>& pt) {
+  const int concat = axes[0], mm = axes[1], outa = axes[2];
+  const size_t O = dims[outa], rest = x.size() / O;
+  DP_REQUIRE((size_t(1) << pt.size()) == O && O >= 2, DP_ERR_SHAPE, "concat matmul: output axis of fewer than two entries");
+  DBuf in = dev.alloc(x.size(), false), out = dev.alloc(rest, true);
+  if (concat > mm || outa == 1) {
+    const int order[3] = {concat, mm, outa};
+    const std::vector<int64_t> y = transpose3(x, dims, order);
+    dev.upload_i64(in, y.data());
+    dev.fix_low(out, in, rest, O, pt.data());
+  } else {
+    dev.upload_i64(in, x.data());
+    if (outa == 0) dev.fix_high(out, in, O, rest, pt.data()); else dev.fix_low(out, in, rest, O, pt.data());
+  }
+  return out;
+}
+// InputMatrixDimensions::build_point_for_input (concat_matmul.rs:116-132): the sub-points in the order of the input's axes, last axis first
+inline std::vector<Ext> cm_input_point(const int axes[3], const std::vector<Ext>& p_concat, const std::vector<Ext>& p_mm, const std::vector<Ext>& p_out) {
+  const std::vector<Ext>* of_axis[3] = {nullptr, nullptr, nullptr};
+  of_axis[axes[0]] = &p_concat; of_axis[axes[1]] = &p_mm; of_axis[axes[2]] = &p_out;
+  std::vector<Ext> pt;
+  for (int d = 2; d >= 0; d--) pt.insert(pt.end(), of_axis[d]->begin(), of_axis[d]->end());
+  return pt;
+}
+// ConcatMatMul::prove_step (concat_matmul.rs:467-566): one degree-3 sumcheck over (chunk, inner index) of beta(chunk) * A_chunk[row point][.]
+// * B_chunk[.][column point]; two claims out, one per input
+inline std::vector<Claim> prove_concat_matmul(ProverState& ps, size_t id, const LayerSpec& l, const Claim& last, const std::vector<int64_t>& a, const std::vector<int64_t>& b) {
+  Dev& dev = *ps.dev;
+  const CmShape g = cm_shape(l);
+  const CmPoint p = cm_split_point(l, g, last.point);
+  size_t mk = dev.mark();
+  DBuf left = cm_fix_output_axis(dev, a, l.cm_a, l.cm_left, p.row), right = cm_fix_output_axis(dev, b, l.cm_b, l.cm_right, p.col);
+  DP_REQUIRE(left.n == g.C * g.M && right.n == left.n, DP_ERR_SHAPE, "concat matmul: reduced tables");
+  std::vector<Ext> bc = host_eq_table(p.concat), bw(g.C * g.M);  // beta(chunk), repeated along the inner axis
+  for (size_t c = 0; c < g.C; c++) for (size_t j = 0; j < g.M; j++) bw[c * g.M + j] = bc[c];
+  DBuf beta = dev.alloc(bw.size(), true);
+  dev.upload(beta, (const u64*)bw.data());
+  DevVP vp(dp_ceil_log2(left.n));
+  vp.add_mle_list({beta, left, right}, ex_one());
+  SumcheckOut sc = sumcheck_prove(dev, vp, *ps.t);
+  dev.release(mk);
+  const unsigned nvm = dp_ceil_log2(g.M);  // split_sumcheck_point (:256-281): the inner coordinates come first
+  const std::vector<Ext> s_mm(sc.proof.point.begin(), sc.proof.point.begin() + nvm), s_concat(sc.proof.point.begin() + nvm, sc.proof.point.end());
+  LayerProof lp; lp.kind = L_CONCAT_MATMUL; lp.cmm.sumcheck = sc.proof; lp.cmm.individual_claims = sc.finals;
+  ps.proofs[id] = lp;
+  return {{cm_input_point(l.cm_left, s_concat, s_mm, p.row), sc.finals[1]}, {cm_input_point(l.cm_right, s_concat, s_mm, p.col), sc.finals[2]}};
+}
+inline SamePolyProof same_poly_prove(Dev& dev, const std::vector<Claim>& claims, const DBuf& poly, Transcript& t);
+// QKV::prove (layers/transformer/qkv.rs:462-630): X W_q, X W_k, X W_v proven by ONE sumcheck (coefficients 1, c1, c2 drawn after the output
+// points and the bias-free evaluations have been absorbed), the three resulting claims on X merged by same_poly; six claims go to the
+// commitments of the weights and biases
+inline std::vector<Claim> prove_qkv(ProverState& ps, size_t id, const LayerSpec& l, const std::vector<Claim>& last, const std::vector<int64_t>& input) {
+  Dev& dev = *ps.dev;
+  const size_t k = l.nrows, n = l.ncols, s_ = input.size() / k;
+  const unsigned nvc = dp_ceil_log2(n), nvr = dp_ceil_log2(s_);
+  DP_REQUIRE(last.size() == 3 && is_pow2(s_) && s_ * k == input.size(), DP_ERR_SHAPE, "qkv: three output claims expected");
+  static const char* const wn[3] = {"WeightQ", "WeightK", "WeightV"}; static const char* const bn[3] = {"BiasQ", "BiasK", "BiasV"};
+  const auto& comms = ps.ctx->model_comms.at(id);
+  size_t mk = dev.mark();
+  std::vector<Ext> rows[3], cols[3];
+  Ext bias_eval[3], pre[3];
+  for (int w = 0; w < 3; w++) {
+    DP_REQUIRE(last[w].point.size() == nvc + nvr, DP_ERR_SHAPE, "qkv: claim point length");
+    cols[w].assign(last[w].point.begin(), last[w].point.begin() + nvc); rows[w].assign(last[w].point.begin() + nvc, last[w].point.end());  // split_claim_point (:173-184)
+    dev.mle_eval_batch(&comms.at(bn[w]).evals, 1, cols[w].data(), nvc, &bias_eval[w]);
+    pre[w] = ex_sub(last[w].eval, bias_eval[w]);
+  }
+  for (int w = 0; w < 3; w++) { ps.t->append_exts(last[w].point); ps.t->append_ext(pre[w]); }  // challenges_for_batched_sumcheck (:210-232)
+  const Ext coeff[3] = {ex_one(), ps.t->read_challenge(), ps.t->read_challenge()};
+  DBuf in = dev.alloc(input.size(), false);
+  dev.upload_i64(in, input.data());
+  DevVP vp(dp_ceil_log2(k));
+  for (int w = 0; w < 3; w++) {
+    DBuf x = dev.alloc(k, true), wm = dev.alloc(k, true);
+    dev.fix_high(x, in, s_, k, rows[w].data());
+    dev.fix_low(wm, comms.at(wn[w]).evals, k, n, cols[w].data());
+    vp.add_mle_list({x, wm}, coeff[w]);
+  }
+  SumcheckOut sc = sumcheck_prove(dev, vp, *ps.t);
+  DP_REQUIRE(sc.finals.size() == 6, DP_ERR_SHAPE, "qkv: six final evaluations expected");
+  std::vector<Claim> on_input(3), on_weight(3);
+  for (int w = 0; w < 3; w++) {  // build_points (:193-204)
+    on_input[w].point = sc.proof.point; on_input[w].point.insert(on_input[w].point.end(), rows[w].begin(), rows[w].end()); on_input[w].eval = sc.finals[2 * w];
+    on_weight[w].point = cols[w]; on_weight[w].point.insert(on_weight[w].point.end(), sc.proof.point.begin(), sc.proof.point.end()); on_weight[w].eval = sc.finals[2 * w + 1];
+  }
+  // add_common_claims walks the node's polynomials in BTreeMap order: BiasK, BiasQ, BiasV, WeightK, WeightQ, WeightV
+  for (int w : {1, 0, 2}) ps.add_witness_claim(comms.at(bn[w]), {cols[w], bias_eval[w]});
+  for (int w : {1, 0, 2}) ps.add_witness_claim(comms.at(wn[w]), on_weight[w]);
+  DBuf xin = dev.alloc(input.size(), true);
+  { std::vector<u64> ww(2 * input.size()); for (size_t i = 0; i < input.size(); i++) { ww[2 * i] = gl_from_i64(input[i]); ww[2 * i + 1] = 0; } dev.upload(xin, ww.data()); }
+  SamePolyProof agg = same_poly_prove(dev, on_input, xin, *ps.t);
+  dev.release(mk);
+  LayerProof lp; lp.kind = L_QKV; lp.qkv.sumcheck = sc.proof; lp.qkv.aggregation = agg; lp.qkv.pre_bias_evals.assign(pre, pre + 3); lp.qkv.individual_claims = sc.finals;
+  ps.proofs[id] = lp;
+  return {{agg.sumcheck.point, agg.evals[1]}};
+}
+
 inline std::vector<u64> ext_words_from_i64(const std::vector<int64_t>& v) { std::vector<u64> w(2 * v.size()); for (size_t i = 0; i < v.size(); i++) { w[2 * i] = gl_from_i64(v[i]); w[2 * i + 1] = 0; } return w; }
 
 inline Claim prove_dense(ProverState& ps, size_t id, const LayerSpec& l, const Claim& last, const std::vector<int64_t>& input) {
@@ -1009,12 +1367,33 @@ inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t) {
   for (auto& kv : ctx.model_comms) for (auto& pc : kv.second) t.append_digest(pc.second.tree.root);
   instantiate_witness_ctx(ps, tr);
   pt.lap("witness columns + commits");
-  const std::vector<int64_t>& out = tr.out.back();
-  std::vector<Ext> r = t.read_challenges(dp_ceil_log2(out.size()));
-  Claim cur; cur.point = r;
-  { std::vector<Ext> ov(out.size()); for (size_t i = 0; i < out.size(); i++) ov[i] = ex_from_i64(out[i]); cur.eval = host_mle_eval(ov, r); }
-  for (size_t id = ctx.model.layers.size(); id-- > 0;) {
-    const LayerSpec& l = ctx.model.layers[id];
+  // a claim per output tensor (iop/prover.rs:419-435); then the nodes in proving order, each node receiving the claims its readers made on
+  // its outputs and making one claim per input (claims_for_node, provable/mod.rs:235-270). A chain: one claim walking from the last node back.
+  const ModelSpec& model = ctx.model;
+  std::vector<Claim> on_outputs;
+  for (const Edge& e : output_edges(model)) {
+    const std::vector<int64_t>& out = tr.tensor(e.from, e.slot);
+    Claim c; c.point = t.read_challenges(dp_ceil_log2(out.size()));
+    std::vector<Ext> ov(out.size()); for (size_t i = 0; i < out.size(); i++) ov[i] = ex_from_i64(out[i]);
+    c.eval = host_mle_eval(ov, c.point);
+    on_outputs.push_back(std::move(c));
+  }
+  const bool chain = model.outputs.empty() && std::all_of(model.layers.begin(), model.layers.end(), [](const LayerSpec& l) { return l.inputs.empty(); });
+  std::map<size_t, std::vector<Claim>> made;  // node -> the claims it made on its inputs
+  std::vector<size_t> order;
+  if (chain) for (size_t id = model.layers.size(); id-- > 0;) order.push_back(id); else order = proving_order(model);
+  for (size_t id : order) {
+    const LayerSpec& l = model.layers[id];
+    std::vector<Claim> got;
+    for (size_t j = 0; j < out_degree(l); j++) {
+      Reader_ r; if (chain) { r.to = id + 1 < model.layers.size() ? (int)id + 1 : -1; r.port = 0; } else r = reader_of(model, (int)id, (int)j);
+      got.push_back(r.to < 0 ? on_outputs.at((size_t)r.port) : made.at((size_t)r.to).at((size_t)r.port));
+    }
+    Claim cur = got[0];
+    if (l.kind == L_MATMUL2) { made[id] = prove_matmul2(ps, id, l, cur, tr.in[id], tr.in2[id]); continue; }
+    if (l.kind == L_ADD2) { made[id] = prove_add2(ps, id, cur, tr.in[id], tr.in2[id]); continue; }
+    if (l.kind == L_CONCAT_MATMUL) { made[id] = prove_concat_matmul(ps, id, l, cur, tr.in[id], tr.in2[id]); continue; }
+    if (l.kind == L_QKV) { made[id] = prove_qkv(ps, id, l, got, tr.in[id]); continue; }
     if (l.kind == L_DENSE) cur = prove_dense(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_MATMUL) cur = prove_matmul(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_ADD) cur = prove_add(ps, id, l, cur, tr.in[id]);
@@ -1025,7 +1404,9 @@ inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t) {
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv.at(id));
     else if (l.kind == L_MAXPOOL) cur = prove_pooling(ps, id, l, cur);
     // L_FLATTEN is not provable: the claim passes through unchanged (iop/prover.rs:449-456)
-    if (pt.on) { static const char* nm[] = {"dense", "requant", "relu", "conv", "maxpool", "flatten"}; char b[64]; snprintf(b, sizeof b, "layer %zu (%s)", id, nm[l.kind]); pt.lap(b); }
+    if (pt.on) { char b[64]; snprintf(b, sizeof b, "layer %zu (kind %d)", id, l.kind); pt.lap(b); }
+    made[id] = {cur};
+    if (chain && id + 1 < model.layers.size()) made.erase(id + 1);
   }
   Proof proof;
   for (auto& tw : ps.table_witness) {
@@ -1074,22 +1455,116 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
   }
   DP_REQUIRE(proof.steps.size() == n_provable, DP_ERR_VERIFY, "unexpected layer proofs");
   for (auto& tp : proof.table_proofs) add_fracs(tp.lookup);
-  // output claim
-  DP_REQUIRE(is_pow2(io.output.size()) && io.input.size() == m.input_len, DP_ERR_VERIFY, "io shapes");
-  std::vector<Ext> r = t.read_challenges(dp_ceil_log2(io.output.size()));
-  Claim cur; cur.point = r;
-  { std::vector<Ext> ov(io.output.size()); for (size_t i = 0; i < ov.size(); i++) ov[i] = ex_from_i64(io.output[i]); cur.eval = host_mle_eval(ov, r); }
+  // output claims: one per output tensor, in the order of the model's outputs (io.output = their concatenation)
+  std::vector<size_t> lens, in_lens, in2_lens;
+  tensor_lens(m, lens, &in_lens, &in2_lens);
+  DP_REQUIRE(io.input.size() == m.input_len && io.output.size() == model_output_len(m), DP_ERR_VERIFY, "io shapes");
+  std::vector<Claim> on_outputs;
+  { size_t off = 0;
+    for (const Edge& e : output_edges(m)) {
+      const size_t n = lens.at((size_t)e.from);
+      DP_REQUIRE(is_pow2(n), DP_ERR_VERIFY, "io shapes");
+      Claim c; c.point = t.read_challenges(dp_ceil_log2(n));
+      std::vector<Ext> ov(n); for (size_t i = 0; i < n; i++) ov[i] = ex_from_i64(io.output[off + i]);
+      c.eval = host_mle_eval(ov, c.point);
+      on_outputs.push_back(std::move(c)); off += n;
+    } }
+  std::map<size_t, std::vector<Claim>> made;  // node -> the claims on its inputs
   std::vector<VerifyClaim> claims, trivial_claims;
   auto add_claim = [&](const Commitment& c, const Claim& cl) {
     VerifyClaim v{c, cl.point, cl.eval};
     if (cl.point.size() <= PCS_BASECODE_LOG) trivial_claims.push_back(v); else claims.push_back(v);
   };
   std::map<size_t, std::map<std::string, Commitment>> unused = vc.model_comms;
-  size_t cur_len = io.output.size();
-  for (size_t id = m.layers.size(); id-- > 0;) {
+  // the verifier's own same_poly (commit/same_poly.rs:157-183), used by ReLU and QKV
+  auto same_poly_verify = [&](const std::vector<Claim>& sp_claims, const SamePolyProof& sp, unsigned nv) -> Claim {
+    DP_REQUIRE(sp.evals.size() == 2, DP_ERR_VERIFY, "same_poly: shapes");
+    for (auto& c : sp_claims) DP_REQUIRE(c.point.size() == nv, DP_ERR_VERIFY, "same_poly: invalid claim length");
+    std::vector<Ext> a = t.read_challenges(sp_claims.size());
+    Ext y = ex_zero();
+    for (size_t i = 0; i < a.size(); i++) y = ex_add(y, ex_mul(sp_claims[i].eval, a[i]));
+    SubClaim sub = sumcheck_verify(y, sp.sumcheck, nv, 2, t);
+    Ext computed = ex_zero();
+    for (size_t i = 0; i < a.size(); i++) computed = ex_add(computed, ex_mul(a[i], identity_eval(sp_claims[i].point, sp.sumcheck.point)));
+    DP_REQUIRE(ex_eq(computed, sp.evals[0]), DP_ERR_VERIFY, "same_poly: beta evaluation mismatch");
+    DP_REQUIRE(ex_eq(ex_mul(sp.evals[0], sp.evals[1]), sub.expected_evaluation), DP_ERR_VERIFY, "same_poly: final evals invalid");
+    return {sp.sumcheck.point, sp.evals[1]};
+  };
+  for (size_t id : proving_order(m)) {
     const LayerSpec& l = m.layers[id];
-    if (l.kind == L_FLATTEN) continue;  // claims pass through a non-provable node unchanged (verifier.rs:205-209)
+    std::vector<Claim> got;
+    for (size_t j = 0; j < out_degree(l); j++) { const Reader_ rd = reader_of(m, (int)id, (int)j); got.push_back(rd.to < 0 ? on_outputs.at((size_t)rd.port) : made.at((size_t)rd.to).at((size_t)rd.port)); }
+    Claim cur = got[0];
+    size_t cur_len = lens[id];
+    if (l.kind == L_FLATTEN) { made[id] = {cur}; continue; }  // claims pass through a non-provable node unchanged (verifier.rs:205-209)
     const LayerProof& lp = proof.steps.at(id);
+    if (l.kind == L_MATMUL2) {  // MatMulCtx::verify_matmul (matrix_mul.rs:1048-1139), both operands inputs: no commitment, two claims out
+      const MatMulProof& mp = lp.matmul;
+      const size_t s_ = l.nrows ? in_lens[id] / l.nrows : 0;
+      const unsigned nvc = dp_ceil_log2(l.ncols), nvr = dp_ceil_log2(s_);
+      DP_REQUIRE(is_pow2(s_) && cur.point.size() == nvc + nvr && mp.individual_claims.size() == 2 && !mp.has_bias, DP_ERR_VERIFY, "matmul2: shapes");
+      std::vector<Ext> cols(cur.point.begin(), cur.point.begin() + nvc), rows(cur.point.begin() + nvc, cur.point.end());
+      SubClaim sub = sumcheck_verify(cur.eval, mp.sumcheck, dp_ceil_log2(l.nrows), 2, t);
+      DP_REQUIRE(ex_eq(ex_mul(mp.individual_claims[0], mp.individual_claims[1]), sub.expected_evaluation), DP_ERR_VERIFY, "matmul2: sumcheck claim failed");
+      std::vector<Ext> pl = sub.point; pl.insert(pl.end(), rows.begin(), rows.end());
+      std::vector<Ext> pr;
+      if (l.mm_transpose) { pr = sub.point; pr.insert(pr.end(), cols.begin(), cols.end()); } else { pr = cols; pr.insert(pr.end(), sub.point.begin(), sub.point.end()); }
+      made[id] = {{pl, mp.individual_claims[0]}, {pr, mp.individual_claims[1]}};
+      continue;
+    }
+    if (l.kind == L_ADD2) {  // AddCtx::verify (add.rs:586-625) without operand
+      const AddProof& ap = lp.add;
+      DP_REQUIRE(cur.point.size() == dp_ceil_log2(cur_len) && l.add_left > 0 && l.add_right > 0, DP_ERR_VERIFY, "add2: shapes");
+      const Ext sum = ex_add(ex_mul_base(ap.left_eval, gl_from_i64(l.add_left)), ex_mul_base(ap.right_eval, gl_from_i64(l.add_right)));
+      DP_REQUIRE(ex_eq(sum, cur.eval), DP_ERR_VERIFY, "Add layer verification failed");
+      made[id] = {{cur.point, ap.left_eval}, {cur.point, ap.right_eval}};
+      continue;
+    }
+    if (l.kind == L_CONCAT_MATMUL) {  // ConcatMatMulCtx::verify (concat_matmul.rs:801-892)
+      const ConcatMatMulProof& cp = lp.cmm;
+      const CmShape g = cm_shape(l);
+      DP_REQUIRE(cp.individual_claims.size() == 3, DP_ERR_VERIFY, "concat matmul: shapes");
+      const unsigned nvm = dp_ceil_log2(g.M), nvs = dp_ceil_log2(g.C * g.M);
+      SubClaim sub = sumcheck_verify(cur.eval, cp.sumcheck, nvs, 3, t);
+      CmPoint p;
+      try { p = cm_split_point(l, g, cur.point); } catch (const DpError&) { DP_REQUIRE(false, DP_ERR_VERIFY, "concat matmul: claim point length"); }
+      const std::vector<Ext> s_mm(sub.point.begin(), sub.point.begin() + nvm), s_concat(sub.point.begin() + nvm, sub.point.end());
+      DP_REQUIRE(ex_eq(identity_eval(s_concat, p.concat), cp.individual_claims[0]), DP_ERR_VERIFY, "concat matmul: wrong evaluation of the beta table");
+      DP_REQUIRE(ex_eq(ex_mul(ex_mul(cp.individual_claims[0], cp.individual_claims[1]), cp.individual_claims[2]), sub.expected_evaluation), DP_ERR_VERIFY, "concat matmul: sumcheck claim failed");
+      made[id] = {{cm_input_point(l.cm_left, s_concat, s_mm, p.row), cp.individual_claims[1]}, {cm_input_point(l.cm_right, s_concat, s_mm, p.col), cp.individual_claims[2]}};
+      continue;
+    }
+    if (l.kind == L_QKV) {  // QKVCtx::verify (qkv.rs:680-810)
+      const QKVProof& qp = lp.qkv;
+      const size_t s_ = l.nrows ? in_lens[id] / l.nrows : 0;
+      const unsigned nvc = dp_ceil_log2(l.ncols), nvr = dp_ceil_log2(s_), nvk = dp_ceil_log2(l.nrows);
+      DP_REQUIRE(got.size() == 3 && is_pow2(s_) && qp.pre_bias_evals.size() == 3 && qp.individual_claims.size() == 6, DP_ERR_VERIFY, "qkv: shapes");
+      static const char* const wn[3] = {"WeightQ", "WeightK", "WeightV"}; static const char* const bn[3] = {"BiasQ", "BiasK", "BiasV"};
+      auto nit = unused.find(id);
+      DP_REQUIRE(nit != unused.end() && nit->second.size() == 6, DP_ERR_VERIFY, "qkv: six commitments expected for the node");
+      for (int w = 0; w < 3; w++) DP_REQUIRE(nit->second.count(wn[w]) && nit->second.count(bn[w]) && got[w].point.size() == nvc + nvr, DP_ERR_VERIFY, "qkv: commitments / claim point length");
+      std::vector<Ext> rows[3], cols[3];
+      for (int w = 0; w < 3; w++) { cols[w].assign(got[w].point.begin(), got[w].point.begin() + nvc); rows[w].assign(got[w].point.begin() + nvc, got[w].point.end()); }
+      for (int w = 0; w < 3; w++) { t.append_exts(got[w].point); t.append_ext(qp.pre_bias_evals[w]); }
+      const Ext coeff[3] = {ex_one(), t.read_challenge(), t.read_challenge()};
+      Ext batched = ex_zero();
+      for (int w = 0; w < 3; w++) batched = ex_add(batched, ex_mul(qp.pre_bias_evals[w], coeff[w]));
+      SubClaim sub = sumcheck_verify(batched, qp.sumcheck, nvk, 2, t);
+      std::vector<Claim> on_input(3), on_weight(3);
+      Ext virt = ex_zero();
+      for (int w = 0; w < 3; w++) {
+        on_input[w].point = sub.point; on_input[w].point.insert(on_input[w].point.end(), rows[w].begin(), rows[w].end()); on_input[w].eval = qp.individual_claims[2 * w];
+        on_weight[w].point = cols[w]; on_weight[w].point.insert(on_weight[w].point.end(), sub.point.begin(), sub.point.end()); on_weight[w].eval = qp.individual_claims[2 * w + 1];
+        virt = ex_add(virt, ex_mul(ex_mul(qp.individual_claims[2 * w], qp.individual_claims[2 * w + 1]), coeff[w]));
+      }
+      // add_common_claims: the node's polynomials in BTreeMap order
+      for (int w : {1, 0, 2}) add_claim(nit->second.at(bn[w]), {cols[w], ex_sub(got[w].eval, qp.pre_bias_evals[w])});
+      for (int w : {1, 0, 2}) add_claim(nit->second.at(wn[w]), on_weight[w]);
+      unused.erase(nit);
+      DP_REQUIRE(ex_eq(virt, sub.expected_evaluation), DP_ERR_VERIFY, "qkv: sumcheck claim failed");
+      made[id] = {same_poly_verify(on_input, qp.aggregation, dp_ceil_log2(in_lens[id]))};
+      continue;
+    }
     if (l.kind == L_CONV) {  // ConvCtx::verify_convolution (convolution.rs:1141-1386)
       const ConvProof& cp = lp.conv;
       size_t fs = l.filter_size();
@@ -1340,6 +1815,7 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       add_claim(ap.commits[1], new_out);
       cur = vcl.claims[0];
     }
+    made[id] = {cur};
   }
   // table proofs (verifier.rs:320-383)
   DP_REQUIRE(proof.table_proofs.size() == vc.tables.size(), DP_ERR_VERIFY, "wrong number of table proofs");
@@ -1368,6 +1844,20 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
   }
   // input claim (provable/mod.rs:542-565); behind an Embeddings layer it is a claim on the one-hot encoding of the tokens:
   // sum_i beta(i, r2) * eq(r1, bits(token_i)), r1 = the vocabulary part of the point (verify_input_claim, embeddings.rs:530-571)
+  // every input tensor of the model against the claim its reader made on it (ModelCtx::input_claims, provable/mod.rs:272-311)
+  const std::vector<size_t> in_tensors = input_tensor_lens(m);
+  if (in_tensors.size() > 1 || !m.layers[0].inputs.empty()) {
+    size_t off = 0;
+    for (size_t q = 0; q < in_tensors.size(); q++) {
+      const Reader_ rd = reader_of(m, -1, (int)q);
+      DP_REQUIRE(rd.to >= 0 && m.layers[(size_t)rd.to].kind != L_EMBED, DP_ERR_VERIFY, "input tensor without a reader (Embeddings is only supported as node 0 of a chain)");
+      const Claim& c = made.at((size_t)rd.to).at((size_t)rd.port);
+      std::vector<Ext> iv(in_tensors[q]); for (size_t i = 0; i < iv.size(); i++) iv[i] = ex_from_i64(io.input[off + i]);
+      DP_REQUIRE(c.point.size() == dp_ceil_log2(iv.size()) && ex_eq(host_mle_eval(iv, c.point), c.eval), DP_ERR_VERIFY, "input claim is incorrect");
+      off += in_tensors[q];
+    }
+  } else {
+  const Claim cur = made.at(0).at(0);
   if (m.layers[0].kind == L_EMBED) {
     const unsigned vnv = dp_ceil_log2(m.layers[0].nrows);
     DP_REQUIRE(cur.point.size() == vnv + dp_ceil_log2(io.input.size()), DP_ERR_VERIFY, "input claim is incorrect");
@@ -1384,6 +1874,7 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
   } else
   { std::vector<Ext> iv(io.input.size()); for (size_t i = 0; i < iv.size(); i++) iv[i] = ex_from_i64(io.input[i]);
     DP_REQUIRE(cur.point.size() == dp_ceil_log2(iv.size()) && ex_eq(host_mle_eval(iv, cur.point), cur.eval), DP_ERR_VERIFY, "input claim is incorrect"); }
+  }
   // commitment openings (commit/context.rs:520-598)
   DP_REQUIRE(unused.empty(), DP_ERR_VERIFY, "not all model commitments have been used");
   DP_REQUIRE(trivial_claims.size() == proof.trivial_proofs.size(), DP_ERR_VERIFY, "number of trivial proofs");
@@ -1400,17 +1891,24 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
 }
 
 // ---- serialisable verifier context (what dp_model_verifier_blob hands out and dp_verify consumes)
-constexpr int N_POLY_IDS = 9;
-inline const char* const* poly_ids() { static const char* const ids[N_POLY_IDS] = {"DenseBias", "DenseWeight", "ConvBias", "ConvFilter", "MatMulBias", "MatMulWeight", "255", "EmbeddingMat", "PositionalMatrix"}; return ids; }
+constexpr int N_POLY_IDS = 15;
+inline const char* const* poly_ids() { static const char* const ids[N_POLY_IDS] = {"DenseBias", "DenseWeight", "ConvBias", "ConvFilter", "MatMulBias", "MatMulWeight", "255", "EmbeddingMat", "PositionalMatrix", "BiasK", "BiasQ", "BiasV", "WeightK", "WeightQ", "WeightV"}; return ids; }
+constexpr u64 VCTX_GRAPH_MARK = 0x0048504152475044ULL;  // "DPGRAPH": the optional trailing section of a verifier blob (edges, multi-tensor io, ConcatMatMul geometry)
+inline bool is_plain_chain(const ModelSpec& m) {
+  if (!m.input_lens.empty() || !m.outputs.empty()) return false;
+  for (auto& l : m.layers) if (!l.inputs.empty() || l.kind == L_CONCAT_MATMUL) return false;
+  return true;
+}
 inline std::vector<u64> vctx_to_words(const VerifierContext& v) {
   std::vector<u64> w;
   w.push_back(0x3158544356504444ULL); w.push_back(v.full_log); w.push_back(v.shape.input_len); w.push_back(v.shape.layers.size());
   for (auto& l : v.shape.layers) {
     w.push_back(l.kind); w.push_back(l.nrows); w.push_back(l.ncols); w.push_back(l.right_shift); w.push_back(l.fp_scale);
-    w.push_back(l.kind == L_ADD || l.kind == L_POSITIONAL ? (u64)l.add_left : (u64)l.fixed_point_multiplier);  // (an Add carries its two multipliers in the requant multiplier / kx slots)
+    const bool adds = l.kind == L_ADD || l.kind == L_ADD2 || l.kind == L_POSITIONAL, mm = l.kind == L_MATMUL || l.kind == L_MATMUL2;
+    w.push_back(adds ? (u64)l.add_left : (u64)l.fixed_point_multiplier);  // (an Add carries its two multipliers in the requant multiplier / kx slots)
     w.push_back(l.intermediate_bit_size);
-    w.push_back(l.kind == L_MATMUL ? (l.mm_transpose ? 1 : 0) : l.kw);  // (a MatMul has no filter count: the slot carries its transpose flag)
-    w.push_back(l.kind == L_ADD || l.kind == L_POSITIONAL ? (u64)l.add_right : l.kx); w.push_back(l.real_nw); w.push_back(l.nw);
+    w.push_back(mm ? (l.mm_transpose ? 1 : 0) : l.kw);  // (a MatMul has no filter count: the slot carries its transpose flag)
+    w.push_back(adds ? (u64)l.add_right : l.kx); w.push_back(l.real_nw); w.push_back(l.nw);
     for (int k = 0; k < 3; k++) w.push_back(l.unp_out[k]);
     for (int k = 0; k < 3; k++) w.push_back(l.pin[k]);
   }
@@ -1425,6 +1923,21 @@ inline std::vector<u64> vctx_to_words(const VerifierContext& v) {
   }
   w.push_back(v.tables.size());
   for (auto& t : v.tables) { w.push_back(t.kind); w.push_back(t.size); }
+  if (!is_plain_chain(v.shape)) {
+    w.push_back(VCTX_GRAPH_MARK);
+    w.push_back(v.shape.input_lens.size()); for (size_t n : v.shape.input_lens) w.push_back(n);
+    w.push_back(v.shape.outputs.size()); for (const Edge& e : v.shape.outputs) { w.push_back((u64)(e.from + 1)); w.push_back((u64)e.slot); }
+    for (auto& l : v.shape.layers) {
+      w.push_back(l.inputs.size()); for (const Edge& e : l.inputs) { w.push_back((u64)(e.from + 1)); w.push_back((u64)e.slot); }
+      if (l.kind == L_CONCAT_MATMUL) {
+        for (int d = 0; d < 3; d++) w.push_back(l.cm_a[d]);
+        for (int d = 0; d < 3; d++) w.push_back(l.cm_b[d]);
+        for (int d = 0; d < 3; d++) w.push_back((u64)l.cm_left[d]);
+        for (int d = 0; d < 3; d++) w.push_back((u64)l.cm_right[d]);
+        w.push_back(l.cm_perm.size()); for (int x : l.cm_perm) w.push_back((u64)x);
+      }
+    }
+  }
   return w;
 }
 inline VerifierContext vctx_from_words(const u64* w, size_t n) {
@@ -1439,8 +1952,9 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
     l.kw = (size_t)rd(); l.kx = (size_t)rd(); l.real_nw = (size_t)rd(); l.nw = (size_t)rd();
     for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();
     for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd();
-    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_POSITIONAL, DP_ERR_ARG, "verifier blob: layer kind");
-    if (l.kind == L_ADD || l.kind == L_POSITIONAL) { l.add_left = l.fixed_point_multiplier; l.add_right = (int64_t)l.kx; l.fixed_point_multiplier = 0; l.kx = 0; DP_REQUIRE(l.add_left > 0 && l.add_right > 0, DP_ERR_ARG, "verifier blob: add multipliers"); }
+    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_QKV, DP_ERR_ARG, "verifier blob: layer kind");
+    if (l.kind == L_MATMUL2) { DP_REQUIRE(l.kw <= 1, DP_ERR_ARG, "verifier blob: matmul flags"); l.mm_transpose = l.kw != 0; l.kw = 0; }
+    if (l.kind == L_ADD || l.kind == L_ADD2 || l.kind == L_POSITIONAL) { l.add_left = l.fixed_point_multiplier; l.add_right = (int64_t)l.kx; l.fixed_point_multiplier = 0; l.kx = 0; DP_REQUIRE(l.add_left > 0 && l.add_right > 0, DP_ERR_ARG, "verifier blob: add multipliers"); }
     if (l.kind == L_MATMUL) { DP_REQUIRE(l.kw <= 1, DP_ERR_ARG, "verifier blob: matmul flags"); l.mm_transpose = l.kw != 0; l.kw = 0; }
     if (l.kind == L_CONV) DP_REQUIRE(is_pow2(l.kw) && is_pow2(l.kx) && is_pow2(l.real_nw) && is_pow2(l.nw) && l.kw <= (1u << 16) && l.kx <= (1u << 16) && l.nw <= (1u << 12) && 2 * l.real_nw <= l.nw && l.unp_out[0] <= l.kw && l.unp_out[1] <= l.nw && l.unp_out[2] <= l.nw, DP_ERR_ARG, "verifier blob: conv shape");
     if (l.kind == L_MAXPOOL) DP_REQUIRE(is_pow2(l.pin[0]) && is_pow2(l.pin[1]) && is_pow2(l.pin[2]) && l.pin[2] >= 2, DP_ERR_ARG, "verifier blob: maxpool shape");
@@ -1449,12 +1963,32 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
   size_t nc = (size_t)rd(); DP_REQUIRE(nc <= nl, DP_ERR_ARG, "verifier blob: commitments");
   for (size_t i = 0; i < nc; i++) {
     size_t id = (size_t)rd(); size_t np = (size_t)rd();
-    DP_REQUIRE(np <= 4, DP_ERR_ARG, "verifier blob: polynomials per node");
+    DP_REQUIRE(np <= 6, DP_ERR_ARG, "verifier blob: polynomials per node");
     for (size_t q = 0; q < np; q++) { u64 code = rd(); DP_REQUIRE(code < (u64)N_POLY_IDS, DP_ERR_ARG, "verifier blob: polynomial id"); Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = rd(); c.num_vars = (unsigned)rd(); c.is_base = rd() != 0; v.model_comms[id][poly_ids()[code]] = c; }
   }
   size_t nt = (size_t)rd(); DP_REQUIRE(nt < 64, DP_ERR_ARG, "verifier blob: tables");
   for (size_t i = 0; i < nt; i++) { TableType t; t.kind = (int)rd(); t.size = (unsigned)rd(); v.tables.push_back(t); }
-  DP_REQUIRE(pos == n, DP_ERR_ARG, "verifier blob: trailing words");
+  if (pos < n) {
+    DP_REQUIRE(rd() == VCTX_GRAPH_MARK, DP_ERR_ARG, "verifier blob: trailing words");
+    auto rd_edge = [&]() { Edge e; u64 f = rd(); DP_REQUIRE(f <= nl, DP_ERR_ARG, "verifier blob: edge"); e.from = (int)f - 1; u64 sl = rd(); DP_REQUIRE(sl < 4096, DP_ERR_ARG, "verifier blob: edge"); e.slot = (int)sl; return e; };
+    size_t ni = (size_t)rd(); DP_REQUIRE(ni < 4096, DP_ERR_ARG, "verifier blob: inputs");
+    for (size_t i = 0; i < ni; i++) v.shape.input_lens.push_back((size_t)rd());
+    size_t no = (size_t)rd(); DP_REQUIRE(no < 4096, DP_ERR_ARG, "verifier blob: outputs");
+    for (size_t i = 0; i < no; i++) v.shape.outputs.push_back(rd_edge());
+    for (auto& l : v.shape.layers) {
+      size_t k = (size_t)rd(); DP_REQUIRE(k <= 2, DP_ERR_ARG, "verifier blob: node inputs");
+      for (size_t i = 0; i < k; i++) l.inputs.push_back(rd_edge());
+      if (l.kind == L_CONCAT_MATMUL) {
+        for (int d = 0; d < 3; d++) { l.cm_a[d] = (size_t)rd(); DP_REQUIRE(is_pow2(l.cm_a[d]) && l.cm_a[d] <= (size_t(1) << 24), DP_ERR_ARG, "verifier blob: concat matmul shape"); }
+        for (int d = 0; d < 3; d++) { l.cm_b[d] = (size_t)rd(); DP_REQUIRE(is_pow2(l.cm_b[d]) && l.cm_b[d] <= (size_t(1) << 24), DP_ERR_ARG, "verifier blob: concat matmul shape"); }
+        for (int d = 0; d < 3; d++) { u64 x = rd(); DP_REQUIRE(x < 3, DP_ERR_ARG, "verifier blob: concat matmul axes"); l.cm_left[d] = (int)x; }
+        for (int d = 0; d < 3; d++) { u64 x = rd(); DP_REQUIRE(x < 3, DP_ERR_ARG, "verifier blob: concat matmul axes"); l.cm_right[d] = (int)x; }
+        size_t np_ = (size_t)rd(); DP_REQUIRE(np_ == 0 || np_ == 3, DP_ERR_ARG, "verifier blob: concat matmul permutation");
+        for (size_t i = 0; i < np_; i++) { u64 x = rd(); DP_REQUIRE(x < 3, DP_ERR_ARG, "verifier blob: concat matmul permutation"); l.cm_perm.push_back((int)x); }
+      }
+    }
+    DP_REQUIRE(pos == n, DP_ERR_ARG, "verifier blob: trailing words");
+  }
   return v;
 }
 

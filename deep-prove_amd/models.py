@@ -6,6 +6,7 @@ import math
 import numpy as np
 
 L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_FLATTEN, L_MATMUL, L_ADD, L_EMBED, L_POSITIONAL = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+L_MATMUL2, L_ADD2, L_CONCAT_MATMUL, L_QKV = 10, 11, 12, 13  # nodes of a model GRAPH: two-input MatMul / Add, ConcatMatMul, QKV
 BIT_LEN = 8
 FIXED_POINT_SCALE = 25  # zkml/src/layers/requant.rs:47
 
@@ -308,6 +309,179 @@ class ModelBuilder:
             elif l["kind"] == L_FLATTEN:
                 pass
         return cur
+
+
+class GraphBuilder:
+    """A model as a GRAPH of nodes (zkml/src/layers/provable/mod.rs:195-565): nodes with two inputs (MatMul / Add of two tensors, ConcatMatMul),
+    a node with three outputs (QKV), several input and output tensors. Tensors are already padded and quantised; an edge is (node, slot) with
+    node = -1 for input tensor `slot` of the model. The reference proves graphs in which every tensor is read exactly once."""
+
+    def __init__(self, input_lens, config=0):
+        self.input_lens = [int(n) for n in input_lens]
+        self.input_len = sum(self.input_lens)
+        self.nodes = []       # (dict, [edges])
+        self.outputs = None   # default: output 0 of the last node
+        self.config = config
+        self._tensor_index = 0
+
+    def _tensor(self, n):
+        t = quantised_tensor(self.config, self._tensor_index, n)
+        self._tensor_index += 1
+        return t
+
+    def _add(self, layer, edges):
+        self.nodes.append((layer, [tuple(e) for e in edges]))
+        return len(self.nodes) - 1
+
+    def qkv(self, src, k, n):
+        """QKV (layers/transformer/qkv.rs): X [s][k] -> X W_q + b_q, X W_k + b_k, X W_v + b_v, outputs (id, 0..2)"""
+        w = self._tensor(3 * k * n).reshape(3, k, n)
+        b = self._tensor(3 * n).reshape(3, n)
+        return self._add(dict(kind=L_QKV, nrows=k, ncols=n, weights=w, bias=b), [src])
+
+    def matmul2(self, a, b, k, n, transpose_b=False):
+        """MatMul of two input tensors (layers/matrix_mul.rs): [s][k] x [k][n] ([n][k] with transpose_b)"""
+        return self._add(dict(kind=L_MATMUL2, nrows=k, ncols=n, transpose_b=transpose_b), [a, b])
+
+    def add2(self, a, b, left=1, right=1):
+        return self._add(dict(kind=L_ADD2, left=left, right=right), [a, b])
+
+    def concat_matmul(self, a, b, a_shape, b_shape, left, right, perm=None):
+        """ConcatMatMul (layers/concat_matmul.rs): rank-3 inputs; left / right = (concat, mat_mul, output) axis of each; perm = permutation
+        of the [concat][rows][cols] result"""
+        return self._add(dict(kind=L_CONCAT_MATMUL, a_shape=tuple(a_shape), b_shape=tuple(b_shape), left=tuple(left), right=tuple(right),
+                              perm=None if perm is None else tuple(perm)), [a, b])
+
+    def matmul_const(self, src, k, n, bias=True):
+        w = self._tensor(k * n).reshape(k, n)
+        b = self._tensor(n) if bias else None
+        return self._add(dict(kind=L_MATMUL, nrows=k, ncols=n, weights=w, bias=b, transpose_b=False), [src])
+
+    def requant(self, src, multiplier, intermediate_bit_size):
+        return self._add(dict(kind=L_REQUANT, **requant_from_multiplier(multiplier, intermediate_bit_size)), [src])
+
+    def relu(self, src):
+        return self._add(dict(kind=L_RELU), [src])
+
+    def set_outputs(self, edges):
+        self.outputs = [tuple(e) for e in edges]
+        return self
+
+    def blob(self):
+        outs = self.outputs if self.outputs is not None else [(len(self.nodes) - 1, 0)]
+        head = [self.input_len, -len(self.nodes), len(self.input_lens), *self.input_lens, len(outs)]
+        for e in outs:
+            head += list(e)
+        parts = [np.array(head, dtype=np.int64)]
+        for l, edges in self.nodes:
+            pre = [l["kind"], len(edges)]
+            for e in edges:
+                pre += list(e)
+            k = l["kind"]
+            if k == L_QKV:
+                parts += [np.array(pre + [l["nrows"], l["ncols"]], dtype=np.int64), l["weights"].reshape(-1), l["bias"].reshape(-1)]
+            elif k == L_MATMUL2:
+                parts.append(np.array(pre + [l["nrows"], l["ncols"], 2 if l["transpose_b"] else 0], dtype=np.int64))
+            elif k == L_ADD2:
+                parts.append(np.array(pre + [l["left"], l["right"]], dtype=np.int64))
+            elif k == L_CONCAT_MATMUL:
+                tail = [1, *l["perm"]] if l["perm"] is not None else [0]
+                parts.append(np.array(pre + [*l["a_shape"], *l["b_shape"], *l["left"], *l["right"], *tail], dtype=np.int64))
+            elif k == L_MATMUL:
+                parts.append(np.array(pre + [l["nrows"], l["ncols"], 0 if l["bias"] is None else 1], dtype=np.int64))
+                parts.append(l["weights"].reshape(-1))
+                if l["bias"] is not None:
+                    parts.append(l["bias"])
+            elif k == L_REQUANT:
+                parts.append(np.array(pre + [l["right_shift"], l["fp_scale"], l["fixed_point_multiplier"], l["intermediate_bit_size"]], dtype=np.int64))
+            elif k == L_RELU:
+                parts.append(np.array(pre, dtype=np.int64))
+            else:
+                raise ValueError("GraphBuilder: unsupported node kind")
+        return np.concatenate(parts)
+
+    def input(self, index=1000, amplitude=127):
+        x = quantised_tensor(self.config, index, self.input_len)
+        return x if amplitude == 127 else x % (2 * amplitude + 1) - amplitude
+
+    def run(self, x):
+        """quantised inference in numpy: the concatenated output tensors"""
+        x = np.asarray(x, dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum(self.input_lens)])
+        vals = {}
+
+        def get(e):
+            return x[offs[e[1]]:offs[e[1] + 1]] if e[0] < 0 else vals[e]
+
+        for i, (l, edges) in enumerate(self.nodes):
+            a = get(edges[0])
+            k = l["kind"]
+            if k == L_QKV:
+                xs = a.reshape(-1, l["nrows"])
+                for w in range(3):
+                    vals[(i, w)] = (xs @ l["weights"][w] + l["bias"][w]).reshape(-1)
+                continue
+            if k == L_MATMUL2:
+                b = get(edges[1])
+                bm = b.reshape(l["ncols"], l["nrows"]).T if l["transpose_b"] else b.reshape(l["nrows"], l["ncols"])
+                y = (a.reshape(-1, l["nrows"]) @ bm).reshape(-1)
+            elif k == L_ADD2:
+                y = l["left"] * a + l["right"] * get(edges[1])
+            elif k == L_CONCAT_MATMUL:
+                b = get(edges[1])
+                ta = a.reshape(l["a_shape"]).transpose(l["left"][0], l["left"][2], l["left"][1])     # [concat][rows][inner]
+                tb = b.reshape(l["b_shape"]).transpose(l["right"][0], l["right"][1], l["right"][2])  # [concat][inner][cols]
+                r = np.einsum("crm,cmn->crn", ta, tb)
+                y = (r if l["perm"] is None else r.transpose(l["perm"])).reshape(-1)
+            elif k == L_MATMUL:
+                y = a.reshape(-1, l["nrows"]) @ l["weights"]
+                y = (y + l["bias"] if l["bias"] is not None else y).reshape(-1)
+            elif k == L_REQUANT:
+                sh = l["fp_scale"] + l["right_shift"]
+                y = np.clip((a * l["fixed_point_multiplier"] + (1 << (sh - 1))) >> sh, -127, 127)
+            elif k == L_RELU:
+                y = np.maximum(a, 0)
+            vals[(i, 0)] = y
+        outs = self.outputs if self.outputs is not None else [(len(self.nodes) - 1, 0)]
+        return np.concatenate([vals[e] for e in outs])
+
+
+def attention_block(seq, emb, heads, head_dim, config):
+    """One attention block WITHOUT softmax, as a graph: X -> QKV -> Requant (x3); scores_h = Q_h K_h^T (ConcatMatMul over [s][h][d] tensors,
+    the heads as the concat axis) -> Requant; out_h = scores_h V_h laid out as [s][h][d] -> Requant; output projection (MatMul with a
+    constant matrix) -> Requant; + the second input tensor (the residual stream enters as its own input: the reference proves graphs whose
+    tensors have ONE reader each). layers/transformer/qkv.rs, layers/concat_matmul.rs, layers/matrix_mul.rs, layers/add.rs"""
+    n = heads * head_dim
+    g = GraphBuilder([seq * emb, seq * emb], config)
+    q = g.qkv((-1, 0), emb, n)
+    gain = 2.5 / math.sqrt(emb) / 127.0
+    rq = [g.requant((q, w), gain, dense_output_bitsize(emb)) for w in range(3)]
+    sc = g.concat_matmul((rq[0], 0), (rq[1], 0), (seq, heads, head_dim), (seq, heads, head_dim), (1, 2, 0), (1, 2, 0))
+    sr = g.requant((sc, 0), 2.5 / math.sqrt(head_dim) / 127.0, dense_output_bitsize(head_dim))
+    av = g.concat_matmul((sr, 0), (rq[2], 0), (heads, seq, seq), (seq, heads, head_dim), (0, 2, 1), (1, 0, 2), perm=(1, 0, 2))
+    ar = g.requant((av, 0), 2.5 / math.sqrt(seq) / 127.0, dense_output_bitsize(seq))
+    pr = g.matmul_const((ar, 0), n, emb)
+    prq = g.requant((pr, 0), 2.5 / math.sqrt(n) / 127.0, dense_output_bitsize(n))
+    g.add2((prq, 0), (-1, 1))
+    return g
+
+
+def matmul_pair(seq, k, n, config, transpose_b=False):
+    """MatMul of two INPUT tensors, + a third one, Requant, ReLU (layers/matrix_mul.rs with two Input operands, layers/add.rs without operand)"""
+    g = GraphBuilder([seq * k, k * n, seq * n], config)
+    mm = g.matmul2((-1, 0), (-1, 1), k, n, transpose_b)
+    ad = g.add2((mm, 0), (-1, 2), 1, 3)
+    r = g.requant((ad, 0), 1.0 / math.sqrt(k) / 127.0, dense_output_bitsize(k) + 2)
+    g.relu((r, 0))
+    return g
+
+
+def qkv_two_outputs(seq, k, n, config):
+    """QKV whose Q is a model output and whose K + 2 V is another: a three-output node feeding an output and a later node"""
+    g = GraphBuilder([seq * k], config)
+    q = g.qkv((-1, 0), k, n)
+    ad = g.add2((q, 1), (q, 2), 1, 2)
+    return g.set_outputs([(q, 0), (ad, 0)])
 
 
 def mlp(num_dense, width, config, input_features=4, output_features=3):

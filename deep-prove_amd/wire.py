@@ -27,6 +27,9 @@ import numpy as np
 
 MAGIC = 0x31464F4F52505044
 L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_MATMUL, L_ADD, L_EMBED, L_POSITIONAL = 0, 1, 2, 3, 4, 6, 7, 8, 9
+# nodes of a model graph: MatMul / Add of two inputs share the reference's MatMulProof / AddProof variants with the constant forms (on the way
+# back from the wire format they come out as kinds 6 / 7); ConcatMatMul and QKV have their own
+L_MATMUL2, L_ADD2, L_CONCAT_MATMUL, L_QKV = 10, 11, 12, 13
 
 
 class Conventions:
@@ -101,11 +104,15 @@ def parse_stream(words):
             lp = {"sub_matrix_evals": r.ve(), "left_eval": r.e(), "right_eval": r.e()}
         elif kind == L_EMBED:
             lp = {"sumcheck": r.iop(), "individual_claims": r.ve()}
-        elif kind == L_ADD:
+        elif kind in (L_ADD, L_ADD2):
             lp = {"left_eval": r.e(), "right_eval": r.e()}
-        elif kind == L_MATMUL:
+        elif kind in (L_MATMUL, L_MATMUL2):
             lp = {"sumcheck": r.iop(), "individual_claims": r.ve()}
             lp["bias_eval"] = r.e() if r.u() else None
+        elif kind == L_CONCAT_MATMUL:
+            lp = {"sumcheck_proof": r.iop(), "individual_claims": r.ve()}
+        elif kind == L_QKV:
+            lp = {"sumcheck": r.iop(), "aggregation_proof": {"sumcheck": r.iop(), "evals": r.ve()}, "pre_bias_evals": r.ve(), "individual_claims": r.ve()}
         elif kind == L_REQUANT:
             lp = {"io_accumulation": r.iop(), "accumulation_evals": r.ve(), "clamping_lookup": r.logup(), "shifted_lookup": r.logup(),
                   "commitments": [r.comm() for _ in range(r.u())]}
@@ -205,9 +212,16 @@ def to_serde_model(tree, conv=Conventions):
                                             "add_proof": {"left_eval": _e(lp["left_eval"], c), "right_eval": _e(lp["right_eval"], c)}}]}}
         elif kind == L_EMBED:  # EmbeddingsProof {sumcheck, individual_claims} (layers/transformer/embeddings.rs:60-67)
             v = {"Embeddings": {"sumcheck": _iop(lp["sumcheck"], c), "individual_claims": _ve(lp["individual_claims"], c)}}
-        elif kind == L_ADD:  # AddProof {left_eval, right_eval} (layers/add.rs:59-63)
+        elif kind in (L_ADD, L_ADD2):  # AddProof {left_eval, right_eval} (layers/add.rs:59-63)
             v = {"Add": {"left_eval": _e(lp["left_eval"], c), "right_eval": _e(lp["right_eval"], c)}}
-        elif kind == L_MATMUL:  # MatMulProof {sumcheck, individual_claims, bias_eval: Option<E>} (layers/matrix_mul.rs:153-161)
+        elif kind == L_CONCAT_MATMUL:  # ConcatMatMulProof {sumcheck_proof, individual_claims} (layers/concat_matmul.rs:365-373)
+            v = {"ConcatMatMul": {"sumcheck_proof": _iop(lp["sumcheck_proof"], c), "individual_claims": _ve(lp["individual_claims"], c)}}
+        elif kind == L_QKV:  # QKVProof {sumcheck, aggregation_proof, pre_bias_evals, individual_claims: [(E, E); 3]} (layers/transformer/qkv.rs:63-83)
+            ic = _ve(lp["individual_claims"], c)
+            v = {"QKV": {"sumcheck": _iop(lp["sumcheck"], c),
+                         "aggregation_proof": {"sumcheck": _iop(lp["aggregation_proof"]["sumcheck"], c), "evals": _ve(lp["aggregation_proof"]["evals"], c)},
+                         "pre_bias_evals": _ve(lp["pre_bias_evals"], c), "individual_claims": [[ic[2 * q], ic[2 * q + 1]] for q in range(3)]}}
+        elif kind in (L_MATMUL, L_MATMUL2):  # MatMulProof {sumcheck, individual_claims, bias_eval: Option<E>} (layers/matrix_mul.rs:153-161)
             v = {"MatMul": {"sumcheck": _iop(lp["sumcheck"], c), "individual_claims": _ve(lp["individual_claims"], c),
                             "bias_eval": None if lp["bias_eval"] is None else _e(lp["bias_eval"], c)}}
         elif kind == L_REQUANT:
@@ -451,7 +465,8 @@ def from_rmp(data, conv=Conventions):
     assert end == len(data), "trailing bytes"
     w = _Writer(conv)
     w.w.append(MAGIC); w.w.append(len(model["steps"]))
-    kinds = {"Dense": L_DENSE, "Requant": L_REQUANT, "Activation": L_RELU, "Convolution": L_CONV, "Pooling": L_MAXPOOL, "MatMul": L_MATMUL, "Add": L_ADD, "Embeddings": L_EMBED, "Positional": L_POSITIONAL}
+    kinds = {"Dense": L_DENSE, "Requant": L_REQUANT, "Activation": L_RELU, "Convolution": L_CONV, "Pooling": L_MAXPOOL, "MatMul": L_MATMUL, "Add": L_ADD, "Embeddings": L_EMBED, "Positional": L_POSITIONAL,
+             "ConcatMatMul": L_CONCAT_MATMUL, "QKV": L_QKV}
     for node in sorted(model["steps"]):
         (name, lp), = model["steps"][node].items()
         w.w.append(node); w.w.append(kinds[name])
@@ -464,6 +479,11 @@ def from_rmp(data, conv=Conventions):
             w.iop(lp["sumcheck"]); w.ve(lp["individual_claims"])
         elif name == "Add":
             w.e(lp["left_eval"]); w.e(lp["right_eval"])
+        elif name == "ConcatMatMul":
+            w.iop(lp["sumcheck_proof"]); w.ve(lp["individual_claims"])
+        elif name == "QKV":
+            w.iop(lp["sumcheck"]); w.iop(lp["aggregation_proof"]["sumcheck"]); w.ve(lp["aggregation_proof"]["evals"]); w.ve(lp["pre_bias_evals"])
+            w.ve([x for pair in lp["individual_claims"] for x in pair])
         elif name == "MatMul":
             w.iop(lp["sumcheck"]); w.ve(lp["individual_claims"])
             w.w.append(0 if lp["bias_eval"] is None else 1)

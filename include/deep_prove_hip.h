@@ -262,7 +262,19 @@ int32_t dp_pcs_simple_batch_verify(size_t max_poly_size, const uint64_t root[4],
  *          (zkml/src/layers/transformer/positional.rs:327-583): the first `tokens` rows of the committed table are added to the
  *          [tokens][size] activation; the proof lifts the claim on that slice to the whole table with one transcript coordinate and
  *          one sub-matrix evaluation per doubling.
- *   (MatMul / Add of two inputs and the other transformer layers are not built: the model is a chain of nodes.) */
+ * GRAPH form (zkml/src/layers/provable/mod.rs:195-565: nodes with several inputs / outputs, models with several input / output tensors):
+ *   input_len (the sum of the input tensors), -(number of nodes) — the NEGATIVE count marks the form —, number of input tensors and their
+ *   lengths, number of output tensors and one (node, slot) pair each; then per node: kind, number of inputs (1 or 2), one (node, slot) pair
+ *   per input (node = -1: input tensor `slot` of the model), then the parameters of the kind as above. A node reads only nodes with
+ *   smaller ids; every tensor has exactly one reader (what the reference proves, provable/mod.rs:235-270). An input vector is the
+ *   concatenation of the input tensors, an output vector that of the output tensors. Kinds that only exist in a graph:
+ *   10 MatMul of two inputs: k, n, flags (2 = TransposeB) — [s][k] x [k][n] ([n][k] transposed), no bias (layers/matrix_mul.rs:633-873)
+ *   11 Add of two inputs: left multiplier, right multiplier (layers/add.rs:81-145)
+ *   12 ConcatMatMul: shape of A (3), shape of B (3), (concat, mat_mul, output) axis of A (3) and of B (3), 0 | 1 followed by the permutation
+ *      (3) of the [concat][rows][cols] result — chunk c of the result = chunk c of A times chunk c of B (layers/concat_matmul.rs:467-616)
+ *   13 QKV: k, n, W_q | W_k | W_v ([k][n] each), b_q | b_k | b_v ([n] each): one [s][k] input, the three outputs X W + b (slots 0, 1, 2)
+ *      (layers/transformer/qkv.rs:462-630)
+ *   Embeddings stay the first node of a chain. Not built: MHA, Softmax, LayerNorm, Logits. */
 int32_t dp_model_setup(dp_ctx* ctx, const int64_t* model_blob, size_t nwords, dp_model** out);
 int32_t dp_model_free(dp_model* m);
 /* runs inference on the host (Model::run, not part of proving time) then Prover::prove on the device.

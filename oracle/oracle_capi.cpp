@@ -17,10 +17,35 @@ static Mle rd_mle(const uint64_t* w, size_t n, int is_ext) {
 }
 static Model parse_model(const int64_t* b, size_t n) {
   size_t pos = 0; auto rd = [&]() { if (pos >= n) throw std::runtime_error("model blob truncated"); return b[pos++]; };
-  Model m; m.input_len = (size_t)rd(); size_t nl = (size_t)rd();
+  Model m; m.input_len = (size_t)rd();
+  // graph form (include/deep_prove_hip.h): a NEGATIVE layer count, then the input tensors, the output wires, and every node's input wires
+  int64_t nl_raw = rd(); const bool graph = nl_raw < 0; size_t nl = (size_t)(graph ? -nl_raw : nl_raw);
+  auto rd_wire = [&]() { Wire w; w.node = (int)rd(); w.index = (int)rd(); return w; };
+  if (graph) {
+    size_t ni = (size_t)rd(); if (ni == 0 || ni > n) throw std::runtime_error("model blob: input count");
+    for (size_t i = 0; i < ni; i++) m.input_lens.push_back((size_t)rd());
+    size_t no = (size_t)rd(); if (no == 0 || no > n) throw std::runtime_error("model blob: output count");
+    for (size_t i = 0; i < no; i++) m.outputs.push_back(rd_wire());
+  }
   for (size_t i = 0; i < nl; i++) {
     Layer l; l.kind = (LayerKind)rd();
-    if (l.kind == L_DENSE) { l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); l.weights.assign(b + pos, b + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols; l.bias.assign(b + pos, b + pos + l.nrows); pos += l.nrows; }
+    if (graph) { size_t nin = (size_t)rd(); if (nin == 0 || nin > 2) throw std::runtime_error("model blob: a node has one or two inputs"); for (size_t q = 0; q < nin; q++) l.inputs.push_back(rd_wire()); }
+    if (l.kind == L_MATMUL2) { l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); l.transpose_b = (rd() & 2) != 0; }
+    else if (l.kind == L_ADD2) { l.add_left = rd(); l.add_right = rd(); }
+    else if (l.kind == L_CONCAT_MATMUL) {
+      for (int d = 0; d < 3; d++) l.cm_a[d] = (size_t)rd();
+      for (int d = 0; d < 3; d++) l.cm_b[d] = (size_t)rd();
+      for (int d = 0; d < 3; d++) l.cm_left[d] = (int)rd();
+      for (int d = 0; d < 3; d++) l.cm_right[d] = (int)rd();
+      if (rd()) for (int d = 0; d < 3; d++) l.cm_perm.push_back((int)rd());
+    }
+    else if (l.kind == L_QKV) {
+      l.nrows = (size_t)rd(); l.ncols = (size_t)rd();
+      if (l.nrows == 0 || l.ncols == 0 || l.nrows > n || l.ncols > n || pos + 3 * l.nrows * l.ncols + 3 * l.ncols > n) throw std::runtime_error("model blob truncated");
+      l.weights.assign(b + pos, b + pos + 3 * l.nrows * l.ncols); pos += 3 * l.nrows * l.ncols;
+      l.bias.assign(b + pos, b + pos + 3 * l.ncols); pos += 3 * l.ncols;
+    }
+    else if (l.kind == L_DENSE) { l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); l.weights.assign(b + pos, b + pos + l.nrows * l.ncols); pos += l.nrows * l.ncols; l.bias.assign(b + pos, b + pos + l.nrows); pos += l.nrows; }
     else if (l.kind == L_POSITIONAL) {
       l.add_left = rd(); l.add_right = rd(); l.nrows = (size_t)rd(); l.ncols = (size_t)rd();
       if (l.nrows == 0 || l.ncols == 0 || l.nrows > n || l.ncols > n || pos + l.nrows * l.ncols > n) throw std::runtime_error("model blob truncated");
@@ -223,7 +248,7 @@ int orc_model_prove(orc_model* m, const int64_t* input, size_t ninput, uint64_t*
     if (prove_ms) *prove_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     std::vector<u64> w = serialize_proof(p);
     *proof_words = copy_out(w); *proof_nwords = w.size();
-    if (output && noutput) { const auto& o = tr.out.back(); if (*noutput < o.size()) throw std::runtime_error("output buffer too small"); memcpy(output, o.data(), o.size() * 8); *noutput = o.size(); }
+    if (output && noutput) { const std::vector<int64_t> o = model_output(m->ctx.model, tr); if (*noutput < o.size()) throw std::runtime_error("output buffer too small"); memcpy(output, o.data(), o.size() * 8); *noutput = o.size(); }
   });
 }
 // CPU throughput baseline: `threads` host threads each prove `per_thread` independent proofs of the same input (the CPU

@@ -169,9 +169,24 @@ static inline LogUpProof logup_batch_prove(const LogUpInput& in, Transcript& t) 
 }
 
 // ------------------------------------------------------------------ model description
-enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8, L_POSITIONAL = 9 };
+enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8, L_POSITIONAL = 9,
+                 L_MATMUL2 = 10, L_ADD2 = 11, L_CONCAT_MATMUL = 12, L_QKV = 13 };
+// An edge of the model graph (layers/provable/mod.rs:195-229, Edge): output `index` of node `node`, or input tensor `index` of the model (node < 0)
+struct Wire { int node = -1; int index = 0; };
 struct Layer {
   LayerKind kind;
+  // where the node's inputs come from (Node::inputs, provable/mod.rs:204-211); empty = the chain form: output 0 of the previous node, the
+  // model's input for node 0. A node only reads nodes with smaller ids.
+  std::vector<Wire> inputs;
+  // matmul2 (layers/matrix_mul.rs, MatMul::new(Input, Input)): left [s][nrows] times right [nrows][ncols] ([ncols][nrows] with transpose_b), no bias
+  // add2 (layers/add.rs, Add::new()): out = add_left * a + add_right * b for two inputs of one length
+  // qkv (layers/transformer/qkv.rs): weights = W_q | W_k | W_v, each [nrows][ncols] row major, bias = b_q | b_k | b_v, each [ncols]; the input a
+  // [s][nrows] matrix, the three outputs X W + b
+  // concat matmul (layers/concat_matmul.rs): two rank-3 inputs of shapes cm_a / cm_b; cm_left / cm_right = (concat, mat_mul, output) dimension
+  // of each (InputMatrixDimensions); cm_perm = the optional permutation of the [concat][rows][cols] result (empty: none)
+  size_t cm_a[3] = {0, 0, 0}, cm_b[3] = {0, 0, 0};
+  int cm_left[3] = {0, 2, 1}, cm_right[3] = {0, 1, 2};
+  std::vector<int> cm_perm;
   // dense (padded to powers of two). matmul (layers/matrix_mul.rs, MatMul::new_constant: Input x Weight [+ bias]): the constant RIGHT
   // matrix is [nrows][ncols] row major, the input a row-major [s][nrows] matrix, bias [ncols] or empty
   size_t nrows = 0, ncols = 0;
@@ -196,7 +211,71 @@ struct Layer {
   unsigned shift() const { return fp_scale + right_shift; }
   unsigned clamping_size() const { return intermediate_bit_size + ceil_log2((size_t)fixed_point_multiplier) - shift(); }  // requant.rs:485-488
 };
-struct Model { size_t input_len = 0; std::vector<Layer> layers; };
+// input_lens: the model's input tensors (empty: one of input_len; otherwise input_len is their sum and the input vector their concatenation);
+// outputs: the model's output tensors (empty: output 0 of the last node), concatenated in this order
+struct Model { size_t input_len = 0; std::vector<Layer> layers; std::vector<size_t> input_lens; std::vector<Wire> outputs; };
+static inline size_t n_outputs(const Layer& l) { return l.kind == L_QKV ? 3 : 1; }
+static inline std::vector<Wire> node_inputs(const Model& m, size_t id) {
+  if (!m.layers[id].inputs.empty()) return m.layers[id].inputs;
+  Wire w; if (id > 0) { w.node = (int)id - 1; w.index = 0; }
+  return {w};
+}
+static inline std::vector<Wire> model_outputs(const Model& m) {
+  if (!m.outputs.empty()) return m.outputs;
+  Wire w; w.node = (int)m.layers.size() - 1; w.index = 0;
+  return {w};
+}
+static inline std::vector<size_t> model_input_lens(const Model& m) { return m.input_lens.empty() ? std::vector<size_t>{m.input_len} : m.input_lens; }
+// the single consumer of an output wire (claims_for_node, provable/mod.rs:235-270: "only one edge per output wire"): input `pos` of node `node`,
+// or output `pos` of the model (node < 0)
+struct WireUse { int node = -1; int pos = 0; bool found = false; };
+static inline WireUse wire_use(const Model& m, int node, int index) {
+  WireUse u; size_t uses = 0;
+  for (size_t id = 0; id < m.layers.size(); id++) { std::vector<Wire> in = node_inputs(m, id); for (size_t q = 0; q < in.size(); q++) if (in[q].node == node && in[q].index == index) { u.node = (int)id; u.pos = (int)q; u.found = true; uses++; } }
+  std::vector<Wire> outs = model_outputs(m);
+  for (size_t q = 0; q < outs.size(); q++) if (outs[q].node == node && outs[q].index == index) { u.node = -1; u.pos = (int)q; u.found = true; uses++; }
+  if (uses != 1) throw std::runtime_error("model graph: every output wire needs exactly one consumer");
+  return u;
+}
+// NodeIterator<_, false> (model/iterator.rs:152-185): the smallest unvisited id all of whose consumers have been visited, again and again
+static inline std::vector<size_t> backward_order(const Model& m) {
+  std::vector<bool> done(m.layers.size(), false);
+  std::vector<size_t> order;
+  for (size_t step = 0; step < m.layers.size(); step++) {
+    bool found = false;
+    for (size_t id = 0; id < m.layers.size() && !found; id++) {
+      if (done[id]) continue;
+      bool ready = true;
+      for (size_t j = 0; j < n_outputs(m.layers[id]) && ready; j++) { WireUse u = wire_use(m, (int)id, (int)j); if (u.node >= 0 && !done[(size_t)u.node]) ready = false; }
+      if (ready) { done[id] = true; order.push_back(id); found = true; }
+    }
+    if (!found) throw std::runtime_error("model graph: cycle");
+  }
+  return order;
+}
+// Tensor::permute3d (tensor.rs:1769-1800): dimension d of the result is dimension order[d] of the input
+template <class T> static inline std::vector<T> permute3d(const std::vector<T>& x, const size_t shape[3], const int order[3], size_t out_shape[3]) {
+  for (int d = 0; d < 3; d++) out_shape[d] = shape[order[d]];
+  std::vector<T> o(x.size());
+  for (size_t i = 0; i < shape[0]; i++) for (size_t j = 0; j < shape[1]; j++) for (size_t k = 0; k < shape[2]; k++) {
+    const size_t pos[3] = {i, j, k};
+    o[(pos[order[0]] * out_shape[1] + pos[order[1]]) * out_shape[2] + pos[order[2]]] = x[(i * shape[1] + j) * shape[2] + k];
+  }
+  return o;
+}
+// InputMatrixDimensions::compute_permutation (concat_matmul.rs:101-114): the order that brings (concat, mat_mul, output) = dims to `expected`;
+// false: already there
+static inline bool cm_permutation(const int dims[3], const int expected[3], int order[3]) {
+  if (dims[0] == expected[0] && dims[1] == expected[1] && dims[2] == expected[2]) return false;
+  order[expected[0]] = dims[0]; order[expected[2]] = dims[2]; order[expected[1]] = dims[1];
+  return true;
+}
+constexpr int CM_EXPECTED_LEFT[3] = {0, 2, 1}, CM_EXPECTED_RIGHT[3] = {0, 1, 2};  // (concat, mat_mul, output) the per-chunk products need (concat_matmul.rs:443-465)
+// shape of ConcatMatMul's output (MatrixPermutations::output_shapes, concat_matmul.rs:206-237)
+static inline void cm_output_shape(const Layer& l, size_t out[3]) {
+  size_t r[3] = {l.cm_a[l.cm_left[0]], l.cm_a[l.cm_left[2]], l.cm_b[l.cm_right[2]]};
+  for (int d = 0; d < 3; d++) out[d] = l.cm_perm.empty() ? r[d] : r[l.cm_perm[d]];
+}
 
 struct TableType {  // lookup/context.rs:55-72 (derive Ord: Relu < GELU < Range < Clamping(n) < ...)
   int kind;  // 0 Relu, 2 Range, 3 Clamping
@@ -230,7 +309,11 @@ struct ConvData {
   std::vector<std::vector<E>> input, input_fft, prod, output;
   std::vector<int64_t> output_as_element;  // conv output AFTER the bias, BEFORE clearing the garbage (convolution.rs:311-316)
 };
-struct Trace { std::vector<std::vector<int64_t>> in, out; std::vector<ConvData> conv; };  // per node input / output tensors
+// per node input / output tensors; in2 = the second input of a two-input node, out_more = the outputs after the first (QKV: K, V)
+struct Trace {
+  std::vector<std::vector<int64_t>> in, out, in2; std::vector<std::vector<std::vector<int64_t>>> out_more; std::vector<ConvData> conv;
+  const std::vector<int64_t>& output(size_t node, size_t index) const { return index == 0 ? out[node] : out_more[node][index - 1]; }
+};
 
 // get_root_of_unity (tensor.rs:220-231)
 static inline E get_root_of_unity(unsigned n) {
@@ -332,12 +415,67 @@ static inline int64_t requant_apply(const Layer& l, int64_t v) {
   int64_t tmp = v * l.fixed_point_multiplier + (int64_t(1) << (sh - 1));
   return clamp_q(tmp >> sh);
 }
+// the concatenated output tensors of the model (ModelSpec::outputs order)
+static inline std::vector<int64_t> model_output(const Model& m, const Trace& tr) {
+  std::vector<int64_t> o;
+  for (const Wire& w : model_outputs(m)) { const std::vector<int64_t>& v = tr.output((size_t)w.node, (size_t)w.index); o.insert(o.end(), v.begin(), v.end()); }
+  return o;
+}
 static inline Trace run_model(const Model& m, const std::vector<int64_t>& input) {
-  Trace tr; std::vector<int64_t> cur = input;
-  if (cur.size() != m.input_len) throw std::runtime_error("input length mismatch");
-  for (auto& l : m.layers) {
+  Trace tr;
+  if (input.size() != m.input_len) throw std::runtime_error("input length mismatch");
+  const std::vector<size_t> in_lens = model_input_lens(m);
+  { size_t tot = 0; for (size_t n : in_lens) tot += n; if (tot != m.input_len) throw std::runtime_error("input tensors do not add up to input_len"); }
+  auto value = [&](const Wire& w) -> std::vector<int64_t> {
+    if (w.node >= 0) { if ((size_t)w.node >= tr.out.size()) throw std::runtime_error("model graph: a node reads a later node"); return tr.output((size_t)w.node, (size_t)w.index); }
+    size_t off = 0; for (int q = 0; q < w.index; q++) off += in_lens.at((size_t)q);
+    return std::vector<int64_t>(input.begin() + off, input.begin() + off + in_lens.at((size_t)w.index));
+  };
+  tr.in2.resize(m.layers.size()); tr.out_more.resize(m.layers.size());
+  for (size_t id = 0; id < m.layers.size(); id++) {
+    const Layer& l = m.layers[id];
+    const std::vector<Wire> wires = node_inputs(m, id);
+    std::vector<int64_t> cur = value(wires[0]);
     tr.in.push_back(cur);
+    if (wires.size() > 1) tr.in2[id] = value(wires[1]);
+    if (wires.size() != ((l.kind == L_MATMUL2 || l.kind == L_ADD2 || l.kind == L_CONCAT_MATMUL) ? 2u : 1u)) throw std::runtime_error("model graph: wrong number of inputs for a node");
     std::vector<int64_t> o;
+    if (l.kind == L_MATMUL2) {  // MatMul::op (matrix_mul.rs:230-311) on two input tensors
+      const std::vector<int64_t>& b = tr.in2[id];
+      const size_t k = l.nrows, n = l.ncols;
+      if (!k || cur.size() % k || b.size() != k * n) throw std::runtime_error("matmul2: input shapes");
+      const size_t s_ = cur.size() / k;
+      o.assign(s_ * n, 0);
+      for (size_t i = 0; i < s_; i++) for (size_t j = 0; j < n; j++) { int64_t a = 0; for (size_t q = 0; q < k; q++) a += cur[i * k + q] * (l.transpose_b ? b[j * k + q] : b[q * n + j]); o[i * n + j] = a; }
+    } else if (l.kind == L_ADD2) {  // Add::evaluate (add.rs:184-210), no operand
+      const std::vector<int64_t>& b = tr.in2[id];
+      if (cur.size() != b.size()) throw std::runtime_error("add2: inputs of different lengths");
+      o.resize(cur.size());
+      for (size_t i = 0; i < cur.size(); i++) o[i] = l.add_left * cur[i] + l.add_right * b[i];
+    } else if (l.kind == L_QKV) {  // QKV::evaluate (qkv.rs:275-340, no cache): X W_q + b_q, X W_k + b_k, X W_v + b_v
+      const size_t k = l.nrows, n = l.ncols;
+      if (!k || cur.size() % k || l.weights.size() != 3 * k * n || l.bias.size() != 3 * n) throw std::runtime_error("qkv: shapes");
+      const size_t s_ = cur.size() / k;
+      for (int w = 0; w < 3; w++) {
+        std::vector<int64_t> y(s_ * n);
+        for (size_t i = 0; i < s_; i++) for (size_t j = 0; j < n; j++) { int64_t a = 0; for (size_t q = 0; q < k; q++) a += cur[i * k + q] * l.weights[(w * k + q) * n + j]; y[i * n + j] = a + l.bias[w * n + j]; }
+        if (w == 0) o = y; else tr.out_more[id].push_back(y);
+      }
+    } else if (l.kind == L_CONCAT_MATMUL) {  // ConcatMatMul::evaluate (concat_matmul.rs:568-616): chunk c of the result = chunk c of A times chunk c of B
+      const std::vector<int64_t>& b0 = tr.in2[id];
+      if (cur.size() != l.cm_a[0] * l.cm_a[1] * l.cm_a[2] || b0.size() != l.cm_b[0] * l.cm_b[1] * l.cm_b[2]) throw std::runtime_error("concat matmul: input shapes");
+      int order[3]; size_t sa[3], sb[3];
+      std::vector<int64_t> a = cur, b = b0;
+      for (int d = 0; d < 3; d++) { sa[d] = l.cm_a[d]; sb[d] = l.cm_b[d]; }
+      if (cm_permutation(l.cm_left, CM_EXPECTED_LEFT, order)) { size_t t[3]; a = permute3d(cur, l.cm_a, order, t); for (int d = 0; d < 3; d++) sa[d] = t[d]; }
+      if (cm_permutation(l.cm_right, CM_EXPECTED_RIGHT, order)) { size_t t[3]; b = permute3d(b0, l.cm_b, order, t); for (int d = 0; d < 3; d++) sb[d] = t[d]; }
+      if (sa[0] != sb[0] || sa[2] != sb[1]) throw std::runtime_error("concat matmul: chunk shapes");
+      const size_t C = sa[0], R = sa[1], M = sa[2], N = sb[2];
+      std::vector<int64_t> r(C * R * N, 0);
+      for (size_t c = 0; c < C; c++) for (size_t i = 0; i < R; i++) for (size_t j = 0; j < N; j++) { int64_t acc = 0; for (size_t q = 0; q < M; q++) acc += a[(c * R + i) * M + q] * b[(c * M + q) * N + j]; r[(c * R + i) * N + j] = acc; }
+      if (l.cm_perm.empty()) o = r;
+      else { const size_t rs[3] = {C, R, N}; const int po[3] = {l.cm_perm[0], l.cm_perm[1], l.cm_perm[2]}; size_t t[3]; o = permute3d(r, rs, po, t); }
+    } else
     if (l.kind == L_DENSE) {
       if (cur.size() != l.ncols) throw std::runtime_error("dense input size mismatch");
       o.resize(l.nrows);
@@ -372,7 +510,7 @@ static inline Trace run_model(const Model& m, const std::vector<int64_t>& input)
     else if (l.kind == L_MAXPOOL) o = maxpool_op(l, cur);
     else if (l.kind == L_FLATTEN) o = cur;
     else throw std::runtime_error("unknown layer kind");
-    tr.out.push_back(o); cur = o;
+    tr.out.push_back(o);
   }
   return tr;
 }
@@ -387,23 +525,44 @@ struct Context {
   size_t max_poly_len = 0;
 };
 static inline size_t next_pow2(size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; }
+// lengths of every node's output tensors (the shape propagation of run_model)
+static inline std::vector<std::vector<size_t>> node_output_lens(const Model& m) {
+  const std::vector<size_t> in_lens = model_input_lens(m);
+  std::vector<std::vector<size_t>> lens(m.layers.size());
+  auto len_of = [&](const Wire& w) { return w.node < 0 ? in_lens.at((size_t)w.index) : lens.at((size_t)w.node).at((size_t)w.index); };
+  for (size_t id = 0; id < m.layers.size(); id++) {
+    const Layer& l = m.layers[id];
+    const std::vector<Wire> wires = node_inputs(m, id);
+    for (const Wire& w : wires) if (w.node >= (int)id) throw std::runtime_error("model graph: a node reads a later node");
+    size_t cur = len_of(wires[0]);
+    if (l.kind == L_DENSE) cur = l.nrows;
+    else if (l.kind == L_MATMUL || l.kind == L_MATMUL2 || l.kind == L_QKV) cur = cur / l.nrows * l.ncols;
+    else if (l.kind == L_EMBED) cur = cur * l.ncols;
+    else if (l.kind == L_CONV) cur = l.kw * l.nw * l.nw;
+    else if (l.kind == L_MAXPOOL) cur = l.pin[0] * (l.pin[1] / 2) * (l.pin[2] / 2);
+    else if (l.kind == L_CONCAT_MATMUL) { size_t o[3]; cm_output_shape(l, o); cur = o[0] * o[1] * o[2]; }
+    lens[id].assign(n_outputs(l), cur);
+  }
+  return lens;
+}
 static inline Context context_generate(const Model& m) {
   Context ctx; ctx.model = m;
-  size_t max_poly_len = m.input_len;
+  size_t max_poly_len = 0;
+  for (size_t n : model_input_lens(m)) max_poly_len = std::max(max_poly_len, n);
   std::vector<TableType> tset;
   auto add_table = [&](TableType t) { for (auto& x : tset) if (x == t) return; tset.push_back(t); };
-  size_t cur_len = m.input_len;
-  for (auto& l : m.layers) {
-    if (l.kind == L_DENSE) { cur_len = l.nrows; }
-    else if (l.kind == L_MATMUL) { cur_len = cur_len / l.nrows * l.ncols; }
-    else if (l.kind == L_EMBED) { cur_len = cur_len * l.ncols; }
-    else if (l.kind == L_REQUANT) { add_table({2, 0}); add_table({3, l.clamping_size()}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
+  const std::vector<std::vector<size_t>> out_lens = node_output_lens(m);
+  for (size_t id_ = 0; id_ < m.layers.size(); id_++) {
+    const Layer& l = m.layers[id_];
+    size_t cur_len = out_lens[id_][0];  // (Requant / Relu keep the length of their input)
+    if (l.kind == L_REQUANT) { add_table({2, 0}); add_table({3, l.clamping_size()}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
     else if (l.kind == L_RELU) { add_table({0, 0}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
     else if (l.kind == L_CONV) { cur_len = l.kw * l.nw * l.nw; }                                                       // convolution.rs:506-511
     else if (l.kind == L_MAXPOOL) { add_table({2, 0}); cur_len = l.pin[0] * (l.pin[1] / 2) * (l.pin[2] / 2); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }  // pooling.rs:131-166
   }
   std::sort(tset.begin(), tset.end());
   for (auto& t : tset) max_poly_len = std::max(max_poly_len, size_t(1) << t.multiplicity_poly_vars());
+  for (auto& l : m.layers) if (l.kind == L_QKV) { max_poly_len = std::max(max_poly_len, next_pow2(l.weights.size() / 3)); max_poly_len = std::max(max_poly_len, next_pow2(l.bias.size() / 3)); }
   for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD || l.kind == L_EMBED || l.kind == L_POSITIONAL) { max_poly_len = std::max(max_poly_len, next_pow2(l.weights.size())); max_poly_len = std::max(max_poly_len, next_pow2(l.bias.size())); }
   max_poly_len = next_pow2(max_poly_len);
   ctx.max_poly_len = max_poly_len;
@@ -418,13 +577,19 @@ static inline Context context_generate(const Model& m) {
     if (m.layers[id].kind == L_EMBED) jobs.push_back({id, "EmbeddingMat"});  // embeddings.rs:271,284-291
     if (m.layers[id].kind == L_ADD) jobs.push_back({id, "255"});  // OPERAND_POLY_ID = 0xff, to_string() (add.rs:32,520)
     if (m.layers[id].kind == L_MATMUL) { jobs.push_back({id, "MatMulWeight"}); if (!m.layers[id].bias.empty()) jobs.push_back({id, "MatMulBias"}); }  // matrix_mul.rs:947-963
+    if (m.layers[id].kind == L_QKV) for (const char* pid : {"WeightQ", "WeightK", "WeightV", "BiasQ", "BiasK", "BiasV"}) jobs.push_back({id, pid});  // qkv.rs:388-418
   }
   for (auto& j : jobs) ctx.model_comms[j.first][j.second];  // create map slots before the threads write into them
   std::vector<std::thread> th;
   for (auto& j : jobs) th.emplace_back([&ctx, &m, j] {
     const Layer& l = m.layers[j.first];
     std::string pid = j.second;
-    Mle poly = Mle::from_i64(pid == "DenseWeight" || pid == "ConvFilter" || pid == "MatMulWeight" || pid == "255" || pid == "EmbeddingMat" || pid == "PositionalMatrix" ? l.weights : l.bias);
+    Mle poly;
+    if (l.kind == L_QKV) {  // the three weight matrices and bias vectors are committed one by one
+      const bool wgt = pid[0] == 'W'; const size_t which = pid.back() == 'Q' ? 0 : pid.back() == 'K' ? 1 : 2;
+      const std::vector<int64_t>& src = wgt ? l.weights : l.bias; const size_t n = src.size() / 3;
+      poly = Mle::from_i64(std::vector<int64_t>(src.begin() + which * n, src.begin() + (which + 1) * n));
+    } else poly = Mle::from_i64(pid == "DenseWeight" || pid == "ConvFilter" || pid == "MatMulWeight" || pid == "255" || pid == "EmbeddingMat" || pid == "PositionalMatrix" ? l.weights : l.bias);
     ctx.model_comms[j.first][j.second] = {pcs_commit(ctx.pp, poly), poly};
   });
   for (auto& t : th) t.join();
@@ -438,6 +603,9 @@ struct AddProof { E left_eval, right_eval; };  // add.rs:59-63
 struct PositionalProof { std::vector<E> sub_matrix_evals; AddProof add_proof; };  // SinglePositionalProof (positional.rs:45-55); one input
 struct MatMulProof { IOPProof sumcheck; std::vector<E> individual_claims; bool has_bias = false; E bias_eval{}; };  // matrix_mul.rs:153-161 (bias_eval: Option<E>)
 struct SamePolyProof { IOPProof sumcheck; std::vector<E> evals; };
+struct ConcatMatMulProof { IOPProof sumcheck; std::vector<E> individual_claims; };  // concat_matmul.rs:365-373
+// qkv.rs:63-83, fields in declaration order; individual_claims = the (input, weight) evaluation pair of Q, K, V
+struct QKVProof { IOPProof sumcheck; SamePolyProof aggregation_proof; std::vector<E> pre_bias_evals; std::vector<E> individual_claims; };
 struct ActivationProof { SamePolyProof io_accumulation; LogUpProof lookup; std::vector<Commitment> commits; };
 struct RequantProof { IOPProof io_accumulation; std::vector<E> accumulation_evals; LogUpProof clamping_lookup, shifted_lookup; std::vector<Commitment> commitments; };
 struct HadamardProof { IOPProof sumcheck; std::vector<E> individual_claim; };  // hadamard.rs:51-56
@@ -454,7 +622,7 @@ struct ConvProof {  // convolution.rs:98-127, fields in declaration order
   HadamardProof clearing_proof;
 };
 struct PoolingProof { IOPProof sumcheck; LogUpProof lookup; std::vector<E> zerocheck_evals; size_t variable_gap = 0; std::vector<Commitment> commitments; };  // pooling.rs:60-76
-struct LayerProof { LayerKind kind; DenseProof dense; MatMulProof matmul; AddProof add; PositionalProof pos; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; };
+struct LayerProof { LayerKind kind; DenseProof dense; MatMulProof matmul; AddProof add; PositionalProof pos; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; ConcatMatMulProof cmm; QKVProof qkv; };
 struct TableProof { Commitment multiplicity_commit; LogUpProof lookup; };
 struct Proof {
   std::map<size_t, LayerProof> steps;  // canonical order: ascending NodeId
@@ -676,6 +844,133 @@ static inline Claim prove_matmul(ProverState& ps, size_t id, const Layer& l, con
   LayerProof lp; lp.kind = L_MATMUL; lp.matmul.sumcheck = proof; lp.matmul.individual_claims = fin; lp.matmul.has_bias = hb; lp.matmul.bias_eval = bias_eval;
   ps.proofs[id] = lp;
   return {point_left, fin[0]};
+}
+// MatMul::prove_step (layers/matrix_mul.rs:701-873) with BOTH matrices inputs: the same sumcheck, no bias, no commitment — both final
+// evaluations leave as claims, the left input's first (the order of the node's inputs)
+static inline std::vector<Claim> prove_matmul2(ProverState& ps, size_t id, const Layer& l, const Claim& last, const std::vector<E>& a, const std::vector<E>& b) {
+  const size_t k = l.nrows, n = l.ncols, s_ = a.size() / k;
+  const unsigned nvc = log2_strict(n), nvr = log2_strict(s_);
+  if (last.point.size() != nvc + nvr) throw std::runtime_error("matmul2: claim point size mismatch");
+  std::vector<E> pt_right(last.point.begin(), last.point.begin() + nvc), pt_left(last.point.begin() + nvc, last.point.end());
+  Mle left = Mle::from_ext(a), right = Mle::from_ext(b);
+  left.fix_high_in_place(pt_left);
+  if (l.transpose_b) right.fix_high_in_place(pt_right); else right.fix_low_in_place(pt_right);
+  if (left.nv != right.nv) throw std::runtime_error("matmul2: inner dimensions differ");
+  VirtualPolynomial vp(left.nv);
+  vp.add_mle_list({mk(left), mk(right)}, e_one());
+  auto [proof, st] = sumcheck_prove(std::move(vp), *ps.t);
+  std::vector<E> fin = st.final_evaluations();
+  std::vector<E> point_left = proof.point; point_left.insert(point_left.end(), pt_left.begin(), pt_left.end());
+  std::vector<E> point_right = l.transpose_b ? proof.point : pt_right;
+  if (l.transpose_b) point_right.insert(point_right.end(), pt_right.begin(), pt_right.end()); else point_right.insert(point_right.end(), proof.point.begin(), proof.point.end());
+  LayerProof lp; lp.kind = L_MATMUL2; lp.matmul.sumcheck = proof; lp.matmul.individual_claims = fin; lp.matmul.has_bias = false;
+  ps.proofs[id] = lp;
+  return {{point_left, fin[0]}, {point_right, fin[1]}};
+}
+// Add::prove_step without operand (layers/add.rs:81-145): both inputs evaluated at the output claim's point, two claims out, no transcript traffic
+static inline std::vector<Claim> prove_add2(ProverState& ps, size_t id, const Claim& last, const std::vector<E>& a, const std::vector<E>& b) {
+  E left_eval = Mle::from_ext(a).evaluate(last.point), right_eval = Mle::from_ext(b).evaluate(last.point);
+  LayerProof lp; lp.kind = L_ADD2; lp.add = {left_eval, right_eval};
+  ps.proofs[id] = lp;
+  return {{last.point, left_eval}, {last.point, right_eval}};
+}
+// MatrixPermutations::split_output_claim_point (concat_matmul.rs:295-343): the point of the output claim cut into the coordinates of its
+// three dimensions (the last dimension = the low variables), handed back as (concat, rows, columns) of the un-permuted result
+static inline void cm_split_output_point(const Layer& l, const std::vector<E>& point, std::vector<E>& p_concat, std::vector<E>& p_row, std::vector<E>& p_col) {
+  size_t os[3]; cm_output_shape(l, os);
+  std::vector<E> parts[3]; size_t hi = point.size();
+  size_t total = 0; for (int d = 0; d < 3; d++) total += log2_strict(os[d]);
+  if (total != point.size()) throw std::runtime_error("concat matmul: point length does not match the output shape");
+  for (int d = 0; d < 3; d++) { size_t nv = log2_strict(os[d]); parts[d].assign(point.begin() + (hi - nv), point.begin() + hi); hi -= nv; }
+  int where[3] = {0, 1, 2};  // where[source dimension] = its position in the (permuted) output
+  if (!l.cm_perm.empty()) for (int i = 0; i < 3; i++) where[l.cm_perm[i]] = i;
+  p_concat = parts[where[0]]; p_row = parts[where[1]]; p_col = parts[where[2]];
+}
+// InputMatrixDimensions::input_mle_for_proving (concat_matmul.rs:134-166): the input with the coordinates of its output dimension fixed; what is
+// left runs over (concat, mat_mul) with the mat_mul variables low
+static inline Mle cm_input_mle(const std::vector<E>& x, const size_t shape[3], const int dims[3], const std::vector<E>& partial) {
+  const int concat = dims[0], mm = dims[1], out = dims[2];
+  if (concat > mm || out == 1) {
+    const int order[3] = {concat, mm, out}; size_t t[3];
+    Mle m = Mle::from_ext(permute3d(x, shape, order, t));
+    m.fix_low_in_place(partial);
+    return m;
+  }
+  Mle m = Mle::from_ext(x);
+  if (out == 0) m.fix_high_in_place(partial); else m.fix_low_in_place(partial);
+  return m;
+}
+// InputMatrixDimensions::build_point_for_input (concat_matmul.rs:116-132): the three sub-points in the order of the input's dimensions, last first
+static inline std::vector<E> cm_build_point(const int dims[3], const std::vector<E>& p_concat, const std::vector<E>& p_mm, const std::vector<E>& p_out) {
+  const std::vector<E>* by_dim[3] = {nullptr, nullptr, nullptr};
+  by_dim[dims[0]] = &p_concat; by_dim[dims[1]] = &p_mm; by_dim[dims[2]] = &p_out;
+  std::vector<E> pt;
+  for (int d = 2; d >= 0; d--) pt.insert(pt.end(), by_dim[d]->begin(), by_dim[d]->end());
+  return pt;
+}
+// ConcatMatMul::prove_step (concat_matmul.rs:467-566): sum over (chunk c, inner index j) of beta(c) * A_c[row point][j] * B_c[j][column point]
+static inline std::vector<Claim> prove_concat_matmul(ProverState& ps, size_t id, const Layer& l, const Claim& last, const std::vector<E>& a, const std::vector<E>& b) {
+  std::vector<E> p_concat, p_row, p_col;
+  cm_split_output_point(l, last.point, p_concat, p_row, p_col);
+  Mle left = cm_input_mle(a, l.cm_a, l.cm_left, p_row), right = cm_input_mle(b, l.cm_b, l.cm_right, p_col);
+  if (left.nv != right.nv) throw std::runtime_error("concat matmul: left and right MLEs differ in size");
+  const size_t M = l.cm_a[l.cm_left[1]];
+  if (M != l.cm_b[l.cm_right[1]]) throw std::runtime_error("concat matmul: mat_mul dimensions differ");
+  std::vector<E> betas = compute_betas_eval(p_concat), beta_evals;
+  for (E e : betas) for (size_t j = 0; j < M; j++) beta_evals.push_back(e);
+  Mle beta = Mle::from_ext(beta_evals);
+  if (beta.nv != left.nv) throw std::runtime_error("concat matmul: beta vector of the wrong size");
+  VirtualPolynomial vp(left.nv);
+  vp.add_mle_list({mk(beta), mk(left), mk(right)}, e_one());
+  auto [proof, st] = sumcheck_prove(std::move(vp), *ps.t);
+  std::vector<E> evals = st.final_evaluations();
+  const unsigned nvm = log2_strict(M);  // split_sumcheck_point (:256-281): the mat_mul coordinates come first
+  std::vector<E> s_mm(proof.point.begin(), proof.point.begin() + nvm), s_concat(proof.point.begin() + nvm, proof.point.end());
+  LayerProof lp; lp.kind = L_CONCAT_MATMUL; lp.cmm.sumcheck = proof; lp.cmm.individual_claims = evals;
+  ps.proofs[id] = lp;
+  return {{cm_build_point(l.cm_left, s_concat, s_mm, p_row), evals[1]}, {cm_build_point(l.cm_right, s_concat, s_mm, p_col), evals[2]}};
+}
+static inline SamePolyProof same_poly_prove(const std::vector<Claim>& claims, const Mle& poly, Transcript& t);
+// QKV::prove (layers/transformer/qkv.rs:462-630): the three products X W_q, X W_k, X W_v in ONE sumcheck batched with two challenges, then the
+// three claims on X merged into one (same_poly)
+static inline std::vector<Claim> prove_qkv(ProverState& ps, size_t id, const Layer& l, const std::vector<Claim>& last, const std::vector<E>& input) {
+  const size_t k = l.nrows, n = l.ncols, s_ = input.size() / k;
+  const unsigned nvc = log2_strict(n), nvr = log2_strict(s_);
+  if (last.size() != 3) throw std::runtime_error("qkv: three output claims expected");
+  std::vector<std::vector<E>> p_row(3), p_col(3);
+  std::vector<E> bias_evals(3), pre_bias(3);
+  for (int w = 0; w < 3; w++) {
+    if (last[w].point.size() != nvc + nvr) throw std::runtime_error("qkv: claim point size mismatch");
+    p_col[w].assign(last[w].point.begin(), last[w].point.begin() + nvc); p_row[w].assign(last[w].point.begin() + nvc, last[w].point.end());  // split_claim_point (:173-184)
+    bias_evals[w] = Mle::from_i64(std::vector<int64_t>(l.bias.begin() + w * n, l.bias.begin() + (w + 1) * n)).evaluate(p_col[w]);
+    pre_bias[w] = esub(last[w].eval, bias_evals[w]);
+  }
+  // challenges_for_batched_sumcheck (:210-232): points and bias-free evaluations enter the transcript; coefficients 1, c1, c2
+  for (int w = 0; w < 3; w++) { ps.t->append_exts(last[w].point); ps.t->append_ext(pre_bias[w]); }
+  std::vector<E> coeff = {e_one(), ps.t->read_challenge(), ps.t->read_challenge()};
+  VirtualPolynomial vp(log2_strict(k));
+  for (int w = 0; w < 3; w++) {
+    Mle x = Mle::from_ext(input); x.fix_high_in_place(p_row[w]);
+    Mle wm = Mle::from_i64(std::vector<int64_t>(l.weights.begin() + w * k * n, l.weights.begin() + (w + 1) * k * n)); wm.fix_low_in_place(p_col[w]);
+    vp.add_mle_list({mk(x), mk(wm)}, coeff[w]);
+  }
+  auto [proof, st] = sumcheck_prove(std::move(vp), *ps.t);
+  std::vector<E> fin = st.final_evaluations();  // (input, weight) of Q, of K, of V
+  if (fin.size() != 6) throw std::runtime_error("qkv: six final evaluations expected");
+  std::vector<Claim> input_claims, weight_claims;
+  for (int w = 0; w < 3; w++) {  // build_points (:193-204)
+    std::vector<E> pi = proof.point; pi.insert(pi.end(), p_row[w].begin(), p_row[w].end());
+    std::vector<E> pw = p_col[w]; pw.insert(pw.end(), proof.point.begin(), proof.point.end());
+    input_claims.push_back({pi, fin[2 * w]}); weight_claims.push_back({pw, fin[2 * w + 1]});
+  }
+  // add_common_claims walks the node's polynomials in BTreeMap order: BiasK, BiasQ, BiasV, WeightK, WeightQ, WeightV
+  const auto& comms = ps.ctx->model_comms.at(id);
+  ps.add_witness_claim(comms.at("BiasK"), {p_col[1], bias_evals[1]}); ps.add_witness_claim(comms.at("BiasQ"), {p_col[0], bias_evals[0]}); ps.add_witness_claim(comms.at("BiasV"), {p_col[2], bias_evals[2]});
+  ps.add_witness_claim(comms.at("WeightK"), weight_claims[1]); ps.add_witness_claim(comms.at("WeightQ"), weight_claims[0]); ps.add_witness_claim(comms.at("WeightV"), weight_claims[2]);
+  SamePolyProof agg = same_poly_prove(input_claims, Mle::from_ext(input), *ps.t);
+  LayerProof lp; lp.kind = L_QKV; lp.qkv.sumcheck = proof; lp.qkv.aggregation_proof = agg; lp.qkv.pre_bias_evals = pre_bias; lp.qkv.individual_claims = fin;
+  ps.proofs[id] = lp;
+  return {{agg.sumcheck.point, agg.evals[1]}};
 }
 // Requant::recombine_claims (requant.rs:499-529)
 static inline E recombine_claims(const Layer& l, E clamping_claim, const std::vector<E>& shifted) {
@@ -1000,11 +1295,25 @@ static inline Proof prove(const Context& ctx, const Trace& tr, Transcript& t) {
   for (auto& [id, m] : ctx.model_comms) for (auto& [pid, pc] : m) t.append_digest(pc.first.codeword_tree.root());
   instantiate_witness_ctx(ps, tr);
   auto to_fields = [](const std::vector<int64_t>& v) { std::vector<E> o(v.size()); for (size_t i = 0; i < v.size(); i++) o[i] = e_from_i64(v[i]); return o; };
-  const std::vector<int64_t>& out = tr.out.back();
-  std::vector<E> r = t.read_challenges(log2_strict(out.size()));
-  Claim cur{r, Mle::from_ext(to_fields(out)).evaluate(r)};
-  for (size_t id = ctx.model.layers.size(); id-- > 0;) {
-    const Layer& l = ctx.model.layers[id];
+  // one claim per output tensor of the model (iop/prover.rs:419-435), then the nodes in backward order, each handing one claim per input to
+  // whoever produces that input (claims_for_node, provable/mod.rs:235-270)
+  const Model& mdl = ctx.model;
+  std::vector<Claim> out_claims;
+  for (const Wire& w : model_outputs(mdl)) {
+    const std::vector<int64_t>& out = tr.output((size_t)w.node, (size_t)w.index);
+    std::vector<E> r = t.read_challenges(log2_strict(out.size()));
+    out_claims.push_back({r, Mle::from_ext(to_fields(out)).evaluate(r)});
+  }
+  std::map<size_t, std::vector<Claim>> claims_by_node;
+  for (size_t id : backward_order(mdl)) {
+    const Layer& l = mdl.layers[id];
+    std::vector<Claim> last;
+    for (size_t j = 0; j < n_outputs(l); j++) { WireUse u = wire_use(mdl, (int)id, (int)j); last.push_back(u.node < 0 ? out_claims.at((size_t)u.pos) : claims_by_node.at((size_t)u.node).at((size_t)u.pos)); }
+    Claim cur = last[0];
+    if (l.kind == L_MATMUL2) { claims_by_node[id] = prove_matmul2(ps, id, l, cur, to_fields(tr.in[id]), to_fields(tr.in2[id])); continue; }
+    if (l.kind == L_ADD2) { claims_by_node[id] = prove_add2(ps, id, cur, to_fields(tr.in[id]), to_fields(tr.in2[id])); continue; }
+    if (l.kind == L_CONCAT_MATMUL) { claims_by_node[id] = prove_concat_matmul(ps, id, l, cur, to_fields(tr.in[id]), to_fields(tr.in2[id])); continue; }
+    if (l.kind == L_QKV) { claims_by_node[id] = prove_qkv(ps, id, l, last, to_fields(tr.in[id])); continue; }
     if (l.kind == L_DENSE) cur = prove_dense(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_MATMUL) cur = prove_matmul(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_ADD) cur = prove_add(ps, id, l, cur, to_fields(tr.in[id]));
@@ -1015,6 +1324,7 @@ static inline Proof prove(const Context& ctx, const Trace& tr, Transcript& t) {
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv[id]);
     else if (l.kind == L_MAXPOOL) cur = prove_pooling(ps, id, l, cur, to_fields(tr.out[id]));
     // L_FLATTEN is not provable: the claim is propagated unchanged (iop/prover.rs:449-456)
+    claims_by_node[id] = {cur};
   }
   Proof proof;
   // prove_tables (iop/prover.rs:110-157)
@@ -1075,6 +1385,10 @@ static inline std::vector<u64> serialize_proof(const Proof& p) {
     else if (lp.kind == L_ADD) { w.e(lp.add.left_eval); w.e(lp.add.right_eval); }
     else if (lp.kind == L_EMBED) { w.iop(lp.matmul.sumcheck); w.ve(lp.matmul.individual_claims); }
     else if (lp.kind == L_POSITIONAL) { w.u(1); w.ve(lp.pos.sub_matrix_evals); w.e(lp.pos.add_proof.left_eval); w.e(lp.pos.add_proof.right_eval); }  // PositionalProof {proofs: [one per input]}
+    else if (lp.kind == L_ADD2) { w.e(lp.add.left_eval); w.e(lp.add.right_eval); }
+    else if (lp.kind == L_MATMUL2) { w.iop(lp.matmul.sumcheck); w.ve(lp.matmul.individual_claims); w.u(0); }  // (bias_eval: None)
+    else if (lp.kind == L_CONCAT_MATMUL) { w.iop(lp.cmm.sumcheck); w.ve(lp.cmm.individual_claims); }
+    else if (lp.kind == L_QKV) { w.iop(lp.qkv.sumcheck); w.iop(lp.qkv.aggregation_proof.sumcheck); w.ve(lp.qkv.aggregation_proof.evals); w.ve(lp.qkv.pre_bias_evals); w.ve(lp.qkv.individual_claims); }
     else if (lp.kind == L_MATMUL) { w.iop(lp.matmul.sumcheck); w.ve(lp.matmul.individual_claims); w.u(lp.matmul.has_bias ? 1 : 0); if (lp.matmul.has_bias) w.e(lp.matmul.bias_eval); }
     else if (lp.kind == L_REQUANT) {
       w.iop(lp.req.io_accumulation); w.ve(lp.req.accumulation_evals); w.logup(lp.req.clamping_lookup); w.logup(lp.req.shifted_lookup);

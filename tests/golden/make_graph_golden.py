@@ -1,0 +1,48 @@
+"""Golden fixture of the GRAPH models (run from the repo root: python tests/golden/make_graph_golden.py): QKV, ConcatMatMul, MatMul and Add of
+two inputs (layers/transformer/qkv.rs, layers/concat_matmul.rs, layers/matrix_mul.rs, layers/add.rs; models with several input and output
+tensors) proved by the ORACLE. Like the other fixtures it pins the oracle against regressions ("parity unpinned"): sha256 of the model blob,
+the input, the output (checked against the numpy inference of models.GraphBuilder.run) and the canonical proof stream."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from support import oracle_lib  # noqa: E402
+import deep_prove_amd as dpa  # noqa: E402
+
+CASES = [
+    ("attention_block", dict(seq=8, emb=16, heads=2, head_dim=8, config=61)),
+    ("attention_block", dict(seq=16, emb=64, heads=4, head_dim=16, config=65)),
+    ("matmul_pair", dict(seq=4, k=8, n=16, config=62)),
+    ("matmul_pair", dict(seq=8, k=32, n=16, config=63, transpose_b=True)),
+    ("qkv_two_outputs", dict(seq=4, k=16, n=16, config=64)),
+]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def build(name, kw):
+    return getattr(dpa.models, name)(**kw)
+
+
+if __name__ == "__main__":
+    o = oracle_lib.load()
+    out = []
+    for name, kw in CASES:
+        g = build(name, kw)
+        blob, x = g.blob(), g.input()
+        h = o.model_setup(blob)
+        proof, y, _ = o.model_prove(h, x)
+        o.model_free(h)
+        assert y.size == g.run(x).size and (y == g.run(x)).all(), name
+        out.append(dict(model=name, args=kw, blob_sha256=sha(blob), input_sha256=sha(x), output_sha256=sha(y), proof_sha256=sha(proof), proof_words=int(proof.size)))
+        print(name, kw, proof.size, "proof words")
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_models.json"), "w") as f:
+        json.dump(out, f, indent=1)

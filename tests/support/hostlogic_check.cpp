@@ -33,8 +33,11 @@ static dp::LayerSpec requant_for(size_t ncols, double m) {
   return l;
 }
 static orc::Model to_orc(const dp::ModelSpec& m) {
-  orc::Model o; o.input_len = m.input_len;
-  for (auto& l : m.layers) { orc::Layer x; x.kind = (orc::LayerKind)l.kind; x.nrows = l.nrows; x.ncols = l.ncols; x.weights = l.weights; x.bias = l.bias; x.transpose_b = l.mm_transpose; x.add_left = l.add_left; x.add_right = l.add_right; x.right_shift = l.right_shift; x.fp_scale = l.fp_scale; x.intermediate_bit_size = l.intermediate_bit_size; x.fixed_point_multiplier = l.fixed_point_multiplier;
+  orc::Model o; o.input_len = m.input_len; o.input_lens = m.input_lens;
+  for (auto& e : m.outputs) { orc::Wire w; w.node = e.from; w.index = e.slot; o.outputs.push_back(w); }
+  for (auto& l : m.layers) { orc::Layer x; x.kind = (orc::LayerKind)l.kind;
+    for (auto& e : l.inputs) { orc::Wire w; w.node = e.from; w.index = e.slot; x.inputs.push_back(w); }
+    for (int d = 0; d < 3; d++) { x.cm_a[d] = l.cm_a[d]; x.cm_b[d] = l.cm_b[d]; x.cm_left[d] = l.cm_left[d]; x.cm_right[d] = l.cm_right[d]; } x.cm_perm = l.cm_perm; x.nrows = l.nrows; x.ncols = l.ncols; x.weights = l.weights; x.bias = l.bias; x.transpose_b = l.mm_transpose; x.add_left = l.add_left; x.add_right = l.add_right; x.right_shift = l.right_shift; x.fp_scale = l.fp_scale; x.intermediate_bit_size = l.intermediate_bit_size; x.fixed_point_multiplier = l.fixed_point_multiplier;
     x.kw = l.kw; x.kx = l.kx; x.real_nw = l.real_nw; x.nw = l.nw; for (int k = 0; k < 3; k++) { x.unp_out[k] = l.unp_out[k]; x.pin[k] = l.pin[k]; }
     o.layers.push_back(x); }
   return o;
@@ -59,6 +62,56 @@ static dp::ModelSpec tiny_cnn(std::vector<int64_t>& in) {
   for (size_t r = 0; r < 5; r++) { for (size_t c = 0; c < OC; c++) for (size_t y = 0; y < UH; y++) for (size_t x = 0; x < UH; x++) d.weights[r * COLS + (c * PH + y) * PH + x] = rq(); d.bias[r] = rq(); }
   m.layers.push_back(d);
   m.layers.push_back(requant_for(COLS, 2.5 / std::sqrt((double)(OC * UH * UH)) / 127));
+  return m;
+}
+// `hostlogic_check graph <variant> <seed>`: models that are GRAPHS (layers/provable/mod.rs:195-565) — nodes with two inputs, a node with three
+// outputs, several input and output tensors
+static dp::ModelSpec g_graph_model; static std::vector<int64_t> g_graph_in;
+static dp::Edge edge(int from, int slot = 0) { dp::Edge e; e.from = from; e.slot = slot; return e; }
+static dp::ModelSpec graph_model(int variant, std::vector<int64_t>& in) {
+  dp::ModelSpec m;
+  dp::LayerSpec relu; relu.kind = dp::L_RELU;
+  auto small = [] { return (int64_t)(rnd() % 15) - 7; };
+  if (variant == 0 || variant == 1) {
+    // two input tensors A [s][k] and B ([k][n]; [n][k] transposed in variant 1), a third C [s][n]: MatMul(A, B) -> Add(., C) -> Requant -> ReLU
+    const size_t S = 4, K = 8, N = 16;
+    m.input_lens = {S * K, K * N, S * N}; m.input_len = S * K + K * N + S * N;
+    dp::LayerSpec mm; mm.kind = dp::L_MATMUL2; mm.nrows = K; mm.ncols = N; mm.mm_transpose = variant == 1; mm.inputs = {edge(-1, 0), edge(-1, 1)};
+    dp::LayerSpec ad; ad.kind = dp::L_ADD2; ad.add_left = 1; ad.add_right = 3; ad.inputs = {edge(0), edge(-1, 2)};
+    dp::LayerSpec rqn = requant_for(K, 1.0 / std::sqrt((double)K) / 127); rqn.inputs = {edge(1)};
+    dp::LayerSpec rl = relu; rl.inputs = {edge(2)};
+    m.layers = {mm, ad, rqn, rl};
+    in.resize(m.input_len); for (auto& x : in) x = rq();
+  } else if (variant == 2) {
+    // QKV with TWO model outputs: Q itself and K + 2 V — the node with three outputs, claims arriving from an output and from a later node
+    const size_t S = 4, K = 16, N = 16;
+    m.input_len = S * K;
+    dp::LayerSpec q; q.kind = dp::L_QKV; q.nrows = K; q.ncols = N; q.weights.resize(3 * K * N); for (auto& x : q.weights) x = rq(); q.bias.resize(3 * N); for (auto& x : q.bias) x = rq(); q.inputs = {edge(-1, 0)};
+    dp::LayerSpec ad; ad.kind = dp::L_ADD2; ad.add_left = 1; ad.add_right = 2; ad.inputs = {edge(0, 1), edge(0, 2)};
+    m.layers = {q, ad};
+    m.outputs = {edge(0, 0), edge(1, 0)};
+    in.resize(m.input_len); for (auto& x : in) x = rq();
+  } else {
+    // an attention block without softmax: X -> QKV; scores_h = Q_h K_h^T (ConcatMatMul over [s][h][d] tensors, heads = the concat axis);
+    // out_h = scores_h V_h, laid back out as [s][h][d] (output permutation); + a second input tensor (Add). Variant 4: the other axis layouts.
+    const size_t S = 4, K = 16, H = 2, D = 8, N = H * D;
+    m.input_lens = {S * K, S * N}; m.input_len = S * K + S * N;
+    dp::LayerSpec q; q.kind = dp::L_QKV; q.nrows = K; q.ncols = N; q.weights.resize(3 * K * N); for (auto& x : q.weights) x = small(); q.bias.resize(3 * N); for (auto& x : q.bias) x = small(); q.inputs = {edge(-1, 0)};
+    dp::LayerSpec sc; sc.kind = dp::L_CONCAT_MATMUL; sc.inputs = {edge(0, 0), edge(0, 1)};
+    sc.cm_a[0] = S; sc.cm_a[1] = H; sc.cm_a[2] = D; sc.cm_b[0] = S; sc.cm_b[1] = H; sc.cm_b[2] = D;
+    sc.cm_left[0] = 1; sc.cm_left[1] = 2; sc.cm_left[2] = 0;     // Q as [s][h][d]: concat over h, inner d, rows s
+    sc.cm_right[0] = 1; sc.cm_right[1] = 2; sc.cm_right[2] = 0;  // K as [s][h][d]: concat over h, inner d, columns s (K^T)
+    if (variant == 4) sc.cm_perm = {0, 2, 1};                     // scores stored transposed: [h][s_k][s_q]
+    dp::LayerSpec av; av.kind = dp::L_CONCAT_MATMUL; av.inputs = {edge(1), edge(0, 2)};
+    av.cm_a[0] = H; av.cm_a[1] = S; av.cm_a[2] = S; av.cm_b[0] = S; av.cm_b[1] = H; av.cm_b[2] = D;
+    if (variant == 4) { av.cm_left[0] = 0; av.cm_left[1] = 1; av.cm_left[2] = 2; }  // [h][s_k][s_q]: inner = axis 1, rows = axis 2
+    else { av.cm_left[0] = 0; av.cm_left[1] = 2; av.cm_left[2] = 1; }
+    av.cm_right[0] = 1; av.cm_right[1] = 0; av.cm_right[2] = 2;  // V as [s][h][d]: concat over h, inner s, columns d
+    av.cm_perm = {1, 0, 2};                                        // [h][s][d] -> [s][h][d]
+    dp::LayerSpec ad; ad.kind = dp::L_ADD2; ad.add_left = 1; ad.add_right = 5; ad.inputs = {edge(2), edge(-1, 1)};
+    m.layers = {q, sc, av, ad};
+    in.resize(m.input_len); for (auto& x : in) x = small();
+  }
   return m;
 }
 // `hostlogic_check sumcheck <seed> <nv>`: the generalised seam 2 (dp_sumcheck_prove's shape: products of 1..5 tables, tables
@@ -360,12 +413,15 @@ int main(int argc, char** argv) {
   if (argc > 1 && std::string(argv[1]) == "sharded") return sharded_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 4);
   if (argc > 1 && std::string(argv[1]) == "sumcheck") return sumcheck_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 6);
   bool cnn = argc > 1 && std::string(argv[1]) == "cnn";
+  const bool graph = argc > 1 && std::string(argv[1]) == "graph";  // `hostlogic_check graph <variant> <seed>`
+  if (graph) { char* a2 = argc > 3 ? argv[3] : (char*)"1"; int variant = argc > 2 ? atoi(argv[2]) : 0; char* a3 = argc > 4 ? argv[4] : nullptr; argv[1] = (char*)"64"; argv[2] = a2; argc = 3; if (a3) { argv[3] = a3; argc = 4; } rs = atoll(a2); std::vector<int64_t> gin; dp::ModelSpec gm = graph_model(variant, gin); g_graph_model = gm; g_graph_in = gin; }
   bool seq = argc > 1 && std::string(argv[1]) == "seq";  // `hostlogic_check seq <seed>`: a per-token MLP over a [8][4] activation out of MatMul layers
   size_t W = argc > 1 && !cnn && !seq ? atoi(argv[1]) : 64; rs = argc > 2 ? atoll(argv[2]) : 1; int tamper = argc > 3 ? atoi(argv[3][0] == '@' ? argv[3] + 1 : argv[3]) : 0; bool tamper_abs = argc > 3 && argv[3][0] == '@';  // "@i": flip word i, else word size/2 + offset
   dp::ModelSpec m; m.input_len = 4;
   dp::LayerSpec relu; relu.kind = dp::L_RELU;
   std::vector<int64_t> in;
-  if (cnn) m = tiny_cnn(in);
+  if (graph) { m = g_graph_model; in = g_graph_in; }
+  else if (cnn) m = tiny_cnn(in);
   else if (seq) {
     const size_t S = 8, F = 4, H = 16;
     m.input_len = S * F;
@@ -447,8 +503,10 @@ int main(int argc, char** argv) {
   // commitments roots compare
   for (auto& kv : ctx->model_comms) for (auto& pc : kv.second) { auto& oc = octx.model_comms.at(kv.first).at(pc.first); bool eq = true; for (int k = 0; k < 4; k++) eq &= oc.first.codeword_tree.root()[k] == pc.second.tree.root.v[k]; if (!eq) printf("ROOT MISMATCH node %zu %s\n", kv.first, pc.first.c_str()); }
   // verifier on the oracle's stream
-  dp::VerifierContext vc = ctx->verifier_ctx();
-  dp::IO io; io.input = in; io.output = tr.out.back();
+  // (through the serialised form dp_verify consumes: the graph section of the verifier blob is exercised too)
+  const std::vector<uint64_t> vcw = dp::vctx_to_words(ctx->verifier_ctx());
+  dp::VerifierContext vc = dp::vctx_from_words(vcw.data(), vcw.size());
+  dp::IO io; io.input = in; io.output = dp::model_output(m, tr);
   int rc = 0;
   for (int which = 0; which < 2; which++) {
     std::vector<uint64_t> w = which ? pw : ow;

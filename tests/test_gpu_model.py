@@ -256,3 +256,41 @@ def test_token_model_proof_bytes_identical_to_oracle(dev, oracle, seq, vocab, wi
     single, sout = dpa.Prover(ctx).prove(xs[6])
     assert proofs[6].size == single.size and (proofs[6] == single).all() and (outs[6] == sout).all()
     ctx.free()
+
+
+def _graph_cases():
+    with open(os.path.join(ROOT, "tests", "golden", "graph_models.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_graph_model_proof_bytes_identical_to_oracle_and_golden(dev, oracle, case):
+    """Models that are GRAPHS (layers/provable/mod.rs:195-565): QKV (three outputs, one batched sumcheck + same_poly), ConcatMatMul (per-head
+    products, degree-3 sumcheck), MatMul and Add of two inputs, several input / output tensors. The device proof equals the oracle's and the
+    committed sha256 (tests/golden/graph_models.json); the verifier accepts it and refuses a flipped word and a wrong input tensor; proofs of
+    a batch (cohorts, device-side Fiat-Shamir) equal the sequential ones."""
+    import deep_prove_amd as dpa
+    c = _graph_cases()[case]
+    g = getattr(dpa.models, c["model"])(**c["args"])
+    x = g.input()
+    ctx, proof, out, oproof, oout = prove_both(dev, oracle, g, x)
+    assert (out == oout).all() and (out == g.run(x)).all()
+    assert proof.size == oproof.size, (proof.size, oproof.size)
+    diff = np.nonzero(proof != oproof)[0]
+    assert diff.size == 0, f"first differing word {diff[:5]} of {proof.size}"
+    assert hashlib.sha256(proof.tobytes()).hexdigest() == c["proof_sha256"]
+    vb = ctx.verifier_blob()
+    dpa.verify(vb, proof, x, out)
+    for at in (3, 40, 90):
+        bad = proof.copy(); bad[at] ^= np.uint64(1)
+        with pytest.raises(dpa.DeepProveError):
+            dpa.verify(vb, bad, x, out)
+    other = x.copy(); other[-1] += 1   # the LAST input tensor: its own claim is checked against it
+    with pytest.raises(dpa.DeepProveError):
+        dpa.verify(vb, proof, other, out)
+    xs = np.stack([g.input(300 + i) for i in range(6)])
+    proofs, outs, _ = dpa.Prover(ctx).prove_batch(xs, 6)
+    single, sout = dpa.Prover(ctx).prove(xs[4])
+    assert proofs[4].size == single.size and (proofs[4] == single).all() and (outs[4] == sout).all()
+    assert (outs[4] == g.run(xs[4])).all()
+    ctx.free()

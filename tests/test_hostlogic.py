@@ -171,6 +171,30 @@ def test_matmul_model_tampered_proof_rejected(hostlogic_bin, where):
     assert "verify(oracle,tampered): REJECT" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("seed", [1, 7])
+def test_graph_model_proof_stream_identical_to_oracle_and_accepted(hostlogic_bin, variant, seed):
+    """Models that are GRAPHS (layers/provable/mod.rs:195-565; Prover::prove over the backward node iterator, iop/prover.rs:437-461): 0 / 1 =
+    MatMul of two input tensors (plain / TransposeB, layers/matrix_mul.rs:633-873) -> Add with a third input (layers/add.rs:81-145) -> Requant
+    -> ReLU; 2 = QKV (layers/transformer/qkv.rs:462-630) with TWO model outputs, Q and K + 2 V; 3 / 4 = QKV -> ConcatMatMul (Q_h K_h^T per head,
+    layers/concat_matmul.rs:467-566, inputs re-laid by their (concat, mat_mul, output) axes) -> ConcatMatMul (scores_h V_h, output permuted
+    back to [s][h][d]; 4: the scores stored transposed) -> Add with a second input. The product's orchestrator over the CPU double gives the
+    oracle's stream; the verifier — fed from the serialised verifier context, graph section included — accepts both."""
+    r = run(hostlogic_bin, "graph", variant, seed)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical=1" in r.stdout
+    assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
+
+
+@pytest.mark.parametrize("variant", [0, 2, 3])
+def test_graph_model_layer_proofs_reject_every_flipped_word(hostlogic_bin, variant):
+    """a single flipped bit in any of the first words of the stream (the layer proofs: sumcheck messages, final evaluations, the QKV
+    aggregation, the pre-bias evaluations) makes the verifier refuse"""
+    for at in list(range(1, 60)) + list(range(60, 330, 9)):
+        r = run(hostlogic_bin, "graph", variant, 11, f"@{at}")
+        assert "verify(oracle,tampered): REJECT" in r.stdout, (at, r.stdout + r.stderr)
+
+
 def test_batch_commit_and_simple_batch_open_over_the_double(hostlogic_bin):
     """PCS::batch_commit + simple_batch_open (mpcs/src/basefold.rs:356-446, 777-861): the product's host code over the CPU double —
     encode every polynomial, the common tree as the ordinary tree over the row hashes (Dev::batch_tree), the commit phase on the

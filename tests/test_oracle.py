@@ -191,3 +191,28 @@ def test_multithreaded_oracle_proof_equals_single_threaded(oracle):
             _, dg = oracle.model_prove_mt(h, x, threads)
             assert dg == want, f"{threads} threads"
         oracle.model_free(h)
+
+
+def test_graph_models_oracle_matches_golden_and_numpy_inference(oracle):
+    """tests/golden/graph_models.json (made by tests/golden/make_graph_golden.py): the oracle's proofs of the graph models — QKV, ConcatMatMul,
+    MatMul / Add of two inputs, several input and output tensors — have not changed, and its inference equals the numpy inference of
+    models.GraphBuilder.run (an independent statement of the layers' arithmetic, ConcatMatMul's axis permutations included)"""
+    import hashlib
+    import json
+    import os
+    import deep_prove_amd as dpa
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    o = oracle
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    with open(os.path.join(ROOT, "tests", "golden", "graph_models.json")) as f:
+        cases = json.load(f)
+    assert len(cases) >= 5
+    for c in cases:
+        g = getattr(dpa.models, c["model"])(**c["args"])
+        blob, x = g.blob(), g.input()
+        assert sha(blob) == c["blob_sha256"] and sha(x) == c["input_sha256"]
+        h = o.model_setup(blob)
+        proof, y, _ = o.model_prove(h, x)
+        o.model_free(h)
+        assert (y == g.run(x)).all() and sha(y) == c["output_sha256"]
+        assert proof.size == c["proof_words"] and sha(proof) == c["proof_sha256"]

@@ -152,3 +152,35 @@ def test_standalone_pcs_proofs_all_three_query_variants(oracle):
     m = msgpack.unpackb(wire.pcs_proof_to_rmp(batched), raw=False, strict_map_key=False)
     assert list(m["query_result_with_merkle_path"]) == ["Batched"] and len(m["sumcheck_proof"]["rounds"]) == 9
     assert (wire.pcs_proof_from_rmp(wire.pcs_proof_to_rmp(batched)) == batched).all()
+
+
+def test_graph_steps_in_the_wire_format(oracle):
+    """LayerProof::QKV(QKVProof {sumcheck, aggregation_proof, pre_bias_evals, individual_claims: [(E, E); 3]}) (transformer/qkv.rs:63-83),
+    LayerProof::ConcatMatMul(ConcatMatMulProof {sumcheck_proof, individual_claims}) (concat_matmul.rs:365-373), and the two-input MatMul / Add
+    in the variants they share with the constant forms: an attention block proved by the oracle, encoded, read by an independent MessagePack
+    decoder, and back (MatMul / Add of two inputs come back as the reference's single variants: kinds 10 / 11 -> 6 / 7)"""
+    import deep_prove_amd as dpa
+    from deep_prove_amd import wire
+    g = dpa.models.attention_block(8, 16, 2, 8, config=61)
+    x = g.input()
+    h = oracle.model_setup(g.blob())
+    p, out, _ = oracle.model_prove(h, x)
+    oracle.model_free(h)
+    data = wire.to_rmp(p)
+    m = msgpack.unpackb(data, raw=False, strict_map_key=False)
+    by_kind = {}
+    for lp in m["steps"].values():
+        for kind, body in lp.items():
+            by_kind.setdefault(kind, []).append(body)
+    assert len(by_kind["QKV"]) == 1 and list(by_kind["QKV"][0]) == ["sumcheck", "aggregation_proof", "pre_bias_evals", "individual_claims"]
+    q = by_kind["QKV"][0]
+    assert len(q["individual_claims"]) == 3 and all(len(pair) == 2 for pair in q["individual_claims"]) and len(q["pre_bias_evals"]) == 3
+    assert list(q["aggregation_proof"]) == ["sumcheck", "evals"]
+    assert len(by_kind["ConcatMatMul"]) == 2 and all(list(b) == ["sumcheck_proof", "individual_claims"] and len(b["individual_claims"]) == 3 for b in by_kind["ConcatMatMul"])
+    assert len(by_kind["Add"]) == 1 and len(by_kind["MatMul"]) == 1 and len(by_kind["Requant"]) == 6
+    back = wire.from_rmp(data)
+    assert wire.to_rmp(back) == data
+    norm = p.copy()  # the canonical stream with kind 11 (Add of two inputs) renamed to 7, as it comes back
+    tree = wire.parse_stream(p)
+    assert sorted(k for _, k, _ in tree["steps"]).count(11) == 1
+    assert wire.parse_stream(back)["steps"][-1][1] == 7
