@@ -163,6 +163,14 @@ class Dev {
     (void)jobs; (void)njobs; (void)tabs; (void)ntabs; (void)terms; (void)coeffs; (void)nterms; (void)nv; (void)max_degree; (void)ch; (void)out;
     return false;
   }
+  // Every delegation sumcheck of one batch FFT / iFFT of the convolution protocol (zkml.h delegate_matrix_evaluation, iop/prover.rs:164-211)
+  // in one go, with the transcript on the device: f_middle[l] (2^(l+1) entries) are the intermediate tables of phi_g_init, r1 (n1 =
+  // |f_middle| + 1 coordinates) the FFT point, r2 (n1 coordinates) the point the batch sumcheck ended at, omegas the 2^n1 powers of the
+  // root of unity. On `true`: for l = |f_middle| - 1 down to 0 the round messages (4 evaluations), the point and the three final
+  // evaluations (beta, phi, f_middle[l]) of that sumcheck; `ch` is the sponge after the last one. `false`: not taken, nothing changed.
+  struct DelegTailArgs { const std::vector<std::vector<Ext>>* f_middle; const Ext* r1; unsigned n1; const Ext* r2; const u64* omegas; size_t nomegas; bool is_fft; };
+  struct DelegTailOut { std::vector<std::vector<std::vector<Ext>>> msgs; std::vector<std::vector<Ext>> points, finals; };
+  virtual bool deleg_tail(const DelegTailArgs& a, Challenger& ch, DelegTailOut& out) { (void)a; (void)ch; (void)out; return false; }
   // The device part of Dense::prove_step (zkml.h prove_dense) in one go, with the transcript on the device: the bias at the
   // output point, W(point, .) (fix_high), and the whole sumcheck of sum_c W(point, c) * in(c) — header, rounds, challenges.
   // On `true`: bias_eval, the round messages (3 evaluations each: degree 2) and challenges of the log2(C) rounds, the final

@@ -15,6 +15,7 @@
 #include "classic_tail.h"
 #include "dense_tail.h"
 #include "eqsum_tail.h"
+#include "deleg_tail.h"
 #include "commit_tail.h"
 #include "sponge_host.h"
 #include "rx.h"
@@ -578,6 +579,7 @@ class HipDev : public Dev {
     if (devclassic_) DP_SET_LDS_ONE(k_classic_tail, 1024, (int)EXCL_LDS);
     if (devdense_) DP_SET_LDS_ONE(k_dense_tail, 1024, (int)EXCL_LDS);
     if (deveqsum_) DP_SET_LDS_ONE(k_eqsum_tail, 1024, (int)EXCL_LDS);
+    if (devdeleg_) DP_SET_LDS_ONE(k_deleg_tail, 1024, (int)EXCL_LDS);
     if (devcommit_) DP_SET_LDS_ONE(k_commit_tail, 1024, (int)EXCL_LDS);
     DP_SET_LDS((k_butterfly_pass<false, false>), 1024, 64 * 1024); DP_SET_LDS((k_butterfly_pass<false, true>), 1024, 64 * 1024);
     DP_SET_LDS((k_butterfly_pass<true, false>), 1024, 64 * 1024); DP_SET_LDS((k_butterfly_pass<true, true>), 1024, 64 * 1024);
@@ -853,6 +855,9 @@ class HipDev : public Dev {
   }
   void eq_table(const DBuf& out, const Ext* pt, unsigned k, Ext scale, bool acc) override {
     DP_REQUIRE(out.ext && out.n == (size_t(1) << k), DP_ERR_SHAPE, "eq_table: output shape");
+    // a plain long table (the commit phase builds eq over 2^20 entries per proof): the chunked low x high form of k_eq_table_many, one
+    // multiplication per entry instead of k (k_eq_table was 1.5 % of the kernel time of a Dense-4M batch, profiles/r03_bench448_kernel_stats.csv)
+    if (!acc && k >= 12 && k <= (unsigned)MAX_PT && scale.c0 == 1 && scale.c1 == 0) { EqJob j{out, pt, k}; eq_table_many(&j, 1); return; }
     nb_ = 16.0 * out.n * (acc ? 2 : 1); DPL(k_eq_table, dim3(grid_for(out.n)), dim3(TPB), (Ext*)out.p, make_point(pt, k), k, scale, acc ? 1 : 0, out.n);
   }
   // ---- lazy eq: remembered here, built inside the persistent sumcheck kernel that consumes it (or materialised by a
@@ -1132,6 +1137,34 @@ class HipDev : public Dev {
     wait_flag_blocks(seq, blocks);
     sponge.done();
     eqsum_tail_parse(hres_, ntabs, nv, md, ch, out);
+    sponge.restore();
+    release(mk);
+    return true;
+  }
+  // ---- Dev::deleg_tail: DP_DEVICE_DELEG (default on): k_deleg_tail, all delegation sumchecks of one batch FFT / iFFT in one launch
+  bool devdeleg_ = knob("DP_DEVICE_DELEG", 1) != 0;
+  bool deleg_tail(const DelegTailArgs& a, Challenger& ch, DelegTailOut& out) override {
+    if (!devdeleg_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
+    if (!deleg_tail_accepts(a)) return false;
+    const size_t fm = a.f_middle->size();
+    const std::vector<size_t> blocks = deleg_tail_blocks(fm);
+    size_t nwords = 0; for (size_t b : blocks) nwords += b;
+    if (nwords > RES_WORDS) return false;
+    flush_pending_eq();
+    const size_t mk = mark();
+    const std::vector<u64> words = deleg_tail_stage(a);
+    DBuf staged = alloc(words.size(), false);
+    upload(staged, words.data());
+    const DelegDesc* dd = nullptr;
+    DelegDesc* d = desc_alloc<DelegDesc>(1, &dd);
+    deleg_tail_fill(d, a, staged, ch, *this);
+    SpongeArm sponge(this, d, ch);
+    const unsigned long long seq = ++seq_;
+    nb_ = 8.0 * (double)words.size();
+    DPL_ONE(k_deleg_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
+    wait_flag_blocks(seq, blocks);
+    sponge.done();
+    deleg_tail_parse(hres_, fm, ch, out);
     sponge.restore();
     release(mk);
     return true;

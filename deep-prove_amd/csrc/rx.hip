@@ -9,6 +9,7 @@
 #include "classic_tail.h"
 #include "dense_tail.h"
 #include "eqsum_tail.h"
+#include "deleg_tail.h"
 #include "commit_tail.h"
 #include "sponge_host.h"
 #include "rx.h"
@@ -267,7 +268,7 @@ const BodyInfo* body_table() {
     auto set = [&](const char* prefix, size_t bytes) { for (int k = 0; k < RX_NBODIES_HOST; k++) if (!strncmp(tab[k].name, prefix, strlen(prefix)) && (tab[k].name[strlen(prefix)] == 0 || tab[k].name[strlen(prefix)] == '<')) tab[k].frame = (bytes + 15) & ~size_t(15); };
     set("k_sc_small", sizeof(rxk::Lds_k_sc_small)); set("k_sc_persist", sizeof(rxk::Lds_k_sc_persist)); set("k_sc_persist_lds", sizeof(rxk::Lds_k_sc_persist_lds));
     set("k_logup_tail", sizeof(rxk::Lds_k_logup_tail)); set("k_classic_tail", sizeof(rxk::Lds_k_classic_tail)); set("k_dense_tail", sizeof(rxk::Lds_k_dense_tail));
-    set("k_eqsum_tail", sizeof(rxk::Lds_k_eqsum_tail)); set("k_commit_tail", sizeof(rxk::Lds_k_commit_tail));
+    set("k_eqsum_tail", sizeof(rxk::Lds_k_eqsum_tail)); set("k_deleg_tail", sizeof(rxk::Lds_k_deleg_tail)); set("k_commit_tail", sizeof(rxk::Lds_k_commit_tail));
     set("k_reduce_publish", sizeof(rxk::Lds_k_reduce_publish)); set("k_classic_reduce", sizeof(rxk::Lds_k_classic_reduce)); set("k_eq_table_many", sizeof(rxk::Lds_k_eq_table_many));
     init = true;
   }

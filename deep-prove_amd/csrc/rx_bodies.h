@@ -24,6 +24,6 @@
   X(RX_STREAM, k_axpy_many) X(RX_STREAM, k_axpy_rep) X(RX_STREAM, k_bf_msg) X(RX_STREAM, k_fri_fold) X(RX_STREAM, k_query_gather) \
   X(RX_BIG, k_sc_small<false>) X(RX_BIG, k_sc_small<true>) X(RX_BIG, k_sc_persist<false>) X(RX_BIG, k_sc_persist<true>) \
   X(RX_BIG, k_sc_persist_lds<false>) X(RX_BIG, k_sc_persist_lds<true>) \
-  X(RX_BIG, k_logup_tail) X(RX_BIG, k_classic_tail) X(RX_BIG, k_dense_tail) X(RX_BIG, k_eqsum_tail) X(RX_BIG, k_commit_tail) X(RX_BIG, k_merkle_tail) \
+  X(RX_BIG, k_logup_tail) X(RX_BIG, k_classic_tail) X(RX_BIG, k_dense_tail) X(RX_BIG, k_eqsum_tail) X(RX_BIG, k_deleg_tail) X(RX_BIG, k_commit_tail) X(RX_BIG, k_merkle_tail) \
   X(RX_BIG, k_butterfly_pass<false, false>) X(RX_BIG, k_butterfly_pass<false, true>) X(RX_BIG, k_butterfly_pass<true, false>) X(RX_BIG, k_butterfly_pass<true, true>) \
   X(RX_BIG, k_commit_small<false>) X(RX_BIG, k_commit_small<true>)

@@ -1164,6 +1164,15 @@ inline MatrixEval delegate_matrix_evaluation(Dev& dev, Transcript& t, const std:
   std::vector<u64> omegas = phi_pow_init((unsigned)r1.size(), is_fft);
   MatrixEval me;
   size_t fm = f_middle.size();
+  {  // a device that keeps the sponge to itself runs the whole chain in one launch (Dev::deleg_tail)
+    Dev::DelegTailArgs da{&f_middle, r1.data(), (unsigned)r1.size(), r2.data(), omegas.data(), omegas.size(), is_fft};
+    Dev::DelegTailOut dout;
+    if (r2.size() == r1.size() && dev.deleg_tail(da, t.challenger(), dout)) {
+      DP_REQUIRE(dout.msgs.size() == fm && dout.points.size() == fm && dout.finals.size() == fm, DP_ERR_SHAPE, "deleg_tail: one sumcheck per intermediate table expected");
+      for (size_t q = 0; q < fm; q++) { IOPProof p; p.point = dout.points[q]; p.proofs = dout.msgs[q]; me.proofs.push_back(std::move(p)); me.claims.push_back(dout.finals[q]); }
+      return me;
+    }
+  }
   for (size_t l = r1.size() - 1; l-- > 0;) {
     size_t mk = dev.mark();
     size_t len = f_middle[l].size();

@@ -487,6 +487,7 @@ int main(int argc, char** argv) {
   printf("emulated k_classic_fused: %zu rounds, %zu factored (lo, hi) pairs; k_eq_outer_many: %zu tables\n", dev.classic_rounds_emulated, dev.classic_factored_pairs, dev.eq_outer_emulated);
   printf("emulated k_dense_tail: %zu dense layers taken\n", dev.dense_taken);
   printf("emulated k_eqsum_tail: %zu eq + sumcheck groups taken\n", dev.eqsum_taken);
+  printf("emulated k_deleg_tail: %zu delegation chains taken (%zu sumchecks)\n", dev.deleg_taken, dev.deleg_sumchecks);
   printf("emulated k_commit_tail: %zu commit-phase tails taken (%zu rounds, %zu codewords merged)\n", dev.commit_taken, dev.commit_rounds_run, dev.commit_merged);
   printf("host sponge service: %zu kernels ran with their sponge on the host, %zu requests served\n", dev.sponge.served_total, dev.sponge.requests());
 #endif

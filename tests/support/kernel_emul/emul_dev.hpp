@@ -8,6 +8,7 @@
 #include "../../../deep-prove_amd/csrc/classic_tail.h"
 #include "../../../deep-prove_amd/csrc/dense_tail.h"
 #include "../../../deep-prove_amd/csrc/eqsum_tail.h"
+#include "../../../deep-prove_amd/csrc/deleg_tail.h"
 #include "../../../deep-prove_amd/csrc/commit_tail.h"
 #include "../../../deep-prove_amd/csrc/sponge_host.h"
 #include "simt.hpp"
@@ -130,6 +131,34 @@ struct EmulDev : CpuDev {
     sponge.restore();
     release(mk);
     eqsum_taken++;
+    return true;
+  }
+  bool deleg = true;  // serve Dev::deleg_tail with the emulated k_deleg_tail
+  size_t deleg_taken = 0, deleg_sumchecks = 0;
+  bool deleg_tail(const DelegTailArgs& a, Challenger& ch, DelegTailOut& out) override {
+    if (!deleg || !deleg_tail_accepts(a)) return false;
+    const size_t fm = a.f_middle->size();
+    const std::vector<size_t> blocks = deleg_tail_blocks(fm);
+    size_t nwords = 0; for (size_t b : blocks) nwords += b;
+    const size_t mk = mark();
+    const std::vector<u64> words = deleg_tail_stage(a);
+    DBuf staged = alloc(words.size(), false);
+    upload(staged, words.data());
+    DelegDesc d;
+    deleg_tail_fill(&d, a, staged, ch, *this);
+    sponge.arm(d, ch);
+    std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
+    unsigned long long flag = 0;
+    const unsigned long long seq = 13000 + deleg_taken;
+    blockDim.x.v = threads;
+    simt::launch(threads, [&] { k_deleg_tail(&d, res.data(), &flag, seq); });
+    if (flag != pub_mix(seq) + logup_tail_checksum(res.data(), blocks)) { fprintf(stderr, "emul: delegation tail: tag does not match the payload\n"); exit(3); }
+    for (size_t i = nwords; i < res.size(); i++) if (res[i] != 0xDEADBEEFDEADBEEFull) { fprintf(stderr, "emul: delegation tail wrote past its message\n"); exit(3); }
+    sponge.done();
+    deleg_tail_parse(res.data(), fm, ch, out);
+    sponge.restore();
+    release(mk);
+    deleg_taken++; deleg_sumchecks += fm;
     return true;
   }
   bool dense = true;  // serve Dev::dense_tail with the emulated k_dense_tail

@@ -68,6 +68,9 @@ def test_whole_model_proofs_with_every_logup_proof_from_the_emulated_kernel():
         assert int(r.stdout.split("k_eq_outer_many: ")[1].split()[0]) >= 1, r.stdout          # ... written out (k_eq_outer_many) where the tail takes over
         assert int(r.stdout.split("emulated k_dense_tail: ")[1].split()[0]) >= 1, r.stdout    # ... and every Dense layer (bias, fix_high, sumcheck)
         assert int(r.stdout.split("emulated k_eqsum_tail: ")[1].split()[0]) >= 2, r.stdout    # ... and the accumulation sumchecks of Requant / ReLU
+        if args[0] == "cnn":  # ... and the delegation chains of the FFT / FFT-of-weights / iFFT of the convolution, each in one launch (k_deleg_tail)
+            dg = r.stdout.split("emulated k_deleg_tail: ")[1].split()
+            assert int(dg[0]) == 3 and int(dg[4].strip("(")) == 24, r.stdout
         assert int(r.stdout.split("emulated k_commit_tail: ")[1].split()[0]) >= 1, r.stdout   # ... and the last rounds of the Basefold commit phase
         if "DP_EMUL_COMMIT_MAX_N" in env:  # several rounds in one launch: FRI folds, messages and Merkle trees, not only the final round
             assert int(r.stdout.split("commit-phase tails taken (")[1].split()[0]) >= 4, r.stdout
