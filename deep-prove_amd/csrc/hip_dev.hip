@@ -1833,7 +1833,7 @@ class HipDev : public Dev {
       unsigned long long seq = ++seq_;
       nb_ = bytes; DPL(k_classic_fused, dim3(nblk), dim3(TPB), fd, cdd, np, r ? *r : ex_zero(), r ? 1 : 0, partial);
       DP_REQUIRE(2 * np <= (rx_ ? 512 : 1024), DP_ERR_SHAPE, "classic round: too many polynomials for one reduction");
-      nb_ = 0; DPL(k_classic_reduce, dim3(1), dim3(np >= 8 ? 1024 : 256), fd, np, (const Ext*)partial, (Ext*)hres_dev_, hflag_dev_, seq);
+      nb_ = 0; DPL(k_classic_reduce, dim3(1), dim3(np >= 8 && !throughput_mode_ ? 1024 : 256), fd, np, (const Ext*)partial, (Ext*)hres_dev_, hflag_dev_, seq);
       wait_flag(seq, (size_t)np * 4);
       for (int i = 0; i < 2 * np; i++) out[i] = ex(hres_[2 * i], hres_[2 * i + 1]);
       release(mk);

@@ -281,11 +281,11 @@ int32_t dp_model_free(dp_model* m);
  * output receives the model output (capacity *noutput on entry, length on exit). prove_ms (nullable) = prove() wall ms */
 int32_t dp_model_prove(dp_model* m, const int64_t* input, size_t ninput, uint64_t** proof_words, size_t* proof_nwords,
                        int64_t* output, size_t* noutput, double* prove_ms);
-/* `nproofs` independent proofs (inputs concatenated, `ninput` words each) with up to `concurrency` (<= 256) proofs in
+/* `nproofs` independent proofs (inputs concatenated, `ninput` words each) with up to `concurrency` (<= 1024) proofs in
  * flight on the model's GPU: every in-flight proof has its own HIP stream, arena and host<->device mailbox; the model
  * commitments are shared read-only. A single proof is a chain of ~10^3 sequential Fiat-Shamir round trips that cannot
  * fill an MI355X, so this is how one GPU is saturated (and how BASELINE config 4, a batch of independent proofs, is
- * served). The proofs in flight are grouped into cohorts of DP_COHORT (default 12) proofs that run in lock step: launch
+ * served). The proofs in flight are grouped into cohorts of DP_COHORT (default: in flight / 22, rounded up) proofs that run in lock step: launch
  * number i of all members of a cohort is ONE kernel launch (blockIdx.z = proof) on the cohort's stream. The proofs are
  * driven by min(#cohorts, DP_HOST_THREADS or dp_host_cpu_budget() - 2) host threads; a thread runs its proofs as
  * cooperative fibers and switches proof at every device wait. `concurrency` is a cap: worker arenas are sized from the
