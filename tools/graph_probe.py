@@ -1,0 +1,29 @@
+"""an attention block (models.attention_block: QKV, ConcatMatMul x2, MatMul, Add of two inputs, five Requants) at a larger shape on the device:
+parity with the oracle for one proof, then single-proof latency and batch throughput"""
+import os, sys, time
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np
+import deep_prove_amd as dpa
+from support import oracle_lib
+seq, emb, heads, hd = (int(a) for a in sys.argv[1:5]) if len(sys.argv) > 4 else (64, 256, 4, 64)
+conc = int(sys.argv[5]) if len(sys.argv) > 5 else 128
+g = dpa.models.attention_block(seq, emb, heads, hd, config=66)
+dev = dpa.Device(0)
+ctx = dpa.Context.generate(dev, g.blob())
+pr = dpa.Prover(ctx)
+x = g.input()
+proof, out = pr.prove(x)
+assert (out == g.run(x)).all()
+o = oracle_lib.load()
+h = o.model_setup(g.blob())
+t0 = time.perf_counter(); oproof, oout, oms = o.model_prove(h, x); o.model_free(h)
+print(f"attention block seq {seq} emb {emb} heads {heads} x {hd}: proof {proof.size} words, identical to the oracle: {bool(proof.size == oproof.size and (proof == oproof).all())} (oracle {oms:.0f} ms on one core)", flush=True)
+dpa.verify(ctx.verifier_blob(), proof, x, out)
+lat = []
+for _ in range(3):
+    t0 = time.perf_counter(); pr.prove(x); lat.append(1000 * (time.perf_counter() - t0))
+xs = np.stack([g.input(100 + i) for i in range(conc * 3)])
+pr.prove_batch(xs[:conc], conc)
+t0 = time.perf_counter(); proofs, outs, _ = pr.prove_batch(xs, conc); dt = time.perf_counter() - t0
+v, _ = dpa.verify_batch(ctx.verifier_blob(), proofs[:16], xs[:16], outs[:16], dev=dev)
+print(f"single proof {sorted(lat)[1]:.1f} ms; batch: {len(xs) / dt:.1f} proofs/s ({conc} in flight, {len(xs)} proofs), rejected of 16: {int(v.sum())}, in flight {pr.in_flight()}", flush=True)
