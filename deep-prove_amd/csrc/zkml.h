@@ -631,6 +631,9 @@ struct ProverState {
   std::map<size_t, std::vector<LogUpWitness>> lookup_witness;
   std::vector<LogUpWitness> table_witness;
   Ext constant_challenge; std::map<TableType, Ext> challenge_map;
+  // activations the layer proofs read as extension tables (Dense inputs, ReLU outputs), already on the device: they rode in the
+  // witness upload instead of costing one upload launch each inside the layer loop
+  std::map<size_t, DBuf> staged_in, staged_out;
   void add_witness_claim(const DevCommit& c, Claim cl) {
     if (c.nv <= PCS_BASECODE_LOG) trivial_claims.push_back({c, std::move(cl)}); else claims.push_back({c, std::move(cl)});
   }
@@ -739,8 +742,20 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
   std::vector<u64> mflat; mflat.reserve(mtotal);
   std::vector<size_t> moffs;
   for (auto& t : tabs) { moffs.push_back(mflat.size()); mflat.insert(mflat.end(), t.mult.begin(), t.mult.end()); }
-  DBuf mbig = dev.alloc(mtotal, false);
+  // ... and the activations of the layer loop, as extension words behind the multiplicities (16-byte aligned)
+  struct Act { size_t node; bool is_out; const std::vector<int64_t>* v; size_t off; };
+  std::vector<Act> acts;
+  static const bool stage_acts = !(getenv("DP_STAGE_ACTIVATIONS") && atoi(getenv("DP_STAGE_ACTIVATIONS")) == 0);  // (0: one upload per layer, as before — for A/B runs)
+  for (size_t id = 0; stage_acts && id < ctx.model.layers.size(); id++) {
+    const int kind = ctx.model.layers[id].kind;
+    if (kind == L_DENSE) acts.push_back({id, false, &tr.in[id], 0});
+    else if (kind == L_RELU) acts.push_back({id, true, &tr.out[id], 0});
+  }
+  if (mflat.size() & 1) mflat.push_back(0);
+  for (Act& a : acts) { a.off = mflat.size(); mflat.reserve(mflat.size() + 2 * a.v->size()); for (int64_t x : *a.v) { mflat.push_back(gl_from_i64(x)); mflat.push_back(0); } }
+  DBuf mbig = dev.alloc(mflat.size(), false);
   dev.upload(mbig, mflat.data());
+  for (const Act& a : acts) { DBuf b; b.p = (char*)mbig.p + a.off * 8; b.n = a.v->size(); b.ext = true; (a.is_out ? ps.staged_out : ps.staged_in)[a.node] = b; }
   wt.lap("  witness: uploads");
   // one batched commit: witness columns in order, then the table multiplicities
   std::vector<DBuf> to_commit(dcol.begin(), dcol.begin() + n_witness_cols);
@@ -1055,8 +1070,9 @@ inline Claim prove_dense(ProverState& ps, size_t id, const LayerSpec& l, const C
   size_t mk = dev.mark();
   const auto& comms = ps.ctx->model_comms.at(id);
   Ext bias_eval;
-  DBuf in = dev.alloc(input.size(), true);  // trace.into_fields(): i64 -> Ext (model/trace.rs:50-92)
-  { std::vector<u64> w = ext_words_from_i64(input); dev.upload(in, w.data()); }
+  DBuf in;  // trace.into_fields(): i64 -> Ext (model/trace.rs:50-92)
+  if (ps.staged_in.count(id) && ps.staged_in[id].n == input.size()) in = ps.staged_in[id];
+  else { in = dev.alloc(input.size(), true); std::vector<u64> w = ext_words_from_i64(input); dev.upload(in, w.data()); }
   SumcheckOut sc;
   Dev::DenseTailOut dto;
   // a device that keeps the sponge to itself does the bias evaluation, fix_high and the sumcheck in one go (Dev::dense_tail)
@@ -1140,8 +1156,9 @@ inline Claim prove_relu(ProverState& ps, size_t id, const Claim& last, const std
   LogUpProof lproof = logup_batch_prove(dev, ps.logup_input(w), *ps.t);
   Claim input_claim = lproof.output_claims[0], output_claim = lproof.output_claims[1];
   size_t mk = dev.mark();
-  DBuf out = dev.alloc(output.size(), true);
-  { std::vector<u64> ww = ext_words_from_i64(output); dev.upload(out, ww.data()); }
+  DBuf out;
+  if (ps.staged_out.count(id) && ps.staged_out[id].n == output.size()) out = ps.staged_out[id];
+  else { out = dev.alloc(output.size(), true); std::vector<u64> ww = ext_words_from_i64(output); dev.upload(out, ww.data()); }
   SamePolyProof sp = same_poly_prove(dev, {last, output_claim}, out, *ps.t);
   dev.release(mk);
   ActivationProof ap; ap.io_accumulation = sp; ap.lookup = lproof;
