@@ -597,9 +597,14 @@ def seam_level(threads, per_thread=6):
     res = {}
     # (the executor variant — 34 proofs/s at 14 threads, profiles/r03_seam_level_t14_executor.json — only on request: a bench line should not
     # depend on two more persistent kernels coming up in a second process)
-    variants = (("executor", 1, threads), ("streams", 0, threads)) if os.environ.get("DP_BENCH_SEAM_EXECUTOR") == "1" else (("streams", 0, threads),)
-    for name, executor, t in variants:
-        env = dict(os.environ, DP_ARENA_BYTES=str(2 << 30))
+    # `streams_throughput`: plain contexts switched to throughput mode (dp_ctx_set_throughput_mode: device-side Fiat-Shamir, fused protocol
+    # kernels). Measured: 40 against 80 proofs/s at 14 threads, 34-36 with 28 / 56 yielding threads (profiles/r03_seam_level_throughput_mode.txt):
+    # without cohorts to merge launches and fibers to keep hundreds of calls in flight the one-wave kernels only add latency
+    variants = [("streams", 0, threads, {}), ("streams_throughput", 2, threads, {})]
+    if os.environ.get("DP_BENCH_SEAM_EXECUTOR") == "1":
+        variants.insert(0, ("executor", 1, threads, {}))
+    for name, executor, t, extra in variants:
+        env = dict(os.environ, DP_ARENA_BYTES=str(2 << 30), **extra)
         try:
             r = subprocess.run([out, str(t), str(per_thread), str(executor)], env=env, capture_output=True, text=True, timeout=120)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -607,7 +612,8 @@ def seam_level(threads, per_thread=6):
         except Exception as e:  # noqa: BLE001
             res[name] = {"error": f"{type(e).__name__}: {e}"}
     res["note"] = ("workload-equivalent proofs per second of a seam-level host (every seam call of one Dense-4M proof, random tables), T threads with one dp_ctx each: "
-                   "`executor` = contexts attached to the resident executor (dp_executor_attach), `streams` = plain contexts (one HIP stream each)")
+                   "`streams` = plain contexts in latency mode (one HIP stream each), `streams_throughput` = the same in throughput mode (dp_ctx_set_throughput_mode), "
+                   "`executor` (DP_BENCH_SEAM_EXECUTOR=1) = contexts attached to the resident executor (dp_executor_attach)")
     return res
 
 

@@ -26,6 +26,7 @@ SIGNATURES = {
     "dp_ctx_create": (C.c_int32, [C.c_int32, C.POINTER(vp)]),
     "dp_ctx_destroy": (C.c_int32, [vp]),
     "dp_ctx_name": (C.c_char_p, [vp]),
+    "dp_ctx_set_throughput_mode": (C.c_int32, [vp, C.c_int32]),
     "dp_executor_start": (C.c_int32, [C.c_int32, C.c_int32]),
     "dp_executor_attach": (C.c_int32, [vp, C.c_int32]),
     "dp_executor_detach": (C.c_int32, [vp]),

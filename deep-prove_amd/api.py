@@ -82,6 +82,11 @@ class Device:
         finally:
             self._lib.dp_free(s)  # the report is malloc'ed by the library
 
+    def set_throughput_mode(self, on=True):
+        """dp_ctx_set_throughput_mode: device-side Fiat-Shamir and the fused protocol kernels for this context's seam-level calls (what the
+        workers of prove_batch run with); results are bit-identical to latency mode"""
+        check(self._lib.dp_ctx_set_throughput_mode(self.h, 1 if on else 0))
+
     def executor_attach(self, slot):
         """dp_executor_attach: this context becomes slot `slot` of the device's resident executor (executor_start first): its seam
         calls run as step descriptors of two persistent kernels, independently of every other attached context"""

@@ -151,6 +151,9 @@ int32_t dp_executor_start(int32_t device_id, int32_t nslots) {
     hip_rx_session(+1);
   });
 }
+int32_t dp_ctx_set_throughput_mode(dp_ctx* ctx, int32_t on) {
+  return guard([&] { DP_REQUIRE(ctx, DP_ERR_ARG, "null ctx"); CtxLock lk(ctx); ctx->dev->sync(); hip_dev_set_latency_mode(ctx->dev, on == 0); });
+}
 int32_t dp_executor_attach(dp_ctx* ctx, int32_t slot) {
   return guard([&] {
     DP_REQUIRE(ctx && slot >= 0, DP_ERR_ARG, "bad arguments");

@@ -43,6 +43,13 @@ void dp_free(void* p); /* ONLY for buffers this library returned (they are recyc
 int32_t dp_ctx_create(int32_t device_id, dp_ctx** out);
 int32_t dp_ctx_destroy(dp_ctx* ctx);
 const char* dp_ctx_name(const dp_ctx* ctx);
+/* A context starts in LATENCY mode (one proof alone on the GPU: host-side Fiat-Shamir — the host's 1 us permutation beats the device's —,
+ * one-workgroup kernels on a whole CU, wide sumcheck rounds spread over several workgroups). on != 0 switches it to THROUGHPUT mode, what
+ * dp_model_prove_batch gives its workers: device-side Fiat-Shamir and the fused protocol kernels (a whole logup-GKR proof, the tail of a
+ * sumcheck, the last commit rounds ... one launch and one wait each), one-workgroup kernels as 256-thread groups that reserve nothing.
+ * For hosts that keep MANY seam-level calls in flight on many contexts (tests/support/seam_bench.c). Results are bit-identical in both
+ * modes. Call it while no operation of the context is in flight. */
+int32_t dp_ctx_set_throughput_mode(dp_ctx* ctx, int32_t on);
 
 /* ---- resident executor for seam-level callers (csrc/rx.h). Between dp_executor_start and dp_executor_stop two persistent kernels
  * serve the device; a context attached to slot i (one context per slot, 0 <= i < nslots) runs in throughput mode and every kernel its

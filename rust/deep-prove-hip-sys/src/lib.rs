@@ -28,6 +28,7 @@ extern "C" {
     pub fn dp_ctx_create(device_id: i32, out_: *mut *mut dp_ctx) -> i32;
     pub fn dp_ctx_destroy(ctx: *mut dp_ctx) -> i32;
     pub fn dp_ctx_name(ctx: *const dp_ctx) -> *const c_char;
+    pub fn dp_ctx_set_throughput_mode(ctx: *mut dp_ctx, on: i32) -> i32;
     pub fn dp_executor_start(device_id: i32, nslots: i32) -> i32;
     pub fn dp_executor_attach(ctx: *mut dp_ctx, slot: i32) -> i32;
     pub fn dp_executor_detach(ctx: *mut dp_ctx) -> i32;

@@ -66,3 +66,47 @@ def test_in_flight_is_a_cap_and_arenas_follow_the_model(dev, monkeypatch):
     with pytest.raises(dpa.DeepProveError):
         pr.prove_batch(xs, 1025)
     ctx.free()
+
+
+def test_throughput_mode_context_seam_calls_match_oracle(oracle):
+    """dp_ctx_set_throughput_mode: a plain context (no cohort, no executor) whose seam-level calls run with device-side Fiat-Shamir and the
+    fused protocol kernels — sumchecks of several shapes, commitments and a batch opening with a 2^16-entry polynomial (factored eq tables,
+    classic tail, commit tail) — give the oracle's streams and leave the transcript in the oracle's state; back in latency mode the same"""
+    import deep_prove_amd as dpa
+    P = 0xFFFFFFFF00000001
+    dev = dpa.Device(0)
+    pcs = dpa.Basefold(dev, 1 << 16)
+    rng = np.random.default_rng(4242)
+    for mode in (True, False):
+        dev.set_throughput_mode(mode)
+        for nv, exts, terms in [(10, [True, True, True], [((P - 1, 0), [0, 2]), ((P - 1, 0), [0, 1]), ((11, 13), [0, 1, 2])]),
+                                (17, [False, False, False], [((1, 0), [0, 1, 2])]),
+                                (13, [True, True, True, True, True], [((1, 0), [0, 1, 4]), ((1, 0), [0, 3, 2]), ((7, 7), [0, 2, 4])])]:
+            raw = [rng.integers(0, P, size=(2 if e else 1) << nv, dtype=np.uint64) for e in exts]
+            mles = [dpa.Mle.from_ext(dev, w) if e else dpa.Mle.from_base(dev, w) for w, e in zip(raw, exts)]
+            vp = dpa.VirtualPolynomial(nv)
+            vp.tables = list(mles)
+            vp.terms = [(c, ix) for c, ix in terms]
+            t = dpa.Transcript(b"test")
+            proof, finals = dpa.prove_parallel(dev, vp, t)
+            ot = oracle.transcript(b"test")
+            oproof, ofinals = oracle.sumcheck_prove(nv, raw, exts, terms, ot)
+            assert proof.size == oproof.size and (proof == oproof).all() and (finals == ofinals).all(), f"throughput={mode}: sumcheck nv={nv}"
+            assert t.read_challenge() == ot.read_challenge()
+            for m in mles:
+                m.free()
+        sizes = (16, 12, 10)
+        polys = [rng.integers(0, P, size=1 << nv, dtype=np.uint64) for nv in sizes]
+        mles = [dpa.Mle.from_base(dev, w) for w in polys]
+        comms = [pcs.commit(m) for m in mles]
+        for c, w in zip(comms, polys):
+            assert list(c.root) == list(oracle.pcs_commit_root(1 << 16, w, False)), f"throughput={mode}: commitment root"
+        points = [[(int(a), int(b)) for a, b in rng.integers(0, P, size=(nv, 2), dtype=np.uint64)] for nv in sizes]
+        evals = [m.evaluate(pt) for m, pt in zip(mles, points)]
+        t = dpa.Transcript(b"test")
+        proof = pcs.batch_open(comms, points, evals, t)
+        ot = oracle.transcript(b"test")
+        oproof = oracle.pcs_batch_open(1 << 16, polys, [False] * 3, points, evals, ot)
+        assert proof.size == oproof.size and (proof == oproof).all(), f"throughput={mode}: batch_open"
+        assert t.read_challenge() == ot.read_challenge()
+    dev.close()
