@@ -897,6 +897,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     const char* rxe = getenv("DP_RX");
     const bool use_rx = rxe && atoi(rxe) && nw > 1 && nw <= RX_MAX_SLOTS;
     const double rx_stagger_ms = getenv("DP_RX_STAGGER_MS") ? atof(getenv("DP_RX_STAGGER_MS")) : 400.0;
+    const double co_stagger_ms = getenv("DP_COHORT_STAGGER_MS") ? atof(getenv("DP_COHORT_STAGGER_MS")) : 0.0;
     const char* ce = getenv("DP_COHORT");
     // Default: as many cohorts as hardware queues serve without time slicing (22 of the 24), each as small as that allows — a merged
     // launch ends with its slowest member, so small cohorts stall less (batch of 8: 121 ms with cohorts of 1, 165 ms with one cohort
@@ -930,6 +931,12 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
         // of slot wi is delayed by wi / nw of DP_RX_STAGGER_MS (default 400: about half a proof in flight).
         if (use_rx && rx_stagger_ms > 0 && wi > 0) {
           const auto until = t0 + std::chrono::microseconds((long long)(1000.0 * rx_stagger_ms * (double)wi / (double)nw));
+          while (std::chrono::steady_clock::now() < until && next.load() < nproofs) { if (fiber_active()) fiber_yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100)); }
+        }
+        // Cohorts, DP_COHORT_STAGGER_MS (default 0: every cohort starts at once): cohort c of nco starts c / nco of that time late, so that
+        // the cohorts do not reach their hash-heavy and their one-wave stretches together (an experiment knob)
+        if (nco > 1 && co_stagger_ms > 0 && wi % nco > 0) {
+          const auto until = t0 + std::chrono::microseconds((long long)(1000.0 * co_stagger_ms * (double)(wi % nco) / (double)nco));
           while (std::chrono::steady_clock::now() < until && next.load() < nproofs) { if (fiber_active()) fiber_yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100)); }
         }
         for (;;) {
