@@ -294,3 +294,40 @@ def test_graph_model_proof_bytes_identical_to_oracle_and_golden(dev, oracle, cas
     assert proofs[4].size == single.size and (proofs[4] == single).all() and (outs[4] == sout).all()
     assert (outs[4] == g.run(xs[4])).all()
     ctx.free()
+
+
+def test_device_proofs_pass_the_independent_iop_verifier(dev, oracle):
+    """tests/support/l2_independent.py — the IOP part of the reference's verifier written a second time in Python (own field, Poseidon2,
+    transcript, sumcheck and logup verifiers) — follows DEVICE proofs (one sequential, one out of a throughput-mode batch) through the
+    whole transcript, and every claim it would hand to the commitment verifier is true for the polynomial itself"""
+    import deep_prove_amd as dpa
+    from deep_prove_amd import wire
+    from support import l0_independent as L, l2_independent as V
+    sys_path_tests = os.path.join(ROOT, "tests")
+    import sys
+    if sys_path_tests not in sys.path:
+        sys.path.insert(0, sys_path_tests)
+    import test_l2_independent as T
+    P = T.P
+    mb = dpa.models.mlp(2, 16, config=44)
+    ctx = dpa.Context.generate(dev, mb.blob())
+    xs = np.stack([mb.input(700 + i) for i in range(6)])
+    proofs, outs, _ = dpa.Prover(ctx).prove_batch(xs, 6)
+    single, sout = dpa.Prover(ctx).prove(xs[0])
+    to_words = lambda v: np.asarray([int(t) % P for t in np.asarray(v).reshape(-1)], dtype=np.uint64)
+    for proof, x, out in ((single, xs[0], sout), (proofs[3], xs[3], outs[3])):
+        layers, cols, lookups, y = T._layers_and_witness(mb, x)
+        assert (out == y).all()
+        sizes = [mb.input_len, 256] + [1 << l["clamping_size"] for l in layers if l["kind"] == "requant"] + [l["weights"].size for l in mb.layers if l["kind"] == 0] + [c[0].size for c in cols.values()]
+        max_poly = 1 << (max(sizes) - 1).bit_length()
+        roots = {node: [("DenseBias", oracle.pcs_commit_root(max_poly, to_words(l["bias"]), False)), ("DenseWeight", oracle.pcs_commit_root(max_poly, to_words(l["weights"]), False))]
+                 for node, l in enumerate(mb.layers) if l["kind"] == 0}
+        claims, _ = V.verify_chain(layers, roots, wire.parse_stream(proof), [int(v) for v in x], [int(v) for v in y])
+        fe = lambda v: (int(v) % P, 0)
+        for c in claims:
+            if c[0] == "model":
+                poly = mb.layers[c[1]]["weights"].reshape(-1) if c[2] == "DenseWeight" else mb.layers[c[1]]["bias"]
+                assert L.mle_eval([fe(v) for v in poly], c[3]) == c[4]
+            elif c[0] == "witness":
+                assert L.mle_eval([fe(v) for v in cols[c[1]][c[2]]], c[4]) == c[5]
+    ctx.free()

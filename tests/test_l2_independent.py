@@ -1,0 +1,156 @@
+"""The IOP part of the verifier a SECOND time (tests/support/l2_independent.py: Python, from the reference's verifier sources, on the
+independent field / Poseidon2 / transcript of l0_independent.py): it follows the oracle's proof of an MLP through the whole transcript —
+model commitments, table challenges, every layer's sumcheck / logup-GKR / accumulation proof, the table proofs, the input claim, the final
+fraction sum — and every claim it would hand to the commitment verifier is then checked against the polynomial itself: the weights and
+biases, the witness columns recomputed here from a numpy inference (Requant: clamping input / output and the range-check chunks; ReLU:
+input / output), the table multiplicities. A misreading of the protocol that the oracle shares with the product's own verifier would have
+to be repeated in this unrelated formulation to go unnoticed."""
+import numpy as np
+import pytest
+
+P = 0xFFFFFFFF00000001
+
+
+def _layers_and_witness(mb, x):
+    """the model as the independent verifier wants it, and every committed witness column from a plain numpy forward pass"""
+    from deep_prove_amd import models as M
+    layers, cols, cur = [], {}, np.asarray(x, dtype=np.int64)
+    lookups = {"relu": [], "range": [], "clamping": {}}
+    for node, l in enumerate(mb.layers):
+        if l["kind"] == M.L_DENSE:
+            layers.append(dict(kind="dense", nrows=l["nrows"], ncols=l["ncols"]))
+            cur = l["weights"] @ cur + l["bias"]
+        elif l["kind"] == M.L_REQUANT:
+            shift = l["fp_scale"] + l["right_shift"]
+            cs = l["intermediate_bit_size"] + int(l["fixed_point_multiplier"] - 1).bit_length() - shift
+            layers.append(dict(kind="requant", clamping_size=cs, **{k: l[k] for k in ("fp_scale", "right_shift", "fixed_point_multiplier")}))
+            tmp = cur * l["fixed_point_multiplier"] + (1 << (shift - 1))
+            cin = tmp >> shift
+            cout = np.clip(cin, -127, 127)
+            masked = tmp & ((1 << shift) - 1)
+            chunks = [(masked >> (8 * j)) & 255 for j in range(shift // 8)]
+            cols[node] = [cin, cout] + chunks
+            lookups["clamping"].setdefault(cs, []).extend(int(v) for v in cin)
+            for c in chunks:
+                lookups["range"].extend(int(v) for v in c)
+            cur = cout
+        else:
+            assert l["kind"] == M.L_RELU
+            layers.append(dict(kind="relu"))
+            out = np.maximum(cur, 0)
+            cols[node] = [cur, out]
+            lookups["relu"].extend(int(v) for v in cur)
+            cur = out
+    return layers, cols, lookups, cur
+
+
+@pytest.mark.parametrize("width,config", [(8, 41), (16, 42)])
+def test_independent_iop_verifier_accepts_the_oracles_proof_and_every_claim_is_true(oracle, width, config):
+    import deep_prove_amd as dpa
+    from deep_prove_amd import wire
+    from support import l0_independent as L, l2_independent as V
+    mb = dpa.models.mlp(2, width, config=config)
+    x = mb.input()
+    layers, cols, lookups, y = _layers_and_witness(mb, x)
+    h = oracle.model_setup(mb.blob())
+    proof, oout, _ = oracle.model_prove(h, x)
+    oracle.model_free(h)
+    assert (oout == y).all()
+    tree = wire.parse_stream(proof)
+    # model commitments (their roots enter the transcript first): the PCS parameters follow the largest committed polynomial
+    sizes = [mb.input_len] + [t for l in layers if l["kind"] == "requant" for t in (256, 1 << l["clamping_size"])] + [256]
+    for l in mb.layers:
+        if l["kind"] == 0:
+            sizes += [l["weights"].size, l["bias"].size]
+    for node, l in enumerate(mb.layers):
+        if l["kind"] in (1, 2):
+            sizes.append(cols[node][0].size)
+    max_poly = 1 << (max(sizes) - 1).bit_length()
+    to_words = lambda v: np.asarray([int(t) % P for t in np.asarray(v).reshape(-1)], dtype=np.uint64)
+    roots = {}
+    for node, l in enumerate(mb.layers):
+        if l["kind"] == 0:
+            roots[node] = [("DenseBias", oracle.pcs_commit_root(max_poly, to_words(l["bias"]), False)), ("DenseWeight", oracle.pcs_commit_root(max_poly, to_words(l["weights"]), False))]
+    claims, _ = V.verify_chain(layers, roots, tree, [int(v) for v in x], [int(v) for v in y])
+    # ---- every claim against the polynomial itself
+    fe = lambda v: (int(v) % P, 0)
+    n_model = n_wit = n_mult = 0
+    for c in claims:
+        if c[0] == "model":
+            _, node, pid, point, ev = c
+            poly = mb.layers[node]["weights"].reshape(-1) if pid == "DenseWeight" else mb.layers[node]["bias"]
+            assert L.mle_eval([fe(v) for v in poly], point) == ev, f"model claim {node} {pid}"
+            n_model += 1
+        elif c[0] == "witness":
+            _, node, k, root, point, ev = c
+            assert L.mle_eval([fe(v) for v in cols[node][k]], point) == ev, f"witness claim of node {node}, column {k}"
+            n_wit += 1
+        else:
+            _, table, root, point, ev = c
+            if table[0] == "relu":
+                lo, hi, data = -128, 128, lookups["relu"]
+            elif table[0] == "range":
+                lo, hi, data = 0, 256, lookups["range"]
+            else:
+                lo, hi, data = -(1 << (table[1] - 1)), 1 << (table[1] - 1), lookups["clamping"][table[1]]
+            mult = [0] * (hi - lo)
+            for v in data:
+                mult[v - lo] += 1
+            assert L.mle_eval([fe(v) for v in mult], point) == ev, f"multiplicity claim of table {table}"
+            n_mult += 1
+    assert n_model == 2 * sum(l["kind"] == "dense" for l in layers) and n_wit >= 4 and n_mult >= 3
+
+
+def test_independent_iop_verifier_rejects_tampered_proofs(oracle):
+    """flipped words in the layer / table proofs: the independent verifier refuses every one of them"""
+    import deep_prove_amd as dpa
+    from deep_prove_amd import wire
+    from support import l2_independent as V
+    mb = dpa.models.mlp(1, 8, config=43)
+    x = mb.input()
+    layers, cols, lookups, y = _layers_and_witness(mb, x)
+    h = oracle.model_setup(mb.blob())
+    proof, _, _ = oracle.model_prove(h, x)
+    oracle.model_free(h)
+    sizes = [mb.input_len, 256] + [1 << l["clamping_size"] for l in layers if l["kind"] == "requant"] + [l["weights"].size for l in mb.layers if l["kind"] == 0]
+    max_poly = 1 << (max(sizes) - 1).bit_length()
+    to_words = lambda v: np.asarray([int(t) % P for t in np.asarray(v).reshape(-1)], dtype=np.uint64)
+    roots = {node: [("DenseBias", oracle.pcs_commit_root(max_poly, to_words(l["bias"]), False)), ("DenseWeight", oracle.pcs_commit_root(max_poly, to_words(l["weights"]), False))]
+             for node, l in enumerate(mb.layers) if l["kind"] == 0}
+    V.verify_chain(layers, roots, wire.parse_stream(proof), [int(v) for v in x], [int(v) for v in y])
+    tree0 = wire.parse_stream(proof)
+
+    def without_commitments(tree):
+        steps = [(n, k, {f: v for f, v in lp.items() if f not in ("commitments", "commits")}) for n, k, lp in tree["steps"]]
+        return steps, [tp["lookup"] for tp in tree["table_proofs"]]
+
+    n_iop = proof.size - _opening_words(tree0)
+    rejected = through = 0
+    for at in list(range(2, 160, 3)) + list(range(160, n_iop, max(1, n_iop // 80))):
+        bad = proof.copy()
+        bad[at] ^= np.uint64(1)
+        try:
+            t1 = wire.parse_stream(bad)
+            V.verify_chain(layers, roots, t1, [int(v) for v in x], [int(v) for v in y])
+        except (AssertionError, ValueError, IndexError, KeyError, ZeroDivisionError, OverflowError, MemoryError):
+            rejected += 1
+            continue
+        # accepted: the flipped word must belong to a commitment (root / num_vars / is_base), which only the opening consumes
+        assert without_commitments(t1) == without_commitments(tree0), f"word {at}: a flipped protocol word was accepted"
+        through += 1
+    assert rejected > 100 and through < rejected // 5, (rejected, through)
+
+
+def _opening_words(tree):
+    """words of the batch opening + trivial openings at the end of the canonical stream"""
+    def bf_words(p):
+        w = 1 + sum(1 + 2 * len(m) for m in p["sumcheck_messages"]) + 1 + 4 * len(p["roots"]) + 1 + 2 * len(p["final_message"]) + 1
+        for q in p["queries"]:
+            w += 3
+            for c in q["oracle_query"] + q["commitments_query"]:
+                w += 1 + (4 if c["is_ext"] else 2) + 1 + 1 + 4 * len(c["path"])
+        w += 1 + sum(1 + 2 * len(m) for m in p["sumcheck_proof"]) + 1
+        for t in p["trivial_proof"]:
+            w += 2 + len(t["w"])
+        return w
+    return bf_words(tree["batch_proof"]) + 1 + sum(bf_words(t) for t in tree["trivial_proofs"])
