@@ -195,7 +195,8 @@ def verify_chain(layers, model_roots, tree, x, y, label=b"m2vec"):
     """Verifier::verify (iop/verifier.rs:72-318) for a chain of Dense / Requant / ReLU nodes. `layers`: dicts with kind in {'dense',
     'requant', 'relu'} and the parameters of the node; model_roots: {node: [(poly id, root words)]} in BTreeMap order; x / y: the padded
     input and output vectors (integers). Returns the claims the commitment verifier would be handed: ('model', node, poly id, point, eval),
-    ('witness', node, k, root, point, eval) with k the position among the node's committed columns, ('multiplicity', table, root, point, eval)."""
+    ('witness', node, k, (root, num_vars), point, eval) with k the position among the node's committed columns, ('multiplicity', table, (root,
+    num_vars), point, eval) — in the order the reference's commitment verifier receives them — and the transcript, ready for the opening."""
     tr = L.Transcript(label)
     for node in sorted(model_roots):
         for _, root in sorted(model_roots[node]):
@@ -282,7 +283,7 @@ def verify_chain(layers, model_roots, tree, x, y, label=b"m2vec"):
             nxt = mul(sub(full, fe(1 << (shift - 1))), L.ext_inv(fe(l["fixed_point_multiplier"])))
             assert len(lp["commitments"]) == len(ae)
             for q, (v, c) in enumerate(zip(ae, lp["commitments"])):
-                out.append(("witness", node, q, tuple(c["root"]), acc_pt, v))
+                out.append(("witness", node, q, (tuple(c["root"]), c["num_vars"]), acc_pt, v))
             cur = {"point": acc_pt, "eval": nxt}
         else:
             assert l["kind"] == "relu"
@@ -290,14 +291,14 @@ def verify_chain(layers, model_roots, tree, x, y, label=b"m2vec"):
             nv = len(cur["point"])
             new_out = same_poly_verify([cur] + claims[1:], lp["io_accumulation"], nv, tr)
             assert len(lp["commits"]) == 2
-            out.append(("witness", node, 0, tuple(lp["commits"][0]["root"]), claims[0]["point"], claims[0]["eval"]))
-            out.append(("witness", node, 1, tuple(lp["commits"][1]["root"]), new_out["point"], new_out["eval"]))
+            out.append(("witness", node, 0, (tuple(lp["commits"][0]["root"]), lp["commits"][0]["num_vars"]), claims[0]["point"], claims[0]["eval"]))
+            out.append(("witness", node, 1, (tuple(lp["commits"][1]["root"]), lp["commits"][1]["num_vars"]), new_out["point"], new_out["eval"]))
             cur = claims[0]
     # table proofs, in the order of the lookup context
     assert len(tree["table_proofs"]) == len(tables)
     for tp, t in zip(tree["table_proofs"], tables):
         claims, _, _ = verify_logup(tp["lookup"], 1, constant, chmap[t], tr)
-        out.append(("multiplicity", t, tuple(tp["multiplicity_commit"]["root"]), claims[0]["point"], claims[0]["eval"]))
+        out.append(("multiplicity", t, (tuple(tp["multiplicity_commit"]["root"]), tp["multiplicity_commit"]["num_vars"]), claims[0]["point"], claims[0]["eval"]))
         expect = table_column_evals(t[0], t[1], claims[0]["point"])
         assert len(expect) == len(claims) - 1
         for cl, ex in zip(claims[1:], expect):

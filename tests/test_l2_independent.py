@@ -71,7 +71,7 @@ def test_independent_iop_verifier_accepts_the_oracles_proof_and_every_claim_is_t
     for node, l in enumerate(mb.layers):
         if l["kind"] == 0:
             roots[node] = [("DenseBias", oracle.pcs_commit_root(max_poly, to_words(l["bias"]), False)), ("DenseWeight", oracle.pcs_commit_root(max_poly, to_words(l["weights"]), False))]
-    claims, _ = V.verify_chain(layers, roots, tree, [int(v) for v in x], [int(v) for v in y])
+    claims, tr = V.verify_chain(layers, roots, tree, [int(v) for v in x], [int(v) for v in y])
     # ---- every claim against the polynomial itself
     fe = lambda v: (int(v) % P, 0)
     n_model = n_wit = n_mult = 0
@@ -82,11 +82,11 @@ def test_independent_iop_verifier_accepts_the_oracles_proof_and_every_claim_is_t
             assert L.mle_eval([fe(v) for v in poly], point) == ev, f"model claim {node} {pid}"
             n_model += 1
         elif c[0] == "witness":
-            _, node, k, root, point, ev = c
+            _, node, k, comm, point, ev = c
             assert L.mle_eval([fe(v) for v in cols[node][k]], point) == ev, f"witness claim of node {node}, column {k}"
             n_wit += 1
         else:
-            _, table, root, point, ev = c
+            _, table, comm, point, ev = c
             if table[0] == "relu":
                 lo, hi, data = -128, 128, lookups["relu"]
             elif table[0] == "range":
@@ -99,6 +99,25 @@ def test_independent_iop_verifier_accepts_the_oracles_proof_and_every_claim_is_t
             assert L.mle_eval([fe(v) for v in mult], point) == ev, f"multiplicity claim of table {table}"
             n_mult += 1
     assert n_model == 2 * sum(l["kind"] == "dense" for l in layers) and n_wit >= 4 and n_mult >= 3
+    # ---- and the openings, by the independent Basefold verifier (l3_independent.py), on the same transcript
+    from support import l3_independent as V3
+    root_of = {(node, pid): r for node, lst in roots.items() for pid, r in lst}
+    uniform = []
+    for c in claims:
+        if c[0] == "model":
+            poly = mb.layers[c[1]]["weights"] if c[2] == "DenseWeight" else mb.layers[c[1]]["bias"]
+            uniform.append(({"root": root_of[(c[1], c[2])], "num_vars": int(poly.size).bit_length() - 1}, c[3], c[4]))
+        elif c[0] == "witness":
+            uniform.append(({"root": list(c[3][0]), "num_vars": c[3][1]}, c[4], c[5]))
+        else:
+            uniform.append(({"root": list(c[2][0]), "num_vars": c[2][1]}, c[3], c[4]))
+    trivial = [u for u in uniform if len(u[1]) <= V3.BASECODE_LOG]
+    batch = [u for u in uniform if len(u[1]) > V3.BASECODE_LOG]
+    assert len(trivial) == len(tree["trivial_proofs"])
+    for (comm, point, ev), tp in zip(trivial, tree["trivial_proofs"]):
+        V3.trivial_verify(comm, point, ev, tp)
+    assert len(batch) >= 3 and len(trivial) >= 4  # (weights and multiplicity polynomials are opened by Basefold, the short columns trivially)
+    V3.batch_verify(max_poly.bit_length() - 1, [u[0] for u in batch], [u[1] for u in batch], [u[2] for u in batch], tree["batch_proof"], tr)
 
 
 def test_independent_iop_verifier_rejects_tampered_proofs(oracle):
@@ -154,3 +173,53 @@ def _opening_words(tree):
             w += 2 + len(t["w"])
         return w
     return bf_words(tree["batch_proof"]) + 1 + sum(bf_words(t) for t in tree["trivial_proofs"])
+
+
+def test_independent_basefold_verifier_rejects_tampered_openings(oracle):
+    """single-word flips inside the batch opening and the trivial openings (sumcheck coefficients, commit-phase messages, roots, the final
+    message, query indices, opened pairs, path digests): the independent verifier (l2 + l3) refuses every one"""
+    import deep_prove_amd as dpa
+    from deep_prove_amd import wire
+    from support import l2_independent as V, l3_independent as V3
+    mb = dpa.models.mlp(1, 16, config=45)
+    x = mb.input()
+    layers, cols, lookups, y = _layers_and_witness(mb, x)
+    h = oracle.model_setup(mb.blob())
+    proof, _, _ = oracle.model_prove(h, x)
+    oracle.model_free(h)
+    sizes = [mb.input_len, 256] + [1 << l["clamping_size"] for l in layers if l["kind"] == "requant"] + [l["weights"].size for l in mb.layers if l["kind"] == 0]
+    max_poly = 1 << (max(sizes) - 1).bit_length()
+    to_words = lambda v: np.asarray([int(t) % P for t in np.asarray(v).reshape(-1)], dtype=np.uint64)
+    roots = {node: [("DenseBias", oracle.pcs_commit_root(max_poly, to_words(l["bias"]), False)), ("DenseWeight", oracle.pcs_commit_root(max_poly, to_words(l["weights"]), False))]
+             for node, l in enumerate(mb.layers) if l["kind"] == 0}
+    root_of = {(node, pid): r for node, lst in roots.items() for pid, r in lst}
+
+    def full_verify(words):
+        tree = wire.parse_stream(words)
+        claims, tr = V.verify_chain(layers, roots, tree, [int(v) for v in x], [int(v) for v in y])
+        uniform = []
+        for c in claims:
+            if c[0] == "model":
+                poly = mb.layers[c[1]]["weights"] if c[2] == "DenseWeight" else mb.layers[c[1]]["bias"]
+                uniform.append(({"root": root_of[(c[1], c[2])], "num_vars": int(poly.size).bit_length() - 1}, c[3], c[4]))
+            else:
+                comm = c[3] if c[0] == "witness" else c[2]
+                uniform.append(({"root": list(comm[0]), "num_vars": comm[1]}, c[-2], c[-1]))
+        trivial = [u for u in uniform if len(u[1]) <= V3.BASECODE_LOG]
+        batch = [u for u in uniform if len(u[1]) > V3.BASECODE_LOG]
+        assert len(trivial) == len(tree["trivial_proofs"])
+        for (comm, point, ev), tp in zip(trivial, tree["trivial_proofs"]):
+            V3.trivial_verify(comm, point, ev, tp)
+        V3.batch_verify(max_poly.bit_length() - 1, [u[0] for u in batch], [u[1] for u in batch], [u[2] for u in batch], tree["batch_proof"], tr)
+
+    full_verify(proof)
+    n_open = _opening_words(wire.parse_stream(proof))
+    start = proof.size - n_open
+    rng = np.random.default_rng(7)
+    # the head of the opening (commit-phase messages, roots, final message), somewhere in the queries, the classic sumcheck near the end, a trivial opening
+    spots = [start + 3, start + 40, start + 300] + [int(v) for v in rng.integers(start + 400, proof.size - 600, size=3)] + [proof.size - 5]
+    for at in spots:
+        bad = proof.copy()
+        bad[at] ^= np.uint64(1)
+        with pytest.raises((AssertionError, ValueError, IndexError, KeyError, ZeroDivisionError, OverflowError, MemoryError)):
+            full_verify(bad)
