@@ -312,3 +312,225 @@ def verify_chain(layers, model_roots, tree, x, y, label=b"m2vec"):
     assert fn == ZERO, "final logup numerator is not zero"
     assert fd != ZERO, "final logup denominator is zero"
     return out, tr
+
+
+# ---------------------------------------------------------------------------------------------------------------- graphs
+def backward_order(nodes, outputs):
+    """NodeIterator<_, false> (model/iterator.rs:152-185): again and again the smallest unvisited id all of whose readers have been visited"""
+    readers = {}
+    for nid, n in enumerate(nodes):
+        for pos, (src, slot) in enumerate(n["inputs"]):
+            readers.setdefault((src, slot), []).append((nid, pos))
+    for k, (src, slot) in enumerate(outputs):
+        readers.setdefault((src, slot), []).append((-1, k))
+    order, done = [], set()
+    while len(order) < len(nodes):
+        for nid, n in enumerate(nodes):
+            if nid in done:
+                continue
+            if all(r[0] < 0 or r[0] in done for j in range(n["n_out"]) for r in readers.get((nid, j), [])):
+                order.append(nid)
+                done.add(nid)
+                break
+        else:
+            raise AssertionError("cycle")
+    return order, readers
+
+
+def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensors, label=b"m2vec"):
+    """Verifier::verify (iop/verifier.rs:72-318) for a GRAPH of QKV / ConcatMatMul / MatMul / Add / Requant nodes. nodes[i]: kind, inputs
+    [(node or -1, slot)], n_out and the parameters of the kind; outputs: [(node, slot)]; input_tensors / output_tensors: lists of integer
+    vectors. Returns (claims for the commitment verifier, transcript). The claims on the model's input tensors are checked here (step 6)."""
+    tr = L.Transcript(label)
+    for node in sorted(model_roots):
+        for _, root in sorted(model_roots[node]):
+            tr.append_field_elements([int(w) for w in root])
+    tables = set()
+    for n in nodes:
+        if n["kind"] == "requant":
+            tables.add(("range", 0))
+            tables.add(("clamping", n["clamping_size"]))
+        elif n["kind"] == "relu":
+            tables.add(("relu", 0))
+    tables = sorted(tables, key=table_order_key)
+    chmap, constant = {}, None
+    if tables:
+        constant = challenge(tr, b"table_constant")
+        for t in tables:
+            chmap[t] = ONE if t[0] == "range" else challenge(tr, b"Relu" if t[0] == "relu" else b"Clamping")
+    steps = {node: (kind, lp) for node, kind, lp in tree["steps"]}
+    nums, dens = [], []
+
+    def fractions(lg):
+        for r in lg["circuit_outputs"]:
+            r = [e(v) for v in r]
+            nums.append(add(mul(r[0], r[3]), mul(r[1], r[2])))
+            dens.append(mul(r[2], r[3]))
+
+    for nid, n in enumerate(nodes):
+        if n["kind"] == "requant":
+            fractions(steps[nid][1]["clamping_lookup"])
+            fractions(steps[nid][1]["shifted_lookup"])
+        elif n["kind"] == "relu":
+            fractions(steps[nid][1]["lookup"])
+    for tp in tree["table_proofs"]:
+        fractions(tp["lookup"])
+    out_claims = []
+    for (src, slot), y in zip(outputs, output_tensors):
+        r = read_challenges(tr, len(y).bit_length() - 1)
+        out_claims.append({"point": r, "eval": L.mle_eval([fe(v) for v in y], r)})
+    order, readers = backward_order(nodes, outputs)
+    made, out = {}, []
+    for nid in order:
+        n = nodes[nid]
+        got = []
+        for j in range(n["n_out"]):
+            (rd,) = readers[(nid, j)]  # exactly one reader per tensor (provable/mod.rs:243-248)
+            got.append(out_claims[rd[1]] if rd[0] < 0 else made[rd[0]][rd[1]])
+        cur = got[0]
+        if n["kind"] == "reshape":
+            made[nid] = [cur]
+            continue
+        kind, lp = steps[nid]
+        if n["kind"] == "add2":  # layers/add.rs:586-625, no operand
+            le, re_ = e(lp["left_eval"]), e(lp["right_eval"])
+            assert add(mul(le, fe(n["left"])), mul(re_, fe(n["right"]))) == cur["eval"], "Add layer verification failed"
+            made[nid] = [{"point": cur["point"], "eval": le}, {"point": cur["point"], "eval": re_}]
+        elif n["kind"] in ("matmul2", "matmul"):  # layers/matrix_mul.rs:1048-1139
+            nvc = (n["ncols"]).bit_length() - 1
+            cols, rows = cur["point"][:nvc], cur["point"][nvc:]  # split_claim: the low coordinates address the columns (:339-356)
+            ev = cur["eval"]
+            if n["kind"] == "matmul" and n.get("bias") is not None:
+                be = e(lp["bias_eval"])
+                out.append(("model", nid, "MatMulBias", cols, be))
+                ev = sub(ev, be)
+            else:
+                assert lp["bias_eval"] is None
+            sc_point = [e(v) for v in lp["sumcheck"]["point"]]
+            chals, expected = L1.verify_sumcheck(ev, sc_point, lp["sumcheck"]["proofs"], (n["nrows"]).bit_length() - 1, 2, tr)
+            ic = [e(v) for v in lp["individual_claims"]]
+            assert mul(ic[0], ic[1]) == expected, "matmul: sumcheck claim failed"
+            p_left = sc_point + rows
+            p_right = (sc_point + cols) if n.get("transpose_b") else (cols + sc_point)  # full_points (:364-383)
+            if n["kind"] == "matmul":
+                out.append(("model", nid, "MatMulWeight", p_right, ic[1]))
+                made[nid] = [{"point": p_left, "eval": ic[0]}]
+            else:
+                made[nid] = [{"point": p_left, "eval": ic[0]}, {"point": p_right, "eval": ic[1]}]
+        elif n["kind"] == "concat_matmul":  # layers/concat_matmul.rs:801-892
+            a_shape, b_shape, left, right, perm = n["a_shape"], n["b_shape"], n["left"], n["right"], n["perm"]
+            C_, R_, M_, N_ = a_shape[left[0]], a_shape[left[2]], a_shape[left[1]], b_shape[right[2]]
+            res_shape = [C_, R_, N_]
+            oshape = res_shape if perm is None else [res_shape[p] for p in perm]
+            sc_point = [e(v) for v in lp["sumcheck_proof"]["point"]]
+            chals, expected = L1.verify_sumcheck(cur["eval"], sc_point, lp["sumcheck_proof"]["proofs"], (C_ * M_).bit_length() - 1, 3, tr)
+            # split_output_claim_point (:295-343): the last axis of the output owns the lowest coordinates
+            parts, hi = [], len(cur["point"])
+            for d in range(3):
+                nv = oshape[d].bit_length() - 1
+                parts.append(cur["point"][hi - nv:hi])
+                hi -= nv
+            assert hi == 0
+            where = [0, 1, 2]
+            if perm is not None:
+                for i, src_dim in enumerate(perm):
+                    where[src_dim] = i
+            p_concat, p_row, p_col = parts[where[0]], parts[where[1]], parts[where[2]]
+            nvm = M_.bit_length() - 1
+            s_mm, s_concat = sc_point[:nvm], sc_point[nvm:]  # split_sumcheck_point (:256-281)
+            ic = [e(v) for v in lp["individual_claims"]]
+            assert identity_eval(s_concat, p_concat) == ic[0], "concat matmul: beta evaluation"
+            assert mul(mul(ic[0], ic[1]), ic[2]) == expected, "concat matmul: sumcheck claim failed"
+
+            def build(dims, po):  # build_point_for_input (:116-132): sub-points sorted by axis, last axis first
+                by = {dims[0]: s_concat, dims[1]: s_mm, dims[2]: po}
+                return [v for d in (2, 1, 0) for v in by[d]]
+
+            made[nid] = [{"point": build(left, p_row), "eval": ic[1]}, {"point": build(right, p_col), "eval": ic[2]}]
+        elif n["kind"] == "qkv":  # layers/transformer/qkv.rs:680-810
+            assert len(got) == 3
+            nvc = (n["ncols"]).bit_length() - 1
+            pre = [e(v) for v in lp["pre_bias_evals"]]
+            cols = [g["point"][:nvc] for g in got]
+            rows = [g["point"][nvc:] for g in got]
+            for g, pv in zip(got, pre):
+                tr.append_field_elements([w for x in g["point"] for w in x])
+                append_ext(tr, pv)
+            coeff = [ONE, tr.read_challenge(), tr.read_challenge()]
+            batched = ZERO
+            for pv, c in zip(pre, coeff):
+                batched = add(batched, mul(pv, c))
+            sc_point = [e(v) for v in lp["sumcheck"]["point"]]
+            chals, expected = L1.verify_sumcheck(batched, sc_point, lp["sumcheck"]["proofs"], (n["nrows"]).bit_length() - 1, 2, tr)
+            ic = [e(v) for v in lp["individual_claims"]]
+            virt = ZERO
+            for w in range(3):
+                virt = add(virt, mul(mul(ic[2 * w], ic[2 * w + 1]), coeff[w]))
+            names_w, names_b = ["WeightQ", "WeightK", "WeightV"], ["BiasQ", "BiasK", "BiasV"]
+            commons = {}
+            for w in range(3):
+                commons[names_w[w]] = (cols[w] + sc_point, ic[2 * w + 1])
+                commons[names_b[w]] = (cols[w], sub(got[w]["eval"], pre[w]))
+            for pid in sorted(commons):  # add_common_claims walks the node's BTreeMap of polynomials
+                out.append(("model", nid, pid, commons[pid][0], commons[pid][1]))
+            assert virt == expected, "qkv: sumcheck claim failed"
+            in_claims = [{"point": sc_point + rows[w], "eval": ic[2 * w]} for w in range(3)]
+            in_len = n["seq"] * n["nrows"]
+            made[nid] = [same_poly_verify(in_claims, lp["aggregation_proof"], in_len.bit_length() - 1, tr)]
+        elif n["kind"] == "relu":  # layers/activation.rs:459-517
+            claims, _, _ = verify_logup(lp["lookup"], 1, constant, chmap[("relu", 0)], tr)
+            new_out = same_poly_verify([cur] + claims[1:], lp["io_accumulation"], len(cur["point"]), tr)
+            out.append(("witness", nid, 0, (tuple(lp["commits"][0]["root"]), lp["commits"][0]["num_vars"]), claims[0]["point"], claims[0]["eval"]))
+            out.append(("witness", nid, 1, (tuple(lp["commits"][1]["root"]), lp["commits"][1]["num_vars"]), new_out["point"], new_out["eval"]))
+            made[nid] = [claims[0]]
+        else:
+            assert n["kind"] == "requant"
+            made[nid], o2 = [None], []
+            ct = ("clamping", n["clamping_size"])
+            shift = n["fp_scale"] + n["right_shift"]
+            inst = shift // BIT_LEN
+            cclaims, _, _ = verify_logup(lp["clamping_lookup"], 1, constant, chmap[ct], tr)
+            sclaims, _, _ = verify_logup(lp["shifted_lookup"], inst, constant, ONE, tr)
+            b = challenge(tr, b"requant_batching")
+            cpt, spt = cclaims[0]["point"], sclaims[0]["point"]
+            init, ch = ZERO, ONE
+            for v in [cur["eval"], cclaims[1]["eval"], cclaims[0]["eval"]] + [c["eval"] for c in sclaims]:
+                init = add(init, mul(ch, v))
+                ch = mul(ch, b)
+            acc_pt = [e(v) for v in lp["io_accumulation"]["point"]]
+            chals, expected = L1.verify_sumcheck(init, acc_pt, lp["io_accumulation"]["proofs"], len(cpt), 2, tr)
+            ae = [e(v) for v in lp["accumulation_evals"]]
+            lb, cb, sb = eq_xy_eval(cur["point"], acc_pt), eq_xy_eval(cpt, acc_pt), eq_xy_eval(spt, acc_pt)
+            calc = mul(add(lb, mul(b, cb)), ae[1])
+            comb = mul(b, b)
+            calc = add(calc, mul(mul(comb, cb), ae[0]))
+            comb = mul(comb, b)
+            for v in ae[2:]:
+                calc = add(calc, mul(mul(v, sb), comb))
+                comb = mul(comb, b)
+            assert calc == expected, f"requant {nid}: accumulation evaluations do not recombine"
+            full, pw = mul(fe(1 << shift), ae[0]), ONE
+            for v in ae[2:]:
+                full = add(full, mul(v, pw))
+                pw = mul(pw, fe(1 << BIT_LEN))
+            nxt = mul(sub(full, fe(1 << (shift - 1))), L.ext_inv(fe(n["fixed_point_multiplier"])))
+            for q, (v, c) in enumerate(zip(ae, lp["commitments"])):
+                out.append(("witness", nid, q, (tuple(c["root"]), c["num_vars"]), acc_pt, v))
+            made[nid] = [{"point": acc_pt, "eval": nxt}]
+    assert len(tree["table_proofs"]) == len(tables)
+    for tp, t in zip(tree["table_proofs"], tables):
+        claims, _, _ = verify_logup(tp["lookup"], 1, constant, chmap[t], tr)
+        out.append(("multiplicity", t, (tuple(tp["multiplicity_commit"]["root"]), tp["multiplicity_commit"]["num_vars"]), claims[0]["point"], claims[0]["eval"]))
+        expect = table_column_evals(t[0], t[1], claims[0]["point"])
+        for cl, ex in zip(claims[1:], expect):
+            assert cl["eval"] == ex, f"table {t}: claimed column evaluation is wrong"
+    # the claims on the model's input tensors (iop/verifier.rs:237-262)
+    for q, x in enumerate(input_tensors):
+        (rd,) = readers[(-1, q)]
+        c = made[rd[0]][rd[1]]
+        assert len(c["point"]) == len(x).bit_length() - 1 and L.mle_eval([fe(v) for v in x], c["point"]) == c["eval"], f"input claim {q} is incorrect"
+    fn, fd = ZERO, ONE
+    for nu, de in zip(nums, dens):
+        fn, fd = add(mul(fn, de), mul(nu, fd)), mul(fd, de)
+    assert fn == ZERO and fd != ZERO, "final logup fraction"
+    return out, tr

@@ -223,3 +223,140 @@ def test_independent_basefold_verifier_rejects_tampered_openings(oracle):
         bad[at] ^= np.uint64(1)
         with pytest.raises((AssertionError, ValueError, IndexError, KeyError, ZeroDivisionError, OverflowError, MemoryError)):
             full_verify(bad)
+
+
+def _graph_description(g, x):
+    """models.GraphBuilder -> the node list of l2_independent.verify_graph, the per-node witness columns of the Requant nodes (numpy), the
+    model's input tensors and output tensors"""
+    from deep_prove_amd import models as M
+    offs = np.concatenate([[0], np.cumsum(g.input_lens)])
+    x = np.asarray(x, dtype=np.int64)
+    vals, nodes, cols, clamp_lookups, range_lookups, relu_lookups = {}, [], {}, {}, [], []
+
+    def get(e):
+        return x[offs[e[1]]:offs[e[1] + 1]] if e[0] < 0 else vals[e]
+
+    for i, (l, edges) in enumerate(g.nodes):
+        a = get(edges[0])
+        k = l["kind"]
+        d = dict(inputs=[tuple(e) for e in edges], n_out=1)
+        if k == M.L_QKV:
+            d.update(kind="qkv", n_out=3, nrows=l["nrows"], ncols=l["ncols"], seq=a.size // l["nrows"])
+            xs = a.reshape(-1, l["nrows"])
+            for w in range(3):
+                vals[(i, w)] = (xs @ l["weights"][w] + l["bias"][w]).reshape(-1)
+        elif k == M.L_MATMUL2:
+            d.update(kind="matmul2", nrows=l["nrows"], ncols=l["ncols"], transpose_b=l["transpose_b"])
+            b = get(edges[1])
+            bm = b.reshape(l["ncols"], l["nrows"]).T if l["transpose_b"] else b.reshape(l["nrows"], l["ncols"])
+            vals[(i, 0)] = (a.reshape(-1, l["nrows"]) @ bm).reshape(-1)
+        elif k == M.L_ADD2:
+            d.update(kind="add2", left=l["left"], right=l["right"])
+            vals[(i, 0)] = l["left"] * a + l["right"] * get(edges[1])
+        elif k == M.L_CONCAT_MATMUL:
+            d.update(kind="concat_matmul", a_shape=l["a_shape"], b_shape=l["b_shape"], left=l["left"], right=l["right"], perm=l["perm"])
+            b = get(edges[1])
+            ta = a.reshape(l["a_shape"]).transpose(l["left"][0], l["left"][2], l["left"][1])
+            tb = b.reshape(l["b_shape"]).transpose(l["right"][0], l["right"][1], l["right"][2])
+            r = np.einsum("crm,cmn->crn", ta, tb)
+            vals[(i, 0)] = (r if l["perm"] is None else r.transpose(l["perm"])).reshape(-1)
+        elif k == M.L_MATMUL:
+            d.update(kind="matmul", nrows=l["nrows"], ncols=l["ncols"], bias=l["bias"], transpose_b=False)
+            y = a.reshape(-1, l["nrows"]) @ l["weights"]
+            vals[(i, 0)] = (y + l["bias"] if l["bias"] is not None else y).reshape(-1)
+        elif k == M.L_REQUANT:
+            shift = l["fp_scale"] + l["right_shift"]
+            cs = l["intermediate_bit_size"] + int(l["fixed_point_multiplier"] - 1).bit_length() - shift
+            d.update(kind="requant", clamping_size=cs, **{q: l[q] for q in ("fp_scale", "right_shift", "fixed_point_multiplier")})
+            tmp = a * l["fixed_point_multiplier"] + (1 << (shift - 1))
+            cin = tmp >> shift
+            cout = np.clip(cin, -127, 127)
+            masked = tmp & ((1 << shift) - 1)
+            chunks = [(masked >> (8 * j)) & 255 for j in range(shift // 8)]
+            cols[i] = [cin, cout] + chunks
+            clamp_lookups.setdefault(cs, []).extend(int(v) for v in cin)
+            for c in chunks:
+                range_lookups.extend(int(v) for v in c)
+            vals[(i, 0)] = cout
+        elif k == M.L_RELU:
+            d.update(kind="relu")
+            cols[i] = [a, np.maximum(a, 0)]
+            relu_lookups.extend(int(v) for v in a)
+            vals[(i, 0)] = np.maximum(a, 0)
+        else:
+            raise AssertionError("unexpected node kind")
+        nodes.append(d)
+    outs = g.outputs if g.outputs is not None else [(len(g.nodes) - 1, 0)]
+    inputs = [[int(v) for v in x[offs[q]:offs[q + 1]]] for q in range(len(g.input_lens))]
+    return nodes, [tuple(o) for o in outs], cols, (clamp_lookups, range_lookups, relu_lookups), inputs, [[int(v) for v in vals[tuple(o)]] for o in outs], vals
+
+
+@pytest.mark.parametrize("name,kw", [("attention_block", dict(seq=8, emb=16, heads=2, head_dim=8, config=61)), ("matmul_pair", dict(seq=8, k=32, n=16, config=63, transpose_b=True)),
+                                     ("qkv_two_outputs", dict(seq=4, k=16, n=16, config=64))])
+def test_independent_verifier_on_graph_models(oracle, name, kw):
+    """the graph layers a second time (l2_independent.verify_graph: QKV, ConcatMatMul, MatMul with two inputs or a constant matrix, Add of two
+    inputs, Requant; the backward node order, one claim per output tensor, the claims on every input tensor) plus the openings (l3): the
+    oracle's proofs of models.attention_block / matmul_pair / qkv_two_outputs are accepted, and every claim on a model polynomial or a
+    witness column is true for the polynomial itself"""
+    import deep_prove_amd as dpa
+    from deep_prove_amd import wire
+    from support import l0_independent as L, l2_independent as V, l3_independent as V3
+    g = getattr(dpa.models, name)(**kw)
+    x = g.input()
+    nodes, outs, cols, (clamp_lookups, range_lookups, relu_lookups), inputs, outputs, vals = _graph_description(g, x)
+    assert (np.concatenate([np.asarray(o) for o in outputs]) == g.run(x)).all()
+    h = oracle.model_setup(g.blob())
+    proof, oout, _ = oracle.model_prove(h, x)
+    oracle.model_free(h)
+    assert (oout == g.run(x)).all()
+    tree = wire.parse_stream(proof)
+    # model polynomials and the size of the PCS parameters
+    polys = {}
+    for i, (l, _) in enumerate(g.nodes):
+        if l["kind"] == 13:
+            for w, (wn, bn) in enumerate((("WeightQ", "BiasQ"), ("WeightK", "BiasK"), ("WeightV", "BiasV"))):
+                polys[(i, wn)] = l["weights"][w].reshape(-1)
+                polys[(i, bn)] = l["bias"][w].reshape(-1)
+        elif l["kind"] == 6:
+            polys[(i, "MatMulWeight")] = l["weights"].reshape(-1)
+            if l["bias"] is not None:
+                polys[(i, "MatMulBias")] = l["bias"].reshape(-1)
+    sizes = list(g.input_lens) + [p.size for p in polys.values()] + [c[0].size for c in cols.values()]
+    for n in nodes:
+        if n["kind"] == "requant":
+            sizes += [256, 1 << n["clamping_size"]]
+        elif n["kind"] == "relu":
+            sizes.append(256)
+    max_poly = 1 << (max(sizes) - 1).bit_length()
+    to_words = lambda v: np.asarray([int(t) % P for t in np.asarray(v).reshape(-1)], dtype=np.uint64)
+    roots = {}
+    for (i, pid), poly in polys.items():
+        roots.setdefault(i, []).append((pid, oracle.pcs_commit_root(max_poly, to_words(poly), False)))
+    claims, tr = V.verify_graph(nodes, outs, roots, tree, inputs, outputs)
+    fe = lambda v: (int(v) % P, 0)
+    root_of = {(node, pid): r for node, lst in roots.items() for pid, r in lst}
+    uniform = []
+    for c in claims:
+        if c[0] == "model":
+            assert L.mle_eval([fe(v) for v in polys[(c[1], c[2])]], c[3]) == c[4], f"model claim {c[1]} {c[2]}"
+            uniform.append(({"root": root_of[(c[1], c[2])], "num_vars": int(polys[(c[1], c[2])].size).bit_length() - 1}, c[3], c[4]))
+        elif c[0] == "witness":
+            assert L.mle_eval([fe(v) for v in cols[c[1]][c[2]]], c[4]) == c[5], f"witness claim of node {c[1]}, column {c[2]}"
+            uniform.append(({"root": list(c[3][0]), "num_vars": c[3][1]}, c[4], c[5]))
+        else:
+            t = c[1]
+            lo, hi, data = (0, 256, range_lookups) if t[0] == "range" else (-128, 128, relu_lookups) if t[0] == "relu" else (-(1 << (t[1] - 1)), 1 << (t[1] - 1), clamp_lookups[t[1]])
+            mult = [0] * (hi - lo)
+            for v in data:
+                mult[v - lo] += 1
+            assert L.mle_eval([fe(v) for v in mult], c[3]) == c[4], f"multiplicity claim of table {t}"
+            uniform.append(({"root": list(c[2][0]), "num_vars": c[2][1]}, c[3], c[4]))
+    trivial = [u for u in uniform if len(u[1]) <= V3.BASECODE_LOG]
+    batch = [u for u in uniform if len(u[1]) > V3.BASECODE_LOG]
+    assert len(trivial) == len(tree["trivial_proofs"])
+    for (comm, point, ev), tp in zip(trivial, tree["trivial_proofs"]):
+        V3.trivial_verify(comm, point, ev, tp)
+    if batch:
+        V3.batch_verify(max_poly.bit_length() - 1, [u[0] for u in batch], [u[1] for u in batch], [u[2] for u in batch], tree["batch_proof"], tr)
+    else:
+        assert not tree["batch_proof"]["queries"]
