@@ -392,7 +392,45 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
             made[nid] = [cur]
             continue
         kind, lp = steps[nid]
-        if n["kind"] == "add2":  # layers/add.rs:586-625, no operand
+        if n["kind"] == "dense":  # layers/dense.rs:576-643
+            bias_eval = e(lp["bias_eval"])
+            sc_point = [e(v) for v in lp["sumcheck"]["point"]]
+            chals, expected = L1.verify_sumcheck(sub(cur["eval"], bias_eval), sc_point, lp["sumcheck"]["proofs"], (n["ncols"]).bit_length() - 1, 2, tr)
+            ic = [e(v) for v in lp["individual_claims"]]
+            out.append(("model", nid, "DenseBias", cur["point"], bias_eval))
+            out.append(("model", nid, "DenseWeight", sc_point + cur["point"], ic[0]))
+            assert mul(ic[0], ic[1]) == expected, f"dense {nid}: sumcheck claim failed"
+            made[nid] = [{"point": sc_point, "eval": ic[1]}]
+        elif n["kind"] == "embeddings":  # layers/transformer/embeddings.rs:473-528
+            nvc = (n["ncols"]).bit_length() - 1
+            cols, rows = cur["point"][:nvc], cur["point"][nvc:]  # split_output_point (:95-106)
+            sc_point = [e(v) for v in lp["sumcheck"]["point"]]
+            chals, expected = L1.verify_sumcheck(cur["eval"], sc_point, lp["sumcheck"]["proofs"], (n["nrows"]).bit_length() - 1, 2, tr)
+            ic = [e(v) for v in lp["individual_claims"]]
+            out.append(("model", nid, "EmbeddingMat", cols + sc_point, ic[1]))
+            assert mul(ic[0], ic[1]) == expected, "embeddings: sumcheck claim failed"
+            made[nid] = [{"point": sc_point + rows, "eval": ic[0], "one_hot_of": n["nrows"]}]
+        elif n["kind"] in ("add_const", "positional"):  # layers/add.rs:586-625 with a static operand; transformer/positional.rs:480-583
+            le, re_ = e(lp["left_eval"]), e(lp["right_eval"])
+            assert add(mul(le, fe(n["left"])), mul(re_, fe(n["right"]))) == cur["eval"], "Add layer verification failed"
+            if n["kind"] == "add_const":
+                out.append(("model", nid, "255", cur["point"], re_))
+            else:
+                diff = n["table_vars"] - len(cur["point"])
+                assert diff >= 0 and len(lp["sub_matrix_evals"]) == diff
+                # sample_random_coordinates (:80-96): both claims enter the transcript, then `diff` plain challenges
+                tr.append_field_elements([w for x in cur["point"] for w in x])
+                append_ext(tr, cur["eval"])
+                tr.append_field_elements([w for x in cur["point"] for w in x])
+                append_ext(tr, re_)
+                extra = read_challenges(tr, diff)
+                point = cur["point"] + extra
+                val = re_
+                for sm, c in zip([e(v) for v in lp["sub_matrix_evals"]], extra):  # compute_positional_matrix_claim (:106-124)
+                    val = add(mul(val, sub(ONE, c)), mul(sm, c))
+                out.append(("model", nid, "PositionalMatrix", point, val))
+            made[nid] = [{"point": cur["point"], "eval": le}]
+        elif n["kind"] == "add2":  # layers/add.rs:586-625, no operand
             le, re_ = e(lp["left_eval"]), e(lp["right_eval"])
             assert add(mul(le, fe(n["left"])), mul(re_, fe(n["right"]))) == cur["eval"], "Add layer verification failed"
             made[nid] = [{"point": cur["point"], "eval": le}, {"point": cur["point"], "eval": re_}]
@@ -528,6 +566,16 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
     for q, x in enumerate(input_tensors):
         (rd,) = readers[(-1, q)]
         c = made[rd[0]][rd[1]]
+        if "one_hot_of" in c:  # Embeddings::verify_input_claim (embeddings.rs:530-571): the claim is on the one-hot encoding of the tokens
+            vnv = (c["one_hot_of"]).bit_length() - 1
+            assert len(c["point"]) == vnv + len(x).bit_length() - 1
+            r1, r2 = c["point"][:vnv], c["point"][vnv:]
+            total = ZERO
+            for token, beta in zip(x, L.eq_table(r2)):
+                bits = [fe((token >> b) & 1) for b in range(vnv)]
+                total = add(total, mul(beta, identity_eval(r1, bits)))
+            assert total == c["eval"], "one hot encoding claim is incorrect"
+            continue
         assert len(c["point"]) == len(x).bit_length() - 1 and L.mle_eval([fe(v) for v in x], c["point"]) == c["eval"], f"input claim {q} is incorrect"
     fn, fd = ZERO, ONE
     for nu, de in zip(nums, dens):

@@ -360,3 +360,115 @@ def test_independent_verifier_on_graph_models(oracle, name, kw):
         V3.batch_verify(max_poly.bit_length() - 1, [u[0] for u in batch], [u[1] for u in batch], [u[2] for u in batch], tree["batch_proof"], tr)
     else:
         assert not tree["batch_proof"]["queries"]
+
+
+def _chain_description(mb, x):
+    """models.ModelBuilder (a chain) -> the node list of l2_independent.verify_graph, model polynomials, witness columns"""
+    from deep_prove_amd import models as M
+    cur = np.asarray(x, dtype=np.int64)
+    nodes, cols, polys = [], {}, {}
+    lk = {"clamp": {}, "range": [], "relu": []}
+    for i, l in enumerate(mb.layers):
+        d = dict(inputs=[(i - 1, 0)], n_out=1)
+        k = l["kind"]
+        if k == M.L_DENSE:
+            d.update(kind="dense", nrows=l["nrows"], ncols=l["ncols"])
+            polys[(i, "DenseWeight")], polys[(i, "DenseBias")] = l["weights"].reshape(-1), l["bias"]
+            cur = l["weights"] @ cur + l["bias"]
+        elif k == M.L_MATMUL:
+            d.update(kind="matmul", nrows=l["nrows"], ncols=l["ncols"], bias=l["bias"], transpose_b=l["transpose_b"])
+            polys[(i, "MatMulWeight")] = l["weights"].reshape(-1)
+            if l["bias"] is not None:
+                polys[(i, "MatMulBias")] = l["bias"]
+            y = cur.reshape(-1, l["nrows"]) @ (l["weights"].T if l["transpose_b"] else l["weights"])
+            cur = (y + l["bias"] if l["bias"] is not None else y).reshape(-1)
+        elif k == M.L_EMBED:
+            d.update(kind="embeddings", nrows=l["nrows"], ncols=l["ncols"])
+            polys[(i, "EmbeddingMat")] = l["table"].reshape(-1)
+            cur = l["table"][cur].reshape(-1)
+        elif k == M.L_POSITIONAL:
+            d.update(kind="positional", left=l["left"], right=l["right"], table_vars=int(l["table"].size).bit_length() - 1)
+            polys[(i, "PositionalMatrix")] = l["table"].reshape(-1)
+            cur = l["left"] * cur + l["right"] * l["table"].reshape(-1)[:cur.size]
+        elif k == M.L_ADD:
+            d.update(kind="add_const", left=l["left"], right=l["right"])
+            polys[(i, "255")] = l["operand"]
+            cur = l["left"] * cur + l["right"] * l["operand"]
+        elif k == M.L_REQUANT:
+            shift = l["fp_scale"] + l["right_shift"]
+            cs = l["intermediate_bit_size"] + int(l["fixed_point_multiplier"] - 1).bit_length() - shift
+            d.update(kind="requant", clamping_size=cs, **{q: l[q] for q in ("fp_scale", "right_shift", "fixed_point_multiplier")})
+            tmp = cur * l["fixed_point_multiplier"] + (1 << (shift - 1))
+            cin = tmp >> shift
+            cout = np.clip(cin, -127, 127)
+            masked = tmp & ((1 << shift) - 1)
+            chunks = [(masked >> (8 * j)) & 255 for j in range(shift // 8)]
+            cols[i] = [cin, cout] + chunks
+            lk["clamp"].setdefault(cs, []).extend(int(v) for v in cin)
+            for c in chunks:
+                lk["range"].extend(int(v) for v in c)
+            cur = cout
+        else:
+            assert k == M.L_RELU
+            d.update(kind="relu")
+            cols[i] = [cur, np.maximum(cur, 0)]
+            lk["relu"].extend(int(v) for v in cur)
+            cur = np.maximum(cur, 0)
+        nodes.append(d)
+    return nodes, cols, polys, lk, cur
+
+
+@pytest.mark.parametrize("name,args,kw", [("token_mlp", (8, 20, 16), dict(config=73, max_positions=30)), ("token_mlp", (8, 20, 16), dict(config=74)),
+                                           ("seq_mlp", (8, 16), dict(config=75, transpose_last=True, positional=True))])
+def test_independent_verifier_on_token_and_sequence_models(oracle, name, args, kw):
+    """Embeddings (tokens in: the input claim is a claim on the one-hot encoding), Positional::Learned with a table longer than the sequence
+    (the slice claim lifted to the table), Add with a static operand, MatMul with a constant matrix (plain and TransposeB), Requant, ReLU —
+    the oracle's proofs through the independent verifier (l2 + l3), every model / witness / multiplicity claim checked on the polynomial"""
+    import deep_prove_amd as dpa
+    from deep_prove_amd import wire
+    from support import l0_independent as L, l2_independent as V, l3_independent as V3
+    mb = getattr(dpa.models, name)(*args, **kw)
+    x = mb.input()
+    nodes, cols, polys, lk, y = _chain_description(mb, x)
+    assert (y == mb.run(x)).all()
+    h = oracle.model_setup(mb.blob())
+    proof, oout, _ = oracle.model_prove(h, x)
+    oracle.model_free(h)
+    assert (oout == y).all()
+    tree = wire.parse_stream(proof)
+    sizes = [mb.input_len] + [p.size for p in polys.values()] + [c[0].size for c in cols.values()]
+    for n in nodes:
+        if n["kind"] == "requant":
+            sizes += [256, 1 << n["clamping_size"]]
+        elif n["kind"] == "relu":
+            sizes.append(256)
+    max_poly = 1 << (max(sizes) - 1).bit_length()
+    to_words = lambda v: np.asarray([int(t) % P for t in np.asarray(v).reshape(-1)], dtype=np.uint64)
+    roots = {}
+    for (i, pid), poly in polys.items():
+        roots.setdefault(i, []).append((pid, oracle.pcs_commit_root(max_poly, to_words(poly), False)))
+    claims, tr = V.verify_graph(nodes, [(len(nodes) - 1, 0)], roots, tree, [[int(v) for v in x]], [[int(v) for v in y]])
+    fe = lambda v: (int(v) % P, 0)
+    root_of = {(node, pid): r for node, lst in roots.items() for pid, r in lst}
+    uniform = []
+    for c in claims:
+        if c[0] == "model":
+            assert L.mle_eval([fe(v) for v in polys[(c[1], c[2])]], c[3]) == c[4], f"model claim {c[1]} {c[2]}"
+            uniform.append(({"root": root_of[(c[1], c[2])], "num_vars": int(polys[(c[1], c[2])].size).bit_length() - 1}, c[3], c[4]))
+        elif c[0] == "witness":
+            assert L.mle_eval([fe(v) for v in cols[c[1]][c[2]]], c[4]) == c[5], f"witness claim of node {c[1]}, column {c[2]}"
+            uniform.append(({"root": list(c[3][0]), "num_vars": c[3][1]}, c[4], c[5]))
+        else:
+            t = c[1]
+            lo, hi, data = (0, 256, lk["range"]) if t[0] == "range" else (-128, 128, lk["relu"]) if t[0] == "relu" else (-(1 << (t[1] - 1)), 1 << (t[1] - 1), lk["clamp"][t[1]])
+            mult = [0] * (hi - lo)
+            for v in data:
+                mult[v - lo] += 1
+            assert L.mle_eval([fe(v) for v in mult], c[3]) == c[4], f"multiplicity claim of table {t}"
+            uniform.append(({"root": list(c[2][0]), "num_vars": c[2][1]}, c[3], c[4]))
+    trivial = [u for u in uniform if len(u[1]) <= V3.BASECODE_LOG]
+    batch = [u for u in uniform if len(u[1]) > V3.BASECODE_LOG]
+    assert len(trivial) == len(tree["trivial_proofs"])
+    for (comm, point, ev), tp in zip(trivial, tree["trivial_proofs"]):
+        V3.trivial_verify(comm, point, ev, tp)
+    V3.batch_verify(max_poly.bit_length() - 1, [u[0] for u in batch], [u[1] for u in batch], [u[2] for u in batch], tree["batch_proof"], tr)
