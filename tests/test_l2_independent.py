@@ -357,7 +357,7 @@ def test_independent_verifier_on_graph_models(oracle, name, kw):
     for (comm, point, ev), tp in zip(trivial, tree["trivial_proofs"]):
         V3.trivial_verify(comm, point, ev, tp)
     if batch:
-        V3.batch_verify(max_poly.bit_length() - 1, [u[0] for u in batch], [u[1] for u in batch], [u[2] for u in batch], tree["batch_proof"], tr)
+        V3.batch_verify(max_poly.bit_length() - 1, [u[0] for u in batch], [u[1] for u in batch], [u[2] for u in batch], tree["batch_proof"], tr, check_every=5)
     else:
         assert not tree["batch_proof"]["queries"]
 
@@ -471,4 +471,4 @@ def test_independent_verifier_on_token_and_sequence_models(oracle, name, args, k
     assert len(trivial) == len(tree["trivial_proofs"])
     for (comm, point, ev), tp in zip(trivial, tree["trivial_proofs"]):
         V3.trivial_verify(comm, point, ev, tp)
-    V3.batch_verify(max_poly.bit_length() - 1, [u[0] for u in batch], [u[1] for u in batch], [u[2] for u in batch], tree["batch_proof"], tr)
+    V3.batch_verify(max_poly.bit_length() - 1, [u[0] for u in batch], [u[1] for u in batch], [u[2] for u in batch], tree["batch_proof"], tr, check_every=5)
