@@ -352,6 +352,8 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
             tables.add(("clamping", n["clamping_size"]))
         elif n["kind"] == "relu":
             tables.add(("relu", 0))
+        elif n["kind"] == "maxpool":
+            tables.add(("range", 0))
     tables = sorted(tables, key=table_order_key)
     chmap, constant = {}, None
     if tables:
@@ -371,7 +373,7 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
         if n["kind"] == "requant":
             fractions(steps[nid][1]["clamping_lookup"])
             fractions(steps[nid][1]["shifted_lookup"])
-        elif n["kind"] == "relu":
+        elif n["kind"] in ("relu", "maxpool"):
             fractions(steps[nid][1]["lookup"])
     for tp in tree["table_proofs"]:
         fractions(tp["lookup"])
@@ -392,7 +394,128 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
             made[nid] = [cur]
             continue
         kind, lp = steps[nid]
-        if n["kind"] == "dense":  # layers/dense.rs:576-643
+        if n["kind"] == "conv":  # layers/convolution.rs:1143-1383 (+ hadamard.rs:128-156, verify_fft_delegation :1090-1141)
+            from .l3_independent import two_adic
+            kw, kx, rnw, nw = n["kw"], n["kx"], n["real_nw"], n["nw"]
+            fs = nw * nw
+            lfs, lkw, lkx = fs.bit_length() - 1, kw.bit_length() - 1, kx.bit_length() - 1
+            l2n = lfs + 1
+            ve = lambda v: [e(t) for t in v]
+
+            def sc(claim, proof, nv, deg):  # IOPVerifierState::verify: rounds and challenges are checked, the caller decides about the final claim
+                pt = ve(proof["point"])
+                _, final = L1.verify_sumcheck(claim, pt, proof["proofs"], nv, deg, tr)
+                return pt, final
+
+            def pow_two_omegas(m, is_fft):  # (:1442-1454)
+                rou = two_adic(m)
+                if is_fft:
+                    rou = L.inv(rou)
+                pows = [rou]
+                for _ in range(1, m - 1):
+                    pows.append(pows[-1] * pows[-1] % P)
+                return pows
+
+            def phi_eval(r, rand1, rand2, exps, first):  # (:1456-1476)
+                ev = ONE
+                for i, ri in enumerate(r):
+                    ev = mul(ev, add(sub(ONE, ri), mul(ri, fe(exps[len(exps) - len(r) + i]))))
+                if first:
+                    return mul(sub(ONE, rand2), add(sub(ONE, rand1), mul(rand1, ev)))
+                return add(sub(ONE, rand1), mul(mul(sub(ONE, add(rand2, rand2)), rand1), ev))
+
+            oc, oh, ow = n["unp_out"]
+            clr = [fe(1 if (c < oc and yy < oh and xx < ow) else 0) for c in range(kw) for yy in range(nw) for xx in range(nw)]  # new_clearing_tensor (:1508-1529)
+            hp, hfinal = sc(cur["eval"], lp["clearing_proof"]["sumcheck"], lfs + lkw, 3)
+            v1, v2 = ve(lp["clearing_proof"]["individual_claim"])
+            assert L.mle_eval(clr, hp) == v2, "Hadamard verification failed for v2 eval"
+            assert mul(mul(identity_eval(cur["point"], hp), v1), v2) == hfinal, "Hadamard verification failed for product eval"
+            last = {"point": hp, "eval": v1}
+            bias_claim = e(lp["bias_claim"])
+            ifft_pt, _ = sc(sub(last["eval"], bias_claim), lp["ifft_proof"], l2n, 2)
+            ifft_claims, dclaims = ve(lp["ifft_claims"]), [ve(c) for c in lp["ifft_delegation_claims"]]
+            it = len(lp["ifft_delegation_proof"])
+            assert it == lfs and len(dclaims) == it
+            claim, exps, prev = ifft_claims[1], pow_two_omegas(it + 1, True), ifft_pt
+            for i in range(it):
+                dpt, _ = sc(claim, lp["ifft_delegation_proof"][i], lfs - i, 3)
+                assert identity_eval(dpt, prev) == dclaims[i][0], f"identity evaluation, ifft delegation {i}"
+                assert phi_eval(dpt, sub(ONE, last["point"][i]), prev[-1], exps, False) == dclaims[i][1], f"phi, ifft delegation {i}"
+                prev, claim = dpt, dclaims[i][2]
+            scale = fe(L.inv((1 << (it + 1)) % P))
+            assert claim == add(mul(scale, prev[0]), mul(scale, sub(ONE, prev[0]))), "final iFFT delegation step"
+            had_clams = ve(lp["hadamard_clams"])
+            had_pt, _ = sc(ifft_claims[0], lp["hadamard_proof"], lkx + lfs + 1, 3)
+            assert had_clams[2] == identity_eval(ifft_pt, had_pt), "Error in Beta evaluation"
+
+            def fft_delegation(claim, proofs, claims, prev):
+                m = len(proofs)
+                exps = pow_two_omegas(m + 1, False)
+                claims = [ve(c) for c in claims]
+                for i in range(m):
+                    dpt, _ = sc(claim, proofs[i], lfs - i, 3)
+                    assert identity_eval(dpt, prev) == claims[i][0], f"identity evaluation, fft delegation {i}"
+                    assert phi_eval(dpt, had_pt[i], prev[-1], exps, i == 0) == claims[i][1], f"phi, fft delegation {i}"
+                    claim, prev = claims[i][2], dpt
+                assert claim == add(sub(mul(sub(ONE, add(had_pt[m], had_pt[m])), prev[0]), prev[0]), ONE), "final FFT delegation step"
+
+            fft_pt, _ = sc(had_clams[1], lp["fft_proof"], l2n, 2)
+            fft_claims = ve(lp["fft_claims"])
+            fft_delegation(fft_claims[1], lp["fft_delegation_proof"], lp["fft_delegation_claims"], fft_pt)
+            fftw_pt, _ = sc(had_clams[0], lp["fft_proof_weights"], l2n, 2)
+            fftw_claims = ve(lp["fft_weight_claims"])
+            fft_delegation(fftw_claims[1], lp["fft_delegation_proof_weights"], lp["fft_delegation_weights_claims"], fftw_pt)
+            wpt = list(fftw_pt)
+            v = L.ext_inv(sub(ONE, wpt.pop()))
+            pe = ve(lp["partial_evals"])
+            yw = ZERO
+            lgnw2 = 2 * (nw.bit_length() - 1)
+            for i in range(rnw):
+                for j in range(rnw):
+                    bits = [fe(((i * nw + j) >> b) & 1) for b in range(lgnw2)]
+                    yw = add(yw, mul(pe[i * rnw + j], identity_eval(bits, wpt)))
+            assert mul(fftw_claims[0], v) == yw, "Error in padded_fft evaluation claim"
+            wrand = read_challenges(tr, (rnw * rnw).bit_length() - 1)
+            point = had_pt + last["point"][lfs:]
+            out.append(("model", nid, "ConvBias", last["point"][it:], bias_claim))
+            out.append(("model", nid, "ConvFilter", wrand + point[(2 * nw * nw).bit_length() - 1:], L.mle_eval(pe, wrand)))
+            ipt = list(fft_pt)
+            v = L.ext_inv(sub(ONE, ipt.pop()))
+            ipt = [sub(ONE, t) for t in ipt]
+            made[nid] = [{"point": ipt + had_pt[(2 * fs).bit_length() - 1:], "eval": mul(fft_claims[0], v)}]
+        elif n["kind"] == "maxpool":  # layers/pooling.rs:525-647
+            claims, _, _ = verify_logup(lp["lookup"], 4, constant, ONE, tr)
+            c_, h_, w_ = n["pin"]
+            nv = (c_ * (h_ // 2) * (w_ // 2)).bit_length() - 1
+            b = challenge(tr, b"batch_pooling")
+            init, comb = ZERO, b
+            for cl in claims:
+                init = add(init, mul(cl["eval"], comb))
+                comb = mul(comb, b)
+            init = add(init, mul(comb, cur["eval"]))
+            zp = [e(v) for v in lp["sumcheck"]["point"]]
+            chals, expected = L1.verify_sumcheck(init, zp, lp["sumcheck"]["proofs"], nv, 5, tr)
+            beta_eval, last_beta = eq_xy_eval(claims[0]["point"], zp), eq_xy_eval(cur["point"], zp)
+            ze = [e(v) for v in lp["zerocheck_evals"]]
+            ks = len(ze) - 1
+            prod_c, sum_c, bc = beta_eval, ZERO, b
+            for v in ze[:ks]:
+                prod_c, sum_c, bc = mul(prod_c, v), add(sum_c, mul(bc, v)), mul(bc, b)
+            out_eval = ze[ks]
+            assert add(add(prod_c, mul(sum_c, beta_eval)), mul(mul(out_eval, last_beta), bc)) == expected, "pooling zerocheck claim"
+            assert len(lp["commitments"]) == len(ze)
+            for q, (v, c) in enumerate(zip(ze, lp["commitments"])):
+                out.append(("witness", nid, q, (tuple(c["root"]), c["num_vars"]), zp, v))
+            r1 = challenge(tr, b"input_batching")  # `[challenge; 2]`: ONE challenge, used twice (:611-614)
+            r2 = r1
+            om1, om2 = sub(ONE, r1), sub(ONE, r2)
+            mults = [mul(om1, om2), mul(om1, r2), mul(r1, om2), mul(r1, r2)]
+            gap = lp["variable_gap"]
+            zin = ZERO
+            for v, m_ in zip(ze[:ks], mults):
+                zin = add(zin, mul(sub(out_eval, v), m_))
+            made[nid] = [{"point": [r1] + zp[:gap] + [r2] + zp[gap:], "eval": zin}]
+        elif n["kind"] == "dense":  # layers/dense.rs:576-643
             bias_eval = e(lp["bias_eval"])
             sc_point = [e(v) for v in lp["sumcheck"]["point"]]
             chals, expected = L1.verify_sumcheck(sub(cur["eval"], bias_eval), sc_point, lp["sumcheck"]["proofs"], (n["ncols"]).bit_length() - 1, 2, tr)

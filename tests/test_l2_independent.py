@@ -408,6 +408,31 @@ def _chain_description(mb, x):
             for c in chunks:
                 lk["range"].extend(int(v) for v in c)
             cur = cout
+        elif k == M.L_CONV:
+            d.update(kind="conv", **{q: l[q] for q in ("kw", "kx", "real_nw", "nw", "unp_out")})
+            polys[(i, "ConvFilter")], polys[(i, "ConvBias")] = l["filter"].reshape(-1), l["bias"]
+            kk, nw = l["kernel"], l["nw"]
+            xs = cur.reshape(l["kx"], nw, nw)
+            oc, oh, ow = l["unp_out"]
+            o = np.zeros((l["kw"], nw, nw), dtype=np.int64)
+            for a in range(kk):
+                for b in range(kk):
+                    o[:, :oh, :ow] += np.einsum("oc,cyx->oyx", l["filter"][:, :, a, b], xs[:, a:a + oh, b:b + ow])
+            o += l["bias"][:, None, None]
+            o[oc:], o[:, oh:], o[:, :, ow:] = 0, 0, 0
+            cur = o.reshape(-1)
+        elif k == M.L_MAXPOOL:
+            d.update(kind="maxpool", pin=l["pin"])
+            c, h, w_ = l["pin"]
+            t = cur.reshape(c, h // 2, 2, w_ // 2, 2)
+            o = t.max(axis=(2, 4))
+            # the four committed difference polynomials (pooling.rs:660-735): (dy, dx) = (0,0), (1,0), (0,1), (1,1), then the output
+            cols[i] = [(o - t[:, :, dy, :, dx]).reshape(-1) for dy, dx in ((0, 0), (1, 0), (0, 1), (1, 1))] + [o.reshape(-1)]
+            for q in cols[i][:4]:
+                lk["range"].extend(int(v) for v in q)
+            cur = o.reshape(-1)
+        elif k == M.L_FLATTEN:
+            d.update(kind="reshape")
         else:
             assert k == M.L_RELU
             d.update(kind="relu")
@@ -419,7 +444,7 @@ def _chain_description(mb, x):
 
 
 @pytest.mark.parametrize("name,args,kw", [("token_mlp", (8, 20, 16), dict(config=73, max_positions=30)), ("token_mlp", (8, 20, 16), dict(config=74)),
-                                           ("seq_mlp", (8, 16), dict(config=75, transpose_last=True, positional=True))])
+                                           ("seq_mlp", (8, 16), dict(config=75, transpose_last=True, positional=True)), ("cnn_tiny", (), dict(config=76))])
 def test_independent_verifier_on_token_and_sequence_models(oracle, name, args, kw):
     """Embeddings (tokens in: the input claim is a claim on the one-hot encoding), Positional::Learned with a table longer than the sequence
     (the slice claim lifted to the table), Add with a static operand, MatMul with a constant matrix (plain and TransposeB), Requant, ReLU —
@@ -440,7 +465,7 @@ def test_independent_verifier_on_token_and_sequence_models(oracle, name, args, k
     for n in nodes:
         if n["kind"] == "requant":
             sizes += [256, 1 << n["clamping_size"]]
-        elif n["kind"] == "relu":
+        elif n["kind"] in ("relu", "maxpool"):
             sizes.append(256)
     max_poly = 1 << (max(sizes) - 1).bit_length()
     to_words = lambda v: np.asarray([int(t) % P for t in np.asarray(v).reshape(-1)], dtype=np.uint64)
@@ -472,3 +497,46 @@ def test_independent_verifier_on_token_and_sequence_models(oracle, name, args, k
     for (comm, point, ev), tp in zip(trivial, tree["trivial_proofs"]):
         V3.trivial_verify(comm, point, ev, tp)
     V3.batch_verify(max_poly.bit_length() - 1, [u[0] for u in batch], [u[1] for u in batch], [u[2] for u in batch], tree["batch_proof"], tr, check_every=5)
+
+
+def test_independent_verifier_rejects_tampered_cnn_proofs(oracle):
+    """flipped words anywhere in the IOP part of a CNN proof (Convolution: the clearing Hadamard product, the iFFT / FFT sumchecks and their
+    delegation chains, the Hadamard sumcheck, partial evaluations; Pooling: logup, zerocheck, evaluations): refused, unless the word belongs
+    to a commitment, which only the opening consumes"""
+    import deep_prove_amd as dpa
+    from deep_prove_amd import wire
+    from support import l2_independent as V
+    mb = dpa.models.cnn_tiny(config=77)
+    x = mb.input()
+    nodes, cols, polys, lk, y = _chain_description(mb, x)
+    h = oracle.model_setup(mb.blob())
+    proof, oout, _ = oracle.model_prove(h, x)
+    oracle.model_free(h)
+    assert (oout == y).all()
+    sizes = [mb.input_len, 256] + [p.size for p in polys.values()] + [c[0].size for c in cols.values()] + [1 << n["clamping_size"] for n in nodes if n["kind"] == "requant"]
+    max_poly = 1 << (max(sizes) - 1).bit_length()
+    to_words = lambda v: np.asarray([int(t) % P for t in np.asarray(v).reshape(-1)], dtype=np.uint64)
+    roots = {}
+    for (i, pid), poly in polys.items():
+        roots.setdefault(i, []).append((pid, oracle.pcs_commit_root(max_poly, to_words(poly), False)))
+    run = lambda tree: V.verify_graph(nodes, [(len(nodes) - 1, 0)], roots, tree, [[int(v) for v in x]], [[int(v) for v in y]])
+    tree0 = wire.parse_stream(proof)
+    run(tree0)
+
+    def without_commitments(tree):
+        return [(n, k, {f: v for f, v in lp.items() if f not in ("commitments", "commits")}) for n, k, lp in tree["steps"]], [tp["lookup"] for tp in tree["table_proofs"]]
+
+    n_iop = proof.size - _opening_words(tree0)
+    rejected = through = 0
+    for at in range(2, n_iop, max(1, n_iop // 90)):
+        bad = proof.copy()
+        bad[at] ^= np.uint64(1)
+        try:
+            t1 = wire.parse_stream(bad)
+            run(t1)
+        except (AssertionError, ValueError, IndexError, KeyError, ZeroDivisionError, OverflowError, MemoryError):
+            rejected += 1
+            continue
+        assert without_commitments(t1) == without_commitments(tree0), f"word {at}: a flipped protocol word was accepted"
+        through += 1
+    assert rejected > 60 and through < rejected // 5, (rejected, through)
