@@ -818,6 +818,13 @@ static ModelSpec parse_model(const int64_t* b, size_t n) {
       l.weights.assign(b + pos, b + pos + nf); pos += nf;
       l.bias.assign(b + pos, b + pos + l.kw); pos += l.kw;
     } else if (l.kind == L_MAXPOOL) { for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd(); }
+    else if (l.kind == L_LAYERNORM) {  // [14, padded dimension, N, multiplier, epsilon bits (f32), range check bits, log2 of the top chunk scalar, gamma[dim], beta[dim]]
+      const size_t dim = (size_t)rd(); l.nrows = dim; l.ln_dim_size = (size_t)rd(); l.ln_multiplier = rd();
+      const int64_t eb = rd(), rcb = rd(), tcs = rd();
+      DP_REQUIRE(dim && dim <= (n - pos) / 2 && eb >= 0 && eb <= 0xFFFFFFFFll && rcb >= 1 && rcb <= 40 && tcs >= 0 && tcs < 8, DP_ERR_ARG, "model blob: layernorm parameters");
+      l.ln_eps_bits = (uint32_t)eb; l.ln_range_check_bits = (unsigned)rcb; l.ln_top_chunk_scalar_log = (unsigned)tcs;
+      l.weights.assign(b + pos, b + pos + dim); pos += dim; l.bias.assign(b + pos, b + pos + dim); pos += dim;
+    }
     else DP_REQUIRE(l.kind == L_RELU || l.kind == L_FLATTEN, DP_ERR_ARG, "model blob: unknown layer kind");
     m.layers.push_back(std::move(l));
   }

@@ -17,6 +17,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <cmath>
 
 namespace dp {
 
@@ -62,6 +64,10 @@ struct LayerSpec {
   // every proof then streams a quarter of the bytes and its dot products vectorise (pmaddwd); w16_max = max |w|
   std::shared_ptr<const std::vector<int16_t>> w16; int64_t w16_max = 0;
   size_t filter_size() const { return nw * nw; }
+  // layernorm (layers/transformer/layernorm.rs:74-101): gamma = weights, beta = bias, both [nrows = the padded normalisation dimension];
+  // QuantisedLayerNormData: N = ln_dim_size, the multiplier of the inverse-square-root input, the f32 bits of the rescaled epsilon (the table's
+  // identity together with ln_range_check_bits), the bits shifted away and range checked, log2 of the scalar of their top chunk
+  size_t ln_dim_size = 0; int64_t ln_multiplier = 0; uint32_t ln_eps_bits = 0; unsigned ln_range_check_bits = 0, ln_top_chunk_scalar_log = 0;
   unsigned right_shift = 0, fp_scale = 0, intermediate_bit_size = 0;
   int64_t fixed_point_multiplier = 0;
   unsigned shift() const { return fp_scale + right_shift; }
@@ -140,19 +146,56 @@ inline CmShape cm_shape(const LayerSpec& l) {
 }
 
 struct TableType {
-  int kind; unsigned size;  // 0 Relu, 2 Range, 3 Clamping(size)  (derive(Ord) order of lookup/context.rs:55-72)
-  bool operator<(const TableType& o) const { return kind != o.kind ? kind < o.kind : size < o.size; }
-  bool operator==(const TableType& o) const { return kind == o.kind && size == o.size; }
-  unsigned vars() const { return kind == 3 ? size : Q_BIT_LEN; }
-  const char* label() const { return kind == 0 ? "Relu" : kind == 3 ? "Clamping" : nullptr; }
+  // 0 Relu, 2 Range, 3 Clamping(size), 7 InverseSQRT{eps_bits = aux, range_check_bits = size}  (derive(Ord) order of lookup/context.rs:55-72,
+  // InverseSQRTTableData :124-131 ordered by (eps_bits, range_check_bits))
+  int kind; unsigned size; uint32_t aux = 0;
+  bool operator<(const TableType& o) const { return kind != o.kind ? kind < o.kind : aux != o.aux ? aux < o.aux : size < o.size; }
+  bool operator==(const TableType& o) const { return kind == o.kind && size == o.size && aux == o.aux; }
+  unsigned vars() const { return kind == 3 ? size : kind == 7 ? 2 * (Q_BIT_LEN - 1) + 1 : Q_BIT_LEN; }  // multiplicity_poly_vars (context.rs:481-492)
+  const char* label() const { return kind == 0 ? "Relu" : kind == 3 ? "Clamping" : kind == 7 ? "InverseSQRT" : nullptr; }
+  bool committed_column() const { return kind == 7; }  // committed_columns (context.rs:495-545): the output column of the table is a commitment of the context
 };
+constexpr unsigned LN_LOG_SCALE = 24, LN_LOG_OUT_SCALE = 10;  // LAYERNORM_SCALE_FACTOR, LAYERNORM_OUTPUT_SCALE_FACTOR (layernorm.rs:61-65)
+// InverseSQRTTableData::table_output (lookup/context.rs:147-157), in f32 as there; a negative argument gives NaN, which `as Element` turns into 0
+inline int64_t inv_sqrt_lut(uint32_t eps_bits, unsigned range_check_bits, int64_t j) {
+  float eps; memcpy(&eps, &eps_bits, 4);
+  const float arg = (float)(j * (int64_t(1) << range_check_bits)) / (float)(1u << LN_LOG_SCALE) + eps;
+  const float r = roundf((1.0f / sqrtf(arg)) * (float)(1u << LN_LOG_OUT_SCALE));
+  if (r != r) return 0;
+  if (r >= 9.2e18f) return INT64_MAX;
+  if (r <= -9.2e18f) return INT64_MIN;
+  return (int64_t)r;
+}
 inline int64_t q_clamp(int64_t x) { return x < Q_MIN ? Q_MIN : x > Q_MAX ? Q_MAX : x; }
 inline int64_t q_relu(int64_t x) { return x < 0 ? 0 : x; }
 inline void table_columns(const TableType& tt, std::vector<int64_t>& merged, std::vector<std::vector<int64_t>>& cols) {
   merged.clear(); cols.clear();
   if (tt.kind == 0) { cols.resize(2); for (int64_t i = Q_MIN - 1; i <= Q_MAX; i++) { int64_t o = q_relu(i); merged.push_back(i + o * COLUMN_SEPARATOR); cols[0].push_back(i); cols[1].push_back(o); } }
   else if (tt.kind == 2) { cols.resize(1); for (int64_t i = 0; i < (int64_t(1) << Q_BIT_LEN); i++) { merged.push_back(i); cols[0].push_back(i); } }
+  else if (tt.kind == 7) { cols.resize(2); int64_t mx = int64_t(1) << (2 * (Q_BIT_LEN - 1)); for (int64_t i = -mx; i < mx; i++) { int64_t o = inv_sqrt_lut(tt.aux, tt.size, i); merged.push_back(i + o * COLUMN_SEPARATOR); cols[0].push_back(i); cols[1].push_back(o); } }
   else { cols.resize(2); int64_t mx = int64_t(1) << (tt.size - 1); for (int64_t i = -mx; i < mx; i++) { int64_t o = q_clamp(i); merged.push_back(i + o * COLUMN_SEPARATOR); cols[0].push_back(i); cols[1].push_back(o); } }
+}
+
+inline TableType layernorm_table(const LayerSpec& l) { TableType t{7, l.ln_range_check_bits}; t.aux = l.ln_eps_bits; return t; }
+// LayerNorm::evaluate on Elements (layernorm.rs:394-470): per row, multiplier (N sum x^2 - (sum x)^2) is split into the bits that are range
+// checked and the input of the inverse-square-root table; out = gamma (N x - sum x) lut(input) + beta
+struct LayerNormTrace { std::vector<int64_t> lookup_input, lookup_output, range_check, row_sum; };
+inline std::vector<int64_t> layernorm_op(const LayerSpec& l, const std::vector<int64_t>& x, LayerNormTrace* d) {
+  const size_t fd = l.weights.size();
+  DP_REQUIRE((fd && !(fd & (fd - 1))) && l.bias.size() == fd && x.size() % fd == 0 && l.ln_dim_size >= 1 && l.ln_dim_size <= fd, DP_ERR_SHAPE, "layernorm: shapes");
+  const int64_t n = (int64_t)l.ln_dim_size, mask = (int64_t(1) << l.ln_range_check_bits) - 1, tmax = int64_t(1) << (2 * (Q_BIT_LEN - 1));
+  std::vector<int64_t> o(x.size());
+  for (size_t c = 0; c < x.size() / fd; c++) {
+    int64_t sq = 0, sum = 0;
+    for (size_t i = 0; i < fd; i++) { const int64_t v = x[c * fd + i]; DP_REQUIRE(v >= -(int64_t(1) << 20) && v <= (int64_t(1) << 20), DP_ERR_ARG, "layernorm: input out of range"); sq += v * v; sum += v; }
+    const int64_t full = n * l.ln_multiplier * sq - l.ln_multiplier * sum * sum;
+    const int64_t in = full >> l.ln_range_check_bits;
+    DP_REQUIRE(in >= -tmax && in < tmax, DP_ERR_ARG, "layernorm: the inverse square root input leaves its table");
+    const int64_t inv = inv_sqrt_lut(l.ln_eps_bits, l.ln_range_check_bits, in);
+    if (d) { d->lookup_input.push_back(in); d->lookup_output.push_back(inv); d->range_check.push_back(full & mask); d->row_sum.push_back(sum); }
+    for (size_t i = 0; i < fd; i++) o[c * fd + i] = l.weights[i] * (n * x[c * fd + i] - sum) * inv + l.bias[i];
+  }
+  return o;
 }
 
 // ---- inference (the reference's Model::run; CPU pre-processing outside "proving time", zkml/src/bin/bench.rs:341-352)
@@ -415,6 +458,7 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
         o.push_back(q_clamp((v * l.fixed_point_multiplier + (int64_t(1) << (sh - 1))) >> sh));
       }
     } else if (l.kind == L_RELU) for (int64_t v : cur) o.push_back(q_relu(v));
+    else if (l.kind == L_LAYERNORM) o = layernorm_op(l, cur, nullptr);
     else if (l.kind == L_CONV) { tr.conv.resize(m.layers.size()); o = conv_op(l, cur, tr.conv[tr.in.size() - 1]); }
     else if (l.kind == L_MAXPOOL) o = maxpool_op(l, cur);
     else if (l.kind == L_FLATTEN) o = cur;
@@ -433,6 +477,7 @@ struct VerifierContext {
   unsigned full_log = 0;
   std::map<size_t, std::map<std::string, Commitment>> model_comms;
   std::vector<TableType> tables;
+  std::map<TableType, Commitment> table_comms;
 };
 
 struct Context {
@@ -445,8 +490,10 @@ struct Context {
   struct ConvDev { DBuf wfft, clearing; };                          // conv: kernel FFTs [kw][kx*2n^2] and the 0/1 clearing tensor
   std::map<size_t, ConvDev> conv_dev;
   std::vector<TableType> tables;
+  std::map<TableType, DevCommit> table_comms;  // the committed columns of the tables that have one (commit/context.rs:105-107)
   VerifierContext verifier_ctx() const {
-    VerifierContext v; v.full_log = full_log; v.tables = tables; v.shape.input_len = model.input_len; v.shape.input_lens = model.input_lens; v.shape.outputs = model.outputs;
+    VerifierContext v; v.full_log = full_log; v.tables = tables;
+    for (auto& kv : table_comms) v.table_comms[kv.first] = pure_commitment(kv.second); v.shape.input_len = model.input_len; v.shape.input_lens = model.input_lens; v.shape.outputs = model.outputs;
     for (auto& l : model.layers) { LayerSpec s = l; s.weights.clear(); s.bias.clear(); s.wfft.reset(); s.w16.reset(); v.shape.layers.push_back(s); }
     for (auto& kv : model_comms) for (auto& pc : kv.second) v.model_comms[kv.first][pc.first] = pure_commitment(pc.second);
     return v;
@@ -454,6 +501,7 @@ struct Context {
   ~Context() {
     if (!dev) return;
     for (auto& kv : model_comms) for (auto& pc : kv.second) dev->free_commit(pc.second);
+    for (auto& kv : table_comms) dev->free_commit(kv.second);
     for (auto& kv : conv_dev) { dev->free_persistent(kv.second.wfft); dev->free_persistent(kv.second.clearing); }
   }
 };
@@ -513,6 +561,12 @@ inline void validate_model(const ModelSpec& m) {
       unsigned cs = l.clamping_size();
       DP_REQUIRE(cs >= 1 && cs <= 24 && cur >= 4, DP_ERR_ARG, "requant: unsupported clamping table size / tensor length");
     } else if (l.kind == L_RELU) { DP_REQUIRE(cur >= 4, DP_ERR_SHAPE, "relu: tensor length must be >= 4"); }
+    else if (l.kind == L_LAYERNORM) {
+      const size_t fd = l.weights.size();
+      DP_REQUIRE(is_pow2(fd) && fd >= 2 && l.bias.size() == fd && l.nrows == fd && is_pow2(cur) && cur % fd == 0 && cur / fd >= 4, DP_ERR_SHAPE, "layernorm: [rows >= 4][dim >= 2] input, gamma and beta of the padded dimension");
+      DP_REQUIRE(l.ln_dim_size >= 1 && next_pow2(l.ln_dim_size) == fd && l.ln_multiplier >= 1 && l.ln_multiplier < (int64_t(1) << 30), DP_ERR_ARG, "layernorm: dim_size / multiplier");
+      DP_REQUIRE(l.ln_range_check_bits >= 1 && l.ln_range_check_bits <= 40 && l.ln_top_chunk_scalar_log == (l.ln_range_check_bits % Q_BIT_LEN ? Q_BIT_LEN - l.ln_range_check_bits % Q_BIT_LEN : 0), DP_ERR_ARG, "layernorm: range check bits and the scalar of their top chunk");
+    }
     else if (l.kind == L_CONV) {
       DP_REQUIRE(is_pow2(l.kw) && is_pow2(l.kx) && is_pow2(l.real_nw) && is_pow2(l.nw) && l.kw >= 2 && l.nw >= 2 && 2 * l.real_nw <= l.nw, DP_ERR_SHAPE, "conv: padded dimensions must be powers of two, padded kernel <= half the padded input side");
       DP_REQUIRE(cur == l.kx * l.nw * l.nw && l.weights.size() == l.kw * l.kx * l.real_nw * l.real_nw && l.bias.size() == l.kw, DP_ERR_SHAPE, "conv: tensor sizes");
@@ -541,11 +595,12 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
     if (l.kind == L_REQUANT) { add({2, 0}); add({3, l.clamping_size()}); mpl = std::max(mpl, next_pow2(cur)); }
     else if (l.kind == L_RELU) { add({0, 0}); mpl = std::max(mpl, next_pow2(cur)); }
     else if (l.kind == L_MAXPOOL) { add({2, 0}); mpl = std::max(mpl, next_pow2(cur)); }
+    else if (l.kind == L_LAYERNORM) { add({2, 0}); add(layernorm_table(l)); mpl = std::max(mpl, next_pow2(cur)); }  // layernorm.rs:587-618
   }
   std::sort(ts.begin(), ts.end());
   for (auto& t : ts) mpl = std::max(mpl, size_t(1) << t.vars());
   for (auto& l : m.layers) if (l.kind == L_QKV) mpl = std::max(mpl, std::max(next_pow2(l.weights.size() / 3), next_pow2(l.bias.size() / 3)));
-  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD || l.kind == L_EMBED || l.kind == L_POSITIONAL) mpl = std::max(mpl, std::max(next_pow2(l.weights.size()), next_pow2(l.bias.size())));
+  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD || l.kind == L_EMBED || l.kind == L_POSITIONAL || l.kind == L_LAYERNORM) mpl = std::max(mpl, std::max(next_pow2(l.weights.size()), next_pow2(l.bias.size())));
   mpl = next_pow2(mpl);
   ctx->max_poly_len = mpl; ctx->full_log = dp_ceil_log2(mpl); ctx->tables = ts;
   dev.pcs_init(ctx->full_log);
@@ -559,6 +614,12 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
         dev.upload_i64(w, &l.weights[q * kn]); dev.upload_i64(b, &l.bias[q * n]);
         ctx->model_comms[id][wn[q]] = dev.commit(w, true); ctx->model_comms[id][bn[q]] = dev.commit(b, true);
       }
+      continue;
+    }
+    if (l.kind == L_LAYERNORM) {  // gamma and beta are model polynomials (layernorm.rs:67-68,603-613)
+      DBuf g = dev.alloc_persistent(l.weights.size(), false), b = dev.alloc_persistent(l.bias.size(), false);
+      dev.upload_i64(g, l.weights.data()); dev.upload_i64(b, l.bias.data());
+      ctx->model_comms[id]["LayerNormGamma"] = dev.commit(g, true); ctx->model_comms[id]["LayerNormBeta"] = dev.commit(b, true);
       continue;
     }
     if (l.kind != L_DENSE && l.kind != L_CONV && l.kind != L_MATMUL && l.kind != L_ADD && l.kind != L_EMBED && l.kind != L_POSITIONAL) continue;
@@ -610,6 +671,13 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
     }
     ctx->weights_dev[id] = w;
   }
+  for (const TableType& tt : ts) if (tt.committed_column()) {  // commit/context.rs:105-107
+    std::vector<int64_t> merged; std::vector<std::vector<int64_t>> tc;
+    table_columns(tt, merged, tc);
+    DBuf col = dev.alloc_persistent(tc[1].size(), false);
+    dev.upload_i64(col, tc[1].data());
+    ctx->table_comms[tt] = dev.commit(col, true);
+  }
   return ctx;
 }
 
@@ -634,6 +702,7 @@ struct ProverState {
   // activations the layer proofs read as extension tables (Dense inputs, ReLU outputs), already on the device: they rode in the
   // witness upload instead of costing one upload launch each inside the layer loop
   std::map<size_t, DBuf> staged_in, staged_out;
+  std::map<size_t, LayerNormTrace> ln_trace;  // LayerNormData of every LayerNorm node (kept from the witness generation for its prover)
   void add_witness_claim(const DevCommit& c, Claim cl) {
     if (c.nv <= PCS_BASECODE_LOG) trivial_claims.push_back({c, std::move(cl)}); else claims.push_back({c, std::move(cl)});
   }
@@ -695,6 +764,21 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       Pending p{id, 0, {cols.size(), cols.size() + 1}, 2, rt};
       cols.push_back({a}); cols.push_back({b});
       pend.push_back(p);
+    } else if (l.kind == L_LAYERNORM) {  // LayerNorm::lookup_witness (layernorm.rs:1103-1218): (input, output) of the inverse square root, then the range-checked chunks
+      LayerNormTrace& d = ps.ln_trace[id];
+      layernorm_op(l, tr.in[id], &d);
+      const unsigned nrc = (l.ln_range_check_bits - 1) / Q_BIT_LEN + 1;
+      const int64_t rmask = (int64_t(1) << Q_BIT_LEN) - 1, top = int64_t(1) << l.ln_top_chunk_scalar_log;
+      TableType it = layernorm_table(l), rt{2, 0};
+      for (size_t i = 0; i < d.lookup_input.size(); i++) counts[it][d.lookup_input[i] + d.lookup_output[i] * COLUMN_SEPARATOR] += 1;
+      Pending pi{id, 0, {cols.size(), cols.size() + 1}, 2, it}, pr{id, 1, {}, 1, rt};
+      cols.push_back({d.lookup_input}); cols.push_back({d.lookup_output});
+      for (unsigned j = 0; j < nrc; j++) {
+        std::vector<int64_t> ch; ch.reserve(d.range_check.size());
+        for (int64_t v : d.range_check) { int64_t c = ((v >> (j * Q_BIT_LEN)) & rmask) * (j + 1 == nrc ? top : 1); ch.push_back(c); counts[rt][c] += 1; }
+        pr.col_ids.push_back(cols.size()); cols.push_back({std::move(ch)});
+      }
+      pend.push_back(pi); pend.push_back(pr);
     } else if (l.kind == L_MAXPOOL) {  // Pooling::gen_lookup_witness (pooling.rs:206-262): 4 difference columns + the output
       TableType rt{2, 0};
       std::vector<std::vector<int64_t>> diffs = maxpool_diff_polys(l, tr.in[id], tr.out[id]);
@@ -1168,6 +1252,105 @@ inline Claim prove_relu(ProverState& ps, size_t id, const Claim& last, const std
   return input_claim;
 }
 
+// LayerNorm::prove + prove_step (layers/transformer/layernorm.rs:729-1100). After the two lookups, three sumchecks: (1) all lookup claims to ONE
+// point; (2) at (1/2, .., 1/2 | that point) — a sum over the normalisation dimension is 2^k times the evaluation with 1/2 in its coordinates —
+// the inverse-square-root input, recombined with its range-checked chunks, is multiplier (N sum x^2 - (sum x)^2); the output claim is gamma (N x -
+// sum x) inv_sqrt + beta; the inv_sqrt column of both is the committed one: three statements batched by two challenges, degree 4;
+// (3) `mean` is the row sum of the input. All tables are built on the host from the trace (row sums, repeated gamma / beta / lookup output) and
+// uploaded as base-field columns; the eq tables are made on the device.
+inline Claim prove_layernorm(ProverState& ps, size_t id, const LayerSpec& l, const Claim& last, const std::vector<int64_t>& input) {
+  Dev& dev = *ps.dev;
+  const size_t fd = l.weights.size(), n = input.size(), rows = n / fd;
+  const unsigned sdv = dp_ceil_log2(fd), nv_full = dp_ceil_log2(n);
+  DP_REQUIRE(last.point.size() == nv_full, DP_ERR_SHAPE, "layernorm: claim point length");
+  std::vector<LogUpWitness>& ws = ps.lookup_witness.at(id);
+  DP_REQUIRE(ws.size() == 2, DP_ERR_SHAPE, "layernorm: two lookups expected");
+  const LayerNormTrace& d = ps.ln_trace.at(id);
+  LayerNormProof pr;
+  for (auto& w : ws) pr.logup_proofs.push_back(logup_batch_prove(dev, ps.logup_input(w), *ps.t));
+  const std::vector<Claim>& inv_claims = pr.logup_proofs[0].output_claims; const std::vector<Claim>& range_claims = pr.logup_proofs[1].output_claims;
+  const unsigned nv = (unsigned)inv_claims[0].point.size();
+  DP_REQUIRE(inv_claims.size() == 2 && range_claims.size() == ws[1].columns.size() && nv + sdv == nv_full, DP_ERR_SHAPE, "layernorm: lookup claims");
+  std::vector<Ext> bc; for (unsigned q = 0; q < dp_ceil_log2(inv_claims.size() + range_claims.size()); q++) bc.push_back(ps.t->get_and_append_challenge("batching"));
+  const std::vector<Ext> rlc = host_eq_table(bc);
+  std::vector<DBuf> columns = ws[0].columns; columns.insert(columns.end(), ws[1].columns.begin(), ws[1].columns.end());
+  std::vector<DevCommit> commits = ws[0].commits; commits.insert(commits.end(), ws[1].commits.begin(), ws[1].commits.end());
+  size_t mk = dev.mark();
+  {
+    DBuf sqrt_eq = dev.alloc(rows, true), range_eq = dev.alloc(rows, true);
+    std::vector<EqAcc> eqs = {{sqrt_eq, inv_claims[0].point, ex_one(), false}, {range_eq, range_claims[0].point, ex_one(), false}};
+    DevVP vp(nv);
+    for (size_t q = 0; q < columns.size(); q++) vp.add_mle_list({columns[q], q < 2 ? sqrt_eq : range_eq}, rlc.at(q));
+    SumcheckOut sc = sumcheck_prove_with_eq(dev, eqs, vp, *ps.t);
+    pr.accumulation_proof = sc.proof;
+    const std::vector<Ext>& fin = sc.finals;  // sqrt_in, sqrt_eq, sqrt_out, range_0, range_eq, range_1, ..
+    pr.acc_evals = {fin[0], fin[2], fin[3]}; pr.acc_evals.insert(pr.acc_evals.end(), fin.begin() + 5, fin.end());
+  }
+  dev.release(mk);
+  const std::vector<Ext> sc_point = pr.accumulation_proof.point;
+  const Ext two_inv = ex_inv(ex_from_u64(2)), two_mul = ex_from_u64(u64(1) << sdv);
+  const Ext c1 = ps.t->get_and_append_challenge("batching"), c2 = ps.t->get_and_append_challenge("batching");
+  const Ext first = ex_mul(ex_sub(ex_one(), c1), ex_sub(ex_one(), c2)), second = ex_mul(c1, ex_sub(ex_one(), c2)), third = ex_mul(ex_sub(ex_one(), c1), c2);
+  std::vector<Ext> full_point(sdv, two_inv); full_point.insert(full_point.end(), sc_point.begin(), sc_point.end());
+  const Ext n_f = ex_from_u64(l.ln_dim_size), mult_f = ex_from_i64(l.ln_multiplier);
+  // input | mean | gamma repeated | beta repeated | lookup output repeated, one upload
+  std::vector<int64_t> host(5 * n);
+  for (size_t c = 0; c < rows; c++) for (size_t i = 0; i < fd; i++) {
+    const size_t j = c * fd + i;
+    host[j] = input[j]; host[n + j] = d.row_sum[c]; host[2 * n + j] = l.weights[i]; host[3 * n + j] = l.bias[i]; host[4 * n + j] = d.lookup_output[c];
+  }
+  DBuf all = dev.alloc(5 * n, false);
+  dev.upload_i64(all, host.data());
+  DBuf input_poly = all.slice(0, n), mean_poly = all.slice(n, n), gamma_poly = all.slice(2 * n, n), beta_poly = all.slice(3 * n, n), inv_poly = all.slice(4 * n, n);
+  Ext input_eval, mean_eval, inv_eval;
+  {
+    size_t mk2 = dev.mark();
+    DBuf input_eq = dev.alloc(n, true), last_eq = dev.alloc(n, true);
+    std::vector<EqAcc> eqs = {{input_eq, full_point, ex_one(), false}, {last_eq, last.point, ex_one(), false}};
+    DevVP vp(nv_full);
+    vp.add_mle_list({input_eq, input_poly, input_poly}, ex_mul(ex_mul(first, mult_f), ex_mul(n_f, two_mul)));
+    vp.add_mle_list({input_eq, mean_poly, mean_poly}, ex_neg(ex_mul(first, mult_f)));
+    vp.add_mle_list({last_eq, gamma_poly, input_poly, inv_poly}, ex_mul(second, n_f));
+    vp.add_mle_list({last_eq, gamma_poly, mean_poly, inv_poly}, ex_neg(second));
+    vp.add_mle_list({last_eq, beta_poly}, second);
+    vp.add_mle_list({input_eq, inv_poly}, third);
+    SumcheckOut sc = sumcheck_prove_with_eq(dev, eqs, vp, *ps.t);
+    pr.io_proof = sc.proof;
+    const std::vector<Ext>& fin = sc.finals;  // input_eq, input, mean, last_eq, gamma, inv_sqrt_out, beta
+    input_eval = fin[1]; mean_eval = fin[2]; pr.gamma_eval = fin[4]; inv_eval = fin[5]; pr.beta_eval = fin[6];
+    dev.release(mk2);
+  }
+  const std::vector<Ext> io_point = pr.io_proof.point;
+  const Ext ic = ps.t->get_and_append_challenge("batching");
+  Claim input_claim;
+  {
+    std::vector<Ext> sum_io(sdv, two_inv); sum_io.insert(sum_io.end(), io_point.begin() + sdv, io_point.end());
+    DBuf eq_io = dev.alloc(n, true), eq_sum = dev.alloc(n, true);
+    std::vector<EqAcc> eqs = {{eq_io, io_point, ex_one(), false}, {eq_sum, sum_io, ex_one(), false}};
+    dev.upload_i64(input_poly, input.data());  // (the io sumcheck folded its copy away)
+    DevVP vp(nv_full);
+    vp.add_mle_list({input_poly, eq_io}, ex_sub(ex_one(), ic));
+    vp.add_mle_list({input_poly, eq_sum}, ex_mul(ic, two_mul));
+    SumcheckOut sc = sumcheck_prove_with_eq(dev, eqs, vp, *ps.t);
+    pr.input_proof = sc.proof;
+    input_claim = {sc.proof.point, sc.finals[0]};
+  }
+  dev.release(mk);
+  // witness claims: the lookup input at the accumulation point, the lookup output at the tail of the io point, the chunks at the accumulation point
+  std::vector<Claim> cl = {{sc_point, pr.acc_evals[0]}, {std::vector<Ext>(io_point.begin() + sdv, io_point.end()), inv_eval}};
+  for (size_t q = 2; q < pr.acc_evals.size(); q++) cl.push_back({sc_point, pr.acc_evals[q]});
+  DP_REQUIRE(cl.size() == commits.size(), DP_ERR_SHAPE, "layernorm: claims and commitments");
+  for (size_t q = 0; q < cl.size(); q++) { pr.commitments.push_back(pure_commitment(commits[q])); pr.evaluations.push_back(cl[q].eval); ps.add_witness_claim(commits[q], cl[q]); }
+  pr.evaluations.push_back(input_eval); pr.evaluations.push_back(mean_eval);
+  // add_common_claims walks the node's BTreeMap: "LayerNormBeta" then "LayerNormGamma"
+  const std::vector<Ext> gp(io_point.begin(), io_point.begin() + sdv);
+  auto& comms = ps.ctx->model_comms.at(id);
+  ps.add_witness_claim(comms.at("LayerNormBeta"), {gp, pr.beta_eval});
+  ps.add_witness_claim(comms.at("LayerNormGamma"), {gp, pr.gamma_eval});
+  LayerProof lp; lp.kind = L_LAYERNORM; lp.ln = pr; ps.proofs[id] = lp;
+  return input_claim;
+}
+
 // ---- convolution (zkCNN FFT protocol, layers/convolution.rs:697-1080 with the helpers of iop/prover.rs:164-399)
 inline DBuf upload_exts(Dev& dev, const std::vector<Ext>& v) {
   DBuf b = dev.alloc(v.size(), true);
@@ -1427,6 +1610,7 @@ inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t) {
     else if (l.kind == L_POSITIONAL) cur = prove_positional(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
     else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, tr.out[id]);
+    else if (l.kind == L_LAYERNORM) cur = prove_layernorm(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv.at(id));
     else if (l.kind == L_MAXPOOL) cur = prove_pooling(ps, id, l, cur);
     // L_FLATTEN is not provable: the claim passes through unchanged (iop/prover.rs:449-456)
@@ -1438,6 +1622,8 @@ inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t) {
   for (auto& tw : ps.table_witness) {
     LogUpProof tp = logup_batch_prove(dev, ps.logup_input(tw), t);
     ps.add_witness_claim(tw.commits[0], tp.output_claims[0]);
+    // table_claims (lookup/context.rs:548-563): the claim on a committed table column (the last one) goes to the opening as well
+    if (tw.table_type.committed_column()) ps.add_witness_claim(ctx.table_comms.at(tw.table_type), tp.output_claims.back());
     proof.table_proofs.push_back({pure_commitment(tw.commits[0]), tp});
   }
   pt.lap("table proofs");
@@ -1478,6 +1664,7 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
     if (it->second.kind == L_RELU) add_fracs(it->second.act.lookup);
     if (it->second.kind == L_REQUANT) { add_fracs(it->second.req.clamping_lookup); add_fracs(it->second.req.shifted_lookup); }
     if (it->second.kind == L_MAXPOOL) add_fracs(it->second.pool.lookup);
+    if (it->second.kind == L_LAYERNORM) for (auto& lg : it->second.ln.logup_proofs) add_fracs(lg);
   }
   DP_REQUIRE(proof.steps.size() == n_provable, DP_ERR_VERIFY, "unexpected layer proofs");
   for (auto& tp : proof.table_proofs) add_fracs(tp.lookup);
@@ -1790,6 +1977,54 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       DP_REQUIRE(ex_eq(ex_mul(mp.individual_claims[0], mp.individual_claims[1]), sub.expected_evaluation), DP_ERR_VERIFY, "matmul: sumcheck claim failed");
       cur = {point_left, mp.individual_claims[0]};
       cur_len = s_ * l.nrows;
+    } else if (l.kind == L_LAYERNORM) {  // LayerNormCtx::verify (layernorm.rs:1230-1505)
+      const LayerNormProof& q = lp.ln;
+      const TableType it = layernorm_table(l);
+      DP_REQUIRE(chmap.count(it) && q.logup_proofs.size() == 2, DP_ERR_VERIFY, "layernorm: lookups");
+      const size_t nrc = (l.ln_range_check_bits - 1) / Q_BIT_LEN + 1;
+      LogUpVerifierClaim ic_ = verify_logup_proof(q.logup_proofs[0], 1, constant_challenge, chmap[it], t, 0);
+      LogUpVerifierClaim rc_ = verify_logup_proof(q.logup_proofs[1], nrc, constant_challenge, ex_one(), t, 0);
+      DP_REQUIRE(ic_.claims.size() == 2 && rc_.claims.size() == nrc && q.acc_evals.size() == 2 + nrc && q.evaluations.size() == 4 + nrc && q.commitments.size() == 2 + nrc, DP_ERR_VERIFY, "layernorm: shapes");
+      std::vector<Ext> bc; for (unsigned k = 0; k < dp_ceil_log2(2 + nrc); k++) bc.push_back(t.get_and_append_challenge("batching"));
+      const std::vector<Ext> rlc = host_eq_table(bc);
+      Ext acc_init = ex_zero();
+      for (size_t k = 0; k < 2 + nrc; k++) acc_init = ex_add(acc_init, ex_mul(k < 2 ? ic_.claims[k].eval : rc_.claims[k - 2].eval, rlc[k]));
+      const unsigned nv = (unsigned)ic_.claims[0].point.size(), sdv = dp_ceil_log2(l.ln_dim_size);
+      DP_REQUIRE(rc_.claims[0].point.size() == nv && cur.point.size() == nv + sdv, DP_ERR_VERIFY, "layernorm: point sizes");
+      SubClaim acc = sumcheck_verify(acc_init, q.accumulation_proof, nv, 2, t);
+      const Ext eq_sqrt = eq_eval(ic_.claims[0].point.data(), acc.point.data(), nv), eq_range = eq_eval(rc_.claims[0].point.data(), acc.point.data(), nv);
+      Ext calc = ex_zero();
+      for (size_t k = 0; k < 2 + nrc; k++) calc = ex_add(calc, ex_mul(ex_mul(q.acc_evals[k], k < 2 ? eq_sqrt : eq_range), rlc[k]));
+      DP_REQUIRE(ex_eq(calc, acc.expected_evaluation), DP_ERR_VERIFY, "layernorm: accumulation claim mismatch");
+      const Ext c1 = t.get_and_append_challenge("batching"), c2 = t.get_and_append_challenge("batching");
+      const Ext first = ex_mul(ex_sub(ex_one(), c1), ex_sub(ex_one(), c2)), second = ex_mul(c1, ex_sub(ex_one(), c2)), third = ex_mul(ex_sub(ex_one(), c1), c2);
+      // the inverse-square-root input, shifted back up, plus the range-checked chunks (the top one divided by its scalar)
+      Ext partial = ex_mul(q.acc_evals[0], ex_from_u64(u64(1) << l.ln_range_check_bits)), pw = ex_one();
+      for (size_t k = 0; k + 1 < nrc; k++) { partial = ex_add(partial, ex_mul(q.acc_evals[2 + k], pw)); pw = ex_mul(pw, ex_from_u64(u64(1) << Q_BIT_LEN)); }
+      const Ext top_inv = ex_inv(ex_from_u64(u64(1) << l.ln_top_chunk_scalar_log));
+      const Ext io_init = ex_add(ex_add(ex_mul(first, ex_add(partial, ex_mul(ex_mul(q.acc_evals.back(), top_inv), pw))), ex_mul(second, cur.eval)), ex_mul(q.acc_evals[1], third));
+      SubClaim io = sumcheck_verify(io_init, q.io_proof, nv + sdv, 4, t);
+      const Ext input_io = q.evaluations[q.evaluations.size() - 2], mean_io = q.evaluations.back(), inv_ev = q.evaluations[1];
+      const Ext n_f = ex_from_u64(l.ln_dim_size), two_inv = ex_inv(ex_from_u64(2)), two_mul = ex_from_u64(u64(1) << sdv), mult_f = ex_from_i64(l.ln_multiplier);
+      std::vector<Ext> full_point(sdv, two_inv); full_point.insert(full_point.end(), acc.point.begin(), acc.point.end());
+      const Ext input_eq = eq_eval(full_point.data(), io.point.data(), io.point.size()), last_eq = eq_eval(cur.point.data(), io.point.data(), io.point.size());
+      const Ext p1 = ex_mul(ex_mul(ex_mul(first, mult_f), input_eq), ex_sub(ex_mul(ex_mul(n_f, two_mul), ex_mul(input_io, input_io)), ex_mul(mean_io, mean_io)));
+      const Ext p2 = ex_mul(ex_mul(second, last_eq), ex_add(ex_mul(ex_mul(inv_ev, q.gamma_eval), ex_sub(ex_mul(n_f, input_io), mean_io)), q.beta_eval));
+      const Ext p3 = ex_mul(ex_mul(third, input_eq), inv_ev);
+      DP_REQUIRE(ex_eq(ex_add(ex_add(p1, p2), p3), io.expected_evaluation), DP_ERR_VERIFY, "layernorm: io claim mismatch");
+      const Ext ich = t.get_and_append_challenge("batching");
+      SubClaim in = sumcheck_verify(ex_add(input_io, ex_mul(ich, ex_sub(mean_io, input_io))), q.input_proof, nv + sdv, 2, t);
+      std::vector<Ext> sum_io(sdv, two_inv); sum_io.insert(sum_io.end(), io.point.begin() + sdv, io.point.end());
+      const Ext eq_io = eq_eval(io.point.data(), in.point.data(), in.point.size()), eq_sum = eq_eval(sum_io.data(), in.point.data(), in.point.size());
+      const Ext non_input = ex_add(eq_io, ex_mul(ich, ex_sub(ex_mul(two_mul, eq_sum), eq_io)));
+      DP_REQUIRE(!ex_is_zero(non_input), DP_ERR_VERIFY, "layernorm: degenerate input point");
+      for (size_t k = 0; k < 2 + nrc; k++) add_claim(q.commitments[k], k == 1 ? Claim{std::vector<Ext>(io.point.begin() + sdv, io.point.end()), q.evaluations[k]} : Claim{acc.point, q.evaluations[k]});
+      auto nit = unused.find(id);
+      DP_REQUIRE(nit != unused.end() && nit->second.count("LayerNormBeta") && nit->second.count("LayerNormGamma"), DP_ERR_VERIFY, "layernorm: no commitments for node");
+      const std::vector<Ext> gp(io.point.begin(), io.point.begin() + sdv);
+      add_claim(nit->second.at("LayerNormBeta"), {gp, q.beta_eval}); add_claim(nit->second.at("LayerNormGamma"), {gp, q.gamma_eval});
+      unused.erase(nit);
+      cur = {in.point, ex_mul(in.expected_evaluation, ex_inv(non_input))};
     } else if (l.kind == L_REQUANT) {  // verify_requant (requant.rs:692-817)
       const RequantProof& rp = lp.req;
       TableType ct{3, l.clamping_size()};
@@ -1845,17 +2080,26 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
   }
   // table proofs (verifier.rs:320-383)
   DP_REQUIRE(proof.table_proofs.size() == vc.tables.size(), DP_ERR_VERIFY, "wrong number of table proofs");
+  std::map<TableType, Commitment> unused_tables = vc.table_comms;
   for (size_t i = 0; i < vc.tables.size(); i++) {
     const TableType& tt = vc.tables[i];
     const TableProof& tp = proof.table_proofs[i];
     LogUpVerifierClaim v = verify_logup_proof(tp.lookup, 1, constant_challenge, chmap[tt], t, 1);
     add_claim(tp.multiplicity_commit, v.claims[0]);
+    if (tt.committed_column()) {  // the claim on the committed column is left to the opening (verifier.rs:352-362)
+      auto ti = unused_tables.find(tt);
+      DP_REQUIRE(ti != unused_tables.end() && v.claims.size() >= 2, DP_ERR_VERIFY, "table: no commitment for its column");
+      add_claim(ti->second, v.claims.back());
+      unused_tables.erase(ti);
+      v.claims.pop_back();
+    }
     const std::vector<Ext>& pt = v.claims[0].point;
     DP_REQUIRE(pt.size() == tt.vars(), DP_ERR_VERIFY, "table: point size");
     std::vector<Ext> expect;  // evaluate_table_columns (lookup/context.rs:302-462)
     Ext idx = ex_zero();
     for (size_t k = 0; k < pt.size(); k++) idx = ex_add(idx, ex_mul(pt[k], ex_from_u64(u64(1) << k)));
     if (tt.kind == 2) expect = {idx};
+    else if (tt.kind == 7) expect = {ex_sub(idx, ex_from_u64(u64(1) << (2 * (Q_BIT_LEN - 1))))};  // (context.rs:445-462)
     else if (tt.kind == 0) {
       Ext second = ex_zero();
       for (size_t k = 0; k + 1 < pt.size(); k++) second = ex_add(second, ex_mul(ex_mul(pt[k], ex_from_u64(u64(1) << k)), pt.back()));
@@ -1903,6 +2147,7 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
   }
   // commitment openings (commit/context.rs:520-598)
   DP_REQUIRE(unused.empty(), DP_ERR_VERIFY, "not all model commitments have been used");
+  DP_REQUIRE(unused_tables.empty(), DP_ERR_VERIFY, "not all table commitments have been used");
   DP_REQUIRE(trivial_claims.size() == proof.trivial_proofs.size(), DP_ERR_VERIFY, "number of trivial proofs");
   for (size_t i = 0; i < trivial_claims.size(); i++) pcs_verify_trivial(trivial_claims[i].comm, trivial_claims[i].point, trivial_claims[i].eval, proof.trivial_proofs[i]);
   VerifierParams vp; vp.full_log = vc.full_log;
@@ -1917,8 +2162,8 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
 }
 
 // ---- serialisable verifier context (what dp_model_verifier_blob hands out and dp_verify consumes)
-constexpr int N_POLY_IDS = 15;
-inline const char* const* poly_ids() { static const char* const ids[N_POLY_IDS] = {"DenseBias", "DenseWeight", "ConvBias", "ConvFilter", "MatMulBias", "MatMulWeight", "255", "EmbeddingMat", "PositionalMatrix", "BiasK", "BiasQ", "BiasV", "WeightK", "WeightQ", "WeightV"}; return ids; }
+constexpr int N_POLY_IDS = 17;
+inline const char* const* poly_ids() { static const char* const ids[N_POLY_IDS] = {"DenseBias", "DenseWeight", "ConvBias", "ConvFilter", "MatMulBias", "MatMulWeight", "255", "EmbeddingMat", "PositionalMatrix", "BiasK", "BiasQ", "BiasV", "WeightK", "WeightQ", "WeightV", "LayerNormBeta", "LayerNormGamma"}; return ids; }
 constexpr u64 VCTX_GRAPH_MARK = 0x0048504152475044ULL;  // "DPGRAPH": the optional trailing section of a verifier blob (edges, multi-tensor io, ConcatMatMul geometry)
 inline bool is_plain_chain(const ModelSpec& m) {
   if (!m.input_lens.empty() || !m.outputs.empty()) return false;
@@ -1928,7 +2173,11 @@ inline bool is_plain_chain(const ModelSpec& m) {
 inline std::vector<u64> vctx_to_words(const VerifierContext& v) {
   std::vector<u64> w;
   w.push_back(0x3158544356504444ULL); w.push_back(v.full_log); w.push_back(v.shape.input_len); w.push_back(v.shape.layers.size());
-  for (auto& l : v.shape.layers) {
+  for (auto& l0 : v.shape.layers) {
+    LayerSpec l = l0;
+    if (l.kind == L_LAYERNORM) {  // a LayerNorm rides in the slots of a Requant: N, range check bits, log2 of the top chunk scalar, multiplier, epsilon bits
+      l.ncols = l.ln_dim_size; l.right_shift = l.ln_range_check_bits; l.fp_scale = l.ln_top_chunk_scalar_log; l.fixed_point_multiplier = l.ln_multiplier; l.intermediate_bit_size = l.ln_eps_bits;
+    }
     w.push_back(l.kind); w.push_back(l.nrows); w.push_back(l.ncols); w.push_back(l.right_shift); w.push_back(l.fp_scale);
     const bool adds = l.kind == L_ADD || l.kind == L_ADD2 || l.kind == L_POSITIONAL, mm = l.kind == L_MATMUL || l.kind == L_MATMUL2;
     w.push_back(adds ? (u64)l.add_left : (u64)l.fixed_point_multiplier);  // (an Add carries its two multipliers in the requant multiplier / kx slots)
@@ -1948,7 +2197,14 @@ inline std::vector<u64> vctx_to_words(const VerifierContext& v) {
     }
   }
   w.push_back(v.tables.size());
-  for (auto& t : v.tables) { w.push_back(t.kind); w.push_back(t.size); }
+  for (auto& t : v.tables) {
+    w.push_back(t.kind); w.push_back(t.size);
+    if (t.committed_column()) {  // (only these entries are longer: the table's second parameter and the commitment of its column)
+      w.push_back(t.aux);
+      auto it = v.table_comms.find(t); DP_REQUIRE(it != v.table_comms.end(), DP_ERR_ARG, "verifier context: table without its commitment");
+      const Commitment& c = it->second; for (int k = 0; k < 4; k++) w.push_back(c.root.v[k]); w.push_back(c.num_vars); w.push_back(c.is_base);
+    }
+  }
   if (!is_plain_chain(v.shape)) {
     w.push_back(VCTX_GRAPH_MARK);
     w.push_back(v.shape.input_lens.size()); for (size_t n : v.shape.input_lens) w.push_back(n);
@@ -1978,7 +2234,12 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
     l.kw = (size_t)rd(); l.kx = (size_t)rd(); l.real_nw = (size_t)rd(); l.nw = (size_t)rd();
     for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();
     for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd();
-    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_QKV, DP_ERR_ARG, "verifier blob: layer kind");
+    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_LAYERNORM, DP_ERR_ARG, "verifier blob: layer kind");
+    if (l.kind == L_LAYERNORM) {
+      l.ln_dim_size = l.ncols; l.ln_range_check_bits = l.right_shift; l.ln_top_chunk_scalar_log = l.fp_scale; l.ln_multiplier = l.fixed_point_multiplier; l.ln_eps_bits = (uint32_t)l.intermediate_bit_size;
+      l.ncols = 0; l.right_shift = l.fp_scale = l.intermediate_bit_size = 0; l.fixed_point_multiplier = 0;
+      DP_REQUIRE(is_pow2(l.nrows) && l.nrows >= 2 && l.nrows <= (size_t(1) << 24) && l.ln_dim_size >= 1 && next_pow2(l.ln_dim_size) == l.nrows && l.ln_multiplier >= 1 && l.ln_range_check_bits >= 1 && l.ln_range_check_bits <= 40 && l.ln_top_chunk_scalar_log < Q_BIT_LEN, DP_ERR_ARG, "verifier blob: layernorm parameters");
+    }
     if (l.kind == L_MATMUL2) { DP_REQUIRE(l.kw <= 1, DP_ERR_ARG, "verifier blob: matmul flags"); l.mm_transpose = l.kw != 0; l.kw = 0; }
     if (l.kind == L_ADD || l.kind == L_ADD2 || l.kind == L_POSITIONAL) { l.add_left = l.fixed_point_multiplier; l.add_right = (int64_t)l.kx; l.fixed_point_multiplier = 0; l.kx = 0; DP_REQUIRE(l.add_left > 0 && l.add_right > 0, DP_ERR_ARG, "verifier blob: add multipliers"); }
     if (l.kind == L_MATMUL) { DP_REQUIRE(l.kw <= 1, DP_ERR_ARG, "verifier blob: matmul flags"); l.mm_transpose = l.kw != 0; l.kw = 0; }
@@ -1993,7 +2254,15 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
     for (size_t q = 0; q < np; q++) { u64 code = rd(); DP_REQUIRE(code < (u64)N_POLY_IDS, DP_ERR_ARG, "verifier blob: polynomial id"); Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = rd(); c.num_vars = (unsigned)rd(); c.is_base = rd() != 0; v.model_comms[id][poly_ids()[code]] = c; }
   }
   size_t nt = (size_t)rd(); DP_REQUIRE(nt < 64, DP_ERR_ARG, "verifier blob: tables");
-  for (size_t i = 0; i < nt; i++) { TableType t; t.kind = (int)rd(); t.size = (unsigned)rd(); v.tables.push_back(t); }
+  for (size_t i = 0; i < nt; i++) {
+    TableType t; t.kind = (int)rd(); t.size = (unsigned)rd();
+    DP_REQUIRE(t.kind == 0 || t.kind == 2 || t.kind == 3 || t.kind == 7, DP_ERR_ARG, "verifier blob: table kind");
+    if (t.committed_column()) {
+      u64 a = rd(); DP_REQUIRE(a <= 0xFFFFFFFFull && t.size >= 1 && t.size <= 40, DP_ERR_ARG, "verifier blob: table parameters"); t.aux = (uint32_t)a;
+      Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = rd(); c.num_vars = (unsigned)rd(); c.is_base = rd() != 0; v.table_comms[t] = c;
+    }
+    v.tables.push_back(t);
+  }
   if (pos < n) {
     DP_REQUIRE(rd() == VCTX_GRAPH_MARK, DP_ERR_ARG, "verifier blob: trailing words");
     auto rd_edge = [&]() { Edge e; u64 f = rd(); DP_REQUIRE(f <= nl, DP_ERR_ARG, "verifier blob: edge"); e.from = (int)f - 1; u64 sl = rd(); DP_REQUIRE(sl < 4096, DP_ERR_ARG, "verifier blob: edge"); e.slot = (int)sl; return e; };

@@ -74,6 +74,12 @@ static Model parse_model(const int64_t* b, size_t n) {
       if (pos + nf + l.kw > n) throw std::runtime_error("model blob truncated");
       l.weights.assign(b + pos, b + pos + nf); pos += nf; l.bias.assign(b + pos, b + pos + l.kw); pos += l.kw;
     } else if (l.kind == L_MAXPOOL) { for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd(); }
+    else if (l.kind == L_LAYERNORM) {  // dim, N, multiplier, eps bits, range check bits, log2 of the top chunk scalar, gamma[dim], beta[dim]
+      size_t dim = (size_t)rd(); l.ln_dim_size = (size_t)rd(); l.ln_multiplier = rd(); l.ln_eps_bits = (uint32_t)rd(); l.ln_range_check_bits = (unsigned)rd(); l.ln_top_chunk_scalar_log = (unsigned)rd();
+      if (dim == 0 || dim > n || pos + 2 * dim > n) throw std::runtime_error("model blob truncated");
+      if (l.ln_range_check_bits == 0 || l.ln_range_check_bits > 40 || l.ln_top_chunk_scalar_log >= 8) throw std::runtime_error("layernorm: range check parameters");
+      l.weights.assign(b + pos, b + pos + dim); pos += dim; l.bias.assign(b + pos, b + pos + dim); pos += dim;
+    }
     else if (l.kind == L_RELU || l.kind == L_FLATTEN) {}
     else throw std::runtime_error("model blob: unknown layer kind");
     m.layers.push_back(std::move(l));

@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <thread>
 #include <string>
+#include <cstring>
+#include <cmath>
 
 namespace orc {
 
@@ -170,7 +172,7 @@ static inline LogUpProof logup_batch_prove(const LogUpInput& in, Transcript& t) 
 
 // ------------------------------------------------------------------ model description
 enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8, L_POSITIONAL = 9,
-                 L_MATMUL2 = 10, L_ADD2 = 11, L_CONCAT_MATMUL = 12, L_QKV = 13 };
+                 L_MATMUL2 = 10, L_ADD2 = 11, L_CONCAT_MATMUL = 12, L_QKV = 13, L_LAYERNORM = 14 };
 // An edge of the model graph (layers/provable/mod.rs:195-229, Edge): output `index` of node `node`, or input tensor `index` of the model (node < 0)
 struct Wire { int node = -1; int index = 0; };
 struct Layer {
@@ -206,6 +208,10 @@ struct Layer {
   // maxpool (layers/pooling.rs): padded input shape [c, h, w]
   size_t pin[3] = {0, 0, 0};
   size_t filter_size() const { return nw * nw; }
+  // layernorm (layers/transformer/layernorm.rs:74-101, QuantisedLayerNormData): gamma in `weights`, beta in `bias`, both as long as the (padded)
+  // normalisation dimension; dim_size = N, the multiplier of the inverse-square-root input, the f32 bits of the rescaled epsilon, the bits that
+  // are shifted away and range checked, log2 of the scalar of their most significant chunk
+  size_t ln_dim_size = 0; int64_t ln_multiplier = 0; uint32_t ln_eps_bits = 0; unsigned ln_range_check_bits = 0, ln_top_chunk_scalar_log = 0;
   unsigned right_shift = 0, fp_scale = 0, intermediate_bit_size = 0;  // requant (requant.rs:46-73)
   int64_t fixed_point_multiplier = 0;
   unsigned shift() const { return fp_scale + right_shift; }
@@ -277,14 +283,29 @@ static inline void cm_output_shape(const Layer& l, size_t out[3]) {
   for (int d = 0; d < 3; d++) out[d] = l.cm_perm.empty() ? r[d] : r[l.cm_perm[d]];
 }
 
-struct TableType {  // lookup/context.rs:55-72 (derive Ord: Relu < GELU < Range < Clamping(n) < ...)
-  int kind;  // 0 Relu, 2 Range, 3 Clamping
-  unsigned size;
-  bool operator<(const TableType& o) const { return kind != o.kind ? kind < o.kind : size < o.size; }
-  bool operator==(const TableType& o) const { return kind == o.kind && size == o.size; }
-  unsigned multiplicity_poly_vars() const { return kind == 3 ? size : BIT_LEN; }
-  const char* challenge_label() const { return kind == 0 ? "Relu" : kind == 3 ? "Clamping" : nullptr; }
+struct TableType {  // lookup/context.rs:55-72 (derive Ord: Relu < GELU < Range < Clamping(n) < Softmax < ErrorTable < ZeroTable < InverseSQRT)
+  int kind;  // 0 Relu, 2 Range, 3 Clamping, 7 InverseSQRT
+  unsigned size;      // Clamping: bits; InverseSQRT: range_check_bits
+  uint32_t aux = 0;   // InverseSQRT: eps_bits (InverseSQRTTableData derives Ord on (eps_bits, range_check_bits))
+  bool operator<(const TableType& o) const { return kind != o.kind ? kind < o.kind : aux != o.aux ? aux < o.aux : size < o.size; }
+  bool operator==(const TableType& o) const { return kind == o.kind && size == o.size && aux == o.aux; }
+  unsigned multiplicity_poly_vars() const { return kind == 3 ? size : kind == 7 ? 2 * (BIT_LEN - 1) + 1 : BIT_LEN; }  // context.rs:481-492
+  const char* challenge_label() const { return kind == 0 ? "Relu" : kind == 3 ? "Clamping" : kind == 7 ? "InverseSQRT" : nullptr; }
+  bool has_committed_column() const { return kind == 7; }  // committed_columns (context.rs:495-545): the output column
 };
+constexpr unsigned LOG_LAYERNORM_SCALE_FACTOR = 24, LOG_LAYERNORM_OUTPUT_SCALE_FACTOR = 10;  // layernorm.rs:61-65
+// InverseSQRTTableData::table_output (lookup/context.rs:147-157): f32 arithmetic, `as Element` of a NaN (negative argument) is 0
+static inline int64_t inv_sqrt_table_output(uint32_t eps_bits, unsigned range_check_bits, int64_t j) {
+  float eps; std::memcpy(&eps, &eps_bits, 4);
+  const int64_t shifted = j * (int64_t(1) << range_check_bits);
+  const float arg = (float)shifted / (float)(1u << LOG_LAYERNORM_SCALE_FACTOR) + eps;
+  const float out = 1.0f / std::sqrt(arg);
+  const float r = std::round(out * (float)(1u << LOG_LAYERNORM_OUTPUT_SCALE_FACTOR));
+  if (std::isnan(r)) return 0;
+  if (r >= 9.2e18f) return INT64_MAX;
+  if (r <= -9.2e18f) return INT64_MIN;
+  return (int64_t)r;
+}
 static inline int64_t relu_apply(int64_t x) { return x < 0 ? 0 : x; }
 static inline int64_t clamp_q(int64_t x) { return x < QMIN ? QMIN : x > QMAX ? QMAX : x; }
 // get_merged_table_column (lookup/context.rs:158-296)
@@ -296,12 +317,17 @@ static inline void table_columns(const TableType& tt, std::vector<int64_t>& merg
   } else if (tt.kind == 2) {
     cols.resize(1);
     for (int64_t i = 0; i < (int64_t(1) << BIT_LEN); i++) { merged.push_back(i); cols[0].push_back(from_i64(i)); }
+  } else if (tt.kind == 7) {  // context.rs:280-294
+    cols.resize(2);
+    int64_t mx = int64_t(1) << (2 * (BIT_LEN - 1));
+    for (int64_t i = -mx; i < mx; i++) { int64_t o = inv_sqrt_table_output(tt.aux, tt.size, i); merged.push_back(i + o * COLUMN_SEPARATOR); cols[0].push_back(from_i64(i)); cols[1].push_back(from_i64(o)); }
   } else {
     cols.resize(2);
     int64_t mx = int64_t(1) << (tt.size - 1);
     for (int64_t i = -mx; i < mx; i++) { int64_t o = clamp_q(i); merged.push_back(i + o * COLUMN_SEPARATOR); cols[0].push_back(from_i64(i)); cols[1].push_back(from_i64(o)); }
   }
 }
+static inline TableType layernorm_table(const Layer& l) { TableType t{7, l.ln_range_check_bits}; t.aux = l.ln_eps_bits; return t; }
 
 // ------------------------------------------------------------------ inference (layers' Evaluate impls)
 // ConvData (tensor.rs:326-372): everything the FFT convolution computes on the way, kept for the prover
@@ -410,6 +436,25 @@ static inline std::vector<std::vector<int64_t>> maxpool_diff_polys(const Layer& 
     }
   return cols;
 }
+// LayerNorm::evaluate on Elements (layernorm.rs:394-470); LayerNormData = what the prover needs later
+struct LayerNormData { std::vector<int64_t> lookup_input, lookup_output, range_check; };
+static inline std::vector<int64_t> layernorm_op(const Layer& l, const std::vector<int64_t>& x, LayerNormData* d) {
+  const size_t fd = l.weights.size();
+  if (!fd || (fd & (fd - 1)) || l.bias.size() != fd || x.size() % fd || !l.ln_dim_size || l.ln_dim_size > fd) throw std::runtime_error("layernorm: shapes");
+  const int64_t n = (int64_t)l.ln_dim_size, mask = (int64_t(1) << l.ln_range_check_bits) - 1, tmax = int64_t(1) << (2 * (BIT_LEN - 1));
+  std::vector<int64_t> o(x.size());
+  for (size_t c = 0; c < x.size() / fd; c++) {
+    int64_t sq = 0, sum = 0;
+    for (size_t i = 0; i < fd; i++) { sq += x[c * fd + i] * x[c * fd + i]; sum += x[c * fd + i]; }
+    const int64_t full = n * l.ln_multiplier * sq - l.ln_multiplier * sum * sum;
+    const int64_t in = full >> l.ln_range_check_bits;
+    if (in < -tmax || in >= tmax) throw std::runtime_error("layernorm: the inverse square root input leaves its table");
+    const int64_t inv = inv_sqrt_table_output(l.ln_eps_bits, l.ln_range_check_bits, in);
+    if (d) { d->lookup_input.push_back(in); d->lookup_output.push_back(inv); d->range_check.push_back(full & mask); }
+    for (size_t i = 0; i < fd; i++) o[c * fd + i] = l.weights[i] * (n * x[c * fd + i] - sum) * inv + l.bias[i];
+  }
+  return o;
+}
 static inline int64_t requant_apply(const Layer& l, int64_t v) {
   unsigned sh = l.shift();
   int64_t tmp = v * l.fixed_point_multiplier + (int64_t(1) << (sh - 1));
@@ -506,6 +551,7 @@ static inline Trace run_model(const Model& m, const std::vector<int64_t>& input)
         o.push_back(requant_apply(l, v));
       }
     } else if (l.kind == L_RELU) { for (int64_t v : cur) o.push_back(relu_apply(v)); }
+    else if (l.kind == L_LAYERNORM) o = layernorm_op(l, cur, nullptr);
     else if (l.kind == L_CONV) { tr.conv.resize(m.layers.size()); o = conv_op(l, cur, tr.conv[tr.in.size() - 1]); }
     else if (l.kind == L_MAXPOOL) o = maxpool_op(l, cur);
     else if (l.kind == L_FLATTEN) o = cur;
@@ -522,6 +568,7 @@ struct Context {
   PcsParams pp;
   std::map<size_t, std::map<std::string, ProverCommitment>> model_comms;  // BTreeMap<NodeId, BTreeMap<PolyId,..>>
   std::vector<TableType> tables;                                           // LookupContext (BTreeSet order)
+  std::map<TableType, ProverCommitment> table_comms;                       // committed table columns (commit/context.rs:105-107)
   size_t max_poly_len = 0;
 };
 static inline size_t next_pow2(size_t x) { size_t p = 1; while (p < x) p <<= 1; return p; }
@@ -557,13 +604,14 @@ static inline Context context_generate(const Model& m) {
     size_t cur_len = out_lens[id_][0];  // (Requant / Relu keep the length of their input)
     if (l.kind == L_REQUANT) { add_table({2, 0}); add_table({3, l.clamping_size()}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
     else if (l.kind == L_RELU) { add_table({0, 0}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
+    else if (l.kind == L_LAYERNORM) { add_table({2, 0}); add_table(layernorm_table(l)); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }  // layernorm.rs:587-618
     else if (l.kind == L_CONV) { cur_len = l.kw * l.nw * l.nw; }                                                       // convolution.rs:506-511
     else if (l.kind == L_MAXPOOL) { add_table({2, 0}); cur_len = l.pin[0] * (l.pin[1] / 2) * (l.pin[2] / 2); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }  // pooling.rs:131-166
   }
   std::sort(tset.begin(), tset.end());
   for (auto& t : tset) max_poly_len = std::max(max_poly_len, size_t(1) << t.multiplicity_poly_vars());
   for (auto& l : m.layers) if (l.kind == L_QKV) { max_poly_len = std::max(max_poly_len, next_pow2(l.weights.size() / 3)); max_poly_len = std::max(max_poly_len, next_pow2(l.bias.size() / 3)); }
-  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD || l.kind == L_EMBED || l.kind == L_POSITIONAL) { max_poly_len = std::max(max_poly_len, next_pow2(l.weights.size())); max_poly_len = std::max(max_poly_len, next_pow2(l.bias.size())); }
+  for (auto& l : m.layers) if (l.kind == L_DENSE || l.kind == L_CONV || l.kind == L_MATMUL || l.kind == L_ADD || l.kind == L_EMBED || l.kind == L_POSITIONAL || l.kind == L_LAYERNORM) { max_poly_len = std::max(max_poly_len, next_pow2(l.weights.size())); max_poly_len = std::max(max_poly_len, next_pow2(l.bias.size())); }
   max_poly_len = next_pow2(max_poly_len);
   ctx.max_poly_len = max_poly_len;
   ctx.pp = pcs_setup(max_poly_len);
@@ -577,6 +625,7 @@ static inline Context context_generate(const Model& m) {
     if (m.layers[id].kind == L_EMBED) jobs.push_back({id, "EmbeddingMat"});  // embeddings.rs:271,284-291
     if (m.layers[id].kind == L_ADD) jobs.push_back({id, "255"});  // OPERAND_POLY_ID = 0xff, to_string() (add.rs:32,520)
     if (m.layers[id].kind == L_MATMUL) { jobs.push_back({id, "MatMulWeight"}); if (!m.layers[id].bias.empty()) jobs.push_back({id, "MatMulBias"}); }  // matrix_mul.rs:947-963
+    if (m.layers[id].kind == L_LAYERNORM) { jobs.push_back({id, "LayerNormGamma"}); jobs.push_back({id, "LayerNormBeta"}); }  // layernorm.rs:67-68,603-613
     if (m.layers[id].kind == L_QKV) for (const char* pid : {"WeightQ", "WeightK", "WeightV", "BiasQ", "BiasK", "BiasV"}) jobs.push_back({id, pid});  // qkv.rs:388-418
   }
   for (auto& j : jobs) ctx.model_comms[j.first][j.second];  // create map slots before the threads write into them
@@ -589,11 +638,18 @@ static inline Context context_generate(const Model& m) {
       const bool wgt = pid[0] == 'W'; const size_t which = pid.back() == 'Q' ? 0 : pid.back() == 'K' ? 1 : 2;
       const std::vector<int64_t>& src = wgt ? l.weights : l.bias; const size_t n = src.size() / 3;
       poly = Mle::from_i64(std::vector<int64_t>(src.begin() + which * n, src.begin() + (which + 1) * n));
-    } else poly = Mle::from_i64(pid == "DenseWeight" || pid == "ConvFilter" || pid == "MatMulWeight" || pid == "255" || pid == "EmbeddingMat" || pid == "PositionalMatrix" ? l.weights : l.bias);
+    } else poly = Mle::from_i64(pid == "DenseWeight" || pid == "ConvFilter" || pid == "MatMulWeight" || pid == "255" || pid == "EmbeddingMat" || pid == "PositionalMatrix" || pid == "LayerNormGamma" ? l.weights : l.bias);
     ctx.model_comms[j.first][j.second] = {pcs_commit(ctx.pp, poly), poly};
   });
   for (auto& t : th) t.join();
-  ctx.tables = tset;  // none of Relu/Range/Clamping has committed columns (lookup/context.rs:492-545)
+  ctx.tables = tset;
+  // Relu / Range / Clamping have no committed columns; InverseSQRT commits its output column (lookup/context.rs:492-545, commit/context.rs:105-107)
+  for (auto& t : tset) if (t.has_committed_column()) {
+    std::vector<int64_t> merged; std::vector<std::vector<u64>> cols;
+    table_columns(t, merged, cols);
+    Mle poly = Mle::from_base(cols[1]);
+    ctx.table_comms[t] = {pcs_commit(ctx.pp, poly), poly};
+  }
   return ctx;
 }
 
@@ -622,7 +678,9 @@ struct ConvProof {  // convolution.rs:98-127, fields in declaration order
   HadamardProof clearing_proof;
 };
 struct PoolingProof { IOPProof sumcheck; LogUpProof lookup; std::vector<E> zerocheck_evals; size_t variable_gap = 0; std::vector<Commitment> commitments; };  // pooling.rs:60-76
-struct LayerProof { LayerKind kind; DenseProof dense; MatMulProof matmul; AddProof add; PositionalProof pos; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; ConcatMatMulProof cmm; QKVProof qkv; };
+// LayerNormProof (layernorm.rs:644-667), fields in declaration order
+struct LayerNormProof { std::vector<LogUpProof> logup_proofs; std::vector<Commitment> commitments; IOPProof accumulation_proof, io_proof, input_proof; std::vector<E> acc_evals, evaluations; E gamma_eval, beta_eval; };
+struct LayerProof { LayerKind kind; DenseProof dense; MatMulProof matmul; AddProof add; PositionalProof pos; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; ConcatMatMulProof cmm; QKVProof qkv; LayerNormProof ln; };
 struct TableProof { Commitment multiplicity_commit; LogUpProof lookup; };
 struct Proof {
   std::map<size_t, LayerProof> steps;  // canonical order: ascending NodeId
@@ -686,6 +744,20 @@ static inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       LogUpWitness w; w.is_table = false; w.columns_per_instance = 2; w.table_type = rt;
       for (auto* col : {&a, &b}) { std::vector<u64> ev = to_base(*col); Mle mle = Mle::from_base(ev); w.commits.push_back({pcs_commit(ctx.pp, mle), mle}); w.column_evals.push_back(ev); }
       ps.lookup_witness[id] = {w};
+    } else if (l.kind == L_LAYERNORM) {  // LayerNorm::lookup_witness (layernorm.rs:1103-1218)
+      LayerNormData d; layernorm_op(l, tr.in[id], &d);
+      const unsigned nrc = (l.ln_range_check_bits - 1) / BIT_LEN + 1;
+      const int64_t rmask = (int64_t(1) << BIT_LEN) - 1, top = int64_t(1) << l.ln_top_chunk_scalar_log;
+      std::vector<std::vector<int64_t>> chunks(nrc);
+      for (unsigned j = 0; j < nrc; j++) for (int64_t v : d.range_check) chunks[j].push_back(((v >> (j * BIT_LEN)) & rmask) * (j + 1 == nrc ? top : 1));
+      TableType it = layernorm_table(l), rt{2, 0};
+      for (auto& ch : chunks) for (int64_t v : ch) count_into(element_count[rt], v);
+      for (size_t i = 0; i < d.lookup_input.size(); i++) count_into(element_count[it], d.lookup_input[i] + d.lookup_output[i] * COLUMN_SEPARATOR);
+      LogUpWitness wi; wi.is_table = false; wi.columns_per_instance = 2; wi.table_type = it;
+      for (auto* col : {&d.lookup_input, &d.lookup_output}) { std::vector<u64> ev = to_base(*col); Mle mle = Mle::from_base(ev); wi.commits.push_back({pcs_commit(ctx.pp, mle), mle}); wi.column_evals.push_back(ev); }
+      LogUpWitness wr; wr.is_table = false; wr.columns_per_instance = 1; wr.table_type = rt;
+      for (auto& ch : chunks) { std::vector<u64> ev = to_base(ch); Mle mle = Mle::from_base(ev); wr.commits.push_back({pcs_commit(ctx.pp, mle), mle}); wr.column_evals.push_back(ev); }
+      ps.lookup_witness[id] = {wi, wr};
     } else if (l.kind == L_MAXPOOL) {  // Pooling::gen_lookup_witness (pooling.rs:206-262)
       TableType rt{2, 0};
       std::vector<std::vector<int64_t>> diffs = maxpool_diff_polys(l, tr.in[id], tr.out[id]);
@@ -1042,6 +1114,87 @@ static inline Claim prove_relu(ProverState& ps, size_t id, const Claim& last, co
   return input_claim;
 }
 
+// LayerNorm::prove + prove_step (layernorm.rs:729-1100). Three sumchecks after the two lookups: (1) every lookup claim moved to ONE point;
+// (2) at that point the inverse-square-root input (recombined with the range-checked chunks) must be multiplier (N sum x^2 - (sum x)^2), the
+// output claim must be gamma (N x - sum x) inv_sqrt + beta, and the inv_sqrt column used in both is the committed one — batched with two
+// challenges; sums over the normalisation dimension are evaluations with 1/2 in that dimension's coordinates times 2^k; (3) `mean` really is
+// the row sum of the input.
+static inline Claim prove_layernorm(ProverState& ps, size_t id, const Layer& l, const Claim& last, const std::vector<E>& input) {
+  const size_t fd = l.weights.size();
+  const unsigned sum_dim_vars = ceil_log2(fd);
+  std::vector<E> mean(input.size());
+  for (size_t c = 0; c < input.size() / fd; c++) { E sum = e_zero(); for (size_t i = 0; i < fd; i++) sum = eadd(sum, input[c * fd + i]); for (size_t i = 0; i < fd; i++) mean[c * fd + i] = sum; }
+  MleP input_poly = mk(Mle::from_ext(input)), mean_poly = mk(Mle::from_ext(mean));
+  std::vector<LogUpWitness> ws = ps.lookup_witness.at(id);
+  if (ws.size() != 2) throw std::runtime_error("LayerNorm requires two lookups");
+  LayerNormProof pr;
+  for (auto& w : ws) pr.logup_proofs.push_back(logup_batch_prove(ps.logup_input(w), *ps.t));
+  const std::vector<Claim>& inv_claims = pr.logup_proofs[0].output_claims; const std::vector<Claim>& range_claims = pr.logup_proofs[1].output_claims;
+  const unsigned nv = (unsigned)inv_claims[0].point.size();
+  std::vector<E> bc; for (unsigned q = 0; q < ceil_log2(inv_claims.size() + range_claims.size()); q++) bc.push_back(ps.t->get_and_append_challenge("batching"));
+  std::vector<E> rlc = compute_betas_eval(bc);
+  MleP sqrt_eq = mk(Mle::from_ext(compute_betas_eval(inv_claims[0].point))), range_eq = mk(Mle::from_ext(compute_betas_eval(range_claims[0].point)));
+  std::vector<ProverCommitment> commits = ws[0].commits; commits.insert(commits.end(), ws[1].commits.begin(), ws[1].commits.end());
+  {
+    VirtualPolynomial vp(nv);
+    for (size_t q = 0; q < commits.size(); q++) vp.add_mle_list({mk(commits[q].second), q < 2 ? sqrt_eq : range_eq}, rlc.at(q));
+    auto [proof, st] = sumcheck_prove(std::move(vp), *ps.t);
+    pr.accumulation_proof = proof;
+    std::vector<E> fin = st.final_evaluations();  // sqrt_in, sqrt_eq, sqrt_out, range_0, range_eq, range_1, ...
+    pr.acc_evals = {fin[0], fin[2], fin[3]}; pr.acc_evals.insert(pr.acc_evals.end(), fin.begin() + 5, fin.end());
+  }
+  const std::vector<E> sc_point = pr.accumulation_proof.point;
+  const E two_inv = einv(e_from_u64(2)), two_mul = e_from_u64(u64(1) << sum_dim_vars);
+  const E c1 = ps.t->get_and_append_challenge("batching"), c2 = ps.t->get_and_append_challenge("batching");
+  const E first = emul(esub(e_one(), c1), esub(e_one(), c2)), second = emul(c1, esub(e_one(), c2)), third = emul(esub(e_one(), c1), c2);
+  std::vector<E> full_point(sum_dim_vars, two_inv); full_point.insert(full_point.end(), sc_point.begin(), sc_point.end());
+  if (full_point.size() != last.point.size()) throw std::runtime_error("layernorm: claim point size mismatch");
+  MleP input_eq = mk(Mle::from_ext(compute_betas_eval(full_point)));
+  const E n_f = e_from_u64(l.ln_dim_size), mult_f = e_from_i64(l.ln_multiplier);
+  const size_t repeats = size_t(1) << (last.point.size() - sum_dim_vars);
+  std::vector<E> g(input.size()), b(input.size()), inv(input.size());
+  for (size_t c = 0; c < repeats; c++) for (size_t i = 0; i < fd; i++) { g[c * fd + i] = e_from_i64(l.weights[i]); b[c * fd + i] = e_from_i64(l.bias[i]); inv[c * fd + i] = e_from_u64(ws[0].column_evals[1][c]); }
+  MleP gamma_poly = mk(Mle::from_ext(g)), beta_poly = mk(Mle::from_ext(b)), inv_poly = mk(Mle::from_ext(inv)), last_eq = mk(Mle::from_ext(compute_betas_eval(last.point)));
+  E input_eval, mean_eval, inv_eval;
+  {
+    VirtualPolynomial vp((unsigned)full_point.size());
+    vp.add_mle_list({input_eq, input_poly, input_poly}, emul(emul(first, mult_f), emul(n_f, two_mul)));
+    vp.add_mle_list({input_eq, mean_poly, mean_poly}, eneg(emul(first, mult_f)));
+    vp.add_mle_list({last_eq, gamma_poly, input_poly, inv_poly}, emul(second, n_f));
+    vp.add_mle_list({last_eq, gamma_poly, mean_poly, inv_poly}, eneg(second));
+    vp.add_mle_list({last_eq, beta_poly}, second);
+    vp.add_mle_list({input_eq, inv_poly}, third);
+    auto [proof, st] = sumcheck_prove(std::move(vp), *ps.t);
+    pr.io_proof = proof;
+    std::vector<E> fin = st.final_evaluations();  // input_eq, input, mean, last_eq, gamma, inv_sqrt_out, beta
+    input_eval = fin[1]; mean_eval = fin[2]; pr.gamma_eval = fin[4]; inv_eval = fin[5]; pr.beta_eval = fin[6];
+  }
+  const std::vector<E> io_point = pr.io_proof.point;
+  const E ic = ps.t->get_and_append_challenge("batching");
+  Claim input_claim;
+  {
+    std::vector<E> sum_io(sum_dim_vars, two_inv); sum_io.insert(sum_io.end(), io_point.begin() + sum_dim_vars, io_point.end());
+    VirtualPolynomial vp((unsigned)io_point.size());
+    vp.add_mle_list({input_poly, mk(Mle::from_ext(compute_betas_eval(io_point)))}, esub(e_one(), ic));
+    vp.add_mle_list({input_poly, mk(Mle::from_ext(compute_betas_eval(sum_io)))}, emul(ic, two_mul));
+    auto [proof, st] = sumcheck_prove(std::move(vp), *ps.t);
+    pr.input_proof = proof;
+    input_claim = {proof.point, st.final_evaluations()[0]};
+  }
+  // witness claims: the lookup input at the accumulation point, the lookup output at the tail of the io point, the range chunks at the accumulation point
+  std::vector<Claim> cl = {{sc_point, pr.acc_evals[0]}, {std::vector<E>(io_point.begin() + sum_dim_vars, io_point.end()), inv_eval}};
+  for (size_t q = 2; q < pr.acc_evals.size(); q++) cl.push_back({sc_point, pr.acc_evals[q]});
+  for (size_t q = 0; q < cl.size(); q++) { pr.commitments.push_back(commits[q].first.pure()); pr.evaluations.push_back(cl[q].eval); ps.add_witness_claim(commits[q], cl[q]); }
+  pr.evaluations.push_back(input_eval); pr.evaluations.push_back(mean_eval);
+  // add_common_claims walks the node's BTreeMap: "LayerNormBeta" then "LayerNormGamma"
+  const std::vector<E> gp(io_point.begin(), io_point.begin() + sum_dim_vars);
+  const auto& comms = ps.ctx->model_comms.at(id);
+  ps.add_witness_claim(comms.at("LayerNormBeta"), {gp, pr.beta_eval});
+  ps.add_witness_claim(comms.at("LayerNormGamma"), {gp, pr.gamma_eval});
+  LayerProof lp; lp.kind = L_LAYERNORM; lp.ln = pr; ps.proofs[id] = lp;
+  return input_claim;
+}
+
 // ------------------------------------------------------------------ convolution (zkCNN FFT protocol)
 // phi_pow_init (iop/prover.rs:214-227): powers of the 2^n-th root of unity (inverted when `is_fft`)
 static inline std::vector<E> phi_pow_init(unsigned n, bool is_fft) {
@@ -1321,6 +1474,7 @@ static inline Proof prove(const Context& ctx, const Trace& tr, Transcript& t) {
     else if (l.kind == L_POSITIONAL) cur = prove_positional(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
     else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, to_fields(tr.out[id]));
+    else if (l.kind == L_LAYERNORM) cur = prove_layernorm(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv[id]);
     else if (l.kind == L_MAXPOOL) cur = prove_pooling(ps, id, l, cur, to_fields(tr.out[id]));
     // L_FLATTEN is not provable: the claim is propagated unchanged (iop/prover.rs:449-456)
@@ -1332,7 +1486,9 @@ static inline Proof prove(const Context& ctx, const Trace& tr, Transcript& t) {
     LogUpInput in = ps.logup_input(tw);
     LogUpProof tp = logup_batch_prove(in, t);
     ps.add_witness_claim(tw.commits[0], tp.output_claims[0]);
-    proof.table_proofs.push_back({tw.commits[0].first.pure(), tp});  // Relu/Range/Clamping have no table poly claims
+    // table_claims (lookup/context.rs:548-563): InverseSQRT hands the claim on its committed output column (the last one) to the opening
+    if (tw.table_type.has_committed_column()) ps.add_witness_claim(ctx.table_comms.at(tw.table_type), tp.output_claims.back());
+    proof.table_proofs.push_back({tw.commits[0].first.pure(), tp});
   }
   // CommitmentProver::prove (commit/context.rs:355-418)
   for (auto& c : ps.trivial_claims) proof.trivial_proofs.push_back(pcs_open_trivial(c.comm.second, c.comm.first));
@@ -1406,6 +1562,11 @@ static inline std::vector<u64> serialize_proof(const Proof& p) {
       vve(c.fft_delegation_claims); vve(c.fft_delegation_weights_claims); vve(c.ifft_delegation_claims);
       w.ve(c.partial_evals); w.ve(c.hadamard_clams); w.e(c.bias_claim);
       w.iop(c.clearing_proof.sumcheck); w.ve(c.clearing_proof.individual_claim);
+    } else if (lp.kind == L_LAYERNORM) {
+      const LayerNormProof& q = lp.ln;
+      w.u(q.logup_proofs.size()); for (auto& x : q.logup_proofs) w.logup(x);
+      w.u(q.commitments.size()); for (auto& c : q.commitments) w.comm(c);
+      w.iop(q.accumulation_proof); w.iop(q.io_proof); w.iop(q.input_proof); w.ve(q.acc_evals); w.ve(q.evaluations); w.e(q.gamma_eval); w.e(q.beta_eval);
     } else if (lp.kind == L_MAXPOOL) {
       w.iop(lp.pool.sumcheck); w.logup(lp.pool.lookup); w.ve(lp.pool.zerocheck_evals); w.u(lp.pool.variable_gap);
       w.u(lp.pool.commitments.size()); for (auto& c : lp.pool.commitments) w.comm(c);

@@ -39,6 +39,7 @@ static orc::Model to_orc(const dp::ModelSpec& m) {
     for (auto& e : l.inputs) { orc::Wire w; w.node = e.from; w.index = e.slot; x.inputs.push_back(w); }
     for (int d = 0; d < 3; d++) { x.cm_a[d] = l.cm_a[d]; x.cm_b[d] = l.cm_b[d]; x.cm_left[d] = l.cm_left[d]; x.cm_right[d] = l.cm_right[d]; } x.cm_perm = l.cm_perm; x.nrows = l.nrows; x.ncols = l.ncols; x.weights = l.weights; x.bias = l.bias; x.transpose_b = l.mm_transpose; x.add_left = l.add_left; x.add_right = l.add_right; x.right_shift = l.right_shift; x.fp_scale = l.fp_scale; x.intermediate_bit_size = l.intermediate_bit_size; x.fixed_point_multiplier = l.fixed_point_multiplier;
     x.kw = l.kw; x.kx = l.kx; x.real_nw = l.real_nw; x.nw = l.nw; for (int k = 0; k < 3; k++) { x.unp_out[k] = l.unp_out[k]; x.pin[k] = l.pin[k]; }
+    x.ln_dim_size = l.ln_dim_size; x.ln_multiplier = l.ln_multiplier; x.ln_eps_bits = l.ln_eps_bits; x.ln_range_check_bits = l.ln_range_check_bits; x.ln_top_chunk_scalar_log = l.ln_top_chunk_scalar_log;
     o.layers.push_back(x); }
   return o;
 }
@@ -91,6 +92,23 @@ static dp::ModelSpec graph_model(int variant, std::vector<int64_t>& in) {
     m.layers = {q, ad};
     m.outputs = {edge(0, 0), edge(1, 0)};
     in.resize(m.input_len); for (auto& x : in) x = rq();
+  } else if (variant == 5 || variant == 6) {
+    // LayerNorm over the last dimension of a [rows][dim] tensor, then the shift-only Requant the reference puts behind it (layernorm.rs:140-257,
+    // 473-513) and a ReLU. Variant 6: N = 12 of a padded dimension of 16 (the padding of input, gamma and beta is zero).
+    const size_t S = 8, D = 16, N = variant == 6 ? 12 : 16;
+    m.input_len = S * D;
+    dp::LayerSpec ln; ln.kind = dp::L_LAYERNORM; ln.nrows = D; ln.ln_dim_size = N;
+    const float in_scale = 1.0f / 127.0f;
+    ln.ln_multiplier = (int64_t)std::llround((double)(float)(1u << 24) * in_scale * in_scale);
+    const unsigned full_bits = 2 * (dp::dp_ceil_log2(N) + 7) + dp::dp_ceil_log2((size_t)ln.ln_multiplier) + 1;
+    ln.ln_range_check_bits = full_bits - 14; ln.ln_top_chunk_scalar_log = ln.ln_range_check_bits % 8 ? 8 - ln.ln_range_check_bits % 8 : 0;
+    { const float eps = (float)(N * N) * 1e-5f; uint32_t b; memcpy(&b, &eps, 4); ln.ln_eps_bits = b; }
+    ln.weights.assign(D, 0); ln.bias.assign(D, 0);
+    for (size_t i = 0; i < N; i++) { ln.weights[i] = rq(); ln.bias[i] = rq() * 4096; }
+    dp::LayerSpec rqn; rqn.kind = dp::L_REQUANT; rqn.right_shift = 19; rqn.fp_scale = 5; rqn.fixed_point_multiplier = 32; rqn.intermediate_bit_size = 35;  // Requant::new_shift
+    m.layers = {ln, rqn, relu};
+    in.assign(m.input_len, 0);
+    for (size_t r = 0; r < S; r++) for (size_t i = 0; i < N; i++) in[r * D + i] = rq();
   } else {
     // an attention block without softmax: X -> QKV; scores_h = Q_h K_h^T (ConcatMatMul over [s][h][d] tensors, heads = the concat axis);
     // out_h = scores_h V_h, laid back out as [s][h][d] (output permutation); + a second input tensor (Add). Variant 4: the other axis layouts.
