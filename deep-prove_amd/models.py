@@ -6,6 +6,7 @@ import math
 import numpy as np
 
 L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_FLATTEN, L_MATMUL, L_ADD, L_EMBED, L_POSITIONAL = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+L_LAYERNORM = 14
 L_MATMUL2, L_ADD2, L_CONCAT_MATMUL, L_QKV = 10, 11, 12, 13  # nodes of a model GRAPH: two-input MatMul / Add, ConcatMatMul, QKV
 BIT_LEN = 8
 FIXED_POINT_SCALE = 25  # zkml/src/layers/requant.rs:47
@@ -39,6 +40,31 @@ def requant_from_multiplier(multiplier, intermediate_bit_size):
     assert intermediate_bit_size + fp_scale <= 63
     return dict(right_shift=int_part, fp_scale=fp_scale, fixed_point_multiplier=fpm,
                 intermediate_bit_size=intermediate_bit_size)
+
+
+def inv_sqrt_table_output(eps_bits, range_check_bits, j):
+    """InverseSQRTTableData::table_output (zkml/src/lookup/context.rs:147-157) for an array of table inputs: f32 arithmetic as there, `round`
+    away from zero, a NaN (negative argument of the square root) becomes 0"""
+    eps = np.array([eps_bits], dtype=np.uint32).view(np.float32)[0]
+    shifted = np.asarray(j, dtype=np.int64) * (1 << range_check_bits)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        x = (np.float32(1.0) / np.sqrt(shifted.astype(np.float32) / np.float32(1 << 24) + eps)) * np.float32(1 << 10)
+    a = np.abs(x)
+    fl = np.floor(a)
+    r = np.where(a - fl >= np.float32(0.5), fl + 1, fl) * np.sign(x)
+    return np.where(np.isnan(r), 0, r).astype(np.int64)
+
+
+def layernorm_apply(l, x):
+    """LayerNorm::evaluate on quantised values (layers/transformer/layernorm.rs:394-470) -> output, (lookup input, lookup output, range-checked part)"""
+    d = l["gamma"].size
+    rows = np.asarray(x, dtype=np.int64).reshape(-1, d)
+    s, sq = rows.sum(axis=1), (rows * rows).sum(axis=1)
+    full = l["dim_size"] * l["multiplier"] * sq - l["multiplier"] * s * s
+    lin = full >> l["range_check_bits"]
+    inv = inv_sqrt_table_output(l["eps_bits"], l["range_check_bits"], lin)
+    out = l["gamma"][None, :] * (l["dim_size"] * rows - s[:, None]) * inv[:, None] + l["beta"][None, :]
+    return out.reshape(-1), (lin, inv, full & ((1 << l["range_check_bits"]) - 1))
 
 
 def dense_output_bitsize(ncols):
@@ -136,6 +162,31 @@ class ModelBuilder:
             gain = 1.0 if k_og <= 4 else 2.5
             rq = requant_from_multiplier(gain / math.sqrt(k_og) / 127.0, dense_output_bitsize(k))
             self.layers.append(dict(kind=L_REQUANT, **rq))
+        return self
+
+    def layernorm(self, eps=1e-5, requant=True):
+        """LayerNorm over the last dimension of a [seq][features] activation, quantised as LayerNorm::quantise does it (layers/transformer/
+        layernorm.rs:140-257: the multiplier of the inverse-square-root input, the bits that are shifted away and range checked, the rescaled
+        epsilon), followed by the shift-only Requant of Requant::new_shift (:473-513). gamma / beta are zero on the padding of the dimension."""
+        assert len(self.shape_og) == 2, "layernorm needs a [seq, features] activation"
+        (s_og, n_og), (s, d) = self.shape_og, self.shape_pad
+        assert s >= 4 and d >= 2 and next_pow2(n_og) == d
+        in_scale = np.float32(1.0 / 127.0)
+        multiplier = int(np.round(np.float32(1 << 24) * in_scale * in_scale))
+        clog = lambda v: max(0, (int(v) - 1).bit_length())
+        rcb = 2 * (clog(n_og) + BIT_LEN - 1) + clog(multiplier) + 1 - 2 * (BIT_LEN - 1)
+        eps_bits = int(np.array([np.float32(n_og * n_og) * np.float32(eps)], dtype=np.float32).view(np.uint32)[0])
+        gamma, beta = np.zeros(d, dtype=np.int64), np.zeros(d, dtype=np.int64)
+        gamma[:n_og] = self._tensor(n_og)
+        beta[:n_og] = self._tensor(n_og) * 4096
+        self.layers.append(dict(kind=L_LAYERNORM, dim=d, dim_size=n_og, multiplier=multiplier, eps_bits=eps_bits, range_check_bits=rcb,
+                                top_chunk_scalar_log=(BIT_LEN - rcb % BIT_LEN) % BIT_LEN, gamma=gamma, beta=beta))
+        if requant:
+            max_lut = int(np.abs(inv_sqrt_table_output(eps_bits, rcb, np.arange(-(1 << 14), 1 << 14))).max())
+            ibs = max(2 * (BIT_LEN - 1) + clog(n_og) + 1 + clog(max_lut), clog(int(np.abs(beta).max()) or 1)) + 1
+            right_shift = ibs - 16  # (the scale of the next layer is chosen so that the clamping table has 2^16 entries)
+            fp_scale = -right_shift % BIT_LEN
+            self.layers.append(dict(kind=L_REQUANT, right_shift=right_shift, fp_scale=fp_scale, fixed_point_multiplier=1 << fp_scale, intermediate_bit_size=ibs))
         return self
 
     def embeddings(self, vocab, emb):
@@ -255,6 +306,10 @@ class ModelBuilder:
                 parts.append(l["bias"])
             elif l["kind"] == L_MAXPOOL:
                 parts.append(np.array([L_MAXPOOL, *l["pin"]], dtype=np.int64))
+            elif l["kind"] == L_LAYERNORM:
+                parts.append(np.array([L_LAYERNORM, l["dim"], l["dim_size"], l["multiplier"], l["eps_bits"], l["range_check_bits"], l["top_chunk_scalar_log"]], dtype=np.int64))
+                parts.append(l["gamma"])
+                parts.append(l["beta"])
             else:
                 parts.append(np.array([l["kind"]], dtype=np.int64))
         return np.concatenate(parts)
@@ -290,6 +345,8 @@ class ModelBuilder:
                 cur = np.clip((cur * l["fixed_point_multiplier"] + (1 << (sh - 1))) >> sh, -127, 127)
             elif l["kind"] == L_RELU:
                 cur = np.maximum(cur, 0)
+            elif l["kind"] == L_LAYERNORM:
+                cur = layernorm_apply(l, cur)[0]
             elif l["kind"] == L_CONV:
                 # direct correlation on the padded tensors; everything outside the unpadded output shape is cleared
                 kw, kx, k, nw = l["kw"], l["kx"], l["kernel"], l["nw"]
@@ -505,6 +562,15 @@ def seq_mlp(seq, width, config, input_features=4, output_features=3, layers=2, t
     for _ in range(layers - 1):
         mb.matmul(width).relu()
     mb.matmul(output_features, bias=False, transpose_b=transpose_last).relu()
+    return mb
+
+
+def layernorm_mlp(seq, features, width, config, output_features=3):
+    """LayerNorm -> Linear -> ReLU -> Linear over a [seq][features] activation: the normalisation in front of the feed-forward part of a
+    transformer block (layers/transformer/layernorm.rs, layers/matrix_mul.rs)"""
+    mb = ModelBuilder((seq, features), config)
+    mb.layernorm().matmul(width).relu()
+    mb.matmul(output_features, bias=False).relu()
     return mb
 
 

@@ -280,6 +280,12 @@ int32_t dp_pcs_simple_batch_verify(size_t max_poly_size, const uint64_t root[4],
  *   12 ConcatMatMul: shape of A (3), shape of B (3), (concat, mat_mul, output) axis of A (3) and of B (3), 0 | 1 followed by the permutation
  *      (3) of the [concat][rows][cols] result — chunk c of the result = chunk c of A times chunk c of B (layers/concat_matmul.rs:467-616)
  *   13 QKV: k, n, W_q | W_k | W_v ([k][n] each), b_q | b_k | b_v ([n] each): one [s][k] input, the three outputs X W + b (slots 0, 1, 2)
+ *   14 LayerNorm (zkml/src/layers/transformer/layernorm.rs:74-101,140-257): dim (the padded normalisation dimension, a power of two), N (its
+ *      unpadded size, next_pow2(N) == dim), multiplier, the f32 bits of the rescaled epsilon, range_check_bits, log2 of the scalar of the top
+ *      range-checked chunk (QuantisedLayerNormData), gamma[dim], beta[dim] (zero on the padding). Input [rows >= 4][dim];
+ *      out = gamma (N x - sum x) lut(multiplier (N sum x^2 - (sum x)^2) >> range_check_bits) + beta with the inverse-square-root table of
+ *      lookup/context.rs:124-157 (2^15 entries; its output column is committed once per context). Usually followed by a Requant (1) whose
+ *      multiplier is a power of two (Requant::new_shift, layernorm.rs:473-513).
  *      (layers/transformer/qkv.rs:462-630)
  *   Embeddings stay the first node of a chain. Not built: MHA, Softmax, LayerNorm, Logits. */
 int32_t dp_model_setup(dp_ctx* ctx, const int64_t* model_blob, size_t nwords, dp_model** out);

@@ -21,6 +21,9 @@ CASES = [
     ("matmul_pair", dict(seq=4, k=8, n=16, config=62)),
     ("matmul_pair", dict(seq=8, k=32, n=16, config=63, transpose_b=True)),
     ("qkv_two_outputs", dict(seq=4, k=16, n=16, config=64)),
+    # LayerNorm (layers/transformer/layernorm.rs) -> Linear -> ReLU -> Linear; the second with N = 12 of a padded dimension of 16
+    ("layernorm_mlp", dict(seq=8, features=16, width=16, config=81)),
+    ("layernorm_mlp", dict(seq=16, features=12, width=32, config=82)),
 ]
 
 

@@ -533,6 +533,17 @@ int main(int argc, char** argv) {
     try { dp::Proof q = dp::deserialize_proof(w.data(), w.size()); dp::Transcript vt = dp::default_transcript(); dp::verify(vc, q, io, vt); printf("verify(%s%s): ACCEPT\n", which ? "product" : "oracle", (tamper && !which) ? ",tampered" : ""); }
     catch (const std::exception& e) { printf("verify(%s%s): REJECT: %s\n", which ? "product" : "oracle", (tamper && !which) ? ",tampered" : "", e.what()); if (!(tamper && !which)) rc = 1; }
   }
+  // DP_FLIP_SWEEP=start:stop:step — one proof, many single-word flips of the oracle's stream, each through the full verifier
+  if (const char* fs = getenv("DP_FLIP_SWEEP")) {
+    size_t a = 0, b = 0, st = 1; sscanf(fs, "%zu:%zu:%zu", &a, &b, &st); if (!st) st = 1; if (b > ow.size()) b = ow.size();
+    size_t flipped = 0, rejected = 0; std::string accepted;
+    for (size_t at = a; at < b; at += st) {
+      std::vector<uint64_t> w = ow; w[at] ^= 1; flipped++;
+      try { dp::Proof q = dp::deserialize_proof(w.data(), w.size()); dp::Transcript vt = dp::default_transcript(); dp::verify(vc, q, io, vt); accepted += " " + std::to_string(at); }
+      catch (const std::exception&) { rejected++; }
+    }
+    printf("flip sweep: %zu flipped, %zu rejected, accepted at:%s\n", flipped, rejected, accepted.c_str());
+  }
   // roundtrip of the stream
   { dp::Proof q = dp::deserialize_proof(pw.data(), pw.size()); if (dp::serialize_proof(q) != pw) { printf("stream roundtrip FAILED\n"); rc = 1; } }
   return (same ? 0 : 2) | rc;

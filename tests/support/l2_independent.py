@@ -180,6 +180,9 @@ def table_column_evals(kind, size, point):
         for k, p in enumerate(point[:-1]):
             second = add(second, mul(mul(p, fe(1 << k)), point[-1]))
         return [sub(idx, fe(1 << (BIT_LEN - 1))), second]
+    if kind == "inv_sqrt":  # only the input column; the output column is a commitment (context.rs:445-462)
+        assert len(point) == 2 * (BIT_LEN - 1) + 1
+        return [sub(idx, fe(1 << (2 * (BIT_LEN - 1))))]
     assert kind == "clamping" and len(point) == size
     mx = 1 << (size - 1)
     col = [fe(min(max(i, Q_MIN), Q_MAX)) for i in range(-mx, mx)]
@@ -188,7 +191,7 @@ def table_column_evals(kind, size, point):
 
 def table_order_key(t):
     """derive(Ord) of lookup/context.rs:52-72: Relu < GELU < Range < Clamping(n) < ..."""
-    return ({"relu": 0, "range": 2, "clamping": 3}[t[0]], t[1])
+    return ({"relu": 0, "range": 2, "clamping": 3, "inv_sqrt": 7}[t[0]], t[1])
 
 
 def verify_chain(layers, model_roots, tree, x, y, label=b"m2vec"):
@@ -354,12 +357,15 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
             tables.add(("relu", 0))
         elif n["kind"] == "maxpool":
             tables.add(("range", 0))
+        elif n["kind"] == "layernorm":
+            tables.add(("range", 0))
+            tables.add(("inv_sqrt", (n["eps_bits"], n["range_check_bits"])))
     tables = sorted(tables, key=table_order_key)
     chmap, constant = {}, None
     if tables:
         constant = challenge(tr, b"table_constant")
         for t in tables:
-            chmap[t] = ONE if t[0] == "range" else challenge(tr, b"Relu" if t[0] == "relu" else b"Clamping")
+            chmap[t] = ONE if t[0] == "range" else challenge(tr, {"relu": b"Relu", "clamping": b"Clamping", "inv_sqrt": b"InverseSQRT"}[t[0]])
     steps = {node: (kind, lp) for node, kind, lp in tree["steps"]}
     nums, dens = [], []
 
@@ -375,6 +381,9 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
             fractions(steps[nid][1]["shifted_lookup"])
         elif n["kind"] in ("relu", "maxpool"):
             fractions(steps[nid][1]["lookup"])
+        elif n["kind"] == "layernorm":
+            for lg in steps[nid][1]["logup_proofs"]:
+                fractions(lg)
     for tp in tree["table_proofs"]:
         fractions(tp["lookup"])
     out_claims = []
@@ -515,6 +524,57 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
             for v, m_ in zip(ze[:ks], mults):
                 zin = add(zin, mul(sub(out_eval, v), m_))
             made[nid] = [{"point": [r1] + zp[:gap] + [r2] + zp[gap:], "eval": zin}]
+        elif n["kind"] == "layernorm":  # layers/transformer/layernorm.rs:1230-1505
+            rcb, nrc = n["range_check_bits"], (n["range_check_bits"] - 1) // BIT_LEN + 1
+            ve = lambda v: [e(t) for t in v]
+            assert len(lp["logup_proofs"]) == 2
+            ic, _, _ = verify_logup(lp["logup_proofs"][0], 1, constant, chmap[("inv_sqrt", (n["eps_bits"], rcb))], tr)
+            rc, _, _ = verify_logup(lp["logup_proofs"][1], nrc, constant, ONE, tr)
+            assert len(ic) == 2 and len(rc) == nrc
+            bc = [challenge(tr, b"batching") for _ in range((2 + nrc - 1).bit_length())]
+            rlc = L.eq_table(bc)
+            acc_init = ZERO
+            for cl, ch in zip(ic + rc, rlc):
+                acc_init = add(acc_init, mul(cl["eval"], ch))
+            nv = len(ic[0]["point"])
+            acc_pt = ve(lp["accumulation_proof"]["point"])
+            _, acc_expected = L1.verify_sumcheck(acc_init, acc_pt, lp["accumulation_proof"]["proofs"], nv, 2, tr)
+            eq_sqrt, eq_range = eq_xy_eval(ic[0]["point"], acc_pt), eq_xy_eval(rc[0]["point"], acc_pt)
+            acc_evals, evaluations = ve(lp["acc_evals"]), ve(lp["evaluations"])
+            assert len(acc_evals) == 2 + nrc and len(evaluations) == 4 + nrc and len(lp["commitments"]) == 2 + nrc
+            calc = ZERO
+            for k, (v, ch) in enumerate(zip(acc_evals, rlc)):
+                calc = add(calc, mul(mul(v, eq_sqrt if k < 2 else eq_range), ch))
+            assert calc == acc_expected, "layernorm: accumulation evaluations do not recombine"
+            c1, c2 = challenge(tr, b"batching"), challenge(tr, b"batching")
+            first, second, third = mul(sub(ONE, c1), sub(ONE, c2)), mul(c1, sub(ONE, c2)), mul(sub(ONE, c1), c2)
+            partial, pw = mul(acc_evals[0], fe(1 << rcb)), ONE
+            for v in acc_evals[2:2 + nrc - 1]:
+                partial, pw = add(partial, mul(v, pw)), mul(pw, fe(1 << BIT_LEN))
+            top_inv = L.ext_inv(fe(1 << n["top_chunk_scalar_log"]))
+            io_init = add(add(mul(first, add(partial, mul(mul(acc_evals[-1], top_inv), pw))), mul(second, cur["eval"])), mul(acc_evals[1], third))
+            sdv = (n["dim_size"] - 1).bit_length()
+            io_pt = ve(lp["io_proof"]["point"])
+            _, io_expected = L1.verify_sumcheck(io_init, io_pt, lp["io_proof"]["proofs"], len(cur["point"]), 4, tr)
+            input_io, mean_io, inv_ev = evaluations[-2], evaluations[-1], evaluations[1]
+            gamma_eval, beta_eval = e(lp["gamma_eval"]), e(lp["beta_eval"])
+            n_f, two_inv, two_mul, mult_f = fe(n["dim_size"]), L.ext_inv(fe(2)), fe(1 << sdv), fe(n["multiplier"])
+            full_point = [two_inv] * sdv + acc_pt
+            input_eq, last_eq = eq_xy_eval(full_point, io_pt), eq_xy_eval(cur["point"], io_pt)
+            p1 = mul(mul(mul(first, mult_f), input_eq), sub(mul(mul(n_f, two_mul), mul(input_io, input_io)), mul(mean_io, mean_io)))
+            p2 = mul(mul(second, last_eq), add(mul(mul(inv_ev, gamma_eval), sub(mul(n_f, input_io), mean_io)), beta_eval))
+            p3 = mul(mul(third, input_eq), inv_ev)
+            assert add(add(p1, p2), p3) == io_expected, "layernorm: io evaluations do not recombine"
+            ich = challenge(tr, b"batching")
+            in_pt = ve(lp["input_proof"]["point"])
+            _, in_expected = L1.verify_sumcheck(add(input_io, mul(ich, sub(mean_io, input_io))), in_pt, lp["input_proof"]["proofs"], len(io_pt), 2, tr)
+            eq_io, eq_sum = eq_xy_eval(io_pt, in_pt), eq_xy_eval([two_inv] * sdv + io_pt[sdv:], in_pt)
+            non_input = add(eq_io, mul(ich, sub(mul(two_mul, eq_sum), eq_io)))
+            for q, (v, c) in enumerate(zip(evaluations[:2 + nrc], lp["commitments"])):
+                out.append(("witness", nid, q, (tuple(c["root"]), c["num_vars"]), io_pt[sdv:] if q == 1 else acc_pt, v))
+            out.append(("model", nid, "LayerNormBeta", io_pt[:sdv], beta_eval))
+            out.append(("model", nid, "LayerNormGamma", io_pt[:sdv], gamma_eval))
+            made[nid] = [{"point": in_pt, "eval": mul(in_expected, L.ext_inv(non_input))}]
         elif n["kind"] == "dense":  # layers/dense.rs:576-643
             bias_eval = e(lp["bias_eval"])
             sc_point = [e(v) for v in lp["sumcheck"]["point"]]
@@ -683,6 +743,10 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
         claims, _, _ = verify_logup(tp["lookup"], 1, constant, chmap[t], tr)
         out.append(("multiplicity", t, (tuple(tp["multiplicity_commit"]["root"]), tp["multiplicity_commit"]["num_vars"]), claims[0]["point"], claims[0]["eval"]))
         expect = table_column_evals(t[0], t[1], claims[0]["point"])
+        if t[0] == "inv_sqrt":  # table_claims (lookup/context.rs:548-563): the claim on the committed output column goes to the opening
+            out.append(("table", t, claims[-1]["point"], claims[-1]["eval"]))
+            claims = claims[:-1]
+        assert len(expect) == len(claims) - 1
         for cl, ex in zip(claims[1:], expect):
             assert cl["eval"] == ex, f"table {t}: claimed column evaluation is wrong"
     # the claims on the model's input tensors (iop/verifier.rs:237-262)

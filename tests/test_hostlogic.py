@@ -171,7 +171,7 @@ def test_matmul_model_tampered_proof_rejected(hostlogic_bin, where):
     assert "verify(oracle,tampered): REJECT" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("seed", [1, 7])
 def test_graph_model_proof_stream_identical_to_oracle_and_accepted(hostlogic_bin, variant, seed):
     """Models that are GRAPHS (layers/provable/mod.rs:195-565; Prover::prove over the backward node iterator, iop/prover.rs:437-461): 0 / 1 =
@@ -193,6 +193,20 @@ def test_graph_model_layer_proofs_reject_every_flipped_word(hostlogic_bin, varia
     for at in list(range(1, 60)) + list(range(60, 330, 9)):
         r = run(hostlogic_bin, "graph", variant, 11, f"@{at}")
         assert "verify(oracle,tampered): REJECT" in r.stdout, (at, r.stdout + r.stderr)
+
+
+@pytest.mark.parametrize("variant", [5, 6])
+def test_layernorm_proofs_reject_every_flipped_word(hostlogic_bin, variant):
+    """LayerNorm (layers/transformer/layernorm.rs:729-1100 / 1230-1505; variants 5 / 6 of the graph models: N = 16, N = 12 of a padded 16) ->
+    shift-only Requant -> ReLU: one proof, a single-bit flip in every 5th of the first 6000 words (the LayerNorm proof: two lookups,
+    commitments, the accumulation / io / input sumchecks, their evaluations; then Requant and ReLU) and in a sample of the rest (table proofs
+    with the committed inverse-square-root column, openings) — the verifier refuses each"""
+    import os, re, subprocess
+    for sweep in ("1:6000:5", "6000:140000:997"):
+        r = subprocess.run([hostlogic_bin, "graph", str(variant), "11"], capture_output=True, text=True, timeout=900, env=dict(os.environ, DP_FLIP_SWEEP=sweep))
+        assert r.returncode == 0 and "identical=1" in r.stdout, r.stdout + r.stderr
+        m = re.search(r"flip sweep: (\d+) flipped, (\d+) rejected, accepted at:(.*)", r.stdout)
+        assert m and int(m.group(1)) > 100 and m.group(1) == m.group(2) and not m.group(3).strip(), r.stdout
 
 
 def test_batch_commit_and_simple_batch_open_over_the_double(hostlogic_bin):

@@ -433,6 +433,17 @@ def _chain_description(mb, x):
             cur = o.reshape(-1)
         elif k == M.L_FLATTEN:
             d.update(kind="reshape")
+        elif k == M.L_LAYERNORM:
+            d.update(kind="layernorm", **{q: l[q] for q in ("dim_size", "multiplier", "eps_bits", "range_check_bits", "top_chunk_scalar_log")})
+            polys[(i, "LayerNormGamma")], polys[(i, "LayerNormBeta")] = l["gamma"], l["beta"]
+            o, (lin, inv, rc) = M.layernorm_apply(l, cur)
+            nrc = (l["range_check_bits"] - 1) // 8 + 1
+            chunks = [((rc >> (8 * j)) & 255) * ((1 << l["top_chunk_scalar_log"]) if j == nrc - 1 else 1) for j in range(nrc)]
+            cols[i] = [lin, inv] + chunks
+            lk.setdefault("inv_sqrt", {}).setdefault((l["eps_bits"], l["range_check_bits"]), []).extend(int(v) for v in lin)
+            for c in chunks:
+                lk["range"].extend(int(v) for v in c)
+            cur = o
         else:
             assert k == M.L_RELU
             d.update(kind="relu")
@@ -444,7 +455,8 @@ def _chain_description(mb, x):
 
 
 @pytest.mark.parametrize("name,args,kw", [("token_mlp", (8, 20, 16), dict(config=73, max_positions=30)), ("token_mlp", (8, 20, 16), dict(config=74)),
-                                           ("seq_mlp", (8, 16), dict(config=75, transpose_last=True, positional=True)), ("cnn_tiny", (), dict(config=76))])
+                                           ("seq_mlp", (8, 16), dict(config=75, transpose_last=True, positional=True)), ("cnn_tiny", (), dict(config=76)),
+                                           ("layernorm_mlp", (8, 12, 16), dict(config=83))])
 def test_independent_verifier_on_token_and_sequence_models(oracle, name, args, kw):
     """Embeddings (tokens in: the input claim is a claim on the one-hot encoding), Positional::Learned with a table longer than the sequence
     (the slice claim lifted to the table), Add with a static operand, MatMul with a constant matrix (plain and TransposeB), Requant, ReLU —
@@ -467,6 +479,8 @@ def test_independent_verifier_on_token_and_sequence_models(oracle, name, args, k
             sizes += [256, 1 << n["clamping_size"]]
         elif n["kind"] in ("relu", "maxpool"):
             sizes.append(256)
+        elif n["kind"] == "layernorm":
+            sizes += [256, 1 << 15]
     max_poly = 1 << (max(sizes) - 1).bit_length()
     to_words = lambda v: np.asarray([int(t) % P for t in np.asarray(v).reshape(-1)], dtype=np.uint64)
     roots = {}
@@ -483,9 +497,14 @@ def test_independent_verifier_on_token_and_sequence_models(oracle, name, args, k
         elif c[0] == "witness":
             assert L.mle_eval([fe(v) for v in cols[c[1]][c[2]]], c[4]) == c[5], f"witness claim of node {c[1]}, column {c[2]}"
             uniform.append(({"root": list(c[3][0]), "num_vars": c[3][1]}, c[4], c[5]))
+        elif c[0] == "table":  # the committed output column of the inverse-square-root table: the claim is true, and it is opened against a commitment made HERE
+            from deep_prove_amd import models as M
+            column = M.inv_sqrt_table_output(c[1][1][0], c[1][1][1], np.arange(-(1 << 14), 1 << 14))
+            assert L.mle_eval([fe(v) for v in column], c[2]) == c[3], f"claim on the column of table {c[1]}"
+            uniform.append(({"root": oracle.pcs_commit_root(max_poly, to_words(column), False), "num_vars": 15}, c[2], c[3]))
         else:
             t = c[1]
-            lo, hi, data = (0, 256, lk["range"]) if t[0] == "range" else (-128, 128, lk["relu"]) if t[0] == "relu" else (-(1 << (t[1] - 1)), 1 << (t[1] - 1), lk["clamp"][t[1]])
+            lo, hi, data = (0, 256, lk["range"]) if t[0] == "range" else (-128, 128, lk["relu"]) if t[0] == "relu" else (-(1 << 14), 1 << 14, lk["inv_sqrt"][t[1]]) if t[0] == "inv_sqrt" else (-(1 << (t[1] - 1)), 1 << (t[1] - 1), lk["clamp"][t[1]])
             mult = [0] * (hi - lo)
             for v in data:
                 mult[v - lo] += 1
