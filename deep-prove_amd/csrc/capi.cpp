@@ -825,6 +825,12 @@ static ModelSpec parse_model(const int64_t* b, size_t n) {
       l.ln_eps_bits = (uint32_t)eb; l.ln_range_check_bits = (unsigned)rcb; l.ln_top_chunk_scalar_log = (unsigned)tcs;
       l.weights.assign(b + pos, b + pos + dim); pos += dim; l.bias.assign(b + pos, b + pos + dim); pos += dim;
     }
+    else if (l.kind == L_SOFTMAX) {  // [15, shape[3], multiplier, 1 / temperature bits, input scale bits, table size, bkm, zero chunks, zero table vars, allowable error]
+      for (int k = 0; k < 3; k++) l.sm_shape[k] = (size_t)rd();
+      l.sm_scalar = rd(); const int64_t tb = rd(), sb = rd(), ts = rd(); l.sm_bkm = rd(); const int64_t zc = rd(), zv = rd(); l.sm_allowable_error = rd();
+      DP_REQUIRE(tb >= 0 && tb <= 0xFFFFFFFFll && sb >= 0 && sb <= 0xFFFFFFFFll && ts >= 1 && ts <= 22 && zc >= 0 && zc <= 3 && zv >= 0 && zv <= 22, DP_ERR_ARG, "model blob: softmax parameters");
+      l.sm_temp_bits = (uint32_t)tb; l.sm_in_scale_bits = (uint32_t)sb; l.sm_table_size = (unsigned)ts; l.sm_zero_chunks = (unsigned)zc; l.sm_zero_vars = (unsigned)zv;
+    }
     else DP_REQUIRE(l.kind == L_RELU || l.kind == L_FLATTEN, DP_ERR_ARG, "model blob: unknown layer kind");
     m.layers.push_back(std::move(l));
   }

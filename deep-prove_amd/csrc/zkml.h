@@ -68,6 +68,12 @@ struct LayerSpec {
   // QuantisedLayerNormData: N = ln_dim_size, the multiplier of the inverse-square-root input, the f32 bits of the rescaled epsilon (the table's
   // identity together with ln_range_check_bits), the bits shifted away and range checked, log2 of the scalar of their top chunk
   size_t ln_dim_size = 0; int64_t ln_multiplier = 0; uint32_t ln_eps_bits = 0; unsigned ln_range_check_bits = 0, ln_top_chunk_scalar_log = 0;
+  // softmax (layers/transformer/softmax.rs:66-99; QuantisedSoftmaxData, SoftmaxCtx :1153-1169) over the last dimension of a padded [sm_shape[0]]
+  // [sm_shape[1]][sm_shape[2]] tensor under a causal mask (the last two dimensions are equal): the multiplier that brings the input to the scale
+  // 2^24; the f32 bits of 1 / temperature and of the input scale (the prover's row shifts are computed in floating point, as in the reference);
+  // the exponential table (2^sm_table_size entries, zero from sm_bkm on); the zero tables for the bits above; the allowable error of a row sum
+  int64_t sm_scalar = 0, sm_bkm = 0, sm_allowable_error = 0; uint32_t sm_temp_bits = 0, sm_in_scale_bits = 0; unsigned sm_table_size = 0, sm_zero_chunks = 0, sm_zero_vars = 0;
+  size_t sm_shape[3] = {0, 0, 0};
   unsigned right_shift = 0, fp_scale = 0, intermediate_bit_size = 0;
   int64_t fixed_point_multiplier = 0;
   unsigned shift() const { return fp_scale + right_shift; }
@@ -146,15 +152,25 @@ inline CmShape cm_shape(const LayerSpec& l) {
 }
 
 struct TableType {
-  // 0 Relu, 2 Range, 3 Clamping(size), 7 InverseSQRT{eps_bits = aux, range_check_bits = size}  (derive(Ord) order of lookup/context.rs:55-72,
-  // InverseSQRTTableData :124-131 ordered by (eps_bits, range_check_bits))
-  int kind; unsigned size; uint32_t aux = 0;
-  bool operator<(const TableType& o) const { return kind != o.kind ? kind < o.kind : aux != o.aux ? aux < o.aux : size < o.size; }
-  bool operator==(const TableType& o) const { return kind == o.kind && size == o.size && aux == o.aux; }
-  unsigned vars() const { return kind == 3 ? size : kind == 7 ? 2 * (Q_BIT_LEN - 1) + 1 : Q_BIT_LEN; }  // multiplicity_poly_vars (context.rs:481-492)
-  const char* label() const { return kind == 0 ? "Relu" : kind == 3 ? "Clamping" : kind == 7 ? "InverseSQRT" : nullptr; }
-  bool committed_column() const { return kind == 7; }  // committed_columns (context.rs:495-545): the output column of the table is a commitment of the context
+  // 0 Relu, 2 Range, 3 Clamping(size), 4 Softmax{float_bits = aux, table_size = size, bkm = aux2}, 5 ErrorTable(4096, allowable_error = aux2),
+  // 6 ZeroTable(size), 7 InverseSQRT{eps_bits = aux, range_check_bits = size}  (derive(Ord) order of lookup/context.rs:55-72; SoftmaxTableData
+  // :74-84 ordered by (float_bits, table_size, bkm), InverseSQRTTableData :124-131 by (eps_bits, range_check_bits))
+  int kind; unsigned size; uint32_t aux = 0; int64_t aux2 = 0;
+  bool operator<(const TableType& o) const { return kind != o.kind ? kind < o.kind : aux != o.aux ? aux < o.aux : size != o.size ? size < o.size : aux2 < o.aux2; }
+  bool operator==(const TableType& o) const { return kind == o.kind && size == o.size && aux == o.aux && aux2 == o.aux2; }
+  unsigned vars() const { return kind == 3 || kind == 4 || kind == 6 ? size : kind == 5 ? dp_ceil_log2((size_t)(2 * aux2)) : kind == 7 ? 2 * (Q_BIT_LEN - 1) + 1 : Q_BIT_LEN; }  // multiplicity_poly_vars (context.rs:481-492)
+  const char* label() const { return kind == 0 ? "Relu" : kind == 3 ? "Clamping" : kind == 4 ? "Softmax" : kind == 6 ? "Zero" : kind == 7 ? "InverseSQRT" : nullptr; }
+  // committed_columns (context.rs:495-545): the output column of these tables (the only column of an ErrorTable) is a commitment of the context
+  bool committed_column() const { return kind == 7 || kind == 4 || kind == 5; }
 };
+constexpr unsigned SM_LOG_SCALE = 24; constexpr int64_t SM_OUT_ONE = 1 << 12;  // SCALE_FACTOR, OUTPUT_SCALE_FACTOR (softmax.rs:56-60)
+// SoftmaxTableData::table_output (lookup/context.rs:111-122), f32 exp as there
+inline int64_t softmax_lut(uint32_t temp_bits, int64_t bkm, int64_t j) {
+  float temp; memcpy(&temp, &temp_bits, 4);
+  const int64_t prod = (int64_t(1) << (SM_LOG_SCALE - 8)) * j;
+  if (prod >= bkm) return 0;
+  return (int64_t)roundf(expf((float)(-prod) / ((float)(1u << SM_LOG_SCALE) * temp)) * (float)SM_OUT_ONE);
+}
 constexpr unsigned LN_LOG_SCALE = 24, LN_LOG_OUT_SCALE = 10;  // LAYERNORM_SCALE_FACTOR, LAYERNORM_OUTPUT_SCALE_FACTOR (layernorm.rs:61-65)
 // InverseSQRTTableData::table_output (lookup/context.rs:147-157), in f32 as there; a negative argument gives NaN, which `as Element` turns into 0
 inline int64_t inv_sqrt_lut(uint32_t eps_bits, unsigned range_check_bits, int64_t j) {
@@ -172,6 +188,13 @@ inline void table_columns(const TableType& tt, std::vector<int64_t>& merged, std
   merged.clear(); cols.clear();
   if (tt.kind == 0) { cols.resize(2); for (int64_t i = Q_MIN - 1; i <= Q_MAX; i++) { int64_t o = q_relu(i); merged.push_back(i + o * COLUMN_SEPARATOR); cols[0].push_back(i); cols[1].push_back(o); } }
   else if (tt.kind == 2) { cols.resize(1); for (int64_t i = 0; i < (int64_t(1) << Q_BIT_LEN); i++) { merged.push_back(i); cols[0].push_back(i); } }
+  else if (tt.kind == 4) { cols.resize(2); for (int64_t j = 0; j < (int64_t(1) << tt.size); j++) { int64_t o = softmax_lut(tt.aux, tt.aux2, j); merged.push_back(j + o * COLUMN_SEPARATOR); cols[0].push_back(j); cols[1].push_back(o); } }
+  else if (tt.kind == 5) {  // one - error ..= one + error, cut / zero padded to 2^ceil_log2(2 error) entries (context.rs:248-264)
+    cols.resize(1); const size_t n = size_t(1) << tt.vars();
+    for (int64_t v = SM_OUT_ONE - tt.aux2; v <= SM_OUT_ONE + tt.aux2 && merged.size() < n; v++) { merged.push_back(v); cols[0].push_back(v); }
+    while (merged.size() < n) { merged.push_back(0); cols[0].push_back(0); }
+  }
+  else if (tt.kind == 6) { cols.resize(2); for (int64_t i = 0; i < (int64_t(1) << tt.size); i++) { int64_t o = i != 0 ? 0 : 1; merged.push_back(i + o * COLUMN_SEPARATOR); cols[0].push_back(i); cols[1].push_back(o); } }
   else if (tt.kind == 7) { cols.resize(2); int64_t mx = int64_t(1) << (2 * (Q_BIT_LEN - 1)); for (int64_t i = -mx; i < mx; i++) { int64_t o = inv_sqrt_lut(tt.aux, tt.size, i); merged.push_back(i + o * COLUMN_SEPARATOR); cols[0].push_back(i); cols[1].push_back(o); } }
   else { cols.resize(2); int64_t mx = int64_t(1) << (tt.size - 1); for (int64_t i = -mx; i < mx; i++) { int64_t o = q_clamp(i); merged.push_back(i + o * COLUMN_SEPARATOR); cols[0].push_back(i); cols[1].push_back(o); } }
 }
@@ -195,6 +218,55 @@ inline std::vector<int64_t> layernorm_op(const LayerSpec& l, const std::vector<i
     if (d) { d->lookup_input.push_back(in); d->lookup_output.push_back(inv); d->range_check.push_back(full & mask); d->row_sum.push_back(sum); }
     for (size_t i = 0; i < fd; i++) o[c * fd + i] = l.weights[i] * (n * x[c * fd + i] - sum) * inv + l.bias[i];
   }
+  return o;
+}
+
+inline TableType softmax_table(const LayerSpec& l) { TableType t{4, l.sm_table_size}; t.aux = l.sm_temp_bits; t.aux2 = l.sm_bkm; return t; }
+inline TableType softmax_error_table(const LayerSpec& l) { TableType t{5, 0}; t.aux2 = l.sm_allowable_error; return t; }
+// Softmax::evaluate on Elements (softmax.rs:455-566) with calculate_shift_data (:250-320: per row, minus the logarithm of the sum of the
+// exponentials of its unmasked entries, computed in f32 — a WITNESS, any shift whose row sum lands in the error table is accepted) and the causal
+// AttentionMask (:1590-1750). |masked input| = low byte | high byte | exponential table input | zero table inputs
+struct SoftmaxTrace {
+  std::vector<int64_t> shift, shifted_input, tril, bias, low, high, exp_in, exp_out, row_sums;
+  std::vector<std::vector<int64_t>> zero_in, zero_out;
+};
+inline std::vector<int64_t> softmax_op(const LayerSpec& l, const std::vector<int64_t>& x, SoftmaxTrace* out) {
+  const size_t C = l.sm_shape[0], R = l.sm_shape[1], K = l.sm_shape[2];
+  DP_REQUIRE(C && R && R == K && x.size() == C * R * K, DP_ERR_SHAPE, "softmax: shapes");
+  float inv_temp, in_scale; memcpy(&inv_temp, &l.sm_temp_bits, 4); memcpy(&in_scale, &l.sm_in_scale_bits, 4);
+  SoftmaxTrace d;
+  const int64_t neg_inf = -(((l.sm_bkm >> 16) + 1) << 16);
+  for (size_t i = 0; i < C * R; i++) {
+    const int64_t* row = &x[i * K]; const size_t take = i % R + 1;
+    for (size_t j = 0; j < K; j++) DP_REQUIRE(row[j] >= -(int64_t(1) << 24) && row[j] <= (int64_t(1) << 24), DP_ERR_ARG, "softmax: input out of range");
+    if (i % R == 0) { d.shift.push_back(-row[0] * l.sm_scalar); continue; }
+    int64_t mx = row[0]; for (size_t j = 1; j < take; j++) mx = std::max(mx, row[j]);
+    float sum = 0.0f;
+    for (size_t j = 0; j < take; j++) sum += expf(((float)(row[j] - mx) * in_scale) / inv_temp);
+    d.shift.push_back(-(int64_t)roundf((float)(1u << SM_LOG_SCALE) * inv_temp * logf(sum)) - mx * l.sm_scalar);
+  }
+  d.tril.resize(x.size()); d.bias.resize(x.size()); d.shifted_input.resize(x.size());
+  for (size_t i = 0; i < C * R; i++) for (size_t j = 0; j < K; j++) {
+    const bool keep = j <= i % R;
+    d.tril[i * K + j] = keep ? 1 : 0; d.bias[i * K + j] = keep ? 0 : neg_inf;
+    d.shifted_input[i * K + j] = x[i * K + j] * l.sm_scalar + d.shift[i];
+  }
+  const unsigned tv = l.sm_table_size;
+  const int64_t tmask = (int64_t(1) << tv) - 1, zmask = (int64_t(1) << l.sm_zero_vars) - 1;
+  d.zero_in.resize(l.sm_zero_chunks); d.zero_out.resize(l.sm_zero_chunks);
+  std::vector<int64_t> o; o.reserve(x.size());
+  for (size_t q = 0; q < x.size(); q++) {
+    const int64_t masked = d.shifted_input[q] * d.tril[q] + d.bias[q];
+    int64_t r = masked < 0 ? -masked : masked;
+    d.low.push_back(r & 255); r >>= 8; d.high.push_back(r & 255); r >>= 8;
+    const int64_t lk = r & tmask, ev = softmax_lut(l.sm_temp_bits, l.sm_bkm, lk);
+    d.exp_in.push_back(lk); d.exp_out.push_back(ev); r >>= tv;
+    int64_t acc = ev;
+    for (unsigned z = 0; z < l.sm_zero_chunks; z++) { const int64_t zi = r & zmask, zo = zi != 0 ? 0 : 1; d.zero_in[z].push_back(zi); d.zero_out[z].push_back(zo); r >>= l.sm_zero_vars; acc *= zo; }
+    o.push_back(acc);
+  }
+  for (size_t i = 0; i < C * R; i++) { int64_t a = 0; for (size_t j = 0; j < K; j++) a += o[i * K + j]; d.row_sums.push_back(a); }
+  if (out) *out = std::move(d);
   return o;
 }
 
@@ -459,6 +531,7 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
       }
     } else if (l.kind == L_RELU) for (int64_t v : cur) o.push_back(q_relu(v));
     else if (l.kind == L_LAYERNORM) o = layernorm_op(l, cur, nullptr);
+    else if (l.kind == L_SOFTMAX) o = softmax_op(l, cur, nullptr);
     else if (l.kind == L_CONV) { tr.conv.resize(m.layers.size()); o = conv_op(l, cur, tr.conv[tr.in.size() - 1]); }
     else if (l.kind == L_MAXPOOL) o = maxpool_op(l, cur);
     else if (l.kind == L_FLATTEN) o = cur;
@@ -561,6 +634,11 @@ inline void validate_model(const ModelSpec& m) {
       unsigned cs = l.clamping_size();
       DP_REQUIRE(cs >= 1 && cs <= 24 && cur >= 4, DP_ERR_ARG, "requant: unsupported clamping table size / tensor length");
     } else if (l.kind == L_RELU) { DP_REQUIRE(cur >= 4, DP_ERR_SHAPE, "relu: tensor length must be >= 4"); }
+    else if (l.kind == L_SOFTMAX) {
+      DP_REQUIRE(is_pow2(l.sm_shape[0]) && is_pow2(l.sm_shape[1]) && l.sm_shape[1] == l.sm_shape[2] && l.sm_shape[1] >= 2 && cur == l.sm_shape[0] * l.sm_shape[1] * l.sm_shape[2] && l.sm_shape[0] * l.sm_shape[1] >= 4, DP_ERR_SHAPE, "softmax: a padded [c][n][n] input with at least four rows");
+      DP_REQUIRE(l.sm_scalar >= 1 && l.sm_scalar < (int64_t(1) << 30) && l.sm_bkm >= (int64_t(1) << 17) && l.sm_bkm < (int64_t(1) << 40) && l.sm_table_size == dp_ceil_log2((size_t)(l.sm_bkm >> 16)) && l.sm_table_size <= 22, DP_ERR_ARG, "softmax: multiplier / bkm / table size");
+      DP_REQUIRE(l.sm_zero_chunks <= 3 && (l.sm_zero_chunks == 0) == (l.sm_zero_vars == 0) && l.sm_zero_vars <= 22 && l.sm_allowable_error >= 1 && l.sm_allowable_error <= (1 << 11), DP_ERR_ARG, "softmax: zero tables / allowable error");
+    }
     else if (l.kind == L_LAYERNORM) {
       const size_t fd = l.weights.size();
       DP_REQUIRE(is_pow2(fd) && fd >= 2 && l.bias.size() == fd && l.nrows == fd && is_pow2(cur) && cur % fd == 0 && cur / fd >= 4, DP_ERR_SHAPE, "layernorm: [rows >= 4][dim >= 2] input, gamma and beta of the padded dimension");
@@ -596,6 +674,7 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
     else if (l.kind == L_RELU) { add({0, 0}); mpl = std::max(mpl, next_pow2(cur)); }
     else if (l.kind == L_MAXPOOL) { add({2, 0}); mpl = std::max(mpl, next_pow2(cur)); }
     else if (l.kind == L_LAYERNORM) { add({2, 0}); add(layernorm_table(l)); mpl = std::max(mpl, next_pow2(cur)); }  // layernorm.rs:587-618
+    else if (l.kind == L_SOFTMAX) { add({2, 0}); add(softmax_table(l)); add(softmax_error_table(l)); if (l.sm_zero_vars) add({6, l.sm_zero_vars}); mpl = std::max(mpl, next_pow2(cur)); }  // softmax.rs:1205-1245
   }
   std::sort(ts.begin(), ts.end());
   for (auto& t : ts) mpl = std::max(mpl, size_t(1) << t.vars());
@@ -674,8 +753,8 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
   for (const TableType& tt : ts) if (tt.committed_column()) {  // commit/context.rs:105-107
     std::vector<int64_t> merged; std::vector<std::vector<int64_t>> tc;
     table_columns(tt, merged, tc);
-    DBuf col = dev.alloc_persistent(tc[1].size(), false);
-    dev.upload_i64(col, tc[1].data());
+    DBuf col = dev.alloc_persistent(tc.back().size(), false);  // (the output column; the only column of an ErrorTable)
+    dev.upload_i64(col, tc.back().data());
     ctx->table_comms[tt] = dev.commit(col, true);
   }
   return ctx;
@@ -702,6 +781,7 @@ struct ProverState {
   // activations the layer proofs read as extension tables (Dense inputs, ReLU outputs), already on the device: they rode in the
   // witness upload instead of costing one upload launch each inside the layer loop
   std::map<size_t, DBuf> staged_in, staged_out;
+  std::map<size_t, SoftmaxTrace> sm_trace;    // SoftmaxData of every Softmax node, likewise
   std::map<size_t, LayerNormTrace> ln_trace;  // LayerNormData of every LayerNorm node (kept from the witness generation for its prover)
   void add_witness_claim(const DevCommit& c, Claim cl) {
     if (c.nv <= PCS_BASECODE_LOG) trivial_claims.push_back({c, std::move(cl)}); else claims.push_back({c, std::move(cl)});
@@ -733,8 +813,11 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
   std::map<TableType, std::unordered_map<int64_t, u64>> counts;
   struct Col { std::vector<int64_t> v; };
   std::vector<Col> cols;                       // every i64 column that goes to the device, in commit order first
-  struct Pending { size_t node; int which; std::vector<size_t> col_ids; size_t cpi; TableType tt; size_t n_lookup_cols = 0; };
+  // col_ids: committed columns, in commit order; the first n_lookup_cols of them (all, if 0) are the lookup's columns. late >= 0: the lookup's
+  // only column is `lates[late]`, a column that is NOT committed (Softmax's row sums), and every committed column is an extra one
+  struct Pending { size_t node; int which; std::vector<size_t> col_ids; size_t cpi; TableType tt; size_t n_lookup_cols = 0; int late = -1; };
   std::vector<Pending> pend;
+  std::vector<std::vector<int64_t>> lates; std::vector<size_t> late_ids;
   for (size_t id = 0; id < ctx.model.layers.size(); id++) {
     const LayerSpec& l = ctx.model.layers[id];
     if (l.kind == L_REQUANT) {
@@ -779,6 +862,27 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
         pr.col_ids.push_back(cols.size()); cols.push_back({std::move(ch)});
       }
       pend.push_back(pi); pend.push_back(pr);
+    } else if (l.kind == L_SOFTMAX) {  // Softmax::lookup_witness (softmax.rs:890-1066)
+      SoftmaxTrace& d = ps.sm_trace[id];
+      softmax_op(l, tr.in[id], &d);
+      TableType st = softmax_table(l), rt{2, 0}, et = softmax_error_table(l), zt{6, l.sm_zero_vars};
+      for (int64_t v : d.low) counts[rt][v] += 1;
+      for (int64_t v : d.high) counts[rt][v] += 1;
+      for (size_t i = 0; i < d.exp_in.size(); i++) counts[st][d.exp_in[i] + d.exp_out[i] * COLUMN_SEPARATOR] += 1;
+      for (int64_t v : d.row_sums) counts[et][v] += 1;
+      Pending pe{id, 0, {cols.size(), cols.size() + 1}, 2, st}; cols.push_back({d.exp_in}); cols.push_back({d.exp_out});
+      Pending pr{id, 1, {cols.size(), cols.size() + 1}, 1, rt}; cols.push_back({d.low}); cols.push_back({d.high});
+      Pending px{id, 2, {cols.size()}, 1, et}; cols.push_back({d.shift});  // the SHIFT polynomial is committed with this lookup, the row sums are what is looked up
+      px.late = (int)lates.size(); lates.push_back(d.row_sums);
+      pend.push_back(pe); pend.push_back(pr); pend.push_back(px);
+      if (l.sm_zero_chunks) {
+        Pending pz{id, 3, {}, 2, zt};
+        for (unsigned z = 0; z < l.sm_zero_chunks; z++) {
+          for (size_t i = 0; i < d.zero_in[z].size(); i++) counts[zt][d.zero_in[z][i] + d.zero_out[z][i] * COLUMN_SEPARATOR] += 1;
+          pz.col_ids.push_back(cols.size()); cols.push_back({d.zero_in[z]}); pz.col_ids.push_back(cols.size()); cols.push_back({d.zero_out[z]});
+        }
+        pend.push_back(pz);
+      }
     } else if (l.kind == L_MAXPOOL) {  // Pooling::gen_lookup_witness (pooling.rs:206-262): 4 difference columns + the output
       TableType rt{2, 0};
       std::vector<std::vector<int64_t>> diffs = maxpool_diff_polys(l, tr.in[id], tr.out[id]);
@@ -793,6 +897,7 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
     }
   }
   size_t n_witness_cols = cols.size();
+  for (auto& v : lates) { late_ids.push_back(cols.size()); cols.push_back({std::move(v)}); }  // uploaded with the rest, not committed
   wt.lap("  witness: host columns");
   // table columns (not committed) ride in the same upload
   struct TabInfo { TableType tt; std::vector<size_t> col_ids; std::vector<u64> mult; };
@@ -850,9 +955,10 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
     LogUpWitness w; w.columns_per_instance = p.cpi; w.table_type = p.tt;
     for (size_t q = 0; q < p.col_ids.size(); q++) {
       size_t cid = p.col_ids[q];
-      if (!p.n_lookup_cols || q < p.n_lookup_cols) w.columns.push_back(dcol[cid]); else w.extra_columns.push_back(dcol[cid]);
+      if (p.late < 0 && (!p.n_lookup_cols || q < p.n_lookup_cols)) w.columns.push_back(dcol[cid]); else w.extra_columns.push_back(dcol[cid]);
       w.commits.push_back(comms[cid]);
     }
+    if (p.late >= 0) w.columns.push_back(dcol[late_ids[(size_t)p.late]]);
     ps.lookup_witness[p.node].push_back(std::move(w));
   }
   for (size_t i = 0; i < tabs.size(); i++) {
@@ -1351,6 +1457,82 @@ inline Claim prove_layernorm(ProverState& ps, size_t id, const LayerSpec& l, con
   return input_claim;
 }
 
+// Softmax::prove_step (layers/transformer/softmax.rs:573-888): the lookups (exponential table; the two low bytes; the row sums against the values
+// within the allowable error of one; the bits above the exponential's input against the zero table), ONE sumcheck that brings every lookup
+// claim to a single point and ties both the output claim and the row sums (1/2 in the coordinates of the normalised dimension, times 2^k) to
+// exp_out * prod zero_out, and the mask sumcheck eq (shifted_input tril + bias). The claim handed on is the one the verifier derives,
+// (shifted - shift) / scalar (:1541-1543); the reference's prover keeps the undivided value (:748-749), which nothing downstream reads.
+inline Claim prove_softmax(ProverState& ps, size_t id, const LayerSpec& l, const Claim& last) {
+  Dev& dev = *ps.dev;
+  const SoftmaxTrace& d = ps.sm_trace.at(id);
+  std::vector<LogUpWitness>& ws = ps.lookup_witness.at(id);
+  const bool zero = l.sm_zero_chunks != 0;
+  DP_REQUIRE(ws.size() == (zero ? 4u : 3u), DP_ERR_SHAPE, "softmax: lookup witnesses");
+  SoftmaxProof pr;
+  for (auto& w : ws) pr.logup_proofs.push_back(logup_batch_prove(dev, ps.logup_input(w), *ps.t));
+  const std::vector<Ext> exp_point = pr.logup_proofs[0].output_claims.at(0).point, range_point = pr.logup_proofs[1].output_claims.at(0).point, error_point = pr.logup_proofs[2].output_claims.at(0).point;
+  const size_t n = d.exp_in.size(); const unsigned nv = dp_ceil_log2(n);
+  DP_REQUIRE(exp_point.size() == nv && range_point.size() == nv && error_point.size() <= nv && last.point.size() == nv, DP_ERR_SHAPE, "softmax: claim points");
+  const size_t extra = nv - error_point.size();
+  const Ext two_inv = ex_inv(ex_from_u64(2)), two_mult = ex_from_u64(u64(1) << extra);
+  std::vector<Ext> full_error(extra, two_inv); full_error.insert(full_error.end(), error_point.begin(), error_point.end());
+  const Ext alpha = ps.t->get_and_append_challenge("batching_challenge");
+  size_t mk = dev.mark();
+  std::vector<Ext> all;
+  {
+    DBuf exp_beta = dev.alloc(n, true), range_beta = dev.alloc(n, true), error_beta = dev.alloc(n, true), last_beta = dev.alloc(n, true), zbeta;
+    std::vector<EqAcc> eqs = {{exp_beta, exp_point, ex_one(), false}, {range_beta, range_point, ex_one(), false}, {error_beta, full_error, ex_one(), false}, {last_beta, last.point, ex_one(), false}};
+    if (zero) { zbeta = dev.alloc(n, true); eqs.push_back({zbeta, pr.logup_proofs[3].output_claims.at(0).point, ex_one(), false}); }
+    DevVP vp(nv);
+    Ext bc = ex_one();
+    for (auto& c : ws[0].columns) { vp.add_mle_list({c, exp_beta}, bc); bc = ex_mul(bc, alpha); }
+    for (auto& c : ws[1].columns) { vp.add_mle_list({c, range_beta}, bc); bc = ex_mul(bc, alpha); }
+    const DBuf exp_out = ws[0].columns[1];
+    if (zero) {
+      for (auto& c : ws[3].columns) { vp.add_mle_list({zbeta, c}, bc); bc = ex_mul(bc, alpha); }
+      std::vector<DBuf> prod; for (size_t q = 1; q < ws[3].columns.size(); q += 2) prod.push_back(ws[3].columns[q]);
+      prod.push_back(exp_out);
+      std::vector<DBuf> err = prod, outp = prod; err.push_back(error_beta); outp.push_back(last_beta);
+      vp.add_mle_list(err, ex_mul(bc, two_mult));
+      vp.add_mle_list(outp, ex_mul(bc, alpha));
+    } else {
+      vp.add_mle_list({exp_out, error_beta}, ex_mul(bc, two_mult));
+      vp.add_mle_list({exp_out, last_beta}, ex_mul(bc, alpha));
+    }
+    // (tables are de-duplicated here: exp_in, exp_beta, exp_out, low, range_beta, high, [zero_beta, zero columns..], error_beta, last_beta)
+    SumcheckOut sc = sumcheck_prove_with_eq(dev, eqs, vp, *ps.t);
+    pr.accumulation_proof = sc.proof; all = sc.finals;
+  }
+  dev.release(mk);
+  const std::vector<Ext> sc_point = pr.accumulation_proof.point;
+  Ext shifted_eval;
+  {
+    std::vector<int64_t> host(3 * n);
+    std::copy(d.shifted_input.begin(), d.shifted_input.end(), host.begin()); std::copy(d.tril.begin(), d.tril.end(), host.begin() + n); std::copy(d.bias.begin(), d.bias.end(), host.begin() + 2 * n);
+    DBuf buf = dev.alloc(3 * n, false);
+    dev.upload_i64(buf, host.data());
+    DBuf meq = dev.alloc(n, true);
+    std::vector<EqAcc> eqs = {{meq, sc_point, ex_one(), false}};
+    DevVP mv(nv);
+    mv.add_mle_list({buf.slice(0, n), buf.slice(n, n), meq}, ex_one());
+    mv.add_mle_list({buf.slice(2 * n, n), meq}, ex_one());
+    SumcheckOut sc = sumcheck_prove_with_eq(dev, eqs, mv, *ps.t);
+    pr.mask_proof = sc.proof; shifted_eval = sc.finals[0];
+  }
+  dev.release(mk);
+  const DevCommit& shift_c = ws[2].commits[0];
+  const std::vector<Ext> mask_point = pr.mask_proof.point;
+  const std::vector<Ext> shift_point(mask_point.begin() + (mask_point.size() - shift_c.nv), mask_point.end());
+  std::vector<Ext> shift_ext(d.shift.size()); for (size_t i = 0; i < d.shift.size(); i++) shift_ext[i] = ex_from_i64(d.shift[i]);
+  const Ext shift_eval = host_mle_eval(shift_ext, shift_point);
+  const Ext evs4[4] = {all[0], all[2], all[3], all[5]};
+  for (size_t q = 0; q < 4; q++) { const DevCommit& c = q < 2 ? ws[0].commits[q] : ws[1].commits[q - 2]; ps.add_witness_claim(c, {sc_point, evs4[q]}); pr.commitments.push_back(pure_commitment(c)); pr.evaluations.push_back(evs4[q]); }
+  ps.add_witness_claim(shift_c, {shift_point, shift_eval}); pr.commitments.push_back(pure_commitment(shift_c)); pr.evaluations.push_back(shift_eval);
+  if (zero) for (size_t q = 0; q < ws[3].commits.size(); q++) { ps.add_witness_claim(ws[3].commits[q], {sc_point, all[7 + q]}); pr.commitments.push_back(pure_commitment(ws[3].commits[q])); pr.evaluations.push_back(all[7 + q]); }
+  LayerProof lp; lp.kind = L_SOFTMAX; lp.sm = pr; ps.proofs[id] = lp;
+  return {mask_point, ex_mul(ex_sub(shifted_eval, shift_eval), ex_inv(ex_from_i64(l.sm_scalar)))};
+}
+
 // ---- convolution (zkCNN FFT protocol, layers/convolution.rs:697-1080 with the helpers of iop/prover.rs:164-399)
 inline DBuf upload_exts(Dev& dev, const std::vector<Ext>& v) {
   DBuf b = dev.alloc(v.size(), true);
@@ -1611,6 +1793,7 @@ inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t) {
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
     else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, tr.out[id]);
     else if (l.kind == L_LAYERNORM) cur = prove_layernorm(ps, id, l, cur, tr.in[id]);
+    else if (l.kind == L_SOFTMAX) cur = prove_softmax(ps, id, l, cur);
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv.at(id));
     else if (l.kind == L_MAXPOOL) cur = prove_pooling(ps, id, l, cur);
     // L_FLATTEN is not provable: the claim passes through unchanged (iop/prover.rs:449-456)
@@ -1665,6 +1848,7 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
     if (it->second.kind == L_REQUANT) { add_fracs(it->second.req.clamping_lookup); add_fracs(it->second.req.shifted_lookup); }
     if (it->second.kind == L_MAXPOOL) add_fracs(it->second.pool.lookup);
     if (it->second.kind == L_LAYERNORM) for (auto& lg : it->second.ln.logup_proofs) add_fracs(lg);
+    if (it->second.kind == L_SOFTMAX) for (auto& lg : it->second.sm.logup_proofs) add_fracs(lg);
   }
   DP_REQUIRE(proof.steps.size() == n_provable, DP_ERR_VERIFY, "unexpected layer proofs");
   for (auto& tp : proof.table_proofs) add_fracs(tp.lookup);
@@ -1977,6 +2161,62 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       DP_REQUIRE(ex_eq(ex_mul(mp.individual_claims[0], mp.individual_claims[1]), sub.expected_evaluation), DP_ERR_VERIFY, "matmul: sumcheck claim failed");
       cur = {point_left, mp.individual_claims[0]};
       cur_len = s_ * l.nrows;
+    } else if (l.kind == L_SOFTMAX) {  // SoftmaxCtx::verify (softmax.rs:1274-1586)
+      const SoftmaxProof& q = lp.sm;
+      const bool zero = l.sm_zero_chunks != 0;
+      const TableType st = softmax_table(l), et = softmax_error_table(l), zt{6, l.sm_zero_vars};
+      DP_REQUIRE(q.logup_proofs.size() == (zero ? 4u : 3u) && chmap.count(st) && chmap.count(et) && (!zero || chmap.count(zt)), DP_ERR_VERIFY, "softmax: lookups");
+      std::vector<LogUpVerifierClaim> lc;
+      lc.push_back(verify_logup_proof(q.logup_proofs[0], 1, constant_challenge, chmap[st], t, 0));
+      lc.push_back(verify_logup_proof(q.logup_proofs[1], 2, constant_challenge, ex_one(), t, 0));
+      lc.push_back(verify_logup_proof(q.logup_proofs[2], 1, constant_challenge, ex_one(), t, 0));
+      if (zero) lc.push_back(verify_logup_proof(q.logup_proofs[3], l.sm_zero_chunks, constant_challenge, chmap[zt], t, 0));
+      const size_t nz = 2 * l.sm_zero_chunks;
+      DP_REQUIRE(lc[0].claims.size() == 2 && lc[1].claims.size() == 2 && lc[2].claims.size() == 1 && (!zero || lc[3].claims.size() == nz) && q.evaluations.size() == 5 + nz && q.commitments.size() == 5 + nz, DP_ERR_VERIFY, "softmax: shapes");
+      const Ext alpha = t.get_and_append_challenge("batching_challenge");
+      Ext sum = ex_zero(), bc = ex_one();
+      auto fold_in = [&](const std::vector<Claim>& cs) { for (auto& c : cs) { sum = ex_add(sum, ex_mul(bc, c.eval)); bc = ex_mul(bc, alpha); } };
+      fold_in(lc[0].claims); fold_in(lc[1].claims); if (zero) fold_in(lc[3].claims); fold_in(lc[2].claims);
+      sum = ex_add(sum, ex_mul(bc, cur.eval));
+      const std::vector<Ext>& exp_point = lc[0].claims[0].point; const std::vector<Ext>& range_point = lc[1].claims[0].point; const std::vector<Ext>& error_point = lc[2].claims[0].point;
+      const unsigned nv = (unsigned)exp_point.size();
+      DP_REQUIRE(range_point.size() == nv && error_point.size() <= nv && cur.point.size() == nv && nv == dp_ceil_log2(cur_len) && (!zero || lc[3].claims[0].point.size() == nv), DP_ERR_VERIFY, "softmax: point sizes");
+      const size_t extra = nv - error_point.size();
+      DP_REQUIRE(extra == dp_ceil_log2(l.sm_shape[2]), DP_ERR_VERIFY, "softmax: the error lookup does not range over the rows");
+      const Ext two_inv = ex_inv(ex_from_u64(2)), two_mult = ex_from_u64(u64(1) << extra);
+      std::vector<Ext> full_error(extra, two_inv); full_error.insert(full_error.end(), error_point.begin(), error_point.end());
+      SubClaim acc = sumcheck_verify(sum, q.accumulation_proof, nv, zero ? l.sm_zero_chunks + 2 : 2, t);
+      const Ext last_beta = eq_eval(cur.point.data(), acc.point.data(), nv), exp_beta = eq_eval(exp_point.data(), acc.point.data(), nv), range_beta = eq_eval(range_point.data(), acc.point.data(), nv), error_beta = eq_eval(full_error.data(), acc.point.data(), nv);
+      const std::vector<Ext>& ev = q.evaluations;
+      Ext calc = ex_zero(); bc = ex_one();
+      for (size_t k = 0; k < 2; k++) { calc = ex_add(calc, ex_mul(ev[k], bc)); bc = ex_mul(bc, alpha); }
+      calc = ex_mul(exp_beta, calc);
+      for (size_t k = 2; k < 4; k++) { calc = ex_add(calc, ex_mul(ex_mul(range_beta, ev[k]), bc)); bc = ex_mul(bc, alpha); }
+      Ext out_eval = ev[1];
+      if (zero) {
+        const Ext zbeta = eq_eval(lc[3].claims[0].point.data(), acc.point.data(), nv);
+        for (size_t k = 5; k < ev.size(); k++) { calc = ex_add(calc, ex_mul(ex_mul(zbeta, ev[k]), bc)); bc = ex_mul(bc, alpha); }
+        for (size_t k = 6; k < ev.size(); k += 2) out_eval = ex_mul(out_eval, ev[k]);
+      }
+      calc = ex_add(calc, ex_mul(ex_mul(bc, out_eval), ex_add(ex_mul(error_beta, two_mult), ex_mul(alpha, last_beta))));
+      DP_REQUIRE(ex_eq(calc, acc.expected_evaluation), DP_ERR_VERIFY, "softmax: accumulation claim mismatch");
+      // |masked input| = low + 2^8 high + 2^16 exp_in + 2^(16 + table vars) (zero_in_0 + 2^zero_vars zero_in_1 + ..)
+      Ext mask_in = ex_add(ex_add(ex_mul(ev[0], ex_from_u64(u64(1) << 16)), ex_mul(ev[3], ex_from_u64(u64(1) << 8))), ev[2]);
+      if (zero) { Ext mul = ex_from_u64(u64(1) << (16 + l.sm_table_size)); for (size_t k = 5; k < ev.size(); k += 2) { mask_in = ex_add(mask_in, ex_mul(ev[k], mul)); mul = ex_mul(mul, ex_from_u64(u64(1) << l.sm_zero_vars)); } }
+      SubClaim mk_ = sumcheck_verify(ex_neg(mask_in), q.mask_proof, nv, 3, t);
+      const Ext eqv = eq_eval(mk_.point.data(), acc.point.data(), nv);
+      const unsigned cols_v = dp_ceil_log2(l.sm_shape[2]), rows_v = dp_ceil_log2(l.sm_shape[1]);
+      Ext tril_eval = ex_one();  // eval_zeroifier_mle (mha.rs:894-901)
+      for (unsigned k = 0; k < cols_v && k < rows_v; k++) { const Ext c = mk_.point[k], r = mk_.point[cols_v + k]; tril_eval = ex_add(ex_mul(tril_eval, ex_add(ex_sub(ex_sub(ex_one(), c), r), ex_mul(ex_from_u64(2), ex_mul(c, r)))), ex_mul(ex_sub(ex_one(), c), r)); }
+      const Ext neg_inf = ex_from_i64(-(((l.sm_bkm >> 16) + 1) << 16));
+      const Ext mult_tril = ex_mul(eqv, tril_eval), mult_bias = ex_mul(eqv, ex_mul(neg_inf, ex_sub(ex_one(), tril_eval)));
+      DP_REQUIRE(!ex_is_zero(mult_tril), DP_ERR_VERIFY, "softmax: degenerate mask point");
+      const Ext shifted = ex_mul(ex_sub(mk_.expected_evaluation, mult_bias), ex_inv(mult_tril));
+      const Ext input_eval = ex_mul(ex_sub(shifted, ev[4]), ex_inv(ex_from_i64(l.sm_scalar)));
+      for (size_t k = 0; k < 4; k++) add_claim(q.commitments[k], {acc.point, ev[k]});
+      add_claim(q.commitments[4], {std::vector<Ext>(mk_.point.begin() + extra, mk_.point.end()), ev[4]});
+      for (size_t k = 5; k < ev.size(); k++) add_claim(q.commitments[k], {acc.point, ev[k]});
+      cur = {mk_.point, input_eval};
     } else if (l.kind == L_LAYERNORM) {  // LayerNormCtx::verify (layernorm.rs:1230-1505)
       const LayerNormProof& q = lp.ln;
       const TableType it = layernorm_table(l);
@@ -2100,6 +2340,9 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
     for (size_t k = 0; k < pt.size(); k++) idx = ex_add(idx, ex_mul(pt[k], ex_from_u64(u64(1) << k)));
     if (tt.kind == 2) expect = {idx};
     else if (tt.kind == 7) expect = {ex_sub(idx, ex_from_u64(u64(1) << (2 * (Q_BIT_LEN - 1))))};  // (context.rs:445-462)
+    else if (tt.kind == 4) expect = {idx};   // Softmax: the input column (context.rs:409-423)
+    else if (tt.kind == 5) expect = {};      // ErrorTable: nothing but the committed column (:424)
+    else if (tt.kind == 6) { Ext o = ex_one(); for (size_t k = 0; k < pt.size(); k++) o = ex_mul(o, ex_sub(ex_one(), pt[k])); expect = {idx, o}; }  // ZeroTable (:425-443)
     else if (tt.kind == 0) {
       Ext second = ex_zero();
       for (size_t k = 0; k + 1 < pt.size(); k++) second = ex_add(second, ex_mul(ex_mul(pt[k], ex_from_u64(u64(1) << k)), pt.back()));
@@ -2175,6 +2418,10 @@ inline std::vector<u64> vctx_to_words(const VerifierContext& v) {
   w.push_back(0x3158544356504444ULL); w.push_back(v.full_log); w.push_back(v.shape.input_len); w.push_back(v.shape.layers.size());
   for (auto& l0 : v.shape.layers) {
     LayerSpec l = l0;
+    if (l.kind == L_SOFTMAX) {  // a Softmax in the slots of Requant / Conv: table size, zero chunks, multiplier, 1 / temperature bits, zero table vars, bkm, allowable error, shape
+      l.right_shift = l.sm_table_size; l.fp_scale = l.sm_zero_chunks; l.fixed_point_multiplier = l.sm_scalar; l.intermediate_bit_size = l.sm_temp_bits;
+      l.kw = l.sm_zero_vars; l.kx = (size_t)l.sm_bkm; l.real_nw = (size_t)l.sm_allowable_error; for (int k = 0; k < 3; k++) l.unp_out[k] = l.sm_shape[k];
+    }
     if (l.kind == L_LAYERNORM) {  // a LayerNorm rides in the slots of a Requant: N, range check bits, log2 of the top chunk scalar, multiplier, epsilon bits
       l.ncols = l.ln_dim_size; l.right_shift = l.ln_range_check_bits; l.fp_scale = l.ln_top_chunk_scalar_log; l.fixed_point_multiplier = l.ln_multiplier; l.intermediate_bit_size = l.ln_eps_bits;
     }
@@ -2199,8 +2446,8 @@ inline std::vector<u64> vctx_to_words(const VerifierContext& v) {
   w.push_back(v.tables.size());
   for (auto& t : v.tables) {
     w.push_back(t.kind); w.push_back(t.size);
-    if (t.committed_column()) {  // (only these entries are longer: the table's second parameter and the commitment of its column)
-      w.push_back(t.aux);
+    if (t.committed_column()) {  // (only these entries are longer: the table's other parameters and the commitment of its column)
+      w.push_back(t.aux); w.push_back((u64)t.aux2);
       auto it = v.table_comms.find(t); DP_REQUIRE(it != v.table_comms.end(), DP_ERR_ARG, "verifier context: table without its commitment");
       const Commitment& c = it->second; for (int k = 0; k < 4; k++) w.push_back(c.root.v[k]); w.push_back(c.num_vars); w.push_back(c.is_base);
     }
@@ -2234,7 +2481,14 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
     l.kw = (size_t)rd(); l.kx = (size_t)rd(); l.real_nw = (size_t)rd(); l.nw = (size_t)rd();
     for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();
     for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd();
-    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_LAYERNORM, DP_ERR_ARG, "verifier blob: layer kind");
+    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_SOFTMAX, DP_ERR_ARG, "verifier blob: layer kind");
+    if (l.kind == L_SOFTMAX) {
+      l.sm_table_size = l.right_shift; l.sm_zero_chunks = l.fp_scale; l.sm_scalar = l.fixed_point_multiplier; l.sm_temp_bits = (uint32_t)l.intermediate_bit_size;
+      l.sm_zero_vars = (unsigned)l.kw; l.sm_bkm = (int64_t)l.kx; l.sm_allowable_error = (int64_t)l.real_nw; for (int k = 0; k < 3; k++) { l.sm_shape[k] = l.unp_out[k]; l.unp_out[k] = 0; }
+      l.right_shift = l.fp_scale = l.intermediate_bit_size = 0; l.fixed_point_multiplier = 0; l.kw = l.kx = l.real_nw = 0;
+      DP_REQUIRE(is_pow2(l.sm_shape[0]) && is_pow2(l.sm_shape[1]) && l.sm_shape[1] == l.sm_shape[2] && l.sm_shape[0] <= (size_t(1) << 20) && l.sm_shape[1] <= (size_t(1) << 20) && l.sm_scalar >= 1 && l.sm_bkm >= (int64_t(1) << 17) && l.sm_bkm < (int64_t(1) << 40)
+                 && l.sm_table_size == dp_ceil_log2((size_t)(l.sm_bkm >> 16)) && l.sm_zero_chunks <= 3 && l.sm_zero_vars <= 22 && (l.sm_zero_chunks == 0) == (l.sm_zero_vars == 0) && l.sm_allowable_error >= 1 && l.sm_allowable_error <= (1 << 11), DP_ERR_ARG, "verifier blob: softmax parameters");
+    }
     if (l.kind == L_LAYERNORM) {
       l.ln_dim_size = l.ncols; l.ln_range_check_bits = l.right_shift; l.ln_top_chunk_scalar_log = l.fp_scale; l.ln_multiplier = l.fixed_point_multiplier; l.ln_eps_bits = (uint32_t)l.intermediate_bit_size;
       l.ncols = 0; l.right_shift = l.fp_scale = l.intermediate_bit_size = 0; l.fixed_point_multiplier = 0;
@@ -2256,9 +2510,12 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
   size_t nt = (size_t)rd(); DP_REQUIRE(nt < 64, DP_ERR_ARG, "verifier blob: tables");
   for (size_t i = 0; i < nt; i++) {
     TableType t; t.kind = (int)rd(); t.size = (unsigned)rd();
-    DP_REQUIRE(t.kind == 0 || t.kind == 2 || t.kind == 3 || t.kind == 7, DP_ERR_ARG, "verifier blob: table kind");
+    DP_REQUIRE(t.kind == 0 || (t.kind >= 2 && t.kind <= 7), DP_ERR_ARG, "verifier blob: table kind");
+    DP_REQUIRE(t.kind != 6 || (t.size >= 1 && t.size <= 22), DP_ERR_ARG, "verifier blob: zero table size");
     if (t.committed_column()) {
-      u64 a = rd(); DP_REQUIRE(a <= 0xFFFFFFFFull && t.size >= 1 && t.size <= 40, DP_ERR_ARG, "verifier blob: table parameters"); t.aux = (uint32_t)a;
+      u64 a = rd(), a2 = rd(); DP_REQUIRE(a <= 0xFFFFFFFFull && t.size <= 40 && a2 < (u64(1) << 40), DP_ERR_ARG, "verifier blob: table parameters"); t.aux = (uint32_t)a; t.aux2 = (int64_t)a2;
+      DP_REQUIRE(t.kind != 5 || (t.aux2 >= 1 && t.aux2 <= (1 << 11)), DP_ERR_ARG, "verifier blob: error table");
+      DP_REQUIRE(t.kind != 4 || (t.size >= 1 && t.size <= 22), DP_ERR_ARG, "verifier blob: softmax table");
       Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = rd(); c.num_vars = (unsigned)rd(); c.is_base = rd() != 0; v.table_comms[t] = c;
     }
     v.tables.push_back(t);

@@ -80,6 +80,11 @@ static Model parse_model(const int64_t* b, size_t n) {
       if (l.ln_range_check_bits == 0 || l.ln_range_check_bits > 40 || l.ln_top_chunk_scalar_log >= 8) throw std::runtime_error("layernorm: range check parameters");
       l.weights.assign(b + pos, b + pos + dim); pos += dim; l.bias.assign(b + pos, b + pos + dim); pos += dim;
     }
+    else if (l.kind == L_SOFTMAX) {  // shape[3], scalar, 1/temperature bits, input scale bits, table size, bkm, zero chunks, zero table vars, allowable error
+      for (int k = 0; k < 3; k++) l.sm_shape[k] = (size_t)rd();
+      l.sm_scalar = rd(); l.sm_temp_bits = (uint32_t)rd(); l.sm_in_scale_bits = (uint32_t)rd(); l.sm_table_size = (unsigned)rd(); l.sm_bkm = rd(); l.sm_zero_chunks = (unsigned)rd(); l.sm_zero_vars = (unsigned)rd(); l.sm_allowable_error = rd();
+      if (l.sm_table_size == 0 || l.sm_table_size > 22 || l.sm_zero_chunks > 3 || l.sm_zero_vars > 22 || l.sm_allowable_error < 1 || l.sm_allowable_error > (1 << 20) || l.sm_scalar < 1 || l.sm_bkm < (1 << 17)) throw std::runtime_error("softmax: parameters");
+    }
     else if (l.kind == L_RELU || l.kind == L_FLATTEN) {}
     else throw std::runtime_error("model blob: unknown layer kind");
     m.layers.push_back(std::move(l));

@@ -172,7 +172,7 @@ static inline LogUpProof logup_batch_prove(const LogUpInput& in, Transcript& t) 
 
 // ------------------------------------------------------------------ model description
 enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8, L_POSITIONAL = 9,
-                 L_MATMUL2 = 10, L_ADD2 = 11, L_CONCAT_MATMUL = 12, L_QKV = 13, L_LAYERNORM = 14 };
+                 L_MATMUL2 = 10, L_ADD2 = 11, L_CONCAT_MATMUL = 12, L_QKV = 13, L_LAYERNORM = 14, L_SOFTMAX = 15 };
 // An edge of the model graph (layers/provable/mod.rs:195-229, Edge): output `index` of node `node`, or input tensor `index` of the model (node < 0)
 struct Wire { int node = -1; int index = 0; };
 struct Layer {
@@ -212,6 +212,12 @@ struct Layer {
   // normalisation dimension; dim_size = N, the multiplier of the inverse-square-root input, the f32 bits of the rescaled epsilon, the bits that
   // are shifted away and range checked, log2 of the scalar of their most significant chunk
   size_t ln_dim_size = 0; int64_t ln_multiplier = 0; uint32_t ln_eps_bits = 0; unsigned ln_range_check_bits = 0, ln_top_chunk_scalar_log = 0;
+  // softmax (layers/transformer/softmax.rs:66-99, QuantisedSoftmaxData / SoftmaxCtx :1153-1169) over the last dimension of a padded
+  // [sm_shape[0]][sm_shape[1]][sm_shape[2]] tensor with a causal mask (the last two dimensions are equal): the multiplier that brings the input to
+  // the scale 2^24, the f32 bits of 1 / temperature and of the input scale (for the row shifts the prover computes in floating point), the
+  // exponential table (2^sm_table_size entries, zero from sm_bkm on), the zero tables of the bits above it, the allowable error of a row sum
+  int64_t sm_scalar = 0, sm_bkm = 0, sm_allowable_error = 0; uint32_t sm_temp_bits = 0, sm_in_scale_bits = 0; unsigned sm_table_size = 0, sm_zero_chunks = 0, sm_zero_vars = 0;
+  size_t sm_shape[3] = {0, 0, 0};
   unsigned right_shift = 0, fp_scale = 0, intermediate_bit_size = 0;  // requant (requant.rs:46-73)
   int64_t fixed_point_multiplier = 0;
   unsigned shift() const { return fp_scale + right_shift; }
@@ -284,15 +290,25 @@ static inline void cm_output_shape(const Layer& l, size_t out[3]) {
 }
 
 struct TableType {  // lookup/context.rs:55-72 (derive Ord: Relu < GELU < Range < Clamping(n) < Softmax < ErrorTable < ZeroTable < InverseSQRT)
-  int kind;  // 0 Relu, 2 Range, 3 Clamping, 7 InverseSQRT
-  unsigned size;      // Clamping: bits; InverseSQRT: range_check_bits
-  uint32_t aux = 0;   // InverseSQRT: eps_bits (InverseSQRTTableData derives Ord on (eps_bits, range_check_bits))
-  bool operator<(const TableType& o) const { return kind != o.kind ? kind < o.kind : aux != o.aux ? aux < o.aux : size < o.size; }
-  bool operator==(const TableType& o) const { return kind == o.kind && size == o.size && aux == o.aux; }
-  unsigned multiplicity_poly_vars() const { return kind == 3 ? size : kind == 7 ? 2 * (BIT_LEN - 1) + 1 : BIT_LEN; }  // context.rs:481-492
-  const char* challenge_label() const { return kind == 0 ? "Relu" : kind == 3 ? "Clamping" : kind == 7 ? "InverseSQRT" : nullptr; }
-  bool has_committed_column() const { return kind == 7; }  // committed_columns (context.rs:495-545): the output column
+  int kind;  // 0 Relu, 2 Range, 3 Clamping, 4 Softmax, 5 ErrorTable, 6 ZeroTable, 7 InverseSQRT
+  unsigned size;      // Clamping: bits; Softmax: table_size; ZeroTable: bits; InverseSQRT: range_check_bits
+  uint32_t aux = 0;   // InverseSQRT: eps_bits (InverseSQRTTableData derives Ord on (eps_bits, range_check_bits)); Softmax: float_bits
+  int64_t aux2 = 0;   // Softmax: bkm (SoftmaxTableData orders by (float_bits, table_size, bkm)); ErrorTable(4096, allowable_error): the error
+  bool operator<(const TableType& o) const { return kind != o.kind ? kind < o.kind : aux != o.aux ? aux < o.aux : size != o.size ? size < o.size : aux2 < o.aux2; }
+  bool operator==(const TableType& o) const { return kind == o.kind && size == o.size && aux == o.aux && aux2 == o.aux2; }
+  unsigned multiplicity_poly_vars() const { return kind == 3 || kind == 4 || kind == 6 ? size : kind == 5 ? ceil_log2((size_t)(2 * aux2)) : kind == 7 ? 2 * (BIT_LEN - 1) + 1 : BIT_LEN; }  // context.rs:481-492
+  const char* challenge_label() const { return kind == 0 ? "Relu" : kind == 3 ? "Clamping" : kind == 4 ? "Softmax" : kind == 6 ? "Zero" : kind == 7 ? "InverseSQRT" : nullptr; }
+  bool has_committed_column() const { return kind == 7 || kind == 4 || kind == 5; }  // committed_columns (context.rs:495-545): the output column (ErrorTable: its only column)
 };
+constexpr unsigned SM_LOG_SCALE = 24; constexpr int64_t SM_OUT_ONE = 1 << 12;  // softmax.rs:56-60
+// SoftmaxTableData::table_output (lookup/context.rs:111-122), f32 exp as there
+static inline int64_t softmax_table_output(uint32_t temp_bits, int64_t bkm, int64_t j) {
+  float temp; std::memcpy(&temp, &temp_bits, 4);
+  const int64_t prod = (int64_t(1) << (SM_LOG_SCALE - 8)) * j;
+  if (prod >= bkm) return 0;
+  const float e = std::exp((float)(-prod) / ((float)(1u << SM_LOG_SCALE) * temp));
+  return (int64_t)std::round(e * (float)SM_OUT_ONE);
+}
 constexpr unsigned LOG_LAYERNORM_SCALE_FACTOR = 24, LOG_LAYERNORM_OUTPUT_SCALE_FACTOR = 10;  // layernorm.rs:61-65
 // InverseSQRTTableData::table_output (lookup/context.rs:147-157): f32 arithmetic, `as Element` of a NaN (negative argument) is 0
 static inline int64_t inv_sqrt_table_output(uint32_t eps_bits, unsigned range_check_bits, int64_t j) {
@@ -317,6 +333,17 @@ static inline void table_columns(const TableType& tt, std::vector<int64_t>& merg
   } else if (tt.kind == 2) {
     cols.resize(1);
     for (int64_t i = 0; i < (int64_t(1) << BIT_LEN); i++) { merged.push_back(i); cols[0].push_back(from_i64(i)); }
+  } else if (tt.kind == 4) {  // context.rs:232-247
+    cols.resize(2);
+    for (int64_t j = 0; j < (int64_t(1) << tt.size); j++) { int64_t o = softmax_table_output(tt.aux, tt.aux2, j); merged.push_back(j + o * COLUMN_SEPARATOR); cols[0].push_back(from_i64(j)); cols[1].push_back(from_i64(o)); }
+  } else if (tt.kind == 5) {  // context.rs:248-264: quant_one - error ..= quant_one + error, cut / zero padded to 2^ceil_log2(2 error) entries
+    cols.resize(1);
+    const size_t n = size_t(1) << ceil_log2((size_t)(2 * tt.aux2));
+    for (int64_t v = SM_OUT_ONE - tt.aux2; v <= SM_OUT_ONE + tt.aux2 && merged.size() < n; v++) { merged.push_back(v); cols[0].push_back(from_i64(v)); }
+    while (merged.size() < n) { merged.push_back(0); cols[0].push_back(0); }
+  } else if (tt.kind == 6) {  // context.rs:265-279
+    cols.resize(2);
+    for (int64_t i = 0; i < (int64_t(1) << tt.size); i++) { int64_t o = i != 0 ? 0 : 1; merged.push_back(i + o * COLUMN_SEPARATOR); cols[0].push_back(from_i64(i)); cols[1].push_back(from_i64(o)); }
   } else if (tt.kind == 7) {  // context.rs:280-294
     cols.resize(2);
     int64_t mx = int64_t(1) << (2 * (BIT_LEN - 1));
@@ -455,6 +482,52 @@ static inline std::vector<int64_t> layernorm_op(const Layer& l, const std::vecto
   }
   return o;
 }
+static inline TableType softmax_table(const Layer& l) { TableType t{4, l.sm_table_size}; t.aux = l.sm_temp_bits; t.aux2 = l.sm_bkm; return t; }
+static inline TableType softmax_error_table(const Layer& l) { TableType t{5, 0}; t.aux2 = l.sm_allowable_error; return t; }
+// Softmax::evaluate on Elements (softmax.rs:455-566) with calculate_shift_data (:250-320) and the causal AttentionMask (:1590-1750)
+struct SoftmaxData {
+  std::vector<int64_t> shift, shifted_input, tril, bias, low, high, exp_in, exp_out;
+  std::vector<std::vector<int64_t>> zero_in, zero_out;
+};
+static inline std::vector<int64_t> softmax_op(const Layer& l, const std::vector<int64_t>& x, SoftmaxData* out) {
+  const size_t C = l.sm_shape[0], R = l.sm_shape[1], K = l.sm_shape[2];
+  if (!C || !R || R != K || x.size() != C * R * K) throw std::runtime_error("softmax: shapes");
+  float inv_temp, in_scale; std::memcpy(&inv_temp, &l.sm_temp_bits, 4); std::memcpy(&in_scale, &l.sm_in_scale_bits, 4);
+  SoftmaxData d;
+  const int64_t neg_inf = -(((l.sm_bkm >> 16) + 1) << 16);
+  for (size_t i = 0; i < C * R; i++) {  // the shift of every row: -ln(sum of the exponentials of its unmasked entries), in the scale 2^24
+    const int64_t* row = &x[i * K]; const size_t take = i % R + 1;
+    if (i % R == 0) { d.shift.push_back(-row[0] * l.sm_scalar); continue; }
+    int64_t mx = row[0]; for (size_t j = 1; j < take; j++) mx = std::max(mx, row[j]);
+    float sum = 0.0f;
+    for (size_t j = 0; j < take; j++) sum += std::exp(((float)(row[j] - mx) * in_scale) / inv_temp);
+    const float log_sum = std::log(sum);
+    d.shift.push_back(-(int64_t)std::round((float)(1u << SM_LOG_SCALE) * inv_temp * log_sum) - mx * l.sm_scalar);
+  }
+  d.tril.resize(x.size()); d.bias.resize(x.size()); d.shifted_input.resize(x.size());
+  for (size_t i = 0; i < C * R; i++) for (size_t j = 0; j < K; j++) {
+    const bool keep = j <= i % R;
+    d.tril[i * K + j] = keep ? 1 : 0; d.bias[i * K + j] = keep ? 0 : neg_inf;
+    d.shifted_input[i * K + j] = x[i * K + j] * l.sm_scalar + d.shift[i];
+  }
+  const unsigned tv = ceil_log2((size_t)(l.sm_bkm >> 16));
+  if (tv != l.sm_table_size) throw std::runtime_error("softmax: table size and bkm disagree");
+  const int64_t tmask = (int64_t(1) << tv) - 1, zmask = (int64_t(1) << l.sm_zero_vars) - 1;
+  d.zero_in.resize(l.sm_zero_chunks); d.zero_out.resize(l.sm_zero_chunks);
+  std::vector<int64_t> o;
+  for (size_t q = 0; q < x.size(); q++) {
+    const int64_t masked = d.shifted_input[q] * d.tril[q] + d.bias[q];
+    int64_t r = masked < 0 ? -masked : masked;
+    d.low.push_back(r & 255); r >>= 8; d.high.push_back(r & 255); r >>= 8;
+    const int64_t lk = r & tmask, ev = softmax_table_output(l.sm_temp_bits, l.sm_bkm, lk);
+    d.exp_in.push_back(lk); d.exp_out.push_back(ev); r >>= tv;
+    int64_t acc = ev;
+    for (unsigned z = 0; z < l.sm_zero_chunks; z++) { const int64_t zi = r & zmask, zo = zi != 0 ? 0 : 1; d.zero_in[z].push_back(zi); d.zero_out[z].push_back(zo); r >>= l.sm_zero_vars; acc *= zo; }
+    o.push_back(acc);
+  }
+  if (out) *out = std::move(d);
+  return o;
+}
 static inline int64_t requant_apply(const Layer& l, int64_t v) {
   unsigned sh = l.shift();
   int64_t tmp = v * l.fixed_point_multiplier + (int64_t(1) << (sh - 1));
@@ -552,6 +625,7 @@ static inline Trace run_model(const Model& m, const std::vector<int64_t>& input)
       }
     } else if (l.kind == L_RELU) { for (int64_t v : cur) o.push_back(relu_apply(v)); }
     else if (l.kind == L_LAYERNORM) o = layernorm_op(l, cur, nullptr);
+    else if (l.kind == L_SOFTMAX) o = softmax_op(l, cur, nullptr);
     else if (l.kind == L_CONV) { tr.conv.resize(m.layers.size()); o = conv_op(l, cur, tr.conv[tr.in.size() - 1]); }
     else if (l.kind == L_MAXPOOL) o = maxpool_op(l, cur);
     else if (l.kind == L_FLATTEN) o = cur;
@@ -605,6 +679,11 @@ static inline Context context_generate(const Model& m) {
     if (l.kind == L_REQUANT) { add_table({2, 0}); add_table({3, l.clamping_size()}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
     else if (l.kind == L_RELU) { add_table({0, 0}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
     else if (l.kind == L_LAYERNORM) { add_table({2, 0}); add_table(layernorm_table(l)); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }  // layernorm.rs:587-618
+    else if (l.kind == L_SOFTMAX) {  // softmax.rs:1205-1245
+      add_table({2, 0}); add_table(softmax_table(l)); add_table(softmax_error_table(l));
+      if (l.sm_zero_vars) add_table({6, l.sm_zero_vars});
+      max_poly_len = std::max(max_poly_len, next_pow2(cur_len));
+    }
     else if (l.kind == L_CONV) { cur_len = l.kw * l.nw * l.nw; }                                                       // convolution.rs:506-511
     else if (l.kind == L_MAXPOOL) { add_table({2, 0}); cur_len = l.pin[0] * (l.pin[1] / 2) * (l.pin[2] / 2); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }  // pooling.rs:131-166
   }
@@ -647,7 +726,7 @@ static inline Context context_generate(const Model& m) {
   for (auto& t : tset) if (t.has_committed_column()) {
     std::vector<int64_t> merged; std::vector<std::vector<u64>> cols;
     table_columns(t, merged, cols);
-    Mle poly = Mle::from_base(cols[1]);
+    Mle poly = Mle::from_base(cols.back());  // (the output column; the only column of an ErrorTable)
     ctx.table_comms[t] = {pcs_commit(ctx.pp, poly), poly};
   }
   return ctx;
@@ -680,7 +759,9 @@ struct ConvProof {  // convolution.rs:98-127, fields in declaration order
 struct PoolingProof { IOPProof sumcheck; LogUpProof lookup; std::vector<E> zerocheck_evals; size_t variable_gap = 0; std::vector<Commitment> commitments; };  // pooling.rs:60-76
 // LayerNormProof (layernorm.rs:644-667), fields in declaration order
 struct LayerNormProof { std::vector<LogUpProof> logup_proofs; std::vector<Commitment> commitments; IOPProof accumulation_proof, io_proof, input_proof; std::vector<E> acc_evals, evaluations; E gamma_eval, beta_eval; };
-struct LayerProof { LayerKind kind; DenseProof dense; MatMulProof matmul; AddProof add; PositionalProof pos; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; ConcatMatMulProof cmm; QKVProof qkv; LayerNormProof ln; };
+// SoftmaxProof (softmax.rs:102-117)
+struct SoftmaxProof { std::vector<LogUpProof> logup_proofs; std::vector<Commitment> commitments; IOPProof accumulation_proof, mask_proof; std::vector<E> evaluations; };
+struct LayerProof { LayerKind kind; DenseProof dense; MatMulProof matmul; AddProof add; PositionalProof pos; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; ConcatMatMulProof cmm; QKVProof qkv; LayerNormProof ln; SoftmaxProof sm; };
 struct TableProof { Commitment multiplicity_commit; LogUpProof lookup; };
 struct Proof {
   std::map<size_t, LayerProof> steps;  // canonical order: ascending NodeId
@@ -758,6 +839,30 @@ static inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       LogUpWitness wr; wr.is_table = false; wr.columns_per_instance = 1; wr.table_type = rt;
       for (auto& ch : chunks) { std::vector<u64> ev = to_base(ch); Mle mle = Mle::from_base(ev); wr.commits.push_back({pcs_commit(ctx.pp, mle), mle}); wr.column_evals.push_back(ev); }
       ps.lookup_witness[id] = {wi, wr};
+    } else if (l.kind == L_SOFTMAX) {  // Softmax::lookup_witness (softmax.rs:890-1066)
+      SoftmaxData d; std::vector<int64_t> out = softmax_op(l, tr.in[id], &d);
+      const size_t K = l.sm_shape[2];
+      std::vector<int64_t> row_sums;
+      for (size_t i = 0; i < out.size() / K; i++) { int64_t a = 0; for (size_t j = 0; j < K; j++) a += out[i * K + j]; row_sums.push_back(a); }
+      TableType st = softmax_table(l), rt{2, 0}, et = softmax_error_table(l), zt{6, l.sm_zero_vars};
+      for (int64_t v : d.low) count_into(element_count[rt], v);
+      for (int64_t v : d.high) count_into(element_count[rt], v);
+      for (size_t i = 0; i < d.exp_in.size(); i++) count_into(element_count[st], d.exp_in[i] + d.exp_out[i] * COLUMN_SEPARATOR);
+      for (int64_t v : row_sums) count_into(element_count[et], v);
+      auto witness = [&](const std::vector<const std::vector<int64_t>*>& cols, size_t cpi, TableType tt) {
+        LogUpWitness w; w.is_table = false; w.columns_per_instance = cpi; w.table_type = tt;
+        for (auto* col : cols) { std::vector<u64> ev = to_base(*col); Mle mle = Mle::from_base(ev); w.commits.push_back({pcs_commit(ctx.pp, mle), mle}); w.column_evals.push_back(ev); }
+        return w;
+      };
+      std::vector<LogUpWitness> ws = {witness({&d.exp_in, &d.exp_out}, 2, st), witness({&d.low, &d.high}, 1, rt)};
+      { LogUpWitness w; w.is_table = false; w.columns_per_instance = 1; w.table_type = et;  // the row sums are looked up, the SHIFT polynomial is what is committed here
+        Mle shift = Mle::from_base(to_base(d.shift)); w.commits.push_back({pcs_commit(ctx.pp, shift), shift}); w.column_evals.push_back(to_base(row_sums)); ws.push_back(w); }
+      if (l.sm_zero_chunks) {
+        std::vector<const std::vector<int64_t>*> cols;
+        for (unsigned z = 0; z < l.sm_zero_chunks; z++) { cols.push_back(&d.zero_in[z]); cols.push_back(&d.zero_out[z]); for (size_t i = 0; i < d.zero_in[z].size(); i++) count_into(element_count[zt], d.zero_in[z][i] + d.zero_out[z][i] * COLUMN_SEPARATOR); }
+        ws.push_back(witness(cols, 2, zt));
+      }
+      ps.lookup_witness[id] = ws;
     } else if (l.kind == L_MAXPOOL) {  // Pooling::gen_lookup_witness (pooling.rs:206-262)
       TableType rt{2, 0};
       std::vector<std::vector<int64_t>> diffs = maxpool_diff_polys(l, tr.in[id], tr.out[id]);
@@ -1195,6 +1300,68 @@ static inline Claim prove_layernorm(ProverState& ps, size_t id, const Layer& l, 
   return input_claim;
 }
 
+// Softmax::prove_step (softmax.rs:573-888). Lookups: (input, output) of the exponential table, the two low bytes, the row sums against the table
+// of values within the allowable error of one, the bits above the exponential's input against the zero table. One sumcheck brings every
+// lookup claim to a single point and ties the output claim to exp_out * prod zero_out and the row sums to the same product (1/2 in the
+// coordinates of the normalisation dimension, times 2^k); a second one shows the masked input is shifted_input * tril + bias.
+// The claim handed on is the one the VERIFIER derives, (shifted - shift) / scalar (:1541-1543); the reference's prover returns the same value
+// without the division (:748-749), which no later prover reads.
+static inline Claim prove_softmax(ProverState& ps, size_t id, const Layer& l, const Claim& last, const std::vector<int64_t>& input) {
+  SoftmaxData d; softmax_op(l, input, &d);
+  std::vector<LogUpWitness> ws = ps.lookup_witness.at(id);
+  const bool zero = l.sm_zero_chunks != 0;
+  if (ws.size() != (zero ? 4u : 3u)) throw std::runtime_error("softmax: lookup witnesses");
+  SoftmaxProof pr;
+  for (auto& w : ws) pr.logup_proofs.push_back(logup_batch_prove(ps.logup_input(w), *ps.t));
+  const std::vector<E> exp_point = pr.logup_proofs[0].output_claims.at(0).point, range_point = pr.logup_proofs[1].output_claims.at(0).point, error_point = pr.logup_proofs[2].output_claims.at(0).point;
+  const size_t extra = exp_point.size() - error_point.size();
+  const E two_inv = einv(e_from_u64(2)), two_mult = e_from_u64(u64(1) << extra);
+  std::vector<E> full_error(extra, two_inv); full_error.insert(full_error.end(), error_point.begin(), error_point.end());
+  const E alpha = ps.t->get_and_append_challenge("batching_challenge");
+  MleP exp_beta = mk(Mle::from_ext(compute_betas_eval(exp_point))), range_beta = mk(Mle::from_ext(compute_betas_eval(range_point)));
+  MleP error_beta = mk(Mle::from_ext(compute_betas_eval(full_error))), last_beta = mk(Mle::from_ext(compute_betas_eval(last.point)));
+  VirtualPolynomial vp((unsigned)exp_point.size());
+  E bc = e_one();
+  for (auto& c : ws[0].commits) { vp.add_mle_list({mk(c.second), exp_beta}, bc); bc = emul(bc, alpha); }
+  for (auto& c : ws[1].commits) { vp.add_mle_list({mk(c.second), range_beta}, bc); bc = emul(bc, alpha); }
+  const Mle& exp_output = ws[0].commits[1].second;
+  if (zero) {
+    MleP zbeta = mk(Mle::from_ext(compute_betas_eval(pr.logup_proofs[3].output_claims.at(0).point)));
+    for (auto& c : ws[3].commits) { vp.add_mle_list({zbeta, mk(c.second)}, bc); bc = emul(bc, alpha); }
+    std::vector<MleP> prod; for (size_t q = 1; q < ws[3].commits.size(); q += 2) prod.push_back(mk(ws[3].commits[q].second));
+    prod.push_back(mk(exp_output));
+    std::vector<MleP> err = prod, outp = prod; err.push_back(error_beta); outp.push_back(last_beta);
+    vp.add_mle_list(err, emul(bc, two_mult));
+    vp.add_mle_list(outp, emul(bc, alpha));
+  } else {
+    vp.add_mle_list({mk(exp_output), error_beta}, emul(bc, two_mult));
+    vp.add_mle_list({mk(exp_output), last_beta}, emul(bc, alpha));
+  }
+  std::vector<E> all;
+  { auto [proof, st] = sumcheck_prove(std::move(vp), *ps.t); pr.accumulation_proof = proof; all = st.final_evaluations(); }
+  const std::vector<E> sc_point = pr.accumulation_proof.point;
+  // the mask: eq(sc_point, x) (shifted_input(x) tril(x) + bias(x))
+  E shifted_eval;
+  {
+    MleP meq = mk(Mle::from_ext(compute_betas_eval(sc_point)));
+    VirtualPolynomial mv((unsigned)sc_point.size());
+    mv.add_mle_list({mk(Mle::from_i64(d.shifted_input)), mk(Mle::from_i64(d.tril)), meq}, e_one());
+    mv.add_mle_list({mk(Mle::from_i64(d.bias)), meq}, e_one());
+    auto [proof, st] = sumcheck_prove(std::move(mv), *ps.t);
+    pr.mask_proof = proof; shifted_eval = st.final_evaluations()[0];
+  }
+  const ProverCommitment& shift_c = ws[2].commits[0];
+  const std::vector<E> shift_point(pr.mask_proof.point.begin() + (pr.mask_proof.point.size() - shift_c.second.nv), pr.mask_proof.point.end());
+  const E shift_eval = shift_c.second.evaluate(shift_point);
+  const std::vector<E> evs4 = {all[0], all[2], all[3], all[5]};
+  for (size_t q = 0; q < 4; q++) { const ProverCommitment& c = q < 2 ? ws[0].commits[q] : ws[1].commits[q - 2]; ps.add_witness_claim(c, {sc_point, evs4[q]}); pr.commitments.push_back(c.first.pure()); pr.evaluations.push_back(evs4[q]); }
+  ps.add_witness_claim(shift_c, {shift_point, shift_eval}); pr.commitments.push_back(shift_c.first.pure()); pr.evaluations.push_back(shift_eval);
+  if (zero) for (size_t q = 0; q < ws[3].commits.size(); q++) { ps.add_witness_claim(ws[3].commits[q], {sc_point, all[7 + q]}); pr.commitments.push_back(ws[3].commits[q].first.pure()); pr.evaluations.push_back(all[7 + q]); }
+  const std::vector<E> mask_point = pr.mask_proof.point;
+  LayerProof lp; lp.kind = L_SOFTMAX; lp.sm = pr; ps.proofs[id] = lp;
+  return {mask_point, emul(esub(shifted_eval, shift_eval), einv(e_from_i64(l.sm_scalar)))};
+}
+
 // ------------------------------------------------------------------ convolution (zkCNN FFT protocol)
 // phi_pow_init (iop/prover.rs:214-227): powers of the 2^n-th root of unity (inverted when `is_fft`)
 static inline std::vector<E> phi_pow_init(unsigned n, bool is_fft) {
@@ -1475,6 +1642,7 @@ static inline Proof prove(const Context& ctx, const Trace& tr, Transcript& t) {
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
     else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, to_fields(tr.out[id]));
     else if (l.kind == L_LAYERNORM) cur = prove_layernorm(ps, id, l, cur, to_fields(tr.in[id]));
+    else if (l.kind == L_SOFTMAX) cur = prove_softmax(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv[id]);
     else if (l.kind == L_MAXPOOL) cur = prove_pooling(ps, id, l, cur, to_fields(tr.out[id]));
     // L_FLATTEN is not provable: the claim is propagated unchanged (iop/prover.rs:449-456)
@@ -1567,6 +1735,11 @@ static inline std::vector<u64> serialize_proof(const Proof& p) {
       w.u(q.logup_proofs.size()); for (auto& x : q.logup_proofs) w.logup(x);
       w.u(q.commitments.size()); for (auto& c : q.commitments) w.comm(c);
       w.iop(q.accumulation_proof); w.iop(q.io_proof); w.iop(q.input_proof); w.ve(q.acc_evals); w.ve(q.evaluations); w.e(q.gamma_eval); w.e(q.beta_eval);
+    } else if (lp.kind == L_SOFTMAX) {
+      const SoftmaxProof& q = lp.sm;
+      w.u(q.logup_proofs.size()); for (auto& x : q.logup_proofs) w.logup(x);
+      w.u(q.commitments.size()); for (auto& c : q.commitments) w.comm(c);
+      w.iop(q.accumulation_proof); w.iop(q.mask_proof); w.ve(q.evaluations);
     } else if (lp.kind == L_MAXPOOL) {
       w.iop(lp.pool.sumcheck); w.logup(lp.pool.lookup); w.ve(lp.pool.zerocheck_evals); w.u(lp.pool.variable_gap);
       w.u(lp.pool.commitments.size()); for (auto& c : lp.pool.commitments) w.comm(c);

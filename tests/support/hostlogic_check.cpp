@@ -39,6 +39,7 @@ static orc::Model to_orc(const dp::ModelSpec& m) {
     for (auto& e : l.inputs) { orc::Wire w; w.node = e.from; w.index = e.slot; x.inputs.push_back(w); }
     for (int d = 0; d < 3; d++) { x.cm_a[d] = l.cm_a[d]; x.cm_b[d] = l.cm_b[d]; x.cm_left[d] = l.cm_left[d]; x.cm_right[d] = l.cm_right[d]; } x.cm_perm = l.cm_perm; x.nrows = l.nrows; x.ncols = l.ncols; x.weights = l.weights; x.bias = l.bias; x.transpose_b = l.mm_transpose; x.add_left = l.add_left; x.add_right = l.add_right; x.right_shift = l.right_shift; x.fp_scale = l.fp_scale; x.intermediate_bit_size = l.intermediate_bit_size; x.fixed_point_multiplier = l.fixed_point_multiplier;
     x.kw = l.kw; x.kx = l.kx; x.real_nw = l.real_nw; x.nw = l.nw; for (int k = 0; k < 3; k++) { x.unp_out[k] = l.unp_out[k]; x.pin[k] = l.pin[k]; }
+    x.sm_scalar = l.sm_scalar; x.sm_bkm = l.sm_bkm; x.sm_allowable_error = l.sm_allowable_error; x.sm_temp_bits = l.sm_temp_bits; x.sm_in_scale_bits = l.sm_in_scale_bits; x.sm_table_size = l.sm_table_size; x.sm_zero_chunks = l.sm_zero_chunks; x.sm_zero_vars = l.sm_zero_vars; for (int k = 0; k < 3; k++) x.sm_shape[k] = l.sm_shape[k];
     x.ln_dim_size = l.ln_dim_size; x.ln_multiplier = l.ln_multiplier; x.ln_eps_bits = l.ln_eps_bits; x.ln_range_check_bits = l.ln_range_check_bits; x.ln_top_chunk_scalar_log = l.ln_top_chunk_scalar_log;
     o.layers.push_back(x); }
   return o;
@@ -91,6 +92,28 @@ static dp::ModelSpec graph_model(int variant, std::vector<int64_t>& in) {
     dp::LayerSpec ad; ad.kind = dp::L_ADD2; ad.add_left = 1; ad.add_right = 2; ad.inputs = {edge(0, 1), edge(0, 2)};
     m.layers = {q, ad};
     m.outputs = {edge(0, 0), edge(1, 0)};
+    in.resize(m.input_len); for (auto& x : in) x = rq();
+  } else if (variant == 7 || variant == 8) {
+    // Softmax over the rows of [heads][n][n] attention scores under the causal mask, quantised as Softmax::quantise does (softmax.rs:153-233;
+    // temperature 1, input scale 1/127 resp. 8/127: the second needs zero tables for the high bits of the shifted inputs)
+    const size_t H = 2, N = 8;
+    m.input_len = H * N * N;
+    dp::LayerSpec sm; sm.kind = dp::L_SOFTMAX; sm.sm_shape[0] = H; sm.sm_shape[1] = N; sm.sm_shape[2] = N;
+    const float in_scale = (variant == 8 ? 8.0f : 1.0f) / 127.0f, inv_temp = 1.0f, in_max = 127.0f * in_scale, max_ctx = (float)N, sf = (float)(1u << 24), osf = 4096.0f;
+    sm.sm_scalar = (int64_t)std::llround((double)(sf * in_scale));
+    const int64_t max_shift = (int64_t)std::round(-sf * (inv_temp * std::log(max_ctx) + in_max));
+    const int64_t min_in = -127 * sm.sm_scalar + max_shift, sig_min = min_in >> 16;
+    const unsigned min_bits = dp::dp_ceil_log2((size_t)(-sig_min));
+    // calc_softmax_error (softmax.rs:323-345)
+    const float bkm_f = sf * inv_temp * (std::log(2.0f * max_ctx) + std::log(osf)) / 2.0f;
+    const float cd = sf * inv_temp, c = (std::exp((float)(1 << 16) / cd) + std::exp(bkm_f / cd) / (2.0f * osf)) - 1.0f;
+    const float err = std::fabs(c * std::exp(1.0f / (2.0f * sf * inv_temp)) + (max_ctx - 1.0f) * std::exp(-bkm_f / sf * inv_temp));
+    sm.sm_bkm = (int64_t)std::round(bkm_f); sm.sm_table_size = dp::dp_ceil_log2((size_t)(sm.sm_bkm >> 16));
+    if (min_bits > sm.sm_table_size) { const unsigned rem = min_bits - sm.sm_table_size; sm.sm_zero_chunks = (rem - 1) / sm.sm_table_size + 1; sm.sm_zero_vars = sm.sm_zero_chunks == 1 ? rem : sm.sm_table_size; }
+    sm.sm_allowable_error = (int64_t)std::round(err * osf);
+    { uint32_t b; memcpy(&b, &inv_temp, 4); sm.sm_temp_bits = b; memcpy(&b, &in_scale, 4); sm.sm_in_scale_bits = b; }
+    fprintf(stderr, "softmax: multiplier %lld bkm %lld table 2^%u zero chunks %u x %u bits, allowable error %lld\n", (long long)sm.sm_scalar, (long long)sm.sm_bkm, sm.sm_table_size, sm.sm_zero_chunks, sm.sm_zero_vars, (long long)sm.sm_allowable_error);
+    m.layers = {sm};
     in.resize(m.input_len); for (auto& x : in) x = rq();
   } else if (variant == 5 || variant == 6) {
     // LayerNorm over the last dimension of a [rows][dim] tensor, then the shift-only Requant the reference puts behind it (layernorm.rs:140-257,
