@@ -6,7 +6,7 @@ import math
 import numpy as np
 
 L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_FLATTEN, L_MATMUL, L_ADD, L_EMBED, L_POSITIONAL = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
-L_LAYERNORM = 14
+L_LAYERNORM, L_SOFTMAX = 14, 15
 L_MATMUL2, L_ADD2, L_CONCAT_MATMUL, L_QKV = 10, 11, 12, 13  # nodes of a model GRAPH: two-input MatMul / Add, ConcatMatMul, QKV
 BIT_LEN = 8
 FIXED_POINT_SCALE = 25  # zkml/src/layers/requant.rs:47
@@ -53,6 +53,93 @@ def inv_sqrt_table_output(eps_bits, range_check_bits, j):
     fl = np.floor(a)
     r = np.where(a - fl >= np.float32(0.5), fl + 1, fl) * np.sign(x)
     return np.where(np.isnan(r), 0, r).astype(np.int64)
+
+
+def _libm():
+    """expf / logf of the C library: the quantised Softmax computes its table and its row shifts in f32 with the platform's libm (Rust's
+    f32::exp / ln call the same functions), so the numpy restatement must not use numpy's own vectorised exp / log"""
+    import ctypes
+    import ctypes.util
+    if not hasattr(_libm, "lib"):
+        lib = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+        for f in (lib.expf, lib.logf):
+            f.restype, f.argtypes = ctypes.c_float, [ctypes.c_float]
+        _libm.lib = lib
+    return _libm.lib
+
+
+def _round_away(x):
+    """f32::round: half away from zero"""
+    x = np.float32(x)
+    a = np.floor(np.abs(x))
+    return int((a + 1 if np.abs(x) - a >= np.float32(0.5) else a) * (1 if x >= 0 else -1))
+
+
+def softmax_params(in_scale, max_context, temperature=1.0):
+    """Softmax::quantise (zkml/src/layers/transformer/softmax.rs:153-233) with calc_softmax_error (:323-345), f32 arithmetic: the multiplier
+    to the scale 2^24, bkm (inputs beyond it are mapped to zero), the size of the exponential table, the zero tables for the remaining
+    high bits, the allowable error of a row sum"""
+    f = np.float32
+    sf, osf, inv_temp, in_scale, ctx = f(1 << 24), f(1 << 12), f(1.0) / f(temperature), f(in_scale), f(max_context)
+    scalar = _round_away(sf * in_scale)
+    max_shift = _round_away(-sf * (inv_temp * np.log(ctx) + f(127) * in_scale))
+    sig_min = (-127 * scalar + max_shift) >> 16
+    min_bits = (abs(sig_min) - 1).bit_length()
+    bkm_f = sf * inv_temp * (np.log(f(2) * ctx) + np.log(osf)) / f(2)
+    cd = sf * inv_temp
+    c = (np.exp(f(1 << 16) / cd) + np.exp(bkm_f / cd) / (f(2) * osf)) - f(1)
+    err = abs(c * np.exp(f(1) / (f(2) * sf * inv_temp)) + (ctx - f(1)) * np.exp(-bkm_f / sf * inv_temp))
+    bkm = _round_away(bkm_f)
+    table_size = ((bkm >> 16) - 1).bit_length()
+    zero_chunks = zero_vars = 0
+    if min_bits > table_size:
+        rem = min_bits - table_size
+        zero_chunks = (rem - 1) // table_size + 1
+        zero_vars = rem if zero_chunks == 1 else table_size
+    return dict(scalar=scalar, temp_bits=int(np.array([inv_temp], dtype=np.float32).view(np.uint32)[0]), in_scale_bits=int(np.array([in_scale], dtype=np.float32).view(np.uint32)[0]),
+                table_size=table_size, bkm=bkm, zero_chunks=zero_chunks, zero_vars=zero_vars, allowable_error=_round_away(f(err) * osf))
+
+
+def softmax_table_output(l, j):
+    """SoftmaxTableData::table_output (zkml/src/lookup/context.rs:111-122)"""
+    prod = (1 << 16) * int(j)
+    if prod >= l["bkm"]:
+        return 0
+    temp = np.array([l["temp_bits"]], dtype=np.uint32).view(np.float32)[0]
+    return _round_away(np.float32(_libm().expf(np.float32(-prod) / (np.float32(1 << 24) * temp))) * np.float32(1 << 12))
+
+
+def softmax_apply(l, x):
+    """Softmax::evaluate on quantised values (softmax.rs:455-566; calculate_shift_data :250-320; the causal AttentionMask :1590-1750) -> output"""
+    m = _libm()
+    C, R, K = l["shape"]
+    x = np.asarray(x, dtype=np.int64).reshape(C * R, K)
+    inv_temp, in_scale = (np.array([l[k]], dtype=np.uint32).view(np.float32)[0] for k in ("temp_bits", "in_scale_bits"))
+    neg_inf = -(((l["bkm"] >> 16) + 1) << 16)
+    tmask, zmask = (1 << l["table_size"]) - 1, (1 << l["zero_vars"]) - 1
+    lut = {}
+    out = np.zeros_like(x)
+    for i in range(C * R):
+        take = i % R + 1
+        row = [int(v) for v in x[i]]
+        if i % R == 0:
+            shift = -row[0] * l["scalar"]
+        else:
+            mx = max(row[:take])
+            total = np.float32(0)
+            for v in row[:take]:
+                total = np.float32(total + np.float32(m.expf(np.float32(np.float32(v - mx) * in_scale) / inv_temp)))
+            shift = -_round_away(np.float32(1 << 24) * inv_temp * np.float32(m.logf(total))) - mx * l["scalar"]
+        for j in range(K):
+            r = abs(row[j] * l["scalar"] + shift if j < take else neg_inf) >> 16
+            key = r & tmask
+            if key not in lut:
+                lut[key] = softmax_table_output(l, key)
+            o, r = lut[key], r >> l["table_size"]
+            for _ in range(l["zero_chunks"]):
+                o, r = (o if (r & zmask) == 0 else 0), r >> l["zero_vars"]
+            out[i, j] = o
+    return out.reshape(-1)
 
 
 def layernorm_apply(l, x):
@@ -189,6 +276,13 @@ class ModelBuilder:
             self.layers.append(dict(kind=L_REQUANT, right_shift=right_shift, fp_scale=fp_scale, fixed_point_multiplier=1 << fp_scale, intermediate_bit_size=ibs))
         return self
 
+    def softmax(self, in_scale=1.0 / 127.0, temperature=1.0):
+        """Softmax over the last dimension of [heads][n][n] attention scores under the causal mask (layers/transformer/softmax.rs), quantised as
+        Softmax::quantise does; the output has the scale 2^-12"""
+        assert len(self.shape_og) == 3 and self.shape_pad[1] == self.shape_pad[2], "softmax needs a [heads, n, n] activation"
+        self.layers.append(dict(kind=L_SOFTMAX, shape=self.shape_pad, **softmax_params(in_scale, self.shape_pad[2], temperature)))
+        return self
+
     def embeddings(self, vocab, emb):
         """Embeddings (layers/transformer/embeddings.rs): the first layer of a model whose input is a vector of token ids; the table is
         [vocab][emb], both padded to powers of two; the output is the [tokens][emb] matrix of the looked-up rows (no requant: the
@@ -306,6 +400,8 @@ class ModelBuilder:
                 parts.append(l["bias"])
             elif l["kind"] == L_MAXPOOL:
                 parts.append(np.array([L_MAXPOOL, *l["pin"]], dtype=np.int64))
+            elif l["kind"] == L_SOFTMAX:
+                parts.append(np.array([L_SOFTMAX, *l["shape"], l["scalar"], l["temp_bits"], l["in_scale_bits"], l["table_size"], l["bkm"], l["zero_chunks"], l["zero_vars"], l["allowable_error"]], dtype=np.int64))
             elif l["kind"] == L_LAYERNORM:
                 parts.append(np.array([L_LAYERNORM, l["dim"], l["dim_size"], l["multiplier"], l["eps_bits"], l["range_check_bits"], l["top_chunk_scalar_log"]], dtype=np.int64))
                 parts.append(l["gamma"])
@@ -347,6 +443,8 @@ class ModelBuilder:
                 cur = np.maximum(cur, 0)
             elif l["kind"] == L_LAYERNORM:
                 cur = layernorm_apply(l, cur)[0]
+            elif l["kind"] == L_SOFTMAX:
+                cur = softmax_apply(l, cur)
             elif l["kind"] == L_CONV:
                 # direct correlation on the padded tensors; everything outside the unpadded output shape is cleared
                 kw, kx, k, nw = l["kw"], l["kx"], l["kernel"], l["nw"]
@@ -562,6 +660,13 @@ def seq_mlp(seq, width, config, input_features=4, output_features=3, layers=2, t
     for _ in range(layers - 1):
         mb.matmul(width).relu()
     mb.matmul(output_features, bias=False, transpose_b=transpose_last).relu()
+    return mb
+
+
+def softmax_only(heads, n, config, in_scale=1.0 / 127.0):
+    """Softmax over [heads][n][n] scores (layers/transformer/softmax.rs); in_scale 8/127 needs the zero tables"""
+    mb = ModelBuilder((heads, n, n), config)
+    mb.softmax(in_scale=in_scale)
     return mb
 
 

@@ -29,7 +29,7 @@ MAGIC = 0x31464F4F52505044
 L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_MATMUL, L_ADD, L_EMBED, L_POSITIONAL = 0, 1, 2, 3, 4, 6, 7, 8, 9
 # nodes of a model graph: MatMul / Add of two inputs share the reference's MatMulProof / AddProof variants with the constant forms (on the way
 # back from the wire format they come out as kinds 6 / 7); ConcatMatMul and QKV have their own
-L_MATMUL2, L_ADD2, L_CONCAT_MATMUL, L_QKV, L_LAYERNORM = 10, 11, 12, 13, 14
+L_MATMUL2, L_ADD2, L_CONCAT_MATMUL, L_QKV, L_LAYERNORM, L_SOFTMAX = 10, 11, 12, 13, 14, 15
 
 
 class Conventions:
@@ -113,6 +113,8 @@ def parse_stream(words):
             lp = {"sumcheck_proof": r.iop(), "individual_claims": r.ve()}
         elif kind == L_QKV:
             lp = {"sumcheck": r.iop(), "aggregation_proof": {"sumcheck": r.iop(), "evals": r.ve()}, "pre_bias_evals": r.ve(), "individual_claims": r.ve()}
+        elif kind == L_SOFTMAX:
+            lp = {"logup_proofs": [r.logup() for _ in range(r.u())], "commitments": [r.comm() for _ in range(r.u())], "accumulation_proof": r.iop(), "mask_proof": r.iop(), "evaluations": r.ve()}
         elif kind == L_LAYERNORM:
             lp = {"logup_proofs": [r.logup() for _ in range(r.u())], "commitments": [r.comm() for _ in range(r.u())], "accumulation_proof": r.iop(), "io_proof": r.iop(),
                   "input_proof": r.iop(), "acc_evals": r.ve(), "evaluations": r.ve(), "gamma_eval": r.e(), "beta_eval": r.e()}
@@ -227,6 +229,9 @@ def to_serde_model(tree, conv=Conventions):
         elif kind in (L_MATMUL, L_MATMUL2):  # MatMulProof {sumcheck, individual_claims, bias_eval: Option<E>} (layers/matrix_mul.rs:153-161)
             v = {"MatMul": {"sumcheck": _iop(lp["sumcheck"], c), "individual_claims": _ve(lp["individual_claims"], c),
                             "bias_eval": None if lp["bias_eval"] is None else _e(lp["bias_eval"], c)}}
+        elif kind == L_SOFTMAX:  # SoftmaxProof (layers/transformer/softmax.rs:102-117)
+            v = {"Softmax": {"logup_proofs": [_logup(x, c) for x in lp["logup_proofs"]], "commitments": [_comm(k, c) for k in lp["commitments"]],
+                             "accumulation_proof": _iop(lp["accumulation_proof"], c), "mask_proof": _iop(lp["mask_proof"], c), "evaluations": _ve(lp["evaluations"], c)}}
         elif kind == L_LAYERNORM:  # LayerNormProof (layers/transformer/layernorm.rs:644-667), fields in declaration order
             v = {"LayerNorm": {"logup_proofs": [_logup(x, c) for x in lp["logup_proofs"]], "commitments": [_comm(k, c) for k in lp["commitments"]],
                                "accumulation_proof": _iop(lp["accumulation_proof"], c), "io_proof": _iop(lp["io_proof"], c), "input_proof": _iop(lp["input_proof"], c),
@@ -473,7 +478,7 @@ def from_rmp(data, conv=Conventions):
     w = _Writer(conv)
     w.w.append(MAGIC); w.w.append(len(model["steps"]))
     kinds = {"Dense": L_DENSE, "Requant": L_REQUANT, "Activation": L_RELU, "Convolution": L_CONV, "Pooling": L_MAXPOOL, "MatMul": L_MATMUL, "Add": L_ADD, "Embeddings": L_EMBED, "Positional": L_POSITIONAL,
-             "ConcatMatMul": L_CONCAT_MATMUL, "QKV": L_QKV, "LayerNorm": L_LAYERNORM}
+             "ConcatMatMul": L_CONCAT_MATMUL, "QKV": L_QKV, "LayerNorm": L_LAYERNORM, "Softmax": L_SOFTMAX}
     for node in sorted(model["steps"]):
         (name, lp), = model["steps"][node].items()
         w.w.append(node); w.w.append(kinds[name])
@@ -496,6 +501,14 @@ def from_rmp(data, conv=Conventions):
             w.w.append(0 if lp["bias_eval"] is None else 1)
             if lp["bias_eval"] is not None:
                 w.e(lp["bias_eval"])
+        elif name == "Softmax":
+            w.w.append(len(lp["logup_proofs"]))
+            for x in lp["logup_proofs"]:
+                w.logup(x)
+            w.w.append(len(lp["commitments"]))
+            for k in lp["commitments"]:
+                w.comm(k)
+            w.iop(lp["accumulation_proof"]); w.iop(lp["mask_proof"]); w.ve(lp["evaluations"])
         elif name == "LayerNorm":
             w.w.append(len(lp["logup_proofs"]))
             for x in lp["logup_proofs"]:

@@ -24,6 +24,9 @@ CASES = [
     # LayerNorm (layers/transformer/layernorm.rs) -> Linear -> ReLU -> Linear; the second with N = 12 of a padded dimension of 16
     ("layernorm_mlp", dict(seq=8, features=16, width=16, config=81)),
     ("layernorm_mlp", dict(seq=16, features=12, width=32, config=82)),
+    # Softmax (layers/transformer/softmax.rs) over [heads][n][n] scores under the causal mask; the second with a zero table
+    ("softmax_only", dict(heads=2, n=8, config=91)),
+    ("softmax_only", dict(heads=4, n=16, config=93, in_scale=3.0 / 127.0)),
 ]
 
 

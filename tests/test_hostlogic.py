@@ -171,7 +171,7 @@ def test_matmul_model_tampered_proof_rejected(hostlogic_bin, where):
     assert "verify(oracle,tampered): REJECT" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("seed", [1, 7])
 def test_graph_model_proof_stream_identical_to_oracle_and_accepted(hostlogic_bin, variant, seed):
     """Models that are GRAPHS (layers/provable/mod.rs:195-565; Prover::prove over the backward node iterator, iop/prover.rs:437-461): 0 / 1 =
@@ -179,7 +179,9 @@ def test_graph_model_proof_stream_identical_to_oracle_and_accepted(hostlogic_bin
     -> ReLU; 2 = QKV (layers/transformer/qkv.rs:462-630) with TWO model outputs, Q and K + 2 V; 3 / 4 = QKV -> ConcatMatMul (Q_h K_h^T per head,
     layers/concat_matmul.rs:467-566, inputs re-laid by their (concat, mat_mul, output) axes) -> ConcatMatMul (scores_h V_h, output permuted
     back to [s][h][d]; 4: the scores stored transposed) -> Add with a second input. The product's orchestrator over the CPU double gives the
-    oracle's stream; the verifier — fed from the serialised verifier context, graph section included — accepts both."""
+    oracle's stream; the verifier — fed from the serialised verifier context, graph section included — accepts both. 5 / 6: LayerNorm (N = 16; N =
+    12 of a padded 16) -> shift-only Requant -> ReLU (layers/transformer/layernorm.rs); 7 / 8: Softmax over [heads][n][n] scores under the causal
+    mask (layers/transformer/softmax.rs), without and with a zero table."""
     r = run(hostlogic_bin, "graph", variant, seed)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "identical=1" in r.stdout
@@ -203,6 +205,19 @@ def test_layernorm_proofs_reject_every_flipped_word(hostlogic_bin, variant):
     with the committed inverse-square-root column, openings) — the verifier refuses each"""
     import os, re, subprocess
     for sweep in ("1:6000:5", "6000:140000:997"):
+        r = subprocess.run([hostlogic_bin, "graph", str(variant), "11"], capture_output=True, text=True, timeout=900, env=dict(os.environ, DP_FLIP_SWEEP=sweep))
+        assert r.returncode == 0 and "identical=1" in r.stdout, r.stdout + r.stderr
+        m = re.search(r"flip sweep: (\d+) flipped, (\d+) rejected, accepted at:(.*)", r.stdout)
+        assert m and int(m.group(1)) > 100 and m.group(1) == m.group(2) and not m.group(3).strip(), r.stdout
+
+
+@pytest.mark.parametrize("variant", [7, 8])
+def test_softmax_proofs_reject_every_flipped_word(hostlogic_bin, variant):
+    """Softmax (layers/transformer/softmax.rs:573-888 / 1274-1586; variants 7 / 8: without / with a zero table): one proof, a single-bit flip in
+    every 3rd of the first 6000 words (the four lookups, the commitments, the accumulation and the mask sumcheck, the evaluations) and in a
+    sample of the rest (table proofs with the committed exponential / error columns, openings) — the verifier refuses each"""
+    import os, re, subprocess
+    for sweep in ("1:6000:3", "6000:74000:211"):
         r = subprocess.run([hostlogic_bin, "graph", str(variant), "11"], capture_output=True, text=True, timeout=900, env=dict(os.environ, DP_FLIP_SWEEP=sweep))
         assert r.returncode == 0 and "identical=1" in r.stdout, r.stdout + r.stderr
         m = re.search(r"flip sweep: (\d+) flipped, (\d+) rejected, accepted at:(.*)", r.stdout)
