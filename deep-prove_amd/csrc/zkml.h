@@ -638,6 +638,9 @@ inline void validate_model(const ModelSpec& m) {
       DP_REQUIRE(is_pow2(l.sm_shape[0]) && is_pow2(l.sm_shape[1]) && l.sm_shape[1] == l.sm_shape[2] && l.sm_shape[1] >= 2 && cur == l.sm_shape[0] * l.sm_shape[1] * l.sm_shape[2] && l.sm_shape[0] * l.sm_shape[1] >= 4, DP_ERR_SHAPE, "softmax: a padded [c][n][n] input with at least four rows");
       DP_REQUIRE(l.sm_scalar >= 1 && l.sm_scalar < (int64_t(1) << 30) && l.sm_bkm >= (int64_t(1) << 17) && l.sm_bkm < (int64_t(1) << 40) && l.sm_table_size == dp_ceil_log2((size_t)(l.sm_bkm >> 16)) && l.sm_table_size <= 22, DP_ERR_ARG, "softmax: multiplier / bkm / table size");
       DP_REQUIRE(l.sm_zero_chunks <= 3 && (l.sm_zero_chunks == 0) == (l.sm_zero_vars == 0) && l.sm_zero_vars <= 22 && l.sm_allowable_error >= 1 && l.sm_allowable_error <= (1 << 11), DP_ERR_ARG, "softmax: zero tables / allowable error");
+      // (the lookup argument here wants columns of at least four entries, logup.h: a one-bit zero table or an error table of two entries is
+      // refused; a front end can always widen the zero table by a bit — the value it holds just has a zero on top)
+      DP_REQUIRE((l.sm_zero_vars == 0 || l.sm_zero_vars >= 2) && l.sm_allowable_error >= 2, DP_ERR_ARG, "softmax: tables of fewer than four entries are not supported");
     }
     else if (l.kind == L_LAYERNORM) {
       const size_t fd = l.weights.size();

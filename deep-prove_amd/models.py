@@ -96,6 +96,7 @@ def softmax_params(in_scale, max_context, temperature=1.0):
         rem = min_bits - table_size
         zero_chunks = (rem - 1) // table_size + 1
         zero_vars = rem if zero_chunks == 1 else table_size
+        zero_vars = max(zero_vars, 2)  # (this prover's lookup argument wants tables of at least four entries: one spare bit, always zero)
     return dict(scalar=scalar, temp_bits=int(np.array([inv_temp], dtype=np.float32).view(np.uint32)[0]), in_scale_bits=int(np.array([in_scale], dtype=np.float32).view(np.uint32)[0]),
                 table_size=table_size, bkm=bkm, zero_chunks=zero_chunks, zero_vars=zero_vars, allowable_error=_round_away(f(err) * osf))
 
@@ -109,8 +110,9 @@ def softmax_table_output(l, j):
     return _round_away(np.float32(_libm().expf(np.float32(-prod) / (np.float32(1 << 24) * temp))) * np.float32(1 << 12))
 
 
-def softmax_apply(l, x):
-    """Softmax::evaluate on quantised values (softmax.rs:455-566; calculate_shift_data :250-320; the causal AttentionMask :1590-1750) -> output"""
+def softmax_apply(l, x, trace=None):
+    """Softmax::evaluate on quantised values (softmax.rs:455-566; calculate_shift_data :250-320; the causal AttentionMask :1590-1750) -> output;
+    `trace` (a dict) receives the columns the prover commits: low, high, exp_in, exp_out, shift, zero_in[z], zero_out[z]"""
     m = _libm()
     C, R, K = l["shape"]
     x = np.asarray(x, dtype=np.int64).reshape(C * R, K)
@@ -119,6 +121,7 @@ def softmax_apply(l, x):
     tmask, zmask = (1 << l["table_size"]) - 1, (1 << l["zero_vars"]) - 1
     lut = {}
     out = np.zeros_like(x)
+    tcols = dict(low=[], high=[], exp_in=[], exp_out=[], shift=[], zero_in=[[] for _ in range(l["zero_chunks"])], zero_out=[[] for _ in range(l["zero_chunks"])])
     for i in range(C * R):
         take = i % R + 1
         row = [int(v) for v in x[i]]
@@ -130,15 +133,25 @@ def softmax_apply(l, x):
             for v in row[:take]:
                 total = np.float32(total + np.float32(m.expf(np.float32(np.float32(v - mx) * in_scale) / inv_temp)))
             shift = -_round_away(np.float32(1 << 24) * inv_temp * np.float32(m.logf(total))) - mx * l["scalar"]
+        tcols["shift"].append(shift)
         for j in range(K):
-            r = abs(row[j] * l["scalar"] + shift if j < take else neg_inf) >> 16
+            full = abs(row[j] * l["scalar"] + shift if j < take else neg_inf)
+            tcols["low"].append(full & 255)
+            tcols["high"].append((full >> 8) & 255)
+            r = full >> 16
             key = r & tmask
             if key not in lut:
                 lut[key] = softmax_table_output(l, key)
             o, r = lut[key], r >> l["table_size"]
-            for _ in range(l["zero_chunks"]):
+            tcols["exp_in"].append(key)
+            tcols["exp_out"].append(o)
+            for z in range(l["zero_chunks"]):
+                tcols["zero_in"][z].append(r & zmask)
+                tcols["zero_out"][z].append(1 if (r & zmask) == 0 else 0)
                 o, r = (o if (r & zmask) == 0 else 0), r >> l["zero_vars"]
             out[i, j] = o
+    if trace is not None:
+        trace.update(tcols)
     return out.reshape(-1)
 
 
@@ -515,6 +528,25 @@ class GraphBuilder:
     def requant(self, src, multiplier, intermediate_bit_size):
         return self._add(dict(kind=L_REQUANT, **requant_from_multiplier(multiplier, intermediate_bit_size)), [src])
 
+    def requant_shift(self, src, right_shift, intermediate_bit_size):
+        """Requant::new_shift (layers/transformer/layernorm.rs:473-513): a power-of-two multiplier"""
+        fp = -right_shift % BIT_LEN
+        return self._add(dict(kind=L_REQUANT, right_shift=right_shift, fp_scale=fp, fixed_point_multiplier=1 << fp, intermediate_bit_size=intermediate_bit_size), [src])
+
+    def layernorm(self, src, dim, eps=1e-5):
+        """LayerNorm over the last dimension `dim` (a power of two) of a [rows][dim] tensor, as ModelBuilder.layernorm; returns (node, the
+        intermediate bit size of its output)"""
+        mb = ModelBuilder((4, dim), self.config)
+        mb._tensor_index = self._tensor_index
+        mb.layernorm(eps=eps, requant=True)
+        self._tensor_index = mb._tensor_index
+        return self._add(mb.layers[0], [src]), mb.layers[1]["intermediate_bit_size"]
+
+    def softmax(self, src, shape, in_scale, temperature=1.0):
+        """Softmax over the last dimension of a [heads][n][n] tensor under the causal mask (layers/transformer/softmax.rs)"""
+        assert len(shape) == 3 and shape[1] == shape[2]
+        return self._add(dict(kind=L_SOFTMAX, shape=tuple(shape), **softmax_params(in_scale, shape[2], temperature)), [src])
+
     def relu(self, src):
         return self._add(dict(kind=L_RELU), [src])
 
@@ -549,6 +581,10 @@ class GraphBuilder:
                     parts.append(l["bias"])
             elif k == L_REQUANT:
                 parts.append(np.array(pre + [l["right_shift"], l["fp_scale"], l["fixed_point_multiplier"], l["intermediate_bit_size"]], dtype=np.int64))
+            elif k == L_LAYERNORM:
+                parts += [np.array(pre + [l["dim"], l["dim_size"], l["multiplier"], l["eps_bits"], l["range_check_bits"], l["top_chunk_scalar_log"]], dtype=np.int64), l["gamma"], l["beta"]]
+            elif k == L_SOFTMAX:
+                parts.append(np.array(pre + [*l["shape"], l["scalar"], l["temp_bits"], l["in_scale_bits"], l["table_size"], l["bkm"], l["zero_chunks"], l["zero_vars"], l["allowable_error"]], dtype=np.int64))
             elif k == L_RELU:
                 parts.append(np.array(pre, dtype=np.int64))
             else:
@@ -596,6 +632,10 @@ class GraphBuilder:
                 y = np.clip((a * l["fixed_point_multiplier"] + (1 << (sh - 1))) >> sh, -127, 127)
             elif k == L_RELU:
                 y = np.maximum(a, 0)
+            elif k == L_LAYERNORM:
+                y = layernorm_apply(l, a)[0]
+            elif k == L_SOFTMAX:
+                y = softmax_apply(l, a)
             vals[(i, 0)] = y
         outs = self.outputs if self.outputs is not None else [(len(self.nodes) - 1, 0)]
         return np.concatenate([vals[e] for e in outs])
@@ -615,6 +655,29 @@ def attention_block(seq, emb, heads, head_dim, config):
     sr = g.requant((sc, 0), 2.5 / math.sqrt(head_dim) / 127.0, dense_output_bitsize(head_dim))
     av = g.concat_matmul((sr, 0), (rq[2], 0), (heads, seq, seq), (seq, heads, head_dim), (0, 2, 1), (1, 0, 2), perm=(1, 0, 2))
     ar = g.requant((av, 0), 2.5 / math.sqrt(seq) / 127.0, dense_output_bitsize(seq))
+    pr = g.matmul_const((ar, 0), n, emb)
+    prq = g.requant((pr, 0), 2.5 / math.sqrt(n) / 127.0, dense_output_bitsize(n))
+    g.add2((prq, 0), (-1, 1))
+    return g
+
+
+def transformer_block(seq, emb, heads, head_dim, config):
+    """The attention half of a pre-LN transformer block, every layer of it proved: X -> LayerNorm -> Requant (shift) -> QKV -> Requant (x3);
+    scores_h = Q_h K_h^T per head ([h][s][s], ConcatMatMul) -> Requant -> Softmax under the causal mask -> probs_h V_h laid out as [s][h][d]
+    (ConcatMatMul; the probabilities carry the scale 2^-12) -> Requant -> output projection -> Requant; + the residual (a second input tensor:
+    the reference proves graphs whose tensors have one reader each). layers/transformer/{layernorm,qkv,softmax}.rs, layers/concat_matmul.rs,
+    layers/matrix_mul.rs, layers/add.rs — what the reference's Mha layer (transformer/mha.rs) bundles into one node, as separate nodes."""
+    n = heads * head_dim
+    g = GraphBuilder([seq * emb, seq * emb], config)
+    ln, ibs = g.layernorm((-1, 0), emb)
+    lr = g.requant_shift((ln, 0), ibs - 16, ibs)
+    q = g.qkv((lr, 0), emb, n)
+    rq = [g.requant((q, w), 2.5 / math.sqrt(emb) / 127.0, dense_output_bitsize(emb)) for w in range(3)]
+    sc = g.concat_matmul((rq[0], 0), (rq[1], 0), (seq, heads, head_dim), (seq, heads, head_dim), (1, 2, 0), (1, 2, 0))
+    sr = g.requant((sc, 0), 2.5 / math.sqrt(head_dim) / 127.0, dense_output_bitsize(head_dim))
+    sm = g.softmax((sr, 0), (heads, seq, seq), in_scale=8.0 / 127.0)
+    av = g.concat_matmul((sm, 0), (rq[2], 0), (heads, seq, seq), (seq, heads, head_dim), (0, 2, 1), (1, 0, 2), perm=(1, 0, 2))
+    ar = g.requant((av, 0), 1.0 / 4096.0, 12 + BIT_LEN + max(0, (seq - 1).bit_length()) + 1)
     pr = g.matmul_const((ar, 0), n, emb)
     prq = g.requant((pr, 0), 2.5 / math.sqrt(n) / 127.0, dense_output_bitsize(n))
     g.add2((prq, 0), (-1, 1))

@@ -286,6 +286,13 @@ int32_t dp_pcs_simple_batch_verify(size_t max_poly_size, const uint64_t root[4],
  *      out = gamma (N x - sum x) lut(multiplier (N sum x^2 - (sum x)^2) >> range_check_bits) + beta with the inverse-square-root table of
  *      lookup/context.rs:124-157 (2^15 entries; its output column is committed once per context). Usually followed by a Requant (1) whose
  *      multiplier is a power of two (Requant::new_shift, layernorm.rs:473-513).
+ *   15 Softmax (zkml/src/layers/transformer/softmax.rs:66-99,153-233) over the last dimension of a padded [c][n][n] tensor under the causal mask
+ *      (entries j > i of row i count as minus infinity): c, n, n, multiplier (brings the input to the scale 2^24), f32 bits of 1 / temperature,
+ *      f32 bits of the input scale (both only steer the row shifts the prover computes, softmax.rs:250-320), table_size (the exponential table has
+ *      2^table_size entries), bkm (inputs from here on are mapped to zero; table_size == ceil_log2(bkm >> 16)), number of zero chunks (<= 3),
+ *      bits per zero chunk (0 or 2..22), allowable error of a row sum (2..2048; QuantisedSoftmaxData / SoftmaxCtx). The output has the scale 2^-12.
+ *      The exponential table and the error table commit their output column once per context. Lookup tables of fewer than four entries (a one-bit
+ *      zero table) are refused: widen the zero table by a bit.
  *      (layers/transformer/qkv.rs:462-630)
  *   Embeddings stay the first node of a chain. Not built: MHA, Softmax, LayerNorm, Logits. */
 int32_t dp_model_setup(dp_ctx* ctx, const int64_t* model_blob, size_t nwords, dp_model** out);

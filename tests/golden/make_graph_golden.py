@@ -27,6 +27,9 @@ CASES = [
     # Softmax (layers/transformer/softmax.rs) over [heads][n][n] scores under the causal mask; the second with a zero table
     ("softmax_only", dict(heads=2, n=8, config=91)),
     ("softmax_only", dict(heads=4, n=16, config=93, in_scale=3.0 / 127.0)),
+    # the attention half of a pre-LN transformer block: LayerNorm, QKV, per-head scores, Softmax, probabilities x V, projection, residual
+    ("transformer_block", dict(seq=8, emb=16, heads=2, head_dim=8, config=95)),
+    ("transformer_block", dict(seq=16, emb=32, heads=4, head_dim=8, config=96)),
 ]
 
 

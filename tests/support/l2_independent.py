@@ -180,6 +180,17 @@ def table_column_evals(kind, size, point):
         for k, p in enumerate(point[:-1]):
             second = add(second, mul(mul(p, fe(1 << k)), point[-1]))
         return [sub(idx, fe(1 << (BIT_LEN - 1))), second]
+    if kind == "softmax":  # the input column; the output column is a commitment (context.rs:409-423)
+        assert len(point) == size[1]
+        return [idx]
+    if kind == "error":  # nothing but the committed column (:424)
+        return []
+    if kind == "zero":  # (:425-443)
+        assert len(point) == size
+        o = ONE
+        for p in point:
+            o = mul(o, sub(ONE, p))
+        return [idx, o]
     if kind == "inv_sqrt":  # only the input column; the output column is a commitment (context.rs:445-462)
         assert len(point) == 2 * (BIT_LEN - 1) + 1
         return [sub(idx, fe(1 << (2 * (BIT_LEN - 1))))]
@@ -191,7 +202,7 @@ def table_column_evals(kind, size, point):
 
 def table_order_key(t):
     """derive(Ord) of lookup/context.rs:52-72: Relu < GELU < Range < Clamping(n) < ..."""
-    return ({"relu": 0, "range": 2, "clamping": 3, "inv_sqrt": 7}[t[0]], t[1])
+    return ({"relu": 0, "range": 2, "clamping": 3, "softmax": 4, "error": 5, "zero": 6, "inv_sqrt": 7}[t[0]], t[1])
 
 
 def verify_chain(layers, model_roots, tree, x, y, label=b"m2vec"):
@@ -360,12 +371,18 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
         elif n["kind"] == "layernorm":
             tables.add(("range", 0))
             tables.add(("inv_sqrt", (n["eps_bits"], n["range_check_bits"])))
+        elif n["kind"] == "softmax":
+            tables.add(("range", 0))
+            tables.add(("softmax", (n["temp_bits"], n["table_size"], n["bkm"])))
+            tables.add(("error", n["allowable_error"]))
+            if n["zero_vars"]:
+                tables.add(("zero", n["zero_vars"]))
     tables = sorted(tables, key=table_order_key)
     chmap, constant = {}, None
     if tables:
         constant = challenge(tr, b"table_constant")
         for t in tables:
-            chmap[t] = ONE if t[0] == "range" else challenge(tr, {"relu": b"Relu", "clamping": b"Clamping", "inv_sqrt": b"InverseSQRT"}[t[0]])
+            chmap[t] = ONE if t[0] in ("range", "error") else challenge(tr, {"relu": b"Relu", "clamping": b"Clamping", "inv_sqrt": b"InverseSQRT", "softmax": b"Softmax", "zero": b"Zero"}[t[0]])
     steps = {node: (kind, lp) for node, kind, lp in tree["steps"]}
     nums, dens = [], []
 
@@ -381,7 +398,7 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
             fractions(steps[nid][1]["shifted_lookup"])
         elif n["kind"] in ("relu", "maxpool"):
             fractions(steps[nid][1]["lookup"])
-        elif n["kind"] == "layernorm":
+        elif n["kind"] in ("layernorm", "softmax"):
             for lg in steps[nid][1]["logup_proofs"]:
                 fractions(lg)
     for tp in tree["table_proofs"]:
@@ -524,6 +541,61 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
             for v, m_ in zip(ze[:ks], mults):
                 zin = add(zin, mul(sub(out_eval, v), m_))
             made[nid] = [{"point": [r1] + zp[:gap] + [r2] + zp[gap:], "eval": zin}]
+        elif n["kind"] == "softmax":  # layers/transformer/softmax.rs:1274-1586
+            zc, zv, ts, bkm = n["zero_chunks"], n["zero_vars"], n["table_size"], n["bkm"]
+            ve = lambda v: [e(t) for t in v]
+            lgs = lp["logup_proofs"]
+            assert len(lgs) == (4 if zc else 3)
+            exp_c, _, _ = verify_logup(lgs[0], 1, constant, chmap[("softmax", (n["temp_bits"], ts, bkm))], tr)
+            rng_c, _, _ = verify_logup(lgs[1], 2, constant, ONE, tr)
+            err_c, _, _ = verify_logup(lgs[2], 1, constant, ONE, tr)
+            zero_c = verify_logup(lgs[3], zc, constant, chmap[("zero", zv)], tr)[0] if zc else []
+            assert len(exp_c) == 2 and len(rng_c) == 2 and len(err_c) == 1 and len(zero_c) == 2 * zc
+            alpha = challenge(tr, b"batching_challenge")
+            total, bc = ZERO, ONE
+            for cl in exp_c + rng_c + zero_c + err_c:
+                total, bc = add(total, mul(bc, cl["eval"])), mul(bc, alpha)
+            total = add(total, mul(bc, cur["eval"]))
+            nv = len(exp_c[0]["point"])
+            extra = nv - len(err_c[0]["point"])
+            C_, R_, K_ = n["shape"]
+            assert extra == K_.bit_length() - 1 and len(cur["point"]) == nv
+            two_inv, two_mult = L.ext_inv(fe(2)), fe(1 << extra)
+            acc_pt = ve(lp["accumulation_proof"]["point"])
+            _, expected = L1.verify_sumcheck(total, acc_pt, lp["accumulation_proof"]["proofs"], nv, zc + 2 if zc else 2, tr)
+            last_beta, exp_beta, range_beta = eq_xy_eval(cur["point"], acc_pt), eq_xy_eval(exp_c[0]["point"], acc_pt), eq_xy_eval(rng_c[0]["point"], acc_pt)
+            error_beta = eq_xy_eval([two_inv] * extra + err_c[0]["point"], acc_pt)
+            ev = ve(lp["evaluations"])
+            assert len(ev) == 5 + 2 * zc and len(lp["commitments"]) == len(ev)
+            calc = mul(exp_beta, add(ev[0], mul(ev[1], alpha)))
+            bc = mul(alpha, alpha)
+            for k in (2, 3):
+                calc, bc = add(calc, mul(mul(range_beta, ev[k]), bc)), mul(bc, alpha)
+            out_eval = ev[1]
+            if zc:
+                zbeta = eq_xy_eval(zero_c[0]["point"], acc_pt)
+                for k in range(5, len(ev)):
+                    calc, bc = add(calc, mul(mul(zbeta, ev[k]), bc)), mul(bc, alpha)
+                for k in range(6, len(ev), 2):
+                    out_eval = mul(out_eval, ev[k])
+            calc = add(calc, mul(mul(bc, out_eval), add(mul(error_beta, two_mult), mul(alpha, last_beta))))
+            assert calc == expected, "softmax: accumulation evaluations do not recombine"
+            mask_in = add(add(mul(ev[0], fe(1 << 16)), mul(ev[3], fe(1 << 8))), ev[2])
+            m_ = fe(1 << (16 + ts))
+            for k in range(5, len(ev), 2):
+                mask_in, m_ = add(mask_in, mul(ev[k], m_)), mul(m_, fe(1 << zv))
+            mpt = ve(lp["mask_proof"]["point"])
+            _, mexp = L1.verify_sumcheck(sub(ZERO, mask_in), mpt, lp["mask_proof"]["proofs"], nv, 3, tr)
+            eqv = eq_xy_eval(mpt, acc_pt)
+            cv, rv = K_.bit_length() - 1, R_.bit_length() - 1
+            tril = ONE  # eval_zeroifier_mle (mha.rs:894-901)
+            for c_, r_ in zip(mpt[:cv], mpt[cv:cv + rv]):
+                tril = add(mul(tril, add(sub(sub(ONE, c_), r_), mul(fe(2), mul(c_, r_)))), mul(sub(ONE, c_), r_))
+            neg_inf = fe((-(((bkm >> 16) + 1) << 16)) % P)
+            shifted = mul(sub(mexp, mul(eqv, mul(neg_inf, sub(ONE, tril)))), L.ext_inv(mul(eqv, tril)))
+            for q, (v, c) in enumerate(zip(ev, lp["commitments"])):
+                out.append(("witness", nid, q, (tuple(c["root"]), c["num_vars"]), mpt[extra:] if q == 4 else acc_pt, v))
+            made[nid] = [{"point": mpt, "eval": mul(sub(shifted, ev[4]), L.ext_inv(fe(n["scalar"])))}]
         elif n["kind"] == "layernorm":  # layers/transformer/layernorm.rs:1230-1505
             rcb, nrc = n["range_check_bits"], (n["range_check_bits"] - 1) // BIT_LEN + 1
             ve = lambda v: [e(t) for t in v]
@@ -743,7 +815,7 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
         claims, _, _ = verify_logup(tp["lookup"], 1, constant, chmap[t], tr)
         out.append(("multiplicity", t, (tuple(tp["multiplicity_commit"]["root"]), tp["multiplicity_commit"]["num_vars"]), claims[0]["point"], claims[0]["eval"]))
         expect = table_column_evals(t[0], t[1], claims[0]["point"])
-        if t[0] == "inv_sqrt":  # table_claims (lookup/context.rs:548-563): the claim on the committed output column goes to the opening
+        if t[0] in ("inv_sqrt", "softmax", "error"):  # table_claims (lookup/context.rs:548-563): the claim on the committed output column goes to the opening
             out.append(("table", t, claims[-1]["point"], claims[-1]["eval"]))
             claims = claims[:-1]
         assert len(expect) == len(claims) - 1

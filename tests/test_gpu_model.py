@@ -263,12 +263,13 @@ def _graph_cases():
         return json.load(f)
 
 
-@pytest.mark.parametrize("case", range(9))
+@pytest.mark.parametrize("case", range(11))
 def test_graph_model_proof_bytes_identical_to_oracle_and_golden(dev, oracle, case):
     """Models that are GRAPHS (layers/provable/mod.rs:195-565): QKV (three outputs, one batched sumcheck + same_poly), ConcatMatMul (per-head
     products, degree-3 sumcheck), MatMul and Add of two inputs, several input / output tensors; cases 5 / 6: LayerNorm (two lookups, one of
     them into the inverse-square-root table whose output column is a commitment of the context, a degree-4 sumcheck); 7 / 8: Softmax (four
-    lookups — exponential, range, error, zero tables — the causal mask, row shifts computed in f32). The device proof equals the oracle's and the
+    lookups — exponential, range, error, zero tables — the causal mask, row shifts computed in f32); 9 / 10: the attention half of a pre-LN
+    transformer block, thirteen nodes from LayerNorm to the residual Add (models.transformer_block). The device proof equals the oracle's and the
     committed sha256 (tests/golden/graph_models.json); the verifier accepts it and refuses a flipped word and a wrong input tensor; proofs of
     a batch (cohorts, device-side Fiat-Shamir) equal the sequential ones."""
     import deep_prove_amd as dpa
