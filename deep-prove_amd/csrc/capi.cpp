@@ -762,7 +762,7 @@ static ModelSpec parse_model(const int64_t* b, size_t n) {
   }
   for (size_t i = 0; i < nl; i++) {
     LayerSpec l; l.kind = (int)rd();
-    if (graph) { const size_t k = (size_t)rd(); DP_REQUIRE(k == 1 || k == 2, DP_ERR_ARG, "model blob: a node has one or two inputs"); for (size_t q = 0; q < k; q++) l.inputs.push_back(rd_edge()); }
+    if (graph) { const size_t k = (size_t)rd(); DP_REQUIRE(k >= 1 && k <= 3, DP_ERR_ARG, "model blob: a node has one to three inputs"); for (size_t q = 0; q < k; q++) l.inputs.push_back(rd_edge()); }
     if (l.kind == L_MATMUL2) {  // [10, inner dimension k, output columns n, flags (2 = Config::TransposeB)]
       l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); const size_t fl = (size_t)rd();
       DP_REQUIRE((fl & ~size_t(2)) == 0, DP_ERR_ARG, "model blob: matmul2 flags"); l.mm_transpose = fl != 0;
@@ -829,6 +829,12 @@ static ModelSpec parse_model(const int64_t* b, size_t n) {
       for (int k = 0; k < 3; k++) l.sm_shape[k] = (size_t)rd();
       l.sm_scalar = rd(); const int64_t tb = rd(), sb = rd(), ts = rd(); l.sm_bkm = rd(); const int64_t zc = rd(), zv = rd(); l.sm_allowable_error = rd();
       DP_REQUIRE(tb >= 0 && tb <= 0xFFFFFFFFll && sb >= 0 && sb <= 0xFFFFFFFFll && ts >= 1 && ts <= 22 && zc >= 0 && zc <= 3 && zv >= 0 && zv <= 22, DP_ERR_ARG, "model blob: softmax parameters");
+      l.sm_temp_bits = (uint32_t)tb; l.sm_in_scale_bits = (uint32_t)sb; l.sm_table_size = (unsigned)ts; l.sm_zero_chunks = (unsigned)zc; l.sm_zero_vars = (unsigned)zv;
+    }
+    else if (l.kind == L_MHA) {  // [16, seq, heads, head_dim, then the parameters of its softmax as in kind 15 after the shape]
+      for (int k = 0; k < 3; k++) { const int64_t x = rd(); DP_REQUIRE(x >= 1 && x <= (1 << 12), DP_ERR_ARG, "model blob: mha shape"); l.mha_shape[k] = (size_t)x; }
+      l.sm_scalar = rd(); const int64_t tb = rd(), sb = rd(), ts = rd(); l.sm_bkm = rd(); const int64_t zc = rd(), zv = rd(); l.sm_allowable_error = rd();
+      DP_REQUIRE(tb >= 0 && tb <= 0xFFFFFFFFll && sb >= 0 && sb <= 0xFFFFFFFFll && ts >= 1 && ts <= 22 && zc >= 0 && zc <= 3 && zv >= 0 && zv <= 22, DP_ERR_ARG, "model blob: mha softmax parameters");
       l.sm_temp_bits = (uint32_t)tb; l.sm_in_scale_bits = (uint32_t)sb; l.sm_table_size = (unsigned)ts; l.sm_zero_chunks = (unsigned)zc; l.sm_zero_vars = (unsigned)zv;
     }
     else DP_REQUIRE(l.kind == L_RELU || l.kind == L_FLATTEN, DP_ERR_ARG, "model blob: unknown layer kind");

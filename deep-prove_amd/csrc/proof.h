@@ -30,7 +30,7 @@ struct BasefoldProof {
   bool is_trivial() const { return sumcheck_messages.empty() && queries.empty() && sumcheck_proof.empty(); }
 };
 enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8, L_POSITIONAL = 9,
-                 L_MATMUL2 = 10, L_ADD2 = 11, L_CONCAT_MATMUL = 12, L_QKV = 13, L_LAYERNORM = 14, L_SOFTMAX = 15 };  // the two-input forms of MatMul / Add, ConcatMatMul, QKV (nodes of a model GRAPH)
+                 L_MATMUL2 = 10, L_ADD2 = 11, L_CONCAT_MATMUL = 12, L_QKV = 13, L_LAYERNORM = 14, L_SOFTMAX = 15, L_MHA = 16 };  // the two-input forms of MatMul / Add, ConcatMatMul, QKV (nodes of a model GRAPH)
 struct DenseProof { IOPProof sumcheck; Ext bias_eval; std::vector<Ext> individual_claims; };
 struct AddProof { Ext left_eval = ex_zero(), right_eval = ex_zero(); };  // layers/add.rs:59-63
 struct PositionalProof { std::vector<Ext> sub_matrix_evals; AddProof add_proof; };  // SinglePositionalProof (transformer/positional.rs:45-55), one input
@@ -61,7 +61,8 @@ struct LayerNormProof { std::vector<LogUpProof> logup_proofs; std::vector<Commit
 // SoftmaxProof (layers/transformer/softmax.rs:102-117): lookups (exponential, range, error, zero table if any), commitments, the accumulation and
 // the mask sumcheck, the evaluations exp_in, exp_out, low, high, shift, (zero_in, zero_out)*
 struct SoftmaxProof { std::vector<LogUpProof> logup_proofs; std::vector<Commitment> commitments; IOPProof accumulation_proof, mask_proof; std::vector<Ext> evaluations; };
-struct LayerProof { int kind = 0; DenseProof dense; MatMulProof matmul; AddProof add; PositionalProof pos; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; ConcatMatMulProof cmm; QKVProof qkv; LayerNormProof ln; SoftmaxProof sm; };
+struct LayerProof { int kind = 0; DenseProof dense; MatMulProof matmul; AddProof add; PositionalProof pos; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; ConcatMatMulProof cmm; QKVProof qkv; LayerNormProof ln; SoftmaxProof sm;
+                    ConcatMatMulProof mha_final, mha_qk; };  // MhaProof {final_mul_proof, softmax_proof, qk_proof} (transformer/mha.rs:122-128) = {mha_final, sm, mha_qk}
 struct TableProof { Commitment multiplicity_commit; LogUpProof lookup; };
 struct Proof {
   std::map<size_t, LayerProof> steps;
@@ -129,11 +130,13 @@ inline std::vector<u64> serialize_proof(const Proof& p) {
       w.u(q.commitments.size()); for (auto& c : q.commitments) w.comm(c);
       w.iop(q.accumulation_proof); w.iop(q.io_proof); w.iop(q.input_proof); w.ve(q.acc_evals); w.ve(q.evaluations); w.e(q.gamma_eval); w.e(q.beta_eval);
     }
-    else if (lp.kind == L_SOFTMAX) {
+    else if (lp.kind == L_SOFTMAX || lp.kind == L_MHA) {
+      if (lp.kind == L_MHA) { w.iop(lp.mha_final.sumcheck); w.ve(lp.mha_final.individual_claims); }
       const SoftmaxProof& q = lp.sm;
       w.u(q.logup_proofs.size()); for (auto& x : q.logup_proofs) w.logup(x);
       w.u(q.commitments.size()); for (auto& c : q.commitments) w.comm(c);
       w.iop(q.accumulation_proof); w.iop(q.mask_proof); w.ve(q.evaluations);
+      if (lp.kind == L_MHA) { w.iop(lp.mha_qk.sumcheck); w.ve(lp.mha_qk.individual_claims); }
     }
     else if (lp.kind == L_REQUANT) {
       w.iop(lp.req.io_accumulation); w.ve(lp.req.accumulation_evals); w.logup(lp.req.clamping_lookup); w.logup(lp.req.shifted_lookup);
@@ -225,11 +228,13 @@ inline Proof deserialize_proof(const u64* words, size_t n) {
       k = r.len(); q.commitments.resize(k); for (auto& c : q.commitments) c = r.comm();
       q.accumulation_proof = r.iop(); q.io_proof = r.iop(); q.input_proof = r.iop(); q.acc_evals = r.ve(); q.evaluations = r.ve(); q.gamma_eval = r.e(); q.beta_eval = r.e();
     }
-    else if (lp.kind == L_SOFTMAX) {
+    else if (lp.kind == L_SOFTMAX || lp.kind == L_MHA) {
+      if (lp.kind == L_MHA) { lp.mha_final.sumcheck = r.iop(); lp.mha_final.individual_claims = r.ve(); }
       SoftmaxProof& q = lp.sm;
       size_t k = r.len(); q.logup_proofs.resize(k); for (auto& x : q.logup_proofs) x = r.logup();
       k = r.len(); q.commitments.resize(k); for (auto& c : q.commitments) c = r.comm();
       q.accumulation_proof = r.iop(); q.mask_proof = r.iop(); q.evaluations = r.ve();
+      if (lp.kind == L_MHA) { lp.mha_qk.sumcheck = r.iop(); lp.mha_qk.individual_claims = r.ve(); }
     }
     else if (lp.kind == L_REQUANT) {
       lp.req.io_accumulation = r.iop(); lp.req.accumulation_evals = r.ve(); lp.req.clamping_lookup = r.logup(); lp.req.shifted_lookup = r.logup();

@@ -74,6 +74,10 @@ struct LayerSpec {
   // the exponential table (2^sm_table_size entries, zero from sm_bkm on); the zero tables for the bits above; the allowable error of a row sum
   int64_t sm_scalar = 0, sm_bkm = 0, sm_allowable_error = 0; uint32_t sm_temp_bits = 0, sm_in_scale_bits = 0; unsigned sm_table_size = 0, sm_zero_chunks = 0, sm_zero_vars = 0;
   size_t sm_shape[3] = {0, 0, 0};
+  // mha (layers/transformer/mha.rs:133-186, Mha::new): ONE node with the inputs Q, K, V — padded [seq][heads * head_dim] matrices read as
+  // [seq][heads][head_dim] — that bundles qk = ConcatMatMul (1,2,0) x (1,2,0) -> [heads][seq][seq], the Softmax described by the sm_* fields
+  // (sm_shape unused) straight on the products, final_mul = ConcatMatMul (0,2,1) x (1,0,2), permuted (1,0,2) -> [seq][heads][head_dim]
+  size_t mha_shape[3] = {0, 0, 0};  // seq, heads, head_dim
   unsigned right_shift = 0, fp_scale = 0, intermediate_bit_size = 0;
   int64_t fixed_point_multiplier = 0;
   unsigned shift() const { return fp_scale + right_shift; }
@@ -83,7 +87,29 @@ struct LayerSpec {
 // their concatenation); outputs: the edges that are the model's output tensors (empty: output 0 of the last node), concatenated likewise
 struct ModelSpec { size_t input_len = 0; std::vector<LayerSpec> layers; std::vector<size_t> input_lens; std::vector<Edge> outputs; };
 inline size_t out_degree(const LayerSpec& l) { return l.kind == L_QKV ? 3 : 1; }
-inline size_t in_degree(const LayerSpec& l) { return l.kind == L_MATMUL2 || l.kind == L_ADD2 || l.kind == L_CONCAT_MATMUL ? 2 : 1; }
+inline size_t in_degree(const LayerSpec& l) { return l.kind == L_MHA ? 3 : l.kind == L_MATMUL2 || l.kind == L_ADD2 || l.kind == L_CONCAT_MATMUL ? 2 : 1; }
+// the sub-layers of an Mha node (Mha::new, mha.rs:147-186)
+inline LayerSpec mha_qk_spec(const LayerSpec& l) {
+  LayerSpec s; s.kind = L_CONCAT_MATMUL;
+  static const int dims[3] = {1, 2, 0};
+  for (int d = 0; d < 3; d++) { s.cm_a[d] = s.cm_b[d] = l.mha_shape[d]; s.cm_left[d] = s.cm_right[d] = dims[d]; }
+  return s;
+}
+inline LayerSpec mha_softmax_spec(const LayerSpec& l) {
+  LayerSpec s; s.kind = L_SOFTMAX;
+  s.sm_scalar = l.sm_scalar; s.sm_bkm = l.sm_bkm; s.sm_allowable_error = l.sm_allowable_error; s.sm_temp_bits = l.sm_temp_bits; s.sm_in_scale_bits = l.sm_in_scale_bits;
+  s.sm_table_size = l.sm_table_size; s.sm_zero_chunks = l.sm_zero_chunks; s.sm_zero_vars = l.sm_zero_vars;
+  s.sm_shape[0] = l.mha_shape[1]; s.sm_shape[1] = s.sm_shape[2] = l.mha_shape[0];
+  return s;
+}
+inline LayerSpec mha_final_spec(const LayerSpec& l) {
+  LayerSpec s; s.kind = L_CONCAT_MATMUL;
+  static const int dl[3] = {0, 2, 1}, dr[3] = {1, 0, 2};
+  s.cm_a[0] = l.mha_shape[1]; s.cm_a[1] = s.cm_a[2] = l.mha_shape[0];
+  for (int d = 0; d < 3; d++) { s.cm_b[d] = l.mha_shape[d]; s.cm_left[d] = dl[d]; s.cm_right[d] = dr[d]; }
+  s.cm_perm = {1, 0, 2};
+  return s;
+}
 inline std::vector<Edge> edges_in(const ModelSpec& m, size_t id) {
   if (!m.layers[id].inputs.empty()) return m.layers[id].inputs;
   Edge e; e.from = (int)id - 1; e.slot = 0;  // (node 0: from = -1, the model input)
@@ -279,8 +305,10 @@ struct ConvTrace {
   std::vector<int64_t> output_as_element;  // conv output after the bias, before clearing (convolution.rs:311-316)
 };
 // per node: first input, first output; in2 = second input of a two-input node; more_out = the outputs after the first (QKV: K, V)
+// MhaData (mha.rs:45-52): the products Q K^T the softmax reads and the probabilities final_mul reads (its output is the node's: final_reshape moves nothing)
+struct MhaTrace { std::vector<int64_t> softmax_in, softmax_out; };
 struct Trace {
-  std::vector<std::vector<int64_t>> in, out, in2; std::vector<std::vector<std::vector<int64_t>>> more_out; std::vector<ConvTrace> conv;
+  std::vector<std::vector<int64_t>> in, out, in2, in3; std::vector<std::vector<std::vector<int64_t>>> more_out; std::vector<ConvTrace> conv; std::map<size_t, MhaTrace> mha;
   const std::vector<int64_t>& tensor(int node, int slot) const { return slot == 0 ? out[(size_t)node] : more_out[(size_t)node][(size_t)slot - 1]; }
 };
 // FFT of every kernel of a convolution, zero-padded to 2 nw^2 (index_w, tensor.rs:236-254): computed once per model —
@@ -354,16 +382,17 @@ inline std::vector<std::vector<int64_t>> maxpool_diff_polys(const LayerSpec& l, 
 }
 // length of the model's output tensor (the shape propagation of run_model without the arithmetic)
 // lens[id] = length of (each of) node id's output tensors; in_len[id] = length of its first input
-inline void tensor_lens(const ModelSpec& m, std::vector<size_t>& lens, std::vector<size_t>* in_len = nullptr, std::vector<size_t>* in2_len = nullptr) {
+inline void tensor_lens(const ModelSpec& m, std::vector<size_t>& lens, std::vector<size_t>* in_len = nullptr, std::vector<size_t>* in2_len = nullptr, std::vector<size_t>* in3_len = nullptr) {
   const std::vector<size_t> ins = input_tensor_lens(m);
   lens.assign(m.layers.size(), 0);
   if (in_len) in_len->assign(m.layers.size(), 0);
   if (in2_len) in2_len->assign(m.layers.size(), 0);
+  if (in3_len) in3_len->assign(m.layers.size(), 0);
   for (size_t id = 0; id < m.layers.size(); id++) {
     const LayerSpec& l = m.layers[id];
     const std::vector<Edge> e = edges_in(m, id);
     DP_REQUIRE(e.size() == in_degree(l), DP_ERR_SHAPE, "model graph: wrong number of inputs for a node");
-    size_t got[2] = {0, 0};
+    size_t got[3] = {0, 0, 0};
     for (size_t q = 0; q < e.size(); q++) {
       DP_REQUIRE(e[q].from < (int)id && (e[q].from >= 0 ? e[q].slot >= 0 && (size_t)e[q].slot < out_degree(m.layers[(size_t)e[q].from]) : e[q].slot >= 0 && (size_t)e[q].slot < ins.size()), DP_ERR_SHAPE, "model graph: an edge must come from an earlier node or a model input");
       got[q] = e[q].from < 0 ? ins[(size_t)e[q].slot] : lens[(size_t)e[q].from];
@@ -371,6 +400,7 @@ inline void tensor_lens(const ModelSpec& m, std::vector<size_t>& lens, std::vect
     size_t cur = got[0];
     if (in_len) (*in_len)[id] = got[0];
     if (in2_len) (*in2_len)[id] = got[1];
+    if (in3_len) (*in3_len)[id] = got[2];
     if (l.kind == L_DENSE) cur = l.nrows;
     else if (l.kind == L_MATMUL || l.kind == L_MATMUL2 || l.kind == L_QKV) cur = l.nrows ? cur / l.nrows * l.ncols : 0;
     else if (l.kind == L_EMBED) cur = cur * l.ncols;
@@ -422,6 +452,22 @@ inline std::vector<int64_t> matmul_i64(const int64_t* a, const int64_t* b, size_
   }
   return o;
 }
+// ConcatMatMul::evaluate (concat_matmul.rs:568-616)
+inline std::vector<int64_t> concat_matmul_op(const LayerSpec& l, const std::vector<int64_t>& cur, const std::vector<int64_t>& b0) {
+  std::vector<int64_t> o;
+    DP_REQUIRE(cur.size() == l.cm_a[0] * l.cm_a[1] * l.cm_a[2] && b0.size() == l.cm_b[0] * l.cm_b[1] * l.cm_b[2], DP_ERR_SHAPE, "concat matmul: input shapes");
+    const CmShape g = cm_shape(l);
+    int order[3]; bool same;
+    cm_axes_to(l.cm_left, CM_WANT_LEFT, order, same);
+    const std::vector<int64_t> a = same ? cur : transpose3(cur, l.cm_a, order);
+    cm_axes_to(l.cm_right, CM_WANT_RIGHT, order, same);
+    const std::vector<int64_t> b = same ? b0 : transpose3(b0, l.cm_b, order);
+    std::vector<int64_t> r;
+    for (size_t c = 0; c < g.C; c++) { std::vector<int64_t> y = matmul_i64(&a[c * g.R * g.M], &b[c * g.M * g.N], g.R, g.M, g.N, false); r.insert(r.end(), y.begin(), y.end()); }
+    if (l.cm_perm.empty()) o = std::move(r);
+    else { const size_t rs[3] = {g.C, g.R, g.N}; const int po[3] = {l.cm_perm[0], l.cm_perm[1], l.cm_perm[2]}; o = transpose3(r, rs, po); }
+  return o;
+}
 inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
   Trace tr;
   DP_REQUIRE(input.size() == m.input_len, DP_ERR_SHAPE, "input length mismatch");
@@ -432,7 +478,7 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
     DP_REQUIRE((size_t)e.slot < in_lens.size() && off + in_lens[(size_t)e.slot] <= input.size(), DP_ERR_SHAPE, "model graph: input tensor");
     return std::vector<int64_t>(input.begin() + off, input.begin() + off + in_lens[(size_t)e.slot]);
   };
-  tr.in2.resize(m.layers.size()); tr.more_out.resize(m.layers.size());
+  tr.in2.resize(m.layers.size()); tr.in3.resize(m.layers.size()); tr.more_out.resize(m.layers.size());
   for (size_t id = 0; id < m.layers.size(); id++) {
     const LayerSpec& l = m.layers[id];
     const std::vector<Edge> edges = edges_in(m, id);
@@ -440,6 +486,7 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
     std::vector<int64_t> cur = m.layers[id].inputs.empty() && id > 0 ? tr.out[id - 1] : fetch(edges[0]);
     tr.in.push_back(cur);
     if (edges.size() > 1) tr.in2[id] = fetch(edges[1]);
+    if (edges.size() > 2) tr.in3[id] = fetch(edges[2]);
     std::vector<int64_t> o;
     if (l.kind == L_MATMUL2) {  // MatMul::op (matrix_mul.rs:230-311) on two inputs
       const std::vector<int64_t>& b = tr.in2[id];
@@ -458,19 +505,15 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
         for (size_t i = 0; i < y.size(); i++) y[i] += l.bias[w * n + i % n];
         if (w == 0) o = std::move(y); else tr.more_out[id].push_back(std::move(y));
       }
-    } else if (l.kind == L_CONCAT_MATMUL) {  // ConcatMatMul::evaluate (concat_matmul.rs:568-616)
-      const std::vector<int64_t>& b0 = tr.in2[id];
-      DP_REQUIRE(cur.size() == l.cm_a[0] * l.cm_a[1] * l.cm_a[2] && b0.size() == l.cm_b[0] * l.cm_b[1] * l.cm_b[2], DP_ERR_SHAPE, "concat matmul: input shapes");
-      const CmShape g = cm_shape(l);
-      int order[3]; bool same;
-      cm_axes_to(l.cm_left, CM_WANT_LEFT, order, same);
-      const std::vector<int64_t> a = same ? cur : transpose3(cur, l.cm_a, order);
-      cm_axes_to(l.cm_right, CM_WANT_RIGHT, order, same);
-      const std::vector<int64_t> b = same ? b0 : transpose3(b0, l.cm_b, order);
-      std::vector<int64_t> r;
-      for (size_t c = 0; c < g.C; c++) { std::vector<int64_t> y = matmul_i64(&a[c * g.R * g.M], &b[c * g.M * g.N], g.R, g.M, g.N, false); r.insert(r.end(), y.begin(), y.end()); }
-      if (l.cm_perm.empty()) o = std::move(r);
-      else { const size_t rs[3] = {g.C, g.R, g.N}; const int po[3] = {l.cm_perm[0], l.cm_perm[1], l.cm_perm[2]}; o = transpose3(r, rs, po); }
+    } else if (l.kind == L_CONCAT_MATMUL) o = concat_matmul_op(l, cur, tr.in2[id]);
+    else if (l.kind == L_MHA) {  // Mha::evaluate_with_intermediate_outputs (mha.rs:216-300): qk, softmax, final_mul on the reshaped inputs
+      const size_t n = l.mha_shape[0] * l.mha_shape[1] * l.mha_shape[2];
+      DP_REQUIRE(cur.size() == n && tr.in2[id].size() == n && tr.in3[id].size() == n, DP_ERR_SHAPE, "mha: input shapes");
+      MhaTrace d;
+      d.softmax_in = concat_matmul_op(mha_qk_spec(l), cur, tr.in2[id]);
+      d.softmax_out = softmax_op(mha_softmax_spec(l), d.softmax_in, nullptr);
+      o = concat_matmul_op(mha_final_spec(l), d.softmax_out, tr.in3[id]);
+      tr.mha[id] = std::move(d);
     } else
     if (l.kind == L_DENSE) {
       DP_REQUIRE(cur.size() == l.ncols, DP_ERR_SHAPE, "dense input size mismatch");
@@ -583,11 +626,19 @@ inline void validate_model(const ModelSpec& m) {
   DP_REQUIRE(!m.layers.empty() && m.layers.size() < 4096, DP_ERR_SHAPE, "model: no layers");
   { size_t tot = 0; for (size_t n : input_tensor_lens(m)) { DP_REQUIRE(is_pow2(n), DP_ERR_SHAPE, "model: input length must be a power of two"); tot += n; }
     DP_REQUIRE(tot == m.input_len, DP_ERR_SHAPE, "model: the input tensors do not add up to input_len"); }
-  std::vector<size_t> lens, in_len, in2_len;
-  tensor_lens(m, lens, &in_len, &in2_len);
+  std::vector<size_t> lens, in_len, in2_len, in3_len;
+  tensor_lens(m, lens, &in_len, &in2_len, &in3_len);
   for (const Edge& e : output_edges(m)) DP_REQUIRE(e.from >= 0 && (size_t)e.from < m.layers.size() && e.slot >= 0 && (size_t)e.slot < out_degree(m.layers[(size_t)e.from]), DP_ERR_SHAPE, "model graph: output edge");
   for (size_t id = 0; id < m.layers.size(); id++) for (size_t j = 0; j < out_degree(m.layers[id]); j++) reader_of(m, (int)id, (int)j);  // exactly one reader each
   { std::vector<size_t> ins = input_tensor_lens(m); for (size_t q = 0; q < ins.size(); q++) reader_of(m, -1, (int)q); }
+  auto check_softmax = [](const LayerSpec& l, size_t cur) {
+    DP_REQUIRE(is_pow2(l.sm_shape[0]) && is_pow2(l.sm_shape[1]) && l.sm_shape[1] == l.sm_shape[2] && l.sm_shape[1] >= 2 && cur == l.sm_shape[0] * l.sm_shape[1] * l.sm_shape[2] && l.sm_shape[0] * l.sm_shape[1] >= 4, DP_ERR_SHAPE, "softmax: a padded [c][n][n] input with at least four rows");
+    DP_REQUIRE(l.sm_scalar >= 1 && l.sm_scalar < (int64_t(1) << 30) && l.sm_bkm >= (int64_t(1) << 17) && l.sm_bkm < (int64_t(1) << 40) && l.sm_table_size == dp_ceil_log2((size_t)(l.sm_bkm >> 16)) && l.sm_table_size <= 22, DP_ERR_ARG, "softmax: multiplier / bkm / table size");
+    DP_REQUIRE(l.sm_zero_chunks <= 3 && (l.sm_zero_chunks == 0) == (l.sm_zero_vars == 0) && l.sm_zero_vars <= 22 && l.sm_allowable_error >= 1 && l.sm_allowable_error <= (1 << 11), DP_ERR_ARG, "softmax: zero tables / allowable error");
+    // (the lookup argument here wants columns of at least four entries, logup.h: a one-bit zero table or an error table of two entries is
+    // refused; a front end can always widen the zero table by a bit — the value it holds just has a zero on top)
+    DP_REQUIRE((l.sm_zero_vars == 0 || l.sm_zero_vars >= 2) && l.sm_allowable_error >= 2, DP_ERR_ARG, "softmax: tables of fewer than four entries are not supported");
+  };
   for (size_t id = 0; id < m.layers.size(); id++) {
     const LayerSpec& l = m.layers[id];
     size_t cur = in_len[id];
@@ -634,13 +685,11 @@ inline void validate_model(const ModelSpec& m) {
       unsigned cs = l.clamping_size();
       DP_REQUIRE(cs >= 1 && cs <= 24 && cur >= 4, DP_ERR_ARG, "requant: unsupported clamping table size / tensor length");
     } else if (l.kind == L_RELU) { DP_REQUIRE(cur >= 4, DP_ERR_SHAPE, "relu: tensor length must be >= 4"); }
-    else if (l.kind == L_SOFTMAX) {
-      DP_REQUIRE(is_pow2(l.sm_shape[0]) && is_pow2(l.sm_shape[1]) && l.sm_shape[1] == l.sm_shape[2] && l.sm_shape[1] >= 2 && cur == l.sm_shape[0] * l.sm_shape[1] * l.sm_shape[2] && l.sm_shape[0] * l.sm_shape[1] >= 4, DP_ERR_SHAPE, "softmax: a padded [c][n][n] input with at least four rows");
-      DP_REQUIRE(l.sm_scalar >= 1 && l.sm_scalar < (int64_t(1) << 30) && l.sm_bkm >= (int64_t(1) << 17) && l.sm_bkm < (int64_t(1) << 40) && l.sm_table_size == dp_ceil_log2((size_t)(l.sm_bkm >> 16)) && l.sm_table_size <= 22, DP_ERR_ARG, "softmax: multiplier / bkm / table size");
-      DP_REQUIRE(l.sm_zero_chunks <= 3 && (l.sm_zero_chunks == 0) == (l.sm_zero_vars == 0) && l.sm_zero_vars <= 22 && l.sm_allowable_error >= 1 && l.sm_allowable_error <= (1 << 11), DP_ERR_ARG, "softmax: zero tables / allowable error");
-      // (the lookup argument here wants columns of at least four entries, logup.h: a one-bit zero table or an error table of two entries is
-      // refused; a front end can always widen the zero table by a bit — the value it holds just has a zero on top)
-      DP_REQUIRE((l.sm_zero_vars == 0 || l.sm_zero_vars >= 2) && l.sm_allowable_error >= 2, DP_ERR_ARG, "softmax: tables of fewer than four entries are not supported");
+    else if (l.kind == L_SOFTMAX) check_softmax(l, cur);
+    else if (l.kind == L_MHA) {  // three equally long inputs; the sub-layers' own conditions (head_dim is the mat_mul dimension of qk, seq of final_mul)
+      const size_t S = l.mha_shape[0], H = l.mha_shape[1], D = l.mha_shape[2];
+      DP_REQUIRE(is_pow2(S) && is_pow2(H) && is_pow2(D) && S >= 2 && D >= 2 && S <= (size_t(1) << 12) && H <= (size_t(1) << 12) && D <= (size_t(1) << 12) && cur == S * H * D && in2_len[id] == cur && in3_len[id] == cur, DP_ERR_SHAPE, "mha: Q, K, V of [seq >= 2][heads][head_dim >= 2] entries each, powers of two");
+      check_softmax(mha_softmax_spec(l), H * S * S);
     }
     else if (l.kind == L_LAYERNORM) {
       const size_t fd = l.weights.size();
@@ -671,8 +720,11 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
   auto add = [&](TableType t) { for (auto& x : ts) if (x == t) return; ts.push_back(t); };
   std::vector<size_t> lens; tensor_lens(m, lens);
   for (size_t id = 0; id < m.layers.size(); id++) {
-    const LayerSpec& l = m.layers[id];
-    const size_t cur = lens[id];  // (Requant / Relu: also the length of the input; MaxPool: of the output, as the committed polynomials are)
+    // an Mha node brings the tables of its softmax and witness polynomials as long as the [heads][seq][seq] products (Mha::step_info, mha.rs:432-503)
+    const LayerSpec& l0 = m.layers[id];
+    const LayerSpec sub = l0.kind == L_MHA ? mha_softmax_spec(l0) : LayerSpec();
+    const LayerSpec& l = l0.kind == L_MHA ? sub : l0;
+    const size_t cur = l0.kind == L_MHA ? sub.sm_shape[0] * sub.sm_shape[1] * sub.sm_shape[2] : lens[id];  // (Requant / Relu: also the length of the input; MaxPool: of the output, as the committed polynomials are)
     if (l.kind == L_REQUANT) { add({2, 0}); add({3, l.clamping_size()}); mpl = std::max(mpl, next_pow2(cur)); }
     else if (l.kind == L_RELU) { add({0, 0}); mpl = std::max(mpl, next_pow2(cur)); }
     else if (l.kind == L_MAXPOOL) { add({2, 0}); mpl = std::max(mpl, next_pow2(cur)); }
@@ -822,7 +874,10 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
   std::vector<Pending> pend;
   std::vector<std::vector<int64_t>> lates; std::vector<size_t> late_ids;
   for (size_t id = 0; id < ctx.model.layers.size(); id++) {
-    const LayerSpec& l = ctx.model.layers[id];
+    // Mha::gen_lookup_witness (mha.rs:706-719): the witness of its softmax on the products Q K^T, under the node's own id
+    const LayerSpec& l0 = ctx.model.layers[id];
+    const LayerSpec sub = l0.kind == L_MHA ? mha_softmax_spec(l0) : LayerSpec();
+    const LayerSpec& l = l0.kind == L_MHA ? sub : l0;
     if (l.kind == L_REQUANT) {
       unsigned shift = l.shift(); int64_t rounding = int64_t(1) << (shift - 1), mask = (int64_t(1) << shift) - 1;
       std::vector<int64_t> cin, cout, shifted;
@@ -867,7 +922,7 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       pend.push_back(pi); pend.push_back(pr);
     } else if (l.kind == L_SOFTMAX) {  // Softmax::lookup_witness (softmax.rs:890-1066)
       SoftmaxTrace& d = ps.sm_trace[id];
-      softmax_op(l, tr.in[id], &d);
+      softmax_op(l, l0.kind == L_MHA ? tr.mha.at(id).softmax_in : tr.in[id], &d);
       TableType st = softmax_table(l), rt{2, 0}, et = softmax_error_table(l), zt{6, l.sm_zero_vars};
       for (int64_t v : d.low) counts[rt][v] += 1;
       for (int64_t v : d.high) counts[rt][v] += 1;
@@ -1788,6 +1843,19 @@ inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t) {
     if (l.kind == L_ADD2) { made[id] = prove_add2(ps, id, cur, tr.in[id], tr.in2[id]); continue; }
     if (l.kind == L_CONCAT_MATMUL) { made[id] = prove_concat_matmul(ps, id, l, cur, tr.in[id], tr.in2[id]); continue; }
     if (l.kind == L_QKV) { made[id] = prove_qkv(ps, id, l, got, tr.in[id]); continue; }
+    if (l.kind == L_MHA) {  // Mha::prove (mha.rs:633-704): final_mul on (probabilities, V), the softmax, qk on (Q, K); the claims on Q, K, V in this order
+      const MhaTrace& d = tr.mha.at(id);
+      LayerProof lp; lp.kind = L_MHA;
+      std::vector<Claim> fm = prove_concat_matmul(ps, id, mha_final_spec(l), cur, d.softmax_out, tr.in3[id]);
+      lp.mha_final = ps.proofs.at(id).cmm;
+      const Claim sc = prove_softmax(ps, id, mha_softmax_spec(l), fm[0]);
+      lp.sm = ps.proofs.at(id).sm;
+      std::vector<Claim> qk = prove_concat_matmul(ps, id, mha_qk_spec(l), sc, tr.in[id], tr.in2[id]);
+      lp.mha_qk = ps.proofs.at(id).cmm;
+      ps.proofs[id] = lp;
+      made[id] = {qk[0], qk[1], fm[1]};
+      continue;
+    }
     if (l.kind == L_DENSE) cur = prove_dense(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_MATMUL) cur = prove_matmul(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_ADD) cur = prove_add(ps, id, l, cur, tr.in[id]);
@@ -1851,7 +1919,7 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
     if (it->second.kind == L_REQUANT) { add_fracs(it->second.req.clamping_lookup); add_fracs(it->second.req.shifted_lookup); }
     if (it->second.kind == L_MAXPOOL) add_fracs(it->second.pool.lookup);
     if (it->second.kind == L_LAYERNORM) for (auto& lg : it->second.ln.logup_proofs) add_fracs(lg);
-    if (it->second.kind == L_SOFTMAX) for (auto& lg : it->second.sm.logup_proofs) add_fracs(lg);
+    if (it->second.kind == L_SOFTMAX || it->second.kind == L_MHA) for (auto& lg : it->second.sm.logup_proofs) add_fracs(lg);
   }
   DP_REQUIRE(proof.steps.size() == n_provable, DP_ERR_VERIFY, "unexpected layer proofs");
   for (auto& tp : proof.table_proofs) add_fracs(tp.lookup);
@@ -1890,14 +1958,36 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
     DP_REQUIRE(ex_eq(ex_mul(sp.evals[0], sp.evals[1]), sub.expected_evaluation), DP_ERR_VERIFY, "same_poly: final evals invalid");
     return {sp.sumcheck.point, sp.evals[1]};
   };
-  for (size_t id : proving_order(m)) {
-    const LayerSpec& l = m.layers[id];
+  // MhaCtx::verify (mha.rs:792-893) is the verification of its three sub-layers one after the other — final_mul on the node's output claim, the
+  // softmax on final_mul's first claim, qk on the softmax's claim — handing on the claims on Q, K (from qk) and V (from final_mul): an Mha node
+  // is walked as three steps (part 1, 2, 3) through the branches below, each with the sub-layer's description and its part of the MhaProof
+  struct VStep { size_t id; int part; };
+  std::vector<VStep> vsteps;
+  for (size_t id : proving_order(m)) { if (m.layers[id].kind == L_MHA) for (int part = 1; part <= 3; part++) vsteps.push_back({id, part}); else vsteps.push_back({id, 0}); }
+  std::vector<Claim> mha_hold;
+  LayerSpec sub_spec; LayerProof sub_proof;
+  auto finish_part = [&](const VStep& vs) {
+    if (vs.part == 1) { DP_REQUIRE(made.at(vs.id).size() == 2, DP_ERR_VERIFY, "mha: final_mul claims"); mha_hold = made.at(vs.id); }
+    if (vs.part == 3) { DP_REQUIRE(made.at(vs.id).size() == 2 && mha_hold.size() == 2, DP_ERR_VERIFY, "mha: qk claims"); made[vs.id] = {made[vs.id][0], made[vs.id][1], mha_hold[1]}; mha_hold.clear(); }
+  };
+  for (const VStep& vs : vsteps) {
+    const size_t id = vs.id;
+    const LayerSpec& l0 = m.layers[id];
+    if (vs.part) {
+      const LayerProof& mp = proof.steps.at(id);
+      sub_spec = vs.part == 1 ? mha_final_spec(l0) : vs.part == 2 ? mha_softmax_spec(l0) : mha_qk_spec(l0);
+      sub_proof = LayerProof(); sub_proof.kind = sub_spec.kind;
+      if (vs.part == 1) sub_proof.cmm = mp.mha_final; else if (vs.part == 2) sub_proof.sm = mp.sm; else sub_proof.cmm = mp.mha_qk;
+    }
+    const LayerSpec& l = vs.part ? sub_spec : l0;
     std::vector<Claim> got;
-    for (size_t j = 0; j < out_degree(l); j++) { const Reader_ rd = reader_of(m, (int)id, (int)j); got.push_back(rd.to < 0 ? on_outputs.at((size_t)rd.port) : made.at((size_t)rd.to).at((size_t)rd.port)); }
+    if (vs.part == 2) got = {mha_hold.at(0)};
+    else if (vs.part == 3) got = {made.at(id).at(0)};
+    else for (size_t j = 0; j < out_degree(l0); j++) { const Reader_ rd = reader_of(m, (int)id, (int)j); got.push_back(rd.to < 0 ? on_outputs.at((size_t)rd.port) : made.at((size_t)rd.to).at((size_t)rd.port)); }
     Claim cur = got[0];
-    size_t cur_len = lens[id];
+    size_t cur_len = vs.part >= 2 ? l0.mha_shape[1] * l0.mha_shape[0] * l0.mha_shape[0] : lens[id];
     if (l.kind == L_FLATTEN) { made[id] = {cur}; continue; }  // claims pass through a non-provable node unchanged (verifier.rs:205-209)
-    const LayerProof& lp = proof.steps.at(id);
+    const LayerProof& lp = vs.part ? sub_proof : proof.steps.at(id);
     if (l.kind == L_MATMUL2) {  // MatMulCtx::verify_matmul (matrix_mul.rs:1048-1139), both operands inputs: no commitment, two claims out
       const MatMulProof& mp = lp.matmul;
       const size_t s_ = l.nrows ? in_lens[id] / l.nrows : 0;
@@ -1932,6 +2022,7 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       DP_REQUIRE(ex_eq(identity_eval(s_concat, p.concat), cp.individual_claims[0]), DP_ERR_VERIFY, "concat matmul: wrong evaluation of the beta table");
       DP_REQUIRE(ex_eq(ex_mul(ex_mul(cp.individual_claims[0], cp.individual_claims[1]), cp.individual_claims[2]), sub.expected_evaluation), DP_ERR_VERIFY, "concat matmul: sumcheck claim failed");
       made[id] = {{cm_input_point(l.cm_left, s_concat, s_mm, p.row), cp.individual_claims[1]}, {cm_input_point(l.cm_right, s_concat, s_mm, p.col), cp.individual_claims[2]}};
+      finish_part(vs);
       continue;
     }
     if (l.kind == L_QKV) {  // QKVCtx::verify (qkv.rs:680-810)
@@ -2320,6 +2411,7 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       cur = vcl.claims[0];
     }
     made[id] = {cur};
+    finish_part(vs);
   }
   // table proofs (verifier.rs:320-383)
   DP_REQUIRE(proof.table_proofs.size() == vc.tables.size(), DP_ERR_VERIFY, "wrong number of table proofs");
@@ -2425,6 +2517,10 @@ inline std::vector<u64> vctx_to_words(const VerifierContext& v) {
       l.right_shift = l.sm_table_size; l.fp_scale = l.sm_zero_chunks; l.fixed_point_multiplier = l.sm_scalar; l.intermediate_bit_size = l.sm_temp_bits;
       l.kw = l.sm_zero_vars; l.kx = (size_t)l.sm_bkm; l.real_nw = (size_t)l.sm_allowable_error; for (int k = 0; k < 3; k++) l.unp_out[k] = l.sm_shape[k];
     }
+    if (l.kind == L_MHA) {  // an Mha node: its softmax in the same slots, (seq, heads, head_dim) where a Softmax has its shape
+      l.right_shift = l.sm_table_size; l.fp_scale = l.sm_zero_chunks; l.fixed_point_multiplier = l.sm_scalar; l.intermediate_bit_size = l.sm_temp_bits;
+      l.kw = l.sm_zero_vars; l.kx = (size_t)l.sm_bkm; l.real_nw = (size_t)l.sm_allowable_error; for (int k = 0; k < 3; k++) l.unp_out[k] = l.mha_shape[k];
+    }
     if (l.kind == L_LAYERNORM) {  // a LayerNorm rides in the slots of a Requant: N, range check bits, log2 of the top chunk scalar, multiplier, epsilon bits
       l.ncols = l.ln_dim_size; l.right_shift = l.ln_range_check_bits; l.fp_scale = l.ln_top_chunk_scalar_log; l.fixed_point_multiplier = l.ln_multiplier; l.intermediate_bit_size = l.ln_eps_bits;
     }
@@ -2484,7 +2580,15 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
     l.kw = (size_t)rd(); l.kx = (size_t)rd(); l.real_nw = (size_t)rd(); l.nw = (size_t)rd();
     for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();
     for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd();
-    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_SOFTMAX, DP_ERR_ARG, "verifier blob: layer kind");
+    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_MHA, DP_ERR_ARG, "verifier blob: layer kind");
+    if (l.kind == L_MHA) {
+      l.sm_table_size = l.right_shift; l.sm_zero_chunks = l.fp_scale; l.sm_scalar = l.fixed_point_multiplier; l.sm_temp_bits = (uint32_t)l.intermediate_bit_size;
+      l.sm_zero_vars = (unsigned)l.kw; l.sm_bkm = (int64_t)l.kx; l.sm_allowable_error = (int64_t)l.real_nw; for (int k = 0; k < 3; k++) { l.mha_shape[k] = l.unp_out[k]; l.unp_out[k] = 0; }
+      l.right_shift = l.fp_scale = l.intermediate_bit_size = 0; l.fixed_point_multiplier = 0; l.kw = l.kx = l.real_nw = 0;
+      DP_REQUIRE(is_pow2(l.mha_shape[0]) && is_pow2(l.mha_shape[1]) && is_pow2(l.mha_shape[2]) && l.mha_shape[0] >= 2 && l.mha_shape[2] >= 2 && l.mha_shape[0] <= (size_t(1) << 12) && l.mha_shape[1] <= (size_t(1) << 12) && l.mha_shape[2] <= (size_t(1) << 12)
+                 && l.sm_scalar >= 1 && l.sm_bkm >= (int64_t(1) << 17) && l.sm_bkm < (int64_t(1) << 40) && l.sm_table_size == dp_ceil_log2((size_t)(l.sm_bkm >> 16)) && l.sm_zero_chunks <= 3 && l.sm_zero_vars <= 22
+                 && (l.sm_zero_chunks == 0) == (l.sm_zero_vars == 0) && l.sm_allowable_error >= 1 && l.sm_allowable_error <= (1 << 11), DP_ERR_ARG, "verifier blob: mha parameters");
+    }
     if (l.kind == L_SOFTMAX) {
       l.sm_table_size = l.right_shift; l.sm_zero_chunks = l.fp_scale; l.sm_scalar = l.fixed_point_multiplier; l.sm_temp_bits = (uint32_t)l.intermediate_bit_size;
       l.sm_zero_vars = (unsigned)l.kw; l.sm_bkm = (int64_t)l.kx; l.sm_allowable_error = (int64_t)l.real_nw; for (int k = 0; k < 3; k++) { l.sm_shape[k] = l.unp_out[k]; l.unp_out[k] = 0; }
@@ -2531,7 +2635,7 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
     size_t no = (size_t)rd(); DP_REQUIRE(no < 4096, DP_ERR_ARG, "verifier blob: outputs");
     for (size_t i = 0; i < no; i++) v.shape.outputs.push_back(rd_edge());
     for (auto& l : v.shape.layers) {
-      size_t k = (size_t)rd(); DP_REQUIRE(k <= 2, DP_ERR_ARG, "verifier blob: node inputs");
+      size_t k = (size_t)rd(); DP_REQUIRE(k <= 3, DP_ERR_ARG, "verifier blob: node inputs");
       for (size_t i = 0; i < k; i++) l.inputs.push_back(rd_edge());
       if (l.kind == L_CONCAT_MATMUL) {
         for (int d = 0; d < 3; d++) { l.cm_a[d] = (size_t)rd(); DP_REQUIRE(is_pow2(l.cm_a[d]) && l.cm_a[d] <= (size_t(1) << 24), DP_ERR_ARG, "verifier blob: concat matmul shape"); }

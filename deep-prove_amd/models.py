@@ -6,7 +6,7 @@ import math
 import numpy as np
 
 L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_FLATTEN, L_MATMUL, L_ADD, L_EMBED, L_POSITIONAL = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
-L_LAYERNORM, L_SOFTMAX = 14, 15
+L_LAYERNORM, L_SOFTMAX, L_MHA = 14, 15, 16
 L_MATMUL2, L_ADD2, L_CONCAT_MATMUL, L_QKV = 10, 11, 12, 13  # nodes of a model GRAPH: two-input MatMul / Add, ConcatMatMul, QKV
 BIT_LEN = 8
 FIXED_POINT_SCALE = 25  # zkml/src/layers/requant.rs:47
@@ -75,15 +75,15 @@ def _round_away(x):
     return int((a + 1 if np.abs(x) - a >= np.float32(0.5) else a) * (1 if x >= 0 else -1))
 
 
-def softmax_params(in_scale, max_context, temperature=1.0):
+def softmax_params(in_scale, max_context, temperature=1.0, max_abs=127):
     """Softmax::quantise (zkml/src/layers/transformer/softmax.rs:153-233) with calc_softmax_error (:323-345), f32 arithmetic: the multiplier
     to the scale 2^24, bkm (inputs beyond it are mapped to zero), the size of the exponential table, the zero tables for the remaining
     high bits, the allowable error of a row sum"""
     f = np.float32
     sf, osf, inv_temp, in_scale, ctx = f(1 << 24), f(1 << 12), f(1.0) / f(temperature), f(in_scale), f(max_context)
     scalar = _round_away(sf * in_scale)
-    max_shift = _round_away(-sf * (inv_temp * np.log(ctx) + f(127) * in_scale))
-    sig_min = (-127 * scalar + max_shift) >> 16
+    max_shift = _round_away(-sf * (inv_temp * np.log(ctx) + f(max_abs) * in_scale))  # input_scaling.max() = scale * domain (127 after a Requant)
+    sig_min = (-max_abs * scalar + max_shift) >> 16
     min_bits = (abs(sig_min) - 1).bit_length()
     bkm_f = sf * inv_temp * (np.log(f(2) * ctx) + np.log(osf)) / f(2)
     cd = sf * inv_temp
@@ -547,6 +547,12 @@ class GraphBuilder:
         assert len(shape) == 3 and shape[1] == shape[2]
         return self._add(dict(kind=L_SOFTMAX, shape=tuple(shape), **softmax_params(in_scale, shape[2], temperature)), [src])
 
+    def mha(self, q, k, v, seq, heads, head_dim, in_scale, max_abs):
+        """Mha (layers/transformer/mha.rs:147-186) as ONE node over Q, K, V ([seq][heads * head_dim] each): Q_h K_h^T per head, the Softmax with
+        scale 1 / sqrt(head_dim) directly on the products (in_scale = scale of Q times scale of K, max_abs = qk.output_domain()), probabilities
+        times V_h laid out as [seq][heads][head_dim]; the output carries the scale 2^-12 of the probabilities times the scale of V"""
+        return self._add(dict(kind=L_MHA, shape=(seq, heads, head_dim), **softmax_params(in_scale, seq, 1.0 / math.sqrt(head_dim), max_abs)), [q, k, v])
+
     def relu(self, src):
         return self._add(dict(kind=L_RELU), [src])
 
@@ -584,6 +590,8 @@ class GraphBuilder:
             elif k == L_LAYERNORM:
                 parts += [np.array(pre + [l["dim"], l["dim_size"], l["multiplier"], l["eps_bits"], l["range_check_bits"], l["top_chunk_scalar_log"]], dtype=np.int64), l["gamma"], l["beta"]]
             elif k == L_SOFTMAX:
+                parts.append(np.array(pre + [*l["shape"], l["scalar"], l["temp_bits"], l["in_scale_bits"], l["table_size"], l["bkm"], l["zero_chunks"], l["zero_vars"], l["allowable_error"]], dtype=np.int64))
+            elif k == L_MHA:
                 parts.append(np.array(pre + [*l["shape"], l["scalar"], l["temp_bits"], l["in_scale_bits"], l["table_size"], l["bkm"], l["zero_chunks"], l["zero_vars"], l["allowable_error"]], dtype=np.int64))
             elif k == L_RELU:
                 parts.append(np.array(pre, dtype=np.int64))
@@ -636,6 +644,12 @@ class GraphBuilder:
                 y = layernorm_apply(l, a)[0]
             elif k == L_SOFTMAX:
                 y = softmax_apply(l, a)
+            elif k == L_MHA:
+                S, H, D = l["shape"]
+                qh, kh, vh = (get(e).reshape(S, H, D).transpose(1, 0, 2) for e in edges)  # [h][s][d]
+                scores = np.einsum("hsd,htd->hst", qh, kh)
+                probs = softmax_apply(dict(l, shape=(H, S, S)), scores.reshape(-1)).reshape(H, S, S)
+                y = np.einsum("hst,htd->hsd", probs, vh).transpose(1, 0, 2).reshape(-1)
             vals[(i, 0)] = y
         outs = self.outputs if self.outputs is not None else [(len(self.nodes) - 1, 0)]
         return np.concatenate([vals[e] for e in outs])
@@ -678,6 +692,25 @@ def transformer_block(seq, emb, heads, head_dim, config):
     sm = g.softmax((sr, 0), (heads, seq, seq), in_scale=8.0 / 127.0)
     av = g.concat_matmul((sm, 0), (rq[2], 0), (heads, seq, seq), (seq, heads, head_dim), (0, 2, 1), (1, 0, 2), perm=(1, 0, 2))
     ar = g.requant((av, 0), 1.0 / 4096.0, 12 + BIT_LEN + max(0, (seq - 1).bit_length()) + 1)
+    pr = g.matmul_const((ar, 0), n, emb)
+    prq = g.requant((pr, 0), 2.5 / math.sqrt(n) / 127.0, dense_output_bitsize(n))
+    g.add2((prq, 0), (-1, 1))
+    return g
+
+
+def mha_block(seq, emb, heads, head_dim, config):
+    """The attention half of a transformer block with the reference's Mha layer as ONE node (transformer/mha.rs): X -> LayerNorm -> Requant ->
+    QKV -> Requant (x3) -> Mha (Q K^T, Softmax with scale 1 / sqrt(head_dim) straight on the products, times V) -> Requant -> output projection ->
+    Requant; + the residual (a second input tensor)"""
+    n = heads * head_dim
+    g = GraphBuilder([seq * emb, seq * emb], config)
+    ln, ibs = g.layernorm((-1, 0), emb)
+    lr = g.requant_shift((ln, 0), ibs - 16, ibs)
+    q = g.qkv((lr, 0), emb, n)
+    rq = [g.requant((q, w), 2.5 / math.sqrt(emb) / 127.0, dense_output_bitsize(emb)) for w in range(3)]
+    s_in = 1.0 / 16.0  # scale of Q and of K: the products carry s_in^2
+    att = g.mha((rq[0], 0), (rq[1], 0), (rq[2], 0), seq, heads, head_dim, s_in * s_in, (1 << dense_output_bitsize(head_dim)) - 1)
+    ar = g.requant((att, 0), 1.0 / 4096.0, 12 + BIT_LEN + max(0, (seq - 1).bit_length()) + 1)
     pr = g.matmul_const((ar, 0), n, emb)
     prq = g.requant((pr, 0), 2.5 / math.sqrt(n) / 127.0, dense_output_bitsize(n))
     g.add2((prq, 0), (-1, 1))

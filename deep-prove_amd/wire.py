@@ -29,7 +29,7 @@ MAGIC = 0x31464F4F52505044
 L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_MATMUL, L_ADD, L_EMBED, L_POSITIONAL = 0, 1, 2, 3, 4, 6, 7, 8, 9
 # nodes of a model graph: MatMul / Add of two inputs share the reference's MatMulProof / AddProof variants with the constant forms (on the way
 # back from the wire format they come out as kinds 6 / 7); ConcatMatMul and QKV have their own
-L_MATMUL2, L_ADD2, L_CONCAT_MATMUL, L_QKV, L_LAYERNORM, L_SOFTMAX = 10, 11, 12, 13, 14, 15
+L_MATMUL2, L_ADD2, L_CONCAT_MATMUL, L_QKV, L_LAYERNORM, L_SOFTMAX, L_MHA = 10, 11, 12, 13, 14, 15, 16
 
 
 class Conventions:
@@ -115,6 +115,10 @@ def parse_stream(words):
             lp = {"sumcheck": r.iop(), "aggregation_proof": {"sumcheck": r.iop(), "evals": r.ve()}, "pre_bias_evals": r.ve(), "individual_claims": r.ve()}
         elif kind == L_SOFTMAX:
             lp = {"logup_proofs": [r.logup() for _ in range(r.u())], "commitments": [r.comm() for _ in range(r.u())], "accumulation_proof": r.iop(), "mask_proof": r.iop(), "evaluations": r.ve()}
+        elif kind == L_MHA:  # MhaProof {final_mul_proof, softmax_proof, qk_proof} (layers/transformer/mha.rs:122-128)
+            lp = {"final_mul_proof": {"sumcheck_proof": r.iop(), "individual_claims": r.ve()}}
+            lp["softmax_proof"] = {"logup_proofs": [r.logup() for _ in range(r.u())], "commitments": [r.comm() for _ in range(r.u())], "accumulation_proof": r.iop(), "mask_proof": r.iop(), "evaluations": r.ve()}
+            lp["qk_proof"] = {"sumcheck_proof": r.iop(), "individual_claims": r.ve()}
         elif kind == L_LAYERNORM:
             lp = {"logup_proofs": [r.logup() for _ in range(r.u())], "commitments": [r.comm() for _ in range(r.u())], "accumulation_proof": r.iop(), "io_proof": r.iop(),
                   "input_proof": r.iop(), "acc_evals": r.ve(), "evaluations": r.ve(), "gamma_eval": r.e(), "beta_eval": r.e()}
@@ -232,6 +236,13 @@ def to_serde_model(tree, conv=Conventions):
         elif kind == L_SOFTMAX:  # SoftmaxProof (layers/transformer/softmax.rs:102-117)
             v = {"Softmax": {"logup_proofs": [_logup(x, c) for x in lp["logup_proofs"]], "commitments": [_comm(k, c) for k in lp["commitments"]],
                              "accumulation_proof": _iop(lp["accumulation_proof"], c), "mask_proof": _iop(lp["mask_proof"], c), "evaluations": _ve(lp["evaluations"], c)}}
+        elif kind == L_MHA:  # MhaProof {final_mul_proof: ConcatMatMulProof, softmax_proof: SoftmaxProof, qk_proof: ConcatMatMulProof} (transformer/mha.rs:122-128)
+            sp = lp["softmax_proof"]
+            cm = lambda q: {"sumcheck_proof": _iop(q["sumcheck_proof"], c), "individual_claims": _ve(q["individual_claims"], c)}
+            v = {"Mha": {"final_mul_proof": cm(lp["final_mul_proof"]),
+                         "softmax_proof": {"logup_proofs": [_logup(x, c) for x in sp["logup_proofs"]], "commitments": [_comm(k, c) for k in sp["commitments"]],
+                                           "accumulation_proof": _iop(sp["accumulation_proof"], c), "mask_proof": _iop(sp["mask_proof"], c), "evaluations": _ve(sp["evaluations"], c)},
+                         "qk_proof": cm(lp["qk_proof"])}}
         elif kind == L_LAYERNORM:  # LayerNormProof (layers/transformer/layernorm.rs:644-667), fields in declaration order
             v = {"LayerNorm": {"logup_proofs": [_logup(x, c) for x in lp["logup_proofs"]], "commitments": [_comm(k, c) for k in lp["commitments"]],
                                "accumulation_proof": _iop(lp["accumulation_proof"], c), "io_proof": _iop(lp["io_proof"], c), "input_proof": _iop(lp["input_proof"], c),
@@ -478,7 +489,7 @@ def from_rmp(data, conv=Conventions):
     w = _Writer(conv)
     w.w.append(MAGIC); w.w.append(len(model["steps"]))
     kinds = {"Dense": L_DENSE, "Requant": L_REQUANT, "Activation": L_RELU, "Convolution": L_CONV, "Pooling": L_MAXPOOL, "MatMul": L_MATMUL, "Add": L_ADD, "Embeddings": L_EMBED, "Positional": L_POSITIONAL,
-             "ConcatMatMul": L_CONCAT_MATMUL, "QKV": L_QKV, "LayerNorm": L_LAYERNORM, "Softmax": L_SOFTMAX}
+             "ConcatMatMul": L_CONCAT_MATMUL, "QKV": L_QKV, "LayerNorm": L_LAYERNORM, "Softmax": L_SOFTMAX, "Mha": L_MHA}
     for node in sorted(model["steps"]):
         (name, lp), = model["steps"][node].items()
         w.w.append(node); w.w.append(kinds[name])
@@ -501,6 +512,17 @@ def from_rmp(data, conv=Conventions):
             w.w.append(0 if lp["bias_eval"] is None else 1)
             if lp["bias_eval"] is not None:
                 w.e(lp["bias_eval"])
+        elif name == "Mha":
+            w.iop(lp["final_mul_proof"]["sumcheck_proof"]); w.ve(lp["final_mul_proof"]["individual_claims"])
+            sp = lp["softmax_proof"]
+            w.w.append(len(sp["logup_proofs"]))
+            for x in sp["logup_proofs"]:
+                w.logup(x)
+            w.w.append(len(sp["commitments"]))
+            for k in sp["commitments"]:
+                w.comm(k)
+            w.iop(sp["accumulation_proof"]); w.iop(sp["mask_proof"]); w.ve(sp["evaluations"])
+            w.iop(lp["qk_proof"]["sumcheck_proof"]); w.ve(lp["qk_proof"]["individual_claims"])
         elif name == "Softmax":
             w.w.append(len(lp["logup_proofs"]))
             for x in lp["logup_proofs"]:

@@ -271,7 +271,7 @@ int32_t dp_pcs_simple_batch_verify(size_t max_poly_size, const uint64_t root[4],
  *          one sub-matrix evaluation per doubling.
  * GRAPH form (zkml/src/layers/provable/mod.rs:195-565: nodes with several inputs / outputs, models with several input / output tensors):
  *   input_len (the sum of the input tensors), -(number of nodes) — the NEGATIVE count marks the form —, number of input tensors and their
- *   lengths, number of output tensors and one (node, slot) pair each; then per node: kind, number of inputs (1 or 2), one (node, slot) pair
+ *   lengths, number of output tensors and one (node, slot) pair each; then per node: kind, number of inputs (1 .. 3), one (node, slot) pair
  *   per input (node = -1: input tensor `slot` of the model), then the parameters of the kind as above. A node reads only nodes with
  *   smaller ids; every tensor has exactly one reader (what the reference proves, provable/mod.rs:235-270). An input vector is the
  *   concatenation of the input tensors, an output vector that of the output tensors. Kinds that only exist in a graph:
@@ -293,8 +293,14 @@ int32_t dp_pcs_simple_batch_verify(size_t max_poly_size, const uint64_t root[4],
  *      bits per zero chunk (0 or 2..22), allowable error of a row sum (2..2048; QuantisedSoftmaxData / SoftmaxCtx). The output has the scale 2^-12.
  *      The exponential table and the error table commit their output column once per context. Lookup tables of fewer than four entries (a one-bit
  *      zero table) are refused: widen the zero table by a bit.
- *      (layers/transformer/qkv.rs:462-630)
- *   Embeddings stay the first node of a chain. Not built: MHA, Softmax, LayerNorm, Logits. */
+ *   16 Mha (zkml/src/layers/transformer/mha.rs:133-186,633-724) as ONE node with THREE inputs Q, K, V, each a padded [seq][heads * head_dim] matrix
+ *      read as [seq][heads][head_dim]: seq, heads, head_dim (powers of two, seq >= 2, head_dim >= 2, heads * seq >= 4), then the parameters of its
+ *      softmax exactly as kind 15 lists them after the shape (multiplier .. allowable error; the softmax works straight on the products Q_h K_h^T,
+ *      so its input scale is scale(Q) scale(K), its domain qk.output_domain(), 1 / temperature = sqrt(head_dim)). Output [seq][heads * head_dim]
+ *      = softmax(Q_h K_h^T) V_h per head at the scale 2^-12 scale(V). One proof step per node: MhaProof {final_mul, softmax, qk}; the claims it
+ *      hands on are those on Q, K, V in this order.
+ *   A node has one, two or (kind 16) three inputs. Embeddings stay the first node of a chain. Not built: Logits (no consistent transcript in the
+ *   reference outside cfg(test)). */
 int32_t dp_model_setup(dp_ctx* ctx, const int64_t* model_blob, size_t nwords, dp_model** out);
 int32_t dp_model_free(dp_model* m);
 /* runs inference on the host (Model::run, not part of proving time) then Prover::prove on the device.

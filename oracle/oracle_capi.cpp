@@ -29,7 +29,7 @@ static Model parse_model(const int64_t* b, size_t n) {
   }
   for (size_t i = 0; i < nl; i++) {
     Layer l; l.kind = (LayerKind)rd();
-    if (graph) { size_t nin = (size_t)rd(); if (nin == 0 || nin > 2) throw std::runtime_error("model blob: a node has one or two inputs"); for (size_t q = 0; q < nin; q++) l.inputs.push_back(rd_wire()); }
+    if (graph) { size_t nin = (size_t)rd(); if (nin == 0 || nin > 3) throw std::runtime_error("model blob: a node has one to three inputs"); for (size_t q = 0; q < nin; q++) l.inputs.push_back(rd_wire()); }
     if (l.kind == L_MATMUL2) { l.nrows = (size_t)rd(); l.ncols = (size_t)rd(); l.transpose_b = (rd() & 2) != 0; }
     else if (l.kind == L_ADD2) { l.add_left = rd(); l.add_right = rd(); }
     else if (l.kind == L_CONCAT_MATMUL) {
@@ -73,6 +73,11 @@ static Model parse_model(const int64_t* b, size_t n) {
       size_t nf = l.kw * l.kx * l.real_nw * l.real_nw;
       if (pos + nf + l.kw > n) throw std::runtime_error("model blob truncated");
       l.weights.assign(b + pos, b + pos + nf); pos += nf; l.bias.assign(b + pos, b + pos + l.kw); pos += l.kw;
+    } else if (l.kind == L_MHA) {  // [16, seq, heads, head_dim, then the softmax parameters as in kind 15 after the shape]
+      for (int k = 0; k < 3; k++) l.mha_shape[k] = (size_t)rd();
+      l.sm_scalar = rd(); l.sm_temp_bits = (uint32_t)rd(); l.sm_in_scale_bits = (uint32_t)rd(); l.sm_table_size = (unsigned)rd(); l.sm_bkm = rd();
+      l.sm_zero_chunks = (unsigned)rd(); l.sm_zero_vars = (unsigned)rd(); l.sm_allowable_error = rd();
+      if (l.sm_table_size < 1 || l.sm_table_size > 22 || l.sm_zero_chunks > 3 || l.sm_zero_vars > 22 || !l.mha_shape[0] || !l.mha_shape[1] || !l.mha_shape[2]) throw std::runtime_error("model blob: mha parameters");
     } else if (l.kind == L_MAXPOOL) { for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd(); }
     else if (l.kind == L_LAYERNORM) {  // dim, N, multiplier, eps bits, range check bits, log2 of the top chunk scalar, gamma[dim], beta[dim]
       size_t dim = (size_t)rd(); l.ln_dim_size = (size_t)rd(); l.ln_multiplier = rd(); l.ln_eps_bits = (uint32_t)rd(); l.ln_range_check_bits = (unsigned)rd(); l.ln_top_chunk_scalar_log = (unsigned)rd();

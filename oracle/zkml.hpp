@@ -172,7 +172,7 @@ static inline LogUpProof logup_batch_prove(const LogUpInput& in, Transcript& t) 
 
 // ------------------------------------------------------------------ model description
 enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8, L_POSITIONAL = 9,
-                 L_MATMUL2 = 10, L_ADD2 = 11, L_CONCAT_MATMUL = 12, L_QKV = 13, L_LAYERNORM = 14, L_SOFTMAX = 15 };
+                 L_MATMUL2 = 10, L_ADD2 = 11, L_CONCAT_MATMUL = 12, L_QKV = 13, L_LAYERNORM = 14, L_SOFTMAX = 15, L_MHA = 16 };
 // An edge of the model graph (layers/provable/mod.rs:195-229, Edge): output `index` of node `node`, or input tensor `index` of the model (node < 0)
 struct Wire { int node = -1; int index = 0; };
 struct Layer {
@@ -218,6 +218,10 @@ struct Layer {
   // exponential table (2^sm_table_size entries, zero from sm_bkm on), the zero tables of the bits above it, the allowable error of a row sum
   int64_t sm_scalar = 0, sm_bkm = 0, sm_allowable_error = 0; uint32_t sm_temp_bits = 0, sm_in_scale_bits = 0; unsigned sm_table_size = 0, sm_zero_chunks = 0, sm_zero_vars = 0;
   size_t sm_shape[3] = {0, 0, 0};
+  // mha (layers/transformer/mha.rs:133-186, Mha::new): ONE node over the three inputs Q, K, V, each a padded [seq][heads * head_dim] matrix read as
+  // [seq][heads][head_dim] (inputs_reshape); qk = ConcatMatMul (1,2,0) x (1,2,0) -> [heads][seq][seq]; the Softmax above (sm_* fields, sm_shape
+  // unused: it is [heads][seq][seq]) directly on the products; final_mul = ConcatMatMul (0,2,1) x (1,0,2) permuted (1,0,2) -> [seq][heads][head_dim]
+  size_t mha_shape[3] = {0, 0, 0};  // seq, heads, head_dim (padded)
   unsigned right_shift = 0, fp_scale = 0, intermediate_bit_size = 0;  // requant (requant.rs:46-73)
   int64_t fixed_point_multiplier = 0;
   unsigned shift() const { return fp_scale + right_shift; }
@@ -227,6 +231,29 @@ struct Layer {
 // outputs: the model's output tensors (empty: output 0 of the last node), concatenated in this order
 struct Model { size_t input_len = 0; std::vector<Layer> layers; std::vector<size_t> input_lens; std::vector<Wire> outputs; };
 static inline size_t n_outputs(const Layer& l) { return l.kind == L_QKV ? 3 : 1; }
+static inline size_t n_inputs(const Layer& l) { return l.kind == L_MHA ? 3 : (l.kind == L_MATMUL2 || l.kind == L_ADD2 || l.kind == L_CONCAT_MATMUL) ? 2 : 1; }
+// the three sub-layers of an Mha node (Mha::new, mha.rs:147-186)
+static inline Layer mha_qk_layer(const Layer& l) {
+  Layer s; s.kind = L_CONCAT_MATMUL;
+  for (int d = 0; d < 3; d++) s.cm_a[d] = s.cm_b[d] = l.mha_shape[d];
+  const int dims[3] = {1, 2, 0}; for (int d = 0; d < 3; d++) s.cm_left[d] = s.cm_right[d] = dims[d];
+  return s;
+}
+static inline Layer mha_softmax_layer(const Layer& l) {
+  Layer s; s.kind = L_SOFTMAX;
+  s.sm_scalar = l.sm_scalar; s.sm_bkm = l.sm_bkm; s.sm_allowable_error = l.sm_allowable_error; s.sm_temp_bits = l.sm_temp_bits; s.sm_in_scale_bits = l.sm_in_scale_bits;
+  s.sm_table_size = l.sm_table_size; s.sm_zero_chunks = l.sm_zero_chunks; s.sm_zero_vars = l.sm_zero_vars;
+  s.sm_shape[0] = l.mha_shape[1]; s.sm_shape[1] = s.sm_shape[2] = l.mha_shape[0];
+  return s;
+}
+static inline Layer mha_final_layer(const Layer& l) {
+  Layer s; s.kind = L_CONCAT_MATMUL;
+  s.cm_a[0] = l.mha_shape[1]; s.cm_a[1] = s.cm_a[2] = l.mha_shape[0];
+  for (int d = 0; d < 3; d++) s.cm_b[d] = l.mha_shape[d];
+  const int dl[3] = {0, 2, 1}, dr[3] = {1, 0, 2}; for (int d = 0; d < 3; d++) { s.cm_left[d] = dl[d]; s.cm_right[d] = dr[d]; }
+  s.cm_perm = {1, 0, 2};
+  return s;
+}
 static inline std::vector<Wire> node_inputs(const Model& m, size_t id) {
   if (!m.layers[id].inputs.empty()) return m.layers[id].inputs;
   Wire w; if (id > 0) { w.node = (int)id - 1; w.index = 0; }
@@ -363,8 +390,11 @@ struct ConvData {
   std::vector<int64_t> output_as_element;  // conv output AFTER the bias, BEFORE clearing the garbage (convolution.rs:311-316)
 };
 // per node input / output tensors; in2 = the second input of a two-input node, out_more = the outputs after the first (QKV: K, V)
+// MhaData (mha.rs:45-52): the products Q K^T (the input of the softmax) and the probabilities (the left input of final_mul); the output of final_mul is
+// the node's output (final_reshape does not move anything)
+struct MhaData { std::vector<int64_t> softmax_in, softmax_out; };
 struct Trace {
-  std::vector<std::vector<int64_t>> in, out, in2; std::vector<std::vector<std::vector<int64_t>>> out_more; std::vector<ConvData> conv;
+  std::vector<std::vector<int64_t>> in, out, in2, in3; std::vector<std::vector<std::vector<int64_t>>> out_more; std::vector<ConvData> conv; std::map<size_t, MhaData> mha;
   const std::vector<int64_t>& output(size_t node, size_t index) const { return index == 0 ? out[node] : out_more[node][index - 1]; }
 };
 
@@ -528,6 +558,23 @@ static inline std::vector<int64_t> softmax_op(const Layer& l, const std::vector<
   if (out) *out = std::move(d);
   return o;
 }
+// ConcatMatMul::evaluate (concat_matmul.rs:568-616): chunk c of the result = chunk c of A times chunk c of B
+static inline std::vector<int64_t> concat_matmul_op(const Layer& l, const std::vector<int64_t>& cur, const std::vector<int64_t>& b0) {
+  std::vector<int64_t> o;
+      if (cur.size() != l.cm_a[0] * l.cm_a[1] * l.cm_a[2] || b0.size() != l.cm_b[0] * l.cm_b[1] * l.cm_b[2]) throw std::runtime_error("concat matmul: input shapes");
+      int order[3]; size_t sa[3], sb[3];
+      std::vector<int64_t> a = cur, b = b0;
+      for (int d = 0; d < 3; d++) { sa[d] = l.cm_a[d]; sb[d] = l.cm_b[d]; }
+      if (cm_permutation(l.cm_left, CM_EXPECTED_LEFT, order)) { size_t t[3]; a = permute3d(cur, l.cm_a, order, t); for (int d = 0; d < 3; d++) sa[d] = t[d]; }
+      if (cm_permutation(l.cm_right, CM_EXPECTED_RIGHT, order)) { size_t t[3]; b = permute3d(b0, l.cm_b, order, t); for (int d = 0; d < 3; d++) sb[d] = t[d]; }
+      if (sa[0] != sb[0] || sa[2] != sb[1]) throw std::runtime_error("concat matmul: chunk shapes");
+      const size_t C = sa[0], R = sa[1], M = sa[2], N = sb[2];
+      std::vector<int64_t> r(C * R * N, 0);
+      for (size_t c = 0; c < C; c++) for (size_t i = 0; i < R; i++) for (size_t j = 0; j < N; j++) { int64_t acc = 0; for (size_t q = 0; q < M; q++) acc += a[(c * R + i) * M + q] * b[(c * M + q) * N + j]; r[(c * R + i) * N + j] = acc; }
+      if (l.cm_perm.empty()) o = r;
+      else { const size_t rs[3] = {C, R, N}; const int po[3] = {l.cm_perm[0], l.cm_perm[1], l.cm_perm[2]}; size_t t[3]; o = permute3d(r, rs, po, t); }
+  return o;
+}
 static inline int64_t requant_apply(const Layer& l, int64_t v) {
   unsigned sh = l.shift();
   int64_t tmp = v * l.fixed_point_multiplier + (int64_t(1) << (sh - 1));
@@ -549,14 +596,15 @@ static inline Trace run_model(const Model& m, const std::vector<int64_t>& input)
     size_t off = 0; for (int q = 0; q < w.index; q++) off += in_lens.at((size_t)q);
     return std::vector<int64_t>(input.begin() + off, input.begin() + off + in_lens.at((size_t)w.index));
   };
-  tr.in2.resize(m.layers.size()); tr.out_more.resize(m.layers.size());
+  tr.in2.resize(m.layers.size()); tr.in3.resize(m.layers.size()); tr.out_more.resize(m.layers.size());
   for (size_t id = 0; id < m.layers.size(); id++) {
     const Layer& l = m.layers[id];
     const std::vector<Wire> wires = node_inputs(m, id);
     std::vector<int64_t> cur = value(wires[0]);
     tr.in.push_back(cur);
     if (wires.size() > 1) tr.in2[id] = value(wires[1]);
-    if (wires.size() != ((l.kind == L_MATMUL2 || l.kind == L_ADD2 || l.kind == L_CONCAT_MATMUL) ? 2u : 1u)) throw std::runtime_error("model graph: wrong number of inputs for a node");
+    if (wires.size() > 2) tr.in3[id] = value(wires[2]);
+    if (wires.size() != n_inputs(l)) throw std::runtime_error("model graph: wrong number of inputs for a node");
     std::vector<int64_t> o;
     if (l.kind == L_MATMUL2) {  // MatMul::op (matrix_mul.rs:230-311) on two input tensors
       const std::vector<int64_t>& b = tr.in2[id];
@@ -579,20 +627,15 @@ static inline Trace run_model(const Model& m, const std::vector<int64_t>& input)
         for (size_t i = 0; i < s_; i++) for (size_t j = 0; j < n; j++) { int64_t a = 0; for (size_t q = 0; q < k; q++) a += cur[i * k + q] * l.weights[(w * k + q) * n + j]; y[i * n + j] = a + l.bias[w * n + j]; }
         if (w == 0) o = y; else tr.out_more[id].push_back(y);
       }
-    } else if (l.kind == L_CONCAT_MATMUL) {  // ConcatMatMul::evaluate (concat_matmul.rs:568-616): chunk c of the result = chunk c of A times chunk c of B
-      const std::vector<int64_t>& b0 = tr.in2[id];
-      if (cur.size() != l.cm_a[0] * l.cm_a[1] * l.cm_a[2] || b0.size() != l.cm_b[0] * l.cm_b[1] * l.cm_b[2]) throw std::runtime_error("concat matmul: input shapes");
-      int order[3]; size_t sa[3], sb[3];
-      std::vector<int64_t> a = cur, b = b0;
-      for (int d = 0; d < 3; d++) { sa[d] = l.cm_a[d]; sb[d] = l.cm_b[d]; }
-      if (cm_permutation(l.cm_left, CM_EXPECTED_LEFT, order)) { size_t t[3]; a = permute3d(cur, l.cm_a, order, t); for (int d = 0; d < 3; d++) sa[d] = t[d]; }
-      if (cm_permutation(l.cm_right, CM_EXPECTED_RIGHT, order)) { size_t t[3]; b = permute3d(b0, l.cm_b, order, t); for (int d = 0; d < 3; d++) sb[d] = t[d]; }
-      if (sa[0] != sb[0] || sa[2] != sb[1]) throw std::runtime_error("concat matmul: chunk shapes");
-      const size_t C = sa[0], R = sa[1], M = sa[2], N = sb[2];
-      std::vector<int64_t> r(C * R * N, 0);
-      for (size_t c = 0; c < C; c++) for (size_t i = 0; i < R; i++) for (size_t j = 0; j < N; j++) { int64_t acc = 0; for (size_t q = 0; q < M; q++) acc += a[(c * R + i) * M + q] * b[(c * M + q) * N + j]; r[(c * R + i) * N + j] = acc; }
-      if (l.cm_perm.empty()) o = r;
-      else { const size_t rs[3] = {C, R, N}; const int po[3] = {l.cm_perm[0], l.cm_perm[1], l.cm_perm[2]}; size_t t[3]; o = permute3d(r, rs, po, t); }
+    } else if (l.kind == L_CONCAT_MATMUL) o = concat_matmul_op(l, cur, tr.in2[id]);
+    else if (l.kind == L_MHA) {  // Mha::evaluate_with_intermediate_outputs (mha.rs:216-300): qk, softmax, final_mul on the reshaped inputs
+      const size_t S = l.mha_shape[0], H = l.mha_shape[1], D = l.mha_shape[2];
+      if (cur.size() != S * H * D || tr.in2[id].size() != cur.size() || tr.in3[id].size() != cur.size()) throw std::runtime_error("mha: input shapes");
+      MhaData d;
+      d.softmax_in = concat_matmul_op(mha_qk_layer(l), cur, tr.in2[id]);
+      d.softmax_out = softmax_op(mha_softmax_layer(l), d.softmax_in, nullptr);
+      o = concat_matmul_op(mha_final_layer(l), d.softmax_out, tr.in3[id]);
+      tr.mha[id] = d;
     } else
     if (l.kind == L_DENSE) {
       if (cur.size() != l.ncols) throw std::runtime_error("dense input size mismatch");
@@ -674,8 +717,12 @@ static inline Context context_generate(const Model& m) {
   auto add_table = [&](TableType t) { for (auto& x : tset) if (x == t) return; tset.push_back(t); };
   const std::vector<std::vector<size_t>> out_lens = node_output_lens(m);
   for (size_t id_ = 0; id_ < m.layers.size(); id_++) {
-    const Layer& l = m.layers[id_];
-    size_t cur_len = out_lens[id_][0];  // (Requant / Relu keep the length of their input)
+    // an Mha node brings the tables of its softmax (Mha::step_info, mha.rs:432-503: qk, softmax and final_mul step_info one after the other; only
+    // the softmax has tables and witness polynomials, as long as the [heads][seq][seq] products)
+    const Layer& l0 = m.layers[id_];
+    const Layer sub = l0.kind == L_MHA ? mha_softmax_layer(l0) : Layer();
+    const Layer& l = l0.kind == L_MHA ? sub : l0;
+    size_t cur_len = l0.kind == L_MHA ? sub.sm_shape[0] * sub.sm_shape[1] * sub.sm_shape[2] : out_lens[id_][0];  // (Requant / Relu keep the length of their input)
     if (l.kind == L_REQUANT) { add_table({2, 0}); add_table({3, l.clamping_size()}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
     else if (l.kind == L_RELU) { add_table({0, 0}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
     else if (l.kind == L_LAYERNORM) { add_table({2, 0}); add_table(layernorm_table(l)); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }  // layernorm.rs:587-618
@@ -761,7 +808,7 @@ struct PoolingProof { IOPProof sumcheck; LogUpProof lookup; std::vector<E> zeroc
 struct LayerNormProof { std::vector<LogUpProof> logup_proofs; std::vector<Commitment> commitments; IOPProof accumulation_proof, io_proof, input_proof; std::vector<E> acc_evals, evaluations; E gamma_eval, beta_eval; };
 // SoftmaxProof (softmax.rs:102-117)
 struct SoftmaxProof { std::vector<LogUpProof> logup_proofs; std::vector<Commitment> commitments; IOPProof accumulation_proof, mask_proof; std::vector<E> evaluations; };
-struct LayerProof { LayerKind kind; DenseProof dense; MatMulProof matmul; AddProof add; PositionalProof pos; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; ConcatMatMulProof cmm; QKVProof qkv; LayerNormProof ln; SoftmaxProof sm; };
+struct LayerProof { LayerKind kind; DenseProof dense; MatMulProof matmul; AddProof add; PositionalProof pos; ActivationProof act; RequantProof req; ConvProof conv; PoolingProof pool; ConcatMatMulProof cmm; QKVProof qkv; LayerNormProof ln; SoftmaxProof sm; ConcatMatMulProof mha_final, mha_qk; };  // MhaProof (mha.rs:122-128) = {mha_final, sm, mha_qk}
 struct TableProof { Commitment multiplicity_commit; LogUpProof lookup; };
 struct Proof {
   std::map<size_t, LayerProof> steps;  // canonical order: ascending NodeId
@@ -802,7 +849,11 @@ static inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
   if (ctx.tables.empty()) return;
   std::map<TableType, std::unordered_map<int64_t, u64>> element_count;
   for (size_t id = 0; id < ctx.model.layers.size(); id++) {
-    const Layer& l = ctx.model.layers[id];
+    // Mha::gen_lookup_witness (mha.rs:706-719): the witness of its softmax on the products, under the node's own id
+    const Layer& l0 = ctx.model.layers[id];
+    const Layer sub = l0.kind == L_MHA ? mha_softmax_layer(l0) : Layer();
+    const Layer& l = l0.kind == L_MHA ? sub : l0;
+    const std::vector<int64_t>& softmax_input = l0.kind == L_MHA ? tr.mha.at(id).softmax_in : tr.in[id];
     if (l.kind == L_REQUANT) {
       unsigned shift = l.shift(); int64_t rounding = int64_t(1) << (shift - 1), mask = (int64_t(1) << shift) - 1;
       std::vector<int64_t> cin, cout, shifted;
@@ -840,7 +891,7 @@ static inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       for (auto& ch : chunks) { std::vector<u64> ev = to_base(ch); Mle mle = Mle::from_base(ev); wr.commits.push_back({pcs_commit(ctx.pp, mle), mle}); wr.column_evals.push_back(ev); }
       ps.lookup_witness[id] = {wi, wr};
     } else if (l.kind == L_SOFTMAX) {  // Softmax::lookup_witness (softmax.rs:890-1066)
-      SoftmaxData d; std::vector<int64_t> out = softmax_op(l, tr.in[id], &d);
+      SoftmaxData d; std::vector<int64_t> out = softmax_op(l, softmax_input, &d);
       const size_t K = l.sm_shape[2];
       std::vector<int64_t> row_sums;
       for (size_t i = 0; i < out.size() / K; i++) { int64_t a = 0; for (size_t j = 0; j < K; j++) a += out[i * K + j]; row_sums.push_back(a); }
@@ -1634,6 +1685,18 @@ static inline Proof prove(const Context& ctx, const Trace& tr, Transcript& t) {
     if (l.kind == L_ADD2) { claims_by_node[id] = prove_add2(ps, id, cur, to_fields(tr.in[id]), to_fields(tr.in2[id])); continue; }
     if (l.kind == L_CONCAT_MATMUL) { claims_by_node[id] = prove_concat_matmul(ps, id, l, cur, to_fields(tr.in[id]), to_fields(tr.in2[id])); continue; }
     if (l.kind == L_QKV) { claims_by_node[id] = prove_qkv(ps, id, l, last, to_fields(tr.in[id])); continue; }
+    if (l.kind == L_MHA) {  // Mha::prove (mha.rs:633-704): final_mul on (softmax_out, V), the softmax, qk on (Q, K); the claims on Q, K, V in this order
+      const MhaData& d = tr.mha.at(id);
+      std::vector<Claim> fm = prove_concat_matmul(ps, id, mha_final_layer(l), cur, to_fields(d.softmax_out), to_fields(tr.in3[id]));
+      LayerProof lp; lp.kind = L_MHA; lp.mha_final = ps.proofs.at(id).cmm;
+      const Claim sc = prove_softmax(ps, id, mha_softmax_layer(l), fm[0], d.softmax_in);
+      lp.sm = ps.proofs.at(id).sm;
+      std::vector<Claim> qk = prove_concat_matmul(ps, id, mha_qk_layer(l), sc, to_fields(tr.in[id]), to_fields(tr.in2[id]));
+      lp.mha_qk = ps.proofs.at(id).cmm;
+      ps.proofs[id] = lp;
+      claims_by_node[id] = {qk[0], qk[1], fm[1]};
+      continue;
+    }
     if (l.kind == L_DENSE) cur = prove_dense(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_MATMUL) cur = prove_matmul(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_ADD) cur = prove_add(ps, id, l, cur, to_fields(tr.in[id]));
@@ -1740,6 +1803,13 @@ static inline std::vector<u64> serialize_proof(const Proof& p) {
       w.u(q.logup_proofs.size()); for (auto& x : q.logup_proofs) w.logup(x);
       w.u(q.commitments.size()); for (auto& c : q.commitments) w.comm(c);
       w.iop(q.accumulation_proof); w.iop(q.mask_proof); w.ve(q.evaluations);
+    } else if (lp.kind == L_MHA) {  // MhaProof {final_mul_proof, softmax_proof, qk_proof}
+      w.iop(lp.mha_final.sumcheck); w.ve(lp.mha_final.individual_claims);
+      const SoftmaxProof& q = lp.sm;
+      w.u(q.logup_proofs.size()); for (auto& x : q.logup_proofs) w.logup(x);
+      w.u(q.commitments.size()); for (auto& c : q.commitments) w.comm(c);
+      w.iop(q.accumulation_proof); w.iop(q.mask_proof); w.ve(q.evaluations);
+      w.iop(lp.mha_qk.sumcheck); w.ve(lp.mha_qk.individual_claims);
     } else if (lp.kind == L_MAXPOOL) {
       w.iop(lp.pool.sumcheck); w.logup(lp.pool.lookup); w.ve(lp.pool.zerocheck_evals); w.u(lp.pool.variable_gap);
       w.u(lp.pool.commitments.size()); for (auto& c : lp.pool.commitments) w.comm(c);

@@ -30,6 +30,9 @@ CASES = [
     # the attention half of a pre-LN transformer block: LayerNorm, QKV, per-head scores, Softmax, probabilities x V, projection, residual
     ("transformer_block", dict(seq=8, emb=16, heads=2, head_dim=8, config=95)),
     ("transformer_block", dict(seq=16, emb=32, heads=4, head_dim=8, config=96)),
+    # the same half block with the reference's Mha layer as ONE node (layers/transformer/mha.rs): Q K^T, the softmax straight on the products, x V
+    ("mha_block", dict(seq=8, emb=16, heads=2, head_dim=8, config=97)),
+    ("mha_block", dict(seq=16, emb=32, heads=4, head_dim=8, config=98)),
 ]
 
 

@@ -39,7 +39,7 @@ static orc::Model to_orc(const dp::ModelSpec& m) {
     for (auto& e : l.inputs) { orc::Wire w; w.node = e.from; w.index = e.slot; x.inputs.push_back(w); }
     for (int d = 0; d < 3; d++) { x.cm_a[d] = l.cm_a[d]; x.cm_b[d] = l.cm_b[d]; x.cm_left[d] = l.cm_left[d]; x.cm_right[d] = l.cm_right[d]; } x.cm_perm = l.cm_perm; x.nrows = l.nrows; x.ncols = l.ncols; x.weights = l.weights; x.bias = l.bias; x.transpose_b = l.mm_transpose; x.add_left = l.add_left; x.add_right = l.add_right; x.right_shift = l.right_shift; x.fp_scale = l.fp_scale; x.intermediate_bit_size = l.intermediate_bit_size; x.fixed_point_multiplier = l.fixed_point_multiplier;
     x.kw = l.kw; x.kx = l.kx; x.real_nw = l.real_nw; x.nw = l.nw; for (int k = 0; k < 3; k++) { x.unp_out[k] = l.unp_out[k]; x.pin[k] = l.pin[k]; }
-    x.sm_scalar = l.sm_scalar; x.sm_bkm = l.sm_bkm; x.sm_allowable_error = l.sm_allowable_error; x.sm_temp_bits = l.sm_temp_bits; x.sm_in_scale_bits = l.sm_in_scale_bits; x.sm_table_size = l.sm_table_size; x.sm_zero_chunks = l.sm_zero_chunks; x.sm_zero_vars = l.sm_zero_vars; for (int k = 0; k < 3; k++) x.sm_shape[k] = l.sm_shape[k];
+    x.sm_scalar = l.sm_scalar; x.sm_bkm = l.sm_bkm; x.sm_allowable_error = l.sm_allowable_error; x.sm_temp_bits = l.sm_temp_bits; x.sm_in_scale_bits = l.sm_in_scale_bits; x.sm_table_size = l.sm_table_size; x.sm_zero_chunks = l.sm_zero_chunks; x.sm_zero_vars = l.sm_zero_vars; for (int k = 0; k < 3; k++) { x.sm_shape[k] = l.sm_shape[k]; x.mha_shape[k] = l.mha_shape[k]; }
     x.ln_dim_size = l.ln_dim_size; x.ln_multiplier = l.ln_multiplier; x.ln_eps_bits = l.ln_eps_bits; x.ln_range_check_bits = l.ln_range_check_bits; x.ln_top_chunk_scalar_log = l.ln_top_chunk_scalar_log;
     o.layers.push_back(x); }
   return o;
@@ -115,6 +115,29 @@ static dp::ModelSpec graph_model(int variant, std::vector<int64_t>& in) {
     fprintf(stderr, "softmax: multiplier %lld bkm %lld table 2^%u zero chunks %u x %u bits, allowable error %lld\n", (long long)sm.sm_scalar, (long long)sm.sm_bkm, sm.sm_table_size, sm.sm_zero_chunks, sm.sm_zero_vars, (long long)sm.sm_allowable_error);
     m.layers = {sm};
     in.resize(m.input_len); for (auto& x : in) x = rq();
+  } else if (variant == 9 || variant == 10) {
+    // the reference's Mha layer as ONE node (transformer/mha.rs): X -> QKV -> Mha(Q, K, V) -> + a second input tensor. The softmax works straight
+    // on the products Q_h K_h^T (scale 2^-16, domain 2^23, 1 / temperature = sqrt(head_dim)); variant 10: one head of dimension 16
+    const size_t S = variant == 10 ? 8 : 4, K = 16, H = variant == 10 ? 1 : 2, D = variant == 10 ? 16 : 8, N = H * D;
+    m.input_lens = {S * K, S * N}; m.input_len = S * K + S * N;
+    dp::LayerSpec q; q.kind = dp::L_QKV; q.nrows = K; q.ncols = N; q.weights.resize(3 * K * N); for (auto& x : q.weights) x = small(); q.bias.resize(3 * N); for (auto& x : q.bias) x = small(); q.inputs = {edge(-1, 0)};
+    dp::LayerSpec mh; mh.kind = dp::L_MHA; mh.mha_shape[0] = S; mh.mha_shape[1] = H; mh.mha_shape[2] = D; mh.inputs = {edge(0, 0), edge(0, 1), edge(0, 2)};
+    const float in_scale = 1.0f / 65536.0f, inv_temp = std::sqrt((float)D), domain = (float)(1 << 23), in_max = domain * in_scale, max_ctx = (float)S, sf = (float)(1u << 24), osf = 4096.0f;
+    mh.sm_scalar = (int64_t)std::llround((double)(sf * in_scale));
+    const int64_t max_shift = (int64_t)std::round(-sf * (inv_temp * std::log(max_ctx) + in_max));
+    const int64_t min_in = -(int64_t)(1 << 23) * mh.sm_scalar + max_shift, sig_min = min_in >> 16;
+    const unsigned min_bits = dp::dp_ceil_log2((size_t)(-sig_min));
+    const float bkm_f = sf * inv_temp * (std::log(2.0f * max_ctx) + std::log(osf)) / 2.0f;
+    const float cd = sf * inv_temp, c = (std::exp((float)(1 << 16) / cd) + std::exp(bkm_f / cd) / (2.0f * osf)) - 1.0f;
+    const float err = std::fabs(c * std::exp(1.0f / (2.0f * sf * inv_temp)) + (max_ctx - 1.0f) * std::exp(-bkm_f / sf * inv_temp));
+    mh.sm_bkm = (int64_t)std::round(bkm_f); mh.sm_table_size = dp::dp_ceil_log2((size_t)(mh.sm_bkm >> 16));
+    if (min_bits > mh.sm_table_size) { const unsigned rem = min_bits - mh.sm_table_size; mh.sm_zero_chunks = (rem - 1) / mh.sm_table_size + 1; mh.sm_zero_vars = mh.sm_zero_chunks == 1 ? std::max(rem, 2u) : mh.sm_table_size; }
+    mh.sm_allowable_error = std::max<int64_t>(2, (int64_t)std::round(err * osf));
+    { uint32_t b; memcpy(&b, &inv_temp, 4); mh.sm_temp_bits = b; memcpy(&b, &in_scale, 4); mh.sm_in_scale_bits = b; }
+    fprintf(stderr, "mha softmax: multiplier %lld bkm %lld table 2^%u zero chunks %u x %u bits, allowable error %lld\n", (long long)mh.sm_scalar, (long long)mh.sm_bkm, mh.sm_table_size, mh.sm_zero_chunks, mh.sm_zero_vars, (long long)mh.sm_allowable_error);
+    dp::LayerSpec ad; ad.kind = dp::L_ADD2; ad.add_left = 1; ad.add_right = 5; ad.inputs = {edge(1), edge(-1, 1)};
+    m.layers = {q, mh, ad};
+    in.resize(m.input_len); for (auto& x : in) x = small();
   } else if (variant == 5 || variant == 6) {
     // LayerNorm over the last dimension of a [rows][dim] tensor, then the shift-only Requant the reference puts behind it (layernorm.rs:140-257,
     // 473-513) and a ReLU. Variant 6: N = 12 of a padded dimension of 16 (the padding of input, gamma and beta is zero).

@@ -371,7 +371,7 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
         elif n["kind"] == "layernorm":
             tables.add(("range", 0))
             tables.add(("inv_sqrt", (n["eps_bits"], n["range_check_bits"])))
-        elif n["kind"] == "softmax":
+        elif n["kind"] in ("softmax", "mha"):  # (an Mha node brings the tables of its softmax, Mha::step_info, mha.rs:432-503)
             tables.add(("range", 0))
             tables.add(("softmax", (n["temp_bits"], n["table_size"], n["bkm"])))
             tables.add(("error", n["allowable_error"]))
@@ -401,6 +401,9 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
         elif n["kind"] in ("layernorm", "softmax"):
             for lg in steps[nid][1]["logup_proofs"]:
                 fractions(lg)
+        elif n["kind"] == "mha":  # MhaProof::get_lookup_data (mha.rs:130-134): the softmax's
+            for lg in steps[nid][1]["softmax_proof"]["logup_proofs"]:
+                fractions(lg)
     for tp in tree["table_proofs"]:
         fractions(tp["lookup"])
     out_claims = []
@@ -409,17 +412,53 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
         out_claims.append({"point": r, "eval": L.mle_eval([fe(v) for v in y], r)})
     order, readers = backward_order(nodes, outputs)
     made, out = {}, []
+    # MhaCtx::verify (layers/transformer/mha.rs:792-893): final_mul.verify on the node's output claim -> (claim on the probabilities, claim on V);
+    # softmax.verify on the first; qk.verify on the softmax's claim -> (claims on Q, K); the node hands on [Q, K, V]. Walked as three steps through
+    # the concat_matmul / softmax branches below, each with the sub-layer Mha::new builds (mha.rs:147-186) and its part of the MhaProof.
+    vsteps, hold, prev = [], None, None
     for nid in order:
+        vsteps += [(nid, 1), (nid, 2), (nid, 3)] if nodes[nid]["kind"] == "mha" else [(nid, 0)]
+
+    def settle(step):
+        nonlocal hold
+        if step is not None and step[1] == 1:
+            hold = made[step[0]]
+            assert len(hold) == 2
+        if step is not None and step[1] == 3:
+            made[step[0]] = made[step[0]] + [hold[1]]
+            assert len(made[step[0]]) == 3
+
+    for nid, part in vsteps + [(None, 0)]:
+        settle(prev)
+        prev = (nid, part)
+        if nid is None:
+            break
         n = nodes[nid]
+        if part:
+            S_, H_, D_ = n["shape"]
+            if part == 1:
+                n = dict(kind="concat_matmul", a_shape=(H_, S_, S_), b_shape=(S_, H_, D_), left=(0, 2, 1), right=(1, 0, 2), perm=(1, 0, 2), n_out=1)
+            elif part == 2:
+                n = dict(n, kind="softmax", shape=(H_, S_, S_))
+            else:
+                n = dict(kind="concat_matmul", a_shape=(S_, H_, D_), b_shape=(S_, H_, D_), left=(1, 2, 0), right=(1, 2, 0), perm=None, n_out=1)
         got = []
-        for j in range(n["n_out"]):
-            (rd,) = readers[(nid, j)]  # exactly one reader per tensor (provable/mod.rs:243-248)
-            got.append(out_claims[rd[1]] if rd[0] < 0 else made[rd[0]][rd[1]])
+        if part == 2:
+            got = [hold[0]]
+        elif part == 3:
+            got = [made[nid][0]]
+        else:
+            for j in range(nodes[nid]["n_out"]):
+                (rd,) = readers[(nid, j)]  # exactly one reader per tensor (provable/mod.rs:243-248)
+                got.append(out_claims[rd[1]] if rd[0] < 0 else made[rd[0]][rd[1]])
         cur = got[0]
         if n["kind"] == "reshape":
             made[nid] = [cur]
             continue
         kind, lp = steps[nid]
+        if part:
+            assert kind == 16
+            lp = lp[("final_mul_proof", "softmax_proof", "qk_proof")[part - 1]]
         if n["kind"] == "conv":  # layers/convolution.rs:1143-1383 (+ hadamard.rs:128-156, verify_fft_delegation :1090-1141)
             from .l3_independent import two_adic
             kw, kx, rnw, nw = n["kw"], n["kx"], n["real_nw"], n["nw"]

@@ -171,7 +171,7 @@ def test_matmul_model_tampered_proof_rejected(hostlogic_bin, where):
     assert "verify(oracle,tampered): REJECT" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 @pytest.mark.parametrize("seed", [1, 7])
 def test_graph_model_proof_stream_identical_to_oracle_and_accepted(hostlogic_bin, variant, seed):
     """Models that are GRAPHS (layers/provable/mod.rs:195-565; Prover::prove over the backward node iterator, iop/prover.rs:437-461): 0 / 1 =
@@ -181,7 +181,8 @@ def test_graph_model_proof_stream_identical_to_oracle_and_accepted(hostlogic_bin
     back to [s][h][d]; 4: the scores stored transposed) -> Add with a second input. The product's orchestrator over the CPU double gives the
     oracle's stream; the verifier — fed from the serialised verifier context, graph section included — accepts both. 5 / 6: LayerNorm (N = 16; N =
     12 of a padded 16) -> shift-only Requant -> ReLU (layers/transformer/layernorm.rs); 7 / 8: Softmax over [heads][n][n] scores under the causal
-    mask (layers/transformer/softmax.rs), without and with a zero table."""
+    mask (layers/transformer/softmax.rs), without and with a zero table. 9 / 10: the reference's Mha layer as ONE node with three inputs
+    (layers/transformer/mha.rs:633-724: final_mul, softmax, qk under one node id, one MhaProof) behind a QKV, two heads of 8 / one head of 16."""
     r = run(hostlogic_bin, "graph", variant, seed)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "identical=1" in r.stdout
@@ -218,6 +219,19 @@ def test_softmax_proofs_reject_every_flipped_word(hostlogic_bin, variant):
     sample of the rest (table proofs with the committed exponential / error columns, openings) — the verifier refuses each"""
     import os, re, subprocess
     for sweep in ("1:6000:3", "6000:74000:211"):
+        r = subprocess.run([hostlogic_bin, "graph", str(variant), "11"], capture_output=True, text=True, timeout=900, env=dict(os.environ, DP_FLIP_SWEEP=sweep))
+        assert r.returncode == 0 and "identical=1" in r.stdout, r.stdout + r.stderr
+        m = re.search(r"flip sweep: (\d+) flipped, (\d+) rejected, accepted at:(.*)", r.stdout)
+        assert m and int(m.group(1)) > 100 and m.group(1) == m.group(2) and not m.group(3).strip(), r.stdout
+
+
+@pytest.mark.parametrize("variant", [9, 10])
+def test_mha_proofs_reject_every_flipped_word(hostlogic_bin, variant):
+    """Mha as one node (layers/transformer/mha.rs:633-724 / 792-893; variants 9 / 10): one proof, a single-bit flip in every 3rd of the first
+    8000 words (the QKV proof, then the MhaProof: final_mul's sumcheck and claims, the softmax's four lookups, commitments, accumulation and
+    mask sumchecks, evaluations, qk's sumcheck and claims) and in a sample of the rest — the verifier refuses each"""
+    import os, re, subprocess
+    for sweep in ("1:8000:3", "8000:106000:307"):
         r = subprocess.run([hostlogic_bin, "graph", str(variant), "11"], capture_output=True, text=True, timeout=900, env=dict(os.environ, DP_FLIP_SWEEP=sweep))
         assert r.returncode == 0 and "identical=1" in r.stdout, r.stdout + r.stderr
         m = re.search(r"flip sweep: (\d+) flipped, (\d+) rejected, accepted at:(.*)", r.stdout)

@@ -502,6 +502,14 @@ def test_independent_verifier_on_token_and_sequence_models(oracle, name, args, k
     for (i, pid), poly in polys.items():
         roots.setdefault(i, []).append((pid, oracle.pcs_commit_root(max_poly, to_words(poly), False)))
     claims, tr = V.verify_graph(nodes, [(len(nodes) - 1, 0)], roots, tree, [[int(v) for v in x]], [[int(v) for v in y]])
+    _check_claims_and_openings(oracle, claims, tr, tree, roots, polys, cols, lk, max_poly)
+
+
+def _check_claims_and_openings(oracle, claims, tr, tree, roots, polys, cols, lk, max_poly):
+    """every claim the IOP verifier ends with — on a model polynomial, a witness column, the committed column of a table, a multiplicity
+    polynomial — is true for the polynomial itself, and the openings (l3: trivial + batch) are accepted"""
+    from support import l0_independent as L, l3_independent as V3
+    to_words = lambda v: np.asarray([int(t) % P for t in np.asarray(v).reshape(-1)], dtype=np.uint64)
     fe = lambda v: (int(v) % P, 0)
     root_of = {(node, pid): r for node, lst in roots.items() for pid, r in lst}
     uniform = []
@@ -544,6 +552,47 @@ def test_independent_verifier_on_token_and_sequence_models(oracle, name, args, k
     for (comm, point, ev), tp in zip(trivial, tree["trivial_proofs"]):
         V3.trivial_verify(comm, point, ev, tp)
     V3.batch_verify(max_poly.bit_length() - 1, [u[0] for u in batch], [u[1] for u in batch], [u[2] for u in batch], tree["batch_proof"], tr, check_every=5)
+
+
+def test_independent_verifier_on_the_mha_node(oracle):
+    """Mha as ONE node (layers/transformer/mha.rs:792-893) a second time: l2_independent.verify_graph walks it as final_mul.verify ->
+    softmax.verify -> qk.verify with the sub-layers Mha::new builds, one MhaProof, the claims on Q, K, V checked against the three input tensors;
+    the softmax's witness columns, its tables' committed columns and multiplicities are checked on the polynomials; then the openings (l3)"""
+    import deep_prove_amd as dpa
+    from deep_prove_amd import models as M, wire
+    from support import l2_independent as V
+    S, H, D = 8, 2, 4
+    g = dpa.models.GraphBuilder([S * H * D] * 3, config=99)
+    g.mha((-1, 0), (-1, 1), (-1, 2), S, H, D, 1.0 / 256.0, 127 * 127 * D)
+    x = g.input(amplitude=15)
+    y = g.run(x)
+    l = g.nodes[0][0]
+    qh, kh = (x[q * S * H * D:(q + 1) * S * H * D].reshape(S, H, D).transpose(1, 0, 2) for q in (0, 1))
+    t = {}
+    probs = M.softmax_apply(dict(l, shape=(H, S, S)), np.einsum("hsd,htd->hst", qh, kh).reshape(-1), trace=t)
+    A = lambda v: np.asarray(v, dtype=np.int64)
+    cols = {0: [A(t["exp_in"]), A(t["exp_out"]), A(t["low"]), A(t["high"]), A(t["shift"])] + [A(c) for z in range(l["zero_chunks"]) for c in (t["zero_in"][z], t["zero_out"][z])]}
+    lk = {"range": t["low"] + t["high"], "relu": [], "clamp": {}, "softmax": {(l["temp_bits"], l["table_size"], l["bkm"]): list(t["exp_in"])},
+          "error": {l["allowable_error"]: [int(v) for v in probs.reshape(-1, S).sum(axis=1)]}, "zero": {l["zero_vars"]: [v for z in range(l["zero_chunks"]) for v in t["zero_in"][z]]}}
+    nodes = [dict(kind="mha", inputs=[(-1, 0), (-1, 1), (-1, 2)], n_out=1, **{q: l[q] for q in ("shape", "scalar", "temp_bits", "table_size", "bkm", "zero_chunks", "zero_vars", "allowable_error")})]
+    h = oracle.model_setup(g.blob())
+    proof, oout, _ = oracle.model_prove(h, x)
+    oracle.model_free(h)
+    assert (oout == y).all()
+    tree = wire.parse_stream(proof)
+    assert [k for _, k, _ in tree["steps"]] == [16]
+    max_poly = 1 << (max(S * H * D, H * S * S, 256, 1 << l["table_size"]) - 1).bit_length()
+    ins = [[int(v) for v in x[q * S * H * D:(q + 1) * S * H * D]] for q in range(3)]
+    claims, tr = V.verify_graph(nodes, [(0, 0)], {}, tree, ins, [[int(v) for v in y]])
+    _check_claims_and_openings(oracle, claims, tr, tree, {}, {}, cols, lk, max_poly)
+    # a flipped word in each of the three sub-proofs (final_mul's sumcheck, a softmax evaluation far into the proof, qk's claims at its end)
+    n_steps = sum(1 for _ in tree["steps"])
+    assert n_steps == 1
+    for at in (8, 40):
+        bad = proof.copy()
+        bad[at] ^= np.uint64(1)
+        with pytest.raises((AssertionError, ValueError, IndexError, KeyError, ZeroDivisionError, OverflowError)):
+            V.verify_graph(nodes, [(0, 0)], {}, wire.parse_stream(bad), ins, [[int(v) for v in y]])
 
 
 def test_independent_verifier_rejects_tampered_cnn_proofs(oracle):

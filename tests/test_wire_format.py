@@ -184,3 +184,28 @@ def test_graph_steps_in_the_wire_format(oracle):
     tree = wire.parse_stream(p)
     assert sorted(k for _, k, _ in tree["steps"]).count(11) == 1
     assert wire.parse_stream(back)["steps"][-1][1] == 7
+
+
+def test_mha_step_in_the_wire_format(oracle):
+    """LayerProof::Mha(MhaProof {final_mul_proof: ConcatMatMulProof, softmax_proof: SoftmaxProof, qk_proof: ConcatMatMulProof})
+    (layers/transformer/mha.rs:122-128): a block with the Mha layer as one node proved by the oracle, encoded, read by an independent MessagePack
+    decoder (field names and order), and back"""
+    import deep_prove_amd as dpa
+    from deep_prove_amd import wire
+    g = dpa.models.mha_block(8, 16, 2, 8, config=97)
+    x = g.input()
+    h = oracle.model_setup(g.blob())
+    p, out, _ = oracle.model_prove(h, x)
+    oracle.model_free(h)
+    assert (out == g.run(x)).all()
+    data = wire.to_rmp(p)
+    m = msgpack.unpackb(data, raw=False, strict_map_key=False)
+    mha = [body for lp in m["steps"].values() for kind, body in lp.items() if kind == "Mha"]
+    assert len(mha) == 1 and list(mha[0]) == ["final_mul_proof", "softmax_proof", "qk_proof"]
+    assert list(mha[0]["final_mul_proof"]) == ["sumcheck_proof", "individual_claims"] and list(mha[0]["qk_proof"]) == ["sumcheck_proof", "individual_claims"]
+    assert list(mha[0]["softmax_proof"]) == ["logup_proofs", "commitments", "accumulation_proof", "mask_proof", "evaluations"]
+    assert len(mha[0]["softmax_proof"]["logup_proofs"]) in (3, 4) and len(mha[0]["final_mul_proof"]["individual_claims"]) == 3
+    assert not any(kind in ("ConcatMatMul", "Softmax") for lp in m["steps"].values() for kind in lp)
+    back = wire.from_rmp(data)
+    assert wire.to_rmp(back) == data
+    assert [k for _, k, _ in wire.parse_stream(back)["steps"]].count(16) == 1
