@@ -717,6 +717,38 @@ def mha_block(seq, emb, heads, head_dim, config):
     return g
 
 
+def transformer_layer(seq, emb, heads, head_dim, ffn, config):
+    """One whole pre-LN transformer layer as ONE graph, every node proved: the attention half of mha_block (LayerNorm -> QKV -> Mha -> projection
+    -> + residual) and the feed-forward half (LayerNorm -> Linear(emb, ffn) -> ReLU -> Linear(ffn, emb) -> + residual). The reference proves graphs
+    whose tensors have ONE reader each (claims_for_node, provable/mod.rs:243-248), so every second use of a tensor enters as an input tensor of
+    its own: inputs = X (normalised by the first LayerNorm), X once more (the residual added to the attention output), H (what the second
+    LayerNorm normalises — in a running model the hidden state X + attention, whose one reader inside the graph is the LAST Add). GELU is not
+    provable in the reference (prover / verifier
+    mismatch): ReLU stands in. layers/transformer/{layernorm,qkv,mha}.rs, layers/matrix_mul.rs, layers/activation.rs, layers/add.rs"""
+    n = heads * head_dim
+    g = GraphBuilder([seq * emb] * 3, config)
+    ln, ibs = g.layernorm((-1, 0), emb)
+    lr = g.requant_shift((ln, 0), ibs - 16, ibs)
+    q = g.qkv((lr, 0), emb, n)
+    rq = [g.requant((q, w), 2.5 / math.sqrt(emb) / 127.0, dense_output_bitsize(emb)) for w in range(3)]
+    s_in = 1.0 / 16.0
+    att = g.mha((rq[0], 0), (rq[1], 0), (rq[2], 0), seq, heads, head_dim, s_in * s_in, (1 << dense_output_bitsize(head_dim)) - 1)
+    ar = g.requant((att, 0), 1.0 / 4096.0, 12 + BIT_LEN + max(0, (seq - 1).bit_length()) + 1)
+    pr = g.matmul_const((ar, 0), n, emb)
+    prq = g.requant((pr, 0), 2.5 / math.sqrt(n) / 127.0, dense_output_bitsize(n))
+    res1 = g.add2((prq, 0), (-1, 1))
+    # feed-forward half on the third input tensor (= the first output; a tensor has one reader)
+    ln2, ibs2 = g.layernorm((-1, 2), emb)
+    lr2 = g.requant_shift((ln2, 0), ibs2 - 16, ibs2)
+    f1 = g.matmul_const((lr2, 0), emb, ffn)
+    f1q = g.requant((f1, 0), 2.5 / math.sqrt(emb) / 127.0, dense_output_bitsize(emb))
+    act = g.relu((f1q, 0))
+    f2 = g.matmul_const((act, 0), ffn, emb)
+    f2q = g.requant((f2, 0), 2.5 / math.sqrt(ffn) / 127.0, dense_output_bitsize(ffn))
+    res2 = g.add2((f2q, 0), (res1, 0))
+    return g.set_outputs([(res2, 0)])
+
+
 def matmul_pair(seq, k, n, config, transpose_b=False):
     """MatMul of two INPUT tensors, + a third one, Requant, ReLU (layers/matrix_mul.rs with two Input operands, layers/add.rs without operand)"""
     g = GraphBuilder([seq * k, k * n, seq * n], config)

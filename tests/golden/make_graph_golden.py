@@ -33,6 +33,8 @@ CASES = [
     # the same half block with the reference's Mha layer as ONE node (layers/transformer/mha.rs): Q K^T, the softmax straight on the products, x V
     ("mha_block", dict(seq=8, emb=16, heads=2, head_dim=8, config=97)),
     ("mha_block", dict(seq=16, emb=32, heads=4, head_dim=8, config=98)),
+    # one whole pre-LN transformer layer as one graph of 19 nodes: attention half (with the Mha node) and feed-forward half, two LayerNorms, three inputs
+    ("transformer_layer", dict(seq=8, emb=16, heads=2, head_dim=8, ffn=32, config=101)),
 ]
 
 

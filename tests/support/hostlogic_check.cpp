@@ -11,6 +11,7 @@ typedef dp::EmulDev TestDev;
 typedef dp::CpuDev TestDev;
 #endif
 #include "../../deep-prove_amd/csrc/zkml.h"
+#include "../../deep-prove_amd/csrc/blob.h"
 #include <cstdio>
 #include <chrono>
 #include <cmath>
@@ -477,8 +478,18 @@ int main(int argc, char** argv) {
   if (argc > 1 && std::string(argv[1]) == "sharded") return sharded_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 4);
   if (argc > 1 && std::string(argv[1]) == "sumcheck") return sumcheck_mode(argc > 2 ? atoll(argv[2]) : 1, argc > 3 ? atoi(argv[3]) : 6);
   bool cnn = argc > 1 && std::string(argv[1]) == "cnn";
-  const bool graph = argc > 1 && std::string(argv[1]) == "graph";  // `hostlogic_check graph <variant> <seed>`
-  if (graph) { char* a2 = argc > 3 ? argv[3] : (char*)"1"; int variant = argc > 2 ? atoi(argv[2]) : 0; char* a3 = argc > 4 ? argv[4] : nullptr; argv[1] = (char*)"64"; argv[2] = a2; argc = 3; if (a3) { argv[3] = a3; argc = 4; } rs = atoll(a2); std::vector<int64_t> gin; dp::ModelSpec gm = graph_model(variant, gin); g_graph_model = gm; g_graph_in = gin; }
+  // `hostlogic_check blob <model blob file> <input file> [@word]`: a model as dp_model_setup receives it (int64 words, written by deep-prove_amd/models.py),
+  // through the product's own blob parser (csrc/blob.h) and orchestrator over the CPU double — next to the oracle on the same description
+  const bool from_blob = argc > 3 && std::string(argv[1]) == "blob";
+  if (from_blob) {
+    auto slurp = [](const char* path) { std::vector<int64_t> v; FILE* f = fopen(path, "rb"); if (!f) { fprintf(stderr, "cannot open %s\n", path); exit(3); } fseek(f, 0, SEEK_END); long n = ftell(f) / 8; fseek(f, 0, SEEK_SET); v.resize((size_t)n); if (n && fread(v.data(), 8, (size_t)n, f) != (size_t)n) exit(3); fclose(f); return v; };
+    const std::vector<int64_t> words = slurp(argv[2]);
+    g_graph_in = slurp(argv[3]);
+    try { g_graph_model = dp::parse_model(words.data(), words.size()); dp::validate_model(g_graph_model); if (g_graph_in.size() != g_graph_model.input_len) throw dp::DpError(dp::DP_ERR_SHAPE, "input length"); } catch (const dp::DpError& e) { printf("blob refused: %s\n", e.what()); return 4; }
+    char* a3 = argc > 4 ? argv[4] : nullptr; argv[1] = (char*)"64"; argv[2] = (char*)"1"; argc = 3; if (a3) { argv[3] = a3; argc = 4; } rs = 1;
+  }
+  const bool graph = from_blob || (argc > 1 && std::string(argv[1]) == "graph");  // `hostlogic_check graph <variant> <seed>`
+  if (graph && !from_blob) { char* a2 = argc > 3 ? argv[3] : (char*)"1"; int variant = argc > 2 ? atoi(argv[2]) : 0; char* a3 = argc > 4 ? argv[4] : nullptr; argv[1] = (char*)"64"; argv[2] = a2; argc = 3; if (a3) { argv[3] = a3; argc = 4; } rs = atoll(a2); std::vector<int64_t> gin; dp::ModelSpec gm = graph_model(variant, gin); g_graph_model = gm; g_graph_in = gin; }
   bool seq = argc > 1 && std::string(argv[1]) == "seq";  // `hostlogic_check seq <seed>`: a per-token MLP over a [8][4] activation out of MatMul layers
   size_t W = argc > 1 && !cnn && !seq ? atoi(argv[1]) : 64; rs = argc > 2 ? atoll(argv[2]) : 1; int tamper = argc > 3 ? atoi(argv[3][0] == '@' ? argv[3] + 1 : argv[3]) : 0; bool tamper_abs = argc > 3 && argv[3][0] == '@';  // "@i": flip word i, else word size/2 + offset
   dp::ModelSpec m; m.input_len = 4;

@@ -259,3 +259,58 @@ def test_batch_open_over_general_evaluation_lists(hostlogic_bin):
         r = subprocess.run([hostlogic_bin, "batchevals", str(shape + 3), str(shape)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "identical to the oracle" in r.stdout and "accepted 1 of 1, rejected 2 of 2" in r.stdout, r.stdout
+
+
+def _graph_golden():
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graph_models.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("case", range(14))
+def test_golden_graph_blobs_through_the_products_blob_parser_on_the_cpu_double(hostlogic_bin, tmp_path, case):
+    """every model of tests/golden/graph_models.json as dp_model_setup receives it: the int64 blob models.py writes, read by the product's own
+    parser (csrc/blob.h, the one behind the C ABI) and proved by the product's orchestrator over the CPU double, gives the oracle's stream (whose
+    sha256 the golden pins, tests/test_oracle.py) word for word; the verifier, fed from the serialised verifier context, accepts it and refuses a
+    flipped word. Cases 11 / 12: the Mha node; 13: a whole transformer layer (19 nodes)."""
+    import subprocess
+    import numpy as np
+    import deep_prove_amd as dpa
+    c = _graph_golden()[case]
+    g = getattr(dpa.models, c["model"])(**c["args"])
+    bp, ip = tmp_path / "model.blob", tmp_path / "input.bin"
+    g.blob().astype(np.int64).tofile(bp)
+    g.input().astype(np.int64).tofile(ip)
+    r = subprocess.run([hostlogic_bin, "blob", str(bp), str(ip)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"oracle words={c['proof_words']} product words={c['proof_words']} identical=1" in r.stdout, r.stdout
+    assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
+    r = subprocess.run([hostlogic_bin, "blob", str(bp), str(ip), "@77"], capture_output=True, text=True, timeout=900)
+    assert "verify(oracle,tampered): REJECT" in r.stdout, r.stdout + r.stderr
+
+
+def test_malformed_model_blobs_are_refused_by_the_products_parser(hostlogic_bin, tmp_path):
+    """the blob parser behind dp_model_setup on truncated / mutated blobs of the Mha block: refused with an error (or, when the mutation leaves a
+    well-formed model, proved) — never a crash"""
+    import subprocess
+    import numpy as np
+    import deep_prove_amd as dpa
+    g = dpa.models.mha_block(8, 16, 2, 8, config=97)
+    blob, x = g.blob().astype(np.int64), g.input().astype(np.int64)
+    ip = tmp_path / "input.bin"
+    x.tofile(ip)
+    rng = np.random.default_rng(5)
+    mha_at = [i for i in range(blob.size - 4) if blob[i] == 16 and blob[i + 1] == 3][0]  # [16, three inputs, ...]
+    variants = [blob[:mha_at + 5], blob[:-3], np.concatenate([blob, [1, 2]])]
+    for off, val in ((1, 4), (1, 0), (8, 3), (9, 5), (10, 0), (14, 40), (16, 7)):  # input count, shape, table size, zero chunks ...
+        b = blob.copy(); b[mha_at + off] = val; variants.append(b)
+    for _ in range(6):
+        b = blob.copy(); b[int(rng.integers(0, 60))] = int(rng.integers(-3, 70)); variants.append(b)
+    refused = 0
+    for k, b in enumerate(variants):
+        bp = tmp_path / f"m{k}.blob"
+        b.tofile(bp)
+        r = subprocess.run([hostlogic_bin, "blob", str(bp), str(ip)], capture_output=True, text=True, timeout=900)
+        assert r.returncode in (0, 1, 2, 4), (k, r.returncode, r.stdout[-300:] + r.stderr[-300:])  # (no signal: negative return codes)
+        refused += r.returncode == 4 or "refused" in r.stdout or r.returncode == 1
+    assert refused >= 8, refused
