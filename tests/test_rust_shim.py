@@ -10,7 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "deep_prove_hip.h")
 SYS = os.path.join(ROOT, "rust", "deep-prove-hip-sys", "src", "lib.rs")
-CALLERS = [os.path.join(ROOT, "rust", "basefold-hip", "src", "lib.rs"), os.path.join(ROOT, "rust", "sumcheck-hip-patch", "prover_hip.rs")]
+CALLERS = [os.path.join(ROOT, "rust", "basefold-hip", "src", "lib.rs"), os.path.join(ROOT, "rust", "sumcheck-hip-patch", "prover_hip.rs"),
+           os.path.join(ROOT, "rust", "zkml-hip-patch", "hip_blob.rs")]
 
 SCALARS = {"int32_t": "i32", "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "size_t": "usize", "double": "f64", "uint8_t": "u8",
            "char": "c_char", "void": "c_void"}
@@ -139,3 +140,23 @@ def test_trait_surface_is_complete():
         assert re.search(rf"\bfn {fn}\(", src), fn
     for ty in ("Param", "ProverParam", "VerifierParam", "CommitmentWithWitness", "Commitment", "CommitmentChunk", "Proof"):
         assert re.search(rf"type {ty} =", src), ty
+
+
+def test_model_blob_writer_uses_the_layer_kinds_of_the_library_and_covers_the_layer_enum():
+    """rust/zkml-hip-patch/hip_blob.rs (seam 3: Model<Element> -> the blob of dp_model_setup): its KIND_* constants equal enum LayerKind of
+    csrc/proof.h (names and numbers, both directions), and it has a match arm for every variant of the reference's Layer enum
+    (zkml/src/layers/mod.rs:66-93; the variant list is restated here: /root/reference is not on the GPU box)"""
+    src = open(os.path.join(ROOT, "rust", "zkml-hip-patch", "hip_blob.rs")).read()
+    rust_kinds = {m.group(1): int(m.group(2)) for m in re.finditer(r"pub const KIND_(\w+): i64 = (\d+);", src)}
+    hdr = open(os.path.join(ROOT, "deep-prove_amd", "csrc", "proof.h")).read()
+    enum = re.search(r"enum LayerKind \{(.*?)\};", hdr, re.S).group(1)
+    c_kinds = {m.group(1): int(m.group(2)) for m in re.finditer(r"L_(\w+) = (\d+)", enum)}
+    assert rust_kinds == c_kinds and len(c_kinds) == 17
+    from deep_prove_amd import models as M
+    for name, val in c_kinds.items():  # the Python writer of the golden fixtures uses the same numbers
+        assert getattr(M, "L_" + name) == val
+    for variant in ("Dense", "MatMul", "Convolution", "SchoolBookConvolution", "Activation", "Requant", "Pooling", "Flatten", "QKV", "Mha", "ConcatMatMul",
+                    "LayerNorm", "Softmax", "Add", "Reshape", "Embeddings", "Positional", "Logits"):
+        assert re.search(rf"Layer::{variant}\b", src), variant
+    for kind in rust_kinds:  # every kind is written by some arm
+        assert len(re.findall(rf"\bKIND_{kind}\b", src)) >= 2, kind
