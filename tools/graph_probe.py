@@ -1,13 +1,16 @@
-"""an attention block (models.attention_block: QKV, ConcatMatMul x2, MatMul, Add of two inputs, five Requants) at a larger shape on the device:
-parity with the oracle for one proof, then single-proof latency and batch throughput"""
+"""a graph model at a larger shape on the device — models.attention_block (QKV, ConcatMatMul x2, MatMul, Add of two inputs, five Requants) or, with
+GRAPH_MODEL=transformer_layer / mha_block / transformer_block, the blocks with LayerNorm, Softmax and the Mha node — parity with the oracle for one
+proof, then single-proof latency and batch throughput. GRAPH_FFN = width of the feed-forward half of transformer_layer (default 4 x emb)."""
 import os, sys, time
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _root); sys.path.insert(0, os.path.join(_root, "tests"))
 import numpy as np
 import deep_prove_amd as dpa
 from support import oracle_lib
 seq, emb, heads, hd = (int(a) for a in sys.argv[1:5]) if len(sys.argv) > 4 else (64, 256, 4, 64)
 conc = int(sys.argv[5]) if len(sys.argv) > 5 else 128
-g = dpa.models.attention_block(seq, emb, heads, hd, config=66)
+name = os.environ.get("GRAPH_MODEL", "attention_block")
+g = dpa.models.transformer_layer(seq, emb, heads, hd, int(os.environ.get("GRAPH_FFN", 4 * emb)), config=66) if name == "transformer_layer" else getattr(dpa.models, name)(seq, emb, heads, hd, config=66)
 dev = dpa.Device(0)
 ctx = dpa.Context.generate(dev, g.blob())
 pr = dpa.Prover(ctx)
@@ -17,7 +20,7 @@ assert (out == g.run(x)).all()
 o = oracle_lib.load()
 h = o.model_setup(g.blob())
 t0 = time.perf_counter(); oproof, oout, oms = o.model_prove(h, x); o.model_free(h)
-print(f"attention block seq {seq} emb {emb} heads {heads} x {hd}: proof {proof.size} words, identical to the oracle: {bool(proof.size == oproof.size and (proof == oproof).all())} (oracle {oms:.0f} ms on one core)", flush=True)
+print(f"{name} ({len(g.nodes)} nodes) seq {seq} emb {emb} heads {heads} x {hd}: proof {proof.size} words, identical to the oracle: {bool(proof.size == oproof.size and (proof == oproof).all())} (oracle {oms:.0f} ms on one core)", flush=True)
 dpa.verify(ctx.verifier_blob(), proof, x, out)
 lat = []
 for _ in range(3):
