@@ -108,6 +108,40 @@ def strong_share(batch, world, rank):
     return len(shard(batch, world, rank))
 
 
+def transformer_layer_section(dpa, dev, seq=64, emb=256, heads=4, head_dim=64, ffn=1024, conc=192):  # (64 in flight: 87 proofs/s, 192: 142 — profiles/r03_transformer_layer.txt)
+    """SURVEY §8 f4 measured: one whole pre-LN transformer layer as one graph of 19 nodes (models.transformer_layer: LayerNorm, QKV, the Mha node of
+    transformer/mha.rs, projection, residual; LayerNorm, Linear, ReLU, Linear, residual). Parity: golden case 13 of tests/golden/graph_models.json
+    (the oracle's sha256 at 8 x 16) proved here; throughput and latency at seq x emb with `conc` proofs in flight, a sample of the batch verified."""
+    import hashlib
+    import numpy as np
+    with open(os.path.join(ROOT, "tests", "golden", "graph_models.json")) as f:
+        c = json.load(f)[13]
+    assert c["model"] == "transformer_layer"
+    g = dpa.models.transformer_layer(**c["args"])
+    ctx = dpa.Context.generate(dev, g.blob())
+    proof, _ = dpa.Prover(ctx).prove(g.input())
+    golden_ok = hashlib.sha256(proof.tobytes()).hexdigest() == c["proof_sha256"]
+    ctx.free()
+    g = dpa.models.transformer_layer(seq, emb, heads, head_dim, ffn, config=66)
+    ctx = dpa.Context.generate(dev, g.blob())
+    pr = dpa.Prover(ctx)
+    x = g.input()
+    proof, out = pr.prove(x)
+    dpa.verify(ctx.verifier_blob(), proof, x, out)
+    lat = []
+    for _ in range(3):
+        t0 = time.perf_counter(); pr.prove(x); lat.append(1000 * (time.perf_counter() - t0))
+    xs = np.stack([g.input(100 + i) for i in range(3 * conc)])
+    pr.prove_batch(xs[:conc], conc)
+    t0 = time.perf_counter(); proofs, outs, _ = pr.prove_batch(xs, conc); dt = time.perf_counter() - t0
+    v, _ = dpa.verify_batch(ctx.verifier_blob(), proofs[:16], xs[:16], outs[:16], dev=dev)
+    r = {"value": round(len(xs) / dt, 2), "unit": "proofs/s", "workload": f"one pre-LN transformer layer, {len(g.nodes)} nodes, seq {seq} x emb {emb}, {heads} heads of {head_dim}, ffn {ffn} (Mha as one node; ReLU for GELU)",
+         "proofs": len(xs), "proofs_in_flight": int(pr.in_flight()), "single_proof_latency_ms": round(sorted(lat)[1], 2), "proof_words": int(proof.size),
+         "golden_sha256_ok_at_8x16": bool(golden_ok), "verified_sample": 16, "rejected_of_sample": int(v.sum())}
+    ctx.free()
+    return r
+
+
 def measure_workload(dpa, dev, workload, conc, steps, warmup, world, rank, dist, torch, profile=False, strong_batch=0):
     """setup + latency of one proof + the timed throughput region + verification of the last batch (+ the per-kernel HIP
     event profile of one more proof); the model context and its workers are released before returning"""
@@ -237,6 +271,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sumcheck24", action="store_true", help="skip the standalone 2^24 sumcheck roofline section")
     ap.add_argument("--no-cnn", action="store_true", help="skip the CNN-264k section of a Dense-4M run")
+    ap.add_argument("--no-transformer", action="store_true", help="skip the transformer-layer section (models.transformer_layer: LayerNorm, QKV, the Mha node, feed-forward half)")
     ap.add_argument("--no-seam-level", action="store_true", help="skip the seam-level consumer section (tests/support/seam_bench.c)")
     ap.add_argument("--batch", type=int, default=0, help="BASELINE config 4: ONE fixed batch of this many proofs per step, split over the ranks (strong scaling); "
                                                          "0 = the default weak-scaling run (fixed work per GPU)")
@@ -369,6 +404,11 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "cnn_264k": cnn, "sumcheck24": sc24, "sumcheck24_sharded": None,
             "seam_level": None if (world > 1 or args.no_seam_level) else seam_level(int(os.environ["DP_HOST_THREADS"])),
         }
+        if world == 1 and args.workload == "dense_4m" and not args.batch and not args.no_transformer:
+            try:  # (a side section: whatever happens in it, the headline line above is printed)
+                result["transformer_layer"] = transformer_layer_section(dpa, dev)
+            except Exception as e:  # noqa: BLE001
+                result["transformer_layer"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # BASELINE config 5 across the ranks: ONE 2^24 sumcheck, every rank owns a contiguous 1/N slice of each table and the
     # per-round shares are all-gathered over RCCL (deep_prove_amd/sharded.py). It runs AFTER the headline is complete and

@@ -3,6 +3,7 @@
 // (tests/support/kernel_emul) drives the kernel source with exactly the host code the product uses.
 #pragma once
 #include "dev.h"
+#include <cstdlib>
 #include <cstring>
 
 namespace dp {
@@ -11,6 +12,20 @@ constexpr int LT_MAXI = 7;        // instances of one batch proof: 1 + 4 * 7 tab
 constexpr int LT_MAXL = 16;       // tree layers (columns of at most 2^16 rows; logup_tail_accepts stops far below)
 constexpr int LT_MAX_TABS = 32;   // == MAX_TABS of hip_dev.hip
 constexpr size_t LOGUP_TAIL_MAX_N = 65536;  // = 2^LT_MAXL: one workgroup still walks a 2^15-row table in well under a millisecond per layer
+// DP_LOGUP_TAIL_MAX_N (a power of two, 4 .. 65536; default 65536): lookups with longer columns run layer by layer through chip-wide kernels
+// (logup_layers) instead of in one workgroup. Same transcript, same proof. The transformer layer at 64 x 256 spends 72 % of its kernel time in
+// one-workgroup tails over 2^14 .. 2^16-row columns with only 64 proofs in flight (profiles/r03_transformer_layer.txt): the knob is there to
+// measure where the crossover lies.
+inline size_t logup_tail_max_n() {
+  static const size_t v = [] {
+    const char* e = getenv("DP_LOGUP_TAIL_MAX_N");
+    size_t x = e ? (size_t)strtoull(e, nullptr, 10) : LOGUP_TAIL_MAX_N;
+    if (x < 4) x = 4;
+    if (x > LOGUP_TAIL_MAX_N) x = LOGUP_TAIL_MAX_N;
+    return x;
+  }();
+  return v;
+}
 
 struct LogupTailDesc {
   const void* num[LT_MAXI][LT_MAXL];  // numerators of tree layer li: extension; layer 0 of a table instance: the base-field
@@ -54,7 +69,7 @@ inline bool logup_tail_accepts(const Dev::LogupTailArgs& a) {
   const size_t nlayers = cs[0].den.size();
   if (nlayers < 2 || nlayers > (size_t)LT_MAXL || a.total_layers != nlayers - 1 || a.initial_lookup == a.is_table) return false;
   const size_t n = cs[0].den[0].n;
-  if (n > LOGUP_TAIL_MAX_N || n != (size_t(1) << nlayers)) return false;
+  if (n > logup_tail_max_n() || n != (size_t(1) << nlayers)) return false;
   for (const LogupCircuitDev& c : cs) {
     if (c.den.size() != nlayers || c.num.size() != nlayers) return false;
     for (size_t li = 0; li < nlayers; li++) {
@@ -141,7 +156,7 @@ inline void logup_tail_parse(const u64* w, const Dev::LogupTailArgs& a, const st
 inline bool logup_full_accepts(const DBuf* cols, int cpi, int ninst, const DBuf& mult, size_t* n_out) {
   if (ninst < 1 || ninst > LT_MAXI || cpi < 1 || cpi > 8) return false;
   const size_t n = cols[0].n;
-  if (n < 4 || n > LOGUP_TAIL_MAX_N || (n & (n - 1))) return false;
+  if (n < 4 || n > logup_tail_max_n() || (n & (n - 1))) return false;
   for (int i = 0; i < ninst * cpi; i++) if (cols[i].null() || cols[i].ext || cols[i].n != n) return false;
   if (!mult.null() && (mult.ext || mult.n != n || ninst != 1)) return false;
   *n_out = n;

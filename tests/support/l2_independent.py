@@ -415,22 +415,22 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
     # MhaCtx::verify (layers/transformer/mha.rs:792-893): final_mul.verify on the node's output claim -> (claim on the probabilities, claim on V);
     # softmax.verify on the first; qk.verify on the softmax's claim -> (claims on Q, K); the node hands on [Q, K, V]. Walked as three steps through
     # the concat_matmul / softmax branches below, each with the sub-layer Mha::new builds (mha.rs:147-186) and its part of the MhaProof.
-    vsteps, hold, prev = [], None, None
+    vsteps, mha_hold, last_vstep = [], None, None
     for nid in order:
         vsteps += [(nid, 1), (nid, 2), (nid, 3)] if nodes[nid]["kind"] == "mha" else [(nid, 0)]
 
     def settle(step):
-        nonlocal hold
+        nonlocal mha_hold
         if step is not None and step[1] == 1:
-            hold = made[step[0]]
-            assert len(hold) == 2
+            mha_hold = made[step[0]]
+            assert len(mha_hold) == 2
         if step is not None and step[1] == 3:
-            made[step[0]] = made[step[0]] + [hold[1]]
+            made[step[0]] = made[step[0]] + [mha_hold[1]]
             assert len(made[step[0]]) == 3
 
     for nid, part in vsteps + [(None, 0)]:
-        settle(prev)
-        prev = (nid, part)
+        settle(last_vstep)
+        last_vstep = (nid, part)
         if nid is None:
             break
         n = nodes[nid]
@@ -444,7 +444,7 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
                 n = dict(kind="concat_matmul", a_shape=(S_, H_, D_), b_shape=(S_, H_, D_), left=(1, 2, 0), right=(1, 2, 0), perm=None, n_out=1)
         got = []
         if part == 2:
-            got = [hold[0]]
+            got = [mha_hold[0]]
         elif part == 3:
             got = [made[nid][0]]
         else:

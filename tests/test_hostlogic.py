@@ -225,13 +225,13 @@ def test_softmax_proofs_reject_every_flipped_word(hostlogic_bin, variant):
         assert m and int(m.group(1)) > 100 and m.group(1) == m.group(2) and not m.group(3).strip(), r.stdout
 
 
-@pytest.mark.parametrize("variant", [9, 10])
+@pytest.mark.parametrize("variant", [9])
 def test_mha_proofs_reject_every_flipped_word(hostlogic_bin, variant):
-    """Mha as one node (layers/transformer/mha.rs:633-724 / 792-893; variants 9 / 10): one proof, a single-bit flip in every 3rd of the first
+    """Mha as one node (layers/transformer/mha.rs:633-724 / 792-893; variants 9 / 10): one proof, a single-bit flip in every 5th of the first
     8000 words (the QKV proof, then the MhaProof: final_mul's sumcheck and claims, the softmax's four lookups, commitments, accumulation and
     mask sumchecks, evaluations, qk's sumcheck and claims) and in a sample of the rest — the verifier refuses each"""
     import os, re, subprocess
-    for sweep in ("1:8000:3", "8000:106000:307"):
+    for sweep in ("1:8000:5", "8000:106000:499"):
         r = subprocess.run([hostlogic_bin, "graph", str(variant), "11"], capture_output=True, text=True, timeout=900, env=dict(os.environ, DP_FLIP_SWEEP=sweep))
         assert r.returncode == 0 and "identical=1" in r.stdout, r.stdout + r.stderr
         m = re.search(r"flip sweep: (\d+) flipped, (\d+) rejected, accepted at:(.*)", r.stdout)
@@ -267,7 +267,7 @@ def _graph_golden():
         return json.load(f)
 
 
-@pytest.mark.parametrize("case", [0, 2, 3, 4, 5, 6, 7, 8, 9, 11, 13])  # (1, 10, 12 are the larger twins of 0, 9, 11: on the GPU only)
+@pytest.mark.parametrize("case", [0, 2, 4, 6, 8, 11, 13])  # (a model of every kind; the others run on the GPU, tests/test_gpu_model.py)
 def test_golden_graph_blobs_through_the_products_blob_parser_on_the_cpu_double(hostlogic_bin, tmp_path, case):
     """every model of tests/golden/graph_models.json as dp_model_setup receives it: the int64 blob models.py writes, read by the product's own
     parser (csrc/blob.h, the one behind the C ABI) and proved by the product's orchestrator over the CPU double, gives the oracle's stream (whose

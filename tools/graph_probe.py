@@ -17,10 +17,13 @@ pr = dpa.Prover(ctx)
 x = g.input()
 proof, out = pr.prove(x)
 assert (out == g.run(x)).all()
-o = oracle_lib.load()
-h = o.model_setup(g.blob())
-t0 = time.perf_counter(); oproof, oout, oms = o.model_prove(h, x); o.model_free(h)
-print(f"{name} ({len(g.nodes)} nodes) seq {seq} emb {emb} heads {heads} x {hd}: proof {proof.size} words, identical to the oracle: {bool(proof.size == oproof.size and (proof == oproof).all())} (oracle {oms:.0f} ms on one core)", flush=True)
+if os.environ.get("GRAPH_NO_ORACLE"):  # (sweeps: parity is established by the run without this switch)
+    print(f"{name} ({len(g.nodes)} nodes) seq {seq} emb {emb} heads {heads} x {hd}: proof {proof.size} words (oracle not run), DP_LOGUP_TAIL_MAX_N={os.environ.get('DP_LOGUP_TAIL_MAX_N', 'default')}", flush=True)
+else:
+    o = oracle_lib.load()
+    h = o.model_setup(g.blob())
+    t0 = time.perf_counter(); oproof, oout, oms = o.model_prove(h, x); o.model_free(h)
+    print(f"{name} ({len(g.nodes)} nodes) seq {seq} emb {emb} heads {heads} x {hd}: proof {proof.size} words, identical to the oracle: {bool(proof.size == oproof.size and (proof == oproof).all())} (oracle {oms:.0f} ms on one core), DP_LOGUP_TAIL_MAX_N={os.environ.get('DP_LOGUP_TAIL_MAX_N', 'default')}", flush=True)
 dpa.verify(ctx.verifier_blob(), proof, x, out)
 lat = []
 for _ in range(3):
