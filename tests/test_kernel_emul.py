@@ -121,3 +121,14 @@ def test_general_evaluation_lists_with_the_emulated_sumcheck_tail():
         r = _model(("batchevals", shape + 3, shape), {})
         assert r.returncode == 0, r.stdout + r.stderr
         assert "identical to the oracle" in r.stdout and "accepted 1 of 1, rejected 2 of 2" in r.stdout, r.stdout
+
+
+def test_logup_tail_threshold_knob_moves_long_lookups_to_the_layer_kernels_without_changing_the_proof():
+    """DP_LOGUP_TAIL_MAX_N (csrc/logup_tail.h: the longest lookup column k_logup_tail proves in one workgroup): with 64, the MLP's longer lookups
+    are declined by the tail and run layer by layer, the shorter ones still come from the emulated kernel — and the proof stream is the oracle's"""
+    r = _model((64, 1), {"DP_LOGUP_TAIL_MAX_N": "64"})
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical=1" in r.stdout and "verify(product): ACCEPT" in r.stdout, r.stdout
+    taken = int(r.stdout.split("logup proofs taken")[0].split()[-1])
+    declined = int(r.stdout.split("logup proofs taken, ")[1].split()[0])
+    assert taken >= 1 and declined >= 1, r.stdout
