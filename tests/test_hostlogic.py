@@ -198,44 +198,48 @@ def test_graph_model_layer_proofs_reject_every_flipped_word(hostlogic_bin, varia
         assert "verify(oracle,tampered): REJECT" in r.stdout, (at, r.stdout + r.stderr)
 
 
-@pytest.mark.parametrize("variant", [5, 6])
+# DP_FULL_SWEEPS=1: both variants of every layer and the dense strides (the default keeps the CPU suite short: one variant, every 2nd flip position)
+_FULL = bool(int(__import__("os").environ.get("DP_FULL_SWEEPS", "0")))
+
+
+@pytest.mark.parametrize("variant", [5, 6] if _FULL else [6])
 def test_layernorm_proofs_reject_every_flipped_word(hostlogic_bin, variant):
     """LayerNorm (layers/transformer/layernorm.rs:729-1100 / 1230-1505; variants 5 / 6 of the graph models: N = 16, N = 12 of a padded 16) ->
     shift-only Requant -> ReLU: one proof, a single-bit flip in every 5th of the first 6000 words (the LayerNorm proof: two lookups,
     commitments, the accumulation / io / input sumchecks, their evaluations; then Requant and ReLU) and in a sample of the rest (table proofs
     with the committed inverse-square-root column, openings) — the verifier refuses each"""
     import os, re, subprocess
-    for sweep in ("1:6000:5", "6000:140000:997"):
+    for sweep in (("1:6000:5", "6000:140000:997") if _FULL else ("1:6000:11", "6000:140000:1999")):
         r = subprocess.run([hostlogic_bin, "graph", str(variant), "11"], capture_output=True, text=True, timeout=900, env=dict(os.environ, DP_FLIP_SWEEP=sweep))
         assert r.returncode == 0 and "identical=1" in r.stdout, r.stdout + r.stderr
         m = re.search(r"flip sweep: (\d+) flipped, (\d+) rejected, accepted at:(.*)", r.stdout)
-        assert m and int(m.group(1)) > 100 and m.group(1) == m.group(2) and not m.group(3).strip(), r.stdout
+        assert m and int(m.group(1)) > (100 if _FULL else 30) and m.group(1) == m.group(2) and not m.group(3).strip(), r.stdout
 
 
-@pytest.mark.parametrize("variant", [7, 8])
+@pytest.mark.parametrize("variant", [7, 8] if _FULL else [8])
 def test_softmax_proofs_reject_every_flipped_word(hostlogic_bin, variant):
     """Softmax (layers/transformer/softmax.rs:573-888 / 1274-1586; variants 7 / 8: without / with a zero table): one proof, a single-bit flip in
     every 3rd of the first 6000 words (the four lookups, the commitments, the accumulation and the mask sumcheck, the evaluations) and in a
     sample of the rest (table proofs with the committed exponential / error columns, openings) — the verifier refuses each"""
     import os, re, subprocess
-    for sweep in ("1:6000:3", "6000:74000:211"):
+    for sweep in (("1:6000:3", "6000:74000:211") if _FULL else ("1:6000:7", "6000:74000:431")):
         r = subprocess.run([hostlogic_bin, "graph", str(variant), "11"], capture_output=True, text=True, timeout=900, env=dict(os.environ, DP_FLIP_SWEEP=sweep))
         assert r.returncode == 0 and "identical=1" in r.stdout, r.stdout + r.stderr
         m = re.search(r"flip sweep: (\d+) flipped, (\d+) rejected, accepted at:(.*)", r.stdout)
-        assert m and int(m.group(1)) > 100 and m.group(1) == m.group(2) and not m.group(3).strip(), r.stdout
+        assert m and int(m.group(1)) > (100 if _FULL else 30) and m.group(1) == m.group(2) and not m.group(3).strip(), r.stdout
 
 
-@pytest.mark.parametrize("variant", [9])
+@pytest.mark.parametrize("variant", [9, 10] if _FULL else [9])
 def test_mha_proofs_reject_every_flipped_word(hostlogic_bin, variant):
     """Mha as one node (layers/transformer/mha.rs:633-724 / 792-893; variants 9 / 10): one proof, a single-bit flip in every 5th of the first
     8000 words (the QKV proof, then the MhaProof: final_mul's sumcheck and claims, the softmax's four lookups, commitments, accumulation and
     mask sumchecks, evaluations, qk's sumcheck and claims) and in a sample of the rest — the verifier refuses each"""
     import os, re, subprocess
-    for sweep in ("1:8000:5", "8000:106000:499"):
+    for sweep in (("1:8000:3", "8000:106000:307") if _FULL else ("1:8000:11", "8000:106000:997")):
         r = subprocess.run([hostlogic_bin, "graph", str(variant), "11"], capture_output=True, text=True, timeout=900, env=dict(os.environ, DP_FLIP_SWEEP=sweep))
         assert r.returncode == 0 and "identical=1" in r.stdout, r.stdout + r.stderr
         m = re.search(r"flip sweep: (\d+) flipped, (\d+) rejected, accepted at:(.*)", r.stdout)
-        assert m and int(m.group(1)) > 100 and m.group(1) == m.group(2) and not m.group(3).strip(), r.stdout
+        assert m and int(m.group(1)) > (100 if _FULL else 30) and m.group(1) == m.group(2) and not m.group(3).strip(), r.stdout
 
 
 def test_batch_commit_and_simple_batch_open_over_the_double(hostlogic_bin):
@@ -305,7 +309,7 @@ def test_malformed_model_blobs_are_refused_by_the_products_parser(hostlogic_bin,
     variants = [blob[:mha_at + 5], blob[:-3], np.concatenate([blob, [1, 2]])]
     for off, val in ((1, 4), (1, 0), (8, 3), (9, 5), (10, 0), (14, 40), (16, 7)):  # input count, shape, table size, zero chunks ...
         b = blob.copy(); b[mha_at + off] = val; variants.append(b)
-    for _ in range(6):
+    for _ in range(2):
         b = blob.copy(); b[int(rng.integers(0, 60))] = int(rng.integers(-3, 70)); variants.append(b)
     refused = 0
     for k, b in enumerate(variants):
@@ -314,4 +318,4 @@ def test_malformed_model_blobs_are_refused_by_the_products_parser(hostlogic_bin,
         r = subprocess.run([hostlogic_bin, "blob", str(bp), str(ip)], capture_output=True, text=True, timeout=900)
         assert r.returncode in (0, 1, 2, 4), (k, r.returncode, r.stdout[-300:] + r.stderr[-300:])  # (no signal: negative return codes)
         refused += r.returncode == 4 or "refused" in r.stdout or r.returncode == 1
-    assert refused >= 8, refused
+    assert refused >= 6, refused
