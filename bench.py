@@ -622,7 +622,7 @@ def sharded_estimate(nv, k, world, stream_tbps=3.4, round_us=17.0, exchange_us=3
 
 def seam_level(threads, per_thread=6):
     """What a host gets that proves THROUGH THE SEAMS (dp_pcs_commit / dp_pcs_batch_open / dp_sumcheck_prove / dp_logup_prove from T
-    threads, each context a slot of the resident executor) instead of handing the model to dp_model_prove_batch: tests/support/
+    threads with one context each) instead of handing the model to dp_model_prove_batch: tests/support/
     seam_bench.c replays the seam calls of one Dense-4M proof, call for call and shape for shape, on random tables — "workload-
     equivalent" proofs (the seams' bit-exactness is the business of the parity tests). Run in its own process (own HIP contexts)."""
     import subprocess
@@ -635,14 +635,10 @@ def seam_level(threads, per_thread=6):
         subprocess.check_call(["gcc", "-std=c11", "-Wall", "-O2", "-o", out, src, "-L", os.path.dirname(dpa.LIB_PATH), "-ldeepprove_hip", "-lpthread",
                                "-Wl,-rpath," + os.path.dirname(dpa.LIB_PATH)])
     res = {}
-    # (the executor variant — 34 proofs/s at 14 threads, profiles/r03_seam_level_t14_executor.json — only on request: a bench line should not
-    # depend on two more persistent kernels coming up in a second process)
     # `streams_throughput`: plain contexts switched to throughput mode (dp_ctx_set_throughput_mode: device-side Fiat-Shamir, fused protocol
     # kernels). Measured: 40 against 80 proofs/s at 14 threads, 34-36 with 28 / 56 yielding threads (profiles/r03_seam_level_throughput_mode.txt):
     # without cohorts to merge launches and fibers to keep hundreds of calls in flight the one-wave kernels only add latency
     variants = [("streams", 0, threads, {}), ("streams_throughput", 2, threads, {})]
-    if os.environ.get("DP_BENCH_SEAM_EXECUTOR") == "1":
-        variants.insert(0, ("executor", 1, threads, {}))
     for name, executor, t, extra in variants:
         env = dict(os.environ, DP_ARENA_BYTES=str(2 << 30), **extra)
         try:
@@ -652,8 +648,7 @@ def seam_level(threads, per_thread=6):
         except Exception as e:  # noqa: BLE001
             res[name] = {"error": f"{type(e).__name__}: {e}"}
     res["note"] = ("workload-equivalent proofs per second of a seam-level host (every seam call of one Dense-4M proof, random tables), T threads with one dp_ctx each: "
-                   "`streams` = plain contexts in latency mode (one HIP stream each), `streams_throughput` = the same in throughput mode (dp_ctx_set_throughput_mode), "
-                   "`executor` (DP_BENCH_SEAM_EXECUTOR=1) = contexts attached to the resident executor (dp_executor_attach)")
+                   "`streams` = plain contexts in latency mode (one HIP stream each), `streams_throughput` = the same in throughput mode (dp_ctx_set_throughput_mode)")
     return res
 
 

@@ -11,7 +11,8 @@ import os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdeepprove_hip.so")
+# DP_LIB_VARIANT=<tag> loads libdeepprove_hip_<tag>.so: a diagnostic build (DP_HIPCC_EXTRA, __graft_entry__.build_hip(variant=...)) next to the release library
+LIB_PATH = os.path.join(_HERE, "libdeepprove_hip" + ("_" + os.environ["DP_LIB_VARIANT"] if os.environ.get("DP_LIB_VARIANT") else "") + ".so")
 
 u64p = C.POINTER(C.c_uint64)
 i64p = C.POINTER(C.c_int64)
@@ -27,10 +28,6 @@ SIGNATURES = {
     "dp_ctx_destroy": (C.c_int32, [vp]),
     "dp_ctx_name": (C.c_char_p, [vp]),
     "dp_ctx_set_throughput_mode": (C.c_int32, [vp, C.c_int32]),
-    "dp_executor_start": (C.c_int32, [C.c_int32, C.c_int32]),
-    "dp_executor_attach": (C.c_int32, [vp, C.c_int32]),
-    "dp_executor_detach": (C.c_int32, [vp]),
-    "dp_executor_stop": (C.c_int32, [C.c_int32]),
     "dp_profile_enable": (C.c_int32, [vp, C.c_int32]),
     "dp_profile_report": (C.c_int32, [vp, C.POINTER(C.c_void_p)]),
     "dp_probe_compress_rate": (C.c_int32, [vp, C.c_size_t, C.c_int32, C.POINTER(C.c_double)]),

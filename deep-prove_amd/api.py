@@ -87,14 +87,6 @@ class Device:
         workers of prove_batch run with); results are bit-identical to latency mode"""
         check(self._lib.dp_ctx_set_throughput_mode(self.h, 1 if on else 0))
 
-    def executor_attach(self, slot):
-        """dp_executor_attach: this context becomes slot `slot` of the device's resident executor (executor_start first): its seam
-        calls run as step descriptors of two persistent kernels, independently of every other attached context"""
-        check(self._lib.dp_executor_attach(self.h, slot))
-
-    def executor_detach(self):
-        check(self._lib.dp_executor_detach(self.h))
-
     def close(self):
         """destroys the dp_ctx; models generated on it hold a dangling device afterwards, so they are freed first"""
         for c in list(self._contexts):
@@ -102,15 +94,6 @@ class Device:
         if self.h:
             self._lib.dp_ctx_destroy(self.h)
             self.h = None
-
-
-def executor_start(device_id=0, nslots=16):
-    """dp_executor_start: the resident executor (csrc/rx.h) for seam-level callers on `device_id`, `nslots` contexts may attach"""
-    check(_lib.load().dp_executor_start(device_id, nslots))
-
-
-def executor_stop(device_id=0):
-    check(_lib.load().dp_executor_stop(device_id))
 
 
 class Transcript:

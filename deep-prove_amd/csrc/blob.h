@@ -16,7 +16,7 @@ inline ModelSpec parse_model(const int64_t* b, size_t n) {
   auto rd_edge = [&]() { Edge e; const int64_t f = rd(), sl = rd(); DP_REQUIRE(f >= -1 && f < (int64_t)nl && sl >= 0 && sl < 4096, DP_ERR_ARG, "model blob: edge"); e.from = (int)f; e.slot = (int)sl; return e; };
   if (graph) {
     const size_t ni = (size_t)rd(); DP_REQUIRE(ni > 0 && ni < 4096, DP_ERR_ARG, "model blob: input tensor count");
-    for (size_t i = 0; i < ni; i++) m.input_lens.push_back((size_t)rd());
+    for (size_t i = 0; i < ni; i++) { const int64_t len = rd(); DP_REQUIRE(len >= 1 && len <= (int64_t(1) << 40), DP_ERR_ARG, "model blob: input tensor length"); m.input_lens.push_back((size_t)len); }
     const size_t no = (size_t)rd(); DP_REQUIRE(no > 0 && no < 4096, DP_ERR_ARG, "model blob: output tensor count");
     for (size_t i = 0; i < no; i++) m.outputs.push_back(rd_edge());
   }
@@ -73,11 +73,13 @@ inline ModelSpec parse_model(const int64_t* b, size_t n) {
     else if (l.kind == L_CONV) {
       l.kw = (size_t)rd(); l.kx = (size_t)rd(); l.real_nw = (size_t)rd(); l.nw = (size_t)rd(); for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();
       DP_REQUIRE(l.kw && l.kx && l.real_nw && l.kw < (1u << 16) && l.kx < (1u << 16) && l.real_nw < (1u << 12), DP_ERR_ARG, "model blob: conv dimensions");
+      DP_REQUIRE(l.nw >= 1 && l.nw <= (size_t(1) << 16), DP_ERR_ARG, "model blob: conv padded size");
+      for (int k = 0; k < 3; k++) DP_REQUIRE(l.unp_out[k] >= 1 && l.unp_out[k] <= (size_t(1) << 24), DP_ERR_ARG, "model blob: conv output shape");
       size_t nf = l.kw * l.kx * l.real_nw * l.real_nw;
       DP_REQUIRE(nf <= n - pos && l.kw <= n - pos - nf, DP_ERR_ARG, "model blob: conv tensor sizes");
       l.weights.assign(b + pos, b + pos + nf); pos += nf;
       l.bias.assign(b + pos, b + pos + l.kw); pos += l.kw;
-    } else if (l.kind == L_MAXPOOL) { for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd(); }
+    } else if (l.kind == L_MAXPOOL) { for (int k = 0; k < 3; k++) { l.pin[k] = (size_t)rd(); DP_REQUIRE(l.pin[k] >= 1 && l.pin[k] <= (size_t(1) << 24), DP_ERR_ARG, "model blob: maxpool input shape"); } }
     else if (l.kind == L_LAYERNORM) {  // [14, padded dimension, N, multiplier, epsilon bits (f32), range check bits, log2 of the top chunk scalar, gamma[dim], beta[dim]]
       const size_t dim = (size_t)rd(); l.nrows = dim; l.ln_dim_size = (size_t)rd(); l.ln_multiplier = rd();
       const int64_t eb = rd(), rcb = rd(), tcs = rd();

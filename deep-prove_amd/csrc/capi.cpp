@@ -4,7 +4,6 @@
 #include "blob.h"
 #include "sharded.h"
 #include "fiber.h"
-#include "rx.h"
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>  // types and enums only: the functions are resolved with dlopen (no link-time dependency on librccl)
@@ -13,11 +12,12 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <set>
 #include <mutex>
 #include <thread>
 
 DP_FIBER_SWITCH_ASM
-namespace dp { struct Cohort; Cohort* hip_cohort_new(); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); struct RxEngine; void hip_dev_rx_attach(Dev* d, RxEngine* e, unsigned slot); void hip_dev_rx_detach(Dev* d); void hip_rx_session(int delta); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_pcs_share(Dev* worker, Dev* owner); void hip_dump_wg_times(); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
+namespace dp { struct Cohort; Cohort* hip_cohort_new(); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_pcs_share(Dev* worker, Dev* owner); void hip_dump_wg_times(); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
 using namespace dp;
 
 // `mu`: PCS::commit is called from rayon workers in the reference (zkml/src/commit/context.rs:79-103 into_par_iter over
@@ -33,8 +33,7 @@ struct dp_batch_commit { DevBatchCommit c; };
 struct dp_model {
   dp_ctx* ctx; std::unique_ptr<Context> zk; std::vector<std::unique_ptr<Dev>> workers; std::vector<dp::Cohort*> cohorts;
   size_t last_in_flight = 0, in_flight_cap = 0; size_t prove_peak = 0;  // largest arena footprint a proof of this model has had so far (sizes the arenas of batch workers)
-  dp::RxEngine* rx = nullptr;  // the resident executor of this model's GPU (rx.h), created by the first batch that uses it
-  ~dp_model() { for (auto* c : cohorts) hip_cohort_free(c); if (rx) rx_engine_free(rx); }
+  ~dp_model() { for (auto* c : cohorts) hip_cohort_free(c); }
 };
 
 // Every cohort stream needs a hardware queue of its own (24 are served without time slicing; the HIP runtime multiplexes streams
@@ -69,6 +68,7 @@ constexpr uint64_t OUT_MAGIC = 0x44504F55544F4B31ULL, OUT_IDLE_MAGIC = 0x44504F5
 struct OutPool {
   std::mutex mu;
   std::multimap<size_t, void*> idle;  // capacity -> block (header address)
+  std::set<void*> live;                // headers of the blocks currently handed out: dp_free validates against it BEFORE it touches a header
   size_t idle_bytes = 0, out_bytes = 0, out_peak = 0;
   // idle blocks kept: at most what was ever handed out at once (one batch of proofs comes back and is handed out again), at least
   // 1 GB, never more than DP_OUT_POOL_BYTES (default 24 GB)
@@ -81,20 +81,23 @@ struct OutPool {
       auto it = idle.lower_bound(cap);
       if (it != idle.end() && it->first <= cap + cap / 4) {
         OutHeader* h = (OutHeader*)it->second; idle_bytes -= it->first; idle.erase(it);
-        h->magic = OUT_MAGIC; out_bytes += h->cap; out_peak = std::max(out_peak, out_bytes);
+        h->magic = OUT_MAGIC; out_bytes += h->cap; out_peak = std::max(out_peak, out_bytes); live.insert(h);
         return (char*)h + sizeof(OutHeader);
       }
     }
     OutHeader* h = (OutHeader*)malloc(sizeof(OutHeader) + cap);
     if (!h) throw std::bad_alloc();
     h->magic = OUT_MAGIC; h->cap = cap; h->pad0 = h->pad1 = 0;
-    { std::lock_guard<std::mutex> g(mu); out_bytes += cap; out_peak = std::max(out_peak, out_bytes); }
+    { std::lock_guard<std::mutex> g(mu); out_bytes += cap; out_peak = std::max(out_peak, out_bytes); live.insert(h); }
     return (char*)h + sizeof(OutHeader);
   }
   // false: not a block this library handed out (or one already given back) — nothing is touched
   bool give(void* p) {
     OutHeader* h = (OutHeader*)((char*)p - sizeof(OutHeader));
     std::lock_guard<std::mutex> g(mu);
+    auto lit = live.find((void*)h);
+    if (lit == live.end()) return false;  // foreign pointer or double free: the header (possibly freed or unmapped memory) is never read
+    live.erase(lit);
     if (h->magic != OUT_MAGIC) return false;
     out_bytes -= std::min<size_t>(out_bytes, h->cap);
     if (idle_bytes + h->cap > keep()) { h->magic = 0; free(h); return true; }
@@ -133,51 +136,8 @@ int32_t dp_ctx_create(int32_t device_id, dp_ctx** out) {
 }
 int32_t dp_ctx_destroy(dp_ctx* ctx) { return guard([&] { if (ctx) { delete ctx->dev; delete ctx; } }); }
 
-// ---- the resident executor for seam-level callers (rx.h): a host that proves through dp_sumcheck_prove / dp_logup_prove / dp_pcs_*
-// from many threads gets, per call, what dp_model_prove_batch gets per proof — every context a slot, every launch a step descriptor,
-// no command processor and no lock step between the callers
-namespace {
-std::mutex g_exec_mu;
-std::map<int, dp::RxEngine*> g_executors;
-inline std::map<int, dp::RxEngine*>& executors() { return g_executors; }
-}
-int32_t dp_executor_start(int32_t device_id, int32_t nslots) {
-  return guard([&] {
-    DP_REQUIRE(nslots >= 1 && nslots <= (int32_t)RX_MAX_SLOTS, DP_ERR_ARG, "executor: 1..1024 slots");
-    std::lock_guard<std::mutex> g(g_exec_mu);
-    dp::RxEngine*& e = executors()[device_id];
-    if (!e) e = rx_engine_new(device_id);
-    DP_REQUIRE(!rx_engine_running(e), DP_ERR_ARG, "executor: already running on this device");
-    rx_engine_start(e, (unsigned)nslots);
-    hip_rx_session(+1);
-  });
-}
 int32_t dp_ctx_set_throughput_mode(dp_ctx* ctx, int32_t on) {
   return guard([&] { DP_REQUIRE(ctx, DP_ERR_ARG, "null ctx"); CtxLock lk(ctx); ctx->dev->sync(); hip_dev_set_latency_mode(ctx->dev, on == 0); });
-}
-int32_t dp_executor_attach(dp_ctx* ctx, int32_t slot) {
-  return guard([&] {
-    DP_REQUIRE(ctx && slot >= 0, DP_ERR_ARG, "bad arguments");
-    std::lock_guard<std::mutex> g(g_exec_mu);
-    auto it = executors().find(ctx->device_id);
-    DP_REQUIRE(it != executors().end() && rx_engine_running(it->second), DP_ERR_ARG, "executor: not running on this context's device (dp_executor_start)");
-    CtxLock lk(ctx);
-    hip_dev_set_latency_mode(ctx->dev, false);  // throughput mode: device-side Fiat-Shamir, fused protocol kernels, 256-thread one-workgroup bodies
-    hip_dev_rx_attach(ctx->dev, it->second, (unsigned)slot);
-  });
-}
-int32_t dp_executor_detach(dp_ctx* ctx) {
-  return guard([&] { DP_REQUIRE(ctx, DP_ERR_ARG, "null ctx"); CtxLock lk(ctx); ctx->dev->sync(); hip_dev_rx_detach(ctx->dev); hip_dev_set_latency_mode(ctx->dev, true); });
-}
-int32_t dp_executor_stop(int32_t device_id) {
-  return guard([&] {
-    std::lock_guard<std::mutex> g(g_exec_mu);
-    auto it = executors().find(device_id);
-    if (it == executors().end() || !rx_engine_running(it->second)) return;
-    hip_rx_session(-1);
-    rx_engine_stop(it->second);
-    if (const char* sf = getenv("DP_RX_STATS")) { if (FILE* f = fopen(sf, "a")) { fprintf(f, "%s\n", rx_engine_stats(it->second).c_str()); fclose(f); } }
-  });
 }
 const char* dp_ctx_name(const dp_ctx* ctx) { return ctx ? ctx->dev->name() : ""; }
 
@@ -814,18 +774,12 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     // Cohorts (hip_dev.hip, struct Cohort): the proofs in flight are grouped into cohorts of DP_COHORT members (default: in flight / 22, rounded up)
     // that prove in lock step — launch number i of all members of a cohort is ONE kernel launch — on one stream and one
     // host thread per cohort. DP_COHORT=0: every proof on its own stream (the round-1 scheme).
-    // DP_RX=1: the resident executor (rx.h) instead of cohorts — every proof is a slot, its launches are step descriptors that two
-    // persistent kernels execute; nothing goes through the command processor while the batch runs
-    const char* rxe = getenv("DP_RX");
-    const bool use_rx = rxe && atoi(rxe) && nw > 1 && nw <= RX_MAX_SLOTS;
-    const double rx_stagger_ms = getenv("DP_RX_STAGGER_MS") ? atof(getenv("DP_RX_STAGGER_MS")) : 400.0;
-    const double co_stagger_ms = getenv("DP_COHORT_STAGGER_MS") ? atof(getenv("DP_COHORT_STAGGER_MS")) : 0.0;
     const char* ce = getenv("DP_COHORT");
     // Default: as many cohorts as hardware queues serve without time slicing (22 of the 24), each as small as that allows — a merged
     // launch ends with its slowest member, so small cohorts stall less (batch of 8: 121 ms with cohorts of 1, 165 ms with one cohort
     // of 8; batch of 64: 262 ms with cohorts of 3, 302 ms with 12; 256 in flight: cohorts of 12; profiles/r02_batch_cohort_sweep.txt)
     size_t csize = ce ? (size_t)std::max(0, atoi(ce)) : std::max<size_t>(1, (nw + 21) / 22);
-    size_t nco = (csize >= 1 && nw > 1 && !use_rx) ? (nw + csize - 1) / csize : 0;
+    size_t nco = (csize >= 1 && nw > 1) ? (nw + csize - 1) / csize : 0;
     while (m->cohorts.size() < nco) m->cohorts.push_back(hip_cohort_new());
     auto dev_of = [&](size_t wi) -> Dev& { return wi == 0 ? *m->ctx->dev : *m->workers[wi - 1]; };
     std::atomic<size_t> next(0);
@@ -833,34 +787,11 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     std::mutex err_mu; std::string err; int err_code = 0;
     for (size_t i = 0; i < nproofs; i++) { proof_words[i] = nullptr; proof_nwords[i] = 0; }
     for (size_t wi = 0; wi < nw && nco; wi++) hip_dev_cohort_attach(&dev_of(wi), m->cohorts[wi % nco]);
-    struct RxSession {  // started before the first proof, stopped (workers gone, caches written back) before anything else touches the GPU
-      dp_model* m; bool on = false;
-      ~RxSession() { if (on) { hip_rx_session(-1); try { rx_engine_stop(m->rx); } catch (...) {} } }
-    } rxs{m};
-    if (use_rx) {
-      if (!m->rx) m->rx = rx_engine_new(m->ctx->device_id);
-      rx_engine_start(m->rx, (unsigned)nw);
-      rxs.on = true; hip_rx_session(+1);
-      for (size_t wi = 0; wi < nw; wi++) hip_dev_rx_attach(&dev_of(wi), m->rx, (unsigned)wi);
-    }
     auto t0 = std::chrono::steady_clock::now();
     auto work = [&](size_t wi) {
       Dev& dev = dev_of(wi);
       try {
         dev.bind_thread();
-        // Resident executor: the proofs of a batch must not march in step — all proofs of an XCD would reach their wide steps together
-        // (a burst of 32 x 256 tiles in one FIFO) and sit in their one-workgroup tails together (every STREAM worker idle). The start
-        // of slot wi is delayed by wi / nw of DP_RX_STAGGER_MS (default 400: about half a proof in flight).
-        if (use_rx && rx_stagger_ms > 0 && wi > 0) {
-          const auto until = t0 + std::chrono::microseconds((long long)(1000.0 * rx_stagger_ms * (double)wi / (double)nw));
-          while (std::chrono::steady_clock::now() < until && next.load() < nproofs) { if (fiber_active()) fiber_yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100)); }
-        }
-        // Cohorts, DP_COHORT_STAGGER_MS (default 0: every cohort starts at once): cohort c of nco starts c / nco of that time late, so that
-        // the cohorts do not reach their hash-heavy and their one-wave stretches together (an experiment knob)
-        if (nco > 1 && co_stagger_ms > 0 && wi % nco > 0) {
-          const auto until = t0 + std::chrono::microseconds((long long)(1000.0 * co_stagger_ms * (double)(wi % nco) / (double)nco));
-          while (std::chrono::steady_clock::now() < until && next.load() < nproofs) { if (fiber_active()) fiber_yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100)); }
-        }
         for (;;) {
           size_t i = next.fetch_add(1);
           if (i >= nproofs) break;
@@ -885,7 +816,6 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
       catch (...) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_ARG; err = "unknown exception in a proof worker"; } next = nproofs; }
       // leaving the cohort releases the launches the other members have queued behind this one
       if (nco) { try { hip_dev_cohort_detach(&dev); } catch (const std::exception& e) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } next = nproofs; } }
-      if (use_rx) hip_dev_rx_detach(&dev);
     };
     // `nw` proofs in flight on `nth` host threads: every worker is a fiber; a thread switches to its next fiber whenever the
     // current one waits for the device (fiber.h). All members of a cohort live on one thread (the cohort has no locks);
@@ -908,13 +838,6 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     for (size_t ti = 1; ti < nth; ti++) th.emplace_back(run_thread, ti);
     run_thread(0);
     for (auto& t : th) t.join();
-    if (rxs.on) {
-      rxs.on = false; hip_rx_session(-1);
-      try { rx_engine_stop(m->rx); } catch (const std::exception& e) { if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } }
-      // DP_RX_STATS=<file>: the per-body accounting of this session (the executor's kernel trace), one JSON line per batch
-      if (const char* sf = getenv("DP_RX_STATS")) { if (FILE* f = fopen(sf, "a")) { fprintf(f, "%s\n", rx_engine_stats(m->rx).c_str()); fclose(f); } }
-      if (getenv("DP_RX_TRACE") && getenv("DP_RX_TRACE_FILE")) { if (FILE* f = fopen(getenv("DP_RX_TRACE_FILE"), "w")) { fputs(rx_engine_trace(m->rx).c_str(), f); fclose(f); } }
-    }
     for (size_t c = 0; c < nco; c++) { try { hip_cohort_drain(m->cohorts[c]); } catch (const std::exception& e) { if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } } }
     if (nco && getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) {
       size_t f = 0, p = 0; for (size_t c = 0; c < nco; c++) { size_t a, b; hip_cohort_stats(m->cohorts[c], &a, &b); f += a; p += b; }

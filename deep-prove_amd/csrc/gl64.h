@@ -55,10 +55,20 @@ DP_HD u64 gl_reduce128(u64 lo, u64 hi) {
   bool c2 = __builtin_add_overflow(r, GL_EPS, &t);
   return c2 ? t : r;                // r >= p  <=>  r + EPS carries
 }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DP_NO_GFX950_ASM)
+namespace gx { __device__ __forceinline__ u64 mul(u64 a, u64 b); }  // gl64_gfx950.h: 12 VALU instructions, any representative
+#endif
 DP_HD u64 gl_mul(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(DP_NO_GFX950_ASM)
+  const u64 r = gx::mul(a, b);
+  u64 t;
+  const bool c = __builtin_add_overflow(r, GL_EPS, &t);
+  return c ? t : r;  // canonical
+#else
   u64 lo, hi;
   mul64wide(a, b, lo, hi);
   return gl_reduce128(lo, hi);
+#endif
 }
 DP_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 DP_HD u64 gl_mul7(u64 a) {  // 7a = 8a - a with the top three bits folded: (a>>61)*2^64 = (a>>61)*EPS
@@ -129,3 +139,4 @@ DP_HD size_t dp_reverse_bits(size_t x, unsigned bits) {
   return r;
 }
 }  // namespace dp
+#include "gl64_gfx950.h"

@@ -48,6 +48,11 @@ DP_HD u64 a3_reduce(const A3& a) {
 }
 // extension product, any-representative result
 DP_HD Ext ex_mul(Ext a, Ext b) {
+#ifdef DP_GFX950_ASM
+  // c0 = a0 b0 + 7 a1 b1, c1 = a0 b1 + a1 b0 with the 12 / 13-instruction multiply and multiply-add of gl64_gfx950.h: 57 VALU instructions
+  const u64 t7 = gx::mul_small(gx::mul(a.c1, b.c1), 7);
+  return ex(gx::fma(a.c0, b.c0, t7), gx::fma(a.c0, b.c1, gx::mul(a.c1, b.c0)));
+#endif
   A3 c0 = a3_zero(), c1 = a3_zero();
   a3_add_prod(c0, a.c0, b.c0); a3_add_prod7(c0, a.c1, b.c1);
   a3_add_prod(c1, a.c0, b.c1); a3_add_prod(c1, a.c1, b.c0);
@@ -55,6 +60,10 @@ DP_HD Ext ex_mul(Ext a, Ext b) {
 }
 // e + r * d  (the fold e0 + r (e1 - e0) with d = e1 - e0 computed by the caller), any-representative result
 DP_HD Ext ex_fma(Ext r, Ext d, Ext e) {
+#ifdef DP_GFX950_ASM
+  const u64 r7 = gx::mul_small(r.c1, 7);  // (loop invariant where r is the round's challenge: the compiler hoists it)
+  return ex(gx::fma(r.c0, d.c0, gx::fma(r7, d.c1, e.c0)), gx::fma(r.c0, d.c1, gx::fma(r.c1, d.c0, e.c1)));
+#endif
   A3 c0 = a3_of(e.c0), c1 = a3_of(e.c1);
   a3_add_prod(c0, r.c0, d.c0); a3_add_prod7(c0, r.c1, d.c1);
   a3_add_prod(c1, r.c0, d.c1); a3_add_prod(c1, r.c1, d.c0);
@@ -62,6 +71,9 @@ DP_HD Ext ex_fma(Ext r, Ext d, Ext e) {
 }
 // a + r * d with base-field a, d (first fold of a base table), any-representative result
 DP_HD Ext ex_fma_base(Ext r, u64 d, u64 a) {
+#ifdef DP_GFX950_ASM
+  return ex(gx::fma(r.c0, d, a), gx::mul(r.c1, d));
+#endif
   unsigned __int128 p0 = (unsigned __int128)r.c0 * d + a, p1 = (unsigned __int128)r.c1 * d;  // r.c0 d + a < 2^128: no overflow
   return ex(p2f::red128((u64)p0, (u64)(p0 >> 64)), p2f::red128((u64)p1, (u64)(p1 >> 64)));
 }

@@ -18,8 +18,6 @@
 #include "deleg_tail.h"
 #include "commit_tail.h"
 #include "sponge_host.h"
-#include "rx.h"
-#include "rx_bodies.h"
 #include <hip/hip_runtime.h>
 #include <sched.h>
 #include <cstdio>
@@ -40,13 +38,6 @@ namespace dp {
 
 #include "kernels.inc"
 
-// ---- the resident executor's view of a body: its index in RX_BODY_LIST (rx_bodies.h; rx.hip switches on the same order) and its class
-template <auto Body> struct RxId { static constexpr int value = -1, klass = -1; };
-enum { RXH_ID_BASE = __COUNTER__ + 1 };
-#define X(c, ...) template <> struct RxId<&__VA_ARGS__> { static constexpr int value = __COUNTER__ - RXH_ID_BASE, klass = (c); };
-RX_BODY_LIST(X)
-#undef X
-static std::atomic<int> g_rx_sessions{0};  // > 0 while a resident executor runs: grid-stride launches use smaller virtual grids
 
 // ================================================================================================ HipDev
 // Grid size for grid-stride kernels. DP_MAX_GRID bounds every launch so that, with several proofs in flight on one GPU,
@@ -56,9 +47,6 @@ static int g_max_grid = [] { const char* e = getenv("DP_MAX_GRID"); return e ? a
 static inline int grid_for(size_t n, int cap = 2048) {
   size_t b = (n + TPB - 1) / TPB;
   if (b < 1) b = 1;
-  // behind the resident executor a proof's tiles run on the workers of ONE XCD (32 CUs): 256 tiles keep them busy, more only costs queue traffic
-  static const int rx_cap = [] { const char* e = getenv("DP_RX_GRID_CAP"); return e ? std::max(2, atoi(e)) : 8; }();  // (measured, Dense-4M, 256 in flight: 128 -> 166, 64 -> 197, 32 -> 322, 16 -> 358, 8 -> 371, 4 -> 349 proofs/s: profiles/r03_rx_*)
-  if (g_rx_sessions.load(std::memory_order_relaxed) > 0) cap = std::min(cap, rx_cap);
   return (int)std::min<size_t>(std::min<size_t>(b, cap), (size_t)g_max_grid);
 }
 
@@ -68,22 +56,26 @@ struct ProfRec { const char* name; double bytes; hipEvent_t a, b; };
 #define DPL_B(kern, maxt, flags, grid, block, lds, ...) do { prof_begin(#kern); LaunchTimer lt_(this); launch_<kern, maxt, flags>(KArgs<decltype(&kern)>(), #kern, grid, block, lds, __VA_ARGS__); lt_.stop(); prof_end(); } while (0)
 #define DPL(kern, grid, block, ...) DPL_B(kern, 1024, KF_NONE, grid, block, 0, __VA_ARGS__)
 #define DPL_LDS(kern, grid, block, lds, ...) DPL_B(kern, 1024, KF_NONE, grid, block, lds, __VA_ARGS__)
+// The throughput-mode form of a one-workgroup body runs at most SHARED_MAXT threads and is COMPILED for that: __launch_bounds__(256) leaves the
+// register allocator 512 VGPRs per lane instead of the 128 of a 1024-thread workgroup — under __launch_bounds__(1024) k_logup_tail spilled 54 VGPRs and
+// k_sc_persist 75 into scratch, on the dependent chain that bounds every tail (round-3 review; profiles/r04_kernel_resources_gfx950.csv).
+constexpr int SHARED_MAXT = 256;
 // one-workgroup-per-proof kernels (persistent sumchecks, fused protocol tails, Merkle tails): `threads` and the CU reservation
 // apply in latency mode; in throughput mode the workgroup shrinks to shared_threads_ and reserves nothing (KF_PRIO above).
 // `lds` = dynamic LDS the body really needs.
-#define DPL_ONE(kern, grid, threads, lds, ...) do { if (shared_now()) { DPL_B(kern, 1024, KF_PRIO, grid, dim3(std::min<unsigned>((unsigned)(threads), (unsigned)shared_threads_)), (size_t)(lds), __VA_ARGS__); } \
+#define DPL_ONE(kern, grid, threads, lds, ...) do { if (shared_now()) { DPL_B(kern, SHARED_MAXT, KF_PRIO, grid, dim3(std::min<unsigned>((unsigned)(threads), (unsigned)shared_threads_)), (size_t)(lds), __VA_ARGS__); } \
                                                      else { DPL_B(kern, 1024, KF_CLAIM, grid, dim3(threads), std::max<size_t>((size_t)(lds), excl_now()), __VA_ARGS__); } } while (0)
 #define DPL_ONE_HI(kern, hi, grid, threads, lds, ...) do { if (hi) { DPL_ONE((kern<true>), grid, threads, lds, __VA_ARGS__); } else { DPL_ONE((kern<false>), grid, threads, lds, __VA_ARGS__); } } while (0)
 #define DPL_HI(kern, hi, grid, block, ...) do { if (hi) { DPL((kern<true>), grid, block, __VA_ARGS__); } else { DPL((kern<false>), grid, block, __VA_ARGS__); } } while (0)
 #define DPL_LDS_HI(kern, hi, grid, block, lds, ...) do { if (hi) { DPL_LDS((kern<true>), grid, block, lds, __VA_ARGS__); } else { DPL_LDS((kern<false>), grid, block, lds, __VA_ARGS__); } } while (0)
 #define DP_SET_LDS(kern, maxt, bytes) set_lds_<kern, maxt, KF_NONE>(KArgs<decltype(&kern)>(), (int)(bytes))
-#define DP_SET_LDS_ONE(kern, maxt, bytes) do { set_lds_<kern, maxt, KF_CLAIM>(KArgs<decltype(&kern)>(), (int)(bytes)); set_lds_<kern, maxt, KF_PRIO>(KArgs<decltype(&kern)>(), (int)(bytes)); } while (0)
+#define DP_SET_LDS_ONE(kern, maxt, bytes) do { set_lds_<kern, maxt, KF_CLAIM>(KArgs<decltype(&kern)>(), (int)(bytes)); set_lds_<kern, SHARED_MAXT, KF_PRIO>(KArgs<decltype(&kern)>(), (int)(bytes)); } while (0)
 
 static const bool g_host_stats = getenv("DP_TIMING") && atoi(getenv("DP_TIMING"));
 // DP_WAIT_YIELD=1: a host thread that waits for the device outside a fiber gives its CPU away (sched_yield) instead of spinning — for
 // seam-level hosts that run more proving threads than they have cores (tests/support/seam_bench.c)
 static const bool g_wait_yield = getenv("DP_WAIT_YIELD") && atoi(getenv("DP_WAIT_YIELD"));
-static inline void dp_spin_pause() { if (g_wait_yield) sched_yield(); else dp_spin_pause(); }
+static inline void dp_spin_pause() { if (g_wait_yield) sched_yield(); else __builtin_ia32_pause(); }
 
 // ------------------------------------------------------------------------------------------------ cohorts
 // A cohort is a set of proofs of the SAME model proved in lock step on one stream by one host thread (each proof a fiber,
@@ -251,8 +243,7 @@ class HipDev : public Dev {
 
   hipStream_t s_ = nullptr;
   Cohort* co_ = nullptr;  // non-null while this context proves as a member of a cohort: launches go to the cohort's stream
-  RxEngine* rx_ = nullptr; unsigned rx_slot_ = 0;  // non-null while this context proves as a slot of the resident executor (rx.h)
-  bool queued_() const { return co_ != nullptr || rx_ != nullptr; }  // launches are packs handed to someone else: data moves with kernels, never with stream commands
+  bool queued_() const { return co_ != nullptr; }  // launches are packs handed to someone else: data moves with kernels, never with stream commands
   size_t co_li_ = 0;      // number of launches this member has issued into the cohort's common sequence
   template <auto Body, int MAXT, int FLAGS, class... A>
   static void fire_(const Cohort::Pending& p, hipStream_t s) {
@@ -262,17 +253,11 @@ class HipDev : public Dev {
   void launch_(KArgs<void (*)(A...)>, const char* name, dim3 g, dim3 b, size_t lds, P... args) {
     static_assert(sizeof...(A) == sizeof...(P), "kernel argument count");
     if (g_host_stats) { if (!first_launch_) first_launch_ = name; last_launch_ = name; by_name_[name]++; }
-    if (!co_ && !rx_) { hipLaunchKernelGGL((kg<Body, MAXT, FLAGS, std::decay_t<A>...>), g, b, lds, s_, static_cast<std::decay_t<A>>(args)...); return; }
+    if (!co_) { hipLaunchKernelGGL((kg<Body, MAXT, FLAGS, std::decay_t<A>...>), g, b, lds, s_, static_cast<std::decay_t<A>>(args)...); return; }
     DP_REQUIRE(g.z == 1, DP_ERR_SHAPE, "cohort launches use blockIdx.z for the proof");
     using Pack = ArgPack<std::decay_t<A>...>;
     static_assert(std::is_trivially_copyable<Pack>::value && std::is_trivially_destructible<Pack>::value, "argument packs travel as bytes");
     Pack pk(static_cast<std::decay_t<A>>(args)...);
-    if (rx_) {  // a step of this proof's chain on the resident executor (rx.h): no launch, a descriptor in the slot's ring
-      constexpr int id = RxId<Body>::value;
-      DP_REQUIRE(id >= 0, DP_ERR_SHAPE, std::string("kernel ") + name + " is not available in the resident executor (csrc/rx_bodies.h)");
-      rx_submit(rx_, rx_slot_, id, RxId<Body>::klass, FLAGS, g.x, g.y, lds, &pk, sizeof(Pack), name);
-      return;
-    }
     co_->submit(co_li_++, &fire_<Body, MAXT, FLAGS, A...>, name, g, b, lds, &pk, sizeof(Pack));
   }
   template <auto Body, int MAXT, int FLAGS, class... A>
@@ -301,9 +286,9 @@ class HipDev : public Dev {
   int tail_many_threads_ = [] { const char* e = getenv("DP_TAIL_MANY_THREADS"); int v = e ? atoi(e) : 1024; return (v == 256 || v == 512) ? v : 1024; }();
   size_t excl_now() const { return (co_ && !cohort_excl_) ? 0 : excl_; }
   // throughput mode (several proofs in flight): one-workgroup kernels reserve nothing and run as 256-thread workgroups with
-  // raised wave priority (KF_PRIO). DP_SHARED_TAILS=0 restores the whole-CU workgroups of round 1, DP_SHARED_THREADS = 64..1024.
+  // raised wave priority (KF_PRIO). DP_SHARED_TAILS=0 restores the whole-CU workgroups of round 1, DP_SHARED_THREADS = 64 / 128 / 256.
   bool shared_tails_ = !(getenv("DP_SHARED_TAILS") && !atoi(getenv("DP_SHARED_TAILS")));
-  int shared_threads_ = [] { const char* e = getenv("DP_SHARED_THREADS"); int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) ? v : 256; }();
+  int shared_threads_ = [] { const char* e = getenv("DP_SHARED_THREADS"); int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 256) ? v : 256; }();  // <= SHARED_MAXT
   bool throughput_mode_ = false;
   bool shared_now() const { return throughput_mode_ && shared_tails_; }
   //   DP_COHORT_PERSIST_THREADS=n  workgroup size of the one-workgroup sumcheck kernels of cohort members (256 / 512 / 1024;
@@ -348,7 +333,7 @@ class HipDev : public Dev {
       const bool fib = fiber_active();
       if (fib) { nyield_++; fiber_yield(); } else dp_spin_pause();
       if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
-        throw DpError(DP_ERR_HIP, std::string("timeout waiting for the device") + (rx_ ? "\n" + rx_engine_dump(rx_, rx_slot_) : std::string()));
+        throw DpError(DP_ERR_HIP, std::string("timeout waiting for the device"));
     }
     desc_off_ = 0; stage_off_ = 0;
     if (co_ && co_li_) co_->note_executed(co_li_ - 1);
@@ -411,7 +396,7 @@ class HipDev : public Dev {
       const bool fib = fiber_active();
       if (fib) { nyield_++; fiber_yield(); } else dp_spin_pause();
       if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
-        throw DpError(DP_ERR_HIP, std::string("timeout waiting for the device") + (rx_ ? "\n" + rx_engine_dump(rx_, rx_slot_) : std::string()));
+        throw DpError(DP_ERR_HIP, std::string("timeout waiting for the device"));
     }
   }
   // wait_flag for a message made of blocks whose checksum runs over block-relative word indices (k_logup_tail)
@@ -433,7 +418,7 @@ class HipDev : public Dev {
       const bool fib = fiber_active();
       if (fib) { nyield_++; fiber_yield(); } else dp_spin_pause();
       if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
-        throw DpError(DP_ERR_HIP, std::string("timeout waiting for the device") + (rx_ ? "\n" + rx_engine_dump(rx_, rx_slot_) : std::string()));
+        throw DpError(DP_ERR_HIP, std::string("timeout waiting for the device"));
     }
   }
   // descriptors for batched kernels: written by the host into the mapped ring and read by the kernel directly (no
@@ -478,7 +463,7 @@ class HipDev : public Dev {
     wait_flag(seq, nwords);
   }
   void reduce_publish(const Ext* partial, size_t nblocks, size_t inner, int nout) {
-    DP_REQUIRE(nout >= 1 && nout <= (rx_ ? 512 : 1024) && (size_t)nout * 2 <= RES_WORDS, DP_ERR_SHAPE, "reduce_publish: too many outputs");
+    DP_REQUIRE(nout >= 1 && nout <= 1024 && (size_t)nout * 2 <= RES_WORDS, DP_ERR_SHAPE, "reduce_publish: too many outputs");
     if (share_x_) {  // the reduction lands in device memory (the tag word too: nobody reads it), the exchange brings the ranks' total to hres_
       int threads = nout >= 8 ? 1024 : nout >= 4 ? 256 : 64 * nout;
       DPL(k_reduce_publish, dim3(1), dim3(threads), partial, nblocks, inner, nout, (Ext*)dshare_, (unsigned long long*)(dshare_ + RES_WORDS), 0ull);
@@ -592,7 +577,6 @@ class HipDev : public Dev {
     pcs_tabs_.reset();
     if (arena_) hipFree(arena_);
     if (dres_) hipFree(dres_);
-    for (auto& kv : ppool_) hipFree(kv.second);
     if (dshare_) hipFree(dshare_);
     if (dgather_) hipFree(dgather_);
     if (fused_ticket_) hipFree(fused_ticket_);
@@ -696,29 +680,15 @@ class HipDev : public Dev {
   DBuf alloc(size_t n, bool ext) override { DBuf b; b.n = n; b.ext = ext; b.p = arena_alloc(std::max<size_t>(n, 1) * (ext ? 16 : 8)); return b; }
   size_t mark() override { return arena_off_; }
   void release(size_t m) override { arena_off_ = m; }
-  // Persistent buffers of a context that is a slot of the resident executor are RECYCLED, never handed back while it runs: hipFree
-  // waits for every stream of the device, and the executor's two kernels never end — a seam-level caller that frees a table
-  // (dp_buf_free, dp_pcs_commit_free) would wait for dp_executor_stop. The blocks go back to the device when the context is destroyed.
-  std::multimap<size_t, void*> ppool_; std::map<void*, size_t> psize_;
   DBuf alloc_persistent(size_t n, bool ext) override {
     DBuf b; b.n = n; b.ext = ext;
     const size_t bytes = (std::max<size_t>(n, 1) * (ext ? 16 : 8) + 255) & ~size_t(255);
-    auto it = ppool_.find(bytes);
-    if (it != ppool_.end()) { b.p = it->second; ppool_.erase(it); return b; }
     HIP_CHECK(hipSetDevice(device_));
     HIP_CHECK(hipMalloc(&b.p, bytes));
-    if (rx_) psize_[b.p] = bytes;
     return b;
   }
   void free_persistent(DBuf& b) override {
     if (!b.p) return;
-    if (rx_) {  // (blocks allocated before the context was attached are not in psize_: their size is what the handle says, rounded as above)
-      auto it = psize_.find(b.p);
-      const size_t bytes = it != psize_.end() ? it->second : ((std::max<size_t>(b.n, 1) * (b.ext ? 16 : 8) + 255) & ~size_t(255));
-      psize_[b.p] = bytes;
-      ppool_.emplace(bytes, b.p); b.p = nullptr; return;
-    }
-    psize_.erase(b.p);
     hipStreamSynchronize(s_); hipFree(b.p); b.p = nullptr;
   }
   // host <-> device copies go through the pinned staging buffer: hipMemcpyAsync on pageable memory pins the user pages
@@ -779,7 +749,7 @@ class HipDev : public Dev {
             const bool fib = fiber_active();
             if (fib) { nyield_++; fiber_yield(); } else dp_spin_pause();
             if ((++spins & (fib ? 0x3FFu : 0xFFFFu)) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
-              throw DpError(DP_ERR_HIP, std::string("timeout waiting for a download") + (rx_ ? "\n" + rx_engine_dump(rx_, rx_slot_) : std::string()));
+              throw DpError(DP_ERR_HIP, std::string("timeout waiting for a download"));
           }
         }
         // every chunk has landed: the copy — and everything queued before it — has run
@@ -824,13 +794,6 @@ class HipDev : public Dev {
   }
   void cohort_detach() { if (co_) { Cohort* c = co_; co_ = nullptr; c->leave(co_li_); } }
   bool in_cohort() const { return co_ != nullptr; }
-  // ---- slot of the resident executor (dp_model_prove_batch with DP_RX): while attached every launch is a step descriptor
-  void rx_attach(RxEngine* e, unsigned slot) {
-    DP_REQUIRE(!co_ && !rx_ && !prof_ && zerocopy_, DP_ERR_ARG, "resident-executor slots need the zero-copy publish path and no per-kernel profiling");
-    HIP_CHECK(hipStreamSynchronize(s_));
-    rx_ = e; rx_slot_ = slot;
-  }
-  void rx_detach() { rx_ = nullptr; }
   void sync() override { stream_wait(); }
 
   // ---- MLE
@@ -939,7 +902,7 @@ class HipDev : public Dev {
   }
   static constexpr size_t SC_LDS_MAX = 128 * 1024;  // dynamic LDS the LDS-resident sumcheck kernel may use
   // (a resident worker of class BIG has 64 KB for the kernel's frame and its tables: larger sumchecks take the global-memory kernel)
-  size_t sc_lds_max() const { return rx_ ? RX_LDS_BIG - 8192 : SC_LDS_MAX; }
+  size_t sc_lds_max() const { return SC_LDS_MAX; }
   // Latency-critical one-workgroup kernels ask for more than half of a CU's 160 KB of LDS even when they need none: two
   // such workgroups can then never share a CU. The workgroup dispatcher otherwise packs the small persistent kernels of
   // all proofs in flight onto the same first CUs (4 kernels of 256 threads fit on one), where they time-share the SIMDs.
@@ -1711,7 +1674,7 @@ class HipDev : public Dev {
       bool small = (size_t(1) << nv) == e0.n && nv >= 1 && (nv <= 7 || (tw_ && nv <= L_ && nv <= (e0.ext ? 10u : 11u)));
       // (the medium path's kernels keep a whole polynomial in up to 128 KB of LDS: not for a resident worker — behind the executor these
       // sizes take the LDS-tiled passes of the large path, whose extra launches cost nothing there)
-      bool medium = !rx_ && !small && !e0.ext && (size_t(1) << nv) == e0.n && tw_ && nv <= L_ && nv >= 12 && nv <= 14;
+      bool medium = !small && !e0.ext && (size_t(1) << nv) == e0.n && tw_ && nv <= L_ && nv >= 12 && nv <= 14;
       if (medium) { commit_medium_group(evals, i, out, done, persistent); continue; }
       if (!small) { out[i] = commit(e0, persistent); done[i] = true; continue; }
       std::vector<size_t> grp;
@@ -1823,8 +1786,8 @@ class HipDev : public Dev {
         const bool folds = r && hd[i].n > 1;
         size_t items = folds ? hd[i].n / 4 : hd[i].n / 2;  // loop iterations of the pair: 4 (2) entries of each table per iteration
         // (behind the resident executor a tile costs ~20 us of queue protocol whatever it does: 32 iterations per thread instead of 4)
-        const size_t per_blk = rx_ ? (size_t)TPB * 32 : (size_t)TPB * 4;
-        size_t nb = std::min<size_t>(std::max<size_t>((items + per_blk - 1) / per_blk, 1), rx_ ? (size_t)64 : (size_t)std::min(1024, g_max_grid));
+        const size_t per_blk = (size_t)TPB * 4;
+        size_t nb = std::min<size_t>(std::max<size_t>((items + per_blk - 1) / per_blk, 1), (size_t)std::min(1024, g_max_grid));
         first[i] = nblk; nblk += (unsigned)nb;
         bytes += hd[i].n * (hd[i].fext ? 16.0 : 8.0) + (folds ? hd[i].n * 8.0 : 0.0) + (fac[i].ln ? 0.0 : hd[i].n * 16.0 + (folds ? hd[i].n * 8.0 : 0.0));
       }
@@ -1832,7 +1795,7 @@ class HipDev : public Dev {
       Ext* partial = (Ext*)arena_alloc((size_t)nblk * 2 * 16);
       unsigned long long seq = ++seq_;
       nb_ = bytes; DPL(k_classic_fused, dim3(nblk), dim3(TPB), fd, cdd, np, r ? *r : ex_zero(), r ? 1 : 0, partial);
-      DP_REQUIRE(2 * np <= (rx_ ? 512 : 1024), DP_ERR_SHAPE, "classic round: too many polynomials for one reduction");
+      DP_REQUIRE(2 * np <= 1024, DP_ERR_SHAPE, "classic round: too many polynomials for one reduction");
       nb_ = 0; DPL(k_classic_reduce, dim3(1), dim3(np >= 8 && !throughput_mode_ ? 1024 : 256), fd, np, (const Ext*)partial, (Ext*)hres_dev_, hflag_dev_, seq);
       wait_flag(seq, (size_t)np * 4);
       for (int i = 0; i < 2 * np; i++) out[i] = ex(hres_[2 * i], hres_[2 * i + 1]);
@@ -1933,9 +1896,6 @@ void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs) {
 }
 void hip_dev_cohort_attach(Dev* d, Cohort* c) { static_cast<HipDev*>(d)->cohort_attach(c); }
 void hip_dev_cohort_detach(Dev* d) { static_cast<HipDev*>(d)->cohort_detach(); }
-void hip_dev_rx_attach(Dev* d, RxEngine* e, unsigned slot) { static_cast<HipDev*>(d)->rx_attach(e, slot); }
-void hip_dev_rx_detach(Dev* d) { static_cast<HipDev*>(d)->rx_detach(); }
-void hip_rx_session(int delta) { g_rx_sessions.fetch_add(delta); }
 void hip_dev_dump_sc_debug(Dev* d) { static_cast<HipDev*>(d)->dump_sc_debug(); }
 size_t hip_dev_arena_peak(Dev* d) { return static_cast<HipDev*>(d)->arena_peak(); }
 double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps) { return static_cast<HipDev*>(d)->probe_compress_rate(nodes, reps); }
@@ -1948,6 +1908,13 @@ void hip_dev_dump_host_stats(Dev* d) { static_cast<HipDev*>(d)->dump_host_stats(
 // DIAGNOSTIC BUILD ONLY (DP_WG_TIMES): per merged launch of k_logup_tail, the spread between its members
 void hip_dump_wg_times() {
 #ifdef DP_WG_TIMES
+  {
+    unsigned long long sp = 0, np = 0, mt = 0, zero = 0;
+    hipMemcpyFromSymbol(&sp, HIP_SYMBOL(g_sponge_ticks), 8); hipMemcpyFromSymbol(&np, HIP_SYMBOL(g_sponge_perms), 8); hipMemcpyFromSymbol(&mt, HIP_SYMBOL(g_member_ticks), 8);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_sponge_ticks), &zero, 8); hipMemcpyToSymbol(HIP_SYMBOL(g_sponge_perms), &zero, 8); hipMemcpyToSymbol(HIP_SYMBOL(g_member_ticks), &zero, 8);
+    if (np) fprintf(stderr, "[dp wg-times] k_logup_tail members: %.1f %% of entry -> exit inside the sponge permutation (%llu permutations, %.2f us each); the rest (table work, barriers, round arithmetic) %.0f us per 100 permutations\n",
+                    100.0 * (double)sp / (double)mt, np, (double)sp / 100.0 / (double)np, (double)(mt - sp) / 100.0 / (double)np * 100.0);
+  }
   unsigned n = 0; if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wgt_n), sizeof(n)) != hipSuccess) return;
   n = std::min(n, 65536u);
   std::vector<unsigned long long> w(4 * (size_t)n);

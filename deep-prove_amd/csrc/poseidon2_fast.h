@@ -8,6 +8,7 @@
 //  * hl * (2^32 - 1) is formed from 32-bit halves: the compiler otherwise emits a fifth v_mad_u64_u32 (quarter rate).
 #pragma once
 #include "gl64.h"
+#include "gl64_gfx950.h"
 
 namespace dp {
 namespace p2f {
@@ -44,8 +45,26 @@ DP_HD u64 red128(u64 lo, u64 hi) {
   return r + (c ? GL_EPS : 0);                                  // wrapped r < t1 <= 2^64 - 2^33 + 1: no second carry
 }
 DP_HD u64 mul(u64 a, u64 b) {
+#ifdef DP_GFX950_ASM
+  return gx::mul(a, b);  // 12 VALU instructions instead of the compiler's 23 (gl64_gfx950.h)
+#else
   unsigned __int128 x = (unsigned __int128)a * b;
   return red128((u64)x, (u64)(x >> 64));
+#endif
+}
+// a * b + sum (sum an exact integer of 64 + 32 bits), any representative: the internal layer's d_i x_i + sum
+DP_HD u64 mul_add_w(u64 a, u64 b, u64 sum_reduced, W sum) {
+#ifdef DP_GFX950_ASM
+  (void)sum;
+  return gx::fma(a, b, sum_reduced);
+#else
+  (void)sum_reduced;
+  unsigned __int128 x = (unsigned __int128)a * b;  // < 2^64 * p: the high word stays below p after + sum
+  u64 lo, hi = (u64)(x >> 64);
+  bool c = __builtin_add_overflow((u64)x, sum.lo, &lo);
+  hi += (u64)sum.hi + (c ? 1u : 0u);
+  return red128(lo, hi);
+#endif
 }
 DP_HD u64 sbox(u64 x) {
   u64 x2 = mul(x, x), x3 = mul(x2, x), x4 = mul(x2, x2);
@@ -95,14 +114,13 @@ DP_HD void permute(u64* s, const u64* rc) {
     W sum = w_of(s[0]);
 #pragma unroll
     for (int i = 1; i < 8; i++) sum = w_add64(sum, s[i]);
+#ifdef DP_GFX950_ASM
+    const u64 sr = w_reduce(sum);  // one reduction of the row sum per round, then eight 13-instruction multiply-adds
+#else
+    const u64 sr = 0;
+#endif
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      unsigned __int128 x = (unsigned __int128)s[i] * rc[86 + i];  // < 2^64 * p: the high word stays below p after + sum
-      u64 lo, hi = (u64)(x >> 64);
-      bool c = __builtin_add_overflow((u64)x, sum.lo, &lo);
-      hi += (u64)sum.hi + (c ? 1u : 0u);
-      s[i] = red128(lo, hi);
-    }
+    for (int i = 0; i < 8; i++) s[i] = mul_add_w(s[i], rc[86 + i], sr, sum);
   }
 #pragma unroll
   for (int i = 0; i < 8; i++) w[i] = w_of(s[i]);

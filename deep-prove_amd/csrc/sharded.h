@@ -107,6 +107,14 @@ inline SumcheckOut sumcheck_prove_sharded(Dev& dev, Exchange& xch, unsigned nv, 
   Dev::ShareExchange* sx = xch.device();
   bool dev_shares = sx && dev.sc_set_share_exchange(sx);
   struct Unset { Dev& d; bool& on; ~Unset() { if (on) d.sc_set_share_exchange(nullptr); } } unset{dev, dev_shares};
+  // the ranks must AGREE on where the shares travel (device exchange = barrier-less ncclAllGather inside sc_round, host exchange = all_gather
+  // here): a rank that decides differently (DP_SHARDED_HOST_EXCHANGE set on one rank only, a device that refuses) would deadlock the others
+  if (W > 1) {
+    u64 mine = dev_shares ? 1 : 0; std::vector<u64> all((size_t)W, 0);
+    xch.all_gather(&mine, 1, all.data());
+    bool every = true; for (u64 v : all) every = every && v == 1;
+    if (!every && dev_shares) { dev.sc_set_share_exchange(nullptr); dev_shares = false; }
+  }
   auto one_round = [&](bool first, bool local) {
     dev.sc_round(tabs.data(), (int)tabs.size(), first ? nullptr : &ch, vp.terms.data(), (int)vp.terms.size(), raw.data());
     if (local && !dev_shares) gather_sum(); else total = raw;  // (device shares: sc_round already returned the sum over the ranks)

@@ -2330,6 +2330,10 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       Ext calc = ex_zero();
       for (size_t k = 0; k < 2 + nrc; k++) calc = ex_add(calc, ex_mul(ex_mul(q.acc_evals[k], k < 2 ? eq_sqrt : eq_range), rlc[k]));
       DP_REQUIRE(ex_eq(calc, acc.expected_evaluation), DP_ERR_VERIFY, "layernorm: accumulation claim mismatch");
+      // STRICTER THAN THE REFERENCE (layernorm.rs:1341-1480 has the same gap): the evaluations the two sumchecks reason about (acc_evals) must be
+      // the ones opened against the witness commitments at acc.point (evaluations) — otherwise the inverse-square-root input and the range
+      // chunks the protocol constrains are not bound to the committed columns. Honest proofs set them equal; the transcript is unchanged.
+      for (size_t k = 0; k < 2 + nrc; k++) if (k != 1) DP_REQUIRE(ex_eq(q.acc_evals[k], q.evaluations[k]), DP_ERR_VERIFY, "layernorm: accumulation evaluation not bound to its commitment");
       const Ext c1 = t.get_and_append_challenge("batching"), c2 = t.get_and_append_challenge("batching");
       const Ext first = ex_mul(ex_sub(ex_one(), c1), ex_sub(ex_one(), c2)), second = ex_mul(c1, ex_sub(ex_one(), c2)), third = ex_mul(ex_sub(ex_one(), c1), c2);
       // the inverse-square-root input, shifted back up, plus the range-checked chunks (the top one divided by its scalar)

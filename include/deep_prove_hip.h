@@ -51,17 +51,6 @@ const char* dp_ctx_name(const dp_ctx* ctx);
  * modes. Call it while no operation of the context is in flight. */
 int32_t dp_ctx_set_throughput_mode(dp_ctx* ctx, int32_t on);
 
-/* ---- resident executor for seam-level callers (csrc/rx.h). Between dp_executor_start and dp_executor_stop two persistent kernels
- * serve the device; a context attached to slot i (one context per slot, 0 <= i < nslots) runs in throughput mode and every kernel its
- * entry points would launch becomes a step descriptor of its slot: T host threads calling dp_sumcheck_prove / dp_logup_prove /
- * dp_pcs_commit / dp_pcs_batch_open on T attached contexts proceed independently — no command processor, no lock step between them
- * (what dp_model_prove_batch does internally with DP_RX=1). Results are bit-identical to the unattached calls. Detach before
- * destroying a context; stop waits for the workers to leave. Host-only entry points (verify, transcript) are unaffected. */
-int32_t dp_executor_start(int32_t device_id, int32_t nslots);
-int32_t dp_executor_attach(dp_ctx* ctx, int32_t slot);
-int32_t dp_executor_detach(dp_ctx* ctx);
-int32_t dp_executor_stop(int32_t device_id);
-
 /* ---- measurement: per-kernel HIP-event timing on the ctx's launch stream (used by bench.py for the roofline object).
  * dp_profile_report returns a malloc'ed JSON array [{"kernel","launches","total_ms","alg_bytes"}...]; free with dp_free. */
 int32_t dp_profile_enable(dp_ctx* ctx, int32_t on);

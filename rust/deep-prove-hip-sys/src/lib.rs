@@ -29,10 +29,6 @@ extern "C" {
     pub fn dp_ctx_destroy(ctx: *mut dp_ctx) -> i32;
     pub fn dp_ctx_name(ctx: *const dp_ctx) -> *const c_char;
     pub fn dp_ctx_set_throughput_mode(ctx: *mut dp_ctx, on: i32) -> i32;
-    pub fn dp_executor_start(device_id: i32, nslots: i32) -> i32;
-    pub fn dp_executor_attach(ctx: *mut dp_ctx, slot: i32) -> i32;
-    pub fn dp_executor_detach(ctx: *mut dp_ctx) -> i32;
-    pub fn dp_executor_stop(device_id: i32) -> i32;
     pub fn dp_profile_enable(ctx: *mut dp_ctx, on: i32) -> i32;
     pub fn dp_profile_report(ctx: *mut dp_ctx, json: *mut *mut c_char) -> i32;
     pub fn dp_probe_compress_rate(ctx: *mut dp_ctx, nodes: usize, reps: i32, per_second: *mut f64) -> i32;

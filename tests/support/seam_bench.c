@@ -108,7 +108,6 @@ static void* run(void* arg) {
   fill(w->point20, 40, &seed); fill(w->point12, 24, &seed); fill(w->point15, 30, &seed); fill(w->point10, 20, &seed);
   pthread_barrier_wait(&g_start);  /* every context exists (the library's code objects are loaded, PCS::setup has run) ... */
   pthread_barrier_wait(&g_start);  /* ... and main has started the executor */
-  if (w->use_executor == 1) CHECK(dp_executor_attach(w->ctx, w->id));
   if (w->use_executor == 2) CHECK(dp_ctx_set_throughput_mode(w->ctx, 1));  /* plain contexts, fused device-side Fiat-Shamir kernels */
   one_proof(w);  /* warm-up */
   pthread_barrier_wait(&g_start);
@@ -116,26 +115,23 @@ static void* run(void* arg) {
   for (int i = 0; i < w->proofs; i++) one_proof(w);
   w->seconds = now_s() - t0;
   pthread_barrier_wait(&g_start);
-  if (w->use_executor == 1) CHECK(dp_executor_detach(w->ctx));
   return NULL;
 }
 
 int main(int argc, char** argv) {
-  const int T = argc > 1 ? atoi(argv[1]) : 8, per = argc > 2 ? atoi(argv[2]) : 4, use_executor = argc > 3 ? atoi(argv[3]) : 1;
+  const int T = argc > 1 ? atoi(argv[1]) : 8, per = argc > 2 ? atoi(argv[2]) : 4, use_executor = argc > 3 ? atoi(argv[3]) : 0;
   if (T < 1 || T > 1024 || per < 1) { fprintf(stderr, "usage: seam_bench <threads> <proofs per thread> [executor 1|0]\n"); return 2; }
   pthread_barrier_init(&g_start, NULL, (unsigned)T + 1);
   struct worker* ws = (struct worker*)calloc((size_t)T, sizeof *ws);
   pthread_t* th = (pthread_t*)calloc((size_t)T, sizeof *th);
   for (int i = 0; i < T; i++) { ws[i].id = i; ws[i].proofs = per; ws[i].use_executor = use_executor; pthread_create(&th[i], NULL, run, &ws[i]); }
   pthread_barrier_wait(&g_start);  /* contexts ready: the executor starts on an otherwise idle, fully initialised device */
-  if (use_executor == 1) CHECK(dp_executor_start(0, T));
   pthread_barrier_wait(&g_start);
   pthread_barrier_wait(&g_start);  /* warm-up proofs done */
   const double t0 = now_s();
   pthread_barrier_wait(&g_start);
   const double dt = now_s() - t0;
   for (int i = 0; i < T; i++) pthread_join(th[i], NULL);
-  if (use_executor == 1) CHECK(dp_executor_stop(0));
   printf("{\"seam_level_proofs_per_s\": %.2f, \"threads\": %d, \"proofs\": %d, \"seconds\": %.3f, \"executor\": %s, \"ms_per_proof_per_thread\": %.1f}\n",
          (double)T * per / dt, T, T * per, dt, use_executor == 1 ? "true" : "false", 1000.0 * dt / per);
   return 0;

@@ -24,7 +24,10 @@ def main():
     for ln in r.stderr.split("\n"):
         m = re.search(r"remark: Function Name: (\S+)", ln)
         if m:
-            cur = {"Kernel": short(m.group(1))}
+            # the launch form of a body: kg / kc<Body, MAXT, FLAGS> — MAXT = __launch_bounds__, FLAGS 1 = KF_CLAIM (latency mode, 1024 threads), 2 = KF_PRIO
+            # (throughput mode, <= 256 threads)
+            f = re.search(r"EELi(\d+)ELi(\d+)E", m.group(1))
+            cur = {"Kernel": short(m.group(1)), "MAXT": f.group(1) if f else "", "FLAGS": {"0": "none", "1": "claim", "2": "prio"}.get(f.group(2), f.group(2)) if f else ""}
             recs.append(cur)
             continue
         m = re.search(r"remark:\s+([A-Za-z][A-Za-z \[\]/]+): (\d+)", ln)
@@ -32,11 +35,11 @@ def main():
             cur[m.group(1).strip()] = int(m.group(2))
     recs.sort(key=lambda x: x["Kernel"].split(":", 1)[-1] + x["Kernel"][:2])
     with open(sys.argv[1], "w", newline="") as f:
-        w = csv.DictWriter(f, fieldnames=["Kernel"] + FIELDS)
+        w = csv.DictWriter(f, fieldnames=["Kernel", "MAXT", "FLAGS"] + FIELDS)
         w.writeheader()
         for x in recs:
-            w.writerow({k: x.get(k, "") for k in ["Kernel"] + FIELDS})
-    spill = [x["Kernel"] for x in recs if x.get("VGPRs Spill", 0)]
+            w.writerow({k: x.get(k, "") for k in ["Kernel", "MAXT", "FLAGS"] + FIELDS})
+    spill = [f'{x["Kernel"]}[{x["MAXT"]},{x["FLAGS"]}]' for x in recs if x.get("VGPRs Spill", 0)]
     print(f"{len(recs)} kernels; with VGPR spills: {', '.join(spill) if spill else 'none'}")
 
 
