@@ -107,6 +107,172 @@ __device__ __forceinline__ u64 mul_small(u64 a, u32 k) {
   return r;
 }
 
+// ------------------------------------------------------------------------------------------------ forms for the ONE-WAVE sponge (kernels.inc, p2l_*)
+// A lone wave pays for every instruction slot (4-5 cycles each, s_nop wait states included: profiles/r04_issue_rate_one_wave.txt) and ~38 cycles for
+// the uniform branch on the rare borrow above. Here the rare condition of a block is written to an SGPR pair (`pend`) by the instruction that produces
+// it and OR-ed into `flag` in the NEXT block, in a slot that would otherwise be a wait state; whoever runs a chain of these checks `flag | pend` once at
+// the end and repeats the chain with the exact forms (FIX = true: the correction always executed, no flags) if it is set — probability ~2^-60 per
+// permutation on real data, exact when it happens.
+#define DP_GX_CLOB "vcc", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57"
+#define DP_GX_TAIL_FLAGS                                     \
+      "v_mad_u64_u32 v[52:53], %[sc], v56, -1, v[48:49]\n"   \
+      "s_or_b64 %[flag], %[flag], %[pend]\n"                 \
+      "s_nop 0\n"                                            \
+      "v_subb_co_u32_e64 %[r0], vcc, v52, v57, %[sc]\n"      \
+      "v_addc_co_u32_e64 v53, %[sc], 0, v53, %[sc]\n"        \
+      "s_nop 0\n"                                            \
+      "v_subbrev_co_u32_e64 %[r1], %[pend], 0, v53, vcc\n"
+#define DP_GX_TAIL_FIX                                       \
+      "v_mad_u64_u32 v[52:53], %[sc], v56, -1, v[48:49]\n"   \
+      "s_nop 1\n"                                            \
+      "v_subb_co_u32_e64 %[r0], vcc, v52, v57, %[sc]\n"      \
+      "v_addc_co_u32_e64 v53, %[sc], 0, v53, %[sc]\n"        \
+      "s_nop 0\n"                                            \
+      "v_subbrev_co_u32_e32 %[r1], vcc, 0, v53, vcc\n"       \
+      "s_nop 1\n"                                            \
+      "v_cndmask_b32_e64 v50, 0, -1, vcc\n"                  \
+      "v_sub_co_u32_e32 %[r0], vcc, %[r0], v50\n"            \
+      "s_nop 1\n"                                            \
+      "v_subbrev_co_u32_e32 %[r1], vcc, 0, %[r1], vcc\n"
+#define DP_GX_PRODUCT                                        \
+      "v_mad_u64_u32 v[48:49], vcc, %[a0], %[b0], 0\n"       \
+      "v_lshrrev_b64 v[50:51], 32, v[48:49]\n"               \
+      "v_mad_u64_u32 v[52:53], vcc, %[a1], %[b0], v[50:51]\n" \
+      "v_mad_u64_u32 v[54:55], %[sc], %[a0], %[b1], v[52:53]\n" \
+      "v_lshrrev_b64 v[50:51], 32, v[54:55]\n"               \
+      "v_mad_u64_u32 v[56:57], vcc, %[a1], %[b1], v[50:51]\n" \
+      "v_mov_b32 v49, v54\n"                                 \
+      "v_addc_co_u32_e64 v57, vcc, 0, v57, %[sc]\n"
+template <bool FIX> __device__ __forceinline__ u64 mul_f(u64 a, u64 b, u64& flag, u64& pend) {
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  u32 r0, r1; u64 sc;
+  if (FIX) asm(DP_GX_PRODUCT DP_GX_TAIL_FIX : [r0] "=&v"(r0), [r1] "=&v"(r1), [sc] "=&s"(sc) : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1) : DP_GX_CLOB);
+  else asm(DP_GX_PRODUCT DP_GX_TAIL_FLAGS : [r0] "=&v"(r0), [r1] "=&v"(r1), [sc] "=&s"(sc), [flag] "+s"(flag), [pend] "+s"(pend) : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1) : DP_GX_CLOB, "scc");
+  return ((u64)r1 << 32) | r0;
+}
+// x * d + A + B 2^22 + C 2^44 for d < p and limb sums A, B < 2^28, C < 2^24 (the internal layer's d_i x_i + row sum, the sum still in limbs):
+// the limbs ride in the multipliers' accumulates (t = A + B 2^22 under the first product, C 2^12 in the 2^32 column); the two carries of that
+// column have weight 2^96 and go into hh. 17 VALU instructions instead of a 6-instruction join and the 13-instruction fma.
+#define DP_GX_FMA3_PRODUCT                                   \
+      "v_mad_u64_u32 v[58:59], vcc, %[B], %[k22], 0\n"       \
+      "v_mad_u64_u32 v[58:59], vcc, %[A], 1, v[58:59]\n"     \
+      "v_mad_u64_u32 v[48:49], %[sc], %[a0], %[b0], v[58:59]\n" \
+      "v_lshrrev_b64 v[50:51], 32, v[48:49]\n"               \
+      "s_nop 0\n"                                            \
+      "v_addc_co_u32_e64 v51, vcc, 0, 0, %[sc]\n"            \
+      "v_mad_u64_u32 v[50:51], vcc, %[C], %[k12], v[50:51]\n" \
+      "v_mad_u64_u32 v[52:53], %[sq], %[a1], %[b0], v[50:51]\n" \
+      "v_mad_u64_u32 v[54:55], %[sc], %[a0], %[b1], v[52:53]\n" \
+      "v_lshrrev_b64 v[50:51], 32, v[54:55]\n"               \
+      "v_mad_u64_u32 v[56:57], vcc, %[a1], %[b1], v[50:51]\n" \
+      "v_mov_b32 v49, v54\n"                                 \
+      "v_addc_co_u32_e64 v57, vcc, 0, v57, %[sq]\n"          \
+      "v_addc_co_u32_e64 v57, vcc, 0, v57, %[sc]\n"
+template <bool FIX> __device__ __forceinline__ u64 fma3_f(u64 x, u64 d, u32 A, u32 B, u32 C, u64& flag, u64& pend) {
+  const u32 a0 = (u32)x, a1 = (u32)(x >> 32), b0 = (u32)d, b1 = (u32)(d >> 32), k22 = 1u << 22, k12 = 1u << 12;
+  u32 r0, r1; u64 sc, sq;
+  if (FIX) asm(DP_GX_FMA3_PRODUCT DP_GX_TAIL_FIX : [r0] "=&v"(r0), [r1] "=&v"(r1), [sc] "=&s"(sc), [sq] "=&s"(sq)
+               : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [A] "v"(A), [B] "v"(B), [C] "v"(C), [k22] "s"(k22), [k12] "s"(k12) : DP_GX_CLOB, "v58", "v59");
+  else asm(DP_GX_FMA3_PRODUCT DP_GX_TAIL_FLAGS : [r0] "=&v"(r0), [r1] "=&v"(r1), [sc] "=&s"(sc), [sq] "=&s"(sq), [flag] "+s"(flag), [pend] "+s"(pend)
+           : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [A] "v"(A), [B] "v"(B), [C] "v"(C), [k22] "s"(k22), [k12] "s"(k12) : DP_GX_CLOB, "v58", "v59", "scc");
+  return ((u64)r1 << 32) | r0;
+}
+// A + B 2^22 + C 2^44 (limb sums A, B, C < 2^28) -> any u64 representative: t = A + B 2^22, Hh = C 2^12 + (t >> 32) (< 2^41), value = t.lo + Hh.lo 2^32 + Hh.hi 2^64;
+// the carry of the last multiply-add (needs the low words close to 2^64: rare) is the block's rare condition
+template <bool FIX> __device__ __forceinline__ u64 join3_f(u32 A, u32 B, u32 C, u64& flag, u64& pend) {
+  const u32 k22 = 1u << 22, k12 = 1u << 12;
+  u32 r0, r1; u64 r, sc;
+  if (FIX) {
+    asm("v_mad_u64_u32 v[48:49], vcc, %[B], %[k22], 0\n"
+        "v_mad_u64_u32 v[48:49], vcc, %[A], 1, v[48:49]\n"
+        "v_lshrrev_b64 v[50:51], 32, v[48:49]\n"
+        "v_mad_u64_u32 v[50:51], vcc, %[C], %[k12], v[50:51]\n"
+        "v_mov_b32 v49, v50\n"
+        "v_mad_u64_u32 v[52:53], %[sc], v51, -1, v[48:49]\n"
+        "s_nop 1\n"
+        "v_cndmask_b32_e64 v50, 0, -1, %[sc]\n"
+        "v_add_co_u32_e32 %[r0], vcc, v52, v50\n"
+        "s_nop 1\n"
+        "v_addc_co_u32_e32 %[r1], vcc, 0, v53, vcc\n"
+        : [r0] "=&v"(r0), [r1] "=&v"(r1), [sc] "=&s"(sc) : [A] "v"(A), [B] "v"(B), [C] "v"(C), [k22] "s"(k22), [k12] "s"(k12) : "vcc", "v48", "v49", "v50", "v51", "v52", "v53");
+    return ((u64)r1 << 32) | r0;
+  }
+  asm("v_mad_u64_u32 v[48:49], vcc, %[B], %[k22], 0\n"
+      "v_mad_u64_u32 v[48:49], vcc, %[A], 1, v[48:49]\n"
+      "s_or_b64 %[flag], %[flag], %[pend]\n"
+      "v_lshrrev_b64 v[50:51], 32, v[48:49]\n"
+      "v_mad_u64_u32 v[50:51], vcc, %[C], %[k12], v[50:51]\n"
+      "v_mov_b32 v49, v50\n"
+      "v_mad_u64_u32 %[r], %[pend], v51, -1, v[48:49]\n"
+      : [r] "=&v"(r), [flag] "+s"(flag), [pend] "+s"(pend) : [A] "v"(A), [B] "v"(B), [C] "v"(C), [k22] "s"(k22), [k12] "s"(k12) : "vcc", "scc", "v48", "v49", "v50", "v51");
+  return r;
+}
+
+// The linear layers of the lane-parallel Poseidon2 on three limbs of 22 / 22 / 20 bits, written out so that every cross-lane operand is the DPP source of
+// an add and no instruction reads through DPP a register written less than two instructions earlier (the gfx950 hazard that otherwise costs s_nop slots):
+// the three limbs are interleaved. State word i of a permutation lives in lane i of its group of 8.
+#define DP_DPP_XOR1 " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define DP_DPP_ROT1 " quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf\n"
+#define DP_DPP_ROT2 " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+#define DP_DPP_REV " quad_perm:[3,2,1,0] row_mask:0xf bank_mask:0xf\n"
+#define DP_DPP_HMIR " row_half_mirror row_mask:0xf bank_mask:0xf\n"
+#define DP_GX_SPLIT                                          \
+      "v_and_b32 %[A], 0x3fffff, %[x0]\n"                    \
+      "v_alignbit_b32 %[B], %[x1], %[x0], 22\n"              \
+      "v_lshrrev_b32 %[C], 12, %[x1]\n"                      \
+      "v_and_b32 %[B], 0x3fffff, %[B]\n"
+// x -> limbs -> external layer circ(2 M4, M4) (+ this lane's round constant, as limbs): out = 2 t + t(lane ^ 4) + rc, t_j = (quad sum) + v_j + 2 v_{j+1}
+__device__ __forceinline__ void lin_full(u64 x, u32 rA, u32 rB, u32 rC, u32& oA, u32& oB, u32& oC) {
+  const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+  u32 A, B, C, pA, pB, pC, qA, qB, qC, nA, nB, nC;
+  asm(DP_GX_SPLIT
+      "v_add_u32_dpp %[pA], %[A], %[A]" DP_DPP_XOR1
+      "v_add_u32_dpp %[pC], %[C], %[C]" DP_DPP_XOR1
+      "v_mov_b32_dpp %[nA], %[A]" DP_DPP_ROT1
+      "v_add_u32_dpp %[pB], %[B], %[B]" DP_DPP_XOR1
+      "v_add_u32_dpp %[qA], %[pA], %[pA]" DP_DPP_ROT2
+      "v_add_u32_dpp %[qC], %[pC], %[pC]" DP_DPP_ROT2
+      "v_mov_b32_dpp %[nC], %[C]" DP_DPP_ROT1
+      "v_add_u32_dpp %[qB], %[pB], %[pB]" DP_DPP_ROT2
+      "v_mov_b32_dpp %[nB], %[B]" DP_DPP_ROT1
+      "v_add_u32 %[qA], %[qA], %[A]\n"
+      "v_add_u32 %[qC], %[qC], %[C]\n"
+      "v_add_u32 %[qB], %[qB], %[B]\n"
+      "v_lshl_add_u32 %[qA], %[nA], 1, %[qA]\n"
+      "v_lshl_add_u32 %[qC], %[nC], 1, %[qC]\n"
+      "v_lshl_add_u32 %[qB], %[nB], 1, %[qB]\n"
+      "v_mov_b32_dpp %[pA], %[qA]" DP_DPP_HMIR
+      "v_mov_b32_dpp %[pC], %[qC]" DP_DPP_HMIR
+      "v_mov_b32_dpp %[pB], %[qB]" DP_DPP_HMIR
+      "v_lshl_add_u32 %[qA], %[qA], 1, %[rA]\n"
+      "v_lshl_add_u32 %[qC], %[qC], 1, %[rC]\n"
+      "v_lshl_add_u32 %[qB], %[qB], 1, %[rB]\n"
+      "v_add_u32_dpp %[oA], %[pA], %[qA]" DP_DPP_REV
+      "v_add_u32_dpp %[oC], %[pC], %[qC]" DP_DPP_REV
+      "v_add_u32_dpp %[oB], %[pB], %[qB]" DP_DPP_REV
+      : [A] "=&v"(A), [B] "=&v"(B), [C] "=&v"(C), [pA] "=&v"(pA), [pB] "=&v"(pB), [pC] "=&v"(pC), [qA] "=&v"(qA), [qB] "=&v"(qB), [qC] "=&v"(qC),
+        [nA] "=&v"(nA), [nB] "=&v"(nB), [nC] "=&v"(nC), [oA] "=&v"(oA), [oB] "=&v"(oB), [oC] "=&v"(oC)
+      : [x0] "v"(x0), [x1] "v"(x1), [rA] "v"(rA), [rB] "v"(rB), [rC] "v"(rC));
+}
+// x -> limbs -> the sum over the 8 lanes of the group, limb by limb (the internal layer's row sum)
+__device__ __forceinline__ void lin_sum8(u64 x, u32& oA, u32& oB, u32& oC) {
+  const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+  u32 A, B, C, pA, pB, pC, qA, qB, qC;
+  asm(DP_GX_SPLIT
+      "v_add_u32_dpp %[pA], %[A], %[A]" DP_DPP_XOR1
+      "v_add_u32_dpp %[pC], %[C], %[C]" DP_DPP_XOR1
+      "v_add_u32_dpp %[pB], %[B], %[B]" DP_DPP_XOR1
+      "v_add_u32_dpp %[qA], %[pA], %[pA]" DP_DPP_ROT2
+      "v_add_u32_dpp %[qC], %[pC], %[pC]" DP_DPP_ROT2
+      "v_add_u32_dpp %[qB], %[pB], %[pB]" DP_DPP_ROT2
+      "v_add_u32_dpp %[oA], %[qA], %[qA]" DP_DPP_HMIR
+      "v_add_u32_dpp %[oC], %[qC], %[qC]" DP_DPP_HMIR
+      "v_add_u32_dpp %[oB], %[qB], %[qB]" DP_DPP_HMIR
+      : [A] "=&v"(A), [B] "=&v"(B), [C] "=&v"(C), [pA] "=&v"(pA), [pB] "=&v"(pB), [pC] "=&v"(pC), [qA] "=&v"(qA), [qB] "=&v"(qB), [qC] "=&v"(qC),
+        [oA] "=&v"(oA), [oB] "=&v"(oB), [oC] "=&v"(oC)
+      : [x0] "v"(x0), [x1] "v"(x1));
+}
+
 }  // namespace gx
 }  // namespace dp
 #endif

@@ -1372,10 +1372,10 @@ class HipDev : public Dev {
         const bool skip1 = claim_hint_ != nullptr;
         // one proof on the GPU: the kernel's last workgroup reduces and publishes (no second launch); cohort members keep the
         // separate reduction (their workgroups of one launch belong to different proofs)
-        // ... which is OFF (DP_FUSED_TICKET=1): measured on the 2^24 sumcheck, the agent-scope release every workgroup needs before
-        // it takes its ticket is an L2 write-back per workgroup — the fused rounds went from 162 / 40 us to 1122 / 230 us
-        // (4096 write-backs per launch); a separate 14 us reduction launch per round is the cheaper way across XCDs.
-        static const bool ticket_env = getenv("DP_FUSED_TICKET") && atoi(getenv("DP_FUSED_TICKET"));
+        // (round 2 had this OFF: its agent-scope release fence per workgroup wrote the XCD's whole L2 back 4096 times per launch, 162 / 40 us -> 1122 / 230 us.
+        // Round 4 publishes the 64 bytes of block sums write-through instead — kernels.inc, k_sc_fused — and it is the default; DP_FUSED_TICKET=0 restores the
+        // separate 14 us reduction launch per round.)
+        static const bool ticket_env = !(getenv("DP_FUSED_TICKET") && !atoi(getenv("DP_FUSED_TICKET")));
         const bool inkernel = ticket_env && zerocopy_ && !queued_() && !share_x_ && fused_ticket_ != nullptr;
         unsigned* tick = inkernel ? fused_ticket_ : nullptr;
         const unsigned long long fseq = inkernel ? ++seq_ : 0;

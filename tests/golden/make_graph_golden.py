@@ -35,7 +35,11 @@ CASES = [
     ("mha_block", dict(seq=16, emb=32, heads=4, head_dim=8, config=98)),
     # one whole pre-LN transformer layer as one graph of 19 nodes: attention half (with the Mha node) and feed-forward half, two LayerNorms, three inputs
     ("transformer_layer", dict(seq=8, emb=16, heads=2, head_dim=8, ffn=32, config=101)),
+    # the same layer at the size bench.py TIMES (section `transformer_layer`: 64 tokens x 256 features, 4 heads of 64, ffn 1024, config 66): ~16 s of oracle time,
+    # 1.29 M proof words. `gpu_only`: the CPU suites (test_oracle, test_hostlogic) skip it; the GPU suite and the bench compare against this sha256.
+    ("transformer_layer", dict(seq=64, emb=256, heads=4, head_dim=64, ffn=1024, config=66)),
 ]
+GPU_ONLY = {14}
 
 
 def sha(a):
@@ -49,14 +53,14 @@ def build(name, kw):
 if __name__ == "__main__":
     o = oracle_lib.load()
     out = []
-    for name, kw in CASES:
+    for ci, (name, kw) in enumerate(CASES):
         g = build(name, kw)
         blob, x = g.blob(), g.input()
         h = o.model_setup(blob)
         proof, y, _ = o.model_prove(h, x)
         o.model_free(h)
         assert y.size == g.run(x).size and (y == g.run(x)).all(), name
-        out.append(dict(model=name, args=kw, blob_sha256=sha(blob), input_sha256=sha(x), output_sha256=sha(y), proof_sha256=sha(proof), proof_words=int(proof.size)))
+        out.append(dict(model=name, args=kw, blob_sha256=sha(blob), input_sha256=sha(x), output_sha256=sha(y), proof_sha256=sha(proof), proof_words=int(proof.size), **({"gpu_only": True} if ci in GPU_ONLY else {})))
         print(name, kw, proof.size, "proof words")
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_models.json"), "w") as f:
         json.dump(out, f, indent=1)

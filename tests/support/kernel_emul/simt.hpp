@@ -78,6 +78,7 @@ static struct { simt::Const x{1}, y{1}, z{1}; } gridDim;
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 #define __hip_atomic_load(p, order, scope) (*(volatile const std::remove_pointer_t<decltype(p)>*)(p))
 inline void __syncthreads() { simt::barrier(); }
+inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 inline unsigned long long __brevll(unsigned long long x) { unsigned long long r = 0; for (int i = 0; i < 64; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
 inline int __shfl(int v, int src, int width = 64) {
@@ -90,6 +91,7 @@ inline int __shfl_down(int v, int d, int width = 64) {
   unsigned src = lane + (unsigned)d < 64u ? me + (unsigned)d : me;
   return (int)simt::exchange((uint32_t)v, src);
 }
+inline int __builtin_amdgcn_readlane(int v, int lane) { return (int)simt::exchange((uint32_t)v, (simt::tid() & ~63u) | ((unsigned)lane & 63u)); }
 // DPP with full row / bank masks: quad_perm (ctrl < 0x100: two selector bits per lane of a quad) and row_half_mirror (0x141)
 inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   (void)old; (void)bound_ctrl;

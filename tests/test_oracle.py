@@ -208,6 +208,8 @@ def test_graph_models_oracle_matches_golden_and_numpy_inference(oracle):
         cases = json.load(f)
     assert len(cases) >= 5
     for c in cases:
+        if c.get("gpu_only"):  # (the transformer layer at the benched size: 16 s of oracle time — pinned by the GPU suite and bench.py against this sha256)
+            continue
         g = getattr(dpa.models, c["model"])(**c["args"])
         blob, x = g.blob(), g.input()
         assert sha(blob) == c["blob_sha256"] and sha(x) == c["input_sha256"]

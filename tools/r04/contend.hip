@@ -25,10 +25,11 @@ template <int PRIO, int COPIES> __global__ void k_sponge(u64* io, int iters, uns
   if (PRIO) __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63;
   u64 s = io[lane & 7] + blockIdx.x;
+  const P2lK pk = p2l_load(lane);
   const unsigned long long t0 = wall_clock64();
   for (int k = 0; k < iters; k++) {
 #pragma unroll
-    for (int c = 0; c < COPIES; c++) s = p2l_permute(s, lane);
+    for (int c = 0; c < COPIES; c++) s = p2l_permute(s, lane, pk);
   }
   const unsigned long long t1 = wall_clock64();
   if (lane < 8) io[8 + lane] = s;

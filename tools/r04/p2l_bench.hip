@@ -22,7 +22,8 @@ namespace dp {
 __global__ void k_p2l_chain(u64* io, int iters) {
   const int lane = threadIdx.x & 63;
   u64 s = io[lane & 7];
-  for (int k = 0; k < iters; k++) s = p2l_permute(s, lane);
+  const P2lK pk = p2l_load(lane);
+  for (int k = 0; k < iters; k++) s = p2l_permute(s, lane, pk);
   if (lane < 8) io[8 + lane] = s;
 }
 }  // namespace dp

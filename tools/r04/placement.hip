@@ -28,8 +28,9 @@ template <int ROT> __global__ void __launch_bounds__(256) k_tail(u64* io, int pe
   const int sw = ROT ? ((blockIdx.x + salt) & 3) : 0;
   if (wave == sw) {
     u64 s = io[lane & 7] + blockIdx.x;
+    const P2lK pk = p2l_load(lane);
     const unsigned long long t0 = wall_clock64();
-    for (int k = 0; k < perms; k++) s = p2l_permute(s, lane);
+    for (int k = 0; k < perms; k++) s = p2l_permute(s, lane, pk);
     const unsigned long long t1 = wall_clock64();
     if (lane < 8) io[64 + lane] = s;
     if (lane == 0) {
