@@ -230,6 +230,21 @@ def kernel_profile(dev, prover, x):
     return rep
 
 
+def valu_accounting(workload):
+    """the newest committed SQ instruction pass of this workload's throughput-mode job (tools/pmc_sq_job.py), or None"""
+    if workload != "dense_4m":
+        return None
+    try:
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if "_pmc_sq_bench" in name and name.endswith(".json"):
+                doc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if doc.get("population") == "dense_4m_throughput_mode_cohort_launches":
+                    return dict(doc, source=f"profiles/{name}")
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def pmc_traffic(kernel, population, launches=None):
     """HBM bytes per launch of `kernel` (mean over its launches) from a committed rocprofv3 PMC pass (profiles/r*_pmc_*.json, made by
     tools/pmc_summary.py: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled for 16 B/lane streaming reads as
@@ -399,6 +414,20 @@ def main():
                                         "note": "one-workgroup protocol kernels (sumcheck rounds + Fiat-Shamir) are latency-bound by construction: kilobytes of tables, a dependent chain of rounds"},
                     "top_kernels": [{"kernel": r["kernel"], "launches": r["launches"], "total_ms": round(r["total_ms"], 3),
                                      "GBps": round((r["alg_bytes"] / max(r["total_ms"], 1e-9)) / 1e6, 1)} for r in rep[:8]]}
+        # ---- the hardware-derived VALU bound next to the self-probed peak (round 4): a counter pass over the same command (tools/pmc_sq_job.py ->
+        # profiles/r*_pmc_sq_bench448.json: SQ_INSTS_VALU of the cohort launches per proof, and of the compress probe per compress) prices every VALU wave
+        # instruction at 4 cycles on 1024 SIMDs at 2.4 GHz. `peak_valu_bound` = compress()/s if EVERY issue slot of the chip ran this kernel's instructions;
+        # `valu_issue_util` = the share of the chip's issue slots the whole timed job uses at the rate measured NOW.
+        sq = valu_accounting(args.workload)
+        if sq:
+            roofline["peak_valu_bound"] = round(sq["compress"]["peak_valu_bound_compress_per_s"] / 1e9, 4) if sq.get("compress") else None
+            roofline["frac_of_valu_bound"] = round(achieved / sq["compress"]["peak_valu_bound_compress_per_s"], 4) if sq.get("compress") else None
+            roofline["probe_frac_of_valu_bound"] = round(peak / sq["compress"]["peak_valu_bound_compress_per_s"], 4) if sq.get("compress") else None
+            roofline["valu_instr_per_compress"] = sq["compress"]["valu_instr_per_compress"] if sq.get("compress") else None
+            roofline["valu_wave_instr_per_proof"] = sq["valu_wave_instr_per_proof"]
+            roofline["valu_issue_util"] = round(sq["valu_wave_instr_per_proof"] * (value / world) / sq["chip_issue_capacity_wave_instr_per_s"], 4)
+            roofline["valu_hash_share"] = sq.get("hash_share"); roofline["valu_one_wave_share"] = sq.get("one_wave_share")
+            roofline["valu_source"] = sq["source"]
         cpu = None if (world > 1 or args.no_cpu_baseline) else cpu_baseline(main_w["mb"], args.workload)
         sc24 = None if (world > 1 or args.no_sumcheck24) else sumcheck24(dev, dpa)
         cnn = None
@@ -429,7 +458,7 @@ def main():
                        "proof_words": main_w["proof_words"], "setup_s": round(main_w["setup_s"], 2), "verified": True, "golden_sha256_ok": main_w["golden_ok"], "verified_proofs_of_last_step": main_w["verified"], "verify_ms_per_proof": main_w["verify_ms"], "verify_batch_ms_per_proof": main_w["verify_batch_ms_per_proof"],
                        "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DP_") or k == "GPU_MAX_HW_QUEUES"}, "device": dev.name},
             "roofline": roofline, "cpu_baseline": cpu, "cnn_264k": cnn, "sumcheck24": sc24, "sumcheck24_sharded": None,
-            "seam_level": None if (world > 1 or args.no_seam_level) else seam_level(int(os.environ["DP_HOST_THREADS"])),
+            "seam_level": None if (world > 1 or args.no_seam_level) else seam_level(int(os.environ["DP_HOST_THREADS"]), batch_rate=value),
         }
         if world == 1 and args.workload == "dense_4m" and not args.batch and not args.no_transformer:
             try:  # (a side section: whatever happens in it, the headline line above is printed)
@@ -647,7 +676,7 @@ def sharded_estimate(nv, k, world, stream_tbps=3.4, round_us=17.0, exchange_us=3
             "note": "model, not measurement; the measured wall_ms of this section is the judge of it"}
 
 
-def seam_level(threads, per_thread=6):
+def seam_level(threads, per_thread=6, batch_rate=None):
     """What a host gets that proves THROUGH THE SEAMS (dp_pcs_commit / dp_pcs_batch_open / dp_sumcheck_prove / dp_logup_prove from T
     threads with one context each) instead of handing the model to dp_model_prove_batch: tests/support/
     seam_bench.c replays the seam calls of one Dense-4M proof, call for call and shape for shape, on random tables — "workload-
@@ -665,17 +694,23 @@ def seam_level(threads, per_thread=6):
     # `streams_throughput`: plain contexts switched to throughput mode (dp_ctx_set_throughput_mode: device-side Fiat-Shamir, fused protocol
     # kernels). Measured: 40 against 80 proofs/s at 14 threads, 34-36 with 28 / 56 yielding threads (profiles/r03_seam_level_throughput_mode.txt):
     # without cohorts to merge launches and fibers to keep hundreds of calls in flight the one-wave kernels only add latency
-    variants = [("streams", 0, threads, {}), ("streams_throughput", 2, threads, {})]
+    # `async_one_thread` (round 4): ONE host thread keeps 64 / 128 proofs in flight through the submit / poll forms (dp_async): calls of identical shape are
+    # merged into lock-step groups by the engine (tests/support/seam_bench.c mode 3)
+    variants = [("streams", 0, threads, {}), ("streams_throughput", 2, threads, {}), ("async_one_thread_64", 3, 64, {}), ("async_one_thread_128", 3, 128, {})]
     for name, executor, t, extra in variants:
         env = dict(os.environ, DP_ARENA_BYTES=str(2 << 30), **extra)
         try:
-            r = subprocess.run([out, str(t), str(per_thread), str(executor)], env=env, capture_output=True, text=True, timeout=120)
+            r = subprocess.run([out, str(t), str(3 if executor == 3 else per_thread), str(executor)], env=env, capture_output=True, text=True, timeout=120)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             res[name] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-300:]}
         except Exception as e:  # noqa: BLE001
             res[name] = {"error": f"{type(e).__name__}: {e}"}
     res["note"] = ("workload-equivalent proofs per second of a seam-level host (every seam call of one Dense-4M proof, random tables), T threads with one dp_ctx each: "
-                   "`streams` = plain contexts in latency mode (one HIP stream each), `streams_throughput` = the same in throughput mode (dp_ctx_set_throughput_mode)")
+                   "`streams` = plain contexts in latency mode (one HIP stream each), `streams_throughput` = the same in throughput mode (dp_ctx_set_throughput_mode), `async_one_thread_N` = one host thread, N proofs in flight through dp_async (submit / poll, "
+                   "merged lock-step groups); `vs_batch` = best seam-level rate / the batch rate of this run")
+    rates = [v.get("seam_level_proofs_per_s", 0.0) for v in res.values() if isinstance(v, dict)]
+    res["best_proofs_per_s"] = max(rates) if rates else None
+    res["vs_batch"] = round(max(rates) / batch_rate, 4) if rates and batch_rate else None
     return res
 
 

@@ -28,6 +28,22 @@ SIGNATURES = {
     "dp_ctx_destroy": (C.c_int32, [vp]),
     "dp_ctx_name": (C.c_char_p, [vp]),
     "dp_ctx_set_throughput_mode": (C.c_int32, [vp, C.c_int32]),
+    "dp_async_create": (C.c_int32, [vp, C.c_int32, C.c_size_t, C.POINTER(vp)]),
+    "dp_async_destroy": (C.c_int32, [vp]),
+    "dp_async_stats": (C.c_int32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "dp_pcs_commit_submit": (C.c_int32, [vp, vp, C.POINTER(vp)]),
+    "dp_mle_fix_high_submit": (C.c_int32, [vp, vp, C.c_size_t, C.c_size_t, u64p, C.POINTER(vp)]),
+    "dp_mle_eval_submit": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.POINTER(vp)]),
+    "dp_ticket_buf": (C.c_int32, [vp, C.POINTER(vp)]),
+    "dp_sumcheck_prove_submit": (C.c_int32, [vp, C.c_uint32, C.POINTER(vp), C.c_int32, i32p, i32p, u64p, C.c_int32, vp, C.POINTER(vp)]),
+    "dp_logup_prove_submit": (C.c_int32, [vp, C.POINTER(vp), C.c_int32, C.c_int32, vp, u64p, u64p, vp, C.POINTER(vp)]),
+    "dp_pcs_batch_open_submit": (C.c_int32, [vp, C.POINTER(vp), C.c_int32, u64p, u64p, vp, C.POINTER(vp)]),
+    "dp_poll": (C.c_int32, [vp]),
+    "dp_wait": (C.c_int32, [vp]),
+    "dp_ticket_words": (C.c_int32, [vp, C.c_int32, C.POINTER(u64p), C.POINTER(C.c_size_t)]),
+    "dp_ticket_values": (C.c_int32, [vp, u64p, C.c_size_t]),
+    "dp_ticket_commit": (C.c_int32, [vp, C.POINTER(vp), u64p]),
+    "dp_ticket_free": (C.c_int32, [vp]),
     "dp_profile_enable": (C.c_int32, [vp, C.c_int32]),
     "dp_profile_report": (C.c_int32, [vp, C.POINTER(C.c_void_p)]),
     "dp_probe_compress_rate": (C.c_int32, [vp, C.c_size_t, C.c_int32, C.POINTER(C.c_double)]),

@@ -297,6 +297,94 @@ def logup_batch_prove(dev, columns, columns_per_instance, constant_challenge, co
     return _take(pw, pn.value)
 
 
+class Ticket:
+    """a submitted seam call (dp_ticket): poll() -> 0 running / 1 done (raises DeepProveError if it failed); the results once done"""
+
+    def __init__(self, handle, keep):
+        self.h, self._keep = vp(handle), keep  # `keep`: the argument arrays and handles the call reads until it completes
+
+    def poll(self):
+        s = _lib.load().dp_poll(self.h)
+        if s < 0:
+            check(s)
+        return s
+
+    def wait(self):
+        check(_lib.load().dp_wait(self.h))
+        return self
+
+    def words(self, which=0):
+        pw, pn = u64p(), C.c_size_t()
+        check(_lib.load().dp_ticket_words(self.h, which, C.byref(pw), C.byref(pn)))
+        return _take(pw, pn.value)
+
+    def values(self, n):
+        out = np.zeros(n, dtype=np.uint64)
+        check(_lib.load().dp_ticket_values(self.h, out.ctypes.data_as(u64p), n))
+        return out
+
+    def commitment(self, dev, poly):
+        h, root = vp(), (C.c_uint64 * 4)()
+        check(_lib.load().dp_ticket_commit(self.h, C.byref(h), root))
+        return Commitment(dev, h, [int(v) for v in root], poly)
+
+    def free(self):
+        if self.h:
+            check(_lib.load().dp_ticket_free(self.h))
+            self.h, self._keep = None, None
+
+
+class AsyncEngine:
+    """dp_async: submit / poll forms of the seam calls — one host thread keeps hundreds of calls in flight; calls of identical shape queued together are
+    proved in lock step with merged launches (include/deep_prove_hip.h, "asynchronous seam calls"). Create it after Basefold(dev, ..) (dp_pcs_setup)."""
+
+    def __init__(self, dev, max_in_flight=64, worker_arena_bytes=0):
+        self.dev, self.h = dev, vp()
+        check(_lib.load().dp_async_create(dev.h, max_in_flight, worker_arena_bytes, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            check(_lib.load().dp_async_destroy(self.h))
+            self.h = None
+
+    def stats(self):
+        a, b, c, d = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        check(_lib.load().dp_async_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {"calls": a.value, "groups": b.value, "merged_calls": c.value, "workers": d.value}
+
+    def prove_parallel(self, vpoly, transcript):
+        nt = len(vpoly.tables)
+        tabs = (vp * nt)(*[t.h for t in vpoly.tables])
+        deg = np.array([len(ix) for _, ix in vpoly.terms], dtype=np.int32)
+        tt = np.array([j for _, ix in vpoly.terms for j in ix], dtype=np.int32)
+        co = np.array([w for c, _ in vpoly.terms for w in c], dtype=np.uint64)
+        t = vp()
+        check(_lib.load().dp_sumcheck_prove_submit(self.h, vpoly.num_vars, tabs, nt, deg.ctypes.data_as(i32p), tt.ctypes.data_as(i32p), co.ctypes.data_as(u64p),
+                                                   len(vpoly.terms), transcript.h, C.byref(t)))
+        return Ticket(t.value, (vpoly, transcript))
+
+    def logup_batch_prove(self, columns, columns_per_instance, constant_challenge, column_separation_challenge, transcript, multiplicities=None):
+        cols = (vp * len(columns))(*[c.h for c in columns])
+        cc = (C.c_uint64 * 2)(*constant_challenge)
+        cs = (C.c_uint64 * 2)(*column_separation_challenge)
+        t = vp()
+        check(_lib.load().dp_logup_prove_submit(self.h, cols, len(columns), columns_per_instance, multiplicities.h if multiplicities is not None else None, cc, cs, transcript.h, C.byref(t)))
+        return Ticket(t.value, (columns, multiplicities, transcript))
+
+    def commit(self, poly):
+        t = vp()
+        check(_lib.load().dp_pcs_commit_submit(self.h, poly.h, C.byref(t)))
+        return Ticket(t.value, (poly,))
+
+    def batch_open(self, comms, points, evals, transcript):
+        hs = (vp * len(comms))(*[c.h for c in comms])
+        pf = np.concatenate([_point(p) for p in points]).astype(np.uint64)
+        ev = _point(evals)
+        t = vp()
+        check(_lib.load().dp_pcs_batch_open_submit(self.h, hs, len(comms), pf.ctypes.data_as(u64p), ev.ctypes.data_as(u64p), transcript.h, C.byref(t)))
+        return Ticket(t.value, (comms, transcript))
+
+
 class Commitment:
     def __init__(self, dev, handle, root, poly):
         self.dev, self.h, self.root, self.poly = dev, handle, root, poly

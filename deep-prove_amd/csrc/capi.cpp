@@ -7,10 +7,14 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>  // types and enums only: the functions are resolved with dlopen (no link-time dependency on librccl)
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <map>
 #include <set>
 #include <mutex>
@@ -626,6 +630,304 @@ int32_t dp_pcs_batch_open_evals(dp_ctx* ctx, const dp_commit* const* comms, int3
     BasefoldProof p = pcs_batch_open_evals(*ctx->dev, 64, cs, pts, evals, t->t);
     Writer w; w.basefold(p);
     *proof_words = copy_out(w.w); *proof_nwords = w.w.size();
+  });
+}
+// ================================================================================================ asynchronous seam calls
+// The reference reaches its seams from rayon workers: PCS::commit per witness column (zkml/src/commit/context.rs:79-103, layers/activation.rs:294-304),
+// one prove_parallel per layer (sumcheck/src/prover.rs:498-501), logup batch_prove per lookup, one batch_open per proof (mpcs/src/lib.rs:111-226). A
+// host bound to these seams with one blocking call per thread keeps a dozen calls in flight and gets a sixth of dp_model_prove_batch's rate (bench.py
+// `seam_level`, round 3): what makes the batch path fast — hundreds of calls in flight per host thread (fibers, fiber.h) and launches merged across
+// calls of the same shape (cohorts, hip_dev.hip) — sits above the seams. dp_async gives it to seam-level hosts: submit returns a ticket at once; engine
+// threads run the calls as fibers on worker contexts (own arena, own stream, the PCS tables of the owning context) in throughput mode (device-side
+// Fiat-Shamir, fused protocol tails) and prove calls of IDENTICAL SHAPE that are queued together in lock step, launch for launch merged into one
+// (the launch sequence of every seam depends on shapes only, never on data). Results are bit-identical to the blocking calls.
+struct dp_ticket {
+  std::atomic<int> state{0};  // 0 queued / running, 1 done, < 0 failed
+  std::string err;
+  std::function<void(Dev&, dp_ticket&)> body;
+  uint64_t sig = 0;
+  std::vector<uint64_t> words[2]; std::vector<uint64_t> finals;  // results: up to two word streams (the seam's malloc'ed outputs) + fixed-size values
+  dp_commit* commit = nullptr; uint64_t root[4] = {0, 0, 0, 0}; dp_buf* buf = nullptr;
+  std::chrono::steady_clock::time_point t_submit;
+};
+struct dp_async {
+  dp_ctx* ctx = nullptr; size_t max_in_flight = 0, arena = 0; size_t group_max = 32, groups_per_thread = 1; double linger_us = 100.0;  // (groups_per_thread: 1 measured best — 111 against 52 proofs/s at 3 on the seam bench, profiles/r04_seam_async.txt)
+  std::mutex mu; std::condition_variable cv; std::deque<dp_ticket*> queue; bool stop = false;
+  std::vector<std::unique_ptr<Dev>> workers; std::vector<Dev*> free_workers;
+  std::vector<std::thread> threads;
+  std::atomic<size_t> ngroups{0}, njobs{0}, nmerged{0}, qsize{0}; std::atomic<unsigned long long> body_us{0}, queue_us{0};  // (summed over calls: time inside the call, time queued before it)  // qsize: queue length, readable without the lock
+  ~dp_async() {
+    { std::lock_guard<std::mutex> g(mu); stop = true; }
+    cv.notify_all();
+    for (auto& t : threads) if (t.joinable()) t.join();
+  }
+};
+namespace {
+uint64_t sig_mix(uint64_t h, uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); return h * 0x100000001B3ull; }
+uint64_t sig_buf(uint64_t h, const DBuf& b) { return sig_mix(sig_mix(h, b.n), b.ext ? 2 : 1); }
+// One engine thread: a fiber scheduler that never blocks in a call. It holds up to `groups_per_thread` GROUPS at a time (a group = the queued calls of one
+// shape it found together, proved in lock step on one cohort stream), admits a new group whenever it has room and workers are free, and gives every live
+// fiber a turn per pass. A thread with nothing to run sleeps on the queue's condition variable.
+struct AsyncGroup { dp::Cohort* cohort = nullptr; bool merged = false; std::vector<Dev*> devs; size_t live = 0; };
+void async_thread(dp_async* a) {
+  std::vector<dp::Cohort*> idle_cohorts;
+  std::vector<std::unique_ptr<AsyncGroup>> groups;
+  FiberSched sched;
+  FiberSched*& cur = fiber_current_sched();
+  cur = &sched;
+  auto admit = [&](bool may_sleep) {
+    std::vector<dp_ticket*> group; std::vector<Dev*> devs;
+    {
+      std::unique_lock<std::mutex> lk(a->mu);
+      if (may_sleep) a->cv.wait(lk, [&] { return a->stop || (!a->queue.empty() && !a->free_workers.empty()); });
+      if (a->queue.empty() || a->free_workers.empty()) return !(a->stop && a->queue.empty());
+      const uint64_t sig = a->queue.front()->sig;
+      auto take = [&] {
+        for (auto it = a->queue.begin(); it != a->queue.end() && group.size() < a->group_max && !a->free_workers.empty();) {
+          if ((*it)->sig == sig) { group.push_back(*it); devs.push_back(a->free_workers.back()); a->free_workers.pop_back(); it = a->queue.erase(it); a->qsize--; } else ++it;
+        }
+      };
+      take();
+      // linger (only a thread with nothing else to run, only for a lone call): a host that drives many proofs in step submits the same call of each of
+      // them within microseconds — give the rest of the wave a moment to arrive
+      if (may_sleep && group.size() == 1 && a->linger_us > 0) {
+        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds((long long)a->linger_us);
+        while (group.size() < a->group_max && !a->stop && std::chrono::steady_clock::now() < until) { a->cv.wait_until(lk, until); take(); }
+      }
+    }
+    if (group.empty()) return true;
+    a->ngroups++; a->njobs += group.size(); if (group.size() > 1) a->nmerged += group.size();
+    std::unique_ptr<AsyncGroup> g(new AsyncGroup());
+    g->merged = group.size() > 1; g->devs = devs; g->live = group.size();
+    try {
+      if (g->merged) { if (idle_cohorts.empty()) idle_cohorts.push_back(hip_cohort_new()); g->cohort = idle_cohorts.back(); idle_cohorts.pop_back(); }
+      for (Dev* d : devs) { hip_dev_set_latency_mode(d, false); if (g->merged) hip_dev_cohort_attach(d, g->cohort); }
+    } catch (const std::exception& e) {
+      for (dp_ticket* t : group) { t->err = e.what(); t->state.store(DP_ERR_HIP, std::memory_order_release); }
+      if (g->cohort) idle_cohorts.push_back(g->cohort);
+      { std::lock_guard<std::mutex> gl(a->mu); for (Dev* d : devs) a->free_workers.push_back(d); }
+      a->cv.notify_all();
+      return true;
+    }
+    AsyncGroup* gp = g.get();
+    for (size_t i = 0; i < group.size(); i++) {
+      dp_ticket* t = group[i]; Dev* d = devs[i];
+      fiber_spawn(sched, [t, d, gp, a] {
+        int code = 1;
+        const auto tb = std::chrono::steady_clock::now();
+        a->queue_us += (unsigned long long)std::chrono::duration<double, std::micro>(tb - t->t_submit).count();
+        try { d->bind_thread(); const size_t mk = d->mark(); t->body(*d, *t); d->sync(); d->release(mk); }
+        catch (const DpError& e) { t->err = e.what(); code = e.code; }
+        catch (const std::bad_alloc&) { t->err = "host out of memory"; code = DP_ERR_OOM; }
+        catch (const std::exception& e) { t->err = e.what(); code = DP_ERR_ARG; }
+        catch (...) { t->err = "unknown error"; code = DP_ERR_ARG; }
+        if (gp->merged) { try { hip_dev_cohort_detach(d); } catch (const std::exception& e) { if (code == 1) { t->err = e.what(); code = DP_ERR_HIP; } } }
+        t->body = nullptr;
+        a->body_us += (unsigned long long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tb).count();
+        gp->live--;
+        t->state.store(code, std::memory_order_release);
+      });
+    }
+    groups.push_back(std::move(g));
+    return true;
+  };
+  for (;;) {
+    if (groups.size() < a->groups_per_thread && (groups.empty() || a->qsize.load(std::memory_order_relaxed))) { if (!admit(groups.empty())) break; }
+    if (groups.empty()) continue;
+    // one turn for every live fiber
+    for (size_t i = 0; i < sched.fibers.size(); i++) {
+      Fiber* f = sched.fibers[i].get();
+      if (f->done) continue;
+      sched.cur = f;
+      dp_fiber_switch(&sched.main_sp, f->sp);
+      sched.cur = nullptr;
+    }
+    // finished groups give their workers and their cohort back; finished fibers give their stacks back
+    bool freed = false;
+    for (size_t gi = 0; gi < groups.size();) {
+      AsyncGroup* g = groups[gi].get();
+      if (g->live) { gi++; continue; }
+      if (g->merged) { try { hip_cohort_drain(g->cohort); } catch (...) {} idle_cohorts.push_back(g->cohort); }
+      { std::lock_guard<std::mutex> gl(a->mu); for (Dev* d : g->devs) a->free_workers.push_back(d); }
+      groups.erase(groups.begin() + (long)gi); freed = true;
+    }
+    if (freed) {
+      a->cv.notify_all();
+      sched.fibers.erase(std::remove_if(sched.fibers.begin(), sched.fibers.end(), [](const std::unique_ptr<Fiber>& f) { return f->done; }), sched.fibers.end());
+    }
+    _mm_pause();
+  }
+  cur = nullptr;
+  for (dp::Cohort* c : idle_cohorts) hip_cohort_free(c);
+}
+int32_t async_submit(dp_async* a, dp_ticket* t, dp_ticket** out) {
+  *out = t;
+  t->t_submit = std::chrono::steady_clock::now();
+  { std::lock_guard<std::mutex> g(a->mu); a->queue.push_back(t); a->qsize++; }
+  a->cv.notify_one();
+  return DP_OK;
+}
+}  // namespace
+int32_t dp_async_create(dp_ctx* ctx, int32_t max_in_flight, size_t worker_arena_bytes, dp_async** out) {
+  return guard([&] {
+    DP_REQUIRE(ctx && out && max_in_flight >= 1 && max_in_flight <= 4096, DP_ERR_ARG, "dp_async_create: 1..4096 calls in flight");
+    std::unique_ptr<dp_async> a(new dp_async());
+    a->ctx = ctx; a->max_in_flight = (size_t)max_in_flight; a->arena = worker_arena_bytes ? worker_arena_bytes : (size_t(512) << 20);
+    if (const char* e = getenv("DP_ASYNC_GROUP")) a->group_max = (size_t)std::max(1, atoi(e));
+    if (const char* e = getenv("DP_ASYNC_LINGER_US")) a->linger_us = std::max(0.0, atof(e));
+    if (const char* e = getenv("DP_ASYNC_GROUPS_PER_THREAD")) a->groups_per_thread = (size_t)std::max(1, atoi(e));
+    CtxLock lk(ctx);
+    size_t fr = 0, tot = 0; hip_mem_info(ctx->device_id, &fr, &tot);
+    const size_t fit = (size_t)(0.9 * (double)fr) / (a->arena + (size_t(16) << 20));
+    DP_REQUIRE(fit >= 1, DP_ERR_OOM, "dp_async_create: not one worker arena fits in the free device memory");
+    a->max_in_flight = std::min(a->max_in_flight, fit);
+    for (size_t i = 0; i < a->max_in_flight; i++) {
+      std::unique_ptr<Dev> w(make_hip_worker(ctx->device_id, a->arena));
+      try { hip_dev_pcs_share(w.get(), ctx->dev); } catch (const DpError&) {}  // (no dp_pcs_setup yet: the PCS calls of this engine will say so)
+      a->free_workers.push_back(w.get()); a->workers.push_back(std::move(w));
+    }
+    const char* te = getenv("DP_HOST_THREADS");
+    size_t nth = te ? (size_t)std::max(1, atoi(te)) : (size_t)std::max(1.0, host_cpu_budget() - 2.0);
+    nth = std::min<size_t>(std::min<size_t>(nth, 22), a->max_in_flight);
+    for (size_t i = 0; i < nth; i++) a->threads.emplace_back(async_thread, a.get());
+    *out = a.release();
+  });
+}
+int32_t dp_async_destroy(dp_async* a) {
+  return guard([&] {
+    if (a && getenv("DP_TIMING") && atoi(getenv("DP_TIMING")) && a->njobs.load())
+      fprintf(stderr, "[dp timing] async engine: %zu calls in %zu groups (%zu merged); per call %.1f us queued before it ran, %.1f us inside\n", a->njobs.load(), a->ngroups.load(), a->nmerged.load(),
+              (double)a->queue_us.load() / (double)a->njobs.load(), (double)a->body_us.load() / (double)a->njobs.load());
+    delete a;
+  });
+}
+int32_t dp_async_stats(dp_async* a, size_t* calls, size_t* groups, size_t* merged_calls, size_t* workers) {
+  return guard([&] { DP_REQUIRE(a, DP_ERR_ARG, "null engine"); if (calls) *calls = a->njobs.load(); if (groups) *groups = a->ngroups.load(); if (merged_calls) *merged_calls = a->nmerged.load(); if (workers) *workers = a->workers.size(); });
+}
+int32_t dp_poll(dp_ticket* t) { if (!t) return DP_ERR_ARG; const int s = t->state.load(std::memory_order_acquire); if (s < 0) g_err = t->err; return s; }
+int32_t dp_wait(dp_ticket* t) {
+  if (!t) return DP_ERR_ARG;
+  for (unsigned spin = 0;; spin++) { const int s = dp_poll(t); if (s != 0) return s < 0 ? s : DP_OK; if (spin < 200) _mm_pause(); else std::this_thread::sleep_for(std::chrono::microseconds(20)); }
+}
+int32_t dp_ticket_words(dp_ticket* t, int32_t which, uint64_t** words, size_t* nwords) {
+  return guard([&] {
+    DP_REQUIRE(t && words && nwords && (which == 0 || which == 1), DP_ERR_ARG, "bad arguments");
+    DP_REQUIRE(t->state.load(std::memory_order_acquire) == 1, DP_ERR_ARG, "dp_ticket_words: the call has not completed successfully");
+    *words = copy_out(t->words[which]); *nwords = t->words[which].size();
+  });
+}
+int32_t dp_ticket_values(dp_ticket* t, uint64_t* values, size_t nvalues) {
+  return guard([&] {
+    DP_REQUIRE(t && values, DP_ERR_ARG, "bad arguments");
+    DP_REQUIRE(t->state.load(std::memory_order_acquire) == 1 && nvalues <= t->finals.size(), DP_ERR_ARG, "dp_ticket_values: not completed, or more values asked than the call produced");
+    memcpy(values, t->finals.data(), nvalues * 8);
+  });
+}
+int32_t dp_ticket_commit(dp_ticket* t, dp_commit** out, uint64_t root[4]) {
+  return guard([&] {
+    DP_REQUIRE(t && out, DP_ERR_ARG, "bad arguments");
+    DP_REQUIRE(t->state.load(std::memory_order_acquire) == 1 && t->commit, DP_ERR_ARG, "dp_ticket_commit: not a completed dp_pcs_commit_submit");
+    *out = t->commit; t->commit = nullptr;
+    if (root) for (int k = 0; k < 4; k++) root[k] = t->root[k];
+  });
+}
+int32_t dp_ticket_free(dp_ticket* t) {
+  return guard([&] {
+    if (!t) return;
+    DP_REQUIRE(t->state.load(std::memory_order_acquire) != 0, DP_ERR_ARG, "dp_ticket_free: the call is still running");
+    DP_REQUIRE(!t->commit && !t->buf, DP_ERR_ARG, "dp_ticket_free: take the commitment / table first (dp_ticket_commit, dp_ticket_buf)");
+    delete t;
+  });
+}
+int32_t dp_sumcheck_prove_submit(dp_async* a, uint32_t nv, const dp_buf* const* tables, int32_t ntables, const int32_t* term_degree, const int32_t* term_tables,
+                                 const uint64_t* term_coeffs, int32_t nterms, dp_transcript* t, dp_ticket** ticket) {
+  return guard([&] {
+    DP_REQUIRE(a && tables && term_degree && term_tables && term_coeffs && t && ticket && ntables > 0 && nterms > 0 && nv > 0 && nv < 48, DP_ERR_ARG, "bad arguments");
+    auto vp = std::make_shared<DevVP>(nv);
+    read_terms(*vp, tables, ntables, term_degree, term_tables, nterms, term_coeffs);
+    std::unique_ptr<dp_ticket> tk(new dp_ticket());
+    uint64_t h = sig_mix(1, nv); for (const DBuf& b : vp->tabs) h = sig_buf(h, b); for (auto& tm : vp->terms) { h = sig_mix(h, (uint64_t)tm.k); for (int j = 0; j < tm.k; j++) h = sig_mix(h, (uint64_t)tm.t[j]); }
+    tk->sig = h;
+    tk->body = [vp, t, ntables](Dev& dev, dp_ticket& me) {
+      SumcheckOut so = sumcheck_prove(dev, *vp, t->t);
+      Writer w; w.iop(so.proof); me.words[0] = std::move(w.w);
+      for (int i = 0; i < ntables; i++) { me.finals.push_back(so.finals[i].c0); me.finals.push_back(so.finals[i].c1); }
+    };
+    async_submit(a, tk.release(), ticket);
+  });
+}
+int32_t dp_logup_prove_submit(dp_async* a, const dp_buf* const* columns, int32_t ncols, int32_t cpi, const dp_buf* mult, const uint64_t cc[2], const uint64_t csc[2],
+                              dp_transcript* t, dp_ticket** ticket) {
+  return guard([&] {
+    DP_REQUIRE(a && columns && ncols > 0 && cc && csc && t && ticket && cpi > 0, DP_ERR_ARG, "bad arguments");
+    auto in = std::make_shared<LogUpInputDev>(); in->is_table = mult != nullptr; in->columns_per_instance = cpi;
+    for (int i = 0; i < ncols; i++) { DP_REQUIRE(columns[i], DP_ERR_ARG, "null column"); in->columns.push_back(columns[i]->b); }
+    if (mult) { DP_REQUIRE(!mult->b.ext && mult->b.n == in->columns[0].n, DP_ERR_SHAPE, "multiplicities shape"); in->multiplicities = mult->b; }
+    in->constant_challenge = read_point(cc, 1)[0]; in->column_separation_challenge = read_point(csc, 1)[0];
+    std::unique_ptr<dp_ticket> tk(new dp_ticket());
+    uint64_t h = sig_mix(2, (uint64_t)cpi); h = sig_mix(h, mult ? 1 : 0); for (const DBuf& b : in->columns) h = sig_buf(h, b);
+    tk->sig = h;
+    tk->body = [in, t](Dev& dev, dp_ticket& me) { LogUpProof p = logup_batch_prove(dev, *in, t->t); Writer w; w.logup(p); me.words[0] = std::move(w.w); };
+    async_submit(a, tk.release(), ticket);
+  });
+}
+/* the two table primitives a Dense layer's prover runs around its sumcheck (dense.rs:423-561): their results come back through the ticket */
+int32_t dp_mle_fix_high_submit(dp_async* a, const dp_buf* m, size_t rows, size_t cols, const uint64_t* point, dp_ticket** ticket) {
+  return guard([&] {
+    DP_REQUIRE(a && m && point && ticket && is_pow2(rows) && is_pow2(cols) && !m->b.ext && m->b.n == rows * cols, DP_ERR_SHAPE, "fix_high: bad matrix shape");
+    auto p = std::make_shared<std::vector<Ext>>(read_point(point, dp_ceil_log2(rows)));
+    const DBuf mb = m->b;
+    std::unique_ptr<dp_ticket> tk(new dp_ticket());
+    tk->sig = sig_mix(sig_mix(5, rows), cols);
+    tk->body = [mb, rows, cols, p](Dev& dev, dp_ticket& me) { DBuf b = dev.alloc_persistent(cols, true); dev.fix_high(b, mb, rows, cols, p->data()); me.buf = new dp_buf{b}; };
+    async_submit(a, tk.release(), ticket);
+  });
+}
+int32_t dp_mle_eval_submit(dp_async* a, const dp_buf* f, const uint64_t* point, uint32_t k, dp_ticket** ticket) {
+  return guard([&] {
+    DP_REQUIRE(a && f && point && ticket, DP_ERR_ARG, "bad arguments");
+    DP_REQUIRE(k < 48 && f->b.n == (size_t(1) << k), DP_ERR_SHAPE, "MLE size does not match the point");
+    auto p = std::make_shared<std::vector<Ext>>(read_point(point, k));
+    const DBuf fb = f->b;
+    std::unique_ptr<dp_ticket> tk(new dp_ticket());
+    tk->sig = sig_buf(sig_mix(6, k), fb);
+    tk->body = [fb, k, p](Dev& dev, dp_ticket& me) { Ext r; dev.mle_eval_batch(&fb, 1, p->data(), k, &r); me.finals.push_back(r.c0); me.finals.push_back(r.c1); };
+    async_submit(a, tk.release(), ticket);
+  });
+}
+int32_t dp_ticket_buf(dp_ticket* t, dp_buf** out) {
+  return guard([&] {
+    DP_REQUIRE(t && out, DP_ERR_ARG, "bad arguments");
+    DP_REQUIRE(t->state.load(std::memory_order_acquire) == 1 && t->buf, DP_ERR_ARG, "dp_ticket_buf: not a completed dp_mle_fix_high_submit");
+    *out = t->buf; t->buf = nullptr;
+  });
+}
+int32_t dp_pcs_commit_submit(dp_async* a, const dp_buf* poly, dp_ticket** ticket) {
+  return guard([&] {
+    DP_REQUIRE(a && poly && ticket, DP_ERR_ARG, "bad arguments");
+    std::unique_ptr<dp_ticket> tk(new dp_ticket());
+    const DBuf b = poly->b;
+    tk->sig = sig_buf(3, b);
+    tk->body = [b](Dev& dev, dp_ticket& me) { DevCommit c = dev.commit(b, true); for (int k = 0; k < 4; k++) me.root[k] = c.tree.root.v[k]; me.commit = new dp_commit{c}; };
+    async_submit(a, tk.release(), ticket);
+  });
+}
+int32_t dp_pcs_batch_open_submit(dp_async* a, const dp_commit* const* comms, int32_t n, const uint64_t* points_flat, const uint64_t* evals, dp_transcript* t, dp_ticket** ticket) {
+  return guard([&] {
+    DP_REQUIRE(a && comms && n > 0 && points_flat && evals && t && ticket, DP_ERR_ARG, "bad arguments");
+    std::vector<unsigned> nvs; for (int i = 0; i < n; i++) { DP_REQUIRE(comms[i], DP_ERR_ARG, "null commitment"); nvs.push_back(comms[i]->c.nv); }
+    auto pts = std::make_shared<std::vector<std::vector<Ext>>>(); auto evs = std::make_shared<std::vector<Ext>>();
+    read_claims(n, points_flat, evals, nvs, *pts, *evs);
+    std::vector<const DevCommit*> cs; for (int i = 0; i < n; i++) cs.push_back(&comms[i]->c);
+    std::unique_ptr<dp_ticket> tk(new dp_ticket());
+    uint64_t h = sig_mix(4, (uint64_t)n); for (int i = 0; i < n; i++) h = sig_mix(sig_mix(h, nvs[i]), comms[i]->c.is_base ? 1 : 2);
+    tk->sig = h;
+    tk->body = [cs, pts, evs, t](Dev& dev, dp_ticket& me) {
+      std::vector<OpenClaim> oc; for (size_t i = 0; i < cs.size(); i++) oc.push_back({cs[i], (*pts)[i], (*evs)[i]});
+      BasefoldProof p = pcs_batch_open(dev, 64, oc, t->t);
+      Writer w; w.basefold(p); me.words[0] = std::move(w.w);
+    };
+    async_submit(a, tk.release(), ticket);
   });
 }
 int32_t dp_pcs_batch_verify_evals(size_t max_poly_size, const uint64_t* roots, const uint32_t* num_vars, const int32_t* is_base, int32_t n_polys, const uint64_t* points_flat,

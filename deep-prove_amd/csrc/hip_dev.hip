@@ -29,6 +29,7 @@
 #include <type_traits>
 #include <chrono>
 #include <map>
+#include <mutex>
 #include <vector>
 #include <string>
 
@@ -43,11 +44,10 @@ namespace dp {
 // Grid size for grid-stride kernels. DP_MAX_GRID bounds every launch so that, with several proofs in flight on one GPU,
 // a large kernel of one proof cannot occupy every wave slot while another proof's latency-critical one-block kernels
 // wait for a CU.
-static int g_max_grid = [] { const char* e = getenv("DP_MAX_GRID"); return e ? atoi(e) : 1 << 30; }();
 static inline int grid_for(size_t n, int cap = 2048) {
   size_t b = (n + TPB - 1) / TPB;
   if (b < 1) b = 1;
-  return (int)std::min<size_t>(std::min<size_t>(b, cap), (size_t)g_max_grid);
+  return (int)std::min<size_t>(b, cap);
 }
 
 struct ProfRec { const char* name; double bytes; hipEvent_t a, b; };
@@ -71,7 +71,8 @@ constexpr int SHARED_MAXT = 256;
 #define DP_SET_LDS(kern, maxt, bytes) set_lds_<kern, maxt, KF_NONE>(KArgs<decltype(&kern)>(), (int)(bytes))
 #define DP_SET_LDS_ONE(kern, maxt, bytes) do { set_lds_<kern, maxt, KF_CLAIM>(KArgs<decltype(&kern)>(), (int)(bytes)); set_lds_<kern, SHARED_MAXT, KF_PRIO>(KArgs<decltype(&kern)>(), (int)(bytes)); } while (0)
 
-static const bool g_host_stats = getenv("DP_TIMING") && atoi(getenv("DP_TIMING"));
+static const int g_timing_level = getenv("DP_TIMING") ? atoi(getenv("DP_TIMING")) : 0;  // 1: host / cohort accounting on stderr; 2: also launches by kernel, long host stretches, device cycle counters of the persistent sumcheck
+static const bool g_host_stats = g_timing_level > 0;
 // DP_WAIT_YIELD=1: a host thread that waits for the device outside a fiber gives its CPU away (sched_yield) instead of spinning — for
 // seam-level hosts that run more proving threads than they have cores (tests/support/seam_bench.c)
 static const bool g_wait_yield = getenv("DP_WAIT_YIELD") && atoi(getenv("DP_WAIT_YIELD"));
@@ -118,18 +119,7 @@ struct Cohort {
     t_fire_ = t; have_fire_ = true;
   }
 
-  // DP_COHORT_XCD=1 (experiment, default off): the cohort's stream is confined to ONE XCD (32 CUs, its own L2) with a CU
-  // mask, cohorts dealt round robin over the 8 XCDs — every kernel of a proof then runs under one coherent L2 and cohorts on
-  // different XCDs cannot take each other's CUs. Mask bit i of a multi-XCD device addresses XCD i % 8, CU i / 8.
   explicit Cohort(size_t ring_bytes = size_t(32) << 20) : ring_cap(ring_bytes) {
-    static std::atomic<unsigned> next_xcd{0};
-    const char* xe = getenv("DP_COHORT_XCD");
-    if (xe && atoi(xe)) {
-      unsigned x = next_xcd.fetch_add(1) % 8;
-      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (unsigned bit = x; bit < 256; bit += 8) mask[bit / 32] |= 1u << (bit % 32);
-      HIP_CHECK(hipExtStreamCreateWithCUMask(&s, 8, mask));
-    } else
     HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     HIP_CHECK(hipHostMalloc((void**)&ring, ring_cap, hipHostMallocMapped | hipHostMallocCoherent));
     HIP_CHECK(hipHostGetDevicePointer((void**)&ring_dev, ring, 0));
@@ -276,29 +266,17 @@ class HipDev : public Dev {
   bool zerocopy_ = true;  // DP_NO_ZEROCOPY=1 falls back to hipMemcpyAsync + hipStreamSynchronize
   bool persist_ = true;   // DP_NO_PERSIST=1 disables the persistent sumcheck kernel
   size_t excl_ = 0;       // dynamic LDS requested by one-workgroup kernels to keep a CU to themselves (DP_NO_EXCLUSIVE_CU=1: none)
-  // Experiment knobs for the cohort regime (defaults = the measured configuration): with 192 proofs in flight
-  // the exclusive workgroups hold ~100 CUs on average and the batched Merkle tail of a cohort asks for 360 at once.
-  //   DP_COHORT_EXCL=0        members of a cohort do not reserve the CU (single proofs still do)
-  //   DP_TAIL_MANY_EXCL=0     batched tails (several trees per launch) do not reserve the CU
-  //   DP_TAIL_MANY_THREADS=n  workgroup size of batched tails (256 / 512 / 1024): 256 threads x 128 VGPRs = a quarter of a CU
-  bool cohort_excl_ = !(getenv("DP_COHORT_EXCL") && !atoi(getenv("DP_COHORT_EXCL")));
-  bool tail_many_excl_ = !(getenv("DP_TAIL_MANY_EXCL") && !atoi(getenv("DP_TAIL_MANY_EXCL")));
-  int tail_many_threads_ = [] { const char* e = getenv("DP_TAIL_MANY_THREADS"); int v = e ? atoi(e) : 1024; return (v == 256 || v == 512) ? v : 1024; }();
-  size_t excl_now() const { return (co_ && !cohort_excl_) ? 0 : excl_; }
+  size_t excl_now() const { return excl_; }
   // throughput mode (several proofs in flight): one-workgroup kernels reserve nothing and run as 256-thread workgroups with
   // raised wave priority (KF_PRIO). DP_SHARED_TAILS=0 restores the whole-CU workgroups of round 1, DP_SHARED_THREADS = 64 / 128 / 256.
   bool shared_tails_ = !(getenv("DP_SHARED_TAILS") && !atoi(getenv("DP_SHARED_TAILS")));
   int shared_threads_ = [] { const char* e = getenv("DP_SHARED_THREADS"); int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 256) ? v : 256; }();  // <= SHARED_MAXT
   bool throughput_mode_ = false;
   bool shared_now() const { return throughput_mode_ && shared_tails_; }
-  //   DP_COHORT_PERSIST_THREADS=n  workgroup size of the one-workgroup sumcheck kernels of cohort members (256 / 512 / 1024;
-  //                                default: 1024 when the CU is reserved, else by the amount of work)
-  int cohort_persist_threads_ = [] { const char* e = getenv("DP_COHORT_PERSIST_THREADS"); int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : 0; }();
   int persist_threads(size_t work) const {
-    if (co_ && cohort_persist_threads_) return cohort_persist_threads_;
     return excl_now() ? 1024 : work >= 2048 ? 1024 : work >= 512 ? 512 : 256;  // exclusive CU: always the full 16 waves
   }
-  unsigned long long* scdbg_ = nullptr;  // DP_SC_DEBUG=1: device cycle counters of the persistent sumcheck kernel
+  unsigned long long* scdbg_ = nullptr;  // DP_TIMING=2: device cycle counters of the persistent sumcheck kernel
   unsigned long long* hmail_ = nullptr;      // host view of the challenge mailbox [seq, c0, c1]
   unsigned long long* hmail_dev_ = nullptr;  // device view
   struct ScSession { bool active = false; int ntabs = 0; size_t n = 0; unsigned long long seq = 0; std::vector<Ext*> a, b; bool nextA = true;
@@ -309,8 +287,6 @@ class HipDev : public Dev {
   unsigned long long* hmflag_dev_ = nullptr;  // device view
   unsigned long long last_tag_multi_[MULTI_MAX_WG];
   bool multi_ = true;  // DP_NO_MULTI=1 disables the multi-workgroup phase of large sumchecks
-  bool multi_mid_ = getenv("DP_MULTI_MID") && atoi(getenv("DP_MULTI_MID"));
-  bool persist_global_mid_ = getenv("DP_PERSIST_GLOBAL_MID") && atoi(getenv("DP_PERSIST_GLOBAL_MID"));
   static bool persist_flag_env(const char* name) { const char* e = getenv(name); return !(e && atoi(e)); }
   // all G workgroups have published round `seq`: every slot's tag matches its payload (same protocol as wait_flag)
   void wait_flags_multi(unsigned long long seq, size_t nwords, int G, size_t slot_words) {
@@ -536,7 +512,7 @@ class HipDev : public Dev {
     multi_ = persist_flag_env("DP_NO_MULTI");
     zerocopy_ = !(getenv("DP_NO_ZEROCOPY") && atoi(getenv("DP_NO_ZEROCOPY")));
     persist_ = zerocopy_ && !(getenv("DP_NO_PERSIST") && atoi(getenv("DP_NO_PERSIST")));
-    if (getenv("DP_SC_DEBUG") && atoi(getenv("DP_SC_DEBUG"))) { HIP_CHECK(hipMalloc((void**)&scdbg_, 64)); HIP_CHECK(hipMemset(scdbg_, 0, 64)); }
+    if (g_timing_level > 1) { HIP_CHECK(hipMalloc((void**)&scdbg_, 64)); HIP_CHECK(hipMemset(scdbg_, 0, 64)); }
     HIP_CHECK(hipMalloc((void**)&dres_, RES_WORDS * 8));
     HIP_CHECK(hipMalloc((void**)&fused_ticket_, 64)); HIP_CHECK(hipMemset(fused_ticket_, 0, 64));
     HIP_CHECK(hipHostMalloc(&hstage_, STAGE_BYTES + DESC_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
@@ -551,7 +527,6 @@ class HipDev : public Dev {
 #ifdef DP_DIAG_SKIP_HASH
     { int sk = getenv("DP_DEBUG_SKIP_HASH") ? atoi(getenv("DP_DEBUG_SKIP_HASH")) : 0; if (sk) HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_dbg_skip_hash), &sk, sizeof(int))); }
 #endif
-    { int ps = getenv("DP_POLL_SLEEP") ? std::max(0, atoi(getenv("DP_POLL_SLEEP"))) : 1; HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_poll_sleep), &ps, sizeof(int))); }
     DP_SET_LDS_ONE((k_sc_persist_lds<false>), 1024, (int)SC_LDS_MAX);
     DP_SET_LDS_ONE((k_sc_persist_lds<true>), 1024, (int)SC_LDS_MAX);
     excl_ = (getenv("DP_NO_EXCLUSIVE_CU") && atoi(getenv("DP_NO_EXCLUSIVE_CU"))) ? 0 : EXCL_LDS;
@@ -577,6 +552,7 @@ class HipDev : public Dev {
     pcs_tabs_.reset();
     if (arena_) hipFree(arena_);
     if (dres_) hipFree(dres_);
+    for (auto& kv : plimbo_) hipFree(kv.second);  // (blocks in the device's pool stay for the next context)
     if (dshare_) hipFree(dshare_);
     if (dgather_) hipFree(dgather_);
     if (fused_ticket_) hipFree(fused_ticket_);
@@ -630,13 +606,13 @@ class HipDev : public Dev {
     if (!g_host_stats) return;
     fprintf(stderr, "[dp timing] device context: %zu launches, %.1f us of host time per launch (%.1f ms total), %zu device waits, %zu fiber yields; host work between waits %.1f ms, inside waits %.1f ms\n", nlaunch_, nlaunch_ ? launch_us_ / nlaunch_ : 0.0, launch_us_ / 1000.0, nwait_, nyield_, work_us_ / 1000.0, waitlat_us_ / 1000.0);
     if (sp_slot_) fprintf(stderr, "[dp timing] host sponge: %llu requests served for this context so far\n", (unsigned long long)sp_slot_->nserved.load());
-    if (getenv("DP_LAUNCH_NAMES")) {  // launches by kernel since the last dump (DP_TIMING=1 DP_LAUNCH_NAMES=1)
+    if (g_timing_level > 1) {  // launches by kernel since the last dump (DP_TIMING=2)
       std::vector<std::pair<size_t, const char*>> v; for (auto& kv : by_name_) v.push_back({kv.second, kv.first});
       std::sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.first > b.first; });
       for (auto& e : v) fprintf(stderr, "[dp launches] %6zu  %s\n", e.first, e.second);
     }
     by_name_.clear();
-    if (getenv("DP_HOST_CHUNKS")) for (auto& c : chunks_) fprintf(stderr, "[dp chunk] before wait %zu: %.0f us of host work, launches %s .. %s\n", c.wait, c.us, c.first ? c.first : "-", c.last ? c.last : "-");
+    if (g_timing_level > 1) for (auto& c : chunks_) fprintf(stderr, "[dp chunk] before wait %zu: %.0f us of host work, launches %s .. %s\n", c.wait, c.us, c.first ? c.first : "-", c.last ? c.last : "-");
     chunks_.clear();
     launch_us_ = 0; nlaunch_ = nwait_ = nyield_ = 0; work_us_ = waitlat_us_ = 0; have_exit_ = false;
   }
@@ -680,15 +656,49 @@ class HipDev : public Dev {
   DBuf alloc(size_t n, bool ext) override { DBuf b; b.n = n; b.ext = ext; b.p = arena_alloc(std::max<size_t>(n, 1) * (ext ? 16 : 8)); return b; }
   size_t mark() override { return arena_off_; }
   void release(size_t m) override { arena_off_ = m; }
+  // Persistent buffers (tables a caller uploads, commitments' trees, fixed matrices) come from hipMalloc; a seam-level host uploads and frees dozens
+  // of small columns per proof, hipMalloc costs ~100 us and hipFree waits for the device. Freed blocks of up to 64 MB are therefore kept in ONE pool per
+  // device (g_persist_pool: a block allocated by an engine worker is usually freed through the caller's context; at most 2 GB, DP_PERSIST_POOL_BYTES) and handed
+  // out again for requests of the same rounded size. A freed block may still be read by launches its context has queued: it waits in the context's
+  // `plimbo_` and enters the pool after the next stream_wait the context performs for that purpose (one per PLIMBO_MAX frees, or when a request finds
+  // the pool empty) — a free is O(1).
+  struct PersistPool { std::mutex mu; std::multimap<size_t, void*> blocks; size_t bytes = 0; size_t cap = [] { const char* e = getenv("DP_PERSIST_POOL_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t(2) << 30); }(); };
+  static PersistPool& persist_pool_(int device) { static PersistPool pools[16]; return pools[device & 15]; }
+  std::vector<std::pair<size_t, void*>> plimbo_;
+  static constexpr size_t PLIMBO_MAX = 64;
+  static size_t persist_round_(size_t n, bool ext) { return (std::max<size_t>(n, 1) * (ext ? 16 : 8) + 4095) & ~size_t(4095); }
+  void plimbo_flush_() {
+    if (plimbo_.empty()) return;
+    stream_wait();
+    PersistPool& pp = persist_pool_(device_);
+    std::lock_guard<std::mutex> g(pp.mu);
+    for (auto& kv : plimbo_) { if (pp.bytes + kv.first <= pp.cap) { pp.blocks.emplace(kv.first, kv.second); pp.bytes += kv.first; } else hipFree(kv.second); }
+    plimbo_.clear();
+  }
   DBuf alloc_persistent(size_t n, bool ext) override {
     DBuf b; b.n = n; b.ext = ext;
-    const size_t bytes = (std::max<size_t>(n, 1) * (ext ? 16 : 8) + 255) & ~size_t(255);
+    const size_t bytes = persist_round_(n, ext);
+    PersistPool& pp = persist_pool_(device_);
+    for (int attempt = 0; attempt < 2; attempt++) {
+      {
+        std::lock_guard<std::mutex> g(pp.mu);
+        auto it = pp.blocks.find(bytes);
+        if (it != pp.blocks.end()) { b.p = it->second; pp.blocks.erase(it); pp.bytes -= bytes; return b; }
+      }
+      if (attempt == 0 && !plimbo_.empty()) plimbo_flush_(); else break;
+    }
     HIP_CHECK(hipSetDevice(device_));
     HIP_CHECK(hipMalloc(&b.p, bytes));
     return b;
   }
   void free_persistent(DBuf& b) override {
     if (!b.p) return;
+    const size_t bytes = persist_round_(b.n, b.ext);
+    if (bytes <= (size_t(64) << 20)) {
+      plimbo_.emplace_back(bytes, b.p); b.p = nullptr;
+      if (plimbo_.size() >= PLIMBO_MAX) plimbo_flush_();
+      return;
+    }
     hipStreamSynchronize(s_); hipFree(b.p); b.p = nullptr;
   }
   // host <-> device copies go through the pinned staging buffer: hipMemcpyAsync on pageable memory pins the user pages
@@ -931,10 +941,8 @@ class HipDev : public Dev {
                std::vector<std::vector<Ext>>& msgs, std::vector<Ext>& point, Ext* finals) override {
     // latency mode (one proof on the GPU) keeps the host sponge: a round trip to the host costs 23-35 us per round, the 8-lane
     // wave sponge ~50-70 us (3-4 permutations of ~16 us: one wave on a dependent chain) — measured on the 2^24 sumcheck, whose
-    // 14-round hand-over phase takes 0.49 ms with the host sponge and 0.99 ms with DP_SC_HANDOVER=1 (profiles/r02_sumcheck24_handover.txt)
-    static const bool handover_env = getenv("DP_SC_HANDOVER") && atoi(getenv("DP_SC_HANDOVER"));
-    const bool handover = handover_env && devfs_env_ < 0 && r && tabs[0].n >= 8192;
-    if (!(devfs_ || handover) || !persist_ || !zerocopy_ || sess_.active) return false;
+    // 14-round hand-over phase took 0.49 ms with the host sponge and 0.99 ms with the device sponge of round 2 (profiles/r02_sumcheck24_handover.txt)
+    if (!devfs_ || !persist_ || !zerocopy_ || sess_.active) return false;
     if (nt > MAX_TABS || nterms > MAX_TERMS || nt <= 0 || nterms <= 0 || md < 1 || md > (unsigned)SC_MAXK) return false;
     size_t n_in = tabs[0].n;
     for (int i = 0; i < nt; i++) if (tabs[i].n != n_in) return false;
@@ -1252,11 +1260,11 @@ class HipDev : public Dev {
       read_terms();
       return;
     }
-    if (!share_x_ && (!r || multi_mid_) && multi_ && persist_ && n_after >= MULTI_MIN_N && n_in <= MULTI_MAX_N && nraw * 2 * MULTI_MAX_WG <= RES_WORDS) {
+    if (!share_x_ && !r && multi_ && persist_ && n_after >= MULTI_MIN_N && n_in <= MULTI_MAX_N && nraw * 2 * MULTI_MAX_WG <= RES_WORDS) {
       // ---- multi-workgroup phase: G workgroups own contiguous slices, fold until the tables are MULTI_TARGET_N long. It may
       // begin in the middle of a sumcheck (r given: the streaming rounds of a large sumcheck hand over as soon as the tables
       // fit): every workgroup then first folds its slice with the pending challenge. Measured on the 2^24 sumcheck that costs
-      // 75 us per round (32 workgroups x PCIe mailbox) against 23 us for one workgroup in LDS, so it is off unless DP_MULTI_MID=1:
+      // 75 us per round (32 workgroups x PCIe mailbox) against 23 us for one workgroup in LDS, so a sumcheck only ENTERS this phase at its first round (round 2 measured the mid-sumcheck entry and rejected it):
       // the hand-over from the streaming rounds goes to the device-side transcript instead (sc_tail).
       flush_pending_eq();
       int G = (int)std::min<size_t>(MULTI_MAX_WG, n_after / 512);
@@ -1285,9 +1293,9 @@ class HipDev : public Dev {
     }
     // A sumcheck that arrives here in the middle (r pending: the streaming rounds of a large one are handing over) enters the
     // persistent kernel only once its tables fit in LDS: the global-memory variant costs 35 us per round on 2^15..2^13-entry
-    // tables against ~20 us for another streaming / one-launch round (DP_PERSIST_GLOBAL_MID=1 restores the early hand-over).
+    // tables against ~20 us for another streaming / one-launch round (round 2 measured the early hand-over and rejected it).
     const bool lds_fits = (size_t)nt * (n_in / 2) * 16 <= sc_lds_max();
-    const bool persist_here = !share_x_ && persist_ && n_after <= SC_PERSIST_MAX && n_after >= 4 && 2 * nraw <= RES_WORDS && (!r || lds_fits || persist_global_mid_ || throughput_mode_);
+    const bool persist_here = !share_x_ && persist_ && n_after <= SC_PERSIST_MAX && n_after >= 4 && 2 * nraw <= RES_WORDS && (!r || lds_fits || throughput_mode_);
     const bool take_persistent = !sess_.active && persist_here;
     if (pend_eq_.p && !(take_persistent && !r)) flush_pending_eq();
     if (persist_here) {
@@ -1517,7 +1525,7 @@ class HipDev : public Dev {
       wait_flag(seq, 4);
       return;
     }
-    nb_ = 0; if (!shared_now() && !tail_many_excl_) { DPL_B(k_merkle_tail, 1024, KF_NONE, dim3((unsigned)nd), dim3(tail_many_threads_), 0, dd, dres_, (u64*)nullptr, (unsigned long long*)nullptr, 0ull); } else DPL_ONE(k_merkle_tail, dim3((unsigned)nd), tail_many_threads_, 0, dd, dres_, (u64*)nullptr, (unsigned long long*)nullptr, 0ull);
+    nb_ = 0; DPL_ONE(k_merkle_tail, dim3((unsigned)nd), 1024, 0, dd, dres_, (u64*)nullptr, (unsigned long long*)nullptr, 0ull);
     fetch(4 * nd);
   }
   // layers of at most this many digests are finished by k_merkle_tail (one workgroup, no relaunch between layers); wider
@@ -1527,7 +1535,6 @@ class HipDev : public Dev {
   // Layers with at most lp_max_ parent nodes use the 8-lanes-per-node kernel (lowest latency per layer, but ~2.2x the
   // VALU work of one node per lane and a grid 8x as large: with many proofs in flight those grids fill the chip and
   // every other stream queues behind them), wider layers hash one node per lane. DP_MERKLE_LP_MAX overrides.
-  int merkle_fuse_ = getenv("DP_MERKLE_FUSE") ? atoi(getenv("DP_MERKLE_FUSE")) : 0;  // layers per launch of k_merkle_layers (0 / 1: off)
   size_t lp_max_ = getenv("DP_MERKLE_LP_MAX") ? strtoull(getenv("DP_MERKLE_LP_MAX"), nullptr, 10) : (size_t(1) << 12);
   // `nodes` must hold 4*(n-1) words; synchronises (root is copied to the host)
   DevTree build_tree_into(const DBuf& leaves, const DBuf& nodes) {
@@ -1539,17 +1546,7 @@ class HipDev : public Dev {
     size_t off = 0, cnt = n / 2;
     while (cnt > TAIL_MAX) {
       size_t next = cnt / 2;
-      if (merkle_fuse_ > 1 && cnt >= 512) {  // several layers per launch (k_merkle_layers): as many as stay above the tail, at most merkle_fuse_
-        int levels = 0;
-        while (levels < merkle_fuse_ && levels < 8 && (cnt >> (levels + 1)) >= TAIL_MAX && (cnt >> (levels + 1)) >= 1) levels++;
-        if (levels >= 2) {
-          nb_ = 0; for (int l = 0; l < levels; l++) nb_ += 96.0 * (double)(cnt >> (l + 1));
-          DPL(k_merkle_layers, dim3((unsigned)(cnt / 512)), dim3(256), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), cnt, levels);
-          for (int l = 0; l < levels; l++) { off += cnt; cnt /= 2; }
-          continue;
-        }
-      }
-      if (next <= lp_max_) { nb_ = 96.0 * next; DPL(k_merkle_layer_lp, dim3((unsigned)std::min<size_t>(std::min<size_t>((next * 8 + 255) / 256, 8192), (size_t)std::max(1, g_max_grid))), dim3(256), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
+      if (next <= lp_max_) { nb_ = 96.0 * next; DPL(k_merkle_layer_lp, dim3((unsigned)std::min<size_t>((next * 8 + 255) / 256, 8192)), dim3(256), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
       else { nb_ = 96.0 * next; DPL(k_merkle_layer, dim3(grid_for(next, 4096)), dim3(TPB), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
       off += cnt; cnt /= 2;
     }
@@ -1568,7 +1565,6 @@ class HipDev : public Dev {
   }
   // stages [s0, s1) of the Moebius transform / DIT NTT of `buf` as LDS-tiled passes (k_butterfly_pass): tiles of 64 KB (2^13 base
   // or 2^12 extension elements); the first pass works on contiguous blocks, later ones on strided tiles of 128-byte segments
-  bool ntt_stagewise_ = getenv("DP_NTT_STAGEWISE") && atoi(getenv("DP_NTT_STAGEWISE"));
   void butterfly_passes(const DBuf& buf, unsigned s0, unsigned s1, bool ntt) {
     const unsigned lgtile = buf.ext ? 12 : 13, lgseg = buf.ext ? 3 : 4;
     const unsigned lgn = dp_ceil_log2(buf.n);
@@ -1599,20 +1595,10 @@ class HipDev : public Dev {
     DBuf tmp = alloc(2 * n, evals.ext);
     copy(co, evals);
     bool E = evals.ext;
-    if (ntt_stagewise_) {
-      for (unsigned s = 0; s < c.nv; s++) {  // K5 evaluations -> multilinear coefficients, one stage per launch (DP_NTT_STAGEWISE=1)
-        if (E) { nb_ = 32.0 * n; DPL(k_mobius_stage<true>, dim3(grid_for(n / 2)), dim3(TPB), co.p, n, s); }
-        else { nb_ = 16.0 * n; DPL(k_mobius_stage<false>, dim3(grid_for(n / 2)), dim3(TPB), co.p, n, s); }
-      }
-    } else butterfly_passes(co, 0, c.nv, false);  // K5 in LDS tiles: 2 passes for 2^20
+    butterfly_passes(co, 0, c.nv, false);  // K5 in LDS tiles: 2 passes for 2^20
     if (E) { nb_ = 48.0 * n; DPL(k_rs_prepare<true>, dim3(grid_for(n)), dim3(TPB), (const void*)co.p, tmp.p, (const u64*)pow7_, c.nv, L_); }
     else { nb_ = 24.0 * n; DPL(k_rs_prepare<false>, dim3(grid_for(n)), dim3(TPB), (const void*)co.p, tmp.p, (const u64*)pow7_, c.nv, L_); }
-    if (ntt_stagewise_) {
-      for (unsigned s = 1; s <= c.nv; s++) {  // K7 remaining DIT stages on 2n points
-        if (E) { nb_ = 64.0 * n; DPL(k_ntt_stage<true>, dim3(grid_for(n)), dim3(TPB), tmp.p, 2 * n, s, (const u64*)tw_, L_); }
-        else { nb_ = 32.0 * n; DPL(k_ntt_stage<false>, dim3(grid_for(n)), dim3(TPB), tmp.p, 2 * n, s, (const u64*)tw_, L_); }
-      }
-    } else butterfly_passes(tmp, 1, c.nv + 1, true);  // K7 stages 1..nv of the 2n-point DIT
+    butterfly_passes(tmp, 1, c.nv + 1, true);  // K7 stages 1..nv of the 2n-point DIT
     bitrev_copy(cw, tmp);            // K6
     bitrev_copy(c.bh_evals, evals);  // K6
     c.tree = build_tree_into(cw, nodes);  // K8 (synchronises: root to host)
@@ -1787,7 +1773,7 @@ class HipDev : public Dev {
         size_t items = folds ? hd[i].n / 4 : hd[i].n / 2;  // loop iterations of the pair: 4 (2) entries of each table per iteration
         // (behind the resident executor a tile costs ~20 us of queue protocol whatever it does: 32 iterations per thread instead of 4)
         const size_t per_blk = (size_t)TPB * 4;
-        size_t nb = std::min<size_t>(std::max<size_t>((items + per_blk - 1) / per_blk, 1), (size_t)std::min(1024, g_max_grid));
+        size_t nb = std::min<size_t>(std::max<size_t>((items + per_blk - 1) / per_blk, 1), (size_t)1024);
         first[i] = nblk; nblk += (unsigned)nb;
         bytes += hd[i].n * (hd[i].fext ? 16.0 : 8.0) + (folds ? hd[i].n * 8.0 : 0.0) + (fac[i].ln ? 0.0 : hd[i].n * 16.0 + (folds ? hd[i].n * 8.0 : 0.0));
       }

@@ -992,8 +992,7 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
   // ... and the activations of the layer loop, as extension words behind the multiplicities (16-byte aligned)
   struct Act { size_t node; bool is_out; const std::vector<int64_t>* v; size_t off; };
   std::vector<Act> acts;
-  static const bool stage_acts = !(getenv("DP_STAGE_ACTIVATIONS") && atoi(getenv("DP_STAGE_ACTIVATIONS")) == 0);  // (0: one upload per layer, as before — for A/B runs)
-  for (size_t id = 0; stage_acts && id < ctx.model.layers.size(); id++) {
+  for (size_t id = 0; id < ctx.model.layers.size(); id++) {
     const int kind = ctx.model.layers[id].kind;
     if (kind == L_DENSE) acts.push_back({id, false, &tr.in[id], 0});
     else if (kind == L_RELU) acts.push_back({id, true, &tr.out[id], 0});

@@ -51,6 +51,45 @@ const char* dp_ctx_name(const dp_ctx* ctx);
  * modes. Call it while no operation of the context is in flight. */
 int32_t dp_ctx_set_throughput_mode(dp_ctx* ctx, int32_t on);
 
+/* ---- asynchronous seam calls: submit / poll forms of dp_pcs_commit, dp_sumcheck_prove, dp_logup_prove and dp_pcs_batch_open.
+ * The reference calls these seams from rayon workers — PCS::commit per witness column (zkml/src/commit/context.rs:79-103,
+ * zkml/src/layers/activation.rs:294-304), one IOPProverState::prove_parallel per layer (sumcheck/src/prover.rs:498-501), batch_prove per lookup
+ * (zkml/src/lookup/logup_gkr/prover.rs:24), one PCS::batch_open per proof (mpcs/src/lib.rs:111-226) — so a host keeps as many calls in flight as it
+ * has threads. An engine lets ONE host thread keep hundreds in flight: a submit returns at once with a ticket; engine threads (DP_HOST_THREADS, default
+ * the usable CPUs - 2) run the calls as fibers on `max_in_flight` worker contexts of the device of `ctx` (each with an arena of `worker_arena_bytes`,
+ * 0 = 512 MB, sharing the PCS tables of `ctx`: call dp_pcs_setup first) in throughput mode, and calls of IDENTICAL SHAPE that are queued together are
+ * proved in lock step with their kernel launches merged (what dp_model_prove_batch does for whole proofs). Outputs are bit-identical to the blocking forms.
+ *  - arguments are read at submit time, except: the tables / columns / commitments must stay alive, and the dp_transcript must not be touched, until the
+ *    ticket has completed (the transcript is advanced by the call, exactly as by the blocking form);
+ *  - dp_poll: 0 = still running, 1 = completed, < 0 = failed with that DP_ERR_* code (dp_last_error() has the message); dp_wait blocks;
+ *  - results of a completed ticket: dp_ticket_words(which = 0) = the seam's proof stream (malloc'ed, dp_free), dp_ticket_values = the fixed-size
+ *    values (dp_sumcheck_prove_submit: the final evaluations, 2 words per table), dp_ticket_commit = the dp_commit and root of a dp_pcs_commit_submit;
+ *  - dp_ticket_free after the results have been taken; dp_async_destroy after every ticket has completed (it waits for queued calls). */
+typedef struct dp_async dp_async;
+typedef struct dp_ticket dp_ticket;
+int32_t dp_async_create(dp_ctx* ctx, int32_t max_in_flight, size_t worker_arena_bytes, dp_async** out);
+int32_t dp_async_destroy(dp_async* a);
+/* counters since creation: calls executed, groups they ran in, calls that ran merged with at least one other, worker contexts */
+int32_t dp_async_stats(dp_async* a, size_t* calls, size_t* groups, size_t* merged_calls, size_t* workers);
+int32_t dp_pcs_commit_submit(dp_async* a, const dp_buf* poly, dp_ticket** ticket);
+/* dp_mle_fix_high / dp_mle_eval as tickets: the fixed table comes back with dp_ticket_buf (free it with dp_buf_free on the engine's context), the evaluation
+ * with dp_ticket_values (2 words) */
+int32_t dp_mle_fix_high_submit(dp_async* a, const dp_buf* matrix, size_t rows, size_t cols, const uint64_t* point, dp_ticket** ticket);
+int32_t dp_mle_eval_submit(dp_async* a, const dp_buf* f, const uint64_t* point, uint32_t k, dp_ticket** ticket);
+int32_t dp_sumcheck_prove_submit(dp_async* a, uint32_t num_vars, const dp_buf* const* tables, int32_t ntables, const int32_t* term_degree,
+                                 const int32_t* term_tables, const uint64_t* term_coeffs, int32_t nterms, dp_transcript* t, dp_ticket** ticket);
+int32_t dp_logup_prove_submit(dp_async* a, const dp_buf* const* columns, int32_t ncols, int32_t cols_per_instance, const dp_buf* multiplicities,
+                              const uint64_t constant_challenge[2], const uint64_t column_separation_challenge[2], dp_transcript* t, dp_ticket** ticket);
+int32_t dp_pcs_batch_open_submit(dp_async* a, const dp_commit* const* comms, int32_t n, const uint64_t* points_flat, const uint64_t* evals,
+                                 dp_transcript* t, dp_ticket** ticket);
+int32_t dp_poll(dp_ticket* t);
+int32_t dp_wait(dp_ticket* t);
+int32_t dp_ticket_words(dp_ticket* t, int32_t which, uint64_t** words, size_t* nwords);
+int32_t dp_ticket_values(dp_ticket* t, uint64_t* values, size_t nvalues);
+int32_t dp_ticket_commit(dp_ticket* t, dp_commit** out, uint64_t root[4]);
+int32_t dp_ticket_buf(dp_ticket* t, dp_buf** out);
+int32_t dp_ticket_free(dp_ticket* t);
+
 /* ---- measurement: per-kernel HIP-event timing on the ctx's launch stream (used by bench.py for the roofline object).
  * dp_profile_report returns a malloc'ed JSON array [{"kernel","launches","total_ms","alg_bytes"}...]; free with dp_free. */
 int32_t dp_profile_enable(dp_ctx* ctx, int32_t on);

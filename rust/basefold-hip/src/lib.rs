@@ -278,5 +278,64 @@ impl PolynomialCommitmentScheme<E> for BasefoldHip {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ asynchronous forms
+/// Submit / poll forms of the two PCS seams (`include/deep_prove_hip.h`, "asynchronous seam calls"). The reference reaches `PCS::commit` from rayon workers
+/// (`zkml/src/commit/context.rs:79-103`): every worker blocks in its own commit, so the number of commits in flight is the size of the thread pool. With an
+/// engine ONE thread submits the commits of every witness column of every proof it is driving and polls the tickets; calls of the same shape that are queued
+/// together run in lock step with merged kernel launches (what `dp_model_prove_batch` does for whole proofs). A `zkml::Prover` patched this way keeps its
+/// control flow — `commit_async(..)` where it called `commit(..)`, `.wait()` where it needs the root for the transcript.
+pub struct AsyncEngine(*mut sys::dp_async);
+unsafe impl Send for AsyncEngine {}
+unsafe impl Sync for AsyncEngine {}
+impl Drop for AsyncEngine { fn drop(&mut self) { unsafe { sys::dp_async_destroy(self.0); } } }
+/// a submitted call; dropping it waits for completion (the engine reads the caller's tables until then)
+pub struct PendingCommit { ticket: *mut sys::dp_ticket, table: Option<DeviceTable>, num_vars: usize, is_base: bool }
+pub struct PendingOpen { ticket: *mut sys::dp_ticket }
+impl AsyncEngine {
+    /// after `BasefoldHip::setup` (the workers share the PCS tables of the context)
+    pub fn new(max_in_flight: usize) -> Result<Self, Error> {
+        let mut h = core::ptr::null_mut();
+        sys::check(unsafe { sys::dp_async_create(ctx(), max_in_flight as i32, 0, &mut h) }).map_err(pcs_err)?;
+        Ok(AsyncEngine(h))
+    }
+    pub fn commit_async(&self, poly: &DenseMultilinearExtension<E>) -> Result<PendingCommit, Error> {
+        let table = upload(poly)?;
+        let mut t = core::ptr::null_mut();
+        sys::check(unsafe { sys::dp_pcs_commit_submit(self.0, table.0, &mut t) }).map_err(pcs_err)?;
+        Ok(PendingCommit { ticket: t, table: Some(table), num_vars: poly.num_vars, is_base: matches!(poly.evaluations, FieldType::Base(_)) })
+    }
+    /// `PCS::batch_open` with `Evaluation::new(i, i, evals[i])` (`zkml/src/commit/context.rs:355-418`); the transcript must not be used until `wait`
+    pub fn batch_open_async(&self, comms: &[HipCommitmentWithWitness], points: &[Vec<E>], evals: &[E], transcript: &mut impl Transcript<E>) -> Result<PendingOpen, Error> {
+        let handles: Vec<*const sys::dp_commit> = comms.iter().map(|c| one(c).map(|h| h as *const sys::dp_commit)).collect::<Result<_, _>>()?;
+        let flat: Vec<u64> = points.iter().flat_map(|p| point_words(p)).collect();
+        let ev: Vec<u64> = evals.iter().flat_map(|e| ext_words(e)).collect();
+        let mut t = core::ptr::null_mut();
+        sys::check(unsafe { sys::dp_pcs_batch_open_submit(self.0, handles.as_ptr(), handles.len() as i32, flat.as_ptr(), ev.as_ptr(), handle_of(transcript), &mut t) }).map_err(pcs_err)?;
+        Ok(PendingOpen { ticket: t })
+    }
+}
+impl PendingCommit {
+    pub fn is_done(&self) -> Result<bool, Error> { let s = unsafe { sys::dp_poll(self.ticket) }; if s < 0 { Err(pcs_err(sys::check(s).unwrap_err())) } else { Ok(s == 1) } }
+    pub fn wait(mut self) -> Result<HipCommitmentWithWitness, Error> {
+        sys::check(unsafe { sys::dp_wait(self.ticket) }).map_err(pcs_err)?;
+        let mut h = core::ptr::null_mut();
+        let mut root = [0u64; 4];
+        sys::check(unsafe { sys::dp_ticket_commit(self.ticket, &mut h, root.as_mut_ptr()) }).map_err(pcs_err)?;
+        let pure = HipCommitment { root, num_vars: self.num_vars, is_base: self.is_base, num_polys: 1 };
+        Ok(HipCommitmentWithWitness { pure, witness: Some(Arc::new(Witness { handle: Handle::One(h), _tables: vec![self.table.take().unwrap()] })) })
+    }
+}
+impl Drop for PendingCommit { fn drop(&mut self) { unsafe { sys::dp_wait(self.ticket); sys::dp_ticket_free(self.ticket); } } }
+impl PendingOpen {
+    pub fn is_done(&self) -> Result<bool, Error> { let s = unsafe { sys::dp_poll(self.ticket) }; if s < 0 { Err(pcs_err(sys::check(s).unwrap_err())) } else { Ok(s == 1) } }
+    pub fn wait(self) -> Result<HipProof, Error> {
+        sys::check(unsafe { sys::dp_wait(self.ticket) }).map_err(pcs_err)?;
+        let (mut w, mut n) = (core::ptr::null_mut(), 0usize);
+        sys::check(unsafe { sys::dp_ticket_words(self.ticket, 0, &mut w, &mut n) }).map_err(pcs_err)?;
+        Ok(take_words(w, n))
+    }
+}
+impl Drop for PendingOpen { fn drop(&mut self) { unsafe { sys::dp_wait(self.ticket); sys::dp_ticket_free(self.ticket); } } }
+
 #[allow(dead_code)]
 fn _label(l: &'static [u8]) -> *const c_char { l.as_ptr() as *const c_char }

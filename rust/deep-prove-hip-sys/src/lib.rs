@@ -20,7 +20,7 @@ pub const DP_ERR_VERIFY: i32 = -5;
 pub const DP_ERR_NODEVICE: i32 = -6;
 
 macro_rules! opaque { ($($n:ident),*) => { $( #[repr(C)] pub struct $n { _p: [u8; 0], _m: core::marker::PhantomData<(*mut u8, core::marker::PhantomPinned)> } )* } }
-opaque!(dp_ctx, dp_buf, dp_transcript, dp_commit, dp_model, dp_sc_session, dp_dist, dp_batch_commit);
+opaque!(dp_ctx, dp_buf, dp_transcript, dp_commit, dp_model, dp_sc_session, dp_dist, dp_batch_commit, dp_async, dp_ticket);
 
 extern "C" {
     pub fn dp_last_error() -> *const c_char;
@@ -29,6 +29,22 @@ extern "C" {
     pub fn dp_ctx_destroy(ctx: *mut dp_ctx) -> i32;
     pub fn dp_ctx_name(ctx: *const dp_ctx) -> *const c_char;
     pub fn dp_ctx_set_throughput_mode(ctx: *mut dp_ctx, on: i32) -> i32;
+    pub fn dp_async_create(ctx: *mut dp_ctx, max_in_flight: i32, worker_arena_bytes: usize, out_: *mut *mut dp_async) -> i32;
+    pub fn dp_async_destroy(a: *mut dp_async) -> i32;
+    pub fn dp_async_stats(a: *mut dp_async, calls: *mut usize, groups: *mut usize, merged_calls: *mut usize, workers: *mut usize) -> i32;
+    pub fn dp_pcs_commit_submit(a: *mut dp_async, poly: *const dp_buf, ticket: *mut *mut dp_ticket) -> i32;
+    pub fn dp_mle_fix_high_submit(a: *mut dp_async, matrix: *const dp_buf, rows: usize, cols: usize, point: *const u64, ticket: *mut *mut dp_ticket) -> i32;
+    pub fn dp_mle_eval_submit(a: *mut dp_async, f: *const dp_buf, point: *const u64, k: u32, ticket: *mut *mut dp_ticket) -> i32;
+    pub fn dp_ticket_buf(t: *mut dp_ticket, out_: *mut *mut dp_buf) -> i32;
+    pub fn dp_sumcheck_prove_submit(a: *mut dp_async, num_vars: u32, tables: *const *const dp_buf, ntables: i32, term_degree: *const i32, term_tables: *const i32, term_coeffs: *const u64, nterms: i32, t: *mut dp_transcript, ticket: *mut *mut dp_ticket) -> i32;
+    pub fn dp_logup_prove_submit(a: *mut dp_async, columns: *const *const dp_buf, ncols: i32, cols_per_instance: i32, multiplicities: *const dp_buf, constant_challenge: *const u64, column_separation_challenge: *const u64, t: *mut dp_transcript, ticket: *mut *mut dp_ticket) -> i32;
+    pub fn dp_pcs_batch_open_submit(a: *mut dp_async, comms: *const *const dp_commit, n: i32, points_flat: *const u64, evals: *const u64, t: *mut dp_transcript, ticket: *mut *mut dp_ticket) -> i32;
+    pub fn dp_poll(t: *mut dp_ticket) -> i32;
+    pub fn dp_wait(t: *mut dp_ticket) -> i32;
+    pub fn dp_ticket_words(t: *mut dp_ticket, which: i32, words: *mut *mut u64, nwords: *mut usize) -> i32;
+    pub fn dp_ticket_values(t: *mut dp_ticket, values: *mut u64, nvalues: usize) -> i32;
+    pub fn dp_ticket_commit(t: *mut dp_ticket, out_: *mut *mut dp_commit, root: *mut u64) -> i32;
+    pub fn dp_ticket_free(t: *mut dp_ticket) -> i32;
     pub fn dp_profile_enable(ctx: *mut dp_ctx, on: i32) -> i32;
     pub fn dp_profile_report(ctx: *mut dp_ctx, json: *mut *mut c_char) -> i32;
     pub fn dp_probe_compress_rate(ctx: *mut dp_ctx, nodes: usize, reps: i32, per_second: *mut f64) -> i32;

