@@ -109,7 +109,7 @@ def strong_share(batch, world, rank):
     return len(shard(batch, world, rank))
 
 
-def transformer_layer_section(dpa, dev, conc=192):  # (64 in flight: 87 proofs/s, 192: 142 — profiles/r03_transformer_layer.txt)
+def transformer_layer_section(dpa, dev, conc=320):  # (round 3: 64 in flight 87 proofs/s, 192: 142; round 4: 192: 163, 320: 186 — profiles/r04_transformer_layer_sweeps.txt)
     """SURVEY §8 f4 measured: one whole pre-LN transformer layer as one graph of 19 nodes (models.transformer_layer: LayerNorm, QKV, the Mha node of
     transformer/mha.rs, projection, residual; LayerNorm, Linear, ReLU, Linear, residual) AT THE SIZE THE GOLDEN PINS: case 14 of
     tests/golden/graph_models.json = the oracle's sha256 at 64 tokens x 256 features, 4 heads of 64, ffn 1024, config 66. The golden input sits in a slot
@@ -694,9 +694,9 @@ def seam_level(threads, per_thread=6, batch_rate=None):
     # `streams_throughput`: plain contexts switched to throughput mode (dp_ctx_set_throughput_mode: device-side Fiat-Shamir, fused protocol
     # kernels). Measured: 40 against 80 proofs/s at 14 threads, 34-36 with 28 / 56 yielding threads (profiles/r03_seam_level_throughput_mode.txt):
     # without cohorts to merge launches and fibers to keep hundreds of calls in flight the one-wave kernels only add latency
-    # `async_one_thread` (round 4): ONE host thread keeps 64 / 128 proofs in flight through the submit / poll forms (dp_async): calls of identical shape are
+    # `async_one_thread` (round 4): ONE host thread keeps 128 / 384 proofs in flight through the submit / poll forms (dp_async): calls of identical shape are
     # merged into lock-step groups by the engine (tests/support/seam_bench.c mode 3)
-    variants = [("streams", 0, threads, {}), ("streams_throughput", 2, threads, {}), ("async_one_thread_64", 3, 64, {}), ("async_one_thread_128", 3, 128, {})]
+    variants = [("streams", 0, threads, {}), ("streams_throughput", 2, threads, {}), ("async_one_thread_128", 3, 128, {}), ("async_one_thread_384", 3, 384, {})]
     for name, executor, t, extra in variants:
         env = dict(os.environ, DP_ARENA_BYTES=str(2 << 30), **extra)
         try:

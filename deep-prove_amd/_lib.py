@@ -32,6 +32,7 @@ SIGNATURES = {
     "dp_async_destroy": (C.c_int32, [vp]),
     "dp_async_stats": (C.c_int32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "dp_pcs_commit_submit": (C.c_int32, [vp, vp, C.POINTER(vp)]),
+    "dp_pcs_commit_host_submit": (C.c_int32, [vp, u64p, C.c_size_t, C.c_int32, C.POINTER(vp)]),
     "dp_mle_fix_high_submit": (C.c_int32, [vp, vp, C.c_size_t, C.c_size_t, u64p, C.POINTER(vp)]),
     "dp_mle_eval_submit": (C.c_int32, [vp, vp, u64p, C.c_uint32, C.POINTER(vp)]),
     "dp_ticket_buf": (C.c_int32, [vp, C.POINTER(vp)]),

@@ -328,6 +328,12 @@ class Ticket:
         check(_lib.load().dp_ticket_commit(self.h, C.byref(h), root))
         return Commitment(dev, h, [int(v) for v in root], poly)
 
+    def table(self, dev):
+        """the device table of a completed commit_host / fix_high ticket (dp_ticket_buf)"""
+        h = vp()
+        check(_lib.load().dp_ticket_buf(self.h, C.byref(h)))
+        return Mle(dev, h)
+
     def free(self):
         if self.h:
             check(_lib.load().dp_ticket_free(self.h))
@@ -375,6 +381,13 @@ class AsyncEngine:
         t = vp()
         check(_lib.load().dp_pcs_commit_submit(self.h, poly.h, C.byref(t)))
         return Ticket(t.value, (poly,))
+
+    def commit_host(self, words, is_ext=False):
+        """PCS::commit(&poly) with the polynomial on the host: upload + commit in one ticket; Ticket.table(dev) then Ticket.commitment(dev, table)"""
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        t = vp()
+        check(_lib.load().dp_pcs_commit_host_submit(self.h, w.ctypes.data_as(u64p), w.size // (2 if is_ext else 1), 1 if is_ext else 0, C.byref(t)))
+        return Ticket(t.value, None)
 
     def batch_open(self, comms, points, evals, transcript):
         hs = (vp * len(comms))(*[c.h for c in comms])

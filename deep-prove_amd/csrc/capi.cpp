@@ -651,7 +651,7 @@ struct dp_ticket {
   std::chrono::steady_clock::time_point t_submit;
 };
 struct dp_async {
-  dp_ctx* ctx = nullptr; size_t max_in_flight = 0, arena = 0; size_t group_max = 32, groups_per_thread = 1; double linger_us = 100.0;  // (groups_per_thread: 1 measured best — 111 against 52 proofs/s at 3 on the seam bench, profiles/r04_seam_async.txt)
+  dp_ctx* ctx = nullptr; size_t max_in_flight = 0, arena = 0; size_t group_max = 32, groups_per_thread = 1; double linger_us = 100.0;  // measured (profiles/r04_seam_async.txt): groups per thread 1 against 3: 111 against 52 proofs/s; groups of up to 64, a linger of 300 us, 22 engine threads: no gain
   std::mutex mu; std::condition_variable cv; std::deque<dp_ticket*> queue; bool stop = false;
   std::vector<std::unique_ptr<Dev>> workers; std::vector<Dev*> free_workers;
   std::vector<std::thread> threads;
@@ -773,9 +773,6 @@ int32_t dp_async_create(dp_ctx* ctx, int32_t max_in_flight, size_t worker_arena_
     DP_REQUIRE(ctx && out && max_in_flight >= 1 && max_in_flight <= 4096, DP_ERR_ARG, "dp_async_create: 1..4096 calls in flight");
     std::unique_ptr<dp_async> a(new dp_async());
     a->ctx = ctx; a->max_in_flight = (size_t)max_in_flight; a->arena = worker_arena_bytes ? worker_arena_bytes : (size_t(512) << 20);
-    if (const char* e = getenv("DP_ASYNC_GROUP")) a->group_max = (size_t)std::max(1, atoi(e));
-    if (const char* e = getenv("DP_ASYNC_LINGER_US")) a->linger_us = std::max(0.0, atof(e));
-    if (const char* e = getenv("DP_ASYNC_GROUPS_PER_THREAD")) a->groups_per_thread = (size_t)std::max(1, atoi(e));
     CtxLock lk(ctx);
     size_t fr = 0, tot = 0; hip_mem_info(ctx->device_id, &fr, &tot);
     const size_t fit = (size_t)(0.9 * (double)fr) / (a->arena + (size_t(16) << 20));
@@ -909,6 +906,27 @@ int32_t dp_pcs_commit_submit(dp_async* a, const dp_buf* poly, dp_ticket** ticket
     const DBuf b = poly->b;
     tk->sig = sig_buf(3, b);
     tk->body = [b](Dev& dev, dp_ticket& me) { DevCommit c = dev.commit(b, true); for (int k = 0; k < 4; k++) me.root[k] = c.tree.root.v[k]; me.commit = new dp_commit{c}; };
+    async_submit(a, tk.release(), ticket);
+  });
+}
+/* PCS::commit(pp, &poly) as the trait has it (mpcs/src/lib.rs:126-129): the polynomial is a HOST object. One ticket uploads the evaluations and commits to
+ * them: dp_ticket_buf = the device table (the commitment refers to it: free it after the commitment), dp_ticket_commit = the commitment and its root. */
+int32_t dp_pcs_commit_host_submit(dp_async* a, const uint64_t* words, size_t n, int32_t is_ext, dp_ticket** ticket) {
+  return guard([&] {
+    DP_REQUIRE(a && words && ticket && n, DP_ERR_ARG, "bad arguments");
+    const size_t nw = n * (is_ext ? 2 : 1);
+    for (size_t i = 0; i < nw; i++) DP_REQUIRE(words[i] < GL_P, DP_ERR_ARG, "non-canonical field element");
+    auto w = std::make_shared<std::vector<uint64_t>>(words, words + nw);
+    std::unique_ptr<dp_ticket> tk(new dp_ticket());
+    tk->sig = sig_mix(sig_mix(7, n), is_ext ? 2 : 1);
+    const bool ext = is_ext != 0;
+    tk->body = [w, n, ext](Dev& dev, dp_ticket& me) {
+      DBuf b = dev.alloc_persistent(n, ext); dev.upload(b, w->data());
+      me.buf = new dp_buf{b};
+      DevCommit c = dev.commit(b, true);
+      for (int k = 0; k < 4; k++) me.root[k] = c.tree.root.v[k];
+      me.commit = new dp_commit{c};
+    };
     async_submit(a, tk.release(), ticket);
   });
 }

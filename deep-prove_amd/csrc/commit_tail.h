@@ -15,11 +15,9 @@ constexpr size_t COMMIT_TAIL_MAX_N = 4096;      // the tail takes over when the 
 // reduction, leaves, Merkle layers, Merkle tail) at the price of ONE workgroup doing the work: a single proof (1024 threads, the GPU
 // otherwise idle) is fastest with 4096; with hundreds of proofs in flight the throughput is the same from 4096 to 65536
 // (profiles/r02_ctail_inflight_sweep.jsonl), so throughput mode takes over at 16384 and spends 22 launches less per proof.
-// DP_COMMIT_TAIL_MAX_N overrides both.
 constexpr size_t COMMIT_TAIL_MAX_N_THROUGHPUT = 16384;
 inline size_t commit_tail_max_n(bool throughput_mode) {
-  static const size_t env = [] { const char* e = getenv("DP_COMMIT_TAIL_MAX_N"); size_t x = e ? (size_t)strtoull(e, nullptr, 10) : 0; return x < 2 ? size_t(0) : std::min<size_t>(x, size_t(1) << 20); }();  // (clamped: one workgroup would grind through anything larger for seconds)
-  return env ? env : throughput_mode ? COMMIT_TAIL_MAX_N_THROUGHPUT : COMMIT_TAIL_MAX_N;
+  return throughput_mode ? COMMIT_TAIL_MAX_N_THROUGHPUT : COMMIT_TAIL_MAX_N;
 }
 
 struct CommitTailDesc {

@@ -265,12 +265,12 @@ class HipDev : public Dev {
   unsigned long long last_tag_ = 0;
   bool zerocopy_ = true;  // DP_NO_ZEROCOPY=1 falls back to hipMemcpyAsync + hipStreamSynchronize
   bool persist_ = true;   // DP_NO_PERSIST=1 disables the persistent sumcheck kernel
-  size_t excl_ = 0;       // dynamic LDS requested by one-workgroup kernels to keep a CU to themselves (DP_NO_EXCLUSIVE_CU=1: none)
+  size_t excl_ = 0;       // dynamic LDS requested by one-workgroup kernels to keep a CU to themselves (latency mode)
   size_t excl_now() const { return excl_; }
   // throughput mode (several proofs in flight): one-workgroup kernels reserve nothing and run as 256-thread workgroups with
-  // raised wave priority (KF_PRIO). DP_SHARED_TAILS=0 restores the whole-CU workgroups of round 1, DP_SHARED_THREADS = 64 / 128 / 256.
-  bool shared_tails_ = !(getenv("DP_SHARED_TAILS") && !atoi(getenv("DP_SHARED_TAILS")));
-  int shared_threads_ = [] { const char* e = getenv("DP_SHARED_THREADS"); int v = e ? atoi(e) : 256; return (v == 64 || v == 128 || v == 256) ? v : 256; }();  // <= SHARED_MAXT
+  // raised wave priority (KF_PRIO); round 1's whole-CU workgroups in throughput mode lost by 2x (tools/hol.hip) and are gone.
+  static constexpr bool shared_tails_ = true;
+  static constexpr int shared_threads_ = SHARED_MAXT;
   bool throughput_mode_ = false;
   bool shared_now() const { return throughput_mode_ && shared_tails_; }
   int persist_threads(size_t work) const {
@@ -286,7 +286,7 @@ class HipDev : public Dev {
   unsigned long long* hmflag_ = nullptr;      // host view of the per-workgroup flags
   unsigned long long* hmflag_dev_ = nullptr;  // device view
   unsigned long long last_tag_multi_[MULTI_MAX_WG];
-  bool multi_ = true;  // DP_NO_MULTI=1 disables the multi-workgroup phase of large sumchecks
+  bool multi_ = true;  // the multi-workgroup phase of large sumchecks (latency mode only)
   static bool persist_flag_env(const char* name) { const char* e = getenv(name); return !(e && atoi(e)); }
   // all G workgroups have published round `seq`: every slot's tag matches its payload (same protocol as wait_flag)
   void wait_flags_multi(unsigned long long seq, size_t nwords, int G, size_t slot_words) {
@@ -327,7 +327,7 @@ class HipDev : public Dev {
   // ASYNC_STAGE, not the context's own staging size: the members of a cohort (the model's context has a larger staging buffer
   // than the batch workers) must take the same decisions, or the cohort falls out of step.
   size_t stage_off_ = 0;
-  int async_upload_env_ = [] { const char* e = getenv("DP_ASYNC_UPLOAD"); return e ? atoi(e) : -1; }();
+  static constexpr int async_upload_env_ = -1;  // (on in throughput mode, off for a single proof)
   bool async_upload_now() const { return async_upload_env_ < 0 ? throughput_mode_ : async_upload_env_ != 0; }
   static constexpr size_t ASYNC_STAGE = size_t(12) << 20, ASYNC_MAX = size_t(2) << 20;
   static constexpr size_t RES_WORDS = 1 << 16;
@@ -509,7 +509,6 @@ class HipDev : public Dev {
     hmail_[0] = hmail_[1] = hmail_[2] = hmail_[3] = 0;
     hmflag_ = hflag_ + 32; hmflag_dev_ = hflag_dev_ + 32;  // one flag word per workgroup of a multi-workgroup sumcheck phase
     for (int i = 0; i < MULTI_MAX_WG; i++) { hmflag_[i] = 0; last_tag_multi_[i] = 0; }
-    multi_ = persist_flag_env("DP_NO_MULTI");
     zerocopy_ = !(getenv("DP_NO_ZEROCOPY") && atoi(getenv("DP_NO_ZEROCOPY")));
     persist_ = zerocopy_ && !(getenv("DP_NO_PERSIST") && atoi(getenv("DP_NO_PERSIST")));
     if (g_timing_level > 1) { HIP_CHECK(hipMalloc((void**)&scdbg_, 64)); HIP_CHECK(hipMemset(scdbg_, 0, 64)); }
@@ -525,11 +524,10 @@ class HipDev : public Dev {
       HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_extrap), ex.data(), ex.size() * 8)); }
     { double ts = getenv("DP_POLL_TIMEOUT_S") ? std::max(0.001, atof(getenv("DP_POLL_TIMEOUT_S"))) : 20.0; unsigned long long tk = (unsigned long long)(ts * 1e8); HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_poll_timeout_ticks), &tk, sizeof(tk))); }
 #ifdef DP_DIAG_SKIP_HASH
-    { int sk = getenv("DP_DEBUG_SKIP_HASH") ? atoi(getenv("DP_DEBUG_SKIP_HASH")) : 0; if (sk) HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_dbg_skip_hash), &sk, sizeof(int))); }
 #endif
     DP_SET_LDS_ONE((k_sc_persist_lds<false>), 1024, (int)SC_LDS_MAX);
     DP_SET_LDS_ONE((k_sc_persist_lds<true>), 1024, (int)SC_LDS_MAX);
-    excl_ = (getenv("DP_NO_EXCLUSIVE_CU") && atoi(getenv("DP_NO_EXCLUSIVE_CU"))) ? 0 : EXCL_LDS;
+    excl_ = EXCL_LDS;
     DP_SET_LDS_ONE((k_sc_persist<false>), 1024, (int)EXCL_LDS);
     DP_SET_LDS_ONE((k_sc_persist<true>), 1024, (int)EXCL_LDS);
     DP_SET_LDS_ONE((k_sc_small<false>), 1024, (int)EXCL_LDS);
@@ -601,7 +599,7 @@ class HipDev : public Dev {
     release(mk);
     return ms > 0 ? (double)nodes * reps / (ms * 1e-3) : 0.0;
   }
-  void set_latency_mode(bool on) { multi_ = on && persist_flag_env("DP_NO_MULTI"); devfs_ = devfs_env_ < 0 ? !on : devfs_env_ != 0; throughput_mode_ = !on; }
+  void set_latency_mode(bool on) { multi_ = on; devfs_ = devfs_env_ < 0 ? !on : devfs_env_ != 0; throughput_mode_ = !on; }
   void dump_host_stats() {
     if (!g_host_stats) return;
     fprintf(stderr, "[dp timing] device context: %zu launches, %.1f us of host time per launch (%.1f ms total), %zu device waits, %zu fiber yields; host work between waits %.1f ms, inside waits %.1f ms\n", nlaunch_, nlaunch_ ? launch_us_ / nlaunch_ : 0.0, launch_us_ / 1000.0, nwait_, nyield_, work_us_ / 1000.0, waitlat_us_ / 1000.0);
@@ -1007,10 +1005,13 @@ class HipDev : public Dev {
   }
   // ---- Dev::logup_tail: DP_DEVICE_LOGUP=1, see k_logup_tail. Declines (returns false) whenever the shape is
   // outside what the kernel was written for; the caller then runs the layers one by one (logup_layers).
-  // fused protocol kernels: on by default whenever the device-side transcript is (throughput mode); DP_DEVICE_<X>=0 turns one off.
+  // fused protocol kernels: on by default whenever the device-side transcript is (throughput mode); DP_FUSED_OFF=<x,y> / DP_DEVICE_LOGUP=0|1 turn them off.
   // Validated on MI355X in round 2 (tests/test_gpu_fused.py: every knob alone and all together, Dense-4M and CNN-264k batches
   // against the sequential proofs; profiles/r02_fused_knob_sweep.jsonl).
   static int knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+  // DP_FUSED_OFF=<comma-separated subset of classic,commit,deleg,dense,eqsum>: those fused protocol kernels decline and their stretch runs launch by launch
+  // (tests/test_gpu_fused.py turns each off alone and all together); the logup kernel has its own three-way switch DP_DEVICE_LOGUP
+  static bool fused_on(const char* what) { const char* e = getenv("DP_FUSED_OFF"); if (!e) return true; const std::string s = std::string(",") + e + ","; return s.find(std::string(",") + what + ",") == std::string::npos; }
   // ---- DP_HOST_SPONGE=1 (sponge_host.h): the fused protocol kernels keep the transcript's sponge on the HOST — a kernel posts the
   // words it absorbs and asks for challenges through a mapped mailbox, DP_SPONGE_THREADS server threads answer (the members of a
   // cohort ask together and sit with different servers). Off by default: new at the end of round 2 (the wave sponge costs ~12 us per permutation, the mailbox 2.9 us per round trip).
@@ -1066,7 +1067,7 @@ class HipDev : public Dev {
     return true;
   }
   // ---- Dev::commit_tail: DP_DEVICE_COMMIT (default on): k_commit_tail, the last rounds of the Basefold commit phase
-  bool devcommit_ = knob("DP_DEVICE_COMMIT", 1) != 0;
+  bool devcommit_ = fused_on("commit");
   bool commit_tail(const CommitTailArgs& a, Challenger& ch, CommitTailOut& out) override {
     if (!devcommit_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_ || !tw_) return false;
     if (!commit_tail_accepts(a, commit_tail_max_n(throughput_mode_)) || dp_ceil_log2(a.folded.n) - 1 > L_) return false;
@@ -1089,7 +1090,7 @@ class HipDev : public Dev {
     return true;
   }
   // ---- Dev::eqsum_tail: DP_DEVICE_EQSUM (default on): k_eqsum_tail, eq tables + accumulation sumcheck in one launch
-  bool deveqsum_ = knob("DP_DEVICE_EQSUM", 1) != 0;
+  bool deveqsum_ = fused_on("eqsum");
   bool eqsum_tail(const EqAccJob* jobs, int njobs, const DBuf* tabs, int ntabs, const ScTerm* terms, const Ext* coeffs, int nterms, unsigned nv, unsigned md,
                   Challenger& ch, EqSumOut& out) override {
     if (!deveqsum_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
@@ -1113,7 +1114,7 @@ class HipDev : public Dev {
     return true;
   }
   // ---- Dev::deleg_tail: DP_DEVICE_DELEG (default on): k_deleg_tail, all delegation sumchecks of one batch FFT / iFFT in one launch
-  bool devdeleg_ = knob("DP_DEVICE_DELEG", 1) != 0;
+  bool devdeleg_ = fused_on("deleg");
   bool deleg_tail(const DelegTailArgs& a, Challenger& ch, DelegTailOut& out) override {
     if (!devdeleg_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
     if (!deleg_tail_accepts(a)) return false;
@@ -1141,7 +1142,7 @@ class HipDev : public Dev {
     return true;
   }
   // ---- Dev::dense_tail: DP_DEVICE_DENSE (default on): k_dense_tail, a Dense layer's device work in one launch
-  bool devdense_ = knob("DP_DEVICE_DENSE", 1) != 0;
+  bool devdense_ = fused_on("dense");
   bool dense_tail(const DBuf& bias, const DBuf& W, size_t R, size_t C, const DBuf& in, const Ext* pt, Challenger& ch, DenseTailOut& out) override {
     if (!devdense_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
     if (!dense_tail_accepts(bias, W, R, C, in)) return false;
@@ -1163,7 +1164,7 @@ class HipDev : public Dev {
     return true;
   }
   // ---- Dev::classic_tail: DP_DEVICE_CLASSIC (default on): k_classic_tail, the last rounds of the batch-opening sumcheck
-  bool devclassic_ = knob("DP_DEVICE_CLASSIC", 1) != 0;
+  bool devclassic_ = fused_on("classic");
   bool classic_tail(const ClassicTailArgs& a, Challenger& ch, std::vector<std::vector<Ext>>& msgs, std::vector<Ext>& challenges) override {
     if (!devclassic_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
     if (!classic_tail_accepts(a)) return false;
@@ -1530,12 +1531,12 @@ class HipDev : public Dev {
   }
   // layers of at most this many digests are finished by k_merkle_tail (one workgroup, no relaunch between layers); wider
   // layers get their own multi-workgroup launch: a 512-parent layer is 4 sequential passes inside the tail workgroup but one
-  // pass spread over 16 CUs as a launch (DP_TAIL_MAX overrides)
-  size_t TAIL_MAX = getenv("DP_TAIL_MAX") ? strtoull(getenv("DP_TAIL_MAX"), nullptr, 10) : 256;
+  // pass spread over 16 CUs as a launch (2048 measured equal in round 2)
+  static constexpr size_t TAIL_MAX = 256;
   // Layers with at most lp_max_ parent nodes use the 8-lanes-per-node kernel (lowest latency per layer, but ~2.2x the
   // VALU work of one node per lane and a grid 8x as large: with many proofs in flight those grids fill the chip and
-  // every other stream queues behind them), wider layers hash one node per lane. DP_MERKLE_LP_MAX overrides.
-  size_t lp_max_ = getenv("DP_MERKLE_LP_MAX") ? strtoull(getenv("DP_MERKLE_LP_MAX"), nullptr, 10) : (size_t(1) << 12);
+  // every other stream queues behind them), wider layers hash one node per lane.
+  static constexpr size_t lp_max_ = size_t(1) << 12;
   // `nodes` must hold 4*(n-1) words; synchronises (root is copied to the host)
   DevTree build_tree_into(const DBuf& leaves, const DBuf& nodes) {
     DevTree t; t.leaves = leaves; t.nleaves = leaves.n; t.nodes = nodes;
@@ -1719,8 +1720,8 @@ class HipDev : public Dev {
   }
 
   // factored eq tables of the batch-opening sumcheck (Dev::classic_round): polynomials of 2^15 entries and more keep eq(x, z) as
-  // (low half, high half) — DP_CLASSIC_EQ_SPLIT=0 materialises them as before
-  bool eq_split_ = knob("DP_CLASSIC_EQ_SPLIT", 1) != 0;
+  // (low half, high half); round 3 measured the materialised form: 320 MB more traffic per proof, same rate
+  static constexpr bool eq_split_ = true;
   unsigned classic_eq_split(unsigned nv) override { return eq_split_ && zerocopy_ && nv >= 15 ? nv / 2 : 0; }
   size_t classic_eq_materialise_n() override { return CLASSIC_TAIL_MAX_N; }
   void eq_outer_many(const EqOuterJob* jobs, size_t n) override {

@@ -72,6 +72,9 @@ int32_t dp_async_destroy(dp_async* a);
 /* counters since creation: calls executed, groups they ran in, calls that ran merged with at least one other, worker contexts */
 int32_t dp_async_stats(dp_async* a, size_t* calls, size_t* groups, size_t* merged_calls, size_t* workers);
 int32_t dp_pcs_commit_submit(dp_async* a, const dp_buf* poly, dp_ticket** ticket);
+/* PCS::commit(pp, &poly) with the polynomial on the HOST, as the trait passes it (mpcs/src/lib.rs:126-129): upload + commit in one ticket; the device table comes
+ * back with dp_ticket_buf (the commitment refers to it: free the commitment first), commitment and root with dp_ticket_commit */
+int32_t dp_pcs_commit_host_submit(dp_async* a, const uint64_t* words, size_t n, int32_t is_ext, dp_ticket** ticket);
 /* dp_mle_fix_high / dp_mle_eval as tickets: the fixed table comes back with dp_ticket_buf (free it with dp_buf_free on the engine's context), the evaluation
  * with dp_ticket_values (2 words) */
 int32_t dp_mle_fix_high_submit(dp_async* a, const dp_buf* matrix, size_t rows, size_t cols, const uint64_t* point, dp_ticket** ticket);

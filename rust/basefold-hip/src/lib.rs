@@ -65,12 +65,15 @@ struct DeviceTable(*mut sys::dp_buf);
 unsafe impl Send for DeviceTable {}
 unsafe impl Sync for DeviceTable {}
 impl Drop for DeviceTable { fn drop(&mut self) { unsafe { sys::dp_buf_free(ctx(), self.0); } } }
-fn upload(poly: &DenseMultilinearExtension<E>) -> Result<DeviceTable, Error> {
-    let (words, n, is_ext): (Vec<u64>, usize, i32) = match &poly.evaluations {
+fn poly_words(poly: &DenseMultilinearExtension<E>) -> Result<(Vec<u64>, usize, i32), Error> {
+    Ok(match &poly.evaluations {
         FieldType::Base(v) => (v.iter().map(|x| x.to_canonical_u64()).collect(), v.len(), 0),
         FieldType::Ext(v) => (v.iter().flat_map(|x| ext_words(x)).collect(), v.len(), 1),
         FieldType::Unreachable => return Err(Error::InvalidPcsParam("unreachable field type".into())),
-    };
+    })
+}
+fn upload(poly: &DenseMultilinearExtension<E>) -> Result<DeviceTable, Error> {
+    let (words, n, is_ext) = poly_words(poly)?;
     let mut b = core::ptr::null_mut();
     sys::check(unsafe { sys::dp_buf_upload(ctx(), words.as_ptr(), n, is_ext, &mut b) }).map_err(pcs_err)?;
     Ok(DeviceTable(b))
@@ -298,11 +301,12 @@ impl AsyncEngine {
         sys::check(unsafe { sys::dp_async_create(ctx(), max_in_flight as i32, 0, &mut h) }).map_err(pcs_err)?;
         Ok(AsyncEngine(h))
     }
+    /// `PCS::commit(pp, &poly)`: the host polynomial is uploaded and committed by ONE ticket (`dp_pcs_commit_host_submit`)
     pub fn commit_async(&self, poly: &DenseMultilinearExtension<E>) -> Result<PendingCommit, Error> {
-        let table = upload(poly)?;
+        let (words, n, is_ext) = poly_words(poly)?;
         let mut t = core::ptr::null_mut();
-        sys::check(unsafe { sys::dp_pcs_commit_submit(self.0, table.0, &mut t) }).map_err(pcs_err)?;
-        Ok(PendingCommit { ticket: t, table: Some(table), num_vars: poly.num_vars, is_base: matches!(poly.evaluations, FieldType::Base(_)) })
+        sys::check(unsafe { sys::dp_pcs_commit_host_submit(self.0, words.as_ptr(), n, is_ext, &mut t) }).map_err(pcs_err)?;
+        Ok(PendingCommit { ticket: t, table: None, num_vars: poly.num_vars, is_base: is_ext == 0 })
     }
     /// `PCS::batch_open` with `Evaluation::new(i, i, evals[i])` (`zkml/src/commit/context.rs:355-418`); the transcript must not be used until `wait`
     pub fn batch_open_async(&self, comms: &[HipCommitmentWithWitness], points: &[Vec<E>], evals: &[E], transcript: &mut impl Transcript<E>) -> Result<PendingOpen, Error> {
@@ -318,6 +322,9 @@ impl PendingCommit {
     pub fn is_done(&self) -> Result<bool, Error> { let s = unsafe { sys::dp_poll(self.ticket) }; if s < 0 { Err(pcs_err(sys::check(s).unwrap_err())) } else { Ok(s == 1) } }
     pub fn wait(mut self) -> Result<HipCommitmentWithWitness, Error> {
         sys::check(unsafe { sys::dp_wait(self.ticket) }).map_err(pcs_err)?;
+        let mut b = core::ptr::null_mut();
+        sys::check(unsafe { sys::dp_ticket_buf(self.ticket, &mut b) }).map_err(pcs_err)?;
+        self.table = Some(DeviceTable(b));
         let mut h = core::ptr::null_mut();
         let mut root = [0u64; 4];
         sys::check(unsafe { sys::dp_ticket_commit(self.ticket, &mut h, root.as_mut_ptr()) }).map_err(pcs_err)?;

@@ -33,6 +33,7 @@ extern "C" {
     pub fn dp_async_destroy(a: *mut dp_async) -> i32;
     pub fn dp_async_stats(a: *mut dp_async, calls: *mut usize, groups: *mut usize, merged_calls: *mut usize, workers: *mut usize) -> i32;
     pub fn dp_pcs_commit_submit(a: *mut dp_async, poly: *const dp_buf, ticket: *mut *mut dp_ticket) -> i32;
+    pub fn dp_pcs_commit_host_submit(a: *mut dp_async, words: *const u64, n: usize, is_ext: i32, ticket: *mut *mut dp_ticket) -> i32;
     pub fn dp_mle_fix_high_submit(a: *mut dp_async, matrix: *const dp_buf, rows: usize, cols: usize, point: *const u64, ticket: *mut *mut dp_ticket) -> i32;
     pub fn dp_mle_eval_submit(a: *mut dp_async, f: *const dp_buf, point: *const u64, k: u32, ticket: *mut *mut dp_ticket) -> i32;
     pub fn dp_ticket_buf(t: *mut dp_ticket, out_: *mut *mut dp_buf) -> i32;

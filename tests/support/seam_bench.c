@@ -104,7 +104,7 @@ static double g_t_begin, g_t_end, g_t_sync;  /* client-thread seconds in uploads
 static void aproof_begin(struct worker* w, struct aproof* p, dp_async* eng) {
   const double tb0 = now_s();
   p->t = dp_transcript_new("m2vec"); p->tk = NULL; p->layer = 0; p->sub = 0; p->col = 0; p->fixed = NULL; p->ncommitted = 0;
-  for (int i = 0; i < NCOLS; i++) { CHECK(dp_buf_upload(w->ctx, w->col_words, N, 0, &p->cols[i])); CHECK(dp_pcs_commit_submit(eng, p->cols[i], &p->ctk[i])); }
+  for (int i = 0; i < NCOLS; i++) CHECK(dp_pcs_commit_host_submit(eng, w->col_words, N, 0, &p->ctk[i]));  /* PCS::commit(&poly): upload + commit, one ticket per column */
   CHECK(dp_buf_upload(w->ctx, w->ext_words, N, 1, &p->e0)); CHECK(dp_buf_upload(w->ctx, w->ext_words + 2 * N, N, 1, &p->e1)); CHECK(dp_buf_upload(w->ctx, w->ext_words + 4 * N, N, 1, &p->e2));
   p->step = ST_COMMITS;
   g_t_begin += now_s() - tb0;
@@ -126,6 +126,7 @@ static int aproof_step(struct worker* w, struct aproof* p, dp_async* eng) {
         if (s == 0) return 0;
         if (s < 0) { fprintf(stderr, "commit ticket failed: [%d] %s\n", s, dp_last_error()); exit(1); }
         uint64_t root[4];
+        CHECK(dp_ticket_buf(p->ctk[p->ncommitted], &p->cols[p->ncommitted]));
         CHECK(dp_ticket_commit(p->ctk[p->ncommitted], &p->comms[p->ncommitted], root)); CHECK(dp_ticket_free(p->ctk[p->ncommitted]));
         CHECK(dp_transcript_append_elements(p->t, root, 4));
         p->ncommitted++;

@@ -42,18 +42,17 @@ def test_throughput_mode_proof_is_the_oracles_proof_at_full_size(dev, workload, 
     ctx.free()
 
 
-ALL_OFF = {"DP_DEVICE_LOGUP": "0", "DP_DEVICE_CLASSIC": "0", "DP_DEVICE_DENSE": "0", "DP_DEVICE_EQSUM": "0", "DP_DEVICE_COMMIT": "0"}
-KNOBS = [{}, {"DP_DEVICE_LOGUP": "0"}, {"DP_DEVICE_LOGUP": "1"}, {"DP_DEVICE_CLASSIC": "0"}, {"DP_DEVICE_DENSE": "0"}, {"DP_DEVICE_EQSUM": "0"},
-         {"DP_DEVICE_COMMIT": "0"}, ALL_OFF, {"DP_TAIL_MAX": "2048"},
-         {"DP_HOST_SPONGE": "1"},  # the fused kernels with the transcript's sponge on the host (csrc/sponge_host.h)
-         {"DP_CLASSIC_EQ_SPLIT": "0"}]   # round 3: materialised eq tables in the batch-opening sumcheck (the default keeps them factored)
+ALL_OFF = {"DP_DEVICE_LOGUP": "0", "DP_FUSED_OFF": "classic,dense,eqsum,commit,deleg"}
+KNOBS = [{}, {"DP_DEVICE_LOGUP": "0"}, {"DP_DEVICE_LOGUP": "1"}, {"DP_FUSED_OFF": "classic"}, {"DP_FUSED_OFF": "dense"}, {"DP_FUSED_OFF": "eqsum"},
+         {"DP_FUSED_OFF": "commit"}, ALL_OFF,
+         {"DP_HOST_SPONGE": "1"}]  # the fused kernels with the transcript's sponge on the host (csrc/sponge_host.h)
 
 
 def _ident(f):
     return "+".join(f"{k[3:].lower()}={v}" for k, v in f.items()) or "default"
 
 
-@pytest.mark.parametrize("workload,conc,knobs", [("dense_4m", 16, k) for k in KNOBS] + [("cnn_264k", 8, k) for k in ({}, {"DP_DEVICE_LOGUP": "1"}, ALL_OFF, {"DP_HOST_SPONGE": "1"}, {"DP_DEVICE_DELEG": "0"})],  # (DELEG=0: one launch per delegation sumcheck)
+@pytest.mark.parametrize("workload,conc,knobs", [("dense_4m", 16, k) for k in KNOBS] + [("cnn_264k", 8, k) for k in ({}, {"DP_DEVICE_LOGUP": "1"}, ALL_OFF, {"DP_HOST_SPONGE": "1"}, {"DP_FUSED_OFF": "deleg"})],  # (deleg off: one launch per delegation sumcheck)
                          ids=lambda v: _ident(v) if isinstance(v, dict) else str(v))
 def test_batch_proof_equals_sequential_proof_under_every_knob(workload, conc, knobs):
     env = dict(os.environ)

@@ -106,12 +106,20 @@ def test_async_commit_and_batch_open_match_the_blocking_calls(dev, oracle):
             got = k.words()
             assert got.size == proof.size and (got == proof).all() and t.read_challenge() == chal
             k.free()
+        # PCS::commit(&poly) with the polynomial on the host: upload + commit in one ticket
+        hk = [eng.commit_host(w, e) for w, (nv, e) in zip(sets[1], shape)]
+        _wait_all(hk)
+        for k, want in zip(hk, ref[1][0]):
+            tab = k.table(dev)
+            c = k.commitment(dev, tab)
+            assert c.root == want
+            k.free()
         # against the oracle and the host verifier
         roots, evals, proof, _ = ref[0]
         ot = oracle.transcript(b"open")
         exp = oracle.pcs_batch_open(maxsize, sets[0], [e for _, e in shape], points, evals, ot)
         assert exp.size == proof.size and (exp == proof).all()
         dpa.Basefold.batch_verify(maxsize, roots, [nv for nv, _ in shape], [not e for _, e in shape], points, evals, proof, dpa.Transcript(b"open"))
-        assert eng.stats()["calls"] == 20  # (how many of them ran merged depends on how fast this interpreter submits: the first test pins the merging)
+        assert eng.stats()["calls"] == 24  # (how many of them ran merged depends on how fast this interpreter submits: the first test pins the merging)
     finally:
         eng.close()
