@@ -51,6 +51,131 @@ def shard(total, world, rank):
     return list(range(rank, total, world))
 
 
+class ClockSampler:
+    """Shader clock, package power and busy percentage of the GPU sampled WHILE the timed steps run (a thread reading the amdgpu hwmon / sysfs files every
+    100 ms; `rocm-smi --json` once a second when sysfs is not visible): a 1.4 kW part running 64-bit integer multiply-adds on every SIMD may not hold its
+    2.4 GHz boost clock, and every "fraction of the VALU issue slots" quoted from a counter pass is only as good as the clock it assumes. Never fails the
+    bench: whatever cannot be read is missing from the summary."""
+
+    def __init__(self, device_index=0, period_s=0.1):
+        import glob
+        self.period = period_s
+        self.rows = []
+        self.files = {}
+        self.smi = None
+        self.pci = None
+        self._stop = None
+        self._thread = None
+        # the sysfs node of THIS process's HIP device, by PCI address (a box shows every GPU of the node in /sys, the container only owns some of them)
+        cards = []
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            if os.path.isdir(f"/sys/bus/pci/devices/{bdf}"):
+                cards = [f"/sys/bus/pci/devices/{bdf}"]
+                device_index = 0
+                self.pci = bdf
+        except Exception:  # noqa: BLE001
+            pass
+        if not cards:
+            for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+                try:
+                    if open(os.path.join(dev, "vendor")).read().strip() == "0x1002":
+                        cards.append(dev)
+                except OSError:
+                    pass
+            if len(cards) > 1:
+                cards = []  # several GPUs in /sys and no PCI address to tell which one is ours: rather no reading than another GPU's
+        if cards:
+            dev = cards[min(device_index, len(cards) - 1)]
+            cand = {"sclk_hz": ["hwmon/hwmon*/freq1_input"], "power_uw": ["hwmon/hwmon*/power1_average", "hwmon/hwmon*/power1_input"],
+                    "busy_pct": ["gpu_busy_percent"], "temp_mc": ["hwmon/hwmon*/temp2_input", "hwmon/hwmon*/temp1_input"]}
+            for key, pats in cand.items():
+                for pat in pats:
+                    hits = sorted(glob.glob(os.path.join(dev, pat)))
+                    if hits:
+                        try:
+                            float(open(hits[0]).read().strip())
+                            self.files[key] = hits[0]
+                            break
+                        except (OSError, ValueError):
+                            pass
+        if "sclk_hz" not in self.files:
+            for exe in ("/opt/rocm/bin/rocm-smi", "rocm-smi"):
+                if os.path.exists(exe) or exe == "rocm-smi":
+                    self.smi = [exe, "-d", str(device_index), "--showclocks", "--showpower", "--showuse", "--json"]
+                    break
+
+    def _read_smi(self):
+        import subprocess
+        try:
+            out = subprocess.run(self.smi, capture_output=True, text=True, timeout=10).stdout
+            doc = json.loads(out[out.index("{"):])
+            card = next(iter(doc.values()))
+            row = {}
+            for k, v in card.items():
+                kl = k.lower()
+                if "sclk" in kl and "mhz" in str(v).lower():
+                    row["sclk_hz"] = 1e6 * float(str(v).lower().replace("mhz", "").strip("() "))
+                elif "power" in kl and "(w)" in kl:
+                    try:
+                        row["power_uw"] = 1e6 * float(v)
+                    except ValueError:
+                        pass
+                elif kl.startswith("gpu use"):
+                    try:
+                        row["busy_pct"] = float(v)
+                    except ValueError:
+                        pass
+            return row
+        except Exception:  # noqa: BLE001
+            return {}
+
+    def _loop(self):
+        while not self._stop.is_set():
+            row = {}
+            if self.files:
+                for key, path in self.files.items():
+                    try:
+                        row[key] = float(open(path).read().strip())
+                    except (OSError, ValueError):
+                        pass
+            elif self.smi:
+                row = self._read_smi()
+            if row:
+                self.rows.append(row)
+            self._stop.wait(self.period if self.files else 2.0)
+
+    def start(self):
+        import threading
+        if not self.files and not self.smi:
+            return self
+        self.rows = []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=15)
+            self._thread = None
+        return self.summary()
+
+    def summary(self):
+        if not self.rows:
+            return None
+
+        def col(key, scale):
+            v = sorted(r[key] * scale for r in self.rows if key in r)
+            return None if not v else {"mean": round(sum(v) / len(v), 1), "min": round(v[0], 1), "median": round(v[len(v) // 2], 1), "max": round(v[-1], 1)}
+
+        return {"samples": len(self.rows), "source": f"amdgpu hwmon (sysfs{', PCI ' + self.pci if self.pci else ''}), 10 Hz" if self.files else "rocm-smi --json, 0.5 Hz", "sclk_mhz": col("sclk_hz", 1e-6),
+                "power_w": col("power_uw", 1e-6), "busy_pct": col("busy_pct", 1.0), "temp_c": col("temp_mc", 1e-3)}
+
+
 def timed_region(prove_batch, my_inputs, conc, steps, warmup, dist=None, device_sync=None, reduce_device="cpu"):
     """W untimed warm-up steps, then exactly K timed steps bracketed by barrier + device sync on both sides; returns
     (MAX over ranks of the elapsed seconds, result of the last step). A step = one batch of `conc` proofs (`conc` here is
@@ -66,6 +191,7 @@ def timed_region(prove_batch, my_inputs, conc, steps, warmup, dist=None, device_
     for i in range(warmup):
         prove_batch(my_inputs[i * conc:(i + 1) * conc])
     barrier()
+    sampler = ClockSampler(int(os.environ.get("LOCAL_RANK", "0"))).start()
     t0 = time.perf_counter()
     last = None
     marks = [t0]
@@ -76,6 +202,7 @@ def timed_region(prove_batch, my_inputs, conc, steps, warmup, dist=None, device_
         marks.append(time.perf_counter())  # (diagnostics only: the measurement is the bracket around all K steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    timed_region.clocks = sampler.stop()
     timed_region.step_ms = [round(1000 * (b - a), 1) for a, b in zip(marks, marks[1:])]
     if dist is not None:
         te = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
@@ -138,7 +265,9 @@ def transformer_layer_section(dpa, dev, conc=320):  # (round 3: 64 in flight 87 
     gslot = (nb - 1) * conc + min(GOLDEN_SLOT, conc - 1)
     xs[gslot] = x
     pr.prove_batch(xs[:conc], conc)
+    sampler = ClockSampler(int(os.environ.get("LOCAL_RANK", "0"))).start()
     t0 = time.perf_counter(); proofs, outs, _ = pr.prove_batch(xs, conc); dt = time.perf_counter() - t0
+    clocks = sampler.stop()
     gp = proofs[gslot]
     golden_ok = bool(gp.size == c["proof_words"] and hashlib.sha256(gp.tobytes()).hexdigest() == c["proof_sha256"]
                      and hashlib.sha256(np.ascontiguousarray(outs[gslot]).tobytes()).hexdigest() == c["output_sha256"])
@@ -148,7 +277,7 @@ def transformer_layer_section(dpa, dev, conc=320):  # (round 3: 64 in flight 87 
     assert not v.any(), f"transformer layer: {int((v != 0).sum())} of {conc} proofs of the last batch were rejected"
     r = {"value": round(len(xs) / dt, 2), "unit": "proofs/s", "workload": f"one pre-LN transformer layer, {len(g.nodes)} nodes, seq {a['seq']} x emb {a['emb']}, {a['heads']} heads of {a['head_dim']}, ffn {a['ffn']} (Mha as one node; ReLU for GELU) = golden case 14",
          "proofs": len(xs), "proofs_in_flight": int(pr.in_flight()), "single_proof_latency_ms": round(sorted(lat)[1], 2), "proof_words": int(proof.size),
-         "golden_sha256_ok": golden_ok, "golden_sha256_ok_latency_mode": latency_golden_ok, "verified": int(conc), "rejected": int(v.sum()), "verify_batch_ms_per_proof": round(vms / conc, 3)}
+         "golden_sha256_ok": golden_ok, "golden_sha256_ok_latency_mode": latency_golden_ok, "verified": int(conc), "rejected": int(v.sum()), "verify_batch_ms_per_proof": round(vms / conc, 3), "gpu_clocks_timed_region": clocks}
     ctx.free()
     return r
 
@@ -190,6 +319,7 @@ def measure_workload(dpa, dev, workload, conc, steps, warmup, world, rank, dist,
     elapsed, last = timed_region(lambda xs: prover.prove_batch(xs, conc), my_inputs, batch, steps, warmup, dist,
                                  torch.cuda.synchronize if cuda else None, "cuda" if cuda else "cpu")
     step_ms = list(getattr(timed_region, "step_ms", []))
+    clocks = getattr(timed_region, "clocks", None)
     # EVERY proof of the last step must verify — an invalid proof voids the measurement. One proof through the host-only
     # verifier (dp_verify, the latency figure: protocol checks on one thread, its Merkle paths on up to 8, DP_VERIFY_THREADS), then the whole step through dp_verify_batch: protocol checks on the host
     # threads, the Merkle paths of each proof (125 000 compress() for Dense-4M) authenticated on the GPU in one launch.
@@ -212,7 +342,7 @@ def measure_workload(dpa, dev, workload, conc, steps, warmup, world, rank, dist,
     rep = kernel_profile(dev, prover, my_inputs[0]) if profile else None
     ctx.free()  # releases the workers' arenas too: the next workload sizes its own against the free HBM
     return dict(mb=mb, elapsed=elapsed, latency_ms=latency_ms, latency_samples_ms=[round(v, 2) for v in lat], first_ms=first_ms, setup_s=setup_s, proof_words=int(last[0][0].size),
-                verified=checked, step_ms=step_ms, verify_ms=round(1000 * one, 2), verify_batch_ms_per_proof=round(vb_ms / max(1, checked), 3), in_flight=in_flight, kernel_report=rep, golden_ok=golden_ok)
+                verified=checked, step_ms=step_ms, verify_ms=round(1000 * one, 2), verify_batch_ms_per_proof=round(vb_ms / max(1, checked), 3), in_flight=in_flight, kernel_report=rep, golden_ok=golden_ok, clocks=clocks)
 
 
 def cnn_steps(steps):
@@ -393,6 +523,19 @@ def main():
         merkle = [r for r in rep if r["kernel"].startswith("k_merkle_layer")]
         nodes_per_proof = sum(r["alg_bytes"] for r in merkle) / 96.0
         peak = max(dev.probe_compress_rate(1 << 21, 8) for _ in range(4))  # best of 4 bursts: a single short burst right after a batch can catch the clocks ramping
+        # the same probe held for ~1.5 s with the clock sampler on: what the kernel sustains once the power management has settled (the bursts above are 8 ms long)
+        sustained = None
+        try:
+            smp = ClockSampler(int(os.environ.get("LOCAL_RANK", "0"))).start()
+            t_s, rates = time.perf_counter(), []
+            while time.perf_counter() - t_s < 1.5:
+                rates.append(dev.probe_compress_rate(1 << 21, 32))
+            sck = smp.stop()
+            tail_rates = rates[len(rates) // 2:]  # the second half: after the clocks have settled
+            sustained = {"compress_per_s": round(sum(tail_rates) / len(tail_rates) / 1e9, 4), "bursts_of_32_launches": len(rates), "first_burst": round(rates[0] / 1e9, 4),
+                         "last_burst": round(rates[-1] / 1e9, 4), "gpu_clocks": sck}
+        except Exception as e:  # noqa: BLE001
+            sustained = {"error": f"{type(e).__name__}: {e}"}
         wide = [r for r in merkle if r["kernel"] == "k_merkle_layer"]  # the one-node-per-lane kernel of the wide layers (the _lp / tail variants serve layers too narrow to fill the chip)
         dom = wide[0] if wide else max(merkle, key=lambda r: r["total_ms"]) if merkle else rep[0]
         avg_ms = dom["total_ms"] / dom["launches"]
@@ -406,6 +549,7 @@ def main():
                     "alg_bytes_per_launch": round(dom["alg_bytes"] / dom["launches"], 1), "nodes_per_launch": round(nodes_per_launch, 1),
                     "launches_per_proof": dom["launches"], "avg_launch_us": round(1000 * avg_ms, 3),
                     "peak_note": "k_merkle_layer on a 2^21-node layer, best of 4 bursts of 8 launches, HIP events, this run; 1 compress = 2 Poseidon2-w8 permutations = ~1040 Goldilocks multiplications",
+                    "peak_sustained": sustained, "job_frac_of_sustained_peak": round(job_compress / (1e9 * sustained["compress_per_s"]), 4) if sustained and sustained.get("compress_per_s") else None,
                     "job_compress_per_s": round(job_compress / 1e9, 4), "job_frac": round(job_compress / peak, 4) if peak else None,
                     "job_goldilocks_mul_per_s": round(1040.0 * job_compress / 1e12, 4), "merkle_nodes_per_proof": int(nodes_per_proof),
                     "job_alg_GBps": round(alg_bytes_per_proof * value / world / 1e9, 1), "job_hbm_frac": round(alg_bytes_per_proof * value / world / 1e9 / HBM_PEAK_GBS, 5),
@@ -427,6 +571,11 @@ def main():
             roofline["valu_wave_instr_per_proof"] = sq["valu_wave_instr_per_proof"]
             roofline["valu_issue_util"] = round(sq["valu_wave_instr_per_proof"] * (value / world) / sq["chip_issue_capacity_wave_instr_per_s"], 4)
             roofline["valu_hash_share"] = sq.get("hash_share"); roofline["valu_one_wave_share"] = sq.get("one_wave_share")
+            # the same share priced at the shader clock the GPU actually held during the timed steps (ClockSampler) instead of the 2.4 GHz the counter pass assumes
+            ck = (main_w.get("clocks") or {}).get("sclk_mhz")
+            if ck and ck.get("mean") and sq.get("assumed", {}).get("clock_hz"):
+                roofline["sclk_mhz_timed_region"] = ck["mean"]
+                roofline["valu_issue_util_at_sampled_clock"] = round(roofline["valu_issue_util"] * sq["assumed"]["clock_hz"] / (1e6 * ck["mean"]), 4)
             roofline["valu_source"] = sq["source"]
         cpu = None if (world > 1 or args.no_cpu_baseline) else cpu_baseline(main_w["mb"], args.workload)
         sc24 = None if (world > 1 or args.no_sumcheck24) else sumcheck24(dev, dpa)
@@ -435,7 +584,7 @@ def main():
             csteps = cnn_steps(args.steps)
             cnn = {"metric": "proofs/sec (prover), CNN-264k", "value": round(rate(cnn_w, csteps), 4), "unit": "proofs/s",
                    "ms_per_step": round(1000.0 * cnn_w["elapsed"] / csteps, 3), "steps": csteps, "proofs_per_step_per_gpu": BATCHES_PER_STEP * conc, "proofs_in_flight_per_gpu": cnn_w["in_flight"],
-                   "single_proof_latency_ms": round(cnn_w["latency_ms"], 2), "vs_baseline": round(rate(cnn_w, csteps) / PUBLISHED["cnn_264k"], 3),
+                   "single_proof_latency_ms": round(cnn_w["latency_ms"], 2), "gpu_clocks_timed_region": cnn_w.get("clocks"), "vs_baseline": round(rate(cnn_w, csteps) / PUBLISHED["cnn_264k"], 3),
                    "baseline_note": "reference README.md:17 CNN-264k proving time 1242 ms on unstated CPU hardware",
                    "workload": WORKLOADS["cnn_264k"], "proof_words": cnn_w["proof_words"], "setup_s": round(cnn_w["setup_s"], 2), "verified": True, "golden_sha256_ok": cnn_w["golden_ok"], "verified_proofs_of_last_step": cnn_w["verified"], "verify_batch_ms_per_proof": cnn_w["verify_batch_ms_per_proof"],
                    "cpu_baseline": None if (world > 1 or args.no_cpu_baseline) else cpu_baseline(cnn_w["mb"], "cnn_264k")}
@@ -453,6 +602,7 @@ def main():
                                                "every rank commits the model itself (Context::generate recomputed per rank, outside the timed region), no data-path collective") if args.batch else None,
                        "single_proof_latency_ms": round(main_w["latency_ms"], 2), "single_proof_latency_samples_ms": main_w["latency_samples_ms"], "first_proof_ms": round(main_w["first_ms"], 2),
                        "host_cpu_budget": budget, "host_threads_per_rank": int(os.environ["DP_HOST_THREADS"]), "host_bound": bool(host_bound),
+                       "gpu_clocks_timed_region": main_w.get("clocks"),
                        "min_cpus_per_gpu": MIN_HOST_THREADS_PER_RANK + 2, "per_rank": per_rank,
                        "parallelism": f"replicas x{world} GPUs x {main_w['in_flight']} proofs in flight per GPU in lock-step cohorts of {os.environ.get('DP_COHORT') or -(-main_w['in_flight'] // 22)} (independent proofs, no data-path collective)",
                        "proof_words": main_w["proof_words"], "setup_s": round(main_w["setup_s"], 2), "verified": True, "golden_sha256_ok": main_w["golden_ok"], "verified_proofs_of_last_step": main_w["verified"], "verify_ms_per_proof": main_w["verify_ms"], "verify_batch_ms_per_proof": main_w["verify_batch_ms_per_proof"],
@@ -462,7 +612,7 @@ def main():
         }
         if world == 1 and args.workload == "dense_4m" and not args.batch and not args.no_transformer:
             try:  # (a side section: whatever happens in it, the headline line above is printed)
-                result["transformer_layer"] = transformer_layer_section(dpa, dev)
+                result["transformer_layer"] = transformer_layer_section(dpa, dev, conc=int(os.environ.get("DP_BENCH_TL_IN_FLIGHT", "320")))
             except Exception as e:  # noqa: BLE001
                 result["transformer_layer"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 

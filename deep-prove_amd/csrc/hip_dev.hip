@@ -41,9 +41,9 @@ namespace dp {
 
 
 // ================================================================================================ HipDev
-// Grid size for grid-stride kernels. DP_MAX_GRID bounds every launch so that, with several proofs in flight on one GPU,
-// a large kernel of one proof cannot occupy every wave slot while another proof's latency-critical one-block kernels
-// wait for a CU.
+// Grid size for grid-stride kernels: `cap` bounds a launch of ONE proof (a merged cohort launch has gridDim.z = members times as many workgroups).
+// A lower global cap was swept at 448 proofs in flight (8 / 24 / 64 / 256 workgroups per proof and launch against up to 4096): 470 / 513 / 566 / 491
+// against 531-534 proofs/s, i.e. nothing outside the +-5 % between runs (profiles/r04_grid_cap_sweep.txt); there is no knob for it any more.
 static inline int grid_for(size_t n, int cap = 2048) {
   size_t b = (n + TPB - 1) / TPB;
   if (b < 1) b = 1;
@@ -1803,19 +1803,49 @@ class HipDev : public Dev {
     for (int i = 0; i < 2 * np; i++) out[i] = ex(hres_[2 * i], hres_[2 * i + 1]);
     release(mk);
   }
+  // DP_AXPY_CLASSES=0: every descriptor straight into the one pass over the accumulator (nd x n_acc multiplications), as before round 4's last session
+  bool axpy_classes_ = knob("DP_AXPY_CLASSES", 1) != 0;
   void axpy_many(const DBuf& acc, const DBuf* init, const AxpyJob* jobs, size_t n) override {
     DP_REQUIRE(acc.ext && (!init || (init->ext && init->n == acc.n)), DP_ERR_SHAPE, "axpy_many: accumulator shape");
-    if (n * sizeof(AxpyDesc) + 64 > DESC_BYTES) { Dev::axpy_many(acc, init, jobs, n); return; }
-    const AxpyDesc* dd = nullptr;
-    AxpyDesc* hd = desc_alloc<AxpyDesc>(std::max<size_t>(n, 1), &dd);
+    for (size_t i = 0; i < n; i++) DP_REQUIRE(acc.n == jobs[i].x.n * jobs[i].rep && (jobs[i].rep & (jobs[i].rep - 1)) == 0, DP_ERR_SHAPE, "axpy_many: shapes");
+    // the jobs shorter than the accumulator, by length: summed among themselves first (k_axpy_classes), added with their repetition afterwards
+    std::map<unsigned, std::vector<size_t>> classes;
+    size_t nshort = 0;
+    if (axpy_classes_) for (size_t i = 0; i < n; i++) if (jobs[i].rep > 1) { classes[dp_ceil_log2(jobs[i].rep)].push_back(i); nshort++; }
+    const bool grouped = nshort >= 2;
+    const size_t nfinal = grouped ? n - nshort + classes.size() : n;
+    if ((n + nfinal + 1) * sizeof(AxpyDesc) + classes.size() * sizeof(AxpyClass) + 256 > DESC_BYTES) { Dev::axpy_many(acc, init, jobs, n); return; }
+    auto fill = [](AxpyDesc& d, const AxpyJob& j, unsigned lg) { d.x = j.x.p; d.xext = j.x.ext; d.lg_rep = lg; d.n_x = j.x.n; d.coeff = j.coeff; };
     double bytes = 16.0 * acc.n * (init ? 2 : 1);
-    for (size_t i = 0; i < n; i++) {
-      const AxpyJob& j = jobs[i];
-      DP_REQUIRE(acc.n == j.x.n * j.rep && (j.rep & (j.rep - 1)) == 0, DP_ERR_SHAPE, "axpy_many: shapes");
-      hd[i].x = j.x.p; hd[i].xext = j.x.ext; hd[i].lg_rep = dp_ceil_log2(j.rep); hd[i].n_x = j.x.n; hd[i].coeff = j.coeff;
-      bytes += j.x.bytes();
+    if (!grouped) {
+      const AxpyDesc* dd = nullptr;
+      AxpyDesc* hd = desc_alloc<AxpyDesc>(std::max<size_t>(n, 1), &dd);
+      for (size_t i = 0; i < n; i++) { fill(hd[i], jobs[i], dp_ceil_log2(jobs[i].rep)); bytes += jobs[i].x.bytes(); }
+      nb_ = bytes; DPL(k_axpy_many, dim3(grid_for(acc.n)), dim3(TPB), (Ext*)acc.p, init ? (const Ext*)init->p : (const Ext*)nullptr, acc.n, dd, (int)n);
+      return;
     }
-    nb_ = bytes; DPL(k_axpy_many, dim3(grid_for(acc.n)), dim3(TPB), (Ext*)acc.p, init ? (const Ext*)init->p : (const Ext*)nullptr, acc.n, dd, (int)n);
+    const size_t mk = mark();
+    // one descriptor block for both launches (a second desc_alloc may wrap the staging ring): [class members][final pass][classes]
+    static_assert(sizeof(AxpyDesc) % 16 == 0 && sizeof(AxpyClass) % 8 == 0, "descriptor layout");
+    const AxpyDesc* cdd = nullptr;
+    AxpyDesc* chd = desc_alloc<AxpyDesc>(nshort + nfinal + (classes.size() * sizeof(AxpyClass) + sizeof(AxpyDesc) - 1) / sizeof(AxpyDesc), &cdd);
+    AxpyDesc* fhd = chd + nshort; const AxpyDesc* fdd = cdd + nshort;
+    AxpyClass* cc = (AxpyClass*)(fhd + nfinal); const AxpyClass* ccd = (const AxpyClass*)(fdd + nfinal);
+    size_t ci = 0, di = 0, fi = 0, maxn = 0;
+    double cbytes = 0;
+    for (size_t i = 0; i < n; i++) if (jobs[i].rep == 1) { fill(fhd[fi++], jobs[i], 0); bytes += jobs[i].x.bytes(); }
+    for (auto& kv : classes) {
+      const size_t cn = acc.n >> kv.first;
+      DBuf sum = alloc(cn, true);
+      cc[ci].out = (Ext*)sum.p; cc[ci].n = cn; cc[ci].first = (int)di; cc[ci].count = (int)kv.second.size();
+      for (size_t i : kv.second) { fill(chd[di++], jobs[i], 0); cbytes += jobs[i].x.bytes(); }
+      fhd[fi].x = sum.p; fhd[fi].xext = 2; fhd[fi].lg_rep = kv.first; fhd[fi].n_x = cn; fhd[fi].coeff = ex_one(); fi++;
+      cbytes += 16.0 * cn; bytes += 16.0 * cn;
+      maxn = std::max(maxn, cn); ci++;
+    }
+    nb_ = cbytes; DPL(k_axpy_classes, dim3(grid_for(maxn, 256), (unsigned)classes.size()), dim3(TPB), ccd, cdd);
+    nb_ = bytes; DPL(k_axpy_many, dim3(grid_for(acc.n)), dim3(TPB), (Ext*)acc.p, init ? (const Ext*)init->p : (const Ext*)nullptr, acc.n, fdd, (int)nfinal);
+    release(mk);
   }
   void axpy_rep(const DBuf& acc, const DBuf& x, Ext coeff, size_t rep) override {
     DP_REQUIRE(acc.ext && acc.n == x.n * rep && (rep & (rep - 1)) == 0, DP_ERR_SHAPE, "axpy_rep: shapes");

@@ -3,7 +3,7 @@ scheme wraps: one single proof (latency mode), one warm batch that creates the w
 usage: python tools/profile_batch.py [workload] [in_flight]"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import deep_prove_amd as dpa
 wl = sys.argv[1] if len(sys.argv) > 1 else "dense_4m"

@@ -3,7 +3,7 @@ Context::generate and of the warm-up proof SEPARATED from the measured proofs: a
 by nothing else) sits between them as a marker, and tools/pmc_summary.py --after-marker k_merkle_paths drops every launch up to it.
 The population of the summary is then exactly `argv[2]` proofs (default 3) — what bench.py's kernel_profile times."""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import deep_prove_amd as dpa
 workload = sys.argv[1] if len(sys.argv) > 1 else "dense_4m"
