@@ -10,6 +10,8 @@ canonical stream must equal the oracle's (`golden_sha256_ok`): what is timed is 
 not merely accepted by the verifier. The same JSON line carries CNN-264k
 (configs[2]) measured the same way, the standalone 2^24 sumcheck (configs[4] on one GPU) with its HBM roofline, and the CPU
 baseline (the oracle, i.e. a single-threaded port of the reference CPU path, on a bounded sample).
+`config.gpu_clocks_timed_region` = shader clock / package power / busy percentage of THIS process's GPU (amdgpu hwmon, found by PCI address) sampled at 10 Hz while the
+timed steps run; `roofline.peak_sustained` = the compress probe held for 1.5 s with the same sampler on.
 Multi-GPU (launched by torch.distributed.run): independent proofs shard across ranks with no data-path collective
 ("replicas") -> weak scaling; only the timing uses a collective (MAX over ranks).
 """
@@ -57,7 +59,8 @@ class ClockSampler:
     2.4 GHz boost clock, and every "fraction of the VALU issue slots" quoted from a counter pass is only as good as the clock it assumes. Never fails the
     bench: whatever cannot be read is missing from the summary."""
 
-    def __init__(self, device_index=0, period_s=0.1):
+    def __init__(self, device_index=0, period_s=0.1, sysfs_device=None):
+        """sysfs_device: the device directory to read instead of looking this process's GPU up (tests point it at a fake tree)"""
         import glob
         self.period = period_s
         self.rows = []
@@ -67,8 +70,10 @@ class ClockSampler:
         self._stop = None
         self._thread = None
         # the sysfs node of THIS process's HIP device, by PCI address (a box shows every GPU of the node in /sys, the container only owns some of them)
-        cards = []
+        cards = [sysfs_device] if sysfs_device else []
         try:
+            if cards:
+                raise LookupError("given")
             import torch
             pr = torch.cuda.get_device_properties(device_index)
             bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
@@ -78,7 +83,7 @@ class ClockSampler:
                 self.pci = bdf
         except Exception:  # noqa: BLE001
             pass
-        if not cards:
+        if not cards and os.path.isdir("/sys/class/drm"):
             for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
                 try:
                     if open(os.path.join(dev, "vendor")).read().strip() == "0x1002":
@@ -88,7 +93,7 @@ class ClockSampler:
             if len(cards) > 1:
                 cards = []  # several GPUs in /sys and no PCI address to tell which one is ours: rather no reading than another GPU's
         if cards:
-            dev = cards[min(device_index, len(cards) - 1)]
+            dev = cards[0]
             cand = {"sclk_hz": ["hwmon/hwmon*/freq1_input"], "power_uw": ["hwmon/hwmon*/power1_average", "hwmon/hwmon*/power1_input"],
                     "busy_pct": ["gpu_busy_percent"], "temp_mc": ["hwmon/hwmon*/temp2_input", "hwmon/hwmon*/temp1_input"]}
             for key, pats in cand.items():

@@ -196,3 +196,27 @@ def test_bench_spawns_its_own_ranks(extra):
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec["launch_check"] and rec["world"] == 2 and rec["ranks_seen"] == 2 and rec["batch"] == (64 if extra else 0)
+
+
+def test_clock_sampler_reads_a_hwmon_tree(tmp_path):
+    """bench.ClockSampler on a fake amdgpu device directory: units (Hz, uW, millidegrees), summary statistics, and silence when nothing can be read"""
+    import time
+    import bench
+    hw = tmp_path / "hwmon" / "hwmon3"
+    hw.mkdir(parents=True)
+    (hw / "freq1_input").write_text("2349000000\n")
+    (hw / "power1_input").write_text("769000000\n")
+    (hw / "temp2_input").write_text("50000\n")
+    (tmp_path / "gpu_busy_percent").write_text("100\n")
+    s = bench.ClockSampler(0, period_s=0.01, sysfs_device=str(tmp_path)).start()
+    time.sleep(0.1)
+    (hw / "freq1_input").write_text("2313000000\n")
+    time.sleep(0.1)
+    r = s.stop()
+    assert r["samples"] >= 4 and r["sclk_mhz"]["max"] == 2349.0 and r["sclk_mhz"]["min"] == 2313.0 and 2313.0 < r["sclk_mhz"]["mean"] < 2349.0
+    assert r["power_w"]["mean"] == 769.0 and r["busy_pct"]["median"] == 100.0 and r["temp_c"]["max"] == 50.0
+    empty = tmp_path / "none"
+    empty.mkdir()
+    e = bench.ClockSampler(0, sysfs_device=str(empty))
+    e.smi = None  # (no rocm-smi fallback in the test)
+    assert e.start().stop() is None
