@@ -12,6 +12,7 @@
 #include "sumcheck.h"
 #include "fiber.h"
 #include "logup_tail.h"
+#include "axpy_many.h"
 #include "classic_tail.h"
 #include "dense_tail.h"
 #include "eqsum_tail.h"
@@ -1807,44 +1808,20 @@ class HipDev : public Dev {
   bool axpy_classes_ = knob("DP_AXPY_CLASSES", 1) != 0;
   void axpy_many(const DBuf& acc, const DBuf* init, const AxpyJob* jobs, size_t n) override {
     DP_REQUIRE(acc.ext && (!init || (init->ext && init->n == acc.n)), DP_ERR_SHAPE, "axpy_many: accumulator shape");
-    for (size_t i = 0; i < n; i++) DP_REQUIRE(acc.n == jobs[i].x.n * jobs[i].rep && (jobs[i].rep & (jobs[i].rep - 1)) == 0, DP_ERR_SHAPE, "axpy_many: shapes");
-    // the jobs shorter than the accumulator, by length: summed among themselves first (k_axpy_classes), added with their repetition afterwards
-    std::map<unsigned, std::vector<size_t>> classes;
-    size_t nshort = 0;
-    if (axpy_classes_) for (size_t i = 0; i < n; i++) if (jobs[i].rep > 1) { classes[dp_ceil_log2(jobs[i].rep)].push_back(i); nshort++; }
-    const bool grouped = nshort >= 2;
-    const size_t nfinal = grouped ? n - nshort + classes.size() : n;
-    if ((n + nfinal + 1) * sizeof(AxpyDesc) + classes.size() * sizeof(AxpyClass) + 256 > DESC_BYTES) { Dev::axpy_many(acc, init, jobs, n); return; }
-    auto fill = [](AxpyDesc& d, const AxpyJob& j, unsigned lg) { d.x = j.x.p; d.xext = j.x.ext; d.lg_rep = lg; d.n_x = j.x.n; d.coeff = j.coeff; };
-    double bytes = 16.0 * acc.n * (init ? 2 : 1);
-    if (!grouped) {
-      const AxpyDesc* dd = nullptr;
-      AxpyDesc* hd = desc_alloc<AxpyDesc>(std::max<size_t>(n, 1), &dd);
-      for (size_t i = 0; i < n; i++) { fill(hd[i], jobs[i], dp_ceil_log2(jobs[i].rep)); bytes += jobs[i].x.bytes(); }
-      nb_ = bytes; DPL(k_axpy_many, dim3(grid_for(acc.n)), dim3(TPB), (Ext*)acc.p, init ? (const Ext*)init->p : (const Ext*)nullptr, acc.n, dd, (int)n);
-      return;
-    }
+    AxpyPlan p = axpy_plan(jobs, n, acc.n, axpy_classes_);  // axpy_many.h: the jobs shorter than the accumulator are summed among their own length first
+    const size_t nfinal = std::max<size_t>(p.final_pass.size(), 1), nclass_desc = (p.classes.size() * sizeof(AxpyClass) + sizeof(AxpyDesc) - 1) / sizeof(AxpyDesc);
+    if ((p.members.size() + nfinal + nclass_desc) * sizeof(AxpyDesc) + 256 > DESC_BYTES) { Dev::axpy_many(acc, init, jobs, n); return; }
     const size_t mk = mark();
     // one descriptor block for both launches (a second desc_alloc may wrap the staging ring): [class members][final pass][classes]
-    static_assert(sizeof(AxpyDesc) % 16 == 0 && sizeof(AxpyClass) % 8 == 0, "descriptor layout");
     const AxpyDesc* cdd = nullptr;
-    AxpyDesc* chd = desc_alloc<AxpyDesc>(nshort + nfinal + (classes.size() * sizeof(AxpyClass) + sizeof(AxpyDesc) - 1) / sizeof(AxpyDesc), &cdd);
-    AxpyDesc* fhd = chd + nshort; const AxpyDesc* fdd = cdd + nshort;
+    AxpyDesc* chd = desc_alloc<AxpyDesc>(p.members.size() + nfinal + nclass_desc, &cdd);
+    AxpyDesc* fhd = chd + p.members.size(); const AxpyDesc* fdd = cdd + p.members.size();
     AxpyClass* cc = (AxpyClass*)(fhd + nfinal); const AxpyClass* ccd = (const AxpyClass*)(fdd + nfinal);
-    size_t ci = 0, di = 0, fi = 0, maxn = 0;
-    double cbytes = 0;
-    for (size_t i = 0; i < n; i++) if (jobs[i].rep == 1) { fill(fhd[fi++], jobs[i], 0); bytes += jobs[i].x.bytes(); }
-    for (auto& kv : classes) {
-      const size_t cn = acc.n >> kv.first;
-      DBuf sum = alloc(cn, true);
-      cc[ci].out = (Ext*)sum.p; cc[ci].n = cn; cc[ci].first = (int)di; cc[ci].count = (int)kv.second.size();
-      for (size_t i : kv.second) { fill(chd[di++], jobs[i], 0); cbytes += jobs[i].x.bytes(); }
-      fhd[fi].x = sum.p; fhd[fi].xext = 2; fhd[fi].lg_rep = kv.first; fhd[fi].n_x = cn; fhd[fi].coeff = ex_one(); fi++;
-      cbytes += 16.0 * cn; bytes += 16.0 * cn;
-      maxn = std::max(maxn, cn); ci++;
-    }
-    nb_ = cbytes; DPL(k_axpy_classes, dim3(grid_for(maxn, 256), (unsigned)classes.size()), dim3(TPB), ccd, cdd);
-    nb_ = bytes; DPL(k_axpy_many, dim3(grid_for(acc.n)), dim3(TPB), (Ext*)acc.p, init ? (const Ext*)init->p : (const Ext*)nullptr, acc.n, fdd, (int)nfinal);
+    for (size_t c = 0; c < p.classes.size(); c++) { DBuf sum = alloc(p.classes[c].n, true); p.classes[c].out = (Ext*)sum.p; p.final_pass[p.class_final[c]].x = sum.p; }
+    std::copy(p.members.begin(), p.members.end(), chd); std::copy(p.final_pass.begin(), p.final_pass.end(), fhd); std::copy(p.classes.begin(), p.classes.end(), cc);
+    if (p.grouped) { nb_ = p.member_bytes; DPL(k_axpy_classes, dim3(grid_for(p.max_class_n, 256), (unsigned)p.classes.size()), dim3(TPB), ccd, cdd); }
+    nb_ = 16.0 * acc.n * (init ? 2 : 1) + p.final_bytes;
+    DPL(k_axpy_many, dim3(grid_for(acc.n)), dim3(TPB), (Ext*)acc.p, init ? (const Ext*)init->p : (const Ext*)nullptr, acc.n, fdd, (int)p.final_pass.size());
     release(mk);
   }
   void axpy_rep(const DBuf& acc, const DBuf& x, Ext coeff, size_t rep) override {

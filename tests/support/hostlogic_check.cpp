@@ -560,6 +560,7 @@ int main(int argc, char** argv) {
   printf("emulated k_logup_tail (%s mode, %u threads): %zu logup proofs taken, %zu declined\n", dev.full ? "full" : "tail", dev.threads, dev.taken, dev.declined);
   printf("emulated k_classic_tail: %zu batch-opening sumcheck tails taken\n", dev.classic_taken);
   printf("emulated k_classic_fused: %zu rounds, %zu factored (lo, hi) pairs; k_eq_outer_many: %zu tables\n", dev.classic_rounds_emulated, dev.classic_factored_pairs, dev.eq_outer_emulated);
+  printf("emulated k_axpy_many: %zu passes, %zu with class sums (k_axpy_classes: %zu classes)\n", dev.axpy_emulated, dev.axpy_grouped, dev.axpy_classes_emulated);
   printf("emulated k_dense_tail: %zu dense layers taken\n", dev.dense_taken);
   printf("emulated k_eqsum_tail: %zu eq + sumcheck groups taken\n", dev.eqsum_taken);
   printf("emulated k_deleg_tail: %zu delegation chains taken (%zu sumchecks)\n", dev.deleg_taken, dev.deleg_sumchecks);

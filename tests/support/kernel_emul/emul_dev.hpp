@@ -5,6 +5,7 @@
 #include "../cpu_dev.hpp"
 #include "../../../deep-prove_amd/csrc/poseidon2_fast.h"
 #include "../../../deep-prove_amd/csrc/logup_tail.h"
+#include "../../../deep-prove_amd/csrc/axpy_many.h"
 #include "../../../deep-prove_amd/csrc/classic_tail.h"
 #include "../../../deep-prove_amd/csrc/dense_tail.h"
 #include "../../../deep-prove_amd/csrc/eqsum_tail.h"
@@ -219,6 +220,28 @@ struct EmulDev : CpuDev {
       out[2 * i] = c0; out[2 * i + 1] = c2;
     }
     classic_rounds_emulated++;
+  }
+  // Dev::axpy_many from the device source of k_axpy_classes / k_axpy_many, planned by the product's own host code (csrc/axpy_many.h): the short jobs summed
+  // among their own length first (blockIdx.y = class), then the pass over the accumulator — three workgroups of 64 lanes each (the unrolled four-elements-
+  // per-lane body AND the scalar remainder loop run); DP_EMUL_AXPY_CLASSES=0: the one-pass form
+  size_t axpy_emulated = 0, axpy_grouped = 0, axpy_classes_emulated = 0;
+  void axpy_many(const DBuf& acc, const DBuf* init, const AxpyJob* jobs, size_t n) override {
+    DP_REQUIRE(acc.ext && (!init || (init->ext && init->n == acc.n)), DP_ERR_SHAPE, "axpy_many: accumulator shape");
+    const char* e = getenv("DP_EMUL_AXPY_CLASSES");
+    AxpyPlan p = axpy_plan(jobs, n, acc.n, !(e && !atoi(e)));
+    const size_t mk = mark();
+    for (size_t c = 0; c < p.classes.size(); c++) { DBuf sum = alloc(p.classes[c].n, true); p.classes[c].out = (Ext*)sum.p; p.final_pass[p.class_final[c]].x = sum.p; }
+    blockDim.x.v = 64; gridDim.x.v = 3;
+    if (p.grouped) {
+      gridDim.y.v = (unsigned)p.classes.size();
+      for (unsigned y = 0; y < p.classes.size(); y++) for (unsigned b = 0; b < 3; b++) { blockIdx.x.v = b; blockIdx.y.v = y; simt::launch(64, [&] { k_axpy_classes(p.classes.data(), p.members.data()); }); }
+      blockIdx.y.v = 0; gridDim.y.v = 1;
+      axpy_grouped++; axpy_classes_emulated += p.classes.size();
+    }
+    for (unsigned b = 0; b < 3; b++) { blockIdx.x.v = b; simt::launch(64, [&] { k_axpy_many((Ext*)acc.p, init ? (const Ext*)init->p : (const Ext*)nullptr, acc.n, p.final_pass.data(), (int)p.final_pass.size()); }); }
+    blockIdx.x.v = 0; gridDim.x.v = 1;
+    release(mk);
+    axpy_emulated++;
   }
   void eq_outer_many(const EqOuterJob* jobs, size_t n) override {
     std::vector<EqOuterDesc> d(n);

@@ -66,6 +66,8 @@ def test_whole_model_proofs_with_every_logup_proof_from_the_emulated_kernel():
         fused = r.stdout.split("emulated k_classic_fused: ")[1].split()  # ... and the streamed rounds before it, on factored eq tables
         assert int(fused[0]) >= 1 and int(fused[2]) >= 1, r.stdout
         assert int(r.stdout.split("k_eq_outer_many: ")[1].split()[0]) >= 1, r.stdout          # ... written out (k_eq_outer_many) where the tail takes over
+        ax = r.stdout.split("emulated k_axpy_many: ")[1].split()  # ... and the batch opening's sums over codewords / evaluation tables, the short ones class by class first (k_axpy_classes)
+        assert int(ax[0]) >= 2 and int(ax[2]) >= 1 and int(ax[7]) >= 2, r.stdout
         assert int(r.stdout.split("emulated k_dense_tail: ")[1].split()[0]) >= 1, r.stdout    # ... and every Dense layer (bias, fix_high, sumcheck)
         assert int(r.stdout.split("emulated k_eqsum_tail: ")[1].split()[0]) >= 2, r.stdout    # ... and the accumulation sumchecks of Requant / ReLU
         if args[0] == "cnn":  # ... and the delegation chains of the FFT / FFT-of-weights / iFFT of the convolution, each in one launch (k_deleg_tail)
@@ -75,6 +77,18 @@ def test_whole_model_proofs_with_every_logup_proof_from_the_emulated_kernel():
         if "DP_EMUL_COMMIT_MAX_N" in env:  # several rounds in one launch: FRI folds, messages and Merkle trees, not only the final round
             assert int(r.stdout.split("commit-phase tails taken (")[1].split()[0]) >= 4, r.stdout
         assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
+
+
+def test_batch_opening_sums_with_and_without_class_sums():
+    """k_axpy_many / k_axpy_classes (csrc/axpy_many.h plans them): the polynomials shorter than the accumulator summed among their own length first, or — DP_EMUL_AXPY_CLASSES=0,
+    the product's DP_AXPY_CLASSES=0 — every descriptor in the one pass; three workgroups of 64 lanes, so the four-elements-per-lane body and the remainder loop both run.
+    Either way the proof equals the oracle's byte for byte"""
+    for env, grouped in (({}, True), ({"DP_EMUL_AXPY_CLASSES": "0"}, False)):
+        r = _model((16, 3), env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "identical=1" in r.stdout and "verify(product): ACCEPT" in r.stdout, r.stdout
+        ax = r.stdout.split("emulated k_axpy_many: ")[1].split()
+        assert int(ax[0]) >= 3 and (int(ax[2]) >= 1) == grouped, r.stdout
 
 
 def test_single_polynomial_open_with_the_emulated_commit_tail():
