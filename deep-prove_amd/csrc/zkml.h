@@ -12,6 +12,7 @@
 #include "pcs.h"
 #include "cnn.h"
 #include <unordered_map>
+#include <mutex>
 #include <algorithm>
 #include <memory>
 #include <chrono>
@@ -607,6 +608,23 @@ struct Context {
   std::map<size_t, ConvDev> conv_dev;
   std::vector<TableType> tables;
   std::map<TableType, DevCommit> table_comms;  // the committed columns of the tables that have one (commit/context.rs:105-107)
+  // The columns of a lookup table are a property of the MODEL: built once per context (a softmax table is 2^size calls of expf, an inverse-square-root
+  // table 2^14 of sqrt), not once per proof as until round 4. inv_cnt[i] = 1 / (number of rows of the table that hold merged[i]) — the zero padding
+  // of an error table repeats a row —, so that a proof's multiplicity of row i is count(merged[i]) * inv_cnt[i]. Shared by the workers of a batch.
+  struct TableData { std::vector<int64_t> merged; std::vector<std::vector<int64_t>> cols; std::vector<u64> inv_cnt; };
+  mutable std::mutex table_data_mu; mutable std::map<TableType, std::unique_ptr<TableData>> table_data_;
+  const TableData& table_data(const TableType& tt) const {
+    std::lock_guard<std::mutex> g(table_data_mu);
+    auto it = table_data_.find(tt);
+    if (it != table_data_.end()) return *it->second;
+    std::unique_ptr<TableData> d(new TableData);
+    table_columns(tt, d->merged, d->cols);
+    std::unordered_map<int64_t, u64> cnt; cnt.reserve(d->merged.size());
+    for (int64_t v : d->merged) cnt[v] += 1;
+    d->inv_cnt.resize(d->merged.size());
+    for (size_t i = 0; i < d->merged.size(); i++) { const u64 c = cnt[d->merged[i]]; d->inv_cnt[i] = c != 1 ? gl_inv(gl_from_u64(c)) : 1; }
+    return *(table_data_[tt] = std::move(d));
+  }
   VerifierContext verifier_ctx() const {
     VerifierContext v; v.full_log = full_log; v.tables = tables;
     for (auto& kv : table_comms) v.table_comms[kv.first] = pure_commitment(kv.second); v.shape.input_len = model.input_len; v.shape.input_lens = model.input_lens; v.shape.outputs = model.outputs;
@@ -866,6 +884,14 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
   if (ctx.tables.empty()) return;
   PhaseTimer wt;
   std::map<TableType, std::unordered_map<int64_t, u64>> counts;
+  // the range table's keys are 0 .. 2^Q_BIT_LEN - 1 and most lookups of a proof go there: counted in an array, merged into `counts` once at the end
+  // (the entry of the range table is created where the first lookup into it is met, as before: the ORDER of `counts` is the order of the table proofs)
+  std::vector<u64> range_hist(size_t(1) << Q_BIT_LEN, 0);
+  bool range_used = false;
+  auto count_range = [&](int64_t v) {  // (a value outside the table keeps its own key, as before: it is no row of the table and the lookup argument will not hold)
+    range_used = true;
+    if (v >= 0 && v < (int64_t(1) << Q_BIT_LEN)) range_hist[(size_t)v] += 1; else counts[TableType{2, 0}][v] += 1;
+  };
   struct Col { std::vector<int64_t> v; };
   std::vector<Col> cols;                       // every i64 column that goes to the device, in commit order first
   // col_ids: committed columns, in commit order; the first n_lookup_cols of them (all, if 0) are the lookup's columns. late >= 0: the lookup's
@@ -885,23 +911,25 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       unsigned nchunks = shift / Q_BIT_LEN; int64_t rmask = (int64_t(1) << Q_BIT_LEN) - 1;
       TableType ct{3, l.clamping_size()}, rt{2, 0};
       int64_t cmax = int64_t(1) << (ct.size - 1);
+      std::unordered_map<int64_t, u64>& cct = counts[ct];
       for (size_t i = 0; i < cin.size(); i++) {
         DP_REQUIRE(cin[i] >= -cmax && cin[i] < cmax, DP_ERR_ARG, "requant: value falls outside the clamping table");
-        counts[ct][cin[i] + cout[i] * COLUMN_SEPARATOR] += 1;
+        cct[cin[i] + cout[i] * COLUMN_SEPARATOR] += 1;
       }
       Pending pc{id, 0, {}, 2, ct}, pr{id, 1, {}, 1, rt};
       pc.col_ids = {cols.size(), cols.size() + 1};
       cols.push_back({cin}); cols.push_back({cout});
       for (unsigned j = 0; j < nchunks; j++) {
         std::vector<int64_t> ch; ch.reserve(shifted.size());
-        for (int64_t sft : shifted) { int64_t v = (sft >> (j * Q_BIT_LEN)) & rmask; ch.push_back(v); counts[rt][v] += 1; }
+        for (int64_t sft : shifted) { int64_t v = (sft >> (j * Q_BIT_LEN)) & rmask; ch.push_back(v); count_range(v); }
         pr.col_ids.push_back(cols.size()); cols.push_back({std::move(ch)});
       }
       pend.push_back(pc); pend.push_back(pr);
     } else if (l.kind == L_RELU) {
       TableType rt{0, 0};
       const auto& a = tr.in[id]; const auto& b = tr.out[id];
-      for (size_t i = 0; i < a.size(); i++) counts[rt][a[i] + COLUMN_SEPARATOR * b[i]] += 1;
+      std::unordered_map<int64_t, u64>& crl = counts[rt];
+      for (size_t i = 0; i < a.size(); i++) crl[a[i] + COLUMN_SEPARATOR * b[i]] += 1;
       Pending p{id, 0, {cols.size(), cols.size() + 1}, 2, rt};
       cols.push_back({a}); cols.push_back({b});
       pend.push_back(p);
@@ -911,12 +939,13 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       const unsigned nrc = (l.ln_range_check_bits - 1) / Q_BIT_LEN + 1;
       const int64_t rmask = (int64_t(1) << Q_BIT_LEN) - 1, top = int64_t(1) << l.ln_top_chunk_scalar_log;
       TableType it = layernorm_table(l), rt{2, 0};
-      for (size_t i = 0; i < d.lookup_input.size(); i++) counts[it][d.lookup_input[i] + d.lookup_output[i] * COLUMN_SEPARATOR] += 1;
+      std::unordered_map<int64_t, u64>& cit = counts[it];
+      for (size_t i = 0; i < d.lookup_input.size(); i++) cit[d.lookup_input[i] + d.lookup_output[i] * COLUMN_SEPARATOR] += 1;
       Pending pi{id, 0, {cols.size(), cols.size() + 1}, 2, it}, pr{id, 1, {}, 1, rt};
       cols.push_back({d.lookup_input}); cols.push_back({d.lookup_output});
       for (unsigned j = 0; j < nrc; j++) {
         std::vector<int64_t> ch; ch.reserve(d.range_check.size());
-        for (int64_t v : d.range_check) { int64_t c = ((v >> (j * Q_BIT_LEN)) & rmask) * (j + 1 == nrc ? top : 1); ch.push_back(c); counts[rt][c] += 1; }
+        for (int64_t v : d.range_check) { int64_t c = ((v >> (j * Q_BIT_LEN)) & rmask) * (j + 1 == nrc ? top : 1); ch.push_back(c); count_range(c); }
         pr.col_ids.push_back(cols.size()); cols.push_back({std::move(ch)});
       }
       pend.push_back(pi); pend.push_back(pr);
@@ -924,10 +953,12 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       SoftmaxTrace& d = ps.sm_trace[id];
       softmax_op(l, l0.kind == L_MHA ? tr.mha.at(id).softmax_in : tr.in[id], &d);
       TableType st = softmax_table(l), rt{2, 0}, et = softmax_error_table(l), zt{6, l.sm_zero_vars};
-      for (int64_t v : d.low) counts[rt][v] += 1;
-      for (int64_t v : d.high) counts[rt][v] += 1;
-      for (size_t i = 0; i < d.exp_in.size(); i++) counts[st][d.exp_in[i] + d.exp_out[i] * COLUMN_SEPARATOR] += 1;
-      for (int64_t v : d.row_sums) counts[et][v] += 1;
+      for (int64_t v : d.low) count_range(v);
+      for (int64_t v : d.high) count_range(v);
+      std::unordered_map<int64_t, u64>& cst = counts[st];
+      for (size_t i = 0; i < d.exp_in.size(); i++) cst[d.exp_in[i] + d.exp_out[i] * COLUMN_SEPARATOR] += 1;
+      std::unordered_map<int64_t, u64>& cet = counts[et];
+      for (int64_t v : d.row_sums) cet[v] += 1;
       Pending pe{id, 0, {cols.size(), cols.size() + 1}, 2, st}; cols.push_back({d.exp_in}); cols.push_back({d.exp_out});
       Pending pr{id, 1, {cols.size(), cols.size() + 1}, 1, rt}; cols.push_back({d.low}); cols.push_back({d.high});
       Pending px{id, 2, {cols.size()}, 1, et}; cols.push_back({d.shift});  // the SHIFT polynomial is committed with this lookup, the row sums are what is looked up
@@ -936,7 +967,8 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       if (l.sm_zero_chunks) {
         Pending pz{id, 3, {}, 2, zt};
         for (unsigned z = 0; z < l.sm_zero_chunks; z++) {
-          for (size_t i = 0; i < d.zero_in[z].size(); i++) counts[zt][d.zero_in[z][i] + d.zero_out[z][i] * COLUMN_SEPARATOR] += 1;
+          std::unordered_map<int64_t, u64>& czt = counts[zt];
+          for (size_t i = 0; i < d.zero_in[z].size(); i++) czt[d.zero_in[z][i] + d.zero_out[z][i] * COLUMN_SEPARATOR] += 1;
           pz.col_ids.push_back(cols.size()); cols.push_back({d.zero_in[z]}); pz.col_ids.push_back(cols.size()); cols.push_back({d.zero_out[z]});
         }
         pend.push_back(pz);
@@ -946,7 +978,7 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       std::vector<std::vector<int64_t>> diffs = maxpool_diff_polys(l, tr.in[id], tr.out[id]);
       Pending p{id, 0, {}, 1, rt};
       for (auto& d : diffs) {
-        for (int64_t v : d) { DP_REQUIRE(v >= 0 && v < (int64_t(1) << Q_BIT_LEN), DP_ERR_ARG, "maxpool: difference outside the range table"); counts[rt][v] += 1; }
+        for (int64_t v : d) { DP_REQUIRE(v >= 0 && v < (int64_t(1) << Q_BIT_LEN), DP_ERR_ARG, "maxpool: difference outside the range table"); count_range(v); }
         p.col_ids.push_back(cols.size()); cols.push_back({std::move(d)});
       }
       p.col_ids.push_back(cols.size()); cols.push_back({tr.out[id]});  // committed, but not a lookup column
@@ -956,23 +988,21 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
   }
   size_t n_witness_cols = cols.size();
   for (auto& v : lates) { late_ids.push_back(cols.size()); cols.push_back({std::move(v)}); }  // uploaded with the rest, not committed
+  if (range_used) { std::unordered_map<int64_t, u64>& crt = counts[TableType{2, 0}]; for (size_t v = 0; v < range_hist.size(); v++) if (range_hist[v]) crt[(int64_t)v] += range_hist[v]; }
   wt.lap("  witness: host columns");
   // table columns (not committed) ride in the same upload
   struct TabInfo { TableType tt; std::vector<size_t> col_ids; std::vector<u64> mult; };
   std::vector<TabInfo> tabs;
   for (auto& kv : counts) {
     const TableType& tt = kv.first;
-    std::vector<int64_t> merged; std::vector<std::vector<int64_t>> tc;
-    table_columns(tt, merged, tc);
-    std::unordered_map<int64_t, u64> cnt; for (int64_t v : merged) cnt[v] += 1;
+    const Context::TableData& td = ctx.table_data(tt);  // the table's columns and the inverse repetition of its rows: per context, not per proof
+    const std::vector<int64_t>& merged = td.merged;
     TabInfo ti; ti.tt = tt; ti.mult.resize(merged.size());
     for (size_t i = 0; i < merged.size(); i++) {
       auto it = kv.second.find(merged[i]);
-      if (it == kv.second.end()) { ti.mult[i] = 0; continue; }
-      u64 c = cnt[merged[i]];
-      ti.mult[i] = gl_mul(gl_from_u64(it->second), c != 1 ? gl_inv(gl_from_u64(c)) : 1);
+      ti.mult[i] = it == kv.second.end() ? 0 : td.inv_cnt[i] == 1 ? gl_from_u64(it->second) : gl_mul(gl_from_u64(it->second), td.inv_cnt[i]);
     }
-    for (auto& c : tc) { ti.col_ids.push_back(cols.size()); cols.push_back({std::move(c)}); }
+    for (auto& c : td.cols) { ti.col_ids.push_back(cols.size()); cols.push_back({c}); }
     tabs.push_back(std::move(ti));
   }
   wt.lap("  witness: multiplicities");
