@@ -1107,6 +1107,37 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     std::mutex err_mu; std::string err; int err_code = 0;
     for (size_t i = 0; i < nproofs; i++) { proof_words[i] = nullptr; proof_nwords[i] = 0; }
     for (size_t wi = 0; wi < nw && nco; wi++) hip_dev_cohort_attach(&dev_of(wi), m->cohorts[wi % nco]);
+    // The host work a proof starts with — inference and the host half of the witness generation (zkml.h witness_host: lookup columns, table multiplicities;
+    // 0.6 ms for Dense-4M, ~10 ms for the transformer layer) — is made AHEAD of the proofs by DP_PREP_THREADS helper threads (default 2, 0 = off): the members of
+    // a cohort start a proof together on ONE host thread, and until the last of them has submitted its first launch the cohort's stream is idle.
+    // pst[i]: 0 nobody has touched input i, 1 being prepared, 2 ready in prep[i], 3 the helper failed (the worker repeats it so that the error is its own).
+    struct Prep { Trace tr; WitnessHost wh; };
+    std::vector<std::unique_ptr<Prep>> prep(nproofs);
+    std::unique_ptr<std::atomic<int>[]> pst(new std::atomic<int>[nproofs]);
+    for (size_t i = 0; i < nproofs; i++) pst[i].store(0, std::memory_order_relaxed);
+    auto make_prep = [&](size_t i) {
+      std::unique_ptr<Prep> p(new Prep);
+      p->tr = run_model(m->zk->model, std::vector<int64_t>(inputs + i * ninput, inputs + (i + 1) * ninput));
+      p->wh = witness_host(*m->zk, p->tr);
+      return p;
+    };
+    const char* pe = getenv("DP_PREP_THREADS");
+    const size_t nprep = nw > 1 ? (size_t)std::max(0, pe ? atoi(pe) : 2) : 0;
+    const size_t prep_ahead = getenv("DP_PREP_AHEAD") ? (size_t)std::max(1, atoi(getenv("DP_PREP_AHEAD"))) : nw;  // inputs prepared beyond the one handed out last
+    std::atomic<size_t> pnext(nw);  // (the first nw proofs start at once: their workers prepare them themselves)
+    std::atomic<bool> pstop(false);
+    auto prep_thread = [&] {
+      for (;;) {
+        const size_t i = pnext.fetch_add(1);
+        if (i >= nproofs) return;
+        while (!pstop.load(std::memory_order_relaxed) && i >= next.load(std::memory_order_relaxed) + prep_ahead) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        if (pstop.load(std::memory_order_relaxed)) return;
+        if (i < next.load(std::memory_order_relaxed)) continue;  // handed out meanwhile (or the batch is being abandoned)
+        int e = 0;
+        if (!pst[i].compare_exchange_strong(e, 1)) continue;
+        try { prep[i] = make_prep(i); pst[i].store(2, std::memory_order_release); } catch (...) { pst[i].store(3, std::memory_order_release); }
+      }
+    };
     auto t0 = std::chrono::steady_clock::now();
     auto work = [&](size_t wi) {
       Dev& dev = dev_of(wi);
@@ -1115,19 +1146,25 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
         for (;;) {
           size_t i = next.fetch_add(1);
           if (i >= nproofs) break;
-          std::vector<int64_t> in(inputs + i * ninput, inputs + (i + 1) * ninput);
           auto h0 = std::chrono::steady_clock::now();
-          Trace tr = run_model(m->zk->model, in);
+          std::unique_ptr<Prep> mine;
+          int e = 0;
+          if (pst[i].compare_exchange_strong(e, 1)) mine = make_prep(i);
+          else {
+            while ((e = pst[i].load(std::memory_order_acquire)) == 1) fiber_yield();
+            mine = e == 2 ? std::move(prep[i]) : make_prep(i);
+          }
+          Trace& tr = mine->tr;
           auto h1 = std::chrono::steady_clock::now();
           Transcript t = default_transcript();
-          Proof p = prove(*m->zk, dev, tr, t);
+          Proof p = prove(*m->zk, dev, tr, t, &mine->wh);
           auto h2 = std::chrono::steady_clock::now();
           std::vector<u64> w = serialize_proof(p);
           auto h3 = std::chrono::steady_clock::now();
           proof_words[i] = copy_out(w); proof_nwords[i] = w.size();
           if (timing && wi == 0) {
             auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            fprintf(stderr, "[dp timing] host phases of one proof: inference %.2f ms, prove %.2f ms (wall, shared thread), serialise %.2f ms, copy out %.2f ms\n", ms(h0, h1), ms(h1, h2), ms(h2, h3), ms(h3, std::chrono::steady_clock::now()));
+            fprintf(stderr, "[dp timing] host phases of one proof: inference + witness columns (or the wait for the helper that made them) %.2f ms, prove %.2f ms (wall, shared thread), serialise %.2f ms, copy out %.2f ms\n", ms(h0, h1), ms(h1, h2), ms(h2, h3), ms(h3, std::chrono::steady_clock::now()));
           }
           if (outputs) { const std::vector<int64_t> o = model_output(m->zk->model, tr); DP_REQUIRE(o.size() <= noutput_cap, DP_ERR_ARG, "output buffer too small"); memcpy(outputs + i * noutput_cap, o.data(), o.size() * 8); if (noutput) *noutput = o.size(); }
         }
@@ -1154,10 +1191,13 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
       fiber_run_all(sched);
       for (auto& f : sched.fibers) if (f->failed) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_ARG; err = "an exception escaped a proof worker's fiber"; } }
     };
-    std::vector<std::thread> th;
+    std::vector<std::thread> th, pth;
+    for (size_t k = 0; k < nprep && nproofs > nw; k++) pth.emplace_back(prep_thread);
     for (size_t ti = 1; ti < nth; ti++) th.emplace_back(run_thread, ti);
     run_thread(0);
     for (auto& t : th) t.join();
+    pstop.store(true);
+    for (auto& t : pth) t.join();
     for (size_t c = 0; c < nco; c++) { try { hip_cohort_drain(m->cohorts[c]); } catch (const std::exception& e) { if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } } }
     if (nco && getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) {
       size_t f = 0, p = 0; for (size_t c = 0; c < nco; c++) { size_t a, b; hip_cohort_stats(m->cohorts[c], &a, &b); f += a; p += b; }

@@ -879,11 +879,29 @@ struct PhaseTimer {  // DP_TIMING=1 prints the host-side wall time of each provi
 // generate_lookup_witnesses (lookup/context.rs:631-781) with gen_lookup_witness of requant.rs:208-345 / activation.rs:238-318.
 // All witness columns of the inference are produced on the host (tiny integer work on activation vectors), shipped to
 // the device in ONE upload and committed in ONE batched call (the reference commits them one by one on rayon threads).
-inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
-  Context& ctx = *ps.ctx; Dev& dev = *ps.dev;
-  if (ctx.tables.empty()) return;
-  PhaseTimer wt;
+// The HOST half of it — everything that is a function of (context, trace) alone: the lookup columns, what each lookup hits in its table, the tables'
+// multiplicities, all of it flattened for the two uploads. No device, no transcript: dp_model_prove_batch computes it for the next inputs on helper threads
+// while the proofs in flight wait for the device (capi.cpp), every other caller inside prove().
+struct WitnessHost {
   std::map<TableType, std::unordered_map<int64_t, u64>> counts;
+  struct Col { std::vector<int64_t> v; };
+  // col_ids: committed columns, in commit order; the first n_lookup_cols of them (all, if 0) are the lookup's columns. late >= 0: the lookup's
+  // only column is `lates[late]`, a column that is NOT committed (Softmax's row sums), and every committed column is an extra one
+  struct Pending { size_t node; int which; std::vector<size_t> col_ids; size_t cpi; TableType tt; size_t n_lookup_cols = 0; int late = -1; };
+  struct TabInfo { TableType tt; std::vector<size_t> col_ids; std::vector<u64> mult; };
+  struct Act { size_t node; bool is_out; size_t n; size_t off; };
+  std::vector<Pending> pend; std::vector<size_t> late_ids; std::vector<TabInfo> tabs; std::vector<Act> acts;
+  size_t n_witness_cols = 0;
+  std::vector<size_t> col_len, offs, moffs;  // per i64 column: length and offset in `flat`; per table: offset of its multiplicities in `mflat`
+  std::vector<int64_t> flat; std::vector<u64> mflat;
+  std::map<size_t, SoftmaxTrace> sm_trace; std::map<size_t, LayerNormTrace> ln_trace;
+};
+inline WitnessHost witness_host(const Context& ctx, const Trace& tr) {
+  WitnessHost wh;
+  if (ctx.tables.empty()) return wh;
+  PhaseTimer wt;
+  using Col = WitnessHost::Col; using Pending = WitnessHost::Pending; using TabInfo = WitnessHost::TabInfo; using Act = WitnessHost::Act;
+  std::map<TableType, std::unordered_map<int64_t, u64>>& counts = wh.counts;
   // the range table's keys are 0 .. 2^Q_BIT_LEN - 1 and most lookups of a proof go there: counted in an array, merged into `counts` once at the end
   // (the entry of the range table is created where the first lookup into it is met, as before: the ORDER of `counts` is the order of the table proofs)
   std::vector<u64> range_hist(size_t(1) << Q_BIT_LEN, 0);
@@ -892,13 +910,9 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
     range_used = true;
     if (v >= 0 && v < (int64_t(1) << Q_BIT_LEN)) range_hist[(size_t)v] += 1; else counts[TableType{2, 0}][v] += 1;
   };
-  struct Col { std::vector<int64_t> v; };
   std::vector<Col> cols;                       // every i64 column that goes to the device, in commit order first
-  // col_ids: committed columns, in commit order; the first n_lookup_cols of them (all, if 0) are the lookup's columns. late >= 0: the lookup's
-  // only column is `lates[late]`, a column that is NOT committed (Softmax's row sums), and every committed column is an extra one
-  struct Pending { size_t node; int which; std::vector<size_t> col_ids; size_t cpi; TableType tt; size_t n_lookup_cols = 0; int late = -1; };
-  std::vector<Pending> pend;
-  std::vector<std::vector<int64_t>> lates; std::vector<size_t> late_ids;
+  std::vector<Pending>& pend = wh.pend;
+  std::vector<std::vector<int64_t>> lates; std::vector<size_t>& late_ids = wh.late_ids;
   for (size_t id = 0; id < ctx.model.layers.size(); id++) {
     // Mha::gen_lookup_witness (mha.rs:706-719): the witness of its softmax on the products Q K^T, under the node's own id
     const LayerSpec& l0 = ctx.model.layers[id];
@@ -934,7 +948,7 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       cols.push_back({a}); cols.push_back({b});
       pend.push_back(p);
     } else if (l.kind == L_LAYERNORM) {  // LayerNorm::lookup_witness (layernorm.rs:1103-1218): (input, output) of the inverse square root, then the range-checked chunks
-      LayerNormTrace& d = ps.ln_trace[id];
+      LayerNormTrace& d = wh.ln_trace[id];
       layernorm_op(l, tr.in[id], &d);
       const unsigned nrc = (l.ln_range_check_bits - 1) / Q_BIT_LEN + 1;
       const int64_t rmask = (int64_t(1) << Q_BIT_LEN) - 1, top = int64_t(1) << l.ln_top_chunk_scalar_log;
@@ -950,7 +964,7 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       }
       pend.push_back(pi); pend.push_back(pr);
     } else if (l.kind == L_SOFTMAX) {  // Softmax::lookup_witness (softmax.rs:890-1066)
-      SoftmaxTrace& d = ps.sm_trace[id];
+      SoftmaxTrace& d = wh.sm_trace[id];
       softmax_op(l, l0.kind == L_MHA ? tr.mha.at(id).softmax_in : tr.in[id], &d);
       TableType st = softmax_table(l), rt{2, 0}, et = softmax_error_table(l), zt{6, l.sm_zero_vars};
       for (int64_t v : d.low) count_range(v);
@@ -986,13 +1000,12 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       pend.push_back(p);
     }
   }
-  size_t n_witness_cols = cols.size();
+  wh.n_witness_cols = cols.size();
   for (auto& v : lates) { late_ids.push_back(cols.size()); cols.push_back({std::move(v)}); }  // uploaded with the rest, not committed
   if (range_used) { std::unordered_map<int64_t, u64>& crt = counts[TableType{2, 0}]; for (size_t v = 0; v < range_hist.size(); v++) if (range_hist[v]) crt[(int64_t)v] += range_hist[v]; }
   wt.lap("  witness: host columns");
   // table columns (not committed) ride in the same upload
-  struct TabInfo { TableType tt; std::vector<size_t> col_ids; std::vector<u64> mult; };
-  std::vector<TabInfo> tabs;
+  std::vector<TabInfo>& tabs = wh.tabs;
   for (auto& kv : counts) {
     const TableType& tt = kv.first;
     const Context::TableData& td = ctx.table_data(tt);  // the table's columns and the inverse repetition of its rows: per context, not per proof
@@ -1006,32 +1019,44 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
     tabs.push_back(std::move(ti));
   }
   wt.lap("  witness: multiplicities");
-  // one upload of all i64 columns, one of all multiplicity vectors
+  // flattened for ONE upload of all i64 columns and ONE of all multiplicity vectors
   size_t total = 0; for (auto& c : cols) total += c.v.size();
-  std::vector<int64_t> flat; flat.reserve(total);
-  std::vector<size_t> offs;
-  for (auto& c : cols) { offs.push_back(flat.size()); flat.insert(flat.end(), c.v.begin(), c.v.end()); }
-  DBuf big = dev.alloc(total, false);
-  dev.upload_i64(big, flat.data());
-  std::vector<DBuf> dcol;
-  for (size_t i = 0; i < cols.size(); i++) dcol.push_back(big.slice(offs[i], cols[i].v.size()));
+  std::vector<int64_t>& flat = wh.flat; flat.reserve(total);
+  for (auto& c : cols) { wh.offs.push_back(flat.size()); wh.col_len.push_back(c.v.size()); flat.insert(flat.end(), c.v.begin(), c.v.end()); }
   size_t mtotal = 0; for (auto& t : tabs) mtotal += t.mult.size();
-  std::vector<u64> mflat; mflat.reserve(mtotal);
-  std::vector<size_t> moffs;
-  for (auto& t : tabs) { moffs.push_back(mflat.size()); mflat.insert(mflat.end(), t.mult.begin(), t.mult.end()); }
+  std::vector<u64>& mflat = wh.mflat; mflat.reserve(mtotal);
+  for (auto& t : tabs) { wh.moffs.push_back(mflat.size()); mflat.insert(mflat.end(), t.mult.begin(), t.mult.end()); }
   // ... and the activations of the layer loop, as extension words behind the multiplicities (16-byte aligned)
-  struct Act { size_t node; bool is_out; const std::vector<int64_t>* v; size_t off; };
-  std::vector<Act> acts;
+  std::vector<std::pair<Act, const std::vector<int64_t>*>> acts;
   for (size_t id = 0; id < ctx.model.layers.size(); id++) {
     const int kind = ctx.model.layers[id].kind;
-    if (kind == L_DENSE) acts.push_back({id, false, &tr.in[id], 0});
-    else if (kind == L_RELU) acts.push_back({id, true, &tr.out[id], 0});
+    if (kind == L_DENSE) acts.push_back({Act{id, false, tr.in[id].size(), 0}, &tr.in[id]});
+    else if (kind == L_RELU) acts.push_back({Act{id, true, tr.out[id].size(), 0}, &tr.out[id]});
   }
   if (mflat.size() & 1) mflat.push_back(0);
-  for (Act& a : acts) { a.off = mflat.size(); mflat.reserve(mflat.size() + 2 * a.v->size()); for (int64_t x : *a.v) { mflat.push_back(gl_from_i64(x)); mflat.push_back(0); } }
-  DBuf mbig = dev.alloc(mflat.size(), false);
-  dev.upload(mbig, mflat.data());
-  for (const Act& a : acts) { DBuf b; b.p = (char*)mbig.p + a.off * 8; b.n = a.v->size(); b.ext = true; (a.is_out ? ps.staged_out : ps.staged_in)[a.node] = b; }
+  for (auto& av : acts) { av.first.off = mflat.size(); mflat.reserve(mflat.size() + 2 * av.second->size()); for (int64_t x : *av.second) { mflat.push_back(gl_from_i64(x)); mflat.push_back(0); } wh.acts.push_back(av.first); }
+  wt.lap("  witness: flatten");
+  return wh;
+}
+// the device half: two uploads, one batched commit, the witnesses of the layer lookups and of the tables, the table challenges
+inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr, WitnessHost* prepared = nullptr) {
+  Context& ctx = *ps.ctx; Dev& dev = *ps.dev;
+  if (ctx.tables.empty()) return;
+  WitnessHost local;
+  if (!prepared) local = witness_host(ctx, tr);
+  WitnessHost& wh = prepared ? *prepared : local;
+  PhaseTimer wt;
+  ps.sm_trace = std::move(wh.sm_trace); ps.ln_trace = std::move(wh.ln_trace);
+  const std::vector<WitnessHost::Pending>& pend = wh.pend; const std::vector<size_t>& late_ids = wh.late_ids; const std::vector<WitnessHost::TabInfo>& tabs = wh.tabs;
+  const size_t n_witness_cols = wh.n_witness_cols;
+  const std::vector<size_t>& moffs = wh.moffs;
+  DBuf big = dev.alloc(wh.flat.size(), false);
+  dev.upload_i64(big, wh.flat.data());
+  std::vector<DBuf> dcol;
+  for (size_t i = 0; i < wh.col_len.size(); i++) dcol.push_back(big.slice(wh.offs[i], wh.col_len[i]));
+  DBuf mbig = dev.alloc(wh.mflat.size(), false);
+  dev.upload(mbig, wh.mflat.data());
+  for (const WitnessHost::Act& a : wh.acts) { DBuf b; b.p = (char*)mbig.p + a.off * 8; b.n = a.n; b.ext = true; (a.is_out ? ps.staged_out : ps.staged_in)[a.node] = b; }
   wt.lap("  witness: uploads");
   // one batched commit: witness columns in order, then the table multiplicities
   std::vector<DBuf> to_commit(dcol.begin(), dcol.begin() + n_witness_cols);
@@ -1056,7 +1081,7 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
     ps.table_witness.push_back(std::move(w));
   }
   ps.constant_challenge = ps.t->get_and_append_challenge("table_constant");
-  for (auto& kv : counts) ps.challenge_map[kv.first] = kv.first.label() ? ps.t->get_and_append_challenge(kv.first.label()) : ex_one();
+  for (auto& kv : wh.counts) ps.challenge_map[kv.first] = kv.first.label() ? ps.t->get_and_append_challenge(kv.first.label()) : ex_one();
 }
 
 // Positional::prove, Learned (layers/transformer/positional.rs:327-452). The Add layer on (input, the first `tokens` rows of the table): both
@@ -1837,13 +1862,14 @@ inline Claim prove_pooling(ProverState& ps, size_t id, const LayerSpec& l, const
 // Prover::prove(trace). `tr` comes from run_model (inference is not part of proving time in the reference either).
 // `dev` may be any device context on the GPU that holds `ctx` (the model commitments are only read), so several proofs
 // can be in flight at once, each on its own stream/arena (dp_model_prove_batch).
-inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t) {
+// `prepared`: the host half of the witness generation of THIS trace, made ahead of time (witness_host; consumed)
+inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t, WitnessHost* prepared = nullptr) {
   PhaseTimer pt;
   sc_stats() = ScStats();
   size_t mk = dev.mark();
   ProverState ps; ps.ctx = &ctx; ps.dev = &dev; ps.t = &t;
   for (auto& kv : ctx.model_comms) for (auto& pc : kv.second) t.append_digest(pc.second.tree.root);
-  instantiate_witness_ctx(ps, tr);
+  instantiate_witness_ctx(ps, tr, prepared);
   pt.lap("witness columns + commits");
   // a claim per output tensor (iop/prover.rs:419-435); then the nodes in proving order, each node receiving the claims its readers made on
   // its outputs and making one claim per input (claims_for_node, provable/mod.rs:235-270). A chain: one claim walking from the last node back.

@@ -45,6 +45,7 @@ def test_throughput_mode_proof_is_the_oracles_proof_at_full_size(dev, workload, 
 ALL_OFF = {"DP_DEVICE_LOGUP": "0", "DP_FUSED_OFF": "classic,dense,eqsum,commit,deleg"}
 KNOBS = [{}, {"DP_DEVICE_LOGUP": "0"}, {"DP_DEVICE_LOGUP": "1"}, {"DP_FUSED_OFF": "classic"}, {"DP_FUSED_OFF": "dense"}, {"DP_FUSED_OFF": "eqsum"},
          {"DP_FUSED_OFF": "commit"}, ALL_OFF,
+         {"DP_PREP_THREADS": "0"},  # no helper threads: every worker runs inference and the host half of the witness generation itself when it starts a proof
          {"DP_AXPY_CLASSES": "0"},  # the batch opening's short polynomials straight into the accumulator pass (k_axpy_classes off)
          {"DP_HOST_SPONGE": "1"}]  # the fused kernels with the transcript's sponge on the host (csrc/sponge_host.h)
 

@@ -19,7 +19,8 @@ for _ in range(3):
     t0 = time.perf_counter(); pr.prove(xs[0]); lat.append(1000 * (time.perf_counter() - t0))
 pr.prove_batch(xs[:conc], conc)
 t0 = time.perf_counter(); proofs, outs, _ = pr.prove_batch(xs, conc); dt = time.perf_counter() - t0
-v, _ = dpa.verify_batch(ctx.verifier_blob(), proofs[:16], xs[:16], outs[:16], dev=dev)
+sel = list(range(8)) + list(range(len(xs) - 8, len(xs)))  # the first wave (prepared by the workers themselves) and the last (prepared ahead by the helper threads)
+v, _ = dpa.verify_batch(ctx.verifier_blob(), [proofs[i] for i in sel], xs[sel], [outs[i] for i in sel], dev=dev)
 print(f"{wl} variant={os.environ.get('DP_LIB_VARIANT', 'release')}: {len(xs) / dt:.1f} proofs/s ({pr.in_flight()} in flight, {len(xs)} proofs, {dt * 1000:.0f} ms); single proof {sorted(lat)[1]:.1f} ms; "
-      f"rejected of 16: {int(v.sum())}; sha256(proof 5) {hashlib.sha256(proofs[5].tobytes()).hexdigest()[:16]}", flush=True)
+      f"rejected of 16: {int(v.sum())}; sha256(proof 5) {hashlib.sha256(proofs[5].tobytes()).hexdigest()[:16]} sha256(proof -3) {hashlib.sha256(proofs[-3].tobytes()).hexdigest()[:16]}", flush=True)
 ctx.free()
