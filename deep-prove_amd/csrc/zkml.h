@@ -428,12 +428,27 @@ DP_HOST_CLONES inline void axpy_i16(int32_t* acc, int32_t x, const int16_t* w, s
 // the weights of a Dense / MatMul layer once more as int16 when they all fit (quantised models: |w| <= 127): the inference that precedes
 // every proof then streams a quarter of the bytes and its multiply-adds vectorise in 32-bit lanes
 inline void prepare_fast_inference(LayerSpec& l) {
-  if (l.kind != L_DENSE && l.kind != L_MATMUL) return;
+  if (l.kind != L_DENSE && l.kind != L_MATMUL && l.kind != L_QKV) return;
   int64_t wm = 0; for (int64_t v : l.weights) wm = std::max(wm, v < 0 ? -v : v);
   if (wm > 32767) return;
   auto w16 = std::make_shared<std::vector<int16_t>>(l.weights.size());
   for (size_t j = 0; j < l.weights.size(); j++) (*w16)[j] = (int16_t)l.weights[j];
   l.w16 = w16; l.w16_max = wm;
+}
+// [s][k] activations (as int16) times a constant [k][n] matrix (or its transpose [n][k]) kept as int16, exact in int32 (the caller has checked the bound), + bias:
+// eight rows of the activation share every pass over the matrix — a row of W (2 KB at n = 1024) is read once per eight tokens
+inline void matmul_w16(const int16_t* x16, size_t s_, size_t k, size_t n, const int16_t* w16, bool transposed, const int64_t* bias, int64_t* o) {
+  const size_t TB = 8;
+  std::vector<int32_t> acc(TB * n);
+  for (size_t i0 = 0; i0 < s_; i0 += TB) {
+    const size_t tb = std::min(TB, s_ - i0);
+    if (transposed) { for (size_t j = 0; j < n; j++) { const int16_t* w = w16 + j * k; for (size_t t = 0; t < tb; t++) acc[t * n + j] = dot_i16(&x16[(i0 + t) * k], w, k); } }
+    else {
+      std::fill(acc.begin(), acc.begin() + tb * n, 0);
+      for (size_t q = 0; q < k; q++) { const int16_t* w = w16 + q * n; for (size_t t = 0; t < tb; t++) { const int32_t xv = x16[(i0 + t) * k + q]; if (xv) axpy_i16(&acc[t * n], xv, w, n); } }
+    }
+    for (size_t t = 0; t < tb; t++) { int64_t* row = &o[(i0 + t) * n]; const int32_t* a = &acc[t * n]; for (size_t j = 0; j < n; j++) row[j] = (int64_t)a[j] + (bias ? bias[j] : 0); }
+  }
 }
 // the model's output tensors, concatenated (ModelSpec::outputs order)
 inline std::vector<int64_t> model_output(const ModelSpec& m, const Trace& tr) {
@@ -501,9 +516,13 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
     } else if (l.kind == L_QKV) {  // QKV::evaluate (qkv.rs:275-340, no cache)
       const size_t k = l.nrows, n = l.ncols;
       DP_REQUIRE(k && cur.size() % k == 0 && l.weights.size() == 3 * k * n && l.bias.size() == 3 * n, DP_ERR_SHAPE, "qkv: shapes");
+      int64_t xmax = 0; for (int64_t v : cur) xmax = std::max(xmax, v < 0 ? -v : v);
+      const bool fast = l.w16 && xmax <= 32767 && (double)xmax * (double)l.w16_max * (double)k < 2.0e9;  // exact in int32: the same integers as matmul_i64 gives
+      std::vector<int16_t> x16; if (fast) { x16.resize(cur.size()); for (size_t j = 0; j < cur.size(); j++) x16[j] = (int16_t)cur[j]; }
       for (size_t w = 0; w < 3; w++) {
-        std::vector<int64_t> y = matmul_i64(cur.data(), &l.weights[w * k * n], cur.size() / k, k, n, false);
-        for (size_t i = 0; i < y.size(); i++) y[i] += l.bias[w * n + i % n];
+        std::vector<int64_t> y;
+        if (fast) { y.resize(cur.size() / k * n); matmul_w16(x16.data(), cur.size() / k, k, n, l.w16->data() + w * k * n, false, &l.bias[w * n], y.data()); }
+        else { y = matmul_i64(cur.data(), &l.weights[w * k * n], cur.size() / k, k, n, false); for (size_t i = 0; i < y.size(); i++) y[i] += l.bias[w * n + i % n]; }
         if (w == 0) o = std::move(y); else tr.more_out[id].push_back(std::move(y));
       }
     } else if (l.kind == L_CONCAT_MATMUL) o = concat_matmul_op(l, cur, tr.in2[id]);
@@ -534,18 +553,7 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
       int64_t xmax = 0; for (int64_t v : cur) xmax = std::max(xmax, v < 0 ? -v : v);
       if (l.w16 && xmax <= 32767 && (double)xmax * (double)l.w16_max * (double)k < 2.0e9) {  // exact in int32: the same integers as the int64 loops below
         std::vector<int16_t> x16(cur.size()); for (size_t j = 0; j < cur.size(); j++) x16[j] = (int16_t)cur[j];
-        // eight rows of the activation share every pass over the matrix: a row of W (2 KB at n = 1024) is read once per eight tokens
-        const size_t TB = 8;
-        std::vector<int32_t> acc(TB * n);
-        for (size_t i0 = 0; i0 < s_; i0 += TB) {
-          const size_t tb = std::min(TB, s_ - i0);
-          if (l.mm_transpose) { for (size_t j = 0; j < n; j++) { const int16_t* w = l.w16->data() + j * k; for (size_t t = 0; t < tb; t++) acc[t * n + j] = dot_i16(&x16[(i0 + t) * k], w, k); } }
-          else {
-            std::fill(acc.begin(), acc.begin() + tb * n, 0);
-            for (size_t q = 0; q < k; q++) { const int16_t* w = l.w16->data() + q * n; for (size_t t = 0; t < tb; t++) { const int32_t xv = x16[(i0 + t) * k + q]; if (xv) axpy_i16(&acc[t * n], xv, w, n); } }
-          }
-          for (size_t t = 0; t < tb; t++) { int64_t* row = &o[(i0 + t) * n]; const int32_t* a = &acc[t * n]; for (size_t j = 0; j < n; j++) row[j] = (int64_t)a[j] + (l.bias.empty() ? 0 : l.bias[j]); }
-        }
+        matmul_w16(x16.data(), s_, k, n, l.w16->data(), l.mm_transpose, l.bias.empty() ? nullptr : l.bias.data(), o.data());
       } else
       for (size_t i = 0; i < s_; i++) {
         int64_t* row = &o[i * n];
@@ -766,6 +774,7 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
         dev.upload_i64(w, &l.weights[q * kn]); dev.upload_i64(b, &l.bias[q * n]);
         ctx->model_comms[id][wn[q]] = dev.commit(w, true); ctx->model_comms[id][bn[q]] = dev.commit(b, true);
       }
+      prepare_fast_inference(l);
       continue;
     }
     if (l.kind == L_LAYERNORM) {  // gamma and beta are model polynomials (layernorm.rs:67-68,603-613)
