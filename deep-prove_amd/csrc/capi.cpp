@@ -716,11 +716,19 @@ void async_thread(dp_async* a) {
         int code = 1;
         const auto tb = std::chrono::steady_clock::now();
         a->queue_us += (unsigned long long)std::chrono::duration<double, std::micro>(tb - t->t_submit).count();
-        try { d->bind_thread(); const size_t mk = d->mark(); t->body(*d, *t); d->sync(); d->release(mk); }
+        // the worker's arena mark is taken OUTSIDE the try: whatever the call throws, its kernels are drained (best effort) and its arena is given back before
+        // the ticket is published — the caller may free the call's input tables as soon as it sees the ticket's state
+        size_t mk = 0; bool marked = false;
+        try { d->bind_thread(); mk = d->mark(); marked = true; t->body(*d, *t); d->sync(); d->release(mk); marked = false; }
         catch (const DpError& e) { t->err = e.what(); code = e.code; }
         catch (const std::bad_alloc&) { t->err = "host out of memory"; code = DP_ERR_OOM; }
         catch (const std::exception& e) { t->err = e.what(); code = DP_ERR_ARG; }
         catch (...) { t->err = "unknown error"; code = DP_ERR_ARG; }
+        if (code != 1) {
+          try { d->abort_call(); } catch (...) {}
+          try { d->sync(); } catch (...) {}
+          if (marked) { try { d->release(mk); } catch (...) {} }
+        }
         if (gp->merged) { try { hip_dev_cohort_detach(d); } catch (const std::exception& e) { if (code == 1) { t->err = e.what(); code = DP_ERR_HIP; } } }
         t->body = nullptr;
         a->body_us += (unsigned long long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tb).count();
@@ -763,8 +771,11 @@ void async_thread(dp_async* a) {
 int32_t async_submit(dp_async* a, dp_ticket* t, dp_ticket** out) {
   *out = t;
   t->t_submit = std::chrono::steady_clock::now();
+  // the tables of the call may have been uploaded through the owning context a moment ago: in throughput mode copies of up to 2 MB return before they ran on ITS
+  // stream, and the call reads the tables on a worker's stream — nothing orders the two but this
+  { CtxLock lk(a->ctx); a->ctx->dev->flush_uploads(); }
   { std::lock_guard<std::mutex> g(a->mu); a->queue.push_back(t); a->qsize++; }
-  a->cv.notify_one();
+  a->cv.notify_all();  // (notify_one could wake a thread lingering for a DIFFERENT shape, which leaves this ticket queued while idle threads sleep)
   return DP_OK;
 }
 }  // namespace
@@ -831,8 +842,11 @@ int32_t dp_ticket_commit(dp_ticket* t, dp_commit** out, uint64_t root[4]) {
 int32_t dp_ticket_free(dp_ticket* t) {
   return guard([&] {
     if (!t) return;
-    DP_REQUIRE(t->state.load(std::memory_order_acquire) != 0, DP_ERR_ARG, "dp_ticket_free: the call is still running");
-    DP_REQUIRE(!t->commit && !t->buf, DP_ERR_ARG, "dp_ticket_free: take the commitment / table first (dp_ticket_commit, dp_ticket_buf)");
+    const int st = t->state.load(std::memory_order_acquire);
+    DP_REQUIRE(st != 0, DP_ERR_ARG, "dp_ticket_free: the call is still running");
+    // a FAILED call holds nothing: its body gives back whatever it had allocated before it threw (see the submit functions)
+    DP_REQUIRE(st < 0 || (!t->commit && !t->buf), DP_ERR_ARG, "dp_ticket_free: take the commitment / table first (dp_ticket_commit, dp_ticket_buf)");
+    delete t->commit; delete t->buf;
     delete t;
   });
 }
@@ -876,7 +890,11 @@ int32_t dp_mle_fix_high_submit(dp_async* a, const dp_buf* m, size_t rows, size_t
     const DBuf mb = m->b;
     std::unique_ptr<dp_ticket> tk(new dp_ticket());
     tk->sig = sig_mix(sig_mix(5, rows), cols);
-    tk->body = [mb, rows, cols, p](Dev& dev, dp_ticket& me) { DBuf b = dev.alloc_persistent(cols, true); dev.fix_high(b, mb, rows, cols, p->data()); me.buf = new dp_buf{b}; };
+    tk->body = [mb, rows, cols, p](Dev& dev, dp_ticket& me) {
+      DBuf b = dev.alloc_persistent(cols, true);
+      try { dev.fix_high(b, mb, rows, cols, p->data()); dev.sync(); } catch (...) { try { dev.sync(); } catch (...) {} dev.free_persistent(b); throw; }
+      me.buf = new dp_buf{b};  // (only a call that succeeded hands out its table)
+    };
     async_submit(a, tk.release(), ticket);
   });
 }
@@ -921,11 +939,11 @@ int32_t dp_pcs_commit_host_submit(dp_async* a, const uint64_t* words, size_t n, 
     tk->sig = sig_mix(sig_mix(7, n), is_ext ? 2 : 1);
     const bool ext = is_ext != 0;
     tk->body = [w, n, ext](Dev& dev, dp_ticket& me) {
-      DBuf b = dev.alloc_persistent(n, ext); dev.upload(b, w->data());
-      me.buf = new dp_buf{b};
-      DevCommit c = dev.commit(b, true);
+      DBuf b = dev.alloc_persistent(n, ext);
+      DevCommit c;
+      try { dev.upload(b, w->data()); c = dev.commit(b, true); } catch (...) { try { dev.sync(); } catch (...) {} dev.free_persistent(b); throw; }
       for (int k = 0; k < 4; k++) me.root[k] = c.tree.root.v[k];
-      me.commit = new dp_commit{c};
+      me.buf = new dp_buf{b}; me.commit = new dp_commit{c};  // (only a call that succeeded hands out its table and its commitment)
     };
     async_submit(a, tk.release(), ticket);
   });

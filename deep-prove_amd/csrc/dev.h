@@ -84,6 +84,11 @@ class Dev {
   virtual void copy(const DBuf& dst, const DBuf& src) = 0;
   virtual void zero(const DBuf& dst) = 0;
   virtual void sync() = 0;
+  // uploads this context has queued but not yet run (throughput mode: copies of up to 2 MB return before they ran) are complete when this returns: called before
+  // ANOTHER context's stream reads the tables (the asynchronous seam engine, capi.cpp)
+  virtual void flush_uploads() { sync(); }
+  // a call on this context failed half-way (an exception crossed it): drop per-call state (an open sumcheck session) so that the next call starts clean
+  virtual void abort_call() {}
   // ---- MLE primitives
   // K4: out[idx] (+)= scale * prod_t (idx_t ? pt[t] : 1 - pt[t])
   virtual void eq_table(const DBuf& out, const Ext* pt, unsigned k, Ext scale, bool accumulate) = 0;

@@ -12,6 +12,14 @@
 #define DP_HD inline
 #endif
 
+// The hand-written instruction sequences of gl64_gfx950.h name gfx950 registers, encodings and hazards: they are compiled in the device pass FOR gfx950 only
+// (the library is built with --offload-arch=gfx950); any other target, the host pass and -DDP_NO_GFX950_ASM get the portable forms of the same functions.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__gfx950__) && !defined(DP_NO_GFX950_ASM)
+#define DP_GX_ON 1
+#else
+#define DP_GX_ON 0
+#endif
+
 namespace dp {
 typedef uint64_t u64;
 typedef uint32_t u32;
@@ -55,7 +63,7 @@ DP_HD u64 gl_reduce128(u64 lo, u64 hi) {
   bool c2 = __builtin_add_overflow(r, GL_EPS, &t);
   return c2 ? t : r;                // r >= p  <=>  r + EPS carries
 }
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DP_NO_GFX950_ASM)
+#if DP_GX_ON
 namespace gx {  // gl64_gfx950.h: hand-written gfx950 sequences, any representative on output
 __device__ __forceinline__ u64 mul(u64 a, u64 b);          // 12 VALU instructions
 __device__ __forceinline__ u64 fma(u64 a, u64 b, u64 d);   // 13
@@ -63,7 +71,7 @@ __device__ __forceinline__ u64 mul_small(u64 a, u32 k);    // 7
 }
 #endif
 DP_HD u64 gl_mul(u64 a, u64 b) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DP_NO_GFX950_ASM)
+#if DP_GX_ON
   const u64 r = gx::mul(a, b);
   u64 t;
   const bool c = __builtin_add_overflow(r, GL_EPS, &t);
@@ -112,7 +120,7 @@ DP_HD Ext ex_neg(Ext a) { return ex(gl_neg(a.c0), gl_neg(a.c1)); }
 DP_HD Ext ex_dbl(Ext a) { return ex_add(a, a); }
 DP_HD u64 gl_canon_any(u64 r) { u64 t; const bool c = __builtin_add_overflow(r, GL_EPS, &t); return c ? t : r; }  // any representative -> canonical
 DP_HD Ext ex_mul(Ext a, Ext b) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DP_NO_GFX950_ASM)
+#if DP_GX_ON
   // device: schoolbook on the 12 / 13-instruction multiply and multiply-add (4 products, the X^2 = 7 factor as a 7-instruction small multiple): ~68 VALU
   // instructions against ~95 for Karatsuba on canonical operations (its five modular additions cost as much as a product here). Same element, canonical.
   const u64 t7 = gx::mul_small(gx::mul(a.c1, b.c1), 7);
@@ -134,14 +142,14 @@ DP_HD Ext ex_from_u64(u64 v) { return ex(gl_from_u64(v), 0); }
 DP_HD Ext ex_from_i64(int64_t v) { return ex(gl_from_i64(v), 0); }
 // a + r*(b-a) with base-field a,b (first sumcheck fold of a base table)
 DP_HD Ext ex_lerp_base(u64 a, u64 b, Ext r) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DP_NO_GFX950_ASM)
+#if DP_GX_ON
   { const u64 dd = gl_sub(b, a); return ex(gl_canon_any(gx::fma(r.c0, dd, a)), gl_canon_any(gx::mul(r.c1, dd))); }
 #endif
   u64 d = gl_sub(b, a);
   return ex(gl_add(gl_mul(r.c0, d), a), gl_mul(r.c1, d));
 }
 DP_HD Ext ex_lerp(Ext a, Ext b, Ext r) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DP_NO_GFX950_ASM)
+#if DP_GX_ON
   const Ext d = ex_sub(b, a);  // a + r d with the addends riding in the multiply-adds
   const u64 r7 = gx::mul_small(r.c1, 7);
   return ex(gl_canon_any(gx::fma(r.c0, d.c0, gx::fma(r7, d.c1, a.c0))), gl_canon_any(gx::fma(r.c0, d.c1, gx::fma(r.c1, d.c0, a.c1))));

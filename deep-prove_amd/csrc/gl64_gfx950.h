@@ -23,7 +23,7 @@
 #pragma once
 #include "gl64.h"
 
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(DP_NO_GFX950_ASM)
+#if DP_GX_ON
 #define DP_GFX950_ASM 1
 namespace dp {
 namespace gx {

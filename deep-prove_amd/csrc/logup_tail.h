@@ -47,7 +47,19 @@ struct LogupTailDesc {
   Ext* den_all[LT_MAXI]; Ext* num_all[LT_MAXI]; // tree storage: den layer li at 2n - (2n >> li) (2n values), num layer li >= 1 at n - (2n >> li)
   Ext* eqn;                                     // n values: eq(final point, .)
   u64 lab_ibatching[2], lab_ialpha[2], lab_ilambda[2];
+  unsigned lds_ext, pad_;                       // extension values of dynamic LDS the launch brings (the layer tables live there once they fit)
 };
+
+// Dynamic LDS of a k_logup_tail launch, in bytes: the kernel keeps table slots of S values — 1 + 4 * ninst tables and the second half of the eq table's
+// double buffer — and takes the tables of a layer into LDS from the first round in which they are at most S long. S = n / 2 (the widest layer from its
+// first round on) when that fits into DP_LOGUP_LDS_KB (default 64, at most 128), else the largest power of two that does.
+inline size_t logup_tail_lds_bytes(size_t n, int ninst) {
+  static const size_t cap = [] { const char* e = getenv("DP_LOGUP_LDS_KB"); size_t kb = e ? (size_t)strtoull(e, nullptr, 10) : 64; if (kb < 4) kb = 4; if (kb > 128) kb = 128; return kb << 10; }();
+  const size_t slots = 2 + 4 * (size_t)ninst;
+  size_t S = 2;
+  while (2 * S <= n / 2 && 2 * S * slots * 16 <= cap) S *= 2;
+  return S * slots * 16;
+}
 
 // a transcript label as the (at most two) field elements append_message makes of it (poseidon2.h Transcript)
 inline void logup_tail_label(const char* lab, u64 out[2]) {
@@ -115,6 +127,7 @@ inline void logup_tail_fill(LogupTailDesc* d, const Dev::LogupTailArgs& a, const
   d->in_len = ch.in_len; d->out_len = ch.out_len;
   logup_tail_label("Internal round", d->lab_round); logup_tail_label("logup_batching", d->lab_batching);
   logup_tail_label("logup_alpha", d->lab_alpha); logup_tail_label("logup_lambda", d->lab_lambda);
+  d->lds_ext = (unsigned)(logup_tail_lds_bytes(n, ninst) / 16);
 }
 
 inline unsigned long long logup_tail_checksum(const volatile u64* w, const std::vector<size_t>& blocks) {
@@ -197,6 +210,7 @@ inline void logup_full_fill(LogupTailDesc* d, const DBuf* cols, int cpi, int nin
   logup_tail_label("Internal round", d->lab_round); logup_tail_label("logup_batching", d->lab_batching);
   logup_tail_label("logup_alpha", d->lab_alpha); logup_tail_label("logup_lambda", d->lab_lambda);
   logup_tail_label("initial_batching", d->lab_ibatching); logup_tail_label("initial_alpha", d->lab_ialpha); logup_tail_label("initial_lambda", d->lab_ilambda);
+  d->lds_ext = (unsigned)(logup_tail_lds_bytes(n, ninst) / 16);
 }
 inline void logup_full_parse(const u64* w, size_t n, int cpi, int ninst, bool is_table, const std::vector<size_t>& blocks, Challenger& ch, Dev::LogupFullOut& out) {
   for (int i = 0; i < 4 * ninst; i++) out.outputs.push_back(ex(w[2 * i], w[2 * i + 1]));

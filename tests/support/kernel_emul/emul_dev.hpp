@@ -47,6 +47,7 @@ struct EmulSponge {
 struct EmulDev : CpuDev {
   EmulSponge sponge;
   unsigned threads = 64;
+  unsigned lds_ext = 0;  // != 0: the dynamic LDS (in extension values) the emulated k_logup_tail launch brings, instead of what logup_tail_lds_bytes asks for
   size_t taken = 0, declined = 0;
   bool full = false;  // serve Dev::logup_full (the kernel's full mode) instead of Dev::logup_tail
   unsigned long long run_kernel(const LogupTailDesc& d, std::vector<u64>& res, const std::vector<size_t>& blocks) {
@@ -286,6 +287,7 @@ struct EmulDev : CpuDev {
     const size_t mk = mark();
     LogupTailDesc d;
     logup_full_fill(&d, cols, cpi, ninst, mult, c, chi, ch, *this);
+    if (lds_ext) d.lds_ext = lds_ext;
     sponge.arm(d, ch);
     std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
     run_kernel(d, res, blocks);
@@ -305,6 +307,7 @@ struct EmulDev : CpuDev {
     const size_t mk = mark();
     LogupTailDesc d;
     logup_tail_fill(&d, a, ch, *this);
+    if (lds_ext) d.lds_ext = lds_ext;
     sponge.arm(d, ch);
     std::vector<u64> res(nwords + 8, 0xDEADBEEFDEADBEEFull);
     run_kernel(d, res, blocks);

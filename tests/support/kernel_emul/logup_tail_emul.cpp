@@ -53,16 +53,22 @@ int main() {
     }
     rs = saved;
   }
+  // every case with the dynamic LDS the host code asks for (0) and with two small ones: the layer tables then start with rounds in global memory
+  // (ping-pong through bufA / bufB) and move into LDS in a later round — every source / destination pairing of a pass runs
+  const unsigned lds_caps[] = {0, 64, 256};
   for (const Case& c : all) {
     CpuDev ref; Ext ref_after;
     std::vector<uint64_t> want = prove(ref, c.n, c.ncols, c.cpi, c.table, ref_after);
-    EmulDev em; em.threads = c.threads; em.full = c.full; Ext em_after;
-    std::vector<uint64_t> got = prove(em, c.n, c.ncols, c.cpi, c.table, em_after);
-    size_t first = 0; while (first < want.size() && first < got.size() && want[first] == got[first]) first++;
-    bool ok = want == got && ex_eq(ref_after, em_after) && em.taken == 1;
-    printf("%s n=%zu columns=%d per_instance=%d %s threads=%u: kernel taken=%zu declined=%zu words=%zu identical=%d first_diff=%zu transcript_after=%d\n", c.full ? "full" : "tail", c.n, c.ncols, c.cpi,
-           c.table ? "table " : "lookup", c.threads, em.taken, em.declined, want.size(), want == got, first, ex_eq(ref_after, em_after));
-    if (!ok) rc = 1;
+    for (unsigned cap : lds_caps) {
+      if (cap && c.n >= 2048 && cap == 64) continue;  // (emulation time)
+      EmulDev em; em.threads = c.threads; em.full = c.full; em.lds_ext = cap; Ext em_after;
+      std::vector<uint64_t> got = prove(em, c.n, c.ncols, c.cpi, c.table, em_after);
+      size_t first = 0; while (first < want.size() && first < got.size() && want[first] == got[first]) first++;
+      bool ok = want == got && ex_eq(ref_after, em_after) && em.taken == 1;
+      printf("%s n=%zu columns=%d per_instance=%d %s threads=%u lds_ext=%u: kernel taken=%zu declined=%zu words=%zu identical=%d first_diff=%zu transcript_after=%d\n", c.full ? "full" : "tail", c.n, c.ncols, c.cpi,
+             c.table ? "table " : "lookup", c.threads, cap, em.taken, em.declined, want.size(), want == got, first, ex_eq(ref_after, em_after));
+      if (!ok) rc = 1;
+    }
   }
   return rc;
 }

@@ -73,12 +73,15 @@ static struct { simt::Const x{1}, y{1}, z{1}; } gridDim;
 #define __restrict__
 #define KBODY inline void
 #define DP_LDS_FRAME(T, f) static T f  // (one workgroup at a time: the frame of a body is a plain static object here)
+#define DP_LDS_DYN(name, T) alignas(16) static unsigned char name[160 << 10]  // (the dynamic LDS of a launch: a CU's whole LDS)
+#define DP_WAVE_SYNC() simt::wave_barrier(simt::tid() >> 6)  // lanes of one wave hand data to each other through LDS: in lock step on the hardware, a rendezvous here
 #define DP_CLAIM_ALL_VGPRS() ((void)0)
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 #define __hip_atomic_load(p, order, scope) (*(volatile const std::remove_pointer_t<decltype(p)>*)(p))
 inline void __syncthreads() { simt::barrier(); }
 inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+inline unsigned __brev(unsigned x) { unsigned r = 0; for (int i = 0; i < 32; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
 inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 inline unsigned long long __brevll(unsigned long long x) { unsigned long long r = 0; for (int i = 0; i < 64; i++) { r = (r << 1) | (x & 1); x >>= 1; } return r; }
 inline int __shfl(int v, int src, int width = 64) {
