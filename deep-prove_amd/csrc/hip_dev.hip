@@ -1060,7 +1060,7 @@ class HipDev : public Dev {
     SpongeArm sponge(this, d, ch);
     const unsigned long long seq = ++seq_;
     nb_ = 0; for (const LogupCircuitDev& c : *a.circuits) for (const DBuf& l : c.den) nb_ += 2.0 * 16.0 * (double)l.n;
-    DPL_ONE(k_logup_tail, dim3(1), 1024, (size_t)d->lds_ext * 16, dd, (u64*)hres_dev_, hflag_dev_, seq);
+    DPL_ONE(k_logup_tail, dim3(1), 1024, (size_t)d->lds_ext * 16 + ((nwords * 8 + 15) & ~size_t(15)), dd, (u64*)hres_dev_, hflag_dev_, seq);  // (table slots + the message, assembled in LDS)
     wait_flag_blocks(seq, blocks);
     sponge.done();
     logup_tail_parse(hres_, a, blocks, ch, layer_msgs, layer_points, round_evals, point);
@@ -1206,7 +1206,7 @@ class HipDev : public Dev {
     SpongeArm sponge(this, d, ch);
     const unsigned long long seq = ++seq_;
     nb_ = (double)ninst * (8.0 * cpi * n + 16.0 * 3 * n) * 2.0;
-    DPL_ONE(k_logup_tail, dim3(1), 1024, (size_t)d->lds_ext * 16, dd, (u64*)hres_dev_, hflag_dev_, seq);
+    DPL_ONE(k_logup_tail, dim3(1), 1024, (size_t)d->lds_ext * 16 + ((nwords * 8 + 15) & ~size_t(15)), dd, (u64*)hres_dev_, hflag_dev_, seq);  // (table slots + the message, assembled in LDS)
     wait_flag_blocks(seq, blocks);
     sponge.done();
     logup_full_parse(hres_, n, cpi, ninst, !mult.null(), blocks, ch, out);
@@ -1909,12 +1909,16 @@ void hip_dump_wg_times() {
     hipMemcpyFromSymbol(&sp, HIP_SYMBOL(g_sponge_ticks), 8); hipMemcpyFromSymbol(&np, HIP_SYMBOL(g_sponge_perms), 8); hipMemcpyFromSymbol(&mt, HIP_SYMBOL(g_member_ticks), 8);
     hipMemcpyToSymbol(HIP_SYMBOL(g_sponge_ticks), &zero, 8); hipMemcpyToSymbol(HIP_SYMBOL(g_sponge_perms), &zero, 8); hipMemcpyToSymbol(HIP_SYMBOL(g_member_ticks), &zero, 8);
     {
-      unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, z8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_phase_ticks), sizeof(ph)); hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), z8, sizeof(z8));
-      if (ph[7]) fprintf(stderr, "[dp wg-times] k_logup_tail, sponge-free time of the sponge wave per member (us): tree + first transcript %.0f, layer set-up %.0f, passes %.0f, message + challenge bookkeeping %.0f, "
-                                 "layer end (final fold, three challenges, next claim) %.0f, column claims %.0f, tail %.0f; %llu members\n",
-                         (double)ph[0] / 100.0 / (double)ph[7], (double)ph[1] / 100.0 / (double)ph[7], (double)ph[2] / 100.0 / (double)ph[7], (double)ph[3] / 100.0 / (double)ph[7],
-                         (double)ph[4] / 100.0 / (double)ph[7], (double)ph[5] / 100.0 / (double)ph[7], (double)ph[6] / 100.0 / (double)ph[7], ph[7]);
+      unsigned long long pha[16], z16[16];
+      for (int k = 0; k < 16; k++) { pha[k] = 0; z16[k] = 0; }
+      hipMemcpyFromSymbol(pha, HIP_SYMBOL(g_phase_ticks), sizeof(pha)); hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), z16, sizeof(z16));
+      for (int big = 0; big < 2; big++) {
+        const unsigned long long* ph = pha + 8 * big;
+        if (ph[7]) fprintf(stderr, "[dp wg-times] k_logup_tail (%s), sponge-free time of the sponge wave per member (us): tree + first transcript %.0f, layer set-up %.0f, passes %.0f, message + challenge bookkeeping %.0f, "
+                                   "layer end (final fold, three challenges, next claim) %.0f, column claims %.0f, tail %.0f; %llu members\n", big ? "columns of more than 1024 rows" : "columns of at most 1024 rows",
+                           (double)ph[0] / 100.0 / (double)ph[7], (double)ph[1] / 100.0 / (double)ph[7], (double)ph[2] / 100.0 / (double)ph[7], (double)ph[3] / 100.0 / (double)ph[7],
+                           (double)ph[4] / 100.0 / (double)ph[7], (double)ph[5] / 100.0 / (double)ph[7], (double)ph[6] / 100.0 / (double)ph[7], ph[7]);
+      }
     }
     if (np) fprintf(stderr, "[dp wg-times] k_logup_tail members: %.1f %% of entry -> exit inside the sponge permutation (%llu permutations, %.2f us each); the rest (table work, barriers, round arithmetic) %.0f us per 100 permutations\n",
                     100.0 * (double)sp / (double)mt, np, (double)sp / 100.0 / (double)np, (double)(mt - sp) / 100.0 / (double)np * 100.0);
