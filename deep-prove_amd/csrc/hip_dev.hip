@@ -966,7 +966,8 @@ class HipDev : public Dev {
     for (int i = 0; i < MAX_TERMS; i++) { a.k[i] = 1; a.off[i] = 0; for (int j = 0; j < SC_MAXK; j++) a.t[i][j] = 0; }
     { int o = 0; for (int i = 0; i < nterms; i++) { a.k[i] = terms[i].k; for (int j = 0; j < SC_MAXK; j++) a.t[i][j] = j < terms[i].k ? terms[i].t[j] : 0; a.off[i] = o; o += terms[i].k + 1; } }
     const size_t lds = (size_t)nt * (n_in / 2) * 16;
-    const bool in_lds = lds <= sc_lds_max();
+    const size_t msg_lds = (nwords * 8 + 15) & ~size_t(15);  // the message is assembled in LDS (kernels.inc: MSG_PUT / msg_flush)
+    const bool in_lds = lds + msg_lds <= sc_lds_max();
     size_t first = r ? n_after : n_after / 2;
     double tab_bytes = 0;
     for (int i = 0; i < nt; i++) {
@@ -987,8 +988,8 @@ class HipDev : public Dev {
     unsigned long long seq = ++seq_;
     size_t work = (size_t)nterms * (n_after / 2) + (size_t)nt * n_after / 4;
     int threads = persist_threads(work);
-    if (in_lds) { nb_ = tab_bytes; DPL_ONE_HI(k_sc_persist_lds, hi, dim3(1), threads, lds, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
-    else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_ONE_HI(k_sc_persist, hi, dim3(1), threads, 0, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
+    if (in_lds) { nb_ = tab_bytes; DPL_ONE_HI(k_sc_persist_lds, hi, dim3(1), threads, lds + msg_lds, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
+    else { nb_ = tab_bytes + 24.0 * (double)n_in * nt; DPL_ONE_HI(k_sc_persist, hi, dim3(1), threads, msg_lds, a, (Ext*)hres_dev_, hflag_dev_, (const unsigned long long*)hmail_dev_, seq - 1, fsd); }
     wait_flag(seq, nwords);
     const u64* w = hres_;
     for (unsigned q = 0; q < rounds; q++) {
@@ -1012,6 +1013,9 @@ class HipDev : public Dev {
   // Validated on MI355X in round 2 (tests/test_gpu_fused.py: every knob alone and all together, Dense-4M and CNN-264k batches
   // against the sequential proofs; profiles/r02_fused_knob_sweep.jsonl).
   static int knob(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+  // dynamic LDS of a fused protocol kernel = its message (assembled in LDS, sent in one burst: kernels.inc MSG_PUT / msg_flush); 0: too long for that, the caller declines
+  static constexpr size_t MSG_LDS_MAX = 48 * 1024;
+  static size_t msg_lds(const std::vector<size_t>& blocks) { size_t n = 0; for (size_t b : blocks) n += b; const size_t bytes = (n * 8 + 15) & ~size_t(15); return bytes <= MSG_LDS_MAX ? bytes : 0; }
   // DP_FUSED_OFF=<comma-separated subset of classic,commit,deleg,dense,eqsum>: those fused protocol kernels decline and their stretch runs launch by launch
   // (tests/test_gpu_fused.py turns each off alone and all together); the logup kernel has its own three-way switch DP_DEVICE_LOGUP
   static bool fused_on(const char* what) { const char* e = getenv("DP_FUSED_OFF"); if (!e) return true; const std::string s = std::string(",") + e + ","; return s.find(std::string(",") + what + ",") == std::string::npos; }
@@ -1051,7 +1055,7 @@ class HipDev : public Dev {
     if (!logup_tail_accepts(a)) return false;
     const std::vector<size_t> blocks = logup_tail_blocks(a);
     size_t nwords = 0; for (size_t b : blocks) nwords += b;
-    if (nwords > RES_WORDS) return false;
+    if (nwords > RES_WORDS || nwords * 8 > MSG_LDS_MAX) return false;
     flush_pending_eq();
     const size_t mk = mark();
     const LogupTailDesc* dd = nullptr;
@@ -1075,7 +1079,7 @@ class HipDev : public Dev {
     if (!devcommit_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_ || !tw_) return false;
     if (!commit_tail_accepts(a, commit_tail_max_n(throughput_mode_)) || dp_ceil_log2(a.folded.n) - 1 > L_) return false;
     const std::vector<size_t> blocks = commit_tail_blocks(a);
-    if (blocks[0] + blocks[1] > RES_WORDS) return false;
+    if (blocks[0] + blocks[1] > RES_WORDS || !msg_lds(blocks)) return false;
     const CommitTailDesc* dd = nullptr;
     CommitTailDesc* d = desc_alloc<CommitTailDesc>(1, &dd);
     std::vector<DevTree> trees;
@@ -1085,7 +1089,7 @@ class HipDev : public Dev {
     SpongeArm sponge(this, d, ch);
     const unsigned long long seq = ++seq_;
     nb_ = 16.0 * (double)a.folded.n * 2.0 + 32.0 * (double)a.sum_evals.n;
-    DPL_ONE(k_commit_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
+    DPL_ONE(k_commit_tail, dim3(1), 1024, msg_lds(blocks), dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
     sponge.done();
     commit_tail_parse(hres_, a, ch, trees, out);
@@ -1099,7 +1103,7 @@ class HipDev : public Dev {
     if (!deveqsum_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
     if (!eqsum_tail_accepts(jobs, njobs, tabs, ntabs, terms, nterms, nv, md)) return false;
     const std::vector<size_t> blocks = eqsum_tail_blocks(ntabs, nv, md);
-    if (blocks[0] + blocks[1] > RES_WORDS) return false;
+    if (blocks[0] + blocks[1] > RES_WORDS || !msg_lds(blocks)) return false;
     flush_pending_eq();
     const size_t mk = mark();
     const EqSumDesc* dd = nullptr;
@@ -1108,7 +1112,7 @@ class HipDev : public Dev {
     SpongeArm sponge(this, d, ch);
     const unsigned long long seq = ++seq_;
     nb_ = 0; for (int i = 0; i < ntabs; i++) nb_ += (double)tabs[i].bytes();
-    DPL_ONE(k_eqsum_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
+    DPL_ONE(k_eqsum_tail, dim3(1), 1024, msg_lds(blocks), dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
     sponge.done();
     eqsum_tail_parse(hres_, ntabs, nv, md, ch, out);
@@ -1124,7 +1128,7 @@ class HipDev : public Dev {
     const size_t fm = a.f_middle->size();
     const std::vector<size_t> blocks = deleg_tail_blocks(fm);
     size_t nwords = 0; for (size_t b : blocks) nwords += b;
-    if (nwords > RES_WORDS) return false;
+    if (nwords > RES_WORDS || !msg_lds(blocks)) return false;
     flush_pending_eq();
     const size_t mk = mark();
     const std::vector<u64> words = deleg_tail_stage(a);
@@ -1136,7 +1140,7 @@ class HipDev : public Dev {
     SpongeArm sponge(this, d, ch);
     const unsigned long long seq = ++seq_;
     nb_ = 8.0 * (double)words.size();
-    DPL_ONE(k_deleg_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
+    DPL_ONE(k_deleg_tail, dim3(1), 1024, msg_lds(blocks), dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
     sponge.done();
     deleg_tail_parse(hres_, fm, ch, out);
@@ -1158,7 +1162,7 @@ class HipDev : public Dev {
     SpongeArm sponge(this, d, ch);
     const unsigned long long seq = ++seq_;
     nb_ = 8.0 * (double)R * (double)C + 16.0 * (double)R + 16.0 * (double)C * 4.0;
-    DPL_ONE(k_dense_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
+    DPL_ONE(k_dense_tail, dim3(1), 1024, msg_lds(blocks), dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
     sponge.done();
     dense_tail_parse(hres_, C, ch, out);
@@ -1172,7 +1176,7 @@ class HipDev : public Dev {
     if (!devclassic_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
     if (!classic_tail_accepts(a)) return false;
     const std::vector<size_t> blocks = classic_tail_blocks(a);
-    if (blocks[0] + blocks[1] > RES_WORDS) return false;
+    if (blocks[0] + blocks[1] > RES_WORDS || !msg_lds(blocks)) return false;
     const size_t mk = mark();
     const ClassicTailDesc* dd = nullptr;
     ClassicTailDesc* d = desc_alloc<ClassicTailDesc>(1, &dd);
@@ -1180,7 +1184,7 @@ class HipDev : public Dev {
     SpongeArm sponge(this, d, ch);
     const unsigned long long seq = ++seq_;
     nb_ = 0; for (int i = 0; i < a.np; i++) nb_ += a.fs[i].bytes() + a.eqs[i].bytes();
-    DPL_ONE(k_classic_tail, dim3(1), 1024, 0, dd, (u64*)hres_dev_, hflag_dev_, seq);
+    DPL_ONE(k_classic_tail, dim3(1), 1024, msg_lds(blocks), dd, (u64*)hres_dev_, hflag_dev_, seq);
     wait_flag_blocks(seq, blocks);
     sponge.done();
     classic_tail_parse(hres_, a, ch, msgs, challenges);
@@ -1197,7 +1201,7 @@ class HipDev : public Dev {
     if (!logup_full_accepts(cols, cpi, ninst, mult, &n)) return false;
     const std::vector<size_t> blocks = logup_full_blocks(n, cpi, ninst, !mult.null());
     size_t nwords = 0; for (size_t b : blocks) nwords += b;
-    if (nwords > RES_WORDS) return false;
+    if (nwords > RES_WORDS || nwords * 8 > MSG_LDS_MAX) return false;
     flush_pending_eq();
     const size_t mk = mark();
     const LogupTailDesc* dd = nullptr;

@@ -74,6 +74,7 @@ static struct { simt::Const x{1}, y{1}, z{1}; } gridDim;
 #define KBODY inline void
 #define DP_LDS_FRAME(T, f) static T f  // (one workgroup at a time: the frame of a body is a plain static object here)
 #define DP_LDS_DYN(name, T) alignas(16) static unsigned char name[160 << 10]  // (the dynamic LDS of a launch: a CU's whole LDS)
+#define MSG_PUT(p, v) (*(p) = (v))  // (kernels.inc: a word of the message a one-workgroup kernel assembles in LDS)
 #define DP_WAVE_SYNC() simt::wave_barrier(simt::tid() >> 6)  // lanes of one wave hand data to each other through LDS: in lock step on the hardware, a rendezvous here
 #define DP_CLAIM_ALL_VGPRS() ((void)0)
 #define __HIP_MEMORY_SCOPE_SYSTEM 0
