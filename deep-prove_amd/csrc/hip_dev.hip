@@ -72,6 +72,12 @@ constexpr int SHARED_MAXT = 256;
 #define DP_SET_LDS(kern, maxt, bytes) set_lds_<kern, maxt, KF_NONE>(KArgs<decltype(&kern)>(), (int)(bytes))
 #define DP_SET_LDS_ONE(kern, maxt, bytes) do { set_lds_<kern, maxt, KF_CLAIM>(KArgs<decltype(&kern)>(), (int)(bytes)); set_lds_<kern, SHARED_MAXT, KF_PRIO>(KArgs<decltype(&kern)>(), (int)(bytes)); } while (0)
 
+// Host memory that the HOST writes before a launch and kernels only READ — the cohorts' argument-pack rings, the descriptor ring — is mapped NON-coherent
+// (coarse-grained): the GPU may keep its lines in L2 for the length of a kernel and drops them at the next kernel's system-scope acquire, so a descriptor costs one
+// PCIe read per kernel and XCD instead of one per workgroup that looks at it (k_classic_fused / k_axpy_many / k_eq_table_many walk descriptor arrays in every
+// workgroup). Memory a kernel WRITES for the host to poll (results, flags, mailboxes, the download staging) stays coherent. DP_HOST_NC=0: everything coherent, as before.
+static const bool g_host_nc = !(getenv("DP_HOST_NC") && !atoi(getenv("DP_HOST_NC")));
+static inline unsigned host_ro_flags() { return hipHostMallocMapped | (g_host_nc ? hipHostMallocNonCoherent : hipHostMallocCoherent); }
 static const int g_timing_level = getenv("DP_TIMING") ? atoi(getenv("DP_TIMING")) : 0;  // 1: host / cohort accounting on stderr; 2: also launches by kernel, long host stretches, device cycle counters of the persistent sumcheck
 static const bool g_host_stats = g_timing_level > 0;
 // DP_WAIT_YIELD=1: a host thread that waits for the device outside a fiber gives its CPU away (sched_yield) instead of spinning — for
@@ -122,7 +128,7 @@ struct Cohort {
 
   explicit Cohort(size_t ring_bytes = size_t(32) << 20) : ring_cap(ring_bytes) {
     HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    HIP_CHECK(hipHostMalloc((void**)&ring, ring_cap, hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_CHECK(hipHostMalloc((void**)&ring, ring_cap, host_ro_flags()));
     HIP_CHECK(hipHostGetDevicePointer((void**)&ring_dev, ring, 0));
   }
   ~Cohort() { if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); } if (ring) hipHostFree(ring); }
@@ -318,8 +324,10 @@ class HipDev : public Dev {
   }
   u64* dres_ = nullptr;   // device result buffer
   unsigned* fused_ticket_ = nullptr;  // "last workgroup" ticket of k_sc_fused (device, zero between launches)
-  void* hstage_ = nullptr;  // pinned + device-mapped staging: [0, DESC_BYTES) descriptor ring read by kernels over PCIe, rest = bulk copies
+  void* hstage_ = nullptr;  // pinned + device-mapped staging of bulk copies (from DESC_BYTES on; coherent: k_download's chunk tags are polled by the host)
   char* hstage_dev_ = nullptr;
+  void* hdesc_ = nullptr;   // descriptor ring: written by the host before a launch, read by its kernels (host_ro_flags: non-coherent, cacheable on the GPU)
+  char* hdesc_dev_ = nullptr;
   size_t desc_off_ = 0;
   // Asynchronous uploads (throughput mode; DP_ASYNC_UPLOAD=0 turns them off, =1 forces them for single proofs too): small
   // host-to-device copies take successive slots of the bulk staging area and are not waited for — like descriptors, the slots
@@ -404,8 +412,8 @@ class HipDev : public Dev {
     size_t bytes = (count * sizeof(T) + 63) & ~size_t(63);
     DP_REQUIRE(bytes <= DESC_BYTES, DP_ERR_SHAPE, "descriptor batch too large");
     if (desc_off_ + bytes > DESC_BYTES) { stream_wait(); }
-    T* h = (T*)((char*)hstage_ + desc_off_);
-    *dev_view = (const T*)(hstage_dev_ + desc_off_);
+    T* h = (T*)((char*)hdesc_ + desc_off_);
+    *dev_view = (const T*)(hdesc_dev_ + desc_off_);
     desc_off_ += bytes;
     return h;
   }
@@ -517,7 +525,8 @@ class HipDev : public Dev {
     HIP_CHECK(hipMalloc((void**)&fused_ticket_, 64)); HIP_CHECK(hipMemset(fused_ticket_, 0, 64));
     HIP_CHECK(hipHostMalloc(&hstage_, STAGE_BYTES + DESC_BYTES, hipHostMallocMapped | hipHostMallocCoherent));
     HIP_CHECK(hipHostGetDevicePointer((void**)&hstage_dev_, hstage_, 0));
-    hstage_dev_ += 0;
+    HIP_CHECK(hipHostMalloc(&hdesc_, DESC_BYTES, host_ro_flags()));
+    HIP_CHECK(hipHostGetDevicePointer((void**)&hdesc_dev_, hdesc_, 0));
     HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(c_rc), POSEIDON2_RC_HOST, sizeof(POSEIDON2_RC_HOST)));
     { std::vector<u64> ex((SC_MAXK + 1) * (SC_MAXK + 1) * (SC_MAXK + 1), 0);  // extrapolation_coeffs(k, at)[i] of sumcheck.h
       for (unsigned k = 1; k < (unsigned)SC_MAXK; k++) for (unsigned at = k + 1; at <= (unsigned)SC_MAXK; at++) for (unsigned i = 0; i <= k; i++)
@@ -559,6 +568,7 @@ class HipDev : public Dev {
     if (hsp_) hipHostFree(hsp_);
     if (hres_) hipHostFree(hres_);
     if (hstage_) hipHostFree(hstage_);
+    if (hdesc_) hipHostFree(hdesc_);
     if (s_) hipStreamDestroy(s_);
   }
   const char* name() const override { return name_.c_str(); }
