@@ -61,16 +61,23 @@ struct ProfRec { const char* name; double bytes; hipEvent_t a, b; };
 // register allocator 512 VGPRs per lane instead of the 128 of a 1024-thread workgroup — under __launch_bounds__(1024) k_logup_tail spilled 54 VGPRs and
 // k_sc_persist 75 into scratch, on the dependent chain that bounds every tail (round-3 review; profiles/r04_kernel_resources_gfx950.csv).
 constexpr int SHARED_MAXT = 256;
+// The latency-mode (whole-CU) form of the same bodies: LAT_MAXT threads, and COMPILED for that many. Round 4 launched and compiled it for 1024 threads — 128 VGPRs
+// per lane: k_sc_persist_lds<false> spilled 59 VGPRs, the claim forms of the tails 23 .. 104 (profiles/r04_kernel_resources_gfx950.csv) — and a Fiat-Shamir round
+// of a single proof spent 14 of its 30 us in the fold and the round sums of kilobyte tables (DP_TIMING=2, tools/r05/call12.sh): scratch reloads on the dependent chain.
+#ifndef DP_LAT_MAXT
+#define DP_LAT_MAXT 512
+#endif
+constexpr int LAT_MAXT = DP_LAT_MAXT;
 // one-workgroup-per-proof kernels (persistent sumchecks, fused protocol tails, Merkle tails): `threads` and the CU reservation
 // apply in latency mode; in throughput mode the workgroup shrinks to shared_threads_ and reserves nothing (KF_PRIO above).
 // `lds` = dynamic LDS the body really needs.
 #define DPL_ONE(kern, grid, threads, lds, ...) do { if (shared_now()) { DPL_B(kern, SHARED_MAXT, KF_PRIO, grid, dim3(std::min<unsigned>((unsigned)(threads), (unsigned)shared_threads_)), (size_t)(lds), __VA_ARGS__); } \
-                                                     else { DPL_B(kern, 1024, KF_CLAIM, grid, dim3(threads), std::max<size_t>((size_t)(lds), excl_now()), __VA_ARGS__); } } while (0)
+                                                     else { DPL_B(kern, LAT_MAXT, KF_CLAIM, grid, dim3(std::min<unsigned>((unsigned)(threads), (unsigned)LAT_MAXT)), std::max<size_t>((size_t)(lds), excl_now()), __VA_ARGS__); } } while (0)
 #define DPL_ONE_HI(kern, hi, grid, threads, lds, ...) do { if (hi) { DPL_ONE((kern<true>), grid, threads, lds, __VA_ARGS__); } else { DPL_ONE((kern<false>), grid, threads, lds, __VA_ARGS__); } } while (0)
 #define DPL_HI(kern, hi, grid, block, ...) do { if (hi) { DPL((kern<true>), grid, block, __VA_ARGS__); } else { DPL((kern<false>), grid, block, __VA_ARGS__); } } while (0)
 #define DPL_LDS_HI(kern, hi, grid, block, lds, ...) do { if (hi) { DPL_LDS((kern<true>), grid, block, lds, __VA_ARGS__); } else { DPL_LDS((kern<false>), grid, block, lds, __VA_ARGS__); } } while (0)
 #define DP_SET_LDS(kern, maxt, bytes) set_lds_<kern, maxt, KF_NONE>(KArgs<decltype(&kern)>(), (int)(bytes))
-#define DP_SET_LDS_ONE(kern, maxt, bytes) do { set_lds_<kern, maxt, KF_CLAIM>(KArgs<decltype(&kern)>(), (int)(bytes)); set_lds_<kern, SHARED_MAXT, KF_PRIO>(KArgs<decltype(&kern)>(), (int)(bytes)); } while (0)
+#define DP_SET_LDS_ONE(kern, maxt, bytes) do { set_lds_<kern, LAT_MAXT, KF_CLAIM>(KArgs<decltype(&kern)>(), (int)(bytes)); set_lds_<kern, SHARED_MAXT, KF_PRIO>(KArgs<decltype(&kern)>(), (int)(bytes)); } while (0)
 
 // Host memory that the HOST writes before a launch and kernels only READ — the cohorts' argument-pack rings, the descriptor ring — is mapped NON-coherent
 // (coarse-grained): the GPU may keep its lines in L2 for the length of a kernel and drops them at the next kernel's system-scope acquire, so a descriptor costs one
