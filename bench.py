@@ -365,15 +365,42 @@ def kernel_profile(dev, prover, x):
     return rep
 
 
+def _source_sha16():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from srchash import source_sha16
+    return source_sha16()
+
+
+def _same_sources(doc):
+    """a committed counter pass / diagnostic timing describes THIS build only if it was collected on the same deep-prove_amd/csrc (tools/srchash.py); files from
+    before round 5 carry no hash and are never quoted"""
+    return bool(doc.get("source_sha16")) and doc["source_sha16"] == _source_sha16()
+
+
 def valu_accounting(workload):
-    """the newest committed SQ instruction pass of this workload's throughput-mode job (tools/pmc_sq_job.py), or None"""
+    """the newest committed SQ instruction pass of this workload's throughput-mode job (tools/pmc_sq_job.py) collected on these sources, or None"""
     if workload != "dense_4m":
         return None
     try:
         for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
             if "_pmc_sq_bench" in name and name.endswith(".json"):
                 doc = json.load(open(os.path.join(ROOT, "profiles", name)))
-                if doc.get("population") == "dense_4m_throughput_mode_cohort_launches":
+                if doc.get("population") == "dense_4m_throughput_mode_cohort_launches" and _same_sources(doc):
+                    return dict(doc, source=f"profiles/{name}")
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
+def tail_roofline():
+    """the one-workgroup protocol tails against their own floor — a member of a merged k_logup_tail launch is a chain of sponge permutations on ONE wave: floor =
+    permutations per member x the permutation's cost in a loop (profiles/r04_p2l_bench_limb_sponge.txt) — from the diagnostic-build timing of this build
+    (tools/tail_roofline.py -> profiles/r*_tail_roofline.json: entry -> exit of every member of every merged launch at 448 proofs in flight), or None"""
+    try:
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if name.endswith("_tail_roofline.json"):
+                doc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if _same_sources(doc):
                     return dict(doc, source=f"profiles/{name}")
     except (OSError, ValueError, KeyError):
         pass
@@ -392,7 +419,7 @@ def pmc_traffic(kernel, population, launches=None):
             if "_pmc_" not in name or not name.endswith(".json"):
                 continue
             doc = json.load(open(os.path.join(ROOT, "profiles", name)))
-            if doc.get("population") != population:
+            if doc.get("population") != population or not _same_sources(doc):  # (another population, or a pass collected on other sources than the ones that run)
                 continue
             for rec in doc["kernels"]:
                 if "hbm_bytes_per_launch" in rec and norm(rec["kernel"]) == norm(kernel):
@@ -434,6 +461,7 @@ def main():
     ap.add_argument("--no-cnn", action="store_true", help="skip the CNN-264k section of a Dense-4M run")
     ap.add_argument("--no-transformer", action="store_true", help="skip the transformer-layer section (models.transformer_layer: LayerNorm, QKV, the Mha node, feed-forward half)")
     ap.add_argument("--no-seam-level", action="store_true", help="skip the seam-level consumer section (tests/support/seam_bench.c)")
+    ap.add_argument("--no-batch64", action="store_true", help="skip the config-4 anchor (one batch of 64 proofs per step on this GPU) of a default run")
     ap.add_argument("--batch", type=int, default=0, help="BASELINE config 4: ONE fixed batch of this many proofs per step, split over the ranks (strong scaling); "
                                                          "0 = the default weak-scaling run (fixed work per GPU)")
     ap.add_argument("--concurrency", type=int, default=0, help=f"independent proofs in flight per GPU (0 = {DEFAULT_IN_FLIGHT})")
@@ -615,6 +643,19 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "cnn_264k": cnn, "sumcheck24": sc24, "sumcheck24_sharded": None,
             "seam_level": None if (world > 1 or args.no_seam_level) else seam_level(int(os.environ["DP_HOST_THREADS"]), batch_rate=value),
         }
+        result["tail_roofline"] = tail_roofline()
+        if world == 1 and args.workload == "dense_4m" and not args.batch and not args.no_batch64:
+            # BASELINE config 4 at N = 1: ONE batch of 64 independent proofs per step, all in flight at once — the anchor the 8-GPU strong-scaling line
+            # (`bench.py --gpus 8 --batch 64`) is read against; the golden input rides in the last step and its proof must have the oracle's sha256
+            try:
+                b_steps = 3
+                b64 = measure_workload(dpa, dev, "dense_4m", conc, b_steps, 1, world, rank, dist, torch, strong_batch=64)
+                result["batch64"] = {"metric": "proofs/sec (prover), Dense-4M, one batch of 64 per step (BASELINE config 4 on 1 GPU)", "value": round(b_steps * 64 / b64["elapsed"], 4), "unit": "proofs/s",
+                                     "ms_per_batch": round(1000.0 * b64["elapsed"] / b_steps, 2), "steps": b_steps, "warmup": 1, "proofs_in_flight": b64["in_flight"], "scaling": "strong",
+                                     "step_ms": [round(v, 1) for v in b64["step_ms"]], "golden_sha256_ok": b64["golden_ok"], "verified_proofs_of_last_step": b64["verified"],
+                                     "command_for_n_gpus": "python bench.py --gpus N --batch 64"}
+            except Exception as e:  # noqa: BLE001
+                result["batch64"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and args.workload == "dense_4m" and not args.batch and not args.no_transformer:
             try:  # (a side section: whatever happens in it, the headline line above is printed)
                 result["transformer_layer"] = transformer_layer_section(dpa, dev, conc=int(os.environ.get("DP_BENCH_TL_IN_FLIGHT", "320")))

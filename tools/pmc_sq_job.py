@@ -13,6 +13,7 @@ import sys
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
 from rocpd_summary import short
+from srchash import source_sha16
 
 SIMDS, CLOCK_HZ, CYC = 1024, 2.4e9, 4.0
 
@@ -42,7 +43,7 @@ def main():
     for r in rows:
         r["share"] = round(r["valu_wave_instr_per_proof"] / total, 4) if total else 0.0
     cap = SIMDS * CLOCK_HZ / CYC
-    doc = {"command": command, "population": "dense_4m_throughput_mode_cohort_launches", "proofs": proofs, "proofs_per_s_unprofiled": rate,
+    doc = {"command": command, "population": "dense_4m_throughput_mode_cohort_launches", "source_sha16": source_sha16(), "proofs": proofs, "proofs_per_s_unprofiled": rate,
            "valu_wave_instr_per_proof": round(total, 1), "valu_wave_instr_per_s": round(total * rate, 1),
            "chip_issue_capacity_wave_instr_per_s": cap, "assumed": {"simds": SIMDS, "clock_hz": CLOCK_HZ, "cycles_per_wave_instr": CYC},
            "valu_issue_util": round(total * rate / cap, 4),
