@@ -722,6 +722,12 @@ class HipDev : public Dev {
   // A cohort member moves data with kernels (k_copy_words through the mapped staging buffer, k_zero_words): a memcpy
   // command queued by one member would overtake the merged launches its cohort has not fired yet.
   void h2d(void* dst, const void* src, size_t bytes) {
+    // an upload of up to the size of the asynchronous staging ring goes through it in slots of at most ASYNC_MAX (no device wait unless the ring wraps): until
+    // round 5 anything above 2 MB took the synchronous path below — the witness columns of a transformer-layer proof (12 MB), member after member of a cohort
+    if (async_upload_now() && zerocopy_ && bytes > ASYNC_MAX && bytes % 8 == 0 && bytes <= ASYNC_STAGE && STAGE_BYTES >= ASYNC_STAGE) {
+      for (size_t off = 0; off < bytes; off += ASYNC_MAX) h2d((char*)dst + off, (const char*)src + off, std::min(ASYNC_MAX, bytes - off));
+      return;
+    }
     if (async_upload_now() && zerocopy_ && bytes > 0 && bytes % 8 == 0 && bytes <= ASYNC_MAX && STAGE_BYTES >= ASYNC_STAGE) {
       const size_t need = (bytes + 255) & ~size_t(255);
       if (stage_off_ + need > ASYNC_STAGE) { stream_wait(); stage_off_ = 0; }

@@ -620,6 +620,10 @@ struct Context {
   // table 2^14 of sqrt), not once per proof as until round 4. inv_cnt[i] = 1 / (number of rows of the table that hold merged[i]) — the zero padding
   // of an error table repeats a row —, so that a proof's multiplicity of row i is count(merged[i]) * inv_cnt[i]. Shared by the workers of a batch.
   struct TableData { std::vector<int64_t> merged; std::vector<std::vector<int64_t>> cols; std::vector<u64> inv_cnt; };
+  // ... and they live ON THE DEVICE for the life of the context, as the weights do (round 5): until then the tables' columns rode in every proof's witness
+  // upload — 68 352 of the 113 444 words of a Dense-4M proof, 307 k of 649 k for CNN-264k, 330 k of 1.87 M for the transformer layer. Base-field columns in
+  // commit order of the table's proof; read-only, shared by the workers of a batch (persistent buffers belong to the device).
+  std::map<TableType, std::vector<DBuf>> table_cols_dev;
   mutable std::mutex table_data_mu; mutable std::map<TableType, std::unique_ptr<TableData>> table_data_;
   const TableData& table_data(const TableType& tt) const {
     std::lock_guard<std::mutex> g(table_data_mu);
@@ -645,6 +649,7 @@ struct Context {
     for (auto& kv : model_comms) for (auto& pc : kv.second) dev->free_commit(pc.second);
     for (auto& kv : table_comms) dev->free_commit(kv.second);
     for (auto& kv : conv_dev) { dev->free_persistent(kv.second.wfft); dev->free_persistent(kv.second.clearing); }
+    for (auto& kv : table_cols_dev) for (DBuf& b : kv.second) dev->free_persistent(b);
   }
 };
 
@@ -839,6 +844,11 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
     dev.upload_i64(col, tc.back().data());
     ctx->table_comms[tt] = dev.commit(col, true);
   }
+  for (const TableType& tt : ts) {  // the columns of every lookup table of the model: built once (Context::table_data), resident from here on
+    const Context::TableData& td = ctx->table_data(tt);
+    std::vector<DBuf>& dc = ctx->table_cols_dev[tt];
+    for (const std::vector<int64_t>& c : td.cols) { DBuf b = dev.alloc_persistent(c.size(), false); dev.upload_i64(b, c.data()); dc.push_back(b); }
+  }
   return ctx;
 }
 
@@ -1013,7 +1023,7 @@ inline WitnessHost witness_host(const Context& ctx, const Trace& tr) {
   for (auto& v : lates) { late_ids.push_back(cols.size()); cols.push_back({std::move(v)}); }  // uploaded with the rest, not committed
   if (range_used) { std::unordered_map<int64_t, u64>& crt = counts[TableType{2, 0}]; for (size_t v = 0; v < range_hist.size(); v++) if (range_hist[v]) crt[(int64_t)v] += range_hist[v]; }
   wt.lap("  witness: host columns");
-  // table columns (not committed) ride in the same upload
+  // the tables' multiplicities (their columns are resident: Context::table_cols_dev)
   std::vector<TabInfo>& tabs = wh.tabs;
   for (auto& kv : counts) {
     const TableType& tt = kv.first;
@@ -1024,7 +1034,8 @@ inline WitnessHost witness_host(const Context& ctx, const Trace& tr) {
       auto it = kv.second.find(merged[i]);
       ti.mult[i] = it == kv.second.end() ? 0 : td.inv_cnt[i] == 1 ? gl_from_u64(it->second) : gl_mul(gl_from_u64(it->second), td.inv_cnt[i]);
     }
-    for (auto& c : td.cols) { ti.col_ids.push_back(cols.size()); cols.push_back({c}); }
+    if (!ctx.table_cols_dev.count(tt))  // (a table the setup did not foresee: its columns ride in the upload as they did until round 4)
+      for (auto& c : td.cols) { ti.col_ids.push_back(cols.size()); cols.push_back({c}); }
     tabs.push_back(std::move(ti));
   }
   wt.lap("  witness: multiplicities");
@@ -1083,9 +1094,12 @@ inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr, WitnessHos
     ps.lookup_witness[p.node].push_back(std::move(w));
   }
   for (size_t i = 0; i < tabs.size(); i++) {
-    LogUpWitness w; w.is_table = true; w.table_type = tabs[i].tt; w.columns_per_instance = tabs[i].col_ids.size();
+    LogUpWitness w; w.is_table = true; w.table_type = tabs[i].tt;
     w.multiplicities = to_commit[n_witness_cols + i];
-    for (size_t cid : tabs[i].col_ids) w.columns.push_back(dcol[cid]);
+    auto res = ctx.table_cols_dev.find(tabs[i].tt);
+    if (res != ctx.table_cols_dev.end()) w.columns = res->second;  // resident since Context::generate
+    else for (size_t cid : tabs[i].col_ids) w.columns.push_back(dcol[cid]);
+    w.columns_per_instance = w.columns.size();
     w.commits.push_back(comms[n_witness_cols + i]);
     ps.table_witness.push_back(std::move(w));
   }
