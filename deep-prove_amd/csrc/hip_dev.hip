@@ -634,8 +634,9 @@ class HipDev : public Dev {
   }
   void dump_sc_debug() {
     if (!scdbg_) return;
-    unsigned long long h[5]; hipStreamSynchronize(s_); hipMemcpy(h, scdbg_, 40, hipMemcpyDeviceToHost); hipMemset(scdbg_, 0, 64);
-    fprintf(stderr, "[dp sc-debug] rounds %llu: cycles/round fold %.0f sums %.0f publish %.0f wait-for-challenge %.0f\n", h[4], (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4]);
+    unsigned long long h[8]; hipStreamSynchronize(s_); hipMemcpy(h, scdbg_, 64, hipMemcpyDeviceToHost); hipMemset(scdbg_, 0, 64);
+    fprintf(stderr, "[dp sc-debug] rounds %llu: cycles/round fold %.0f sums %.0f publish %.0f wait-for-challenge %.0f; of the fold: barrier after the challenge %.0f, the fold loop %.0f, barrier behind it %.0f\n", h[4], (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4],
+            (double)h[5] / h[4], (double)h[6] / h[4], (double)h[7] / h[4]);
   }
   void bind_thread() override { HIP_CHECK(hipSetDevice(device_)); }
   hipStream_t stream() const { return s_; }

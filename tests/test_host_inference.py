@@ -6,7 +6,11 @@ import pytest
 
 
 @pytest.mark.parametrize("name,args,kw", [("mlp", (2, 64), dict(config=31)), ("dense_4m", (), {}), ("cnn_tiny", (), {}), ("seq_mlp", (16, 64), dict(config=63, transpose_last=True, positional=True)),
-                                          ("seq_1m", (), {}), ("token_mlp", (32, 300, 128), dict(config=72, max_positions=50))])
+                                          ("seq_1m", (), {}), ("token_mlp", (32, 300, 128), dict(config=72, max_positions=50)),
+                                          # the lookup-table semantics the oracle and the product share as TEXT (softmax / inverse-square-root tables, the FFT convolution):
+                                          # models.py restates them in numpy from the reference (softmax.rs:153-345,455-566; layernorm.rs; convolution.rs) — a third reading
+                                          ("cnn_264k", (), {}), ("transformer_layer", (16, 64, 4, 16, 128), dict(config=65)), ("transformer_layer", (64, 256, 4, 64, 1024), dict(config=66)),
+                                          ("attention_block", (16, 64, 4, 16), dict(config=64))])
 def test_library_inference_equals_numpy(name, args, kw):
     import deep_prove_amd as dpa
     mb = getattr(dpa.models, name)(*args, **kw)
