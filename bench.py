@@ -509,6 +509,7 @@ def main():
         return None
     if "DP_FORCE_DEVICE" in os.environ:
         local_rank = int(os.environ["DP_FORCE_DEVICE"])
+        os.environ.setdefault("DP_HBM_FRACTION", f"{0.8 / max(1, local_world):.3f}")  # the ranks share ONE GPU's memory: each sizes its workers against its share
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
     # host threads per rank: this rank's share of the CPUs the job may use (cgroup quota), two left to the HIP runtime
@@ -644,6 +645,14 @@ def main():
             "seam_level": None if (world > 1 or args.no_seam_level) else seam_level(int(os.environ["DP_HOST_THREADS"]), batch_rate=value),
         }
         result["tail_roofline"] = tail_roofline()
+        if sc24 is not None and not args.batch:
+            # the size sumcheck/benches/devirgo_sumcheck.rs itself runs, on ONE GPU: the anchor of the sharded 2^26 run (`sumcheck26_sharded` of an N > 1 line; the model of
+            # DESIGN.md §7 says 2^24 on 8 GPUs is SLOWER than on one — 24 exchanges of ~35 us against 0.3 ms of streaming — and that 2^26 is where sharding starts to pay).
+            # No oracle golden at this size (the oracle needs ~80 s of one core): the proof is checked by the host verifier and by its final evaluations.
+            try:
+                result["sumcheck26"] = sumcheck24(dev, dpa, nv=26)
+            except Exception as e:  # noqa: BLE001
+                result["sumcheck26"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if world == 1 and args.workload == "dense_4m" and not args.batch and not args.no_batch64:
             # BASELINE config 4 at N = 1: ONE batch of 64 independent proofs per step, all in flight at once — the anchor the 8-GPU strong-scaling line
             # (`bench.py --gpus 8 --batch 64`) is read against; the golden input rides in the last step and its proof must have the oracle's sha256

@@ -1096,7 +1096,10 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
       if (!m->in_flight_cap) {
         size_t free_b = 0, total_b = 0; hip_mem_info(m->ctx->device_id, &free_b, &total_b);
         const size_t per = arena + (size_t(24) << 20);  // + the worker's staging and small buffers (the twiddle / coset tables are the context's, shared)
-        m->in_flight_cap = m->workers.size() + 1 + (size_t)((double)free_b * 0.9 / (double)per);
+        // DP_HBM_FRACTION (default 0.9): the share of the FREE HBM this process sizes its workers against — less when several processes share one GPU
+        // (bench.py with DP_FORCE_DEVICE: both ranks read the same free figure at the same moment)
+        const double frac = getenv("DP_HBM_FRACTION") ? std::min(0.95, std::max(0.01, atof(getenv("DP_HBM_FRACTION")))) : 0.9;
+        m->in_flight_cap = m->workers.size() + 1 + (size_t)((double)free_b * frac / (double)per);
         if (m->in_flight_cap < nw && getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) fprintf(stderr, "[dp timing] prove_batch: %zu proofs in flight asked, %zu fit in %.1f GB of free HBM (%.0f MB per worker)\n", nw, m->in_flight_cap, free_b / 1e9, per / 1048576.0);
       }
       nw = std::min(nw, m->in_flight_cap);
@@ -1104,7 +1107,17 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     // the context's tables may have been rebuilt for another parameter size since this model was loaded
     auto share_pcs = [&](Dev* w) { m->ctx->dev->pcs_init(m->zk->full_log); hip_dev_pcs_share(w, m->ctx->dev); };
     for (auto& w : m->workers) share_pcs(w.get());
-    while (m->workers.size() + 1 < nw) { std::unique_ptr<Dev> w(make_hip_worker(m->ctx->device_id, arena)); share_pcs(w.get()); m->workers.push_back(std::move(w)); }
+    while (m->workers.size() + 1 < nw) {
+      std::unique_ptr<Dev> w;
+      try { w.reset(make_hip_worker(m->ctx->device_id, arena)); }
+      catch (const DpError& e) {
+        // the device ran out of memory after all (another process took it meanwhile): go on with the workers there are — `concurrency` is a cap, not a demand
+        if (e.code != DP_ERR_OOM || m->workers.empty()) throw;
+        nw = m->workers.size() + 1; m->in_flight_cap = nw;
+        break;
+      }
+      share_pcs(w.get()); m->workers.push_back(std::move(w));
+    }
     m->last_in_flight = nw;
     // several proofs in flight: throughput mode on every context (see hip_dev_set_latency_mode)
     hip_dev_set_latency_mode(m->ctx->dev, nw == 1);

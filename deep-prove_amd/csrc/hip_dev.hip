@@ -36,7 +36,7 @@
 
 namespace dp {
 
-#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw DpError(DP_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+#define HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { if (e_ == hipErrorOutOfMemory) (void)hipGetLastError(); throw DpError(e_ == hipErrorOutOfMemory ? DP_ERR_OOM : DP_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } } while (0)
 
 #include "kernels.inc"
 

@@ -37,6 +37,17 @@ KERNEL32(k_mad_u32_u24, "v_mad_u32_u24 %0, %0, %1, %2")
 KERNEL32(k_mul_hi_u32_u24, "v_mul_hi_u32_u24 %0, %0, %1")
 KERNEL32(k_add3, "v_add3_u32 %0, %0, %1, %2")
 KERNEL32(k_cmp_u32, "v_cmp_lt_u32 vcc, %0, %1\n v_add_u32 %0, %0, %2")
+KERNEL32(k_mad_u32_u16, "v_mad_u32_u16 %0, %0, %1, %2")
+KERNEL32(k_dot4_u32_u8, "v_dot4_u32_u8 %0, %0, %1, %2")
+KERNEL32(k_dot2_u32_u16, "v_dot2_u32_u16 %0, %0, %1, %2")
+KERNEL32(k_pk_mul_lo_u16, "v_pk_mul_lo_u16 %0, %0, %1")
+KERNEL32(k_pk_mad_u16, "v_pk_mad_u16 %0, %0, %1, %2")
+KERNEL32(k_pk_add_u16, "v_pk_add_u16 %0, %0, %1")
+KERNEL32(k_lshl_add_u32, "v_lshl_add_u32 %0, %0, 1, %1")
+KERNEL32(k_alignbit, "v_alignbit_b32 %0, %0, %1, 22")
+KERNEL32(k_and_or, "v_and_or_b32 %0, %0, %1, %2")
+KERNEL32(k_add_u32_dpp, "v_add_u32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+KERNEL32(k_pair_add_mul24, "v_add_u32 %0, %0, %1\n v_mul_u32_u24 %0, %0, %2")
 KERNEL64(k_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
 KERNEL64(k_mad_u64_u32_s, "v_mad_u64_u32 %0, s[20:21], %1, %2, %0")
 KERNEL64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %3")
@@ -65,5 +76,10 @@ int main() {
 #define RUN(NAME, N) { double ms = run(NAME, d, blocks); double cyc = (ms * 1e-3) * clk * simds / (winstr * N); if (!base) base = cyc; printf("%-22s %8.3f ms  %6.2f cycles/wave-instr (x%.2f of v_add_u32)\n", #NAME, ms, cyc, cyc / base); }
   RUN(k_add_u32, 1) RUN(k_add_co_u32, 1) RUN(k_addc_co_u32, 1) RUN(k_cndmask, 1) RUN(k_mul_lo_u32, 1) RUN(k_mul_hi_u32, 1)
   RUN(k_mad_u64_u32, 1) RUN(k_mad_u64_u32_s, 1) RUN(k_lshl_add_u64, 1) RUN(k_cmp_u64, 2) RUN(k_lshlrev_b64, 1)
+  // round 5 (review item 7: is there a multiplier cheaper than v_mad_u64_u32 to build the S-box on?): the narrow multipliers, the packed 16-bit forms, the
+  // dot products, the shift / mask helpers of a limb representation, a DPP add, FP64 (exact for 26-bit limbs), and an add + 24-bit multiply pair
+  RUN(k_mul_u32_u24, 1) RUN(k_mad_u32_u24, 1) RUN(k_mul_hi_u32_u24, 1) RUN(k_mad_u32_u16, 1) RUN(k_dot4_u32_u8, 1) RUN(k_dot2_u32_u16, 1)
+  RUN(k_pk_mul_lo_u16, 1) RUN(k_pk_mad_u16, 1) RUN(k_pk_add_u16, 1) RUN(k_add3, 1) RUN(k_lshl_add_u32, 1) RUN(k_alignbit, 1) RUN(k_and_or, 1)
+  RUN(k_add_u32_dpp, 1) RUN(k_cmp_u32, 2) RUN(k_pair_add_mul24, 2) RUN(k_fma_f64, 1) RUN(k_mul_f64, 1) RUN(k_add_f64, 1)
   return 0;
 }
