@@ -21,7 +21,7 @@
 #include <thread>
 
 DP_FIBER_SWITCH_ASM
-namespace dp { struct Cohort; Cohort* hip_cohort_new(); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_pcs_share(Dev* worker, Dev* owner); void hip_dump_wg_times(); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
+namespace dp { struct Cohort; Cohort* hip_cohort_new(); Cohort* hip_cohort_new_sharing(Cohort* with); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_pcs_share(Dev* worker, Dev* owner); void hip_dump_wg_times(); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
 using namespace dp;
 
 // `mu`: PCS::commit is called from rayon workers in the reference (zkml/src/commit/context.rs:79-103 into_par_iter over
@@ -37,7 +37,7 @@ struct dp_batch_commit { DevBatchCommit c; };
 struct dp_model {
   dp_ctx* ctx; std::unique_ptr<Context> zk; std::vector<std::unique_ptr<Dev>> workers; std::vector<dp::Cohort*> cohorts;
   size_t last_in_flight = 0, in_flight_cap = 0; size_t prove_peak = 0;  // largest arena footprint a proof of this model has had so far (sizes the arenas of batch workers)
-  ~dp_model() { for (auto* c : cohorts) hip_cohort_free(c); }
+  ~dp_model() { for (size_t i = cohorts.size(); i-- > 0;) hip_cohort_free(cohorts[i]); }  // (last first: a cohort that shares a stream goes before the one that owns it)
 };
 
 // Every cohort stream needs a hardware queue of its own (24 are served without time slicing; the HIP runtime multiplexes streams
@@ -1129,9 +1129,12 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     // Default: as many cohorts as hardware queues serve without time slicing (22 of the 24), each as small as that allows — a merged
     // launch ends with its slowest member, so small cohorts stall less (batch of 8: 121 ms with cohorts of 1, 165 ms with one cohort
     // of 8; batch of 64: 262 ms with cohorts of 3, 302 ms with 12; 256 in flight: cohorts of 12; profiles/r02_batch_cohort_sweep.txt)
-    size_t csize = ce ? (size_t)std::max(0, atoi(ce)) : std::max<size_t>(1, (nw + 21) / 22);
+    // DP_STREAM_SHARE = k (default 1): k cohorts take turns on one stream (hardware queue) — cohorts of in flight / (22 k) members, and while one cohort's members
+    // digest a result on the host its queue-mate's launch runs
+    const size_t share = (size_t)std::max(1, getenv("DP_STREAM_SHARE") ? atoi(getenv("DP_STREAM_SHARE")) : 1);
+    size_t csize = ce ? (size_t)std::max(0, atoi(ce)) : std::max<size_t>(1, (nw + 22 * share - 1) / (22 * share));
     size_t nco = (csize >= 1 && nw > 1) ? (nw + csize - 1) / csize : 0;
-    while (m->cohorts.size() < nco) m->cohorts.push_back(hip_cohort_new());
+    while (m->cohorts.size() < nco) { const size_t c = m->cohorts.size(); m->cohorts.push_back(c % share ? hip_cohort_new_sharing(m->cohorts[c - c % share]) : hip_cohort_new()); }
     auto dev_of = [&](size_t wi) -> Dev& { return wi == 0 ? *m->ctx->dev : *m->workers[wi - 1]; };
     std::atomic<size_t> next(0);
     const bool timing = getenv("DP_TIMING") && atoi(getenv("DP_TIMING"));
@@ -1169,6 +1172,27 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
         try { prep[i] = make_prep(i); pst[i].store(2, std::memory_order_release); } catch (...) { pst[i].store(3, std::memory_order_release); }
       }
     };
+    // Serialising a finished proof (2.1 ms for the 5.9 MB of a Dense-4M proof) and copying it out used to run on the cohort's thread: the members of a cohort
+    // finish a proof together, so every pass of a cohort ended with members x 2.3 ms of host work during which its stream had nothing queued (48 ms of a 533 ms
+    // pass at 21 members). DP_SER_THREADS helper threads (default 2, 0 = inline) take it over; the batch returns when they have drained their queue.
+    // Measured (tools/r05/call20.sh, one box, alternating): WORSE — 483-512 against 679-694 proofs/s with two threads: the 14 proving threads spin on all the CPUs
+    // the process has, the helpers get their cycles late, and the last wave's 448 proofs queue behind two threads. Off by default; the faster serialiser
+    // (proof.h Writer: reserved once, bulk appends) is what shortens the stall instead.
+    const size_t nser = nw > 1 ? (size_t)std::max(0, getenv("DP_SER_THREADS") ? atoi(getenv("DP_SER_THREADS")) : 0) : 0;
+    std::mutex ser_mu; std::condition_variable ser_cv; std::deque<std::pair<size_t, Proof>> ser_q; bool ser_stop = false;
+    auto ser_thread = [&] {
+      for (;;) {
+        std::pair<size_t, Proof> job;
+        {
+          std::unique_lock<std::mutex> lk(ser_mu);
+          ser_cv.wait(lk, [&] { return ser_stop || !ser_q.empty(); });
+          if (ser_q.empty()) return;
+          job = std::move(ser_q.front()); ser_q.pop_front();
+        }
+        try { std::vector<u64> w = serialize_proof(job.second); proof_words[job.first] = copy_out(w); proof_nwords[job.first] = w.size(); }
+        catch (const std::exception& e) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_OOM; err = std::string("serialising a proof: ") + e.what(); } }
+      }
+    };
     auto t0 = std::chrono::steady_clock::now();
     auto work = [&](size_t wi) {
       Dev& dev = dev_of(wi);
@@ -1190,9 +1214,11 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
           Transcript t = default_transcript();
           Proof p = prove(*m->zk, dev, tr, t, &mine->wh);
           auto h2 = std::chrono::steady_clock::now();
-          std::vector<u64> w = serialize_proof(p);
+          if (nser) {  // several proofs in flight: the finished proof goes to the serialiser threads, this fiber to its next proof (see `ser_thread`)
+            { std::lock_guard<std::mutex> g(ser_mu); ser_q.emplace_back(i, std::move(p)); }
+            ser_cv.notify_one();
+          } else { static thread_local std::vector<u64> ser_buf; serialize_proof_to(p, ser_buf); proof_words[i] = copy_out(ser_buf); proof_nwords[i] = ser_buf.size(); }
           auto h3 = std::chrono::steady_clock::now();
-          proof_words[i] = copy_out(w); proof_nwords[i] = w.size();
           if (timing && wi == 0) {
             auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
             fprintf(stderr, "[dp timing] host phases of one proof: inference + witness columns (or the wait for the helper that made them) %.2f ms, prove %.2f ms (wall, shared thread), serialise %.2f ms, copy out %.2f ms\n", ms(h0, h1), ms(h1, h2), ms(h2, h3), ms(h3, std::chrono::steady_clock::now()));
@@ -1222,13 +1248,17 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
       fiber_run_all(sched);
       for (auto& f : sched.fibers) if (f->failed) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_ARG; err = "an exception escaped a proof worker's fiber"; } }
     };
-    std::vector<std::thread> th, pth;
+    std::vector<std::thread> th, pth, sth;
+    for (size_t k = 0; k < nser; k++) sth.emplace_back(ser_thread);
     for (size_t k = 0; k < nprep && nproofs > nw; k++) pth.emplace_back(prep_thread);
     for (size_t ti = 1; ti < nth; ti++) th.emplace_back(run_thread, ti);
     run_thread(0);
     for (auto& t : th) t.join();
     pstop.store(true);
     for (auto& t : pth) t.join();
+    { std::lock_guard<std::mutex> g(ser_mu); ser_stop = true; }
+    ser_cv.notify_all();
+    for (auto& t : sth) t.join();  // (they leave when the queue is empty: every proof is serialised and copied out)
     for (size_t c = 0; c < nco; c++) { try { hip_cohort_drain(m->cohorts[c]); } catch (const std::exception& e) { if (!err_code) { err_code = DP_ERR_HIP; err = e.what(); } } }
     if (nco && getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) {
       size_t f = 0, p = 0; for (size_t c = 0; c < nco; c++) { size_t a, b; hip_cohort_stats(m->cohorts[c], &a, &b); f += a; p += b; }

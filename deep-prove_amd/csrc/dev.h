@@ -322,6 +322,16 @@ class Dev {
   }
   // K14: for each descriptor: the leaf pair (as stored) followed by the Merkle path (height-1 digests)
   virtual void query_gather(const QueryDesc* d, size_t nd, std::vector<std::vector<u64>>& out) = 0;
+  // the same words in ONE buffer: descriptor i at flat[off[i] .. off[i + 1]). A Dense-4M batch opening gathers 10 000 (pair, path) records, 5.8 MB: the
+  // vector-per-record form cost the proving thread ~20 000 heap allocations and two extra copies per proof (the members of a cohort run it one after the other)
+  virtual void query_gather_flat(const QueryDesc* d, size_t nd, std::vector<u64>& flat, std::vector<size_t>& off) {
+    std::vector<std::vector<u64>> out;
+    query_gather(d, nd, out);
+    off.assign(nd + 1, 0);
+    for (size_t i = 0; i < nd; i++) off[i + 1] = off[i] + out[i].size();
+    flat.resize(off[nd]);
+    for (size_t i = 0; i < nd; i++) std::copy(out[i].begin(), out[i].end(), flat.begin() + off[i]);
+  }
 };
 
 }  // namespace dp

@@ -133,12 +133,17 @@ struct Cohort {
     t_fire_ = t; have_fire_ = true;
   }
 
-  explicit Cohort(size_t ring_bytes = size_t(32) << 20) : ring_cap(ring_bytes) {
-    HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  // `share`: run on the stream of another cohort (which must outlive this one: dp_model_prove_batch keeps the cohorts of a model together). Two cohorts on one
+  // stream take turns on ONE hardware queue: while the members of one digest a result on the host — 21 members x ~65 us on one thread, the queue idle — the
+  // other's launch runs (DP_STREAM_SHARE)
+  bool owns_stream = true;
+  explicit Cohort(size_t ring_bytes = size_t(32) << 20, const Cohort* share = nullptr) : ring_cap(ring_bytes) {
+    if (share) { s = share->s; owns_stream = false; }
+    else HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     HIP_CHECK(hipHostMalloc((void**)&ring, ring_cap, host_ro_flags()));
     HIP_CHECK(hipHostGetDevicePointer((void**)&ring_dev, ring, 0));
   }
-  ~Cohort() { if (s) { hipStreamSynchronize(s); hipStreamDestroy(s); } if (ring) hipHostFree(ring); }
+  ~Cohort() { if (s) { hipStreamSynchronize(s); if (owns_stream) hipStreamDestroy(s); } if (ring) hipHostFree(ring); }
   Cohort(const Cohort&) = delete;
   Cohort& operator=(const Cohort&) = delete;
 
@@ -1880,8 +1885,9 @@ class HipDev : public Dev {
     nb_ = 16.0 * o.n + 8.0 * o.n; DPL(k_fri_fold, dim3(grid_for(out.n)), dim3(TPB), (const Ext*)o.p, (Ext*)out.p, out.n, level, (const u64*)tw_, L_, gam, ninv, ch);
     return out;
   }
-  void query_gather(const QueryDesc* d, size_t nd, std::vector<std::vector<u64>>& out) override {
-    out.resize(nd);
+  void query_gather_flat(const QueryDesc* d, size_t nd, std::vector<u64>& flat, std::vector<size_t>& off) override {
+    off.assign(nd + 1, 0);
+    flat.clear();
     if (!nd) return;
     const GatherDesc* dd = nullptr;
     GatherDesc* hd = desc_alloc<GatherDesc>(nd, &dd);
@@ -1891,18 +1897,20 @@ class HipDev : public Dev {
       hd[i].leaves = t.leaves.p; hd[i].nodes = (const u64*)t.nodes.p; hd[i].nleaves = t.nleaves; hd[i].p0 = d[i].p0;
       hd[i].ext = t.leaves.ext; hd[i].height = (int)t.height(); hd[i].out_off = total;
       total += (t.leaves.ext ? 4 : 2) + 4 * (size_t)(t.height() - 1);
+      off[i + 1] = total;
     }
     size_t mk = mark();
     u64* dout = (u64*)arena_alloc(total * 8);
     DPL(k_query_gather, dim3((unsigned)((nd + 3) / 4)), dim3(TPB), dd, nd, dout);
-    std::vector<u64> flat(total);
-    stream_wait();
-    d2h(flat.data(), dout, total * 8);
-    for (size_t i = 0; i < nd; i++) {
-      size_t len = (hd[i].ext ? 4 : 2) + 4 * (size_t)(hd[i].height - 1);
-      out[i].assign(flat.begin() + hd[i].out_off, flat.begin() + hd[i].out_off + len);
-    }
+    flat.resize(total);
+    d2h(flat.data(), dout, total * 8);  // (the copy follows the gather on the stream: no wait of its own in between, as there was until round 5)
     release(mk);
+  }
+  void query_gather(const QueryDesc* d, size_t nd, std::vector<std::vector<u64>>& out) override {
+    std::vector<u64> flat; std::vector<size_t> off;
+    query_gather_flat(d, nd, flat, off);
+    out.resize(nd);
+    for (size_t i = 0; i < nd; i++) out[i].assign(flat.begin() + off[i], flat.begin() + off[i + 1]);
   }
 };
 
@@ -1910,6 +1918,7 @@ Dev* make_hip_dev(int device) { return new HipDev(device); }
 Dev* make_hip_worker(int device, size_t arena_bytes) { return new HipDev(device, arena_bytes, size_t(16) << 20); }
 // cohorts (lock-step batches of proofs, see struct Cohort): created and driven by dp_model_prove_batch
 Cohort* hip_cohort_new() { const char* e = getenv("DP_COHORT_RING_BYTES"); return e ? new Cohort(strtoull(e, nullptr, 10)) : new Cohort(); }
+Cohort* hip_cohort_new_sharing(Cohort* with) { const char* e = getenv("DP_COHORT_RING_BYTES"); return new Cohort(e ? strtoull(e, nullptr, 10) : size_t(32) << 20, with); }
 void hip_cohort_free(Cohort* c) { delete c; }
 void hip_cohort_drain(Cohort* c) { c->drain(); }
 void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs) {

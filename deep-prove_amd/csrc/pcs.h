@@ -32,15 +32,16 @@ inline BasefoldProof pcs_open_trivial(Dev& dev, const DevCommit& c) {
 struct OpenClaim { const DevCommit* comm; std::vector<Ext> point; Ext eval; };
 
 // words of Dev::query_gather for one (tree, pair) -> the opened pair with its Merkle path (query_phase.rs:669-700)
-inline CodewordQuery query_from_words(const QueryDesc& d, const std::vector<u64>& w) {
+inline CodewordQuery query_from_words(const QueryDesc& d, const u64* w, size_t n) {
   CodewordQuery q; q.is_ext = d.tree->leaves.ext; q.index = d.p0;
   size_t o = 0;
   if (q.is_ext) { q.left = ex(w[0], w[1]); q.right = ex(w[2], w[3]); o = 4; } else { q.left = ex(w[0], 0); q.right = ex(w[1], 0); o = 2; }
-  size_t npath = (w.size() - o) / 4;
-  q.path.reserve(npath);
-  for (size_t j = 0; j < npath; j++) { Digest dg; for (int k = 0; k < 4; k++) dg.v[k] = w[o + 4 * j + k]; q.path.push_back(dg); }
+  const size_t npath = (n - o) / 4;
+  q.path.resize(npath);
+  if (npath) memcpy((void*)q.path.data(), w + o, npath * sizeof(Digest));  // (a digest is its four words)
   return q;
 }
+inline CodewordQuery query_from_words(const QueryDesc& d, const std::vector<u64>& flat, const std::vector<size_t>& off, size_t i) { return query_from_words(d, flat.data() + off[i], off[i + 1] - off[i]); }
 
 // Rounds [first, num_rounds) of batch_commit_phase (commit_phase.rs:187-359): per round absorb the pending sumcheck message,
 // draw the folding challenge, merge the committed codewords of the running oracle's size, FRI-fold, fold the sumcheck pairs;
@@ -243,14 +244,14 @@ inline BasefoldProof pcs_batch_open_evals(Dev& dev, unsigned full_log, const std
     for (auto& tr : trees) { size_t p1 = index | 1; descs.push_back({&tr, p1 - 1}); index >>= 1; }
     for (const DevCommit* c : comms) { size_t xi = x >> (cw_log - c->tree.height()); size_t p1 = xi | 1; descs.push_back({&c->tree, p1 - 1}); }
   }
-  std::vector<std::vector<u64>> got;
-  dev.query_gather(descs.data(), descs.size(), got);
+  std::vector<u64> got; std::vector<size_t> goff;
+  dev.query_gather_flat(descs.data(), descs.size(), got, goff);
   size_t di = 0;
   for (size_t x : qidx) {
     BatchedQuery bq; bq.index = x;
     bq.oracle_query.reserve(trees.size()); bq.commitments_query.reserve(nc);
-    for (size_t k = 0; k < trees.size(); k++, di++) bq.oracle_query.push_back(query_from_words(descs[di], got[di]));
-    for (size_t k = 0; k < nc; k++, di++) bq.commitments_query.push_back(query_from_words(descs[di], got[di]));
+    for (size_t k = 0; k < trees.size(); k++, di++) bq.oracle_query.push_back(query_from_words(descs[di], got, goff, di));
+    for (size_t k = 0; k < nc; k++, di++) bq.commitments_query.push_back(query_from_words(descs[di], got, goff, di));
     proof.queries.push_back(std::move(bq));
   }
   lap("query phase");
@@ -300,13 +301,13 @@ inline BasefoldProof pcs_open(Dev& dev, unsigned full_log, const DevCommit& c, c
     for (auto& tr : trees) { descs.push_back({&tr, (index | 1) - 1}); index >>= 1; }
     descs.push_back({&c.tree, (x | 1) - 1});
   }
-  std::vector<std::vector<u64>> got;
-  dev.query_gather(descs.data(), descs.size(), got);
+  std::vector<u64> got; std::vector<size_t> goff;
+  dev.query_gather_flat(descs.data(), descs.size(), got, goff);
   size_t di = 0;
   for (size_t x : qidx) {
     BatchedQuery bq; bq.index = x;
-    for (size_t k = 0; k < trees.size(); k++, di++) bq.oracle_query.push_back(query_from_words(descs[di], got[di]));
-    bq.commitments_query.push_back(query_from_words(descs[di], got[di])); di++;
+    for (size_t k = 0; k < trees.size(); k++, di++) bq.oracle_query.push_back(query_from_words(descs[di], got, goff, di));
+    bq.commitments_query.push_back(query_from_words(descs[di], got, goff, di)); di++;
     proof.queries.push_back(std::move(bq));
   }
   dev.release(mk);
@@ -381,14 +382,14 @@ inline BasefoldProof pcs_simple_batch_open(Dev& dev, const DevBatchCommit& c, co
     for (size_t q = 0; q < k; q++) descs.push_back({&c.polys[q].tree, p0});
     if (k > 1) descs.push_back({&c.tree, 2 * p0});  // row hashes: two entries per row; the first digest of that path is hash(row p0 + 1)
   }
-  std::vector<std::vector<u64>> got;
-  dev.query_gather(descs.data(), descs.size(), got);
+  std::vector<u64> got; std::vector<size_t> goff;
+  dev.query_gather_flat(descs.data(), descs.size(), got, goff);
   size_t di = 0;
   for (size_t x : qidx) {
     BatchedQuery bq; bq.index = x;
-    for (size_t j = 0; j < trees.size(); j++, di++) bq.oracle_query.push_back(query_from_words(descs[di], got[di]));
-    for (size_t q = 0; q < k; q++, di++) { CodewordQuery cq = query_from_words(descs[di], got[di]); if (k > 1) cq.path.clear(); bq.commitments_query.push_back(std::move(cq)); }
-    if (k > 1) { CodewordQuery rows = query_from_words(descs[di], got[di]); di++; bq.commitments_query[0].path.assign(rows.path.begin() + 1, rows.path.end()); }
+    for (size_t j = 0; j < trees.size(); j++, di++) bq.oracle_query.push_back(query_from_words(descs[di], got, goff, di));
+    for (size_t q = 0; q < k; q++, di++) { CodewordQuery cq = query_from_words(descs[di], got, goff, di); if (k > 1) cq.path.clear(); bq.commitments_query.push_back(std::move(cq)); }
+    if (k > 1) { CodewordQuery rows = query_from_words(descs[di], got, goff, di); di++; bq.commitments_query[0].path.assign(rows.path.begin() + 1, rows.path.end()); }
     proof.queries.push_back(std::move(bq));
   }
   dev.release(mk);
