@@ -1573,6 +1573,11 @@ class HipDev : public Dev {
   // VALU work of one node per lane and a grid 8x as large: with many proofs in flight those grids fill the chip and
   // every other stream queues behind them), wider layers hash one node per lane.
   static constexpr size_t lp_max_ = size_t(1) << 12;
+  // ... in THROUGHPUT mode the launch of a layer is merged over the ~20 members of a cohort: 20 x 1024 parents fill the chip with one node per lane, and
+  // the 8-lane form's 2.2x VALU work is paid for nothing (k_merkle_layer_lp was 35 % of the Merkle kernel time of the cohort regime for ~10 % of the
+  // nodes: profiles/r05_bench448_kernel_stats_lds_msgs.csv). DP_LP_MAX_TP (default 512): the widest layer that still takes the 8-lane kernel there.
+  size_t lp_max_tp_ = [] { const char* e = getenv("DP_LP_MAX_TP"); return e ? (size_t)strtoull(e, nullptr, 10) : size_t(512); }();
+  size_t lp_max_now() const { return throughput_mode_ ? lp_max_tp_ : lp_max_; }
   // `nodes` must hold 4*(n-1) words; synchronises (root is copied to the host)
   DevTree build_tree_into(const DBuf& leaves, const DBuf& nodes) {
     DevTree t; t.leaves = leaves; t.nleaves = leaves.n; t.nodes = nodes;
@@ -1583,7 +1588,7 @@ class HipDev : public Dev {
     size_t off = 0, cnt = n / 2;
     while (cnt > TAIL_MAX) {
       size_t next = cnt / 2;
-      if (next <= lp_max_) { nb_ = 96.0 * next; DPL(k_merkle_layer_lp, dim3((unsigned)std::min<size_t>((next * 8 + 255) / 256, 8192)), dim3(256), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
+      if (next <= lp_max_now()) { nb_ = 96.0 * next; DPL(k_merkle_layer_lp, dim3((unsigned)std::min<size_t>((next * 8 + 255) / 256, 8192)), dim3(256), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
       else { nb_ = 96.0 * next; DPL(k_merkle_layer, dim3(grid_for(next, 4096)), dim3(TPB), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
       off += cnt; cnt /= 2;
     }
