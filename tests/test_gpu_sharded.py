@@ -188,6 +188,27 @@ def test_config5_prove_parallel_at_size_equals_oracle_golden(dev, nv):
     _check_against_golden(dpa, gold, nv, proof, finals, t)
 
 
+def test_fused_round_ticket_under_reuse_of_its_partial_buffer(dev):
+    """k_sc_fused's in-kernel "last workgroup" reduction (kernels.inc: block sums written through, a relaxed device-scope ticket, no fence — the default since round 4;
+    DP_FUSED_TICKET=0 is the fallback with a separate k_reduce_publish launch) relies on write-through / L2-bypass behaviour of sc0 sc1 accesses that the HIP memory model
+    does not spell out. Stress: the same 2^22 sumcheck 40 times back to back — every repetition reuses the SAME partial-sum buffer and ticket, the last workgroup lands
+    on a different XCD from launch to launch, stale lines of the previous repetition sit in eight L2s — and every proof must equal the oracle's golden (advisor, round 4)."""
+    import hashlib
+    import deep_prove_amd as dpa
+    nv = 22
+    gold, k = _golden_sc(nv)
+    tabs = [dpa.Mle.from_base(dev, dpa.models.splitmix64(0xD33B0000 ^ (5 << 32) ^ j, 1 << nv) % np.uint64(P)) for j in range(k)]
+    try:
+        vp = dpa.VirtualPolynomial(nv)
+        vp.add_mle_list(tabs, (1, 0))
+        for rep in range(40):
+            proof, finals = dpa.prove_parallel(dev, vp, dpa.Transcript(b"test"))
+            assert hashlib.sha256(proof.tobytes()).hexdigest() == gold["sha256"], f"repetition {rep}: the proof differs from the oracle's"
+    finally:
+        for m in tabs:
+            m.free()
+
+
 @pytest.mark.parametrize("nv,world", [(22, 4), (24, 8)])
 def test_config5_sharded_in_library_at_size_equals_oracle_golden(nv, world):
     """the same sumcheck through dp_sumcheck_prove_sharded_local: `world` device contexts (one thread each) own contiguous slices,

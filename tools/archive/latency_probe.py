@@ -1,6 +1,6 @@
 """single-proof latency, several proofs in a row (latency mode), with and without keeping the proofs alive"""
 import sys, os, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # (the repository root, wherever the command is started from)
 import deep_prove_amd as dpa
 dev = dpa.Device(0)
 mb = dpa.models.dense_4m()

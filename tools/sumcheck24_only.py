@@ -1,6 +1,6 @@
 """standalone 2^24 sumcheck (BASELINE config 5 on one GPU), a few repetitions — the command the rocprofv3 PMC passes wrap"""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (the repository root, wherever the command is started from)
 import numpy as np
 import deep_prove_amd as dpa
 nv, k = 24, 3
