@@ -640,8 +640,8 @@ class HipDev : public Dev {
   void dump_sc_debug() {
     if (!scdbg_) return;
     unsigned long long h[8]; hipStreamSynchronize(s_); hipMemcpy(h, scdbg_, 64, hipMemcpyDeviceToHost); hipMemset(scdbg_, 0, 64);
-    fprintf(stderr, "[dp sc-debug] rounds %llu: cycles/round fold %.0f sums %.0f publish %.0f wait-for-challenge %.0f; of the fold: barrier after the challenge %.0f, the fold loop %.0f, barrier behind it %.0f\n", h[4], (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4],
-            (double)h[5] / h[4], (double)h[6] / h[4], (double)h[7] / h[4]);
+    fprintf(stderr, "[dp sc-debug] rounds %llu: cycles/round fold %.0f sums %.0f publish %.0f wait-for-challenge %.0f; speculated rounds %llu, cycles per speculation (wave 1) %.0f; wave 0 at the barrier behind its wait: %.0f cycles per round\n", h[4], (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4],
+            h[6], h[6] ? (double)h[5] / h[6] : 0.0, (double)h[7] / h[4]);
   }
   void bind_thread() override { HIP_CHECK(hipSetDevice(device_)); }
   hipStream_t stream() const { return s_; }
@@ -1322,7 +1322,7 @@ class HipDev : public Dev {
       sess_.active = true; sess_.multi = true; sess_.G = G; sess_.rounds_a = rounds_a; sess_.folds = 0; sess_.shift = r ? 1 : 0; sess_.slot_words = 2 * nraw;
       sess_.ntabs = nt; sess_.n = n_after; sess_.n0 = n_in; sess_.seq = seq_;
       seq_ += (unsigned)rounds_a;  // one publication per round of the phase
-      nb_ = bytes; if (hi) { DPL_B((k_sc_persist<true>), 1024, KF_CLAIM, dim3(G), dim3(1024), 0, a, (Ext*)hres_dev_, hmflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); } else { DPL_B((k_sc_persist<false>), 1024, KF_CLAIM, dim3(G), dim3(1024), 0, a, (Ext*)hres_dev_, hmflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }  // (latency mode only: G whole-CU workgroups)
+      nb_ = bytes; if (hi) { DPL_B((k_sc_persist<true>), LAT_MAXT, KF_CLAIM, dim3(G), dim3(LAT_MAXT), 0, a, (Ext*)hres_dev_, hmflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); } else { DPL_B((k_sc_persist<false>), LAT_MAXT, KF_CLAIM, dim3(G), dim3(LAT_MAXT), 0, a, (Ext*)hres_dev_, hmflag_dev_, (const unsigned long long*)hmail_dev_, sess_.seq, (const ScFsArgs*)nullptr); }  // (latency mode only: G whole-CU workgroups)
       wait_flags_multi(++sess_.seq, 2 * nraw, G, sess_.slot_words);
       if (r) for (int i = 0; i < nt; i++) { tabs[i].p = sess_.a[i]; tabs[i].n = n_after; tabs[i].ext = true; }
       read_shares(G, sess_.slot_words);
