@@ -21,6 +21,7 @@
 #include "sponge_host.h"
 #include <hip/hip_runtime.h>
 #include <sched.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -298,6 +299,8 @@ class HipDev : public Dev {
   unsigned long long* scdbg_ = nullptr;  // DP_TIMING=2: device cycle counters of the persistent sumcheck kernel
   unsigned long long* hmail_ = nullptr;      // host view of the challenge mailbox [seq, c0, c1]
   unsigned long long* hmail_dev_ = nullptr;  // device view
+  unsigned long long* vmail_ = nullptr;      // the mailbox in DEVICE memory the CPU writes through the PCIe BAR (mailbox_dev below)
+  bool vmail_tried_ = false;
   struct ScSession { bool active = false; int ntabs = 0; size_t n = 0; unsigned long long seq = 0; std::vector<Ext*> a, b; bool nextA = true;
                      bool multi = false; int G = 0, rounds_a = 0, folds = 0, shift = 0; size_t slot_words = 0, n0 = 0; } sess_;
   static constexpr int MULTI_MAX_WG = 32;
@@ -579,6 +582,7 @@ class HipDev : public Dev {
     if (sp_slot_) { sponge_disarm_(); sponge_slot_free(sp_slot_); sp_slot_ = nullptr; }
     if (hsp_) hipHostFree(hsp_);
     if (hres_) hipHostFree(hres_);
+    if (vmail_) hipFree(vmail_);
     if (hstage_) hipHostFree(hstage_);
     if (hdesc_) hipHostFree(hdesc_);
     if (s_) hipStreamDestroy(s_);
@@ -948,6 +952,45 @@ class HipDev : public Dev {
   // all proofs in flight onto the same first CUs (4 kernels of 256 threads fit on one), where they time-share the SIMDs.
   static constexpr size_t EXCL_LDS = 84 * 1024;
   static constexpr size_t SC_PERSIST_MAX = 16384;  // sumchecks whose tables are at most this long run in the persistent kernel
+  // The challenge mailbox of the host-driven persistent sumchecks. In host memory every poll of the waiting kernel is a PCIe READ
+  // (a round trip of microseconds, and the challenge is seen half a poll period later on average). With the whole of device
+  // memory visible to the CPU (large BAR) the mailbox lives in fine-grained DEVICE memory instead: the CPU's store is a posted
+  // PCIe write, the kernel polls its own HBM. Set up at the first host-driven session of a context (throughput-mode workers
+  // never get here); checked, not assumed: the page must be CPU-writable (probed through a pipe, no fault) and a kernel must read
+  // back two successive CPU writes. DP_MAILBOX_VRAM=0 keeps the mailbox in host memory.
+  static bool cpu_can_write_(void* p) {
+    int fd[2];
+    if (pipe(fd) != 0) return false;
+    unsigned long long v = 0; bool ok = false;
+    if (write(fd[1], &v, 8) == 8) ok = read(fd[0], p, 8) == 8;  // copy_to_user: EFAULT instead of a fault when the page is not mapped writable
+    close(fd[0]); close(fd[1]);
+    return ok;
+  }
+  const unsigned long long* mailbox_dev() {
+    if (vmail_tried_ || !zerocopy_ || throughput_mode_ || sess_.active) return hmail_dev_;  // (a worker of a cohort keeps the sponge on the device: no host-driven sessions worth the page)
+    vmail_tried_ = true;
+    static std::atomic<int> works{0};  // process-wide: -1 = a context found it not to work
+    if (works.load() < 0 || (getenv("DP_MAILBOX_VRAM") && !atoi(getenv("DP_MAILBOX_VRAM")))) return hmail_dev_;
+    void* p = nullptr;
+    if (hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) != hipSuccess || !p) { (void)hipGetLastError(); works = -1; return hmail_dev_; }
+    bool ok = cpu_can_write_((char*)p + 2048);
+    for (unsigned long long probe = 0x5EED0001ull; ok && probe <= 0x5EED0002ull; probe++) {  // the second value: no cached copy of the first is served
+      ((volatile unsigned long long*)p)[16] = probe;
+      std::atomic_thread_fence(std::memory_order_seq_cst);
+      unsigned long long seq = ++seq_;
+      nb_ = 0; DPL(k_publish, dim3(1), dim3(64), (const u64*)p + 16, hres_dev_, (size_t)1, hflag_dev_, seq);
+      wait_flag(seq, 1);
+      ok = hres_[0] == probe;
+    }
+    if (!ok) { (void)hipGetLastError(); hipFree(p); works = -1; if (g_timing_level) fprintf(stderr, "[dp] challenge mailbox stays in host memory (device memory is not CPU-writable here)\n"); return hmail_dev_; }
+    works = 1;
+    vmail_ = (unsigned long long*)p;
+    vmail_[0] = vmail_[1] = vmail_[2] = vmail_[3] = 0;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    hmail_ = hmail_dev_ = vmail_;
+    if (g_timing_level) fprintf(stderr, "[dp] challenge mailbox in device memory (CPU writes through the BAR)\n");
+    return hmail_dev_;
+  }
   void post_challenge(Ext r) {
     hmail_[1] = r.c0; hmail_[2] = r.c1; hmail_[3] = pub_mix(sess_.seq) + r.c0 + 2 * r.c1;  // tag: the device re-polls a torn payload
     std::atomic_thread_fence(std::memory_order_release);
@@ -1304,6 +1347,7 @@ class HipDev : public Dev {
       // 75 us per round (32 workgroups x PCIe mailbox) against 23 us for one workgroup in LDS, so a sumcheck only ENTERS this phase at its first round (round 2 measured the mid-sumcheck entry and rejected it):
       // the hand-over from the streaming rounds goes to the device-side transcript instead (sc_tail).
       flush_pending_eq();
+      mailbox_dev();
       int G = (int)std::min<size_t>(MULTI_MAX_WG, n_after / 512);
       int rounds_a = (int)(dp_ceil_log2(n_after) - dp_ceil_log2(MULTI_TARGET_N));
       ScPersistArgs a;
@@ -1336,6 +1380,7 @@ class HipDev : public Dev {
     const bool take_persistent = !sess_.active && persist_here;
     if (pend_eq_.p && !(take_persistent && !r)) flush_pending_eq();
     if (persist_here) {
+      if (take_persistent) mailbox_dev();
       ScPersistArgs a;
       a.eq_tab = -1; a.eq_k = 0;
       if (pend_eq_.p) {

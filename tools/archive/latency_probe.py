@@ -3,7 +3,7 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # (the repository root, wherever the command is started from)
 import deep_prove_amd as dpa
 dev = dpa.Device(0)
-mb = dpa.models.dense_4m()
+mb = getattr(dpa.models, sys.argv[1] if len(sys.argv) > 1 else 'dense_4m')()
 ctx = dpa.Context.generate(dev, mb.blob())
 pr = dpa.Prover(ctx)
 keep = []
