@@ -99,6 +99,7 @@ inline ModelSpec parse_model(const int64_t* b, size_t n) {
       DP_REQUIRE(tb >= 0 && tb <= 0xFFFFFFFFll && sb >= 0 && sb <= 0xFFFFFFFFll && ts >= 1 && ts <= 22 && zc >= 0 && zc <= 3 && zv >= 0 && zv <= 22, DP_ERR_ARG, "model blob: mha softmax parameters");
       l.sm_temp_bits = (uint32_t)tb; l.sm_in_scale_bits = (uint32_t)sb; l.sm_table_size = (unsigned)ts; l.sm_zero_chunks = (unsigned)zc; l.sm_zero_vars = (unsigned)zv;
     }
+    else if (l.kind == L_GELU) { l.fixed_point_multiplier = rd(); DP_REQUIRE(l.fixed_point_multiplier >= 1 && l.fixed_point_multiplier <= (int64_t(1) << 12), DP_ERR_ARG, "model blob: gelu multiplier"); }  // [17, multiplier = round(2^12 * input scale)]
     else DP_REQUIRE(l.kind == L_RELU || l.kind == L_FLATTEN, DP_ERR_ARG, "model blob: unknown layer kind");
     m.layers.push_back(std::move(l));
   }

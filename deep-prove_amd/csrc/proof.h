@@ -30,7 +30,7 @@ struct BasefoldProof {
   bool is_trivial() const { return sumcheck_messages.empty() && queries.empty() && sumcheck_proof.empty(); }
 };
 enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8, L_POSITIONAL = 9,
-                 L_MATMUL2 = 10, L_ADD2 = 11, L_CONCAT_MATMUL = 12, L_QKV = 13, L_LAYERNORM = 14, L_SOFTMAX = 15, L_MHA = 16 };  // the two-input forms of MatMul / Add, ConcatMatMul, QKV (nodes of a model GRAPH)
+                 L_MATMUL2 = 10, L_ADD2 = 11, L_CONCAT_MATMUL = 12, L_QKV = 13, L_LAYERNORM = 14, L_SOFTMAX = 15, L_MHA = 16, L_GELU = 17 };  // the two-input forms of MatMul / Add, ConcatMatMul, QKV (nodes of a model GRAPH)
 struct DenseProof { IOPProof sumcheck; Ext bias_eval; std::vector<Ext> individual_claims; };
 struct AddProof { Ext left_eval = ex_zero(), right_eval = ex_zero(); };  // layers/add.rs:59-63
 struct PositionalProof { std::vector<Ext> sub_matrix_evals; AddProof add_proof; };  // SinglePositionalProof (transformer/positional.rs:45-55), one input
@@ -146,7 +146,7 @@ inline void serialize_proof_to(const Proof& p, std::vector<u64>& out) {
     else if (lp.kind == L_REQUANT) {
       w.iop(lp.req.io_accumulation); w.ve(lp.req.accumulation_evals); w.logup(lp.req.clamping_lookup); w.logup(lp.req.shifted_lookup);
       w.u(lp.req.commitments.size()); for (auto& c : lp.req.commitments) w.comm(c);
-    } else if (lp.kind == L_RELU) {
+    } else if (lp.kind == L_RELU || lp.kind == L_GELU) {
       w.iop(lp.act.io_accumulation.sumcheck); w.ve(lp.act.io_accumulation.evals); w.logup(lp.act.lookup);
       w.u(lp.act.commits.size()); for (auto& c : lp.act.commits) w.comm(c);
     } else if (lp.kind == L_CONV) {
@@ -245,7 +245,7 @@ inline Proof deserialize_proof(const u64* words, size_t n) {
     else if (lp.kind == L_REQUANT) {
       lp.req.io_accumulation = r.iop(); lp.req.accumulation_evals = r.ve(); lp.req.clamping_lookup = r.logup(); lp.req.shifted_lookup = r.logup();
       size_t k = r.len(); lp.req.commitments.resize(k); for (auto& c : lp.req.commitments) c = r.comm();
-    } else if (lp.kind == L_RELU) {
+    } else if (lp.kind == L_RELU || lp.kind == L_GELU) {
       lp.act.io_accumulation.sumcheck = r.iop(); lp.act.io_accumulation.evals = r.ve(); lp.act.lookup = r.logup();
       size_t k = r.len(); lp.act.commits.resize(k); for (auto& c : lp.act.commits) c = r.comm();
     } else if (lp.kind == L_CONV) {

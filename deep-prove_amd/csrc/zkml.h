@@ -179,16 +179,16 @@ inline CmShape cm_shape(const LayerSpec& l) {
 }
 
 struct TableType {
-  // 0 Relu, 2 Range, 3 Clamping(size), 4 Softmax{float_bits = aux, table_size = size, bkm = aux2}, 5 ErrorTable(4096, allowable_error = aux2),
+  // 0 Relu, 1 GELU{multiplier = aux2, table_size = size: GELUQuantData's min / max are -+2^(size - 1)}, 2 Range, 3 Clamping(size), 4 Softmax{float_bits = aux, table_size = size, bkm = aux2}, 5 ErrorTable(4096, allowable_error = aux2),
   // 6 ZeroTable(size), 7 InverseSQRT{eps_bits = aux, range_check_bits = size}  (derive(Ord) order of lookup/context.rs:55-72; SoftmaxTableData
   // :74-84 ordered by (float_bits, table_size, bkm), InverseSQRTTableData :124-131 by (eps_bits, range_check_bits))
   int kind; unsigned size; uint32_t aux = 0; int64_t aux2 = 0;
   bool operator<(const TableType& o) const { return kind != o.kind ? kind < o.kind : aux != o.aux ? aux < o.aux : size != o.size ? size < o.size : aux2 < o.aux2; }
   bool operator==(const TableType& o) const { return kind == o.kind && size == o.size && aux == o.aux && aux2 == o.aux2; }
-  unsigned vars() const { return kind == 3 || kind == 4 || kind == 6 ? size : kind == 5 ? dp_ceil_log2((size_t)(2 * aux2)) : kind == 7 ? 2 * (Q_BIT_LEN - 1) + 1 : Q_BIT_LEN; }  // multiplicity_poly_vars (context.rs:481-492)
-  const char* label() const { return kind == 0 ? "Relu" : kind == 3 ? "Clamping" : kind == 4 ? "Softmax" : kind == 6 ? "Zero" : kind == 7 ? "InverseSQRT" : nullptr; }
+  unsigned vars() const { return kind == 1 || kind == 3 || kind == 4 || kind == 6 ? size : kind == 5 ? dp_ceil_log2((size_t)(2 * aux2)) : kind == 7 ? 2 * (Q_BIT_LEN - 1) + 1 : Q_BIT_LEN; }  // multiplicity_poly_vars (context.rs:481-492)
+  const char* label() const { return kind == 0 ? "Relu" : kind == 1 ? "GELU" : kind == 3 ? "Clamping" : kind == 4 ? "Softmax" : kind == 6 ? "Zero" : kind == 7 ? "InverseSQRT" : nullptr; }
   // committed_columns (context.rs:495-545): the output column of these tables (the only column of an ErrorTable) is a commitment of the context
-  bool committed_column() const { return kind == 7 || kind == 4 || kind == 5; }
+  bool committed_column() const { return kind == 7 || kind == 4 || kind == 5 || kind == 1; }
 };
 constexpr unsigned SM_LOG_SCALE = 24; constexpr int64_t SM_OUT_ONE = 1 << 12;  // SCALE_FACTOR, OUTPUT_SCALE_FACTOR (softmax.rs:56-60)
 // SoftmaxTableData::table_output (lookup/context.rs:111-122), f32 exp as there
@@ -209,11 +209,32 @@ inline int64_t inv_sqrt_lut(uint32_t eps_bits, unsigned range_check_bits, int64_
   if (r <= -9.2e18f) return INT64_MIN;
   return (int64_t)r;
 }
+// GELUQuantData::table_output (layers/activation.rs:582-588) with gelu_float (:623-627), in f32 and in that order of operations; the argument is the
+// SCALED input (input * multiplier), the table's unit 2^-12 (GELU_SCALE_FACTOR, :42-43). Every intermediate goes through a volatile float: no
+// compiler may fuse x + 0.044715 x^3 into one rounding (the reference's code is not contracted).
+constexpr unsigned GELU_LOG_SCALE = 12;
+inline int64_t gelu_lut(int64_t scaled) {
+  volatile float x = (float)scaled / (float)(1u << GELU_LOG_SCALE);
+  volatile float x2 = x * x;
+  volatile float x3 = x2 * x;
+  volatile float c = 0.044715f * x3;
+  volatile float s = x + c;
+  volatile float k = sqrtf(2.0f / 3.14159265358979323846f);
+  volatile float inner = k * s;
+  volatile float th = tanhf(inner);
+  volatile float one_plus = 1.0f + th;
+  volatile float hx = 0.5f * x;
+  volatile float g = hx * one_plus;
+  volatile float q = g * (float)Q_MAX;
+  return (int64_t)roundf(q);
+}
+inline unsigned gelu_table_vars(int64_t multiplier) { return Q_BIT_LEN + dp_ceil_log2((size_t)multiplier); }  // min = -2^(7 + ceil_log2(multiplier)), max = -min (GELU::quantize, :629-659)
 inline int64_t q_clamp(int64_t x) { return x < Q_MIN ? Q_MIN : x > Q_MAX ? Q_MAX : x; }
 inline int64_t q_relu(int64_t x) { return x < 0 ? 0 : x; }
 inline void table_columns(const TableType& tt, std::vector<int64_t>& merged, std::vector<std::vector<int64_t>>& cols) {
   merged.clear(); cols.clear();
   if (tt.kind == 0) { cols.resize(2); for (int64_t i = Q_MIN - 1; i <= Q_MAX; i++) { int64_t o = q_relu(i); merged.push_back(i + o * COLUMN_SEPARATOR); cols[0].push_back(i); cols[1].push_back(o); } }
+  else if (tt.kind == 1) { cols.resize(2); int64_t mx = int64_t(1) << (tt.size - 1); for (int64_t i = -mx; i < mx; i++) { int64_t o = gelu_lut(i); merged.push_back(i + o * COLUMN_SEPARATOR); cols[0].push_back(i); cols[1].push_back(o); } }  // GELUQuantData::table: min .. max, max excluded (:579-581)
   else if (tt.kind == 2) { cols.resize(1); for (int64_t i = 0; i < (int64_t(1) << Q_BIT_LEN); i++) { merged.push_back(i); cols[0].push_back(i); } }
   else if (tt.kind == 4) { cols.resize(2); for (int64_t j = 0; j < (int64_t(1) << tt.size); j++) { int64_t o = softmax_lut(tt.aux, tt.aux2, j); merged.push_back(j + o * COLUMN_SEPARATOR); cols[0].push_back(j); cols[1].push_back(o); } }
   else if (tt.kind == 5) {  // one - error ..= one + error, cut / zero padded to 2^ceil_log2(2 error) entries (context.rs:248-264)
@@ -226,6 +247,14 @@ inline void table_columns(const TableType& tt, std::vector<int64_t>& merged, std
   else { cols.resize(2); int64_t mx = int64_t(1) << (tt.size - 1); for (int64_t i = -mx; i < mx; i++) { int64_t o = q_clamp(i); merged.push_back(i + o * COLUMN_SEPARATOR); cols[0].push_back(i); cols[1].push_back(o); } }
 }
 
+inline TableType gelu_table(const LayerSpec& l) { TableType t{1, gelu_table_vars(l.fixed_point_multiplier)}; t.aux2 = l.fixed_point_multiplier; return t; }  // (a GELU node keeps its multiplier where a Requant keeps its own)
+// Activation::Gelu on Elements (GELU::apply, activation.rs:661-671): the table is looked up at input * multiplier. The reference accepts scaled == max, which is
+// no row of its table (the lookup argument then fails): refused here
+inline int64_t gelu_op(const LayerSpec& l, int64_t v) {
+  const int64_t mx = int64_t(1) << (gelu_table_vars(l.fixed_point_multiplier) - 1), scaled = v * l.fixed_point_multiplier;
+  DP_REQUIRE(v >= -(int64_t(1) << 20) && v <= (int64_t(1) << 20) && scaled >= -mx && scaled < mx, DP_ERR_ARG, "gelu: input out of range");
+  return gelu_lut(scaled);
+}
 inline TableType layernorm_table(const LayerSpec& l) { TableType t{7, l.ln_range_check_bits}; t.aux = l.ln_eps_bits; return t; }
 // LayerNorm::evaluate on Elements (layernorm.rs:394-470): per row, multiplier (N sum x^2 - (sum x)^2) is split into the bits that are range
 // checked and the input of the inverse-square-root table; out = gamma (N x - sum x) lut(input) + beta
@@ -582,6 +611,7 @@ inline Trace run_model(const ModelSpec& m, const std::vector<int64_t>& input) {
         o.push_back(q_clamp((v * l.fixed_point_multiplier + (int64_t(1) << (sh - 1))) >> sh));
       }
     } else if (l.kind == L_RELU) for (int64_t v : cur) o.push_back(q_relu(v));
+    else if (l.kind == L_GELU) for (int64_t v : cur) o.push_back(gelu_op(l, v));
     else if (l.kind == L_LAYERNORM) o = layernorm_op(l, cur, nullptr);
     else if (l.kind == L_SOFTMAX) o = softmax_op(l, cur, nullptr);
     else if (l.kind == L_CONV) { tr.conv.resize(m.layers.size()); o = conv_op(l, cur, tr.conv[tr.in.size() - 1]); }
@@ -716,6 +746,7 @@ inline void validate_model(const ModelSpec& m) {
       unsigned cs = l.clamping_size();
       DP_REQUIRE(cs >= 1 && cs <= 24 && cur >= 4, DP_ERR_ARG, "requant: unsupported clamping table size / tensor length");
     } else if (l.kind == L_RELU) { DP_REQUIRE(cur >= 4, DP_ERR_SHAPE, "relu: tensor length must be >= 4"); }
+    else if (l.kind == L_GELU) { DP_REQUIRE(cur >= 4 && l.fixed_point_multiplier >= 1 && l.fixed_point_multiplier <= (int64_t(1) << 12), DP_ERR_ARG, "gelu: tensor length must be >= 4, the table at most 2^20 rows (activation.rs:643-648)"); }
     else if (l.kind == L_SOFTMAX) check_softmax(l, cur);
     else if (l.kind == L_MHA) {  // three equally long inputs; the sub-layers' own conditions (head_dim is the mat_mul dimension of qk, seq of final_mul)
       const size_t S = l.mha_shape[0], H = l.mha_shape[1], D = l.mha_shape[2];
@@ -758,6 +789,7 @@ inline std::unique_ptr<Context> context_generate(Dev& dev, const ModelSpec& m) {
     const size_t cur = l0.kind == L_MHA ? sub.sm_shape[0] * sub.sm_shape[1] * sub.sm_shape[2] : lens[id];  // (Requant / Relu: also the length of the input; MaxPool: of the output, as the committed polynomials are)
     if (l.kind == L_REQUANT) { add({2, 0}); add({3, l.clamping_size()}); mpl = std::max(mpl, next_pow2(cur)); }
     else if (l.kind == L_RELU) { add({0, 0}); mpl = std::max(mpl, next_pow2(cur)); }
+    else if (l.kind == L_GELU) { add(gelu_table(l)); mpl = std::max(mpl, next_pow2(cur)); }
     else if (l.kind == L_MAXPOOL) { add({2, 0}); mpl = std::max(mpl, next_pow2(cur)); }
     else if (l.kind == L_LAYERNORM) { add({2, 0}); add(layernorm_table(l)); mpl = std::max(mpl, next_pow2(cur)); }  // layernorm.rs:587-618
     else if (l.kind == L_SOFTMAX) { add({2, 0}); add(softmax_table(l)); add(softmax_error_table(l)); if (l.sm_zero_vars) add({6, l.sm_zero_vars}); mpl = std::max(mpl, next_pow2(cur)); }  // softmax.rs:1205-1245
@@ -958,6 +990,16 @@ inline WitnessHost witness_host(const Context& ctx, const Trace& tr) {
         pr.col_ids.push_back(cols.size()); cols.push_back({std::move(ch)});
       }
       pend.push_back(pc); pend.push_back(pr);
+    } else if (l.kind == L_GELU) {  // Activation::gen_lookup_witness (activation.rs:238-318): the first column is the SCALED input, what the table is indexed by
+      TableType gt = gelu_table(l);
+      std::vector<int64_t> a; a.reserve(tr.in[id].size());
+      for (int64_t v : tr.in[id]) a.push_back(v * l.fixed_point_multiplier);
+      const auto& b = tr.out[id];
+      std::unordered_map<int64_t, u64>& cg = counts[gt];
+      for (size_t i = 0; i < a.size(); i++) cg[a[i] + COLUMN_SEPARATOR * b[i]] += 1;
+      Pending p{id, 0, {cols.size(), cols.size() + 1}, 2, gt};
+      cols.push_back({std::move(a)}); cols.push_back({b});
+      pend.push_back(p);
     } else if (l.kind == L_RELU) {
       TableType rt{0, 0};
       const auto& a = tr.in[id]; const auto& b = tr.out[id];
@@ -1051,7 +1093,7 @@ inline WitnessHost witness_host(const Context& ctx, const Trace& tr) {
   for (size_t id = 0; id < ctx.model.layers.size(); id++) {
     const int kind = ctx.model.layers[id].kind;
     if (kind == L_DENSE) acts.push_back({Act{id, false, tr.in[id].size(), 0}, &tr.in[id]});
-    else if (kind == L_RELU) acts.push_back({Act{id, true, tr.out[id].size(), 0}, &tr.out[id]});
+    else if (kind == L_RELU || kind == L_GELU) acts.push_back({Act{id, true, tr.out[id].size(), 0}, &tr.out[id]});
   }
   if (mflat.size() & 1) mflat.push_back(0);
   for (auto& av : acts) { av.first.off = mflat.size(); mflat.reserve(mflat.size() + 2 * av.second->size()); for (int64_t x : *av.second) { mflat.push_back(gl_from_i64(x)); mflat.push_back(0); } wh.acts.push_back(av.first); }
@@ -1475,7 +1517,14 @@ inline SamePolyProof same_poly_prove(Dev& dev, const std::vector<Claim>& claims,
   dev.release(mk);
   return {sc.proof, sc.finals};
 }
-inline Claim prove_relu(ProverState& ps, size_t id, const Claim& last, const std::vector<int64_t>& output) {
+// Activation::prove_step (activation.rs:385-456) for both activations. GELU (`multiplier` > 0): the first lookup column holds input * multiplier, the claim
+// handed on is the lookup's claim times 1 / multiplier (:405-413). The COMMITTED column is the scaled one, and the verifier opens it at the lookup's own claim
+// (verify_activation, :495-505: `verifier_claims.claims().iter().take(1)`). The reference's prover hands its commitment prover the DESCALED claim instead
+// (:419-421 shadow `input_claim` before the `commits` array is built): its batch opening then starts from a wrong sum and cannot verify, except where the
+// claim is never used — polynomials of at most 2^7 entries, opened by showing them (`_eval` of Basefold::open, mpcs/src/basefold.rs:466-483; the size of
+// the reference's own test, activation.rs:686-697) — or multiplier = 1. Here the commitment gets the claim the verifier will check; the proof stream is
+// the reference's wherever the reference produces one that verifies.
+inline Claim prove_relu(ProverState& ps, size_t id, const Claim& last, const std::vector<int64_t>& output, int64_t multiplier = 0) {
   Dev& dev = *ps.dev;
   LogUpWitness& w = ps.lookup_witness.at(id)[0];
   LogUpProof lproof = logup_batch_prove(dev, ps.logup_input(w), *ps.t);
@@ -1489,7 +1538,8 @@ inline Claim prove_relu(ProverState& ps, size_t id, const Claim& last, const std
   ActivationProof ap; ap.io_accumulation = sp; ap.lookup = lproof;
   ps.add_witness_claim(w.commits[0], input_claim); ap.commits.push_back(pure_commitment(w.commits[0]));
   ps.add_witness_claim(w.commits[1], {sp.sumcheck.point, sp.evals[1]}); ap.commits.push_back(pure_commitment(w.commits[1]));
-  LayerProof lp; lp.kind = L_RELU; lp.act = ap; ps.proofs[id] = lp;
+  LayerProof lp; lp.kind = multiplier ? L_GELU : L_RELU; lp.act = ap; ps.proofs[id] = lp;
+  if (multiplier) input_claim.eval = ex_mul(input_claim.eval, ex_inv(ex_from_i64(multiplier)));
   return input_claim;
 }
 
@@ -1941,6 +1991,7 @@ inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t, Witne
     else if (l.kind == L_POSITIONAL) cur = prove_positional(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
     else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, tr.out[id]);
+    else if (l.kind == L_GELU) cur = prove_relu(ps, id, cur, tr.out[id], l.fixed_point_multiplier);
     else if (l.kind == L_LAYERNORM) cur = prove_layernorm(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_SOFTMAX) cur = prove_softmax(ps, id, l, cur);
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv.at(id));
@@ -1993,7 +2044,7 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
     n_provable++;
     auto it = proof.steps.find(id);
     DP_REQUIRE(it != proof.steps.end() && it->second.kind == m.layers[id].kind, DP_ERR_VERIFY, "missing or mistyped layer proof");
-    if (it->second.kind == L_RELU) add_fracs(it->second.act.lookup);
+    if (it->second.kind == L_RELU || it->second.kind == L_GELU) add_fracs(it->second.act.lookup);
     if (it->second.kind == L_REQUANT) { add_fracs(it->second.req.clamping_lookup); add_fracs(it->second.req.shifted_lookup); }
     if (it->second.kind == L_MAXPOOL) add_fracs(it->second.pool.lookup);
     if (it->second.kind == L_LAYERNORM) for (auto& lg : it->second.ln.logup_proofs) add_fracs(lg);
@@ -2472,7 +2523,8 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       cur = {sub.point, next};
     } else {  // verify_activation (activation.rs:459-517)
       const ActivationProof& ap = lp.act;
-      TableType rt{0, 0};
+      DP_REQUIRE(l.kind == L_RELU || l.kind == L_GELU, DP_ERR_VERIFY, "unknown layer kind");
+      TableType rt = l.kind == L_GELU ? gelu_table(l) : TableType{0, 0};
       DP_REQUIRE(chmap.count(rt), DP_ERR_VERIFY, "relu: no challenge for table");
       LogUpVerifierClaim vcl = verify_logup_proof(ap.lookup, 1, constant_challenge, chmap[rt], t, 0);
       DP_REQUIRE(vcl.claims.size() == 2 && ap.commits.size() == 2 && ap.io_accumulation.evals.size() == 2, DP_ERR_VERIFY, "relu: shapes");
@@ -2491,6 +2543,7 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
       add_claim(ap.commits[0], vcl.claims[0]);
       add_claim(ap.commits[1], new_out);
       cur = vcl.claims[0];
+      if (l.kind == L_GELU) cur.eval = ex_mul(cur.eval, ex_inv(ex_from_i64(l.fixed_point_multiplier)));  // the claim on the input itself (:507-515)
     }
     made[id] = {cur};
     finish_part(vs);
@@ -2516,6 +2569,7 @@ inline void verify(const VerifierContext& vc, const Proof& proof, const IO& io, 
     Ext idx = ex_zero();
     for (size_t k = 0; k < pt.size(); k++) idx = ex_add(idx, ex_mul(pt[k], ex_from_u64(u64(1) << k)));
     if (tt.kind == 2) expect = {idx};
+    else if (tt.kind == 1) expect = {ex_sub(idx, ex_from_u64(u64(1) << (tt.size - 1)))};  // GELU: the input column, the output column is committed (context.rs:364-378)
     else if (tt.kind == 7) expect = {ex_sub(idx, ex_from_u64(u64(1) << (2 * (Q_BIT_LEN - 1))))};  // (context.rs:445-462)
     else if (tt.kind == 4) expect = {idx};   // Softmax: the input column (context.rs:409-423)
     else if (tt.kind == 5) expect = {};      // ErrorTable: nothing but the committed column (:424)
@@ -2662,7 +2716,8 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
     l.kw = (size_t)rd(); l.kx = (size_t)rd(); l.real_nw = (size_t)rd(); l.nw = (size_t)rd();
     for (int k = 0; k < 3; k++) l.unp_out[k] = (size_t)rd();
     for (int k = 0; k < 3; k++) l.pin[k] = (size_t)rd();
-    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_MHA, DP_ERR_ARG, "verifier blob: layer kind");
+    DP_REQUIRE(l.kind >= L_DENSE && l.kind <= L_GELU, DP_ERR_ARG, "verifier blob: layer kind");
+    if (l.kind == L_GELU) DP_REQUIRE(l.fixed_point_multiplier >= 1 && l.fixed_point_multiplier <= (int64_t(1) << 12), DP_ERR_ARG, "verifier blob: gelu multiplier");
     if (l.kind == L_MHA) {
       l.sm_table_size = l.right_shift; l.sm_zero_chunks = l.fp_scale; l.sm_scalar = l.fixed_point_multiplier; l.sm_temp_bits = (uint32_t)l.intermediate_bit_size;
       l.sm_zero_vars = (unsigned)l.kw; l.sm_bkm = (int64_t)l.kx; l.sm_allowable_error = (int64_t)l.real_nw; for (int k = 0; k < 3; k++) { l.mha_shape[k] = l.unp_out[k]; l.unp_out[k] = 0; }
@@ -2699,12 +2754,13 @@ inline VerifierContext vctx_from_words(const u64* w, size_t n) {
   size_t nt = (size_t)rd(); DP_REQUIRE(nt < 64, DP_ERR_ARG, "verifier blob: tables");
   for (size_t i = 0; i < nt; i++) {
     TableType t; t.kind = (int)rd(); t.size = (unsigned)rd();
-    DP_REQUIRE(t.kind == 0 || (t.kind >= 2 && t.kind <= 7), DP_ERR_ARG, "verifier blob: table kind");
+    DP_REQUIRE(t.kind >= 0 && t.kind <= 7, DP_ERR_ARG, "verifier blob: table kind");
     DP_REQUIRE(t.kind != 6 || (t.size >= 1 && t.size <= 22), DP_ERR_ARG, "verifier blob: zero table size");
     if (t.committed_column()) {
       u64 a = rd(), a2 = rd(); DP_REQUIRE(a <= 0xFFFFFFFFull && t.size <= 40 && a2 < (u64(1) << 40), DP_ERR_ARG, "verifier blob: table parameters"); t.aux = (uint32_t)a; t.aux2 = (int64_t)a2;
       DP_REQUIRE(t.kind != 5 || (t.aux2 >= 1 && t.aux2 <= (1 << 11)), DP_ERR_ARG, "verifier blob: error table");
       DP_REQUIRE(t.kind != 4 || (t.size >= 1 && t.size <= 22), DP_ERR_ARG, "verifier blob: softmax table");
+      DP_REQUIRE(t.kind != 1 || (t.aux2 >= 1 && t.aux2 <= (int64_t(1) << 12) && t.size == gelu_table_vars(t.aux2) && t.aux == 0), DP_ERR_ARG, "verifier blob: gelu table");
       Commitment c; for (int k = 0; k < 4; k++) c.root.v[k] = rd(); c.num_vars = (unsigned)rd(); c.is_base = rd() != 0; v.table_comms[t] = c;
     }
     v.tables.push_back(t);

@@ -6,7 +6,7 @@ import math
 import numpy as np
 
 L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_FLATTEN, L_MATMUL, L_ADD, L_EMBED, L_POSITIONAL = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
-L_LAYERNORM, L_SOFTMAX, L_MHA = 14, 15, 16
+L_LAYERNORM, L_SOFTMAX, L_MHA, L_GELU = 14, 15, 16, 17
 L_MATMUL2, L_ADD2, L_CONCAT_MATMUL, L_QKV = 10, 11, 12, 13  # nodes of a model GRAPH: two-input MatMul / Add, ConcatMatMul, QKV
 BIT_LEN = 8
 FIXED_POINT_SCALE = 25  # zkml/src/layers/requant.rs:47
@@ -62,7 +62,7 @@ def _libm():
     import ctypes.util
     if not hasattr(_libm, "lib"):
         lib = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
-        for f in (lib.expf, lib.logf):
+        for f in (lib.expf, lib.logf, lib.tanhf):
             f.restype, f.argtypes = ctypes.c_float, [ctypes.c_float]
         _libm.lib = lib
     return _libm.lib
@@ -73,6 +73,34 @@ def _round_away(x):
     x = np.float32(x)
     a = np.floor(np.abs(x))
     return int((a + 1 if np.abs(x) - a >= np.float32(0.5) else a) * (1 if x >= 0 else -1))
+
+
+def gelu_multiplier(in_scale):
+    """GELU::quantize (zkml/src/layers/activation.rs:629-659): the integer the quantised input is multiplied by so that it counts units of 2^-12"""
+    m = _round_away(np.float32(1 << 12) * np.float32(in_scale))
+    assert 1 <= m <= 1 << 12  # the table has 2^(8 + ceil_log2(m)) rows, at most 2^20 (:643-648)
+    return m
+
+
+def gelu_table_output(scaled):
+    """GELUQuantData::table_output / gelu_float (activation.rs:582-588, 623-627) for ONE scaled input: f32 after every operation, tanhf of the C
+    library (Rust's f32::tanh calls the same function), round half away from zero"""
+    f = np.float32
+    x = f(int(scaled)) / f(1 << 12)
+    cubed = f(f(x * x) * x)
+    inner = f(f(np.sqrt(f(2.0) / f(np.pi))) * f(x + f(f(0.044715) * cubed)))
+    g = f(f(f(0.5) * x) * f(f(1.0) + f(_libm().tanhf(inner))))
+    return _round_away(f(g * f(127)))
+
+
+def gelu_apply(l, x):
+    """Activation::Gelu on Elements (GELU::apply, activation.rs:661-671): the table row of input * multiplier (the table ends one before its max)"""
+    m = l["multiplier"]
+    edge = 1 << (7 + (m - 1).bit_length())
+    scaled = np.asarray(x, dtype=np.int64) * m
+    assert scaled.min() >= -edge and scaled.max() < edge, "gelu: input out of range"
+    lut = {}
+    return np.array([lut.setdefault(int(v), gelu_table_output(int(v))) for v in scaled], dtype=np.int64)
 
 
 def softmax_params(in_scale, max_context, temperature=1.0, max_abs=127):
@@ -343,6 +371,11 @@ class ModelBuilder:
         self.layers.append(dict(kind=L_RELU))
         return self
 
+    def gelu(self, in_scale=1.0 / 128.0):
+        """Activation::Gelu behind a Requant whose output carries `in_scale` (layers/activation.rs:559-671)"""
+        self.layers.append(dict(kind=L_GELU, multiplier=gelu_multiplier(in_scale)))
+        return self
+
     def conv(self, out_channels, kernel, requant=True):
         """Convolution (stride 1, no padding) as pad_conv + into_padded_and_ffted lay it out (padding.rs:218-260,
         convolution.rs:290-301, tensor.rs:409-431): filter zero padded to powers of two in every dimension, nw = the
@@ -419,6 +452,8 @@ class ModelBuilder:
                 parts.append(np.array([L_LAYERNORM, l["dim"], l["dim_size"], l["multiplier"], l["eps_bits"], l["range_check_bits"], l["top_chunk_scalar_log"]], dtype=np.int64))
                 parts.append(l["gamma"])
                 parts.append(l["beta"])
+            elif l["kind"] == L_GELU:
+                parts.append(np.array([L_GELU, l["multiplier"]], dtype=np.int64))
             else:
                 parts.append(np.array([l["kind"]], dtype=np.int64))
         return np.concatenate(parts)
@@ -454,6 +489,8 @@ class ModelBuilder:
                 cur = np.clip((cur * l["fixed_point_multiplier"] + (1 << (sh - 1))) >> sh, -127, 127)
             elif l["kind"] == L_RELU:
                 cur = np.maximum(cur, 0)
+            elif l["kind"] == L_GELU:
+                cur = gelu_apply(l, cur)
             elif l["kind"] == L_LAYERNORM:
                 cur = layernorm_apply(l, cur)[0]
             elif l["kind"] == L_SOFTMAX:
@@ -556,6 +593,9 @@ class GraphBuilder:
     def relu(self, src):
         return self._add(dict(kind=L_RELU), [src])
 
+    def gelu(self, src, in_scale=1.0 / 128.0):
+        return self._add(dict(kind=L_GELU, multiplier=gelu_multiplier(in_scale)), [src])
+
     def set_outputs(self, edges):
         self.outputs = [tuple(e) for e in edges]
         return self
@@ -595,6 +635,8 @@ class GraphBuilder:
                 parts.append(np.array(pre + [*l["shape"], l["scalar"], l["temp_bits"], l["in_scale_bits"], l["table_size"], l["bkm"], l["zero_chunks"], l["zero_vars"], l["allowable_error"]], dtype=np.int64))
             elif k == L_RELU:
                 parts.append(np.array(pre, dtype=np.int64))
+            elif k == L_GELU:
+                parts.append(np.array(pre + [l["multiplier"]], dtype=np.int64))
             else:
                 raise ValueError("GraphBuilder: unsupported node kind")
         return np.concatenate(parts)
@@ -640,6 +682,8 @@ class GraphBuilder:
                 y = np.clip((a * l["fixed_point_multiplier"] + (1 << (sh - 1))) >> sh, -127, 127)
             elif k == L_RELU:
                 y = np.maximum(a, 0)
+            elif k == L_GELU:
+                y = gelu_apply(l, a)
             elif k == L_LAYERNORM:
                 y = layernorm_apply(l, a)[0]
             elif k == L_SOFTMAX:
@@ -717,14 +761,15 @@ def mha_block(seq, emb, heads, head_dim, config):
     return g
 
 
-def transformer_layer(seq, emb, heads, head_dim, ffn, config):
+def transformer_layer(seq, emb, heads, head_dim, ffn, config, gelu=False):
     """One whole pre-LN transformer layer as ONE graph, every node proved: the attention half of mha_block (LayerNorm -> QKV -> Mha -> projection
     -> + residual) and the feed-forward half (LayerNorm -> Linear(emb, ffn) -> ReLU -> Linear(ffn, emb) -> + residual). The reference proves graphs
     whose tensors have ONE reader each (claims_for_node, provable/mod.rs:243-248), so every second use of a tensor enters as an input tensor of
     its own: inputs = X (normalised by the first LayerNorm), X once more (the residual added to the attention output), H (what the second
-    LayerNorm normalises — in a running model the hidden state X + attention, whose one reader inside the graph is the LAST Add). GELU is not
-    provable in the reference (prover / verifier
-    mismatch): ReLU stands in. layers/transformer/{layernorm,qkv,mha}.rs, layers/matrix_mul.rs, layers/activation.rs, layers/add.rs"""
+    LayerNorm normalises — in a running model the hidden state X + attention, whose one reader inside the graph is the LAST Add). gelu=False: ReLU
+    stands in for the GELU of the feed-forward half (what golden case 14 and the bench line prove). The reference's GELU prover files a claim its verifier
+    does not check (activation.rs:405-430 against :495-505), so its proofs only verify for columns of at most 2^7 entries; gelu=True puts this library's
+    GELU there (csrc/zkml.h prove_relu), input scale 1 / 128. layers/transformer/{layernorm,qkv,mha}.rs, layers/matrix_mul.rs, layers/activation.rs, layers/add.rs"""
     n = heads * head_dim
     g = GraphBuilder([seq * emb] * 3, config)
     ln, ibs = g.layernorm((-1, 0), emb)
@@ -742,7 +787,7 @@ def transformer_layer(seq, emb, heads, head_dim, ffn, config):
     lr2 = g.requant_shift((ln2, 0), ibs2 - 16, ibs2)
     f1 = g.matmul_const((lr2, 0), emb, ffn)
     f1q = g.requant((f1, 0), 2.5 / math.sqrt(emb) / 127.0, dense_output_bitsize(emb))
-    act = g.relu((f1q, 0))
+    act = g.gelu((f1q, 0)) if gelu else g.relu((f1q, 0))
     f2 = g.matmul_const((act, 0), ffn, emb)
     f2q = g.requant((f2, 0), 2.5 / math.sqrt(ffn) / 127.0, dense_output_bitsize(ffn))
     res2 = g.add2((f2q, 0), (res1, 0))
@@ -775,6 +820,19 @@ def mlp(num_dense, width, config, input_features=4, output_features=3):
     for _ in range(num_dense - 1):
         mb.dense(width, width).relu()
     mb.dense(output_features, width).relu()
+    return mb
+
+
+def gelu_only(n, config, in_scale=1.0 / 128.0):
+    """the reference's own GELU proving test (zkml/src/layers/activation.rs:686-697: one Activation::Gelu over a small tensor) at `n` entries"""
+    return ModelBuilder(n, config).gelu(in_scale)
+
+
+def gelu_mlp(width, config, input_features=4, output_features=3, in_scale=1.0 / 128.0):
+    """Linear(4, W) + GELU + Linear(W, 3): the feed-forward shape with the activation a transformer uses (layers/activation.rs Activation::Gelu)"""
+    mb = ModelBuilder(input_features, config)
+    mb.dense(width, input_features).gelu(in_scale)
+    mb.dense(output_features, width)
     return mb
 
 

@@ -30,6 +30,7 @@ L_DENSE, L_REQUANT, L_RELU, L_CONV, L_MAXPOOL, L_MATMUL, L_ADD, L_EMBED, L_POSIT
 # nodes of a model graph: MatMul / Add of two inputs share the reference's MatMulProof / AddProof variants with the constant forms (on the way
 # back from the wire format they come out as kinds 6 / 7); ConcatMatMul and QKV have their own
 L_MATMUL2, L_ADD2, L_CONCAT_MATMUL, L_QKV, L_LAYERNORM, L_SOFTMAX, L_MHA = 10, 11, 12, 13, 14, 15, 16
+L_GELU = 17  # Activation::Gelu: the reference's ActivationProof, as for a Relu (back from the wire format it is kind 2)
 
 
 class Conventions:
@@ -125,7 +126,7 @@ def parse_stream(words):
         elif kind == L_REQUANT:
             lp = {"io_accumulation": r.iop(), "accumulation_evals": r.ve(), "clamping_lookup": r.logup(), "shifted_lookup": r.logup(),
                   "commitments": [r.comm() for _ in range(r.u())]}
-        elif kind == L_RELU:
+        elif kind in (L_RELU, L_GELU):
             lp = {"io_accumulation": {"sumcheck": r.iop(), "evals": r.ve()}, "lookup": r.logup(), "commits": [r.comm() for _ in range(r.u())]}
         elif kind == L_CONV:
             lp = {"fft_proof": r.iop(), "fft_proof_weights": r.iop(), "fft_delegation_proof": [r.iop() for _ in range(r.u())],
@@ -251,7 +252,7 @@ def to_serde_model(tree, conv=Conventions):
             v = {"Requant": {"io_accumulation": _iop(lp["io_accumulation"], c), "accumulation_evals": _ve(lp["accumulation_evals"], c),
                              "clamping_lookup": _logup(lp["clamping_lookup"], c), "shifted_lookup": _logup(lp["shifted_lookup"], c),
                              "commitments": [_comm(k, c) for k in lp["commitments"]]}}
-        elif kind == L_RELU:
+        elif kind in (L_RELU, L_GELU):
             v = {"Activation": {"io_accumulation": {"sumcheck": _iop(lp["io_accumulation"]["sumcheck"], c), "evals": _ve(lp["io_accumulation"]["evals"], c)},
                                 "lookup": _logup(lp["lookup"], c), "commits": [_comm(k, c) for k in lp["commits"]]}}
         elif kind == L_CONV:

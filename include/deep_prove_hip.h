@@ -330,6 +330,11 @@ int32_t dp_pcs_simple_batch_verify(size_t max_poly_size, const uint64_t root[4],
  *      so its input scale is scale(Q) scale(K), its domain qk.output_domain(), 1 / temperature = sqrt(head_dim)). Output [seq][heads * head_dim]
  *      = softmax(Q_h K_h^T) V_h per head at the scale 2^-12 scale(V). One proof step per node: MhaProof {final_mul, softmax, qk}; the claims it
  *      hands on are those on Q, K, V in this order.
+ *   17 Gelu (zkml/src/layers/activation.rs:559-671, Activation::Gelu; also a layer of a chain): multiplier = round(2^12 * input scale), 1 .. 4096
+ *      (GELU::quantize). The input (>= 4 entries) times the multiplier must lie in [-2^(7 + ceil_log2(multiplier)), 2^(7 + ceil_log2(multiplier))), the
+ *      rows of its table (its output column, round(127 gelu(i / 2^12)) in f32 with the C library's tanhf, is a commitment of the context). Proved as the
+ *      reference's ActivationProof; the committed scaled-input column is opened at the lookup's own claim — what verify_activation checks (:495-505); the
+ *      reference's prover files that claim divided by the multiplier (:405-430) and only verifies where the column is opened by showing it (<= 2^7 entries).
  *   A node has one, two or (kind 16) three inputs. Embeddings stay the first node of a chain. Not built: Logits (no consistent transcript in the
  *   reference outside cfg(test)). */
 int32_t dp_model_setup(dp_ctx* ctx, const int64_t* model_blob, size_t nwords, dp_model** out);

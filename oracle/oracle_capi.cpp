@@ -90,6 +90,7 @@ static Model parse_model(const int64_t* b, size_t n) {
       l.sm_scalar = rd(); l.sm_temp_bits = (uint32_t)rd(); l.sm_in_scale_bits = (uint32_t)rd(); l.sm_table_size = (unsigned)rd(); l.sm_bkm = rd(); l.sm_zero_chunks = (unsigned)rd(); l.sm_zero_vars = (unsigned)rd(); l.sm_allowable_error = rd();
       if (l.sm_table_size == 0 || l.sm_table_size > 22 || l.sm_zero_chunks > 3 || l.sm_zero_vars > 22 || l.sm_allowable_error < 1 || l.sm_allowable_error > (1 << 20) || l.sm_scalar < 1 || l.sm_bkm < (1 << 17)) throw std::runtime_error("softmax: parameters");
     }
+    else if (l.kind == L_GELU) { l.gelu_multiplier = rd(); if (l.gelu_multiplier < 1 || l.gelu_multiplier > 4096) throw std::runtime_error("model blob: gelu multiplier"); }
     else if (l.kind == L_RELU || l.kind == L_FLATTEN) {}
     else throw std::runtime_error("model blob: unknown layer kind");
     m.layers.push_back(std::move(l));
@@ -101,6 +102,9 @@ struct orc_model { Context ctx; };
 
 extern "C" {
 const char* orc_last_error(void) { return g_err.c_str(); }
+// which claim a GELU's prover files with the commitment of its scaled input column (zkml.hpp prove_relu): 0 = the reference to the letter (activation.rs:419-430,
+// verifiable only when the column is opened by showing it), 1 = the lookup's own claim, the one verify_activation checks (:495-505)
+void orc_set_gelu_files_lookup_claim(int on) { g_gelu_files_lookup_claim = on != 0; }
 void orc_free(void* p) { free(p); }
 
 // constants + algebra self checks (SURVEY.md Appendix B fingerprints, A.1 generators). 0 = ok, else a failing check id.

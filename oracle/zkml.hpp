@@ -172,7 +172,7 @@ static inline LogUpProof logup_batch_prove(const LogUpInput& in, Transcript& t) 
 
 // ------------------------------------------------------------------ model description
 enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8, L_POSITIONAL = 9,
-                 L_MATMUL2 = 10, L_ADD2 = 11, L_CONCAT_MATMUL = 12, L_QKV = 13, L_LAYERNORM = 14, L_SOFTMAX = 15, L_MHA = 16 };
+                 L_MATMUL2 = 10, L_ADD2 = 11, L_CONCAT_MATMUL = 12, L_QKV = 13, L_LAYERNORM = 14, L_SOFTMAX = 15, L_MHA = 16, L_GELU = 17 };
 // An edge of the model graph (layers/provable/mod.rs:195-229, Edge): output `index` of node `node`, or input tensor `index` of the model (node < 0)
 struct Wire { int node = -1; int index = 0; };
 struct Layer {
@@ -222,6 +222,9 @@ struct Layer {
   // [seq][heads][head_dim] (inputs_reshape); qk = ConcatMatMul (1,2,0) x (1,2,0) -> [heads][seq][seq]; the Softmax above (sm_* fields, sm_shape
   // unused: it is [heads][seq][seq]) directly on the products; final_mul = ConcatMatMul (0,2,1) x (1,0,2) permuted (1,0,2) -> [seq][heads][head_dim]
   size_t mha_shape[3] = {0, 0, 0};  // seq, heads, head_dim (padded)
+  // gelu (layers/activation.rs:559-572, GELUQuantData): the integer the input is multiplied by before the table is consulted,
+  // round(2^12 * input scale) (GELU::quantize, :629-659); the table runs over [-2^(7 + ceil_log2(m)), 2^(7 + ceil_log2(m)))
+  int64_t gelu_multiplier = 0;
   unsigned right_shift = 0, fp_scale = 0, intermediate_bit_size = 0;  // requant (requant.rs:46-73)
   int64_t fixed_point_multiplier = 0;
   unsigned shift() const { return fp_scale + right_shift; }
@@ -317,15 +320,16 @@ static inline void cm_output_shape(const Layer& l, size_t out[3]) {
 }
 
 struct TableType {  // lookup/context.rs:55-72 (derive Ord: Relu < GELU < Range < Clamping(n) < Softmax < ErrorTable < ZeroTable < InverseSQRT)
-  int kind;  // 0 Relu, 2 Range, 3 Clamping, 4 Softmax, 5 ErrorTable, 6 ZeroTable, 7 InverseSQRT
+  int kind;  // 0 Relu, 1 GELU (aux2 = GELUQuantData::multiplier, size = log2 of the table length; min / max follow from the multiplier, so derive(Ord) on
+             // (multiplier, min, max) is the order of the multipliers), 2 Range, 3 Clamping, 4 Softmax, 5 ErrorTable, 6 ZeroTable, 7 InverseSQRT
   unsigned size;      // Clamping: bits; Softmax: table_size; ZeroTable: bits; InverseSQRT: range_check_bits
   uint32_t aux = 0;   // InverseSQRT: eps_bits (InverseSQRTTableData derives Ord on (eps_bits, range_check_bits)); Softmax: float_bits
   int64_t aux2 = 0;   // Softmax: bkm (SoftmaxTableData orders by (float_bits, table_size, bkm)); ErrorTable(4096, allowable_error): the error
   bool operator<(const TableType& o) const { return kind != o.kind ? kind < o.kind : aux != o.aux ? aux < o.aux : size != o.size ? size < o.size : aux2 < o.aux2; }
   bool operator==(const TableType& o) const { return kind == o.kind && size == o.size && aux == o.aux && aux2 == o.aux2; }
-  unsigned multiplicity_poly_vars() const { return kind == 3 || kind == 4 || kind == 6 ? size : kind == 5 ? ceil_log2((size_t)(2 * aux2)) : kind == 7 ? 2 * (BIT_LEN - 1) + 1 : BIT_LEN; }  // context.rs:481-492
-  const char* challenge_label() const { return kind == 0 ? "Relu" : kind == 3 ? "Clamping" : kind == 4 ? "Softmax" : kind == 6 ? "Zero" : kind == 7 ? "InverseSQRT" : nullptr; }
-  bool has_committed_column() const { return kind == 7 || kind == 4 || kind == 5; }  // committed_columns (context.rs:495-545): the output column (ErrorTable: its only column)
+  unsigned multiplicity_poly_vars() const { return kind == 1 || kind == 3 || kind == 4 || kind == 6 ? size : kind == 5 ? ceil_log2((size_t)(2 * aux2)) : kind == 7 ? 2 * (BIT_LEN - 1) + 1 : BIT_LEN; }  // context.rs:481-492
+  const char* challenge_label() const { return kind == 0 ? "Relu" : kind == 1 ? "GELU" : kind == 3 ? "Clamping" : kind == 4 ? "Softmax" : kind == 6 ? "Zero" : kind == 7 ? "InverseSQRT" : nullptr; }
+  bool has_committed_column() const { return kind == 1 || kind == 7 || kind == 4 || kind == 5; }  // committed_columns (context.rs:495-545): the output column (ErrorTable: its only column)
 };
 constexpr unsigned SM_LOG_SCALE = 24; constexpr int64_t SM_OUT_ONE = 1 << 12;  // softmax.rs:56-60
 // SoftmaxTableData::table_output (lookup/context.rs:111-122), f32 exp as there
@@ -350,6 +354,28 @@ static inline int64_t inv_sqrt_table_output(uint32_t eps_bits, unsigned range_ch
   return (int64_t)r;
 }
 static inline int64_t relu_apply(int64_t x) { return x < 0 ? 0 : x; }
+// gelu_float (activation.rs:623-627) and GELUQuantData::table_output (:582-588), single precision throughout. Each product and sum is its own statement on a
+// float the optimiser has to store: the Rust code rounds after every operation, a fused multiply-add here would not.
+static inline float gelu_f32(float x) {
+  volatile float cube = x * x; cube = cube * x;
+  volatile float poly = 0.044715f * cube; poly = x + poly;
+  volatile float root = 2.0f / 3.14159265358979323846f; root = std::sqrt((float)root);
+  volatile float arg = root * poly;
+  volatile float t = std::tanh((float)arg); t = 1.0f + t;
+  volatile float half = 0.5f * x;
+  return half * t;
+}
+static inline int64_t gelu_table_output(int64_t scaled_input) {
+  const float fin = (float)scaled_input / 4096.0f;  // GELU_SCALE_FACTOR = 1 << 12 (:42-43)
+  volatile float prod = gelu_f32(fin) * (float)QMAX;
+  return (int64_t)std::round((float)prod);
+}
+static inline unsigned gelu_table_log2(int64_t multiplier) { return 7 + ceil_log2((size_t)multiplier) + 1; }
+static inline int64_t gelu_apply(int64_t multiplier, int64_t x) {  // GELU::apply (:661-671); scaled == max is let through there although the table ends one before it
+  const int64_t scaled = x * multiplier, edge = int64_t(1) << (gelu_table_log2(multiplier) - 1);
+  if (scaled < -edge || scaled >= edge) throw std::runtime_error("gelu: Input out of range");
+  return gelu_table_output(scaled);
+}
 static inline int64_t clamp_q(int64_t x) { return x < QMIN ? QMIN : x > QMAX ? QMAX : x; }
 // get_merged_table_column (lookup/context.rs:158-296)
 static inline void table_columns(const TableType& tt, std::vector<int64_t>& merged, std::vector<std::vector<u64>>& cols) {
@@ -357,6 +383,10 @@ static inline void table_columns(const TableType& tt, std::vector<int64_t>& merg
   if (tt.kind == 0) {
     cols.resize(2);
     for (int64_t i = QMIN - 1; i <= QMAX; i++) { int64_t o = relu_apply(i); merged.push_back(i + o * COLUMN_SEPARATOR); cols[0].push_back(from_i64(i)); cols[1].push_back(from_i64(o)); }
+  } else if (tt.kind == 1) {  // context.rs:163-182, GELUQuantData::table (:579-581): the rows min .. max - 1
+    cols.resize(2);
+    const int64_t edge = int64_t(1) << (tt.size - 1);
+    for (int64_t i = -edge; i < edge; i++) { const int64_t o = gelu_table_output(i); merged.push_back(i + o * COLUMN_SEPARATOR); cols[0].push_back(from_i64(i)); cols[1].push_back(from_i64(o)); }
   } else if (tt.kind == 2) {
     cols.resize(1);
     for (int64_t i = 0; i < (int64_t(1) << BIT_LEN); i++) { merged.push_back(i); cols[0].push_back(from_i64(i)); }
@@ -667,6 +697,7 @@ static inline Trace run_model(const Model& m, const std::vector<int64_t>& input)
         o.push_back(requant_apply(l, v));
       }
     } else if (l.kind == L_RELU) { for (int64_t v : cur) o.push_back(relu_apply(v)); }
+    else if (l.kind == L_GELU) { for (int64_t v : cur) o.push_back(gelu_apply(l.gelu_multiplier, v)); }
     else if (l.kind == L_LAYERNORM) o = layernorm_op(l, cur, nullptr);
     else if (l.kind == L_SOFTMAX) o = softmax_op(l, cur, nullptr);
     else if (l.kind == L_CONV) { tr.conv.resize(m.layers.size()); o = conv_op(l, cur, tr.conv[tr.in.size() - 1]); }
@@ -725,6 +756,7 @@ static inline Context context_generate(const Model& m) {
     size_t cur_len = l0.kind == L_MHA ? sub.sm_shape[0] * sub.sm_shape[1] * sub.sm_shape[2] : out_lens[id_][0];  // (Requant / Relu keep the length of their input)
     if (l.kind == L_REQUANT) { add_table({2, 0}); add_table({3, l.clamping_size()}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
     else if (l.kind == L_RELU) { add_table({0, 0}); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }
+    else if (l.kind == L_GELU) { TableType g{1, gelu_table_log2(l.gelu_multiplier)}; g.aux2 = l.gelu_multiplier; add_table(g); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }  // activation.rs:163-167
     else if (l.kind == L_LAYERNORM) { add_table({2, 0}); add_table(layernorm_table(l)); max_poly_len = std::max(max_poly_len, next_pow2(cur_len)); }  // layernorm.rs:587-618
     else if (l.kind == L_SOFTMAX) {  // softmax.rs:1205-1245
       add_table({2, 0}); add_table(softmax_table(l)); add_table(softmax_error_table(l));
@@ -869,12 +901,14 @@ static inline void instantiate_witness_ctx(ProverState& ps, const Trace& tr) {
       LogUpWitness ws; ws.is_table = false; ws.columns_per_instance = 1; ws.table_type = rt;
       for (auto& ch : chunks) { std::vector<u64> ev = to_base(ch); Mle mle = Mle::from_base(ev); ws.commits.push_back({pcs_commit(ctx.pp, mle), mle}); ws.column_evals.push_back(ev); }
       ps.lookup_witness[id] = {wc, ws};
-    } else if (l.kind == L_RELU) {
+    } else if (l.kind == L_RELU || l.kind == L_GELU) {
       TableType rt{0, 0};
-      const auto& a = tr.in[id]; const auto& b = tr.out[id];
+      if (l.kind == L_GELU) { rt = TableType{1, gelu_table_log2(l.gelu_multiplier)}; rt.aux2 = l.gelu_multiplier; }
+      std::vector<int64_t> a = tr.in[id]; const auto& b = tr.out[id];
+      if (l.kind == L_GELU) for (auto& v : a) v *= l.gelu_multiplier;  // (activation.rs:268-276: the looked-up element is the scaled input)
       for (size_t i = 0; i < a.size(); i++) count_into(element_count[rt], a[i] + COLUMN_SEPARATOR * b[i]);
       LogUpWitness w; w.is_table = false; w.columns_per_instance = 2; w.table_type = rt;
-      for (auto* col : {&a, &b}) { std::vector<u64> ev = to_base(*col); Mle mle = Mle::from_base(ev); w.commits.push_back({pcs_commit(ctx.pp, mle), mle}); w.column_evals.push_back(ev); }
+      for (const std::vector<int64_t>* col : {(const std::vector<int64_t>*)&a, &b}) { std::vector<u64> ev = to_base(*col); Mle mle = Mle::from_base(ev); w.commits.push_back({pcs_commit(ctx.pp, mle), mle}); w.column_evals.push_back(ev); }
       ps.lookup_witness[id] = {w};
     } else if (l.kind == L_LAYERNORM) {  // LayerNorm::lookup_witness (layernorm.rs:1103-1218)
       LayerNormData d; layernorm_op(l, tr.in[id], &d);
@@ -1255,18 +1289,24 @@ static inline SamePolyProof same_poly_prove(const std::vector<Claim>& claims, co
   auto [sp, st] = sumcheck_prove(std::move(vp), t);
   return {sp, st.final_evaluations()};
 }
-// Activation::prove_step (activation.rs:385-456), Relu only
-static inline Claim prove_relu(ProverState& ps, size_t id, const Claim& last, const std::vector<E>& output) {
+// Activation::prove_step (activation.rs:385-456). For a GELU the claim that leaves the step is the lookup's claim on the scaled column divided by the multiplier
+// (:405-413) — and, because that line re-binds `input_claim`, it is ALSO the claim the reference files with the commitment of the scaled column (:419-430),
+// where the verifier files the lookup's own claim (:495-505). g_gelu_files_lookup_claim = true files the lookup's claim instead (what a verifier can
+// check); false is the reference to the letter.
+static bool g_gelu_files_lookup_claim = false;
+static inline Claim prove_relu(ProverState& ps, size_t id, const Claim& last, const std::vector<E>& output, int64_t gelu_multiplier = 0) {
   std::vector<LogUpWitness> ws = ps.lookup_witness.at(id);
   LogUpInput in = ps.logup_input(ws[0]);
   LogUpProof lproof = logup_batch_prove(in, *ps.t);
   Claim input_claim = lproof.output_claims[0], output_claim = lproof.output_claims[1];
+  const Claim lookup_claim = input_claim;
+  if (gelu_multiplier) input_claim.eval = emul(input_claim.eval, einv(e_from_i64(gelu_multiplier)));
   SamePolyProof sp = same_poly_prove({last, output_claim}, Mle::from_ext(output), *ps.t);
   ActivationProof ap; ap.io_accumulation = sp; ap.lookup = lproof;
   Claim c2{sp.sumcheck.point, sp.evals[1]};
-  ps.add_witness_claim(ws[0].commits[0], input_claim); ap.commits.push_back(ws[0].commits[0].first.pure());
+  ps.add_witness_claim(ws[0].commits[0], gelu_multiplier && g_gelu_files_lookup_claim ? lookup_claim : input_claim); ap.commits.push_back(ws[0].commits[0].first.pure());
   ps.add_witness_claim(ws[0].commits[1], c2); ap.commits.push_back(ws[0].commits[1].first.pure());
-  LayerProof lp; lp.kind = L_RELU; lp.act = ap; ps.proofs[id] = lp;
+  LayerProof lp; lp.kind = gelu_multiplier ? L_GELU : L_RELU; lp.act = ap; ps.proofs[id] = lp;
   return input_claim;
 }
 
@@ -1704,6 +1744,7 @@ static inline Proof prove(const Context& ctx, const Trace& tr, Transcript& t) {
     else if (l.kind == L_POSITIONAL) cur = prove_positional(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_REQUANT) cur = prove_requant(ps, id, l, cur);
     else if (l.kind == L_RELU) cur = prove_relu(ps, id, cur, to_fields(tr.out[id]));
+    else if (l.kind == L_GELU) cur = prove_relu(ps, id, cur, to_fields(tr.out[id]), l.gelu_multiplier);
     else if (l.kind == L_LAYERNORM) cur = prove_layernorm(ps, id, l, cur, to_fields(tr.in[id]));
     else if (l.kind == L_SOFTMAX) cur = prove_softmax(ps, id, l, cur, tr.in[id]);
     else if (l.kind == L_CONV) cur = prove_conv(ps, id, l, cur, tr.conv[id]);
@@ -1780,7 +1821,7 @@ static inline std::vector<u64> serialize_proof(const Proof& p) {
     else if (lp.kind == L_REQUANT) {
       w.iop(lp.req.io_accumulation); w.ve(lp.req.accumulation_evals); w.logup(lp.req.clamping_lookup); w.logup(lp.req.shifted_lookup);
       w.u(lp.req.commitments.size()); for (auto& c : lp.req.commitments) w.comm(c);
-    } else if (lp.kind == L_RELU) {
+    } else if (lp.kind == L_RELU || lp.kind == L_GELU) {
       w.iop(lp.act.io_accumulation.sumcheck); w.ve(lp.act.io_accumulation.evals); w.logup(lp.act.lookup);
       w.u(lp.act.commits.size()); for (auto& c : lp.act.commits) w.comm(c);
     } else if (lp.kind == L_CONV) {

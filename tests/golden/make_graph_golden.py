@@ -38,8 +38,15 @@ CASES = [
     # the same layer at the size bench.py TIMES (section `transformer_layer`: 64 tokens x 256 features, 4 heads of 64, ffn 1024, config 66): ~16 s of oracle time,
     # 1.29 M proof words. `gpu_only`: the CPU suites (test_oracle, test_hostlogic) skip it; the GPU suite and the bench compare against this sha256.
     ("transformer_layer", dict(seq=64, emb=256, heads=4, head_dim=64, ffn=1024, config=66)),
+    # Activation::Gelu (layers/activation.rs:559-671). 15: the reference's own proving test (:686-697), one GELU over 32 entries: committed columns that small are
+    # opened by showing them, and the oracle runs TO THE LETTER of the reference (GELU_LITERAL below). 16 / 17: columns with a real opening — the reference's prover
+    # files a claim its verifier does not check there (:419-430 against :495-505), the oracle files the verifier's (oracle_lib.set_gelu_files_lookup_claim)
+    ("gelu_only", dict(n=32, config=111)),
+    ("gelu_mlp", dict(width=256, config=112)),
+    ("transformer_layer", dict(seq=8, emb=16, heads=2, head_dim=8, ffn=32, config=101, gelu=True)),
 ]
 GPU_ONLY = {14}
+GELU_LITERAL = {15}
 
 
 def sha(a):
@@ -56,11 +63,12 @@ if __name__ == "__main__":
     for ci, (name, kw) in enumerate(CASES):
         g = build(name, kw)
         blob, x = g.blob(), g.input()
+        o.set_gelu_files_lookup_claim(ci not in GELU_LITERAL)
         h = o.model_setup(blob)
         proof, y, _ = o.model_prove(h, x)
         o.model_free(h)
         assert y.size == g.run(x).size and (y == g.run(x)).all(), name
-        out.append(dict(model=name, args=kw, blob_sha256=sha(blob), input_sha256=sha(x), output_sha256=sha(y), proof_sha256=sha(proof), proof_words=int(proof.size), **({"gpu_only": True} if ci in GPU_ONLY else {})))
+        out.append(dict(model=name, args=kw, blob_sha256=sha(blob), input_sha256=sha(x), output_sha256=sha(y), proof_sha256=sha(proof), proof_words=int(proof.size), **({"gpu_only": True} if ci in GPU_ONLY else {}), **({"oracle_gelu_claim": "reference"} if ci in GELU_LITERAL else {})))
         print(name, kw, proof.size, "proof words")
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph_models.json"), "w") as f:
         json.dump(out, f, indent=1)

@@ -41,6 +41,7 @@ static orc::Model to_orc(const dp::ModelSpec& m) {
     for (int d = 0; d < 3; d++) { x.cm_a[d] = l.cm_a[d]; x.cm_b[d] = l.cm_b[d]; x.cm_left[d] = l.cm_left[d]; x.cm_right[d] = l.cm_right[d]; } x.cm_perm = l.cm_perm; x.nrows = l.nrows; x.ncols = l.ncols; x.weights = l.weights; x.bias = l.bias; x.transpose_b = l.mm_transpose; x.add_left = l.add_left; x.add_right = l.add_right; x.right_shift = l.right_shift; x.fp_scale = l.fp_scale; x.intermediate_bit_size = l.intermediate_bit_size; x.fixed_point_multiplier = l.fixed_point_multiplier;
     x.kw = l.kw; x.kx = l.kx; x.real_nw = l.real_nw; x.nw = l.nw; for (int k = 0; k < 3; k++) { x.unp_out[k] = l.unp_out[k]; x.pin[k] = l.pin[k]; }
     x.sm_scalar = l.sm_scalar; x.sm_bkm = l.sm_bkm; x.sm_allowable_error = l.sm_allowable_error; x.sm_temp_bits = l.sm_temp_bits; x.sm_in_scale_bits = l.sm_in_scale_bits; x.sm_table_size = l.sm_table_size; x.sm_zero_chunks = l.sm_zero_chunks; x.sm_zero_vars = l.sm_zero_vars; for (int k = 0; k < 3; k++) { x.sm_shape[k] = l.sm_shape[k]; x.mha_shape[k] = l.mha_shape[k]; }
+    if (l.kind == dp::L_GELU) x.gelu_multiplier = l.fixed_point_multiplier;
     x.ln_dim_size = l.ln_dim_size; x.ln_multiplier = l.ln_multiplier; x.ln_eps_bits = l.ln_eps_bits; x.ln_range_check_bits = l.ln_range_check_bits; x.ln_top_chunk_scalar_log = l.ln_top_chunk_scalar_log;
     o.layers.push_back(x); }
   return o;
@@ -139,6 +140,22 @@ static dp::ModelSpec graph_model(int variant, std::vector<int64_t>& in) {
     dp::LayerSpec ad; ad.kind = dp::L_ADD2; ad.add_left = 1; ad.add_right = 5; ad.inputs = {edge(1), edge(-1, 1)};
     m.layers = {q, mh, ad};
     in.resize(m.input_len); for (auto& x : in) x = small();
+  } else if (variant >= 11 && variant <= 13) {
+    // Activation::Gelu (layers/activation.rs). 11: the reference's own test shape (test_activation_gelu_proving, :686-697: one GELU over a [3][5] input, padded
+    // here to 32 entries — committed columns of 2^5 entries are opened by showing them); 12: 256 entries, a real batch opening of the scaled column;
+    // 13: Dense -> Requant -> GELU -> Dense -> Requant with the multiplier of another input scale (45: a table of 2^14 rows)
+    dp::LayerSpec g; g.kind = dp::L_GELU; g.fixed_point_multiplier = variant == 13 ? 45 : 32;  // round(2^12 * input scale), input scale 1 / 128 resp. ~1.4 / 128
+    if (variant == 13) {
+      const size_t W = 64;
+      m.input_len = 4;
+      m.layers = {dense(W, 4), requant_for(4, 0.5 / 127), g, dense(4, W), requant_for(W, 1.0 / std::sqrt((double)W) / 127)};
+      in = {rq(), rq(), rq(), rq()};
+    } else {
+      m.input_len = variant == 11 ? 32 : 256;
+      m.layers = {g};
+      in.assign(m.input_len, 0);
+      for (size_t i = 0; i < m.input_len; i++) if (variant == 12 || (i % 8 < 5 && i / 8 < 3)) in[i] = rq();
+    }
   } else if (variant == 5 || variant == 6) {
     // LayerNorm over the last dimension of a [rows][dim] tensor, then the shift-only Requant the reference puts behind it (layernorm.rs:140-257,
     // 473-513) and a ReLU. Variant 6: N = 12 of a padded dimension of 16 (the padding of input, gamma and beta is zero).
@@ -526,6 +543,7 @@ int main(int argc, char** argv) {
     in = {rq(), rq(), rq(), rq()};
   }
   // oracle
+  orc::g_gelu_files_lookup_claim = !getenv("HL_GELU_LITERAL");  // (HL_GELU_LITERAL=1: the claim activation.rs:419-430 files with the scaled column's commitment, to the letter)
   auto t0 = std::chrono::steady_clock::now();
   orc::Context octx = orc::context_generate(to_orc(m));
   orc::Transcript ot = orc::default_transcript();

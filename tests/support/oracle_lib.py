@@ -71,6 +71,10 @@ class Oracle:
     def __init__(self, lib):
         self.lib = lib
 
+    def set_gelu_files_lookup_claim(self, on):
+        """False (the library's default): a GELU's prover files the claim the reference files (activation.rs:419-430); True: the claim its verifier checks"""
+        self.lib.orc_set_gelu_files_lookup_claim(C.c_int(1 if on else 0))
+
     def _ok(self, rc):
         if rc != 0:
             raise RuntimeError("oracle: " + self.lib.orc_last_error().decode())

@@ -10,13 +10,26 @@ import pytest
                                           # the lookup-table semantics the oracle and the product share as TEXT (softmax / inverse-square-root tables, the FFT convolution):
                                           # models.py restates them in numpy from the reference (softmax.rs:153-345,455-566; layernorm.rs; convolution.rs) — a third reading
                                           ("cnn_264k", (), {}), ("transformer_layer", (16, 64, 4, 16, 128), dict(config=65)), ("transformer_layer", (64, 256, 4, 64, 1024), dict(config=66)),
-                                          ("attention_block", (16, 64, 4, 16), dict(config=64))])
+                                          ("attention_block", (16, 64, 4, 16), dict(config=64)),
+                                          ("gelu_mlp", (256,), dict(config=112)), ("transformer_layer", (16, 64, 4, 16, 128), dict(config=65, gelu=True))])
 def test_library_inference_equals_numpy(name, args, kw):
     import deep_prove_amd as dpa
     mb = getattr(dpa.models, name)(*args, **kw)
     for idx in (1000, 1001):
         x = mb.input(idx)
         assert (dpa.infer_host(mb.blob(), x) == mb.run(x)).all()
+
+
+def test_gelu_table_on_every_input_of_the_quantised_range():
+    """the library's inference of a GELU over all of -128 .. 127 equals models.gelu_apply (f32 after every operation, the C library's tanhf) for the
+    multipliers of four input scales — a table of 2^13, 2^14 and 2^20 rows among them"""
+    import deep_prove_amd as dpa
+    x = np.arange(256, dtype=np.int64) - 128
+    for scale in (1.0 / 128.0, 1.4 / 128.0, 1.0 / 4096.0 * 3, 1.0):
+        mb = dpa.models.gelu_only(256, config=113, in_scale=scale)
+        m = mb.layers[0]["multiplier"]
+        xs = x if -128 * m >= -(1 << (7 + (m - 1).bit_length())) else np.clip(x, -127, 127)
+        assert (dpa.infer_host(mb.blob(), xs) == mb.run(xs)).all(), scale
 
 
 def test_large_inputs_take_the_64_bit_path():

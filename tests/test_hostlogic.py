@@ -1,6 +1,7 @@
 """Host logic of the product (transcript order, claim routing, proof assembly, verifier) checked WITHOUT a GPU: the
 orchestrator of deep-prove_amd/csrc runs over the CPU test double of tests/support/cpu_dev.hpp and is byte-compared with
 the oracle; the product verifier must accept both proofs and reject tampered ones."""
+import os
 import subprocess
 
 import pytest
@@ -271,12 +272,13 @@ def _graph_golden():
         return json.load(f)
 
 
-@pytest.mark.parametrize("case", [0, 2, 4, 6, 8, 11, 13])  # (a model of every kind; the others run on the GPU, tests/test_gpu_model.py)
+@pytest.mark.parametrize("case", [0, 2, 4, 6, 8, 11, 13, 15, 16, 17])  # (a model of every kind; the others run on the GPU, tests/test_gpu_model.py)
 def test_golden_graph_blobs_through_the_products_blob_parser_on_the_cpu_double(hostlogic_bin, tmp_path, case):
     """every model of tests/golden/graph_models.json as dp_model_setup receives it: the int64 blob models.py writes, read by the product's own
     parser (csrc/blob.h, the one behind the C ABI) and proved by the product's orchestrator over the CPU double, gives the oracle's stream (whose
     sha256 the golden pins, tests/test_oracle.py) word for word; the verifier, fed from the serialised verifier context, accepts it and refuses a
-    flipped word. Cases 11 / 12: the Mha node; 13: a whole transformer layer (19 nodes)."""
+    flipped word. Cases 11 / 12: the Mha node; 13: a whole transformer layer (19 nodes); 15 - 17: Activation::Gelu (15: the reference's own test
+    shape, the oracle to the letter of the reference's prover; 16 / 17: with the claim the reference's VERIFIER checks, see test_gelu_* below)."""
     import subprocess
     import numpy as np
     import deep_prove_amd as dpa
@@ -285,13 +287,45 @@ def test_golden_graph_blobs_through_the_products_blob_parser_on_the_cpu_double(h
     bp, ip = tmp_path / "model.blob", tmp_path / "input.bin"
     g.blob().astype(np.int64).tofile(bp)
     g.input().astype(np.int64).tofile(ip)
-    r = subprocess.run([hostlogic_bin, "blob", str(bp), str(ip)], capture_output=True, text=True, timeout=900)
+    env = dict(os.environ, HL_GELU_LITERAL="1") if c.get("oracle_gelu_claim") == "reference" else dict(os.environ)
+    r = subprocess.run([hostlogic_bin, "blob", str(bp), str(ip)], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert f"oracle words={c['proof_words']} product words={c['proof_words']} identical=1" in r.stdout, r.stdout
     assert "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
     if case >= 11:
         r = subprocess.run([hostlogic_bin, "blob", str(bp), str(ip), "@77"], capture_output=True, text=True, timeout=900)
         assert "verify(oracle,tampered): REJECT" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("variant", [11, 12, 13])
+def test_gelu_proof_stream_identical_to_oracle_and_accepted(hostlogic_bin, variant):
+    """Activation::Gelu (zkml/src/layers/activation.rs:238-318 witness, :385-456 prove_step, :459-517 verify_activation; the table of
+    lookup/context.rs:163-182, 364-378, 495-503): 11 = the reference's own proving test (one GELU over a small tensor), 12 = 256 entries, 13 = Dense ->
+    Requant -> GELU (multiplier 45, a table of 2^14 rows) -> Dense -> Requant. Product stream over the CPU double = the oracle's, both accepted."""
+    r = run(hostlogic_bin, "graph", variant, 5)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical=1" in r.stdout and "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout
+
+
+def test_gelu_to_the_letter_of_the_reference_only_verifies_when_the_column_is_shown(hostlogic_bin):
+    """The reference's GELU prover hands its commitment prover the lookup claim DIVIDED by the multiplier (activation.rs:405-430: `input_claim` is re-bound
+    before the `commits` array is built) where its verifier files the lookup's own claim (:495-505). With the oracle to the letter (HL_GELU_LITERAL=1):
+    variant 11 — columns of 2^5 entries, opened by showing them (Basefold::open ignores the evaluation, mpcs/src/basefold.rs:466-483) — is the product's
+    stream word for word and verifies; variant 12 — 2^8 entries, a batch opening that starts from the claimed evaluations (basefold.rs:601-685) — differs
+    from the product's stream and the verifier refuses it, while the product's own proof of the same model is accepted."""
+    env = dict(os.environ, HL_GELU_LITERAL="1")
+    r = subprocess.run([hostlogic_bin, "graph", "11", "5"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "identical=1" in r.stdout and "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([hostlogic_bin, "graph", "12", "5"], capture_output=True, text=True, timeout=900, env=env)
+    assert "identical=0" in r.stdout and "verify(oracle): REJECT" in r.stdout and "verify(product): ACCEPT" in r.stdout, r.stdout + r.stderr
+
+
+def test_gelu_layer_proofs_reject_every_flipped_word(hostlogic_bin):
+    """every third word of the first 6000 of a GELU proof (variant 13: the activation's lookup, its accumulation sumcheck, the table proof with the
+    committed output column) flipped, each through the full verifier: all refused"""
+    r = subprocess.run([hostlogic_bin, "graph", "13", "11"], capture_output=True, text=True, timeout=900, env=dict(os.environ, DP_FLIP_SWEEP="2:6000:3"))
+    assert "accepted at:\n" in r.stdout or r.stdout.rstrip().endswith("accepted at:"), r.stdout[-600:]
+    assert "flip sweep:" in r.stdout
 
 
 def test_malformed_model_blobs_are_refused_by_the_products_parser(hostlogic_bin, tmp_path):
