@@ -1617,7 +1617,7 @@ class HipDev : public Dev {
   // Layers with at most lp_max_ parent nodes use the 8-lanes-per-node kernel (lowest latency per layer, but ~2.2x the
   // VALU work of one node per lane and a grid 8x as large: with many proofs in flight those grids fill the chip and
   // every other stream queues behind them), wider layers hash one node per lane.
-  size_t lp_max_ = [] { const char* e = getenv("DP_LP_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : size_t(1) << 12; }();  // (latency mode; DP_LP_MAX to sweep it)
+  size_t lp_max_ = [] { const char* e = getenv("DP_LP_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : size_t(1) << 16; }();  // (latency mode: one proof has the chip to itself, a 2^16-parent layer is one pass of 8-lane groups at the latency of two permutations instead of a one-lane compress; 2^12 -> 2^16: CNN-264k 57.6 -> 55.0 ms, Dense-4M ~ -1 ms, tools/r05/call28.sh)
   // ... in THROUGHPUT mode the launch of a layer is merged over the ~20 members of a cohort: 20 x 1024 parents fill the chip with one node per lane, and
   // the 8-lane form's 2.2x VALU work is paid for nothing (k_merkle_layer_lp was 35 % of the Merkle kernel time of the cohort regime for ~10 % of the
   // nodes: profiles/r05_bench448_kernel_stats_lds_msgs.csv). DP_LP_MAX_TP (default 512): the widest layer that still takes the 8-lane kernel there.

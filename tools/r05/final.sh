@@ -51,6 +51,16 @@ f=$(find $o/sq -name '*_results.db' | head -1); g=$(find $o/sqp -name '*_results
 [ -n "$f" ] && python tools/pmc_sq_job.py "$f" 896 "$rate" $o/r05_pmc_sq_bench448.json "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -- python tools/profile_batch.py dense_4m 448 (cohort launches of the two 448-proof batches; final build of round 5)" "$g" 2097152 > $o/pmc_sq.txt 2>&1 && cp $o/r05_pmc_sq_bench448.json profiles/
 head -6 $o/pmc_sq.txt | cut -c1-250
 find $o -name '*.db' -size +2M -delete
+step "single-proof latency A/B (after a warm-up process: the first GPU process of a box runs ~4 ms slower)"
+timeout -s KILL 200 python tools/archive/latency_probe.py > $o/lat_warmup.txt 2>&1
+for rep in 1 2; do
+  timeout -s KILL 200 python tools/archive/latency_probe.py > $o/lat_default_$rep.txt 2>&1; echo "default:            $(grep -E 'proof [3-5]' $o/lat_default_$rep.txt | sed 's/.*library //' | tr '\n' ' ')"
+  DP_LP_MAX=4096 timeout -s KILL 200 python tools/archive/latency_probe.py > $o/lat_lp4096_$rep.txt 2>&1; echo "DP_LP_MAX=4096:     $(grep -E 'proof [3-5]' $o/lat_lp4096_$rep.txt | sed 's/.*library //' | tr '\n' ' ')"
+  DP_MAILBOX_VRAM=0 timeout -s KILL 200 python tools/archive/latency_probe.py > $o/lat_hostmail_$rep.txt 2>&1; echo "DP_MAILBOX_VRAM=0:  $(grep -E 'proof [3-5]' $o/lat_hostmail_$rep.txt | sed 's/.*library //' | tr '\n' ' ')"
+done
+timeout -s KILL 200 python tools/archive/latency_probe.py cnn_264k > $o/lat_cnn.txt 2>&1; echo "cnn_264k default:   $(grep -E 'proof [3-5]' $o/lat_cnn.txt | sed 's/.*library //' | tr '\n' ' ')"
+DP_TIMING=2 timeout -s KILL 200 python tools/archive/latency_probe.py > $o/lat_t2.txt 2>&1; grep -E "sc-debug|sumcheck rounds" $o/lat_t2.txt | tail -2 | cut -c1-260
+( for f in default_1 lp4096_1 hostmail_1 default_2 lp4096_2 hostmail_2; do echo "$f: $(grep -E 'proof [3-5]' $o/lat_$f.txt | sed 's/.*library //' | tr '\n' ' ')"; done; echo "cnn_264k: $(grep -E 'proof [3-5]' $o/lat_cnn.txt | sed 's/.*library //' | tr '\n' ' ')"; grep -E "sc-debug|sumcheck rounds" $o/lat_t2.txt | tail -2 ) > $o/r05_latency_ab.txt
 step "bench"
 timeout -s KILL 1500 python bench.py > $o/bench.json 2> $o/bench.err; echo "bench rc=$?"; tail -3 $o/bench.err | cut -c1-300
 python - <<'PY'
