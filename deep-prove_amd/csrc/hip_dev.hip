@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <sched.h>
 #include <unistd.h>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -510,6 +511,7 @@ class HipDev : public Dev {
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) throw DpError(DP_ERR_NODEVICE, "no HIP device available: the MI355X path is mandatory, there is no CPU fallback");
     DP_REQUIRE(device >= 0 && device < cnt, DP_ERR_ARG, "bad device id");
     HIP_CHECK(hipSetDevice(device));
+    numa_pin_(device);
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device));
     name_ = std::string("hip:") + prop.name + ":" + prop.gcnArchName;
@@ -958,6 +960,40 @@ class HipDev : public Dev {
   // PCIe write, the kernel polls its own HBM. Set up at the first host-driven session of a context (throughput-mode workers
   // never get here); checked, not assumed: the page must be CPU-writable (probed through a pipe, no fault) and a kernel must read
   // back two successive CPU writes. DP_MAILBOX_VRAM=0 keeps the mailbox in host memory.
+  // Keep the calling thread (and the threads it creates later: the cohort threads, the engine) on the CPUs of the GPU's own NUMA node. Every Fiat-Shamir round
+  // of a single proof crosses PCIe twice; from the other socket of a two-socket host each crossing also crosses the socket interconnect: one Dense-4M proof
+  // 34.7 ms from node 0 against 30.7 ms from the GPU's node 1, four processes each (profiles/r05_numa_latency.txt). The affinity is only ever NARROWED, to the
+  // intersection of what the thread may use with the node's CPUs (/sys/bus/pci/devices/<bdf>/local_cpulist), and left alone when that is empty, when the
+  // thread is already confined to the node, or with DP_NUMA_PIN=0.
+  static void numa_pin_(int device) {
+    if (getenv("DP_NUMA_PIN") && !atoi(getenv("DP_NUMA_PIN"))) return;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf) - 1, device) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (char* c = bdf; *c; c++) *c = (char)tolower(*c);
+    std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/local_cpulist";
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return;
+    char line[4096] = {0};
+    const bool got = fgets(line, sizeof(line), f) != nullptr;
+    fclose(f);
+    if (!got) return;
+    cpu_set_t local; CPU_ZERO(&local);
+    for (char* q = line; *q && *q != '\n';) {  // "64-127,192-255"
+      char* e = nullptr;
+      long a = strtol(q, &e, 10); if (e == q) break;
+      long b = a;
+      if (*e == '-') { q = e + 1; b = strtol(q, &e, 10); if (e == q) break; }
+      for (long c = a; c <= b && c < CPU_SETSIZE; c++) if (c >= 0) CPU_SET((int)c, &local);
+      q = *e == ',' ? e + 1 : e;
+      if (*e != ',') break;
+    }
+    cpu_set_t cur; CPU_ZERO(&cur);
+    if (sched_getaffinity(0, sizeof(cur), &cur) != 0) return;
+    cpu_set_t both; CPU_AND(&both, &cur, &local);
+    const int nb = CPU_COUNT(&both), nc = CPU_COUNT(&cur);
+    if (nb == 0 || nb == nc) return;
+    if (sched_setaffinity(0, sizeof(both), &both) == 0 && g_timing_level) fprintf(stderr, "[dp] host thread kept on the %d CPUs of the GPU's NUMA node (%s: %s)\n", nb, bdf, strtok(line, "\n"));
+  }
   static bool cpu_can_write_(void* p) {
     int fd[2];
     if (pipe(fd) != 0) return false;

@@ -57,10 +57,11 @@ for rep in 1 2; do
   timeout -s KILL 200 python tools/archive/latency_probe.py > $o/lat_default_$rep.txt 2>&1; echo "default:            $(grep -E 'proof [3-5]' $o/lat_default_$rep.txt | sed 's/.*library //' | tr '\n' ' ')"
   DP_LP_MAX=4096 timeout -s KILL 200 python tools/archive/latency_probe.py > $o/lat_lp4096_$rep.txt 2>&1; echo "DP_LP_MAX=4096:     $(grep -E 'proof [3-5]' $o/lat_lp4096_$rep.txt | sed 's/.*library //' | tr '\n' ' ')"
   DP_MAILBOX_VRAM=0 timeout -s KILL 200 python tools/archive/latency_probe.py > $o/lat_hostmail_$rep.txt 2>&1; echo "DP_MAILBOX_VRAM=0:  $(grep -E 'proof [3-5]' $o/lat_hostmail_$rep.txt | sed 's/.*library //' | tr '\n' ' ')"
+  DP_NUMA_PIN=0 timeout -s KILL 200 python tools/archive/latency_probe.py > $o/lat_nopin_$rep.txt 2>&1; echo "DP_NUMA_PIN=0:      $(grep -E 'proof [3-5]' $o/lat_nopin_$rep.txt | sed 's/.*library //' | tr '\n' ' ')"
 done
 timeout -s KILL 200 python tools/archive/latency_probe.py cnn_264k > $o/lat_cnn.txt 2>&1; echo "cnn_264k default:   $(grep -E 'proof [3-5]' $o/lat_cnn.txt | sed 's/.*library //' | tr '\n' ' ')"
 DP_TIMING=2 timeout -s KILL 200 python tools/archive/latency_probe.py > $o/lat_t2.txt 2>&1; grep -E "sc-debug|sumcheck rounds" $o/lat_t2.txt | tail -2 | cut -c1-260
-( for f in default_1 lp4096_1 hostmail_1 default_2 lp4096_2 hostmail_2; do echo "$f: $(grep -E 'proof [3-5]' $o/lat_$f.txt | sed 's/.*library //' | tr '\n' ' ')"; done; echo "cnn_264k: $(grep -E 'proof [3-5]' $o/lat_cnn.txt | sed 's/.*library //' | tr '\n' ' ')"; grep -E "sc-debug|sumcheck rounds" $o/lat_t2.txt | tail -2 ) > $o/r05_latency_ab.txt
+( for f in default_1 lp4096_1 hostmail_1 nopin_1 default_2 lp4096_2 hostmail_2 nopin_2; do echo "$f: $(grep -E 'proof [3-5]' $o/lat_$f.txt | sed 's/.*library //' | tr '\n' ' ')"; done; echo "cnn_264k: $(grep -E 'proof [3-5]' $o/lat_cnn.txt | sed 's/.*library //' | tr '\n' ' ')"; grep -E "sc-debug|sumcheck rounds" $o/lat_t2.txt | tail -2 ) > $o/r05_latency_ab.txt
 step "bench"
 timeout -s KILL 1500 python bench.py > $o/bench.json 2> $o/bench.err; echo "bench rc=$?"; tail -3 $o/bench.err | cut -c1-300
 python - <<'PY'
