@@ -12,11 +12,13 @@
 //! kind, #in, (node, slot).., parameters. Node ids are renumbered to positions in `to_forward_iterator()` order (a node only reads earlier ones).
 use std::collections::HashMap;
 
+use anyhow::anyhow;
+
 use deep_prove_hip_sys as sys;
 
 use crate::{
     Element,
-    layers::{Layer, matrix_mul::OperandMatrix, pooling::Pooling, provable::{Edge, NodeId}, transformer::positional::Positional},
+    layers::{Layer, activation::Activation, matrix_mul::OperandMatrix, pooling::Pooling, provable::{Edge, NodeId}, transformer::positional::Positional},
     model::Model,
     tensor::Tensor,
 };
@@ -38,6 +40,7 @@ pub const KIND_QKV: i64 = 13;
 pub const KIND_LAYERNORM: i64 = 14;
 pub const KIND_SOFTMAX: i64 = 15;
 pub const KIND_MHA: i64 = 16;
+pub const KIND_GELU: i64 = 17;
 
 #[derive(Debug)]
 pub enum BlobError { Unsupported(String), Shape(String), Ffi(sys::DpError) }
@@ -86,7 +89,11 @@ pub fn model_to_blob(model: &Model<Element>) -> Result<Vec<i64>, BlobError> {
                 head(&mut w, KIND_DENSE); w.extend([s[0] as i64, s[1] as i64]); w.extend(data(&d.matrix)); w.extend(data(&d.bias));
             }
             Layer::Requant(r) => { head(&mut w, KIND_REQUANT); w.extend([r.right_shift as i64, r.fp_scale as i64, r.fixed_point_multiplier as i64, r.intermediate_bit_size as i64]); }
-            Layer::Activation(_) => head(&mut w, KIND_RELU),  // (Activation::Relu is the only provable one: GELU's prover and verifier disagree)
+            // Activation::Gelu: one word, GELUQuantData::multiplier (layers/activation.rs:565-572; the field is private there: this patch adds
+            // `pub(crate) fn multiplier(&self) -> Element` next to table_size() and `pub(crate) fn quant_data(&self) -> Option<&GELUQuantData>` on GELU). The library opens the scaled column at the claim verify_activation
+            // files (:495-505), not at the divided one the reference's prove_step files (:405-430), so its proofs verify at every size.
+            Layer::Activation(Activation::Relu(_)) => head(&mut w, KIND_RELU),
+            Layer::Activation(Activation::Gelu(g)) => { head(&mut w, KIND_GELU); w.push(g.quant_data().ok_or_else(|| anyhow!("GELU not quantized"))?.multiplier() as i64); }
             Layer::Flatten(_) | Layer::Reshape(_) => head(&mut w, KIND_FLATTEN),  // tensors cross the ABI flat: the claim passes through
             Layer::Convolution(c) => {  // [3, kw, kx, kernel side, input side, unpadded output shape (3), filter, bias]: needs the UN-FFTed padded filter,
                 // `Convolution::padded_filter()` (the quantised op keeps the FFT, convolution.rs:52-60; the library transforms the kernels itself)

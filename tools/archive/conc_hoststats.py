@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np
 import deep_prove_amd as dpa
 conc = int(sys.argv[1])
-dev = dpa.Device(0); mb = dpa.models.dense_4m(); ctx = dpa.Context.generate(dev, mb.blob()); pr = dpa.Prover(ctx)
+dev = dpa.Device(0); mb = getattr(dpa.models, sys.argv[2] if len(sys.argv) > 2 else 'dense_4m')(); ctx = dpa.Context.generate(dev, mb.blob()); pr = dpa.Prover(ctx)
 xs = np.stack([mb.input(3000 + i) for i in range(4 * conc)])
 pr.prove(xs[0])  # the arena of a worker follows the footprint of a proof already proved
 pr.prove_batch(xs[:conc], conc)
