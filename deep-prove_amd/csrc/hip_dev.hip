@@ -1762,9 +1762,7 @@ class HipDev : public Dev {
       hd[q].evals = ev.p; hd[q].cw = cws[q].p; hd[q].bh = bhs[q].p; hd[q].nodes = (u64*)nodes[q].p; hd[q].tmp = tmp.p;
       td[q].nodes = (u64*)nodes[q].p; td[q].off = off; td[q].cnt = cnt;
     }
-    static const bool med_split = !(getenv("DP_MED_SPLIT") && !atoi(getenv("DP_MED_SPLIT")));
-    const unsigned split = med_split && nv > MED_NTT_LG ? nv - MED_NTT_LG : 0;  // at most 64 KB of LDS per workgroup (kernels.inc)
-    nb_ = g * 32.0 * n; DPL_LDS(k_med_prepare, dim3((unsigned)(g << split)), dim3(1024), (n >> split) * 8, dd, nv, L_, (const u64*)pow7_, split);
+    nb_ = g * 32.0 * n; DPL_LDS(k_med_prepare, dim3((unsigned)g), dim3(1024), n * 8, dd, nv, L_, (const u64*)pow7_);
     unsigned lgblk = std::min<unsigned>(nv + 1, MED_NTT_LG), smax = std::min<unsigned>(nv, lgblk - 1);
     nb_ = g * 32.0 * n; DPL_LDS(k_med_ntt_local, dim3((unsigned)(N >> lgblk), (unsigned)g), dim3(1024), (size_t(1) << lgblk) * 8, dd, lgblk, smax, (const u64*)tw_, L_);
     for (unsigned st = smax + 1; st <= nv; st++) { nb_ = g * 32.0 * n; DPL(k_ntt_stage_many, dim3(grid_for(n, 64), (unsigned)g), dim3(TPB), dd, N, st, (const u64*)tw_, L_); }
