@@ -75,6 +75,11 @@ constexpr int LAT_MAXT = DP_LAT_MAXT;
 // `lds` = dynamic LDS the body really needs.
 #define DPL_ONE(kern, grid, threads, lds, ...) do { if (shared_now()) { DPL_B(kern, SHARED_MAXT, KF_PRIO, grid, dim3(std::min<unsigned>((unsigned)(threads), (unsigned)shared_threads_)), (size_t)(lds), __VA_ARGS__); } \
                                                      else { DPL_B(kern, LAT_MAXT, KF_CLAIM, grid, dim3(std::min<unsigned>((unsigned)(threads), (unsigned)LAT_MAXT)), std::max<size_t>((size_t)(lds), excl_now()), __VA_ARGS__); } } while (0)
+// ... and a WIDE throughput-mode form for the few one-workgroup launches whose table passes dominate (a lookup over 2^13 .. 2^16 rows: 3.8 ms of table passes
+// against 0.3 ms for a 2^10-row column at 256 threads, profiles/r05_wgphases_448_summary.txt): WIDE_MAXT threads, still no reservation, the sponge wave unchanged
+constexpr int WIDE_MAXT = 512;
+#define DPL_ONE_W(kern, wide, grid, threads, lds, ...) do { if ((wide) && shared_now()) { DPL_B(kern, WIDE_MAXT, KF_PRIO, grid, dim3(std::min<unsigned>((unsigned)(threads), (unsigned)WIDE_MAXT)), (size_t)(lds), __VA_ARGS__); } \
+                                                           else { DPL_ONE(kern, grid, threads, lds, __VA_ARGS__); } } while (0)
 #define DPL_ONE_HI(kern, hi, grid, threads, lds, ...) do { if (hi) { DPL_ONE((kern<true>), grid, threads, lds, __VA_ARGS__); } else { DPL_ONE((kern<false>), grid, threads, lds, __VA_ARGS__); } } while (0)
 #define DPL_HI(kern, hi, grid, block, ...) do { if (hi) { DPL((kern<true>), grid, block, __VA_ARGS__); } else { DPL((kern<false>), grid, block, __VA_ARGS__); } } while (0)
 #define DPL_LDS_HI(kern, hi, grid, block, lds, ...) do { if (hi) { DPL_LDS((kern<true>), grid, block, lds, __VA_ARGS__); } else { DPL_LDS((kern<false>), grid, block, lds, __VA_ARGS__); } } while (0)
@@ -560,7 +565,7 @@ class HipDev : public Dev {
     DP_SET_LDS_ONE((k_sc_small<false>), 1024, (int)EXCL_LDS);
     DP_SET_LDS_ONE((k_sc_small<true>), 1024, (int)EXCL_LDS);
     DP_SET_LDS_ONE(k_merkle_tail, 1024, (int)EXCL_LDS);
-    if (devlogup_ || devlogup_full_) DP_SET_LDS_ONE(k_logup_tail, 1024, 128 * 1024);  // (logup_tail.h: logup_tail_lds_bytes)
+    if (devlogup_ || devlogup_full_) { DP_SET_LDS_ONE(k_logup_tail, 1024, 128 * 1024); set_lds_<k_logup_tail, WIDE_MAXT, KF_PRIO>(KArgs<decltype(&k_logup_tail)>(), 128 * 1024); }  // (logup_tail.h: logup_tail_lds_bytes)
     if (devclassic_) DP_SET_LDS_ONE(k_classic_tail, 1024, (int)EXCL_LDS);
     if (devdense_) DP_SET_LDS_ONE(k_dense_tail, 1024, (int)EXCL_LDS);
     if (deveqsum_) DP_SET_LDS_ONE(k_eqsum_tail, 1024, (int)EXCL_LDS);
@@ -1303,6 +1308,7 @@ class HipDev : public Dev {
   // ---- Dev::logup_full: DP_DEVICE_LOGUP=2 (the default): k_logup_tail in full mode — one launch and one device wait per
   // logup-GKR batch proof
   bool devlogup_full_ = knob("DP_DEVICE_LOGUP", 2) == 2;
+  size_t logup_wide_n_ = (size_t)knob("DP_LOGUP_WIDE_N", 2048);  // lookups of at least this many rows take the 512-thread form in throughput mode (0: never)
   bool logup_full(const DBuf* cols, int cpi, int ninst, const DBuf& mult, Ext c, Ext chi, Challenger& ch, LogupFullOut& out) override {
     if (!devlogup_full_ || !devfs_ || !persist_ || !zerocopy_ || sess_.active || prof_) return false;
     size_t n = 0;
@@ -1318,7 +1324,7 @@ class HipDev : public Dev {
     SpongeArm sponge(this, d, ch);
     const unsigned long long seq = ++seq_;
     nb_ = (double)ninst * (8.0 * cpi * n + 16.0 * 3 * n) * 2.0;
-    DPL_ONE(k_logup_tail, dim3(1), 1024, (size_t)d->lds_ext * 16 + ((nwords * 8 + 15) & ~size_t(15)), dd, (u64*)hres_dev_, hflag_dev_, seq);  // (table slots + the message, assembled in LDS)
+    DPL_ONE_W(k_logup_tail, logup_wide_n_ && n >= logup_wide_n_, dim3(1), 1024, (size_t)d->lds_ext * 16 + ((nwords * 8 + 15) & ~size_t(15)), dd, (u64*)hres_dev_, hflag_dev_, seq);  // (table slots + the message, assembled in LDS)
     wait_flag_blocks(seq, blocks);
     sponge.done();
     logup_full_parse(hres_, n, cpi, ninst, !mult.null(), blocks, ch, out);
