@@ -180,6 +180,9 @@ def table_column_evals(kind, size, point):
         for k, p in enumerate(point[:-1]):
             second = add(second, mul(mul(p, fe(1 << k)), point[-1]))
         return [sub(idx, fe(1 << (BIT_LEN - 1))), second]
+    if kind == "gelu":  # the input column min .. max - 1 with min = -2^(size - 1); the output column is a commitment (context.rs:364-378)
+        assert len(point) == size[1]
+        return [sub(idx, fe(1 << (size[1] - 1)))]
     if kind == "softmax":  # the input column; the output column is a commitment (context.rs:409-423)
         assert len(point) == size[1]
         return [idx]
@@ -202,7 +205,7 @@ def table_column_evals(kind, size, point):
 
 def table_order_key(t):
     """derive(Ord) of lookup/context.rs:52-72: Relu < GELU < Range < Clamping(n) < ..."""
-    return ({"relu": 0, "range": 2, "clamping": 3, "softmax": 4, "error": 5, "zero": 6, "inv_sqrt": 7}[t[0]], t[1])
+    return ({"relu": 0, "gelu": 1, "range": 2, "clamping": 3, "softmax": 4, "error": 5, "zero": 6, "inv_sqrt": 7}[t[0]], t[1])
 
 
 def verify_chain(layers, model_roots, tree, x, y, label=b"m2vec"):
@@ -366,6 +369,8 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
             tables.add(("clamping", n["clamping_size"]))
         elif n["kind"] == "relu":
             tables.add(("relu", 0))
+        elif n["kind"] == "gelu":  # TableType::GELU(GELUQuantData {multiplier, min, max}) (activation.rs:163-167): (multiplier, log2 of the table length)
+            tables.add(("gelu", (n["multiplier"], 8 + (n["multiplier"] - 1).bit_length())))
         elif n["kind"] == "maxpool":
             tables.add(("range", 0))
         elif n["kind"] == "layernorm":
@@ -382,7 +387,7 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
     if tables:
         constant = challenge(tr, b"table_constant")
         for t in tables:
-            chmap[t] = ONE if t[0] in ("range", "error") else challenge(tr, {"relu": b"Relu", "clamping": b"Clamping", "inv_sqrt": b"InverseSQRT", "softmax": b"Softmax", "zero": b"Zero"}[t[0]])
+            chmap[t] = ONE if t[0] in ("range", "error") else challenge(tr, {"relu": b"Relu", "gelu": b"GELU", "clamping": b"Clamping", "inv_sqrt": b"InverseSQRT", "softmax": b"Softmax", "zero": b"Zero"}[t[0]])
     steps = {node: (kind, lp) for node, kind, lp in tree["steps"]}
     nums, dens = [], []
 
@@ -396,7 +401,7 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
         if n["kind"] == "requant":
             fractions(steps[nid][1]["clamping_lookup"])
             fractions(steps[nid][1]["shifted_lookup"])
-        elif n["kind"] in ("relu", "maxpool"):
+        elif n["kind"] in ("relu", "gelu", "maxpool"):
             fractions(steps[nid][1]["lookup"])
         elif n["kind"] in ("layernorm", "softmax"):
             for lg in steps[nid][1]["logup_proofs"]:
@@ -809,12 +814,16 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
             in_claims = [{"point": sc_point + rows[w], "eval": ic[2 * w]} for w in range(3)]
             in_len = n["seq"] * n["nrows"]
             made[nid] = [same_poly_verify(in_claims, lp["aggregation_proof"], in_len.bit_length() - 1, tr)]
-        elif n["kind"] == "relu":  # layers/activation.rs:459-517
-            claims, _, _ = verify_logup(lp["lookup"], 1, constant, chmap[("relu", 0)], tr)
+        elif n["kind"] in ("relu", "gelu"):  # ActivationCtx::verify_activation (layers/activation.rs:459-517)
+            t = ("relu", 0) if n["kind"] == "relu" else ("gelu", (n["multiplier"], 8 + (n["multiplier"] - 1).bit_length()))
+            claims, _, _ = verify_logup(lp["lookup"], 1, constant, chmap[t], tr)
             new_out = same_poly_verify([cur] + claims[1:], lp["io_accumulation"], len(cur["point"]), tr)
+            # (:495-505) the commitment verifier gets `verifier_claims.claims().iter().take(1)` — the lookup's OWN claim on the first column, for a GELU the
+            # column of input * multiplier — and the accumulated output claim
             out.append(("witness", nid, 0, (tuple(lp["commits"][0]["root"]), lp["commits"][0]["num_vars"]), claims[0]["point"], claims[0]["eval"]))
             out.append(("witness", nid, 1, (tuple(lp["commits"][1]["root"]), lp["commits"][1]["num_vars"]), new_out["point"], new_out["eval"]))
-            made[nid] = [claims[0]]
+            # (:507-515) what goes on to the previous node: the claim itself for a Relu, the claim times 1 / multiplier for a GELU
+            made[nid] = [claims[0] if n["kind"] == "relu" else {"point": claims[0]["point"], "eval": mul(claims[0]["eval"], L.ext_inv(fe(n["multiplier"])))}]
         else:
             assert n["kind"] == "requant"
             made[nid], o2 = [None], []
@@ -854,7 +863,7 @@ def verify_graph(nodes, outputs, model_roots, tree, input_tensors, output_tensor
         claims, _, _ = verify_logup(tp["lookup"], 1, constant, chmap[t], tr)
         out.append(("multiplicity", t, (tuple(tp["multiplicity_commit"]["root"]), tp["multiplicity_commit"]["num_vars"]), claims[0]["point"], claims[0]["eval"]))
         expect = table_column_evals(t[0], t[1], claims[0]["point"])
-        if t[0] in ("inv_sqrt", "softmax", "error"):  # table_claims (lookup/context.rs:548-563): the claim on the committed output column goes to the opening
+        if t[0] in ("inv_sqrt", "softmax", "error", "gelu"):  # table_claims (lookup/context.rs:548-563): the claim on the committed output column goes to the opening
             out.append(("table", t, claims[-1]["point"], claims[-1]["eval"]))
             claims = claims[:-1]
         assert len(expect) == len(claims) - 1

@@ -456,6 +456,12 @@ def _chain_description(mb, x):
             for c in chunks:
                 lk["range"].extend(int(v) for v in c)
             cur = o
+        elif k == M.L_GELU:
+            d.update(kind="gelu", multiplier=l["multiplier"])
+            o = M.gelu_apply(l, cur)
+            cols[i] = [cur * l["multiplier"], o]  # (activation.rs:268-276: the committed first column is the SCALED input)
+            lk.setdefault("gelu", {}).setdefault((l["multiplier"], 8 + (l["multiplier"] - 1).bit_length()), []).extend(int(v) * l["multiplier"] for v in cur)
+            cur = o
         else:
             assert k == M.L_RELU
             d.update(kind="relu")
@@ -492,6 +498,8 @@ def test_independent_verifier_on_token_and_sequence_models(oracle, name, args, k
             sizes += [256, 1 << n["clamping_size"]]
         elif n["kind"] in ("relu", "maxpool"):
             sizes.append(256)
+        elif n["kind"] == "gelu":
+            sizes.append(1 << (8 + (n["multiplier"] - 1).bit_length()))
         elif n["kind"] == "layernorm":
             sizes += [256, 1 << 15]
         elif n["kind"] == "softmax":
@@ -503,6 +511,57 @@ def test_independent_verifier_on_token_and_sequence_models(oracle, name, args, k
         roots.setdefault(i, []).append((pid, oracle.pcs_commit_root(max_poly, to_words(poly), False)))
     claims, tr = V.verify_graph(nodes, [(len(nodes) - 1, 0)], roots, tree, [[int(v) for v in x]], [[int(v) for v in y]])
     _check_claims_and_openings(oracle, claims, tr, tree, roots, polys, cols, lk, max_poly)
+
+
+def _gelu_through_the_independent_verifier(oracle, mb, files_lookup_claim):
+    import deep_prove_amd as dpa  # noqa: F401
+    from deep_prove_amd import wire
+    from support import l2_independent as V
+    x = mb.input()
+    nodes, cols, polys, lk, y = _chain_description(mb, x)
+    assert (y == mb.run(x)).all()
+    oracle.set_gelu_files_lookup_claim(files_lookup_claim)
+    try:
+        h = oracle.model_setup(mb.blob())
+        proof, oout, _ = oracle.model_prove(h, x)
+        oracle.model_free(h)
+    finally:
+        oracle.set_gelu_files_lookup_claim(False)
+    assert (oout == y).all()
+    tree = wire.parse_stream(proof)
+    sizes = [mb.input_len] + [p.size for p in polys.values()] + [c[0].size for c in cols.values()]
+    for n in nodes:
+        if n["kind"] == "requant":
+            sizes += [256, 1 << n["clamping_size"]]
+        elif n["kind"] == "gelu":
+            sizes.append(1 << (8 + (n["multiplier"] - 1).bit_length()))
+    max_poly = 1 << (max(sizes) - 1).bit_length()
+    to_words = lambda v: np.asarray([int(t) % P for t in np.asarray(v).reshape(-1)], dtype=np.uint64)
+    roots = {}
+    for (i, pid), poly in polys.items():
+        roots.setdefault(i, []).append((pid, oracle.pcs_commit_root(max_poly, to_words(poly), False)))
+    claims, tr = V.verify_graph(nodes, [(len(nodes) - 1, 0)], roots, tree, [[int(v) for v in x]], [[int(v) for v in y]])
+    _check_claims_and_openings(oracle, claims, tr, tree, roots, polys, cols, lk, max_poly)
+
+
+def test_independent_verifier_on_gelu_models(oracle):
+    """Activation::Gelu a second time (l2_independent.verify_graph, from layers/activation.rs:459-517 and lookup/context.rs:364-378, 466, 548-563): the
+    table (multiplier, size) in derive(Ord) order with the label "GELU", its input column evaluated by the verifier and its output column opened against a
+    commitment made HERE from the numpy table (models.gelu_table_output), the lookup's claim on the scaled column filed with the first witness commitment,
+    the claim / multiplier handed on. gelu_only(32) — the reference's own test shape, columns opened by showing them — is accepted with the oracle TO THE
+    LETTER of the reference's prover; gelu_mlp(256) — a real batch opening (l3) — is accepted when the prover files the claim this verifier files."""
+    import deep_prove_amd as dpa
+    _gelu_through_the_independent_verifier(oracle, dpa.models.gelu_only(32, config=111), files_lookup_claim=False)
+    _gelu_through_the_independent_verifier(oracle, dpa.models.gelu_mlp(256, config=112), files_lookup_claim=True)
+
+
+def test_independent_verifier_refuses_the_references_gelu_prover_beyond_trivial_openings(oracle):
+    """... and refuses gelu_mlp(256) proved to the letter of the reference (prove_step files the lookup claim DIVIDED by the multiplier with the commitment
+    of the scaled column, activation.rs:405-430): every IOP check passes — the independent verifier gets as far as the openings — and the batch opening
+    (l3_independent.batch_verify), which starts from the claims the VERIFIER holds, fails"""
+    import deep_prove_amd as dpa
+    with pytest.raises(AssertionError, match="batch opening: sumcheck round inconsistent"):
+        _gelu_through_the_independent_verifier(oracle, dpa.models.gelu_mlp(256, config=112), files_lookup_claim=False)
 
 
 def _check_claims_and_openings(oracle, claims, tr, tree, roots, polys, cols, lk, max_poly):
@@ -522,7 +581,9 @@ def _check_claims_and_openings(oracle, claims, tr, tree, roots, polys, cols, lk,
             uniform.append(({"root": list(c[3][0]), "num_vars": c[3][1]}, c[4], c[5]))
         elif c[0] == "table":  # the committed column of a table (inverse square root, exponential, error): the claim is true, and it is opened against a commitment made HERE
             from deep_prove_amd import models as M
-            if c[1][0] == "softmax":
+            if c[1][0] == "gelu":
+                column = np.asarray([M.gelu_table_output(j) for j in range(-(1 << (c[1][1][1] - 1)), 1 << (c[1][1][1] - 1))], dtype=np.int64)
+            elif c[1][0] == "softmax":
                 column = np.asarray([M.softmax_table_output(dict(temp_bits=c[1][1][0], bkm=c[1][1][2]), j) for j in range(1 << c[1][1][1])], dtype=np.int64)
             elif c[1][0] == "error":
                 nt = 1 << (2 * c[1][1] - 1).bit_length()
@@ -533,7 +594,9 @@ def _check_claims_and_openings(oracle, claims, tr, tree, roots, polys, cols, lk,
             uniform.append(({"root": oracle.pcs_commit_root(max_poly, to_words(column), False), "num_vars": int(column.size).bit_length() - 1}, c[2], c[3]))
         else:
             t = c[1]
-            if t[0] == "softmax":
+            if t[0] == "gelu":
+                lo, hi, data = -(1 << (t[1][1] - 1)), 1 << (t[1][1] - 1), lk["gelu"][t[1]]
+            elif t[0] == "softmax":
                 lo, hi, data = 0, 1 << t[1][1], lk["softmax"][t[1]]
             elif t[0] == "zero":
                 lo, hi, data = 0, 1 << t[1], lk["zero"][t[1]]
