@@ -4,7 +4,8 @@ import deep_prove_amd as dpa
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 bases = [dpa.models.mlp(1, 8, config=3), dpa.models.cnn_tiny(), dpa.models.seq_mlp(4, 8, config=4, transpose_last=True, positional=True), dpa.models.token_mlp(4, 10, 8, config=5, max_positions=9),
          # graph blobs: edges, several input / output tensors, ConcatMatMul geometry, QKV
-         dpa.models.attention_block(4, 8, 2, 4, config=6), dpa.models.matmul_pair(4, 8, 8, config=7, transpose_b=True), dpa.models.qkv_two_outputs(4, 8, 8, config=8)]
+         dpa.models.attention_block(4, 8, 2, 4, config=6), dpa.models.matmul_pair(4, 8, 8, config=7, transpose_b=True), dpa.models.qkv_two_outputs(4, 8, 8, config=8),
+         dpa.models.gelu_mlp(8, config=9)]  # Activation::Gelu: the multiplier word
 ok = err = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 3000):
     mb = bases[it % len(bases)]

@@ -209,3 +209,31 @@ def test_mha_step_in_the_wire_format(oracle):
     back = wire.from_rmp(data)
     assert wire.to_rmp(back) == data
     assert [k for _, k, _ in wire.parse_stream(back)["steps"]].count(16) == 1
+
+
+def test_gelu_step_in_the_wire_format(oracle):
+    """LayerProof::Activation(ActivationProof {io_accumulation, lookup, commits}) (layers/activation.rs:60-76) carries a GELU exactly as it carries a Relu:
+    the canonical stream's kind 17 becomes the variant "Activation", and comes back as kind 2 (the wire format cannot tell them apart, as for MatMul / Add of
+    two inputs); the MessagePack bytes survive the round trip"""
+    import deep_prove_amd as dpa
+    from deep_prove_amd import wire
+    mb = dpa.models.gelu_mlp(64, config=114)
+    x = mb.input()
+    oracle.set_gelu_files_lookup_claim(True)
+    try:
+        h = oracle.model_setup(mb.blob())
+        p, out, _ = oracle.model_prove(h, x)
+        oracle.model_free(h)
+    finally:
+        oracle.set_gelu_files_lookup_claim(False)
+    assert (out == mb.run(x)).all()
+    assert [k for _, k, _ in wire.parse_stream(p)["steps"]].count(17) == 1
+    data = wire.to_rmp(p)
+    m = msgpack.unpackb(data, raw=False, strict_map_key=False)
+    act = [body for lp in m["steps"].values() for kind, body in lp.items() if kind == "Activation"]
+    assert len(act) == 1 and list(act[0]) == ["io_accumulation", "lookup", "commits"] and len(act[0]["commits"]) == 2
+    back = wire.from_rmp(data)
+    assert wire.to_rmp(back) == data
+    kinds, kinds_back = [k for _, k, _ in wire.parse_stream(p)["steps"]], [k for _, k, _ in wire.parse_stream(back)["steps"]]
+    assert kinds_back == [2 if k == 17 else k for k in kinds] and kinds_back.count(2) == 1  # (base-field trivial openings come back empty, as for every model: not compared word for word)
+
