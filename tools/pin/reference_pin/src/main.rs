@@ -1,11 +1,9 @@
 //! Prints ONE JSON object: what the reference's own crates compute on the fixed inputs tests/test_reference_pin.py replays through the oracle.
 //! Every value is a canonical u64 (extension elements as [c0, c1]). Written against the reference @ 2025-08-08 without a compiler at hand: the API
 //! names are the ones read in the sources (cited), a maintainer may have to touch an import.
-use std::sync::Arc;
-
 use ff_ext::{ExtensionField, GoldilocksExt2, PoseidonField};
-use mpcs::{Basefold, BasefoldRSParams, PolynomialCommitmentScheme, util::hash::PoseidonHasher};
-use multilinear_extensions::{mle::DenseMultilinearExtension, virtual_poly::VirtualPolynomial};
+use mpcs::{Basefold, BasefoldRSParams, Hasher, PolynomialCommitmentScheme}; // Hasher = PoseidonHasher without the `blake` feature (mpcs/src/lib.rs:339-342)
+use multilinear_extensions::{mle::DenseMultilinearExtension, virtual_poly::{ArcMultilinearExtension, VirtualPolynomial}};
 use p3_field::{FieldAlgebra, FieldExtensionAlgebra, PrimeField64};
 use p3_goldilocks::Goldilocks;
 use p3_symmetric::Permutation;
@@ -14,7 +12,7 @@ use sumcheck::structs::IOPProverState;
 use transcript::{Transcript, basic::BasicTranscript};
 
 type E = GoldilocksExt2;
-type Pcs = Basefold<E, BasefoldRSParams<PoseidonHasher>>; // zkml/src/bin/bench.rs:26
+type Pcs = Basefold<E, BasefoldRSParams<Hasher>>; // zkml/src/bin/bench.rs:13, 24-26
 
 fn f(v: u64) -> Goldilocks { Goldilocks::from_canonical_u64(v) }
 fn ext(e: &E) -> Vec<u64> { e.as_base_slice().iter().map(|x| x.as_canonical_u64()).collect() } // ff_ext: as_bases()
@@ -38,7 +36,8 @@ fn main() {
     out.insert("transcript_m2vec_then_internal_round".into(), ext(&c2).into());
     // 4. prove_parallel (sumcheck/src/prover.rs:498-585) of sum_b f(b) g(b) h(b), 4 variables, f = 1..16, g = 17..32, h = 3 i + 1: messages, point
     let nv = 4usize;
-    let mk = |g: &dyn Fn(u64) -> u64| Arc::new(DenseMultilinearExtension::<E>::from_evaluations_vec(nv, (0..1u64 << nv).map(|i| f(g(i))).collect()));
+    // (DenseMultilinearExtension -> ArcMultilinearExtension by `.into()`, as zkml/src/layers/dense.rs:494 does)
+    let mk = |g: &dyn Fn(u64) -> u64| -> ArcMultilinearExtension<'static, E> { DenseMultilinearExtension::<E>::from_evaluations_vec(nv, (0..1u64 << nv).map(|i| f(g(i))).collect()).into() };
     let (a, b, c) = (mk(&|i| i + 1), mk(&|i| i + 17), mk(&|i| 3 * i + 1));
     let mut vp = VirtualPolynomial::<E>::new(nv);
     vp.add_mle_list(vec![a.clone(), b.clone(), c.clone()], E::ONE);
