@@ -772,7 +772,7 @@ def sumcheck24(dev, dpa, nv=24, k=3):
     # their aggregate is `achieved_GBps_all_streaming_rounds`, every instantiation is in `kernels`
     big = max(stream, key=lambda r: r["total_ms"] / r["launches"])
     big_gbs = (big["alg_bytes"] / big["launches"]) / (big["total_ms"] / big["launches"] * 1e-3) / 1e9
-    pmc = pmc_traffic(big["kernel"], "sumcheck24")
+    pmc = pmc_traffic(big["kernel"], f"sumcheck{nv}")  # (the counter pass of THIS size: round 5 quoted the 2^24 pass for the 2^26 object)
     trusted = prof_total_ms <= 1.2 * wall_ms
     roofline = {"bound": "hbm", "kernel": big["kernel"], "achieved": round(big_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(big_gbs / HBM_PEAK_GBS, 4), "traffic": pmc["hbm_bytes_per_launch"] if pmc else None, "traffic_source": pmc["source"] if pmc else None,

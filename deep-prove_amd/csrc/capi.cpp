@@ -394,7 +394,7 @@ int32_t dp_sumcheck_prove_sharded_local(dp_ctx* const* ctxs, int32_t world, uint
     for (int g = 0; g < world; g++) th.emplace_back([&, g] {
       try {
         DP_REQUIRE(ctxs[g] && transcripts[g], DP_ERR_ARG, "null context / transcript");
-        ctxs[g]->dev->bind_thread();
+        ctxs[g]->dev->bind_thread(); ctxs[g]->dev->pin_thread();
         DevVP vp(num_vars - k);
         read_terms(vp, tables + (size_t)g * ntables, ntables, term_degree, term_tables, nterms, term_coeffs);
         ThreadExchange xch(hub, g);
@@ -670,6 +670,7 @@ uint64_t sig_buf(uint64_t h, const DBuf& b) { return sig_mix(sig_mix(h, b.n), b.
 // fiber a turn per pass. A thread with nothing to run sleeps on the queue's condition variable.
 struct AsyncGroup { dp::Cohort* cohort = nullptr; bool merged = false; std::vector<Dev*> devs; size_t live = 0; };
 void async_thread(dp_async* a) {
+  a->ctx->dev->pin_thread();  // (an engine thread is the library's own: it keeps to the CPUs of the GPU's NUMA node)
   std::vector<dp::Cohort*> idle_cohorts;
   std::vector<std::unique_ptr<AsyncGroup>> groups;
   FiberSched sched;
@@ -1241,17 +1242,23 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
       const int S = getenv("DP_SPONGE_THREADS") ? std::max(1, atoi(getenv("DP_SPONGE_THREADS"))) : 6;
       nth = (size_t)std::max(2.0, host_cpu_budget() - 2.0 - (double)S);
     }
+    // with sleeping idle threads (fiber.h, DP_IDLE_SLEEP_US) a cohort's thread costs what its members' host work costs (~0.3 cores), not a whole core of polling:
+    // one thread per cohort as long as that is at most twice the CPU budget (22 cohorts on a 16-CPU quota: 6.3 cores busy)
+    if (!te && nco && nw > 1 && fiber_idle_sleep_ns() > 0 && (double)nco <= 2.0 * host_cpu_budget()) nth = std::max(nth, nco);
     nth = std::min(nth, nco ? nco : nw);
     auto run_thread = [&](size_t ti) {
       FiberSched sched;
+      sched.idle_sleep = nw > 1;
       for (size_t wi = 0; wi < nw; wi++) if ((nco ? wi % nco : wi) % nth == ti) fiber_spawn(sched, [&work, wi] { work(wi); });
       fiber_run_all(sched);
       for (auto& f : sched.fibers) if (f->failed) { std::lock_guard<std::mutex> g(err_mu); if (!err_code) { err_code = DP_ERR_ARG; err = "an exception escaped a proof worker's fiber"; } }
     };
     std::vector<std::thread> th, pth, sth;
-    for (size_t k = 0; k < nser; k++) sth.emplace_back(ser_thread);
-    for (size_t k = 0; k < nprep && nproofs > nw; k++) pth.emplace_back(prep_thread);
-    for (size_t ti = 1; ti < nth; ti++) th.emplace_back(run_thread, ti);
+    // (threads this call spawns keep to the CPUs of the GPU's NUMA node, Dev::pin_thread; thread 0 is the caller's and keeps the affinity it came with)
+    Dev* pin_dev = m->ctx->dev;
+    for (size_t k = 0; k < nser; k++) sth.emplace_back([&, pin_dev] { pin_dev->pin_thread(); ser_thread(); });
+    for (size_t k = 0; k < nprep && nproofs > nw; k++) pth.emplace_back([&, pin_dev] { pin_dev->pin_thread(); prep_thread(); });
+    for (size_t ti = 1; ti < nth; ti++) th.emplace_back([&, pin_dev, ti] { pin_dev->pin_thread(); run_thread(ti); });
     run_thread(0);
     for (auto& t : th) t.join();
     pstop.store(true);
@@ -1367,7 +1374,7 @@ int32_t dp_verify_batch(dp_ctx* ctx, const uint64_t* vb, size_t vn, const uint64
       }
     };
     std::vector<std::thread> th;
-    for (size_t k = 1; k < nth; k++) th.emplace_back(work);
+    for (size_t k = 1; k < nth; k++) th.emplace_back([&] { if (ctx) ctx->dev->pin_thread(); work(); });
     work();
     for (auto& t : th) t.join();
     if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

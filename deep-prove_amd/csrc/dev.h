@@ -72,6 +72,7 @@ class Dev {
   virtual ~Dev() {}
   virtual const char* name() const = 0;
   virtual void bind_thread() {}  // make this context current for the calling host thread
+  virtual void pin_thread() {}   // a thread the library spawned for this context keeps to the CPUs of the device's NUMA node (HipDev::pin_thread)
   // ---- memory. alloc() is an arena (stack discipline via mark/release); persistent allocations outlive proofs.
   virtual DBuf alloc(size_t n, bool ext) = 0;
   virtual size_t mark() = 0;

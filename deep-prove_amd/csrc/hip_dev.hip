@@ -21,6 +21,7 @@
 #include "sponge_host.h"
 #include <hip/hip_runtime.h>
 #include <sched.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 #include <cctype>
 #include <cstdio>
@@ -47,7 +48,7 @@ namespace dp {
 // Grid size for grid-stride kernels: `cap` bounds a launch of ONE proof (a merged cohort launch has gridDim.z = members times as many workgroups).
 // A lower global cap was swept at 448 proofs in flight (8 / 24 / 64 / 256 workgroups per proof and launch against up to 4096): 470 / 513 / 566 / 491
 // against 531-534 proofs/s, i.e. nothing outside the +-5 % between runs (profiles/r04_grid_cap_sweep.txt); there is no knob for it any more.
-static inline int grid_for(size_t n, int cap = 2048) {
+static inline int grid_for_uncapped(size_t n, int cap = 2048) {
   size_t b = (n + TPB - 1) / TPB;
   if (b < 1) b = 1;
   return (int)std::min<size_t>(b, cap);
@@ -201,7 +202,8 @@ struct Cohort {
   }
   // a member has seen the result of its launch number `li` (or of a later round of it): everything before it has run
   void note_executed(size_t li) { if (li > executed) executed = li; }
-  void join() { if (!q.empty()) throw DpError(DP_ERR_SHAPE, "a proof cannot join a cohort in the middle of a step"); members++; }
+  int nominal = 0;  // members when the batch started (every member joins before the first launch): what launch shapes may depend on — `members` shrinks while a batch drains
+  void join() { if (!q.empty()) throw DpError(DP_ERR_SHAPE, "a proof cannot join a cohort in the middle of a step"); members++; nominal = members; }
   // a member leaves (its proofs are done, or it failed) having issued `li` launches: later launches no longer wait for it
   void leave(size_t li) {
     members--;
@@ -231,6 +233,7 @@ class HipDev : public Dev {
     return t;
   }
   void wait_exit_(std::chrono::steady_clock::time_point t0) {
+    fiber_note_progress();
     if (!g_host_stats) return;
     last_exit_ = std::chrono::steady_clock::now(); have_exit_ = true;
     waitlat_us_ += std::chrono::duration<double, std::micro>(last_exit_ - t0).count();
@@ -516,7 +519,8 @@ class HipDev : public Dev {
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) throw DpError(DP_ERR_NODEVICE, "no HIP device available: the MI355X path is mandatory, there is no CPU fallback");
     DP_REQUIRE(device >= 0 && device < cnt, DP_ERR_ARG, "bad device id");
     HIP_CHECK(hipSetDevice(device));
-    numa_pin_(device);
+    numa_mask_init_(device);
+    if (!arena_bytes) numa_pin_creator_();  // (arena_bytes != 0: a worker of a batch or of the engine — the calling thread is not its to move)
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device));
     name_ = std::string("hip:") + prop.name + ":" + prop.gcnArchName;
@@ -577,6 +581,7 @@ class HipDev : public Dev {
     DP_SET_LDS(k_med_ntt_local, 1024, 64 * 1024);
   }
   ~HipDev() override {
+    numa_unpin_creator_();
     hipSetDevice(device_);
     if (s_) hipStreamSynchronize(s_);
     pcs_tabs_.reset();
@@ -780,7 +785,7 @@ class HipDev : public Dev {
         const size_t tag_off = (nwords * 8 + 255) & ~size_t(255);
         if (g_host_stats) by_name_["  (k_download)"]++;
         const unsigned long long seq = ++seq_;
-        nb_ = 0; DPL(k_download, dim3((unsigned)std::min<size_t>(nch, 256)), dim3(TPB), (const u64*)((const char*)src + off), (u64*)(hstage_dev_ + DESC_BYTES), nwords, (u64*)(hstage_dev_ + DESC_BYTES + tag_off), seq);
+        nb_ = 0; DPL(k_download, dim3((unsigned)std::min<size_t>(nch, (size_t)grid_for(nch * TPB, 256))), dim3(TPB), (const u64*)((const char*)src + off), (u64*)(hstage_dev_ + DESC_BYTES), nwords, (u64*)(hstage_dev_ + DESC_BYTES + tag_off), seq);
         auto t0 = wait_enter_();
         nwait_++;
         volatile u64* pay = (volatile u64*)bulk_stage();
@@ -965,13 +970,27 @@ class HipDev : public Dev {
   // PCIe write, the kernel polls its own HBM. Set up at the first host-driven session of a context (throughput-mode workers
   // never get here); checked, not assumed: the page must be CPU-writable (probed through a pipe, no fault) and a kernel must read
   // back two successive CPU writes. DP_MAILBOX_VRAM=0 keeps the mailbox in host memory.
-  // Keep the calling thread (and the threads it creates later: the cohort threads, the engine) on the CPUs of the GPU's own NUMA node. Every Fiat-Shamir round
-  // of a single proof crosses PCIe twice; from the other socket of a two-socket host each crossing also crosses the socket interconnect: one Dense-4M proof
-  // 34.7 ms from node 0 against 30.7 ms from the GPU's node 1, four processes each (profiles/r05_numa_latency.txt). The affinity is only ever NARROWED, to the
-  // intersection of what the thread may use with the node's CPUs (/sys/bus/pci/devices/<bdf>/local_cpulist), and left alone when that is empty, when the
-  // thread is already confined to the node, or with DP_NUMA_PIN=0.
-  static void numa_pin_(int device) {
+  // Host threads that drive this GPU stay on the CPUs of the GPU's own NUMA node. Every Fiat-Shamir round of a single proof crosses PCIe twice; from the other
+  // socket of a two-socket host each crossing also crosses the socket interconnect: one Dense-4M proof 34.7 ms from node 0 against 30.7 ms from the GPU's node 1,
+  // four processes each (profiles/r05_numa_latency.txt). Who is pinned (round 6, after the advisor's finding that round 5 narrowed the APPLICATION's thread for
+  // good and let the first GPU's node win for every later context):
+  //  * the mask is per DEVICE: the node's CPUs (/sys/bus/pci/devices/<bdf>/local_cpulist) intersected with the affinity the PROCESS had when the library first
+  //    looked (not with whatever an earlier context narrowed the thread to) — a context for a GPU on the other socket gets that socket's CPUs;
+  //  * library-owned threads (cohort threads, engine threads, helpers) pin themselves for their whole life: pin_thread();
+  //  * the thread that CREATES an owning context (dp_ctx_create) is narrowed too — it is the thread that proves single proofs — but its previous affinity is
+  //    remembered and put back when the context is destroyed (or when the same thread creates a context on another device: the newest wins, the oldest
+  //    saved mask is the one restored); workers of a batch (make_hip_worker) never touch the calling thread;
+  //  * nothing happens when the intersection is empty, when the thread is already inside the node, or with DP_NUMA_PIN=0.
+  static const cpu_set_t& process_affinity_() {
+    static const cpu_set_t orig = [] { cpu_set_t c; CPU_ZERO(&c); if (sched_getaffinity(0, sizeof(c), &c) != 0) CPU_ZERO(&c); return c; }();
+    return orig;
+  }
+  cpu_set_t numa_cpus_; bool have_numa_ = false;        // this device's mask (see above)
+  cpu_set_t saved_affinity_; pid_t pinned_tid_ = 0;     // the creating thread's affinity before this context narrowed it
+  void numa_mask_init_(int device) {
+    CPU_ZERO(&numa_cpus_); CPU_ZERO(&saved_affinity_);
     if (getenv("DP_NUMA_PIN") && !atoi(getenv("DP_NUMA_PIN"))) return;
+    const cpu_set_t& orig = process_affinity_();
     char bdf[64] = {0};
     if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf) - 1, device) != hipSuccess) { (void)hipGetLastError(); return; }
     for (char* c = bdf; *c; c++) *c = (char)tolower(*c);
@@ -992,13 +1011,25 @@ class HipDev : public Dev {
       q = *e == ',' ? e + 1 : e;
       if (*e != ',') break;
     }
-    cpu_set_t cur; CPU_ZERO(&cur);
-    if (sched_getaffinity(0, sizeof(cur), &cur) != 0) return;
-    cpu_set_t both; CPU_AND(&both, &cur, &local);
-    const int nb = CPU_COUNT(&both), nc = CPU_COUNT(&cur);
-    if (nb == 0 || nb == nc) return;
-    if (sched_setaffinity(0, sizeof(both), &both) == 0 && g_timing_level) fprintf(stderr, "[dp] host thread kept on the %d CPUs of the GPU's NUMA node (%s: %s)\n", nb, bdf, strtok(line, "\n"));
+    CPU_AND(&numa_cpus_, &orig, &local);
+    const int nb = CPU_COUNT(&numa_cpus_), nc = CPU_COUNT(&orig);
+    have_numa_ = nb > 0 && nb < nc;
+    if (have_numa_ && g_timing_level) fprintf(stderr, "[dp] device %d: host threads of this context stay on the %d CPUs of the GPU's NUMA node (%s: %s)\n", device, nb, bdf, strtok(line, "\n"));
   }
+  // the creating thread of an owning context: narrowed now, restored by the destructor
+  void numa_pin_creator_() {
+    if (!have_numa_) return;
+    cpu_set_t cur; CPU_ZERO(&cur);
+    if (sched_getaffinity(0, sizeof(cur), &cur) != 0 || CPU_EQUAL(&cur, &numa_cpus_)) return;
+    if (sched_setaffinity(0, sizeof(numa_cpus_), &numa_cpus_) == 0) { saved_affinity_ = cur; pinned_tid_ = (pid_t)syscall(SYS_gettid); }
+  }
+  void numa_unpin_creator_() {
+    if (!pinned_tid_) return;
+    (void)sched_setaffinity(pinned_tid_, sizeof(saved_affinity_), &saved_affinity_);  // (ESRCH when the thread is gone: nothing to restore)
+    pinned_tid_ = 0;
+  }
+  // a thread the LIBRARY owns (it ends with the call that spawned it) keeps to this device's node
+  void pin_thread() override { if (have_numa_) (void)sched_setaffinity(0, sizeof(numa_cpus_), &numa_cpus_); }
   static bool cpu_can_write_(void* p) {
     int fd[2];
     if (pipe(fd) != 0) return false;
@@ -1665,6 +1696,31 @@ class HipDev : public Dev {
   // nodes: profiles/r05_bench448_kernel_stats_lds_msgs.csv). DP_LP_MAX_TP (default 512): the widest layer that still takes the 8-lane kernel there.
   size_t lp_max_tp_ = [] { const char* e = getenv("DP_LP_MAX_TP"); return e ? (size_t)strtoull(e, nullptr, 10) : size_t(512); }();
   size_t lp_max_now() const { return throughput_mode_ ? lp_max_tp_ : lp_max_; }
+  // DP_MERKLE_WG_CAP (throughput mode; 0 = off): workgroups of ONE merged k_merkle_layer launch, all members together. A hash workgroup lives ~200 us (18 700 VALU
+  // instructions per lane, 7 waves per SIMD) and an uncapped layer of a cohort (21 x 2048 workgroups) takes every wave slot of the chip for milliseconds: the
+  // workgroups of every other queue — the streaming kernels of the batch opening, the one-workgroup tails, k_publish — then wait for a slot to drain
+  // (k_axpy_many: 12.8 ms per launch for 0.2 ms of work, profiles/r05_bench448_kernel_stats.csv). The VALU is saturated by 2-3 hash waves per SIMD.
+  size_t merkle_wg_cap_ = [] { const char* e = getenv("DP_MERKLE_WG_CAP"); return e ? (size_t)strtoull(e, nullptr, 10) : size_t(0); }();
+  int merkle_grid(size_t nodes) const {
+    if (!throughput_mode_ || !merkle_wg_cap_) return grid_for(nodes, 4096);
+    const size_t m = co_ && co_->nominal > 0 ? (size_t)co_->nominal : 1;
+    return grid_for_uncapped(nodes, (int)std::max<size_t>(1, merkle_wg_cap_ / m));
+  }
+  // ---- every grid-stride launch of a cohort member is PLACEABLE AT ONCE (DP_WIDE_WG_CAP, throughput mode). Measured with tools/r06/qprobe.hip
+  // (profiles/r06_qprobe.txt): a chain of dependent one-wave kernels on one queue costs 2.8 us per link on an idle chip, 45 us when 22 other queues run
+  // long LIGHT kernels, 55 us when they run VALU-saturating persistent kernels of 64 workgroups each (22 x 64 < the ~2 000 workgroup slots of the chip) —
+  // and 1.8 ms per link when those queues launch grids that do NOT fit (chip-filling, or 512 workgroups each): a grid that cannot be placed keeps its queue's
+  // pipe of the command processor until its last workgroup has found a slot, and every other queue served by that pipe (22 queues on 4 pipes) waits behind it,
+  // whatever it wants to launch. That is the "small kernels stretch with the number of active kernels" of rounds 2-5 (k_publish 1.7 ms with 20 kernels
+  // active) and why capping ONE kernel family never moved the rate: the sum over all queues has to fit. The cap is per merged launch, all members together.
+  size_t wide_wg_cap_ = [] { const char* e = getenv("DP_WIDE_WG_CAP"); return e ? (size_t)strtoull(e, nullptr, 10) : size_t(0); }();
+  int grid_for(size_t n, int cap = 2048) const {
+    if (throughput_mode_ && wide_wg_cap_ && co_) {
+      const size_t m = co_->nominal > 0 ? (size_t)co_->nominal : 1;
+      cap = std::min<int>(cap, (int)std::max<size_t>(1, wide_wg_cap_ / m));
+    }
+    return grid_for_uncapped(n, cap);
+  }
   // `nodes` must hold 4*(n-1) words; synchronises (root is copied to the host)
   DevTree build_tree_into(const DBuf& leaves, const DBuf& nodes) {
     DevTree t; t.leaves = leaves; t.nleaves = leaves.n; t.nodes = nodes;
@@ -1675,8 +1731,8 @@ class HipDev : public Dev {
     size_t off = 0, cnt = n / 2;
     while (cnt > TAIL_MAX) {
       size_t next = cnt / 2;
-      if (next <= lp_max_now()) { nb_ = 96.0 * next; DPL(k_merkle_layer_lp, dim3((unsigned)std::min<size_t>((next * 8 + 255) / 256, 8192)), dim3(256), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
-      else { nb_ = 96.0 * next; DPL(k_merkle_layer, dim3(grid_for(next, 4096)), dim3(TPB), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
+      if (next <= lp_max_now()) { nb_ = 96.0 * next; DPL(k_merkle_layer_lp, dim3((unsigned)grid_for(next * 8, 8192)), dim3(256), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
+      else { nb_ = 96.0 * next; DPL(k_merkle_layer, dim3(merkle_grid(next)), dim3(TPB), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
       off += cnt; cnt /= 2;
     }
     const TailDesc* dd = nullptr;
@@ -1902,7 +1958,7 @@ class HipDev : public Dev {
         size_t items = folds ? hd[i].n / 4 : hd[i].n / 2;  // loop iterations of the pair: 4 (2) entries of each table per iteration
         // (behind the resident executor a tile costs ~20 us of queue protocol whatever it does: 32 iterations per thread instead of 4)
         const size_t per_blk = (size_t)TPB * 4;
-        size_t nb = std::min<size_t>(std::max<size_t>((items + per_blk - 1) / per_blk, 1), (size_t)1024);
+        size_t nb = std::min<size_t>(std::max<size_t>((items + per_blk - 1) / per_blk, 1), (size_t)grid_for(items, 1024));  // (per polynomial; every polynomial keeps one workgroup)
         first[i] = nblk; nblk += (unsigned)nb;
         bytes += hd[i].n * (hd[i].fext ? 16.0 : 8.0) + (folds ? hd[i].n * 8.0 : 0.0) + (fac[i].ln ? 0.0 : hd[i].n * 16.0 + (folds ? hd[i].n * 8.0 : 0.0));
       }
@@ -1993,7 +2049,7 @@ class HipDev : public Dev {
     }
     size_t mk = mark();
     u64* dout = (u64*)arena_alloc(total * 8);
-    DPL(k_query_gather, dim3((unsigned)((nd + 3) / 4)), dim3(TPB), dd, nd, dout);
+    DPL(k_query_gather, dim3((unsigned)grid_for(nd * 64, 1 << 20)), dim3(TPB), dd, nd, dout);  // (one wave per descriptor, grid-stride)
     flat.resize(total);
     d2h(flat.data(), dout, total * 8);  // (the copy follows the gather on the stream: no wait of its own in between, as there was until round 5)
     release(mk);

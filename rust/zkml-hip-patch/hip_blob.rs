@@ -3,7 +3,7 @@
 //! throughput is measured on (cohorts, device-side Fiat-Shamir, fused tails all live behind it). Add to the `zkml` crate as
 //! `zkml/src/hip_blob.rs` with `mod hip_blob;` in `lib.rs` and a dependency on `deep-prove-hip-sys`: the module reads `pub(crate)` fields
 //! of the layer structs; where a field is private to its module the accessor named in the comment has to be added next to the struct
-//! (each is a one-line getter). UNBUILT in the repository's environment (no Rust toolchain); what IS checked on every CPU test run
+//! (each is a one-line getter; `accessors.patch` beside this file lists every one of them as a hunk against the reference). UNBUILT in the repository's environment (no Rust toolchain); what IS checked on every CPU test run
 //! (`tests/test_rust_shim.py`): the kind numbers below against `enum LayerKind` of `csrc/proof.h`, that every variant of the reference's
 //! `Layer` enum (`zkml/src/layers/mod.rs:66-93`) has an arm here, and every `sys::dp_*` call against the extern block. The word order per
 //! kind follows `csrc/blob.h` (the parser) and `deep-prove_amd/models.py` (the writer the golden fixtures come from).
@@ -11,8 +11,6 @@
 //! Blob (include/deep_prove_hip.h "model blob", GRAPH form): input_len, -(#nodes), #inputs, len.., #outputs, (node, slot).., then per node
 //! kind, #in, (node, slot).., parameters. Node ids are renumbered to positions in `to_forward_iterator()` order (a node only reads earlier ones).
 use std::collections::HashMap;
-
-use anyhow::anyhow;
 
 use deep_prove_hip_sys as sys;
 
@@ -93,7 +91,7 @@ pub fn model_to_blob(model: &Model<Element>) -> Result<Vec<i64>, BlobError> {
             // `pub(crate) fn multiplier(&self) -> Element` next to table_size() and `pub(crate) fn quant_data(&self) -> Option<&GELUQuantData>` on GELU). The library opens the scaled column at the claim verify_activation
             // files (:495-505), not at the divided one the reference's prove_step files (:405-430), so its proofs verify at every size.
             Layer::Activation(Activation::Relu(_)) => head(&mut w, KIND_RELU),
-            Layer::Activation(Activation::Gelu(g)) => { head(&mut w, KIND_GELU); w.push(g.quant_data().ok_or_else(|| anyhow!("GELU not quantized"))?.multiplier() as i64); }
+            Layer::Activation(Activation::Gelu(g)) => { head(&mut w, KIND_GELU); w.push(g.quant_data().ok_or_else(|| BlobError::Unsupported("GELU not quantized".into()))?.multiplier() as i64); }
             Layer::Flatten(_) | Layer::Reshape(_) => head(&mut w, KIND_FLATTEN),  // tensors cross the ABI flat: the claim passes through
             Layer::Convolution(c) => {  // [3, kw, kx, kernel side, input side, unpadded output shape (3), filter, bias]: needs the UN-FFTed padded filter,
                 // `Convolution::padded_filter()` (the quantised op keeps the FFT, convolution.rs:52-60; the library transforms the kernels itself)

@@ -160,3 +160,18 @@ def test_model_blob_writer_uses_the_layer_kinds_of_the_library_and_covers_the_la
         assert re.search(rf"Layer::{variant}\b", src), variant
     for kind in rust_kinds:  # every kind is written by some arm
         assert len(re.findall(rf"\bKIND_{kind}\b", src)) >= 2, kind
+
+
+def test_model_blob_writer_compiles_against_its_own_error_type_and_lists_its_accessors():
+    """ADVICE r05: `model_to_blob` returns Result<_, BlobError>, so no arm may build an anyhow error with `?` (there is no From<anyhow::Error>); and
+    every getter hip_blob.rs calls that the reference's structs do not have is an explicit `+` hunk of rust/zkml-hip-patch/accessors.patch"""
+    src = open(os.path.join(ROOT, "rust", "zkml-hip-patch", "hip_blob.rs")).read()
+    assert "anyhow!" not in src and "use anyhow" not in src
+    patch = open(os.path.join(ROOT, "rust", "zkml-hip-patch", "accessors.patch")).read()
+    added = set(re.findall(r"^\+\s+pub\(crate\) fn (\w+)\(", patch, re.M))
+    for fn in ("quant_data", "multiplier", "operand", "multipliers", "is_transposed_b", "inner_and_output_dims", "padded_filter", "padded_input_side",
+               "unpadded_output_shape", "table", "padded_input_shapes_of", "padded_input_shape_of"):
+        assert re.search(rf"\.{fn}\(", src), fn
+        assert fn in added, fn
+    for line in patch.splitlines():  # hunks only add
+        assert not (line.startswith("-") and not line.startswith("---")), line

@@ -1,9 +1,10 @@
-"""standalone 2^24 sumcheck (BASELINE config 5 on one GPU), a few repetitions — the command the rocprofv3 PMC passes wrap"""
+"""standalone 2^nv sumcheck (BASELINE config 5 on one GPU; nv = 24, or argv[2]: 26 for the size the sharded estimate is quoted at), a few repetitions — the
+command the rocprofv3 PMC passes wrap. usage: sumcheck24_only.py [repetitions] [nv]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # (the repository root, wherever the command is started from)
 import numpy as np
 import deep_prove_amd as dpa
-nv, k = 24, 3
+nv, k = (int(sys.argv[2]) if len(sys.argv) > 2 else 24), 3
 dev = dpa.Device(0)
 n = 1 << nv
 tabs = [dpa.Mle.from_base(dev, dpa.models.splitmix64(0xD33B0000 ^ (5 << 32) ^ j, n) % np.uint64(dpa.P)) for j in range(k)]
