@@ -901,18 +901,23 @@ def seam_level(threads, per_thread=6, batch_rate=None):
     # without cohorts to merge launches and fibers to keep hundreds of calls in flight the one-wave kernels only add latency
     # `async_one_thread` (round 4): ONE host thread keeps 128 / 384 proofs in flight through the submit / poll forms (dp_async): calls of identical shape are
     # merged into lock-step groups by the engine (tests/support/seam_bench.c mode 3)
-    variants = [("streams", 0, threads, {}), ("streams_throughput", 2, threads, {}), ("async_one_thread_128", 3, 128, {}), ("async_one_thread_384", 3, 384, {})]
+    # `blocking_routed_T` (round 6): T host threads making the BLOCKING seam calls on one context routed to one engine (dp_ctx_route_to_engine: every call is a
+    # submit + wait, calls of one shape from different threads are merged; tests/support/seam_bench.c mode 4) — the form a host written against the reference's
+    # synchronous traits has; its rate is bounded by T / (latency of one proof's chain of calls), so it is quoted at the thread count of `streams` and at 128
+    variants = [("streams", 0, threads, {}), ("streams_throughput", 2, threads, {}), ("async_one_thread_128", 3, 128, {}), ("async_one_thread_384", 3, 384, {}),
+                (f"blocking_routed_{threads}", 4, threads, {}), ("blocking_routed_128", 4, 128, {})]
     for name, executor, t, extra in variants:
         env = dict(os.environ, DP_ARENA_BYTES=str(2 << 30), **extra)
         try:
-            r = subprocess.run([out, str(t), str(3 if executor == 3 else per_thread), str(executor)], env=env, capture_output=True, text=True, timeout=120)
+            r = subprocess.run([out, str(t), str(3 if executor == 3 or t > 64 else per_thread), str(executor)], env=env, capture_output=True, text=True, timeout=120)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             res[name] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-300:]}
         except Exception as e:  # noqa: BLE001
             res[name] = {"error": f"{type(e).__name__}: {e}"}
     res["note"] = ("workload-equivalent proofs per second of a seam-level host (every seam call of one Dense-4M proof, random tables), T threads with one dp_ctx each: "
                    "`streams` = plain contexts in latency mode (one HIP stream each), `streams_throughput` = the same in throughput mode (dp_ctx_set_throughput_mode), `async_one_thread_N` = one host thread, N proofs in flight through dp_async (submit / poll, "
-                   "merged lock-step groups); `vs_batch` = best seam-level rate / the batch rate of this run")
+                   "merged lock-step groups), `blocking_routed_T` = T threads making the blocking calls on one context routed to one engine (dp_ctx_route_to_engine: submit + wait, merged across threads); "
+                   "`vs_batch` = best seam-level rate / the batch rate of this run")
     rates = [v.get("seam_level_proofs_per_s", 0.0) for v in res.values() if isinstance(v, dict)]
     res["best_proofs_per_s"] = max(rates) if rates else None
     res["vs_batch"] = round(max(rates) / batch_rate, 4) if rates and batch_rate else None

@@ -29,6 +29,7 @@ SIGNATURES = {
     "dp_ctx_name": (C.c_char_p, [vp]),
     "dp_ctx_set_throughput_mode": (C.c_int32, [vp, C.c_int32]),
     "dp_async_create": (C.c_int32, [vp, C.c_int32, C.c_size_t, C.POINTER(vp)]),
+    "dp_ctx_route_to_engine": (C.c_int32, [vp, vp]),
     "dp_async_destroy": (C.c_int32, [vp]),
     "dp_async_stats": (C.c_int32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "dp_pcs_commit_submit": (C.c_int32, [vp, vp, C.POINTER(vp)]),

@@ -350,8 +350,14 @@ class AsyncEngine:
 
     def close(self):
         if self.h:
+            self.route_blocking_calls(False)
             check(_lib.load().dp_async_destroy(self.h))
             self.h = None
+
+    def route_blocking_calls(self, on=True):
+        """dp_ctx_route_to_engine: the BLOCKING seam calls of the device's context (prove_parallel, logup_batch_prove, Basefold.commit / batch_open,
+        fix_high, evaluate) become submit + wait on this engine — calls of one shape made by other threads at the same moment are merged"""
+        check(_lib.load().dp_ctx_route_to_engine(self.dev.h, self.h if on else None))
 
     def stats(self):
         a, b, c, d = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()

@@ -28,8 +28,19 @@ using namespace dp;
 // nodes, activation.rs:294-304 over columns): the entry points a host would call that way (uploads, commit, frees) take the
 // context's lock and bind the device to the calling thread — the device work of one context is one stream, so concurrent
 // callers are queued, not run in parallel.
-struct dp_ctx { Dev* dev; int device_id; std::recursive_mutex mu; };
+struct dp_async;
+struct dp_ctx { Dev* dev; int device_id; std::recursive_mutex mu; std::atomic<dp_async*> engine{nullptr}; };  // engine: dp_ctx_route_to_engine — the blocking seam calls of this context are submit + wait there
 struct CtxLock { std::unique_lock<std::recursive_mutex> l; explicit CtxLock(dp_ctx* c) : l(c->mu) { c->dev->bind_thread(); } };
+// ---- blocking seam calls routed through an engine (dp_ctx_route_to_engine): submit + wait. The ticket is freed whatever happens; a failed submit / wait /
+// result call rethrows the library's error (g_err holds its message) so that the blocking entry point reports it like one of its own.
+struct RoutedTicket {
+  dp_ticket* t = nullptr;
+  void wait();
+  dp_ctx* t_ctx();
+  ~RoutedTicket();
+};
+static void routed_check(int32_t rc);
+static dp_async* routed_engine(dp_ctx* ctx);
 struct dp_buf { DBuf b; };
 struct dp_transcript { Transcript t; };
 struct dp_commit { DevCommit c; };
@@ -192,6 +203,7 @@ int32_t dp_mle_eval(dp_ctx* ctx, const dp_buf* f, const uint64_t* point, uint32_
   return guard([&] {
     DP_REQUIRE(ctx && f && point && out, DP_ERR_ARG, "bad arguments");
     DP_REQUIRE(k < 48 && f->b.n == (size_t(1) << k), DP_ERR_SHAPE, "MLE size does not match the point");
+    if (dp_async* eng = routed_engine(ctx)) { RoutedTicket tk; routed_check(dp_mle_eval_submit(eng, f, point, k, &tk.t)); tk.wait(); routed_check(dp_ticket_values(tk.t, out, 2)); return; }
     std::vector<Ext> p = read_point(point, k); Ext r;
     ctx->dev->mle_eval_batch(&f->b, 1, p.data(), k, &r);
     out[0] = r.c0; out[1] = r.c1;
@@ -200,6 +212,7 @@ int32_t dp_mle_eval(dp_ctx* ctx, const dp_buf* f, const uint64_t* point, uint32_
 int32_t dp_mle_fix_high(dp_ctx* ctx, const dp_buf* m, size_t rows, size_t cols, const uint64_t* point, dp_buf** out) {
   return guard([&] {
     DP_REQUIRE(ctx && m && point && out && is_pow2(rows) && is_pow2(cols) && !m->b.ext && m->b.n == rows * cols, DP_ERR_SHAPE, "fix_high: bad matrix shape");
+    if (dp_async* eng = routed_engine(ctx)) { RoutedTicket tk; routed_check(dp_mle_fix_high_submit(eng, m, rows, cols, point, &tk.t)); tk.wait(); routed_check(dp_ticket_buf(tk.t, out)); return; }
     std::vector<Ext> p = read_point(point, dp_ceil_log2(rows));
     DBuf b = ctx->dev->alloc_persistent(cols, true);
     ctx->dev->fix_high(b, m->b, rows, cols, p.data());
@@ -233,6 +246,12 @@ int32_t dp_sumcheck_prove(dp_ctx* ctx, uint32_t nv, const dp_buf* const* tables,
   return guard([&] {
     DP_REQUIRE(ctx && tables && term_degree && term_tables && term_coeffs && t && proof_words && proof_nwords && ntables > 0 && nterms > 0 && nv > 0, DP_ERR_ARG, "bad arguments");
     DP_REQUIRE(nv < 48, DP_ERR_SHAPE, "num_vars out of range");
+    if (dp_async* eng = routed_engine(ctx)) {
+      RoutedTicket tk; routed_check(dp_sumcheck_prove_submit(eng, nv, tables, ntables, term_degree, term_tables, term_coeffs, nterms, t, &tk.t)); tk.wait();
+      routed_check(dp_ticket_words(tk.t, 0, proof_words, proof_nwords));
+      if (finals) routed_check(dp_ticket_values(tk.t, finals, 2 * (size_t)ntables));
+      return;
+    }
     DevVP vp(nv);
     read_terms(vp, tables, ntables, term_degree, term_tables, nterms, term_coeffs);
     SumcheckOut so = sumcheck_prove(*ctx->dev, vp, t->t);
@@ -459,6 +478,7 @@ int32_t dp_logup_prove(dp_ctx* ctx, const dp_buf* const* columns, int32_t ncols,
                        const uint64_t cc[2], const uint64_t csc[2], dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords) {
   return guard([&] {
     DP_REQUIRE(ctx && columns && ncols > 0 && cc && csc && t && proof_words && proof_nwords && cpi > 0, DP_ERR_ARG, "bad arguments");
+    if (dp_async* eng = routed_engine(ctx)) { RoutedTicket tk; routed_check(dp_logup_prove_submit(eng, columns, ncols, cpi, mult, cc, csc, t, &tk.t)); tk.wait(); routed_check(dp_ticket_words(tk.t, 0, proof_words, proof_nwords)); return; }
     LogUpInputDev in; in.is_table = mult != nullptr; in.columns_per_instance = cpi;
     for (int i = 0; i < ncols; i++) { DP_REQUIRE(columns[i], DP_ERR_ARG, "null column"); in.columns.push_back(columns[i]->b); }
     if (mult) { DP_REQUIRE(!mult->b.ext && mult->b.n == in.columns[0].n, DP_ERR_SHAPE, "multiplicities shape"); in.multiplicities = mult->b; }
@@ -504,6 +524,7 @@ int32_t dp_pcs_setup(dp_ctx* ctx, size_t max_poly_size) {
 int32_t dp_pcs_commit(dp_ctx* ctx, const dp_buf* poly, dp_commit** out, uint64_t root[4]) {
   return guard([&] {
     DP_REQUIRE(ctx && poly && out, DP_ERR_ARG, "bad arguments");
+    if (dp_async* eng = routed_engine(ctx)) { RoutedTicket tk; routed_check(dp_pcs_commit_submit(eng, poly, &tk.t)); tk.wait(); routed_check(dp_ticket_commit(tk.t, out, root)); return; }
     CtxLock lk(ctx);  // callable from several threads at once (queued on the context's stream)
     DevCommit c = ctx->dev->commit(poly->b, true);
     if (root) for (int k = 0; k < 4; k++) root[k] = c.tree.root.v[k];
@@ -574,6 +595,7 @@ int32_t dp_pcs_batch_open(dp_ctx* ctx, const dp_commit* const* comms, int32_t n,
                           dp_transcript* t, uint64_t** proof_words, size_t* proof_nwords) {
   return guard([&] {
     DP_REQUIRE(ctx && comms && n > 0 && points_flat && evals && t && proof_words && proof_nwords, DP_ERR_ARG, "bad arguments");
+    if (dp_async* eng = routed_engine(ctx)) { RoutedTicket tk; routed_check(dp_pcs_batch_open_submit(eng, comms, n, points_flat, evals, t, &tk.t)); tk.wait(); routed_check(dp_ticket_words(tk.t, 0, proof_words, proof_nwords)); return; }
     CtxLock lk(ctx);
     std::vector<unsigned> nvs; for (int i = 0; i < n; i++) { DP_REQUIRE(comms[i], DP_ERR_ARG, "null commitment"); nvs.push_back(comms[i]->c.nv); }
     std::vector<std::vector<Ext>> pts; std::vector<Ext> evs;
@@ -642,6 +664,7 @@ int32_t dp_pcs_batch_open_evals(dp_ctx* ctx, const dp_commit* const* comms, int3
 // Fiat-Shamir, fused protocol tails) and prove calls of IDENTICAL SHAPE that are queued together in lock step, launch for launch merged into one
 // (the launch sequence of every seam depends on shapes only, never on data). Results are bit-identical to the blocking calls.
 struct dp_ticket {
+  dp_ctx* owner = nullptr;    // the context of the engine the call was submitted to (its device pool holds what the call allocated)
   std::atomic<int> state{0};  // 0 queued / running, 1 done, < 0 failed
   std::string err;
   std::function<void(Dev&, dp_ticket&)> body;
@@ -729,6 +752,10 @@ void async_thread(dp_async* a) {
           try { d->abort_call(); } catch (...) {}
           try { d->sync(); } catch (...) {}
           if (marked) { try { d->release(mk); } catch (...) {} }
+          // a body that had already handed out its commitment / table when a later step (the final sync) failed: the device objects go back now — the ticket of
+          // a failed call holds nothing (dp_ticket_free only deletes wrappers)
+          if (t->commit) { try { d->free_commit(t->commit->c); } catch (...) {} delete t->commit; t->commit = nullptr; }
+          if (t->buf) { try { d->free_persistent(t->buf->b); } catch (...) {} delete t->buf; t->buf = nullptr; }
         }
         if (gp->merged) { try { hip_dev_cohort_detach(d); } catch (const std::exception& e) { if (code == 1) { t->err = e.what(); code = DP_ERR_HIP; } } }
         t->body = nullptr;
@@ -770,11 +797,15 @@ void async_thread(dp_async* a) {
   for (dp::Cohort* c : idle_cohorts) hip_cohort_free(c);
 }
 int32_t async_submit(dp_async* a, dp_ticket* t, dp_ticket** out) {
-  *out = t;
+  *out = t; t->owner = a->ctx;
   t->t_submit = std::chrono::steady_clock::now();
   // the tables of the call may have been uploaded through the owning context a moment ago: in throughput mode copies of up to 2 MB return before they ran on ITS
   // stream, and the call reads the tables on a worker's stream — nothing orders the two but this
-  { CtxLock lk(a->ctx); a->ctx->dev->flush_uploads(); }
+  // (a flush that fails — device timeout, HIP error — must not leave a ticket that is neither queued nor finished: the caller holds it already and would
+  // wait for ever, and dp_ticket_free refuses a running call: the ticket completes with the error instead)
+  try { CtxLock lk(a->ctx); a->ctx->dev->flush_uploads(); }
+  catch (const DpError& e) { t->err = e.what(); t->body = nullptr; t->state.store(e.code, std::memory_order_release); return DP_OK; }
+  catch (const std::exception& e) { t->err = e.what(); t->body = nullptr; t->state.store(DP_ERR_HIP, std::memory_order_release); return DP_OK; }
   { std::lock_guard<std::mutex> g(a->mu); a->queue.push_back(t); a->qsize++; }
   a->cv.notify_all();  // (notify_one could wake a thread lingering for a DIFFERENT shape, which leaves this ticket queued while idle threads sleep)
   return DP_OK;
@@ -800,6 +831,35 @@ int32_t dp_async_create(dp_ctx* ctx, int32_t max_in_flight, size_t worker_arena_
     nth = std::min<size_t>(std::min<size_t>(nth, 22), a->max_in_flight);
     for (size_t i = 0; i < nth; i++) a->threads.emplace_back(async_thread, a.get());
     *out = a.release();
+  });
+}
+/* Blocking seam calls that MERGE: after dp_ctx_route_to_engine(ctx, eng) the blocking forms of the seams on `ctx` — dp_pcs_commit, dp_pcs_batch_open,
+ * dp_sumcheck_prove, dp_logup_prove, dp_mle_fix_high, dp_mle_eval — are a submit to `eng` plus a wait: calls of the same shape that other threads make within
+ * the engine's linger window are proved in lock step with merged launches, exactly like the submit / poll forms, and the calling thread sleeps meanwhile
+ * instead of spinning on a stream of its own. This is what a host written against the reference's synchronous traits gets without restructuring
+ * (rust/basefold-hip, rust/sumcheck-hip-patch: rayon workers inside PCS::commit / prove_parallel): many blocked threads, few busy cores.
+ * The tables may have been uploaded through `ctx` a moment ago: its pending uploads are flushed before the submit. */
+static dp_async* routed_engine(dp_ctx* ctx) {
+  dp_async* eng = ctx ? ctx->engine.load(std::memory_order_acquire) : nullptr;
+  if (eng && eng->ctx != ctx) { CtxLock lk(ctx); ctx->dev->flush_uploads(); }  // (async_submit flushes the engine's own context)
+  return eng;
+}
+static void routed_check(int32_t rc) { if (rc != DP_OK) throw DpError(rc, g_err); }
+void RoutedTicket::wait() { routed_check(dp_wait(t)); }
+dp_ctx* RoutedTicket::t_ctx() { return t->owner; }
+RoutedTicket::~RoutedTicket() {
+  if (!t) return;
+  if (t->state.load(std::memory_order_acquire) == 0) dp_wait(t);  // (never free a running call: its body holds references to the caller's arguments)
+  // results nobody took (an error on the way): the device objects go back through the engine's context
+  if (t->commit) { CtxLock lk(t_ctx()); t_ctx()->dev->free_commit(t->commit->c); delete t->commit; t->commit = nullptr; }
+  if (t->buf) { CtxLock lk(t_ctx()); t_ctx()->dev->free_persistent(t->buf->b); delete t->buf; t->buf = nullptr; }
+  delete t;
+}
+int32_t dp_ctx_route_to_engine(dp_ctx* ctx, dp_async* engine) {
+  return guard([&] {
+    DP_REQUIRE(ctx, DP_ERR_ARG, "null context");
+    DP_REQUIRE(!engine || engine->ctx->device_id == ctx->device_id, DP_ERR_ARG, "dp_ctx_route_to_engine: the engine drives another device");
+    ctx->engine.store(engine, std::memory_order_release);
   });
 }
 int32_t dp_async_destroy(dp_async* a) {

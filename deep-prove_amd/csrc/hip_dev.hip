@@ -513,7 +513,13 @@ class HipDev : public Dev {
   }
 
  public:
+  // (the constructor allocates a stream, the arena — hundreds of megabytes for a batch worker — and pinned buffers one after the other: when a later one fails,
+  // typically with the device out of memory, what the earlier ones took goes back before the error travels on; the destructor of a half-built object never runs)
   explicit HipDev(int device, size_t arena_bytes = 0, size_t stage_bytes = 0) : device_(device) {
+    CPU_ZERO(&numa_cpus_); CPU_ZERO(&saved_affinity_);
+    try { init_(device, arena_bytes, stage_bytes); } catch (...) { destroy_(); throw; }
+  }
+  void init_(int device, size_t arena_bytes, size_t stage_bytes) {
     if (stage_bytes) STAGE_BYTES = stage_bytes;
     int cnt = 0;
     if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) throw DpError(DP_ERR_NODEVICE, "no HIP device available: the MI355X path is mandatory, there is no CPU fallback");
@@ -580,7 +586,8 @@ class HipDev : public Dev {
     DP_SET_LDS(k_med_prepare, 1024, 128 * 1024);
     DP_SET_LDS(k_med_ntt_local, 1024, 64 * 1024);
   }
-  ~HipDev() override {
+  ~HipDev() override { destroy_(); }
+  void destroy_() noexcept {
     numa_unpin_creator_();
     hipSetDevice(device_);
     if (s_) hipStreamSynchronize(s_);

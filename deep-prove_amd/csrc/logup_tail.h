@@ -52,9 +52,12 @@ struct LogupTailDesc {
 
 // Dynamic LDS of a k_logup_tail launch, in bytes: the kernel keeps table slots of S values — 1 + 4 * ninst tables and the second half of the eq table's
 // double buffer — and takes the tables of a layer into LDS from the first round in which they are at most S long. S = n / 2 (the widest layer from its
-// first round on) when that fits into DP_LOGUP_LDS_KB (default 64, at most 128), else the largest power of two that does.
+// first round on) when that fits into DP_LOGUP_LDS_KB (default 64, at most 80), else the largest power of two that does. 80: the launch also brings the
+// message (up to MSG_LDS_MAX = 48 KB, hip_dev.hip) in dynamic LDS and the kernel's attribute is 128 KB (DP_SET_LDS_ONE; with the 6.6 KB static frame still
+// inside the CU's 160 KB) — a larger setting made the LAUNCH fail instead of the kernel declining (advisor, round 5).
+constexpr size_t LOGUP_TAIL_LDS_CAP_KB = 80;
 inline size_t logup_tail_lds_bytes(size_t n, int ninst) {
-  static const size_t cap = [] { const char* e = getenv("DP_LOGUP_LDS_KB"); size_t kb = e ? (size_t)strtoull(e, nullptr, 10) : 64; if (kb < 4) kb = 4; if (kb > 128) kb = 128; return kb << 10; }();
+  static const size_t cap = [] { const char* e = getenv("DP_LOGUP_LDS_KB"); size_t kb = e ? (size_t)strtoull(e, nullptr, 10) : 64; if (kb < 4) kb = 4; if (kb > LOGUP_TAIL_LDS_CAP_KB) kb = LOGUP_TAIL_LDS_CAP_KB; return kb << 10; }();
   const size_t slots = 2 + 4 * (size_t)ninst;
   size_t S = 2;
   while (2 * S <= n / 2 && 2 * S * slots * 16 <= cap) S *= 2;

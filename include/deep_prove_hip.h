@@ -72,6 +72,13 @@ int32_t dp_ctx_set_throughput_mode(dp_ctx* ctx, int32_t on);
 typedef struct dp_async dp_async;
 typedef struct dp_ticket dp_ticket;
 int32_t dp_async_create(dp_ctx* ctx, int32_t max_in_flight, size_t worker_arena_bytes, dp_async** out);
+/* Blocking calls that merge (round 6): after this the BLOCKING forms of the seams on `ctx` — dp_pcs_commit, dp_pcs_batch_open (mpcs/src/lib.rs:111-226),
+ * dp_sumcheck_prove (sumcheck/src/prover.rs:498-501), dp_logup_prove (zkml/src/lookup/logup_gkr/prover.rs:24), dp_mle_fix_high, dp_mle_eval — are a submit to
+ * `engine` plus a wait: calls of identical shape made by OTHER threads (on this or any other context routed to the same engine) within its linger window
+ * are proved in lock step with merged launches, and the calling thread sleeps meanwhile. What a host written against the reference's synchronous traits
+ * gets without restructuring: the rayon workers of commit/context.rs:79-103 blocked inside PCS::commit are exactly such threads. engine = NULL detaches.
+ * The engine must drive the same device as `ctx`; results, errors and transcript effects are those of the un-routed calls. */
+int32_t dp_ctx_route_to_engine(dp_ctx* ctx, dp_async* engine);
 int32_t dp_async_destroy(dp_async* a);
 /* counters since creation: calls executed, groups they ran in, calls that ran merged with at least one other, worker contexts */
 int32_t dp_async_stats(dp_async* a, size_t* calls, size_t* groups, size_t* merged_calls, size_t* workers);

@@ -290,7 +290,7 @@ impl PolynomialCommitmentScheme<E> for BasefoldHip {
 pub struct AsyncEngine(*mut sys::dp_async);
 unsafe impl Send for AsyncEngine {}
 unsafe impl Sync for AsyncEngine {}
-impl Drop for AsyncEngine { fn drop(&mut self) { unsafe { sys::dp_async_destroy(self.0); } } }
+impl Drop for AsyncEngine { fn drop(&mut self) { unsafe { sys::dp_ctx_route_to_engine(ctx(), core::ptr::null_mut()); sys::dp_async_destroy(self.0); } } }
 /// a submitted call; dropping it waits for completion (the engine reads the caller's tables until then)
 pub struct PendingCommit { ticket: *mut sys::dp_ticket, table: Option<DeviceTable>, num_vars: usize, is_base: bool }
 pub struct PendingOpen { ticket: *mut sys::dp_ticket }
@@ -301,6 +301,12 @@ impl AsyncEngine {
         sys::check(unsafe { sys::dp_async_create(ctx(), max_in_flight as i32, 0, &mut h) }).map_err(pcs_err)?;
         Ok(AsyncEngine(h))
     }
+    /// Round 6: route the BLOCKING trait methods of this crate (`BasefoldHip::commit`, `batch_open`, and `prove_parallel` of `sumcheck-hip-patch`) through this
+    /// engine (`dp_ctx_route_to_engine`): every call becomes submit + wait, and calls of one shape that other rayon workers make at the same moment — the
+    /// `into_par_iter` over nodes of `zkml/src/commit/context.rs:79-103`, over columns of `layers/activation.rs:294-304` — are proved in lock step with merged
+    /// launches. The synchronous traits stay as they are; the number of calls in flight is the number of threads blocked in them.
+    pub fn route_blocking_calls(&self) -> Result<(), Error> { sys::check(unsafe { sys::dp_ctx_route_to_engine(ctx(), self.0) }).map_err(pcs_err) }
+    pub fn unroute_blocking_calls(&self) -> Result<(), Error> { sys::check(unsafe { sys::dp_ctx_route_to_engine(ctx(), core::ptr::null_mut()) }).map_err(pcs_err) }
     /// `PCS::commit(pp, &poly)`: the host polynomial is uploaded and committed by ONE ticket (`dp_pcs_commit_host_submit`)
     pub fn commit_async(&self, poly: &DenseMultilinearExtension<E>) -> Result<PendingCommit, Error> {
         let (words, n, is_ext) = poly_words(poly)?;

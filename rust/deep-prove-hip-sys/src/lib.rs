@@ -31,6 +31,7 @@ extern "C" {
     pub fn dp_ctx_set_throughput_mode(ctx: *mut dp_ctx, on: i32) -> i32;
     pub fn dp_async_create(ctx: *mut dp_ctx, max_in_flight: i32, worker_arena_bytes: usize, out_: *mut *mut dp_async) -> i32;
     pub fn dp_async_destroy(a: *mut dp_async) -> i32;
+    pub fn dp_ctx_route_to_engine(ctx: *mut dp_ctx, engine: *mut dp_async) -> i32;
     pub fn dp_async_stats(a: *mut dp_async, calls: *mut usize, groups: *mut usize, merged_calls: *mut usize, workers: *mut usize) -> i32;
     pub fn dp_pcs_commit_submit(a: *mut dp_async, poly: *const dp_buf, ticket: *mut *mut dp_ticket) -> i32;
     pub fn dp_pcs_commit_host_submit(a: *mut dp_async, words: *const u64, n: usize, is_ext: i32, ticket: *mut *mut dp_ticket) -> i32;

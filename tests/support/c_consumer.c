@@ -52,7 +52,7 @@ static int symbols_only(void) {
     (fn_t)dp_model_setup, (fn_t)dp_model_free, (fn_t)dp_model_prove, (fn_t)dp_model_prove_batch, (fn_t)dp_model_in_flight, (fn_t)dp_model_output_len,
     (fn_t)dp_host_cpu_budget, (fn_t)dp_host_poseidon2, (fn_t)dp_model_infer_host, (fn_t)dp_model_verifier_blob, (fn_t)dp_verify, (fn_t)dp_verify_batch, (fn_t)dp_dist_unique_id, (fn_t)dp_dist_init, (fn_t)dp_dist_free,
     (fn_t)dp_sumcheck_prove_sharded, (fn_t)dp_sumcheck_prove_sharded_local,
-    (fn_t)dp_ctx_set_throughput_mode, (fn_t)dp_async_create, (fn_t)dp_async_destroy, (fn_t)dp_async_stats, (fn_t)dp_pcs_commit_submit, (fn_t)dp_sumcheck_prove_submit,
+    (fn_t)dp_ctx_set_throughput_mode, (fn_t)dp_async_create, (fn_t)dp_ctx_route_to_engine, (fn_t)dp_async_destroy, (fn_t)dp_async_stats, (fn_t)dp_pcs_commit_submit, (fn_t)dp_sumcheck_prove_submit,
     (fn_t)dp_logup_prove_submit, (fn_t)dp_pcs_batch_open_submit, (fn_t)dp_poll, (fn_t)dp_wait, (fn_t)dp_ticket_words, (fn_t)dp_ticket_values, (fn_t)dp_ticket_commit, (fn_t)dp_ticket_free, (fn_t)dp_mle_fix_high_submit, (fn_t)dp_mle_eval_submit, (fn_t)dp_ticket_buf, (fn_t)dp_pcs_commit_host_submit};
   size_t n = sizeof syms / sizeof syms[0], ok = 0;
   for (size_t i = 0; i < n; i++) ok += syms[i] != NULL;

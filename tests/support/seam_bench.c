@@ -14,7 +14,9 @@
  * seams' bit-exactness is what tests/test_gpu_primitives.py, test_gpu_c_consumer.py and test_gpu_zzzz_rx.py establish). The figure
  * is therefore "seam-level, workload-equivalent proofs per second", to be read next to dp_model_prove_batch's rate.
  * usage: seam_bench <threads> <proofs per thread> [0: plain contexts | 2: plain contexts in throughput mode (dp_ctx_set_throughput_mode) |
- * 3: ONE thread, <threads> proofs in flight on one context through dp_async (submit / poll)] */
+ * 3: ONE thread, <threads> proofs in flight on one context through dp_async (submit / poll) |
+ * 4: <threads> threads making the BLOCKING calls of mode 0 on ONE shared context routed to one engine (dp_ctx_route_to_engine): what a host written against
+ *    the reference's synchronous traits gets — every call is a submit + wait, calls of the same shape from different threads are merged] */
 #define _POSIX_C_SOURCE 200809L
 #include "../../include/deep_prove_hip.h"
 #include <pthread.h>
@@ -250,6 +252,44 @@ static void worker_setup(struct worker* w) {
   fill(w->point20, 40, &seed); fill(w->point12, 24, &seed); fill(w->point15, 30, &seed); fill(w->point10, 20, &seed);
 }
 
+/* ---- mode 4: T threads, blocking calls, ONE context whose seam calls are routed to one engine */
+static struct worker g_shared;
+static void* run_routed(void* arg) {
+  struct worker* w = (struct worker*)arg;
+  pthread_barrier_wait(&g_start);
+  one_proof(w);  /* warm-up */
+  pthread_barrier_wait(&g_start);
+  const double t0 = now_s();
+  for (int i = 0; i < w->proofs; i++) one_proof(w);
+  w->seconds = now_s() - t0;
+  pthread_barrier_wait(&g_start);
+  return NULL;
+}
+static int run_routed_main(int T, int per) {
+  memset(&g_shared, 0, sizeof g_shared);
+  worker_setup(&g_shared);
+  dp_async* eng = NULL;
+  CHECK(dp_async_create(g_shared.ctx, T > 64 ? T : 64, 0, &eng));
+  CHECK(dp_ctx_route_to_engine(g_shared.ctx, eng));
+  pthread_barrier_init(&g_start, NULL, (unsigned)T + 1);
+  struct worker* ws = (struct worker*)calloc((size_t)T, sizeof *ws);
+  pthread_t* th = (pthread_t*)calloc((size_t)T, sizeof *th);
+  for (int i = 0; i < T; i++) { ws[i] = g_shared; ws[i].id = i; ws[i].proofs = per; pthread_create(&th[i], NULL, run_routed, &ws[i]); }
+  pthread_barrier_wait(&g_start);
+  pthread_barrier_wait(&g_start);  /* warm-up proofs done */
+  const double t0 = now_s();
+  pthread_barrier_wait(&g_start);
+  const double dt = now_s() - t0;
+  for (int i = 0; i < T; i++) pthread_join(th[i], NULL);
+  size_t calls = 0, groups = 0, merged = 0, workers = 0;
+  CHECK(dp_async_stats(eng, &calls, &groups, &merged, &workers));
+  CHECK(dp_ctx_route_to_engine(g_shared.ctx, NULL));
+  CHECK(dp_async_destroy(eng));
+  printf("{\"seam_level_proofs_per_s\": %.2f, \"threads\": %d, \"proofs\": %d, \"seconds\": %.3f, \"blocking_calls_routed_to_engine\": true, \"calls\": %zu, \"groups\": %zu, \"calls_merged\": %zu, \"workers\": %zu, "
+         "\"ms_per_proof_per_thread\": %.1f}\n", (double)T * per / dt, T, T * per, dt, calls, groups, merged, workers, 1000.0 * dt / per);
+  return 0;
+}
+
 static void* run(void* arg) {
   struct worker* w = (struct worker*)arg;
   worker_setup(w);
@@ -267,8 +307,9 @@ static void* run(void* arg) {
 
 int main(int argc, char** argv) {
   const int T = argc > 1 ? atoi(argv[1]) : 8, per = argc > 2 ? atoi(argv[2]) : 4, use_executor = argc > 3 ? atoi(argv[3]) : 0;
-  if (T < 1 || T > 1024 || per < 1) { fprintf(stderr, "usage: seam_bench <threads | proofs in flight> <proofs per thread> [0 | 2 | 3]\n"); return 2; }
+  if (T < 1 || T > 1024 || per < 1) { fprintf(stderr, "usage: seam_bench <threads | proofs in flight> <proofs per thread> [0 | 2 | 3 | 4]\n"); return 2; }
   if (use_executor == 3) return run_async(T, per);
+  if (use_executor == 4) return run_routed_main(T, per);
   pthread_barrier_init(&g_start, NULL, (unsigned)T + 1);
   struct worker* ws = (struct worker*)calloc((size_t)T, sizeof *ws);
   pthread_t* th = (pthread_t*)calloc((size_t)T, sizeof *th);

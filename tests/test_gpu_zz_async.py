@@ -124,3 +124,57 @@ def test_async_commit_and_batch_open_match_the_blocking_calls(dev, oracle):
         assert eng.stats()["calls"] == 24  # (how many of them ran merged depends on how fast this interpreter submits: the first test pins the merging)
     finally:
         eng.close()
+
+
+def test_blocking_calls_routed_to_an_engine_merge_across_threads_and_match_the_unrouted_calls(dev, oracle):
+    """dp_ctx_route_to_engine (round 6): the BLOCKING seam calls of a context become submit + wait on an engine. Eight host threads make the same sumcheck / lookup /
+    commit / fix_high / evaluate calls a seam-level host makes; every result equals the un-routed blocking call's, the transcripts end in the same state, and the
+    engine's counters say that calls of different threads ran merged. (ctypes releases the GIL inside the calls: the threads really block concurrently.)"""
+    import threading
+    import deep_prove_amd as dpa
+    rng = np.random.default_rng(909)
+    pcs = dpa.Basefold(dev, 1 << 14)
+    nv, n, T = 10, 1 << 10, 8
+    jobs = []
+    for j in range(T):
+        tabs = [rand_base(rng, n) for _ in range(2)]
+        cols = [rng.integers(0, 1 << 20, size=n, dtype=np.uint64) for _ in range(2)]
+        jobs.append((tabs, cols, rand_point(rng, 1)[0], rand_point(rng, 1)[0], rand_point(rng, nv), rand_base(rng, 1 << 12)))
+
+    def one(job, out, idx):
+        tabs, cols, cc, csc, pt, poly = job
+        t1, t2 = dpa.Transcript(b"routed"), dpa.Transcript(b"routed")
+        m = [dpa.Mle.from_base(dev, tabs[0]), dpa.Mle.from_base(dev, tabs[1])]
+        vp = dpa.VirtualPolynomial(nv)
+        vp.add_mle_list([m[0], m[1]], (1, 0))
+        pw, fin = dpa.prove_parallel(dev, vp, t1)
+        lw = dpa.logup_batch_prove(dev, [dpa.Mle.from_base(dev, c) for c in cols], 2, cc, csc, t2)
+        ev = m[0].evaluate(pt)
+        com = pcs.commit(dpa.Mle.from_base(dev, poly))
+        out[idx] = (pw, fin, t1.read_challenge(), lw, t2.read_challenge(), ev, np.array(com.root))
+
+    ref = [None] * T
+    for j in range(T):
+        one(jobs[j], ref, j)
+    eng = dpa.AsyncEngine(dev, max_in_flight=16, worker_arena_bytes=256 << 20)
+    try:
+        eng.route_blocking_calls()
+        got = [None] * T
+        th = [threading.Thread(target=one, args=(jobs[j], got, j)) for j in range(T)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for j in range(T):
+            assert got[j] is not None, "a routed thread failed"
+            for a, b in zip(ref[j], got[j]):
+                assert np.array_equal(np.asarray(a), np.asarray(b))
+        st = eng.stats()
+        assert st["calls"] >= 4 * T and st["merged_calls"] >= 2, st  # (how many meet in one group is timing; that the merged path ran is not)
+        eng.route_blocking_calls(False)
+        again = [None]
+        one(jobs[0], again, 0)  # detached: the plain blocking path again
+        for a, b in zip(ref[0], again[0]):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+    finally:
+        eng.close()
