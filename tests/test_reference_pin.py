@@ -45,6 +45,86 @@ def oracle_values():
     return v
 
 
+def _ext_pairs(a, b):
+    """interleaved words of the extension vector (a_i, b_i)"""
+    return np.stack([np.asarray(a, dtype=np.uint64), np.asarray(b, dtype=np.uint64)], axis=1).reshape(-1)
+
+
+def oracle_objects():
+    """the L3 / L4 objects of the pin kit (items 7-10 of tools/pin/reference_pin/src/main.rs) as canonical streams of csrc/proof.h, from the oracle:
+    {name: (stream, kind)} with kind in logup / basefold / proof, plus the scalar values printed beside them"""
+    from support import oracle_lib
+    import deep_prove_amd.models as M
+    o = oracle_lib.load()
+    obj, val = {}, {}
+    # 7. logup-GKR: a 2^6-row lookup into a 2^8-row table, then the table's own proof
+    i = np.arange(256, dtype=np.uint64)
+    tab0, tab1 = i, (i * i) % np.uint64(251)
+    rows = (np.uint64(37) * np.arange(64, dtype=np.uint64) + np.uint64(11)) % np.uint64(256)
+    l0, l1 = rows, (rows * rows) % np.uint64(251)
+    mult = np.bincount(rows.astype(np.int64), minlength=256).astype(np.uint64)
+    cc, chi = (12345, 678), (91011, 1213)
+    t = o.transcript(b"m2vec")
+    obj["logup_lookup_proof"] = (o.logup_prove([l0, l1], 2, cc, chi, t, None), "logup")
+    val["logup_lookup_next_challenge"] = [int(x) for x in t.read_challenge()]
+    t = o.transcript(b"m2vec")
+    obj["logup_table_proof"] = (o.logup_prove([tab0, tab1], 2, cc, chi, t, mult), "logup")
+    val["logup_table_next_challenge"] = [int(x) for x in t.read_challenge()]
+    # 8. batch_open of 8 / 10 (extension) / 12 variables, each polynomial at its own point
+    k8, k10, k12 = (np.arange(1 << n, dtype=np.uint64) for n in (8, 10, 12))
+    polys = [k8 * k8 + 1, _ext_pairs(k10 + 1, 2 * k10 + 3), 5 * k12 + 7]
+    is_ext = [False, True, False]
+    points = [[(1000 * k + j + 1, 7 * j + k) for j in range(n)] for k, n in enumerate((8, 10, 12))]
+    evals = [tuple(int(x) for x in o.mle_eval(polys[k], is_ext[k], points[k])) for k in range(3)]
+    val["batch_open_values"] = [list(e) for e in evals]
+    val["batch_open_roots"] = [[int(x) for x in o.pcs_commit_root(1 << 12, polys[k], is_ext[k])] for k in range(3)]
+    t = o.transcript(b"m2vec")
+    obj["batch_open_proof"] = (o.pcs_batch_open(1 << 12, polys, is_ext, points, evals, t), "basefold")
+    val["batch_open_next_challenge"] = [int(x) for x in t.read_challenge()]
+    # 9. / 10. whole proofs: Dense 128 x 128 (BASELINE config 1) and one Dense + Requant + ReLU block of width 64 (tensors of config 7)
+    for name, mb in (("dense128", M.dense_128()), ("block", M.ModelBuilder(64, config=7).dense(64, 64).relu())):
+        h = o.model_setup(mb.blob())
+        proof, out, _ = o.model_prove(h, mb.input())
+        o.model_free(h)
+        obj[name + "_proof"] = (proof, "proof")
+        val[name + "_output"] = [int(x) for x in out]
+    return obj, val
+
+
+def _rmp(stream, kind, conv):
+    from deep_prove_amd import wire
+    if kind == "proof":
+        return wire.to_rmp(stream, conv)
+    if kind == "basefold":
+        return wire.pcs_proof_to_rmp(stream, False, conv)
+    r = wire._Reader(stream)
+    out = []
+    wire._pack(wire._logup(r.logup(), conv), out, conv)
+    return b"".join(out)
+
+
+P = 0xFFFFFFFF00000001
+
+
+def _leaves(tree, out):
+    """every leaf of a decoded msgpack tree in order, integers reduced mod p (the reference may serialise a non-canonical Goldilocks word), maps with
+    integer keys (HashMap<NodeId, LayerProof>: arbitrary order in the reference, F4) visited in ascending key order, map keys that are strings kept: the
+    comparison does not depend on how field / extension elements are wrapped (wire.Conventions), only on names, order and values"""
+    if isinstance(tree, dict):
+        items = sorted(tree.items()) if all(isinstance(k, int) for k in tree) else tree.items()
+        for k, x in items:
+            out.append(k)
+            _leaves(x, out)
+    elif isinstance(tree, (list, tuple)):
+        for x in tree:
+            _leaves(x, out)
+    elif isinstance(tree, int) and not isinstance(tree, bool):
+        out.append(tree % P)
+    else:
+        out.append(tree)
+    return out
+
+
 @pytest.fixture(scope="module")
 def vals():
     return oracle_values()
@@ -55,6 +135,53 @@ def test_oracle_still_produces_the_recorded_expectations(vals):
         json.dump(vals, open(EXPECTED, "w"), indent=1)
     want = json.load(open(EXPECTED))
     assert want == vals, "the oracle's values on the pin kit's inputs changed: L0-L2 of the restatement moved"
+
+
+EXPECTED_OBJECTS = os.path.join(ROOT, "tests", "golden", "reference_pin_expected_objects_by_oracle.json")
+
+
+@pytest.fixture(scope="module")
+def objects():
+    return oracle_objects()
+
+
+def test_oracle_still_produces_the_recorded_l3_l4_objects(objects):
+    """items 7-10 of the pin kit (logup-GKR batch_prove, batch_open, two whole proofs): the oracle's canonical streams and their msgpack form under the default
+    conventions, recorded by length and sha256 (the objects are megabytes) next to the scalar values the binary prints beside them"""
+    import hashlib
+    from deep_prove_amd import wire
+    obj, val = objects
+    rec = dict(val)
+    for name, (stream, kind) in obj.items():
+        b = _rmp(stream, kind, wire.Conventions)
+        rec[name] = {"stream_words": int(stream.size), "stream_sha256": hashlib.sha256(np.ascontiguousarray(stream).tobytes()).hexdigest(),
+                     "rmp_named_bytes_default_conventions": len(b), "rmp_named_sha256_default_conventions": hashlib.sha256(b).hexdigest()}
+    if not os.path.exists(EXPECTED_OBJECTS) or os.environ.get("DP_REGENERATE_PIN_EXPECTATIONS"):
+        json.dump(rec, open(EXPECTED_OBJECTS, "w"), indent=1)
+    assert json.load(open(EXPECTED_OBJECTS)) == rec, "the oracle's L3 / L4 objects on the pin kit's inputs changed"
+
+
+def test_l3_l4_objects_survive_the_wire_format_and_the_leaf_comparison_is_convention_free(objects):
+    """what the comparison with the reference will rest on, exercised without the reference: every object's msgpack form decodes, its leaves (names, order,
+    values mod p) are the same under all eight settings of wire.Conventions, and a changed word of the stream changes them"""
+    from deep_prove_amd import wire
+    obj, _ = objects
+    for name, (stream, kind) in obj.items():
+        base = None
+        for fm, em, ph in itertools.product((True, False), repeat=3):
+            conv = type("C", (), dict(field_as_map=fm, ext_as_map=em, phantom_is_empty_array=ph))
+            tree, end = wire._unpack(_rmp(stream, kind, conv), 0)
+            lv = [x for x in _leaves(tree, []) if x != "value" and x is not None and x != []]
+            base = base or lv
+            assert lv == base, name
+        s2 = np.array(stream, copy=True)
+        s2[s2.size // 2] ^= np.uint64(1)
+        try:
+            tree, _ = wire._unpack(_rmp(s2, kind, wire.Conventions), 0)
+            changed = [x for x in _leaves(tree, []) if x != "value" and x is not None and x != []] != base
+        except Exception:  # noqa: BLE001  (a flipped length word makes the stream unparsable: also a difference)
+            changed = True
+        assert changed, name
 
 
 def _wire_bytes(vals, conv):
@@ -89,3 +216,29 @@ def test_oracle_equals_the_reference(vals):
     assert hits, "no setting of wire.Conventions reproduces the reference's rmp_serde bytes of the sumcheck proof"
     dflt = (wire.Conventions.field_as_map, wire.Conventions.ext_as_map, wire.Conventions.phantom_is_empty_array)
     assert any(h[:2] == dflt[:2] for h in hits), f"wire.Conventions defaults {dflt} differ from what the reference writes: {hits}"
+
+
+@pytest.mark.skipif(not os.path.exists(PIN), reason="tests/golden/reference_pin.json absent: run tools/pin_with_cargo.sh on a machine with cargo (nightly-2025-05-22) and the Plonky3 dependencies")
+@pytest.mark.parametrize("name,rows", [("logup_lookup_proof", "a8"), ("logup_table_proof", "a8"), ("batch_open_proof", "a12-a16"),
+                                       ("dense128_proof", "a2 a19 a22"), ("block_proof", "a9 a10 a20")])
+def test_l3_l4_objects_equal_the_reference(objects, name, rows):
+    """one assertion per group of SURVEY §8(a) rows: the reference's rmp_serde bytes of the object decode to the same leaves (field names, order, values mod p;
+    HashMap entries by ascending NodeId) as the oracle's canonical stream put through deep-prove_amd/wire.py — then, for some setting of the recalled
+    conventions, to the same BYTES"""
+    from deep_prove_amd import wire
+    ref = json.load(open(PIN))
+    obj, val = objects
+    for key, mine in val.items():
+        if key.startswith(name.rsplit("_", 1)[0]):
+            assert ref.get(key) == mine, f"{key} (rows {rows}): the reference computes {ref.get(key)}, the oracle {mine}"
+    want = bytes.fromhex(ref[name + "_rmp_named_hex"])
+    stream, kind = obj[name]
+    clean = lambda t: [x for x in _leaves(t, []) if x != "value" and x is not None and x != []]  # noqa: E731
+    rt, end = wire._unpack(want, 0)
+    assert end == len(want)
+    mt, _ = wire._unpack(_rmp(stream, kind, wire.Conventions), 0)
+    a, b = clean(rt), clean(mt)
+    first = next((i for i, (x, y) in enumerate(zip(a, b)) if x != y), min(len(a), len(b)))
+    assert a == b, f"{name} (rows {rows}): leaf {first} of {len(a)} / {len(b)}: the reference has {a[first:first + 4]}, the oracle {b[first:first + 4]} (after {a[max(0, first - 6):first]})"
+    hits = [c for c in itertools.product((True, False), repeat=3) if _rmp(stream, kind, type("C", (), dict(field_as_map=c[0], ext_as_map=c[1], phantom_is_empty_array=c[2]))) == want]
+    assert hits, f"{name}: same leaves, but no setting of wire.Conventions reproduces the reference's bytes"
