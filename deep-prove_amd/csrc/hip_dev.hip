@@ -1420,7 +1420,8 @@ class HipDev : public Dev {
       read_terms();
       return;
     }
-    if (!share_x_ && !r && multi_ && persist_ && n_after >= MULTI_MIN_N && n_in <= MULTI_MAX_N && nraw * 2 * MULTI_MAX_WG <= RES_WORDS) {
+    static const bool multi_mid = getenv("DP_MULTI_MID") && atoi(getenv("DP_MULTI_MID"));  // (experiment, round 6: enter the phase in the middle of a streaming sumcheck — the mailbox is device memory now)
+    if (!share_x_ && (!r || (multi_mid && !throughput_mode_)) && multi_ && persist_ && n_after >= MULTI_MIN_N && n_in <= MULTI_MAX_N && nraw * 2 * MULTI_MAX_WG <= RES_WORDS) {
       // ---- multi-workgroup phase: G workgroups own contiguous slices, fold until the tables are MULTI_TARGET_N long. It may
       // begin in the middle of a sumcheck (r given: the streaming rounds of a large sumcheck hand over as soon as the tables
       // fit): every workgroup then first folds its slice with the pending challenge. Measured on the 2^24 sumcheck that costs
