@@ -21,7 +21,7 @@
 #include <thread>
 
 DP_FIBER_SWITCH_ASM
-namespace dp { struct Cohort; Cohort* hip_cohort_new(); Cohort* hip_cohort_new_sharing(Cohort* with); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_pcs_share(Dev* worker, Dev* owner); void hip_dump_wg_times(); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
+namespace dp { struct Cohort; struct PhaseGate; PhaseGate* hip_gate_new(); void hip_gate_free(PhaseGate* g); void hip_gate_set(PhaseGate* g, int slots); size_t hip_gate_waits(PhaseGate* g); void hip_cohort_set_gate(Cohort* c, PhaseGate* g); Cohort* hip_cohort_new(); Cohort* hip_cohort_new_sharing(Cohort* with); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_pcs_share(Dev* worker, Dev* owner); void hip_dump_wg_times(); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
 using namespace dp;
 
 // `mu`: PCS::commit is called from rayon workers in the reference (zkml/src/commit/context.rs:79-103 into_par_iter over
@@ -48,7 +48,8 @@ struct dp_batch_commit { DevBatchCommit c; };
 struct dp_model {
   dp_ctx* ctx; std::unique_ptr<Context> zk; std::vector<std::unique_ptr<Dev>> workers; std::vector<dp::Cohort*> cohorts;
   size_t last_in_flight = 0, in_flight_cap = 0; size_t prove_peak = 0;  // largest arena footprint a proof of this model has had so far (sizes the arenas of batch workers)
-  ~dp_model() { for (size_t i = cohorts.size(); i-- > 0;) hip_cohort_free(cohorts[i]); }  // (last first: a cohort that shares a stream goes before the one that owns it)
+  dp::PhaseGate* gate = nullptr;  // admission to the GPU-heavy stretch of a proof (Dev::phase_gate), shared by the cohorts of this model
+  ~dp_model() { for (size_t i = cohorts.size(); i-- > 0;) hip_cohort_free(cohorts[i]); if (gate) hip_gate_free(gate); }  // (last first: a cohort that shares a stream goes before the one that owns it)
 };
 
 // Every cohort stream needs a hardware queue of its own (24 are served without time slicing; the HIP runtime multiplexes streams
@@ -1196,6 +1197,13 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     size_t csize = ce ? (size_t)std::max(0, atoi(ce)) : std::max<size_t>(1, (nw + 22 * share - 1) / (22 * share));
     size_t nco = (csize >= 1 && nw > 1) ? (nw + csize - 1) / csize : 0;
     while (m->cohorts.size() < nco) { const size_t c = m->cohorts.size(); m->cohorts.push_back(c % share ? hip_cohort_new_sharing(m->cohorts[c - c % share]) : hip_cohort_new()); }
+    // DP_HEAVY_GATE = L (0 = off): at most L cohorts inside the batch opening at a time (struct PhaseGate, hip_dev.hip) — the others wait at its door
+    // while the chip is busy, and their protocol tails then run beside the hashing of those inside instead of all tails / all hashing at once
+    const int gate_slots = getenv("DP_HEAVY_GATE") ? std::max(0, atoi(getenv("DP_HEAVY_GATE"))) : 0;
+    const bool gated = gate_slots > 0 && (size_t)gate_slots < nco;
+    if (gated && !m->gate) m->gate = hip_gate_new();
+    if (gated) hip_gate_set(m->gate, gate_slots);
+    for (size_t c = 0; c < nco; c++) hip_cohort_set_gate(m->cohorts[c], gated ? m->gate : nullptr);
     auto dev_of = [&](size_t wi) -> Dev& { return wi == 0 ? *m->ctx->dev : *m->workers[wi - 1]; };
     std::atomic<size_t> next(0);
     const bool timing = getenv("DP_TIMING") && atoi(getenv("DP_TIMING"));
@@ -1330,6 +1338,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     if (nco && getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) {
       size_t f = 0, p = 0; for (size_t c = 0; c < nco; c++) { size_t a, b; hip_cohort_stats(m->cohorts[c], &a, &b); f += a; p += b; }
       fprintf(stderr, "[dp timing] %zu cohorts of <= %zu proofs: %zu merged launches for %zu proof launches\n", nco, csize, f, p);
+      if (gated) fprintf(stderr, "[dp timing] heavy-stretch gate: %d slots, %zu polls found it full\n", gate_slots, hip_gate_waits(m->gate));
     }
     if (getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) {
       size_t wpeak = 0; for (auto& w : m->workers) wpeak = std::max(wpeak, hip_dev_arena_peak(w.get()));

@@ -108,7 +108,19 @@ static inline void dp_spin_pause() { if (g_wait_yield) sched_yield(); else __bui
 // dozen independent streams of tiny kernels) are paid once per cohort step instead of once per proof step.
 // A member never blocks at a launch: it drops its argument pack and goes on to its next wait (where it yields to the next
 // member); whoever completes a launch's set of packs fires it. Everything is driven from the cohort's one host thread.
+// Admission gate of the GPU-heavy stretch (Dev::phase_gate): `slots` cohorts may be inside at a time; one gate per model (dp_model_prove_batch).
+// The cohorts of a batch start together and issue identical launch sequences: left alone they stay in phase — every queue hashes Merkle layers at the same
+// time (launches wait milliseconds for wave slots) and every queue runs one-workgroup tails at the same time (44 % of the k_logup_tail launches of a 448-proof
+// batch ran with NO wide kernel on the chip, profiles/r06_trace_analysis_448_mid_round.txt; VALU issue 0.63). With the gate the cohorts that cannot enter wait
+// at the door while the chip is busy with those inside, and from then on their light stretches run beside the others' heavy ones.
+struct PhaseGate {
+  std::atomic<int> free_slots{0};
+  std::atomic<size_t> waits{0};  // (statistics: polls that found the gate full)
+};
 struct Cohort {
+  PhaseGate* gate = nullptr;  // null: no admission control
+  int gate_state = 0;         // 0 outside, 1 a member is acquiring a slot, 2 inside (all members of a cohort live on one host thread: plain ints)
+  int gate_inside = 0;        // members between enter and leave
   struct Pending {
     void (*fire)(const Pending&, hipStream_t);  // also the identity of the kernel (one instantiation per Body)
     const char* name;
@@ -221,6 +233,7 @@ class HipDev : public Dev {
   // of a wait to its success (device latency + the other fibers of this thread)
   struct Chunk { size_t wait; double us; const char* first; const char* last; };
   std::vector<Chunk> chunks_; const char* first_launch_ = nullptr; const char* last_launch_ = nullptr;
+  std::map<std::pair<const char*, const char*>, std::pair<double, size_t>> chunk_by_;  // DP_TIMING=3: host work before a wait by (first, last) launch issued in it
   double work_us_ = 0, waitlat_us_ = 0; std::chrono::steady_clock::time_point last_exit_{}; bool have_exit_ = false;
   std::chrono::steady_clock::time_point wait_enter_() {
     auto t = std::chrono::steady_clock::now();
@@ -228,6 +241,7 @@ class HipDev : public Dev {
       double c = std::chrono::duration<double, std::micro>(t - last_exit_).count();
       work_us_ += c;
       if (c > 150.0 && chunks_.size() < 400) chunks_.push_back({nwait_, c, first_launch_, last_launch_});
+      if (g_timing_level > 2) { auto& e = chunk_by_[{first_launch_, last_launch_}]; e.first += c; e.second++; }
     }
     first_launch_ = nullptr;
     return t;
@@ -658,6 +672,13 @@ class HipDev : public Dev {
     by_name_.clear();
     if (g_timing_level > 1) for (auto& c : chunks_) fprintf(stderr, "[dp chunk] before wait %zu: %.0f us of host work, launches %s .. %s\n", c.wait, c.us, c.first ? c.first : "-", c.last ? c.last : "-");
     chunks_.clear();
+    if (g_timing_level > 2) {
+      std::vector<std::pair<double, std::string>> v;
+      for (auto& kv : chunk_by_) { char b[256]; snprintf(b, sizeof b, "%8.1f us total, %5zu times, %7.1f us each: %s .. %s", kv.second.first, kv.second.second, kv.second.first / kv.second.second, kv.first.first ? kv.first.first : "-", kv.first.second ? kv.first.second : "-"); v.push_back({kv.second.first, b}); }
+      std::sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.first > b.first; });
+      for (auto& e : v) fprintf(stderr, "[dp host-work] %s\n", e.second.c_str());
+    }
+    chunk_by_.clear();
     launch_us_ = 0; nlaunch_ = nwait_ = nyield_ = 0; work_us_ = waitlat_us_ = 0; have_exit_ = false;
   }
   void dump_sc_debug() {
@@ -853,8 +874,35 @@ class HipDev : public Dev {
     HIP_CHECK(hipStreamSynchronize(s_));
     co->join(); co_ = co; co_li_ = co->q_base;
   }
-  void cohort_detach() { if (co_) { Cohort* c = co_; co_ = nullptr; c->leave(co_li_); } }
+  void cohort_detach() { if (co_) { if (gate_in_) phase_gate(false); Cohort* c = co_; co_ = nullptr; c->leave(co_li_); } }
   bool in_cohort() const { return co_ != nullptr; }
+  // Dev::phase_gate: the first member of the cohort that arrives takes one of the gate's slots for the whole cohort (yielding to the other fibers of its thread while
+  // there is none), the members behind it wait until it has it; the last member that leaves gives the slot back. The members run in lock step, so nobody can be
+  // through the stretch before everybody has entered it.
+  bool gate_in_ = false;
+  void phase_gate(bool enter) override {
+    Cohort* c = co_;
+    if (!c || !c->gate || !fiber_active()) return;
+    if (enter) {
+      if (gate_in_) return;
+      if (c->gate_state == 0) {
+        c->gate_state = 1;
+        for (;;) {
+          int f = c->gate->free_slots.load(std::memory_order_relaxed);
+          if (f > 0 && c->gate->free_slots.compare_exchange_weak(f, f - 1, std::memory_order_acquire)) break;
+          c->gate->waits.fetch_add(1, std::memory_order_relaxed);
+          fiber_yield();
+        }
+        c->gate_state = 2;
+        fiber_note_progress();
+      } else while (c->gate_state != 2) fiber_yield();
+      c->gate_inside++; gate_in_ = true;
+    } else {
+      if (!gate_in_) return;
+      gate_in_ = false;
+      if (--c->gate_inside == 0) { c->gate_state = 0; c->gate->free_slots.fetch_add(1, std::memory_order_release); }
+    }
+  }
   void sync() override { stream_wait(); }
   void flush_uploads() override { if (stage_off_) { stream_wait(); stage_off_ = 0; } }
   void abort_call() override { sess_ = ScSession(); }
@@ -2076,6 +2124,11 @@ Dev* make_hip_worker(int device, size_t arena_bytes) { return new HipDev(device,
 Cohort* hip_cohort_new() { const char* e = getenv("DP_COHORT_RING_BYTES"); return e ? new Cohort(strtoull(e, nullptr, 10)) : new Cohort(); }
 Cohort* hip_cohort_new_sharing(Cohort* with) { const char* e = getenv("DP_COHORT_RING_BYTES"); return new Cohort(e ? strtoull(e, nullptr, 10) : size_t(32) << 20, with); }
 void hip_cohort_free(Cohort* c) { delete c; }
+PhaseGate* hip_gate_new() { return new PhaseGate(); }
+void hip_gate_free(PhaseGate* g) { delete g; }
+void hip_gate_set(PhaseGate* g, int slots) { g->free_slots.store(slots); g->waits.store(0); }
+size_t hip_gate_waits(PhaseGate* g) { return g->waits.load(); }
+void hip_cohort_set_gate(Cohort* c, PhaseGate* g) { c->gate = g; c->gate_state = 0; c->gate_inside = 0; }
 void hip_cohort_drain(Cohort* c) { c->drain(); }
 void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs) {
   *fired = c->nfired; *packs = c->npacks; c->nfired = c->npacks = 0;

@@ -1524,6 +1524,7 @@ inline SamePolyProof same_poly_prove(Dev& dev, const std::vector<Claim>& claims,
 // claim is never used — polynomials of at most 2^7 entries, opened by showing them (`_eval` of Basefold::open, mpcs/src/basefold.rs:466-483; the size of
 // the reference's own test, activation.rs:686-697) — or multiplier = 1. Here the commitment gets the claim the verifier will check; the proof stream is
 // the reference's wherever the reference produces one that verifies.
+inline bool gelu_reference_letter() { const char* e = getenv("DP_GELU_REFERENCE_LETTER"); return e && atoi(e) != 0; }  // (read per proof: a host may switch between proofs)
 inline Claim prove_relu(ProverState& ps, size_t id, const Claim& last, const std::vector<int64_t>& output, int64_t multiplier = 0) {
   Dev& dev = *ps.dev;
   LogUpWitness& w = ps.lookup_witness.at(id)[0];
@@ -1536,11 +1537,14 @@ inline Claim prove_relu(ProverState& ps, size_t id, const Claim& last, const std
   SamePolyProof sp = same_poly_prove(dev, {last, output_claim}, out, *ps.t);
   dev.release(mk);
   ActivationProof ap; ap.io_accumulation = sp; ap.lookup = lproof;
-  ps.add_witness_claim(w.commits[0], input_claim); ap.commits.push_back(pure_commitment(w.commits[0]));
+  Claim descaled = input_claim;
+  if (multiplier) descaled.eval = ex_mul(input_claim.eval, ex_inv(ex_from_i64(multiplier)));
+  // DP_GELU_REFERENCE_LETTER=1: the commitment of the scaled column gets the DESCALED claim, as the reference's prover files it (:419-430) — the reference
+  // prover's byte stream for every GELU model; it only verifies where the reference's own does (columns of <= 2^7 entries, or multiplier 1)
+  ps.add_witness_claim(w.commits[0], multiplier && gelu_reference_letter() ? descaled : input_claim); ap.commits.push_back(pure_commitment(w.commits[0]));
   ps.add_witness_claim(w.commits[1], {sp.sumcheck.point, sp.evals[1]}); ap.commits.push_back(pure_commitment(w.commits[1]));
   LayerProof lp; lp.kind = multiplier ? L_GELU : L_RELU; lp.act = ap; ps.proofs[id] = lp;
-  if (multiplier) input_claim.eval = ex_mul(input_claim.eval, ex_inv(ex_from_i64(multiplier)));
-  return input_claim;
+  return descaled;
 }
 
 // LayerNorm::prove + prove_step (layers/transformer/layernorm.rs:729-1100). After the two lookups, three sumchecks: (1) all lookup claims to ONE
@@ -2014,7 +2018,9 @@ inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t, Witne
   pt.lap("trivial openings");
   std::vector<OpenClaim> oc;
   for (auto& c : ps.claims) oc.push_back({&c.comm, c.claim.point, c.claim.eval});
-  proof.batch_proof = pcs_batch_open(dev, ctx.full_log, oc, t);
+  dev.phase_gate(true);
+  try { proof.batch_proof = pcs_batch_open(dev, ctx.full_log, oc, t); } catch (...) { dev.phase_gate(false); throw; }
+  dev.phase_gate(false);
   pt.lap("batch_open");
   if (pt.on) fprintf(stderr, "[dp timing] sumcheck rounds %zu: device wait %.3f ms, host transcript+algebra %.3f ms\n", sc_stats().rounds, sc_stats().dev_ms, sc_stats().host_ms);
   proof.steps = ps.proofs;

@@ -61,3 +61,31 @@ def test_gelu_model_proof_bytes_identical_to_oracle_and_golden(dev, oracle, case
     v, _ = dpa.verify_batch(vb, proofs, xs, outs, dev=dev)
     assert not v.any()
     ctx.free()
+
+
+def test_gelu_reference_letter_switch_on_the_device(dev, oracle, monkeypatch):
+    """DP_GELU_REFERENCE_LETTER=1 (csrc/zkml.h prove_relu): the library emits the reference PROVER's bytes — the descaled claim filed with the scaled column's
+    commitment (activation.rs:419-430). Case 16 (a 2^8-entry column): word for word the oracle's letter-mode stream, in latency mode and inside a batch; the verifier
+    refuses it (as it would the reference's own proof), and accepts the default-mode proof of the same input."""
+    import deep_prove_amd as dpa
+    c = _cases()[16]
+    g = getattr(dpa.models, c["model"])(**c["args"])
+    x, blob = g.input(), g.blob()
+    ctx = dpa.Context.generate(dev, blob)
+    pr = dpa.Prover(ctx)
+    default_proof, out = pr.prove(x)
+    monkeypatch.setenv("DP_GELU_REFERENCE_LETTER", "1")
+    proof, out2 = pr.prove(x)
+    xs = np.stack([x] + [g.input(300 + i) for i in range(3)])
+    proofs, _, _ = pr.prove_batch(xs, 4)
+    monkeypatch.delenv("DP_GELU_REFERENCE_LETTER")
+    oracle.set_gelu_files_lookup_claim(False)  # (the oracle's default: to the letter of the reference's prover)
+    h = oracle.model_setup(blob)
+    oproof, _, _ = oracle.model_prove(h, x)
+    oracle.model_free(h)
+    assert (out == out2).all() and proof.size == oproof.size and (proof == oproof).all() and (proofs[0] == oproof).all()
+    assert proof.size == default_proof.size and (proof != default_proof).any()
+    vb = ctx.verifier_blob()
+    dpa.verify(vb, default_proof, x, out)
+    with pytest.raises(dpa.DeepProveError):
+        dpa.verify(vb, proof, x, out)

@@ -320,6 +320,20 @@ def test_gelu_to_the_letter_of_the_reference_only_verifies_when_the_column_is_sh
     assert "identical=0" in r.stdout and "verify(oracle): REJECT" in r.stdout and "verify(product): ACCEPT" in r.stdout, r.stdout + r.stderr
 
 
+def test_gelu_reference_letter_switch(hostlogic_bin):
+    """DP_GELU_REFERENCE_LETTER=1 (csrc/zkml.h prove_relu): the PRODUCT files the descaled claim with the scaled column's commitment, as the reference's prover does
+    (activation.rs:419-430). Against the oracle to the letter (HL_GELU_LITERAL=1): variant 11 (2^5 entries, shown) and 13 (Dense -> Requant -> GELU -> ..., a table of 2^14 rows, a column of 2^6 entries)
+    identical and accepted; variant 12 (2^8 entries) identical word for word — the reference prover's stream — and refused by the verifier, like the reference's own
+    proof would be."""
+    env = dict(os.environ, HL_GELU_LITERAL="1", DP_GELU_REFERENCE_LETTER="1")
+    r = subprocess.run([hostlogic_bin, "graph", "11", "5"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "identical=1" in r.stdout and "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([hostlogic_bin, "graph", "12", "5"], capture_output=True, text=True, timeout=900, env=env)
+    assert "identical=1" in r.stdout and "verify(oracle): REJECT" in r.stdout and "verify(product): REJECT" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([hostlogic_bin, "graph", "13", "5"], capture_output=True, text=True, timeout=900, env=env)  # (its GELU column has 2^6 entries: shown, so the claim is never used)
+    assert "identical=1" in r.stdout and "verify(oracle): ACCEPT" in r.stdout and "verify(product): ACCEPT" in r.stdout, r.stdout + r.stderr
+
+
 def test_gelu_layer_proofs_reject_every_flipped_word(hostlogic_bin):
     """every third word of the first 6000 of a GELU proof (variant 13: the activation's lookup, its accumulation sumcheck, the table proof with the
     committed output column) flipped, each through the full verifier: all refused"""

@@ -1,7 +1,7 @@
 """host-side launch cost / waits per device context with several proofs in flight (DP_TIMING)"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
-os.environ["DP_TIMING"] = "1"
+os.environ.setdefault("DP_TIMING", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # (the repository root, wherever the command is started from)
 import numpy as np
 import deep_prove_amd as dpa
