@@ -1314,7 +1314,14 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     // one thread per cohort as long as that is at most twice the CPU budget (22 cohorts on a 16-CPU quota: 6.3 cores busy)
     if (!te && nco && nw > 1 && fiber_idle_sleep_ns() > 0 && (double)nco <= 2.0 * host_cpu_budget()) nth = std::max(nth, nco);
     nth = std::min(nth, nco ? nco : nw);
+    // DP_COHORT_GROUPS = G, DP_COHORT_STAGGER_MS = d (experiment, round 6): the cohorts of a batch issue identical launch sequences from a common start and stay IN PHASE —
+    // every queue in one-workgroup tails at once (the chip idle), then every queue in the wide streaming kernels, then every queue hashing (tools/timeline_occupancy.py,
+    // profiles/r06_timeline_448.txt). Group g = thread index mod G starts g * d milliseconds late, so that the groups' stretches interleave; the proofs are handed out
+    // dynamically, so the early groups simply prove more of them.
+    const int stagger_groups = getenv("DP_COHORT_GROUPS") ? std::max(1, atoi(getenv("DP_COHORT_GROUPS"))) : 1;
+    const double stagger_ms = getenv("DP_COHORT_STAGGER_MS") ? std::max(0.0, atof(getenv("DP_COHORT_STAGGER_MS"))) : 0.0;
     auto run_thread = [&](size_t ti) {
+      if (nco && stagger_groups > 1 && stagger_ms > 0 && nproofs > nw) std::this_thread::sleep_for(std::chrono::microseconds((long)((double)(ti % (size_t)stagger_groups) * stagger_ms * 1000.0)));
       FiberSched sched;
       sched.idle_sleep = nw > 1;
       for (size_t wi = 0; wi < nw; wi++) if ((nco ? wi % nco : wi) % nth == ti) fiber_spawn(sched, [&work, wi] { work(wi); });

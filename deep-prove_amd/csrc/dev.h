@@ -327,6 +327,19 @@ class Dev {
   }
   // K14: for each descriptor: the leaf pair (as stored) followed by the Merkle path (height-1 digests)
   virtual void query_gather(const QueryDesc* d, size_t nd, std::vector<std::vector<u64>>& out) = 0;
+  // the same words scattered into a buffer the caller lays out: descriptor i's pair words (4 for an extension tree, 2 for a base one) at dst[pair_off[i]], its
+  // path words at dst[path_off[i]]; `total` = the length of dst. Words of dst outside those ranges are UNSPECIFIED afterwards (the caller writes its headers
+  // there after the call): the device gathers into an image of dst and the image comes back in one copy
+  virtual void query_gather_into(const QueryDesc* d, size_t nd, const size_t* pair_off, const size_t* path_off, u64* dst, size_t total) {
+    std::vector<std::vector<u64>> out;
+    query_gather(d, nd, out);
+    for (size_t i = 0; i < nd; i++) {
+      const size_t np = d[i].tree->leaves.ext ? 4 : 2;
+      DP_REQUIRE(out[i].size() >= np && pair_off[i] + np <= total && path_off[i] + (out[i].size() - np) <= total, DP_ERR_SHAPE, "query_gather_into: layout outside the buffer");
+      std::copy(out[i].begin(), out[i].begin() + np, dst + pair_off[i]);
+      std::copy(out[i].begin() + np, out[i].end(), dst + path_off[i]);
+    }
+  }
   // the same words in ONE buffer: descriptor i at flat[off[i] .. off[i + 1]). A Dense-4M batch opening gathers 10 000 (pair, path) records, 5.8 MB: the
   // vector-per-record form cost the proving thread ~20 000 heap allocations and two extra copies per proof (the members of a cohort run it one after the other)
   virtual void query_gather_flat(const QueryDesc* d, size_t nd, std::vector<u64>& flat, std::vector<size_t>& off) {

@@ -2099,7 +2099,7 @@ class HipDev : public Dev {
     for (size_t i = 0; i < nd; i++) {
       const DevTree& t = *d[i].tree;
       hd[i].leaves = t.leaves.p; hd[i].nodes = (const u64*)t.nodes.p; hd[i].nleaves = t.nleaves; hd[i].p0 = d[i].p0;
-      hd[i].ext = t.leaves.ext; hd[i].height = (int)t.height(); hd[i].out_off = total;
+      hd[i].ext = t.leaves.ext; hd[i].height = (int)t.height(); hd[i].out_off = total; hd[i].path_off = total + (t.leaves.ext ? 4 : 2);
       total += (t.leaves.ext ? 4 : 2) + 4 * (size_t)(t.height() - 1);
       off[i + 1] = total;
     }
@@ -2108,6 +2108,22 @@ class HipDev : public Dev {
     DPL(k_query_gather, dim3((unsigned)grid_for(nd * 64, 1 << 20)), dim3(TPB), dd, nd, dout);  // (one wave per descriptor, grid-stride)
     flat.resize(total);
     d2h(flat.data(), dout, total * 8);  // (the copy follows the gather on the stream: no wait of its own in between, as there was until round 5)
+    release(mk);
+  }
+  void query_gather_into(const QueryDesc* d, size_t nd, const size_t* pair_off, const size_t* path_off, u64* dst, size_t total) override {
+    if (!nd) return;
+    const GatherDesc* dd = nullptr;
+    GatherDesc* hd = desc_alloc<GatherDesc>(nd, &dd);
+    for (size_t i = 0; i < nd; i++) {
+      const DevTree& t = *d[i].tree;
+      hd[i].leaves = t.leaves.p; hd[i].nodes = (const u64*)t.nodes.p; hd[i].nleaves = t.nleaves; hd[i].p0 = d[i].p0;
+      hd[i].ext = t.leaves.ext; hd[i].height = (int)t.height(); hd[i].out_off = pair_off[i]; hd[i].path_off = path_off[i];
+      DP_REQUIRE(pair_off[i] + (t.leaves.ext ? 4 : 2) <= total && path_off[i] + 4 * (size_t)(t.height() - 1) <= total, DP_ERR_SHAPE, "query_gather_into: layout outside the buffer");
+    }
+    size_t mk = mark();
+    u64* dout = (u64*)arena_alloc(total * 8);
+    DPL(k_query_gather, dim3((unsigned)grid_for(nd * 64, 1 << 20)), dim3(TPB), dd, nd, dout);
+    d2h(dst, dout, total * 8);
     release(mk);
   }
   void query_gather(const QueryDesc* d, size_t nd, std::vector<std::vector<u64>>& out) override {

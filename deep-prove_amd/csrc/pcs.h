@@ -244,15 +244,41 @@ inline BasefoldProof pcs_batch_open_evals(Dev& dev, unsigned full_log, const std
     for (auto& tr : trees) { size_t p1 = index | 1; descs.push_back({&tr, p1 - 1}); index >>= 1; }
     for (const DevCommit* c : comms) { size_t xi = x >> (cw_log - c->tree.height()); size_t p1 = xi | 1; descs.push_back({&c->tree, p1 - 1}); }
   }
-  std::vector<u64> got; std::vector<size_t> goff;
-  dev.query_gather_flat(descs.data(), descs.size(), got, goff);
-  size_t di = 0;
-  for (size_t x : qidx) {
-    BatchedQuery bq; bq.index = x;
-    bq.oracle_query.reserve(trees.size()); bq.commitments_query.reserve(nc);
-    for (size_t k = 0; k < trees.size(); k++, di++) bq.oracle_query.push_back(query_from_words(descs[di], got, goff, di));
-    for (size_t k = 0; k < nc; k++, di++) bq.commitments_query.push_back(query_from_words(descs[di], got, goff, di));
-    proof.queries.push_back(std::move(bq));
+  // The query section is laid out as its stream words (proof.h Writer::basefold / cq) and the device gathers straight into that image: per opened pair
+  // [is_ext] [pair: 4 or 2 words] [index] [path length] [path digests]; per query [index] [#oracle] .. [#commitments] ..; the count in front. The headers are
+  // written after the image has come back (Dev::query_gather_into leaves them unspecified).
+  {
+    const size_t nd = descs.size();
+    std::vector<size_t> pair_off(nd), path_off(nd);
+    size_t pos = 1, di = 0;
+    for (size_t qi = 0; qi < qidx.size(); qi++) {
+      pos += 2;  // index, #oracle
+      for (size_t k = 0; k < trees.size() + nc; k++, di++) {
+        if (k == trees.size()) pos += 1;  // #commitments
+        const bool e = descs[di].tree->leaves.ext;
+        pair_off[di] = pos + 1; path_off[di] = pos + 1 + (e ? 4 : 2) + 2;
+        pos = path_off[di] + 4 * (size_t)(descs[di].tree->height() - 1);
+      }
+      if (nc == 0) pos += 1;
+    }
+    std::vector<u64>& ser = proof.queries_ser;
+    ser.resize(pos);
+    dev.query_gather_into(descs.data(), nd, pair_off.data(), path_off.data(), ser.data(), pos);
+    ser[0] = qidx.size();
+    size_t hp = 1; di = 0;
+    for (size_t x : qidx) {
+      ser[hp] = x; ser[hp + 1] = trees.size(); hp += 2;
+      for (size_t k = 0; k < trees.size() + nc; k++, di++) {
+        if (k == trees.size()) ser[hp++] = nc;
+        const bool e = descs[di].tree->leaves.ext;
+        ser[hp] = e ? 1 : 0;
+        ser[pair_off[di] + (e ? 4 : 2)] = descs[di].p0;
+        ser[pair_off[di] + (e ? 4 : 2) + 1] = (u64)(descs[di].tree->height() - 1);
+        hp = path_off[di] + 4 * (size_t)(descs[di].tree->height() - 1);
+      }
+      if (nc == 0) ser[hp++] = 0;
+    }
+    DP_REQUIRE(hp == pos, DP_ERR_SHAPE, "batch_open: query section layout");
   }
   lap("query phase");
   dev.release(mk);

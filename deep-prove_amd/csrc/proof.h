@@ -25,9 +25,14 @@ struct BasefoldProof {
   std::vector<Digest> roots;
   std::vector<Ext> final_message;
   std::vector<BatchedQuery> queries;
+  // The query section as its stream words (everything Writer::basefold emits for `queries`, from the count on), when the prover assembled it straight from the
+  // device's gather buffer (pcs_batch_open_evals): `queries` is then empty. A Dense-4M batch opening has 200 x 56 opened pairs with a Merkle path each — 5.8 MB,
+  // nine tenths of the proof: as vectors of CodewordQuery that was 11 200 heap allocations, a copy into them, a copy out of them into the stream and as many
+  // frees per proof, 1.3 ms of the proving thread that the ~20 other members of its cohort wait behind (profiles/r06_host_work_by_launch.txt).
+  std::vector<u64> queries_ser;
   std::vector<std::vector<Ext>> sumcheck_proof;
   std::vector<FieldVec> trivial_proof;
-  bool is_trivial() const { return sumcheck_messages.empty() && queries.empty() && sumcheck_proof.empty(); }
+  bool is_trivial() const { return sumcheck_messages.empty() && queries.empty() && queries_ser.empty() && sumcheck_proof.empty(); }
 };
 enum LayerKind { L_DENSE = 0, L_REQUANT = 1, L_RELU = 2, L_CONV = 3, L_MAXPOOL = 4, L_FLATTEN = 5, L_MATMUL = 6, L_ADD = 7, L_EMBED = 8, L_POSITIONAL = 9,
                  L_MATMUL2 = 10, L_ADD2 = 11, L_CONCAT_MATMUL = 12, L_QKV = 13, L_LAYERNORM = 14, L_SOFTMAX = 15, L_MHA = 16, L_GELU = 17 };  // the two-input forms of MatMul / Add, ConcatMatMul, QKV (nodes of a model GRAPH)
@@ -104,11 +109,14 @@ struct Writer {
     u(p.sumcheck_messages.size()); for (auto& m : p.sumcheck_messages) ve(m);
     u(p.roots.size()); words((const u64*)p.roots.data(), 4 * p.roots.size());
     ve(p.final_message);
-    u(p.queries.size());
-    for (auto& q : p.queries) {
-      u(q.index);
-      u(q.oracle_query.size()); for (auto& c : q.oracle_query) cq(c);
-      u(q.commitments_query.size()); for (auto& c : q.commitments_query) cq(c);
+    if (!p.queries_ser.empty()) words(p.queries_ser.data(), p.queries_ser.size());
+    else {
+      u(p.queries.size());
+      for (auto& q : p.queries) {
+        u(q.index);
+        u(q.oracle_query.size()); for (auto& c : q.oracle_query) cq(c);
+        u(q.commitments_query.size()); for (auto& c : q.commitments_query) cq(c);
+      }
     }
     u(p.sumcheck_proof.size()); for (auto& m : p.sumcheck_proof) ve(m);
     u(p.trivial_proof.size());
