@@ -21,7 +21,7 @@
 #include <thread>
 
 DP_FIBER_SWITCH_ASM
-namespace dp { struct Cohort; struct PhaseGate; PhaseGate* hip_gate_new(); void hip_gate_free(PhaseGate* g); void hip_gate_set(PhaseGate* g, int slots); size_t hip_gate_waits(PhaseGate* g); void hip_cohort_set_gate(Cohort* c, PhaseGate* g); Cohort* hip_cohort_new(); Cohort* hip_cohort_new_sharing(Cohort* with); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_pcs_share(Dev* worker, Dev* owner); void hip_dump_wg_times(); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
+namespace dp { struct Cohort; struct PhaseGate; void* hip_hash_stream_new(); void hip_hash_stream_free(void* h); void hip_cohort_set_hash_stream(Cohort* c, void* h); PhaseGate* hip_gate_new(); void hip_gate_free(PhaseGate* g); void hip_gate_set(PhaseGate* g, int slots); size_t hip_gate_waits(PhaseGate* g); void hip_cohort_set_gate(Cohort* c, int which, PhaseGate* g); Cohort* hip_cohort_new(); Cohort* hip_cohort_new_sharing(Cohort* with); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_pcs_share(Dev* worker, Dev* owner); void hip_dump_wg_times(); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
 using namespace dp;
 
 // `mu`: PCS::commit is called from rayon workers in the reference (zkml/src/commit/context.rs:79-103 into_par_iter over
@@ -48,8 +48,10 @@ struct dp_batch_commit { DevBatchCommit c; };
 struct dp_model {
   dp_ctx* ctx; std::unique_ptr<Context> zk; std::vector<std::unique_ptr<Dev>> workers; std::vector<dp::Cohort*> cohorts;
   size_t last_in_flight = 0, in_flight_cap = 0; size_t prove_peak = 0;  // largest arena footprint a proof of this model has had so far (sizes the arenas of batch workers)
-  dp::PhaseGate* gate = nullptr;  // admission to the GPU-heavy stretch of a proof (Dev::phase_gate), shared by the cohorts of this model
-  ~dp_model() { for (size_t i = cohorts.size(); i-- > 0;) hip_cohort_free(cohorts[i]); if (gate) hip_gate_free(gate); }  // (last first: a cohort that shares a stream goes before the one that owns it)
+  dp::PhaseGate* gate = nullptr;   // admission to the GPU-heavy stretch of a proof (Dev::phase_gate), shared by the cohorts of this model
+  dp::PhaseGate* hgate = nullptr;  // admission to the building of a large Merkle tree (DP_HASH_GATE)
+  std::vector<void*> hash_streams;  // low-priority streams of the wide hash layers (DP_HASH_STREAMS), dealt to the cohorts round robin
+  ~dp_model() { for (size_t i = cohorts.size(); i-- > 0;) { hip_cohort_set_hash_stream(cohorts[i], nullptr); hip_cohort_free(cohorts[i]); } for (void* h : hash_streams) hip_hash_stream_free(h); if (gate) hip_gate_free(gate); if (hgate) hip_gate_free(hgate); }  // (last first: a cohort that shares a stream goes before the one that owns it)
 };
 
 // Every cohort stream needs a hardware queue of its own (24 are served without time slicing; the HIP runtime multiplexes streams
@@ -1203,7 +1205,17 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     const bool gated = gate_slots > 0 && (size_t)gate_slots < nco;
     if (gated && !m->gate) m->gate = hip_gate_new();
     if (gated) hip_gate_set(m->gate, gate_slots);
-    for (size_t c = 0; c < nco; c++) hip_cohort_set_gate(m->cohorts[c], gated ? m->gate : nullptr);
+    for (size_t c = 0; c < nco; c++) hip_cohort_set_gate(m->cohorts[c], 0, gated ? m->gate : nullptr);
+    // DP_HASH_STREAMS = N (0 = off): the wide hash layers of the cohorts run on N streams of the lowest hardware-queue priority (Cohort::hs), cohort c on stream c mod N
+    const size_t nhs = nco ? (size_t)std::max(0, getenv("DP_HASH_STREAMS") ? atoi(getenv("DP_HASH_STREAMS")) : 0) : 0;
+    while (m->hash_streams.size() < nhs) m->hash_streams.push_back(hip_hash_stream_new());
+    for (size_t c = 0; c < nco; c++) hip_cohort_set_hash_stream(m->cohorts[c], nhs ? m->hash_streams[c % nhs] : nullptr);
+    // DP_HASH_GATE = L (0 = off): at most L cohorts build a large Merkle tree at a time (HipDev::build_tree_into)
+    const int hgate_slots = getenv("DP_HASH_GATE") ? std::max(0, atoi(getenv("DP_HASH_GATE"))) : 0;
+    const bool hgated = hgate_slots > 0 && (size_t)hgate_slots < nco;
+    if (hgated && !m->hgate) m->hgate = hip_gate_new();
+    if (hgated) hip_gate_set(m->hgate, hgate_slots);
+    for (size_t c = 0; c < nco; c++) hip_cohort_set_gate(m->cohorts[c], 1, hgated ? m->hgate : nullptr);
     auto dev_of = [&](size_t wi) -> Dev& { return wi == 0 ? *m->ctx->dev : *m->workers[wi - 1]; };
     std::atomic<size_t> next(0);
     const bool timing = getenv("DP_TIMING") && atoi(getenv("DP_TIMING"));
@@ -1346,6 +1358,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
       size_t f = 0, p = 0; for (size_t c = 0; c < nco; c++) { size_t a, b; hip_cohort_stats(m->cohorts[c], &a, &b); f += a; p += b; }
       fprintf(stderr, "[dp timing] %zu cohorts of <= %zu proofs: %zu merged launches for %zu proof launches\n", nco, csize, f, p);
       if (gated) fprintf(stderr, "[dp timing] heavy-stretch gate: %d slots, %zu polls found it full\n", gate_slots, hip_gate_waits(m->gate));
+      if (hgated) fprintf(stderr, "[dp timing] hash gate: %d slots, %zu polls found it full\n", hgate_slots, hip_gate_waits(m->hgate));
     }
     if (getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) {
       size_t wpeak = 0; for (auto& w : m->workers) wpeak = std::max(wpeak, hip_dev_arena_peak(w.get()));
