@@ -29,13 +29,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # proofs per step = WAVES_PER_STEP x proofs in flight: every call of dp_model_prove_batch starts with all cohorts in phase and ends
 # with a drain (~0.2 s together, profiles/r02_waves.jsonl: 1 wave 327, 2 waves 352, 4 waves 410, 8 waves 431 proofs/s), a service
 # feeds its prover continuously
-BATCHES_PER_STEP = 6
+BATCHES_PER_STEP = 6  # (6 waves of 448 until round 5: 2 688 proofs per step; 6 of 704 since round 6: 4 224 — 4 waves measured 1 020 proofs/s where 12-wave batches give 1 108, tools/r06/call24.sh, call25.sh)
 # proofs in flight per GPU, in lock-step cohorts (csrc/hip_dev.hip, struct Cohort). The library cuts the number to what fits in the
 # free HBM (worker arenas are sized from the footprint of the model's first proof: 448 MB for Dense-4M since the batch-opening
 # sumcheck keeps its eq tables factored — 576 MB and at most 423 in flight before). 448 against 256 in flight, same build and box,
 # alternating: 466 / 511 against 452 / 448 proofs/s in the bench's own steps (profiles/r03_graph1_bench_inflight.txt), 480 against 453
 # on average in single batches (profiles/r03_cohort_inflight_ab.txt).
-DEFAULT_IN_FLIGHT = 448
+# Round 6: worker arenas of 336 MB (1.125 x the footprint + 16 MB) let ~700 proofs fit, and the rate still grows with the number in flight once the streaming kernels are
+# capped and prioritised (tools/r06/call22.sh - call24.sh: 1 047-1 066 proofs/s at 448, 1 100-1 116 at 660, 1 108 at 704 in 12-wave batches): 704 = 22 cohorts of 32.
+DEFAULT_IN_FLIGHT = 704
 GOLDEN = {"dense_4m": "dense4m_proof.json", "cnn_264k": "cnn264k_proof.json"}
 MIN_HOST_THREADS_PER_RANK = 3  # proving threads per rank below which a multi-GPU run is flagged host-bound (each rank also wants 2 CPUs for the HIP runtime)
 GOLDEN_SLOT = 7  # index inside the last timed step at which the golden input is proved

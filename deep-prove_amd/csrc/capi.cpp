@@ -21,7 +21,7 @@
 #include <thread>
 
 DP_FIBER_SWITCH_ASM
-namespace dp { struct Cohort; struct PhaseGate; void* hip_hash_stream_new(); void hip_hash_stream_free(void* h); void hip_cohort_set_hash_stream(Cohort* c, void* h); PhaseGate* hip_gate_new(); void hip_gate_free(PhaseGate* g); void hip_gate_set(PhaseGate* g, int slots); size_t hip_gate_waits(PhaseGate* g); void hip_cohort_set_gate(Cohort* c, int which, PhaseGate* g); Cohort* hip_cohort_new(); Cohort* hip_cohort_new_sharing(Cohort* with); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_pcs_share(Dev* worker, Dev* owner); void hip_dump_wg_times(); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
+namespace dp { struct Cohort; Cohort* hip_cohort_new(); Cohort* hip_cohort_new_sharing(Cohort* with); void hip_cohort_free(Cohort* c); void hip_cohort_drain(Cohort* c); void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs); void hip_dev_cohort_attach(Dev* d, Cohort* c); void hip_dev_cohort_detach(Dev* d); void hip_dev_set_latency_mode(Dev* d, bool on); void hip_dev_pcs_share(Dev* worker, Dev* owner); void hip_dump_wg_times(); void hip_dev_dump_host_stats(Dev* d); size_t hip_dev_arena_peak(Dev* d); double hip_dev_probe_compress_rate(Dev* d, size_t nodes, int reps); void hip_dev_arena_peak_reset(Dev* d); void hip_mem_info(int device, size_t* free_bytes, size_t* total_bytes); void hip_dev_dump_sc_debug(Dev* d); Dev* make_hip_worker(int device, size_t arena_bytes); Dev* make_hip_dev(int device); void hip_dev_profile_enable(Dev* d, bool on); std::string hip_dev_profile_report(Dev* d); }
 using namespace dp;
 
 // `mu`: PCS::commit is called from rayon workers in the reference (zkml/src/commit/context.rs:79-103 into_par_iter over
@@ -48,10 +48,7 @@ struct dp_batch_commit { DevBatchCommit c; };
 struct dp_model {
   dp_ctx* ctx; std::unique_ptr<Context> zk; std::vector<std::unique_ptr<Dev>> workers; std::vector<dp::Cohort*> cohorts;
   size_t last_in_flight = 0, in_flight_cap = 0; size_t prove_peak = 0;  // largest arena footprint a proof of this model has had so far (sizes the arenas of batch workers)
-  dp::PhaseGate* gate = nullptr;   // admission to the GPU-heavy stretch of a proof (Dev::phase_gate), shared by the cohorts of this model
-  dp::PhaseGate* hgate = nullptr;  // admission to the building of a large Merkle tree (DP_HASH_GATE)
-  std::vector<void*> hash_streams;  // low-priority streams of the wide hash layers (DP_HASH_STREAMS), dealt to the cohorts round robin
-  ~dp_model() { for (size_t i = cohorts.size(); i-- > 0;) { hip_cohort_set_hash_stream(cohorts[i], nullptr); hip_cohort_free(cohorts[i]); } for (void* h : hash_streams) hip_hash_stream_free(h); if (gate) hip_gate_free(gate); if (hgate) hip_gate_free(hgate); }  // (last first: a cohort that shares a stream goes before the one that owns it)
+  ~dp_model() { for (size_t i = cohorts.size(); i-- > 0;) hip_cohort_free(cohorts[i]); }  // (last first: a cohort that shares a stream goes before the one that owns it)
 };
 
 // Every cohort stream needs a hardware queue of its own (24 are served without time slicing; the HIP runtime multiplexes streams
@@ -1154,7 +1151,11 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     // 90 % of the free HBM instead of failing: `concurrency` is a cap, not a demand.
     const char* env = getenv("DP_WORKER_ARENA_BYTES");
     const size_t MB64 = size_t(64) << 20;
-    size_t arena = env ? strtoull(env, nullptr, 10) : m->prove_peak ? std::max(4 * MB64, ((m->prove_peak + m->prove_peak / 4 + MB64 + MB64 - 1) / MB64) * MB64) : (size_t(3) << 29);
+    // (round 6: 1.125 x the footprint + 16 MB in steps of 16 MB — 336 MB for Dense-4M where 1.25 x + 64 MB in steps of 64 gave 448: a proof's footprint does not depend on
+    // its input, the margin only has to cover what latency mode and throughput mode allocate differently, and throughput mode allocates LESS; ~700 proofs fit in flight
+    // instead of ~540, and the rate still grows with them: 1 066 / 1 116 proofs/s at 448 / 660, tools/r06/call23.sh)
+    const size_t MB16 = size_t(16) << 20;
+    size_t arena = env ? strtoull(env, nullptr, 10) : m->prove_peak ? std::max(4 * MB64, ((m->prove_peak + m->prove_peak / 8 + MB16 + MB16 - 1) / MB16) * MB16) : (size_t(3) << 29);
     if (m->workers.size() + 1 < nw) {
       // the cap is fixed by the first batch that needs more workers than exist (later batches must not creep into the reserve)
       if (!m->in_flight_cap) {
@@ -1199,23 +1200,6 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     size_t csize = ce ? (size_t)std::max(0, atoi(ce)) : std::max<size_t>(1, (nw + 22 * share - 1) / (22 * share));
     size_t nco = (csize >= 1 && nw > 1) ? (nw + csize - 1) / csize : 0;
     while (m->cohorts.size() < nco) { const size_t c = m->cohorts.size(); m->cohorts.push_back(c % share ? hip_cohort_new_sharing(m->cohorts[c - c % share]) : hip_cohort_new()); }
-    // DP_HEAVY_GATE = L (0 = off): at most L cohorts inside the batch opening at a time (struct PhaseGate, hip_dev.hip) — the others wait at its door
-    // while the chip is busy, and their protocol tails then run beside the hashing of those inside instead of all tails / all hashing at once
-    const int gate_slots = getenv("DP_HEAVY_GATE") ? std::max(0, atoi(getenv("DP_HEAVY_GATE"))) : 0;
-    const bool gated = gate_slots > 0 && (size_t)gate_slots < nco;
-    if (gated && !m->gate) m->gate = hip_gate_new();
-    if (gated) hip_gate_set(m->gate, gate_slots);
-    for (size_t c = 0; c < nco; c++) hip_cohort_set_gate(m->cohorts[c], 0, gated ? m->gate : nullptr);
-    // DP_HASH_STREAMS = N (0 = off): the wide hash layers of the cohorts run on N streams of the lowest hardware-queue priority (Cohort::hs), cohort c on stream c mod N
-    const size_t nhs = nco ? (size_t)std::max(0, getenv("DP_HASH_STREAMS") ? atoi(getenv("DP_HASH_STREAMS")) : 0) : 0;
-    while (m->hash_streams.size() < nhs) m->hash_streams.push_back(hip_hash_stream_new());
-    for (size_t c = 0; c < nco; c++) hip_cohort_set_hash_stream(m->cohorts[c], nhs ? m->hash_streams[c % nhs] : nullptr);
-    // DP_HASH_GATE = L (0 = off): at most L cohorts build a large Merkle tree at a time (HipDev::build_tree_into)
-    const int hgate_slots = getenv("DP_HASH_GATE") ? std::max(0, atoi(getenv("DP_HASH_GATE"))) : 0;
-    const bool hgated = hgate_slots > 0 && (size_t)hgate_slots < nco;
-    if (hgated && !m->hgate) m->hgate = hip_gate_new();
-    if (hgated) hip_gate_set(m->hgate, hgate_slots);
-    for (size_t c = 0; c < nco; c++) hip_cohort_set_gate(m->cohorts[c], 1, hgated ? m->hgate : nullptr);
     auto dev_of = [&](size_t wi) -> Dev& { return wi == 0 ? *m->ctx->dev : *m->workers[wi - 1]; };
     std::atomic<size_t> next(0);
     const bool timing = getenv("DP_TIMING") && atoi(getenv("DP_TIMING"));
@@ -1326,14 +1310,7 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     // one thread per cohort as long as that is at most twice the CPU budget (22 cohorts on a 16-CPU quota: 6.3 cores busy)
     if (!te && nco && nw > 1 && fiber_idle_sleep_ns() > 0 && (double)nco <= 2.0 * host_cpu_budget()) nth = std::max(nth, nco);
     nth = std::min(nth, nco ? nco : nw);
-    // DP_COHORT_GROUPS = G, DP_COHORT_STAGGER_MS = d (experiment, round 6): the cohorts of a batch issue identical launch sequences from a common start and stay IN PHASE —
-    // every queue in one-workgroup tails at once (the chip idle), then every queue in the wide streaming kernels, then every queue hashing (tools/timeline_occupancy.py,
-    // profiles/r06_timeline_448.txt). Group g = thread index mod G starts g * d milliseconds late, so that the groups' stretches interleave; the proofs are handed out
-    // dynamically, so the early groups simply prove more of them.
-    const int stagger_groups = getenv("DP_COHORT_GROUPS") ? std::max(1, atoi(getenv("DP_COHORT_GROUPS"))) : 1;
-    const double stagger_ms = getenv("DP_COHORT_STAGGER_MS") ? std::max(0.0, atof(getenv("DP_COHORT_STAGGER_MS"))) : 0.0;
     auto run_thread = [&](size_t ti) {
-      if (nco && stagger_groups > 1 && stagger_ms > 0 && nproofs > nw) std::this_thread::sleep_for(std::chrono::microseconds((long)((double)(ti % (size_t)stagger_groups) * stagger_ms * 1000.0)));
       FiberSched sched;
       sched.idle_sleep = nw > 1;
       for (size_t wi = 0; wi < nw; wi++) if ((nco ? wi % nco : wi) % nth == ti) fiber_spawn(sched, [&work, wi] { work(wi); });
@@ -1357,8 +1334,6 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     if (nco && getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) {
       size_t f = 0, p = 0; for (size_t c = 0; c < nco; c++) { size_t a, b; hip_cohort_stats(m->cohorts[c], &a, &b); f += a; p += b; }
       fprintf(stderr, "[dp timing] %zu cohorts of <= %zu proofs: %zu merged launches for %zu proof launches\n", nco, csize, f, p);
-      if (gated) fprintf(stderr, "[dp timing] heavy-stretch gate: %d slots, %zu polls found it full\n", gate_slots, hip_gate_waits(m->gate));
-      if (hgated) fprintf(stderr, "[dp timing] hash gate: %d slots, %zu polls found it full\n", hgate_slots, hip_gate_waits(m->hgate));
     }
     if (getenv("DP_TIMING") && atoi(getenv("DP_TIMING"))) {
       size_t wpeak = 0; for (auto& w : m->workers) wpeak = std::max(wpeak, hip_dev_arena_peak(w.get()));

@@ -72,10 +72,6 @@ class Dev {
   virtual ~Dev() {}
   virtual const char* name() const = 0;
   virtual void bind_thread() {}  // make this context current for the calling host thread
-  // Admission to the GPU-heavy stretch of a proof (the batch opening: every large Merkle tree, the classic sumcheck, the linear combinations): proofs in flight are
-  // grouped into lock-step cohorts that run the same sequence from the same start, so without a gate ALL of them hash at once and then ALL of them sit in one-workgroup
-  // protocol tails at once (HipDev::phase_gate / struct PhaseGate, hip_dev.hip). enter = true before the stretch, false behind it. No-op outside a cohort.
-  virtual void phase_gate(bool enter) { (void)enter; }
   virtual void pin_thread() {}   // a thread the library spawned for this context keeps to the CPUs of the device's NUMA node (HipDev::pin_thread)
   // ---- memory. alloc() is an arena (stack discipline via mark/release); persistent allocations outlive proofs.
   virtual DBuf alloc(size_t n, bool ext) = 0;

@@ -108,20 +108,7 @@ static inline void dp_spin_pause() { if (g_wait_yield) sched_yield(); else __bui
 // dozen independent streams of tiny kernels) are paid once per cohort step instead of once per proof step.
 // A member never blocks at a launch: it drops its argument pack and goes on to its next wait (where it yields to the next
 // member); whoever completes a launch's set of packs fires it. Everything is driven from the cohort's one host thread.
-// Admission gate of the GPU-heavy stretch (Dev::phase_gate): `slots` cohorts may be inside at a time; one gate per model (dp_model_prove_batch).
-// The cohorts of a batch start together and issue identical launch sequences: left alone they stay in phase — every queue hashes Merkle layers at the same
-// time (launches wait milliseconds for wave slots) and every queue runs one-workgroup tails at the same time (44 % of the k_logup_tail launches of a 448-proof
-// batch ran with NO wide kernel on the chip, profiles/r06_trace_analysis_448_mid_round.txt; VALU issue 0.63). With the gate the cohorts that cannot enter wait
-// at the door while the chip is busy with those inside, and from then on their light stretches run beside the others' heavy ones.
-struct PhaseGate {
-  std::atomic<int> free_slots{0};
-  std::atomic<size_t> waits{0};  // (statistics: polls that found the gate full)
-};
 struct Cohort {
-  // two gates: [0] the whole batch opening (Dev::phase_gate, DP_HEAVY_GATE), [1] the building of one large Merkle tree (HipDev::build_tree_into, DP_HASH_GATE)
-  PhaseGate* gate[2] = {nullptr, nullptr};  // null: no admission control
-  int gate_state[2] = {0, 0};               // 0 outside, 1 a member is acquiring a slot, 2 inside (all members of a cohort live on one host thread: plain ints)
-  int gate_inside[2] = {0, 0};              // members between enter and leave
   struct Pending {
     void (*fire)(const Pending&, hipStream_t);  // also the identity of the kernel (one instantiation per Body)
     const char* name;
@@ -129,24 +116,8 @@ struct Cohort {
     char* packs; const char* packs_dev;
     int count, expected;
     size_t ring_begin, ring_end;
-    bool hash;  // a wide hash layer: fired on the cohort's LOW-priority stream when it has one (hs)
   };
   hipStream_t s = nullptr;
-  // DP_HASH_STREAMS (round 6): the wide hash layers of a tree — the one VALU-bound stretch of a proof, 72 % of its VALU instructions — run on a stream of the LOWEST
-  // hardware-queue priority (shared by a few cohorts, hip_hash_stream), everything else on the cohort's own stream: when wave slots free up the command processor
-  // serves the latency-bound chains of the other cohorts first and the hash grids take what is left (tools/r06/prioprobe.hip). The two streams hand over
-  // through an event at every switch, so the launch ORDER of the cohort is what it was.
-  hipStream_t hs = nullptr; hipEvent_t hev = nullptr; bool on_hash = false;
-  void set_hash_stream(hipStream_t h) {
-    if (on_hash) switch_stream_(false);
-    hs = h;
-    if (h && !hev) HIP_CHECK(hipEventCreateWithFlags(&hev, hipEventDisableTiming));
-  }
-  void switch_stream_(bool to_hash) {
-    HIP_CHECK(hipEventRecord(hev, on_hash ? hs : s));
-    HIP_CHECK(hipStreamWaitEvent(to_hash ? hs : s, hev, 0));
-    on_hash = to_hash;
-  }
   int members = 0;  // proofs currently in the cohort
   char* ring = nullptr; const char* ring_dev = nullptr;
   size_t ring_cap = 0, ring_off = 0;
@@ -180,7 +151,7 @@ struct Cohort {
     HIP_CHECK(hipHostMalloc((void**)&ring, ring_cap, host_ro_flags()));
     HIP_CHECK(hipHostGetDevicePointer((void**)&ring_dev, ring, 0));
   }
-  ~Cohort() { if (hs && on_hash) hipStreamSynchronize(hs); if (s) { hipStreamSynchronize(s); if (owns_stream) hipStreamDestroy(s); } if (hev) hipEventDestroy(hev); if (ring) hipHostFree(ring); }
+  ~Cohort() { if (s) { hipStreamSynchronize(s); if (owns_stream) hipStreamDestroy(s); } if (ring) hipHostFree(ring); }
   Cohort(const Cohort&) = delete;
   Cohort& operator=(const Cohort&) = delete;
 
@@ -198,12 +169,12 @@ struct Cohort {
     return head;
   }
   // member `li`-th launch of its sequence: add its pack to launch number `li`, fire every launch whose set is complete
-  void submit(size_t li, void (*fire)(const Pending&, hipStream_t), const char* name, dim3 g, dim3 b, size_t lds, const void* pack, size_t pack_bytes, bool hash = false) {
+  void submit(size_t li, void (*fire)(const Pending&, hipStream_t), const char* name, dim3 g, dim3 b, size_t lds, const void* pack, size_t pack_bytes) {
     if (li < q_base) throw DpError(DP_ERR_SHAPE, std::string("cohort out of step: a member reached launch ") + name + " after it was fired (the proofs of a cohort must issue identical launch sequences)");
     size_t k = li - q_base;
     if (k > q.size()) throw DpError(DP_ERR_SHAPE, "cohort out of step: launch sequence gap");
     if (k == q.size()) {
-      Pending p; p.fire = fire; p.name = name; p.g = g; p.b = b; p.lds = lds; p.pack_bytes = pack_bytes; p.count = 0; p.expected = members; p.hash = hash;
+      Pending p; p.fire = fire; p.name = name; p.g = g; p.b = b; p.lds = lds; p.pack_bytes = pack_bytes; p.count = 0; p.expected = members;
       p.ring_begin = ring_take(pack_bytes * (size_t)members); p.ring_end = ring_off;
       p.packs = ring + p.ring_begin % ring_cap; p.packs_dev = ring_dev + p.ring_begin % ring_cap;
       q.push_back(p);
@@ -222,8 +193,7 @@ struct Cohort {
       if (p.count > 0) {
         std::atomic_thread_fence(std::memory_order_release);
         if (g_host_stats) note_fire();
-        if (hs && p.hash != on_hash) switch_stream_(p.hash);
-        p.fire(p, hs && p.hash ? hs : s);
+        p.fire(p, s);
         inflight.push_back({q_base, p.ring_begin});
         nfired++;
       }
@@ -240,7 +210,7 @@ struct Cohort {
     for (size_t k = li > q_base ? li - q_base : 0; k < q.size(); k++) q[k].expected--;
     flush();
   }
-  void drain() { if (hs && on_hash) switch_stream_(false); HIP_CHECK(hipStreamSynchronize(s)); inflight.clear(); executed = q_base; }
+  void drain() { HIP_CHECK(hipStreamSynchronize(s)); inflight.clear(); executed = q_base; }
 };
 
 
@@ -300,7 +270,6 @@ class HipDev : public Dev {
   static void fire_(const Cohort::Pending& p, hipStream_t s) {
     hipLaunchKernelGGL((kc<Body, MAXT, FLAGS, std::decay_t<A>...>), dim3(p.g.x, p.g.y, (unsigned)p.count), p.b, p.lds, s, (const ArgPack<std::decay_t<A>...>*)p.packs_dev);
   }
-  bool next_hash_ = false;  // the launches issued while this is set are wide hash layers (build_tree_into): Cohort::Pending::hash
   template <auto Body, int MAXT, int FLAGS, class... A, class... P>
   void launch_(KArgs<void (*)(A...)>, const char* name, dim3 g, dim3 b, size_t lds, P... args) {
     static_assert(sizeof...(A) == sizeof...(P), "kernel argument count");
@@ -310,7 +279,7 @@ class HipDev : public Dev {
     using Pack = ArgPack<std::decay_t<A>...>;
     static_assert(std::is_trivially_copyable<Pack>::value && std::is_trivially_destructible<Pack>::value, "argument packs travel as bytes");
     Pack pk(static_cast<std::decay_t<A>>(args)...);
-    co_->submit(co_li_++, &fire_<Body, MAXT, FLAGS, A...>, name, g, b, lds, &pk, sizeof(Pack), next_hash_);
+    co_->submit(co_li_++, &fire_<Body, MAXT, FLAGS, A...>, name, g, b, lds, &pk, sizeof(Pack));
   }
   template <auto Body, int MAXT, int FLAGS, class... A>
   static void set_lds_(KArgs<void (*)(A...)>, int bytes) {
@@ -893,37 +862,8 @@ class HipDev : public Dev {
     HIP_CHECK(hipStreamSynchronize(s_));
     co->join(); co_ = co; co_li_ = co->q_base;
   }
-  void cohort_detach() { if (co_) { gate_pass_(1, false); gate_pass_(0, false); Cohort* c = co_; co_ = nullptr; c->leave(co_li_); } }
+  void cohort_detach() { if (co_) { Cohort* c = co_; co_ = nullptr; c->leave(co_li_); } }
   bool in_cohort() const { return co_ != nullptr; }
-  // Dev::phase_gate: the first member of the cohort that arrives takes one of the gate's slots for the whole cohort (yielding to the other fibers of its thread while
-  // there is none), the members behind it wait until it has it; the last member that leaves gives the slot back. The members run in lock step, so nobody can be
-  // through the stretch before everybody has entered it.
-  bool gate_in_[2] = {false, false};
-  void gate_pass_(int w, bool enter) {
-    Cohort* c = co_;
-    if (!c || !c->gate[w] || !fiber_active()) return;
-    PhaseGate* g = c->gate[w];
-    if (enter) {
-      if (gate_in_[w]) return;
-      if (c->gate_state[w] == 0) {
-        c->gate_state[w] = 1;
-        for (;;) {
-          int f = g->free_slots.load(std::memory_order_relaxed);
-          if (f > 0 && g->free_slots.compare_exchange_weak(f, f - 1, std::memory_order_acquire)) break;
-          g->waits.fetch_add(1, std::memory_order_relaxed);
-          fiber_yield();
-        }
-        c->gate_state[w] = 2;
-        fiber_note_progress();
-      } else while (c->gate_state[w] != 2) fiber_yield();
-      c->gate_inside[w]++; gate_in_[w] = true;
-    } else {
-      if (!gate_in_[w]) return;
-      gate_in_[w] = false;
-      if (--c->gate_inside[w] == 0) { c->gate_state[w] = 0; g->free_slots.fetch_add(1, std::memory_order_release); }
-    }
-  }
-  void phase_gate(bool enter) override { gate_pass_(0, enter); }
   void sync() override { stream_wait(); }
   void flush_uploads() override { if (stage_off_) { stream_wait(); stage_off_ = 0; } }
   void abort_call() override { sess_ = ScSession(); }
@@ -1778,8 +1718,6 @@ class HipDev : public Dev {
   // workgroups of every other queue — the streaming kernels of the batch opening, the one-workgroup tails, k_publish — then wait for a slot to drain
   // (k_axpy_many: 12.8 ms per launch for 0.2 ms of work, profiles/r05_bench448_kernel_stats.csv). The VALU is saturated by 2-3 hash waves per SIMD.
   size_t merkle_wg_cap_ = [] { const char* e = getenv("DP_MERKLE_WG_CAP"); return e ? (size_t)strtoull(e, nullptr, 10) : size_t(0); }();
-  size_t hash_stream_min_ = [] { const char* e = getenv("DP_HASH_STREAM_MIN_N"); return e ? (size_t)strtoull(e, nullptr, 10) : size_t(1) << 12; }();  // parents per member: narrower layers stay on the cohort's stream
-  size_t hash_gate_min_ = [] { const char* e = getenv("DP_HASH_GATE_MIN_N"); return e ? (size_t)strtoull(e, nullptr, 10) : size_t(1) << 15; }();
   int merkle_grid(size_t nodes) const {
     if (!throughput_mode_ || !merkle_wg_cap_) return grid_for(nodes, 4096);
     const size_t m = co_ && co_->nominal > 0 ? (size_t)co_->nominal : 1;
@@ -1807,20 +1745,13 @@ class HipDev : public Dev {
     DevTree t; t.leaves = leaves; t.nleaves = leaves.n; t.nodes = nodes;
     size_t n = leaves.n;
     u64* nd = (u64*)t.nodes.p;
-    // DP_HASH_GATE (throughput mode): a tree of >= hash_gate_min_ leaves is built by at most L cohorts at a time (Cohort::gate[1]). The hash layers are the one
-    // VALU-bound stretch of a proof (72 % of its VALU instructions); everything around them is a latency-bound chain of small launches that a chip full of hash
-    // waves stalls (no wave slot, the queue's pipe held). With the builds admitted one or two at a time and their grids capped (DP_MERKLE_WG_CAP) the hashing
-    // of one cohort runs beside the chains of the others instead of all cohorts hashing, then all chaining.
-    const bool gated = throughput_mode_ && co_ && co_->gate[1] && n >= hash_gate_min_;
-    if (gated) gate_pass_(1, true);
-    struct GateGuard { HipDev* d; bool on; ~GateGuard() { if (on) d->gate_pass_(1, false); } } gate_guard{this, gated};
     if (leaves.ext) { nb_ = 16.0 * n + 16.0 * n; DPL(k_merkle_leaves<true>, dim3(grid_for(n / 2)), dim3(TPB), (const void*)leaves.p, nd, n / 2); }
     else { nb_ = 8.0 * n + 16.0 * n; DPL(k_merkle_leaves<false>, dim3(grid_for(n / 2)), dim3(TPB), (const void*)leaves.p, nd, n / 2); }
     size_t off = 0, cnt = n / 2;
     while (cnt > TAIL_MAX) {
       size_t next = cnt / 2;
       if (next <= lp_max_now()) { nb_ = 96.0 * next; DPL(k_merkle_layer_lp, dim3((unsigned)grid_for(next * 8, 8192)), dim3(256), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
-      else { nb_ = 96.0 * next; next_hash_ = throughput_mode_ && next >= hash_stream_min_; DPL(k_merkle_layer, dim3(merkle_grid(next)), dim3(TPB), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); next_hash_ = false; }
+      else { nb_ = 96.0 * next; DPL(k_merkle_layer, dim3(merkle_grid(next)), dim3(TPB), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
       off += cnt; cnt /= 2;
     }
     const TailDesc* dd = nullptr;
@@ -2172,15 +2103,6 @@ Dev* make_hip_worker(int device, size_t arena_bytes) { return new HipDev(device,
 Cohort* hip_cohort_new() { const char* e = getenv("DP_COHORT_RING_BYTES"); return e ? new Cohort(strtoull(e, nullptr, 10)) : new Cohort(); }
 Cohort* hip_cohort_new_sharing(Cohort* with) { const char* e = getenv("DP_COHORT_RING_BYTES"); return new Cohort(e ? strtoull(e, nullptr, 10) : size_t(32) << 20, with); }
 void hip_cohort_free(Cohort* c) { delete c; }
-// a stream of the lowest hardware-queue priority for the wide hash layers of the cohorts it is given to (Cohort::hs)
-void* hip_hash_stream_new() { int lo = 0, hi = 0; HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi)); hipStream_t h; HIP_CHECK(hipStreamCreateWithPriority(&h, hipStreamNonBlocking, lo)); return (void*)h; }
-void hip_hash_stream_free(void* h) { if (h) { hipStreamSynchronize((hipStream_t)h); hipStreamDestroy((hipStream_t)h); } }
-void hip_cohort_set_hash_stream(Cohort* c, void* h) { c->set_hash_stream((hipStream_t)h); }
-PhaseGate* hip_gate_new() { return new PhaseGate(); }
-void hip_gate_free(PhaseGate* g) { delete g; }
-void hip_gate_set(PhaseGate* g, int slots) { g->free_slots.store(slots); g->waits.store(0); }
-size_t hip_gate_waits(PhaseGate* g) { return g->waits.load(); }
-void hip_cohort_set_gate(Cohort* c, int which, PhaseGate* g) { c->gate[which] = g; c->gate_state[which] = 0; c->gate_inside[which] = 0; }
 void hip_cohort_drain(Cohort* c) { c->drain(); }
 void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs) {
   *fired = c->nfired; *packs = c->npacks; c->nfired = c->npacks = 0;

@@ -2018,9 +2018,7 @@ inline Proof prove(Context& ctx, Dev& dev, const Trace& tr, Transcript& t, Witne
   pt.lap("trivial openings");
   std::vector<OpenClaim> oc;
   for (auto& c : ps.claims) oc.push_back({&c.comm, c.claim.point, c.claim.eval});
-  dev.phase_gate(true);
-  try { proof.batch_proof = pcs_batch_open(dev, ctx.full_log, oc, t); } catch (...) { dev.phase_gate(false); throw; }
-  dev.phase_gate(false);
+  proof.batch_proof = pcs_batch_open(dev, ctx.full_log, oc, t);
   pt.lap("batch_open");
   if (pt.on) fprintf(stderr, "[dp timing] sumcheck rounds %zu: device wait %.3f ms, host transcript+algebra %.3f ms\n", sc_stats().rounds, sc_stats().dev_ms, sc_stats().host_ms);
   proof.steps = ps.proofs;

@@ -35,7 +35,7 @@ def main():
         raise SystemExit("tail_roofline: no member count in the phases log")
     per_member = nperm / nmemb
     floor_us = per_member * perm_us
-    doc = {"kernel": "kc:k_logup_tail", "population": "dense_4m_448_in_flight_cohort_launches", "source_sha16": source_sha16(),
+    doc = {"kernel": "kc:k_logup_tail", "population": "dense_4m_in_flight_cohort_launches", "source_sha16": source_sha16(),
            "bound": "latency of one wave: the transcript's sponge is a dependent chain of Poseidon2 permutations",
            "permutations_per_member": round(per_member, 1), "permutation_us_in_a_loop": perm_us, "floor_us_per_member": round(floor_us, 1),
            "median_member_us": median, "merged_launch_us": span, "merged_launches": launches, "members_per_launch": members,
