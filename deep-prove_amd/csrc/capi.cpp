@@ -1310,7 +1310,13 @@ int32_t dp_model_prove_batch(dp_model* m, const int64_t* inputs, size_t nproofs,
     // one thread per cohort as long as that is at most twice the CPU budget (22 cohorts on a 16-CPU quota: 6.3 cores busy)
     if (!te && nco && nw > 1 && fiber_idle_sleep_ns() > 0 && (double)nco <= 2.0 * host_cpu_budget()) nth = std::max(nth, nco);
     nth = std::min(nth, nco ? nco : nw);
+    // DP_COHORT_STAGGER_MS = d (diagnostic, default 0): cohort c starts c * d milliseconds late. The cohorts of a batch otherwise run IN PHASE — identical launch sequences
+    // from a common start: every queue in one-workgroup tails, then every queue in the streaming kernels, then every queue hashing (profiles/r06_timeline_704.txt). A
+    // staggered start persists (profiles/r06_timeline_704_staggered.txt) and changes the rate by nothing, in every combination tried (profiles/r06_plateau_sweeps.txt,
+    // call 16 / 20 / 21 / 24): a tail that starts beside other cohorts' hash layers waits milliseconds for room.
+    const double stagger_ms = getenv("DP_COHORT_STAGGER_MS") ? std::max(0.0, atof(getenv("DP_COHORT_STAGGER_MS"))) : 0.0;
     auto run_thread = [&](size_t ti) {
+      if (nco && stagger_ms > 0 && nproofs > nw) std::this_thread::sleep_for(std::chrono::microseconds((long)((double)(ti % nco) * stagger_ms * 1000.0)));
       FiberSched sched;
       sched.idle_sleep = nw > 1;
       for (size_t wi = 0; wi < nw; wi++) if ((nco ? wi % nco : wi) % nth == ti) fiber_spawn(sched, [&work, wi] { work(wi); });

@@ -1731,7 +1731,8 @@ class HipDev : public Dev {
   // whatever it wants to launch. That is the "small kernels stretch with the number of active kernels" of rounds 2-5 (k_publish 1.7 ms with 20 kernels
   // active) and why capping ONE kernel family never moved the rate: the sum over all queues has to fit. The cap is per merged launch, all members together.
   // Default 256 (round 6, tools/r06/call20.sh, call21.sh: 12 waves of 448 Dense-4M proofs, alternating on one box): 983 / 1 006 / 1 009 / 995 proofs/s with the cap against
-  // 937 / 944 / 928 without, 1 034 against 959 at 660 in flight; 192 the same, 128 and 384 less. Capping the hash layers as well (DP_MERKLE_WG_CAP) adds nothing.
+  // 937 / 944 / 928 without, 1 034 against 959 at 660 in flight; 192 the same, 128 and 384 less. The hash layers take the same cap (merkle_grid goes through grid_for)
+  // unless DP_MERKLE_WG_CAP gives them their own: 512 / 1 024 / 2 048 for them measured 1 037 / 1 023 / 987 against 1 047-1 058 (tools/r06/call24.sh).
   size_t wide_wg_cap_ = [] { const char* e = getenv("DP_WIDE_WG_CAP"); return e ? (size_t)strtoull(e, nullptr, 10) : size_t(256); }();
   int grid_for(size_t n, int cap = 2048) const {
     if (throughput_mode_ && wide_wg_cap_ && co_) {

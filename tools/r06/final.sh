@@ -41,6 +41,7 @@ db=$(find $o/prof -name "*.db" | head -1)
 if [ -n "$db" ]; then
   python tools/rocpd_summary.py "$db" $o/r06_bench${N}_kernel_stats.csv > $o/summary.err 2>&1; head -8 $o/r06_bench${N}_kernel_stats.csv | cut -c1-120
   python tools/trace_analyze.py "$db" > $o/r06_trace_analysis_${N}.txt 2>&1; sed -n 1,14p $o/r06_trace_analysis_${N}.txt | cut -c1-160
+  python tools/timeline_occupancy.py "$db" 5 > $o/r06_timeline_${N}.txt 2>&1; sed -n 1,12p $o/r06_timeline_${N}.txt | cut -c1-200
 fi
 rate=$(grep -E 'proofs/s' $o/prof.log | tail -1 | sed 's/.* \([0-9.]*\) proofs\/s.*/\1/')
 step "SQ instruction pass (rate of the un-profiled job: $rate proofs/s)"

@@ -3,7 +3,7 @@
 (trace_analyze.py looks at one queue at a time). usage:
   python tools/timeline_occupancy.py <x_results.db> [bin_ms]
 Classes of a cohort launch (kc:*), by what it can keep busy:
-  H  hash layers that fill the chip: k_merkle_layer / k_merkle_leaves* with >= 1024 workgroups over all members (VALU bound: one compress per lane)
+  H  wide hash layers: k_merkle_layer / k_merkle_leaves* with >= 128 workgroups over all members (VALU bound: one compress per lane; a merged launch is capped at 256)
   h  narrower hash launches (k_merkle_layer below that, k_merkle_layer_lp, k_merkle_tail)
   W  other wide launches (>= 1024 workgroups): the streaming kernels of the batch opening and the commits
   w  other launches of 2 .. 1023 workgroups per member set
@@ -25,7 +25,7 @@ def klass(name, wgs):
     if "merkle_layer_lp" in k or "merkle_tail" in k:
         return "h"
     if "merkle_layer" in k or "merkle_leaves" in k:
-        return "H" if wgs >= 1024 else "h"
+        return "H" if wgs >= 128 else "h"  # (round 6 caps every merged launch at 256 workgroups: a hash layer that takes its whole cap is a wide one)
     if any(t in k for t in ("_tail", "sc_persist", "sc_small")):
         return "T"
     return "W" if wgs >= 1024 else "w"
@@ -103,7 +103,7 @@ def main():
                 line += "."
             else:
                 line += occ[i].most_common(1)[0][0]
-        print("   " + line[:200])
+        print("   " + line[:420])
 
 
 if __name__ == "__main__":
