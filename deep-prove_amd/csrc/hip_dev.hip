@@ -133,12 +133,16 @@ struct Cohort {
   void note_wake() {
     if (awake_ || !have_fire_) return;
     awake_ = true; t_wake_ = std::chrono::steady_clock::now(); nwakes++;
-    dev_phase_us += std::chrono::duration<double, std::micro>(t_wake_ - t_fire_).count();
+    const double d = std::chrono::duration<double, std::micro>(t_wake_ - t_fire_).count();
+    dev_phase_us += d;
+    if (g_timing_level > 2 && last_fired_) { auto& e = dev_by_[last_fired_]; e.first += d; e.second++; }
   }
-  void note_fire() {
+  // (DP_TIMING=3) host and device phases by the launch that ENDS a host phase / is waited for: where in the proof a cohort's queue stands empty
+  std::map<const char*, std::pair<double, size_t>> host_by_, dev_by_; const char* last_fired_ = nullptr;
+  void note_fire(const char* name = nullptr) {
     auto t = std::chrono::steady_clock::now();
-    if (awake_) { host_phase_us += std::chrono::duration<double, std::micro>(t - t_wake_).count(); awake_ = false; }
-    t_fire_ = t; have_fire_ = true;
+    if (awake_) { const double h = std::chrono::duration<double, std::micro>(t - t_wake_).count(); host_phase_us += h; awake_ = false; if (g_timing_level > 2 && name) { auto& e = host_by_[name]; e.first += h; e.second++; } }
+    t_fire_ = t; have_fire_ = true; last_fired_ = name;
   }
 
   // `share`: run on the stream of another cohort (which must outlive this one: dp_model_prove_batch keeps the cohorts of a model together). Two cohorts on one
@@ -192,7 +196,7 @@ struct Cohort {
       Pending& p = q.front();
       if (p.count > 0) {
         std::atomic_thread_fence(std::memory_order_release);
-        if (g_host_stats) note_fire();
+        if (g_host_stats) note_fire(p.name);
         p.fire(p, s);
         inflight.push_back({q_base, p.ring_begin});
         nfired++;
@@ -2109,6 +2113,15 @@ void hip_cohort_stats(Cohort* c, size_t* fired, size_t* packs) {
   *fired = c->nfired; *packs = c->npacks; c->nfired = c->npacks = 0;
   if (g_host_stats && c->nwakes) fprintf(stderr, "[dp timing] cohort: %zu wake-ups; device phases (fire -> first member sees a result) %.1f ms, host phases (wake-up -> next fire) %.1f ms = %.1f us each\n",
                                         c->nwakes, c->dev_phase_us / 1000.0, c->host_phase_us / 1000.0, c->host_phase_us / c->nwakes);
+  if (g_timing_level > 2) {
+    for (int which = 0; which < 2; which++) {
+      std::vector<std::pair<double, std::string>> v;
+      for (auto& kv : which ? c->dev_by_ : c->host_by_) { char b[200]; snprintf(b, sizeof b, "%9.1f ms in %5zu phases, %8.1f us each: %s", kv.second.first / 1000.0, kv.second.second, kv.second.first / kv.second.second, kv.first); v.push_back({kv.second.first, b}); }
+      std::sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.first > b.first; });
+      for (size_t i = 0; i < v.size() && i < 14; i++) fprintf(stderr, "[dp cohort %s] %s\n", which ? "device phase ended by the result of" : "host phase before the fire of", v[i].second.c_str());
+    }
+  }
+  c->host_by_.clear(); c->dev_by_.clear();
   c->dev_phase_us = c->host_phase_us = 0; c->nwakes = 0; c->awake_ = false; c->have_fire_ = false;
 }
 void hip_dev_cohort_attach(Dev* d, Cohort* c) { static_cast<HipDev*>(d)->cohort_attach(c); }
