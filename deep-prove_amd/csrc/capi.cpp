@@ -60,7 +60,7 @@ __attribute__((constructor)) static void dp_default_hw_queues() { setenv("GPU_MA
 // the host transcript's Poseidon2: the AVX-512 permutation of p2_avx512.cpp when the CPU has it (DP_NO_AVX512=1: the scalar code)
 __attribute__((constructor)) static void dp_install_fast_poseidon2() {
   const char* e = getenv("DP_NO_AVX512");
-  if (!(e && atoi(e)) && dp::p2_cpu_has_avx512()) { dp::p2_fast() = dp::p2_permute_avx512; dp::p2_fast_compress8() = dp::p2_compress8_avx512; }
+  if (!(e && atoi(e)) && dp::p2_cpu_has_avx512()) { dp::p2_fast() = dp::p2_permute_avx512; dp::p2_fast_compress8() = dp::p2_compress8_avx512; dp::dl_copy_sum_fast() = dp::dl_copy_sum_avx512; }
 }
 static thread_local std::string g_err;
 template <class F>

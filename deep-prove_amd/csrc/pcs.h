@@ -261,9 +261,9 @@ inline BasefoldProof pcs_batch_open_evals(Dev& dev, unsigned full_log, const std
       }
       if (nc == 0) pos += 1;
     }
-    std::vector<u64>& ser = proof.queries_ser;
-    ser.resize(pos);
-    dev.query_gather_into(descs.data(), nd, pair_off.data(), path_off.data(), ser.data(), pos);
+    proof.queries_ser.acquire(pos);
+    u64* const ser = proof.queries_ser.data();
+    dev.query_gather_into(descs.data(), nd, pair_off.data(), path_off.data(), ser, pos);
     ser[0] = qidx.size();
     size_t hp = 1; di = 0;
     for (size_t x : qidx) {

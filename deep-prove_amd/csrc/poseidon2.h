@@ -155,6 +155,8 @@ inline void permute_scalar(u64* s) {
 // installed by the library when the CPU has AVX-512F/DQ (capi.cpp; DP_NO_AVX512=1 keeps the scalar code). Word-for-word equal results.
 void p2_permute_avx512(u64* s);
 bool p2_cpu_has_avx512();
+u64 dl_copy_sum_avx512(const u64* src, u64* dst, size_t n);  // (p2_avx512.cpp) copy + sum (i + 1) * word_i: the download path's chunk check
+inline u64 (*&dl_copy_sum_fast())(const u64*, u64*, size_t) { static u64 (*f)(const u64*, u64*, size_t) = nullptr; return f; }  // installed with p2_fast() when the CPU has AVX-512
 void p2_compress8_avx512(const u64 (*left)[4], const u64 (*right)[4], u64 (*out)[4]);  // eight compressions side by side (lane = pair)
 inline void (*&p2_fast())(u64*) { static void (*f)(u64*) = nullptr; return f; }
 inline void (*&p2_fast_compress8())(const u64 (*)[4], const u64 (*)[4], u64 (*)[4]) { static void (*f)(const u64 (*)[4], const u64 (*)[4], u64 (*)[4]) = nullptr; return f; }

@@ -20,6 +20,35 @@ struct Commitment { Digest root; unsigned num_vars = 0; bool is_base = true; };
 struct FieldVec { bool is_ext = false; std::vector<u64> w; size_t len() const { return is_ext ? w.size() / 2 : w.size(); } };
 struct CodewordQuery { bool is_ext = false; Ext left, right; size_t index = 0; std::vector<Digest> path; };
 struct BatchedQuery { size_t index = 0; std::vector<CodewordQuery> oracle_query, commitments_query; };
+// A block of words WITHOUT value-initialisation whose storage is recycled per host thread: the query section of a batch opening is 5.8 MB that the device's image overwrites
+// entirely — as a std::vector it was zero-filled on every resize and came from fresh zero pages on every proof (a page fault per 4 KB), ~0.6 ms of the proving thread.
+struct RawWords {
+  u64* p = nullptr; size_t n = 0, cap = 0;
+  RawWords() = default;
+  RawWords(const RawWords& o) { if (o.n) { acquire(o.n); memcpy(p, o.p, o.n * 8); } }
+  RawWords(RawWords&& o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+  RawWords& operator=(RawWords o) noexcept { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); return *this; }
+  ~RawWords() { release(); }
+  static std::vector<std::pair<u64*, size_t>>& pool() { static thread_local struct P { std::vector<std::pair<u64*, size_t>> v; ~P() { for (auto& b : v) free(b.first); } } pl; return pl.v; }
+  void acquire(size_t words) {
+    release();
+    auto& pl = pool();
+    for (size_t i = 0; i < pl.size(); i++) if (pl[i].second >= words) { p = pl[i].first; cap = pl[i].second; pl.erase(pl.begin() + (long)i); n = words; return; }
+    p = (u64*)malloc(std::max<size_t>(words, 1) * 8);
+    if (!p) throw std::bad_alloc();
+    cap = words; n = words;
+  }
+  void release() {
+    if (!p) return;
+    auto& pl = pool();
+    if (pl.size() < 3) pl.push_back({p, cap}); else free(p);  // (a thread serialises a proof before its next member finishes one: a few blocks cover it)
+    p = nullptr; n = cap = 0;
+  }
+  u64* data() { return p; }
+  const u64* data() const { return p; }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+};
 struct BasefoldProof {
   std::vector<std::vector<Ext>> sumcheck_messages;
   std::vector<Digest> roots;
@@ -29,7 +58,7 @@ struct BasefoldProof {
   // device's gather buffer (pcs_batch_open_evals): `queries` is then empty. A Dense-4M batch opening has 200 x 56 opened pairs with a Merkle path each — 5.8 MB,
   // nine tenths of the proof: as vectors of CodewordQuery that was 11 200 heap allocations, a copy into them, a copy out of them into the stream and as many
   // frees per proof, 1.3 ms of the proving thread that the ~20 other members of its cohort wait behind (profiles/r06_host_work_by_launch.txt).
-  std::vector<u64> queries_ser;
+  RawWords queries_ser;
   std::vector<std::vector<Ext>> sumcheck_proof;
   std::vector<FieldVec> trivial_proof;
   bool is_trivial() const { return sumcheck_messages.empty() && queries.empty() && queries_ser.empty() && sumcheck_proof.empty(); }

@@ -50,7 +50,7 @@ timeout -s KILL 500 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES GRBM_G
 timeout -s KILL 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES -d "$R/$o/sqp" -o x -- python "$R/tools/r04/probe_compress.py" > "$R/$o/sqp.log" 2>&1; echo "sqp rc=$?"
 cd "$R"
 f=$(find $o/sq -name '*_results.db' | head -1); g=$(find $o/sqp -name '*_results.db' | head -1)
-[ -n "$f" ] && python tools/pmc_sq_job.py "$f" $((2*N)) "$rate" $o/r06_pmc_sq_bench${N}.json "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -- python tools/profile_batch.py dense_4m 448 (cohort launches of the two 448-proof batches; final build of round 6)" "$g" 2097152 > $o/pmc_sq.txt 2>&1 && cp $o/r06_pmc_sq_bench${N}.json profiles/
+[ -n "$f" ] && python tools/pmc_sq_job.py "$f" $((2*N)) "$rate" $o/r06_pmc_sq_bench${N}.json "rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -- python tools/profile_batch.py dense_4m ${N} (cohort launches of the two ${N}-proof batches; final build of round 6)" "$g" 2097152 > $o/pmc_sq.txt 2>&1 && cp $o/r06_pmc_sq_bench${N}.json profiles/
 head -6 $o/pmc_sq.txt | cut -c1-250
 find $o -name '*.db' -size +2M -delete
 step "single-proof latency A/B (after a warm-up process: the first GPU process of a box runs ~4 ms slower)"
