@@ -517,12 +517,14 @@ def main():
     # host threads per rank: this rank's share of the CPUs the job may use (cgroup quota), two left to the HIP runtime
     budget = dpa.api.host_cpu_budget()
     host_threads = max(1, int(budget / max(1, local_world)) - 2)
-    os.environ.setdefault("DP_HOST_THREADS", str(host_threads))
+    if local_world > 1:  # (one rank on the node: the library's own default — one idle-sleeping thread per cohort — applies; several ranks share the CPUs: each gets its share)
+        os.environ.setdefault("DP_HOST_THREADS", str(host_threads))
+    host_threads = int(os.environ.get("DP_HOST_THREADS", host_threads))
     # A rank needs ~4 ms of host work per Dense-4M proof (transcript, claims, launch packs: DESIGN.md §7): ONE thread sustains ~250 proofs/s, the GPU
     # ~500. With fewer than 3 proving threads per rank the host, not the GPU, bounds the rate — say so instead of letting it read as a scaling loss.
-    host_bound = int(os.environ["DP_HOST_THREADS"]) < MIN_HOST_THREADS_PER_RANK
+    host_bound = host_threads < MIN_HOST_THREADS_PER_RANK
     if host_bound and rank == 0:
-        print(f"[bench] WARNING: {budget:.1f} usable CPUs for {local_world} rank(s) on this node = {os.environ['DP_HOST_THREADS']} proving thread(s) per rank "
+        print(f"[bench] WARNING: {budget:.1f} usable CPUs for {local_world} rank(s) on this node = {host_threads} proving thread(s) per rank "
               f"(< {MIN_HOST_THREADS_PER_RANK}): this run is HOST-BOUND; give every GPU at least {MIN_HOST_THREADS_PER_RANK + 2} CPUs", file=sys.stderr, flush=True)
     conc = args.concurrency if args.concurrency > 0 else DEFAULT_IN_FLIGHT
 
@@ -535,7 +537,7 @@ def main():
     per_rank = None
     if dist is not None and world > 1:  # what every rank saw: a slow rank (setup, one long step) must be visible in the N > 1 line
         mine = {"rank": rank, "step_ms": [round(v, 1) for v in main_w["step_ms"]], "setup_s": round(main_w["setup_s"], 2), "single_proof_latency_ms": round(main_w["latency_ms"], 2),
-                "host_threads": int(os.environ["DP_HOST_THREADS"]), "in_flight": int(main_w["in_flight"])}
+                "host_threads": host_threads, "in_flight": int(main_w["in_flight"])}
         per_rank = [None] * world
         try:
             dist.all_gather_object(per_rank, mine)
@@ -637,14 +639,14 @@ def main():
                        "strong_scaling_note": (f"BASELINE config 4: one batch of {args.batch} independent proofs per step split over {world} GPU(s) (rank r proves proofs r, r+{world}, ...); "
                                                "every rank commits the model itself (Context::generate recomputed per rank, outside the timed region), no data-path collective") if args.batch else None,
                        "single_proof_latency_ms": round(main_w["latency_ms"], 2), "single_proof_latency_samples_ms": main_w["latency_samples_ms"], "first_proof_ms": round(main_w["first_ms"], 2),
-                       "host_cpu_budget": budget, "host_threads_per_rank": int(os.environ["DP_HOST_THREADS"]), "host_bound": bool(host_bound),
+                       "host_cpu_budget": budget, "host_threads_per_rank": host_threads, "host_bound": bool(host_bound),
                        "gpu_clocks_timed_region": main_w.get("clocks"),
                        "min_cpus_per_gpu": MIN_HOST_THREADS_PER_RANK + 2, "per_rank": per_rank,
                        "parallelism": f"replicas x{world} GPUs x {main_w['in_flight']} proofs in flight per GPU in lock-step cohorts of {os.environ.get('DP_COHORT') or -(-main_w['in_flight'] // 22)} (independent proofs, no data-path collective)",
                        "proof_words": main_w["proof_words"], "setup_s": round(main_w["setup_s"], 2), "verified": True, "golden_sha256_ok": main_w["golden_ok"], "verified_proofs_of_last_step": main_w["verified"], "verify_ms_per_proof": main_w["verify_ms"], "verify_batch_ms_per_proof": main_w["verify_batch_ms_per_proof"],
                        "env_knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("DP_") or k == "GPU_MAX_HW_QUEUES"}, "device": dev.name},
             "roofline": roofline, "cpu_baseline": cpu, "cnn_264k": cnn, "sumcheck24": sc24, "sumcheck24_sharded": None,
-            "seam_level": None if (world > 1 or args.no_seam_level) else seam_level(int(os.environ["DP_HOST_THREADS"]), batch_rate=value),
+            "seam_level": None if (world > 1 or args.no_seam_level) else seam_level(host_threads, batch_rate=value),
         }
         result["tail_roofline"] = tail_roofline()
         if sc24 is not None and not args.batch:
