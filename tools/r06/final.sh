@@ -24,6 +24,17 @@ if [ -n "$f" ] && [ -n "$w" ]; then
   python tools/pmc_summary.py --after-marker k_merkle_paths --population dense_4m_latency_proofs --units 3 "$f" "$w" "$o/r06_pmc_dense4m_proofs.json" "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python tools/proof_only.py dense_4m 3 (launches after the k_merkle_paths marker: 3 latency-mode proofs, no setup; final build of round 6, tools/r06/final.sh)" > "$o/pmc_dense4m.txt" 2>&1
   cp "$o/r06_pmc_dense4m_proofs.json" profiles/ && echo "pmc dense4m written"
 fi
+step "PMC: 2^26 sumcheck"
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -s KILL 300 rocprofv3 --kernel-trace --pmc $c -d "$R/$o/sc26_$c" -o x -- python "$R/tools/sumcheck24_only.py" 3 26 > "$R/$o/sc26_$c.log" 2>&1; echo "sc26 $c rc=$?"
+done
+cd "$R"
+f=$(find "$o/sc26_FETCH_SIZE" -name '*_results.db' | head -1); w=$(find "$o/sc26_WRITE_SIZE" -name '*_results.db' | head -1)
+if [ -n "$f" ] && [ -n "$w" ]; then
+  python tools/pmc_summary.py --population sumcheck26 --units 3 "$f" "$w" "$o/r06_pmc_sumcheck26.json" "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python tools/sumcheck24_only.py 3 26 (3 repetitions of the 2^26 sumcheck; final build of round 6, tools/r06/final.sh)" k_sc > "$o/pmc_sc26.txt" 2>&1
+  cp "$o/r06_pmc_sumcheck26.json" profiles/ && echo "pmc sumcheck26 written"; tail -3 "$o/pmc_sc26.txt" | cut -c1-300
+fi
 f=$(find "$o/sc24_FETCH_SIZE" -name '*_results.db' | head -1); w=$(find "$o/sc24_WRITE_SIZE" -name '*_results.db' | head -1)
 if [ -n "$f" ] && [ -n "$w" ]; then
   python tools/pmc_summary.py --population sumcheck24 --units 3 "$f" "$w" "$o/r06_pmc_sumcheck24.json" "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python tools/sumcheck24_only.py 3 (3 repetitions of the 2^24 sumcheck; final build of round 6, tools/r06/final.sh)" k_sc > "$o/pmc_sc24.txt" 2>&1
