@@ -336,6 +336,52 @@ class Dev {
       std::copy(out[i].begin() + np, out[i].end(), dst + path_off[i]);
     }
   }
+  // The whole query section of a batch opening as its stream words (proof.h Writer::basefold; batch_prover_query_phase, query_phase.rs:67-102, 419-472): the count,
+  // then per query [index x] [#oracle] entries [#commitments] entries, an entry = [is_ext] [pair: 4 or 2 words] [index of the pair's left element] [path length]
+  // [path digests]. Every query opens the same trees — the oracles of the commit phase first, the committed codewords after them — at the pair
+  // p0 = (x >> shift) & ~1 (oracle k: shift = 1 + k; a codeword of height h below a running oracle of cw_log: shift = cw_log - h), so the section is a regular
+  // image: a query's block has a fixed length and tree k sits at a fixed offset in it. A device that can (HipDev) writes the image itself from the 200 query
+  // indices and the list of trees — headers included — instead of reading 11 200 expanded descriptors (56 B each) from the host; this default builds the
+  // descriptors and the headers on the host (the CPU double, devices without the kernel).
+  struct QueryTree { const DevTree* tree; unsigned shift; };
+  // offsets of the entries in a query's block (words from the block's first word), the position of the [#commitments] word, the block's length
+  static size_t query_section_layout(const QueryTree* trees, size_t noracle, size_t ncomm, std::vector<size_t>& rel, size_t& ncomm_pos) {
+    rel.assign(noracle + ncomm, 0);
+    size_t pos = 2;
+    ncomm_pos = 0;
+    for (size_t k = 0; k < noracle + ncomm; k++) {
+      if (k == noracle) ncomm_pos = pos++;
+      rel[k] = pos;
+      pos += 1 + (trees[k].tree->leaves.ext ? 4 : 2) + 2 + 4 * (size_t)(trees[k].tree->height() - 1);
+    }
+    if (ncomm == 0) ncomm_pos = pos++;
+    return pos;
+  }
+  virtual void query_section(const size_t* qidx, size_t nq, const QueryTree* trees, size_t noracle, size_t ncomm, u64* dst, size_t total) {
+    const size_t nt = noracle + ncomm;
+    std::vector<size_t> rel; size_t cpos;
+    const size_t stride = query_section_layout(trees, noracle, ncomm, rel, cpos);
+    DP_REQUIRE(total == 1 + nq * stride, DP_ERR_SHAPE, "query_section: layout");
+    std::vector<QueryDesc> descs(nq * nt);
+    std::vector<size_t> pair_off(nq * nt), path_off(nq * nt);
+    for (size_t qi = 0, di = 0; qi < nq; qi++)
+      for (size_t k = 0; k < nt; k++, di++) {
+        const size_t e = 1 + qi * stride + rel[k];
+        descs[di] = {trees[k].tree, (qidx[qi] >> trees[k].shift) & ~size_t(1)};
+        pair_off[di] = e + 1; path_off[di] = e + 1 + (trees[k].tree->leaves.ext ? 4 : 2) + 2;
+      }
+    query_gather_into(descs.data(), descs.size(), pair_off.data(), path_off.data(), dst, total);
+    dst[0] = nq;
+    for (size_t qi = 0, di = 0; qi < nq; qi++) {
+      u64* o = dst + 1 + qi * stride;
+      o[0] = qidx[qi]; o[1] = noracle; o[cpos] = ncomm;
+      for (size_t k = 0; k < nt; k++, di++) {
+        const size_t nw = trees[k].tree->leaves.ext ? 4 : 2;
+        u64* e = o + rel[k];
+        e[0] = nw == 4 ? 1 : 0; e[1 + nw] = descs[di].p0; e[2 + nw] = (u64)(trees[k].tree->height() - 1);
+      }
+    }
+  }
   // the same words in ONE buffer: descriptor i at flat[off[i] .. off[i + 1]). A Dense-4M batch opening gathers 10 000 (pair, path) records, 5.8 MB: the
   // vector-per-record form cost the proving thread ~20 000 heap allocations and two extra copies per proof (the members of a cohort run it one after the other)
   virtual void query_gather_flat(const QueryDesc* d, size_t nd, std::vector<u64>& flat, std::vector<size_t>& off) {

@@ -60,6 +60,12 @@ struct ProfRec { const char* name; double bytes; hipEvent_t a, b; };
 #define DPL_B(kern, maxt, flags, grid, block, lds, ...) do { prof_begin(#kern); LaunchTimer lt_(this); launch_<kern, maxt, flags>(KArgs<decltype(&kern)>(), #kern, grid, block, lds, __VA_ARGS__); lt_.stop(); prof_end(); } while (0)
 #define DPL(kern, grid, block, ...) DPL_B(kern, 1024, KF_NONE, grid, block, 0, __VA_ARGS__)
 #define DPL_LDS(kern, grid, block, lds, ...) DPL_B(kern, 1024, KF_NONE, grid, block, lds, __VA_ARGS__)
+// the bulk hash layers (kernels.inc DP_HASH_VGPRS: a build that makes their waves own a tail-sized share of the register file)
+#if DP_HASH_VGPRS
+#define DPL_HASH(kern, grid, block, ...) DPL_B(kern, 256, KF_HASH, grid, block, 0, __VA_ARGS__)
+#else
+#define DPL_HASH(kern, grid, block, ...) DPL(kern, grid, block, __VA_ARGS__)
+#endif
 // The throughput-mode form of a one-workgroup body runs at most SHARED_MAXT threads and is COMPILED for that: __launch_bounds__(256) leaves the
 // register allocator 512 VGPRs per lane instead of the 128 of a 1024-thread workgroup — under __launch_bounds__(1024) k_logup_tail spilled 54 VGPRs and
 // k_sc_persist 75 into scratch, on the dependent chain that bounds every tail (round-3 review; profiles/r04_kernel_resources_gfx950.csv).
@@ -642,9 +648,9 @@ class HipDev : public Dev {
     DBuf in = alloc(8 * nodes, false), out = alloc(4 * nodes, false);
     nb_ = 0; DPL(k_zero_words, dim3(grid_for(8 * nodes)), dim3(TPB), (u64*)in.p, 8 * nodes);
     hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-    nb_ = 96.0 * nodes; DPL(k_merkle_layer, dim3(grid_for(nodes, 4096)), dim3(TPB), (const u64*)in.p, (u64*)out.p, nodes);
+    nb_ = 96.0 * nodes; DPL_HASH(k_merkle_layer, dim3(grid_for(nodes, 4096)), dim3(TPB), (const u64*)in.p, (u64*)out.p, nodes);
     HIP_CHECK(hipEventRecord(a, s_));
-    for (int r = 0; r < reps; r++) { nb_ = 96.0 * nodes; DPL(k_merkle_layer, dim3(grid_for(nodes, 4096)), dim3(TPB), (const u64*)in.p, (u64*)out.p, nodes); }
+    for (int r = 0; r < reps; r++) { nb_ = 96.0 * nodes; DPL_HASH(k_merkle_layer, dim3(grid_for(nodes, 4096)), dim3(TPB), (const u64*)in.p, (u64*)out.p, nodes); }
     HIP_CHECK(hipEventRecord(b, s_)); HIP_CHECK(hipEventSynchronize(b));
     float ms = 0; HIP_CHECK(hipEventElapsedTime(&ms, a, b));
     hipEventDestroy(a); hipEventDestroy(b);
@@ -1757,7 +1763,7 @@ class HipDev : public Dev {
     while (cnt > TAIL_MAX) {
       size_t next = cnt / 2;
       if (next <= lp_max_now()) { nb_ = 96.0 * next; DPL(k_merkle_layer_lp, dim3((unsigned)grid_for(next * 8, 8192)), dim3(256), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
-      else { nb_ = 96.0 * next; DPL(k_merkle_layer, dim3(merkle_grid(next)), dim3(TPB), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
+      else { nb_ = 96.0 * next; DPL_HASH(k_merkle_layer, dim3(merkle_grid(next)), dim3(TPB), (const u64*)(nd + 4 * off), nd + 4 * (off + cnt), next); }
       off += cnt; cnt /= 2;
     }
     const TailDesc* dd = nullptr;
@@ -2092,6 +2098,33 @@ class HipDev : public Dev {
     size_t mk = mark();
     u64* dout = (u64*)arena_alloc(total * 8);
     DPL(k_query_gather, dim3((unsigned)grid_for(nd * 64, 1 << 20)), dim3(TPB), dd, nd, dout);
+    d2h(dst, dout, total * 8);
+    release(mk);
+  }
+  // the image written by the device from the query indices and the tree list (kernels.inc k_query_section): 4 KB of host-written words per opening instead of
+  // 11 200 expanded descriptors (627 KB read by the kernel across PCIe) and a host pass over the image for its headers — 1.27 ms of the proving thread per
+  // Dense-4M proof, spent with the cohort's queue empty (profiles/r06_cohort_phases_704.txt: 40.7 ms per cohort and pass before k_query_gather). DP_QUERY_SECTION_HOST=1: the host form.
+  void query_section(const size_t* qidx, size_t nq, const QueryTree* trees, size_t noracle, size_t ncomm, u64* dst, size_t total) override {
+    static const bool host_form = getenv("DP_QUERY_SECTION_HOST") && atoi(getenv("DP_QUERY_SECTION_HOST"));
+    const size_t nt = noracle + ncomm;
+    if (host_form || !nq || !nt) { Dev::query_section(qidx, nq, trees, noracle, ncomm, dst, total); return; }
+    std::vector<size_t> rel; size_t cpos;
+    const size_t stride = query_section_layout(trees, noracle, ncomm, rel, cpos);
+    DP_REQUIRE(total == 1 + nq * stride, DP_ERR_SHAPE, "query_section: layout");
+    const u64* dd = nullptr;
+    u64* hd = desc_alloc<u64>(8 + nq + 5 * nt, &dd);
+    hd[0] = nq; hd[1] = nt; hd[2] = noracle; hd[3] = ncomm; hd[4] = stride; hd[5] = cpos; hd[6] = hd[7] = 0;
+    for (size_t i = 0; i < nq; i++) hd[8 + i] = qidx[i];
+    for (size_t k = 0; k < nt; k++) {
+      const DevTree& t = *trees[k].tree;
+      DP_REQUIRE(trees[k].shift < 64 && t.height() >= 1 && ((size_t(1) << t.height()) == t.nleaves), DP_ERR_SHAPE, "query_section: tree");
+      u64* w = hd + 8 + nq + 5 * k;
+      w[0] = (u64)t.leaves.p; w[1] = (u64)t.nodes.p; w[2] = t.nleaves; w[3] = (u64)trees[k].shift | ((u64)(t.leaves.ext ? 1 : 0) << 8) | ((u64)t.height() << 16); w[4] = rel[k];
+    }
+    for (size_t i = 0; i < nq; i++) for (size_t k = 0; k < nt; k++) DP_REQUIRE((((qidx[i] >> trees[k].shift) | 1) < trees[k].tree->nleaves), DP_ERR_SHAPE, "query_section: query index outside a tree");
+    size_t mk = mark();
+    u64* dout = (u64*)arena_alloc(total * 8);
+    DPL(k_query_section, dim3((unsigned)grid_for(nq * nt * 64, 1 << 20)), dim3(TPB), dd, dout);
     d2h(dst, dout, total * 8);
     release(mk);
   }

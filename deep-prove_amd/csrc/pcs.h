@@ -237,48 +237,17 @@ inline BasefoldProof pcs_batch_open_evals(Dev& dev, unsigned full_log, const std
   // ---- batch_prover_query_phase (query_phase.rs:67-102, 419-472) and Merkle paths (:1062-1087)
   std::vector<size_t> qidx;
   for (unsigned q = 0; q < PCS_NUM_QUERIES; q++) qidx.push_back((size_t)(t.get_and_append_challenge("query indices").c0 % cw_size));
-  std::vector<QueryDesc> descs;
-  unsigned cw_log = num_vars + PCS_RATE_LOG;
-  for (size_t x : qidx) {
-    size_t index = x >> 1;
-    for (auto& tr : trees) { size_t p1 = index | 1; descs.push_back({&tr, p1 - 1}); index >>= 1; }
-    for (const DevCommit* c : comms) { size_t xi = x >> (cw_log - c->tree.height()); size_t p1 = xi | 1; descs.push_back({&c->tree, p1 - 1}); }
-  }
-  // The query section is laid out as its stream words (proof.h Writer::basefold / cq) and the device gathers straight into that image: per opened pair
-  // [is_ext] [pair: 4 or 2 words] [index] [path length] [path digests]; per query [index] [#oracle] .. [#commitments] ..; the count in front. The headers are
-  // written after the image has come back (Dev::query_gather_into leaves them unspecified).
+  // The query section is laid out as its stream words (proof.h Writer::basefold / cq) and the device writes it in that form (Dev::query_section): every query opens
+  // the pair (index | 1) - 1 of each oracle, index = x >> 1 halving from oracle to oracle, and the pair (xi | 1) - 1, xi = x >> (cw_log - height), of each codeword
   {
-    const size_t nd = descs.size();
-    std::vector<size_t> pair_off(nd), path_off(nd);
-    size_t pos = 1, di = 0;
-    for (size_t qi = 0; qi < qidx.size(); qi++) {
-      pos += 2;  // index, #oracle
-      for (size_t k = 0; k < trees.size() + nc; k++, di++) {
-        if (k == trees.size()) pos += 1;  // #commitments
-        const bool e = descs[di].tree->leaves.ext;
-        pair_off[di] = pos + 1; path_off[di] = pos + 1 + (e ? 4 : 2) + 2;
-        pos = path_off[di] + 4 * (size_t)(descs[di].tree->height() - 1);
-      }
-      if (nc == 0) pos += 1;
-    }
-    proof.queries_ser.acquire(pos);
-    u64* const ser = proof.queries_ser.data();
-    dev.query_gather_into(descs.data(), nd, pair_off.data(), path_off.data(), ser, pos);
-    ser[0] = qidx.size();
-    size_t hp = 1; di = 0;
-    for (size_t x : qidx) {
-      ser[hp] = x; ser[hp + 1] = trees.size(); hp += 2;
-      for (size_t k = 0; k < trees.size() + nc; k++, di++) {
-        if (k == trees.size()) ser[hp++] = nc;
-        const bool e = descs[di].tree->leaves.ext;
-        ser[hp] = e ? 1 : 0;
-        ser[pair_off[di] + (e ? 4 : 2)] = descs[di].p0;
-        ser[pair_off[di] + (e ? 4 : 2) + 1] = (u64)(descs[di].tree->height() - 1);
-        hp = path_off[di] + 4 * (size_t)(descs[di].tree->height() - 1);
-      }
-      if (nc == 0) ser[hp++] = 0;
-    }
-    DP_REQUIRE(hp == pos, DP_ERR_SHAPE, "batch_open: query section layout");
+    const unsigned cw_log = num_vars + PCS_RATE_LOG;
+    std::vector<Dev::QueryTree> qt;
+    for (size_t k = 0; k < trees.size(); k++) qt.push_back({&trees[k], (unsigned)(1 + k)});
+    for (const DevCommit* c : comms) qt.push_back({&c->tree, cw_log - c->tree.height()});
+    std::vector<size_t> rel; size_t cpos;
+    const size_t total = 1 + qidx.size() * Dev::query_section_layout(qt.data(), trees.size(), nc, rel, cpos);
+    proof.queries_ser.acquire(total);
+    dev.query_section(qidx.data(), qidx.size(), qt.data(), trees.size(), nc, proof.queries_ser.data(), total);
   }
   lap("query phase");
   dev.release(mk);

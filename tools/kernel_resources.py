@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Per-kernel register / LDS / scratch use of libdeepprove_hip.so's device code as the compiler reports it
-(hipcc -Rpass-analysis=kernel-resource-usage, gfx950) -> CSV. Needs no GPU.  usage: python tools/kernel_resources.py out.csv"""
+(hipcc -Rpass-analysis=kernel-resource-usage, gfx950) -> CSV. Needs no GPU.  usage: python tools/kernel_resources.py out.csv
+(DP_HIPCC_EXTRA="-D..." in the environment: the resources of a variant build)"""
 import csv
 import os
 import re
@@ -19,7 +20,7 @@ def main():
     src = os.path.join(ROOT, "deep-prove_amd", "csrc", "hip_dev.hip")
     with tempfile.TemporaryDirectory() as d:
         r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-Wno-unused-value",
-                            "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(d, "x.o"), src], capture_output=True, text=True)
+                            "-Rpass-analysis=kernel-resource-usage", "-o", os.path.join(d, "x.o"), src] + os.environ.get("DP_HIPCC_EXTRA", "").split(), capture_output=True, text=True)
     recs, cur = [], None
     for ln in r.stderr.split("\n"):
         m = re.search(r"remark: Function Name: (\S+)", ln)
