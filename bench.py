@@ -661,11 +661,11 @@ def main():
             # BASELINE config 4 at N = 1: ONE batch of 64 independent proofs per step, all in flight at once — the anchor the 8-GPU strong-scaling line
             # (`bench.py --gpus 8 --batch 64`) is read against; the golden input rides in the last step and its proof must have the oracle's sha256
             try:
-                b_steps = 3
+                b_steps = 6  # (six 0.14 s steps: one step of three now and then takes 220 ms instead of 137 — the first batch after the large job's workers were torn down)
                 b64 = measure_workload(dpa, dev, "dense_4m", conc, b_steps, 1, world, rank, dist, torch, strong_batch=64)
                 result["batch64"] = {"metric": "proofs/sec (prover), Dense-4M, one batch of 64 per step (BASELINE config 4 on 1 GPU)", "value": round(b_steps * 64 / b64["elapsed"], 4), "unit": "proofs/s",
                                      "ms_per_batch": round(1000.0 * b64["elapsed"] / b_steps, 2), "steps": b_steps, "warmup": 1, "proofs_in_flight": b64["in_flight"], "scaling": "strong",
-                                     "step_ms": [round(v, 1) for v in b64["step_ms"]], "golden_sha256_ok": b64["golden_ok"], "verified_proofs_of_last_step": b64["verified"],
+                                     "step_ms": [round(v, 1) for v in b64["step_ms"]], "ms_per_batch_median": round(sorted(b64["step_ms"])[len(b64["step_ms"]) // 2], 2), "golden_sha256_ok": b64["golden_ok"], "verified_proofs_of_last_step": b64["verified"],
                                      "command_for_n_gpus": "python bench.py --gpus N --batch 64"}
             except Exception as e:  # noqa: BLE001
                 result["batch64"] = {"error": f"{type(e).__name__}: {e}"[:300]}

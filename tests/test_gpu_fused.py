@@ -48,6 +48,7 @@ KNOBS = [{}, {"DP_DEVICE_LOGUP": "0"}, {"DP_DEVICE_LOGUP": "1"}, {"DP_FUSED_OFF"
          {"DP_PREP_THREADS": "0"},  # no helper threads: every worker runs inference and the host half of the witness generation itself when it starts a proof
          {"DP_AXPY_CLASSES": "0"},  # the batch opening's short polynomials straight into the accumulator pass (k_axpy_classes off)
          {"DP_HOST_SPONGE": "1"},  # the fused kernels with the transcript's sponge on the host (csrc/sponge_host.h)
+         {"DP_QUERY_SECTION_HOST": "1"},  # the batch opening's query section from host-built descriptors (k_query_gather) instead of k_query_section
          {"DP_LOGUP_WIDE_N": "0"}, {"DP_LOGUP_WIDE_N": "1024"},  # k_logup_tail's 512-thread throughput form: never / from 1 024 rows on (default 2 048)
          {"DP_MAILBOX_VRAM": "0", "DP_LP_MAX": "4096", "DP_NUMA_PIN": "0"}]  # the single proof the batch is compared with: mailbox in host memory, round 4's Merkle threshold, no affinity
 
