@@ -1098,6 +1098,11 @@ class HipDev : public Dev {
   }
   static constexpr size_t SC_SMALL_MAX = 8192;  // tables up to this length (after the fold) take the one-launch path
   const Ext* claim_hint_ = nullptr;  // set for the duration of sc_round_claim: the fused streaming path may skip t = 1
+  // "grid2" (round 6; kernels.inc k_sc_terms2 / k_sc_fused2): the first two rounds of one product of <= 3 large BASE tables from ONE pass over them, both folds in one more.
+  // stage 1: the sixteen grid sums are here and round 1 has been answered, the tables are still whole; stage 2: round 2 has been answered from the grid at r1, both folds are due.
+  // One proof on the GPU only (latency mode, in-kernel ticket); DP_SC_GRID2=0 keeps the round-by-round form. 2^24 sumcheck 0.985 -> see profiles/r06_sumcheck_grid2_ab.txt.
+  struct Grid2 { int stage = 0; int nt = 0; size_t n = 0; u64 A[16]; Ext r1; } grid2_;
+  static constexpr size_t GRID2_MIN_N = size_t(1) << 20;
   void sc_round_claim(DBuf* tabs, int nt, const Ext* r, const ScTerm* terms, int nterms, const Ext* claim, Ext* out) override {
     claim_hint_ = nterms == 1 ? claim : nullptr;
     try { sc_round(tabs, nt, r, terms, nterms, out); } catch (...) { claim_hint_ = nullptr; throw; }
@@ -1414,6 +1419,75 @@ class HipDev : public Dev {
         out[o] = acc;
       }
     };
+    if (!r) grid2_.stage = 0;  // (a sumcheck abandoned between its first rounds leaves nothing behind)
+    if (grid2_.stage) {
+      DP_REQUIRE(r && nt == grid2_.nt && n_in == grid2_.n && nterms == 1 && terms[0].k == nt && !sess_.active, DP_ERR_ARG, "sumcheck out of sync (two-round grid)");
+      const int K = nt;
+      if (grid2_.stage == 1) {  // round 2 from the grid: s2(u2) = sum_u1 L_u1(r1) A[u1][u2], nodes 0..K — no launch, nothing folded yet
+        for (int u2 = 0; u2 <= K; u2++) {
+          Ext col[4];
+          for (int u1 = 0; u1 <= K; u1++) col[u1] = ex_base(grid2_.A[u1 * 4 + u2]);
+          out[u2] = lagrange_eval_small(col, (size_t)K + 1, *r);
+        }
+        grid2_.r1 = *r; grid2_.stage = 2;
+        return;
+      }
+      // stage 2: both folds and the sums of round 3 in one pass over the base tables
+      grid2_.stage = 0;
+      const void* in[3] = {nullptr, nullptr, nullptr}; Ext* outp[3] = {nullptr, nullptr, nullptr};
+      const size_t n_out = n_in / 4;
+      double bytes = 0;
+      for (int j = 0; j < nt; j++) {
+        int ti = terms[0].t[j];
+        DP_REQUIRE(!tabs[ti].ext, DP_ERR_ARG, "sumcheck out of sync (two-round grid: folded tables)");
+        DBuf o = alloc(n_out, true);
+        in[j] = tabs[ti].p; outp[j] = (Ext*)o.p;
+        bytes += tabs[ti].bytes() + o.bytes();
+        tabs[ti] = o;
+      }
+      const size_t nocts = n_in / 8;
+      size_t mk = mark();
+      int g = grid_for(nocts, 4096);
+      Ext* partial = (Ext*)arena_alloc((size_t)g * 4 * 16);
+      nb_ = bytes;
+      const bool skip1 = claim_hint_ != nullptr;
+      const unsigned long long fseq = ++seq_;
+      #define LAUNCH_F2(KK) do { if (skip1) DPL_B((k_sc_fused2<KK, true>), 256, KF_NONE, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], outp[0], outp[1], outp[2], nocts, grid2_.r1, *r, partial, fused_ticket_, (Ext*)hres_dev_, hflag_dev_, fseq); \
+                                 else DPL_B((k_sc_fused2<KK, false>), 256, KF_NONE, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], outp[0], outp[1], outp[2], nocts, grid2_.r1, *r, partial, fused_ticket_, (Ext*)hres_dev_, hflag_dev_, fseq); } while (0)
+      if (nt == 1) LAUNCH_F2(1); else if (nt == 2) LAUNCH_F2(2); else LAUNCH_F2(3);
+      #undef LAUNCH_F2
+      wait_flag(fseq, 8);
+      for (int t = 0; t <= K; t++) out[t] = ex(hres_[2 * t], hres_[2 * t + 1]);
+      if (skip1) out[1] = ex_sub(*claim_hint_, out[0]);  // s(0) + s(1) = claim, exactly
+      release(mk);
+      return;
+    }
+    {
+      static const bool grid2_env = !(getenv("DP_SC_GRID2") && !atoi(getenv("DP_SC_GRID2")));
+      bool take = grid2_env && !r && !throughput_mode_ && !share_x_ && zerocopy_ && !queued_() && fused_ticket_ != nullptr && !sess_.active && !pend_eq_.p
+                  && nterms == 1 && terms[0].k == nt && nt <= 3 && n_in >= GRID2_MIN_N;
+      for (int i = 0; take && i < nt; i++) { take = !tabs[i].ext; for (int j = 0; j < i; j++) take = take && terms[0].t[i] != terms[0].t[j]; }
+      if (take) {
+        const void* in[3] = {nullptr, nullptr, nullptr};
+        double bytes = 0;
+        for (int j = 0; j < nt; j++) { in[j] = tabs[terms[0].t[j]].p; bytes += tabs[terms[0].t[j]].bytes(); }
+        const size_t nquads = n_in / 4;
+        size_t mk = mark();
+        int g = grid_for(nquads, 768);  // (chip-sized: kernels.inc, k_sc_terms2)
+        Ext* partial = (Ext*)arena_alloc((size_t)g * 8 * 16);
+        nb_ = bytes;
+        const unsigned long long fseq = ++seq_;
+        if (nt == 1) DPL_B((k_sc_terms2<1>), 256, KF_NONE, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], nquads, partial, fused_ticket_, (Ext*)hres_dev_, hflag_dev_, fseq);
+        else if (nt == 2) DPL_B((k_sc_terms2<2>), 256, KF_NONE, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], nquads, partial, fused_ticket_, (Ext*)hres_dev_, hflag_dev_, fseq);
+        else DPL_B((k_sc_terms2<3>), 256, KF_NONE, dim3(g), dim3(TPB), 0, in[0], in[1], in[2], nquads, partial, fused_ticket_, (Ext*)hres_dev_, hflag_dev_, fseq);
+        wait_flag(fseq, 16);
+        for (int i = 0; i < 16; i++) grid2_.A[i] = hres_[i];
+        release(mk);
+        for (int t = 0; t <= nt; t++) out[t] = ex_base(gl_add(grid2_.A[t * 4 + 0], grid2_.A[t * 4 + 1]));  // s1(u1) = A[u1][0] + A[u1][1]
+        grid2_.stage = 1; grid2_.nt = nt; grid2_.n = n_in;
+        return;
+      }
+    }
     if (sess_.active && sess_.multi) {  // multi-workgroup phase: every workgroup folds its slice with this challenge
       DP_REQUIRE(r && nt == sess_.ntabs && n_in == sess_.n, DP_ERR_ARG, "sumcheck session out of sync");
       post_challenge(*r);

@@ -95,6 +95,11 @@ SC_CASES = [
     (11, [False, True, False, True, True, False], [((3, 1), [0, 1, 2, 3]), ((1, 0), [4, 5]), ((P - 2, 7), [5, 4, 3, 2, 1]), ((9, 0), [0])]),
     (17, [False, False, True, True], [((1, 0), [0, 1, 2, 3])]),
     (14, [True, False, False, True, True], [((2, 3), [0, 1, 2, 3, 4]), ((1, 0), [3, 4])]),
+    # round 6: single products of base tables of 2^20 entries and more take the two-round grid (k_sc_terms2 / k_sc_fused2: rounds 1 and 2 from one pass, both folds
+    # in one more) — cases 11 and 14 above are its degree-3 forms with and without the claim; degree 2 (tables in swapped order) and degree 1 here
+    (20, [False, False], [((1, 0), [1, 0])]),
+    (20, [False], [((1, 0), [0])]),
+    (20, [False, False], [((6, 2), [0, 1])]),
 ]
 # tables with FEWER variables than the polynomial (sumcheck_macro/src/lib.rs:236-247): (nv, [(table nv, is_ext)], terms)
 SC_MIXED = [

@@ -1,6 +1,7 @@
 """GPU parity of the sharded sumcheck (BASELINE config 5): W device contexts each own a contiguous slice of every
 table and run dp_sc_session_* on it; the shares are combined by deep_prove_amd.sharded.prove_sharded. The proof must be
 bit-identical to the unsharded device prover and to the oracle."""
+import os
 import numpy as np
 import pytest
 
@@ -186,6 +187,22 @@ def test_config5_prove_parallel_at_size_equals_oracle_golden(dev, nv):
         for m in tabs:
             m.free()
     _check_against_golden(dpa, gold, nv, proof, finals, t)
+
+
+def test_config5_round_by_round_form_equals_oracle_golden():
+    """DP_SC_GRID2=0: the round-by-round streaming form (k_sc_terms, then one k_sc_fused launch per round) that the two-round grid replaced as the default for large
+    base-table products stays the fallback — same golden sha256 at 2^22, in its own process (the knob is read once)"""
+    import subprocess
+    import sys
+    gold, _ = _golden_sc(22)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for knob in ("0", "1"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "sumcheck24_only.py"), "2", "22"], capture_output=True, text=True, timeout=300, cwd=root,
+                           env=dict(os.environ, DP_SC_GRID2=knob, SC24_PROFILE="1"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        shas = [ln.split()[-1] for ln in r.stdout.splitlines() if "proof sha256" in ln]
+        assert len(shas) == 2 and all(h == gold["sha256"][:16] for h in shas), (knob, r.stdout)
+        assert ("k_sc_terms2" in r.stdout) == (knob == "1"), (knob, r.stdout)  # the form that ran is the one asked for
 
 
 def test_fused_round_ticket_under_reuse_of_its_partial_buffer(dev):
