@@ -783,8 +783,12 @@ def sumcheck24(dev, dpa, nv=24, k=3):
                 "alg_bytes_per_launch": round(big["alg_bytes"] / big["launches"], 1),
                 "avg_launch_us": round(1000 * big["total_ms"] / big["launches"], 2), "launches": big["launches"],
                 "timing": "HIP events on the launch stream, median of 5 profiled repetitions after 1 profiled warm-up",
-                "note": "a fold+sum pass does ~36 Goldilocks multiplications per 192 B moved; at the measured ~1.0e12 mul/s of the chip the "
-                        "VALU-integer bound (~0.15 ms for the first fused round) is above the HBM bound (0.13 ms at 6.3 TB/s)"}
+                "note": ("k_sc_fused2 (round 6, the two-round grid): both folds of rounds 1 and 2 and the sums of round 3 in ONE pass over the base tables — per 8 base entries of "
+                         "each table (64 B read, 32 B written) 16 multiplications for the folds and 8 for the three extension products; k_sc_terms2 before it reads the tables once for "
+                         "the 4 x 4 grid that answers rounds 1 and 2 (32 multiplications per 96 B: VALU-bound). DP_SC_GRID2=0: the round-by-round form (k_sc_terms + one k_sc_fused per round)")
+                        if big["kernel"].startswith("k_sc_fused2") else
+                        ("a fold+sum pass does ~36 Goldilocks multiplications per 192 B moved; at the measured ~1.0e12 mul/s of the chip the "
+                         "VALU-integer bound (~0.15 ms for the first fused round) is above the HBM bound (0.13 ms at 6.3 TB/s)")}
     return {"workload": f"standalone sumcheck, one product of {k} base MLEs, 2^{nv} entries each (BASELINE config 5 on 1 GPU)",
             "wall_ms": round(wall_ms, 3), "wall_ms_samples": [round(w, 3) for w in walls], "rounds": nv, "golden_sha256_ok": golden_ok, "verified": True,
             "streaming_kernels_ms": round(ms, 3), "profiled_kernel_total_ms": round(prof_total_ms, 3), "profiled_non_kernel_records_ms": round(prof_other_ms, 3),
