@@ -1447,7 +1447,7 @@ class HipDev : public Dev {
       }
       const size_t nocts = n_in / 8;
       size_t mk = mark();
-      int g = grid_for(nocts, 4096);
+      int g = grid_for(nocts, 1024);  // (4096 -> 1024: 154 -> 136 us at 3 x 2^24 entries; 512: 152 — tools/r06/call47.sh)
       Ext* partial = (Ext*)arena_alloc((size_t)g * 4 * 16);
       nb_ = bytes;
       const bool skip1 = claim_hint_ != nullptr;
@@ -1631,7 +1631,9 @@ class HipDev : public Dev {
         }
         size_t nquads = n_in / 4;
         size_t mk = mark();
-        int g = grid_for(nquads, 4096);
+        // grid: at most 512 workgroups since round 6 (4096 before: the ten rounds of a 2^24 sumcheck between 2^22 and 2^13 entries 0.302 -> 0.251 ms, 1024: 0.269; every workgroup
+        // ends with four block reductions, a write-through of its sums and a ticket, and the last one reads all of them past its L2 — tools/r06/call47.sh, profiles/r06_sumcheck_grid2_ab.txt)
+        int g = grid_for(nquads, 512);
         Ext* partial = (Ext*)arena_alloc((size_t)g * 4 * 16);
         nb_ = bytes;
         const bool skip1 = claim_hint_ != nullptr;
