@@ -881,13 +881,15 @@ def sharded_estimate(nv, k, world, stream_tbps=3.4, round_us=17.0, exchange_us=3
     streaming of 48 k N bytes at the rate the fused rounds reach (3.4 TB/s over all streaming rounds, profiles/r03_call1_bench.json)
     plus ~17 us per round of reduction + host round trip; W GPUs stream 1/W of it but pay an exchange per local round on top —
     ncclAllGather of <= 256 B over xGMI + the share-sum kernel + its publication, ~35 us assumed with the shares kept on the device
-    (csrc/sharded.h; ~3 host hops more without). Sharding pays when 48kN/BW (1 - 1/W) > (nv - log2 W) exchange_us."""
+    (csrc/sharded.h; ~3 host hops more without). Sharding pays when (32 - 48/W) kN/BW > (nv - log2 W) exchange_us - round_us (round 6: the single GPU streams 32kN, the
+    two-round grid)."""
     lg = world.bit_length() - 1
     n = 1 << nv
     stream_ms = 48.0 * k * n / (stream_tbps * 1e12) * 1e3
-    one = stream_ms + nv * round_us * 1e-3
+    # (round 6: ONE GPU runs the two-round grid — 32 k N bytes, one host round trip less; the shards of a sharded run keep the round-by-round form, their round sums being shares)
+    one = 32.0 * k * n / (stream_tbps * 1e12) * 1e3 + (nv - 1) * round_us * 1e-3
     many = stream_ms / world + (nv - lg) * (round_us + exchange_us) * 1e-3 + lg * round_us * 1e-3
-    cross = next((v for v in range(lg + 1, 40) if 48.0 * k * (1 << v) / (stream_tbps * 1e12) * (1 - 1.0 / world) * 1e6 > (v - lg) * exchange_us), None)
+    cross = next((v for v in range(lg + 1, 40) if (32.0 - 48.0 / world) * k * (1 << v) / (stream_tbps * 1e12) * 1e6 > (v - lg) * exchange_us - round_us), None)
     return {"one_gpu_ms": round(one, 3), f"{world}_gpus_ms": round(many, 3), "assumed": {"streaming_TBps": stream_tbps, "round_us": round_us, "exchange_us_per_local_round": exchange_us},
             "crossover_nv": cross, "verdict": ("worth sharding" if many < one else f"not worth sharding at 2^{nv} on {world} GPUs: the per-round exchange outweighs the streaming saved (crossover 2^{cross})"),
             "note": "model, not measurement; the measured wall_ms of this section is the judge of it"}
