@@ -788,7 +788,7 @@ def sumcheck24(dev, dpa, nv=24, k=3):
                          "the 4 x 4 grid that answers rounds 1 and 2 (32 multiplications per 96 B: VALU-bound). DP_SC_GRID2=0: the round-by-round form (k_sc_terms + one k_sc_fused per round)")
                         if big["kernel"].startswith("k_sc_fused2") else
                         ("k_sc_terms2 (round 6, the two-round grid): ONE pass over the base tables answers rounds 1 and 2 — the 4 x 4 grid of sums over every quad's bilinear extension, "
-                         "32 Goldilocks multiplications and ~50 modular additions per 96 B read: VALU-integer bound (~750 VALU instructions per quad, 768 resident workgroups), so its HBM "
+                         "taken at the points {0, 1, oo, -1}^2: 32 Goldilocks multiplications and 36 modular subtractions per 96 B read: VALU-integer bound (~600 VALU instructions per quad, 768 resident workgroups), so its HBM "
                          "fraction is not its roofline; k_sc_fused2 after it (both folds + round 3, 604 MB) runs at ~4.4 TB/s. DP_SC_GRID2=0: the round-by-round form")
                         if big["kernel"].startswith("k_sc_terms2") else
                         ("a fold+sum pass does ~36 Goldilocks multiplications per 192 B moved; at the measured ~1.0e12 mul/s of the chip the "

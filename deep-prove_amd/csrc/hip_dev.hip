@@ -1101,7 +1101,19 @@ class HipDev : public Dev {
   // "grid2" (round 6; kernels.inc k_sc_terms2 / k_sc_fused2): the first two rounds of one product of <= 3 large BASE tables from ONE pass over them, both folds in one more.
   // stage 1: the sixteen grid sums are here and round 1 has been answered, the tables are still whole; stage 2: round 2 has been answered from the grid at r1, both folds are due.
   // One proof on the GPU only (latency mode, in-kernel ticket); DP_SC_GRID2=0 keeps the round-by-round form. 2^24 sumcheck 0.985 -> see profiles/r06_sumcheck_grid2_ab.txt.
-  struct Grid2 { int stage = 0; int nt = 0; size_t n = 0; u64 A[16]; Ext r1; } grid2_;
+  struct Grid2 { int stage = 0; int nt = 0; size_t n = 0; u64 A[16]; Ext r1; } grid2_;  // A[4 i + j]: the sums at the i-th point of x1 and the j-th of x2, points (0, 1, oo, -1)
+  // coefficients of the polynomial of degree K <= 3 with the values v[0], v[1] at 0 and 1, the leading coefficient v[2] ("oo") and — needed for K = 3 only — the value v[3] at -1
+  static void grid2_coeffs(int K, const Ext v[4], Ext c[4]) {
+    c[0] = v[0]; c[1] = c[2] = c[3] = ex_zero();
+    if (K == 1) c[1] = ex_sub(v[1], v[0]);
+    else if (K == 2) { c[2] = v[2]; c[1] = ex_sub(ex_sub(v[1], v[0]), v[2]); }
+    else {
+      static const u64 half = gl_inv(2);
+      const Ext s = ex_mul_base(ex_add(v[1], v[3]), half), d = ex_mul_base(ex_sub(v[1], v[3]), half);  // c0 + c2, c1 + c3
+      c[3] = v[2]; c[2] = ex_sub(s, v[0]); c[1] = ex_sub(d, v[2]);
+    }
+  }
+  static Ext grid2_eval(const Ext c[4], Ext x) { return ex_add(ex_mul(ex_add(ex_mul(ex_add(ex_mul(c[3], x), c[2]), x), c[1]), x), c[0]); }
   static constexpr size_t GRID2_MIN_N = size_t(1) << 20;
   void sc_round_claim(DBuf* tabs, int nt, const Ext* r, const ScTerm* terms, int nterms, const Ext* claim, Ext* out) override {
     claim_hint_ = nterms == 1 ? claim : nullptr;
@@ -1423,12 +1435,15 @@ class HipDev : public Dev {
     if (grid2_.stage) {
       DP_REQUIRE(r && nt == grid2_.nt && n_in == grid2_.n && nterms == 1 && terms[0].k == nt && !sess_.active, DP_ERR_ARG, "sumcheck out of sync (two-round grid)");
       const int K = nt;
-      if (grid2_.stage == 1) {  // round 2 from the grid: s2(u2) = sum_u1 L_u1(r1) A[u1][u2], nodes 0..K — no launch, nothing folded yet
-        for (int u2 = 0; u2 <= K; u2++) {
-          Ext col[4];
-          for (int u1 = 0; u1 <= K; u1++) col[u1] = ex_base(grid2_.A[u1 * 4 + u2]);
-          out[u2] = lagrange_eval_small(col, (size_t)K + 1, *r);
+      if (grid2_.stage == 1) {  // round 2 from the grid: g(X2) = Q(r1, X2) from its values at 0, 1, -1 and its leading coefficient, each Q(., p2) evaluated at r1 — no launch, nothing folded yet
+        Ext gv[4], c[4];
+        for (int p2 = 0; p2 < 4; p2++) {
+          const Ext col[4] = {ex_base(grid2_.A[0 + p2]), ex_base(grid2_.A[4 + p2]), ex_base(grid2_.A[8 + p2]), ex_base(grid2_.A[12 + p2])};
+          grid2_coeffs(K, col, c);
+          gv[p2] = grid2_eval(c, *r);
         }
+        grid2_coeffs(K, gv, c);
+        for (int t = 0; t <= K; t++) out[t] = grid2_eval(c, ex_from_u64((u64)t));
         grid2_.r1 = *r; grid2_.stage = 2;
         return;
       }
@@ -1483,7 +1498,12 @@ class HipDev : public Dev {
         wait_flag(fseq, 16);
         for (int i = 0; i < 16; i++) grid2_.A[i] = hres_[i];
         release(mk);
-        for (int t = 0; t <= nt; t++) out[t] = ex_base(gl_add(grid2_.A[t * 4 + 0], grid2_.A[t * 4 + 1]));  // s1(u1) = A[u1][0] + A[u1][1]
+        {  // s1(t) = Q(t, 0) + Q(t, 1): the two polynomials in X1 from their values at 0, 1, -1 and their leading coefficients
+          Ext c0[4], c1[4];
+          const Ext col0[4] = {ex_base(grid2_.A[0]), ex_base(grid2_.A[4]), ex_base(grid2_.A[8]), ex_base(grid2_.A[12])}, col1[4] = {ex_base(grid2_.A[1]), ex_base(grid2_.A[5]), ex_base(grid2_.A[9]), ex_base(grid2_.A[13])};
+          grid2_coeffs(nt, col0, c0); grid2_coeffs(nt, col1, c1);
+          for (int t = 0; t <= nt; t++) out[t] = ex_add(grid2_eval(c0, ex_from_u64((u64)t)), grid2_eval(c1, ex_from_u64((u64)t)));
+        }
         grid2_.stage = 1; grid2_.nt = nt; grid2_.n = n_in;
         return;
       }
