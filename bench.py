@@ -915,10 +915,11 @@ def seam_level(threads, per_thread=6, batch_rate=None):
     # without cohorts to merge launches and fibers to keep hundreds of calls in flight the one-wave kernels only add latency
     # `async_one_thread` (round 4): ONE host thread keeps 128 / 384 proofs in flight through the submit / poll forms (dp_async): calls of identical shape are
     # merged into lock-step groups by the engine (tests/support/seam_bench.c mode 3)
+    # (192 in flight — six groups of 32 per call shape — is where the engine's grouping works best: 480-497 proofs/s against 373-432 at 128 / 160 / 224 / 256 / 384, tools/r06/call49.sh)
     # `blocking_routed_T` (round 6): T host threads making the BLOCKING seam calls on one context routed to one engine (dp_ctx_route_to_engine: every call is a
     # submit + wait, calls of one shape from different threads are merged; tests/support/seam_bench.c mode 4) — the form a host written against the reference's
     # synchronous traits has; its rate is bounded by T / (latency of one proof's chain of calls), so it is quoted at the thread count of `streams` and at 128
-    variants = [("streams", 0, threads, {}), ("streams_throughput", 2, threads, {}), ("async_one_thread_128", 3, 128, {}), ("async_one_thread_384", 3, 384, {}),
+    variants = [("streams", 0, threads, {}), ("streams_throughput", 2, threads, {}), ("async_one_thread_128", 3, 128, {}), ("async_one_thread_192", 3, 192, {}), ("async_one_thread_384", 3, 384, {}),
                 (f"blocking_routed_{threads}", 4, threads, {}), ("blocking_routed_128", 4, 128, {})]
     for name, executor, t, extra in variants:
         env = dict(os.environ, DP_ARENA_BYTES=str(2 << 30), **extra)
